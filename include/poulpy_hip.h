@@ -1,0 +1,246 @@
+/*
+ * poulpy_hip.h — C ABI of libpoulpy_hip.so, the MI355X (gfx950) FFT64 backend
+ * for poulpy-hal.
+ *
+ * Every entry point below is what a `poulpy-hip-mi355x` Rust crate binds with
+ * `extern "C"` to implement `unsafe trait HalImpl<FFT64Hip>`
+ * (poulpy-hal/src/oep/hal_impl.rs:25) for the FFT64 hot path; the reference
+ * method each function replaces is cited as hal_impl.rs:<line> (all paths
+ * relative to /root/reference).  INTEGRATION.md shows the Rust side.
+ *
+ * Conventions
+ *  - Plain pointers + sizes only.  A VecZnx / VecZnxDft / VecZnxBig is passed as
+ *    (ptr, cols, size): limb j of column i starts at scalar offset
+ *    n*(j*cols + i) (poulpy-hal/src/layouts/znx_base.rs:52-82); n comes from the
+ *    module.  `size` is the *current* size (VecZnx::size(), after set_size).
+ *  - Pointers may be host memory (pageable, or pinned from pz_alloc_bytes) or
+ *    device memory (pz_device_alloc): the library detects which
+ *    (hipPointerGetAttributes).  Host buffers are staged through the module's
+ *    device workspace (H2D, kernels, D2H) and the call returns only when the
+ *    results are visible in the caller's buffer — "logically synchronous"
+ *    (poulpy-hal/docs/backend_safety_contract.md:16-19).  Device buffers are
+ *    processed in place on the module stream; the call returns after enqueue
+ *    and pz_module_sync() (or any host-pointer call) drains the stream.
+ *  - The bytes of VecZnxDft / SvpPPol / VmpPMat (ScalarPrep = f64) are
+ *    backend-private ("device order"): same byte sizes as the
+ *    reference (n*cols*size*8, module.rs:51-65) but NOT the reference's
+ *    [re | im] bit-reversed layout; callers must treat them as opaque, which is
+ *    what poulpy-core does.
+ *  - Return value: 0 on success, negative pz_status on failure.  Nothing throws
+ *    across the ABI; pz_last_error() gives a thread-local message.  The Rust
+ *    shim panics on non-zero, matching the reference's assert!/panic! behaviour.
+ *  - All *_batched entry points take DEVICE pointers only and treat `batch`
+ *    independent objects laid out back to back (object b at ptr + b*object_len).
+ */
+#ifndef POULPY_HIP_H
+#define POULPY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pz_module pz_module;
+
+typedef enum {
+    PZ_OK = 0,
+    PZ_ERR_INVALID = -1,     /* shape / argument violation (reference: assert!/debug_assert!) */
+    PZ_ERR_UNSUPPORTED = -2, /* e.g. n < 32 */
+    PZ_ERR_HIP = -3,         /* HIP runtime failure (no device, OOM, launch error) */
+    PZ_ERR_ALIAS = -4,       /* overlapping arguments that the op cannot honour */
+    PZ_ERR_RCCL = -5
+} pz_status;
+
+const char* pz_last_error(void);
+/* library/ABI version, bumped on any signature change */
+uint32_t pz_abi_version(void);
+
+/* ---- module (Backend + HalImpl::new) ------------------------------------ */
+/* HalImpl::new, hal_impl.rs:320 ; FFT64RefHandle, poulpy-cpu-ref/src/fft64/module.rs:34-69 */
+int pz_module_new(uint64_t n, pz_module** out);
+int pz_module_new_on_device(uint64_t n, int device, pz_module** out);
+/* Backend::destroy, poulpy-hal/src/layouts/module.rs:74-82,260-266 */
+void pz_module_free(pz_module* m);
+uint64_t pz_module_n(const pz_module* m);
+int pz_module_device(const pz_module* m);
+/* drains the module stream (needed only after device-pointer calls) */
+int pz_module_sync(pz_module* m);
+/* raw hipStream_t of the module, for callers that want to order their own work */
+void* pz_module_stream(pz_module* m);
+
+/* Backend::alloc_bytes, module.rs:38-43 — pinned host memory, 64 B aligned (lib.rs:146) */
+void* pz_alloc_bytes(size_t len);
+void pz_free_bytes(void* p);
+/* device-resident buffers for the batched path */
+int pz_device_alloc(pz_module* m, size_t len, void** out);
+int pz_device_free(pz_module* m, void* p);
+int pz_memcpy_h2d(pz_module* m, void* dst_dev, const void* src_host, size_t len);
+int pz_memcpy_d2h(pz_module* m, void* dst_host, const void* src_dev, size_t len);
+int pz_memset_d(pz_module* m, void* dst_dev, int value, size_t len);
+
+/* Backend::bytes_of_*, module.rs:51-65 */
+size_t pz_bytes_of_vec_znx(uint64_t n, size_t cols, size_t size);
+size_t pz_bytes_of_vec_znx_dft(uint64_t n, size_t cols, size_t size);
+size_t pz_bytes_of_vec_znx_big(uint64_t n, size_t cols, size_t size);
+size_t pz_bytes_of_svp_ppol(uint64_t n, size_t cols);
+size_t pz_bytes_of_vmp_pmat(uint64_t n, size_t rows, size_t cols_in, size_t cols_out, size_t size);
+
+/* ---- VecZnxDft ----------------------------------------------------------- */
+/* hal_impl.rs:529 vec_znx_dft_apply */
+int pz_vec_znx_dft_apply(pz_module* m, size_t step, size_t offset,
+                         double* res, size_t res_cols, size_t res_size, size_t res_col,
+                         const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+/* hal_impl.rs:534 */
+size_t pz_vec_znx_idft_apply_tmp_bytes(const pz_module* m);
+/* hal_impl.rs:536 vec_znx_idft_apply */
+int pz_vec_znx_idft_apply(pz_module* m,
+                          int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                          const double* a, size_t a_cols, size_t a_size, size_t a_col);
+/* hal_impl.rs:541 vec_znx_idft_apply_tmpa (a may be clobbered) */
+int pz_vec_znx_idft_apply_tmpa(pz_module* m,
+                               int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                               double* a, size_t a_cols, size_t a_size, size_t a_col);
+/* hal_impl.rs:546 vec_znx_idft_apply_consume: all cols x limbs in place, buffer re-typed to VecZnxBig */
+int pz_vec_znx_idft_apply_consume(pz_module* m, void* data, size_t cols, size_t size);
+/* hal_impl.rs:553 */
+int pz_vec_znx_dft_add_into(pz_module* m, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                            const double* a, size_t a_cols, size_t a_size, size_t a_col,
+                            const double* b, size_t b_cols, size_t b_size, size_t b_col);
+/* hal_impl.rs:559 */
+int pz_vec_znx_dft_add_scaled_assign(pz_module* m, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                                     const double* a, size_t a_cols, size_t a_size, size_t a_col, int64_t a_scale);
+/* hal_impl.rs:564 */
+int pz_vec_znx_dft_add_assign(pz_module* m, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                              const double* a, size_t a_cols, size_t a_size, size_t a_col);
+/* hal_impl.rs:569 */
+int pz_vec_znx_dft_sub(pz_module* m, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                       const double* a, size_t a_cols, size_t a_size, size_t a_col,
+                       const double* b, size_t b_cols, size_t b_size, size_t b_col);
+/* hal_impl.rs:575 */
+int pz_vec_znx_dft_sub_assign(pz_module* m, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                              const double* a, size_t a_cols, size_t a_size, size_t a_col);
+/* hal_impl.rs:580 */
+int pz_vec_znx_dft_sub_negate_assign(pz_module* m, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                                     const double* a, size_t a_cols, size_t a_size, size_t a_col);
+/* hal_impl.rs:585 */
+int pz_vec_znx_dft_copy(pz_module* m, size_t step, size_t offset,
+                        double* res, size_t res_cols, size_t res_size, size_t res_col,
+                        const double* a, size_t a_cols, size_t a_size, size_t a_col);
+/* hal_impl.rs:590 */
+int pz_vec_znx_dft_zero(pz_module* m, double* res, size_t res_cols, size_t res_size, size_t res_col);
+
+/* ---- SVP ------------------------------------------------------------------ */
+/* hal_impl.rs:595 svp_prepare (ScalarZnx(n, a_cols) -> SvpPPol(n, res_cols)) */
+int pz_svp_prepare(pz_module* m, double* res, size_t res_cols, size_t res_col,
+                   const int64_t* a, size_t a_cols, size_t a_col);
+/* hal_impl.rs:600 svp_apply_dft */
+int pz_svp_apply_dft(pz_module* m, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                     const double* ppol, size_t a_cols, size_t a_col,
+                     const int64_t* b, size_t b_cols, size_t b_size, size_t b_col);
+/* hal_impl.rs:606 svp_apply_dft_to_dft */
+int pz_svp_apply_dft_to_dft(pz_module* m, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                            const double* ppol, size_t a_cols, size_t a_col,
+                            const double* b, size_t b_cols, size_t b_size, size_t b_col);
+/* hal_impl.rs:612 svp_apply_dft_to_dft_assign */
+int pz_svp_apply_dft_to_dft_assign(pz_module* m, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                                   const double* ppol, size_t a_cols, size_t a_col);
+
+/* ---- VMP ------------------------------------------------------------------ */
+/* hal_impl.rs:618 ; the reference's scratch sizes are returned unchanged so that
+ * poulpy-core sizes its host arena identically — the device path
+ * does not use caller scratch. */
+size_t pz_vmp_prepare_tmp_bytes(const pz_module* m, size_t rows, size_t cols_in, size_t cols_out, size_t size);
+/* hal_impl.rs:620 vmp_prepare (MatZnx -> VmpPMat, device order) */
+int pz_vmp_prepare(pz_module* m, double* pmat, const int64_t* mat,
+                   size_t rows, size_t cols_in, size_t cols_out, size_t size);
+/* hal_impl.rs:626 */
+size_t pz_vmp_apply_dft_tmp_bytes(const pz_module* m, size_t res_size, size_t a_size,
+                                  size_t b_rows, size_t b_cols_in, size_t b_cols_out, size_t b_size);
+/* hal_impl.rs:636 vmp_apply_dft */
+int pz_vmp_apply_dft(pz_module* m, double* res, size_t res_cols, size_t res_size,
+                     const int64_t* a, size_t a_cols, size_t a_size,
+                     const double* pmat, size_t rows, size_t cols_in, size_t cols_out, size_t size);
+/* hal_impl.rs:643 */
+size_t pz_vmp_apply_dft_to_dft_tmp_bytes(const pz_module* m, size_t res_size, size_t a_size,
+                                         size_t b_rows, size_t b_cols_in, size_t b_cols_out, size_t b_size);
+/* hal_impl.rs:653 vmp_apply_dft_to_dft.  limb_offset > 0 follows the NTT120 sibling's
+ * semantics: every limb of res is written, limbs with no pmat column are zeroed
+ * (SURVEY.md A.2). */
+int pz_vmp_apply_dft_to_dft(pz_module* m, double* res, size_t res_cols, size_t res_size,
+                            const double* a, size_t a_cols, size_t a_size,
+                            const double* pmat, size_t rows, size_t cols_in, size_t cols_out, size_t size,
+                            size_t limb_offset);
+/* hal_impl.rs:665 vmp_zero */
+int pz_vmp_zero(pz_module* m, double* pmat, size_t rows, size_t cols_in, size_t cols_out, size_t size);
+
+/* ---- VecZnxBig ------------------------------------------------------------- */
+/* hal_impl.rs:428 */
+size_t pz_vec_znx_big_normalize_tmp_bytes(const pz_module* m);
+/* hal_impl.rs:431 vec_znx_big_normalize (same- and cross-base2k, any res_offset) */
+int pz_vec_znx_big_normalize(pz_module* m,
+                             int64_t* res, size_t res_cols, size_t res_size, size_t res_base2k, int64_t res_offset, size_t res_col,
+                             const int64_t* a, size_t a_cols, size_t a_size, size_t a_base2k, size_t a_col);
+/* hal_impl.rs:362 vec_znx_big_add_small_assign */
+int pz_vec_znx_big_add_small_assign(pz_module* m, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                                    const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+
+/* ---- batched, device-resident path (the measured one) ---------------------- *
+ * Coarser boundary: unsafe trait CoreImpl<BE>, poulpy-core/src/oep/core_impl.rs:34
+ *   glwe_external_product :120  (poulpy-core/src/external_product/glwe.rs:99-141,197-271)
+ *   glwe_keyswitch        :42   (poulpy-core/src/keyswitching/glwe.rs:53-109,207-239,298-380)
+ * applied to `batch` independent GLWE ciphertexts that share one prepared key.
+ * All pointers are device pointers; ciphertext b of `a` starts at
+ * a + b*n*(rank+1)*a_size, of `res` at res + b*n*(rank+1)*res_size.            */
+typedef struct {
+    uint64_t rank;        /* GLWE rank; cols = rank + 1 */
+    uint64_t dnum;        /* rows of the prepared GGSW / GGLWE */
+    uint64_t dsize;       /* digit size (1 on every BASELINE config) */
+    uint64_t key_size;    /* limbs of the prepared key */
+    uint64_t key_base2k;
+    uint64_t a_size;
+    uint64_t a_base2k;
+    uint64_t res_size;
+    uint64_t res_base2k;
+    uint64_t rank_out;    /* keyswitch only: output rank (key cols_out = rank_out+1, cols_in = rank) */
+} pz_glwe_op_params;
+
+int pz_glwe_external_product_batched(pz_module* m, int64_t* res, const int64_t* a, const double* ggsw_pmat,
+                                     const pz_glwe_op_params* p, size_t batch);
+int pz_glwe_keyswitch_batched(pz_module* m, int64_t* res, const int64_t* a, const double* key_pmat,
+                              const pz_glwe_op_params* p, size_t batch);
+/* workspace the two calls above need for `batch` ciphertexts (bytes, device) */
+size_t pz_glwe_op_workspace_bytes(const pz_module* m, const pz_glwe_op_params* p, size_t batch, int keyswitch);
+/* Tuning knob: number of ciphertexts pushed through the three-kernel pipeline per
+ * wave so that intermediates stay in the 256 MiB Infinity Cache (0 = auto). */
+int pz_module_set_chunk(pz_module* m, size_t cts_per_chunk);
+
+/* batched primitives (device pointers; object b at ptr + b*len(object)) */
+int pz_vec_znx_dft_apply_batched(pz_module* m, size_t batch, size_t step, size_t offset,
+                                 double* res, size_t res_cols, size_t res_size, size_t res_col,
+                                 const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+int pz_vec_znx_idft_apply_consume_batched(pz_module* m, size_t batch, void* data, size_t cols, size_t size);
+int pz_vmp_apply_dft_to_dft_batched(pz_module* m, size_t batch, double* res, size_t res_cols, size_t res_size,
+                                    const double* a, size_t a_cols, size_t a_size,
+                                    const double* pmat, size_t rows, size_t cols_in, size_t cols_out, size_t size,
+                                    size_t limb_offset);
+int pz_vec_znx_big_normalize_batched(pz_module* m, size_t batch,
+                                     int64_t* res, size_t res_cols, size_t res_size, size_t res_base2k, int64_t res_offset, size_t res_col,
+                                     const int64_t* a, size_t a_cols, size_t a_size, size_t a_base2k, size_t a_col);
+
+/* ---- instrumentation ------------------------------------------------------- */
+/* Times `reps` back-to-back launches of the last pipeline's dominant kernel with HIP
+ * events on the module stream; bench.py uses pz_event_* to bracket launches. */
+int pz_event_create(void** ev);
+int pz_event_destroy(void* ev);
+int pz_event_record(pz_module* m, void* ev);
+int pz_event_elapsed_ms(void* ev0, void* ev1, float* ms); /* synchronises on ev1 */
+/* largest |x - round(x)| seen by the last inverse-FFT epilogue when enabled (exactness margin) */
+int pz_module_set_margin_probe(pz_module* m, int enable);
+int pz_module_get_margin(pz_module* m, double* max_frac);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1443 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY (see fft64_ref.h for the full header note).
+ * "parity unpinned" by reference fixtures: the Rust reference cannot be built in
+ * this image and ships no golden vectors; pinned by exact-arithmetic properties.
+ *
+ * Plain-C restatement of poulpy-cpu-ref's FFT64 family.  Same operation order
+ * as the reference so that f64 spectra come out bit-identical to the Rust code
+ * when built with -ffp-contract=off against the same libm.
+ */
+#include "fft64_ref.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------ */
+/* twiddle tables: reim/table_fft.rs, reim/table_ifft.rs, reim/mod.rs:50-64  */
+/* ------------------------------------------------------------------------ */
+
+struct pzr_tables {
+    size_t m;
+    double* fwd; /* 2m */
+    double* inv; /* 2m */
+};
+
+static const double PZR_PI = 3.14159265358979323846264338327950288;
+
+/* reim/mod.rs:50-64 */
+static double frac_rev_bits(size_t x) {
+    if (x == 0) return 0.0;
+    if (x == 1) return 0.5;
+    if ((x & 1) == 0) return frac_rev_bits(x >> 1) * 0.5;
+    return frac_rev_bits(x >> 1) * 0.5 + 0.5;
+}
+
+static size_t log2_ceil(size_t m) { /* usize::BITS - (m-1).leading_zeros() */
+    size_t l = 0;
+    size_t v = m - 1;
+    while (v) { ++l; v >>= 1; }
+    return l;
+}
+
+/* table_fft.rs:85-93 */
+static size_t fill_fft2(double j, double* omg, size_t pos) {
+    double* o = omg + pos;
+    double angle = j / 2.0;
+    double two_pi = 2.0 * PZR_PI;
+    o[0] = cos(two_pi * angle);
+    o[1] = sin(two_pi * angle);
+    return pos + 2;
+}
+
+/* table_fft.rs:96-107 */
+static size_t fill_fft4(double j, double* omg, size_t pos) {
+    double* o = omg + pos;
+    double a1 = j / 2.0, a2 = j / 4.0;
+    double two_pi = 2.0 * PZR_PI;
+    o[0] = cos(two_pi * a1);
+    o[1] = sin(two_pi * a1);
+    o[2] = cos(two_pi * a2);
+    o[3] = sin(two_pi * a2);
+    return pos + 4;
+}
+
+/* table_fft.rs:110-127 */
+static size_t fill_fft8(double j, double* omg, size_t pos) {
+    double* o = omg + pos;
+    double e8 = 1. / 8.;
+    double a1 = j / 2.0, a2 = j / 4.0, a4 = j / 8.0;
+    double two_pi = 2.0 * PZR_PI;
+    o[0] = cos(two_pi * a1);
+    o[1] = sin(two_pi * a1);
+    o[2] = cos(two_pi * a2);
+    o[3] = sin(two_pi * a2);
+    o[4] = cos(two_pi * a4);
+    o[5] = cos(two_pi * (a4 + e8));
+    o[6] = sin(two_pi * a4);
+    o[7] = sin(two_pi * (a4 + e8));
+    return pos + 8;
+}
+
+/* table_fft.rs:130-157 */
+static size_t fill_fft16(double j, double* omg, size_t pos) {
+    double* o = omg + pos;
+    double e8 = 1. / 8., e16 = 1. / 16.;
+    double a1 = j / 2.0, a2 = j / 4.0, a4 = j / 8.0, a8 = j / 16.0;
+    double two_pi = 2.0 * PZR_PI;
+    o[0] = cos(two_pi * a1);
+    o[1] = sin(two_pi * a1);
+    o[2] = cos(two_pi * a2);
+    o[3] = sin(two_pi * a2);
+    o[4] = cos(two_pi * a4);
+    o[5] = sin(two_pi * a4);
+    o[6] = cos(two_pi * (a4 + e8));
+    o[7] = sin(two_pi * (a4 + e8));
+    o[8] = cos(two_pi * a8);
+    o[9] = cos(two_pi * (a8 + e8));
+    o[10] = cos(two_pi * (a8 + e16));
+    o[11] = cos(two_pi * (a8 + e8 + e16));
+    o[12] = sin(two_pi * a8);
+    o[13] = sin(two_pi * (a8 + e8));
+    o[14] = sin(two_pi * (a8 + e16));
+    o[15] = sin(two_pi * (a8 + e8 + e16));
+    return pos + 16;
+}
+
+/* table_fft.rs:160-200 */
+static size_t fill_fft_bfs_16(size_t m, double j, double* omg, size_t pos) {
+    size_t log_m = log2_ceil(m);
+    size_t mm = m;
+    double jj = j;
+    double two_pi = 2.0 * PZR_PI;
+    if (log_m & 1) {
+        size_t h = mm >> 1;
+        double j2 = jj * 0.5;
+        omg[pos] = cos(two_pi * j2);
+        omg[pos + 1] = sin(two_pi * j2);
+        pos += 2;
+        mm = h;
+        jj = j2;
+    }
+    while (mm > 16) {
+        size_t h = mm >> 2;
+        double j4 = jj * (1. / 4.);
+        for (size_t i = 0; i < m; i += mm) {
+            double rs_0 = j4 + frac_rev_bits(i / mm) * (1. / 4.);
+            double rs_1 = 2.0 * rs_0;
+            omg[pos] = cos(two_pi * rs_1);
+            omg[pos + 1] = sin(two_pi * rs_1);
+            omg[pos + 2] = cos(two_pi * rs_0);
+            omg[pos + 3] = sin(two_pi * rs_0);
+            pos += 4;
+        }
+        mm = h;
+        jj = j4;
+    }
+    for (size_t i = 0; i < m; i += 16) {
+        double jb = jj + frac_rev_bits(i >> 4);
+        fill_fft16(jb, omg, pos);
+        pos += 16;
+    }
+    return pos;
+}
+
+/* table_fft.rs:203-217 */
+static size_t fill_fft_rec_16(size_t m, double j, double* omg, size_t pos) {
+    if (m <= 2048) return fill_fft_bfs_16(m, j, omg, pos);
+    size_t h = m >> 1;
+    double s = j * 0.5;
+    double two_pi = 2.0 * PZR_PI;
+    omg[pos] = cos(two_pi * s);
+    omg[pos + 1] = sin(two_pi * s);
+    pos += 2;
+    pos = fill_fft_rec_16(h, s, omg, pos);
+    pos = fill_fft_rec_16(h, s + 0.5, omg, pos);
+    return pos;
+}
+
+/* table_ifft.rs:85-93 (note the exp2(2) forms there) */
+static size_t fill_ifft2(double j, double* omg, size_t pos) {
+    double* o = omg + pos;
+    double angle = j / exp2(2.0);
+    double two_pi = exp2(2.0) * PZR_PI;
+    o[0] = cos(two_pi * angle);
+    o[1] = -sin(two_pi * angle);
+    return pos + 2;
+}
+
+/* table_ifft.rs:96-107 */
+static size_t fill_ifft4(double j, double* omg, size_t pos) {
+    double* o = omg + pos;
+    double a1 = j / 2.0, a2 = j / 4.0;
+    double two_pi = 2.0 * PZR_PI;
+    o[0] = cos(two_pi * a2);
+    o[1] = -sin(two_pi * a2);
+    o[2] = cos(two_pi * a1);
+    o[3] = -sin(two_pi * a1);
+    return pos + 4;
+}
+
+/* table_ifft.rs:110-127 */
+static size_t fill_ifft8(double j, double* omg, size_t pos) {
+    double* o = omg + pos;
+    double e8 = 1. / 8.;
+    double a1 = j / 2.0, a2 = j / 4.0, a4 = j / 8.0;
+    double two_pi = 2.0 * PZR_PI;
+    o[0] = cos(two_pi * a4);
+    o[1] = cos(two_pi * (a4 + e8));
+    o[2] = -sin(two_pi * a4);
+    o[3] = -sin(two_pi * (a4 + e8));
+    o[4] = cos(two_pi * a2);
+    o[5] = -sin(two_pi * a2);
+    o[6] = cos(two_pi * a1);
+    o[7] = -sin(two_pi * a1);
+    return pos + 8;
+}
+
+/* table_ifft.rs:130-157 */
+static size_t fill_ifft16(double j, double* omg, size_t pos) {
+    double* o = omg + pos;
+    double e8 = 1. / 8., e16 = 1. / 16.;
+    double a1 = j / 2.0, a2 = j / 4.0, a4 = j / 8.0, a8 = j / 16.0;
+    double two_pi = 2.0 * PZR_PI;
+    o[0] = cos(two_pi * a8);
+    o[1] = cos(two_pi * (a8 + e8));
+    o[2] = cos(two_pi * (a8 + e16));
+    o[3] = cos(two_pi * (a8 + e8 + e16));
+    o[4] = -sin(two_pi * a8);
+    o[5] = -sin(two_pi * (a8 + e8));
+    o[6] = -sin(two_pi * (a8 + e16));
+    o[7] = -sin(two_pi * (a8 + e8 + e16));
+    o[8] = cos(two_pi * a4);
+    o[9] = -sin(two_pi * a4);
+    o[10] = cos(two_pi * (a4 + e8));
+    o[11] = -sin(two_pi * (a4 + e8));
+    o[12] = cos(two_pi * a2);
+    o[13] = -sin(two_pi * a2);
+    o[14] = cos(two_pi * a1);
+    o[15] = -sin(two_pi * a1);
+    return pos + 16;
+}
+
+/* table_ifft.rs:160-200 */
+static size_t fill_ifft_bfs_16(size_t m, double j, double* omg, size_t pos) {
+    size_t log_m = log2_ceil(m);
+    double jj = j * 16.0 / (double)m;
+    for (size_t i = 0; i < m; i += 16) {
+        double jb = jj + frac_rev_bits(i >> 4);
+        fill_ifft16(jb, omg, pos);
+        pos += 16;
+    }
+    size_t h = 16;
+    size_t m_half = m >> 1;
+    double two_pi = 2.0 * PZR_PI;
+    while (h < m_half) {
+        size_t mm = h << 2;
+        for (size_t i = 0; i < m; i += mm) {
+            double rs_0 = jj + frac_rev_bits(i / mm) / 4.0;
+            double rs_1 = 2.0 * rs_0;
+            omg[pos] = cos(two_pi * rs_0);
+            omg[pos + 1] = -sin(two_pi * rs_0);
+            omg[pos + 2] = cos(two_pi * rs_1);
+            omg[pos + 3] = -sin(two_pi * rs_1);
+            pos += 4;
+        }
+        h = mm;
+        jj = jj * 4.0;
+    }
+    if (log_m & 1) {
+        omg[pos] = cos(two_pi * jj);
+        omg[pos + 1] = -sin(two_pi * jj);
+        pos += 2;
+        jj = jj * 2.0;
+    }
+    /* table_ifft.rs:197 asserts jj == j here */
+    if (jj != j) abort();
+    return pos;
+}
+
+/* table_ifft.rs:203-216 */
+static size_t fill_ifft_rec_16(size_t m, double j, double* omg, size_t pos) {
+    if (m <= 2048) return fill_ifft_bfs_16(m, j, omg, pos);
+    size_t h = m >> 1;
+    double s = j / 2.0;
+    pos = fill_ifft_rec_16(h, s, omg, pos);
+    pos = fill_ifft_rec_16(h, s + 0.5, omg, pos);
+    double two_pi = 2.0 * PZR_PI;
+    omg[pos] = cos(two_pi * s);
+    omg[pos + 1] = -sin(two_pi * s);
+    pos += 2;
+    return pos;
+}
+
+/* ReimFFTTable::new / ReimIFFTTable::new  (table_fft.rs:39-69, table_ifft.rs:39-69) */
+pzr_tables* pzr_tables_new(uint64_t n) {
+    if (n < 2 || (n & (n - 1))) return NULL;
+    size_t m = (size_t)(n >> 1);
+    pzr_tables* t = (pzr_tables*)calloc(1, sizeof(*t));
+    t->m = m;
+    t->fwd = (double*)calloc(2 * m + 16, sizeof(double));
+    t->inv = (double*)calloc(2 * m + 16, sizeof(double));
+    double quarter = 1. / 4.;
+    double quarter_inv = exp2(-2.0);
+    switch (m) {
+        case 1: break;
+        case 2: fill_fft2(quarter, t->fwd, 0); fill_ifft2(quarter_inv, t->inv, 0); break;
+        case 4: fill_fft4(quarter, t->fwd, 0); fill_ifft4(quarter_inv, t->inv, 0); break;
+        case 8: fill_fft8(quarter, t->fwd, 0); fill_ifft8(quarter_inv, t->inv, 0); break;
+        case 16: fill_fft16(quarter, t->fwd, 0); fill_ifft16(quarter_inv, t->inv, 0); break;
+        default:
+            if (m <= 2048) {
+                fill_fft_bfs_16(m, quarter, t->fwd, 0);
+                fill_ifft_bfs_16(m, quarter_inv, t->inv, 0);
+            } else {
+                fill_fft_rec_16(m, quarter, t->fwd, 0);
+                fill_ifft_rec_16(m, quarter_inv, t->inv, 0);
+            }
+    }
+    return t;
+}
+
+void pzr_tables_free(pzr_tables* t) {
+    if (!t) return;
+    free(t->fwd);
+    free(t->inv);
+    free(t);
+}
+uint64_t pzr_tables_m(const pzr_tables* t) { return t->m; }
+const double* pzr_tables_omg_fft(const pzr_tables* t) { return t->fwd; }
+const double* pzr_tables_omg_ifft(const pzr_tables* t) { return t->inv; }
+
+/* ------------------------------------------------------------------------ */
+/* forward FFT: reim/fft_ref.rs                                              */
+/* ------------------------------------------------------------------------ */
+
+/* fft_ref.rs:60-67 */
+static inline void ctw(double* ra, double* ia, double* rb, double* ib, double wr, double wi) {
+    double dr = *rb * wr - *ib * wi;
+    double di = *rb * wi + *ib * wr;
+    *rb = *ra - dr;
+    *ib = *ia - di;
+    *ra = *ra + dr;
+    *ia = *ia + di;
+}
+
+/* fft_ref.rs:70-77 */
+static inline void citw(double* ra, double* ia, double* rb, double* ib, double wr, double wi) {
+    double dr = *rb * wi + *ib * wr;
+    double di = *rb * wr - *ib * wi;
+    *rb = *ra + dr;
+    *ib = *ia - di;
+    *ra = *ra - dr;
+    *ia = *ia + di;
+}
+
+#define TW(a, b, wr, wi) ctw(&re[a], &im[a], &re[b], &im[b], (wr), (wi))
+#define ITW(a, b, wr, wi) citw(&re[a], &im[a], &re[b], &im[b], (wr), (wi))
+
+/* fft_ref.rs:80-85 */
+static void fft2(double* re, double* im, const double* o) { TW(0, 1, o[0], o[1]); }
+
+/* fft_ref.rs:88-105 */
+static void fft4(double* re, double* im, const double* o) {
+    TW(0, 2, o[0], o[1]);
+    TW(1, 3, o[0], o[1]);
+    TW(0, 1, o[2], o[3]);
+    ITW(2, 3, o[2], o[3]);
+}
+
+/* fft_ref.rs:108-140 */
+static void fft8(double* re, double* im, const double* o) {
+    for (int i = 0; i < 4; ++i) TW(i, i + 4, o[0], o[1]);
+    for (int i = 0; i < 2; ++i) TW(i, i + 2, o[2], o[3]);
+    for (int i = 4; i < 6; ++i) ITW(i, i + 2, o[2], o[3]);
+    TW(0, 1, o[4], o[6]);
+    ITW(2, 3, o[4], o[6]);
+    TW(4, 5, o[5], o[7]);
+    ITW(6, 7, o[5], o[7]);
+}
+
+/* fft_ref.rs:143-244 */
+static void fft16(double* re, double* im, const double* o) {
+    for (int i = 0; i < 8; ++i) TW(i, i + 8, o[0], o[1]);
+    for (int i = 0; i < 4; ++i) TW(i, i + 4, o[2], o[3]);
+    for (int i = 8; i < 12; ++i) ITW(i, i + 4, o[2], o[3]);
+    TW(0, 2, o[4], o[5]);
+    TW(1, 3, o[4], o[5]);
+    TW(8, 10, o[6], o[7]);
+    TW(9, 11, o[6], o[7]);
+    ITW(4, 6, o[4], o[5]);
+    ITW(5, 7, o[4], o[5]);
+    ITW(12, 14, o[6], o[7]);
+    ITW(13, 15, o[6], o[7]);
+    TW(0, 1, o[8], o[12]);
+    TW(4, 5, o[9], o[13]);
+    TW(8, 9, o[10], o[14]);
+    TW(12, 13, o[11], o[15]);
+    ITW(2, 3, o[8], o[12]);
+    ITW(6, 7, o[9], o[13]);
+    ITW(10, 11, o[10], o[14]);
+    ITW(14, 15, o[11], o[15]);
+}
+
+/* fft_ref.rs:280-290 */
+static void twiddle_fft(size_t h, double* re, double* im, const double* o) {
+    for (size_t i = 0; i < h; ++i) ctw(&re[i], &im[i], &re[h + i], &im[h + i], o[0], o[1]);
+}
+
+/* fft_ref.rs:293-316 */
+static void bitwiddle_fft(size_t h, double* re, double* im, const double* o) {
+    double *r0 = re, *r1 = re + h, *r2 = re + 2 * h, *r3 = re + 3 * h;
+    double *i0 = im, *i1 = im + h, *i2 = im + 2 * h, *i3 = im + 3 * h;
+    for (size_t i = 0; i < h; ++i) {
+        ctw(&r0[i], &i0[i], &r2[i], &i2[i], o[0], o[1]);
+        ctw(&r1[i], &i1[i], &r3[i], &i3[i], o[0], o[1]);
+    }
+    for (size_t i = 0; i < h; ++i) {
+        ctw(&r0[i], &i0[i], &r1[i], &i1[i], o[2], o[3]);
+        citw(&r2[i], &i2[i], &r3[i], &i3[i], o[2], o[3]);
+    }
+}
+
+/* fft_ref.rs:247-277 */
+static size_t fft_bfs_16(size_t m, double* re, double* im, const double* omg, size_t pos) {
+    size_t log_m = log2_ceil(m);
+    size_t mm = m;
+    if (log_m & 1) {
+        size_t h = mm >> 1;
+        twiddle_fft(h, re, im, omg + pos);
+        pos += 2;
+        mm = h;
+    }
+    while (mm > 16) {
+        size_t h = mm >> 2;
+        for (size_t off = 0; off < m; off += mm) {
+            bitwiddle_fft(h, re + off, im + off, omg + pos);
+            pos += 4;
+        }
+        mm = h;
+    }
+    for (size_t off = 0; off < m; off += 16) {
+        fft16(re + off, im + off, omg + pos);
+        pos += 16;
+    }
+    return pos;
+}
+
+/* fft_ref.rs:46-57 */
+static size_t fft_rec_16(size_t m, double* re, double* im, const double* omg, size_t pos) {
+    if (m <= 2048) return fft_bfs_16(m, re, im, omg, pos);
+    size_t h = m >> 1;
+    twiddle_fft(h, re, im, omg + pos);
+    pos += 2;
+    pos = fft_rec_16(h, re, im, omg, pos);
+    pos = fft_rec_16(h, re + h, im + h, omg, pos);
+    return pos;
+}
+
+/* fft_ref.rs:25-43 */
+void pzr_fft(const pzr_tables* t, double* data) {
+    size_t m = t->m;
+    double* re = data;
+    double* im = data + m;
+    const double* omg = t->fwd;
+    if (m <= 16) {
+        switch (m) {
+            case 2: fft2(re, im, omg); break;
+            case 4: fft4(re, im, omg); break;
+            case 8: fft8(re, im, omg); break;
+            case 16: fft16(re, im, omg); break;
+            default: break;
+        }
+    } else if (m <= 2048) {
+        fft_bfs_16(m, re, im, omg, 0);
+    } else {
+        fft_rec_16(m, re, im, omg, 0);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* inverse FFT: reim/ifft_ref.rs                                             */
+/* ------------------------------------------------------------------------ */
+
+/* ifft_ref.rs:91-98 */
+static inline void invtw(double* ra, double* ia, double* rb, double* ib, double wr, double wi) {
+    double rd = *ra - *rb;
+    double id = *ia - *ib;
+    *ra = *ra + *rb;
+    *ia = *ia + *ib;
+    *rb = rd * wr - id * wi;
+    *ib = rd * wi + id * wr;
+}
+
+/* ifft_ref.rs:101-108 */
+static inline void invitw(double* ra, double* ia, double* rb, double* ib, double wr, double wi) {
+    double rd = *ra - *rb;
+    double id = *ia - *ib;
+    *ra = *ra + *rb;
+    *ia = *ia + *ib;
+    *rb = rd * wi + id * wr;
+    *ib = -rd * wr + id * wi;
+}
+
+#define IW(a, b, wr, wi) invtw(&re[a], &im[a], &re[b], &im[b], (wr), (wi))
+#define IIW(a, b, wr, wi) invitw(&re[a], &im[a], &re[b], &im[b], (wr), (wi))
+
+/* ifft_ref.rs:111-116 */
+static void ifft2(double* re, double* im, const double* o) { IW(0, 1, o[0], o[1]); }
+
+/* ifft_ref.rs:119-137 */
+static void ifft4(double* re, double* im, const double* o) {
+    IW(0, 1, o[0], o[1]);
+    IIW(2, 3, o[0], o[1]);
+    IW(0, 2, o[2], o[3]);
+    IW(1, 3, o[2], o[3]);
+}
+
+/* ifft_ref.rs:140-172 */
+static void ifft8(double* re, double* im, const double* o) {
+    IW(0, 1, o[0], o[2]);
+    IIW(2, 3, o[0], o[2]);
+    IW(4, 5, o[1], o[3]);
+    IIW(6, 7, o[1], o[3]);
+    IW(0, 2, o[4], o[5]);
+    IW(1, 3, o[4], o[5]);
+    IIW(4, 6, o[4], o[5]);
+    IIW(5, 7, o[4], o[5]);
+    for (int i = 0; i < 4; ++i) IW(i, i + 4, o[6], o[7]);
+}
+
+/* ifft_ref.rs:175-272 */
+static void ifft16(double* re, double* im, const double* o) {
+    IW(0, 1, o[0], o[4]);
+    IIW(2, 3, o[0], o[4]);
+    IW(4, 5, o[1], o[5]);
+    IIW(6, 7, o[1], o[5]);
+    IW(8, 9, o[2], o[6]);
+    IIW(10, 11, o[2], o[6]);
+    IW(12, 13, o[3], o[7]);
+    IIW(14, 15, o[3], o[7]);
+
+    IW(0, 2, o[8], o[9]);
+    IW(1, 3, o[8], o[9]);
+    IIW(4, 6, o[8], o[9]);
+    IIW(5, 7, o[8], o[9]);
+    IW(8, 10, o[10], o[11]);
+    IW(9, 11, o[10], o[11]);
+    IIW(12, 14, o[10], o[11]);
+    IIW(13, 15, o[10], o[11]);
+
+    for (int i = 0; i < 4; ++i) IW(i, i + 4, o[12], o[13]);
+    for (int i = 8; i < 12; ++i) IIW(i, i + 4, o[12], o[13]);
+
+    for (int i = 0; i < 8; ++i) IW(i, i + 8, o[14], o[15]);
+}
+
+/* ifft_ref.rs:275-285 */
+static void inv_twiddle_ifft(size_t h, double* re, double* im, const double* o) {
+    for (size_t i = 0; i < h; ++i) invtw(&re[i], &im[i], &re[h + i], &im[h + i], o[0], o[1]);
+}
+
+/* ifft_ref.rs:288-311 */
+static void inv_bitwiddle_ifft(size_t h, double* re, double* im, const double* o) {
+    double *r0 = re, *r1 = re + h, *r2 = re + 2 * h, *r3 = re + 3 * h;
+    double *i0 = im, *i1 = im + h, *i2 = im + 2 * h, *i3 = im + 3 * h;
+    for (size_t i = 0; i < h; ++i) {
+        invtw(&r0[i], &i0[i], &r1[i], &i1[i], o[0], o[1]);
+        invitw(&r2[i], &i2[i], &r3[i], &i3[i], o[0], o[1]);
+    }
+    for (size_t i = 0; i < h; ++i) {
+        invtw(&r0[i], &i0[i], &r2[i], &i2[i], o[2], o[3]);
+        invtw(&r1[i], &i1[i], &r3[i], &i3[i], o[2], o[3]);
+    }
+}
+
+/* ifft_ref.rs:58-88 */
+static size_t ifft_bfs_16(size_t m, double* re, double* im, const double* omg, size_t pos) {
+    size_t log_m = log2_ceil(m);
+    for (size_t off = 0; off < m; off += 16) {
+        ifft16(re + off, im + off, omg + pos);
+        pos += 16;
+    }
+    size_t h = 16;
+    size_t m_half = m >> 1;
+    while (h < m_half) {
+        size_t mm = h << 2;
+        for (size_t off = 0; off < m; off += mm) {
+            inv_bitwiddle_ifft(h, re + off, im + off, omg + pos);
+            pos += 4;
+        }
+        h = mm;
+    }
+    if (log_m & 1) {
+        inv_twiddle_ifft(h, re, im, omg + pos);
+        pos += 2;
+    }
+    return pos;
+}
+
+/* ifft_ref.rs:45-55 */
+static size_t ifft_rec_16(size_t m, double* re, double* im, const double* omg, size_t pos) {
+    if (m <= 2048) return ifft_bfs_16(m, re, im, omg, pos);
+    size_t h = m >> 1;
+    pos = ifft_rec_16(h, re, im, omg, pos);
+    pos = ifft_rec_16(h, re + h, im + h, omg, pos);
+    inv_twiddle_ifft(h, re, im, omg + pos);
+    pos += 2;
+    return pos;
+}
+
+/* ifft_ref.rs:24-42 */
+void pzr_ifft(const pzr_tables* t, double* data) {
+    size_t m = t->m;
+    double* re = data;
+    double* im = data + m;
+    const double* omg = t->inv;
+    if (m <= 16) {
+        switch (m) {
+            case 2: ifft2(re, im, omg); break;
+            case 4: ifft4(re, im, omg); break;
+            case 8: ifft8(re, im, omg); break;
+            case 16: ifft16(re, im, omg); break;
+            default: break;
+        }
+    } else if (m <= 2048) {
+        ifft_bfs_16(m, re, im, omg, 0);
+    } else {
+        ifft_rec_16(m, re, im, omg, 0);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* conversions: reim/conversion.rs                                           */
+/* ------------------------------------------------------------------------ */
+
+/* conversion.rs:19-28 */
+void pzr_reim_from_znx_i64(double* res, const int64_t* a, size_t len) {
+    for (size_t i = 0; i < len; ++i) res[i] = (double)a[i];
+}
+
+/* Rust `f64 as i64`: saturating, NaN -> 0 */
+static inline int64_t f64_to_i64_sat(double x) {
+    if (x != x) return 0;
+    if (x >= 9223372036854775808.0) return INT64_MAX;
+    if (x <= -9223372036854775808.0) return INT64_MIN;
+    return (int64_t)x;
+}
+
+/* conversion.rs:43-52 ; f64::round = half away from zero = C round() */
+void pzr_reim_to_znx_i64(int64_t* res, double divisor, const double* a, size_t len) {
+    double inv_div = 1. / divisor;
+    for (size_t i = 0; i < len; ++i) res[i] = f64_to_i64_sat(round(a[i] * inv_div));
+}
+
+/* conversion.rs:55-60 */
+void pzr_reim_to_znx_i64_assign(double* res, double divisor, size_t len) {
+    double inv_div = 1. / divisor;
+    for (size_t i = 0; i < len; ++i) {
+        int64_t v = f64_to_i64_sat(round(res[i] * inv_div));
+        memcpy(&res[i], &v, sizeof(v));
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* pointwise helpers: reim/fft_vec.rs                                        */
+/* ------------------------------------------------------------------------ */
+
+static inline double* at_f64(double* p, size_t n, size_t cols, size_t col, size_t limb) { return p + n * (limb * cols + col); }
+static inline const double* at_cf64(const double* p, size_t n, size_t cols, size_t col, size_t limb) { return p + n * (limb * cols + col); }
+static inline int64_t* at_i64(int64_t* p, size_t n, size_t cols, size_t col, size_t limb) { return p + n * (limb * cols + col); }
+static inline const int64_t* at_ci64(const int64_t* p, size_t n, size_t cols, size_t col, size_t limb) { return p + n * (limb * cols + col); }
+static inline size_t zmin(size_t a, size_t b) { return a < b ? a : b; }
+
+static void reim_zero(double* r, size_t len) { memset(r, 0, len * sizeof(double)); }
+static void reim_copy(double* r, const double* a, size_t len) { memmove(r, a, len * sizeof(double)); }
+
+/* fft_vec.rs:150-173 (res = a*b) ; :124-147 (res = a*res) */
+static void reim_mul(double* res, const double* a, const double* b, size_t n) {
+    size_t m = n >> 1;
+    for (size_t i = 0; i < m; ++i) {
+        double ar = a[i], ai = a[m + i], br = b[i], bi = b[m + i];
+        double rr = ar * br - ai * bi;
+        double ri = ar * bi + ai * br;
+        res[i] = rr;
+        res[m + i] = ri;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* reference/fft64/vec_znx_dft.rs                                            */
+/* ------------------------------------------------------------------------ */
+
+/* vec_znx_dft.rs:160-200 */
+void pzr_vec_znx_dft_apply(const pzr_tables* t, size_t step, size_t offset,
+                           double* res, size_t res_cols, size_t res_size, size_t res_col,
+                           const int64_t* a, size_t a_cols, size_t a_size, size_t a_col) {
+    size_t n = t->m << 1;
+    size_t steps = (a_size + step - 1) / step;
+    size_t min_steps = zmin(res_size, steps);
+    for (size_t j = 0; j < min_steps; ++j) {
+        size_t limb = offset + j * step;
+        if (limb < a_size) {
+            double* out = at_f64(res, n, res_cols, res_col, j);
+            pzr_reim_from_znx_i64(out, at_ci64(a, n, a_cols, a_col, limb), n);
+            pzr_fft(t, out);
+        } /* else: left untouched (vec_znx_dft.rs:191-194) */
+    }
+    for (size_t j = min_steps; j < res_size; ++j) reim_zero(at_f64(res, n, res_cols, res_col, j), n);
+}
+
+/* vec_znx_dft.rs:202-232 */
+void pzr_vec_znx_idft_apply(const pzr_tables* t,
+                            int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                            const double* a, size_t a_cols, size_t a_size, size_t a_col) {
+    size_t n = t->m << 1;
+    size_t min_size = zmin(res_size, a_size);
+    double divisor = (double)t->m;
+    for (size_t j = 0; j < min_size; ++j) {
+        double* slot = (double*)at_i64(res, n, res_cols, res_col, j);
+        reim_copy(slot, at_cf64(a, n, a_cols, a_col, j), n);
+        pzr_ifft(t, slot);
+        pzr_reim_to_znx_i64_assign(slot, divisor, n);
+    }
+    for (size_t j = min_size; j < res_size; ++j) memset(at_i64(res, n, res_cols, res_col, j), 0, n * sizeof(int64_t));
+}
+
+/* vec_znx_dft.rs:234-262 */
+void pzr_vec_znx_idft_apply_tmpa(const pzr_tables* t,
+                                 int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                                 double* a, size_t a_cols, size_t a_size, size_t a_col) {
+    size_t n = t->m << 1;
+    size_t min_size = zmin(res_size, a_size);
+    double divisor = (double)t->m;
+    for (size_t j = 0; j < min_size; ++j) {
+        double* aj = at_f64(a, n, a_cols, a_col, j);
+        pzr_ifft(t, aj);
+        pzr_reim_to_znx_i64(at_i64(res, n, res_cols, res_col, j), divisor, aj, n);
+    }
+    for (size_t j = min_size; j < res_size; ++j) memset(at_i64(res, n, res_cols, res_col, j), 0, n * sizeof(int64_t));
+}
+
+/* vec_znx_dft.rs:264-288 */
+void pzr_vec_znx_idft_apply_consume(const pzr_tables* t, double* data, size_t cols, size_t size) {
+    size_t n = t->m << 1;
+    double divisor = (double)t->m;
+    for (size_t i = 0; i < cols; ++i)
+        for (size_t j = 0; j < size; ++j) {
+            double* p = at_f64(data, n, cols, i, j);
+            pzr_ifft(t, p);
+            pzr_reim_to_znx_i64_assign(p, divisor, n);
+        }
+}
+
+/* vec_znx_dft.rs:14-66 (SUB=0) and :290-342 (SUB=1) */
+static void dft_add_sub(int sub, size_t n, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                        const double* a, size_t a_cols, size_t a_size, size_t a_col,
+                        const double* b, size_t b_cols, size_t b_size, size_t b_col) {
+    int a_le_b = a_size <= b_size;
+    size_t sum_size = zmin(a_le_b ? a_size : b_size, res_size);
+    size_t cpy_size = zmin(a_le_b ? b_size : a_size, res_size);
+    for (size_t j = 0; j < sum_size; ++j) {
+        double* r = at_f64(res, n, res_cols, res_col, j);
+        const double* x = at_cf64(a, n, a_cols, a_col, j);
+        const double* y = at_cf64(b, n, b_cols, b_col, j);
+        for (size_t i = 0; i < n; ++i) r[i] = sub ? x[i] - y[i] : x[i] + y[i];
+    }
+    for (size_t j = sum_size; j < cpy_size; ++j) {
+        double* r = at_f64(res, n, res_cols, res_col, j);
+        if (a_le_b) {
+            const double* y = at_cf64(b, n, b_cols, b_col, j);
+            if (sub) { for (size_t i = 0; i < n; ++i) r[i] = -y[i]; }
+            else reim_copy(r, y, n);
+        } else {
+            reim_copy(r, at_cf64(a, n, a_cols, a_col, j), n);
+        }
+    }
+    for (size_t j = cpy_size; j < res_size; ++j) reim_zero(at_f64(res, n, res_cols, res_col, j), n);
+}
+
+void pzr_vec_znx_dft_add_into(size_t n, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                              const double* a, size_t a_cols, size_t a_size, size_t a_col,
+                              const double* b, size_t b_cols, size_t b_size, size_t b_col) {
+    dft_add_sub(0, n, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col, b, b_cols, b_size, b_col);
+}
+void pzr_vec_znx_dft_sub(size_t n, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                         const double* a, size_t a_cols, size_t a_size, size_t a_col,
+                         const double* b, size_t b_cols, size_t b_size, size_t b_col) {
+    dft_add_sub(1, n, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col, b, b_cols, b_size, b_col);
+}
+
+/* vec_znx_dft.rs:68-91 */
+void pzr_vec_znx_dft_add_assign(size_t n, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                                const double* a, size_t a_cols, size_t a_size, size_t a_col) {
+    size_t sum_size = zmin(a_size, res_size);
+    for (size_t j = 0; j < sum_size; ++j) {
+        double* r = at_f64(res, n, res_cols, res_col, j);
+        const double* x = at_cf64(a, n, a_cols, a_col, j);
+        for (size_t i = 0; i < n; ++i) r[i] += x[i];
+    }
+}
+
+/* vec_znx_dft.rs:93-128 */
+void pzr_vec_znx_dft_add_scaled_assign(size_t n, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                                       const double* a, size_t a_cols, size_t a_size, size_t a_col, int64_t a_scale) {
+    size_t res_shift = 0, a_shift = 0, sum_size;
+    if (a_scale > 0) {
+        size_t shift = zmin((size_t)a_scale, a_size);
+        size_t mn = zmin(a_size, res_size);
+        sum_size = mn > shift ? mn - shift : 0;
+        a_shift = shift;
+    } else if (a_scale < 0) {
+        size_t shift = zmin((size_t)(-a_scale), res_size);
+        sum_size = zmin(a_size, res_size - shift);
+        res_shift = shift;
+    } else {
+        sum_size = zmin(a_size, res_size);
+    }
+    for (size_t j = 0; j < sum_size; ++j) {
+        double* r = at_f64(res, n, res_cols, res_col, j + res_shift);
+        const double* x = at_cf64(a, n, a_cols, a_col, j + a_shift);
+        for (size_t i = 0; i < n; ++i) r[i] += x[i];
+    }
+}
+
+/* vec_znx_dft.rs:344-366 */
+void pzr_vec_znx_dft_sub_assign(size_t n, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                                const double* a, size_t a_cols, size_t a_size, size_t a_col) {
+    size_t sum_size = zmin(a_size, res_size);
+    for (size_t j = 0; j < sum_size; ++j) {
+        double* r = at_f64(res, n, res_cols, res_col, j);
+        const double* x = at_cf64(a, n, a_cols, a_col, j);
+        for (size_t i = 0; i < n; ++i) r[i] -= x[i];
+    }
+}
+
+/* vec_znx_dft.rs:368-394 */
+void pzr_vec_znx_dft_sub_negate_assign(size_t n, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                                       const double* a, size_t a_cols, size_t a_size, size_t a_col) {
+    size_t sum_size = zmin(a_size, res_size);
+    for (size_t j = 0; j < sum_size; ++j) {
+        double* r = at_f64(res, n, res_cols, res_col, j);
+        const double* x = at_cf64(a, n, a_cols, a_col, j);
+        for (size_t i = 0; i < n; ++i) r[i] = x[i] - r[i];
+    }
+    for (size_t j = sum_size; j < res_size; ++j) {
+        double* r = at_f64(res, n, res_cols, res_col, j);
+        for (size_t i = 0; i < n; ++i) r[i] = -r[i];
+    }
+}
+
+/* vec_znx_dft.rs:130-158 */
+void pzr_vec_znx_dft_copy(size_t n, size_t step, size_t offset,
+                          double* res, size_t res_cols, size_t res_size, size_t res_col,
+                          const double* a, size_t a_cols, size_t a_size, size_t a_col) {
+    size_t steps = (a_size + step - 1) / step;
+    size_t min_steps = zmin(res_size, steps);
+    for (size_t j = 0; j < min_steps; ++j) {
+        size_t limb = offset + j * step;
+        if (limb < a_size) reim_copy(at_f64(res, n, res_cols, res_col, j), at_cf64(a, n, a_cols, a_col, limb), n);
+        else reim_zero(at_f64(res, n, res_cols, res_col, j), n);
+    }
+    for (size_t j = min_steps; j < res_size; ++j) reim_zero(at_f64(res, n, res_cols, res_col, j), n);
+}
+
+/* vec_znx_dft.rs:396-405 */
+void pzr_vec_znx_dft_zero(size_t n, double* res, size_t res_cols, size_t res_size, size_t res_col) {
+    for (size_t j = 0; j < res_size; ++j) reim_zero(at_f64(res, n, res_cols, res_col, j), n);
+}
+
+/* ------------------------------------------------------------------------ */
+/* reference/fft64/svp.rs                                                    */
+/* ------------------------------------------------------------------------ */
+
+/* svp.rs:9-19 ; SvpPPol(n, cols) has size 1, ScalarZnx(n, cols) likewise */
+void pzr_svp_prepare(const pzr_tables* t, double* res, size_t res_cols, size_t res_col,
+                     const int64_t* a, size_t a_cols, size_t a_col) {
+    size_t n = t->m << 1;
+    (void)res_cols; (void)a_cols;
+    double* out = res + n * res_col;
+    pzr_reim_from_znx_i64(out, a + n * a_col, n);
+    pzr_fft(t, out);
+}
+
+/* svp.rs:21-54 */
+void pzr_svp_apply_dft(const pzr_tables* t,
+                       double* res, size_t res_cols, size_t res_size, size_t res_col,
+                       const double* ppol, size_t a_cols, size_t a_col,
+                       const int64_t* b, size_t b_cols, size_t b_size, size_t b_col) {
+    size_t n = t->m << 1;
+    (void)a_cols;
+    size_t min_size = zmin(res_size, b_size);
+    const double* pp = ppol + n * a_col;
+    for (size_t j = 0; j < min_size; ++j) {
+        double* out = at_f64(res, n, res_cols, res_col, j);
+        pzr_reim_from_znx_i64(out, at_ci64(b, n, b_cols, b_col, j), n);
+        pzr_fft(t, out);
+        reim_mul(out, pp, out, n); /* reim_mul_assign(out, ppol): a=ppol, b=out (fft_vec.rs:124-147) */
+    }
+    for (size_t j = min_size; j < res_size; ++j) reim_zero(at_f64(res, n, res_cols, res_col, j), n);
+}
+
+/* svp.rs:56-79 */
+void pzr_svp_apply_dft_to_dft(size_t n,
+                              double* res, size_t res_cols, size_t res_size, size_t res_col,
+                              const double* ppol, size_t a_cols, size_t a_col,
+                              const double* b, size_t b_cols, size_t b_size, size_t b_col) {
+    (void)a_cols;
+    size_t min_size = zmin(res_size, b_size);
+    const double* pp = ppol + n * a_col;
+    for (size_t j = 0; j < min_size; ++j) reim_mul(at_f64(res, n, res_cols, res_col, j), pp, at_cf64(b, n, b_cols, b_col, j), n);
+    for (size_t j = min_size; j < res_size; ++j) reim_zero(at_f64(res, n, res_cols, res_col, j), n);
+}
+
+/* svp.rs:81-94 */
+void pzr_svp_apply_dft_to_dft_assign(size_t n,
+                                     double* res, size_t res_cols, size_t res_size, size_t res_col,
+                                     const double* ppol, size_t a_cols, size_t a_col) {
+    (void)a_cols;
+    const double* pp = ppol + n * a_col;
+    for (size_t j = 0; j < res_size; ++j) {
+        double* r = at_f64(res, n, res_cols, res_col, j);
+        reim_mul(r, pp, r, n);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* reference/fft64/vmp.rs + reim4/arithmetic_ref.rs                          */
+/* ------------------------------------------------------------------------ */
+
+size_t pzr_vmp_prepare_tmp_bytes(size_t n) { return n * sizeof(int64_t); } /* vmp.rs:13-15 */
+size_t pzr_vmp_apply_dft_to_dft_tmp_bytes(size_t a_size, size_t prows, size_t pcols_in) { /* vmp.rs:132-135 */
+    size_t row_max = zmin(a_size, prows);
+    return (16 + 8 * row_max * pcols_in) * sizeof(double);
+}
+size_t pzr_vmp_apply_dft_tmp_bytes(size_t n, size_t a_size, size_t prows, size_t pcols_in) { /* vmp.rs:95-98 */
+    size_t row_max = zmin(a_size, prows);
+    return (16 + (n + 8) * row_max * pcols_in) * sizeof(double);
+}
+
+/* arithmetic_ref.rs:21-35 */
+static void reim4_extract_1blk(size_t m, size_t rows, size_t blk, double* dst, const double* src) {
+    size_t off = blk << 2;
+    for (size_t r = 0; r < 2 * rows; ++r) memcpy(dst + 4 * r, src + r * m + off, 4 * sizeof(double));
+}
+
+/* arithmetic_ref.rs:223-232 */
+static inline void reim4_add_mul(double* dst, const double* a, const double* b) {
+    for (int k = 0; k < 4; ++k) {
+        double ar = a[k], br = b[k], ai = a[k + 4], bi = b[k + 4];
+        dst[k] += ar * br - ai * bi;
+        dst[k + 4] += ar * bi + ai * br;
+    }
+}
+
+/* arithmetic_ref.rs:138-158 */
+static void reim4_mat1col(size_t nrows, double* dst, const double* u, const double* v) {
+    double acc[8] = {0};
+    for (size_t i = 0; i < nrows; ++i) reim4_add_mul(acc, u + 8 * i, v + 8 * i);
+    memcpy(dst, acc, sizeof(acc));
+}
+
+/* arithmetic_ref.rs:161-186 */
+static void reim4_mat2cols(size_t nrows, double* dst, const double* u, const double* v) {
+    double acc0[8] = {0}, acc1[8] = {0};
+    for (size_t i = 0; i < nrows; ++i) {
+        reim4_add_mul(acc0, u + 8 * i, v + 16 * i);
+        reim4_add_mul(acc1, u + 8 * i, v + 16 * i + 8);
+    }
+    memcpy(dst, acc0, sizeof(acc0));
+    memcpy(dst + 8, acc1, sizeof(acc1));
+}
+
+/* arithmetic_ref.rs:189-220 */
+static void reim4_mat2cols_2ndcol(size_t nrows, double* dst, const double* u, const double* v) {
+    double acc[8] = {0};
+    for (size_t i = 0; i < nrows; ++i) reim4_add_mul(acc, u + 8 * i, v + 16 * i + 8);
+    memcpy(dst, acc, sizeof(acc));
+}
+
+/* arithmetic_ref.rs:53-82 (OVERWRITE = true) */
+static void reim4_save_1blk(size_t m, size_t blk, double* dst, const double* src) {
+    size_t off = blk << 2;
+    memcpy(dst + off, src, 4 * sizeof(double));
+    memcpy(dst + off + m, src + 4, 4 * sizeof(double));
+}
+
+/* arithmetic_ref.rs:85-135 (OVERWRITE = true) */
+static void reim4_save_2blk(size_t m, size_t blk, double* dst, const double* src) {
+    size_t off = blk << 2;
+    memcpy(dst + off, src, 4 * sizeof(double));
+    memcpy(dst + off + m, src + 4, 4 * sizeof(double));
+    memcpy(dst + off + 2 * m, src + 8, 4 * sizeof(double));
+    memcpy(dst + off + 3 * m, src + 12, 4 * sizeof(double));
+}
+
+/* vmp.rs:17-93 */
+void pzr_vmp_prepare(const pzr_tables* t, double* pmat, const int64_t* mat,
+                     size_t rows, size_t cols_in, size_t cols_out, size_t size) {
+    size_t m = t->m, n = m << 1;
+    size_t nrows = cols_in * rows;
+    size_t ncols = cols_out * size;
+    size_t offset = nrows * ncols * 8;
+    double* tmp = (double*)malloc(n * sizeof(double));
+    for (size_t row_i = 0; row_i < nrows; ++row_i) {
+        for (size_t col_i = 0; col_i < ncols; ++col_i) {
+            size_t pos = n * (row_i * ncols + col_i);
+            pzr_reim_from_znx_i64(tmp, mat + pos, n);
+            pzr_fft(t, tmp);
+            double* dst;
+            if (col_i == ncols - 1 && (ncols & 1)) dst = pmat + col_i * nrows * 8 + row_i * 8;
+            else dst = pmat + (col_i / 2) * (nrows * 16) + row_i * 16 + (col_i % 2) * 8;
+            for (size_t blk = 0; blk < (m >> 2); ++blk) reim4_extract_1blk(m, 1, blk, dst + blk * offset, tmp);
+        }
+    }
+    free(tmp);
+}
+
+/* vmp.rs:186-264 (OVERWRITE = true).  NOTE: for limb_offset > 0 the reference
+ * leaves res columns [col_max - limb_offset, col_max) unwritten;
+ * that is restated literally here. */
+static void vmp_apply_core(size_t n, double* res, size_t res_polys, const double* a, size_t a_polys,
+                           const double* pmat, size_t limb_offset, size_t nrows, size_t ncols) {
+    size_t m = n >> 1;
+    size_t row_max = zmin(nrows, a_polys);
+    size_t col_max = zmin(ncols, res_polys);
+    if (limb_offset >= col_max) {
+        reim_zero(res, res_polys * n);
+        return;
+    }
+    double out[16];
+    double* ext = (double*)malloc((8 * row_max + 8) * sizeof(double));
+    for (size_t blk = 0; blk < (m >> 2); ++blk) {
+        const double* mat_blk = pmat + blk * (8 * nrows * ncols);
+        reim4_extract_1blk(m, row_max, blk, ext, a);
+        if ((limb_offset & 1) == 0) {
+            size_t col_res = 0;
+            for (size_t col_pmat = limb_offset; col_pmat + 1 < col_max; col_pmat += 2, col_res += 2) {
+                reim4_mat2cols(row_max, out, ext, mat_blk + col_pmat * (8 * nrows));
+                reim4_save_2blk(m, blk, res + col_res * n, out);
+            }
+        } else {
+            reim4_mat2cols_2ndcol(row_max, out, ext, mat_blk + (limb_offset - 1) * (8 * nrows));
+            reim4_save_1blk(m, blk, res, out);
+            size_t col_res = 1;
+            for (size_t col_pmat = limb_offset + 1; col_pmat + 1 < col_max; col_pmat += 2, col_res += 2) {
+                reim4_mat2cols(row_max, out, ext, mat_blk + col_pmat * (8 * nrows));
+                reim4_save_2blk(m, blk, res + col_res * n, out);
+            }
+        }
+        if (col_max & 1) {
+            size_t last_col = col_max - 1;
+            if (last_col >= limb_offset) {
+                if (ncols == col_max) reim4_mat1col(row_max, out, ext, mat_blk + last_col * (8 * nrows));
+                else reim4_mat2cols(row_max, out, ext, mat_blk + last_col * (8 * nrows));
+                reim4_save_1blk(m, blk, res + (last_col - limb_offset) * n, out);
+            }
+        }
+    }
+    free(ext);
+    reim_zero(res + col_max * n, (res_polys - col_max) * n);
+}
+
+/* vmp.rs:144-183 */
+void pzr_vmp_apply_dft_to_dft(size_t n,
+                              double* res, size_t res_cols, size_t res_size,
+                              const double* a, size_t a_cols, size_t a_size,
+                              const double* pmat, size_t rows, size_t cols_in, size_t cols_out, size_t size,
+                              size_t limb_offset) {
+    size_t nrows = cols_in * rows;
+    size_t ncols = cols_out * size;
+    vmp_apply_core(n, res, res_cols * res_size, a, a_cols * a_size, pmat, limb_offset * cols_out, nrows, ncols);
+}
+
+/* vmp.rs:100-130 (hal_impl/family_common.rs:17-54 is the same glue) */
+void pzr_vmp_apply_dft(const pzr_tables* t,
+                       double* res, size_t res_cols, size_t res_size,
+                       const int64_t* a, size_t a_cols, size_t a_size,
+                       const double* pmat, size_t rows, size_t cols_in, size_t cols_out, size_t size) {
+    size_t n = t->m << 1;
+    size_t cols = cols_in;
+    size_t sz = zmin(a_size, rows);
+    double* a_dft = (double*)malloc(n * cols * sz * sizeof(double) + 8);
+    size_t offset = cols - a_cols;
+    /* NOTE vmp.rs:124-126 calls vec_znx_dft_apply(.., &mut a_dft, j, &a, offset + j): literal restatement.
+     * With a_cols == cols (every caller) offset is 0. */
+    for (size_t j = 0; j < cols; ++j) {
+        if (offset + j < a_cols) pzr_vec_znx_dft_apply(t, 1, 0, a_dft, cols, sz, j, a, a_cols, a_size, offset + j);
+        else pzr_vec_znx_dft_zero(n, a_dft, cols, sz, j);
+    }
+    pzr_vmp_apply_dft_to_dft(n, res, res_cols, res_size, a_dft, cols, sz, pmat, rows, cols_in, cols_out, size, 0);
+    free(a_dft);
+}
+
+/* ------------------------------------------------------------------------ */
+/* reference/znx/normalization.rs                                            */
+/* ------------------------------------------------------------------------ */
+
+static inline int64_t wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
+static inline int64_t wshl(int64_t a, size_t s) { return (int64_t)((uint64_t)a << s); }
+/* normalization.rs:4-6 */
+static inline int64_t get_digit(size_t k, int64_t x) { return (int64_t)((uint64_t)x << (64 - k)) >> (64 - k); }
+/* normalization.rs:9-11 */
+static inline int64_t get_carry(size_t k, int64_t x, int64_t d) { return (int64_t)((uint64_t)x - (uint64_t)d) >> k; }
+
+/* normalization.rs:24-41 */
+static void nz_first_step_carry_only(size_t k, size_t lsh, const int64_t* x, int64_t* c, size_t n) {
+    size_t kk = lsh == 0 ? k : k - lsh;
+    for (size_t i = 0; i < n; ++i) c[i] = get_carry(kk, x[i], get_digit(kk, x[i]));
+}
+
+/* normalization.rs:107-129 */
+static void nz_middle_step_carry_only(size_t k, size_t lsh, const int64_t* x, int64_t* c, size_t n) {
+    size_t kk = lsh == 0 ? k : k - lsh;
+    for (size_t i = 0; i < n; ++i) {
+        int64_t d = get_digit(kk, x[i]);
+        int64_t cr = get_carry(kk, x[i], d);
+        int64_t dpc = wadd(wshl(d, lsh), c[i]);
+        c[i] = wadd(cr, get_carry(k, dpc, get_digit(k, dpc)));
+    }
+}
+
+/* normalization.rs:132-157 */
+static void nz_middle_step_assign(size_t k, size_t lsh, int64_t* x, int64_t* c, size_t n) {
+    size_t kk = lsh == 0 ? k : k - lsh;
+    for (size_t i = 0; i < n; ++i) {
+        int64_t d = get_digit(kk, x[i]);
+        int64_t cr = get_carry(kk, x[i], d);
+        int64_t dpc = wadd(wshl(d, lsh), c[i]);
+        x[i] = get_digit(k, dpc);
+        c[i] = wadd(cr, get_carry(k, dpc, x[i]));
+    }
+}
+
+/* normalization.rs:160-166 */
+static void nz_extract_digit_addmul(size_t k, size_t lsh, int64_t* res, int64_t* src, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        int64_t d = get_digit(k, src[i]);
+        src[i] = get_carry(k, src[i], d);
+        res[i] = wadd(res[i], wshl(d, lsh));
+    }
+}
+
+/* normalization.rs:179-221 (OVERWRITE = true) */
+static void nz_middle_step(size_t k, size_t lsh, int64_t* x, const int64_t* a, int64_t* c, size_t n) {
+    size_t kk = lsh == 0 ? k : k - lsh;
+    for (size_t i = 0; i < n; ++i) {
+        int64_t d = get_digit(kk, a[i]);
+        int64_t cr = get_carry(kk, a[i], d);
+        int64_t dpc = wadd(wshl(d, lsh), c[i]);
+        int64_t x1 = get_digit(k, dpc);
+        x[i] = x1;
+        c[i] = wadd(cr, get_carry(k, dpc, x1));
+    }
+}
+
+/* normalization.rs:254-272 */
+static void nz_final_step_assign(size_t k, size_t lsh, int64_t* x, int64_t* c, size_t n) {
+    size_t kk = lsh == 0 ? k : k - lsh;
+    for (size_t i = 0; i < n; ++i) x[i] = get_digit(k, wadd(wshl(get_digit(kk, x[i]), lsh), c[i]));
+}
+
+/* znx/mul.rs:30-49 */
+static void znx_mul_power_of_two_assign(int64_t kp, int64_t* x, size_t n) {
+    if (kp == 0) return;
+    if (kp > 0) {
+        for (size_t i = 0; i < n; ++i) x[i] = wshl(x[i], (size_t)kp);
+        return;
+    }
+    size_t k = (size_t)(-kp);
+    for (size_t i = 0; i < n; ++i) {
+        int64_t sign_bit = (x[i] >> 63) & 1;
+        int64_t bias = ((int64_t)1 << (k - 1)) - sign_bit;
+        x[i] = wadd(x[i], bias) >> k;
+    }
+}
+
+static void znx_add_assign(int64_t* r, const int64_t* a, size_t n) {
+    for (size_t i = 0; i < n; ++i) r[i] = wadd(r[i], a[i]);
+}
+
+static inline int64_t clampi(int64_t v, int64_t lo, int64_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* ------------------------------------------------------------------------ */
+/* reference/vec_znx/normalize.rs                                            */
+/* ------------------------------------------------------------------------ */
+
+size_t pzr_vec_znx_normalize_tmp_bytes(size_t n) { return 3 * n * sizeof(int64_t); } /* normalize.rs:13-15 */
+
+/* normalize.rs:50-144 */
+static void normalize_inter(size_t n, size_t base2k,
+                            int64_t* res, size_t res_cols, size_t res_size, int64_t res_offset, size_t res_col,
+                            const int64_t* a, size_t a_cols, size_t a_size, size_t a_col, int64_t* carry) {
+    int64_t lsh = res_offset % (int64_t)base2k;
+    int64_t limbs_offset = res_offset / (int64_t)base2k;
+    if (res_offset < 0 && lsh != 0) {
+        lsh = (lsh + (int64_t)base2k) % (int64_t)base2k;
+        limbs_offset -= 1;
+    }
+    size_t lsh_pos = (size_t)lsh;
+    size_t res_end = (size_t)clampi(-limbs_offset, 0, (int64_t)res_size);
+    size_t res_start = (size_t)clampi((int64_t)a_size - limbs_offset, 0, (int64_t)res_size);
+    size_t a_end = (size_t)clampi(limbs_offset, 0, (int64_t)a_size);
+    size_t a_start = (size_t)clampi((int64_t)res_size + limbs_offset, 0, (int64_t)a_size);
+    size_t a_out_range = a_size > a_start ? a_size - a_start : 0;
+
+    for (size_t j = 0; j < a_out_range; ++j) {
+        const int64_t* aj = at_ci64(a, n, a_cols, a_col, a_size - j - 1);
+        if (j == 0) nz_first_step_carry_only(base2k, lsh_pos, aj, carry, n);
+        else nz_middle_step_carry_only(base2k, lsh_pos, aj, carry, n);
+    }
+    if (a_out_range == 0) memset(carry, 0, n * sizeof(int64_t));
+    for (size_t j = res_start; j < res_size; ++j) memset(at_i64(res, n, res_cols, res_col, j), 0, n * sizeof(int64_t));
+    size_t mid_range = a_start > a_end ? a_start - a_end : 0;
+    for (size_t j = 0; j < mid_range; ++j)
+        nz_middle_step(base2k, lsh_pos, at_i64(res, n, res_cols, res_col, res_start - j - 1),
+                       at_ci64(a, n, a_cols, a_col, a_start - j - 1), carry, n);
+    for (size_t j = 0; j < res_end; ++j) {
+        int64_t* r = at_i64(res, n, res_cols, res_col, res_end - j - 1);
+        memset(r, 0, n * sizeof(int64_t));
+        if (j == res_end - 1) nz_final_step_assign(base2k, lsh_pos, r, carry, n);
+        else nz_middle_step_assign(base2k, lsh_pos, r, carry, n);
+    }
+}
+
+/* normalize.rs:147-401 */
+static void normalize_cross(size_t n,
+                            int64_t* res, size_t res_cols, size_t res_size, size_t res_base2k, int64_t res_offset, size_t res_col,
+                            const int64_t* a, size_t a_cols, size_t a_size, size_t a_base2k, size_t a_col, int64_t* scratch) {
+    int64_t* a_norm = scratch;
+    int64_t* res_carry = scratch + n;
+    int64_t* a_carry = scratch + 2 * n;
+    memset(res_carry, 0, n * sizeof(int64_t));
+
+    size_t a_tot_bits = a_size * a_base2k;
+    size_t res_tot_bits = res_size * res_base2k;
+
+    int64_t lsh = res_offset % (int64_t)a_base2k;
+    int64_t limbs_offset = res_offset / (int64_t)a_base2k;
+    if (res_offset < 0 && lsh != 0) {
+        lsh = (lsh + (int64_t)a_base2k) % (int64_t)a_base2k;
+        limbs_offset -= 1;
+    }
+    size_t lsh_pos = (size_t)lsh;
+
+    size_t res_end_bit = (size_t)clampi(-limbs_offset * (int64_t)a_base2k, 0, (int64_t)res_tot_bits);
+    size_t res_start_bit = (size_t)clampi((int64_t)a_tot_bits - limbs_offset * (int64_t)a_base2k, 0, (int64_t)res_tot_bits);
+    size_t a_end_bit = (size_t)clampi(limbs_offset * (int64_t)a_base2k, 0, (int64_t)a_tot_bits);
+    size_t a_start_bit = (size_t)clampi((int64_t)res_tot_bits + limbs_offset * (int64_t)a_base2k, 0, (int64_t)a_tot_bits);
+
+    size_t res_end = res_end_bit / res_base2k;
+    size_t res_start = (res_start_bit + res_base2k - 1) / res_base2k;
+    size_t a_end = a_end_bit / a_base2k;
+    size_t a_start = (a_start_bit + a_base2k - 1) / a_base2k;
+
+    for (size_t j = 0; j < res_size; ++j) memset(at_i64(res, n, res_cols, res_col, j), 0, n * sizeof(int64_t));
+    if (res_start == 0) return;
+
+    size_t a_out_range = a_size > a_start ? a_size - a_start : 0;
+    for (size_t j = 0; j < a_out_range; ++j) {
+        const int64_t* aj = at_ci64(a, n, a_cols, a_col, a_size - j - 1);
+        if (j == 0) nz_first_step_carry_only(a_base2k, lsh_pos, aj, a_carry, n);
+        else nz_middle_step_carry_only(a_base2k, lsh_pos, aj, a_carry, n);
+    }
+    if (a_out_range == 0) memset(a_carry, 0, n * sizeof(int64_t));
+
+    size_t res_acc_left = res_base2k;
+    size_t res_limb = res_start - 1;
+    size_t mid_range = a_start > a_end ? a_start - a_end : 0;
+
+    for (size_t j = 0; j < mid_range; ++j) {
+        size_t a_limb = a_start - j - 1;
+        const int64_t* a_slice = at_ci64(a, n, a_cols, a_col, a_limb);
+        size_t a_take_left = a_base2k;
+        nz_middle_step(a_base2k, lsh_pos, a_norm, a_slice, a_carry, n);
+        if (j == 0) {
+            if ((a_tot_bits - a_start_bit) % a_base2k != 0) {
+                size_t take = (a_tot_bits - a_start_bit) % a_base2k;
+                znx_mul_power_of_two_assign(-(int64_t)take, a_norm, n);
+                a_take_left -= take;
+            } else if ((res_tot_bits - res_start_bit) % res_base2k != 0) {
+                res_acc_left -= (res_tot_bits - res_start_bit) % res_base2k;
+            }
+        }
+        int done = 0;
+        for (;;) { /* 'inner: normalize.rs:299-370 */
+            int64_t* res_slice = at_i64(res, n, res_cols, res_col, res_limb);
+            size_t a_take = zmin(zmin(a_base2k, a_take_left), res_acc_left);
+            if (a_take != 0) {
+                size_t scale = res_base2k - res_acc_left;
+                nz_extract_digit_addmul(a_take, scale, res_slice, a_norm, n);
+                a_take_left -= a_take;
+                res_acc_left -= a_take;
+            }
+            if (res_acc_left == 0 || a_limb == 0) {
+                if (a_limb == 0 && a_take_left == 0) { /* normalize.rs:326-355 */
+                    znx_add_assign(a_carry, a_norm, n);
+                    if (res_acc_left != 0) {
+                        size_t scale = res_base2k - res_acc_left;
+                        nz_extract_digit_addmul(res_acc_left, scale, res_slice, a_carry, n);
+                    }
+                    nz_middle_step_assign(res_base2k, 0, res_slice, res_carry, n);
+                    znx_add_assign(res_carry, a_carry, n);
+                    done = 1; /* break 'outer */
+                    break;
+                }
+                if (res_limb == 0) { /* normalize.rs:358-360 */
+                    done = 1;
+                    break;
+                }
+                res_acc_left += res_base2k;
+                res_limb -= 1;
+            }
+            if (a_take_left == 0) { /* normalize.rs:366-369 */
+                znx_add_assign(a_carry, a_norm, n);
+                break;
+            }
+        }
+        if (done) break;
+    }
+
+    if (res_end != 0) {
+        int64_t* carry_to_use = (a_start == a_end) ? a_carry : res_carry;
+        for (size_t j = 0; j < res_end; ++j) {
+            int64_t* r = at_i64(res, n, res_cols, res_col, res_end - j - 1);
+            if (j == res_end - 1) nz_final_step_assign(res_base2k, 0, r, carry_to_use, n);
+            else nz_middle_step_assign(res_base2k, 0, r, carry_to_use, n);
+        }
+    }
+}
+
+/* normalize.rs:18-48 */
+void pzr_vec_znx_normalize(size_t n,
+                           int64_t* res, size_t res_cols, size_t res_size, size_t res_base2k, int64_t res_offset, size_t res_col,
+                           const int64_t* a, size_t a_cols, size_t a_size, size_t a_base2k, size_t a_col) {
+    int64_t* scratch = (int64_t*)malloc(3 * n * sizeof(int64_t));
+    if (res_base2k == a_base2k)
+        normalize_inter(n, res_base2k, res, res_cols, res_size, res_offset, res_col, a, a_cols, a_size, a_col, scratch);
+    else
+        normalize_cross(n, res, res_cols, res_size, res_base2k, res_offset, res_col, a, a_cols, a_size, a_base2k, a_col, scratch);
+    free(scratch);
+}
+
+/* vec_znx_big.rs:122-138 -> vec_znx/add.rs:60-82 */
+void pzr_vec_znx_big_add_small_assign(size_t n, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                                      const int64_t* a, size_t a_cols, size_t a_size, size_t a_col) {
+    size_t sum_size = zmin(a_size, res_size);
+    for (size_t j = 0; j < sum_size; ++j) znx_add_assign(at_i64(res, n, res_cols, res_col, j), at_ci64(a, n, a_cols, a_col, j), n);
+}
+
+/* ------------------------------------------------------------------------ */
+/* poulpy-core callers                                                       */
+/* ------------------------------------------------------------------------ */
+
+static size_t div_ceil(size_t a, size_t b) { return (a + b - 1) / b; }
+
+/* external_product/glwe.rs:99-141 (default) + :197-271 (internal) */
+void pzr_glwe_external_product(const pzr_tables* t, size_t rank,
+                               int64_t* res, size_t res_size, size_t res_base2k,
+                               const int64_t* a, size_t a_size, size_t a_base2k,
+                               const double* ggsw_pmat, size_t dnum, size_t ggsw_size, size_t dsize, size_t ggsw_base2k) {
+    size_t n = t->m << 1;
+    size_t cols = rank + 1;
+    int64_t* a_conv = NULL;
+    if (a_base2k != ggsw_base2k) { /* glwe.rs:124-132 ; operations/glwe.rs:1286-1310 */
+        size_t conv_size = div_ceil(a_size * a_base2k, ggsw_base2k);
+        a_conv = (int64_t*)calloc(n * cols * conv_size, sizeof(int64_t));
+        for (size_t i = 0; i < cols; ++i)
+            pzr_vec_znx_normalize(n, a_conv, cols, conv_size, ggsw_base2k, 0, i, a, cols, a_size, a_base2k, i);
+        a = a_conv;
+        a_size = conv_size;
+    }
+    double* res_dft = (double*)calloc(n * cols * ggsw_size, sizeof(double)); /* glwe.rs:121-122 */
+    size_t a_dft_max = div_ceil(a_size, dsize);
+    double* a_dft = (double*)calloc(n * cols * a_dft_max + 8, sizeof(double)); /* glwe.rs:225-226 */
+    size_t res_dft_size = ggsw_size;
+    if (dsize == 1) {
+        for (size_t j = 0; j < cols; ++j) pzr_vec_znx_dft_apply(t, 1, 0, a_dft, cols, a_size, j, a, cols, a_size, j);
+        pzr_vmp_apply_dft_to_dft(n, res_dft, cols, ggsw_size, a_dft, cols, a_size, ggsw_pmat, dnum, cols, cols, ggsw_size, 0);
+    } else {
+        /* glwe.rs:235-267.  The reference takes res_dft_tmp from scratch un-zeroed; it is zeroed here
+         * (deterministic choice). */
+        double* tmp = (double*)calloc(n * cols * ggsw_size, sizeof(double));
+        for (size_t di = 0; di < dsize; ++di) {
+            size_t a_sz = (a_size + di) / dsize;
+            long drop = (long)(dsize - di) - 2;
+            res_dft_size = ggsw_size - (size_t)(drop > 0 ? drop : 0);
+            for (size_t j = 0; j < cols; ++j)
+                pzr_vec_znx_dft_apply(t, dsize, dsize - 1 - di, a_dft, cols, a_sz, j, a, cols, a_size, j);
+            if (di == 0) {
+                pzr_vmp_apply_dft_to_dft(n, res_dft, cols, res_dft_size, a_dft, cols, a_sz, ggsw_pmat, dnum, cols, cols, ggsw_size, 0);
+            } else {
+                pzr_vmp_apply_dft_to_dft(n, tmp, cols, res_dft_size, a_dft, cols, a_sz, ggsw_pmat, dnum, cols, cols, ggsw_size, di);
+                for (size_t c = 0; c < cols; ++c)
+                    pzr_vec_znx_dft_add_assign(n, res_dft, cols, res_dft_size, c, tmp, cols, res_dft_size, c);
+            }
+        }
+        free(tmp);
+    }
+    /* glwe.rs:270: consume with the size set by the last iteration */
+    pzr_vec_znx_idft_apply_consume(t, res_dft, cols, res_dft_size);
+    const int64_t* res_big = (const int64_t*)res_dft;
+    for (size_t j = 0; j < cols; ++j) /* glwe.rs:138-140 */
+        pzr_vec_znx_normalize(n, res, cols, res_size, res_base2k, 0, j, res_big, cols, res_dft_size, ggsw_base2k, j);
+    free(a_dft);
+    free(res_dft);
+    free(a_conv);
+}
+
+/* keyswitching/glwe.rs:53-109 (default), :207-239 (internal), :298-380 (gglwe_product_dft) */
+void pzr_glwe_keyswitch(const pzr_tables* t, size_t rank_in, size_t rank_out,
+                        int64_t* res, size_t res_size, size_t res_base2k,
+                        const int64_t* a, size_t a_size, size_t a_base2k,
+                        const double* key_pmat, size_t dnum, size_t key_size, size_t dsize, size_t key_base2k) {
+    size_t n = t->m << 1;
+    size_t cols_a = rank_in + 1;
+    size_t cols_out = rank_out + 1;
+    int64_t* a_conv = NULL;
+    if (a_base2k != key_base2k) {
+        size_t conv_size = div_ceil(a_size * a_base2k, key_base2k);
+        a_conv = (int64_t*)calloc(n * cols_a * conv_size, sizeof(int64_t));
+        for (size_t i = 0; i < cols_a; ++i)
+            pzr_vec_znx_normalize(n, a_conv, cols_a, conv_size, key_base2k, 0, i, a, cols_a, a_size, a_base2k, i);
+        a = a_conv;
+        a_size = conv_size;
+    }
+    double* res_dft = (double*)calloc(n * cols_out * key_size, sizeof(double));
+    size_t cin = cols_a - 1;
+    double* a_dft = (double*)calloc(n * cin * a_size + 8, sizeof(double));
+    for (size_t c = 0; c < cin; ++c) /* mask columns only: glwe.rs:231-234 */
+        pzr_vec_znx_dft_apply(t, 1, 0, a_dft, cin, a_size, c, a, cols_a, a_size, c + 1);
+    if (dsize == 1) {
+        pzr_vmp_apply_dft_to_dft(n, res_dft, cols_out, key_size, a_dft, cin, a_size, key_pmat, dnum, cin, cols_out, key_size, 0);
+    } else {
+        size_t ai_max = zmin(div_ceil(a_size, dsize), dnum);
+        double* ai = (double*)calloc(n * cin * ai_max + 8, sizeof(double));
+        double* tmp = (double*)calloc(n * cols_out * key_size, sizeof(double));
+        for (size_t di = 0; di < dsize; ++di) {
+            size_t ai_sz = zmin((a_size + di) / dsize, dnum);
+            long drop = (long)(dsize - di) - 2;
+            size_t r_sz = key_size - (size_t)(drop > 0 ? drop : 0);
+            for (size_t j = 0; j < cin; ++j)
+                pzr_vec_znx_dft_copy(n, dsize, dsize - di - 1, ai, cin, ai_sz, j, a_dft, cin, a_size, j);
+            if (di == 0) {
+                pzr_vmp_apply_dft_to_dft(n, res_dft, cols_out, r_sz, ai, cin, ai_sz, key_pmat, dnum, cin, cols_out, key_size, 0);
+            } else {
+                pzr_vmp_apply_dft_to_dft(n, tmp, cols_out, r_sz, ai, cin, ai_sz, key_pmat, dnum, cin, cols_out, key_size, di);
+                for (size_t c = 0; c < cols_out; ++c)
+                    pzr_vec_znx_dft_add_assign(n, res_dft, cols_out, r_sz, c, tmp, cols_out, r_sz, c);
+            }
+        }
+        free(ai);
+        free(tmp);
+        /* glwe.rs:378: res.set_size(res.max_size()) */
+    }
+    pzr_vec_znx_idft_apply_consume(t, res_dft, cols_out, key_size);
+    int64_t* res_big = (int64_t*)res_dft;
+    pzr_vec_znx_big_add_small_assign(n, res_big, cols_out, key_size, 0, a, cols_a, a_size, 0); /* glwe.rs:237 */
+    for (size_t i = 0; i < cols_out; ++i) /* glwe.rs:105-108 */
+        pzr_vec_znx_normalize(n, res, cols_out, res_size, res_base2k, 0, i, res_big, cols_out, key_size, key_base2k, i);
+    free(a_dft);
+    free(res_dft);
+    free(a_conv);
+}

@@ -1,0 +1,136 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product.
+ *
+ * CPU restatement (plain C) of poulpy-cpu-ref's FFT64 family, the path
+ * BASELINE.json's north_star names.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may link or call this; poulpy_amd/ never does.
+ *
+ * PARITY STATUS: "parity unpinned" by reference fixtures.  The reference
+ * (Rust, nightly toolchain) cannot be compiled in this image and its test
+ * suite holds no golden vectors (all tests are differential).
+ * The restatement is instead pinned by exact-arithmetic properties that the
+ * reference's own cross-backend tests rely on (FFT64Ref == NTT120Ref on the
+ * normalized i64 limbs, poulpy-cpu-ref/src/tests.rs:133-141): see
+ * oracle/exact.py and tests/test_oracle_*.py.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference).  Compile with -O2 -ffp-contract=off: Rust never contracts
+ * a*b+c, and the reference butterflies are written unfused.
+ *
+ * Layout conventions (poulpy-hal/src/layouts/znx_base.rs:52-82):
+ *   VecZnx / VecZnxDft / VecZnxBig (n, cols, size): limb j of column i starts
+ *   at scalar offset n*(j*cols + i).  A DFT polynomial is [re(0..m) | im(0..m)],
+ *   m = n/2 (reim/fft_ref.rs:25-27).
+ */
+#ifndef PZR_FFT64_REF_H
+#define PZR_FFT64_REF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pzr_tables pzr_tables;
+
+/* FFT64RefHandle { table_fft, table_ifft }  (poulpy-cpu-ref/src/fft64/module.rs:34-69) */
+pzr_tables* pzr_tables_new(uint64_t n);
+void pzr_tables_free(pzr_tables* t);
+uint64_t pzr_tables_m(const pzr_tables* t);
+const double* pzr_tables_omg_fft(const pzr_tables* t);  /* 2m doubles */
+const double* pzr_tables_omg_ifft(const pzr_tables* t); /* 2m doubles */
+
+/* reim/fft_ref.rs:25-43, reim/ifft_ref.rs:24-42; data = [re(m) | im(m)] in place */
+void pzr_fft(const pzr_tables* t, double* data);
+void pzr_ifft(const pzr_tables* t, double* data);
+
+/* reim/conversion.rs:19-60 */
+void pzr_reim_from_znx_i64(double* res, const int64_t* a, size_t len);
+void pzr_reim_to_znx_i64(int64_t* res, double divisor, const double* a, size_t len);
+void pzr_reim_to_znx_i64_assign(double* res, double divisor, size_t len);
+
+/* reference/fft64/vec_znx_dft.rs */
+void pzr_vec_znx_dft_apply(const pzr_tables* t, size_t step, size_t offset,
+                           double* res, size_t res_cols, size_t res_size, size_t res_col,
+                           const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+void pzr_vec_znx_idft_apply(const pzr_tables* t,
+                            int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                            const double* a, size_t a_cols, size_t a_size, size_t a_col);
+void pzr_vec_znx_idft_apply_tmpa(const pzr_tables* t,
+                                 int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                                 double* a, size_t a_cols, size_t a_size, size_t a_col);
+void pzr_vec_znx_idft_apply_consume(const pzr_tables* t, double* data, size_t cols, size_t size);
+void pzr_vec_znx_dft_add_into(size_t n, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                              const double* a, size_t a_cols, size_t a_size, size_t a_col,
+                              const double* b, size_t b_cols, size_t b_size, size_t b_col);
+void pzr_vec_znx_dft_sub(size_t n, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                         const double* a, size_t a_cols, size_t a_size, size_t a_col,
+                         const double* b, size_t b_cols, size_t b_size, size_t b_col);
+void pzr_vec_znx_dft_add_assign(size_t n, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                                const double* a, size_t a_cols, size_t a_size, size_t a_col);
+void pzr_vec_znx_dft_add_scaled_assign(size_t n, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                                       const double* a, size_t a_cols, size_t a_size, size_t a_col, int64_t a_scale);
+void pzr_vec_znx_dft_sub_assign(size_t n, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                                const double* a, size_t a_cols, size_t a_size, size_t a_col);
+void pzr_vec_znx_dft_sub_negate_assign(size_t n, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                                       const double* a, size_t a_cols, size_t a_size, size_t a_col);
+void pzr_vec_znx_dft_copy(size_t n, size_t step, size_t offset,
+                          double* res, size_t res_cols, size_t res_size, size_t res_col,
+                          const double* a, size_t a_cols, size_t a_size, size_t a_col);
+void pzr_vec_znx_dft_zero(size_t n, double* res, size_t res_cols, size_t res_size, size_t res_col);
+
+/* reference/fft64/svp.rs */
+void pzr_svp_prepare(const pzr_tables* t, double* res, size_t res_cols, size_t res_col,
+                     const int64_t* a, size_t a_cols, size_t a_col);
+void pzr_svp_apply_dft(const pzr_tables* t,
+                       double* res, size_t res_cols, size_t res_size, size_t res_col,
+                       const double* ppol, size_t a_cols, size_t a_col,
+                       const int64_t* b, size_t b_cols, size_t b_size, size_t b_col);
+void pzr_svp_apply_dft_to_dft(size_t n,
+                              double* res, size_t res_cols, size_t res_size, size_t res_col,
+                              const double* ppol, size_t a_cols, size_t a_col,
+                              const double* b, size_t b_cols, size_t b_size, size_t b_col);
+void pzr_svp_apply_dft_to_dft_assign(size_t n,
+                                     double* res, size_t res_cols, size_t res_size, size_t res_col,
+                                     const double* ppol, size_t a_cols, size_t a_col);
+
+/* reference/fft64/vmp.rs */
+size_t pzr_vmp_prepare_tmp_bytes(size_t n);
+size_t pzr_vmp_apply_dft_to_dft_tmp_bytes(size_t a_size, size_t prows, size_t pcols_in);
+size_t pzr_vmp_apply_dft_tmp_bytes(size_t n, size_t a_size, size_t prows, size_t pcols_in);
+void pzr_vmp_prepare(const pzr_tables* t, double* pmat, const int64_t* mat,
+                     size_t rows, size_t cols_in, size_t cols_out, size_t size);
+void pzr_vmp_apply_dft_to_dft(size_t n,
+                              double* res, size_t res_cols, size_t res_size,
+                              const double* a, size_t a_cols, size_t a_size,
+                              const double* pmat, size_t rows, size_t cols_in, size_t cols_out, size_t size,
+                              size_t limb_offset);
+void pzr_vmp_apply_dft(const pzr_tables* t,
+                       double* res, size_t res_cols, size_t res_size,
+                       const int64_t* a, size_t a_cols, size_t a_size,
+                       const double* pmat, size_t rows, size_t cols_in, size_t cols_out, size_t size);
+
+/* reference/fft64/vec_znx_big.rs:122-138, 236-278 ; reference/vec_znx/normalize.rs */
+void pzr_vec_znx_big_add_small_assign(size_t n, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                                      const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+size_t pzr_vec_znx_normalize_tmp_bytes(size_t n);
+void pzr_vec_znx_normalize(size_t n,
+                           int64_t* res, size_t res_cols, size_t res_size, size_t res_base2k, int64_t res_offset, size_t res_col,
+                           const int64_t* a, size_t a_cols, size_t a_size, size_t a_base2k, size_t a_col);
+
+/* poulpy-core callers restated on top of the primitives above (rank = cols-1):
+ *   external_product/glwe.rs:99-141,197-271 ; keyswitching/glwe.rs:53-109,207-239,298-380 */
+void pzr_glwe_external_product(const pzr_tables* t, size_t rank,
+                               int64_t* res, size_t res_size, size_t res_base2k,
+                               const int64_t* a, size_t a_size, size_t a_base2k,
+                               const double* ggsw_pmat, size_t dnum, size_t ggsw_size, size_t dsize, size_t ggsw_base2k);
+void pzr_glwe_keyswitch(const pzr_tables* t, size_t rank_in, size_t rank_out,
+                        int64_t* res, size_t res_size, size_t res_base2k,
+                        const int64_t* a, size_t a_size, size_t a_base2k,
+                        const double* key_pmat, size_t dnum, size_t key_size, size_t dsize, size_t key_base2k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

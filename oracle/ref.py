@@ -1,0 +1,212 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY ("parity unpinned" by reference fixtures, see fft64_ref.h).
+
+ctypes wrapper over oracle/_build/libpoulpy_oracle.so exposing the C restatement of
+poulpy-cpu-ref's FFT64 family through the same method names and container classes as
+poulpy_amd.hal.Module, so that parity tests read `ref.op(...)` / `hip.op(...)` like the
+reference's cross_backend_test_suite (poulpy-hal/src/test_suite/mod.rs:64-95).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from ctypes import c_double, c_int64, c_size_t, c_uint64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(_HERE, "_build", "libpoulpy_oracle.so")
+SO_FAST = os.path.join(_HERE, "_build", "libpoulpy_oracle_fast.so")
+
+
+def build(fast: bool = False) -> str:
+    target = "fast" if fast else "all"
+    subprocess.run(["make", "-s", "-C", _HERE, target], check=True)
+    return SO_FAST if fast else SO
+
+
+def load(fast: bool = False) -> C.CDLL:
+    path = SO_FAST if fast else SO
+    if not os.path.exists(path):
+        build(fast)
+    lib = C.CDLL(path)
+    lib.pzr_tables_new.restype = c_void_p
+    lib.pzr_tables_new.argtypes = [c_uint64]
+    lib.pzr_tables_free.argtypes = [c_void_p]
+    lib.pzr_tables_omg_fft.restype = C.POINTER(c_double)
+    lib.pzr_tables_omg_ifft.restype = C.POINTER(c_double)
+    lib.pzr_tables_omg_fft.argtypes = [c_void_p]
+    lib.pzr_tables_omg_ifft.argtypes = [c_void_p]
+    for name in ("pzr_vmp_prepare_tmp_bytes", "pzr_vmp_apply_dft_to_dft_tmp_bytes", "pzr_vmp_apply_dft_tmp_bytes",
+                 "pzr_vec_znx_normalize_tmp_bytes"):
+        getattr(lib, name).restype = c_size_t
+    return lib
+
+
+def _p(arr):
+    return arr.ctypes.data_as(c_void_p)
+
+
+def _sz(*xs):
+    return [c_size_t(int(x)) for x in xs]
+
+
+class RefModule:
+    """``Module<FFT64Ref>`` restated (poulpy-cpu-ref/src/fft64/module.rs)."""
+
+    def __init__(self, n: int, fast: bool = False):
+        self.lib = load(fast)
+        self._n = int(n)
+        self.t = c_void_p(self.lib.pzr_tables_new(c_uint64(n)))
+        if not self.t.value:
+            raise ValueError(f"n must be a power of two >= 2 but is {n}")
+
+    def n(self):
+        return self._n
+
+    def __del__(self):
+        try:
+            if self.t is not None and self.t.value:
+                self.lib.pzr_tables_free(self.t)
+                self.t = None
+        except Exception:
+            pass
+
+    # raw transforms on [re | im] arrays
+    def fft(self, data: np.ndarray):
+        assert data.dtype == np.float64 and data.size == self._n
+        self.lib.pzr_fft(self.t, _p(data))
+
+    def ifft(self, data: np.ndarray):
+        assert data.dtype == np.float64 and data.size == self._n
+        self.lib.pzr_ifft(self.t, _p(data))
+
+    def omg_fft(self) -> np.ndarray:
+        return np.ctypeslib.as_array(self.lib.pzr_tables_omg_fft(self.t), shape=(self._n,)).copy()
+
+    def omg_ifft(self) -> np.ndarray:
+        return np.ctypeslib.as_array(self.lib.pzr_tables_omg_ifft(self.t), shape=(self._n,)).copy()
+
+    # allocation helpers with the reference's layouts
+    def vec_znx_dft_alloc(self, cols, size):
+        from poulpy_amd.layouts import VecZnxDft
+        return VecZnxDft(self._n, cols, size)
+
+    def vec_znx_big_alloc(self, cols, size):
+        from poulpy_amd.layouts import VecZnxBig
+        return VecZnxBig(self._n, cols, size)
+
+    def svp_ppol_alloc(self, cols):
+        from poulpy_amd.layouts import SvpPPol
+        return SvpPPol(self._n, cols)
+
+    def vmp_pmat_alloc(self, rows, cols_in, cols_out, size):
+        from poulpy_amd.layouts import VmpPMat
+        return VmpPMat(self._n, rows, cols_in, cols_out, size)
+
+    # VecZnxDft
+    def vec_znx_dft_apply(self, step, offset, res, res_col, a, a_col):
+        self.lib.pzr_vec_znx_dft_apply(self.t, *_sz(step, offset), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                       *_sz(a.cols, a.size, a_col))
+
+    def vec_znx_idft_apply(self, res, res_col, a, a_col, scratch=None):
+        self.lib.pzr_vec_znx_idft_apply(self.t, _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data), *_sz(a.cols, a.size, a_col))
+
+    def vec_znx_idft_apply_tmpa(self, res, res_col, a, a_col):
+        self.lib.pzr_vec_znx_idft_apply_tmpa(self.t, _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                             *_sz(a.cols, a.size, a_col))
+
+    def vec_znx_idft_apply_consume(self, a):
+        self.lib.pzr_vec_znx_idft_apply_consume(self.t, _p(a.data), *_sz(a.cols, a.size))
+        return a.into_big()
+
+    def _dft3(self, fn, res, res_col, a, a_col, b, b_col):
+        fn(c_size_t(self._n), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data), *_sz(a.cols, a.size, a_col), _p(b.data),
+           *_sz(b.cols, b.size, b_col))
+
+    def _dft2(self, fn, res, res_col, a, a_col, *extra):
+        fn(c_size_t(self._n), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data), *_sz(a.cols, a.size, a_col), *extra)
+
+    def vec_znx_dft_add_into(self, res, res_col, a, a_col, b, b_col):
+        self._dft3(self.lib.pzr_vec_znx_dft_add_into, res, res_col, a, a_col, b, b_col)
+
+    def vec_znx_dft_sub(self, res, res_col, a, a_col, b, b_col):
+        self._dft3(self.lib.pzr_vec_znx_dft_sub, res, res_col, a, a_col, b, b_col)
+
+    def vec_znx_dft_add_assign(self, res, res_col, a, a_col):
+        self._dft2(self.lib.pzr_vec_znx_dft_add_assign, res, res_col, a, a_col)
+
+    def vec_znx_dft_add_scaled_assign(self, res, res_col, a, a_col, a_scale):
+        self._dft2(self.lib.pzr_vec_znx_dft_add_scaled_assign, res, res_col, a, a_col, c_int64(a_scale))
+
+    def vec_znx_dft_sub_assign(self, res, res_col, a, a_col):
+        self._dft2(self.lib.pzr_vec_znx_dft_sub_assign, res, res_col, a, a_col)
+
+    def vec_znx_dft_sub_negate_assign(self, res, res_col, a, a_col):
+        self._dft2(self.lib.pzr_vec_znx_dft_sub_negate_assign, res, res_col, a, a_col)
+
+    def vec_znx_dft_copy(self, step, offset, res, res_col, a, a_col):
+        self.lib.pzr_vec_znx_dft_copy(c_size_t(self._n), *_sz(step, offset), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                      *_sz(a.cols, a.size, a_col))
+
+    def vec_znx_dft_zero(self, res, res_col):
+        self.lib.pzr_vec_znx_dft_zero(c_size_t(self._n), _p(res.data), *_sz(res.cols, res.size, res_col))
+
+    # SVP
+    def svp_prepare(self, res, res_col, a, a_col):
+        self.lib.pzr_svp_prepare(self.t, _p(res.data), *_sz(res.cols, res_col), _p(a.data), *_sz(a.cols, a_col))
+
+    def svp_apply_dft(self, res, res_col, a, a_col, b, b_col):
+        self.lib.pzr_svp_apply_dft(self.t, _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data), *_sz(a.cols, a_col), _p(b.data),
+                                   *_sz(b.cols, b.size, b_col))
+
+    def svp_apply_dft_to_dft(self, res, res_col, a, a_col, b, b_col):
+        self.lib.pzr_svp_apply_dft_to_dft(c_size_t(self._n), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                          *_sz(a.cols, a_col), _p(b.data), *_sz(b.cols, b.size, b_col))
+
+    def svp_apply_dft_to_dft_assign(self, res, res_col, a, a_col):
+        self.lib.pzr_svp_apply_dft_to_dft_assign(c_size_t(self._n), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                                 *_sz(a.cols, a_col))
+
+    # VMP
+    def vmp_prepare(self, res, a, scratch=None):
+        self.lib.pzr_vmp_prepare(self.t, _p(res.data), _p(a.data), *_sz(a.rows, a.cols_in, a.cols_out, a.size))
+
+    def vmp_apply_dft(self, res, a, b, scratch=None):
+        self.lib.pzr_vmp_apply_dft(self.t, _p(res.data), *_sz(res.cols, res.size), _p(a.data), *_sz(a.cols, a.size), _p(b.data),
+                                   *_sz(b.rows, b.cols_in, b.cols_out, b.size))
+
+    def vmp_apply_dft_to_dft(self, res, a, b, limb_offset=0, scratch=None):
+        self.lib.pzr_vmp_apply_dft_to_dft(c_size_t(self._n), _p(res.data), *_sz(res.cols, res.size), _p(a.data), *_sz(a.cols, a.size),
+                                          _p(b.data), *_sz(b.rows, b.cols_in, b.cols_out, b.size), c_size_t(limb_offset))
+
+    def vmp_apply_dft_to_dft_tmp_bytes(self, res_size, a_size, b_rows, b_cols_in, b_cols_out, b_size):
+        return self.lib.pzr_vmp_apply_dft_to_dft_tmp_bytes(*_sz(a_size, b_rows, b_cols_in))
+
+    def vmp_prepare_tmp_bytes(self, rows, cols_in, cols_out, size):
+        return self.lib.pzr_vmp_prepare_tmp_bytes(c_size_t(self._n))
+
+    def vec_znx_big_normalize_tmp_bytes(self):
+        return self.lib.pzr_vec_znx_normalize_tmp_bytes(c_size_t(self._n))
+
+    # VecZnxBig
+    def vec_znx_big_normalize(self, res, res_base2k, res_offset, res_col, a, a_base2k, a_col, scratch=None):
+        self.lib.pzr_vec_znx_normalize(c_size_t(self._n), _p(res.data), *_sz(res.cols, res.size, res_base2k), c_int64(res_offset),
+                                       c_size_t(res_col), _p(a.data), *_sz(a.cols, a.size, a_base2k, a_col))
+
+    vec_znx_normalize = vec_znx_big_normalize
+
+    def vec_znx_big_add_small_assign(self, res, res_col, a, a_col):
+        self.lib.pzr_vec_znx_big_add_small_assign(c_size_t(self._n), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                                  *_sz(a.cols, a.size, a_col))
+
+    # poulpy-core callers
+    def glwe_external_product(self, res, res_base2k, a, a_base2k, pmat, dsize, ggsw_base2k):
+        rank = a.cols - 1
+        self.lib.pzr_glwe_external_product(self.t, c_size_t(rank), _p(res.data), *_sz(res.size, res_base2k), _p(a.data),
+                                           *_sz(a.size, a_base2k), _p(pmat.data), *_sz(pmat.rows, pmat.size, dsize, ggsw_base2k))
+
+    def glwe_keyswitch(self, res, res_base2k, a, a_base2k, pmat, dsize, key_base2k):
+        rank_in, rank_out = a.cols - 1, res.cols - 1
+        self.lib.pzr_glwe_keyswitch(self.t, *_sz(rank_in, rank_out), _p(res.data), *_sz(res.size, res_base2k), _p(a.data),
+                                    *_sz(a.size, a_base2k), _p(pmat.data), *_sz(pmat.rows, pmat.size, dsize, key_base2k))

@@ -1,0 +1,1047 @@
+// api.hip — the C ABI of libpoulpy_hip.so (include/poulpy_hip.h) on top of the
+// gfx950 kernels in device_fft.hpp / device_ops.hpp.
+//
+// Structure: every public entry point (a) validates shapes the way the reference
+// asserts them, (b) resolves each pointer to a device pointer (staging host
+// buffers), (c) calls a `dev_*` routine that only sees device pointers and batch
+// strides, (d) copies results back for host buffers.  The batched entry points
+// call the same `dev_*` routines with batch > 1.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "device_fft.hpp"
+#include "device_ops.hpp"
+#include "module.hpp"
+
+using namespace pz;
+
+// ------------------------------------------------------------------------------
+// kernel dispatch
+// ------------------------------------------------------------------------------
+#define PZ_P1_CASES(X) X(4, 1, 4) X(8, 1, 4) X(8, 1, 16) X(16, 1, 16) X(8, 4, 16) X(8, 8, 16) X(16, 8, 16) X(16, 16, 16)
+#define PZ_P2_CASES(X) X(4, 1, 4) X(8, 1, 4) X(16, 1, 4) X(16, 1, 16) X(8, 4, 16) X(8, 8, 16) X(16, 8, 16) X(16, 16, 16)
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024)
+        PZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return PZ_OK;
+}
+
+static int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* T) {
+    const FftPlan& pl = M->plan;
+    const int blocks = npolys * (pl.m2 / pl.cb);
+    if (blocks == 0) return PZ_OK;
+#define X(A, B, C)                                                                                              \
+    if (pl.r1a == A && pl.r1b == B && pl.cb == C) {                                                             \
+        const size_t lds = (size_t)(A + 1) * C * B * sizeof(cplx);                                              \
+        PZ_TRY(set_lds(k_fwd_pass1<A, B, C>, lds));                                                             \
+        hipLaunchKernelGGL((k_fwd_pass1<A, B, C>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, src, smap, T, \
+                           pl.m2, M->tw1, M->wL1, M->tw12);                                                     \
+        PZ_HIP(hipGetLastError());                                                                              \
+        return PZ_OK;                                                                                           \
+    }
+    PZ_P1_CASES(X)
+#undef X
+    return fail(PZ_ERR_UNSUPPORTED, "no forward pass-1 kernel for m1=%d", pl.m1);
+}
+
+static int launch_fwd_pass2(pz_module* M, int npolys, const cplx* T, double* dst, PolyMap dmap, const cplx* mul) {
+    const FftPlan& pl = M->plan;
+    const int blocks = npolys * (pl.m1 / pl.qb);
+    if (blocks == 0) return PZ_OK;
+#define X(A, B, C)                                                                                              \
+    if (pl.r2a == A && pl.r2b == B && pl.qb == C) {                                                             \
+        const size_t lds = (size_t)A * B * C * sizeof(cplx);                                                    \
+        PZ_TRY(set_lds(k_fwd_pass2<A, B, C>, lds));                                                             \
+        hipLaunchKernelGGL((k_fwd_pass2<A, B, C>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, T, dst, dmap, \
+                           pl.m1, M->wL2, mul);                                                                 \
+        PZ_HIP(hipGetLastError());                                                                              \
+        return PZ_OK;                                                                                           \
+    }
+    PZ_P2_CASES(X)
+#undef X
+    return fail(PZ_ERR_UNSUPPORTED, "no forward pass-2 kernel for m2=%d", pl.m2);
+}
+
+static int launch_inv_pass2(pz_module* M, int npolys, const double* src, PolyMap smap, cplx* T) {
+    const FftPlan& pl = M->plan;
+    const int blocks = npolys * (pl.m1 / pl.qb);
+    if (blocks == 0) return PZ_OK;
+#define X(A, B, C)                                                                                              \
+    if (pl.r2a == A && pl.r2b == B && pl.qb == C) {                                                             \
+        const size_t lds = (size_t)A * B * C * sizeof(cplx);                                                    \
+        PZ_TRY(set_lds(k_inv_pass2<A, B, C>, lds));                                                             \
+        hipLaunchKernelGGL((k_inv_pass2<A, B, C>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, src, smap, T, \
+                           pl.m1, M->wL2, M->tw12);                                                             \
+        PZ_HIP(hipGetLastError());                                                                              \
+        return PZ_OK;                                                                                           \
+    }
+    PZ_P2_CASES(X)
+#undef X
+    return fail(PZ_ERR_UNSUPPORTED, "no inverse pass-2 kernel for m2=%d", pl.m2);
+}
+
+static int launch_inv_pass1(pz_module* M, int npolys, const cplx* T, long long* dst, PolyMap dmap) {
+    const FftPlan& pl = M->plan;
+    const int blocks = npolys * (pl.m2 / pl.cb);
+    if (blocks == 0) return PZ_OK;
+#define X(A, B, C)                                                                                              \
+    if (pl.r1a == A && pl.r1b == B && pl.cb == C) {                                                             \
+        const size_t lds = (size_t)(A + 1) * C * B * sizeof(cplx);                                              \
+        if (M->probe) {                                                                                         \
+            PZ_TRY(set_lds(k_inv_pass1<A, B, C, true>, lds));                                                   \
+            hipLaunchKernelGGL((k_inv_pass1<A, B, C, true>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, T, \
+                               dst, dmap, pl.m2, M->tw1inv, M->wL1, M->margin);                                 \
+        } else {                                                                                                \
+            PZ_TRY(set_lds(k_inv_pass1<A, B, C, false>, lds));                                                  \
+            hipLaunchKernelGGL((k_inv_pass1<A, B, C, false>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, T, \
+                               dst, dmap, pl.m2, M->tw1inv, M->wL1, M->margin);                                 \
+        }                                                                                                       \
+        PZ_HIP(hipGetLastError());                                                                              \
+        return PZ_OK;                                                                                           \
+    }
+    PZ_P1_CASES(X)
+#undef X
+    return fail(PZ_ERR_UNSUPPORTED, "no inverse pass-1 kernel for m1=%d", pl.m1);
+}
+
+static int launch_ew(pz_module* M, int op, void* res, long long res_bs, long long res_ls, const void* a, long long a_bs,
+                     long long a_ls, const void* b, long long b_bs, long long b_ls, int nlimbs, int batch) {
+    if (nlimbs <= 0 || batch <= 0) return PZ_OK;
+    EwArgs g;
+    g.res = res; g.a = a; g.b = b;
+    g.res_bs = res_bs; g.res_ls = res_ls; g.a_bs = a_bs; g.a_ls = a_ls; g.b_bs = b_bs; g.b_ls = b_ls;
+    g.nlimbs = nlimbs; g.n = (int)M->n; g.batch = batch; g.op = op;
+    const long long total = (long long)batch * nlimbs * (long long)(M->n / 2);
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_ew, dim3(blocks), dim3(256), 0, M->stream, g);
+    PZ_HIP(hipGetLastError());
+    return PZ_OK;
+}
+
+// ------------------------------------------------------------------------------
+// device-level operations (device pointers, batch strides in scalars)
+// ------------------------------------------------------------------------------
+struct DV {          // a batched VecZnx-like container on the device
+    void* p;
+    long long bs;    // scalars between consecutive batch objects
+    int cols, size;
+};
+static inline long long limb_stride(const pz_module* M, const DV& v) { return (long long)v.cols * (long long)M->n; }
+static inline void* poly_ptr(const pz_module* M, const DV& v, int col, int limb) {
+    return (char*)v.p + 8 * ((long long)M->n * ((long long)limb * v.cols + col));
+}
+
+// vec_znx_dft_apply on `ncs` consecutive columns (res_col.., a_col..)  [vec_znx_dft.rs:160-200]
+static int dev_dft_apply(pz_module* M, int batch, int step, int offset, DV res, int res_col, DV a, int a_col, int ncs,
+                         const cplx* mul, cplx* T) {
+    const long long n = (long long)M->n;
+    const int steps = (a.size + step - 1) / step;
+    const int min_steps = std::min(res.size, steps);
+    int nv = 0;
+    if (offset < a.size) nv = std::min(min_steps, (a.size - offset + step - 1) / step);
+    if (nv > 0) {
+        PolyMap sm{nv, ncs, a.bs, (long long)step * a.cols * n, n, n * ((long long)offset * a.cols + a_col)};
+        PolyMap dm{nv, ncs, res.bs, (long long)res.cols * n, n, n * res_col};
+        const int npolys = batch * nv * ncs;
+        PZ_TRY(launch_fwd_pass1(M, npolys, (const long long*)a.p, sm, T));
+        PZ_TRY(launch_fwd_pass2(M, npolys, T, (double*)res.p, dm, mul));
+    }
+    // limbs [nv, min_steps) are left untouched (vec_znx_dft.rs:191-194); the rest is zeroed
+    for (int c = 0; c < ncs; ++c)
+        PZ_TRY(launch_ew(M, EW_ZERO, poly_ptr(M, res, res_col + c, min_steps), res.bs, limb_stride(M, res), nullptr, 0, 0,
+                         nullptr, 0, 0, res.size - min_steps, batch));
+    return PZ_OK;
+}
+
+// inverse transform of `nlimbs` limbs x `ncs` columns: a (f64) -> res (i64)
+static int dev_idft(pz_module* M, int batch, DV res, int res_col, DV a, int a_col, int ncs, int nlimbs, cplx* T) {
+    const long long n = (long long)M->n;
+    if (nlimbs <= 0) return PZ_OK;
+    PolyMap sm{nlimbs, ncs, a.bs, (long long)a.cols * n, n, n * a_col};
+    PolyMap dm{nlimbs, ncs, res.bs, (long long)res.cols * n, n, n * res_col};
+    const int npolys = batch * nlimbs * ncs;
+    PZ_TRY(launch_inv_pass2(M, npolys, (const double*)a.p, sm, T));
+    PZ_TRY(launch_inv_pass1(M, npolys, T, (long long*)res.p, dm));
+    return PZ_OK;
+}
+
+// vmp_apply_dft_to_dft  [vmp.rs:144-264, zero-tail semantics for limb_offset > 0]
+static int dev_vmp(pz_module* M, int batch, DV res, DV a, const double* pmat, int rows, int cols_in, int cols_out, int size,
+                   int limb_offset) {
+    const int nrows = rows * cols_in, ncols = cols_out * size;
+    const int a_polys = a.cols * a.size, res_polys = res.cols * res.size;
+    const int row_max = std::min(nrows, a_polys);
+    const int off = limb_offset * cols_out;
+    const int ncomp = off < ncols ? std::min(res_polys, ncols - off) : 0;
+    if (res_polys == 0) return PZ_OK;
+    if (ncomp == 0) {
+        return launch_ew(M, EW_ZERO, res.p, res.bs, (long long)M->n, nullptr, 0, 0, nullptr, 0, 0, res_polys, batch);
+    }
+    const int m = (int)M->m;
+    if (batch >= 4) {
+        dim3 grid((m + 63) / 64, (res_polys + 15) / 16, (batch + 3) / 4);
+        hipLaunchKernelGGL((k_vmp<4, 4>), grid, dim3(256), 0, M->stream, (double*)res.p, res.bs, res_polys, (const double*)a.p,
+                           a.bs, pmat, ncols, off, row_max, ncomp, m, batch);
+    } else {
+        dim3 grid((m + 63) / 64, (res_polys + 15) / 16, batch);
+        hipLaunchKernelGGL((k_vmp<1, 4>), grid, dim3(256), 0, M->stream, (double*)res.p, res.bs, res_polys, (const double*)a.p,
+                           a.bs, pmat, ncols, off, row_max, ncomp, m, batch);
+    }
+    PZ_HIP(hipGetLastError());
+    return PZ_OK;
+}
+
+// vec_znx_(big_)normalize on one column  [normalize.rs:18-401]
+static int dev_normalize(pz_module* M, int batch, DV res, int res_base2k, long long res_offset, int res_col, DV a, int a_base2k,
+                         int a_col) {
+    NzArgs g;
+    g.res = (long long*)res.p; g.a = (const long long*)a.p;
+    g.res_bs = res.bs; g.a_bs = a.bs;
+    g.n = (int)M->n; g.batch = batch;
+    g.res_cols = res.cols; g.res_size = res.size; g.res_col = res_col;
+    g.a_cols = a.cols; g.a_size = a.size; g.a_col = a_col;
+    g.res_base2k = res_base2k; g.a_base2k = a_base2k;
+    g.lsh = g.res_end = g.res_start = g.a_end = g.a_start = 0;
+    const long long total = (long long)batch * (long long)M->n;
+    const int blocks = (int)((total + 255) / 256);
+    if (blocks == 0) return PZ_OK;
+    if (res_base2k == a_base2k) {
+        const long long k = res_base2k;
+        long long lsh = res_offset % k, lo = res_offset / k;
+        if (res_offset < 0 && lsh != 0) { lsh = (lsh + k) % k; lo -= 1; }
+        auto cl = [](long long v, long long lo_, long long hi_) { return v < lo_ ? lo_ : (v > hi_ ? hi_ : v); };
+        g.lsh = (int)lsh;
+        g.res_end = (int)cl(-lo, 0, res.size);
+        g.res_start = (int)cl((long long)a.size - lo, 0, res.size);
+        g.a_end = (int)cl(lo, 0, a.size);
+        g.a_start = (int)cl((long long)res.size + lo, 0, a.size);
+        hipLaunchKernelGGL(k_normalize_inter, dim3(blocks), dim3(256), 0, M->stream, g);
+    } else {
+        hipLaunchKernelGGL(k_normalize_cross, dim3(blocks), dim3(256), 0, M->stream, g, res_offset);
+    }
+    PZ_HIP(hipGetLastError());
+    return PZ_OK;
+}
+
+// ------------------------------------------------------------------------------
+// host/device pointer resolution
+// ------------------------------------------------------------------------------
+static bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // clear sticky error for unregistered host memory
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+// A staged argument: device view of a (possibly host) container of `bytes` bytes.
+struct Stage {
+    pz_module* M;
+    void* host = nullptr;
+    void* dev = nullptr;
+    size_t bytes = 0;
+    bool owned = false, out = false;
+    int in(const void* p, size_t nbytes, bool copy_in, bool copy_out, pz_module* mod) {
+        M = mod; bytes = nbytes; out = copy_out;
+        if (nbytes == 0) { dev = (void*)p; return PZ_OK; }
+        if (is_device_ptr(p)) { dev = (void*)p; owned = false; return PZ_OK; }
+        host = (void*)p;
+        owned = true;
+        PZ_HIP(hipMallocAsync(&dev, nbytes, M->stream));
+        if (copy_in) PZ_HIP(hipMemcpyAsync(dev, host, nbytes, hipMemcpyHostToDevice, M->stream));
+        return PZ_OK;
+    }
+    int finish() {
+        if (!owned) return PZ_OK;
+        if (out) PZ_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, M->stream));
+        PZ_HIP(hipFreeAsync(dev, M->stream));
+        owned = false;
+        return PZ_OK;
+    }
+    ~Stage() {
+        if (owned && dev) (void)hipFreeAsync(dev, M->stream);
+    }
+};
+
+static int finish_call(pz_module* M, bool any_host) {
+    if (any_host) PZ_HIP(hipStreamSynchronize(M->stream));
+    return PZ_OK;
+}
+
+#define PZ_ENTER(M)                                              \
+    if (!(M)) return fail(PZ_ERR_INVALID, "null module");        \
+    std::lock_guard<std::mutex> lock_((M)->mu);                  \
+    PZ_HIP(hipSetDevice((M)->device));
+
+static inline size_t vbytes(const pz_module* M, size_t cols, size_t size) { return (size_t)M->n * cols * size * 8; }
+
+// ------------------------------------------------------------------------------
+// public: misc
+// ------------------------------------------------------------------------------
+extern "C" {
+
+const char* pz_last_error(void) { return last_error_ref().c_str(); }
+uint32_t pz_abi_version(void) { return 1; }
+
+int pz_module_new_on_device(uint64_t n, int device, pz_module** out) {
+    if (!out) return fail(PZ_ERR_INVALID, "null out");
+    *out = nullptr;
+    FftPlan pl;
+    if (n < 2 || (n & (n - 1))) return fail(PZ_ERR_INVALID, "n must be a power of two but is %llu", (unsigned long long)n);
+    if (!make_plan(n, pl)) return fail(PZ_ERR_UNSUPPORTED, "n=%llu unsupported (need 32 <= n <= 131072)", (unsigned long long)n);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return fail(PZ_ERR_HIP, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(PZ_ERR_INVALID, "device %d out of range (have %d)", device, ndev);
+    PZ_HIP(hipSetDevice(device));
+    pz_module* M = new pz_module();
+    M->n = n; M->m = n >> 1; M->device = device; M->plan = pl;
+    int r = PZ_OK;
+    do {
+        if (hipStreamCreateWithFlags(&M->stream, hipStreamNonBlocking) != hipSuccess) { r = fail(PZ_ERR_HIP, "stream create failed"); break; }
+        if ((r = build_tables(M)) != PZ_OK) break;
+        if (hipMalloc(&M->margin, 8) != hipSuccess) { r = fail(PZ_ERR_HIP, "margin alloc failed"); break; }
+        if (hipMemset(M->margin, 0, 8) != hipSuccess) { r = fail(PZ_ERR_HIP, "margin memset failed"); break; }
+    } while (0);
+    if (r != PZ_OK) { pz_module_free(M); return r; }
+    *out = M;
+    return PZ_OK;
+}
+int pz_module_new(uint64_t n, pz_module** out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    return pz_module_new_on_device(n, dev, out);
+}
+void pz_module_free(pz_module* M) {
+    if (!M) return;
+    (void)hipSetDevice(M->device);
+    if (M->stream) (void)hipStreamSynchronize(M->stream);
+    for (void* p : {(void*)M->tw1, (void*)M->tw1inv, (void*)M->wL1, (void*)M->wL2, (void*)M->tw12, M->ws, (void*)M->margin})
+        if (p) (void)hipFree(p);
+    if (M->stream) (void)hipStreamDestroy(M->stream);
+    delete M;
+}
+uint64_t pz_module_n(const pz_module* M) { return M ? M->n : 0; }
+int pz_module_device(const pz_module* M) { return M ? M->device : -1; }
+int pz_module_sync(pz_module* M) {
+    if (!M) return fail(PZ_ERR_INVALID, "null module");
+    PZ_HIP(hipSetDevice(M->device));
+    PZ_HIP(hipStreamSynchronize(M->stream));
+    return PZ_OK;
+}
+void* pz_module_stream(pz_module* M) { return M ? (void*)M->stream : nullptr; }
+int pz_module_set_chunk(pz_module* M, size_t c) {
+    if (!M) return fail(PZ_ERR_INVALID, "null module");
+    M->chunk = c;
+    return PZ_OK;
+}
+int pz_module_set_margin_probe(pz_module* M, int enable) {
+    PZ_ENTER(M);
+    M->probe = enable != 0;
+    PZ_HIP(hipMemsetAsync(M->margin, 0, 8, M->stream));
+    PZ_HIP(hipStreamSynchronize(M->stream));
+    return PZ_OK;
+}
+int pz_module_get_margin(pz_module* M, double* max_frac) {
+    PZ_ENTER(M);
+    unsigned long long bits = 0;
+    PZ_HIP(hipStreamSynchronize(M->stream));
+    PZ_HIP(hipMemcpy(&bits, M->margin, 8, hipMemcpyDeviceToHost));
+    double d;
+    memcpy(&d, &bits, 8);
+    if (max_frac) *max_frac = d;
+    return PZ_OK;
+}
+
+void* pz_alloc_bytes(size_t len) {
+    void* p = nullptr;
+    if (len == 0) len = 64;
+    if (hipHostMalloc(&p, len, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    memset(p, 0, len);
+    return p;
+}
+void pz_free_bytes(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+int pz_device_alloc(pz_module* M, size_t len, void** out) {
+    if (!M || !out) return fail(PZ_ERR_INVALID, "null argument");
+    PZ_HIP(hipSetDevice(M->device));
+    PZ_HIP(hipMalloc(out, len ? len : 64));
+    return PZ_OK;
+}
+int pz_device_free(pz_module* M, void* p) {
+    if (!M) return fail(PZ_ERR_INVALID, "null module");
+    PZ_HIP(hipSetDevice(M->device));
+    PZ_HIP(hipStreamSynchronize(M->stream));
+    if (p) PZ_HIP(hipFree(p));
+    return PZ_OK;
+}
+int pz_memcpy_h2d(pz_module* M, void* d, const void* s, size_t len) {
+    if (!M) return fail(PZ_ERR_INVALID, "null module");
+    PZ_HIP(hipSetDevice(M->device));
+    PZ_HIP(hipMemcpyAsync(d, s, len, hipMemcpyHostToDevice, M->stream));
+    PZ_HIP(hipStreamSynchronize(M->stream));
+    return PZ_OK;
+}
+int pz_memcpy_d2h(pz_module* M, void* d, const void* s, size_t len) {
+    if (!M) return fail(PZ_ERR_INVALID, "null module");
+    PZ_HIP(hipSetDevice(M->device));
+    PZ_HIP(hipMemcpyAsync(d, s, len, hipMemcpyDeviceToHost, M->stream));
+    PZ_HIP(hipStreamSynchronize(M->stream));
+    return PZ_OK;
+}
+int pz_memset_d(pz_module* M, void* d, int v, size_t len) {
+    if (!M) return fail(PZ_ERR_INVALID, "null module");
+    PZ_HIP(hipSetDevice(M->device));
+    PZ_HIP(hipMemsetAsync(d, v, len, M->stream));
+    return PZ_OK;
+}
+
+size_t pz_bytes_of_vec_znx(uint64_t n, size_t cols, size_t size) { return (size_t)n * cols * size * 8; }
+size_t pz_bytes_of_vec_znx_dft(uint64_t n, size_t cols, size_t size) { return (size_t)n * cols * size * 8; }
+size_t pz_bytes_of_vec_znx_big(uint64_t n, size_t cols, size_t size) { return (size_t)n * cols * size * 8; }
+size_t pz_bytes_of_svp_ppol(uint64_t n, size_t cols) { return (size_t)n * cols * 8; }
+size_t pz_bytes_of_vmp_pmat(uint64_t n, size_t rows, size_t cols_in, size_t cols_out, size_t size) {
+    return (size_t)n * rows * cols_in * cols_out * size * 8;
+}
+
+int pz_event_create(void** ev) {
+    hipEvent_t e;
+    PZ_HIP(hipEventCreate(&e));
+    *ev = (void*)e;
+    return PZ_OK;
+}
+int pz_event_destroy(void* ev) {
+    PZ_HIP(hipEventDestroy((hipEvent_t)ev));
+    return PZ_OK;
+}
+int pz_event_record(pz_module* M, void* ev) {
+    if (!M) return fail(PZ_ERR_INVALID, "null module");
+    PZ_HIP(hipEventRecord((hipEvent_t)ev, M->stream));
+    return PZ_OK;
+}
+int pz_event_elapsed_ms(void* e0, void* e1, float* ms) {
+    PZ_HIP(hipEventSynchronize((hipEvent_t)e1));
+    PZ_HIP(hipEventElapsedTime(ms, (hipEvent_t)e0, (hipEvent_t)e1));
+    return PZ_OK;
+}
+
+// ------------------------------------------------------------------------------
+// public: VecZnxDft
+// ------------------------------------------------------------------------------
+#define PZ_CHECK_COL(col, cols, what) PZ_REQUIRE((col) < (cols), "%s: col %zu >= cols %zu", what, (size_t)(col), (size_t)(cols))
+
+static int need_T(pz_module* M, size_t npolys, cplx** T) {
+    PZ_TRY(ws_reserve(M, npolys * (size_t)M->m * sizeof(cplx)));
+    *T = (cplx*)M->ws;
+    return PZ_OK;
+}
+
+int pz_vec_znx_dft_apply(pz_module* M, size_t step, size_t offset, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                         const int64_t* a, size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    PZ_REQUIRE(step > 0, "vec_znx_dft_apply: step must be > 0");
+    PZ_CHECK_COL(res_col, res_cols, "vec_znx_dft_apply(res)");
+    PZ_CHECK_COL(a_col, a_cols, "vec_znx_dft_apply(a)");
+    Stage sr, sa;
+    PZ_TRY(sa.in(a, vbytes(M, a_cols, a_size), true, false, M));
+    PZ_TRY(sr.in(res, vbytes(M, res_cols, res_size), true, true, M));  // inout: untouched limbs / other columns survive
+    cplx* T;
+    PZ_TRY(need_T(M, std::min(res_size, a_size), &T));
+    DV dr{sr.dev, 0, (int)res_cols, (int)res_size}, da{sa.dev, 0, (int)a_cols, (int)a_size};
+    PZ_TRY(dev_dft_apply(M, 1, (int)step, (int)offset, dr, (int)res_col, da, (int)a_col, 1, nullptr, T));
+    const bool host = sr.owned || sa.owned;
+    PZ_TRY(sr.finish());
+    PZ_TRY(sa.finish());
+    return finish_call(M, host);
+}
+
+int pz_vec_znx_dft_apply_batched(pz_module* M, size_t batch, size_t step, size_t offset, double* res, size_t res_cols,
+                                 size_t res_size, size_t res_col, const int64_t* a, size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    PZ_REQUIRE(step > 0, "vec_znx_dft_apply: step must be > 0");
+    PZ_CHECK_COL(res_col, res_cols, "vec_znx_dft_apply(res)");
+    PZ_CHECK_COL(a_col, a_cols, "vec_znx_dft_apply(a)");
+    PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(a), "batched entry points take device pointers");
+    cplx* T;
+    PZ_TRY(need_T(M, batch * std::min(res_size, a_size), &T));
+    DV dr{res, (long long)(M->n * res_cols * res_size), (int)res_cols, (int)res_size};
+    DV da{(void*)a, (long long)(M->n * a_cols * a_size), (int)a_cols, (int)a_size};
+    return dev_dft_apply(M, (int)batch, (int)step, (int)offset, dr, (int)res_col, da, (int)a_col, 1, nullptr, T);
+}
+
+size_t pz_vec_znx_idft_apply_tmp_bytes(const pz_module*) { return 0; }  // hal_defaults/vec_znx_dft.rs:68-73
+
+static int idft_common(pz_module* M, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const double* a,
+                       size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_CHECK_COL(res_col, res_cols, "vec_znx_idft_apply(res)");
+    PZ_CHECK_COL(a_col, a_cols, "vec_znx_idft_apply(a)");
+    Stage sr, sa;
+    PZ_TRY(sa.in(a, vbytes(M, a_cols, a_size), true, false, M));
+    PZ_TRY(sr.in(res, vbytes(M, res_cols, res_size), true, true, M));
+    const int min_size = (int)std::min(res_size, a_size);
+    cplx* T;
+    PZ_TRY(need_T(M, min_size, &T));
+    DV dr{sr.dev, 0, (int)res_cols, (int)res_size}, da{sa.dev, 0, (int)a_cols, (int)a_size};
+    PZ_TRY(dev_idft(M, 1, dr, (int)res_col, da, (int)a_col, 1, min_size, T));
+    PZ_TRY(launch_ew(M, EW_ZERO, poly_ptr(M, dr, (int)res_col, min_size), 0, limb_stride(M, dr), nullptr, 0, 0, nullptr, 0, 0,
+                     (int)res_size - min_size, 1));
+    const bool host = sr.owned || sa.owned;
+    PZ_TRY(sr.finish());
+    PZ_TRY(sa.finish());
+    return finish_call(M, host);
+}
+
+int pz_vec_znx_idft_apply(pz_module* M, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const double* a,
+                          size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    return idft_common(M, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col);
+}
+int pz_vec_znx_idft_apply_tmpa(pz_module* M, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, double* a,
+                               size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_ENTER(M);  // `a` may be used as scratch by the reference; this backend leaves it intact
+    return idft_common(M, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col);
+}
+
+static int consume_common(pz_module* M, size_t batch, void* data, size_t cols, size_t size, bool require_dev) {
+    if (require_dev) PZ_REQUIRE(is_device_ptr(data), "batched entry points take device pointers");
+    Stage sd;
+    if (require_dev) { sd.M = M; sd.dev = data; }
+    else PZ_TRY(sd.in(data, vbytes(M, cols, size), true, true, M));
+    cplx* T;
+    PZ_TRY(need_T(M, batch * cols * size, &T));
+    DV d{sd.dev, (long long)(M->n * cols * size), (int)cols, (int)size};
+    PZ_TRY(dev_idft(M, (int)batch, d, 0, d, 0, (int)cols, (int)size, T));
+    const bool host = sd.owned;
+    PZ_TRY(sd.finish());
+    return finish_call(M, host);
+}
+int pz_vec_znx_idft_apply_consume(pz_module* M, void* data, size_t cols, size_t size) {
+    PZ_ENTER(M);
+    return consume_common(M, 1, data, cols, size, false);
+}
+int pz_vec_znx_idft_apply_consume_batched(pz_module* M, size_t batch, void* data, size_t cols, size_t size) {
+    PZ_ENTER(M);
+    return consume_common(M, batch, data, cols, size, true);
+}
+
+// generic staged three-operand limb-range op helper
+struct Tri {
+    Stage sr, sa, sb;
+    DV dr, da, db;
+    bool host = false;
+};
+static int tri_in(pz_module* M, Tri& t, double* res, size_t rc, size_t rs, const double* a, size_t ac, size_t as_, const double* b,
+                  size_t bc, size_t bs_) {
+    PZ_TRY(t.sa.in(a, a ? vbytes(M, ac, as_) : 0, true, false, M));
+    if (b) PZ_TRY(t.sb.in(b, vbytes(M, bc, bs_), true, false, M));
+    // res aliasing a or b (assign forms pass res as operand): reuse the same staging
+    if ((const void*)res == (const void*)a) { t.sr.M = M; t.sr.dev = t.sa.dev; t.sa.out = true; }
+    else PZ_TRY(t.sr.in(res, vbytes(M, rc, rs), true, true, M));
+    t.dr = DV{t.sr.dev, 0, (int)rc, (int)rs};
+    t.da = DV{t.sa.dev, 0, (int)ac, (int)as_};
+    t.db = DV{t.sb.dev, 0, (int)bc, (int)bs_};
+    t.host = t.sr.owned || t.sa.owned || t.sb.owned;
+    return PZ_OK;
+}
+static int tri_out(pz_module* M, Tri& t) {
+    PZ_TRY(t.sr.finish());
+    PZ_TRY(t.sa.finish());
+    PZ_TRY(t.sb.finish());
+    return finish_call(M, t.host);
+}
+static int ew_limbs(pz_module* M, int op, const DV& r, int rcol, int rl0, const DV* a, int acol, int al0, const DV* b, int bcol,
+                    int bl0, int nl) {
+    return launch_ew(M, op, poly_ptr(M, r, rcol, rl0), 0, limb_stride(M, r), a ? poly_ptr(M, *a, acol, al0) : nullptr, 0,
+                     a ? limb_stride(M, *a) : 0, b ? poly_ptr(M, *b, bcol, bl0) : nullptr, 0, b ? limb_stride(M, *b) : 0, nl, 1);
+}
+
+static int add_sub_into(pz_module* M, bool sub, double* res, size_t res_cols, size_t res_size, size_t res_col, const double* a,
+                        size_t a_cols, size_t a_size, size_t a_col, const double* b, size_t b_cols, size_t b_size, size_t b_col) {
+    PZ_CHECK_COL(res_col, res_cols, "vec_znx_dft_add/sub(res)");
+    PZ_CHECK_COL(a_col, a_cols, "vec_znx_dft_add/sub(a)");
+    PZ_CHECK_COL(b_col, b_cols, "vec_znx_dft_add/sub(b)");
+    PZ_REQUIRE((const void*)res != (const void*)b, "vec_znx_dft_add/sub: res must not alias b (use the *_assign form)");
+    Tri t;
+    PZ_TRY(tri_in(M, t, res, res_cols, res_size, a, a_cols, a_size, b, b_cols, b_size));
+    const bool a_le_b = a_size <= b_size;
+    const int sum = (int)std::min(a_le_b ? a_size : b_size, res_size);
+    const int cpy = (int)std::min(a_le_b ? b_size : a_size, res_size);
+    PZ_TRY(ew_limbs(M, sub ? EW_SUB : EW_ADD, t.dr, (int)res_col, 0, &t.da, (int)a_col, 0, &t.db, (int)b_col, 0, sum));
+    if (a_le_b) PZ_TRY(ew_limbs(M, sub ? EW_NEG : EW_COPY, t.dr, (int)res_col, sum, &t.db, (int)b_col, sum, nullptr, 0, 0, cpy - sum));
+    else PZ_TRY(ew_limbs(M, EW_COPY, t.dr, (int)res_col, sum, &t.da, (int)a_col, sum, nullptr, 0, 0, cpy - sum));
+    PZ_TRY(ew_limbs(M, EW_ZERO, t.dr, (int)res_col, cpy, nullptr, 0, 0, nullptr, 0, 0, (int)res_size - cpy));
+    return tri_out(M, t);
+}
+int pz_vec_znx_dft_add_into(pz_module* M, double* res, size_t res_cols, size_t res_size, size_t res_col, const double* a,
+                            size_t a_cols, size_t a_size, size_t a_col, const double* b, size_t b_cols, size_t b_size, size_t b_col) {
+    PZ_ENTER(M);
+    return add_sub_into(M, false, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col, b, b_cols, b_size, b_col);
+}
+int pz_vec_znx_dft_sub(pz_module* M, double* res, size_t res_cols, size_t res_size, size_t res_col, const double* a, size_t a_cols,
+                       size_t a_size, size_t a_col, const double* b, size_t b_cols, size_t b_size, size_t b_col) {
+    PZ_ENTER(M);
+    return add_sub_into(M, true, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col, b, b_cols, b_size, b_col);
+}
+
+// res (op)= a over limb ranges; shifts express add_scaled_assign
+static int assign_op(pz_module* M, int op_res_a /*EW_ADD: res+a, EW_SUB: res-a, -EW_SUB: a-res*/, double* res, size_t res_cols,
+                     size_t res_size, size_t res_col, const double* a, size_t a_cols, size_t a_size, size_t a_col, int res_shift,
+                     int a_shift, int nl, bool negate_tail) {
+    PZ_CHECK_COL(res_col, res_cols, "vec_znx_dft_*_assign(res)");
+    PZ_CHECK_COL(a_col, a_cols, "vec_znx_dft_*_assign(a)");
+    Tri t;
+    PZ_TRY(tri_in(M, t, res, res_cols, res_size, a, a_cols, a_size, nullptr, 0, 0));
+    if (op_res_a == EW_ADD || op_res_a == EW_SUB)
+        PZ_TRY(ew_limbs(M, op_res_a, t.dr, (int)res_col, res_shift, &t.dr, (int)res_col, res_shift, &t.da, (int)a_col, a_shift, nl));
+    else
+        PZ_TRY(ew_limbs(M, EW_SUB, t.dr, (int)res_col, res_shift, &t.da, (int)a_col, a_shift, &t.dr, (int)res_col, res_shift, nl));
+    if (negate_tail)
+        PZ_TRY(ew_limbs(M, EW_NEG, t.dr, (int)res_col, nl, &t.dr, (int)res_col, nl, nullptr, 0, 0, (int)res_size - nl));
+    return tri_out(M, t);
+}
+int pz_vec_znx_dft_add_assign(pz_module* M, double* res, size_t res_cols, size_t res_size, size_t res_col, const double* a,
+                              size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    return assign_op(M, EW_ADD, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col, 0, 0, (int)std::min(a_size, res_size), false);
+}
+int pz_vec_znx_dft_sub_assign(pz_module* M, double* res, size_t res_cols, size_t res_size, size_t res_col, const double* a,
+                              size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    return assign_op(M, EW_SUB, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col, 0, 0, (int)std::min(a_size, res_size), false);
+}
+int pz_vec_znx_dft_sub_negate_assign(pz_module* M, double* res, size_t res_cols, size_t res_size, size_t res_col, const double* a,
+                                     size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    return assign_op(M, -EW_SUB, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col, 0, 0, (int)std::min(a_size, res_size), true);
+}
+int pz_vec_znx_dft_add_scaled_assign(pz_module* M, double* res, size_t res_cols, size_t res_size, size_t res_col, const double* a,
+                                     size_t a_cols, size_t a_size, size_t a_col, int64_t a_scale) {
+    PZ_ENTER(M);
+    int rs = 0, as_ = 0, nl;  // vec_znx_dft.rs:93-128
+    if (a_scale > 0) {
+        size_t shift = std::min<size_t>((size_t)a_scale, a_size);
+        size_t mn = std::min(a_size, res_size);
+        nl = (int)(mn > shift ? mn - shift : 0);
+        as_ = (int)shift;
+    } else if (a_scale < 0) {
+        size_t shift = std::min<size_t>((size_t)(-a_scale), res_size);
+        nl = (int)std::min(a_size, res_size - shift);
+        rs = (int)shift;
+    } else {
+        nl = (int)std::min(a_size, res_size);
+    }
+    return assign_op(M, EW_ADD, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col, rs, as_, nl, false);
+}
+
+int pz_vec_znx_dft_copy(pz_module* M, size_t step, size_t offset, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                        const double* a, size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    PZ_REQUIRE(step > 0, "vec_znx_dft_copy: step must be > 0");
+    PZ_CHECK_COL(res_col, res_cols, "vec_znx_dft_copy(res)");
+    PZ_CHECK_COL(a_col, a_cols, "vec_znx_dft_copy(a)");
+    PZ_REQUIRE((const void*)res != (const void*)a, "vec_znx_dft_copy: res must not alias a");
+    Tri t;
+    PZ_TRY(tri_in(M, t, res, res_cols, res_size, a, a_cols, a_size, nullptr, 0, 0));
+    const int steps = (int)((a_size + step - 1) / step);
+    const int min_steps = std::min((int)res_size, steps);
+    int nv = 0;
+    if (offset < a_size) nv = std::min(min_steps, (int)((a_size - offset + step - 1) / step));
+    // strided source limbs: limb stride of the source is step*cols*n
+    PZ_TRY(launch_ew(M, EW_COPY, poly_ptr(M, t.dr, (int)res_col, 0), 0, limb_stride(M, t.dr), poly_ptr(M, t.da, (int)a_col, (int)offset),
+                     0, (long long)step * limb_stride(M, t.da), nullptr, 0, 0, nv, 1));
+    PZ_TRY(ew_limbs(M, EW_ZERO, t.dr, (int)res_col, nv, nullptr, 0, 0, nullptr, 0, 0, (int)res_size - nv));
+    return tri_out(M, t);
+}
+int pz_vec_znx_dft_zero(pz_module* M, double* res, size_t res_cols, size_t res_size, size_t res_col) {
+    PZ_ENTER(M);
+    PZ_CHECK_COL(res_col, res_cols, "vec_znx_dft_zero(res)");
+    Tri t;
+    PZ_TRY(tri_in(M, t, res, res_cols, res_size, nullptr, 0, 0, nullptr, 0, 0));
+    PZ_TRY(ew_limbs(M, EW_ZERO, t.dr, (int)res_col, 0, nullptr, 0, 0, nullptr, 0, 0, (int)res_size));
+    return tri_out(M, t);
+}
+
+// ------------------------------------------------------------------------------
+// public: SVP
+// ------------------------------------------------------------------------------
+int pz_svp_prepare(pz_module* M, double* res, size_t res_cols, size_t res_col, const int64_t* a, size_t a_cols, size_t a_col) {
+    PZ_ENTER(M);
+    PZ_CHECK_COL(res_col, res_cols, "svp_prepare(res)");
+    PZ_CHECK_COL(a_col, a_cols, "svp_prepare(a)");
+    Stage sr, sa;
+    PZ_TRY(sa.in(a, vbytes(M, a_cols, 1), true, false, M));
+    PZ_TRY(sr.in(res, vbytes(M, res_cols, 1), true, true, M));
+    cplx* T;
+    PZ_TRY(need_T(M, 1, &T));
+    DV dr{sr.dev, 0, (int)res_cols, 1}, da{sa.dev, 0, (int)a_cols, 1};
+    PZ_TRY(dev_dft_apply(M, 1, 1, 0, dr, (int)res_col, da, (int)a_col, 1, nullptr, T));
+    const bool host = sr.owned || sa.owned;
+    PZ_TRY(sr.finish());
+    PZ_TRY(sa.finish());
+    return finish_call(M, host);
+}
+
+int pz_svp_apply_dft(pz_module* M, double* res, size_t res_cols, size_t res_size, size_t res_col, const double* ppol, size_t a_cols,
+                     size_t a_col, const int64_t* b, size_t b_cols, size_t b_size, size_t b_col) {
+    PZ_ENTER(M);
+    PZ_CHECK_COL(res_col, res_cols, "svp_apply_dft(res)");
+    PZ_CHECK_COL(a_col, a_cols, "svp_apply_dft(ppol)");
+    PZ_CHECK_COL(b_col, b_cols, "svp_apply_dft(b)");
+    Stage sr, sp, sb;
+    PZ_TRY(sp.in(ppol, vbytes(M, a_cols, 1), true, false, M));
+    PZ_TRY(sb.in(b, vbytes(M, b_cols, b_size), true, false, M));
+    PZ_TRY(sr.in(res, vbytes(M, res_cols, res_size), true, true, M));
+    const int min_size = (int)std::min(res_size, b_size);
+    cplx* T;
+    PZ_TRY(need_T(M, min_size, &T));
+    // svp.rs:21-54: FFT of limbs < min_size times ppol, the rest zero
+    DV dr{sr.dev, 0, (int)res_cols, min_size}, db{sb.dev, 0, (int)b_cols, (int)b_size};
+    const cplx* mul = reinterpret_cast<const cplx*>((const double*)sp.dev + (size_t)M->n * a_col);
+    PZ_TRY(dev_dft_apply(M, 1, 1, 0, dr, (int)res_col, db, (int)b_col, 1, mul, T));
+    DV drf{sr.dev, 0, (int)res_cols, (int)res_size};
+    PZ_TRY(ew_limbs(M, EW_ZERO, drf, (int)res_col, min_size, nullptr, 0, 0, nullptr, 0, 0, (int)res_size - min_size));
+    const bool host = sr.owned || sp.owned || sb.owned;
+    PZ_TRY(sr.finish());
+    PZ_TRY(sp.finish());
+    PZ_TRY(sb.finish());
+    return finish_call(M, host);
+}
+
+static int svp_dft_to_dft(pz_module* M, double* res, size_t res_cols, size_t res_size, size_t res_col, const double* ppol,
+                          size_t a_cols, size_t a_col, const double* b, size_t b_cols, size_t b_size, size_t b_col) {
+    PZ_CHECK_COL(res_col, res_cols, "svp_apply_dft_to_dft(res)");
+    PZ_CHECK_COL(a_col, a_cols, "svp_apply_dft_to_dft(ppol)");
+    PZ_CHECK_COL(b_col, b_cols, "svp_apply_dft_to_dft(b)");
+    Stage sp;
+    PZ_TRY(sp.in(ppol, vbytes(M, a_cols, 1), true, false, M));
+    Tri t;
+    PZ_TRY(tri_in(M, t, res, res_cols, res_size, b, b_cols, b_size, nullptr, 0, 0));
+    const int min_size = (int)std::min(res_size, b_size);
+    // res[j] = ppol * b[j]: the prepared polynomial is the same for every limb (limb stride 0)
+    PZ_TRY(launch_ew(M, EW_CMUL, poly_ptr(M, t.dr, (int)res_col, 0), 0, limb_stride(M, t.dr),
+                     (const double*)sp.dev + (size_t)M->n * a_col, 0, 0, poly_ptr(M, t.da, (int)b_col, 0), 0, limb_stride(M, t.da),
+                     min_size, 1));
+    PZ_TRY(ew_limbs(M, EW_ZERO, t.dr, (int)res_col, min_size, nullptr, 0, 0, nullptr, 0, 0, (int)res_size - min_size));
+    t.host = t.host || sp.owned;
+    PZ_TRY(sp.finish());
+    return tri_out(M, t);
+}
+int pz_svp_apply_dft_to_dft(pz_module* M, double* res, size_t res_cols, size_t res_size, size_t res_col, const double* ppol,
+                            size_t a_cols, size_t a_col, const double* b, size_t b_cols, size_t b_size, size_t b_col) {
+    PZ_ENTER(M);
+    return svp_dft_to_dft(M, res, res_cols, res_size, res_col, ppol, a_cols, a_col, b, b_cols, b_size, b_col);
+}
+int pz_svp_apply_dft_to_dft_assign(pz_module* M, double* res, size_t res_cols, size_t res_size, size_t res_col, const double* ppol,
+                                   size_t a_cols, size_t a_col) {
+    PZ_ENTER(M);
+    return svp_dft_to_dft(M, res, res_cols, res_size, res_col, ppol, a_cols, a_col, res, res_cols, res_size, res_col);
+}
+
+// ------------------------------------------------------------------------------
+// public: VMP
+// ------------------------------------------------------------------------------
+size_t pz_vmp_prepare_tmp_bytes(const pz_module* M, size_t, size_t, size_t, size_t) { return M ? (size_t)M->n * 8 : 0; }
+size_t pz_vmp_apply_dft_to_dft_tmp_bytes(const pz_module*, size_t, size_t a_size, size_t b_rows, size_t b_cols_in, size_t, size_t) {
+    return (16 + 8 * std::min(a_size, b_rows) * b_cols_in) * 8;  // vmp.rs:132-135
+}
+size_t pz_vmp_apply_dft_tmp_bytes(const pz_module* M, size_t res_size, size_t a_size, size_t b_rows, size_t b_cols_in,
+                                  size_t b_cols_out, size_t b_size) {
+    // hal_impl/family_common.rs:3-15
+    return pz_bytes_of_vec_znx_dft(M ? M->n : 0, b_cols_in, std::min(a_size, b_rows)) +
+           pz_vmp_apply_dft_to_dft_tmp_bytes(M, res_size, a_size, b_rows, b_cols_in, b_cols_out, b_size);
+}
+
+int pz_vmp_prepare(pz_module* M, double* pmat, const int64_t* mat, size_t rows, size_t cols_in, size_t cols_out, size_t size) {
+    PZ_ENTER(M);
+    const size_t npolys = rows * cols_in * cols_out * size;
+    Stage sp, sm;
+    PZ_TRY(sm.in(mat, npolys * M->n * 8, true, false, M));
+    PZ_TRY(sp.in(pmat, npolys * M->n * 8, false, true, M));
+    // Device VmpPMat = spectra of the MatZnx polynomials in MatZnx order (entry (r, c) at (r*ncols + c)*n):
+    // one FFT per matrix entry (vmp.rs:52-93) and no block re-layout.
+    const size_t group = 256;
+    cplx* T;
+    PZ_TRY(need_T(M, std::min(npolys, group), &T));
+    const long long n = (long long)M->n;
+    for (size_t p0 = 0; p0 < npolys; p0 += group) {
+        const int cnt = (int)std::min(group, npolys - p0);
+        PolyMap sm_{cnt, 1, 0, n, 0, (long long)p0 * n};
+        PolyMap dm_{cnt, 1, 0, n, 0, (long long)p0 * n};
+        PZ_TRY(launch_fwd_pass1(M, cnt, (const long long*)sm.dev, sm_, T));
+        PZ_TRY(launch_fwd_pass2(M, cnt, T, (double*)sp.dev, dm_, nullptr));
+    }
+    const bool host = sp.owned || sm.owned;
+    PZ_TRY(sp.finish());
+    PZ_TRY(sm.finish());
+    return finish_call(M, host);
+}
+
+int pz_vmp_zero(pz_module* M, double* pmat, size_t rows, size_t cols_in, size_t cols_out, size_t size) {
+    PZ_ENTER(M);
+    const size_t bytes = rows * cols_in * cols_out * size * M->n * 8;
+    if (is_device_ptr(pmat)) PZ_HIP(hipMemsetAsync(pmat, 0, bytes, M->stream));
+    else memset(pmat, 0, bytes);
+    return PZ_OK;
+}
+
+static int vmp_checks(pz_module* M, size_t res_cols, size_t a_cols, size_t cols_in, size_t cols_out) {
+    (void)M;
+    PZ_REQUIRE(res_cols == cols_out, "vmp_apply: res.cols %zu != pmat.cols_out %zu", res_cols, cols_out);
+    PZ_REQUIRE(a_cols == cols_in, "vmp_apply: a.cols %zu != pmat.cols_in %zu", a_cols, cols_in);
+    return PZ_OK;
+}
+
+int pz_vmp_apply_dft_to_dft(pz_module* M, double* res, size_t res_cols, size_t res_size, const double* a, size_t a_cols, size_t a_size,
+                            const double* pmat, size_t rows, size_t cols_in, size_t cols_out, size_t size, size_t limb_offset) {
+    PZ_ENTER(M);
+    PZ_TRY(vmp_checks(M, res_cols, a_cols, cols_in, cols_out));
+    PZ_REQUIRE((const void*)res != (const void*)a, "vmp_apply_dft_to_dft: res must not alias a");
+    Stage sr, sa, sp;
+    PZ_TRY(sa.in(a, vbytes(M, a_cols, a_size), true, false, M));
+    PZ_TRY(sp.in(pmat, rows * cols_in * cols_out * size * M->n * 8, true, false, M));
+    PZ_TRY(sr.in(res, vbytes(M, res_cols, res_size), false, true, M));
+    DV dr{sr.dev, 0, (int)res_cols, (int)res_size}, da{sa.dev, 0, (int)a_cols, (int)a_size};
+    PZ_TRY(dev_vmp(M, 1, dr, da, (const double*)sp.dev, (int)rows, (int)cols_in, (int)cols_out, (int)size, (int)limb_offset));
+    const bool host = sr.owned || sa.owned || sp.owned;
+    PZ_TRY(sr.finish());
+    PZ_TRY(sa.finish());
+    PZ_TRY(sp.finish());
+    return finish_call(M, host);
+}
+
+int pz_vmp_apply_dft_to_dft_batched(pz_module* M, size_t batch, double* res, size_t res_cols, size_t res_size, const double* a,
+                                    size_t a_cols, size_t a_size, const double* pmat, size_t rows, size_t cols_in, size_t cols_out,
+                                    size_t size, size_t limb_offset) {
+    PZ_ENTER(M);
+    PZ_TRY(vmp_checks(M, res_cols, a_cols, cols_in, cols_out));
+    PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(a) && is_device_ptr(pmat), "batched entry points take device pointers");
+    DV dr{res, (long long)(M->n * res_cols * res_size), (int)res_cols, (int)res_size};
+    DV da{(void*)a, (long long)(M->n * a_cols * a_size), (int)a_cols, (int)a_size};
+    return dev_vmp(M, (int)batch, dr, da, pmat, (int)rows, (int)cols_in, (int)cols_out, (int)size, (int)limb_offset);
+}
+
+int pz_vmp_apply_dft(pz_module* M, double* res, size_t res_cols, size_t res_size, const int64_t* a, size_t a_cols, size_t a_size,
+                     const double* pmat, size_t rows, size_t cols_in, size_t cols_out, size_t size) {
+    PZ_ENTER(M);
+    PZ_REQUIRE(res_cols == cols_out, "vmp_apply_dft: res.cols %zu != pmat.cols_out %zu", res_cols, cols_out);
+    PZ_REQUIRE(a_cols <= cols_in, "vmp_apply_dft: a.cols %zu > pmat.cols_in %zu", a_cols, cols_in);
+    Stage sr, sa, sp;
+    PZ_TRY(sa.in(a, vbytes(M, a_cols, a_size), true, false, M));
+    PZ_TRY(sp.in(pmat, rows * cols_in * cols_out * size * M->n * 8, true, false, M));
+    PZ_TRY(sr.in(res, vbytes(M, res_cols, res_size), false, true, M));
+    // family_common.rs:17-54: DFT of a right-aligned into cols_in columns (leading columns zero), then the product
+    const size_t sz = std::min(a_size, rows);
+    const size_t adft_bytes = vbytes(M, cols_in, sz);
+    PZ_TRY(ws_reserve(M, adft_bytes + sz * a_cols * M->m * sizeof(cplx)));
+    double* adft = (double*)M->ws;
+    cplx* T = (cplx*)((char*)M->ws + adft_bytes);
+    PZ_HIP(hipMemsetAsync(adft, 0, adft_bytes, M->stream));
+    DV dad{adft, 0, (int)cols_in, (int)sz}, da{sa.dev, 0, (int)a_cols, (int)a_size};
+    PZ_TRY(dev_dft_apply(M, 1, 1, 0, dad, (int)(cols_in - a_cols), da, 0, (int)a_cols, nullptr, T));
+    DV dr{sr.dev, 0, (int)res_cols, (int)res_size};
+    PZ_TRY(dev_vmp(M, 1, dr, dad, (const double*)sp.dev, (int)rows, (int)cols_in, (int)cols_out, (int)size, 0));
+    const bool host = sr.owned || sa.owned || sp.owned;
+    PZ_TRY(sr.finish());
+    PZ_TRY(sa.finish());
+    PZ_TRY(sp.finish());
+    return finish_call(M, host);
+}
+
+// ------------------------------------------------------------------------------
+// public: VecZnxBig
+// ------------------------------------------------------------------------------
+size_t pz_vec_znx_big_normalize_tmp_bytes(const pz_module* M) { return M ? 3 * (size_t)M->n * 8 : 0; }  // normalize.rs:13-15
+
+static int normalize_checks(size_t res_col, size_t res_cols, size_t a_col, size_t a_cols, size_t res_base2k, size_t a_base2k) {
+    PZ_CHECK_COL(res_col, res_cols, "vec_znx_big_normalize(res)");
+    PZ_CHECK_COL(a_col, a_cols, "vec_znx_big_normalize(a)");
+    PZ_REQUIRE(res_base2k >= 1 && res_base2k <= 63 && a_base2k >= 1 && a_base2k <= 63, "vec_znx_big_normalize: base2k out of range");
+    return PZ_OK;
+}
+
+int pz_vec_znx_big_normalize(pz_module* M, int64_t* res, size_t res_cols, size_t res_size, size_t res_base2k, int64_t res_offset,
+                             size_t res_col, const int64_t* a, size_t a_cols, size_t a_size, size_t a_base2k, size_t a_col) {
+    PZ_ENTER(M);
+    PZ_TRY(normalize_checks(res_col, res_cols, a_col, a_cols, res_base2k, a_base2k));
+    PZ_REQUIRE((const void*)res != (const void*)a, "vec_znx_big_normalize: res must not alias a");
+    Stage sr, sa;
+    PZ_TRY(sa.in(a, vbytes(M, a_cols, a_size), true, false, M));
+    PZ_TRY(sr.in(res, vbytes(M, res_cols, res_size), true, true, M));
+    DV dr{sr.dev, 0, (int)res_cols, (int)res_size}, da{sa.dev, 0, (int)a_cols, (int)a_size};
+    PZ_TRY(dev_normalize(M, 1, dr, (int)res_base2k, res_offset, (int)res_col, da, (int)a_base2k, (int)a_col));
+    const bool host = sr.owned || sa.owned;
+    PZ_TRY(sr.finish());
+    PZ_TRY(sa.finish());
+    return finish_call(M, host);
+}
+
+int pz_vec_znx_big_normalize_batched(pz_module* M, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_base2k,
+                                     int64_t res_offset, size_t res_col, const int64_t* a, size_t a_cols, size_t a_size,
+                                     size_t a_base2k, size_t a_col) {
+    PZ_ENTER(M);
+    PZ_TRY(normalize_checks(res_col, res_cols, a_col, a_cols, res_base2k, a_base2k));
+    PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(a), "batched entry points take device pointers");
+    DV dr{res, (long long)(M->n * res_cols * res_size), (int)res_cols, (int)res_size};
+    DV da{(void*)a, (long long)(M->n * a_cols * a_size), (int)a_cols, (int)a_size};
+    return dev_normalize(M, (int)batch, dr, (int)res_base2k, res_offset, (int)res_col, da, (int)a_base2k, (int)a_col);
+}
+
+int pz_vec_znx_big_add_small_assign(pz_module* M, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a,
+                                    size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    PZ_CHECK_COL(res_col, res_cols, "vec_znx_big_add_small_assign(res)");
+    PZ_CHECK_COL(a_col, a_cols, "vec_znx_big_add_small_assign(a)");
+    Tri t;
+    PZ_TRY(tri_in(M, t, (double*)res, res_cols, res_size, (const double*)a, a_cols, a_size, nullptr, 0, 0));
+    PZ_TRY(ew_limbs(M, EW_ADD_I64, t.dr, (int)res_col, 0, &t.dr, (int)res_col, 0, &t.da, (int)a_col, 0, (int)std::min(a_size, res_size)));
+    return tri_out(M, t);
+}
+
+// ------------------------------------------------------------------------------
+// public: batched GLWE operations (device-resident)
+// ------------------------------------------------------------------------------
+struct OpShape {
+    int cols_a, cols_in, cols_out;  // columns of `a`, VMP input columns, output columns
+    int a_size_eff;                 // limbs of `a` in the key's base (after optional conversion)
+    bool convert;
+};
+static OpShape op_shape(const pz_glwe_op_params* p, bool ks) {
+    OpShape s;
+    s.cols_a = (int)p->rank + 1;
+    s.cols_in = ks ? (int)p->rank : (int)p->rank + 1;
+    s.cols_out = ks ? (int)p->rank_out + 1 : (int)p->rank + 1;
+    s.convert = p->a_base2k != p->key_base2k;
+    s.a_size_eff = s.convert ? (int)((p->a_size * p->a_base2k + p->key_base2k - 1) / p->key_base2k) : (int)p->a_size;
+    return s;
+}
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct OpWs {
+    size_t a_conv, a_dft, res_dft, tmp_dft, T, total;
+};
+static OpWs op_ws(const pz_module* M, const pz_glwe_op_params* p, const OpShape& s, size_t chunk, bool ks) {
+    OpWs w;
+    const size_t n8 = (size_t)M->n * 8;
+    const size_t dsz = p->dsize;
+    w.a_conv = s.convert ? align256(chunk * n8 * s.cols_a * s.a_size_eff) : 0;
+    w.a_dft = align256(chunk * n8 * s.cols_in * (size_t)s.a_size_eff);
+    w.res_dft = align256(chunk * n8 * s.cols_out * p->key_size);
+    w.tmp_dft = dsz > 1 ? align256(chunk * n8 * (s.cols_out * p->key_size + (ks ? s.cols_in * (size_t)s.a_size_eff : 0))) : 0;
+    const size_t tp = std::max((size_t)s.cols_in * s.a_size_eff, (size_t)s.cols_out * p->key_size);
+    w.T = align256(chunk * tp * (size_t)M->m * sizeof(cplx));
+    w.total = w.a_conv + w.a_dft + w.res_dft + w.tmp_dft + w.T;
+    return w;
+}
+static size_t pick_chunk(const pz_module* M, const pz_glwe_op_params* p, const OpShape& s, size_t batch) {
+    if (M->chunk) return std::min(M->chunk, batch);
+    // keep (a_dft + res_dft + T) of one chunk around half of the 256 MiB Infinity Cache
+    const size_t per_ct = (size_t)M->n * 8 * ((size_t)s.cols_in * s.a_size_eff + 2 * (size_t)s.cols_out * p->key_size);
+    size_t c = (128u << 20) / std::max<size_t>(per_ct, 1);
+    c = std::max<size_t>(c, 4);
+    return std::min(c, batch);
+}
+
+size_t pz_glwe_op_workspace_bytes(const pz_module* M, const pz_glwe_op_params* p, size_t batch, int keyswitch) {
+    if (!M || !p) return 0;
+    OpShape s = op_shape(p, keyswitch != 0);
+    return op_ws(M, p, s, pick_chunk(M, p, s, batch), keyswitch != 0).total;
+}
+
+static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double* pmat, const pz_glwe_op_params* p, size_t batch) {
+    PZ_REQUIRE(p != nullptr, "null params");
+    PZ_REQUIRE(p->dsize >= 1 && p->dnum >= 1 && p->key_size >= 1 && p->a_size >= 1 && p->res_size >= 1, "glwe op: empty shape");
+    PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(a) && is_device_ptr(pmat), "batched entry points take device pointers");
+    if (batch == 0) return PZ_OK;
+    const OpShape s = op_shape(p, ks);
+    const size_t chunk = pick_chunk(M, p, s, batch);
+    const OpWs w = op_ws(M, p, s, chunk, ks);
+    PZ_TRY(ws_reserve(M, w.total));
+    char* base = (char*)M->ws;
+    int64_t* a_conv = (int64_t*)base; base += w.a_conv;
+    double* a_dft = (double*)base; base += w.a_dft;
+    double* res_dft = (double*)base; base += w.res_dft;
+    double* tmp_dft = (double*)base; base += w.tmp_dft;
+    cplx* T = (cplx*)base;
+    const long long n = (long long)M->n;
+    const int dsize = (int)p->dsize, dnum = (int)p->dnum, ksz = (int)p->key_size;
+    const long long a_ct = n * s.cols_a * (long long)p->a_size;
+    const long long res_ct = n * s.cols_out * (long long)p->res_size;
+
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const int nb = (int)std::min(chunk, batch - b0);
+        DV av{(void*)(a + (long long)b0 * a_ct), a_ct, s.cols_a, (int)p->a_size};
+        if (s.convert) {  // glwe_normalize into the key's base (external_product/glwe.rs:124-132)
+            DV cv{a_conv, n * s.cols_a * s.a_size_eff, s.cols_a, s.a_size_eff};
+            for (int c = 0; c < s.cols_a; ++c)
+                PZ_TRY(dev_normalize(M, nb, cv, (int)p->key_base2k, 0, c, av, (int)p->a_base2k, c));
+            av = cv;
+        }
+        const int a_size = av.size;
+        const int a_col0 = ks ? 1 : 0;  // key-switch transforms the mask columns only (keyswitching/glwe.rs:231-234)
+        DV rd{res_dft, n * s.cols_out * ksz, s.cols_out, ksz};
+        int res_dft_size = ksz;
+        if (dsize == 1) {
+            DV ad{a_dft, n * s.cols_in * a_size, s.cols_in, a_size};
+            PZ_TRY(dev_dft_apply(M, nb, 1, 0, ad, 0, av, a_col0, s.cols_in, nullptr, T));
+            PZ_TRY(dev_vmp(M, nb, rd, ad, pmat, dnum, s.cols_in, s.cols_out, ksz, 0));
+        } else {
+            // external_product/glwe.rs:235-267 ; keyswitching/glwe.rs:332-379
+            // res_dft starts zeroed (glwe.rs:122): limbs skipped by the first iterations are only ever added to
+            PZ_HIP(hipMemsetAsync(res_dft, 0, (size_t)nb * rd.bs * 8, M->stream));
+            DV td{tmp_dft, n * s.cols_out * ksz, s.cols_out, ksz};
+            for (int di = 0; di < dsize; ++di) {
+                int a_sz = (a_size + di) / dsize;
+                if (ks) a_sz = std::min(a_sz, dnum);
+                const int drop = std::max(dsize - di - 2, 0);
+                res_dft_size = ksz - drop;
+                DV ad{a_dft, n * s.cols_in * a_sz, s.cols_in, a_sz};
+                PZ_TRY(dev_dft_apply(M, nb, dsize, dsize - 1 - di, ad, 0, av, a_col0, s.cols_in, nullptr, T));
+                DV rdi{res_dft, rd.bs, s.cols_out, res_dft_size};
+                if (di == 0) {
+                    PZ_TRY(dev_vmp(M, nb, rdi, ad, pmat, dnum, s.cols_in, s.cols_out, ksz, 0));
+                } else {
+                    DV tdi{tmp_dft, td.bs, s.cols_out, res_dft_size};
+                    PZ_TRY(dev_vmp(M, nb, tdi, ad, pmat, dnum, s.cols_in, s.cols_out, ksz, di));
+                    PZ_TRY(launch_ew(M, EW_ADD, res_dft, rd.bs, n, res_dft, rd.bs, n, tmp_dft, td.bs, n, s.cols_out * res_dft_size, nb));
+                }
+            }
+            if (ks) res_dft_size = ksz;  // keyswitching/glwe.rs:378 res.set_size(res.max_size())
+            if (ks && dsize > 2) {
+                // limbs dropped by the last iterations keep the value of the earlier ones (reference behaviour); nothing to do
+            }
+        }
+        DV rb{res_dft, rd.bs, s.cols_out, res_dft_size};
+        PZ_TRY(dev_idft(M, nb, rb, 0, rb, 0, s.cols_out, res_dft_size, T));
+        if (ks)  // body column added after the inverse transform (keyswitching/glwe.rs:237)
+            PZ_TRY(launch_ew(M, EW_ADD_I64, res_dft, rb.bs, (long long)s.cols_out * n, res_dft, rb.bs, (long long)s.cols_out * n,
+                             av.p, av.bs, (long long)av.cols * n, std::min(res_dft_size, a_size), nb));
+        DV rv{(void*)(res + (long long)b0 * res_ct), res_ct, s.cols_out, (int)p->res_size};
+        for (int c = 0; c < s.cols_out; ++c)
+            PZ_TRY(dev_normalize(M, nb, rv, (int)p->res_base2k, 0, c, rb, (int)p->key_base2k, c));
+    }
+    return PZ_OK;
+}
+
+int pz_glwe_external_product_batched(pz_module* M, int64_t* res, const int64_t* a, const double* ggsw_pmat,
+                                     const pz_glwe_op_params* p, size_t batch) {
+    PZ_ENTER(M);
+    return glwe_op(M, false, res, a, ggsw_pmat, p, batch);
+}
+int pz_glwe_keyswitch_batched(pz_module* M, int64_t* res, const int64_t* a, const double* key_pmat, const pz_glwe_op_params* p,
+                              size_t batch) {
+    PZ_ENTER(M);
+    return glwe_op(M, true, res, a, key_pmat, p, batch);
+}
+
+}  // extern "C"

@@ -1,0 +1,354 @@
+// device_ops.hpp — DFT-domain products (VMP / SVP), limb-wise elementwise ops
+// and the base-2^k carry/normalize kernels.  All kernels are batched: object b
+// of a batch sits `*_bs` scalars after object b-1.
+#pragma once
+#include "device_fft.hpp"
+
+namespace pz {
+
+// =================================================================================
+// VMP: res[b][c][q] = sum_{r < row_max} a[b][r][q] * P[r][c + off][q]
+//   (reference/fft64/vmp.rs:186-264 computes the same sums 4 points at a time)
+// a, res: VecZnxDft in device order, polynomial r at r*m cplx.
+// P     : device VmpPMat = the rows*cols_in x size*cols_out matrix of spectra,
+//         entry (r, c) at (r*ncols + c)*m cplx  (see DESIGN.md "VmpPMat layout").
+// One lane per frequency point; each lane keeps a CT x CC block of accumulators
+// (CT ciphertexts x CC output polynomials) so that every P and a value fetched is
+// used CT resp. CC times.  Waves of a workgroup take different column tiles of the
+// same points/ciphertexts, so their `a` reads hit the CU's L1.
+// Columns c >= ncomp are written as zero (OVERWRITE semantics, all limbs written).
+// =================================================================================
+template <int CT, int CC>
+__global__ void __launch_bounds__(256)
+k_vmp(double* __restrict__ res, long long res_bs, int res_polys,
+      const double* __restrict__ a, long long a_bs,
+      const double* __restrict__ pmat, int ncols, int off, int row_max, int ncomp,
+      int m, int batch) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + lane;
+    const int c0 = (blockIdx.y * 4 + wave) * CC;
+    const int b0 = blockIdx.z * CT;
+    if (c0 >= res_polys || q >= m) return;
+
+    cplx acc[CT][CC];
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int j = 0; j < CC; ++j) acc[i][j] = make_double2(0.0, 0.0);
+
+    const cplx* ap[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+        const int b = min(b0 + i, batch - 1);
+        ap[i] = reinterpret_cast<const cplx*>(a + (long long)b * a_bs) + q;
+    }
+    const cplx* pp[CC];
+#pragma unroll
+    for (int j = 0; j < CC; ++j) {
+        const int c = min(c0 + j, ncomp - 1);
+        pp[j] = reinterpret_cast<const cplx*>(pmat) + (long long)(c + off) * m + q;
+    }
+    const long long prow = (long long)ncols * m;
+
+    if (c0 < ncomp) {
+        for (int r = 0; r < row_max; ++r) {
+            cplx av[CT], pv[CC];
+#pragma unroll
+            for (int i = 0; i < CT; ++i) av[i] = ap[i][(long long)r * m];
+#pragma unroll
+            for (int j = 0; j < CC; ++j) pv[j] = pp[j][(long long)r * prow];
+#pragma unroll
+            for (int i = 0; i < CT; ++i)
+#pragma unroll
+                for (int j = 0; j < CC; ++j) {
+                    acc[i][j].x = __builtin_fma(av[i].x, pv[j].x, acc[i][j].x);
+                    acc[i][j].x = __builtin_fma(-av[i].y, pv[j].y, acc[i][j].x);
+                    acc[i][j].y = __builtin_fma(av[i].x, pv[j].y, acc[i][j].y);
+                    acc[i][j].y = __builtin_fma(av[i].y, pv[j].x, acc[i][j].y);
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+        const int b = b0 + i;
+        if (b >= batch) continue;
+        cplx* rp = reinterpret_cast<cplx*>(res + (long long)b * res_bs) + q;
+#pragma unroll
+        for (int j = 0; j < CC; ++j) {
+            const int c = c0 + j;
+            if (c >= res_polys) continue;
+            rp[(long long)c * m] = (c < ncomp) ? acc[i][j] : make_double2(0.0, 0.0);
+        }
+    }
+}
+
+// =================================================================================
+// limb-wise elementwise ops on whole polynomials (f64 spectra or i64 limbs)
+// =================================================================================
+enum EwOp : int {
+    EW_ZERO = 0,
+    EW_COPY = 1,     // res = a
+    EW_NEG = 2,      // res = -a
+    EW_ADD = 3,      // res = a + b
+    EW_SUB = 4,      // res = a - b
+    EW_CMUL = 5,     // res = a * b  (complex pointwise, interleaved; `a` is the prepared poly)
+    EW_ADD_I64 = 6,  // res = a + b  (wrapping i64)
+};
+
+// polynomial (b, j) of operand X sits at X + b*bs + j*ls ; n scalars per polynomial;
+// one thread per 2 scalars (16 B)
+struct EwArgs {
+    void* res; const void* a; const void* b;
+    long long res_bs, res_ls, a_bs, a_ls, b_bs, b_ls;
+    int nlimbs, n, batch, op;
+};
+
+__global__ void __launch_bounds__(256) k_ew(EwArgs g) {
+    const long long half = g.n >> 1;
+    const long long total = (long long)g.batch * g.nlimbs * half;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const long long e = t % half;
+        const long long pj = t / half;
+        const int j = (int)(pj % g.nlimbs);
+        const long long b = pj / g.nlimbs;
+        double2* r = reinterpret_cast<double2*>((double*)g.res + b * g.res_bs + j * g.res_ls) + e;
+        const double2* x = g.a ? reinterpret_cast<const double2*>((const double*)g.a + b * g.a_bs + j * g.a_ls) + e : nullptr;
+        const double2* y = g.b ? reinterpret_cast<const double2*>((const double*)g.b + b * g.b_bs + j * g.b_ls) + e : nullptr;
+        switch (g.op) {
+            case EW_ZERO: *r = make_double2(0.0, 0.0); break;
+            case EW_COPY: *r = *x; break;
+            case EW_NEG: { double2 v = *x; *r = make_double2(-v.x, -v.y); } break;
+            case EW_ADD: { double2 v = *x, w = *y; *r = make_double2(v.x + w.x, v.y + w.y); } break;
+            case EW_SUB: { double2 v = *x, w = *y; *r = make_double2(v.x - w.x, v.y - w.y); } break;
+            case EW_CMUL: { double2 v = *x, w = *y; *r = cmul(v, w); } break;
+            case EW_ADD_I64: {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(x);
+                const ulonglong2 w = *reinterpret_cast<const ulonglong2*>(y);
+                *reinterpret_cast<ulonglong2*>(r) = make_ulonglong2(v.x + w.x, v.y + w.y);
+            } break;
+        }
+    }
+}
+
+// =================================================================================
+// normalize: reference/vec_znx/normalize.rs + reference/znx/normalization.rs.
+// The carry chain runs across limbs, never across coefficients, so one thread owns
+// one coefficient and walks the limbs with the carry in a register.  Arithmetic is
+// exact-integer and mirrors the reference step functions bit for bit.
+// =================================================================================
+__device__ __forceinline__ long long nz_digit(int k, long long x) {
+    return (long long)((unsigned long long)x << (64 - k)) >> (64 - k);
+}
+__device__ __forceinline__ long long nz_carry(int k, long long x, long long d) {
+    return (long long)((unsigned long long)x - (unsigned long long)d) >> k;
+}
+__device__ __forceinline__ long long wadd(long long a, long long b) {
+    return (long long)((unsigned long long)a + (unsigned long long)b);
+}
+__device__ __forceinline__ long long wshl(long long a, int s) { return (long long)((unsigned long long)a << s); }
+
+struct NzArgs {
+    long long* res; const long long* a;
+    long long res_bs, a_bs;      // batch strides (scalars)
+    int n, batch;
+    int res_cols, res_size, res_col;
+    int a_cols, a_size, a_col;
+    int res_base2k, a_base2k;
+    // same-base plan (normalize.rs:83-101)
+    int lsh, res_end, res_start, a_end, a_start;
+};
+
+// normalize.rs:50-144 (vec_znx_normalize_inter_base2k)
+__global__ void __launch_bounds__(256) k_normalize_inter(NzArgs g) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)g.batch * g.n) return;
+    const int i = (int)(t % g.n);
+    const long long b = t / g.n;
+    const long long* a = g.a + b * g.a_bs + (long long)g.a_col * g.n + i;
+    long long* r = g.res + b * g.res_bs + (long long)g.res_col * g.n + i;
+    const long long als = (long long)g.a_cols * g.n;
+    const long long rls = (long long)g.res_cols * g.n;
+    const int k = g.res_base2k;
+    const int lsh = g.lsh;
+    const int kk = lsh == 0 ? k : k - lsh;
+
+    long long c = 0;
+    const int a_out_range = g.a_size > g.a_start ? g.a_size - g.a_start : 0;
+    for (int j = 0; j < a_out_range; ++j) {
+        const long long x = a[(long long)(g.a_size - j - 1) * als];
+        const long long d = nz_digit(kk, x);
+        const long long cr = nz_carry(kk, x, d);
+        if (j == 0) {
+            c = cr;  // znx_normalize_first_step_carry_only, normalization.rs:24-41
+        } else {     // znx_normalize_middle_step_carry_only, normalization.rs:107-129
+            const long long dpc = wadd(wshl(d, lsh), c);
+            c = wadd(cr, nz_carry(k, dpc, nz_digit(k, dpc)));
+        }
+    }
+    for (int j = g.res_start; j < g.res_size; ++j) r[(long long)j * rls] = 0;
+    const int mid = g.a_start > g.a_end ? g.a_start - g.a_end : 0;
+    for (int j = 0; j < mid; ++j) {  // znx_normalize_middle_step<true>, normalization.rs:179-221
+        const long long x = a[(long long)(g.a_start - j - 1) * als];
+        const long long d = nz_digit(kk, x);
+        const long long cr = nz_carry(kk, x, d);
+        const long long dpc = wadd(wshl(d, lsh), c);
+        const long long x1 = nz_digit(k, dpc);
+        r[(long long)(g.res_start - j - 1) * rls] = x1;
+        c = wadd(cr, nz_carry(k, dpc, x1));
+    }
+    for (int j = 0; j < g.res_end; ++j) {
+        // limb zeroed, then middle_step_assign / final_step_assign on a zero limb:
+        // digit(kk, 0) = 0 -> dpc = c  (normalization.rs:132-157, 254-272)
+        const long long x1 = nz_digit(k, c);
+        r[(long long)(g.res_end - j - 1) * rls] = x1;
+        if (j != g.res_end - 1) c = nz_carry(k, c, x1);
+    }
+}
+
+// normalize.rs:147-401 (vec_znx_normalize_cross_base2k).  The control flow depends
+// only on shapes, so every thread of a launch walks the same path; the three
+// per-coefficient scratch values of the reference (a_norm, res_carry, a_carry) live
+// in registers and the res limbs are read-modify-written in place.
+__global__ void __launch_bounds__(256) k_normalize_cross(NzArgs g, long long res_offset) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)g.batch * g.n) return;
+    const int i = (int)(t % g.n);
+    const long long b = t / g.n;
+    const long long* a = g.a + b * g.a_bs + (long long)g.a_col * g.n + i;
+    long long* r = g.res + b * g.res_bs + (long long)g.res_col * g.n + i;
+    const long long als = (long long)g.a_cols * g.n;
+    const long long rls = (long long)g.res_cols * g.n;
+    const int ak = g.a_base2k, rk = g.res_base2k;
+    const int a_size = g.a_size, res_size = g.res_size;
+
+    long long a_norm = 0, res_carry = 0, a_carry = 0;
+    const long long a_tot_bits = (long long)a_size * ak;
+    const long long res_tot_bits = (long long)res_size * rk;
+    long long lsh = res_offset % ak;
+    long long limbs_offset = res_offset / ak;
+    if (res_offset < 0 && lsh != 0) {
+        lsh = (lsh + ak) % ak;
+        limbs_offset -= 1;
+    }
+    const int lsh_pos = (int)lsh;
+    auto clampll = [](long long v, long long lo, long long hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    const long long res_end_bit = clampll(-limbs_offset * ak, 0, res_tot_bits);
+    const long long res_start_bit = clampll(a_tot_bits - limbs_offset * ak, 0, res_tot_bits);
+    const long long a_end_bit = clampll(limbs_offset * ak, 0, a_tot_bits);
+    const long long a_start_bit = clampll(res_tot_bits + limbs_offset * ak, 0, a_tot_bits);
+    const int res_end = (int)(res_end_bit / rk);
+    const int res_start = (int)((res_start_bit + rk - 1) / rk);
+    const int a_end = (int)(a_end_bit / ak);
+    const int a_start = (int)((a_start_bit + ak - 1) / ak);
+
+    for (int j = 0; j < res_size; ++j) r[(long long)j * rls] = 0;
+    if (res_start == 0) return;
+
+    const int kk = lsh_pos == 0 ? ak : ak - lsh_pos;
+    const int a_out_range = a_size > a_start ? a_size - a_start : 0;
+    for (int j = 0; j < a_out_range; ++j) {
+        const long long x = a[(long long)(a_size - j - 1) * als];
+        const long long d = nz_digit(kk, x);
+        const long long cr = nz_carry(kk, x, d);
+        if (j == 0) a_carry = cr;
+        else {
+            const long long dpc = wadd(wshl(d, lsh_pos), a_carry);
+            a_carry = wadd(cr, nz_carry(ak, dpc, nz_digit(ak, dpc)));
+        }
+    }
+    int res_acc_left = rk;
+    int res_limb = res_start - 1;
+    const int mid = a_start > a_end ? a_start - a_end : 0;
+    long long cur = 0;  // value of res[res_limb] (zero until touched)
+    bool done = false;
+    for (int j = 0; j < mid && !done; ++j) {
+        const int a_limb = a_start - j - 1;
+        int a_take_left = ak;
+        {   // znx_normalize_middle_step<true>(a_base2k, lsh, a_norm, a_slice, a_carry)
+            const long long x = a[(long long)a_limb * als];
+            const long long d = nz_digit(kk, x);
+            const long long cr = nz_carry(kk, x, d);
+            const long long dpc = wadd(wshl(d, lsh_pos), a_carry);
+            a_norm = nz_digit(ak, dpc);
+            a_carry = wadd(cr, nz_carry(ak, dpc, a_norm));
+        }
+        if (j == 0) {
+            if ((a_tot_bits - a_start_bit) % ak != 0) {
+                const int take = (int)((a_tot_bits - a_start_bit) % ak);
+                // znx_mul_power_of_two_assign(-take, a_norm), znx/mul.rs:30-49
+                const long long sign_bit = (a_norm >> 63) & 1;
+                const long long bias = ((long long)1 << (take - 1)) - sign_bit;
+                a_norm = wadd(a_norm, bias) >> take;
+                a_take_left -= take;
+            } else if ((res_tot_bits - res_start_bit) % rk != 0) {
+                res_acc_left -= (int)((res_tot_bits - res_start_bit) % rk);
+            }
+        }
+        for (;;) {
+            const int a_take = min(min(ak, a_take_left), res_acc_left);
+            if (a_take != 0) {  // znx_extract_digit_addmul(a_take, scale, res_slice, a_norm)
+                const int scale = rk - res_acc_left;
+                const long long d = nz_digit(a_take, a_norm);
+                a_norm = nz_carry(a_take, a_norm, d);
+                cur = wadd(cur, wshl(d, scale));
+                a_take_left -= a_take;
+                res_acc_left -= a_take;
+            }
+            if (res_acc_left == 0 || a_limb == 0) {
+                if (a_limb == 0 && a_take_left == 0) {
+                    a_carry = wadd(a_carry, a_norm);
+                    if (res_acc_left != 0) {
+                        const int scale = rk - res_acc_left;
+                        const long long d = nz_digit(res_acc_left, a_carry);
+                        a_carry = nz_carry(res_acc_left, a_carry, d);
+                        cur = wadd(cur, wshl(d, scale));
+                    }
+                    {   // znx_normalize_middle_step_assign(res_base2k, 0, res_slice, res_carry)
+                        const long long d = nz_digit(rk, cur);
+                        const long long cr = nz_carry(rk, cur, d);
+                        const long long dpc = wadd(d, res_carry);
+                        cur = nz_digit(rk, dpc);
+                        res_carry = wadd(cr, nz_carry(rk, dpc, cur));
+                    }
+                    res_carry = wadd(res_carry, a_carry);
+                    done = true;
+                    break;
+                }
+                if (res_limb == 0) {
+                    done = true;
+                    break;
+                }
+                r[(long long)res_limb * rls] = cur;
+                cur = 0;
+                res_acc_left += rk;
+                res_limb -= 1;
+            }
+            if (a_take_left == 0) {
+                a_carry = wadd(a_carry, a_norm);
+                break;
+            }
+        }
+    }
+    r[(long long)res_limb * rls] = cur;
+
+    if (res_end != 0) {
+        long long c = (a_start == a_end) ? a_carry : res_carry;
+        for (int j = 0; j < res_end; ++j) {
+            long long* rp = r + (long long)(res_end - j - 1) * rls;
+            const long long x = *rp;
+            const long long d = nz_digit(rk, x);
+            if (j == res_end - 1) {
+                *rp = nz_digit(rk, wadd(d, c));
+            } else {
+                const long long cr = nz_carry(rk, x, d);
+                const long long dpc = wadd(d, c);
+                const long long x1 = nz_digit(rk, dpc);
+                *rp = x1;
+                c = wadd(cr, nz_carry(rk, dpc, x1));
+            }
+        }
+    }
+}
+
+}  // namespace pz

@@ -1,0 +1,165 @@
+// module.hpp — pz_module: per-(N, device) state of the backend.
+// Mirrors FFT64RefHandle { table_fft, table_ifft } (poulpy-cpu-ref/src/fft64/module.rs:34-69):
+// immutable twiddle tables built once per Module, here resident in HBM, plus a
+// stream and a grow-only device workspace for intermediates.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/poulpy_hip.h"
+#include "device_fft.hpp"
+
+namespace pz {
+
+inline std::string& last_error_ref() {
+    thread_local std::string e;
+    return e;
+}
+inline int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error_ref() = buf;
+    return code;
+}
+
+#define PZ_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return pz::fail(PZ_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define PZ_TRY(expr)          \
+    do {                      \
+        int r_ = (expr);      \
+        if (r_ != PZ_OK) return r_; \
+    } while (0)
+#define PZ_REQUIRE(cond, ...)                                   \
+    do {                                                        \
+        if (!(cond)) return pz::fail(PZ_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+struct FftPlan {
+    int m1, m2;        // m = m1*m2, m2 >= m1
+    int r1a, r1b;      // radices of the length-m1 pass
+    int r2a, r2b;      // radices of the length-m2 pass
+    int cb, qb;        // column block of pass 1 / q1 block of pass 2
+};
+
+inline bool radices_for(int L, int& ra, int& rb) {
+    switch (L) {
+        case 4: ra = 4; rb = 1; return true;
+        case 8: ra = 8; rb = 1; return true;
+        case 16: ra = 16; rb = 1; return true;
+        case 32: ra = 8; rb = 4; return true;
+        case 64: ra = 8; rb = 8; return true;
+        case 128: ra = 16; rb = 8; return true;
+        case 256: ra = 16; rb = 16; return true;
+        default: return false;
+    }
+}
+
+inline bool make_plan(uint64_t n, FftPlan& pl) {
+    if (n < 32 || (n & (n - 1))) return false;
+    uint64_t m = n >> 1;
+    int k = 0;
+    while ((1ull << k) < m) ++k;
+    int k1 = k / 2;
+    pl.m1 = 1 << k1;
+    pl.m2 = 1 << (k - k1);
+    if (!radices_for(pl.m1, pl.r1a, pl.r1b)) return false;
+    if (!radices_for(pl.m2, pl.r2a, pl.r2b)) return false;
+    pl.cb = pl.m2 >= 16 ? 16 : 4;
+    pl.qb = pl.m1 >= 16 ? 16 : 4;
+    return true;
+}
+
+}  // namespace pz
+
+struct pz_module {
+    uint64_t n = 0, m = 0;
+    int device = 0;
+    pz::FftPlan plan{};
+    hipStream_t stream = nullptr;
+    // device tables (cplx): tw1[m1], tw1inv[m1], wL1[m1], wL2[m2], tw12[m] ([j2][q1])
+    pz::cplx *tw1 = nullptr, *tw1inv = nullptr, *wL1 = nullptr, *wL2 = nullptr, *tw12 = nullptr;
+    // grow-only workspace
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    std::mutex mu;
+    unsigned long long* margin = nullptr;  // device word, bits of max |x-round(x)|
+    bool probe = false;
+    size_t chunk = 0;
+};
+
+namespace pz {
+
+inline int ws_reserve(pz_module* M, size_t bytes) {
+    if (bytes <= M->ws_bytes) return PZ_OK;
+    PZ_HIP(hipStreamSynchronize(M->stream));
+    if (M->ws) PZ_HIP(hipFree(M->ws));
+    M->ws = nullptr;
+    M->ws_bytes = 0;
+    size_t want = bytes + (bytes >> 3);
+    PZ_HIP(hipMalloc(&M->ws, want));
+    M->ws_bytes = want;
+    return PZ_OK;
+}
+
+inline void root_of_unity(long long num, long long den, double& c, double& s) {
+    // exp(2*pi*i*num/den) evaluated in long double, rounded once to double
+    num %= den;
+    if (num < 0) num += den;
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    long double ang = two_pi * (long double)num / (long double)den;
+    c = (double)cosl(ang);
+    s = (double)sinl(ang);
+    // exact values on the axes
+    if (num == 0) { c = 1; s = 0; }
+    else if (4 * num == den) { c = 0; s = 1; }
+    else if (2 * num == den) { c = -1; s = 0; }
+    else if (4 * num == 3 * den) { c = 0; s = -1; }
+}
+
+inline int upload_table(cplx** dst, const std::vector<cplx>& h) {
+    PZ_HIP(hipMalloc(dst, h.size() * sizeof(cplx)));
+    PZ_HIP(hipMemcpy(*dst, h.data(), h.size() * sizeof(cplx), hipMemcpyHostToDevice));
+    return PZ_OK;
+}
+
+inline int build_tables(pz_module* M) {
+    const long long m = (long long)M->m;
+    const int m1 = M->plan.m1, m2 = M->plan.m2;
+    std::vector<cplx> h;
+    double c, s;
+    h.resize(m1);
+    for (int j1 = 0; j1 < m1; ++j1) { root_of_unity(j1, 4ll * m1, c, s); h[j1] = make_double2(c, s); }
+    PZ_TRY(upload_table(&M->tw1, h));
+    const double inv_m = 1.0 / (double)m;  // exact power of two
+    for (int j1 = 0; j1 < m1; ++j1) { h[j1].x = h[j1].x * inv_m; h[j1].y = -h[j1].y * inv_m; }
+    PZ_TRY(upload_table(&M->tw1inv, h));
+    for (int t = 0; t < m1; ++t) { root_of_unity(t, m1, c, s); h[t] = make_double2(c, s); }
+    PZ_TRY(upload_table(&M->wL1, h));
+    h.resize(m2);
+    for (int t = 0; t < m2; ++t) { root_of_unity(t, m2, c, s); h[t] = make_double2(c, s); }
+    PZ_TRY(upload_table(&M->wL2, h));
+    h.resize((size_t)m);
+    for (long long j2 = 0; j2 < m2; ++j2)
+        for (long long q1 = 0; q1 < m1; ++q1) {
+            root_of_unity(j2 * (4 * q1 + 1), 4 * m, c, s);
+            h[(size_t)(j2 * m1 + q1)] = make_double2(c, s);
+        }
+    PZ_TRY(upload_table(&M->tw12, h));
+    return PZ_OK;
+}
+
+}  // namespace pz

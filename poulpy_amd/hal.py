@@ -1,0 +1,310 @@
+"""ctypes binding of libpoulpy_hip.so + a ``Module`` with poulpy-hal's method names.
+
+Method names / argument order follow the api traits of the reference
+(poulpy-hal/src/api/{vec_znx_dft,svp_ppol,vmp_pmat,vec_znx_big}.rs), minus the
+``scratch`` argument (the device path keeps its own workspace; the `*_tmp_bytes`
+functions still return the reference's sizes).  A non-zero status from the C ABI raises
+``PoulpyHipError`` — the Rust shim panics in the same places.
+
+This module NEVER falls back to a CPU implementation: without the shared library or
+without a HIP device every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from ctypes import POINTER, c_double, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+import numpy as np
+
+from .layouts import MatZnx, ScalarZnx, SvpPPol, VecZnx, VecZnxBig, VecZnxDft, VmpPMat
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpoulpy_hip.so")
+
+
+class PoulpyHipError(RuntimeError):
+    pass
+
+
+class GlweOpParams(C.Structure):
+    """pz_glwe_op_params (include/poulpy_hip.h)"""
+    _fields_ = [(k, c_uint64) for k in (
+        "rank", "dnum", "dsize", "key_size", "key_base2k", "a_size", "a_base2k", "res_size", "res_base2k", "rank_out")]
+
+
+_lib = None
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    """Load libpoulpy_hip.so (built by ``__graft_entry__.build()``); raises if missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise PoulpyHipError(
+            f"{p} not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(p)
+    lib.pz_last_error.restype = C.c_char_p
+    lib.pz_abi_version.restype = C.c_uint32
+    lib.pz_module_n.restype = c_uint64
+    lib.pz_alloc_bytes.restype = c_void_p
+    lib.pz_alloc_bytes.argtypes = [c_size_t]
+    lib.pz_free_bytes.argtypes = [c_void_p]
+    lib.pz_module_stream.restype = c_void_p
+    for name in ("pz_bytes_of_vec_znx", "pz_bytes_of_vec_znx_dft", "pz_bytes_of_vec_znx_big", "pz_bytes_of_svp_ppol",
+                 "pz_bytes_of_vmp_pmat", "pz_vec_znx_idft_apply_tmp_bytes", "pz_vmp_prepare_tmp_bytes",
+                 "pz_vmp_apply_dft_tmp_bytes", "pz_vmp_apply_dft_to_dft_tmp_bytes", "pz_vec_znx_big_normalize_tmp_bytes",
+                 "pz_glwe_op_workspace_bytes"):
+        getattr(lib, name).restype = c_size_t
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _p(arr: np.ndarray):
+    return arr.ctypes.data_as(c_void_p)
+
+
+def _sz(*xs):
+    return [c_size_t(int(x)) for x in xs]
+
+
+class DeviceBuffer:
+    """A raw HBM allocation owned by a Module (pz_device_alloc)."""
+
+    def __init__(self, module: "Module", nbytes: int):
+        self.module, self.nbytes = module, int(nbytes)
+        out = c_void_p()
+        module._ck(module.lib.pz_device_alloc(module.handle, c_size_t(self.nbytes), C.byref(out)))
+        self.ptr = out
+
+    def upload(self, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.module._ck(self.module.lib.pz_memcpy_h2d(self.module.handle, self.ptr, _p(arr), c_size_t(arr.nbytes)))
+        return self
+
+    def download(self, dtype, count: int, offset_bytes: int = 0) -> np.ndarray:
+        out = np.empty(count, dtype=dtype)
+        src = c_void_p(self.ptr.value + offset_bytes)
+        self.module._ck(self.module.lib.pz_memcpy_d2h(self.module.handle, _p(out), src, c_size_t(out.nbytes)))
+        return out
+
+    def at(self, offset_bytes: int) -> c_void_p:
+        return c_void_p(self.ptr.value + int(offset_bytes))
+
+    def free(self):
+        if self.ptr is not None and self.ptr.value:
+            self.module.lib.pz_device_free(self.module.handle, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Module:
+    """``Module<FFT64Hip>`` — poulpy-hal/src/layouts/module.rs:97-189."""
+
+    def __init__(self, n: int, device: int | None = None, lib: C.CDLL | None = None):
+        self.lib = lib or load_library()
+        h = c_void_p()
+        if device is None:
+            st = self.lib.pz_module_new(c_uint64(n), C.byref(h))
+        else:
+            st = self.lib.pz_module_new_on_device(c_uint64(n), c_int(device), C.byref(h))
+        self.handle = h
+        self._n = int(n)
+        if st != 0:
+            self.handle = None
+            raise PoulpyHipError(f"pz_module_new({n}) failed [{st}]: {self.lib.pz_last_error().decode()}")
+
+    # -- plumbing -------------------------------------------------------------
+    def _ck(self, st: int):
+        if st != 0:
+            raise PoulpyHipError(f"[{st}] {self.lib.pz_last_error().decode()}")
+
+    def n(self) -> int:
+        return self._n
+
+    def sync(self):
+        self._ck(self.lib.pz_module_sync(self.handle))
+
+    def close(self):
+        if self.handle is not None:
+            self.lib.pz_module_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def set_chunk(self, cts: int):
+        self._ck(self.lib.pz_module_set_chunk(self.handle, c_size_t(cts)))
+
+    def set_margin_probe(self, enable: bool):
+        self._ck(self.lib.pz_module_set_margin_probe(self.handle, c_int(1 if enable else 0)))
+
+    def get_margin(self) -> float:
+        out = c_double()
+        self._ck(self.lib.pz_module_get_margin(self.handle, C.byref(out)))
+        return out.value
+
+    # -- allocation (api/*Alloc traits) -----------------------------------------
+    def vec_znx_dft_alloc(self, cols, size) -> VecZnxDft:
+        return VecZnxDft(self._n, cols, size)
+
+    def vec_znx_big_alloc(self, cols, size) -> VecZnxBig:
+        return VecZnxBig(self._n, cols, size)
+
+    def svp_ppol_alloc(self, cols) -> SvpPPol:
+        return SvpPPol(self._n, cols)
+
+    def vmp_pmat_alloc(self, rows, cols_in, cols_out, size) -> VmpPMat:
+        return VmpPMat(self._n, rows, cols_in, cols_out, size)
+
+    def bytes_of_vec_znx_dft(self, cols, size) -> int:
+        return self.lib.pz_bytes_of_vec_znx_dft(c_uint64(self._n), *_sz(cols, size))
+
+    def bytes_of_vmp_pmat(self, rows, cols_in, cols_out, size) -> int:
+        return self.lib.pz_bytes_of_vmp_pmat(c_uint64(self._n), *_sz(rows, cols_in, cols_out, size))
+
+    # -- VecZnxDft (api/vec_znx_dft.rs) -------------------------------------------
+    def vec_znx_dft_apply(self, step, offset, res: VecZnxDft, res_col, a: VecZnx, a_col):
+        self._ck(self.lib.pz_vec_znx_dft_apply(self.handle, *_sz(step, offset), _p(res.data), *_sz(res.cols, res.size, res_col),
+                                               _p(a.data), *_sz(a.cols, a.size, a_col)))
+
+    def vec_znx_idft_apply_tmp_bytes(self) -> int:
+        return self.lib.pz_vec_znx_idft_apply_tmp_bytes(self.handle)
+
+    def vec_znx_idft_apply(self, res: VecZnxBig, res_col, a: VecZnxDft, a_col, scratch=None):
+        self._ck(self.lib.pz_vec_znx_idft_apply(self.handle, _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                                *_sz(a.cols, a.size, a_col)))
+
+    def vec_znx_idft_apply_tmpa(self, res: VecZnxBig, res_col, a: VecZnxDft, a_col):
+        self._ck(self.lib.pz_vec_znx_idft_apply_tmpa(self.handle, _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                                     *_sz(a.cols, a.size, a_col)))
+
+    def vec_znx_idft_apply_consume(self, a: VecZnxDft) -> VecZnxBig:
+        self._ck(self.lib.pz_vec_znx_idft_apply_consume(self.handle, _p(a.data), *_sz(a.cols, a.size)))
+        return a.into_big()
+
+    def _dft3(self, fn, res, res_col, a, a_col, b, b_col):
+        self._ck(fn(self.handle, _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data), *_sz(a.cols, a.size, a_col),
+                    _p(b.data), *_sz(b.cols, b.size, b_col)))
+
+    def _dft2(self, fn, res, res_col, a, a_col, *extra):
+        self._ck(fn(self.handle, _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data), *_sz(a.cols, a.size, a_col), *extra))
+
+    def vec_znx_dft_add_into(self, res, res_col, a, a_col, b, b_col):
+        self._dft3(self.lib.pz_vec_znx_dft_add_into, res, res_col, a, a_col, b, b_col)
+
+    def vec_znx_dft_sub(self, res, res_col, a, a_col, b, b_col):
+        self._dft3(self.lib.pz_vec_znx_dft_sub, res, res_col, a, a_col, b, b_col)
+
+    def vec_znx_dft_add_assign(self, res, res_col, a, a_col):
+        self._dft2(self.lib.pz_vec_znx_dft_add_assign, res, res_col, a, a_col)
+
+    def vec_znx_dft_add_scaled_assign(self, res, res_col, a, a_col, a_scale):
+        self._dft2(self.lib.pz_vec_znx_dft_add_scaled_assign, res, res_col, a, a_col, c_int64(a_scale))
+
+    def vec_znx_dft_sub_assign(self, res, res_col, a, a_col):
+        self._dft2(self.lib.pz_vec_znx_dft_sub_assign, res, res_col, a, a_col)
+
+    def vec_znx_dft_sub_negate_assign(self, res, res_col, a, a_col):
+        self._dft2(self.lib.pz_vec_znx_dft_sub_negate_assign, res, res_col, a, a_col)
+
+    def vec_znx_dft_copy(self, step, offset, res, res_col, a, a_col):
+        self._ck(self.lib.pz_vec_znx_dft_copy(self.handle, *_sz(step, offset), _p(res.data), *_sz(res.cols, res.size, res_col),
+                                              _p(a.data), *_sz(a.cols, a.size, a_col)))
+
+    def vec_znx_dft_zero(self, res, res_col):
+        self._ck(self.lib.pz_vec_znx_dft_zero(self.handle, _p(res.data), *_sz(res.cols, res.size, res_col)))
+
+    # -- SVP (api/svp_ppol.rs) -------------------------------------------------------
+    def svp_prepare(self, res: SvpPPol, res_col, a: ScalarZnx, a_col):
+        self._ck(self.lib.pz_svp_prepare(self.handle, _p(res.data), *_sz(res.cols, res_col), _p(a.data), *_sz(a.cols, a_col)))
+
+    def svp_apply_dft(self, res: VecZnxDft, res_col, a: SvpPPol, a_col, b: VecZnx, b_col):
+        self._ck(self.lib.pz_svp_apply_dft(self.handle, _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                           *_sz(a.cols, a_col), _p(b.data), *_sz(b.cols, b.size, b_col)))
+
+    def svp_apply_dft_to_dft(self, res: VecZnxDft, res_col, a: SvpPPol, a_col, b: VecZnxDft, b_col):
+        self._ck(self.lib.pz_svp_apply_dft_to_dft(self.handle, _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                                  *_sz(a.cols, a_col), _p(b.data), *_sz(b.cols, b.size, b_col)))
+
+    def svp_apply_dft_to_dft_assign(self, res: VecZnxDft, res_col, a: SvpPPol, a_col):
+        self._ck(self.lib.pz_svp_apply_dft_to_dft_assign(self.handle, _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                                         *_sz(a.cols, a_col)))
+
+    # -- VMP (api/vmp_pmat.rs) -------------------------------------------------------
+    def vmp_prepare_tmp_bytes(self, rows, cols_in, cols_out, size) -> int:
+        return self.lib.pz_vmp_prepare_tmp_bytes(self.handle, *_sz(rows, cols_in, cols_out, size))
+
+    def vmp_prepare(self, res: VmpPMat, a: MatZnx, scratch=None):
+        assert (res.rows, res.cols_in, res.cols_out, res.size) == (a.rows, a.cols_in, a.cols_out, a.size)
+        self._ck(self.lib.pz_vmp_prepare(self.handle, _p(res.data), _p(a.data), *_sz(a.rows, a.cols_in, a.cols_out, a.size)))
+
+    def vmp_apply_dft_tmp_bytes(self, res_size, a_size, b_rows, b_cols_in, b_cols_out, b_size) -> int:
+        return self.lib.pz_vmp_apply_dft_tmp_bytes(self.handle, *_sz(res_size, a_size, b_rows, b_cols_in, b_cols_out, b_size))
+
+    def vmp_apply_dft(self, res: VecZnxDft, a: VecZnx, b: VmpPMat, scratch=None):
+        self._ck(self.lib.pz_vmp_apply_dft(self.handle, _p(res.data), *_sz(res.cols, res.size), _p(a.data), *_sz(a.cols, a.size),
+                                           _p(b.data), *_sz(b.rows, b.cols_in, b.cols_out, b.size)))
+
+    def vmp_apply_dft_to_dft_tmp_bytes(self, res_size, a_size, b_rows, b_cols_in, b_cols_out, b_size) -> int:
+        return self.lib.pz_vmp_apply_dft_to_dft_tmp_bytes(self.handle, *_sz(res_size, a_size, b_rows, b_cols_in, b_cols_out, b_size))
+
+    def vmp_apply_dft_to_dft(self, res: VecZnxDft, a: VecZnxDft, b: VmpPMat, limb_offset=0, scratch=None):
+        self._ck(self.lib.pz_vmp_apply_dft_to_dft(self.handle, _p(res.data), *_sz(res.cols, res.size), _p(a.data),
+                                                  *_sz(a.cols, a.size), _p(b.data), *_sz(b.rows, b.cols_in, b.cols_out, b.size),
+                                                  c_size_t(limb_offset)))
+
+    def vmp_zero(self, res: VmpPMat):
+        self._ck(self.lib.pz_vmp_zero(self.handle, _p(res.data), *_sz(res.rows, res.cols_in, res.cols_out, res.size)))
+
+    # -- VecZnxBig (api/vec_znx_big.rs) ------------------------------------------------
+    def vec_znx_big_normalize_tmp_bytes(self) -> int:
+        return self.lib.pz_vec_znx_big_normalize_tmp_bytes(self.handle)
+
+    def vec_znx_big_normalize(self, res: VecZnx, res_base2k, res_offset, res_col, a: VecZnxBig, a_base2k, a_col, scratch=None):
+        self._ck(self.lib.pz_vec_znx_big_normalize(self.handle, _p(res.data), *_sz(res.cols, res.size, res_base2k), c_int64(res_offset),
+                                                   c_size_t(res_col), _p(a.data), *_sz(a.cols, a.size, a_base2k, a_col)))
+
+    def vec_znx_big_add_small_assign(self, res: VecZnxBig, res_col, a: VecZnx, a_col):
+        self._ck(self.lib.pz_vec_znx_big_add_small_assign(self.handle, _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                                          *_sz(a.cols, a.size, a_col)))
+
+    # -- batched device-resident GLWE ops (CoreImpl overrides) ---------------------------
+    def glwe_external_product_batched(self, res: c_void_p, a: c_void_p, ggsw_pmat: c_void_p, params: GlweOpParams, batch: int):
+        self._ck(self.lib.pz_glwe_external_product_batched(self.handle, res, a, ggsw_pmat, C.byref(params), c_size_t(batch)))
+
+    def glwe_keyswitch_batched(self, res: c_void_p, a: c_void_p, key_pmat: c_void_p, params: GlweOpParams, batch: int):
+        self._ck(self.lib.pz_glwe_keyswitch_batched(self.handle, res, a, key_pmat, C.byref(params), c_size_t(batch)))
+
+    def glwe_op_workspace_bytes(self, params: GlweOpParams, batch: int, keyswitch: bool) -> int:
+        return self.lib.pz_glwe_op_workspace_bytes(self.handle, C.byref(params), c_size_t(batch), c_int(1 if keyswitch else 0))
+
+    # events on the module stream
+    def event_create(self) -> c_void_p:
+        ev = c_void_p()
+        self._ck(self.lib.pz_event_create(C.byref(ev)))
+        return ev
+
+    def event_record(self, ev):
+        self._ck(self.lib.pz_event_record(self.handle, ev))
+
+    def event_elapsed_ms(self, e0, e1) -> float:
+        ms = C.c_float()
+        self._ck(self.lib.pz_event_elapsed_ms(e0, e1, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,237 @@
+"""GPU parity: libpoulpy_hip.so (through the C ABI) vs the CPU oracle on the same inputs.
+
+Mirrors the reference's cross-backend HAL suite (poulpy-hal/src/test_suite/{vec_znx_dft,svp,vmp,
+vec_znx_big}.rs): DFT-domain values are never compared; results are pushed through
+idft + normalize and the final i64 limbs must be IDENTICAL (bit-exact).
+"""
+import numpy as np
+import pytest
+
+from poulpy_amd.layouts import MatZnx, ScalarZnx, SvpPPol, VecZnx, VecZnxBig, VecZnxDft, VmpPMat
+from tests.helpers import garbage_dft, normalize_all, seeded
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from oracle.ref import RefModule
+    from poulpy_amd.hal import Module
+    cache = {}
+
+    def get(n):
+        if n not in cache:
+            cache[n] = (RefModule(n), Module(n))
+        return cache[n]
+    return get
+
+
+@pytest.mark.parametrize("n", [32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536])
+def test_dft_idft_roundtrip_and_oracle(mods, n):
+    """vec_znx_dft_apply -> vec_znx_idft_apply returns the input exactly, for every plan size."""
+    ref, hip = mods(n)
+    rng = seeded(n)
+    a = VecZnx(n, 2, 3).fill_uniform(40, rng)
+    a_before = a.data.copy()
+    d = hip.vec_znx_dft_alloc(2, 3)
+    for c in range(2):
+        hip.vec_znx_dft_apply(1, 0, d, c, a, c)
+    assert np.array_equal(a.data, a_before)
+    big = hip.vec_znx_big_alloc(2, 3)
+    for c in range(2):
+        hip.vec_znx_idft_apply(big, c, d, c)
+    assert np.array_equal(big.data, a.data)
+    # forward spectrum against the oracle's, slot k of the reference <-> natural index bitrev(k)
+    m = n // 2
+    lg = m.bit_length() - 1
+    dr = ref.vec_znx_dft_alloc(2, 3)
+    ref.vec_znx_dft_apply(1, 0, dr, 0, a, 0)
+    rr = dr.at(0, 1)
+    spec_ref = rr[:m] + 1j * rr[m:]
+    hh = d.at(0, 1).view(np.complex128)
+    idx = np.arange(m)
+    rev = np.zeros(m, dtype=np.int64)
+    for bit in range(lg):
+        rev |= ((idx >> bit) & 1) << (lg - 1 - bit)
+    scale = np.abs(spec_ref).max()
+    assert np.abs(hh[rev] - spec_ref).max() <= 1e-10 * scale
+
+
+@pytest.mark.parametrize("step,offset", [(1, 0), (1, 1), (1, 2), (2, 2), (2, 1), (3, 0)])
+def test_vec_znx_dft_apply_step_offset(mods, step, offset):
+    """poulpy-hal/src/test_suite/vec_znx_dft.rs:360-456: (step, offset) limb selection, untouched limbs."""
+    n, base2k = 256, 12
+    ref, hip = mods(n)
+    rng = seeded(1000 + step * 10 + offset)
+    for a_size in range(1, 6):
+        for res_size in range(1, 6):
+            a = VecZnx(n, 2, a_size).fill_uniform(base2k, rng)
+            pre = rng.standard_normal((res_size, 2, n))
+            dr, dh = VecZnxDft(n, 2, res_size, pre.copy()), VecZnxDft(n, 2, res_size, pre.copy())
+            for c in range(2):
+                ref.vec_znx_dft_apply(step, offset, dr, c, a, 1 - c)
+                hip.vec_znx_dft_apply(step, offset, dh, c, a, 1 - c)
+            # limbs the reference leaves untouched must be untouched (bitwise) on the GPU too
+            steps = -(-a_size // step)
+            min_steps = min(res_size, steps)
+            for j in range(min_steps):
+                if offset + j * step >= a_size:
+                    assert np.array_equal(dh.data[j], pre[j])
+                    dh.data[j] = 0.0
+                    dr.data[j] = 0.0
+            br, bh = ref.vec_znx_idft_apply_consume(dr), hip.vec_znx_idft_apply_consume(dh)
+            assert np.array_equal(br.data, bh.data)
+
+
+def test_svp(mods):
+    """poulpy-hal/src/test_suite/svp.rs: prepare + apply_dft / dft_to_dft / assign."""
+    n, base2k = 256, 12
+    ref, hip = mods(n)
+    rng = seeded(7)
+    for cols in (1, 2):
+        for a_size in range(1, 5):
+            for res_size in range(1, 5):
+                s = ScalarZnx(n, cols).fill_uniform(base2k, rng)
+                pr, ph = SvpPPol(n, cols), SvpPPol(n, cols)
+                b = VecZnx(n, cols, a_size).fill_uniform(base2k, rng)
+                for c in range(cols):
+                    ref.svp_prepare(pr, c, s, c)
+                    hip.svp_prepare(ph, c, s, c)
+                dr, dh = garbage_dft(n, cols, res_size, rng), garbage_dft(n, cols, res_size, rng)
+                for c in range(cols):
+                    ref.svp_apply_dft(dr, c, pr, c, b, c)
+                    hip.svp_apply_dft(dh, c, ph, c, b, c)
+                # dft_to_dft on top
+                er, eh = garbage_dft(n, cols, res_size, rng), garbage_dft(n, cols, res_size, rng)
+                bdr, bdh = ref.vec_znx_dft_alloc(cols, a_size), hip.vec_znx_dft_alloc(cols, a_size)
+                for c in range(cols):
+                    ref.vec_znx_dft_apply(1, 0, bdr, c, b, c)
+                    hip.vec_znx_dft_apply(1, 0, bdh, c, b, c)
+                    ref.svp_apply_dft_to_dft(er, c, pr, c, bdr, c)
+                    hip.svp_apply_dft_to_dft(eh, c, ph, c, bdh, c)
+                    ref.svp_apply_dft_to_dft_assign(bdr, c, pr, c)
+                    hip.svp_apply_dft_to_dft_assign(bdh, c, ph, c)
+                for (xr, xh) in ((dr, dh), (er, eh), (bdr, bdh)):
+                    nr = normalize_all(ref, ref.vec_znx_idft_apply_consume(xr), base2k)
+                    nh = normalize_all(hip, hip.vec_znx_idft_apply_consume(xh), base2k)
+                    assert np.array_equal(nr.data, nh.data)
+
+
+@pytest.mark.parametrize("n", [64, 256])
+def test_vmp_apply_dft_to_dft(mods, n):
+    """poulpy-hal/src/test_suite/vmp.rs:150-310 incl. limb_offset 1..size_out."""
+    base2k = 12
+    ref, hip = mods(n)
+    rng = seeded(n + 3)
+    for cols_in in (1, 2):
+        for cols_out in (1, 2):
+            for size_in in range(1, 5):
+                for size_out in range(1, 5):
+                    rows = size_in
+                    a = VecZnx(n, cols_in, size_in).fill_uniform(base2k, rng)
+                    a0 = a.data.copy()
+                    adr, adh = ref.vec_znx_dft_alloc(cols_in, size_in), hip.vec_znx_dft_alloc(cols_in, size_in)
+                    for j in range(cols_in):
+                        ref.vec_znx_dft_apply(1, 0, adr, j, a, j)
+                        hip.vec_znx_dft_apply(1, 0, adh, j, a, j)
+                    mat = MatZnx(n, rows, cols_in, cols_out, size_out).fill_uniform(base2k, rng)
+                    m0 = mat.data.copy()
+                    pr, ph = ref.vmp_pmat_alloc(rows, cols_in, cols_out, size_out), hip.vmp_pmat_alloc(rows, cols_in, cols_out, size_out)
+                    ref.vmp_prepare(pr, mat)
+                    hip.vmp_prepare(ph, mat)
+                    assert np.array_equal(mat.data, m0) and np.array_equal(a.data, a0)
+                    rr, rh = garbage_dft(n, cols_out, size_out, rng), garbage_dft(n, cols_out, size_out, rng)
+                    ref.vmp_apply_dft_to_dft(rr, adr, pr, 0)
+                    hip.vmp_apply_dft_to_dft(rh, adh, ph, 0)
+                    nr = normalize_all(ref, ref.vec_znx_idft_apply_consume(rr), base2k)
+                    nh = normalize_all(hip, hip.vec_znx_idft_apply_consume(rh), base2k)
+                    assert np.array_equal(nr.data, nh.data), (cols_in, cols_out, size_in, size_out)
+                    for limb_offset in range(1, size_out):
+                        rr, rh = ref.vec_znx_dft_alloc(cols_out, size_out), hip.vec_znx_dft_alloc(cols_out, size_out)
+                        ref.vmp_apply_dft_to_dft(rr, adr, pr, limb_offset)
+                        hip.vmp_apply_dft_to_dft(rh, adh, ph, limb_offset)
+                        nr = normalize_all(ref, ref.vec_znx_idft_apply_consume(rr), base2k)
+                        nh = normalize_all(hip, hip.vec_znx_idft_apply_consume(rh), base2k)
+                        assert np.array_equal(nr.data, nh.data), (cols_in, cols_out, size_in, size_out, limb_offset)
+                    # vmp_apply_dft (family_common.rs:17-54)
+                    rr, rh = garbage_dft(n, cols_out, size_out, rng), garbage_dft(n, cols_out, size_out, rng)
+                    ref.vmp_apply_dft(rr, a, pr)
+                    hip.vmp_apply_dft(rh, a, ph)
+                    nr = normalize_all(ref, ref.vec_znx_idft_apply_consume(rr), base2k)
+                    nh = normalize_all(hip, hip.vec_znx_idft_apply_consume(rh), base2k)
+                    assert np.array_equal(nr.data, nh.data)
+
+
+def test_vec_znx_big_normalize_offsets(mods):
+    """poulpy-hal/src/test_suite/vec_znx_big.rs:785-872: 63-bit inputs, res_offset in [-base2k, base2k],
+    same base and cross base."""
+    n = 64
+    ref, hip = mods(n)
+    rng = seeded(11)
+    for a_base2k, res_base2k in ((12, 12), (17, 17), (12, 17), (19, 12), (50, 13), (7, 31)):
+        for a_size in (1, 2, 3, 5):
+            for res_size in (1, 2, 4):
+                a = VecZnxBig(n, 2, a_size).fill_uniform(63, rng)
+                for off in range(-a_base2k, a_base2k + 1, 3):
+                    rr, rh = VecZnx(n, 2, res_size), VecZnx(n, 2, res_size)
+                    rr.data[...] = 77
+                    rh.data[...] = 77
+                    for c in range(2):
+                        ref.vec_znx_big_normalize(rr, res_base2k, off, c, a, a_base2k, 1 - c)
+                        hip.vec_znx_big_normalize(rh, res_base2k, off, c, a, a_base2k, 1 - c)
+                    assert np.array_equal(rr.data, rh.data), (a_base2k, res_base2k, a_size, res_size, off)
+
+
+def test_dft_elementwise_ops(mods):
+    """poulpy-hal/src/test_suite/vec_znx_dft.rs add/sub/copy/zero family, compared after idft+normalize."""
+    n, base2k = 128, 12
+    ref, hip = mods(n)
+    rng = seeded(5)
+    for a_size in (1, 2, 4):
+        for b_size in (1, 3):
+            for res_size in (1, 2, 5):
+                a = VecZnx(n, 2, a_size).fill_uniform(base2k, rng)
+                b = VecZnx(n, 2, b_size).fill_uniform(base2k, rng)
+                r0 = VecZnx(n, 2, res_size).fill_uniform(base2k, rng)
+
+                def spectra(mod):
+                    da, db, dr = mod.vec_znx_dft_alloc(2, a_size), mod.vec_znx_dft_alloc(2, b_size), mod.vec_znx_dft_alloc(2, res_size)
+                    for c in range(2):
+                        mod.vec_znx_dft_apply(1, 0, da, c, a, c)
+                        mod.vec_znx_dft_apply(1, 0, db, c, b, c)
+                        mod.vec_znx_dft_apply(1, 0, dr, c, r0, c)
+                    return da, db, dr
+
+                ops = [
+                    lambda mod, da, db, dr: [mod.vec_znx_dft_add_into(dr, c, da, c, db, 1 - c) for c in range(2)],
+                    lambda mod, da, db, dr: [mod.vec_znx_dft_sub(dr, c, da, c, db, 1 - c) for c in range(2)],
+                    lambda mod, da, db, dr: [mod.vec_znx_dft_add_assign(dr, c, da, 1 - c) for c in range(2)],
+                    lambda mod, da, db, dr: [mod.vec_znx_dft_sub_assign(dr, c, da, 1 - c) for c in range(2)],
+                    lambda mod, da, db, dr: [mod.vec_znx_dft_sub_negate_assign(dr, c, da, 1 - c) for c in range(2)],
+                    lambda mod, da, db, dr: [mod.vec_znx_dft_add_scaled_assign(dr, c, da, c, 1) for c in range(2)],
+                    lambda mod, da, db, dr: [mod.vec_znx_dft_add_scaled_assign(dr, c, da, c, -2) for c in range(2)],
+                    lambda mod, da, db, dr: [mod.vec_znx_dft_copy(2, 1, dr, c, da, c) for c in range(2)],
+                    lambda mod, da, db, dr: [mod.vec_znx_dft_copy(1, 0, dr, c, db, c) for c in range(2)],
+                    lambda mod, da, db, dr: [mod.vec_znx_dft_zero(dr, 1)],
+                ]
+                for k, op in enumerate(ops):
+                    outs = []
+                    for mod in (ref, hip):
+                        da, db, dr = spectra(mod)
+                        op(mod, da, db, dr)
+                        outs.append(normalize_all(mod, mod.vec_znx_idft_apply_consume(dr), base2k).data)
+                    assert np.array_equal(outs[0], outs[1]), (k, a_size, b_size, res_size)
+
+
+def test_big_add_small_assign(mods):
+    n = 64
+    ref, hip = mods(n)
+    rng = seeded(9)
+    for a_size in (1, 3):
+        for res_size in (1, 2, 4):
+            a = VecZnx(n, 2, a_size).fill_uniform(30, rng)
+            r = VecZnxBig(n, 2, res_size).fill_uniform(62, rng)
+            rr, rh = r.copy(), r.copy()
+            ref.vec_znx_big_add_small_assign(rr, 1, a, 0)
+            hip.vec_znx_big_add_small_assign(rh, 1, a, 0)
+            assert np.array_equal(rr.data, rh.data)
