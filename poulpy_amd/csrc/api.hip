@@ -242,8 +242,11 @@ static bool is_device_ptr(const void* p) {
 }
 
 // A staged argument: device view of a (possibly host) container of `bytes` bytes.
+// Host buffers are copied into the module's staging arena; outputs are copied back by
+// finish_call() after the stream has drained (blocking hipMemcpy: no reliance on the ordering
+// of asynchronous copies into pageable memory).
 struct Stage {
-    pz_module* M;
+    pz_module* M = nullptr;
     void* host = nullptr;
     void* dev = nullptr;
     size_t bytes = 0;
@@ -254,31 +257,31 @@ struct Stage {
         if (is_device_ptr(p)) { dev = (void*)p; owned = false; return PZ_OK; }
         host = (void*)p;
         owned = true;
-        PZ_HIP(hipMallocAsync(&dev, nbytes, M->stream));
+        PZ_TRY(arena_alloc(M, nbytes, &dev));
         if (copy_in) PZ_HIP(hipMemcpyAsync(dev, host, nbytes, hipMemcpyHostToDevice, M->stream));
         return PZ_OK;
     }
     int finish() {
-        if (!owned) return PZ_OK;
-        if (out) PZ_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, M->stream));
-        PZ_HIP(hipFreeAsync(dev, M->stream));
+        if (owned && out) M->pending_out.push_back({host, dev, bytes});
         owned = false;
         return PZ_OK;
-    }
-    ~Stage() {
-        if (owned && dev) (void)hipFreeAsync(dev, M->stream);
     }
 };
 
 static int finish_call(pz_module* M, bool any_host) {
-    if (any_host) PZ_HIP(hipStreamSynchronize(M->stream));
+    if (any_host || !M->pending_out.empty()) {
+        PZ_HIP(hipStreamSynchronize(M->stream));
+        for (auto& po : M->pending_out) PZ_HIP(hipMemcpy(po.host, po.dev, po.bytes, hipMemcpyDeviceToHost));
+        M->pending_out.clear();
+    }
     return PZ_OK;
 }
 
 #define PZ_ENTER(M)                                              \
     if (!(M)) return fail(PZ_ERR_INVALID, "null module");        \
     std::lock_guard<std::mutex> lock_((M)->mu);                  \
-    PZ_HIP(hipSetDevice((M)->device));
+    PZ_HIP(hipSetDevice((M)->device));                           \
+    arena_reset(M);
 
 static inline size_t vbytes(const pz_module* M, size_t cols, size_t size) { return (size_t)M->n * cols * size * 8; }
 
@@ -325,6 +328,7 @@ void pz_module_free(pz_module* M) {
     if (M->stream) (void)hipStreamSynchronize(M->stream);
     for (void* p : {(void*)M->tw1, (void*)M->tw1inv, (void*)M->wL1, (void*)M->wL2, (void*)M->tw12, M->ws, (void*)M->margin})
         if (p) (void)hipFree(p);
+    for (auto& c : M->arena) (void)hipFree(c.p);
     if (M->stream) (void)hipStreamDestroy(M->stream);
     delete M;
 }

@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -95,6 +96,13 @@ struct pz_module {
     // grow-only workspace
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    // staging arena for host-pointer calls: chunks are kept for the module's lifetime and the bump
+    // pointer is reset at the start of every call (calls are serialised by `mu` and end with a sync)
+    struct Chunk { void* p; size_t bytes; };
+    std::vector<Chunk> arena;
+    size_t arena_chunk = 0, arena_off = 0;
+    struct PendingOut { void* host; const void* dev; size_t bytes; };
+    std::vector<PendingOut> pending_out;
     std::mutex mu;
     unsigned long long* margin = nullptr;  // device word, bits of max |x-round(x)|
     bool probe = false;
@@ -112,6 +120,34 @@ inline int ws_reserve(pz_module* M, size_t bytes) {
     size_t want = bytes + (bytes >> 3);
     PZ_HIP(hipMalloc(&M->ws, want));
     M->ws_bytes = want;
+    return PZ_OK;
+}
+
+inline void arena_reset(pz_module* M) {
+    M->arena_chunk = 0;
+    M->arena_off = 0;
+    M->pending_out.clear();
+}
+inline int arena_alloc(pz_module* M, size_t bytes, void** out) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    while (M->arena_chunk < M->arena.size()) {
+        auto& c = M->arena[M->arena_chunk];
+        if (M->arena_off + bytes <= c.bytes) {
+            *out = (char*)c.p + M->arena_off;
+            M->arena_off += bytes;
+            return PZ_OK;
+        }
+        M->arena_chunk++;
+        M->arena_off = 0;
+    }
+    size_t want = std::max<size_t>(bytes, (size_t)8 << 20);
+    if (!M->arena.empty()) want = std::max(want, 2 * M->arena.back().bytes);
+    void* p = nullptr;
+    PZ_HIP(hipMalloc(&p, want));
+    M->arena.push_back({p, want});
+    M->arena_chunk = M->arena.size() - 1;
+    M->arena_off = bytes;
+    *out = p;
     return PZ_OK;
 }
 

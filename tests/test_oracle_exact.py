@@ -1,0 +1,179 @@
+"""CPU: pin the C restatement (oracle/fft64_ref.c) with exact-integer statements (oracle/exact.py).
+
+The reference ships no golden vectors and cannot be built here, so these
+properties are what anchors the oracle:
+  P1  idft(vmp(dft(a), prepare(M))) == exact bivariate negacyclic product       (tests.rs:133-141)
+  P2  idft(svp(dft(b), prepare(s))) == exact negacyclic product                  (test_suite/svp.rs)
+  P3  normalize == big-int balanced digit decomposition / torus value preserved  (normalize.rs:428-540)
+  A1  spectral identity of fft_ref (slot k <-> root exp(2 pi i (4 bitrev(k)+1)/(4m)))
+"""
+import numpy as np
+import pytest
+
+from oracle import exact
+from oracle.ref import RefModule
+from poulpy_amd.layouts import MatZnx, ScalarZnx, SvpPPol, VecZnx, VecZnxBig, VecZnxDft
+from tests.helpers import normalize_all, seeded
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32, 64, 128, 256, 1024])
+def test_fft_spectral_identity(n):
+    R = RefModule(n)
+    m = n // 2
+    rng = seeded(n)
+    a = rng.integers(-1000, 1000, n).astype(np.float64)
+    d = a.copy()
+    R.fft(d)
+    z = a[:m] + 1j * a[m:]
+    lg = m.bit_length() - 1
+    rev = [int(format(k, "0%db" % lg)[::-1], 2) if lg else 0 for k in range(m)]
+    want = np.array([np.sum(z * np.exp(2j * np.pi * np.arange(m) * (4 * rev[k] + 1) / (4 * m))) for k in range(m)])
+    got = d[:m] + 1j * d[m:]
+    assert np.abs(got - want).max() <= 1e-9 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("n", [4, 16, 64, 2048, 4096, 8192, 65536])
+def test_fft_ifft_roundtrip(n):
+    R = RefModule(n)
+    rng = seeded(n + 1)
+    a = rng.integers(-(1 << 40), 1 << 40, n).astype(np.float64)
+    d = a.copy()
+    R.fft(d)
+    R.ifft(d)
+    assert np.array_equal(np.round(d / (n // 2)), a)
+
+
+@pytest.mark.parametrize("n,base2k", [(8, 12), (16, 17), (64, 12), (256, 19)])
+def test_P1_vmp_equals_exact_product(n, base2k):
+    """Shape grid of poulpy-hal/src/test_suite/vmp.rs:180-308 against the exact product."""
+    R = RefModule(n)
+    rng = seeded(n * 31 + base2k)
+    for cols_in in (1, 2):
+        for cols_out in (1, 2):
+            for size_in in range(1, 4):
+                for size_out in range(1, 4):
+                    rows = size_in
+                    a = VecZnx(n, cols_in, size_in).fill_uniform(base2k, rng)
+                    mat = MatZnx(n, rows, cols_in, cols_out, size_out).fill_uniform(base2k, rng)
+                    ad = R.vec_znx_dft_alloc(cols_in, size_in)
+                    for j in range(cols_in):
+                        R.vec_znx_dft_apply(1, 0, ad, j, a, j)
+                    pm = R.vmp_pmat_alloc(rows, cols_in, cols_out, size_out)
+                    R.vmp_prepare(pm, mat)
+                    for limb_offset in range(0, size_out):
+                        rd = R.vec_znx_dft_alloc(cols_out, size_out)  # zeroed, like test_suite/vmp.rs:260-262
+                        R.vmp_apply_dft_to_dft(rd, ad, pm, limb_offset)
+                        big = R.vec_znx_idft_apply_consume(rd)
+                        want = exact.vmp_exact(a.data, mat.data, limb_offset, size_out)
+                        assert np.array_equal(big.data.astype(object), want), (cols_in, cols_out, size_in, size_out, limb_offset)
+
+
+def test_P2_svp_equals_exact_product():
+    n, base2k = 64, 17
+    R = RefModule(n)
+    rng = seeded(5)
+    s = ScalarZnx(n, 2).fill_uniform(base2k, rng)
+    b = VecZnx(n, 2, 3).fill_uniform(base2k, rng)
+    pp = SvpPPol(n, 2)
+    for c in range(2):
+        R.svp_prepare(pp, c, s, c)
+    d = R.vec_znx_dft_alloc(2, 4)
+    d.data[...] = 123.0
+    for c in range(2):
+        R.svp_apply_dft(d, c, pp, 1 - c, b, c)
+    big = R.vec_znx_idft_apply_consume(d)
+    for c in range(2):
+        for j in range(3):
+            want = exact.negacyclic_mul(s.at(1 - c, 0), b.at(c, j))
+            assert np.array_equal(big.at(c, j).astype(object), want)
+        assert not big.at(c, 3).any()
+
+
+@pytest.mark.parametrize("base2k", [1, 2, 12, 17, 19, 31, 52])
+def test_P3_normalize_same_base_exact(base2k):
+    n = 32
+    R = RefModule(n)
+    rng = seeded(base2k)
+    for a_size in range(1, 6):
+        for res_size in range(1, 6):
+            # keep |value| small enough that the reference's i64 carries cannot overflow
+            a = VecZnxBig(n, 2, a_size).fill_uniform(min(62, 2 * base2k + 20), rng)
+            res = VecZnx(n, 2, res_size)
+            res.data[...] = -1
+            R.vec_znx_big_normalize(res, base2k, 0, 1, a, base2k, 0)
+            want = exact.normalize_exact(a.data[:, 0, :], base2k, res_size)
+            assert np.array_equal(res.data[:, 1, :], want), (a_size, res_size)
+            h = 1 << (base2k - 1)
+            assert res.data[:, 1, :].min() >= -h and res.data[:, 1, :].max() < h
+            assert np.all(res.data[:, 0, :] == -1)  # other column untouched
+
+
+def test_P3_normalize_cross_base_value_preserved():
+    """All (a_base2k, res_base2k) pairs on a coarse grid x offsets: torus value preserved."""
+    n = 16
+    R = RefModule(n)
+    rng = seeded(77)
+    bases = [1, 2, 3, 7, 12, 13, 17, 19, 26, 31, 40, 51]
+    for ak in bases:
+        for rk in bases:
+            for a_size, res_size in ((3, 3), (2, 5), (5, 2), (1, 4)):
+                a = VecZnx(n, 1, a_size).fill_uniform(ak, rng)  # normalized input, like the reference test
+                for off in (0, 1, -1, ak // 2, -(ak // 2), ak, -ak, 2 * ak + 1):
+                    res = VecZnx(n, 1, res_size)
+                    res.data[...] = 99
+                    R.vec_znx_big_normalize(res, rk, off, 0, a, ak, 0)
+                    assert exact.torus_equal(a.data[:, 0, :], ak, res.data[:, 0, :], rk, off), (ak, rk, a_size, res_size, off)
+
+
+def test_dft_apply_step_offset_semantics():
+    """vec_znx_dft.rs:160-200: limb selection, limbs past a.size left untouched, tail zeroed."""
+    n = 32
+    R = RefModule(n)
+    rng = seeded(3)
+    a = VecZnx(n, 1, 5).fill_uniform(12, rng)
+    for step, offset in ((1, 0), (1, 2), (2, 2), (2, 1), (3, 1)):
+        for res_size in (1, 3, 6):
+            d = VecZnxDft(n, 1, res_size)
+            d.data[...] = 7.5
+            R.vec_znx_dft_apply(step, offset, d, 0, a, 0)
+            steps = -(-5 // step)
+            min_steps = min(res_size, steps)
+            for j in range(res_size):
+                limb = offset + j * step
+                if j >= min_steps:
+                    assert not d.data[j].any()
+                elif limb >= 5:
+                    assert np.all(d.data[j] == 7.5)
+                else:
+                    single = VecZnxDft(n, 1, 1)
+                    R.vec_znx_dft_apply(1, 0, single, 0, VecZnx(n, 1, 1, a.data[limb].copy()), 0)
+                    assert np.array_equal(single.data[0], d.data[j])
+
+
+@pytest.mark.parametrize("dsize", [1, 2, 3])
+def test_external_product_and_keyswitch_match_exact(dsize):
+    """poulpy-core glue restated in the oracle (external_product/glwe.rs, keyswitching/glwe.rs) vs the
+    exact bivariate product + big-int normalize, incl. dsize > 1 folding (zero-tail semantics)."""
+    n, base2k, rank = 32, 12, 1
+    cols = rank + 1
+    R = RefModule(n)
+    rng = seeded(40 + dsize)
+    a_size, dnum = 4, 2 if dsize > 1 else 4
+    key_size = 5
+    a = VecZnx(n, cols, a_size).fill_uniform(base2k, rng)
+    mat = MatZnx(n, dnum, cols, cols, key_size).fill_uniform(base2k, rng)
+    pm = R.vmp_pmat_alloc(dnum, cols, cols, key_size)
+    R.vmp_prepare(pm, mat)
+    res = VecZnx(n, cols, 4)
+    R.glwe_external_product(res, base2k, a, base2k, pm, dsize, base2k)
+    # exact: sum over digits di of (limbs offset+j*dsize of a) x (mat shifted by di limbs)
+    big = np.zeros((key_size, cols, n), dtype=object)
+    for di in range(dsize):
+        sel = a.data[dsize - 1 - di::dsize][: (a_size + di) // dsize]
+        drop = max(dsize - di - 2, 0)
+        part = exact.vmp_exact(sel, mat.data, di, key_size - drop)
+        big[: key_size - drop] += part
+    want = np.zeros((4, cols, n), dtype=np.int64)
+    for c in range(cols):
+        want[:, c, :] = exact.normalize_exact(big[:, c, :], base2k, 4)
+    assert np.array_equal(res.data, want)
