@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py — GLWE (x) GGSW external products / s at N=2^16, 8 limbs on N MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver
+launches this file under torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints ONE
+JSON line.
+
+Workload ("metric" row of BASELINE.md §3): rank 1 (cols = 2), dsize 1, base2k 12, 8 limbs,
+GGSW = VmpPMat(rows 8, cols_in 2, cols_out 2, size 8) shared by the whole batch.  A step is
+one pz_glwe_external_product_batched() over `--batch` ciphertexts resident in HBM on every
+GPU (weak scaling: per-GPU work fixed).  The evaluation key is prepared on rank 0 and
+broadcast with RCCL; there is no other collective on the data path.
+
+PyTorch is plumbing only (device buffers for the synthetic inputs, torch.distributed).
+The measured code is libpoulpy_hip.so through its C ABI.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N = 1 << 16
+RANK_GLWE = 1
+SIZE = 8
+BASE2K = 12
+DNUM = 8
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (≈6.3 TB/s achievable)
+
+
+def algorithmic_bytes_per_unit(batch: int) -> float:
+    """B_ep = 2*cols*size*N*8 + rows*cols*cols*size*N*8 / batch."""
+    cols = RANK_GLWE + 1
+    return 2 * cols * SIZE * N * 8 + DNUM * cols * cols * SIZE * N * 8 / batch
+
+
+def cpu_baseline(sample_cts_per_thread: int = 4, max_threads: int | None = None) -> dict:
+    """Oracle (C restatement, built -O3 -march=native on this host) timed on the host cores over a
+    bounded sample of the same workload: independent ciphertexts, one thread each."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle.ref import RefModule
+    from poulpy_amd.layouts import MatZnx, VecZnx
+
+    threads = min(os.cpu_count() or 1, max_threads or 64)
+    ref = RefModule(N, fast=True)
+    rng = np.random.default_rng(0x6657)
+    cols = RANK_GLWE + 1
+    mat = MatZnx(N, DNUM, cols, cols, SIZE).fill_uniform(BASE2K, rng)
+    pm = ref.vmp_pmat_alloc(DNUM, cols, cols, SIZE)
+    ref.vmp_prepare(pm, mat)
+    cts = [VecZnx(N, cols, SIZE).fill_uniform(BASE2K, rng) for _ in range(threads)]
+    outs = [VecZnx(N, cols, SIZE) for _ in range(threads)]
+
+    def work(i):
+        for _ in range(sample_cts_per_thread):
+            ref.glwe_external_product(outs[i], BASE2K, cts[i], BASE2K, pm, 1, BASE2K)
+
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(work, range(threads)))  # warm-up (page faults, tables)
+        t0 = time.perf_counter()
+        list(ex.map(work, range(threads)))
+        dt = time.perf_counter() - t0
+    units = threads * sample_cts_per_thread
+    return {"value": units / dt, "unit": "external-products/s", "cores": threads, "kind": "port",
+            "sample": f"{units} external products (N=2^16, 8 limbs, rank 1, dnum 8), {threads} threads x "
+                      f"{sample_cts_per_thread}, oracle/fft64_ref.c built -O3 -march=native, {dt:.2f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=128, help="ciphertexts per GPU per step")
+    ap.add_argument("--chunk", type=int, default=0, help="ciphertexts per pipeline wave (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from poulpy_amd.hal import GlweOpParams, Module
+    from poulpy_amd import dist as pdist
+
+    mod = Module(N, device=local_rank)
+    if args.chunk:
+        mod.set_chunk(args.chunk)
+    dev = torch.device("cuda", local_rank)
+    cols = RANK_GLWE + 1
+    half = 1 << (BASE2K - 1)
+
+    # evaluation key: synthetic MatZnx (same distribution as test_suite/vmp.rs:200-201), prepared on rank 0,
+    # broadcast over RCCL — the only collective
+    key_elems = N * DNUM * cols * cols * SIZE
+    pmat = torch.empty(key_elems, dtype=torch.float64, device=dev)
+    if rank == 0:
+        g = torch.Generator(device=dev)
+        g.manual_seed(0x6657)
+        mat = torch.randint(-half, half, (key_elems,), dtype=torch.int64, device=dev, generator=g)
+        torch.cuda.synchronize()
+        mod._ck(mod.lib.pz_vmp_prepare(mod.handle, C.c_void_p(pmat.data_ptr()), C.c_void_p(mat.data_ptr()),
+                                       C.c_size_t(DNUM), C.c_size_t(cols), C.c_size_t(cols), C.c_size_t(SIZE)))
+        mod.sync()
+        del mat
+    if distributed:
+        pdist.broadcast_key(pmat, src=0)
+
+    # this rank's shard of the (weak-scaled) batch: `batch` ciphertexts per GPU, seeds by global index
+    lo, hi = pdist.shard_range(args.batch * world, world, rank)
+    nct = hi - lo
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x5EED0000 + rank)
+    a = torch.randint(-half, half, (nct, SIZE, cols, N), dtype=torch.int64, device=dev, generator=g)
+    res = torch.empty((nct, SIZE, cols, N), dtype=torch.int64, device=dev)
+    params = GlweOpParams(rank=RANK_GLWE, dnum=DNUM, dsize=1, key_size=SIZE, key_base2k=BASE2K, a_size=SIZE, a_base2k=BASE2K,
+                          res_size=SIZE, res_base2k=BASE2K, rank_out=RANK_GLWE)
+    a_ptr, res_ptr, key_ptr = C.c_void_p(a.data_ptr()), C.c_void_p(res.data_ptr()), C.c_void_p(pmat.data_ptr())
+    torch.cuda.synchronize()
+
+    def step():
+        mod.glwe_external_product_batched(res_ptr, a_ptr, key_ptr, params, nct)
+
+    for _ in range(args.warmup):
+        step()
+    mod.sync()
+
+    timing = (not args.no_kernel_timing)
+    if timing:
+        mod.set_kernel_timing(True)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    mod.sync()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    stats = mod.kernel_stats() if timing else {}
+    if timing:
+        mod.set_kernel_timing(False)
+
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # cheap size-independent sanity on the timed output: digits are balanced base-2^12
+    ok = bool((res.min() >= -half).item() and (res.max() < half).item())
+
+    if rank == 0:
+        total_units = args.batch * world * args.steps
+        value = total_units / dt
+        b_unit = algorithmic_bytes_per_unit(args.batch)
+        roof = None
+        if stats:
+            dom = max(stats.items(), key=lambda kv: kv[1][1])
+            name, (cnt, ms) = dom
+            if cnt:
+                units_per_launch = nct * args.steps / cnt
+                avg_s = ms / cnt / 1e3
+                achieved = b_unit * units_per_launch / avg_s / 1e9
+                roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_ms": ms / cnt, "launches": cnt, "units_per_launch": units_per_launch,
+                        "algorithmic_bytes_per_unit": b_unit,
+                        "pipeline_achieved": value / world * b_unit / 1e9,
+                        "kernel_ms": {k: round(v[1], 3) for k, v in stats.items() if v[0]}}
+        line = {
+            "metric": "GGSW external-products/sec (N=2^16, 8 limbs)", "value": value, "unit": "external-products/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "GLWE(rank 1) x GGSW external product, N=65536, 8 limbs, base2k=12, dnum=8, dsize=1",
+                       "batch_per_gpu": args.batch, "parallelism": f"batch-sharded x{world}, key broadcast (RCCL)",
+                       "output_digits_balanced": ok},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the baseline is reported, never required for the GPU number
+                line["cpu_baseline"] = {"value": None, "unit": "external-products/s", "cores": 0, "kind": "port",
+                                        "sample": f"failed: {e}"}
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -215,6 +215,9 @@ size_t pz_glwe_op_workspace_bytes(const pz_module* m, const pz_glwe_op_params* p
 /* Tuning knob: number of ciphertexts pushed through the three-kernel pipeline per
  * wave so that intermediates stay in the 256 MiB Infinity Cache (0 = auto). */
 int pz_module_set_chunk(pz_module* m, size_t cts_per_chunk);
+/* Kernel-fusion knobs of the batched GLWE ops (both on by default; the unfused path is the per-op one,
+ * kept selectable so that tests can compare the two bit for bit). */
+int pz_module_set_fusion(pz_module* m, int fuse_tail, int fuse_mid);
 
 /* batched primitives (device pointers; object b at ptr + b*len(object)) */
 int pz_vec_znx_dft_apply_batched(pz_module* m, size_t batch, size_t step, size_t offset,
@@ -236,6 +239,25 @@ int pz_event_create(void** ev);
 int pz_event_destroy(void* ev);
 int pz_event_record(pz_module* m, void* ev);
 int pz_event_elapsed_ms(void* ev0, void* ev1, float* ms); /* synchronises on ev1 */
+/* Per-kernel-class timing with HIP events on the module stream (what bench.py's "roofline"
+ * object is computed from).  Classes: */
+enum {
+    PZ_K_FWD_PASS1 = 0, /* i64 -> T      (column pass of the forward transform)        */
+    PZ_K_FWD_PASS2 = 1, /* T -> spectrum  (row pass)                                    */
+    PZ_K_VMP = 2,       /* vector-matrix product in the DFT domain                      */
+    PZ_K_INV_PASS2 = 3, /* spectrum -> T                                                */
+    PZ_K_INV_PASS1 = 4, /* T -> i64, round(x/m)                                         */
+    PZ_K_NORMALIZE = 5, /* base-2^k carry chain                                         */
+    PZ_K_ELEMENTWISE = 6,
+    PZ_K_FUSED_MID = 7, /* fused row pass + VMP + inverse row pass                      */
+    PZ_K_FUSED_TAIL = 8, /* fused inverse column pass + normalize                       */
+    PZ_KCLASS_COUNT = 9
+};
+int pz_module_set_kernel_timing(pz_module* m, int enable); /* enabling resets the counters */
+/* synchronises the stream and returns accumulated launches / milliseconds of one class */
+int pz_module_get_kernel_stats(pz_module* m, int kclass, uint64_t* launches, double* total_ms);
+const char* pz_kernel_class_name(int kclass);
+
 /* largest |x - round(x)| seen by the last inverse-FFT epilogue when enabled (exactness margin) */
 int pz_module_set_margin_probe(pz_module* m, int enable);
 int pz_module_get_margin(pz_module* m, double* max_frac);

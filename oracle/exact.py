@@ -96,21 +96,24 @@ def normalize_exact(a_limbs: np.ndarray, base2k: int, res_size: int) -> np.ndarr
     return out
 
 
-def torus_equal(a_limbs: np.ndarray, a_base2k: int, res_limbs: np.ndarray, res_base2k: int, res_offset: int = 0) -> bool:
-    """True iff res encodes the same torus value as a * 2^res_offset up to res's precision, i.e.
-    |a*2^off - res| <= 2^-(res_bits) (mod 1), the criterion of test_vec_znx_normalize_cross_base2k
-    (reference/vec_znx/normalize.rs:428-540)."""
+def torus_equal(a_limbs: np.ndarray, a_base2k: int, res_limbs: np.ndarray, res_base2k: int, res_offset: int = 0,
+                slack_bits: int = 1) -> bool:
+    """Criterion of test_vec_znx_normalize_cross_base2k (reference/vec_znx/normalize.rs:428-540):
+    with want = value(a) * 2^res_offset and have = value(res), both reduced mod 1,
+    |have - want| <= 2^(-min_prec + slack_bits), min_prec = min(a bits, res bits).  Exact big-int
+    arithmetic (the reference uses 128-bit floats)."""
     a_bits = a_limbs.shape[0] * a_base2k
     r_bits = res_limbs.shape[0] * res_base2k
-    tot = max(a_bits, r_bits) + abs(res_offset) + 2
-    va = torus_value(a_limbs, a_base2k, tot)
+    min_prec = min(a_bits, r_bits)
+    tot = max(a_bits, r_bits) + abs(res_offset) + 4
+    va = torus_value(a_limbs, a_base2k, tot)      # numerators over 2^tot
     vr = torus_value(res_limbs, res_base2k, tot)
     if res_offset >= 0:
         va = va * (1 << res_offset)
     else:
-        va = va >> (-res_offset)  # floor: error below one unit of `tot`
+        va = va >> (-res_offset)                   # floor; error < 2^-tot
     mod = 1 << tot
     diff = (va - vr) % mod
     diff = np.where(diff > mod // 2, mod - diff, diff)
-    bound = (1 << (tot - r_bits)) + (1 << max(tot - a_bits, 0)) + 2
+    bound = (1 << (tot - min_prec + slack_bits)) + 1
     return bool(np.all(diff <= bound))

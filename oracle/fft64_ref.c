@@ -1357,8 +1357,12 @@ void pzr_glwe_external_product(const pzr_tables* t, size_t rank,
         for (size_t j = 0; j < cols; ++j) pzr_vec_znx_dft_apply(t, 1, 0, a_dft, cols, a_size, j, a, cols, a_size, j);
         pzr_vmp_apply_dft_to_dft(n, res_dft, cols, ggsw_size, a_dft, cols, a_size, ggsw_pmat, dnum, cols, cols, ggsw_size, 0);
     } else {
-        /* glwe.rs:235-267.  The reference takes res_dft_tmp from scratch un-zeroed; it is zeroed here
-         * (deterministic choice). */
+        /* glwe.rs:235-267.  The reference takes res_dft_tmp from scratch un-zeroed and its FFT64
+         * vmp core leaves the last limb_offset limbs of the output unwritten, so
+         * cpu-ref's dsize > 1 result depends on stale scratch.  The restatement takes the NTT120
+         * sibling's (evidently intended) zero-tail semantics: tmp is cleared before every product.
+         * Byte parity with cpu-ref is therefore claimed for dsize = 1 only; dsize > 1 is validated
+         * against the exact bivariate product (tests/test_oracle_exact.py). */
         double* tmp = (double*)calloc(n * cols * ggsw_size, sizeof(double));
         for (size_t di = 0; di < dsize; ++di) {
             size_t a_sz = (a_size + di) / dsize;
@@ -1369,6 +1373,7 @@ void pzr_glwe_external_product(const pzr_tables* t, size_t rank,
             if (di == 0) {
                 pzr_vmp_apply_dft_to_dft(n, res_dft, cols, res_dft_size, a_dft, cols, a_sz, ggsw_pmat, dnum, cols, cols, ggsw_size, 0);
             } else {
+                memset(tmp, 0, n * cols * ggsw_size * sizeof(double));
                 pzr_vmp_apply_dft_to_dft(n, tmp, cols, res_dft_size, a_dft, cols, a_sz, ggsw_pmat, dnum, cols, cols, ggsw_size, di);
                 for (size_t c = 0; c < cols; ++c)
                     pzr_vec_znx_dft_add_assign(n, res_dft, cols, res_dft_size, c, tmp, cols, res_dft_size, c);
@@ -1423,6 +1428,7 @@ void pzr_glwe_keyswitch(const pzr_tables* t, size_t rank_in, size_t rank_out,
             if (di == 0) {
                 pzr_vmp_apply_dft_to_dft(n, res_dft, cols_out, r_sz, ai, cin, ai_sz, key_pmat, dnum, cin, cols_out, key_size, 0);
             } else {
+                memset(tmp, 0, n * cols_out * key_size * sizeof(double)); /* zero-tail semantics, see above */
                 pzr_vmp_apply_dft_to_dft(n, tmp, cols_out, r_sz, ai, cin, ai_sz, key_pmat, dnum, cin, cols_out, key_size, di);
                 for (size_t c = 0; c < cols_out; ++c)
                     pzr_vec_znx_dft_add_assign(n, res_dft, cols_out, r_sz, c, tmp, cols_out, r_sz, c);

@@ -17,10 +17,15 @@
 
 using namespace pz;
 
+#ifndef PZ_VMP_RB
+#define PZ_VMP_RB 2
+#endif
+
 // ------------------------------------------------------------------------------
 // kernel dispatch
 // ------------------------------------------------------------------------------
 #define PZ_P1_CASES(X) X(4, 1, 4) X(8, 1, 4) X(8, 1, 16) X(16, 1, 16) X(8, 4, 16) X(8, 8, 16) X(16, 8, 16) X(16, 16, 16)
+#define PZ_P1F_CASES(X) X(4, 1, 4) X(8, 1, 4) X(8, 1, 16) X(16, 1, 16) X(4, 8, 16) X(8, 8, 16) X(8, 16, 16) X(16, 16, 16)
 #define PZ_P2_CASES(X) X(4, 1, 4) X(8, 1, 4) X(16, 1, 4) X(16, 1, 16) X(8, 4, 16) X(8, 8, 16) X(16, 8, 16) X(16, 16, 16)
 
 template <typename K>
@@ -34,8 +39,9 @@ static int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, Poly
     const FftPlan& pl = M->plan;
     const int blocks = npolys * (pl.m2 / pl.cb);
     if (blocks == 0) return PZ_OK;
+    KTimer kt(M, PZ_K_FWD_PASS1);
 #define X(A, B, C)                                                                                              \
-    if (pl.r1a == A && pl.r1b == B && pl.cb == C) {                                                             \
+    if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
         const size_t lds = (size_t)(A + 1) * C * B * sizeof(cplx);                                              \
         PZ_TRY(set_lds(k_fwd_pass1<A, B, C>, lds));                                                             \
         hipLaunchKernelGGL((k_fwd_pass1<A, B, C>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, src, smap, T, \
@@ -43,7 +49,7 @@ static int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, Poly
         PZ_HIP(hipGetLastError());                                                                              \
         return PZ_OK;                                                                                           \
     }
-    PZ_P1_CASES(X)
+    PZ_P1F_CASES(X)
 #undef X
     return fail(PZ_ERR_UNSUPPORTED, "no forward pass-1 kernel for m1=%d", pl.m1);
 }
@@ -52,6 +58,7 @@ static int launch_fwd_pass2(pz_module* M, int npolys, const cplx* T, double* dst
     const FftPlan& pl = M->plan;
     const int blocks = npolys * (pl.m1 / pl.qb);
     if (blocks == 0) return PZ_OK;
+    KTimer kt(M, PZ_K_FWD_PASS2);
 #define X(A, B, C)                                                                                              \
     if (pl.r2a == A && pl.r2b == B && pl.qb == C) {                                                             \
         const size_t lds = (size_t)A * B * C * sizeof(cplx);                                                    \
@@ -70,6 +77,7 @@ static int launch_inv_pass2(pz_module* M, int npolys, const double* src, PolyMap
     const FftPlan& pl = M->plan;
     const int blocks = npolys * (pl.m1 / pl.qb);
     if (blocks == 0) return PZ_OK;
+    KTimer kt(M, PZ_K_INV_PASS2);
 #define X(A, B, C)                                                                                              \
     if (pl.r2a == A && pl.r2b == B && pl.qb == C) {                                                             \
         const size_t lds = (size_t)A * B * C * sizeof(cplx);                                                    \
@@ -88,6 +96,7 @@ static int launch_inv_pass1(pz_module* M, int npolys, const cplx* T, long long* 
     const FftPlan& pl = M->plan;
     const int blocks = npolys * (pl.m2 / pl.cb);
     if (blocks == 0) return PZ_OK;
+    KTimer kt(M, PZ_K_INV_PASS1);
 #define X(A, B, C)                                                                                              \
     if (pl.r1a == A && pl.r1b == B && pl.cb == C) {                                                             \
         const size_t lds = (size_t)(A + 1) * C * B * sizeof(cplx);                                              \
@@ -108,6 +117,39 @@ static int launch_inv_pass1(pz_module* M, int npolys, const cplx* T, long long* 
     return fail(PZ_ERR_UNSUPPORTED, "no inverse pass-1 kernel for m1=%d", pl.m1);
 }
 
+// the two roles of k_inv_tail must be whole waves
+static bool tail_supported(const pz_module* M) { return (M->plan.f1b * M->plan.cb) % 64 == 0; }
+
+static int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
+                           int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
+                           int base2k) {
+    const FftPlan& pl = M->plan;
+    const int blocks = batch * ncols * (pl.m2 / pl.cb);
+    if (blocks == 0) return PZ_OK;
+    KTimer kt(M, PZ_K_FUSED_TAIL);
+    TailArgs g;
+    g.T = T; g.res = res; g.small = small; g.res_bs = res_bs; g.small_bs = small_bs;
+    g.nlimbs = nlimbs; g.ncols = ncols; g.res_cols = res_cols; g.res_size = res_size;
+    g.small_cols = small_cols; g.small_size = small_size; g.base2k = base2k; g.m2 = pl.m2;
+    g.tw1inv = M->tw1inv; g.wL1 = M->wL1; g.margin = M->margin;
+#define X(A, B, C)                                                                                              \
+    if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
+        const size_t lds = (size_t)2 * (A + 1) * C * B * sizeof(cplx);                  \
+        if (M->probe) {                                                                                         \
+            PZ_TRY(set_lds(k_inv_tail<A, B, C, true>, lds));                                                    \
+            hipLaunchKernelGGL((k_inv_tail<A, B, C, true>), dim3(blocks), dim3((A + B) * C), lds, M->stream, g); \
+        } else {                                                                                                \
+            PZ_TRY(set_lds(k_inv_tail<A, B, C, false>, lds));                                                   \
+            hipLaunchKernelGGL((k_inv_tail<A, B, C, false>), dim3(blocks), dim3((A + B) * C), lds, M->stream, g); \
+        }                                                                                                       \
+        PZ_HIP(hipGetLastError());                                                                              \
+        return PZ_OK;                                                                                           \
+    }
+    PZ_P1F_CASES(X)
+#undef X
+    return fail(PZ_ERR_UNSUPPORTED, "no fused tail kernel for m1=%d", pl.m1);
+}
+
 static int launch_ew(pz_module* M, int op, void* res, long long res_bs, long long res_ls, const void* a, long long a_bs,
                      long long a_ls, const void* b, long long b_bs, long long b_ls, int nlimbs, int batch) {
     if (nlimbs <= 0 || batch <= 0) return PZ_OK;
@@ -117,6 +159,7 @@ static int launch_ew(pz_module* M, int op, void* res, long long res_bs, long lon
     g.nlimbs = nlimbs; g.n = (int)M->n; g.batch = batch; g.op = op;
     const long long total = (long long)batch * nlimbs * (long long)(M->n / 2);
     const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 16);
+    KTimer kt(M, PZ_K_ELEMENTWISE);
     hipLaunchKernelGGL(k_ew, dim3(blocks), dim3(256), 0, M->stream, g);
     PZ_HIP(hipGetLastError());
     return PZ_OK;
@@ -182,7 +225,12 @@ static int dev_vmp(pz_module* M, int batch, DV res, DV a, const double* pmat, in
         return launch_ew(M, EW_ZERO, res.p, res.bs, (long long)M->n, nullptr, 0, 0, nullptr, 0, 0, res_polys, batch);
     }
     const int m = (int)M->m;
-    if (batch >= 4) {
+    KTimer kt(M, PZ_K_VMP);
+    if (batch >= 6) {
+        const int n_pb = (m + 63) / 64, n_cg = (res_polys + 15) / 16, n_ct = (batch + 7) / 8;
+        hipLaunchKernelGGL((k_vmp_lds<8, 2, PZ_VMP_RB>), dim3(n_pb * n_cg * n_ct), dim3(512), 0, M->stream, (double*)res.p, res.bs, res_polys,
+                           (const double*)a.p, a.bs, pmat, ncols, off, row_max, ncomp, m, batch, n_pb, n_cg, n_ct);
+    } else if (batch >= 4) {
         dim3 grid((m + 63) / 64, (res_polys + 15) / 16, (batch + 3) / 4);
         hipLaunchKernelGGL((k_vmp<4, 4>), grid, dim3(256), 0, M->stream, (double*)res.p, res.bs, res_polys, (const double*)a.p,
                            a.bs, pmat, ncols, off, row_max, ncomp, m, batch);
@@ -209,6 +257,7 @@ static int dev_normalize(pz_module* M, int batch, DV res, int res_base2k, long l
     const long long total = (long long)batch * (long long)M->n;
     const int blocks = (int)((total + 255) / 256);
     if (blocks == 0) return PZ_OK;
+    KTimer kt(M, PZ_K_NORMALIZE);
     if (res_base2k == a_base2k) {
         const long long k = res_base2k;
         long long lsh = res_offset % k, lo = res_offset / k;
@@ -329,6 +378,8 @@ void pz_module_free(pz_module* M) {
     for (void* p : {(void*)M->tw1, (void*)M->tw1inv, (void*)M->wL1, (void*)M->wL2, (void*)M->tw12, M->ws, (void*)M->margin})
         if (p) (void)hipFree(p);
     for (auto& c : M->arena) (void)hipFree(c.p);
+    for (auto& t : M->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
+    for (auto e : M->event_pool) (void)hipEventDestroy(e);
     if (M->stream) (void)hipStreamDestroy(M->stream);
     delete M;
 }
@@ -346,12 +397,52 @@ int pz_module_set_chunk(pz_module* M, size_t c) {
     M->chunk = c;
     return PZ_OK;
 }
+int pz_module_set_fusion(pz_module* M, int fuse_tail, int fuse_mid) {
+    if (!M) return fail(PZ_ERR_INVALID, "null module");
+    M->fuse_tail = fuse_tail != 0;
+    M->fuse_mid = fuse_mid != 0;
+    return PZ_OK;
+}
 int pz_module_set_margin_probe(pz_module* M, int enable) {
     PZ_ENTER(M);
     M->probe = enable != 0;
     PZ_HIP(hipMemsetAsync(M->margin, 0, 8, M->stream));
     PZ_HIP(hipStreamSynchronize(M->stream));
     return PZ_OK;
+}
+static int drain_timers(pz_module* M) {
+    PZ_HIP(hipStreamSynchronize(M->stream));
+    for (auto& t : M->timed) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) {
+            M->cls_ms[t.cls] += ms;
+            M->cls_count[t.cls] += 1;
+        }
+        M->event_pool.push_back(t.e0);
+        M->event_pool.push_back(t.e1);
+    }
+    M->timed.clear();
+    return PZ_OK;
+}
+int pz_module_set_kernel_timing(pz_module* M, int enable) {
+    PZ_ENTER(M);
+    PZ_TRY(drain_timers(M));
+    M->timing = enable != 0;
+    if (enable) for (int i = 0; i < PZ_KCLASS_COUNT; ++i) { M->cls_ms[i] = 0; M->cls_count[i] = 0; }
+    return PZ_OK;
+}
+int pz_module_get_kernel_stats(pz_module* M, int kclass, uint64_t* launches, double* total_ms) {
+    PZ_ENTER(M);
+    PZ_REQUIRE(kclass >= 0 && kclass < PZ_KCLASS_COUNT, "kernel class out of range");
+    PZ_TRY(drain_timers(M));
+    if (launches) *launches = M->cls_count[kclass];
+    if (total_ms) *total_ms = M->cls_ms[kclass];
+    return PZ_OK;
+}
+const char* pz_kernel_class_name(int k) {
+    static const char* names[PZ_KCLASS_COUNT] = {"fwd_pass1", "fwd_pass2", "vmp", "inv_pass2", "inv_pass1", "normalize",
+                                                 "elementwise", "fused_mid", "fused_tail"};
+    return (k >= 0 && k < PZ_KCLASS_COUNT) ? names[k] : "?";
 }
 int pz_module_get_margin(pz_module* M, double* max_frac) {
     PZ_ENTER(M);
@@ -949,10 +1040,12 @@ static OpWs op_ws(const pz_module* M, const pz_glwe_op_params* p, const OpShape&
 }
 static size_t pick_chunk(const pz_module* M, const pz_glwe_op_params* p, const OpShape& s, size_t batch) {
     if (M->chunk) return std::min(M->chunk, batch);
-    // keep (a_dft + res_dft + T) of one chunk around half of the 256 MiB Infinity Cache
+    // Measured on MI355X (profiles/r01_chunk_sweep.txt): with separate kernels the intermediates do not
+    // stay in the Infinity Cache anyway and every wave re-streams the key, so larger waves win; cap the
+    // workspace at ~4 GiB.
     const size_t per_ct = (size_t)M->n * 8 * ((size_t)s.cols_in * s.a_size_eff + 2 * (size_t)s.cols_out * p->key_size);
-    size_t c = (128u << 20) / std::max<size_t>(per_ct, 1);
-    c = std::max<size_t>(c, 4);
+    size_t c = ((size_t)4 << 30) / std::max<size_t>(per_ct, 1);
+    c = std::max<size_t>(c & ~(size_t)7, 8);
     return std::min(c, batch);
 }
 
@@ -1026,13 +1119,21 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
             }
         }
         DV rb{res_dft, rd.bs, s.cols_out, res_dft_size};
-        PZ_TRY(dev_idft(M, nb, rb, 0, rb, 0, s.cols_out, res_dft_size, T));
-        if (ks)  // body column added after the inverse transform (keyswitching/glwe.rs:237)
-            PZ_TRY(launch_ew(M, EW_ADD_I64, res_dft, rb.bs, (long long)s.cols_out * n, res_dft, rb.bs, (long long)s.cols_out * n,
-                             av.p, av.bs, (long long)av.cols * n, std::min(res_dft_size, a_size), nb));
         DV rv{(void*)(res + (long long)b0 * res_ct), res_ct, s.cols_out, (int)p->res_size};
-        for (int c = 0; c < s.cols_out; ++c)
-            PZ_TRY(dev_normalize(M, nb, rv, (int)p->res_base2k, 0, c, rb, (int)p->key_base2k, c));
+        if (p->res_base2k == p->key_base2k && M->fuse_tail && tail_supported(M)) {
+            // inverse pass 2, then the fused tail: inverse pass 1 + body add + carry chain, no VecZnxBig in HBM
+            PolyMap sm{res_dft_size, s.cols_out, rb.bs, (long long)s.cols_out * n, n, 0};
+            PZ_TRY(launch_inv_pass2(M, nb * res_dft_size * s.cols_out, res_dft, sm, T));
+            PZ_TRY(launch_inv_tail(M, nb, T, res_dft_size, s.cols_out, (long long*)rv.p, rv.bs, rv.cols, rv.size,
+                                   ks ? (const long long*)av.p : nullptr, av.bs, av.cols, a_size, (int)p->res_base2k));
+        } else {
+            PZ_TRY(dev_idft(M, nb, rb, 0, rb, 0, s.cols_out, res_dft_size, T));
+            if (ks)  // body column added after the inverse transform (keyswitching/glwe.rs:237)
+                PZ_TRY(launch_ew(M, EW_ADD_I64, res_dft, rb.bs, (long long)s.cols_out * n, res_dft, rb.bs, (long long)s.cols_out * n,
+                                 av.p, av.bs, (long long)av.cols * n, std::min(res_dft_size, a_size), nb));
+            for (int c = 0; c < s.cols_out; ++c)
+                PZ_TRY(dev_normalize(M, nb, rv, (int)p->res_base2k, 0, c, rb, (int)p->key_base2k, c));
+        }
     }
     return PZ_OK;
 }

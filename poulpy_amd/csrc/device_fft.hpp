@@ -97,14 +97,26 @@ __device__ __forceinline__ long long map_off(const PolyMap& mp, int p) {
     return (long long)b * mp.sb + (long long)j * mp.sj + (long long)i * mp.si + mp.s0;
 }
 
-// Rust `(x).round() as i64`: half away from zero, saturating, NaN -> 0
-// (reim/conversion.rs:43-60)
-__device__ __forceinline__ long long round_to_i64(double x) {
-    double r = round(x);
-    if (!(r == r)) return 0;
-    if (r >= 9223372036854775808.0) return 0x7fffffffffffffffLL;
-    if (r <= -9223372036854775808.0) return (long long)0x8000000000000000ULL;
-    return (long long)r;
+// Rust `(x).round() as i64`: half away from zero, saturating, NaN -> 0 (reim/conversion.rs:43-60).
+// Branch-free: round = trunc(x) +- 1 when the (exactly computed) fraction reaches one half.
+__device__ __forceinline__ double round_half_away(double x) {
+    const double t = trunc(x);
+    const double f = x - t;  // exact
+    return t + ((fabs(f) >= 0.5) ? copysign(1.0, x) : 0.0);
+}
+__device__ __forceinline__ long long sat_i64_from_integral(double r) {
+    // r is integral (or NaN/inf).  In-range conversion after clamping, then the saturated cases by select.
+    const double rc = fmin(fmax(r, -9223372036854775808.0), 9223372036854774784.0);
+    long long v = (long long)rc;
+    v = (r >= 9223372036854775808.0) ? 0x7fffffffffffffffLL : v;
+    v = (r != r) ? 0 : v;
+    return v;
+}
+__device__ __forceinline__ long long round_to_i64(double x) { return sat_i64_from_integral(round_half_away(x)); }
+// exact for |r| < 2^51, r integral: the integer sits in the mantissa of r + 1.5*2^52
+__device__ __forceinline__ long long fast_i64_from_integral(double r) {
+    const double magic = 6755399441055744.0;  // 1.5 * 2^52
+    return __double_as_longlong(r + magic) - __double_as_longlong(magic);
 }
 
 template <int A, int B>
@@ -311,6 +323,172 @@ k_inv_pass1(const cplx* __restrict__ T, long long* __restrict__ dst, PolyMap dma
             }
         }
         if (PROBE) atomicMax(margin, (unsigned long long)__double_as_longlong(worst));
+    }
+}
+
+// =================================================================================
+// fused tail: inverse pass 1 + (optional) vec_znx_big_add_small_assign + same-base
+// vec_znx_big_normalize (res_offset = 0), for one output column of one ciphertext.
+//
+// One workgroup owns a block of CB columns j2 of one (ciphertext, column) and walks its
+// limbs from the least significant one to limb 0, exactly like the reference's carry chain
+// (reference/vec_znx/normalize.rs:50-144 with lsh = 0): per limb it runs the inverse
+// length-m1 transform of that limb's T block, rounds to i64 (the VecZnxBig value, which is
+// never written to HBM), stages the 2*m1*CB coefficients in LDS and lets every thread
+// normalize 2*min(R1,R2) of them with the carries held in registers, storing the balanced
+// digits as full 128-byte runs.  Saves the 16 B/coefficient round trip of VecZnxBig.
+//   T      : [poly p][j2][q1], p = (b*nlimbs + limb)*ncols + col  (output of inverse pass 2)
+//   res    : VecZnx (res_cols, res_size), batch stride res_bs; column res_col0 + col
+//   small  : optional VecZnx added to column 0 before normalizing (key-switch body, glwe.rs:237)
+// grid.x = batch*ncols*(m2/CB)
+// =================================================================================
+struct TailArgs {
+    const cplx* T;
+    long long* res;
+    const long long* small;      // may be null
+    long long res_bs, small_bs;  // batch strides (scalars)
+    int nlimbs, ncols;           // limbs / columns of the VecZnxBig being consumed
+    int res_cols, res_size;      // output container
+    int small_cols, small_size;
+    int base2k, m2;
+    const cplx* tw1inv;
+    const cplx* wL1;
+    unsigned long long* margin;
+};
+
+// Workgroup = (R2 + R1)*CB threads in two wave-uniform roles (R2*CB must be a multiple of 64):
+//   B' waves (tid <  R2*CB): second butterfly stage of limb j, rounding, carry chain, stores;
+//   A' waves (tid >= R2*CB): loads + first butterfly stage of limb j-1 into the other half of the
+//                            double-buffered exchange, and the loads of limb j-2 behind that.
+// The two roles run concurrently (one barrier per limb), so the HBM latency of the next limbs hides
+// behind the arithmetic of the current one, and each role only pays for its own registers.
+template <int R1, int R2, int CB, bool PROBE>
+__global__ void __launch_bounds__((R1 + R2) * CB, 3)
+k_inv_tail(TailArgs g) {
+    constexpr int M1 = R1 * R2;
+    constexpr int XCH = (R1 + 1) * CB * R2;  // cplx per exchange buffer
+    extern __shared__ cplx xch[];            // 2 * XCH
+    const int tid = threadIdx.x;
+    const int ncb = g.m2 / CB;
+    const int c0 = (blockIdx.x % ncb) * CB;
+    const int bc = blockIdx.x / ncb;
+    const int col = bc % g.ncols;
+    const int b = bc / g.ncols;
+    const long long m = (long long)M1 * g.m2;
+    const long long n = 2 * m;
+    const int L = g.nlimbs;
+
+    if (tid >= R2 * CB) {
+        // ------------------------------ role A' ------------------------------
+        const int ta = tid - R2 * CB;
+        const int k1 = ta % R1, c = ta / R1;
+        const cplx* Tb = g.T + ((long long)b * L * g.ncols + col) * m + (long long)(c0 + c) * M1 + k1;
+        const long long limb_stride = (long long)g.ncols * m;
+        cplx u[R2];
+        if (L > 0) {
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) u[k2] = Tb[(long long)(L - 1) * limb_stride + R1 * k2];
+        }
+        // iteration t produces limb L-1-t into buffer (L-1-t)&1; t = 0 is the prologue
+        for (int t = 0; t <= L; ++t) {
+            const int j = L - 1 - t;  // limb produced in this iteration (none when j < 0)
+            if (j >= 0) {
+                Bfly<R2, true>::run(u);
+                cplx* buf = xch + (j & 1) * XCH;
+#pragma unroll
+                for (int o = 0; o < R2; ++o) {
+                    cplx x = u[o];
+                    if (R2 > 1 && k1 > 0 && o > 0) x = cmulc(x, g.wL1[o * k1]);
+                    buf[(o * CB + c) * (R1 + 1) + k1] = x;
+                }
+                if (j > 0) {
+#pragma unroll
+                    for (int k2 = 0; k2 < R2; ++k2) u[k2] = Tb[(long long)(j - 1) * limb_stride + R1 * k2];
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // ------------------------------ role B' ------------------------------
+    const int k = g.base2k;
+    const int b_o = tid / CB, b_c = tid % CB;
+    long long carry[2 * R1];
+#pragma unroll
+    for (int u = 0; u < 2 * R1; ++u) carry[u] = 0;
+    long long* res_col = g.res + (long long)b * g.res_bs + (long long)col * n;
+    const long long res_ls = (long long)g.res_cols * n;
+    const long long* small_col = (g.small && col == 0) ? g.small + (long long)b * g.small_bs : nullptr;
+    const long long small_ls = (long long)g.small_cols * n;
+    // limbs of res beyond the precision of the big value are zero (normalize.rs:118-120)
+    for (int j = L; j < g.res_size; ++j)
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) {
+            const long long idx = (long long)(b_o + R2 * n1) * g.m2 + c0 + b_c;
+            res_col[(long long)j * res_ls + idx] = 0;
+            res_col[(long long)j * res_ls + idx + m] = 0;
+        }
+    __syncthreads();  // matches the prologue iteration of role A'
+    for (int j = L - 1; j >= 0; --j) {
+        const cplx* buf = xch + (j & 1) * XCH;
+        cplx v[R1];
+#pragma unroll
+        for (int k1 = 0; k1 < R1; ++k1) v[k1] = buf[(b_o * CB + b_c) * (R1 + 1) + k1];
+        Bfly<R1, true>::run(v);
+        const bool writes = j < g.res_size;
+        const bool first = j == L - 1;
+        const bool add_small = small_col && j < g.small_size;
+        double worst = 0.0;
+        // round first (branch-free), remember whether any value leaves the fast-conversion range
+        double rr[2 * R1];
+        double big = 0.0;
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) {
+            const cplx w = cmul(v[n1], g.tw1inv[b_o + R2 * n1]);
+            rr[2 * n1] = round_half_away(w.x);
+            rr[2 * n1 + 1] = round_half_away(w.y);
+            big = fmax(big, fmax(fabs(rr[2 * n1]), fabs(rr[2 * n1 + 1])));
+            if (PROBE) {
+                worst = fmax(worst, fabs(w.x - rr[2 * n1]));
+                worst = fmax(worst, fabs(w.y - rr[2 * n1 + 1]));
+            }
+        }
+        long long xi[2 * R1];
+        if (big < 2251799813685248.0) {  // 2^51 (false for NaN too): 3-instruction conversion
+#pragma unroll
+            for (int t = 0; t < 2 * R1; ++t) xi[t] = fast_i64_from_integral(rr[t]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2 * R1; ++t) xi[t] = sat_i64_from_integral(rr[t]);
+        }
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) {
+            const int j1 = b_o + R2 * n1;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const long long idx = (long long)j1 * g.m2 + c0 + b_c + (h ? m : 0);
+                long long x = xi[2 * n1 + h];
+                if (add_small) x = (long long)((unsigned long long)x + (unsigned long long)small_col[(long long)j * small_ls + idx]);
+                // znx_normalize_{first,middle}_step(_carry_only), reference/znx/normalization.rs:24-41,107-129,179-221,
+                // with digit(x) = ((x + 2^(k-1)) mod 2^k) - 2^(k-1) and carry(x) = (x + 2^(k-1)) >> k (same values as the
+                // reference's shift pairs, fewer 64-bit operations)
+                long long& cy = carry[2 * n1 + h];
+                const unsigned long long half = 1ull << (k - 1), mask = (1ull << k) - 1;
+                const unsigned long long y = (unsigned long long)x + half;
+                const long long d = (long long)(y & mask) - (long long)half;
+                const long long cr = (long long)y >> k;
+                if (first && !writes) {
+                    cy = cr;
+                } else {
+                    const unsigned long long y2 = (unsigned long long)d + (unsigned long long)cy + half;
+                    const long long x1 = (long long)(y2 & mask) - (long long)half;
+                    cy = (long long)((unsigned long long)cr + (unsigned long long)((long long)y2 >> k));
+                    if (writes) res_col[(long long)j * res_ls + idx] = x1;
+                }
+            }
+        }
+        if (PROBE) atomicMax(g.margin, (unsigned long long)__double_as_longlong(worst));
+        __syncthreads();
     }
 }
 

@@ -83,6 +83,134 @@ k_vmp(double* __restrict__ res, long long res_bs, int res_polys,
     }
 }
 
+// Batched variant for CT >= 8 ciphertexts that share the key: the `a` values of the current
+// input row are staged once per workgroup in LDS (double-buffered, prefetched one row ahead)
+// and shared by the four waves, each of which owns 4 output columns; P streams straight from
+// L2/HBM into registers, one row ahead.  Per row and workgroup: 8 KiB of `a` + 16 KiB of P
+// feed 8*64*16 complex MACs, so neither the L1 nor the LDS pipe limits the FP64 issue rate.
+template <int CT, int CC, int RB>
+__global__ void __launch_bounds__(64 * (16 / CC))
+k_vmp_lds(double* __restrict__ res, long long res_bs, int res_polys,
+          const double* __restrict__ a, long long a_bs,
+          const double* __restrict__ pmat, int ncols, int off, int row_max, int ncomp,
+          int m, int batch, int n_pb, int n_cg, int n_ct) {
+    constexpr int NW = 16 / CC;          // waves per workgroup; the workgroup covers 16 output columns
+    constexpr int NLD = (CT + NW - 1) / NW;  // staging loads per thread and row
+    __shared__ cplx a_s[2][RB][NLD * NW][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    // XCD-aware decode of the 1-D grid (n_pb point blocks x n_cg column groups x n_ct ciphertext tiles):
+    // workgroups are dealt round-robin over the 8 XCDs, so bid % 8 labels the XCD.  Every ciphertext tile
+    // of one point block is given to the same XCD, back to back, so that the 256 KiB slice of P they share
+    // is fetched from HBM once and then served by that XCD's L2 (speed only; any placement is correct).
+    int pb, cg, ct;
+    {
+        const int bid = blockIdx.x;
+        if ((n_pb & 7) == 0) {
+            const int xcd = bid & 7, local = bid >> 3;
+            ct = local % n_ct;
+            const int t = local / n_ct;
+            cg = t % n_cg;
+            pb = (t / n_cg) * 8 + xcd;
+        } else {
+            ct = bid % n_ct;
+            const int t = bid / n_ct;
+            cg = t % n_cg;
+            pb = t / n_cg;
+        }
+    }
+    const int q = min(pb * 64 + lane, m - 1);
+    const bool q_ok = pb * 64 + lane < m;
+    const int c0 = (cg * NW + wave) * CC;
+    const int b0 = ct * CT;
+
+    cplx acc[CT][CC];
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int j = 0; j < CC; ++j) acc[i][j] = make_double2(0.0, 0.0);
+
+    // cooperative staging: wave w fetches ciphertexts w + NW*i at point `lane`
+    const cplx* ap[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int b = min(b0 + wave + NW * i, batch - 1);
+        ap[i] = reinterpret_cast<const cplx*>(a + (long long)b * a_bs) + q;
+    }
+    const cplx* pp[CC];
+#pragma unroll
+    for (int j = 0; j < CC; ++j) {
+        const int c = min(c0 + j, ncomp - 1);
+        pp[j] = reinterpret_cast<const cplx*>(pmat) + (long long)(c + off) * m + q;
+    }
+    const long long prow = (long long)ncols * m;
+
+    // rows are processed in blocks of RB; the loads of block k+1 are in flight while block k is computed
+    // (RB*CT*CC*4 FMAs per wave ~ 1000+ cycles of cover for an HBM miss)
+    cplx pn[RB * CC], pv[RB * CC];
+    // `a` rows go HBM -> LDS directly (global_load_lds, 16 B per lane, lane-linear destination);
+    // P rows go to registers.  Both are issued one block of RB rows ahead.
+#define PZ_LDS_DMA(GPTR, LPTR)                                                                             \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(GPTR),                \
+                                     (__attribute__((address_space(3))) void*)(LPTR), 16, 0, 0)
+#pragma unroll
+    for (int k = 0; k < RB; ++k) {
+        const int r = min(k, row_max - 1);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) PZ_LDS_DMA(ap[i] + (long long)r * m, &a_s[0][k][wave + NW * i][0]);
+#pragma unroll
+        for (int j = 0; j < CC; ++j) pn[k * CC + j] = pp[j][(long long)r * prow];
+    }
+    __syncthreads();
+    for (int r0 = 0; r0 < row_max; r0 += RB) {
+        const int half = (r0 / RB) & 1;
+#pragma unroll
+        for (int t = 0; t < RB * CC; ++t) pv[t] = pn[t];
+        if (r0 + RB < row_max) {
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                const int r = min(r0 + RB + k, row_max - 1);
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) PZ_LDS_DMA(ap[i] + (long long)r * m, &a_s[half ^ 1][k][wave + NW * i][0]);
+#pragma unroll
+                for (int j = 0; j < CC; ++j) pn[k * CC + j] = pp[j][(long long)r * prow];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+            if (r0 + k < row_max) {
+#pragma unroll
+                for (int i = 0; i < CT; ++i) {
+                    const cplx av = a_s[half][k][i][lane];
+#pragma unroll
+                    for (int j = 0; j < CC; ++j) {
+                        const cplx p_ = pv[k * CC + j];
+                        acc[i][j].x = __builtin_fma(av.x, p_.x, acc[i][j].x);
+                        acc[i][j].x = __builtin_fma(-av.y, p_.y, acc[i][j].x);
+                        acc[i][j].y = __builtin_fma(av.x, p_.y, acc[i][j].y);
+                        acc[i][j].y = __builtin_fma(av.y, p_.x, acc[i][j].y);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#undef PZ_LDS_DMA
+    if (!q_ok || c0 >= res_polys) return;
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+        const int b = b0 + i;
+        if (b >= batch) continue;
+        cplx* rp = reinterpret_cast<cplx*>(res + (long long)b * res_bs) + q;
+#pragma unroll
+        for (int j = 0; j < CC; ++j) {
+            const int c = c0 + j;
+            if (c >= res_polys) continue;
+            rp[(long long)c * m] = (c < ncomp) ? acc[i][j] : make_double2(0.0, 0.0);
+        }
+    }
+}
+
 // =================================================================================
 // limb-wise elementwise ops on whole polynomials (f64 spectra or i64 limbs)
 // =================================================================================

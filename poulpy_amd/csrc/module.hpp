@@ -51,7 +51,9 @@ inline int fail(int code, const char* fmt, ...) {
 
 struct FftPlan {
     int m1, m2;        // m = m1*m2, m2 >= m1
-    int r1a, r1b;      // radices of the length-m1 pass
+    int r1a, r1b;      // radices of the length-m1 pass (inverse direction / tail)
+    int f1a, f1b;      // radices of the FORWARD length-m1 pass: smaller radix first, so that every thread of the
+                       // workgroup issues global loads in the load stage
     int r2a, r2b;      // radices of the length-m2 pass
     int cb, qb;        // column block of pass 1 / q1 block of pass 2
 };
@@ -79,6 +81,9 @@ inline bool make_plan(uint64_t n, FftPlan& pl) {
     pl.m2 = 1 << (k - k1);
     if (!radices_for(pl.m1, pl.r1a, pl.r1b)) return false;
     if (!radices_for(pl.m2, pl.r2a, pl.r2b)) return false;
+    pl.f1a = pl.r1a; pl.f1b = pl.r1b;
+    if (pl.m1 == 32) { pl.f1a = 4; pl.f1b = 8; }
+    if (pl.m1 == 128) { pl.f1a = 8; pl.f1b = 16; }
     pl.cb = pl.m2 >= 16 ? 16 : 4;
     pl.qb = pl.m1 >= 16 ? 16 : 4;
     return true;
@@ -107,9 +112,41 @@ struct pz_module {
     unsigned long long* margin = nullptr;  // device word, bits of max |x-round(x)|
     bool probe = false;
     size_t chunk = 0;
+    bool fuse_tail = true, fuse_mid = true;  // kernel-fusion knobs of the batched GLWE ops (tests run both settings)
+    // per-kernel-class HIP-event timing (bench.py's roofline leg); off by default
+    bool timing = false;
+    struct Timed { int cls; hipEvent_t e0, e1; };
+    std::vector<Timed> timed;
+    std::vector<hipEvent_t> event_pool;
+    double cls_ms[PZ_KCLASS_COUNT] = {0};
+    unsigned long long cls_count[PZ_KCLASS_COUNT] = {0};
 };
 
 namespace pz {
+
+// RAII bracket: records an event pair around one kernel launch when timing is on
+struct KTimer {
+    pz_module* M;
+    int cls;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    static hipEvent_t get(pz_module* M) {
+        if (!M->event_pool.empty()) { hipEvent_t e = M->event_pool.back(); M->event_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+    KTimer(pz_module* M_, int cls_) : M(M_), cls(cls_) {
+        if (!M->timing || M->timed.size() >= (1u << 16)) return;
+        e0 = get(M); e1 = get(M);
+        if (e0 && e1) (void)hipEventRecord(e0, M->stream);
+    }
+    ~KTimer() {
+        if (e0 && e1) {
+            (void)hipEventRecord(e1, M->stream);
+            M->timed.push_back({cls, e0, e1});
+        }
+    }
+};
 
 inline int ws_reserve(pz_module* M, size_t bytes) {
     if (bytes <= M->ws_bytes) return PZ_OK;

@@ -41,7 +41,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("POULPY_HIP_LIB") or LIB_PATH
     if not os.path.exists(p):
         raise PoulpyHipError(
             f"{p} not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; g.build()'`). "
@@ -152,6 +152,9 @@ class Module:
     def set_chunk(self, cts: int):
         self._ck(self.lib.pz_module_set_chunk(self.handle, c_size_t(cts)))
 
+    def set_fusion(self, fuse_tail: bool = True, fuse_mid: bool = True):
+        self._ck(self.lib.pz_module_set_fusion(self.handle, c_int(int(fuse_tail)), c_int(int(fuse_mid))))
+
     def set_margin_probe(self, enable: bool):
         self._ck(self.lib.pz_module_set_margin_probe(self.handle, c_int(1 if enable else 0)))
 
@@ -159,6 +162,21 @@ class Module:
         out = c_double()
         self._ck(self.lib.pz_module_get_margin(self.handle, C.byref(out)))
         return out.value
+
+    KERNEL_CLASSES = ("fwd_pass1", "fwd_pass2", "vmp", "inv_pass2", "inv_pass1", "normalize", "elementwise", "fused_mid",
+                      "fused_tail")
+
+    def set_kernel_timing(self, enable: bool):
+        self._ck(self.lib.pz_module_set_kernel_timing(self.handle, c_int(1 if enable else 0)))
+
+    def kernel_stats(self) -> dict:
+        """{class name: (launches, total_ms)} measured with HIP events on the module stream."""
+        out = {}
+        for k, name in enumerate(self.KERNEL_CLASSES):
+            cnt, ms = c_uint64(), c_double()
+            self._ck(self.lib.pz_module_get_kernel_stats(self.handle, c_int(k), C.byref(cnt), C.byref(ms)))
+            out[name] = (cnt.value, ms.value)
+        return out
 
     # -- allocation (api/*Alloc traits) -----------------------------------------
     def vec_znx_dft_alloc(self, cols, size) -> VecZnxDft:

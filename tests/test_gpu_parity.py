@@ -235,3 +235,118 @@ def test_big_add_small_assign(mods):
             ref.vec_znx_big_add_small_assign(rr, 1, a, 0)
             hip.vec_znx_big_add_small_assign(rh, 1, a, 0)
             assert np.array_equal(rr.data, rh.data)
+
+
+# ------------------------------------------------------------------------------------------
+# batched, device-resident GLWE operations (CoreImpl-level boundary)
+# ------------------------------------------------------------------------------------------
+def _run_glwe_op(hip, ref, ks, n, rank, rank_out, a_size, a_base2k, key_size, key_base2k, dnum, dsize, res_size, res_base2k, batch,
+                 seed, chunk=0, fuse=(True, True)):
+    from poulpy_amd.hal import GlweOpParams
+    rng = seeded(seed)
+    cols_a = rank + 1
+    cols_in = rank if ks else rank + 1
+    cols_out = (rank_out if ks else rank) + 1
+    mat = MatZnx(n, dnum, cols_in, cols_out, key_size).fill_uniform(key_base2k, rng)
+    pr, ph = ref.vmp_pmat_alloc(dnum, cols_in, cols_out, key_size), hip.vmp_pmat_alloc(dnum, cols_in, cols_out, key_size)
+    ref.vmp_prepare(pr, mat)
+    hip.vmp_prepare(ph, mat)
+    a_all = np.empty((batch, a_size, cols_a, n), dtype=np.int64)
+    want = np.empty((batch, res_size, cols_out, n), dtype=np.int64)
+    for b in range(batch):
+        a = VecZnx(n, cols_a, a_size).fill_uniform(a_base2k, rng)
+        a_all[b] = a.data
+        res = VecZnx(n, cols_out, res_size)
+        if ks:
+            ref.glwe_keyswitch(res, res_base2k, a, a_base2k, pr, dsize, key_base2k)
+        else:
+            ref.glwe_external_product(res, res_base2k, a, a_base2k, pr, dsize, key_base2k)
+        want[b] = res.data
+    d_a = hip.device_alloc(a_all.nbytes).upload(a_all)
+    d_key = hip.device_alloc(ph.data.nbytes).upload(ph.data)
+    d_res = hip.device_alloc(want.nbytes)
+    hip.lib.pz_memset_d(hip.handle, d_res.ptr, 0x5A, want.nbytes)
+    p = GlweOpParams(rank=rank, dnum=dnum, dsize=dsize, key_size=key_size, key_base2k=key_base2k, a_size=a_size, a_base2k=a_base2k,
+                     res_size=res_size, res_base2k=res_base2k, rank_out=rank_out)
+    hip.set_chunk(chunk)
+    hip.set_fusion(*fuse)
+    if ks:
+        hip.glwe_keyswitch_batched(d_res.ptr, d_a.ptr, d_key.ptr, p, batch)
+    else:
+        hip.glwe_external_product_batched(d_res.ptr, d_a.ptr, d_key.ptr, p, batch)
+    hip.sync()
+    got = d_res.download(np.int64, want.size).reshape(want.shape)
+    hip.set_chunk(0)
+    hip.set_fusion(True, True)
+    for buf in (d_a, d_key, d_res):
+        buf.free()
+    return got, want
+
+
+@pytest.mark.parametrize("fuse", [(True, True), (False, False)], ids=["fused", "unfused"])
+@pytest.mark.parametrize("rank", [1, 2])
+@pytest.mark.parametrize("dsize", [1, 2, 3])
+def test_glwe_external_product_batched(mods, rank, dsize, fuse):
+    """poulpy-core/src/test_suite/external_product/glwe_ct.rs sweeps rank in {1,2}, dsize 1..max and
+    different base2k for input / key / output; here against the oracle's restatement, bit-exact."""
+    n = 256
+    ref, hip = mods(n)
+    for (a_b, k_b, r_b) in ((12, 12, 12), (17, 14, 15)):
+        dnum = 5 if dsize == 1 else 2
+        got, want = _run_glwe_op(hip, ref, False, n, rank, rank, 5, a_b, 6, k_b, dnum, dsize, 4, r_b, batch=7,
+                                 seed=100 * rank + dsize + a_b, chunk=3, fuse=fuse)
+        assert np.array_equal(got, want), (rank, dsize, a_b, k_b, r_b)
+
+
+@pytest.mark.parametrize("fuse", [(True, True), (False, False)], ids=["fused", "unfused"])
+@pytest.mark.parametrize("dsize", [1, 2])
+def test_glwe_keyswitch_batched(mods, dsize, fuse):
+    n = 256
+    ref, hip = mods(n)
+    for (rank_in, rank_out) in ((1, 1), (2, 1), (1, 2)):
+        for (a_b, k_b, r_b) in ((12, 12, 12), (16, 13, 15)):
+            got, want = _run_glwe_op(hip, ref, True, n, rank_in, rank_out, 4, a_b, 5, k_b, 3 if dsize == 1 else 2, dsize, 4, r_b,
+                                     batch=5, seed=7 + rank_in * 10 + rank_out + dsize, chunk=2, fuse=fuse)
+            assert np.array_equal(got, want), (rank_in, rank_out, dsize, a_b, k_b, r_b)
+
+
+def test_config2_external_product_n4096(mods):
+    """BASELINE configs[1]: GGSW external product, N=2^12, 4 limbs, base2k=17 (batch reduced to what the
+    CPU oracle checks in seconds; the batch dimension is embarrassingly parallel)."""
+    n = 4096
+    ref, hip = mods(n)
+    got, want = _run_glwe_op(hip, ref, False, n, 1, 1, 4, 17, 4, 17, 4, 1, 4, 17, batch=16, seed=4096)
+    assert np.array_equal(got, want)
+
+
+def test_metric_config_external_product_n65536(mods):
+    """The metric configuration (N=2^16, 8 limbs, rank 1, base2k=12, dnum=8) on a few ciphertexts, with
+    the exactness margin of the inverse transform reported (SURVEY.md §7 'exactness margin')."""
+    n = 65536
+    ref, hip = mods(n)
+    hip.set_margin_probe(True)
+    got, want = _run_glwe_op(hip, ref, False, n, 1, 1, 8, 12, 8, 12, 8, 1, 8, 12, batch=3, seed=65536)
+    margin = hip.get_margin()
+    hip.set_margin_probe(False)
+    assert np.array_equal(got, want)
+    assert margin < 0.05, f"rounding margin too thin: max |x-round(x)| = {margin}"
+
+
+def test_config3_keyswitch_n65536(mods):
+    """BASELINE configs[2]: GLWE key-switch via VmpPMat, N=2^16, 8 limbs (GGLWE rows=8, cols_in=1, cols_out=2)."""
+    n = 65536
+    ref, hip = mods(n)
+    got, want = _run_glwe_op(hip, ref, True, n, 1, 1, 8, 12, 8, 12, 8, 1, 8, 12, batch=2, seed=3)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n", [32, 64, 512, 2048, 16384])
+def test_fused_tail_shapes(mods, n):
+    """Fused inverse-pass-1 + normalize against the oracle for every plan family and for output sizes smaller /
+    larger than the key size (carry-only limbs, zero-filled limbs)."""
+    ref, hip = mods(n)
+    for res_size in (2, 4, 6):
+        got, want = _run_glwe_op(hip, ref, False, n, 1, 1, 3, 14, 4, 14, 3, 1, res_size, 14, batch=9, seed=n + res_size)
+        assert np.array_equal(got, want), (n, res_size)
+        got, want = _run_glwe_op(hip, ref, True, n, 2, 1, 3, 14, 4, 14, 3, 1, res_size, 14, batch=3, seed=n + res_size + 1)
+        assert np.array_equal(got, want), (n, res_size)

@@ -108,21 +108,25 @@ def test_P3_normalize_same_base_exact(base2k):
             assert np.all(res.data[:, 0, :] == -1)  # other column untouched
 
 
-def test_P3_normalize_cross_base_value_preserved():
-    """All (a_base2k, res_base2k) pairs on a coarse grid x offsets: torus value preserved."""
-    n = 16
+@pytest.mark.parametrize("prec", [128])
+def test_P3_normalize_cross_base_value_preserved(prec):
+    """Mirror of test_vec_znx_normalize_cross_base2k (reference/vec_znx/normalize.rs:428-540): all
+    in/out base2k pairs, the reference's 13 offsets, 60-bit un-normalized inputs, output sized so that
+    no precision is lost; the torus value must be preserved to 2^(-min_prec+1)."""
+    n = 8
     R = RefModule(n)
-    rng = seeded(77)
-    bases = [1, 2, 3, 7, 12, 13, 17, 19, 26, 31, 40, 51]
+    rng = seeded(prec)
+    bases = range(1, 52)
     for ak in bases:
         for rk in bases:
-            for a_size, res_size in ((3, 3), (2, 5), (5, 2), (1, 4)):
-                a = VecZnx(n, 1, a_size).fill_uniform(ak, rng)  # normalized input, like the reference test
-                for off in (0, 1, -1, ak // 2, -(ak // 2), ak, -ak, 2 * ak + 1):
-                    res = VecZnx(n, 1, res_size)
-                    res.data[...] = 99
-                    R.vec_znx_big_normalize(res, rk, off, 0, a, ak, 0)
-                    assert exact.torus_equal(a.data[:, 0, :], ak, res.data[:, 0, :], rk, off), (ak, rk, a_size, res_size, off)
+            in_size = -(-prec // ak)
+            in_prec = in_size * ak
+            out_size = -(-in_prec // rk)
+            a = VecZnx(n, 1, in_size).fill_uniform(60, rng)
+            for off in (-prec, -(prec - 1), -(prec - ak), -(ak + 1), ak, -(ak - 1), 0, ak - 1, ak, ak + 1, prec - ak, prec - 1, prec):
+                res = VecZnx(n, 1, out_size).fill_uniform(60, rng)
+                R.vec_znx_big_normalize(res, rk, off, 0, a, ak, 0)
+                assert exact.torus_equal(a.data[:, 0, :], ak, res.data[:, 0, :], rk, off), (ak, rk, off)
 
 
 def test_dft_apply_step_offset_semantics():

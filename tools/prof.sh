@@ -1,0 +1,31 @@
+#!/bin/bash
+# rocprofv3 recipe for the bench (run on the GPU box through gpurun); outputs under gpurun_out/prof
+set -x
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py $ARGS > $OUT/pmc_write.log 2>&1
+cd $OUT && find . -name "*.csv" | head -30
+# keep only small summaries: stats + aggregated counters
+python3 - <<'PY'
+import csv, glob, collections, os
+for kind in ("pmc_fetch", "pmc_write"):
+    files = glob.glob(f"{kind}/**/*counter_collection.csv", recursive=True)
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            k = (row.get("Kernel_Name", "?")[:80], row.get("Counter_Name"))
+            agg[k][0] += 1
+            agg[k][1] += float(row.get("Counter_Value", 0))
+    with open(f"{kind}_summary.txt", "w") as o:
+        for (k, c), (n, v) in sorted(agg.items()):
+            o.write(f"{k}\t{c}\tdispatches={n}\tsum={v:.1f}\tper_dispatch={v/max(n,1):.1f}\n")
+    for f in files:
+        os.remove(f)
+PY
+find . -name "*kernel_trace.csv" -size +2M -delete
+ls -la $OUT $OUT/*
