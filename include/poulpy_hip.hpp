@@ -1,0 +1,137 @@
+// poulpy_hip.hpp — header-only C++ mirror of the reference's operator interface for the FFT64 hot
+// path, on top of the C ABI (poulpy_hip.h).  Same method names, argument order and error behaviour
+// as poulpy-hal's api traits (poulpy-hal/src/api/{vec_znx_dft,svp_ppol,vmp_pmat,vec_znx_big}.rs):
+// shape violations and runtime failures throw pz::Error where the reference panics.
+// Containers are non-owning views with the reference's layout (znx_base.rs:52-82).
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "poulpy_hip.h"
+
+namespace pz {
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int st, const std::string& what) : std::runtime_error(what), status(st) {}
+};
+inline void check(int st, const char* what) {
+    if (st != 0) throw Error(st, std::string(what) + ": " + pz_last_error());
+}
+
+template <typename T>
+struct Znx {  // VecZnx (T = int64_t), VecZnxBig (int64_t), VecZnxDft (double)
+    T* data;
+    size_t n, cols, size;
+    T* at(size_t col, size_t limb) const { return data + n * (limb * cols + col); }
+};
+using VecZnx = Znx<int64_t>;
+using VecZnxBig = Znx<int64_t>;
+using VecZnxDft = Znx<double>;
+struct ScalarZnx { int64_t* data; size_t n, cols; };
+struct SvpPPol { double* data; size_t n, cols; };
+struct MatZnx { int64_t* data; size_t n, rows, cols_in, cols_out, size; };
+struct VmpPMat { double* data; size_t n, rows, cols_in, cols_out, size; };
+
+class Module {  // Module<FFT64Hip>, poulpy-hal/src/layouts/module.rs:97-189
+  public:
+    explicit Module(uint64_t n) { check(pz_module_new(n, &m_), "Module::new"); }
+    Module(uint64_t n, int device) { check(pz_module_new_on_device(n, device, &m_), "Module::new"); }
+    ~Module() { pz_module_free(m_); }
+    Module(const Module&) = delete;
+    Module& operator=(const Module&) = delete;
+    uint64_t n() const { return pz_module_n(m_); }
+    pz_module* raw() const { return m_; }
+    void sync() { check(pz_module_sync(m_), "sync"); }
+
+    // VecZnxDft
+    void vec_znx_dft_apply(size_t step, size_t offset, VecZnxDft& res, size_t res_col, const VecZnx& a, size_t a_col) {
+        check(pz_vec_znx_dft_apply(m_, step, offset, res.data, res.cols, res.size, res_col, a.data, a.cols, a.size, a_col), "vec_znx_dft_apply");
+    }
+    size_t vec_znx_idft_apply_tmp_bytes() const { return pz_vec_znx_idft_apply_tmp_bytes(m_); }
+    void vec_znx_idft_apply(VecZnxBig& res, size_t res_col, const VecZnxDft& a, size_t a_col) {
+        check(pz_vec_znx_idft_apply(m_, res.data, res.cols, res.size, res_col, a.data, a.cols, a.size, a_col), "vec_znx_idft_apply");
+    }
+    void vec_znx_idft_apply_tmpa(VecZnxBig& res, size_t res_col, VecZnxDft& a, size_t a_col) {
+        check(pz_vec_znx_idft_apply_tmpa(m_, res.data, res.cols, res.size, res_col, a.data, a.cols, a.size, a_col), "vec_znx_idft_apply_tmpa");
+    }
+    VecZnxBig vec_znx_idft_apply_consume(VecZnxDft a) {
+        check(pz_vec_znx_idft_apply_consume(m_, a.data, a.cols, a.size), "vec_znx_idft_apply_consume");
+        return VecZnxBig{reinterpret_cast<int64_t*>(a.data), a.n, a.cols, a.size};
+    }
+    void vec_znx_dft_add_into(VecZnxDft& r, size_t rc, const VecZnxDft& a, size_t ac, const VecZnxDft& b, size_t bc) {
+        check(pz_vec_znx_dft_add_into(m_, r.data, r.cols, r.size, rc, a.data, a.cols, a.size, ac, b.data, b.cols, b.size, bc), "vec_znx_dft_add_into");
+    }
+    void vec_znx_dft_sub(VecZnxDft& r, size_t rc, const VecZnxDft& a, size_t ac, const VecZnxDft& b, size_t bc) {
+        check(pz_vec_znx_dft_sub(m_, r.data, r.cols, r.size, rc, a.data, a.cols, a.size, ac, b.data, b.cols, b.size, bc), "vec_znx_dft_sub");
+    }
+    void vec_znx_dft_add_assign(VecZnxDft& r, size_t rc, const VecZnxDft& a, size_t ac) {
+        check(pz_vec_znx_dft_add_assign(m_, r.data, r.cols, r.size, rc, a.data, a.cols, a.size, ac), "vec_znx_dft_add_assign");
+    }
+    void vec_znx_dft_add_scaled_assign(VecZnxDft& r, size_t rc, const VecZnxDft& a, size_t ac, int64_t a_scale) {
+        check(pz_vec_znx_dft_add_scaled_assign(m_, r.data, r.cols, r.size, rc, a.data, a.cols, a.size, ac, a_scale), "vec_znx_dft_add_scaled_assign");
+    }
+    void vec_znx_dft_sub_assign(VecZnxDft& r, size_t rc, const VecZnxDft& a, size_t ac) {
+        check(pz_vec_znx_dft_sub_assign(m_, r.data, r.cols, r.size, rc, a.data, a.cols, a.size, ac), "vec_znx_dft_sub_assign");
+    }
+    void vec_znx_dft_sub_negate_assign(VecZnxDft& r, size_t rc, const VecZnxDft& a, size_t ac) {
+        check(pz_vec_znx_dft_sub_negate_assign(m_, r.data, r.cols, r.size, rc, a.data, a.cols, a.size, ac), "vec_znx_dft_sub_negate_assign");
+    }
+    void vec_znx_dft_copy(size_t step, size_t offset, VecZnxDft& r, size_t rc, const VecZnxDft& a, size_t ac) {
+        check(pz_vec_znx_dft_copy(m_, step, offset, r.data, r.cols, r.size, rc, a.data, a.cols, a.size, ac), "vec_znx_dft_copy");
+    }
+    void vec_znx_dft_zero(VecZnxDft& r, size_t rc) { check(pz_vec_znx_dft_zero(m_, r.data, r.cols, r.size, rc), "vec_znx_dft_zero"); }
+
+    // SVP
+    void svp_prepare(SvpPPol& res, size_t res_col, const ScalarZnx& a, size_t a_col) {
+        check(pz_svp_prepare(m_, res.data, res.cols, res_col, a.data, a.cols, a_col), "svp_prepare");
+    }
+    void svp_apply_dft(VecZnxDft& res, size_t res_col, const SvpPPol& a, size_t a_col, const VecZnx& b, size_t b_col) {
+        check(pz_svp_apply_dft(m_, res.data, res.cols, res.size, res_col, a.data, a.cols, a_col, b.data, b.cols, b.size, b_col), "svp_apply_dft");
+    }
+    void svp_apply_dft_to_dft(VecZnxDft& res, size_t res_col, const SvpPPol& a, size_t a_col, const VecZnxDft& b, size_t b_col) {
+        check(pz_svp_apply_dft_to_dft(m_, res.data, res.cols, res.size, res_col, a.data, a.cols, a_col, b.data, b.cols, b.size, b_col), "svp_apply_dft_to_dft");
+    }
+    void svp_apply_dft_to_dft_assign(VecZnxDft& res, size_t res_col, const SvpPPol& a, size_t a_col) {
+        check(pz_svp_apply_dft_to_dft_assign(m_, res.data, res.cols, res.size, res_col, a.data, a.cols, a_col), "svp_apply_dft_to_dft_assign");
+    }
+
+    // VMP
+    size_t vmp_prepare_tmp_bytes(size_t rows, size_t ci, size_t co, size_t size) const { return pz_vmp_prepare_tmp_bytes(m_, rows, ci, co, size); }
+    void vmp_prepare(VmpPMat& res, const MatZnx& a) {
+        if (res.rows != a.rows || res.cols_in != a.cols_in || res.cols_out != a.cols_out || res.size != a.size)
+            throw Error(PZ_ERR_INVALID, "vmp_prepare: shape mismatch");
+        check(pz_vmp_prepare(m_, res.data, a.data, a.rows, a.cols_in, a.cols_out, a.size), "vmp_prepare");
+    }
+    void vmp_apply_dft(VecZnxDft& res, const VecZnx& a, const VmpPMat& b) {
+        check(pz_vmp_apply_dft(m_, res.data, res.cols, res.size, a.data, a.cols, a.size, b.data, b.rows, b.cols_in, b.cols_out, b.size), "vmp_apply_dft");
+    }
+    void vmp_apply_dft_to_dft(VecZnxDft& res, const VecZnxDft& a, const VmpPMat& b, size_t limb_offset) {
+        check(pz_vmp_apply_dft_to_dft(m_, res.data, res.cols, res.size, a.data, a.cols, a.size, b.data, b.rows, b.cols_in, b.cols_out, b.size, limb_offset), "vmp_apply_dft_to_dft");
+    }
+    void vmp_zero(VmpPMat& r) { check(pz_vmp_zero(m_, r.data, r.rows, r.cols_in, r.cols_out, r.size), "vmp_zero"); }
+
+    // VecZnxBig
+    size_t vec_znx_big_normalize_tmp_bytes() const { return pz_vec_znx_big_normalize_tmp_bytes(m_); }
+    void vec_znx_big_normalize(VecZnx& res, size_t res_base2k, int64_t res_offset, size_t res_col, const VecZnxBig& a, size_t a_base2k, size_t a_col) {
+        check(pz_vec_znx_big_normalize(m_, res.data, res.cols, res.size, res_base2k, res_offset, res_col, a.data, a.cols, a.size, a_base2k, a_col), "vec_znx_big_normalize");
+    }
+    void vec_znx_big_add_small_assign(VecZnxBig& res, size_t res_col, const VecZnx& a, size_t a_col) {
+        check(pz_vec_znx_big_add_small_assign(m_, res.data, res.cols, res.size, res_col, a.data, a.cols, a.size, a_col), "vec_znx_big_add_small_assign");
+    }
+
+    // batched device-resident GLWE operations (CoreImpl level)
+    void glwe_external_product_batched(int64_t* res, const int64_t* a, const double* ggsw, const pz_glwe_op_params& p, size_t batch) {
+        check(pz_glwe_external_product_batched(m_, res, a, ggsw, &p, batch), "glwe_external_product_batched");
+    }
+    void glwe_keyswitch_batched(int64_t* res, const int64_t* a, const double* key, const pz_glwe_op_params& p, size_t batch) {
+        check(pz_glwe_keyswitch_batched(m_, res, a, key, &p, batch), "glwe_keyswitch_batched");
+    }
+
+  private:
+    pz_module* m_ = nullptr;
+};
+
+}  // namespace pz

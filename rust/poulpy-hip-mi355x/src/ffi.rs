@@ -1,0 +1,91 @@
+//! `extern "C"` declarations of include/poulpy_hip.h (hot-path subset used by the shim).
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+pub struct pz_module {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct pz_glwe_op_params {
+    pub rank: u64,
+    pub dnum: u64,
+    pub dsize: u64,
+    pub key_size: u64,
+    pub key_base2k: u64,
+    pub a_size: u64,
+    pub a_base2k: u64,
+    pub res_size: u64,
+    pub res_base2k: u64,
+    pub rank_out: u64,
+}
+
+unsafe extern "C" {
+    pub fn pz_last_error() -> *const c_char;
+    pub fn pz_module_new(n: u64, out: *mut *mut pz_module) -> c_int;
+    pub fn pz_module_free(m: *mut pz_module);
+    pub fn pz_module_sync(m: *mut pz_module) -> c_int;
+    pub fn pz_alloc_bytes(len: usize) -> *mut c_void;
+    pub fn pz_free_bytes(p: *mut c_void);
+
+    pub fn pz_vec_znx_dft_apply(m: *mut pz_module, step: usize, offset: usize, res: *mut f64, res_cols: usize, res_size: usize,
+        res_col: usize, a: *const i64, a_cols: usize, a_size: usize, a_col: usize) -> c_int;
+    pub fn pz_vec_znx_idft_apply(m: *mut pz_module, res: *mut i64, res_cols: usize, res_size: usize, res_col: usize,
+        a: *const f64, a_cols: usize, a_size: usize, a_col: usize) -> c_int;
+    pub fn pz_vec_znx_idft_apply_tmpa(m: *mut pz_module, res: *mut i64, res_cols: usize, res_size: usize, res_col: usize,
+        a: *mut f64, a_cols: usize, a_size: usize, a_col: usize) -> c_int;
+    pub fn pz_vec_znx_idft_apply_consume(m: *mut pz_module, data: *mut c_void, cols: usize, size: usize) -> c_int;
+    pub fn pz_vec_znx_dft_add_into(m: *mut pz_module, res: *mut f64, rc: usize, rs: usize, rcol: usize, a: *const f64, ac: usize,
+        as_: usize, acol: usize, b: *const f64, bc: usize, bs: usize, bcol: usize) -> c_int;
+    pub fn pz_vec_znx_dft_sub(m: *mut pz_module, res: *mut f64, rc: usize, rs: usize, rcol: usize, a: *const f64, ac: usize,
+        as_: usize, acol: usize, b: *const f64, bc: usize, bs: usize, bcol: usize) -> c_int;
+    pub fn pz_vec_znx_dft_add_assign(m: *mut pz_module, res: *mut f64, rc: usize, rs: usize, rcol: usize, a: *const f64, ac: usize,
+        as_: usize, acol: usize) -> c_int;
+    pub fn pz_vec_znx_dft_add_scaled_assign(m: *mut pz_module, res: *mut f64, rc: usize, rs: usize, rcol: usize, a: *const f64,
+        ac: usize, as_: usize, acol: usize, a_scale: i64) -> c_int;
+    pub fn pz_vec_znx_dft_sub_assign(m: *mut pz_module, res: *mut f64, rc: usize, rs: usize, rcol: usize, a: *const f64, ac: usize,
+        as_: usize, acol: usize) -> c_int;
+    pub fn pz_vec_znx_dft_sub_negate_assign(m: *mut pz_module, res: *mut f64, rc: usize, rs: usize, rcol: usize, a: *const f64,
+        ac: usize, as_: usize, acol: usize) -> c_int;
+    pub fn pz_vec_znx_dft_copy(m: *mut pz_module, step: usize, offset: usize, res: *mut f64, rc: usize, rs: usize, rcol: usize,
+        a: *const f64, ac: usize, as_: usize, acol: usize) -> c_int;
+    pub fn pz_vec_znx_dft_zero(m: *mut pz_module, res: *mut f64, rc: usize, rs: usize, rcol: usize) -> c_int;
+
+    pub fn pz_svp_prepare(m: *mut pz_module, res: *mut f64, res_cols: usize, res_col: usize, a: *const i64, a_cols: usize,
+        a_col: usize) -> c_int;
+    pub fn pz_svp_apply_dft(m: *mut pz_module, res: *mut f64, rc: usize, rs: usize, rcol: usize, ppol: *const f64, ac: usize,
+        acol: usize, b: *const i64, bc: usize, bs: usize, bcol: usize) -> c_int;
+    pub fn pz_svp_apply_dft_to_dft(m: *mut pz_module, res: *mut f64, rc: usize, rs: usize, rcol: usize, ppol: *const f64,
+        ac: usize, acol: usize, b: *const f64, bc: usize, bs: usize, bcol: usize) -> c_int;
+    pub fn pz_svp_apply_dft_to_dft_assign(m: *mut pz_module, res: *mut f64, rc: usize, rs: usize, rcol: usize, ppol: *const f64,
+        ac: usize, acol: usize) -> c_int;
+
+    pub fn pz_vmp_prepare(m: *mut pz_module, pmat: *mut f64, mat: *const i64, rows: usize, cols_in: usize, cols_out: usize,
+        size: usize) -> c_int;
+    pub fn pz_vmp_apply_dft(m: *mut pz_module, res: *mut f64, rc: usize, rs: usize, a: *const i64, ac: usize, as_: usize,
+        pmat: *const f64, rows: usize, cols_in: usize, cols_out: usize, size: usize) -> c_int;
+    pub fn pz_vmp_apply_dft_to_dft(m: *mut pz_module, res: *mut f64, rc: usize, rs: usize, a: *const f64, ac: usize, as_: usize,
+        pmat: *const f64, rows: usize, cols_in: usize, cols_out: usize, size: usize, limb_offset: usize) -> c_int;
+    pub fn pz_vmp_zero(m: *mut pz_module, pmat: *mut f64, rows: usize, cols_in: usize, cols_out: usize, size: usize) -> c_int;
+
+    pub fn pz_vec_znx_big_normalize(m: *mut pz_module, res: *mut i64, rc: usize, rs: usize, res_base2k: usize, res_offset: i64,
+        rcol: usize, a: *const i64, ac: usize, as_: usize, a_base2k: usize, acol: usize) -> c_int;
+    pub fn pz_vec_znx_big_add_small_assign(m: *mut pz_module, res: *mut i64, rc: usize, rs: usize, rcol: usize, a: *const i64,
+        ac: usize, as_: usize, acol: usize) -> c_int;
+
+    pub fn pz_glwe_external_product_batched(m: *mut pz_module, res: *mut i64, a: *const i64, ggsw: *const f64,
+        p: *const pz_glwe_op_params, batch: usize) -> c_int;
+    pub fn pz_glwe_keyswitch_batched(m: *mut pz_module, res: *mut i64, a: *const i64, key: *const f64,
+        p: *const pz_glwe_op_params, batch: usize) -> c_int;
+}
+
+/// The reference panics (`assert!`) on shape / scratch violations; so does the shim.
+#[inline]
+pub fn check(status: c_int, what: &str) {
+    if status != 0 {
+        let msg = unsafe { std::ffi::CStr::from_ptr(pz_last_error()) }.to_string_lossy().into_owned();
+        panic!("{what}: libpoulpy_hip status {status}: {msg}");
+    }
+}

@@ -1,0 +1,84 @@
+"""Runs one golden fixture (tests/golden/*.npz) through a module that has the hal method names
+(oracle.ref.RefModule on CPU, poulpy_amd.hal.Module on the GPU) and compares bit for bit."""
+from __future__ import annotations
+
+import glob
+import os
+
+import numpy as np
+
+from poulpy_amd.layouts import MatZnx, ScalarZnx, SvpPPol, VecZnx, VecZnxBig
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def fixtures():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def run_fixture(path: str, module_factory) -> None:
+    z = np.load(path)
+    kind, n, base2k = str(z["kind"]), int(z["n"]), int(z["base2k"])
+    mod = module_factory(n)
+    if kind == "vmp":
+        a_np, mat_np = z["a"], z["mat"]
+        a_size, cols_in, _ = a_np.shape
+        rows, _, size, cols_out, _ = mat_np.shape
+        res_size = z["res_big"].shape[0]
+        a = VecZnx(n, cols_in, a_size, np.ascontiguousarray(a_np))
+        mat = MatZnx(n, rows, cols_in, cols_out, size, np.ascontiguousarray(mat_np))
+        ad = mod.vec_znx_dft_alloc(cols_in, a_size)
+        for j in range(cols_in):
+            mod.vec_znx_dft_apply(1, 0, ad, j, a, j)
+        pm = mod.vmp_pmat_alloc(rows, cols_in, cols_out, size)
+        mod.vmp_prepare(pm, mat)
+        rd = mod.vec_znx_dft_alloc(cols_out, res_size)
+        mod.vmp_apply_dft_to_dft(rd, ad, pm, int(z["limb_offset"]))
+        big = mod.vec_znx_idft_apply_consume(rd)
+        assert np.array_equal(big.data, z["res_big"]), f"{path}: res_big differs"
+        res = VecZnx(n, cols_out, res_size)
+        res.data[...] = -7
+        for c in range(cols_out):
+            mod.vec_znx_big_normalize(res, base2k, 0, c, big, base2k, c)
+        assert np.array_equal(res.data, z["res_norm"]), f"{path}: normalized result differs"
+    elif kind == "svp":
+        s_np, b_np = z["s"], z["b"]
+        size, cols, _ = b_np.shape
+        s = ScalarZnx(n, cols, 1, np.ascontiguousarray(s_np))
+        b = VecZnx(n, cols, size, np.ascontiguousarray(b_np))
+        pp = SvpPPol(n, cols)
+        d = mod.vec_znx_dft_alloc(cols, size)
+        for c in range(cols):
+            mod.svp_prepare(pp, c, s, c)
+        for c in range(cols):
+            mod.svp_apply_dft(d, c, pp, c, b, c)
+        big = mod.vec_znx_idft_apply_consume(d)
+        assert np.array_equal(big.data, z["res_big"]), f"{path}: svp product differs"
+    elif kind == "normalize":
+        a_np = z["a"]
+        a = VecZnxBig(n, 1, a_np.shape[0], np.ascontiguousarray(a_np))
+        res = VecZnx(n, 1, z["res"].shape[0])
+        res.data[...] = 3
+        mod.vec_znx_big_normalize(res, base2k, 0, 0, a, base2k, 0)
+        assert np.array_equal(res.data, z["res"]), f"{path}: normalize differs"
+    elif kind == "external_product":
+        a_np, mat_np, want = z["a"], z["mat"], z["res"]
+        a_size, cols, _ = a_np.shape
+        dnum, _, key_size, _, _ = mat_np.shape
+        a = VecZnx(n, cols, a_size, np.ascontiguousarray(a_np))
+        mat = MatZnx(n, dnum, cols, cols, key_size, np.ascontiguousarray(mat_np))
+        pm = mod.vmp_pmat_alloc(dnum, cols, cols, key_size)
+        mod.vmp_prepare(pm, mat)
+        # the op sequence of poulpy-core/src/external_product/glwe.rs:99-141,197-271 (dsize = 1) through the HAL methods
+        ad = mod.vec_znx_dft_alloc(cols, a_size)
+        for j in range(cols):
+            mod.vec_znx_dft_apply(1, 0, ad, j, a, j)
+        rd = mod.vec_znx_dft_alloc(cols, key_size)
+        mod.vmp_apply_dft_to_dft(rd, ad, pm, 0)
+        big = mod.vec_znx_idft_apply_consume(rd)
+        res = VecZnx(n, cols, want.shape[0])
+        for c in range(cols):
+            mod.vec_znx_big_normalize(res, base2k, 0, c, big, base2k, c)
+        assert np.array_equal(res.data, want), f"{path}: external product differs"
+    else:
+        raise AssertionError(f"unknown fixture kind {kind}")

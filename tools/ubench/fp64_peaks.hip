@@ -158,7 +158,7 @@ int main() {
   for (int wpc : {4, 8, 16, 32}) {  // waves per CU
     int blocks = cus * wpc / 4;
     float ms = time_ms([&] { k_fma<<<blocks, 256>>>(out, iters, 0.999); }, 5);
-    double flops = 2.0 * 64 * 8.0 * iters * (double)blocks * 256;
+    double flops = 2.0 * 64 * iters * (double)blocks * 256;  // 8 chains x 8 unrolled FMAs per iteration
     printf("fma_f64      waves/CU %2d: %8.3f ms  %7.2f TFLOP/s\n", wpc, ms, flops / ms * 1e-9);
   }
   for (int wpc : {4, 8, 16}) {
@@ -184,7 +184,7 @@ int main() {
     int b2 = cus * 2;
     float ms = time_ms([&] { k_mix_waves<<<b2, 512>>>(out, iters, 0.5); }, 5);
     double mf = 2.0 * 1024 * 4.0 * iters * (double)b2 * 4;
-    double vf = 2.0 * 64 * 64.0 * iters * (double)b2 * 4;
+    double vf = 2.0 * 64 * 64.0 * iters * (double)b2 * 4;  // 64 FMAs x 64 lanes per iteration, 4 VALU waves per block
     printf("mix diff waves     : %8.3f ms  mfma %7.2f + valu %7.2f = %7.2f TFLOP/s\n", ms, mf / ms * 1e-9, vf / ms * 1e-9, (mf + vf) / ms * 1e-9);
   }
   {
