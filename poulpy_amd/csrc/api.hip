@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "device_fft.hpp"
+#include "device_mid.hpp"
 #include "device_ops.hpp"
 #include "module.hpp"
 
@@ -35,7 +36,7 @@ static int set_lds(K kernel, size_t bytes) {
     return PZ_OK;
 }
 
-static int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* T) {
+static int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* T, bool rowmajor = false) {
     const FftPlan& pl = M->plan;
     const int blocks = npolys * (pl.m2 / pl.cb);
     if (blocks == 0) return PZ_OK;
@@ -43,9 +44,15 @@ static int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, Poly
 #define X(A, B, C)                                                                                              \
     if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
         const size_t lds = (size_t)(A + 1) * C * B * sizeof(cplx);                                              \
-        PZ_TRY(set_lds(k_fwd_pass1<A, B, C>, lds));                                                             \
-        hipLaunchKernelGGL((k_fwd_pass1<A, B, C>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, src, smap, T, \
-                           pl.m2, M->tw1, M->wL1, M->tw12);                                                     \
+        if (rowmajor) {                                                                                         \
+            PZ_TRY(set_lds(k_fwd_pass1<A, B, C, true>, lds));                                                   \
+            hipLaunchKernelGGL((k_fwd_pass1<A, B, C, true>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, src, smap, \
+                               T, pl.m2, M->tw1, M->wL1, M->tw12t);                                             \
+        } else {                                                                                                \
+            PZ_TRY(set_lds(k_fwd_pass1<A, B, C>, lds));                                                         \
+            hipLaunchKernelGGL((k_fwd_pass1<A, B, C>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, src, smap, T, \
+                               pl.m2, M->tw1, M->wL1, M->tw12);                                                 \
+        }                                                                                                       \
         PZ_HIP(hipGetLastError());                                                                              \
         return PZ_OK;                                                                                           \
     }
@@ -122,7 +129,7 @@ static bool tail_supported(const pz_module* M) { return (M->plan.f1b * M->plan.c
 
 static int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
                            int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
-                           int base2k) {
+                           int base2k, bool rowmajor = false) {
     const FftPlan& pl = M->plan;
     const int blocks = batch * ncols * (pl.m2 / pl.cb);
     if (blocks == 0) return PZ_OK;
@@ -134,13 +141,19 @@ static int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, i
     g.tw1inv = M->tw1inv; g.wL1 = M->wL1; g.margin = M->margin;
 #define X(A, B, C)                                                                                              \
     if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
-        const size_t lds = (size_t)2 * (A + 1) * C * B * sizeof(cplx);                  \
-        if (M->probe) {                                                                                         \
-            PZ_TRY(set_lds(k_inv_tail<A, B, C, true>, lds));                                                    \
-            hipLaunchKernelGGL((k_inv_tail<A, B, C, true>), dim3(blocks), dim3((A + B) * C), lds, M->stream, g); \
+        const size_t lds = ((size_t)2 * (A + 1) * C * B + 2 * A * B) * sizeof(cplx);                  \
+        if (M->probe && rowmajor) {                                                                             \
+            PZ_TRY(set_lds(k_inv_tail<A, B, C, true, true>, lds));                                              \
+            hipLaunchKernelGGL((k_inv_tail<A, B, C, true, true>), dim3(blocks), dim3((A + B) * C), lds, M->stream, g); \
+        } else if (M->probe) {                                                                                  \
+            PZ_TRY(set_lds(k_inv_tail<A, B, C, true, false>, lds));                                             \
+            hipLaunchKernelGGL((k_inv_tail<A, B, C, true, false>), dim3(blocks), dim3((A + B) * C), lds, M->stream, g); \
+        } else if (rowmajor) {                                                                                  \
+            PZ_TRY(set_lds(k_inv_tail<A, B, C, false, true>, lds));                                             \
+            hipLaunchKernelGGL((k_inv_tail<A, B, C, false, true>), dim3(blocks), dim3((A + B) * C), lds, M->stream, g); \
         } else {                                                                                                \
-            PZ_TRY(set_lds(k_inv_tail<A, B, C, false>, lds));                                                   \
-            hipLaunchKernelGGL((k_inv_tail<A, B, C, false>), dim3(blocks), dim3((A + B) * C), lds, M->stream, g); \
+            PZ_TRY(set_lds(k_inv_tail<A, B, C, false, false>, lds));                                            \
+            hipLaunchKernelGGL((k_inv_tail<A, B, C, false, false>), dim3(blocks), dim3((A + B) * C), lds, M->stream, g); \
         }                                                                                                       \
         PZ_HIP(hipGetLastError());                                                                              \
         return PZ_OK;                                                                                           \
@@ -148,6 +161,38 @@ static int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, i
     PZ_P1F_CASES(X)
 #undef X
     return fail(PZ_ERR_UNSUPPORTED, "no fused tail kernel for m1=%d", pl.m1);
+}
+
+static bool mid_supported(const pz_module* M, int npi, int npo) {
+    return M->plan.m2 == 256 && (M->plan.m1 % 16) == 0 && npi >= 1 && npi <= 16 && npo >= 1 && npo <= 16;
+}
+static int launch_permute_pmat(pz_module* M, const double* P, cplx* Pp, int npolys) {
+    const FftPlan& pl = M->plan;
+    const int blocks = npolys * (pl.m1 / 16) * (pl.m2 / 16);
+    KTimer kt(M, PZ_K_ELEMENTWISE);
+    hipLaunchKernelGGL(k_permute_pmat, dim3(blocks), dim3(256), 0, M->stream, reinterpret_cast<const cplx*>(P), Pp, npolys, pl.m1, pl.m2);
+    PZ_HIP(hipGetLastError());
+    return PZ_OK;
+}
+static constexpr size_t kMidDummyBytes = (size_t)512 * 256 * sizeof(cplx);  // scratch rows behind T2
+static int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp, int npi, int npo, int nrows, int ncols, cplx* dummy) {
+    constexpr int CT = 2;
+    MidArgs g;
+    g.T = T; g.T2 = T2; g.P = Pp; g.npi = npi; g.npo = npo; g.nrows = nrows; g.ncols = ncols;
+    g.row_max = std::min(nrows, npi);
+    g.ncomp = std::min(npo, ncols);
+    g.batch = batch; g.m1 = M->plan.m1; g.n_ct = (batch + CT - 1) / CT;
+    g.wL2 = M->wL2; g.tw12t = M->tw12t; g.dummy = dummy;
+    const size_t lds = ((size_t)CT * 16 * 17 * 16 + 512) * sizeof(cplx);
+    KTimer kt(M, PZ_K_FUSED_MID);
+    PZ_TRY(set_lds(k_mid<CT>, lds));
+    // persistent: one 512-thread workgroup (136 KiB of LDS) per CU
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, M->device);
+    const int grid = std::min(ncu, g.m1 * g.n_ct);
+    hipLaunchKernelGGL((k_mid<CT>), dim3(grid), dim3(512), lds, M->stream, g);
+    PZ_HIP(hipGetLastError());
+    return PZ_OK;
 }
 
 static int launch_ew(pz_module* M, int op, void* res, long long res_bs, long long res_ls, const void* a, long long a_bs,
@@ -375,7 +420,7 @@ void pz_module_free(pz_module* M) {
     if (!M) return;
     (void)hipSetDevice(M->device);
     if (M->stream) (void)hipStreamSynchronize(M->stream);
-    for (void* p : {(void*)M->tw1, (void*)M->tw1inv, (void*)M->wL1, (void*)M->wL2, (void*)M->tw12, M->ws, (void*)M->margin})
+    for (void* p : {(void*)M->tw1, (void*)M->tw1inv, (void*)M->wL1, (void*)M->wL2, (void*)M->tw12, (void*)M->tw12t, M->ws, (void*)M->margin})
         if (p) (void)hipFree(p);
     for (auto& c : M->arena) (void)hipFree(c.p);
     for (auto& t : M->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
@@ -1062,6 +1107,49 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
     if (batch == 0) return PZ_OK;
     const OpShape s = op_shape(p, ks);
     const size_t chunk = pick_chunk(M, p, s, batch);
+    const long long n = (long long)M->n;
+    const int dsize = (int)p->dsize, dnum = (int)p->dnum, ksz = (int)p->key_size;
+    const long long a_ct = n * s.cols_a * (long long)p->a_size;
+    const long long res_ct = n * s.cols_out * (long long)p->res_size;
+    const int npi = s.cols_in * s.a_size_eff, npo = s.cols_out * ksz;
+    const int nrows = dnum * s.cols_in, ncols = s.cols_out * ksz;
+
+    // ---- fully fused pipeline: pass 1 (row-major) | row pass + VMP + inverse row pass | tail ----
+    if (M->fuse_mid && M->fuse_tail && dsize == 1 && p->res_base2k == p->key_base2k && tail_supported(M) && mid_supported(M, npi, npo)) {
+        const size_t key_bytes = align256((size_t)nrows * ncols * (size_t)M->n * 8);
+        const size_t conv_bytes = s.convert ? align256(chunk * (size_t)M->n * 8 * s.cols_a * s.a_size_eff) : 0;
+        const size_t t_bytes = align256(chunk * (size_t)npi * M->m * sizeof(cplx));
+        const size_t t2_bytes = align256(chunk * (size_t)npo * M->m * sizeof(cplx));
+        PZ_TRY(ws_reserve(M, key_bytes + conv_bytes + t_bytes + t2_bytes + kMidDummyBytes));
+        char* base = (char*)M->ws;
+        cplx* Pp = (cplx*)base; base += key_bytes;
+        int64_t* a_conv = (int64_t*)base; base += conv_bytes;
+        cplx* T = (cplx*)base; base += t_bytes;
+        cplx* T2 = (cplx*)base; base += t2_bytes;
+        cplx* mid_dummy = (cplx*)base;
+        // the key arrives in the standard device layout; its row-sliced copy is rebuilt per call (2 x 128 MiB of
+        // traffic at the metric shape, ~4 % of a 128-ciphertext call) so that no stale copy can ever be used
+        PZ_TRY(launch_permute_pmat(M, pmat, Pp, nrows * ncols));
+        for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+            const int nb = (int)std::min(chunk, batch - b0);
+            DV av{(void*)(a + (long long)b0 * a_ct), a_ct, s.cols_a, (int)p->a_size};
+            if (s.convert) {
+                DV cv{a_conv, n * s.cols_a * s.a_size_eff, s.cols_a, s.a_size_eff};
+                for (int c = 0; c < s.cols_a; ++c)
+                    PZ_TRY(dev_normalize(M, nb, cv, (int)p->key_base2k, 0, c, av, (int)p->a_base2k, c));
+                av = cv;
+            }
+            const int a_size = av.size;
+            const int a_col0 = ks ? 1 : 0;
+            PolyMap sm{a_size, s.cols_in, av.bs, (long long)av.cols * n, n, n * a_col0};
+            PZ_TRY(launch_fwd_pass1(M, nb * npi, (const long long*)av.p, sm, T, true));
+            PZ_TRY(launch_mid(M, nb, T, T2, Pp, npi, npo, nrows, ncols, mid_dummy));
+            PZ_TRY(launch_inv_tail(M, nb, T2, ksz, s.cols_out, (long long*)(res + (long long)b0 * res_ct), res_ct, s.cols_out, (int)p->res_size,
+                                   ks ? (const long long*)av.p : nullptr, av.bs, av.cols, a_size, (int)p->res_base2k, true));
+        }
+        return PZ_OK;
+    }
+
     const OpWs w = op_ws(M, p, s, chunk, ks);
     PZ_TRY(ws_reserve(M, w.total));
     char* base = (char*)M->ws;
@@ -1070,10 +1158,6 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
     double* res_dft = (double*)base; base += w.res_dft;
     double* tmp_dft = (double*)base; base += w.tmp_dft;
     cplx* T = (cplx*)base;
-    const long long n = (long long)M->n;
-    const int dsize = (int)p->dsize, dnum = (int)p->dnum, ksz = (int)p->key_size;
-    const long long a_ct = n * s.cols_a * (long long)p->a_size;
-    const long long res_ct = n * s.cols_out * (long long)p->res_size;
 
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const int nb = (int)std::min(chunk, batch - b0);

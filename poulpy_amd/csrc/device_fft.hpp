@@ -128,7 +128,9 @@ struct MaxOf {
 // forward pass 1: i64 coefficients -> T[j2][q1]
 //   grid.x = npolys * (m2/CB); block = max(R1,R2)*CB threads; LDS (R1+1)*CB*R2 cplx
 // =================================================================================
-template <int R1, int R2, int CB>
+// ROWMAJOR = true writes T'[q1][j2] (rows of m2 contiguous points, what the fused middle kernel
+// consumes; tw12 must then be the [q1][j2] copy of the table) instead of the transposed T[j2][q1].
+template <int R1, int R2, int CB, bool ROWMAJOR = false>
 __global__ void __launch_bounds__((R1 > R2 ? R1 : R2) * CB)
 k_fwd_pass1(const long long* __restrict__ src, PolyMap smap, cplx* __restrict__ T, int m2,
             const cplx* __restrict__ tw1, const cplx* __restrict__ wL1, const cplx* __restrict__ tw12) {
@@ -163,14 +165,15 @@ k_fwd_pass1(const long long* __restrict__ src, PolyMap smap, cplx* __restrict__ 
     }
     __syncthreads();
     if (tid < R1 * CB) {
-        const int k1 = tid % R1, c = tid / R1;
+        const int k1 = ROWMAJOR ? tid / CB : tid % R1;
+        const int c = ROWMAJOR ? tid % CB : tid / R1;
         cplx u[R2];
 #pragma unroll
         for (int o = 0; o < R2; ++o) u[o] = lds[(o * CB + c) * (R1 + 1) + k1];
         Bfly<R2, false>::run(u);
 #pragma unroll
         for (int k2 = 0; k2 < R2; ++k2) {
-            const long long tix = (long long)(c0 + c) * M1 + k1 + R1 * k2;
+            const long long tix = ROWMAJOR ? (long long)(k1 + R1 * k2) * m2 + c0 + c : (long long)(c0 + c) * M1 + k1 + R1 * k2;
             Tp[tix] = cmul(u[k2], tw12[tix]);
         }
     }
@@ -362,13 +365,22 @@ struct TailArgs {
 //                            double-buffered exchange, and the loads of limb j-2 behind that.
 // The two roles run concurrently (one barrier per limb), so the HBM latency of the next limbs hides
 // behind the arithmetic of the current one, and each role only pays for its own registers.
-template <int R1, int R2, int CB, bool PROBE>
+template <int R1, int R2, int CB, bool PROBE, bool ROWMAJOR = false>
 __global__ void __launch_bounds__((R1 + R2) * CB, 3)
 k_inv_tail(TailArgs g) {
     constexpr int M1 = R1 * R2;
     constexpr int XCH = (R1 + 1) * CB * R2;  // cplx per exchange buffer
-    extern __shared__ cplx xch[];            // 2 * XCH
+    extern __shared__ cplx xch[];            // 2 * XCH | wL1[M1] | tw1inv[M1]
+    // stage roots and the untwist table (both M1 entries) in LDS: a global gather in front of dependent
+    // arithmetic costs a memory latency per use at this occupancy
+    cplx* wl = xch + 2 * XCH;
+    cplx* twi = wl + M1;
     const int tid = threadIdx.x;
+    for (int t = tid; t < M1; t += (R1 + R2) * CB) {
+        wl[t] = g.wL1[t];
+        twi[t] = g.tw1inv[t];
+    }
+    __syncthreads();
     const int ncb = g.m2 / CB;
     const int c0 = (blockIdx.x % ncb) * CB;
     const int bc = blockIdx.x / ncb;
@@ -381,13 +393,17 @@ k_inv_tail(TailArgs g) {
     if (tid >= R2 * CB) {
         // ------------------------------ role A' ------------------------------
         const int ta = tid - R2 * CB;
-        const int k1 = ta % R1, c = ta / R1;
-        const cplx* Tb = g.T + ((long long)b * L * g.ncols + col) * m + (long long)(c0 + c) * M1 + k1;
+        const int k1 = ROWMAJOR ? ta / CB : ta % R1;
+        const int c = ROWMAJOR ? ta % CB : ta / R1;
+        // element (q1 = k1 + R1*k2, j2 = c0 + c): T[j2][q1] or, ROWMAJOR, T'[q1][j2]
+        const cplx* Tb = g.T + ((long long)b * L * g.ncols + col) * m +
+                         (ROWMAJOR ? (long long)k1 * g.m2 + c0 + c : (long long)(c0 + c) * M1 + k1);
+        const long long k2s = ROWMAJOR ? (long long)R1 * g.m2 : (long long)R1;  // stride of k2
         const long long limb_stride = (long long)g.ncols * m;
         cplx u[R2];
         if (L > 0) {
 #pragma unroll
-            for (int k2 = 0; k2 < R2; ++k2) u[k2] = Tb[(long long)(L - 1) * limb_stride + R1 * k2];
+            for (int k2 = 0; k2 < R2; ++k2) u[k2] = Tb[(long long)(L - 1) * limb_stride + k2s * k2];
         }
         // iteration t produces limb L-1-t into buffer (L-1-t)&1; t = 0 is the prologue
         for (int t = 0; t <= L; ++t) {
@@ -398,12 +414,12 @@ k_inv_tail(TailArgs g) {
 #pragma unroll
                 for (int o = 0; o < R2; ++o) {
                     cplx x = u[o];
-                    if (R2 > 1 && k1 > 0 && o > 0) x = cmulc(x, g.wL1[o * k1]);
+                    if (R2 > 1 && k1 > 0 && o > 0) x = cmulc(x, wl[o * k1]);
                     buf[(o * CB + c) * (R1 + 1) + k1] = x;
                 }
                 if (j > 0) {
 #pragma unroll
-                    for (int k2 = 0; k2 < R2; ++k2) u[k2] = Tb[(long long)(j - 1) * limb_stride + R1 * k2];
+                    for (int k2 = 0; k2 < R2; ++k2) u[k2] = Tb[(long long)(j - 1) * limb_stride + k2s * k2];
                 }
             }
             __syncthreads();
@@ -444,7 +460,7 @@ k_inv_tail(TailArgs g) {
         double big = 0.0;
 #pragma unroll
         for (int n1 = 0; n1 < R1; ++n1) {
-            const cplx w = cmul(v[n1], g.tw1inv[b_o + R2 * n1]);
+            const cplx w = cmul(v[n1], twi[b_o + R2 * n1]);
             rr[2 * n1] = round_half_away(w.x);
             rr[2 * n1 + 1] = round_half_away(w.y);
             big = fmax(big, fmax(fabs(rr[2 * n1]), fabs(rr[2 * n1 + 1])));

@@ -1,0 +1,233 @@
+// device_mid.hpp — fused middle of the GLWE product pipeline for m2 = 256:
+//   forward row pass (length-256 DFT over j2)  ->  vector-matrix product with the prepared key
+//   ->  inverse row pass (x conj tw12), for CT ciphertexts and one frequency row q1 per workgroup.
+// The spectra (VecZnxDft a_dft / res_dft of the reference's op sequence,
+// poulpy-core/src/external_product/glwe.rs:231-234,270) never leave the CU: a tile of
+// CT x 16 polynomials x 256 points lives in LDS (<= 136 KiB), which removes two of the five
+// HBM round trips of the unfused pipeline.
+//
+//   T   : T'[b*npi + r][q1][j2]   rows of 256 contiguous points (k_fwd_pass1<ROWMAJOR>)
+//   T2  : T2'[b*npo + c][q1][j2]  (consumed by k_inv_tail<ROWMAJOR>)
+//   P   : P'[q1][r][c][q2]        key permuted so that a row's slice is contiguous along q2
+// r = limb_in*cols_in + col_in, c = limb_out*cols_out + col_out (the flat VMP indices).
+// Threads: 512 = (row of the tile: 32) x (16 lanes per row); each thread always holds 16 points.
+// The key slice of a row (npi*npo*256 points, 1 MiB at 16x16) is shared by every ciphertext tile of
+// that row; the 1-D grid is decoded so that those workgroups run back to back on ONE XCD and the
+// slice is served by its L2 after the first fetch.
+#pragma once
+#include "device_fft.hpp"
+
+namespace pz {
+
+struct MidArgs {
+    const cplx* T;
+    cplx* T2;
+    const cplx* P;
+    int npi, npo;       // polynomials per ciphertext in / out (<= 16 each)
+    int nrows, ncols;   // key matrix: rows*cols_in x cols_out*size
+    int row_max;        // min(nrows, npi)
+    int ncomp;          // output polynomials that have a key column; the rest are zero
+    int batch, m1, n_ct;
+    const cplx* wL2;    // exp(2*pi*i*t/256)
+    const cplx* tw12t;  // [q1][j2]
+    cplx* dummy;        // >= 512*256 points of scratch: where rows without an output polynomial store
+};
+
+// LDS traffic between the 16 lanes that own one row needs no workgroup barrier: the lanes are in one wave,
+// whose LDS instructions execute in order; this only stops the compiler from moving them across.
+__device__ __forceinline__ void row_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Workgroup barrier that only orders LDS traffic (s_waitcnt lgkmcnt(0); s_barrier).  __syncthreads() also
+// drains vmcnt, which would make every barrier wait for the tile's global stores and for the prefetched
+// loads; threads of this kernel never exchange data through global memory, so LDS ordering is sufficient.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Persistent: gridDim.x = 8*W workgroups (one per CU); workgroup (xcd = bid & 7, w = bid >> 3) walks the tiles
+// (q1 = 8*k + xcd, ciphertext tile) of "its" XCD with stride W, so the W workgroups of an XCD sweep the
+// ciphertext tiles of one frequency row together and share its key slice through that XCD's L2.  The loads
+// of the next tile are issued before the inverse row pass of the current one.
+template <int CT>
+__global__ void __launch_bounds__(512)
+k_mid(MidArgs g) {
+    constexpr int M2 = 256;
+    constexpr int RS = 17 * 16;  // padded row stride (points)
+    extern __shared__ cplx lds[];  // CT*16 rows x RS | wL2[256] | tw12t row [256]
+    const int tid = threadIdx.x;
+    const long long m = (long long)g.m1 * M2;
+    const int row = tid >> 4, o = tid & 15;
+    const int ctl = row >> 4, rr = row & 15;  // ciphertext within the tile, polynomial slot
+    cplx* rowbuf = lds + row * RS;
+    // twiddles are read from LDS: a global gather in front of dependent arithmetic costs a full memory latency
+    // per use at this occupancy (one workgroup per CU) and its vmcnt wait would also drain the tile stores
+    cplx* wl = lds + CT * 16 * RS;
+    cplx* twrow = wl + M2;
+
+    const bool xcd_map = (g.m1 & 7) == 0 && (gridDim.x & 7) == 0;
+    const int xcd = xcd_map ? (blockIdx.x & 7) : 0;
+    const int w = xcd_map ? (blockIdx.x >> 3) : blockIdx.x;
+    const int W = xcd_map ? (gridDim.x >> 3) : gridDim.x;
+    const int ntiles = (xcd_map ? g.m1 / 8 : g.m1) * g.n_ct;
+    if (w >= ntiles) return;
+    if (tid < M2) wl[tid] = g.wL2[tid];
+    __syncthreads();
+
+    // Loop shape (software pipeline, one tile per iteration):
+    //   prologue : loads(t0); forward row DFT(t0) -> S
+    //   iteration: product(t) ; issue loads(t+1) ; inverse row DFT(t) ; 16 stores(t) ; barrier ;
+    //              forward row DFT(t+1) -> S
+    // Loads and stores are UNCONDITIONAL (absent rows read row 0 of a valid polynomial and write to the
+    // scratch rows behind T2), so that exactly 16 stores are younger than the 16 loads when the next forward
+    // pass needs them: the compiler can then wait with vmcnt(16) and the stores of tile t drain under the
+    // forward pass and the product of tile t+1.
+    cplx x[16];
+    auto tile_q1 = [&](int L) { return xcd_map ? (L / g.n_ct) * 8 + xcd : L / g.n_ct; };
+    auto src_ptr = [&](int L) {
+        const int Lc = min(L, ntiles - 1);
+        const int b_ = min((Lc % g.n_ct) * CT + ctl, g.batch - 1);
+        const int r_ = min(rr, g.npi - 1);
+        return g.T + ((long long)b_ * g.npi + r_) * m + (long long)tile_q1(Lc) * M2 + o;
+    };
+    auto in_active = [&](int L) { return L < ntiles && (L % g.n_ct) * CT + ctl < g.batch && rr < g.npi; };
+
+#define PZ_MID_FWD(ACTIVE)                                                                        \
+    {                                                                                             \
+        if (!(ACTIVE)) {                                                                          \
+            _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1) x[n1] = make_double2(0.0, 0.0);     \
+        }                                                                                         \
+        Bfly<16, false>::run(x);                                                                  \
+        _Pragma("unroll") for (int k1 = 0; k1 < 16; ++k1) {                                       \
+            cplx v = x[k1];                                                                       \
+            if (k1 > 0) v = cmul(v, wl[o * k1]);                                                  \
+            rowbuf[k1 * 17 + o] = v;                                                              \
+        }                                                                                         \
+        row_sync();                                                                               \
+        _Pragma("unroll") for (int oo = 0; oo < 16; ++oo) x[oo] = rowbuf[o * 17 + oo];            \
+        Bfly<16, false>::run(x);                                                                  \
+        row_sync();                                                                               \
+        _Pragma("unroll") for (int k2 = 0; k2 < 16; ++k2) rowbuf[o + 16 * k2] = x[k2];            \
+        lds_barrier();                                                                            \
+    }
+
+    cplx twn = make_double2(0.0, 0.0);  // this thread's entry of the next tile's inter-pass twiddle row
+    {
+        const cplx* src = src_ptr(w);
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) x[n1] = src[16 * n1];
+        twn = g.tw12t[(long long)tile_q1(w) * M2 + (tid & 255)];
+    }
+    if (tid < M2) twrow[tid] = twn;
+    PZ_MID_FWD(in_active(w))
+
+    for (int L = w; L < ntiles; L += W) {
+        const int q1 = tile_q1(L);
+        const int b = (L % g.n_ct) * CT + ctl;
+
+        // ---------------- product: res[b][c][q] = sum_r a[b][r][q] * P[r][c][q] ----------------
+        {
+            const int q2 = tid & 255, cg = tid >> 8;  // 8 output polynomials per half of the workgroup
+            cplx acc[CT][8];
+#pragma unroll
+            for (int i = 0; i < CT; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = make_double2(0.0, 0.0);
+            const cplx* pp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = min(cg * 8 + j, g.ncomp - 1);
+                pp[j] = g.P + ((long long)q1 * g.nrows * g.ncols + c) * M2 + q2;
+            }
+            const long long prow = (long long)g.ncols * M2;
+            cplx pn[8];  // key row r+1 travels while row r is consumed (deeper prefetch spills at 256 VGPRs and did not pay)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pn[j] = pp[j][0];
+            for (int r = 0; r < g.row_max; ++r) {
+                cplx pv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pv[j] = pn[j];
+                {
+                    const int rn = min(r + 1, g.row_max - 1);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pn[j] = pp[j][(long long)rn * prow];
+                }
+#pragma unroll
+                for (int i = 0; i < CT; ++i) {
+                    const cplx av = lds[(i * 16 + r) * RS + q2];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        acc[i][j].x = __builtin_fma(av.x, pv[j].x, acc[i][j].x);
+                        acc[i][j].x = __builtin_fma(-av.y, pv[j].y, acc[i][j].x);
+                        acc[i][j].y = __builtin_fma(av.x, pv[j].y, acc[i][j].y);
+                        acc[i][j].y = __builtin_fma(av.y, pv[j].x, acc[i][j].y);
+                    }
+                }
+            }
+            lds_barrier();  // every a value has been read: the tile can be overwritten with the products
+#pragma unroll
+            for (int i = 0; i < CT; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = cg * 8 + j;
+                    lds[(i * 16 + c) * RS + q2] = (c < g.ncomp) ? acc[i][j] : make_double2(0.0, 0.0);
+                }
+            lds_barrier();
+        }
+
+        // next tile's inputs start travelling now (always 16 loads)
+        {
+            const cplx* src = src_ptr(L + W);
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) x[n1] = src[16 * n1];
+            twn = g.tw12t[(long long)tile_q1(min(L + W, ntiles - 1)) * M2 + (tid & 255)];
+        }
+
+        // ---------------- inverse row DFT of the output polynomials, always 16 stores ----------------
+        {
+            cplx u[16];
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) u[k2] = rowbuf[o + 16 * k2];  // k1 = o
+            Bfly<16, true>::run(u);
+            row_sync();
+#pragma unroll
+            for (int oo = 0; oo < 16; ++oo) {
+                cplx v = u[oo];
+                if (o > 0 && oo > 0) v = cmulc(v, wl[oo * o]);
+                rowbuf[o * 17 + oo] = v;  // z[k1 = o][oo]
+            }
+            row_sync();
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) u[k1] = rowbuf[k1 * 17 + o];
+            Bfly<16, true>::run(u);
+            const bool active = b < g.batch && rr < g.npo;
+            cplx* dst = active ? g.T2 + ((long long)b * g.npo + rr) * m + (long long)q1 * M2 + o
+                               : g.dummy + (long long)tid * 16 * 16 + o;
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) dst[16 * n1] = cmulc(u[n1], twrow[o + 16 * n1]);
+        }
+        lds_barrier();  // the tile is rewritten by the forward pass below
+        if (tid < M2) twrow[tid] = twn;  // read again only after the barriers of the next product phase
+        PZ_MID_FWD(in_active(L + W))
+    }
+#undef PZ_MID_FWD
+}
+
+// standard device VmpPMat  P[p][q1 + m1*q2]  ->  P'[q1][p][q2]   (p = r*ncols + c), 16x16 tiles through LDS
+__global__ void __launch_bounds__(256)
+k_permute_pmat(const cplx* __restrict__ P, cplx* __restrict__ Pp, int npolys, int m1, int m2) {
+    __shared__ cplx tile[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int tiles_q1 = m1 / 16, tiles_q2 = m2 / 16;
+    int t = blockIdx.x;
+    const int tq1 = t % tiles_q1; t /= tiles_q1;
+    const int tq2 = t % tiles_q2; t /= tiles_q2;
+    const int p = t;
+    const long long m = (long long)m1 * m2;
+    tile[ty][tx] = P[(long long)p * m + (long long)(tq2 * 16 + ty) * m1 + tq1 * 16 + tx];
+    __syncthreads();
+    Pp[((long long)(tq1 * 16 + ty) * npolys + p) * m2 + tq2 * 16 + tx] = tile[tx][ty];
+}
+
+}  // namespace pz

@@ -98,6 +98,7 @@ struct pz_module {
     hipStream_t stream = nullptr;
     // device tables (cplx): tw1[m1], tw1inv[m1], wL1[m1], wL2[m2], tw12[m] ([j2][q1])
     pz::cplx *tw1 = nullptr, *tw1inv = nullptr, *wL1 = nullptr, *wL2 = nullptr, *tw12 = nullptr;
+    pz::cplx* tw12t = nullptr;  // the same table as [q1][j2] (row-major pipeline)
     // grow-only workspace
     void* ws = nullptr;
     size_t ws_bytes = 0;
@@ -232,6 +233,12 @@ inline int build_tables(pz_module* M) {
             h[(size_t)(j2 * m1 + q1)] = make_double2(c, s);
         }
     PZ_TRY(upload_table(&M->tw12, h));
+    {
+        std::vector<cplx> ht((size_t)m);
+        for (long long j2 = 0; j2 < m2; ++j2)
+            for (long long q1 = 0; q1 < m1; ++q1) ht[(size_t)(q1 * m2 + j2)] = h[(size_t)(j2 * m1 + q1)];
+        PZ_TRY(upload_table(&M->tw12t, ht));
+    }
     return PZ_OK;
 }
 
