@@ -26,7 +26,7 @@ using namespace pz;
 // kernel dispatch
 // ------------------------------------------------------------------------------
 #define PZ_P1_CASES(X) X(4, 1, 4) X(8, 1, 4) X(8, 1, 16) X(16, 1, 16) X(8, 4, 16) X(8, 8, 16) X(16, 8, 16) X(16, 16, 16)
-#define PZ_P1F_CASES(X) X(4, 1, 4) X(8, 1, 4) X(8, 1, 16) X(16, 1, 16) X(4, 8, 16) X(8, 8, 16) X(8, 16, 16) X(16, 16, 16)
+#define PZ_P1F_CASES(X) X(4, 1, 4) X(8, 1, 4) X(8, 1, 16) X(16, 1, 16) X(4, 8, 16) X(8, 8, 16) X(8, 16, 16) X(16, 16, 16) X(8, 16, 8)
 #define PZ_P2_CASES(X) X(4, 1, 4) X(8, 1, 4) X(16, 1, 4) X(16, 1, 16) X(8, 4, 16) X(8, 8, 16) X(16, 8, 16) X(16, 16, 16)
 
 template <typename K>
@@ -43,7 +43,7 @@ static int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, Poly
     KTimer kt(M, PZ_K_FWD_PASS1);
 #define X(A, B, C)                                                                                              \
     if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
-        const size_t lds = (size_t)(A + 1) * C * B * sizeof(cplx);                                              \
+        const size_t lds = ((size_t)(A + 1) * C * B + 2 * A * B) * sizeof(cplx);                                              \
         if (rowmajor) {                                                                                         \
             PZ_TRY(set_lds(k_fwd_pass1<A, B, C, true>, lds));                                                   \
             hipLaunchKernelGGL((k_fwd_pass1<A, B, C, true>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, src, smap, \

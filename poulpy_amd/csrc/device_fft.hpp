@@ -135,7 +135,8 @@ __global__ void __launch_bounds__((R1 > R2 ? R1 : R2) * CB)
 k_fwd_pass1(const long long* __restrict__ src, PolyMap smap, cplx* __restrict__ T, int m2,
             const cplx* __restrict__ tw1, const cplx* __restrict__ wL1, const cplx* __restrict__ tw12) {
     constexpr int M1 = R1 * R2;
-    extern __shared__ cplx lds[];
+    constexpr int NT = (R1 > R2 ? R1 : R2) * CB;
+    extern __shared__ cplx lds[];  // (R1+1)*CB*R2 exchange | tw1[M1] | wL1[M1]
     const int tid = threadIdx.x;
     const int ncb = m2 / CB;
     const int p = blockIdx.x / ncb;
@@ -143,23 +144,37 @@ k_fwd_pass1(const long long* __restrict__ src, PolyMap smap, cplx* __restrict__ 
     const long long m = (long long)M1 * m2;
     const long long* a = src + map_off(smap, p);
     cplx* Tp = T + (long long)p * m;
+    // twist and stage roots from LDS (a global gather in front of dependent arithmetic costs a memory latency)
+    cplx* tws = lds + (R1 + 1) * CB * R2;
+    cplx* wls = tws + M1;
 
-    if (tid < R2 * CB) {
-        const int o = tid / CB, c = tid % CB;
-        cplx v[R1];
+    const bool is_a = tid < R2 * CB;
+    const int o = tid / CB, c = tid % CB;
+    // issue the coefficient loads first, stage the tables while they travel
+    long long raw_re[R1], raw_im[R1];
+    if (is_a) {
 #pragma unroll
         for (int n1 = 0; n1 < R1; ++n1) {
-            const int j1 = o + R2 * n1;
-            const long long idx = (long long)j1 * m2 + c0 + c;
-            const double re = (double)a[idx];
-            const double im = (double)a[idx + m];
-            v[n1] = cmul(make_double2(re, im), tw1[j1]);
+            const long long idx = (long long)(o + R2 * n1) * m2 + c0 + c;
+            raw_re[n1] = a[idx];
+            raw_im[n1] = a[idx + m];
         }
+    }
+    for (int t = tid; t < M1; t += NT) {
+        tws[t] = tw1[t];
+        wls[t] = wL1[t];
+    }
+    __syncthreads();
+    if (is_a) {
+        cplx v[R1];
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1)
+            v[n1] = cmul(make_double2((double)raw_re[n1], (double)raw_im[n1]), tws[o + R2 * n1]);
         Bfly<R1, false>::run(v);
 #pragma unroll
         for (int k1 = 0; k1 < R1; ++k1) {
             cplx x = v[k1];
-            if (R2 > 1 && k1 > 0) x = cmul(x, wL1[o * k1]);
+            if (R2 > 1 && k1 > 0) x = cmul(x, wls[o * k1]);
             lds[(o * CB + c) * (R1 + 1) + k1] = x;
         }
     }

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <mutex>
@@ -86,6 +87,7 @@ inline bool make_plan(uint64_t n, FftPlan& pl) {
     if (pl.m1 == 128) { pl.f1a = 8; pl.f1b = 16; }
     pl.cb = pl.m2 >= 16 ? 16 : 4;
     pl.qb = pl.m1 >= 16 ? 16 : 4;
+    if (const char* e = getenv("POULPY_DBG_CB")) pl.cb = atoi(e);  // diagnostic: column-block width of pass 1 / tail
     return true;
 }
 
