@@ -175,24 +175,33 @@ static int launch_permute_pmat(pz_module* M, const double* P, cplx* Pp, int npol
     return PZ_OK;
 }
 static constexpr size_t kMidDummyBytes = (size_t)512 * 256 * sizeof(cplx);  // scratch rows behind T2
+template <int CT>
+static int launch_mid_ct(pz_module* M, MidArgs g, int batch) {
+    g.n_ct = (batch + CT - 1) / CT;
+    const size_t lds = ((size_t)CT * 16 * 17 * 16 + 512) * sizeof(cplx);
+    KTimer kt(M, PZ_K_FUSED_MID);
+    PZ_TRY(set_lds(k_mid<CT>, lds));
+    // persistent: as many workgroups as fit (LDS-bound: 144 KiB -> 1 per CU at CT = 2, 76 KiB -> 2 per CU at CT = 1)
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, M->device);
+    const int per_cu = CT == 1 ? 2 : 1;
+    const int grid = std::min(ncu * per_cu, g.m1 * g.n_ct);
+    hipLaunchKernelGGL((k_mid<CT>), dim3(grid), dim3(CT * 256), lds, M->stream, g);
+    PZ_HIP(hipGetLastError());
+    return PZ_OK;
+}
 static int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp, int npi, int npo, int nrows, int ncols, cplx* dummy) {
-    constexpr int CT = 2;
     MidArgs g;
     g.T = T; g.T2 = T2; g.P = Pp; g.npi = npi; g.npo = npo; g.nrows = nrows; g.ncols = ncols;
     g.row_max = std::min(nrows, npi);
     g.ncomp = std::min(npo, ncols);
-    g.batch = batch; g.m1 = M->plan.m1; g.n_ct = (batch + CT - 1) / CT;
+    g.batch = batch; g.m1 = M->plan.m1; g.n_ct = 0;
     g.wL2 = M->wL2; g.tw12t = M->tw12t; g.dummy = dummy;
-    const size_t lds = ((size_t)CT * 16 * 17 * 16 + 512) * sizeof(cplx);
-    KTimer kt(M, PZ_K_FUSED_MID);
-    PZ_TRY(set_lds(k_mid<CT>, lds));
-    // persistent: one 512-thread workgroup (136 KiB of LDS) per CU
-    int ncu = 256;
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, M->device);
-    const int grid = std::min(ncu, g.m1 * g.n_ct);
-    hipLaunchKernelGGL((k_mid<CT>), dim3(grid), dim3(512), lds, M->stream, g);
-    PZ_HIP(hipGetLastError());
-    return PZ_OK;
+    static const int groups = getenv("POULPY_DBG_MID_GROUPS") ? atoi(getenv("POULPY_DBG_MID_GROUPS")) : 1;
+    g.groups = groups;
+    static const int ct = getenv("POULPY_DBG_MID_CT") ? atoi(getenv("POULPY_DBG_MID_CT")) : 2;  // diagnostic knob
+    if (ct == 1) return launch_mid_ct<1>(M, g, batch);
+    return launch_mid_ct<2>(M, g, batch);
 }
 
 static int launch_ew(pz_module* M, int op, void* res, long long res_bs, long long res_ls, const void* a, long long a_bs,

@@ -381,7 +381,7 @@ struct TailArgs {
 // The two roles run concurrently (one barrier per limb), so the HBM latency of the next limbs hides
 // behind the arithmetic of the current one, and each role only pays for its own registers.
 template <int R1, int R2, int CB, bool PROBE, bool ROWMAJOR = false>
-__global__ void __launch_bounds__((R1 + R2) * CB, 3)
+__global__ void __launch_bounds__((R1 + R2) * CB, ((R1 + R2) * CB >= 512 ? 2 : 3))
 k_inv_tail(TailArgs g) {
     constexpr int M1 = R1 * R2;
     constexpr int XCH = (R1 + 1) * CB * R2;  // cplx per exchange buffer

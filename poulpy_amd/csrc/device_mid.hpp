@@ -31,6 +31,7 @@ struct MidArgs {
     const cplx* wL2;    // exp(2*pi*i*t/256)
     const cplx* tw12t;  // [q1][j2]
     cplx* dummy;        // >= 512*256 points of scratch: where rows without an output polynomial store
+    int groups;         // row groups per XCD (see k_mid)
 };
 
 // LDS traffic between the 16 lanes that own one row needs no workgroup barrier: the lanes are in one wave,
@@ -51,9 +52,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // ciphertext tiles of one frequency row together and share its key slice through that XCD's L2.  The loads
 // of the next tile are issued before the inverse row pass of the current one.
 template <int CT>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(CT * 256)
 k_mid(MidArgs g) {
     constexpr int M2 = 256;
+    constexpr int NC = 16 / CT;  // output polynomials per thread in the product phase (CT*256 threads cover 256 points x 16)
     constexpr int RS = 17 * 16;  // padded row stride (points)
     extern __shared__ cplx lds[];  // CT*16 rows x RS | wL2[256] | tw12t row [256]
     const int tid = threadIdx.x;
@@ -66,11 +68,17 @@ k_mid(MidArgs g) {
     cplx* wl = lds + CT * 16 * RS;
     cplx* twrow = wl + M2;
 
+    // tile enumeration: XCD x owns the rows q1 = 8*k + x; its W workgroups are split into G groups, group gi sweeps
+    // the rows k = gi (mod G) with stride W/G over (row, ciphertext tile).  G > 1 keeps several key slices in flight
+    // per XCD (still L2 resident) and lowers the number of workgroups hammering the same lines at once.
     const bool xcd_map = (g.m1 & 7) == 0 && (gridDim.x & 7) == 0;
     const int xcd = xcd_map ? (blockIdx.x & 7) : 0;
-    const int w = xcd_map ? (blockIdx.x >> 3) : blockIdx.x;
-    const int W = xcd_map ? (gridDim.x >> 3) : gridDim.x;
-    const int ntiles = (xcd_map ? g.m1 / 8 : g.m1) * g.n_ct;
+    const int wx = xcd_map ? (blockIdx.x >> 3) : blockIdx.x;
+    const int Wx = xcd_map ? (gridDim.x >> 3) : gridDim.x;
+    const int rows_x = xcd_map ? g.m1 / 8 : g.m1;
+    const int G = (g.groups > 0 && Wx % g.groups == 0 && rows_x % g.groups == 0) ? g.groups : 1;
+    const int W = Wx / G, gi = wx / W, w = wx % W;
+    const int ntiles = (rows_x / G) * g.n_ct;
     if (w >= ntiles) return;
     if (tid < M2) wl[tid] = g.wL2[tid];
     __syncthreads();
@@ -84,7 +92,7 @@ k_mid(MidArgs g) {
     // pass needs them: the compiler can then wait with vmcnt(16) and the stores of tile t drain under the
     // forward pass and the product of tile t+1.
     cplx x[16];
-    auto tile_q1 = [&](int L) { return xcd_map ? (L / g.n_ct) * 8 + xcd : L / g.n_ct; };
+    auto tile_q1 = [&](int L) { const int k = (L / g.n_ct) * G + gi; return xcd_map ? k * 8 + xcd : k; };
     auto src_ptr = [&](int L) {
         const int Lc = min(L, ntiles - 1);
         const int b_ = min((Lc % g.n_ct) * CT + ctl, g.batch - 1);
@@ -120,6 +128,20 @@ k_mid(MidArgs g) {
         twn = g.tw12t[(long long)tile_q1(w) * M2 + (tid & 255)];
     }
     if (tid < M2) twrow[tid] = twn;
+    // first key row of the coming product: requested before the forward pass so that its L2 latency is hidden
+    const int vq2 = tid & 255, vcg = tid >> 8;
+    // The workgroups of an XCD sweep the same key slice at the same time; each starts the row loop at a different
+    // row so that they do not all hit the same L2 channels at once (sum order differs per workgroup, far inside the
+    // rounding margin; results stay deterministic for a given launch geometry)
+    const int rot = g.row_max > 0 ? (w % g.row_max) : 0;
+    cplx pn[NC];
+#define PZ_MID_P0(LT)                                                                                  \
+    {                                                                                                  \
+        const long long base_ = (long long)tile_q1(min((LT), ntiles - 1)) * g.nrows * g.ncols;         \
+        _Pragma("unroll") for (int j = 0; j < NC; ++j)                                                 \
+            pn[j] = g.P[(base_ + (long long)rot * g.ncols + min(vcg * NC + j, g.ncomp - 1)) * M2 + vq2];  \
+    }
+    PZ_MID_P0(w)
     PZ_MID_FWD(in_active(w))
 
     for (int L = w; L < ntiles; L += W) {
@@ -128,36 +150,38 @@ k_mid(MidArgs g) {
 
         // ---------------- product: res[b][c][q] = sum_r a[b][r][q] * P[r][c][q] ----------------
         {
-            const int q2 = tid & 255, cg = tid >> 8;  // 8 output polynomials per half of the workgroup
-            cplx acc[CT][8];
+            const int q2 = tid & 255, cg = tid >> 8;  // NC output polynomials per 256-thread slice of the workgroup
+            cplx acc[CT][NC];
 #pragma unroll
             for (int i = 0; i < CT; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][j] = make_double2(0.0, 0.0);
-            const cplx* pp[8];
+                for (int j = 0; j < NC; ++j) acc[i][j] = make_double2(0.0, 0.0);
+            const cplx* pp[NC];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int c = min(cg * 8 + j, g.ncomp - 1);
+            for (int j = 0; j < NC; ++j) {
+                const int c = min(cg * NC + j, g.ncomp - 1);
                 pp[j] = g.P + ((long long)q1 * g.nrows * g.ncols + c) * M2 + q2;
             }
             const long long prow = (long long)g.ncols * M2;
-            cplx pn[8];  // key row r+1 travels while row r is consumed (deeper prefetch spills at 256 VGPRs and did not pay)
+            // key row r+1 travels while row r is consumed (row 0 was requested before the forward pass; deeper
+            // prefetch spills at 256 VGPRs and did not pay)
+            for (int it = 0; it < g.row_max; ++it) {
+                int r = it + rot;
+                if (r >= g.row_max) r -= g.row_max;
+                cplx pv[NC];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pn[j] = pp[j][0];
-            for (int r = 0; r < g.row_max; ++r) {
-                cplx pv[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pv[j] = pn[j];
+                for (int j = 0; j < NC; ++j) pv[j] = pn[j];
                 {
-                    const int rn = min(r + 1, g.row_max - 1);
+                    int rn = r + 1;
+                    if (rn >= g.row_max) rn = 0;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) pn[j] = pp[j][(long long)rn * prow];
+                    for (int j = 0; j < NC; ++j) pn[j] = pp[j][(long long)rn * prow];
                 }
 #pragma unroll
                 for (int i = 0; i < CT; ++i) {
                     const cplx av = lds[(i * 16 + r) * RS + q2];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < NC; ++j) {
                         acc[i][j].x = __builtin_fma(av.x, pv[j].x, acc[i][j].x);
                         acc[i][j].x = __builtin_fma(-av.y, pv[j].y, acc[i][j].x);
                         acc[i][j].y = __builtin_fma(av.x, pv[j].y, acc[i][j].y);
@@ -169,8 +193,8 @@ k_mid(MidArgs g) {
 #pragma unroll
             for (int i = 0; i < CT; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int c = cg * 8 + j;
+                for (int j = 0; j < NC; ++j) {
+                    const int c = cg * NC + j;
                     lds[(i * 16 + c) * RS + q2] = (c < g.ncomp) ? acc[i][j] : make_double2(0.0, 0.0);
                 }
             lds_barrier();
@@ -209,9 +233,11 @@ k_mid(MidArgs g) {
         }
         lds_barrier();  // the tile is rewritten by the forward pass below
         if (tid < M2) twrow[tid] = twn;  // read again only after the barriers of the next product phase
+        PZ_MID_P0(L + W)
         PZ_MID_FWD(in_active(L + W))
     }
 #undef PZ_MID_FWD
+#undef PZ_MID_P0
 }
 
 // standard device VmpPMat  P[p][q1 + m1*q2]  ->  P'[q1][p][q2]   (p = r*ncols + c), 16x16 tiles through LDS

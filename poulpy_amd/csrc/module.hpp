@@ -78,6 +78,7 @@ inline bool make_plan(uint64_t n, FftPlan& pl) {
     int k = 0;
     while ((1ull << k) < m) ++k;
     int k1 = k / 2;
+    if (const char* e = getenv("POULPY_DBG_SPLIT")) { if (e[0] == 'w' && (k & 1)) k1 = (k + 1) / 2; }  // diagnostic: m1 > m2
     pl.m1 = 1 << k1;
     pl.m2 = 1 << (k - k1);
     if (!radices_for(pl.m1, pl.r1a, pl.r1b)) return false;
