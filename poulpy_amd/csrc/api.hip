@@ -164,7 +164,7 @@ static int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, i
 }
 
 static bool mid_supported(const pz_module* M, int npi, int npo) {
-    return M->plan.m2 == 256 && (M->plan.m1 % 16) == 0 && npi >= 1 && npi <= 16 && npo >= 1 && npo <= 16;
+    return (M->plan.m2 == 256 || M->plan.m2 == 128) && (M->plan.m1 % 16) == 0 && npi >= 1 && npi <= 16 && npo >= 1 && npo <= 16;
 }
 static int launch_permute_pmat(pz_module* M, const double* P, cplx* Pp, int npolys) {
     const FftPlan& pl = M->plan;
@@ -174,7 +174,7 @@ static int launch_permute_pmat(pz_module* M, const double* P, cplx* Pp, int npol
     PZ_HIP(hipGetLastError());
     return PZ_OK;
 }
-static constexpr size_t kMidDummyBytes = (size_t)512 * 256 * sizeof(cplx);  // scratch rows behind T2
+static constexpr size_t kMidDummyBytes = (size_t)512 * 256 * sizeof(cplx) + (1 << 20);  // scratch rows behind T2 (+ diagnostic stamps)
 template <int CT>
 static int launch_mid_ct(pz_module* M, MidArgs g, int batch) {
     g.n_ct = (batch + CT - 1) / CT;
@@ -199,6 +199,19 @@ static int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cp
     g.wL2 = M->wL2; g.tw12t = M->tw12t; g.dummy = dummy;
     static const int groups = getenv("POULPY_DBG_MID_GROUPS") ? atoi(getenv("POULPY_DBG_MID_GROUPS")) : 1;
     g.groups = groups;
+    if (M->plan.m2 == 128) {
+        constexpr int CT = 4;
+        g.n_ct = (batch + CT - 1) / CT;
+        const size_t lds = ((size_t)CT * 16 * 16 * 9 + 256) * sizeof(cplx);
+        KTimer kt(M, PZ_K_FUSED_MID);
+        PZ_TRY(set_lds(k_mid128<CT>, lds));
+        int ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, M->device);
+        const int grid = std::min(ncu, g.m1 * g.n_ct);
+        hipLaunchKernelGGL((k_mid128<CT>), dim3(grid), dim3(CT * 128), lds, M->stream, g);
+        PZ_HIP(hipGetLastError());
+        return PZ_OK;
+    }
     static const int ct = getenv("POULPY_DBG_MID_CT") ? atoi(getenv("POULPY_DBG_MID_CT")) : 2;  // diagnostic knob
     if (ct == 1) return launch_mid_ct<1>(M, g, batch);
     return launch_mid_ct<2>(M, g, batch);

@@ -240,6 +240,193 @@ k_mid(MidArgs g) {
 #undef PZ_MID_P0
 }
 
+// =================================================================================
+// Same fused middle for plans with m2 = 128 (m1 = 256): rows of 128 points are owned by 8 lanes
+// (16 points each: one radix-16 butterfly, then two radix-8 butterflies), so a tile of FOUR ciphertexts
+// x 16 polynomials fits in LDS (144 KiB) and every key value fetched serves four ciphertexts instead of
+// two.  512 threads = 64 rows x 8 lanes; product phase: 128 points x 4 groups of 4 outputs.
+// Measured (round 1): middle kernel 13 % faster than the m2 = 256 form, but pass 1 / tail at m1 = 256 are
+// 5-8 % slower, so the default plan stays m1 = 128, m2 = 256; POULPY_DBG_SPLIT=w selects this one.
+// =================================================================================
+template <int CT>
+__global__ void __launch_bounds__(CT * 128)
+k_mid128(MidArgs g) {
+    constexpr int M2 = 128;
+    constexpr int NT = CT * 128;
+    constexpr int NCG = NT / M2;       // column groups in the product phase
+    constexpr int NC = 16 / NCG;       // outputs per thread
+    constexpr int RS = 16 * 9;         // padded row stride (points): z[k1][o] at k1*9 + o
+    extern __shared__ cplx lds[];      // CT*16 rows x RS | wL2[128] | tw12t row [128]
+    const int tid = threadIdx.x;
+    const long long m = (long long)g.m1 * M2;
+    const int row = tid >> 3, o = tid & 7;
+    const int ctl = row >> 4, rr = row & 15;
+    cplx* rowbuf = lds + row * RS;
+    cplx* wl = lds + CT * 16 * RS;
+    cplx* twrow = wl + M2;
+
+    const bool xcd_map = (g.m1 & 7) == 0 && (gridDim.x & 7) == 0;
+    const int xcd = xcd_map ? (blockIdx.x & 7) : 0;
+    const int w = xcd_map ? (blockIdx.x >> 3) : blockIdx.x;
+    const int W = xcd_map ? (gridDim.x >> 3) : gridDim.x;
+    const int rows_x = xcd_map ? g.m1 / 8 : g.m1;
+    const int ntiles = rows_x * g.n_ct;
+    if (w >= ntiles) return;
+    if (tid < M2) wl[tid] = g.wL2[tid];
+    __syncthreads();
+
+    cplx x[16];
+    auto tile_q1 = [&](int L) { const int k = L / g.n_ct; return xcd_map ? k * 8 + xcd : k; };
+    auto src_ptr = [&](int L) {
+        const int Lc = min(L, ntiles - 1);
+        const int b_ = min((Lc % g.n_ct) * CT + ctl, g.batch - 1);
+        const int r_ = min(rr, g.npi - 1);
+        return g.T + ((long long)b_ * g.npi + r_) * m + (long long)tile_q1(Lc) * M2 + o;
+    };
+    auto in_active = [&](int L) { return L < ntiles && (L % g.n_ct) * CT + ctl < g.batch && rr < g.npi; };
+
+    // forward row DFT: x[n1] = row[o + 8*n1] -> radix 16 over n1 (k1) -> x W128^(o*k1) -> z[k1][o];
+    // then this lane takes k1 = o and o+8: radix 8 over o -> S[row][q2 = k1 + 16*k2]
+#define PZ_MID_FWD(ACTIVE)                                                                        \
+    {                                                                                             \
+        if (!(ACTIVE)) {                                                                          \
+            _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1) x[n1] = make_double2(0.0, 0.0);     \
+        }                                                                                         \
+        Bfly<16, false>::run(x);                                                                  \
+        _Pragma("unroll") for (int k1 = 0; k1 < 16; ++k1) {                                       \
+            cplx v = x[k1];                                                                       \
+            if (k1 > 0) v = cmul(v, wl[o * k1]);                                                  \
+            rowbuf[k1 * 9 + o] = v;                                                               \
+        }                                                                                         \
+        row_sync();                                                                               \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                           \
+            _Pragma("unroll") for (int oo = 0; oo < 8; ++oo) x[8 * h + oo] = rowbuf[(o + 8 * h) * 9 + oo]; \
+        }                                                                                         \
+        Bfly<8, false>::run(x);                                                                   \
+        Bfly<8, false>::run(x + 8);                                                               \
+        row_sync();                                                                               \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                           \
+            _Pragma("unroll") for (int k2 = 0; k2 < 8; ++k2) rowbuf[o + 8 * h + 16 * k2] = x[8 * h + k2]; \
+        }                                                                                         \
+        lds_barrier();                                                                            \
+    }
+
+    cplx twn = make_double2(0.0, 0.0);
+    {
+        const cplx* src = src_ptr(w);
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) x[n1] = src[8 * n1];
+        twn = g.tw12t[(long long)tile_q1(w) * M2 + (tid & (M2 - 1))];
+    }
+    if (tid < M2) twrow[tid] = twn;
+    const int vq2 = tid & (M2 - 1), vcg = tid / M2;
+    const int rot = g.row_max > 0 ? (w % g.row_max) : 0;
+    cplx pn[NC];
+#define PZ_MID_P0(LT)                                                                                  \
+    {                                                                                                  \
+        const long long base_ = (long long)tile_q1(min((LT), ntiles - 1)) * g.nrows * g.ncols;         \
+        _Pragma("unroll") for (int j = 0; j < NC; ++j)                                                 \
+            pn[j] = g.P[(base_ + (long long)rot * g.ncols + min(vcg * NC + j, g.ncomp - 1)) * M2 + vq2];  \
+    }
+    PZ_MID_P0(w)
+    PZ_MID_FWD(in_active(w))
+
+    for (int L = w; L < ntiles; L += W) {
+        const int q1 = tile_q1(L);
+        const int b = (L % g.n_ct) * CT + ctl;
+        {
+            const int q2 = vq2, cg = vcg;
+            cplx acc[CT][NC];
+#pragma unroll
+            for (int i = 0; i < CT; ++i)
+#pragma unroll
+                for (int j = 0; j < NC; ++j) acc[i][j] = make_double2(0.0, 0.0);
+            const cplx* pp[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const int c = min(cg * NC + j, g.ncomp - 1);
+                pp[j] = g.P + ((long long)q1 * g.nrows * g.ncols + c) * M2 + q2;
+            }
+            const long long prow = (long long)g.ncols * M2;
+            for (int it = 0; it < g.row_max; ++it) {
+                int r = it + rot;
+                if (r >= g.row_max) r -= g.row_max;
+                cplx pv[NC];
+#pragma unroll
+                for (int j = 0; j < NC; ++j) pv[j] = pn[j];
+                {
+                    int rn = r + 1;
+                    if (rn >= g.row_max) rn = 0;
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) pn[j] = pp[j][(long long)rn * prow];
+                }
+#pragma unroll
+                for (int i = 0; i < CT; ++i) {
+                    const cplx av = lds[(i * 16 + r) * RS + q2];
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) {
+                        acc[i][j].x = __builtin_fma(av.x, pv[j].x, acc[i][j].x);
+                        acc[i][j].x = __builtin_fma(-av.y, pv[j].y, acc[i][j].x);
+                        acc[i][j].y = __builtin_fma(av.x, pv[j].y, acc[i][j].y);
+                        acc[i][j].y = __builtin_fma(av.y, pv[j].x, acc[i][j].y);
+                    }
+                }
+            }
+            lds_barrier();
+#pragma unroll
+            for (int i = 0; i < CT; ++i)
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {
+                    const int c = cg * NC + j;
+                    lds[(i * 16 + c) * RS + q2] = (c < g.ncomp) ? acc[i][j] : make_double2(0.0, 0.0);
+                }
+            lds_barrier();
+        }
+        {
+            const cplx* src = src_ptr(L + W);
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) x[n1] = src[8 * n1];
+            twn = g.tw12t[(long long)tile_q1(min(L + W, ntiles - 1)) * M2 + (tid & (M2 - 1))];
+        }
+        // inverse row DFT: this lane owns k1 = o and o+8: radix 8 over k2 -> z[k1][oo] x conj W128^(oo*k1);
+        // then lane o gathers z[k1][o] over k1: radix 16 -> row[o + 8*n1]
+        {
+            cplx u[16];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) u[8 * h + k2] = rowbuf[o + 8 * h + 16 * k2];
+            Bfly<8, true>::run(u);
+            Bfly<8, true>::run(u + 8);
+            row_sync();
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int oo = 0; oo < 8; ++oo) {
+                    cplx v = u[8 * h + oo];
+                    const int k1 = o + 8 * h;
+                    if (k1 > 0 && oo > 0) v = cmulc(v, wl[oo * k1]);
+                    rowbuf[k1 * 9 + oo] = v;
+                }
+            row_sync();
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) u[k1] = rowbuf[k1 * 9 + o];
+            Bfly<16, true>::run(u);
+            const bool active = b < g.batch && rr < g.npo;
+            cplx* dst = active ? g.T2 + ((long long)b * g.npo + rr) * m + (long long)q1 * M2 + o
+                               : g.dummy + (long long)tid * 16 * 16 + o;
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) dst[8 * n1] = cmulc(u[n1], twrow[o + 8 * n1]);
+        }
+        lds_barrier();
+        if (tid < M2) twrow[tid] = twn;
+        PZ_MID_P0(L + W)
+        PZ_MID_FWD(in_active(L + W))
+    }
+#undef PZ_MID_FWD
+#undef PZ_MID_P0
+}
+
 // standard device VmpPMat  P[p][q1 + m1*q2]  ->  P'[q1][p][q2]   (p = r*ncols + c), 16x16 tiles through LDS
 __global__ void __launch_bounds__(256)
 k_permute_pmat(const cplx* __restrict__ P, cplx* __restrict__ Pp, int npolys, int m1, int m2) {
