@@ -165,30 +165,42 @@ k_mid(MidArgs g) {
             const long long prow = (long long)g.ncols * M2;
             // key row r+1 travels while row r is consumed (row 0 was requested before the forward pass; deeper
             // prefetch spills at 256 VGPRs and did not pay)
-            for (int it = 0; it < g.row_max; ++it) {
-                int r = it + rot;
-                if (r >= g.row_max) r -= g.row_max;
-                cplx pv[NC];
-#pragma unroll
-                for (int j = 0; j < NC; ++j) pv[j] = pn[j];
-                {
-                    int rn = r + 1;
-                    if (rn >= g.row_max) rn = 0;
-#pragma unroll
-                    for (int j = 0; j < NC; ++j) pn[j] = pp[j][(long long)rn * prow];
-                }
-#pragma unroll
-                for (int i = 0; i < CT; ++i) {
-                    const cplx av = lds[(i * 16 + r) * RS + q2];
-#pragma unroll
-                    for (int j = 0; j < NC; ++j) {
-                        acc[i][j].x = __builtin_fma(av.x, pv[j].x, acc[i][j].x);
-                        acc[i][j].x = __builtin_fma(-av.y, pv[j].y, acc[i][j].x);
-                        acc[i][j].y = __builtin_fma(av.x, pv[j].y, acc[i][j].y);
-                        acc[i][j].y = __builtin_fma(av.y, pv[j].x, acc[i][j].y);
-                    }
-                }
+            // Two register slots in ping-pong (pn = the row about to be used, pb = the one after): written so that no
+            // register copy sits between a load and its use — a copy makes the compiler wait for the load at the end of
+            // the iteration that issued it, which exposed the full L2 latency on every row.
+            cplx pb[NC];
+#define PZ_LOADROW(DST, IT)                                                                     \
+    {                                                                                           \
+        int r_ = (IT) + rot;                                                                    \
+        r_ -= (r_ >= g.row_max) ? g.row_max : 0;                                                \
+        r_ -= (r_ >= g.row_max) ? g.row_max : 0;                                                \
+        const long long off_ = (long long)r_ * prow;                                            \
+        _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = pp[j][off_];                    \
+    }
+#define PZ_USEROW(SRC, IT)                                                                      \
+    {                                                                                           \
+        int r_ = (IT) + rot;                                                                    \
+        r_ -= (r_ >= g.row_max) ? g.row_max : 0;                                                \
+        _Pragma("unroll") for (int i = 0; i < CT; ++i) {                                        \
+            const cplx av = lds[(i * 16 + r_) * RS + q2];                                       \
+            _Pragma("unroll") for (int j = 0; j < NC; ++j) {                                    \
+                acc[i][j].x = __builtin_fma(av.x, SRC[j].x, acc[i][j].x);                       \
+                acc[i][j].x = __builtin_fma(-av.y, SRC[j].y, acc[i][j].x);                      \
+                acc[i][j].y = __builtin_fma(av.x, SRC[j].y, acc[i][j].y);                       \
+                acc[i][j].y = __builtin_fma(av.y, SRC[j].x, acc[i][j].y);                       \
+            }                                                                                   \
+        }                                                                                       \
+    }
+            int it = 0;
+            for (; it + 1 < g.row_max; it += 2) {
+                PZ_LOADROW(pb, it + 1)
+                PZ_USEROW(pn, it)
+                PZ_LOADROW(pn, it + 2)   // wraps to a valid row at the end; that load is simply unused
+                PZ_USEROW(pb, it + 1)
             }
+            if (it < g.row_max) PZ_USEROW(pn, it)
+#undef PZ_LOADROW
+#undef PZ_USEROW
             lds_barrier();  // every a value has been read: the tile can be overwritten with the products
 #pragma unroll
             for (int i = 0; i < CT; ++i)

@@ -350,3 +350,18 @@ def test_fused_tail_shapes(mods, n):
         assert np.array_equal(got, want), (n, res_size)
         got, want = _run_glwe_op(hip, ref, True, n, 2, 1, 3, 14, 4, 14, 3, 1, res_size, 14, batch=3, seed=n + res_size + 1)
         assert np.array_equal(got, want), (n, res_size)
+
+
+def test_wide_plan_external_product_n65536(monkeypatch):
+    """The alternative four-step split (m1 = 256, m2 = 128: k_mid128, four ciphertexts per tile) gives the same bits."""
+    from oracle.ref import RefModule
+    from poulpy_amd.hal import Module
+    monkeypatch.setenv("POULPY_DBG_SPLIT", "w")
+    n = 65536
+    ref, hip = RefModule(n), Module(n)
+    monkeypatch.delenv("POULPY_DBG_SPLIT")
+    got, want = _run_glwe_op(hip, ref, False, n, 1, 1, 8, 12, 8, 12, 8, 1, 8, 12, batch=5, seed=99)
+    assert np.array_equal(got, want)
+    got, want = _run_glwe_op(hip, ref, True, n, 1, 1, 8, 12, 8, 12, 8, 1, 6, 12, batch=3, seed=98)
+    assert np.array_equal(got, want)
+    hip.close()
