@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=128, help="ciphertexts per GPU per step")
     ap.add_argument("--chunk", type=int, default=0, help="ciphertexts per pipeline wave (0 = auto)")
+    ap.add_argument("--op", choices=("external_product", "keyswitch"), default="external_product",
+                    help="keyswitch = BASELINE configs[2] (secondary metric; GGLWE rows 8, cols_in 1, cols_out 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -131,7 +133,9 @@ def main():
 
     # evaluation key: synthetic MatZnx (same distribution as test_suite/vmp.rs:200-201), prepared on rank 0,
     # broadcast over RCCL — the only collective
-    key_elems = N * DNUM * cols * cols * SIZE
+    ks = args.op == "keyswitch"
+    cols_in = RANK_GLWE if ks else cols
+    key_elems = N * DNUM * cols_in * cols * SIZE
     pmat = torch.empty(key_elems, dtype=torch.float64, device=dev)
     if rank == 0:
         g = torch.Generator(device=dev)
@@ -139,7 +143,7 @@ def main():
         mat = torch.randint(-half, half, (key_elems,), dtype=torch.int64, device=dev, generator=g)
         torch.cuda.synchronize()
         mod._ck(mod.lib.pz_vmp_prepare(mod.handle, C.c_void_p(pmat.data_ptr()), C.c_void_p(mat.data_ptr()),
-                                       C.c_size_t(DNUM), C.c_size_t(cols), C.c_size_t(cols), C.c_size_t(SIZE)))
+                                       C.c_size_t(DNUM), C.c_size_t(cols_in), C.c_size_t(cols), C.c_size_t(SIZE)))
         mod.sync()
         del mat
     if distributed:
@@ -158,7 +162,10 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        mod.glwe_external_product_batched(res_ptr, a_ptr, key_ptr, params, nct)
+        if ks:
+            mod.glwe_keyswitch_batched(res_ptr, a_ptr, key_ptr, params, nct)
+        else:
+            mod.glwe_external_product_batched(res_ptr, a_ptr, key_ptr, params, nct)
 
     for _ in range(args.warmup):
         step()
@@ -193,7 +200,7 @@ def main():
     if rank == 0:
         total_units = args.batch * world * args.steps
         value = total_units / dt
-        b_unit = algorithmic_bytes_per_unit(args.batch)
+        b_unit = algorithmic_bytes_per_unit(args.batch) if not ks else (2 * cols * SIZE * N * 8 + DNUM * cols_in * cols * SIZE * N * 8 / args.batch)
         roof = None
         if stats:
             dom = max(stats.items(), key=lambda kv: kv[1][1])
@@ -209,15 +216,17 @@ def main():
                         "pipeline_achieved": value / world * b_unit / 1e9,
                         "kernel_ms": {k: round(v[1], 3) for k, v in stats.items() if v[0]}}
         line = {
-            "metric": "GGSW external-products/sec (N=2^16, 8 limbs)", "value": value, "unit": "external-products/s",
+            "metric": ("GLWE key-switches/sec (N=2^16, 8 limbs)" if ks else "GGSW external-products/sec (N=2^16, 8 limbs)"),
+            "value": value, "unit": ("key-switches/s" if ks else "external-products/s"),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "GLWE(rank 1) x GGSW external product, N=65536, 8 limbs, base2k=12, dnum=8, dsize=1",
+            "config": {"workload": ("GLWE(rank 1) key-switch via GGLWE VmpPMat, N=65536, 8 limbs, base2k=12, dnum=8, dsize=1" if ks else
+                                    "GLWE(rank 1) x GGSW external product, N=65536, 8 limbs, base2k=12, dnum=8, dsize=1"),
                        "batch_per_gpu": args.batch, "parallelism": f"batch-sharded x{world}, key broadcast (RCCL)",
                        "output_digits_balanced": ok},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not ks:
             try:
                 # the port scales poorly past one socket's worth of threads on this host; report the better of two thread counts
                 cands = [cpu_baseline(max_threads=t) for t in (64, 128) if t <= (os.cpu_count() or 1)] or [cpu_baseline()]

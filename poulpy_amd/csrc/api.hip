@@ -139,22 +139,22 @@ static int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, i
     g.nlimbs = nlimbs; g.ncols = ncols; g.res_cols = res_cols; g.res_size = res_size;
     g.small_cols = small_cols; g.small_size = small_size; g.base2k = base2k; g.m2 = pl.m2;
     g.tw1inv = M->tw1inv; g.wL1 = M->wL1; g.margin = M->margin;
+    const bool has_small = small != nullptr;
+// one instantiation per (probe, row-major, body add) combination actually requested
+#define PZ_TAIL_ONE(A, B, C, P_, R_, S_)                                                                        \
+    if (M->probe == P_ && rowmajor == R_ && has_small == S_) {                                                  \
+        PZ_TRY(set_lds(k_inv_tail<A, B, C, P_, R_, S_>, lds));                                                  \
+        hipLaunchKernelGGL((k_inv_tail<A, B, C, P_, R_, S_>), dim3(blocks), dim3((A + B) * C), lds, M->stream, g); \
+    }
+#define PZ_TAIL_LAUNCH(A, B, C)                                                                                 \
+    PZ_TAIL_ONE(A, B, C, false, false, false) PZ_TAIL_ONE(A, B, C, false, false, true)                          \
+    PZ_TAIL_ONE(A, B, C, false, true, false) PZ_TAIL_ONE(A, B, C, false, true, true)                            \
+    PZ_TAIL_ONE(A, B, C, true, false, false) PZ_TAIL_ONE(A, B, C, true, false, true)                            \
+    PZ_TAIL_ONE(A, B, C, true, true, false) PZ_TAIL_ONE(A, B, C, true, true, true)
 #define X(A, B, C)                                                                                              \
     if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
         const size_t lds = ((size_t)2 * (A + 1) * C * B + 2 * A * B) * sizeof(cplx);                  \
-        if (M->probe && rowmajor) {                                                                             \
-            PZ_TRY(set_lds(k_inv_tail<A, B, C, true, true>, lds));                                              \
-            hipLaunchKernelGGL((k_inv_tail<A, B, C, true, true>), dim3(blocks), dim3((A + B) * C), lds, M->stream, g); \
-        } else if (M->probe) {                                                                                  \
-            PZ_TRY(set_lds(k_inv_tail<A, B, C, true, false>, lds));                                             \
-            hipLaunchKernelGGL((k_inv_tail<A, B, C, true, false>), dim3(blocks), dim3((A + B) * C), lds, M->stream, g); \
-        } else if (rowmajor) {                                                                                  \
-            PZ_TRY(set_lds(k_inv_tail<A, B, C, false, true>, lds));                                             \
-            hipLaunchKernelGGL((k_inv_tail<A, B, C, false, true>), dim3(blocks), dim3((A + B) * C), lds, M->stream, g); \
-        } else {                                                                                                \
-            PZ_TRY(set_lds(k_inv_tail<A, B, C, false, false>, lds));                                            \
-            hipLaunchKernelGGL((k_inv_tail<A, B, C, false, false>), dim3(blocks), dim3((A + B) * C), lds, M->stream, g); \
-        }                                                                                                       \
+        PZ_TAIL_LAUNCH(A, B, C)                                                                                 \
         PZ_HIP(hipGetLastError());                                                                              \
         return PZ_OK;                                                                                           \
     }

@@ -380,8 +380,8 @@ struct TailArgs {
 //                            double-buffered exchange, and the loads of limb j-2 behind that.
 // The two roles run concurrently (one barrier per limb), so the HBM latency of the next limbs hides
 // behind the arithmetic of the current one, and each role only pays for its own registers.
-template <int R1, int R2, int CB, bool PROBE, bool ROWMAJOR = false>
-__global__ void __launch_bounds__((R1 + R2) * CB, ((R1 + R2) * CB >= 512 ? 2 : 3))
+template <int R1, int R2, int CB, bool PROBE, bool ROWMAJOR = false, bool SMALL = false>
+__global__ void __launch_bounds__((R1 + R2) * CB, (((R1 + R2) * CB >= 512 || SMALL) ? 2 : 3))
 k_inv_tail(TailArgs g) {
     constexpr int M1 = R1 * R2;
     constexpr int XCH = (R1 + 1) * CB * R2;  // cplx per exchange buffer
@@ -462,6 +462,19 @@ k_inv_tail(TailArgs g) {
     __syncthreads();  // matches the prologue iteration of role A'
     for (int j = L - 1; j >= 0; --j) {
         const cplx* buf = xch + (j & 1) * XCH;
+        // key-switch body limb: requested first so that its latency hides behind the butterfly
+        long long sm[SMALL ? 2 * R1 : 1];
+        if (SMALL && small_col && j < g.small_size) {
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) {
+                const long long idx = (long long)(b_o + R2 * n1) * g.m2 + c0 + b_c;
+                sm[2 * n1] = small_col[(long long)j * small_ls + idx];
+                sm[2 * n1 + 1] = small_col[(long long)j * small_ls + idx + m];
+            }
+        } else if (SMALL) {
+#pragma unroll
+            for (int t = 0; t < 2 * R1; ++t) sm[t] = 0;
+        }
         cplx v[R1];
 #pragma unroll
         for (int k1 = 0; k1 < R1; ++k1) v[k1] = buf[(b_o * CB + b_c) * (R1 + 1) + k1];
@@ -470,54 +483,47 @@ k_inv_tail(TailArgs g) {
         const bool first = j == L - 1;
         const bool add_small = small_col && j < g.small_size;
         double worst = 0.0;
-        // round first (branch-free), remember whether any value leaves the fast-conversion range
-        double rr[2 * R1];
+        // scale/untwist in place and bound the magnitudes: below 2^51 the 3-instruction conversion is exact
         double big = 0.0;
 #pragma unroll
         for (int n1 = 0; n1 < R1; ++n1) {
-            const cplx w = cmul(v[n1], twi[b_o + R2 * n1]);
-            rr[2 * n1] = round_half_away(w.x);
-            rr[2 * n1 + 1] = round_half_away(w.y);
-            big = fmax(big, fmax(fabs(rr[2 * n1]), fabs(rr[2 * n1 + 1])));
-            if (PROBE) {
-                worst = fmax(worst, fabs(w.x - rr[2 * n1]));
-                worst = fmax(worst, fabs(w.y - rr[2 * n1 + 1]));
-            }
+            v[n1] = cmul(v[n1], twi[b_o + R2 * n1]);
+            big = fmax(big, fmax(fabs(v[n1].x), fabs(v[n1].y)));
         }
-        long long xi[2 * R1];
-        if (big < 2251799813685248.0) {  // 2^51 (false for NaN too): 3-instruction conversion
-#pragma unroll
-            for (int t = 0; t < 2 * R1; ++t) xi[t] = fast_i64_from_integral(rr[t]);
+        const unsigned long long half = 1ull << (k - 1), mask = (1ull << k) - 1;
+        // One pass per coefficient: round, convert, (+ body), carry step, store.  digit(x) = ((x + 2^(k-1)) mod 2^k) -
+        // 2^(k-1), carry(x) = (x + 2^(k-1)) >> k: the values of the reference's shift pairs
+        // (reference/znx/normalization.rs:4-11,24-41,107-129,179-221) with fewer 64-bit operations.
+#define PZ_TAIL_COEFFS(CONVERT)                                                                               \
+    _Pragma("unroll") for (int n1 = 0; n1 < R1; ++n1) {                                                      \
+        const int j1 = b_o + R2 * n1;                                                                        \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                      \
+            const long long idx = (long long)j1 * g.m2 + c0 + b_c + (h ? m : 0);                             \
+            const double val = h ? v[n1].y : v[n1].x;                                                        \
+            const double r = round_half_away(val);                                                           \
+            if (PROBE) worst = fmax(worst, fabs(val - r));                                                   \
+            long long x = CONVERT(r);                                                                        \
+            if (SMALL && add_small) x = (long long)((unsigned long long)x + (unsigned long long)sm[SMALL ? 2 * n1 + h : 0]); \
+            long long& cy = carry[2 * n1 + h];                                                               \
+            const unsigned long long y = (unsigned long long)x + half;                                       \
+            const long long d = (long long)(y & mask) - (long long)half;                                     \
+            const long long cr = (long long)y >> k;                                                          \
+            if (first && !writes) {                                                                          \
+                cy = cr;                                                                                     \
+            } else {                                                                                         \
+                const unsigned long long y2 = (unsigned long long)d + (unsigned long long)cy + half;         \
+                const long long x1 = (long long)(y2 & mask) - (long long)half;                               \
+                cy = (long long)((unsigned long long)cr + (unsigned long long)((long long)y2 >> k));         \
+                if (writes) res_col[(long long)j * res_ls + idx] = x1;                                       \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+        if (big < 2251799813685247.0) {  // 2^51 - 1 (false for NaN too)
+            PZ_TAIL_COEFFS(fast_i64_from_integral)
         } else {
-#pragma unroll
-            for (int t = 0; t < 2 * R1; ++t) xi[t] = sat_i64_from_integral(rr[t]);
+            PZ_TAIL_COEFFS(sat_i64_from_integral)
         }
-#pragma unroll
-        for (int n1 = 0; n1 < R1; ++n1) {
-            const int j1 = b_o + R2 * n1;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const long long idx = (long long)j1 * g.m2 + c0 + b_c + (h ? m : 0);
-                long long x = xi[2 * n1 + h];
-                if (add_small) x = (long long)((unsigned long long)x + (unsigned long long)small_col[(long long)j * small_ls + idx]);
-                // znx_normalize_{first,middle}_step(_carry_only), reference/znx/normalization.rs:24-41,107-129,179-221,
-                // with digit(x) = ((x + 2^(k-1)) mod 2^k) - 2^(k-1) and carry(x) = (x + 2^(k-1)) >> k (same values as the
-                // reference's shift pairs, fewer 64-bit operations)
-                long long& cy = carry[2 * n1 + h];
-                const unsigned long long half = 1ull << (k - 1), mask = (1ull << k) - 1;
-                const unsigned long long y = (unsigned long long)x + half;
-                const long long d = (long long)(y & mask) - (long long)half;
-                const long long cr = (long long)y >> k;
-                if (first && !writes) {
-                    cy = cr;
-                } else {
-                    const unsigned long long y2 = (unsigned long long)d + (unsigned long long)cy + half;
-                    const long long x1 = (long long)(y2 & mask) - (long long)half;
-                    cy = (long long)((unsigned long long)cr + (unsigned long long)((long long)y2 >> k));
-                    if (writes) res_col[(long long)j * res_ls + idx] = x1;
-                }
-            }
-        }
+#undef PZ_TAIL_COEFFS
         if (PROBE) atomicMax(g.margin, (unsigned long long)__double_as_longlong(worst));
         __syncthreads();
     }
