@@ -218,6 +218,9 @@ int pz_module_set_chunk(pz_module* m, size_t cts_per_chunk);
 /* Kernel-fusion knobs of the batched GLWE ops (both on by default; the unfused path is the per-op one,
  * kept selectable so that tests can compare the two bit for bit). */
 int pz_module_set_fusion(pz_module* m, int fuse_tail, int fuse_mid);
+/* Diagnostic only: run a subset of the fused pipeline's stages (bit 0 pass 1, bit 1 middle, bit 2 tail); outputs are
+ * meaningless unless mask == 7.  Used by tools/dbg to measure stage overlap. */
+int pz_module_set_debug_stages(pz_module* m, int mask);
 
 /* batched primitives (device pointers; object b at ptr + b*len(object)) */
 int pz_vec_znx_dft_apply_batched(pz_module* m, size_t batch, size_t step, size_t offset,

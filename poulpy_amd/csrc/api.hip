@@ -200,15 +200,23 @@ static int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cp
     static const int groups = getenv("POULPY_DBG_MID_GROUPS") ? atoi(getenv("POULPY_DBG_MID_GROUPS")) : 1;
     g.groups = groups;
     if (M->plan.m2 == 128) {
-        constexpr int CT = 4;
-        g.n_ct = (batch + CT - 1) / CT;
-        const size_t lds = ((size_t)CT * 16 * 16 * 9 + 256) * sizeof(cplx);
-        KTimer kt(M, PZ_K_FUSED_MID);
-        PZ_TRY(set_lds(k_mid128<CT>, lds));
+        static const int ct128 = getenv("POULPY_DBG_MID_CT") ? atoi(getenv("POULPY_DBG_MID_CT")) : 4;  // diagnostic knob
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, M->device);
-        const int grid = std::min(ncu, g.m1 * g.n_ct);
-        hipLaunchKernelGGL((k_mid128<CT>), dim3(grid), dim3(CT * 128), lds, M->stream, g);
+        KTimer kt(M, PZ_K_FUSED_MID);
+        if (ct128 == 2) {
+            constexpr int CT = 2;
+            g.n_ct = (batch + CT - 1) / CT;
+            const size_t lds = ((size_t)CT * 16 * 16 * 9 + 256) * sizeof(cplx);
+            PZ_TRY(set_lds(k_mid128<CT>, lds));
+            hipLaunchKernelGGL((k_mid128<CT>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(CT * 128), lds, M->stream, g);
+        } else {
+            constexpr int CT = 4;
+            g.n_ct = (batch + CT - 1) / CT;
+            const size_t lds = ((size_t)CT * 16 * 16 * 9 + 256) * sizeof(cplx);
+            PZ_TRY(set_lds(k_mid128<CT>, lds));
+            hipLaunchKernelGGL((k_mid128<CT>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(CT * 128), lds, M->stream, g);
+        }
         PZ_HIP(hipGetLastError());
         return PZ_OK;
     }
@@ -468,6 +476,11 @@ int pz_module_set_fusion(pz_module* M, int fuse_tail, int fuse_mid) {
     if (!M) return fail(PZ_ERR_INVALID, "null module");
     M->fuse_tail = fuse_tail != 0;
     M->fuse_mid = fuse_mid != 0;
+    return PZ_OK;
+}
+int pz_module_set_debug_stages(pz_module* M, int mask) {
+    if (!M) return fail(PZ_ERR_INVALID, "null module");
+    M->dbg_stages = mask;
     return PZ_OK;
 }
 int pz_module_set_margin_probe(pz_module* M, int enable) {
@@ -1151,7 +1164,7 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
         cplx* mid_dummy = (cplx*)base;
         // the key arrives in the standard device layout; its row-sliced copy is rebuilt per call (2 x 128 MiB of
         // traffic at the metric shape, ~4 % of a 128-ciphertext call) so that no stale copy can ever be used
-        PZ_TRY(launch_permute_pmat(M, pmat, Pp, nrows * ncols));
+        if (M->dbg_stages & 2) PZ_TRY(launch_permute_pmat(M, pmat, Pp, nrows * ncols));
         for (size_t b0 = 0; b0 < batch; b0 += chunk) {
             const int nb = (int)std::min(chunk, batch - b0);
             DV av{(void*)(a + (long long)b0 * a_ct), a_ct, s.cols_a, (int)p->a_size};
@@ -1164,9 +1177,9 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
             const int a_size = av.size;
             const int a_col0 = ks ? 1 : 0;
             PolyMap sm{a_size, s.cols_in, av.bs, (long long)av.cols * n, n, n * a_col0};
-            PZ_TRY(launch_fwd_pass1(M, nb * npi, (const long long*)av.p, sm, T, true));
-            PZ_TRY(launch_mid(M, nb, T, T2, Pp, npi, npo, nrows, ncols, mid_dummy));
-            PZ_TRY(launch_inv_tail(M, nb, T2, ksz, s.cols_out, (long long*)(res + (long long)b0 * res_ct), res_ct, s.cols_out, (int)p->res_size,
+            if (M->dbg_stages & 1) PZ_TRY(launch_fwd_pass1(M, nb * npi, (const long long*)av.p, sm, T, true));
+            if (M->dbg_stages & 2) PZ_TRY(launch_mid(M, nb, T, T2, Pp, npi, npo, nrows, ncols, mid_dummy));
+            if (M->dbg_stages & 4) PZ_TRY(launch_inv_tail(M, nb, T2, ksz, s.cols_out, (long long*)(res + (long long)b0 * res_ct), res_ct, s.cols_out, (int)p->res_size,
                                    ks ? (const long long*)av.p : nullptr, av.bs, av.cols, a_size, (int)p->res_base2k, true));
         }
         return PZ_OK;

@@ -119,11 +119,6 @@ __device__ __forceinline__ long long fast_i64_from_integral(double r) {
     return __double_as_longlong(r + magic) - __double_as_longlong(magic);
 }
 
-template <int A, int B>
-struct MaxOf {
-    static constexpr int v = A > B ? A : B;
-};
-
 // =================================================================================
 // forward pass 1: i64 coefficients -> T[j2][q1]
 //   grid.x = npolys * (m2/CB); block = max(R1,R2)*CB threads; LDS (R1+1)*CB*R2 cplx

@@ -116,6 +116,7 @@ struct pz_module {
     unsigned long long* margin = nullptr;  // device word, bits of max |x-round(x)|
     bool probe = false;
     size_t chunk = 0;
+    int dbg_stages = 7;  // diagnostic: bit 0 pass 1, bit 1 middle, bit 2 tail of the fused pipeline (results invalid unless 7)
     bool fuse_tail = true, fuse_mid = true;  // kernel-fusion knobs of the batched GLWE ops (tests run both settings)
     // per-kernel-class HIP-event timing (bench.py's roofline leg); off by default
     bool timing = false;
