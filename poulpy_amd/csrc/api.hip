@@ -199,6 +199,12 @@ static int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cp
     g.wL2 = M->wL2; g.tw12t = M->tw12t; g.dummy = dummy;
     static const int groups = getenv("POULPY_DBG_MID_GROUPS") ? atoi(getenv("POULPY_DBG_MID_GROUPS")) : 1;
     g.groups = groups;
+    // phase stagger: workgroup w starts (w mod 4) x ~3.4 us late so that the HBM-heavy row passes of some CUs overlap
+    // the L2-heavy product phases of others (measured: middle kernel -3 %); off for the m2 = 128 form, where it did not pay
+    static const int stg = getenv("POULPY_DBG_MID_STAGGER") ? atoi(getenv("POULPY_DBG_MID_STAGGER")) : -1;
+    static const int stm = getenv("POULPY_DBG_MID_STAGGER_MOD") ? atoi(getenv("POULPY_DBG_MID_STAGGER_MOD")) : 4;
+    g.stagger = stg >= 0 ? stg : (M->plan.m2 == 128 ? 0 : 1);
+    g.stagger_mod = std::max(1, stm);
     if (M->plan.m2 == 128) {
         static const int ct128 = getenv("POULPY_DBG_MID_CT") ? atoi(getenv("POULPY_DBG_MID_CT")) : 4;  // diagnostic knob
         int ncu = 256;
@@ -209,7 +215,10 @@ static int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cp
             g.n_ct = (batch + CT - 1) / CT;
             const size_t lds = ((size_t)CT * 16 * 16 * 9 + 256) * sizeof(cplx);
             PZ_TRY(set_lds(k_mid128<CT>, lds));
-            hipLaunchKernelGGL((k_mid128<CT>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(CT * 128), lds, M->stream, g);
+            static const int percu = getenv("POULPY_DBG_MID_PERCU") ? atoi(getenv("POULPY_DBG_MID_PERCU")) : 2;
+            static bool once = false;
+            if (!once && getenv("POULPY_DBG_VERBOSE")) { once = true; int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mid128<CT>, CT * 128, lds); fprintf(stderr, "k_mid128<2>: %d blocks/CU at lds=%zu\n", nb, lds); }
+            hipLaunchKernelGGL((k_mid128<CT>), dim3(std::min(ncu * percu, g.m1 * g.n_ct)), dim3(CT * 128), lds, M->stream, g);
         } else {
             constexpr int CT = 4;
             g.n_ct = (batch + CT - 1) / CT;

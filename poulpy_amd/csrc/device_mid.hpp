@@ -32,6 +32,7 @@ struct MidArgs {
     const cplx* tw12t;  // [q1][j2]
     cplx* dummy;        // >= 512*256 points of scratch: where rows without an output polynomial store
     int groups;         // row groups per XCD (see k_mid)
+    int stagger, stagger_mod;  // start delay of workgroup w: ((w >> 3) % stagger_mod) * stagger * s_sleep(127)
 };
 
 // LDS traffic between the 16 lanes that own one row needs no workgroup barrier: the lanes are in one wave,
@@ -82,6 +83,11 @@ k_mid(MidArgs g) {
     if (w >= ntiles) return;
     if (tid < M2) wl[tid] = g.wL2[tid];
     __syncthreads();
+    // phase stagger (see launch_mid): workgroups start up to (stagger_mod-1) x stagger x 8128 clocks apart
+    if (g.stagger > 0) {
+        const int k = (blockIdx.x >> 3) % g.stagger_mod;
+        for (int i = 0; i < k * g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     // Loop shape (software pipeline, one tile per iteration):
     //   prologue : loads(t0); forward row DFT(t0) -> S
@@ -257,8 +263,10 @@ k_mid(MidArgs g) {
 // (16 points each: one radix-16 butterfly, then two radix-8 butterflies), so a tile of FOUR ciphertexts
 // x 16 polynomials fits in LDS (144 KiB) and every key value fetched serves four ciphertexts instead of
 // two.  512 threads = 64 rows x 8 lanes; product phase: 128 points x 4 groups of 4 outputs.
-// Measured (round 1): middle kernel 13 % faster than the m2 = 256 form, but pass 1 / tail at m1 = 256 are
-// 5-8 % slower, so the default plan stays m1 = 128, m2 = 256; POULPY_DBG_SPLIT=w selects this one.
+// Measured (round 1): middle kernel 19 % faster than the m2 = 256 form (0.70 vs 0.86 ms per 128 ciphertexts: the
+// key slice is streamed from L2 half as often), but the m1 = 256 tail needs radix 16 x 16 and spills (+14 % on the
+// external product, 2x on the key switch), so the default plan stays m1 = 128, m2 = 256; POULPY_DBG_SPLIT=w
+// selects this one.  POULPY_DBG_MID_CT=2 runs it with two ciphertexts per tile and two workgroups per CU.
 // =================================================================================
 template <int CT>
 __global__ void __launch_bounds__(CT * 128)
@@ -286,6 +294,10 @@ k_mid128(MidArgs g) {
     if (w >= ntiles) return;
     if (tid < M2) wl[tid] = g.wL2[tid];
     __syncthreads();
+    if (g.stagger > 0) {
+        const int k = (blockIdx.x / 256) % g.stagger_mod;
+        for (int i = 0; i < k * g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     cplx x[16];
     auto tile_q1 = [&](int L) { const int k = L / g.n_ct; return xcd_map ? k * 8 + xcd : k; };
@@ -360,30 +372,39 @@ k_mid128(MidArgs g) {
                 pp[j] = g.P + ((long long)q1 * g.nrows * g.ncols + c) * M2 + q2;
             }
             const long long prow = (long long)g.ncols * M2;
-            for (int it = 0; it < g.row_max; ++it) {
-                int r = it + rot;
-                if (r >= g.row_max) r -= g.row_max;
-                cplx pv[NC];
-#pragma unroll
-                for (int j = 0; j < NC; ++j) pv[j] = pn[j];
-                {
-                    int rn = r + 1;
-                    if (rn >= g.row_max) rn = 0;
-#pragma unroll
-                    for (int j = 0; j < NC; ++j) pn[j] = pp[j][(long long)rn * prow];
-                }
-#pragma unroll
-                for (int i = 0; i < CT; ++i) {
-                    const cplx av = lds[(i * 16 + r) * RS + q2];
-#pragma unroll
-                    for (int j = 0; j < NC; ++j) {
-                        acc[i][j].x = __builtin_fma(av.x, pv[j].x, acc[i][j].x);
-                        acc[i][j].x = __builtin_fma(-av.y, pv[j].y, acc[i][j].x);
-                        acc[i][j].y = __builtin_fma(av.x, pv[j].y, acc[i][j].y);
-                        acc[i][j].y = __builtin_fma(av.y, pv[j].x, acc[i][j].y);
-                    }
-                }
+            cplx pb[NC];  // ping-pong with pn, as in k_mid
+#define PZ_LOADROW(DST, IT)                                                                     \
+    {                                                                                           \
+        int r_ = (IT) + rot;                                                                    \
+        r_ -= (r_ >= g.row_max) ? g.row_max : 0;                                                \
+        r_ -= (r_ >= g.row_max) ? g.row_max : 0;                                                \
+        const long long off_ = (long long)r_ * prow;                                            \
+        _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = pp[j][off_];                    \
+    }
+#define PZ_USEROW(SRC, IT)                                                                      \
+    {                                                                                           \
+        int r_ = (IT) + rot;                                                                    \
+        r_ -= (r_ >= g.row_max) ? g.row_max : 0;                                                \
+        _Pragma("unroll") for (int i = 0; i < CT; ++i) {                                        \
+            const cplx av = lds[(i * 16 + r_) * RS + q2];                                       \
+            _Pragma("unroll") for (int j = 0; j < NC; ++j) {                                    \
+                acc[i][j].x = __builtin_fma(av.x, SRC[j].x, acc[i][j].x);                       \
+                acc[i][j].x = __builtin_fma(-av.y, SRC[j].y, acc[i][j].x);                      \
+                acc[i][j].y = __builtin_fma(av.x, SRC[j].y, acc[i][j].y);                       \
+                acc[i][j].y = __builtin_fma(av.y, SRC[j].x, acc[i][j].y);                       \
+            }                                                                                   \
+        }                                                                                       \
+    }
+            int it = 0;
+            for (; it + 1 < g.row_max; it += 2) {
+                PZ_LOADROW(pb, it + 1)
+                PZ_USEROW(pn, it)
+                PZ_LOADROW(pn, it + 2)
+                PZ_USEROW(pb, it + 1)
             }
+            if (it < g.row_max) PZ_USEROW(pn, it)
+#undef PZ_LOADROW
+#undef PZ_USEROW
             lds_barrier();
 #pragma unroll
             for (int i = 0; i < CT; ++i)
