@@ -101,8 +101,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=128, help="ciphertexts per GPU per step")
     ap.add_argument("--chunk", type=int, default=0, help="ciphertexts per pipeline wave (0 = auto)")
-    ap.add_argument("--op", choices=("external_product", "keyswitch"), default="external_product",
-                    help="keyswitch = BASELINE configs[2] (secondary metric; GGLWE rows 8, cols_in 1, cols_out 2)")
+    ap.add_argument("--op", choices=("external_product", "keyswitch", "automorphism", "automorphism_add"), default="external_product",
+                    help="keyswitch = BASELINE configs[2] (secondary metric; GGLWE rows 8, cols_in 1, cols_out 2); automorphism[_add] = "
+                         "glwe_automorphism[_add] with Galois element 5 on the same key shape (CKKS-rotate shape of configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -133,7 +134,8 @@ def main():
 
     # evaluation key: synthetic MatZnx (same distribution as test_suite/vmp.rs:200-201), prepared on rank 0,
     # broadcast over RCCL — the only collective
-    ks = args.op == "keyswitch"
+    ks = args.op != "external_product"
+    auto_mode = {"automorphism": "automorphism", "automorphism_add": "add"}.get(args.op)
     cols_in = RANK_GLWE if ks else cols
     key_elems = N * DNUM * cols_in * cols * SIZE
     pmat = torch.empty(key_elems, dtype=torch.float64, device=dev)
@@ -162,7 +164,9 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        if ks:
+        if auto_mode:
+            mod.glwe_automorphism_batched(res_ptr, a_ptr, key_ptr, params, 5, auto_mode, nct)
+        elif ks:
             mod.glwe_keyswitch_batched(res_ptr, a_ptr, key_ptr, params, nct)
         else:
             mod.glwe_external_product_batched(res_ptr, a_ptr, key_ptr, params, nct)
@@ -195,7 +199,10 @@ def main():
         dt = float(t.item())
 
     # cheap size-independent sanity on the timed output: digits are balanced base-2^12
-    ok = bool((res.min() >= -half).item() and (res.max() < half).item())
+    # (glwe_automorphism permutes AFTER normalizing, so a digit -2^(k-1) may come out negated: closed interval there,
+    # exactly as in the reference, automorphism/glwe_ct.rs:65-71)
+    hi_ok = (res.max() <= half) if auto_mode == "automorphism" else (res.max() < half)
+    ok = bool((res.min() >= -half).item() and hi_ok.item())
 
     if rank == 0:
         total_units = args.batch * world * args.steps
@@ -216,11 +223,13 @@ def main():
                         "pipeline_achieved": value / world * b_unit / 1e9,
                         "kernel_ms": {k: round(v[1], 3) for k, v in stats.items() if v[0]}}
         line = {
-            "metric": ("GLWE key-switches/sec (N=2^16, 8 limbs)" if ks else "GGSW external-products/sec (N=2^16, 8 limbs)"),
-            "value": value, "unit": ("key-switches/s" if ks else "external-products/s"),
+            "metric": (f"GLWE {args.op.replace('_', ' ')}s/sec (N=2^16, 8 limbs)" if auto_mode else
+                       "GLWE key-switches/sec (N=2^16, 8 limbs)" if ks else "GGSW external-products/sec (N=2^16, 8 limbs)"),
+            "value": value, "unit": (f"{args.op}s/s" if auto_mode else "key-switches/s" if ks else "external-products/s"),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("GLWE(rank 1) key-switch via GGLWE VmpPMat, N=65536, 8 limbs, base2k=12, dnum=8, dsize=1" if ks else
+            "config": {"workload": (f"glwe_{args.op} (Galois element 5) via GGLWE VmpPMat, N=65536, 8 limbs, base2k=12, dnum=8, dsize=1" if auto_mode else
+                                    "GLWE(rank 1) key-switch via GGLWE VmpPMat, N=65536, 8 limbs, base2k=12, dnum=8, dsize=1" if ks else
                                     "GLWE(rank 1) x GGSW external product, N=65536, 8 limbs, base2k=12, dnum=8, dsize=1"),
                        "batch_per_gpu": args.batch, "parallelism": f"batch-sharded x{world}, key broadcast (RCCL)",
                        "output_digits_balanced": ok},

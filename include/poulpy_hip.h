@@ -186,6 +186,20 @@ int pz_vec_znx_big_normalize(pz_module* m,
 int pz_vec_znx_big_add_small_assign(pz_module* m, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
                                     const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
 
+/* ---- X -> X^p on i64 containers (the glwe_automorphism callers) ---------------------- *
+ * hal_impl.rs:236 vec_znx_automorphism, :241 _assign_tmp_bytes, :243 _assign; :517 vec_znx_big_automorphism, :522, :524.
+ * reference/znx/automorphism.rs:1-17: res[(i*p) mod 2n] = a[i], negated when the index wraps past n; limbs of res beyond
+ * a.size are zeroed (vec_znx/automorphism.rs:32-34).  p may be negative; it must be odd (an even p is not a ring
+ * automorphism: PZ_ERR_INVALID).  The non-assign forms reject res == a.                                           */
+size_t pz_vec_znx_automorphism_assign_tmp_bytes(const pz_module* m);
+int pz_vec_znx_automorphism(pz_module* m, int64_t p, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                            const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+int pz_vec_znx_automorphism_assign(pz_module* m, int64_t p, int64_t* res, size_t cols, size_t size, size_t col);
+size_t pz_vec_znx_big_automorphism_assign_tmp_bytes(const pz_module* m);
+int pz_vec_znx_big_automorphism(pz_module* m, int64_t p, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                                const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+int pz_vec_znx_big_automorphism_assign(pz_module* m, int64_t p, int64_t* res, size_t cols, size_t size, size_t col);
+
 /* ---- batched, device-resident path (the measured one) ---------------------- *
  * Coarser boundary: unsafe trait CoreImpl<BE>, poulpy-core/src/oep/core_impl.rs:34
  *   glwe_external_product :120  (poulpy-core/src/external_product/glwe.rs:99-141,197-271)
@@ -210,7 +224,24 @@ int pz_glwe_external_product_batched(pz_module* m, int64_t* res, const int64_t* 
                                      const pz_glwe_op_params* p, size_t batch);
 int pz_glwe_keyswitch_batched(pz_module* m, int64_t* res, const int64_t* a, const double* key_pmat,
                               const pz_glwe_op_params* p, size_t batch);
-/* workspace the two calls above need for `batch` ciphertexts (bytes, device) */
+/* CoreImpl glwe_automorphism family (poulpy-core/src/automorphism/glwe_ct.rs) on `batch` ciphertexts sharing one
+ * prepared automorphism key (a GGLWE rank -> rank; `gal` = key.p(), odd):
+ *   PZ_AUTO             res = phi(keyswitch(a))                      glwe_ct.rs:51-72
+ *   PZ_AUTO_ADD         res = normalize(phi(big) + a)                :96-140
+ *   PZ_AUTO_SUB         res = normalize(phi(big) - a)                :185-229
+ *   PZ_AUTO_SUB_NEGATE  res = normalize(a - phi(big))                :231-275
+ * with big = the key-switch value before normalization (keyswitching/glwe.rs:207-239) and phi = X -> X^gal.
+ * The *_assign forms of the reference are the same calls with res == a (same layout), which is allowed: every
+ * ciphertext is fully consumed before its result is written.                                                    */
+enum { PZ_AUTO = 0, PZ_AUTO_ADD = 1, PZ_AUTO_SUB = 2, PZ_AUTO_SUB_NEGATE = 3 };
+int pz_glwe_automorphism_batched(pz_module* m, int64_t* res, const int64_t* a, const double* key_pmat,
+                                 const pz_glwe_op_params* p, int64_t gal, int mode, size_t batch);
+/* CoreImpl ggsw_external_product (poulpy-core/src/external_product/ggsw.rs:54-58): res[row][col] = a[row][col] (x) ggsw
+ * for the a_dnum * (rank+1) GLWE entries of the GGSW `a` (MatZnx layout: entries are contiguous), device pointers. */
+int pz_ggsw_external_product(pz_module* m, int64_t* res, const int64_t* a, size_t a_dnum, const double* ggsw_pmat,
+                             const pz_glwe_op_params* p);
+/* workspace the calls above need for `batch` ciphertexts (bytes, device); keyswitch: 0 external product, 1 key switch,
+ * 2 automorphism family */
 size_t pz_glwe_op_workspace_bytes(const pz_module* m, const pz_glwe_op_params* p, size_t batch, int keyswitch);
 /* Tuning knob: number of ciphertexts pushed through the three-kernel pipeline per
  * wave so that intermediates stay in the 256 MiB Infinity Cache (0 = auto). */

@@ -121,6 +121,19 @@ class Module {  // Module<FFT64Hip>, poulpy-hal/src/layouts/module.rs:97-189
     void vec_znx_big_add_small_assign(VecZnxBig& res, size_t res_col, const VecZnx& a, size_t a_col) {
         check(pz_vec_znx_big_add_small_assign(m_, res.data, res.cols, res.size, res_col, a.data, a.cols, a.size, a_col), "vec_znx_big_add_small_assign");
     }
+    // X -> X^p on i64 containers (hal_impl.rs:236-243, :517-524)
+    void vec_znx_automorphism(int64_t p, VecZnx& res, size_t res_col, const VecZnx& a, size_t a_col) {
+        check(pz_vec_znx_automorphism(m_, p, res.data, res.cols, res.size, res_col, a.data, a.cols, a.size, a_col), "vec_znx_automorphism");
+    }
+    void vec_znx_automorphism_assign(int64_t p, VecZnx& res, size_t res_col) {
+        check(pz_vec_znx_automorphism_assign(m_, p, res.data, res.cols, res.size, res_col), "vec_znx_automorphism_assign");
+    }
+    void vec_znx_big_automorphism(int64_t p, VecZnxBig& res, size_t res_col, const VecZnxBig& a, size_t a_col) {
+        check(pz_vec_znx_big_automorphism(m_, p, res.data, res.cols, res.size, res_col, a.data, a.cols, a.size, a_col), "vec_znx_big_automorphism");
+    }
+    void vec_znx_big_automorphism_assign(int64_t p, VecZnxBig& res, size_t res_col) {
+        check(pz_vec_znx_big_automorphism_assign(m_, p, res.data, res.cols, res.size, res_col), "vec_znx_big_automorphism_assign");
+    }
 
     // batched device-resident GLWE operations (CoreImpl level)
     void glwe_external_product_batched(int64_t* res, const int64_t* a, const double* ggsw, const pz_glwe_op_params& p, size_t batch) {
@@ -128,6 +141,13 @@ class Module {  // Module<FFT64Hip>, poulpy-hal/src/layouts/module.rs:97-189
     }
     void glwe_keyswitch_batched(int64_t* res, const int64_t* a, const double* key, const pz_glwe_op_params& p, size_t batch) {
         check(pz_glwe_keyswitch_batched(m_, res, a, key, &p, batch), "glwe_keyswitch_batched");
+    }
+    // mode: PZ_AUTO | PZ_AUTO_ADD | PZ_AUTO_SUB | PZ_AUTO_SUB_NEGATE (poulpy-core automorphism/glwe_ct.rs:51-275)
+    void glwe_automorphism_batched(int64_t* res, const int64_t* a, const double* key, const pz_glwe_op_params& p, int64_t gal, int mode, size_t batch) {
+        check(pz_glwe_automorphism_batched(m_, res, a, key, &p, gal, mode, batch), "glwe_automorphism_batched");
+    }
+    void ggsw_external_product(int64_t* res, const int64_t* a, size_t a_dnum, const double* ggsw, const pz_glwe_op_params& p) {
+        check(pz_ggsw_external_product(m_, res, a, a_dnum, ggsw, &p), "ggsw_external_product");
     }
 
   private:

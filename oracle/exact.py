@@ -117,3 +117,18 @@ def torus_equal(a_limbs: np.ndarray, a_base2k: int, res_limbs: np.ndarray, res_b
     diff = np.where(diff > mod // 2, mod - diff, diff)
     bound = (1 << (tot - min_prec + slack_bits)) + 1
     return bool(np.all(diff <= bound))
+
+
+def automorphism_exact(a: np.ndarray, p: int) -> np.ndarray:
+    """X -> X^p on the last axis (length n), stated directly: coefficient i moves to i*p mod 2n and changes sign when
+    that index is >= n (X^n = -1).  p odd."""
+    a = np.asarray(a)
+    n = a.shape[-1]
+    out = np.zeros_like(a)
+    for i in range(n):
+        k = (i * p) % (2 * n)
+        if k < n:
+            out[..., k] = a[..., i]
+        else:
+            out[..., k - n] = -a[..., i]
+    return out

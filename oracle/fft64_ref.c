@@ -1327,6 +1327,66 @@ void pzr_vec_znx_big_add_small_assign(size_t n, int64_t* res, size_t res_cols, s
     for (size_t j = 0; j < sum_size; ++j) znx_add_assign(at_i64(res, n, res_cols, res_col, j), at_ci64(a, n, a_cols, a_col, j), n);
 }
 
+/* reference/znx/automorphism.rs:1-17: res[(i*p) mod 2n] = a[i], negated when the index wraps past n.
+ * Sequential scatter exactly as the reference (so an even p overwrites the same way). */
+static void znx_automorphism(int64_t p, int64_t* res, const int64_t* a, size_t n) {
+    size_t mask = 2 * n - 1;
+    size_t p_2n = (size_t)(p & (int64_t)mask);
+    size_t k = 0;
+    res[0] = a[0];
+    for (size_t i = 1; i < n; ++i) {
+        k = (k + p_2n) & mask;
+        if (k < n) res[k] = a[i];
+        else res[k - n] = (int64_t)(0 - (uint64_t)a[i]);
+    }
+}
+
+/* reference/vec_znx/automorphism.rs:10-35 (also vec_znx_big_automorphism, fft64/vec_znx_big.rs:144-170: same
+ * function on the i64 big container) */
+void pzr_vec_znx_automorphism(size_t n, int64_t p, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                              const int64_t* a, size_t a_cols, size_t a_size, size_t a_col) {
+    size_t min_size = zmin(res_size, a_size);
+    for (size_t j = 0; j < min_size; ++j) znx_automorphism(p, at_i64(res, n, res_cols, res_col, j), at_ci64(a, n, a_cols, a_col, j), n);
+    for (size_t j = min_size; j < res_size; ++j) memset(at_i64(res, n, res_cols, res_col, j), 0, n * sizeof(int64_t));
+}
+
+/* reference/vec_znx/automorphism.rs:37-51 (tmp = one polynomial) */
+void pzr_vec_znx_automorphism_assign(size_t n, int64_t p, int64_t* res, size_t res_cols, size_t res_size, size_t res_col) {
+    int64_t* tmp = (int64_t*)malloc(n * sizeof(int64_t));
+    for (size_t j = 0; j < res_size; ++j) {
+        int64_t* r = at_i64(res, n, res_cols, res_col, j);
+        znx_automorphism(p, tmp, r, n);
+        memcpy(r, tmp, n * sizeof(int64_t));
+    }
+    free(tmp);
+}
+
+/* fft64/vec_znx_big.rs:499-516 -> vec_znx/sub.rs:60-82 : res -= a over min sizes */
+void pzr_vec_znx_big_sub_small_assign(size_t n, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                                      const int64_t* a, size_t a_cols, size_t a_size, size_t a_col) {
+    size_t sum_size = zmin(a_size, res_size);
+    for (size_t j = 0; j < sum_size; ++j) {
+        int64_t* r = at_i64(res, n, res_cols, res_col, j);
+        const int64_t* x = at_ci64(a, n, a_cols, a_col, j);
+        for (size_t i = 0; i < n; ++i) r[i] = (int64_t)((uint64_t)r[i] - (uint64_t)x[i]);
+    }
+}
+
+/* fft64/vec_znx_big.rs:519-536 -> vec_znx/sub.rs:84-110 : res = a - res over min sizes, res = -res beyond */
+void pzr_vec_znx_big_sub_small_negate_assign(size_t n, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                                             const int64_t* a, size_t a_cols, size_t a_size, size_t a_col) {
+    size_t sum_size = zmin(a_size, res_size);
+    for (size_t j = 0; j < res_size; ++j) {
+        int64_t* r = at_i64(res, n, res_cols, res_col, j);
+        if (j < sum_size) {
+            const int64_t* x = at_ci64(a, n, a_cols, a_col, j);
+            for (size_t i = 0; i < n; ++i) r[i] = (int64_t)((uint64_t)x[i] - (uint64_t)r[i]);
+        } else {
+            for (size_t i = 0; i < n; ++i) r[i] = (int64_t)(0 - (uint64_t)r[i]);
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------ */
 /* poulpy-core callers                                                       */
 /* ------------------------------------------------------------------------ */
@@ -1391,11 +1451,15 @@ void pzr_glwe_external_product(const pzr_tables* t, size_t rank,
     free(a_conv);
 }
 
-/* keyswitching/glwe.rs:53-109 (default), :207-239 (internal), :298-380 (gglwe_product_dft) */
-void pzr_glwe_keyswitch(const pzr_tables* t, size_t rank_in, size_t rank_out,
-                        int64_t* res, size_t res_size, size_t res_base2k,
-                        const int64_t* a, size_t a_size, size_t a_base2k,
-                        const double* key_pmat, size_t dnum, size_t key_size, size_t dsize, size_t key_base2k) {
+/* keyswitching/glwe.rs:53-109 (default), :207-239 (internal), :298-380 (gglwe_product_dft);
+ * mode != PZR_KS_PLAIN: the automorphism family on top of it, automorphism/glwe_ct.rs:51-72 (AUTO: key switch, then the
+ * automorphism of the normalized result), :96-140 (ADD), :185-229 (SUB), :231-275 (SUB_NEGATE): automorphism of the big
+ * value, +/- a, then normalize. */
+static void glwe_keyswitch_core(const pzr_tables* t, size_t rank_in, size_t rank_out,
+                                int64_t* res, size_t res_size, size_t res_base2k,
+                                const int64_t* a, size_t a_size, size_t a_base2k,
+                                const double* key_pmat, size_t dnum, size_t key_size, size_t dsize, size_t key_base2k,
+                                int mode, int64_t p) {
     size_t n = t->m << 1;
     size_t cols_a = rank_in + 1;
     size_t cols_out = rank_out + 1;
@@ -1441,9 +1505,38 @@ void pzr_glwe_keyswitch(const pzr_tables* t, size_t rank_in, size_t rank_out,
     pzr_vec_znx_idft_apply_consume(t, res_dft, cols_out, key_size);
     int64_t* res_big = (int64_t*)res_dft;
     pzr_vec_znx_big_add_small_assign(n, res_big, cols_out, key_size, 0, a, cols_a, a_size, 0); /* glwe.rs:237 */
-    for (size_t i = 0; i < cols_out; ++i) /* glwe.rs:105-108 */
+    for (size_t i = 0; i < cols_out; ++i) {
+        if (mode == PZR_KS_AUTO_ADD || mode == PZR_KS_AUTO_SUB || mode == PZR_KS_AUTO_SUB_NEGATE) {
+            /* glwe_ct.rs:134-137 / :223-226 / :269-272 (a is a_conv when the bases differ: :126-130) */
+            pzr_vec_znx_automorphism_assign(n, p, res_big, cols_out, key_size, i);
+            if (mode == PZR_KS_AUTO_ADD) pzr_vec_znx_big_add_small_assign(n, res_big, cols_out, key_size, i, a, cols_a, a_size, i);
+            else if (mode == PZR_KS_AUTO_SUB) pzr_vec_znx_big_sub_small_assign(n, res_big, cols_out, key_size, i, a, cols_a, a_size, i);
+            else pzr_vec_znx_big_sub_small_negate_assign(n, res_big, cols_out, key_size, i, a, cols_a, a_size, i);
+        }
+        /* glwe.rs:105-108 */
         pzr_vec_znx_normalize(n, res, cols_out, res_size, res_base2k, 0, i, res_big, cols_out, key_size, key_base2k, i);
+    }
+    if (mode == PZR_KS_AUTO) /* glwe_ct.rs:69-71 */
+        for (size_t i = 0; i < cols_out; ++i) pzr_vec_znx_automorphism_assign(n, p, res, cols_out, res_size, i);
     free(a_dft);
     free(res_dft);
     free(a_conv);
+}
+
+void pzr_glwe_keyswitch(const pzr_tables* t, size_t rank_in, size_t rank_out,
+                        int64_t* res, size_t res_size, size_t res_base2k,
+                        const int64_t* a, size_t a_size, size_t a_base2k,
+                        const double* key_pmat, size_t dnum, size_t key_size, size_t dsize, size_t key_base2k) {
+    glwe_keyswitch_core(t, rank_in, rank_out, res, res_size, res_base2k, a, a_size, a_base2k, key_pmat, dnum, key_size, dsize,
+                        key_base2k, PZR_KS_PLAIN, 0);
+}
+
+/* automorphism/glwe_ct.rs:51-275: `mode` selects glwe_automorphism / _add / _sub / _sub_negate; the key is the prepared
+ * automorphism key (a GGLWE with rank_in = rank_out = rank) and p its Galois element (key.p()). */
+void pzr_glwe_automorphism(const pzr_tables* t, size_t rank, int mode, int64_t p,
+                           int64_t* res, size_t res_size, size_t res_base2k,
+                           const int64_t* a, size_t a_size, size_t a_base2k,
+                           const double* key_pmat, size_t dnum, size_t key_size, size_t dsize, size_t key_base2k) {
+    glwe_keyswitch_core(t, rank, rank, res, res_size, res_base2k, a, a_size, a_base2k, key_pmat, dnum, key_size, dsize,
+                        key_base2k, mode, p);
 }

@@ -130,6 +130,23 @@ void pzr_glwe_keyswitch(const pzr_tables* t, size_t rank_in, size_t rank_out,
                         const int64_t* a, size_t a_size, size_t a_base2k,
                         const double* key_pmat, size_t dnum, size_t key_size, size_t dsize, size_t key_base2k);
 
+
+/* reference/vec_znx/automorphism.rs:10-51 (= vec_znx_big_automorphism[_assign], fft64/vec_znx_big.rs:144-188) */
+void pzr_vec_znx_automorphism(size_t n, int64_t p, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                              const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+void pzr_vec_znx_automorphism_assign(size_t n, int64_t p, int64_t* res, size_t res_cols, size_t res_size, size_t res_col);
+void pzr_vec_znx_big_sub_small_assign(size_t n, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                                      const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+void pzr_vec_znx_big_sub_small_negate_assign(size_t n, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                                             const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+
+/* automorphism/glwe_ct.rs:51-275 */
+enum { PZR_KS_PLAIN = 0, PZR_KS_AUTO = 1, PZR_KS_AUTO_ADD = 2, PZR_KS_AUTO_SUB = 3, PZR_KS_AUTO_SUB_NEGATE = 4 };
+void pzr_glwe_automorphism(const pzr_tables* t, size_t rank, int mode, int64_t p,
+                           int64_t* res, size_t res_size, size_t res_base2k,
+                           const int64_t* a, size_t a_size, size_t a_base2k,
+                           const double* key_pmat, size_t dnum, size_t key_size, size_t dsize, size_t key_base2k);
+
 #ifdef __cplusplus
 }
 #endif

@@ -210,3 +210,30 @@ class RefModule:
         rank_in, rank_out = a.cols - 1, res.cols - 1
         self.lib.pzr_glwe_keyswitch(self.t, *_sz(rank_in, rank_out), _p(res.data), *_sz(res.size, res_base2k), _p(a.data),
                                     *_sz(a.size, a_base2k), _p(pmat.data), *_sz(pmat.rows, pmat.size, dsize, key_base2k))
+
+    # automorphism family (reference/vec_znx/automorphism.rs, fft64/vec_znx_big.rs:144-188, poulpy-core automorphism/glwe_ct.rs)
+    def vec_znx_automorphism(self, p, res, res_col, a, a_col):
+        self.lib.pzr_vec_znx_automorphism(c_size_t(self._n), c_int64(p), _p(res.data), *_sz(res.cols, res.size, res_col),
+                                          _p(a.data), *_sz(a.cols, a.size, a_col))
+
+    def vec_znx_automorphism_assign(self, p, res, res_col, scratch=None):
+        self.lib.pzr_vec_znx_automorphism_assign(c_size_t(self._n), c_int64(p), _p(res.data), *_sz(res.cols, res.size, res_col))
+
+    vec_znx_big_automorphism = vec_znx_automorphism
+    vec_znx_big_automorphism_assign = vec_znx_automorphism_assign
+
+    def vec_znx_big_sub_small_assign(self, res, res_col, a, a_col):
+        self.lib.pzr_vec_znx_big_sub_small_assign(c_size_t(self._n), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                                  *_sz(a.cols, a.size, a_col))
+
+    def vec_znx_big_sub_small_negate_assign(self, res, res_col, a, a_col):
+        self.lib.pzr_vec_znx_big_sub_small_negate_assign(c_size_t(self._n), _p(res.data), *_sz(res.cols, res.size, res_col),
+                                                         _p(a.data), *_sz(a.cols, a.size, a_col))
+
+    AUTO_MODES = {"automorphism": 1, "add": 2, "sub": 3, "sub_negate": 4}
+
+    def glwe_automorphism(self, res, res_base2k, a, a_base2k, pmat, dsize, key_base2k, p, mode="automorphism"):
+        rank = a.cols - 1
+        self.lib.pzr_glwe_automorphism(self.t, c_size_t(rank), C.c_int(self.AUTO_MODES[mode]), c_int64(p), _p(res.data),
+                                       *_sz(res.size, res_base2k), _p(a.data), *_sz(a.size, a_base2k), _p(pmat.data),
+                                       *_sz(pmat.rows, pmat.size, dsize, key_base2k))

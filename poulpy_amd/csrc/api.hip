@@ -129,7 +129,7 @@ static bool tail_supported(const pz_module* M) { return (M->plan.f1b * M->plan.c
 
 static int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
                            int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
-                           int base2k, bool rowmajor = false) {
+                           int base2k, bool rowmajor = false, bool small_all = false, unsigned auto_mul = 0, bool auto_neg = false) {
     const FftPlan& pl = M->plan;
     const int blocks = batch * ncols * (pl.m2 / pl.cb);
     if (blocks == 0) return PZ_OK;
@@ -139,6 +139,7 @@ static int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, i
     g.nlimbs = nlimbs; g.ncols = ncols; g.res_cols = res_cols; g.res_size = res_size;
     g.small_cols = small_cols; g.small_size = small_size; g.base2k = base2k; g.m2 = pl.m2;
     g.tw1inv = M->tw1inv; g.wL1 = M->wL1; g.margin = M->margin;
+    g.small_all = small_all ? 1 : 0; g.auto_mul = auto_mul; g.auto_neg = auto_neg ? 1 : 0;
     const bool has_small = small != nullptr;
 // one instantiation per (probe, row-major, body add) combination actually requested
 #define PZ_TAIL_ONE(A, B, C, P_, R_, S_)                                                                        \
@@ -245,6 +246,29 @@ static int launch_ew(pz_module* M, int op, void* res, long long res_bs, long lon
     const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 16);
     KTimer kt(M, PZ_K_ELEMENTWISE);
     hipLaunchKernelGGL(k_ew, dim3(blocks), dim3(256), 0, M->stream, g);
+    PZ_HIP(hipGetLastError());
+    return PZ_OK;
+}
+
+// multiplicative inverse of an odd p modulo 2n (n a power of two): Newton iteration doubles the valid bits
+static unsigned inv_mod_2n(long long p, long long n) {
+    const unsigned long long mask = 2ull * (unsigned long long)n - 1ull;
+    const unsigned long long a = (unsigned long long)p & mask;
+    unsigned long long x = a;  // correct to 3 bits
+    for (int i = 0; i < 6; ++i) x *= 2ull - a * x;
+    return (unsigned)(x & mask);
+}
+// dst = +-src(X^p-gather with multiplier mul) [+ add]; see k_automorphism
+static int launch_automorphism(pz_module* M, int npolys, const long long* src, PolyMap sm, long long* dst, PolyMap dm, unsigned mul,
+                               int flags, const long long* add = nullptr, PolyMap am = PolyMap{1, 1, 0, 0, 0, 0}) {
+    if (npolys <= 0) return PZ_OK;
+    AutoArgs g;
+    g.src = src; g.dst = dst; g.add = add; g.sm = sm; g.dm = dm; g.am = am;
+    g.npolys = npolys; g.n = (int)M->n; g.mul = mul; g.flags = flags;
+    const int bpp = M->n >= 512 ? (int)(M->n / 512) : 1;
+    const int blocks = ((npolys + 7) / 8) * 8 * bpp;
+    KTimer kt(M, PZ_K_ELEMENTWISE);
+    hipLaunchKernelGGL(k_automorphism, dim3(blocks), dim3(256), 0, M->stream, g);
     PZ_HIP(hipGetLastError());
     return PZ_OK;
 }
@@ -1092,6 +1116,65 @@ int pz_vec_znx_big_add_small_assign(pz_module* M, int64_t* res, size_t res_cols,
     return tri_out(M, t);
 }
 
+// vec_znx_automorphism (hal_impl.rs:236) and vec_znx_big_automorphism (:517) are the same operation on i64 containers
+// (fft64/vec_znx_big.rs:144-170 re-types the big container and calls the VecZnx function)
+static int automorphism_into(pz_module* M, int64_t p, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                             const int64_t* a, size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_CHECK_COL(res_col, res_cols, "vec_znx_automorphism(res)");
+    PZ_CHECK_COL(a_col, a_cols, "vec_znx_automorphism(a)");
+    PZ_REQUIRE((p & 1) != 0, "vec_znx_automorphism: the Galois element must be odd");
+    PZ_REQUIRE((const void*)res != (const void*)a, "vec_znx_automorphism: res must not alias a (use the *_assign form)");
+    Tri t;
+    PZ_TRY(tri_in(M, t, (double*)res, res_cols, res_size, (const double*)a, a_cols, a_size, nullptr, 0, 0));
+    const int min_size = (int)std::min(res_size, a_size);
+    const long long n = (long long)M->n;
+    PolyMap sm{std::max(min_size, 1), 1, 0, (long long)a_cols * n, 0, n * (long long)a_col};
+    PolyMap dm{std::max(min_size, 1), 1, 0, (long long)res_cols * n, 0, n * (long long)res_col};
+    PZ_TRY(launch_automorphism(M, min_size, (const long long*)t.da.p, sm, (long long*)t.dr.p, dm, inv_mod_2n(p, n), 1));
+    PZ_TRY(ew_limbs(M, EW_ZERO, t.dr, (int)res_col, min_size, nullptr, 0, 0, nullptr, 0, 0, (int)res_size - min_size));  // automorphism.rs:32-34
+    return tri_out(M, t);
+}
+static int automorphism_assign(pz_module* M, int64_t p, int64_t* res, size_t cols, size_t size, size_t col) {
+    PZ_CHECK_COL(col, cols, "vec_znx_automorphism_assign(res)");
+    PZ_REQUIRE((p & 1) != 0, "vec_znx_automorphism_assign: the Galois element must be odd");
+    Stage sr;
+    PZ_TRY(sr.in(res, vbytes(M, cols, size), true, true, M));
+    const long long n = (long long)M->n;
+    if (size > 0) {
+        // the reference permutes through one polynomial of scratch (automorphism.rs:37-51); here: the column's limbs are
+        // copied to the workspace and gathered back
+        PZ_TRY(ws_reserve(M, (size_t)size * (size_t)n * 8));
+        DV dr{sr.dev, 0, (int)cols, (int)size};
+        PZ_TRY(launch_ew(M, EW_COPY, M->ws, 0, n, poly_ptr(M, dr, (int)col, 0), 0, limb_stride(M, dr), nullptr, 0, 0, (int)size, 1));
+        PolyMap sm{(int)size, 1, 0, n, 0, 0};
+        PolyMap dm{(int)size, 1, 0, (long long)cols * n, 0, n * (long long)col};
+        PZ_TRY(launch_automorphism(M, (int)size, (const long long*)M->ws, sm, (long long*)sr.dev, dm, inv_mod_2n(p, n), 1));
+    }
+    const bool host = sr.owned;
+    PZ_TRY(sr.finish());
+    return finish_call(M, host);
+}
+size_t pz_vec_znx_automorphism_assign_tmp_bytes(const pz_module* M) { return M ? (size_t)M->n * 8 : 0; }      // automorphism.rs:6-8
+size_t pz_vec_znx_big_automorphism_assign_tmp_bytes(const pz_module* M) { return M ? (size_t)M->n * 8 : 0; }  // vec_znx_big.rs:140-142
+int pz_vec_znx_automorphism(pz_module* M, int64_t p, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a,
+                            size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    return automorphism_into(M, p, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col);
+}
+int pz_vec_znx_automorphism_assign(pz_module* M, int64_t p, int64_t* res, size_t cols, size_t size, size_t col) {
+    PZ_ENTER(M);
+    return automorphism_assign(M, p, res, cols, size, col);
+}
+int pz_vec_znx_big_automorphism(pz_module* M, int64_t p, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                                const int64_t* a, size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    return automorphism_into(M, p, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col);
+}
+int pz_vec_znx_big_automorphism_assign(pz_module* M, int64_t p, int64_t* res, size_t cols, size_t size, size_t col) {
+    PZ_ENTER(M);
+    return automorphism_assign(M, p, res, cols, size, col);
+}
+
 // ------------------------------------------------------------------------------
 // public: batched GLWE operations (device-resident)
 // ------------------------------------------------------------------------------
@@ -1112,9 +1195,9 @@ static OpShape op_shape(const pz_glwe_op_params* p, bool ks) {
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct OpWs {
-    size_t a_conv, a_dft, res_dft, tmp_dft, T, total;
+    size_t a_conv, a_dft, res_dft, tmp_dft, T, res_tmp, total;
 };
-static OpWs op_ws(const pz_module* M, const pz_glwe_op_params* p, const OpShape& s, size_t chunk, bool ks) {
+static OpWs op_ws(const pz_module* M, const pz_glwe_op_params* p, const OpShape& s, size_t chunk, bool ks, bool au = false) {
     OpWs w;
     const size_t n8 = (size_t)M->n * 8;
     const size_t dsz = p->dsize;
@@ -1124,7 +1207,8 @@ static OpWs op_ws(const pz_module* M, const pz_glwe_op_params* p, const OpShape&
     w.tmp_dft = dsz > 1 ? align256(chunk * n8 * (s.cols_out * p->key_size + (ks ? s.cols_in * (size_t)s.a_size_eff : 0))) : 0;
     const size_t tp = std::max((size_t)s.cols_in * s.a_size_eff, (size_t)s.cols_out * p->key_size);
     w.T = align256(chunk * tp * (size_t)M->m * sizeof(cplx));
-    w.total = w.a_conv + w.a_dft + w.res_dft + w.tmp_dft + w.T;
+    w.res_tmp = au ? align256(chunk * n8 * s.cols_out * p->res_size) : 0;  // normalized result before the final permutation
+    w.total = w.a_conv + w.a_dft + w.res_dft + w.tmp_dft + w.T + w.res_tmp;
     return w;
 }
 static size_t pick_chunk(const pz_module* M, const pz_glwe_op_params* p, const OpShape& s, size_t batch) {
@@ -1141,10 +1225,22 @@ static size_t pick_chunk(const pz_module* M, const pz_glwe_op_params* p, const O
 size_t pz_glwe_op_workspace_bytes(const pz_module* M, const pz_glwe_op_params* p, size_t batch, int keyswitch) {
     if (!M || !p) return 0;
     OpShape s = op_shape(p, keyswitch != 0);
-    return op_ws(M, p, s, pick_chunk(M, p, s, batch), keyswitch != 0).total;
+    return op_ws(M, p, s, pick_chunk(M, p, s, batch), keyswitch != 0, keyswitch == 2).total;
 }
 
-static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double* pmat, const pz_glwe_op_params* p, size_t batch) {
+// Automorphism family on top of the key switch (poulpy-core automorphism/glwe_ct.rs:51-275).  With phi = X -> X^p:
+//   mode 0  res = phi(normalize(big))                       (:65-71)
+//   mode 1  res = normalize(phi(big) + a)   (add, :133-138)   2: phi(big) - a (:222-227)   3: a - phi(big) (:268-273)
+// where big is the key-switch value including the body (keyswitching/glwe.rs:236-237).  Normalization acts per
+// coefficient, so modes 1-3 are computed as  phi(normalize'(s .* (big + small)))  with small = -+phi^-1(a) (+ body) built
+// by one gather kernel, s(n) the sign phi gives coefficient n (applied inside the tail before the carry chain; flipped
+// for mode 3) and a final sign-free permutation; mode 0 is the plain key switch followed by the signed permutation.
+struct AutoSpec {
+    long long p;
+    int mode;
+};
+static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double* pmat, const pz_glwe_op_params* p, size_t batch,
+                   const AutoSpec* au = nullptr) {
     PZ_REQUIRE(p != nullptr, "null params");
     PZ_REQUIRE(p->dsize >= 1 && p->dnum >= 1 && p->key_size >= 1 && p->a_size >= 1 && p->res_size >= 1, "glwe op: empty shape");
     PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(a) && is_device_ptr(pmat), "batched entry points take device pointers");
@@ -1157,6 +1253,14 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
     const long long res_ct = n * s.cols_out * (long long)p->res_size;
     const int npi = s.cols_in * s.a_size_eff, npo = s.cols_out * ksz;
     const int nrows = dnum * s.cols_in, ncols = s.cols_out * ksz;
+    const bool au_big = au && au->mode != 0;
+    const unsigned au_p = au ? (unsigned)((unsigned long long)au->p & (2ull * (unsigned long long)n - 1ull)) : 0u;
+    const unsigned au_g = au ? inv_mod_2n(au->p, n) : 0u;
+    if (au) {
+        PZ_REQUIRE(ks && s.cols_a == s.cols_out, "glwe_automorphism: the key must map rank -> rank");
+        PZ_REQUIRE((au->p & 1) != 0, "glwe_automorphism: the Galois element must be odd");
+        PZ_REQUIRE(au->mode >= 0 && au->mode <= 3, "glwe_automorphism: unknown mode");
+    }
 
     // ---- fully fused pipeline: pass 1 (row-major) | row pass + VMP + inverse row pass | tail ----
     if (M->fuse_mid && M->fuse_tail && dsize == 1 && p->res_base2k == p->key_base2k && tail_supported(M) && mid_supported(M, npi, npo)) {
@@ -1164,12 +1268,16 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
         const size_t conv_bytes = s.convert ? align256(chunk * (size_t)M->n * 8 * s.cols_a * s.a_size_eff) : 0;
         const size_t t_bytes = align256(chunk * (size_t)npi * M->m * sizeof(cplx));
         const size_t t2_bytes = align256(chunk * (size_t)npo * M->m * sizeof(cplx));
-        PZ_TRY(ws_reserve(M, key_bytes + conv_bytes + t_bytes + t2_bytes + kMidDummyBytes));
+        const size_t rtmp_bytes = au ? align256(chunk * (size_t)res_ct * 8) : 0;
+        const size_t small2_bytes = au_big ? align256(chunk * (size_t)M->n * 8 * s.cols_a * s.a_size_eff) : 0;
+        PZ_TRY(ws_reserve(M, key_bytes + conv_bytes + t_bytes + t2_bytes + rtmp_bytes + small2_bytes + kMidDummyBytes));
         char* base = (char*)M->ws;
         cplx* Pp = (cplx*)base; base += key_bytes;
         int64_t* a_conv = (int64_t*)base; base += conv_bytes;
         cplx* T = (cplx*)base; base += t_bytes;
         cplx* T2 = (cplx*)base; base += t2_bytes;
+        int64_t* res_tmp = (int64_t*)base; base += rtmp_bytes;
+        int64_t* small2 = (int64_t*)base; base += small2_bytes;
         cplx* mid_dummy = (cplx*)base;
         // the key arrives in the standard device layout; its row-sliced copy is rebuilt per call (2 x 128 MiB of
         // traffic at the metric shape, ~4 % of a 128-ciphertext call) so that no stale copy can ever be used
@@ -1188,20 +1296,38 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
             PolyMap sm{a_size, s.cols_in, av.bs, (long long)av.cols * n, n, n * a_col0};
             if (M->dbg_stages & 1) PZ_TRY(launch_fwd_pass1(M, nb * npi, (const long long*)av.p, sm, T, true));
             if (M->dbg_stages & 2) PZ_TRY(launch_mid(M, nb, T, T2, Pp, npi, npo, nrows, ncols, mid_dummy));
-            if (M->dbg_stages & 4) PZ_TRY(launch_inv_tail(M, nb, T2, ksz, s.cols_out, (long long*)(res + (long long)b0 * res_ct), res_ct, s.cols_out, (int)p->res_size,
-                                   ks ? (const long long*)av.p : nullptr, av.bs, av.cols, a_size, (int)p->res_base2k, true));
+            int64_t* res_b = res + (long long)b0 * res_ct;
+            const long long* small = ks ? (const long long*)av.p : nullptr;
+            long long small_bs = av.bs;
+            if (au_big) {
+                // small2[c][j] = -+phi^-1(a)[c][j]  (+ a[0][j], the key-switch body, for c = 0)
+                PolyMap am{a_size, s.cols_a, av.bs, (long long)av.cols * n, n, 0};
+                PolyMap dm{a_size, s.cols_a, n * s.cols_a * a_size, (long long)s.cols_a * n, n, 0};
+                PZ_TRY(launch_automorphism(M, nb * a_size * s.cols_a, (const long long*)av.p, am, (long long*)small2, dm, au_p,
+                                           1 | (au->mode == 1 ? 0 : 2) | 4, (const long long*)av.p, am));
+                small = (const long long*)small2;
+                small_bs = n * s.cols_a * a_size;
+            }
+            if (M->dbg_stages & 4) PZ_TRY(launch_inv_tail(M, nb, T2, ksz, s.cols_out, (long long*)(au ? res_tmp : res_b), res_ct, s.cols_out, (int)p->res_size,
+                                   small, small_bs, s.cols_a, a_size, (int)p->res_base2k, true, au_big, au_big ? au_p : 0u, au && au->mode == 3));
+            if (au) {
+                PolyMap tm{(int)p->res_size, s.cols_out, res_ct, (long long)s.cols_out * n, n, 0};
+                PZ_TRY(launch_automorphism(M, nb * (int)p->res_size * s.cols_out, (const long long*)res_tmp, tm, (long long*)res_b, tm, au_g,
+                                           au->mode == 0 ? 1 : 0));
+            }
         }
         return PZ_OK;
     }
 
-    const OpWs w = op_ws(M, p, s, chunk, ks);
+    const OpWs w = op_ws(M, p, s, chunk, ks, au != nullptr);
     PZ_TRY(ws_reserve(M, w.total));
     char* base = (char*)M->ws;
     int64_t* a_conv = (int64_t*)base; base += w.a_conv;
     double* a_dft = (double*)base; base += w.a_dft;
     double* res_dft = (double*)base; base += w.res_dft;
     double* tmp_dft = (double*)base; base += w.tmp_dft;
-    cplx* T = (cplx*)base;
+    cplx* T = (cplx*)base; base += w.T;
+    int64_t* res_tmp = (int64_t*)base;
 
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const int nb = (int)std::min(chunk, batch - b0);
@@ -1248,7 +1374,38 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
         }
         DV rb{res_dft, rd.bs, s.cols_out, res_dft_size};
         DV rv{(void*)(res + (long long)b0 * res_ct), res_ct, s.cols_out, (int)p->res_size};
-        if (p->res_base2k == p->key_base2k && M->fuse_tail && tail_supported(M)) {
+        if (au) {
+            // op-by-op, as the reference: big value, body, [automorphism of the big value, +- a], normalize, [automorphism]
+            PZ_TRY(dev_idft(M, nb, rb, 0, rb, 0, s.cols_out, res_dft_size, T));
+            const long long big_ls = (long long)s.cols_out * n, a_ls = (long long)av.cols * n;
+            PZ_TRY(launch_ew(M, EW_ADD_I64, res_dft, rb.bs, big_ls, res_dft, rb.bs, big_ls, av.p, av.bs, a_ls, std::min(res_dft_size, a_size), nb));
+            DV nsrc = rb;
+            if (au_big) {
+                int64_t* big2 = (int64_t*)T;  // free again: same bytes as the big value
+                PolyMap bm{res_dft_size, s.cols_out, rb.bs, big_ls, n, 0};
+                PZ_TRY(launch_automorphism(M, nb * res_dft_size * s.cols_out, (const long long*)res_dft, bm, (long long*)big2, bm, au_g, 1));
+                const int sum = std::min(res_dft_size, a_size);
+                for (int c = 0; c < s.cols_out; ++c) {
+                    int64_t* bc = big2 + (long long)c * n;
+                    const int64_t* ac = (const int64_t*)av.p + (long long)c * n;
+                    if (au->mode == 1) PZ_TRY(launch_ew(M, EW_ADD_I64, bc, rb.bs, big_ls, bc, rb.bs, big_ls, ac, av.bs, a_ls, sum, nb));
+                    else if (au->mode == 2) PZ_TRY(launch_ew(M, EW_SUB_I64, bc, rb.bs, big_ls, bc, rb.bs, big_ls, ac, av.bs, a_ls, sum, nb));
+                    else {  // a - big, and -big where a has no limb (vec_znx/sub.rs:84-110)
+                        PZ_TRY(launch_ew(M, EW_SUB_I64, bc, rb.bs, big_ls, ac, av.bs, a_ls, bc, rb.bs, big_ls, sum, nb));
+                        PZ_TRY(launch_ew(M, EW_NEG_I64, bc + (long long)sum * big_ls, rb.bs, big_ls, bc + (long long)sum * big_ls, rb.bs, big_ls,
+                                         nullptr, 0, 0, res_dft_size - sum, nb));
+                    }
+                }
+                nsrc = DV{big2, rb.bs, s.cols_out, res_dft_size};
+            }
+            DV nd = au->mode == 0 ? DV{res_tmp, res_ct, s.cols_out, (int)p->res_size} : rv;
+            for (int c = 0; c < s.cols_out; ++c)
+                PZ_TRY(dev_normalize(M, nb, nd, (int)p->res_base2k, 0, c, nsrc, (int)p->key_base2k, c));
+            if (au->mode == 0) {
+                PolyMap tm{(int)p->res_size, s.cols_out, res_ct, (long long)s.cols_out * n, n, 0};
+                PZ_TRY(launch_automorphism(M, nb * (int)p->res_size * s.cols_out, (const long long*)res_tmp, tm, (long long*)rv.p, tm, au_g, 1));
+            }
+        } else if (p->res_base2k == p->key_base2k && M->fuse_tail && tail_supported(M)) {
             // inverse pass 2, then the fused tail: inverse pass 1 + body add + carry chain, no VecZnxBig in HBM
             PolyMap sm{res_dft_size, s.cols_out, rb.bs, (long long)s.cols_out * n, n, 0};
             PZ_TRY(launch_inv_pass2(M, nb * res_dft_size * s.cols_out, res_dft, sm, T));
@@ -1275,6 +1432,20 @@ int pz_glwe_keyswitch_batched(pz_module* M, int64_t* res, const int64_t* a, cons
                               size_t batch) {
     PZ_ENTER(M);
     return glwe_op(M, true, res, a, key_pmat, p, batch);
+}
+int pz_glwe_automorphism_batched(pz_module* M, int64_t* res, const int64_t* a, const double* key_pmat, const pz_glwe_op_params* p,
+                                 int64_t gal, int mode, size_t batch) {
+    PZ_ENTER(M);
+    AutoSpec au{(long long)gal, mode};
+    return glwe_op(M, true, res, a, key_pmat, p, batch, &au);
+}
+// ggsw_external_product (external_product/ggsw.rs:54-58): every (row, column) entry of the GGSW `a` is a GLWE and the entries
+// are contiguous in the MatZnx layout, so the operation is one batched external product over dnum_a * (rank+1) ciphertexts
+int pz_ggsw_external_product(pz_module* M, int64_t* res, const int64_t* a, size_t a_dnum, const double* ggsw_pmat,
+                             const pz_glwe_op_params* p) {
+    PZ_ENTER(M);
+    PZ_REQUIRE(p != nullptr, "null params");
+    return glwe_op(M, false, res, a, ggsw_pmat, p, a_dnum * (p->rank + 1));
 }
 
 }  // extern "C"

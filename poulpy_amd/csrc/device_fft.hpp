@@ -367,6 +367,12 @@ struct TailArgs {
     const cplx* tw1inv;
     const cplx* wL1;
     unsigned long long* margin;
+    // automorphism family (poulpy-core automorphism/glwe_ct.rs:96-275): the value that enters the carry chain is
+    // s(n) * (big[n] + small[n]) with s(n) = -1 iff (n * auto_mul) mod 2N >= N (auto_neg flips every sign);
+    // small_all: `small` has an operand for every column, not only the body column
+    int small_all;
+    unsigned auto_mul;  // 0: no sign
+    int auto_neg;
 };
 
 // Workgroup = (R2 + R1)*CB threads in two wave-uniform roles (R2*CB must be a multiple of 64):
@@ -444,7 +450,8 @@ k_inv_tail(TailArgs g) {
     for (int u = 0; u < 2 * R1; ++u) carry[u] = 0;
     long long* res_col = g.res + (long long)b * g.res_bs + (long long)col * n;
     const long long res_ls = (long long)g.res_cols * n;
-    const long long* small_col = (g.small && col == 0) ? g.small + (long long)b * g.small_bs : nullptr;
+    const long long* small_col =
+        (g.small && (col == 0 || g.small_all)) ? g.small + (long long)b * g.small_bs + (g.small_all ? (long long)col * n : 0) : nullptr;
     const long long small_ls = (long long)g.small_cols * n;
     // limbs of res beyond the precision of the big value are zero (normalize.rs:118-120)
     for (int j = L; j < g.res_size; ++j)
@@ -499,6 +506,10 @@ k_inv_tail(TailArgs g) {
             if (PROBE) worst = fmax(worst, fabs(val - r));                                                   \
             long long x = CONVERT(r);                                                                        \
             if (SMALL && add_small) x = (long long)((unsigned long long)x + (unsigned long long)sm[SMALL ? 2 * n1 + h : 0]); \
+            if (SMALL && g.auto_mul) {                                                                       \
+                const bool ng_ = (((unsigned)idx * g.auto_mul) & (unsigned)(2 * n - 1)) >= (unsigned)n;      \
+                if (ng_ != (g.auto_neg != 0)) x = (long long)(0ull - (unsigned long long)x);                 \
+            }                                                                                                \
             long long& cy = carry[2 * n1 + h];                                                               \
             const unsigned long long y = (unsigned long long)x + half;                                       \
             const long long d = (long long)(y & mask) - (long long)half;                                     \

@@ -222,6 +222,8 @@ enum EwOp : int {
     EW_SUB = 4,      // res = a - b
     EW_CMUL = 5,     // res = a * b  (complex pointwise, interleaved; `a` is the prepared poly)
     EW_ADD_I64 = 6,  // res = a + b  (wrapping i64)
+    EW_SUB_I64 = 7,  // res = a - b  (wrapping i64)
+    EW_NEG_I64 = 8,  // res = -a
 };
 
 // polynomial (b, j) of operand X sits at X + b*bs + j*ls ; n scalars per polynomial;
@@ -255,8 +257,65 @@ __global__ void __launch_bounds__(256) k_ew(EwArgs g) {
                 const ulonglong2 w = *reinterpret_cast<const ulonglong2*>(y);
                 *reinterpret_cast<ulonglong2*>(r) = make_ulonglong2(v.x + w.x, v.y + w.y);
             } break;
+            case EW_SUB_I64: {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(x);
+                const ulonglong2 w = *reinterpret_cast<const ulonglong2*>(y);
+                *reinterpret_cast<ulonglong2*>(r) = make_ulonglong2(v.x - w.x, v.y - w.y);
+            } break;
+            case EW_NEG_I64: {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(x);
+                *reinterpret_cast<ulonglong2*>(r) = make_ulonglong2(0ull - v.x, 0ull - v.y);
+            } break;
         }
     }
+}
+
+// =================================================================================
+// vec_znx_automorphism / vec_znx_big_automorphism  X -> X^p on i64 polynomials
+// (reference/znx/automorphism.rs:1-17: res[(i*p) mod 2n] = a[i], negated when the index wraps past n).
+// Gather form, so that stores are coalesced: with g = p^-1 mod 2n,  i0 = (j*g) mod 2n,
+//   res[j] = a[i0]  if i0 < n,   res[j] = -a[i0 - n]  otherwise.
+// The gathers of one polynomial (n*8 B: 512 KiB at n = 2^16) hit in L2: the 1-D grid is decoded so that every block of
+// a polynomial runs on the same XCD, i.e. each source line is fetched from HBM once.
+// flags: 1 apply the sign; 2 negate every output; 4 `add` only for polynomials whose innermost PolyMap index is 0.
+// =================================================================================
+struct AutoArgs {
+    const long long* src;
+    long long* dst;
+    const long long* add;  // optional second operand (same coefficient order as dst): dst = +-gather(src) + add
+    PolyMap sm, dm, am;
+    int npolys, n;
+    unsigned mul;          // gather multiplier g (odd, < 2n)
+    int flags;
+};
+
+__global__ void __launch_bounds__(256) k_automorphism(AutoArgs g) {
+    const int bpp = g.n >= 512 ? g.n / 512 : 1;  // blocks per polynomial, 2 coefficients per thread
+    const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+    const int poly = (r / bpp) * 8 + xcd, blk = r % bpp;
+    if (poly >= g.npolys) return;
+    const long long* src = g.src + map_off(g.sm, poly);
+    long long* dst = g.dst + map_off(g.dm, poly);
+    const bool has_add = g.add != nullptr && (!(g.flags & 4) || (poly % g.am.ni) == 0);
+    const long long* add = has_add ? g.add + map_off(g.am, poly) : nullptr;
+    const unsigned mask2 = 2u * (unsigned)g.n - 1u, nn = (unsigned)g.n;
+    const int j = blk * 512 + threadIdx.x * 2;
+    if (j >= g.n) return;
+    unsigned long long out[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const unsigned i0 = ((unsigned)(j + e) * g.mul) & mask2;
+        unsigned long long v = (unsigned long long)src[i0 & (nn - 1u)];
+        bool neg = (g.flags & 1) && i0 >= nn;
+        if (g.flags & 2) neg = !neg;
+        out[e] = neg ? 0ull - v : v;
+    }
+    if (has_add) {
+        const ulonglong2 w = *reinterpret_cast<const ulonglong2*>(add + j);
+        out[0] += w.x;
+        out[1] += w.y;
+    }
+    *reinterpret_cast<ulonglong2*>(dst + j) = make_ulonglong2(out[0], out[1]);
 }
 
 // =================================================================================

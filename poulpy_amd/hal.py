@@ -57,7 +57,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     for name in ("pz_bytes_of_vec_znx", "pz_bytes_of_vec_znx_dft", "pz_bytes_of_vec_znx_big", "pz_bytes_of_svp_ppol",
                  "pz_bytes_of_vmp_pmat", "pz_vec_znx_idft_apply_tmp_bytes", "pz_vmp_prepare_tmp_bytes",
                  "pz_vmp_apply_dft_tmp_bytes", "pz_vmp_apply_dft_to_dft_tmp_bytes", "pz_vec_znx_big_normalize_tmp_bytes",
-                 "pz_glwe_op_workspace_bytes"):
+                 "pz_glwe_op_workspace_bytes", "pz_vec_znx_automorphism_assign_tmp_bytes",
+                 "pz_vec_znx_big_automorphism_assign_tmp_bytes"):
         getattr(lib, name).restype = c_size_t
     if path is None:
         _lib = lib
@@ -303,7 +304,40 @@ class Module:
         self._ck(self.lib.pz_vec_znx_big_add_small_assign(self.handle, _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
                                                           *_sz(a.cols, a.size, a_col)))
 
+    # -- X -> X^p on i64 containers (hal_impl.rs:236-243, :517-524) ----------------------------
+    def vec_znx_automorphism(self, p: int, res: VecZnx, res_col, a: VecZnx, a_col):
+        self._ck(self.lib.pz_vec_znx_automorphism(self.handle, c_int64(p), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                                  *_sz(a.cols, a.size, a_col)))
+
+    def vec_znx_automorphism_assign(self, p: int, res: VecZnx, res_col, scratch=None):
+        self._ck(self.lib.pz_vec_znx_automorphism_assign(self.handle, c_int64(p), _p(res.data), *_sz(res.cols, res.size, res_col)))
+
+    def vec_znx_automorphism_assign_tmp_bytes(self) -> int:
+        return self.lib.pz_vec_znx_automorphism_assign_tmp_bytes(self.handle)
+
+    def vec_znx_big_automorphism(self, p: int, res: VecZnxBig, res_col, a: VecZnxBig, a_col):
+        self._ck(self.lib.pz_vec_znx_big_automorphism(self.handle, c_int64(p), _p(res.data), *_sz(res.cols, res.size, res_col),
+                                                      _p(a.data), *_sz(a.cols, a.size, a_col)))
+
+    def vec_znx_big_automorphism_assign(self, p: int, res: VecZnxBig, res_col, scratch=None):
+        self._ck(self.lib.pz_vec_znx_big_automorphism_assign(self.handle, c_int64(p), _p(res.data), *_sz(res.cols, res.size, res_col)))
+
+    def vec_znx_big_automorphism_assign_tmp_bytes(self) -> int:
+        return self.lib.pz_vec_znx_big_automorphism_assign_tmp_bytes(self.handle)
+
     # -- batched device-resident GLWE ops (CoreImpl overrides) ---------------------------
+    AUTO_MODES = {"automorphism": 0, "add": 1, "sub": 2, "sub_negate": 3}
+
+    def glwe_automorphism_batched(self, res: c_void_p, a: c_void_p, key_pmat: c_void_p, params: GlweOpParams, gal: int, mode, batch: int):
+        """poulpy-core automorphism/glwe_ct.rs:51-275; mode: "automorphism" | "add" | "sub" | "sub_negate"."""
+        mode = self.AUTO_MODES[mode] if isinstance(mode, str) else int(mode)
+        self._ck(self.lib.pz_glwe_automorphism_batched(self.handle, res, a, key_pmat, C.byref(params), c_int64(gal), c_int(mode),
+                                                       c_size_t(batch)))
+
+    def ggsw_external_product(self, res: c_void_p, a: c_void_p, a_dnum: int, ggsw_pmat: c_void_p, params: GlweOpParams):
+        """poulpy-core external_product/ggsw.rs:54-58 on a device-resident GGSW (MatZnx layout)."""
+        self._ck(self.lib.pz_ggsw_external_product(self.handle, res, a, c_size_t(a_dnum), ggsw_pmat, C.byref(params)))
+
     def glwe_external_product_batched(self, res: c_void_p, a: c_void_p, ggsw_pmat: c_void_p, params: GlweOpParams, batch: int):
         self._ck(self.lib.pz_glwe_external_product_batched(self.handle, res, a, ggsw_pmat, C.byref(params), c_size_t(batch)))
 
@@ -311,7 +345,7 @@ class Module:
         self._ck(self.lib.pz_glwe_keyswitch_batched(self.handle, res, a, key_pmat, C.byref(params), c_size_t(batch)))
 
     def glwe_op_workspace_bytes(self, params: GlweOpParams, batch: int, keyswitch: bool) -> int:
-        return self.lib.pz_glwe_op_workspace_bytes(self.handle, C.byref(params), c_size_t(batch), c_int(1 if keyswitch else 0))
+        return self.lib.pz_glwe_op_workspace_bytes(self.handle, C.byref(params), c_size_t(batch), c_int(int(keyswitch)))
 
     # events on the module stream
     def event_create(self) -> c_void_p:

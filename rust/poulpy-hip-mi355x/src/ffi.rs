@@ -75,10 +75,24 @@ unsafe extern "C" {
     pub fn pz_vec_znx_big_add_small_assign(m: *mut pz_module, res: *mut i64, rc: usize, rs: usize, rcol: usize, a: *const i64,
         ac: usize, as_: usize, acol: usize) -> c_int;
 
+    pub fn pz_vec_znx_automorphism(m: *mut pz_module, p: i64, res: *mut i64, rc: usize, rs: usize, rcol: usize, a: *const i64,
+        ac: usize, as_: usize, acol: usize) -> c_int;
+    pub fn pz_vec_znx_automorphism_assign(m: *mut pz_module, p: i64, res: *mut i64, rc: usize, rs: usize, rcol: usize) -> c_int;
+    pub fn pz_vec_znx_automorphism_assign_tmp_bytes(m: *const pz_module) -> usize;
+    pub fn pz_vec_znx_big_automorphism(m: *mut pz_module, p: i64, res: *mut i64, rc: usize, rs: usize, rcol: usize, a: *const i64,
+        ac: usize, as_: usize, acol: usize) -> c_int;
+    pub fn pz_vec_znx_big_automorphism_assign(m: *mut pz_module, p: i64, res: *mut i64, rc: usize, rs: usize, rcol: usize) -> c_int;
+    pub fn pz_vec_znx_big_automorphism_assign_tmp_bytes(m: *const pz_module) -> usize;
+
     pub fn pz_glwe_external_product_batched(m: *mut pz_module, res: *mut i64, a: *const i64, ggsw: *const f64,
         p: *const pz_glwe_op_params, batch: usize) -> c_int;
     pub fn pz_glwe_keyswitch_batched(m: *mut pz_module, res: *mut i64, a: *const i64, key: *const f64,
         p: *const pz_glwe_op_params, batch: usize) -> c_int;
+    /// mode: 0 glwe_automorphism, 1 _add, 2 _sub, 3 _sub_negate (poulpy-core/src/automorphism/glwe_ct.rs:51-275)
+    pub fn pz_glwe_automorphism_batched(m: *mut pz_module, res: *mut i64, a: *const i64, key: *const f64,
+        p: *const pz_glwe_op_params, gal: i64, mode: c_int, batch: usize) -> c_int;
+    pub fn pz_ggsw_external_product(m: *mut pz_module, res: *mut i64, a: *const i64, a_dnum: usize, ggsw: *const f64,
+        p: *const pz_glwe_op_params) -> c_int;
 }
 
 /// The reference panics (`assert!`) on shape / scratch violations; so does the shim.

@@ -136,6 +136,16 @@ unsafe impl HalImpl<FFT64Hip> for FFT64Hip {
         );
     }
 
+    // hal_impl.rs:517 / :524 — used by glwe_automorphism_{add,sub,sub_negate} (poulpy-core automorphism/glwe_ct.rs:96-275)
+    fn vec_znx_big_automorphism_assign<A>(module: &Module<Self>, k: i64, a: &mut A, a_col: usize, _s: &mut Scratch<Self>)
+    where A: VecZnxBigToMut<Self> {
+        let mut a = a.to_mut();
+        check(unsafe { ffi::pz_vec_znx_big_automorphism_assign(raw(module), k, a.as_mut_ptr(), a.cols(), a.size(), a_col) },
+              "vec_znx_big_automorphism_assign");
+    }
+    // (vec_znx_automorphism :236 / _assign :243 on the small container may either use pz_vec_znx_automorphism[_assign] or stay
+    //  on the inherited cpu-ref implementation: they are pure i64 host operations in the reference.)
+
     // The remaining DFT-domain methods (vec_znx_idft_apply_tmpa :541, vec_znx_dft_{add_into :553, add_scaled_assign :559,
     // add_assign :564, sub :569, sub_assign :575, sub_negate_assign :580, copy :585, zero :590}, svp_{prepare :595,
     // apply_dft :600, apply_dft_to_dft :606, apply_dft_to_dft_assign :612}, vmp_{apply_dft :636, zero :665},

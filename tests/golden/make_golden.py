@@ -71,6 +71,26 @@ def gen_external_product(name, seed, n, base2k, rank, a_size, dnum, key_size, re
     np.savez_compressed(os.path.join(HERE, name), kind="external_product", n=n, base2k=base2k, rank=rank, a=a, mat=mat, res=res)
 
 
+def gen_glwe_automorphism(name, seed, n, base2k, rank, a_size, dnum, key_size, res_size, p):
+    """dsize = 1 glwe_automorphism / glwe_automorphism_add (poulpy-core/src/automorphism/glwe_ct.rs:51-72, :96-140):
+    big = mask x key + body (keyswitching/glwe.rs:207-239); res_auto = phi(normalize(big)); res_add = normalize(phi(big) + a)."""
+    rng = np.random.default_rng(seed)
+    cols = rank + 1
+    a = uniform(rng, base2k, (a_size, cols, n))
+    mat = uniform(rng, base2k, (dnum, rank, key_size, cols, n))
+    big = exact.vmp_exact(np.ascontiguousarray(a[:, 1:, :]), mat, 0, key_size)
+    big[:a_size, 0, :] += a[:, 0, :].astype(object)
+    res_auto = np.zeros((res_size, cols, n), dtype=np.int64)
+    res_add = np.zeros((res_size, cols, n), dtype=np.int64)
+    for c in range(cols):
+        res_auto[:, c, :] = exact.automorphism_exact(exact.normalize_exact(big[:, c, :], base2k, res_size), p)
+        v = exact.automorphism_exact(big[:, c, :], p)
+        v[:a_size] += a[:, c, :].astype(object)
+        res_add[:, c, :] = exact.normalize_exact(v, base2k, res_size)
+    np.savez_compressed(os.path.join(HERE, name), kind="glwe_automorphism", n=n, base2k=base2k, rank=rank, p=p, a=a, mat=mat,
+                        res_auto=res_auto, res_add=res_add)
+
+
 def main():
     # shape grid of poulpy-hal/src/test_suite/vmp.rs (sizes 1..4, cols 1..2, limb_offset) at small N
     gen_vmp("vmp_n32_b12.npz", 1, 32, 12, rows=3, cols_in=2, cols_out=2, size=4, a_size=3, res_size=4, limb_offset=0)
@@ -83,6 +103,8 @@ def main():
     gen_svp("config1_svp_n1024_b17.npz", 7, 1024, 17, cols=2, size=2)
     gen_external_product("extprod_n256_b12_rank1.npz", 8, 256, 12, rank=1, a_size=4, dnum=4, key_size=4, res_size=4)
     gen_external_product("extprod_n128_b14_rank2.npz", 9, 128, 14, rank=2, a_size=3, dnum=3, key_size=4, res_size=3)
+    gen_glwe_automorphism("glwe_automorphism_n128_b13_rank1.npz", 10, 128, 13, rank=1, a_size=3, dnum=3, key_size=4, res_size=4, p=-5)
+    gen_glwe_automorphism("glwe_automorphism_n64_b12_rank2.npz", 11, 64, 12, rank=2, a_size=4, dnum=4, key_size=4, res_size=3, p=25)
     print("golden fixtures written to", HERE)
 
 

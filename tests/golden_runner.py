@@ -80,5 +80,39 @@ def run_fixture(path: str, module_factory) -> None:
         for c in range(cols):
             mod.vec_znx_big_normalize(res, base2k, 0, c, big, base2k, c)
         assert np.array_equal(res.data, want), f"{path}: external product differs"
+    elif kind == "glwe_automorphism":
+        a_np, mat_np, gal = z["a"], z["mat"], int(z["p"])
+        a_size, cols, _ = a_np.shape
+        dnum, rank, key_size, _, _ = mat_np.shape
+        a = VecZnx(n, cols, a_size, np.ascontiguousarray(a_np))
+        mat = MatZnx(n, dnum, rank, cols, key_size, np.ascontiguousarray(mat_np))
+        pm = mod.vmp_pmat_alloc(dnum, rank, cols, key_size)
+        mod.vmp_prepare(pm, mat)
+
+        def keyswitch_big():  # keyswitching/glwe.rs:207-239 through the HAL methods
+            ad = mod.vec_znx_dft_alloc(rank, a_size)
+            for j in range(rank):
+                mod.vec_znx_dft_apply(1, 0, ad, j, a, j + 1)
+            rd = mod.vec_znx_dft_alloc(cols, key_size)
+            mod.vmp_apply_dft_to_dft(rd, ad, pm, 0)
+            big = mod.vec_znx_idft_apply_consume(rd)
+            mod.vec_znx_big_add_small_assign(big, 0, a, 0)
+            return big
+
+        # glwe_automorphism (automorphism/glwe_ct.rs:51-72): normalize, then the automorphism of the result
+        big = keyswitch_big()
+        res = VecZnx(n, cols, z["res_auto"].shape[0])
+        for c in range(cols):
+            mod.vec_znx_big_normalize(res, base2k, 0, c, big, base2k, c)
+            mod.vec_znx_automorphism_assign(gal, res, c)
+        assert np.array_equal(res.data, z["res_auto"]), f"{path}: glwe_automorphism differs"
+        # glwe_automorphism_add (:96-140): automorphism of the big value, + a, normalize
+        big = keyswitch_big()
+        res = VecZnx(n, cols, z["res_add"].shape[0])
+        for c in range(cols):
+            mod.vec_znx_big_automorphism_assign(gal, big, c)
+            mod.vec_znx_big_add_small_assign(big, c, a, c)
+            mod.vec_znx_big_normalize(res, base2k, 0, c, big, base2k, c)
+        assert np.array_equal(res.data, z["res_add"]), f"{path}: glwe_automorphism_add differs"
     else:
         raise AssertionError(f"unknown fixture kind {kind}")

@@ -241,7 +241,8 @@ def test_big_add_small_assign(mods):
 # batched, device-resident GLWE operations (CoreImpl-level boundary)
 # ------------------------------------------------------------------------------------------
 def _run_glwe_op(hip, ref, ks, n, rank, rank_out, a_size, a_base2k, key_size, key_base2k, dnum, dsize, res_size, res_base2k, batch,
-                 seed, chunk=0, fuse=(True, True)):
+                 seed, chunk=0, fuse=(True, True), auto=None, in_place=False):
+    """auto = (galois element, mode) runs the glwe_automorphism family on top of the key switch."""
     from poulpy_amd.hal import GlweOpParams
     rng = seeded(seed)
     cols_a = rank + 1
@@ -257,20 +258,28 @@ def _run_glwe_op(hip, ref, ks, n, rank, rank_out, a_size, a_base2k, key_size, ke
         a = VecZnx(n, cols_a, a_size).fill_uniform(a_base2k, rng)
         a_all[b] = a.data
         res = VecZnx(n, cols_out, res_size)
-        if ks:
+        if auto is not None:
+            ref.glwe_automorphism(res, res_base2k, a, a_base2k, pr, dsize, key_base2k, auto[0], auto[1])
+        elif ks:
             ref.glwe_keyswitch(res, res_base2k, a, a_base2k, pr, dsize, key_base2k)
         else:
             ref.glwe_external_product(res, res_base2k, a, a_base2k, pr, dsize, key_base2k)
         want[b] = res.data
     d_a = hip.device_alloc(a_all.nbytes).upload(a_all)
     d_key = hip.device_alloc(ph.data.nbytes).upload(ph.data)
-    d_res = hip.device_alloc(want.nbytes)
-    hip.lib.pz_memset_d(hip.handle, d_res.ptr, 0x5A, want.nbytes)
+    if in_place:
+        assert a_all.shape == want.shape
+        d_res = d_a
+    else:
+        d_res = hip.device_alloc(want.nbytes)
+        hip.lib.pz_memset_d(hip.handle, d_res.ptr, 0x5A, want.nbytes)
     p = GlweOpParams(rank=rank, dnum=dnum, dsize=dsize, key_size=key_size, key_base2k=key_base2k, a_size=a_size, a_base2k=a_base2k,
                      res_size=res_size, res_base2k=res_base2k, rank_out=rank_out)
     hip.set_chunk(chunk)
     hip.set_fusion(*fuse)
-    if ks:
+    if auto is not None:
+        hip.glwe_automorphism_batched(d_res.ptr, d_a.ptr, d_key.ptr, p, auto[0], auto[1], batch)
+    elif ks:
         hip.glwe_keyswitch_batched(d_res.ptr, d_a.ptr, d_key.ptr, p, batch)
     else:
         hip.glwe_external_product_batched(d_res.ptr, d_a.ptr, d_key.ptr, p, batch)
@@ -278,7 +287,7 @@ def _run_glwe_op(hip, ref, ks, n, rank, rank_out, a_size, a_base2k, key_size, ke
     got = d_res.download(np.int64, want.size).reshape(want.shape)
     hip.set_chunk(0)
     hip.set_fusion(True, True)
-    for buf in (d_a, d_key, d_res):
+    for buf in ((d_a, d_key) if in_place else (d_a, d_key, d_res)):
         buf.free()
     return got, want
 
@@ -365,3 +374,112 @@ def test_wide_plan_external_product_n65536(monkeypatch):
     got, want = _run_glwe_op(hip, ref, True, n, 1, 1, 8, 12, 8, 12, 8, 1, 6, 12, batch=3, seed=98)
     assert np.array_equal(got, want)
     hip.close()
+
+
+# ------------------------------------------------------------------------------------------
+# automorphism family (HAL ops + CoreImpl glwe_automorphism*) and ggsw_external_product
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [32, 256, 1024, 65536])
+def test_vec_znx_automorphism(mods, n):
+    """poulpy-hal/src/test_suite/vec_znx.rs automorphism tests: p in {-5, 5} there; more Galois elements and ragged
+    sizes here (res limbs beyond a.size zeroed, garbage-prefilled outputs)."""
+    ref, hip = mods(n)
+    rng = seeded(n + 1)
+    for p in (-5, 5, 3, -1, 2 * n - 1, 2 * n + 7, 5 ** 7):
+        for (a_size, res_size) in ((3, 3), (2, 4), (4, 1)):
+            a = VecZnx(n, 2, a_size).fill_uniform(50, rng)
+            rr = VecZnx(n, 3, res_size).fill_uniform(60, rng)
+            rh = rr.copy()
+            ref.vec_znx_automorphism(p, rr, 2, a, 1)
+            hip.vec_znx_automorphism(p, rh, 2, a, 1)
+            assert np.array_equal(rr.data, rh.data), (p, a_size, res_size)
+            br, bh = VecZnxBig(n, 2, a_size), VecZnxBig(n, 2, a_size)
+            br.data[:] = a.data
+            bh.data[:] = a.data
+            ref.vec_znx_big_automorphism_assign(p, br, 0)
+            hip.vec_znx_big_automorphism_assign(p, bh, 0)
+            assert np.array_equal(br.data, bh.data), (p, a_size)
+            ar, ah = a.copy(), a.copy()
+            ref.vec_znx_automorphism_assign(p, ar, 1)
+            hip.vec_znx_automorphism_assign(p, ah, 1)
+            assert np.array_equal(ar.data, ah.data)
+
+
+def test_vec_znx_automorphism_rejects_even_and_alias(mods):
+    from poulpy_amd.hal import PoulpyHipError
+    n = 64
+    _, hip = mods(n)
+    a = VecZnx(n, 1, 2)
+    r = VecZnx(n, 1, 2)
+    with pytest.raises(PoulpyHipError):
+        hip.vec_znx_automorphism(4, r, 0, a, 0)
+    with pytest.raises(PoulpyHipError):
+        hip.vec_znx_automorphism(3, a, 0, a, 0)
+
+
+@pytest.mark.parametrize("fuse", [(True, True), (False, False)], ids=["fused", "unfused"])
+@pytest.mark.parametrize("mode", ["automorphism", "add", "sub", "sub_negate"])
+def test_glwe_automorphism_batched(mods, mode, fuse):
+    """poulpy-core/src/test_suite/automorphism/glwe_ct.rs sweeps rank and dsize for p = -5; here every variant of
+    automorphism/glwe_ct.rs:51-275 against the oracle's restatement, bit-exact, incl. cross-base2k and dsize 2."""
+    n = 256
+    ref, hip = mods(n)
+    for rank in (1, 2):
+        for (a_b, k_b, r_b, dsize) in ((12, 12, 12, 1), (16, 13, 15, 1), (13, 13, 13, 2)):
+            for gal in (-5, 3 ** 5):
+                got, want = _run_glwe_op(hip, ref, True, n, rank, rank, 4, a_b, 5, k_b, 3 if dsize == 1 else 2, dsize, 4, r_b,
+                                         batch=5, seed=17 + rank + dsize, chunk=2, fuse=fuse, auto=(gal, mode))
+                assert np.array_equal(got, want), (mode, rank, a_b, k_b, r_b, dsize, gal)
+
+
+@pytest.mark.parametrize("mode", ["automorphism", "add"])
+def test_glwe_automorphism_assign_form(mods, mode):
+    """glwe_automorphism_assign / _add_assign (glwe_ct.rs:74-94, :142-183): res == a."""
+    n = 512
+    ref, hip = mods(n)
+    got, want = _run_glwe_op(hip, ref, True, n, 1, 1, 4, 14, 4, 14, 4, 1, 4, 14, batch=6, seed=99, chunk=4, auto=(-5, mode),
+                             in_place=True)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("mode", ["automorphism", "sub_negate"])
+def test_config5_shape_automorphism_n65536(mods, mode):
+    """CKKS-rotate shape of BASELINE configs[4] at the FFT64-representable base: N=2^16, 8 limbs, rank 1, p = 5."""
+    n = 65536
+    ref, hip = mods(n)
+    got, want = _run_glwe_op(hip, ref, True, n, 1, 1, 8, 12, 8, 12, 8, 1, 8, 12, batch=2, seed=5, auto=(5, mode))
+    assert np.array_equal(got, want)
+
+
+def test_ggsw_external_product(mods):
+    """external_product/ggsw.rs:54-58: a loop of GLWE external products over the (row, column) entries of a GGSW."""
+    from poulpy_amd.hal import GlweOpParams
+    n, rank, dnum_a, size, base2k, dnum = 256, 1, 3, 4, 13, 4
+    ref, hip = mods(n)
+    rng = seeded(77)
+    cols = rank + 1
+    mat = MatZnx(n, dnum, cols, cols, size).fill_uniform(base2k, rng)
+    pr, ph = ref.vmp_pmat_alloc(dnum, cols, cols, size), hip.vmp_pmat_alloc(dnum, cols, cols, size)
+    ref.vmp_prepare(pr, mat)
+    hip.vmp_prepare(ph, mat)
+    a = MatZnx(n, dnum_a, cols, cols, size).fill_uniform(base2k, rng)   # the GGSW being multiplied
+    want = np.empty_like(a.data)
+    flat_a = a.data.reshape(dnum_a * cols, size, cols, n)
+    flat_w = want.reshape(dnum_a * cols, size, cols, n)
+    for e in range(dnum_a * cols):
+        ct = VecZnx(n, cols, size)
+        ct.data[:] = flat_a[e]
+        res = VecZnx(n, cols, size)
+        ref.glwe_external_product(res, base2k, ct, base2k, pr, 1, base2k)
+        flat_w[e] = res.data
+    d_a = hip.device_alloc(a.data.nbytes).upload(a.data)
+    d_key = hip.device_alloc(ph.data.nbytes).upload(ph.data)
+    d_res = hip.device_alloc(want.nbytes)
+    p = GlweOpParams(rank=rank, dnum=dnum, dsize=1, key_size=size, key_base2k=base2k, a_size=size, a_base2k=base2k, res_size=size,
+                     res_base2k=base2k, rank_out=rank)
+    hip.ggsw_external_product(d_res.ptr, d_a.ptr, dnum_a, d_key.ptr, p)
+    hip.sync()
+    got = d_res.download(np.int64, want.size).reshape(want.shape)
+    for buf in (d_a, d_key, d_res):
+        buf.free()
+    assert np.array_equal(got, want)

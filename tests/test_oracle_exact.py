@@ -5,6 +5,7 @@ properties are what anchors the oracle:
   P1  idft(vmp(dft(a), prepare(M))) == exact bivariate negacyclic product       (tests.rs:133-141)
   P2  idft(svp(dft(b), prepare(s))) == exact negacyclic product                  (test_suite/svp.rs)
   P3  normalize == big-int balanced digit decomposition / torus value preserved  (normalize.rs:428-540)
+  P5  automorphism family == X -> X^p stated directly on exact integers            (automorphism/glwe_ct.rs)
   A1  spectral identity of fft_ref (slot k <-> root exp(2 pi i (4 bitrev(k)+1)/(4m)))
 """
 import numpy as np
@@ -181,3 +182,56 @@ def test_external_product_and_keyswitch_match_exact(dsize):
     for c in range(cols):
         want[:, c, :] = exact.normalize_exact(big[:, c, :], base2k, 4)
     assert np.array_equal(res.data, want)
+
+
+@pytest.mark.parametrize("n", [8, 64, 1024])
+def test_P5_vec_znx_automorphism_direct(n):
+    """reference/znx/automorphism.rs restated (sequential index walk) vs the direct statement of X -> X^p, incl. the
+    reference's own test values p = -5, 5 (poulpy-hal/src/test_suite/vec_znx.rs), negative and > 2n elements, zeroed
+    tail limbs, and the composition law phi_p(phi_q(a)) = phi_{pq}(a)."""
+    R = RefModule(n)
+    rng = seeded(n)
+    a = VecZnx(n, 2, 3).fill_uniform(40, rng)
+    for p in (-5, 5, 3, -1, 2 * n - 1, 2 * n + 3, 5 ** 9):
+        r = VecZnx(n, 2, 4).fill_uniform(10, rng)
+        R.vec_znx_automorphism(p, r, 1, a, 0)
+        assert np.array_equal(r.data[:3, 1], exact.automorphism_exact(a.data[:, 0], p))
+        assert not r.data[3, 1].any()
+        q = 7
+        t = a.copy()
+        R.vec_znx_automorphism_assign(q, t, 0)
+        R.vec_znx_automorphism_assign(p, t, 0)
+        assert np.array_equal(t.data[:, 0], exact.automorphism_exact(a.data[:, 0], p * q))
+        assert np.array_equal(t.data[:, 1], a.data[:, 1])
+
+
+@pytest.mark.parametrize("mode", ["automorphism", "add", "sub", "sub_negate"])
+@pytest.mark.parametrize("rank", [1, 2])
+def test_P5_glwe_automorphism_family_matches_exact(mode, rank):
+    """automorphism/glwe_ct.rs:51-275 restated in the oracle vs exact integers: big = exact key-switch value (mask x key
+    + body), then phi / +-a / big-int normalize in the order the reference applies them."""
+    n, base2k = 32, 13
+    cols = rank + 1
+    R = RefModule(n)
+    rng = seeded(500 + rank)
+    a_size, dnum, key_size, res_size = 3, 3, 4, 4
+    a = VecZnx(n, cols, a_size).fill_uniform(base2k, rng)
+    mat = MatZnx(n, dnum, rank, cols, key_size).fill_uniform(base2k, rng)
+    pm = R.vmp_pmat_alloc(dnum, rank, cols, key_size)
+    R.vmp_prepare(pm, mat)
+    big = exact.vmp_exact(np.ascontiguousarray(a.data[:, 1:, :]), mat.data, 0, key_size)
+    big[:a_size, 0, :] += a.data[:, 0, :].astype(object)
+    for p in (-5, 3, 2 * n - 1):
+        res = VecZnx(n, cols, res_size)
+        R.glwe_automorphism(res, base2k, a, base2k, pm, 1, base2k, p, mode)
+        want = np.zeros((res_size, cols, n), dtype=np.int64)
+        for c in range(cols):
+            if mode == "automorphism":
+                want[:, c, :] = exact.automorphism_exact(exact.normalize_exact(big[:, c, :], base2k, res_size), p)
+                continue
+            v = exact.automorphism_exact(big[:, c, :], p)
+            av = np.zeros_like(v)
+            av[:a_size] = a.data[:, c, :].astype(object)
+            v = {"add": v + av, "sub": v - av, "sub_negate": av - v}[mode]
+            want[:, c, :] = exact.normalize_exact(v, base2k, res_size)
+        assert np.array_equal(res.data, want), (mode, rank, p)
