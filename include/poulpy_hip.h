@@ -240,6 +240,31 @@ int pz_glwe_automorphism_batched(pz_module* m, int64_t* res, const int64_t* a, c
  * for the a_dnum * (rank+1) GLWE entries of the GGSW `a` (MatZnx layout: entries are contiguous), device pointers. */
 int pz_ggsw_external_product(pz_module* m, int64_t* res, const int64_t* a, size_t a_dnum, const double* ggsw_pmat,
                              const pz_glwe_op_params* p);
+/* BlindRotationExecute<CGGI>::blind_rotation_execute (poulpy-bin-fhe/src/blind_rotation/algorithms/cggi/algorithm.rs:76-118)
+ * on `batch` LWE ciphertexts that share the lookup table and the prepared blind-rotation key:
+ *   block_size > 1 : execute_block_binary  (:265-368)       block_size == 1 : execute_standard (:370-440)
+ * (extension_factor > 1, execute_block_binary_extended :121-263, is not provided: PZ_ERR_UNSUPPORTED upstream of this call).
+ *   res     batch x GLWE(rank+1, res_size), overwritten
+ *   lwe_2n  batch x (n_lwe+1) i64: the output of mod_switch_2n (algorithms/mod.rs:136-171, host i64 code that stays in the
+ *           caller): [b, a_1 .. a_n_lwe]
+ *   lut     VecZnx(1, lut_size), shared                      brk  n_lwe prepared GGSWs (pz_vmp_prepare; rows = dnum,
+ *           cols_in = cols_out = rank+1, size = brk_size), contiguous, shared
+ * The prepared monomials x_pow_a of BlindRotationKeyPrepared (key_prepared.rs:66-74) are not an argument: in this
+ * backend's spectrum order DFT(X^a) is a row of roots of unity and is generated from a 2n-entry table.
+ * All pointers are device pointers. */
+typedef struct {
+    uint64_t rank;
+    uint64_t n_lwe;
+    uint64_t block_size;
+    uint64_t dnum;      /* rows of each GGSW of the key */
+    uint64_t brk_size;  /* limbs of the key */
+    uint64_t base2k;    /* of res, lut and key (the reference asserts they agree) */
+    uint64_t res_size;
+    uint64_t lut_size;
+} pz_blind_rotation_params;
+int pz_blind_rotation_execute_batched(pz_module* m, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
+                                      const pz_blind_rotation_params* p, size_t batch);
+size_t pz_blind_rotation_workspace_bytes(const pz_module* m, const pz_blind_rotation_params* p, size_t batch);
 /* workspace the calls above need for `batch` ciphertexts (bytes, device); keyswitch: 0 external product, 1 key switch,
  * 2 automorphism family */
 size_t pz_glwe_op_workspace_bytes(const pz_module* m, const pz_glwe_op_params* p, size_t batch, int keyswitch);

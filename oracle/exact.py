@@ -132,3 +132,17 @@ def automorphism_exact(a: np.ndarray, p: int) -> np.ndarray:
         else:
             out[..., k - n] = -a[..., i]
     return out
+
+
+def rotate_exact(a: np.ndarray, p: int) -> np.ndarray:
+    """X^p * a on the last axis, stated directly: coefficient i moves to (i + p) mod 2n, negated when >= n."""
+    a = np.asarray(a)
+    n = a.shape[-1]
+    out = np.zeros_like(a)
+    for i in range(n):
+        k = (i + p) % (2 * n)
+        if k < n:
+            out[..., k] = a[..., i]
+        else:
+            out[..., k - n] = -a[..., i]
+    return out

@@ -1540,3 +1540,138 @@ void pzr_glwe_automorphism(const pzr_tables* t, size_t rank, int mode, int64_t p
     glwe_keyswitch_core(t, rank, rank, res, res_size, res_base2k, a, a_size, a_base2k, key_pmat, dnum, key_size, dsize,
                         key_base2k, mode, p);
 }
+
+/* ------------------------------------------------------------------------ */
+/* poulpy-bin-fhe blind rotation (CGGI), SURVEY.md 8f rank 2                  */
+/* ------------------------------------------------------------------------ */
+
+/* reference/znx/rotate.rs:3-27: res = X^p * src in Z[X]/(X^n+1) */
+static void znx_rotate(int64_t p, int64_t* res, const int64_t* src, size_t n) {
+    size_t mp_2n = (size_t)(p & (int64_t)(2 * n - 1));
+    size_t mp_1n = mp_2n & (n - 1);
+    size_t mp_1n_neg = n - mp_1n;
+    int neg_first = mp_2n < n;
+    /* dst1 = res[0..mp_1n] <- src2 = src[mp_1n_neg..n] ; dst2 = res[mp_1n..n] <- src1 = src[0..mp_1n_neg] */
+    for (size_t i = 0; i < mp_1n; ++i) {
+        int64_t v = src[mp_1n_neg + i];
+        res[i] = neg_first ? (int64_t)(0 - (uint64_t)v) : v;
+    }
+    for (size_t i = 0; i < mp_1n_neg; ++i) {
+        int64_t v = src[i];
+        res[mp_1n + i] = neg_first ? v : (int64_t)(0 - (uint64_t)v);
+    }
+}
+
+/* reference/vec_znx/rotate.rs:10-36 */
+void pzr_vec_znx_rotate(size_t n, int64_t p, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                        const int64_t* a, size_t a_cols, size_t a_size, size_t a_col) {
+    size_t min_size = zmin(res_size, a_size);
+    for (size_t j = 0; j < min_size; ++j) znx_rotate(p, at_i64(res, n, res_cols, res_col, j), at_ci64(a, n, a_cols, a_col, j), n);
+    for (size_t j = min_size; j < res_size; ++j) memset(at_i64(res, n, res_cols, res_col, j), 0, n * sizeof(int64_t));
+}
+
+/* reference/vec_znx/mul_xp_minus_one.rs:23-37: res = (X^p - 1) * res, limb by limb through one polynomial of scratch */
+void pzr_vec_znx_mul_xp_minus_one_assign(size_t n, int64_t p, int64_t* res, size_t res_cols, size_t res_size, size_t res_col) {
+    int64_t* tmp = (int64_t*)malloc(n * sizeof(int64_t));
+    for (size_t j = 0; j < res_size; ++j) {
+        int64_t* r = at_i64(res, n, res_cols, res_col, j);
+        znx_rotate(p, tmp, r, n);
+        for (size_t i = 0; i < n; ++i) r[i] = (int64_t)((uint64_t)tmp[i] - (uint64_t)r[i]); /* znx_sub_negate_assign */
+    }
+    free(tmp);
+}
+
+/* reference/vec_znx/normalize.rs:403-425 (in place, same base) ; first step: znx/normalization.rs:44-65 */
+void pzr_vec_znx_normalize_assign(size_t n, size_t base2k, int64_t* res, size_t res_cols, size_t res_size, size_t res_col) {
+    int64_t* carry = (int64_t*)calloc(n, sizeof(int64_t));
+    for (size_t jj = res_size; jj-- > 0;) {
+        int64_t* x = at_i64(res, n, res_cols, res_col, jj);
+        if (jj == res_size - 1) {
+            for (size_t i = 0; i < n; ++i) {
+                int64_t d = get_digit(base2k, x[i]);
+                carry[i] = get_carry(base2k, x[i], d);
+                x[i] = d;
+            }
+        } else if (jj == 0) {
+            nz_final_step_assign(base2k, 0, x, carry, n);
+        } else {
+            nz_middle_step_assign(base2k, 0, x, carry, n);
+        }
+    }
+    free(carry);
+}
+
+/* blind_rotation/utils.rs:6-40 + algorithms/cggi/key_prepared.rs:66-74: x_pow_a[i] = svp_prepare(X^i), i in [0, 2n),
+ * with X^i = -X^(i-n) for i >= n.  out: 2n SvpPPol(cols = 1), n doubles each. */
+void pzr_blind_rotation_x_pow_a(const pzr_tables* t, double* out) {
+    size_t n = t->m << 1;
+    int64_t* buf = (int64_t*)calloc(n, sizeof(int64_t));
+    for (size_t ai = 0; ai < 2 * n; ++ai) {
+        if (ai < n) buf[ai] = 1;
+        else buf[(ai - n) & (n - 1)] = -1;
+        pzr_svp_prepare(t, out + ai * n, 1, 0, buf, 1, 0);
+        if (ai < n) buf[ai] = 0;
+        else buf[(ai - n) & (n - 1)] = 0;
+    }
+    free(buf);
+}
+
+/* blind_rotation/algorithms/cggi/algorithm.rs: execute_block_binary (:265-368) when block_size > 1, execute_standard
+ * (:370-440) when block_size == 1 (extension_factor = 1).  lwe_2n = the n_lwe+1 values produced by mod_switch_2n
+ * (algorithms/mod.rs:136-171: [b, a_1..a_n_lwe]); lut = VecZnx(1, lut_size); brk = n_lwe prepared GGSWs
+ * (VmpPMat rows = dnum, cols_in = cols_out = rank+1, size = brk_size), contiguous; res = GLWE(rank+1, res_size). */
+void pzr_blind_rotation_execute(const pzr_tables* t, size_t rank, size_t n_lwe, size_t block_size,
+                                int64_t* res, size_t res_size, size_t base2k,
+                                const int64_t* lwe_2n, const int64_t* lut, size_t lut_size,
+                                const double* brk, size_t dnum, size_t brk_size, const double* x_pow_a) {
+    size_t n = t->m << 1;
+    size_t cols = rank + 1;
+    size_t two_n = 2 * n;
+    size_t pmat_doubles = n * dnum * cols * cols * brk_size;
+    const int64_t* a = lwe_2n + 1;
+    int64_t b = lwe_2n[0];
+    memset(res, 0, n * cols * res_size * sizeof(int64_t));                /* :298 / :413 out_mut.data_mut().zero() */
+    pzr_vec_znx_rotate(n, b, res, cols, res_size, 0, lut, 1, lut_size, 0); /* :301 / :416 */
+    if (block_size > 1) {
+        double* acc_dft = (double*)calloc(n * cols * dnum, sizeof(double));
+        double* vmp_res = (double*)calloc(n * cols * brk_size, sizeof(double));
+        double* acc_add_dft = (double*)calloc(n * cols * brk_size, sizeof(double));
+        double* vmp_xai = (double*)calloc(n * brk_size, sizeof(double));
+        int64_t* acc_add_big = (int64_t*)calloc(n * brk_size, sizeof(int64_t));
+        for (size_t blk = 0; blk + block_size <= n_lwe; blk += block_size) { /* chunks_exact: a trailing partial block is dropped */
+            for (size_t j = 0; j < cols; ++j) { /* :319-322 */
+                pzr_vec_znx_dft_apply(t, 1, 0, acc_dft, cols, dnum, j, res, cols, res_size, j);
+                pzr_vec_znx_dft_zero(n, acc_add_dft, cols, brk_size, j);
+            }
+            for (size_t k = 0; k < block_size; ++k) { /* :324-337 */
+                size_t idx = blk + k;
+                size_t ai_pos = (size_t)((a[idx] + (int64_t)two_n) & (int64_t)(two_n - 1));
+                pzr_vmp_apply_dft_to_dft(n, vmp_res, cols, brk_size, acc_dft, cols, dnum, brk + idx * pmat_doubles, dnum, cols, cols, brk_size, 0);
+                for (size_t i = 0; i < cols; ++i) {
+                    pzr_svp_apply_dft_to_dft(n, vmp_xai, 1, brk_size, 0, x_pow_a + ai_pos * n, 1, 0, vmp_res, cols, brk_size, i);
+                    pzr_vec_znx_dft_add_assign(n, acc_add_dft, cols, brk_size, i, vmp_xai, 1, brk_size, 0);
+                    pzr_vec_znx_dft_sub_assign(n, acc_add_dft, cols, brk_size, i, vmp_res, cols, brk_size, i);
+                }
+            }
+            for (size_t i = 0; i < cols; ++i) { /* :342-346 */
+                pzr_vec_znx_idft_apply(t, acc_add_big, 1, brk_size, 0, acc_add_dft, cols, brk_size, i);
+                pzr_vec_znx_big_add_small_assign(n, acc_add_big, 1, brk_size, 0, res, cols, res_size, i);
+                pzr_vec_znx_normalize(n, res, cols, res_size, base2k, 0, i, acc_add_big, 1, brk_size, base2k, 0);
+            }
+        }
+        free(acc_dft);
+        free(vmp_res);
+        free(acc_add_dft);
+        free(vmp_xai);
+        free(acc_add_big);
+    } else {
+        int64_t* acc_tmp = (int64_t*)calloc(n * cols * res_size, sizeof(int64_t));
+        for (size_t idx = 0; idx < n_lwe; ++idx) { /* :423-433 */
+            pzr_glwe_external_product(t, rank, acc_tmp, res_size, base2k, res, res_size, base2k, brk + idx * pmat_doubles, dnum, brk_size, 1, base2k);
+            for (size_t i = 0; i < cols; ++i) pzr_vec_znx_mul_xp_minus_one_assign(n, a[idx], acc_tmp, cols, res_size, i);
+            for (size_t i = 0; i < cols; ++i) pzr_vec_znx_big_add_small_assign(n, res, cols, res_size, i, acc_tmp, cols, res_size, i); /* glwe_add_assign */
+        }
+        for (size_t i = 0; i < cols; ++i) pzr_vec_znx_normalize_assign(n, base2k, res, cols, res_size, i); /* :437 */
+        free(acc_tmp);
+    }
+}

@@ -147,6 +147,19 @@ void pzr_glwe_automorphism(const pzr_tables* t, size_t rank, int mode, int64_t p
                            const int64_t* a, size_t a_size, size_t a_base2k,
                            const double* key_pmat, size_t dnum, size_t key_size, size_t dsize, size_t key_base2k);
 
+/* reference/vec_znx/rotate.rs:10-36, mul_xp_minus_one.rs:23-37, normalize.rs:403-425 */
+void pzr_vec_znx_rotate(size_t n, int64_t p, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                        const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+void pzr_vec_znx_mul_xp_minus_one_assign(size_t n, int64_t p, int64_t* res, size_t res_cols, size_t res_size, size_t res_col);
+void pzr_vec_znx_normalize_assign(size_t n, size_t base2k, int64_t* res, size_t res_cols, size_t res_size, size_t res_col);
+
+/* poulpy-bin-fhe/src/blind_rotation: key_prepared.rs:66-74 (x_pow_a table) and algorithms/cggi/algorithm.rs:265-440 */
+void pzr_blind_rotation_x_pow_a(const pzr_tables* t, double* out /* 2n * n doubles */);
+void pzr_blind_rotation_execute(const pzr_tables* t, size_t rank, size_t n_lwe, size_t block_size,
+                                int64_t* res, size_t res_size, size_t base2k,
+                                const int64_t* lwe_2n, const int64_t* lut, size_t lut_size,
+                                const double* brk, size_t dnum, size_t brk_size, const double* x_pow_a);
+
 #ifdef __cplusplus
 }
 #endif

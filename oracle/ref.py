@@ -237,3 +237,30 @@ class RefModule:
         self.lib.pzr_glwe_automorphism(self.t, c_size_t(rank), C.c_int(self.AUTO_MODES[mode]), c_int64(p), _p(res.data),
                                        *_sz(res.size, res_base2k), _p(a.data), *_sz(a.size, a_base2k), _p(pmat.data),
                                        *_sz(pmat.rows, pmat.size, dsize, key_base2k))
+
+    # blind rotation (poulpy-bin-fhe/src/blind_rotation/algorithms/cggi), SURVEY.md 8f rank 2
+    def vec_znx_rotate(self, p, res, res_col, a, a_col):
+        self.lib.pzr_vec_znx_rotate(c_size_t(self._n), c_int64(p), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                    *_sz(a.cols, a.size, a_col))
+
+    def vec_znx_mul_xp_minus_one_assign(self, p, res, res_col, scratch=None):
+        self.lib.pzr_vec_znx_mul_xp_minus_one_assign(c_size_t(self._n), c_int64(p), _p(res.data), *_sz(res.cols, res.size, res_col))
+
+    def vec_znx_normalize_assign(self, base2k, res, res_col, scratch=None):
+        self.lib.pzr_vec_znx_normalize_assign(c_size_t(self._n), c_size_t(base2k), _p(res.data), *_sz(res.cols, res.size, res_col))
+
+    def blind_rotation_x_pow_a(self) -> np.ndarray:
+        """key_prepared.rs:66-74: the 2n prepared monomials X^i (SvpPPol, cols = 1), as one (2n, n) f64 array."""
+        out = np.zeros((2 * self._n, self._n), dtype=np.float64)
+        self.lib.pzr_blind_rotation_x_pow_a(self.t, _p(out))
+        return out
+
+    def blind_rotation_execute(self, res, base2k, lwe_2n: np.ndarray, lut, brk: np.ndarray, dnum, brk_size, block_size,
+                               x_pow_a: np.ndarray):
+        """algorithm.rs:265-440 on one LWE ciphertext: res GLWE (VecZnx cols = rank+1), lwe_2n = mod-switched [b, a_1..a_n],
+        lut VecZnx(1, size), brk = (n_lwe, prepared GGSW doubles) array."""
+        rank = res.cols - 1
+        n_lwe = lwe_2n.shape[0] - 1
+        assert brk.dtype == np.float64 and brk.flags["C_CONTIGUOUS"] and lwe_2n.dtype == np.int64
+        self.lib.pzr_blind_rotation_execute(self.t, *_sz(rank, n_lwe, block_size), _p(res.data), *_sz(res.size, base2k), _p(lwe_2n),
+                                            _p(lut.data), c_size_t(lut.size), _p(brk), *_sz(dnum, brk_size), _p(x_pow_a))

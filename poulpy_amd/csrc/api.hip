@@ -273,6 +273,28 @@ static int launch_automorphism(pz_module* M, int npolys, const long long* src, P
     return PZ_OK;
 }
 
+static int launch_rotate(pz_module* M, int npolys, const long long* src, PolyMap sm, long long* dst, PolyMap dm, int mode,
+                         int polys_per_batch, const long long* shift, long long shift_bs, long long shift_idx, long long shift_const) {
+    if (npolys <= 0) return PZ_OK;
+    RotArgs g;
+    g.src = src; g.dst = dst; g.sm = sm; g.dm = dm; g.npolys = npolys; g.n = (int)M->n;
+    g.polys_per_batch = std::max(polys_per_batch, 1); g.mode = mode;
+    g.shift = shift; g.shift_bs = shift_bs; g.shift_idx = shift_idx; g.shift_const = shift_const;
+    const int bpp = M->n >= 512 ? (int)(M->n / 512) : 1;
+    KTimer kt(M, PZ_K_ELEMENTWISE);
+    hipLaunchKernelGGL(k_rotate, dim3(npolys * bpp), dim3(256), 0, M->stream, g);
+    PZ_HIP(hipGetLastError());
+    return PZ_OK;
+}
+static int ensure_w2n(pz_module* M) {
+    if (M->w2n) return PZ_OK;
+    const long long two_n = 2 * (long long)M->n;
+    std::vector<cplx> h((size_t)two_n);
+    double c, s;
+    for (long long t = 0; t < two_n; ++t) { root_of_unity(t, two_n, c, s); h[(size_t)t] = make_double2(c, s); }
+    return upload_table(&M->w2n, h);
+}
+
 // ------------------------------------------------------------------------------
 // device-level operations (device pointers, batch strides in scalars)
 // ------------------------------------------------------------------------------
@@ -483,7 +505,7 @@ void pz_module_free(pz_module* M) {
     if (!M) return;
     (void)hipSetDevice(M->device);
     if (M->stream) (void)hipStreamSynchronize(M->stream);
-    for (void* p : {(void*)M->tw1, (void*)M->tw1inv, (void*)M->wL1, (void*)M->wL2, (void*)M->tw12, (void*)M->tw12t, M->ws, (void*)M->margin})
+    for (void* p : {(void*)M->tw1, (void*)M->tw1inv, (void*)M->wL1, (void*)M->wL2, (void*)M->tw12, (void*)M->tw12t, (void*)M->w2n, M->ws, (void*)M->margin})
         if (p) (void)hipFree(p);
     for (auto& c : M->arena) (void)hipFree(c.p);
     for (auto& t : M->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
@@ -1446,6 +1468,123 @@ int pz_ggsw_external_product(pz_module* M, int64_t* res, const int64_t* a, size_
     PZ_ENTER(M);
     PZ_REQUIRE(p != nullptr, "null params");
     return glwe_op(M, false, res, a, ggsw_pmat, p, a_dnum * (p->rank + 1));
+}
+
+// ------------------------------------------------------------------------------
+// public: CGGI blind rotation on a batch of LWE ciphertexts (device-resident)
+// poulpy-bin-fhe/src/blind_rotation/algorithms/cggi/algorithm.rs:76-118 (dispatch), :265-368 (block binary), :370-440 (standard)
+// ------------------------------------------------------------------------------
+size_t pz_blind_rotation_workspace_bytes(const pz_module* M, const pz_blind_rotation_params* p, size_t batch) {
+    if (!M || !p) return 0;
+    const size_t n8 = (size_t)M->n * 8, cols = p->rank + 1;
+    const size_t tp = cols * std::max({(size_t)p->dnum, (size_t)p->brk_size, (size_t)p->res_size});
+    const size_t T = align256(batch * tp * (size_t)M->m * sizeof(cplx));
+    if (p->block_size > 1)
+        return align256(batch * n8 * cols * p->dnum) + 2 * align256(batch * n8 * cols * p->brk_size) + T;
+    pz_glwe_op_params ep;
+    ep.rank = p->rank; ep.dnum = p->dnum; ep.dsize = 1; ep.key_size = p->brk_size; ep.key_base2k = p->base2k;
+    ep.a_size = p->res_size; ep.a_base2k = p->base2k; ep.res_size = p->res_size; ep.res_base2k = p->base2k; ep.rank_out = p->rank;
+    return align256(batch * n8 * cols * p->res_size) + pz_glwe_op_workspace_bytes(M, &ep, batch, 0);
+}
+
+int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
+                                      const pz_blind_rotation_params* p, size_t batch) {
+    PZ_ENTER(M);
+    PZ_REQUIRE(p != nullptr, "null params");
+    PZ_REQUIRE(p->n_lwe >= 1 && p->block_size >= 1 && p->dnum >= 1 && p->brk_size >= 1 && p->res_size >= 1 && p->lut_size >= 1,
+               "blind_rotation: empty shape");
+    PZ_REQUIRE(p->base2k >= 1 && p->base2k <= 63, "blind_rotation: base2k out of range");
+    PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(lwe_2n) && is_device_ptr(lut) && is_device_ptr(brk),
+               "batched entry points take device pointers");
+    if (batch == 0) return PZ_OK;
+    const long long n = (long long)M->n;
+    const int cols = (int)p->rank + 1, dnum = (int)p->dnum, bsz = (int)p->brk_size, rsz = (int)p->res_size;
+    const int B = (int)batch, n_lwe = (int)p->n_lwe, blk = (int)p->block_size, k = (int)p->base2k;
+    const long long lwe_bs = (long long)n_lwe + 1;
+    const size_t pmat_doubles = (size_t)n * dnum * cols * cols * bsz;
+    const long long res_ct = n * cols * rsz;
+    DV rv{res, res_ct, cols, rsz};
+
+    // acc = X^b * LUT in column 0, zero elsewhere (:298-301 / :413-416)
+    PZ_HIP(hipMemsetAsync(res, 0, (size_t)B * res_ct * 8, M->stream));
+    {
+        const int nl = std::min(rsz, (int)p->lut_size);
+        PolyMap sm{nl, 1, 0, n, 0, 0};                     // the LUT is shared: batch stride 0, VecZnx(1, lut_size)
+        PolyMap dm{nl, 1, res_ct, (long long)cols * n, 0, 0};
+        PZ_TRY(launch_rotate(M, B * nl, (const long long*)lut, sm, (long long*)res, dm, 0, nl, (const long long*)lwe_2n, lwe_bs, 0, 0));
+    }
+
+    if (blk > 1) {
+        PZ_TRY(ensure_w2n(M));
+        const size_t n8 = (size_t)M->n * 8;
+        const size_t acc_dft_bytes = align256(batch * n8 * cols * dnum), vr_bytes = align256(batch * n8 * cols * bsz);
+        const size_t tp = (size_t)cols * std::max({dnum, bsz, rsz});
+        const size_t t_bytes = align256(batch * tp * (size_t)M->m * sizeof(cplx));
+        PZ_TRY(ws_reserve(M, acc_dft_bytes + 2 * vr_bytes + t_bytes));
+        char* base = (char*)M->ws;
+        double* acc_dft = (double*)base; base += acc_dft_bytes;
+        double* vmp_res = (double*)base; base += vr_bytes;
+        double* acc_add = (double*)base; base += vr_bytes;
+        cplx* T = (cplx*)base;
+        DV ad{acc_dft, n * cols * dnum, cols, dnum}, vr{vmp_res, n * cols * bsz, cols, bsz}, aa{acc_add, n * cols * bsz, cols, bsz};
+        const bool tail = M->fuse_tail && tail_supported(M);
+        for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {  // chunks_exact: a trailing partial block is ignored, as in the reference
+            PZ_TRY(dev_dft_apply(M, B, 1, 0, ad, 0, rv, 0, cols, nullptr, T));                      // :319-321
+            PZ_HIP(hipMemsetAsync(acc_add, 0, (size_t)B * aa.bs * 8, M->stream));                     // :321
+            for (int i = b0; i < b0 + blk; ++i) {                                                       // :324-337
+                PZ_TRY(dev_vmp(M, B, vr, ad, brk + (size_t)i * pmat_doubles, dnum, cols, cols, bsz, 0));
+                XaiArgs g;
+                g.acc = (cplx*)acc_add; g.v = (const cplx*)vmp_res; g.acc_bs = aa.bs / 2; g.v_bs = vr.bs / 2;
+                g.polys = cols * bsz; g.m = (int)M->m; g.batch = B;
+                g.lwe = (const long long*)lwe_2n; g.lwe_bs = lwe_bs; g.idx = i; g.w2n = M->w2n;
+                const long long total = (long long)B * g.polys * g.m;
+                KTimer kt(M, PZ_K_ELEMENTWISE);
+                hipLaunchKernelGGL(k_xai_acc, dim3((unsigned)std::min<long long>((total + 255) / 256, 256 * 16)), dim3(256), 0, M->stream, g);
+                PZ_HIP(hipGetLastError());
+            }
+            // acc = normalize(idft(acc_add) + acc)  (:342-346)
+            if (tail) {
+                PolyMap sm{bsz, cols, aa.bs, (long long)cols * n, n, 0};
+                PZ_TRY(launch_inv_pass2(M, B * bsz * cols, acc_add, sm, T));
+                PZ_TRY(launch_inv_tail(M, B, T, bsz, cols, (long long*)res, res_ct, cols, rsz, (const long long*)res, res_ct, cols, rsz, k,
+                                       false, true));
+            } else {
+                PZ_TRY(dev_idft(M, B, aa, 0, aa, 0, cols, bsz, T));
+                for (int c = 0; c < cols; ++c) {
+                    PZ_TRY(launch_ew(M, EW_ADD_I64, (int64_t*)acc_add + (long long)c * n, aa.bs, (long long)cols * n,
+                                     (int64_t*)acc_add + (long long)c * n, aa.bs, (long long)cols * n, res + (long long)c * n, res_ct,
+                                     (long long)cols * n, std::min(bsz, rsz), B));
+                    PZ_TRY(dev_normalize(M, B, rv, k, 0, c, aa, k, c));
+                }
+            }
+        }
+        return PZ_OK;
+    }
+
+    // standard: acc += (X^a_i - 1) * (acc (x) BRK_i) per coefficient, one normalization at the end (:423-437)
+    pz_glwe_op_params ep;
+    ep.rank = p->rank; ep.dnum = p->dnum; ep.dsize = 1; ep.key_size = p->brk_size; ep.key_base2k = p->base2k;
+    ep.a_size = p->res_size; ep.a_base2k = p->base2k; ep.res_size = p->res_size; ep.res_base2k = p->base2k; ep.rank_out = p->rank;
+    // acc_tmp lives in its own allocation: the external product owns the module workspace
+    int64_t* acc_tmp = nullptr;
+    PZ_HIP(hipMalloc(&acc_tmp, (size_t)B * res_ct * 8));
+    int st = PZ_OK;
+    PolyMap pm{rsz, cols, res_ct, (long long)cols * n, n, 0};
+    for (int i = 0; i < n_lwe && st == PZ_OK; ++i) {
+        st = glwe_op(M, false, acc_tmp, res, brk + (size_t)i * pmat_doubles, &ep, batch);
+        if (st == PZ_OK)
+            st = launch_rotate(M, B * rsz * cols, (const long long*)acc_tmp, pm, (long long*)res, pm, 2, rsz * cols, (const long long*)lwe_2n,
+                               lwe_bs, 1 + i, 0);
+    }
+    if (st == PZ_OK) {
+        // vec_znx_normalize_assign (normalize.rs:403-425) == out-of-place same-base normalize of a copy
+        PZ_HIP(hipMemcpyAsync(acc_tmp, res, (size_t)B * res_ct * 8, hipMemcpyDeviceToDevice, M->stream));
+        DV tv{acc_tmp, res_ct, cols, rsz};
+        for (int c = 0; c < cols && st == PZ_OK; ++c) st = dev_normalize(M, B, rv, k, 0, c, tv, k, c);
+    }
+    (void)hipStreamSynchronize(M->stream);
+    (void)hipFree(acc_tmp);
+    return st;
 }
 
 }  // extern "C"

@@ -319,6 +319,88 @@ __global__ void __launch_bounds__(256) k_automorphism(AutoArgs g) {
 }
 
 // =================================================================================
+// vec_znx_rotate family with a per-ciphertext exponent (reference/znx/rotate.rs:3-27: res = X^k * src), gather form:
+//   res[j] = +-src[(j - k) mod 2n]   (negated when that index is >= n).
+// mode 0: dst = X^k src;  1: dst = X^k src - src  (vec_znx_mul_xp_minus_one, mul_xp_minus_one.rs:13-37);
+// mode 2: dst += X^k src - src  (mul_xp_minus_one followed by glwe_add_assign: the standard blind-rotation step).
+// k of polynomial p: shift[(p / polys_per_batch) * shift_bs + shift_idx] when shift != nullptr, else shift_const.
+// =================================================================================
+struct RotArgs {
+    const long long* src;
+    long long* dst;
+    PolyMap sm, dm;
+    int npolys, n, polys_per_batch, mode;
+    const long long* shift;
+    long long shift_bs, shift_idx, shift_const;
+};
+
+__global__ void __launch_bounds__(256) k_rotate(RotArgs g) {
+    const int bpp = g.n >= 512 ? g.n / 512 : 1;
+    const int poly = blockIdx.x / bpp, blk = blockIdx.x % bpp;
+    if (poly >= g.npolys) return;
+    const long long k = g.shift ? g.shift[(long long)(poly / g.polys_per_batch) * g.shift_bs + g.shift_idx] : g.shift_const;
+    const unsigned mask2 = 2u * (unsigned)g.n - 1u, nn = (unsigned)g.n;
+    const unsigned kk = (unsigned)((unsigned long long)k & (unsigned long long)mask2);
+    const long long* src = g.src + map_off(g.sm, poly);
+    long long* dst = g.dst + map_off(g.dm, poly);
+    const int j = blk * 512 + threadIdx.x * 2;
+    if (j >= g.n) return;
+    unsigned long long out[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const unsigned i0 = ((unsigned)(j + e) - kk) & mask2;
+        const unsigned long long v = (unsigned long long)src[i0 & (nn - 1u)];
+        out[e] = i0 >= nn ? 0ull - v : v;
+    }
+    if (g.mode >= 1) {
+        const ulonglong2 s = *reinterpret_cast<const ulonglong2*>(src + j);
+        out[0] -= s.x;
+        out[1] -= s.y;
+    }
+    if (g.mode == 2) {
+        const ulonglong2 d = *reinterpret_cast<const ulonglong2*>(dst + j);
+        out[0] += d.x;
+        out[1] += d.y;
+    }
+    *reinterpret_cast<ulonglong2*>(dst + j) = make_ulonglong2(out[0], out[1]);
+}
+
+// =================================================================================
+// Blind-rotation accumulation step (poulpy-bin-fhe blind_rotation/algorithms/cggi/algorithm.rs:331-335):
+//   acc[b][p] += DFT(X^a_b) (.) v[b][p] - v[b][p]      for the cols*size polynomials p of ciphertext b,
+// a_b = lwe_2n[b][1 + idx] mod 2n.  The reference multiplies by a prepared monomial x_pow_a[a] (an SvpPPol); in this
+// backend's spectrum order DFT(X^a)[q] = exp(2 pi i a (4q+1) / 2n), read from the 2n-entry root table w2n, so no
+// 2n x n table is needed (it would be 4 GiB at n = 2^14).
+// =================================================================================
+struct XaiArgs {
+    cplx* acc;
+    const cplx* v;
+    long long acc_bs, v_bs;      // points between ciphertexts
+    int polys, m, batch;
+    const long long* lwe;        // [batch][n_lwe + 1]
+    long long lwe_bs, idx;       // a_b = lwe[b*lwe_bs + 1 + idx]
+    const cplx* w2n;             // exp(2 pi i t / 2n), t < 2n = 4m
+};
+
+__global__ void __launch_bounds__(256) k_xai_acc(XaiArgs g) {
+    const long long per_ct = (long long)g.polys * g.m;
+    const long long total = (long long)g.batch * per_ct;
+    const unsigned mask = 4u * (unsigned)g.m - 1u;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const long long b = t / per_ct, e = t % per_ct;
+        const unsigned q = (unsigned)(e % g.m);
+        const unsigned a = (unsigned)((unsigned long long)g.lwe[b * g.lwe_bs + 1 + g.idx] & (unsigned long long)mask);
+        const cplx x = g.w2n[(a * (4u * q + 1u)) & mask];
+        const cplx v = g.v[b * g.v_bs + e];
+        cplx r = g.acc[b * g.acc_bs + e];
+        const cplx xv = cmul(x, v);
+        r.x = (r.x + xv.x) - v.x;
+        r.y = (r.y + xv.y) - v.y;
+        g.acc[b * g.acc_bs + e] = r;
+    }
+}
+
+// =================================================================================
 // normalize: reference/vec_znx/normalize.rs + reference/znx/normalization.rs.
 // The carry chain runs across limbs, never across coefficients, so one thread owns
 // one coefficient and walks the limbs with the carry in a register.  Arithmetic is

@@ -102,6 +102,7 @@ struct pz_module {
     // device tables (cplx): tw1[m1], tw1inv[m1], wL1[m1], wL2[m2], tw12[m] ([j2][q1])
     pz::cplx *tw1 = nullptr, *tw1inv = nullptr, *wL1 = nullptr, *wL2 = nullptr, *tw12 = nullptr;
     pz::cplx* tw12t = nullptr;  // the same table as [q1][j2] (row-major pipeline)
+    pz::cplx* w2n = nullptr;    // exp(2 pi i t / 2n), t < 2n: DFT of the monomials X^a (blind rotation), built on first use
     // grow-only workspace
     void* ws = nullptr;
     size_t ws_bytes = 0;

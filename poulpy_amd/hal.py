@@ -33,6 +33,11 @@ class GlweOpParams(C.Structure):
         "rank", "dnum", "dsize", "key_size", "key_base2k", "a_size", "a_base2k", "res_size", "res_base2k", "rank_out")]
 
 
+class BlindRotationParams(C.Structure):
+    """pz_blind_rotation_params (include/poulpy_hip.h)"""
+    _fields_ = [(k, c_uint64) for k in ("rank", "n_lwe", "block_size", "dnum", "brk_size", "base2k", "res_size", "lut_size")]
+
+
 _lib = None
 
 
@@ -58,7 +63,7 @@ def load_library(path: str | None = None) -> C.CDLL:
                  "pz_bytes_of_vmp_pmat", "pz_vec_znx_idft_apply_tmp_bytes", "pz_vmp_prepare_tmp_bytes",
                  "pz_vmp_apply_dft_tmp_bytes", "pz_vmp_apply_dft_to_dft_tmp_bytes", "pz_vec_znx_big_normalize_tmp_bytes",
                  "pz_glwe_op_workspace_bytes", "pz_vec_znx_automorphism_assign_tmp_bytes",
-                 "pz_vec_znx_big_automorphism_assign_tmp_bytes"):
+                 "pz_vec_znx_big_automorphism_assign_tmp_bytes", "pz_blind_rotation_workspace_bytes"):
         getattr(lib, name).restype = c_size_t
     if path is None:
         _lib = lib
@@ -343,6 +348,14 @@ class Module:
 
     def glwe_keyswitch_batched(self, res: c_void_p, a: c_void_p, key_pmat: c_void_p, params: GlweOpParams, batch: int):
         self._ck(self.lib.pz_glwe_keyswitch_batched(self.handle, res, a, key_pmat, C.byref(params), c_size_t(batch)))
+
+    def blind_rotation_execute_batched(self, res: c_void_p, lwe_2n: c_void_p, lut: c_void_p, brk: c_void_p, params: BlindRotationParams,
+                                       batch: int):
+        """poulpy-bin-fhe blind_rotation/algorithms/cggi/algorithm.rs:76-118,265-440 on a batch of mod-switched LWE ciphertexts."""
+        self._ck(self.lib.pz_blind_rotation_execute_batched(self.handle, res, lwe_2n, lut, brk, C.byref(params), c_size_t(batch)))
+
+    def blind_rotation_workspace_bytes(self, params: BlindRotationParams, batch: int) -> int:
+        return self.lib.pz_blind_rotation_workspace_bytes(self.handle, C.byref(params), c_size_t(batch))
 
     def glwe_op_workspace_bytes(self, params: GlweOpParams, batch: int, keyswitch: bool) -> int:
         return self.lib.pz_glwe_op_workspace_bytes(self.handle, C.byref(params), c_size_t(batch), c_int(int(keyswitch)))

@@ -483,3 +483,65 @@ def test_ggsw_external_product(mods):
     for buf in (d_a, d_key, d_res):
         buf.free()
     assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------
+# SURVEY.md 8f rank 2 / BASELINE configs[3]: CGGI blind rotation on a batch of LWE ciphertexts
+# ------------------------------------------------------------------------------------------
+def _run_blind_rotation(hip, ref, n, rank, n_lwe, block_size, dnum, brk_size, res_size, base2k, batch, seed):
+    from poulpy_amd.hal import BlindRotationParams
+    rng = seeded(seed)
+    cols = rank + 1
+    lut = VecZnx(n, 1, res_size).fill_uniform(base2k, rng)
+    brk_r = np.empty((n_lwe, n * dnum * cols * cols * brk_size), dtype=np.float64)
+    brk_h = np.empty_like(brk_r)
+    for i in range(n_lwe):
+        mat = MatZnx(n, dnum, cols, cols, brk_size).fill_uniform(base2k, rng)
+        pr, ph = ref.vmp_pmat_alloc(dnum, cols, cols, brk_size), hip.vmp_pmat_alloc(dnum, cols, cols, brk_size)
+        ref.vmp_prepare(pr, mat)
+        hip.vmp_prepare(ph, mat)
+        brk_r[i] = pr.data.reshape(-1)
+        brk_h[i] = ph.data.reshape(-1)
+    lwe = rng.integers(-n, n, (batch, n_lwe + 1), dtype=np.int64)   # mod_switch_2n output range
+    lwe[0, 1] = 0        # X^0 - 1 = 0: a coefficient that contributes nothing
+    lwe[-1, 0] = n - 1
+    xpa = ref.blind_rotation_x_pow_a() if block_size > 1 else np.zeros((1, 1))
+    want = np.empty((batch, res_size, cols, n), dtype=np.int64)
+    for b in range(batch):
+        res = VecZnx(n, cols, res_size)
+        ref.blind_rotation_execute(res, base2k, np.ascontiguousarray(lwe[b]), lut, brk_r, dnum, brk_size, block_size, xpa)
+        want[b] = res.data
+    d_lwe = hip.device_alloc(lwe.nbytes).upload(lwe)
+    d_lut = hip.device_alloc(lut.data.nbytes).upload(lut.data)
+    d_brk = hip.device_alloc(brk_h.nbytes).upload(brk_h)
+    d_res = hip.device_alloc(want.nbytes)
+    hip.lib.pz_memset_d(hip.handle, d_res.ptr, 0x33, want.nbytes)
+    p = BlindRotationParams(rank=rank, n_lwe=n_lwe, block_size=block_size, dnum=dnum, brk_size=brk_size, base2k=base2k,
+                            res_size=res_size, lut_size=res_size)
+    hip.blind_rotation_execute_batched(d_res.ptr, d_lwe.ptr, d_lut.ptr, d_brk.ptr, p, batch)
+    hip.sync()
+    got = d_res.download(np.int64, want.size).reshape(want.shape)
+    for buf in (d_lwe, d_lut, d_brk, d_res):
+        buf.free()
+    return got, want
+
+
+@pytest.mark.parametrize("block_size", [1, 3])
+@pytest.mark.parametrize("rank", [1, 2])
+def test_blind_rotation_batched(mods, rank, block_size):
+    """poulpy-bin-fhe/src/blind_rotation/tests/test_suite: block sizes 1 and 7 at n_glwe 256; here both variants of
+    algorithm.rs against the oracle's restatement on random key material, bit-exact (7 LWE coefficients: a trailing
+    partial block, which chunks_exact drops)."""
+    n = 256
+    ref, hip = mods(n)
+    got, want = _run_blind_rotation(hip, ref, n, rank, 7, block_size, 2, 3, 2, 14, batch=5, seed=31 + rank)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n,block_size", [(1024, 7), (1024, 1), (2048, 4)])
+def test_config4_shape_blind_rotation(mods, n, block_size):
+    """BASELINE configs[3] shape (gate-bootstrap blind rotation, N = 2^10 class parameters: rank 1, 2 limbs of 17 bits,
+    dnum 2, block size 7) on a short LWE (28 coefficients) so that the CPU oracle finishes in seconds."""
+    ref, hip = mods(n)
+    got, want = _run_blind_rotation(hip, ref, n, 1, 28, block_size, 2, 2, 2, 17, batch=9, seed=n + block_size)
+    assert np.array_equal(got, want)

@@ -6,6 +6,7 @@ properties are what anchors the oracle:
   P2  idft(svp(dft(b), prepare(s))) == exact negacyclic product                  (test_suite/svp.rs)
   P3  normalize == big-int balanced digit decomposition / torus value preserved  (normalize.rs:428-540)
   P5  automorphism family == X -> X^p stated directly on exact integers            (automorphism/glwe_ct.rs)
+  P6  CGGI blind rotation (block-binary and standard) == the same recurrence on exact integers  (algorithm.rs:265-440)
   A1  spectral identity of fft_ref (slot k <-> root exp(2 pi i (4 bitrev(k)+1)/(4m)))
 """
 import numpy as np
@@ -235,3 +236,79 @@ def test_P5_glwe_automorphism_family_matches_exact(mode, rank):
             v = {"add": v + av, "sub": v - av, "sub_negate": av - v}[mode]
             want[:, c, :] = exact.normalize_exact(v, base2k, res_size)
         assert np.array_equal(res.data, want), (mode, rank, p)
+
+
+def _blind_rotation_inputs(n, rank, n_lwe, dnum, brk_size, res_size, base2k, seed):
+    rng = seeded(seed)
+    cols = rank + 1
+    lut = VecZnx(n, 1, res_size).fill_uniform(base2k, rng)
+    mats = [MatZnx(n, dnum, cols, cols, brk_size).fill_uniform(base2k, rng) for _ in range(n_lwe)]
+    lwe_2n = rng.integers(-n, n, n_lwe + 1, dtype=np.int64)   # what mod_switch_2n produces: values in [-n, n)
+    return lut, mats, lwe_2n
+
+
+@pytest.mark.parametrize("n", [16, 64])
+def test_P6_rotate_and_normalize_assign(n):
+    R = RefModule(n)
+    rng = seeded(n + 3)
+    a = VecZnx(n, 2, 3).fill_uniform(40, rng)
+    for p in (0, 1, -1, 5, n - 1, n, n + 3, 2 * n - 1, -n, 3 * n + 2):
+        r = VecZnx(n, 2, 4).fill_uniform(20, rng)
+        R.vec_znx_rotate(p, r, 1, a, 0)
+        assert np.array_equal(r.data[:3, 1], exact.rotate_exact(a.data[:, 0], p))
+        assert not r.data[3, 1].any()
+        t = a.copy()
+        R.vec_znx_mul_xp_minus_one_assign(p, t, 1)
+        assert np.array_equal(t.data[:, 1], exact.rotate_exact(a.data[:, 1], p) - a.data[:, 1])
+    # in-place same-base normalize == the out-of-place one == big-int digits
+    for base2k in (7, 12, 19):
+        x = VecZnx(n, 1, 4).fill_uniform(55, rng)
+        want = exact.normalize_exact(x.data[:, 0, :].astype(object), base2k, 4)
+        y = x.copy()
+        R.vec_znx_normalize_assign(base2k, y, 0)
+        assert np.array_equal(y.data[:, 0, :], want)
+
+
+@pytest.mark.parametrize("block_size", [1, 3])
+@pytest.mark.parametrize("rank", [1, 2])
+def test_P6_blind_rotation_matches_exact(block_size, rank):
+    """algorithm.rs:265-368 (block binary) / :370-440 (standard) restated in the oracle vs the same recurrence on
+    exact integers: acc <- normalize(acc + sum_i (X^a_i - 1) * (acc (x) BRK_i))."""
+    n, base2k, n_lwe, dnum, brk_size, res_size = 32, 10, 6, 2, 3, 2
+    cols = rank + 1
+    R = RefModule(n)
+    lut, mats, lwe_2n = _blind_rotation_inputs(n, rank, n_lwe, dnum, brk_size, res_size, base2k, 900 + rank)
+    brk = np.stack([R.vmp_pmat_alloc(dnum, cols, cols, brk_size).data for _ in range(n_lwe)])
+    for i, mt in enumerate(mats):
+        pm = R.vmp_pmat_alloc(dnum, cols, cols, brk_size)
+        R.vmp_prepare(pm, mt)
+        brk[i] = pm.data
+    brk = np.ascontiguousarray(brk.reshape(n_lwe, -1))
+    xpa = R.blind_rotation_x_pow_a()
+    res = VecZnx(n, cols, res_size)
+    res.data[...] = 77
+    R.blind_rotation_execute(res, base2k, lwe_2n, lut, brk, dnum, brk_size, block_size, xpa)
+
+    acc = np.zeros((res_size, cols, n), dtype=object)
+    acc[:, 0, :] = exact.rotate_exact(lut.data[:, 0, :].astype(object), int(lwe_2n[0]))
+    a = [int(v) for v in lwe_2n[1:]]
+    if block_size > 1:
+        for blk in range(0, n_lwe - block_size + 1, block_size):
+            add = np.zeros((brk_size, cols, n), dtype=object)
+            acc_in = np.array(acc[:min(dnum, res_size)], dtype=np.int64)
+            for k in range(blk, blk + block_size):
+                v = exact.vmp_exact(acc_in, mats[k].data, 0, brk_size)
+                add += exact.rotate_exact(v, a[k]) - v
+            add[:min(brk_size, res_size)] += acc[:min(brk_size, res_size)]
+            for c in range(cols):
+                acc[:, c, :] = exact.normalize_exact(add[:, c, :], base2k, res_size)
+    else:
+        for k in range(n_lwe):
+            v = exact.vmp_exact(np.array(acc, dtype=np.int64), mats[k].data, 0, brk_size)
+            tmp = np.zeros((res_size, cols, n), dtype=object)
+            for c in range(cols):
+                tmp[:, c, :] = exact.normalize_exact(v[:, c, :], base2k, res_size)
+            acc = acc + exact.rotate_exact(tmp, a[k]) - tmp
+        for c in range(cols):
+            acc[:, c, :] = exact.normalize_exact(acc[:, c, :], base2k, res_size)
+    assert np.array_equal(res.data, np.array(acc, dtype=np.int64))
