@@ -13,6 +13,7 @@
 
 #include "device_fft.hpp"
 #include "device_mid.hpp"
+#include "device_br.hpp"
 #include "device_ops.hpp"
 #include "module.hpp"
 
@@ -1516,6 +1517,43 @@ int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t*
 
     if (blk > 1) {
         PZ_TRY(ensure_w2n(M));
+        // whole rotation in one kernel, accumulators resident in LDS (device_br.hpp), when the shape fits
+        {
+            const int in_limbs = std::min(dnum, rsz), row_max = cols * in_limbs, ncols = cols * bsz, P = std::max(row_max, ncols);
+            const int m = (int)M->m, mp = m + (m >> 4);
+            constexpr int NT = 512;
+            const int r0 = m == 128 ? 2 : (m == 256 ? 4 : 8);
+            auto lds_for = [&](int ct) { return ((size_t)m + (size_t)ct * P * mp) * sizeof(cplx) + (size_t)ct * rsz * cols * (size_t)n * 8; };
+            auto fits = [&](int ct) {
+                return lds_for(ct) <= 160 * 1024 && ct * P * (m / 8) <= NT && ct * P * (m / r0) <= 2 * NT;
+            };
+            static const int force_ct = getenv("POULPY_DBG_BR_CT") ? atoi(getenv("POULPY_DBG_BR_CT")) : 0;
+            if (M->fuse_mid && (m == 128 || m == 256 || m == 512) && row_max <= 8 && ncols <= 8 && m * ((ncols + 3) / 4) <= 2 * NT && fits(1)) {
+                const int ct = (force_ct == 1 || !fits(2) || B < 2) ? 1 : 2;
+                const size_t lds = lds_for(ct);
+                BrFusedArgs g;
+                g.res = (long long*)res; g.lut = (const long long*)lut; g.lwe = (const long long*)lwe_2n; g.brk = (const cplx*)brk;
+                g.w2n = M->w2n; g.key_stride = (long long)(pmat_doubles / 2);
+                g.n_lwe = n_lwe; g.blk = blk; g.cols = cols; g.rsz = rsz; g.dnum = dnum; g.bsz = bsz; g.lut_size = (int)p->lut_size;
+                g.base2k = k; g.m = m; g.batch = B;
+                KTimer kt(M, PZ_K_FUSED_MID);
+#define PZ_BR_LAUNCH(R0_, CT_, PJ_)                                                                                        \
+    {                                                                                                                      \
+        PZ_TRY(set_lds(k_br_fused<R0_, CT_, NT, PJ_>, lds));                                                               \
+        hipLaunchKernelGGL((k_br_fused<R0_, CT_, NT, PJ_>), dim3((B + CT_ - 1) / CT_), dim3(NT), lds, M->stream, g);       \
+    }
+#define PZ_BR_R0(CT_, PJ_)                                                                                                 \
+    {                                                                                                                      \
+        if (m == 128) PZ_BR_LAUNCH(2, CT_, PJ_) else if (m == 256) PZ_BR_LAUNCH(4, CT_, PJ_) else PZ_BR_LAUNCH(8, CT_, PJ_)  \
+    }
+                const int pj = m * ((ncols + 3) / 4) <= NT ? 1 : 2;
+                if (ct == 2 && pj == 1) PZ_BR_R0(2, 1) else if (ct == 2) PZ_BR_R0(2, 2) else if (pj == 1) PZ_BR_R0(1, 1) else PZ_BR_R0(1, 2)
+#undef PZ_BR_R0
+#undef PZ_BR_LAUNCH
+                PZ_HIP(hipGetLastError());
+                return PZ_OK;
+            }
+        }
         const size_t n8 = (size_t)M->n * 8;
         const size_t acc_dft_bytes = align256(batch * n8 * cols * dnum), vr_bytes = align256(batch * n8 * cols * bsz);
         const size_t tp = (size_t)cols * std::max({dnum, bsz, rsz});
@@ -1530,6 +1568,20 @@ int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t*
         const bool tail = M->fuse_tail && tail_supported(M);
         for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {  // chunks_exact: a trailing partial block is ignored, as in the reference
             PZ_TRY(dev_dft_apply(M, B, 1, 0, ad, 0, rv, 0, cols, nullptr, T));                      // :319-321
+            const int row_max = std::min(dnum * cols, cols * std::min(dnum, rsz));
+            if (M->fuse_mid && row_max <= 8 && cols * bsz <= 8) {
+                // zero + block_size x (vmp, svp, add, sub) in one kernel, nothing but acc_add written (:321-337)
+                BrBlockArgs g;
+                g.acc_dft = (const cplx*)acc_dft; g.acc_add = (cplx*)acc_add; g.a_bs = ad.bs / 2; g.o_bs = aa.bs / 2;
+                g.brk = (const cplx*)brk; g.key_stride = (long long)(pmat_doubles / 2);
+                g.row_max = row_max; g.ncols = cols * bsz; g.m = (int)M->m; g.batch = B; g.i0 = b0; g.blk = blk;
+                g.lwe = (const long long*)lwe_2n; g.lwe_bs = lwe_bs; g.w2n = M->w2n;
+                constexpr int CT = 2;
+                KTimer kt(M, PZ_K_VMP);
+                hipLaunchKernelGGL((k_br_block<CT, 8, 8>), dim3((unsigned)((M->m + 255) / 256), (unsigned)((B + CT - 1) / CT)), dim3(256), 0,
+                                   M->stream, g);
+                PZ_HIP(hipGetLastError());
+            } else {
             PZ_HIP(hipMemsetAsync(acc_add, 0, (size_t)B * aa.bs * 8, M->stream));                     // :321
             for (int i = b0; i < b0 + blk; ++i) {                                                       // :324-337
                 PZ_TRY(dev_vmp(M, B, vr, ad, brk + (size_t)i * pmat_doubles, dnum, cols, cols, bsz, 0));
@@ -1541,6 +1593,7 @@ int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t*
                 KTimer kt(M, PZ_K_ELEMENTWISE);
                 hipLaunchKernelGGL(k_xai_acc, dim3((unsigned)std::min<long long>((total + 255) / 256, 256 * 16)), dim3(256), 0, M->stream, g);
                 PZ_HIP(hipGetLastError());
+            }
             }
             // acc = normalize(idft(acc_add) + acc)  (:342-346)
             if (tail) {

@@ -1,0 +1,259 @@
+// device_br.hpp — CGGI block-binary blind rotation as ONE kernel per batch
+// (poulpy-bin-fhe/src/blind_rotation/algorithms/cggi/algorithm.rs:265-368, execute_block_binary).
+//
+// One workgroup owns CT LWE ciphertexts for the whole rotation: the accumulator GLWEs (i64 limbs) and ONE complex
+// work buffer per ciphertext live in LDS from the first block to the last, so per block only the prepared key is read
+// (from L2: every workgroup walks the same keys in the same order, and the CT ciphertexts of a workgroup share each
+// key value) and nothing is written; HBM sees the LUT, the LWE exponents and the final GLWEs.  The reference's
+// per-block op sequence
+//     vec_znx_dft_apply x cols | vec_znx_dft_zero | block_size x (vmp_apply_dft_to_dft, svp_apply_dft_to_dft, add, sub)
+//     | vec_znx_idft_apply, big_add_small_assign, big_normalize x cols
+// becomes: pack+twist -> 3 Stockham passes (R0 x 8 x 8, natural order in and out) -> pointwise product with
+// (DFT(X^a) - 1) folded in -> 3 inverse passes -> untwist, round, + acc, carry chain.  Every pass and the product
+// work IN PLACE on the one buffer: all threads first read their inputs into registers, a barrier, then they write.
+// Sizes: m = N/2 in {128, 256, 512}; rows of the product <= 8, output polynomials <= 8; LDS <= 160 KiB.
+#pragma once
+#include "device_fft.hpp"
+
+namespace pz {
+
+struct BrFusedArgs {
+    long long* res;        // [batch] GLWE(cols, rsz), overwritten
+    const long long* lut;  // VecZnx(1, lut_size)
+    const long long* lwe;  // [batch][n_lwe + 1] = mod_switch_2n output: [b, a_1 .. a_n]
+    const cplx* brk;       // n_lwe prepared GGSWs, P[(r*ncols + c)*m + q]
+    const cplx* w2n;       // exp(2 pi i t / 4m), t < 4m
+    long long key_stride;  // points between consecutive keys
+    int n_lwe, blk, cols, rsz, dnum, bsz, lut_size, base2k, m, batch;
+};
+
+// one extra point per 16: radix passes read with stride m/R and write with stride p, both powers of two
+__device__ __forceinline__ int br_pad(int i) { return i + (i >> 4); }
+
+// Stockham autosort pass, in place (natural order in and out): sub-transforms of length p are done, this pass makes p*R.
+//   u[r] = buf[i + r*m/R] * w^(+-k r), w = exp(2 pi i/(pR)), k = i mod p;  DFT_R;  buf[(i-k)*R + k + s*p] = u[s]
+// A thread owns up to JMAX butterflies (job = tid + jj*NT) and keeps them in registers across the barrier.
+template <int R, bool INV, int JMAX, int NT>
+__device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int mp, int m, int p, const cplx* W, int tid) {
+    const int t = m / R;
+    const int wstep = m / (p * R);
+    const int njobs = njobs_poly * t;
+    cplx u[JMAX][R];
+#pragma unroll
+    for (int jj = 0; jj < JMAX; ++jj) {
+        const int job = tid + jj * NT;
+        if (job < njobs) {
+            const int poly = job / t, i = job - poly * t;
+            const int k = i & (p - 1);
+            const cplx* src = buf + poly * mp;
+#pragma unroll
+            for (int r = 0; r < R; ++r) u[jj][r] = src[br_pad(i + r * t)];
+            if (p > 1) {
+#pragma unroll
+                for (int r = 1; r < R; ++r) u[jj][r] = cmul_t<INV>(u[jj][r], W[(r * k) * wstep]);
+            }
+            Bfly<R, INV>::run(u[jj]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < JMAX; ++jj) {
+        const int job = tid + jj * NT;
+        if (job < njobs) {
+            const int poly = job / t, i = job - poly * t;
+            const int k = i & (p - 1);
+            cplx* dst = buf + poly * mp;
+            const int j = (i - k) * R + k;
+#pragma unroll
+            for (int s = 0; s < R; ++s) dst[br_pad(j + s * p)] = u[jj][s];
+        }
+    }
+    __syncthreads();
+}
+
+// CT ciphertexts per workgroup, NT threads, PJ product jobs per thread (m * ceil(ncols/4) <= PJ*NT).
+// LDS: W[m] | X[CT][P][mp] (cplx) | acc[CT][rsz][cols][n] (i64)
+template <int R0, int CT, int NT, int PJ>
+__global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
+    extern __shared__ cplx lds_br[];
+    const int tid = threadIdx.x;
+    const int m = g.m, n = 2 * m, cols = g.cols;
+    const int mp = br_pad(m);
+    const int in_limbs = min(g.dnum, g.rsz);  // limbs of acc that enter the product (acc_dft has dnum limbs, the rest are zero)
+    const int row_max = cols * in_limbs, ncols = cols * g.bsz;
+    const int P = max(row_max, ncols);
+    const int ct_polys = g.rsz * cols;        // accumulator polynomials per ciphertext
+    cplx* W = lds_br;                         // exp(2 pi i t / m)
+    cplx* X = W + m;
+    long long* acc = reinterpret_cast<long long*>(X + CT * P * mp);
+    const int b0 = blockIdx.x * CT;
+    const unsigned mask2 = 2u * (unsigned)n - 1u;
+
+    for (int t = tid; t < m; t += NT) W[t] = g.w2n[4 * t];
+    // acc = X^b * LUT in column 0, zero elsewhere (:298-301)
+    for (int e = tid; e < CT * ct_polys * n; e += NT) {
+        const int j = e % n, pc = (e / n) % ct_polys, ct = e / (n * ct_polys);
+        const int col = pc % cols, limb = pc / cols;
+        const int b = min(b0 + ct, g.batch - 1);
+        long long v = 0;
+        if (col == 0 && limb < g.lut_size) {
+            const unsigned kk = (unsigned)((unsigned long long)g.lwe[(long long)b * (g.n_lwe + 1)] & (unsigned long long)mask2);
+            const unsigned i0 = ((unsigned)j - kk) & mask2;
+            const long long s = g.lut[(long long)limb * n + (i0 & (unsigned)(n - 1))];
+            v = i0 >= (unsigned)n ? (long long)(0ull - (unsigned long long)s) : s;
+        }
+        acc[e] = v;
+    }
+    __syncthreads();
+
+    const int k = g.base2k;
+    const unsigned long long half = 1ull << (k - 1), dmask = (1ull << k) - 1;
+    const double inv_m = 1.0 / (double)m;
+    const int ncg = (ncols + 3) / 4;          // output polynomials are handled four at a time
+    const int njobs_prod = m * ncg;           // product jobs (q, column group); a job covers the CT ciphertexts
+
+    for (int blk0 = 0; blk0 + g.blk <= g.n_lwe; blk0 += g.blk) {
+        // ---- pack + twist: X[ct][r][j] = (acc[r][j] + i acc[r][j+m]) * exp(2 pi i j / 4m),  r = limb*cols + col (:319-320)
+        for (int job = tid; job < CT * row_max * m; job += NT) {
+            const int j = job % m, r = (job / m) % row_max, ct = job / (m * row_max);
+            const long long* a = acc + ((long long)ct * ct_polys + r) * n;
+            const cplx z = make_double2((double)a[j], (double)a[j + m]);
+            X[(ct * P + r) * mp + br_pad(j)] = cmul(z, g.w2n[j]);
+        }
+        __syncthreads();
+        // forward DFT of the CT*row_max input polynomials (they sit at poly index ct*P + r: run the passes over whole
+        // ciphertext slots when row_max == P, otherwise per ciphertext)
+        for (int ct = 0; ct < (row_max == P ? 1 : CT); ++ct) {
+            cplx* buf = X + ct * P * mp;
+            const int np = row_max == P ? CT * P : row_max;
+            br_pass<R0, false, 2, NT>(buf, np, mp, m, 1, W, tid);
+            br_pass<8, false, 1, NT>(buf, np, mp, m, R0, W, tid);
+            br_pass<8, false, 1, NT>(buf, np, mp, m, R0 * 8, W, tid);
+        }
+        // ---- product, in place: X[ct][c][q] = sum_i (DFT(X^a_i)[q] - 1) * sum_r X[ct][r][q] * BRK_i[r][c][q]   (:321-337)
+        {
+            cplx out[PJ][CT][4];
+#pragma unroll
+            for (int pj = 0; pj < PJ; ++pj) {
+                const int job = tid + pj * NT;
+                if (job < njobs_prod) {
+                    // m is a multiple of 64, so a wave has one column group: keep it (and every key row pointer) in SGPRs,
+                    // the loads then need one VGPR offset instead of a 64-bit VGPR pointer each
+                    const int q = job % m, cg = __builtin_amdgcn_readfirstlane(job / m);
+                    cplx a[CT][8];
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) a[ct][r] = r < row_max ? X[(ct * P + r) * mp + br_pad(q)] : make_double2(0.0, 0.0);
+                    // output polynomial by output polynomial (static register indices), the block's coefficients inside:
+                    // eight key values in flight per step
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = min(cg * 4 + j, ncols - 1);
+                        cplx o[CT];
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) o[ct] = make_double2(0.0, 0.0);
+                        for (int i = blk0; i < blk0 + g.blk; ++i) {
+                            const cplx* K = g.brk + (long long)i * g.key_stride + (long long)c * m;
+                            cplx kv[8];
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) kv[r] = (K + (long long)(min(r, row_max - 1) * ncols) * m)[q];
+                            cplx xm[CT];
+#pragma unroll
+                            for (int ct = 0; ct < CT; ++ct) {
+                                const int b = min(b0 + ct, g.batch - 1);
+                                const unsigned ai = (unsigned)((unsigned long long)g.lwe[(long long)b * (g.n_lwe + 1) + 1 + i] & (unsigned long long)mask2);
+                                xm[ct] = g.w2n[(ai * (4u * (unsigned)q + 1u)) & mask2];
+                            }
+#pragma unroll
+                            for (int ct = 0; ct < CT; ++ct) {
+                                cplx s = make_double2(0.0, 0.0);
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) {
+                                    if (r < row_max) {
+                                        s.x = __builtin_fma(a[ct][r].x, kv[r].x, s.x);
+                                        s.x = __builtin_fma(-a[ct][r].y, kv[r].y, s.x);
+                                        s.y = __builtin_fma(a[ct][r].x, kv[r].y, s.y);
+                                        s.y = __builtin_fma(a[ct][r].y, kv[r].x, s.y);
+                                    }
+                                }
+                                const cplx xv = cmul(xm[ct], s);
+                                o[ct].x = (o[ct].x + xv.x) - s.x;
+                                o[ct].y = (o[ct].y + xv.y) - s.y;
+                            }
+                        }
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) out[pj][ct][j] = o[ct];
+                    }
+                }
+            }
+            __syncthreads();  // every input point has been read: the outputs may overwrite them
+#pragma unroll
+            for (int pj = 0; pj < PJ; ++pj) {
+                const int job = tid + pj * NT;
+                if (job < njobs_prod) {
+                    const int q = job % m, cg = job / m;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int c = cg * 4 + j;
+                            if (c < ncols) X[(ct * P + c) * mp + br_pad(q)] = out[pj][ct][j];
+                        }
+                }
+            }
+            __syncthreads();
+        }
+        // inverse DFT of the CT*ncols output polynomials
+        for (int ct = 0; ct < (ncols == P ? 1 : CT); ++ct) {
+            cplx* buf = X + ct * P * mp;
+            const int np = ncols == P ? CT * P : ncols;
+            br_pass<R0, true, 2, NT>(buf, np, mp, m, 1, W, tid);
+            br_pass<8, true, 1, NT>(buf, np, mp, m, R0, W, tid);
+            br_pass<8, true, 1, NT>(buf, np, mp, m, R0 * 8, W, tid);
+        }
+        // ---- untwist, round(x/m), + acc, carry chain from the last limb to limb 0 (:342-346); thread = (ct, column, j < m):
+        //      coefficients j and j+m.  Same digit/carry arithmetic as the fused tail (device_fft.hpp, PZ_TAIL_COEFFS).
+        for (int job = tid; job < CT * cols * m; job += NT) {
+            const int j = job % m, col = (job / m) % cols, ct = job / (m * cols);
+            const cplx tw = g.w2n[j];
+            long long cy[2] = {0, 0};
+            for (int limb = g.bsz - 1; limb >= 0; --limb) {
+                const cplx v = cmulc(X[(ct * P + limb * cols + col) * mp + br_pad(j)], tw);
+                const bool writes = limb < g.rsz;
+                const bool first = limb == g.bsz - 1;
+                long long* a = acc + ((long long)ct * ct_polys + (long long)limb * cols + col) * n;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const double val = (h ? v.y : v.x) * inv_m;
+                    long long x = sat_i64_from_integral(round_half_away(val));
+                    if (writes) x = (long long)((unsigned long long)x + (unsigned long long)a[j + h * m]);
+                    const unsigned long long y = (unsigned long long)x + half;
+                    const long long d = (long long)(y & dmask) - (long long)half;
+                    const long long cr = (long long)y >> k;
+                    if (first && !writes) {
+                        cy[h] = cr;
+                    } else {
+                        const unsigned long long y2 = (unsigned long long)d + (unsigned long long)cy[h] + half;
+                        const long long x1 = (long long)(y2 & dmask) - (long long)half;
+                        cy[h] = (long long)((unsigned long long)cr + (unsigned long long)((long long)y2 >> k));
+                        if (writes) a[j + h * m] = x1;
+                    }
+                }
+            }
+            // limbs of acc beyond the precision of the big value are zero (normalize.rs:118-120)
+            for (int limb = g.bsz; limb < g.rsz; ++limb) {
+                long long* a = acc + ((long long)ct * ct_polys + (long long)limb * cols + col) * n;
+                a[j] = 0;
+                a[j + m] = 0;
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < CT * ct_polys * n; e += NT) {
+        const int ct = e / (ct_polys * n);
+        if (b0 + ct < g.batch) g.res[(long long)b0 * ct_polys * n + e] = acc[e];
+    }
+}
+
+}  // namespace pz

@@ -401,6 +401,94 @@ __global__ void __launch_bounds__(256) k_xai_acc(XaiArgs g) {
 }
 
 // =================================================================================
+// One block of the block-binary blind rotation in the DFT domain (algorithm.rs:319-337), fused:
+//   acc_add[b][c] = sum_{i in block} (DFT(X^a_{b,i}) - 1) (.) ( sum_r acc_dft[b][r] (.) BRK_i[r][c] )
+// i.e. vec_znx_dft_zero + block_size x (vmp_apply_dft_to_dft, svp_apply_dft_to_dft, dft_add_assign, dft_sub_assign)
+// without vmp_res / vmp_xai ever leaving registers.  Thread = one frequency point q of CT ciphertexts: the key
+// values of a point are loaded once and used by the CT ciphertexts; lanes run along q (contiguous in every operand).
+// nrows <= MAXR (= dnum*cols rows actually present in acc_dft), ncols <= MAXC (= cols*brk_size).
+// =================================================================================
+struct BrBlockArgs {
+    const cplx* acc_dft;   // [batch][nrows_a][m]
+    cplx* acc_add;         // [batch][ncols][m]
+    long long a_bs, o_bs;  // points between ciphertexts
+    const cplx* brk;       // prepared keys, key i at brk + i*key_stride; P[(r*ncols + c)*m + q]
+    long long key_stride;
+    int row_max, ncols, m, batch;
+    int i0, blk;           // LWE coefficients i0 .. i0+blk-1
+    const long long* lwe;  // [batch][n_lwe+1]
+    long long lwe_bs;
+    const cplx* w2n;
+};
+
+template <int CT, int MAXR, int MAXC>
+__global__ void __launch_bounds__(256) k_br_block(BrBlockArgs g) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= g.m) return;
+    const int b0 = blockIdx.y * CT;
+    const unsigned mask = 4u * (unsigned)g.m - 1u;
+    cplx a[CT][MAXR];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int b = min(b0 + t, g.batch - 1);
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r)
+            a[t][r] = r < g.row_max ? g.acc_dft[(long long)b * g.a_bs + (long long)r * g.m + q] : make_double2(0.0, 0.0);
+    }
+    cplx out[CT][MAXC];
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) out[t][c] = make_double2(0.0, 0.0);
+    for (int i = g.i0; i < g.i0 + g.blk; ++i) {
+        const cplx* K = g.brk + (long long)i * g.key_stride + q;
+        cplx xm[CT];   // DFT(X^a)[q] for each ciphertext of the tile
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int b = min(b0 + t, g.batch - 1);
+            const unsigned ai = (unsigned)((unsigned long long)g.lwe[(long long)b * g.lwe_bs + 1 + i] & (unsigned long long)mask);
+            xm[t] = g.w2n[(ai * (4u * (unsigned)q + 1u)) & mask];
+        }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            if (c < g.ncols) {
+                cplx s[CT];
+#pragma unroll
+                for (int t = 0; t < CT; ++t) s[t] = make_double2(0.0, 0.0);
+#pragma unroll
+                for (int r = 0; r < MAXR; ++r) {
+                    if (r < g.row_max) {
+                        const cplx kv = K[(long long)(r * g.ncols + c) * g.m];
+#pragma unroll
+                        for (int t = 0; t < CT; ++t) {
+                            s[t].x = __builtin_fma(a[t][r].x, kv.x, s[t].x);
+                            s[t].x = __builtin_fma(-a[t][r].y, kv.y, s[t].x);
+                            s[t].y = __builtin_fma(a[t][r].x, kv.y, s[t].y);
+                            s[t].y = __builtin_fma(a[t][r].y, kv.x, s[t].y);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < CT; ++t) {
+                    const cplx xv = cmul(xm[t], s[t]);
+                    out[t][c].x = (out[t][c].x + xv.x) - s[t].x;
+                    out[t][c].y = (out[t][c].y + xv.y) - s[t].y;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int b = b0 + t;
+        if (b < g.batch) {
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (c < g.ncols) g.acc_add[(long long)b * g.o_bs + (long long)c * g.m + q] = out[t][c];
+        }
+    }
+}
+
+// =================================================================================
 // normalize: reference/vec_znx/normalize.rs + reference/znx/normalization.rs.
 // The carry chain runs across limbs, never across coefficients, so one thread owns
 // one coefficient and walks the limbs with the carry in a register.  Arithmetic is

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Secondary measurement (BASELINE configs[3]): CGGI blind rotations / s on one MI355X for a batch of LWE ciphertexts.
+
+Shapes: `ref` = poulpy-bench/src/bench_suite/schemes/blind_rotation.rs:39-75 (n_glwe 512, n_lwe 687, rank 3, block 3,
+base2k 18, dnum 1, key size 2, res size 1); `cbt` = the blind-rotation layout of the circuit-bootstrapping bench
+(circuit_bootstrapping.rs:48-55: n_glwe 1024, n_lwe 574, base2k 13, dnum 3, rank 1), block size 7.
+Synthetic key material (uniform digits); the oracle is timed single-threaded on a few ciphertexts beside it.
+
+    python tools/bench_blind_rotation.py [--shape ref|cbt] [--batch 1024] [--reps 3]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+SHAPES = {
+    "ref": dict(n=512, n_lwe=687, rank=3, block_size=3, base2k=18, dnum=1, brk_size=2, res_size=1),
+    "cbt": dict(n=1024, n_lwe=574, rank=1, block_size=7, base2k=13, dnum=3, brk_size=3, res_size=3),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", choices=sorted(SHAPES), default="ref")
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--cpu-cts", type=int, default=2)
+    args = ap.parse_args()
+    import torch
+    from poulpy_amd.hal import BlindRotationParams, Module
+    s = SHAPES[args.shape]
+    n, cols = s["n"], s["rank"] + 1
+    dev = torch.device("cuda", 0)
+    mod = Module(n, device=0)
+    half = 1 << (s["base2k"] - 1)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    pm_elems = n * s["dnum"] * cols * cols * s["brk_size"]
+    brk = torch.empty((s["n_lwe"], pm_elems), dtype=torch.float64, device=dev)
+    mat = torch.randint(-half, half, (pm_elems,), dtype=torch.int64, device=dev, generator=g)
+    for i in range(s["n_lwe"]):   # same synthetic GGSW for every coefficient would let caches lie: permute it per key
+        mi = torch.roll(mat, i * 977)
+        mod._ck(mod.lib.pz_vmp_prepare(mod.handle, C.c_void_p(brk[i].data_ptr()), C.c_void_p(mi.data_ptr()), C.c_size_t(s["dnum"]),
+                                       C.c_size_t(cols), C.c_size_t(cols), C.c_size_t(s["brk_size"])))
+    mod.sync()
+    lut = torch.randint(-half, half, (s["res_size"], 1, n), dtype=torch.int64, device=dev, generator=g)
+    lwe = torch.randint(-n, n, (args.batch, s["n_lwe"] + 1), dtype=torch.int64, device=dev, generator=g)
+    res = torch.empty((args.batch, s["res_size"], cols, n), dtype=torch.int64, device=dev)
+    p = BlindRotationParams(rank=s["rank"], n_lwe=s["n_lwe"], block_size=s["block_size"], dnum=s["dnum"], brk_size=s["brk_size"],
+                            base2k=s["base2k"], res_size=s["res_size"], lut_size=s["res_size"])
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    torch.cuda.synchronize()
+    mod.blind_rotation_execute_batched(ptr(res), ptr(lwe), ptr(lut), ptr(brk), p, args.batch)   # warm-up
+    mod.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        mod.blind_rotation_execute_batched(ptr(res), ptr(lwe), ptr(lut), ptr(brk), p, args.batch)
+    mod.sync()
+    dt = (time.perf_counter() - t0) / args.reps
+    mod.set_kernel_timing(True)   # one more pass with per-class HIP-event timing (adds event overhead: not the timed run)
+    mod.blind_rotation_execute_batched(ptr(res), ptr(lwe), ptr(lut), ptr(brk), p, args.batch)
+    mod.sync()
+    kstats = {k: (v[0], round(v[1], 3)) for k, v in mod.kernel_stats().items() if v[0]}
+    mod.set_kernel_timing(False)
+    out = {"metric": "CGGI blind rotations/s", "shape": args.shape, **s, "batch": args.batch, "value": args.batch / dt,
+           "ms_per_batch": dt * 1e3, "kernel_classes_launches_ms": kstats, "digits_balanced": bool((res.min() >= -half).item() and (res.max() < half).item())}
+    # CPU port beside it (single thread) on a few of the same ciphertexts, and parity on those
+    if args.cpu_cts:
+        from oracle.ref import RefModule
+        from poulpy_amd.layouts import VecZnx
+        ref = RefModule(n, fast=True)
+        # the oracle needs the key in ITS prepared order: prepare the same matrices with it
+        brk_r = np.empty((s["n_lwe"], pm_elems), dtype=np.float64)
+        mat_h = mat.cpu().numpy()
+        from poulpy_amd.layouts import MatZnx
+        for i in range(s["n_lwe"]):
+            mz = MatZnx(n, s["dnum"], cols, cols, s["brk_size"], np.ascontiguousarray(np.roll(mat_h, i * 977)))
+            pr = ref.vmp_pmat_alloc(s["dnum"], cols, cols, s["brk_size"])
+            ref.vmp_prepare(pr, mz)
+            brk_r[i] = pr.data.reshape(-1)
+        xpa = ref.blind_rotation_x_pow_a()
+        lut_h = VecZnx(n, 1, s["res_size"], np.ascontiguousarray(lut.cpu().numpy()))
+        lwe_h = lwe[:args.cpu_cts].cpu().numpy()
+        got = res[:args.cpu_cts].cpu().numpy()
+        t0 = time.perf_counter()
+        ok = True
+        for b in range(args.cpu_cts):
+            r = VecZnx(n, cols, s["res_size"])
+            ref.blind_rotation_execute(r, s["base2k"], np.ascontiguousarray(lwe_h[b]), lut_h, brk_r, s["dnum"], s["brk_size"],
+                                       s["block_size"], xpa)
+            ok = ok and bool(np.array_equal(r.data, got[b]))
+        cdt = (time.perf_counter() - t0) / args.cpu_cts
+        out["cpu_port_1thread_per_s"] = 1.0 / cdt
+        out["parity_on_cpu_sample"] = ok
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
