@@ -146,6 +146,9 @@ class Module {  // Module<FFT64Hip>, poulpy-hal/src/layouts/module.rs:97-189
     void glwe_automorphism_batched(int64_t* res, const int64_t* a, const double* key, const pz_glwe_op_params& p, int64_t gal, int mode, size_t batch) {
         check(pz_glwe_automorphism_batched(m_, res, a, key, &p, gal, mode, batch), "glwe_automorphism_batched");
     }
+    void blind_rotation_execute_batched(int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk, const pz_blind_rotation_params& p, size_t batch) {
+        check(pz_blind_rotation_execute_batched(m_, res, lwe_2n, lut, brk, &p, batch), "blind_rotation_execute_batched");
+    }
     void ggsw_external_product(int64_t* res, const int64_t* a, size_t a_dnum, const double* ggsw, const pz_glwe_op_params& p) {
         check(pz_ggsw_external_product(m_, res, a, a_dnum, ggsw, &p), "ggsw_external_product");
     }

@@ -1528,7 +1528,7 @@ int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t*
                 return lds_for(ct) <= 160 * 1024 && ct * P * (m / 8) <= NT && ct * P * (m / r0) <= 2 * NT;
             };
             static const int force_ct = getenv("POULPY_DBG_BR_CT") ? atoi(getenv("POULPY_DBG_BR_CT")) : 0;
-            if (M->fuse_mid && (m == 128 || m == 256 || m == 512) && row_max <= 8 && ncols <= 8 && m * ((ncols + 3) / 4) <= 2 * NT && fits(1)) {
+            if (M->fuse_mid && (m == 128 || m == 256 || m == 512) && NT % m == 0 && row_max <= 8 && ncols <= 8 && m * ((ncols + 3) / 4) <= 2 * NT && fits(1)) {
                 const int ct = (force_ct == 1 || !fits(2) || B < 2) ? 1 : 2;
                 const size_t lds = lds_for(ct);
                 BrFusedArgs g;
@@ -1536,19 +1536,28 @@ int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t*
                 g.w2n = M->w2n; g.key_stride = (long long)(pmat_doubles / 2);
                 g.n_lwe = n_lwe; g.blk = blk; g.cols = cols; g.rsz = rsz; g.dnum = dnum; g.bsz = bsz; g.lut_size = (int)p->lut_size;
                 g.base2k = k; g.m = m; g.batch = B;
+                static const int br_skip = getenv("POULPY_DBG_BR_SKIP") ? atoi(getenv("POULPY_DBG_BR_SKIP")) : 0;
+                g.dbg_skip = br_skip;
                 KTimer kt(M, PZ_K_FUSED_MID);
+#define PZ_BR_LAUNCH1(R0_, CT_, PJ_, MR_, CG_)                                                                             \
+    {                                                                                                                      \
+        PZ_TRY(set_lds(k_br_fused<R0_, CT_, NT, PJ_, MR_, CG_>, lds));                                                     \
+        hipLaunchKernelGGL((k_br_fused<R0_, CT_, NT, PJ_, MR_, CG_>), dim3((B + CT_ - 1) / CT_), dim3(NT), lds, M->stream, g); \
+    }
 #define PZ_BR_LAUNCH(R0_, CT_, PJ_)                                                                                        \
     {                                                                                                                      \
-        PZ_TRY(set_lds(k_br_fused<R0_, CT_, NT, PJ_>, lds));                                                               \
-        hipLaunchKernelGGL((k_br_fused<R0_, CT_, NT, PJ_>), dim3((B + CT_ - 1) / CT_), dim3(NT), lds, M->stream, g);       \
+        if (cgsz == 3) PZ_BR_LAUNCH1(R0_, CT_, PJ_, 8, 3)                                                                  \
+        else if (row_max <= 4) PZ_BR_LAUNCH1(R0_, CT_, PJ_, 4, 4) else PZ_BR_LAUNCH1(R0_, CT_, PJ_, 8, 4)                  \
     }
 #define PZ_BR_R0(CT_, PJ_)                                                                                                 \
     {                                                                                                                      \
         if (m == 128) PZ_BR_LAUNCH(2, CT_, PJ_) else if (m == 256) PZ_BR_LAUNCH(4, CT_, PJ_) else PZ_BR_LAUNCH(8, CT_, PJ_)  \
     }
-                const int pj = m * ((ncols + 3) / 4) <= NT ? 1 : 2;
+                const int cgsz = (ncols % 3 == 0 && ncols % 4 != 0) ? 3 : 4;  // 6 output polynomials: two groups of 3, no idle slot
+                const int pj = m * ((ncols + cgsz - 1) / cgsz) <= NT ? 1 : 2;
                 if (ct == 2 && pj == 1) PZ_BR_R0(2, 1) else if (ct == 2) PZ_BR_R0(2, 2) else if (pj == 1) PZ_BR_R0(1, 1) else PZ_BR_R0(1, 2)
 #undef PZ_BR_R0
+#undef PZ_BR_LAUNCH1
 #undef PZ_BR_LAUNCH
                 PZ_HIP(hipGetLastError());
                 return PZ_OK;

@@ -25,6 +25,7 @@ struct BrFusedArgs {
     const cplx* w2n;       // exp(2 pi i t / 4m), t < 4m
     long long key_stride;  // points between consecutive keys
     int n_lwe, blk, cols, rsz, dnum, bsz, lut_size, base2k, m, batch;
+    int dbg_skip;          // timing diagnostic (wrong results): 1 no DFT passes, 2 no product, 4 no carry phase, 8 no pack
 };
 
 // one extra point per 16: radix passes read with stride m/R and write with stride p, both powers of two
@@ -71,9 +72,10 @@ __device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int mp, int m
     __syncthreads();
 }
 
-// CT ciphertexts per workgroup, NT threads, PJ product jobs per thread (m * ceil(ncols/4) <= PJ*NT).
+// CT ciphertexts per workgroup, NT threads, output polynomials in groups of CG, PJ product jobs per thread
+// (m * ceil(ncols/CG) <= PJ*NT), row_max <= MAXR.
 // LDS: W[m] | X[CT][P][mp] (cplx) | acc[CT][rsz][cols][n] (i64)
-template <int R0, int CT, int NT, int PJ>
+template <int R0, int CT, int NT, int PJ, int MAXR, int CG>
 __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
     extern __shared__ cplx lds_br[];
     const int tid = threadIdx.x;
@@ -90,6 +92,9 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
     const unsigned mask2 = 2u * (unsigned)n - 1u;
 
     for (int t = tid; t < m; t += NT) W[t] = g.w2n[4 * t];
+    // NT is a multiple of m (host-checked): a thread's pack / carry jobs all have j = tid mod m, so its twist factor
+    // exp(2 pi i j / 4m) is fetched once
+    const cplx tw_j = g.w2n[tid % m];
     // acc = X^b * LUT in column 0, zero elsewhere (:298-301)
     for (int e = tid; e < CT * ct_polys * n; e += NT) {
         const int j = e % n, pc = (e / n) % ct_polys, ct = e / (n * ct_polys);
@@ -109,20 +114,22 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
     const int k = g.base2k;
     const unsigned long long half = 1ull << (k - 1), dmask = (1ull << k) - 1;
     const double inv_m = 1.0 / (double)m;
-    const int ncg = (ncols + 3) / 4;          // output polynomials are handled four at a time
+    const int ncg = (ncols + CG - 1) / CG;    // output polynomials are handled CG at a time
     const int njobs_prod = m * ncg;           // product jobs (q, column group); a job covers the CT ciphertexts
 
     for (int blk0 = 0; blk0 + g.blk <= g.n_lwe; blk0 += g.blk) {
         // ---- pack + twist: X[ct][r][j] = (acc[r][j] + i acc[r][j+m]) * exp(2 pi i j / 4m),  r = limb*cols + col (:319-320)
+        if (!(g.dbg_skip & 8))
         for (int job = tid; job < CT * row_max * m; job += NT) {
             const int j = job % m, r = (job / m) % row_max, ct = job / (m * row_max);
             const long long* a = acc + ((long long)ct * ct_polys + r) * n;
             const cplx z = make_double2((double)a[j], (double)a[j + m]);
-            X[(ct * P + r) * mp + br_pad(j)] = cmul(z, g.w2n[j]);
+            X[(ct * P + r) * mp + br_pad(j)] = cmul(z, tw_j);
         }
         __syncthreads();
         // forward DFT of the CT*row_max input polynomials (they sit at poly index ct*P + r: run the passes over whole
         // ciphertext slots when row_max == P, otherwise per ciphertext)
+        if (!(g.dbg_skip & 1))
         for (int ct = 0; ct < (row_max == P ? 1 : CT); ++ct) {
             cplx* buf = X + ct * P * mp;
             const int np = row_max == P ? CT * P : row_max;
@@ -131,8 +138,8 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
             br_pass<8, false, 1, NT>(buf, np, mp, m, R0 * 8, W, tid);
         }
         // ---- product, in place: X[ct][c][q] = sum_i (DFT(X^a_i)[q] - 1) * sum_r X[ct][r][q] * BRK_i[r][c][q]   (:321-337)
-        {
-            cplx out[PJ][CT][4];
+        if (!(g.dbg_skip & 2)) {
+            cplx out[PJ][CT][CG];
 #pragma unroll
             for (int pj = 0; pj < PJ; ++pj) {
                 const int job = tid + pj * NT;
@@ -140,50 +147,52 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
                     // m is a multiple of 64, so a wave has one column group: keep it (and every key row pointer) in SGPRs,
                     // the loads then need one VGPR offset instead of a 64-bit VGPR pointer each
                     const int q = job % m, cg = __builtin_amdgcn_readfirstlane(job / m);
-                    cplx a[CT][8];
+                    cplx a[CT][MAXR];
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) a[ct][r] = r < row_max ? X[(ct * P + r) * mp + br_pad(q)] : make_double2(0.0, 0.0);
-                    // output polynomial by output polynomial (static register indices), the block's coefficients inside:
-                    // eight key values in flight per step
+                        for (int r = 0; r < MAXR; ++r) a[ct][r] = r < row_max ? X[(ct * P + r) * mp + br_pad(q)] : make_double2(0.0, 0.0);
+                    // coefficient by coefficient: the CG x row_max key values of this thread's column group are requested
+                    // together (one exposed L2 latency per coefficient), then consumed
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int c = min(cg * 4 + j, ncols - 1);
-                        cplx o[CT];
+                    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) o[ct] = make_double2(0.0, 0.0);
-                        for (int i = blk0; i < blk0 + g.blk; ++i) {
-                            const cplx* K = g.brk + (long long)i * g.key_stride + (long long)c * m;
-                            cplx kv[8];
+                        for (int j = 0; j < CG; ++j) out[pj][ct][j] = make_double2(0.0, 0.0);
+                    for (int i = blk0; i < blk0 + g.blk; ++i) {
+                        const cplx* K = g.brk + (long long)i * g.key_stride;
+                        cplx kv[CG][MAXR];
 #pragma unroll
-                            for (int r = 0; r < 8; ++r) kv[r] = (K + (long long)(min(r, row_max - 1) * ncols) * m)[q];
-                            cplx xm[CT];
+                        for (int j = 0; j < CG; ++j) {
+                            const int c = min(cg * CG + j, ncols - 1);
 #pragma unroll
-                            for (int ct = 0; ct < CT; ++ct) {
-                                const int b = min(b0 + ct, g.batch - 1);
-                                const unsigned ai = (unsigned)((unsigned long long)g.lwe[(long long)b * (g.n_lwe + 1) + 1 + i] & (unsigned long long)mask2);
-                                xm[ct] = g.w2n[(ai * (4u * (unsigned)q + 1u)) & mask2];
-                            }
+                            for (int r = 0; r < MAXR; ++r) kv[j][r] = (K + (long long)(min(r, row_max - 1) * ncols + c) * m)[q];
+                        }
+                        cplx xm[CT];
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) {
+                            const int b = min(b0 + ct, g.batch - 1);
+                            const unsigned ai = (unsigned)((unsigned long long)g.lwe[(long long)b * (g.n_lwe + 1) + 1 + i] & (unsigned long long)mask2);
+                            xm[ct] = g.w2n[(ai * (4u * (unsigned)q + 1u)) & mask2];
+                        }
+#pragma unroll
+                        for (int j = 0; j < CG; ++j) {
 #pragma unroll
                             for (int ct = 0; ct < CT; ++ct) {
                                 cplx s = make_double2(0.0, 0.0);
 #pragma unroll
-                                for (int r = 0; r < 8; ++r) {
+                                for (int r = 0; r < MAXR; ++r) {
                                     if (r < row_max) {
-                                        s.x = __builtin_fma(a[ct][r].x, kv[r].x, s.x);
-                                        s.x = __builtin_fma(-a[ct][r].y, kv[r].y, s.x);
-                                        s.y = __builtin_fma(a[ct][r].x, kv[r].y, s.y);
-                                        s.y = __builtin_fma(a[ct][r].y, kv[r].x, s.y);
+                                        s.x = __builtin_fma(a[ct][r].x, kv[j][r].x, s.x);
+                                        s.x = __builtin_fma(-a[ct][r].y, kv[j][r].y, s.x);
+                                        s.y = __builtin_fma(a[ct][r].x, kv[j][r].y, s.y);
+                                        s.y = __builtin_fma(a[ct][r].y, kv[j][r].x, s.y);
                                     }
                                 }
                                 const cplx xv = cmul(xm[ct], s);
-                                o[ct].x = (o[ct].x + xv.x) - s.x;
-                                o[ct].y = (o[ct].y + xv.y) - s.y;
+                                out[pj][ct][j].x = (out[pj][ct][j].x + xv.x) - s.x;
+                                out[pj][ct][j].y = (out[pj][ct][j].y + xv.y) - s.y;
                             }
                         }
-#pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) out[pj][ct][j] = o[ct];
                     }
                 }
             }
@@ -196,8 +205,8 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int c = cg * 4 + j;
+                        for (int j = 0; j < CG; ++j) {
+                            const int c = cg * CG + j;
                             if (c < ncols) X[(ct * P + c) * mp + br_pad(q)] = out[pj][ct][j];
                         }
                 }
@@ -205,6 +214,7 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
             __syncthreads();
         }
         // inverse DFT of the CT*ncols output polynomials
+        if (!(g.dbg_skip & 1))
         for (int ct = 0; ct < (ncols == P ? 1 : CT); ++ct) {
             cplx* buf = X + ct * P * mp;
             const int np = ncols == P ? CT * P : ncols;
@@ -214,9 +224,10 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
         }
         // ---- untwist, round(x/m), + acc, carry chain from the last limb to limb 0 (:342-346); thread = (ct, column, j < m):
         //      coefficients j and j+m.  Same digit/carry arithmetic as the fused tail (device_fft.hpp, PZ_TAIL_COEFFS).
+        if (!(g.dbg_skip & 4))
         for (int job = tid; job < CT * cols * m; job += NT) {
             const int j = job % m, col = (job / m) % cols, ct = job / (m * cols);
-            const cplx tw = g.w2n[j];
+            const cplx tw = tw_j;
             long long cy[2] = {0, 0};
             for (int limb = g.bsz - 1; limb >= 0; --limb) {
                 const cplx v = cmulc(X[(ct * P + limb * cols + col) * mp + br_pad(j)], tw);
@@ -226,7 +237,9 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const double val = (h ? v.y : v.x) * inv_m;
-                    long long x = sat_i64_from_integral(round_half_away(val));
+                    const double rv = round_half_away(val);
+                    // 3-instruction conversion when exact (|x| < 2^51), the saturating one otherwise (Rust `as i64`)
+                    long long x = fabs(rv) < 2251799813685247.0 ? fast_i64_from_integral(rv) : sat_i64_from_integral(rv);
                     if (writes) x = (long long)((unsigned long long)x + (unsigned long long)a[j + h * m]);
                     const unsigned long long y = (unsigned long long)x + half;
                     const long long d = (long long)(y & dmask) - (long long)half;

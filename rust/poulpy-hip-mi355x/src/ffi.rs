@@ -91,8 +91,18 @@ unsafe extern "C" {
     /// mode: 0 glwe_automorphism, 1 _add, 2 _sub, 3 _sub_negate (poulpy-core/src/automorphism/glwe_ct.rs:51-275)
     pub fn pz_glwe_automorphism_batched(m: *mut pz_module, res: *mut i64, a: *const i64, key: *const f64,
         p: *const pz_glwe_op_params, gal: i64, mode: c_int, batch: usize) -> c_int;
+    /// BlindRotationExecute<CGGI>::blind_rotation_execute on a batch (poulpy-bin-fhe blind_rotation/algorithms/cggi/algorithm.rs)
+    pub fn pz_blind_rotation_execute_batched(m: *mut pz_module, res: *mut i64, lwe_2n: *const i64, lut: *const i64, brk: *const f64,
+        p: *const pz_blind_rotation_params, batch: usize) -> c_int;
+    pub fn pz_blind_rotation_workspace_bytes(m: *const pz_module, p: *const pz_blind_rotation_params, batch: usize) -> usize;
     pub fn pz_ggsw_external_product(m: *mut pz_module, res: *mut i64, a: *const i64, a_dnum: usize, ggsw: *const f64,
         p: *const pz_glwe_op_params) -> c_int;
+}
+
+#[repr(C)]
+pub struct pz_blind_rotation_params {
+    pub rank: u64, pub n_lwe: u64, pub block_size: u64, pub dnum: u64, pub brk_size: u64, pub base2k: u64, pub res_size: u64,
+    pub lut_size: u64,
 }
 
 /// The reference panics (`assert!`) on shape / scratch violations; so does the shim.

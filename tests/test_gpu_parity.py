@@ -488,7 +488,7 @@ def test_ggsw_external_product(mods):
 # ------------------------------------------------------------------------------------------
 # SURVEY.md 8f rank 2 / BASELINE configs[3]: CGGI blind rotation on a batch of LWE ciphertexts
 # ------------------------------------------------------------------------------------------
-def _run_blind_rotation(hip, ref, n, rank, n_lwe, block_size, dnum, brk_size, res_size, base2k, batch, seed):
+def _run_blind_rotation(hip, ref, n, rank, n_lwe, block_size, dnum, brk_size, res_size, base2k, batch, seed, fuse=(True, True)):
     from poulpy_amd.hal import BlindRotationParams
     rng = seeded(seed)
     cols = rank + 1
@@ -518,24 +518,39 @@ def _run_blind_rotation(hip, ref, n, rank, n_lwe, block_size, dnum, brk_size, re
     hip.lib.pz_memset_d(hip.handle, d_res.ptr, 0x33, want.nbytes)
     p = BlindRotationParams(rank=rank, n_lwe=n_lwe, block_size=block_size, dnum=dnum, brk_size=brk_size, base2k=base2k,
                             res_size=res_size, lut_size=res_size)
+    hip.set_fusion(*fuse)
     hip.blind_rotation_execute_batched(d_res.ptr, d_lwe.ptr, d_lut.ptr, d_brk.ptr, p, batch)
     hip.sync()
+    hip.set_fusion(True, True)
     got = d_res.download(np.int64, want.size).reshape(want.shape)
     for buf in (d_lwe, d_lut, d_brk, d_res):
         buf.free()
     return got, want
 
 
+@pytest.mark.parametrize("fuse", [(True, True), (False, False)], ids=["one-kernel", "composed"])
 @pytest.mark.parametrize("block_size", [1, 3])
 @pytest.mark.parametrize("rank", [1, 2])
-def test_blind_rotation_batched(mods, rank, block_size):
+def test_blind_rotation_batched(mods, rank, block_size, fuse):
     """poulpy-bin-fhe/src/blind_rotation/tests/test_suite: block sizes 1 and 7 at n_glwe 256; here both variants of
     algorithm.rs against the oracle's restatement on random key material, bit-exact (7 LWE coefficients: a trailing
     partial block, which chunks_exact drops)."""
     n = 256
     ref, hip = mods(n)
-    got, want = _run_blind_rotation(hip, ref, n, rank, 7, block_size, 2, 3, 2, 14, batch=5, seed=31 + rank)
+    got, want = _run_blind_rotation(hip, ref, n, rank, 7, block_size, 2, 3, 2, 14, batch=5, seed=31 + rank, fuse=fuse)
     assert np.array_equal(got, want)
+
+
+def test_blind_rotation_shapes(mods):
+    """Shapes that exercise every branch of the one-kernel path: res limbs beyond the key precision (zeroed), more key limbs
+    than result limbs (carry-only first step), odd batch (half-empty last tile), lut shorter than res, rank 3 (the reference
+    bench shape, 4 x 8 product), n = 256 / 512 / 1024."""
+    for (n, rank, n_lwe, blk, dnum, bsz, rsz, k, batch) in ((256, 1, 6, 2, 1, 2, 3, 12, 3), (512, 3, 6, 3, 1, 2, 1, 18, 5),
+                                                            (1024, 1, 8, 4, 3, 3, 3, 13, 3), (256, 2, 4, 2, 2, 2, 2, 15, 1),
+                                                            (512, 1, 5, 5, 1, 3, 2, 16, 2)):
+        ref, hip = mods(n)
+        got, want = _run_blind_rotation(hip, ref, n, rank, n_lwe, blk, dnum, bsz, rsz, k, batch=batch, seed=n + rank + blk)
+        assert np.array_equal(got, want), (n, rank, n_lwe, blk, dnum, bsz, rsz, k, batch)
 
 
 @pytest.mark.parametrize("n,block_size", [(1024, 7), (1024, 1), (2048, 4)])
