@@ -1523,14 +1523,27 @@ int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t*
             const int m = (int)M->m, mp = m + (m >> 4);
             constexpr int NT = 512;
             const int r0 = m == 128 ? 2 : (m == 256 ? 4 : 8);
-            auto lds_for = [&](int ct) { return ((size_t)m + (size_t)ct * P * mp) * sizeof(cplx) + (size_t)ct * rsz * cols * (size_t)n * 8; };
-            auto fits = [&](int ct) {
-                return lds_for(ct) <= 160 * 1024 && ct * P * (m / 8) <= NT && ct * P * (m / r0) <= 2 * NT;
+            auto lds_for = [&](int ct, bool a32) {
+                return ((size_t)m + (size_t)ct * P * mp) * sizeof(cplx) + (size_t)ct * rsz * cols * (size_t)n * (a32 ? 4 : 8);
+            };
+            auto fits = [&](int ct, bool a32) {
+                return lds_for(ct, a32) <= 160 * 1024 && ct * P * (m / 8) <= ((ct == 2 && r0 == 8) ? 2 : 1) * NT && ct * P * (m / r0) <= 2 * NT &&
+                       (!a32 || k <= 31);
             };
             static const int force_ct = getenv("POULPY_DBG_BR_CT") ? atoi(getenv("POULPY_DBG_BR_CT")) : 0;
-            if (M->fuse_mid && (m == 128 || m == 256 || m == 512) && NT % m == 0 && row_max <= 8 && ncols <= 8 && m * ((ncols + 3) / 4) <= 2 * NT && fits(1)) {
-                const int ct = (force_ct == 1 || !fits(2) || B < 2) ? 1 : 2;
-                const size_t lds = lds_for(ct);
+            const int cgsz = (ncols % 3 == 0 && ncols % 4 != 0) ? 3 : 4;  // 6 output polynomials: two groups of 3, no idle slot
+            const int pj = m * ((ncols + cgsz - 1) / cgsz) <= NT ? 1 : 2;
+            if (M->fuse_mid && (m == 128 || m == 256 || m == 512) && NT % m == 0 && row_max <= 8 && ncols <= 8 &&
+                m * ((ncols + cgsz - 1) / cgsz) <= 2 * NT && fits(1, false)) {
+                // two ciphertexts per workgroup share every key value; with 64-bit accumulators when that fits in LDS, else
+                // with 32-bit digit accumulators (m = 128 is only built with one ciphertext per workgroup)
+                int ct = 1;
+                bool a32 = false;
+                if (force_ct != 1 && B >= 2 && m != 128) {
+                    if (fits(2, false)) ct = 2;
+                    else if (fits(2, true)) { ct = 2; a32 = true; }
+                }
+                const size_t lds = lds_for(ct, a32);
                 BrFusedArgs g;
                 g.res = (long long*)res; g.lut = (const long long*)lut; g.lwe = (const long long*)lwe_2n; g.brk = (const cplx*)brk;
                 g.w2n = M->w2n; g.key_stride = (long long)(pmat_doubles / 2);
@@ -1539,26 +1552,23 @@ int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t*
                 static const int br_skip = getenv("POULPY_DBG_BR_SKIP") ? atoi(getenv("POULPY_DBG_BR_SKIP")) : 0;
                 g.dbg_skip = br_skip;
                 KTimer kt(M, PZ_K_FUSED_MID);
-#define PZ_BR_LAUNCH1(R0_, CT_, PJ_, MR_, CG_)                                                                             \
-    {                                                                                                                      \
-        PZ_TRY(set_lds(k_br_fused<R0_, CT_, NT, PJ_, MR_, CG_>, lds));                                                     \
-        hipLaunchKernelGGL((k_br_fused<R0_, CT_, NT, PJ_, MR_, CG_>), dim3((B + CT_ - 1) / CT_), dim3(NT), lds, M->stream, g); \
+                bool launched = false;
+#define PZ_BR_ONE(R0_, CT_, PJ_, MR_, CG_, A32_)                                                                             \
+    if (!launched && r0 == R0_ && ct == CT_ && pj == PJ_ && mr == MR_ && cgsz == CG_ && a32 == A32_) {                       \
+        PZ_TRY(set_lds(k_br_fused<R0_, CT_, NT, PJ_, MR_, CG_, A32_>, lds));                                                 \
+        hipLaunchKernelGGL((k_br_fused<R0_, CT_, NT, PJ_, MR_, CG_, A32_>), dim3((B + CT_ - 1) / CT_), dim3(NT), lds, M->stream, g); \
+        launched = true;                                                                                                     \
     }
-#define PZ_BR_LAUNCH(R0_, CT_, PJ_)                                                                                        \
-    {                                                                                                                      \
-        if (cgsz == 3) PZ_BR_LAUNCH1(R0_, CT_, PJ_, 8, 3)                                                                  \
-        else if (row_max <= 4) PZ_BR_LAUNCH1(R0_, CT_, PJ_, 4, 4) else PZ_BR_LAUNCH1(R0_, CT_, PJ_, 8, 4)                  \
-    }
-#define PZ_BR_R0(CT_, PJ_)                                                                                                 \
-    {                                                                                                                      \
-        if (m == 128) PZ_BR_LAUNCH(2, CT_, PJ_) else if (m == 256) PZ_BR_LAUNCH(4, CT_, PJ_) else PZ_BR_LAUNCH(8, CT_, PJ_)  \
-    }
-                const int cgsz = (ncols % 3 == 0 && ncols % 4 != 0) ? 3 : 4;  // 6 output polynomials: two groups of 3, no idle slot
-                const int pj = m * ((ncols + cgsz - 1) / cgsz) <= NT ? 1 : 2;
-                if (ct == 2 && pj == 1) PZ_BR_R0(2, 1) else if (ct == 2) PZ_BR_R0(2, 2) else if (pj == 1) PZ_BR_R0(1, 1) else PZ_BR_R0(1, 2)
-#undef PZ_BR_R0
-#undef PZ_BR_LAUNCH1
-#undef PZ_BR_LAUNCH
+#define PZ_BR_SHAPES(R0_, CT_, A32_)                                                                                         \
+    PZ_BR_ONE(R0_, CT_, 1, 4, 4, A32_) PZ_BR_ONE(R0_, CT_, 2, 4, 4, A32_) PZ_BR_ONE(R0_, CT_, 1, 6, 3, A32_) PZ_BR_ONE(R0_, CT_, 2, 6, 3, A32_) \
+    PZ_BR_ONE(R0_, CT_, 1, 8, 4, A32_) PZ_BR_ONE(R0_, CT_, 2, 8, 4, A32_) PZ_BR_ONE(R0_, CT_, 1, 8, 3, A32_) PZ_BR_ONE(R0_, CT_, 2, 8, 3, A32_)
+                const int mr = row_max <= 4 && cgsz == 4 ? 4 : (row_max <= 6 && cgsz == 3 ? 6 : 8);
+                PZ_BR_SHAPES(2, 1, false)
+                PZ_BR_SHAPES(4, 1, false) PZ_BR_SHAPES(4, 2, false) PZ_BR_SHAPES(4, 2, true)
+                PZ_BR_SHAPES(8, 1, false) PZ_BR_SHAPES(8, 2, false) PZ_BR_SHAPES(8, 2, true)
+#undef PZ_BR_SHAPES
+#undef PZ_BR_ONE
+                if (!launched) return fail(PZ_ERR_UNSUPPORTED, "blind_rotation: no one-kernel variant for this shape");
                 PZ_HIP(hipGetLastError());
                 return PZ_OK;
             }

@@ -28,6 +28,9 @@ struct BrFusedArgs {
     int dbg_skip;          // timing diagnostic (wrong results): 1 no DFT passes, 2 no product, 4 no carry phase, 8 no pack
 };
 
+template <bool ACC32> struct AccT { typedef long long type; };
+template <> struct AccT<true> { typedef int type; };
+
 // one extra point per 16: radix passes read with stride m/R and write with stride p, both powers of two
 __device__ __forceinline__ int br_pad(int i) { return i + (i >> 4); }
 
@@ -74,9 +77,13 @@ __device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int mp, int m
 
 // CT ciphertexts per workgroup, NT threads, output polynomials in groups of CG, PJ product jobs per thread
 // (m * ceil(ncols/CG) <= PJ*NT), row_max <= MAXR.
-// LDS: W[m] | X[CT][P][mp] (cplx) | acc[CT][rsz][cols][n] (i64)
-template <int R0, int CT, int NT, int PJ, int MAXR, int CG>
+// LDS: W[m] | X[CT][P][mp] (cplx) | acc[CT][rsz][cols][n].  ACC32 stores the accumulators as 32-bit digits (base2k <= 31):
+// after the first block they are normalized digits; the first block reads X^b * LUT (any i64) straight from global memory.
+template <int R0, int CT, int NT, int PJ, int MAXR, int CG, bool ACC32>
 __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
+    typedef typename AccT<ACC32>::type acc_t;
+    // radix-8 butterflies a thread may own per pass (CT*P*m/8 <= JM8*NT, host-checked): two only for m = 512 with CT = 2
+    constexpr int JM8 = (CT == 2 && R0 == 8) ? 2 : 1;
     extern __shared__ cplx lds_br[];
     const int tid = threadIdx.x;
     const int m = g.m, n = 2 * m, cols = g.cols;
@@ -87,7 +94,7 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
     const int ct_polys = g.rsz * cols;        // accumulator polynomials per ciphertext
     cplx* W = lds_br;                         // exp(2 pi i t / m)
     cplx* X = W + m;
-    long long* acc = reinterpret_cast<long long*>(X + CT * P * mp);
+    acc_t* acc = reinterpret_cast<acc_t*>(X + CT * P * mp);
     const int b0 = blockIdx.x * CT;
     const unsigned mask2 = 2u * (unsigned)n - 1u;
 
@@ -95,19 +102,20 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
     // NT is a multiple of m (host-checked): a thread's pack / carry jobs all have j = tid mod m, so its twist factor
     // exp(2 pi i j / 4m) is fetched once
     const cplx tw_j = g.w2n[tid % m];
-    // acc = X^b * LUT in column 0, zero elsewhere (:298-301)
-    for (int e = tid; e < CT * ct_polys * n; e += NT) {
-        const int j = e % n, pc = (e / n) % ct_polys, ct = e / (n * ct_polys);
-        const int col = pc % cols, limb = pc / cols;
+    // X^b * LUT in column 0, zero elsewhere (:298-301): coefficient idx of (ct, limb, col)
+    auto lut_rot = [&](int ct, int limb, int col, int idx) -> long long {
+        if (col != 0 || limb >= g.lut_size) return 0;
         const int b = min(b0 + ct, g.batch - 1);
-        long long v = 0;
-        if (col == 0 && limb < g.lut_size) {
-            const unsigned kk = (unsigned)((unsigned long long)g.lwe[(long long)b * (g.n_lwe + 1)] & (unsigned long long)mask2);
-            const unsigned i0 = ((unsigned)j - kk) & mask2;
-            const long long s = g.lut[(long long)limb * n + (i0 & (unsigned)(n - 1))];
-            v = i0 >= (unsigned)n ? (long long)(0ull - (unsigned long long)s) : s;
+        const unsigned kk = (unsigned)((unsigned long long)g.lwe[(long long)b * (g.n_lwe + 1)] & (unsigned long long)mask2);
+        const unsigned i0 = ((unsigned)idx - kk) & mask2;
+        const long long s = g.lut[(long long)limb * n + (i0 & (unsigned)(n - 1))];
+        return i0 >= (unsigned)n ? (long long)(0ull - (unsigned long long)s) : s;
+    };
+    if (!ACC32) {
+        for (int e = tid; e < CT * ct_polys * n; e += NT) {
+            const int j = e % n, pc = (e / n) % ct_polys, ct = e / (n * ct_polys);
+            acc[e] = (acc_t)lut_rot(ct, pc / cols, pc % cols, j);
         }
-        acc[e] = v;
     }
     __syncthreads();
 
@@ -118,12 +126,14 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
     const int njobs_prod = m * ncg;           // product jobs (q, column group); a job covers the CT ciphertexts
 
     for (int blk0 = 0; blk0 + g.blk <= g.n_lwe; blk0 += g.blk) {
+        const bool from_lut = ACC32 && blk0 == 0;  // the accumulator is still X^b * LUT in global memory
         // ---- pack + twist: X[ct][r][j] = (acc[r][j] + i acc[r][j+m]) * exp(2 pi i j / 4m),  r = limb*cols + col (:319-320)
         if (!(g.dbg_skip & 8))
         for (int job = tid; job < CT * row_max * m; job += NT) {
             const int j = job % m, r = (job / m) % row_max, ct = job / (m * row_max);
-            const long long* a = acc + ((long long)ct * ct_polys + r) * n;
-            const cplx z = make_double2((double)a[j], (double)a[j + m]);
+            const acc_t* a = acc + ((long long)ct * ct_polys + r) * n;
+            const cplx z = from_lut ? make_double2((double)lut_rot(ct, r / cols, r % cols, j), (double)lut_rot(ct, r / cols, r % cols, j + m))
+                                    : make_double2((double)a[j], (double)a[j + m]);
             X[(ct * P + r) * mp + br_pad(j)] = cmul(z, tw_j);
         }
         __syncthreads();
@@ -134,8 +144,8 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
             cplx* buf = X + ct * P * mp;
             const int np = row_max == P ? CT * P : row_max;
             br_pass<R0, false, 2, NT>(buf, np, mp, m, 1, W, tid);
-            br_pass<8, false, 1, NT>(buf, np, mp, m, R0, W, tid);
-            br_pass<8, false, 1, NT>(buf, np, mp, m, R0 * 8, W, tid);
+            br_pass<8, false, JM8, NT>(buf, np, mp, m, R0, W, tid);
+            br_pass<8, false, JM8, NT>(buf, np, mp, m, R0 * 8, W, tid);
         }
         // ---- product, in place: X[ct][c][q] = sum_i (DFT(X^a_i)[q] - 1) * sum_r X[ct][r][q] * BRK_i[r][c][q]   (:321-337)
         if (!(g.dbg_skip & 2)) {
@@ -158,6 +168,8 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
                     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                         for (int j = 0; j < CG; ++j) out[pj][ct][j] = make_double2(0.0, 0.0);
+                    // (a second register set that prefetches coefficient i+1 during the arithmetic of i was tried: it spills
+                    // at 256 VGPRs and is 5-12 % slower)
                     for (int i = blk0; i < blk0 + g.blk; ++i) {
                         const cplx* K = g.brk + (long long)i * g.key_stride;
                         cplx kv[CG][MAXR];
@@ -219,8 +231,8 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
             cplx* buf = X + ct * P * mp;
             const int np = ncols == P ? CT * P : ncols;
             br_pass<R0, true, 2, NT>(buf, np, mp, m, 1, W, tid);
-            br_pass<8, true, 1, NT>(buf, np, mp, m, R0, W, tid);
-            br_pass<8, true, 1, NT>(buf, np, mp, m, R0 * 8, W, tid);
+            br_pass<8, true, JM8, NT>(buf, np, mp, m, R0, W, tid);
+            br_pass<8, true, JM8, NT>(buf, np, mp, m, R0 * 8, W, tid);
         }
         // ---- untwist, round(x/m), + acc, carry chain from the last limb to limb 0 (:342-346); thread = (ct, column, j < m):
         //      coefficients j and j+m.  Same digit/carry arithmetic as the fused tail (device_fft.hpp, PZ_TAIL_COEFFS).
@@ -233,14 +245,17 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
                 const cplx v = cmulc(X[(ct * P + limb * cols + col) * mp + br_pad(j)], tw);
                 const bool writes = limb < g.rsz;
                 const bool first = limb == g.bsz - 1;
-                long long* a = acc + ((long long)ct * ct_polys + (long long)limb * cols + col) * n;
+                acc_t* a = acc + ((long long)ct * ct_polys + (long long)limb * cols + col) * n;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const double val = (h ? v.y : v.x) * inv_m;
                     const double rv = round_half_away(val);
                     // 3-instruction conversion when exact (|x| < 2^51), the saturating one otherwise (Rust `as i64`)
                     long long x = fabs(rv) < 2251799813685247.0 ? fast_i64_from_integral(rv) : sat_i64_from_integral(rv);
-                    if (writes) x = (long long)((unsigned long long)x + (unsigned long long)a[j + h * m]);
+                    if (writes) {
+                        const long long prev = from_lut ? lut_rot(ct, limb, col, j + h * m) : (long long)a[j + h * m];
+                        x = (long long)((unsigned long long)x + (unsigned long long)prev);
+                    }
                     const unsigned long long y = (unsigned long long)x + half;
                     const long long d = (long long)(y & dmask) - (long long)half;
                     const long long cr = (long long)y >> k;
@@ -250,13 +265,13 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
                         const unsigned long long y2 = (unsigned long long)d + (unsigned long long)cy[h] + half;
                         const long long x1 = (long long)(y2 & dmask) - (long long)half;
                         cy[h] = (long long)((unsigned long long)cr + (unsigned long long)((long long)y2 >> k));
-                        if (writes) a[j + h * m] = x1;
+                        if (writes) a[j + h * m] = (acc_t)x1;
                     }
                 }
             }
             // limbs of acc beyond the precision of the big value are zero (normalize.rs:118-120)
             for (int limb = g.bsz; limb < g.rsz; ++limb) {
-                long long* a = acc + ((long long)ct * ct_polys + (long long)limb * cols + col) * n;
+                acc_t* a = acc + ((long long)ct * ct_polys + (long long)limb * cols + col) * n;
                 a[j] = 0;
                 a[j + m] = 0;
             }
@@ -265,7 +280,12 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
     }
     for (int e = tid; e < CT * ct_polys * n; e += NT) {
         const int ct = e / (ct_polys * n);
-        if (b0 + ct < g.batch) g.res[(long long)b0 * ct_polys * n + e] = acc[e];
+        if (b0 + ct < g.batch) {
+            // (no complete block at all: the result is the rotated LUT itself)
+            const bool untouched = ACC32 && g.blk > g.n_lwe;
+            const int pc = (e / n) % ct_polys;
+            g.res[(long long)b0 * ct_polys * n + e] = untouched ? lut_rot(ct, pc / cols, pc % cols, e % n) : (long long)acc[e];
+        }
     }
 }
 
