@@ -506,7 +506,7 @@ void pz_module_free(pz_module* M) {
     if (!M) return;
     (void)hipSetDevice(M->device);
     if (M->stream) (void)hipStreamSynchronize(M->stream);
-    for (void* p : {(void*)M->tw1, (void*)M->tw1inv, (void*)M->wL1, (void*)M->wL2, (void*)M->tw12, (void*)M->tw12t, (void*)M->w2n, M->ws, (void*)M->margin})
+    for (void* p : {(void*)M->tw1, (void*)M->tw1inv, (void*)M->wL1, (void*)M->wL2, (void*)M->tw12, (void*)M->tw12t, (void*)M->w2n, M->ws, M->ws2, (void*)M->margin})
         if (p) (void)hipFree(p);
     for (auto& c : M->arena) (void)hipFree(c.p);
     for (auto& t : M->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
@@ -1637,26 +1637,20 @@ int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t*
     pz_glwe_op_params ep;
     ep.rank = p->rank; ep.dnum = p->dnum; ep.dsize = 1; ep.key_size = p->brk_size; ep.key_base2k = p->base2k;
     ep.a_size = p->res_size; ep.a_base2k = p->base2k; ep.res_size = p->res_size; ep.res_base2k = p->base2k; ep.rank_out = p->rank;
-    // acc_tmp lives in its own allocation: the external product owns the module workspace
-    int64_t* acc_tmp = nullptr;
-    PZ_HIP(hipMalloc(&acc_tmp, (size_t)B * res_ct * 8));
-    int st = PZ_OK;
+    // acc_tmp lives in the module's second workspace: the external product owns the first one
+    PZ_TRY(ws2_reserve(M, (size_t)B * res_ct * 8));
+    int64_t* acc_tmp = (int64_t*)M->ws2;
     PolyMap pm{rsz, cols, res_ct, (long long)cols * n, n, 0};
-    for (int i = 0; i < n_lwe && st == PZ_OK; ++i) {
-        st = glwe_op(M, false, acc_tmp, res, brk + (size_t)i * pmat_doubles, &ep, batch);
-        if (st == PZ_OK)
-            st = launch_rotate(M, B * rsz * cols, (const long long*)acc_tmp, pm, (long long*)res, pm, 2, rsz * cols, (const long long*)lwe_2n,
-                               lwe_bs, 1 + i, 0);
+    for (int i = 0; i < n_lwe; ++i) {
+        PZ_TRY(glwe_op(M, false, acc_tmp, res, brk + (size_t)i * pmat_doubles, &ep, batch));
+        PZ_TRY(launch_rotate(M, B * rsz * cols, (const long long*)acc_tmp, pm, (long long*)res, pm, 2, rsz * cols, (const long long*)lwe_2n,
+                             lwe_bs, 1 + i, 0));
     }
-    if (st == PZ_OK) {
-        // vec_znx_normalize_assign (normalize.rs:403-425) == out-of-place same-base normalize of a copy
-        PZ_HIP(hipMemcpyAsync(acc_tmp, res, (size_t)B * res_ct * 8, hipMemcpyDeviceToDevice, M->stream));
-        DV tv{acc_tmp, res_ct, cols, rsz};
-        for (int c = 0; c < cols && st == PZ_OK; ++c) st = dev_normalize(M, B, rv, k, 0, c, tv, k, c);
-    }
-    (void)hipStreamSynchronize(M->stream);
-    (void)hipFree(acc_tmp);
-    return st;
+    // vec_znx_normalize_assign (normalize.rs:403-425) == out-of-place same-base normalize of a copy
+    PZ_HIP(hipMemcpyAsync(acc_tmp, res, (size_t)B * res_ct * 8, hipMemcpyDeviceToDevice, M->stream));
+    DV tv{acc_tmp, res_ct, cols, rsz};
+    for (int c = 0; c < cols; ++c) PZ_TRY(dev_normalize(M, B, rv, k, 0, c, tv, k, c));
+    return PZ_OK;
 }
 
 }  // extern "C"

@@ -106,6 +106,8 @@ struct pz_module {
     // grow-only workspace
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    void* ws2 = nullptr;   // second grow-only buffer for callers that nest an operation which owns `ws`
+    size_t ws2_bytes = 0;
     // staging arena for host-pointer calls: chunks are kept for the module's lifetime and the bump
     // pointer is reset at the start of every call (calls are serialised by `mu` and end with a sync)
     struct Chunk { void* p; size_t bytes; };
@@ -163,6 +165,17 @@ inline int ws_reserve(pz_module* M, size_t bytes) {
     size_t want = bytes + (bytes >> 3);
     PZ_HIP(hipMalloc(&M->ws, want));
     M->ws_bytes = want;
+    return PZ_OK;
+}
+
+inline int ws2_reserve(pz_module* M, size_t bytes) {
+    if (bytes <= M->ws2_bytes) return PZ_OK;
+    PZ_HIP(hipStreamSynchronize(M->stream));
+    if (M->ws2) PZ_HIP(hipFree(M->ws2));
+    M->ws2 = nullptr;
+    M->ws2_bytes = 0;
+    PZ_HIP(hipMalloc(&M->ws2, bytes));
+    M->ws2_bytes = bytes;
     return PZ_OK;
 }
 
