@@ -128,11 +128,11 @@ static int launch_inv_pass1(pz_module* M, int npolys, const cplx* T, long long* 
 // the two roles of k_inv_tail must be whole waves
 static bool tail_supported(const pz_module* M) { return (M->plan.f1b * M->plan.cb) % 64 == 0; }
 
-static int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
-                           int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
-                           int base2k, bool rowmajor = false, bool small_all = false, unsigned auto_mul = 0, bool auto_neg = false) {
+static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
+                                int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
+                                int base2k, bool rowmajor, bool small_all, unsigned auto_mul, bool auto_neg, int col_base, int col_count) {
     const FftPlan& pl = M->plan;
-    const int blocks = batch * ncols * (pl.m2 / pl.cb);
+    const int blocks = batch * col_count * (pl.m2 / pl.cb);
     if (blocks == 0) return PZ_OK;
     KTimer kt(M, PZ_K_FUSED_TAIL);
     TailArgs g;
@@ -141,6 +141,7 @@ static int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, i
     g.small_cols = small_cols; g.small_size = small_size; g.base2k = base2k; g.m2 = pl.m2;
     g.tw1inv = M->tw1inv; g.wL1 = M->wL1; g.margin = M->margin;
     g.small_all = small_all ? 1 : 0; g.auto_mul = auto_mul; g.auto_neg = auto_neg ? 1 : 0;
+    g.col_base = col_base; g.col_count = col_count;
     const bool has_small = small != nullptr;
 // one instantiation per (probe, row-major, body add) combination actually requested
 #define PZ_TAIL_ONE(A, B, C, P_, R_, S_)                                                                        \
@@ -163,6 +164,20 @@ static int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, i
     PZ_P1F_CASES(X)
 #undef X
     return fail(PZ_ERR_UNSUPPORTED, "no fused tail kernel for m1=%d", pl.m1);
+}
+// The body operand of a key switch only exists for column 0: that column runs the variant that prefetches it (more
+// registers, one workgroup less per CU), the other columns the plain one.
+static int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
+                           int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
+                           int base2k, bool rowmajor = false, bool small_all = false, unsigned auto_mul = 0, bool auto_neg = false) {
+    if (small != nullptr && !small_all && ncols > 1) {
+        PZ_TRY(launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, small, small_bs, small_cols, small_size,
+                                    base2k, rowmajor, false, auto_mul, auto_neg, 0, 1));
+        return launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, nullptr, 0, small_cols, small_size,
+                                    base2k, rowmajor, false, 0, false, 1, ncols - 1);
+    }
+    return launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, small, small_bs, small_cols, small_size, base2k,
+                                rowmajor, small_all, auto_mul, auto_neg, 0, ncols);
 }
 
 static bool mid_supported(const pz_module* M, int npi, int npo) {

@@ -353,7 +353,7 @@ k_inv_pass1(const cplx* __restrict__ T, long long* __restrict__ dst, PolyMap dma
 //   T      : [poly p][j2][q1], p = (b*nlimbs + limb)*ncols + col  (output of inverse pass 2)
 //   res    : VecZnx (res_cols, res_size), batch stride res_bs; column res_col0 + col
 //   small  : optional VecZnx added to column 0 before normalizing (key-switch body, glwe.rs:237)
-// grid.x = batch*ncols*(m2/CB)
+// grid.x = batch*col_count*(m2/CB)
 // =================================================================================
 struct TailArgs {
     const cplx* T;
@@ -373,6 +373,7 @@ struct TailArgs {
     int small_all;
     unsigned auto_mul;  // 0: no sign
     int auto_neg;
+    int col_base, col_count;  // this launch covers columns [col_base, col_base + col_count) of the ncols
 };
 
 // Workgroup = (R2 + R1)*CB threads in two wave-uniform roles (R2*CB must be a multiple of 64):
@@ -400,8 +401,8 @@ k_inv_tail(TailArgs g) {
     const int ncb = g.m2 / CB;
     const int c0 = (blockIdx.x % ncb) * CB;
     const int bc = blockIdx.x / ncb;
-    const int col = bc % g.ncols;
-    const int b = bc / g.ncols;
+    const int col = g.col_base + bc % g.col_count;
+    const int b = bc / g.col_count;
     const long long m = (long long)M1 * g.m2;
     const long long n = 2 * m;
     const int L = g.nlimbs;
