@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--op", choices=("external_product", "keyswitch", "automorphism", "automorphism_add"), default="external_product",
                     help="keyswitch = BASELINE configs[2] (secondary metric; GGLWE rows 8, cols_in 1, cols_out 2); automorphism[_add] = "
                          "glwe_automorphism[_add] with Galois element 5 on the same key shape (CKKS-rotate shape of configs[4])")
+    ap.add_argument("--no-pin-key", action="store_true", help="rebuild the key's row-sliced copy on every call (pz_module_pin_key not used)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -161,6 +162,8 @@ def main():
     params = GlweOpParams(rank=RANK_GLWE, dnum=DNUM, dsize=1, key_size=SIZE, key_base2k=BASE2K, a_size=SIZE, a_base2k=BASE2K,
                           res_size=SIZE, res_base2k=BASE2K, rank_out=RANK_GLWE)
     a_ptr, res_ptr, key_ptr = C.c_void_p(a.data_ptr()), C.c_void_p(res.data_ptr()), C.c_void_p(pmat.data_ptr())
+    if not args.no_pin_key:   # evaluation keys are immutable for the lifetime of the job: let the backend keep its row-sliced copy
+        mod.pin_key(key_ptr, DNUM, cols_in, cols, SIZE)
     torch.cuda.synchronize()
 
     def step():

@@ -268,6 +268,11 @@ size_t pz_blind_rotation_workspace_bytes(const pz_module* m, const pz_blind_rota
 /* workspace the calls above need for `batch` ciphertexts (bytes, device); keyswitch: 0 external product, 1 key switch,
  * 2 automorphism family */
 size_t pz_glwe_op_workspace_bytes(const pz_module* m, const pz_glwe_op_params* p, size_t batch, int keyswitch);
+/* Optional: declare a prepared key (device pointer from pz_vmp_prepare) immutable until unpinned.  The batched calls
+ * above then reuse a row-sliced copy built once here instead of rebuilding it per call (+~3 % at the metric shape,
+ * costs one extra copy of the key in HBM).  Modifying a pinned key without unpinning it first is a caller error. */
+int pz_module_pin_key(pz_module* m, const double* pmat, size_t rows, size_t cols_in, size_t cols_out, size_t size);
+int pz_module_unpin_key(pz_module* m, const double* pmat);
 /* Tuning knob: number of ciphertexts pushed through the three-kernel pipeline per
  * wave so that intermediates stay in the 256 MiB Infinity Cache (0 = auto). */
 int pz_module_set_chunk(pz_module* m, size_t cts_per_chunk);

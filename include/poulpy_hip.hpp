@@ -149,6 +149,10 @@ class Module {  // Module<FFT64Hip>, poulpy-hal/src/layouts/module.rs:97-189
     void blind_rotation_execute_batched(int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk, const pz_blind_rotation_params& p, size_t batch) {
         check(pz_blind_rotation_execute_batched(m_, res, lwe_2n, lut, brk, &p, batch), "blind_rotation_execute_batched");
     }
+    void pin_key(const double* pmat, size_t rows, size_t cols_in, size_t cols_out, size_t size) {
+        check(pz_module_pin_key(m_, pmat, rows, cols_in, cols_out, size), "module_pin_key");
+    }
+    void unpin_key(const double* pmat) { check(pz_module_unpin_key(m_, pmat), "module_unpin_key"); }
     void ggsw_external_product(int64_t* res, const int64_t* a, size_t a_dnum, const double* ggsw, const pz_glwe_op_params& p) {
         check(pz_ggsw_external_product(m_, res, a, a_dnum, ggsw, &p), "ggsw_external_product");
     }

@@ -120,6 +120,9 @@ struct pz_module {
     bool probe = false;
     size_t chunk = 0;
     int dbg_stages = 7;  // diagnostic: bit 0 pass 1, bit 1 middle, bit 2 tail of the fused pipeline (results invalid unless 7)
+    // prepared keys the caller declared immutable (pz_module_pin_key): their row-sliced copies for the fused pipeline
+    struct PinnedKey { const void* key; pz::cplx* sliced; size_t bytes; };
+    std::vector<PinnedKey> pinned;
     bool fuse_tail = true, fuse_mid = true;  // kernel-fusion knobs of the batched GLWE ops (tests run both settings)
     // per-kernel-class HIP-event timing (bench.py's roofline leg); off by default
     bool timing = false;

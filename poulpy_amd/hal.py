@@ -357,6 +357,13 @@ class Module:
     def blind_rotation_workspace_bytes(self, params: BlindRotationParams, batch: int) -> int:
         return self.lib.pz_blind_rotation_workspace_bytes(self.handle, C.byref(params), c_size_t(batch))
 
+    def pin_key(self, pmat: c_void_p, rows: int, cols_in: int, cols_out: int, size: int):
+        """Declare a prepared device key immutable: the fused pipeline keeps its row-sliced copy instead of rebuilding it per call."""
+        self._ck(self.lib.pz_module_pin_key(self.handle, pmat, *_sz(rows, cols_in, cols_out, size)))
+
+    def unpin_key(self, pmat: c_void_p):
+        self._ck(self.lib.pz_module_unpin_key(self.handle, pmat))
+
     def glwe_op_workspace_bytes(self, params: GlweOpParams, batch: int, keyswitch: bool) -> int:
         return self.lib.pz_glwe_op_workspace_bytes(self.handle, C.byref(params), c_size_t(batch), c_int(int(keyswitch)))
 

@@ -95,6 +95,8 @@ unsafe extern "C" {
     pub fn pz_blind_rotation_execute_batched(m: *mut pz_module, res: *mut i64, lwe_2n: *const i64, lut: *const i64, brk: *const f64,
         p: *const pz_blind_rotation_params, batch: usize) -> c_int;
     pub fn pz_blind_rotation_workspace_bytes(m: *const pz_module, p: *const pz_blind_rotation_params, batch: usize) -> usize;
+    pub fn pz_module_pin_key(m: *mut pz_module, pmat: *const f64, rows: usize, cols_in: usize, cols_out: usize, size: usize) -> c_int;
+    pub fn pz_module_unpin_key(m: *mut pz_module, pmat: *const f64) -> c_int;
     pub fn pz_ggsw_external_product(m: *mut pz_module, res: *mut i64, a: *const i64, a_dnum: usize, ggsw: *const f64,
         p: *const pz_glwe_op_params) -> c_int;
 }

@@ -241,7 +241,7 @@ def test_big_add_small_assign(mods):
 # batched, device-resident GLWE operations (CoreImpl-level boundary)
 # ------------------------------------------------------------------------------------------
 def _run_glwe_op(hip, ref, ks, n, rank, rank_out, a_size, a_base2k, key_size, key_base2k, dnum, dsize, res_size, res_base2k, batch,
-                 seed, chunk=0, fuse=(True, True), auto=None, in_place=False):
+                 seed, chunk=0, fuse=(True, True), auto=None, in_place=False, pin=False):
     """auto = (galois element, mode) runs the glwe_automorphism family on top of the key switch."""
     from poulpy_amd.hal import GlweOpParams
     rng = seeded(seed)
@@ -277,6 +277,9 @@ def _run_glwe_op(hip, ref, ks, n, rank, rank_out, a_size, a_base2k, key_size, ke
                      res_size=res_size, res_base2k=res_base2k, rank_out=rank_out)
     hip.set_chunk(chunk)
     hip.set_fusion(*fuse)
+    if pin:
+        hip.pin_key(d_key.ptr, dnum, cols_in, cols_out, key_size)
+        hip.glwe_external_product_batched(d_res.ptr, d_a.ptr, d_key.ptr, p, batch) if not ks else None  # first call after pinning
     if auto is not None:
         hip.glwe_automorphism_batched(d_res.ptr, d_a.ptr, d_key.ptr, p, auto[0], auto[1], batch)
     elif ks:
@@ -285,6 +288,8 @@ def _run_glwe_op(hip, ref, ks, n, rank, rank_out, a_size, a_base2k, key_size, ke
         hip.glwe_external_product_batched(d_res.ptr, d_a.ptr, d_key.ptr, p, batch)
     hip.sync()
     got = d_res.download(np.int64, want.size).reshape(want.shape)
+    if pin:
+        hip.unpin_key(d_key.ptr)
     hip.set_chunk(0)
     hip.set_fusion(True, True)
     for buf in ((d_a, d_key) if in_place else (d_a, d_key, d_res)):
@@ -339,6 +344,26 @@ def test_metric_config_external_product_n65536(mods):
     hip.set_margin_probe(False)
     assert np.array_equal(got, want)
     assert margin < 0.05, f"rounding margin too thin: max |x-round(x)| = {margin}"
+
+
+def test_pinned_key_n65536(mods):
+    """pz_module_pin_key: the cached row-sliced key gives the same bits (external product and key switch), the pin is refused
+    twice, and unpinning an unknown key is an error."""
+    from poulpy_amd.hal import PoulpyHipError
+    n = 65536
+    ref, hip = mods(n)
+    got, want = _run_glwe_op(hip, ref, False, n, 1, 1, 8, 12, 8, 12, 8, 1, 8, 12, batch=3, seed=11, pin=True)
+    assert np.array_equal(got, want)
+    got, want = _run_glwe_op(hip, ref, True, n, 1, 1, 8, 12, 8, 12, 8, 1, 8, 12, batch=2, seed=12, pin=True)
+    assert np.array_equal(got, want)
+    buf = hip.device_alloc(n * 8 * 4)
+    hip.pin_key(buf.ptr, 1, 1, 2, 2)
+    with pytest.raises(PoulpyHipError):
+        hip.pin_key(buf.ptr, 1, 1, 2, 2)
+    hip.unpin_key(buf.ptr)
+    with pytest.raises(PoulpyHipError):
+        hip.unpin_key(buf.ptr)
+    buf.free()
 
 
 def test_config3_keyswitch_n65536(mods):
