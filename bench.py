@@ -104,10 +104,22 @@ def main():
     ap.add_argument("--op", choices=("external_product", "keyswitch", "automorphism", "automorphism_add"), default="external_product",
                     help="keyswitch = BASELINE configs[2] (secondary metric; GGLWE rows 8, cols_in 1, cols_out 2); automorphism[_add] = "
                          "glwe_automorphism[_add] with Galois element 5 on the same key shape (CKKS-rotate shape of configs[4])")
+    ap.add_argument("--n", type=int, default=0, help="override the ring degree (0 = 65536, the metric configuration); "
+                                                     "--n 4096 --limbs 4 --base2k 17 --batch 1024 = BASELINE configs[1]")
+    ap.add_argument("--base2k", type=int, default=0)
+    ap.add_argument("--limbs", type=int, default=0, help="override the number of limbs (and dnum); 16 = CKKS shape of BASELINE configs[4]; "
+                                                         "0 = the metric configuration (8)")
     ap.add_argument("--no-pin-key", action="store_true", help="rebuild the key's row-sliced copy on every call (pz_module_pin_key not used)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
+    global SIZE, DNUM, N, BASE2K
+    if args.limbs:
+        SIZE = DNUM = args.limbs
+    if args.n:
+        N = args.n
+    if args.base2k:
+        BASE2K = args.base2k
 
     import torch
     import torch.distributed as dist
@@ -226,14 +238,14 @@ def main():
                         "pipeline_achieved": value / world * b_unit / 1e9,
                         "kernel_ms": {k: round(v[1], 3) for k, v in stats.items() if v[0]}}
         line = {
-            "metric": (f"GLWE {args.op.replace('_', ' ')}s/sec (N=2^16, 8 limbs)" if auto_mode else
-                       "GLWE key-switches/sec (N=2^16, 8 limbs)" if ks else "GGSW external-products/sec (N=2^16, 8 limbs)"),
+            "metric": (f"GLWE {args.op.replace('_', ' ')}s/sec (N={N}, {SIZE} limbs)" if auto_mode else
+                       f"GLWE key-switches/sec (N={N}, {SIZE} limbs)" if ks else f"GGSW external-products/sec (N={N}, {SIZE} limbs)"),
             "value": value, "unit": (f"{args.op}s/s" if auto_mode else "key-switches/s" if ks else "external-products/s"),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"glwe_{args.op} (Galois element 5) via GGLWE VmpPMat, N=65536, 8 limbs, base2k=12, dnum=8, dsize=1" if auto_mode else
-                                    "GLWE(rank 1) key-switch via GGLWE VmpPMat, N=65536, 8 limbs, base2k=12, dnum=8, dsize=1" if ks else
-                                    "GLWE(rank 1) x GGSW external product, N=65536, 8 limbs, base2k=12, dnum=8, dsize=1"),
+            "config": {"workload": (f"glwe_{args.op} (Galois element 5) via GGLWE VmpPMat, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize=1" if auto_mode else
+                                    f"GLWE(rank 1) key-switch via GGLWE VmpPMat, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize=1" if ks else
+                                    f"GLWE(rank 1) x GGSW external product, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize=1"),
                        "batch_per_gpu": args.batch, "parallelism": f"batch-sharded x{world}, key broadcast (RCCL)",
                        "output_digits_balanced": ok},
             "roofline": roof,

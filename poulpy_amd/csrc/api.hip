@@ -27,7 +27,7 @@ using namespace pz;
 // kernel dispatch
 // ------------------------------------------------------------------------------
 #define PZ_P1_CASES(X) X(4, 1, 4) X(8, 1, 4) X(8, 1, 16) X(16, 1, 16) X(8, 4, 16) X(8, 8, 16) X(16, 8, 16) X(16, 16, 16)
-#define PZ_P1F_CASES(X) X(4, 1, 4) X(8, 1, 4) X(8, 1, 16) X(16, 1, 16) X(4, 8, 16) X(8, 8, 16) X(8, 16, 16) X(16, 16, 16) X(8, 16, 8)
+#define PZ_P1F_CASES(X) X(4, 1, 4) X(8, 1, 4) X(8, 1, 16) X(16, 1, 16) X(4, 4, 16) X(4, 8, 16) X(8, 8, 16) X(8, 16, 16) X(16, 16, 16) X(8, 16, 8)
 #define PZ_P2_CASES(X) X(4, 1, 4) X(8, 1, 4) X(16, 1, 4) X(16, 1, 16) X(8, 4, 16) X(8, 8, 16) X(16, 8, 16) X(16, 16, 16)
 
 template <typename K>
@@ -223,19 +223,16 @@ static int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cp
     g.stagger = stg >= 0 ? stg : (M->plan.m2 == 128 ? 0 : 1);
     g.stagger_mod = std::max(1, stm);
     if (M->plan.m2 == 128) {
-        static const int ct128 = getenv("POULPY_DBG_MID_CT") ? atoi(getenv("POULPY_DBG_MID_CT")) : 4;  // diagnostic knob
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, M->device);
         KTimer kt(M, PZ_K_FUSED_MID);
-        if (ct128 == 2) {
-            constexpr int CT = 2;
+        if (npi <= 8 && npo <= 8) {
+            // <= 8 polynomials in and out (e.g. rank 1 with 4 limbs, BASELINE configs[1]): 8 ciphertexts x 8 slots per tile
+            constexpr int CT = 8;
             g.n_ct = (batch + CT - 1) / CT;
-            const size_t lds = ((size_t)CT * 16 * 16 * 9 + 256) * sizeof(cplx);
-            PZ_TRY(set_lds(k_mid128<CT>, lds));
-            static const int percu = getenv("POULPY_DBG_MID_PERCU") ? atoi(getenv("POULPY_DBG_MID_PERCU")) : 2;
-            static bool once = false;
-            if (!once && getenv("POULPY_DBG_VERBOSE")) { once = true; int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mid128<CT>, CT * 128, lds); fprintf(stderr, "k_mid128<2>: %d blocks/CU at lds=%zu\n", nb, lds); }
-            hipLaunchKernelGGL((k_mid128<CT>), dim3(std::min(ncu * percu, g.m1 * g.n_ct)), dim3(CT * 128), lds, M->stream, g);
+            const size_t lds = ((size_t)CT * 8 * 16 * 9 + 256) * sizeof(cplx);
+            PZ_TRY(set_lds((k_mid128<CT, 8>), lds));
+            hipLaunchKernelGGL((k_mid128<CT, 8>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(512), lds, M->stream, g);
         } else {
             constexpr int CT = 4;
             g.n_ct = (batch + CT - 1) / CT;

@@ -266,23 +266,30 @@ k_mid(MidArgs g) {
 // Measured (round 1): middle kernel 19 % faster than the m2 = 256 form (0.70 vs 0.86 ms per 128 ciphertexts: the
 // key slice is streamed from L2 half as often), but the m1 = 256 tail needs radix 16 x 16 and spills (+14 % on the
 // external product, 2x on the key switch), so the default plan stays m1 = 128, m2 = 256; POULPY_DBG_SPLIT=w
-// selects this one.  POULPY_DBG_MID_CT=2 runs it with two ciphertexts per tile and two workgroups per CU.
+// selects this one.  (Two ciphertexts per tile with two workgroups per CU was no faster: DESIGN.md.)
 // =================================================================================
-template <int CT>
-__global__ void __launch_bounds__(CT * 128)
+// NP = polynomial slots per ciphertext (16, or 8 for shapes with <= 8 polynomials in and out such as rank 1 with 4 limbs:
+// twice the ciphertexts per tile and per key fetch).  The 4 thread groups of the product phase split into GC column groups x GT
+// ciphertext groups so that a thread always owns 4 ciphertexts x 4 outputs.
+template <int CT, int NP = 16>
+__global__ void __launch_bounds__(CT * NP * 8)
 k_mid128(MidArgs g) {
     constexpr int M2 = 128;
-    constexpr int NT = CT * 128;
-    constexpr int NCG = NT / M2;       // column groups in the product phase
-    constexpr int NC = 16 / NCG;       // outputs per thread
+    constexpr int NT = CT * NP * 8;
+    constexpr int NCG = NT / M2;       // thread groups in the product phase
+    constexpr int NC = 4;              // outputs per thread
+    constexpr int GC = NP / NC;        // column groups
+    constexpr int GT = NCG / GC;       // ciphertext groups
+    constexpr int CTt = CT / GT;       // ciphertexts per thread
+    static_assert(GC * GT == NCG && CTt * GT == CT && NT == 512, "k_mid128 tile shape");
     constexpr int RS = 16 * 9;         // padded row stride (points): z[k1][o] at k1*9 + o
     extern __shared__ cplx lds[];      // CT*16 rows x RS | wL2[128] | tw12t row [128]
     const int tid = threadIdx.x;
     const long long m = (long long)g.m1 * M2;
     const int row = tid >> 3, o = tid & 7;
-    const int ctl = row >> 4, rr = row & 15;
+    const int ctl = row / NP, rr = row % NP;
     cplx* rowbuf = lds + row * RS;
-    cplx* wl = lds + CT * 16 * RS;
+    cplx* wl = lds + CT * NP * RS;
     cplx* twrow = wl + M2;
 
     const bool xcd_map = (g.m1 & 7) == 0 && (gridDim.x & 7) == 0;
@@ -343,7 +350,7 @@ k_mid128(MidArgs g) {
         twn = g.tw12t[(long long)tile_q1(w) * M2 + (tid & (M2 - 1))];
     }
     if (tid < M2) twrow[tid] = twn;
-    const int vq2 = tid & (M2 - 1), vcg = tid / M2;
+    const int vq2 = tid & (M2 - 1), vcg = (tid / M2) % GC, vtg = (tid / M2) / GC;
     const int rot = g.row_max > 0 ? (w % g.row_max) : 0;
     cplx pn[NC];
 #define PZ_MID_P0(LT)                                                                                  \
@@ -360,9 +367,9 @@ k_mid128(MidArgs g) {
         const int b = (L % g.n_ct) * CT + ctl;
         {
             const int q2 = vq2, cg = vcg;
-            cplx acc[CT][NC];
+            cplx acc[CTt][NC];
 #pragma unroll
-            for (int i = 0; i < CT; ++i)
+            for (int i = 0; i < CTt; ++i)
 #pragma unroll
                 for (int j = 0; j < NC; ++j) acc[i][j] = make_double2(0.0, 0.0);
             const cplx* pp[NC];
@@ -385,8 +392,8 @@ k_mid128(MidArgs g) {
     {                                                                                           \
         int r_ = (IT) + rot;                                                                    \
         r_ -= (r_ >= g.row_max) ? g.row_max : 0;                                                \
-        _Pragma("unroll") for (int i = 0; i < CT; ++i) {                                        \
-            const cplx av = lds[(i * 16 + r_) * RS + q2];                                       \
+        _Pragma("unroll") for (int i = 0; i < CTt; ++i) {                                       \
+            const cplx av = lds[((vtg * CTt + i) * NP + r_) * RS + q2];                                       \
             _Pragma("unroll") for (int j = 0; j < NC; ++j) {                                    \
                 acc[i][j].x = __builtin_fma(av.x, SRC[j].x, acc[i][j].x);                       \
                 acc[i][j].x = __builtin_fma(-av.y, SRC[j].y, acc[i][j].x);                      \
@@ -407,11 +414,11 @@ k_mid128(MidArgs g) {
 #undef PZ_USEROW
             lds_barrier();
 #pragma unroll
-            for (int i = 0; i < CT; ++i)
+            for (int i = 0; i < CTt; ++i)
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
                     const int c = cg * NC + j;
-                    lds[(i * 16 + c) * RS + q2] = (c < g.ncomp) ? acc[i][j] : make_double2(0.0, 0.0);
+                    lds[((vtg * CTt + i) * NP + c) * RS + q2] = (c < g.ncomp) ? acc[i][j] : make_double2(0.0, 0.0);
                 }
             lds_barrier();
         }

@@ -78,12 +78,17 @@ inline bool make_plan(uint64_t n, FftPlan& pl) {
     int k = 0;
     while ((1ull << k) < m) ++k;
     int k1 = k / 2;
+    // N = 4096 / 8192: rows of 128 points (m1 = 16 / 32) instead of the balanced 32 x 64 / 64 x 64, so that the batched GLWE
+    // pipeline can use the fused middle kernel (BASELINE configs[1] is N = 4096)
+    if (k == 11) k1 = 4;
+    if (k == 12) k1 = 5;
     if (const char* e = getenv("POULPY_DBG_SPLIT")) { if (e[0] == 'w' && (k & 1)) k1 = (k + 1) / 2; }  // diagnostic: m1 > m2
     pl.m1 = 1 << k1;
     pl.m2 = 1 << (k - k1);
     if (!radices_for(pl.m1, pl.r1a, pl.r1b)) return false;
     if (!radices_for(pl.m2, pl.r2a, pl.r2b)) return false;
     pl.f1a = pl.r1a; pl.f1b = pl.r1b;
+    if (pl.m1 == 16) { pl.f1a = 4; pl.f1b = 4; }
     if (pl.m1 == 32) { pl.f1a = 4; pl.f1b = 8; }
     if (pl.m1 == 128) { pl.f1a = 8; pl.f1b = 16; }
     pl.cb = pl.m2 >= 16 ? 16 : 4;
