@@ -238,8 +238,8 @@ def main():
                         "pipeline_achieved": value / world * b_unit / 1e9,
                         "kernel_ms": {k: round(v[1], 3) for k, v in stats.items() if v[0]}}
         line = {
-            "metric": (f"GLWE {args.op.replace('_', ' ')}s/sec (N={N}, {SIZE} limbs)" if auto_mode else
-                       f"GLWE key-switches/sec (N={N}, {SIZE} limbs)" if ks else f"GGSW external-products/sec (N={N}, {SIZE} limbs)"),
+            "metric": (f"GLWE {args.op.replace('_', ' ')}s/sec (N=2^{N.bit_length() - 1}, {SIZE} limbs)" if auto_mode else
+                       f"GLWE key-switches/sec (N=2^{N.bit_length() - 1}, {SIZE} limbs)" if ks else f"GGSW external-products/sec (N=2^{N.bit_length() - 1}, {SIZE} limbs)"),
             "value": value, "unit": (f"{args.op}s/s" if auto_mode else "key-switches/s" if ks else "external-products/s"),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
