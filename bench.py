@@ -47,13 +47,16 @@ KERNEL_OF_CLASS = {"fused_mid": "pz::k_mid", "fused_tail": "pz::k_inv_tail", "fw
 
 def pmc_traffic(kernel_class: str, batch: int):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (FETCH_SIZE x2 + WRITE_SIZE,
-    separate passes, tools/prof.sh); only valid for the batch the profile was taken at (128)."""
+    separate passes, tools/prof.sh); only valid for the batch the profile was taken at (its `batch_per_launch`)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-    if not files or batch != 128:
+    if not files:
         return None
     try:
-        data = json.load(open(files[-1]))["kernels"]
+        doc = json.load(open(files[-1]))
+        if int(doc.get("batch_per_launch", 128)) != batch:
+            return None
+        data = doc["kernels"]
         prefix = KERNEL_OF_CLASS.get(kernel_class, "?")
         best = max((v["hbm_bytes_per_dispatch_corrected"] for k, v in data.items() if k.startswith(prefix)), default=None)
         return best
@@ -99,7 +102,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=128, help="ciphertexts per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="ciphertexts per GPU per step (16 GiB of GLWE in + out at the metric shape)")
     ap.add_argument("--chunk", type=int, default=0, help="ciphertexts per pipeline wave (0 = auto)")
     ap.add_argument("--op", choices=("external_product", "keyswitch", "automorphism", "automorphism_add"), default="external_product",
                     help="keyswitch = BASELINE configs[2] (secondary metric; GGLWE rows 8, cols_in 1, cols_out 2); automorphism[_add] = "

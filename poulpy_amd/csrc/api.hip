@@ -1277,11 +1277,11 @@ static OpWs op_ws(const pz_module* M, const pz_glwe_op_params* p, const OpShape&
 }
 static size_t pick_chunk(const pz_module* M, const pz_glwe_op_params* p, const OpShape& s, size_t batch) {
     if (M->chunk) return std::min(M->chunk, batch);
-    // Measured on MI355X (profiles/r01_chunk_sweep.txt): with separate kernels the intermediates do not
-    // stay in the Infinity Cache anyway and every wave re-streams the key, so larger waves win; cap the
-    // workspace at ~4 GiB.
+    // Measured on MI355X (profiles/r01_chunk_sweep.txt, r01_batch_sweep.txt): the intermediates do not stay in the Infinity
+    // Cache anyway and every wave re-streams the key and pays the pipeline fill of the persistent middle kernel, so larger
+    // waves win (128 -> 1024 ciphertexts per wave: +13 %); cap the workspace at ~24 GiB of the 288 GB.
     const size_t per_ct = (size_t)M->n * 8 * ((size_t)s.cols_in * s.a_size_eff + 2 * (size_t)s.cols_out * p->key_size);
-    size_t c = ((size_t)4 << 30) / std::max<size_t>(per_ct, 1);
+    size_t c = ((size_t)24 << 30) / std::max<size_t>(per_ct, 1);
     c = std::max<size_t>(c & ~(size_t)7, 8);
     return std::min(c, batch);
 }
