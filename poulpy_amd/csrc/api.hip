@@ -147,7 +147,7 @@ static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlim
 #define PZ_TAIL_ONE(A, B, C, P_, R_, S_)                                                                        \
     if (M->probe == P_ && rowmajor == R_ && has_small == S_) {                                                  \
         PZ_TRY(set_lds(k_inv_tail<A, B, C, P_, R_, S_>, lds));                                                  \
-        hipLaunchKernelGGL((k_inv_tail<A, B, C, P_, R_, S_>), dim3(blocks), dim3((A + B) * C), lds, M->stream, g); \
+        hipLaunchKernelGGL((k_inv_tail<A, B, C, P_, R_, S_>), dim3(blocks), dim3(TailShape<A, B, C>::NT), lds, M->stream, g); \
     }
 #define PZ_TAIL_LAUNCH(A, B, C)                                                                                 \
     PZ_TAIL_ONE(A, B, C, false, false, false) PZ_TAIL_ONE(A, B, C, false, false, true)                          \

@@ -382,9 +382,23 @@ struct TailArgs {
 //                            double-buffered exchange, and the loads of limb j-2 behind that.
 // The two roles run concurrently (one barrier per limb), so the HBM latency of the next limbs hides
 // behind the arithmetic of the current one, and each role only pays for its own registers.
+// R1 = 16 (m1 = 256): the B' role is SPLIT over two threads per column position — the last radix-16 butterfly is one
+// radix-2 step (sum half / twiddled difference half, both read all 16 inputs from the exchange buffer) followed by a
+// radix-8 butterfly, so a thread owns 8 outputs and 16 carries like in the R1 = 8 plans instead of 16 and 32 (which spills).
+template <int R1, int R2, int CB>
+struct TailShape {
+    static constexpr bool SPLIT = R1 == 16;
+    static constexpr int RE = SPLIT ? 8 : R1;                   // outputs per B' thread
+    static constexpr int NB = (SPLIT ? 2 : 1) * R2 * CB;        // B' threads
+    static constexpr int NT = NB + R1 * CB;                     // + A' threads
+};
 template <int R1, int R2, int CB, bool PROBE, bool ROWMAJOR = false, bool SMALL = false>
-__global__ void __launch_bounds__((R1 + R2) * CB, (((R1 + R2) * CB >= 512 || SMALL) ? 2 : 3))
+__global__ void __launch_bounds__(((R1 == 16 ? 2 : 1) * R2 + R1) * CB, ((((R1 == 16 ? 2 : 1) * R2 + R1) * CB >= 512) ? 1 : (SMALL ? 2 : 3)))
 k_inv_tail(TailArgs g) {
+    constexpr bool SPLIT = TailShape<R1, R2, CB>::SPLIT;
+    constexpr int RE = TailShape<R1, R2, CB>::RE;
+    constexpr int NB = TailShape<R1, R2, CB>::NB;
+    constexpr int NT = TailShape<R1, R2, CB>::NT;
     constexpr int M1 = R1 * R2;
     constexpr int XCH = (R1 + 1) * CB * R2;  // cplx per exchange buffer
     extern __shared__ cplx xch[];            // 2 * XCH | wL1[M1] | tw1inv[M1]
@@ -393,7 +407,7 @@ k_inv_tail(TailArgs g) {
     cplx* wl = xch + 2 * XCH;
     cplx* twi = wl + M1;
     const int tid = threadIdx.x;
-    for (int t = tid; t < M1; t += (R1 + R2) * CB) {
+    for (int t = tid; t < M1; t += NT) {
         wl[t] = g.wL1[t];
         twi[t] = g.tw1inv[t];
     }
@@ -407,9 +421,9 @@ k_inv_tail(TailArgs g) {
     const long long n = 2 * m;
     const int L = g.nlimbs;
 
-    if (tid >= R2 * CB) {
+    if (tid >= NB) {
         // ------------------------------ role A' ------------------------------
-        const int ta = tid - R2 * CB;
+        const int ta = tid - NB;
         const int k1 = ROWMAJOR ? ta / CB : ta % R1;
         const int c = ROWMAJOR ? ta % CB : ta / R1;
         // element (q1 = k1 + R1*k2, j2 = c0 + c): T[j2][q1] or, ROWMAJOR, T'[q1][j2]
@@ -445,10 +459,13 @@ k_inv_tail(TailArgs g) {
     }
     // ------------------------------ role B' ------------------------------
     const int k = g.base2k;
-    const int b_o = tid / CB, b_c = tid % CB;
-    long long carry[2 * R1];
+    const int hs = SPLIT ? tid / (R2 * CB) : 0;                  // which half of the last butterfly (wave-uniform)
+    const int tb = SPLIT ? tid - hs * (R2 * CB) : tid;
+    const int b_o = tb / CB, b_c = tb % CB;
+#define PZ_TAIL_N1(E) (SPLIT ? 2 * (E) + hs : (E))              /* butterfly output index of this thread's E-th value */
+    long long carry[2 * RE];
 #pragma unroll
-    for (int u = 0; u < 2 * R1; ++u) carry[u] = 0;
+    for (int u = 0; u < 2 * RE; ++u) carry[u] = 0;
     long long* res_col = g.res + (long long)b * g.res_bs + (long long)col * n;
     const long long res_ls = (long long)g.res_cols * n;
     const long long* small_col =
@@ -457,7 +474,8 @@ k_inv_tail(TailArgs g) {
     // limbs of res beyond the precision of the big value are zero (normalize.rs:118-120)
     for (int j = L; j < g.res_size; ++j)
 #pragma unroll
-        for (int n1 = 0; n1 < R1; ++n1) {
+        for (int e = 0; e < RE; ++e) {
+            const int n1 = PZ_TAIL_N1(e);
             const long long idx = (long long)(b_o + R2 * n1) * g.m2 + c0 + b_c;
             res_col[(long long)j * res_ls + idx] = 0;
             res_col[(long long)j * res_ls + idx + m] = 0;
@@ -466,22 +484,35 @@ k_inv_tail(TailArgs g) {
     for (int j = L - 1; j >= 0; --j) {
         const cplx* buf = xch + (j & 1) * XCH;
         // key-switch body limb: requested first so that its latency hides behind the butterfly
-        long long sm[SMALL ? 2 * R1 : 1];
+        long long sm[SMALL ? 2 * RE : 1];
         if (SMALL && small_col && j < g.small_size) {
 #pragma unroll
-            for (int n1 = 0; n1 < R1; ++n1) {
-                const long long idx = (long long)(b_o + R2 * n1) * g.m2 + c0 + b_c;
-                sm[2 * n1] = small_col[(long long)j * small_ls + idx];
-                sm[2 * n1 + 1] = small_col[(long long)j * small_ls + idx + m];
+            for (int e = 0; e < RE; ++e) {
+                const long long idx = (long long)(b_o + R2 * PZ_TAIL_N1(e)) * g.m2 + c0 + b_c;
+                sm[2 * e] = small_col[(long long)j * small_ls + idx];
+                sm[2 * e + 1] = small_col[(long long)j * small_ls + idx + m];
             }
         } else if (SMALL) {
 #pragma unroll
-            for (int t = 0; t < 2 * R1; ++t) sm[t] = 0;
+            for (int t = 0; t < 2 * RE; ++t) sm[t] = 0;
         }
-        cplx v[R1];
+        cplx v[RE];
+        if (SPLIT) {
+            // first step of the inverse radix-16 butterfly: this thread keeps the sums (hs = 0: even outputs) or the
+            // twiddled differences (hs = 1: odd outputs), then a radix-8 butterfly
+            const cplx* in = buf + (b_o * CB + b_c) * (R1 + 1);
+            if (hs == 0) {
 #pragma unroll
-        for (int k1 = 0; k1 < R1; ++k1) v[k1] = buf[(b_o * CB + b_c) * (R1 + 1) + k1];
-        Bfly<R1, true>::run(v);
+                for (int n = 0; n < RE; ++n) v[n] = cadd(in[n], in[n + R1 / 2]);
+            } else {
+#pragma unroll
+                for (int n = 0; n < RE; ++n) v[n] = tw_small<R1, true>(csub(in[n], in[n + R1 / 2]), n);
+            }
+        } else {
+#pragma unroll
+            for (int k1 = 0; k1 < RE; ++k1) v[k1] = buf[(b_o * CB + b_c) * (R1 + 1) + k1];
+        }
+        Bfly<RE, true>::run(v);
         const bool writes = j < g.res_size;
         const bool first = j == L - 1;
         const bool add_small = small_col && j < g.small_size;
@@ -489,17 +520,17 @@ k_inv_tail(TailArgs g) {
         // scale/untwist in place and bound the magnitudes: below 2^51 the 3-instruction conversion is exact
         double big = 0.0;
 #pragma unroll
-        for (int n1 = 0; n1 < R1; ++n1) {
-            v[n1] = cmul(v[n1], twi[b_o + R2 * n1]);
-            big = fmax(big, fmax(fabs(v[n1].x), fabs(v[n1].y)));
+        for (int e = 0; e < RE; ++e) {
+            v[e] = cmul(v[e], twi[b_o + R2 * PZ_TAIL_N1(e)]);
+            big = fmax(big, fmax(fabs(v[e].x), fabs(v[e].y)));
         }
         const unsigned long long half = 1ull << (k - 1), mask = (1ull << k) - 1;
         // One pass per coefficient: round, convert, (+ body), carry step, store.  digit(x) = ((x + 2^(k-1)) mod 2^k) -
         // 2^(k-1), carry(x) = (x + 2^(k-1)) >> k: the values of the reference's shift pairs
         // (reference/znx/normalization.rs:4-11,24-41,107-129,179-221) with fewer 64-bit operations.
 #define PZ_TAIL_COEFFS(CONVERT)                                                                               \
-    _Pragma("unroll") for (int n1 = 0; n1 < R1; ++n1) {                                                      \
-        const int j1 = b_o + R2 * n1;                                                                        \
+    _Pragma("unroll") for (int n1 = 0; n1 < RE; ++n1) {                                                      \
+        const int j1 = b_o + R2 * PZ_TAIL_N1(n1);                                                            \
         _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                      \
             const long long idx = (long long)j1 * g.m2 + c0 + b_c + (h ? m : 0);                             \
             const double val = h ? v[n1].y : v[n1].x;                                                        \
@@ -535,5 +566,7 @@ k_inv_tail(TailArgs g) {
         __syncthreads();
     }
 }
+
+#undef PZ_TAIL_N1
 
 }  // namespace pz

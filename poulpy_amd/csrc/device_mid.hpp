@@ -263,10 +263,10 @@ k_mid(MidArgs g) {
 // (16 points each: one radix-16 butterfly, then two radix-8 butterflies), so a tile of FOUR ciphertexts
 // x 16 polynomials fits in LDS (144 KiB) and every key value fetched serves four ciphertexts instead of
 // two.  512 threads = 64 rows x 8 lanes; product phase: 128 points x 4 groups of 4 outputs.
-// Measured (round 1): middle kernel 19 % faster than the m2 = 256 form (0.70 vs 0.86 ms per 128 ciphertexts: the
-// key slice is streamed from L2 half as often), but the m1 = 256 tail needs radix 16 x 16 and spills (+14 % on the
-// external product, 2x on the key switch), so the default plan stays m1 = 128, m2 = 256; POULPY_DBG_SPLIT=w
-// selects this one.  (Two ciphertexts per tile with two workgroups per CU was no faster: DESIGN.md.)
+// Measured (round 1): middle kernel 16-19 % faster than the m2 = 256 form (the key slice is streamed from L2 half as
+// often); default at N = 2^16 since the radix 16 x 16 tail of the m1 = 256 column passes no longer spills
+// (device_fft.hpp, SPLIT).  POULPY_DBG_SPLIT=t selects the 128 x 256 split (k_mid<2>) instead.  (Two ciphertexts per tile
+// with two workgroups per CU was no faster: DESIGN.md.)
 // =================================================================================
 // NP = polynomial slots per ciphertext (16, or 8 for shapes with <= 8 polynomials in and out such as rank 1 with 4 limbs:
 // twice the ciphertexts per tile and per key fetch).  The 4 thread groups of the product phase split into GC column groups x GT

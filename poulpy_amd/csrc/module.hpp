@@ -82,7 +82,15 @@ inline bool make_plan(uint64_t n, FftPlan& pl) {
     // pipeline can use the fused middle kernel (BASELINE configs[1] is N = 4096)
     if (k == 11) k1 = 4;
     if (k == 12) k1 = 5;
-    if (const char* e = getenv("POULPY_DBG_SPLIT")) { if (e[0] == 'w' && (k & 1)) k1 = (k + 1) / 2; }  // diagnostic: m1 > m2
+    // N = 65536: 256 x 128 ("wide"): rows of 128 points let the middle kernel hold four ciphertexts per tile, i.e. every key
+    // value fetched from L2 serves four ciphertexts instead of two (middle kernel -16 %, external product +8 %); the
+    // radix-16 x 16 column passes cost the same as the 8 x 16 ones of the 128 x 256 split once the tail's last butterfly is
+    // shared by two threads (device_fft.hpp, SPLIT)
+    if (k == 15) k1 = 8;
+    if (const char* e = getenv("POULPY_DBG_SPLIT")) {  // diagnostic: force m1 > m2 ('w') or the balanced / m1 < m2 split ('t')
+        if (e[0] == 'w' && (k & 1)) k1 = (k + 1) / 2;
+        if (e[0] == 't') k1 = k / 2;
+    }
     pl.m1 = 1 << k1;
     pl.m2 = 1 << (k - k1);
     if (!radices_for(pl.m1, pl.r1a, pl.r1b)) return false;

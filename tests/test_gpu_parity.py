@@ -386,11 +386,12 @@ def test_fused_tail_shapes(mods, n):
         assert np.array_equal(got, want), (n, res_size)
 
 
-def test_wide_plan_external_product_n65536(monkeypatch):
-    """The alternative four-step split (m1 = 256, m2 = 128: k_mid128, four ciphertexts per tile) gives the same bits."""
+def test_tall_plan_external_product_n65536(monkeypatch):
+    """The alternative four-step split at N = 2^16 (m1 = 128, m2 = 256: k_mid<2>, two ciphertexts per tile; the default is
+    256 x 128 with k_mid128<4>) gives the same bits."""
     from oracle.ref import RefModule
     from poulpy_amd.hal import Module
-    monkeypatch.setenv("POULPY_DBG_SPLIT", "w")
+    monkeypatch.setenv("POULPY_DBG_SPLIT", "t")
     n = 65536
     ref, hip = RefModule(n), Module(n)
     monkeypatch.delenv("POULPY_DBG_SPLIT")
