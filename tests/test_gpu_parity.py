@@ -366,6 +366,17 @@ def test_pinned_key_n65536(mods):
     buf.free()
 
 
+def test_small_shapes_on_the_fused_pipeline(mods):
+    """<= 8 polynomials in and out select the 8-slot tile of the middle kernel (8 ciphertexts per tile): 4 limbs at N = 2^16 and
+    2^13, external product and key switch, batches that leave the last tile partly empty."""
+    for (n, size, batch) in ((65536, 4, 9), (8192, 4, 11), (4096, 3, 17)):
+        ref, hip = mods(n)
+        got, want = _run_glwe_op(hip, ref, False, n, 1, 1, size, 13, size, 13, size, 1, size, 13, batch=batch, seed=n + size)
+        assert np.array_equal(got, want), (n, size, "external product")
+        got, want = _run_glwe_op(hip, ref, True, n, 1, 1, size, 13, size, 13, size, 1, size, 13, batch=batch - 2, seed=n + size + 1)
+        assert np.array_equal(got, want), (n, size, "key switch")
+
+
 def test_config3_keyswitch_n65536(mods):
     """BASELINE configs[2]: GLWE key-switch via VmpPMat, N=2^16, 8 limbs (GGLWE rows=8, cols_in=1, cols_out=2)."""
     n = 65536
