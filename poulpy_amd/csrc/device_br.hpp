@@ -126,10 +126,16 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
     const int njobs_prod = m * ncg;           // product jobs (q, column group); a job covers the CT ciphertexts
 
     for (int blk0 = 0; blk0 + g.blk <= g.n_lwe; blk0 += g.blk) {
+        // Everything the phases derive from the thread index (butterfly positions, LDS offsets, key offsets) is loop-invariant;
+        // hoisted out of this loop it would stay live across all phases and spill.  An opaque copy of the index per
+        // iteration makes the compiler recompute those few integer operations where they are used.
+        // Only where it would spill (two ciphertexts at m = 512): elsewhere keeping them in registers is faster (9-13 %).
+        int tidv = tid;
+        if (CT == 2 && R0 == 8) asm volatile("" : "+v"(tidv));
         const bool from_lut = ACC32 && blk0 == 0;  // the accumulator is still X^b * LUT in global memory
         // ---- pack + twist: X[ct][r][j] = (acc[r][j] + i acc[r][j+m]) * exp(2 pi i j / 4m),  r = limb*cols + col (:319-320)
         if (!(g.dbg_skip & 8))
-        for (int job = tid; job < CT * row_max * m; job += NT) {
+        for (int job = tidv; job < CT * row_max * m; job += NT) {
             const int j = job % m, r = (job / m) % row_max, ct = job / (m * row_max);
             const acc_t* a = acc + ((long long)ct * ct_polys + r) * n;
             const cplx z = from_lut ? make_double2((double)lut_rot(ct, r / cols, r % cols, j), (double)lut_rot(ct, r / cols, r % cols, j + m))
@@ -143,25 +149,32 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
         for (int ct = 0; ct < (row_max == P ? 1 : CT); ++ct) {
             cplx* buf = X + ct * P * mp;
             const int np = row_max == P ? CT * P : row_max;
-            br_pass<R0, false, 2, NT>(buf, np, mp, m, 1, W, tid);
-            br_pass<8, false, JM8, NT>(buf, np, mp, m, R0, W, tid);
-            br_pass<8, false, JM8, NT>(buf, np, mp, m, R0 * 8, W, tid);
+            br_pass<R0, false, 2, NT>(buf, np, mp, m, 1, W, tidv);
+            br_pass<8, false, JM8, NT>(buf, np, mp, m, R0, W, tidv);
+            br_pass<8, false, JM8, NT>(buf, np, mp, m, R0 * 8, W, tidv);
         }
         // ---- product, in place: X[ct][c][q] = sum_i (DFT(X^a_i)[q] - 1) * sum_r X[ct][r][q] * BRK_i[r][c][q]   (:321-337)
         if (!(g.dbg_skip & 2)) {
             cplx out[PJ][CT][CG];
 #pragma unroll
             for (int pj = 0; pj < PJ; ++pj) {
-                const int job = tid + pj * NT;
+                const int job = tidv + pj * NT;
                 if (job < njobs_prod) {
                     // m is a multiple of 64, so a wave has one column group: keep it (and every key row pointer) in SGPRs,
                     // the loads then need one VGPR offset instead of a 64-bit VGPR pointer each
                     const int q = job % m, cg = __builtin_amdgcn_readfirstlane(job / m);
-                    cplx a[CT][MAXR];
+                    // input points of this frequency: in registers for the whole block, or (ALDS: two ciphertexts with more than
+                    // 4 rows, where registers would spill) re-read from LDS at each use
+                    constexpr bool ALDS = CT == 2 && MAXR > 4;
+                    cplx a[ALDS ? 1 : CT][ALDS ? 1 : MAXR];
+                    if (!ALDS) {
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
+                        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                        for (int r = 0; r < MAXR; ++r) a[ct][r] = r < row_max ? X[(ct * P + r) * mp + br_pad(q)] : make_double2(0.0, 0.0);
+                            for (int r = 0; r < MAXR; ++r)
+                                a[ALDS ? 0 : ct][ALDS ? 0 : r] = r < row_max ? X[(ct * P + r) * mp + br_pad(q)] : make_double2(0.0, 0.0);
+                    }
+#define PZ_BR_A(CT_, R_) (ALDS ? X[((CT_) * P + (R_)) * mp + br_pad(q)] : a[ALDS ? 0 : (CT_)][ALDS ? 0 : (R_)])
                     // coefficient by coefficient: the CG x row_max key values of this thread's column group are requested
                     // together (one exposed L2 latency per coefficient), then consumed
 #pragma unroll
@@ -194,10 +207,11 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
 #pragma unroll
                                 for (int r = 0; r < MAXR; ++r) {
                                     if (r < row_max) {
-                                        s.x = __builtin_fma(a[ct][r].x, kv[j][r].x, s.x);
-                                        s.x = __builtin_fma(-a[ct][r].y, kv[j][r].y, s.x);
-                                        s.y = __builtin_fma(a[ct][r].x, kv[j][r].y, s.y);
-                                        s.y = __builtin_fma(a[ct][r].y, kv[j][r].x, s.y);
+                                        const cplx av = PZ_BR_A(ct, r);
+                                        s.x = __builtin_fma(av.x, kv[j][r].x, s.x);
+                                        s.x = __builtin_fma(-av.y, kv[j][r].y, s.x);
+                                        s.y = __builtin_fma(av.x, kv[j][r].y, s.y);
+                                        s.y = __builtin_fma(av.y, kv[j][r].x, s.y);
                                     }
                                 }
                                 const cplx xv = cmul(xm[ct], s);
@@ -208,10 +222,11 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
                     }
                 }
             }
+#undef PZ_BR_A
             __syncthreads();  // every input point has been read: the outputs may overwrite them
 #pragma unroll
             for (int pj = 0; pj < PJ; ++pj) {
-                const int job = tid + pj * NT;
+                const int job = tidv + pj * NT;
                 if (job < njobs_prod) {
                     const int q = job % m, cg = job / m;
 #pragma unroll
@@ -230,14 +245,14 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
         for (int ct = 0; ct < (ncols == P ? 1 : CT); ++ct) {
             cplx* buf = X + ct * P * mp;
             const int np = ncols == P ? CT * P : ncols;
-            br_pass<R0, true, 2, NT>(buf, np, mp, m, 1, W, tid);
-            br_pass<8, true, JM8, NT>(buf, np, mp, m, R0, W, tid);
-            br_pass<8, true, JM8, NT>(buf, np, mp, m, R0 * 8, W, tid);
+            br_pass<R0, true, 2, NT>(buf, np, mp, m, 1, W, tidv);
+            br_pass<8, true, JM8, NT>(buf, np, mp, m, R0, W, tidv);
+            br_pass<8, true, JM8, NT>(buf, np, mp, m, R0 * 8, W, tidv);
         }
         // ---- untwist, round(x/m), + acc, carry chain from the last limb to limb 0 (:342-346); thread = (ct, column, j < m):
         //      coefficients j and j+m.  Same digit/carry arithmetic as the fused tail (device_fft.hpp, PZ_TAIL_COEFFS).
         if (!(g.dbg_skip & 4))
-        for (int job = tid; job < CT * cols * m; job += NT) {
+        for (int job = tidv; job < CT * cols * m; job += NT) {
             const int j = job % m, col = (job / m) % cols, ct = job / (m * cols);
             const cplx tw = tw_j;
             long long cy[2] = {0, 0};
