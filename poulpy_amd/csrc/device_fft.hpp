@@ -482,13 +482,17 @@ k_inv_tail(TailArgs g) {
         }
     __syncthreads();  // matches the prologue iteration of role A'
     for (int j = L - 1; j >= 0; --j) {
+        // (SMALL: the per-output address arithmetic is loop-invariant and would be hoisted out of the limb loop into ~32
+        //  live registers; an opaque copy of the lane coordinates per limb makes the compiler recompute it instead)
+        int b_ov = b_o, b_cv = b_c;
+        if (SMALL) asm volatile("" : "+v"(b_ov), "+v"(b_cv));
         const cplx* buf = xch + (j & 1) * XCH;
         // key-switch body limb: requested first so that its latency hides behind the butterfly
         long long sm[SMALL ? 2 * RE : 1];
         if (SMALL && small_col && j < g.small_size) {
 #pragma unroll
             for (int e = 0; e < RE; ++e) {
-                const long long idx = (long long)(b_o + R2 * PZ_TAIL_N1(e)) * g.m2 + c0 + b_c;
+                const long long idx = (long long)(b_ov + R2 * PZ_TAIL_N1(e)) * g.m2 + c0 + b_cv;
                 sm[2 * e] = small_col[(long long)j * small_ls + idx];
                 sm[2 * e + 1] = small_col[(long long)j * small_ls + idx + m];
             }
@@ -500,7 +504,7 @@ k_inv_tail(TailArgs g) {
         if (SPLIT) {
             // first step of the inverse radix-16 butterfly: this thread keeps the sums (hs = 0: even outputs) or the
             // twiddled differences (hs = 1: odd outputs), then a radix-8 butterfly
-            const cplx* in = buf + (b_o * CB + b_c) * (R1 + 1);
+            const cplx* in = buf + (b_ov * CB + b_cv) * (R1 + 1);
             if (hs == 0) {
 #pragma unroll
                 for (int n = 0; n < RE; ++n) v[n] = cadd(in[n], in[n + R1 / 2]);
@@ -510,7 +514,7 @@ k_inv_tail(TailArgs g) {
             }
         } else {
 #pragma unroll
-            for (int k1 = 0; k1 < RE; ++k1) v[k1] = buf[(b_o * CB + b_c) * (R1 + 1) + k1];
+            for (int k1 = 0; k1 < RE; ++k1) v[k1] = buf[(b_ov * CB + b_cv) * (R1 + 1) + k1];
         }
         Bfly<RE, true>::run(v);
         const bool writes = j < g.res_size;
@@ -521,7 +525,7 @@ k_inv_tail(TailArgs g) {
         double big = 0.0;
 #pragma unroll
         for (int e = 0; e < RE; ++e) {
-            v[e] = cmul(v[e], twi[b_o + R2 * PZ_TAIL_N1(e)]);
+            v[e] = cmul(v[e], twi[b_ov + R2 * PZ_TAIL_N1(e)]);
             big = fmax(big, fmax(fabs(v[e].x), fabs(v[e].y)));
         }
         const unsigned long long half = 1ull << (k - 1), mask = (1ull << k) - 1;
@@ -530,9 +534,9 @@ k_inv_tail(TailArgs g) {
         // (reference/znx/normalization.rs:4-11,24-41,107-129,179-221) with fewer 64-bit operations.
 #define PZ_TAIL_COEFFS(CONVERT)                                                                               \
     _Pragma("unroll") for (int n1 = 0; n1 < RE; ++n1) {                                                      \
-        const int j1 = b_o + R2 * PZ_TAIL_N1(n1);                                                            \
+        const int j1 = b_ov + R2 * PZ_TAIL_N1(n1);                                                            \
         _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                      \
-            const long long idx = (long long)j1 * g.m2 + c0 + b_c + (h ? m : 0);                             \
+            const long long idx = (long long)j1 * g.m2 + c0 + b_cv + (h ? m : 0);                             \
             const double val = h ? v[n1].y : v[n1].x;                                                        \
             const double r = round_half_away(val);                                                           \
             if (PROBE) worst = fmax(worst, fabs(val - r));                                                   \
