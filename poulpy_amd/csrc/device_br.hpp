@@ -37,17 +37,22 @@ __device__ __forceinline__ int br_pad(int i) { return i + (i >> 4); }
 // Stockham autosort pass, in place (natural order in and out): sub-transforms of length p are done, this pass makes p*R.
 //   u[r] = buf[i + r*m/R] * w^(+-k r), w = exp(2 pi i/(pR)), k = i mod p;  DFT_R;  buf[(i-k)*R + k + s*p] = u[s]
 // A thread owns up to JMAX butterflies (job = tid + jj*NT) and keeps them in registers across the barrier.
+template <int R> struct Log2 { static constexpr int v = 1 + Log2<R / 2>::v; };
+template <> struct Log2<1> { static constexpr int v = 0; };
+
 template <int R, bool INV, int JMAX, int NT>
-__device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int mp, int m, int p, const cplx* W, int tid) {
-    const int t = m / R;
-    const int wstep = m / (p * R);
-    const int njobs = njobs_poly * t;
+__device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int mp, int m, int lm, int p, const cplx* W, int tid) {
+    // m, p and R are powers of two: positions come from shifts and masks (lm = log2 m), never from integer division
+    const int lt = lm - Log2<R>::v;
+    const int t = 1 << lt;
+    const int wstep = (m >> Log2<R>::v) / p;
+    const int njobs = njobs_poly << lt;
     cplx u[JMAX][R];
 #pragma unroll
     for (int jj = 0; jj < JMAX; ++jj) {
         const int job = tid + jj * NT;
         if (job < njobs) {
-            const int poly = job / t, i = job - poly * t;
+            const int poly = job >> lt, i = job & (t - 1);
             const int k = i & (p - 1);
             const cplx* src = buf + poly * mp;
 #pragma unroll
@@ -64,7 +69,7 @@ __device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int mp, int m
     for (int jj = 0; jj < JMAX; ++jj) {
         const int job = tid + jj * NT;
         if (job < njobs) {
-            const int poly = job / t, i = job - poly * t;
+            const int poly = job >> lt, i = job & (t - 1);
             const int k = i & (p - 1);
             cplx* dst = buf + poly * mp;
             const int j = (i - k) * R + k;
@@ -87,6 +92,7 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
     extern __shared__ cplx lds_br[];
     const int tid = threadIdx.x;
     const int m = g.m, n = 2 * m, cols = g.cols;
+    const int lm = 31 - __builtin_clz((unsigned)m);  // m is a power of two and NT a multiple of it (host-checked)
     const int mp = br_pad(m);
     const int in_limbs = min(g.dnum, g.rsz);  // limbs of acc that enter the product (acc_dft has dnum limbs, the rest are zero)
     const int row_max = cols * in_limbs, ncols = cols * g.bsz;
@@ -135,8 +141,8 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
         const bool from_lut = ACC32 && blk0 == 0;  // the accumulator is still X^b * LUT in global memory
         // ---- pack + twist: X[ct][r][j] = (acc[r][j] + i acc[r][j+m]) * exp(2 pi i j / 4m),  r = limb*cols + col (:319-320)
         if (!(g.dbg_skip & 8))
-        for (int job = tidv; job < CT * row_max * m; job += NT) {
-            const int j = job % m, r = (job / m) % row_max, ct = job / (m * row_max);
+        for (int pr = tidv >> lm; pr < CT * row_max; pr += NT >> lm) {  // (ciphertext, row) pairs; j = tid mod m is fixed
+            const int j = tidv & (m - 1), ct = (CT == 2 && pr >= row_max) ? 1 : 0, r = pr - ct * row_max;
             const acc_t* a = acc + ((long long)ct * ct_polys + r) * n;
             const cplx z = from_lut ? make_double2((double)lut_rot(ct, r / cols, r % cols, j), (double)lut_rot(ct, r / cols, r % cols, j + m))
                                     : make_double2((double)a[j], (double)a[j + m]);
@@ -149,9 +155,9 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
         for (int ct = 0; ct < (row_max == P ? 1 : CT); ++ct) {
             cplx* buf = X + ct * P * mp;
             const int np = row_max == P ? CT * P : row_max;
-            br_pass<R0, false, 2, NT>(buf, np, mp, m, 1, W, tidv);
-            br_pass<8, false, JM8, NT>(buf, np, mp, m, R0, W, tidv);
-            br_pass<8, false, JM8, NT>(buf, np, mp, m, R0 * 8, W, tidv);
+            br_pass<R0, false, 2, NT>(buf, np, mp, m, lm, 1, W, tidv);
+            br_pass<8, false, JM8, NT>(buf, np, mp, m, lm, R0, W, tidv);
+            br_pass<8, false, JM8, NT>(buf, np, mp, m, lm, R0 * 8, W, tidv);
         }
         // ---- product, in place: X[ct][c][q] = sum_i (DFT(X^a_i)[q] - 1) * sum_r X[ct][r][q] * BRK_i[r][c][q]   (:321-337)
         if (!(g.dbg_skip & 2)) {
@@ -162,7 +168,7 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
                 if (job < njobs_prod) {
                     // m is a multiple of 64, so a wave has one column group: keep it (and every key row pointer) in SGPRs,
                     // the loads then need one VGPR offset instead of a 64-bit VGPR pointer each
-                    const int q = job % m, cg = __builtin_amdgcn_readfirstlane(job / m);
+                    const int q = job & (m - 1), cg = __builtin_amdgcn_readfirstlane(job >> lm);
                     // input points of this frequency: in registers for the whole block, or (ALDS: two ciphertexts with more than
                     // 4 rows, where registers would spill) re-read from LDS at each use
                     constexpr bool ALDS = CT == 2 && MAXR > 4;
@@ -228,7 +234,7 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
             for (int pj = 0; pj < PJ; ++pj) {
                 const int job = tidv + pj * NT;
                 if (job < njobs_prod) {
-                    const int q = job % m, cg = job / m;
+                    const int q = job & (m - 1), cg = job >> lm;
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -245,15 +251,15 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
         for (int ct = 0; ct < (ncols == P ? 1 : CT); ++ct) {
             cplx* buf = X + ct * P * mp;
             const int np = ncols == P ? CT * P : ncols;
-            br_pass<R0, true, 2, NT>(buf, np, mp, m, 1, W, tidv);
-            br_pass<8, true, JM8, NT>(buf, np, mp, m, R0, W, tidv);
-            br_pass<8, true, JM8, NT>(buf, np, mp, m, R0 * 8, W, tidv);
+            br_pass<R0, true, 2, NT>(buf, np, mp, m, lm, 1, W, tidv);
+            br_pass<8, true, JM8, NT>(buf, np, mp, m, lm, R0, W, tidv);
+            br_pass<8, true, JM8, NT>(buf, np, mp, m, lm, R0 * 8, W, tidv);
         }
         // ---- untwist, round(x/m), + acc, carry chain from the last limb to limb 0 (:342-346); thread = (ct, column, j < m):
         //      coefficients j and j+m.  Same digit/carry arithmetic as the fused tail (device_fft.hpp, PZ_TAIL_COEFFS).
         if (!(g.dbg_skip & 4))
-        for (int job = tidv; job < CT * cols * m; job += NT) {
-            const int j = job % m, col = (job / m) % cols, ct = job / (m * cols);
+        for (int pc = tidv >> lm; pc < CT * cols; pc += NT >> lm) {  // (ciphertext, column) pairs; j = tid mod m is fixed
+            const int j = tidv & (m - 1), ct = (CT == 2 && pc >= cols) ? 1 : 0, col = pc - ct * cols;
             const cplx tw = tw_j;
             long long cy[2] = {0, 0};
             for (int limb = g.bsz - 1; limb >= 0; --limb) {
