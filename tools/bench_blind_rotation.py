@@ -31,9 +31,12 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--cpu-cts", type=int, default=2)
+    ap.add_argument("--with-keyswitch", action="store_true",
+                    help="also time blind rotation + GLWE key switch of the result (the two heavy steps of a gate bootstrap, "
+                         "BASELINE configs[3]); rank-1 shapes only")
     args = ap.parse_args()
     import torch
-    from poulpy_amd.hal import BlindRotationParams, Module
+    from poulpy_amd.hal import BlindRotationParams, GlweOpParams, Module
     s = SHAPES[args.shape]
     n, cols = s["n"], s["rank"] + 1
     dev = torch.device("cuda", 0)
@@ -68,8 +71,34 @@ def main():
     mod.sync()
     kstats = {k: (v[0], round(v[1], 3)) for k, v in mod.kernel_stats().items() if v[0]}
     mod.set_kernel_timing(False)
+    ks_stats = None
+    if args.with_keyswitch and s["rank"] == 1:
+        # key-switching key: GGLWE rows = dnum, cols_in = 1, cols_out = 2, same size / base2k as the accumulator
+        ksz = s["res_size"]
+        kmat = torch.randint(-half, half, (n * ksz * 1 * cols * ksz,), dtype=torch.int64, device=dev, generator=g)
+        kpm = torch.empty(kmat.numel(), dtype=torch.float64, device=dev)
+        mod._ck(mod.lib.pz_vmp_prepare(mod.handle, C.c_void_p(kpm.data_ptr()), C.c_void_p(kmat.data_ptr()), C.c_size_t(ksz), C.c_size_t(1),
+                                       C.c_size_t(cols), C.c_size_t(ksz)))
+        kp = GlweOpParams(rank=1, dnum=ksz, dsize=1, key_size=ksz, key_base2k=s["base2k"], a_size=ksz, a_base2k=s["base2k"],
+                          res_size=ksz, res_base2k=s["base2k"], rank_out=1)
+        res2 = torch.empty_like(res)
+        mod.sync()
+
+        def bootstrap():
+            mod.blind_rotation_execute_batched(ptr(res), ptr(lwe), ptr(lut), ptr(brk), p, args.batch)
+            mod.glwe_keyswitch_batched(ptr(res2), ptr(res), ptr(kpm), kp, args.batch)
+        bootstrap()
+        mod.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            bootstrap()
+        mod.sync()
+        dtb = (time.perf_counter() - t0) / args.reps
+        ks_stats = {"blind_rotation_plus_keyswitch_per_s": args.batch / dtb, "ms_per_batch": dtb * 1e3}
     out = {"metric": "CGGI blind rotations/s", "shape": args.shape, **s, "batch": args.batch, "value": args.batch / dt,
            "ms_per_batch": dt * 1e3, "kernel_classes_launches_ms": kstats, "digits_balanced": bool((res.min() >= -half).item() and (res.max() < half).item())}
+    if ks_stats:
+        out["gate_bootstrap_heavy_steps"] = ks_stats
     # CPU port beside it (single thread) on a few of the same ciphertexts, and parity on those
     if args.cpu_cts:
         from oracle.ref import RefModule
