@@ -364,7 +364,7 @@ static int dev_vmp(pz_module* M, int batch, DV res, DV a, const double* pmat, in
     const int off = limb_offset * cols_out;
     const int ncomp = off < ncols ? std::min(res_polys, ncols - off) : 0;
     if (res_polys == 0) return PZ_OK;
-    if (ncomp == 0) {
+    if (ncomp == 0 || row_max == 0) {  // nothing to read from the key, or an empty input (a.size = 0: dsize > a.size): the sum is empty
         return launch_ew(M, EW_ZERO, res.p, res.bs, (long long)M->n, nullptr, 0, 0, nullptr, 0, 0, res_polys, batch);
     }
     const int m = (int)M->m;

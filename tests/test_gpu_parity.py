@@ -597,3 +597,61 @@ def test_config4_shape_blind_rotation(mods, n, block_size):
     ref, hip = mods(n)
     got, want = _run_blind_rotation(hip, ref, n, 1, 28, block_size, 2, 2, 2, 17, batch=9, seed=n + block_size)
     assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------
+# seeded shape sweep over the batched entry points (every plan family, fused and five-kernel paths)
+# ------------------------------------------------------------------------------------------
+def test_seeded_shape_sweep(mods):
+    """40 random shapes (fixed seed): N in 2^9..2^16, rank 1-2, 1-8 limbs for input / key / output, dnum, dsize 1-2, same or
+    different base2k, ragged batches, external product / key switch / automorphism family, against the oracle, bit-exact."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("POULPY_SWEEP_SEED", "20260101")))   # other seeds / longer sweeps by hand
+    for case in range(int(os.environ.get("POULPY_SWEEP_CASES", "40"))):
+        n = int(2 ** rng.integers(9, 17))
+        rank = int(rng.integers(1, 3))
+        a_size, key_size, res_size = (int(x) for x in rng.integers(1, 9 if n < 65536 else 7, 3))
+        dsize = int(rng.integers(1, 3))
+        dnum = int(rng.integers(1, max(2, (a_size + dsize - 1) // dsize + 1)))
+        same = bool(rng.integers(0, 3))                      # two thirds same base (the fused pipeline), one third mixed
+        key_b = int(rng.integers(10, 15))
+        a_b, res_b = (key_b, key_b) if same else (int(rng.integers(9, 18)), int(rng.integers(9, 18)))
+        batch = int(rng.integers(1, 12)) if n >= 16384 else int(rng.integers(1, 40))
+        kind = int(rng.integers(0, 4))
+        ref, hip = mods(n)
+        seed = 7000 + case
+        if os.environ.get("POULPY_SWEEP_VERBOSE"):
+            print(dict(case=case, n=n, rank=rank, a_size=a_size, key_size=key_size, res_size=res_size, dsize=dsize, dnum=dnum, a_b=a_b,
+                       key_b=key_b, res_b=res_b, batch=batch, kind=kind), flush=True)
+        if kind == 0:
+            got, want = _run_glwe_op(hip, ref, False, n, rank, rank, a_size, a_b, key_size, key_b, dnum, dsize, res_size, res_b, batch, seed)
+        elif kind == 1:
+            rank_out = int(rng.integers(1, 3))
+            got, want = _run_glwe_op(hip, ref, True, n, rank, rank_out, a_size, a_b, key_size, key_b, dnum, dsize, res_size, res_b, batch, seed)
+        else:
+            mode = ["automorphism", "add", "sub", "sub_negate"][int(rng.integers(0, 4))]
+            gal = int(rng.choice([-5, 5, 25, 2 * n - 1, 3]))
+            got, want = _run_glwe_op(hip, ref, True, n, rank, rank, a_size, a_b, key_size, key_b, dnum, dsize, res_size, res_b, batch, seed,
+                                     auto=(gal, mode))
+        assert np.array_equal(got, want), dict(case=case, n=n, rank=rank, a_size=a_size, key_size=key_size, res_size=res_size, dsize=dsize,
+                                               dnum=dnum, a_b=a_b, key_b=key_b, res_b=res_b, batch=batch, kind=kind)
+
+
+def test_seeded_blind_rotation_sweep(mods):
+    """25 random blind-rotation shapes (fixed seed): N 2^8..2^11, rank 1-3, block size 1-5, 1-3 limbs for key / accumulator / LUT,
+    dnum 1-3, ragged batches: the one-kernel path where it applies (N <= 1024 and the shape fits LDS), the composed path elsewhere."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("POULPY_SWEEP_SEED", "77")))
+    for case in range(int(os.environ.get("POULPY_SWEEP_CASES", "25"))):
+        n = int(2 ** rng.integers(8, 12))
+        rank = int(rng.integers(1, 4))
+        blk = int(rng.integers(1, 6))
+        n_lwe = int(rng.integers(1, 4)) * blk + int(rng.integers(0, blk))   # usually a trailing partial block
+        dnum, bsz, rsz = (int(x) for x in rng.integers(1, 4, 3))
+        k = int(rng.integers(10, 16))
+        batch = int(rng.integers(1, 8))
+        ref, hip = mods(n)
+        if os.environ.get("POULPY_SWEEP_VERBOSE"):
+            print(dict(case=case, n=n, rank=rank, blk=blk, n_lwe=n_lwe, dnum=dnum, bsz=bsz, rsz=rsz, k=k, batch=batch), flush=True)
+        got, want = _run_blind_rotation(hip, ref, n, rank, n_lwe, blk, dnum, bsz, rsz, k, batch=batch, seed=9000 + case)
+        assert np.array_equal(got, want), dict(case=case, n=n, rank=rank, blk=blk, n_lwe=n_lwe, dnum=dnum, bsz=bsz, rsz=rsz, k=k, batch=batch)
