@@ -997,7 +997,8 @@ void pzr_vmp_prepare(const pzr_tables* t, double* pmat, const int64_t* mat,
 
 /* vmp.rs:186-264 (OVERWRITE = true).  NOTE: for limb_offset > 0 the reference
  * leaves res columns [col_max - limb_offset, col_max) unwritten;
- * that is restated literally here. */
+ * that is restated literally here; pzr_vmp_apply_dft_to_dft builds the NTT120
+ * semantics the build follows on top of it. */
 static void vmp_apply_core(size_t n, double* res, size_t res_polys, const double* a, size_t a_polys,
                            const double* pmat, size_t limb_offset, size_t nrows, size_t ncols) {
     size_t m = n >> 1;
@@ -1048,7 +1049,20 @@ void pzr_vmp_apply_dft_to_dft(size_t n,
                               size_t limb_offset) {
     size_t nrows = cols_in * rows;
     size_t ncols = cols_out * size;
-    vmp_apply_core(n, res, res_cols * res_size, a, a_cols * a_size, pmat, limb_offset * cols_out, nrows, ncols);
+    size_t res_polys = res_cols * res_size, off = limb_offset * cols_out;
+    if (off == 0) {
+        vmp_apply_core(n, res, res_polys, a, a_cols * a_size, pmat, 0, nrows, ncols);
+        return;
+    }
+    /* limb_offset > 0: the FFT64 core clamps the key columns it reads to res_polys and leaves the last `off` of them
+     * unwritten, while its NTT120 sibling (reference/ntt120/vmp.rs:190,281-287) reads key columns up to res_polys + off and
+     * zeroes the rest.  SURVEY.md A.2 resolves this in favour of the NTT120 (evidently intended, deterministic) semantics:
+     *   res[c] = sum_r a[r] * P[r][c + off] for c < min(res_polys, ncols - off), zero beyond.
+     * Obtained from the literal core by running it on a zeroed result that is `off` polynomials longer. */
+    double* tmp = (double*)calloc((res_polys + off) * n, sizeof(double));
+    vmp_apply_core(n, tmp, res_polys + off, a, a_cols * a_size, pmat, off, nrows, ncols);
+    memcpy(res, tmp, res_polys * n * sizeof(double));
+    free(tmp);
 }
 
 /* vmp.rs:100-130 (hal_impl/family_common.rs:17-54 is the same glue) */

@@ -299,7 +299,7 @@ def _run_glwe_op(hip, ref, ks, n, rank, rank_out, a_size, a_base2k, key_size, ke
 
 @pytest.mark.parametrize("fuse", [(True, True), (False, False)], ids=["fused", "unfused"])
 @pytest.mark.parametrize("rank", [1, 2])
-@pytest.mark.parametrize("dsize", [1, 2, 3])
+@pytest.mark.parametrize("dsize", [1, 2, 3, 4])
 def test_glwe_external_product_batched(mods, rank, dsize, fuse):
     """poulpy-core/src/test_suite/external_product/glwe_ct.rs sweeps rank in {1,2}, dsize 1..max and
     different base2k for input / key / output; here against the oracle's restatement, bit-exact."""
@@ -655,3 +655,51 @@ def test_seeded_blind_rotation_sweep(mods):
             print(dict(case=case, n=n, rank=rank, blk=blk, n_lwe=n_lwe, dnum=dnum, bsz=bsz, rsz=rsz, k=k, batch=batch), flush=True)
         got, want = _run_blind_rotation(hip, ref, n, rank, n_lwe, blk, dnum, bsz, rsz, k, batch=batch, seed=9000 + case)
         assert np.array_equal(got, want), dict(case=case, n=n, rank=rank, blk=blk, n_lwe=n_lwe, dnum=dnum, bsz=bsz, rsz=rsz, k=k, batch=batch)
+
+
+def test_seeded_per_op_sweep(mods):
+    """60 random shapes (fixed seed) through the per-op ABI: vec_znx_dft_apply with any (step, offset) incl. out of range,
+    vmp_apply_dft_to_dft with more / fewer rows than input limbs and any limb_offset incl. >= size, idft into smaller / larger
+    outputs, cross-base normalize with offsets; N 2^5..2^13 (every plan family)."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("POULPY_SWEEP_SEED", "4242")))
+    for case in range(int(os.environ.get("POULPY_SWEEP_CASES", "60"))):
+        n = int(2 ** rng.integers(5, 14))
+        ref, hip = mods(n)
+        cols_in, cols_out = (int(x) for x in rng.integers(1, 4, 2))
+        a_size, rows, size, res_size = (int(x) for x in rng.integers(1, 7, 4))
+        step, offset = int(rng.integers(1, 4)), int(rng.integers(0, 8))
+        limb_offset = int(rng.integers(0, size + 2))
+        k = int(rng.integers(9, 16))
+        desc = dict(case=case, n=n, cols_in=cols_in, cols_out=cols_out, a_size=a_size, rows=rows, size=size, res_size=res_size, step=step,
+                    offset=offset, limb_offset=limb_offset, k=k)
+        if os.environ.get("POULPY_SWEEP_VERBOSE"):
+            print(desc, flush=True)
+        a = VecZnx(n, cols_in, a_size).fill_uniform(k, rng)
+        mat = MatZnx(n, rows, cols_in, cols_out, size).fill_uniform(k, rng)
+        d_size = int(rng.integers(1, 7))
+        outs = []
+        for mod in (ref, hip):
+            ad = mod.vec_znx_dft_alloc(cols_in, d_size)
+            ad.data[...] = 0.0                                   # limbs the (step, offset) selection leaves untouched must agree
+            for j in range(cols_in):
+                mod.vec_znx_dft_apply(step, offset, ad, j, a, j)
+            pm = mod.vmp_pmat_alloc(rows, cols_in, cols_out, size)
+            mod.vmp_prepare(pm, mat)
+            rd = mod.vec_znx_dft_alloc(cols_out, res_size)
+            rd.data[...] = 0.0                                   # zero-tail semantics are only claimed on a zeroed result (SURVEY.md A.2)
+            mod.vmp_apply_dft_to_dft(rd, ad, pm, limb_offset)
+            big = VecZnxBig(n, cols_out, int(rng.integers(1, 7)) if mod is ref else outs[0][1])
+            big_size = big.size
+            big.data[...] = 13
+            for c in range(cols_out):
+                mod.vec_znx_idft_apply(big, c, rd, c)
+            res_k = int(rng.integers(9, 20)) if mod is ref else outs[0][2]
+            off = int(rng.integers(-k, k + 1)) if mod is ref else outs[0][3]
+            res = VecZnx(n, cols_out, int(rng.integers(1, 7)) if mod is ref else outs[0][4])
+            res.data[...] = -9
+            for c in range(cols_out):
+                mod.vec_znx_big_normalize(res, res_k, off, c, big, k, c)
+            outs.append((res.data.copy(), big_size, res_k, off, res.size, big.data.copy()))
+        assert np.array_equal(outs[0][5], outs[1][5]), ("big", desc)
+        assert np.array_equal(outs[0][0], outs[1][0]), ("normalized", desc)

@@ -156,7 +156,7 @@ def test_dft_apply_step_offset_semantics():
                     assert np.array_equal(single.data[0], d.data[j])
 
 
-@pytest.mark.parametrize("dsize", [1, 2, 3])
+@pytest.mark.parametrize("dsize", [1, 2, 3, 4, 5])
 def test_external_product_and_keyswitch_match_exact(dsize):
     """poulpy-core glue restated in the oracle (external_product/glwe.rs, keyswitching/glwe.rs) vs the
     exact bivariate product + big-int normalize, incl. dsize > 1 folding (zero-tail semantics)."""
