@@ -664,7 +664,7 @@ def test_seeded_per_op_sweep(mods):
     import os
     rng = np.random.default_rng(int(os.environ.get("POULPY_SWEEP_SEED", "4242")))
     for case in range(int(os.environ.get("POULPY_SWEEP_CASES", "60"))):
-        n = int(2 ** rng.integers(5, 14))
+        n = int(2 ** rng.integers(5, int(os.environ.get("POULPY_SWEEP_MAXLOGN", "13")) + 1))
         ref, hip = mods(n)
         cols_in, cols_out = (int(x) for x in rng.integers(1, 4, 2))
         a_size, rows, size, res_size = (int(x) for x in rng.integers(1, 7, 4))
@@ -703,3 +703,73 @@ def test_seeded_per_op_sweep(mods):
             outs.append((res.data.copy(), big_size, res_k, off, res.size, big.data.copy()))
         assert np.array_equal(outs[0][5], outs[1][5]), ("big", desc)
         assert np.array_equal(outs[0][0], outs[1][0]), ("normalized", desc)
+
+
+def test_seeded_svp_and_elementwise_sweep(mods):
+    """50 random shapes (fixed seed) through svp_prepare / svp_apply_dft / _dft_to_dft / _assign, the limb-wise DFT-domain family
+    (add_into, sub, add_assign, sub_assign, sub_negate_assign, add_scaled_assign, copy with (step, offset), zero), idft_tmpa,
+    big_add_small_assign and the automorphism ops, with ragged sizes; compared after idft + normalize."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("POULPY_SWEEP_SEED", "909")))
+    for case in range(int(os.environ.get("POULPY_SWEEP_CASES", "50"))):
+        n = int(2 ** rng.integers(5, 13))
+        ref, hip = mods(n)
+        cols = int(rng.integers(1, 4))
+        sa, sb, sr = (int(x) for x in rng.integers(1, 6, 3))
+        k = int(rng.integers(9, 15))
+        step, offset, scale = int(rng.integers(1, 4)), int(rng.integers(0, 6)), int(rng.integers(-3, 4))
+        gal = int(rng.choice([-5, 5, 3, 2 * n - 1, 25]))
+        op = int(rng.integers(0, 8))
+        ca, cb, cr = (int(x) for x in rng.integers(0, cols, 3))
+        desc = dict(case=case, n=n, cols=cols, sa=sa, sb=sb, sr=sr, k=k, step=step, offset=offset, scale=scale, gal=gal, op=op, ca=ca, cb=cb, cr=cr)
+        if os.environ.get("POULPY_SWEEP_VERBOSE"):
+            print(desc, flush=True)
+        a = VecZnx(n, cols, sa).fill_uniform(k, rng)
+        b = VecZnx(n, cols, sb).fill_uniform(k, rng)
+        sc = ScalarZnx(n, cols).fill_uniform(k, rng)
+        r0 = rng.standard_normal((sr, cols, n)) * 1e3
+        outs = []
+        for mod in (ref, hip):
+            da, db, dr = mod.vec_znx_dft_alloc(cols, sa), mod.vec_znx_dft_alloc(cols, sb), mod.vec_znx_dft_alloc(cols, sr)
+            for c in range(cols):
+                mod.vec_znx_dft_apply(1, 0, da, c, a, c)
+                mod.vec_znx_dft_apply(1, 0, db, c, b, c)
+                mod.vec_znx_dft_apply(1, 0, dr, c, VecZnx(n, cols, sr, np.ascontiguousarray(np.rint(r0).astype(np.int64))), c)
+            pp = SvpPPol(n, cols)
+            for c in range(cols):
+                mod.svp_prepare(pp, c, sc, c)
+            if op == 0:
+                mod.vec_znx_dft_add_into(dr, cr, da, ca, db, cb)
+            elif op == 1:
+                mod.vec_znx_dft_sub(dr, cr, da, ca, db, cb)
+            elif op == 2:
+                mod.vec_znx_dft_add_assign(dr, cr, da, ca)
+                mod.vec_znx_dft_sub_assign(dr, cr, db, cb)
+            elif op == 3:
+                mod.vec_znx_dft_sub_negate_assign(dr, cr, da, ca)
+                mod.vec_znx_dft_add_scaled_assign(dr, cr, db, cb, scale)
+            elif op == 4:
+                mod.vec_znx_dft_copy(step, offset, dr, cr, da, ca)
+            elif op == 5:
+                mod.svp_apply_dft(dr, cr, pp, ca, b, cb)
+                mod.svp_apply_dft_to_dft_assign(dr, cr, pp, cb)
+            elif op == 6:
+                mod.svp_apply_dft_to_dft(dr, cr, pp, ca, db, cb)
+                mod.vec_znx_dft_zero(dr, (cr + 1) % cols)
+            else:
+                mod.vec_znx_dft_add_assign(dr, cr, da, ca)
+            big = VecZnxBig(n, cols, sr)
+            big.data[...] = 3
+            for c in range(cols):
+                mod.vec_znx_idft_apply_tmpa(big, c, dr, c)
+            mod.vec_znx_big_add_small_assign(big, cr, a, ca)
+            mod.vec_znx_big_automorphism_assign(gal, big, cr)
+            res = VecZnx(n, cols, sr + 1)
+            res.data[...] = -1
+            for c in range(cols):
+                mod.vec_znx_big_normalize(res, k, 0, c, big, k, c)
+            rot = VecZnx(n, cols, sb)
+            mod.vec_znx_automorphism(gal, rot, cb, res, cr)
+            outs.append((res.data.copy(), rot.data.copy()))
+        assert np.array_equal(outs[0][0], outs[1][0]), desc
+        assert np.array_equal(outs[0][1], outs[1][1]), desc
