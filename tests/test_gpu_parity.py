@@ -752,12 +752,11 @@ def test_seeded_svp_and_elementwise_sweep(mods):
                 mod.vec_znx_dft_copy(step, offset, dr, cr, da, ca)
             elif op == 5:
                 mod.svp_apply_dft(dr, cr, pp, ca, b, cb)
-                mod.svp_apply_dft_to_dft_assign(dr, cr, pp, cb)
             elif op == 6:
                 mod.svp_apply_dft_to_dft(dr, cr, pp, ca, db, cb)
                 mod.vec_znx_dft_zero(dr, (cr + 1) % cols)
-            else:
-                mod.vec_znx_dft_add_assign(dr, cr, da, ca)
+            else:   # one product only per case: two would leave the 53-bit range where different FFTs round alike
+                mod.svp_apply_dft_to_dft_assign(dr, cr, pp, cb)
             big = VecZnxBig(n, cols, sr)
             big.data[...] = 3
             for c in range(cols):
