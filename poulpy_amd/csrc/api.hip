@@ -521,7 +521,7 @@ void pz_module_free(pz_module* M) {
     for (void* p : {(void*)M->tw1, (void*)M->tw1inv, (void*)M->wL1, (void*)M->wL2, (void*)M->tw12, (void*)M->tw12t, (void*)M->w2n, M->ws, M->ws2, (void*)M->margin})
         if (p) (void)hipFree(p);
     for (auto& c : M->arena) (void)hipFree(c.p);
-    for (auto& k : M->pinned) (void)hipFree(k.sliced);
+    for (auto& k : M->pinned) if (k.sliced) (void)hipFree(k.sliced);
     for (auto& t : M->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
     for (auto e : M->event_pool) (void)hipEventDestroy(e);
     if (M->stream) (void)hipStreamDestroy(M->stream);
@@ -554,7 +554,10 @@ int pz_module_pin_key(pz_module* M, const double* pmat, size_t rows, size_t cols
     PZ_REQUIRE(is_device_ptr(pmat), "pz_module_pin_key takes a device pointer");
     PZ_REQUIRE(rows >= 1 && cols_in >= 1 && cols_out >= 1 && size >= 1, "pz_module_pin_key: empty shape");
     for (auto& k : M->pinned) PZ_REQUIRE(k.key != (const void*)pmat, "pz_module_pin_key: key already pinned");
-    if (!(M->plan.m2 == 256 || M->plan.m2 == 128) || (M->plan.m1 % 16) != 0) return PZ_OK;  // no fused pipeline at this N: nothing to cache
+    if (!(M->plan.m2 == 256 || M->plan.m2 == 128) || (M->plan.m1 % 16) != 0) {  // no fused pipeline at this N: nothing to cache,
+        M->pinned.push_back({(const void*)pmat, nullptr, 0});                      // but the pin is remembered so that unpin succeeds
+        return PZ_OK;
+    }
     const size_t npolys = rows * cols_in * cols_out * size;
     const size_t bytes = npolys * (size_t)M->n * 8;
     cplx* sliced = nullptr;
@@ -569,7 +572,7 @@ int pz_module_unpin_key(pz_module* M, const double* pmat) {
     for (size_t i = 0; i < M->pinned.size(); ++i)
         if (M->pinned[i].key == (const void*)pmat) {
             PZ_HIP(hipStreamSynchronize(M->stream));
-            (void)hipFree(M->pinned[i].sliced);
+            if (M->pinned[i].sliced) (void)hipFree(M->pinned[i].sliced);
             M->pinned.erase(M->pinned.begin() + (long)i);
             return PZ_OK;
         }
@@ -1347,7 +1350,7 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
         // traffic at the metric shape, ~4 % of a 128-ciphertext call) so that no stale copy can ever be used
         bool pinned = false;
         for (auto& pk : M->pinned)
-            if (pk.key == (const void*)pmat && pk.bytes == (size_t)nrows * ncols * (size_t)M->n * 8) { Pp = pk.sliced; pinned = true; }
+            if (pk.key == (const void*)pmat && pk.sliced && pk.bytes == (size_t)nrows * ncols * (size_t)M->n * 8) { Pp = pk.sliced; pinned = true; }
         if (!pinned && (M->dbg_stages & 2)) PZ_TRY(launch_permute_pmat(M, pmat, Pp, nrows * ncols));
         for (size_t b0 = 0; b0 < batch; b0 += chunk) {
             const int nb = (int)std::min(chunk, batch - b0);

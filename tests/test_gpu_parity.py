@@ -618,23 +618,27 @@ def test_seeded_shape_sweep(mods):
         a_b, res_b = (key_b, key_b) if same else (int(rng.integers(9, 18)), int(rng.integers(9, 18)))
         batch = int(rng.integers(1, 12)) if n >= 16384 else int(rng.integers(1, 40))
         kind = int(rng.integers(0, 4))
+        chunk = int(rng.integers(0, batch + 1)) if rng.integers(0, 2) else 0     # waves of `chunk` ciphertexts, or one wave
+        fuse = (True, True) if rng.integers(0, 4) else (False, False)             # a quarter on the five-kernel path
         ref, hip = mods(n)
         seed = 7000 + case
         if os.environ.get("POULPY_SWEEP_VERBOSE"):
             print(dict(case=case, n=n, rank=rank, a_size=a_size, key_size=key_size, res_size=res_size, dsize=dsize, dnum=dnum, a_b=a_b,
                        key_b=key_b, res_b=res_b, batch=batch, kind=kind), flush=True)
         if kind == 0:
-            got, want = _run_glwe_op(hip, ref, False, n, rank, rank, a_size, a_b, key_size, key_b, dnum, dsize, res_size, res_b, batch, seed)
+            got, want = _run_glwe_op(hip, ref, False, n, rank, rank, a_size, a_b, key_size, key_b, dnum, dsize, res_size, res_b, batch, seed,
+                                     chunk=chunk, fuse=fuse, pin=bool(rng.integers(0, 2)))
         elif kind == 1:
             rank_out = int(rng.integers(1, 3))
-            got, want = _run_glwe_op(hip, ref, True, n, rank, rank_out, a_size, a_b, key_size, key_b, dnum, dsize, res_size, res_b, batch, seed)
+            got, want = _run_glwe_op(hip, ref, True, n, rank, rank_out, a_size, a_b, key_size, key_b, dnum, dsize, res_size, res_b, batch, seed,
+                                     chunk=chunk, fuse=fuse)
         else:
             mode = ["automorphism", "add", "sub", "sub_negate"][int(rng.integers(0, 4))]
             gal = int(rng.choice([-5, 5, 25, 2 * n - 1, 3]))
             got, want = _run_glwe_op(hip, ref, True, n, rank, rank, a_size, a_b, key_size, key_b, dnum, dsize, res_size, res_b, batch, seed,
-                                     auto=(gal, mode))
+                                     chunk=chunk, fuse=fuse, auto=(gal, mode))
         assert np.array_equal(got, want), dict(case=case, n=n, rank=rank, a_size=a_size, key_size=key_size, res_size=res_size, dsize=dsize,
-                                               dnum=dnum, a_b=a_b, key_b=key_b, res_b=res_b, batch=batch, kind=kind)
+                                               dnum=dnum, a_b=a_b, key_b=key_b, res_b=res_b, batch=batch, kind=kind, chunk=chunk, fuse=fuse)
 
 
 def test_seeded_blind_rotation_sweep(mods):
