@@ -181,7 +181,8 @@ static int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, i
 }
 
 static bool mid_supported(const pz_module* M, int npi, int npo) {
-    return (M->plan.m2 == 256 || M->plan.m2 == 128) && (M->plan.m1 % 16) == 0 && npi >= 1 && npi <= 16 && npo >= 1 && npo <= 16;
+    const int np_max = M->plan.m2 == 128 ? 32 : 16;  // 128-point rows: up to 32 polynomial slots (two ciphertexts per tile)
+    return (M->plan.m2 == 256 || M->plan.m2 == 128) && (M->plan.m1 % 16) == 0 && npi >= 1 && npi <= np_max && npo >= 1 && npo <= np_max;
 }
 static int launch_permute_pmat(pz_module* M, const double* P, cplx* Pp, int npolys) {
     const FftPlan& pl = M->plan;
@@ -233,6 +234,13 @@ static int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cp
             const size_t lds = ((size_t)CT * 8 * 16 * 9 + 256) * sizeof(cplx);
             PZ_TRY(set_lds((k_mid128<CT, 8>), lds));
             hipLaunchKernelGGL((k_mid128<CT, 8>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(512), lds, M->stream, g);
+        } else if (npi > 16 || npo > 16) {
+            // 17..32 polynomials in or out (rank 2-3 with 8 limbs, rank 1 with 16 limbs): 2 ciphertexts x 32 slots per tile
+            constexpr int CT = 2;
+            g.n_ct = (batch + CT - 1) / CT;
+            const size_t lds = ((size_t)CT * 32 * 16 * 9 + 256) * sizeof(cplx);
+            PZ_TRY(set_lds((k_mid128<CT, 32>), lds));
+            hipLaunchKernelGGL((k_mid128<CT, 32>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(512), lds, M->stream, g);
         } else {
             constexpr int CT = 4;
             g.n_ct = (batch + CT - 1) / CT;

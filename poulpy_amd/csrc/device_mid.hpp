@@ -268,16 +268,16 @@ k_mid(MidArgs g) {
 // (device_fft.hpp, SPLIT).  POULPY_DBG_SPLIT=t selects the 128 x 256 split (k_mid<2>) instead.  (Two ciphertexts per tile
 // with two workgroups per CU was no faster: DESIGN.md.)
 // =================================================================================
-// NP = polynomial slots per ciphertext (16, or 8 for shapes with <= 8 polynomials in and out such as rank 1 with 4 limbs:
-// twice the ciphertexts per tile and per key fetch).  The 4 thread groups of the product phase split into GC column groups x GT
-// ciphertext groups so that a thread always owns 4 ciphertexts x 4 outputs.
+// NP = polynomial slots per ciphertext: 16; 8 for shapes with <= 8 polynomials in and out such as rank 1 with 4 limbs (twice the
+// ciphertexts per tile and per key fetch); 32 for rank 2-3 or 16 limbs (two ciphertexts per tile).  The 4 thread groups of the product phase split into GC column groups x GT
+// ciphertext groups so that a thread always owns 16 accumulators (4 ciphertexts x 4 outputs, or 2 x 8).
 template <int CT, int NP = 16>
 __global__ void __launch_bounds__(CT * NP * 8)
 k_mid128(MidArgs g) {
     constexpr int M2 = 128;
     constexpr int NT = CT * NP * 8;
     constexpr int NCG = NT / M2;       // thread groups in the product phase
-    constexpr int NC = 4;              // outputs per thread
+    constexpr int NC = NP == 32 ? 8 : 4;  // outputs per thread (NP = 32: two ciphertexts x 8 outputs, as in k_mid<2>)
     constexpr int GC = NP / NC;        // column groups
     constexpr int GT = NCG / GC;       // ciphertext groups
     constexpr int CTt = CT / GT;       // ciphertexts per thread

@@ -377,6 +377,17 @@ def test_small_shapes_on_the_fused_pipeline(mods):
         assert np.array_equal(got, want), (n, size, "key switch")
 
 
+def test_large_shapes_on_the_fused_pipeline(mods):
+    """17..32 polynomials in or out select the 32-slot tile of the middle kernel (two ciphertexts per tile): rank 2 with 8 limbs
+    (24 polynomials), rank 1 with 16 limbs (BASELINE configs[4] shape: 32 output polynomials), rank 3 at N = 2^13."""
+    for (n, rank, size, dnum, batch) in ((65536, 2, 8, 8, 3), (65536, 1, 16, 16, 3), (8192, 3, 6, 4, 7), (16384, 1, 12, 5, 5)):
+        ref, hip = mods(n)
+        got, want = _run_glwe_op(hip, ref, False, n, rank, rank, size, 12, size, 12, dnum, 1, size, 12, batch=batch, seed=n + rank + size)
+        assert np.array_equal(got, want), (n, rank, size, "external product")
+        got, want = _run_glwe_op(hip, ref, True, n, rank, rank, size, 12, size, 12, dnum, 1, size - 1, 12, batch=batch, seed=n + rank + size + 1)
+        assert np.array_equal(got, want), (n, rank, size, "key switch")
+
+
 def test_config3_keyswitch_n65536(mods):
     """BASELINE configs[2]: GLWE key-switch via VmpPMat, N=2^16, 8 limbs (GGLWE rows=8, cols_in=1, cols_out=2)."""
     n = 65536
