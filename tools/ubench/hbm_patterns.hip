@@ -20,6 +20,12 @@ __global__ void __launch_bounds__(256) k_read(const cplx* __restrict__ a, double
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) { cplx v = a[i]; s += v.x + v.y; }
     if (s == 1.234e-300) out[0] = s;
 }
+__global__ void __launch_bounds__(256) k_write_nt(cplx* __restrict__ b, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        __builtin_nontemporal_store(1.0, &b[i].x);
+        __builtin_nontemporal_store(2.0, &b[i].y);
+    }
+}
 __global__ void __launch_bounds__(256) k_write(cplx* __restrict__ b, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) b[i] = make_double2(1.0, 2.0);
 }
@@ -52,6 +58,7 @@ int main() {
     time([&] { k_copy_nt<<<G, 256>>>(a, b, n); }, "linear copy, nontemporal stores", 2.0 * n * 16);
     time([&] { k_read<<<G, 256>>>(a, out, n); }, "read only", 1.0 * n * 16);
     time([&] { k_write<<<G, 256>>>(b, n); }, "write only", 1.0 * n * 16);
+    time([&] { k_write_nt<<<G, 256>>>(b, n); }, "write only, nontemporal", 1.0 * n * 16);
     time([&] { hipMemcpyAsync(b, a, n * 16, hipMemcpyDeviceToDevice, 0); }, "hipMemcpy D2D (R+W bytes)", 2.0 * n * 16);
     // matrices of 128 rows x 256 points (one polynomial of the tall plan): segment = 16 points (256 B), stride 4 KiB
     time([&] { k_seg<16><<<G, 256>>>(a, b, 128, 256, n / (128 * 256)); }, "256 B segments, stride 4 KiB (pass1/tail)", 2.0 * n * 16);
