@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--shape", choices=sorted(SHAPES), default="ref")
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--block-size", type=int, default=0, help="override the block size (1 = execute_standard)")
     ap.add_argument("--cpu-cts", type=int, default=2)
     ap.add_argument("--with-keyswitch", action="store_true",
                     help="also time blind rotation + GLWE key switch of the result (the two heavy steps of a gate bootstrap, "
@@ -37,7 +38,9 @@ def main():
     args = ap.parse_args()
     import torch
     from poulpy_amd.hal import BlindRotationParams, GlweOpParams, Module
-    s = SHAPES[args.shape]
+    s = dict(SHAPES[args.shape])
+    if args.block_size:
+        s["block_size"] = args.block_size
     n, cols = s["n"], s["rank"] + 1
     dev = torch.device("cuda", 0)
     mod = Module(n, device=0)
