@@ -787,3 +787,31 @@ def test_seeded_svp_and_elementwise_sweep(mods):
             outs.append((res.data.copy(), rot.data.copy()))
         assert np.array_equal(outs[0][0], outs[1][0]), desc
         assert np.array_equal(outs[0][1], outs[1][1]), desc
+
+
+def test_concurrent_callers_on_one_module(mods):
+    """poulpy-bin-fhe shares one &Module between scoped worker threads (bdd_arithmetic/eval.rs:210-221): concurrent calls on one
+    module with disjoint buffers must be safe (serialised internally) and every caller must get its own result."""
+    from concurrent.futures import ThreadPoolExecutor
+    n, cols, size, k = 2048, 2, 3, 14
+    ref, hip = mods(n)
+
+    def work(seed):
+        rng = seeded(seed)
+        a = VecZnx(n, cols, size).fill_uniform(k, rng)
+        s = ScalarZnx(n, cols).fill_uniform(k, rng)
+        outs = []
+        for mod in (ref, hip):
+            pp = SvpPPol(n, cols)
+            d = mod.vec_znx_dft_alloc(cols, size)
+            for c in range(cols):
+                mod.svp_prepare(pp, c, s, c)
+            for c in range(cols):
+                mod.svp_apply_dft(d, c, pp, c, a, c)
+            big = mod.vec_znx_idft_apply_consume(d)
+            outs.append(normalize_all(mod, big, k).data.copy())
+        return np.array_equal(outs[0], outs[1])
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        results = list(ex.map(work, range(300, 340)))
+    assert all(results)
