@@ -1570,16 +1570,18 @@ int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t*
         PZ_TRY(launch_rotate(M, B * nl, (const long long*)lut, sm, (long long*)res, dm, 0, nl, (const long long*)lwe_2n, lwe_bs, 0, 0));
     }
 
-    if (blk > 1) {
-        PZ_TRY(ensure_w2n(M));
+    PZ_TRY(ensure_w2n(M));
+    {
         // whole rotation in one kernel, accumulators resident in LDS (device_br.hpp), when the shape fits
+        // (std_variant: execute_standard, one ciphertext per workgroup and a second accumulator-sized array)
+        const bool std_variant = blk == 1;
         {
             const int in_limbs = std::min(dnum, rsz), row_max = cols * in_limbs, ncols = cols * bsz, P = std::max(row_max, ncols);
             const int m = (int)M->m, mp = m + (m >> 4);
             constexpr int NT = 512;
             const int r0 = m == 128 ? 2 : (m == 256 ? 4 : 8);
             auto lds_for = [&](int ct, bool a32) {
-                return ((size_t)m + (size_t)ct * P * mp) * sizeof(cplx) + (size_t)ct * rsz * cols * (size_t)n * (a32 ? 4 : 8);
+                return ((size_t)m + (size_t)ct * P * mp) * sizeof(cplx) + (size_t)ct * rsz * cols * (size_t)n * (a32 ? 4 : 8) * (std_variant ? 2 : 1);
             };
             auto fits = [&](int ct, bool a32) {
                 return lds_for(ct, a32) <= 160 * 1024 && ct * P * (m / 8) <= ((ct == 2 && r0 == 8) ? 2 : 1) * NT && ct * P * (m / r0) <= 2 * NT &&
@@ -1594,7 +1596,7 @@ int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t*
                 // with 32-bit digit accumulators (m = 128 is only built with one ciphertext per workgroup)
                 int ct = 1;
                 bool a32 = false;
-                if (force_ct != 1 && B >= 2 && m != 128) {
+                if (force_ct != 1 && B >= 2 && m != 128 && !std_variant) {
                     if (fits(2, false)) ct = 2;
                     else if (fits(2, true)) { ct = 2; a32 = true; }
                 }
@@ -1608,8 +1610,17 @@ int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t*
                 g.dbg_skip = br_skip;
                 KTimer kt(M, PZ_K_FUSED_MID);
                 bool launched = false;
+#define PZ_BR_STD(R0_, PJ_, MR_, CG_)                                                                                        \
+    if (!launched && std_variant && r0 == R0_ && pj == PJ_ && mr == MR_ && cgsz == CG_) {                                    \
+        PZ_TRY(set_lds((k_br_fused<R0_, 1, NT, PJ_, MR_, CG_, false, true>), lds));                                           \
+        hipLaunchKernelGGL((k_br_fused<R0_, 1, NT, PJ_, MR_, CG_, false, true>), dim3(B), dim3(NT), lds, M->stream, g);       \
+        launched = true;                                                                                                     \
+    }
+#define PZ_BR_STD_SHAPES(R0_)                                                                                                \
+    PZ_BR_STD(R0_, 1, 4, 4) PZ_BR_STD(R0_, 2, 4, 4) PZ_BR_STD(R0_, 1, 6, 3) PZ_BR_STD(R0_, 2, 6, 3)                          \
+    PZ_BR_STD(R0_, 1, 8, 4) PZ_BR_STD(R0_, 2, 8, 4) PZ_BR_STD(R0_, 1, 8, 3) PZ_BR_STD(R0_, 2, 8, 3)
 #define PZ_BR_ONE(R0_, CT_, PJ_, MR_, CG_, A32_)                                                                             \
-    if (!launched && r0 == R0_ && ct == CT_ && pj == PJ_ && mr == MR_ && cgsz == CG_ && a32 == A32_) {                       \
+    if (!launched && !std_variant && r0 == R0_ && ct == CT_ && pj == PJ_ && mr == MR_ && cgsz == CG_ && a32 == A32_) {       \
         PZ_TRY(set_lds(k_br_fused<R0_, CT_, NT, PJ_, MR_, CG_, A32_>, lds));                                                 \
         hipLaunchKernelGGL((k_br_fused<R0_, CT_, NT, PJ_, MR_, CG_, A32_>), dim3((B + CT_ - 1) / CT_), dim3(NT), lds, M->stream, g); \
         launched = true;                                                                                                     \
@@ -1618,16 +1629,21 @@ int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t*
     PZ_BR_ONE(R0_, CT_, 1, 4, 4, A32_) PZ_BR_ONE(R0_, CT_, 2, 4, 4, A32_) PZ_BR_ONE(R0_, CT_, 1, 6, 3, A32_) PZ_BR_ONE(R0_, CT_, 2, 6, 3, A32_) \
     PZ_BR_ONE(R0_, CT_, 1, 8, 4, A32_) PZ_BR_ONE(R0_, CT_, 2, 8, 4, A32_) PZ_BR_ONE(R0_, CT_, 1, 8, 3, A32_) PZ_BR_ONE(R0_, CT_, 2, 8, 3, A32_)
                 const int mr = row_max <= 4 && cgsz == 4 ? 4 : (row_max <= 6 && cgsz == 3 ? 6 : 8);
+                PZ_BR_STD_SHAPES(2) PZ_BR_STD_SHAPES(4) PZ_BR_STD_SHAPES(8)
                 PZ_BR_SHAPES(2, 1, false)
                 PZ_BR_SHAPES(4, 1, false) PZ_BR_SHAPES(4, 2, false) PZ_BR_SHAPES(4, 2, true)
                 PZ_BR_SHAPES(8, 1, false) PZ_BR_SHAPES(8, 2, false) PZ_BR_SHAPES(8, 2, true)
 #undef PZ_BR_SHAPES
 #undef PZ_BR_ONE
+#undef PZ_BR_STD_SHAPES
+#undef PZ_BR_STD
                 if (!launched) return fail(PZ_ERR_UNSUPPORTED, "blind_rotation: no one-kernel variant for this shape");
                 PZ_HIP(hipGetLastError());
                 return PZ_OK;
             }
         }
+    }
+    if (blk > 1) {
         const size_t n8 = (size_t)M->n * 8;
         const size_t acc_dft_bytes = align256(batch * n8 * cols * dnum), vr_bytes = align256(batch * n8 * cols * bsz);
         const size_t tp = (size_t)cols * std::max({dnum, bsz, rsz});

@@ -1,5 +1,5 @@
-// device_br.hpp — CGGI block-binary blind rotation as ONE kernel per batch
-// (poulpy-bin-fhe/src/blind_rotation/algorithms/cggi/algorithm.rs:265-368, execute_block_binary).
+// device_br.hpp — CGGI blind rotation as ONE kernel per batch
+// (poulpy-bin-fhe/src/blind_rotation/algorithms/cggi/algorithm.rs:265-368, execute_block_binary; :370-440, execute_standard).
 //
 // One workgroup owns CT LWE ciphertexts for the whole rotation: the accumulator GLWEs (i64 limbs) and ONE complex
 // work buffer per ciphertext live in LDS from the first block to the last, so per block only the prepared key is read
@@ -84,8 +84,12 @@ __device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int mp, int m
 // (m * ceil(ncols/CG) <= PJ*NT), row_max <= MAXR.
 // LDS: W[m] | X[CT][P][mp] (cplx) | acc[CT][rsz][cols][n].  ACC32 stores the accumulators as 32-bit digits (base2k <= 31):
 // after the first block they are normalized digits; the first block reads X^b * LUT (any i64) straight from global memory.
-template <int R0, int CT, int NT, int PJ, int MAXR, int CG, bool ACC32>
+// STD = execute_standard (algorithm.rs:370-440, block size 1): per LWE coefficient  tmp = external_product(acc, BRK_i)  (product
+// without the monomial factor, rounding, carry chain WITHOUT adding acc),  acc += (X^a_i - 1) * tmp  on the i64 limbs (a gather in
+// LDS), and one in-place normalization of acc at the very end; needs a second accumulator-sized LDS array for tmp.
+template <int R0, int CT, int NT, int PJ, int MAXR, int CG, bool ACC32, bool STD = false>
 __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
+    static_assert(!(STD && ACC32), "the standard variant keeps un-normalized sums: 64-bit accumulators");
     typedef typename AccT<ACC32>::type acc_t;
     // radix-8 butterflies a thread may own per pass (CT*P*m/8 <= JM8*NT, host-checked): two only for m = 512 with CT = 2
     constexpr int JM8 = (CT == 2 && R0 == 8) ? 2 : 1;
@@ -101,6 +105,7 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
     cplx* W = lds_br;                         // exp(2 pi i t / m)
     cplx* X = W + m;
     acc_t* acc = reinterpret_cast<acc_t*>(X + CT * P * mp);
+    acc_t* tmpd = acc + (STD ? CT * g.rsz * cols * n : 0);  // STD: digits of the current external product
     const int b0 = blockIdx.x * CT;
     const unsigned mask2 = 2u * (unsigned)n - 1u;
 
@@ -220,9 +225,14 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
                                         s.y = __builtin_fma(av.y, kv[j][r].x, s.y);
                                     }
                                 }
-                                const cplx xv = cmul(xm[ct], s);
-                                out[pj][ct][j].x = (out[pj][ct][j].x + xv.x) - s.x;
-                                out[pj][ct][j].y = (out[pj][ct][j].y + xv.y) - s.y;
+                                if (STD) {
+                                    out[pj][ct][j].x += s.x;
+                                    out[pj][ct][j].y += s.y;
+                                } else {
+                                    const cplx xv = cmul(xm[ct], s);
+                                    out[pj][ct][j].x = (out[pj][ct][j].x + xv.x) - s.x;
+                                    out[pj][ct][j].y = (out[pj][ct][j].y + xv.y) - s.y;
+                                }
                             }
                         }
                     }
@@ -266,14 +276,14 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
                 const cplx v = cmulc(X[(ct * P + limb * cols + col) * mp + br_pad(j)], tw);
                 const bool writes = limb < g.rsz;
                 const bool first = limb == g.bsz - 1;
-                acc_t* a = acc + ((long long)ct * ct_polys + (long long)limb * cols + col) * n;
+                acc_t* a = (STD ? tmpd : acc) + ((long long)ct * ct_polys + (long long)limb * cols + col) * n;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const double val = (h ? v.y : v.x) * inv_m;
                     const double rv = round_half_away(val);
                     // 3-instruction conversion when exact (|x| < 2^51), the saturating one otherwise (Rust `as i64`)
                     long long x = fabs(rv) < 2251799813685247.0 ? fast_i64_from_integral(rv) : sat_i64_from_integral(rv);
-                    if (writes) {
+                    if (writes && !STD) {
                         const long long prev = from_lut ? lut_rot(ct, limb, col, j + h * m) : (long long)a[j + h * m];
                         x = (long long)((unsigned long long)x + (unsigned long long)prev);
                     }
@@ -292,9 +302,42 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
             }
             // limbs of acc beyond the precision of the big value are zero (normalize.rs:118-120)
             for (int limb = g.bsz; limb < g.rsz; ++limb) {
-                acc_t* a = acc + ((long long)ct * ct_polys + (long long)limb * cols + col) * n;
+                acc_t* a = (STD ? tmpd : acc) + ((long long)ct * ct_polys + (long long)limb * cols + col) * n;
                 a[j] = 0;
                 a[j + m] = 0;
+            }
+        }
+        __syncthreads();
+        if (STD) {
+            // acc += (X^a - 1) * tmp, limb by limb (glwe_mul_xp_minus_one_assign + glwe_add_assign, :426-432)
+            for (int e = tidv; e < CT * ct_polys * n; e += NT) {
+                const int jj = e & (n - 1), ct = e >= ct_polys * n ? 1 : 0;
+                const int b = min(b0 + ct, g.batch - 1);
+                const unsigned kk = (unsigned)((unsigned long long)g.lwe[(long long)b * (g.n_lwe + 1) + 1 + blk0] & (unsigned long long)mask2);
+                const unsigned i0 = ((unsigned)jj - kk) & mask2;
+                const long long src = (long long)tmpd[e - jj + (int)(i0 & (unsigned)(n - 1))];
+                const long long rot = i0 >= (unsigned)n ? -src : src;
+                acc[e] = (acc_t)((long long)acc[e] + rot - (long long)tmpd[e]);
+            }
+            __syncthreads();
+        }
+    }
+    if (STD) {
+        // one in-place normalization of acc at the end (vec_znx_normalize_assign, :437)
+        for (int pc = tid >> lm; pc < CT * cols; pc += NT >> lm) {
+            const int j = tid & (m - 1), ct = (CT == 2 && pc >= cols) ? 1 : 0, col = pc - ct * cols;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                long long cy = 0;
+                for (int limb = g.rsz - 1; limb >= 0; --limb) {
+                    acc_t* a = acc + ((long long)ct * ct_polys + (long long)limb * cols + col) * n;
+                    const unsigned long long y = (unsigned long long)(long long)a[j + h * m] + half;
+                    const long long d = (long long)(y & dmask) - (long long)half;
+                    const long long cr = (long long)y >> k;
+                    const unsigned long long y2 = (unsigned long long)d + (unsigned long long)cy + half;
+                    a[j + h * m] = (acc_t)((long long)(y2 & dmask) - (long long)half);
+                    cy = (long long)((unsigned long long)cr + (unsigned long long)((long long)y2 >> k));
+                }
             }
         }
         __syncthreads();
