@@ -1668,8 +1668,15 @@ int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t*
                 g.lwe = (const long long*)lwe_2n; g.lwe_bs = lwe_bs; g.w2n = M->w2n;
                 constexpr int CT = 2;
                 KTimer kt(M, PZ_K_VMP);
-                hipLaunchKernelGGL((k_br_block<CT, 8, 8>), dim3((unsigned)((M->m + 255) / 256), (unsigned)((B + CT - 1) / CT)), dim3(256), 0,
-                                   M->stream, g);
+                const int nc = cols * bsz;
+                const unsigned gx = (unsigned)((B + CT - 1) / CT), gy = (unsigned)((M->m + 255) / 256);
+                if (nc % 3 == 0 && nc % 4 != 0) {   // 3, 6: groups of 3
+                    if (row_max <= 6) hipLaunchKernelGGL((k_br_block<CT, 6, 3>), dim3(gx, gy, (unsigned)(nc / 3)), dim3(256), 0, M->stream, g);
+                    else hipLaunchKernelGGL((k_br_block<CT, 8, 3>), dim3(gx, gy, (unsigned)(nc / 3)), dim3(256), 0, M->stream, g);
+                } else {
+                    if (row_max <= 4) hipLaunchKernelGGL((k_br_block<CT, 4, 4>), dim3(gx, gy, (unsigned)((nc + 3) / 4)), dim3(256), 0, M->stream, g);
+                    else hipLaunchKernelGGL((k_br_block<CT, 8, 4>), dim3(gx, gy, (unsigned)((nc + 3) / 4)), dim3(256), 0, M->stream, g);
+                }
                 PZ_HIP(hipGetLastError());
             } else {
             PZ_HIP(hipMemsetAsync(acc_add, 0, (size_t)B * aa.bs * 8, M->stream));                     // :321

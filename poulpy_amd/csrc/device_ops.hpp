@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(256) k_xai_acc(XaiArgs g) {
 // i.e. vec_znx_dft_zero + block_size x (vmp_apply_dft_to_dft, svp_apply_dft_to_dft, dft_add_assign, dft_sub_assign)
 // without vmp_res / vmp_xai ever leaving registers.  Thread = one frequency point q of CT ciphertexts: the key
 // values of a point are loaded once and used by the CT ciphertexts; lanes run along q (contiguous in every operand).
-// nrows <= MAXR (= dnum*cols rows actually present in acc_dft), ncols <= MAXC (= cols*brk_size).
+// nrows <= MAXR (= dnum*cols rows actually present in acc_dft); the cols*brk_size outputs are split into groups of CG.
 // =================================================================================
 struct BrBlockArgs {
     const cplx* acc_dft;   // [batch][nrows_a][m]
@@ -421,11 +421,16 @@ struct BrBlockArgs {
     const cplx* w2n;
 };
 
-template <int CT, int MAXR, int MAXC>
+// grid = (ceil(batch/CT), m/256, column groups of CG): the column group is uniform per workgroup, so the key row
+// pointers stay in SGPRs and the CG x row_max loads of a coefficient are issued together (one exposed L2 latency per
+// coefficient), as in the one-kernel path (device_br.hpp).
+template <int CT, int MAXR, int CG>
 __global__ void __launch_bounds__(256) k_br_block(BrBlockArgs g) {
-    const int q = blockIdx.x * 256 + threadIdx.x;
+    // ciphertext tiles fastest: the workgroups that run together share one 256-point slice of the block's keys (L2 resident)
+    const int q = blockIdx.y * 256 + threadIdx.x;
     if (q >= g.m) return;
-    const int b0 = blockIdx.y * CT;
+    const int b0 = blockIdx.x * CT;
+    const int cg = blockIdx.z;
     const unsigned mask = 4u * (unsigned)g.m - 1u;
     cplx a[CT][MAXR];
 #pragma unroll
@@ -435,13 +440,21 @@ __global__ void __launch_bounds__(256) k_br_block(BrBlockArgs g) {
         for (int r = 0; r < MAXR; ++r)
             a[t][r] = r < g.row_max ? g.acc_dft[(long long)b * g.a_bs + (long long)r * g.m + q] : make_double2(0.0, 0.0);
     }
-    cplx out[CT][MAXC];
+    cplx out[CT][CG];
 #pragma unroll
     for (int t = 0; t < CT; ++t)
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) out[t][c] = make_double2(0.0, 0.0);
+        for (int j = 0; j < CG; ++j) out[t][j] = make_double2(0.0, 0.0);
+    // (a second register set prefetching coefficient i+1 drops the occupancy to one wave per SIMD and is 15 % slower)
     for (int i = g.i0; i < g.i0 + g.blk; ++i) {
-        const cplx* K = g.brk + (long long)i * g.key_stride + q;
+        const cplx* K = g.brk + (long long)i * g.key_stride;
+        cplx kv[CG][MAXR];
+#pragma unroll
+        for (int j = 0; j < CG; ++j) {
+            const int c = min(cg * CG + j, g.ncols - 1);
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) kv[j][r] = (K + (long long)(min(r, g.row_max - 1) * g.ncols + c) * g.m)[q];
+        }
         cplx xm[CT];   // DFT(X^a)[q] for each ciphertext of the tile
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
@@ -450,30 +463,22 @@ __global__ void __launch_bounds__(256) k_br_block(BrBlockArgs g) {
             xm[t] = g.w2n[(ai * (4u * (unsigned)q + 1u)) & mask];
         }
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            if (c < g.ncols) {
-                cplx s[CT];
+        for (int j = 0; j < CG; ++j) {
 #pragma unroll
-                for (int t = 0; t < CT; ++t) s[t] = make_double2(0.0, 0.0);
+            for (int t = 0; t < CT; ++t) {
+                cplx s = make_double2(0.0, 0.0);
 #pragma unroll
                 for (int r = 0; r < MAXR; ++r) {
                     if (r < g.row_max) {
-                        const cplx kv = K[(long long)(r * g.ncols + c) * g.m];
-#pragma unroll
-                        for (int t = 0; t < CT; ++t) {
-                            s[t].x = __builtin_fma(a[t][r].x, kv.x, s[t].x);
-                            s[t].x = __builtin_fma(-a[t][r].y, kv.y, s[t].x);
-                            s[t].y = __builtin_fma(a[t][r].x, kv.y, s[t].y);
-                            s[t].y = __builtin_fma(a[t][r].y, kv.x, s[t].y);
-                        }
+                        s.x = __builtin_fma(a[t][r].x, kv[j][r].x, s.x);
+                        s.x = __builtin_fma(-a[t][r].y, kv[j][r].y, s.x);
+                        s.y = __builtin_fma(a[t][r].x, kv[j][r].y, s.y);
+                        s.y = __builtin_fma(a[t][r].y, kv[j][r].x, s.y);
                     }
                 }
-#pragma unroll
-                for (int t = 0; t < CT; ++t) {
-                    const cplx xv = cmul(xm[t], s[t]);
-                    out[t][c].x = (out[t][c].x + xv.x) - s[t].x;
-                    out[t][c].y = (out[t][c].y + xv.y) - s[t].y;
-                }
+                const cplx xv = cmul(xm[t], s);
+                out[t][j].x = (out[t][j].x + xv.x) - s.x;
+                out[t][j].y = (out[t][j].y + xv.y) - s.y;
             }
         }
     }
@@ -482,8 +487,10 @@ __global__ void __launch_bounds__(256) k_br_block(BrBlockArgs g) {
         const int b = b0 + t;
         if (b < g.batch) {
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c)
-                if (c < g.ncols) g.acc_add[(long long)b * g.o_bs + (long long)c * g.m + q] = out[t][c];
+            for (int j = 0; j < CG; ++j) {
+                const int c = cg * CG + j;
+                if (c < g.ncols) g.acc_add[(long long)b * g.o_bs + (long long)c * g.m + q] = out[t][j];
+            }
         }
     }
 }

@@ -22,6 +22,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 SHAPES = {
     "ref": dict(n=512, n_lwe=687, rank=3, block_size=3, base2k=18, dnum=1, brk_size=2, res_size=1),
     "cbt": dict(n=1024, n_lwe=574, rank=1, block_size=7, base2k=13, dnum=3, brk_size=3, res_size=3),
+    # the large ring degree of BASELINE configs[3] ("N = 2^10 / 2^14"): same key layout at N = 2^14 (composed path: the
+    # accumulators do not fit in LDS)
+    "big": dict(n=16384, n_lwe=574, rank=1, block_size=7, base2k=13, dnum=3, brk_size=3, res_size=3),
 }
 
 
@@ -31,6 +34,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--block-size", type=int, default=0, help="override the block size (1 = execute_standard)")
+    ap.add_argument("--base2k", type=int, default=0, help="override base2k (the exactness margin shrinks with N * 2^(2 base2k))")
+    ap.add_argument("--n-lwe", type=int, default=0)
     ap.add_argument("--cpu-cts", type=int, default=2)
     ap.add_argument("--with-keyswitch", action="store_true",
                     help="also time blind rotation + GLWE key switch of the result (the two heavy steps of a gate bootstrap, "
@@ -41,6 +46,10 @@ def main():
     s = dict(SHAPES[args.shape])
     if args.block_size:
         s["block_size"] = args.block_size
+    if args.base2k:
+        s["base2k"] = args.base2k
+    if args.n_lwe:
+        s["n_lwe"] = args.n_lwe
     n, cols = s["n"], s["rank"] + 1
     dev = torch.device("cuda", 0)
     mod = Module(n, device=0)
@@ -54,6 +63,7 @@ def main():
         mi = torch.roll(mat, i * 977)
         mod._ck(mod.lib.pz_vmp_prepare(mod.handle, C.c_void_p(brk[i].data_ptr()), C.c_void_p(mi.data_ptr()), C.c_size_t(s["dnum"]),
                                        C.c_size_t(cols), C.c_size_t(cols), C.c_size_t(s["brk_size"])))
+        mod.sync()   # device-pointer calls are stream-ordered on the module's stream: `mi` must outlive the kernels that read it
     mod.sync()
     lut = torch.randint(-half, half, (s["res_size"], 1, n), dtype=torch.int64, device=dev, generator=g)
     lwe = torch.randint(-n, n, (args.batch, s["n_lwe"] + 1), dtype=torch.int64, device=dev, generator=g)
