@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the per-op host-pointer path (the HalImpl-level boundary): one GLWE (x) GGSW external product at the
+metric shape (N = 2^16, 8 limbs, rank 1, dnum 8) written as the reference's op sequence over HOST containers
+(external_product/glwe.rs:197-271: dft_apply x cols, vmp_apply_dft_to_dft, idft_apply_consume, big_normalize x cols); every call
+stages its operands through the module's device arena (H2D, kernels, D2H).  Not the headline metric: DESIGN.md §1.
+The prepared GGSW is uploaded once and passed as a device pointer (as a shim's DeviceBuf would be)."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from poulpy_amd.hal import Module
+from poulpy_amd.layouts import MatZnx, VecZnx, VmpPMat
+
+
+def main():
+    n, cols, size, dnum, k, reps = 65536, 2, 8, 8, 12, 10
+    mod = Module(n)
+    rng = np.random.default_rng(1)
+    mat = MatZnx(n, dnum, cols, cols, size).fill_uniform(k, rng)
+    pm = mod.vmp_pmat_alloc(dnum, cols, cols, size)
+    mod.vmp_prepare(pm, mat)
+    d_key = mod.device_alloc(pm.data.nbytes).upload(pm.data)
+    pm_dev = VmpPMat.__new__(VmpPMat)
+    a = VecZnx(n, cols, size).fill_uniform(k, rng)
+    res = VecZnx(n, cols, size)
+
+    def one():
+        ad = mod.vec_znx_dft_alloc(cols, size)
+        for c in range(cols):
+            mod.vec_znx_dft_apply(1, 0, ad, c, a, c)
+        rd = mod.vec_znx_dft_alloc(cols, size)
+        mod._ck(mod.lib.pz_vmp_apply_dft_to_dft(mod.handle, rd.data.ctypes.data_as(C.c_void_p), C.c_size_t(cols), C.c_size_t(size),
+                                                ad.data.ctypes.data_as(C.c_void_p), C.c_size_t(cols), C.c_size_t(size), d_key.ptr,
+                                                C.c_size_t(dnum), C.c_size_t(cols), C.c_size_t(cols), C.c_size_t(size), C.c_size_t(0)))
+        big = mod.vec_znx_idft_apply_consume(rd)
+        for c in range(cols):
+            mod.vec_znx_big_normalize(res, k, 0, c, big, k, c)
+
+    one()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one()
+    dt = (time.perf_counter() - t0) / reps
+    print(json.dumps({"metric": "external products/s, per-op host-pointer path (PCIe-inclusive, pageable host memory, 1 ciphertext per call)",
+                      "value": 1.0 / dt, "ms_per_product": dt * 1e3, "n": n, "limbs": size}))
+
+
+if __name__ == "__main__":
+    main()
