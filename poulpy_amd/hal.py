@@ -357,6 +357,24 @@ class Module:
     def blind_rotation_workspace_bytes(self, params: BlindRotationParams, batch: int) -> int:
         return self.lib.pz_blind_rotation_workspace_bytes(self.handle, C.byref(params), c_size_t(batch))
 
+    # -- batched primitives on device pointers (object b at ptr + b * len(object)) ----------------
+    def vec_znx_dft_apply_batched(self, batch, step, offset, res: c_void_p, res_cols, res_size, res_col, a: c_void_p, a_cols, a_size, a_col):
+        self._ck(self.lib.pz_vec_znx_dft_apply_batched(self.handle, *_sz(batch, step, offset), res, *_sz(res_cols, res_size, res_col), a,
+                                                       *_sz(a_cols, a_size, a_col)))
+
+    def vec_znx_idft_apply_consume_batched(self, batch, data: c_void_p, cols, size):
+        self._ck(self.lib.pz_vec_znx_idft_apply_consume_batched(self.handle, c_size_t(batch), data, *_sz(cols, size)))
+
+    def vmp_apply_dft_to_dft_batched(self, batch, res: c_void_p, res_cols, res_size, a: c_void_p, a_cols, a_size, pmat: c_void_p, rows, cols_in,
+                                     cols_out, size, limb_offset=0):
+        self._ck(self.lib.pz_vmp_apply_dft_to_dft_batched(self.handle, c_size_t(batch), res, *_sz(res_cols, res_size), a, *_sz(a_cols, a_size),
+                                                          pmat, *_sz(rows, cols_in, cols_out, size, limb_offset)))
+
+    def vec_znx_big_normalize_batched(self, batch, res: c_void_p, res_cols, res_size, res_base2k, res_offset, res_col, a: c_void_p, a_cols,
+                                      a_size, a_base2k, a_col):
+        self._ck(self.lib.pz_vec_znx_big_normalize_batched(self.handle, c_size_t(batch), res, *_sz(res_cols, res_size, res_base2k),
+                                                           c_int64(res_offset), c_size_t(res_col), a, *_sz(a_cols, a_size, a_base2k, a_col)))
+
     def pin_key(self, pmat: c_void_p, rows: int, cols_in: int, cols_out: int, size: int):
         """Declare a prepared device key immutable: the fused pipeline keeps its row-sliced copy instead of rebuilding it per call."""
         self._ck(self.lib.pz_module_pin_key(self.handle, pmat, *_sz(rows, cols_in, cols_out, size)))

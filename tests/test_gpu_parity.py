@@ -815,3 +815,52 @@ def test_concurrent_callers_on_one_module(mods):
     with ThreadPoolExecutor(max_workers=8) as ex:
         results = list(ex.map(work, range(300, 340)))
     assert all(results)
+
+
+@pytest.mark.parametrize("n", [512, 4096, 65536])
+def test_batched_primitives_compose_an_external_product(mods, n):
+    """The four batched primitives of the ABI (pz_vec_znx_dft_apply_batched, pz_vmp_apply_dft_to_dft_batched,
+    pz_vec_znx_idft_apply_consume_batched, pz_vec_znx_big_normalize_batched) on device-resident ciphertexts, composed exactly like
+    external_product/glwe.rs:197-271 (incl. a (step, offset) limb selection and a limb_offset), against the oracle per ciphertext."""
+    ref, hip = mods(n)
+    rng = seeded(n + 77)
+    cols, a_size, size, dnum, k, batch = 2, 5, 4, 3, 13, 6
+    for (step, offset, limb_offset) in ((1, 0, 0), (2, 1, 1)):
+        sel = len(range(offset, a_size, step))
+        d_size = min(sel, dnum)
+        mat = MatZnx(n, dnum, cols, cols, size).fill_uniform(k, rng)
+        pr, ph = ref.vmp_pmat_alloc(dnum, cols, cols, size), hip.vmp_pmat_alloc(dnum, cols, cols, size)
+        ref.vmp_prepare(pr, mat)
+        hip.vmp_prepare(ph, mat)
+        a_all = np.empty((batch, a_size, cols, n), dtype=np.int64)
+        want = np.empty((batch, size, cols, n), dtype=np.int64)
+        for b in range(batch):
+            a = VecZnx(n, cols, a_size).fill_uniform(k, rng)
+            a_all[b] = a.data
+            ad = ref.vec_znx_dft_alloc(cols, d_size)
+            for c in range(cols):
+                ref.vec_znx_dft_apply(step, offset, ad, c, a, c)
+            rd = ref.vec_znx_dft_alloc(cols, size)
+            ref.vmp_apply_dft_to_dft(rd, ad, pr, limb_offset)
+            big = ref.vec_znx_idft_apply_consume(rd)
+            res = VecZnx(n, cols, size)
+            for c in range(cols):
+                ref.vec_znx_big_normalize(res, k, 0, c, big, k, c)
+            want[b] = res.data
+        d_a = hip.device_alloc(a_all.nbytes).upload(a_all)
+        d_key = hip.device_alloc(ph.data.nbytes).upload(ph.data)
+        d_ad = hip.device_alloc(batch * d_size * cols * n * 8)
+        d_rd = hip.device_alloc(batch * size * cols * n * 8)
+        d_res = hip.device_alloc(want.nbytes)
+        hip.lib.pz_memset_d(hip.handle, d_rd.ptr, 0, batch * size * cols * n * 8)
+        for c in range(cols):
+            hip.vec_znx_dft_apply_batched(batch, step, offset, d_ad.ptr, cols, d_size, c, d_a.ptr, cols, a_size, c)
+        hip.vmp_apply_dft_to_dft_batched(batch, d_rd.ptr, cols, size, d_ad.ptr, cols, d_size, d_key.ptr, dnum, cols, cols, size, limb_offset)
+        hip.vec_znx_idft_apply_consume_batched(batch, d_rd.ptr, cols, size)
+        for c in range(cols):
+            hip.vec_znx_big_normalize_batched(batch, d_res.ptr, cols, size, k, 0, c, d_rd.ptr, cols, size, k, c)
+        hip.sync()
+        got = d_res.download(np.int64, want.size).reshape(want.shape)
+        for buf in (d_a, d_key, d_ad, d_rd, d_res):
+            buf.free()
+        assert np.array_equal(got, want), (n, step, offset, limb_offset)
