@@ -864,3 +864,32 @@ def test_batched_primitives_compose_an_external_product(mods, n):
         for buf in (d_a, d_key, d_ad, d_rd, d_res):
             buf.free()
         assert np.array_equal(got, want), (n, step, offset, limb_offset)
+
+
+def test_tmp_bytes_workspace_and_small_utilities(mods):
+    """*_tmp_bytes must return the reference's numbers (poulpy-core sizes its scratch arenas from them); vmp_zero,
+    workspace queries and the event helpers behave."""
+    from poulpy_amd.hal import BlindRotationParams, GlweOpParams
+    n = 1024
+    ref, hip = mods(n)
+    assert hip.vec_znx_big_normalize_tmp_bytes() == ref.vec_znx_big_normalize_tmp_bytes() == 3 * n * 8        # normalize.rs:13-15
+    assert hip.vec_znx_idft_apply_tmp_bytes() == 0                                                          # hal_defaults/vec_znx_dft.rs:68-73
+    for (rs, asz, rows, ci, co, sz) in ((4, 3, 5, 2, 2, 4), (1, 1, 1, 1, 1, 1), (6, 7, 3, 1, 2, 5)):
+        assert hip.vmp_apply_dft_to_dft_tmp_bytes(rs, asz, rows, ci, co, sz) == ref.vmp_apply_dft_to_dft_tmp_bytes(rs, asz, rows, ci, co, sz)
+        assert hip.vmp_prepare_tmp_bytes(rows, ci, co, sz) == ref.vmp_prepare_tmp_bytes(rows, ci, co, sz) == n * 8   # vmp.rs:13-15
+        # family_common.rs:3-15: the DFT of a (cols_in x min(a.size, rows)) plus the dft_to_dft scratch
+        assert hip.vmp_apply_dft_tmp_bytes(rs, asz, rows, ci, co, sz) == n * 8 * ci * min(asz, rows) + ref.vmp_apply_dft_to_dft_tmp_bytes(
+            rs, min(asz, rows), rows, ci, co, sz)
+    pm = hip.vmp_pmat_alloc(2, 1, 2, 2)
+    pm.data[...] = 3.5
+    hip.vmp_zero(pm)
+    assert not pm.data.any()
+    p = GlweOpParams(rank=1, dnum=2, dsize=1, key_size=2, key_base2k=12, a_size=2, a_base2k=12, res_size=2, res_base2k=12, rank_out=1)
+    w1, w8 = hip.glwe_op_workspace_bytes(p, 1, 0), hip.glwe_op_workspace_bytes(p, 8, 0)
+    assert 0 < w1 <= w8 and hip.glwe_op_workspace_bytes(p, 8, 2) >= hip.glwe_op_workspace_bytes(p, 8, 1) > 0
+    bp = BlindRotationParams(rank=1, n_lwe=10, block_size=5, dnum=2, brk_size=2, base2k=12, res_size=2, lut_size=2)
+    assert hip.blind_rotation_workspace_bytes(bp, 4) > 0
+    e0, e1 = hip.event_create(), hip.event_create()
+    hip.event_record(e0)
+    hip.event_record(e1)
+    assert hip.event_elapsed_ms(e0, e1) >= 0.0
