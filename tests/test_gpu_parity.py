@@ -893,3 +893,41 @@ def test_tmp_bytes_workspace_and_small_utilities(mods):
     hip.event_record(e0)
     hip.event_record(e1)
     assert hip.event_elapsed_ms(e0, e1) >= 0.0
+
+
+def test_batched_entry_points_reject_bad_arguments(mods):
+    """Shape / pointer violations are reported (PZ_ERR_INVALID -> PoulpyHipError), never undefined behaviour: host pointers where
+    device pointers are required, empty shapes, an even Galois element, an automorphism key that changes the rank, an unknown mode,
+    base2k out of range; a zero batch is a no-op."""
+    import ctypes as C
+    from poulpy_amd.hal import BlindRotationParams, GlweOpParams, PoulpyHipError
+    n = 256
+    _, hip = mods(n)
+    good = GlweOpParams(rank=1, dnum=2, dsize=1, key_size=2, key_base2k=12, a_size=2, a_base2k=12, res_size=2, res_base2k=12, rank_out=1)
+    d = hip.device_alloc(n * 8 * 64)
+    host = np.zeros(n * 64, dtype=np.int64)
+    hp = host.ctypes.data_as(C.c_void_p)
+    hip.glwe_external_product_batched(d.ptr, d.ptr, d.ptr, good, 0)                      # batch 0: nothing to do
+    with pytest.raises(PoulpyHipError):
+        hip.glwe_external_product_batched(hp, d.ptr, d.ptr, good, 1)                     # host pointer
+    with pytest.raises(PoulpyHipError):
+        hip.glwe_keyswitch_batched(d.ptr, d.ptr, hp, good, 1)
+    bad = GlweOpParams(rank=1, dnum=0, dsize=1, key_size=2, key_base2k=12, a_size=2, a_base2k=12, res_size=2, res_base2k=12, rank_out=1)
+    with pytest.raises(PoulpyHipError):
+        hip.glwe_external_product_batched(d.ptr, d.ptr, d.ptr, bad, 1)                   # empty shape
+    with pytest.raises(PoulpyHipError):
+        hip.glwe_automorphism_batched(d.ptr, d.ptr, d.ptr, good, 4, "automorphism", 1)   # even Galois element
+    with pytest.raises(PoulpyHipError):
+        hip.glwe_automorphism_batched(d.ptr, d.ptr, d.ptr, good, 5, 9, 1)                # unknown mode
+    rk = GlweOpParams(rank=1, dnum=2, dsize=1, key_size=2, key_base2k=12, a_size=2, a_base2k=12, res_size=2, res_base2k=12, rank_out=2)
+    with pytest.raises(PoulpyHipError):
+        hip.glwe_automorphism_batched(d.ptr, d.ptr, d.ptr, rk, 5, "add", 1)              # key changes the rank
+    br = BlindRotationParams(rank=1, n_lwe=4, block_size=2, dnum=1, brk_size=1, base2k=70, res_size=1, lut_size=1)
+    with pytest.raises(PoulpyHipError):
+        hip.blind_rotation_execute_batched(d.ptr, d.ptr, d.ptr, d.ptr, br, 1)            # base2k out of range
+    br0 = BlindRotationParams(rank=1, n_lwe=0, block_size=2, dnum=1, brk_size=1, base2k=12, res_size=1, lut_size=1)
+    with pytest.raises(PoulpyHipError):
+        hip.blind_rotation_execute_batched(d.ptr, d.ptr, d.ptr, d.ptr, br0, 1)           # empty LWE
+    with pytest.raises(PoulpyHipError):
+        hip.vec_znx_big_normalize_batched(1, hp, 1, 1, 12, 0, 0, d.ptr, 1, 1, 12, 0)     # host pointer to a batched primitive
+    d.free()
