@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="ciphertexts per GPU per step (16 GiB of GLWE in + out at the metric shape)")
     ap.add_argument("--chunk", type=int, default=0, help="ciphertexts per pipeline wave (0 = auto)")
-    ap.add_argument("--op", choices=("external_product", "keyswitch", "automorphism", "automorphism_add"), default="external_product",
+    ap.add_argument("--op", choices=("external_product", "keyswitch", "automorphism", "automorphism_add", "trace"), default="external_product",
                     help="keyswitch = BASELINE configs[2] (secondary metric; GGLWE rows 8, cols_in 1, cols_out 2); automorphism[_add] = "
                          "glwe_automorphism[_add] with Galois element 5 on the same key shape (CKKS-rotate shape of configs[4])")
     ap.add_argument("--n", type=int, default=0, help="override the ring degree (0 = 65536, the metric configuration); "
@@ -152,6 +152,7 @@ def main():
     # broadcast over RCCL — the only collective
     ks = args.op != "external_product"
     auto_mode = {"automorphism": "automorphism", "automorphism_add": "add"}.get(args.op)
+    trace = args.op == "trace"   # full glwe_trace: log2(N) steps of rsh + glwe_automorphism_add_assign, one key per step
     cols_in = RANK_GLWE if ks else cols
     key_elems = N * DNUM * cols_in * cols * SIZE
     pmat = torch.empty(key_elems, dtype=torch.float64, device=dev)
@@ -179,10 +180,21 @@ def main():
     a_ptr, res_ptr, key_ptr = C.c_void_p(a.data_ptr()), C.c_void_p(res.data_ptr()), C.c_void_p(pmat.data_ptr())
     if not args.no_pin_key:   # evaluation keys are immutable for the lifetime of the job: let the backend keep its row-sliced copy
         mod.pin_key(key_ptr, DNUM, cols_in, cols, SIZE)
+    trace_keys, trace_gals = [], []
+    if trace:
+        nst = N.bit_length() - 1
+        trace_gals = [-1] + [pow(5, 1 << i, 2 * N) for i in range(nst - 1)]
+        trace_keys = [pmat] + [pmat.clone() for _ in range(nst - 1)]          # one (synthetic) prepared key per step
+        if not args.no_pin_key:
+            for t in trace_keys[1:]:
+                mod.pin_key(C.c_void_p(t.data_ptr()), DNUM, cols_in, cols, SIZE)
+        res.copy_(a)
     torch.cuda.synchronize()
 
     def step():
-        if auto_mode:
+        if trace:
+            mod.glwe_trace_batched(res_ptr, trace_gals, [t.data_ptr() for t in trace_keys], params, nct)
+        elif auto_mode:
             mod.glwe_automorphism_batched(res_ptr, a_ptr, key_ptr, params, 5, auto_mode, nct)
         elif ks:
             mod.glwe_keyswitch_batched(res_ptr, a_ptr, key_ptr, params, nct)
@@ -241,12 +253,13 @@ def main():
                         "pipeline_achieved": value / world * b_unit / 1e9,
                         "kernel_ms": {k: round(v[1], 3) for k, v in stats.items() if v[0]}}
         line = {
-            "metric": (f"GLWE {args.op.replace('_', ' ')}s/sec (N=2^{N.bit_length() - 1}, {SIZE} limbs)" if auto_mode else
+            "metric": (f"GLWE {args.op.replace('_', ' ')}s/sec (N=2^{N.bit_length() - 1}, {SIZE} limbs)" if (auto_mode or trace) else
                        f"GLWE key-switches/sec (N=2^{N.bit_length() - 1}, {SIZE} limbs)" if ks else f"GGSW external-products/sec (N=2^{N.bit_length() - 1}, {SIZE} limbs)"),
-            "value": value, "unit": (f"{args.op}s/s" if auto_mode else "key-switches/s" if ks else "external-products/s"),
+            "value": value, "unit": (f"{args.op}s/s" if (auto_mode or trace) else "key-switches/s" if ks else "external-products/s"),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"glwe_{args.op} (Galois element 5) via GGLWE VmpPMat, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize=1" if auto_mode else
+            "config": {"workload": (f"glwe_trace (log2 N steps of rsh + glwe_automorphism_add_assign, one key per step), N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}" if trace else
+                                    f"glwe_{args.op} (Galois element 5) via GGLWE VmpPMat, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize=1" if auto_mode else
                                     f"GLWE(rank 1) key-switch via GGLWE VmpPMat, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize=1" if ks else
                                     f"GLWE(rank 1) x GGSW external product, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize=1"),
                        "batch_per_gpu": args.batch, "parallelism": f"batch-sharded x{world}, key broadcast (RCCL)",

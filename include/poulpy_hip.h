@@ -186,6 +186,11 @@ int pz_vec_znx_big_normalize(pz_module* m,
 int pz_vec_znx_big_add_small_assign(pz_module* m, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
                                     const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
 
+/* hal_impl.rs:217 vec_znx_rsh_assign (reference/vec_znx/shift.rs:186-243): res >>= k bits in place, normalizing; used by
+ * glwe_rsh / glwe_trace.  k <= base2k * size. */
+size_t pz_vec_znx_rsh_tmp_bytes(const pz_module* m);
+int pz_vec_znx_rsh_assign(pz_module* m, size_t base2k, size_t k, int64_t* res, size_t cols, size_t size, size_t col);
+
 /* ---- X -> X^p on i64 containers (the glwe_automorphism callers) ---------------------- *
  * hal_impl.rs:236 vec_znx_automorphism, :241 _assign_tmp_bytes, :243 _assign; :517 vec_znx_big_automorphism, :522, :524.
  * reference/znx/automorphism.rs:1-17: res[(i*p) mod 2n] = a[i], negated when the index wraps past n; limbs of res beyond
@@ -236,6 +241,13 @@ int pz_glwe_keyswitch_batched(pz_module* m, int64_t* res, const int64_t* a, cons
 enum { PZ_AUTO = 0, PZ_AUTO_ADD = 1, PZ_AUTO_SUB = 2, PZ_AUTO_SUB_NEGATE = 3 };
 int pz_glwe_automorphism_batched(pz_module* m, int64_t* res, const int64_t* a, const double* key_pmat,
                                  const pz_glwe_op_params* p, int64_t gal, int mode, size_t batch);
+/* CoreImpl glwe_trace_assign (poulpy-core/src/glwe_trace.rs:129-176) on `batch` ciphertexts, for res and keys of one base2k:
+ * for s < nsteps:  res = rsh(res, 1 bit);  res = glwe_automorphism_add_assign(res, key_s)   (:164-174).
+ * The caller resolves the steps skip..log_n into Galois elements (i = 0: -1, else galois_element(2^(i-1)),
+ * poulpy-hal/src/layouts/module.rs:214-226) and the matching prepared automorphism keys: gals[s], key_pmats[s] are HOST
+ * arrays; each key_pmats[s] and res are device pointers.  p describes one step (a_size = res_size, equal base2k). */
+int pz_glwe_trace_batched(pz_module* m, int64_t* res, size_t nsteps, const int64_t* gals, const double* const* key_pmats,
+                          const pz_glwe_op_params* p, size_t batch);
 /* CoreImpl ggsw_external_product (poulpy-core/src/external_product/ggsw.rs:54-58): res[row][col] = a[row][col] (x) ggsw
  * for the a_dnum * (rank+1) GLWE entries of the GGSW `a` (MatZnx layout: entries are contiguous), device pointers. */
 int pz_ggsw_external_product(pz_module* m, int64_t* res, const int64_t* a, size_t a_dnum, const double* ggsw_pmat,

@@ -153,6 +153,13 @@ class Module {  // Module<FFT64Hip>, poulpy-hal/src/layouts/module.rs:97-189
         check(pz_module_pin_key(m_, pmat, rows, cols_in, cols_out, size), "module_pin_key");
     }
     void unpin_key(const double* pmat) { check(pz_module_unpin_key(m_, pmat), "module_unpin_key"); }
+    void vec_znx_rsh_assign(size_t base2k, size_t k, VecZnx& res, size_t res_col) {
+        check(pz_vec_znx_rsh_assign(m_, base2k, k, res.data, res.cols, res.size, res_col), "vec_znx_rsh_assign");
+    }
+    // gals / keys: nsteps host arrays (Galois element and device pointer of the prepared key of every step)
+    void glwe_trace_batched(int64_t* res, size_t nsteps, const int64_t* gals, const double* const* keys, const pz_glwe_op_params& p, size_t batch) {
+        check(pz_glwe_trace_batched(m_, res, nsteps, gals, keys, &p, batch), "glwe_trace_batched");
+    }
     void ggsw_external_product(int64_t* res, const int64_t* a, size_t a_dnum, const double* ggsw, const pz_glwe_op_params& p) {
         check(pz_ggsw_external_product(m_, res, a, a_dnum, ggsw, &p), "ggsw_external_product");
     }

@@ -1689,3 +1689,55 @@ void pzr_blind_rotation_execute(const pzr_tables* t, size_t rank, size_t n_lwe, 
         free(acc_tmp);
     }
 }
+
+/* ------------------------------------------------------------------------ */
+/* glwe_trace (circuit bootstrapping around the blind rotation) */
+/* ------------------------------------------------------------------------ */
+
+/* reference/vec_znx/shift.rs:186-243 : res >>= k bits (in place, normalizing), through the shifted normalization steps */
+void pzr_vec_znx_rsh_assign(size_t n, size_t base2k, size_t k, int64_t* res, size_t res_cols, size_t res_size, size_t res_col) {
+    size_t size = res_size;
+    size_t steps = k / base2k;
+    size_t k_rem = k % base2k;
+    if (k % base2k != 0) steps += 1; /* rsh by one more limb, then lsh by base2k - k_rem inside the steps */
+    size_t lsh = (base2k - k_rem) % base2k;
+    int64_t* carry = (int64_t*)calloc(n, sizeof(int64_t));
+    int64_t* tmp = (int64_t*)malloc(n * sizeof(int64_t));
+    if (steps > size) steps = size; /* (the reference indexes res.at(size - j - 1): k beyond the precision is not a supported call) */
+    for (size_t j = 0; j < steps; ++j) {
+        const int64_t* x = at_ci64(res, n, res_cols, res_col, size - j - 1);
+        if (j == 0) nz_first_step_carry_only(base2k, lsh, x, carry, n);
+        else nz_middle_step_carry_only(base2k, lsh, x, carry, n);
+    }
+    for (size_t j = 0; j + steps < size; ++j) {
+        memcpy(tmp, at_ci64(res, n, res_cols, res_col, size - steps - j - 1), n * sizeof(int64_t));
+        nz_middle_step_assign(base2k, lsh, tmp, carry, n);
+        memcpy(at_i64(res, n, res_cols, res_col, size - j - 1), tmp, n * sizeof(int64_t));
+    }
+    for (size_t j = 0; j < steps; ++j) {
+        memset(at_i64(res, n, res_cols, res_col, j), 0, n * sizeof(int64_t));
+        int64_t* x = at_i64(res, n, res_cols, res_col, steps - j - 1);
+        if (j == 0) nz_final_step_assign(base2k, lsh, x, carry, n);
+        else nz_middle_step_assign(base2k, lsh, x, carry, n);
+    }
+    free(carry);
+    free(tmp);
+}
+
+/* glwe_trace.rs:129-176 (same base2k for res and keys): for every step  res = rsh(res, 1);  res = automorphism_add_assign(res, key_p)
+ * (:164-174).  The caller resolves the Galois elements p (i = 0: -1, else galois_element(2^(i-1))) and the matching prepared keys:
+ * gals[s] / key_pmats[s] for the steps skip..log_n in order. */
+void pzr_glwe_trace_assign(const pzr_tables* t, size_t rank, int64_t* res, size_t res_size, size_t base2k,
+                           size_t nsteps, const int64_t* gals, const double* const* key_pmats,
+                           size_t dnum, size_t key_size, size_t dsize) {
+    size_t n = t->m << 1;
+    size_t cols = rank + 1;
+    int64_t* a = (int64_t*)malloc(n * cols * res_size * sizeof(int64_t));
+    for (size_t s = 0; s < nsteps; ++s) {
+        for (size_t c = 0; c < cols; ++c) pzr_vec_znx_rsh_assign(n, base2k, 1, res, cols, res_size, c); /* glwe_rsh(1, res), operations/glwe.rs:1096-1112 */
+        memcpy(a, res, n * cols * res_size * sizeof(int64_t));
+        pzr_glwe_automorphism(t, rank, PZR_KS_AUTO_ADD, gals[s], res, res_size, base2k, a, res_size, base2k, key_pmats[s], dnum, key_size,
+                              dsize, base2k);
+    }
+    free(a);
+}

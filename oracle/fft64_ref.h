@@ -160,6 +160,12 @@ void pzr_blind_rotation_execute(const pzr_tables* t, size_t rank, size_t n_lwe, 
                                 const int64_t* lwe_2n, const int64_t* lut, size_t lut_size,
                                 const double* brk, size_t dnum, size_t brk_size, const double* x_pow_a);
 
+/* reference/vec_znx/shift.rs:186-243 ; poulpy-core/src/glwe_trace.rs:129-176 (equal bases) */
+void pzr_vec_znx_rsh_assign(size_t n, size_t base2k, size_t k, int64_t* res, size_t res_cols, size_t res_size, size_t res_col);
+void pzr_glwe_trace_assign(const pzr_tables* t, size_t rank, int64_t* res, size_t res_size, size_t base2k,
+                           size_t nsteps, const int64_t* gals, const double* const* key_pmats,
+                           size_t dnum, size_t key_size, size_t dsize);
+
 #ifdef __cplusplus
 }
 #endif

@@ -264,3 +264,16 @@ class RefModule:
         assert brk.dtype == np.float64 and brk.flags["C_CONTIGUOUS"] and lwe_2n.dtype == np.int64
         self.lib.pzr_blind_rotation_execute(self.t, *_sz(rank, n_lwe, block_size), _p(res.data), *_sz(res.size, base2k), _p(lwe_2n),
                                             _p(lut.data), c_size_t(lut.size), _p(brk), *_sz(dnum, brk_size), _p(x_pow_a))
+
+    # glwe_trace (poulpy-core/src/glwe_trace.rs) and the shift it uses
+    def vec_znx_rsh_assign(self, base2k, k, res, res_col, scratch=None):
+        self.lib.pzr_vec_znx_rsh_assign(c_size_t(self._n), *_sz(base2k, k), _p(res.data), *_sz(res.cols, res.size, res_col))
+
+    def glwe_trace_assign(self, res, base2k, gals, pmats, dsize=1):
+        """glwe_trace.rs:129-176 at equal bases: gals[s], pmats[s] (prepared automorphism keys) for the steps skip..log_n."""
+        rank = res.cols - 1
+        ns = len(gals)
+        g = (c_int64 * ns)(*[int(x) for x in gals])
+        ptrs = (c_void_p * ns)(*[pm.data.ctypes.data for pm in pmats])
+        self.lib.pzr_glwe_trace_assign(self.t, c_size_t(rank), _p(res.data), *_sz(res.size, base2k), c_size_t(ns), g, ptrs,
+                                       *_sz(pmats[0].rows, pmats[0].size, dsize))

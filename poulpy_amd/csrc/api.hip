@@ -307,6 +307,21 @@ static int launch_rotate(pz_module* M, int npolys, const long long* src, PolyMap
     PZ_HIP(hipGetLastError());
     return PZ_OK;
 }
+static int launch_rsh(pz_module* M, int batch, long long* data, long long bs, int cols, int size, int col0, int ncols, int base2k, int k) {
+    if (batch <= 0 || ncols <= 0 || size <= 0) return PZ_OK;
+    RshArgs g;
+    g.data = data; g.bs = bs; g.cols = cols; g.size = size; g.col0 = col0; g.ncols = ncols; g.n = (int)M->n; g.batch = batch;
+    g.base2k = base2k; g.k = k;
+    KTimer kt(M, PZ_K_NORMALIZE);
+    for (int b0 = 0; b0 < batch; b0 += 65535) {   // gridDim.z limit
+        RshArgs gb = g;
+        gb.data = data + (long long)b0 * bs;
+        const int nb = std::min(65535, batch - b0);
+        hipLaunchKernelGGL(k_rsh_assign, dim3((unsigned)((M->n / 2 + 255) / 256), (unsigned)ncols, (unsigned)nb), dim3(256), 0, M->stream, gb);
+    }
+    PZ_HIP(hipGetLastError());
+    return PZ_OK;
+}
 static int ensure_w2n(pz_module* M) {
     if (M->w2n) return PZ_OK;
     const long long two_n = 2 * (long long)M->n;
@@ -1524,6 +1539,43 @@ int pz_ggsw_external_product(pz_module* M, int64_t* res, const int64_t* a, size_
     PZ_ENTER(M);
     PZ_REQUIRE(p != nullptr, "null params");
     return glwe_op(M, false, res, a, ggsw_pmat, p, a_dnum * (p->rank + 1));
+}
+
+// vec_znx_rsh_assign (hal_impl.rs:217; reference/vec_znx/shift.rs:186-243)
+size_t pz_vec_znx_rsh_tmp_bytes(const pz_module* M) { return M ? 2 * (size_t)M->n * 8 : 0; }  // shift.rs: carry + one polynomial
+int pz_vec_znx_rsh_assign(pz_module* M, size_t base2k, size_t k, int64_t* res, size_t cols, size_t size, size_t col) {
+    PZ_ENTER(M);
+    PZ_CHECK_COL(col, cols, "vec_znx_rsh_assign(res)");
+    PZ_REQUIRE(base2k >= 1 && base2k <= 63, "vec_znx_rsh_assign: base2k out of range");
+    PZ_REQUIRE(k <= base2k * size, "vec_znx_rsh_assign: shift beyond the precision of res");
+    Stage sr;
+    PZ_TRY(sr.in(res, vbytes(M, cols, size), true, true, M));
+    PZ_TRY(launch_rsh(M, 1, (long long*)sr.dev, 0, (int)cols, (int)size, (int)col, 1, (int)base2k, (int)k));
+    const bool host = sr.owned;
+    PZ_TRY(sr.finish());
+    return finish_call(M, host);
+}
+
+// glwe_trace_assign (poulpy-core/src/glwe_trace.rs:129-176) on `batch` ciphertexts, equal base2k for res and keys:
+//   for every step s:  res = rsh(res, 1 bit) on every column (operations/glwe.rs:1096-1112);  res = glwe_automorphism_add_assign(res, key_s)
+int pz_glwe_trace_batched(pz_module* M, int64_t* res, size_t nsteps, const int64_t* gals, const double* const* key_pmats,
+                          const pz_glwe_op_params* p, size_t batch) {
+    PZ_ENTER(M);
+    PZ_REQUIRE(p != nullptr && (nsteps == 0 || (gals != nullptr && key_pmats != nullptr)), "glwe_trace: null argument");
+    PZ_REQUIRE(p->a_size == p->res_size && p->a_base2k == p->res_base2k && p->res_base2k == p->key_base2k && p->rank_out == p->rank,
+               "glwe_trace: res and keys must share base2k, and a/res one layout (the other cases re-normalize around this call)");
+    PZ_REQUIRE(is_device_ptr(res), "batched entry points take device pointers");
+    if (batch == 0) return PZ_OK;
+    const long long n = (long long)M->n;
+    const int cols = (int)p->rank + 1;
+    const long long ct = n * cols * (long long)p->res_size;
+    for (size_t s = 0; s < nsteps; ++s) {
+        PZ_REQUIRE((gals[s] & 1) != 0, "glwe_trace: Galois elements must be odd");
+        PZ_TRY(launch_rsh(M, (int)batch, (long long*)res, ct, cols, (int)p->res_size, 0, cols, (int)p->res_base2k, 1));
+        AutoSpec au{(long long)gals[s], 1};
+        PZ_TRY(glwe_op(M, true, res, res, key_pmats[s], p, batch, &au));
+    }
+    return PZ_OK;
 }
 
 // ------------------------------------------------------------------------------

@@ -715,4 +715,76 @@ __global__ void __launch_bounds__(256) k_normalize_cross(NzArgs g, long long res
     }
 }
 
+// =================================================================================
+// vec_znx_rsh_assign (reference/vec_znx/shift.rs:186-243): res >>= k bits in place through the shifted normalization steps
+// (znx/normalization.rs, lsh = (base2k - k mod base2k) mod base2k).  The carry chain runs across limbs only: one thread owns
+// two coefficients and replays the reference's step sequence literally, including its limb aliasing in the last loop.
+// =================================================================================
+struct RshArgs {
+    long long* data;
+    long long bs;        // scalars between batch objects
+    int cols, size, col0, ncols, n, batch;
+    int base2k, k;
+};
+
+__global__ void __launch_bounds__(256) k_rsh_assign(RshArgs g) {
+    const int per = g.n / 2;                       // threads per polynomial column: two adjacent coefficients (16 B) each
+    const int bk = g.base2k;
+    int steps = g.k / bk;
+    const int k_rem = g.k % bk;
+    if (k_rem != 0) steps += 1;
+    const int lsh = (bk - k_rem) % bk;
+    const int kk = lsh == 0 ? bk : bk - lsh;
+    if (steps > g.size) steps = g.size;
+    const long long ls = (long long)g.cols * g.n;   // limb stride
+    // grid = (blocks along a column, columns, batch): no per-thread division
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= per) return;
+    long long* base = g.data + (long long)blockIdx.z * g.bs + (long long)(g.col0 + blockIdx.y) * g.n + 2 * e;
+    long long carry[2] = {0, 0};
+    for (int j = 0; j < steps; ++j) {   // limbs that fall off: carry only (:219-225)
+        const longlong2 v2 = *reinterpret_cast<const longlong2*>(base + (long long)(g.size - j - 1) * ls);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long v = h ? v2.y : v2.x;
+            const long long d = nz_digit(kk, v);
+            const long long cr = nz_carry(kk, v, d);
+            if (j == 0) {
+                carry[h] = cr;
+            } else {
+                const long long dpc = wadd(wshl(d, lsh), carry[h]);
+                carry[h] = wadd(cr, nz_carry(bk, dpc, nz_digit(bk, dpc)));
+            }
+        }
+    }
+    for (int j = 0; j + steps < g.size; ++j) {   // shifted normalization (:228-232)
+        const longlong2 v2 = *reinterpret_cast<const longlong2*>(base + (long long)(g.size - steps - j - 1) * ls);
+        long long nv[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long v = h ? v2.y : v2.x;
+            const long long d = nz_digit(kk, v);
+            const long long cr = nz_carry(kk, v, d);
+            const long long dpc = wadd(wshl(d, lsh), carry[h]);
+            nv[h] = nz_digit(bk, dpc);
+            carry[h] = wadd(cr, nz_carry(bk, dpc, nv[h]));
+        }
+        *reinterpret_cast<longlong2*>(base + (long long)(g.size - j - 1) * ls) = make_longlong2(nv[0], nv[1]);
+    }
+    for (int j = 0; j < steps; ++j) {   // top limbs (:235-242), literally: zero limb j, then step limb steps-1-j
+        *reinterpret_cast<longlong2*>(base + (long long)j * ls) = make_longlong2(0, 0);
+        const longlong2 v2 = *reinterpret_cast<const longlong2*>(base + (long long)(steps - j - 1) * ls);
+        long long nv[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long v = h ? v2.y : v2.x;
+            const long long d = nz_digit(kk, v);
+            const long long dpc = wadd(wshl(d, lsh), carry[h]);
+            nv[h] = nz_digit(bk, dpc);
+            if (j != 0) carry[h] = wadd(nz_carry(kk, v, d), nz_carry(bk, dpc, nv[h]));
+        }
+        *reinterpret_cast<longlong2*>(base + (long long)(steps - j - 1) * ls) = make_longlong2(nv[0], nv[1]);
+    }
+}
+
 }  // namespace pz

@@ -63,7 +63,7 @@ def load_library(path: str | None = None) -> C.CDLL:
                  "pz_bytes_of_vmp_pmat", "pz_vec_znx_idft_apply_tmp_bytes", "pz_vmp_prepare_tmp_bytes",
                  "pz_vmp_apply_dft_tmp_bytes", "pz_vmp_apply_dft_to_dft_tmp_bytes", "pz_vec_znx_big_normalize_tmp_bytes",
                  "pz_glwe_op_workspace_bytes", "pz_vec_znx_automorphism_assign_tmp_bytes",
-                 "pz_vec_znx_big_automorphism_assign_tmp_bytes", "pz_blind_rotation_workspace_bytes"):
+                 "pz_vec_znx_big_automorphism_assign_tmp_bytes", "pz_blind_rotation_workspace_bytes", "pz_vec_znx_rsh_tmp_bytes"):
         getattr(lib, name).restype = c_size_t
     if path is None:
         _lib = lib
@@ -329,6 +329,17 @@ class Module:
 
     def vec_znx_big_automorphism_assign_tmp_bytes(self) -> int:
         return self.lib.pz_vec_znx_big_automorphism_assign_tmp_bytes(self.handle)
+
+    def vec_znx_rsh_assign(self, base2k: int, k: int, res: VecZnx, res_col, scratch=None):
+        """hal_impl.rs:217 (reference/vec_znx/shift.rs:186-243)."""
+        self._ck(self.lib.pz_vec_znx_rsh_assign(self.handle, *_sz(base2k, k), _p(res.data), *_sz(res.cols, res.size, res_col)))
+
+    def glwe_trace_batched(self, res: c_void_p, gals, key_ptrs, params: GlweOpParams, batch: int):
+        """poulpy-core glwe_trace.rs:129-176 on device-resident ciphertexts: gals[s] / key_ptrs[s] (device pointers) per step."""
+        ns = len(gals)
+        g = (c_int64 * ns)(*[int(x) for x in gals])
+        ptrs = (c_void_p * ns)(*[p.value if isinstance(p, c_void_p) else int(p) for p in key_ptrs])
+        self._ck(self.lib.pz_glwe_trace_batched(self.handle, res, c_size_t(ns), g, ptrs, C.byref(params), c_size_t(batch)))
 
     # -- batched device-resident GLWE ops (CoreImpl overrides) ---------------------------
     AUTO_MODES = {"automorphism": 0, "add": 1, "sub": 2, "sub_negate": 3}

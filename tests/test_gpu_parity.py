@@ -931,3 +931,59 @@ def test_batched_entry_points_reject_bad_arguments(mods):
     with pytest.raises(PoulpyHipError):
         hip.vec_znx_big_normalize_batched(1, hp, 1, 1, 12, 0, 0, d.ptr, 1, 1, 12, 0)     # host pointer to a batched primitive
     d.free()
+
+
+@pytest.mark.parametrize("n", [64, 2048, 65536])
+def test_vec_znx_rsh_assign(mods, n):
+    """hal_impl.rs:217: every shift 0..base2k*size incl. several limbs falling off (where the reference's last loop aliases limbs:
+    replayed literally), ragged sizes, the other column untouched."""
+    ref, hip = mods(n)
+    rng = seeded(n + 9)
+    for base2k in (7, 13):
+        for size in (1, 2, 4):
+            for k in sorted(set([0, 1, 2, base2k - 1, base2k, base2k + 1, 2 * base2k, base2k * size])):
+                if k > base2k * size:
+                    continue
+                a = VecZnx(n, 2, size).fill_uniform(40, rng)
+                r, h = a.copy(), a.copy()
+                ref.vec_znx_rsh_assign(base2k, k, r, 1)
+                hip.vec_znx_rsh_assign(base2k, k, h, 1)
+                assert np.array_equal(r.data, h.data), (base2k, size, k)
+
+
+@pytest.mark.parametrize("fuse", [(True, True), (False, False)], ids=["fused", "unfused"])
+def test_glwe_trace_batched(mods, fuse):
+    """poulpy-core/src/glwe_trace.rs:129-176 on device-resident ciphertexts against the oracle: the Galois elements of a full trace
+    (-1, 5, 5^2, ...) with one prepared key per step, N = 512 (five-kernel path) and N = 8192 (fused pipeline)."""
+    from poulpy_amd.hal import GlweOpParams
+    for (n, rank, size, dnum, key_size, k, batch, nsteps) in ((512, 1, 3, 3, 4, 13, 5, 4), (8192, 1, 4, 4, 4, 12, 3, 3), (8192, 2, 3, 2, 3, 14, 2, 2)):
+        ref, hip = mods(n)
+        rng = seeded(n + rank)
+        cols = rank + 1
+        gals = [-1] + [pow(5, 1 << i, 2 * n) for i in range(nsteps - 1)]
+        prs, d_keys = [], []
+        for _ in gals:
+            mat = MatZnx(n, dnum, rank, cols, key_size).fill_uniform(k, rng)
+            pr, ph = ref.vmp_pmat_alloc(dnum, rank, cols, key_size), hip.vmp_pmat_alloc(dnum, rank, cols, key_size)
+            ref.vmp_prepare(pr, mat)
+            hip.vmp_prepare(ph, mat)
+            prs.append(pr)
+            d_keys.append(hip.device_alloc(ph.data.nbytes).upload(ph.data))
+        cts = np.empty((batch, size, cols, n), dtype=np.int64)
+        want = np.empty_like(cts)
+        for b in range(batch):
+            ct = VecZnx(n, cols, size).fill_uniform(k, rng)
+            cts[b] = ct.data
+            ref.glwe_trace_assign(ct, k, gals, prs)
+            want[b] = ct.data
+        d_res = hip.device_alloc(cts.nbytes).upload(cts)
+        p = GlweOpParams(rank=rank, dnum=dnum, dsize=1, key_size=key_size, key_base2k=k, a_size=size, a_base2k=k, res_size=size,
+                         res_base2k=k, rank_out=rank)
+        hip.set_fusion(*fuse)
+        hip.glwe_trace_batched(d_res.ptr, gals, [d.ptr for d in d_keys], p, batch)
+        hip.sync()
+        hip.set_fusion(True, True)
+        got = d_res.download(np.int64, want.size).reshape(want.shape)
+        for d in d_keys + [d_res]:
+            d.free()
+        assert np.array_equal(got, want), (n, rank, size)

@@ -7,6 +7,7 @@ properties are what anchors the oracle:
   P3  normalize == big-int balanced digit decomposition / torus value preserved  (normalize.rs:428-540)
   P5  automorphism family == X -> X^p stated directly on exact integers            (automorphism/glwe_ct.rs)
   P6  CGGI blind rotation (block-binary and standard) == the same recurrence on exact integers  (algorithm.rs:265-440)
+  P7  vec_znx_rsh_assign (k <= base2k) == exact shift with round-to-nearest; glwe_trace == its recurrence on exact integers
   A1  spectral identity of fft_ref (slot k <-> root exp(2 pi i (4 bitrev(k)+1)/(4m)))
 """
 import numpy as np
@@ -312,3 +313,59 @@ def test_P6_blind_rotation_matches_exact(block_size, rank):
         for c in range(cols):
             acc[:, c, :] = exact.normalize_exact(acc[:, c, :], base2k, res_size)
     assert np.array_equal(res.data, np.array(acc, dtype=np.int64))
+
+
+def _val(limbs, base2k):
+    tot = base2k * len(limbs)
+    return sum(int(v) << (tot - (j + 1) * base2k) for j, v in enumerate(limbs))
+
+
+def test_P7_rsh_assign_is_a_rounded_shift():
+    """reference/vec_znx/shift.rs:186-243 restated: for k <= base2k (one limb falls off; glwe_trace uses k = 1) the result is the
+    value shifted by k bits, rounded to nearest at the precision of res, in balanced digits, other columns untouched."""
+    n = 16
+    R = RefModule(n)
+    rng = seeded(21)
+    for base2k in (5, 12, 17):
+        for k in (1, 2, base2k - 1, base2k):
+            for size in (1, 3, 4):
+                a = VecZnx(n, 2, size).fill_uniform(base2k, rng)
+                b = a.copy()
+                R.vec_znx_rsh_assign(base2k, k, b, 1)
+                assert np.array_equal(a.data[:, 0], b.data[:, 0])
+                assert np.abs(b.data[:, 1]).max() <= 1 << (base2k - 1)
+                for i in range(n):
+                    va, vb = _val(a.data[:, 1, i], base2k), _val(b.data[:, 1, i], base2k)
+                    assert abs(va - (vb << k)) <= 1 << (k - 1), (base2k, k, size)
+
+
+def test_P7_glwe_trace_matches_exact():
+    """glwe_trace.rs:164-174 restated in the oracle vs exact integers: per step res <- normalize(phi_p(KS_p(rsh(res))) + rsh(res))
+    with the exact key-switch value (mask x key + body) and the oracle's own rsh (pinned above)."""
+    n, base2k, rank = 32, 13, 1
+    cols = rank + 1
+    R = RefModule(n)
+    rng = seeded(77)
+    size, dnum, key_size = 3, 3, 4
+    gals = [-1, 5, 25 % (2 * n)]
+    mats = [MatZnx(n, dnum, rank, cols, key_size).fill_uniform(base2k, rng) for _ in gals]
+    pms = []
+    for mt in mats:
+        pm = R.vmp_pmat_alloc(dnum, rank, cols, key_size)
+        R.vmp_prepare(pm, mt)
+        pms.append(pm)
+    res = VecZnx(n, cols, size).fill_uniform(base2k, rng)
+    cur = res.copy()
+    R.glwe_trace_assign(res, base2k, gals, pms)
+    for p, mt in zip(gals, mats):
+        for c in range(cols):
+            R.vec_znx_rsh_assign(base2k, 1, cur, c)
+        big = exact.vmp_exact(np.ascontiguousarray(cur.data[:, 1:, :]), mt.data, 0, key_size)
+        big[:size, 0, :] += cur.data[:, 0, :].astype(object)
+        nxt = np.zeros_like(cur.data)
+        for c in range(cols):
+            v = exact.automorphism_exact(big[:, c, :], p)
+            v[:size] += cur.data[:, c, :].astype(object)
+            nxt[:, c, :] = exact.normalize_exact(v, base2k, size)
+        cur.data[...] = nxt
+    assert np.array_equal(res.data, cur.data)
