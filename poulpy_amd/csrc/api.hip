@@ -130,7 +130,8 @@ static bool tail_supported(const pz_module* M) { return (M->plan.f1b * M->plan.c
 
 static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
                                 int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
-                                int base2k, bool rowmajor, bool small_all, unsigned auto_mul, bool auto_neg, int col_base, int col_count) {
+                                int base2k, bool rowmajor, bool small_all, unsigned auto_mul, bool auto_neg, int col_base, int col_count,
+                                unsigned gather_mul = 0, bool gather_neg = false) {
     const FftPlan& pl = M->plan;
     const int blocks = batch * col_count * (pl.m2 / pl.cb);
     if (blocks == 0) return PZ_OK;
@@ -142,6 +143,8 @@ static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlim
     g.tw1inv = M->tw1inv; g.wL1 = M->wL1; g.margin = M->margin;
     g.small_all = small_all ? 1 : 0; g.auto_mul = auto_mul; g.auto_neg = auto_neg ? 1 : 0;
     g.col_base = col_base; g.col_count = col_count;
+    g.gather_mul = gather_mul; g.gather_neg = gather_neg ? 1 : 0;
+    g.xcd_map = (gather_mul != 0 && blocks % (8 * (pl.m2 / pl.cb)) == 0) ? 1 : 0;
     const bool has_small = small != nullptr;
 // one instantiation per (probe, row-major, body add) combination actually requested
 #define PZ_TAIL_ONE(A, B, C, P_, R_, S_)                                                                        \
@@ -169,7 +172,8 @@ static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlim
 // registers, one workgroup less per CU), the other columns the plain one.
 static int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
                            int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
-                           int base2k, bool rowmajor = false, bool small_all = false, unsigned auto_mul = 0, bool auto_neg = false) {
+                           int base2k, bool rowmajor = false, bool small_all = false, unsigned auto_mul = 0, bool auto_neg = false,
+                           unsigned gather_mul = 0, bool gather_neg = false) {
     if (small != nullptr && !small_all && ncols > 1) {
         PZ_TRY(launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, small, small_bs, small_cols, small_size,
                                     base2k, rowmajor, false, auto_mul, auto_neg, 0, 1));
@@ -177,7 +181,7 @@ static int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, i
                                     base2k, rowmajor, false, 0, false, 1, ncols - 1);
     }
     return launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, small, small_bs, small_cols, small_size, base2k,
-                                rowmajor, small_all, auto_mul, auto_neg, 0, ncols);
+                                rowmajor, small_all, auto_mul, auto_neg, 0, ncols, gather_mul, gather_neg);
 }
 
 static bool mid_supported(const pz_module* M, int npi, int npo) {
@@ -1359,7 +1363,7 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
         const size_t t_bytes = align256(chunk * (size_t)npi * M->m * sizeof(cplx));
         const size_t t2_bytes = align256(chunk * (size_t)npo * M->m * sizeof(cplx));
         const size_t rtmp_bytes = au ? align256(chunk * (size_t)res_ct * 8) : 0;
-        const size_t small2_bytes = au_big ? align256(chunk * (size_t)M->n * 8 * s.cols_a * s.a_size_eff) : 0;
+        const size_t small2_bytes = 0;  // (the pre-gathered operand of the add / sub variants is no longer materialised)
         PZ_TRY(ws_reserve(M, key_bytes + conv_bytes + t_bytes + t2_bytes + rtmp_bytes + small2_bytes + kMidDummyBytes));
         char* base = (char*)M->ws;
         cplx* Pp = (cplx*)base; base += key_bytes;
@@ -1392,17 +1396,11 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
             int64_t* res_b = res + (long long)b0 * res_ct;
             const long long* small = ks ? (const long long*)av.p : nullptr;
             long long small_bs = av.bs;
-            if (au_big) {
-                // small2[c][j] = -+phi^-1(a)[c][j]  (+ a[0][j], the key-switch body, for c = 0)
-                PolyMap am{a_size, s.cols_a, av.bs, (long long)av.cols * n, n, 0};
-                PolyMap dm{a_size, s.cols_a, n * s.cols_a * a_size, (long long)s.cols_a * n, n, 0};
-                PZ_TRY(launch_automorphism(M, nb * a_size * s.cols_a, (const long long*)av.p, am, (long long*)small2, dm, au_p,
-                                           1 | (au->mode == 1 ? 0 : 2) | 4, (const long long*)av.p, am));
-                small = (const long long*)small2;
-                small_bs = n * s.cols_a * a_size;
-            }
+            // au_big: the operand -+phi^-1(a) (+ body for column 0) is gathered from `a` inside the tail (TailArgs::gather_mul)
+            (void)small2;
             if (M->dbg_stages & 4) PZ_TRY(launch_inv_tail(M, nb, T2, ksz, s.cols_out, (long long*)(au ? res_tmp : res_b), res_ct, s.cols_out, (int)p->res_size,
-                                   small, small_bs, s.cols_a, a_size, (int)p->res_base2k, true, au_big, au_big ? au_p : 0u, au && au->mode == 3));
+                                   small, small_bs, s.cols_a, a_size, (int)p->res_base2k, true, au_big, au_big ? au_p : 0u, au && au->mode == 3,
+                                   au_big ? au_p : 0u, au_big && au->mode != 1));
             if (au) {
                 PolyMap tm{(int)p->res_size, s.cols_out, res_ct, (long long)s.cols_out * n, n, 0};
                 PZ_TRY(launch_automorphism(M, nb * (int)p->res_size * s.cols_out, (const long long*)res_tmp, tm, (long long*)res_b, tm, au_g,

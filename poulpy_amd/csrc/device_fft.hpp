@@ -374,6 +374,13 @@ struct TailArgs {
     unsigned auto_mul;  // 0: no sign
     int auto_neg;
     int col_base, col_count;  // this launch covers columns [col_base, col_base + col_count) of the ncols
+    // gather_mul != 0 (with small_all): the operand added before the carry chain is  -+phi^-1(small)[n] (+ small[col 0][n], the
+    // key-switch body, for column 0), gathered here from the natural-order `small` instead of being prepared by a separate pass:
+    //   phi^-1(a)[n] = +-a[(n * gather_mul) mod 2N]  (negated when that index is >= N); gather_neg: operand = -phi^-1(a) (sub modes).
+    // xcd_map: decode blockIdx so that all column blocks of one (ciphertext, column) run on one XCD (its L2 then serves the 8-byte
+    // gathers: every line of the 512 KiB limb is fetched from HBM once)
+    unsigned gather_mul;
+    int gather_neg, xcd_map;
 };
 
 // Workgroup = (R2 + R1)*CB threads in two wave-uniform roles (R2*CB must be a multiple of 64):
@@ -413,8 +420,13 @@ k_inv_tail(TailArgs g) {
     }
     __syncthreads();
     const int ncb = g.m2 / CB;
-    const int c0 = (blockIdx.x % ncb) * CB;
-    const int bc = blockIdx.x / ncb;
+    int bid = blockIdx.x;
+    if (g.xcd_map) {  // (gridDim.x is a multiple of 8 * ncb: host-checked)
+        const int xcd = bid & 7, slot = bid >> 3;
+        bid = ((slot / ncb) * 8 + xcd) * ncb + slot % ncb;
+    }
+    const int c0 = (bid % ncb) * CB;
+    const int bc = bid / ncb;
     const int col = g.col_base + bc % g.col_count;
     const int b = bc / g.col_count;
     const long long m = (long long)M1 * g.m2;
@@ -489,7 +501,22 @@ k_inv_tail(TailArgs g) {
         const cplx* buf = xch + (j & 1) * XCH;
         // key-switch body limb: requested first so that its latency hides behind the butterfly
         long long sm[SMALL ? 2 * RE : 1];
-        if (SMALL && small_col && j < g.small_size) {
+        if (SMALL && small_col && j < g.small_size && g.gather_mul) {
+            const long long* body = col == 0 ? g.small + (long long)b * g.small_bs + (long long)j * small_ls : nullptr;
+#pragma unroll
+            for (int e = 0; e < RE; ++e) {
+                const long long idx = (long long)(b_ov + R2 * PZ_TAIL_N1(e)) * g.m2 + c0 + b_cv;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned ih = (unsigned)(idx + (h ? m : 0));
+                    const unsigned i0 = (ih * g.gather_mul) & (unsigned)(2 * n - 1);
+                    unsigned long long v = (unsigned long long)small_col[(long long)j * small_ls + (long long)(i0 & (unsigned)(n - 1))];
+                    if ((i0 >= (unsigned)n) != (g.gather_neg != 0)) v = 0ull - v;
+                    if (body) v += (unsigned long long)body[ih];
+                    sm[2 * e + h] = (long long)v;
+                }
+            }
+        } else if (SMALL && small_col && j < g.small_size) {
 #pragma unroll
             for (int e = 0; e < RE; ++e) {
                 const long long idx = (long long)(b_ov + R2 * PZ_TAIL_N1(e)) * g.m2 + c0 + b_cv;
