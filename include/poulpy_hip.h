@@ -186,6 +186,12 @@ int pz_vec_znx_big_normalize(pz_module* m,
 int pz_vec_znx_big_add_small_assign(pz_module* m, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
                                     const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
 
+/* hal_impl.rs:225 vec_znx_rotate, :230 _assign_tmp_bytes, :232 _assign (reference/znx/rotate.rs:3-27: res = X^k * a in Z[X]/(X^n+1),
+ * any k; limbs of res beyond a.size zeroed).  Used by glwe_rotate_assign between the rows of a circuit bootstrapping. */
+size_t pz_vec_znx_rotate_assign_tmp_bytes(const pz_module* m);
+int pz_vec_znx_rotate(pz_module* m, int64_t k, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                      const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+int pz_vec_znx_rotate_assign(pz_module* m, int64_t k, int64_t* res, size_t cols, size_t size, size_t col);
 /* hal_impl.rs:217 vec_znx_rsh_assign (reference/vec_znx/shift.rs:186-243): res >>= k bits in place, normalizing; used by
  * glwe_rsh / glwe_trace.  k <= base2k * size. */
 size_t pz_vec_znx_rsh_tmp_bytes(const pz_module* m);

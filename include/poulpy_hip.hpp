@@ -153,6 +153,12 @@ class Module {  // Module<FFT64Hip>, poulpy-hal/src/layouts/module.rs:97-189
         check(pz_module_pin_key(m_, pmat, rows, cols_in, cols_out, size), "module_pin_key");
     }
     void unpin_key(const double* pmat) { check(pz_module_unpin_key(m_, pmat), "module_unpin_key"); }
+    void vec_znx_rotate(int64_t k, VecZnx& res, size_t res_col, const VecZnx& a, size_t a_col) {
+        check(pz_vec_znx_rotate(m_, k, res.data, res.cols, res.size, res_col, a.data, a.cols, a.size, a_col), "vec_znx_rotate");
+    }
+    void vec_znx_rotate_assign(int64_t k, VecZnx& res, size_t res_col) {
+        check(pz_vec_znx_rotate_assign(m_, k, res.data, res.cols, res.size, res_col), "vec_znx_rotate_assign");
+    }
     void vec_znx_rsh_assign(size_t base2k, size_t k, VecZnx& res, size_t res_col) {
         check(pz_vec_znx_rsh_assign(m_, base2k, k, res.data, res.cols, res.size, res_col), "vec_znx_rsh_assign");
     }

@@ -1539,6 +1539,44 @@ int pz_ggsw_external_product(pz_module* M, int64_t* res, const int64_t* a, size_
     return glwe_op(M, false, res, a, ggsw_pmat, p, a_dnum * (p->rank + 1));
 }
 
+// vec_znx_rotate (hal_impl.rs:225) / vec_znx_rotate_assign (:232): res = X^k * a (reference/znx/rotate.rs:3-27), limbs of res
+// beyond a.size zeroed (vec_znx/rotate.rs:33-35)
+size_t pz_vec_znx_rotate_assign_tmp_bytes(const pz_module* M) { return M ? (size_t)M->n * 8 : 0; }
+int pz_vec_znx_rotate(pz_module* M, int64_t k, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a,
+                      size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    PZ_CHECK_COL(res_col, res_cols, "vec_znx_rotate(res)");
+    PZ_CHECK_COL(a_col, a_cols, "vec_znx_rotate(a)");
+    PZ_REQUIRE((const void*)res != (const void*)a, "vec_znx_rotate: res must not alias a (use the *_assign form)");
+    Tri t;
+    PZ_TRY(tri_in(M, t, (double*)res, res_cols, res_size, (const double*)a, a_cols, a_size, nullptr, 0, 0));
+    const int min_size = (int)std::min(res_size, a_size);
+    const long long n = (long long)M->n;
+    PolyMap sm{std::max(min_size, 1), 1, 0, (long long)a_cols * n, 0, n * (long long)a_col};
+    PolyMap dm{std::max(min_size, 1), 1, 0, (long long)res_cols * n, 0, n * (long long)res_col};
+    PZ_TRY(launch_rotate(M, min_size, (const long long*)t.da.p, sm, (long long*)t.dr.p, dm, 0, std::max(min_size, 1), nullptr, 0, 0, (long long)k));
+    PZ_TRY(ew_limbs(M, EW_ZERO, t.dr, (int)res_col, min_size, nullptr, 0, 0, nullptr, 0, 0, (int)res_size - min_size));
+    return tri_out(M, t);
+}
+int pz_vec_znx_rotate_assign(pz_module* M, int64_t k, int64_t* res, size_t cols, size_t size, size_t col) {
+    PZ_ENTER(M);
+    PZ_CHECK_COL(col, cols, "vec_znx_rotate_assign(res)");
+    Stage sr;
+    PZ_TRY(sr.in(res, vbytes(M, cols, size), true, true, M));
+    const long long n = (long long)M->n;
+    if (size > 0) {
+        PZ_TRY(ws_reserve(M, (size_t)size * (size_t)n * 8));
+        DV dr{sr.dev, 0, (int)cols, (int)size};
+        PZ_TRY(launch_ew(M, EW_COPY, M->ws, 0, n, poly_ptr(M, dr, (int)col, 0), 0, limb_stride(M, dr), nullptr, 0, 0, (int)size, 1));
+        PolyMap sm{(int)size, 1, 0, n, 0, 0};
+        PolyMap dm{(int)size, 1, 0, (long long)cols * n, 0, n * (long long)col};
+        PZ_TRY(launch_rotate(M, (int)size, (const long long*)M->ws, sm, (long long*)sr.dev, dm, 0, (int)size, nullptr, 0, 0, (long long)k));
+    }
+    const bool host = sr.owned;
+    PZ_TRY(sr.finish());
+    return finish_call(M, host);
+}
+
 // vec_znx_rsh_assign (hal_impl.rs:217; reference/vec_znx/shift.rs:186-243)
 size_t pz_vec_znx_rsh_tmp_bytes(const pz_module* M) { return M ? 2 * (size_t)M->n * 8 : 0; }  // shift.rs: carry + one polynomial
 int pz_vec_znx_rsh_assign(pz_module* M, size_t base2k, size_t k, int64_t* res, size_t cols, size_t size, size_t col) {

@@ -63,7 +63,7 @@ def load_library(path: str | None = None) -> C.CDLL:
                  "pz_bytes_of_vmp_pmat", "pz_vec_znx_idft_apply_tmp_bytes", "pz_vmp_prepare_tmp_bytes",
                  "pz_vmp_apply_dft_tmp_bytes", "pz_vmp_apply_dft_to_dft_tmp_bytes", "pz_vec_znx_big_normalize_tmp_bytes",
                  "pz_glwe_op_workspace_bytes", "pz_vec_znx_automorphism_assign_tmp_bytes",
-                 "pz_vec_znx_big_automorphism_assign_tmp_bytes", "pz_blind_rotation_workspace_bytes", "pz_vec_znx_rsh_tmp_bytes"):
+                 "pz_vec_znx_big_automorphism_assign_tmp_bytes", "pz_blind_rotation_workspace_bytes", "pz_vec_znx_rsh_tmp_bytes", "pz_vec_znx_rotate_assign_tmp_bytes"):
         getattr(lib, name).restype = c_size_t
     if path is None:
         _lib = lib
@@ -329,6 +329,14 @@ class Module:
 
     def vec_znx_big_automorphism_assign_tmp_bytes(self) -> int:
         return self.lib.pz_vec_znx_big_automorphism_assign_tmp_bytes(self.handle)
+
+    def vec_znx_rotate(self, k: int, res: VecZnx, res_col, a: VecZnx, a_col):
+        """hal_impl.rs:225: res = X^k * a."""
+        self._ck(self.lib.pz_vec_znx_rotate(self.handle, c_int64(k), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                            *_sz(a.cols, a.size, a_col)))
+
+    def vec_znx_rotate_assign(self, k: int, res: VecZnx, res_col, scratch=None):
+        self._ck(self.lib.pz_vec_znx_rotate_assign(self.handle, c_int64(k), _p(res.data), *_sz(res.cols, res.size, res_col)))
 
     def vec_znx_rsh_assign(self, base2k: int, k: int, res: VecZnx, res_col, scratch=None):
         """hal_impl.rs:217 (reference/vec_znx/shift.rs:186-243)."""

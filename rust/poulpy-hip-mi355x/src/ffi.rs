@@ -97,6 +97,9 @@ unsafe extern "C" {
     pub fn pz_blind_rotation_workspace_bytes(m: *const pz_module, p: *const pz_blind_rotation_params, batch: usize) -> usize;
     pub fn pz_module_pin_key(m: *mut pz_module, pmat: *const f64, rows: usize, cols_in: usize, cols_out: usize, size: usize) -> c_int;
     pub fn pz_module_unpin_key(m: *mut pz_module, pmat: *const f64) -> c_int;
+    pub fn pz_vec_znx_rotate(m: *mut pz_module, k: i64, res: *mut i64, rc: usize, rs: usize, rcol: usize, a: *const i64, ac: usize,
+        as_: usize, acol: usize) -> c_int;
+    pub fn pz_vec_znx_rotate_assign(m: *mut pz_module, k: i64, res: *mut i64, rc: usize, rs: usize, rcol: usize) -> c_int;
     pub fn pz_vec_znx_rsh_assign(m: *mut pz_module, base2k: usize, k: usize, res: *mut i64, rc: usize, rs: usize, rcol: usize) -> c_int;
     /// glwe_trace_assign (poulpy-core/src/glwe_trace.rs:129-176): host arrays of Galois elements / device key pointers per step
     pub fn pz_glwe_trace_batched(m: *mut pz_module, res: *mut i64, nsteps: usize, gals: *const i64, keys: *const *const f64,

@@ -987,3 +987,25 @@ def test_glwe_trace_batched(mods, fuse):
         for d in d_keys + [d_res]:
             d.free()
         assert np.array_equal(got, want), (n, rank, size)
+
+
+@pytest.mark.parametrize("n", [32, 1024, 65536])
+def test_vec_znx_rotate(mods, n):
+    """hal_impl.rs:225-232: res = X^k * a for any k (negative, > 2n), ragged sizes, the assign form, other columns untouched."""
+    ref, hip = mods(n)
+    rng = seeded(n + 5)
+    for k in (0, 1, -1, 7, n - 1, n, n + 1, 2 * n - 1, 2 * n, -n - 3, 5 * n + 2):
+        for (a_size, res_size) in ((3, 3), (2, 4), (4, 1)):
+            a = VecZnx(n, 2, a_size).fill_uniform(50, rng)
+            rr = VecZnx(n, 3, res_size).fill_uniform(60, rng)
+            rh = rr.copy()
+            ref.vec_znx_rotate(k, rr, 2, a, 1)
+            hip.vec_znx_rotate(k, rh, 2, a, 1)
+            assert np.array_equal(rr.data, rh.data), (k, a_size, res_size)
+            want = a.copy()
+            tmp = VecZnx(n, 2, a_size)
+            ref.vec_znx_rotate(k, tmp, 0, a, 1)
+            want.data[:, 1] = tmp.data[:, 0]
+            got = a.copy()
+            hip.vec_znx_rotate_assign(k, got, 1)
+            assert np.array_equal(got.data, want.data), (k, a_size)
