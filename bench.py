@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="ciphertexts per GPU per step (16 GiB of GLWE in + out at the metric shape)")
     ap.add_argument("--chunk", type=int, default=0, help="ciphertexts per pipeline wave (0 = auto)")
-    ap.add_argument("--op", choices=("external_product", "keyswitch", "automorphism", "automorphism_add", "trace"), default="external_product",
+    ap.add_argument("--op", choices=("external_product", "keyswitch", "automorphism", "automorphism_add", "trace", "ggsw_expand_row"), default="external_product",
                     help="keyswitch = BASELINE configs[2] (secondary metric; GGLWE rows 8, cols_in 1, cols_out 2); automorphism[_add] = "
                          "glwe_automorphism[_add] with Galois element 5 on the same key shape (CKKS-rotate shape of configs[4])")
     ap.add_argument("--n", type=int, default=0, help="override the ring degree (0 = 65536, the metric configuration); "
@@ -153,6 +153,7 @@ def main():
     ks = args.op != "external_product"
     auto_mode = {"automorphism": "automorphism", "automorphism_add": "add"}.get(args.op)
     trace = args.op == "trace"   # full glwe_trace: log2(N) steps of rsh + glwe_automorphism_add_assign, one key per step
+    expand = args.op == "ggsw_expand_row"   # batch/dnum GGSWs per step, each dnum rows x rank key switches (body on column col)
     cols_in = RANK_GLWE if ks else cols
     key_elems = N * DNUM * cols_in * cols * SIZE
     pmat = torch.empty(key_elems, dtype=torch.float64, device=dev)
@@ -175,9 +176,16 @@ def main():
     g.manual_seed(0x5EED0000 + rank)
     a = torch.randint(-half, half, (nct, SIZE, cols, N), dtype=torch.int64, device=dev, generator=g)
     res = torch.empty((nct, SIZE, cols, N), dtype=torch.int64, device=dev)
+    if expand:   # the GGSWs: entries (row, 0) = a, entries (row, col >= 1) are produced in place
+        del res
+        res = torch.empty((nct, cols, SIZE, cols, N), dtype=torch.int64, device=dev)
+        res[:, 0].copy_(a)
+        res[:, 1:].zero_()
     params = GlweOpParams(rank=RANK_GLWE, dnum=DNUM, dsize=1, key_size=SIZE, key_base2k=BASE2K, a_size=SIZE, a_base2k=BASE2K,
                           res_size=SIZE, res_base2k=BASE2K, rank_out=RANK_GLWE)
     a_ptr, res_ptr, key_ptr = C.c_void_p(a.data_ptr()), C.c_void_p(res.data_ptr()), C.c_void_p(pmat.data_ptr())
+    if expand and nct % DNUM:
+        raise SystemExit("--op ggsw_expand_row: --batch must be a multiple of the number of GGSW rows")
     if not args.no_pin_key:   # evaluation keys are immutable for the lifetime of the job: let the backend keep its row-sliced copy
         mod.pin_key(key_ptr, DNUM, cols_in, cols, SIZE)
     trace_keys, trace_gals = [], []
@@ -194,6 +202,8 @@ def main():
     def step():
         if trace:
             mod.glwe_trace_batched(res_ptr, trace_gals, [t.data_ptr() for t in trace_keys], params, nct)
+        elif expand:
+            mod.ggsw_expand_row_batched(res_ptr, DNUM, [key_ptr] * RANK_GLWE, params, nct // DNUM)
         elif auto_mode:
             mod.glwe_automorphism_batched(res_ptr, a_ptr, key_ptr, params, 5, auto_mode, nct)
         elif ks:
@@ -235,7 +245,7 @@ def main():
     ok = bool((res.min() >= -half).item() and hi_ok.item())
 
     if rank == 0:
-        total_units = args.batch * world * args.steps
+        total_units = args.batch * world * args.steps // (DNUM if expand else 1)
         value = total_units / dt
         b_unit = algorithmic_bytes_per_unit(args.batch) if not ks else (2 * cols * SIZE * N * 8 + DNUM * cols_in * cols * SIZE * N * 8 / args.batch)
         roof = None
@@ -250,15 +260,17 @@ def main():
                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(name, args.batch),
                         "avg_launch_ms": ms / cnt, "launches": cnt, "units_per_launch": units_per_launch,
                         "algorithmic_bytes_per_unit": b_unit,
-                        "pipeline_achieved": value / world * b_unit / 1e9,
+                        "pipeline_achieved": value * (DNUM if expand else 1) / world * b_unit / 1e9,
                         "kernel_ms": {k: round(v[1], 3) for k, v in stats.items() if v[0]}}
         line = {
-            "metric": (f"GLWE {args.op.replace('_', ' ')}s/sec (N=2^{N.bit_length() - 1}, {SIZE} limbs)" if (auto_mode or trace) else
+            "metric": (f"GGSW expand-rows/sec (N=2^{N.bit_length() - 1}, {SIZE} limbs, {DNUM} rows)" if expand else
+                       f"GLWE {args.op.replace('_', ' ')}s/sec (N=2^{N.bit_length() - 1}, {SIZE} limbs)" if (auto_mode or trace) else
                        f"GLWE key-switches/sec (N=2^{N.bit_length() - 1}, {SIZE} limbs)" if ks else f"GGSW external-products/sec (N=2^{N.bit_length() - 1}, {SIZE} limbs)"),
-            "value": value, "unit": (f"{args.op}s/s" if (auto_mode or trace) else "key-switches/s" if ks else "external-products/s"),
+            "value": value, "unit": ("GGSWs/s" if expand else f"{args.op}s/s" if (auto_mode or trace) else "key-switches/s" if ks else "external-products/s"),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"glwe_trace (log2 N steps of rsh + glwe_automorphism_add_assign, one key per step), N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}" if trace else
+            "config": {"workload": (f"ggsw_expand_row on batch/{DNUM} GGSWs of {DNUM} rows (rank {RANK_GLWE}: one key switch per row, body on column 1), N={N}, {SIZE} limbs, base2k={BASE2K}, key dnum={DNUM}" if expand else
+                                    f"glwe_trace (log2 N steps of rsh + glwe_automorphism_add_assign, one key per step), N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}" if trace else
                                     f"glwe_{args.op} (Galois element 5) via GGLWE VmpPMat, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize=1" if auto_mode else
                                     f"GLWE(rank 1) key-switch via GGLWE VmpPMat, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize=1" if ks else
                                     f"GLWE(rank 1) x GGSW external product, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize=1"),

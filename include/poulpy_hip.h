@@ -258,6 +258,14 @@ int pz_glwe_trace_batched(pz_module* m, int64_t* res, size_t nsteps, const int64
  * for the a_dnum * (rank+1) GLWE entries of the GGSW `a` (MatZnx layout: entries are contiguous), device pointers. */
 int pz_ggsw_external_product(pz_module* m, int64_t* res, const int64_t* a, size_t a_dnum, const double* ggsw_pmat,
                              const pz_glwe_op_params* p);
+/* CoreImpl ggsw_expand_row (poulpy-core/src/conversion/gglwe_to_ggsw.rs:116-268; the second half of ggsw_from_gglwe
+ * :32-61 and of circuit bootstrapping) on `count` contiguous GGSWs (MatZnx layout, rows = dnum, cols_in = cols_out =
+ * rank+1, size = p->res_size), in place: entry (row, col), col >= 1, becomes the key switch of the mask of entry (row, 0)
+ * by tsk_pmat[col-1] (= tsk.at(col-1), a prepared GGLWE rank -> rank) with the body of entry (row, 0) added to column
+ * `col`; entries (row, 0) are not written.  tsk_pmat is a HOST array of rank device pointers; p describes the key switch
+ * (a_size = res_size, a_base2k = res_base2k = the GGSW's; rank_out = rank). */
+int pz_ggsw_expand_row_batched(pz_module* m, int64_t* ggsw, size_t dnum, const double* const* tsk_pmat,
+                               const pz_glwe_op_params* p, size_t count);
 /* BlindRotationExecute<CGGI>::blind_rotation_execute (poulpy-bin-fhe/src/blind_rotation/algorithms/cggi/algorithm.rs:76-118)
  * on `batch` LWE ciphertexts that share the lookup table and the prepared blind-rotation key:
  *   block_size > 1 : execute_block_binary  (:265-368)       block_size == 1 : execute_standard (:370-440)

@@ -1473,7 +1473,7 @@ static void glwe_keyswitch_core(const pzr_tables* t, size_t rank_in, size_t rank
                                 int64_t* res, size_t res_size, size_t res_base2k,
                                 const int64_t* a, size_t a_size, size_t a_base2k,
                                 const double* key_pmat, size_t dnum, size_t key_size, size_t dsize, size_t key_base2k,
-                                int mode, int64_t p) {
+                                int mode, int64_t p, size_t body_col) {
     size_t n = t->m << 1;
     size_t cols_a = rank_in + 1;
     size_t cols_out = rank_out + 1;
@@ -1518,7 +1518,8 @@ static void glwe_keyswitch_core(const pzr_tables* t, size_t rank_in, size_t rank
     }
     pzr_vec_znx_idft_apply_consume(t, res_dft, cols_out, key_size);
     int64_t* res_big = (int64_t*)res_dft;
-    pzr_vec_znx_big_add_small_assign(n, res_big, cols_out, key_size, 0, a, cols_a, a_size, 0); /* glwe.rs:237 */
+    /* glwe.rs:237 (body_col = 0); conversion/gglwe_to_ggsw.rs:251 adds it to column `col` instead */
+    pzr_vec_znx_big_add_small_assign(n, res_big, cols_out, key_size, body_col, a, cols_a, a_size, 0);
     for (size_t i = 0; i < cols_out; ++i) {
         if (mode == PZR_KS_AUTO_ADD || mode == PZR_KS_AUTO_SUB || mode == PZR_KS_AUTO_SUB_NEGATE) {
             /* glwe_ct.rs:134-137 / :223-226 / :269-272 (a is a_conv when the bases differ: :126-130) */
@@ -1542,7 +1543,7 @@ void pzr_glwe_keyswitch(const pzr_tables* t, size_t rank_in, size_t rank_out,
                         const int64_t* a, size_t a_size, size_t a_base2k,
                         const double* key_pmat, size_t dnum, size_t key_size, size_t dsize, size_t key_base2k) {
     glwe_keyswitch_core(t, rank_in, rank_out, res, res_size, res_base2k, a, a_size, a_base2k, key_pmat, dnum, key_size, dsize,
-                        key_base2k, PZR_KS_PLAIN, 0);
+                        key_base2k, PZR_KS_PLAIN, 0, 0);
 }
 
 /* automorphism/glwe_ct.rs:51-275: `mode` selects glwe_automorphism / _add / _sub / _sub_negate; the key is the prepared
@@ -1552,7 +1553,26 @@ void pzr_glwe_automorphism(const pzr_tables* t, size_t rank, int mode, int64_t p
                            const int64_t* a, size_t a_size, size_t a_base2k,
                            const double* key_pmat, size_t dnum, size_t key_size, size_t dsize, size_t key_base2k) {
     glwe_keyswitch_core(t, rank, rank, res, res_size, res_base2k, a, a_size, a_base2k, key_pmat, dnum, key_size, dsize,
-                        key_base2k, mode, p);
+                        key_base2k, mode, p, 0);
+}
+
+/* conversion/gglwe_to_ggsw.rs:116-162 (ggsw_expand_row_default) + :182-268 (ggsw_expand_rows_internal): for every row
+ * of the GGSW, column `col` >= 1 is the gglwe product of the mask of res.at(row, 0) with tsk.at(col - 1), plus the body
+ * of res.at(row, 0) added to column `col` of the big value, normalized into res.at(row, col).  That is the key-switch
+ * core with the body landing in column `col`; a_dft / a_0 (:140-158) are its a_conv / DFT of the mask, including the
+ * cross-base case (:152-158).  ggsw: MatZnx(rows = dnum, cols_in = cols, cols_out = cols, size); keys[c]: the prepared
+ * GGLWE tsk.at(c) (rank -> rank), c in [0, rank). */
+void pzr_ggsw_expand_row(const pzr_tables* t, size_t rank, int64_t* ggsw, size_t dnum, size_t size, size_t base2k,
+                         const double* const* keys, size_t key_dnum, size_t key_size, size_t dsize, size_t key_base2k) {
+    size_t n = t->m << 1;
+    size_t cols = rank + 1;
+    size_t ct = n * cols * size;
+    for (size_t row = 0; row < dnum; ++row) {
+        const int64_t* a = ggsw + (row * cols) * ct;
+        for (size_t col = 1; col < cols; ++col)
+            glwe_keyswitch_core(t, rank, rank, ggsw + (row * cols + col) * ct, size, base2k, a, size, base2k, keys[col - 1],
+                                key_dnum, key_size, dsize, key_base2k, PZR_KS_PLAIN, 0, col);
+    }
 }
 
 /* ------------------------------------------------------------------------ */

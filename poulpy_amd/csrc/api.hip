@@ -131,7 +131,7 @@ static bool tail_supported(const pz_module* M) { return (M->plan.f1b * M->plan.c
 static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
                                 int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
                                 int base2k, bool rowmajor, bool small_all, unsigned auto_mul, bool auto_neg, int col_base, int col_count,
-                                unsigned gather_mul = 0, bool gather_neg = false) {
+                                unsigned gather_mul = 0, bool gather_neg = false, int body_col = 0) {
     const FftPlan& pl = M->plan;
     const int blocks = batch * col_count * (pl.m2 / pl.cb);
     if (blocks == 0) return PZ_OK;
@@ -142,7 +142,7 @@ static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlim
     g.small_cols = small_cols; g.small_size = small_size; g.base2k = base2k; g.m2 = pl.m2;
     g.tw1inv = M->tw1inv; g.wL1 = M->wL1; g.margin = M->margin;
     g.small_all = small_all ? 1 : 0; g.auto_mul = auto_mul; g.auto_neg = auto_neg ? 1 : 0;
-    g.col_base = col_base; g.col_count = col_count;
+    g.col_base = col_base; g.col_count = col_count; g.body_col = body_col;
     g.gather_mul = gather_mul; g.gather_neg = gather_neg ? 1 : 0;
     g.xcd_map = (gather_mul != 0 && blocks % (8 * (pl.m2 / pl.cb)) == 0) ? 1 : 0;
     const bool has_small = small != nullptr;
@@ -168,20 +168,23 @@ static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlim
 #undef X
     return fail(PZ_ERR_UNSUPPORTED, "no fused tail kernel for m1=%d", pl.m1);
 }
-// The body operand of a key switch only exists for column 0: that column runs the variant that prefetches it (more
-// registers, one workgroup less per CU), the other columns the plain one.
+// The body operand of a key switch only exists for one column (0; `body_col` for ggsw_expand_row): that column runs the
+// variant that prefetches it (more registers, one workgroup less per CU), the other columns the plain one.
 static int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
                            int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
                            int base2k, bool rowmajor = false, bool small_all = false, unsigned auto_mul = 0, bool auto_neg = false,
-                           unsigned gather_mul = 0, bool gather_neg = false) {
+                           unsigned gather_mul = 0, bool gather_neg = false, int body_col = 0) {
     if (small != nullptr && !small_all && ncols > 1) {
         PZ_TRY(launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, small, small_bs, small_cols, small_size,
-                                    base2k, rowmajor, false, auto_mul, auto_neg, 0, 1));
+                                    base2k, rowmajor, false, auto_mul, auto_neg, body_col, 1, 0, false, body_col));
+        if (body_col > 0)
+            PZ_TRY(launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, nullptr, 0, small_cols, small_size,
+                                        base2k, rowmajor, false, 0, false, 0, body_col));
         return launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, nullptr, 0, small_cols, small_size,
-                                    base2k, rowmajor, false, 0, false, 1, ncols - 1);
+                                    base2k, rowmajor, false, 0, false, body_col + 1, ncols - 1 - body_col);
     }
     return launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, small, small_bs, small_cols, small_size, base2k,
-                                rowmajor, small_all, auto_mul, auto_neg, 0, ncols, gather_mul, gather_neg);
+                                rowmajor, small_all, auto_mul, auto_neg, 0, ncols, gather_mul, gather_neg, body_col);
 }
 
 static bool mid_supported(const pz_module* M, int npi, int npo) {
@@ -1333,8 +1336,13 @@ struct AutoSpec {
     long long p;
     int mode;
 };
+// ciphertexts that are not tightly packed (the entries of one column of a GGSW) and a body that lands in another column
+struct OpLayout {
+    long long a_stride, res_stride;  // in i64 elements between consecutive ciphertexts
+    int body_col;
+};
 static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double* pmat, const pz_glwe_op_params* p, size_t batch,
-                   const AutoSpec* au = nullptr) {
+                   const AutoSpec* au = nullptr, const OpLayout* lay = nullptr) {
     PZ_REQUIRE(p != nullptr, "null params");
     PZ_REQUIRE(p->dsize >= 1 && p->dnum >= 1 && p->key_size >= 1 && p->a_size >= 1 && p->res_size >= 1, "glwe op: empty shape");
     PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(a) && is_device_ptr(pmat), "batched entry points take device pointers");
@@ -1350,6 +1358,10 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
     const bool au_big = au && au->mode != 0;
     const unsigned au_p = au ? (unsigned)((unsigned long long)au->p & (2ull * (unsigned long long)n - 1ull)) : 0u;
     const unsigned au_g = au ? inv_mod_2n(au->p, n) : 0u;
+    const long long a_bs = lay ? lay->a_stride : a_ct, res_bs = lay ? lay->res_stride : res_ct;
+    const int body_col = lay ? lay->body_col : 0;
+    PZ_REQUIRE(!(au && lay), "glwe_automorphism: packed ciphertexts only");
+    PZ_REQUIRE(body_col >= 0 && body_col < s.cols_out, "body column out of range");
     if (au) {
         PZ_REQUIRE(ks && s.cols_a == s.cols_out, "glwe_automorphism: the key must map rank -> rank");
         PZ_REQUIRE((au->p & 1) != 0, "glwe_automorphism: the Galois element must be odd");
@@ -1381,7 +1393,7 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
         if (!pinned && (M->dbg_stages & 2)) PZ_TRY(launch_permute_pmat(M, pmat, Pp, nrows * ncols));
         for (size_t b0 = 0; b0 < batch; b0 += chunk) {
             const int nb = (int)std::min(chunk, batch - b0);
-            DV av{(void*)(a + (long long)b0 * a_ct), a_ct, s.cols_a, (int)p->a_size};
+            DV av{(void*)(a + (long long)b0 * a_bs), a_bs, s.cols_a, (int)p->a_size};
             if (s.convert) {
                 DV cv{a_conv, n * s.cols_a * s.a_size_eff, s.cols_a, s.a_size_eff};
                 for (int c = 0; c < s.cols_a; ++c)
@@ -1393,14 +1405,14 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
             PolyMap sm{a_size, s.cols_in, av.bs, (long long)av.cols * n, n, n * a_col0};
             if (M->dbg_stages & 1) PZ_TRY(launch_fwd_pass1(M, nb * npi, (const long long*)av.p, sm, T, true));
             if (M->dbg_stages & 2) PZ_TRY(launch_mid(M, nb, T, T2, Pp, npi, npo, nrows, ncols, mid_dummy));
-            int64_t* res_b = res + (long long)b0 * res_ct;
+            int64_t* res_b = res + (long long)b0 * res_bs;
             const long long* small = ks ? (const long long*)av.p : nullptr;
             long long small_bs = av.bs;
             // au_big: the operand -+phi^-1(a) (+ body for column 0) is gathered from `a` inside the tail (TailArgs::gather_mul)
             (void)small2;
-            if (M->dbg_stages & 4) PZ_TRY(launch_inv_tail(M, nb, T2, ksz, s.cols_out, (long long*)(au ? res_tmp : res_b), res_ct, s.cols_out, (int)p->res_size,
+            if (M->dbg_stages & 4) PZ_TRY(launch_inv_tail(M, nb, T2, ksz, s.cols_out, (long long*)(au ? res_tmp : res_b), au ? res_ct : res_bs, s.cols_out, (int)p->res_size,
                                    small, small_bs, s.cols_a, a_size, (int)p->res_base2k, true, au_big, au_big ? au_p : 0u, au && au->mode == 3,
-                                   au_big ? au_p : 0u, au_big && au->mode != 1));
+                                   au_big ? au_p : 0u, au_big && au->mode != 1, body_col));
             if (au) {
                 PolyMap tm{(int)p->res_size, s.cols_out, res_ct, (long long)s.cols_out * n, n, 0};
                 PZ_TRY(launch_automorphism(M, nb * (int)p->res_size * s.cols_out, (const long long*)res_tmp, tm, (long long*)res_b, tm, au_g,
@@ -1422,7 +1434,7 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
 
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const int nb = (int)std::min(chunk, batch - b0);
-        DV av{(void*)(a + (long long)b0 * a_ct), a_ct, s.cols_a, (int)p->a_size};
+        DV av{(void*)(a + (long long)b0 * a_bs), a_bs, s.cols_a, (int)p->a_size};
         if (s.convert) {  // glwe_normalize into the key's base (external_product/glwe.rs:124-132)
             DV cv{a_conv, n * s.cols_a * s.a_size_eff, s.cols_a, s.a_size_eff};
             for (int c = 0; c < s.cols_a; ++c)
@@ -1464,7 +1476,7 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
             }
         }
         DV rb{res_dft, rd.bs, s.cols_out, res_dft_size};
-        DV rv{(void*)(res + (long long)b0 * res_ct), res_ct, s.cols_out, (int)p->res_size};
+        DV rv{(void*)(res + (long long)b0 * res_bs), res_bs, s.cols_out, (int)p->res_size};
         if (au) {
             // op-by-op, as the reference: big value, body, [automorphism of the big value, +- a], normalize, [automorphism]
             PZ_TRY(dev_idft(M, nb, rb, 0, rb, 0, s.cols_out, res_dft_size, T));
@@ -1501,12 +1513,14 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
             PolyMap sm{res_dft_size, s.cols_out, rb.bs, (long long)s.cols_out * n, n, 0};
             PZ_TRY(launch_inv_pass2(M, nb * res_dft_size * s.cols_out, res_dft, sm, T));
             PZ_TRY(launch_inv_tail(M, nb, T, res_dft_size, s.cols_out, (long long*)rv.p, rv.bs, rv.cols, rv.size,
-                                   ks ? (const long long*)av.p : nullptr, av.bs, av.cols, a_size, (int)p->res_base2k));
+                                   ks ? (const long long*)av.p : nullptr, av.bs, av.cols, a_size, (int)p->res_base2k, false, false, 0, false, 0,
+                                   false, body_col));
         } else {
             PZ_TRY(dev_idft(M, nb, rb, 0, rb, 0, s.cols_out, res_dft_size, T));
             if (ks)  // body column added after the inverse transform (keyswitching/glwe.rs:237)
-                PZ_TRY(launch_ew(M, EW_ADD_I64, res_dft, rb.bs, (long long)s.cols_out * n, res_dft, rb.bs, (long long)s.cols_out * n,
-                                 av.p, av.bs, (long long)av.cols * n, std::min(res_dft_size, a_size), nb));
+                PZ_TRY(launch_ew(M, EW_ADD_I64, res_dft + (long long)body_col * n, rb.bs, (long long)s.cols_out * n,
+                                 res_dft + (long long)body_col * n, rb.bs, (long long)s.cols_out * n, av.p, av.bs, (long long)av.cols * n,
+                                 std::min(res_dft_size, a_size), nb));
             for (int c = 0; c < s.cols_out; ++c)
                 PZ_TRY(dev_normalize(M, nb, rv, (int)p->res_base2k, 0, c, rb, (int)p->key_base2k, c));
         }
@@ -1537,6 +1551,26 @@ int pz_ggsw_external_product(pz_module* M, int64_t* res, const int64_t* a, size_
     PZ_ENTER(M);
     PZ_REQUIRE(p != nullptr, "null params");
     return glwe_op(M, false, res, a, ggsw_pmat, p, a_dnum * (p->rank + 1));
+}
+
+// ggsw_expand_row (conversion/gglwe_to_ggsw.rs:116-268): column `col` >= 1 of every row is the key switch of the mask of
+// res.at(row, 0) by tsk.at(col - 1), with the body of res.at(row, 0) added to column `col` of the big value before the
+// normalization.  The entries (row, 0) of `count` contiguous GGSWs are `count * dnum` ciphertexts at a fixed stride, so
+// each column is one batched key switch; column 0 is left untouched.
+int pz_ggsw_expand_row_batched(pz_module* M, int64_t* ggsw, size_t dnum, const double* const* tsk_pmat, const pz_glwe_op_params* p,
+                               size_t count) {
+    PZ_ENTER(M);
+    PZ_REQUIRE(p != nullptr && tsk_pmat != nullptr, "null params");
+    PZ_REQUIRE(p->a_size == p->res_size && p->a_base2k == p->res_base2k, "ggsw_expand_row: a and res describe the same GGSW");
+    PZ_REQUIRE(dnum >= 1, "ggsw_expand_row: empty GGSW");
+    const size_t cols = p->rank + 1;
+    const long long ct = (long long)M->n * (long long)cols * (long long)p->res_size;
+    for (size_t col = 1; col < cols; ++col) {
+        PZ_REQUIRE(tsk_pmat[col - 1] != nullptr, "ggsw_expand_row: null tensor key");
+        OpLayout lay{ct * (long long)cols, ct * (long long)cols, (int)col};
+        PZ_TRY(glwe_op(M, true, ggsw + (long long)col * ct, ggsw, tsk_pmat[col - 1], p, count * dnum, nullptr, &lay));
+    }
+    return PZ_OK;
 }
 
 // vec_znx_rotate (hal_impl.rs:225) / vec_znx_rotate_assign (:232): res = X^k * a (reference/znx/rotate.rs:3-27), limbs of res

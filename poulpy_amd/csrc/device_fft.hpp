@@ -374,6 +374,7 @@ struct TailArgs {
     unsigned auto_mul;  // 0: no sign
     int auto_neg;
     int col_base, col_count;  // this launch covers columns [col_base, col_base + col_count) of the ncols
+    int body_col;             // without small_all: the column that receives `small` column 0 (0 for a key switch, `col` for ggsw_expand_row)
     // gather_mul != 0 (with small_all): the operand added before the carry chain is  -+phi^-1(small)[n] (+ small[col 0][n], the
     // key-switch body, for column 0), gathered here from the natural-order `small` instead of being prepared by a separate pass:
     //   phi^-1(a)[n] = +-a[(n * gather_mul) mod 2N]  (negated when that index is >= N); gather_neg: operand = -phi^-1(a) (sub modes).
@@ -481,7 +482,7 @@ k_inv_tail(TailArgs g) {
     long long* res_col = g.res + (long long)b * g.res_bs + (long long)col * n;
     const long long res_ls = (long long)g.res_cols * n;
     const long long* small_col =
-        (g.small && (col == 0 || g.small_all)) ? g.small + (long long)b * g.small_bs + (g.small_all ? (long long)col * n : 0) : nullptr;
+        (g.small && (col == g.body_col || g.small_all)) ? g.small + (long long)b * g.small_bs + (g.small_all ? (long long)col * n : 0) : nullptr;
     const long long small_ls = (long long)g.small_cols * n;
     // limbs of res beyond the precision of the big value are zero (normalize.rs:118-120)
     for (int j = L; j < g.res_size; ++j)
@@ -502,7 +503,7 @@ k_inv_tail(TailArgs g) {
         // key-switch body limb: requested first so that its latency hides behind the butterfly
         long long sm[SMALL ? 2 * RE : 1];
         if (SMALL && small_col && j < g.small_size && g.gather_mul) {
-            const long long* body = col == 0 ? g.small + (long long)b * g.small_bs + (long long)j * small_ls : nullptr;
+            const long long* body = col == g.body_col ? g.small + (long long)b * g.small_bs + (long long)j * small_ls : nullptr;
 #pragma unroll
             for (int e = 0; e < RE; ++e) {
                 const long long idx = (long long)(b_ov + R2 * PZ_TAIL_N1(e)) * g.m2 + c0 + b_cv;

@@ -106,6 +106,10 @@ unsafe extern "C" {
         p: *const pz_glwe_op_params, batch: usize) -> c_int;
     pub fn pz_ggsw_external_product(m: *mut pz_module, res: *mut i64, a: *const i64, a_dnum: usize, ggsw: *const f64,
         p: *const pz_glwe_op_params) -> c_int;
+    /// ggsw_expand_row (poulpy-core/src/conversion/gglwe_to_ggsw.rs:116-268), in place on `count` contiguous device GGSWs;
+    /// tsk: host array of `rank` device pointers (tsk.at(col - 1))
+    pub fn pz_ggsw_expand_row_batched(m: *mut pz_module, ggsw: *mut i64, dnum: usize, tsk: *const *const f64,
+        p: *const pz_glwe_op_params, count: usize) -> c_int;
 }
 
 #[repr(C)]

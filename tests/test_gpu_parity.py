@@ -533,6 +533,48 @@ def test_ggsw_external_product(mods):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n,rank,dnum,size,key_dnum,key_size,base2k,dsize,count", [
+    (256, 1, 3, 4, 4, 4, 13, 1, 1),     # five-kernel path (N below the fused plans)
+    (256, 2, 2, 3, 3, 5, 13, 1, 2),     # rank 2: two tensor keys, body in column 1 / 2; two GGSWs
+    (4096, 1, 2, 4, 4, 4, 14, 1, 3),    # fused pipeline, body column 1
+    (4096, 2, 2, 3, 3, 4, 13, 1, 1),    # fused pipeline, rank 2: body columns 1 and 2 (split column launches)
+    (8192, 3, 1, 2, 2, 3, 12, 1, 1),    # rank 3
+    (1024, 1, 2, 4, 2, 5, 12, 2, 2),    # dsize 2
+    (65536, 1, 2, 8, 8, 8, 12, 1, 1),   # metric-shape ring
+])
+def test_ggsw_expand_row_batched(mods, n, rank, dnum, size, key_dnum, key_size, base2k, dsize, count):
+    """conversion/gglwe_to_ggsw.rs:116-268 in place on `count` contiguous device GGSWs vs the oracle's restatement; column 0
+    entries must come back untouched."""
+    from poulpy_amd.hal import GlweOpParams
+    ref, hip = mods(n)
+    rng = seeded(900 + n + rank)
+    cols = rank + 1
+    keys_r, keys_d = [], []
+    for c in range(rank):
+        mat = MatZnx(n, key_dnum, rank, cols, key_size).fill_uniform(base2k, rng)
+        pr, ph = ref.vmp_pmat_alloc(key_dnum, rank, cols, key_size), hip.vmp_pmat_alloc(key_dnum, rank, cols, key_size)
+        ref.vmp_prepare(pr, mat)
+        hip.vmp_prepare(ph, mat)
+        hip.sync()
+        keys_r.append(pr)
+        keys_d.append(hip.device_alloc(ph.data.nbytes).upload(ph.data))
+    ggsws = [MatZnx(n, dnum, cols, cols, size).fill_uniform(base2k, rng) for _ in range(count)]
+    flat = np.stack([g.data for g in ggsws])
+    d = hip.device_alloc(flat.nbytes).upload(flat)
+    for g in ggsws:
+        ref.ggsw_expand_row(g, base2k, keys_r, dsize, base2k)
+    want = np.stack([g.data for g in ggsws])
+    p = GlweOpParams(rank=rank, dnum=key_dnum, dsize=dsize, key_size=key_size, key_base2k=base2k, a_size=size, a_base2k=base2k,
+                     res_size=size, res_base2k=base2k, rank_out=rank)
+    hip.ggsw_expand_row_batched(d.ptr, dnum, [k.ptr for k in keys_d], p, count)
+    hip.sync()
+    got = d.download(np.int64, want.size).reshape(want.shape)
+    for buf in keys_d + [d]:
+        buf.free()
+    assert np.array_equal(got[:, :, 0], flat[:, :, 0])
+    assert np.array_equal(got, want)
+
+
 # ------------------------------------------------------------------------------------------
 # SURVEY.md 8f rank 2 / BASELINE configs[3]: CGGI blind rotation on a batch of LWE ciphertexts
 # ------------------------------------------------------------------------------------------

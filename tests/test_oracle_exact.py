@@ -186,6 +186,36 @@ def test_external_product_and_keyswitch_match_exact(dsize):
     assert np.array_equal(res.data, want)
 
 
+@pytest.mark.parametrize("rank", [1, 2, 3])
+def test_P8_ggsw_expand_row_matches_exact(rank):
+    """conversion/gglwe_to_ggsw.rs:116-268 restated in the oracle vs exact integers: res.at(row, col) = normalize(mask of
+    res.at(row, 0) x tsk.at(col-1) + body of res.at(row, 0) on column col); column 0 untouched."""
+    n, base2k = 32, 13
+    cols = rank + 1
+    R = RefModule(n)
+    rng = seeded(800 + rank)
+    dnum, size, key_dnum, key_size = 2, 3, 3, 4
+    ggsw = MatZnx(n, dnum, cols, cols, size).fill_uniform(base2k, rng)
+    before = ggsw.data.copy()
+    mats, keys = [], []
+    for c in range(rank):
+        mat = MatZnx(n, key_dnum, rank, cols, key_size).fill_uniform(base2k, rng)
+        pm = R.vmp_pmat_alloc(key_dnum, rank, cols, key_size)
+        R.vmp_prepare(pm, mat)
+        mats.append(mat)
+        keys.append(pm)
+    R.ggsw_expand_row(ggsw, base2k, keys, 1, base2k)
+    for row in range(dnum):
+        a = before[row, 0]  # (size, cols, n)
+        assert np.array_equal(ggsw.data[row, 0], a)
+        for col in range(1, cols):
+            big = exact.vmp_exact(np.ascontiguousarray(a[:, 1:, :]), mats[col - 1].data, 0, key_size)
+            big[:size, col, :] += a[:, 0, :].astype(object)
+            for c in range(cols):
+                want = exact.normalize_exact(big[:, c, :], base2k, size)
+                assert np.array_equal(ggsw.data[row, col, :, c, :], want), (rank, row, col, c)
+
+
 @pytest.mark.parametrize("n", [8, 64, 1024])
 def test_P5_vec_znx_automorphism_direct(n):
     """reference/znx/automorphism.rs restated (sequential index walk) vs the direct statement of X -> X^p, incl. the
