@@ -266,6 +266,11 @@ int pz_ggsw_external_product(pz_module* m, int64_t* res, const int64_t* a, size_
  * (a_size = res_size, a_base2k = res_base2k = the GGSW's; rank_out = rank). */
 int pz_ggsw_expand_row_batched(pz_module* m, int64_t* ggsw, size_t dnum, const double* const* tsk_pmat,
                                const pz_glwe_op_params* p, size_t count);
+/* CoreImpl ggsw_from_gglwe (poulpy-core/src/conversion/gglwe_to_ggsw.rs:32-61) on `count` contiguous device GGLWEs `a`
+ * (MatZnx layout, rows = dnum, cols_in = a_cols_in, cols_out = rank+1, size = p->res_size: same size and base as the
+ * GGSW) -> `count` contiguous GGSWs: entries (row, 0) are copied from a.at(row, 0), then pz_ggsw_expand_row_batched. */
+int pz_ggsw_from_gglwe_batched(pz_module* m, int64_t* ggsw, const int64_t* a, size_t a_cols_in, size_t dnum,
+                               const double* const* tsk_pmat, const pz_glwe_op_params* p, size_t count);
 /* BlindRotationExecute<CGGI>::blind_rotation_execute (poulpy-bin-fhe/src/blind_rotation/algorithms/cggi/algorithm.rs:76-118)
  * on `batch` LWE ciphertexts that share the lookup table and the prepared blind-rotation key:
  *   block_size > 1 : execute_block_binary  (:265-368)       block_size == 1 : execute_standard (:370-440)

@@ -169,6 +169,10 @@ class Module {  // Module<FFT64Hip>, poulpy-hal/src/layouts/module.rs:97-189
     void ggsw_external_product(int64_t* res, const int64_t* a, size_t a_dnum, const double* ggsw, const pz_glwe_op_params& p) {
         check(pz_ggsw_external_product(m_, res, a, a_dnum, ggsw, &p), "ggsw_external_product");
     }
+    void ggsw_from_gglwe_batched(int64_t* ggsw, const int64_t* a, size_t a_cols_in, size_t dnum, const double* const* tsk,
+                                 const pz_glwe_op_params& p, size_t count) {
+        check(pz_ggsw_from_gglwe_batched(m_, ggsw, a, a_cols_in, dnum, tsk, &p, count), "ggsw_from_gglwe_batched");
+    }
     void ggsw_expand_row_batched(int64_t* ggsw, size_t dnum, const double* const* tsk, const pz_glwe_op_params& p, size_t count) {
         check(pz_ggsw_expand_row_batched(m_, ggsw, dnum, tsk, &p, count), "ggsw_expand_row_batched");
     }

@@ -1575,6 +1575,24 @@ void pzr_ggsw_expand_row(const pzr_tables* t, size_t rank, int64_t* ggsw, size_t
     }
 }
 
+/* conversion/gglwe_to_ggsw.rs:32-61 (ggsw_from_gglwe_default): res.at(row, 0) <- a.at(row, 0) (glwe_copy,
+ * api/operations.rs:557-577: vec_znx_copy per column = the common limbs, zero tail), then ggsw_expand_row.
+ * a: the GGLWE, MatZnx(rows = dnum, cols_in = a_cols_in, cols_out = rank+1, a_size). */
+void pzr_ggsw_from_gglwe(const pzr_tables* t, size_t rank, int64_t* ggsw, size_t dnum, size_t size, size_t base2k,
+                         const int64_t* a, size_t a_cols_in, size_t a_size,
+                         const double* const* keys, size_t key_dnum, size_t key_size, size_t dsize, size_t key_base2k) {
+    size_t n = t->m << 1;
+    size_t cols = rank + 1;
+    size_t min_size = zmin(size, a_size);
+    for (size_t row = 0; row < dnum; ++row) {
+        int64_t* r = ggsw + (row * cols) * (n * cols * size);
+        const int64_t* src = a + (row * a_cols_in) * (n * cols * a_size);
+        memcpy(r, src, n * cols * min_size * sizeof(int64_t));
+        memset(r + n * cols * min_size, 0, n * cols * (size - min_size) * sizeof(int64_t));
+    }
+    pzr_ggsw_expand_row(t, rank, ggsw, dnum, size, base2k, keys, key_dnum, key_size, dsize, key_base2k);
+}
+
 /* ------------------------------------------------------------------------ */
 /* poulpy-bin-fhe blind rotation (CGGI), SURVEY.md 8f rank 2                  */
 /* ------------------------------------------------------------------------ */

@@ -151,6 +151,11 @@ void pzr_glwe_automorphism(const pzr_tables* t, size_t rank, int mode, int64_t p
 void pzr_ggsw_expand_row(const pzr_tables* t, size_t rank, int64_t* ggsw, size_t dnum, size_t size, size_t base2k,
                          const double* const* keys, size_t key_dnum, size_t key_size, size_t dsize, size_t key_base2k);
 
+/* conversion/gglwe_to_ggsw.rs:32-61 (ggsw_from_gglwe): copy of the a.at(row, 0) entries, then ggsw_expand_row */
+void pzr_ggsw_from_gglwe(const pzr_tables* t, size_t rank, int64_t* ggsw, size_t dnum, size_t size, size_t base2k,
+                         const int64_t* a, size_t a_cols_in, size_t a_size,
+                         const double* const* keys, size_t key_dnum, size_t key_size, size_t dsize, size_t key_base2k);
+
 /* reference/vec_znx/rotate.rs:10-36, mul_xp_minus_one.rs:23-37, normalize.rs:403-425 */
 void pzr_vec_znx_rotate(size_t n, int64_t p, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
                         const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);

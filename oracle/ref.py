@@ -245,6 +245,14 @@ class RefModule:
         self.lib.pzr_ggsw_expand_row(self.t, c_size_t(rank), _p(ggsw.data), *_sz(ggsw.rows, ggsw.size, base2k), arr,
                                      *_sz(keys[0].rows, keys[0].size, dsize, key_base2k))
 
+    def ggsw_from_gglwe(self, ggsw, base2k, a, keys, dsize, key_base2k):
+        """conversion/gglwe_to_ggsw.rs:32-61; a: the GGLWE as a MatZnx (rows = dnum, cols_in, cols_out = rank+1)."""
+        rank = ggsw.cols_out - 1
+        assert a.rows == ggsw.rows and a.cols_out == ggsw.cols_out
+        arr = (C.c_void_p * len(keys))(*[k.data.ctypes.data for k in keys])
+        self.lib.pzr_ggsw_from_gglwe(self.t, c_size_t(rank), _p(ggsw.data), *_sz(ggsw.rows, ggsw.size, base2k), _p(a.data),
+                                     *_sz(a.cols_in, a.size), arr, *_sz(keys[0].rows, keys[0].size, dsize, key_base2k))
+
     # blind rotation (poulpy-bin-fhe/src/blind_rotation/algorithms/cggi), SURVEY.md 8f rank 2
     def vec_znx_rotate(self, p, res, res_col, a, a_col):
         self.lib.pzr_vec_znx_rotate(c_size_t(self._n), c_int64(p), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),

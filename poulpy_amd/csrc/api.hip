@@ -1557,9 +1557,7 @@ int pz_ggsw_external_product(pz_module* M, int64_t* res, const int64_t* a, size_
 // res.at(row, 0) by tsk.at(col - 1), with the body of res.at(row, 0) added to column `col` of the big value before the
 // normalization.  The entries (row, 0) of `count` contiguous GGSWs are `count * dnum` ciphertexts at a fixed stride, so
 // each column is one batched key switch; column 0 is left untouched.
-int pz_ggsw_expand_row_batched(pz_module* M, int64_t* ggsw, size_t dnum, const double* const* tsk_pmat, const pz_glwe_op_params* p,
-                               size_t count) {
-    PZ_ENTER(M);
+static int ggsw_expand_row(pz_module* M, int64_t* ggsw, size_t dnum, const double* const* tsk_pmat, const pz_glwe_op_params* p, size_t count) {
     PZ_REQUIRE(p != nullptr && tsk_pmat != nullptr, "null params");
     PZ_REQUIRE(p->a_size == p->res_size && p->a_base2k == p->res_base2k, "ggsw_expand_row: a and res describe the same GGSW");
     PZ_REQUIRE(dnum >= 1, "ggsw_expand_row: empty GGSW");
@@ -1571,6 +1569,27 @@ int pz_ggsw_expand_row_batched(pz_module* M, int64_t* ggsw, size_t dnum, const d
         PZ_TRY(glwe_op(M, true, ggsw + (long long)col * ct, ggsw, tsk_pmat[col - 1], p, count * dnum, nullptr, &lay));
     }
     return PZ_OK;
+}
+int pz_ggsw_expand_row_batched(pz_module* M, int64_t* ggsw, size_t dnum, const double* const* tsk_pmat, const pz_glwe_op_params* p,
+                               size_t count) {
+    PZ_ENTER(M);
+    return ggsw_expand_row(M, ggsw, dnum, tsk_pmat, p, count);
+}
+
+// ggsw_from_gglwe (conversion/gglwe_to_ggsw.rs:32-61): entries (row, 0) of the GGSW are copies of the entries (row, 0) of
+// the GGLWE `a` (glwe_copy), then ggsw_expand_row.  `count` contiguous GGLWEs -> `count` contiguous GGSWs, one strided copy.
+int pz_ggsw_from_gglwe_batched(pz_module* M, int64_t* ggsw, const int64_t* a, size_t a_cols_in, size_t dnum,
+                               const double* const* tsk_pmat, const pz_glwe_op_params* p, size_t count) {
+    PZ_ENTER(M);
+    PZ_REQUIRE(p != nullptr, "null params");
+    PZ_REQUIRE(is_device_ptr(ggsw) && is_device_ptr(a), "batched entry points take device pointers");
+    PZ_REQUIRE(a_cols_in >= 1 && dnum >= 1, "ggsw_from_gglwe: empty GGLWE");
+    PZ_REQUIRE((const void*)ggsw != (const void*)a, "ggsw_from_gglwe: res must not alias a");
+    const size_t cols = p->rank + 1;
+    const long long n = (long long)M->n, ct = n * (long long)cols * (long long)p->res_size;
+    PZ_TRY(launch_ew(M, EW_COPY, ggsw, (long long)cols * ct, n, a, (long long)a_cols_in * ct, n, nullptr, 0, 0, (int)(cols * p->res_size),
+                     (int)(count * dnum)));
+    return ggsw_expand_row(M, ggsw, dnum, tsk_pmat, p, count);  // (the module lock is not recursive)
 }
 
 // vec_znx_rotate (hal_impl.rs:225) / vec_znx_rotate_assign (:232): res = X^k * a (reference/znx/rotate.rs:3-27), limbs of res

@@ -362,6 +362,11 @@ class Module:
         """poulpy-core external_product/ggsw.rs:54-58 on a device-resident GGSW (MatZnx layout)."""
         self._ck(self.lib.pz_ggsw_external_product(self.handle, res, a, c_size_t(a_dnum), ggsw_pmat, C.byref(params)))
 
+    def ggsw_from_gglwe_batched(self, ggsw: c_void_p, a: c_void_p, a_cols_in: int, dnum: int, tsk_pmats, params: GlweOpParams, count: int = 1):
+        """conversion/gglwe_to_ggsw.rs:32-61 on `count` contiguous device GGLWEs -> GGSWs."""
+        arr = (c_void_p * len(tsk_pmats))(*[k.value if isinstance(k, c_void_p) else int(k) for k in tsk_pmats])
+        self._ck(self.lib.pz_ggsw_from_gglwe_batched(self.handle, ggsw, a, *_sz(a_cols_in, dnum), arr, C.byref(params), c_size_t(count)))
+
     def ggsw_expand_row_batched(self, ggsw: c_void_p, dnum: int, tsk_pmats, params: GlweOpParams, count: int = 1):
         """conversion/gglwe_to_ggsw.rs:116-268 on `count` contiguous device GGSWs, in place; tsk_pmats: rank device pointers."""
         arr = (c_void_p * len(tsk_pmats))(*[k.value if isinstance(k, c_void_p) else int(k) for k in tsk_pmats])

@@ -108,6 +108,9 @@ unsafe extern "C" {
         p: *const pz_glwe_op_params) -> c_int;
     /// ggsw_expand_row (poulpy-core/src/conversion/gglwe_to_ggsw.rs:116-268), in place on `count` contiguous device GGSWs;
     /// tsk: host array of `rank` device pointers (tsk.at(col - 1))
+    /// ggsw_from_gglwe (conversion/gglwe_to_ggsw.rs:32-61): strided copy of a.at(row, 0), then ggsw_expand_row
+    pub fn pz_ggsw_from_gglwe_batched(m: *mut pz_module, ggsw: *mut i64, a: *const i64, a_cols_in: usize, dnum: usize,
+        tsk: *const *const f64, p: *const pz_glwe_op_params, count: usize) -> c_int;
     pub fn pz_ggsw_expand_row_batched(m: *mut pz_module, ggsw: *mut i64, dnum: usize, tsk: *const *const f64,
         p: *const pz_glwe_op_params, count: usize) -> c_int;
 }

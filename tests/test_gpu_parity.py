@@ -575,6 +575,43 @@ def test_ggsw_expand_row_batched(mods, n, rank, dnum, size, key_dnum, key_size, 
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n,rank,cols_in", [(256, 1, 1), (4096, 2, 2), (4096, 1, 3)])
+def test_ggsw_from_gglwe_batched(mods, n, rank, cols_in):
+    """conversion/gglwe_to_ggsw.rs:32-61: strided copy of the a.at(row, 0) entries + ggsw_expand_row, two GGLWEs per call."""
+    from poulpy_amd.hal import GlweOpParams
+    dnum, size, key_dnum, key_size, base2k, count = 2, 3, 3, 4, 13, 2
+    ref, hip = mods(n)
+    rng = seeded(950 + n + rank)
+    cols = rank + 1
+    keys_r, keys_d = [], []
+    for c in range(rank):
+        mat = MatZnx(n, key_dnum, rank, cols, key_size).fill_uniform(base2k, rng)
+        pr, ph = ref.vmp_pmat_alloc(key_dnum, rank, cols, key_size), hip.vmp_pmat_alloc(key_dnum, rank, cols, key_size)
+        ref.vmp_prepare(pr, mat)
+        hip.vmp_prepare(ph, mat)
+        hip.sync()
+        keys_r.append(pr)
+        keys_d.append(hip.device_alloc(ph.data.nbytes).upload(ph.data))
+    gglwes = [MatZnx(n, dnum, cols_in, cols, size).fill_uniform(base2k, rng) for _ in range(count)]
+    want = []
+    for a in gglwes:
+        g = MatZnx(n, dnum, cols, cols, size).fill_uniform(base2k, rng)   # stale contents must be overwritten
+        ref.ggsw_from_gglwe(g, base2k, a, keys_r, 1, base2k)
+        want.append(g.data)
+    want = np.stack(want)
+    flat_a = np.stack([a.data for a in gglwes])
+    d_a = hip.device_alloc(flat_a.nbytes).upload(flat_a)
+    d_g = hip.device_alloc(want.nbytes).upload(rng.integers(-9, 9, want.shape, dtype=np.int64))
+    p = GlweOpParams(rank=rank, dnum=key_dnum, dsize=1, key_size=key_size, key_base2k=base2k, a_size=size, a_base2k=base2k,
+                     res_size=size, res_base2k=base2k, rank_out=rank)
+    hip.ggsw_from_gglwe_batched(d_g.ptr, d_a.ptr, cols_in, dnum, [k.ptr for k in keys_d], p, count)
+    hip.sync()
+    got = d_g.download(np.int64, want.size).reshape(want.shape)
+    for buf in keys_d + [d_a, d_g]:
+        buf.free()
+    assert np.array_equal(got, want)
+
+
 # ------------------------------------------------------------------------------------------
 # SURVEY.md 8f rank 2 / BASELINE configs[3]: CGGI blind rotation on a batch of LWE ciphertexts
 # ------------------------------------------------------------------------------------------
