@@ -296,6 +296,31 @@ typedef struct {
 int pz_blind_rotation_execute_batched(pz_module* m, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
                                       const pz_blind_rotation_params* p, size_t batch);
 size_t pz_blind_rotation_workspace_bytes(const pz_module* m, const pz_blind_rotation_params* p, size_t batch);
+/* CircuitBootstrappingExecute::circuit_bootstrapping_execute_to_constant (poulpy-bin-fhe/src/circuit_bootstrapping/
+ * circuit.rs:177-195, core :219-370 with to_exponent = false) on `batch` LWE ciphertexts -> `batch` contiguous GGSWs
+ * (MatZnx layout, rows = res_dnum, cols_in = cols_out = rank+1, size = res_size), for the case the reference's own
+ * benchmark runs (poulpy-bench bench_suite/schemes/circuit_bootstrapping.rs): one base2k for the blind-rotation key, the
+ * automorphism keys, the tensor keys and the result, extension_factor = 1.  Other bases / the exponent mode stay on the
+ * generic per-op path.
+ *   lwe_2n, lut, brk   as for pz_blind_rotation_execute_batched (the shim builds the table with the reference's host code
+ *                      lookup_table.rs and passes gap = 2*lut.drift/extension_factor, circuit.rs:333)
+ *   gals / atk_pmats   HOST arrays, one per trace step 0..log_n (as for pz_glwe_trace_batched): prepared automorphism keys
+ *                      (rank -> rank, rows = atk_dnum, size = atk_size)
+ *   tsk_pmats          HOST array of rank prepared tensor keys tsk.at(c) (rows = tsk_dnum, size = tsk_size)
+ *   tmp                device scratch of pz_circuit_bootstrapping_tmp_bytes (the reference's `scratch`, circuit.rs:149-175) */
+typedef struct {
+    pz_blind_rotation_params br; /* res_size = limbs of the GLWE the rotation produces (brk layout = atk layout) */
+    uint64_t atk_dnum, atk_size;
+    uint64_t tsk_dnum, tsk_size;
+    uint64_t res_dnum, res_size; /* the output GGSW */
+    uint64_t gap;
+} pz_circuit_bootstrapping_params;
+size_t pz_circuit_bootstrapping_tmp_bytes(const pz_module* m, const pz_circuit_bootstrapping_params* p, size_t batch);
+int pz_circuit_bootstrapping_execute_to_constant_batched(pz_module* m, int64_t* ggsw, const int64_t* lwe_2n, const int64_t* lut,
+                                                         const double* brk, size_t nsteps, const int64_t* gals,
+                                                         const double* const* atk_pmats, const double* const* tsk_pmats,
+                                                         const pz_circuit_bootstrapping_params* p, void* tmp, size_t tmp_bytes,
+                                                         size_t batch);
 /* workspace the calls above need for `batch` ciphertexts (bytes, device); keyswitch: 0 external product, 1 key switch,
  * 2 automorphism family */
 size_t pz_glwe_op_workspace_bytes(const pz_module* m, const pz_glwe_op_params* p, size_t batch, int keyswitch);

@@ -169,6 +169,16 @@ class Module {  // Module<FFT64Hip>, poulpy-hal/src/layouts/module.rs:97-189
     void ggsw_external_product(int64_t* res, const int64_t* a, size_t a_dnum, const double* ggsw, const pz_glwe_op_params& p) {
         check(pz_ggsw_external_product(m_, res, a, a_dnum, ggsw, &p), "ggsw_external_product");
     }
+    void circuit_bootstrapping_execute_to_constant_batched(int64_t* ggsw, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
+                                                           size_t nsteps, const int64_t* gals, const double* const* atk,
+                                                           const double* const* tsk, const pz_circuit_bootstrapping_params& p, void* tmp,
+                                                           size_t tmp_bytes, size_t batch) {
+        check(pz_circuit_bootstrapping_execute_to_constant_batched(m_, ggsw, lwe_2n, lut, brk, nsteps, gals, atk, tsk, &p, tmp, tmp_bytes, batch),
+              "circuit_bootstrapping_execute_to_constant_batched");
+    }
+    size_t circuit_bootstrapping_tmp_bytes(const pz_circuit_bootstrapping_params& p, size_t batch) const {
+        return pz_circuit_bootstrapping_tmp_bytes(m_, &p, batch);
+    }
     void ggsw_from_gglwe_batched(int64_t* ggsw, const int64_t* a, size_t a_cols_in, size_t dnum, const double* const* tsk,
                                  const pz_glwe_op_params& p, size_t count) {
         check(pz_ggsw_from_gglwe_batched(m_, ggsw, a, a_cols_in, dnum, tsk, &p, count), "ggsw_from_gglwe_batched");

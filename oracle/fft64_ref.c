@@ -1779,3 +1779,43 @@ void pzr_glwe_trace_assign(const pzr_tables* t, size_t rank, int64_t* res, size_
     }
     free(a);
 }
+
+/* poulpy-bin-fhe/src/circuit_bootstrapping/circuit.rs:219-370 (circuit_bootstrap_core) with to_exponent = false and one
+ * base2k for the blind-rotation key, the automorphism keys, the tensor keys and the result, i.e. the `copy` branches of
+ * :326-327 and of glwe_trace (poulpy-core/src/glwe_trace.rs:114-115, :121-122).  The lookup table (:274-301, host code
+ * of lookup_table.rs) and gap = 2*lut.drift/extension_factor (:333) are inputs.
+ *   :321-331  acc = blind_rotation(lwe, lut) ; copy into the atk layout (same limbs)
+ *   :344-366  row i of the GGSW, column 0 = glwe_trace(acc, skip = 0) truncated to res_size limbs; acc = X^-gap * acc
+ *   :369      ggsw_expand_row */
+void pzr_circuit_bootstrap_to_constant(const pzr_tables* t, size_t rank, size_t base2k,
+                                       size_t n_lwe, size_t block_size, const int64_t* lwe_2n, const int64_t* lut, size_t lut_size,
+                                       const double* brk, size_t brk_dnum, size_t brk_size, size_t glwe_size, const double* x_pow_a,
+                                       size_t nsteps, const int64_t* gals, const double* const* atk, size_t atk_dnum, size_t atk_size,
+                                       int64_t* ggsw, size_t res_dnum, size_t res_size, size_t gap,
+                                       const double* const* tsk, size_t tsk_dnum, size_t tsk_size) {
+    size_t n = t->m << 1;
+    size_t cols = rank + 1;
+    size_t tmp_size = glwe_size > res_size ? glwe_size : res_size; /* glwe_trace.rs:107-112: k = max(a.k, res.k) */
+    int64_t* acc = (int64_t*)calloc(n * cols * glwe_size, sizeof(int64_t));
+    int64_t* rot = (int64_t*)calloc(n * cols * glwe_size, sizeof(int64_t));
+    int64_t* tmp = (int64_t*)calloc(n * cols * tmp_size, sizeof(int64_t));
+    pzr_blind_rotation_execute(t, rank, n_lwe, block_size, acc, glwe_size, base2k, lwe_2n, lut, lut_size, brk, brk_dnum, brk_size, x_pow_a);
+    size_t ct_res = n * cols * res_size;
+    for (size_t i = 0; i < res_dnum; ++i) {
+        /* glwe_trace.rs:114-115 glwe_copy(tmp, a): common limbs, zero tail */
+        memset(tmp, 0, n * cols * tmp_size * sizeof(int64_t));
+        memcpy(tmp, acc, n * cols * glwe_size * sizeof(int64_t));
+        pzr_glwe_trace_assign(t, rank, tmp, tmp_size, base2k, nsteps, gals, atk, atk_dnum, atk_size, 1);
+        /* glwe_trace.rs:121-122 glwe_copy(res, tmp): the first res_size limbs */
+        memcpy(ggsw + (i * cols) * ct_res, tmp, ct_res * sizeof(int64_t));
+        if (i + 1 < res_dnum) { /* circuit.rs:363-365 glwe_rotate_assign(-gap) */
+            for (size_t c = 0; c < cols; ++c)
+                pzr_vec_znx_rotate(n, -(int64_t)gap, rot, cols, glwe_size, c, acc, cols, glwe_size, c);
+            memcpy(acc, rot, n * cols * glwe_size * sizeof(int64_t));
+        }
+    }
+    pzr_ggsw_expand_row(t, rank, ggsw, res_dnum, res_size, base2k, tsk, tsk_dnum, tsk_size, 1, base2k);
+    free(acc);
+    free(rot);
+    free(tmp);
+}

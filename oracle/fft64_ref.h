@@ -175,6 +175,15 @@ void pzr_glwe_trace_assign(const pzr_tables* t, size_t rank, int64_t* res, size_
                            size_t nsteps, const int64_t* gals, const double* const* key_pmats,
                            size_t dnum, size_t key_size, size_t dsize);
 
+/* poulpy-bin-fhe/src/circuit_bootstrapping/circuit.rs:219-370, to_exponent = false, one base2k everywhere; the lookup
+ * table and gap (:274-301, :333) are inputs */
+void pzr_circuit_bootstrap_to_constant(const pzr_tables* t, size_t rank, size_t base2k,
+                                       size_t n_lwe, size_t block_size, const int64_t* lwe_2n, const int64_t* lut, size_t lut_size,
+                                       const double* brk, size_t brk_dnum, size_t brk_size, size_t glwe_size, const double* x_pow_a,
+                                       size_t nsteps, const int64_t* gals, const double* const* atk, size_t atk_dnum, size_t atk_size,
+                                       int64_t* ggsw, size_t res_dnum, size_t res_size, size_t gap,
+                                       const double* const* tsk, size_t tsk_dnum, size_t tsk_size);
+
 #ifdef __cplusplus
 }
 #endif

@@ -280,6 +280,21 @@ class RefModule:
         self.lib.pzr_blind_rotation_execute(self.t, *_sz(rank, n_lwe, block_size), _p(res.data), *_sz(res.size, base2k), _p(lwe_2n),
                                             _p(lut.data), c_size_t(lut.size), _p(brk), *_sz(dnum, brk_size), _p(x_pow_a))
 
+    def circuit_bootstrap_to_constant(self, ggsw, base2k, lwe_2n, lut, brk, brk_dnum, brk_size, glwe_size, block_size, x_pow_a, gals,
+                                      atk, tsk, gap):
+        """circuit_bootstrapping/circuit.rs:219-370 (to_exponent = false, one base2k); ggsw: MatZnx(res_dnum, cols, cols, res_size),
+        atk: prepared automorphism keys of the trace steps (with gals), tsk: the rank prepared tensor keys."""
+        rank = ggsw.cols_out - 1
+        n_lwe = lwe_2n.shape[0] - 1
+        ns = len(gals)
+        g = (c_int64 * ns)(*[int(x) for x in gals])
+        ap = (c_void_p * ns)(*[pm.data.ctypes.data for pm in atk])
+        tp = (c_void_p * len(tsk))(*[pm.data.ctypes.data for pm in tsk])
+        self.lib.pzr_circuit_bootstrap_to_constant(
+            self.t, *_sz(rank, base2k, n_lwe, block_size), _p(lwe_2n), _p(lut.data), c_size_t(lut.size), _p(brk),
+            *_sz(brk_dnum, brk_size, glwe_size), _p(x_pow_a), c_size_t(ns), g, ap, *_sz(atk[0].rows, atk[0].size), _p(ggsw.data),
+            *_sz(ggsw.rows, ggsw.size, gap), tp, *_sz(tsk[0].rows, tsk[0].size))
+
     # glwe_trace (poulpy-core/src/glwe_trace.rs) and the shift it uses
     def vec_znx_rsh_assign(self, base2k, k, res, res_col, scratch=None):
         self.lib.pzr_vec_znx_rsh_assign(c_size_t(self._n), *_sz(base2k, k), _p(res.data), *_sz(res.cols, res.size, res_col))

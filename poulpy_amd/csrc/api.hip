@@ -1647,9 +1647,8 @@ int pz_vec_znx_rsh_assign(pz_module* M, size_t base2k, size_t k, int64_t* res, s
 
 // glwe_trace_assign (poulpy-core/src/glwe_trace.rs:129-176) on `batch` ciphertexts, equal base2k for res and keys:
 //   for every step s:  res = rsh(res, 1 bit) on every column (operations/glwe.rs:1096-1112);  res = glwe_automorphism_add_assign(res, key_s)
-int pz_glwe_trace_batched(pz_module* M, int64_t* res, size_t nsteps, const int64_t* gals, const double* const* key_pmats,
-                          const pz_glwe_op_params* p, size_t batch) {
-    PZ_ENTER(M);
+static int glwe_trace(pz_module* M, int64_t* res, size_t nsteps, const int64_t* gals, const double* const* key_pmats,
+                      const pz_glwe_op_params* p, size_t batch) {
     PZ_REQUIRE(p != nullptr && (nsteps == 0 || (gals != nullptr && key_pmats != nullptr)), "glwe_trace: null argument");
     PZ_REQUIRE(p->a_size == p->res_size && p->a_base2k == p->res_base2k && p->res_base2k == p->key_base2k && p->rank_out == p->rank,
                "glwe_trace: res and keys must share base2k, and a/res one layout (the other cases re-normalize around this call)");
@@ -1665,6 +1664,12 @@ int pz_glwe_trace_batched(pz_module* M, int64_t* res, size_t nsteps, const int64
         PZ_TRY(glwe_op(M, true, res, res, key_pmats[s], p, batch, &au));
     }
     return PZ_OK;
+}
+
+int pz_glwe_trace_batched(pz_module* M, int64_t* res, size_t nsteps, const int64_t* gals, const double* const* key_pmats,
+                          const pz_glwe_op_params* p, size_t batch) {
+    PZ_ENTER(M);
+    return glwe_trace(M, res, nsteps, gals, key_pmats, p, batch);
 }
 
 // ------------------------------------------------------------------------------
@@ -1684,9 +1689,8 @@ size_t pz_blind_rotation_workspace_bytes(const pz_module* M, const pz_blind_rota
     return align256(batch * n8 * cols * p->res_size) + pz_glwe_op_workspace_bytes(M, &ep, batch, 0);
 }
 
-int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
-                                      const pz_blind_rotation_params* p, size_t batch) {
-    PZ_ENTER(M);
+static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
+                          const pz_blind_rotation_params* p, size_t batch) {
     PZ_REQUIRE(p != nullptr, "null params");
     PZ_REQUIRE(p->n_lwe >= 1 && p->block_size >= 1 && p->dnum >= 1 && p->brk_size >= 1 && p->res_size >= 1 && p->lut_size >= 1,
                "blind_rotation: empty shape");
@@ -1870,6 +1874,63 @@ int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t*
     DV tv{acc_tmp, res_ct, cols, rsz};
     for (int c = 0; c < cols; ++c) PZ_TRY(dev_normalize(M, B, rv, k, 0, c, tv, k, c));
     return PZ_OK;
+}
+
+int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
+                                      const pz_blind_rotation_params* p, size_t batch) {
+    PZ_ENTER(M);
+    return blind_rotation(M, res, lwe_2n, lut, brk, p, batch);
+}
+
+// ------------------------------------------------------------------------------
+// public: circuit bootstrapping LWE -> GGSW, constant mode, one base2k for every key and the result
+// poulpy-bin-fhe/src/circuit_bootstrapping/circuit.rs:219-370 (circuit_bootstrap_core, to_exponent = false):
+//   :321-331  acc = blind_rotation(lwe, lut)                                       (copy into the atk layout: same limbs)
+//   :344-366  entry (i, 0) of the GGSW = glwe_trace(X^(-i*gap) * acc, skip 0)       (the reference rotates acc in place between rows)
+//   :369      ggsw_expand_row
+// The dnum_res traces of one LWE are independent, so all batch * dnum_res of them run as one batched trace.
+// ------------------------------------------------------------------------------
+static inline size_t cbt_tmp_size(const pz_circuit_bootstrapping_params* p) { return (size_t)std::max(p->br.res_size, p->res_size); }
+size_t pz_circuit_bootstrapping_tmp_bytes(const pz_module* M, const pz_circuit_bootstrapping_params* p, size_t batch) {
+    if (!M || !p) return 0;
+    const size_t n8 = (size_t)M->n * 8, cols = p->br.rank + 1;
+    return align256(batch * n8 * cols * p->br.res_size) + align256(batch * p->res_dnum * n8 * cols * cbt_tmp_size(p));
+}
+int pz_circuit_bootstrapping_execute_to_constant_batched(pz_module* M, int64_t* ggsw, const int64_t* lwe_2n, const int64_t* lut,
+                                                         const double* brk, size_t nsteps, const int64_t* gals,
+                                                         const double* const* atk_pmats, const double* const* tsk_pmats,
+                                                         const pz_circuit_bootstrapping_params* p, void* tmp, size_t tmp_bytes,
+                                                         size_t batch) {
+    PZ_ENTER(M);
+    PZ_REQUIRE(p != nullptr, "null params");
+    PZ_REQUIRE(p->res_dnum >= 1 && p->res_size >= 1 && p->atk_dnum >= 1 && p->atk_size >= 1 && p->tsk_dnum >= 1 && p->tsk_size >= 1,
+               "circuit_bootstrapping: empty shape");
+    PZ_REQUIRE(is_device_ptr(ggsw) && is_device_ptr(tmp), "batched entry points take device pointers");
+    PZ_REQUIRE(tmp_bytes >= pz_circuit_bootstrapping_tmp_bytes(M, p, batch), "circuit_bootstrapping: tmp is smaller than pz_circuit_bootstrapping_tmp_bytes");
+    if (batch == 0) return PZ_OK;
+    const long long n = (long long)M->n;
+    const int cols = (int)p->br.rank + 1, gsz = (int)p->br.res_size, rsz = (int)p->res_size, tsz = (int)cbt_tmp_size(p);
+    const int rows = (int)p->res_dnum, B = (int)batch;
+    const long long ct_g = n * cols * gsz, ct_t = n * cols * tsz, ct_r = n * cols * rsz;
+    int64_t* acc = (int64_t*)tmp;
+    int64_t* tr = (int64_t*)((char*)tmp + align256((size_t)B * ct_g * 8));
+    PZ_TRY(blind_rotation(M, acc, lwe_2n, lut, brk, &p->br, batch));
+    if (tsz > gsz) PZ_HIP(hipMemsetAsync(tr, 0, (size_t)B * rows * ct_t * 8, M->stream));  // glwe_copy zero-extends (glwe_trace.rs:114)
+    for (int i = 0; i < rows; ++i) {
+        PolyMap sm{gsz, cols, ct_g, (long long)cols * n, n, 0};
+        PolyMap dm{gsz, cols, (long long)rows * ct_t, (long long)cols * n, n, (long long)i * ct_t};
+        PZ_TRY(launch_rotate(M, B * gsz * cols, (const long long*)acc, sm, (long long*)tr, dm, 0, gsz * cols, nullptr, 0, 0,
+                             -(long long)i * (long long)p->gap));
+    }
+    pz_glwe_op_params tp;
+    tp.rank = p->br.rank; tp.dnum = p->atk_dnum; tp.dsize = 1; tp.key_size = p->atk_size; tp.key_base2k = p->br.base2k;
+    tp.a_size = (uint64_t)tsz; tp.a_base2k = p->br.base2k; tp.res_size = (uint64_t)tsz; tp.res_base2k = p->br.base2k; tp.rank_out = p->br.rank;
+    PZ_TRY(glwe_trace(M, tr, nsteps, gals, atk_pmats, &tp, (size_t)B * rows));
+    // glwe_copy(res.at(i, 0), tmp) (glwe_trace.rs:121): the first res_size limbs, into the strided (row, 0) entries
+    PZ_TRY(launch_ew(M, EW_COPY, ggsw, (long long)cols * ct_r, n, tr, ct_t, n, nullptr, 0, 0, cols * rsz, B * rows));
+    pz_glwe_op_params ep = tp;
+    ep.dnum = p->tsk_dnum; ep.key_size = p->tsk_size; ep.a_size = (uint64_t)rsz; ep.res_size = (uint64_t)rsz;
+    return ggsw_expand_row(M, ggsw, p->res_dnum, tsk_pmats, &ep, batch);
 }
 
 }  // extern "C"

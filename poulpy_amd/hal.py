@@ -38,6 +38,12 @@ class BlindRotationParams(C.Structure):
     _fields_ = [(k, c_uint64) for k in ("rank", "n_lwe", "block_size", "dnum", "brk_size", "base2k", "res_size", "lut_size")]
 
 
+class CircuitBootstrappingParams(C.Structure):
+    """pz_circuit_bootstrapping_params (include/poulpy_hip.h)"""
+    _fields_ = [("br", BlindRotationParams)] + [(k, c_uint64) for k in ("atk_dnum", "atk_size", "tsk_dnum", "tsk_size", "res_dnum",
+                                                                         "res_size", "gap")]
+
+
 _lib = None
 
 
@@ -63,7 +69,8 @@ def load_library(path: str | None = None) -> C.CDLL:
                  "pz_bytes_of_vmp_pmat", "pz_vec_znx_idft_apply_tmp_bytes", "pz_vmp_prepare_tmp_bytes",
                  "pz_vmp_apply_dft_tmp_bytes", "pz_vmp_apply_dft_to_dft_tmp_bytes", "pz_vec_znx_big_normalize_tmp_bytes",
                  "pz_glwe_op_workspace_bytes", "pz_vec_znx_automorphism_assign_tmp_bytes",
-                 "pz_vec_znx_big_automorphism_assign_tmp_bytes", "pz_blind_rotation_workspace_bytes", "pz_vec_znx_rsh_tmp_bytes", "pz_vec_znx_rotate_assign_tmp_bytes"):
+                 "pz_vec_znx_big_automorphism_assign_tmp_bytes", "pz_blind_rotation_workspace_bytes", "pz_vec_znx_rsh_tmp_bytes", "pz_vec_znx_rotate_assign_tmp_bytes",
+                 "pz_circuit_bootstrapping_tmp_bytes"):
         getattr(lib, name).restype = c_size_t
     if path is None:
         _lib = lib
@@ -382,6 +389,20 @@ class Module:
                                        batch: int):
         """poulpy-bin-fhe blind_rotation/algorithms/cggi/algorithm.rs:76-118,265-440 on a batch of mod-switched LWE ciphertexts."""
         self._ck(self.lib.pz_blind_rotation_execute_batched(self.handle, res, lwe_2n, lut, brk, C.byref(params), c_size_t(batch)))
+
+    def circuit_bootstrapping_tmp_bytes(self, params: CircuitBootstrappingParams, batch: int) -> int:
+        return self.lib.pz_circuit_bootstrapping_tmp_bytes(self.handle, C.byref(params), c_size_t(batch))
+
+    def circuit_bootstrapping_execute_to_constant_batched(self, ggsw: c_void_p, lwe_2n: c_void_p, lut: c_void_p, brk: c_void_p, gals,
+                                                          atk_ptrs, tsk_ptrs, params: CircuitBootstrappingParams, tmp: c_void_p,
+                                                          tmp_bytes: int, batch: int):
+        """poulpy-bin-fhe circuit_bootstrapping/circuit.rs:177-195 (core :219-370, constant mode, one base2k) on a batch of LWEs."""
+        ns = len(gals)
+        g = (c_int64 * ns)(*[int(x) for x in gals])
+        ap = (c_void_p * ns)(*[k.value if isinstance(k, c_void_p) else int(k) for k in atk_ptrs])
+        tp = (c_void_p * len(tsk_ptrs))(*[k.value if isinstance(k, c_void_p) else int(k) for k in tsk_ptrs])
+        self._ck(self.lib.pz_circuit_bootstrapping_execute_to_constant_batched(self.handle, ggsw, lwe_2n, lut, brk, c_size_t(ns), g, ap, tp,
+                                                                               C.byref(params), tmp, c_size_t(tmp_bytes), c_size_t(batch)))
 
     def blind_rotation_workspace_bytes(self, params: BlindRotationParams, batch: int) -> int:
         return self.lib.pz_blind_rotation_workspace_bytes(self.handle, C.byref(params), c_size_t(batch))

@@ -129,3 +129,23 @@ pub fn check(status: c_int, what: &str) {
         panic!("{what}: libpoulpy_hip status {status}: {msg}");
     }
 }
+
+#[repr(C)]
+pub struct pz_circuit_bootstrapping_params {
+    pub br: pz_blind_rotation_params,
+    pub atk_dnum: u64,
+    pub atk_size: u64,
+    pub tsk_dnum: u64,
+    pub tsk_size: u64,
+    pub res_dnum: u64,
+    pub res_size: u64,
+    pub gap: u64,
+}
+
+extern "C" {
+    /// circuit_bootstrapping_execute_to_constant (poulpy-bin-fhe/src/circuit_bootstrapping/circuit.rs:177-195, :219-370), one base2k
+    pub fn pz_circuit_bootstrapping_tmp_bytes(m: *const pz_module, p: *const pz_circuit_bootstrapping_params, batch: usize) -> usize;
+    pub fn pz_circuit_bootstrapping_execute_to_constant_batched(m: *mut pz_module, ggsw: *mut i64, lwe_2n: *const i64, lut: *const i64,
+        brk: *const f64, nsteps: usize, gals: *const i64, atk: *const *const f64, tsk: *const *const f64,
+        p: *const pz_circuit_bootstrapping_params, tmp: *mut c_void, tmp_bytes: usize, batch: usize) -> c_int;
+}

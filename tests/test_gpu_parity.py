@@ -1088,3 +1088,83 @@ def test_vec_znx_rotate(mods, n):
             got = a.copy()
             hip.vec_znx_rotate_assign(k, got, 1)
             assert np.array_equal(got.data, want.data), (k, a_size)
+
+
+# ------------------------------------------------------------------------------------------
+# circuit bootstrapping (constant mode): blind rotation -> dnum traces of rotated copies -> ggsw_expand_row
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,rank,n_lwe,block_size,brk_dnum,glwe_size,res_dnum,res_size,batch", [
+    (256, 1, 6, 3, 2, 3, 2, 2, 2),     # GGSW narrower than the GLWE of the rotation (the reference bench's proportions)
+    (256, 2, 4, 2, 3, 4, 2, 2, 3),     # rank 2 as in poulpy-bench's circuit_bootstrapping shape
+    (512, 1, 4, 1, 2, 2, 3, 3, 2),     # standard (block_size 1) rotation; GGSW wider than the GLWE: zero-extended trace input
+    (1024, 2, 7, 7, 3, 4, 2, 2, 2),    # N = 1024, rank 2, block 7, size 4, dnum 3 (bench shape, short LWE)
+])
+def test_circuit_bootstrapping_to_constant(mods, n, rank, n_lwe, block_size, brk_dnum, glwe_size, res_dnum, res_size, batch):
+    """circuit_bootstrapping/circuit.rs:219-370 (constant mode, one base2k) through the C ABI vs the oracle's composition of the
+    pinned pieces (blind rotation, glwe_trace, rotate, ggsw_expand_row); random lookup table and gap."""
+    from poulpy_amd.hal import BlindRotationParams, CircuitBootstrappingParams
+    base2k, atk_dnum, tsk_dnum = 13, 3, 2
+    ref, hip = mods(n)
+    rng = seeded(1300 + n + rank)
+    cols = rank + 1
+    log_n = n.bit_length() - 1
+    gap = 2 * int(rng.integers(1, n // 8))
+
+    def prepared(rows, cols_in, size):
+        mat = MatZnx(n, rows, cols_in, cols, size).fill_uniform(base2k, rng)
+        pr, ph = ref.vmp_pmat_alloc(rows, cols_in, cols, size), hip.vmp_pmat_alloc(rows, cols_in, cols, size)
+        ref.vmp_prepare(pr, mat)
+        hip.vmp_prepare(ph, mat)
+        hip.sync()
+        return pr, ph
+
+    lut = VecZnx(n, 1, glwe_size).fill_uniform(base2k, rng)
+    brk_r = np.empty((n_lwe, n * brk_dnum * cols * cols * glwe_size), dtype=np.float64)
+    brk_h = np.empty_like(brk_r)
+    for i in range(n_lwe):
+        pr, ph = prepared(brk_dnum, cols, glwe_size)
+        brk_r[i], brk_h[i] = pr.data.reshape(-1), ph.data.reshape(-1)
+    tmp_size = max(glwe_size, res_size)
+    gals = [-1] + [pow(5, 1 << i, 2 * n) for i in range(log_n - 1)]
+    atk = [prepared(atk_dnum, rank, tmp_size) for _ in gals]
+    tsk = [prepared(tsk_dnum, rank, res_size + 1) for _ in range(rank)]
+    lwe = rng.integers(-n, n, (batch, n_lwe + 1), dtype=np.int64)
+    xpa = ref.blind_rotation_x_pow_a() if block_size > 1 else np.zeros((1, 1))
+    want = np.empty((batch, res_dnum, cols, res_size, cols, n), dtype=np.int64)
+    for b in range(batch):
+        g = MatZnx(n, res_dnum, cols, cols, res_size)
+        ref.circuit_bootstrap_to_constant(g, base2k, np.ascontiguousarray(lwe[b]), lut, brk_r, brk_dnum, glwe_size, glwe_size, block_size,
+                                          xpa, gals, [a[0] for a in atk], [t[0] for t in tsk], gap)
+        want[b] = g.data
+
+    bufs = []
+
+    def up(arr):
+        d = hip.device_alloc(arr.nbytes).upload(arr)
+        bufs.append(d)
+        return d
+
+    d_lwe, d_lut, d_brk = up(lwe), up(lut.data), up(brk_h)
+    d_atk = [up(a[1].data) for a in atk]
+    d_tsk = [up(t[1].data) for t in tsk]
+    d_res = up(rng.integers(-5, 5, want.shape, dtype=np.int64))   # stale contents must be overwritten
+    p = CircuitBootstrappingParams(
+        br=BlindRotationParams(rank=rank, n_lwe=n_lwe, block_size=block_size, dnum=brk_dnum, brk_size=glwe_size, base2k=base2k,
+                               res_size=glwe_size, lut_size=glwe_size),
+        atk_dnum=atk_dnum, atk_size=tmp_size, tsk_dnum=tsk_dnum, tsk_size=res_size + 1, res_dnum=res_dnum, res_size=res_size, gap=gap)
+    nbytes = hip.circuit_bootstrapping_tmp_bytes(p, batch)
+    assert nbytes > 0
+    d_tmp = hip.device_alloc(nbytes)
+    bufs.append(d_tmp)
+    with pytest.raises(Exception):   # undersized scratch is refused, as the reference's scratch.available() assert
+        hip.circuit_bootstrapping_execute_to_constant_batched(d_res.ptr, d_lwe.ptr, d_lut.ptr, d_brk.ptr, gals, [k.ptr for k in d_atk],
+                                                              [k.ptr for k in d_tsk], p, d_tmp.ptr, nbytes - 1, batch)
+    hip.circuit_bootstrapping_execute_to_constant_batched(d_res.ptr, d_lwe.ptr, d_lut.ptr, d_brk.ptr, gals, [k.ptr for k in d_atk],
+                                                          [k.ptr for k in d_tsk], p, d_tmp.ptr, nbytes, batch)
+    hip.sync()
+    got = d_res.download(np.int64, want.size).reshape(want.shape)
+    for buf in bufs:
+        buf.free()
+    assert np.array_equal(got[:, :, 0], want[:, :, 0]), "trace rows differ"
+    assert np.array_equal(got, want)
+
