@@ -1804,23 +1804,52 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
         for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {  // chunks_exact: a trailing partial block is ignored, as in the reference
             PZ_TRY(dev_dft_apply(M, B, 1, 0, ad, 0, rv, 0, cols, nullptr, T));                      // :319-321
             const int row_max = std::min(dnum * cols, cols * std::min(dnum, rsz));
-            if (M->fuse_mid && row_max <= 8 && cols * bsz <= 8) {
+            if (M->fuse_mid && row_max <= 12 && blk <= 64) {
                 // zero + block_size x (vmp, svp, add, sub) in one kernel, nothing but acc_add written (:321-337)
                 BrBlockArgs g;
                 g.acc_dft = (const cplx*)acc_dft; g.acc_add = (cplx*)acc_add; g.a_bs = ad.bs / 2; g.o_bs = aa.bs / 2;
                 g.brk = (const cplx*)brk; g.key_stride = (long long)(pmat_doubles / 2);
                 g.row_max = row_max; g.ncols = cols * bsz; g.m = (int)M->m; g.batch = B; g.i0 = b0; g.blk = blk;
                 g.lwe = (const long long*)lwe_2n; g.lwe_bs = lwe_bs; g.w2n = M->w2n;
+                static const int brl_dbg = getenv("POULPY_DBG_BRL") ? atoi(getenv("POULPY_DBG_BRL")) : 0;
+                g.dbg = brl_dbg; g.gx = g.gy = g.gz = 1; g.xcd = 0;
                 constexpr int CT = 2;
                 KTimer kt(M, PZ_K_VMP);
                 const int nc = cols * bsz;
                 const unsigned gx = (unsigned)((B + CT - 1) / CT), gy = (unsigned)((M->m + 255) / 256);
-                if (nc % 3 == 0 && nc % 4 != 0) {   // 3, 6: groups of 3
-                    if (row_max <= 6) hipLaunchKernelGGL((k_br_block<CT, 6, 3>), dim3(gx, gy, (unsigned)(nc / 3)), dim3(256), 0, M->stream, g);
-                    else hipLaunchKernelGGL((k_br_block<CT, 8, 3>), dim3(gx, gy, (unsigned)(nc / 3)), dim3(256), 0, M->stream, g);
+                // (input polynomials kept in registers, output columns per workgroup): rank 2 with 3-4 decomposition rows (the
+                // circuit-bootstrapping shape) has 9 or 12 inputs, so fewer columns per workgroup there
+                int mr, cgs;
+                if (row_max > 9 || (row_max > 8 && nc % 3 != 0)) { mr = 12; cgs = 2; }
+                else if (row_max > 8) { mr = 9; cgs = 3; }
+                else if (nc % 3 == 0 && nc % 4 != 0) { mr = row_max <= 6 ? 6 : 8; cgs = 3; }   // 3, 6 columns: groups of 3
+                else { mr = row_max <= 4 ? 4 : 8; cgs = 4; }
+                const int ngroups = (nc + cgs - 1) / cgs;
+                // keys staged in LDS once per 4 waves x 2 ciphertexts (k_br_block_lds): POULPY_DBG_BR_LDS = 0 never, 1 only for
+                // more than 8 inputs, 2 always
+                static const int br_lds = getenv("POULPY_DBG_BR_LDS") ? atoi(getenv("POULPY_DBG_BR_LDS")) : 2;
+                const bool use_lds = M->m % 64 == 0 && (br_lds >= 2 || (br_lds == 1 && row_max > 8));
+                bool launched = false;
+                if (use_lds) {
+                    g.gx = (B + 7) / 8; g.gy = (int)(M->m / 64); g.gz = ngroups;
+                    static const int br_xcd = getenv("POULPY_DBG_BR_XCD") ? atoi(getenv("POULPY_DBG_BR_XCD")) : 1;
+                    g.xcd = (br_xcd && (g.gx * g.gy) % 8 == 0) ? 1 : 0;
+                    const unsigned total = (unsigned)(g.gx * g.gy * g.gz);
+#define PZ_BRB(MR_, CG_)                                                                                           \
+    if (!launched && mr == MR_ && cgs == CG_) {                                                                    \
+        hipLaunchKernelGGL((k_br_block_lds<2, MR_, CG_>), dim3(total), dim3(256), 0, M->stream, g);                \
+        launched = true;                                                                                           \
+    }
+                    PZ_BRB(12, 2) PZ_BRB(9, 3) PZ_BRB(6, 3) PZ_BRB(8, 3) PZ_BRB(4, 4) PZ_BRB(8, 4)
+#undef PZ_BRB
                 } else {
-                    if (row_max <= 4) hipLaunchKernelGGL((k_br_block<CT, 4, 4>), dim3(gx, gy, (unsigned)((nc + 3) / 4)), dim3(256), 0, M->stream, g);
-                    else hipLaunchKernelGGL((k_br_block<CT, 8, 4>), dim3(gx, gy, (unsigned)((nc + 3) / 4)), dim3(256), 0, M->stream, g);
+#define PZ_BRB(MR_, CG_)                                                                                           \
+    if (!launched && mr == MR_ && cgs == CG_) {                                                                    \
+        hipLaunchKernelGGL((k_br_block<CT, MR_, CG_>), dim3(gx, gy, (unsigned)ngroups), dim3(256), 0, M->stream, g); \
+        launched = true;                                                                                           \
+    }
+                    PZ_BRB(12, 2) PZ_BRB(9, 3) PZ_BRB(6, 3) PZ_BRB(8, 3) PZ_BRB(4, 4) PZ_BRB(8, 4)
+#undef PZ_BRB
                 }
                 PZ_HIP(hipGetLastError());
             } else {

@@ -419,6 +419,8 @@ struct BrBlockArgs {
     const long long* lwe;  // [batch][n_lwe+1]
     long long lwe_bs;
     const cplx* w2n;
+    int dbg;               // diagnostic (tools/dbg): bit 0 no key loads, bit 1 no products, bit 2 no accumulator loads, bit 3 no LDS staging
+    int gx, gy, gz, xcd;   // k_br_block_lds: logical grid (ciphertext tiles, 64-point slices, column groups) of the 1-D launch
 };
 
 // grid = (ceil(batch/CT), m/256, column groups of CG): the column group is uniform per workgroup, so the key row
@@ -445,6 +447,22 @@ __global__ void __launch_bounds__(256) k_br_block(BrBlockArgs g) {
     for (int t = 0; t < CT; ++t)
 #pragma unroll
         for (int j = 0; j < CG; ++j) out[t][j] = make_double2(0.0, 0.0);
+    // The rotation amounts of the block are loaded once (lane l holds coefficient i0 + l; blk <= 64) and DFT(X^a)[q] of
+    // coefficient i+1 is fetched while coefficient i is multiplied: the lwe -> w2n chain is two dependent round trips that
+    // would otherwise sit in front of every coefficient.
+    unsigned aiv[CT];
+    cplx xn[CT];
+    {
+        const int li = min((int)(threadIdx.x & 63), g.blk - 1);
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int b = min(b0 + t, g.batch - 1);
+            aiv[t] = (unsigned)((unsigned long long)g.lwe[(long long)b * g.lwe_bs + 1 + g.i0 + li] & (unsigned long long)mask);
+        }
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+            xn[t] = g.w2n[((unsigned)__builtin_amdgcn_readlane((int)aiv[t], 0) * (4u * (unsigned)q + 1u)) & mask];
+    }
     // (a second register set prefetching coefficient i+1 drops the occupancy to one wave per SIMD and is 15 % slower)
     for (int i = g.i0; i < g.i0 + g.blk; ++i) {
         const cplx* K = g.brk + (long long)i * g.key_stride;
@@ -456,11 +474,13 @@ __global__ void __launch_bounds__(256) k_br_block(BrBlockArgs g) {
             for (int r = 0; r < MAXR; ++r) kv[j][r] = (K + (long long)(min(r, g.row_max - 1) * g.ncols + c) * g.m)[q];
         }
         cplx xm[CT];   // DFT(X^a)[q] for each ciphertext of the tile
+        {
+            const int nx = min(i + 1 - g.i0, g.blk - 1);
 #pragma unroll
-        for (int t = 0; t < CT; ++t) {
-            const int b = min(b0 + t, g.batch - 1);
-            const unsigned ai = (unsigned)((unsigned long long)g.lwe[(long long)b * g.lwe_bs + 1 + i] & (unsigned long long)mask);
-            xm[t] = g.w2n[(ai * (4u * (unsigned)q + 1u)) & mask];
+            for (int t = 0; t < CT; ++t) {
+                xm[t] = xn[t];
+                xn[t] = g.w2n[((unsigned)__builtin_amdgcn_readlane((int)aiv[t], nx) * (4u * (unsigned)q + 1u)) & mask];
+            }
         }
 #pragma unroll
         for (int j = 0; j < CG; ++j) {
@@ -481,6 +501,141 @@ __global__ void __launch_bounds__(256) k_br_block(BrBlockArgs g) {
                 out[t][j].y = (out[t][j].y + xv.y) - s.y;
             }
         }
+    }
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int b = b0 + t;
+        if (b < g.batch) {
+#pragma unroll
+            for (int j = 0; j < CG; ++j) {
+                const int c = cg * CG + j;
+                if (c < g.ncols) g.acc_add[(long long)b * g.o_bs + (long long)c * g.m + q] = out[t][j];
+            }
+        }
+    }
+}
+
+// Same block step for the shapes whose keys no longer stay L2-resident per ciphertext pair (rank 2 with 3-4 decomposition
+// rows: 9-12 input polynomials, 12-16 output columns): a workgroup is 4 waves x CT ciphertexts at 64 spectrum points, and the
+// CG x row_max key values of a coefficient are staged once per workgroup in LDS (double-buffered: the loads of coefficient
+// i+1 are in flight while coefficient i is multiplied), so every key value is fetched from L2 once per 4*CT ciphertexts
+// instead of once per 2.  The per-(ciphertext, column) FMA chains are the ones of k_br_block, in the same order.
+// Logical grid = (gx = ceil(batch / (4*CT)), gy = m/64, gz = column groups of CG), launched 1-D; requires m % 64 == 0.
+// The gz workgroups that read the same accumulator tile run back to back on ONE XCD (workgroup ids go round-robin over
+// the 8 XCDs), so the tile comes from HBM once and from that XCD's L2 afterwards, and the tiles an XCD works on at any
+// time share their 64-point key slice.
+template <int MAXR, int CG, int PER>
+__device__ __forceinline__ void brl_fetch(cplx (&nxt)[PER], const BrBlockArgs& g, int i, int w, int cg, int q) {
+    const cplx* K = g.brk + (long long)i * g.key_stride;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = min(u * 4 + w, CG * MAXR - 1);
+        const int j = e / MAXR, r = e % MAXR;
+        const int c = min(cg * CG + j, g.ncols - 1);
+        nxt[u] = (g.dbg & 1) ? make_double2(1.0, (double)e) : (K + (long long)(min(r, g.row_max - 1) * g.ncols + c) * g.m)[q];
+    }
+}
+template <int PER, int NE>
+__device__ __forceinline__ void brl_stage(const cplx (&nxt)[PER], cplx (*ks)[64], int w, int lane) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = u * 4 + w;
+        if (e < NE) ks[e][lane] = nxt[u];
+    }
+}
+template <int CT, int MAXR, int CG>
+__global__ void __launch_bounds__(256) k_br_block_lds(BrBlockArgs g) {
+    constexpr int NW = 4, NE = CG * MAXR, PER = (NE + NW - 1) / NW;
+    __shared__ cplx ks[2][NE][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int tile, cg;
+    if (g.xcd) {
+        const int L = blockIdx.x, k = L >> 3;
+        cg = k % g.gz;
+        tile = (k / g.gz) * 8 + (L & 7);
+    } else {
+        cg = blockIdx.x % g.gz;
+        tile = blockIdx.x / g.gz;
+    }
+    const int q = (tile / g.gx) * 64 + lane;
+    const int b0 = ((tile % g.gx) * NW + w) * CT;
+    const unsigned mask = 4u * (unsigned)g.m - 1u;
+    cplx a[CT][MAXR];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int b = min(b0 + t, g.batch - 1);
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r)
+            a[t][r] = (r < g.row_max && !(g.dbg & 4)) ? g.acc_dft[(long long)b * g.a_bs + (long long)r * g.m + q] : make_double2(0.0, (double)b);
+    }
+    cplx out[CT][CG];
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int j = 0; j < CG; ++j) out[t][j] = make_double2(0.0, 0.0);
+    cplx nxt[PER];
+    brl_fetch<MAXR, CG, PER>(nxt, g, g.i0, w, cg, q);
+    // rotation amounts of the block: lane l holds coefficient i0 + l (blk <= 64); DFT(X^a)[q] is fetched one coefficient ahead
+    unsigned aiv[CT];
+    cplx xn[CT];
+    {
+        const int li = min(lane, g.blk - 1);
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int b = min(b0 + t, g.batch - 1);
+            aiv[t] = (unsigned)((unsigned long long)g.lwe[(long long)b * g.lwe_bs + 1 + g.i0 + li] & (unsigned long long)mask);
+        }
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+            xn[t] = g.w2n[((unsigned)__builtin_amdgcn_readlane((int)aiv[t], 0) * (4u * (unsigned)q + 1u)) & mask];
+    }
+    brl_stage<PER, NE>(nxt, ks[0], w, lane);
+    __syncthreads();
+    const int iend = g.i0 + g.blk;
+    for (int i = g.i0; i < iend; ++i) {
+        const int buf = (i - g.i0) & 1;
+        brl_fetch<MAXR, CG, PER>(nxt, g, min(i + 1, iend - 1), w, cg, q);  // (unconditional: a guarded array stays in scratch)
+        cplx xm[CT];
+        {
+            const int nx = min(i + 1 - g.i0, g.blk - 1);
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                xm[t] = xn[t];
+                xn[t] = g.w2n[((unsigned)__builtin_amdgcn_readlane((int)aiv[t], nx) * (4u * (unsigned)q + 1u)) & mask];
+            }
+        }
+        cplx sacc[CT][CG];
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int j = 0; j < CG; ++j) sacc[t][j] = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            if (r < g.row_max && !(g.dbg & 2)) {
+#pragma unroll
+                for (int j = 0; j < CG; ++j) {
+                    const cplx kv = ks[buf][j * MAXR + r][lane];
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) {
+                        cplx& sv = sacc[t][j];
+                        sv.x = __builtin_fma(a[t][r].x, kv.x, sv.x);
+                        sv.x = __builtin_fma(-a[t][r].y, kv.y, sv.x);
+                        sv.y = __builtin_fma(a[t][r].x, kv.y, sv.y);
+                        sv.y = __builtin_fma(a[t][r].y, kv.x, sv.y);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CG; ++j)
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const cplx xv = cmul(xm[t], sacc[t][j]);
+                out[t][j].x = (out[t][j].x + xv.x) - sacc[t][j].x;
+                out[t][j].y = (out[t][j].y + xv.y) - sacc[t][j].y;
+            }
+        if (!(g.dbg & 8)) brl_stage<PER, NE>(nxt, ks[buf ^ 1], w, lane);
+        __syncthreads();
     }
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
