@@ -1735,7 +1735,8 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
             static const int force_ct = getenv("POULPY_DBG_BR_CT") ? atoi(getenv("POULPY_DBG_BR_CT")) : 0;
             const int cgsz = (ncols % 3 == 0 && ncols % 4 != 0) ? 3 : 4;  // 6 output polynomials: two groups of 3, no idle slot
             const int pj = m * ((ncols + cgsz - 1) / cgsz) <= NT ? 1 : 2;
-            if (M->fuse_mid && (m == 128 || m == 256 || m == 512) && NT % m == 0 && row_max <= 8 && ncols <= 8 &&
+            static const int br_one = getenv("POULPY_DBG_BR_ONE") ? atoi(getenv("POULPY_DBG_BR_ONE")) : 1;  // 0: composed path everywhere
+            if (br_one && M->fuse_mid && (m == 128 || m == 256 || m == 512) && NT % m == 0 && row_max <= 8 && ncols <= 8 &&
                 m * ((ncols + cgsz - 1) / cgsz) <= 2 * NT && fits(1, false)) {
                 // two ciphertexts per workgroup share every key value; with 64-bit accumulators when that fits in LDS, else
                 // with 32-bit digit accumulators (m = 128 is only built with one ciphertext per workgroup)
