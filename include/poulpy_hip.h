@@ -300,11 +300,13 @@ size_t pz_blind_rotation_workspace_bytes(const pz_module* m, const pz_blind_rota
  * circuit.rs:177-195, core :219-370 with to_exponent = false) on `batch` LWE ciphertexts -> `batch` contiguous GGSWs
  * (MatZnx layout, rows = res_dnum, cols_in = cols_out = rank+1, size = res_size), for the case the reference's own
  * benchmark runs (poulpy-bench bench_suite/schemes/circuit_bootstrapping.rs): one base2k for the blind-rotation key, the
- * automorphism keys, the tensor keys and the result, extension_factor = 1.  Other bases / the exponent mode stay on the
- * generic per-op path.
+ * automorphism keys, the tensor keys and the result, extension_factor = 1.  execute_to_exponent (:197-216) with
+ * log_gap_in == log_gap_out is the same call with the step list of the partial trace (post_process :418-420: steps
+ * log_n - log_gap_in + 1 .. log_n) and the table / mod-switch direction the shim builds for that mode (:276-301);
+ * other bases and the repacking branch of post_process (glwe_pack, :392-417) stay on the generic per-op path.
  *   lwe_2n, lut, brk   as for pz_blind_rotation_execute_batched (the shim builds the table with the reference's host code
  *                      lookup_table.rs and passes gap = 2*lut.drift/extension_factor, circuit.rs:333)
- *   gals / atk_pmats   HOST arrays, one per trace step 0..log_n (as for pz_glwe_trace_batched): prepared automorphism keys
+ *   gals / atk_pmats   HOST arrays, one per trace step skip..log_n (as for pz_glwe_trace_batched; skip = 0 in constant mode): prepared automorphism keys
  *                      (rank -> rank, rows = atk_dnum, size = atk_size)
  *   tsk_pmats          HOST array of rank prepared tensor keys tsk.at(c) (rows = tsk_dnum, size = tsk_size)
  *   tmp                device scratch of pz_circuit_bootstrapping_tmp_bytes (the reference's `scratch`, circuit.rs:149-175) */

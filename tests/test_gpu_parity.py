@@ -1093,13 +1093,14 @@ def test_vec_znx_rotate(mods, n):
 # ------------------------------------------------------------------------------------------
 # circuit bootstrapping (constant mode): blind rotation -> dnum traces of rotated copies -> ggsw_expand_row
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n,rank,n_lwe,block_size,brk_dnum,glwe_size,res_dnum,res_size,batch", [
-    (256, 1, 6, 3, 2, 3, 2, 2, 2),     # GGSW narrower than the GLWE of the rotation (the reference bench's proportions)
-    (256, 2, 4, 2, 3, 4, 2, 2, 3),     # rank 2 as in poulpy-bench's circuit_bootstrapping shape
-    (512, 1, 4, 1, 2, 2, 3, 3, 2),     # standard (block_size 1) rotation; GGSW wider than the GLWE: zero-extended trace input
-    (1024, 2, 7, 7, 3, 4, 2, 2, 2),    # N = 1024, rank 2, block 7, size 4, dnum 3 (bench shape, short LWE)
+@pytest.mark.parametrize("n,rank,n_lwe,block_size,brk_dnum,glwe_size,res_dnum,res_size,batch,skip", [
+    (256, 1, 6, 3, 2, 3, 2, 2, 2, 0),     # GGSW narrower than the GLWE of the rotation (the reference bench's proportions)
+    (256, 2, 4, 2, 3, 4, 2, 2, 3, 0),     # rank 2 as in poulpy-bench's circuit_bootstrapping shape
+    (512, 1, 4, 1, 2, 2, 3, 3, 2, 0),     # standard (block_size 1) rotation; GGSW wider than the GLWE: zero-extended trace input
+    (1024, 2, 7, 7, 3, 4, 2, 2, 2, 0),    # N = 1024, rank 2, block 7, size 4, dnum 3 (bench shape, short LWE)
+    (256, 1, 6, 3, 2, 3, 2, 2, 2, 3),     # partial trace (steps 3..log_n): the exponent mode's post_process with equal gaps (circuit.rs:418-420)
 ])
-def test_circuit_bootstrapping_to_constant(mods, n, rank, n_lwe, block_size, brk_dnum, glwe_size, res_dnum, res_size, batch):
+def test_circuit_bootstrapping_to_constant(mods, n, rank, n_lwe, block_size, brk_dnum, glwe_size, res_dnum, res_size, batch, skip):
     """circuit_bootstrapping/circuit.rs:219-370 (constant mode, one base2k) through the C ABI vs the oracle's composition of the
     pinned pieces (blind rotation, glwe_trace, rotate, ggsw_expand_row); random lookup table and gap."""
     from poulpy_amd.hal import BlindRotationParams, CircuitBootstrappingParams
@@ -1125,7 +1126,7 @@ def test_circuit_bootstrapping_to_constant(mods, n, rank, n_lwe, block_size, brk
         pr, ph = prepared(brk_dnum, cols, glwe_size)
         brk_r[i], brk_h[i] = pr.data.reshape(-1), ph.data.reshape(-1)
     tmp_size = max(glwe_size, res_size)
-    gals = [-1] + [pow(5, 1 << i, 2 * n) for i in range(log_n - 1)]
+    gals = ([-1] + [pow(5, 1 << i, 2 * n) for i in range(log_n - 1)])[skip:]   # glwe_trace.rs:166-168, steps skip..log_n
     atk = [prepared(atk_dnum, rank, tmp_size) for _ in gals]
     tsk = [prepared(tsk_dnum, rank, res_size + 1) for _ in range(rank)]
     lwe = rng.integers(-n, n, (batch, n_lwe + 1), dtype=np.int64)
