@@ -337,6 +337,13 @@ int pz_module_set_chunk(pz_module* m, size_t cts_per_chunk);
 /* Kernel-fusion knobs of the batched GLWE ops (both on by default; the unfused path is the per-op one,
  * kept selectable so that tests can compare the two bit for bit). */
 int pz_module_set_fusion(pz_module* m, int fuse_tail, int fuse_mid);
+/* The launch-bound composite calls (pz_blind_rotation_execute_batched, pz_glwe_trace_batched,
+ * pz_circuit_bootstrapping_execute_to_constant_batched: hundreds of short kernels per call) are captured into a HIP graph
+ * the second time they are issued with the same arguments and replayed as one graph launch afterwards (on by default;
+ * the buffers' CONTENTS may change between calls, their addresses and shapes are the key).  pz_module_graph_launches
+ * counts the calls served by a graph. */
+int pz_module_set_graphs(pz_module* m, int enable);
+uint64_t pz_module_graph_launches(const pz_module* m);
 /* Diagnostic only: run a subset of the fused pipeline's stages (bit 0 pass 1, bit 1 middle, bit 2 tail); outputs are
  * meaningless unless mask == 7.  Used by tools/dbg to measure stage overlap. */
 int pz_module_set_debug_stages(pz_module* m, int mask);

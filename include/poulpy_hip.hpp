@@ -179,6 +179,8 @@ class Module {  // Module<FFT64Hip>, poulpy-hal/src/layouts/module.rs:97-189
     size_t circuit_bootstrapping_tmp_bytes(const pz_circuit_bootstrapping_params& p, size_t batch) const {
         return pz_circuit_bootstrapping_tmp_bytes(m_, &p, batch);
     }
+    void set_graphs(bool enable) { check(pz_module_set_graphs(m_, enable ? 1 : 0), "set_graphs"); }
+    uint64_t graph_launches() const { return pz_module_graph_launches(m_); }
     void ggsw_from_gglwe_batched(int64_t* ggsw, const int64_t* a, size_t a_cols_in, size_t dnum, const double* const* tsk,
                                  const pz_glwe_op_params& p, size_t count) {
         check(pz_ggsw_from_gglwe_batched(m_, ggsw, a, a_cols_in, dnum, tsk, &p, count), "ggsw_from_gglwe_batched");

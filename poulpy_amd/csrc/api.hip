@@ -508,6 +508,80 @@ static int finish_call(pz_module* M, bool any_host) {
 static inline size_t vbytes(const pz_module* M, size_t cols, size_t size) { return (size_t)M->n * cols * size * 8; }
 
 // ------------------------------------------------------------------------------
+// HIP graphs for the launch-bound composite calls.  A blind rotation on the composed path is 5 launches per LWE block
+// (hundreds per call), a trace 6-8 per step: at small batches the kernels are shorter than their launch cost.  The first
+// call with a given argument set runs normally (it sizes the workspaces and builds tables: nothing that allocates or
+// synchronizes may happen under capture); the second one is captured on the module's stream and instantiated; from then on
+// the call is one hipGraphLaunch.  The key covers every value a kernel argument is derived from (pointers, shapes, the
+// module's workspaces and knobs); entries are evicted least-recently-used.  Capture failures fall back to plain launches.
+// ------------------------------------------------------------------------------
+struct KeyHash {
+    uint64_t h = 1469598103934665603ull;
+    void bytes(const void* p, size_t len) {
+        const unsigned char* c = (const unsigned char*)p;
+        for (size_t i = 0; i < len; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+    }
+    template <typename T> void add(const T& v) { bytes(&v, sizeof(T)); }
+};
+static void graph_key_module(const pz_module* M, KeyHash& k) {
+    k.add(M->ws); k.add(M->ws2); k.add(M->ws_bytes); k.add(M->ws2_bytes); k.add(M->fuse_mid); k.add(M->fuse_tail); k.add(M->chunk);
+    k.add(M->dbg_stages); k.add(M->probe); k.add(M->graph_epoch); k.add(M->w2n);
+}
+static void graph_drop(pz_module::GraphEntry& e) {
+    if (e.exec) (void)hipGraphExecDestroy(e.exec);
+    if (e.graph) (void)hipGraphDestroy(e.graph);
+    e.exec = nullptr; e.graph = nullptr;
+}
+template <typename F>
+static int with_graph(pz_module* M, uint64_t key, F&& body) {
+    static const int env_on = getenv("POULPY_DBG_GRAPHS") ? atoi(getenv("POULPY_DBG_GRAPHS")) : 1;
+    if (!env_on || !M->graphs_on || M->timing) return body();
+    pz_module::GraphEntry* e = nullptr;
+    for (auto& ge : M->graphs) if (ge.key == key) e = &ge;
+    if (e && e->exec) {
+        e->stamp = ++M->graph_clock;
+        PZ_HIP(hipGraphLaunch(e->exec, M->stream));
+        M->graph_launches++;
+        return PZ_OK;
+    }
+    if (!e) {  // first sight: plain run, remember the key
+        const int rc = body();
+        if (rc != PZ_OK) return rc;
+        if (M->graphs.size() >= 16) {
+            size_t lru = 0;
+            for (size_t i = 1; i < M->graphs.size(); ++i) if (M->graphs[i].stamp < M->graphs[lru].stamp) lru = i;
+            graph_drop(M->graphs[lru]);
+            M->graphs.erase(M->graphs.begin() + (long)lru);
+        }
+        M->graphs.push_back({key, nullptr, nullptr, ++M->graph_clock, false});
+        return PZ_OK;
+    }
+    if (e->failed) return body();
+    e->stamp = ++M->graph_clock;
+    if (hipStreamBeginCapture(M->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        e->failed = true;
+        return body();
+    }
+    const int rc = body();
+    hipGraph_t g = nullptr;
+    const hipError_t ce = hipStreamEndCapture(M->stream, &g);
+    hipGraphExec_t ex = nullptr;
+    if (rc == PZ_OK && ce == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess && ex) {
+        // (e may dangle if body() touched M->graphs: it does not — nested calls never go through with_graph)
+        e->graph = g; e->exec = ex;
+        PZ_HIP(hipGraphLaunch(ex, M->stream));
+        M->graph_launches++;
+        return PZ_OK;
+    }
+    (void)hipGetLastError();
+    if (g) (void)hipGraphDestroy(g);
+    e->failed = true;
+    if (rc != PZ_OK) return rc;
+    return body();  // nothing ran under the failed capture
+}
+
+// ------------------------------------------------------------------------------
 // public: misc
 // ------------------------------------------------------------------------------
 extern "C" {
@@ -554,6 +628,10 @@ void pz_module_free(pz_module* M) {
     for (auto& k : M->pinned) if (k.sliced) (void)hipFree(k.sliced);
     for (auto& t : M->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
     for (auto e : M->event_pool) (void)hipEventDestroy(e);
+    for (auto& ge : M->graphs) {
+        if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
+        if (ge.graph) (void)hipGraphDestroy(ge.graph);
+    }
     if (M->stream) (void)hipStreamDestroy(M->stream);
     delete M;
 }
@@ -568,6 +646,7 @@ int pz_module_sync(pz_module* M) {
 void* pz_module_stream(pz_module* M) { return M ? (void*)M->stream : nullptr; }
 int pz_module_set_chunk(pz_module* M, size_t c) {
     if (!M) return fail(PZ_ERR_INVALID, "null module");
+    M->graph_epoch++;
     M->chunk = c;
     return PZ_OK;
 }
@@ -581,6 +660,7 @@ int pz_module_set_fusion(pz_module* M, int fuse_tail, int fuse_mid) {
 // once here instead of on every batched call (saves 2 x key bytes of HBM traffic per call, ~3 % at the metric shape).
 int pz_module_pin_key(pz_module* M, const double* pmat, size_t rows, size_t cols_in, size_t cols_out, size_t size) {
     PZ_ENTER(M);
+    M->graph_epoch++;
     PZ_REQUIRE(is_device_ptr(pmat), "pz_module_pin_key takes a device pointer");
     PZ_REQUIRE(rows >= 1 && cols_in >= 1 && cols_out >= 1 && size >= 1, "pz_module_pin_key: empty shape");
     for (auto& k : M->pinned) PZ_REQUIRE(k.key != (const void*)pmat, "pz_module_pin_key: key already pinned");
@@ -599,6 +679,7 @@ int pz_module_pin_key(pz_module* M, const double* pmat, size_t rows, size_t cols
 }
 int pz_module_unpin_key(pz_module* M, const double* pmat) {
     PZ_ENTER(M);
+    M->graph_epoch++;
     for (size_t i = 0; i < M->pinned.size(); ++i)
         if (M->pinned[i].key == (const void*)pmat) {
             PZ_HIP(hipStreamSynchronize(M->stream));
@@ -608,6 +689,14 @@ int pz_module_unpin_key(pz_module* M, const double* pmat) {
         }
     return fail(PZ_ERR_INVALID, "pz_module_unpin_key: key is not pinned");
 }
+// HIP-graph replay of the composite calls (on by default); launches: number of calls served by a graph so far
+int pz_module_set_graphs(pz_module* M, int enable) {
+    if (!M) return fail(PZ_ERR_INVALID, "null module");
+    std::lock_guard<std::mutex> lock_(M->mu);
+    M->graphs_on = enable != 0;
+    return PZ_OK;
+}
+uint64_t pz_module_graph_launches(const pz_module* M) { return M ? (uint64_t)M->graph_launches : 0; }
 int pz_module_set_debug_stages(pz_module* M, int mask) {
     if (!M) return fail(PZ_ERR_INVALID, "null module");
     M->dbg_stages = mask;
@@ -1669,7 +1758,12 @@ static int glwe_trace(pz_module* M, int64_t* res, size_t nsteps, const int64_t* 
 int pz_glwe_trace_batched(pz_module* M, int64_t* res, size_t nsteps, const int64_t* gals, const double* const* key_pmats,
                           const pz_glwe_op_params* p, size_t batch) {
     PZ_ENTER(M);
-    return glwe_trace(M, res, nsteps, gals, key_pmats, p, batch);
+    KeyHash k;
+    k.add((int)1); k.add(res); k.add(nsteps); k.add(batch);
+    if (p) k.add(*p);
+    for (size_t s = 0; s < nsteps && gals && key_pmats; ++s) { k.add(gals[s]); k.add(key_pmats[s]); }
+    graph_key_module(M, k);
+    return with_graph(M, k.h, [&]() { return glwe_trace(M, res, nsteps, gals, key_pmats, p, batch); });
 }
 
 // ------------------------------------------------------------------------------
@@ -1909,7 +2003,11 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
 int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
                                       const pz_blind_rotation_params* p, size_t batch) {
     PZ_ENTER(M);
-    return blind_rotation(M, res, lwe_2n, lut, brk, p, batch);
+    KeyHash k;
+    k.add((int)2); k.add(res); k.add(lwe_2n); k.add(lut); k.add(brk); k.add(batch);
+    if (p) k.add(*p);
+    graph_key_module(M, k);
+    return with_graph(M, k.h, [&]() { return blind_rotation(M, res, lwe_2n, lut, brk, p, batch); });
 }
 
 // ------------------------------------------------------------------------------
@@ -1926,12 +2024,9 @@ size_t pz_circuit_bootstrapping_tmp_bytes(const pz_module* M, const pz_circuit_b
     const size_t n8 = (size_t)M->n * 8, cols = p->br.rank + 1;
     return align256(batch * n8 * cols * p->br.res_size) + align256(batch * p->res_dnum * n8 * cols * cbt_tmp_size(p));
 }
-int pz_circuit_bootstrapping_execute_to_constant_batched(pz_module* M, int64_t* ggsw, const int64_t* lwe_2n, const int64_t* lut,
-                                                         const double* brk, size_t nsteps, const int64_t* gals,
-                                                         const double* const* atk_pmats, const double* const* tsk_pmats,
-                                                         const pz_circuit_bootstrapping_params* p, void* tmp, size_t tmp_bytes,
-                                                         size_t batch) {
-    PZ_ENTER(M);
+static int circuit_bootstrapping(pz_module* M, int64_t* ggsw, const int64_t* lwe_2n, const int64_t* lut, const double* brk, size_t nsteps,
+                                 const int64_t* gals, const double* const* atk_pmats, const double* const* tsk_pmats,
+                                 const pz_circuit_bootstrapping_params* p, void* tmp, size_t tmp_bytes, size_t batch) {
     PZ_REQUIRE(p != nullptr, "null params");
     PZ_REQUIRE(p->res_dnum >= 1 && p->res_size >= 1 && p->atk_dnum >= 1 && p->atk_size >= 1 && p->tsk_dnum >= 1 && p->tsk_size >= 1,
                "circuit_bootstrapping: empty shape");
@@ -1961,6 +2056,24 @@ int pz_circuit_bootstrapping_execute_to_constant_batched(pz_module* M, int64_t* 
     pz_glwe_op_params ep = tp;
     ep.dnum = p->tsk_dnum; ep.key_size = p->tsk_size; ep.a_size = (uint64_t)rsz; ep.res_size = (uint64_t)rsz;
     return ggsw_expand_row(M, ggsw, p->res_dnum, tsk_pmats, &ep, batch);
+}
+int pz_circuit_bootstrapping_execute_to_constant_batched(pz_module* M, int64_t* ggsw, const int64_t* lwe_2n, const int64_t* lut,
+                                                         const double* brk, size_t nsteps, const int64_t* gals,
+                                                         const double* const* atk_pmats, const double* const* tsk_pmats,
+                                                         const pz_circuit_bootstrapping_params* p, void* tmp, size_t tmp_bytes,
+                                                         size_t batch) {
+    PZ_ENTER(M);
+    KeyHash k;
+    k.add((int)3); k.add(ggsw); k.add(lwe_2n); k.add(lut); k.add(brk); k.add(nsteps); k.add(tmp); k.add(tmp_bytes); k.add(batch);
+    if (p) {
+        k.add(*p);
+        for (size_t s = 0; s < nsteps && gals && atk_pmats; ++s) { k.add(gals[s]); k.add(atk_pmats[s]); }
+        for (size_t c = 0; c < p->br.rank && tsk_pmats; ++c) k.add(tsk_pmats[c]);
+    }
+    graph_key_module(M, k);
+    return with_graph(M, k.h, [&]() {
+        return circuit_bootstrapping(M, ggsw, lwe_2n, lut, brk, nsteps, gals, atk_pmats, tsk_pmats, p, tmp, tmp_bytes, batch);
+    });
 }
 
 }  // extern "C"

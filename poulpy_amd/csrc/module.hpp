@@ -144,6 +144,13 @@ struct pz_module {
     std::vector<hipEvent_t> event_pool;
     double cls_ms[PZ_KCLASS_COUNT] = {0};
     unsigned long long cls_count[PZ_KCLASS_COUNT] = {0};
+    // HIP graphs of the launch-bound composite calls (blind rotation, trace, circuit bootstrapping): a call seen twice with the
+    // same arguments is captured once and replayed afterwards (api.hip, with_graph)
+    struct GraphEntry { uint64_t key; hipGraph_t graph; hipGraphExec_t exec; uint64_t stamp; bool failed; };
+    std::vector<GraphEntry> graphs;
+    uint64_t graph_clock = 0, graph_epoch = 0;  // epoch: bumped by anything that changes what a captured call would launch
+    bool graphs_on = true;
+    unsigned long long graph_launches = 0;
 };
 
 namespace pz {

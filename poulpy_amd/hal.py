@@ -65,6 +65,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.pz_alloc_bytes.argtypes = [c_size_t]
     lib.pz_free_bytes.argtypes = [c_void_p]
     lib.pz_module_stream.restype = c_void_p
+    lib.pz_module_graph_launches.restype = c_uint64
     for name in ("pz_bytes_of_vec_znx", "pz_bytes_of_vec_znx_dft", "pz_bytes_of_vec_znx_big", "pz_bytes_of_svp_ppol",
                  "pz_bytes_of_vmp_pmat", "pz_vec_znx_idft_apply_tmp_bytes", "pz_vmp_prepare_tmp_bytes",
                  "pz_vmp_apply_dft_tmp_bytes", "pz_vmp_apply_dft_to_dft_tmp_bytes", "pz_vec_znx_big_normalize_tmp_bytes",
@@ -389,6 +390,13 @@ class Module:
                                        batch: int):
         """poulpy-bin-fhe blind_rotation/algorithms/cggi/algorithm.rs:76-118,265-440 on a batch of mod-switched LWE ciphertexts."""
         self._ck(self.lib.pz_blind_rotation_execute_batched(self.handle, res, lwe_2n, lut, brk, C.byref(params), c_size_t(batch)))
+
+    def set_graphs(self, enable: bool):
+        """HIP-graph replay of the launch-bound composite calls (blind rotation, trace, circuit bootstrapping); on by default."""
+        self._ck(self.lib.pz_module_set_graphs(self.handle, C.c_int(1 if enable else 0)))
+
+    def graph_launches(self) -> int:
+        return int(self.lib.pz_module_graph_launches(self.handle))
 
     def circuit_bootstrapping_tmp_bytes(self, params: CircuitBootstrappingParams, batch: int) -> int:
         return self.lib.pz_circuit_bootstrapping_tmp_bytes(self.handle, C.byref(params), c_size_t(batch))

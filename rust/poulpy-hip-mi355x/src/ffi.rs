@@ -144,6 +144,9 @@ pub struct pz_circuit_bootstrapping_params {
 
 extern "C" {
     /// circuit_bootstrapping_execute_to_constant (poulpy-bin-fhe/src/circuit_bootstrapping/circuit.rs:177-195, :219-370), one base2k
+    /// HIP-graph replay of the launch-bound composite calls (on by default)
+    pub fn pz_module_set_graphs(m: *mut pz_module, enable: c_int) -> c_int;
+    pub fn pz_module_graph_launches(m: *const pz_module) -> u64;
     pub fn pz_circuit_bootstrapping_tmp_bytes(m: *const pz_module, p: *const pz_circuit_bootstrapping_params, batch: usize) -> usize;
     pub fn pz_circuit_bootstrapping_execute_to_constant_batched(m: *mut pz_module, ggsw: *mut i64, lwe_2n: *const i64, lut: *const i64,
         brk: *const f64, nsteps: usize, gals: *const i64, atk: *const *const f64, tsk: *const *const f64,

@@ -1169,3 +1169,52 @@ def test_circuit_bootstrapping_to_constant(mods, n, rank, n_lwe, block_size, brk
     assert np.array_equal(got[:, :, 0], want[:, :, 0]), "trace rows differ"
     assert np.array_equal(got, want)
 
+
+def test_composite_calls_replay_as_hip_graphs(mods):
+    """The launch-bound composite calls are captured into a HIP graph the second time they come with the same arguments and
+    replayed afterwards: same addresses and shapes, NEW contents every call, results must follow the contents (composed
+    blind-rotation path: hundreds of launches per call)."""
+    from poulpy_amd.hal import BlindRotationParams
+    n, rank, n_lwe, blk, dnum, bsz, rsz, k, batch = 2048, 1, 6, 3, 2, 2, 2, 13, 3
+    ref, hip = mods(n)
+    rng = seeded(4100)
+    cols = rank + 1
+    lut = VecZnx(n, 1, rsz).fill_uniform(k, rng)
+    brk_r = np.empty((n_lwe, n * dnum * cols * cols * bsz), dtype=np.float64)
+    brk_h = np.empty_like(brk_r)
+    for i in range(n_lwe):
+        mat = MatZnx(n, dnum, cols, cols, bsz).fill_uniform(k, rng)
+        pr, ph = ref.vmp_pmat_alloc(dnum, cols, cols, bsz), hip.vmp_pmat_alloc(dnum, cols, cols, bsz)
+        ref.vmp_prepare(pr, mat)
+        hip.vmp_prepare(ph, mat)
+        brk_r[i], brk_h[i] = pr.data.reshape(-1), ph.data.reshape(-1)
+    xpa = ref.blind_rotation_x_pow_a()
+    d_lwe = hip.device_alloc(batch * (n_lwe + 1) * 8)
+    d_lut = hip.device_alloc(lut.data.nbytes).upload(lut.data)
+    d_brk = hip.device_alloc(brk_h.nbytes).upload(brk_h)
+    d_res = hip.device_alloc(batch * rsz * cols * n * 8)
+    p = BlindRotationParams(rank=rank, n_lwe=n_lwe, block_size=blk, dnum=dnum, brk_size=bsz, base2k=k, res_size=rsz, lut_size=rsz)
+    hip.set_graphs(True)
+    before = hip.graph_launches()
+    for it in range(5):
+        lwe = rng.integers(-n, n, (batch, n_lwe + 1), dtype=np.int64)
+        d_lwe.upload(lwe)
+        hip.blind_rotation_execute_batched(d_res.ptr, d_lwe.ptr, d_lut.ptr, d_brk.ptr, p, batch)
+        hip.sync()
+        got = d_res.download(np.int64, batch * rsz * cols * n).reshape(batch, rsz, cols, n)
+        for b in range(batch):
+            res = VecZnx(n, cols, rsz)
+            ref.blind_rotation_execute(res, k, np.ascontiguousarray(lwe[b]), lut, brk_r, dnum, bsz, blk, xpa)
+            assert np.array_equal(got[b], res.data), (it, b)
+    assert hip.graph_launches() - before >= 2, "the repeated call was never served by a graph"
+    # switched off: plain launches again, same results
+    hip.set_graphs(False)
+    mid = hip.graph_launches()
+    hip.blind_rotation_execute_batched(d_res.ptr, d_lwe.ptr, d_lut.ptr, d_brk.ptr, p, batch)
+    hip.sync()
+    assert hip.graph_launches() == mid
+    assert np.array_equal(d_res.download(np.int64, batch * rsz * cols * n).reshape(batch, rsz, cols, n), got)
+    hip.set_graphs(True)
+    for buf in (d_lwe, d_lut, d_brk, d_res):
+        buf.free()
+
