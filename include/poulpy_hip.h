@@ -197,6 +197,36 @@ int pz_vec_znx_rotate_assign(pz_module* m, int64_t k, int64_t* res, size_t cols,
 size_t pz_vec_znx_rsh_tmp_bytes(const pz_module* m);
 int pz_vec_znx_rsh_assign(pz_module* m, size_t base2k, size_t k, int64_t* res, size_t cols, size_t size, size_t col);
 
+/* ---- i64 VecZnx limb-wise family (hal_impl.rs:34 zero, :41 normalize, :55 normalize_assign, :59 add_into,
+ * :65 add_assign, :90 sub, :96 sub_assign, :101 sub_negate_assign, :126 negate, :131 negate_assign, :289 copy): the i64
+ * operations poulpy-core runs between the hot-path calls (glwe_add / sub / copy / normalize ...), so that ciphertexts can
+ * stay on the device.  Limb-range rules of reference/vec_znx/{add,sub,negate,copy}.rs (common limbs combined, the longer
+ * operand copied / negated, the rest of res zeroed), wrapping i64 arithmetic.  Host or device pointers. ------------------- */
+int pz_vec_znx_add_into(pz_module* m, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                        const int64_t* a, size_t a_cols, size_t a_size, size_t a_col,
+                        const int64_t* b, size_t b_cols, size_t b_size, size_t b_col);
+int pz_vec_znx_sub(pz_module* m, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                   const int64_t* a, size_t a_cols, size_t a_size, size_t a_col,
+                   const int64_t* b, size_t b_cols, size_t b_size, size_t b_col);
+int pz_vec_znx_add_assign(pz_module* m, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                          const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+int pz_vec_znx_sub_assign(pz_module* m, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                          const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+int pz_vec_znx_sub_negate_assign(pz_module* m, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                                 const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+int pz_vec_znx_negate(pz_module* m, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                      const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+int pz_vec_znx_negate_assign(pz_module* m, int64_t* res, size_t res_cols, size_t res_size, size_t res_col);
+int pz_vec_znx_copy(pz_module* m, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                    const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+int pz_vec_znx_zero(pz_module* m, int64_t* res, size_t res_cols, size_t res_size, size_t res_col);
+/* vec_znx_normalize: the function vec_znx_big_normalize forwards to when ScalarBig = i64; _assign: in place, same base
+ * (reference/vec_znx/normalize.rs:18-48, :403-425) */
+size_t pz_vec_znx_normalize_tmp_bytes(const pz_module* m);
+int pz_vec_znx_normalize(pz_module* m, int64_t* res, size_t res_cols, size_t res_size, size_t res_base2k, int64_t res_offset,
+                         size_t res_col, const int64_t* a, size_t a_cols, size_t a_size, size_t a_base2k, size_t a_col);
+int pz_vec_znx_normalize_assign(pz_module* m, size_t base2k, int64_t* res, size_t cols, size_t size, size_t col);
+
 /* ---- X -> X^p on i64 containers (the glwe_automorphism callers) ---------------------- *
  * hal_impl.rs:236 vec_znx_automorphism, :241 _assign_tmp_bytes, :243 _assign; :517 vec_znx_big_automorphism, :522, :524.
  * reference/znx/automorphism.rs:1-17: res[(i*p) mod 2n] = a[i], negated when the index wraps past n; limbs of res beyond

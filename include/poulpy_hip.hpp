@@ -179,6 +179,39 @@ class Module {  // Module<FFT64Hip>, poulpy-hal/src/layouts/module.rs:97-189
     size_t circuit_bootstrapping_tmp_bytes(const pz_circuit_bootstrapping_params& p, size_t batch) const {
         return pz_circuit_bootstrapping_tmp_bytes(m_, &p, batch);
     }
+    // i64 VecZnx limb-wise family (hal_impl.rs:34-131, :289)
+    void vec_znx_add_into(int64_t* res, size_t rc, size_t rs, size_t rcol, const int64_t* a, size_t ac, size_t as, size_t acol, const int64_t* b,
+                          size_t bc, size_t bs, size_t bcol) {
+        check(pz_vec_znx_add_into(m_, res, rc, rs, rcol, a, ac, as, acol, b, bc, bs, bcol), "vec_znx_add_into");
+    }
+    void vec_znx_sub(int64_t* res, size_t rc, size_t rs, size_t rcol, const int64_t* a, size_t ac, size_t as, size_t acol, const int64_t* b,
+                     size_t bc, size_t bs, size_t bcol) {
+        check(pz_vec_znx_sub(m_, res, rc, rs, rcol, a, ac, as, acol, b, bc, bs, bcol), "vec_znx_sub");
+    }
+    void vec_znx_add_assign(int64_t* res, size_t rc, size_t rs, size_t rcol, const int64_t* a, size_t ac, size_t as, size_t acol) {
+        check(pz_vec_znx_add_assign(m_, res, rc, rs, rcol, a, ac, as, acol), "vec_znx_add_assign");
+    }
+    void vec_znx_sub_assign(int64_t* res, size_t rc, size_t rs, size_t rcol, const int64_t* a, size_t ac, size_t as, size_t acol) {
+        check(pz_vec_znx_sub_assign(m_, res, rc, rs, rcol, a, ac, as, acol), "vec_znx_sub_assign");
+    }
+    void vec_znx_sub_negate_assign(int64_t* res, size_t rc, size_t rs, size_t rcol, const int64_t* a, size_t ac, size_t as, size_t acol) {
+        check(pz_vec_znx_sub_negate_assign(m_, res, rc, rs, rcol, a, ac, as, acol), "vec_znx_sub_negate_assign");
+    }
+    void vec_znx_negate(int64_t* res, size_t rc, size_t rs, size_t rcol, const int64_t* a, size_t ac, size_t as, size_t acol) {
+        check(pz_vec_znx_negate(m_, res, rc, rs, rcol, a, ac, as, acol), "vec_znx_negate");
+    }
+    void vec_znx_negate_assign(int64_t* res, size_t rc, size_t rs, size_t rcol) { check(pz_vec_znx_negate_assign(m_, res, rc, rs, rcol), "vec_znx_negate_assign"); }
+    void vec_znx_copy(int64_t* res, size_t rc, size_t rs, size_t rcol, const int64_t* a, size_t ac, size_t as, size_t acol) {
+        check(pz_vec_znx_copy(m_, res, rc, rs, rcol, a, ac, as, acol), "vec_znx_copy");
+    }
+    void vec_znx_zero(int64_t* res, size_t rc, size_t rs, size_t rcol) { check(pz_vec_znx_zero(m_, res, rc, rs, rcol), "vec_znx_zero"); }
+    void vec_znx_normalize(int64_t* res, size_t rc, size_t rs, size_t res_base2k, int64_t res_offset, size_t rcol, const int64_t* a, size_t ac,
+                           size_t as, size_t a_base2k, size_t acol) {
+        check(pz_vec_znx_normalize(m_, res, rc, rs, res_base2k, res_offset, rcol, a, ac, as, a_base2k, acol), "vec_znx_normalize");
+    }
+    void vec_znx_normalize_assign(size_t base2k, int64_t* res, size_t rc, size_t rs, size_t rcol) {
+        check(pz_vec_znx_normalize_assign(m_, base2k, res, rc, rs, rcol), "vec_znx_normalize_assign");
+    }
     void set_graphs(bool enable) { check(pz_module_set_graphs(m_, enable ? 1 : 0), "set_graphs"); }
     uint64_t graph_launches() const { return pz_module_graph_launches(m_); }
     void ggsw_from_gglwe_batched(int64_t* ggsw, const int64_t* a, size_t a_cols_in, size_t dnum, const double* const* tsk,

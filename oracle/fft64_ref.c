@@ -1402,6 +1402,89 @@ void pzr_vec_znx_big_sub_small_negate_assign(size_t n, int64_t* res, size_t res_
 }
 
 /* ------------------------------------------------------------------------ */
+/* i64 VecZnx limb-wise family                           */
+/* reference/vec_znx/add.rs:6-109, sub.rs:6-112, negate.rs:6-44, copy.rs, zero.rs; wrapping i64 arithmetic */
+/* ------------------------------------------------------------------------ */
+static void znx_add_sub(int sub, size_t n, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                        const int64_t* a, size_t a_cols, size_t a_size, size_t a_col,
+                        const int64_t* b, size_t b_cols, size_t b_size, size_t b_col) {
+    int a_le_b = a_size <= b_size;
+    size_t sum_size = zmin(a_le_b ? a_size : b_size, res_size);
+    size_t cpy_size = zmin(a_le_b ? b_size : a_size, res_size);
+    for (size_t j = 0; j < res_size; ++j) {
+        int64_t* r = at_i64(res, n, res_cols, res_col, j);
+        if (j < sum_size) {
+            const int64_t* x = at_ci64(a, n, a_cols, a_col, j);
+            const int64_t* y = at_ci64(b, n, b_cols, b_col, j);
+            for (size_t i = 0; i < n; ++i)
+                r[i] = sub ? (int64_t)((uint64_t)x[i] - (uint64_t)y[i]) : (int64_t)((uint64_t)x[i] + (uint64_t)y[i]);
+        } else if (j < cpy_size) {
+            if (a_le_b) { /* add.rs:35-37 copy b ; sub.rs:37-39 negate b */
+                const int64_t* y = at_ci64(b, n, b_cols, b_col, j);
+                for (size_t i = 0; i < n; ++i) r[i] = sub ? (int64_t)(0 - (uint64_t)y[i]) : y[i];
+            } else {
+                const int64_t* x = at_ci64(a, n, a_cols, a_col, j);
+                for (size_t i = 0; i < n; ++i) r[i] = x[i];
+            }
+        } else {
+            memset(r, 0, n * sizeof(int64_t));
+        }
+    }
+}
+void pzr_vec_znx_add_into(size_t n, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                          const int64_t* a, size_t a_cols, size_t a_size, size_t a_col,
+                          const int64_t* b, size_t b_cols, size_t b_size, size_t b_col) {
+    znx_add_sub(0, n, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col, b, b_cols, b_size, b_col);
+}
+void pzr_vec_znx_sub(size_t n, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                     const int64_t* a, size_t a_cols, size_t a_size, size_t a_col,
+                     const int64_t* b, size_t b_cols, size_t b_size, size_t b_col) {
+    znx_add_sub(1, n, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col, b, b_cols, b_size, b_col);
+}
+/* add.rs:88-109, sub.rs:60-82 (mode 0 res += a, 1 res -= a over the common limbs), sub.rs:84-112 (mode 2: res = a - res, -res beyond) */
+void pzr_vec_znx_assign_op(int mode, size_t n, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                           const int64_t* a, size_t a_cols, size_t a_size, size_t a_col) {
+    size_t sum_size = zmin(a_size, res_size);
+    for (size_t j = 0; j < res_size; ++j) {
+        int64_t* r = at_i64(res, n, res_cols, res_col, j);
+        if (j < sum_size) {
+            const int64_t* x = at_ci64(a, n, a_cols, a_col, j);
+            for (size_t i = 0; i < n; ++i) {
+                uint64_t rv = (uint64_t)r[i], xv = (uint64_t)x[i];
+                r[i] = (int64_t)(mode == 0 ? rv + xv : mode == 1 ? rv - xv : xv - rv);
+            }
+        } else if (mode == 2) {
+            for (size_t i = 0; i < n; ++i) r[i] = (int64_t)(0 - (uint64_t)r[i]);
+        }
+    }
+}
+/* negate.rs:6-29 (res = -a, zero tail), :31-44 (in place, a == NULL) */
+void pzr_vec_znx_negate(size_t n, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                        const int64_t* a, size_t a_cols, size_t a_size, size_t a_col) {
+    for (size_t j = 0; j < res_size; ++j) {
+        int64_t* r = at_i64(res, n, res_cols, res_col, j);
+        if (!a) {
+            for (size_t i = 0; i < n; ++i) r[i] = (int64_t)(0 - (uint64_t)r[i]);
+        } else if (j < zmin(res_size, a_size)) {
+            const int64_t* x = at_ci64(a, n, a_cols, a_col, j);
+            for (size_t i = 0; i < n; ++i) r[i] = (int64_t)(0 - (uint64_t)x[i]);
+        } else {
+            memset(r, 0, n * sizeof(int64_t));
+        }
+    }
+}
+/* copy.rs (common limbs, zero tail) */
+void pzr_vec_znx_copy(size_t n, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                      const int64_t* a, size_t a_cols, size_t a_size, size_t a_col) {
+    size_t min_size = zmin(res_size, a_size);
+    for (size_t j = 0; j < res_size; ++j) {
+        int64_t* r = at_i64(res, n, res_cols, res_col, j);
+        if (j < min_size) memcpy(r, at_ci64(a, n, a_cols, a_col, j), n * sizeof(int64_t));
+        else memset(r, 0, n * sizeof(int64_t));
+    }
+}
+
+/* ------------------------------------------------------------------------ */
 /* poulpy-core callers                                                       */
 /* ------------------------------------------------------------------------ */
 

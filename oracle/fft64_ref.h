@@ -147,6 +147,21 @@ void pzr_glwe_automorphism(const pzr_tables* t, size_t rank, int mode, int64_t p
                            const int64_t* a, size_t a_size, size_t a_base2k,
                            const double* key_pmat, size_t dnum, size_t key_size, size_t dsize, size_t key_base2k);
 
+/* i64 VecZnx limb-wise family: reference/vec_znx/add.rs, sub.rs, negate.rs, copy.rs (wrapping arithmetic).
+ * assign_op mode: 0 res += a, 1 res -= a, 2 res = a - res (and -res beyond a's limbs); negate with a == NULL is in place */
+void pzr_vec_znx_add_into(size_t n, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                          const int64_t* a, size_t a_cols, size_t a_size, size_t a_col,
+                          const int64_t* b, size_t b_cols, size_t b_size, size_t b_col);
+void pzr_vec_znx_sub(size_t n, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                     const int64_t* a, size_t a_cols, size_t a_size, size_t a_col,
+                     const int64_t* b, size_t b_cols, size_t b_size, size_t b_col);
+void pzr_vec_znx_assign_op(int mode, size_t n, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                           const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+void pzr_vec_znx_negate(size_t n, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                        const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+void pzr_vec_znx_copy(size_t n, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                      const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+
 /* conversion/gglwe_to_ggsw.rs:116-268 (ggsw_expand_row); ggsw = MatZnx(dnum, cols, cols, size), keys[c] = tsk.at(c) */
 void pzr_ggsw_expand_row(const pzr_tables* t, size_t rank, int64_t* ggsw, size_t dnum, size_t size, size_t base2k,
                          const double* const* keys, size_t key_dnum, size_t key_size, size_t dsize, size_t key_base2k);

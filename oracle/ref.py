@@ -238,6 +238,39 @@ class RefModule:
                                        *_sz(res.size, res_base2k), _p(a.data), *_sz(a.size, a_base2k), _p(pmat.data),
                                        *_sz(pmat.rows, pmat.size, dsize, key_base2k))
 
+    # i64 VecZnx limb-wise family (reference/vec_znx/add.rs, sub.rs, negate.rs, copy.rs)
+    def vec_znx_add_into(self, res, res_col, a, a_col, b, b_col):
+        self.lib.pzr_vec_znx_add_into(c_size_t(self._n), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                      *_sz(a.cols, a.size, a_col), _p(b.data), *_sz(b.cols, b.size, b_col))
+
+    def vec_znx_sub(self, res, res_col, a, a_col, b, b_col):
+        self.lib.pzr_vec_znx_sub(c_size_t(self._n), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                 *_sz(a.cols, a.size, a_col), _p(b.data), *_sz(b.cols, b.size, b_col))
+
+    def _vec_znx_assign_op(self, mode, res, res_col, a, a_col):
+        self.lib.pzr_vec_znx_assign_op(C.c_int(mode), c_size_t(self._n), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                       *_sz(a.cols, a.size, a_col))
+
+    def vec_znx_add_assign(self, res, res_col, a, a_col):
+        self._vec_znx_assign_op(0, res, res_col, a, a_col)
+
+    def vec_znx_sub_assign(self, res, res_col, a, a_col):
+        self._vec_znx_assign_op(1, res, res_col, a, a_col)
+
+    def vec_znx_sub_negate_assign(self, res, res_col, a, a_col):
+        self._vec_znx_assign_op(2, res, res_col, a, a_col)
+
+    def vec_znx_negate(self, res, res_col, a, a_col):
+        self.lib.pzr_vec_znx_negate(c_size_t(self._n), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                    *_sz(a.cols, a.size, a_col))
+
+    def vec_znx_negate_assign(self, res, res_col):
+        self.lib.pzr_vec_znx_negate(c_size_t(self._n), _p(res.data), *_sz(res.cols, res.size, res_col), None, *_sz(0, 0, 0))
+
+    def vec_znx_copy(self, res, res_col, a, a_col):
+        self.lib.pzr_vec_znx_copy(c_size_t(self._n), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                  *_sz(a.cols, a.size, a_col))
+
     def ggsw_expand_row(self, ggsw, base2k, keys, dsize, key_base2k):
         """conversion/gglwe_to_ggsw.rs:116-268; ggsw: MatZnx (rows, cols_in = cols_out = rank+1), keys: rank prepared GGLWEs."""
         rank = ggsw.cols_out - 1

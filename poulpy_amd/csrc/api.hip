@@ -960,8 +960,14 @@ static int ew_limbs(pz_module* M, int op, const DV& r, int rcol, int rl0, const 
                      a ? limb_stride(M, *a) : 0, b ? poly_ptr(M, *b, bcol, bl0) : nullptr, 0, b ? limb_stride(M, *b) : 0, nl, 1);
 }
 
+// i64 = true: the same limb-range logic on i64 containers (reference/vec_znx/add.rs:6-65, sub.rs:6-58), wrapping arithmetic
+static inline int ew_for(int op, bool i64) {
+    if (!i64) return op;
+    return op == EW_ADD ? EW_ADD_I64 : op == EW_SUB ? EW_SUB_I64 : op == EW_NEG ? EW_NEG_I64 : op;
+}
 static int add_sub_into(pz_module* M, bool sub, double* res, size_t res_cols, size_t res_size, size_t res_col, const double* a,
-                        size_t a_cols, size_t a_size, size_t a_col, const double* b, size_t b_cols, size_t b_size, size_t b_col) {
+                        size_t a_cols, size_t a_size, size_t a_col, const double* b, size_t b_cols, size_t b_size, size_t b_col,
+                        bool i64 = false) {
     PZ_CHECK_COL(res_col, res_cols, "vec_znx_dft_add/sub(res)");
     PZ_CHECK_COL(a_col, a_cols, "vec_znx_dft_add/sub(a)");
     PZ_CHECK_COL(b_col, b_cols, "vec_znx_dft_add/sub(b)");
@@ -971,8 +977,8 @@ static int add_sub_into(pz_module* M, bool sub, double* res, size_t res_cols, si
     const bool a_le_b = a_size <= b_size;
     const int sum = (int)std::min(a_le_b ? a_size : b_size, res_size);
     const int cpy = (int)std::min(a_le_b ? b_size : a_size, res_size);
-    PZ_TRY(ew_limbs(M, sub ? EW_SUB : EW_ADD, t.dr, (int)res_col, 0, &t.da, (int)a_col, 0, &t.db, (int)b_col, 0, sum));
-    if (a_le_b) PZ_TRY(ew_limbs(M, sub ? EW_NEG : EW_COPY, t.dr, (int)res_col, sum, &t.db, (int)b_col, sum, nullptr, 0, 0, cpy - sum));
+    PZ_TRY(ew_limbs(M, ew_for(sub ? EW_SUB : EW_ADD, i64), t.dr, (int)res_col, 0, &t.da, (int)a_col, 0, &t.db, (int)b_col, 0, sum));
+    if (a_le_b) PZ_TRY(ew_limbs(M, ew_for(sub ? EW_NEG : EW_COPY, i64), t.dr, (int)res_col, sum, &t.db, (int)b_col, sum, nullptr, 0, 0, cpy - sum));
     else PZ_TRY(ew_limbs(M, EW_COPY, t.dr, (int)res_col, sum, &t.da, (int)a_col, sum, nullptr, 0, 0, cpy - sum));
     PZ_TRY(ew_limbs(M, EW_ZERO, t.dr, (int)res_col, cpy, nullptr, 0, 0, nullptr, 0, 0, (int)res_size - cpy));
     return tri_out(M, t);
@@ -991,17 +997,17 @@ int pz_vec_znx_dft_sub(pz_module* M, double* res, size_t res_cols, size_t res_si
 // res (op)= a over limb ranges; shifts express add_scaled_assign
 static int assign_op(pz_module* M, int op_res_a /*EW_ADD: res+a, EW_SUB: res-a, -EW_SUB: a-res*/, double* res, size_t res_cols,
                      size_t res_size, size_t res_col, const double* a, size_t a_cols, size_t a_size, size_t a_col, int res_shift,
-                     int a_shift, int nl, bool negate_tail) {
+                     int a_shift, int nl, bool negate_tail, bool i64 = false) {
     PZ_CHECK_COL(res_col, res_cols, "vec_znx_dft_*_assign(res)");
     PZ_CHECK_COL(a_col, a_cols, "vec_znx_dft_*_assign(a)");
     Tri t;
     PZ_TRY(tri_in(M, t, res, res_cols, res_size, a, a_cols, a_size, nullptr, 0, 0));
     if (op_res_a == EW_ADD || op_res_a == EW_SUB)
-        PZ_TRY(ew_limbs(M, op_res_a, t.dr, (int)res_col, res_shift, &t.dr, (int)res_col, res_shift, &t.da, (int)a_col, a_shift, nl));
+        PZ_TRY(ew_limbs(M, ew_for(op_res_a, i64), t.dr, (int)res_col, res_shift, &t.dr, (int)res_col, res_shift, &t.da, (int)a_col, a_shift, nl));
     else
-        PZ_TRY(ew_limbs(M, EW_SUB, t.dr, (int)res_col, res_shift, &t.da, (int)a_col, a_shift, &t.dr, (int)res_col, res_shift, nl));
+        PZ_TRY(ew_limbs(M, ew_for(EW_SUB, i64), t.dr, (int)res_col, res_shift, &t.da, (int)a_col, a_shift, &t.dr, (int)res_col, res_shift, nl));
     if (negate_tail)
-        PZ_TRY(ew_limbs(M, EW_NEG, t.dr, (int)res_col, nl, &t.dr, (int)res_col, nl, nullptr, 0, 0, (int)res_size - nl));
+        PZ_TRY(ew_limbs(M, ew_for(EW_NEG, i64), t.dr, (int)res_col, nl, &t.dr, (int)res_col, nl, nullptr, 0, 0, (int)res_size - nl));
     return tri_out(M, t);
 }
 int pz_vec_znx_dft_add_assign(pz_module* M, double* res, size_t res_cols, size_t res_size, size_t res_col, const double* a,
@@ -1018,6 +1024,79 @@ int pz_vec_znx_dft_sub_negate_assign(pz_module* M, double* res, size_t res_cols,
                                      size_t a_cols, size_t a_size, size_t a_col) {
     PZ_ENTER(M);
     return assign_op(M, -EW_SUB, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col, 0, 0, (int)std::min(a_size, res_size), true);
+}
+// ---- i64 VecZnx limb-wise family (hal_impl.rs:59 add_into, :65 add_assign, :90 sub, :96 sub_assign, :101 sub_negate_assign,
+//      :126 negate, :131 negate_assign, :289 copy, :34 zero): SURVEY.md 8f rank 3, so that ciphertexts stay on the device
+//      between the hot-path operations.  Same limb-range rules as the DFT-domain family above, wrapping i64 arithmetic.
+int pz_vec_znx_add_into(pz_module* M, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a, size_t a_cols,
+                        size_t a_size, size_t a_col, const int64_t* b, size_t b_cols, size_t b_size, size_t b_col) {
+    PZ_ENTER(M);
+    return add_sub_into(M, false, (double*)res, res_cols, res_size, res_col, (const double*)a, a_cols, a_size, a_col, (const double*)b, b_cols,
+                        b_size, b_col, true);
+}
+int pz_vec_znx_sub(pz_module* M, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a, size_t a_cols,
+                   size_t a_size, size_t a_col, const int64_t* b, size_t b_cols, size_t b_size, size_t b_col) {
+    PZ_ENTER(M);
+    return add_sub_into(M, true, (double*)res, res_cols, res_size, res_col, (const double*)a, a_cols, a_size, a_col, (const double*)b, b_cols,
+                        b_size, b_col, true);
+}
+int pz_vec_znx_add_assign(pz_module* M, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a, size_t a_cols,
+                          size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    return assign_op(M, EW_ADD, (double*)res, res_cols, res_size, res_col, (const double*)a, a_cols, a_size, a_col, 0, 0,
+                     (int)std::min(a_size, res_size), false, true);
+}
+int pz_vec_znx_sub_assign(pz_module* M, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a, size_t a_cols,
+                          size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    return assign_op(M, EW_SUB, (double*)res, res_cols, res_size, res_col, (const double*)a, a_cols, a_size, a_col, 0, 0,
+                     (int)std::min(a_size, res_size), false, true);
+}
+int pz_vec_znx_sub_negate_assign(pz_module* M, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a,
+                                 size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    return assign_op(M, -EW_SUB, (double*)res, res_cols, res_size, res_col, (const double*)a, a_cols, a_size, a_col, 0, 0,
+                     (int)std::min(a_size, res_size), true, true);
+}
+// res = -a over the common limbs, zero beyond (negate.rs:6-29); copy: res = a, zero beyond (copy.rs)
+static int negate_or_copy(pz_module* M, int op, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a,
+                          size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_CHECK_COL(res_col, res_cols, "vec_znx_negate/copy(res)");
+    PZ_CHECK_COL(a_col, a_cols, "vec_znx_negate/copy(a)");
+    Tri t;
+    PZ_TRY(tri_in(M, t, (double*)res, res_cols, res_size, (const double*)a, a_cols, a_size, nullptr, 0, 0));
+    const int mn = (int)std::min(res_size, a_size);
+    PZ_TRY(ew_limbs(M, op, t.dr, (int)res_col, 0, &t.da, (int)a_col, 0, nullptr, 0, 0, mn));
+    PZ_TRY(ew_limbs(M, EW_ZERO, t.dr, (int)res_col, mn, nullptr, 0, 0, nullptr, 0, 0, (int)res_size - mn));
+    return tri_out(M, t);
+}
+int pz_vec_znx_negate(pz_module* M, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a, size_t a_cols,
+                      size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    return negate_or_copy(M, EW_NEG_I64, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col);
+}
+int pz_vec_znx_copy(pz_module* M, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a, size_t a_cols,
+                    size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    PZ_REQUIRE(!((const void*)res == (const void*)a && res_col != a_col), "vec_znx_copy: column-to-column copy inside one container is not supported");
+    if ((const void*)res == (const void*)a) return PZ_OK;
+    return negate_or_copy(M, EW_COPY, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col);
+}
+int pz_vec_znx_negate_assign(pz_module* M, int64_t* res, size_t res_cols, size_t res_size, size_t res_col) {
+    PZ_ENTER(M);
+    PZ_CHECK_COL(res_col, res_cols, "vec_znx_negate_assign(res)");
+    Tri t;
+    PZ_TRY(tri_in(M, t, (double*)res, res_cols, res_size, nullptr, 0, 0, nullptr, 0, 0));
+    PZ_TRY(ew_limbs(M, EW_NEG_I64, t.dr, (int)res_col, 0, &t.dr, (int)res_col, 0, nullptr, 0, 0, (int)res_size));
+    return tri_out(M, t);
+}
+int pz_vec_znx_zero(pz_module* M, int64_t* res, size_t res_cols, size_t res_size, size_t res_col) {
+    PZ_ENTER(M);
+    PZ_CHECK_COL(res_col, res_cols, "vec_znx_zero(res)");
+    Tri t;
+    PZ_TRY(tri_in(M, t, (double*)res, res_cols, res_size, nullptr, 0, 0, nullptr, 0, 0));
+    PZ_TRY(ew_limbs(M, EW_ZERO, t.dr, (int)res_col, 0, nullptr, 0, 0, nullptr, 0, 0, (int)res_size));
+    return tri_out(M, t);
 }
 int pz_vec_znx_dft_add_scaled_assign(pz_module* M, double* res, size_t res_cols, size_t res_size, size_t res_col, const double* a,
                                      size_t a_cols, size_t a_size, size_t a_col, int64_t a_scale) {
@@ -1264,9 +1343,8 @@ static int normalize_checks(size_t res_col, size_t res_cols, size_t a_col, size_
     return PZ_OK;
 }
 
-int pz_vec_znx_big_normalize(pz_module* M, int64_t* res, size_t res_cols, size_t res_size, size_t res_base2k, int64_t res_offset,
-                             size_t res_col, const int64_t* a, size_t a_cols, size_t a_size, size_t a_base2k, size_t a_col) {
-    PZ_ENTER(M);
+static int normalize_impl(pz_module* M, int64_t* res, size_t res_cols, size_t res_size, size_t res_base2k, int64_t res_offset,
+                          size_t res_col, const int64_t* a, size_t a_cols, size_t a_size, size_t a_base2k, size_t a_col) {
     PZ_TRY(normalize_checks(res_col, res_cols, a_col, a_cols, res_base2k, a_base2k));
     PZ_REQUIRE((const void*)res != (const void*)a, "vec_znx_big_normalize: res must not alias a");
     Stage sr, sa;
@@ -1277,6 +1355,39 @@ int pz_vec_znx_big_normalize(pz_module* M, int64_t* res, size_t res_cols, size_t
     const bool host = sr.owned || sa.owned;
     PZ_TRY(sr.finish());
     PZ_TRY(sa.finish());
+    return finish_call(M, host);
+}
+
+int pz_vec_znx_big_normalize(pz_module* M, int64_t* res, size_t res_cols, size_t res_size, size_t res_base2k, int64_t res_offset,
+                             size_t res_col, const int64_t* a, size_t a_cols, size_t a_size, size_t a_base2k, size_t a_col) {
+    PZ_ENTER(M);
+    return normalize_impl(M, res, res_cols, res_size, res_base2k, res_offset, res_col, a, a_cols, a_size, a_base2k, a_col);
+}
+// vec_znx_normalize (hal_impl.rs:41): with ScalarBig = i64 (poulpy-cpu-ref/src/fft64/module.rs:40-43) it is the function
+// vec_znx_big_normalize forwards to (reference/fft64/vec_znx_big.rs:241-278 -> vec_znx/normalize.rs:18-48)
+size_t pz_vec_znx_normalize_tmp_bytes(const pz_module* M) { return pz_vec_znx_big_normalize_tmp_bytes(M); }
+int pz_vec_znx_normalize(pz_module* M, int64_t* res, size_t res_cols, size_t res_size, size_t res_base2k, int64_t res_offset,
+                         size_t res_col, const int64_t* a, size_t a_cols, size_t a_size, size_t a_base2k, size_t a_col) {
+    PZ_ENTER(M);
+    return normalize_impl(M, res, res_cols, res_size, res_base2k, res_offset, res_col, a, a_cols, a_size, a_base2k, a_col);
+}
+// vec_znx_normalize_assign (hal_impl.rs:55; reference/vec_znx/normalize.rs:403-425): in place, same base == the out-of-place
+// same-base normalization of a copy of the column
+int pz_vec_znx_normalize_assign(pz_module* M, size_t base2k, int64_t* res, size_t cols, size_t size, size_t col) {
+    PZ_ENTER(M);
+    PZ_CHECK_COL(col, cols, "vec_znx_normalize_assign(res)");
+    PZ_REQUIRE(base2k >= 1 && base2k <= 63, "vec_znx_normalize_assign: base2k out of range");
+    if (size == 0) return PZ_OK;
+    Stage sr;
+    PZ_TRY(sr.in(res, vbytes(M, cols, size), true, true, M));
+    const long long n = (long long)M->n;
+    PZ_TRY(ws_reserve(M, (size_t)size * (size_t)n * 8));
+    DV dr{sr.dev, 0, (int)cols, (int)size};
+    PZ_TRY(launch_ew(M, EW_COPY, M->ws, 0, n, poly_ptr(M, dr, (int)col, 0), 0, limb_stride(M, dr), nullptr, 0, 0, (int)size, 1));
+    DV tv{M->ws, 0, 1, (int)size};
+    PZ_TRY(dev_normalize(M, 1, dr, (int)base2k, 0, (int)col, tv, (int)base2k, 0));
+    const bool host = sr.owned;
+    PZ_TRY(sr.finish());
     return finish_call(M, host);
 }
 

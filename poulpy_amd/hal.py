@@ -71,7 +71,7 @@ def load_library(path: str | None = None) -> C.CDLL:
                  "pz_vmp_apply_dft_tmp_bytes", "pz_vmp_apply_dft_to_dft_tmp_bytes", "pz_vec_znx_big_normalize_tmp_bytes",
                  "pz_glwe_op_workspace_bytes", "pz_vec_znx_automorphism_assign_tmp_bytes",
                  "pz_vec_znx_big_automorphism_assign_tmp_bytes", "pz_blind_rotation_workspace_bytes", "pz_vec_znx_rsh_tmp_bytes", "pz_vec_znx_rotate_assign_tmp_bytes",
-                 "pz_circuit_bootstrapping_tmp_bytes"):
+                 "pz_circuit_bootstrapping_tmp_bytes", "pz_vec_znx_normalize_tmp_bytes"):
         getattr(lib, name).restype = c_size_t
     if path is None:
         _lib = lib
@@ -316,6 +316,51 @@ class Module:
     def vec_znx_big_add_small_assign(self, res: VecZnxBig, res_col, a: VecZnx, a_col):
         self._ck(self.lib.pz_vec_znx_big_add_small_assign(self.handle, _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
                                                           *_sz(a.cols, a.size, a_col)))
+
+    # -- i64 VecZnx limb-wise family (hal_impl.rs:34-131, :289) ---------------------------------------
+    def _znx3(self, fn, res, res_col, a, a_col, b, b_col):
+        self._ck(fn(self.handle, _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data), *_sz(a.cols, a.size, a_col), _p(b.data),
+                    *_sz(b.cols, b.size, b_col)))
+
+    def _znx2(self, fn, res, res_col, a, a_col):
+        self._ck(fn(self.handle, _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data), *_sz(a.cols, a.size, a_col)))
+
+    def vec_znx_add_into(self, res: VecZnx, res_col, a: VecZnx, a_col, b: VecZnx, b_col):
+        self._znx3(self.lib.pz_vec_znx_add_into, res, res_col, a, a_col, b, b_col)
+
+    def vec_znx_sub(self, res: VecZnx, res_col, a: VecZnx, a_col, b: VecZnx, b_col):
+        self._znx3(self.lib.pz_vec_znx_sub, res, res_col, a, a_col, b, b_col)
+
+    def vec_znx_add_assign(self, res: VecZnx, res_col, a: VecZnx, a_col):
+        self._znx2(self.lib.pz_vec_znx_add_assign, res, res_col, a, a_col)
+
+    def vec_znx_sub_assign(self, res: VecZnx, res_col, a: VecZnx, a_col):
+        self._znx2(self.lib.pz_vec_znx_sub_assign, res, res_col, a, a_col)
+
+    def vec_znx_sub_negate_assign(self, res: VecZnx, res_col, a: VecZnx, a_col):
+        self._znx2(self.lib.pz_vec_znx_sub_negate_assign, res, res_col, a, a_col)
+
+    def vec_znx_negate(self, res: VecZnx, res_col, a: VecZnx, a_col):
+        self._znx2(self.lib.pz_vec_znx_negate, res, res_col, a, a_col)
+
+    def vec_znx_copy(self, res: VecZnx, res_col, a: VecZnx, a_col):
+        self._znx2(self.lib.pz_vec_znx_copy, res, res_col, a, a_col)
+
+    def vec_znx_negate_assign(self, res: VecZnx, res_col):
+        self._ck(self.lib.pz_vec_znx_negate_assign(self.handle, _p(res.data), *_sz(res.cols, res.size, res_col)))
+
+    def vec_znx_zero(self, res: VecZnx, res_col):
+        self._ck(self.lib.pz_vec_znx_zero(self.handle, _p(res.data), *_sz(res.cols, res.size, res_col)))
+
+    def vec_znx_normalize_tmp_bytes(self) -> int:
+        return self.lib.pz_vec_znx_normalize_tmp_bytes(self.handle)
+
+    def vec_znx_normalize(self, res: VecZnx, res_base2k, res_offset, res_col, a: VecZnx, a_base2k, a_col, scratch=None):
+        self._ck(self.lib.pz_vec_znx_normalize(self.handle, _p(res.data), *_sz(res.cols, res.size, res_base2k), c_int64(res_offset),
+                                               c_size_t(res_col), _p(a.data), *_sz(a.cols, a.size, a_base2k, a_col)))
+
+    def vec_znx_normalize_assign(self, base2k, res: VecZnx, res_col, scratch=None):
+        self._ck(self.lib.pz_vec_znx_normalize_assign(self.handle, c_size_t(base2k), _p(res.data), *_sz(res.cols, res.size, res_col)))
 
     # -- X -> X^p on i64 containers (hal_impl.rs:236-243, :517-524) ----------------------------
     def vec_znx_automorphism(self, p: int, res: VecZnx, res_col, a: VecZnx, a_col):

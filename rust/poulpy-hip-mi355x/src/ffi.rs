@@ -144,6 +144,27 @@ pub struct pz_circuit_bootstrapping_params {
 
 extern "C" {
     /// circuit_bootstrapping_execute_to_constant (poulpy-bin-fhe/src/circuit_bootstrapping/circuit.rs:177-195, :219-370), one base2k
+    // i64 VecZnx limb-wise family (hal_impl.rs:34-131, :289)
+    pub fn pz_vec_znx_add_into(m: *mut pz_module, res: *mut i64, rc: usize, rs: usize, rcol: usize, a: *const i64, ac: usize, as_: usize,
+        acol: usize, b: *const i64, bc: usize, bs: usize, bcol: usize) -> c_int;
+    pub fn pz_vec_znx_sub(m: *mut pz_module, res: *mut i64, rc: usize, rs: usize, rcol: usize, a: *const i64, ac: usize, as_: usize,
+        acol: usize, b: *const i64, bc: usize, bs: usize, bcol: usize) -> c_int;
+    pub fn pz_vec_znx_add_assign(m: *mut pz_module, res: *mut i64, rc: usize, rs: usize, rcol: usize, a: *const i64, ac: usize, as_: usize,
+        acol: usize) -> c_int;
+    pub fn pz_vec_znx_sub_assign(m: *mut pz_module, res: *mut i64, rc: usize, rs: usize, rcol: usize, a: *const i64, ac: usize, as_: usize,
+        acol: usize) -> c_int;
+    pub fn pz_vec_znx_sub_negate_assign(m: *mut pz_module, res: *mut i64, rc: usize, rs: usize, rcol: usize, a: *const i64, ac: usize,
+        as_: usize, acol: usize) -> c_int;
+    pub fn pz_vec_znx_negate(m: *mut pz_module, res: *mut i64, rc: usize, rs: usize, rcol: usize, a: *const i64, ac: usize, as_: usize,
+        acol: usize) -> c_int;
+    pub fn pz_vec_znx_negate_assign(m: *mut pz_module, res: *mut i64, rc: usize, rs: usize, rcol: usize) -> c_int;
+    pub fn pz_vec_znx_copy(m: *mut pz_module, res: *mut i64, rc: usize, rs: usize, rcol: usize, a: *const i64, ac: usize, as_: usize,
+        acol: usize) -> c_int;
+    pub fn pz_vec_znx_zero(m: *mut pz_module, res: *mut i64, rc: usize, rs: usize, rcol: usize) -> c_int;
+    pub fn pz_vec_znx_normalize_tmp_bytes(m: *const pz_module) -> usize;
+    pub fn pz_vec_znx_normalize(m: *mut pz_module, res: *mut i64, rc: usize, rs: usize, res_base2k: usize, res_offset: i64, rcol: usize,
+        a: *const i64, ac: usize, as_: usize, a_base2k: usize, acol: usize) -> c_int;
+    pub fn pz_vec_znx_normalize_assign(m: *mut pz_module, base2k: usize, res: *mut i64, rc: usize, rs: usize, rcol: usize) -> c_int;
     /// HIP-graph replay of the launch-bound composite calls (on by default)
     pub fn pz_module_set_graphs(m: *mut pz_module, enable: c_int) -> c_int;
     pub fn pz_module_graph_launches(m: *const pz_module) -> u64;

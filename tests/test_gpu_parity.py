@@ -1218,3 +1218,48 @@ def test_composite_calls_replay_as_hip_graphs(mods):
     for buf in (d_lwe, d_lut, d_brk, d_res):
         buf.free()
 
+
+@pytest.mark.parametrize("n", [32, 1024, 65536])
+def test_vec_znx_limbwise_family(mods, n):
+    """i64 VecZnx add / sub / negate / copy / zero / normalize[_assign] (hal_impl.rs:34-131, :289) vs the oracle's restatement of
+    reference/vec_znx/{add,sub,negate,copy,normalize}.rs: every ordering of the three sizes, other columns untouched, 63-bit
+    values (wrapping arithmetic), in-place forms."""
+    ref, hip = mods(n)
+    rng = seeded(5200 + n)
+    sizes = [(3, 2, 4), (3, 4, 2), (2, 3, 3), (4, 1, 1), (1, 3, 2)] if n <= 1024 else [(3, 2, 4), (2, 3, 1)]
+    for rs, asz, bsz in sizes:
+        a = VecZnx(n, 2, asz).fill_uniform(63, rng)
+        b = VecZnx(n, 3, bsz).fill_uniform(63, rng)
+        for name in ("vec_znx_add_into", "vec_znx_sub"):
+            r1, r2 = VecZnx(n, 2, rs).fill_uniform(20, rng), None
+            r2 = r1.copy()
+            getattr(ref, name)(r1, 1, a, 0, b, 2)
+            getattr(hip, name)(r2, 1, a, 0, b, 2)
+            assert np.array_equal(r1.data, r2.data), (name, rs, asz, bsz)
+        for name in ("vec_znx_add_assign", "vec_znx_sub_assign", "vec_znx_sub_negate_assign", "vec_znx_negate", "vec_znx_copy"):
+            r1 = VecZnx(n, 2, rs).fill_uniform(63, rng)
+            r2 = r1.copy()
+            getattr(ref, name)(r1, 0, a, 1)
+            getattr(hip, name)(r2, 0, a, 1)
+            assert np.array_equal(r1.data, r2.data), (name, rs, asz)
+        r1 = VecZnx(n, 2, rs).fill_uniform(63, rng)
+        r2 = r1.copy()
+        ref.vec_znx_negate_assign(r1, 1)
+        hip.vec_znx_negate_assign(r2, 1)
+        assert np.array_equal(r1.data, r2.data)
+        hip.vec_znx_zero(r2, 0)
+        assert not r2.data[:, 0].any() and np.array_equal(r2.data[:, 1], r1.data[:, 1])
+        # normalize: out of place (cross base) == vec_znx_big_normalize's oracle; in place, same base
+        for (rk, ak, off) in ((12, 12, 0), (15, 11, 3), (9, 17, -4)):
+            src = VecZnx(n, 2, asz).fill_uniform(50, rng)
+            r1 = VecZnx(n, 2, rs).fill_uniform(20, rng)
+            r2 = r1.copy()
+            ref.vec_znx_big_normalize(r1, rk, off, 1, src, ak, 0)
+            hip.vec_znx_normalize(r2, rk, off, 1, src, ak, 0)
+            assert np.array_equal(r1.data, r2.data), (rk, ak, off)
+        r1 = VecZnx(n, 2, rs).fill_uniform(55, rng)
+        r2 = r1.copy()
+        ref.vec_znx_normalize_assign(13, r1, 1)
+        hip.vec_znx_normalize_assign(13, r2, 1)
+        assert np.array_equal(r1.data, r2.data)
+

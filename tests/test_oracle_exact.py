@@ -399,3 +399,44 @@ def test_P7_glwe_trace_matches_exact():
             nxt[:, c, :] = exact.normalize_exact(v, base2k, size)
         cur.data[...] = nxt
     assert np.array_equal(res.data, cur.data)
+
+
+def test_P9_vec_znx_limbwise_family_direct():
+    """reference/vec_znx/{add,sub,negate,copy}.rs restated in the oracle vs the direct numpy statement (zero-extended operands,
+    wrapping i64), for every ordering of the sizes."""
+    n = 16
+    R = RefModule(n)
+    rng = seeded(99)
+
+    def ext(v, col, size):   # limbs of column col, zero-extended / truncated to `size`
+        out = np.zeros((size, n), dtype=np.int64)
+        k = min(size, v.size)
+        out[:k] = v.data[:k, col]
+        return out
+
+    with np.errstate(over="ignore"):
+        for rs, asz, bsz in [(3, 2, 4), (3, 4, 2), (2, 3, 3), (4, 1, 1), (1, 3, 2), (2, 2, 2)]:
+            a = VecZnx(n, 2, asz).fill_uniform(63, rng)
+            b = VecZnx(n, 2, bsz).fill_uniform(63, rng)
+            r = VecZnx(n, 2, rs).fill_uniform(63, rng)
+            R.vec_znx_add_into(r, 1, a, 0, b, 1)
+            assert np.array_equal(r.data[:, 1], ext(a, 0, rs) + ext(b, 1, rs))
+            R.vec_znx_sub(r, 0, a, 1, b, 0)
+            assert np.array_equal(r.data[:, 0], ext(a, 1, rs) - ext(b, 0, rs))
+            r0 = r.copy()
+            R.vec_znx_add_assign(r, 0, a, 0)
+            assert np.array_equal(r.data[:, 0], r0.data[:, 0] + ext(a, 0, rs)) and np.array_equal(r.data[:, 1], r0.data[:, 1])
+            r0 = r.copy()
+            R.vec_znx_sub_assign(r, 1, a, 1)
+            assert np.array_equal(r.data[:, 1], r0.data[:, 1] - ext(a, 1, rs))
+            r0 = r.copy()
+            R.vec_znx_sub_negate_assign(r, 0, b, 0)
+            assert np.array_equal(r.data[:, 0], ext(b, 0, rs) - r0.data[:, 0])
+            R.vec_znx_negate(r, 1, b, 1)
+            assert np.array_equal(r.data[:, 1], -ext(b, 1, rs))
+            r0 = r.copy()
+            R.vec_znx_negate_assign(r, 0)
+            assert np.array_equal(r.data[:, 0], -r0.data[:, 0])
+            R.vec_znx_copy(r, 0, a, 1)
+            assert np.array_equal(r.data[:, 0], ext(a, 1, rs))
+
