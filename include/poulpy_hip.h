@@ -226,6 +226,15 @@ size_t pz_vec_znx_normalize_tmp_bytes(const pz_module* m);
 int pz_vec_znx_normalize(pz_module* m, int64_t* res, size_t res_cols, size_t res_size, size_t res_base2k, int64_t res_offset,
                          size_t res_col, const int64_t* a, size_t a_cols, size_t a_size, size_t a_base2k, size_t a_col);
 int pz_vec_znx_normalize_assign(pz_module* m, size_t base2k, int64_t* res, size_t cols, size_t size, size_t col);
+/* vec_znx_lsh (hal_impl.rs:165), vec_znx_rsh (:137), vec_znx_lsh_assign (:221), tmp bytes (:163): bit shifts of the torus value
+ * by k bits with renormalization (reference/vec_znx/shift.rs:68-135, :245-342, :16-66); at equal bases these are the limb
+ * walks of vec_znx_normalize with res_offset = +k / -k.  (vec_znx_rsh_assign: below.) */
+size_t pz_vec_znx_lsh_tmp_bytes(const pz_module* m);
+int pz_vec_znx_lsh(pz_module* m, size_t base2k, size_t k, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                   const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+int pz_vec_znx_rsh(pz_module* m, size_t base2k, size_t k, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                   const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+int pz_vec_znx_lsh_assign(pz_module* m, size_t base2k, size_t k, int64_t* res, size_t cols, size_t size, size_t col);
 
 /* ---- X -> X^p on i64 containers (the glwe_automorphism callers) ---------------------- *
  * hal_impl.rs:236 vec_znx_automorphism, :241 _assign_tmp_bytes, :243 _assign; :517 vec_znx_big_automorphism, :522, :524.

@@ -212,6 +212,15 @@ class Module {  // Module<FFT64Hip>, poulpy-hal/src/layouts/module.rs:97-189
     void vec_znx_normalize_assign(size_t base2k, int64_t* res, size_t rc, size_t rs, size_t rcol) {
         check(pz_vec_znx_normalize_assign(m_, base2k, res, rc, rs, rcol), "vec_znx_normalize_assign");
     }
+    void vec_znx_lsh(size_t base2k, size_t k, int64_t* res, size_t rc, size_t rs, size_t rcol, const int64_t* a, size_t ac, size_t as, size_t acol) {
+        check(pz_vec_znx_lsh(m_, base2k, k, res, rc, rs, rcol, a, ac, as, acol), "vec_znx_lsh");
+    }
+    void vec_znx_rsh(size_t base2k, size_t k, int64_t* res, size_t rc, size_t rs, size_t rcol, const int64_t* a, size_t ac, size_t as, size_t acol) {
+        check(pz_vec_znx_rsh(m_, base2k, k, res, rc, rs, rcol, a, ac, as, acol), "vec_znx_rsh");
+    }
+    void vec_znx_lsh_assign(size_t base2k, size_t k, int64_t* res, size_t rc, size_t rs, size_t rcol) {
+        check(pz_vec_znx_lsh_assign(m_, base2k, k, res, rc, rs, rcol), "vec_znx_lsh_assign");
+    }
     void set_graphs(bool enable) { check(pz_module_set_graphs(m_, enable ? 1 : 0), "set_graphs"); }
     uint64_t graph_launches() const { return pz_module_graph_launches(m_); }
     void ggsw_from_gglwe_batched(int64_t* ggsw, const int64_t* a, size_t a_cols_in, size_t dnum, const double* const* tsk,

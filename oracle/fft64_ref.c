@@ -1484,6 +1484,91 @@ void pzr_vec_znx_copy(size_t n, int64_t* res, size_t res_cols, size_t res_size, 
     }
 }
 
+/* reference/vec_znx/shift.rs:68-135 (vec_znx_lsh, OVERWRITE = true), :16-66 (vec_znx_lsh_assign), :245-342 (vec_znx_rsh,
+ * OVERWRITE = true), restated literally with the step functions of znx/normalization.rs.  (They are the same limb walk as
+ * vec_znx_normalize with res_offset = +k / -k at equal bases: tests/test_oracle_exact.py P10 pins that equality, and the
+ * device exposes them through its normalize kernels.) */
+static void nz_final_step(size_t k, size_t lsh, int64_t* x, const int64_t* a, const int64_t* c, size_t n) { /* normalization.rs:274-300 */
+    size_t kk = lsh == 0 ? k : k - lsh;
+    for (size_t i = 0; i < n; ++i) x[i] = get_digit(k, wadd(wshl(get_digit(kk, a[i]), lsh), c[i]));
+}
+static void nz_first_step_assign(size_t k, size_t lsh, int64_t* x, int64_t* c, size_t n) { /* normalization.rs:44-65 */
+    size_t kk = lsh == 0 ? k : k - lsh;
+    for (size_t i = 0; i < n; ++i) {
+        int64_t d = get_digit(kk, x[i]);
+        c[i] = get_carry(kk, x[i], d);
+        x[i] = wshl(d, lsh);
+    }
+}
+void pzr_vec_znx_lsh(size_t n, size_t base2k, size_t k, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                     const int64_t* a, size_t a_cols, size_t a_size, size_t a_col) {
+    size_t steps = k / base2k, k_rem = k % base2k;
+    if (steps >= (res_size > a_size ? res_size : a_size)) {
+        for (size_t j = 0; j < res_size; ++j) memset(at_i64(res, n, res_cols, res_col, j), 0, n * sizeof(int64_t));
+        return;
+    }
+    int64_t* carry = (int64_t*)calloc(n, sizeof(int64_t));
+    size_t min_size = zmin(res_size, a_size > steps ? a_size - steps : 0);
+    size_t carry_only_start = zmin(steps + min_size, a_size);
+    for (size_t j = a_size; j-- > carry_only_start;) {
+        if (j == a_size - 1) nz_first_step_carry_only(base2k, k_rem, at_ci64(a, n, a_cols, a_col, j), carry, n);
+        else nz_middle_step_carry_only(base2k, k_rem, at_ci64(a, n, a_cols, a_col, j), carry, n);
+    }
+    if (carry_only_start == a_size) memset(carry, 0, n * sizeof(int64_t));
+    for (size_t j = min_size; j-- > 0;) {
+        if (j == 0) nz_final_step(base2k, k_rem, at_i64(res, n, res_cols, res_col, j), at_ci64(a, n, a_cols, a_col, j + steps), carry, n);
+        else nz_middle_step(base2k, k_rem, at_i64(res, n, res_cols, res_col, j), at_ci64(a, n, a_cols, a_col, j + steps), carry, n);
+    }
+    for (size_t j = min_size; j < res_size; ++j) memset(at_i64(res, n, res_cols, res_col, j), 0, n * sizeof(int64_t));
+    free(carry);
+}
+void pzr_vec_znx_lsh_assign(size_t n, size_t base2k, size_t k, int64_t* res, size_t res_cols, size_t res_size, size_t res_col) {
+    size_t steps = k / base2k, k_rem = k % base2k;
+    if (steps >= res_size) {
+        for (size_t j = 0; j < res_size; ++j) memset(at_i64(res, n, res_cols, res_col, j), 0, n * sizeof(int64_t));
+        return;
+    }
+    if (steps > 0) {
+        for (size_t j = 0; j < res_size - steps; ++j)
+            memcpy(at_i64(res, n, res_cols, res_col, j), at_i64(res, n, res_cols, res_col, j + steps), n * sizeof(int64_t));
+        for (size_t j = res_size - steps; j < res_size; ++j) memset(at_i64(res, n, res_cols, res_col, j), 0, n * sizeof(int64_t));
+    }
+    int64_t* carry = (int64_t*)calloc(n, sizeof(int64_t));
+    for (size_t j = res_size - steps; j-- > 0;) {
+        int64_t* x = at_i64(res, n, res_cols, res_col, j);
+        if (j == res_size - steps - 1) nz_first_step_assign(base2k, k_rem, x, carry, n);
+        else if (j == 0) nz_final_step_assign(base2k, k_rem, x, carry, n);
+        else nz_middle_step_assign(base2k, k_rem, x, carry, n);
+    }
+    free(carry);
+}
+void pzr_vec_znx_rsh(size_t n, size_t base2k, size_t k, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                     const int64_t* a, size_t a_cols, size_t a_size, size_t a_col) {
+    size_t steps = k / base2k, k_rem = k % base2k;
+    if (k_rem != 0) steps += 1;
+    size_t lsh = (base2k - k_rem) % base2k;
+    size_t res_end = zmin(res_size, steps);
+    size_t res_start = zmin(res_size, a_size + steps);
+    size_t a_start = zmin(a_size, res_size > steps ? res_size - steps : 0);
+    size_t a_out_range = a_size - a_start;
+    int64_t* carry = (int64_t*)calloc(n, sizeof(int64_t));
+    for (size_t j = 0; j < a_out_range; ++j) {
+        if (j == 0) nz_first_step_carry_only(base2k, lsh, at_ci64(a, n, a_cols, a_col, a_size - j - 1), carry, n);
+        else nz_middle_step_carry_only(base2k, lsh, at_ci64(a, n, a_cols, a_col, a_size - j - 1), carry, n);
+    }
+    if (a_out_range == 0) memset(carry, 0, n * sizeof(int64_t));
+    for (size_t j = 0; j < res_size; ++j) memset(at_i64(res, n, res_cols, res_col, j), 0, n * sizeof(int64_t));
+    size_t mid_range = res_start > res_end ? res_start - res_end : 0;
+    for (size_t j = 0; j < mid_range; ++j)
+        nz_middle_step(base2k, lsh, at_i64(res, n, res_cols, res_col, res_start - j - 1), at_ci64(a, n, a_cols, a_col, a_start - j - 1), carry, n);
+    for (size_t j = 0; j < res_end; ++j) {
+        int64_t* r = at_i64(res, n, res_cols, res_col, res_end - j - 1);
+        if (j == res_end - 1) nz_final_step_assign(base2k, lsh, r, carry, n);
+        else nz_middle_step_assign(base2k, lsh, r, carry, n);
+    }
+    free(carry);
+}
+
 /* ------------------------------------------------------------------------ */
 /* poulpy-core callers                                                       */
 /* ------------------------------------------------------------------------ */

@@ -162,6 +162,13 @@ void pzr_vec_znx_negate(size_t n, int64_t* res, size_t res_cols, size_t res_size
 void pzr_vec_znx_copy(size_t n, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
                       const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
 
+/* reference/vec_znx/shift.rs:68-135 (lsh), :16-66 (lsh_assign), :245-342 (rsh), OVERWRITE = true */
+void pzr_vec_znx_lsh(size_t n, size_t base2k, size_t k, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                     const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+void pzr_vec_znx_lsh_assign(size_t n, size_t base2k, size_t k, int64_t* res, size_t res_cols, size_t res_size, size_t res_col);
+void pzr_vec_znx_rsh(size_t n, size_t base2k, size_t k, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                     const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+
 /* conversion/gglwe_to_ggsw.rs:116-268 (ggsw_expand_row); ggsw = MatZnx(dnum, cols, cols, size), keys[c] = tsk.at(c) */
 void pzr_ggsw_expand_row(const pzr_tables* t, size_t rank, int64_t* ggsw, size_t dnum, size_t size, size_t base2k,
                          const double* const* keys, size_t key_dnum, size_t key_size, size_t dsize, size_t key_base2k);

@@ -271,6 +271,17 @@ class RefModule:
         self.lib.pzr_vec_znx_copy(c_size_t(self._n), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
                                   *_sz(a.cols, a.size, a_col))
 
+    def vec_znx_lsh(self, base2k, k, res, res_col, a, a_col, scratch=None):
+        self.lib.pzr_vec_znx_lsh(c_size_t(self._n), *_sz(base2k, k), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                 *_sz(a.cols, a.size, a_col))
+
+    def vec_znx_rsh(self, base2k, k, res, res_col, a, a_col, scratch=None):
+        self.lib.pzr_vec_znx_rsh(c_size_t(self._n), *_sz(base2k, k), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                 *_sz(a.cols, a.size, a_col))
+
+    def vec_znx_lsh_assign(self, base2k, k, res, res_col, scratch=None):
+        self.lib.pzr_vec_znx_lsh_assign(c_size_t(self._n), *_sz(base2k, k), _p(res.data), *_sz(res.cols, res.size, res_col))
+
     def ggsw_expand_row(self, ggsw, base2k, keys, dsize, key_base2k):
         """conversion/gglwe_to_ggsw.rs:116-268; ggsw: MatZnx (rows, cols_in = cols_out = rank+1), keys: rank prepared GGLWEs."""
         rank = ggsw.cols_out - 1

@@ -1391,6 +1391,41 @@ int pz_vec_znx_normalize_assign(pz_module* M, size_t base2k, int64_t* res, size_
     return finish_call(M, host);
 }
 
+// vec_znx_lsh (hal_impl.rs:165), vec_znx_rsh (:137), vec_znx_lsh_assign (:221): reference/vec_znx/shift.rs:68-135, :245-342,
+// :16-66 walk the limbs exactly as vec_znx_normalize does at equal bases with res_offset = +k / -k (same step functions, same
+// ranges; pinned on the literal restatement by tests/test_oracle_exact.py P10), so they run on the normalize kernels.
+size_t pz_vec_znx_lsh_tmp_bytes(const pz_module* M) { return M ? (size_t)M->n * 8 : 0; }  // shift.rs:12-14
+int pz_vec_znx_lsh(pz_module* M, size_t base2k, size_t k, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a,
+                   size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    PZ_REQUIRE(k <= ((size_t)1 << 40), "vec_znx_lsh: shift out of range");
+    return normalize_impl(M, res, res_cols, res_size, base2k, (int64_t)k, res_col, a, a_cols, a_size, base2k, a_col);
+}
+int pz_vec_znx_rsh(pz_module* M, size_t base2k, size_t k, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a,
+                   size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    PZ_REQUIRE(k <= ((size_t)1 << 40), "vec_znx_rsh: shift out of range");
+    return normalize_impl(M, res, res_cols, res_size, base2k, -(int64_t)k, res_col, a, a_cols, a_size, base2k, a_col);
+}
+int pz_vec_znx_lsh_assign(pz_module* M, size_t base2k, size_t k, int64_t* res, size_t cols, size_t size, size_t col) {
+    PZ_ENTER(M);
+    PZ_CHECK_COL(col, cols, "vec_znx_lsh_assign(res)");
+    PZ_REQUIRE(base2k >= 1 && base2k <= 63, "vec_znx_lsh_assign: base2k out of range");
+    PZ_REQUIRE(k <= ((size_t)1 << 40), "vec_znx_lsh_assign: shift out of range");
+    if (size == 0) return PZ_OK;
+    Stage sr;
+    PZ_TRY(sr.in(res, vbytes(M, cols, size), true, true, M));
+    const long long n = (long long)M->n;
+    PZ_TRY(ws_reserve(M, (size_t)size * (size_t)n * 8));
+    DV dr{sr.dev, 0, (int)cols, (int)size};
+    PZ_TRY(launch_ew(M, EW_COPY, M->ws, 0, n, poly_ptr(M, dr, (int)col, 0), 0, limb_stride(M, dr), nullptr, 0, 0, (int)size, 1));
+    DV tv{M->ws, 0, 1, (int)size};
+    PZ_TRY(dev_normalize(M, 1, dr, (int)base2k, (long long)k, (int)col, tv, (int)base2k, 0));
+    const bool host = sr.owned;
+    PZ_TRY(sr.finish());
+    return finish_call(M, host);
+}
+
 int pz_vec_znx_big_normalize_batched(pz_module* M, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_base2k,
                                      int64_t res_offset, size_t res_col, const int64_t* a, size_t a_cols, size_t a_size,
                                      size_t a_base2k, size_t a_col) {

@@ -71,7 +71,7 @@ def load_library(path: str | None = None) -> C.CDLL:
                  "pz_vmp_apply_dft_tmp_bytes", "pz_vmp_apply_dft_to_dft_tmp_bytes", "pz_vec_znx_big_normalize_tmp_bytes",
                  "pz_glwe_op_workspace_bytes", "pz_vec_znx_automorphism_assign_tmp_bytes",
                  "pz_vec_znx_big_automorphism_assign_tmp_bytes", "pz_blind_rotation_workspace_bytes", "pz_vec_znx_rsh_tmp_bytes", "pz_vec_znx_rotate_assign_tmp_bytes",
-                 "pz_circuit_bootstrapping_tmp_bytes", "pz_vec_znx_normalize_tmp_bytes"):
+                 "pz_circuit_bootstrapping_tmp_bytes", "pz_vec_znx_normalize_tmp_bytes", "pz_vec_znx_lsh_tmp_bytes"):
         getattr(lib, name).restype = c_size_t
     if path is None:
         _lib = lib
@@ -361,6 +361,17 @@ class Module:
 
     def vec_znx_normalize_assign(self, base2k, res: VecZnx, res_col, scratch=None):
         self._ck(self.lib.pz_vec_znx_normalize_assign(self.handle, c_size_t(base2k), _p(res.data), *_sz(res.cols, res.size, res_col)))
+
+    def vec_znx_lsh(self, base2k, k, res: VecZnx, res_col, a: VecZnx, a_col, scratch=None):
+        self._ck(self.lib.pz_vec_znx_lsh(self.handle, *_sz(base2k, k), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                         *_sz(a.cols, a.size, a_col)))
+
+    def vec_znx_rsh(self, base2k, k, res: VecZnx, res_col, a: VecZnx, a_col, scratch=None):
+        self._ck(self.lib.pz_vec_znx_rsh(self.handle, *_sz(base2k, k), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                         *_sz(a.cols, a.size, a_col)))
+
+    def vec_znx_lsh_assign(self, base2k, k, res: VecZnx, res_col, scratch=None):
+        self._ck(self.lib.pz_vec_znx_lsh_assign(self.handle, *_sz(base2k, k), _p(res.data), *_sz(res.cols, res.size, res_col)))
 
     # -- X -> X^p on i64 containers (hal_impl.rs:236-243, :517-524) ----------------------------
     def vec_znx_automorphism(self, p: int, res: VecZnx, res_col, a: VecZnx, a_col):

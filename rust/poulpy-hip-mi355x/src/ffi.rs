@@ -165,6 +165,12 @@ extern "C" {
     pub fn pz_vec_znx_normalize(m: *mut pz_module, res: *mut i64, rc: usize, rs: usize, res_base2k: usize, res_offset: i64, rcol: usize,
         a: *const i64, ac: usize, as_: usize, a_base2k: usize, acol: usize) -> c_int;
     pub fn pz_vec_znx_normalize_assign(m: *mut pz_module, base2k: usize, res: *mut i64, rc: usize, rs: usize, rcol: usize) -> c_int;
+    pub fn pz_vec_znx_lsh_tmp_bytes(m: *const pz_module) -> usize;
+    pub fn pz_vec_znx_lsh(m: *mut pz_module, base2k: usize, k: usize, res: *mut i64, rc: usize, rs: usize, rcol: usize, a: *const i64,
+        ac: usize, as_: usize, acol: usize) -> c_int;
+    pub fn pz_vec_znx_rsh(m: *mut pz_module, base2k: usize, k: usize, res: *mut i64, rc: usize, rs: usize, rcol: usize, a: *const i64,
+        ac: usize, as_: usize, acol: usize) -> c_int;
+    pub fn pz_vec_znx_lsh_assign(m: *mut pz_module, base2k: usize, k: usize, res: *mut i64, rc: usize, rs: usize, rcol: usize) -> c_int;
     /// HIP-graph replay of the launch-bound composite calls (on by default)
     pub fn pz_module_set_graphs(m: *mut pz_module, enable: c_int) -> c_int;
     pub fn pz_module_graph_launches(m: *const pz_module) -> u64;

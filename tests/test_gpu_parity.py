@@ -1263,3 +1263,26 @@ def test_vec_znx_limbwise_family(mods, n):
         hip.vec_znx_normalize_assign(13, r2, 1)
         assert np.array_equal(r1.data, r2.data)
 
+
+@pytest.mark.parametrize("n", [64, 4096])
+def test_vec_znx_shifts(mods, n):
+    """vec_znx_lsh / vec_znx_rsh / vec_znx_lsh_assign (hal_impl.rs:137-221) vs the oracle's literal restatement of
+    reference/vec_znx/shift.rs: shifts from 0 past the total precision, every ordering of the sizes."""
+    ref, hip = mods(n)
+    rng = seeded(5300 + n)
+    base2k = 13
+    for rs, asz in [(3, 3), (2, 4), (4, 2)]:
+        for k in (0, 1, 7, 13, 14, 26, 30, 39, 40, 60):
+            a = VecZnx(n, 2, asz).fill_uniform(45, rng)
+            for name in ("vec_znx_lsh", "vec_znx_rsh"):
+                r1 = VecZnx(n, 2, rs).fill_uniform(20, rng)
+                r2 = r1.copy()
+                getattr(ref, name)(base2k, k, r1, 1, a, 0)
+                getattr(hip, name)(base2k, k, r2, 1, a, 0)
+                assert np.array_equal(r1.data, r2.data), (name, rs, asz, k)
+            x1 = VecZnx(n, 2, rs).fill_uniform(45, rng)
+            x2 = x1.copy()
+            ref.vec_znx_lsh_assign(base2k, k, x1, 0)
+            hip.vec_znx_lsh_assign(base2k, k, x2, 0)
+            assert np.array_equal(x1.data, x2.data), ("lsh_assign", rs, k)
+

@@ -440,3 +440,38 @@ def test_P9_vec_znx_limbwise_family_direct():
             R.vec_znx_copy(r, 0, a, 1)
             assert np.array_equal(r.data[:, 0], ext(a, 1, rs))
 
+
+def test_P10_shifts_are_offset_normalizations():
+    """reference/vec_znx/shift.rs restated literally (lsh, lsh_assign, rsh out of place) vs vec_znx_normalize at equal bases with
+    res_offset = +k / -k, and vs the exact value: lsh/rsh by k bits multiplies the torus value by 2^(+-k) (mod 1, rounding of
+    the dropped bits as the normalization does); every (res_size, a_size) ordering, k from 0 past the total precision."""
+    n, base2k = 16, 11
+    R = RefModule(n)
+    rng = seeded(1010)
+    for rs, asz in [(3, 3), (2, 4), (4, 2), (1, 3), (3, 1)]:
+        for k in list(range(0, base2k * (max(rs, asz) + 1) + 3)):
+            a = VecZnx(n, 2, asz).fill_uniform(40, rng)
+            r1 = VecZnx(n, 2, rs).fill_uniform(20, rng)
+            r2 = r1.copy()
+            R.vec_znx_lsh(base2k, k, r1, 1, a, 0)
+            R.vec_znx_big_normalize(r2, base2k, k, 1, a, base2k, 0)
+            assert np.array_equal(r1.data, r2.data), ("lsh", rs, asz, k)
+            r1 = VecZnx(n, 2, rs).fill_uniform(20, rng)
+            r2 = r1.copy()
+            R.vec_znx_rsh(base2k, k, r1, 0, a, 1)
+            R.vec_znx_big_normalize(r2, base2k, -k, 0, a, base2k, 1)
+            assert np.array_equal(r1.data, r2.data), ("rsh", rs, asz, k)
+        for k in range(0, base2k * rs + 3):
+            x = VecZnx(n, 2, rs).fill_uniform(40, rng)
+            y = x.copy()
+            z = VecZnx(n, 2, rs)
+            R.vec_znx_lsh_assign(base2k, k, x, 1)
+            R.vec_znx_lsh(base2k, k, z, 1, y, 1)
+            assert np.array_equal(x.data[:, 1], z.data[:, 1]) and np.array_equal(x.data[:, 0], y.data[:, 0]), ("lsh_assign", rs, k)
+    # exact value: rsh keeps the torus value / 2^k up to the precision of res (balanced rounding of what falls off)
+    a = VecZnx(n, 1, 3).fill_uniform(base2k, rng)
+    for k in (1, 5, 11, 13):
+        r = VecZnx(n, 1, 4)
+        R.vec_znx_rsh(base2k, k, r, 0, a, 0)
+        assert exact.torus_equal(a.data[:, 0], base2k, r.data[:, 0], base2k, res_offset=-k)
+
