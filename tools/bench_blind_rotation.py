@@ -61,6 +61,7 @@ def main():
     mat = torch.randint(-half, half, (pm_elems,), dtype=torch.int64, device=dev, generator=g)
     for i in range(s["n_lwe"]):   # same synthetic GGSW for every coefficient would let caches lie: permute it per key
         mi = torch.roll(mat, i * 977)
+        torch.cuda.synchronize()   # torch's stream and the module's stream are not ordered: the roll must have finished
         mod._ck(mod.lib.pz_vmp_prepare(mod.handle, C.c_void_p(brk[i].data_ptr()), C.c_void_p(mi.data_ptr()), C.c_size_t(s["dnum"]),
                                        C.c_size_t(cols), C.c_size_t(cols), C.c_size_t(s["brk_size"])))
         mod.sync()   # device-pointer calls are stream-ordered on the module's stream: `mi` must outlive the kernels that read it

@@ -55,6 +55,7 @@ def main():
     def synth(rows, cols_in, size, count):
         base = torch.randint(-half, half, (n * rows * cols_in * cols * size,), dtype=torch.int64, device=dev, generator=g)
         mats = [torch.roll(base, i * 977) for i in range(count)]   # distinct keys (one shared key would let the caches lie)
+        torch.cuda.synchronize()   # torch's stream and the module's stream are not ordered: the rolls must have finished
         return mats, [prepare(m, rows, cols_in, size) for m in mats]
 
     brk_m, brk_p = synth(s["brk_dnum"], cols, s["glwe_size"], s["n_lwe"])
