@@ -20,7 +20,11 @@
  *    results are visible in the caller's buffer — "logically synchronous"
  *    (poulpy-hal/docs/backend_safety_contract.md:16-19).  Device buffers are
  *    processed in place on the module stream; the call returns after enqueue
- *    and pz_module_sync() (or any host-pointer call) drains the stream.
+ *    and pz_module_sync() (or any host-pointer call) drains the stream.  The
+ *    module stream is NOT ordered with any other stream (it is non-blocking with
+ *    respect to the null stream too): a device buffer written by the caller's own
+ *    kernels or copies on another stream must be complete (event or stream sync)
+ *    before it is passed in, and must stay alive until pz_module_sync().
  *  - The bytes of VecZnxDft / SvpPPol / VmpPMat (ScalarPrep = f64) are
  *    backend-private ("device order"): same byte sizes as the
  *    reference (n*cols*size*8, module.rs:51-65) but NOT the reference's
