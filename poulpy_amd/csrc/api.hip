@@ -2053,7 +2053,7 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
                 g.row_max = row_max; g.ncols = cols * bsz; g.m = (int)M->m; g.batch = B; g.i0 = b0; g.blk = blk;
                 g.lwe = (const long long*)lwe_2n; g.lwe_bs = lwe_bs; g.w2n = M->w2n;
                 static const int brl_dbg = getenv("POULPY_DBG_BRL") ? atoi(getenv("POULPY_DBG_BRL")) : 0;
-                g.dbg = brl_dbg; g.gx = g.gy = g.gz = 1; g.xcd = 0;
+                g.dbg = brl_dbg; g.gx = g.gy = g.gz = 1; g.xcd = 0; g.allcg = 0;
                 constexpr int CT = 2;
                 KTimer kt(M, PZ_K_VMP);
                 const int nc = cols * bsz;
@@ -2075,7 +2075,9 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
                     g.gx = (B + 7) / 8; g.gy = (int)(M->m / 64); g.gz = ngroups;
                     static const int br_xcd = getenv("POULPY_DBG_BR_XCD") ? atoi(getenv("POULPY_DBG_BR_XCD")) : 1;
                     g.xcd = (br_xcd && (g.gx * g.gy) % 8 == 0) ? 1 : 0;
-                    const unsigned total = (unsigned)(g.gx * g.gy * g.gz);
+                    static const int br_allcg = getenv("POULPY_DBG_BR_ALLCG") ? atoi(getenv("POULPY_DBG_BR_ALLCG")) : 1;
+                    g.allcg = br_allcg ? 1 : 0;
+                    const unsigned total = (unsigned)(g.gx * g.gy * (g.allcg ? 1 : g.gz));
 #define PZ_BRB(MR_, CG_)                                                                                           \
     if (!launched && mr == MR_ && cgs == CG_) {                                                                    \
         hipLaunchKernelGGL((k_br_block_lds<2, MR_, CG_>), dim3(total), dim3(256), 0, M->stream, g);                \

@@ -420,6 +420,7 @@ struct BrBlockArgs {
     long long lwe_bs;
     const cplx* w2n;
     int dbg;               // diagnostic (tools/dbg): bit 0 no key loads, bit 1 no products, bit 2 no accumulator loads, bit 3 no LDS staging
+    int allcg;             // k_br_block_lds: one workgroup walks all gz column groups of its tile (accumulator tile read once)
     int gx, gy, gz, xcd;   // k_br_block_lds: logical grid (ciphertext tiles, 64-point slices, column groups) of the 1-D launch
 };
 
@@ -548,13 +549,16 @@ __global__ void __launch_bounds__(256) k_br_block_lds(BrBlockArgs g) {
     constexpr int NW = 4, NE = CG * MAXR, PER = (NE + NW - 1) / NW;
     __shared__ cplx ks[2][NE][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int tile, cg;
-    if (g.xcd) {
+    int tile, cg0;
+    if (g.allcg) {
+        tile = blockIdx.x;
+        cg0 = 0;
+    } else if (g.xcd) {
         const int L = blockIdx.x, k = L >> 3;
-        cg = k % g.gz;
+        cg0 = k % g.gz;
         tile = (k / g.gz) * 8 + (L & 7);
     } else {
-        cg = blockIdx.x % g.gz;
+        cg0 = blockIdx.x % g.gz;
         tile = blockIdx.x / g.gz;
     }
     const int q = (tile / g.gx) * 64 + lane;
@@ -574,7 +578,7 @@ __global__ void __launch_bounds__(256) k_br_block_lds(BrBlockArgs g) {
 #pragma unroll
         for (int j = 0; j < CG; ++j) out[t][j] = make_double2(0.0, 0.0);
     cplx nxt[PER];
-    brl_fetch<MAXR, CG, PER>(nxt, g, g.i0, w, cg, q);
+    brl_fetch<MAXR, CG, PER>(nxt, g, g.i0, w, cg0, q);
     // rotation amounts of the block: lane l holds coefficient i0 + l (blk <= 64); DFT(X^a)[q] is fetched one coefficient ahead
     unsigned aiv[CT];
     cplx xn[CT];
@@ -591,18 +595,20 @@ __global__ void __launch_bounds__(256) k_br_block_lds(BrBlockArgs g) {
     }
     brl_stage<PER, NE>(nxt, ks[0], w, lane);
     __syncthreads();
-    const int iend = g.i0 + g.blk;
-    for (int i = g.i0; i < iend; ++i) {
-        const int buf = (i - g.i0) & 1;
-        brl_fetch<MAXR, CG, PER>(nxt, g, min(i + 1, iend - 1), w, cg, q);  // (unconditional: a guarded array stays in scratch)
+    // stages = (column group, coefficient) pairs in order; the loads of stage s+1 are in flight while stage s is multiplied
+    const int nst = (g.allcg ? g.gz : 1) * g.blk;
+    int is = 0, cgs = cg0;
+    for (int s = 0; s < nst; ++s) {
+        const int buf = s & 1;
+        int is_n = is + 1, cg_n = cgs;
+        if (is_n == g.blk) { is_n = 0; cg_n = cgs + 1; }
+        if (s + 1 >= nst) { is_n = is; cg_n = cgs; }  // (unconditional fetch: a guarded array stays in scratch)
+        brl_fetch<MAXR, CG, PER>(nxt, g, g.i0 + is_n, w, cg_n, q);
         cplx xm[CT];
-        {
-            const int nx = min(i + 1 - g.i0, g.blk - 1);
 #pragma unroll
-            for (int t = 0; t < CT; ++t) {
-                xm[t] = xn[t];
-                xn[t] = g.w2n[((unsigned)__builtin_amdgcn_readlane((int)aiv[t], nx) * (4u * (unsigned)q + 1u)) & mask];
-            }
+        for (int t = 0; t < CT; ++t) {
+            xm[t] = xn[t];
+            xn[t] = g.w2n[((unsigned)__builtin_amdgcn_readlane((int)aiv[t], is_n) * (4u * (unsigned)q + 1u)) & mask];
         }
         cplx sacc[CT][CG];
 #pragma unroll
@@ -634,19 +640,22 @@ __global__ void __launch_bounds__(256) k_br_block_lds(BrBlockArgs g) {
                 out[t][j].x = (out[t][j].x + xv.x) - sacc[t][j].x;
                 out[t][j].y = (out[t][j].y + xv.y) - sacc[t][j].y;
             }
-        if (!(g.dbg & 8)) brl_stage<PER, NE>(nxt, ks[buf ^ 1], w, lane);
-        __syncthreads();
-    }
+        if (is == g.blk - 1) {  // last coefficient of this column group: store and restart the accumulators
 #pragma unroll
-    for (int t = 0; t < CT; ++t) {
-        const int b = b0 + t;
-        if (b < g.batch) {
+            for (int t = 0; t < CT; ++t) {
+                const int b = b0 + t;
 #pragma unroll
-            for (int j = 0; j < CG; ++j) {
-                const int c = cg * CG + j;
-                if (c < g.ncols) g.acc_add[(long long)b * g.o_bs + (long long)c * g.m + q] = out[t][j];
+                for (int j = 0; j < CG; ++j) {
+                    const int c = cgs * CG + j;
+                    if (b < g.batch && c < g.ncols) g.acc_add[(long long)b * g.o_bs + (long long)c * g.m + q] = out[t][j];
+                    out[t][j] = make_double2(0.0, 0.0);
+                }
             }
         }
+        if (!(g.dbg & 8)) brl_stage<PER, NE>(nxt, ks[buf ^ 1], w, lane);
+        __syncthreads();
+        is = is_n;
+        cgs = cg_n;
     }
 }
 
