@@ -297,6 +297,18 @@ int pz_glwe_automorphism_batched(pz_module* m, int64_t* res, const int64_t* a, c
  * arrays; each key_pmats[s] and res are device pointers.  p describes one step (a_size = res_size, equal base2k). */
 int pz_glwe_trace_batched(pz_module* m, int64_t* res, size_t nsteps, const int64_t* gals, const double* const* key_pmats,
                           const pz_glwe_op_params* p, size_t batch);
+/* GLWEPacking::glwe_pack (poulpy-core/src/glwe_packing.rs:122-176, pack_internal :15-87) on `batch` independent packing
+ * problems that share the occupancy pattern; ciphertexts, keys and result share base2k and size (p: a_size = res_size).
+ *   indices / cts   HOST arrays of nslots entries: cts[s] -> the `batch` contiguous device GLWEs of index indices[s] (the
+ *                   reference's HashMap<usize, &mut GLWE>); they are CLOBBERED, as the reference's entries are
+ *   gals / key_pmats HOST arrays of log2(n) entries: Galois element and prepared automorphism key of trace step i
+ *                   (i = 0: -1, else galois_element(2^(i-1)); glwe_pack_galois_elements :100-102)
+ *   res             batch contiguous GLWEs: the packed result after the final partial trace (:175)
+ *   tmp             device scratch of pz_glwe_pack_tmp_bytes */
+size_t pz_glwe_pack_tmp_bytes(const pz_module* m, const pz_glwe_op_params* p, size_t batch);
+int pz_glwe_pack_batched(pz_module* m, int64_t* res, size_t nslots, const uint64_t* indices, int64_t* const* cts,
+                         size_t log_gap_out, const int64_t* gals, const double* const* key_pmats, const pz_glwe_op_params* p,
+                         void* tmp, size_t tmp_bytes, size_t batch);
 /* CoreImpl ggsw_external_product (poulpy-core/src/external_product/ggsw.rs:54-58): res[row][col] = a[row][col] (x) ggsw
  * for the a_dnum * (rank+1) GLWE entries of the GGSW `a` (MatZnx layout: entries are contiguous), device pointers. */
 int pz_ggsw_external_product(pz_module* m, int64_t* res, const int64_t* a, size_t a_dnum, const double* ggsw_pmat,

@@ -221,6 +221,11 @@ class Module {  // Module<FFT64Hip>, poulpy-hal/src/layouts/module.rs:97-189
     void vec_znx_lsh_assign(size_t base2k, size_t k, int64_t* res, size_t rc, size_t rs, size_t rcol) {
         check(pz_vec_znx_lsh_assign(m_, base2k, k, res, rc, rs, rcol), "vec_znx_lsh_assign");
     }
+    size_t glwe_pack_tmp_bytes(const pz_glwe_op_params& p, size_t batch) const { return pz_glwe_pack_tmp_bytes(m_, &p, batch); }
+    void glwe_pack_batched(int64_t* res, size_t nslots, const uint64_t* indices, int64_t* const* cts, size_t log_gap_out, const int64_t* gals,
+                           const double* const* keys, const pz_glwe_op_params& p, void* tmp, size_t tmp_bytes, size_t batch) {
+        check(pz_glwe_pack_batched(m_, res, nslots, indices, cts, log_gap_out, gals, keys, &p, tmp, tmp_bytes, batch), "glwe_pack_batched");
+    }
     void set_graphs(bool enable) { check(pz_module_set_graphs(m_, enable ? 1 : 0), "set_graphs"); }
     uint64_t graph_launches() const { return pz_module_graph_launches(m_); }
     void ggsw_from_gglwe_batched(int64_t* ggsw, const int64_t* a, size_t a_cols_in, size_t dnum, const double* const* tsk,

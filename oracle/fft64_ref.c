@@ -1987,3 +1987,73 @@ void pzr_circuit_bootstrap_to_constant(const pzr_tables* t, size_t rank, size_t 
     free(rot);
     free(tmp);
 }
+
+/* ------------------------------------------------------------------------ */
+/* poulpy-core/src/glwe_packing.rs: pack_internal :15-87, glwe_pack_default :122-176                                  */
+/* One base2k and one size for the ciphertexts, the keys' output and the result.  slots[j] (j < n) is the GLWE at index j   */
+/* of the reference's HashMap or NULL; present entries are modified in place exactly as the reference's `&mut` entries.   */
+/* gals[i] / keys[i], i < log_n: the automorphism keys of trace step i (i = 0: -1, else galois_element(2^(i-1))).        */
+/* ------------------------------------------------------------------------ */
+static void glwe_rsh1(size_t n, size_t cols, size_t size, size_t base2k, int64_t* x) {
+    for (size_t c = 0; c < cols; ++c) pzr_vec_znx_rsh_assign(n, base2k, 1, x, cols, size, c); /* operations/glwe.rs:1096-1112 */
+}
+static void glwe_rotate_to(size_t n, size_t cols, size_t size, int64_t k, int64_t* res, const int64_t* a) {
+    for (size_t c = 0; c < cols; ++c) pzr_vec_znx_rotate(n, k, res, cols, size, c, a, cols, size, c);
+}
+void pzr_glwe_pack(const pzr_tables* t, size_t rank, int64_t* res, int64_t** slots, size_t size, size_t base2k, size_t log_gap_out,
+                   const int64_t* gals, const double* const* keys, size_t dnum, size_t key_size) {
+    size_t n = t->m << 1, cols = rank + 1, ct = n * cols * size;
+    size_t log_n = 0;
+    while (((size_t)1 << log_n) < n) ++log_n;
+    int64_t* tmp_b = (int64_t*)malloc(ct * sizeof(int64_t));
+    int64_t* tmp = (int64_t*)malloc(ct * sizeof(int64_t));
+    for (size_t i = 0; i + log_gap_out < log_n; ++i) { /* :156 */
+        size_t tt = (size_t)1 << (log_n - 1 - i);      /* :157 and pack_internal :39 */
+        for (size_t j = 0; j < tt; ++j) {
+            int64_t* a = slots[j];
+            int64_t* b = slots[j + tt];
+            slots[j] = NULL;
+            slots[j + tt] = NULL;
+            if (a) {
+                if (b) { /* :41-70 */
+                    glwe_rotate_to(n, cols, size, -(int64_t)tt, tmp, a);           /* a = a * X^-t */
+                    memcpy(a, tmp, ct * sizeof(int64_t));
+                    for (size_t c = 0; c < cols; ++c) pzr_vec_znx_sub(n, tmp_b, cols, size, c, a, cols, size, c, b, cols, size, c);
+                    glwe_rsh1(n, cols, size, base2k, tmp_b);
+                    for (size_t c = 0; c < cols; ++c) pzr_vec_znx_assign_op(0, n, a, cols, size, c, b, cols, size, c); /* a += b */
+                    glwe_rsh1(n, cols, size, base2k, a);
+                    for (size_t c = 0; c < cols; ++c) pzr_vec_znx_normalize_assign(n, base2k, tmp_b, cols, size, c);
+                    memcpy(tmp, tmp_b, ct * sizeof(int64_t));                         /* tmp_b = phi(tmp_b) (glwe_automorphism_assign) */
+                    pzr_glwe_automorphism(t, rank, PZR_KS_AUTO, gals[i], tmp_b, size, base2k, tmp, size, base2k, keys[i], dnum, key_size, 1, base2k);
+                    for (size_t c = 0; c < cols; ++c) pzr_vec_znx_assign_op(1, n, a, cols, size, c, tmp_b, cols, size, c); /* a -= tmp_b */
+                    for (size_t c = 0; c < cols; ++c) pzr_vec_znx_normalize_assign(n, base2k, a, cols, size, c);
+                    glwe_rotate_to(n, cols, size, (int64_t)tt, tmp, a);              /* a = a * X^t */
+                    memcpy(a, tmp, ct * sizeof(int64_t));
+                } else { /* :71-75 */
+                    glwe_rsh1(n, cols, size, base2k, a);
+                    memcpy(tmp, a, ct * sizeof(int64_t));
+                    pzr_glwe_automorphism(t, rank, PZR_KS_AUTO_ADD, gals[i], a, size, base2k, tmp, size, base2k, keys[i], dnum, key_size, 1, base2k);
+                }
+                slots[j] = a; /* :168-169 */
+            } else if (b) { /* :76-86 */
+                glwe_rotate_to(n, cols, size, (int64_t)tt, tmp_b, b);
+                glwe_rsh1(n, cols, size, base2k, tmp_b);
+                pzr_glwe_automorphism(t, rank, PZR_KS_AUTO_SUB_NEGATE, gals[i], b, size, base2k, tmp_b, size, base2k, keys[i], dnum, key_size, 1,
+                                      base2k);
+                slots[j] = b; /* :170-171 */
+            }
+        }
+    }
+    /* :175 glwe_trace(res, log_n - log_gap_out, a[0]) : copy, trace_assign over the remaining steps, copy (glwe_trace.rs:92-123) */
+    if (!slots[0]) { /* the reference panics here (a.get(&0).unwrap()): res is left untouched */
+        free(tmp_b);
+        free(tmp);
+        return;
+    }
+    memcpy(res, slots[0], ct * sizeof(int64_t));
+    size_t skip = log_n - log_gap_out;
+    pzr_glwe_trace_assign(t, rank, res, size, base2k, log_n - skip, gals + skip, keys + skip, dnum, key_size, 1);
+    free(tmp_b);
+    free(tmp);
+}
+

@@ -206,6 +206,10 @@ void pzr_circuit_bootstrap_to_constant(const pzr_tables* t, size_t rank, size_t 
                                        int64_t* ggsw, size_t res_dnum, size_t res_size, size_t gap,
                                        const double* const* tsk, size_t tsk_dnum, size_t tsk_size);
 
+/* poulpy-core/src/glwe_packing.rs:15-87, :122-176 (one base2k, one size); slots: n pointers (NULL = absent), clobbered */
+void pzr_glwe_pack(const pzr_tables* t, size_t rank, int64_t* res, int64_t** slots, size_t size, size_t base2k, size_t log_gap_out,
+                   const int64_t* gals, const double* const* keys, size_t dnum, size_t key_size);
+
 #ifdef __cplusplus
 }
 #endif

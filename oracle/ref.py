@@ -339,6 +339,20 @@ class RefModule:
             *_sz(brk_dnum, brk_size, glwe_size), _p(x_pow_a), c_size_t(ns), g, ap, *_sz(atk[0].rows, atk[0].size), _p(ggsw.data),
             *_sz(ggsw.rows, ggsw.size, gap), tp, *_sz(tsk[0].rows, tsk[0].size))
 
+    def glwe_pack(self, res, base2k, cts: dict, log_gap_out, gals, pmats):
+        """glwe_packing.rs:122-176 at one base2k / size: cts {index: VecZnx GLWE} (clobbered), gals / pmats for the log_n trace steps."""
+        rank = res.cols - 1
+        n = self._n
+        slots = (c_void_p * n)()
+        for j, ct in cts.items():
+            assert ct.cols == res.cols and ct.size == res.size
+            slots[j] = ct.data.ctypes.data
+        ns = len(gals)
+        g = (c_int64 * ns)(*[int(x) for x in gals])
+        ptrs = (c_void_p * ns)(*[pm.data.ctypes.data for pm in pmats])
+        self.lib.pzr_glwe_pack(self.t, c_size_t(rank), _p(res.data), slots, *_sz(res.size, base2k, log_gap_out), g, ptrs,
+                               *_sz(pmats[0].rows, pmats[0].size))
+
     # glwe_trace (poulpy-core/src/glwe_trace.rs) and the shift it uses
     def vec_znx_rsh_assign(self, base2k, k, res, res_col, scratch=None):
         self.lib.pzr_vec_znx_rsh_assign(c_size_t(self._n), *_sz(base2k, k), _p(res.data), *_sz(res.cols, res.size, res_col))
@@ -347,6 +361,8 @@ class RefModule:
         """glwe_trace.rs:129-176 at equal bases: gals[s], pmats[s] (prepared automorphism keys) for the steps skip..log_n."""
         rank = res.cols - 1
         ns = len(gals)
+        if ns == 0:
+            return
         g = (c_int64 * ns)(*[int(x) for x in gals])
         ptrs = (c_void_p * ns)(*[pm.data.ctypes.data for pm in pmats])
         self.lib.pzr_glwe_trace_assign(self.t, c_size_t(rank), _p(res.data), *_sz(res.size, base2k), c_size_t(ns), g, ptrs,

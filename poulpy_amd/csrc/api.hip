@@ -2224,4 +2224,107 @@ int pz_circuit_bootstrapping_execute_to_constant_batched(pz_module* M, int64_t* 
     });
 }
 
+// ------------------------------------------------------------------------------
+// public: GLWEPacking::glwe_pack (poulpy-core/src/glwe_packing.rs:122-176, pack_internal :15-87) on `batch` independent packing
+// problems with the same occupancy pattern, one base2k / size for ciphertexts, keys and result.  cts[s] points to the `batch`
+// contiguous GLWEs of index indices[s] (the reference's HashMap entry); they are clobbered, as the reference's `&mut` entries.
+// The tree is walked on the host exactly as the reference does; every step is a batched launch of the i64 kernels
+// (rotate, add / sub, rsh, normalize) or of the fused automorphism pipeline.
+// ------------------------------------------------------------------------------
+size_t pz_glwe_pack_tmp_bytes(const pz_module* M, const pz_glwe_op_params* p, size_t batch) {
+    if (!M || !p) return 0;
+    return 3 * align256(batch * (size_t)M->n * (p->rank + 1) * p->res_size * 8);
+}
+static int glwe_pack(pz_module* M, int64_t* res, size_t nslots, const uint64_t* indices, int64_t* const* cts, size_t log_gap_out,
+                     const int64_t* gals, const double* const* key_pmats, const pz_glwe_op_params* p, void* tmp, size_t tmp_bytes,
+                     size_t batch) {
+    PZ_REQUIRE(p != nullptr && indices != nullptr && cts != nullptr && gals != nullptr && key_pmats != nullptr, "glwe_pack: null argument");
+    PZ_REQUIRE(p->a_size == p->res_size && p->a_base2k == p->res_base2k && p->res_base2k == p->key_base2k && p->rank_out == p->rank &&
+                   p->dsize == 1,
+               "glwe_pack: ciphertexts, keys and result share base2k and size (the other cases re-normalize around this call)");
+    size_t log_n = 0;
+    while (((size_t)1 << log_n) < (size_t)M->n) ++log_n;
+    PZ_REQUIRE(log_gap_out <= log_n && nslots >= 1, "glwe_pack: bad shape");
+    PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(tmp), "batched entry points take device pointers");
+    PZ_REQUIRE(tmp_bytes >= pz_glwe_pack_tmp_bytes(M, p, batch), "glwe_pack: tmp is smaller than pz_glwe_pack_tmp_bytes");
+    if (batch == 0) return PZ_OK;
+    const long long n = (long long)M->n;
+    const int cols = (int)p->rank + 1, size = (int)p->res_size, k = (int)p->res_base2k, B = (int)batch;
+    const long long ct = n * cols * size;
+    const size_t ctb = align256((size_t)B * ct * 8);
+    int64_t* tmp_b = (int64_t*)tmp;
+    int64_t* t1 = (int64_t*)((char*)tmp + ctb);
+    int64_t* t2 = (int64_t*)((char*)tmp + 2 * ctb);
+    std::vector<int64_t*> slots((size_t)M->n, nullptr);
+    for (size_t s = 0; s < nslots; ++s) {
+        PZ_REQUIRE(indices[s] < (uint64_t)M->n, "glwe_pack: index out of range");   // glwe_packing.rs:138
+        PZ_REQUIRE(cts[s] != nullptr && is_device_ptr(cts[s]) && slots[indices[s]] == nullptr, "glwe_pack: bad or duplicate entry");
+        slots[indices[s]] = cts[s];
+    }
+    const PolyMap pm{size, cols, ct, (long long)cols * n, n, 0};
+    const int npolys = B * size * cols;
+    auto rotate_to = [&](long long kk, int64_t* dst, const int64_t* src) {
+        return launch_rotate(M, npolys, (const long long*)src, pm, (long long*)dst, pm, 0, size * cols, nullptr, 0, 0, kk);
+    };
+    auto rotate_assign = [&](long long kk, int64_t* x) {
+        PZ_TRY(rotate_to(kk, t1, x));
+        return launch_ew(M, EW_COPY, x, ct, n, t1, ct, n, nullptr, 0, 0, cols * size, B);
+    };
+    auto ew3 = [&](int op, int64_t* r, const int64_t* x, const int64_t* y) {   // limb-wise over whole ciphertexts (equal sizes)
+        return launch_ew(M, op, r, ct, n, x, ct, n, y, ct, n, cols * size, B);
+    };
+    auto rsh1 = [&](int64_t* x) { return launch_rsh(M, B, (long long*)x, ct, cols, size, 0, cols, k, 1); };
+    auto normalize_assign = [&](int64_t* x) {
+        PZ_TRY(launch_ew(M, EW_COPY, t2, ct, n, x, ct, n, nullptr, 0, 0, cols * size, B));
+        DV xv{x, ct, cols, size}, tv{t2, ct, cols, size};
+        for (int c = 0; c < cols; ++c) PZ_TRY(dev_normalize(M, B, xv, k, 0, c, tv, k, c));
+        return (int)PZ_OK;
+    };
+    for (size_t i = 0; i + log_gap_out < log_n; ++i) {
+        const size_t tt = (size_t)1 << (log_n - 1 - i);
+        PZ_REQUIRE((gals[i] & 1) != 0 && key_pmats[i] != nullptr, "glwe_pack: bad automorphism key");
+        for (size_t j = 0; j < tt; ++j) {
+            int64_t* a = slots[j];
+            int64_t* b = slots[j + tt];
+            slots[j] = nullptr;
+            slots[j + tt] = nullptr;
+            if (a && b) {                                                       // :41-70
+                PZ_TRY(rotate_assign(-(long long)tt, a));
+                PZ_TRY(ew3(EW_SUB_I64, tmp_b, a, b));
+                PZ_TRY(rsh1(tmp_b));
+                PZ_TRY(ew3(EW_ADD_I64, a, a, b));
+                PZ_TRY(rsh1(a));
+                PZ_TRY(normalize_assign(tmp_b));
+                AutoSpec au{(long long)gals[i], 0};
+                PZ_TRY(glwe_op(M, true, tmp_b, tmp_b, key_pmats[i], p, batch, &au));
+                PZ_TRY(ew3(EW_SUB_I64, a, a, tmp_b));
+                PZ_TRY(normalize_assign(a));
+                PZ_TRY(rotate_assign((long long)tt, a));
+                slots[j] = a;
+            } else if (a) {                                                     // :71-75
+                PZ_TRY(rsh1(a));
+                AutoSpec au{(long long)gals[i], 1};
+                PZ_TRY(glwe_op(M, true, a, a, key_pmats[i], p, batch, &au));
+                slots[j] = a;
+            } else if (b) {                                                     // :76-86
+                PZ_TRY(rotate_to((long long)tt, tmp_b, b));
+                PZ_TRY(rsh1(tmp_b));
+                AutoSpec au{(long long)gals[i], 3};
+                PZ_TRY(glwe_op(M, true, b, tmp_b, key_pmats[i], p, batch, &au));
+                slots[j] = b;
+            }
+        }
+    }
+    PZ_REQUIRE(slots[0] != nullptr, "glwe_pack: no ciphertext ends at index 0");   // :175 a.get(&0).unwrap()
+    PZ_TRY(launch_ew(M, EW_COPY, res, ct, n, slots[0], ct, n, nullptr, 0, 0, cols * size, B));
+    const size_t skip = log_n - log_gap_out;
+    return glwe_trace(M, res, log_n - skip, gals + skip, key_pmats + skip, p, batch);
+}
+int pz_glwe_pack_batched(pz_module* M, int64_t* res, size_t nslots, const uint64_t* indices, int64_t* const* cts, size_t log_gap_out,
+                         const int64_t* gals, const double* const* key_pmats, const pz_glwe_op_params* p, void* tmp, size_t tmp_bytes,
+                         size_t batch) {
+    PZ_ENTER(M);
+    return glwe_pack(M, res, nslots, indices, cts, log_gap_out, gals, key_pmats, p, tmp, tmp_bytes, batch);
+}
+
 }  // extern "C"

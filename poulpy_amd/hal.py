@@ -71,7 +71,7 @@ def load_library(path: str | None = None) -> C.CDLL:
                  "pz_vmp_apply_dft_tmp_bytes", "pz_vmp_apply_dft_to_dft_tmp_bytes", "pz_vec_znx_big_normalize_tmp_bytes",
                  "pz_glwe_op_workspace_bytes", "pz_vec_znx_automorphism_assign_tmp_bytes",
                  "pz_vec_znx_big_automorphism_assign_tmp_bytes", "pz_blind_rotation_workspace_bytes", "pz_vec_znx_rsh_tmp_bytes", "pz_vec_znx_rotate_assign_tmp_bytes",
-                 "pz_circuit_bootstrapping_tmp_bytes", "pz_vec_znx_normalize_tmp_bytes", "pz_vec_znx_lsh_tmp_bytes"):
+                 "pz_circuit_bootstrapping_tmp_bytes", "pz_vec_znx_normalize_tmp_bytes", "pz_vec_znx_lsh_tmp_bytes", "pz_glwe_pack_tmp_bytes"):
         getattr(lib, name).restype = c_size_t
     if path is None:
         _lib = lib
@@ -446,6 +446,21 @@ class Module:
                                        batch: int):
         """poulpy-bin-fhe blind_rotation/algorithms/cggi/algorithm.rs:76-118,265-440 on a batch of mod-switched LWE ciphertexts."""
         self._ck(self.lib.pz_blind_rotation_execute_batched(self.handle, res, lwe_2n, lut, brk, C.byref(params), c_size_t(batch)))
+
+    def glwe_pack_tmp_bytes(self, params: GlweOpParams, batch: int) -> int:
+        return self.lib.pz_glwe_pack_tmp_bytes(self.handle, C.byref(params), c_size_t(batch))
+
+    def glwe_pack_batched(self, res: c_void_p, indices, ct_ptrs, log_gap_out: int, gals, key_ptrs, params: GlweOpParams, tmp: c_void_p,
+                          tmp_bytes: int, batch: int):
+        """poulpy-core glwe_packing.rs:122-176 on `batch` problems: ct_ptrs[s] -> batch contiguous device GLWEs of index indices[s]."""
+        ns = len(indices)
+        idx = (c_uint64 * ns)(*[int(i) for i in indices])
+        cp = (c_void_p * ns)(*[p.value if isinstance(p, c_void_p) else int(p) for p in ct_ptrs])
+        ng = len(gals)
+        g = (c_int64 * ng)(*[int(x) for x in gals])
+        kp = (c_void_p * ng)(*[p.value if isinstance(p, c_void_p) else int(p) for p in key_ptrs])
+        self._ck(self.lib.pz_glwe_pack_batched(self.handle, res, c_size_t(ns), idx, cp, c_size_t(log_gap_out), g, kp, C.byref(params), tmp,
+                                               c_size_t(tmp_bytes), c_size_t(batch)))
 
     def set_graphs(self, enable: bool):
         """HIP-graph replay of the launch-bound composite calls (blind rotation, trace, circuit bootstrapping); on by default."""

@@ -171,6 +171,11 @@ extern "C" {
     pub fn pz_vec_znx_rsh(m: *mut pz_module, base2k: usize, k: usize, res: *mut i64, rc: usize, rs: usize, rcol: usize, a: *const i64,
         ac: usize, as_: usize, acol: usize) -> c_int;
     pub fn pz_vec_znx_lsh_assign(m: *mut pz_module, base2k: usize, k: usize, res: *mut i64, rc: usize, rs: usize, rcol: usize) -> c_int;
+    /// glwe_pack (poulpy-core/src/glwe_packing.rs:122-176): host arrays of indices / device ciphertext pointers / per-step keys
+    pub fn pz_glwe_pack_tmp_bytes(m: *const pz_module, p: *const pz_glwe_op_params, batch: usize) -> usize;
+    pub fn pz_glwe_pack_batched(m: *mut pz_module, res: *mut i64, nslots: usize, indices: *const u64, cts: *const *mut i64,
+        log_gap_out: usize, gals: *const i64, keys: *const *const f64, p: *const pz_glwe_op_params, tmp: *mut c_void, tmp_bytes: usize,
+        batch: usize) -> c_int;
     /// HIP-graph replay of the launch-bound composite calls (on by default)
     pub fn pz_module_set_graphs(m: *mut pz_module, enable: c_int) -> c_int;
     pub fn pz_module_graph_launches(m: *const pz_module) -> u64;

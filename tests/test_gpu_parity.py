@@ -1286,3 +1286,50 @@ def test_vec_znx_shifts(mods, n):
             hip.vec_znx_lsh_assign(base2k, k, x2, 0)
             assert np.array_equal(x1.data, x2.data), ("lsh_assign", rs, k)
 
+
+@pytest.mark.parametrize("n,rank,size,log_gap_out,indices,batch", [
+    (64, 1, 3, 2, [0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52, 56, 60], 2),   # dense at gap 4: every step merges pairs
+    (64, 1, 3, 0, [0, 5, 17, 32, 33, 63], 3),                                        # sparse: all three branches of pack_internal
+    (256, 2, 2, 3, [0, 8, 16, 128, 136], 2),                                         # rank 2
+    (4096, 1, 3, 9, [0, 512, 1024, 2048, 3584], 2),                                  # fused automorphism pipeline
+    (64, 1, 2, 6, [0], 2),                                                           # nothing to pack: the final trace is empty too
+])
+def test_glwe_pack_batched(mods, n, rank, size, log_gap_out, indices, batch):
+    """glwe_packing.rs:122-176 through the C ABI vs the oracle's restatement (tree walk, pack_internal's three cases, final partial
+    trace); every ciphertext of the batch is an independent problem with the same occupancy pattern."""
+    from poulpy_amd.hal import GlweOpParams
+    base2k, dnum = 13, 3
+    ref, hip = mods(n)
+    rng = seeded(6100 + n + rank + log_gap_out)
+    cols = rank + 1
+    log_n = n.bit_length() - 1
+    gals = [-1] + [pow(5, 1 << i, 2 * n) for i in range(log_n - 1)]
+    keys_r, keys_d = [], []
+    for _ in gals:
+        mat = MatZnx(n, dnum, rank, cols, size).fill_uniform(base2k, rng)
+        pr, ph = ref.vmp_pmat_alloc(dnum, rank, cols, size), hip.vmp_pmat_alloc(dnum, rank, cols, size)
+        ref.vmp_prepare(pr, mat)
+        hip.vmp_prepare(ph, mat)
+        hip.sync()
+        keys_r.append(pr)
+        keys_d.append(hip.device_alloc(ph.data.nbytes).upload(ph.data))
+    data = {j: rng.integers(-(1 << (base2k - 1)), 1 << (base2k - 1), (batch, size, cols, n), dtype=np.int64) for j in indices}
+    want = np.empty((batch, size, cols, n), dtype=np.int64)
+    for b in range(batch):
+        cts = {j: VecZnx(n, cols, size, data[j][b].copy()) for j in indices}
+        res = VecZnx(n, cols, size)
+        ref.glwe_pack(res, base2k, cts, log_gap_out, gals, keys_r)
+        want[b] = res.data
+    d_cts = [hip.device_alloc(data[j].nbytes).upload(data[j]) for j in indices]
+    d_res = hip.device_alloc(want.nbytes)
+    p = GlweOpParams(rank=rank, dnum=dnum, dsize=1, key_size=size, key_base2k=base2k, a_size=size, a_base2k=base2k, res_size=size,
+                     res_base2k=base2k, rank_out=rank)
+    nbytes = hip.glwe_pack_tmp_bytes(p, batch)
+    d_tmp = hip.device_alloc(nbytes)
+    hip.glwe_pack_batched(d_res.ptr, indices, [d.ptr for d in d_cts], log_gap_out, gals, [k.ptr for k in keys_d], p, d_tmp.ptr, nbytes, batch)
+    hip.sync()
+    got = d_res.download(np.int64, want.size).reshape(want.shape)
+    for buf in keys_d + d_cts + [d_res, d_tmp]:
+        buf.free()
+    assert np.array_equal(got, want)
+

@@ -475,3 +475,77 @@ def test_P10_shifts_are_offset_normalizations():
         R.vec_znx_rsh(base2k, k, r, 0, a, 0)
         assert exact.torus_equal(a.data[:, 0], base2k, r.data[:, 0], base2k, res_offset=-k)
 
+
+def test_P11_glwe_pack_tree_walk():
+    """The oracle's C restatement of glwe_pack (glwe_packing.rs:122-176) vs an independent Python walk of the same tree with
+    a dict, as the reference's HashMap code reads, built from the oracle's primitive operations (rotate, add / sub, rsh,
+    normalize_assign, the pinned glwe_automorphism family, trace): sparse and dense occupancy, every branch of pack_internal."""
+    n, rank, size, base2k, dnum = 32, 1, 3, 12, 3
+    cols = rank + 1
+    log_n = 5
+    R = RefModule(n)
+    rng = seeded(1111)
+    gals = [-1] + [pow(5, 1 << i, 2 * n) for i in range(log_n - 1)]
+    keys = []
+    for _ in gals:
+        mat = MatZnx(n, dnum, rank, cols, size).fill_uniform(base2k, rng)
+        pm = R.vmp_pmat_alloc(dnum, rank, cols, size)
+        R.vmp_prepare(pm, mat)
+        keys.append(pm)
+
+    def glwe(fn, *cts_and_args):
+        for c in range(cols):
+            fn(c)
+
+    def py_pack(cts, log_gap_out):
+        a = dict(cts)
+        for i in range(log_n - log_gap_out):
+            t = 1 << (log_n - 1 - i)
+            for j in range(t):
+                lo, hi = a.pop(j, None), a.pop(j + t, None)
+                if lo is not None and hi is not None:
+                    tmp = lo.copy()
+                    for c in range(cols):
+                        R.vec_znx_rotate(-t, lo, c, tmp, c)
+                    tmp_b = VecZnx(n, cols, size)
+                    for c in range(cols):
+                        R.vec_znx_sub(tmp_b, c, lo, c, hi, c)
+                        R.vec_znx_rsh_assign(base2k, 1, tmp_b, c)
+                        R.vec_znx_add_assign(lo, c, hi, c)
+                        R.vec_znx_rsh_assign(base2k, 1, lo, c)
+                        R.vec_znx_normalize_assign(base2k, tmp_b, c)
+                    src = tmp_b.copy()
+                    R.glwe_automorphism(tmp_b, base2k, src, base2k, keys[i], 1, base2k, gals[i], "automorphism")
+                    for c in range(cols):
+                        R.vec_znx_sub_assign(lo, c, tmp_b, c)
+                        R.vec_znx_normalize_assign(base2k, lo, c)
+                    tmp = lo.copy()
+                    for c in range(cols):
+                        R.vec_znx_rotate(t, lo, c, tmp, c)
+                elif lo is not None:
+                    for c in range(cols):
+                        R.vec_znx_rsh_assign(base2k, 1, lo, c)
+                    src = lo.copy()
+                    R.glwe_automorphism(lo, base2k, src, base2k, keys[i], 1, base2k, gals[i], "add")
+                elif hi is not None:
+                    tmp_b = VecZnx(n, cols, size)
+                    for c in range(cols):
+                        R.vec_znx_rotate(t, tmp_b, c, hi, c)
+                        R.vec_znx_rsh_assign(base2k, 1, tmp_b, c)
+                    R.glwe_automorphism(hi, base2k, tmp_b, base2k, keys[i], 1, base2k, gals[i], "sub_negate")
+                if lo is not None:
+                    a[j] = lo
+                elif hi is not None:
+                    a[j] = hi
+        res = a[0].copy()
+        skip = log_n - log_gap_out
+        R.glwe_trace_assign(res, base2k, gals[skip:], keys[skip:])
+        return res
+
+    for indices, log_gap_out in (([0, 4, 8, 12, 16, 20, 24, 28], 2), ([0, 3, 9, 16, 17, 31], 0), ([4], 2), ([0, 16], 4)):
+        cts = {j: VecZnx(n, cols, size).fill_uniform(base2k, rng) for j in indices}
+        want = py_pack({j: v.copy() for j, v in cts.items()}, log_gap_out)
+        res = VecZnx(n, cols, size)
+        R.glwe_pack(res, base2k, cts, log_gap_out, gals, keys)
+        assert np.array_equal(res.data, want.data), (indices, log_gap_out)
+
