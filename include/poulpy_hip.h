@@ -358,7 +358,8 @@ size_t pz_blind_rotation_workspace_bytes(const pz_module* m, const pz_blind_rota
  * automorphism keys, the tensor keys and the result, extension_factor = 1.  execute_to_exponent (:197-216) with
  * log_gap_in == log_gap_out is the same call with the step list of the partial trace (post_process :418-420: steps
  * log_n - log_gap_in + 1 .. log_n) and the table / mod-switch direction the shim builds for that mode (:276-301);
- * other bases and the repacking branch of post_process (glwe_pack, :392-417) stay on the generic per-op path.
+ * pz_circuit_bootstrapping_execute_to_exponent_batched below does that mapping and the repacking branch (:392-417); other
+ * bases stay on the generic per-op path.
  *   lwe_2n, lut, brk   as for pz_blind_rotation_execute_batched (the shim builds the table with the reference's host code
  *                      lookup_table.rs and passes gap = 2*lut.drift/extension_factor, circuit.rs:333)
  *   gals / atk_pmats   HOST arrays, one per trace step skip..log_n (as for pz_glwe_trace_batched; skip = 0 in constant mode): prepared automorphism keys
@@ -378,6 +379,17 @@ int pz_circuit_bootstrapping_execute_to_constant_batched(pz_module* m, int64_t* 
                                                          const double* const* atk_pmats, const double* const* tsk_pmats,
                                                          const pz_circuit_bootstrapping_params* p, void* tmp, size_t tmp_bytes,
                                                          size_t batch);
+/* circuit_bootstrapping_execute_to_exponent (circuit.rs:197-216, post_process :373-421), same conventions; gals / atk_pmats
+ * cover ALL log2(n) trace steps; log_gap_in = bits(gap * next_pow2(res_dnum) - 1) (circuit.rs:342) comes from the shim.
+ * log_gap_in == log_gap_out: the partial trace (:418-420); otherwise the repacking branch (:392-417: 2^log_domain shifted
+ * copies + glwe_pack), which needs res_size <= br.res_size and the larger scratch of *_to_exponent_tmp_bytes. */
+size_t pz_circuit_bootstrapping_to_exponent_tmp_bytes(const pz_module* m, const pz_circuit_bootstrapping_params* p, size_t log_domain,
+                                                      size_t batch);
+int pz_circuit_bootstrapping_execute_to_exponent_batched(pz_module* m, int64_t* ggsw, const int64_t* lwe_2n, const int64_t* lut,
+                                                         const double* brk, const int64_t* gals, const double* const* atk_pmats,
+                                                         const double* const* tsk_pmats, const pz_circuit_bootstrapping_params* p,
+                                                         size_t log_gap_in, size_t log_gap_out, size_t log_domain, void* tmp,
+                                                         size_t tmp_bytes, size_t batch);
 /* workspace the calls above need for `batch` ciphertexts (bytes, device); keyswitch: 0 external product, 1 key switch,
  * 2 automorphism family */
 size_t pz_glwe_op_workspace_bytes(const pz_module* m, const pz_glwe_op_params* p, size_t batch, int keyswitch);

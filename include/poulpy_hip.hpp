@@ -176,6 +176,17 @@ class Module {  // Module<FFT64Hip>, poulpy-hal/src/layouts/module.rs:97-189
         check(pz_circuit_bootstrapping_execute_to_constant_batched(m_, ggsw, lwe_2n, lut, brk, nsteps, gals, atk, tsk, &p, tmp, tmp_bytes, batch),
               "circuit_bootstrapping_execute_to_constant_batched");
     }
+    void circuit_bootstrapping_execute_to_exponent_batched(int64_t* ggsw, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
+                                                           const int64_t* gals, const double* const* atk, const double* const* tsk,
+                                                           const pz_circuit_bootstrapping_params& p, size_t log_gap_in, size_t log_gap_out,
+                                                           size_t log_domain, void* tmp, size_t tmp_bytes, size_t batch) {
+        check(pz_circuit_bootstrapping_execute_to_exponent_batched(m_, ggsw, lwe_2n, lut, brk, gals, atk, tsk, &p, log_gap_in, log_gap_out,
+                                                                   log_domain, tmp, tmp_bytes, batch),
+              "circuit_bootstrapping_execute_to_exponent_batched");
+    }
+    size_t circuit_bootstrapping_to_exponent_tmp_bytes(const pz_circuit_bootstrapping_params& p, size_t log_domain, size_t batch) const {
+        return pz_circuit_bootstrapping_to_exponent_tmp_bytes(m_, &p, log_domain, batch);
+    }
     size_t circuit_bootstrapping_tmp_bytes(const pz_circuit_bootstrapping_params& p, size_t batch) const {
         return pz_circuit_bootstrapping_tmp_bytes(m_, &p, batch);
     }

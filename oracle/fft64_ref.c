@@ -2057,3 +2057,56 @@ void pzr_glwe_pack(const pzr_tables* t, size_t rank, int64_t* res, int64_t** slo
     free(tmp);
 }
 
+/* poulpy-bin-fhe/src/circuit_bootstrapping/circuit.rs:219-370 with to_exponent = true and post_process :373-421, one base2k,
+ * res_size <= glwe_size (so that every intermediate has the GLWE's size).  The lookup table, gap (:333) and log_gap_in (:342)
+ * are inputs; gals / atk: all log_n trace steps.
+ *   log_gap_in == log_gap_out: res_row = glwe_trace(a, skip = log_n - log_gap_in + 1)                         (:418-420)
+ *   otherwise: a_trace = that partial trace; cts[s] = X^(-s 2^log_gap_in) a_trace at index s 2^log_gap_out,
+ *              s < 2^log_domain; res_row = glwe_pack(cts, log_gap_out)                                          (:392-417) */
+void pzr_circuit_bootstrap_to_exponent(const pzr_tables* t, size_t rank, size_t base2k,
+                                       size_t n_lwe, size_t block_size, const int64_t* lwe_2n, const int64_t* lut, size_t lut_size,
+                                       const double* brk, size_t brk_dnum, size_t brk_size, size_t glwe_size, const double* x_pow_a,
+                                       const int64_t* gals, const double* const* atk, size_t atk_dnum, size_t atk_size,
+                                       int64_t* ggsw, size_t res_dnum, size_t res_size, size_t gap,
+                                       size_t log_gap_in, size_t log_gap_out, size_t log_domain,
+                                       const double* const* tsk, size_t tsk_dnum, size_t tsk_size) {
+    size_t n = t->m << 1, cols = rank + 1, ct_g = n * cols * glwe_size, ct_res = n * cols * res_size;
+    size_t log_n = 0;
+    while (((size_t)1 << log_n) < n) ++log_n;
+    int64_t* acc = (int64_t*)calloc(ct_g, sizeof(int64_t));
+    int64_t* rot = (int64_t*)calloc(ct_g, sizeof(int64_t));
+    int64_t* a_trace = (int64_t*)calloc(ct_g, sizeof(int64_t));
+    int64_t* packed = (int64_t*)calloc(ct_g, sizeof(int64_t));
+    size_t steps = (size_t)1 << log_domain;
+    int64_t* cts = (int64_t*)calloc(steps * ct_g, sizeof(int64_t));
+    int64_t** slots = (int64_t**)calloc(n, sizeof(int64_t*));
+    pzr_blind_rotation_execute(t, rank, n_lwe, block_size, acc, glwe_size, base2k, lwe_2n, lut, lut_size, brk, brk_dnum, brk_size, x_pow_a);
+    size_t skip = log_n - log_gap_in + 1;
+    for (size_t i = 0; i < res_dnum; ++i) {
+        memcpy(a_trace, acc, ct_g * sizeof(int64_t));
+        pzr_glwe_trace_assign(t, rank, a_trace, glwe_size, base2k, log_n - skip, gals + skip, atk + skip, atk_dnum, atk_size, 1);
+        const int64_t* row_src = a_trace;
+        if (log_gap_in != log_gap_out) {
+            memset(slots, 0, n * sizeof(int64_t*));
+            for (size_t s = 0; s < steps; ++s) {
+                if (s != 0) { /* :405-407 glwe_rotate_assign(-(1 << log_gap_in), a_trace) */
+                    for (size_t c = 0; c < cols; ++c)
+                        pzr_vec_znx_rotate(n, -((int64_t)1 << log_gap_in), rot, cols, glwe_size, c, a_trace, cols, glwe_size, c);
+                    memcpy(a_trace, rot, ct_g * sizeof(int64_t));
+                }
+                memcpy(cts + s * ct_g, a_trace, ct_g * sizeof(int64_t));
+                slots[s << log_gap_out] = cts + s * ct_g;
+            }
+            pzr_glwe_pack(t, rank, packed, slots, glwe_size, base2k, log_gap_out, gals, atk, atk_dnum, atk_size);
+            row_src = packed;
+        }
+        memcpy(ggsw + (i * cols) * ct_res, row_src, ct_res * sizeof(int64_t)); /* glwe_copy: the first res_size limbs */
+        if (i + 1 < res_dnum) {
+            for (size_t c = 0; c < cols; ++c) pzr_vec_znx_rotate(n, -(int64_t)gap, rot, cols, glwe_size, c, acc, cols, glwe_size, c);
+            memcpy(acc, rot, ct_g * sizeof(int64_t));
+        }
+    }
+    pzr_ggsw_expand_row(t, rank, ggsw, res_dnum, res_size, base2k, tsk, tsk_dnum, tsk_size, 1, base2k);
+    free(acc); free(rot); free(a_trace); free(packed); free(cts); free(slots);
+}
+

@@ -210,6 +210,15 @@ void pzr_circuit_bootstrap_to_constant(const pzr_tables* t, size_t rank, size_t 
 void pzr_glwe_pack(const pzr_tables* t, size_t rank, int64_t* res, int64_t** slots, size_t size, size_t base2k, size_t log_gap_out,
                    const int64_t* gals, const double* const* keys, size_t dnum, size_t key_size);
 
+/* circuit.rs:219-370 with to_exponent = true (+ post_process :373-421), one base2k, res_size <= glwe_size */
+void pzr_circuit_bootstrap_to_exponent(const pzr_tables* t, size_t rank, size_t base2k,
+                                       size_t n_lwe, size_t block_size, const int64_t* lwe_2n, const int64_t* lut, size_t lut_size,
+                                       const double* brk, size_t brk_dnum, size_t brk_size, size_t glwe_size, const double* x_pow_a,
+                                       const int64_t* gals, const double* const* atk, size_t atk_dnum, size_t atk_size,
+                                       int64_t* ggsw, size_t res_dnum, size_t res_size, size_t gap,
+                                       size_t log_gap_in, size_t log_gap_out, size_t log_domain,
+                                       const double* const* tsk, size_t tsk_dnum, size_t tsk_size);
+
 #ifdef __cplusplus
 }
 #endif

@@ -353,6 +353,20 @@ class RefModule:
         self.lib.pzr_glwe_pack(self.t, c_size_t(rank), _p(res.data), slots, *_sz(res.size, base2k, log_gap_out), g, ptrs,
                                *_sz(pmats[0].rows, pmats[0].size))
 
+    def circuit_bootstrap_to_exponent(self, ggsw, base2k, lwe_2n, lut, brk, brk_dnum, brk_size, glwe_size, block_size, x_pow_a, gals,
+                                      atk, tsk, gap, log_gap_in, log_gap_out, log_domain):
+        """circuit.rs:219-421 (to_exponent = true, one base2k); gals / atk: all log_n trace steps."""
+        rank = ggsw.cols_out - 1
+        n_lwe = lwe_2n.shape[0] - 1
+        ns = len(gals)
+        g = (c_int64 * ns)(*[int(x) for x in gals])
+        ap = (c_void_p * ns)(*[pm.data.ctypes.data for pm in atk])
+        tp = (c_void_p * len(tsk))(*[pm.data.ctypes.data for pm in tsk])
+        self.lib.pzr_circuit_bootstrap_to_exponent(
+            self.t, *_sz(rank, base2k, n_lwe, block_size), _p(lwe_2n), _p(lut.data), c_size_t(lut.size), _p(brk),
+            *_sz(brk_dnum, brk_size, glwe_size), _p(x_pow_a), g, ap, *_sz(atk[0].rows, atk[0].size), _p(ggsw.data),
+            *_sz(ggsw.rows, ggsw.size, gap, log_gap_in, log_gap_out, log_domain), tp, *_sz(tsk[0].rows, tsk[0].size))
+
     # glwe_trace (poulpy-core/src/glwe_trace.rs) and the shift it uses
     def vec_znx_rsh_assign(self, base2k, k, res, res_col, scratch=None):
         self.lib.pzr_vec_znx_rsh_assign(c_size_t(self._n), *_sz(base2k, k), _p(res.data), *_sz(res.cols, res.size, res_col))

@@ -2166,20 +2166,35 @@ int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t*
 //   :369      ggsw_expand_row
 // The dnum_res traces of one LWE are independent, so all batch * dnum_res of them run as one batched trace.
 // ------------------------------------------------------------------------------
+static int glwe_pack(pz_module* M, int64_t* res, size_t nslots, const uint64_t* indices, int64_t* const* cts, size_t log_gap_out,
+                     const int64_t* gals, const double* const* key_pmats, const pz_glwe_op_params* p, void* tmp, size_t tmp_bytes,
+                     size_t batch);
+struct CbtRepack { size_t log_gap_in, log_gap_out, log_domain; };  // exponent mode with log_gap_in != log_gap_out (post_process)
 static inline size_t cbt_tmp_size(const pz_circuit_bootstrapping_params* p) { return (size_t)std::max(p->br.res_size, p->res_size); }
 size_t pz_circuit_bootstrapping_tmp_bytes(const pz_module* M, const pz_circuit_bootstrapping_params* p, size_t batch) {
     if (!M || !p) return 0;
     const size_t n8 = (size_t)M->n * 8, cols = p->br.rank + 1;
     return align256(batch * n8 * cols * p->br.res_size) + align256(batch * p->res_dnum * n8 * cols * cbt_tmp_size(p));
 }
+size_t pz_circuit_bootstrapping_to_exponent_tmp_bytes(const pz_module* M, const pz_circuit_bootstrapping_params* p, size_t log_domain,
+                                                      size_t batch) {
+    if (!M || !p || log_domain > 20) return 0;
+    const size_t n8 = (size_t)M->n * 8, cols = p->br.rank + 1;
+    const size_t rows_ct = align256(batch * p->res_dnum * n8 * cols * cbt_tmp_size(p));
+    // acc | rotated rows | 2^log_domain shifted copies | packed result | glwe_pack scratch (3 ciphertext arrays)
+    return pz_circuit_bootstrapping_tmp_bytes(M, p, batch) + (((size_t)1 << log_domain) + 1 + 3) * rows_ct;
+}
 static int circuit_bootstrapping(pz_module* M, int64_t* ggsw, const int64_t* lwe_2n, const int64_t* lut, const double* brk, size_t nsteps,
                                  const int64_t* gals, const double* const* atk_pmats, const double* const* tsk_pmats,
-                                 const pz_circuit_bootstrapping_params* p, void* tmp, size_t tmp_bytes, size_t batch) {
+                                 const pz_circuit_bootstrapping_params* p, void* tmp, size_t tmp_bytes, size_t batch,
+                                 const CbtRepack* rp = nullptr) {
     PZ_REQUIRE(p != nullptr, "null params");
     PZ_REQUIRE(p->res_dnum >= 1 && p->res_size >= 1 && p->atk_dnum >= 1 && p->atk_size >= 1 && p->tsk_dnum >= 1 && p->tsk_size >= 1,
                "circuit_bootstrapping: empty shape");
     PZ_REQUIRE(is_device_ptr(ggsw) && is_device_ptr(tmp), "batched entry points take device pointers");
-    PZ_REQUIRE(tmp_bytes >= pz_circuit_bootstrapping_tmp_bytes(M, p, batch), "circuit_bootstrapping: tmp is smaller than pz_circuit_bootstrapping_tmp_bytes");
+    PZ_REQUIRE(tmp_bytes >= (rp ? pz_circuit_bootstrapping_to_exponent_tmp_bytes(M, p, rp->log_domain, batch)
+                                : pz_circuit_bootstrapping_tmp_bytes(M, p, batch)),
+               "circuit_bootstrapping: tmp is smaller than the *_tmp_bytes of this call");
     if (batch == 0) return PZ_OK;
     const long long n = (long long)M->n;
     const int cols = (int)p->br.rank + 1, gsz = (int)p->br.res_size, rsz = (int)p->res_size, tsz = (int)cbt_tmp_size(p);
@@ -2198,9 +2213,39 @@ static int circuit_bootstrapping(pz_module* M, int64_t* ggsw, const int64_t* lwe
     pz_glwe_op_params tp;
     tp.rank = p->br.rank; tp.dnum = p->atk_dnum; tp.dsize = 1; tp.key_size = p->atk_size; tp.key_base2k = p->br.base2k;
     tp.a_size = (uint64_t)tsz; tp.a_base2k = p->br.base2k; tp.res_size = (uint64_t)tsz; tp.res_base2k = p->br.base2k; tp.rank_out = p->br.rank;
-    PZ_TRY(glwe_trace(M, tr, nsteps, gals, atk_pmats, &tp, (size_t)B * rows));
+    const int64_t* row_src = tr;
+    if (!rp) {
+        PZ_TRY(glwe_trace(M, tr, nsteps, gals, atk_pmats, &tp, (size_t)B * rows));
+    } else {
+        // post_process (circuit.rs:373-421) with log_gap_in != log_gap_out: partial trace, 2^log_domain shifted copies, glwe_pack
+        size_t log_n = 0;
+        while (((size_t)1 << log_n) < (size_t)M->n) ++log_n;
+        PZ_REQUIRE(nsteps == log_n, "circuit_bootstrapping (exponent mode): gals / atk_pmats must cover all log2(n) trace steps");
+        PZ_REQUIRE(rsz <= gsz, "circuit_bootstrapping (exponent mode): the GGSW must not have more limbs than the GLWE of the rotation");
+        PZ_REQUIRE(rp->log_gap_in >= 1 && rp->log_gap_in <= log_n && rp->log_gap_out <= log_n && rp->log_domain <= 20 &&
+                       (((size_t)1 << rp->log_domain) - 1) << rp->log_gap_out < (size_t)M->n,
+                   "circuit_bootstrapping (exponent mode): gaps / domain out of range");
+        const size_t skip = log_n - rp->log_gap_in + 1;
+        PZ_TRY(glwe_trace(M, tr, log_n - skip, gals + skip, atk_pmats + skip, &tp, (size_t)B * rows));
+        const size_t steps = (size_t)1 << rp->log_domain;
+        const size_t rows_ct = align256((size_t)B * rows * ct_t * 8);
+        char* base = (char*)tr + rows_ct;
+        std::vector<int64_t*> cts(steps);
+        std::vector<uint64_t> idx(steps);
+        const PolyMap pm{tsz, cols, ct_t, (long long)cols * n, n, 0};
+        for (size_t sidx = 0; sidx < steps; ++sidx) {
+            cts[sidx] = (int64_t*)(base + sidx * rows_ct);
+            idx[sidx] = (uint64_t)(sidx << rp->log_gap_out);
+            PZ_TRY(launch_rotate(M, B * rows * tsz * cols, (const long long*)tr, pm, (long long*)cts[sidx], pm, 0, tsz * cols, nullptr, 0, 0,
+                                 -(long long)(sidx << rp->log_gap_in)));
+        }
+        int64_t* packed = (int64_t*)(base + steps * rows_ct);
+        void* pack_tmp = (void*)(base + (steps + 1) * rows_ct);
+        PZ_TRY(glwe_pack(M, packed, steps, idx.data(), cts.data(), rp->log_gap_out, gals, atk_pmats, &tp, pack_tmp, 3 * rows_ct, (size_t)B * rows));
+        row_src = packed;
+    }
     // glwe_copy(res.at(i, 0), tmp) (glwe_trace.rs:121): the first res_size limbs, into the strided (row, 0) entries
-    PZ_TRY(launch_ew(M, EW_COPY, ggsw, (long long)cols * ct_r, n, tr, ct_t, n, nullptr, 0, 0, cols * rsz, B * rows));
+    PZ_TRY(launch_ew(M, EW_COPY, ggsw, (long long)cols * ct_r, n, row_src, ct_t, n, nullptr, 0, 0, cols * rsz, B * rows));
     pz_glwe_op_params ep = tp;
     ep.dnum = p->tsk_dnum; ep.key_size = p->tsk_size; ep.a_size = (uint64_t)rsz; ep.res_size = (uint64_t)rsz;
     return ggsw_expand_row(M, ggsw, p->res_dnum, tsk_pmats, &ep, batch);
@@ -2222,6 +2267,26 @@ int pz_circuit_bootstrapping_execute_to_constant_batched(pz_module* M, int64_t* 
     return with_graph(M, k.h, [&]() {
         return circuit_bootstrapping(M, ggsw, lwe_2n, lut, brk, nsteps, gals, atk_pmats, tsk_pmats, p, tmp, tmp_bytes, batch);
     });
+}
+
+// circuit_bootstrapping_execute_to_exponent (circuit.rs:197-216): equal gaps = the partial trace of post_process (:418-420),
+// otherwise the repacking branch (:392-417).  gals / atk_pmats cover all log2(n) trace steps.
+int pz_circuit_bootstrapping_execute_to_exponent_batched(pz_module* M, int64_t* ggsw, const int64_t* lwe_2n, const int64_t* lut,
+                                                         const double* brk, const int64_t* gals, const double* const* atk_pmats,
+                                                         const double* const* tsk_pmats, const pz_circuit_bootstrapping_params* p,
+                                                         size_t log_gap_in, size_t log_gap_out, size_t log_domain, void* tmp,
+                                                         size_t tmp_bytes, size_t batch) {
+    PZ_ENTER(M);
+    PZ_REQUIRE(gals != nullptr && atk_pmats != nullptr, "circuit_bootstrapping: null argument");
+    size_t log_n = 0;
+    while (((size_t)1 << log_n) < (size_t)M->n) ++log_n;
+    PZ_REQUIRE(log_gap_in >= 1 && log_gap_in <= log_n, "circuit_bootstrapping (exponent mode): log_gap_in out of range");
+    if (log_gap_in == log_gap_out) {
+        const size_t skip = log_n - log_gap_in + 1;
+        return circuit_bootstrapping(M, ggsw, lwe_2n, lut, brk, log_n - skip, gals + skip, atk_pmats + skip, tsk_pmats, p, tmp, tmp_bytes, batch);
+    }
+    CbtRepack rp{log_gap_in, log_gap_out, log_domain};
+    return circuit_bootstrapping(M, ggsw, lwe_2n, lut, brk, log_n, gals, atk_pmats, tsk_pmats, p, tmp, tmp_bytes, batch, &rp);
 }
 
 // ------------------------------------------------------------------------------

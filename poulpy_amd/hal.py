@@ -71,7 +71,8 @@ def load_library(path: str | None = None) -> C.CDLL:
                  "pz_vmp_apply_dft_tmp_bytes", "pz_vmp_apply_dft_to_dft_tmp_bytes", "pz_vec_znx_big_normalize_tmp_bytes",
                  "pz_glwe_op_workspace_bytes", "pz_vec_znx_automorphism_assign_tmp_bytes",
                  "pz_vec_znx_big_automorphism_assign_tmp_bytes", "pz_blind_rotation_workspace_bytes", "pz_vec_znx_rsh_tmp_bytes", "pz_vec_znx_rotate_assign_tmp_bytes",
-                 "pz_circuit_bootstrapping_tmp_bytes", "pz_vec_znx_normalize_tmp_bytes", "pz_vec_znx_lsh_tmp_bytes", "pz_glwe_pack_tmp_bytes"):
+                 "pz_circuit_bootstrapping_tmp_bytes", "pz_vec_znx_normalize_tmp_bytes", "pz_vec_znx_lsh_tmp_bytes", "pz_glwe_pack_tmp_bytes",
+                 "pz_circuit_bootstrapping_to_exponent_tmp_bytes"):
         getattr(lib, name).restype = c_size_t
     if path is None:
         _lib = lib
@@ -482,6 +483,21 @@ class Module:
         tp = (c_void_p * len(tsk_ptrs))(*[k.value if isinstance(k, c_void_p) else int(k) for k in tsk_ptrs])
         self._ck(self.lib.pz_circuit_bootstrapping_execute_to_constant_batched(self.handle, ggsw, lwe_2n, lut, brk, c_size_t(ns), g, ap, tp,
                                                                                C.byref(params), tmp, c_size_t(tmp_bytes), c_size_t(batch)))
+
+    def circuit_bootstrapping_to_exponent_tmp_bytes(self, params: CircuitBootstrappingParams, log_domain: int, batch: int) -> int:
+        return self.lib.pz_circuit_bootstrapping_to_exponent_tmp_bytes(self.handle, C.byref(params), *_sz(log_domain, batch))
+
+    def circuit_bootstrapping_execute_to_exponent_batched(self, ggsw: c_void_p, lwe_2n: c_void_p, lut: c_void_p, brk: c_void_p, gals,
+                                                          atk_ptrs, tsk_ptrs, params: CircuitBootstrappingParams, log_gap_in: int,
+                                                          log_gap_out: int, log_domain: int, tmp: c_void_p, tmp_bytes: int, batch: int):
+        """circuit.rs:197-216 + post_process :373-421 (one base2k); gals / atk_ptrs: all log2(n) trace steps."""
+        ns = len(gals)
+        g = (c_int64 * ns)(*[int(x) for x in gals])
+        ap = (c_void_p * ns)(*[k.value if isinstance(k, c_void_p) else int(k) for k in atk_ptrs])
+        tp = (c_void_p * len(tsk_ptrs))(*[k.value if isinstance(k, c_void_p) else int(k) for k in tsk_ptrs])
+        self._ck(self.lib.pz_circuit_bootstrapping_execute_to_exponent_batched(
+            self.handle, ggsw, lwe_2n, lut, brk, g, ap, tp, C.byref(params), *_sz(log_gap_in, log_gap_out, log_domain), tmp,
+            c_size_t(tmp_bytes), c_size_t(batch)))
 
     def blind_rotation_workspace_bytes(self, params: BlindRotationParams, batch: int) -> int:
         return self.lib.pz_blind_rotation_workspace_bytes(self.handle, C.byref(params), c_size_t(batch))

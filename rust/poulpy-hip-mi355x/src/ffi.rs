@@ -179,6 +179,11 @@ extern "C" {
     /// HIP-graph replay of the launch-bound composite calls (on by default)
     pub fn pz_module_set_graphs(m: *mut pz_module, enable: c_int) -> c_int;
     pub fn pz_module_graph_launches(m: *const pz_module) -> u64;
+    pub fn pz_circuit_bootstrapping_to_exponent_tmp_bytes(m: *const pz_module, p: *const pz_circuit_bootstrapping_params, log_domain: usize,
+        batch: usize) -> usize;
+    pub fn pz_circuit_bootstrapping_execute_to_exponent_batched(m: *mut pz_module, ggsw: *mut i64, lwe_2n: *const i64, lut: *const i64,
+        brk: *const f64, gals: *const i64, atk: *const *const f64, tsk: *const *const f64, p: *const pz_circuit_bootstrapping_params,
+        log_gap_in: usize, log_gap_out: usize, log_domain: usize, tmp: *mut c_void, tmp_bytes: usize, batch: usize) -> c_int;
     pub fn pz_circuit_bootstrapping_tmp_bytes(m: *const pz_module, p: *const pz_circuit_bootstrapping_params, batch: usize) -> usize;
     pub fn pz_circuit_bootstrapping_execute_to_constant_batched(m: *mut pz_module, ggsw: *mut i64, lwe_2n: *const i64, lut: *const i64,
         brk: *const f64, nsteps: usize, gals: *const i64, atk: *const *const f64, tsk: *const *const f64,

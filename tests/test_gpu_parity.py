@@ -1333,3 +1333,74 @@ def test_glwe_pack_batched(mods, n, rank, size, log_gap_out, indices, batch):
         buf.free()
     assert np.array_equal(got, want)
 
+
+@pytest.mark.parametrize("n,rank,log_gap_in,log_gap_out,log_domain", [
+    (256, 1, 4, 2, 2),      # repacking branch of post_process: 4 shifted copies at gap 16 packed to gap 4
+    (256, 2, 5, 0, 1),      # rank 2, packed to consecutive coefficients
+    (256, 1, 4, 4, 2),      # equal gaps: the partial trace only
+    (4096, 1, 9, 7, 1),     # fused automorphism pipeline inside the trace and the pack
+])
+def test_circuit_bootstrapping_to_exponent(mods, n, rank, log_gap_in, log_gap_out, log_domain):
+    """circuit.rs:197-216 + post_process :373-421 (one base2k) through the C ABI vs the oracle's composition (blind rotation, partial
+    trace, shifted copies, glwe_pack, ggsw_expand_row); random lookup table and gap."""
+    from poulpy_amd.hal import BlindRotationParams, CircuitBootstrappingParams
+    base2k, n_lwe, block_size, brk_dnum, glwe_size, res_dnum, res_size, batch, atk_dnum, tsk_dnum = 13, 6, 3, 2, 3, 2, 2, 2, 3, 2
+    ref, hip = mods(n)
+    rng = seeded(8800 + n + rank + log_gap_out)
+    cols = rank + 1
+    log_n = n.bit_length() - 1
+    gap = 2 * int(rng.integers(1, n // 8))
+
+    def prepared(rows, cols_in, size):
+        mat = MatZnx(n, rows, cols_in, cols, size).fill_uniform(base2k, rng)
+        pr, ph = ref.vmp_pmat_alloc(rows, cols_in, cols, size), hip.vmp_pmat_alloc(rows, cols_in, cols, size)
+        ref.vmp_prepare(pr, mat)
+        hip.vmp_prepare(ph, mat)
+        hip.sync()
+        return pr, ph
+
+    lut = VecZnx(n, 1, glwe_size).fill_uniform(base2k, rng)
+    brk_r = np.empty((n_lwe, n * brk_dnum * cols * cols * glwe_size), dtype=np.float64)
+    brk_h = np.empty_like(brk_r)
+    for i in range(n_lwe):
+        pr, ph = prepared(brk_dnum, cols, glwe_size)
+        brk_r[i], brk_h[i] = pr.data.reshape(-1), ph.data.reshape(-1)
+    gals = [-1] + [pow(5, 1 << i, 2 * n) for i in range(log_n - 1)]
+    atk = [prepared(atk_dnum, rank, glwe_size) for _ in gals]
+    tsk = [prepared(tsk_dnum, rank, res_size + 1) for _ in range(rank)]
+    lwe = rng.integers(-n, n, (batch, n_lwe + 1), dtype=np.int64)
+    xpa = ref.blind_rotation_x_pow_a()
+    want = np.empty((batch, res_dnum, cols, res_size, cols, n), dtype=np.int64)
+    for b in range(batch):
+        g = MatZnx(n, res_dnum, cols, cols, res_size)
+        ref.circuit_bootstrap_to_exponent(g, base2k, np.ascontiguousarray(lwe[b]), lut, brk_r, brk_dnum, glwe_size, glwe_size, block_size,
+                                          xpa, gals, [a[0] for a in atk], [t[0] for t in tsk], gap, log_gap_in, log_gap_out, log_domain)
+        want[b] = g.data
+    bufs = []
+
+    def up(arr):
+        d = hip.device_alloc(arr.nbytes).upload(arr)
+        bufs.append(d)
+        return d
+
+    d_lwe, d_lut, d_brk = up(lwe), up(lut.data), up(brk_h)
+    d_atk = [up(a[1].data) for a in atk]
+    d_tsk = [up(t[1].data) for t in tsk]
+    d_res = up(rng.integers(-5, 5, want.shape, dtype=np.int64))
+    p = CircuitBootstrappingParams(
+        br=BlindRotationParams(rank=rank, n_lwe=n_lwe, block_size=block_size, dnum=brk_dnum, brk_size=glwe_size, base2k=base2k,
+                               res_size=glwe_size, lut_size=glwe_size),
+        atk_dnum=atk_dnum, atk_size=glwe_size, tsk_dnum=tsk_dnum, tsk_size=res_size + 1, res_dnum=res_dnum, res_size=res_size, gap=gap)
+    nbytes = hip.circuit_bootstrapping_to_exponent_tmp_bytes(p, log_domain, batch)
+    d_tmp = hip.device_alloc(nbytes)
+    bufs.append(d_tmp)
+    hip.circuit_bootstrapping_execute_to_exponent_batched(d_res.ptr, d_lwe.ptr, d_lut.ptr, d_brk.ptr, gals, [k.ptr for k in d_atk],
+                                                          [k.ptr for k in d_tsk], p, log_gap_in, log_gap_out, log_domain, d_tmp.ptr, nbytes,
+                                                          batch)
+    hip.sync()
+    got = d_res.download(np.int64, want.size).reshape(want.shape)
+    for buf in bufs:
+        buf.free()
+    assert np.array_equal(got[:, :, 0], want[:, :, 0]), "packed rows differ"
+    assert np.array_equal(got, want)
+
