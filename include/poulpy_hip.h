@@ -329,7 +329,7 @@ int pz_ggsw_from_gglwe_batched(pz_module* m, int64_t* ggsw, const int64_t* a, si
 /* BlindRotationExecute<CGGI>::blind_rotation_execute (poulpy-bin-fhe/src/blind_rotation/algorithms/cggi/algorithm.rs:76-118)
  * on `batch` LWE ciphertexts that share the lookup table and the prepared blind-rotation key:
  *   block_size > 1 : execute_block_binary  (:265-368)       block_size == 1 : execute_standard (:370-440)
- * (extension_factor > 1, execute_block_binary_extended :121-263, is not provided: PZ_ERR_UNSUPPORTED upstream of this call).
+ * (extension_factor > 1, execute_block_binary_extended :121-273: pz_blind_rotation_execute_extended_batched below).
  *   res     batch x GLWE(rank+1, res_size), overwritten
  *   lwe_2n  batch x (n_lwe+1) i64: the output of mod_switch_2n (algorithms/mod.rs:136-171, host i64 code that stays in the
  *           caller): [b, a_1 .. a_n_lwe]
@@ -351,6 +351,14 @@ typedef struct {
 int pz_blind_rotation_execute_batched(pz_module* m, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
                                       const pz_blind_rotation_params* p, size_t batch);
 size_t pz_blind_rotation_workspace_bytes(const pz_module* m, const pz_blind_rotation_params* p, size_t batch);
+/* execute_block_binary_extended (algorithm.rs:121-273): extension_factor > 1 (a power of two), block_size > 1.  lwe_2n is the
+ * output of mod_switch_2n(2 * n * extension_factor); lut = the extension_factor polynomials lut.data[j], each
+ * VecZnx(1, lut_size), contiguous; tmp = device scratch of pz_blind_rotation_extended_tmp_bytes; batch * extension_factor
+ * <= 65535 per call.  The reference's skipped updates (:217, :233, :244) are reproduced. */
+size_t pz_blind_rotation_extended_tmp_bytes(const pz_module* m, const pz_blind_rotation_params* p, size_t extension_factor, size_t batch);
+int pz_blind_rotation_execute_extended_batched(pz_module* m, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
+                                               const pz_blind_rotation_params* p, size_t extension_factor, void* tmp, size_t tmp_bytes,
+                                               size_t batch);
 /* CircuitBootstrappingExecute::circuit_bootstrapping_execute_to_constant (poulpy-bin-fhe/src/circuit_bootstrapping/
  * circuit.rs:177-195, core :219-370 with to_exponent = false) on `batch` LWE ciphertexts -> `batch` contiguous GGSWs
  * (MatZnx layout, rows = res_dnum, cols_in = cols_out = rank+1, size = res_size), for the case the reference's own

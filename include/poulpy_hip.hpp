@@ -237,6 +237,14 @@ class Module {  // Module<FFT64Hip>, poulpy-hal/src/layouts/module.rs:97-189
                            const double* const* keys, const pz_glwe_op_params& p, void* tmp, size_t tmp_bytes, size_t batch) {
         check(pz_glwe_pack_batched(m_, res, nslots, indices, cts, log_gap_out, gals, keys, &p, tmp, tmp_bytes, batch), "glwe_pack_batched");
     }
+    size_t blind_rotation_extended_tmp_bytes(const pz_blind_rotation_params& p, size_t ext, size_t batch) const {
+        return pz_blind_rotation_extended_tmp_bytes(m_, &p, ext, batch);
+    }
+    void blind_rotation_execute_extended_batched(int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
+                                                 const pz_blind_rotation_params& p, size_t ext, void* tmp, size_t tmp_bytes, size_t batch) {
+        check(pz_blind_rotation_execute_extended_batched(m_, res, lwe_2n, lut, brk, &p, ext, tmp, tmp_bytes, batch),
+              "blind_rotation_execute_extended_batched");
+    }
     void set_graphs(bool enable) { check(pz_module_set_graphs(m_, enable ? 1 : 0), "set_graphs"); }
     uint64_t graph_launches() const { return pz_module_graph_launches(m_); }
     void ggsw_from_gglwe_batched(int64_t* ggsw, const int64_t* a, size_t a_cols_in, size_t dnum, const double* const* tsk,

@@ -1896,6 +1896,71 @@ void pzr_blind_rotation_execute(const pzr_tables* t, size_t rank, size_t n_lwe, 
     }
 }
 
+/* blind_rotation/algorithms/cggi/algorithm.rs:121-273 (execute_block_binary_extended): extension_factor `ext` > 1 accumulators
+ * acc[0..ext) of ring degree n hold the table of domain n*ext; lwe_2n = mod_switch_2n(2*n*ext) output; lut = the ext
+ * polynomials lut.data[j], each VecZnx(1, lut_size), contiguous; res = acc[0] at the end (:270-272).  The skipped updates of
+ * :217, :233, :244 (a multiplier that would be X^0) are part of the reference's behaviour and are restated as they are. */
+void pzr_blind_rotation_execute_extended(const pzr_tables* t, size_t rank, size_t n_lwe, size_t block_size, size_t ext,
+                                         int64_t* res, size_t res_size, size_t base2k,
+                                         const int64_t* lwe_2n, const int64_t* lut, size_t lut_size,
+                                         const double* brk, size_t dnum, size_t brk_size, const double* x_pow_a) {
+    size_t n = t->m << 1, cols = rank + 1, two_n = 2 * n, two_n_ext = 2 * n * ext;
+    size_t pmat_doubles = n * dnum * cols * cols * brk_size;
+    size_t ct = n * cols * res_size, ctd = n * cols * dnum, ctb = n * cols * brk_size;
+    int64_t* acc = (int64_t*)calloc(ext * ct, sizeof(int64_t)); /* :159-161 zero */
+    double* acc_dft = (double*)calloc(ext * ctd, sizeof(double));
+    double* vmp_res = (double*)calloc(ext * ctb, sizeof(double));
+    double* acc_add_dft = (double*)calloc(ext * ctb, sizeof(double));
+    double* vmp_xai = (double*)calloc(n * brk_size, sizeof(double));
+    int64_t* acc_add_big = (int64_t*)calloc(n * brk_size, sizeof(int64_t));
+    const int64_t* a = lwe_2n + 1;
+    size_t b_pos = (size_t)((lwe_2n[0] + (int64_t)two_n_ext) & (int64_t)(two_n_ext - 1)); /* :180 */
+    size_t b_hi = b_pos / ext, b_lo = b_pos & (ext - 1);
+    for (size_t i = 0; i < b_lo; ++i) /* :185-187 */
+        pzr_vec_znx_rotate(n, (int64_t)b_hi + 1, acc + i * ct, cols, res_size, 0, lut + (ext - b_lo + i) * n * lut_size, 1, lut_size, 0);
+    for (size_t i = b_lo; i < ext; ++i) /* :188-190 */
+        pzr_vec_znx_rotate(n, (int64_t)b_hi, acc + i * ct, cols, res_size, 0, lut + (i - b_lo) * n * lut_size, 1, lut_size, 0);
+    for (size_t blk = 0; blk + block_size <= n_lwe; blk += block_size) {
+        for (size_t i = 0; i < ext; ++i)
+            for (size_t j = 0; j < cols; ++j) { /* :195-200 */
+                pzr_vec_znx_dft_apply(t, 1, 0, acc_dft + i * ctd, cols, dnum, j, acc + i * ct, cols, res_size, j);
+                pzr_vec_znx_dft_zero(n, acc_add_dft + i * ctb, cols, brk_size, j);
+            }
+        for (size_t kk = 0; kk < block_size; ++kk) {
+            size_t idx = blk + kk;
+            size_t ai_pos = (size_t)((a[idx] + (int64_t)two_n_ext) & (int64_t)(two_n_ext - 1));
+            size_t ai_hi = ai_pos / ext, ai_lo = ai_pos & (ext - 1);
+            for (size_t i = 0; i < ext; ++i) /* :209-211 */
+                pzr_vmp_apply_dft_to_dft(n, vmp_res + i * ctb, cols, brk_size, acc_dft + i * ctd, cols, dnum, brk + idx * pmat_doubles, dnum, cols,
+                                         cols, brk_size, 0);
+#define PZR_EXT_UPD(I_, J_, HI_)                                                                                              \
+    for (size_t c_ = 0; c_ < cols; ++c_) {                                                                                    \
+        pzr_svp_apply_dft_to_dft(n, vmp_xai, 1, brk_size, 0, x_pow_a + (HI_) * n, 1, 0, vmp_res + (J_) * ctb, cols, brk_size, c_); \
+        pzr_vec_znx_dft_add_assign(n, acc_add_dft + (I_) * ctb, cols, brk_size, c_, vmp_xai, 1, brk_size, 0);                 \
+        pzr_vec_znx_dft_sub_assign(n, acc_add_dft + (I_) * ctb, cols, brk_size, c_, vmp_res + (I_) * ctb, cols, brk_size, c_); \
+    }
+            if (ai_lo == 0) { /* :214-226 */
+                if (ai_hi != 0)
+                    for (size_t j = 0; j < ext; ++j) PZR_EXT_UPD(j, j, ai_hi)
+            } else {
+                if (((ai_hi + 1) & (two_n - 1)) != 0) /* :233-241 */
+                    for (size_t i = 0; i < ai_lo; ++i) PZR_EXT_UPD(i, ext - ai_lo + i, ai_hi + 1)
+                if (ai_hi != 0) /* :244-253 */
+                    for (size_t i = ai_lo; i < ext; ++i) PZR_EXT_UPD(i, i - ai_lo, ai_hi)
+            }
+#undef PZR_EXT_UPD
+        }
+        for (size_t j = 0; j < ext; ++j)
+            for (size_t i = 0; i < cols; ++i) { /* :260-266 */
+                pzr_vec_znx_idft_apply(t, acc_add_big, 1, brk_size, 0, acc_add_dft + j * ctb, cols, brk_size, i);
+                pzr_vec_znx_big_add_small_assign(n, acc_add_big, 1, brk_size, 0, acc + j * ct, cols, res_size, i);
+                pzr_vec_znx_normalize(n, acc + j * ct, cols, res_size, base2k, 0, i, acc_add_big, 1, brk_size, base2k, 0);
+            }
+    }
+    memcpy(res, acc, ct * sizeof(int64_t)); /* :270-272 */
+    free(acc); free(acc_dft); free(vmp_res); free(acc_add_dft); free(vmp_xai); free(acc_add_big);
+}
+
 /* ------------------------------------------------------------------------ */
 /* glwe_trace (circuit bootstrapping around the blind rotation) */
 /* ------------------------------------------------------------------------ */

@@ -191,6 +191,13 @@ void pzr_blind_rotation_execute(const pzr_tables* t, size_t rank, size_t n_lwe, 
                                 const int64_t* lwe_2n, const int64_t* lut, size_t lut_size,
                                 const double* brk, size_t dnum, size_t brk_size, const double* x_pow_a);
 
+/* algorithm.rs:121-273 (execute_block_binary_extended): ext accumulators, lut = ext polynomials VecZnx(1, lut_size), x_pow_a with
+ * 2n entries (X^(2n) = X^0 is never used: :233) */
+void pzr_blind_rotation_execute_extended(const pzr_tables* t, size_t rank, size_t n_lwe, size_t block_size, size_t ext,
+                                         int64_t* res, size_t res_size, size_t base2k,
+                                         const int64_t* lwe_2n, const int64_t* lut, size_t lut_size,
+                                         const double* brk, size_t dnum, size_t brk_size, const double* x_pow_a);
+
 /* reference/vec_znx/shift.rs:186-243 ; poulpy-core/src/glwe_trace.rs:129-176 (equal bases) */
 void pzr_vec_znx_rsh_assign(size_t n, size_t base2k, size_t k, int64_t* res, size_t res_cols, size_t res_size, size_t res_col);
 void pzr_glwe_trace_assign(const pzr_tables* t, size_t rank, int64_t* res, size_t res_size, size_t base2k,

@@ -367,6 +367,15 @@ class RefModule:
             *_sz(brk_dnum, brk_size, glwe_size), _p(x_pow_a), g, ap, *_sz(atk[0].rows, atk[0].size), _p(ggsw.data),
             *_sz(ggsw.rows, ggsw.size, gap, log_gap_in, log_gap_out, log_domain), tp, *_sz(tsk[0].rows, tsk[0].size))
 
+    def blind_rotation_execute_extended(self, res, base2k, lwe_2n, luts, brk, dnum, brk_size, block_size, x_pow_a):
+        """algorithm.rs:121-273: luts = (ext, lut_size, 1, n) i64 array (lut.data[j]), lwe_2n switched to 2*n*ext."""
+        rank = res.cols - 1
+        n_lwe = lwe_2n.shape[0] - 1
+        ext, lut_size = luts.shape[0], luts.shape[1]
+        assert luts.dtype == np.int64 and luts.flags["C_CONTIGUOUS"]
+        self.lib.pzr_blind_rotation_execute_extended(self.t, *_sz(rank, n_lwe, block_size, ext), _p(res.data), *_sz(res.size, base2k),
+                                                     _p(lwe_2n), _p(luts), c_size_t(lut_size), _p(brk), *_sz(dnum, brk_size), _p(x_pow_a))
+
     # glwe_trace (poulpy-core/src/glwe_trace.rs) and the shift it uses
     def vec_znx_rsh_assign(self, base2k, k, res, res_col, scratch=None):
         self.lib.pzr_vec_znx_rsh_assign(c_size_t(self._n), *_sz(base2k, k), _p(res.data), *_sz(res.cols, res.size, res_col))

@@ -2148,6 +2148,90 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
     return PZ_OK;
 }
 
+// execute_block_binary_extended (algorithm.rs:121-273; extension_factor > 1, block_size > 1): the ext accumulators of a
+// ciphertext are one more batch dimension ([b][e]); per LWE block: batched forward DFT | per coefficient: batched VMP, then
+// k_xai_ext moves the products between the accumulators as the reference does | inverse DFT + acc + carry chain (fused tail).
+size_t pz_blind_rotation_extended_tmp_bytes(const pz_module* M, const pz_blind_rotation_params* p, size_t extension_factor, size_t batch) {
+    if (!M || !p) return 0;
+    const size_t n8 = (size_t)M->n * 8, cols = p->rank + 1, be = batch * extension_factor;
+    return align256(be * n8 * cols * p->res_size) + align256(be * n8 * cols * p->dnum) + 2 * align256(be * n8 * cols * p->brk_size) +
+           align256(be * cols * std::max({(size_t)p->dnum, (size_t)p->brk_size, (size_t)p->res_size}) * (size_t)M->m * sizeof(cplx));
+}
+int pz_blind_rotation_execute_extended_batched(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
+                                               const pz_blind_rotation_params* p, size_t extension_factor, void* tmp, size_t tmp_bytes,
+                                               size_t batch) {
+    PZ_ENTER(M);
+    PZ_REQUIRE(p != nullptr, "null params");
+    PZ_REQUIRE(p->n_lwe >= 1 && p->block_size >= 1 && p->dnum >= 1 && p->brk_size >= 1 && p->res_size >= 1 && p->lut_size >= 1,
+               "blind_rotation: empty shape");
+    PZ_REQUIRE(p->base2k >= 1 && p->base2k <= 63, "blind_rotation: base2k out of range");
+    PZ_REQUIRE(extension_factor >= 1 && (extension_factor & (extension_factor - 1)) == 0 && extension_factor <= 64,
+               "blind_rotation: extension_factor must be a power of two");
+    PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(lwe_2n) && is_device_ptr(lut) && is_device_ptr(brk) && is_device_ptr(tmp),
+               "batched entry points take device pointers");
+    PZ_REQUIRE(tmp_bytes >= pz_blind_rotation_extended_tmp_bytes(M, p, extension_factor, batch), "blind_rotation: tmp is too small");
+    if (batch == 0) return PZ_OK;
+    PZ_TRY(ensure_w2n(M));
+    int log_ext = 0;
+    while (((size_t)1 << log_ext) < extension_factor) ++log_ext;
+    const long long n = (long long)M->n;
+    const int cols = (int)p->rank + 1, dnum = (int)p->dnum, bsz = (int)p->brk_size, rsz = (int)p->res_size, k = (int)p->base2k;
+    const int B = (int)batch, BE = B * (int)extension_factor, n_lwe = (int)p->n_lwe, blk = (int)p->block_size;
+    const long long lwe_bs = (long long)n_lwe + 1, res_ct = n * cols * rsz;
+    const size_t pmat_doubles = (size_t)M->n * dnum * cols * cols * bsz;
+    const size_t n8 = (size_t)M->n * 8;
+    char* base = (char*)tmp;
+    int64_t* acc = (int64_t*)base; base += align256((size_t)BE * n8 * cols * rsz);
+    double* acc_dft = (double*)base; base += align256((size_t)BE * n8 * cols * dnum);
+    double* vmp_res = (double*)base; base += align256((size_t)BE * n8 * cols * bsz);
+    double* acc_add = (double*)base; base += align256((size_t)BE * n8 * cols * bsz);
+    cplx* T = (cplx*)base;
+    // :159-161 zero, :180-190 rotated table
+    PZ_HIP(hipMemsetAsync(acc, 0, (size_t)BE * res_ct * 8, M->stream));
+    {
+        BrExtInitArgs g;
+        g.acc = (long long*)acc; g.lut = (const long long*)lut; g.lwe = (const long long*)lwe_2n; g.lwe_bs = lwe_bs;
+        g.n = (int)M->n; g.log_ext = log_ext; g.cols = cols; g.rsz = rsz; g.lut_size = (int)p->lut_size;
+        g.nl = std::min(rsz, (int)p->lut_size); g.batch = B;
+        KTimer kt(M, PZ_K_ELEMENTWISE);
+        PZ_REQUIRE(BE <= 65535, "blind_rotation: batch * extension_factor exceeds 65535 (split the batch)");
+        hipLaunchKernelGGL(k_br_ext_init, dim3((unsigned)((M->n / 2 + 255) / 256), (unsigned)g.nl, (unsigned)BE), dim3(256), 0, M->stream, g);
+        PZ_HIP(hipGetLastError());
+    }
+    DV rv{acc, res_ct, cols, rsz};
+    DV ad{acc_dft, n * cols * dnum, cols, dnum}, vr{vmp_res, n * cols * bsz, cols, bsz}, aa{acc_add, n * cols * bsz, cols, bsz};
+    const bool tail = M->fuse_tail && tail_supported(M);
+    for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {
+        PZ_TRY(dev_dft_apply(M, BE, 1, 0, ad, 0, rv, 0, cols, nullptr, T));                           // :195-200
+        PZ_HIP(hipMemsetAsync(acc_add, 0, (size_t)BE * aa.bs * 8, M->stream));
+        for (int i = b0; i < b0 + blk; ++i) {
+            PZ_TRY(dev_vmp(M, BE, vr, ad, brk + (size_t)i * pmat_doubles, dnum, cols, cols, bsz, 0));   // :209-211
+            XaiExtArgs g;
+            g.acc = (cplx*)acc_add; g.v = (const cplx*)vmp_res; g.polys = cols * bsz; g.m = (int)M->m; g.log_ext = log_ext; g.batch = B;
+            g.lwe = (const long long*)lwe_2n; g.lwe_bs = lwe_bs; g.idx = i; g.w2n = M->w2n;
+            const long long total = (long long)BE * g.polys * g.m;
+            KTimer kt(M, PZ_K_ELEMENTWISE);
+            hipLaunchKernelGGL(k_xai_ext, dim3((unsigned)std::min<long long>((total + 255) / 256, 256 * 16)), dim3(256), 0, M->stream, g);
+            PZ_HIP(hipGetLastError());
+        }
+        if (tail) {                                                                                    // :260-266
+            PolyMap sm{bsz, cols, aa.bs, (long long)cols * n, n, 0};
+            PZ_TRY(launch_inv_pass2(M, BE * bsz * cols, acc_add, sm, T));
+            PZ_TRY(launch_inv_tail(M, BE, T, bsz, cols, (long long*)acc, res_ct, cols, rsz, (const long long*)acc, res_ct, cols, rsz, k, false, true));
+        } else {
+            PZ_TRY(dev_idft(M, BE, aa, 0, aa, 0, cols, bsz, T));
+            for (int c = 0; c < cols; ++c) {
+                PZ_TRY(launch_ew(M, EW_ADD_I64, (int64_t*)acc_add + (long long)c * n, aa.bs, (long long)cols * n,
+                                 (int64_t*)acc_add + (long long)c * n, aa.bs, (long long)cols * n, acc + (long long)c * n, res_ct,
+                                 (long long)cols * n, std::min(bsz, rsz), BE));
+                PZ_TRY(dev_normalize(M, BE, rv, k, 0, c, aa, k, c));
+            }
+        }
+    }
+    // :270-272 res = acc[0]
+    return launch_ew(M, EW_COPY, res, res_ct, n, acc, (long long)extension_factor * res_ct, n, nullptr, 0, 0, cols * rsz, B);
+}
+
 int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
                                       const pz_blind_rotation_params* p, size_t batch) {
     PZ_ENTER(M);

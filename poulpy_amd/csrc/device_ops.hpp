@@ -401,6 +401,80 @@ __global__ void __launch_bounds__(256) k_xai_acc(XaiArgs g) {
 }
 
 // =================================================================================
+// execute_block_binary_extended (algorithm.rs:121-273): ext accumulators per ciphertext, laid out [b][e].
+// k_br_ext_init (:180-190): acc[b][i] col 0 = X^(b_hi (+1)) * lut[j], with b_pos = lwe[b][0] mod 2 n ext, b_hi = b_pos / ext,
+//   b_lo = b_pos mod ext; i < b_lo: j = ext - b_lo + i and one more unit of rotation, else j = i - b_lo.
+// k_xai_ext (:205-254): acc_add[b][i] += DFT(X^mult) (.) v[b][j] - v[b][i] with (j, mult) chosen from a = lwe[b][1+idx] as the
+//   reference does, INCLUDING its skipped updates when the multiplier would be X^0 (:217, :233, :244).
+// =================================================================================
+struct BrExtInitArgs {
+    long long* acc;          // [batch*ext] GLWE(cols, rsz), zeroed beforehand
+    const long long* lut;    // ext x VecZnx(1, lut_size)
+    const long long* lwe;
+    long long lwe_bs;
+    int n, log_ext, cols, rsz, lut_size, nl, batch;
+};
+__global__ void __launch_bounds__(256) k_br_ext_init(BrExtInitArgs g) {
+    const int ext = 1 << g.log_ext;
+    const int be = blockIdx.z, limb = blockIdx.y;
+    const int b = be >> g.log_ext, i = be & (ext - 1);
+    const int t0 = (blockIdx.x * 256 + threadIdx.x) * 2;
+    if (t0 >= g.n) return;
+    const unsigned maskx = 2u * (unsigned)g.n * (unsigned)ext - 1u, mask2 = 2u * (unsigned)g.n - 1u;
+    const unsigned b_pos = (unsigned)((unsigned long long)g.lwe[(long long)b * g.lwe_bs] & (unsigned long long)maskx);
+    const unsigned b_hi = b_pos >> g.log_ext, b_lo = b_pos & (unsigned)(ext - 1);
+    const int j = (unsigned)i < b_lo ? ext - (int)b_lo + i : i - (int)b_lo;
+    const unsigned kk = ((unsigned)i < b_lo ? b_hi + 1u : b_hi) & mask2;
+    const long long* src = g.lut + ((long long)j * g.lut_size + limb) * g.n;
+    long long* dst = g.acc + (((long long)be * g.rsz + limb) * g.cols) * g.n;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const unsigned i0 = ((unsigned)(t0 + e) - kk) & mask2;
+        const unsigned long long v = (unsigned long long)src[i0 & (unsigned)(g.n - 1)];
+        dst[t0 + e] = (long long)(i0 >= (unsigned)g.n ? 0ull - v : v);
+    }
+}
+
+struct XaiExtArgs {
+    cplx* acc;               // [batch*ext][polys][m]
+    const cplx* v;           // same layout
+    int polys, m, log_ext, batch;
+    const long long* lwe;
+    long long lwe_bs, idx;
+    const cplx* w2n;
+};
+__global__ void __launch_bounds__(256) k_xai_ext(XaiExtArgs g) {
+    const int ext = 1 << g.log_ext;
+    const long long per = (long long)g.polys * g.m;
+    const long long total = (long long)g.batch * ext * per;
+    const unsigned mask = 4u * (unsigned)g.m - 1u;                       // 2n - 1
+    const unsigned maskx = (4u * (unsigned)g.m << g.log_ext) - 1u;       // 2 n ext - 1
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const long long be = t / per, e = t % per;
+        const long long b = be >> g.log_ext;
+        const int i = (int)(be & (ext - 1));
+        const unsigned q = (unsigned)(e % g.m);
+        const unsigned a = (unsigned)((unsigned long long)g.lwe[b * g.lwe_bs + 1 + g.idx] & (unsigned long long)maskx);
+        const unsigned hi = a >> g.log_ext, lo = a & (unsigned)(ext - 1);
+        int j;
+        unsigned mult;
+        bool skip;
+        if (lo == 0) { j = i; mult = hi; skip = hi == 0; }
+        else if ((unsigned)i < lo) { j = ext - (int)lo + i; mult = hi + 1u; skip = ((hi + 1u) & mask) == 0; }
+        else { j = i - (int)lo; mult = hi; skip = hi == 0; }
+        if (skip) continue;
+        const cplx x = g.w2n[(mult * (4u * q + 1u)) & mask];
+        const cplx vj = g.v[((b << g.log_ext) + j) * per + e];
+        const cplx vi = g.v[be * per + e];
+        cplx r = g.acc[be * per + e];
+        const cplx xv = cmul(x, vj);
+        r.x = (r.x + xv.x) - vi.x;
+        r.y = (r.y + xv.y) - vi.y;
+        g.acc[be * per + e] = r;
+    }
+}
+
+// =================================================================================
 // One block of the block-binary blind rotation in the DFT domain (algorithm.rs:319-337), fused:
 //   acc_add[b][c] = sum_{i in block} (DFT(X^a_{b,i}) - 1) (.) ( sum_r acc_dft[b][r] (.) BRK_i[r][c] )
 // i.e. vec_znx_dft_zero + block_size x (vmp_apply_dft_to_dft, svp_apply_dft_to_dft, dft_add_assign, dft_sub_assign)

@@ -72,7 +72,7 @@ def load_library(path: str | None = None) -> C.CDLL:
                  "pz_glwe_op_workspace_bytes", "pz_vec_znx_automorphism_assign_tmp_bytes",
                  "pz_vec_znx_big_automorphism_assign_tmp_bytes", "pz_blind_rotation_workspace_bytes", "pz_vec_znx_rsh_tmp_bytes", "pz_vec_znx_rotate_assign_tmp_bytes",
                  "pz_circuit_bootstrapping_tmp_bytes", "pz_vec_znx_normalize_tmp_bytes", "pz_vec_znx_lsh_tmp_bytes", "pz_glwe_pack_tmp_bytes",
-                 "pz_circuit_bootstrapping_to_exponent_tmp_bytes"):
+                 "pz_circuit_bootstrapping_to_exponent_tmp_bytes", "pz_blind_rotation_extended_tmp_bytes"):
         getattr(lib, name).restype = c_size_t
     if path is None:
         _lib = lib
@@ -498,6 +498,15 @@ class Module:
         self._ck(self.lib.pz_circuit_bootstrapping_execute_to_exponent_batched(
             self.handle, ggsw, lwe_2n, lut, brk, g, ap, tp, C.byref(params), *_sz(log_gap_in, log_gap_out, log_domain), tmp,
             c_size_t(tmp_bytes), c_size_t(batch)))
+
+    def blind_rotation_extended_tmp_bytes(self, params: BlindRotationParams, ext: int, batch: int) -> int:
+        return self.lib.pz_blind_rotation_extended_tmp_bytes(self.handle, C.byref(params), *_sz(ext, batch))
+
+    def blind_rotation_execute_extended_batched(self, res: c_void_p, lwe_2n: c_void_p, lut: c_void_p, brk: c_void_p,
+                                                params: BlindRotationParams, ext: int, tmp: c_void_p, tmp_bytes: int, batch: int):
+        """algorithm.rs:121-273 (extension_factor > 1): lut = ext contiguous VecZnx(1, lut_size), lwe_2n switched to 2*n*ext."""
+        self._ck(self.lib.pz_blind_rotation_execute_extended_batched(self.handle, res, lwe_2n, lut, brk, C.byref(params), c_size_t(ext), tmp,
+                                                                     c_size_t(tmp_bytes), c_size_t(batch)))
 
     def blind_rotation_workspace_bytes(self, params: BlindRotationParams, batch: int) -> int:
         return self.lib.pz_blind_rotation_workspace_bytes(self.handle, C.byref(params), c_size_t(batch))

@@ -176,6 +176,10 @@ extern "C" {
     pub fn pz_glwe_pack_batched(m: *mut pz_module, res: *mut i64, nslots: usize, indices: *const u64, cts: *const *mut i64,
         log_gap_out: usize, gals: *const i64, keys: *const *const f64, p: *const pz_glwe_op_params, tmp: *mut c_void, tmp_bytes: usize,
         batch: usize) -> c_int;
+    /// execute_block_binary_extended (algorithm.rs:121-273): extension_factor > 1
+    pub fn pz_blind_rotation_extended_tmp_bytes(m: *const pz_module, p: *const pz_blind_rotation_params, ext: usize, batch: usize) -> usize;
+    pub fn pz_blind_rotation_execute_extended_batched(m: *mut pz_module, res: *mut i64, lwe_2n: *const i64, lut: *const i64,
+        brk: *const f64, p: *const pz_blind_rotation_params, ext: usize, tmp: *mut c_void, tmp_bytes: usize, batch: usize) -> c_int;
     /// HIP-graph replay of the launch-bound composite calls (on by default)
     pub fn pz_module_set_graphs(m: *mut pz_module, enable: c_int) -> c_int;
     pub fn pz_module_graph_launches(m: *const pz_module) -> u64;

@@ -1404,3 +1404,56 @@ def test_circuit_bootstrapping_to_exponent(mods, n, rank, log_gap_in, log_gap_ou
     assert np.array_equal(got[:, :, 0], want[:, :, 0]), "packed rows differ"
     assert np.array_equal(got, want)
 
+
+@pytest.mark.parametrize("n,rank,ext,n_lwe,blk,dnum,bsz,rsz,batch,fuse", [
+    (256, 1, 2, 7, 3, 2, 2, 2, 5, True),
+    (256, 1, 4, 6, 2, 2, 3, 2, 4, True),
+    (512, 2, 8, 4, 2, 3, 2, 3, 3, True),
+    (4096, 1, 2, 4, 2, 2, 2, 2, 2, True),
+    (256, 1, 4, 6, 3, 2, 2, 3, 3, False),
+])
+def test_blind_rotation_extended(mods, n, rank, ext, n_lwe, blk, dnum, bsz, rsz, batch, fuse):
+    """execute_block_binary_extended (algorithm.rs:121-273, extension_factor > 1) vs the oracle's literal restatement; the LWE
+    values include every special case of the reference (a = 0, a multiple of ext, ai_hi = 0 with ai_lo != 0, ai_hi + 1 = 2n)."""
+    from poulpy_amd.hal import BlindRotationParams
+    k = 13
+    ref, hip = mods(n)
+    rng = seeded(9900 + n + ext)
+    cols = rank + 1
+    luts = rng.integers(-(1 << (k - 1)), 1 << (k - 1), (ext, rsz, 1, n), dtype=np.int64)
+    brk_r = np.empty((n_lwe, n * dnum * cols * cols * bsz), dtype=np.float64)
+    brk_h = np.empty_like(brk_r)
+    for i in range(n_lwe):
+        mat = MatZnx(n, dnum, cols, cols, bsz).fill_uniform(k, rng)
+        pr, ph = ref.vmp_pmat_alloc(dnum, cols, cols, bsz), hip.vmp_pmat_alloc(dnum, cols, cols, bsz)
+        ref.vmp_prepare(pr, mat)
+        hip.vmp_prepare(ph, mat)
+        brk_r[i], brk_h[i] = pr.data.reshape(-1), ph.data.reshape(-1)
+    lwe = rng.integers(-n * ext, n * ext, (batch, n_lwe + 1), dtype=np.int64)   # mod_switch_2n(2 n ext) output range
+    lwe[0, 1] = 0                       # contributes nothing
+    lwe[0, 2] = ext * 5                 # ai_lo = 0
+    lwe[1 % batch, 1] = ext - 1         # ai_hi = 0, ai_lo != 0: the second half is skipped
+    lwe[1 % batch, 2] = 2 * n * ext - 1  # ai_hi + 1 = 2n: the first half is skipped
+    lwe[-1, 0] = n * ext - 1
+    xpa = ref.blind_rotation_x_pow_a()
+    want = np.empty((batch, rsz, cols, n), dtype=np.int64)
+    for b in range(batch):
+        res = VecZnx(n, cols, rsz)
+        ref.blind_rotation_execute_extended(res, k, np.ascontiguousarray(lwe[b]), luts, brk_r, dnum, bsz, blk, xpa)
+        want[b] = res.data
+    d_lwe = hip.device_alloc(lwe.nbytes).upload(lwe)
+    d_lut = hip.device_alloc(luts.nbytes).upload(luts)
+    d_brk = hip.device_alloc(brk_h.nbytes).upload(brk_h)
+    d_res = hip.device_alloc(want.nbytes)
+    p = BlindRotationParams(rank=rank, n_lwe=n_lwe, block_size=blk, dnum=dnum, brk_size=bsz, base2k=k, res_size=rsz, lut_size=rsz)
+    nbytes = hip.blind_rotation_extended_tmp_bytes(p, ext, batch)
+    d_tmp = hip.device_alloc(nbytes)
+    hip.set_fusion(fuse, fuse)
+    hip.blind_rotation_execute_extended_batched(d_res.ptr, d_lwe.ptr, d_lut.ptr, d_brk.ptr, p, ext, d_tmp.ptr, nbytes, batch)
+    hip.sync()
+    hip.set_fusion(True, True)
+    got = d_res.download(np.int64, want.size).reshape(want.shape)
+    for buf in (d_lwe, d_lut, d_brk, d_res, d_tmp):
+        buf.free()
+    assert np.array_equal(got, want)
+

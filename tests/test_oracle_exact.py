@@ -549,3 +549,32 @@ def test_P11_glwe_pack_tree_walk():
         R.glwe_pack(res, base2k, cts, log_gap_out, gals, keys)
         assert np.array_equal(res.data, want.data), (indices, log_gap_out)
 
+
+def test_P12_extended_blind_rotation_degenerates_to_block_binary():
+    """execute_block_binary_extended restated literally (algorithm.rs:121-273): with extension_factor 1 it must reproduce the
+    block-binary rotation (pinned by P6) bit for bit; with extension_factor > 1 and every a_i a multiple of the factor
+    (ai_lo = 0: no movement between the accumulators) accumulator 0 is the block-binary rotation of lut[0] by a_i / ext."""
+    n, rank, n_lwe, blk, dnum, bsz, rsz, k = 64, 1, 6, 3, 2, 2, 2, 12
+    R = RefModule(n)
+    rng = seeded(1212)
+    cols = rank + 1
+    brk = np.empty((n_lwe, n * dnum * cols * cols * bsz))
+    for i in range(n_lwe):
+        mat = MatZnx(n, dnum, cols, cols, bsz).fill_uniform(k, rng)
+        pm = R.vmp_pmat_alloc(dnum, cols, cols, bsz)
+        R.vmp_prepare(pm, mat)
+        brk[i] = pm.data.reshape(-1)
+    xpa = R.blind_rotation_x_pow_a()
+    lut = VecZnx(n, 1, rsz).fill_uniform(k, rng)
+    lwe = rng.integers(-n, n, n_lwe + 1, dtype=np.int64)
+    r1, r2 = VecZnx(n, cols, rsz), VecZnx(n, cols, rsz)
+    R.blind_rotation_execute(r1, k, lwe, lut, brk, dnum, bsz, blk, xpa)
+    R.blind_rotation_execute_extended(r2, k, lwe, np.ascontiguousarray(lut.data.reshape(1, rsz, 1, n)), brk, dnum, bsz, blk, xpa)
+    assert np.array_equal(r1.data, r2.data)
+    ext = 4
+    luts = rng.integers(-(1 << (k - 1)), 1 << (k - 1), (ext, rsz, 1, n), dtype=np.int64)
+    luts[0] = lut.data.reshape(rsz, 1, n)
+    r3 = VecZnx(n, cols, rsz)
+    R.blind_rotation_execute_extended(r3, k, lwe * ext, luts, brk, dnum, bsz, blk, xpa)
+    assert np.array_equal(r3.data, r1.data)
+
