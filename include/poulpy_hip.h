@@ -363,7 +363,7 @@ int pz_blind_rotation_execute_extended_batched(pz_module* m, int64_t* res, const
  * circuit.rs:177-195, core :219-370 with to_exponent = false) on `batch` LWE ciphertexts -> `batch` contiguous GGSWs
  * (MatZnx layout, rows = res_dnum, cols_in = cols_out = rank+1, size = res_size), for the case the reference's own
  * benchmark runs (poulpy-bench bench_suite/schemes/circuit_bootstrapping.rs): one base2k for the blind-rotation key, the
- * automorphism keys, the tensor keys and the result, extension_factor = 1.  execute_to_exponent (:197-216) with
+ * automorphism keys, the tensor keys and the result.  execute_to_exponent (:197-216) with
  * log_gap_in == log_gap_out is the same call with the step list of the partial trace (post_process :418-420: steps
  * log_n - log_gap_in + 1 .. log_n) and the table / mod-switch direction the shim builds for that mode (:276-301);
  * pz_circuit_bootstrapping_execute_to_exponent_batched below does that mapping and the repacking branch (:392-417); other
@@ -380,6 +380,8 @@ typedef struct {
     uint64_t tsk_dnum, tsk_size;
     uint64_t res_dnum, res_size; /* the output GGSW */
     uint64_t gap;
+    uint64_t extension_factor;   /* 0 or 1: execute_block_binary / execute_standard; > 1: the extended rotation (lut = that many
+                                    polynomials, lwe_2n switched to 2*n*extension_factor, gap as circuit.rs:333 computes it) */
 } pz_circuit_bootstrapping_params;
 size_t pz_circuit_bootstrapping_tmp_bytes(const pz_module* m, const pz_circuit_bootstrapping_params* p, size_t batch);
 int pz_circuit_bootstrapping_execute_to_constant_batched(pz_module* m, int64_t* ggsw, const int64_t* lwe_2n, const int64_t* lut,

@@ -2157,10 +2157,8 @@ size_t pz_blind_rotation_extended_tmp_bytes(const pz_module* M, const pz_blind_r
     return align256(be * n8 * cols * p->res_size) + align256(be * n8 * cols * p->dnum) + 2 * align256(be * n8 * cols * p->brk_size) +
            align256(be * cols * std::max({(size_t)p->dnum, (size_t)p->brk_size, (size_t)p->res_size}) * (size_t)M->m * sizeof(cplx));
 }
-int pz_blind_rotation_execute_extended_batched(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
-                                               const pz_blind_rotation_params* p, size_t extension_factor, void* tmp, size_t tmp_bytes,
-                                               size_t batch) {
-    PZ_ENTER(M);
+static int blind_rotation_extended(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
+                                   const pz_blind_rotation_params* p, size_t extension_factor, void* tmp, size_t tmp_bytes, size_t batch) {
     PZ_REQUIRE(p != nullptr, "null params");
     PZ_REQUIRE(p->n_lwe >= 1 && p->block_size >= 1 && p->dnum >= 1 && p->brk_size >= 1 && p->res_size >= 1 && p->lut_size >= 1,
                "blind_rotation: empty shape");
@@ -2231,6 +2229,12 @@ int pz_blind_rotation_execute_extended_batched(pz_module* M, int64_t* res, const
     // :270-272 res = acc[0]
     return launch_ew(M, EW_COPY, res, res_ct, n, acc, (long long)extension_factor * res_ct, n, nullptr, 0, 0, cols * rsz, B);
 }
+int pz_blind_rotation_execute_extended_batched(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
+                                               const pz_blind_rotation_params* p, size_t extension_factor, void* tmp, size_t tmp_bytes,
+                                               size_t batch) {
+    PZ_ENTER(M);
+    return blind_rotation_extended(M, res, lwe_2n, lut, brk, p, extension_factor, tmp, tmp_bytes, batch);
+}
 
 int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
                                       const pz_blind_rotation_params* p, size_t batch) {
@@ -2255,10 +2259,12 @@ static int glwe_pack(pz_module* M, int64_t* res, size_t nslots, const uint64_t* 
                      size_t batch);
 struct CbtRepack { size_t log_gap_in, log_gap_out, log_domain; };  // exponent mode with log_gap_in != log_gap_out (post_process)
 static inline size_t cbt_tmp_size(const pz_circuit_bootstrapping_params* p) { return (size_t)std::max(p->br.res_size, p->res_size); }
+static inline size_t cbt_ext(const pz_circuit_bootstrapping_params* p) { return p->extension_factor > 1 ? (size_t)p->extension_factor : 1; }
 size_t pz_circuit_bootstrapping_tmp_bytes(const pz_module* M, const pz_circuit_bootstrapping_params* p, size_t batch) {
     if (!M || !p) return 0;
     const size_t n8 = (size_t)M->n * 8, cols = p->br.rank + 1;
-    return align256(batch * n8 * cols * p->br.res_size) + align256(batch * p->res_dnum * n8 * cols * cbt_tmp_size(p));
+    const size_t ext_bytes = cbt_ext(p) > 1 ? align256(pz_blind_rotation_extended_tmp_bytes(M, &p->br, cbt_ext(p), batch)) : 0;
+    return align256(batch * n8 * cols * p->br.res_size) + align256(batch * p->res_dnum * n8 * cols * cbt_tmp_size(p)) + ext_bytes;
 }
 size_t pz_circuit_bootstrapping_to_exponent_tmp_bytes(const pz_module* M, const pz_circuit_bootstrapping_params* p, size_t log_domain,
                                                       size_t batch) {
@@ -2286,7 +2292,14 @@ static int circuit_bootstrapping(pz_module* M, int64_t* ggsw, const int64_t* lwe
     const long long ct_g = n * cols * gsz, ct_t = n * cols * tsz, ct_r = n * cols * rsz;
     int64_t* acc = (int64_t*)tmp;
     int64_t* tr = (int64_t*)((char*)tmp + align256((size_t)B * ct_g * 8));
-    PZ_TRY(blind_rotation(M, acc, lwe_2n, lut, brk, &p->br, batch));
+    if (cbt_ext(p) > 1) {  // key.brk.execute dispatches on lut.extension_factor() (algorithm.rs:76-118); the scratch sits behind ours
+        const size_t eb = align256(pz_blind_rotation_extended_tmp_bytes(M, &p->br, cbt_ext(p), batch));
+        void* etmp = (char*)tmp + (rp ? pz_circuit_bootstrapping_to_exponent_tmp_bytes(M, p, rp->log_domain, batch)
+                                      : pz_circuit_bootstrapping_tmp_bytes(M, p, batch)) - eb;
+        PZ_TRY(blind_rotation_extended(M, acc, lwe_2n, lut, brk, &p->br, cbt_ext(p), etmp, eb, batch));
+    } else {
+        PZ_TRY(blind_rotation(M, acc, lwe_2n, lut, brk, &p->br, batch));
+    }
     if (tsz > gsz) PZ_HIP(hipMemsetAsync(tr, 0, (size_t)B * rows * ct_t * 8, M->stream));  // glwe_copy zero-extends (glwe_trace.rs:114)
     for (int i = 0; i < rows; ++i) {
         PolyMap sm{gsz, cols, ct_g, (long long)cols * n, n, 0};

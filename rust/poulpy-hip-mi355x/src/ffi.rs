@@ -140,6 +140,7 @@ pub struct pz_circuit_bootstrapping_params {
     pub res_dnum: u64,
     pub res_size: u64,
     pub gap: u64,
+    pub extension_factor: u64,
 }
 
 extern "C" {

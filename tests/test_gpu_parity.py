@@ -1457,3 +1457,75 @@ def test_blind_rotation_extended(mods, n, rank, ext, n_lwe, blk, dnum, bsz, rsz,
         buf.free()
     assert np.array_equal(got, want)
 
+
+def test_circuit_bootstrapping_with_extension_factor(mods):
+    """circuit.rs:219-370 with extension_factor 2 (the rotation dispatches to execute_block_binary_extended, algorithm.rs:76-118):
+    expected GGSW composed in Python from the oracle's pieces (extended rotation, rotate, glwe_trace, ggsw_expand_row)."""
+    from poulpy_amd.hal import BlindRotationParams, CircuitBootstrappingParams
+    n, rank, ext, n_lwe, blk, brk_dnum, gsz, res_dnum, rsz, batch, base2k, atk_dnum, tsk_dnum = 256, 1, 2, 6, 3, 2, 3, 2, 2, 3, 13, 3, 2
+    ref, hip = mods(n)
+    rng = seeded(31337)
+    cols = rank + 1
+    log_n = n.bit_length() - 1
+    gap = 2 * int(rng.integers(1, n // 8))
+
+    def prepared(rows, cols_in, size):
+        mat = MatZnx(n, rows, cols_in, cols, size).fill_uniform(base2k, rng)
+        pr, ph = ref.vmp_pmat_alloc(rows, cols_in, cols, size), hip.vmp_pmat_alloc(rows, cols_in, cols, size)
+        ref.vmp_prepare(pr, mat)
+        hip.vmp_prepare(ph, mat)
+        hip.sync()
+        return pr, ph
+
+    luts = rng.integers(-(1 << (base2k - 1)), 1 << (base2k - 1), (ext, gsz, 1, n), dtype=np.int64)
+    brk_r = np.empty((n_lwe, n * brk_dnum * cols * cols * gsz), dtype=np.float64)
+    brk_h = np.empty_like(brk_r)
+    for i in range(n_lwe):
+        pr, ph = prepared(brk_dnum, cols, gsz)
+        brk_r[i], brk_h[i] = pr.data.reshape(-1), ph.data.reshape(-1)
+    gals = [-1] + [pow(5, 1 << i, 2 * n) for i in range(log_n - 1)]
+    atk = [prepared(atk_dnum, rank, gsz) for _ in gals]
+    tsk = [prepared(tsk_dnum, rank, rsz + 1) for _ in range(rank)]
+    lwe = rng.integers(-n * ext, n * ext, (batch, n_lwe + 1), dtype=np.int64)
+    xpa = ref.blind_rotation_x_pow_a()
+    want = np.empty((batch, res_dnum, cols, rsz, cols, n), dtype=np.int64)
+    for b in range(batch):
+        acc = VecZnx(n, cols, gsz)
+        ref.blind_rotation_execute_extended(acc, base2k, np.ascontiguousarray(lwe[b]), luts, brk_r, brk_dnum, gsz, blk, xpa)
+        g = MatZnx(n, res_dnum, cols, cols, rsz)
+        for i in range(res_dnum):
+            row = acc.copy()
+            ref.glwe_trace_assign(row, base2k, gals, [a[0] for a in atk])
+            g.data[i, 0] = row.data[:rsz]
+            if i + 1 < res_dnum:
+                nxt = acc.copy()
+                for c in range(cols):
+                    ref.vec_znx_rotate(-gap, nxt, c, acc, c)
+                acc = nxt
+        ref.ggsw_expand_row(g, base2k, [t[0] for t in tsk], 1, base2k)
+        want[b] = g.data
+    bufs = []
+
+    def up(arr):
+        d = hip.device_alloc(arr.nbytes).upload(arr)
+        bufs.append(d)
+        return d
+
+    d_lwe, d_lut, d_brk = up(lwe), up(luts), up(brk_h)
+    d_atk = [up(a[1].data) for a in atk]
+    d_tsk = [up(t[1].data) for t in tsk]
+    d_res = up(np.zeros(want.shape, dtype=np.int64))
+    p = CircuitBootstrappingParams(
+        br=BlindRotationParams(rank=rank, n_lwe=n_lwe, block_size=blk, dnum=brk_dnum, brk_size=gsz, base2k=base2k, res_size=gsz, lut_size=gsz),
+        atk_dnum=atk_dnum, atk_size=gsz, tsk_dnum=tsk_dnum, tsk_size=rsz + 1, res_dnum=res_dnum, res_size=rsz, gap=gap, extension_factor=ext)
+    nbytes = hip.circuit_bootstrapping_tmp_bytes(p, batch)
+    d_tmp = hip.device_alloc(nbytes)
+    bufs.append(d_tmp)
+    hip.circuit_bootstrapping_execute_to_constant_batched(d_res.ptr, d_lwe.ptr, d_lut.ptr, d_brk.ptr, gals, [k.ptr for k in d_atk],
+                                                          [k.ptr for k in d_tsk], p, d_tmp.ptr, nbytes, batch)
+    hip.sync()
+    got = d_res.download(np.int64, want.size).reshape(want.shape)
+    for buf in bufs:
+        buf.free()
+    assert np.array_equal(got, want)
+
