@@ -1529,3 +1529,42 @@ def test_circuit_bootstrapping_with_extension_factor(mods):
         buf.free()
     assert np.array_equal(got, want)
 
+
+def test_seeded_glwe_pack_sweep(mods):
+    """20 random packing problems (fixed seed; POULPY_SWEEP_SEED / POULPY_SWEEP_CASES by hand): ring 2^5..2^7, rank 1-2, 2-3 limbs,
+    random output gap and random occupancy on the grid of that gap (index 0 always present so that the tree ends there)."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("POULPY_SWEEP_SEED", "515")))
+    for case in range(int(os.environ.get("POULPY_SWEEP_CASES", "20"))):
+        n = int(2 ** rng.integers(5, 8))
+        log_n = n.bit_length() - 1
+        rank = int(rng.integers(1, 3))
+        size = int(rng.integers(2, 4))
+        log_gap_out = int(rng.integers(0, log_n + 1))
+        grid = list(range(0, n, 1 << log_gap_out))
+        extra = [int(x) for x in rng.choice(grid[1:], size=int(rng.integers(0, min(len(grid) - 1, 9) + 1)), replace=False)] if len(grid) > 1 else []
+        indices = [0] + sorted(extra)
+        batch = int(rng.integers(1, 4))
+        if os.environ.get("POULPY_SWEEP_VERBOSE"):
+            print(dict(case=case, n=n, rank=rank, size=size, log_gap_out=log_gap_out, indices=indices, batch=batch), flush=True)
+        test_glwe_pack_batched(mods, n, rank, size, log_gap_out, indices, batch)
+
+
+def test_seeded_extended_rotation_sweep(mods):
+    """15 random extended blind rotations (fixed seed): ring 2^7..2^9, rank 1-2, extension factor 2-8, block size 2-4, 1-3 limbs,
+    ragged batches, both the fused-tail and the op-by-op epilogue."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("POULPY_SWEEP_SEED", "616")))
+    for case in range(int(os.environ.get("POULPY_SWEEP_CASES", "15"))):
+        n = int(2 ** rng.integers(7, 10))
+        rank = int(rng.integers(1, 3))
+        ext = int(2 ** rng.integers(1, 4))
+        blk = int(rng.integers(2, 5))
+        n_lwe = int(rng.integers(1, 3)) * blk + int(rng.integers(0, blk))
+        dnum, bsz, rsz = (int(x) for x in rng.integers(1, 4, 3))
+        batch = int(rng.integers(1, 5))
+        fuse = bool(rng.integers(0, 2))
+        if os.environ.get("POULPY_SWEEP_VERBOSE"):
+            print(dict(case=case, n=n, rank=rank, ext=ext, blk=blk, n_lwe=n_lwe, dnum=dnum, bsz=bsz, rsz=rsz, batch=batch, fuse=fuse), flush=True)
+        test_blind_rotation_extended(mods, n, rank, ext, max(n_lwe, 2), blk, dnum, bsz, rsz, batch, fuse)
+
