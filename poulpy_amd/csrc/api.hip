@@ -131,7 +131,8 @@ static bool tail_supported(const pz_module* M) { return (M->plan.f1b * M->plan.c
 static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
                                 int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
                                 int base2k, bool rowmajor, bool small_all, unsigned auto_mul, bool auto_neg, int col_base, int col_count,
-                                unsigned gather_mul = 0, bool gather_neg = false, int body_col = 0) {
+                                unsigned gather_mul = 0, bool gather_neg = false, int body_col = 0, const long long* body_src = nullptr,
+                                long long body_bs = 0, long long body_ls = 0, bool small_neg = false) {
     const FftPlan& pl = M->plan;
     const int blocks = batch * col_count * (pl.m2 / pl.cb);
     if (blocks == 0) return PZ_OK;
@@ -144,6 +145,7 @@ static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlim
     g.small_all = small_all ? 1 : 0; g.auto_mul = auto_mul; g.auto_neg = auto_neg ? 1 : 0;
     g.col_base = col_base; g.col_count = col_count; g.body_col = body_col;
     g.gather_mul = gather_mul; g.gather_neg = gather_neg ? 1 : 0;
+    g.pre_body = body_src != nullptr ? 1 : 0; g.small_neg = small_neg ? 1 : 0; g.body_src = body_src; g.body_bs = body_bs; g.body_ls = body_ls;
     g.xcd_map = (gather_mul != 0 && blocks % (8 * (pl.m2 / pl.cb)) == 0) ? 1 : 0;
     const bool has_small = small != nullptr;
 // one instantiation per (probe, row-major, body add) combination actually requested
@@ -173,7 +175,8 @@ static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlim
 static int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
                            int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
                            int base2k, bool rowmajor = false, bool small_all = false, unsigned auto_mul = 0, bool auto_neg = false,
-                           unsigned gather_mul = 0, bool gather_neg = false, int body_col = 0) {
+                           unsigned gather_mul = 0, bool gather_neg = false, int body_col = 0, const long long* body_src = nullptr,
+                           long long body_bs = 0, long long body_ls = 0, bool small_neg = false) {
     if (small != nullptr && !small_all && ncols > 1) {
         PZ_TRY(launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, small, small_bs, small_cols, small_size,
                                     base2k, rowmajor, false, auto_mul, auto_neg, body_col, 1, 0, false, body_col));
@@ -184,7 +187,8 @@ static int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, i
                                     base2k, rowmajor, false, 0, false, body_col + 1, ncols - 1 - body_col);
     }
     return launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, small, small_bs, small_cols, small_size, base2k,
-                                rowmajor, small_all, auto_mul, auto_neg, 0, ncols, gather_mul, gather_neg, body_col);
+                                rowmajor, small_all, auto_mul, auto_neg, 0, ncols, gather_mul, gather_neg, body_col, body_src, body_bs, body_ls,
+                                small_neg);
 }
 
 static bool mid_supported(const pz_module* M, int npi, int npo) {
@@ -215,8 +219,13 @@ static int launch_mid_ct(pz_module* M, MidArgs g, int batch) {
     PZ_HIP(hipGetLastError());
     return PZ_OK;
 }
-static int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp, int npi, int npo, int nrows, int ncols, cplx* dummy) {
+// perm_mul != 0: spectrum permutation of X -> X^p folded into the middle kernel (m2 = 128 plans only; see MidArgs)
+static int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp, int npi, int npo, int nrows, int ncols, cplx* dummy,
+                      unsigned perm_mul = 0, unsigned perm_add = 0) {
     MidArgs g;
+    g.perm_mul = perm_mul; g.perm_add = perm_add; g.log_m1 = 0;
+    while ((1 << g.log_m1) < M->plan.m1) ++g.log_m1;
+    const bool perm = perm_mul != 0;
     g.T = T; g.T2 = T2; g.P = Pp; g.npi = npi; g.npo = npo; g.nrows = nrows; g.ncols = ncols;
     g.row_max = std::min(nrows, npi);
     g.ncomp = std::min(npo, ncols);
@@ -239,21 +248,36 @@ static int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cp
             constexpr int CT = 8;
             g.n_ct = (batch + CT - 1) / CT;
             const size_t lds = ((size_t)CT * 8 * 16 * 9 + 256) * sizeof(cplx);
-            PZ_TRY(set_lds((k_mid128<CT, 8>), lds));
-            hipLaunchKernelGGL((k_mid128<CT, 8>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(512), lds, M->stream, g);
+            if (perm) {
+                PZ_TRY(set_lds((k_mid128<CT, 8, true>), lds));
+                hipLaunchKernelGGL((k_mid128<CT, 8, true>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(512), lds, M->stream, g);
+            } else {
+                PZ_TRY(set_lds((k_mid128<CT, 8>), lds));
+                hipLaunchKernelGGL((k_mid128<CT, 8>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(512), lds, M->stream, g);
+            }
         } else if (npi > 16 || npo > 16) {
             // 17..32 polynomials in or out (rank 2-3 with 8 limbs, rank 1 with 16 limbs): 2 ciphertexts x 32 slots per tile
             constexpr int CT = 2;
             g.n_ct = (batch + CT - 1) / CT;
             const size_t lds = ((size_t)CT * 32 * 16 * 9 + 256) * sizeof(cplx);
-            PZ_TRY(set_lds((k_mid128<CT, 32>), lds));
-            hipLaunchKernelGGL((k_mid128<CT, 32>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(512), lds, M->stream, g);
+            if (perm) {
+                PZ_TRY(set_lds((k_mid128<CT, 32, true>), lds));
+                hipLaunchKernelGGL((k_mid128<CT, 32, true>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(512), lds, M->stream, g);
+            } else {
+                PZ_TRY(set_lds((k_mid128<CT, 32>), lds));
+                hipLaunchKernelGGL((k_mid128<CT, 32>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(512), lds, M->stream, g);
+            }
         } else {
             constexpr int CT = 4;
             g.n_ct = (batch + CT - 1) / CT;
             const size_t lds = ((size_t)CT * 16 * 16 * 9 + 256) * sizeof(cplx);
-            PZ_TRY(set_lds(k_mid128<CT>, lds));
-            hipLaunchKernelGGL((k_mid128<CT>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(CT * 128), lds, M->stream, g);
+            if (perm) {
+                PZ_TRY(set_lds((k_mid128<CT, 16, true>), lds));
+                hipLaunchKernelGGL((k_mid128<CT, 16, true>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(CT * 128), lds, M->stream, g);
+            } else {
+                PZ_TRY(set_lds(k_mid128<CT>, lds));
+                hipLaunchKernelGGL((k_mid128<CT>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(CT * 128), lds, M->stream, g);
+            }
         }
         PZ_HIP(hipGetLastError());
         return PZ_OK;
@@ -1639,8 +1663,34 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
             const int a_col0 = ks ? 1 : 0;
             PolyMap sm{a_size, s.cols_in, av.bs, (long long)av.cols * n, n, n * a_col0};
             if (M->dbg_stages & 1) PZ_TRY(launch_fwd_pass1(M, nb * npi, (const long long*)av.p, sm, T, true));
-            if (M->dbg_stages & 2) PZ_TRY(launch_mid(M, nb, T, T2, Pp, npi, npo, nrows, ncols, mid_dummy));
+            // X -> X^p with p = 1 mod 4 on the big value (the add / sub / sub_negate forms): DFT(phi(a))[q] = DFT(a)[p q + (p-1)/4 mod m]
+            // is an affine map of the spectrum index that sends rows of the four-step layout to rows, so the middle kernel writes
+            // its product at the permuted position (k_mid128<.., PERM>) and the tail's inverse transform is phi(big) itself.  The
+            // tail then adds ONE operand stream per column at the natural index -- +-a[col], and on the body column
+            // +-(phi(body) +- a0) prepared by one k_automorphism pass over that column into the (cache-resident) workspace -- and
+            // writes the final result: no permutation pass over the result, no gathers in the tail, in-place forms safe.
+            static const int au_spec = getenv("POULPY_DBG_AUTO_SPECTRAL") ? atoi(getenv("POULPY_DBG_AUTO_SPECTRAL")) : 1;
+            const bool spec = au_spec && au_big && (au_p & 3u) == 1u && M->plan.m2 == 128 && M->dbg_stages == 7;
+            unsigned perm_mul = 0, perm_add = 0;
+            if (spec) {
+                const unsigned mm = (unsigned)M->m;
+                perm_mul = au_g & (mm - 1u);
+                const unsigned long long c0 = (unsigned long long)(((au_p - 1u) >> 2) & (mm - 1u));
+                perm_add = (unsigned)((mm - (unsigned)(((unsigned long long)perm_mul * c0) & (unsigned long long)(mm - 1u))) & (mm - 1u));
+            }
+            if (M->dbg_stages & 2) PZ_TRY(launch_mid(M, nb, T, T2, Pp, npi, npo, nrows, ncols, mid_dummy, perm_mul, perm_add));
             int64_t* res_b = res + (long long)b0 * res_bs;
+            if (spec) {
+                PolyMap bsm{a_size, 1, av.bs, (long long)av.cols * n, 0, 0}, bdm{a_size, 1, (long long)a_size * n, n, 0, 0};
+                // operand of the body column, one stream: phi(body) + a0 (add) or -phi(body) + a0 (sub forms: the tail negates every operand)
+                PZ_TRY(launch_automorphism(M, nb * a_size, (const long long*)av.p, bsm, (long long*)res_tmp, bdm, au_g, au->mode == 1 ? 1 : 3,
+                                           (const long long*)av.p, bsm));
+                PZ_TRY(launch_inv_tail(M, nb, T2, ksz, s.cols_out, (long long*)res_b, res_bs, s.cols_out, (int)p->res_size,
+                                       (const long long*)av.p, av.bs, s.cols_a, a_size, (int)p->res_base2k, true, true,
+                                       au->mode == 3 ? 2u * (unsigned)n : 0u, au->mode == 3, 0u, false, body_col, (const long long*)res_tmp,
+                                       (long long)a_size * n, n, au->mode != 1));
+                continue;
+            }
             const long long* small = ks ? (const long long*)av.p : nullptr;
             long long small_bs = av.bs;
             // au_big: the operand -+phi^-1(a) (+ body for column 0) is gathered from `a` inside the tail (TailArgs::gather_mul)

@@ -382,6 +382,12 @@ struct TailArgs {
     // gathers: every line of the 512 KiB limb is fetched from HBM once)
     unsigned gather_mul;
     int gather_neg, xcd_map;
+    // pre_body (with small_all): the big value arrives already permuted (the middle kernel moved the spectrum, so the inverse
+    // transform is phi(big)); the operand is one stream per column at the natural index: small[col][n], or on the body column
+    // body_src[n] (phi(body) +- a0, prepared by k_automorphism in the workspace); small_neg negates it (sub forms)
+    int pre_body, small_neg;
+    const long long* body_src;
+    long long body_bs, body_ls;
 };
 
 // Workgroup = (R2 + R1)*CB threads in two wave-uniform roles (R2*CB must be a multiple of 64):
@@ -502,7 +508,20 @@ k_inv_tail(TailArgs g) {
         const cplx* buf = xch + (j & 1) * XCH;
         // key-switch body limb: requested first so that its latency hides behind the butterfly
         long long sm[SMALL ? 2 * RE : 1];
-        if (SMALL && small_col && j < g.small_size && g.gather_mul) {
+        if (SMALL && small_col && j < g.small_size && g.pre_body) {
+            const long long* bsrc = col == g.body_col ? g.body_src + (long long)b * g.body_bs + (long long)j * g.body_ls : nullptr;
+#pragma unroll
+            for (int e = 0; e < RE; ++e) {
+                const long long idx = (long long)(b_ov + R2 * PZ_TAIL_N1(e)) * g.m2 + c0 + b_cv;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const long long ih = idx + (h ? m : 0);
+                    unsigned long long v = bsrc ? (unsigned long long)bsrc[ih] : (unsigned long long)small_col[(long long)j * small_ls + ih];
+                    if (g.small_neg) v = 0ull - v;
+                    sm[2 * e + h] = (long long)v;
+                }
+            }
+        } else if (SMALL && small_col && j < g.small_size && g.gather_mul) {
             const long long* body = col == g.body_col ? g.small + (long long)b * g.small_bs + (long long)j * small_ls : nullptr;
 #pragma unroll
             for (int e = 0; e < RE; ++e) {

@@ -33,6 +33,11 @@ struct MidArgs {
     cplx* dummy;        // >= 512*256 points of scratch: where rows without an output polynomial store
     int groups;         // row groups per XCD (see k_mid)
     int stagger, stagger_mod;  // start delay of workgroup w: ((w >> 3) % stagger_mod) * stagger * s_sleep(127)
+    // k_mid128<.., PERM = true>: the product is written to spectrum position q_out = perm_mul * q_in + perm_add (mod m), so that
+    // the inverse transform of the result is phi(big) for X -> X^p with p = 1 mod 4:  DFT(phi(a))[q] = DFT(a)[p q + (p-1)/4],
+    // perm_mul = p^-1, perm_add = -p^-1 (p-1)/4.  Rows map to rows (q1_out depends on q1 only), q2 moves inside the row.
+    unsigned perm_mul, perm_add;
+    int log_m1;
 };
 
 // LDS traffic between the 16 lanes that own one row needs no workgroup barrier: the lanes are in one wave,
@@ -271,7 +276,7 @@ k_mid(MidArgs g) {
 // NP = polynomial slots per ciphertext: 16; 8 for shapes with <= 8 polynomials in and out such as rank 1 with 4 limbs (twice the
 // ciphertexts per tile and per key fetch); 32 for rank 2-3 or 16 limbs (two ciphertexts per tile).  The 4 thread groups of the product phase split into GC column groups x GT
 // ciphertext groups so that a thread always owns 16 accumulators (4 ciphertexts x 4 outputs, or 2 x 8).
-template <int CT, int NP = 16>
+template <int CT, int NP = 16, bool PERM = false>
 __global__ void __launch_bounds__(CT * NP * 8)
 k_mid128(MidArgs g) {
     constexpr int M2 = 128;
@@ -308,6 +313,7 @@ k_mid128(MidArgs g) {
 
     cplx x[16];
     auto tile_q1 = [&](int L) { const int k = L / g.n_ct; return xcd_map ? k * 8 + xcd : k; };
+    auto out_q1 = [&](int q1_) { return PERM ? (int)((g.perm_mul * (unsigned)q1_ + g.perm_add) & (unsigned)(g.m1 - 1)) : q1_; };
     auto src_ptr = [&](int L) {
         const int Lc = min(L, ntiles - 1);
         const int b_ = min((Lc % g.n_ct) * CT + ctl, g.batch - 1);
@@ -347,7 +353,7 @@ k_mid128(MidArgs g) {
         const cplx* src = src_ptr(w);
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) x[n1] = src[8 * n1];
-        twn = g.tw12t[(long long)tile_q1(w) * M2 + (tid & (M2 - 1))];
+        twn = g.tw12t[(long long)out_q1(tile_q1(w)) * M2 + (tid & (M2 - 1))];
     }
     if (tid < M2) twrow[tid] = twn;
     const int vq2 = tid & (M2 - 1), vcg = (tid / M2) % GC, vtg = (tid / M2) / GC;
@@ -418,7 +424,8 @@ k_mid128(MidArgs g) {
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
                     const int c = cg * NC + j;
-                    lds[((vtg * CTt + i) * NP + c) * RS + q2] = (c < g.ncomp) ? acc[i][j] : make_double2(0.0, 0.0);
+                    const int q2o = PERM ? (int)((((g.perm_mul * (unsigned)q1 + g.perm_add) >> g.log_m1) + g.perm_mul * (unsigned)q2) & (unsigned)(M2 - 1)) : q2;
+                    lds[((vtg * CTt + i) * NP + c) * RS + q2o] = (c < g.ncomp) ? acc[i][j] : make_double2(0.0, 0.0);
                 }
             lds_barrier();
         }
@@ -426,7 +433,7 @@ k_mid128(MidArgs g) {
             const cplx* src = src_ptr(L + W);
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) x[n1] = src[8 * n1];
-            twn = g.tw12t[(long long)tile_q1(min(L + W, ntiles - 1)) * M2 + (tid & (M2 - 1))];
+            twn = g.tw12t[(long long)out_q1(tile_q1(min(L + W, ntiles - 1))) * M2 + (tid & (M2 - 1))];
         }
         // inverse row DFT: this lane owns k1 = o and o+8: radix 8 over k2 -> z[k1][oo] x conj W128^(oo*k1);
         // then lane o gathers z[k1][o] over k1: radix 16 -> row[o + 8*n1]
@@ -453,7 +460,7 @@ k_mid128(MidArgs g) {
             for (int k1 = 0; k1 < 16; ++k1) u[k1] = rowbuf[k1 * 9 + o];
             Bfly<16, true>::run(u);
             const bool active = b < g.batch && rr < g.npo;
-            cplx* dst = active ? g.T2 + ((long long)b * g.npo + rr) * m + (long long)q1 * M2 + o
+            cplx* dst = active ? g.T2 + ((long long)b * g.npo + rr) * m + (long long)out_q1(q1) * M2 + o
                                : g.dummy + (long long)tid * 16 * 16 + o;
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) dst[8 * n1] = cmulc(u[n1], twrow[o + 8 * n1]);

@@ -1568,3 +1568,17 @@ def test_seeded_extended_rotation_sweep(mods):
             print(dict(case=case, n=n, rank=rank, ext=ext, blk=blk, n_lwe=n_lwe, dnum=dnum, bsz=bsz, rsz=rsz, batch=batch, fuse=fuse), flush=True)
         test_blind_rotation_extended(mods, n, rank, ext, max(n_lwe, 2), blk, dnum, bsz, rsz, batch, fuse)
 
+
+@pytest.mark.parametrize("in_place", [False, True], ids=["out-of-place", "in-place"])
+@pytest.mark.parametrize("mode", ["add", "sub", "sub_negate"])
+@pytest.mark.parametrize("n,rank,p", [(4096, 1, 5), (4096, 2, 13), (8192, 1, 5 ** 7), (4096, 1, 2 * 4096 - 3), (65536, 1, 5 ** 9)])
+def test_glwe_automorphism_spectral_path(mods, n, rank, p, mode, in_place):
+    """glwe_automorphism_add / _sub / _sub_negate with Galois elements = 1 mod 4 on the fused pipeline: the permutation is folded
+    into the middle kernel's spectrum position (k_mid128<.., PERM>) and the tail writes the final result.  Every mode, ranks 1-2,
+    small and large elements, the in-place (`_assign`) forms; and the generic scheme (POULPY-level: fusion off) must agree."""
+    limbs = 3 if n < 65536 else 8
+    got, want = _run_glwe_op(hip=mods(n)[1], ref=mods(n)[0], ks=True, n=n, rank=rank, rank_out=rank, a_size=limbs, a_base2k=12, key_size=limbs,
+                             key_base2k=12, dnum=limbs, dsize=1, res_size=limbs, res_base2k=12, batch=3, seed=4200 + rank, auto=(p % (2 * n), mode),
+                             in_place=in_place)
+    assert np.array_equal(got, want)
+
