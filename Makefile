@@ -5,8 +5,17 @@ LIB   := poulpy_amd/libpoulpy_hip.so
 
 all: $(LIB) oracle
 
-$(LIB): $(wildcard $(CSRC)/*.hip $(CSRC)/*.hpp) include/poulpy_hip.h
-	cd $(CSRC) && $(HIPCC) -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -o ../libpoulpy_hip.so api.hip
+UNITS := $(wildcard $(CSRC)/*.hip)
+OBJS  := $(patsubst $(CSRC)/%.hip,$(CSRC)/_obj/%.o,$(UNITS))
+RCCL  := $(if $(wildcard /opt/rocm/include/rccl/rccl.h),-L/opt/rocm/lib -lrccl,)
+
+# one object per translation unit (make -j8 compiles them in parallel; launch_br.hip is the long pole, ~75 s)
+$(CSRC)/_obj/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.hpp) include/poulpy_hip.h
+	@mkdir -p $(CSRC)/_obj
+	cd $(CSRC) && $(HIPCC) -O3 -std=c++17 --offload-arch=gfx950 -fPIC -c $(notdir $<) -o _obj/$(notdir $@)
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $(OBJS) $(RCCL)
 
 oracle:
 	$(MAKE) -s -C oracle
@@ -32,6 +41,7 @@ bench:
 
 clean:
 	rm -f $(LIB) tests/cpp/test_abi
+	rm -rf $(CSRC)/_obj
 	rm -rf oracle/_build
 
 .PHONY: all oracle cpp-test kres test-cpu test-gpu bench clean

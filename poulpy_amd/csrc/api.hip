@@ -1,5 +1,5 @@
 // api.hip — the C ABI of libpoulpy_hip.so (include/poulpy_hip.h) on top of the
-// gfx950 kernels in device_fft.hpp / device_ops.hpp.
+// gfx950 kernels (launch_*.hip; interfaces in internal.hpp).
 //
 // Structure: every public entry point (a) validates shapes the way the reference
 // asserts them, (b) resolves each pointer to a device pointer (staging host
@@ -11,296 +11,9 @@
 #include <algorithm>
 #include <vector>
 
-#include "device_fft.hpp"
-#include "device_mid.hpp"
-#include "device_br.hpp"
-#include "device_ops.hpp"
-#include "module.hpp"
+#include "internal.hpp"
 
 using namespace pz;
-
-#ifndef PZ_VMP_RB
-#define PZ_VMP_RB 2
-#endif
-
-// ------------------------------------------------------------------------------
-// kernel dispatch
-// ------------------------------------------------------------------------------
-#define PZ_P1_CASES(X) X(4, 1, 4) X(8, 1, 4) X(8, 1, 16) X(16, 1, 16) X(8, 4, 16) X(8, 8, 16) X(16, 8, 16) X(16, 16, 16)
-#define PZ_P1F_CASES(X) X(4, 1, 4) X(8, 1, 4) X(8, 1, 16) X(16, 1, 16) X(4, 4, 16) X(4, 8, 16) X(8, 8, 16) X(8, 16, 16) X(16, 16, 16) X(8, 16, 8)
-#define PZ_P2_CASES(X) X(4, 1, 4) X(8, 1, 4) X(16, 1, 4) X(16, 1, 16) X(8, 4, 16) X(8, 8, 16) X(16, 8, 16) X(16, 16, 16)
-
-template <typename K>
-static int set_lds(K kernel, size_t bytes) {
-    if (bytes > 48 * 1024)
-        PZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return PZ_OK;
-}
-
-static int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* T, bool rowmajor = false) {
-    const FftPlan& pl = M->plan;
-    const int blocks = npolys * (pl.m2 / pl.cb);
-    if (blocks == 0) return PZ_OK;
-    KTimer kt(M, PZ_K_FWD_PASS1);
-#define X(A, B, C)                                                                                              \
-    if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
-        const size_t lds = ((size_t)(A + 1) * C * B + 2 * A * B) * sizeof(cplx);                                              \
-        if (rowmajor) {                                                                                         \
-            PZ_TRY(set_lds(k_fwd_pass1<A, B, C, true>, lds));                                                   \
-            hipLaunchKernelGGL((k_fwd_pass1<A, B, C, true>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, src, smap, \
-                               T, pl.m2, M->tw1, M->wL1, M->tw12t);                                             \
-        } else {                                                                                                \
-            PZ_TRY(set_lds(k_fwd_pass1<A, B, C>, lds));                                                         \
-            hipLaunchKernelGGL((k_fwd_pass1<A, B, C>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, src, smap, T, \
-                               pl.m2, M->tw1, M->wL1, M->tw12);                                                 \
-        }                                                                                                       \
-        PZ_HIP(hipGetLastError());                                                                              \
-        return PZ_OK;                                                                                           \
-    }
-    PZ_P1F_CASES(X)
-#undef X
-    return fail(PZ_ERR_UNSUPPORTED, "no forward pass-1 kernel for m1=%d", pl.m1);
-}
-
-static int launch_fwd_pass2(pz_module* M, int npolys, const cplx* T, double* dst, PolyMap dmap, const cplx* mul) {
-    const FftPlan& pl = M->plan;
-    const int blocks = npolys * (pl.m1 / pl.qb);
-    if (blocks == 0) return PZ_OK;
-    KTimer kt(M, PZ_K_FWD_PASS2);
-#define X(A, B, C)                                                                                              \
-    if (pl.r2a == A && pl.r2b == B && pl.qb == C) {                                                             \
-        const size_t lds = (size_t)A * B * C * sizeof(cplx);                                                    \
-        PZ_TRY(set_lds(k_fwd_pass2<A, B, C>, lds));                                                             \
-        hipLaunchKernelGGL((k_fwd_pass2<A, B, C>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, T, dst, dmap, \
-                           pl.m1, M->wL2, mul);                                                                 \
-        PZ_HIP(hipGetLastError());                                                                              \
-        return PZ_OK;                                                                                           \
-    }
-    PZ_P2_CASES(X)
-#undef X
-    return fail(PZ_ERR_UNSUPPORTED, "no forward pass-2 kernel for m2=%d", pl.m2);
-}
-
-static int launch_inv_pass2(pz_module* M, int npolys, const double* src, PolyMap smap, cplx* T) {
-    const FftPlan& pl = M->plan;
-    const int blocks = npolys * (pl.m1 / pl.qb);
-    if (blocks == 0) return PZ_OK;
-    KTimer kt(M, PZ_K_INV_PASS2);
-#define X(A, B, C)                                                                                              \
-    if (pl.r2a == A && pl.r2b == B && pl.qb == C) {                                                             \
-        const size_t lds = (size_t)A * B * C * sizeof(cplx);                                                    \
-        PZ_TRY(set_lds(k_inv_pass2<A, B, C>, lds));                                                             \
-        hipLaunchKernelGGL((k_inv_pass2<A, B, C>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, src, smap, T, \
-                           pl.m1, M->wL2, M->tw12);                                                             \
-        PZ_HIP(hipGetLastError());                                                                              \
-        return PZ_OK;                                                                                           \
-    }
-    PZ_P2_CASES(X)
-#undef X
-    return fail(PZ_ERR_UNSUPPORTED, "no inverse pass-2 kernel for m2=%d", pl.m2);
-}
-
-static int launch_inv_pass1(pz_module* M, int npolys, const cplx* T, long long* dst, PolyMap dmap) {
-    const FftPlan& pl = M->plan;
-    const int blocks = npolys * (pl.m2 / pl.cb);
-    if (blocks == 0) return PZ_OK;
-    KTimer kt(M, PZ_K_INV_PASS1);
-#define X(A, B, C)                                                                                              \
-    if (pl.r1a == A && pl.r1b == B && pl.cb == C) {                                                             \
-        const size_t lds = (size_t)(A + 1) * C * B * sizeof(cplx);                                              \
-        if (M->probe) {                                                                                         \
-            PZ_TRY(set_lds(k_inv_pass1<A, B, C, true>, lds));                                                   \
-            hipLaunchKernelGGL((k_inv_pass1<A, B, C, true>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, T, \
-                               dst, dmap, pl.m2, M->tw1inv, M->wL1, M->margin);                                 \
-        } else {                                                                                                \
-            PZ_TRY(set_lds(k_inv_pass1<A, B, C, false>, lds));                                                  \
-            hipLaunchKernelGGL((k_inv_pass1<A, B, C, false>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, T, \
-                               dst, dmap, pl.m2, M->tw1inv, M->wL1, M->margin);                                 \
-        }                                                                                                       \
-        PZ_HIP(hipGetLastError());                                                                              \
-        return PZ_OK;                                                                                           \
-    }
-    PZ_P1_CASES(X)
-#undef X
-    return fail(PZ_ERR_UNSUPPORTED, "no inverse pass-1 kernel for m1=%d", pl.m1);
-}
-
-// the two roles of k_inv_tail must be whole waves
-static bool tail_supported(const pz_module* M) { return (M->plan.f1b * M->plan.cb) % 64 == 0; }
-
-static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
-                                int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
-                                int base2k, bool rowmajor, bool small_all, unsigned auto_mul, bool auto_neg, int col_base, int col_count,
-                                unsigned gather_mul = 0, bool gather_neg = false, int body_col = 0, const long long* body_src = nullptr,
-                                long long body_bs = 0, long long body_ls = 0, bool small_neg = false) {
-    const FftPlan& pl = M->plan;
-    const int blocks = batch * col_count * (pl.m2 / pl.cb);
-    if (blocks == 0) return PZ_OK;
-    KTimer kt(M, PZ_K_FUSED_TAIL);
-    TailArgs g;
-    g.T = T; g.res = res; g.small = small; g.res_bs = res_bs; g.small_bs = small_bs;
-    g.nlimbs = nlimbs; g.ncols = ncols; g.res_cols = res_cols; g.res_size = res_size;
-    g.small_cols = small_cols; g.small_size = small_size; g.base2k = base2k; g.m2 = pl.m2;
-    g.tw1inv = M->tw1inv; g.wL1 = M->wL1; g.margin = M->margin;
-    g.small_all = small_all ? 1 : 0; g.auto_mul = auto_mul; g.auto_neg = auto_neg ? 1 : 0;
-    g.col_base = col_base; g.col_count = col_count; g.body_col = body_col;
-    g.gather_mul = gather_mul; g.gather_neg = gather_neg ? 1 : 0;
-    g.pre_body = body_src != nullptr ? 1 : 0; g.small_neg = small_neg ? 1 : 0; g.body_src = body_src; g.body_bs = body_bs; g.body_ls = body_ls;
-    g.xcd_map = (gather_mul != 0 && blocks % (8 * (pl.m2 / pl.cb)) == 0) ? 1 : 0;
-    const bool has_small = small != nullptr;
-// one instantiation per (probe, row-major, body add) combination actually requested
-#define PZ_TAIL_ONE(A, B, C, P_, R_, S_)                                                                        \
-    if (M->probe == P_ && rowmajor == R_ && has_small == S_) {                                                  \
-        PZ_TRY(set_lds(k_inv_tail<A, B, C, P_, R_, S_>, lds));                                                  \
-        hipLaunchKernelGGL((k_inv_tail<A, B, C, P_, R_, S_>), dim3(blocks), dim3(TailShape<A, B, C>::NT), lds, M->stream, g); \
-    }
-#define PZ_TAIL_LAUNCH(A, B, C)                                                                                 \
-    PZ_TAIL_ONE(A, B, C, false, false, false) PZ_TAIL_ONE(A, B, C, false, false, true)                          \
-    PZ_TAIL_ONE(A, B, C, false, true, false) PZ_TAIL_ONE(A, B, C, false, true, true)                            \
-    PZ_TAIL_ONE(A, B, C, true, false, false) PZ_TAIL_ONE(A, B, C, true, false, true)                            \
-    PZ_TAIL_ONE(A, B, C, true, true, false) PZ_TAIL_ONE(A, B, C, true, true, true)
-#define X(A, B, C)                                                                                              \
-    if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
-        const size_t lds = ((size_t)2 * (A + 1) * C * B + 2 * A * B) * sizeof(cplx);                  \
-        PZ_TAIL_LAUNCH(A, B, C)                                                                                 \
-        PZ_HIP(hipGetLastError());                                                                              \
-        return PZ_OK;                                                                                           \
-    }
-    PZ_P1F_CASES(X)
-#undef X
-    return fail(PZ_ERR_UNSUPPORTED, "no fused tail kernel for m1=%d", pl.m1);
-}
-// The body operand of a key switch only exists for one column (0; `body_col` for ggsw_expand_row): that column runs the
-// variant that prefetches it (more registers, one workgroup less per CU), the other columns the plain one.
-static int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
-                           int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
-                           int base2k, bool rowmajor = false, bool small_all = false, unsigned auto_mul = 0, bool auto_neg = false,
-                           unsigned gather_mul = 0, bool gather_neg = false, int body_col = 0, const long long* body_src = nullptr,
-                           long long body_bs = 0, long long body_ls = 0, bool small_neg = false) {
-    if (small != nullptr && !small_all && ncols > 1) {
-        PZ_TRY(launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, small, small_bs, small_cols, small_size,
-                                    base2k, rowmajor, false, auto_mul, auto_neg, body_col, 1, 0, false, body_col));
-        if (body_col > 0)
-            PZ_TRY(launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, nullptr, 0, small_cols, small_size,
-                                        base2k, rowmajor, false, 0, false, 0, body_col));
-        return launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, nullptr, 0, small_cols, small_size,
-                                    base2k, rowmajor, false, 0, false, body_col + 1, ncols - 1 - body_col);
-    }
-    return launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, small, small_bs, small_cols, small_size, base2k,
-                                rowmajor, small_all, auto_mul, auto_neg, 0, ncols, gather_mul, gather_neg, body_col, body_src, body_bs, body_ls,
-                                small_neg);
-}
-
-static bool mid_supported(const pz_module* M, int npi, int npo) {
-    const int np_max = M->plan.m2 == 128 ? 32 : 16;  // 128-point rows: up to 32 polynomial slots (two ciphertexts per tile)
-    return (M->plan.m2 == 256 || M->plan.m2 == 128) && (M->plan.m1 % 16) == 0 && npi >= 1 && npi <= np_max && npo >= 1 && npo <= np_max;
-}
-static int launch_permute_pmat(pz_module* M, const double* P, cplx* Pp, int npolys) {
-    const FftPlan& pl = M->plan;
-    const int blocks = npolys * (pl.m1 / 16) * (pl.m2 / 16);
-    KTimer kt(M, PZ_K_ELEMENTWISE);
-    hipLaunchKernelGGL(k_permute_pmat, dim3(blocks), dim3(256), 0, M->stream, reinterpret_cast<const cplx*>(P), Pp, npolys, pl.m1, pl.m2);
-    PZ_HIP(hipGetLastError());
-    return PZ_OK;
-}
-static constexpr size_t kMidDummyBytes = (size_t)512 * 256 * sizeof(cplx) + (1 << 20);  // scratch rows behind T2 (+ diagnostic stamps)
-template <int CT>
-static int launch_mid_ct(pz_module* M, MidArgs g, int batch) {
-    g.n_ct = (batch + CT - 1) / CT;
-    const size_t lds = ((size_t)CT * 16 * 17 * 16 + 512) * sizeof(cplx);
-    KTimer kt(M, PZ_K_FUSED_MID);
-    PZ_TRY(set_lds(k_mid<CT>, lds));
-    // persistent: as many workgroups as fit (LDS-bound: 144 KiB -> 1 per CU at CT = 2, 76 KiB -> 2 per CU at CT = 1)
-    int ncu = 256;
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, M->device);
-    const int per_cu = CT == 1 ? 2 : 1;
-    const int grid = std::min(ncu * per_cu, g.m1 * g.n_ct);
-    hipLaunchKernelGGL((k_mid<CT>), dim3(grid), dim3(CT * 256), lds, M->stream, g);
-    PZ_HIP(hipGetLastError());
-    return PZ_OK;
-}
-// perm_mul != 0: spectrum permutation of X -> X^p folded into the middle kernel (m2 = 128 plans only; see MidArgs)
-static int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp, int npi, int npo, int nrows, int ncols, cplx* dummy,
-                      unsigned perm_mul = 0, unsigned perm_add = 0) {
-    MidArgs g;
-    g.perm_mul = perm_mul; g.perm_add = perm_add; g.log_m1 = 0;
-    while ((1 << g.log_m1) < M->plan.m1) ++g.log_m1;
-    const bool perm = perm_mul != 0;
-    g.T = T; g.T2 = T2; g.P = Pp; g.npi = npi; g.npo = npo; g.nrows = nrows; g.ncols = ncols;
-    g.row_max = std::min(nrows, npi);
-    g.ncomp = std::min(npo, ncols);
-    g.batch = batch; g.m1 = M->plan.m1; g.n_ct = 0;
-    g.wL2 = M->wL2; g.tw12t = M->tw12t; g.dummy = dummy;
-    static const int groups = getenv("POULPY_DBG_MID_GROUPS") ? atoi(getenv("POULPY_DBG_MID_GROUPS")) : 1;
-    g.groups = groups;
-    // phase stagger: workgroup w starts (w mod 4) x ~3.4 us late so that the HBM-heavy row passes of some CUs overlap
-    // the L2-heavy product phases of others (measured: middle kernel -3 %); off for the m2 = 128 form, where it did not pay
-    static const int stg = getenv("POULPY_DBG_MID_STAGGER") ? atoi(getenv("POULPY_DBG_MID_STAGGER")) : -1;
-    static const int stm = getenv("POULPY_DBG_MID_STAGGER_MOD") ? atoi(getenv("POULPY_DBG_MID_STAGGER_MOD")) : 4;
-    g.stagger = stg >= 0 ? stg : (M->plan.m2 == 128 ? 0 : 1);
-    g.stagger_mod = std::max(1, stm);
-    if (M->plan.m2 == 128) {
-        int ncu = 256;
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, M->device);
-        KTimer kt(M, PZ_K_FUSED_MID);
-        if (npi <= 8 && npo <= 8) {
-            // <= 8 polynomials in and out (e.g. rank 1 with 4 limbs, BASELINE configs[1]): 8 ciphertexts x 8 slots per tile
-            constexpr int CT = 8;
-            g.n_ct = (batch + CT - 1) / CT;
-            const size_t lds = ((size_t)CT * 8 * 16 * 9 + 256) * sizeof(cplx);
-            if (perm) {
-                PZ_TRY(set_lds((k_mid128<CT, 8, true>), lds));
-                hipLaunchKernelGGL((k_mid128<CT, 8, true>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(512), lds, M->stream, g);
-            } else {
-                PZ_TRY(set_lds((k_mid128<CT, 8>), lds));
-                hipLaunchKernelGGL((k_mid128<CT, 8>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(512), lds, M->stream, g);
-            }
-        } else if (npi > 16 || npo > 16) {
-            // 17..32 polynomials in or out (rank 2-3 with 8 limbs, rank 1 with 16 limbs): 2 ciphertexts x 32 slots per tile
-            constexpr int CT = 2;
-            g.n_ct = (batch + CT - 1) / CT;
-            const size_t lds = ((size_t)CT * 32 * 16 * 9 + 256) * sizeof(cplx);
-            if (perm) {
-                PZ_TRY(set_lds((k_mid128<CT, 32, true>), lds));
-                hipLaunchKernelGGL((k_mid128<CT, 32, true>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(512), lds, M->stream, g);
-            } else {
-                PZ_TRY(set_lds((k_mid128<CT, 32>), lds));
-                hipLaunchKernelGGL((k_mid128<CT, 32>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(512), lds, M->stream, g);
-            }
-        } else {
-            constexpr int CT = 4;
-            g.n_ct = (batch + CT - 1) / CT;
-            const size_t lds = ((size_t)CT * 16 * 16 * 9 + 256) * sizeof(cplx);
-            if (perm) {
-                PZ_TRY(set_lds((k_mid128<CT, 16, true>), lds));
-                hipLaunchKernelGGL((k_mid128<CT, 16, true>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(CT * 128), lds, M->stream, g);
-            } else {
-                PZ_TRY(set_lds(k_mid128<CT>, lds));
-                hipLaunchKernelGGL((k_mid128<CT>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(CT * 128), lds, M->stream, g);
-            }
-        }
-        PZ_HIP(hipGetLastError());
-        return PZ_OK;
-    }
-    static const int ct = getenv("POULPY_DBG_MID_CT") ? atoi(getenv("POULPY_DBG_MID_CT")) : 2;  // diagnostic knob
-    if (ct == 1) return launch_mid_ct<1>(M, g, batch);
-    return launch_mid_ct<2>(M, g, batch);
-}
-
-static int launch_ew(pz_module* M, int op, void* res, long long res_bs, long long res_ls, const void* a, long long a_bs,
-                     long long a_ls, const void* b, long long b_bs, long long b_ls, int nlimbs, int batch) {
-    if (nlimbs <= 0 || batch <= 0) return PZ_OK;
-    EwArgs g;
-    g.res = res; g.a = a; g.b = b;
-    g.res_bs = res_bs; g.res_ls = res_ls; g.a_bs = a_bs; g.a_ls = a_ls; g.b_bs = b_bs; g.b_ls = b_ls;
-    g.nlimbs = nlimbs; g.n = (int)M->n; g.batch = batch; g.op = op;
-    const long long total = (long long)batch * nlimbs * (long long)(M->n / 2);
-    const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 16);
-    KTimer kt(M, PZ_K_ELEMENTWISE);
-    hipLaunchKernelGGL(k_ew, dim3(blocks), dim3(256), 0, M->stream, g);
-    PZ_HIP(hipGetLastError());
-    return PZ_OK;
-}
 
 // multiplicative inverse of an odd p modulo 2n (n a power of two): Newton iteration doubles the valid bits
 static unsigned inv_mod_2n(long long p, long long n) {
@@ -309,49 +22,6 @@ static unsigned inv_mod_2n(long long p, long long n) {
     unsigned long long x = a;  // correct to 3 bits
     for (int i = 0; i < 6; ++i) x *= 2ull - a * x;
     return (unsigned)(x & mask);
-}
-// dst = +-src(X^p-gather with multiplier mul) [+ add]; see k_automorphism
-static int launch_automorphism(pz_module* M, int npolys, const long long* src, PolyMap sm, long long* dst, PolyMap dm, unsigned mul,
-                               int flags, const long long* add = nullptr, PolyMap am = PolyMap{1, 1, 0, 0, 0, 0}) {
-    if (npolys <= 0) return PZ_OK;
-    AutoArgs g;
-    g.src = src; g.dst = dst; g.add = add; g.sm = sm; g.dm = dm; g.am = am;
-    g.npolys = npolys; g.n = (int)M->n; g.mul = mul; g.flags = flags;
-    const int bpp = M->n >= 512 ? (int)(M->n / 512) : 1;
-    const int blocks = ((npolys + 7) / 8) * 8 * bpp;
-    KTimer kt(M, PZ_K_ELEMENTWISE);
-    hipLaunchKernelGGL(k_automorphism, dim3(blocks), dim3(256), 0, M->stream, g);
-    PZ_HIP(hipGetLastError());
-    return PZ_OK;
-}
-
-static int launch_rotate(pz_module* M, int npolys, const long long* src, PolyMap sm, long long* dst, PolyMap dm, int mode,
-                         int polys_per_batch, const long long* shift, long long shift_bs, long long shift_idx, long long shift_const) {
-    if (npolys <= 0) return PZ_OK;
-    RotArgs g;
-    g.src = src; g.dst = dst; g.sm = sm; g.dm = dm; g.npolys = npolys; g.n = (int)M->n;
-    g.polys_per_batch = std::max(polys_per_batch, 1); g.mode = mode;
-    g.shift = shift; g.shift_bs = shift_bs; g.shift_idx = shift_idx; g.shift_const = shift_const;
-    const int bpp = M->n >= 512 ? (int)(M->n / 512) : 1;
-    KTimer kt(M, PZ_K_ELEMENTWISE);
-    hipLaunchKernelGGL(k_rotate, dim3(npolys * bpp), dim3(256), 0, M->stream, g);
-    PZ_HIP(hipGetLastError());
-    return PZ_OK;
-}
-static int launch_rsh(pz_module* M, int batch, long long* data, long long bs, int cols, int size, int col0, int ncols, int base2k, int k) {
-    if (batch <= 0 || ncols <= 0 || size <= 0) return PZ_OK;
-    RshArgs g;
-    g.data = data; g.bs = bs; g.cols = cols; g.size = size; g.col0 = col0; g.ncols = ncols; g.n = (int)M->n; g.batch = batch;
-    g.base2k = base2k; g.k = k;
-    KTimer kt(M, PZ_K_NORMALIZE);
-    for (int b0 = 0; b0 < batch; b0 += 65535) {   // gridDim.z limit
-        RshArgs gb = g;
-        gb.data = data + (long long)b0 * bs;
-        const int nb = std::min(65535, batch - b0);
-        hipLaunchKernelGGL(k_rsh_assign, dim3((unsigned)((M->n / 2 + 255) / 256), (unsigned)ncols, (unsigned)nb), dim3(256), 0, M->stream, gb);
-    }
-    PZ_HIP(hipGetLastError());
-    return PZ_OK;
 }
 static int ensure_w2n(pz_module* M) {
     if (M->w2n) return PZ_OK;
@@ -365,16 +35,6 @@ static int ensure_w2n(pz_module* M) {
 // ------------------------------------------------------------------------------
 // device-level operations (device pointers, batch strides in scalars)
 // ------------------------------------------------------------------------------
-struct DV {          // a batched VecZnx-like container on the device
-    void* p;
-    long long bs;    // scalars between consecutive batch objects
-    int cols, size;
-};
-static inline long long limb_stride(const pz_module* M, const DV& v) { return (long long)v.cols * (long long)M->n; }
-static inline void* poly_ptr(const pz_module* M, const DV& v, int col, int limb) {
-    return (char*)v.p + 8 * ((long long)M->n * ((long long)limb * v.cols + col));
-}
-
 // vec_znx_dft_apply on `ncs` consecutive columns (res_col.., a_col..)  [vec_znx_dft.rs:160-200]
 static int dev_dft_apply(pz_module* M, int batch, int step, int offset, DV res, int res_col, DV a, int a_col, int ncs,
                          const cplx* mul, cplx* T) {
@@ -406,70 +66,6 @@ static int dev_idft(pz_module* M, int batch, DV res, int res_col, DV a, int a_co
     const int npolys = batch * nlimbs * ncs;
     PZ_TRY(launch_inv_pass2(M, npolys, (const double*)a.p, sm, T));
     PZ_TRY(launch_inv_pass1(M, npolys, T, (long long*)res.p, dm));
-    return PZ_OK;
-}
-
-// vmp_apply_dft_to_dft  [vmp.rs:144-264, zero-tail semantics for limb_offset > 0]
-static int dev_vmp(pz_module* M, int batch, DV res, DV a, const double* pmat, int rows, int cols_in, int cols_out, int size,
-                   int limb_offset) {
-    const int nrows = rows * cols_in, ncols = cols_out * size;
-    const int a_polys = a.cols * a.size, res_polys = res.cols * res.size;
-    const int row_max = std::min(nrows, a_polys);
-    const int off = limb_offset * cols_out;
-    const int ncomp = off < ncols ? std::min(res_polys, ncols - off) : 0;
-    if (res_polys == 0) return PZ_OK;
-    if (ncomp == 0 || row_max == 0) {  // nothing to read from the key, or an empty input (a.size = 0: dsize > a.size): the sum is empty
-        return launch_ew(M, EW_ZERO, res.p, res.bs, (long long)M->n, nullptr, 0, 0, nullptr, 0, 0, res_polys, batch);
-    }
-    const int m = (int)M->m;
-    KTimer kt(M, PZ_K_VMP);
-    if (batch >= 6) {
-        const int n_pb = (m + 63) / 64, n_cg = (res_polys + 15) / 16, n_ct = (batch + 7) / 8;
-        hipLaunchKernelGGL((k_vmp_lds<8, 2, PZ_VMP_RB>), dim3(n_pb * n_cg * n_ct), dim3(512), 0, M->stream, (double*)res.p, res.bs, res_polys,
-                           (const double*)a.p, a.bs, pmat, ncols, off, row_max, ncomp, m, batch, n_pb, n_cg, n_ct);
-    } else if (batch >= 4) {
-        dim3 grid((m + 63) / 64, (res_polys + 15) / 16, (batch + 3) / 4);
-        hipLaunchKernelGGL((k_vmp<4, 4>), grid, dim3(256), 0, M->stream, (double*)res.p, res.bs, res_polys, (const double*)a.p,
-                           a.bs, pmat, ncols, off, row_max, ncomp, m, batch);
-    } else {
-        dim3 grid((m + 63) / 64, (res_polys + 15) / 16, batch);
-        hipLaunchKernelGGL((k_vmp<1, 4>), grid, dim3(256), 0, M->stream, (double*)res.p, res.bs, res_polys, (const double*)a.p,
-                           a.bs, pmat, ncols, off, row_max, ncomp, m, batch);
-    }
-    PZ_HIP(hipGetLastError());
-    return PZ_OK;
-}
-
-// vec_znx_(big_)normalize on one column  [normalize.rs:18-401]
-static int dev_normalize(pz_module* M, int batch, DV res, int res_base2k, long long res_offset, int res_col, DV a, int a_base2k,
-                         int a_col) {
-    NzArgs g;
-    g.res = (long long*)res.p; g.a = (const long long*)a.p;
-    g.res_bs = res.bs; g.a_bs = a.bs;
-    g.n = (int)M->n; g.batch = batch;
-    g.res_cols = res.cols; g.res_size = res.size; g.res_col = res_col;
-    g.a_cols = a.cols; g.a_size = a.size; g.a_col = a_col;
-    g.res_base2k = res_base2k; g.a_base2k = a_base2k;
-    g.lsh = g.res_end = g.res_start = g.a_end = g.a_start = 0;
-    const long long total = (long long)batch * (long long)M->n;
-    const int blocks = (int)((total + 255) / 256);
-    if (blocks == 0) return PZ_OK;
-    KTimer kt(M, PZ_K_NORMALIZE);
-    if (res_base2k == a_base2k) {
-        const long long k = res_base2k;
-        long long lsh = res_offset % k, lo = res_offset / k;
-        if (res_offset < 0 && lsh != 0) { lsh = (lsh + k) % k; lo -= 1; }
-        auto cl = [](long long v, long long lo_, long long hi_) { return v < lo_ ? lo_ : (v > hi_ ? hi_ : v); };
-        g.lsh = (int)lsh;
-        g.res_end = (int)cl(-lo, 0, res.size);
-        g.res_start = (int)cl((long long)a.size - lo, 0, res.size);
-        g.a_end = (int)cl(lo, 0, a.size);
-        g.a_start = (int)cl((long long)res.size + lo, 0, a.size);
-        hipLaunchKernelGGL(k_normalize_inter, dim3(blocks), dim3(256), 0, M->stream, g);
-    } else {
-        hipLaunchKernelGGL(k_normalize_cross, dim3(blocks), dim3(256), 0, M->stream, g, res_offset);
-    }
-    PZ_HIP(hipGetLastError());
     return PZ_OK;
 }
 
@@ -1548,7 +1144,6 @@ static OpShape op_shape(const pz_glwe_op_params* p, bool ks) {
     s.a_size_eff = s.convert ? (int)((p->a_size * p->a_base2k + p->key_base2k - 1) / p->key_base2k) : (int)p->a_size;
     return s;
 }
-static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct OpWs {
     size_t a_conv, a_dft, res_dft, tmp_dft, T, res_tmp, total;
@@ -1633,7 +1228,10 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
         const size_t conv_bytes = s.convert ? align256(chunk * (size_t)M->n * 8 * s.cols_a * s.a_size_eff) : 0;
         const size_t t_bytes = align256(chunk * (size_t)npi * M->m * sizeof(cplx));
         const size_t t2_bytes = align256(chunk * (size_t)npo * M->m * sizeof(cplx));
-        const size_t rtmp_bytes = au ? align256(chunk * (size_t)res_ct * 8) : 0;
+        // res_tmp holds the normalized result before the final permutation (mode 0 / gather scheme) OR, in the spectral form, the
+        // body-column operand (min(a_size, key_size) limbs of one column): sized for the larger of the two
+        const size_t body_limbs = (size_t)std::min<long long>((long long)s.a_size_eff, (long long)ksz);
+        const size_t rtmp_bytes = au ? align256(chunk * (size_t)M->n * 8 * std::max((size_t)s.cols_out * p->res_size, body_limbs)) : 0;
         const size_t small2_bytes = 0;  // (the pre-gathered operand of the add / sub variants is no longer materialised)
         PZ_TRY(ws_reserve(M, key_bytes + conv_bytes + t_bytes + t2_bytes + rtmp_bytes + small2_bytes + kMidDummyBytes));
         char* base = (char*)M->ws;
@@ -1681,14 +1279,16 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
             if (M->dbg_stages & 2) PZ_TRY(launch_mid(M, nb, T, T2, Pp, npi, npo, nrows, ncols, mid_dummy, perm_mul, perm_add));
             int64_t* res_b = res + (long long)b0 * res_bs;
             if (spec) {
-                PolyMap bsm{a_size, 1, av.bs, (long long)av.cols * n, 0, 0}, bdm{a_size, 1, (long long)a_size * n, n, 0, 0};
+                // (the tail reads operand limbs j < min(key_size, a_size) only: the pre-pass covers exactly those)
+                const int bl = std::min(a_size, ksz);
+                PolyMap bsm{bl, 1, av.bs, (long long)av.cols * n, 0, 0}, bdm{bl, 1, (long long)bl * n, n, 0, 0};
                 // operand of the body column, one stream: phi(body) + a0 (add) or -phi(body) + a0 (sub forms: the tail negates every operand)
-                PZ_TRY(launch_automorphism(M, nb * a_size, (const long long*)av.p, bsm, (long long*)res_tmp, bdm, au_g, au->mode == 1 ? 1 : 3,
+                PZ_TRY(launch_automorphism(M, nb * bl, (const long long*)av.p, bsm, (long long*)res_tmp, bdm, au_g, au->mode == 1 ? 1 : 3,
                                            (const long long*)av.p, bsm));
                 PZ_TRY(launch_inv_tail(M, nb, T2, ksz, s.cols_out, (long long*)res_b, res_bs, s.cols_out, (int)p->res_size,
                                        (const long long*)av.p, av.bs, s.cols_a, a_size, (int)p->res_base2k, true, true,
                                        au->mode == 3 ? 2u * (unsigned)n : 0u, au->mode == 3, 0u, false, body_col, (const long long*)res_tmp,
-                                       (long long)a_size * n, n, au->mode != 1));
+                                       (long long)bl * n, n, au->mode != 1));
                 continue;
             }
             const long long* small = ks ? (const long long*)av.p : nullptr;
@@ -2007,77 +1607,9 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
 
     PZ_TRY(ensure_w2n(M));
     {
-        // whole rotation in one kernel, accumulators resident in LDS (device_br.hpp), when the shape fits
-        // (std_variant: execute_standard, one ciphertext per workgroup and a second accumulator-sized array)
-        const bool std_variant = blk == 1;
-        {
-            const int in_limbs = std::min(dnum, rsz), row_max = cols * in_limbs, ncols = cols * bsz, P = std::max(row_max, ncols);
-            const int m = (int)M->m, mp = m + (m >> 4);
-            constexpr int NT = 512;
-            const int r0 = m == 128 ? 2 : (m == 256 ? 4 : 8);
-            auto lds_for = [&](int ct, bool a32) {
-                return ((size_t)m + (size_t)ct * P * mp) * sizeof(cplx) + (size_t)ct * rsz * cols * (size_t)n * (a32 ? 4 : 8) * (std_variant ? 2 : 1);
-            };
-            auto fits = [&](int ct, bool a32) {
-                return lds_for(ct, a32) <= 160 * 1024 && ct * P * (m / 8) <= ((ct == 2 && r0 == 8) ? 2 : 1) * NT && ct * P * (m / r0) <= 2 * NT &&
-                       (!a32 || k <= 31);
-            };
-            static const int force_ct = getenv("POULPY_DBG_BR_CT") ? atoi(getenv("POULPY_DBG_BR_CT")) : 0;
-            const int cgsz = (ncols % 3 == 0 && ncols % 4 != 0) ? 3 : 4;  // 6 output polynomials: two groups of 3, no idle slot
-            const int pj = m * ((ncols + cgsz - 1) / cgsz) <= NT ? 1 : 2;
-            static const int br_one = getenv("POULPY_DBG_BR_ONE") ? atoi(getenv("POULPY_DBG_BR_ONE")) : 1;  // 0: composed path everywhere
-            if (br_one && M->fuse_mid && (m == 128 || m == 256 || m == 512) && NT % m == 0 && row_max <= 8 && ncols <= 8 &&
-                m * ((ncols + cgsz - 1) / cgsz) <= 2 * NT && fits(1, false)) {
-                // two ciphertexts per workgroup share every key value; with 64-bit accumulators when that fits in LDS, else
-                // with 32-bit digit accumulators (m = 128 is only built with one ciphertext per workgroup)
-                int ct = 1;
-                bool a32 = false;
-                if (force_ct != 1 && B >= 2 && m != 128 && !std_variant) {
-                    if (fits(2, false)) ct = 2;
-                    else if (fits(2, true)) { ct = 2; a32 = true; }
-                }
-                const size_t lds = lds_for(ct, a32);
-                BrFusedArgs g;
-                g.res = (long long*)res; g.lut = (const long long*)lut; g.lwe = (const long long*)lwe_2n; g.brk = (const cplx*)brk;
-                g.w2n = M->w2n; g.key_stride = (long long)(pmat_doubles / 2);
-                g.n_lwe = n_lwe; g.blk = blk; g.cols = cols; g.rsz = rsz; g.dnum = dnum; g.bsz = bsz; g.lut_size = (int)p->lut_size;
-                g.base2k = k; g.m = m; g.batch = B;
-                static const int br_skip = getenv("POULPY_DBG_BR_SKIP") ? atoi(getenv("POULPY_DBG_BR_SKIP")) : 0;
-                g.dbg_skip = br_skip;
-                KTimer kt(M, PZ_K_FUSED_MID);
-                bool launched = false;
-#define PZ_BR_STD(R0_, PJ_, MR_, CG_)                                                                                        \
-    if (!launched && std_variant && r0 == R0_ && pj == PJ_ && mr == MR_ && cgsz == CG_) {                                    \
-        PZ_TRY(set_lds((k_br_fused<R0_, 1, NT, PJ_, MR_, CG_, false, true>), lds));                                           \
-        hipLaunchKernelGGL((k_br_fused<R0_, 1, NT, PJ_, MR_, CG_, false, true>), dim3(B), dim3(NT), lds, M->stream, g);       \
-        launched = true;                                                                                                     \
-    }
-#define PZ_BR_STD_SHAPES(R0_)                                                                                                \
-    PZ_BR_STD(R0_, 1, 4, 4) PZ_BR_STD(R0_, 2, 4, 4) PZ_BR_STD(R0_, 1, 6, 3) PZ_BR_STD(R0_, 2, 6, 3)                          \
-    PZ_BR_STD(R0_, 1, 8, 4) PZ_BR_STD(R0_, 2, 8, 4) PZ_BR_STD(R0_, 1, 8, 3) PZ_BR_STD(R0_, 2, 8, 3)
-#define PZ_BR_ONE(R0_, CT_, PJ_, MR_, CG_, A32_)                                                                             \
-    if (!launched && !std_variant && r0 == R0_ && ct == CT_ && pj == PJ_ && mr == MR_ && cgsz == CG_ && a32 == A32_) {       \
-        PZ_TRY(set_lds(k_br_fused<R0_, CT_, NT, PJ_, MR_, CG_, A32_>, lds));                                                 \
-        hipLaunchKernelGGL((k_br_fused<R0_, CT_, NT, PJ_, MR_, CG_, A32_>), dim3((B + CT_ - 1) / CT_), dim3(NT), lds, M->stream, g); \
-        launched = true;                                                                                                     \
-    }
-#define PZ_BR_SHAPES(R0_, CT_, A32_)                                                                                         \
-    PZ_BR_ONE(R0_, CT_, 1, 4, 4, A32_) PZ_BR_ONE(R0_, CT_, 2, 4, 4, A32_) PZ_BR_ONE(R0_, CT_, 1, 6, 3, A32_) PZ_BR_ONE(R0_, CT_, 2, 6, 3, A32_) \
-    PZ_BR_ONE(R0_, CT_, 1, 8, 4, A32_) PZ_BR_ONE(R0_, CT_, 2, 8, 4, A32_) PZ_BR_ONE(R0_, CT_, 1, 8, 3, A32_) PZ_BR_ONE(R0_, CT_, 2, 8, 3, A32_)
-                const int mr = row_max <= 4 && cgsz == 4 ? 4 : (row_max <= 6 && cgsz == 3 ? 6 : 8);
-                PZ_BR_STD_SHAPES(2) PZ_BR_STD_SHAPES(4) PZ_BR_STD_SHAPES(8)
-                PZ_BR_SHAPES(2, 1, false)
-                PZ_BR_SHAPES(4, 1, false) PZ_BR_SHAPES(4, 2, false) PZ_BR_SHAPES(4, 2, true)
-                PZ_BR_SHAPES(8, 1, false) PZ_BR_SHAPES(8, 2, false) PZ_BR_SHAPES(8, 2, true)
-#undef PZ_BR_SHAPES
-#undef PZ_BR_ONE
-#undef PZ_BR_STD_SHAPES
-#undef PZ_BR_STD
-                if (!launched) return fail(PZ_ERR_UNSUPPORTED, "blind_rotation: no one-kernel variant for this shape");
-                PZ_HIP(hipGetLastError());
-                return PZ_OK;
-            }
-        }
+        bool launched = false;
+        PZ_TRY(br_try_fused(M, res, lwe_2n, lut, brk, p, batch, &launched));
+        if (launched) return PZ_OK;
     }
     if (blk > 1) {
         const size_t n8 = (size_t)M->n * 8;
@@ -2095,68 +1627,13 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
         for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {  // chunks_exact: a trailing partial block is ignored, as in the reference
             PZ_TRY(dev_dft_apply(M, B, 1, 0, ad, 0, rv, 0, cols, nullptr, T));                      // :319-321
             const int row_max = std::min(dnum * cols, cols * std::min(dnum, rsz));
-            if (M->fuse_mid && row_max <= 12 && blk <= 64) {
-                // zero + block_size x (vmp, svp, add, sub) in one kernel, nothing but acc_add written (:321-337)
-                BrBlockArgs g;
-                g.acc_dft = (const cplx*)acc_dft; g.acc_add = (cplx*)acc_add; g.a_bs = ad.bs / 2; g.o_bs = aa.bs / 2;
-                g.brk = (const cplx*)brk; g.key_stride = (long long)(pmat_doubles / 2);
-                g.row_max = row_max; g.ncols = cols * bsz; g.m = (int)M->m; g.batch = B; g.i0 = b0; g.blk = blk;
-                g.lwe = (const long long*)lwe_2n; g.lwe_bs = lwe_bs; g.w2n = M->w2n;
-                static const int brl_dbg = getenv("POULPY_DBG_BRL") ? atoi(getenv("POULPY_DBG_BRL")) : 0;
-                g.dbg = brl_dbg; g.gx = g.gy = g.gz = 1; g.xcd = 0; g.allcg = 0;
-                constexpr int CT = 2;
-                KTimer kt(M, PZ_K_VMP);
-                const int nc = cols * bsz;
-                const unsigned gx = (unsigned)((B + CT - 1) / CT), gy = (unsigned)((M->m + 255) / 256);
-                // (input polynomials kept in registers, output columns per workgroup): rank 2 with 3-4 decomposition rows (the
-                // circuit-bootstrapping shape) has 9 or 12 inputs, so fewer columns per workgroup there
-                int mr, cgs;
-                if (row_max > 9 || (row_max > 8 && nc % 3 != 0)) { mr = 12; cgs = 2; }
-                else if (row_max > 8) { mr = 9; cgs = 3; }
-                else if (nc % 3 == 0 && nc % 4 != 0) { mr = row_max <= 6 ? 6 : 8; cgs = 3; }   // 3, 6 columns: groups of 3
-                else { mr = row_max <= 4 ? 4 : 8; cgs = 4; }
-                const int ngroups = (nc + cgs - 1) / cgs;
-                // keys staged in LDS once per 4 waves x 2 ciphertexts (k_br_block_lds): POULPY_DBG_BR_LDS = 0 never, 1 only for
-                // more than 8 inputs, 2 always
-                static const int br_lds = getenv("POULPY_DBG_BR_LDS") ? atoi(getenv("POULPY_DBG_BR_LDS")) : 2;
-                const bool use_lds = M->m % 64 == 0 && (br_lds >= 2 || (br_lds == 1 && row_max > 8));
-                bool launched = false;
-                if (use_lds) {
-                    g.gx = (B + 7) / 8; g.gy = (int)(M->m / 64); g.gz = ngroups;
-                    static const int br_xcd = getenv("POULPY_DBG_BR_XCD") ? atoi(getenv("POULPY_DBG_BR_XCD")) : 1;
-                    g.xcd = (br_xcd && (g.gx * g.gy) % 8 == 0) ? 1 : 0;
-                    static const int br_allcg = getenv("POULPY_DBG_BR_ALLCG") ? atoi(getenv("POULPY_DBG_BR_ALLCG")) : 1;
-                    g.allcg = br_allcg ? 1 : 0;
-                    const unsigned total = (unsigned)(g.gx * g.gy * (g.allcg ? 1 : g.gz));
-#define PZ_BRB(MR_, CG_)                                                                                           \
-    if (!launched && mr == MR_ && cgs == CG_) {                                                                    \
-        hipLaunchKernelGGL((k_br_block_lds<2, MR_, CG_>), dim3(total), dim3(256), 0, M->stream, g);                \
-        launched = true;                                                                                           \
-    }
-                    PZ_BRB(12, 2) PZ_BRB(9, 3) PZ_BRB(6, 3) PZ_BRB(8, 3) PZ_BRB(4, 4) PZ_BRB(8, 4)
-#undef PZ_BRB
-                } else {
-#define PZ_BRB(MR_, CG_)                                                                                           \
-    if (!launched && mr == MR_ && cgs == CG_) {                                                                    \
-        hipLaunchKernelGGL((k_br_block<CT, MR_, CG_>), dim3(gx, gy, (unsigned)ngroups), dim3(256), 0, M->stream, g); \
-        launched = true;                                                                                           \
-    }
-                    PZ_BRB(12, 2) PZ_BRB(9, 3) PZ_BRB(6, 3) PZ_BRB(8, 3) PZ_BRB(4, 4) PZ_BRB(8, 4)
-#undef PZ_BRB
-                }
-                PZ_HIP(hipGetLastError());
-            } else {
+            bool block_done = false;
+            if (M->fuse_mid) PZ_TRY(br_block_step(M, acc_dft, ad.bs, acc_add, aa.bs, brk, pmat_doubles, row_max, cols * bsz, B, b0, blk, lwe_2n, lwe_bs, &block_done));
+            if (!block_done) {
             PZ_HIP(hipMemsetAsync(acc_add, 0, (size_t)B * aa.bs * 8, M->stream));                     // :321
             for (int i = b0; i < b0 + blk; ++i) {                                                       // :324-337
                 PZ_TRY(dev_vmp(M, B, vr, ad, brk + (size_t)i * pmat_doubles, dnum, cols, cols, bsz, 0));
-                XaiArgs g;
-                g.acc = (cplx*)acc_add; g.v = (const cplx*)vmp_res; g.acc_bs = aa.bs / 2; g.v_bs = vr.bs / 2;
-                g.polys = cols * bsz; g.m = (int)M->m; g.batch = B;
-                g.lwe = (const long long*)lwe_2n; g.lwe_bs = lwe_bs; g.idx = i; g.w2n = M->w2n;
-                const long long total = (long long)B * g.polys * g.m;
-                KTimer kt(M, PZ_K_ELEMENTWISE);
-                hipLaunchKernelGGL(k_xai_acc, dim3((unsigned)std::min<long long>((total + 255) / 256, 256 * 16)), dim3(256), 0, M->stream, g);
-                PZ_HIP(hipGetLastError());
+                PZ_TRY(launch_xai_acc(M, acc_add, aa.bs, vmp_res, vr.bs, cols * bsz, B, lwe_2n, lwe_bs, i));
             }
             }
             // acc = normalize(idft(acc_add) + acc)  (:342-346)
@@ -2236,16 +1713,8 @@ static int blind_rotation_extended(pz_module* M, int64_t* res, const int64_t* lw
     cplx* T = (cplx*)base;
     // :159-161 zero, :180-190 rotated table
     PZ_HIP(hipMemsetAsync(acc, 0, (size_t)BE * res_ct * 8, M->stream));
-    {
-        BrExtInitArgs g;
-        g.acc = (long long*)acc; g.lut = (const long long*)lut; g.lwe = (const long long*)lwe_2n; g.lwe_bs = lwe_bs;
-        g.n = (int)M->n; g.log_ext = log_ext; g.cols = cols; g.rsz = rsz; g.lut_size = (int)p->lut_size;
-        g.nl = std::min(rsz, (int)p->lut_size); g.batch = B;
-        KTimer kt(M, PZ_K_ELEMENTWISE);
-        PZ_REQUIRE(BE <= 65535, "blind_rotation: batch * extension_factor exceeds 65535 (split the batch)");
-        hipLaunchKernelGGL(k_br_ext_init, dim3((unsigned)((M->n / 2 + 255) / 256), (unsigned)g.nl, (unsigned)BE), dim3(256), 0, M->stream, g);
-        PZ_HIP(hipGetLastError());
-    }
+    PZ_REQUIRE(BE <= 65535, "blind_rotation: batch * extension_factor exceeds 65535 (split the batch)");
+    PZ_TRY(launch_br_ext_init(M, acc, lut, lwe_2n, lwe_bs, log_ext, cols, rsz, (int)p->lut_size, B));
     DV rv{acc, res_ct, cols, rsz};
     DV ad{acc_dft, n * cols * dnum, cols, dnum}, vr{vmp_res, n * cols * bsz, cols, bsz}, aa{acc_add, n * cols * bsz, cols, bsz};
     const bool tail = M->fuse_tail && tail_supported(M);
@@ -2254,13 +1723,7 @@ static int blind_rotation_extended(pz_module* M, int64_t* res, const int64_t* lw
         PZ_HIP(hipMemsetAsync(acc_add, 0, (size_t)BE * aa.bs * 8, M->stream));
         for (int i = b0; i < b0 + blk; ++i) {
             PZ_TRY(dev_vmp(M, BE, vr, ad, brk + (size_t)i * pmat_doubles, dnum, cols, cols, bsz, 0));   // :209-211
-            XaiExtArgs g;
-            g.acc = (cplx*)acc_add; g.v = (const cplx*)vmp_res; g.polys = cols * bsz; g.m = (int)M->m; g.log_ext = log_ext; g.batch = B;
-            g.lwe = (const long long*)lwe_2n; g.lwe_bs = lwe_bs; g.idx = i; g.w2n = M->w2n;
-            const long long total = (long long)BE * g.polys * g.m;
-            KTimer kt(M, PZ_K_ELEMENTWISE);
-            hipLaunchKernelGGL(k_xai_ext, dim3((unsigned)std::min<long long>((total + 255) / 256, 256 * 16)), dim3(256), 0, M->stream, g);
-            PZ_HIP(hipGetLastError());
+            PZ_TRY(launch_xai_ext(M, acc_add, vmp_res, cols * bsz, log_ext, B, lwe_2n, lwe_bs, i));
         }
         if (tail) {                                                                                    // :260-266
             PolyMap sm{bsz, cols, aa.bs, (long long)cols * n, n, 0};
@@ -2540,3 +2003,4 @@ int pz_glwe_pack_batched(pz_module* M, int64_t* res, size_t nslots, const uint64
 }
 
 }  // extern "C"
+

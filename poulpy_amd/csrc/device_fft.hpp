@@ -83,6 +83,19 @@ struct Bfly<1, INV> {
     static __device__ __forceinline__ void run(cplx*) {}
 };
 
+// limb-wise elementwise ops of k_ew (device_ops.hpp); shared with the host-side composition code
+enum EwOp : int {
+    EW_ZERO = 0,
+    EW_COPY = 1,     // res = a
+    EW_NEG = 2,      // res = -a
+    EW_ADD = 3,      // res = a + b
+    EW_SUB = 4,      // res = a - b
+    EW_CMUL = 5,     // res = a * b  (complex pointwise, interleaved; `a` is the prepared poly)
+    EW_ADD_I64 = 6,  // res = a + b  (wrapping i64)
+    EW_SUB_I64 = 7,  // res = a - b  (wrapping i64)
+    EW_NEG_I64 = 8,  // res = -a
+};
+
 // ---- addressing of the polynomials a launch works on --------------------------
 // polynomial p = (b*nj + j)*ni + i lives at element offset b*sb + j*sj + i*si + s0
 struct PolyMap {

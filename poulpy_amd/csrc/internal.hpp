@@ -1,0 +1,89 @@
+// internal.hpp — interfaces between the translation units of libpoulpy_hip.so.
+//
+//   launch_fft.hip   the four passes of the two-pass negacyclic FFT (device_fft.hpp)
+//   launch_tail.hip  fused inverse column pass + carry chain (k_inv_tail)
+//   launch_mid.hip   fused row pass + VMP + inverse row pass (device_mid.hpp), key re-slicing
+//   launch_small.hip whole-polynomial-in-LDS pipeline for N <= 2^13 (device_small.hpp)
+//   launch_ops.hip   elementwise / permutation / normalize / VMP kernels (device_ops.hpp)
+//   launch_br.hip    blind-rotation kernels (device_br.hpp + the block step of device_ops.hpp)
+//   launch_cnv.hip   bivariate convolution kernels (device_cnv.hpp)
+//   api*.hip         the C ABI: validation, host/device staging, composition of the launches
+//
+// Every kernel is instantiated in exactly one translation unit (the one that launches it), so the units compile
+// independently and in parallel; only plain functions cross unit boundaries.
+#pragma once
+#include "module.hpp"
+
+namespace pz {
+
+// ---- shared small helpers -----------------------------------------------------------------------------------------
+template <typename K>
+inline int set_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024)
+        PZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return PZ_OK;
+}
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct DV {          // a batched VecZnx-like container on the device
+    void* p;
+    long long bs;    // scalars between consecutive batch objects
+    int cols, size;
+};
+inline long long limb_stride(const pz_module* M, const DV& v) { return (long long)v.cols * (long long)M->n; }
+inline void* poly_ptr(const pz_module* M, const DV& v, int col, int limb) {
+    return (char*)v.p + 8 * ((long long)M->n * ((long long)limb * v.cols + col));
+}
+
+// ---- launch_fft.hip -----------------------------------------------------------------------------------------------
+int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* T, bool rowmajor = false);
+int launch_fwd_pass2(pz_module* M, int npolys, const cplx* T, double* dst, PolyMap dmap, const cplx* mul);
+int launch_inv_pass2(pz_module* M, int npolys, const double* src, PolyMap smap, cplx* T);
+int launch_inv_pass1(pz_module* M, int npolys, const cplx* T, long long* dst, PolyMap dmap);
+
+// ---- launch_tail.hip ----------------------------------------------------------------------------------------------
+bool tail_supported(const pz_module* M);
+int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
+                    int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
+                    int base2k, bool rowmajor = false, bool small_all = false, unsigned auto_mul = 0, bool auto_neg = false,
+                    unsigned gather_mul = 0, bool gather_neg = false, int body_col = 0, const long long* body_src = nullptr,
+                    long long body_bs = 0, long long body_ls = 0, bool small_neg = false);
+
+// ---- launch_mid.hip -----------------------------------------------------------------------------------------------
+constexpr size_t kMidDummyBytes = (size_t)512 * 256 * sizeof(cplx) + (1 << 20);  // scratch rows behind T2 (+ diagnostic stamps)
+bool mid_supported(const pz_module* M, int npi, int npo);
+int launch_permute_pmat(pz_module* M, const double* P, cplx* Pp, int npolys);
+// perm_mul != 0: spectrum permutation of X -> X^p folded into the middle kernel (m2 = 128 plans only; see MidArgs)
+int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp, int npi, int npo, int nrows, int ncols, cplx* dummy,
+               unsigned perm_mul = 0, unsigned perm_add = 0);
+
+// ---- launch_ops.hip -----------------------------------------------------------------------------------------------
+int launch_ew(pz_module* M, int op, void* res, long long res_bs, long long res_ls, const void* a, long long a_bs,
+              long long a_ls, const void* b, long long b_bs, long long b_ls, int nlimbs, int batch);
+// dst = +-src(X^p-gather with multiplier mul) [+ add]; see k_automorphism
+int launch_automorphism(pz_module* M, int npolys, const long long* src, PolyMap sm, long long* dst, PolyMap dm, unsigned mul,
+                        int flags, const long long* add = nullptr, PolyMap am = PolyMap{1, 1, 0, 0, 0, 0});
+int launch_rotate(pz_module* M, int npolys, const long long* src, PolyMap sm, long long* dst, PolyMap dm, int mode,
+                  int polys_per_batch, const long long* shift, long long shift_bs, long long shift_idx, long long shift_const);
+int launch_rsh(pz_module* M, int batch, long long* data, long long bs, int cols, int size, int col0, int ncols, int base2k, int k);
+// vmp_apply_dft_to_dft  [vmp.rs:144-264, zero-tail semantics for limb_offset > 0]
+int dev_vmp(pz_module* M, int batch, DV res, DV a, const double* pmat, int rows, int cols_in, int cols_out, int size, int limb_offset);
+// vec_znx_(big_)normalize on one column  [normalize.rs:18-401]
+int dev_normalize(pz_module* M, int batch, DV res, int res_base2k, long long res_offset, int res_col, DV a, int a_base2k, int a_col);
+
+// ---- launch_br.hip ------------------------------------------------------------------------------------------------
+// whole rotation in one kernel (device_br.hpp) when the shape fits: *launched says whether it did
+int br_try_fused(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
+                 const pz_blind_rotation_params* p, size_t batch, bool* launched);
+// zero + block_size x (vmp, svp, add, sub) of one LWE block in one kernel; *launched = false: shape not covered
+int br_block_step(pz_module* M, const double* acc_dft, long long a_bs, double* acc_add, long long o_bs, const double* brk,
+                  size_t pmat_doubles, int row_max, int ncols, int B, int i0, int blk, const int64_t* lwe_2n, long long lwe_bs,
+                  bool* launched);
+int launch_xai_acc(pz_module* M, double* acc_add, long long acc_bs, const double* v, long long v_bs, int polys, int B,
+                   const int64_t* lwe_2n, long long lwe_bs, int idx);
+int launch_xai_ext(pz_module* M, double* acc_add, const double* v, int polys, int log_ext, int B, const int64_t* lwe_2n, long long lwe_bs,
+                   int idx);
+int launch_br_ext_init(pz_module* M, int64_t* acc, const int64_t* lut, const int64_t* lwe_2n, long long lwe_bs, int log_ext, int cols,
+                       int rsz, int lut_size, int B);
+
+}  // namespace pz

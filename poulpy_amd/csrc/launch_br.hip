@@ -1,0 +1,194 @@
+// launch_br.hip — blind-rotation kernels: the one-kernel rotation (device_br.hpp), the fused block step and the
+// accumulation kernels of the composed path.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "internal.hpp"
+#include "device_br.hpp"
+#include "device_br_ops.hpp"
+
+namespace pz {
+
+int br_try_fused(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
+                 const pz_blind_rotation_params* p, size_t batch, bool* launched_out) {
+    *launched_out = false;
+    const long long n = (long long)M->n;
+    const int cols = (int)p->rank + 1, dnum = (int)p->dnum, bsz = (int)p->brk_size, rsz = (int)p->res_size;
+    const int B = (int)batch, n_lwe = (int)p->n_lwe, blk = (int)p->block_size, k = (int)p->base2k;
+    const size_t pmat_doubles = (size_t)n * dnum * cols * cols * bsz;
+    {
+        // whole rotation in one kernel, accumulators resident in LDS (device_br.hpp), when the shape fits
+        // (std_variant: execute_standard, one ciphertext per workgroup and a second accumulator-sized array)
+        const bool std_variant = blk == 1;
+        {
+            const int in_limbs = std::min(dnum, rsz), row_max = cols * in_limbs, ncols = cols * bsz, P = std::max(row_max, ncols);
+            const int m = (int)M->m, mp = m + (m >> 4);
+            constexpr int NT = 512;
+            const int r0 = m == 128 ? 2 : (m == 256 ? 4 : 8);
+            auto lds_for = [&](int ct, bool a32) {
+                return ((size_t)m + (size_t)ct * P * mp) * sizeof(cplx) + (size_t)ct * rsz * cols * (size_t)n * (a32 ? 4 : 8) * (std_variant ? 2 : 1);
+            };
+            auto fits = [&](int ct, bool a32) {
+                return lds_for(ct, a32) <= 160 * 1024 && ct * P * (m / 8) <= ((ct == 2 && r0 == 8) ? 2 : 1) * NT && ct * P * (m / r0) <= 2 * NT &&
+                       (!a32 || k <= 31);
+            };
+            static const int force_ct = getenv("POULPY_DBG_BR_CT") ? atoi(getenv("POULPY_DBG_BR_CT")) : 0;
+            const int cgsz = (ncols % 3 == 0 && ncols % 4 != 0) ? 3 : 4;  // 6 output polynomials: two groups of 3, no idle slot
+            const int pj = m * ((ncols + cgsz - 1) / cgsz) <= NT ? 1 : 2;
+            static const int br_one = getenv("POULPY_DBG_BR_ONE") ? atoi(getenv("POULPY_DBG_BR_ONE")) : 1;  // 0: composed path everywhere
+            if (br_one && M->fuse_mid && (m == 128 || m == 256 || m == 512) && NT % m == 0 && row_max <= 8 && ncols <= 8 &&
+                m * ((ncols + cgsz - 1) / cgsz) <= 2 * NT && fits(1, false)) {
+                // two ciphertexts per workgroup share every key value; with 64-bit accumulators when that fits in LDS, else
+                // with 32-bit digit accumulators (m = 128 is only built with one ciphertext per workgroup)
+                int ct = 1;
+                bool a32 = false;
+                if (force_ct != 1 && B >= 2 && m != 128 && !std_variant) {
+                    if (fits(2, false)) ct = 2;
+                    else if (fits(2, true)) { ct = 2; a32 = true; }
+                }
+                const size_t lds = lds_for(ct, a32);
+                BrFusedArgs g;
+                g.res = (long long*)res; g.lut = (const long long*)lut; g.lwe = (const long long*)lwe_2n; g.brk = (const cplx*)brk;
+                g.w2n = M->w2n; g.key_stride = (long long)(pmat_doubles / 2);
+                g.n_lwe = n_lwe; g.blk = blk; g.cols = cols; g.rsz = rsz; g.dnum = dnum; g.bsz = bsz; g.lut_size = (int)p->lut_size;
+                g.base2k = k; g.m = m; g.batch = B;
+                static const int br_skip = getenv("POULPY_DBG_BR_SKIP") ? atoi(getenv("POULPY_DBG_BR_SKIP")) : 0;
+                g.dbg_skip = br_skip;
+                KTimer kt(M, PZ_K_FUSED_MID);
+                bool launched = false;
+#define PZ_BR_STD(R0_, PJ_, MR_, CG_)                                                                                        \
+    if (!launched && std_variant && r0 == R0_ && pj == PJ_ && mr == MR_ && cgsz == CG_) {                                    \
+        PZ_TRY(set_lds((k_br_fused<R0_, 1, NT, PJ_, MR_, CG_, false, true>), lds));                                           \
+        hipLaunchKernelGGL((k_br_fused<R0_, 1, NT, PJ_, MR_, CG_, false, true>), dim3(B), dim3(NT), lds, M->stream, g);       \
+        launched = true;                                                                                                     \
+    }
+#define PZ_BR_STD_SHAPES(R0_)                                                                                                \
+    PZ_BR_STD(R0_, 1, 4, 4) PZ_BR_STD(R0_, 2, 4, 4) PZ_BR_STD(R0_, 1, 6, 3) PZ_BR_STD(R0_, 2, 6, 3)                          \
+    PZ_BR_STD(R0_, 1, 8, 4) PZ_BR_STD(R0_, 2, 8, 4) PZ_BR_STD(R0_, 1, 8, 3) PZ_BR_STD(R0_, 2, 8, 3)
+#define PZ_BR_ONE(R0_, CT_, PJ_, MR_, CG_, A32_)                                                                             \
+    if (!launched && !std_variant && r0 == R0_ && ct == CT_ && pj == PJ_ && mr == MR_ && cgsz == CG_ && a32 == A32_) {       \
+        PZ_TRY(set_lds(k_br_fused<R0_, CT_, NT, PJ_, MR_, CG_, A32_>, lds));                                                 \
+        hipLaunchKernelGGL((k_br_fused<R0_, CT_, NT, PJ_, MR_, CG_, A32_>), dim3((B + CT_ - 1) / CT_), dim3(NT), lds, M->stream, g); \
+        launched = true;                                                                                                     \
+    }
+#define PZ_BR_SHAPES(R0_, CT_, A32_)                                                                                         \
+    PZ_BR_ONE(R0_, CT_, 1, 4, 4, A32_) PZ_BR_ONE(R0_, CT_, 2, 4, 4, A32_) PZ_BR_ONE(R0_, CT_, 1, 6, 3, A32_) PZ_BR_ONE(R0_, CT_, 2, 6, 3, A32_) \
+    PZ_BR_ONE(R0_, CT_, 1, 8, 4, A32_) PZ_BR_ONE(R0_, CT_, 2, 8, 4, A32_) PZ_BR_ONE(R0_, CT_, 1, 8, 3, A32_) PZ_BR_ONE(R0_, CT_, 2, 8, 3, A32_)
+                const int mr = row_max <= 4 && cgsz == 4 ? 4 : (row_max <= 6 && cgsz == 3 ? 6 : 8);
+                PZ_BR_STD_SHAPES(2) PZ_BR_STD_SHAPES(4) PZ_BR_STD_SHAPES(8)
+                PZ_BR_SHAPES(2, 1, false)
+                PZ_BR_SHAPES(4, 1, false) PZ_BR_SHAPES(4, 2, false) PZ_BR_SHAPES(4, 2, true)
+                PZ_BR_SHAPES(8, 1, false) PZ_BR_SHAPES(8, 2, false) PZ_BR_SHAPES(8, 2, true)
+#undef PZ_BR_SHAPES
+#undef PZ_BR_ONE
+#undef PZ_BR_STD_SHAPES
+#undef PZ_BR_STD
+                if (!launched) return fail(PZ_ERR_UNSUPPORTED, "blind_rotation: no one-kernel variant for this shape");
+                PZ_HIP(hipGetLastError());
+                *launched_out = true;
+                return PZ_OK;
+            }
+        }
+    }
+    return PZ_OK;
+}
+
+int br_block_step(pz_module* M, const double* acc_dft, long long a_bs, double* acc_add, long long o_bs, const double* brk,
+                  size_t pmat_doubles, int row_max, int ncols, int B, int i0, int blk, const int64_t* lwe_2n, long long lwe_bs,
+                  bool* launched_out) {
+    *launched_out = false;
+    if (!(row_max <= 12 && blk <= 64)) return PZ_OK;
+                // zero + block_size x (vmp, svp, add, sub) in one kernel, nothing but acc_add written (:321-337)
+                BrBlockArgs g;
+                g.acc_dft = (const cplx*)acc_dft; g.acc_add = (cplx*)acc_add; g.a_bs = a_bs / 2; g.o_bs = o_bs / 2;
+                g.brk = (const cplx*)brk; g.key_stride = (long long)(pmat_doubles / 2);
+                g.row_max = row_max; g.ncols = ncols; g.m = (int)M->m; g.batch = B; g.i0 = i0; g.blk = blk;
+                g.lwe = (const long long*)lwe_2n; g.lwe_bs = lwe_bs; g.w2n = M->w2n;
+                static const int brl_dbg = getenv("POULPY_DBG_BRL") ? atoi(getenv("POULPY_DBG_BRL")) : 0;
+                g.dbg = brl_dbg; g.gx = g.gy = g.gz = 1; g.xcd = 0; g.allcg = 0;
+                constexpr int CT = 2;
+                KTimer kt(M, PZ_K_VMP);
+                const int nc = ncols;
+                const unsigned gx = (unsigned)((B + CT - 1) / CT), gy = (unsigned)((M->m + 255) / 256);
+                // (input polynomials kept in registers, output columns per workgroup): rank 2 with 3-4 decomposition rows (the
+                // circuit-bootstrapping shape) has 9 or 12 inputs, so fewer columns per workgroup there
+                int mr, cgs;
+                if (row_max > 9 || (row_max > 8 && nc % 3 != 0)) { mr = 12; cgs = 2; }
+                else if (row_max > 8) { mr = 9; cgs = 3; }
+                else if (nc % 3 == 0 && nc % 4 != 0) { mr = row_max <= 6 ? 6 : 8; cgs = 3; }   // 3, 6 columns: groups of 3
+                else { mr = row_max <= 4 ? 4 : 8; cgs = 4; }
+                const int ngroups = (nc + cgs - 1) / cgs;
+                // keys staged in LDS once per 4 waves x 2 ciphertexts (k_br_block_lds): POULPY_DBG_BR_LDS = 0 never, 1 only for
+                // more than 8 inputs, 2 always
+                static const int br_lds = getenv("POULPY_DBG_BR_LDS") ? atoi(getenv("POULPY_DBG_BR_LDS")) : 2;
+                const bool use_lds = M->m % 64 == 0 && (br_lds >= 2 || (br_lds == 1 && row_max > 8));
+                bool launched = false;
+                if (use_lds) {
+                    g.gx = (B + 7) / 8; g.gy = (int)(M->m / 64); g.gz = ngroups;
+                    static const int br_xcd = getenv("POULPY_DBG_BR_XCD") ? atoi(getenv("POULPY_DBG_BR_XCD")) : 1;
+                    g.xcd = (br_xcd && (g.gx * g.gy) % 8 == 0) ? 1 : 0;
+                    static const int br_allcg = getenv("POULPY_DBG_BR_ALLCG") ? atoi(getenv("POULPY_DBG_BR_ALLCG")) : 1;
+                    g.allcg = br_allcg ? 1 : 0;
+                    const unsigned total = (unsigned)(g.gx * g.gy * (g.allcg ? 1 : g.gz));
+#define PZ_BRB(MR_, CG_)                                                                                           \
+    if (!launched && mr == MR_ && cgs == CG_) {                                                                    \
+        hipLaunchKernelGGL((k_br_block_lds<2, MR_, CG_>), dim3(total), dim3(256), 0, M->stream, g);                \
+        launched = true;                                                                                           \
+    }
+                    PZ_BRB(12, 2) PZ_BRB(9, 3) PZ_BRB(6, 3) PZ_BRB(8, 3) PZ_BRB(4, 4) PZ_BRB(8, 4)
+#undef PZ_BRB
+                } else {
+#define PZ_BRB(MR_, CG_)                                                                                           \
+    if (!launched && mr == MR_ && cgs == CG_) {                                                                    \
+        hipLaunchKernelGGL((k_br_block<CT, MR_, CG_>), dim3(gx, gy, (unsigned)ngroups), dim3(256), 0, M->stream, g); \
+        launched = true;                                                                                           \
+    }
+                    PZ_BRB(12, 2) PZ_BRB(9, 3) PZ_BRB(6, 3) PZ_BRB(8, 3) PZ_BRB(4, 4) PZ_BRB(8, 4)
+#undef PZ_BRB
+                }
+                PZ_HIP(hipGetLastError());
+    *launched_out = true;
+    return PZ_OK;
+}
+
+int launch_xai_acc(pz_module* M, double* acc_add, long long acc_bs, const double* v, long long v_bs, int polys, int B,
+                   const int64_t* lwe_2n, long long lwe_bs, int idx) {
+    XaiArgs g;
+    g.acc = (cplx*)acc_add; g.v = (const cplx*)v; g.acc_bs = acc_bs / 2; g.v_bs = v_bs / 2;
+    g.polys = polys; g.m = (int)M->m; g.batch = B;
+    g.lwe = (const long long*)lwe_2n; g.lwe_bs = lwe_bs; g.idx = idx; g.w2n = M->w2n;
+    const long long total = (long long)B * g.polys * g.m;
+    KTimer kt(M, PZ_K_ELEMENTWISE);
+    hipLaunchKernelGGL(k_xai_acc, dim3((unsigned)std::min<long long>((total + 255) / 256, 256 * 16)), dim3(256), 0, M->stream, g);
+    PZ_HIP(hipGetLastError());
+    return PZ_OK;
+}
+
+int launch_xai_ext(pz_module* M, double* acc_add, const double* v, int polys, int log_ext, int B, const int64_t* lwe_2n, long long lwe_bs,
+                   int idx) {
+    XaiExtArgs g;
+    g.acc = (cplx*)acc_add; g.v = (const cplx*)v; g.polys = polys; g.m = (int)M->m; g.log_ext = log_ext; g.batch = B;
+    g.lwe = (const long long*)lwe_2n; g.lwe_bs = lwe_bs; g.idx = idx; g.w2n = M->w2n;
+    const long long total = ((long long)B << log_ext) * g.polys * g.m;
+    KTimer kt(M, PZ_K_ELEMENTWISE);
+    hipLaunchKernelGGL(k_xai_ext, dim3((unsigned)std::min<long long>((total + 255) / 256, 256 * 16)), dim3(256), 0, M->stream, g);
+    PZ_HIP(hipGetLastError());
+    return PZ_OK;
+}
+
+int launch_br_ext_init(pz_module* M, int64_t* acc, const int64_t* lut, const int64_t* lwe_2n, long long lwe_bs, int log_ext, int cols,
+                       int rsz, int lut_size, int B) {
+    BrExtInitArgs g;
+    g.acc = (long long*)acc; g.lut = (const long long*)lut; g.lwe = (const long long*)lwe_2n; g.lwe_bs = lwe_bs;
+    g.n = (int)M->n; g.log_ext = log_ext; g.cols = cols; g.rsz = rsz; g.lut_size = lut_size;
+    g.nl = std::min(rsz, lut_size); g.batch = B;
+    const int BE = B << log_ext;
+    KTimer kt(M, PZ_K_ELEMENTWISE);
+    hipLaunchKernelGGL(k_br_ext_init, dim3((unsigned)((M->n / 2 + 255) / 256), (unsigned)g.nl, (unsigned)BE), dim3(256), 0, M->stream, g);
+    PZ_HIP(hipGetLastError());
+    return PZ_OK;
+}
+
+}  // namespace pz

@@ -1,0 +1,108 @@
+// launch_mid.hip — dispatch of the fused middle kernels and the key re-slicing (device_mid.hpp).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "internal.hpp"
+#include "device_mid.hpp"
+
+namespace pz {
+
+bool mid_supported(const pz_module* M, int npi, int npo) {
+    const int np_max = M->plan.m2 == 128 ? 32 : 16;  // 128-point rows: up to 32 polynomial slots (two ciphertexts per tile)
+    return (M->plan.m2 == 256 || M->plan.m2 == 128) && (M->plan.m1 % 16) == 0 && npi >= 1 && npi <= np_max && npo >= 1 && npo <= np_max;
+}
+int launch_permute_pmat(pz_module* M, const double* P, cplx* Pp, int npolys) {
+    const FftPlan& pl = M->plan;
+    const int blocks = npolys * (pl.m1 / 16) * (pl.m2 / 16);
+    KTimer kt(M, PZ_K_ELEMENTWISE);
+    hipLaunchKernelGGL(k_permute_pmat, dim3(blocks), dim3(256), 0, M->stream, reinterpret_cast<const cplx*>(P), Pp, npolys, pl.m1, pl.m2);
+    PZ_HIP(hipGetLastError());
+    return PZ_OK;
+}
+template <int CT>
+static int launch_mid_ct(pz_module* M, MidArgs g, int batch) {
+    g.n_ct = (batch + CT - 1) / CT;
+    const size_t lds = ((size_t)CT * 16 * 17 * 16 + 512) * sizeof(cplx);
+    KTimer kt(M, PZ_K_FUSED_MID);
+    PZ_TRY(set_lds(k_mid<CT>, lds));
+    // persistent: as many workgroups as fit (LDS-bound: 144 KiB -> 1 per CU at CT = 2, 76 KiB -> 2 per CU at CT = 1)
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, M->device);
+    const int per_cu = CT == 1 ? 2 : 1;
+    const int grid = std::min(ncu * per_cu, g.m1 * g.n_ct);
+    hipLaunchKernelGGL((k_mid<CT>), dim3(grid), dim3(CT * 256), lds, M->stream, g);
+    PZ_HIP(hipGetLastError());
+    return PZ_OK;
+}
+// perm_mul != 0: spectrum permutation of X -> X^p folded into the middle kernel (m2 = 128 plans only; see MidArgs)
+int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp, int npi, int npo, int nrows, int ncols, cplx* dummy,
+               unsigned perm_mul, unsigned perm_add) {
+    MidArgs g;
+    g.perm_mul = perm_mul; g.perm_add = perm_add; g.log_m1 = 0;
+    while ((1 << g.log_m1) < M->plan.m1) ++g.log_m1;
+    const bool perm = perm_mul != 0;
+    g.T = T; g.T2 = T2; g.P = Pp; g.npi = npi; g.npo = npo; g.nrows = nrows; g.ncols = ncols;
+    g.row_max = std::min(nrows, npi);
+    g.ncomp = std::min(npo, ncols);
+    g.batch = batch; g.m1 = M->plan.m1; g.n_ct = 0;
+    g.wL2 = M->wL2; g.tw12t = M->tw12t; g.dummy = dummy;
+    static const int groups = getenv("POULPY_DBG_MID_GROUPS") ? atoi(getenv("POULPY_DBG_MID_GROUPS")) : 1;
+    g.groups = groups;
+    // phase stagger: workgroup w starts (w mod 4) x ~3.4 us late so that the HBM-heavy row passes of some CUs overlap
+    // the L2-heavy product phases of others (measured: middle kernel -3 %); off for the m2 = 128 form, where it did not pay
+    static const int stg = getenv("POULPY_DBG_MID_STAGGER") ? atoi(getenv("POULPY_DBG_MID_STAGGER")) : -1;
+    static const int stm = getenv("POULPY_DBG_MID_STAGGER_MOD") ? atoi(getenv("POULPY_DBG_MID_STAGGER_MOD")) : 4;
+    g.stagger = stg >= 0 ? stg : (M->plan.m2 == 128 ? 0 : 1);
+    g.stagger_mod = std::max(1, stm);
+    if (M->plan.m2 == 128) {
+        int ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, M->device);
+        KTimer kt(M, PZ_K_FUSED_MID);
+        if (npi <= 8 && npo <= 8) {
+            // <= 8 polynomials in and out (e.g. rank 1 with 4 limbs, BASELINE configs[1]): 8 ciphertexts x 8 slots per tile
+            constexpr int CT = 8;
+            g.n_ct = (batch + CT - 1) / CT;
+            const size_t lds = ((size_t)CT * 8 * 16 * 9 + 256) * sizeof(cplx);
+            if (perm) {
+                PZ_TRY(set_lds((k_mid128<CT, 8, true>), lds));
+                hipLaunchKernelGGL((k_mid128<CT, 8, true>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(512), lds, M->stream, g);
+            } else {
+                PZ_TRY(set_lds((k_mid128<CT, 8>), lds));
+                hipLaunchKernelGGL((k_mid128<CT, 8>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(512), lds, M->stream, g);
+            }
+        } else if (npi > 16 || npo > 16) {
+            // 17..32 polynomials in or out (rank 2-3 with 8 limbs, rank 1 with 16 limbs): 2 ciphertexts x 32 slots per tile
+            constexpr int CT = 2;
+            g.n_ct = (batch + CT - 1) / CT;
+            const size_t lds = ((size_t)CT * 32 * 16 * 9 + 256) * sizeof(cplx);
+            if (perm) {
+                PZ_TRY(set_lds((k_mid128<CT, 32, true>), lds));
+                hipLaunchKernelGGL((k_mid128<CT, 32, true>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(512), lds, M->stream, g);
+            } else {
+                PZ_TRY(set_lds((k_mid128<CT, 32>), lds));
+                hipLaunchKernelGGL((k_mid128<CT, 32>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(512), lds, M->stream, g);
+            }
+        } else {
+            constexpr int CT = 4;
+            g.n_ct = (batch + CT - 1) / CT;
+            const size_t lds = ((size_t)CT * 16 * 16 * 9 + 256) * sizeof(cplx);
+            if (perm) {
+                PZ_TRY(set_lds((k_mid128<CT, 16, true>), lds));
+                hipLaunchKernelGGL((k_mid128<CT, 16, true>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(CT * 128), lds, M->stream, g);
+            } else {
+                PZ_TRY(set_lds(k_mid128<CT>, lds));
+                hipLaunchKernelGGL((k_mid128<CT>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(CT * 128), lds, M->stream, g);
+            }
+        }
+        PZ_HIP(hipGetLastError());
+        return PZ_OK;
+    }
+    static const int ct = getenv("POULPY_DBG_MID_CT") ? atoi(getenv("POULPY_DBG_MID_CT")) : 2;  // diagnostic knob
+    if (ct == 1) return launch_mid_ct<1>(M, g, batch);
+    return launch_mid_ct<2>(M, g, batch);
+}
+
+
+}  // namespace pz

@@ -1,0 +1,80 @@
+// launch_tail.hip — dispatch of the fused tail (k_inv_tail, device_fft.hpp).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "internal.hpp"
+
+namespace pz {
+
+#define PZ_P1F_CASES(X) X(4, 1, 4) X(8, 1, 4) X(8, 1, 16) X(16, 1, 16) X(4, 4, 16) X(4, 8, 16) X(8, 8, 16) X(8, 16, 16) X(16, 16, 16) X(8, 16, 8)
+
+// the two roles of k_inv_tail must be whole waves
+bool tail_supported(const pz_module* M) { return (M->plan.f1b * M->plan.cb) % 64 == 0; }
+
+static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
+                                int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
+                                int base2k, bool rowmajor, bool small_all, unsigned auto_mul, bool auto_neg, int col_base, int col_count,
+                                unsigned gather_mul = 0, bool gather_neg = false, int body_col = 0, const long long* body_src = nullptr,
+                                long long body_bs = 0, long long body_ls = 0, bool small_neg = false) {
+    const FftPlan& pl = M->plan;
+    const int blocks = batch * col_count * (pl.m2 / pl.cb);
+    if (blocks == 0) return PZ_OK;
+    KTimer kt(M, PZ_K_FUSED_TAIL);
+    TailArgs g;
+    g.T = T; g.res = res; g.small = small; g.res_bs = res_bs; g.small_bs = small_bs;
+    g.nlimbs = nlimbs; g.ncols = ncols; g.res_cols = res_cols; g.res_size = res_size;
+    g.small_cols = small_cols; g.small_size = small_size; g.base2k = base2k; g.m2 = pl.m2;
+    g.tw1inv = M->tw1inv; g.wL1 = M->wL1; g.margin = M->margin;
+    g.small_all = small_all ? 1 : 0; g.auto_mul = auto_mul; g.auto_neg = auto_neg ? 1 : 0;
+    g.col_base = col_base; g.col_count = col_count; g.body_col = body_col;
+    g.gather_mul = gather_mul; g.gather_neg = gather_neg ? 1 : 0;
+    g.pre_body = body_src != nullptr ? 1 : 0; g.small_neg = small_neg ? 1 : 0; g.body_src = body_src; g.body_bs = body_bs; g.body_ls = body_ls;
+    g.xcd_map = (gather_mul != 0 && blocks % (8 * (pl.m2 / pl.cb)) == 0) ? 1 : 0;
+    const bool has_small = small != nullptr;
+// one instantiation per (probe, row-major, body add) combination actually requested
+#define PZ_TAIL_ONE(A, B, C, P_, R_, S_)                                                                        \
+    if (M->probe == P_ && rowmajor == R_ && has_small == S_) {                                                  \
+        PZ_TRY(set_lds(k_inv_tail<A, B, C, P_, R_, S_>, lds));                                                  \
+        hipLaunchKernelGGL((k_inv_tail<A, B, C, P_, R_, S_>), dim3(blocks), dim3(TailShape<A, B, C>::NT), lds, M->stream, g); \
+    }
+#define PZ_TAIL_LAUNCH(A, B, C)                                                                                 \
+    PZ_TAIL_ONE(A, B, C, false, false, false) PZ_TAIL_ONE(A, B, C, false, false, true)                          \
+    PZ_TAIL_ONE(A, B, C, false, true, false) PZ_TAIL_ONE(A, B, C, false, true, true)                            \
+    PZ_TAIL_ONE(A, B, C, true, false, false) PZ_TAIL_ONE(A, B, C, true, false, true)                            \
+    PZ_TAIL_ONE(A, B, C, true, true, false) PZ_TAIL_ONE(A, B, C, true, true, true)
+#define X(A, B, C)                                                                                              \
+    if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
+        const size_t lds = ((size_t)2 * (A + 1) * C * B + 2 * A * B) * sizeof(cplx);                  \
+        PZ_TAIL_LAUNCH(A, B, C)                                                                                 \
+        PZ_HIP(hipGetLastError());                                                                              \
+        return PZ_OK;                                                                                           \
+    }
+    PZ_P1F_CASES(X)
+#undef X
+    return fail(PZ_ERR_UNSUPPORTED, "no fused tail kernel for m1=%d", pl.m1);
+}
+// The body operand of a key switch only exists for one column (0; `body_col` for ggsw_expand_row): that column runs the
+// variant that prefetches it (more registers, one workgroup less per CU), the other columns the plain one.
+int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
+                    int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
+                    int base2k, bool rowmajor, bool small_all, unsigned auto_mul, bool auto_neg,
+                    unsigned gather_mul, bool gather_neg, int body_col, const long long* body_src,
+                    long long body_bs, long long body_ls, bool small_neg) {
+    if (small != nullptr && !small_all && ncols > 1) {
+        PZ_TRY(launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, small, small_bs, small_cols, small_size,
+                                    base2k, rowmajor, false, auto_mul, auto_neg, body_col, 1, 0, false, body_col));
+        if (body_col > 0)
+            PZ_TRY(launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, nullptr, 0, small_cols, small_size,
+                                        base2k, rowmajor, false, 0, false, 0, body_col));
+        return launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, nullptr, 0, small_cols, small_size,
+                                    base2k, rowmajor, false, 0, false, body_col + 1, ncols - 1 - body_col);
+    }
+    return launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, small, small_bs, small_cols, small_size, base2k,
+                                rowmajor, small_all, auto_mul, auto_neg, 0, ncols, gather_mul, gather_neg, body_col, body_src, body_bs, body_ls,
+                                small_neg);
+}
+
+
+}  // namespace pz
