@@ -97,11 +97,50 @@ def cpu_baseline(sample_cts_per_thread: int = 4, max_threads: int | None = None)
                       f"{sample_cts_per_thread}, oracle/fft64_ref.c built -O3 -march=native, {dt:.2f} s wall"}
 
 
+def parity_sample(args, mod, a, res, mat_host, lo, nct, ks, auto_mode, unsupported, cols, cols_in) -> dict:
+    """Checks `--parity-samples` ciphertexts of the timed output (first, last, and indices spread over the tiles / XCD slots /
+    the last partial wave of the launch) against the CPU oracle on the same inputs, bit for bit.  The oracle is the checker
+    only: nothing here is timed."""
+    import numpy as np
+    import torch
+    if unsupported:
+        return {"n": 0, "ok": None, "note": "no single-ciphertext oracle entry point for this op (covered by tests/)"}
+    from oracle.ref import RefModule
+    from poulpy_amd.layouts import MatZnx, VecZnx
+    k = min(args.parity_samples, nct)
+    picks = sorted({0, nct - 1, *[(i * 2654435761 + 17) % nct for i in range(1, max(k - 1, 1))]})[:max(k, 1)]
+    if (nct - 1) not in picks:
+        picks[-1] = nct - 1
+    if mat_host is None:   # ranks > 0 regenerate the key material (same device generator, same seed)
+        g = torch.Generator(device=a.device)
+        g.manual_seed(0x6657)
+        half = 1 << (BASE2K - 1)
+        mat_host = torch.randint(-half, half, (N * DNUM * cols_in * cols * SIZE,), dtype=torch.int64, device=a.device, generator=g).cpu().numpy()
+    ref = RefModule(N)
+    mat = MatZnx(N, DNUM, cols_in, cols, SIZE, np.ascontiguousarray(mat_host))
+    pm = ref.vmp_pmat_alloc(DNUM, cols_in, cols, SIZE)
+    ref.vmp_prepare(pm, mat)
+    bad = []
+    for i in picks:
+        ai = VecZnx(N, cols, SIZE, a[i].cpu().numpy())
+        want = VecZnx(N, cols, SIZE)
+        if auto_mode:
+            ref.glwe_automorphism(want, BASE2K, ai, BASE2K, pm, 1, BASE2K, 5, auto_mode)
+        elif ks:
+            ref.glwe_keyswitch(want, BASE2K, ai, BASE2K, pm, 1, BASE2K)
+        else:
+            ref.glwe_external_product(want, BASE2K, ai, BASE2K, pm, 1, BASE2K)
+        if not np.array_equal(res[i].cpu().numpy(), want.data):
+            bad.append(int(lo + i))
+    return {"n": len(picks), "ok": not bad, "indices": [int(lo + i) for i in picks], "mismatched": bad,
+            "against": "oracle/fft64_ref.c (strict build, -ffp-contract=off), bit-exact i64 limbs"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (default: ~1.1 s of GPU time at the metric shape)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="ciphertexts per GPU per step (16 GiB of GLWE in + out at the metric shape)")
     ap.add_argument("--chunk", type=int, default=0, help="ciphertexts per pipeline wave (0 = auto)")
     ap.add_argument("--op", choices=("external_product", "keyswitch", "automorphism", "automorphism_add", "trace", "ggsw_expand_row"), default="external_product",
@@ -114,7 +153,9 @@ def main():
                                                          "0 = the metric configuration (8)")
     ap.add_argument("--no-pin-key", action="store_true", help="rebuild the key's row-sliced copy on every call (pz_module_pin_key not used)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the separate per-kernel-class timing pass (no roofline object)")
+    ap.add_argument("--timing-steps", type=int, default=10, help="steps of the separate HIP-event pass that feeds the roofline object")
+    ap.add_argument("--parity-samples", type=int, default=8, help="timed-output ciphertexts checked against the CPU oracle (0 = none)")
     args = ap.parse_args()
     global SIZE, DNUM, N, BASE2K
     if args.limbs:
@@ -157,11 +198,13 @@ def main():
     cols_in = RANK_GLWE if ks else cols
     key_elems = N * DNUM * cols_in * cols * SIZE
     pmat = torch.empty(key_elems, dtype=torch.float64, device=dev)
+    mat_host = None
     if rank == 0:
         g = torch.Generator(device=dev)
         g.manual_seed(0x6657)
         mat = torch.randint(-half, half, (key_elems,), dtype=torch.int64, device=dev, generator=g)
         torch.cuda.synchronize()
+        mat_host = mat.cpu().numpy() if args.parity_samples else None
         mod._ck(mod.lib.pz_vmp_prepare(mod.handle, C.c_void_p(pmat.data_ptr()), C.c_void_p(mat.data_ptr()),
                                        C.c_size_t(DNUM), C.c_size_t(cols_in), C.c_size_t(cols), C.c_size_t(SIZE)))
         mod.sync()
@@ -172,9 +215,12 @@ def main():
     # this rank's shard of the (weak-scaled) batch: `batch` ciphertexts per GPU, seeds by global index
     lo, hi = pdist.shard_range(args.batch * world, world, rank)
     nct = hi - lo
+    # ciphertext i of the global batch is drawn from its own stream, seed 0x5eed0000 + i, whatever the sharding
     g = torch.Generator(device=dev)
-    g.manual_seed(0x5EED0000 + rank)
-    a = torch.randint(-half, half, (nct, SIZE, cols, N), dtype=torch.int64, device=dev, generator=g)
+    a = torch.empty((nct, SIZE, cols, N), dtype=torch.int64, device=dev)
+    for i in range(nct):
+        g.manual_seed(0x5EED0000 + lo + i)
+        a[i].random_(-half, half, generator=g)
     res = torch.empty((nct, SIZE, cols, N), dtype=torch.int64, device=dev)
     if expand:   # the GGSWs: entries (row, 0) = a, entries (row, col >= 1) are produced in place
         del res
@@ -215,9 +261,7 @@ def main():
         step()
     mod.sync()
 
-    timing = (not args.no_kernel_timing)
-    if timing:
-        mod.set_kernel_timing(True)
+    # headline: plain launches (HIP-graph replay where the op uses it), no per-launch events inside the timed region
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -229,14 +273,34 @@ def main():
     if distributed:
         dist.barrier()
     dt = time.perf_counter() - t0
-    stats = mod.kernel_stats() if timing else {}
+
+    # timed output of the LAST step -> parity sample against the CPU oracle (taken before the instrumented pass re-runs the op)
+    parity = parity_sample(args, mod, a, res, mat_host, lo, nct, ks, auto_mode, trace or expand, cols, cols_in) if args.parity_samples else None
+
+    # roofline leg: the same steps again with one HIP-event pair per launch on the module stream
+    stats = {}
+    timing = (not args.no_kernel_timing)
     if timing:
+        if trace:
+            res.copy_(a)
+            torch.cuda.synchronize()
+        mod.set_kernel_timing(True)
+        for _ in range(max(1, args.timing_steps)):
+            step()
+        mod.sync()
+        stats = mod.kernel_stats()
         mod.set_kernel_timing(False)
 
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        if parity is not None and parity.get("ok") is not None:   # every rank checks its own shard; the line reports the AND
+            v = torch.tensor([1 if parity["ok"] else 0, parity["n"]], dtype=torch.int64, device=dev)
+            mn = v.clone()
+            dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            parity = dict(parity, ok=bool(mn[0].item()), n=int(v[1].item()), ranks=world)
 
     # cheap size-independent sanity on the timed output: digits are balanced base-2^12
     # (glwe_automorphism permutes AFTER normalizing, so a digit -2^(k-1) may come out negated: closed interval there,
@@ -253,7 +317,7 @@ def main():
             dom = max(stats.items(), key=lambda kv: kv[1][1])
             name, (cnt, ms) = dom
             if cnt:
-                units_per_launch = nct * args.steps / cnt
+                units_per_launch = nct * max(1, args.timing_steps) / cnt
                 avg_s = ms / cnt / 1e3
                 achieved = b_unit * units_per_launch / avg_s / 1e9
                 roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -277,6 +341,7 @@ def main():
                        "batch_per_gpu": args.batch, "parallelism": f"batch-sharded x{world}, key broadcast (RCCL)",
                        "output_digits_balanced": ok},
             "roofline": roof,
+            "parity_sample": parity,
         }
         if world == 1 and not args.no_cpu_baseline and not ks:
             try:
@@ -289,6 +354,8 @@ def main():
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()
+    if parity is not None and parity.get("ok") is False:
+        raise SystemExit(3)   # a fast wrong answer is not a result
 
 
 if __name__ == "__main__":

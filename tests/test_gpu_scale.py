@@ -1,0 +1,231 @@
+"""GPU parity at the LAUNCH GEOMETRY of bench.py / BASELINE.json.
+
+The small-batch parity tests run the persistent middle kernel with one tile per workgroup; the multi-tile software pipeline
+(prefetch of tile t+1 under the inverse pass of t, XCD-aware tile order, per-workgroup row rotation, dummy stores of partial
+tiles) only runs at hundreds of ciphertexts per launch.  Here the batch is BASELINE's: a pool of P distinct ciphertexts (P
+coprime with every tile size) is replicated on the device to `batch` ciphertexts, the oracle computes the P expected results,
+and EVERY output ciphertext of the launch is compared with the expected result of its pool entry — every tile, every XCD slot,
+the last partial wave.  Bit-exact.
+
+PyTorch is plumbing only here (large device buffers, gather / compare on the device); the op under test goes through the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from poulpy_amd.layouts import MatZnx, VecZnx
+from tests.helpers import seeded
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from oracle.ref import RefModule
+    from poulpy_amd.hal import Module
+    cache = {}
+
+    def get(n):
+        if n not in cache:
+            cache[n] = (RefModule(n), Module(n))
+        return cache[n]
+    return get
+
+
+def _pool_parity(hip, ref, ks, n, rank, size, base2k, dnum, batch, pool, seed, chunk=0, pin=False, in_chunks=64):
+    """external product (ks = False) / key switch (ks = True) on `batch` device-resident ciphertexts; returns the number of
+    output ciphertexts that differ from the oracle (0 = parity)."""
+    import torch
+    from poulpy_amd.hal import GlweOpParams
+    rng = seeded(seed)
+    cols = rank + 1
+    cols_in = rank if ks else cols
+    mat = MatZnx(n, dnum, cols_in, cols, size).fill_uniform(base2k, rng)
+    pr, ph = ref.vmp_pmat_alloc(dnum, cols_in, cols, size), hip.vmp_pmat_alloc(dnum, cols_in, cols, size)
+    ref.vmp_prepare(pr, mat)
+    hip.vmp_prepare(ph, mat)
+    a_pool = np.empty((pool, size, cols, n), dtype=np.int64)
+    want_pool = np.empty((pool, size, cols, n), dtype=np.int64)
+    for i in range(pool):
+        a = VecZnx(n, cols, size).fill_uniform(base2k, rng)
+        a_pool[i] = a.data
+        r = VecZnx(n, cols, size)
+        (ref.glwe_keyswitch if ks else ref.glwe_external_product)(r, base2k, a, base2k, pr, 1, base2k)
+        want_pool[i] = r.data
+    dev = torch.device("cuda", 0)
+    d_pool = torch.from_numpy(a_pool).to(dev)
+    d_want = torch.from_numpy(want_pool).to(dev)
+    idx = torch.arange(batch, device=dev) % pool
+    a_all = d_pool[idx].contiguous()                      # ciphertext b = pool entry b mod P
+    res = torch.full((batch, size, cols, n), 0x5A5A5A5A, dtype=torch.int64, device=dev)
+    key = torch.from_numpy(ph.data).to(dev)
+    torch.cuda.synchronize()
+    p = GlweOpParams(rank=rank, dnum=dnum, dsize=1, key_size=size, key_base2k=base2k, a_size=size, a_base2k=base2k,
+                     res_size=size, res_base2k=base2k, rank_out=rank)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    hip.set_chunk(chunk)
+    if pin:
+        hip.pin_key(ptr(key), dnum, cols_in, cols, size)
+    try:
+        (hip.glwe_keyswitch_batched if ks else hip.glwe_external_product_batched)(ptr(res), ptr(a_all), ptr(key), p, batch)
+        hip.sync()
+    finally:
+        if pin:
+            hip.unpin_key(ptr(key))
+        hip.set_chunk(0)
+    bad = 0
+    for b0 in range(0, batch, in_chunks):                 # compare on the device, a slab at a time
+        b1 = min(batch, b0 + in_chunks)
+        eq = (res[b0:b1] == d_want[idx[b0:b1]]).reshape(b1 - b0, -1).all(dim=1)
+        bad += int((~eq).sum().item())
+    del a_all, res, d_pool, d_want, key
+    torch.cuda.empty_cache()
+    return bad
+
+
+@pytest.mark.parametrize("pin,chunk", [(True, 0), (False, 0), (True, 384)], ids=["pinned-one-wave", "unpinned-one-wave", "pinned-chunked"])
+def test_metric_config_at_bench_batch(mods, pin, chunk):
+    """The metric configuration (N = 2^16, 8 limbs, rank 1, base2k 12, dnum 8) at 1030 ciphertexts per call: k_mid128<4,16> walks
+    >= 3 tiles per workgroup (258 ciphertext tiles x 32 rows per XCD over 32 workgroups), the last tile is half empty; pinned and
+    unpinned key; one wave and three waves of 384 / 384 / 262."""
+    n = 65536
+    ref, hip = mods(n)
+    assert _pool_parity(hip, ref, False, n, 1, 8, 12, 8, batch=1030, pool=37, seed=1030 + chunk, chunk=chunk, pin=pin) == 0
+
+
+def test_config3_keyswitch_at_batch_4096(mods):
+    """BASELINE configs[2]: GLWE key-switch via VmpPMat, N = 2^16, 8 limbs, batch 4096 (32 GiB in, 32 GiB out; the pipeline splits
+    it into waves by itself)."""
+    n = 65536
+    ref, hip = mods(n)
+    assert _pool_parity(hip, ref, True, n, 1, 8, 12, 8, batch=4096, pool=29, seed=4096, pin=True) == 0
+
+
+def test_config2_external_product_at_batch_1024(mods):
+    """BASELINE configs[1]: GGSW external product, N = 2^12, 4 limbs, base2k 17, batch 1024."""
+    n = 4096
+    ref, hip = mods(n)
+    assert _pool_parity(hip, ref, False, n, 1, 4, 17, 4, batch=1024, pool=41, seed=1024) == 0
+    assert _pool_parity(hip, ref, False, n, 1, 4, 17, 4, batch=1027, pool=41, seed=1027, pin=True) == 0
+
+
+def test_config5_shape_keyswitch_16_limbs_at_batch_256(mods):
+    """BASELINE configs[4] shape (N = 2^16, 16 limbs: 32 output polynomials, k_mid128<2,32>) at 259 ciphertexts per call."""
+    n = 65536
+    ref, hip = mods(n)
+    assert _pool_parity(hip, ref, True, n, 1, 16, 12, 16, batch=259, pool=7, seed=259, pin=True) == 0
+
+
+def test_config4_blind_rotation_n16384(mods):
+    """BASELINE configs[3], N = 2^14 leg: CGGI block-binary blind rotation at N = 16384 (accumulators do not fit LDS: the composed
+    path with the LDS-staged block step) on a short LWE so that the CPU oracle finishes in about a minute; batch 9 (ragged
+    against the 8-ciphertext tile of the block step)."""
+    from tests.test_gpu_parity import _run_blind_rotation
+    n = 16384
+    ref, hip = mods(n)
+    got, want = _run_blind_rotation(hip, ref, n, 1, 8, 4, 2, 2, 2, 17, batch=9, seed=16384)
+    assert np.array_equal(got, want)
+    # standard variant (block size 1) on the same ring
+    got, want = _run_blind_rotation(hip, ref, n, 1, 3, 1, 2, 2, 2, 15, batch=3, seed=16385)
+    assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------
+# conversion quirks: round half away, saturating `as i64`, NaN -> 0, and the >= 2^51 slow path of the tail
+# reference: poulpy-cpu-ref/src/reference/fft64/reim/conversion.rs:43-60
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [64, 4096, 65536])
+def test_saturating_and_large_conversions(mods, n):
+    """Inverse transforms whose values leave +-2^51 (exact slow path) and +-2^63 (saturation), and NaN (-> 0).
+
+    A CONSTANT spectrum c (every frequency slot = c_re + i c_im) is exact in any FFT ordering and any butterfly schedule: each
+    butterfly sees equal inputs, so sums double exactly and differences are exactly zero; the inverse transform is c_re at
+    coefficient 0, c_im at coefficient n/2 and exact zeros elsewhere.  Constant fills also mean the same thing in the oracle's
+    [re | im] bit-reversed layout and in this backend's interleaved natural-order layout, so both sides get identical inputs."""
+    from poulpy_amd.layouts import VecZnxBig, VecZnxDft
+    ref, hip = mods(n)
+    m = n // 2
+    cases = [
+        (2.0 ** 52 + 3.0, -(2.0 ** 51 + 1.0)),     # beyond the 3-instruction fast conversion, exactly representable
+        (2.0 ** 62 + 2.0 ** 11, -(2.0 ** 62)),     # large, in range
+        (1.0e19, -1.0e19),                         # > 2^63: saturates to i64::MAX / i64::MIN
+        (2.0 ** 63, -(2.0 ** 63)),                 # boundary: 2^63 saturates, -2^63 is i64::MIN exactly
+        (0.5, -0.5), (1.5, -2.5), (0.49999999999999994, -0.49999999999999994), (2.0 ** 51 - 0.5, -(2.0 ** 51) + 0.5),   # half away from zero
+        (float("nan"), float("nan")),              # NaN -> 0 (a NaN in one component only taints a backend-specific set of outputs)
+    ]
+    import math
+
+    def rust_round_as_i64(x):
+        if x != x:
+            return 0
+        t = math.trunc(x)
+        r = t + (int(math.copysign(1, x)) if abs(x - t) >= 0.5 else 0)
+        return max(-(2 ** 63), min(2 ** 63 - 1, r))
+
+    for (cre, cim) in cases:
+        dr, dh = VecZnxDft(n, 1, 2), VecZnxDft(n, 1, 2)
+        for d in (dr, dh):
+            d.data[...] = 0.0
+        rr = dr.at(0, 0)           # the inverse transform divides by m: a constant spectrum c comes out as c at coefficient 0 / m
+        rr[:m] = cre
+        rr[m:] = cim
+        hh = dh.at(0, 0).view(np.complex128)
+        hh[:] = complex(cre, cim)
+        want, got = VecZnxBig(n, 1, 2), VecZnxBig(n, 1, 2)
+        want.data[...] = 7
+        got.data[...] = 7
+        ref.vec_znx_idft_apply(want, 0, dr, 0)
+        hip.vec_znx_idft_apply(got, 0, dh, 0)
+        assert np.array_equal(got.data, want.data), (n, cre, cim, got.data[0, 0, :2], want.data[0, 0, :2])
+        # the expected values, stated directly (Rust: f64::round() as i64)
+        assert int(got.data[0, 0, 0]) == rust_round_as_i64(cre) and int(got.data[0, 0, m]) == rust_round_as_i64(cim), (cre, cim)
+        assert not got.data[0, 0, 1:m].any() and not got.data[0, 0, m + 1:].any()
+    # the consuming form goes through the same epilogue
+    d = VecZnxDft(n, 1, 1)
+    d.at(0, 0).view(np.complex128)[:] = complex(1.0e19, -(2.0 ** 52 + 1.0))
+    big = hip.vec_znx_idft_apply_consume(d)
+    assert int(big.data[0, 0, 0]) == np.iinfo(np.int64).max and int(big.data[0, 0, m]) == -(2 ** 52 + 1)
+
+
+@pytest.mark.parametrize("n", [4096, 65536])
+def test_fused_tail_large_and_saturating_values(mods, n):
+    """The fused tail's slow conversion path (`big >= 2^51`) and its saturation, through the batched external product: constant
+    polynomials (only coefficient 0 non-zero) have constant spectra, and ONE non-zero input row keeps the product a single
+    exactly-representable term, so GPU and oracle agree bit for bit although the values exceed 2^51 / 2^63."""
+    from poulpy_amd.hal import GlweOpParams
+    ref, hip = mods(n)
+    rank, size, dnum, base2k = 1, 4, 4, 20
+    cols = rank + 1
+    for (ca, ck) in ((2 ** 30 + 1, 2 ** 22 + 1), (2 ** 40, 2 ** 30), (-(2 ** 40), 2 ** 30), (2 ** 31 + 5, -(2 ** 21 + 3))):
+        mat = MatZnx(n, dnum, cols, cols, size)
+        mat.data[:, :, :, :, 0] = ck                       # every key entry = the constant ck
+        mat.data[0, 0, 1, 1, 0] = ck + 1
+        pr, ph = ref.vmp_pmat_alloc(dnum, cols, cols, size), hip.vmp_pmat_alloc(dnum, cols, cols, size)
+        ref.vmp_prepare(pr, mat)
+        hip.vmp_prepare(ph, mat)
+        batch = 5
+        a_all = np.zeros((batch, size, cols, n), dtype=np.int64)
+        want = np.empty_like(a_all)
+        for b in range(batch):
+            a_all[b, b % size, b % cols, 0] = ca + b       # one non-zero input polynomial -> one product term per output
+            a = VecZnx(n, cols, size, a_all[b].copy())
+            r = VecZnx(n, cols, size)
+            ref.glwe_external_product(r, base2k, a, base2k, pr, 1, base2k)
+            want[b] = r.data
+        d_a = hip.device_alloc(a_all.nbytes).upload(a_all)
+        d_k = hip.device_alloc(ph.data.nbytes).upload(ph.data)
+        d_r = hip.device_alloc(want.nbytes)
+        p = GlweOpParams(rank=rank, dnum=dnum, dsize=1, key_size=size, key_base2k=base2k, a_size=size, a_base2k=base2k,
+                         res_size=size, res_base2k=base2k, rank_out=rank)
+        for fuse in ((True, True), (False, False)):
+            hip.lib.pz_memset_d(hip.handle, d_r.ptr, 0x11, want.nbytes)
+            hip.set_fusion(*fuse)
+            hip.glwe_external_product_batched(d_r.ptr, d_a.ptr, d_k.ptr, p, batch)
+            hip.sync()
+            hip.set_fusion(True, True)
+            got = d_r.download(np.int64, want.size).reshape(want.shape)
+            assert np.array_equal(got, want), (n, ca, ck, fuse)
+        assert np.abs(want).max() > 0
+        for buf in (d_a, d_k, d_r):
+            buf.free()
