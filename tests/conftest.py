@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """GPU runs: initialise torch's HIP runtime BEFORE libpoulpy_hip.so is loaded.  The at-scale tests use torch tensors as plumbing;
+    torch ships its own libamdhip64 and reports "No HIP GPUs are available" when another copy of the runtime initialised first."""
+    if any(it.get_closest_marker("gpu") for it in items):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
+
+
 @pytest.fixture(scope="session")
 def oracle_lib():
     from oracle import ref
