@@ -1633,6 +1633,37 @@ void pzr_glwe_external_product(const pzr_tables* t, size_t rank,
     free(a_conv);
 }
 
+/* keyswitching/glwe.rs:298-380 (gglwe_product_dft): res_dft(cols_out, key_size) = a_dft(cin, a_size) x key, digit by digit for
+ * dsize > 1.  res_dft arrives zeroed. */
+static void gglwe_product_dft(size_t n, double* res_dft, size_t cols_out, size_t key_size, const double* a_dft, size_t cin, size_t a_size,
+                              const double* key_pmat, size_t dnum, size_t dsize) {
+    if (dsize == 1) {
+        pzr_vmp_apply_dft_to_dft(n, res_dft, cols_out, key_size, a_dft, cin, a_size, key_pmat, dnum, cin, cols_out, key_size, 0);
+    } else {
+        size_t ai_max = zmin(div_ceil(a_size, dsize), dnum);
+        double* ai = (double*)calloc(n * cin * ai_max + 8, sizeof(double));
+        double* tmp = (double*)calloc(n * cols_out * key_size, sizeof(double));
+        for (size_t di = 0; di < dsize; ++di) {
+            size_t ai_sz = zmin((a_size + di) / dsize, dnum);
+            long drop = (long)(dsize - di) - 2;
+            size_t r_sz = key_size - (size_t)(drop > 0 ? drop : 0);
+            for (size_t j = 0; j < cin; ++j)
+                pzr_vec_znx_dft_copy(n, dsize, dsize - di - 1, ai, cin, ai_sz, j, a_dft, cin, a_size, j);
+            if (di == 0) {
+                pzr_vmp_apply_dft_to_dft(n, res_dft, cols_out, r_sz, ai, cin, ai_sz, key_pmat, dnum, cin, cols_out, key_size, 0);
+            } else {
+                memset(tmp, 0, n * cols_out * key_size * sizeof(double)); /* zero-tail semantics, see above */
+                pzr_vmp_apply_dft_to_dft(n, tmp, cols_out, r_sz, ai, cin, ai_sz, key_pmat, dnum, cin, cols_out, key_size, di);
+                for (size_t c = 0; c < cols_out; ++c)
+                    pzr_vec_znx_dft_add_assign(n, res_dft, cols_out, r_sz, c, tmp, cols_out, r_sz, c);
+            }
+        }
+        free(ai);
+        free(tmp);
+        /* glwe.rs:378: res.set_size(res.max_size()) */
+    }
+}
+
 /* keyswitching/glwe.rs:53-109 (default), :207-239 (internal), :298-380 (gglwe_product_dft);
  * mode != PZR_KS_PLAIN: the automorphism family on top of it, automorphism/glwe_ct.rs:51-72 (AUTO: key switch, then the
  * automorphism of the normalized result), :96-140 (ADD), :185-229 (SUB), :231-275 (SUB_NEGATE): automorphism of the big
@@ -1659,31 +1690,7 @@ static void glwe_keyswitch_core(const pzr_tables* t, size_t rank_in, size_t rank
     double* a_dft = (double*)calloc(n * cin * a_size + 8, sizeof(double));
     for (size_t c = 0; c < cin; ++c) /* mask columns only: glwe.rs:231-234 */
         pzr_vec_znx_dft_apply(t, 1, 0, a_dft, cin, a_size, c, a, cols_a, a_size, c + 1);
-    if (dsize == 1) {
-        pzr_vmp_apply_dft_to_dft(n, res_dft, cols_out, key_size, a_dft, cin, a_size, key_pmat, dnum, cin, cols_out, key_size, 0);
-    } else {
-        size_t ai_max = zmin(div_ceil(a_size, dsize), dnum);
-        double* ai = (double*)calloc(n * cin * ai_max + 8, sizeof(double));
-        double* tmp = (double*)calloc(n * cols_out * key_size, sizeof(double));
-        for (size_t di = 0; di < dsize; ++di) {
-            size_t ai_sz = zmin((a_size + di) / dsize, dnum);
-            long drop = (long)(dsize - di) - 2;
-            size_t r_sz = key_size - (size_t)(drop > 0 ? drop : 0);
-            for (size_t j = 0; j < cin; ++j)
-                pzr_vec_znx_dft_copy(n, dsize, dsize - di - 1, ai, cin, ai_sz, j, a_dft, cin, a_size, j);
-            if (di == 0) {
-                pzr_vmp_apply_dft_to_dft(n, res_dft, cols_out, r_sz, ai, cin, ai_sz, key_pmat, dnum, cin, cols_out, key_size, 0);
-            } else {
-                memset(tmp, 0, n * cols_out * key_size * sizeof(double)); /* zero-tail semantics, see above */
-                pzr_vmp_apply_dft_to_dft(n, tmp, cols_out, r_sz, ai, cin, ai_sz, key_pmat, dnum, cin, cols_out, key_size, di);
-                for (size_t c = 0; c < cols_out; ++c)
-                    pzr_vec_znx_dft_add_assign(n, res_dft, cols_out, r_sz, c, tmp, cols_out, r_sz, c);
-            }
-        }
-        free(ai);
-        free(tmp);
-        /* glwe.rs:378: res.set_size(res.max_size()) */
-    }
+    gglwe_product_dft(n, res_dft, cols_out, key_size, a_dft, cin, a_size, key_pmat, dnum, dsize);
     pzr_vec_znx_idft_apply_consume(t, res_dft, cols_out, key_size);
     int64_t* res_big = (int64_t*)res_dft;
     /* glwe.rs:237 (body_col = 0); conversion/gglwe_to_ggsw.rs:251 adds it to column `col` instead */
@@ -2175,3 +2182,296 @@ void pzr_circuit_bootstrap_to_exponent(const pzr_tables* t, size_t rank, size_t 
     free(acc); free(rot); free(a_trace); free(packed); free(cts); free(slots);
 }
 
+
+/* ------------------------------------------------------------------------ */
+/* reference/fft64/convolution.rs (HalImpl cnv_*, hal_impl.rs:670-754)        */
+/* CnvPVecL / CnvPVecR (FFT64): [col][blk < m/4][limb < size][re x4 | im x4]   */
+/* ------------------------------------------------------------------------ */
+
+/* reim/conversion.rs:31-40 */
+static void reim_from_znx_i64_masked(double* res, const int64_t* a, int64_t mask, size_t len) {
+    for (size_t i = 0; i < len; ++i) res[i] = (double)(a[i] & mask);
+}
+
+/* hal_defaults/convolution.rs:40-45, :63-68 */
+size_t pzr_cnv_prepare_tmp_bytes(size_t n, size_t res_size, size_t a_size) { return n * zmin(res_size, a_size) * sizeof(double); }
+
+/* convolution.rs:35-80 (convolution_prepare; _left and _right are the same function for FFT64) */
+void pzr_cnv_prepare(const pzr_tables* t, double* res, size_t res_cols, size_t res_size,
+                     const int64_t* a, size_t a_cols, size_t a_size, int64_t mask) {
+    size_t m = t->m, n = m << 1;
+    size_t min_size = zmin(res_size, a_size);
+    double* tmp = (double*)calloc(n * (min_size ? min_size : 1), sizeof(double)); /* VecZnxDft(1, min(res.size, a.size)) */
+    for (size_t i = 0; i < res_cols; ++i) {
+        pzr_vec_znx_dft_apply(t, 1, 0, tmp, 1, min_size, 0, a, a_cols, a_size, i);
+        if (min_size > 0) { /* :56-61: the last active limb again, masked */
+            size_t last = min_size - 1;
+            reim_from_znx_i64_masked(tmp + n * last, at_ci64(a, n, a_cols, i, last), mask, n);
+            pzr_fft(t, tmp + n * last);
+        }
+        double* res_col = res + i * n * res_size;
+        for (size_t blk = 0; blk < m / 4; ++blk) {
+            reim4_extract_1blk(m, min_size, blk, res_col + blk * res_size * 8, tmp);
+            reim_zero(res_col + blk * res_size * 8 + min_size * 8, (res_size - min_size) * 8);
+        }
+    }
+    free(tmp);
+}
+
+/* convolution.rs:82-140 (convolution_prepare_self): left prepared as above, right = a copy of it */
+void pzr_cnv_prepare_self(const pzr_tables* t, double* left, double* right, size_t cols, size_t size,
+                          const int64_t* a, size_t a_cols, size_t a_size, int64_t mask) {
+    size_t n = t->m << 1;
+    pzr_cnv_prepare(t, left, cols, size, a, a_cols, a_size, mask);
+    memcpy(right, left, n * cols * size * sizeof(double));
+}
+
+/* reim4/arithmetic_ref.rs:235-247 */
+static void reim4_convolution_1coeff(size_t k, double* dst, const double* a, size_t a_size, const double* b, size_t b_size) {
+    reim_zero(dst, 8);
+    if (k >= a_size + b_size) return;
+    size_t j_min = k >= a_size - 1 ? k - (a_size - 1) : 0;
+    size_t j_max = zmin(k + 1, b_size);
+    for (size_t j = j_min; j < j_max; ++j) reim4_add_mul(dst, a + 8 * (k - j), b + 8 * j);
+}
+
+/* reim4/mod.rs:46-58 */
+static void reim4_convolution(double* dst, size_t dst_size, size_t offset, const double* a, size_t a_size, const double* b, size_t b_size) {
+    for (size_t k = 0; k < dst_size; ++k) reim4_convolution_1coeff(k + offset, dst + 8 * k, a, a_size, b, b_size);
+}
+
+/* reim4/arithmetic_ref.rs:37-50: 2*rows rows of 4 values, row r at dst + r*m + 4*blk (the [re | im] polynomials of a one-column
+ * VecZnxDft are exactly such rows) */
+static void reim4_save_1blk_contiguous(size_t m, size_t rows, size_t blk, double* dst, const double* src) {
+    size_t off = blk << 2;
+    for (size_t r = 0; r < 2 * rows; ++r) memcpy(dst + r * m + off, src + 4 * r, 4 * sizeof(double));
+}
+
+size_t pzr_cnv_apply_dft_tmp_bytes(size_t res_size, size_t a_size, size_t b_size) { /* convolution.rs:205-208 */
+    return sizeof(double) * 8 * zmin(res_size, a_size + b_size - 1);
+}
+size_t pzr_cnv_pairwise_apply_dft_tmp_bytes(size_t res_size, size_t a_size, size_t b_size) { /* :261-263 */
+    return pzr_cnv_apply_dft_tmp_bytes(res_size, a_size, b_size) + (a_size + b_size) * sizeof(double) * 8;
+}
+size_t pzr_cnv_by_const_apply_tmp_bytes(size_t res_size, size_t a_size, size_t b_size) { /* :142-145 */
+    return sizeof(int64_t) * (zmin(res_size, a_size + b_size - 1) + a_size) * 8;
+}
+
+/* convolution.rs:210-259 (convolution_apply_dft).  NOTE: the reference saves the blocks at the RAW start of `res`
+ * (:232, :251: res.raw_mut() with rows spaced by m), i.e. it ignores res_col and assumes a one-column res; only the zero fill
+ * (:256-258) uses res_col.  Restated literally; every caller passes a one-column res_dft with res_col = 0. */
+void pzr_cnv_apply_dft(size_t n, size_t cnv_offset, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                       const double* a, size_t a_size, size_t a_col, const double* b, size_t b_size, size_t b_col) {
+    size_t m = n >> 1;
+    size_t bound = a_size + b_size - 1;
+    size_t min_size = zmin(res_size, bound);
+    size_t offset = zmin(cnv_offset, bound);
+    double* tmp = (double*)calloc(8 * (min_size ? min_size : 1), sizeof(double));
+    const double* ap = a + a_col * n * a_size;
+    const double* bp = b + b_col * n * b_size;
+    for (size_t blk = 0; blk < m / 4; ++blk) {
+        reim4_convolution(tmp, min_size, offset, ap, a_size, bp, b_size);
+        reim4_save_1blk_contiguous(m, min_size, blk, res, tmp);
+        ap += a_size * 8;
+        bp += b_size * 8;
+    }
+    for (size_t j = min_size; j < res_size; ++j) reim_zero(at_f64(res, n, res_cols, res_col, j), n);
+    free(tmp);
+}
+
+/* convolution.rs:265-345 (convolution_pairwise_apply_dft): (a_i + a_j) * (b_i + b_j) */
+void pzr_cnv_pairwise_apply_dft(size_t n, size_t cnv_offset, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                                const double* a, size_t a_size, const double* b, size_t b_size, size_t col_i, size_t col_j) {
+    if (col_i == col_j) {
+        pzr_cnv_apply_dft(n, cnv_offset, res, res_cols, res_size, res_col, a, a_size, col_i, b, b_size, col_j);
+        return;
+    }
+    size_t m = n >> 1;
+    size_t bound = a_size + b_size - 1;
+    size_t min_size = zmin(res_size, bound);
+    size_t offset = zmin(cnv_offset, bound);
+    double* tmp_a = (double*)calloc(8 * a_size, sizeof(double));
+    double* tmp_b = (double*)calloc(8 * b_size, sizeof(double));
+    double* tmp_res = (double*)calloc(8 * (min_size ? min_size : 1), sizeof(double));
+    const double *a0 = a + col_i * n * a_size, *a1 = a + col_j * n * a_size;
+    const double *b0 = b + col_i * n * b_size, *b1 = b + col_j * n * b_size;
+    for (size_t blk = 0; blk < m / 4; ++blk) {
+        for (size_t x = 0; x < 8 * a_size; ++x) tmp_a[x] = a0[x] + a1[x]; /* reim_add */
+        for (size_t x = 0; x < 8 * b_size; ++x) tmp_b[x] = b0[x] + b1[x];
+        reim4_convolution(tmp_res, min_size, offset, tmp_a, a_size, tmp_b, b_size);
+        reim4_save_1blk_contiguous(m, min_size, blk, res, tmp_res);
+        a0 += 8 * a_size; a1 += 8 * a_size; b0 += 8 * b_size; b1 += 8 * b_size;
+    }
+    for (size_t j = min_size; j < res_size; ++j) reim_zero(at_f64(res, n, res_cols, res_col, j), n);
+    free(tmp_a); free(tmp_b); free(tmp_res);
+}
+
+/* convolution.rs:147-203 (convolution_by_const_apply) with :395-421 (i64_convolution_by_const_1coeff_ref): res limb k =
+ * sum_j a[k + offset - j] * b[j], wrapping i64, coefficient-wise */
+void pzr_cnv_by_const_apply(size_t n, size_t cnv_offset, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                            const int64_t* a, size_t a_cols, size_t a_size, size_t a_col, const int64_t* b, size_t b_size) {
+    size_t bound = a_size + b_size - 1;
+    size_t min_size = zmin(res_size, bound);
+    size_t offset = zmin(cnv_offset, bound);
+    for (size_t kk = 0; kk < min_size; ++kk) {
+        size_t k = kk + offset;
+        int64_t* dst = at_i64(res, n, res_cols, res_col, kk);
+        memset(dst, 0, n * sizeof(int64_t));
+        if (k >= a_size + b_size) continue;
+        size_t j_min = k >= a_size - 1 ? k - (a_size - 1) : 0;
+        size_t j_max = zmin(k + 1, b_size);
+        for (size_t j = j_min; j < j_max; ++j) {
+            const int64_t* ai = at_ci64(a, n, a_cols, a_col, k - j);
+            uint64_t bj = (uint64_t)b[j];
+            for (size_t x = 0; x < n; ++x) dst[x] = (int64_t)((uint64_t)dst[x] + (uint64_t)ai[x] * bj);
+        }
+    }
+    for (size_t j = min_size; j < res_size; ++j) memset(at_i64(res, n, res_cols, res_col, j), 0, n * sizeof(int64_t));
+}
+
+/* ------------------------------------------------------------------------ */
+/* poulpy-core/src/operations/glwe.rs: GLWE tensoring (CKKS multiplication)   */
+/* ------------------------------------------------------------------------ */
+
+/* operations/glwe.rs:921-926 */
+int64_t pzr_msb_mask_bottom_limb(size_t base2k, size_t k) {
+    size_t r = k % base2k;
+    return r == 0 ? ~(int64_t)0 : (int64_t)(~(uint64_t)0 << (base2k - r));
+}
+/* operations/glwe.rs:929-957 */
+static size_t normalize_input_limb_bound_with_offset(size_t full_size, size_t res_size, size_t res_base2k, size_t in_base2k, int64_t res_offset) {
+    int64_t offset_bits = res_offset % (int64_t)in_base2k;
+    if (res_offset < 0 && offset_bits != 0) offset_bits += (int64_t)in_base2k;
+    return zmin(full_size, div_ceil(res_size * res_base2k + (size_t)offset_bits, in_base2k));
+}
+
+/* One product term of the tensor (operations/glwe.rs:752-760 / :785-792): cnv -> idft (consume) -> normalize with
+ * cnv_offset_lo into a one-column VecZnx `tmp` of res_size limbs */
+static void tensor_term(const pzr_tables* t, size_t cnv_offset_hi, int64_t cnv_offset_lo, size_t dft_size, int64_t* tmp, size_t res_size,
+                        size_t res_base2k, const double* a_prep, size_t a_size, const double* b_prep, size_t b_size, size_t ab_base2k,
+                        size_t i, size_t j) {
+    size_t n = t->m << 1;
+    double* res_dft = (double*)calloc(n * (dft_size ? dft_size : 1), sizeof(double));
+    if (i == j) pzr_cnv_apply_dft(n, cnv_offset_hi, res_dft, 1, dft_size, 0, a_prep, a_size, i, b_prep, b_size, i);
+    else pzr_cnv_pairwise_apply_dft(n, cnv_offset_hi, res_dft, 1, dft_size, 0, a_prep, a_size, b_prep, b_size, i, j);
+    pzr_vec_znx_idft_apply_consume(t, res_dft, 1, dft_size);
+    pzr_vec_znx_normalize(n, tmp, 1, res_size, res_base2k, cnv_offset_lo, 0, (const int64_t*)res_dft, 1, dft_size, ab_base2k, 0);
+    free(res_dft);
+}
+
+/* operations/glwe.rs:700-807 (glwe_tensor_apply, add_assign = 0) and :809-913 (glwe_tensor_apply_add_assign, add_assign = 1).
+ * res: GLWETensor data = VecZnx(cols (cols + 1) / 2, res_size); column of the pair (i, j >= i) = i cols - i (i + 1) / 2 + j. */
+void pzr_glwe_tensor_apply(const pzr_tables* t, size_t rank, size_t cnv_offset, int add_assign,
+                           int64_t* res, size_t res_size, size_t res_base2k,
+                           const int64_t* a, size_t a_size, size_t a_effective_k,
+                           const int64_t* b, size_t b_size, size_t b_effective_k, size_t ab_base2k) {
+    size_t n = t->m << 1;
+    size_t cols = rank + 1, tcols = cols * (cols + 1) / 2;
+    double* a_prep = (double*)calloc(n * cols * a_size, sizeof(double));
+    double* b_prep = (double*)calloc(n * cols * b_size, sizeof(double));
+    pzr_cnv_prepare(t, a_prep, cols, a_size, a, cols, a_size, pzr_msb_mask_bottom_limb(ab_base2k, a_effective_k));
+    pzr_cnv_prepare(t, b_prep, cols, b_size, b, cols, b_size, pzr_msb_mask_bottom_limb(ab_base2k, b_effective_k));
+    size_t hi;
+    int64_t lo;
+    if (cnv_offset < ab_base2k) { hi = 0; lo = -(int64_t)(ab_base2k - (cnv_offset % ab_base2k)); }
+    else { size_t q = cnv_offset / ab_base2k; hi = q ? q - 1 : 0; lo = (int64_t)(cnv_offset % ab_base2k); }
+    size_t dft_size = normalize_input_limb_bound_with_offset(a_size + b_size - hi, res_size, res_base2k, ab_base2k, lo);
+    int64_t* tmp = (int64_t*)calloc(n * res_size, sizeof(int64_t));
+    for (size_t i = 0; i < cols; ++i) {
+        size_t col_i = i * cols - (i * (i + 1) / 2);
+        tensor_term(t, hi, lo, dft_size, tmp, res_size, res_base2k, a_prep, a_size, b_prep, b_size, ab_base2k, i, i);
+        if (add_assign) pzr_vec_znx_assign_op(0, n, res, tcols, res_size, col_i + i, tmp, 1, res_size, 0);
+        else pzr_vec_znx_copy(n, res, tcols, res_size, col_i + i, tmp, 1, res_size, 0);
+        for (size_t j = 0; j < cols; ++j) {
+            if (j == i) continue;
+            if (j < i) {
+                size_t col_j = j * cols - (j * (j + 1) / 2);
+                pzr_vec_znx_assign_op(1, n, res, tcols, res_size, col_j + i, tmp, 1, res_size, 0);
+            } else if (add_assign) {
+                pzr_vec_znx_assign_op(1, n, res, tcols, res_size, col_i + j, tmp, 1, res_size, 0);
+            } else {
+                pzr_vec_znx_negate(n, res, tcols, res_size, col_i + j, tmp, 1, res_size, 0);
+            }
+        }
+    }
+    for (size_t i = 0; i < cols; ++i) {
+        size_t col_i = i * cols - (i * (i + 1) / 2);
+        for (size_t j = i + 1; j < cols; ++j) {
+            tensor_term(t, hi, lo, dft_size, tmp, res_size, res_base2k, a_prep, a_size, b_prep, b_size, ab_base2k, i, j);
+            pzr_vec_znx_assign_op(0, n, res, tcols, res_size, col_i + j, tmp, 1, res_size, 0);
+        }
+    }
+    free(tmp); free(a_prep); free(b_prep);
+}
+
+/* operations/glwe.rs:609-698 (glwe_tensor_square_apply) */
+void pzr_glwe_tensor_square_apply(const pzr_tables* t, size_t rank, size_t cnv_offset,
+                                  int64_t* res, size_t res_size, size_t res_base2k,
+                                  const int64_t* a, size_t a_size, size_t a_effective_k, size_t a_base2k) {
+    size_t n = t->m << 1;
+    size_t cols = rank + 1, tcols = cols * (cols + 1) / 2;
+    double* a_prep = (double*)calloc(n * cols * a_size, sizeof(double));
+    double* b_prep = (double*)calloc(n * cols * a_size, sizeof(double));
+    pzr_cnv_prepare_self(t, a_prep, b_prep, cols, a_size, a, cols, a_size, pzr_msb_mask_bottom_limb(a_base2k, a_effective_k));
+    int64_t* diag = (int64_t*)calloc(n * cols * res_size, sizeof(int64_t));
+    size_t hi;
+    int64_t lo;
+    if (cnv_offset < a_base2k) { hi = 0; lo = -(int64_t)(a_base2k - (cnv_offset % a_base2k)); }
+    else { size_t q = cnv_offset / a_base2k; hi = q ? q - 1 : 0; lo = (int64_t)(cnv_offset % a_base2k); }
+    size_t dft_size = normalize_input_limb_bound_with_offset(2 * a_size - hi, res_size, res_base2k, a_base2k, lo);
+    int64_t* tmp = (int64_t*)calloc(n * res_size, sizeof(int64_t));
+    for (size_t i = 0; i < cols; ++i) {
+        size_t col_i = i * cols - (i * (i + 1) / 2);
+        tensor_term(t, hi, lo, dft_size, tmp, res_size, res_base2k, a_prep, a_size, b_prep, a_size, a_base2k, i, i);
+        pzr_vec_znx_copy(n, diag, cols, res_size, i, tmp, 1, res_size, 0);            /* normalized straight into diag_terms col i */
+        pzr_vec_znx_copy(n, res, tcols, res_size, col_i + i, diag, cols, res_size, i);
+    }
+    for (size_t i = 0; i < cols; ++i) {
+        size_t col_i = i * cols - (i * (i + 1) / 2);
+        for (size_t j = i + 1; j < cols; ++j) {
+            tensor_term(t, hi, lo, dft_size, tmp, res_size, res_base2k, a_prep, a_size, b_prep, a_size, a_base2k, i, j);
+            pzr_vec_znx_copy(n, res, tcols, res_size, col_i + j, tmp, 1, res_size, 0); /* normalized straight into res col */
+            pzr_vec_znx_assign_op(1, n, res, tcols, res_size, col_i + j, diag, cols, res_size, i);
+            pzr_vec_znx_assign_op(1, n, res, tcols, res_size, col_i + j, diag, cols, res_size, j);
+        }
+    }
+    free(tmp); free(diag); free(a_prep); free(b_prep);
+}
+
+/* operations/glwe.rs:541-607 (glwe_tensor_relinearize): a = GLWETensor data VecZnx(cols + pairs, a_size); the `pairs` = rank (rank + 1) / 2
+ * columns behind the first cols are key-switched by tsk (prepared GGLWE pairs -> rank, tsk_size limbs) and the first cols are
+ * added to the big value.  NOTE (:588-598): the un-normalized a is added whenever res_base2k == key_base2k, even if a_base2k
+ * differs; restated literally. */
+void pzr_glwe_tensor_relinearize(const pzr_tables* t, size_t rank,
+                                 int64_t* res, size_t res_size, size_t res_base2k,
+                                 const int64_t* a, size_t a_size, size_t a_base2k,
+                                 const double* tsk_pmat, size_t dnum, size_t tsk_size, size_t dsize, size_t key_base2k) {
+    size_t n = t->m << 1;
+    size_t cols = rank + 1, pairs = rank * (rank + 1) / 2, acols = cols + pairs;
+    size_t a_dft_size = div_ceil(a_size * a_base2k, key_base2k);
+    double* a_dft = (double*)calloc(n * pairs * a_dft_size + 8, sizeof(double));
+    int64_t* a_conv = (int64_t*)calloc(n * a_dft_size, sizeof(int64_t));
+    if (a_base2k != key_base2k) {
+        for (size_t i = 0; i < pairs; ++i) {
+            pzr_vec_znx_normalize(n, a_conv, 1, a_dft_size, key_base2k, 0, 0, a, acols, a_size, a_base2k, cols + i);
+            pzr_vec_znx_dft_apply(t, 1, 0, a_dft, pairs, a_dft_size, i, a_conv, 1, a_dft_size, 0);
+        }
+    } else {
+        for (size_t i = 0; i < pairs; ++i) pzr_vec_znx_dft_apply(t, 1, 0, a_dft, pairs, a_dft_size, i, a, acols, a_size, cols + i);
+    }
+    double* res_dft = (double*)calloc(n * cols * tsk_size, sizeof(double));
+    gglwe_product_dft(n, res_dft, cols, tsk_size, a_dft, pairs, a_dft_size, tsk_pmat, dnum, dsize);
+    pzr_vec_znx_idft_apply_consume(t, res_dft, cols, tsk_size);
+    int64_t* res_big = (int64_t*)res_dft;
+    if (res_base2k == key_base2k) {
+        for (size_t i = 0; i < cols; ++i) pzr_vec_znx_big_add_small_assign(n, res_big, cols, tsk_size, i, a, acols, a_size, i);
+    } else {
+        for (size_t i = 0; i < cols; ++i) {
+            pzr_vec_znx_normalize(n, a_conv, 1, a_dft_size, key_base2k, 0, 0, a, acols, a_size, a_base2k, i);
+            pzr_vec_znx_big_add_small_assign(n, res_big, cols, tsk_size, i, a_conv, 1, a_dft_size, 0);
+        }
+    }
+    for (size_t i = 0; i < cols; ++i)
+        pzr_vec_znx_normalize(n, res, cols, res_size, res_base2k, 0, i, res_big, cols, tsk_size, key_base2k, i);
+    free(a_dft); free(a_conv); free(res_dft);
+}

@@ -226,6 +226,38 @@ void pzr_circuit_bootstrap_to_exponent(const pzr_tables* t, size_t rank, size_t 
                                        size_t log_gap_in, size_t log_gap_out, size_t log_domain,
                                        const double* const* tsk, size_t tsk_dnum, size_t tsk_size);
 
+/* reference/fft64/convolution.rs (HalImpl cnv_*, poulpy-hal/src/oep/hal_impl.rs:670-754).  CnvPVecL / CnvPVecR bytes (FFT64):
+ * [col][blk < m/4][limb < size][re x4 | im x4]; a / b below are such buffers of (cols, a_size) / (cols, b_size). */
+size_t pzr_cnv_prepare_tmp_bytes(size_t n, size_t res_size, size_t a_size);
+void pzr_cnv_prepare(const pzr_tables* t, double* res, size_t res_cols, size_t res_size,
+                     const int64_t* a, size_t a_cols, size_t a_size, int64_t mask);
+void pzr_cnv_prepare_self(const pzr_tables* t, double* left, double* right, size_t cols, size_t size,
+                          const int64_t* a, size_t a_cols, size_t a_size, int64_t mask);
+size_t pzr_cnv_apply_dft_tmp_bytes(size_t res_size, size_t a_size, size_t b_size);
+size_t pzr_cnv_pairwise_apply_dft_tmp_bytes(size_t res_size, size_t a_size, size_t b_size);
+size_t pzr_cnv_by_const_apply_tmp_bytes(size_t res_size, size_t a_size, size_t b_size);
+void pzr_cnv_apply_dft(size_t n, size_t cnv_offset, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                       const double* a, size_t a_size, size_t a_col, const double* b, size_t b_size, size_t b_col);
+void pzr_cnv_pairwise_apply_dft(size_t n, size_t cnv_offset, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                                const double* a, size_t a_size, const double* b, size_t b_size, size_t col_i, size_t col_j);
+void pzr_cnv_by_const_apply(size_t n, size_t cnv_offset, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                            const int64_t* a, size_t a_cols, size_t a_size, size_t a_col, const int64_t* b, size_t b_size);
+
+/* poulpy-core/src/operations/glwe.rs: msb_mask_bottom_limb :921-926; glwe_tensor_apply :700-807 / _add_assign :809-913;
+ * glwe_tensor_square_apply :609-698; glwe_tensor_relinearize :541-607.  GLWETensor data = VecZnx((rank+1)(rank+2)/2, size). */
+int64_t pzr_msb_mask_bottom_limb(size_t base2k, size_t k);
+void pzr_glwe_tensor_apply(const pzr_tables* t, size_t rank, size_t cnv_offset, int add_assign,
+                           int64_t* res, size_t res_size, size_t res_base2k,
+                           const int64_t* a, size_t a_size, size_t a_effective_k,
+                           const int64_t* b, size_t b_size, size_t b_effective_k, size_t ab_base2k);
+void pzr_glwe_tensor_square_apply(const pzr_tables* t, size_t rank, size_t cnv_offset,
+                                  int64_t* res, size_t res_size, size_t res_base2k,
+                                  const int64_t* a, size_t a_size, size_t a_effective_k, size_t a_base2k);
+void pzr_glwe_tensor_relinearize(const pzr_tables* t, size_t rank,
+                                 int64_t* res, size_t res_size, size_t res_base2k,
+                                 const int64_t* a, size_t a_size, size_t a_base2k,
+                                 const double* tsk_pmat, size_t dnum, size_t tsk_size, size_t dsize, size_t key_base2k);
+
 #ifdef __cplusplus
 }
 #endif

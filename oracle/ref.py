@@ -38,8 +38,10 @@ def load(fast: bool = False) -> C.CDLL:
     lib.pzr_tables_omg_fft.argtypes = [c_void_p]
     lib.pzr_tables_omg_ifft.argtypes = [c_void_p]
     for name in ("pzr_vmp_prepare_tmp_bytes", "pzr_vmp_apply_dft_to_dft_tmp_bytes", "pzr_vmp_apply_dft_tmp_bytes",
-                 "pzr_vec_znx_normalize_tmp_bytes"):
+                 "pzr_vec_znx_normalize_tmp_bytes", "pzr_cnv_prepare_tmp_bytes", "pzr_cnv_apply_dft_tmp_bytes",
+                 "pzr_cnv_pairwise_apply_dft_tmp_bytes", "pzr_cnv_by_const_apply_tmp_bytes"):
         getattr(lib, name).restype = c_size_t
+    lib.pzr_msb_mask_bottom_limb.restype = c_int64
     return lib
 
 
@@ -390,3 +392,73 @@ class RefModule:
         ptrs = (c_void_p * ns)(*[pm.data.ctypes.data for pm in pmats])
         self.lib.pzr_glwe_trace_assign(self.t, c_size_t(rank), _p(res.data), *_sz(res.size, base2k), c_size_t(ns), g, ptrs,
                                        *_sz(pmats[0].rows, pmats[0].size, dsize))
+
+    # convolution family (reference/fft64/convolution.rs; HalImpl cnv_*, hal_impl.rs:670-754)
+    def cnv_pvec_left_alloc(self, cols, size):
+        from poulpy_amd.layouts import CnvPVecL
+        return CnvPVecL(self._n, cols, size)
+
+    def cnv_pvec_right_alloc(self, cols, size):
+        from poulpy_amd.layouts import CnvPVecR
+        return CnvPVecR(self._n, cols, size)
+
+    def cnv_prepare_left_tmp_bytes(self, res_size, a_size):
+        return self.lib.pzr_cnv_prepare_tmp_bytes(*_sz(self._n, res_size, a_size))
+
+    cnv_prepare_right_tmp_bytes = cnv_prepare_left_tmp_bytes
+    cnv_prepare_self_tmp_bytes = cnv_prepare_left_tmp_bytes
+
+    def cnv_apply_dft_tmp_bytes(self, cnv_offset, res_size, a_size, b_size):
+        return self.lib.pzr_cnv_apply_dft_tmp_bytes(*_sz(res_size, a_size, b_size))
+
+    def cnv_pairwise_apply_dft_tmp_bytes(self, cnv_offset, res_size, a_size, b_size):
+        return self.lib.pzr_cnv_pairwise_apply_dft_tmp_bytes(*_sz(res_size, a_size, b_size))
+
+    def cnv_by_const_apply_tmp_bytes(self, cnv_offset, res_size, a_size, b_size):
+        return self.lib.pzr_cnv_by_const_apply_tmp_bytes(*_sz(res_size, a_size, b_size))
+
+    def cnv_prepare_left(self, res, a, mask=-1, scratch=None):
+        assert res.cols == a.cols
+        self.lib.pzr_cnv_prepare(self.t, _p(res.data), *_sz(res.cols, res.size), _p(a.data), *_sz(a.cols, a.size), c_int64(mask))
+
+    cnv_prepare_right = cnv_prepare_left
+
+    def cnv_prepare_self(self, left, right, a, mask=-1, scratch=None):
+        assert left.cols == right.cols == a.cols and left.size == right.size
+        self.lib.pzr_cnv_prepare_self(self.t, _p(left.data), _p(right.data), *_sz(left.cols, left.size), _p(a.data),
+                                      *_sz(a.cols, a.size), c_int64(mask))
+
+    def cnv_apply_dft(self, cnv_offset, res, res_col, a, a_col, b, b_col, scratch=None):
+        self.lib.pzr_cnv_apply_dft(*_sz(self._n, cnv_offset), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                   *_sz(a.size, a_col), _p(b.data), *_sz(b.size, b_col))
+
+    def cnv_pairwise_apply_dft(self, cnv_offset, res, res_col, a, b, i, j, scratch=None):
+        self.lib.pzr_cnv_pairwise_apply_dft(*_sz(self._n, cnv_offset), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                            c_size_t(a.size), _p(b.data), *_sz(b.size, i, j))
+
+    def cnv_by_const_apply(self, cnv_offset, res, res_col, a, a_col, b, scratch=None):
+        b = np.ascontiguousarray(b, dtype=np.int64)
+        self.lib.pzr_cnv_by_const_apply(*_sz(self._n, cnv_offset), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                        *_sz(a.cols, a.size, a_col), _p(b), c_size_t(b.size))
+
+    # GLWE tensoring (poulpy-core/src/operations/glwe.rs:541-913)
+    def msb_mask_bottom_limb(self, base2k, k) -> int:
+        return int(self.lib.pzr_msb_mask_bottom_limb(*_sz(base2k, k)))
+
+    def glwe_tensor_apply(self, cnv_offset, res, res_base2k, a, a_effective_k, b, b_effective_k, ab_base2k, add_assign=False):
+        rank = a.cols - 1
+        assert res.cols == (rank + 1) * (rank + 2) // 2 and b.cols == a.cols
+        self.lib.pzr_glwe_tensor_apply(self.t, *_sz(rank, cnv_offset), C.c_int(int(add_assign)), _p(res.data), *_sz(res.size, res_base2k),
+                                       _p(a.data), *_sz(a.size, a_effective_k), _p(b.data), *_sz(b.size, b_effective_k, ab_base2k))
+
+    def glwe_tensor_square_apply(self, cnv_offset, res, res_base2k, a, a_effective_k, a_base2k):
+        rank = a.cols - 1
+        assert res.cols == (rank + 1) * (rank + 2) // 2
+        self.lib.pzr_glwe_tensor_square_apply(self.t, *_sz(rank, cnv_offset), _p(res.data), *_sz(res.size, res_base2k), _p(a.data),
+                                              *_sz(a.size, a_effective_k, a_base2k))
+
+    def glwe_tensor_relinearize(self, res, res_base2k, a, a_base2k, tsk_pmat, dsize, key_base2k):
+        rank = res.cols - 1
+        assert a.cols == (rank + 1) * (rank + 2) // 2
+        self.lib.pzr_glwe_tensor_relinearize(self.t, c_size_t(rank), _p(res.data), *_sz(res.size, res_base2k), _p(a.data),
+                                             *_sz(a.size, a_base2k), _p(tsk_pmat.data), *_sz(tsk_pmat.rows, tsk_pmat.size, dsize, key_base2k))

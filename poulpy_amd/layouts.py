@@ -81,6 +81,17 @@ class SvpPPol(_Znx):
         super().__init__(n, cols, 1, data)
 
 
+class CnvPVecL(_Znx):
+    """poulpy-hal/src/layouts/convolution.rs — prepared left operand of the bivariate convolution (ScalarPrep = f64, opaque bytes:
+    n * cols * size scalars, module.rs:66-69)."""
+    dtype = np.float64
+
+
+class CnvPVecR(_Znx):
+    """poulpy-hal/src/layouts/convolution.rs — prepared right operand (same byte size)."""
+    dtype = np.float64
+
+
 class MatZnx:
     """poulpy-hal/src/layouts/mat_znx.rs:28-35,161-181: entry (row, col_in) is a VecZnx(cols_out, size)."""
 
