@@ -97,7 +97,7 @@ def cpu_baseline(sample_cts_per_thread: int = 4, max_threads: int | None = None)
                       f"{sample_cts_per_thread}, oracle/fft64_ref.c built -O3 -march=native, {dt:.2f} s wall"}
 
 
-def parity_sample(args, mod, a, res, mat_host, lo, nct, ks, auto_mode, unsupported, cols, cols_in) -> dict:
+def parity_sample(args, mod, a, res, mat_host, lo, nct, ks, auto_mode, unsupported, cols, cols_in, relin=False) -> dict:
     """Checks `--parity-samples` ciphertexts of the timed output (first, last, and indices spread over the tiles / XCD slots /
     the last partial wave of the launch) against the CPU oracle on the same inputs, bit for bit.  The oracle is the checker
     only: nothing here is timed."""
@@ -122,9 +122,11 @@ def parity_sample(args, mod, a, res, mat_host, lo, nct, ks, auto_mode, unsupport
     ref.vmp_prepare(pm, mat)
     bad = []
     for i in picks:
-        ai = VecZnx(N, cols, SIZE, a[i].cpu().numpy())
+        ai = VecZnx(N, a.shape[2], SIZE, a[i].cpu().numpy())
         want = VecZnx(N, cols, SIZE)
-        if auto_mode:
+        if relin:
+            ref.glwe_tensor_relinearize(want, BASE2K, ai, BASE2K, pm, 1, BASE2K)
+        elif auto_mode:
             ref.glwe_automorphism(want, BASE2K, ai, BASE2K, pm, 1, BASE2K, 5, auto_mode)
         elif ks:
             ref.glwe_keyswitch(want, BASE2K, ai, BASE2K, pm, 1, BASE2K)
@@ -143,9 +145,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="ciphertexts per GPU per step (16 GiB of GLWE in + out at the metric shape)")
     ap.add_argument("--chunk", type=int, default=0, help="ciphertexts per pipeline wave (0 = auto)")
-    ap.add_argument("--op", choices=("external_product", "keyswitch", "automorphism", "automorphism_add", "trace", "ggsw_expand_row"), default="external_product",
+    ap.add_argument("--op", choices=("external_product", "keyswitch", "automorphism", "automorphism_add", "trace", "ggsw_expand_row", "relinearize"), default="external_product",
                     help="keyswitch = BASELINE configs[2] (secondary metric; GGLWE rows 8, cols_in 1, cols_out 2); automorphism[_add] = "
-                         "glwe_automorphism[_add] with Galois element 5 on the same key shape (CKKS-rotate shape of configs[4])")
+                         "glwe_automorphism[_add] with Galois element 5 on the same key shape (CKKS-rotate shape of configs[4]); "
+                         "relinearize = glwe_tensor_relinearize of a rank-1 GLWETensor (3 columns) with a tensor key 1 -> 1 "
+                         "(--limbs 16: the relinearize half of configs[4])")
     ap.add_argument("--n", type=int, default=0, help="override the ring degree (0 = 65536, the metric configuration); "
                                                      "--n 4096 --limbs 4 --base2k 17 --batch 1024 = BASELINE configs[1]")
     ap.add_argument("--base2k", type=int, default=0)
@@ -195,6 +199,8 @@ def main():
     auto_mode = {"automorphism": "automorphism", "automorphism_add": "add"}.get(args.op)
     trace = args.op == "trace"   # full glwe_trace: log2(N) steps of rsh + glwe_automorphism_add_assign, one key per step
     expand = args.op == "ggsw_expand_row"   # batch/dnum GGSWs per step, each dnum rows x rank key switches (body on column col)
+    relin = args.op == "relinearize"        # operations/glwe.rs:541-607: tensor of cols + pairs columns -> GLWE
+    a_cols = cols + RANK_GLWE * (RANK_GLWE + 1) // 2 if relin else cols
     cols_in = RANK_GLWE if ks else cols
     key_elems = N * DNUM * cols_in * cols * SIZE
     pmat = torch.empty(key_elems, dtype=torch.float64, device=dev)
@@ -217,7 +223,7 @@ def main():
     nct = hi - lo
     # ciphertext i of the global batch is drawn from its own stream, seed 0x5eed0000 + i, whatever the sharding
     g = torch.Generator(device=dev)
-    a = torch.empty((nct, SIZE, cols, N), dtype=torch.int64, device=dev)
+    a = torch.empty((nct, SIZE, a_cols, N), dtype=torch.int64, device=dev)
     for i in range(nct):
         g.manual_seed(0x5EED0000 + lo + i)
         a[i].random_(-half, half, generator=g)
@@ -250,6 +256,8 @@ def main():
             mod.glwe_trace_batched(res_ptr, trace_gals, [t.data_ptr() for t in trace_keys], params, nct)
         elif expand:
             mod.ggsw_expand_row_batched(res_ptr, DNUM, [key_ptr] * RANK_GLWE, params, nct // DNUM)
+        elif relin:
+            mod.glwe_tensor_relinearize_batched(res_ptr, a_ptr, key_ptr, params, nct)
         elif auto_mode:
             mod.glwe_automorphism_batched(res_ptr, a_ptr, key_ptr, params, 5, auto_mode, nct)
         elif ks:
@@ -275,7 +283,7 @@ def main():
     dt = time.perf_counter() - t0
 
     # timed output of the LAST step -> parity sample against the CPU oracle (taken before the instrumented pass re-runs the op)
-    parity = parity_sample(args, mod, a, res, mat_host, lo, nct, ks, auto_mode, trace or expand, cols, cols_in) if args.parity_samples else None
+    parity = parity_sample(args, mod, a, res, mat_host, lo, nct, ks, auto_mode, trace or expand, cols, cols_in, relin) if args.parity_samples else None
 
     # roofline leg: the same steps again with one HIP-event pair per launch on the module stream
     stats = {}
@@ -311,7 +319,7 @@ def main():
     if rank == 0:
         total_units = args.batch * world * args.steps // (DNUM if expand else 1)
         value = total_units / dt
-        b_unit = algorithmic_bytes_per_unit(args.batch) if not ks else (2 * cols * SIZE * N * 8 + DNUM * cols_in * cols * SIZE * N * 8 / args.batch)
+        b_unit = algorithmic_bytes_per_unit(args.batch) if not ks else ((a_cols + cols) * SIZE * N * 8 + DNUM * cols_in * cols * SIZE * N * 8 / args.batch)
         roof = None
         if stats:
             dom = max(stats.items(), key=lambda kv: kv[1][1])
@@ -327,13 +335,15 @@ def main():
                         "pipeline_achieved": value * (DNUM if expand else 1) / world * b_unit / 1e9,
                         "kernel_ms": {k: round(v[1], 3) for k, v in stats.items() if v[0]}}
         line = {
-            "metric": (f"GGSW expand-rows/sec (N=2^{N.bit_length() - 1}, {SIZE} limbs, {DNUM} rows)" if expand else
+            "metric": (f"GLWE tensor relinearizations/sec (N=2^{N.bit_length() - 1}, {SIZE} limbs)" if relin else
+                       f"GGSW expand-rows/sec (N=2^{N.bit_length() - 1}, {SIZE} limbs, {DNUM} rows)" if expand else
                        f"GLWE {args.op.replace('_', ' ')}s/sec (N=2^{N.bit_length() - 1}, {SIZE} limbs)" if (auto_mode or trace) else
                        f"GLWE key-switches/sec (N=2^{N.bit_length() - 1}, {SIZE} limbs)" if ks else f"GGSW external-products/sec (N=2^{N.bit_length() - 1}, {SIZE} limbs)"),
-            "value": value, "unit": ("GGSWs/s" if expand else f"{args.op}s/s" if (auto_mode or trace) else "key-switches/s" if ks else "external-products/s"),
+            "value": value, "unit": ("relinearizations/s" if relin else "GGSWs/s" if expand else f"{args.op}s/s" if (auto_mode or trace) else "key-switches/s" if ks else "external-products/s"),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"ggsw_expand_row on batch/{DNUM} GGSWs of {DNUM} rows (rank {RANK_GLWE}: one key switch per row, body on column 1), N={N}, {SIZE} limbs, base2k={BASE2K}, key dnum={DNUM}" if expand else
+            "config": {"workload": (f"glwe_tensor_relinearize (rank 1: 3-column GLWETensor, tensor key 1 -> 1 via GGLWE VmpPMat), N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize=1" if relin else
+                                    f"ggsw_expand_row on batch/{DNUM} GGSWs of {DNUM} rows (rank {RANK_GLWE}: one key switch per row, body on column 1), N={N}, {SIZE} limbs, base2k={BASE2K}, key dnum={DNUM}" if expand else
                                     f"glwe_trace (log2 N steps of rsh + glwe_automorphism_add_assign, one key per step), N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}" if trace else
                                     f"glwe_{args.op} (Galois element 5) via GGLWE VmpPMat, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize=1" if auto_mode else
                                     f"GLWE(rank 1) key-switch via GGLWE VmpPMat, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize=1" if ks else

@@ -169,9 +169,12 @@ int pz_vmp_apply_dft(pz_module* m, double* res, size_t res_cols, size_t res_size
 /* hal_impl.rs:643 */
 size_t pz_vmp_apply_dft_to_dft_tmp_bytes(const pz_module* m, size_t res_size, size_t a_size,
                                          size_t b_rows, size_t b_cols_in, size_t b_cols_out, size_t b_size);
-/* hal_impl.rs:653 vmp_apply_dft_to_dft.  limb_offset > 0 follows the NTT120 sibling's
- * semantics: every limb of res is written, limbs with no pmat column are zeroed
- * (SURVEY.md A.2). */
+/* hal_impl.rs:653 vmp_apply_dft_to_dft.  DEVIATION for limb_offset > 0: cpu-ref's FFT64 core clamps the key columns it reads to
+ * res_size and leaves the last limb_offset limbs of res unwritten (stale scratch, vmp.rs:217-263); this backend follows the NTT120
+ * sibling's semantics instead (reference/ntt120/vmp.rs:190,281-287): res[c] = sum_r a[r] * P[r][c + off] for every c with a key
+ * column, zero beyond — every limb of res is written.  Byte parity with FFT64Ref is therefore claimed for
+ * limb_offset = 0 (dsize = 1: every BASELINE config) only; limb_offset > 0 (the dsize > 1 callers) is validated against the exact
+ * bivariate product. */
 int pz_vmp_apply_dft_to_dft(pz_module* m, double* res, size_t res_cols, size_t res_size,
                             const double* a, size_t a_cols, size_t a_size,
                             const double* pmat, size_t rows, size_t cols_in, size_t cols_out, size_t size,
@@ -326,6 +329,68 @@ int pz_ggsw_expand_row_batched(pz_module* m, int64_t* ggsw, size_t dnum, const d
  * GGSW) -> `count` contiguous GGSWs: entries (row, 0) are copied from a.at(row, 0), then pz_ggsw_expand_row_batched. */
 int pz_ggsw_from_gglwe_batched(pz_module* m, int64_t* ggsw, const int64_t* a, size_t a_cols_in, size_t dnum,
                                const double* const* tsk_pmat, const pz_glwe_op_params* p, size_t count);
+/* ---- convolution family (BASELINE configs[4], CKKS tensoring) ----------------------------- *
+ * Bivariate convolution over Z[X, Y]/(X^N + 1), Y = 2^-base2k (poulpy-hal/src/api/convolution.rs; reference
+ * poulpy-cpu-ref/src/reference/fft64/convolution.rs).  CnvPVecL / CnvPVecR (ScalarPrep = f64) are opaque prepared operands of
+ * n * cols * size scalars (module.rs:66-73), passed as (ptr, cols, size); in this backend polynomial (col, limb) is its spectrum
+ * in device order at (col*size + limb)*n.  Host or device pointers, like every per-op entry point.
+ * cnv_apply_dft: res limb k (k < min(res_size, a_size + b_size - 1)) = sum_j a[k + offset - j] * b[j], offset = min(cnv_offset,
+ * a_size + b_size - 1); the other limbs of column res_col are zeroed.  NOTE: the reference's FFT64 implementation stores the
+ * product at the raw start of `res` (convolution.rs:232, :251), i.e. it is only meaningful for a one-column res with
+ * res_col = 0, which is what every caller passes; this backend writes column res_col of a res with any number of columns. */
+/* hal_impl.rs:670 */
+size_t pz_cnv_prepare_left_tmp_bytes(const pz_module* m, size_t res_size, size_t a_size);
+/* hal_impl.rs:672 cnv_prepare_left: DFT of every limb of every column; `mask` is ANDed into the coefficients of the last active
+ * limb min(res_size, a_size) - 1 (convolution.rs:56-61); limbs beyond it are zero */
+int pz_cnv_prepare_left(pz_module* m, double* res, size_t res_cols, size_t res_size,
+                        const int64_t* a, size_t a_cols, size_t a_size, int64_t mask);
+/* hal_impl.rs:677, :679 */
+size_t pz_cnv_prepare_right_tmp_bytes(const pz_module* m, size_t res_size, size_t a_size);
+int pz_cnv_prepare_right(pz_module* m, double* res, size_t res_cols, size_t res_size,
+                         const int64_t* a, size_t a_cols, size_t a_size, int64_t mask);
+/* hal_impl.rs:684, :686 */
+size_t pz_cnv_apply_dft_tmp_bytes(const pz_module* m, size_t cnv_offset, size_t res_size, size_t a_size, size_t b_size);
+size_t pz_cnv_by_const_apply_tmp_bytes(const pz_module* m, size_t cnv_offset, size_t res_size, size_t a_size, size_t b_size);
+/* hal_impl.rs:695 cnv_by_const_apply: i64 domain, res (VecZnxBig) limb k = sum_j a[k + offset - j] * b[j] (wrapping), b = b_len constants */
+int pz_cnv_by_const_apply(pz_module* m, size_t cnv_offset, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                          const int64_t* a, size_t a_cols, size_t a_size, size_t a_col, const int64_t* b, size_t b_len);
+/* hal_impl.rs:709 cnv_apply_dft */
+int pz_cnv_apply_dft(pz_module* m, size_t cnv_offset, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                     const double* a, size_t a_cols, size_t a_size, size_t a_col,
+                     const double* b, size_t b_cols, size_t b_size, size_t b_col);
+/* hal_impl.rs:724, :733 cnv_pairwise_apply_dft: (a[i] + a[j]) * (b[i] + b[j]); i == j: a[i] * b[i] */
+size_t pz_cnv_pairwise_apply_dft_tmp_bytes(const pz_module* m, size_t cnv_offset, size_t res_size, size_t a_size, size_t b_size);
+int pz_cnv_pairwise_apply_dft(pz_module* m, size_t cnv_offset, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                              const double* a, size_t a_cols, size_t a_size, const double* b, size_t b_cols, size_t b_size,
+                              size_t col_i, size_t col_j);
+/* hal_impl.rs:748, :750 cnv_prepare_self: left and right prepared from the same `a` (both (cols, size)) */
+size_t pz_cnv_prepare_self_tmp_bytes(const pz_module* m, size_t res_size, size_t a_size);
+int pz_cnv_prepare_self(pz_module* m, double* left, double* right, size_t cols, size_t size,
+                        const int64_t* a, size_t a_cols, size_t a_size, int64_t mask);
+
+/* GLWE tensoring on `batch` device-resident ciphertext pairs (poulpy-core/src/operations/glwe.rs): PZ_TENSOR_APPLY glwe_tensor_apply
+ * :700-807, PZ_TENSOR_APPLY_ADD_ASSIGN glwe_tensor_apply_add_assign :809-913, PZ_TENSOR_SQUARE glwe_tensor_square_apply :609-698
+ * (b is ignored).  a / b: batch GLWEs (rank+1 columns, a_size / b_size limbs, one base2k); res: batch GLWETensors =
+ * VecZnx((rank+1)(rank+2)/2, res_size), the pair (i, j >= i) in column i*(rank+1) - i*(i+1)/2 + j.  a_effective_k / b_effective_k:
+ * the callers' precision in bits (div_ceil(base2k) must equal the size; the bits below it in the bottom limb are masked). */
+typedef struct {
+    uint64_t rank;
+    uint64_t a_size, b_size, ab_base2k;
+    uint64_t a_effective_k, b_effective_k;
+    uint64_t res_size, res_base2k;
+    uint64_t cnv_offset;
+} pz_glwe_tensor_params;
+enum { PZ_TENSOR_APPLY = 0, PZ_TENSOR_APPLY_ADD_ASSIGN = 1, PZ_TENSOR_SQUARE = 2 };
+size_t pz_glwe_tensor_apply_workspace_bytes(const pz_module* m, const pz_glwe_tensor_params* p, int mode, size_t batch);
+int pz_glwe_tensor_apply_batched(pz_module* m, int64_t* res, const int64_t* a, const int64_t* b, const pz_glwe_tensor_params* p, int mode,
+                                 size_t batch);
+/* glwe_tensor_relinearize (operations/glwe.rs:541-607) on `batch` GLWETensors `a` (VecZnx((rank+1)(rank+2)/2, p->a_size)) sharing one
+ * prepared tensor key tsk_pmat (GGLWE rank*(rank+1)/2 -> rank: rows = p->dnum, cols_in = rank*(rank+1)/2, cols_out = rank+1,
+ * size = p->key_size): the pair columns are key-switched, the first rank+1 columns are added to the big value, res = batch GLWEs
+ * (rank+1, p->res_size).  Runs on the fused three-kernel pipeline for dsize = 1 and equal base2k (the configs[4] case). */
+int pz_glwe_tensor_relinearize_batched(pz_module* m, int64_t* res, const int64_t* a, const double* tsk_pmat, const pz_glwe_op_params* p,
+                                       size_t batch);
+
 /* BlindRotationExecute<CGGI>::blind_rotation_execute (poulpy-bin-fhe/src/blind_rotation/algorithms/cggi/algorithm.rs:76-118)
  * on `batch` LWE ciphertexts that share the lookup table and the prepared blind-rotation key:
  *   block_size > 1 : execute_block_binary  (:265-368)       block_size == 1 : execute_standard (:370-440)

@@ -11,121 +11,9 @@
 #include <algorithm>
 #include <vector>
 
-#include "internal.hpp"
+#include "api_common.hpp"
 
 using namespace pz;
-
-// multiplicative inverse of an odd p modulo 2n (n a power of two): Newton iteration doubles the valid bits
-static unsigned inv_mod_2n(long long p, long long n) {
-    const unsigned long long mask = 2ull * (unsigned long long)n - 1ull;
-    const unsigned long long a = (unsigned long long)p & mask;
-    unsigned long long x = a;  // correct to 3 bits
-    for (int i = 0; i < 6; ++i) x *= 2ull - a * x;
-    return (unsigned)(x & mask);
-}
-static int ensure_w2n(pz_module* M) {
-    if (M->w2n) return PZ_OK;
-    const long long two_n = 2 * (long long)M->n;
-    std::vector<cplx> h((size_t)two_n);
-    double c, s;
-    for (long long t = 0; t < two_n; ++t) { root_of_unity(t, two_n, c, s); h[(size_t)t] = make_double2(c, s); }
-    return upload_table(&M->w2n, h);
-}
-
-// ------------------------------------------------------------------------------
-// device-level operations (device pointers, batch strides in scalars)
-// ------------------------------------------------------------------------------
-// vec_znx_dft_apply on `ncs` consecutive columns (res_col.., a_col..)  [vec_znx_dft.rs:160-200]
-static int dev_dft_apply(pz_module* M, int batch, int step, int offset, DV res, int res_col, DV a, int a_col, int ncs,
-                         const cplx* mul, cplx* T) {
-    const long long n = (long long)M->n;
-    const int steps = (a.size + step - 1) / step;
-    const int min_steps = std::min(res.size, steps);
-    int nv = 0;
-    if (offset < a.size) nv = std::min(min_steps, (a.size - offset + step - 1) / step);
-    if (nv > 0) {
-        PolyMap sm{nv, ncs, a.bs, (long long)step * a.cols * n, n, n * ((long long)offset * a.cols + a_col)};
-        PolyMap dm{nv, ncs, res.bs, (long long)res.cols * n, n, n * res_col};
-        const int npolys = batch * nv * ncs;
-        PZ_TRY(launch_fwd_pass1(M, npolys, (const long long*)a.p, sm, T));
-        PZ_TRY(launch_fwd_pass2(M, npolys, T, (double*)res.p, dm, mul));
-    }
-    // limbs [nv, min_steps) are left untouched (vec_znx_dft.rs:191-194); the rest is zeroed
-    for (int c = 0; c < ncs; ++c)
-        PZ_TRY(launch_ew(M, EW_ZERO, poly_ptr(M, res, res_col + c, min_steps), res.bs, limb_stride(M, res), nullptr, 0, 0,
-                         nullptr, 0, 0, res.size - min_steps, batch));
-    return PZ_OK;
-}
-
-// inverse transform of `nlimbs` limbs x `ncs` columns: a (f64) -> res (i64)
-static int dev_idft(pz_module* M, int batch, DV res, int res_col, DV a, int a_col, int ncs, int nlimbs, cplx* T) {
-    const long long n = (long long)M->n;
-    if (nlimbs <= 0) return PZ_OK;
-    PolyMap sm{nlimbs, ncs, a.bs, (long long)a.cols * n, n, n * a_col};
-    PolyMap dm{nlimbs, ncs, res.bs, (long long)res.cols * n, n, n * res_col};
-    const int npolys = batch * nlimbs * ncs;
-    PZ_TRY(launch_inv_pass2(M, npolys, (const double*)a.p, sm, T));
-    PZ_TRY(launch_inv_pass1(M, npolys, T, (long long*)res.p, dm));
-    return PZ_OK;
-}
-
-// ------------------------------------------------------------------------------
-// host/device pointer resolution
-// ------------------------------------------------------------------------------
-static bool is_device_ptr(const void* p) {
-    if (!p) return false;
-    hipPointerAttribute_t at;
-    hipError_t e = hipPointerGetAttributes(&at, p);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();  // clear sticky error for unregistered host memory
-        return false;
-    }
-    return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
-}
-
-// A staged argument: device view of a (possibly host) container of `bytes` bytes.
-// Host buffers are copied into the module's staging arena; outputs are copied back by
-// finish_call() after the stream has drained (blocking hipMemcpy: no reliance on the ordering
-// of asynchronous copies into pageable memory).
-struct Stage {
-    pz_module* M = nullptr;
-    void* host = nullptr;
-    void* dev = nullptr;
-    size_t bytes = 0;
-    bool owned = false, out = false;
-    int in(const void* p, size_t nbytes, bool copy_in, bool copy_out, pz_module* mod) {
-        M = mod; bytes = nbytes; out = copy_out;
-        if (nbytes == 0) { dev = (void*)p; return PZ_OK; }
-        if (is_device_ptr(p)) { dev = (void*)p; owned = false; return PZ_OK; }
-        host = (void*)p;
-        owned = true;
-        PZ_TRY(arena_alloc(M, nbytes, &dev));
-        if (copy_in) PZ_HIP(hipMemcpyAsync(dev, host, nbytes, hipMemcpyHostToDevice, M->stream));
-        return PZ_OK;
-    }
-    int finish() {
-        if (owned && out) M->pending_out.push_back({host, dev, bytes});
-        owned = false;
-        return PZ_OK;
-    }
-};
-
-static int finish_call(pz_module* M, bool any_host) {
-    if (any_host || !M->pending_out.empty()) {
-        PZ_HIP(hipStreamSynchronize(M->stream));
-        for (auto& po : M->pending_out) PZ_HIP(hipMemcpy(po.host, po.dev, po.bytes, hipMemcpyDeviceToHost));
-        M->pending_out.clear();
-    }
-    return PZ_OK;
-}
-
-#define PZ_ENTER(M)                                              \
-    if (!(M)) return fail(PZ_ERR_INVALID, "null module");        \
-    std::lock_guard<std::mutex> lock_((M)->mu);                  \
-    PZ_HIP(hipSetDevice((M)->device));                           \
-    arena_reset(M);
-
-static inline size_t vbytes(const pz_module* M, size_t cols, size_t size) { return (size_t)M->n * cols * size * 8; }
 
 // ------------------------------------------------------------------------------
 // HIP graphs for the launch-bound composite calls.  A blind rotation on the composed path is 5 launches per LWE block
@@ -197,8 +85,9 @@ static int with_graph(pz_module* M, uint64_t key, F&& body) {
     (void)hipGetLastError();
     if (g) (void)hipGraphDestroy(g);
     e->failed = true;
-    if (rc != PZ_OK) return rc;
-    return body();  // nothing ran under the failed capture
+    // nothing ran under the failed / invalidated capture (launches issued while capturing only record nodes): run the call plainly,
+    // also when body() reported an error that the broken capture itself produced
+    return body();
 }
 
 // ------------------------------------------------------------------------------
@@ -207,7 +96,7 @@ static int with_graph(pz_module* M, uint64_t key, F&& body) {
 extern "C" {
 
 const char* pz_last_error(void) { return last_error_ref().c_str(); }
-uint32_t pz_abi_version(void) { return 1; }
+uint32_t pz_abi_version(void) { return 2; }
 
 int pz_module_new_on_device(uint64_t n, int device, pz_module** out) {
     if (!out) return fail(PZ_ERR_INVALID, "null out");
@@ -259,6 +148,7 @@ uint64_t pz_module_n(const pz_module* M) { return M ? M->n : 0; }
 int pz_module_device(const pz_module* M) { return M ? M->device : -1; }
 int pz_module_sync(pz_module* M) {
     if (!M) return fail(PZ_ERR_INVALID, "null module");
+    std::lock_guard<std::mutex> lock_(M->mu);
     PZ_HIP(hipSetDevice(M->device));
     PZ_HIP(hipStreamSynchronize(M->stream));
     return PZ_OK;
@@ -266,12 +156,15 @@ int pz_module_sync(pz_module* M) {
 void* pz_module_stream(pz_module* M) { return M ? (void*)M->stream : nullptr; }
 int pz_module_set_chunk(pz_module* M, size_t c) {
     if (!M) return fail(PZ_ERR_INVALID, "null module");
+    std::lock_guard<std::mutex> lock_(M->mu);
     M->graph_epoch++;
     M->chunk = c;
     return PZ_OK;
 }
 int pz_module_set_fusion(pz_module* M, int fuse_tail, int fuse_mid) {
     if (!M) return fail(PZ_ERR_INVALID, "null module");
+    std::lock_guard<std::mutex> lock_(M->mu);
+    M->graph_epoch++;
     M->fuse_tail = fuse_tail != 0;
     M->fuse_mid = fuse_mid != 0;
     return PZ_OK;
@@ -319,6 +212,7 @@ int pz_module_set_graphs(pz_module* M, int enable) {
 uint64_t pz_module_graph_launches(const pz_module* M) { return M ? (uint64_t)M->graph_launches : 0; }
 int pz_module_set_debug_stages(pz_module* M, int mask) {
     if (!M) return fail(PZ_ERR_INVALID, "null module");
+    std::lock_guard<std::mutex> lock_(M->mu);
     M->dbg_stages = mask;
     return PZ_OK;
 }
@@ -395,6 +289,7 @@ int pz_device_alloc(pz_module* M, size_t len, void** out) {
 }
 int pz_device_free(pz_module* M, void* p) {
     if (!M) return fail(PZ_ERR_INVALID, "null module");
+    std::lock_guard<std::mutex> lock_(M->mu);
     PZ_HIP(hipSetDevice(M->device));
     PZ_HIP(hipStreamSynchronize(M->stream));
     if (p) PZ_HIP(hipFree(p));
@@ -402,6 +297,7 @@ int pz_device_free(pz_module* M, void* p) {
 }
 int pz_memcpy_h2d(pz_module* M, void* d, const void* s, size_t len) {
     if (!M) return fail(PZ_ERR_INVALID, "null module");
+    std::lock_guard<std::mutex> lock_(M->mu);
     PZ_HIP(hipSetDevice(M->device));
     PZ_HIP(hipMemcpyAsync(d, s, len, hipMemcpyHostToDevice, M->stream));
     PZ_HIP(hipStreamSynchronize(M->stream));
@@ -409,6 +305,7 @@ int pz_memcpy_h2d(pz_module* M, void* d, const void* s, size_t len) {
 }
 int pz_memcpy_d2h(pz_module* M, void* d, const void* s, size_t len) {
     if (!M) return fail(PZ_ERR_INVALID, "null module");
+    std::lock_guard<std::mutex> lock_(M->mu);
     PZ_HIP(hipSetDevice(M->device));
     PZ_HIP(hipMemcpyAsync(d, s, len, hipMemcpyDeviceToHost, M->stream));
     PZ_HIP(hipStreamSynchronize(M->stream));
@@ -416,6 +313,7 @@ int pz_memcpy_d2h(pz_module* M, void* d, const void* s, size_t len) {
 }
 int pz_memset_d(pz_module* M, void* d, int v, size_t len) {
     if (!M) return fail(PZ_ERR_INVALID, "null module");
+    std::lock_guard<std::mutex> lock_(M->mu);
     PZ_HIP(hipSetDevice(M->device));
     PZ_HIP(hipMemsetAsync(d, v, len, M->stream));
     return PZ_OK;
@@ -441,6 +339,7 @@ int pz_event_destroy(void* ev) {
 }
 int pz_event_record(pz_module* M, void* ev) {
     if (!M) return fail(PZ_ERR_INVALID, "null module");
+    std::lock_guard<std::mutex> lock_(M->mu);
     PZ_HIP(hipEventRecord((hipEvent_t)ev, M->stream));
     return PZ_OK;
 }
@@ -453,13 +352,7 @@ int pz_event_elapsed_ms(void* e0, void* e1, float* ms) {
 // ------------------------------------------------------------------------------
 // public: VecZnxDft
 // ------------------------------------------------------------------------------
-#define PZ_CHECK_COL(col, cols, what) PZ_REQUIRE((col) < (cols), "%s: col %zu >= cols %zu", what, (size_t)(col), (size_t)(cols))
 
-static int need_T(pz_module* M, size_t npolys, cplx** T) {
-    PZ_TRY(ws_reserve(M, npolys * (size_t)M->m * sizeof(cplx)));
-    *T = (cplx*)M->ws;
-    return PZ_OK;
-}
 
 int pz_vec_znx_dft_apply(pz_module* M, size_t step, size_t offset, double* res, size_t res_cols, size_t res_size, size_t res_col,
                          const int64_t* a, size_t a_cols, size_t a_size, size_t a_col) {
@@ -1132,11 +1025,23 @@ int pz_vec_znx_big_automorphism_assign(pz_module* M, int64_t p, int64_t* res, si
 // ------------------------------------------------------------------------------
 struct OpShape {
     int cols_a, cols_in, cols_out;  // columns of `a`, VMP input columns, output columns
+    int a_col0;                     // first column of `a` that enters the product
     int a_size_eff;                 // limbs of `a` in the key's base (after optional conversion)
     bool convert;
 };
-static OpShape op_shape(const pz_glwe_op_params* p, bool ks) {
+// kind: 0 external product, 1 key switch (mask columns 1.. of a GLWE), 2 tensor relinearization (operations/glwe.rs:541-607: `a` is
+// a GLWETensor of cols + pairs columns, the pairs = rank (rank + 1) / 2 columns behind the first cols = rank + 1 are key-switched
+// and the first cols are added to every column of the big value)
+static OpShape op_shape(const pz_glwe_op_params* p, bool ks, bool tensor = false) {
     OpShape s;
+    if (tensor) {
+        const int cols = (int)p->rank + 1, pairs = (int)(p->rank * (p->rank + 1) / 2);
+        s.cols_a = cols + pairs; s.cols_in = pairs; s.cols_out = cols; s.a_col0 = cols;
+        s.convert = p->a_base2k != p->key_base2k;
+        s.a_size_eff = s.convert ? (int)((p->a_size * p->a_base2k + p->key_base2k - 1) / p->key_base2k) : (int)p->a_size;
+        return s;
+    }
+    s.a_col0 = ks ? 1 : 0;
     s.cols_a = (int)p->rank + 1;
     s.cols_in = ks ? (int)p->rank : (int)p->rank + 1;
     s.cols_out = ks ? (int)p->rank_out + 1 : (int)p->rank + 1;
@@ -1196,14 +1101,16 @@ struct OpLayout {
     int body_col;
 };
 static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double* pmat, const pz_glwe_op_params* p, size_t batch,
-                   const AutoSpec* au = nullptr, const OpLayout* lay = nullptr) {
+                   const AutoSpec* au = nullptr, const OpLayout* lay = nullptr, bool tensor = false) {
     PZ_REQUIRE(p != nullptr, "null params");
     PZ_REQUIRE(p->dsize >= 1 && p->dnum >= 1 && p->key_size >= 1 && p->a_size >= 1 && p->res_size >= 1, "glwe op: empty shape");
     PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(a) && is_device_ptr(pmat), "batched entry points take device pointers");
     if (batch == 0) return PZ_OK;
-    const OpShape s = op_shape(p, ks);
+    if (tensor) ks = true;   // the product is gglwe_product_dft, as for a key switch
+    const OpShape s = op_shape(p, ks, tensor);
     const size_t chunk = pick_chunk(M, p, s, batch);
     const long long n = (long long)M->n;
+    PZ_REQUIRE(!(tensor && (au || lay)), "glwe_tensor_relinearize: packed tensors, no automorphism");
     const int dsize = (int)p->dsize, dnum = (int)p->dnum, ksz = (int)p->key_size;
     const long long a_ct = n * s.cols_a * (long long)p->a_size;
     const long long res_ct = n * s.cols_out * (long long)p->res_size;
@@ -1223,7 +1130,8 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
     }
 
     // ---- fully fused pipeline: pass 1 (row-major) | row pass + VMP + inverse row pass | tail ----
-    if (M->fuse_mid && M->fuse_tail && dsize == 1 && p->res_base2k == p->key_base2k && tail_supported(M) && mid_supported(M, npi, npo)) {
+    if (M->fuse_mid && M->fuse_tail && dsize == 1 && p->res_base2k == p->key_base2k && tail_supported(M) && mid_supported(M, npi, npo) &&
+        !(tensor && s.convert)) {
         const size_t key_bytes = align256((size_t)nrows * ncols * (size_t)M->n * 8);
         const size_t conv_bytes = s.convert ? align256(chunk * (size_t)M->n * 8 * s.cols_a * s.a_size_eff) : 0;
         const size_t t_bytes = align256(chunk * (size_t)npi * M->m * sizeof(cplx));
@@ -1258,7 +1166,7 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
                 av = cv;
             }
             const int a_size = av.size;
-            const int a_col0 = ks ? 1 : 0;
+            const int a_col0 = s.a_col0;
             PolyMap sm{a_size, s.cols_in, av.bs, (long long)av.cols * n, n, n * a_col0};
             if (M->dbg_stages & 1) PZ_TRY(launch_fwd_pass1(M, nb * npi, (const long long*)av.p, sm, T, true));
             // X -> X^p with p = 1 mod 4 on the big value (the add / sub / sub_negate forms): DFT(phi(a))[q] = DFT(a)[p q + (p-1)/4 mod m]
@@ -1296,7 +1204,7 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
             // au_big: the operand -+phi^-1(a) (+ body for column 0) is gathered from `a` inside the tail (TailArgs::gather_mul)
             (void)small2;
             if (M->dbg_stages & 4) PZ_TRY(launch_inv_tail(M, nb, T2, ksz, s.cols_out, (long long*)(au ? res_tmp : res_b), au ? res_ct : res_bs, s.cols_out, (int)p->res_size,
-                                   small, small_bs, s.cols_a, a_size, (int)p->res_base2k, true, au_big, au_big ? au_p : 0u, au && au->mode == 3,
+                                   small, small_bs, s.cols_a, a_size, (int)p->res_base2k, true, au_big || tensor, au_big ? au_p : 0u, au && au->mode == 3,
                                    au_big ? au_p : 0u, au_big && au->mode != 1, body_col));
             if (au) {
                 PolyMap tm{(int)p->res_size, s.cols_out, res_ct, (long long)s.cols_out * n, n, 0};
@@ -1326,8 +1234,9 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
                 PZ_TRY(dev_normalize(M, nb, cv, (int)p->key_base2k, 0, c, av, (int)p->a_base2k, c));
             av = cv;
         }
+        const DV raw_av{(void*)(a + (long long)b0 * a_bs), a_bs, s.cols_a, (int)p->a_size};
         const int a_size = av.size;
-        const int a_col0 = ks ? 1 : 0;  // key-switch transforms the mask columns only (keyswitching/glwe.rs:231-234)
+        const int a_col0 = s.a_col0;  // key-switch transforms the mask columns only (keyswitching/glwe.rs:231-234)
         DV rd{res_dft, n * s.cols_out * ksz, s.cols_out, ksz};
         int res_dft_size = ksz;
         if (dsize == 1) {
@@ -1397,12 +1306,21 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
             // inverse pass 2, then the fused tail: inverse pass 1 + body add + carry chain, no VecZnxBig in HBM
             PolyMap sm{res_dft_size, s.cols_out, rb.bs, (long long)s.cols_out * n, n, 0};
             PZ_TRY(launch_inv_pass2(M, nb * res_dft_size * s.cols_out, res_dft, sm, T));
+            // (tensor: every column receives its operand; with a conversion the reference still adds the UN-normalized a when
+            //  res_base2k == key_base2k, operations/glwe.rs:588-592)
+            const DV& sv = tensor ? raw_av : av;
             PZ_TRY(launch_inv_tail(M, nb, T, res_dft_size, s.cols_out, (long long*)rv.p, rv.bs, rv.cols, rv.size,
-                                   ks ? (const long long*)av.p : nullptr, av.bs, av.cols, a_size, (int)p->res_base2k, false, false, 0, false, 0,
+                                   ks ? (const long long*)sv.p : nullptr, sv.bs, sv.cols, sv.size, (int)p->res_base2k, false, tensor, 0, false, 0,
                                    false, body_col));
         } else {
             PZ_TRY(dev_idft(M, nb, rb, 0, rb, 0, s.cols_out, res_dft_size, T));
-            if (ks)  // body column added after the inverse transform (keyswitching/glwe.rs:237)
+            if (tensor) {  // operations/glwe.rs:588-598: + a[col] on every column (raw a when res_base2k == key_base2k, else the converted one)
+                const DV& sv = p->res_base2k == p->key_base2k ? raw_av : av;
+                for (int c = 0; c < s.cols_out; ++c)
+                    PZ_TRY(launch_ew(M, EW_ADD_I64, res_dft + (long long)c * n, rb.bs, (long long)s.cols_out * n, res_dft + (long long)c * n, rb.bs,
+                                     (long long)s.cols_out * n, (const int64_t*)sv.p + (long long)c * n, sv.bs, (long long)sv.cols * n,
+                                     std::min(res_dft_size, sv.size), nb));
+            } else if (ks)  // body column added after the inverse transform (keyswitching/glwe.rs:237)
                 PZ_TRY(launch_ew(M, EW_ADD_I64, res_dft + (long long)body_col * n, rb.bs, (long long)s.cols_out * n,
                                  res_dft + (long long)body_col * n, rb.bs, (long long)s.cols_out * n, av.p, av.bs, (long long)av.cols * n,
                                  std::min(res_dft_size, a_size), nb));
@@ -1428,6 +1346,14 @@ int pz_glwe_automorphism_batched(pz_module* M, int64_t* res, const int64_t* a, c
     PZ_ENTER(M);
     AutoSpec au{(long long)gal, mode};
     return glwe_op(M, true, res, a, key_pmat, p, batch, &au);
+}
+// glwe_tensor_relinearize (poulpy-core/src/operations/glwe.rs:541-607) on `batch` GLWETensors sharing one prepared tensor key
+int pz_glwe_tensor_relinearize_batched(pz_module* M, int64_t* res, const int64_t* a, const double* tsk_pmat, const pz_glwe_op_params* p,
+                                       size_t batch) {
+    PZ_ENTER(M);
+    PZ_REQUIRE(p != nullptr, "null params");
+    PZ_REQUIRE(p->rank >= 1 && p->rank_out == p->rank, "glwe_tensor_relinearize: the tensor key maps rank (rank + 1) / 2 -> rank");
+    return glwe_op(M, true, res, a, tsk_pmat, p, batch, nullptr, nullptr, true);
 }
 // ggsw_external_product (external_product/ggsw.rs:54-58): every (row, column) entry of the GGSW `a` is a GLWE and the entries
 // are contiguous in the MatZnx layout, so the operation is one batched external product over dnum_a * (rank+1) ciphertexts

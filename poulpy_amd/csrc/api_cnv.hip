@@ -1,0 +1,309 @@
+// api_cnv.hip — C ABI of the convolution family (HalImpl cnv_*, poulpy-hal/src/oep/hal_impl.rs:670-754; reference
+// poulpy-cpu-ref/src/reference/fft64/convolution.rs) and of GLWE tensoring on device-resident batches
+// (poulpy-core/src/operations/glwe.rs:609-913), SURVEY.md §8f rank 4 / BASELINE configs[4].
+#include "api_common.hpp"
+
+// CnvPVecL / CnvPVecR bytes in this backend: polynomial (col, limb) = its spectrum in device order at (col*size + limb)*n doubles.
+static inline size_t cnv_bytes(const pz_module* M, size_t cols, size_t size) { return (size_t)M->n * cols * size * 8; }
+
+// convolution.rs:35-80: limbs < min_size - 1 plain forward transforms, limb min_size - 1 with `mask` applied to the coefficients,
+// limbs >= min_size zero.  `a` batched with stride a_bs (scalars), res with stride res_bs.
+static int dev_cnv_prepare(pz_module* M, int batch, double* res, long long res_bs, int cols, int res_size, const int64_t* a, long long a_bs,
+                           int a_cols, int a_size, long long mask, cplx* T) {
+    const long long n = (long long)M->n;
+    const int min_size = std::min(res_size, a_size);
+    if (min_size > 1) {
+        const int nl = min_size - 1;
+        PolyMap sm{nl, cols, a_bs, (long long)a_cols * n, n, 0};
+        PolyMap dm{nl, cols, res_bs, n, (long long)res_size * n, 0};
+        PZ_TRY(launch_fwd_pass1(M, batch * nl * cols, (const long long*)a, sm, T));
+        PZ_TRY(launch_fwd_pass2(M, batch * nl * cols, T, res, dm, nullptr));
+    }
+    if (min_size > 0) {
+        const int last = min_size - 1;
+        PolyMap sm{1, cols, a_bs, 0, n, (long long)last * a_cols * n};
+        PolyMap dm{1, cols, res_bs, 0, (long long)res_size * n, (long long)last * n};
+        PZ_TRY(launch_fwd_pass1(M, batch * cols, (const long long*)a, sm, T, false, mask));
+        PZ_TRY(launch_fwd_pass2(M, batch * cols, T, res, dm, nullptr));
+    }
+    for (int c = 0; c < cols && res_size > min_size; ++c)
+        PZ_TRY(launch_ew(M, EW_ZERO, res + ((long long)c * res_size + min_size) * n, res_bs, n, nullptr, 0, 0, nullptr, 0, 0, res_size - min_size, batch));
+    return PZ_OK;
+}
+
+extern "C" {
+
+// hal_defaults/convolution.rs:40-45, :63-68, and cnv_prepare_self_tmp_bytes: one VecZnxDft(1, min(res_size, a_size))
+size_t pz_cnv_prepare_left_tmp_bytes(const pz_module* M, size_t res_size, size_t a_size) {
+    return M ? (size_t)M->n * std::min(res_size, a_size) * 8 : 0;
+}
+size_t pz_cnv_prepare_right_tmp_bytes(const pz_module* M, size_t res_size, size_t a_size) { return pz_cnv_prepare_left_tmp_bytes(M, res_size, a_size); }
+size_t pz_cnv_prepare_self_tmp_bytes(const pz_module* M, size_t res_size, size_t a_size) { return pz_cnv_prepare_left_tmp_bytes(M, res_size, a_size); }
+// convolution.rs:205-208, :261-263, :142-145
+size_t pz_cnv_apply_dft_tmp_bytes(const pz_module*, size_t, size_t res_size, size_t a_size, size_t b_size) {
+    return 8 * 8 * std::min(res_size, a_size + b_size - 1);
+}
+size_t pz_cnv_pairwise_apply_dft_tmp_bytes(const pz_module* M, size_t cnv_offset, size_t res_size, size_t a_size, size_t b_size) {
+    return pz_cnv_apply_dft_tmp_bytes(M, cnv_offset, res_size, a_size, b_size) + (a_size + b_size) * 8 * 8;
+}
+size_t pz_cnv_by_const_apply_tmp_bytes(const pz_module*, size_t, size_t res_size, size_t a_size, size_t b_size) {
+    return 8 * (std::min(res_size, a_size + b_size - 1) + a_size) * 8;
+}
+
+static int cnv_prepare_one(pz_module* M, double* res, size_t res_cols, size_t res_size, const int64_t* a, size_t a_cols, size_t a_size,
+                           int64_t mask, double* copy_to) {
+    PZ_REQUIRE(a_cols == res_cols, "cnv_prepare: a.cols %zu != res.cols %zu", a_cols, res_cols);   // convolution.rs:46
+    Stage sr, sa, sc;
+    PZ_TRY(sa.in(a, vbytes(M, a_cols, a_size), true, false, M));
+    PZ_TRY(sr.in(res, cnv_bytes(M, res_cols, res_size), false, true, M));
+    if (copy_to) PZ_TRY(sc.in(copy_to, cnv_bytes(M, res_cols, res_size), false, true, M));
+    cplx* T;
+    PZ_TRY(need_T(M, res_cols * std::max<size_t>(std::min(res_size, a_size), 1), &T));
+    PZ_TRY(dev_cnv_prepare(M, 1, (double*)sr.dev, 0, (int)res_cols, (int)res_size, (const int64_t*)sa.dev, 0, (int)a_cols, (int)a_size,
+                           (long long)mask, T));
+    if (copy_to)   // convolution.rs:134-138: right = left (identical data for FFT64)
+        PZ_TRY(launch_ew(M, EW_COPY, sc.dev, 0, (long long)M->n, sr.dev, 0, (long long)M->n, nullptr, 0, 0, (int)(res_cols * res_size), 1));
+    const bool host = sr.owned || sa.owned || sc.owned;
+    PZ_TRY(sr.finish());
+    PZ_TRY(sa.finish());
+    PZ_TRY(sc.finish());
+    return finish_call(M, host);
+}
+int pz_cnv_prepare_left(pz_module* M, double* res, size_t res_cols, size_t res_size, const int64_t* a, size_t a_cols, size_t a_size,
+                        int64_t mask) {
+    PZ_ENTER(M);
+    return cnv_prepare_one(M, res, res_cols, res_size, a, a_cols, a_size, mask, nullptr);
+}
+int pz_cnv_prepare_right(pz_module* M, double* res, size_t res_cols, size_t res_size, const int64_t* a, size_t a_cols, size_t a_size,
+                         int64_t mask) {
+    PZ_ENTER(M);
+    return cnv_prepare_one(M, res, res_cols, res_size, a, a_cols, a_size, mask, nullptr);
+}
+int pz_cnv_prepare_self(pz_module* M, double* left, double* right, size_t cols, size_t size, const int64_t* a, size_t a_cols, size_t a_size,
+                        int64_t mask) {
+    PZ_ENTER(M);
+    PZ_REQUIRE((const void*)left != (const void*)right, "cnv_prepare_self: left and right must be distinct buffers");
+    return cnv_prepare_one(M, left, cols, size, a, a_cols, a_size, mask, right);
+}
+
+static int cnv_apply_common(pz_module* M, size_t cnv_offset, double* res, size_t res_cols, size_t res_size, size_t res_col, const double* a,
+                            size_t a_cols, size_t a_size, const double* b, size_t b_cols, size_t b_size, size_t a_i, size_t b_i, int a_j,
+                            int b_j) {
+    PZ_CHECK_COL(res_col, res_cols, "cnv_apply_dft(res)");
+    PZ_CHECK_COL(a_i, a_cols, "cnv_apply_dft(a)");
+    PZ_CHECK_COL(b_i, b_cols, "cnv_apply_dft(b)");
+    PZ_REQUIRE(a_size > 0 && b_size > 0, "cnv_apply_dft: empty operand");                                // reim4/mod.rs:47-48
+    PZ_REQUIRE((const void*)res != (const void*)a && (const void*)res != (const void*)b, "cnv_apply_dft: res must not alias an operand");
+    Stage sr, sa, sb;
+    PZ_TRY(sa.in(a, cnv_bytes(M, a_cols, a_size), true, false, M));
+    if ((const void*)b == (const void*)a) { sb.M = M; sb.dev = sa.dev; }
+    else PZ_TRY(sb.in(b, cnv_bytes(M, b_cols, b_size), true, false, M));
+    PZ_TRY(sr.in(res, vbytes(M, res_cols, res_size), true, true, M));   // inout: other columns survive
+    const size_t bound = a_size + b_size - 1;
+    const int min_size = (int)std::min(res_size, bound), offset = (int)std::min(cnv_offset, bound);
+    PZ_TRY(launch_cnv_apply(M, 1, (double*)sr.dev, 0, (int)res_cols, (int)res_col, min_size, offset, (const double*)sa.dev, 0, (int)a_size,
+                            (int)a_i, a_j, (const double*)sb.dev, 0, (int)b_size, (int)b_i, b_j));
+    DV dr{sr.dev, 0, (int)res_cols, (int)res_size};
+    PZ_TRY(launch_ew(M, EW_ZERO, poly_ptr(M, dr, (int)res_col, min_size), 0, limb_stride(M, dr), nullptr, 0, 0, nullptr, 0, 0,
+                     (int)res_size - min_size, 1));                                                     // convolution.rs:256-258
+    const bool host = sr.owned || sa.owned || sb.owned;
+    PZ_TRY(sr.finish());
+    PZ_TRY(sa.finish());
+    PZ_TRY(sb.finish());
+    return finish_call(M, host);
+}
+int pz_cnv_apply_dft(pz_module* M, size_t cnv_offset, double* res, size_t res_cols, size_t res_size, size_t res_col, const double* a,
+                     size_t a_cols, size_t a_size, size_t a_col, const double* b, size_t b_cols, size_t b_size, size_t b_col) {
+    PZ_ENTER(M);
+    return cnv_apply_common(M, cnv_offset, res, res_cols, res_size, res_col, a, a_cols, a_size, b, b_cols, b_size, a_col, b_col, -1, -1);
+}
+int pz_cnv_pairwise_apply_dft(pz_module* M, size_t cnv_offset, double* res, size_t res_cols, size_t res_size, size_t res_col,
+                              const double* a, size_t a_cols, size_t a_size, const double* b, size_t b_cols, size_t b_size, size_t col_i,
+                              size_t col_j) {
+    PZ_ENTER(M);
+    PZ_CHECK_COL(col_j, a_cols, "cnv_pairwise_apply_dft(a)");
+    PZ_CHECK_COL(col_j, b_cols, "cnv_pairwise_apply_dft(b)");
+    const int j = col_i == col_j ? -1 : (int)col_j;                                                     // convolution.rs:281-284
+    return cnv_apply_common(M, cnv_offset, res, res_cols, res_size, res_col, a, a_cols, a_size, b, b_cols, b_size, col_i, col_i, j, j);
+}
+
+int pz_cnv_by_const_apply(pz_module* M, size_t cnv_offset, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a,
+                          size_t a_cols, size_t a_size, size_t a_col, const int64_t* b, size_t b_len) {
+    PZ_ENTER(M);
+    PZ_CHECK_COL(res_col, res_cols, "cnv_by_const_apply(res)");
+    PZ_CHECK_COL(a_col, a_cols, "cnv_by_const_apply(a)");
+    PZ_REQUIRE(a_size > 0 && b_len > 0, "cnv_by_const_apply: empty operand");
+    PZ_REQUIRE((const void*)res != (const void*)a, "cnv_by_const_apply: res must not alias a");
+    Stage sr, sa, sb;
+    PZ_TRY(sa.in(a, vbytes(M, a_cols, a_size), true, false, M));
+    PZ_TRY(sb.in(b, b_len * 8, true, false, M));
+    PZ_TRY(sr.in(res, vbytes(M, res_cols, res_size), true, true, M));
+    const size_t bound = a_size + b_len - 1;
+    const int min_size = (int)std::min(res_size, bound), offset = (int)std::min(cnv_offset, bound);
+    PZ_TRY(launch_cnv_by_const(M, (long long*)sr.dev, (int)res_cols, (int)res_col, min_size, offset, (const long long*)sa.dev, (int)a_cols,
+                               (int)a_size, (int)a_col, (const long long*)sb.dev, (int)b_len));
+    DV dr{sr.dev, 0, (int)res_cols, (int)res_size};
+    PZ_TRY(launch_ew(M, EW_ZERO, poly_ptr(M, dr, (int)res_col, min_size), 0, limb_stride(M, dr), nullptr, 0, 0, nullptr, 0, 0,
+                     (int)res_size - min_size, 1));
+    const bool host = sr.owned || sa.owned || sb.owned;
+    PZ_TRY(sr.finish());
+    PZ_TRY(sa.finish());
+    PZ_TRY(sb.finish());
+    return finish_call(M, host);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GLWE tensoring on `batch` device-resident ciphertext pairs (poulpy-core/src/operations/glwe.rs:700-807 glwe_tensor_apply,
+// :809-913 _add_assign, :609-698 glwe_tensor_square_apply).  res: batch GLWETensors = VecZnx((rank+1)(rank+2)/2, res_size);
+// column of the pair (i, j >= i) = i cols - i (i + 1) / 2 + j.
+// Composition, every step one batched launch: prepare (forward transforms of all columns x limbs, bottom limb masked) | per product
+// term: limb convolution in the DFT domain -> inverse transform -> normalize with cnv_offset_lo into a one-column temporary
+// -> the reference's copy / negate / add / sub into the tensor columns.
+// ---------------------------------------------------------------------------------------------------------------------
+static inline long long msb_mask_bottom_limb(size_t base2k, size_t k) {   // operations/glwe.rs:921-926
+    const size_t r = k % base2k;
+    return r == 0 ? -1ll : (long long)(~0ull << (base2k - r));
+}
+static inline size_t tensor_dft_size(size_t full, size_t res_size, size_t res_base2k, size_t in_base2k, long long res_offset) {   // :929-957
+    long long ob = res_offset % (long long)in_base2k;
+    if (res_offset < 0 && ob != 0) ob += (long long)in_base2k;
+    return std::min(full, (res_size * res_base2k + (size_t)ob + in_base2k - 1) / in_base2k);
+}
+struct TensorPlan {
+    int cols, tcols, a_size, b_size, res_size, dft_size, hi;
+    long long lo;
+    size_t prep_a, prep_b, res_dft, tmp, diag, T, per_ct;
+};
+static int tensor_plan(const pz_module* M, const pz_glwe_tensor_params* p, int mode, TensorPlan& t) {
+    PZ_REQUIRE(p != nullptr, "null params");
+    PZ_REQUIRE(mode >= PZ_TENSOR_APPLY && mode <= PZ_TENSOR_SQUARE, "glwe_tensor_apply: unknown mode");
+    PZ_REQUIRE(p->rank >= 1 && p->a_size >= 1 && p->res_size >= 1 && (mode == PZ_TENSOR_SQUARE || p->b_size >= 1), "glwe_tensor_apply: empty shape");
+    PZ_REQUIRE(p->ab_base2k >= 1 && p->ab_base2k <= 63 && p->res_base2k >= 1 && p->res_base2k <= 63, "glwe_tensor_apply: base2k out of range");
+    const size_t ab = p->ab_base2k, bsz = mode == PZ_TENSOR_SQUARE ? p->a_size : p->b_size;
+    const size_t bk = mode == PZ_TENSOR_SQUARE ? p->a_effective_k : p->b_effective_k;
+    PZ_REQUIRE((p->a_effective_k + ab - 1) / ab == p->a_size && (bk + ab - 1) / ab == bsz,
+               "glwe_tensor_apply: effective_k.div_ceil(base2k) must equal the size");                  // :721-722
+    t.cols = (int)p->rank + 1;
+    t.tcols = t.cols * (t.cols + 1) / 2;
+    t.a_size = (int)p->a_size; t.b_size = (int)bsz; t.res_size = (int)p->res_size;
+    if (p->cnv_offset < ab) { t.hi = 0; t.lo = -(long long)(ab - (p->cnv_offset % ab)); }               // :733-737
+    else { const size_t q = p->cnv_offset / ab; t.hi = (int)(q ? q - 1 : 0); t.lo = (long long)(p->cnv_offset % ab); }
+    PZ_REQUIRE((size_t)t.hi < p->a_size + bsz, "glwe_tensor_apply: cnv_offset beyond the product");
+    t.dft_size = (int)tensor_dft_size(p->a_size + bsz - (size_t)t.hi, p->res_size, p->res_base2k, ab, t.lo);
+    const size_t n8 = (size_t)M->n * 8;
+    t.prep_a = n8 * t.cols * t.a_size;
+    t.prep_b = n8 * t.cols * t.b_size;
+    t.res_dft = n8 * std::max(t.dft_size, 1);
+    t.tmp = n8 * t.res_size;
+    t.diag = mode == PZ_TENSOR_SQUARE ? n8 * t.cols * t.res_size : 0;
+    t.T = (size_t)M->m * sizeof(cplx) * std::max({t.cols * t.a_size, t.cols * t.b_size, t.dft_size, 1});
+    t.per_ct = t.prep_a + t.prep_b + t.res_dft + t.tmp + t.diag + t.T;
+    return PZ_OK;
+}
+static size_t tensor_chunk(const pz_module* M, const TensorPlan& t, size_t batch) {
+    if (M->chunk) return std::min(M->chunk, batch);
+    size_t c = ((size_t)16 << 30) / std::max<size_t>(t.per_ct, 1);
+    return std::min(std::max<size_t>(c, 1), batch);
+}
+size_t pz_glwe_tensor_apply_workspace_bytes(const pz_module* M, const pz_glwe_tensor_params* p, int mode, size_t batch) {
+    TensorPlan t;
+    if (!M || tensor_plan(M, p, mode, t) != PZ_OK) return 0;
+    return tensor_chunk(M, t, batch) * (t.per_ct + 6 * 256);
+}
+
+int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, const int64_t* b, const pz_glwe_tensor_params* p, int mode,
+                                 size_t batch) {
+    PZ_ENTER(M);
+    TensorPlan t;
+    PZ_TRY(tensor_plan(M, p, mode, t));
+    const bool square = mode == PZ_TENSOR_SQUARE, add = mode == PZ_TENSOR_APPLY_ADD_ASSIGN;
+    if (square) b = a;
+    PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(a) && is_device_ptr(b), "batched entry points take device pointers");
+    PZ_REQUIRE((const void*)res != (const void*)a && (const void*)res != (const void*)b, "glwe_tensor_apply: res must not alias an operand");
+    if (batch == 0) return PZ_OK;
+    const long long n = (long long)M->n;
+    const size_t chunk = tensor_chunk(M, t, batch);
+    const size_t s_pa = align256(chunk * t.prep_a), s_pb = square ? 0 : align256(chunk * t.prep_b), s_rd = align256(chunk * t.res_dft);
+    const size_t s_tmp = align256(chunk * t.tmp), s_dg = align256(chunk * t.diag), s_T = align256(chunk * t.T);
+    PZ_TRY(ws_reserve(M, s_pa + s_pb + s_rd + s_tmp + s_dg + s_T));
+    char* base = (char*)M->ws;
+    double* pa = (double*)base; base += s_pa;
+    double* pb = square ? pa : (double*)base; base += s_pb;     // convolution.rs:134-138: right = left for FFT64
+    double* rd = (double*)base; base += s_rd;
+    int64_t* tmp = (int64_t*)base; base += s_tmp;
+    int64_t* diag = (int64_t*)base; base += s_dg;
+    cplx* T = (cplx*)base;
+    const long long a_ct = n * t.cols * t.a_size, b_ct = n * t.cols * t.b_size, r_ct = n * t.tcols * t.res_size;
+    const long long pa_bs = n * t.cols * t.a_size, pb_bs = n * t.cols * t.b_size, rd_bs = n * std::max(t.dft_size, 1), tmp_bs = n * t.res_size;
+    const long long dg_bs = n * t.cols * t.res_size;
+    const long long a_mask = msb_mask_bottom_limb(p->ab_base2k, p->a_effective_k);
+    const long long b_mask = square ? a_mask : msb_mask_bottom_limb(p->ab_base2k, p->b_effective_k);
+    const long long rls = (long long)t.tcols * n;   // limb stride of the tensor
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const int nb = (int)std::min(chunk, batch - b0);
+        const int64_t* ab = a + (long long)b0 * a_ct;
+        int64_t* rb = res + (long long)b0 * r_ct;
+        PZ_TRY(dev_cnv_prepare(M, nb, pa, pa_bs, t.cols, t.a_size, ab, a_ct, t.cols, t.a_size, a_mask, T));
+        if (!square) PZ_TRY(dev_cnv_prepare(M, nb, pb, pb_bs, t.cols, t.b_size, b + (long long)b0 * b_ct, b_ct, t.cols, t.b_size, b_mask, T));
+        // one product term (i, j): convolution -> inverse transform in place -> normalize(res_base2k, cnv_offset_lo) into `dst` column dcol
+        auto term = [&](int i, int j, int64_t* dst, long long dst_bs, int dst_cols, int dcol) -> int {
+            const int bound = t.a_size + t.b_size - 1;
+            const int min_size = std::min(t.dft_size, bound), off = std::min(t.hi, bound);
+            PZ_TRY(launch_cnv_apply(M, nb, rd, rd_bs, 1, 0, min_size, off, pa, pa_bs, t.a_size, i, i == j ? -1 : j, pb, pb_bs, t.b_size, i,
+                                    i == j ? -1 : j));
+            if (t.dft_size > min_size)
+                PZ_TRY(launch_ew(M, EW_ZERO, rd + (long long)min_size * n, rd_bs, n, nullptr, 0, 0, nullptr, 0, 0, t.dft_size - min_size, nb));
+            DV dv{rd, rd_bs, 1, t.dft_size};
+            PZ_TRY(dev_idft(M, nb, dv, 0, dv, 0, 1, t.dft_size, T));
+            DV out{dst, dst_bs, dst_cols, t.res_size};
+            return dev_normalize(M, nb, out, (int)p->res_base2k, t.lo, dcol, dv, (int)p->ab_base2k, 0);
+        };
+        auto col_ptr = [&](int col) { return rb + (long long)col * n; };
+        auto ew_res = [&](int op, int col, const int64_t* x, long long x_bs, long long x_ls, const int64_t* y, long long y_bs, long long y_ls) {
+            return launch_ew(M, op, col_ptr(col), r_ct, rls, x, x_bs, x_ls, y, y_bs, y_ls, t.res_size, nb);
+        };
+        if (square) {   // :651-697
+            for (int i = 0; i < t.cols; ++i) {
+                const int col_i = i * t.cols - (i * (i + 1) / 2);
+                PZ_TRY(term(i, i, diag, dg_bs, t.cols, i));
+                PZ_TRY(ew_res(EW_COPY, col_i + i, diag + (long long)i * n, dg_bs, (long long)t.cols * n, nullptr, 0, 0));
+            }
+            for (int i = 0; i < t.cols; ++i) {
+                const int col_i = i * t.cols - (i * (i + 1) / 2);
+                for (int j = i + 1; j < t.cols; ++j) {
+                    PZ_TRY(term(i, j, rb, r_ct, t.tcols, col_i + j));
+                    PZ_TRY(ew_res(EW_SUB_I64, col_i + j, col_ptr(col_i + j), r_ct, rls, diag + (long long)i * n, dg_bs, (long long)t.cols * n));
+                    PZ_TRY(ew_res(EW_SUB_I64, col_i + j, col_ptr(col_i + j), r_ct, rls, diag + (long long)j * n, dg_bs, (long long)t.cols * n));
+                }
+            }
+            continue;
+        }
+        for (int i = 0; i < t.cols; ++i) {   // :762-783 / :870-890
+            const int col_i = i * t.cols - (i * (i + 1) / 2);
+            PZ_TRY(term(i, i, tmp, tmp_bs, 1, 0));
+            if (add) PZ_TRY(ew_res(EW_ADD_I64, col_i + i, col_ptr(col_i + i), r_ct, rls, tmp, tmp_bs, n));
+            else PZ_TRY(ew_res(EW_COPY, col_i + i, tmp, tmp_bs, n, nullptr, 0, 0));
+            for (int j = 0; j < t.cols; ++j) {
+                if (j == i) continue;
+                if (j < i) {
+                    const int col_j = j * t.cols - (j * (j + 1) / 2);
+                    PZ_TRY(ew_res(EW_SUB_I64, col_j + i, col_ptr(col_j + i), r_ct, rls, tmp, tmp_bs, n));
+                } else if (add) {
+                    PZ_TRY(ew_res(EW_SUB_I64, col_i + j, col_ptr(col_i + j), r_ct, rls, tmp, tmp_bs, n));
+                } else {
+                    PZ_TRY(ew_res(EW_NEG_I64, col_i + j, tmp, tmp_bs, n, nullptr, 0, 0));
+                }
+            }
+        }
+        for (int i = 0; i < t.cols; ++i) {   // :785-805
+            const int col_i = i * t.cols - (i * (i + 1) / 2);
+            for (int j = i + 1; j < t.cols; ++j) {
+                PZ_TRY(term(i, j, tmp, tmp_bs, 1, 0));
+                PZ_TRY(ew_res(EW_ADD_I64, col_i + j, col_ptr(col_i + j), r_ct, rls, tmp, tmp_bs, n));
+            }
+        }
+    }
+    return PZ_OK;
+}
+
+}  // extern "C"

@@ -141,7 +141,7 @@ __device__ __forceinline__ long long fast_i64_from_integral(double r) {
 template <int R1, int R2, int CB, bool ROWMAJOR = false>
 __global__ void __launch_bounds__((R1 > R2 ? R1 : R2) * CB)
 k_fwd_pass1(const long long* __restrict__ src, PolyMap smap, cplx* __restrict__ T, int m2,
-            const cplx* __restrict__ tw1, const cplx* __restrict__ wL1, const cplx* __restrict__ tw12) {
+            const cplx* __restrict__ tw1, const cplx* __restrict__ wL1, const cplx* __restrict__ tw12, long long mask) {
     constexpr int M1 = R1 * R2;
     constexpr int NT = (R1 > R2 ? R1 : R2) * CB;
     extern __shared__ cplx lds[];  // (R1+1)*CB*R2 exchange | tw1[M1] | wL1[M1]
@@ -164,8 +164,8 @@ k_fwd_pass1(const long long* __restrict__ src, PolyMap smap, cplx* __restrict__ 
 #pragma unroll
         for (int n1 = 0; n1 < R1; ++n1) {
             const long long idx = (long long)(o + R2 * n1) * m2 + c0 + c;
-            raw_re[n1] = a[idx];
-            raw_im[n1] = a[idx + m];
+            raw_re[n1] = a[idx] & mask;   // mask = -1 except for cnv_prepare's last active limb (reim/conversion.rs:31-40)
+            raw_im[n1] = a[idx + m] & mask;
         }
     }
     for (int t = tid; t < M1; t += NT) {

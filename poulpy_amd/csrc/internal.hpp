@@ -36,7 +36,7 @@ inline void* poly_ptr(const pz_module* M, const DV& v, int col, int limb) {
 }
 
 // ---- launch_fft.hip -----------------------------------------------------------------------------------------------
-int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* T, bool rowmajor = false);
+int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* T, bool rowmajor = false, long long mask = -1);
 int launch_fwd_pass2(pz_module* M, int npolys, const cplx* T, double* dst, PolyMap dmap, const cplx* mul);
 int launch_inv_pass2(pz_module* M, int npolys, const double* src, PolyMap smap, cplx* T);
 int launch_inv_pass1(pz_module* M, int npolys, const cplx* T, long long* dst, PolyMap dmap);
@@ -85,5 +85,16 @@ int launch_xai_ext(pz_module* M, double* acc_add, const double* v, int polys, in
                    int idx);
 int launch_br_ext_init(pz_module* M, int64_t* acc, const int64_t* lut, const int64_t* lwe_2n, long long lwe_bs, int log_ext, int cols,
                        int rsz, int lut_size, int B);
+
+// ---- launch_cnv.hip -----------------------------------------------------------------------------------------------
+// bivariate convolution in the DFT domain (reference/fft64/convolution.rs:210-345): res limb kk of column res_col =
+//   sum_j A[kk + offset - j] * B[j],  A = a[col_i] (+ a[col_j] when pairwise), B = b[b_i] (+ b[b_j]); limbs >= min_size untouched here.
+// a / b: device CnvPVec layout [col][limb][m points], batch strides in doubles; res: VecZnxDft layout.
+int launch_cnv_apply(pz_module* M, int batch, double* res, long long res_bs, int res_cols, int res_col, int min_size, int offset,
+                     const double* a, long long a_bs, int a_size, int a_i, int a_j, const double* b, long long b_bs, int b_size, int b_i,
+                     int b_j);
+// convolution.rs:147-203: i64, wrapping; bconst: b_size device constants
+int launch_cnv_by_const(pz_module* M, long long* res, int res_cols, int res_col, int min_size, int offset, const long long* a, int a_cols,
+                        int a_size, int a_col, const long long* bconst, int b_size);
 
 }  // namespace pz

@@ -1,0 +1,47 @@
+// launch_cnv.hip — bivariate-convolution kernels (device_cnv.hpp).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "internal.hpp"
+#include "device_cnv.hpp"
+
+namespace pz {
+
+int launch_cnv_apply(pz_module* M, int batch, double* res, long long res_bs, int res_cols, int res_col, int min_size, int offset,
+                     const double* a, long long a_bs, int a_size, int a_i, int a_j, const double* b, long long b_bs, int b_size, int b_i,
+                     int b_j) {
+    if (batch <= 0 || min_size <= 0) return PZ_OK;
+    CnvArgs g;
+    g.res = res; g.a = (const cplx*)a; g.b = (const cplx*)b;
+    g.res_bs = res_bs / 2; g.a_bs = a_bs / 2; g.b_bs = b_bs / 2;
+    g.res_cols = res_cols; g.res_col = res_col; g.min_size = min_size; g.offset = offset;
+    g.a_size = a_size; g.a_i = a_i; g.a_j = a_j; g.b_size = b_size; g.b_i = b_i; g.b_j = b_j;
+    g.m = (int)M->m; g.batch = batch;
+    KTimer kt(M, PZ_K_VMP);
+    for (int b0 = 0; b0 < batch; b0 += 65535) {   // gridDim.z limit
+        CnvArgs gb = g;
+        gb.res = res + (long long)b0 * res_bs;
+        gb.a = g.a + (long long)b0 * g.a_bs;
+        gb.b = g.b + (long long)b0 * g.b_bs;
+        const int nb = std::min(65535, batch - b0);
+        hipLaunchKernelGGL(k_cnv_apply, dim3((unsigned)((M->m + 255) / 256), (unsigned)min_size, (unsigned)nb), dim3(256), 0, M->stream, gb);
+    }
+    PZ_HIP(hipGetLastError());
+    return PZ_OK;
+}
+
+int launch_cnv_by_const(pz_module* M, long long* res, int res_cols, int res_col, int min_size, int offset, const long long* a, int a_cols,
+                        int a_size, int a_col, const long long* bconst, int b_size) {
+    if (min_size <= 0) return PZ_OK;
+    CnvConstArgs g;
+    g.res = res; g.a = a; g.b = bconst;
+    g.res_cols = res_cols; g.res_col = res_col; g.a_cols = a_cols; g.a_col = a_col; g.a_size = a_size; g.b_size = b_size;
+    g.min_size = min_size; g.offset = offset; g.n = (int)M->n;
+    KTimer kt(M, PZ_K_ELEMENTWISE);
+    hipLaunchKernelGGL(k_cnv_by_const, dim3((unsigned)((M->n + 255) / 256), (unsigned)min_size), dim3(256), 0, M->stream, g);
+    PZ_HIP(hipGetLastError());
+    return PZ_OK;
+}
+
+}  // namespace pz

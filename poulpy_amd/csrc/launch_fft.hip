@@ -13,7 +13,7 @@ namespace pz {
 #define PZ_P2_CASES(X) X(4, 1, 4) X(8, 1, 4) X(16, 1, 4) X(16, 1, 16) X(8, 4, 16) X(8, 8, 16) X(16, 8, 16) X(16, 16, 16)
 
 
-int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* T, bool rowmajor) {
+int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* T, bool rowmajor, long long mask) {
     const FftPlan& pl = M->plan;
     const int blocks = npolys * (pl.m2 / pl.cb);
     if (blocks == 0) return PZ_OK;
@@ -24,11 +24,11 @@ int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap sma
         if (rowmajor) {                                                                                         \
             PZ_TRY(set_lds(k_fwd_pass1<A, B, C, true>, lds));                                                   \
             hipLaunchKernelGGL((k_fwd_pass1<A, B, C, true>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, src, smap, \
-                               T, pl.m2, M->tw1, M->wL1, M->tw12t);                                             \
+                               T, pl.m2, M->tw1, M->wL1, M->tw12t, mask);                                             \
         } else {                                                                                                \
             PZ_TRY(set_lds(k_fwd_pass1<A, B, C>, lds));                                                         \
             hipLaunchKernelGGL((k_fwd_pass1<A, B, C>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, src, smap, T, \
-                               pl.m2, M->tw1, M->wL1, M->tw12);                                                 \
+                               pl.m2, M->tw1, M->wL1, M->tw12, mask);                                                 \
         }                                                                                                       \
         PZ_HIP(hipGetLastError());                                                                              \
         return PZ_OK;                                                                                           \

@@ -17,7 +17,7 @@ from ctypes import POINTER, c_double, c_int, c_int64, c_size_t, c_uint64, c_void
 
 import numpy as np
 
-from .layouts import MatZnx, ScalarZnx, SvpPPol, VecZnx, VecZnxBig, VecZnxDft, VmpPMat
+from .layouts import CnvPVecL, CnvPVecR, MatZnx, ScalarZnx, SvpPPol, VecZnx, VecZnxBig, VecZnxDft, VmpPMat
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpoulpy_hip.so")
@@ -42,6 +42,12 @@ class CircuitBootstrappingParams(C.Structure):
     """pz_circuit_bootstrapping_params (include/poulpy_hip.h)"""
     _fields_ = [("br", BlindRotationParams)] + [(k, c_uint64) for k in ("atk_dnum", "atk_size", "tsk_dnum", "tsk_size", "res_dnum",
                                                                          "res_size", "gap", "extension_factor")]
+
+
+class GlweTensorParams(C.Structure):
+    """pz_glwe_tensor_params (include/poulpy_hip.h)"""
+    _fields_ = [(k, c_uint64) for k in ("rank", "a_size", "b_size", "ab_base2k", "a_effective_k", "b_effective_k", "res_size",
+                                        "res_base2k", "cnv_offset")]
 
 
 _lib = None
@@ -72,7 +78,9 @@ def load_library(path: str | None = None) -> C.CDLL:
                  "pz_glwe_op_workspace_bytes", "pz_vec_znx_automorphism_assign_tmp_bytes",
                  "pz_vec_znx_big_automorphism_assign_tmp_bytes", "pz_blind_rotation_workspace_bytes", "pz_vec_znx_rsh_tmp_bytes", "pz_vec_znx_rotate_assign_tmp_bytes",
                  "pz_circuit_bootstrapping_tmp_bytes", "pz_vec_znx_normalize_tmp_bytes", "pz_vec_znx_lsh_tmp_bytes", "pz_glwe_pack_tmp_bytes",
-                 "pz_circuit_bootstrapping_to_exponent_tmp_bytes", "pz_blind_rotation_extended_tmp_bytes"):
+                 "pz_circuit_bootstrapping_to_exponent_tmp_bytes", "pz_blind_rotation_extended_tmp_bytes",
+                 "pz_cnv_prepare_left_tmp_bytes", "pz_cnv_prepare_right_tmp_bytes", "pz_cnv_prepare_self_tmp_bytes", "pz_cnv_apply_dft_tmp_bytes",
+                 "pz_cnv_pairwise_apply_dft_tmp_bytes", "pz_cnv_by_const_apply_tmp_bytes", "pz_glwe_tensor_apply_workspace_bytes"):
         getattr(lib, name).restype = c_size_t
     if path is None:
         _lib = lib
@@ -528,6 +536,70 @@ class Module:
                                       a_size, a_base2k, a_col):
         self._ck(self.lib.pz_vec_znx_big_normalize_batched(self.handle, c_size_t(batch), res, *_sz(res_cols, res_size, res_base2k),
                                                            c_int64(res_offset), c_size_t(res_col), a, *_sz(a_cols, a_size, a_base2k, a_col)))
+
+    # -- convolution family (api/convolution.rs; hal_impl.rs:670-754) --------------------------------------
+    def cnv_pvec_left_alloc(self, cols, size) -> CnvPVecL:
+        return CnvPVecL(self._n, cols, size)
+
+    def cnv_pvec_right_alloc(self, cols, size) -> CnvPVecR:
+        return CnvPVecR(self._n, cols, size)
+
+    def cnv_prepare_left_tmp_bytes(self, res_size, a_size) -> int:
+        return self.lib.pz_cnv_prepare_left_tmp_bytes(self.handle, *_sz(res_size, a_size))
+
+    def cnv_prepare_right_tmp_bytes(self, res_size, a_size) -> int:
+        return self.lib.pz_cnv_prepare_right_tmp_bytes(self.handle, *_sz(res_size, a_size))
+
+    def cnv_prepare_self_tmp_bytes(self, res_size, a_size) -> int:
+        return self.lib.pz_cnv_prepare_self_tmp_bytes(self.handle, *_sz(res_size, a_size))
+
+    def cnv_apply_dft_tmp_bytes(self, cnv_offset, res_size, a_size, b_size) -> int:
+        return self.lib.pz_cnv_apply_dft_tmp_bytes(self.handle, *_sz(cnv_offset, res_size, a_size, b_size))
+
+    def cnv_pairwise_apply_dft_tmp_bytes(self, cnv_offset, res_size, a_size, b_size) -> int:
+        return self.lib.pz_cnv_pairwise_apply_dft_tmp_bytes(self.handle, *_sz(cnv_offset, res_size, a_size, b_size))
+
+    def cnv_by_const_apply_tmp_bytes(self, cnv_offset, res_size, a_size, b_size) -> int:
+        return self.lib.pz_cnv_by_const_apply_tmp_bytes(self.handle, *_sz(cnv_offset, res_size, a_size, b_size))
+
+    def cnv_prepare_left(self, res: CnvPVecL, a: VecZnx, mask: int = -1, scratch=None):
+        self._ck(self.lib.pz_cnv_prepare_left(self.handle, _p(res.data), *_sz(res.cols, res.size), _p(a.data), *_sz(a.cols, a.size), c_int64(mask)))
+
+    def cnv_prepare_right(self, res: CnvPVecR, a: VecZnx, mask: int = -1, scratch=None):
+        self._ck(self.lib.pz_cnv_prepare_right(self.handle, _p(res.data), *_sz(res.cols, res.size), _p(a.data), *_sz(a.cols, a.size), c_int64(mask)))
+
+    def cnv_prepare_self(self, left: CnvPVecL, right: CnvPVecR, a: VecZnx, mask: int = -1, scratch=None):
+        assert (left.cols, left.size) == (right.cols, right.size)
+        self._ck(self.lib.pz_cnv_prepare_self(self.handle, _p(left.data), _p(right.data), *_sz(left.cols, left.size), _p(a.data),
+                                              *_sz(a.cols, a.size), c_int64(mask)))
+
+    def cnv_apply_dft(self, cnv_offset, res: VecZnxDft, res_col, a: CnvPVecL, a_col, b: CnvPVecR, b_col, scratch=None):
+        self._ck(self.lib.pz_cnv_apply_dft(self.handle, c_size_t(cnv_offset), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                           *_sz(a.cols, a.size, a_col), _p(b.data), *_sz(b.cols, b.size, b_col)))
+
+    def cnv_pairwise_apply_dft(self, cnv_offset, res: VecZnxDft, res_col, a: CnvPVecL, b: CnvPVecR, i, j, scratch=None):
+        self._ck(self.lib.pz_cnv_pairwise_apply_dft(self.handle, c_size_t(cnv_offset), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                                    *_sz(a.cols, a.size), _p(b.data), *_sz(b.cols, b.size, i, j)))
+
+    def cnv_by_const_apply(self, cnv_offset, res: VecZnxBig, res_col, a: VecZnx, a_col, b, scratch=None):
+        b = np.ascontiguousarray(b, dtype=np.int64)
+        self._ck(self.lib.pz_cnv_by_const_apply(self.handle, c_size_t(cnv_offset), _p(res.data), *_sz(res.cols, res.size, res_col), _p(a.data),
+                                                *_sz(a.cols, a.size, a_col), _p(b), c_size_t(b.size)))
+
+    TENSOR_MODES = {"apply": 0, "add_assign": 1, "square": 2}
+
+    def glwe_tensor_apply_workspace_bytes(self, params: GlweTensorParams, mode, batch: int) -> int:
+        mode = self.TENSOR_MODES[mode] if isinstance(mode, str) else int(mode)
+        return self.lib.pz_glwe_tensor_apply_workspace_bytes(self.handle, C.byref(params), c_int(mode), c_size_t(batch))
+
+    def glwe_tensor_apply_batched(self, res: c_void_p, a: c_void_p, b, params: GlweTensorParams, mode, batch: int):
+        """poulpy-core operations/glwe.rs:609-913 on device-resident ciphertexts; mode: "apply" | "add_assign" | "square"."""
+        mode = self.TENSOR_MODES[mode] if isinstance(mode, str) else int(mode)
+        self._ck(self.lib.pz_glwe_tensor_apply_batched(self.handle, res, a, b if b is not None else a, C.byref(params), c_int(mode), c_size_t(batch)))
+
+    def glwe_tensor_relinearize_batched(self, res: c_void_p, a: c_void_p, tsk_pmat: c_void_p, params: GlweOpParams, batch: int):
+        """poulpy-core operations/glwe.rs:541-607 on device-resident GLWETensors sharing one prepared tensor key."""
+        self._ck(self.lib.pz_glwe_tensor_relinearize_batched(self.handle, res, a, tsk_pmat, C.byref(params), c_size_t(batch)))
 
     def pin_key(self, pmat: c_void_p, rows: int, cols_in: int, cols_out: int, size: int):
         """Declare a prepared device key immutable: the fused pipeline keeps its row-sliced copy instead of rebuilding it per call."""
