@@ -1,28 +1,39 @@
-//! `FFT64Hip`: poulpy-hal backend whose FFT64 hot path runs on an MI355X through libpoulpy_hip.so.
+//! `FFT64Hip`: a poulpy-hal backend whose FFT64 family runs on an AMD MI355X (gfx950) through libpoulpy_hip.so.
 //!
-//! Shape of the crate (same as poulpy-cpu-avx, poulpy-cpu-avx/src/hal_impl.rs:51-61):
-//!   * `impl Backend for FFT64Hip` — `ScalarPrep = f64`, `ScalarBig = i64`, pinned host buffers,
-//!     handle = the C module (device twiddle tables, stream, workspace);
-//!   * `unsafe impl HalImpl<FFT64Hip>` — every method that touches `ScalarPrep` bytes
-//!     (VecZnxDft / SvpPPol / VmpPMat) forwards to the C ABI, because those bytes are in the
-//!     backend's private "device order"; pure-`i64` `VecZnx` ops reuse poulpy-cpu-ref's defaults
-//!     through the `hal_impl_*!` macros exactly as FFT64Avx does.
-//!   * (feature `core-fused`) `CoreImpl` overrides for `glwe_external_product` / `glwe_keyswitch`
-//!     that keep ciphertexts on the device.
+//! Shape of the crate — the same as poulpy-cpu-avx (poulpy-cpu-avx/src/lib.rs, src/hal_impl.rs):
+//!   * [`FFT64Hip`]: the backend marker; `impl Backend` with `ScalarPrep = f64`, `ScalarBig = i64`, pinned host buffers, and a handle
+//!     that owns the C module (device twiddle tables, stream, workspaces);
+//!   * `znx.rs`: the `Znx*` single-polynomial traits, delegated to poulpy-cpu-ref's reference kernels — they are what the portable
+//!     defaults of the pure-i64 families are written against (poulpy-cpu-ref/src/fft64/znx.rs does the same for `FFT64Ref`);
+//!   * `hal_impl.rs`: `unsafe impl HalImpl<FFT64Hip>` — all 105 required methods: DFT-domain families forward to the C ABI;
+//!   * `core_impl.rs` (feature `core-fused`, default): `unsafe impl CoreImpl<FFT64Hip>` with the GLWE-level key switch / external
+//!     product / automorphism family on the fused three-kernel device pipeline;
+//!   * `tests.rs`: the reference's own `cross_backend_test_suite!` against `FFT64Ref`, as poulpy-cpu-avx/src/fft64/tests.rs.
 //!
-//! The convolution family (`cnv_*`, hal_impl.rs:670-754) also produces `VecZnxDft`; it is not part
-//! of this path and panics with `unimplemented!` in this backend.
+//! Bytes of `VecZnxDft` / `SvpPPol` / `VmpPMat` / `CnvPVec*` are backend-private ("device order": natural-frequency, interleaved
+//! re/im); callers treat them as opaque, which poulpy-core does.  `i64` containers have the reference's layout.
 mod ffi;
 mod hal_impl;
+mod znx;
+
+#[cfg(feature = "core-fused")]
+mod core_impl;
+
+#[cfg(test)]
+mod tests;
 
 use std::ptr::NonNull;
 
 use poulpy_hal::layouts::Backend;
 
+pub use ffi::{pz_blind_rotation_params, pz_circuit_bootstrapping_params, pz_glwe_op_params, pz_glwe_tensor_params};
+
+/// Backend marker (`Module<FFT64Hip>`).
+#[derive(Debug, Clone, Copy)]
 pub struct FFT64Hip;
 
-/// `Backend::Handle`: owns the C module.  Immutable after construction except for the module's
-/// internal, mutex-protected workspace, so `&Module<FFT64Hip>` is `Sync` like the CPU backends.
+/// `Backend::Handle`: owns the C module.  Calls on one module are serialized inside the library (one HIP stream per module), so
+/// `&Module<FFT64Hip>` is `Sync` like the CPU backends (`unsafe impl Sync for Module`, poulpy-hal/src/layouts/module.rs:103-104).
 #[repr(C)]
 pub struct FFT64HipHandle {
     pub(crate) raw: *mut ffi::pz_module,
@@ -30,24 +41,39 @@ pub struct FFT64HipHandle {
 unsafe impl Send for FFT64HipHandle {}
 unsafe impl Sync for FFT64HipHandle {}
 
-/// Pinned, 64-byte aligned host memory from `pz_alloc_bytes` (hipHostMalloc): CPU-dereferenceable
-/// as `Backend::OwnedBuf: DataMut` requires (poulpy-hal/src/layouts/mod.rs:63), DMA-able for the
-/// staged H2D/D2H copies.
+impl FFT64HipHandle {
+    /// The raw `pz_module*`, for callers that drive the batched device-resident entry points of include/poulpy_hip.h directly
+    /// (`pz_glwe_external_product_batched`, `pz_blind_rotation_execute_batched`, ... on `pz_device_alloc` buffers).
+    pub fn as_raw(&self) -> *mut std::ffi::c_void {
+        self.raw as *mut std::ffi::c_void
+    }
+}
+
+/// `Backend::OwnedBuf`: pinned, 64-byte aligned host memory from `pz_alloc_bytes` (hipHostMalloc) — CPU-dereferenceable as
+/// `DataMut` requires (poulpy-hal/src/layouts/mod.rs:63), DMA-able for the staged H2D / D2H copies of the per-op path.
 pub struct PinnedBuf {
     ptr: NonNull<u8>,
     len: usize,
 }
 unsafe impl Send for PinnedBuf {}
 unsafe impl Sync for PinnedBuf {}
+
 impl PinnedBuf {
     pub fn new(len: usize) -> Self {
         let p = unsafe { ffi::pz_alloc_bytes(len) } as *mut u8;
-        Self { ptr: NonNull::new(p).expect("pz_alloc_bytes failed"), len }
+        Self { ptr: NonNull::new(p).expect("pz_alloc_bytes failed (no HIP device / out of pinned memory)"), len }
+    }
+}
+impl Default for PinnedBuf {
+    fn default() -> Self {
+        Self { ptr: NonNull::dangling(), len: 0 }
     }
 }
 impl Drop for PinnedBuf {
     fn drop(&mut self) {
-        unsafe { ffi::pz_free_bytes(self.ptr.as_ptr() as *mut _) }
+        if self.len != 0 {
+            unsafe { ffi::pz_free_bytes(self.ptr.as_ptr() as *mut std::ffi::c_void) }
+        }
     }
 }
 impl AsRef<[u8]> for PinnedBuf {
@@ -60,23 +86,29 @@ impl AsMut<[u8]> for PinnedBuf {
         unsafe { std::slice::from_raw_parts_mut(self.ptr.as_ptr(), self.len) }
     }
 }
+impl PartialEq for PinnedBuf {
+    fn eq(&self, other: &Self) -> bool {
+        self.as_ref() == other.as_ref()
+    }
+}
+impl Eq for PinnedBuf {}
 
 impl Backend for FFT64Hip {
-    type ScalarPrep = f64; // opaque device order, same byte size as the reference (module.rs:51-65)
+    type ScalarPrep = f64; // opaque device order, the reference's byte sizes (poulpy-hal/src/layouts/module.rs:51-73)
     type ScalarBig = i64;
     type OwnedBuf = PinnedBuf;
     type Handle = FFT64HipHandle;
     fn alloc_bytes(len: usize) -> Self::OwnedBuf {
-        PinnedBuf::new(len)
+        PinnedBuf::new(len.max(1))
     }
     fn from_bytes(bytes: Vec<u8>) -> Self::OwnedBuf {
-        let mut b = PinnedBuf::new(bytes.len());
-        b.as_mut().copy_from_slice(&bytes);
+        let mut b = PinnedBuf::new(bytes.len().max(1));
+        b.as_mut()[..bytes.len()].copy_from_slice(&bytes);
         b
     }
     unsafe fn destroy(handle: NonNull<Self::Handle>) {
         unsafe {
-            let h = Box::from_raw(handle.as_ptr());
+            let h: Box<FFT64HipHandle> = Box::from_raw(handle.as_ptr());
             ffi::pz_module_free(h.raw);
         }
     }

@@ -1,0 +1,208 @@
+"""The Rust crate rust/poulpy-hip-mi355x cannot be compiled in this image (no cargo / rustc).  These CPU tests pin what can be
+pinned without a compiler:
+
+* `src/ffi.rs` is exactly what tools/gen_rust_ffi.py generates from include/poulpy_hip.h, and — checked independently of the
+  generator — every `extern "C"` declaration has the header's arity and parameter types;
+* `src/hal_impl.rs` defines every required fn of `unsafe trait HalImpl` (poulpy-hal/src/oep/hal_impl.rs:25-755; the names are the
+  fixture tests/golden/hal_impl_fns.txt, re-derived from the reference checkout when it is present), none elided, none
+  `unimplemented!`, and only calls C functions the header declares;
+* `src/core_impl.rs` covers every required fn of `unsafe trait CoreImpl` (fixture tests/golden/core_impl_fns.txt): three families
+  written out, four through the reference's `impl_core_*_default_methods!` macros;
+* `src/tests.rs` instantiates every cross-backend test of the reference's HAL suite for the families this backend implements.
+"""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CRATE = os.path.join(ROOT, "rust", "poulpy-hip-mi355x")
+REF = "/root/reference"
+
+
+def read(*p):
+    return open(os.path.join(*p)).read()
+
+
+def strip_rust_comments(s):
+    s = re.sub(r"//[^\n]*", "", s)
+    return re.sub(r"/\*.*?\*/", "", s, flags=re.S)
+
+
+def fixture(name):
+    return [l.strip() for l in read(ROOT, "tests", "golden", name).splitlines() if l.strip() and not l.startswith("#")]
+
+
+def test_ffi_rs_is_generated_from_the_header():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_ffi.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+C2R = {"size_t": "usize", "int64_t": "i64", "uint64_t": "u64", "uint32_t": "u32", "int": "c_int", "double": "f64", "float": "f32",
+       "char": "c_char", "void": "c_void"}
+
+
+def header_functions():
+    """{name: (ret, [normalised C parameter types])} — a small independent parser of the header."""
+    text = re.sub(r"/\*.*?\*/", " ", read(ROOT, "include", "poulpy_hip.h"), flags=re.S)
+    text = re.sub(r"typedef\s+struct\s*\{.*?\}\s*\w+\s*;", " ", text, flags=re.S)
+    text = re.sub(r"(typedef\s+)?enum\s*\{.*?\}\s*\w*\s*;", " ", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b([A-Za-z_][\w\s\*]*?)\b(pz_\w+)\s*\(([^()]*)\)\s*;", text):
+        params = []
+        raw = " ".join(m.group(3).split())
+        if raw and raw != "void":
+            for a in raw.split(","):
+                toks = a.replace("*", " * ").split()
+                if toks[-1] not in ("*",) and toks[-1] not in C2R and not toks[-1].startswith("pz_") and len(toks) > 1:
+                    toks = toks[:-1]                      # drop the parameter name
+                params.append(" ".join(toks))
+        out[m.group(2)] = (" ".join(m.group(1).split()), params)
+    return out
+
+
+def c_to_rust(ctype):
+    toks = ctype.replace("*", " * ").split()
+    consts, base, stars = [], None, []
+    i = 0
+    const_next = False
+    if toks[0] == "const":
+        const_next, i = True, 1
+    base = toks[i]
+    i += 1
+    if i < len(toks) and toks[i] == "const":
+        const_next, i = True, i + 1
+    r = C2R.get(base, base)
+    while i < len(toks):
+        assert toks[i] == "*"
+        i += 1
+        r = ("*const " if const_next else "*mut ") + r
+        const_next = False
+        if i < len(toks) and toks[i] == "const":
+            const_next, i = True, i + 1
+    return r
+
+
+def test_every_extern_declaration_matches_the_header():
+    hdr = header_functions()
+    ffi = strip_rust_comments(read(CRATE, "src", "ffi.rs"))
+    block = ffi[ffi.index('unsafe extern "C" {'):]
+    decls = {}
+    for m in re.finditer(r"pub fn (pz_\w+)\(([^)]*)\)(?:\s*->\s*([^;]+))?;", block):
+        params = [p.split(":", 1)[1].strip() for p in m.group(2).split(",") if p.strip()]
+        decls[m.group(1)] = ((m.group(3) or "").strip(), params)
+    assert set(decls) == set(hdr), (sorted(set(hdr) - set(decls)), sorted(set(decls) - set(hdr)))
+    assert len(decls) >= 125
+    for name, (ret, params) in hdr.items():
+        rret, rparams = decls[name]
+        assert len(params) == len(rparams), name
+        for cp, rp in zip(params, rparams):
+            assert c_to_rust(cp) == rp, (name, cp, rp)
+        assert (rret == "" and ret == "void") or c_to_rust(ret) == rret, (name, ret, rret)
+    # repr(C) structs: field-for-field
+    for sname, body in re.findall(r"typedef\s+struct\s*\{(.*?)\}\s*(\w+)\s*;", re.sub(r"/\*.*?\*/", " ", read(ROOT, "include", "poulpy_hip.h"), flags=re.S), flags=re.S)[::1]:
+        pass
+    text = re.sub(r"/\*.*?\*/", " ", read(ROOT, "include", "poulpy_hip.h"), flags=re.S)
+    for body, sname in re.findall(r"typedef\s+struct\s*\{(.*?)\}\s*(\w+)\s*;", text, flags=re.S):
+        cfields = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if decl:
+                ty, rest = decl.split(" ", 1)
+                cfields += [(n.strip(), C2R.get(ty, ty)) for n in rest.split(",")]
+        rs = re.search(r"pub struct %s \{(.*?)\}" % sname, ffi, flags=re.S).group(1)
+        rfields = [(a.strip(), b.strip()) for a, b in re.findall(r"pub (\w+): ([\w_]+),", rs)]
+        assert rfields == cfields, sname
+
+
+def rust_fn_names(src):
+    return re.findall(r"\n\s*(?:pub\s+)?(?:unsafe\s+)?fn (\w+)", strip_rust_comments(src))
+
+
+def test_hal_impl_defines_every_required_method_of_the_trait():
+    want = fixture("hal_impl_fns.txt")
+    assert len(want) == 105
+    src = read(CRATE, "src", "hal_impl.rs")
+    code = strip_rust_comments(src)
+    body = code[code.index("unsafe impl HalImpl<FFT64Hip> for FFT64Hip {"):]
+    have = re.findall(r"\n    fn (\w+)", body)
+    assert sorted(have) == sorted(want), (sorted(set(want) - set(have)), sorted(set(have) - set(want)))
+    assert len(have) == len(set(have))
+    for bad in ("unimplemented!", "todo!", "unreachable!", "hal_impl_scratch!", "hal_impl_vec_znx!"):
+        assert bad not in code, bad
+    # every forwarded call exists in the header, and every ScalarPrep-touching family is forwarded (not a CPU default)
+    hdr = header_functions()
+    used = set(re.findall(r"ffi::(pz_\w+)\(", code))
+    assert used <= set(hdr), used - set(hdr)
+    for name in want:
+        if name.startswith(("vec_znx_dft_", "vec_znx_idft_", "svp_", "vmp_", "cnv_")):
+            m = re.search(r"\n    fn %s\b.*?\n    \}\n" % name, body, flags=re.S)
+            assert m and "ffi::pz_" + name in m.group(0), name
+    assert code.count("{") == code.count("}") and code.count("(") == code.count(")")
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present (GPU box)")
+def test_fixtures_are_the_reference_traits():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_shim as g
+    names = [m[0] for m in g.parse_trait(os.path.join(REF, "poulpy-hal", "src", "oep", "hal_impl.rs"))]
+    assert names == fixture("hal_impl_fns.txt")
+    core = [m[0] for m in g.parse_trait_named(os.path.join(REF, "poulpy-core", "src", "oep", "core_impl.rs"), "pub unsafe trait CoreImpl")]
+    assert core == fixture("core_impl_fns.txt")
+    # and the committed sources are what the generator writes today
+    before = {f: read(CRATE, "src", f) for f in ("hal_impl.rs", "core_impl.rs")}
+    g.main()
+    g.core_main(REF)
+    for f, txt in before.items():
+        assert read(CRATE, "src", f) == txt, f + " is stale: run python tools/gen_rust_shim.py"
+
+
+def test_core_impl_covers_the_trait():
+    want = fixture("core_impl_fns.txt")
+    code = strip_rust_comments(read(CRATE, "src", "core_impl.rs"))
+    body = code[code.index("unsafe impl CoreImpl<FFT64Hip> for FFT64Hip {"):]
+    written = re.findall(r"\n    fn (\w+)", body)
+    assert len(written) == len(set(written)) == 35
+    macros = re.findall(r"poulpy_core::(impl_core_\w+_default_methods)!\(FFT64Hip\);", body)
+    assert sorted(macros) == ["impl_core_conversion_default_methods", "impl_core_decryption_default_methods",
+                              "impl_core_encryption_default_methods", "impl_core_operations_default_methods"]
+    assert set(written) <= set(want)
+    fused = [n for n in written if re.search(r"\n    fn %s\b.*?ffi::pz_glwe_\w+_batched" % n, body[:body.index("\n    fn " + n) + 4000] if False else
+                                              re.search(r"\n    fn %s\b.*?\n    \}\n" % n, body, flags=re.S).group(0), flags=re.S)]
+    assert sorted(fused) == sorted(["glwe_external_product", "glwe_external_product_assign", "glwe_keyswitch", "glwe_keyswitch_assign",
+                                    "glwe_automorphism", "glwe_automorphism_assign", "glwe_automorphism_add", "glwe_automorphism_add_assign",
+                                    "glwe_automorphism_sub", "glwe_automorphism_sub_assign", "glwe_automorphism_sub_negate",
+                                    "glwe_automorphism_sub_negate_assign"])
+    if os.path.isdir(REF):   # the four macro families + the 35 written-out fns are the whole trait
+        n_macro = 0
+        for fam in ("decryption", "conversion", "operations", "encryption"):
+            s = read(REF, "poulpy-core", "src", "oep", fam + ".rs")
+            n_macro += len(re.findall(r"\n        fn (\w+)", s[s.index("macro_rules!"):]))
+        assert n_macro + len(written) == len(want)
+    assert code.count("{") == code.count("}") and code.count("(") == code.count(")")
+
+
+def test_lib_znx_and_tests_rs():
+    lib = strip_rust_comments(read(CRATE, "src", "lib.rs"))
+    for needle in ("impl Backend for FFT64Hip", "type ScalarPrep = f64", "type ScalarBig = i64", "type OwnedBuf = PinnedBuf",
+                   "unsafe fn destroy", "mod hal_impl;", "mod znx;", "mod core_impl;", "mod tests;"):
+        assert needle in lib, needle
+    znx = strip_rust_comments(read(CRATE, "src", "znx.rs"))
+    traits = re.findall(r"\n    (Znx\w+)::", znx)
+    assert len(traits) == len(set(traits)) == 27          # the 27 Znx* impls of poulpy-cpu-ref/src/fft64/znx.rs
+    if os.path.isdir(REF):
+        ref = read(REF, "poulpy-cpu-ref", "src", "fft64", "znx.rs")
+        assert sorted(traits) == sorted(re.findall(r"\nimpl (Znx\w+) for FFT64Ref", ref))
+    t = strip_rust_comments(read(CRATE, "src", "tests.rs"))
+    listed = set(re.findall(r"\b(test_\w+)\b", t))
+    assert "cross_backend_test_suite!" in t and "backend_ref = poulpy_cpu_ref::FFT64Ref" in t and "backend_test = crate::FFT64Hip" in t
+    if os.path.isdir(REF):
+        for mod_ in ("vec_znx", "vec_znx_big", "vec_znx_dft", "svp", "vmp"):
+            s = read(REF, "poulpy-hal", "src", "test_suite", mod_ + ".rs")
+            cross = [m.group(1) for m in re.finditer(r"pub fn (test_\w+)(?:<[^>]*>)?\s*\(\s*params", s)]
+            assert cross and set(cross) <= listed, (mod_, set(cross) - listed)
+    for f in ("lib.rs", "znx.rs", "tests.rs"):
+        c = strip_rust_comments(read(CRATE, "src", f))
+        assert c.count("{") == c.count("}") and c.count("(") == c.count(")"), f
