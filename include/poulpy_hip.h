@@ -35,6 +35,13 @@
  *    shim panics on non-zero, matching the reference's assert!/panic! behaviour.
  *  - All *_batched entry points take DEVICE pointers only and treat `batch`
  *    independent objects laid out back to back (object b at ptr + b*object_len).
+ *    Exception: the four GLWE-level calls pz_glwe_external_product_batched, pz_glwe_keyswitch_batched,
+ *    pz_glwe_automorphism_batched and pz_glwe_tensor_relinearize_batched also accept HOST containers for res / a (staged, the
+ *    call is then logically synchronous) and a HOST-resident prepared key: poulpy-hal's buffers are host-addressable by contract
+ *    (Backend::OwnedBuf: DataMut), so this is what the Rust shim's CoreImpl overrides pass.  A host key is mirrored on the
+ *    device on first use and re-used afterwards; the mirror is validated on every call by a sampled fingerprint of the host
+ *    bytes and dropped by pz_vmp_prepare / pz_vmp_zero on that buffer.  A caller that modifies a prepared matrix in place by
+ *    other means (e.g. deserializes into it) must call pz_module_forget_host_key before the next use.
  */
 #ifndef POULPY_HIP_H
 #define POULPY_HIP_H
@@ -473,6 +480,8 @@ size_t pz_glwe_op_workspace_bytes(const pz_module* m, const pz_glwe_op_params* p
  * costs one extra copy of the key in HBM).  Modifying a pinned key without unpinning it first is a caller error. */
 int pz_module_pin_key(pz_module* m, const double* pmat, size_t rows, size_t cols_in, size_t cols_out, size_t size);
 int pz_module_unpin_key(pz_module* m, const double* pmat);
+/* drops the device mirror of a host-resident prepared key (see "Conventions" above); unknown pointers are ignored */
+int pz_module_forget_host_key(pz_module* m, const double* host_pmat);
 /* Tuning knob: number of ciphertexts pushed through the three-kernel pipeline per
  * wave so that intermediates stay in the 256 MiB Infinity Cache (0 = auto). */
 int pz_module_set_chunk(pz_module* m, size_t cts_per_chunk);

@@ -91,6 +91,118 @@ static int with_graph(pz_module* M, uint64_t key, F&& body) {
 }
 
 // ------------------------------------------------------------------------------
+// host containers at the batched GLWE entry points (what the Rust shim's CoreImpl overrides pass: poulpy-hal buffers are host
+// addressable by contract).  Ciphertexts are staged like any per-op argument; prepared keys get a device mirror.
+// ------------------------------------------------------------------------------
+static uint64_t host_fingerprint(const void* p, size_t bytes) {
+    // FNV-1a over the first / last 4 KiB and ~8192 words strided over the rest: any (re)preparation of the key changes it with
+    // overwhelming probability; a caller that patches a prepared matrix in place behind the backend's back calls
+    // pz_module_forget_host_key (include/poulpy_hip.h)
+    const uint64_t* w = (const uint64_t*)p;
+    const size_t nw = bytes / 8;
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)bytes;
+    auto mix = [&](uint64_t v) { h ^= v; h *= 1099511628211ull; h ^= h >> 29; };
+    const size_t edge = std::min<size_t>(nw, 512);
+    for (size_t i = 0; i < edge; ++i) mix(w[i]);
+    for (size_t i = nw - edge; i < nw; ++i) mix(w[i]);
+    const size_t stride = std::max<size_t>(1, nw / 8192) | 1;
+    for (size_t i = 0; i < nw; i += stride) mix(w[i]);
+    return h;
+}
+static void drop_mirror_at(pz_module* M, size_t i) {
+    auto& mr = M->mirrors[i];
+    for (size_t k = 0; k < M->pinned.size(); ++k)
+        if (M->pinned[k].key == mr.dev) {
+            if (M->pinned[k].sliced) (void)hipFree(M->pinned[k].sliced);
+            M->pinned.erase(M->pinned.begin() + (long)k);
+            break;
+        }
+    if (mr.dev) (void)hipFree(mr.dev);
+    M->mirrors.erase(M->mirrors.begin() + (long)i);
+    M->graph_epoch++;
+}
+static int forget_host_key(pz_module* M, const void* host) {
+    for (size_t i = 0; i < M->mirrors.size(); ++i)
+        if (M->mirrors[i].host == host) {
+            PZ_HIP(hipStreamSynchronize(M->stream));
+            drop_mirror_at(M, i);
+            return PZ_OK;
+        }
+    return PZ_OK;
+}
+// device pointer of a prepared key: itself when it is one, else its (validated, possibly refreshed) mirror; the mirror also gets
+// the row-sliced copy of the fused pipeline (as pz_module_pin_key would build it), valid for as long as the mirror is
+static int resolve_key(pz_module* M, const double* pmat, size_t bytes, const double** out) {
+    if (is_device_ptr(pmat)) { *out = pmat; return PZ_OK; }
+    const uint64_t fp = host_fingerprint(pmat, bytes);
+    for (size_t i = 0; i < M->mirrors.size(); ++i) {
+        auto& mr = M->mirrors[i];
+        if (mr.host != (const void*)pmat) continue;
+        if (mr.bytes == bytes && mr.fp == fp) { mr.stamp = ++M->mirror_clock; *out = (const double*)mr.dev; return PZ_OK; }
+        PZ_HIP(hipStreamSynchronize(M->stream));
+        drop_mirror_at(M, i);
+        break;
+    }
+    size_t total = bytes;
+    for (auto& mr : M->mirrors) total += mr.bytes;
+    while (!M->mirrors.empty() && (M->mirrors.size() >= 64 || total > ((size_t)48 << 30))) {   // LRU: at most 64 keys / 48 GiB mirrored
+        size_t lru = 0;
+        for (size_t i = 1; i < M->mirrors.size(); ++i) if (M->mirrors[i].stamp < M->mirrors[lru].stamp) lru = i;
+        total -= M->mirrors[lru].bytes;
+        PZ_HIP(hipStreamSynchronize(M->stream));
+        drop_mirror_at(M, lru);
+    }
+    void* dev = nullptr;
+    PZ_HIP(hipMalloc(&dev, bytes));
+    if (hipMemcpyAsync(dev, pmat, bytes, hipMemcpyHostToDevice, M->stream) != hipSuccess) {
+        (void)hipFree(dev);
+        return fail(PZ_ERR_HIP, "upload of a host-resident prepared key failed");
+    }
+    M->mirrors.push_back({(const void*)pmat, bytes, dev, fp, ++M->mirror_clock});
+    M->graph_epoch++;
+    if ((M->plan.m2 == 256 || M->plan.m2 == 128) && (M->plan.m1 % 16) == 0) {
+        const size_t npolys = bytes / ((size_t)M->n * 8);
+        cplx* sliced = nullptr;
+        if (hipMalloc(&sliced, bytes) == hipSuccess) {
+            if (launch_permute_pmat(M, (const double*)dev, sliced, (int)npolys) == PZ_OK) M->pinned.push_back({(const void*)dev, sliced, bytes});
+            else (void)hipFree(sliced);
+        } else {
+            (void)hipGetLastError();   // no room for the sliced copy: the pipeline rebuilds it per call
+        }
+    }
+    *out = (const double*)dev;
+    return PZ_OK;
+}
+// a batched GLWE op whose ciphertext arguments may be host containers
+struct GlweArgs {
+    Stage sa, sr;
+    int64_t* res = nullptr;
+    const int64_t* a = nullptr;
+    const double* key = nullptr;
+    bool host = false;
+};
+static int glwe_args_in(pz_module* M, GlweArgs& g, int64_t* res, const int64_t* a, const double* pmat, size_t res_bytes, size_t a_bytes,
+                        size_t key_bytes) {
+    PZ_REQUIRE(res != nullptr && a != nullptr && pmat != nullptr, "null argument");
+    PZ_TRY(resolve_key(M, pmat, key_bytes, &g.key));
+    PZ_TRY(g.sa.in(a, a_bytes, true, false, M));
+    if ((const void*)res == (const void*)a) {   // *_assign forms
+        PZ_REQUIRE(res_bytes == a_bytes, "in-place call with different layouts for a and res");
+        g.sr.M = M; g.sr.dev = g.sa.dev; g.sa.out = true;
+    } else {
+        PZ_TRY(g.sr.in(res, res_bytes, false, true, M));
+    }
+    g.res = (int64_t*)g.sr.dev; g.a = (const int64_t*)g.sa.dev;
+    g.host = g.sa.owned || g.sr.owned;
+    return PZ_OK;
+}
+static int glwe_args_out(pz_module* M, GlweArgs& g) {
+    PZ_TRY(g.sr.finish());
+    PZ_TRY(g.sa.finish());
+    return finish_call(M, g.host);
+}
+
+// ------------------------------------------------------------------------------
 // public: misc
 // ------------------------------------------------------------------------------
 extern "C" {
@@ -135,6 +247,7 @@ void pz_module_free(pz_module* M) {
         if (p) (void)hipFree(p);
     for (auto& c : M->arena) (void)hipFree(c.p);
     for (auto& k : M->pinned) if (k.sliced) (void)hipFree(k.sliced);
+    for (auto& mr : M->mirrors) if (mr.dev) (void)hipFree(mr.dev);
     for (auto& t : M->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
     for (auto e : M->event_pool) (void)hipEventDestroy(e);
     for (auto& ge : M->graphs) {
@@ -750,6 +863,7 @@ size_t pz_vmp_apply_dft_tmp_bytes(const pz_module* M, size_t res_size, size_t a_
 
 int pz_vmp_prepare(pz_module* M, double* pmat, const int64_t* mat, size_t rows, size_t cols_in, size_t cols_out, size_t size) {
     PZ_ENTER(M);
+    PZ_TRY(forget_host_key(M, (const void*)pmat));   // (a device mirror of this host buffer would be stale)
     const size_t npolys = rows * cols_in * cols_out * size;
     Stage sp, sm;
     PZ_TRY(sm.in(mat, npolys * M->n * 8, true, false, M));
@@ -775,6 +889,7 @@ int pz_vmp_prepare(pz_module* M, double* pmat, const int64_t* mat, size_t rows, 
 
 int pz_vmp_zero(pz_module* M, double* pmat, size_t rows, size_t cols_in, size_t cols_out, size_t size) {
     PZ_ENTER(M);
+    PZ_TRY(forget_host_key(M, (const void*)pmat));
     const size_t bytes = rows * cols_in * cols_out * size * M->n * 8;
     if (is_device_ptr(pmat)) PZ_HIP(hipMemsetAsync(pmat, 0, bytes, M->stream));
     else memset(pmat, 0, bytes);
@@ -1331,21 +1446,36 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
     return PZ_OK;
 }
 
+// The four GLWE-level entry points accept device pointers (batched, device-resident: the measured path) or HOST containers
+// (what a CoreImpl override of the Rust shim passes): host ciphertexts are staged, a host-resident prepared key is mirrored on
+// the device (resolve_key); the call is then logically synchronous like every host-pointer call.
+static int glwe_entry(pz_module* M, bool ks, bool tensor, int64_t* res, const int64_t* a, const double* pmat, const pz_glwe_op_params* p,
+                      size_t batch, const AutoSpec* au) {
+    PZ_REQUIRE(p != nullptr, "null params");
+    PZ_REQUIRE(p->dsize >= 1 && p->dnum >= 1 && p->key_size >= 1 && p->a_size >= 1 && p->res_size >= 1, "glwe op: empty shape");
+    const OpShape s = op_shape(p, ks || tensor, tensor);
+    const size_t n8 = (size_t)M->n * 8;
+    GlweArgs g;
+    PZ_TRY(glwe_args_in(M, g, res, a, pmat, batch * n8 * s.cols_out * p->res_size, batch * n8 * s.cols_a * p->a_size,
+                        n8 * p->dnum * s.cols_in * s.cols_out * p->key_size));
+    PZ_TRY(glwe_op(M, ks, g.res, g.a, g.key, p, batch, au, nullptr, tensor));
+    return glwe_args_out(M, g);
+}
 int pz_glwe_external_product_batched(pz_module* M, int64_t* res, const int64_t* a, const double* ggsw_pmat,
                                      const pz_glwe_op_params* p, size_t batch) {
     PZ_ENTER(M);
-    return glwe_op(M, false, res, a, ggsw_pmat, p, batch);
+    return glwe_entry(M, false, false, res, a, ggsw_pmat, p, batch, nullptr);
 }
 int pz_glwe_keyswitch_batched(pz_module* M, int64_t* res, const int64_t* a, const double* key_pmat, const pz_glwe_op_params* p,
                               size_t batch) {
     PZ_ENTER(M);
-    return glwe_op(M, true, res, a, key_pmat, p, batch);
+    return glwe_entry(M, true, false, res, a, key_pmat, p, batch, nullptr);
 }
 int pz_glwe_automorphism_batched(pz_module* M, int64_t* res, const int64_t* a, const double* key_pmat, const pz_glwe_op_params* p,
                                  int64_t gal, int mode, size_t batch) {
     PZ_ENTER(M);
     AutoSpec au{(long long)gal, mode};
-    return glwe_op(M, true, res, a, key_pmat, p, batch, &au);
+    return glwe_entry(M, true, false, res, a, key_pmat, p, batch, &au);
 }
 // glwe_tensor_relinearize (poulpy-core/src/operations/glwe.rs:541-607) on `batch` GLWETensors sharing one prepared tensor key
 int pz_glwe_tensor_relinearize_batched(pz_module* M, int64_t* res, const int64_t* a, const double* tsk_pmat, const pz_glwe_op_params* p,
@@ -1353,7 +1483,11 @@ int pz_glwe_tensor_relinearize_batched(pz_module* M, int64_t* res, const int64_t
     PZ_ENTER(M);
     PZ_REQUIRE(p != nullptr, "null params");
     PZ_REQUIRE(p->rank >= 1 && p->rank_out == p->rank, "glwe_tensor_relinearize: the tensor key maps rank (rank + 1) / 2 -> rank");
-    return glwe_op(M, true, res, a, tsk_pmat, p, batch, nullptr, nullptr, true);
+    return glwe_entry(M, true, true, res, a, tsk_pmat, p, batch, nullptr);
+}
+int pz_module_forget_host_key(pz_module* M, const double* host_pmat) {
+    PZ_ENTER(M);
+    return forget_host_key(M, (const void*)host_pmat);
 }
 // ggsw_external_product (external_product/ggsw.rs:54-58): every (row, column) entry of the GGSW `a` is a GLWE and the entries
 // are contiguous in the MatZnx layout, so the operation is one batched external product over dnum_a * (rank+1) ciphertexts

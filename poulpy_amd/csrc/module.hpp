@@ -136,6 +136,12 @@ struct pz_module {
     // prepared keys the caller declared immutable (pz_module_pin_key): their row-sliced copies for the fused pipeline
     struct PinnedKey { const void* key; pz::cplx* sliced; size_t bytes; };
     std::vector<PinnedKey> pinned;
+    // device mirrors of HOST-resident prepared keys handed to the batched GLWE entry points (the Rust shim's prepared layouts
+    // live in pinned host memory, poulpy-hal requires host-addressable buffers): uploaded on first use, re-validated on every
+    // call by a sampled fingerprint of the host bytes, dropped by pz_vmp_prepare / pz_vmp_zero / pz_module_forget_host_key
+    struct KeyMirror { const void* host; size_t bytes; void* dev; uint64_t fp; uint64_t stamp; };
+    std::vector<KeyMirror> mirrors;
+    uint64_t mirror_clock = 0;
     bool fuse_tail = true, fuse_mid = true;  // kernel-fusion knobs of the batched GLWE ops (tests run both settings)
     // per-kernel-class HIP-event timing (bench.py's roofline leg); off by default
     bool timing = false;

@@ -976,7 +976,7 @@ def test_tmp_bytes_workspace_and_small_utilities(mods):
 
 def test_batched_entry_points_reject_bad_arguments(mods):
     """Shape / pointer violations are reported (PZ_ERR_INVALID -> PoulpyHipError), never undefined behaviour: host pointers where
-    device pointers are required, empty shapes, an even Galois element, an automorphism key that changes the rank, an unknown mode,
+    device pointers are required (the GLWE-level calls accept host containers: test_glwe_ops_on_host_containers), empty shapes, an even Galois element, an automorphism key that changes the rank, an unknown mode,
     base2k out of range; a zero batch is a no-op."""
     import ctypes as C
     from poulpy_amd.hal import BlindRotationParams, GlweOpParams, PoulpyHipError
@@ -988,9 +988,11 @@ def test_batched_entry_points_reject_bad_arguments(mods):
     hp = host.ctypes.data_as(C.c_void_p)
     hip.glwe_external_product_batched(d.ptr, d.ptr, d.ptr, good, 0)                      # batch 0: nothing to do
     with pytest.raises(PoulpyHipError):
-        hip.glwe_external_product_batched(hp, d.ptr, d.ptr, good, 1)                     # host pointer
+        hip.glwe_external_product_batched(None, d.ptr, d.ptr, good, 1)                   # null pointer
     with pytest.raises(PoulpyHipError):
-        hip.glwe_keyswitch_batched(d.ptr, d.ptr, hp, good, 1)
+        hip.glwe_keyswitch_batched(d.ptr, d.ptr, None, good, 1)
+    with pytest.raises(PoulpyHipError):
+        hip.glwe_pack_batched(hp, [0], [d.ptr], 0, [5] * 8, [d.ptr] * 8, good, d.ptr, 1 << 20, 1)   # host pointer where a device one is required
     bad = GlweOpParams(rank=1, dnum=0, dsize=1, key_size=2, key_base2k=12, a_size=2, a_base2k=12, res_size=2, res_base2k=12, rank_out=1)
     with pytest.raises(PoulpyHipError):
         hip.glwe_external_product_batched(d.ptr, d.ptr, d.ptr, bad, 1)                   # empty shape
@@ -1582,3 +1584,101 @@ def test_glwe_automorphism_spectral_path(mods, n, rank, p, mode, in_place):
                              in_place=in_place)
     assert np.array_equal(got, want)
 
+
+
+# ------------------------------------------------------------------------------------------
+# host containers at the GLWE-level entry points (what the Rust shim's CoreImpl overrides pass)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [256, 4096, 65536])
+def test_glwe_ops_on_host_containers(mods, n):
+    """pz_glwe_{external_product,keyswitch,automorphism}_batched / pz_glwe_tensor_relinearize_batched with HOST ciphertexts and a
+    HOST-resident prepared key: staged ciphertexts, device mirror of the key (re-used across calls, refreshed when the host bytes
+    change, dropped by vmp_prepare and pz_module_forget_host_key), in-place forms, mixed host / device arguments."""
+    import ctypes as C
+    from poulpy_amd.hal import GlweOpParams
+    ref, hip = mods(n)
+    rng = seeded(n + 77)
+    rank, size, base2k, dnum = 1, (8 if n == 65536 else 3), 12, (8 if n == 65536 else 3)
+    cols = rank + 1
+    hp = lambda arr: arr.ctypes.data_as(C.c_void_p)
+    p = GlweOpParams(rank=rank, dnum=dnum, dsize=1, key_size=size, key_base2k=base2k, a_size=size, a_base2k=base2k, res_size=size,
+                     res_base2k=base2k, rank_out=rank)
+    batch = 2
+    for kind in ("external_product", "keyswitch", "automorphism_add", "relinearize"):
+        ks = kind != "external_product"
+        cols_in = rank if ks else cols
+        a_cols = cols + 1 if kind == "relinearize" else cols
+        mat = MatZnx(n, dnum, cols_in, cols, size).fill_uniform(base2k, rng)
+        pr, ph = ref.vmp_pmat_alloc(dnum, cols_in, cols, size), hip.vmp_pmat_alloc(dnum, cols_in, cols, size)
+        ref.vmp_prepare(pr, mat)
+        hip.vmp_prepare(ph, mat)
+        a_all = np.empty((batch, size, a_cols, n), dtype=np.int64)
+        want = np.empty((batch, size, cols, n), dtype=np.int64)
+
+        def oracle(pm):
+            for t in range(batch):
+                a = VecZnx(n, a_cols, size, a_all[t].copy())
+                r = VecZnx(n, cols, size)
+                if kind == "external_product":
+                    ref.glwe_external_product(r, base2k, a, base2k, pm, 1, base2k)
+                elif kind == "keyswitch":
+                    ref.glwe_keyswitch(r, base2k, a, base2k, pm, 1, base2k)
+                elif kind == "automorphism_add":
+                    ref.glwe_automorphism(r, base2k, a, base2k, pm, 1, base2k, 5, "add")
+                else:
+                    ref.glwe_tensor_relinearize(r, base2k, a, base2k, pm, 1, base2k)
+                want[t] = r.data
+
+        def run(res_arr, a_arr, key_ptr):
+            rp = res_arr if isinstance(res_arr, C.c_void_p) else hp(res_arr)
+            ap = a_arr if isinstance(a_arr, C.c_void_p) else hp(a_arr)
+            if kind == "external_product":
+                hip.glwe_external_product_batched(rp, ap, key_ptr, p, batch)
+            elif kind == "keyswitch":
+                hip.glwe_keyswitch_batched(rp, ap, key_ptr, p, batch)
+            elif kind == "automorphism_add":
+                hip.glwe_automorphism_batched(rp, ap, key_ptr, p, 5, "add", batch)
+            else:
+                hip.glwe_tensor_relinearize_batched(rp, ap, key_ptr, p, batch)
+
+        for t in range(batch):
+            a_all[t] = VecZnx(n, a_cols, size).fill_uniform(base2k, rng).data
+        oracle(pr)
+        got = np.full_like(want, 0x5A)
+        a_before = a_all.copy()
+        run(got, a_all, hp(ph.data))                 # everything on the host: first use uploads the key mirror
+        assert np.array_equal(got, want) and np.array_equal(a_all, a_before), kind
+        got[...] = 1
+        run(got, a_all, hp(ph.data))                 # second use: mirror re-used
+        assert np.array_equal(got, want), kind
+        if a_cols == cols:                           # *_assign form: res is the input container
+            inout = a_all.copy()
+            run(inout, inout, hp(ph.data))
+            assert np.array_equal(inout, want), kind
+        # mixed: device ciphertexts, host key
+        d_a = hip.device_alloc(a_all.nbytes).upload(a_all)
+        d_r = hip.device_alloc(want.nbytes)
+        run(d_r.ptr, d_a.ptr, hp(ph.data))
+        hip.sync()
+        assert np.array_equal(d_r.download(np.int64, want.size).reshape(want.shape), want), kind
+        # the host key changes: re-prepared in place (mirror dropped by vmp_prepare) ...
+        mat2 = MatZnx(n, dnum, cols_in, cols, size).fill_uniform(base2k, rng)
+        ref.vmp_prepare(pr, mat2)
+        hip.vmp_prepare(ph, mat2)
+        oracle(pr)
+        run(got, a_all, hp(ph.data))
+        assert np.array_equal(got, want), kind
+        # ... or overwritten behind the backend's back (fingerprint mismatch -> refreshed), here with the first key again
+        ph1 = hip.vmp_pmat_alloc(dnum, cols_in, cols, size)
+        hip.vmp_prepare(ph1, mat)
+        ph.data[...] = ph1.data
+        ref.vmp_prepare(pr, mat)
+        oracle(pr)
+        run(got, a_all, hp(ph.data))
+        assert np.array_equal(got, want), kind
+        assert hip.lib.pz_module_forget_host_key(hip.handle, hp(ph.data)) == 0
+        run(got, a_all, hp(ph.data))
+        assert np.array_equal(got, want), kind
+        assert hip.lib.pz_module_forget_host_key(hip.handle, hp(ph.data)) == 0
+        for buf in (d_a, d_r):
+            buf.free()
