@@ -36,6 +36,27 @@ __device__ __forceinline__ cplx cmulc(cplx a, cplx b) {
 template <bool CONJ>
 __device__ __forceinline__ cplx cmul_t(cplx a, cplx b) { return CONJ ? cmulc(a, b) : cmul(a, b); }
 
+// Streaming hints for data that is touched once per kernel (the i64 limbs, T', T2'): non-temporal loads / stores.  Measured on
+// MI355X (profiles/r02_hbm_copy_tuned.txt): a 16 B-per-lane copy runs at 6.25 TB/s plain and 6.5-6.6 TB/s with both hints.
+// PZ_STREAM_HINTS: bit 0 loads, bit 1 stores (build-time, for A/B runs; default both).
+#ifndef PZ_STREAM_HINTS
+#define PZ_STREAM_HINTS 3
+#endif
+typedef double pz_dbl2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cplx ld_stream(const cplx* p) {
+    if (PZ_STREAM_HINTS & 1) { const pz_dbl2 v = __builtin_nontemporal_load(reinterpret_cast<const pz_dbl2*>(p)); return make_double2(v.x, v.y); }
+    return *p;
+}
+__device__ __forceinline__ long long ld_stream(const long long* p) { return (PZ_STREAM_HINTS & 1) ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void st_stream(cplx* p, cplx v) {
+    if (PZ_STREAM_HINTS & 2) { const pz_dbl2 t = {v.x, v.y}; __builtin_nontemporal_store(t, reinterpret_cast<pz_dbl2*>(p)); }
+    else *p = v;
+}
+__device__ __forceinline__ void st_stream(long long* p, long long v) {
+    if (PZ_STREAM_HINTS & 2) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 // ---- in-register radix-R DFT, R in {1,2,4,8,16}; natural-order output --------
 // X[k] = sum_n v[n] * w^(+nk) (INV=false) or w^(-nk) (INV=true), w = exp(2*pi*i/R).
 #define PZ_C8 0.70710678118654752440084436210485   /* cos(pi/4) */
@@ -164,8 +185,8 @@ k_fwd_pass1(const long long* __restrict__ src, PolyMap smap, cplx* __restrict__ 
 #pragma unroll
         for (int n1 = 0; n1 < R1; ++n1) {
             const long long idx = (long long)(o + R2 * n1) * m2 + c0 + c;
-            raw_re[n1] = a[idx] & mask;   // mask = -1 except for cnv_prepare's last active limb (reim/conversion.rs:31-40)
-            raw_im[n1] = a[idx + m] & mask;
+            raw_re[n1] = (ROWMAJOR ? ld_stream(a + idx) : a[idx]) & mask;   // mask = -1 except for cnv_prepare's last active limb (reim/conversion.rs:31-40)
+            raw_im[n1] = (ROWMAJOR ? ld_stream(a + idx + m) : a[idx + m]) & mask;
         }
     }
     for (int t = tid; t < M1; t += NT) {
@@ -197,7 +218,8 @@ k_fwd_pass1(const long long* __restrict__ src, PolyMap smap, cplx* __restrict__ 
 #pragma unroll
         for (int k2 = 0; k2 < R2; ++k2) {
             const long long tix = ROWMAJOR ? (long long)(k1 + R1 * k2) * m2 + c0 + c : (long long)(c0 + c) * M1 + k1 + R1 * k2;
-            Tp[tix] = cmul(u[k2], tw12[tix]);
+            if (ROWMAJOR) st_stream(Tp + tix, cmul(u[k2], tw12[tix]));
+            else Tp[tix] = cmul(u[k2], tw12[tix]);
         }
     }
 }
@@ -466,7 +488,7 @@ k_inv_tail(TailArgs g) {
         cplx u[R2];
         if (L > 0) {
 #pragma unroll
-            for (int k2 = 0; k2 < R2; ++k2) u[k2] = Tb[(long long)(L - 1) * limb_stride + k2s * k2];
+            for (int k2 = 0; k2 < R2; ++k2) u[k2] = ROWMAJOR ? ld_stream(Tb + (long long)(L - 1) * limb_stride + k2s * k2) : Tb[(long long)(L - 1) * limb_stride + k2s * k2];
         }
         // iteration t produces limb L-1-t into buffer (L-1-t)&1; t = 0 is the prologue
         for (int t = 0; t <= L; ++t) {
@@ -482,7 +504,7 @@ k_inv_tail(TailArgs g) {
                 }
                 if (j > 0) {
 #pragma unroll
-                    for (int k2 = 0; k2 < R2; ++k2) u[k2] = Tb[(long long)(j - 1) * limb_stride + k2s * k2];
+                    for (int k2 = 0; k2 < R2; ++k2) u[k2] = ROWMAJOR ? ld_stream(Tb + (long long)(j - 1) * limb_stride + k2s * k2) : Tb[(long long)(j - 1) * limb_stride + k2s * k2];
                 }
             }
             __syncthreads();
@@ -616,7 +638,7 @@ k_inv_tail(TailArgs g) {
                 const unsigned long long y2 = (unsigned long long)d + (unsigned long long)cy + half;         \
                 const long long x1 = (long long)(y2 & mask) - (long long)half;                               \
                 cy = (long long)((unsigned long long)cr + (unsigned long long)((long long)y2 >> k));         \
-                if (writes) res_col[(long long)j * res_ls + idx] = x1;                                       \
+                if (writes) { if (ROWMAJOR) st_stream(res_col + (long long)j * res_ls + idx, x1); else res_col[(long long)j * res_ls + idx] = x1; } \
             }                                                                                                \
         }                                                                                                    \
     }

@@ -352,7 +352,7 @@ k_mid128(MidArgs g) {
     {
         const cplx* src = src_ptr(w);
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) x[n1] = src[8 * n1];
+        for (int n1 = 0; n1 < 16; ++n1) x[n1] = ld_stream(src + 8 * n1);
         twn = g.tw12t[(long long)out_q1(tile_q1(w)) * M2 + (tid & (M2 - 1))];
     }
     if (tid < M2) twrow[tid] = twn;
@@ -432,7 +432,7 @@ k_mid128(MidArgs g) {
         {
             const cplx* src = src_ptr(L + W);
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) x[n1] = src[8 * n1];
+            for (int n1 = 0; n1 < 16; ++n1) x[n1] = ld_stream(src + 8 * n1);
             twn = g.tw12t[(long long)out_q1(tile_q1(min(L + W, ntiles - 1))) * M2 + (tid & (M2 - 1))];
         }
         // inverse row DFT: this lane owns k1 = o and o+8: radix 8 over k2 -> z[k1][oo] x conj W128^(oo*k1);
@@ -463,7 +463,7 @@ k_mid128(MidArgs g) {
             cplx* dst = active ? g.T2 + ((long long)b * g.npo + rr) * m + (long long)out_q1(q1) * M2 + o
                                : g.dummy + (long long)tid * 16 * 16 + o;
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) dst[8 * n1] = cmulc(u[n1], twrow[o + 8 * n1]);
+            for (int n1 = 0; n1 < 16; ++n1) st_stream(dst + 8 * n1, cmulc(u[n1], twrow[o + 8 * n1]));
         }
         lds_barrier();
         if (tid < M2) twrow[tid] = twn;
