@@ -7,7 +7,7 @@ all: $(LIB) oracle
 
 UNITS := $(wildcard $(CSRC)/*.hip)
 OBJS  := $(patsubst $(CSRC)/%.hip,$(CSRC)/_obj/%.o,$(UNITS))
-RCCL  := $(if $(wildcard /opt/rocm/include/rccl/rccl.h),-L/opt/rocm/lib -lrccl,)
+RCCL  := -ldl   # RCCL itself is dlopen-ed at the first pz_comm_* call (api_dist.hip)
 
 # one object per translation unit (make -j8 compiles them in parallel; launch_br.hip is the long pole, ~75 s)
 $(CSRC)/_obj/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.hpp) include/poulpy_hip.h

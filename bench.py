@@ -216,7 +216,12 @@ def main():
         mod.sync()
         del mat
     if distributed:
-        pdist.broadcast_key(pmat, src=0)
+        # the only collective of the path.  POULPY_BENCH_BCAST=cabi: through the C ABI (pz_bcast_key, RCCL on the module stream:
+        # what a Rust / C++ caller uses) instead of torch.distributed
+        if os.environ.get("POULPY_BENCH_BCAST", "torch") == "cabi":
+            pdist.broadcast_key_cabi(mod, pmat, src=0)
+        else:
+            pdist.broadcast_key(pmat, src=0)
 
     # this rank's shard of the (weak-scaled) batch: `batch` ciphertexts per GPU, seeds by global index
     lo, hi = pdist.shard_range(args.batch * world, world, rank)

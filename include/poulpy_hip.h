@@ -512,6 +512,50 @@ int pz_vec_znx_big_normalize_batched(pz_module* m, size_t batch,
                                      int64_t* res, size_t res_cols, size_t res_size, size_t res_base2k, int64_t res_offset, size_t res_col,
                                      const int64_t* a, size_t a_cols, size_t a_size, size_t a_base2k, size_t a_col);
 
+/* ---- batched i64 VecZnx family: the limb-wise ops poulpy-core runs between the hot-path calls, on `batch`
+ * device-resident containers back to back (object b at ptr + b*n*cols*size) — one launch per limb range instead of one call per
+ * ciphertext.  Same semantics as the per-container functions above (hal_impl.rs:59-131, :225, :289, :41, :137, :165). ----------- */
+int pz_vec_znx_add_into_batched(pz_module* m, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                                const int64_t* a, size_t a_cols, size_t a_size, size_t a_col,
+                                const int64_t* b, size_t b_cols, size_t b_size, size_t b_col);
+int pz_vec_znx_sub_batched(pz_module* m, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                           const int64_t* a, size_t a_cols, size_t a_size, size_t a_col,
+                           const int64_t* b, size_t b_cols, size_t b_size, size_t b_col);
+int pz_vec_znx_add_assign_batched(pz_module* m, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                                  const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+int pz_vec_znx_sub_assign_batched(pz_module* m, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                                  const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+int pz_vec_znx_sub_negate_assign_batched(pz_module* m, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                                         const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+int pz_vec_znx_negate_batched(pz_module* m, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                              const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+int pz_vec_znx_copy_batched(pz_module* m, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                            const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+int pz_vec_znx_zero_batched(pz_module* m, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_col);
+int pz_vec_znx_rotate_batched(pz_module* m, size_t batch, int64_t k, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                              const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+int pz_vec_znx_normalize_batched(pz_module* m, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_base2k,
+                                 int64_t res_offset, size_t res_col, const int64_t* a, size_t a_cols, size_t a_size, size_t a_base2k,
+                                 size_t a_col);
+int pz_vec_znx_lsh_batched(pz_module* m, size_t batch, size_t base2k, size_t k, int64_t* res, size_t res_cols, size_t res_size,
+                           size_t res_col, const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+int pz_vec_znx_rsh_batched(pz_module* m, size_t batch, size_t base2k, size_t k, int64_t* res, size_t res_cols, size_t res_size,
+                           size_t res_col, const int64_t* a, size_t a_cols, size_t a_size, size_t a_col);
+
+/* ---- multi-GPU ---------------------------------------------------------------------------------- *
+ * One process per GPU; independent ciphertexts are block-sharded over the ranks by the caller and never exchanged.  The only
+ * collective of the path is the broadcast of a prepared evaluation key from the rank that prepared it: RCCL (ncclBroadcast)
+ * over xGMI, on the module stream.  RCCL is loaded on first use.  Bootstrap like NCCL: rank 0 obtains an id, every rank
+ * receives it out of band (MPI, a file, torch.distributed ...) and calls pz_comm_init_rank. */
+size_t pz_comm_unique_id_bytes(void);                 /* 128 */
+int pz_comm_unique_id(void* out_id);                  /* ncclGetUniqueId */
+int pz_comm_init_rank(pz_module* m, int world_size, int rank, const void* unique_id);
+int pz_comm_destroy(pz_module* m);
+int pz_comm_rank(const pz_module* m);                 /* -1 without a communicator */
+int pz_comm_world_size(const pz_module* m);
+/* in-place broadcast of `bytes` bytes of device memory from `root` (64 MiB buckets); asynchronous on the module stream */
+int pz_bcast_key(pz_module* m, void* dev_buf, size_t bytes, int root);
+
 /* ---- instrumentation ------------------------------------------------------- */
 /* Times `reps` back-to-back launches of the last pipeline's dominant kernel with HIP
  * events on the module stream; bench.py uses pz_event_* to bracket launches. */

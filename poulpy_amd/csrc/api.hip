@@ -248,6 +248,7 @@ void pz_module_free(pz_module* M) {
     for (auto& c : M->arena) (void)hipFree(c.p);
     for (auto& k : M->pinned) if (k.sliced) (void)hipFree(k.sliced);
     for (auto& mr : M->mirrors) if (mr.dev) (void)hipFree(mr.dev);
+    if (M->comm) (void)pz_comm_destroy(M);
     for (auto& t : M->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
     for (auto e : M->event_pool) (void)hipEventDestroy(e);
     for (auto& ge : M->graphs) {

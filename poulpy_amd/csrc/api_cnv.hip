@@ -307,3 +307,143 @@ int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, c
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Batched i64 VecZnx family: the limb-wise operations poulpy-core runs between the
+// hot-path calls (glwe_add / sub / negate / copy / rotate / normalize / lsh / rsh), on `batch` device-resident containers laid
+// out back to back — one launch per limb range instead of one call per ciphertext.  Same limb-range rules as the per-container
+// entry points (reference/vec_znx/{add,sub,negate,copy,rotate,shift}.rs).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct BV {   // a batched device container
+    DV v;
+    int col;
+};
+inline DV dvb(const pz_module* M, const void* p, size_t cols, size_t size) { return DV{(void*)p, (long long)(M->n * cols * size), (int)cols, (int)size}; }
+inline int ewb(pz_module* M, int op, int batch, const DV& r, int rcol, int rl0, const DV* a, int acol, int al0, const DV* b, int bcol, int bl0, int nl) {
+    return launch_ew(M, op, poly_ptr(M, r, rcol, rl0), r.bs, limb_stride(M, r), a ? poly_ptr(M, *a, acol, al0) : nullptr, a ? a->bs : 0,
+                     a ? limb_stride(M, *a) : 0, b ? poly_ptr(M, *b, bcol, bl0) : nullptr, b ? b->bs : 0, b ? limb_stride(M, *b) : 0, nl, batch);
+}
+int check_batched(const pz_module* M, const void* res, const void* a, const void* b, size_t res_col, size_t res_cols, size_t a_col,
+                  size_t a_cols, size_t b_col, size_t b_cols) {
+    (void)M;
+    PZ_CHECK_COL(res_col, res_cols, "vec_znx_*_batched(res)");
+    if (a) PZ_CHECK_COL(a_col, a_cols, "vec_znx_*_batched(a)");
+    if (b) PZ_CHECK_COL(b_col, b_cols, "vec_znx_*_batched(b)");
+    PZ_REQUIRE(is_device_ptr(res) && (!a || is_device_ptr(a)) && (!b || is_device_ptr(b)), "batched entry points take device pointers");
+    return PZ_OK;
+}
+// res = a +- b  (add.rs:6-65, sub.rs:6-58)
+int add_sub_batched(pz_module* M, bool sub, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a,
+                    size_t a_cols, size_t a_size, size_t a_col, const int64_t* b, size_t b_cols, size_t b_size, size_t b_col) {
+    PZ_TRY(check_batched(M, res, a, b, res_col, res_cols, a_col, a_cols, b_col, b_cols));
+    PZ_REQUIRE((const void*)res != (const void*)b, "vec_znx_add/sub_batched: res must not alias b (use the *_assign form)");
+    const DV r = dvb(M, res, res_cols, res_size), av = dvb(M, a, a_cols, a_size), bv = dvb(M, b, b_cols, b_size);
+    const bool a_le_b = a_size <= b_size;
+    const int sum = (int)std::min(a_le_b ? a_size : b_size, res_size), cpy = (int)std::min(a_le_b ? b_size : a_size, res_size);
+    const int B = (int)batch;
+    PZ_TRY(ewb(M, sub ? EW_SUB_I64 : EW_ADD_I64, B, r, (int)res_col, 0, &av, (int)a_col, 0, &bv, (int)b_col, 0, sum));
+    if (a_le_b) PZ_TRY(ewb(M, sub ? EW_NEG_I64 : EW_COPY, B, r, (int)res_col, sum, &bv, (int)b_col, sum, nullptr, 0, 0, cpy - sum));
+    else PZ_TRY(ewb(M, EW_COPY, B, r, (int)res_col, sum, &av, (int)a_col, sum, nullptr, 0, 0, cpy - sum));
+    return ewb(M, EW_ZERO, B, r, (int)res_col, cpy, nullptr, 0, 0, nullptr, 0, 0, (int)res_size - cpy);
+}
+// mode 0: res += a, 1: res -= a, 2: res = a - res (and -res beyond a.size)   (add.rs:88-109, sub.rs:60-112)
+int assign_batched(pz_module* M, int mode, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a,
+                   size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_TRY(check_batched(M, res, a, nullptr, res_col, res_cols, a_col, a_cols, 0, 0));
+    const DV r = dvb(M, res, res_cols, res_size), av = dvb(M, a, a_cols, a_size);
+    const int nl = (int)std::min(a_size, res_size), B = (int)batch;
+    if (mode == 2) {
+        PZ_TRY(ewb(M, EW_SUB_I64, B, r, (int)res_col, 0, &av, (int)a_col, 0, &r, (int)res_col, 0, nl));
+        return ewb(M, EW_NEG_I64, B, r, (int)res_col, nl, &r, (int)res_col, nl, nullptr, 0, 0, (int)res_size - nl);
+    }
+    return ewb(M, mode == 0 ? EW_ADD_I64 : EW_SUB_I64, B, r, (int)res_col, 0, &r, (int)res_col, 0, &av, (int)a_col, 0, nl);
+}
+// op = EW_NEG_I64 / EW_COPY: res = op(a) over the common limbs, zero beyond   (negate.rs:6-29, copy.rs)
+int unary_batched(pz_module* M, int op, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a,
+                  size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_TRY(check_batched(M, res, a, nullptr, res_col, res_cols, a_col, a_cols, 0, 0));
+    const DV r = dvb(M, res, res_cols, res_size), av = dvb(M, a, a_cols, a_size);
+    const int mn = (int)std::min(res_size, a_size), B = (int)batch;
+    PZ_TRY(ewb(M, op, B, r, (int)res_col, 0, &av, (int)a_col, 0, nullptr, 0, 0, mn));
+    return ewb(M, EW_ZERO, B, r, (int)res_col, mn, nullptr, 0, 0, nullptr, 0, 0, (int)res_size - mn);
+}
+}  // namespace
+
+extern "C" {
+
+int pz_vec_znx_add_into_batched(pz_module* M, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a,
+                                size_t a_cols, size_t a_size, size_t a_col, const int64_t* b, size_t b_cols, size_t b_size, size_t b_col) {
+    PZ_ENTER(M);
+    return add_sub_batched(M, false, batch, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col, b, b_cols, b_size, b_col);
+}
+int pz_vec_znx_sub_batched(pz_module* M, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a,
+                           size_t a_cols, size_t a_size, size_t a_col, const int64_t* b, size_t b_cols, size_t b_size, size_t b_col) {
+    PZ_ENTER(M);
+    return add_sub_batched(M, true, batch, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col, b, b_cols, b_size, b_col);
+}
+int pz_vec_znx_add_assign_batched(pz_module* M, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a,
+                                  size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    return assign_batched(M, 0, batch, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col);
+}
+int pz_vec_znx_sub_assign_batched(pz_module* M, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a,
+                                  size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    return assign_batched(M, 1, batch, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col);
+}
+int pz_vec_znx_sub_negate_assign_batched(pz_module* M, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                                         const int64_t* a, size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    return assign_batched(M, 2, batch, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col);
+}
+int pz_vec_znx_negate_batched(pz_module* M, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a,
+                              size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    return unary_batched(M, EW_NEG_I64, batch, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col);
+}
+int pz_vec_znx_copy_batched(pz_module* M, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_col, const int64_t* a,
+                            size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    PZ_REQUIRE((const void*)res != (const void*)a, "vec_znx_copy_batched: res must not alias a");
+    return unary_batched(M, EW_COPY, batch, res, res_cols, res_size, res_col, a, a_cols, a_size, a_col);
+}
+int pz_vec_znx_zero_batched(pz_module* M, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_col) {
+    PZ_ENTER(M);
+    PZ_TRY(check_batched(M, res, nullptr, nullptr, res_col, res_cols, 0, 0, 0, 0));
+    const DV r = dvb(M, res, res_cols, res_size);
+    return ewb(M, EW_ZERO, (int)batch, r, (int)res_col, 0, nullptr, 0, 0, nullptr, 0, 0, (int)res_size);
+}
+// res = X^k * a (rotate.rs:3-27); limbs of res beyond a.size zeroed
+int pz_vec_znx_rotate_batched(pz_module* M, size_t batch, int64_t k, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                              const int64_t* a, size_t a_cols, size_t a_size, size_t a_col) {
+    PZ_ENTER(M);
+    PZ_TRY(check_batched(M, res, a, nullptr, res_col, res_cols, a_col, a_cols, 0, 0));
+    PZ_REQUIRE((const void*)res != (const void*)a, "vec_znx_rotate_batched: res must not alias a");
+    const DV r = dvb(M, res, res_cols, res_size), av = dvb(M, a, a_cols, a_size);
+    const int mn = (int)std::min(res_size, a_size);
+    const long long n = (long long)M->n;
+    if (mn > 0 && batch > 0) {
+        PolyMap sm{mn, 1, av.bs, (long long)a_cols * n, 0, n * (long long)a_col};
+        PolyMap dm{mn, 1, r.bs, (long long)res_cols * n, 0, n * (long long)res_col};
+        PZ_TRY(launch_rotate(M, (int)batch * mn, (const long long*)a, sm, (long long*)res, dm, 0, mn, nullptr, 0, 0, (long long)k));
+    }
+    return ewb(M, EW_ZERO, (int)batch, r, (int)res_col, mn, nullptr, 0, 0, nullptr, 0, 0, (int)res_size - mn);
+}
+// vec_znx_normalize (same / cross base, any res_offset), vec_znx_lsh / rsh (= the same limb walk with res_offset = +-k at equal bases)
+int pz_vec_znx_normalize_batched(pz_module* M, size_t batch, int64_t* res, size_t res_cols, size_t res_size, size_t res_base2k, int64_t res_offset,
+                                 size_t res_col, const int64_t* a, size_t a_cols, size_t a_size, size_t a_base2k, size_t a_col) {
+    return pz_vec_znx_big_normalize_batched(M, batch, res, res_cols, res_size, res_base2k, res_offset, res_col, a, a_cols, a_size, a_base2k, a_col);
+}
+int pz_vec_znx_lsh_batched(pz_module* M, size_t batch, size_t base2k, size_t k, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                           const int64_t* a, size_t a_cols, size_t a_size, size_t a_col) {
+    if (k > ((size_t)1 << 40)) return fail(PZ_ERR_INVALID, "vec_znx_lsh_batched: shift out of range");
+    return pz_vec_znx_big_normalize_batched(M, batch, res, res_cols, res_size, base2k, (int64_t)k, res_col, a, a_cols, a_size, base2k, a_col);
+}
+int pz_vec_znx_rsh_batched(pz_module* M, size_t batch, size_t base2k, size_t k, int64_t* res, size_t res_cols, size_t res_size, size_t res_col,
+                           const int64_t* a, size_t a_cols, size_t a_size, size_t a_col) {
+    if (k > ((size_t)1 << 40)) return fail(PZ_ERR_INVALID, "vec_znx_rsh_batched: shift out of range");
+    return pz_vec_znx_big_normalize_batched(M, batch, res, res_cols, res_size, base2k, -(int64_t)k, res_col, a, a_cols, a_size, base2k, a_col);
+}
+
+}  // extern "C"

@@ -142,6 +142,9 @@ struct pz_module {
     struct KeyMirror { const void* host; size_t bytes; void* dev; uint64_t fp; uint64_t stamp; };
     std::vector<KeyMirror> mirrors;
     uint64_t mirror_clock = 0;
+    // RCCL communicator for pz_bcast_key (api_dist.hip); owned by the module
+    void* comm = nullptr;
+    int comm_world = 0, comm_rank = 0;
     bool fuse_tail = true, fuse_mid = true;  // kernel-fusion knobs of the batched GLWE ops (tests run both settings)
     // per-kernel-class HIP-event timing (bench.py's roofline leg); off by default
     bool timing = false;

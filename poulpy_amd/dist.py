@@ -27,3 +27,25 @@ def broadcast_key(pmat, src: int = 0, bucket_bytes: int = 64 << 20):
     for off in range(0, flat.numel(), per):
         dist.broadcast(flat[off:off + per], src=src)
     return pmat
+
+
+def broadcast_key_cabi(mod, pmat, src: int = 0):
+    """The same broadcast through the C ABI (`pz_bcast_key`: ncclBroadcast on the module's own stream), i.e. the route a Rust /
+    C++ caller takes.  torch.distributed is only the out-of-band channel for the 128-byte RCCL id (any process group works,
+    gloo included).  The communicator is created on first use and owned by the module."""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if mod.lib.pz_comm_world_size(mod.handle) == 0:
+        obj = [mod.comm_unique_id() if rank == src else None]
+        dist.broadcast_object_list(obj, src=src)
+        mod.comm_init_rank(world, rank, obj[0])
+    flat = pmat.view(-1)
+    if flat.is_cuda:
+        torch.cuda.current_stream(flat.device).synchronize()   # the module stream is not ordered with torch's streams
+    mod.bcast_key(C.c_void_p(flat.data_ptr()), flat.numel() * flat.element_size(), src)
+    mod.sync()
+    return pmat

@@ -80,7 +80,8 @@ def load_library(path: str | None = None) -> C.CDLL:
                  "pz_circuit_bootstrapping_tmp_bytes", "pz_vec_znx_normalize_tmp_bytes", "pz_vec_znx_lsh_tmp_bytes", "pz_glwe_pack_tmp_bytes",
                  "pz_circuit_bootstrapping_to_exponent_tmp_bytes", "pz_blind_rotation_extended_tmp_bytes",
                  "pz_cnv_prepare_left_tmp_bytes", "pz_cnv_prepare_right_tmp_bytes", "pz_cnv_prepare_self_tmp_bytes", "pz_cnv_apply_dft_tmp_bytes",
-                 "pz_cnv_pairwise_apply_dft_tmp_bytes", "pz_cnv_by_const_apply_tmp_bytes", "pz_glwe_tensor_apply_workspace_bytes"):
+                 "pz_cnv_pairwise_apply_dft_tmp_bytes", "pz_cnv_by_const_apply_tmp_bytes", "pz_glwe_tensor_apply_workspace_bytes",
+                 "pz_comm_unique_id_bytes"):
         getattr(lib, name).restype = c_size_t
     if path is None:
         _lib = lib
@@ -600,6 +601,24 @@ class Module:
     def glwe_tensor_relinearize_batched(self, res: c_void_p, a: c_void_p, tsk_pmat: c_void_p, params: GlweOpParams, batch: int):
         """poulpy-core operations/glwe.rs:541-607 on device-resident GLWETensors sharing one prepared tensor key."""
         self._ck(self.lib.pz_glwe_tensor_relinearize_batched(self.handle, res, a, tsk_pmat, C.byref(params), c_size_t(batch)))
+
+    # -- multi-GPU (SURVEY.md 8e): RCCL broadcast of prepared keys on the module stream ---------------------
+    def comm_unique_id(self) -> bytes:
+        """ncclGetUniqueId (call on ONE rank, ship the bytes to the others out of band)."""
+        n = self.lib.pz_comm_unique_id_bytes()
+        buf = C.create_string_buffer(n)
+        self._ck(self.lib.pz_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init_rank(self, world_size: int, rank: int, unique_id: bytes):
+        self._ck(self.lib.pz_comm_init_rank(self.handle, c_int(world_size), c_int(rank), C.c_char_p(unique_id)))
+
+    def comm_destroy(self):
+        self._ck(self.lib.pz_comm_destroy(self.handle))
+
+    def bcast_key(self, dev_ptr: c_void_p, nbytes: int, root: int = 0):
+        """In-place ncclBroadcast of a device buffer (a prepared key) from `root`, asynchronous on the module stream."""
+        self._ck(self.lib.pz_bcast_key(self.handle, dev_ptr, c_size_t(nbytes), c_int(root)))
 
     def pin_key(self, pmat: c_void_p, rows: int, cols_in: int, cols_out: int, size: int):
         """Declare a prepared device key immutable: the fused pipeline keeps its row-sliced copy instead of rebuilding it per call."""

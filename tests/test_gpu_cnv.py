@@ -243,3 +243,67 @@ def test_config5_relinearize_n65536_16_limbs(mods):
     for pin in (False, True):
         got, want = _run_relinearize(hip, ref, n, 1, 16, 12, 16, 12, 16, 1, 16, 12, batch=3, seed=5 + pin, pin=pin)
         assert np.array_equal(got, want), pin
+
+
+# ------------------------------------------------------------------------------------------
+# batched i64 VecZnx family (pz_vec_znx_*_batched): one launch for `batch` device-resident containers
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [64, 4096, 65536])
+def test_vec_znx_family_batched(mods, n):
+    import ctypes as C
+    ref, hip = mods(n)
+    rng = seeded(n + 9)
+    batch = 5 if n < 65536 else 3
+    sz = lambda *xs: [C.c_size_t(int(x)) for x in xs]
+    for (rc, rs, ac, as_, bc, bs) in ((2, 3, 2, 3, 2, 3), (3, 4, 2, 2, 1, 5), (1, 2, 2, 4, 3, 3)):
+        a = rng.integers(-(1 << 40), 1 << 40, (batch, as_, ac, n), dtype=np.int64)
+        b = rng.integers(-(1 << 40), 1 << 40, (batch, bs, bc, n), dtype=np.int64)
+        r0 = rng.integers(-(1 << 40), 1 << 40, (batch, rs, rc, n), dtype=np.int64)
+        d_a, d_b = hip.device_alloc(a.nbytes).upload(a), hip.device_alloc(b.nbytes).upload(b)
+        d_r = hip.device_alloc(r0.nbytes)
+        rcol, acol, bcol = rc - 1, ac - 1, 0
+
+        def oracle(fn):
+            out = r0.copy()
+            for t in range(batch):
+                fn(VecZnx(n, rc, rs, out[t]), VecZnx(n, ac, as_, a[t].copy()), VecZnx(n, bc, bs, b[t].copy()))
+            return out
+
+        def device(call):
+            d_r.upload(r0)
+            hip._ck(call())
+            hip.sync()
+            return d_r.download(np.int64, r0.size).reshape(r0.shape)
+
+        L = hip.lib
+        cases = {
+            "add_into": (lambda r, x, y: ref.vec_znx_add_into(r, rcol, x, acol, y, bcol),
+                         lambda: L.pz_vec_znx_add_into_batched(hip.handle, C.c_size_t(batch), d_r.ptr, *sz(rc, rs, rcol), d_a.ptr, *sz(ac, as_, acol), d_b.ptr, *sz(bc, bs, bcol))),
+            "sub": (lambda r, x, y: ref.vec_znx_sub(r, rcol, x, acol, y, bcol),
+                    lambda: L.pz_vec_znx_sub_batched(hip.handle, C.c_size_t(batch), d_r.ptr, *sz(rc, rs, rcol), d_a.ptr, *sz(ac, as_, acol), d_b.ptr, *sz(bc, bs, bcol))),
+            "add_assign": (lambda r, x, y: ref.vec_znx_add_assign(r, rcol, x, acol),
+                           lambda: L.pz_vec_znx_add_assign_batched(hip.handle, C.c_size_t(batch), d_r.ptr, *sz(rc, rs, rcol), d_a.ptr, *sz(ac, as_, acol))),
+            "sub_assign": (lambda r, x, y: ref.vec_znx_sub_assign(r, rcol, x, acol),
+                           lambda: L.pz_vec_znx_sub_assign_batched(hip.handle, C.c_size_t(batch), d_r.ptr, *sz(rc, rs, rcol), d_a.ptr, *sz(ac, as_, acol))),
+            "sub_negate_assign": (lambda r, x, y: ref.vec_znx_sub_negate_assign(r, rcol, x, acol),
+                                  lambda: L.pz_vec_znx_sub_negate_assign_batched(hip.handle, C.c_size_t(batch), d_r.ptr, *sz(rc, rs, rcol), d_a.ptr, *sz(ac, as_, acol))),
+            "negate": (lambda r, x, y: ref.vec_znx_negate(r, rcol, x, acol),
+                       lambda: L.pz_vec_znx_negate_batched(hip.handle, C.c_size_t(batch), d_r.ptr, *sz(rc, rs, rcol), d_a.ptr, *sz(ac, as_, acol))),
+            "copy": (lambda r, x, y: ref.vec_znx_copy(r, rcol, x, acol),
+                     lambda: L.pz_vec_znx_copy_batched(hip.handle, C.c_size_t(batch), d_r.ptr, *sz(rc, rs, rcol), d_a.ptr, *sz(ac, as_, acol))),
+            "rotate": (lambda r, x, y: ref.vec_znx_rotate(-7 - n, r, rcol, x, acol),
+                       lambda: L.pz_vec_znx_rotate_batched(hip.handle, C.c_size_t(batch), C.c_int64(-7 - n), d_r.ptr, *sz(rc, rs, rcol), d_a.ptr, *sz(ac, as_, acol))),
+            "normalize": (lambda r, x, y: ref.vec_znx_normalize(r, 13, -5, rcol, x, 17, acol),
+                          lambda: L.pz_vec_znx_normalize_batched(hip.handle, C.c_size_t(batch), d_r.ptr, *sz(rc, rs, 13), C.c_int64(-5), C.c_size_t(rcol), d_a.ptr, *sz(ac, as_, 17, acol))),
+            "lsh": (lambda r, x, y: ref.vec_znx_lsh(14, 19, r, rcol, x, acol),
+                    lambda: L.pz_vec_znx_lsh_batched(hip.handle, C.c_size_t(batch), *sz(14, 19), d_r.ptr, *sz(rc, rs, rcol), d_a.ptr, *sz(ac, as_, acol))),
+            "rsh": (lambda r, x, y: ref.vec_znx_rsh(14, 23, r, rcol, x, acol),
+                    lambda: L.pz_vec_znx_rsh_batched(hip.handle, C.c_size_t(batch), *sz(14, 23), d_r.ptr, *sz(rc, rs, rcol), d_a.ptr, *sz(ac, as_, acol))),
+        }
+        for name, (of, df) in cases.items():
+            assert np.array_equal(device(df), oracle(of)), (n, name, rc, rs, ac, as_)
+        want = r0.copy()
+        want[:, :, rcol] = 0
+        assert np.array_equal(device(lambda: L.pz_vec_znx_zero_batched(hip.handle, C.c_size_t(batch), d_r.ptr, *sz(rc, rs, rcol))), want)
+        for buf in (d_a, d_b, d_r):
+            buf.free()

@@ -229,3 +229,39 @@ def test_fused_tail_large_and_saturating_values(mods, n):
         assert np.abs(want).max() > 0
         for buf in (d_a, d_k, d_r):
             buf.free()
+
+
+# ------------------------------------------------------------------------------------------
+# multi-GPU plumbing at the C-ABI level, single rank (the only size a 1-GPU box can run): RCCL communicator + broadcast
+# ------------------------------------------------------------------------------------------
+def test_pz_bcast_key_single_rank_rccl(mods):
+    """pz_comm_unique_id / pz_comm_init_rank / pz_bcast_key / pz_comm_destroy with world size 1 (RCCL loads, the communicator
+    comes up on the module's device, the in-place broadcast leaves the key intact and is ordered on the module stream), then an
+    external product with the broadcast key is still bit-exact."""
+    import ctypes as C
+    from poulpy_amd.hal import PoulpyHipError
+    n = 4096
+    ref, hip = mods(n)
+    assert hip.lib.pz_comm_world_size(hip.handle) == 0 and hip.lib.pz_comm_rank(hip.handle) == -1
+    buf = hip.device_alloc(1 << 20)
+    with pytest.raises(PoulpyHipError):
+        hip.bcast_key(buf.ptr, 1 << 20, 0)            # no communicator yet
+    uid = hip.comm_unique_id()
+    assert len(uid) == 128
+    hip.comm_init_rank(1, 0, uid)
+    assert hip.lib.pz_comm_world_size(hip.handle) == 1 and hip.lib.pz_comm_rank(hip.handle) == 0
+    with pytest.raises(PoulpyHipError):
+        hip.comm_init_rank(1, 0, uid)                 # one communicator per module
+    data = np.arange((200 << 20) // 8, dtype=np.float64)   # 200 MiB: four buckets
+    big = hip.device_alloc(data.nbytes).upload(data)
+    hip.bcast_key(big.ptr, data.nbytes, 0)
+    with pytest.raises(PoulpyHipError):
+        hip.bcast_key(big.ptr, data.nbytes, 3)        # root out of range
+    hip.sync()
+    assert np.array_equal(big.download(np.float64, data.size), data)
+    assert _pool_parity(hip, ref, False, n, 1, 4, 17, 4, batch=40, pool=5, seed=77) == 0
+    hip.comm_destroy()
+    hip.comm_destroy()                                # idempotent
+    assert hip.lib.pz_comm_world_size(hip.handle) == 0
+    for b in (buf, big):
+        b.free()
