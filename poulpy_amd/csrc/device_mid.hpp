@@ -38,6 +38,8 @@ struct MidArgs {
     // perm_mul = p^-1, perm_add = -p^-1 (p-1)/4.  Rows map to rows (q1_out depends on q1 only), q2 moves inside the row.
     unsigned perm_mul, perm_add;
     int log_m1;
+    int dbg;   // timing ablation of k_mid128 (POULPY_DBG_MID_SKIP; results invalid): 1 no product FMAs, 2 no key loads, 4 no T' loads,
+               // 8 no T2' stores, 16 no row DFTs
 };
 
 // LDS traffic between the 16 lanes that own one row needs no workgroup barrier: the lanes are in one wave,
@@ -329,7 +331,7 @@ k_mid128(MidArgs g) {
         if (!(ACTIVE)) {                                                                          \
             _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1) x[n1] = make_double2(0.0, 0.0);     \
         }                                                                                         \
-        Bfly<16, false>::run(x);                                                                  \
+        if (!(g.dbg & 16)) Bfly<16, false>::run(x);                                               \
         _Pragma("unroll") for (int k1 = 0; k1 < 16; ++k1) {                                       \
             cplx v = x[k1];                                                                       \
             if (k1 > 0) v = cmul(v, wl[o * k1]);                                                  \
@@ -339,8 +341,7 @@ k_mid128(MidArgs g) {
         _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                           \
             _Pragma("unroll") for (int oo = 0; oo < 8; ++oo) x[8 * h + oo] = rowbuf[(o + 8 * h) * 9 + oo]; \
         }                                                                                         \
-        Bfly<8, false>::run(x);                                                                   \
-        Bfly<8, false>::run(x + 8);                                                               \
+        if (!(g.dbg & 16)) { Bfly<8, false>::run(x); Bfly<8, false>::run(x + 8); }                \
         row_sync();                                                                               \
         _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                           \
             _Pragma("unroll") for (int k2 = 0; k2 < 8; ++k2) rowbuf[o + 8 * h + 16 * k2] = x[8 * h + k2]; \
@@ -352,7 +353,7 @@ k_mid128(MidArgs g) {
     {
         const cplx* src = src_ptr(w);
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) x[n1] = ld_stream(src + 8 * n1);
+        for (int n1 = 0; n1 < 16; ++n1) x[n1] = (g.dbg & 4) ? make_double2(1.0, (double)n1) : ld_stream(src + 8 * n1);
         twn = g.tw12t[(long long)out_q1(tile_q1(w)) * M2 + (tid & (M2 - 1))];
     }
     if (tid < M2) twrow[tid] = twn;
@@ -362,8 +363,8 @@ k_mid128(MidArgs g) {
 #define PZ_MID_P0(LT)                                                                                  \
     {                                                                                                  \
         const long long base_ = (long long)tile_q1(min((LT), ntiles - 1)) * g.nrows * g.ncols;         \
-        _Pragma("unroll") for (int j = 0; j < NC; ++j)                                                 \
-            pn[j] = g.P[(base_ + (long long)rot * g.ncols + min(vcg * NC + j, g.ncomp - 1)) * M2 + vq2];  \
+        if (!(g.dbg & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j)                             \
+            pn[j] = g.P[(base_ + (long long)rot * g.ncols + min(vcg * NC + j, g.ncomp - 1)) * M2 + vq2]; } \
     }
     PZ_MID_P0(w)
     PZ_MID_FWD(in_active(w))
@@ -392,13 +393,13 @@ k_mid128(MidArgs g) {
         r_ -= (r_ >= g.row_max) ? g.row_max : 0;                                                \
         r_ -= (r_ >= g.row_max) ? g.row_max : 0;                                                \
         const long long off_ = (long long)r_ * prow;                                            \
-        _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = pp[j][off_];                    \
+        if (!(g.dbg & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = pp[j][off_]; }  \
     }
 #define PZ_USEROW(SRC, IT)                                                                      \
     {                                                                                           \
         int r_ = (IT) + rot;                                                                    \
         r_ -= (r_ >= g.row_max) ? g.row_max : 0;                                                \
-        _Pragma("unroll") for (int i = 0; i < CTt; ++i) {                                       \
+        if (!(g.dbg & 1)) _Pragma("unroll") for (int i = 0; i < CTt; ++i) {                      \
             const cplx av = lds[((vtg * CTt + i) * NP + r_) * RS + q2];                                       \
             _Pragma("unroll") for (int j = 0; j < NC; ++j) {                                    \
                 acc[i][j].x = __builtin_fma(av.x, SRC[j].x, acc[i][j].x);                       \
@@ -432,7 +433,7 @@ k_mid128(MidArgs g) {
         {
             const cplx* src = src_ptr(L + W);
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) x[n1] = ld_stream(src + 8 * n1);
+            for (int n1 = 0; n1 < 16; ++n1) x[n1] = (g.dbg & 4) ? make_double2(1.0, (double)n1) : ld_stream(src + 8 * n1);
             twn = g.tw12t[(long long)out_q1(tile_q1(min(L + W, ntiles - 1))) * M2 + (tid & (M2 - 1))];
         }
         // inverse row DFT: this lane owns k1 = o and o+8: radix 8 over k2 -> z[k1][oo] x conj W128^(oo*k1);
@@ -443,8 +444,7 @@ k_mid128(MidArgs g) {
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) u[8 * h + k2] = rowbuf[o + 8 * h + 16 * k2];
-            Bfly<8, true>::run(u);
-            Bfly<8, true>::run(u + 8);
+            if (!(g.dbg & 16)) { Bfly<8, true>::run(u); Bfly<8, true>::run(u + 8); }
             row_sync();
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -458,12 +458,12 @@ k_mid128(MidArgs g) {
             row_sync();
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) u[k1] = rowbuf[k1 * 9 + o];
-            Bfly<16, true>::run(u);
+            if (!(g.dbg & 16)) Bfly<16, true>::run(u);
             const bool active = b < g.batch && rr < g.npo;
             cplx* dst = active ? g.T2 + ((long long)b * g.npo + rr) * m + (long long)out_q1(q1) * M2 + o
                                : g.dummy + (long long)tid * 16 * 16 + o;
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) st_stream(dst + 8 * n1, cmulc(u[n1], twrow[o + 8 * n1]));
+            for (int n1 = 0; n1 < 16; ++n1) if (!(g.dbg & 8) || u[n1].x == 1.2345e300) st_stream(dst + 8 * n1, cmulc(u[n1], twrow[o + 8 * n1]));
         }
         lds_barrier();
         if (tid < M2) twrow[tid] = twn;
@@ -473,6 +473,14 @@ k_mid128(MidArgs g) {
 #undef PZ_MID_FWD
 #undef PZ_MID_P0
 }
+
+// (Round 2 experiment, removed: "k_mid128L" — four extra loader waves that request tile t+1 at the top of iteration t, hold it in
+//  registers and hand it over through LDS once the compute waves release the tile, so that HBM loads never sit in front of the
+//  compute waves' L2-served key loads.  Bit-exact, but 9 % SLOWER (5.19 vs 4.76 ms per 1024 ciphertexts,
+//  profiles/r02_ab_mid_loader_waves.txt): the timing ablation of this kernel (POULPY_DBG_MID_SKIP, profiles/r02_mid_ablation.txt)
+//  shows why — with every global access, every FMA and every butterfly removed it still takes 1.97 of its 4.96 ms (LDS traffic of
+//  the seven exchange passes + the product's operand reads, barriers), and no single component is worth more than 1 ms: HBM waits
+//  are not the exposed part, so hiding them buys nothing while the extra LDS pass and the 168-VGPR cap cost.)
 
 // standard device VmpPMat  P[p][q1 + m1*q2]  ->  P'[q1][p][q2]   (p = r*ncols + c), 16x16 tiles through LDS
 __global__ void __launch_bounds__(256)

@@ -41,6 +41,8 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
                unsigned perm_mul, unsigned perm_add) {
     MidArgs g;
     g.perm_mul = perm_mul; g.perm_add = perm_add; g.log_m1 = 0;
+    static const int mid_skip = getenv("POULPY_DBG_MID_SKIP") ? atoi(getenv("POULPY_DBG_MID_SKIP")) : 0;
+    g.dbg = mid_skip;
     while ((1 << g.log_m1) < M->plan.m1) ++g.log_m1;
     const bool perm = perm_mul != 0;
     g.T = T; g.T2 = T2; g.P = Pp; g.npi = npi; g.npo = npo; g.nrows = nrows; g.ncols = ncols;
@@ -60,42 +62,29 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, M->device);
         KTimer kt(M, PZ_K_FUSED_MID);
+#define PZ_MID128_LAUNCH(CT_, NP_)                                                                                         \
+    {                                                                                                                      \
+        g.n_ct = (batch + CT_ - 1) / CT_;                                                                                  \
+        const size_t lds = ((size_t)CT_ * NP_ * 16 * 9 + 256) * sizeof(cplx);                                              \
+        const dim3 grid_(std::min(ncu, g.m1 * g.n_ct));                                                                    \
+        if (perm) {                                                                                                        \
+            PZ_TRY(set_lds((k_mid128<CT_, NP_, true>), lds));                                                              \
+            hipLaunchKernelGGL((k_mid128<CT_, NP_, true>), grid_, dim3(512), lds, M->stream, g);                           \
+        } else {                                                                                                           \
+            PZ_TRY(set_lds((k_mid128<CT_, NP_, false>), lds));                                                             \
+            hipLaunchKernelGGL((k_mid128<CT_, NP_, false>), grid_, dim3(512), lds, M->stream, g);                          \
+        }                                                                                                                  \
+    }
         if (npi <= 8 && npo <= 8) {
             // <= 8 polynomials in and out (e.g. rank 1 with 4 limbs, BASELINE configs[1]): 8 ciphertexts x 8 slots per tile
-            constexpr int CT = 8;
-            g.n_ct = (batch + CT - 1) / CT;
-            const size_t lds = ((size_t)CT * 8 * 16 * 9 + 256) * sizeof(cplx);
-            if (perm) {
-                PZ_TRY(set_lds((k_mid128<CT, 8, true>), lds));
-                hipLaunchKernelGGL((k_mid128<CT, 8, true>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(512), lds, M->stream, g);
-            } else {
-                PZ_TRY(set_lds((k_mid128<CT, 8>), lds));
-                hipLaunchKernelGGL((k_mid128<CT, 8>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(512), lds, M->stream, g);
-            }
+            PZ_MID128_LAUNCH(8, 8)
         } else if (npi > 16 || npo > 16) {
             // 17..32 polynomials in or out (rank 2-3 with 8 limbs, rank 1 with 16 limbs): 2 ciphertexts x 32 slots per tile
-            constexpr int CT = 2;
-            g.n_ct = (batch + CT - 1) / CT;
-            const size_t lds = ((size_t)CT * 32 * 16 * 9 + 256) * sizeof(cplx);
-            if (perm) {
-                PZ_TRY(set_lds((k_mid128<CT, 32, true>), lds));
-                hipLaunchKernelGGL((k_mid128<CT, 32, true>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(512), lds, M->stream, g);
-            } else {
-                PZ_TRY(set_lds((k_mid128<CT, 32>), lds));
-                hipLaunchKernelGGL((k_mid128<CT, 32>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(512), lds, M->stream, g);
-            }
+            PZ_MID128_LAUNCH(2, 32)
         } else {
-            constexpr int CT = 4;
-            g.n_ct = (batch + CT - 1) / CT;
-            const size_t lds = ((size_t)CT * 16 * 16 * 9 + 256) * sizeof(cplx);
-            if (perm) {
-                PZ_TRY(set_lds((k_mid128<CT, 16, true>), lds));
-                hipLaunchKernelGGL((k_mid128<CT, 16, true>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(CT * 128), lds, M->stream, g);
-            } else {
-                PZ_TRY(set_lds(k_mid128<CT>, lds));
-                hipLaunchKernelGGL((k_mid128<CT>), dim3(std::min(ncu, g.m1 * g.n_ct)), dim3(CT * 128), lds, M->stream, g);
-            }
+            PZ_MID128_LAUNCH(4, 16)
         }
+#undef PZ_MID128_LAUNCH
         PZ_HIP(hipGetLastError());
         return PZ_OK;
     }
