@@ -225,6 +225,19 @@ int pz_module_new_on_device(uint64_t n, int device, pz_module** out) {
     M->n = n; M->m = n >> 1; M->device = device; M->plan = pl;
     int r = PZ_OK;
     do {
+        if (const char* cm = getenv("POULPY_DBG_CU_MASK")) {
+            // diagnostic: restrict the module stream to N CUs ("N" or "N,mode": mode 0 = the first N mask bits, 1 = spread evenly)
+            int ncus = atoi(cm), mode = 0;
+            if (const char* c = strchr(cm, ',')) mode = atoi(c + 1);
+            uint32_t mask[8] = {0};
+            int on = 0;
+            for (int i = 0; i < 256; ++i) {
+                const bool en = mode == 0 ? i < ncus : ((long long)(i + 1) * ncus / 256 > (long long)i * ncus / 256);
+                if (en) { mask[i >> 5] |= 1u << (i & 31); ++on; }
+            }
+            if (hipExtStreamCreateWithCUMask(&M->stream, 8, mask) != hipSuccess) { r = fail(PZ_ERR_HIP, "masked stream create failed"); break; }
+            M->cu_count = on;
+        } else
         if (hipStreamCreateWithFlags(&M->stream, hipStreamNonBlocking) != hipSuccess) { r = fail(PZ_ERR_HIP, "stream create failed"); break; }
         if ((r = build_tables(M)) != PZ_OK) break;
         if (hipMalloc(&M->margin, 8) != hipSuccess) { r = fail(PZ_ERR_HIP, "margin alloc failed"); break; }
@@ -1216,6 +1229,14 @@ struct OpLayout {
     long long a_stride, res_stride;  // in i64 elements between consecutive ciphertexts
     int body_col;
 };
+// (Round 2 experiment, removed — git history has it: a CU-partitioned, overlapped form of the fused pipeline.  With a CU mask spread
+//  over the 8 XCDs (hipExtStreamCreateWithCUMask; POULPY_DBG_CU_MASK still runs the whole pipeline under one) pass 1 and the tail
+//  keep their full rate down to 64 CUs while the middle kernel scales with its CU count (profiles/r02_cu_mask_scaling.txt), so chunk
+//  c+1's pass 1, chunk c's middle kernel and chunk c-1's tail were run concurrently on disjoint CU sets, chained by events.
+//  Bit-exact, but slower in every split tried (best 73 500/s with 8 + 8 CUs per XCD for the two streams against 88 700/s back to
+//  back, profiles/r02_overlap_sweep.txt): under concurrency the three kernels share HBM at ~4.7 TB/s aggregate — no better than
+//  the 4.7 TB/s the back-to-back sequence averages — and the three-deep chunk pipeline adds its fill / drain per call.)
+
 static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double* pmat, const pz_glwe_op_params* p, size_t batch,
                    const AutoSpec* au = nullptr, const OpLayout* lay = nullptr, bool tensor = false) {
     PZ_REQUIRE(p != nullptr, "null params");

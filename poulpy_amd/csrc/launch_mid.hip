@@ -30,6 +30,7 @@ static int launch_mid_ct(pz_module* M, MidArgs g, int batch) {
     // persistent: as many workgroups as fit (LDS-bound: 144 KiB -> 1 per CU at CT = 2, 76 KiB -> 2 per CU at CT = 1)
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, M->device);
+        if (M->cu_count > 0) ncu = (M->cu_count / 8) * 8 > 0 ? (M->cu_count / 8) * 8 : M->cu_count;
     const int per_cu = CT == 1 ? 2 : 1;
     const int grid = std::min(ncu * per_cu, g.m1 * g.n_ct);
     hipLaunchKernelGGL((k_mid<CT>), dim3(grid), dim3(CT * 256), lds, M->stream, g);
@@ -61,6 +62,7 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
     if (M->plan.m2 == 128) {
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, M->device);
+        if (M->cu_count > 0) ncu = (M->cu_count / 8) * 8 > 0 ? (M->cu_count / 8) * 8 : M->cu_count;
         KTimer kt(M, PZ_K_FUSED_MID);
 #define PZ_MID128_LAUNCH(CT_, NP_)                                                                                         \
     {                                                                                                                      \

@@ -112,6 +112,7 @@ struct pz_module {
     int device = 0;
     pz::FftPlan plan{};
     hipStream_t stream = nullptr;
+    int cu_count = 0;   // CUs the module stream may use (0 = all; diagnostic POULPY_DBG_CU_MASK): grid of the persistent kernels
     // device tables (cplx): tw1[m1], tw1inv[m1], wL1[m1], wL2[m2], tw12[m] ([j2][q1])
     pz::cplx *tw1 = nullptr, *tw1inv = nullptr, *wL1 = nullptr, *wL2 = nullptr, *tw12 = nullptr;
     pz::cplx* tw12t = nullptr;  // the same table as [q1][j2] (row-major pipeline)
