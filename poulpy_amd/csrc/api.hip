@@ -1267,8 +1267,36 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
     }
 
     // ---- fully fused pipeline: pass 1 (row-major) | row pass + VMP + inverse row pass | tail ----
-    if (M->fuse_mid && M->fuse_tail && dsize == 1 && p->res_base2k == p->key_base2k && tail_supported(M) && mid_supported(M, npi, npo) &&
-        !(tensor && s.convert)) {
+    // dsize > 1 (digit-selected product inside the middle kernel) and res_base2k != key_base2k (the tail normalizes into the key's base,
+    // one cross-base pass follows) ride on the same three kernels; both need the 128-point-row plans and no automorphism
+    const bool digits = dsize > 1, cross_out = p->res_base2k != p->key_base2k;
+    if (M->fuse_mid && M->fuse_tail && tail_supported(M) && mid_supported(M, npi, npo) && !(tensor && s.convert) &&
+        (!(digits || cross_out) || (M->plan.m2 == 128 && !au && dnum * s.cols_in <= 255 && ncols <= 255))) {
+        MidDigits dg;
+        if (digits) {
+            // external_product/glwe.rs:235-267, keyswitching/glwe.rs:332-379: limb l of `a` is digit di = (dsize - 1 - l) mod dsize, element
+            // k = (l - (dsize - 1 - di)) / dsize of that digit's vector (vec_znx_dft_apply with step dsize, offset dsize - 1 - di); the
+            // vector has (a_size + di) / dsize elements (at most dnum for a key switch) and multiplies key rows k (all input columns) with
+            // limb_offset di, into a result of key_size - max(dsize - di - 2, 0) limbs (zero-tail semantics of SURVEY.md A.2)
+            for (int l = 0; l < s.a_size_eff; ++l) {
+                const int di = ((dsize - 1 - l) % dsize + dsize) % dsize;
+                const int k = (l - (dsize - 1 - di)) / dsize;
+                int a_sz = (s.a_size_eff + di) / dsize;
+                if (ks) a_sz = std::min(a_sz, dnum);
+                if (k < 0 || k >= a_sz || k >= dnum) continue;
+                const int r_sz = ksz - std::max(dsize - di - 2, 0);
+                const int off = di * s.cols_out;
+                const int cb = off < ncols ? std::min(s.cols_out * r_sz, ncols - off) : 0;
+                if (cb <= 0) continue;
+                for (int c = 0; c < s.cols_in; ++c) {
+                    dg.in[dg.n] = (unsigned char)(l * s.cols_in + c);
+                    dg.row[dg.n] = (unsigned char)(k * s.cols_in + c);
+                    dg.coff[dg.n] = (unsigned char)off;
+                    dg.cb[dg.n] = (unsigned char)cb;
+                    ++dg.n;
+                }
+            }
+        }
         const size_t key_bytes = align256((size_t)nrows * ncols * (size_t)M->n * 8);
         const size_t conv_bytes = s.convert ? align256(chunk * (size_t)M->n * 8 * s.cols_a * s.a_size_eff) : 0;
         const size_t t_bytes = align256(chunk * (size_t)npi * M->m * sizeof(cplx));
@@ -1277,7 +1305,8 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
         // body-column operand (min(a_size, key_size) limbs of one column): sized for the larger of the two
         const size_t body_limbs = (size_t)std::min<long long>((long long)s.a_size_eff, (long long)ksz);
         const size_t rtmp_bytes = au ? align256(chunk * (size_t)M->n * 8 * std::max((size_t)s.cols_out * p->res_size, body_limbs)) : 0;
-        const size_t small2_bytes = 0;  // (the pre-gathered operand of the add / sub variants is no longer materialised)
+        // cross_out: the tail's key-base digits (cols_out x key_size limbs per ciphertext) before the cross-base pass
+        const size_t small2_bytes = cross_out ? align256(chunk * (size_t)M->n * 8 * s.cols_out * ksz) : 0;
         PZ_TRY(ws_reserve(M, key_bytes + conv_bytes + t_bytes + t2_bytes + rtmp_bytes + small2_bytes + kMidDummyBytes));
         char* base = (char*)M->ws;
         cplx* Pp = (cplx*)base; base += key_bytes;
@@ -1321,7 +1350,10 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
                 const unsigned long long c0 = (unsigned long long)(((au_p - 1u) >> 2) & (mm - 1u));
                 perm_add = (unsigned)((mm - (unsigned)(((unsigned long long)perm_mul * c0) & (unsigned long long)(mm - 1u))) & (mm - 1u));
             }
-            if (M->dbg_stages & 2) PZ_TRY(launch_mid(M, nb, T, T2, Pp, npi, npo, nrows, ncols, mid_dummy, perm_mul, perm_add));
+            if (digits && dg.n == 0) {   // nothing reaches the product (e.g. dsize > a.size): the big value is the body alone
+                PZ_HIP(hipMemsetAsync(T2, 0, (size_t)nb * npo * M->m * sizeof(cplx), M->stream));
+            } else if (M->dbg_stages & 2)
+                PZ_TRY(launch_mid(M, nb, T, T2, Pp, npi, npo, nrows, ncols, mid_dummy, perm_mul, perm_add, digits ? &dg : nullptr));
             int64_t* res_b = res + (long long)b0 * res_bs;
             if (spec) {
                 // (the tail reads operand limbs j < min(key_size, a_size) only: the pre-pass covers exactly those)
@@ -1340,6 +1372,19 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
             long long small_bs = av.bs;
             // au_big: the operand -+phi^-1(a) (+ body for column 0) is gathered from `a` inside the tail (TailArgs::gather_mul)
             (void)small2;
+            if (cross_out) {
+                // vec_znx_big_normalize(res_base2k <- key_base2k) in two exact steps: the tail's carry chain writes balanced key-base digits
+                // (all key_size limbs: nothing is dropped), the cross-base kernel converts them.  Both steps are functions of the torus
+                // value only, so the result equals the reference's single cross-base pass over the big value (checked on the oracle over
+                // thousands of random shapes / edge digits, and by the parity tests).
+                const long long tmp_ct = n * s.cols_out * (long long)ksz;
+                PZ_TRY(launch_inv_tail(M, nb, T2, ksz, s.cols_out, (long long*)small2, tmp_ct, s.cols_out, ksz, small, small_bs, s.cols_a, a_size,
+                                       (int)p->key_base2k, true, tensor, 0u, false, 0u, false, body_col));
+                DV tv{small2, tmp_ct, s.cols_out, ksz}, rv{res_b, res_bs, s.cols_out, (int)p->res_size};
+                for (int c = 0; c < s.cols_out; ++c)
+                    PZ_TRY(dev_normalize(M, nb, rv, (int)p->res_base2k, 0, c, tv, (int)p->key_base2k, c));
+                continue;
+            }
             if (M->dbg_stages & 4) PZ_TRY(launch_inv_tail(M, nb, T2, ksz, s.cols_out, (long long*)(au ? res_tmp : res_b), au ? res_ct : res_bs, s.cols_out, (int)p->res_size,
                                    small, small_bs, s.cols_a, a_size, (int)p->res_base2k, true, au_big || tensor, au_big ? au_p : 0u, au && au->mode == 3,
                                    au_big ? au_p : 0u, au_big && au->mode != 1, body_col));

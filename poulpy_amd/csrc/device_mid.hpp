@@ -38,6 +38,12 @@ struct MidArgs {
     // perm_mul = p^-1, perm_add = -p^-1 (p-1)/4.  Rows map to rows (q1_out depends on q1 only), q2 moves inside the row.
     unsigned perm_mul, perm_add;
     int log_m1;
+    // k_mid128<.., DS = true> (dsize > 1, poulpy-core external_product/glwe.rs:235-267, keyswitching/glwe.rs:332-379): the limbs of `a`
+    // are digits of dsize groups; input polynomial ds_in[t] (its slot in the tile) multiplies key row ds_row[t] shifted by ds_coff[t]
+    // columns and only reaches the first ds_cb[t] output polynomials (the reference's per-digit limb_offset and its dropped limbs):
+    //   res[c] = sum_t a[ds_in[t]] * P[ds_row[t]][c + ds_coff[t]]   for c < ds_cb[t]
+    int ds_n;
+    unsigned char ds_in[32], ds_row[32], ds_coff[32], ds_cb[32];
     int dbg;   // timing ablation of k_mid128 (POULPY_DBG_MID_SKIP; results invalid): 1 no product FMAs, 2 no key loads, 4 no T' loads,
                // 8 no T2' stores, 16 no row DFTs
 };
@@ -278,7 +284,7 @@ k_mid(MidArgs g) {
 // NP = polynomial slots per ciphertext: 16; 8 for shapes with <= 8 polynomials in and out such as rank 1 with 4 limbs (twice the
 // ciphertexts per tile and per key fetch); 32 for rank 2-3 or 16 limbs (two ciphertexts per tile).  The 4 thread groups of the product phase split into GC column groups x GT
 // ciphertext groups so that a thread always owns 16 accumulators (4 ciphertexts x 4 outputs, or 2 x 8).
-template <int CT, int NP = 16, bool PERM = false>
+template <int CT, int NP = 16, bool PERM = false, bool DS = false>
 __global__ void __launch_bounds__(CT * NP * 8)
 k_mid128(MidArgs g) {
     constexpr int M2 = 128;
@@ -358,13 +364,15 @@ k_mid128(MidArgs g) {
     }
     if (tid < M2) twrow[tid] = twn;
     const int vq2 = tid & (M2 - 1), vcg = (tid / M2) % GC, vtg = (tid / M2) / GC;
-    const int rot = g.row_max > 0 ? (w % g.row_max) : 0;
+    const int nrow = DS ? g.ds_n : g.row_max;          // product terms per output
+    const int rot = nrow > 0 ? (w % nrow) : 0;
     cplx pn[NC];
 #define PZ_MID_P0(LT)                                                                                  \
     {                                                                                                  \
         const long long base_ = (long long)tile_q1(min((LT), ntiles - 1)) * g.nrows * g.ncols;         \
-        if (!(g.dbg & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j)                             \
-            pn[j] = g.P[(base_ + (long long)rot * g.ncols + min(vcg * NC + j, g.ncomp - 1)) * M2 + vq2]; } \
+        if (!(g.dbg & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j) {                           \
+            const int c_ = DS ? min(vcg * NC + j, max((int)g.ds_cb[rot], 1) - 1) + (int)g.ds_coff[rot] : min(vcg * NC + j, g.ncomp - 1); \
+            pn[j] = g.P[(base_ + (long long)(DS ? (int)g.ds_row[rot] : rot) * g.ncols + c_) * M2 + vq2]; } } \
     }
     PZ_MID_P0(w)
     PZ_MID_FWD(in_active(w))
@@ -382,7 +390,7 @@ k_mid128(MidArgs g) {
             const cplx* pp[NC];
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
-                const int c = min(cg * NC + j, g.ncomp - 1);
+                const int c = DS ? 0 : min(cg * NC + j, g.ncomp - 1);   // DS: the column is part of the per-row offset
                 pp[j] = g.P + ((long long)q1 * g.nrows * g.ncols + c) * M2 + q2;
             }
             const long long prow = (long long)g.ncols * M2;
@@ -390,15 +398,28 @@ k_mid128(MidArgs g) {
 #define PZ_LOADROW(DST, IT)                                                                     \
     {                                                                                           \
         int r_ = (IT) + rot;                                                                    \
-        r_ -= (r_ >= g.row_max) ? g.row_max : 0;                                                \
-        r_ -= (r_ >= g.row_max) ? g.row_max : 0;                                                \
-        const long long off_ = (long long)r_ * prow;                                            \
-        if (!(g.dbg & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = pp[j][off_]; }  \
+        r_ -= (r_ >= nrow) ? nrow : 0;                                                          \
+        r_ -= (r_ >= nrow) ? nrow : 0;                                                          \
+        if (DS) {                                                                               \
+            const int cb_ = max((int)g.ds_cb[r_], 1) - 1, co_ = (int)g.ds_coff[r_];             \
+            const long long ro_ = (long long)g.ds_row[r_] * prow;                               \
+            if (!(g.dbg & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j)                  \
+                DST[j] = pp[j][ro_ + (long long)(min(cg * NC + j, cb_) + co_) * M2]; }          \
+        } else {                                                                                \
+            const long long off_ = (long long)r_ * prow;                                        \
+            if (!(g.dbg & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = pp[j][off_]; }  \
+        }                                                                                       \
     }
 #define PZ_USEROW(SRC, IT)                                                                      \
     {                                                                                           \
         int r_ = (IT) + rot;                                                                    \
-        r_ -= (r_ >= g.row_max) ? g.row_max : 0;                                                \
+        r_ -= (r_ >= nrow) ? nrow : 0;                                                          \
+        if (DS) {                                                                               \
+            const int cbv_ = (int)g.ds_cb[r_];                                                  \
+            _Pragma("unroll") for (int j = 0; j < NC; ++j)                                      \
+                if (cg * NC + j >= cbv_) SRC[j] = make_double2(0.0, 0.0);                       \
+            r_ = (int)g.ds_in[r_];                                                              \
+        }                                                                                       \
         if (!(g.dbg & 1)) _Pragma("unroll") for (int i = 0; i < CTt; ++i) {                      \
             const cplx av = lds[((vtg * CTt + i) * NP + r_) * RS + q2];                                       \
             _Pragma("unroll") for (int j = 0; j < NC; ++j) {                                    \
@@ -410,13 +431,13 @@ k_mid128(MidArgs g) {
         }                                                                                       \
     }
             int it = 0;
-            for (; it + 1 < g.row_max; it += 2) {
+            for (; it + 1 < nrow; it += 2) {
                 PZ_LOADROW(pb, it + 1)
                 PZ_USEROW(pn, it)
                 PZ_LOADROW(pn, it + 2)
                 PZ_USEROW(pb, it + 1)
             }
-            if (it < g.row_max) PZ_USEROW(pn, it)
+            if (it < nrow) PZ_USEROW(pn, it)
 #undef PZ_LOADROW
 #undef PZ_USEROW
             lds_barrier();

@@ -54,8 +54,14 @@ constexpr size_t kMidDummyBytes = (size_t)512 * 256 * sizeof(cplx) + (1 << 20); 
 bool mid_supported(const pz_module* M, int npi, int npo);
 int launch_permute_pmat(pz_module* M, const double* P, cplx* Pp, int npolys);
 // perm_mul != 0: spectrum permutation of X -> X^p folded into the middle kernel (m2 = 128 plans only; see MidArgs)
+// digit-selected product (dsize > 1, m2 = 128 plans): term t = input polynomial in[t] x key row row[t], columns shifted by coff[t],
+// reaching the first cb[t] output polynomials
+struct MidDigits {
+    int n = 0;
+    unsigned char in[32], row[32], coff[32], cb[32];
+};
 int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp, int npi, int npo, int nrows, int ncols, cplx* dummy,
-               unsigned perm_mul = 0, unsigned perm_add = 0);
+               unsigned perm_mul = 0, unsigned perm_add = 0, const MidDigits* dg = nullptr);
 
 // ---- launch_ops.hip -----------------------------------------------------------------------------------------------
 int launch_ew(pz_module* M, int op, void* res, long long res_bs, long long res_ls, const void* a, long long a_bs,

@@ -15,9 +15,13 @@ namespace pz {
 
 int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* T, bool rowmajor, long long mask) {
     const FftPlan& pl = M->plan;
-    const int blocks = npolys * (pl.m2 / pl.cb);
-    if (blocks == 0) return PZ_OK;
+    if (npolys == 0) return PZ_OK;
     KTimer kt(M, PZ_K_FWD_PASS1);
+    // (Round 2: 32-column blocks for the row-major output at m1 = 256 — 256-byte read runs / 512-byte write runs, the shape that moves
+    //  a pure copy from 5.3 to 6.0 TB/s, profiles/r02_hbm_pass_pattern.txt — were measured SLOWER, 3.55 vs 3.32 ms per 1024 ciphertexts:
+    //  the 147 KiB exchange buffer leaves one 512-thread workgroup per CU, whose load / exchange / store phases no longer overlap with
+    //  a second workgroup's.  The kernel sits at the ceiling of its 16-column access shape: 5.3 TB/s.)
+    const int blocks = npolys * (pl.m2 / pl.cb);
 #define X(A, B, C)                                                                                              \
     if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
         const size_t lds = ((size_t)(A + 1) * C * B + 2 * A * B) * sizeof(cplx);                                              \

@@ -39,8 +39,14 @@ static int launch_mid_ct(pz_module* M, MidArgs g, int batch) {
 }
 // perm_mul != 0: spectrum permutation of X -> X^p folded into the middle kernel (m2 = 128 plans only; see MidArgs)
 int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp, int npi, int npo, int nrows, int ncols, cplx* dummy,
-               unsigned perm_mul, unsigned perm_add) {
+               unsigned perm_mul, unsigned perm_add, const MidDigits* dg) {
     MidArgs g;
+    g.ds_n = 0;
+    const bool ds = dg != nullptr && dg->n > 0;
+    if (ds) {
+        g.ds_n = dg->n;
+        for (int t = 0; t < dg->n; ++t) { g.ds_in[t] = dg->in[t]; g.ds_row[t] = dg->row[t]; g.ds_coff[t] = dg->coff[t]; g.ds_cb[t] = dg->cb[t]; }
+    }
     g.perm_mul = perm_mul; g.perm_add = perm_add; g.log_m1 = 0;
     static const int mid_skip = getenv("POULPY_DBG_MID_SKIP") ? atoi(getenv("POULPY_DBG_MID_SKIP")) : 0;
     g.dbg = mid_skip;
@@ -69,7 +75,10 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
         g.n_ct = (batch + CT_ - 1) / CT_;                                                                                  \
         const size_t lds = ((size_t)CT_ * NP_ * 16 * 9 + 256) * sizeof(cplx);                                              \
         const dim3 grid_(std::min(ncu, g.m1 * g.n_ct));                                                                    \
-        if (perm) {                                                                                                        \
+        if (ds) {                                                                                                          \
+            PZ_TRY(set_lds((k_mid128<CT_, NP_, false, true>), lds));                                                       \
+            hipLaunchKernelGGL((k_mid128<CT_, NP_, false, true>), grid_, dim3(512), lds, M->stream, g);                    \
+        } else if (perm) {                                                                                                 \
             PZ_TRY(set_lds((k_mid128<CT_, NP_, true>), lds));                                                              \
             hipLaunchKernelGGL((k_mid128<CT_, NP_, true>), grid_, dim3(512), lds, M->stream, g);                           \
         } else {                                                                                                           \

@@ -265,3 +265,39 @@ def test_pz_bcast_key_single_rank_rccl(mods):
     assert hip.lib.pz_comm_world_size(hip.handle) == 0
     for b in (buf, big):
         b.free()
+
+
+# ------------------------------------------------------------------------------------------
+# dsize > 1 and res_base2k != key_base2k on the fused three-kernel pipeline
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [4096, 8192, 65536])
+def test_fused_pipeline_digits_and_cross_base_output(mods, n):
+    """poulpy-core's own sweeps (test_suite/external_product/glwe_ct.rs:34-40, keyswitching) vary dsize and use different base2k for
+    input / key / output; on the 128-point-row plans those shapes now run the fused pipeline: digit-selected rows and column offsets
+    inside the middle kernel's product (k_mid128<.., DS>), cross-base output as tail (key base) + one cross-base pass.  Fused and
+    five-kernel paths against the oracle, bit-exact; includes dsize > a.size (empty product), dnum smaller than the digit count, and
+    the tensor relinearization."""
+    from tests.test_gpu_parity import _run_glwe_op
+    from tests.test_gpu_cnv import _run_relinearize
+    ref, hip = mods(n)
+    big = n == 65536
+    shapes = [  # ks, rank, rank_out, a_size, a_b, key_size, k_b, dnum, dsize, res_size, r_b
+        (False, 1, 1, 5, 12, 6, 12, 3, 2, 4, 12), (False, 1, 1, 5, 12, 6, 12, 2, 3, 5, 12), (False, 2, 2, 4, 13, 5, 13, 1, 4, 4, 13),
+        (True, 1, 1, 6, 12, 6, 12, 3, 2, 5, 12), (True, 2, 1, 5, 12, 7, 12, 2, 3, 6, 12), (True, 1, 2, 4, 12, 5, 12, 1, 5, 4, 12),
+        (False, 1, 1, 5, 12, 6, 12, 5, 1, 4, 15), (True, 1, 1, 5, 14, 6, 14, 5, 1, 6, 11), (False, 1, 1, 4, 17, 6, 13, 3, 2, 4, 15),
+        (True, 2, 2, 4, 15, 5, 12, 2, 2, 4, 14),
+    ]
+    if big:
+        shapes = shapes[:2] + shapes[3:4] + shapes[6:9]
+    for (ks, rank, rank_out, a_size, a_b, key_size, k_b, dnum, dsize, res_size, r_b) in shapes:
+        for fuse in ((True, True), (False, False)):
+            got, want = _run_glwe_op(hip, ref, ks, n, rank, rank_out, a_size, a_b, key_size, k_b, dnum, dsize, res_size, r_b,
+                                     batch=3 if big else 9, seed=n + dsize * 7 + a_b + r_b, fuse=fuse)
+            assert np.array_equal(got, want), (n, ks, rank, rank_out, a_size, a_b, key_size, k_b, dnum, dsize, res_size, r_b, fuse)
+    for (rank, a_size, a_b, key_size, k_b, dnum, dsize, res_size, r_b) in ((1, 5, 12, 6, 12, 3, 2, 5, 12), (2, 4, 13, 5, 13, 4, 1, 4, 11),
+                                                                          (1, 4, 12, 5, 12, 2, 3, 4, 14)):
+        if big and rank == 2:
+            continue
+        got, want = _run_relinearize(hip, ref, n, rank, a_size, a_b, key_size, k_b, dnum, dsize, res_size, r_b, batch=3 if big else 7,
+                                     seed=n + rank + dsize)
+        assert np.array_equal(got, want), (n, "relinearize", rank, a_size, a_b, key_size, k_b, dnum, dsize, res_size, r_b)
