@@ -97,7 +97,7 @@ def cpu_baseline(sample_cts_per_thread: int = 4, max_threads: int | None = None)
                       f"{sample_cts_per_thread}, oracle/fft64_ref.c built -O3 -march=native, {dt:.2f} s wall"}
 
 
-def parity_sample(args, mod, a, res, mat_host, lo, nct, ks, auto_mode, unsupported, cols, cols_in, relin=False) -> dict:
+def parity_sample(args, mod, a, res, mat_host, lo, nct, ks, auto_mode, unsupported, cols, cols_in, relin=False, dsize=1) -> dict:
     """Checks `--parity-samples` ciphertexts of the timed output (first, last, and indices spread over the tiles / XCD slots /
     the last partial wave of the launch) against the CPU oracle on the same inputs, bit for bit.  The oracle is the checker
     only: nothing here is timed."""
@@ -125,13 +125,13 @@ def parity_sample(args, mod, a, res, mat_host, lo, nct, ks, auto_mode, unsupport
         ai = VecZnx(N, a.shape[2], SIZE, a[i].cpu().numpy())
         want = VecZnx(N, cols, SIZE)
         if relin:
-            ref.glwe_tensor_relinearize(want, BASE2K, ai, BASE2K, pm, 1, BASE2K)
+            ref.glwe_tensor_relinearize(want, BASE2K, ai, BASE2K, pm, dsize, BASE2K)
         elif auto_mode:
-            ref.glwe_automorphism(want, BASE2K, ai, BASE2K, pm, 1, BASE2K, 5, auto_mode)
+            ref.glwe_automorphism(want, BASE2K, ai, BASE2K, pm, dsize, BASE2K, 5, auto_mode)
         elif ks:
-            ref.glwe_keyswitch(want, BASE2K, ai, BASE2K, pm, 1, BASE2K)
+            ref.glwe_keyswitch(want, BASE2K, ai, BASE2K, pm, dsize, BASE2K)
         else:
-            ref.glwe_external_product(want, BASE2K, ai, BASE2K, pm, 1, BASE2K)
+            ref.glwe_external_product(want, BASE2K, ai, BASE2K, pm, dsize, BASE2K)
         if not np.array_equal(res[i].cpu().numpy(), want.data):
             bad.append(int(lo + i))
     return {"n": len(picks), "ok": not bad, "indices": [int(lo + i) for i in picks], "mismatched": bad,
@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--base2k", type=int, default=0)
     ap.add_argument("--limbs", type=int, default=0, help="override the number of limbs (and dnum); 16 = CKKS shape of BASELINE configs[4]; "
                                                          "0 = the metric configuration (8)")
+    ap.add_argument("--dsize", type=int, default=1, help="digit size of the key (dnum = limbs / dsize rows); > 1 runs the digit-selected middle kernel")
     ap.add_argument("--no-pin-key", action="store_true", help="rebuild the key's row-sliced copy on every call (pz_module_pin_key not used)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the separate per-kernel-class timing pass (no roofline object)")
@@ -168,6 +169,9 @@ def main():
         N = args.n
     if args.base2k:
         BASE2K = args.base2k
+    DSIZE = max(1, args.dsize)
+    if DSIZE > 1:
+        DNUM = max(1, SIZE // DSIZE)
 
     import torch
     import torch.distributed as dist
@@ -238,7 +242,7 @@ def main():
         res = torch.empty((nct, cols, SIZE, cols, N), dtype=torch.int64, device=dev)
         res[:, 0].copy_(a)
         res[:, 1:].zero_()
-    params = GlweOpParams(rank=RANK_GLWE, dnum=DNUM, dsize=1, key_size=SIZE, key_base2k=BASE2K, a_size=SIZE, a_base2k=BASE2K,
+    params = GlweOpParams(rank=RANK_GLWE, dnum=DNUM, dsize=DSIZE, key_size=SIZE, key_base2k=BASE2K, a_size=SIZE, a_base2k=BASE2K,
                           res_size=SIZE, res_base2k=BASE2K, rank_out=RANK_GLWE)
     a_ptr, res_ptr, key_ptr = C.c_void_p(a.data_ptr()), C.c_void_p(res.data_ptr()), C.c_void_p(pmat.data_ptr())
     if expand and nct % DNUM:
@@ -288,7 +292,7 @@ def main():
     dt = time.perf_counter() - t0
 
     # timed output of the LAST step -> parity sample against the CPU oracle (taken before the instrumented pass re-runs the op)
-    parity = parity_sample(args, mod, a, res, mat_host, lo, nct, ks, auto_mode, trace or expand, cols, cols_in, relin) if args.parity_samples else None
+    parity = parity_sample(args, mod, a, res, mat_host, lo, nct, ks, auto_mode, trace or expand, cols, cols_in, relin, DSIZE) if args.parity_samples else None
 
     # roofline leg: the same steps again with one HIP-event pair per launch on the module stream
     stats = {}
@@ -347,12 +351,12 @@ def main():
             "value": value, "unit": ("relinearizations/s" if relin else "GGSWs/s" if expand else f"{args.op}s/s" if (auto_mode or trace) else "key-switches/s" if ks else "external-products/s"),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"glwe_tensor_relinearize (rank 1: 3-column GLWETensor, tensor key 1 -> 1 via GGLWE VmpPMat), N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize=1" if relin else
+            "config": {"workload": (f"glwe_tensor_relinearize (rank 1: 3-column GLWETensor, tensor key 1 -> 1 via GGLWE VmpPMat), N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize={DSIZE}" if relin else
                                     f"ggsw_expand_row on batch/{DNUM} GGSWs of {DNUM} rows (rank {RANK_GLWE}: one key switch per row, body on column 1), N={N}, {SIZE} limbs, base2k={BASE2K}, key dnum={DNUM}" if expand else
                                     f"glwe_trace (log2 N steps of rsh + glwe_automorphism_add_assign, one key per step), N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}" if trace else
-                                    f"glwe_{args.op} (Galois element 5) via GGLWE VmpPMat, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize=1" if auto_mode else
-                                    f"GLWE(rank 1) key-switch via GGLWE VmpPMat, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize=1" if ks else
-                                    f"GLWE(rank 1) x GGSW external product, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize=1"),
+                                    f"glwe_{args.op} (Galois element 5) via GGLWE VmpPMat, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize={DSIZE}" if auto_mode else
+                                    f"GLWE(rank 1) key-switch via GGLWE VmpPMat, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize={DSIZE}" if ks else
+                                    f"GLWE(rank 1) x GGSW external product, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize={DSIZE}"),
                        "batch_per_gpu": args.batch, "parallelism": f"batch-sharded x{world}, key broadcast (RCCL)",
                        "output_digits_balanced": ok},
             "roofline": roof,

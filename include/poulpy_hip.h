@@ -472,8 +472,9 @@ int pz_circuit_bootstrapping_execute_to_exponent_batched(pz_module* m, int64_t* 
                                                          const double* const* tsk_pmats, const pz_circuit_bootstrapping_params* p,
                                                          size_t log_gap_in, size_t log_gap_out, size_t log_domain, void* tmp,
                                                          size_t tmp_bytes, size_t batch);
-/* workspace the calls above need for `batch` ciphertexts (bytes, device); keyswitch: 0 external product, 1 key switch,
- * 2 automorphism family */
+/* device workspace the GLWE-level calls reserve for `batch` ciphertexts, for the pipeline the call will actually take (fused
+ * three-kernel or five-kernel) incl. the growth slack of the module's grow-only arena; keyswitch: 0 external product, 1 key switch,
+ * 2 automorphism family, 3 tensor relinearization */
 size_t pz_glwe_op_workspace_bytes(const pz_module* m, const pz_glwe_op_params* p, size_t batch, int keyswitch);
 /* Optional: declare a prepared key (device pointer from pz_vmp_prepare) immutable until unpinned.  The batched calls
  * above then reuse a row-sliced copy built once here instead of rebuilding it per call (+~3 % at the metric shape,

@@ -1207,10 +1207,44 @@ static size_t pick_chunk(const pz_module* M, const pz_glwe_op_params* p, const O
     return std::min(c, batch);
 }
 
+// which pipeline glwe_op takes for a shape, and what it reserves there (one definition for the call and for the workspace query)
+static bool fused_applies(const pz_module* M, const pz_glwe_op_params* p, const OpShape& s, bool ks, bool tensor, bool au) {
+    const int npi = s.cols_in * s.a_size_eff, npo = s.cols_out * (int)p->key_size;
+    const bool digits = p->dsize > 1, cross_out = p->res_base2k != p->key_base2k;
+    (void)ks;
+    return M->fuse_mid && M->fuse_tail && tail_supported(M) && mid_supported(M, npi, npo) && !(tensor && s.convert) &&
+           (!(digits || cross_out) || (M->plan.m2 == 128 && !au && (int)p->dnum * s.cols_in <= 255 && npo <= 255));
+}
+struct FusedWs {
+    size_t key, conv, t, t2, rtmp, small2, total;
+};
+static FusedWs fused_ws(const pz_module* M, const pz_glwe_op_params* p, const OpShape& s, size_t chunk, bool au) {
+    FusedWs w;
+    const size_t n8 = (size_t)M->n * 8, ksz = p->key_size;
+    const size_t npi = (size_t)s.cols_in * s.a_size_eff, npo = (size_t)s.cols_out * ksz;
+    w.key = align256((size_t)p->dnum * s.cols_in * npo * n8);
+    w.conv = s.convert ? align256(chunk * n8 * s.cols_a * s.a_size_eff) : 0;
+    w.t = align256(chunk * npi * M->m * sizeof(cplx));
+    w.t2 = align256(chunk * npo * M->m * sizeof(cplx));
+    // res_tmp holds the normalized result before the final permutation (mode 0 / gather scheme) OR, in the spectral form, the
+    // body-column operand (min(a_size, key_size) limbs of one column): sized for the larger of the two
+    const size_t body_limbs = std::min<size_t>((size_t)s.a_size_eff, ksz);
+    w.rtmp = au ? align256(chunk * n8 * std::max((size_t)s.cols_out * p->res_size, body_limbs)) : 0;
+    // cross-base output: the tail's key-base digits (cols_out x key_size limbs per ciphertext) before the cross-base pass
+    w.small2 = p->res_base2k != p->key_base2k ? align256(chunk * n8 * s.cols_out * ksz) : 0;
+    w.total = w.key + w.conv + w.t + w.t2 + w.rtmp + w.small2 + kMidDummyBytes;
+    return w;
+}
+// keyswitch: 0 external product, 1 key switch, 2 automorphism family, 3 tensor relinearization.  The figure is what the call reserves
+// in the module's grow-only workspace (+ the 12.5 % growth slack of its first allocation); a key that is neither pinned nor mirrored
+// costs its row-sliced copy, which is included.
 size_t pz_glwe_op_workspace_bytes(const pz_module* M, const pz_glwe_op_params* p, size_t batch, int keyswitch) {
-    if (!M || !p) return 0;
-    OpShape s = op_shape(p, keyswitch != 0);
-    return op_ws(M, p, s, pick_chunk(M, p, s, batch), keyswitch != 0, keyswitch == 2).total;
+    if (!M || !p || p->key_size == 0 || p->a_size == 0) return 0;
+    const bool tensor = keyswitch == 3, ks = keyswitch != 0, au = keyswitch == 2;
+    const OpShape s = op_shape(p, ks, tensor);
+    const size_t chunk = pick_chunk(M, p, s, batch);
+    const size_t bytes = fused_applies(M, p, s, ks, tensor, au) ? fused_ws(M, p, s, chunk, au).total : op_ws(M, p, s, chunk, ks, au).total;
+    return bytes + (bytes >> 3);
 }
 
 // Automorphism family on top of the key switch (poulpy-core automorphism/glwe_ct.rs:51-275).  With phi = X -> X^p:
@@ -1270,8 +1304,7 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
     // dsize > 1 (digit-selected product inside the middle kernel) and res_base2k != key_base2k (the tail normalizes into the key's base,
     // one cross-base pass follows) ride on the same three kernels; both need the 128-point-row plans and no automorphism
     const bool digits = dsize > 1, cross_out = p->res_base2k != p->key_base2k;
-    if (M->fuse_mid && M->fuse_tail && tail_supported(M) && mid_supported(M, npi, npo) && !(tensor && s.convert) &&
-        (!(digits || cross_out) || (M->plan.m2 == 128 && !au && dnum * s.cols_in <= 255 && ncols <= 255))) {
+    if (fused_applies(M, p, s, ks, tensor, au != nullptr)) {
         MidDigits dg;
         if (digits) {
             // external_product/glwe.rs:235-267, keyswitching/glwe.rs:332-379: limb l of `a` is digit di = (dsize - 1 - l) mod dsize, element
@@ -1297,16 +1330,8 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
                 }
             }
         }
-        const size_t key_bytes = align256((size_t)nrows * ncols * (size_t)M->n * 8);
-        const size_t conv_bytes = s.convert ? align256(chunk * (size_t)M->n * 8 * s.cols_a * s.a_size_eff) : 0;
-        const size_t t_bytes = align256(chunk * (size_t)npi * M->m * sizeof(cplx));
-        const size_t t2_bytes = align256(chunk * (size_t)npo * M->m * sizeof(cplx));
-        // res_tmp holds the normalized result before the final permutation (mode 0 / gather scheme) OR, in the spectral form, the
-        // body-column operand (min(a_size, key_size) limbs of one column): sized for the larger of the two
-        const size_t body_limbs = (size_t)std::min<long long>((long long)s.a_size_eff, (long long)ksz);
-        const size_t rtmp_bytes = au ? align256(chunk * (size_t)M->n * 8 * std::max((size_t)s.cols_out * p->res_size, body_limbs)) : 0;
-        // cross_out: the tail's key-base digits (cols_out x key_size limbs per ciphertext) before the cross-base pass
-        const size_t small2_bytes = cross_out ? align256(chunk * (size_t)M->n * 8 * s.cols_out * ksz) : 0;
+        const FusedWs fw = fused_ws(M, p, s, chunk, au != nullptr);
+        const size_t key_bytes = fw.key, conv_bytes = fw.conv, t_bytes = fw.t, t2_bytes = fw.t2, rtmp_bytes = fw.rtmp, small2_bytes = fw.small2;
         PZ_TRY(ws_reserve(M, key_bytes + conv_bytes + t_bytes + t2_bytes + rtmp_bytes + small2_bytes + kMidDummyBytes));
         char* base = (char*)M->ws;
         cplx* Pp = (cplx*)base; base += key_bytes;

@@ -2,7 +2,7 @@
 # SQ counter pass for the bench kernels (run on the GPU box through gpurun)
 REPO=$(pwd); OUT=$REPO/gpurun_out/prof_sq; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --parity-samples 0"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/a -- python3 $REPO/bench.py $ARGS > $OUT/a.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/b -- python3 $REPO/bench.py $ARGS > $OUT/b.log 2>&1
 cd $OUT
