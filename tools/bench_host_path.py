@@ -64,6 +64,30 @@ def main():
     print(json.dumps({"metric": "external products/s, per-op host-pointer path (PCIe-inclusive, %s host memory, 1 ciphertext per call)" % ("pinned" if use_pinned else "pageable"),
                       "value": 1.0 / dt, "ms_per_product": dt * 1e3, "n": n, "limbs": size}))
 
+    # the CoreImpl-level call on HOST containers (what the Rust shim's `core-fused` override issues): ciphertexts staged, the
+    # host-resident prepared key mirrored on the device at first use; 1 ciphertext and 16 ciphertexts per call
+    from poulpy_amd.hal import GlweOpParams
+    p = GlweOpParams(rank=cols - 1, dnum=dnum, dsize=1, key_size=size, key_base2k=k, a_size=size, a_base2k=k, res_size=size, res_base2k=k,
+                     rank_out=cols - 1)
+    key_host = pinned(mod, pm.data.shape, np.float64) if use_pinned else pm.data
+    if use_pinned:
+        key_host[...] = pm.data
+    hp = lambda arr: arr.ctypes.data_as(C.c_void_p)
+    for batch in (1, 16):
+        shape = (batch, size, cols, n)
+        ab = pinned(mod, shape, np.int64) if use_pinned else np.empty(shape, dtype=np.int64)
+        rb = pinned(mod, shape, np.int64) if use_pinned else np.empty(shape, dtype=np.int64)
+        ab[...] = a.data
+        mod.glwe_external_product_batched(hp(rb), hp(ab), hp(key_host), p, batch)      # uploads the key mirror
+        assert np.array_equal(rb[0], res.data)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            mod.glwe_external_product_batched(hp(rb), hp(ab), hp(key_host), p, batch)
+        dt = (time.perf_counter() - t0) / reps
+        print(json.dumps({"metric": "external products/s, fused GLWE-level call on host containers (PCIe-inclusive, %s host memory, "
+                                    "%d ciphertext(s) per call, host key mirrored)" % ("pinned" if use_pinned else "pageable", batch),
+                          "value": batch / dt, "ms_per_call": dt * 1e3, "n": n, "limbs": size}))
+
 
 if __name__ == "__main__":
     main()

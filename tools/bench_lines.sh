@@ -1,0 +1,34 @@
+#!/bin/bash
+# secondary bench.py lines at HEAD (run on the GPU box through gpurun): one JSON line each into gpurun_out/bench_lines.jsonl
+OUT=gpurun_out/bench_lines.jsonl; : > $OUT
+B="python bench.py --no-cpu-baseline --parity-samples 4 --steps 30"
+$B >> $OUT 2>/dev/null
+$B --op keyswitch >> $OUT 2>/dev/null
+$B --op keyswitch --batch 4096 --steps 10 >> $OUT 2>/dev/null
+$B --op automorphism >> $OUT 2>/dev/null
+$B --op automorphism_add >> $OUT 2>/dev/null
+$B --op trace --steps 5 >> $OUT 2>/dev/null
+$B --op ggsw_expand_row >> $OUT 2>/dev/null
+$B --op relinearize >> $OUT 2>/dev/null
+$B --op relinearize --limbs 16 --batch 512 --steps 20 >> $OUT 2>/dev/null
+$B --op keyswitch --limbs 16 --batch 512 --steps 20 >> $OUT 2>/dev/null
+$B --op automorphism --limbs 16 --batch 512 --steps 20 >> $OUT 2>/dev/null
+$B --dsize 2 >> $OUT 2>/dev/null
+$B --op keyswitch --dsize 2 >> $OUT 2>/dev/null
+$B --base2k 14 >> $OUT 2>/dev/null
+$B --n 4096 --limbs 4 --base2k 17 >> $OUT 2>/dev/null
+$B --n 8192 >> $OUT 2>/dev/null
+$B --n 16384 >> $OUT 2>/dev/null
+$B --n 32768 >> $OUT 2>/dev/null
+$B --no-pin-key >> $OUT 2>/dev/null
+python - <<'PY'
+import json
+for l in open("gpurun_out/bench_lines.jsonl"):
+    try:
+        d = json.loads(l)
+    except Exception:
+        continue
+    r = d.get("roofline") or {}
+    print(f'{d["value"]:12.0f} {d["unit"]:24s} {d["ms_per_step"]:8.3f} ms/step  parity={d.get("parity_sample", {}).get("ok")}  {d["config"]["workload"][:110]}  batch={d["config"]["batch_per_gpu"]}  {r.get("kernel_ms")}')
+PY
+python tools/bench_host_path.py 2>/dev/null; python tools/bench_host_path.py --pinned 2>/dev/null

@@ -8,7 +8,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 prof = os.path.join(root, "gpurun_out", "prof")
-stats = sorted(glob.glob(os.path.join(prof, "trace", "**", "*kernel_stats.csv"), recursive=True))
+stats = sorted(glob.glob(os.path.join(prof, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)   # newest last
 if stats:
     rows = [r for r in csv.reader(open(stats[-1]))]
     with open(os.path.join(root, "profiles", f"{tag}_kernel_stats.csv"), "w") as o:
