@@ -40,7 +40,7 @@
  *    call is then logically synchronous) and a HOST-resident prepared key: poulpy-hal's buffers are host-addressable by contract
  *    (Backend::OwnedBuf: DataMut), so this is what the Rust shim's CoreImpl overrides pass.  A host key is mirrored on the
  *    device on first use and re-used afterwards; the mirror is validated on every call by a sampled fingerprint of the host
- *    bytes and dropped by pz_vmp_prepare / pz_vmp_zero on that buffer.  A caller that modifies a prepared matrix in place by
+ *    bytes and dropped by pz_vmp_prepare / pz_vmp_zero on that buffer and by pz_free_bytes of its block.  A caller that modifies a prepared matrix in place by
  *    other means (e.g. deserializes into it) must call pz_module_forget_host_key before the next use.
  */
 #ifndef POULPY_HIP_H
@@ -83,6 +83,8 @@ void* pz_module_stream(pz_module* m);
 
 /* Backend::alloc_bytes, module.rs:38-43 — pinned host memory, 64 B aligned (lib.rs:146) */
 void* pz_alloc_bytes(size_t len);
+/* also drops, in every live module, the device mirror of a host-resident prepared key that lies inside the block (see "host
+ * containers" below) — a prepared key's `Drop` needs no other hook */
 void pz_free_bytes(void* p);
 /* device-resident buffers for the batched path */
 int pz_device_alloc(pz_module* m, size_t len, void** out);
@@ -483,6 +485,8 @@ int pz_module_pin_key(pz_module* m, const double* pmat, size_t rows, size_t cols
 int pz_module_unpin_key(pz_module* m, const double* pmat);
 /* drops the device mirror of a host-resident prepared key (see "Conventions" above); unknown pointers are ignored */
 int pz_module_forget_host_key(pz_module* m, const double* host_pmat);
+/* number of host-resident prepared keys currently mirrored on the device (diagnostic) */
+size_t pz_module_host_key_mirrors(pz_module* m);
 /* Tuning knob: number of ciphertexts pushed through the three-kernel pipeline per
  * wave so that intermediates stay in the 256 MiB Infinity Cache (0 = auto). */
 int pz_module_set_chunk(pz_module* m, size_t cts_per_chunk);

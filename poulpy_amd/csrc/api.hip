@@ -202,6 +202,12 @@ static int glwe_args_out(pz_module* M, GlweArgs& g) {
     return finish_call(M, g.host);
 }
 
+// live modules, so that pz_free_bytes can drop the device mirror of a prepared key whose pinned host buffer is being released (the
+// Rust shim's `PinnedBuf::drop`): a later allocation at the same address then never meets a stale mirror, fingerprint or not
+static std::mutex g_modules_mu;
+static std::vector<pz_module*> g_modules;
+static std::vector<std::pair<void*, size_t>> g_host_allocs;   // pz_alloc_bytes blocks (a prepared key may sit inside one)
+
 // ------------------------------------------------------------------------------
 // public: misc
 // ------------------------------------------------------------------------------
@@ -244,6 +250,10 @@ int pz_module_new_on_device(uint64_t n, int device, pz_module** out) {
         if (hipMemset(M->margin, 0, 8) != hipSuccess) { r = fail(PZ_ERR_HIP, "margin memset failed"); break; }
     } while (0);
     if (r != PZ_OK) { pz_module_free(M); return r; }
+    {
+        std::lock_guard<std::mutex> g(g_modules_mu);
+        g_modules.push_back(M);
+    }
     *out = M;
     return PZ_OK;
 }
@@ -254,6 +264,10 @@ int pz_module_new(uint64_t n, pz_module** out) {
 }
 void pz_module_free(pz_module* M) {
     if (!M) return;
+    {
+        std::lock_guard<std::mutex> g(g_modules_mu);
+        g_modules.erase(std::remove(g_modules.begin(), g_modules.end(), M), g_modules.end());
+    }
     (void)hipSetDevice(M->device);
     if (M->stream) (void)hipStreamSynchronize(M->stream);
     for (void* p : {(void*)M->tw1, (void*)M->tw1inv, (void*)M->wL1, (void*)M->wL2, (void*)M->tw12, (void*)M->tw12t, (void*)M->w2n, M->ws, M->ws2, (void*)M->margin})
@@ -403,10 +417,36 @@ void* pz_alloc_bytes(size_t len) {
         return nullptr;
     }
     memset(p, 0, len);
+    {
+        std::lock_guard<std::mutex> g(g_modules_mu);
+        g_host_allocs.emplace_back(p, len);
+    }
     return p;
 }
 void pz_free_bytes(void* p) {
-    if (p) (void)hipHostFree(p);
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> g(g_modules_mu);
+        size_t len = 1;
+        for (size_t i = 0; i < g_host_allocs.size(); ++i)
+            if (g_host_allocs[i].first == p) {
+                len = g_host_allocs[i].second;
+                g_host_allocs[i] = g_host_allocs.back();
+                g_host_allocs.pop_back();
+                break;
+            }
+        for (pz_module* M : g_modules) {
+            std::lock_guard<std::mutex> lock_(M->mu);
+            for (size_t i = M->mirrors.size(); i-- > 0;) {
+                const char* h = (const char*)M->mirrors[i].host;
+                if (h < (const char*)p || h >= (const char*)p + len) continue;
+                (void)hipSetDevice(M->device);
+                (void)hipStreamSynchronize(M->stream);
+                drop_mirror_at(M, i);
+            }
+        }
+    }
+    (void)hipHostFree(p);
 }
 int pz_device_alloc(pz_module* M, size_t len, void** out) {
     if (!M || !out) return fail(PZ_ERR_INVALID, "null argument");
@@ -1580,6 +1620,11 @@ int pz_glwe_tensor_relinearize_batched(pz_module* M, int64_t* res, const int64_t
 int pz_module_forget_host_key(pz_module* M, const double* host_pmat) {
     PZ_ENTER(M);
     return forget_host_key(M, (const void*)host_pmat);
+}
+size_t pz_module_host_key_mirrors(pz_module* M) {
+    if (!M) return 0;
+    std::lock_guard<std::mutex> lock_(M->mu);
+    return M->mirrors.size();
 }
 // ggsw_external_product (external_product/ggsw.rs:54-58): every (row, column) entry of the GGSW `a` is a GLWE and the entries
 // are contiguous in the MatZnx layout, so the operation is one batched external product over dnum_a * (rank+1) ciphertexts

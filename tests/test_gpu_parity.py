@@ -1680,5 +1680,18 @@ def test_glwe_ops_on_host_containers(mods, n):
         run(got, a_all, hp(ph.data))
         assert np.array_equal(got, want), kind
         assert hip.lib.pz_module_forget_host_key(hip.handle, hp(ph.data)) == 0
+        # a key inside a pz_alloc_bytes block (Backend::OwnedBuf of the Rust shim): releasing the block drops its mirror
+        lib = hip.lib
+        lib.pz_module_host_key_mirrors.restype = C.c_size_t
+        lib.pz_module_host_key_mirrors.argtypes = [C.c_void_p]
+        before = lib.pz_module_host_key_mirrors(hip.handle)
+        blk = lib.pz_alloc_bytes(ph.data.nbytes + 4096)
+        inner = np.ctypeslib.as_array(C.cast(blk + 4096, C.POINTER(C.c_double)), shape=(ph.data.size,))
+        inner[...] = ph.data.reshape(-1)
+        run(got, a_all, C.c_void_p(blk + 4096))
+        assert np.array_equal(got, want), kind
+        assert lib.pz_module_host_key_mirrors(hip.handle) == before + 1
+        lib.pz_free_bytes(C.c_void_p(blk))
+        assert lib.pz_module_host_key_mirrors(hip.handle) == before
         for buf in (d_a, d_r):
             buf.free()
