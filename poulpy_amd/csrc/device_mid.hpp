@@ -495,6 +495,12 @@ k_mid128(MidArgs g) {
 #undef PZ_MID_P0
 }
 
+// (Round 2 experiment, removed: "k_midr<LPR = 4>" — the same kernel for rows of 64 points owned by 4 lanes (m = 512 x 64): a tile of four
+//  ciphertexts is then 65 KiB and TWO 256-thread workgroups share a CU at the same four ciphertexts per key fetch.  Timed at that geometry:
+//  5.7 ms against 5.0 ms (profiles/r02_ab_mid64_rows.txt).  With the T' / T2' traffic removed both shapes take 4.1-4.2 ms: the on-CU work
+//  (LDS exchanges, product FMAs + key through L1, butterflies) is serial in both and a second workgroup does not overlap it any better,
+//  while the 64-byte global runs of 4-lane rows stream worse.)
+
 // (Round 2 experiment, removed: "k_mid128L" — four extra loader waves that request tile t+1 at the top of iteration t, hold it in
 //  registers and hand it over through LDS once the compute waves release the tile, so that HBM loads never sit in front of the
 //  compute waves' L2-served key loads.  Bit-exact, but 9 % SLOWER (5.19 vs 4.76 ms per 1024 ciphertexts,

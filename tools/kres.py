@@ -3,10 +3,17 @@
 usage: python tools/kres.py [filter-substring]"""
 import re, subprocess, sys, os
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "poulpy_amd", "csrc")
-out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-                      "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/kres.so", "api.hip"],
-                     cwd=root, capture_output=True, text=True).stderr
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
+# kernels live in the launch_*.hip translation units; `--tu launch_mid` restricts the (slow) compile to one of them
+tus = sorted(f for f in os.listdir(root) if f.startswith("launch_") and f.endswith(".hip"))
+if "--tu" in sys.argv:
+    tus = [sys.argv[sys.argv.index("--tu") + 1] + ".hip"]
+    flt = "" if flt == "--tu" else flt
+out = ""
+for tu in tus:
+    out += subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-c",
+                           "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/kres.o", tu],
+                          cwd=root, capture_output=True, text=True).stderr
 cur = None
 rows = []
 for line in out.splitlines():
