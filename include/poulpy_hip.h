@@ -425,6 +425,34 @@ typedef struct {
 int pz_blind_rotation_execute_batched(pz_module* m, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
                                       const pz_blind_rotation_params* p, size_t batch);
 size_t pz_blind_rotation_workspace_bytes(const pz_module* m, const pz_blind_rotation_params* p, size_t batch);
+
+/* ---- LWE glue of the gate bootstrap (BASELINE configs[3]: mod switch -> blind rotation -> sample extract / LWE key switch) on
+ * device-resident batches.  An LWE is the reference's container VecZnx(n = n_lwe + 1, one column, `size` limbs): limb i =
+ * [b, a_0 .. a_{n_lwe-1}] at i * (n_lwe + 1); a batch is `batch` of them back to back.  Device pointers only.
+ *
+ * mod_switch_2n (poulpy-bin-fhe/src/blind_rotation/algorithms/mod.rs:136-176): res = batch vectors of n_lwe + 1 values, the input
+ * of pz_blind_rotation_execute_batched; n2 = 2 * extension_factor * n_glwe; negate != 0 = LookUpTableRotationDirection::Left.
+ * Restated literally: base2k > log2n rounds limb 0, otherwise the following limbs are appended (un-negated, as in the reference). */
+int pz_lwe_mod_switch_2n_batched(pz_module* m, int64_t* res, const int64_t* lwe, size_t n_lwe, size_t lwe_size, size_t base2k, size_t n2,
+                                 int negate, size_t batch);
+/* LWESampleExtract::lwe_sample_extract (poulpy-core/src/api/conversion.rs:15-40): coefficient 0 of column 0 and the first
+ * res_n_lwe coefficients of column 1 of each GLWE (a_cols columns, a_size limbs); limbs beyond min(res_size, a_size) are zero */
+int pz_lwe_sample_extract_batched(pz_module* m, int64_t* res, size_t res_n_lwe, size_t res_size, const int64_t* a, size_t a_cols,
+                                  size_t a_size, size_t batch);
+/* LWEKeySwitch::lwe_keyswitch (poulpy-core/src/keyswitching/lwe.rs:49-94): embed -> glwe_keyswitch -> sample extract.
+ * p: rank = rank_out = 1; a_size / a_base2k = the input LWE's, res_size / res_base2k = the output LWE's; ksk_pmat: the prepared
+ * GGLWE (rows = p->dnum, cols_in = 1, cols_out = 2, size = p->key_size), device or host-resident like any prepared key */
+int pz_lwe_keyswitch_batched(pz_module* m, int64_t* res, size_t res_n_lwe, const int64_t* a, size_t a_n_lwe, const double* ksk_pmat,
+                             const pz_glwe_op_params* p, size_t batch);
+/* GLWEFromLWE::glwe_from_lwe (poulpy-core/src/conversion/lwe_to_glwe.rs:46-121): the LWE is embedded into a rank-1 GLWE in the
+ * KEY's base with p->a_size = ceil(lwe_size * lwe_base2k / key_base2k) limbs (cross-base: vec_znx_normalize per column, :82-116),
+ * then key-switched rank 1 -> p->rank_out.  res = batch GLWEs (rank_out + 1, p->res_size). */
+int pz_glwe_from_lwe_batched(pz_module* m, int64_t* res, const int64_t* lwe, size_t n_lwe, size_t lwe_size, size_t lwe_base2k,
+                             const double* ksk_pmat, const pz_glwe_op_params* p, size_t batch);
+/* LWEFromGLWE::lwe_from_glwe (poulpy-core/src/conversion/glwe_to_lwe.rs:42-90): multiply by X^-a_idx (a_idx != 0), key switch
+ * p->rank -> 1 into a GLWE with the LWE's base and size, sample extract.  a = batch GLWEs (p->rank + 1, p->a_size). */
+int pz_lwe_from_glwe_batched(pz_module* m, int64_t* res, size_t res_n_lwe, const int64_t* a, size_t a_idx, const double* ksk_pmat,
+                             const pz_glwe_op_params* p, size_t batch);
 /* execute_block_binary_extended (algorithm.rs:121-273): extension_factor > 1 (a power of two), block_size > 1.  lwe_2n is the
  * output of mod_switch_2n(2 * n * extension_factor); lut = the extension_factor polynomials lut.data[j], each
  * VecZnx(1, lut_size), contiguous; tmp = device scratch of pz_blind_rotation_extended_tmp_bytes; batch * extension_factor

@@ -2475,3 +2475,120 @@ void pzr_glwe_tensor_relinearize(const pzr_tables* t, size_t rank,
         pzr_vec_znx_normalize(n, res, cols, res_size, res_base2k, 0, i, res_big, cols, tsk_size, key_base2k, i);
     free(a_dft); free(a_conv); free(res_dft);
 }
+
+/* ------------------------------------------------------------------------ */
+/* LWE glue of the gate bootstrap (BASELINE configs[3]: blind-rotate + key switch) */
+/* ------------------------------------------------------------------------ */
+
+/* poulpy-bin-fhe/src/blind_rotation/algorithms/mod.rs:136-171 (`mod_switch_2n`) and :173-176 (`div_round_by_pow2`).
+ * lwe: VecZnx(n = n_lwe + 1, cols = 1, lwe_size); res: n_lwe + 1 values.  Restated literally, including that only limb 0 is
+ * negated for `Left` and that the low limbs are appended without rounding in the multi-limb branch. */
+void pzr_mod_switch_2n(size_t n2, int64_t* res, const int64_t* lwe, size_t n_lwe, size_t lwe_size, size_t base2k, int negate) {
+    size_t len = n_lwe + 1;
+    size_t log2n = 1;
+    {   /* usize::BITS - (n - 1).leading_zeros() + 1 */
+        size_t v = n2 - 1, bits = 0;
+        while (v) { ++bits; v >>= 1; }
+        log2n = bits + 1;
+    }
+    for (size_t i = 0; i < len; ++i) res[i] = negate ? (int64_t)(0 - (uint64_t)lwe[i]) : lwe[i];
+    if (base2k > log2n) {
+        size_t diff = base2k - (log2n - 1);
+        for (size_t i = 0; i < len; ++i) res[i] = (int64_t)((uint64_t)res[i] + ((uint64_t)1 << (diff - 1))) >> diff;
+    } else {
+        size_t rem = base2k - (log2n % base2k);
+        size_t size = div_ceil(log2n, base2k);
+        (void)lwe_size;
+        for (size_t i = 1; i < size; ++i) {
+            const int64_t* x = lwe + i * len;
+            if (i == size - 1 && rem != base2k) {
+                size_t k_rem = base2k - rem;
+                for (size_t j = 0; j < len; ++j) res[j] = (int64_t)(((uint64_t)res[j] << k_rem) + (uint64_t)(x[j] >> rem));
+            } else {
+                for (size_t j = 0; j < len; ++j) res[j] = (int64_t)(((uint64_t)res[j] << base2k) + (uint64_t)x[j]);
+            }
+        }
+    }
+}
+
+/* poulpy-core/src/api/conversion.rs:15-40 (`lwe_sample_extract`): constant coefficient of column 0 and the first res_n_lwe
+ * coefficients of column 1, limb by limb; limbs beyond min(res_size, a_size) are zero.  res: VecZnx(res_n_lwe + 1, 1, res_size). */
+void pzr_lwe_sample_extract(size_t n, int64_t* res, size_t res_n_lwe, size_t res_size, const int64_t* a, size_t a_cols, size_t a_size) {
+    size_t len = res_n_lwe + 1;
+    size_t min_size = zmin(res_size, a_size);
+    memset(res, 0, len * res_size * sizeof(int64_t));
+    for (size_t i = 0; i < min_size; ++i) {
+        int64_t* r = res + i * len;
+        r[0] = a[n * (i * a_cols + 0)];
+        memcpy(r + 1, a + n * (i * a_cols + 1), res_n_lwe * sizeof(int64_t));
+    }
+}
+
+/* the LWE -> rank-1 GLWE embedding shared by keyswitching/lwe.rs:69-80 and conversion/lwe_to_glwe.rs:71-80: b to the constant
+ * coefficient of column 0, a_0.. to the first n_lwe coefficients of column 1; glwe is zeroed first */
+static void lwe_embed(size_t n, int64_t* glwe, size_t glwe_size, const int64_t* lwe, size_t n_lwe, size_t lwe_size) {
+    size_t len = n_lwe + 1;
+    memset(glwe, 0, n * 2 * glwe_size * sizeof(int64_t));
+    for (size_t i = 0; i < lwe_size; ++i) {
+        glwe[n * (i * 2 + 0)] = lwe[i * len];
+        memcpy(glwe + n * (i * 2 + 1), lwe + i * len + 1, n_lwe * sizeof(int64_t));
+    }
+}
+
+/* poulpy-core/src/keyswitching/lwe.rs:49-94 (`lwe_keyswitch_default`): embed (glwe_in has a's base and size), rank-1 -> rank-1
+ * glwe_keyswitch into a GLWE with res's base and size, sample extract */
+void pzr_lwe_keyswitch(const pzr_tables* t, int64_t* res, size_t res_n_lwe, size_t res_size, size_t res_base2k,
+                       const int64_t* a, size_t a_n_lwe, size_t a_size, size_t a_base2k,
+                       const double* key_pmat, size_t dnum, size_t key_size, size_t dsize, size_t key_base2k) {
+    size_t n = t->m << 1;
+    int64_t* glwe_in = (int64_t*)malloc(n * 2 * a_size * sizeof(int64_t));
+    int64_t* glwe_out = (int64_t*)calloc(n * 2 * res_size, sizeof(int64_t));
+    lwe_embed(n, glwe_in, a_size, a, a_n_lwe, a_size);
+    pzr_glwe_keyswitch(t, 1, 1, glwe_out, res_size, res_base2k, glwe_in, a_size, a_base2k, key_pmat, dnum, key_size, dsize, key_base2k);
+    pzr_lwe_sample_extract(n, res, res_n_lwe, res_size, glwe_out, 2, res_size);
+    free(glwe_in); free(glwe_out);
+}
+
+/* poulpy-core/src/conversion/lwe_to_glwe.rs:46-121 (`glwe_from_lwe_default`): the rank-1 GLWE has the KEY's base and
+ * glwe_size = ceil(lwe.max_k / key_base2k) limbs; same base: plain embedding (:75-80), else the two columns are embedded into a
+ * one-column VecZnx and normalized across bases (:82-116); then glwe_keyswitch (rank 1 -> rank_out) */
+void pzr_glwe_from_lwe(const pzr_tables* t, size_t rank_out, int64_t* res, size_t res_size, size_t res_base2k,
+                       const int64_t* lwe, size_t n_lwe, size_t lwe_size, size_t lwe_base2k, size_t glwe_size,
+                       const double* key_pmat, size_t dnum, size_t key_size, size_t dsize, size_t key_base2k) {
+    size_t n = t->m << 1;
+    size_t len = n_lwe + 1;
+    int64_t* glwe = (int64_t*)calloc(n * 2 * glwe_size, sizeof(int64_t));
+    if (lwe_base2k == key_base2k) {
+        for (size_t i = 0; i < lwe_size; ++i) {
+            glwe[n * (i * 2 + 0)] = lwe[i * len];
+            memcpy(glwe + n * (i * 2 + 1), lwe + i * len + 1, n_lwe * sizeof(int64_t));
+        }
+    } else {
+        int64_t* a_conv = (int64_t*)calloc(n * lwe_size, sizeof(int64_t));
+        for (size_t j = 0; j < lwe_size; ++j) a_conv[n * j] = lwe[j * len];
+        pzr_vec_znx_normalize(n, glwe, 2, glwe_size, key_base2k, 0, 0, a_conv, 1, lwe_size, lwe_base2k, 0);
+        memset(a_conv, 0, n * lwe_size * sizeof(int64_t));
+        for (size_t j = 0; j < lwe_size; ++j) memcpy(a_conv + n * j, lwe + j * len + 1, n_lwe * sizeof(int64_t));
+        pzr_vec_znx_normalize(n, glwe, 2, glwe_size, key_base2k, 0, 1, a_conv, 1, lwe_size, lwe_base2k, 0);
+        free(a_conv);
+    }
+    pzr_glwe_keyswitch(t, 1, rank_out, res, res_size, res_base2k, glwe, glwe_size, key_base2k, key_pmat, dnum, key_size, dsize, key_base2k);
+    free(glwe);
+}
+
+/* poulpy-core/src/conversion/glwe_to_lwe.rs:42-90 (`lwe_from_glwe_default`): rotate by X^-a_idx when a_idx != 0 (glwe_rotate =
+ * vec_znx_rotate on every column, all limbs), key switch rank_in -> 1 into a GLWE with res's base and size, sample extract */
+void pzr_lwe_from_glwe(const pzr_tables* t, size_t rank_in, int64_t* res, size_t res_n_lwe, size_t res_size, size_t res_base2k,
+                       const int64_t* a, size_t a_size, size_t a_base2k, size_t a_idx,
+                       const double* key_pmat, size_t dnum, size_t key_size, size_t dsize, size_t key_base2k) {
+    size_t n = t->m << 1;
+    size_t cols = rank_in + 1;
+    int64_t* tmp_in = (int64_t*)malloc(n * cols * a_size * sizeof(int64_t));
+    int64_t* tmp1 = (int64_t*)calloc(n * 2 * res_size, sizeof(int64_t));
+    if (a_idx == 0) memcpy(tmp_in, a, n * cols * a_size * sizeof(int64_t));
+    else
+        for (size_t c = 0; c < cols; ++c) pzr_vec_znx_rotate(n, -(int64_t)a_idx, tmp_in, cols, a_size, c, a, cols, a_size, c);
+    pzr_glwe_keyswitch(t, rank_in, 1, tmp1, res_size, res_base2k, tmp_in, a_size, a_base2k, key_pmat, dnum, key_size, dsize, key_base2k);
+    pzr_lwe_sample_extract(n, res, res_n_lwe, res_size, tmp1, 2, res_size);
+    free(tmp_in); free(tmp1);
+}

@@ -258,6 +258,21 @@ void pzr_glwe_tensor_relinearize(const pzr_tables* t, size_t rank,
                                  const int64_t* a, size_t a_size, size_t a_base2k,
                                  const double* tsk_pmat, size_t dnum, size_t tsk_size, size_t dsize, size_t key_base2k);
 
+/* LWE glue of the gate bootstrap: poulpy-bin-fhe blind_rotation/algorithms/mod.rs:136-176 (mod_switch_2n), poulpy-core
+ * api/conversion.rs:15-40 (lwe_sample_extract), keyswitching/lwe.rs:49-94 (lwe_keyswitch), conversion/lwe_to_glwe.rs:46-121
+ * (glwe_from_lwe), conversion/glwe_to_lwe.rs:42-90 (lwe_from_glwe).  LWE = VecZnx(n_lwe + 1, 1 column, size): [b, a_0..] per limb. */
+void pzr_mod_switch_2n(size_t n2, int64_t* res, const int64_t* lwe, size_t n_lwe, size_t lwe_size, size_t base2k, int negate);
+void pzr_lwe_sample_extract(size_t n, int64_t* res, size_t res_n_lwe, size_t res_size, const int64_t* a, size_t a_cols, size_t a_size);
+void pzr_lwe_keyswitch(const pzr_tables* t, int64_t* res, size_t res_n_lwe, size_t res_size, size_t res_base2k,
+                       const int64_t* a, size_t a_n_lwe, size_t a_size, size_t a_base2k,
+                       const double* key_pmat, size_t dnum, size_t key_size, size_t dsize, size_t key_base2k);
+void pzr_glwe_from_lwe(const pzr_tables* t, size_t rank_out, int64_t* res, size_t res_size, size_t res_base2k,
+                       const int64_t* lwe, size_t n_lwe, size_t lwe_size, size_t lwe_base2k, size_t glwe_size,
+                       const double* key_pmat, size_t dnum, size_t key_size, size_t dsize, size_t key_base2k);
+void pzr_lwe_from_glwe(const pzr_tables* t, size_t rank_in, int64_t* res, size_t res_n_lwe, size_t res_size, size_t res_base2k,
+                       const int64_t* a, size_t a_size, size_t a_base2k, size_t a_idx,
+                       const double* key_pmat, size_t dnum, size_t key_size, size_t dsize, size_t key_base2k);
+
 #ifdef __cplusplus
 }
 #endif

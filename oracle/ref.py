@@ -462,3 +462,36 @@ class RefModule:
         assert a.cols == (rank + 1) * (rank + 2) // 2
         self.lib.pzr_glwe_tensor_relinearize(self.t, c_size_t(rank), _p(res.data), *_sz(res.size, res_base2k), _p(a.data),
                                              *_sz(a.size, a_base2k), _p(tsk_pmat.data), *_sz(tsk_pmat.rows, tsk_pmat.size, dsize, key_base2k))
+
+    # ---- LWE glue of the gate bootstrap (mod_switch_2n, sample extract, LWE key switch, LWE <-> GLWE) ----
+    # an LWE is a numpy int64 array of shape (size, n_lwe + 1): limb i = [b, a_0, ..., a_{n_lwe-1}]  (VecZnx(n_lwe + 1, 1, size))
+    def mod_switch_2n(self, n2, lwe, base2k, negate=False):
+        lwe = np.ascontiguousarray(lwe, dtype=np.int64)
+        size, length = lwe.shape
+        res = np.zeros(length, dtype=np.int64)
+        self.lib.pzr_mod_switch_2n(c_size_t(n2), _p(res), _p(lwe), *_sz(length - 1, size, base2k), C.c_int(1 if negate else 0))
+        return res
+
+    def lwe_sample_extract(self, res_n_lwe, res_size, a):
+        res = np.zeros((res_size, res_n_lwe + 1), dtype=np.int64)
+        self.lib.pzr_lwe_sample_extract(c_size_t(self._n), _p(res), *_sz(res_n_lwe, res_size), _p(a.data), *_sz(a.cols, a.size))
+        return res
+
+    def lwe_keyswitch(self, res_n_lwe, res_size, res_base2k, a, a_base2k, pmat, dsize, key_base2k):
+        a = np.ascontiguousarray(a, dtype=np.int64)
+        res = np.zeros((res_size, res_n_lwe + 1), dtype=np.int64)
+        self.lib.pzr_lwe_keyswitch(self.t, _p(res), *_sz(res_n_lwe, res_size, res_base2k), _p(a),
+                                   *_sz(a.shape[1] - 1, a.shape[0], a_base2k), _p(pmat.data), *_sz(pmat.rows, pmat.size, dsize, key_base2k))
+        return res
+
+    def glwe_from_lwe(self, res, res_base2k, lwe, lwe_base2k, glwe_size, pmat, dsize, key_base2k):
+        lwe = np.ascontiguousarray(lwe, dtype=np.int64)
+        self.lib.pzr_glwe_from_lwe(self.t, c_size_t(res.cols - 1), _p(res.data), *_sz(res.size, res_base2k), _p(lwe),
+                                   *_sz(lwe.shape[1] - 1, lwe.shape[0], lwe_base2k, glwe_size), _p(pmat.data),
+                                   *_sz(pmat.rows, pmat.size, dsize, key_base2k))
+
+    def lwe_from_glwe(self, res_n_lwe, res_size, res_base2k, a, a_base2k, a_idx, pmat, dsize, key_base2k):
+        res = np.zeros((res_size, res_n_lwe + 1), dtype=np.int64)
+        self.lib.pzr_lwe_from_glwe(self.t, c_size_t(a.cols - 1), _p(res), *_sz(res_n_lwe, res_size, res_base2k), _p(a.data),
+                                   *_sz(a.size, a_base2k, a_idx), _p(pmat.data), *_sz(pmat.rows, pmat.size, dsize, key_base2k))
+        return res

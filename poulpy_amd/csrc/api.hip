@@ -2201,3 +2201,10 @@ int pz_glwe_pack_batched(pz_module* M, int64_t* res, size_t nslots, const uint64
 
 }  // extern "C"
 
+// api_lwe.hip composes the LWE <-> GLWE conversions around the batched key switch while holding the module lock
+namespace pz {
+int glwe_keyswitch_nolock(pz_module* M, int64_t* res, const int64_t* a, const double* key_pmat, const pz_glwe_op_params* p, size_t batch) {
+    return glwe_entry(M, true, false, res, a, key_pmat, p, batch, nullptr);
+}
+}  // namespace pz
+

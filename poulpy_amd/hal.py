@@ -602,6 +602,31 @@ class Module:
         """poulpy-core operations/glwe.rs:541-607 on device-resident GLWETensors sharing one prepared tensor key."""
         self._ck(self.lib.pz_glwe_tensor_relinearize_batched(self.handle, res, a, tsk_pmat, C.byref(params), c_size_t(batch)))
 
+    # -- LWE glue of the gate bootstrap (device-resident batches; an LWE = VecZnx(n_lwe + 1, 1, size)) -------------
+    def lwe_mod_switch_2n_batched(self, res: c_void_p, lwe: c_void_p, n_lwe: int, lwe_size: int, base2k: int, n2: int, negate: bool, batch: int):
+        """poulpy-bin-fhe blind_rotation/algorithms/mod.rs:136-176."""
+        self._ck(self.lib.pz_lwe_mod_switch_2n_batched(self.handle, res, lwe, c_size_t(n_lwe), c_size_t(lwe_size), c_size_t(base2k), c_size_t(n2),
+                                                       c_int(1 if negate else 0), c_size_t(batch)))
+
+    def lwe_sample_extract_batched(self, res: c_void_p, res_n_lwe: int, res_size: int, a: c_void_p, a_cols: int, a_size: int, batch: int):
+        """poulpy-core api/conversion.rs:15-40."""
+        self._ck(self.lib.pz_lwe_sample_extract_batched(self.handle, res, c_size_t(res_n_lwe), c_size_t(res_size), a, c_size_t(a_cols),
+                                                        c_size_t(a_size), c_size_t(batch)))
+
+    def lwe_keyswitch_batched(self, res: c_void_p, res_n_lwe: int, a: c_void_p, a_n_lwe: int, ksk_pmat: c_void_p, params: GlweOpParams, batch: int):
+        """poulpy-core keyswitching/lwe.rs:49-94."""
+        self._ck(self.lib.pz_lwe_keyswitch_batched(self.handle, res, c_size_t(res_n_lwe), a, c_size_t(a_n_lwe), ksk_pmat, C.byref(params), c_size_t(batch)))
+
+    def glwe_from_lwe_batched(self, res: c_void_p, lwe: c_void_p, n_lwe: int, lwe_size: int, lwe_base2k: int, ksk_pmat: c_void_p,
+                              params: GlweOpParams, batch: int):
+        """poulpy-core conversion/lwe_to_glwe.rs:46-121."""
+        self._ck(self.lib.pz_glwe_from_lwe_batched(self.handle, res, lwe, c_size_t(n_lwe), c_size_t(lwe_size), c_size_t(lwe_base2k), ksk_pmat,
+                                                   C.byref(params), c_size_t(batch)))
+
+    def lwe_from_glwe_batched(self, res: c_void_p, res_n_lwe: int, a: c_void_p, a_idx: int, ksk_pmat: c_void_p, params: GlweOpParams, batch: int):
+        """poulpy-core conversion/glwe_to_lwe.rs:42-90."""
+        self._ck(self.lib.pz_lwe_from_glwe_batched(self.handle, res, c_size_t(res_n_lwe), a, c_size_t(a_idx), ksk_pmat, C.byref(params), c_size_t(batch)))
+
     # -- multi-GPU (SURVEY.md 8e): RCCL broadcast of prepared keys on the module stream ---------------------
     def comm_unique_id(self) -> bytes:
         """ncclGetUniqueId (call on ONE rank, ship the bytes to the others out of band)."""
