@@ -1768,8 +1768,14 @@ size_t pz_blind_rotation_workspace_bytes(const pz_module* M, const pz_blind_rota
     const size_t n8 = (size_t)M->n * 8, cols = p->rank + 1;
     const size_t tp = cols * std::max({(size_t)p->dnum, (size_t)p->brk_size, (size_t)p->res_size});
     const size_t T = align256(batch * tp * (size_t)M->m * sizeof(cplx));
-    if (p->block_size > 1)
-        return align256(batch * n8 * cols * p->dnum) + 2 * align256(batch * n8 * cols * p->brk_size) + T;
+    if (p->block_size > 1) {
+        // the composed path, or (plans with 128-point rows) the row-sliced keys of one block + T' + T2' of the three-kernel block step
+        const size_t composed = align256(batch * n8 * cols * p->dnum) + 2 * align256(batch * n8 * cols * p->brk_size) + T;
+        const size_t mid = align256((size_t)p->block_size * p->dnum * cols * cols * p->brk_size * n8) +
+                           align256(batch * n8 * cols * std::min((size_t)p->dnum, (size_t)p->res_size)) + align256(batch * n8 * cols * p->brk_size) +
+                           kMidDummyBytes;
+        return std::max(composed, mid);
+    }
     pz_glwe_op_params ep;
     ep.rank = p->rank; ep.dnum = p->dnum; ep.dsize = 1; ep.key_size = p->brk_size; ep.key_base2k = p->base2k;
     ep.a_size = p->res_size; ep.a_base2k = p->base2k; ep.res_size = p->res_size; ep.res_base2k = p->base2k; ep.rank_out = p->rank;
@@ -1810,6 +1816,34 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
     }
     if (blk > 1) {
         const size_t n8 = (size_t)M->n * 8;
+        // plans with 128-point rows (N >= 4096): the block step on the three-kernel pipeline of the GLWE products — pass 1 of the
+        // accumulator limbs | k_mid128<.., BR> (row DFT, the block's blk products weighted by DFT(X^a_i - 1), inverse row DFT) | tail
+        // (inverse column pass + accumulator + carry chain): the spectra never reach HBM and one launch covers the whole block
+        {
+            const int npi = cols * std::min(dnum, rsz), npo = cols * bsz, nrows_key = dnum * cols, ncols_key = cols * bsz;
+            static const int br_mid = getenv("POULPY_DBG_BR_MID") ? atoi(getenv("POULPY_DBG_BR_MID")) : 1;
+            if (br_mid && M->fuse_mid && M->fuse_tail && tail_supported(M) && M->plan.m2 == 128 && mid_supported(M, npi, npo) &&
+                npi == nrows_key && blk <= 16) {
+                const size_t key_bytes = align256((size_t)blk * nrows_key * ncols_key * n8);
+                const size_t t_bytes = align256(batch * npi * (size_t)M->m * sizeof(cplx)), t2_bytes = align256(batch * npo * (size_t)M->m * sizeof(cplx));
+                PZ_TRY(ws_reserve(M, key_bytes + t_bytes + t2_bytes + kMidDummyBytes));
+                char* base = (char*)M->ws;
+                cplx* Pp = (cplx*)base; base += key_bytes;
+                cplx* T = (cplx*)base; base += t_bytes;
+                cplx* T2 = (cplx*)base; base += t2_bytes;
+                cplx* mid_dummy = (cplx*)base;
+                PolyMap sm{npi / cols, cols, res_ct, (long long)cols * n, n, 0};
+                for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {
+                    PZ_TRY(launch_permute_pmat(M, brk + (size_t)b0 * pmat_doubles, Pp, blk * nrows_key * ncols_key));
+                    PZ_TRY(launch_fwd_pass1(M, B * npi, (const long long*)res, sm, T, true));
+                    MidBr mb{(const long long*)lwe_2n, lwe_bs, b0, blk};
+                    PZ_TRY(launch_mid(M, B, T, T2, Pp, npi, npo, nrows_key, ncols_key, mid_dummy, 0, 0, nullptr, &mb));
+                    PZ_TRY(launch_inv_tail(M, B, T2, bsz, cols, (long long*)res, res_ct, cols, rsz, (const long long*)res, res_ct, cols, rsz, k,
+                                           true, true));
+                }
+                return PZ_OK;
+            }
+        }
         const size_t acc_dft_bytes = align256(batch * n8 * cols * dnum), vr_bytes = align256(batch * n8 * cols * bsz);
         const size_t tp = (size_t)cols * std::max({dnum, bsz, rsz});
         const size_t t_bytes = align256(batch * tp * (size_t)M->m * sizeof(cplx));

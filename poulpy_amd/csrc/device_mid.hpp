@@ -44,6 +44,14 @@ struct MidArgs {
     //   res[c] = sum_t a[ds_in[t]] * P[ds_row[t]][c + ds_coff[t]]   for c < ds_cb[t]
     int ds_n;
     unsigned char ds_in[32], ds_row[32], ds_coff[32], ds_cb[32];
+    // k_mid128<.., BR = true> (CGGI block step, poulpy-bin-fhe blind_rotation/algorithms/cggi/algorithm.rs:319-337): P holds the br_blk
+    // GGSWs of one LWE block as br_blk * br_rm key rows; term t = (i, r) multiplies input slot r by key row t and by the monomial factor
+    //   DFT(X^a_i - 1)[q] = w2n[a_i (4q + 1) mod 2n] - 1,   a_i = br_lwe[b * br_lwe_bs + 1 + br_i0 + i]
+    // of its ciphertext (what the reference does with svp_apply_dft_to_dft on x_pow_a[a_i] and two vec_znx_dft additions, :331-335)
+    const long long* br_lwe;
+    long long br_lwe_bs;
+    int br_i0, br_blk, br_rm;
+    const cplx* w2n;
     int dbg;   // timing ablation of k_mid128 (POULPY_DBG_MID_SKIP; results invalid): 1 no product FMAs, 2 no key loads, 4 no T' loads,
                // 8 no T2' stores, 16 no row DFTs
 };
@@ -284,7 +292,7 @@ k_mid(MidArgs g) {
 // NP = polynomial slots per ciphertext: 16; 8 for shapes with <= 8 polynomials in and out such as rank 1 with 4 limbs (twice the
 // ciphertexts per tile and per key fetch); 32 for rank 2-3 or 16 limbs (two ciphertexts per tile).  The 4 thread groups of the product phase split into GC column groups x GT
 // ciphertext groups so that a thread always owns 16 accumulators (4 ciphertexts x 4 outputs, or 2 x 8).
-template <int CT, int NP = 16, bool PERM = false, bool DS = false>
+template <int CT, int NP = 16, bool PERM = false, bool DS = false, bool BR = false>
 __global__ void __launch_bounds__(CT * NP * 8)
 k_mid128(MidArgs g) {
     constexpr int M2 = 128;
@@ -304,6 +312,7 @@ k_mid128(MidArgs g) {
     cplx* rowbuf = lds + row * RS;
     cplx* wl = lds + CT * NP * RS;
     cplx* twrow = wl + M2;
+    unsigned* abuf = reinterpret_cast<unsigned*>(twrow + M2);   // BR: a_i mod 2n of the tile's ciphertexts, [ct][16]
 
     const bool xcd_map = (g.m1 & 7) == 0 && (gridDim.x & 7) == 0;
     const int xcd = xcd_map ? (blockIdx.x & 7) : 0;
@@ -364,8 +373,22 @@ k_mid128(MidArgs g) {
     }
     if (tid < M2) twrow[tid] = twn;
     const int vq2 = tid & (M2 - 1), vcg = (tid / M2) % GC, vtg = (tid / M2) / GC;
-    const int nrow = DS ? g.ds_n : g.row_max;          // product terms per output
-    const int rot = nrow > 0 ? (w % nrow) : 0;
+    const int nrow = DS ? g.ds_n : g.row_max;          // product terms per output (BR: br_blk * br_rm, in order)
+    const int rot = (!BR && nrow > 0) ? (w % nrow) : 0;
+    const unsigned w2n_mask = 4u * (unsigned)(g.m1 * M2) - 1u;   // 2n - 1
+    // BR: the tile's exponents to LDS (read by the product phase after the forward pass's barrier)
+#define PZ_MID_ABUF(LT)                                                                              \
+    if constexpr (BR) {                                                                                \
+        if (tid < CT * 16) {                                                                           \
+            const int ct_ = tid >> 4, i_ = tid & 15;                                                   \
+            const int Lc_ = min((LT), ntiles - 1);                                                     \
+            const int b_ = (Lc_ % g.n_ct) * CT + ct_;                                                  \
+            unsigned a_ = 0u;                                                                          \
+            if (b_ < g.batch && i_ < g.br_blk)                                                         \
+                a_ = (unsigned)((unsigned long long)g.br_lwe[(long long)b_ * g.br_lwe_bs + 1 + g.br_i0 + i_] & (unsigned long long)w2n_mask); \
+            abuf[tid] = a_;                                                                            \
+        }                                                                                              \
+    }
     cplx pn[NC];
 #define PZ_MID_P0(LT)                                                                                  \
     {                                                                                                  \
@@ -375,6 +398,7 @@ k_mid128(MidArgs g) {
             pn[j] = g.P[(base_ + (long long)(DS ? (int)g.ds_row[rot] : rot) * g.ncols + c_) * M2 + vq2]; } } \
     }
     PZ_MID_P0(w)
+    PZ_MID_ABUF(w)
     PZ_MID_FWD(in_active(w))
 
     for (int L = w; L < ntiles; L += W) {
@@ -382,6 +406,21 @@ k_mid128(MidArgs g) {
         const int b = (L % g.n_ct) * CT + ctl;
         {
             const int q2 = vq2, cg = vcg;
+            // BR: monomial factors of the current (f) and the next (fn, raw table values) block coefficient for this thread's ciphertexts
+            const unsigned tq = 4u * ((unsigned)q1 + ((unsigned)q2 << g.log_m1)) + 1u;
+            cplx f[BR ? CTt : 1], fn[BR ? CTt : 1];
+            int br_slot = 0, br_i = 0;
+#define PZ_MID_LOADF(DST, II)                                                                   \
+    {                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < CTt; ++i)                                         \
+            DST[i] = g.w2n[(abuf[(vtg * CTt + i) * 16 + min((II), 15)] * tq) & w2n_mask];       \
+    }
+            if constexpr (BR) {
+                PZ_MID_LOADF(f, 0)
+                PZ_MID_LOADF(fn, 1)
+#pragma unroll
+                for (int i = 0; i < CTt; ++i) f[i].x -= 1.0;
+            }
             cplx acc[CTt][NC];
 #pragma unroll
             for (int i = 0; i < CTt; ++i)
@@ -420,8 +459,10 @@ k_mid128(MidArgs g) {
                 if (cg * NC + j >= cbv_) SRC[j] = make_double2(0.0, 0.0);                       \
             r_ = (int)g.ds_in[r_];                                                              \
         }                                                                                       \
+        if constexpr (BR) r_ = br_slot;                                                         \
         if (!(g.dbg & 1)) _Pragma("unroll") for (int i = 0; i < CTt; ++i) {                      \
-            const cplx av = lds[((vtg * CTt + i) * NP + r_) * RS + q2];                                       \
+            cplx av = lds[((vtg * CTt + i) * NP + r_) * RS + q2];                               \
+            if constexpr (BR) av = cmul(av, f[i]);                                              \
             _Pragma("unroll") for (int j = 0; j < NC; ++j) {                                    \
                 acc[i][j].x = __builtin_fma(av.x, SRC[j].x, acc[i][j].x);                       \
                 acc[i][j].x = __builtin_fma(-av.y, SRC[j].y, acc[i][j].x);                      \
@@ -429,8 +470,17 @@ k_mid128(MidArgs g) {
                 acc[i][j].y = __builtin_fma(av.y, SRC[j].x, acc[i][j].y);                       \
             }                                                                                   \
         }                                                                                       \
+        if constexpr (BR) {                                                                     \
+            if (++br_slot == g.br_rm) {        /* next block coefficient: fn becomes f, the one after starts travelling */ \
+                br_slot = 0;                                                                    \
+                ++br_i;                                                                         \
+                _Pragma("unroll") for (int i = 0; i < CTt; ++i) f[i] = make_double2(fn[i].x - 1.0, fn[i].y); \
+                PZ_MID_LOADF(fn, br_i + 1)                                                      \
+            }                                                                                   \
+        }                                                                                       \
     }
             int it = 0;
+            // (BR: deeper key prefetch — rings of three / four row slots — spills at the 256-VGPR cap and measured slower: 30.1 vs 26.8 ms)
             for (; it + 1 < nrow; it += 2) {
                 PZ_LOADROW(pb, it + 1)
                 PZ_USEROW(pn, it)
@@ -440,6 +490,7 @@ k_mid128(MidArgs g) {
             if (it < nrow) PZ_USEROW(pn, it)
 #undef PZ_LOADROW
 #undef PZ_USEROW
+#undef PZ_MID_LOADF
             lds_barrier();
 #pragma unroll
             for (int i = 0; i < CTt; ++i)
@@ -481,18 +532,23 @@ k_mid128(MidArgs g) {
             for (int k1 = 0; k1 < 16; ++k1) u[k1] = rowbuf[k1 * 9 + o];
             if (!(g.dbg & 16)) Bfly<16, true>::run(u);
             const bool active = b < g.batch && rr < g.npo;
+            // rows without an output polynomial store to a scratch row of their OWN workgroup (one 2 KiB row per tile row): with a
+            // shared scratch every workgroup of the chip wrote the same lines, which cost more than the real stores (measured on the
+            // blind-rotation block step, 6 of 8 slots active: middle kernel 37.8 -> 28 ms per 82 blocks)
             cplx* dst = active ? g.T2 + ((long long)b * g.npo + rr) * m + (long long)out_q1(q1) * M2 + o
-                               : g.dummy + (long long)tid * 16 * 16 + o;
+                               : g.dummy + ((long long)blockIdx.x * (NT / 8) + row) * M2 + o;
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) if (!(g.dbg & 8) || u[n1].x == 1.2345e300) st_stream(dst + 8 * n1, cmulc(u[n1], twrow[o + 8 * n1]));
         }
         lds_barrier();
         if (tid < M2) twrow[tid] = twn;
         PZ_MID_P0(L + W)
+        PZ_MID_ABUF(L + W)
         PZ_MID_FWD(in_active(L + W))
     }
 #undef PZ_MID_FWD
 #undef PZ_MID_P0
+#undef PZ_MID_ABUF
 }
 
 // (Round 2 experiment, removed: "k_midr<LPR = 4>" — the same kernel for rows of 64 points owned by 4 lanes (m = 512 x 64): a tile of four

@@ -3,7 +3,6 @@
 //   launch_fft.hip   the four passes of the two-pass negacyclic FFT (device_fft.hpp)
 //   launch_tail.hip  fused inverse column pass + carry chain (k_inv_tail)
 //   launch_mid.hip   fused row pass + VMP + inverse row pass (device_mid.hpp), key re-slicing
-//   launch_small.hip whole-polynomial-in-LDS pipeline for N <= 2^13 (device_small.hpp)
 //   launch_ops.hip   elementwise / permutation / normalize / VMP kernels (device_ops.hpp)
 //   launch_br.hip    blind-rotation kernels (device_br.hpp + the block step of device_ops.hpp)
 //   launch_cnv.hip   bivariate convolution kernels (device_cnv.hpp)
@@ -50,7 +49,9 @@ int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncol
                     long long body_bs = 0, long long body_ls = 0, bool small_neg = false);
 
 // ---- launch_mid.hip -----------------------------------------------------------------------------------------------
-constexpr size_t kMidDummyBytes = (size_t)512 * 256 * sizeof(cplx) + (1 << 20);  // scratch rows behind T2 (+ diagnostic stamps)
+// scratch rows behind T2: one 64-row x 128-point tile per persistent workgroup of k_mid128 (<= 256 of them: 32 MiB), which also covers
+// the 512 x 256 points k_mid<CT> shares
+constexpr size_t kMidDummyBytes = (size_t)256 * 64 * 128 * sizeof(cplx) + (1 << 20);
 bool mid_supported(const pz_module* M, int npi, int npo);
 int launch_permute_pmat(pz_module* M, const double* P, cplx* Pp, int npolys);
 // perm_mul != 0: spectrum permutation of X -> X^p folded into the middle kernel (m2 = 128 plans only; see MidArgs)
@@ -60,8 +61,15 @@ struct MidDigits {
     int n = 0;
     unsigned char in[32], row[32], coff[32], cb[32];
 };
+// CGGI block step (m2 = 128 plans): Pp = the row-sliced copy of the blk GGSWs of one LWE block (blk * nrows key rows per frequency
+// row), nrows = npi; the products are weighted by the monomial factors DFT(X^a_i - 1) of each ciphertext (MidArgs, BR)
+struct MidBr {
+    const long long* lwe;   // [batch][lwe_bs] mod-switched LWEs
+    long long lwe_bs;
+    int i0, blk;            // first coefficient of the block, block size (<= 16)
+};
 int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp, int npi, int npo, int nrows, int ncols, cplx* dummy,
-               unsigned perm_mul = 0, unsigned perm_add = 0, const MidDigits* dg = nullptr);
+               unsigned perm_mul = 0, unsigned perm_add = 0, const MidDigits* dg = nullptr, const MidBr* br = nullptr);
 
 // ---- launch_ops.hip -----------------------------------------------------------------------------------------------
 int launch_ew(pz_module* M, int op, void* res, long long res_bs, long long res_ls, const void* a, long long a_bs,

@@ -39,8 +39,14 @@ static int launch_mid_ct(pz_module* M, MidArgs g, int batch) {
 }
 // perm_mul != 0: spectrum permutation of X -> X^p folded into the middle kernel (m2 = 128 plans only; see MidArgs)
 int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp, int npi, int npo, int nrows, int ncols, cplx* dummy,
-               unsigned perm_mul, unsigned perm_add, const MidDigits* dg) {
+               unsigned perm_mul, unsigned perm_add, const MidDigits* dg, const MidBr* br) {
     MidArgs g;
+    g.br_lwe = nullptr; g.br_lwe_bs = 0; g.br_i0 = 0; g.br_blk = 0; g.br_rm = 0; g.w2n = M->w2n;
+    if (br) {
+        // nrows = the key rows of ONE GGSW (= npi here); Pp holds br->blk of them per frequency row
+        g.br_lwe = br->lwe; g.br_lwe_bs = br->lwe_bs; g.br_i0 = br->i0; g.br_blk = br->blk; g.br_rm = nrows;
+        nrows *= br->blk;
+    }
     g.ds_n = 0;
     const bool ds = dg != nullptr && dg->n > 0;
     if (ds) {
@@ -53,7 +59,7 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
     while ((1 << g.log_m1) < M->plan.m1) ++g.log_m1;
     const bool perm = perm_mul != 0;
     g.T = T; g.T2 = T2; g.P = Pp; g.npi = npi; g.npo = npo; g.nrows = nrows; g.ncols = ncols;
-    g.row_max = std::min(nrows, npi);
+    g.row_max = br ? nrows : std::min(nrows, npi);
     g.ncomp = std::min(npo, ncols);
     g.batch = batch; g.m1 = M->plan.m1; g.n_ct = 0;
     g.wL2 = M->wL2; g.tw12t = M->tw12t; g.dummy = dummy;
@@ -73,9 +79,12 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
 #define PZ_MID128_LAUNCH(CT_, NP_)                                                                                         \
     {                                                                                                                      \
         g.n_ct = (batch + CT_ - 1) / CT_;                                                                                  \
-        const size_t lds = ((size_t)CT_ * NP_ * 16 * 9 + 256) * sizeof(cplx);                                              \
-        const dim3 grid_(std::min(ncu, g.m1 * g.n_ct));                                                                    \
-        if (ds) {                                                                                                          \
+        const size_t lds = ((size_t)CT_ * NP_ * 16 * 9 + 256 + 32) * sizeof(cplx);                                         \
+        const dim3 grid_(std::min({ncu, 256, g.m1 * g.n_ct}));   /* <= 256: one scratch tile per workgroup (kMidDummyBytes) */ \
+        if (br) {                                                                                                          \
+            PZ_TRY(set_lds((k_mid128<CT_, NP_, false, false, true>), lds));                                                \
+            hipLaunchKernelGGL((k_mid128<CT_, NP_, false, false, true>), grid_, dim3(512), lds, M->stream, g);             \
+        } else if (ds) {                                                                                                          \
             PZ_TRY(set_lds((k_mid128<CT_, NP_, false, true>), lds));                                                       \
             hipLaunchKernelGGL((k_mid128<CT_, NP_, false, true>), grid_, dim3(512), lds, M->stream, g);                    \
         } else if (perm) {                                                                                                 \

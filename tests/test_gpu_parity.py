@@ -689,6 +689,25 @@ def test_config4_shape_blind_rotation(mods, n, block_size):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n,rank,n_lwe,blk,dnum,bsz,rsz,k,batch", [
+    (4096, 1, 9, 3, 2, 2, 2, 14, 11),      # 4 polynomials in / out: eight ciphertexts per tile, ragged last tile
+    (4096, 1, 15, 7, 3, 3, 3, 13, 9),      # circuit-bootstrapping key layout, two blocks + a trailing partial block
+    (8192, 2, 4, 2, 2, 3, 2, 13, 5),       # 6 in, 9 out: four ciphertexts x 16 slots; key limbs > result limbs
+    (4096, 3, 6, 3, 3, 3, 3, 12, 3),       # rank 3: 12 x 12
+    (4096, 3, 4, 2, 3, 5, 3, 12, 2),       # 20 output polynomials: two ciphertexts x 32 slots
+    (32768, 1, 4, 4, 2, 2, 3, 12, 2),      # 128 x 128 plan, result limbs beyond the key precision
+    (4096, 1, 6, 3, 3, 2, 2, 14, 4),       # dnum > res_size: not covered by the block step on the pipeline (composed path)
+])
+def test_blind_rotation_block_step_on_the_glwe_pipeline(mods, n, rank, n_lwe, blk, dnum, bsz, rsz, k, batch):
+    """execute_block_binary (algorithm.rs:265-368) for ring degrees whose plan has 128-point rows: every LWE block is one pass of the
+    three-kernel pipeline (k_mid128<.., BR>); against the oracle, and against the composed path bit for bit."""
+    ref, hip = mods(n)
+    got, want = _run_blind_rotation(hip, ref, n, rank, n_lwe, blk, dnum, bsz, rsz, k, batch=batch, seed=n + rank + blk + dnum)
+    assert np.array_equal(got, want), (n, rank, n_lwe, blk, dnum, bsz, rsz, k, batch)
+    got2, _ = _run_blind_rotation(hip, ref, n, rank, n_lwe, blk, dnum, bsz, rsz, k, batch=batch, seed=n + rank + blk + dnum, fuse=(False, False))
+    assert np.array_equal(got2, want)
+
+
 # ------------------------------------------------------------------------------------------
 # seeded shape sweep over the batched entry points (every plan family, fused and five-kernel paths)
 # ------------------------------------------------------------------------------------------
