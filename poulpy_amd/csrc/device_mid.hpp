@@ -266,7 +266,7 @@ k_mid(MidArgs g) {
             Bfly<16, true>::run(u);
             const bool active = b < g.batch && rr < g.npo;
             cplx* dst = active ? g.T2 + ((long long)b * g.npo + rr) * m + (long long)q1 * M2 + o
-                               : g.dummy + (long long)tid * 16 * 16 + o;
+                               : g.dummy + ((long long)blockIdx.x * (CT * 16) + row) * M2 + o;   // this workgroup's own scratch rows (see k_mid128)
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) dst[16 * n1] = cmulc(u[n1], twrow[o + 16 * n1]);
         }
