@@ -521,6 +521,9 @@ int pz_module_set_chunk(pz_module* m, size_t cts_per_chunk);
 /* Kernel-fusion knobs of the batched GLWE ops (both on by default; the unfused path is the per-op one,
  * kept selectable so that tests can compare the two bit for bit). */
 int pz_module_set_fusion(pz_module* m, int fuse_tail, int fuse_mid);
+/* N = 4096 only: plain external products / key switches with <= 4 key limbs run a two-kernel pipeline (whole polynomials in LDS,
+ * the spectra cross HBM once) instead of the three-kernel one; on by default, selectable so that tests can compare the two. */
+int pz_module_set_small_path(pz_module* m, int enable);
 /* The launch-bound composite calls (pz_blind_rotation_execute_batched, pz_glwe_trace_batched,
  * pz_circuit_bootstrapping_execute_to_constant_batched: hundreds of short kernels per call) are captured into a HIP graph
  * the second time they are issued with the same arguments and replayed as one graph launch afterwards (on by default;

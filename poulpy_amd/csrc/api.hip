@@ -32,7 +32,7 @@ struct KeyHash {
     template <typename T> void add(const T& v) { bytes(&v, sizeof(T)); }
 };
 static void graph_key_module(const pz_module* M, KeyHash& k) {
-    k.add(M->ws); k.add(M->ws2); k.add(M->ws_bytes); k.add(M->ws2_bytes); k.add(M->fuse_mid); k.add(M->fuse_tail); k.add(M->chunk);
+    k.add(M->ws); k.add(M->ws2); k.add(M->ws_bytes); k.add(M->ws2_bytes); k.add(M->fuse_mid); k.add(M->fuse_tail); k.add(M->small_path); k.add(M->chunk);
     k.add(M->dbg_stages); k.add(M->probe); k.add(M->graph_epoch); k.add(M->w2n);
 }
 static void graph_drop(pz_module::GraphEntry& e) {
@@ -300,6 +300,13 @@ int pz_module_set_chunk(pz_module* M, size_t c) {
     std::lock_guard<std::mutex> lock_(M->mu);
     M->graph_epoch++;
     M->chunk = c;
+    return PZ_OK;
+}
+int pz_module_set_small_path(pz_module* M, int enable) {
+    if (!M) return fail(PZ_ERR_INVALID, "null module");
+    std::lock_guard<std::mutex> lock_(M->mu);
+    M->small_path = enable != 0;
+    M->graph_epoch++;
     return PZ_OK;
 }
 int pz_module_set_fusion(pz_module* M, int fuse_tail, int fuse_mid) {
@@ -1399,6 +1406,16 @@ static int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const 
             const int a_size = av.size;
             const int a_col0 = s.a_col0;
             PolyMap sm{a_size, s.cols_in, av.bs, (long long)av.cols * n, n, n * a_col0};
+            // N = 4096, plain external product / key switch with <= 4 key limbs: two kernels, the spectra cross HBM once (device_small.hpp)
+            static const int small_env = getenv("POULPY_DBG_SMALL") ? atoi(getenv("POULPY_DBG_SMALL")) : 1;
+            if (small_env && M->small_path && !au && !tensor && !digits && !cross_out && !M->probe && M->dbg_stages == 7 &&
+                small_supported(M, npi, ksz)) {
+                PZ_TRY(launch_small_fwd(M, nb * npi, (const long long*)av.p, sm, T));
+                PZ_TRY(launch_small_inv(M, nb, T, Pp, npi, nrows, ncols, s.cols_out, ksz, (long long*)(res + (long long)b0 * res_bs), res_bs,
+                                        s.cols_out, (int)p->res_size, ks ? (const long long*)av.p : nullptr, av.bs, s.cols_a, a_size,
+                                        (int)p->res_base2k, body_col));
+                continue;
+            }
             if (M->dbg_stages & 1) PZ_TRY(launch_fwd_pass1(M, nb * npi, (const long long*)av.p, sm, T, true));
             // X -> X^p with p = 1 mod 4 on the big value (the add / sub / sub_negate forms): DFT(phi(a))[q] = DFT(a)[p q + (p-1)/4 mod m]
             // is an affine map of the spectrum index that sends rows of the four-step layout to rows, so the middle kernel writes

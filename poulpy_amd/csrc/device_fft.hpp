@@ -57,6 +57,19 @@ __device__ __forceinline__ void st_stream(long long* p, long long v) {
     else *p = v;
 }
 
+// LDS traffic between the 16 lanes that own one row needs no workgroup barrier: the lanes are in one wave,
+// whose LDS instructions execute in order; this only stops the compiler from moving them across.
+__device__ __forceinline__ void row_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Workgroup barrier that only orders LDS traffic (s_waitcnt lgkmcnt(0); s_barrier).  __syncthreads() also
+// drains vmcnt, which would make every barrier wait for the tile's global stores and for the prefetched
+// loads; threads of this kernel never exchange data through global memory, so LDS ordering is sufficient.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- in-register radix-R DFT, R in {1,2,4,8,16}; natural-order output --------
 // X[k] = sum_n v[n] * w^(+nk) (INV=false) or w^(-nk) (INV=true), w = exp(2*pi*i/R).
 #define PZ_C8 0.70710678118654752440084436210485   /* cos(pi/4) */

@@ -56,19 +56,6 @@ struct MidArgs {
                // 8 no T2' stores, 16 no row DFTs
 };
 
-// LDS traffic between the 16 lanes that own one row needs no workgroup barrier: the lanes are in one wave,
-// whose LDS instructions execute in order; this only stops the compiler from moving them across.
-__device__ __forceinline__ void row_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// Workgroup barrier that only orders LDS traffic (s_waitcnt lgkmcnt(0); s_barrier).  __syncthreads() also
-// drains vmcnt, which would make every barrier wait for the tile's global stores and for the prefetched
-// loads; threads of this kernel never exchange data through global memory, so LDS ordering is sufficient.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // Persistent: gridDim.x = 8*W workgroups (one per CU); workgroup (xcd = bid & 7, w = bid >> 3) walks the tiles
 // (q1 = 8*k + xcd, ciphertext tile) of "its" XCD with stride W, so the W workgroups of an XCD sweep the
 // ciphertext tiles of one frequency row together and share its key slice through that XCD's L2.  The loads

@@ -3,6 +3,7 @@
 //   launch_fft.hip   the four passes of the two-pass negacyclic FFT (device_fft.hpp)
 //   launch_tail.hip  fused inverse column pass + carry chain (k_inv_tail)
 //   launch_mid.hip   fused row pass + VMP + inverse row pass (device_mid.hpp), key re-slicing
+//   launch_small.hip two-kernel pipeline for N = 4096: whole polynomials in LDS (device_small.hpp)
 //   launch_ops.hip   elementwise / permutation / normalize / VMP kernels (device_ops.hpp)
 //   launch_br.hip    blind-rotation kernels (device_br.hpp + the block step of device_ops.hpp)
 //   launch_cnv.hip   bivariate convolution kernels (device_cnv.hpp)
@@ -70,6 +71,15 @@ struct MidBr {
 };
 int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp, int npi, int npo, int nrows, int ncols, cplx* dummy,
                unsigned perm_mul = 0, unsigned perm_add = 0, const MidDigits* dg = nullptr, const MidBr* br = nullptr);
+
+// ---- launch_small.hip ---------------------------------------------------------------------------------------------
+// two-kernel pipeline for N = 4096 (device_small.hpp): full forward transform -> S[poly][q1][q2]; product with the row-sliced key +
+// full inverse transform + carry chain per (ciphertext, output column).  dsize 1, one base2k, <= 4 key limbs.
+bool small_supported(const pz_module* M, int npi, int key_limbs);
+int launch_small_fwd(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* S);
+int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int npi, int nrows, int ncols, int cols_out, int ksz,
+                     long long* res, long long res_bs, int res_cols, int res_size, const long long* small, long long small_bs,
+                     int small_cols, int small_size, int base2k, int body_col);
 
 // ---- launch_ops.hip -----------------------------------------------------------------------------------------------
 int launch_ew(pz_module* M, int op, void* res, long long res_bs, long long res_ls, const void* a, long long a_bs,

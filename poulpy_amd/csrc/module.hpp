@@ -147,6 +147,7 @@ struct pz_module {
     void* comm = nullptr;
     int comm_world = 0, comm_rank = 0;
     bool fuse_tail = true, fuse_mid = true;  // kernel-fusion knobs of the batched GLWE ops (tests run both settings)
+    bool small_path = true;                  // N = 4096: the two-kernel pipeline of device_small.hpp where it applies
     // per-kernel-class HIP-event timing (bench.py's roofline leg); off by default
     bool timing = false;
     struct Timed { int cls; hipEvent_t e0, e1; };

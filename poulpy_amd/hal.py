@@ -179,6 +179,10 @@ class Module:
     def set_fusion(self, fuse_tail: bool = True, fuse_mid: bool = True):
         self._ck(self.lib.pz_module_set_fusion(self.handle, c_int(int(fuse_tail)), c_int(int(fuse_mid))))
 
+    def set_small_path(self, enable: bool = True):
+        """N = 4096: the two-kernel pipeline (device_small.hpp) on / off (on by default)."""
+        self._ck(self.lib.pz_module_set_small_path(self.handle, c_int(1 if enable else 0)))
+
     def set_margin_probe(self, enable: bool):
         self._ck(self.lib.pz_module_set_margin_probe(self.handle, c_int(1 if enable else 0)))
 

@@ -708,6 +708,35 @@ def test_blind_rotation_block_step_on_the_glwe_pipeline(mods, n, rank, n_lwe, bl
     assert np.array_equal(got2, want)
 
 
+@pytest.mark.parametrize("ks,rank,rank_out,a_size,key_size,dnum,res_size,batch,in_place", [
+    (False, 1, 1, 4, 4, 4, 4, 19, False),     # BASELINE configs[1] shape, ragged batch (19 = 2 x 8 + 3: partly filled XCD slots)
+    (False, 1, 1, 4, 4, 4, 4, 8, True),       # in place
+    (True, 1, 1, 4, 4, 4, 4, 5, False),       # key switch: body added before the carry chain
+    (True, 1, 1, 3, 3, 3, 3, 9, True),        # odd number of limbs (a pair with one polynomial), in place
+    (False, 1, 1, 2, 4, 2, 2, 3, False),      # key limbs below the result: carry-only first steps
+    (False, 1, 1, 3, 2, 3, 4, 4, False),      # result limbs beyond the key precision: zero limbs
+    (False, 2, 2, 2, 3, 2, 3, 5, False),      # rank 2: three output columns per ciphertext
+    (True, 2, 1, 4, 4, 4, 2, 6, False),       # rank 2 -> 1 key switch
+    (True, 1, 3, 1, 1, 1, 1, 10, False),      # single limb everywhere, four output columns
+])
+def test_small_ring_two_kernel_pipeline(mods, ks, rank, rank_out, a_size, key_size, dnum, res_size, batch, in_place):
+    """N = 4096: k_small_fwd + k_small_inv (whole polynomials in LDS, the spectra cross HBM once) against the oracle, and the three-kernel
+    pipeline on the same inputs bit for bit."""
+    n, k = 4096, 17
+    ref, hip = mods(n)
+    hip.set_small_path(True)
+    got, want = _run_glwe_op(hip, ref, ks, n, rank, rank_out, a_size, k, key_size, k, dnum, 1, res_size, k, batch, seed=900 + a_size + key_size + batch,
+                             in_place=in_place)
+    assert np.array_equal(got, want)
+    hip.set_small_path(False)
+    try:
+        got3, _ = _run_glwe_op(hip, ref, ks, n, rank, rank_out, a_size, k, key_size, k, dnum, 1, res_size, k, batch, seed=900 + a_size + key_size + batch,
+                               in_place=in_place)
+    finally:
+        hip.set_small_path(True)
+    assert np.array_equal(got3, want)
+
+
 # ------------------------------------------------------------------------------------------
 # seeded shape sweep over the batched entry points (every plan family, fused and five-kernel paths)
 # ------------------------------------------------------------------------------------------
