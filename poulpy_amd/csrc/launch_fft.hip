@@ -21,18 +21,23 @@ int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap sma
     //  a pure copy from 5.3 to 6.0 TB/s, profiles/r02_hbm_pass_pattern.txt — were measured SLOWER, 3.55 vs 3.32 ms per 1024 ciphertexts:
     //  the 147 KiB exchange buffer leaves one 512-thread workgroup per CU, whose load / exchange / store phases no longer overlap with
     //  a second workgroup's.  The kernel sits at the ceiling of its 16-column access shape: 5.3 TB/s.)
-    const int blocks = npolys * (pl.m2 / pl.cb);
+    const int ncb = pl.m2 / pl.cb;
+    const int blocks = npolys * ncb;
+    // row-major (pipeline) launches use the XCD-aware block order of k_fwd_pass1: grid padded to whole groups of 8 polynomials
+    static const int xcd_order = getenv("POULPY_DBG_XCD_ORDER") ? atoi(getenv("POULPY_DBG_XCD_ORDER")) : 1;
+    const int npx = (rowmajor && xcd_order) ? npolys : 0;
+    const int blocks_rm = npx ? ((npolys + 7) / 8) * 8 * ncb : blocks;
 #define X(A, B, C)                                                                                              \
     if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
         const size_t lds = ((size_t)(A + 1) * C * B + 2 * A * B) * sizeof(cplx);                                              \
         if (rowmajor) {                                                                                         \
             PZ_TRY(set_lds(k_fwd_pass1<A, B, C, true>, lds));                                                   \
-            hipLaunchKernelGGL((k_fwd_pass1<A, B, C, true>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, src, smap, \
-                               T, pl.m2, M->tw1, M->wL1, M->tw12t, mask);                                             \
+            hipLaunchKernelGGL((k_fwd_pass1<A, B, C, true>), dim3(blocks_rm), dim3((A > B ? A : B) * C), lds, M->stream, src, smap, \
+                               T, pl.m2, M->tw1, M->wL1, M->tw12t, mask, npx);                                        \
         } else {                                                                                                \
             PZ_TRY(set_lds(k_fwd_pass1<A, B, C>, lds));                                                         \
             hipLaunchKernelGGL((k_fwd_pass1<A, B, C>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, src, smap, T, \
-                               pl.m2, M->tw1, M->wL1, M->tw12, mask);                                                 \
+                               pl.m2, M->tw1, M->wL1, M->tw12, mask, 0);                                              \
         }                                                                                                       \
         PZ_HIP(hipGetLastError());                                                                              \
         return PZ_OK;                                                                                           \

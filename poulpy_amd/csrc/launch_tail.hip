@@ -19,7 +19,7 @@ static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlim
                                 unsigned gather_mul = 0, bool gather_neg = false, int body_col = 0, const long long* body_src = nullptr,
                                 long long body_bs = 0, long long body_ls = 0, bool small_neg = false) {
     const FftPlan& pl = M->plan;
-    const int blocks = batch * col_count * (pl.m2 / pl.cb);
+    int blocks = batch * col_count * (pl.m2 / pl.cb);
     if (blocks == 0) return PZ_OK;
     KTimer kt(M, PZ_K_FUSED_TAIL);
     TailArgs g;
@@ -31,7 +31,16 @@ static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlim
     g.col_base = col_base; g.col_count = col_count; g.body_col = body_col;
     g.gather_mul = gather_mul; g.gather_neg = gather_neg ? 1 : 0;
     g.pre_body = body_src != nullptr ? 1 : 0; g.small_neg = small_neg ? 1 : 0; g.body_src = body_src; g.body_bs = body_bs; g.body_ls = body_ls;
-    g.xcd_map = (gather_mul != 0 && blocks % (8 * (pl.m2 / pl.cb)) == 0) ? 1 : 0;
+    // XCD-aware block order (all column blocks of one (ciphertext, column) on one XCD, back to back): the gathers of the automorphism
+    // forms need it for L2 locality, and the row-major pipeline streams faster with it (see k_fwd_pass1); the grid is padded to whole
+    // groups of 8 (ciphertext, column) pairs
+    static const int xcd_order = getenv("POULPY_DBG_XCD_ORDER") ? atoi(getenv("POULPY_DBG_XCD_ORDER")) : 1;
+    g.xcd_map = 0;
+    if (gather_mul != 0 || (rowmajor && xcd_order)) {
+        const int nbc = batch * col_count, ncb = pl.m2 / pl.cb;
+        g.xcd_map = nbc;
+        blocks = ((nbc + 7) / 8) * 8 * ncb;
+    }
     const bool has_small = small != nullptr;
 // one instantiation per (probe, row-major, body add) combination actually requested
 #define PZ_TAIL_ONE(A, B, C, P_, R_, S_)                                                                        \

@@ -25,6 +25,28 @@ __global__ void __launch_bounds__(256) k_pass1_shape(const long long* __restrict
         if (NT) __builtin_nontemporal_store(v, dst + idx); else dst[idx] = v;
     }
 }
+// variant: XCD-aware block order — the 8 column blocks of one polynomial run back to back on ONE XCD (workgroup ids go round-robin
+// over the 8 XCDs), so that the eight 128 B pieces of every 1 KiB row are requested through one L2 close in time
+template <int CB, bool NT>
+__global__ void __launch_bounds__(256) k_pass1_xcd(const long long* __restrict__ a, v2* __restrict__ t, int npolys) {
+    constexpr int M1 = 256, M2 = 128;
+    const int ncb = M2 / CB;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int p = (slot / ncb) * 8 + xcd, c0 = (slot % ncb) * CB;
+    if (p >= npolys) return;
+    const long long* src = a + (long long)p * 2 * M1 * M2;
+    v2* dst = t + (long long)p * M1 * M2;
+    const int c = threadIdx.x % CB, r0 = threadIdx.x / CB;
+    constexpr int RPI = 256 / CB;
+#pragma unroll 4
+    for (int r = r0; r < M1; r += RPI) {
+        const long long idx = (long long)r * M2 + c0 + c;
+        const long long re = NT ? __builtin_nontemporal_load(src + idx) : src[idx];
+        const long long im = NT ? __builtin_nontemporal_load(src + idx + M1 * M2) : src[idx + M1 * M2];
+        v2 v = {(double)re, (double)im};
+        if (NT) __builtin_nontemporal_store(v, dst + idx); else dst[idx] = v;
+    }
+}
 // variant: T' stored BLOCKED as [polynomial][column block][row][CB columns], so that the 256 x (CB x 16 B) pieces one workgroup
 // writes are ONE contiguous 64 KiB run (reads unchanged)
 template <int CB, bool NT>
@@ -107,6 +129,8 @@ int main() {
     time([&] { k_pass1_shape<32, true><<<npolys * 4, 256>>>(a, t, npolys); }, "CB 32, non-temporal");
     time([&] { k_pass1_shape<64, true><<<npolys * 2, 256>>>(a, t, npolys); }, "CB 64, non-temporal");
     time([&] { k_pass1_shape<128, true><<<npolys * 1, 256>>>(a, t, npolys); }, "CB 128 (whole rows), non-temporal");
+    time([&] { k_pass1_xcd<16, false><<<npolys * 8, 256>>>(a, t, npolys); }, "pass 1, CB 16, column blocks of a polynomial on one XCD");
+    time([&] { k_pass1_xcd<16, true><<<npolys * 8, 256>>>(a, t, npolys); }, "pass 1, CB 16, one XCD per polynomial, non-temporal");
     time([&] { k_pass1_blocked<16, false><<<npolys * 8, 256>>>(a, t, npolys); }, "pass 1, CB 16, T' blocked (64 KiB write runs)");
     time([&] { k_pass1_blocked<16, true><<<npolys * 8, 256>>>(a, t, npolys); }, "pass 1, CB 16, T' blocked, non-temporal");
     time([&] { k_tail_shape<16, true, false><<<npolys * 8, 256>>>(t, a, npolys); }, "tail, CB 16, row-major T2', non-temporal");
