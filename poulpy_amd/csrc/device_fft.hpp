@@ -52,8 +52,11 @@ __device__ __forceinline__ void st_stream(cplx* p, cplx v) {
     if (PZ_STREAM_HINTS & 2) { const pz_dbl2 t = {v.x, v.y}; __builtin_nontemporal_store(t, reinterpret_cast<pz_dbl2*>(p)); }
     else *p = v;
 }
+#ifndef PZ_STREAM_I64_NT
+#define PZ_STREAM_I64_NT 1   // the tail's digit stores (A/B knob)
+#endif
 __device__ __forceinline__ void st_stream(long long* p, long long v) {
-    if (PZ_STREAM_HINTS & 2) __builtin_nontemporal_store(v, p);
+    if ((PZ_STREAM_HINTS & 2) && PZ_STREAM_I64_NT) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
 

@@ -86,6 +86,26 @@ __global__ void __launch_bounds__(256) k_tail_shape(const v2* __restrict__ t, lo
         else { dst[idx] = (long long)v.x; dst[idx + M1 * M2] = (long long)v.y; }
     }
 }
+// the tail with the XCD-aware block order
+template <int CB, bool NT>
+__global__ void __launch_bounds__(256) k_tail_xcd(const v2* __restrict__ t, long long* __restrict__ a, int npolys) {
+    constexpr int M1 = 256, M2 = 128;
+    const int ncb = M2 / CB;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int p = (slot / ncb) * 8 + xcd, c0 = (slot % ncb) * CB;
+    if (p >= npolys) return;
+    long long* dst = a + (long long)p * 2 * M1 * M2;
+    const v2* src = t + (long long)p * M1 * M2;
+    const int c = threadIdx.x % CB, r0 = threadIdx.x / CB;
+    constexpr int RPI = 256 / CB;
+#pragma unroll 4
+    for (int r = r0; r < M1; r += RPI) {
+        const long long idx = (long long)r * M2 + c0 + c;
+        const v2 v = NT ? __builtin_nontemporal_load(src + idx) : src[idx];
+        if (NT) { __builtin_nontemporal_store((long long)v.x, dst + idx); __builtin_nontemporal_store((long long)v.y, dst + idx + M1 * M2); }
+        else { dst[idx] = (long long)v.x; dst[idx + M1 * M2] = (long long)v.y; }
+    }
+}
 // the middle kernel's shape: 512 threads = 64 rows x 8 lanes; a tile = 64 rows (one frequency row q1 of 64 polynomials), every lane
 // 16 x 16 B at stride 128 B: row-major rows are 2 KiB contiguous; blocked rows are 8 pieces of 256 B, 64 KiB apart.  Copy T' -> T2'.
 template <bool NT, bool BLOCKED>
@@ -135,6 +155,10 @@ int main() {
     time([&] { k_pass1_blocked<16, true><<<npolys * 8, 256>>>(a, t, npolys); }, "pass 1, CB 16, T' blocked, non-temporal");
     time([&] { k_tail_shape<16, true, false><<<npolys * 8, 256>>>(t, a, npolys); }, "tail, CB 16, row-major T2', non-temporal");
     time([&] { k_tail_shape<16, true, true><<<npolys * 8, 256>>>(t, a, npolys); }, "tail, CB 16, T2' blocked, non-temporal");
+    time([&] { k_tail_xcd<16, true><<<npolys * 8, 256>>>(t, a, npolys); }, "tail, CB 16, one XCD per polynomial, non-temporal");
+    time([&] { k_tail_xcd<16, false><<<npolys * 8, 256>>>(t, a, npolys); }, "tail, CB 16, one XCD per polynomial, plain");
+    time([&] { k_tail_xcd<32, true><<<npolys * 4, 256>>>(t, a, npolys); }, "tail, CB 32, one XCD per polynomial, non-temporal");
+    time([&] { k_tail_shape<32, true, false><<<npolys * 4, 256>>>(t, a, npolys); }, "tail, CB 32, row-major, non-temporal");
     v2* t2; hipMalloc(&t2, (size_t)npolys * 32768 * 16);
     time([&] { k_mid_shape<true, false><<<256, 512>>>(t, t2, npolys); }, "mid shape (persistent 256 WGs), row-major, nt");
     time([&] { k_mid_shape<true, true><<<256, 512>>>(t, t2, npolys); }, "mid shape, blocked, nt");
