@@ -325,11 +325,19 @@ k_mid128(MidArgs g) {
         return g.T + ((long long)b_ * g.npi + r_) * m + (long long)tile_q1(Lc) * M2 + o;
     };
     auto in_active = [&](int L) { return L < ntiles && (L % g.n_ct) * CT + ctl < g.batch && rr < g.npi; };
+    // A wave owns 8 consecutive polynomial slots of one ciphertext.  Waves whose slots all lie beyond the input (resp. output)
+    // polynomials skip the forward (resp. inverse) row pass, its loads and its stores altogether — e.g. the upper half of every
+    // ciphertext's 16 slots in a key switch (8 polynomials in): the product never reads those rows.  (Wave-uniform branches.)
+    // (only where a ciphertext has more than 8 slots, and not in the BR / DS variants, whose register allocation the extra branches push
+    //  over the 256-VGPR cap)
+    constexpr bool SKIPW = NP > 8 && !BR && !DS;
+    const bool wave_in = !SKIPW || (rr & ~7) < g.npi, wave_out = !SKIPW || (rr & ~7) < g.npo;
 
     // forward row DFT: x[n1] = row[o + 8*n1] -> radix 16 over n1 (k1) -> x W128^(o*k1) -> z[k1][o];
     // then this lane takes k1 = o and o+8: radix 8 over o -> S[row][q2 = k1 + 16*k2]
 #define PZ_MID_FWD(ACTIVE)                                                                        \
     {                                                                                             \
+      if (wave_in) {                                                                              \
         if (!(ACTIVE)) {                                                                          \
             _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1) x[n1] = make_double2(0.0, 0.0);     \
         }                                                                                         \
@@ -348,14 +356,17 @@ k_mid128(MidArgs g) {
         _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                           \
             _Pragma("unroll") for (int k2 = 0; k2 < 8; ++k2) rowbuf[o + 8 * h + 16 * k2] = x[8 * h + k2]; \
         }                                                                                         \
+      }                                                                                           \
         lds_barrier();                                                                            \
     }
 
     cplx twn = make_double2(0.0, 0.0);
     {
         const cplx* src = src_ptr(w);
+        if (wave_in) {
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) x[n1] = (g.dbg & 4) ? make_double2(1.0, (double)n1) : ld_stream(src + 8 * n1);
+            for (int n1 = 0; n1 < 16; ++n1) x[n1] = (g.dbg & 4) ? make_double2(1.0, (double)n1) : ld_stream(src + 8 * n1);
+        }
         twn = g.tw12t[(long long)out_q1(tile_q1(w)) * M2 + (tid & (M2 - 1))];
     }
     if (tid < M2) twrow[tid] = twn;
@@ -491,13 +502,15 @@ k_mid128(MidArgs g) {
         }
         {
             const cplx* src = src_ptr(L + W);
+            if (wave_in) {
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) x[n1] = (g.dbg & 4) ? make_double2(1.0, (double)n1) : ld_stream(src + 8 * n1);
+                for (int n1 = 0; n1 < 16; ++n1) x[n1] = (g.dbg & 4) ? make_double2(1.0, (double)n1) : ld_stream(src + 8 * n1);
+            }
             twn = g.tw12t[(long long)out_q1(tile_q1(min(L + W, ntiles - 1))) * M2 + (tid & (M2 - 1))];
         }
         // inverse row DFT: this lane owns k1 = o and o+8: radix 8 over k2 -> z[k1][oo] x conj W128^(oo*k1);
         // then lane o gathers z[k1][o] over k1: radix 16 -> row[o + 8*n1]
-        {
+        if (wave_out) {
             cplx u[16];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
