@@ -1634,6 +1634,17 @@ def test_glwe_automorphism_spectral_path(mods, n, rank, p, mode, in_place):
 
 
 
+@pytest.mark.parametrize("n,a_size,key_size,res_size,batch,chunk", [(4096, 8, 2, 1, 16, 0), (65536, 8, 2, 1, 5, 4), (8192, 6, 3, 1, 9, 0)])
+def test_glwe_automorphism_spectral_path_long_input(mods, n, a_size, key_size, res_size, batch, chunk):
+    """the spectral form with MORE input limbs than cols_out * res_size result limbs (the body operand of the tail has its own
+    workspace segment, min(a_size, key_size) limbs per ciphertext: round-1 advisor finding), several waves, every mode"""
+    for mode in ("add", "sub", "sub_negate"):
+        got, want = _run_glwe_op(hip=mods(n)[1], ref=mods(n)[0], ks=True, n=n, rank=1, rank_out=1, a_size=a_size, a_base2k=12, key_size=key_size,
+                                 key_base2k=12, dnum=key_size, dsize=1, res_size=res_size, res_base2k=12, batch=batch, seed=5100 + a_size,
+                                 auto=(5, mode), chunk=chunk)
+        assert np.array_equal(got, want), mode
+
+
 # ------------------------------------------------------------------------------------------
 # host containers at the GLWE-level entry points (what the Rust shim's CoreImpl overrides pass)
 # ------------------------------------------------------------------------------------------
