@@ -548,6 +548,14 @@ k_inv_tail(TailArgs g) {
     long long carry[2 * RE];
 #pragma unroll
     for (int u = 0; u < 2 * RE; ++u) carry[u] = 0;
+    // Without a body operand (external product) and digits of at most 31 bits the carry chain runs in f64 while every value is an exact
+    // integer below 2^51 (the same test that allows the 3-instruction conversion): v = r + carry, q = floor((v + 2^(k-1)) 2^-k),
+    // digit = v - q 2^k — the reference's two steps in one (digit(x + c) = digit(digit(x) + c), carry(x + c) = carry(x) +
+    // carry(digit(x) + c) while nothing overflows), five f64 operations instead of ~25 32-bit integer ones.  The carries then hold the
+    // bits of a double; the first limb that needs the saturating path converts them once and the thread stays on the integer chain.
+    constexpr bool FCARRY = !SMALL;
+    bool icarry = !FCARRY || k > 31;
+    const double halfd = (double)(1ull << (k - 1)), twok = 2.0 * halfd, invk = 1.0 / twok;
     long long* res_col = g.res + (long long)b * g.res_bs + (long long)col * n;
     const long long res_ls = (long long)g.res_cols * n;
     const long long* small_col =
@@ -670,10 +678,36 @@ k_inv_tail(TailArgs g) {
             }                                                                                                \
         }                                                                                                    \
     }
-        if (big < 2251799813685247.0) {  // 2^51 - 1 (false for NaN too)
-            PZ_TAIL_COEFFS(fast_i64_from_integral)
+        if (FCARRY && !icarry && big < 2251799813685247.0) {
+#pragma unroll
+            for (int n1 = 0; n1 < RE; ++n1) {
+                const int j1 = b_ov + R2 * PZ_TAIL_N1(n1);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const long long idx = (long long)j1 * g.m2 + c0 + b_cv + (h ? m : 0);
+                    const double val = h ? v[n1].y : v[n1].x;
+                    const double r = round_half_away(val);
+                    if (PROBE) worst = fmax(worst, fabs(val - r));
+                    const double vv = r + __longlong_as_double(carry[2 * n1 + h]);
+                    const double q = floor((vv + halfd) * invk);
+                    carry[2 * n1 + h] = __double_as_longlong(q);
+                    if (writes) {
+                        const long long x1 = (long long)(int)__builtin_fma(-q, twok, vv);
+                        if (ROWMAJOR) st_stream(res_col + (long long)j * res_ls + idx, x1); else res_col[(long long)j * res_ls + idx] = x1;
+                    }
+                }
+            }
         } else {
-            PZ_TAIL_COEFFS(sat_i64_from_integral)
+            if (FCARRY && !icarry) {   // leave the f64 chain: the carries become integers, for good
+                icarry = true;
+#pragma unroll
+                for (int u = 0; u < 2 * RE; ++u) carry[u] = fast_i64_from_integral(__longlong_as_double(carry[u]));
+            }
+            if (big < 2251799813685247.0) {  // 2^51 - 1 (false for NaN too)
+                PZ_TAIL_COEFFS(fast_i64_from_integral)
+            } else {
+                PZ_TAIL_COEFFS(sat_i64_from_integral)
+            }
         }
 #undef PZ_TAIL_COEFFS
         if (PROBE) atomicMax(g.margin, (unsigned long long)__double_as_longlong(worst));
