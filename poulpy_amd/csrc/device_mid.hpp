@@ -19,6 +19,11 @@
 
 namespace pz {
 
+#ifndef PZ_MID_RS
+#define PZ_MID_RS 144
+#endif
+constexpr int kMidRS = PZ_MID_RS;   // row stride of the k_mid128 tile (see there; build-time for A/B runs)
+
 struct MidArgs {
     const cplx* T;
     cplx* T2;
@@ -290,7 +295,11 @@ k_mid128(MidArgs g) {
     constexpr int GT = NCG / GC;       // ciphertext groups
     constexpr int CTt = CT / GT;       // ciphertexts per thread
     static_assert(GC * GT == NCG && CTt * GT == CT && NT == 512, "k_mid128 tile shape");
-    constexpr int RS = 16 * 9;         // padded row stride (points): z[k1][o] at k1*9 + o
+    // padded row stride (points): z[k1][o] at k1*9 + o needs 143.  With 144 (= 0 mod 16) the rows alias in the 16-lane groups of
+    // ds_read_b128 and three of the seven read passes of a tile are 2-way bank conflicts (SQ_LDS_BANK_CONFLICT = 16 % of the LDS cycles);
+    // 152 (= 8 mod 16, -DPZ_MID_RS=152) makes them conflict-free and was measured identical (51.2 vs 51.2 ms per 10 launches): those
+    // passes are not on the critical path.  144 it stays (16 KiB of LDS less).
+    constexpr int RS = kMidRS;
     extern __shared__ cplx lds[];      // CT*16 rows x RS | wL2[128] | tw12t row [128]
     const int tid = threadIdx.x;
     const long long m = (long long)g.m1 * M2;

@@ -79,7 +79,7 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
 #define PZ_MID128_LAUNCH(CT_, NP_)                                                                                         \
     {                                                                                                                      \
         g.n_ct = (batch + CT_ - 1) / CT_;                                                                                  \
-        const size_t lds = ((size_t)CT_ * NP_ * 16 * 9 + 256 + 32) * sizeof(cplx);                                         \
+        const size_t lds = ((size_t)CT_ * NP_ * kMidRS + 256 + 32) * sizeof(cplx);                                         \
         const dim3 grid_(std::min({ncu, 256, g.m1 * g.n_ct}));   /* <= 256: one scratch tile per workgroup (kMidDummyBytes) */ \
         if (br) {                                                                                                          \
             PZ_TRY(set_lds((k_mid128<CT_, NP_, false, false, true>), lds));                                                \
