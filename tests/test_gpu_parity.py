@@ -26,7 +26,7 @@ def mods():
     return get
 
 
-@pytest.mark.parametrize("n", [32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536])
+@pytest.mark.parametrize("n", [32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072])
 def test_dft_idft_roundtrip_and_oracle(mods, n):
     """vec_znx_dft_apply -> vec_znx_idft_apply returns the input exactly, for every plan size."""
     ref, hip = mods(n)
@@ -735,6 +735,17 @@ def test_small_ring_two_kernel_pipeline(mods, ks, rank, rank_out, a_size, key_si
     finally:
         hip.set_small_path(True)
     assert np.array_equal(got3, want)
+
+
+@pytest.mark.parametrize("ks", [False, True], ids=["external_product", "keyswitch"])
+@pytest.mark.parametrize("fuse", [(True, True), (False, False)], ids=["pipeline", "five-kernel"])
+def test_largest_ring_degree(mods, ks, fuse):
+    """N = 131072, the largest ring degree the module accepts (m = 256 x 256: the pipeline runs `k_mid<2>`, two ciphertexts per tile):
+    external product and key switch against the oracle, ragged batch."""
+    n = 131072
+    ref, hip = mods(n)
+    got, want = _run_glwe_op(hip, ref, ks, n, 1, 1, 3, 12, 3, 12, 3, 1, 3, 12, batch=3, seed=131 + ks, fuse=fuse)
+    assert np.array_equal(got, want)
 
 
 # ------------------------------------------------------------------------------------------
