@@ -101,7 +101,10 @@ struct SmallInvArgs {
 // 1024 threads (16 waves: the product phase is latency-bound with fewer), one workgroup per CU: LDS holds the KS output polynomials of one (ciphertext, column) (KS x 16 rows x 144 points + wL2,
 // 149.5 KiB at KS = 4).  Variants that kept two workgroups per CU — two limbs in LDS at a time, the other accumulators in registers, or one
 // product pass per limb pair — either spilled (128 accumulator registers at 256 threads) or re-read S from HBM (0.26 - 0.36 ms per 1024
-// ciphertexts against 0.35 ms for the whole three-kernel pipeline).  KS = key limbs (g.ksz).
+// ciphertexts against 0.35 ms for the whole three-kernel pipeline).  Also tried: a persistent workgroup in two roles of 512 threads (role A:
+// the next item's product in registers, role B: this item's transforms in the tile, hand-over between barriers) — at the 128-VGPR cap of a
+// 1024-thread workgroup role A's 64 accumulator registers leave no room for prefetch slots (spills, 0.93 ms at 4 limbs; 0.25 vs 0.17 ms
+// at 3).  KS = key limbs (g.ksz).
 template <int KS>
 __global__ void __launch_bounds__(1024) k_small_inv(SmallInvArgs g) {
     constexpr int M2 = kSmallM2, RS = kSmallRS, L = KS;
