@@ -1,0 +1,485 @@
+// api_br.hip — C ABI of the composite calls built on the batched GLWE product: CGGI blind rotation (block-binary, standard, extended),
+// circuit bootstrapping (constant / exponent mode) and GLWE packing.  poulpy-bin-fhe blind_rotation/algorithms/cggi/algorithm.rs,
+// circuit_bootstrapping/circuit.rs; poulpy-core glwe_packing.rs.  SURVEY.md §8f rank 2.
+#include "api_common.hpp"
+#include "api_glwe.hpp"
+
+using namespace pz;
+
+extern "C" {
+
+// ------------------------------------------------------------------------------
+// public: CGGI blind rotation on a batch of LWE ciphertexts (device-resident)
+// poulpy-bin-fhe/src/blind_rotation/algorithms/cggi/algorithm.rs:76-118 (dispatch), :265-368 (block binary), :370-440 (standard)
+// ------------------------------------------------------------------------------
+size_t pz_blind_rotation_workspace_bytes(const pz_module* M, const pz_blind_rotation_params* p, size_t batch) {
+    if (!M || !p) return 0;
+    const size_t n8 = (size_t)M->n * 8, cols = p->rank + 1;
+    const size_t tp = cols * std::max({(size_t)p->dnum, (size_t)p->brk_size, (size_t)p->res_size});
+    const size_t T = align256(batch * tp * (size_t)M->m * sizeof(cplx));
+    if (p->block_size > 1) {
+        // the composed path, or (plans with 128-point rows) the row-sliced keys of one block + T' + T2' of the three-kernel block step
+        const size_t composed = align256(batch * n8 * cols * p->dnum) + 2 * align256(batch * n8 * cols * p->brk_size) + T;
+        const size_t mid = align256((size_t)p->block_size * p->dnum * cols * cols * p->brk_size * n8) +
+                           align256(batch * n8 * cols * std::min((size_t)p->dnum, (size_t)p->res_size)) + align256(batch * n8 * cols * p->brk_size) +
+                           kMidDummyBytes;
+        return std::max(composed, mid);
+    }
+    pz_glwe_op_params ep;
+    ep.rank = p->rank; ep.dnum = p->dnum; ep.dsize = 1; ep.key_size = p->brk_size; ep.key_base2k = p->base2k;
+    ep.a_size = p->res_size; ep.a_base2k = p->base2k; ep.res_size = p->res_size; ep.res_base2k = p->base2k; ep.rank_out = p->rank;
+    return align256(batch * n8 * cols * p->res_size) + pz_glwe_op_workspace_bytes(M, &ep, batch, 0);
+}
+
+static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
+                          const pz_blind_rotation_params* p, size_t batch) {
+    PZ_REQUIRE(p != nullptr, "null params");
+    PZ_REQUIRE(p->n_lwe >= 1 && p->block_size >= 1 && p->dnum >= 1 && p->brk_size >= 1 && p->res_size >= 1 && p->lut_size >= 1,
+               "blind_rotation: empty shape");
+    PZ_REQUIRE(p->base2k >= 1 && p->base2k <= 63, "blind_rotation: base2k out of range");
+    PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(lwe_2n) && is_device_ptr(lut) && is_device_ptr(brk),
+               "batched entry points take device pointers");
+    if (batch == 0) return PZ_OK;
+    const long long n = (long long)M->n;
+    const int cols = (int)p->rank + 1, dnum = (int)p->dnum, bsz = (int)p->brk_size, rsz = (int)p->res_size;
+    const int B = (int)batch, n_lwe = (int)p->n_lwe, blk = (int)p->block_size, k = (int)p->base2k;
+    const long long lwe_bs = (long long)n_lwe + 1;
+    const size_t pmat_doubles = (size_t)n * dnum * cols * cols * bsz;
+    const long long res_ct = n * cols * rsz;
+    DV rv{res, res_ct, cols, rsz};
+
+    // acc = X^b * LUT in column 0, zero elsewhere (:298-301 / :413-416)
+    PZ_HIP(hipMemsetAsync(res, 0, (size_t)B * res_ct * 8, M->stream));
+    {
+        const int nl = std::min(rsz, (int)p->lut_size);
+        PolyMap sm{nl, 1, 0, n, 0, 0};                     // the LUT is shared: batch stride 0, VecZnx(1, lut_size)
+        PolyMap dm{nl, 1, res_ct, (long long)cols * n, 0, 0};
+        PZ_TRY(launch_rotate(M, B * nl, (const long long*)lut, sm, (long long*)res, dm, 0, nl, (const long long*)lwe_2n, lwe_bs, 0, 0));
+    }
+
+    PZ_TRY(ensure_w2n(M));
+    {
+        bool launched = false;
+        PZ_TRY(br_try_fused(M, res, lwe_2n, lut, brk, p, batch, &launched));
+        if (launched) return PZ_OK;
+    }
+    if (blk > 1) {
+        const size_t n8 = (size_t)M->n * 8;
+        // plans with 128-point rows (N >= 4096): the block step on the three-kernel pipeline of the GLWE products — pass 1 of the
+        // accumulator limbs | k_mid128<.., BR> (row DFT, the block's blk products weighted by DFT(X^a_i - 1), inverse row DFT) | tail
+        // (inverse column pass + accumulator + carry chain): the spectra never reach HBM and one launch covers the whole block
+        {
+            const int npi = cols * std::min(dnum, rsz), npo = cols * bsz, nrows_key = dnum * cols, ncols_key = cols * bsz;
+            static const int br_mid = getenv("POULPY_DBG_BR_MID") ? atoi(getenv("POULPY_DBG_BR_MID")) : 1;
+            if (br_mid && M->fuse_mid && M->fuse_tail && tail_supported(M) && M->plan.m2 == 128 && mid_supported(M, npi, npo) &&
+                npi == nrows_key && blk <= 16) {
+                const size_t key_bytes = align256((size_t)blk * nrows_key * ncols_key * n8);
+                const size_t t_bytes = align256(batch * npi * (size_t)M->m * sizeof(cplx)), t2_bytes = align256(batch * npo * (size_t)M->m * sizeof(cplx));
+                PZ_TRY(ws_reserve(M, key_bytes + t_bytes + t2_bytes + kMidDummyBytes));
+                char* base = (char*)M->ws;
+                cplx* Pp = (cplx*)base; base += key_bytes;
+                cplx* T = (cplx*)base; base += t_bytes;
+                cplx* T2 = (cplx*)base; base += t2_bytes;
+                cplx* mid_dummy = (cplx*)base;
+                PolyMap sm{npi / cols, cols, res_ct, (long long)cols * n, n, 0};
+                for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {
+                    PZ_TRY(launch_permute_pmat(M, brk + (size_t)b0 * pmat_doubles, Pp, blk * nrows_key * ncols_key));
+                    PZ_TRY(launch_fwd_pass1(M, B * npi, (const long long*)res, sm, T, true));
+                    MidBr mb{(const long long*)lwe_2n, lwe_bs, b0, blk};
+                    PZ_TRY(launch_mid(M, B, T, T2, Pp, npi, npo, nrows_key, ncols_key, mid_dummy, 0, 0, nullptr, &mb));
+                    PZ_TRY(launch_inv_tail(M, B, T2, bsz, cols, (long long*)res, res_ct, cols, rsz, (const long long*)res, res_ct, cols, rsz, k,
+                                           true, true));
+                }
+                return PZ_OK;
+            }
+        }
+        const size_t acc_dft_bytes = align256(batch * n8 * cols * dnum), vr_bytes = align256(batch * n8 * cols * bsz);
+        const size_t tp = (size_t)cols * std::max({dnum, bsz, rsz});
+        const size_t t_bytes = align256(batch * tp * (size_t)M->m * sizeof(cplx));
+        PZ_TRY(ws_reserve(M, acc_dft_bytes + 2 * vr_bytes + t_bytes));
+        char* base = (char*)M->ws;
+        double* acc_dft = (double*)base; base += acc_dft_bytes;
+        double* vmp_res = (double*)base; base += vr_bytes;
+        double* acc_add = (double*)base; base += vr_bytes;
+        cplx* T = (cplx*)base;
+        DV ad{acc_dft, n * cols * dnum, cols, dnum}, vr{vmp_res, n * cols * bsz, cols, bsz}, aa{acc_add, n * cols * bsz, cols, bsz};
+        const bool tail = M->fuse_tail && tail_supported(M);
+        for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {  // chunks_exact: a trailing partial block is ignored, as in the reference
+            PZ_TRY(dev_dft_apply(M, B, 1, 0, ad, 0, rv, 0, cols, nullptr, T));                      // :319-321
+            const int row_max = std::min(dnum * cols, cols * std::min(dnum, rsz));
+            bool block_done = false;
+            if (M->fuse_mid) PZ_TRY(br_block_step(M, acc_dft, ad.bs, acc_add, aa.bs, brk, pmat_doubles, row_max, cols * bsz, B, b0, blk, lwe_2n, lwe_bs, &block_done));
+            if (!block_done) {
+            PZ_HIP(hipMemsetAsync(acc_add, 0, (size_t)B * aa.bs * 8, M->stream));                     // :321
+            for (int i = b0; i < b0 + blk; ++i) {                                                       // :324-337
+                PZ_TRY(dev_vmp(M, B, vr, ad, brk + (size_t)i * pmat_doubles, dnum, cols, cols, bsz, 0));
+                PZ_TRY(launch_xai_acc(M, acc_add, aa.bs, vmp_res, vr.bs, cols * bsz, B, lwe_2n, lwe_bs, i));
+            }
+            }
+            // acc = normalize(idft(acc_add) + acc)  (:342-346)
+            if (tail) {
+                PolyMap sm{bsz, cols, aa.bs, (long long)cols * n, n, 0};
+                PZ_TRY(launch_inv_pass2(M, B * bsz * cols, acc_add, sm, T));
+                PZ_TRY(launch_inv_tail(M, B, T, bsz, cols, (long long*)res, res_ct, cols, rsz, (const long long*)res, res_ct, cols, rsz, k,
+                                       false, true));
+            } else {
+                PZ_TRY(dev_idft(M, B, aa, 0, aa, 0, cols, bsz, T));
+                for (int c = 0; c < cols; ++c) {
+                    PZ_TRY(launch_ew(M, EW_ADD_I64, (int64_t*)acc_add + (long long)c * n, aa.bs, (long long)cols * n,
+                                     (int64_t*)acc_add + (long long)c * n, aa.bs, (long long)cols * n, res + (long long)c * n, res_ct,
+                                     (long long)cols * n, std::min(bsz, rsz), B));
+                    PZ_TRY(dev_normalize(M, B, rv, k, 0, c, aa, k, c));
+                }
+            }
+        }
+        return PZ_OK;
+    }
+
+    // standard: acc += (X^a_i - 1) * (acc (x) BRK_i) per coefficient, one normalization at the end (:423-437)
+    pz_glwe_op_params ep;
+    ep.rank = p->rank; ep.dnum = p->dnum; ep.dsize = 1; ep.key_size = p->brk_size; ep.key_base2k = p->base2k;
+    ep.a_size = p->res_size; ep.a_base2k = p->base2k; ep.res_size = p->res_size; ep.res_base2k = p->base2k; ep.rank_out = p->rank;
+    // acc_tmp lives in the module's second workspace: the external product owns the first one
+    PZ_TRY(ws2_reserve(M, (size_t)B * res_ct * 8));
+    int64_t* acc_tmp = (int64_t*)M->ws2;
+    PolyMap pm{rsz, cols, res_ct, (long long)cols * n, n, 0};
+    for (int i = 0; i < n_lwe; ++i) {
+        PZ_TRY(glwe_op(M, false, acc_tmp, res, brk + (size_t)i * pmat_doubles, &ep, batch));
+        PZ_TRY(launch_rotate(M, B * rsz * cols, (const long long*)acc_tmp, pm, (long long*)res, pm, 2, rsz * cols, (const long long*)lwe_2n,
+                             lwe_bs, 1 + i, 0));
+    }
+    // vec_znx_normalize_assign (normalize.rs:403-425) == out-of-place same-base normalize of a copy
+    PZ_HIP(hipMemcpyAsync(acc_tmp, res, (size_t)B * res_ct * 8, hipMemcpyDeviceToDevice, M->stream));
+    DV tv{acc_tmp, res_ct, cols, rsz};
+    for (int c = 0; c < cols; ++c) PZ_TRY(dev_normalize(M, B, rv, k, 0, c, tv, k, c));
+    return PZ_OK;
+}
+
+// execute_block_binary_extended (algorithm.rs:121-273; extension_factor > 1, block_size > 1): the ext accumulators of a
+// ciphertext are one more batch dimension ([b][e]); per LWE block: batched forward DFT | per coefficient: batched VMP, then
+// k_xai_ext moves the products between the accumulators as the reference does | inverse DFT + acc + carry chain (fused tail).
+size_t pz_blind_rotation_extended_tmp_bytes(const pz_module* M, const pz_blind_rotation_params* p, size_t extension_factor, size_t batch) {
+    if (!M || !p) return 0;
+    const size_t n8 = (size_t)M->n * 8, cols = p->rank + 1, be = batch * extension_factor;
+    return align256(be * n8 * cols * p->res_size) + align256(be * n8 * cols * p->dnum) + 2 * align256(be * n8 * cols * p->brk_size) +
+           align256(be * cols * std::max({(size_t)p->dnum, (size_t)p->brk_size, (size_t)p->res_size}) * (size_t)M->m * sizeof(cplx));
+}
+static int blind_rotation_extended(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
+                                   const pz_blind_rotation_params* p, size_t extension_factor, void* tmp, size_t tmp_bytes, size_t batch) {
+    PZ_REQUIRE(p != nullptr, "null params");
+    PZ_REQUIRE(p->n_lwe >= 1 && p->block_size >= 1 && p->dnum >= 1 && p->brk_size >= 1 && p->res_size >= 1 && p->lut_size >= 1,
+               "blind_rotation: empty shape");
+    PZ_REQUIRE(p->base2k >= 1 && p->base2k <= 63, "blind_rotation: base2k out of range");
+    PZ_REQUIRE(extension_factor >= 1 && (extension_factor & (extension_factor - 1)) == 0 && extension_factor <= 64,
+               "blind_rotation: extension_factor must be a power of two");
+    PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(lwe_2n) && is_device_ptr(lut) && is_device_ptr(brk) && is_device_ptr(tmp),
+               "batched entry points take device pointers");
+    PZ_REQUIRE(tmp_bytes >= pz_blind_rotation_extended_tmp_bytes(M, p, extension_factor, batch), "blind_rotation: tmp is too small");
+    if (batch == 0) return PZ_OK;
+    PZ_TRY(ensure_w2n(M));
+    int log_ext = 0;
+    while (((size_t)1 << log_ext) < extension_factor) ++log_ext;
+    const long long n = (long long)M->n;
+    const int cols = (int)p->rank + 1, dnum = (int)p->dnum, bsz = (int)p->brk_size, rsz = (int)p->res_size, k = (int)p->base2k;
+    const int B = (int)batch, BE = B * (int)extension_factor, n_lwe = (int)p->n_lwe, blk = (int)p->block_size;
+    const long long lwe_bs = (long long)n_lwe + 1, res_ct = n * cols * rsz;
+    const size_t pmat_doubles = (size_t)M->n * dnum * cols * cols * bsz;
+    const size_t n8 = (size_t)M->n * 8;
+    char* base = (char*)tmp;
+    int64_t* acc = (int64_t*)base; base += align256((size_t)BE * n8 * cols * rsz);
+    double* acc_dft = (double*)base; base += align256((size_t)BE * n8 * cols * dnum);
+    double* vmp_res = (double*)base; base += align256((size_t)BE * n8 * cols * bsz);
+    double* acc_add = (double*)base; base += align256((size_t)BE * n8 * cols * bsz);
+    cplx* T = (cplx*)base;
+    // :159-161 zero, :180-190 rotated table
+    PZ_HIP(hipMemsetAsync(acc, 0, (size_t)BE * res_ct * 8, M->stream));
+    PZ_REQUIRE(BE <= 65535, "blind_rotation: batch * extension_factor exceeds 65535 (split the batch)");
+    PZ_TRY(launch_br_ext_init(M, acc, lut, lwe_2n, lwe_bs, log_ext, cols, rsz, (int)p->lut_size, B));
+    DV rv{acc, res_ct, cols, rsz};
+    DV ad{acc_dft, n * cols * dnum, cols, dnum}, vr{vmp_res, n * cols * bsz, cols, bsz}, aa{acc_add, n * cols * bsz, cols, bsz};
+    const bool tail = M->fuse_tail && tail_supported(M);
+    for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {
+        PZ_TRY(dev_dft_apply(M, BE, 1, 0, ad, 0, rv, 0, cols, nullptr, T));                           // :195-200
+        PZ_HIP(hipMemsetAsync(acc_add, 0, (size_t)BE * aa.bs * 8, M->stream));
+        for (int i = b0; i < b0 + blk; ++i) {
+            PZ_TRY(dev_vmp(M, BE, vr, ad, brk + (size_t)i * pmat_doubles, dnum, cols, cols, bsz, 0));   // :209-211
+            PZ_TRY(launch_xai_ext(M, acc_add, vmp_res, cols * bsz, log_ext, B, lwe_2n, lwe_bs, i));
+        }
+        if (tail) {                                                                                    // :260-266
+            PolyMap sm{bsz, cols, aa.bs, (long long)cols * n, n, 0};
+            PZ_TRY(launch_inv_pass2(M, BE * bsz * cols, acc_add, sm, T));
+            PZ_TRY(launch_inv_tail(M, BE, T, bsz, cols, (long long*)acc, res_ct, cols, rsz, (const long long*)acc, res_ct, cols, rsz, k, false, true));
+        } else {
+            PZ_TRY(dev_idft(M, BE, aa, 0, aa, 0, cols, bsz, T));
+            for (int c = 0; c < cols; ++c) {
+                PZ_TRY(launch_ew(M, EW_ADD_I64, (int64_t*)acc_add + (long long)c * n, aa.bs, (long long)cols * n,
+                                 (int64_t*)acc_add + (long long)c * n, aa.bs, (long long)cols * n, acc + (long long)c * n, res_ct,
+                                 (long long)cols * n, std::min(bsz, rsz), BE));
+                PZ_TRY(dev_normalize(M, BE, rv, k, 0, c, aa, k, c));
+            }
+        }
+    }
+    // :270-272 res = acc[0]
+    return launch_ew(M, EW_COPY, res, res_ct, n, acc, (long long)extension_factor * res_ct, n, nullptr, 0, 0, cols * rsz, B);
+}
+int pz_blind_rotation_execute_extended_batched(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
+                                               const pz_blind_rotation_params* p, size_t extension_factor, void* tmp, size_t tmp_bytes,
+                                               size_t batch) {
+    PZ_ENTER(M);
+    return blind_rotation_extended(M, res, lwe_2n, lut, brk, p, extension_factor, tmp, tmp_bytes, batch);
+}
+
+int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
+                                      const pz_blind_rotation_params* p, size_t batch) {
+    PZ_ENTER(M);
+    KeyHash k;
+    k.add((int)2); k.add(res); k.add(lwe_2n); k.add(lut); k.add(brk); k.add(batch);
+    if (p) k.add(*p);
+    graph_key_module(M, k);
+    return with_graph(M, k.h, [&]() { return blind_rotation(M, res, lwe_2n, lut, brk, p, batch); });
+}
+
+// ------------------------------------------------------------------------------
+// public: circuit bootstrapping LWE -> GGSW, constant mode, one base2k for every key and the result
+// poulpy-bin-fhe/src/circuit_bootstrapping/circuit.rs:219-370 (circuit_bootstrap_core, to_exponent = false):
+//   :321-331  acc = blind_rotation(lwe, lut)                                       (copy into the atk layout: same limbs)
+//   :344-366  entry (i, 0) of the GGSW = glwe_trace(X^(-i*gap) * acc, skip 0)       (the reference rotates acc in place between rows)
+//   :369      ggsw_expand_row
+// The dnum_res traces of one LWE are independent, so all batch * dnum_res of them run as one batched trace.
+// ------------------------------------------------------------------------------
+static int glwe_pack(pz_module* M, int64_t* res, size_t nslots, const uint64_t* indices, int64_t* const* cts, size_t log_gap_out,
+                     const int64_t* gals, const double* const* key_pmats, const pz_glwe_op_params* p, void* tmp, size_t tmp_bytes,
+                     size_t batch);
+struct CbtRepack { size_t log_gap_in, log_gap_out, log_domain; };  // exponent mode with log_gap_in != log_gap_out (post_process)
+static inline size_t cbt_tmp_size(const pz_circuit_bootstrapping_params* p) { return (size_t)std::max(p->br.res_size, p->res_size); }
+static inline size_t cbt_ext(const pz_circuit_bootstrapping_params* p) { return p->extension_factor > 1 ? (size_t)p->extension_factor : 1; }
+size_t pz_circuit_bootstrapping_tmp_bytes(const pz_module* M, const pz_circuit_bootstrapping_params* p, size_t batch) {
+    if (!M || !p) return 0;
+    const size_t n8 = (size_t)M->n * 8, cols = p->br.rank + 1;
+    const size_t ext_bytes = cbt_ext(p) > 1 ? align256(pz_blind_rotation_extended_tmp_bytes(M, &p->br, cbt_ext(p), batch)) : 0;
+    return align256(batch * n8 * cols * p->br.res_size) + align256(batch * p->res_dnum * n8 * cols * cbt_tmp_size(p)) + ext_bytes;
+}
+size_t pz_circuit_bootstrapping_to_exponent_tmp_bytes(const pz_module* M, const pz_circuit_bootstrapping_params* p, size_t log_domain,
+                                                      size_t batch) {
+    if (!M || !p || log_domain > 20) return 0;
+    const size_t n8 = (size_t)M->n * 8, cols = p->br.rank + 1;
+    const size_t rows_ct = align256(batch * p->res_dnum * n8 * cols * cbt_tmp_size(p));
+    // acc | rotated rows | 2^log_domain shifted copies | packed result | glwe_pack scratch (3 ciphertext arrays)
+    return pz_circuit_bootstrapping_tmp_bytes(M, p, batch) + (((size_t)1 << log_domain) + 1 + 3) * rows_ct;
+}
+static int circuit_bootstrapping(pz_module* M, int64_t* ggsw, const int64_t* lwe_2n, const int64_t* lut, const double* brk, size_t nsteps,
+                                 const int64_t* gals, const double* const* atk_pmats, const double* const* tsk_pmats,
+                                 const pz_circuit_bootstrapping_params* p, void* tmp, size_t tmp_bytes, size_t batch,
+                                 const CbtRepack* rp = nullptr) {
+    PZ_REQUIRE(p != nullptr, "null params");
+    PZ_REQUIRE(p->res_dnum >= 1 && p->res_size >= 1 && p->atk_dnum >= 1 && p->atk_size >= 1 && p->tsk_dnum >= 1 && p->tsk_size >= 1,
+               "circuit_bootstrapping: empty shape");
+    PZ_REQUIRE(is_device_ptr(ggsw) && is_device_ptr(tmp), "batched entry points take device pointers");
+    PZ_REQUIRE(tmp_bytes >= (rp ? pz_circuit_bootstrapping_to_exponent_tmp_bytes(M, p, rp->log_domain, batch)
+                                : pz_circuit_bootstrapping_tmp_bytes(M, p, batch)),
+               "circuit_bootstrapping: tmp is smaller than the *_tmp_bytes of this call");
+    if (batch == 0) return PZ_OK;
+    const long long n = (long long)M->n;
+    const int cols = (int)p->br.rank + 1, gsz = (int)p->br.res_size, rsz = (int)p->res_size, tsz = (int)cbt_tmp_size(p);
+    const int rows = (int)p->res_dnum, B = (int)batch;
+    const long long ct_g = n * cols * gsz, ct_t = n * cols * tsz, ct_r = n * cols * rsz;
+    int64_t* acc = (int64_t*)tmp;
+    int64_t* tr = (int64_t*)((char*)tmp + align256((size_t)B * ct_g * 8));
+    if (cbt_ext(p) > 1) {  // key.brk.execute dispatches on lut.extension_factor() (algorithm.rs:76-118); the scratch sits behind ours
+        const size_t eb = align256(pz_blind_rotation_extended_tmp_bytes(M, &p->br, cbt_ext(p), batch));
+        void* etmp = (char*)tmp + (rp ? pz_circuit_bootstrapping_to_exponent_tmp_bytes(M, p, rp->log_domain, batch)
+                                      : pz_circuit_bootstrapping_tmp_bytes(M, p, batch)) - eb;
+        PZ_TRY(blind_rotation_extended(M, acc, lwe_2n, lut, brk, &p->br, cbt_ext(p), etmp, eb, batch));
+    } else {
+        PZ_TRY(blind_rotation(M, acc, lwe_2n, lut, brk, &p->br, batch));
+    }
+    if (tsz > gsz) PZ_HIP(hipMemsetAsync(tr, 0, (size_t)B * rows * ct_t * 8, M->stream));  // glwe_copy zero-extends (glwe_trace.rs:114)
+    for (int i = 0; i < rows; ++i) {
+        PolyMap sm{gsz, cols, ct_g, (long long)cols * n, n, 0};
+        PolyMap dm{gsz, cols, (long long)rows * ct_t, (long long)cols * n, n, (long long)i * ct_t};
+        PZ_TRY(launch_rotate(M, B * gsz * cols, (const long long*)acc, sm, (long long*)tr, dm, 0, gsz * cols, nullptr, 0, 0,
+                             -(long long)i * (long long)p->gap));
+    }
+    pz_glwe_op_params tp;
+    tp.rank = p->br.rank; tp.dnum = p->atk_dnum; tp.dsize = 1; tp.key_size = p->atk_size; tp.key_base2k = p->br.base2k;
+    tp.a_size = (uint64_t)tsz; tp.a_base2k = p->br.base2k; tp.res_size = (uint64_t)tsz; tp.res_base2k = p->br.base2k; tp.rank_out = p->br.rank;
+    const int64_t* row_src = tr;
+    if (!rp) {
+        PZ_TRY(glwe_trace(M, tr, nsteps, gals, atk_pmats, &tp, (size_t)B * rows));
+    } else {
+        // post_process (circuit.rs:373-421) with log_gap_in != log_gap_out: partial trace, 2^log_domain shifted copies, glwe_pack
+        size_t log_n = 0;
+        while (((size_t)1 << log_n) < (size_t)M->n) ++log_n;
+        PZ_REQUIRE(nsteps == log_n, "circuit_bootstrapping (exponent mode): gals / atk_pmats must cover all log2(n) trace steps");
+        PZ_REQUIRE(rsz <= gsz, "circuit_bootstrapping (exponent mode): the GGSW must not have more limbs than the GLWE of the rotation");
+        PZ_REQUIRE(rp->log_gap_in >= 1 && rp->log_gap_in <= log_n && rp->log_gap_out <= log_n && rp->log_domain <= 20 &&
+                       (((size_t)1 << rp->log_domain) - 1) << rp->log_gap_out < (size_t)M->n,
+                   "circuit_bootstrapping (exponent mode): gaps / domain out of range");
+        const size_t skip = log_n - rp->log_gap_in + 1;
+        PZ_TRY(glwe_trace(M, tr, log_n - skip, gals + skip, atk_pmats + skip, &tp, (size_t)B * rows));
+        const size_t steps = (size_t)1 << rp->log_domain;
+        const size_t rows_ct = align256((size_t)B * rows * ct_t * 8);
+        char* base = (char*)tr + rows_ct;
+        std::vector<int64_t*> cts(steps);
+        std::vector<uint64_t> idx(steps);
+        const PolyMap pm{tsz, cols, ct_t, (long long)cols * n, n, 0};
+        for (size_t sidx = 0; sidx < steps; ++sidx) {
+            cts[sidx] = (int64_t*)(base + sidx * rows_ct);
+            idx[sidx] = (uint64_t)(sidx << rp->log_gap_out);
+            PZ_TRY(launch_rotate(M, B * rows * tsz * cols, (const long long*)tr, pm, (long long*)cts[sidx], pm, 0, tsz * cols, nullptr, 0, 0,
+                                 -(long long)(sidx << rp->log_gap_in)));
+        }
+        int64_t* packed = (int64_t*)(base + steps * rows_ct);
+        void* pack_tmp = (void*)(base + (steps + 1) * rows_ct);
+        PZ_TRY(glwe_pack(M, packed, steps, idx.data(), cts.data(), rp->log_gap_out, gals, atk_pmats, &tp, pack_tmp, 3 * rows_ct, (size_t)B * rows));
+        row_src = packed;
+    }
+    // glwe_copy(res.at(i, 0), tmp) (glwe_trace.rs:121): the first res_size limbs, into the strided (row, 0) entries
+    PZ_TRY(launch_ew(M, EW_COPY, ggsw, (long long)cols * ct_r, n, row_src, ct_t, n, nullptr, 0, 0, cols * rsz, B * rows));
+    pz_glwe_op_params ep = tp;
+    ep.dnum = p->tsk_dnum; ep.key_size = p->tsk_size; ep.a_size = (uint64_t)rsz; ep.res_size = (uint64_t)rsz;
+    return ggsw_expand_row(M, ggsw, p->res_dnum, tsk_pmats, &ep, batch);
+}
+int pz_circuit_bootstrapping_execute_to_constant_batched(pz_module* M, int64_t* ggsw, const int64_t* lwe_2n, const int64_t* lut,
+                                                         const double* brk, size_t nsteps, const int64_t* gals,
+                                                         const double* const* atk_pmats, const double* const* tsk_pmats,
+                                                         const pz_circuit_bootstrapping_params* p, void* tmp, size_t tmp_bytes,
+                                                         size_t batch) {
+    PZ_ENTER(M);
+    KeyHash k;
+    k.add((int)3); k.add(ggsw); k.add(lwe_2n); k.add(lut); k.add(brk); k.add(nsteps); k.add(tmp); k.add(tmp_bytes); k.add(batch);
+    if (p) {
+        k.add(*p);
+        for (size_t s = 0; s < nsteps && gals && atk_pmats; ++s) { k.add(gals[s]); k.add(atk_pmats[s]); }
+        for (size_t c = 0; c < p->br.rank && tsk_pmats; ++c) k.add(tsk_pmats[c]);
+    }
+    graph_key_module(M, k);
+    return with_graph(M, k.h, [&]() {
+        return circuit_bootstrapping(M, ggsw, lwe_2n, lut, brk, nsteps, gals, atk_pmats, tsk_pmats, p, tmp, tmp_bytes, batch);
+    });
+}
+
+// circuit_bootstrapping_execute_to_exponent (circuit.rs:197-216): equal gaps = the partial trace of post_process (:418-420),
+// otherwise the repacking branch (:392-417).  gals / atk_pmats cover all log2(n) trace steps.
+int pz_circuit_bootstrapping_execute_to_exponent_batched(pz_module* M, int64_t* ggsw, const int64_t* lwe_2n, const int64_t* lut,
+                                                         const double* brk, const int64_t* gals, const double* const* atk_pmats,
+                                                         const double* const* tsk_pmats, const pz_circuit_bootstrapping_params* p,
+                                                         size_t log_gap_in, size_t log_gap_out, size_t log_domain, void* tmp,
+                                                         size_t tmp_bytes, size_t batch) {
+    PZ_ENTER(M);
+    PZ_REQUIRE(gals != nullptr && atk_pmats != nullptr, "circuit_bootstrapping: null argument");
+    size_t log_n = 0;
+    while (((size_t)1 << log_n) < (size_t)M->n) ++log_n;
+    PZ_REQUIRE(log_gap_in >= 1 && log_gap_in <= log_n, "circuit_bootstrapping (exponent mode): log_gap_in out of range");
+    if (log_gap_in == log_gap_out) {
+        const size_t skip = log_n - log_gap_in + 1;
+        return circuit_bootstrapping(M, ggsw, lwe_2n, lut, brk, log_n - skip, gals + skip, atk_pmats + skip, tsk_pmats, p, tmp, tmp_bytes, batch);
+    }
+    CbtRepack rp{log_gap_in, log_gap_out, log_domain};
+    return circuit_bootstrapping(M, ggsw, lwe_2n, lut, brk, log_n, gals, atk_pmats, tsk_pmats, p, tmp, tmp_bytes, batch, &rp);
+}
+
+// ------------------------------------------------------------------------------
+// public: GLWEPacking::glwe_pack (poulpy-core/src/glwe_packing.rs:122-176, pack_internal :15-87) on `batch` independent packing
+// problems with the same occupancy pattern, one base2k / size for ciphertexts, keys and result.  cts[s] points to the `batch`
+// contiguous GLWEs of index indices[s] (the reference's HashMap entry); they are clobbered, as the reference's `&mut` entries.
+// The tree is walked on the host exactly as the reference does; every step is a batched launch of the i64 kernels
+// (rotate, add / sub, rsh, normalize) or of the fused automorphism pipeline.
+// ------------------------------------------------------------------------------
+size_t pz_glwe_pack_tmp_bytes(const pz_module* M, const pz_glwe_op_params* p, size_t batch) {
+    if (!M || !p) return 0;
+    return 3 * align256(batch * (size_t)M->n * (p->rank + 1) * p->res_size * 8);
+}
+static int glwe_pack(pz_module* M, int64_t* res, size_t nslots, const uint64_t* indices, int64_t* const* cts, size_t log_gap_out,
+                     const int64_t* gals, const double* const* key_pmats, const pz_glwe_op_params* p, void* tmp, size_t tmp_bytes,
+                     size_t batch) {
+    PZ_REQUIRE(p != nullptr && indices != nullptr && cts != nullptr && gals != nullptr && key_pmats != nullptr, "glwe_pack: null argument");
+    PZ_REQUIRE(p->a_size == p->res_size && p->a_base2k == p->res_base2k && p->res_base2k == p->key_base2k && p->rank_out == p->rank &&
+                   p->dsize == 1,
+               "glwe_pack: ciphertexts, keys and result share base2k and size (the other cases re-normalize around this call)");
+    size_t log_n = 0;
+    while (((size_t)1 << log_n) < (size_t)M->n) ++log_n;
+    PZ_REQUIRE(log_gap_out <= log_n && nslots >= 1, "glwe_pack: bad shape");
+    PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(tmp), "batched entry points take device pointers");
+    PZ_REQUIRE(tmp_bytes >= pz_glwe_pack_tmp_bytes(M, p, batch), "glwe_pack: tmp is smaller than pz_glwe_pack_tmp_bytes");
+    if (batch == 0) return PZ_OK;
+    const long long n = (long long)M->n;
+    const int cols = (int)p->rank + 1, size = (int)p->res_size, k = (int)p->res_base2k, B = (int)batch;
+    const long long ct = n * cols * size;
+    const size_t ctb = align256((size_t)B * ct * 8);
+    int64_t* tmp_b = (int64_t*)tmp;
+    int64_t* t1 = (int64_t*)((char*)tmp + ctb);
+    int64_t* t2 = (int64_t*)((char*)tmp + 2 * ctb);
+    std::vector<int64_t*> slots((size_t)M->n, nullptr);
+    for (size_t s = 0; s < nslots; ++s) {
+        PZ_REQUIRE(indices[s] < (uint64_t)M->n, "glwe_pack: index out of range");   // glwe_packing.rs:138
+        PZ_REQUIRE(cts[s] != nullptr && is_device_ptr(cts[s]) && slots[indices[s]] == nullptr, "glwe_pack: bad or duplicate entry");
+        slots[indices[s]] = cts[s];
+    }
+    const PolyMap pm{size, cols, ct, (long long)cols * n, n, 0};
+    const int npolys = B * size * cols;
+    auto rotate_to = [&](long long kk, int64_t* dst, const int64_t* src) {
+        return launch_rotate(M, npolys, (const long long*)src, pm, (long long*)dst, pm, 0, size * cols, nullptr, 0, 0, kk);
+    };
+    auto rotate_assign = [&](long long kk, int64_t* x) {
+        PZ_TRY(rotate_to(kk, t1, x));
+        return launch_ew(M, EW_COPY, x, ct, n, t1, ct, n, nullptr, 0, 0, cols * size, B);
+    };
+    auto ew3 = [&](int op, int64_t* r, const int64_t* x, const int64_t* y) {   // limb-wise over whole ciphertexts (equal sizes)
+        return launch_ew(M, op, r, ct, n, x, ct, n, y, ct, n, cols * size, B);
+    };
+    auto rsh1 = [&](int64_t* x) { return launch_rsh(M, B, (long long*)x, ct, cols, size, 0, cols, k, 1); };
+    auto normalize_assign = [&](int64_t* x) {
+        PZ_TRY(launch_ew(M, EW_COPY, t2, ct, n, x, ct, n, nullptr, 0, 0, cols * size, B));
+        DV xv{x, ct, cols, size}, tv{t2, ct, cols, size};
+        for (int c = 0; c < cols; ++c) PZ_TRY(dev_normalize(M, B, xv, k, 0, c, tv, k, c));
+        return (int)PZ_OK;
+    };
+    for (size_t i = 0; i + log_gap_out < log_n; ++i) {
+        const size_t tt = (size_t)1 << (log_n - 1 - i);
+        PZ_REQUIRE((gals[i] & 1) != 0 && key_pmats[i] != nullptr, "glwe_pack: bad automorphism key");
+        for (size_t j = 0; j < tt; ++j) {
+            int64_t* a = slots[j];
+            int64_t* b = slots[j + tt];
+            slots[j] = nullptr;
+            slots[j + tt] = nullptr;
+            if (a && b) {                                                       // :41-70
+                PZ_TRY(rotate_assign(-(long long)tt, a));
+                PZ_TRY(ew3(EW_SUB_I64, tmp_b, a, b));
+                PZ_TRY(rsh1(tmp_b));
+                PZ_TRY(ew3(EW_ADD_I64, a, a, b));
+                PZ_TRY(rsh1(a));
+                PZ_TRY(normalize_assign(tmp_b));
+                AutoSpec au{(long long)gals[i], 0};
+                PZ_TRY(glwe_op(M, true, tmp_b, tmp_b, key_pmats[i], p, batch, &au));
+                PZ_TRY(ew3(EW_SUB_I64, a, a, tmp_b));
+                PZ_TRY(normalize_assign(a));
+                PZ_TRY(rotate_assign((long long)tt, a));
+                slots[j] = a;
+            } else if (a) {                                                     // :71-75
+                PZ_TRY(rsh1(a));
+                AutoSpec au{(long long)gals[i], 1};
+                PZ_TRY(glwe_op(M, true, a, a, key_pmats[i], p, batch, &au));
+                slots[j] = a;
+            } else if (b) {                                                     // :76-86
+                PZ_TRY(rotate_to((long long)tt, tmp_b, b));
+                PZ_TRY(rsh1(tmp_b));
+                AutoSpec au{(long long)gals[i], 3};
+                PZ_TRY(glwe_op(M, true, b, tmp_b, key_pmats[i], p, batch, &au));
+                slots[j] = b;
+            }
+        }
+    }
+    PZ_REQUIRE(slots[0] != nullptr, "glwe_pack: no ciphertext ends at index 0");   // :175 a.get(&0).unwrap()
+    PZ_TRY(launch_ew(M, EW_COPY, res, ct, n, slots[0], ct, n, nullptr, 0, 0, cols * size, B));
+    const size_t skip = log_n - log_gap_out;
+    return glwe_trace(M, res, log_n - skip, gals + skip, key_pmats + skip, p, batch);
+}
+int pz_glwe_pack_batched(pz_module* M, int64_t* res, size_t nslots, const uint64_t* indices, int64_t* const* cts, size_t log_gap_out,
+                         const int64_t* gals, const double* const* key_pmats, const pz_glwe_op_params* p, void* tmp, size_t tmp_bytes,
+                         size_t batch) {
+    PZ_ENTER(M);
+    return glwe_pack(M, res, nslots, indices, cts, log_gap_out, gals, key_pmats, p, tmp, tmp_bytes, batch);
+}
+
+}  // extern "C"

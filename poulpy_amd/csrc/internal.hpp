@@ -7,7 +7,13 @@
 //   launch_ops.hip   elementwise / permutation / normalize / VMP kernels (device_ops.hpp)
 //   launch_br.hip    blind-rotation kernels (device_br.hpp + the block step of device_ops.hpp)
 //   launch_cnv.hip   bivariate convolution kernels (device_cnv.hpp)
-//   api*.hip         the C ABI: validation, host/device staging, composition of the launches
+//   api.hip          C ABI: module, memory, the batched GLWE product (glwe_op) and its direct callers, key pinning / mirrors
+//   api_hal.hip      C ABI: the per-op HalImpl methods (VecZnxDft, SVP, VMP, VecZnxBig, i64 VecZnx family)
+//   api_br.hip       C ABI: blind rotation, circuit bootstrapping, GLWE packing (composites on glwe_op; HIP-graph replay)
+//   api_cnv.hip      C ABI: convolution family, GLWE tensoring, batched i64 family
+//   api_lwe.hip      C ABI: LWE glue of the gate bootstrap (+ its index kernels)
+//   api_dist.hip     C ABI: RCCL key broadcast (dlopen)
+//   api_common.hpp / api_glwe.hpp   what those share (staging, graph cache, glwe_op / glwe_trace / ggsw_expand_row)
 //
 // Every kernel is instantiated in exactly one translation unit (the one that launches it), so the units compile
 // independently and in parallel; only plain functions cross unit boundaries.
