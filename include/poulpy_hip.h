@@ -77,6 +77,12 @@ void pz_module_free(pz_module* m);
 uint64_t pz_module_n(const pz_module* m);
 int pz_module_device(const pz_module* m);
 /* drains the module stream (needed only after device-pointer calls) */
+/* A sibling of `m` for another host thread.  Calls on ONE module are serialised by its lock (one HIP stream, one workspace); poulpy
+ * callers share `&Module` across scoped threads (poulpy-bin-fhe bdd_arithmetic/eval.rs:210-221), so the shim gives every other thread a
+ * sibling: it shares m's immutable device tables (reference-counted: free in any order) and owns its stream, workspaces, staging arena,
+ * pinned-key list, key mirrors, graph cache and lock — calls on different siblings overlap on the device (copies of one with kernels of
+ * another).  Knobs (fusion, chunk, graphs) are copied at clone time. */
+int pz_module_clone(pz_module* m, pz_module** out);
 int pz_module_sync(pz_module* m);
 /* raw hipStream_t of the module, for callers that want to order their own work */
 void* pz_module_stream(pz_module* m);

@@ -176,6 +176,36 @@ int pz_module_new_on_device(uint64_t n, int device, pz_module** out) {
         if (hipMemset(M->margin, 0, 8) != hipSuccess) { r = fail(PZ_ERR_HIP, "margin memset failed"); break; }
     } while (0);
     if (r != PZ_OK) { pz_module_free(M); return r; }
+    M->tables_ref = new std::atomic<int>(1);
+    {
+        std::lock_guard<std::mutex> g(g_modules_mu);
+        g_modules.push_back(M);
+    }
+    *out = M;
+    return PZ_OK;
+}
+// A sibling for another host thread (concurrent calls on one `&Module` happen, poulpy-bin-fhe bdd_arithmetic/eval.rs:210-221):
+// it shares the immutable device tables and owns everything a call mutates — stream, workspaces, staging arena, pinned-key list, key
+// mirrors, graph cache, lock — so calls on different siblings run concurrently instead of queueing on one mutex.
+int pz_module_clone(pz_module* P, pz_module** out) {
+    if (!P || !out) return fail(PZ_ERR_INVALID, "null argument");
+    *out = nullptr;
+    std::lock_guard<std::mutex> lock_(P->mu);
+    PZ_HIP(hipSetDevice(P->device));
+    PZ_TRY(ensure_w2n(P));   // built lazily otherwise: the siblings must agree on who owns it
+    pz_module* M = new pz_module();
+    M->n = P->n; M->m = P->m; M->device = P->device; M->plan = P->plan;
+    M->tw1 = P->tw1; M->tw1inv = P->tw1inv; M->wL1 = P->wL1; M->wL2 = P->wL2; M->tw12 = P->tw12; M->tw12t = P->tw12t; M->w2n = P->w2n;
+    M->tables_ref = P->tables_ref;
+    M->tables_ref->fetch_add(1);
+    M->fuse_tail = P->fuse_tail; M->fuse_mid = P->fuse_mid; M->small_path = P->small_path; M->chunk = P->chunk; M->graphs_on = P->graphs_on;
+    int r = PZ_OK;
+    do {
+        if (hipStreamCreateWithFlags(&M->stream, hipStreamNonBlocking) != hipSuccess) { r = fail(PZ_ERR_HIP, "stream create failed"); break; }
+        if (hipMalloc(&M->margin, 8) != hipSuccess) { r = fail(PZ_ERR_HIP, "margin alloc failed"); break; }
+        if (hipMemset(M->margin, 0, 8) != hipSuccess) { r = fail(PZ_ERR_HIP, "margin memset failed"); break; }
+    } while (0);
+    if (r != PZ_OK) { pz_module_free(M); return r; }
     {
         std::lock_guard<std::mutex> g(g_modules_mu);
         g_modules.push_back(M);
@@ -196,7 +226,14 @@ void pz_module_free(pz_module* M) {
     }
     (void)hipSetDevice(M->device);
     if (M->stream) (void)hipStreamSynchronize(M->stream);
-    for (void* p : {(void*)M->tw1, (void*)M->tw1inv, (void*)M->wL1, (void*)M->wL2, (void*)M->tw12, (void*)M->tw12t, (void*)M->w2n, M->ws, M->ws2, (void*)M->margin})
+    // the tables go with the last sibling (a module whose construction failed early owns them alone)
+    const bool last = !M->tables_ref || M->tables_ref->fetch_sub(1) == 1;
+    if (last) {
+        for (void* p : {(void*)M->tw1, (void*)M->tw1inv, (void*)M->wL1, (void*)M->wL2, (void*)M->tw12, (void*)M->tw12t, (void*)M->w2n})
+            if (p) (void)hipFree(p);
+        delete M->tables_ref;
+    }
+    for (void* p : {M->ws, M->ws2, (void*)M->margin})
         if (p) (void)hipFree(p);
     for (auto& c : M->arena) (void)hipFree(c.p);
     for (auto& k : M->pinned) if (k.sliced) (void)hipFree(k.sliced);

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -117,6 +118,8 @@ struct pz_module {
     pz::cplx *tw1 = nullptr, *tw1inv = nullptr, *wL1 = nullptr, *wL2 = nullptr, *tw12 = nullptr;
     pz::cplx* tw12t = nullptr;  // the same table as [q1][j2] (row-major pipeline)
     pz::cplx* w2n = nullptr;    // exp(2 pi i t / 2n), t < 2n: DFT of the monomials X^a (blind rotation), built on first use
+    // the seven tables above are immutable and shared by the siblings of pz_module_clone: freed by the last one (atomic count on the heap)
+    std::atomic<int>* tables_ref = nullptr;
     // grow-only workspace
     void* ws = nullptr;
     size_t ws_bytes = 0;

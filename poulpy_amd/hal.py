@@ -159,6 +159,17 @@ class Module:
     def sync(self):
         self._ck(self.lib.pz_module_sync(self.handle))
 
+    def clone(self) -> "Module":
+        """A sibling for another host thread (pz_module_clone): shares the device tables, owns its stream / workspaces / lock."""
+        sib = object.__new__(Module)
+        sib.lib, sib._n = self.lib, self._n
+        h = c_void_p()
+        st = self.lib.pz_module_clone(self.handle, C.byref(h))
+        sib.handle = h if st == 0 else None
+        if st != 0:
+            raise PoulpyHipError(f"pz_module_clone failed [{st}]: {self.lib.pz_last_error().decode()}")
+        return sib
+
     def close(self):
         if self.handle is not None:
             self.lib.pz_module_free(self.handle)

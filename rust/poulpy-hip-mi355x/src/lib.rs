@@ -32,16 +32,46 @@ pub use ffi::{pz_blind_rotation_params, pz_circuit_bootstrapping_params, pz_glwe
 #[derive(Debug, Clone, Copy)]
 pub struct FFT64Hip;
 
-/// `Backend::Handle`: owns the C module.  Calls on one module are serialized inside the library (one HIP stream per module), so
-/// `&Module<FFT64Hip>` is `Sync` like the CPU backends (`unsafe impl Sync for Module`, poulpy-hal/src/layouts/module.rs:103-104).
-#[repr(C)]
+/// `Backend::Handle`: owns the C module and the siblings other threads use.  Calls on one C module are serialized inside the library (one
+/// HIP stream per module); `&Module<FFT64Hip>` is `Sync` like the CPU backends (`unsafe impl Sync for Module`, poulpy-hal/src/layouts/
+/// module.rs:103-104) and threads other than the creating one run on their own sibling module (`pz_module_clone`).
 pub struct FFT64HipHandle {
     pub(crate) raw: *mut ffi::pz_module,
+    /// the thread that created the module uses `raw`; every other thread gets a sibling on first use (freed with the handle)
+    owner: std::thread::ThreadId,
+    siblings: std::sync::Mutex<std::collections::HashMap<std::thread::ThreadId, usize>>,
 }
 unsafe impl Send for FFT64HipHandle {}
 unsafe impl Sync for FFT64HipHandle {}
 
 impl FFT64HipHandle {
+    pub(crate) fn new(raw: *mut ffi::pz_module) -> Self {
+        Self { raw, owner: std::thread::current().id(), siblings: std::sync::Mutex::new(std::collections::HashMap::new()) }
+    }
+
+    /// The C module for the calling thread (see `hal_impl::raw`).
+    pub(crate) fn for_this_thread(&self) -> *mut ffi::pz_module {
+        let me = std::thread::current().id();
+        if me == self.owner {
+            return self.raw;
+        }
+        let mut map = self.siblings.lock().unwrap();
+        if let Some(p) = map.get(&me) {
+            return *p as *mut ffi::pz_module;
+        }
+        let mut sib: *mut ffi::pz_module = std::ptr::null_mut();
+        ffi::check(unsafe { ffi::pz_module_clone(self.raw, &mut sib) }, "pz_module_clone");
+        map.insert(me, sib as usize);
+        sib
+    }
+
+    fn free_all(&self) {
+        for (_, p) in self.siblings.lock().unwrap().drain() {
+            unsafe { ffi::pz_module_free(p as *mut ffi::pz_module) }
+        }
+        unsafe { ffi::pz_module_free(self.raw) }
+    }
+
     /// The raw `pz_module*`, for callers that drive the batched device-resident entry points of include/poulpy_hip.h directly
     /// (`pz_glwe_external_product_batched`, `pz_blind_rotation_execute_batched`, ... on `pz_device_alloc` buffers).
     pub fn as_raw(&self) -> *mut std::ffi::c_void {
@@ -109,7 +139,7 @@ impl Backend for FFT64Hip {
     unsafe fn destroy(handle: NonNull<Self::Handle>) {
         unsafe {
             let h: Box<FFT64HipHandle> = Box::from_raw(handle.as_ptr());
-            ffi::pz_module_free(h.raw);
+            h.free_all();
         }
     }
 }

@@ -955,6 +955,73 @@ def test_concurrent_callers_on_one_module(mods):
     assert all(results)
 
 
+def test_sibling_modules_run_concurrently(mods):
+    """pz_module_clone: every worker thread on its own sibling (shared device tables; own stream, workspaces, lock) — per-op host calls
+    and fused GLWE calls on host containers from 6 threads at once, each result against the oracle; siblings outlive their parent."""
+    import ctypes as C
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    from poulpy_amd.hal import GlweOpParams, Module
+    n, cols, size, k = 4096, 2, 3, 14
+    ref, _ = mods(n)
+    parent = Module(n)
+    tls = threading.local()
+    sibs, sibs_lock = [], threading.Lock()
+
+    def my_module():
+        if not hasattr(tls, "mod"):
+            tls.mod = parent.clone()
+            with sibs_lock:
+                sibs.append(tls.mod)
+        return tls.mod
+
+    mat = MatZnx(n, size, cols, cols, size).fill_uniform(k, seeded(1))
+    pr = ref.vmp_pmat_alloc(size, cols, cols, size)
+    ref.vmp_prepare(pr, mat)
+    p = GlweOpParams(rank=1, dnum=size, dsize=1, key_size=size, key_base2k=k, a_size=size, a_base2k=k, res_size=size, res_base2k=k, rank_out=1)
+    hp = lambda arr: arr.ctypes.data_as(C.c_void_p)
+
+    def work(seed):
+        hip = my_module()
+        rng = seeded(seed)
+        ok = True
+        # per-op sequence on host containers
+        a = VecZnx(n, cols, size).fill_uniform(k, rng)
+        sc = ScalarZnx(n, cols).fill_uniform(k, rng)
+        outs = []
+        for mod in (ref, hip):
+            pp = SvpPPol(n, cols)
+            d = mod.vec_znx_dft_alloc(cols, size)
+            for c in range(cols):
+                mod.svp_prepare(pp, c, sc, c)
+            for c in range(cols):
+                mod.svp_apply_dft(d, c, pp, c, a, c)
+            outs.append(normalize_all(mod, mod.vec_znx_idft_apply_consume(d), k).data.copy())
+        ok = ok and np.array_equal(outs[0], outs[1])
+        # fused external product on host containers with this sibling's own key mirror
+        ph = hip.vmp_pmat_alloc(size, cols, cols, size)
+        hip.vmp_prepare(ph, mat)
+        want = VecZnx(n, cols, size)
+        ref.glwe_external_product(want, k, a, k, pr, 1, k)
+        got = np.zeros_like(want.data)
+        hip.glwe_external_product_batched(hp(got), hp(a.data), hp(ph.data), p, 1)
+        return ok and np.array_equal(got, want.data)
+
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        results = list(ex.map(work, range(700, 736)))
+    assert all(results)
+    assert 1 <= len(sibs) <= 6
+    parent.close()                       # the tables are reference-counted: siblings keep working after their parent is gone
+    a = VecZnx(n, cols, size).fill_uniform(k, seeded(9))
+    d = sibs[0].vec_znx_dft_alloc(cols, size)
+    sibs[0].vec_znx_dft_apply(1, 0, d, 0, a, 0)
+    big = sibs[0].vec_znx_big_alloc(cols, size)
+    sibs[0].vec_znx_idft_apply(big, 0, d, 0)
+    assert np.array_equal(big.data[:, 0], a.data[:, 0])
+    for sib in sibs:
+        sib.close()
+
+
 @pytest.mark.parametrize("n", [512, 4096, 65536])
 def test_batched_primitives_compose_an_external_product(mods, n):
     """The four batched primitives of the ABI (pz_vec_znx_dft_apply_batched, pz_vmp_apply_dft_to_dft_batched,

@@ -25,6 +25,7 @@ SHAPES = {
     # the large ring degree of BASELINE configs[3] ("N = 2^10 / 2^14"): same key layout at N = 2^14 (composed path: the
     # accumulators do not fit in LDS)
     "big": dict(n=16384, n_lwe=574, rank=1, block_size=7, base2k=13, dnum=3, brk_size=3, res_size=3),
+    "n2048": dict(n=2048, n_lwe=574, rank=1, block_size=7, base2k=13, dnum=3, brk_size=3, res_size=3),
     "n4096": dict(n=4096, n_lwe=574, rank=1, block_size=7, base2k=13, dnum=3, brk_size=3, res_size=3),
 }
 

@@ -30,7 +30,7 @@ V = "{0}.cols(), {0}.size()"
 FORWARD = {
     "new": """        let mut raw: *mut ffi::pz_module = std::ptr::null_mut();
         check(unsafe { ffi::pz_module_new(n, &mut raw) }, "Module::new");
-        let handle: Box<FFT64HipHandle> = Box::new(FFT64HipHandle { raw });
+        let handle: Box<FFT64HipHandle> = Box::new(FFT64HipHandle::new(raw));
         unsafe { Module::from_nonnull(NonNull::from(Box::leak(handle)), n) }""",
     # ---- VecZnxBig: the two hot-path ops (SURVEY.md a13, a14) ----
     "vec_znx_big_normalize_tmp_bytes": "        unsafe { ffi::pz_vec_znx_big_normalize_tmp_bytes(raw(module)) }",
@@ -273,10 +273,12 @@ use poulpy_hal::{
 
 use crate::{FFT64Hip, FFT64HipHandle, ffi, ffi::check};
 
-/// The C module behind a `Module<FFT64Hip>`.
+/// The C module a call on `module` from THIS thread uses: the handle's own module on the thread that created it, a sibling
+/// (`pz_module_clone`: shared device tables, own stream / workspaces / lock) on any other thread, so that the scoped threads poulpy
+/// runs over one `&Module` (poulpy-bin-fhe bdd_arithmetic/eval.rs:210-221) overlap on the device instead of queueing on one lock.
 #[inline]
 pub(crate) fn raw(module: &Module<FFT64Hip>) -> *mut ffi::pz_module {
-    unsafe { (*module.ptr()).raw }
+    unsafe { (*module.ptr()).for_this_thread() }
 }
 
 unsafe impl HalImpl<FFT64Hip> for FFT64Hip {''' % len(methods)]
