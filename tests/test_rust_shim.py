@@ -174,7 +174,10 @@ def test_core_impl_covers_the_trait():
     assert sorted(fused) == sorted(["glwe_external_product", "glwe_external_product_assign", "glwe_keyswitch", "glwe_keyswitch_assign",
                                     "glwe_automorphism", "glwe_automorphism_assign", "glwe_automorphism_add", "glwe_automorphism_add_assign",
                                     "glwe_automorphism_sub", "glwe_automorphism_sub_assign", "glwe_automorphism_sub_negate",
-                                    "glwe_automorphism_sub_negate_assign"])
+                                    "glwe_automorphism_sub_negate_assign",
+                                    # matrix-level forms: one batched call over the (row, column) entries
+                                    "gglwe_keyswitch", "gglwe_keyswitch_assign", "gglwe_external_product", "gglwe_external_product_assign",
+                                    "ggsw_external_product", "ggsw_external_product_assign"])
     if os.path.isdir(REF):   # the four macro families + the 35 written-out fns are the whole trait
         n_macro = 0
         for fam in ("decryption", "conversion", "operations", "encryption"):

@@ -351,6 +351,68 @@ for base, mode in (("glwe_automorphism", "PZ_AUTO"), ("glwe_automorphism_add", "
     CORE_FORWARD[base] = KS_BODY.format(a="a", take=TAKE_2, what=base, call=call)
     CORE_FORWARD[base + "_assign"] = KS_BODY.format(a="res", take=TAKE_1, what=base + "_assign", call=call)
 
+# matrix-level forms (keyswitching/gglwe.rs:29-75, external_product/gglwe.rs:26-77, external_product/ggsw.rs:29-65): the reference loops
+# glwe_keyswitch / glwe_external_product over the (row, column) entries; the entries of a GGLWE / GGSW are contiguous GLWEs, so the loop
+# is ONE batched call (staged once, `batch` = rows x columns) instead of rows x columns host round trips
+MAT_KS_BODY = """        let _ = scratch;
+        let res = &mut res.to_mut();
+{a_view}
+        assert_eq!(res.rank_in(), {a}.rank_in());
+        assert_eq!({a}.rank_out(), key.rank_in());
+        assert_eq!(res.rank_out(), key.rank_out());
+        assert!(res.dnum() <= {a}.dnum());
+        assert_eq!(res.base2k(), {a}.base2k());
+        let batch = res.dnum().as_usize() * res.rank_in().as_usize();
+        if batch == 0 {{
+            return;
+        }}
+        let p = op_params({a}.rank_out().as_usize(), res.rank_out().as_usize(), key.dnum().as_usize(), key.dsize().as_usize(), key.size(),
+            key.base2k().as_usize(), {a}.size(), {a}.base2k().as_usize(), res.size(), res.base2k().as_usize());
+        let k = key.to_ref();
+{ptrs}
+        check(unsafe {{ ffi::pz_glwe_keyswitch_batched(raw(module), rp, ap, k.data().as_ptr(), &p, batch) }}, "{what}");"""
+MAT_EP_BODY = """        let _ = scratch;
+        let res = &mut res.to_mut();
+{a_view}
+        let g = {ggsw}.to_ref();
+        assert_eq!(res.{rank_in}(), {a}.{rank_in}());
+        assert_eq!({a}.{rank_out}(), g.rank());
+        assert_eq!(res.{rank_out}(), g.rank());
+        assert_eq!(res.base2k(), {a}.base2k());
+        let cols_m: usize = {cols_m};
+        let rows = res.dnum().as_usize().min({a}.dnum().as_usize());
+        let batch = rows * cols_m;
+        if batch != 0 {{
+            let p = op_params(g.rank().as_usize(), g.rank().as_usize(), g.dnum().as_usize(), g.dsize().as_usize(), g.size(),
+                g.base2k().as_usize(), {a}.size(), {a}.base2k().as_usize(), res.size(), res.base2k().as_usize());
+{ptrs}
+            check(unsafe {{ ffi::pz_glwe_external_product_batched(raw(module), rp, ap, g.data().as_ptr(), &p, batch) }}, "{what}");
+        }}
+        for row in rows..res.dnum().as_usize() {{
+            for col in 0..cols_m {{
+                res.at_mut(row, col).data_mut().zero();
+            }}
+        }}"""
+MAT_A_VIEW = "        let a = &a.to_ref();"
+MAT_PTRS_2 = """        let rp = res.at_mut(0, 0).data_mut().as_mut_ptr();
+        let ap = a.at(0, 0).data().as_ptr();"""
+MAT_PTRS_1 = """        let rp = res.at_mut(0, 0).data_mut().as_mut_ptr();
+        let ap = rp as *const i64;   // *_assign: every entry is consumed before its result is written"""
+def _indent(t):
+    return "\n".join("    " + l for l in t.split("\n"))
+CORE_FORWARD["gglwe_keyswitch"] = MAT_KS_BODY.format(a="a", a_view=MAT_A_VIEW, ptrs=MAT_PTRS_2, what="gglwe_keyswitch")
+CORE_FORWARD["gglwe_keyswitch_assign"] = MAT_KS_BODY.format(a="res", a_view="", ptrs=MAT_PTRS_1, what="gglwe_keyswitch_assign")
+CORE_FORWARD["gglwe_external_product"] = MAT_EP_BODY.format(a="a", a_view=MAT_A_VIEW, ggsw="b", rank_in="rank_in", rank_out="rank_out",
+                                                            cols_m="res.rank_in().as_usize()", ptrs=_indent(MAT_PTRS_2), what="gglwe_external_product")
+CORE_FORWARD["gglwe_external_product_assign"] = MAT_EP_BODY.format(a="res", a_view="", ggsw="a", rank_in="rank_in", rank_out="rank_out",
+                                                                   cols_m="res.rank_in().as_usize()", ptrs=_indent(MAT_PTRS_1),
+                                                                   what="gglwe_external_product_assign")
+CORE_FORWARD["ggsw_external_product"] = MAT_EP_BODY.format(a="a", a_view=MAT_A_VIEW, ggsw="b", rank_in="rank", rank_out="rank",
+                                                           cols_m="res.rank().as_usize() + 1", ptrs=_indent(MAT_PTRS_2), what="ggsw_external_product")
+CORE_FORWARD["ggsw_external_product_assign"] = MAT_EP_BODY.format(a="res", a_view="", ggsw="a", rank_in="rank", rank_out="rank",
+                                                                  cols_m="res.rank().as_usize() + 1", ptrs=_indent(MAT_PTRS_1),
+                                                                  what="ggsw_external_product_assign")
+
 CORE_FAMILIES = (("keyswitching", "CoreKeyswitchDefaults"), ("external_product", "CoreExternalProductDefaults"),
                  ("automorphism", "CoreAutomorphismDefaults"))
 
@@ -381,7 +443,7 @@ use poulpy_core::{
     },
     oep::{CoreAutomorphismDefaults, CoreExternalProductDefaults, CoreImpl, CoreKeyswitchDefaults},
 };
-use poulpy_hal::layouts::{Module, Scratch, ZnxView, ZnxViewMut};
+use poulpy_hal::layouts::{Module, Scratch, ZnxView, ZnxViewMut, ZnxZero};
 
 use crate::{FFT64Hip, ffi, ffi::check, hal_impl::raw};
 
