@@ -258,6 +258,13 @@ int pz_module_sync(pz_module* M) {
     return PZ_OK;
 }
 void* pz_module_stream(pz_module* M) { return M ? (void*)M->stream : nullptr; }
+int pz_module_set_ws_shift(pz_module* M, size_t bytes) {   // diagnostic (not in the header): extra padding in front of T2'
+    if (!M) return fail(PZ_ERR_INVALID, "null module");
+    std::lock_guard<std::mutex> lock_(M->mu);
+    M->ws_shift = bytes;
+    M->graph_epoch++;
+    return PZ_OK;
+}
 int pz_module_set_chunk(pz_module* M, size_t c) {
     if (!M) return fail(PZ_ERR_INVALID, "null module");
     std::lock_guard<std::mutex> lock_(M->mu);
@@ -569,7 +576,7 @@ static FusedWs fused_ws(const pz_module* M, const pz_glwe_op_params* p, const Op
     w.rtmp = au ? align256(chunk * n8 * std::max((size_t)s.cols_out * p->res_size, body_limbs)) : 0;
     // cross-base output: the tail's key-base digits (cols_out x key_size limbs per ciphertext) before the cross-base pass
     w.small2 = p->res_base2k != p->key_base2k ? align256(chunk * n8 * s.cols_out * ksz) : 0;
-    w.total = w.key + w.conv + w.t + w.t2 + w.rtmp + w.small2 + kMidDummyBytes;
+    w.total = w.key + w.conv + w.t + w.t2 + w.rtmp + w.small2 + kMidDummyBytes + align256(M->ws_shift) + ((size_t)1 << 20);
     return w;
 }
 // keyswitch: 0 external product, 1 key switch, 2 automorphism family, 3 tensor relinearization.  The figure is what the call reserves
@@ -660,11 +667,19 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
         }
         const FusedWs fw = fused_ws(M, p, s, chunk, au != nullptr);
         const size_t key_bytes = fw.key, conv_bytes = fw.conv, t_bytes = fw.t, t2_bytes = fw.t2, rtmp_bytes = fw.rtmp, small2_bytes = fw.small2;
-        PZ_TRY(ws_reserve(M, key_bytes + conv_bytes + t_bytes + t2_bytes + rtmp_bytes + small2_bytes + kMidDummyBytes));
+        PZ_TRY(ws_reserve(M, fw.total));
         char* base = (char*)M->ws;
         cplx* Pp = (cplx*)base; base += key_bytes;
         int64_t* a_conv = (int64_t*)base; base += conv_bytes;
         cplx* T = (cplx*)base; base += t_bytes;
+        // Placement of T2' relative to the result.  The tail of ciphertext b reads T2' + X and writes res + X and res + X + N*4 bytes
+        // (the two coefficient halves), the same X for every workgroup; with both buffers on the same 1 MiB phase (large allocations
+        // are 2 MiB aligned) the read and the two write streams of every workgroup meet on the same HBM channels: tail 3.55 ms per
+        // 1024 ciphertexts in most processes, 3.14 in some, depending on the physical placement.  With T2' three quarters of a MiB
+        // out of phase it is 3.08 - 3.25 ms in every process (measured at N = 2^16: profiles/r02_t2_placement.txt; applied there).  Pass 1 has
+        // the mirrored structure (reads a + X, a + X + N*4, writes T' + X) but showed no such dependence: T' stays where it is.
+        if (M->n == 65536) base += ((size_t)0xC0000 - (size_t)(((uintptr_t)base - (uintptr_t)res) & 0xFFFFF)) & 0xFFFFF;
+        base += align256(M->ws_shift);
         cplx* T2 = (cplx*)base; base += t2_bytes;
         int64_t* res_tmp = (int64_t*)base; base += rtmp_bytes;
         int64_t* small2 = (int64_t*)base; base += small2_bytes;

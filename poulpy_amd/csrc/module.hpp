@@ -136,6 +136,7 @@ struct pz_module {
     unsigned long long* margin = nullptr;  // device word, bits of max |x-round(x)|
     bool probe = false;
     size_t chunk = 0;
+    size_t ws_shift = 0;   // diagnostic: extra bytes of padding in front of T2' in the fused workspace (placement experiments)
     int dbg_stages = 7;  // diagnostic: bit 0 pass 1, bit 1 middle, bit 2 tail of the fused pipeline (results invalid unless 7)
     // prepared keys the caller declared immutable (pz_module_pin_key): their row-sliced copies for the fused pipeline
     struct PinnedKey { const void* key; pz::cplx* sliced; size_t bytes; };
