@@ -241,6 +241,7 @@ void pz_module_free(pz_module* M) {
     if (M->comm) (void)pz_comm_destroy(M);
     for (auto& t : M->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
     for (auto e : M->event_pool) (void)hipEventDestroy(e);
+    for (auto& pt : M->phase_tune) { (void)hipEventDestroy(pt.e0); (void)hipEventDestroy(pt.e1); }
     for (auto& ge : M->graphs) {
         if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
         if (ge.graph) (void)hipGraphDestroy(ge.graph);
@@ -576,7 +577,7 @@ static FusedWs fused_ws(const pz_module* M, const pz_glwe_op_params* p, const Op
     w.rtmp = au ? align256(chunk * n8 * std::max((size_t)s.cols_out * p->res_size, body_limbs)) : 0;
     // cross-base output: the tail's key-base digits (cols_out x key_size limbs per ciphertext) before the cross-base pass
     w.small2 = p->res_base2k != p->key_base2k ? align256(chunk * n8 * s.cols_out * ksz) : 0;
-    w.total = w.key + w.conv + w.t + w.t2 + w.rtmp + w.small2 + kMidDummyBytes + align256(M->ws_shift) + ((size_t)1 << 20);
+    w.total = w.key + w.conv + w.t + w.t2 + w.rtmp + w.small2 + kMidDummyBytes + align256(M->ws_shift) + ((size_t)4 << 20);
     return w;
 }
 // keyswitch: 0 external product, 1 key switch, 2 automorphism family, 3 tensor relinearization.  The figure is what the call reserves
@@ -675,10 +676,55 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
         // Placement of T2' relative to the result.  The tail of ciphertext b reads T2' + X and writes res + X and res + X + N*4 bytes
         // (the two coefficient halves), the same X for every workgroup; with both buffers on the same 1 MiB phase (large allocations
         // are 2 MiB aligned) the read and the two write streams of every workgroup meet on the same HBM channels: tail 3.55 ms per
-        // 1024 ciphertexts in most processes, 3.14 in some, depending on the physical placement.  With T2' three quarters of a MiB
-        // out of phase it is 3.08 - 3.25 ms in every process (measured at N = 2^16: profiles/r02_t2_placement.txt; applied there).  Pass 1 has
-        // the mirrored structure (reads a + X, a + X + N*4, writes T' + X) but showed no such dependence: T' stays where it is.
-        if (M->n == 65536) base += ((size_t)0xC0000 - (size_t)(((uintptr_t)base - (uintptr_t)res) & 0xFFFFF)) & 0xFFFFF;
+        // 1024 ciphertexts in most processes, 3.14 in some, depending on the physical pages (profiles/r02_t2_placement.txt); the
+        // middle kernel (T' -> T2') shows a smaller effect of the same kind.  Which phase is best depends on the placement too, so it is
+        // MEASURED: after a warm-up call, the next kPhaseCount calls with a given argument set each run with one candidate phase and time middle kernel + tail
+        // with two events (read at the next call); from then on the best one is used.  Results do not depend on the phase.
+        static const size_t kPhase[] = {0xC0000, 0x40000, 0x80000, 0x140000, 0x1C0000, 0x240000, 0x340000, 0x3C0000};
+        constexpr int kPhaseCount = (int)(sizeof(kPhase) / sizeof(kPhase[0]));
+        int phase_idx = 0;
+        pz_module::PhaseTune* tune = nullptr;
+        bool tune_measure = false;
+        static const int tune_env = getenv("POULPY_DBG_PHASE_TUNE") ? atoi(getenv("POULPY_DBG_PHASE_TUNE")) : 1;
+        if (M->n >= 32768 && tune_env && M->phase_tuning && !M->timing) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(M->stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusActive; }
+            if (cs == hipStreamCaptureStatusNone) {
+                KeyHash kh;
+                kh.add((const void*)res); kh.add((const void*)a); kh.add(batch); kh.add(chunk); kh.add(npi); kh.add(npo); kh.add(*p); kh.add(ks);
+                kh.add(M->ws);
+                for (auto& e : M->phase_tune) if (e.key == kh.h) tune = &e;
+                if (!tune) {
+                    if (M->phase_tune.size() >= 16) {
+                        size_t lru = 0;
+                        for (size_t i = 1; i < M->phase_tune.size(); ++i) if (M->phase_tune[i].stamp < M->phase_tune[lru].stamp) lru = i;
+                        (void)hipEventDestroy(M->phase_tune[lru].e0); (void)hipEventDestroy(M->phase_tune[lru].e1);
+                        M->phase_tune.erase(M->phase_tune.begin() + (long)lru);
+                    }
+                    pz_module::PhaseTune e{kh.h, 0, 0, 1e30f, -1, nullptr, nullptr, 0};
+                    if (hipEventCreate(&e.e0) == hipSuccess && hipEventCreate(&e.e1) == hipSuccess) {
+                        M->phase_tune.push_back(e);
+                        tune = &M->phase_tune.back();
+                    } else (void)hipGetLastError();
+                }
+                if (tune) {
+                    tune->stamp = ++M->phase_clock;
+                    if (tune->pending >= 0) {   // the previous call's measurement
+                        float ms = 0.f;
+                        if (hipEventSynchronize(tune->e1) == hipSuccess && hipEventElapsedTime(&ms, tune->e0, tune->e1) == hipSuccess) {
+                            if (tune_env > 1) fprintf(stderr, "[phase tune] phase %#zx: %.3f ms\n", kPhase[tune->pending], ms);
+                            if (ms < tune->best_ms) { tune->best_ms = ms; tune->best = tune->pending; }
+                        } else (void)hipGetLastError();
+                        tune->pending = -1;
+                    }
+                    // call 0 warms up (first touch of the workspace: not representative), calls 1 .. kPhaseCount try the candidates
+                    if (tune->calls == 0) { phase_idx = 0; tune->calls = 1; }
+                    else if (tune->calls <= kPhaseCount) { phase_idx = tune->calls - 1; tune_measure = true; }
+                    else phase_idx = tune->best;
+                }
+            }
+        }
+        base += ((size_t)kPhase[phase_idx] - (size_t)(((uintptr_t)base - (uintptr_t)res) & 0x3FFFFF)) & 0x3FFFFF;
         base += align256(M->ws_shift);
         cplx* T2 = (cplx*)base; base += t2_bytes;
         int64_t* res_tmp = (int64_t*)base; base += rtmp_bytes;
@@ -690,6 +736,7 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
         for (auto& pk : M->pinned)
             if (pk.key == (const void*)pmat && pk.sliced && pk.bytes == (size_t)nrows * ncols * (size_t)M->n * 8) { Pp = pk.sliced; pinned = true; }
         if (!pinned && (M->dbg_stages & 2)) PZ_TRY(launch_permute_pmat(M, pmat, Pp, nrows * ncols));
+        if (tune_measure) PZ_HIP(hipEventRecord(tune->e0, M->stream));
         for (size_t b0 = 0; b0 < batch; b0 += chunk) {
             const int nb = (int)std::min(chunk, batch - b0);
             DV av{(void*)(a + (long long)b0 * a_bs), a_bs, s.cols_a, (int)p->a_size};
@@ -771,6 +818,11 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
                 PZ_TRY(launch_automorphism(M, nb * (int)p->res_size * s.cols_out, (const long long*)res_tmp, tm, (long long*)res_b, tm, au_g,
                                            au->mode == 0 ? 1 : 0));
             }
+        }
+        if (tune_measure) {
+            PZ_HIP(hipEventRecord(tune->e1, M->stream));
+            tune->pending = phase_idx;
+            tune->calls++;
         }
         return PZ_OK;
     }

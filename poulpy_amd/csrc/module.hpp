@@ -166,6 +166,12 @@ struct pz_module {
     uint64_t graph_clock = 0, graph_epoch = 0;  // epoch: bumped by anything that changes what a captured call would launch
     bool graphs_on = true;
     unsigned long long graph_launches = 0;
+    // Placement of T2' relative to the result buffer (api.hip, fused pipeline): after a warm-up call, kPhaseCount calls with a given argument
+    // set each try one phase and time the middle kernel + tail with events; later calls use the best one.
+    struct PhaseTune { uint64_t key; int calls; int best; float best_ms; int pending; hipEvent_t e0, e1; uint64_t stamp; };
+    std::vector<PhaseTune> phase_tune;
+    uint64_t phase_clock = 0;
+    bool phase_tuning = true;
 };
 
 namespace pz {
