@@ -686,7 +686,7 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
         pz_module::PhaseTune* tune = nullptr;
         bool tune_measure = false;
         static const int tune_env = getenv("POULPY_DBG_PHASE_TUNE") ? atoi(getenv("POULPY_DBG_PHASE_TUNE")) : 1;
-        if (M->n >= 32768 && tune_env && M->phase_tuning && !M->timing) {
+        if (M->n >= 32768 && tune_env && M->phase_tuning) {
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(M->stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusActive; }
             if (cs == hipStreamCaptureStatusNone) {
@@ -718,7 +718,9 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
                         tune->pending = -1;
                     }
                     // call 0 warms up (first touch of the workspace: not representative), calls 1 .. kPhaseCount try the candidates
-                    if (tune->calls == 0) { phase_idx = 0; tune->calls = 1; }
+                    // (under per-launch kernel timing nothing is measured: the instrumented pass uses what the plain calls found)
+                    if (M->timing) phase_idx = tune->calls > kPhaseCount ? tune->best : 0;
+                    else if (tune->calls == 0) { phase_idx = 0; tune->calls = 1; }
                     else if (tune->calls <= kPhaseCount) { phase_idx = tune->calls - 1; tune_measure = true; }
                     else phase_idx = tune->best;
                 }
