@@ -190,10 +190,13 @@ int pz_module_new_on_device(uint64_t n, int device, pz_module** out) {
 int pz_module_clone(pz_module* P, pz_module** out) {
     if (!P || !out) return fail(PZ_ERR_INVALID, "null argument");
     *out = nullptr;
+    pz_module* M = nullptr;
+    {
+    // (P's lock is released before the sibling is registered: pz_free_bytes takes the registry lock first, then module locks)
     std::lock_guard<std::mutex> lock_(P->mu);
     PZ_HIP(hipSetDevice(P->device));
     PZ_TRY(ensure_w2n(P));   // built lazily otherwise: the siblings must agree on who owns it
-    pz_module* M = new pz_module();
+    M = new pz_module();
     M->n = P->n; M->m = P->m; M->device = P->device; M->plan = P->plan;
     M->tw1 = P->tw1; M->tw1inv = P->tw1inv; M->wL1 = P->wL1; M->wL2 = P->wL2; M->tw12 = P->tw12; M->tw12t = P->tw12t; M->w2n = P->w2n;
     M->tables_ref = P->tables_ref;
@@ -205,7 +208,9 @@ int pz_module_clone(pz_module* P, pz_module** out) {
         if (hipMalloc(&M->margin, 8) != hipSuccess) { r = fail(PZ_ERR_HIP, "margin alloc failed"); break; }
         if (hipMemset(M->margin, 0, 8) != hipSuccess) { r = fail(PZ_ERR_HIP, "margin memset failed"); break; }
     } while (0);
-    if (r != PZ_OK) { pz_module_free(M); return r; }
+    if (r != PZ_OK) { M->tables_ref->fetch_sub(1); M->tables_ref = nullptr; M->tw1 = M->tw1inv = M->wL1 = M->wL2 = M->tw12 = M->tw12t = M->w2n = nullptr; }
+    if (r != PZ_OK) { pz_module* dead = M; M = nullptr; pz_module_free(dead); return r; }
+    }
     {
         std::lock_guard<std::mutex> g(g_modules_mu);
         g_modules.push_back(M);
