@@ -240,6 +240,9 @@ void pz_module_free(pz_module* M) {
     }
     for (void* p : {M->ws, M->ws2, (void*)M->margin})
         if (p) (void)hipFree(p);
+    if (M->s_owned)
+        for (void* p : {(void*)M->s_tw1, (void*)M->s_tw1inv, (void*)M->s_tw12t, (void*)M->s_wL2})
+            if (p) (void)hipFree(p);
     for (auto& c : M->arena) (void)hipFree(c.p);
     for (auto& k : M->pinned) if (k.sliced) (void)hipFree(k.sliced);
     for (auto& mr : M->mirrors) if (mr.dev) (void)hipFree(mr.dev);
@@ -832,6 +835,32 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
             tune->calls++;
         }
         return PZ_OK;
+    }
+
+    // ---- N = 1024 / 2048: no pipeline plan (their per-op split is 16 x 32 / 32 x 32), but whole polynomials fit LDS: the two-kernel
+    // pipeline of device_small.hpp with its own m = M1 x 128 tables.  Plain external product / key switch, dsize 1, one base2k, <= 4 key
+    // limbs; anything else stays on the five-kernel path below ----
+    {
+        static const int small_env = getenv("POULPY_DBG_SMALL") ? atoi(getenv("POULPY_DBG_SMALL")) : 1;
+        if (small_env && M->small_path && M->fuse_mid && M->fuse_tail && M->n < 4096 && !au && !tensor && !digits && !cross_out && !s.convert &&
+            !M->probe && M->dbg_stages == 7 && small_supported(M, npi, ksz)) {
+            const size_t n8 = (size_t)M->n * 8;
+            const size_t key_bytes = align256((size_t)nrows * ncols * n8), s_bytes = align256(chunk * npi * (size_t)M->m * sizeof(cplx));
+            PZ_TRY(ws_reserve(M, key_bytes + s_bytes));
+            cplx* Pp = (cplx*)M->ws;
+            cplx* S = (cplx*)((char*)M->ws + key_bytes);
+            PZ_TRY(launch_small_permute(M, pmat, Pp, nrows * ncols));
+            for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+                const int nb = (int)std::min(chunk, batch - b0);
+                const int64_t* a_b = a + (long long)b0 * a_bs;
+                PolyMap sm{(int)p->a_size, s.cols_in, a_bs, (long long)s.cols_a * n, n, n * s.a_col0};
+                PZ_TRY(launch_small_fwd(M, nb * npi, (const long long*)a_b, sm, S));
+                PZ_TRY(launch_small_inv(M, nb, S, Pp, npi, nrows, ncols, s.cols_out, ksz, (long long*)(res + (long long)b0 * res_bs), res_bs,
+                                        s.cols_out, (int)p->res_size, ks ? (const long long*)a_b : nullptr, a_bs, s.cols_a, (int)p->a_size,
+                                        (int)p->res_base2k, body_col));
+            }
+            return PZ_OK;
+        }
     }
 
     const OpWs w = op_ws(M, p, s, chunk, ks, au != nullptr);

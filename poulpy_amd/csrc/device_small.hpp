@@ -1,5 +1,5 @@
-// device_small.hpp — two-kernel GLWE product pipeline for N = 4096 (m = 2048 = 16 x 128), where a whole polynomial (32 KiB of
-// spectrum) fits in LDS.  The three-kernel pipeline moves 1.5 MiB per ciphertext at BASELINE configs[1] (N = 4096, 4 limbs: limbs in,
+// device_small.hpp — two-kernel GLWE product pipeline for N = 1024 / 2048 / 4096 (m = M1 x 128, M1 = 4 / 8 / 16), where a whole
+// polynomial (<= 32 KiB of spectrum) fits in LDS.  The three-kernel pipeline moves 1.5 MiB per ciphertext at BASELINE configs[1] (N = 4096, 4 limbs: limbs in,
 // T', T' again, T2', T2' again, limbs out); here the spectra cross HBM once:
 //   k_small_fwd : i64 limbs -> full forward transform in LDS (column pass in registers, row pass as in the middle kernel) -> S
 //   k_small_inv : one workgroup per (ciphertext, output column): pointwise product with the row-sliced key in registers (no LDS:
@@ -14,7 +14,7 @@
 
 namespace pz {
 
-constexpr int kSmallM1 = 16, kSmallM2 = 128, kSmallRS = 16 * 9;   // row stride as in k_mid128 (z[k1][o] at k1*9 + o)
+constexpr int kSmallM2 = 128, kSmallRS = 16 * 9;   // row stride as in k_mid128 (z[k1][o] at k1*9 + o)
 
 struct SmallFwdArgs {
     const long long* src;
@@ -26,62 +26,78 @@ struct SmallFwdArgs {
     const cplx* wL2;     // exp(2 pi i t / 128)
 };
 
-// 256 threads = 2 polynomials x 128 threads; LDS 2 x 16 rows x 144 points + wL2
+// 256 threads = 2 polynomials x 128 threads; LDS 2 x M1 rows x 144 points + wL2
+template <int M1>
 __global__ void __launch_bounds__(256, 2) k_small_fwd(SmallFwdArgs g) {
     constexpr int M2 = kSmallM2, RS = kSmallRS;
-    constexpr long long m = (long long)kSmallM1 * kSmallM2;
+    constexpr long long m = (long long)M1 * kSmallM2;
     extern __shared__ cplx lds[];
     const int tid = threadIdx.x, pl = tid >> 7, t = tid & 127;
-    cplx* wl = lds + 2 * 16 * RS;
+    cplx* wl = lds + 2 * M1 * RS;
     if (tid < M2) wl[tid] = g.wL2[tid];
     const int p = blockIdx.x * 2 + pl;
     const bool active = p < g.npolys;
     const long long* a = g.src + map_off(g.smap, active ? p : g.npolys - 1);
-    cplx* buf = lds + pl * 16 * RS;
-    // ---- column pass: thread t owns column j2 = t, 16 points over j1 (k_fwd_pass1 with one radix-16 butterfly)
+    cplx* buf = lds + pl * M1 * RS;
+    // ---- column pass: thread t owns column j2 = t, M1 points over j1 (k_fwd_pass1 with one radix-M1 butterfly)
     {
-        long long re[16], im[16];
+        long long re[M1], im[M1];
 #pragma unroll
-        for (int j1 = 0; j1 < 16; ++j1) {
+        for (int j1 = 0; j1 < M1; ++j1) {
             re[j1] = ld_stream(a + j1 * M2 + t);
             im[j1] = ld_stream(a + m + j1 * M2 + t);
         }
-        cplx v[16];
+        cplx v[M1];
 #pragma unroll
-        for (int j1 = 0; j1 < 16; ++j1) v[j1] = cmul(make_double2((double)re[j1], (double)im[j1]), g.tw1[j1]);
-        Bfly<16, false>::run(v);
+        for (int j1 = 0; j1 < M1; ++j1) v[j1] = cmul(make_double2((double)re[j1], (double)im[j1]), g.tw1[j1]);
+        Bfly<M1, false>::run(v);
 #pragma unroll
-        for (int q1 = 0; q1 < 16; ++q1) buf[q1 * RS + t] = cmul(v[q1], g.tw12t[q1 * M2 + t]);
+        for (int q1 = 0; q1 < M1; ++q1) buf[q1 * RS + t] = cmul(v[q1], g.tw12t[q1 * M2 + t]);
     }
     __syncthreads();
-    // ---- row pass: 8 lanes per row, exactly the forward pass of k_mid128
+    // ---- row pass: 8 lanes per row, exactly the forward pass of k_mid128 (8 * M1 of the polynomial's 128 threads)
     const int row = t >> 3, o = t & 7;
-    cplx* rowbuf = buf + row * RS;
-    cplx x[16];
+    if (row < M1) {
+        cplx* rowbuf = buf + row * RS;
+        cplx x[16];
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) x[n1] = rowbuf[o + 8 * n1];
-    row_sync();
-    Bfly<16, false>::run(x);
+        for (int n1 = 0; n1 < 16; ++n1) x[n1] = rowbuf[o + 8 * n1];
+        row_sync();
+        Bfly<16, false>::run(x);
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) {
-        cplx v = x[k1];
-        if (k1 > 0) v = cmul(v, wl[o * k1]);
-        rowbuf[k1 * 9 + o] = v;
-    }
-    row_sync();
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int oo = 0; oo < 8; ++oo) x[8 * h + oo] = rowbuf[(o + 8 * h) * 9 + oo];
-    Bfly<8, false>::run(x);
-    Bfly<8, false>::run(x + 8);
-    if (active) {
-        cplx* dst = g.S + (long long)p * m + (long long)row * M2 + o;
+        for (int k1 = 0; k1 < 16; ++k1) {
+            cplx v = x[k1];
+            if (k1 > 0) v = cmul(v, wl[o * k1]);
+            rowbuf[k1 * 9 + o] = v;
+        }
+        row_sync();
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int k2 = 0; k2 < 8; ++k2) dst[8 * h + 16 * k2] = x[8 * h + k2];   // S[q1][q2 = o + 8h + 16 k2]: re-read twice, kept cacheable
+            for (int oo = 0; oo < 8; ++oo) x[8 * h + oo] = rowbuf[(o + 8 * h) * 9 + oo];
+        Bfly<8, false>::run(x);
+        Bfly<8, false>::run(x + 8);
+        if (active) {
+            cplx* dst = g.S + (long long)p * m + (long long)row * M2 + o;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) dst[8 * h + 16 * k2] = x[8 * h + k2];   // S[q1][q2 = o + 8h + 16 k2]: re-read twice, kept cacheable
+        }
     }
+}
+
+// standard device VmpPMat  P[p][q1 + M1*q2]  ->  P'[q1][p][q2]  for the ring degrees without a pipeline plan (one thread per point)
+template <int M1>
+__global__ void __launch_bounds__(256) k_small_permute(const cplx* __restrict__ P, cplx* __restrict__ Pp, int npolys) {
+    constexpr int M2 = kSmallM2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // over [q1][p][q2]
+    const long long total = (long long)M1 * npolys * M2;
+    if (idx >= total) return;
+    const int q2 = (int)(idx % M2);
+    const long long t = idx / M2;
+    const int p = (int)(t % npolys), q1 = (int)(t / npolys);
+    Pp[idx] = P[(long long)p * (M1 * M2) + q1 + M1 * q2];
 }
 
 struct SmallInvArgs {
@@ -98,29 +114,31 @@ struct SmallInvArgs {
     int dbg;                     // timing ablation (POULPY_DBG_SMALL_SKIP; results invalid): 1 no key loads, 2 no S loads, 4 no stores, 8 no LDS phases
 };
 
-// 1024 threads (16 waves: the product phase is latency-bound with fewer), one workgroup per CU: LDS holds the KS output polynomials of one (ciphertext, column) (KS x 16 rows x 144 points + wL2,
-// 149.5 KiB at KS = 4).  Variants that kept two workgroups per CU — two limbs in LDS at a time, the other accumulators in registers, or one
+// 64 M1 threads (1024 at N = 4096: 16 waves, the product phase is latency-bound with fewer); LDS holds the KS output polynomials of one
+// (ciphertext, column): KS x M1 rows x 144 points + wL2 — 149.5 KiB at N = 4096, KS = 4 (one workgroup per CU), 75.7 KiB at N = 2048 (two),
+// 38.9 KiB at N = 1024 (four).  Variants that kept two workgroups per CU — two limbs in LDS at a time, the other accumulators in registers, or one
 // product pass per limb pair — either spilled (128 accumulator registers at 256 threads) or re-read S from HBM (0.26 - 0.36 ms per 1024
 // ciphertexts against 0.35 ms for the whole three-kernel pipeline).  Also tried: a persistent workgroup in two roles of 512 threads (role A:
 // the next item's product in registers, role B: this item's transforms in the tile, hand-over between barriers) — at the 128-VGPR cap of a
 // 1024-thread workgroup role A's 64 accumulator registers leave no room for prefetch slots (spills, 0.93 ms at 4 limbs; 0.25 vs 0.17 ms
 // at 3).  KS = key limbs (g.ksz).
-template <int KS>
-__global__ void __launch_bounds__(1024) k_small_inv(SmallInvArgs g) {
+template <int M1, int KS>
+__global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
+    constexpr int NT = 64 * M1;          // 2 product positions per thread (m = 128 M1 points)
     constexpr int M2 = kSmallM2, RS = kSmallRS, L = KS;
-    constexpr long long m = (long long)kSmallM1 * kSmallM2, n = 2 * m;
+    constexpr long long m = (long long)M1 * kSmallM2, n = 2 * m;
     extern __shared__ cplx lds[];
     const int tid = threadIdx.x;
     // both columns of a ciphertext on one XCD (consecutive workgroup ids go to consecutive XCDs): the second one finds S in its L2
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int b = (slot / g.cols_out) * 8 + xcd, col = slot % g.cols_out;
     if (b >= g.batch) return;
-    cplx* wl = lds + KS * 16 * RS;
+    cplx* wl = lds + KS * M1 * RS;
     if (tid < M2) wl[tid] = g.wL2[tid];
     const int k = g.base2k;
     const int row_max = min(g.nrows, g.npi);
-    // ---------------- product, one pass over S: acc[l][j] = sum_r S[r][pos_j] * P'[q1_j][r][l * cols_out + col][q2_j], pos_j = tid + 1024 j ----------------
-    const int pq2 = tid & 127, pq1 = tid >> 7;   // q1 = pq1 + 8 j
+    // ---------------- product, one pass over S: acc[l][j] = sum_r S[r][pos_j] * P'[q1_j][r][l * cols_out + col][q2_j], pos_j = tid + NT j ----------------
+    const int pq2 = tid & 127, pq1 = tid >> 7;   // q1 = pq1 + (M1 / 2) j
     cplx acc[KS][2];
 #pragma unroll
     for (int l = 0; l < KS; ++l)
@@ -128,7 +146,7 @@ __global__ void __launch_bounds__(1024) k_small_inv(SmallInvArgs g) {
         for (int j = 0; j < 2; ++j) acc[l][j] = make_double2(0.0, 0.0);
     {
         const cplx* Sb = g.S + (long long)b * g.npi * m + tid;
-        const long long qstride = (long long)8 * g.nrows * g.ncols * M2;   // q1 advances by 8 per j
+        const long long qstride = (long long)(M1 / 2) * g.nrows * g.ncols * M2;   // q1 advances by M1 / 2 per j
         const long long prow = (long long)g.ncols * M2;
         const long long lstride = (long long)g.cols_out * M2;
         const cplx* kp = g.Pp + ((long long)pq1 * g.nrows * g.ncols + col) * M2 + pq2;
@@ -136,7 +154,7 @@ __global__ void __launch_bounds__(1024) k_small_inv(SmallInvArgs g) {
         cplx aA, kA[KS], aB, kB[KS];
 #define PZ_SMALL_LOAD(A_, K_, R_, J_)                                                              \
     {                                                                                               \
-        if (!(g.dbg & 2)) A_ = Sb[(long long)(R_) * m + 1024 * (J_)];                               \
+        if (!(g.dbg & 2)) A_ = Sb[(long long)(R_) * m + NT * (J_)];                                 \
         if (!(g.dbg & 1)) { _Pragma("unroll") for (int l = 0; l < KS; ++l) K_[l] = kp[(long long)(R_) * prow + l * lstride + (J_) * qstride]; } \
     }
 #define PZ_SMALL_USE(A_, K_, J_)                                                                   \
@@ -168,13 +186,13 @@ __global__ void __launch_bounds__(1024) k_small_inv(SmallInvArgs g) {
 #pragma unroll
     for (int l = 0; l < KS; ++l)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) lds[(l * 16 + pq1 + 8 * j) * RS + pq2] = acc[l][j];
+        for (int j = 0; j < 2; ++j) lds[(l * M1 + pq1 + (M1 / 2) * j) * RS + pq2] = acc[l][j];
     __syncthreads();
     // ---------------- inverse row pass (k_mid128) of the KS polynomials, x conj tw12, back into the tile as T2[q1][j2] ----------------
     {
-        const int rp = tid >> 7, rrow = (tid & 127) >> 3, ro = tid & 7;
+        const int rp = tid / (8 * M1), rrow = (tid % (8 * M1)) >> 3, ro = tid & 7;   // 8 M1 threads per polynomial
         if (rp < KS) {
-            cplx* rowbuf = lds + (rp * 16 + rrow) * RS;
+            cplx* rowbuf = lds + (rp * M1 + rrow) * RS;
             cplx u[16];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -203,26 +221,27 @@ __global__ void __launch_bounds__(1024) k_small_inv(SmallInvArgs g) {
         }
     }
     __syncthreads();
-    // ---------------- inverse column pass + rounding, all limbs at once: thread = (limb, column j2); the 32 integers go back into the
-    // tile in place of the column's 16 complex values (same bytes) ----------------
-    {
-        const int cl = tid >> 7, cj = tid & 127;
-        if (cl < KS) {
-            cplx v[16];
+    // ---------------- inverse column pass + rounding, NT / 128 limbs at a time: thread = (limb, column j2); the 2 M1 integers go back
+    // into the tile in place of the column's M1 complex values (same bytes) ----------------
 #pragma unroll
-            for (int q1 = 0; q1 < 16; ++q1) v[q1] = lds[(cl * 16 + q1) * RS + cj];
-            Bfly<16, true>::run(v);
+    for (int cl0 = 0; cl0 < KS; cl0 += NT / 128) {
+        const int cl = cl0 + (tid >> 7), cj = tid & 127;
+        if (cl < KS) {
+            cplx v[M1];
+#pragma unroll
+            for (int q1 = 0; q1 < M1; ++q1) v[q1] = lds[(cl * M1 + q1) * RS + cj];
+            Bfly<M1, true>::run(v);
             // |component of v * tw1inv| <= (|v.x| + |v.y|) / m <= big: below 2^51 the 3-instruction conversion is exact.  A SUM, so that a
             // NaN or an infinity anywhere reaches `big` (fmax would drop a NaN) and selects the saturating conversion
             double big = 0.0;
 #pragma unroll
-            for (int j1 = 0; j1 < 16; ++j1) big += fabs(v[j1].x) + fabs(v[j1].y);
+            for (int j1 = 0; j1 < M1; ++j1) big += fabs(v[j1].x) + fabs(v[j1].y);
             big *= 1.0 / (double)m;
             longlong2* out = reinterpret_cast<longlong2*>(lds);
 #define PZ_SMALL_ROUND(CONVERT)                                                                               \
-    _Pragma("unroll") for (int j1 = 0; j1 < 16; ++j1) {                                                      \
+    _Pragma("unroll") for (int j1 = 0; j1 < M1; ++j1) {                                                      \
         const cplx val = cmul(v[j1], g.tw1inv[j1]);                                                          \
-        out[(cl * 16 + j1) * RS + cj] = make_longlong2(CONVERT(round_half_away(val.x)), CONVERT(round_half_away(val.y))); \
+        out[(cl * M1 + j1) * RS + cj] = make_longlong2(CONVERT(round_half_away(val.x)), CONVERT(round_half_away(val.y))); \
     }
             if (big < 2251799813685247.0) {   // 2^51 - 1 (false for NaN too)
                 PZ_SMALL_ROUND(fast_i64_from_integral)
@@ -234,7 +253,8 @@ __global__ void __launch_bounds__(1024) k_small_inv(SmallInvArgs g) {
     }
     __syncthreads();
     // ---------------- (+ key-switch body), carry chain from the last limb up, stores: thread = (column j2, component, j1 parity), 8 coefficients ----------------
-    const int cj2 = tid & 127, ch = (tid >> 7) & 1, jq = tid >> 8;   // component 0: coefficients j < m, 1: j >= m; j1 = 4 e + jq
+    constexpr int JG = M1 / 4;   // thread groups over j1 (NT / 256): this thread's outputs are j1 = JG e + jq, e < 4
+    const int cj2 = tid & 127, ch = (tid >> 7) & 1, jq = tid >> 8;   // component 0: coefficients j < m, 1: j >= m
     long long carry[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) carry[u] = 0;
@@ -246,7 +266,7 @@ __global__ void __launch_bounds__(1024) k_small_inv(SmallInvArgs g) {
     // limbs of res beyond the precision of the big value are zero (normalize.rs:118-120)
     for (int j = L; j < g.res_size; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) res_col[(long long)j * res_ls + 4 * e * M2] = 0;
+        for (int e = 0; e < 4; ++e) res_col[(long long)j * res_ls + JG * e * M2] = 0;
     const unsigned long long half = 1ull << (k - 1), mask = (1ull << k) - 1;
     const long long* xin = reinterpret_cast<const long long*>(lds) + ch;
 #pragma unroll
@@ -257,8 +277,8 @@ __global__ void __launch_bounds__(1024) k_small_inv(SmallInvArgs g) {
         const bool first = j == L - 1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            long long x = xin[2 * ((j * 16 + 4 * e + jq) * RS + cj2)];
-            if (add_small) x = (long long)((unsigned long long)x + (unsigned long long)sm_limb[4 * e * M2]);
+            long long x = xin[2 * ((j * M1 + JG * e + jq) * RS + cj2)];
+            if (add_small) x = (long long)((unsigned long long)x + (unsigned long long)sm_limb[JG * e * M2]);
             long long& cy = carry[e];
             const unsigned long long y = (unsigned long long)x + half;
             const long long d = (long long)(y & mask) - (long long)half;
@@ -269,7 +289,7 @@ __global__ void __launch_bounds__(1024) k_small_inv(SmallInvArgs g) {
                 const unsigned long long y2 = (unsigned long long)d + (unsigned long long)cy + half;
                 const long long x1 = (long long)(y2 & mask) - (long long)half;
                 cy = (long long)((unsigned long long)cr + (unsigned long long)((long long)y2 >> k));
-                if (writes && (!(g.dbg & 4) || x1 == 0x7fffffffffffLL)) st_stream(res_col + (long long)j * res_ls + 4 * e * M2, x1);
+                if (writes && (!(g.dbg & 4) || x1 == 0x7fffffffffffLL)) st_stream(res_col + (long long)j * res_ls + JG * e * M2, x1);
             }
         }
     }

@@ -79,9 +79,11 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
                unsigned perm_mul = 0, unsigned perm_add = 0, const MidDigits* dg = nullptr, const MidBr* br = nullptr);
 
 // ---- launch_small.hip ---------------------------------------------------------------------------------------------
-// two-kernel pipeline for N = 4096 (device_small.hpp): full forward transform -> S[poly][q1][q2]; product with the row-sliced key +
+// two-kernel pipeline for N = 1024 / 2048 / 4096 (device_small.hpp): full forward transform -> S[poly][q1][q2]; product with the row-sliced key +
 // full inverse transform + carry chain per (ciphertext, output column).  dsize 1, one base2k, <= 4 key limbs.
 bool small_supported(const pz_module* M, int npi, int key_limbs);
+// standard device VmpPMat -> P'[q1][p][q2] with m = M1 x 128 (ring degrees whose plan is not M1 x 128: no launch_permute_pmat there)
+int launch_small_permute(pz_module* M, const double* P, cplx* Pp, int npolys);
 int launch_small_fwd(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* S);
 int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int npi, int nrows, int ncols, int cols_out, int ksz,
                      long long* res, long long res_bs, int res_cols, int res_size, const long long* small, long long small_bs,

@@ -1,54 +1,114 @@
-// launch_small.hip — the two-kernel GLWE product pipeline for N = 4096 (device_small.hpp).
+// launch_small.hip — the two-kernel GLWE product pipeline for N = 1024 / 2048 / 4096 (device_small.hpp).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "internal.hpp"
 #include "device_small.hpp"
 
 namespace pz {
 
-bool small_supported(const pz_module* M, int npi, int npo_limbs) {
-    return M->plan.m1 == kSmallM1 && M->plan.m2 == kSmallM2 && npi >= 1 && npo_limbs >= 1 && npo_limbs <= 4;
+static inline int small_m1(const pz_module* M) { return (int)(M->m / kSmallM2); }
+
+bool small_supported(const pz_module* M, int npi, int key_limbs) {
+    const int m1 = small_m1(M);
+    return (M->m % kSmallM2) == 0 && (m1 == 4 || m1 == 8 || m1 == 16) && npi >= 1 && key_limbs >= 1 && key_limbs <= 4;
+}
+
+// The small pipeline splits m = M1 x 128 whatever the module's own plan is (N = 1024 / 2048 use 16 x 32 / 32 x 32 for the per-op kernels):
+// its four tables are built on first use — the module's own where the plan already is M1 x 128 (N = 4096).
+static int ensure_small_tables(pz_module* M) {
+    if (M->s_tw1) return PZ_OK;
+    const int m1 = small_m1(M);
+    if (M->plan.m1 == m1 && M->plan.m2 == kSmallM2) {
+        M->s_tw1 = M->tw1; M->s_tw1inv = M->tw1inv; M->s_tw12t = M->tw12t; M->s_wL2 = M->wL2;
+        M->s_owned = false;
+        return PZ_OK;
+    }
+    const long long m = (long long)M->m;
+    std::vector<cplx> h((size_t)m1);
+    double c, s;
+    for (int j1 = 0; j1 < m1; ++j1) { root_of_unity(j1, 4ll * m1, c, s); h[(size_t)j1] = make_double2(c, s); }
+    PZ_TRY(upload_table(&M->s_tw1, h));
+    const double inv_m = 1.0 / (double)m;
+    for (int j1 = 0; j1 < m1; ++j1) { h[(size_t)j1].x = h[(size_t)j1].x * inv_m; h[(size_t)j1].y = -h[(size_t)j1].y * inv_m; }
+    PZ_TRY(upload_table(&M->s_tw1inv, h));
+    h.resize(kSmallM2);
+    for (int t = 0; t < kSmallM2; ++t) { root_of_unity(t, kSmallM2, c, s); h[(size_t)t] = make_double2(c, s); }
+    PZ_TRY(upload_table(&M->s_wL2, h));
+    h.resize((size_t)m);
+    for (long long q1 = 0; q1 < m1; ++q1)
+        for (long long j2 = 0; j2 < kSmallM2; ++j2) {
+            root_of_unity(j2 * (4 * q1 + 1), 4 * m, c, s);
+            h[(size_t)(q1 * kSmallM2 + j2)] = make_double2(c, s);
+        }
+    PZ_TRY(upload_table(&M->s_tw12t, h));
+    M->s_owned = true;
+    return PZ_OK;
+}
+
+int launch_small_permute(pz_module* M, const double* P, cplx* Pp, int npolys) {
+    const long long total = (long long)M->m * npolys;
+    KTimer kt(M, PZ_K_ELEMENTWISE);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    switch (small_m1(M)) {
+        case 4: hipLaunchKernelGGL(k_small_permute<4>, grid, dim3(256), 0, M->stream, reinterpret_cast<const cplx*>(P), Pp, npolys); break;
+        case 8: hipLaunchKernelGGL(k_small_permute<8>, grid, dim3(256), 0, M->stream, reinterpret_cast<const cplx*>(P), Pp, npolys); break;
+        default: hipLaunchKernelGGL(k_small_permute<16>, grid, dim3(256), 0, M->stream, reinterpret_cast<const cplx*>(P), Pp, npolys); break;
+    }
+    PZ_HIP(hipGetLastError());
+    return PZ_OK;
 }
 
 int launch_small_fwd(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* S) {
     if (npolys <= 0) return PZ_OK;
+    PZ_TRY(ensure_small_tables(M));
     SmallFwdArgs g;
-    g.src = src; g.smap = smap; g.S = S; g.npolys = npolys; g.tw1 = M->tw1; g.tw12t = M->tw12t; g.wL2 = M->wL2;
-    const size_t lds = ((size_t)2 * 16 * kSmallRS + kSmallM2) * sizeof(cplx);
+    g.src = src; g.smap = smap; g.S = S; g.npolys = npolys; g.tw1 = M->s_tw1; g.tw12t = M->s_tw12t; g.wL2 = M->s_wL2;
+    const int m1 = small_m1(M);
+    const size_t lds = ((size_t)2 * m1 * kSmallRS + kSmallM2) * sizeof(cplx);
     KTimer kt(M, PZ_K_FWD_PASS1);
-    PZ_TRY(set_lds(k_small_fwd, lds));
-    hipLaunchKernelGGL(k_small_fwd, dim3((npolys + 1) / 2), dim3(256), lds, M->stream, g);
-    PZ_HIP(hipGetLastError());
-    return PZ_OK;
+    const dim3 grid((unsigned)((npolys + 1) / 2));
+#define X(M1_)                                                                                      \
+    if (m1 == M1_) {                                                                                \
+        PZ_TRY(set_lds(k_small_fwd<M1_>, lds));                                                     \
+        hipLaunchKernelGGL(k_small_fwd<M1_>, grid, dim3(256), lds, M->stream, g);                   \
+        PZ_HIP(hipGetLastError());                                                                  \
+        return PZ_OK;                                                                               \
+    }
+    X(4) X(8) X(16)
+#undef X
+    return fail(PZ_ERR_UNSUPPORTED, "small-ring pipeline: m1 = %d", m1);
 }
 
 int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int npi, int nrows, int ncols, int cols_out, int ksz,
                      long long* res, long long res_bs, int res_cols, int res_size, const long long* small, long long small_bs,
                      int small_cols, int small_size, int base2k, int body_col) {
     if (batch <= 0) return PZ_OK;
+    PZ_TRY(ensure_small_tables(M));
     SmallInvArgs g;
     g.S = S; g.Pp = Pp; g.res = res; g.small = small; g.res_bs = res_bs; g.small_bs = small_bs;
     g.batch = batch; g.npi = npi; g.nrows = nrows; g.ncols = ncols; g.cols_out = cols_out; g.ksz = ksz;
     g.res_cols = res_cols; g.res_size = res_size; g.small_cols = small_cols; g.small_size = small_size; g.base2k = base2k; g.body_col = body_col;
-    g.tw12t = M->tw12t; g.wL2 = M->wL2; g.tw1inv = M->tw1inv;
+    g.tw12t = M->s_tw12t; g.wL2 = M->s_wL2; g.tw1inv = M->s_tw1inv;
     static const int skip = getenv("POULPY_DBG_SMALL_SKIP") ? atoi(getenv("POULPY_DBG_SMALL_SKIP")) : 0;
     g.dbg = skip;
-    const size_t lds = ((size_t)ksz * 16 * kSmallRS + kSmallM2) * sizeof(cplx);
+    const int m1 = small_m1(M);
+    const size_t lds = ((size_t)ksz * m1 * kSmallRS + kSmallM2) * sizeof(cplx);
     // workgroup id -> (xcd = id & 7, slot = id >> 3): ciphertext (slot / cols_out) * 8 + xcd, column slot % cols_out
     const int grid = ((batch + 7) / 8) * 8 * cols_out;
     KTimer kt(M, PZ_K_FUSED_TAIL);
-#define X(KS_)                                                                                      \
-    if (ksz == KS_) {                                                                               \
-        PZ_TRY(set_lds(k_small_inv<KS_>, lds));                                                     \
-        hipLaunchKernelGGL(k_small_inv<KS_>, dim3(grid), dim3(1024), lds, M->stream, g);             \
+#define X(M1_, KS_)                                                                                 \
+    if (m1 == M1_ && ksz == KS_) {                                                                  \
+        PZ_TRY(set_lds((k_small_inv<M1_, KS_>), lds));                                              \
+        hipLaunchKernelGGL((k_small_inv<M1_, KS_>), dim3(grid), dim3(64 * M1_), lds, M->stream, g); \
         PZ_HIP(hipGetLastError());                                                                  \
         return PZ_OK;                                                                               \
     }
-    X(1) X(2) X(3) X(4)
+    X(4, 1) X(4, 2) X(4, 3) X(4, 4) X(8, 1) X(8, 2) X(8, 3) X(8, 4) X(16, 1) X(16, 2) X(16, 3) X(16, 4)
 #undef X
-    return fail(PZ_ERR_UNSUPPORTED, "small-ring pipeline: %d key limbs", ksz);
+    return fail(PZ_ERR_UNSUPPORTED, "small-ring pipeline: m1 = %d, %d key limbs", m1, ksz);
 }
 
 }  // namespace pz

@@ -120,6 +120,9 @@ struct pz_module {
     pz::cplx* w2n = nullptr;    // exp(2 pi i t / 2n), t < 2n: DFT of the monomials X^a (blind rotation), built on first use
     // the seven tables above are immutable and shared by the siblings of pz_module_clone: freed by the last one (atomic count on the heap)
     std::atomic<int>* tables_ref = nullptr;
+    // tables of the small-ring pipeline (m = M1 x 128; launch_small.hip): the module's own at N = 4096, built on first use otherwise
+    pz::cplx *s_tw1 = nullptr, *s_tw1inv = nullptr, *s_tw12t = nullptr, *s_wL2 = nullptr;
+    bool s_owned = false;
     // grow-only workspace
     void* ws = nullptr;
     size_t ws_bytes = 0;

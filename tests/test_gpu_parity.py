@@ -719,10 +719,11 @@ def test_blind_rotation_block_step_on_the_glwe_pipeline(mods, n, rank, n_lwe, bl
     (True, 2, 1, 4, 4, 4, 2, 6, False),       # rank 2 -> 1 key switch
     (True, 1, 3, 1, 1, 1, 1, 10, False),      # single limb everywhere, four output columns
 ])
-def test_small_ring_two_kernel_pipeline(mods, ks, rank, rank_out, a_size, key_size, dnum, res_size, batch, in_place):
-    """N = 4096: k_small_fwd + k_small_inv (whole polynomials in LDS, the spectra cross HBM once) against the oracle, and the three-kernel
-    pipeline on the same inputs bit for bit."""
-    n, k = 4096, 17
+@pytest.mark.parametrize("n", [1024, 2048, 4096])
+def test_small_ring_two_kernel_pipeline(mods, n, ks, rank, rank_out, a_size, key_size, dnum, res_size, batch, in_place):
+    """N = 1024 / 2048 / 4096: k_small_fwd + k_small_inv (whole polynomials in LDS, the spectra cross HBM once) against the oracle, and
+    the other pipeline (three kernels at N = 4096, five below) on the same inputs bit for bit."""
+    k = 17
     ref, hip = mods(n)
     hip.set_small_path(True)
     got, want = _run_glwe_op(hip, ref, ks, n, rank, rank_out, a_size, k, key_size, k, dnum, 1, res_size, k, batch, seed=900 + a_size + key_size + batch,
