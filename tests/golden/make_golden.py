@@ -91,6 +91,52 @@ def gen_glwe_automorphism(name, seed, n, base2k, rank, a_size, dnum, key_size, r
                         res_auto=res_auto, res_add=res_add)
 
 
+def gen_glwe_batched(name, seed, n, base2k, rank, a_size, dnum, key_size, res_size, batch, keyswitch):
+    """A batch of dsize = 1 GLWE (x) GGSW external products or GLWE key switches sharing one key — what the batched device entry
+    points (pz_glwe_external_product_batched / pz_glwe_keyswitch_batched: the fused pipelines) must return.  Key switch: big = mask x key
+    + body on column 0 (keyswitching/glwe.rs:207-239)."""
+    rng = np.random.default_rng(seed)
+    cols = rank + 1
+    cols_in = rank if keyswitch else cols
+    a = uniform(rng, base2k, (batch, a_size, cols, n))
+    mat = uniform(rng, base2k, (dnum, cols_in, key_size, cols, n))
+    res = np.zeros((batch, res_size, cols, n), dtype=np.int64)
+    for b in range(batch):
+        big = exact.vmp_exact(np.ascontiguousarray(a[b][:, (1 if keyswitch else 0):, :]), mat, 0, key_size)
+        if keyswitch:
+            big[:min(a_size, key_size), 0, :] += a[b][:min(a_size, key_size), 0, :].astype(object)
+        for c in range(cols):
+            res[b, :, c, :] = exact.normalize_exact(big[:, c, :], base2k, res_size)
+    np.savez_compressed(os.path.join(HERE, name), kind="glwe_batched", n=n, base2k=base2k, rank=rank, keyswitch=int(keyswitch), a=a, mat=mat, res=res)
+
+
+def gen_lwe_keyswitch(name, seed, n, base2k, n_lwe_in, n_lwe_out, size, dnum, key_size, batch, n2):
+    """mod_switch_2n (poulpy-bin-fhe blind_rotation/algorithms/mod.rs:136-176, the one-limb branch: round(limb0 * n2 / 2^base2k), half up)
+    and lwe_keyswitch (poulpy-core keyswitching/lwe.rs:49-94): embed b -> X^0 of column 0 and a_i -> the first coefficients of column 1,
+    rank-1 key switch on exact integers, extract."""
+    rng = np.random.default_rng(seed)
+    lwe = uniform(rng, base2k, (batch, size, n_lwe_in + 1))
+    mat = uniform(rng, base2k, (dnum, 1, key_size, 2, n))
+    log2n = (n2 - 1).bit_length() + 1
+    assert base2k > log2n
+    diff = base2k - (log2n - 1)
+    ms = (lwe[:, 0, :] + (1 << (diff - 1))) >> diff
+    out = np.zeros((batch, size, n_lwe_out + 1), dtype=np.int64)
+    for b in range(batch):
+        glwe = np.zeros((size, 2, n), dtype=np.int64)
+        glwe[:, 0, 0] = lwe[b, :, 0]
+        glwe[:, 1, :n_lwe_in] = lwe[b, :, 1:]
+        big = exact.vmp_exact(np.ascontiguousarray(glwe[:, 1:, :]), mat, 0, key_size)
+        big[:min(size, key_size), 0, :] += glwe[:min(size, key_size), 0, :].astype(object)
+        for c in range(2):
+            d = exact.normalize_exact(big[:, c, :], base2k, size)
+            if c == 0:
+                out[b, :, 0] = d[:, 0]
+            else:
+                out[b, :, 1:] = d[:, :n_lwe_out]
+    np.savez_compressed(os.path.join(HERE, name), kind="lwe_keyswitch", n=n, base2k=base2k, n2=n2, lwe=lwe, mat=mat, mod_switched=ms, res=out)
+
+
 def main():
     # shape grid of poulpy-hal/src/test_suite/vmp.rs (sizes 1..4, cols 1..2, limb_offset) at small N
     gen_vmp("vmp_n32_b12.npz", 1, 32, 12, rows=3, cols_in=2, cols_out=2, size=4, a_size=3, res_size=4, limb_offset=0)
@@ -105,6 +151,11 @@ def main():
     gen_external_product("extprod_n128_b14_rank2.npz", 9, 128, 14, rank=2, a_size=3, dnum=3, key_size=4, res_size=3)
     gen_glwe_automorphism("glwe_automorphism_n128_b13_rank1.npz", 10, 128, 13, rank=1, a_size=3, dnum=3, key_size=4, res_size=4, p=-5)
     gen_glwe_automorphism("glwe_automorphism_n64_b12_rank2.npz", 11, 64, 12, rank=2, a_size=4, dnum=4, key_size=4, res_size=3, p=25)
+    # the batched GLWE entry points at ring degrees with a device pipeline of their own (two-kernel: N = 1024; three-kernel: N = 8192)
+    gen_glwe_batched("glwe_batched_extprod_n1024_b17.npz", 12, 1024, 17, rank=1, a_size=3, dnum=3, key_size=3, res_size=3, batch=3, keyswitch=False)
+    gen_glwe_batched("glwe_batched_keyswitch_n1024_b14.npz", 13, 1024, 14, rank=1, a_size=2, dnum=2, key_size=3, res_size=2, batch=2, keyswitch=True)
+    gen_glwe_batched("glwe_batched_extprod_n4096_b12.npz", 14, 4096, 12, rank=1, a_size=2, dnum=2, key_size=2, res_size=2, batch=2, keyswitch=False)
+    gen_lwe_keyswitch("lwe_keyswitch_n256_b17.npz", 15, 256, 17, n_lwe_in=100, n_lwe_out=77, size=2, dnum=2, key_size=3, batch=3, n2=512)
     print("golden fixtures written to", HERE)
 
 

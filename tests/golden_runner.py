@@ -114,5 +114,62 @@ def run_fixture(path: str, module_factory) -> None:
             mod.vec_znx_big_add_small_assign(big, c, a, c)
             mod.vec_znx_big_normalize(res, base2k, 0, c, big, base2k, c)
         assert np.array_equal(res.data, z["res_add"]), f"{path}: glwe_automorphism_add differs"
+    elif kind == "glwe_batched":
+        a_np, mat_np, want = z["a"], z["mat"], z["res"]
+        ks, rank = bool(int(z["keyswitch"])), int(z["rank"])
+        batch, a_size, cols, _ = a_np.shape
+        dnum, cols_in, key_size, _, _ = mat_np.shape
+        res_size = want.shape[1]
+        mat = MatZnx(n, dnum, cols_in, cols, key_size, np.ascontiguousarray(mat_np))
+        pm = mod.vmp_pmat_alloc(dnum, cols_in, cols, key_size)
+        mod.vmp_prepare(pm, mat)
+        if hasattr(mod, "glwe_external_product_batched"):   # the device library: ONE batched call on device-resident ciphertexts
+            from poulpy_amd.hal import GlweOpParams
+            p = GlweOpParams(rank=rank, dnum=dnum, dsize=1, key_size=key_size, key_base2k=base2k, a_size=a_size, a_base2k=base2k,
+                             res_size=res_size, res_base2k=base2k, rank_out=rank)
+            d_a = mod.device_alloc(a_np.nbytes).upload(np.ascontiguousarray(a_np))
+            d_k = mod.device_alloc(pm.data.nbytes).upload(pm.data)
+            d_r = mod.device_alloc(want.nbytes)
+            (mod.glwe_keyswitch_batched if ks else mod.glwe_external_product_batched)(d_r.ptr, d_a.ptr, d_k.ptr, p, batch)
+            mod.sync()
+            got = d_r.download(np.int64, want.size).reshape(want.shape)
+            for buf in (d_a, d_k, d_r):
+                buf.free()
+        else:                                                # the oracle: the reference's per-ciphertext op
+            got = np.empty_like(want)
+            for b in range(batch):
+                a = VecZnx(n, cols, a_size, np.ascontiguousarray(a_np[b]))
+                res = VecZnx(n, cols, res_size)
+                (mod.glwe_keyswitch if ks else mod.glwe_external_product)(res, base2k, a, base2k, pm, 1, base2k)
+                got[b] = res.data
+        assert np.array_equal(got, want), f"{path}: batched GLWE product differs"
+    elif kind == "lwe_keyswitch":
+        lwe, mat_np, want, want_ms, n2 = z["lwe"], z["mat"], z["res"], z["mod_switched"], int(z["n2"])
+        batch, size, len_in = lwe.shape
+        n_out = want.shape[2] - 1
+        dnum, _, key_size, _, _ = mat_np.shape
+        mat = MatZnx(n, dnum, 1, 2, key_size, np.ascontiguousarray(mat_np))
+        pm = mod.vmp_pmat_alloc(dnum, 1, 2, key_size)
+        mod.vmp_prepare(pm, mat)
+        if hasattr(mod, "lwe_keyswitch_batched"):
+            from poulpy_amd.hal import GlweOpParams
+            p = GlweOpParams(rank=1, dnum=dnum, dsize=1, key_size=key_size, key_base2k=base2k, a_size=size, a_base2k=base2k, res_size=size,
+                             res_base2k=base2k, rank_out=1)
+            d_l = mod.device_alloc(lwe.nbytes).upload(np.ascontiguousarray(lwe))
+            d_k = mod.device_alloc(pm.data.nbytes).upload(pm.data)
+            d_r = mod.device_alloc(want.nbytes)
+            d_m = mod.device_alloc(want_ms.nbytes)
+            mod.lwe_keyswitch_batched(d_r.ptr, n_out, d_l.ptr, len_in - 1, d_k.ptr, p, batch)
+            mod.lwe_mod_switch_2n_batched(d_m.ptr, d_l.ptr, len_in - 1, size, base2k, n2, False, batch)
+            mod.sync()
+            got = d_r.download(np.int64, want.size).reshape(want.shape)
+            got_ms = d_m.download(np.int64, want_ms.size).reshape(want_ms.shape)
+            for buf in (d_l, d_k, d_r, d_m):
+                buf.free()
+        else:
+            got = np.stack([mod.lwe_keyswitch(n_out, size, base2k, lwe[b], base2k, pm, 1, base2k) for b in range(batch)])
+            got_ms = np.stack([mod.mod_switch_2n(n2, lwe[b], base2k, False) for b in range(batch)])
+        assert np.array_equal(got_ms, want_ms), f"{path}: mod_switch_2n differs"
+        assert np.array_equal(got, want), f"{path}: lwe_keyswitch differs"
     else:
         raise AssertionError(f"unknown fixture kind {kind}")
