@@ -488,6 +488,15 @@ k_mid128(MidArgs g) {
     }
             int it = 0;
             // (BR: deeper key prefetch — rings of three / four row slots — spills at the 256-VGPR cap and measured slower: 30.1 vs 26.8 ms)
+            if constexpr (NP == 32) {
+                // 8 key values per thread and row: the second register slot of the ping-pong is what pushes this shape over the 256-VGPR
+                // cap (132-164 bytes of scratch, 57.9 -> 50.3 ms per 10 launches at 16 limbs without it); one slot, the next row requested
+                // right after the current one has been consumed
+                for (; it < nrow; ++it) {
+                    PZ_USEROW(pn, it)
+                    PZ_LOADROW(pn, it + 1)
+                }
+            } else {
             for (; it + 1 < nrow; it += 2) {
                 PZ_LOADROW(pb, it + 1)
                 PZ_USEROW(pn, it)
@@ -495,6 +504,7 @@ k_mid128(MidArgs g) {
                 PZ_USEROW(pb, it + 1)
             }
             if (it < nrow) PZ_USEROW(pn, it)
+            }
 #undef PZ_LOADROW
 #undef PZ_USEROW
 #undef PZ_MID_LOADF
