@@ -93,6 +93,32 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
                 return PZ_OK;
             }
         }
+        // N = 1024 / 2048 (4096 with POULPY_DBG_BR_MID=0) off the one-kernel path (accumulators beyond LDS: N = 2048, rank 2 at N = 1024):
+        // the transforms around the block step are the two kernels of the small-ring pipeline (device_small.hpp) - the whole forward
+        // transform of the accumulator limbs in LDS, written in the standard spectrum order | the block step on the standard keys |
+        // whole inverse transform + accumulator + carry chain per (ciphertext, column) - instead of pass 1 / pass 2 and pass 2 / tail
+        {
+            const int npi = cols * std::min(dnum, rsz), nrows_key = dnum * cols, ncols_key = cols * bsz;
+            static const int br_small = getenv("POULPY_DBG_BR_SMALL") ? atoi(getenv("POULPY_DBG_BR_SMALL")) : 1;
+            if (br_small && M->small_path && M->fuse_mid && M->fuse_tail && small_supported(M, npi, bsz) && npi == nrows_key && npi <= 12 &&
+                blk <= 64) {
+                const size_t s_bytes = align256(batch * npi * (size_t)M->m * sizeof(cplx)), a_bytes = align256(batch * ncols_key * (size_t)M->m * sizeof(cplx));
+                PZ_TRY(ws_reserve(M, s_bytes + a_bytes));
+                cplx* S = (cplx*)M->ws;
+                cplx* A = (cplx*)((char*)M->ws + s_bytes);
+                PolyMap sm{npi / cols, cols, res_ct, (long long)cols * n, n, 0};
+                for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {
+                    PZ_TRY(launch_small_fwd(M, B * npi, (const long long*)res, sm, S, true));
+                    bool done = false;
+                    PZ_TRY(br_block_step(M, (const double*)S, (long long)npi * n, (double*)A, (long long)ncols_key * n, brk, pmat_doubles, npi, ncols_key, B,
+                                         b0, blk, lwe_2n, lwe_bs, &done));
+                    if (!done) return fail(PZ_ERR_UNSUPPORTED, "blind_rotation: block step not launched");
+                    PZ_TRY(launch_small_inv(M, B, A, nullptr, ncols_key, 0, 0, cols, bsz, (long long*)res, res_ct, cols, rsz, (const long long*)res,
+                                            res_ct, cols, rsz, k, -1, true));
+                }
+                return PZ_OK;
+            }
+        }
         const size_t acc_dft_bytes = align256(batch * n8 * cols * dnum), vr_bytes = align256(batch * n8 * cols * bsz);
         const size_t tp = (size_t)cols * std::max({dnum, bsz, rsz});
         const size_t t_bytes = align256(batch * tp * (size_t)M->m * sizeof(cplx));
@@ -198,14 +224,25 @@ static int blind_rotation_extended(pz_module* M, int64_t* res, const int64_t* lw
     DV rv{acc, res_ct, cols, rsz};
     DV ad{acc_dft, n * cols * dnum, cols, dnum}, vr{vmp_res, n * cols * bsz, cols, bsz}, aa{acc_add, n * cols * bsz, cols, bsz};
     const bool tail = M->fuse_tail && tail_supported(M);
+    // N = 1024 / 2048 / 4096: the transforms of the small-ring pipeline around the per-coefficient steps, as in blind_rotation()
+    static const int br_small = getenv("POULPY_DBG_BR_SMALL") ? atoi(getenv("POULPY_DBG_BR_SMALL")) : 1;
+    const int npi = cols * std::min(dnum, rsz);
+    const bool small_tf = br_small && M->small_path && M->fuse_mid && M->fuse_tail && small_supported(M, npi, bsz) && npi == dnum * cols;
     for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {
+        if (small_tf) {
+            PolyMap sm{npi / cols, cols, res_ct, (long long)cols * n, n, 0};
+            PZ_TRY(launch_small_fwd(M, BE * npi, (const long long*)acc, sm, (cplx*)acc_dft, true));
+        } else
         PZ_TRY(dev_dft_apply(M, BE, 1, 0, ad, 0, rv, 0, cols, nullptr, T));                           // :195-200
         PZ_HIP(hipMemsetAsync(acc_add, 0, (size_t)BE * aa.bs * 8, M->stream));
         for (int i = b0; i < b0 + blk; ++i) {
             PZ_TRY(dev_vmp(M, BE, vr, ad, brk + (size_t)i * pmat_doubles, dnum, cols, cols, bsz, 0));   // :209-211
             PZ_TRY(launch_xai_ext(M, acc_add, vmp_res, cols * bsz, log_ext, B, lwe_2n, lwe_bs, i));
         }
-        if (tail) {                                                                                    // :260-266
+        if (small_tf) {
+            PZ_TRY(launch_small_inv(M, BE, (const cplx*)acc_add, nullptr, cols * bsz, 0, 0, cols, bsz, (long long*)acc, res_ct, cols, rsz,
+                                    (const long long*)acc, res_ct, cols, rsz, k, -1, true));
+        } else if (tail) {                                                                             // :260-266
             PolyMap sm{bsz, cols, aa.bs, (long long)cols * n, n, 0};
             PZ_TRY(launch_inv_pass2(M, BE * bsz * cols, acc_add, sm, T));
             PZ_TRY(launch_inv_tail(M, BE, T, bsz, cols, (long long*)acc, res_ct, cols, rsz, (const long long*)acc, res_ct, cols, rsz, k, false, true));

@@ -149,6 +149,7 @@ __global__ void __launch_bounds__(256) k_br_block(BrBlockArgs g) {
     const int b0 = blockIdx.x * CT;
     const int cg = blockIdx.z;
     const unsigned mask = 4u * (unsigned)g.m - 1u;
+    const unsigned qf = 4u * (unsigned)q + 1u;
     cplx a[CT][MAXR];
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
@@ -176,7 +177,7 @@ __global__ void __launch_bounds__(256) k_br_block(BrBlockArgs g) {
         }
 #pragma unroll
         for (int t = 0; t < CT; ++t)
-            xn[t] = g.w2n[((unsigned)__builtin_amdgcn_readlane((int)aiv[t], 0) * (4u * (unsigned)q + 1u)) & mask];
+            xn[t] = g.w2n[((unsigned)__builtin_amdgcn_readlane((int)aiv[t], 0) * qf) & mask];
     }
     // (a second register set prefetching coefficient i+1 drops the occupancy to one wave per SIMD and is 15 % slower)
     for (int i = g.i0; i < g.i0 + g.blk; ++i) {
@@ -194,7 +195,7 @@ __global__ void __launch_bounds__(256) k_br_block(BrBlockArgs g) {
 #pragma unroll
             for (int t = 0; t < CT; ++t) {
                 xm[t] = xn[t];
-                xn[t] = g.w2n[((unsigned)__builtin_amdgcn_readlane((int)aiv[t], nx) * (4u * (unsigned)q + 1u)) & mask];
+                xn[t] = g.w2n[((unsigned)__builtin_amdgcn_readlane((int)aiv[t], nx) * qf) & mask];
             }
         }
 #pragma unroll
@@ -278,6 +279,7 @@ __global__ void __launch_bounds__(256) k_br_block_lds(BrBlockArgs g) {
     const int q = (tile / g.gx) * 64 + lane;
     const int b0 = ((tile % g.gx) * NW + w) * CT;
     const unsigned mask = 4u * (unsigned)g.m - 1u;
+    const unsigned qf = 4u * (unsigned)q + 1u;
     cplx a[CT][MAXR];
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
@@ -305,7 +307,7 @@ __global__ void __launch_bounds__(256) k_br_block_lds(BrBlockArgs g) {
         }
 #pragma unroll
         for (int t = 0; t < CT; ++t)
-            xn[t] = g.w2n[((unsigned)__builtin_amdgcn_readlane((int)aiv[t], 0) * (4u * (unsigned)q + 1u)) & mask];
+            xn[t] = g.w2n[((unsigned)__builtin_amdgcn_readlane((int)aiv[t], 0) * qf) & mask];
     }
     brl_stage<PER, NE>(nxt, ks[0], w, lane);
     __syncthreads();
@@ -322,7 +324,7 @@ __global__ void __launch_bounds__(256) k_br_block_lds(BrBlockArgs g) {
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
             xm[t] = xn[t];
-            xn[t] = g.w2n[((unsigned)__builtin_amdgcn_readlane((int)aiv[t], is_n) * (4u * (unsigned)q + 1u)) & mask];
+            xn[t] = g.w2n[((unsigned)__builtin_amdgcn_readlane((int)aiv[t], is_n) * qf) & mask];
         }
         cplx sacc[CT][CG];
 #pragma unroll

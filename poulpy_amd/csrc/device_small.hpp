@@ -24,6 +24,8 @@ struct SmallFwdArgs {
     const cplx* tw1;     // [16] twist of the column pass
     const cplx* tw12t;   // [q1][j2]
     const cplx* wL2;     // exp(2 pi i t / 128)
+    int natural;         // 1: spectrum written in the standard device order [q1 + M1 q2] (pointwise consumers holding standard keys: the
+                         // blind rotation's block step) instead of S[q1][q2]; the 8 M1 threads of a store still cover 8 M1 consecutive points
 };
 
 // 256 threads = 2 polynomials x 128 threads; LDS 2 x M1 rows x 144 points + wL2
@@ -78,11 +80,12 @@ __global__ void __launch_bounds__(256, 2) k_small_fwd(SmallFwdArgs g) {
         Bfly<8, false>::run(x);
         Bfly<8, false>::run(x + 8);
         if (active) {
-            cplx* dst = g.S + (long long)p * m + (long long)row * M2 + o;
+            cplx* dst = g.S + (long long)p * m + (g.natural ? row + M1 * o : row * M2 + o);
+            const int qs = g.natural ? M1 : 1;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int k2 = 0; k2 < 8; ++k2) dst[8 * h + 16 * k2] = x[8 * h + k2];   // S[q1][q2 = o + 8h + 16 k2]: re-read twice, kept cacheable
+                for (int k2 = 0; k2 < 8; ++k2) dst[(8 * h + 16 * k2) * qs] = x[8 * h + k2];   // S[q1][q2 = o + 8h + 16 k2]: re-read twice, kept cacheable
         }
     }
 }
@@ -121,8 +124,9 @@ struct SmallInvArgs {
 // ciphertexts against 0.35 ms for the whole three-kernel pipeline).  Also tried: a persistent workgroup in two roles of 512 threads (role A:
 // the next item's product in registers, role B: this item's transforms in the tile, hand-over between barriers) — at the 128-VGPR cap of a
 // 1024-thread workgroup role A's 64 accumulator registers leave no room for prefetch slots (spills, 0.93 ms at 4 limbs; 0.25 vs 0.17 ms
-// at 3).  KS = key limbs (g.ksz).
-template <int M1, int KS>
+// at 3).  KS = key limbs (g.ksz).  NOPROD: the spectra of the (ciphertext, column) are given, in the standard device order [q1 + M1 q2]:
+// S[b][l * cols_out + col] (npi = ksz * cols_out), no key (the blind rotation's block step produced them).
+template <int M1, int KS, bool NOPROD = false>
 __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
     constexpr int NT = 64 * M1;          // 2 product positions per thread (m = 128 M1 points)
     constexpr int M2 = kSmallM2, RS = kSmallRS, L = KS;
@@ -144,7 +148,21 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
     for (int l = 0; l < KS; ++l)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[l][j] = make_double2(0.0, 0.0);
-    {
+    if constexpr (NOPROD) {
+        // consecutive threads read consecutive points q = q1 + M1 q2 and drop them at (q1, q2) of the tile
+        const cplx* Sb = g.S + ((long long)b * g.npi + col) * m + tid;
+#pragma unroll
+        for (int l = 0; l < KS; ++l)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[l][j] = Sb[(long long)l * g.cols_out * m + NT * j];
+#pragma unroll
+        for (int l = 0; l < KS; ++l)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = tid + NT * j;
+                lds[(l * M1 + (q % M1)) * RS + q / M1] = acc[l][j];
+            }
+    } else {
         const cplx* Sb = g.S + (long long)b * g.npi * m + tid;
         const long long qstride = (long long)(M1 / 2) * g.nrows * g.ncols * M2;   // q1 advances by M1 / 2 per j
         const long long prow = (long long)g.ncols * M2;
@@ -183,10 +201,12 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
 #undef PZ_SMALL_LOAD
 #undef PZ_SMALL_USE
     }
+    if constexpr (!NOPROD) {
 #pragma unroll
-    for (int l = 0; l < KS; ++l)
+        for (int l = 0; l < KS; ++l)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) lds[(l * M1 + pq1 + (M1 / 2) * j) * RS + pq2] = acc[l][j];
+            for (int j = 0; j < 2; ++j) lds[(l * M1 + pq1 + (M1 / 2) * j) * RS + pq2] = acc[l][j];
+    }
     __syncthreads();
     // ---------------- inverse row pass (k_mid128) of the KS polynomials, x conj tw12, back into the tile as T2[q1][j2] ----------------
     {
@@ -261,7 +281,9 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
     long long* res_col = g.res + (long long)b * g.res_bs + (long long)col * n + (ch ? m : 0) + cj2 + (long long)jq * M2;
     const long long res_ls = (long long)g.res_cols * n;
     const long long* small_col =
-        (g.small && col == g.body_col) ? g.small + (long long)b * g.small_bs + (ch ? m : 0) + cj2 + (long long)jq * M2 : nullptr;
+        (g.small && (col == g.body_col || g.body_col < 0))   // body_col < 0: every column gets its own column of `small`
+            ? g.small + (long long)b * g.small_bs + (g.body_col < 0 ? (long long)col * n : 0) + (ch ? m : 0) + cj2 + (long long)jq * M2
+            : nullptr;
     const long long small_ls = (long long)g.small_cols * n;
     // limbs of res beyond the precision of the big value are zero (normalize.rs:118-120)
     for (int j = L; j < g.res_size; ++j)

@@ -61,11 +61,11 @@ int launch_small_permute(pz_module* M, const double* P, cplx* Pp, int npolys) {
     return PZ_OK;
 }
 
-int launch_small_fwd(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* S) {
+int launch_small_fwd(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* S, bool natural_order) {
     if (npolys <= 0) return PZ_OK;
     PZ_TRY(ensure_small_tables(M));
     SmallFwdArgs g;
-    g.src = src; g.smap = smap; g.S = S; g.npolys = npolys; g.tw1 = M->s_tw1; g.tw12t = M->s_tw12t; g.wL2 = M->s_wL2;
+    g.src = src; g.smap = smap; g.S = S; g.npolys = npolys; g.tw1 = M->s_tw1; g.tw12t = M->s_tw12t; g.wL2 = M->s_wL2; g.natural = natural_order ? 1 : 0;
     const int m1 = small_m1(M);
     const size_t lds = ((size_t)2 * m1 * kSmallRS + kSmallM2) * sizeof(cplx);
     KTimer kt(M, PZ_K_FWD_PASS1);
@@ -84,7 +84,7 @@ int launch_small_fwd(pz_module* M, int npolys, const long long* src, PolyMap sma
 
 int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int npi, int nrows, int ncols, int cols_out, int ksz,
                      long long* res, long long res_bs, int res_cols, int res_size, const long long* small, long long small_bs,
-                     int small_cols, int small_size, int base2k, int body_col) {
+                     int small_cols, int small_size, int base2k, int body_col, bool noprod) {
     if (batch <= 0) return PZ_OK;
     PZ_TRY(ensure_small_tables(M));
     SmallInvArgs g;
@@ -99,12 +99,17 @@ int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int
     // workgroup id -> (xcd = id & 7, slot = id >> 3): ciphertext (slot / cols_out) * 8 + xcd, column slot % cols_out
     const int grid = ((batch + 7) / 8) * 8 * cols_out;
     KTimer kt(M, PZ_K_FUSED_TAIL);
-#define X(M1_, KS_)                                                                                 \
-    if (m1 == M1_ && ksz == KS_) {                                                                  \
-        PZ_TRY(set_lds((k_small_inv<M1_, KS_>), lds));                                              \
-        hipLaunchKernelGGL((k_small_inv<M1_, KS_>), dim3(grid), dim3(64 * M1_), lds, M->stream, g); \
-        PZ_HIP(hipGetLastError());                                                                  \
-        return PZ_OK;                                                                               \
+#define X(M1_, KS_)                                                                                           \
+    if (m1 == M1_ && ksz == KS_) {                                                                            \
+        if (noprod) {                                                                                         \
+            PZ_TRY(set_lds((k_small_inv<M1_, KS_, true>), lds));                                              \
+            hipLaunchKernelGGL((k_small_inv<M1_, KS_, true>), dim3(grid), dim3(64 * M1_), lds, M->stream, g); \
+        } else {                                                                                              \
+            PZ_TRY(set_lds((k_small_inv<M1_, KS_>), lds));                                                    \
+            hipLaunchKernelGGL((k_small_inv<M1_, KS_>), dim3(grid), dim3(64 * M1_), lds, M->stream, g);       \
+        }                                                                                                     \
+        PZ_HIP(hipGetLastError());                                                                            \
+        return PZ_OK;                                                                                         \
     }
     X(4, 1) X(4, 2) X(4, 3) X(4, 4) X(8, 1) X(8, 2) X(8, 3) X(8, 4) X(16, 1) X(16, 2) X(16, 3) X(16, 4)
 #undef X

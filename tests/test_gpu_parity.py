@@ -708,6 +708,32 @@ def test_blind_rotation_block_step_on_the_glwe_pipeline(mods, n, rank, n_lwe, bl
     assert np.array_equal(got2, want)
 
 
+@pytest.mark.parametrize("n,rank,n_lwe,blk,dnum,bsz,rsz,k,batch", [
+    (2048, 1, 15, 7, 3, 3, 3, 13, 9),      # the gate-bootstrap key layout at N = 2048: two blocks + a trailing partial block, ragged batch
+    (2048, 1, 8, 4, 2, 2, 3, 14, 3),       # result limbs beyond the key precision (zeroed)
+    (2048, 1, 6, 3, 2, 4, 2, 12, 17),      # key limbs > result limbs (carry-only first steps), three XCD rounds
+    (1024, 2, 6, 3, 3, 3, 3, 13, 5),       # rank 2 at N = 1024 (the circuit-bootstrapping shape: 9 inputs, 9 outputs)
+    (1024, 2, 4, 2, 4, 3, 4, 12, 2),       # 12 inputs
+    (2048, 2, 4, 2, 2, 2, 2, 15, 4),       # rank 2 at N = 2048
+    (2048, 3, 6, 3, 2, 1, 2, 16, 3),       # rank 3, one key limb
+    (4096, 1, 6, 3, 3, 2, 2, 14, 4),       # N = 4096 with dnum > res_size: neither pipeline form applies (composed path, per-op kernels)
+])
+def test_blind_rotation_small_ring_transforms(mods, n, rank, n_lwe, blk, dnum, bsz, rsz, k, batch):
+    """execute_block_binary (algorithm.rs:265-368) at N = 1024 / 2048 off the one-kernel path: k_small_fwd | block step on S-ordered spectra
+    with the block's keys re-ordered | k_small_inv (no product: inverse transform + accumulator + carry chain) — against the oracle, and
+    against the per-op composition bit for bit."""
+    ref, hip = mods(n)
+    hip.set_small_path(True)
+    got, want = _run_blind_rotation(hip, ref, n, rank, n_lwe, blk, dnum, bsz, rsz, k, batch=batch, seed=n + rank + blk + dnum)
+    assert np.array_equal(got, want), (n, rank, n_lwe, blk, dnum, bsz, rsz, k, batch)
+    hip.set_small_path(False)
+    try:
+        got2, _ = _run_blind_rotation(hip, ref, n, rank, n_lwe, blk, dnum, bsz, rsz, k, batch=batch, seed=n + rank + blk + dnum)
+    finally:
+        hip.set_small_path(True)
+    assert np.array_equal(got2, want)
+
+
 @pytest.mark.parametrize("ks,rank,rank_out,a_size,key_size,dnum,res_size,batch,in_place", [
     (False, 1, 1, 4, 4, 4, 4, 19, False),     # BASELINE configs[1] shape, ragged batch (19 = 2 x 8 + 3: partly filled XCD slots)
     (False, 1, 1, 4, 4, 4, 4, 8, True),       # in place
@@ -1539,6 +1565,9 @@ def test_circuit_bootstrapping_to_exponent(mods, n, rank, log_gap_in, log_gap_ou
     (256, 1, 4, 6, 2, 2, 3, 2, 4, True),
     (512, 2, 8, 4, 2, 3, 2, 3, 3, True),
     (4096, 1, 2, 4, 2, 2, 2, 2, 2, True),
+    (2048, 1, 4, 6, 3, 3, 3, 3, 3, True),      # transforms of the small-ring pipeline around the per-coefficient steps
+    (1024, 2, 2, 4, 2, 2, 3, 2, 5, True),
+    (2048, 1, 2, 4, 2, 2, 2, 4, 2, True),      # result limbs beyond the key precision
     (256, 1, 4, 6, 3, 2, 2, 3, 3, False),
 ])
 def test_blind_rotation_extended(mods, n, rank, ext, n_lwe, blk, dnum, bsz, rsz, batch, fuse):
