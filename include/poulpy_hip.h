@@ -470,12 +470,12 @@ int pz_blind_rotation_execute_extended_batched(pz_module* m, int64_t* res, const
 /* CircuitBootstrappingExecute::circuit_bootstrapping_execute_to_constant (poulpy-bin-fhe/src/circuit_bootstrapping/
  * circuit.rs:177-195, core :219-370 with to_exponent = false) on `batch` LWE ciphertexts -> `batch` contiguous GGSWs
  * (MatZnx layout, rows = res_dnum, cols_in = cols_out = rank+1, size = res_size), for the case the reference's own
- * benchmark runs (poulpy-bench bench_suite/schemes/circuit_bootstrapping.rs): one base2k for the blind-rotation key, the
- * automorphism keys, the tensor keys and the result.  execute_to_exponent (:197-216) with
+ * benchmark runs (poulpy-bench bench_suite/schemes/circuit_bootstrapping.rs: one base2k for the blind-rotation key, the
+ * automorphism keys, the tensor keys and the result) and the one its tests run (a base2k per object: the fields at the end of
+ * the params).  execute_to_exponent (:197-216) with
  * log_gap_in == log_gap_out is the same call with the step list of the partial trace (post_process :418-420: steps
  * log_n - log_gap_in + 1 .. log_n) and the table / mod-switch direction the shim builds for that mode (:276-301);
- * pz_circuit_bootstrapping_execute_to_exponent_batched below does that mapping and the repacking branch (:392-417); other
- * bases stay on the generic per-op path.
+ * pz_circuit_bootstrapping_execute_to_exponent_batched below does that mapping and the repacking branch (:392-417).
  *   lwe_2n, lut, brk   as for pz_blind_rotation_execute_batched (the shim builds the table with the reference's host code
  *                      lookup_table.rs and passes gap = 2*lut.drift/extension_factor, circuit.rs:333)
  *   gals / atk_pmats   HOST arrays, one per trace step skip..log_n (as for pz_glwe_trace_batched; skip = 0 in constant mode): prepared automorphism keys
@@ -490,6 +490,13 @@ typedef struct {
     uint64_t gap;
     uint64_t extension_factor;   /* 0 or 1: execute_block_binary / execute_standard; > 1: the extended rotation (lut = that many
                                     polynomials, lwe_2n switched to 2*n*extension_factor, gap as circuit.rs:333 computes it) */
+    /* One base2k per object, as the reference's own tests run it (circuit_bootstrapping/tests/circuit_bootstrapping.rs:49-53: result 15,
+     * blind-rotation key 13, automorphism keys 11, tensor keys 12); br.base2k is the blind-rotation key's.  0 = br.base2k. */
+    uint64_t atk_base2k, tsk_base2k, res_base2k;
+    uint64_t atk_glwe_size;      /* limbs of the rotated GLWE re-expressed in the automorphism keys' base (circuit.rs:311-331:
+                                    ceil(brk.max_k / atk_base2k)); 0 = br.res_size */
+    uint64_t trace_size;         /* limbs of glwe_trace's temporary (glwe_trace.rs:107-112: ceil(max(brk.max_k, res.max_k) / atk_base2k));
+                                    0 = max(atk_glwe_size, res_size), which is that value when the bases are equal */
 } pz_circuit_bootstrapping_params;
 size_t pz_circuit_bootstrapping_tmp_bytes(const pz_module* m, const pz_circuit_bootstrapping_params* p, size_t batch);
 int pz_circuit_bootstrapping_execute_to_constant_batched(pz_module* m, int64_t* ggsw, const int64_t* lwe_2n, const int64_t* lut,

@@ -2033,31 +2033,11 @@ void pzr_circuit_bootstrap_to_constant(const pzr_tables* t, size_t rank, size_t 
                                        size_t nsteps, const int64_t* gals, const double* const* atk, size_t atk_dnum, size_t atk_size,
                                        int64_t* ggsw, size_t res_dnum, size_t res_size, size_t gap,
                                        const double* const* tsk, size_t tsk_dnum, size_t tsk_size) {
-    size_t n = t->m << 1;
-    size_t cols = rank + 1;
+    size_t bases[4] = {base2k, base2k, base2k, base2k};
     size_t tmp_size = glwe_size > res_size ? glwe_size : res_size; /* glwe_trace.rs:107-112: k = max(a.k, res.k) */
-    int64_t* acc = (int64_t*)calloc(n * cols * glwe_size, sizeof(int64_t));
-    int64_t* rot = (int64_t*)calloc(n * cols * glwe_size, sizeof(int64_t));
-    int64_t* tmp = (int64_t*)calloc(n * cols * tmp_size, sizeof(int64_t));
-    pzr_blind_rotation_execute(t, rank, n_lwe, block_size, acc, glwe_size, base2k, lwe_2n, lut, lut_size, brk, brk_dnum, brk_size, x_pow_a);
-    size_t ct_res = n * cols * res_size;
-    for (size_t i = 0; i < res_dnum; ++i) {
-        /* glwe_trace.rs:114-115 glwe_copy(tmp, a): common limbs, zero tail */
-        memset(tmp, 0, n * cols * tmp_size * sizeof(int64_t));
-        memcpy(tmp, acc, n * cols * glwe_size * sizeof(int64_t));
-        pzr_glwe_trace_assign(t, rank, tmp, tmp_size, base2k, nsteps, gals, atk, atk_dnum, atk_size, 1);
-        /* glwe_trace.rs:121-122 glwe_copy(res, tmp): the first res_size limbs */
-        memcpy(ggsw + (i * cols) * ct_res, tmp, ct_res * sizeof(int64_t));
-        if (i + 1 < res_dnum) { /* circuit.rs:363-365 glwe_rotate_assign(-gap) */
-            for (size_t c = 0; c < cols; ++c)
-                pzr_vec_znx_rotate(n, -(int64_t)gap, rot, cols, glwe_size, c, acc, cols, glwe_size, c);
-            memcpy(acc, rot, n * cols * glwe_size * sizeof(int64_t));
-        }
-    }
-    pzr_ggsw_expand_row(t, rank, ggsw, res_dnum, res_size, base2k, tsk, tsk_dnum, tsk_size, 1, base2k);
-    free(acc);
-    free(rot);
-    free(tmp);
+    pzr_circuit_bootstrap_bases(t, rank, bases, 0, n_lwe, block_size, lwe_2n, lut, lut_size, brk, brk_dnum, brk_size, glwe_size, glwe_size,
+                                tmp_size, x_pow_a, nsteps, gals, atk, atk_dnum, atk_size, ggsw, res_dnum, res_size, gap, 0, 0, 0, tsk, tsk_dnum,
+                                tsk_size);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -2142,46 +2122,96 @@ void pzr_circuit_bootstrap_to_exponent(const pzr_tables* t, size_t rank, size_t 
                                        int64_t* ggsw, size_t res_dnum, size_t res_size, size_t gap,
                                        size_t log_gap_in, size_t log_gap_out, size_t log_domain,
                                        const double* const* tsk, size_t tsk_dnum, size_t tsk_size) {
-    size_t n = t->m << 1, cols = rank + 1, ct_g = n * cols * glwe_size, ct_res = n * cols * res_size;
-    size_t log_n = 0;
-    while (((size_t)1 << log_n) < n) ++log_n;
-    int64_t* acc = (int64_t*)calloc(ct_g, sizeof(int64_t));
-    int64_t* rot = (int64_t*)calloc(ct_g, sizeof(int64_t));
-    int64_t* a_trace = (int64_t*)calloc(ct_g, sizeof(int64_t));
-    int64_t* packed = (int64_t*)calloc(ct_g, sizeof(int64_t));
-    size_t steps = (size_t)1 << log_domain;
-    int64_t* cts = (int64_t*)calloc(steps * ct_g, sizeof(int64_t));
-    int64_t** slots = (int64_t**)calloc(n, sizeof(int64_t*));
-    pzr_blind_rotation_execute(t, rank, n_lwe, block_size, acc, glwe_size, base2k, lwe_2n, lut, lut_size, brk, brk_dnum, brk_size, x_pow_a);
-    size_t skip = log_n - log_gap_in + 1;
-    for (size_t i = 0; i < res_dnum; ++i) {
-        memcpy(a_trace, acc, ct_g * sizeof(int64_t));
-        pzr_glwe_trace_assign(t, rank, a_trace, glwe_size, base2k, log_n - skip, gals + skip, atk + skip, atk_dnum, atk_size, 1);
-        const int64_t* row_src = a_trace;
-        if (log_gap_in != log_gap_out) {
-            memset(slots, 0, n * sizeof(int64_t*));
-            for (size_t s = 0; s < steps; ++s) {
-                if (s != 0) { /* :405-407 glwe_rotate_assign(-(1 << log_gap_in), a_trace) */
-                    for (size_t c = 0; c < cols; ++c)
-                        pzr_vec_znx_rotate(n, -((int64_t)1 << log_gap_in), rot, cols, glwe_size, c, a_trace, cols, glwe_size, c);
-                    memcpy(a_trace, rot, ct_g * sizeof(int64_t));
-                }
-                memcpy(cts + s * ct_g, a_trace, ct_g * sizeof(int64_t));
-                slots[s << log_gap_out] = cts + s * ct_g;
-            }
-            pzr_glwe_pack(t, rank, packed, slots, glwe_size, base2k, log_gap_out, gals, atk, atk_dnum, atk_size);
-            row_src = packed;
-        }
-        memcpy(ggsw + (i * cols) * ct_res, row_src, ct_res * sizeof(int64_t)); /* glwe_copy: the first res_size limbs */
-        if (i + 1 < res_dnum) {
-            for (size_t c = 0; c < cols; ++c) pzr_vec_znx_rotate(n, -(int64_t)gap, rot, cols, glwe_size, c, acc, cols, glwe_size, c);
-            memcpy(acc, rot, ct_g * sizeof(int64_t));
-        }
-    }
-    pzr_ggsw_expand_row(t, rank, ggsw, res_dnum, res_size, base2k, tsk, tsk_dnum, tsk_size, 1, base2k);
-    free(acc); free(rot); free(a_trace); free(packed); free(cts); free(slots);
+    size_t bases[4] = {base2k, base2k, base2k, base2k};
+    pzr_circuit_bootstrap_bases(t, rank, bases, 1, n_lwe, block_size, lwe_2n, lut, lut_size, brk, brk_dnum, brk_size, glwe_size, glwe_size,
+                                glwe_size, x_pow_a, 0, gals, atk, atk_dnum, atk_size, ggsw, res_dnum, res_size, gap, log_gap_in, log_gap_out,
+                                log_domain, tsk, tsk_dnum, tsk_size);
 }
 
+/* circuit.rs:219-370 (+ post_process :373-421) with one base2k per object, as the reference's tests run it
+ * (circuit_bootstrapping/tests/circuit_bootstrapping.rs:49-53).  bases = {brk, atk, tsk, res}.
+ *   :321-331  acc = blind_rotation(lwe, lut) in the brk base (glwe_size limbs); glwe_copy / glwe_normalize (operations/glwe.rs:1286-1310)
+ *             into the atk layout (atk_glwe_size limbs)
+ *   :344-366  per row: glwe_trace (poulpy-core/src/glwe_trace.rs:91-127: temporary of trace_size limbs in the atk base = zero-extended
+ *             copy of a, trace_assign, then glwe_copy or glwe_normalize into the row) or post_process; acc = X^-gap * acc
+ *   :369      ggsw_expand_row (res base, tsk base)
+ * constant mode: gals / atk = the nsteps steps of the full trace; exponent mode: all log2(n) steps (nsteps ignored). */
+static void cbt_finish_row(size_t n, size_t cols, int64_t* row, size_t res_size, size_t k_res, const int64_t* tmp, size_t tmp_size, size_t k_atk) {
+    if (k_res == k_atk) { /* glwe_copy: common limbs, zero tail */
+        size_t common = res_size < tmp_size ? res_size : tmp_size;
+        memset(row, 0, n * cols * res_size * sizeof(int64_t));
+        memcpy(row, tmp, n * cols * common * sizeof(int64_t));
+    } else {
+        for (size_t c = 0; c < cols; ++c) pzr_vec_znx_normalize(n, row, cols, res_size, k_res, 0, c, tmp, cols, tmp_size, k_atk, c);
+    }
+}
+void pzr_circuit_bootstrap_bases(const pzr_tables* t, size_t rank, const size_t* bases, int to_exponent,
+                                 size_t n_lwe, size_t block_size, const int64_t* lwe_2n, const int64_t* lut, size_t lut_size,
+                                 const double* brk, size_t brk_dnum, size_t brk_size, size_t glwe_size, size_t atk_glwe_size, size_t trace_size,
+                                 const double* x_pow_a, size_t nsteps, const int64_t* gals, const double* const* atk, size_t atk_dnum,
+                                 size_t atk_size, int64_t* ggsw, size_t res_dnum, size_t res_size, size_t gap,
+                                 size_t log_gap_in, size_t log_gap_out, size_t log_domain,
+                                 const double* const* tsk, size_t tsk_dnum, size_t tsk_size) {
+    const size_t k_brk = bases[0], k_atk = bases[1], k_tsk = bases[2], k_res = bases[3];
+    size_t n = t->m << 1, cols = rank + 1, asz = atk_glwe_size, tsz = trace_size;
+    size_t ct_a = n * cols * asz, ct_t = n * cols * tsz, ct_res = n * cols * res_size;
+    size_t log_n = 0;
+    while (((size_t)1 << log_n) < n) ++log_n;
+    int64_t* acc_brk = (int64_t*)calloc(n * cols * glwe_size, sizeof(int64_t));
+    int64_t* acc = (int64_t*)calloc(ct_a, sizeof(int64_t));
+    int64_t* rot = (int64_t*)calloc(ct_a, sizeof(int64_t));
+    int64_t* tmp = (int64_t*)calloc(ct_t, sizeof(int64_t));
+    pzr_blind_rotation_execute(t, rank, n_lwe, block_size, acc_brk, glwe_size, k_brk, lwe_2n, lut, lut_size, brk, brk_dnum, brk_size, x_pow_a);
+    if (k_atk == k_brk) { /* glwe_copy */
+        memcpy(acc, acc_brk, n * cols * (asz < glwe_size ? asz : glwe_size) * sizeof(int64_t));
+    } else {
+        for (size_t c = 0; c < cols; ++c) pzr_vec_znx_normalize(n, acc, cols, asz, k_atk, 0, c, acc_brk, cols, glwe_size, k_brk, c);
+    }
+    size_t steps = (size_t)1 << log_domain;
+    int64_t* a_trace = NULL; int64_t* packed = NULL; int64_t* cts = NULL; int64_t** slots = NULL;
+    const int repack = to_exponent && log_gap_in != log_gap_out;
+    if (repack) {
+        a_trace = (int64_t*)calloc(ct_a, sizeof(int64_t));
+        packed = (int64_t*)calloc(ct_a, sizeof(int64_t));
+        cts = (int64_t*)calloc(steps * ct_a, sizeof(int64_t));
+        slots = (int64_t**)calloc(n, sizeof(int64_t*));
+    }
+    size_t skip = to_exponent ? log_n - log_gap_in + 1 : 0;
+    size_t tsteps = to_exponent ? log_n - skip : nsteps;
+    for (size_t i = 0; i < res_dnum; ++i) {
+        int64_t* row = ggsw + (i * cols) * ct_res;
+        if (!repack) {
+            /* glwe_trace.rs:107-119: tmp = zero-extended copy of a, trace over the steps skip.. */
+            memset(tmp, 0, ct_t * sizeof(int64_t));
+            memcpy(tmp, acc, (ct_a < ct_t ? ct_a : ct_t) * sizeof(int64_t));
+            pzr_glwe_trace_assign(t, rank, tmp, tsz, k_atk, tsteps, gals + skip, atk + skip, atk_dnum, atk_size, 1);
+            cbt_finish_row(n, cols, row, res_size, k_res, tmp, tsz, k_atk);
+        } else {
+            /* post_process :392-417: partial trace in a's layout, 2^log_domain shifted copies, glwe_pack whose closing glwe_trace
+             * (glwe_packing.rs:166) runs on a temporary of trace_size limbs — here trace_size == atk_glwe_size (brk.max_k >= res.max_k) */
+            memcpy(a_trace, acc, ct_a * sizeof(int64_t));
+            pzr_glwe_trace_assign(t, rank, a_trace, asz, k_atk, tsteps, gals + skip, atk + skip, atk_dnum, atk_size, 1);
+            memset(slots, 0, n * sizeof(int64_t*));
+            for (size_t sidx = 0; sidx < steps; ++sidx) {
+                if (sidx != 0) { /* :405-407 glwe_rotate_assign(-(1 << log_gap_in), a_trace) */
+                    for (size_t c = 0; c < cols; ++c)
+                        pzr_vec_znx_rotate(n, -((int64_t)1 << log_gap_in), rot, cols, asz, c, a_trace, cols, asz, c);
+                    memcpy(a_trace, rot, ct_a * sizeof(int64_t));
+                }
+                memcpy(cts + sidx * ct_a, a_trace, ct_a * sizeof(int64_t));
+                slots[sidx << log_gap_out] = cts + sidx * ct_a;
+            }
+            pzr_glwe_pack(t, rank, packed, slots, asz, k_atk, log_gap_out, gals, atk, atk_dnum, atk_size);
+            cbt_finish_row(n, cols, row, res_size, k_res, packed, asz, k_atk);
+        }
+        if (i + 1 < res_dnum) { /* circuit.rs:363-365 glwe_rotate_assign(-gap) */
+            for (size_t c = 0; c < cols; ++c) pzr_vec_znx_rotate(n, -(int64_t)gap, rot, cols, asz, c, acc, cols, asz, c);
+            memcpy(acc, rot, ct_a * sizeof(int64_t));
+        }
+    }
+    pzr_ggsw_expand_row(t, rank, ggsw, res_dnum, res_size, k_res, tsk, tsk_dnum, tsk_size, 1, k_tsk);
+    free(acc_brk); free(acc); free(rot); free(tmp); free(a_trace); free(packed); free(cts); free(slots);
+}
 
 /* ------------------------------------------------------------------------ */
 /* reference/fft64/convolution.rs (HalImpl cnv_*, hal_impl.rs:670-754)        */

@@ -226,6 +226,18 @@ void pzr_circuit_bootstrap_to_exponent(const pzr_tables* t, size_t rank, size_t 
                                        size_t log_gap_in, size_t log_gap_out, size_t log_domain,
                                        const double* const* tsk, size_t tsk_dnum, size_t tsk_size);
 
+/* circuit.rs:219-421 with one base2k per object (bases = {brk, atk, tsk, res}), the way the reference's tests run it
+ * (circuit_bootstrapping/tests/circuit_bootstrapping.rs:49-53); glwe_size = limbs of the rotation in the brk base, atk_glwe_size =
+ * ceil(brk.max_k / atk base), trace_size = ceil(max(brk.max_k, res.max_k) / atk base) (glwe_trace.rs:107-112).  to_exponent = 0: gals / atk
+ * hold the nsteps steps of the full trace; 1: all log2(n) steps, gaps / domain as in pzr_circuit_bootstrap_to_exponent */
+void pzr_circuit_bootstrap_bases(const pzr_tables* t, size_t rank, const size_t* bases, int to_exponent,
+                                 size_t n_lwe, size_t block_size, const int64_t* lwe_2n, const int64_t* lut, size_t lut_size,
+                                 const double* brk, size_t brk_dnum, size_t brk_size, size_t glwe_size, size_t atk_glwe_size, size_t trace_size,
+                                 const double* x_pow_a, size_t nsteps, const int64_t* gals, const double* const* atk, size_t atk_dnum,
+                                 size_t atk_size, int64_t* ggsw, size_t res_dnum, size_t res_size, size_t gap,
+                                 size_t log_gap_in, size_t log_gap_out, size_t log_domain,
+                                 const double* const* tsk, size_t tsk_dnum, size_t tsk_size);
+
 /* reference/fft64/convolution.rs (HalImpl cnv_*, poulpy-hal/src/oep/hal_impl.rs:670-754).  CnvPVecL / CnvPVecR bytes (FFT64):
  * [col][blk < m/4][limb < size][re x4 | im x4]; a / b below are such buffers of (cols, a_size) / (cols, b_size). */
 size_t pzr_cnv_prepare_tmp_bytes(size_t n, size_t res_size, size_t a_size);

@@ -369,6 +369,23 @@ class RefModule:
             *_sz(brk_dnum, brk_size, glwe_size), _p(x_pow_a), g, ap, *_sz(atk[0].rows, atk[0].size), _p(ggsw.data),
             *_sz(ggsw.rows, ggsw.size, gap, log_gap_in, log_gap_out, log_domain), tp, *_sz(tsk[0].rows, tsk[0].size))
 
+    def circuit_bootstrap_bases(self, ggsw, bases, to_exponent, lwe_2n, lut, brk, brk_dnum, brk_size, glwe_size, atk_glwe_size, trace_size,
+                                block_size, x_pow_a, gals, atk, tsk, gap, log_gap_in=0, log_gap_out=0, log_domain=0):
+        """circuit.rs:219-421 with one base2k per object: bases = (brk, atk, tsk, res); gals / atk: the steps of the full trace (constant
+        mode) or all log_n steps (exponent mode)."""
+        rank = ggsw.cols_out - 1
+        n_lwe = lwe_2n.shape[0] - 1
+        ns = len(gals)
+        g = (c_int64 * ns)(*[int(x) for x in gals])
+        ap = (c_void_p * ns)(*[pm.data.ctypes.data for pm in atk])
+        tp = (c_void_p * len(tsk))(*[pm.data.ctypes.data for pm in tsk])
+        b = (c_size_t * 4)(*[int(x) for x in bases])
+        self.lib.pzr_circuit_bootstrap_bases(
+            self.t, c_size_t(rank), b, C.c_int(1 if to_exponent else 0), *_sz(n_lwe, block_size), _p(lwe_2n), _p(lut.data), c_size_t(lut.size),
+            _p(brk), *_sz(brk_dnum, brk_size, glwe_size, atk_glwe_size, trace_size), _p(x_pow_a), c_size_t(ns), g, ap,
+            *_sz(atk[0].rows, atk[0].size), _p(ggsw.data), *_sz(ggsw.rows, ggsw.size, gap, log_gap_in, log_gap_out, log_domain), tp,
+            *_sz(tsk[0].rows, tsk[0].size))
+
     def blind_rotation_execute_extended(self, res, base2k, lwe_2n, luts, brk, dnum, brk_size, block_size, x_pow_a):
         """algorithm.rs:121-273: luts = (ext, lut_size, 1, n) i64 array (lut.data[j]), lwe_2n switched to 2*n*ext."""
         rank = res.cols - 1

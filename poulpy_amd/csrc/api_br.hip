@@ -288,13 +288,19 @@ static int glwe_pack(pz_module* M, int64_t* res, size_t nslots, const uint64_t* 
                      const int64_t* gals, const double* const* key_pmats, const pz_glwe_op_params* p, void* tmp, size_t tmp_bytes,
                      size_t batch);
 struct CbtRepack { size_t log_gap_in, log_gap_out, log_domain; };  // exponent mode with log_gap_in != log_gap_out (post_process)
-static inline size_t cbt_tmp_size(const pz_circuit_bootstrapping_params* p) { return (size_t)std::max(p->br.res_size, p->res_size); }
+static inline size_t cbt_atk_size(const pz_circuit_bootstrapping_params* p) { return (size_t)(p->atk_glwe_size ? p->atk_glwe_size : p->br.res_size); }
+static inline size_t cbt_tmp_size(const pz_circuit_bootstrapping_params* p) {
+    return (size_t)(p->trace_size ? p->trace_size : std::max((uint64_t)cbt_atk_size(p), p->res_size));
+}
+static inline uint64_t cbt_base(const pz_circuit_bootstrapping_params* p, uint64_t b) { return b ? b : p->br.base2k; }
 static inline size_t cbt_ext(const pz_circuit_bootstrapping_params* p) { return p->extension_factor > 1 ? (size_t)p->extension_factor : 1; }
 size_t pz_circuit_bootstrapping_tmp_bytes(const pz_module* M, const pz_circuit_bootstrapping_params* p, size_t batch) {
     if (!M || !p) return 0;
     const size_t n8 = (size_t)M->n * 8, cols = p->br.rank + 1;
     const size_t ext_bytes = cbt_ext(p) > 1 ? align256(pz_blind_rotation_extended_tmp_bytes(M, &p->br, cbt_ext(p), batch)) : 0;
-    return align256(batch * n8 * cols * p->br.res_size) + align256(batch * p->res_dnum * n8 * cols * cbt_tmp_size(p)) + ext_bytes;
+    // acc | (bases differ) acc in the automorphism keys' base | the dnum_res rotated copies / traces | extended rotation scratch
+    const size_t conv = cbt_base(p, p->atk_base2k) != p->br.base2k ? align256(batch * n8 * cols * cbt_atk_size(p)) : 0;
+    return align256(batch * n8 * cols * p->br.res_size) + align256(batch * p->res_dnum * n8 * cols * cbt_tmp_size(p)) + conv + ext_bytes;
 }
 size_t pz_circuit_bootstrapping_to_exponent_tmp_bytes(const pz_module* M, const pz_circuit_bootstrapping_params* p, size_t log_domain,
                                                       size_t batch) {
@@ -317,18 +323,31 @@ static int circuit_bootstrapping(pz_module* M, int64_t* ggsw, const int64_t* lwe
                "circuit_bootstrapping: tmp is smaller than the *_tmp_bytes of this call");
     if (batch == 0) return PZ_OK;
     const long long n = (long long)M->n;
-    const int cols = (int)p->br.rank + 1, gsz = (int)p->br.res_size, rsz = (int)p->res_size, tsz = (int)cbt_tmp_size(p);
+    const int cols = (int)p->br.rank + 1, bsz_g = (int)p->br.res_size, rsz = (int)p->res_size, tsz = (int)cbt_tmp_size(p);
+    const int gsz = (int)cbt_atk_size(p);   // limbs of the rotated GLWE in the automorphism keys' base
     const int rows = (int)p->res_dnum, B = (int)batch;
-    const long long ct_g = n * cols * gsz, ct_t = n * cols * tsz, ct_r = n * cols * rsz;
+    const int k_brk = (int)p->br.base2k, k_atk = (int)cbt_base(p, p->atk_base2k), k_tsk = (int)cbt_base(p, p->tsk_base2k),
+              k_res = (int)cbt_base(p, p->res_base2k);
+    PZ_REQUIRE(k_atk >= 1 && k_atk <= 63 && k_tsk >= 1 && k_tsk <= 63 && k_res >= 1 && k_res <= 63, "circuit_bootstrapping: base2k out of range");
+    PZ_REQUIRE(k_atk != k_brk || gsz == bsz_g, "circuit_bootstrapping: atk_glwe_size must be br.res_size when the bases are equal");
+    PZ_REQUIRE(tsz >= gsz, "circuit_bootstrapping: trace_size below atk_glwe_size");
+    const long long ct_b = n * cols * bsz_g, ct_g = n * cols * gsz, ct_t = n * cols * tsz, ct_r = n * cols * rsz;
     int64_t* acc = (int64_t*)tmp;
-    int64_t* tr = (int64_t*)((char*)tmp + align256((size_t)B * ct_g * 8));
+    int64_t* acc_brk = acc;
+    char* after_acc = (char*)tmp + align256((size_t)B * ct_b * 8);
+    if (k_atk != k_brk) { acc = (int64_t*)after_acc; after_acc += align256((size_t)B * ct_g * 8); }
+    int64_t* tr = (int64_t*)after_acc;
     if (cbt_ext(p) > 1) {  // key.brk.execute dispatches on lut.extension_factor() (algorithm.rs:76-118); the scratch sits behind ours
         const size_t eb = align256(pz_blind_rotation_extended_tmp_bytes(M, &p->br, cbt_ext(p), batch));
         void* etmp = (char*)tmp + (rp ? pz_circuit_bootstrapping_to_exponent_tmp_bytes(M, p, rp->log_domain, batch)
                                       : pz_circuit_bootstrapping_tmp_bytes(M, p, batch)) - eb;
-        PZ_TRY(blind_rotation_extended(M, acc, lwe_2n, lut, brk, &p->br, cbt_ext(p), etmp, eb, batch));
+        PZ_TRY(blind_rotation_extended(M, acc_brk, lwe_2n, lut, brk, &p->br, cbt_ext(p), etmp, eb, batch));
     } else {
-        PZ_TRY(blind_rotation(M, acc, lwe_2n, lut, brk, &p->br, batch));
+        PZ_TRY(blind_rotation(M, acc_brk, lwe_2n, lut, brk, &p->br, batch));
+    }
+    if (k_atk != k_brk) {   // circuit.rs:326-330 glwe_normalize into the automorphism keys' layout (operations/glwe.rs:1286-1310)
+        DV dv{acc, ct_g, cols, gsz}, sv{acc_brk, ct_b, cols, bsz_g};
+        for (int c = 0; c < cols; ++c) PZ_TRY(dev_normalize(M, B, dv, k_atk, 0, c, sv, k_brk, c));
     }
     if (tsz > gsz) PZ_HIP(hipMemsetAsync(tr, 0, (size_t)B * rows * ct_t * 8, M->stream));  // glwe_copy zero-extends (glwe_trace.rs:114)
     for (int i = 0; i < rows; ++i) {
@@ -338,8 +357,8 @@ static int circuit_bootstrapping(pz_module* M, int64_t* ggsw, const int64_t* lwe
                              -(long long)i * (long long)p->gap));
     }
     pz_glwe_op_params tp;
-    tp.rank = p->br.rank; tp.dnum = p->atk_dnum; tp.dsize = 1; tp.key_size = p->atk_size; tp.key_base2k = p->br.base2k;
-    tp.a_size = (uint64_t)tsz; tp.a_base2k = p->br.base2k; tp.res_size = (uint64_t)tsz; tp.res_base2k = p->br.base2k; tp.rank_out = p->br.rank;
+    tp.rank = p->br.rank; tp.dnum = p->atk_dnum; tp.dsize = 1; tp.key_size = p->atk_size; tp.key_base2k = (uint64_t)k_atk;
+    tp.a_size = (uint64_t)tsz; tp.a_base2k = (uint64_t)k_atk; tp.res_size = (uint64_t)tsz; tp.res_base2k = (uint64_t)k_atk; tp.rank_out = p->br.rank;
     const int64_t* row_src = tr;
     if (!rp) {
         PZ_TRY(glwe_trace(M, tr, nsteps, gals, atk_pmats, &tp, (size_t)B * rows));
@@ -348,7 +367,7 @@ static int circuit_bootstrapping(pz_module* M, int64_t* ggsw, const int64_t* lwe
         size_t log_n = 0;
         while (((size_t)1 << log_n) < (size_t)M->n) ++log_n;
         PZ_REQUIRE(nsteps == log_n, "circuit_bootstrapping (exponent mode): gals / atk_pmats must cover all log2(n) trace steps");
-        PZ_REQUIRE(rsz <= gsz, "circuit_bootstrapping (exponent mode): the GGSW must not have more limbs than the GLWE of the rotation");
+        PZ_REQUIRE(tsz == gsz, "circuit_bootstrapping (exponent mode): the GGSW must not be more precise than the GLWE of the rotation");
         PZ_REQUIRE(rp->log_gap_in >= 1 && rp->log_gap_in <= log_n && rp->log_gap_out <= log_n && rp->log_domain <= 20 &&
                        (((size_t)1 << rp->log_domain) - 1) << rp->log_gap_out < (size_t)M->n,
                    "circuit_bootstrapping (exponent mode): gaps / domain out of range");
@@ -371,10 +390,18 @@ static int circuit_bootstrapping(pz_module* M, int64_t* ggsw, const int64_t* lwe
         PZ_TRY(glwe_pack(M, packed, steps, idx.data(), cts.data(), rp->log_gap_out, gals, atk_pmats, &tp, pack_tmp, 3 * rows_ct, (size_t)B * rows));
         row_src = packed;
     }
-    // glwe_copy(res.at(i, 0), tmp) (glwe_trace.rs:121): the first res_size limbs, into the strided (row, 0) entries
-    PZ_TRY(launch_ew(M, EW_COPY, ggsw, (long long)cols * ct_r, n, row_src, ct_t, n, nullptr, 0, 0, cols * rsz, B * rows));
+    if (k_res == k_atk) {
+        // glwe_copy(res.at(i, 0), tmp) (glwe_trace.rs:121-123): the first res_size limbs, into the strided (row, 0) entries
+        PZ_REQUIRE(rsz <= tsz, "circuit_bootstrapping: res_size above trace_size");
+        PZ_TRY(launch_ew(M, EW_COPY, ggsw, (long long)cols * ct_r, n, row_src, ct_t, n, nullptr, 0, 0, cols * rsz, B * rows));
+    } else {
+        // glwe_normalize(res.at(i, 0), tmp) (glwe_trace.rs:124-126)
+        DV dv{ggsw, (long long)cols * ct_r, cols, rsz}, sv{(int64_t*)row_src, ct_t, cols, tsz};
+        for (int c = 0; c < cols; ++c) PZ_TRY(dev_normalize(M, B * rows, dv, k_res, 0, c, sv, k_atk, c));
+    }
     pz_glwe_op_params ep = tp;
     ep.dnum = p->tsk_dnum; ep.key_size = p->tsk_size; ep.a_size = (uint64_t)rsz; ep.res_size = (uint64_t)rsz;
+    ep.key_base2k = (uint64_t)k_tsk; ep.a_base2k = (uint64_t)k_res; ep.res_base2k = (uint64_t)k_res;
     return ggsw_expand_row(M, ggsw, p->res_dnum, tsk_pmats, &ep, batch);
 }
 int pz_circuit_bootstrapping_execute_to_constant_batched(pz_module* M, int64_t* ggsw, const int64_t* lwe_2n, const int64_t* lut,

@@ -41,7 +41,8 @@ class BlindRotationParams(C.Structure):
 class CircuitBootstrappingParams(C.Structure):
     """pz_circuit_bootstrapping_params (include/poulpy_hip.h)"""
     _fields_ = [("br", BlindRotationParams)] + [(k, c_uint64) for k in ("atk_dnum", "atk_size", "tsk_dnum", "tsk_size", "res_dnum",
-                                                                         "res_size", "gap", "extension_factor")]
+                                                                         "res_size", "gap", "extension_factor", "atk_base2k",
+                                                                         "tsk_base2k", "res_base2k", "atk_glwe_size", "trace_size")]
 
 
 class GlweTensorParams(C.Structure):

@@ -1560,6 +1560,85 @@ def test_circuit_bootstrapping_to_exponent(mods, n, rank, log_gap_in, log_gap_ou
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n,rank,bases,res_limbs,block_size,mode", [
+    (256, 1, (13, 11, 12, 15), 2, 3, "constant"),     # the reference's test bases (brk, atk, tsk, res), tests/circuit_bootstrapping.rs:49-53
+    (256, 2, (13, 11, 12, 15), 2, 2, "constant"),     # rank 2
+    (512, 1, (12, 17, 12, 9), 3, 1, "constant"),      # automorphism keys in the largest base, standard rotation
+    (256, 1, (13, 11, 12, 15), 2, 3, "exponent"),     # post_process with equal gaps (partial trace)
+    (256, 1, (13, 11, 12, 15), 2, 3, "repack"),       # post_process with repacking (tests/circuit_bootstrapping.rs:36-227)
+    (2048, 1, (13, 11, 12, 15), 2, 3, "constant"),    # small-ring transforms in the rotation, two-kernel pipeline in the trace
+    (256, 1, (13, 13, 13, 15), 2, 3, "constant"),     # only the result in another base
+])
+def test_circuit_bootstrapping_one_base2k_per_object(mods, n, rank, bases, res_limbs, block_size, mode):
+    """circuit.rs:219-421 the way the reference's own tests run it: the blind-rotation key, the automorphism keys, the tensor keys and the
+    result each in their own base2k (glwe_normalize between the layouts, glwe_trace's closing normalize, ggsw_expand_row's conversion);
+    through the C ABI vs the oracle (tests/test_oracle_cbt.py pins that one on the composition of the primitives)."""
+    from poulpy_amd.hal import BlindRotationParams, CircuitBootstrappingParams
+    from tests.test_oracle_cbt import cbt_shape, make_cbt_inputs
+    k_brk, k_atk, k_tsk, k_res = bases
+    n_lwe, brk_dnum, res_dnum, batch = 6, 2, 2, 3
+    ref, hip = mods(n)
+    rng = seeded(4400 + n + rank + sum(bases))
+    cols = rank + 1
+    log_n = n.bit_length() - 1
+    sh = cbt_shape(k_res, k_brk, k_tsk, k_atk, res_limbs)
+    atk_dnum, tsk_dnum = sh["trace_size"], sh["res_conv_size"]
+
+    def prep_hip(rows, cols_in, size, mat):
+        ph = hip.vmp_pmat_alloc(rows, cols_in, cols, size)
+        hip.vmp_prepare(ph, mat)
+        hip.sync()
+        return ph
+
+    lut, brk, gals, atk, tsk = make_cbt_inputs(ref, n, rank, n_lwe, brk_dnum, bases, sh, atk_dnum, tsk_dnum, rng, prepare_also=prep_hip)
+    brk_r = np.stack([b[0].data.reshape(-1) for b in brk])
+    brk_h = np.stack([b[1].data.reshape(-1) for b in brk])
+    lwe = rng.integers(-n, n, (batch, n_lwe + 1), dtype=np.int64)
+    gap = 2 * int(rng.integers(1, n // 8))
+    log_gap_in, log_gap_out, log_domain = {"constant": (0, 0, 0), "exponent": (4, 4, 2), "repack": (4, 2, 2)}[mode]
+    xpa = ref.blind_rotation_x_pow_a() if block_size > 1 else np.zeros((1, 1))
+    want = np.empty((batch, res_dnum, cols, sh["res_size"], cols, n), dtype=np.int64)
+    for b in range(batch):
+        g = MatZnx(n, res_dnum, cols, cols, sh["res_size"])
+        ref.circuit_bootstrap_bases(g, bases, mode != "constant", np.ascontiguousarray(lwe[b]), lut, brk_r, brk_dnum, sh["glwe_size"],
+                                    sh["glwe_size"], sh["atk_glwe_size"], sh["trace_size"], block_size, xpa, gals, [a[0] for a in atk],
+                                    [t[0] for t in tsk], gap, log_gap_in, log_gap_out, log_domain)
+        want[b] = g.data
+    bufs = []
+
+    def up(arr):
+        d = hip.device_alloc(arr.nbytes).upload(arr)
+        bufs.append(d)
+        return d
+
+    d_lwe, d_lut, d_brk = up(lwe), up(lut.data), up(brk_h)
+    d_atk = [up(a[1].data) for a in atk]
+    d_tsk = [up(t[1].data) for t in tsk]
+    d_res = up(rng.integers(-5, 5, want.shape, dtype=np.int64))
+    p = CircuitBootstrappingParams(
+        br=BlindRotationParams(rank=rank, n_lwe=n_lwe, block_size=block_size, dnum=brk_dnum, brk_size=sh["glwe_size"], base2k=k_brk,
+                               res_size=sh["glwe_size"], lut_size=sh["glwe_size"]),
+        atk_dnum=atk_dnum, atk_size=sh["atk_size"], tsk_dnum=tsk_dnum, tsk_size=sh["tsk_size"], res_dnum=res_dnum, res_size=sh["res_size"],
+        gap=gap, atk_base2k=k_atk, tsk_base2k=k_tsk, res_base2k=k_res, atk_glwe_size=sh["atk_glwe_size"], trace_size=sh["trace_size"])
+    if mode == "constant":
+        nbytes = hip.circuit_bootstrapping_tmp_bytes(p, batch)
+        d_tmp = up(np.zeros(nbytes // 8 + 1, dtype=np.int64))
+        hip.circuit_bootstrapping_execute_to_constant_batched(d_res.ptr, d_lwe.ptr, d_lut.ptr, d_brk.ptr, gals, [k.ptr for k in d_atk],
+                                                              [k.ptr for k in d_tsk], p, d_tmp.ptr, nbytes, batch)
+    else:
+        nbytes = hip.circuit_bootstrapping_to_exponent_tmp_bytes(p, log_domain, batch)
+        d_tmp = up(np.zeros(nbytes // 8 + 1, dtype=np.int64))
+        hip.circuit_bootstrapping_execute_to_exponent_batched(d_res.ptr, d_lwe.ptr, d_lut.ptr, d_brk.ptr, gals, [k.ptr for k in d_atk],
+                                                              [k.ptr for k in d_tsk], p, log_gap_in, log_gap_out, log_domain, d_tmp.ptr,
+                                                              nbytes, batch)
+    hip.sync()
+    got = d_res.download(np.int64, want.size).reshape(want.shape)
+    for buf in bufs:
+        buf.free()
+    assert np.array_equal(got[:, :, 0], want[:, :, 0]), "rows before ggsw_expand_row differ"
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("n,rank,ext,n_lwe,blk,dnum,bsz,rsz,batch,fuse", [
     (256, 1, 2, 7, 3, 2, 2, 2, 5, True),
     (256, 1, 4, 6, 2, 2, 3, 2, 4, True),
