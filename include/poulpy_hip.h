@@ -308,11 +308,14 @@ int pz_glwe_keyswitch_batched(pz_module* m, int64_t* res, const int64_t* a, cons
 enum { PZ_AUTO = 0, PZ_AUTO_ADD = 1, PZ_AUTO_SUB = 2, PZ_AUTO_SUB_NEGATE = 3 };
 int pz_glwe_automorphism_batched(pz_module* m, int64_t* res, const int64_t* a, const double* key_pmat,
                                  const pz_glwe_op_params* p, int64_t gal, int mode, size_t batch);
-/* CoreImpl glwe_trace_assign (poulpy-core/src/glwe_trace.rs:129-176) on `batch` ciphertexts, for res and keys of one base2k:
+/* CoreImpl glwe_trace_assign (poulpy-core/src/glwe_trace.rs:129-176) on `batch` ciphertexts:
  * for s < nsteps:  res = rsh(res, 1 bit);  res = glwe_automorphism_add_assign(res, key_s)   (:164-174).
  * The caller resolves the steps skip..log_n into Galois elements (i = 0: -1, else galois_element(2^(i-1)),
  * poulpy-hal/src/layouts/module.rs:214-226) and the matching prepared automorphism keys: gals[s], key_pmats[s] are HOST
- * arrays; each key_pmats[s] and res are device pointers.  p describes one step (a_size = res_size, equal base2k). */
+ * arrays; each key_pmats[s] and res are device pointers.  res and keys of one base2k: p describes one step (a_size = res_size,
+ * equal base2k).  res in another base than the keys (:153-163, the case test_suite/trace.rs runs): (res_size, res_base2k) is res,
+ * (a_size, a_base2k = key_base2k) its layout re-expressed in the keys' base, a_size = ceil(res.max_k / key_base2k); res is
+ * normalized into a temporary of that layout, traced there and normalized back. */
 int pz_glwe_trace_batched(pz_module* m, int64_t* res, size_t nsteps, const int64_t* gals, const double* const* key_pmats,
                           const pz_glwe_op_params* p, size_t batch);
 /* GLWEPacking::glwe_pack (poulpy-core/src/glwe_packing.rs:122-176, pack_internal :15-87) on `batch` independent packing
@@ -327,6 +330,13 @@ size_t pz_glwe_pack_tmp_bytes(const pz_module* m, const pz_glwe_op_params* p, si
 int pz_glwe_pack_batched(pz_module* m, int64_t* res, size_t nslots, const uint64_t* indices, int64_t* const* cts,
                          size_t log_gap_out, const int64_t* gals, const double* const* key_pmats, const pz_glwe_op_params* p,
                          void* tmp, size_t tmp_bytes, size_t batch);
+/* the same with the automorphism keys in their own base (the case test_suite/glwe_packing.rs:40-42 runs: ciphertexts and result in
+ * base2k - 1, keys in base2k): p->a = p->res = the ciphertexts' layout, p->key_base2k the keys'; trace_size = limbs of the closing
+ * trace's temporary in the keys' base, ceil(max(a.max_k, res.max_k) / key_base2k) (glwe_trace.rs:107-112) */
+size_t pz_glwe_pack_bases_tmp_bytes(const pz_module* m, const pz_glwe_op_params* p, size_t trace_size, size_t batch);
+int pz_glwe_pack_bases_batched(pz_module* m, int64_t* res, size_t nslots, const uint64_t* indices, int64_t* const* cts,
+                               size_t log_gap_out, const int64_t* gals, const double* const* key_pmats, const pz_glwe_op_params* p,
+                               size_t trace_size, void* tmp, size_t tmp_bytes, size_t batch);
 /* CoreImpl ggsw_external_product (poulpy-core/src/external_product/ggsw.rs:54-58): res[row][col] = a[row][col] (x) ggsw
  * for the a_dnum * (rank+1) GLWE entries of the GGSW `a` (MatZnx layout: entries are contiguous), device pointers. */
 int pz_ggsw_external_product(pz_module* m, int64_t* res, const int64_t* a, size_t a_dnum, const double* ggsw_pmat,

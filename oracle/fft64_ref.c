@@ -2054,6 +2054,14 @@ static void glwe_rotate_to(size_t n, size_t cols, size_t size, int64_t k, int64_
 }
 void pzr_glwe_pack(const pzr_tables* t, size_t rank, int64_t* res, int64_t** slots, size_t size, size_t base2k, size_t log_gap_out,
                    const int64_t* gals, const double* const* keys, size_t dnum, size_t key_size) {
+    pzr_glwe_pack_bases(t, rank, res, slots, size, base2k, base2k, size, log_gap_out, gals, keys, dnum, key_size);
+}
+
+/* the same with the automorphism keys in their own base (test_suite/glwe_packing.rs:40-42: ciphertexts and result base2k - 1, keys
+ * base2k): pack_internal's arithmetic stays in the ciphertexts' base, the automorphisms convert (automorphism/glwe_ct.rs), the closing
+ * glwe_trace (glwe_trace.rs:91-127) runs on a temporary of trace_size = ceil(max(a.k, res.k) / key_base2k) limbs in the keys' base */
+void pzr_glwe_pack_bases(const pzr_tables* t, size_t rank, int64_t* res, int64_t** slots, size_t size, size_t base2k, size_t key_base2k,
+                         size_t trace_size, size_t log_gap_out, const int64_t* gals, const double* const* keys, size_t dnum, size_t key_size) {
     size_t n = t->m << 1, cols = rank + 1, ct = n * cols * size;
     size_t log_n = 0;
     while (((size_t)1 << log_n) < n) ++log_n;
@@ -2076,7 +2084,7 @@ void pzr_glwe_pack(const pzr_tables* t, size_t rank, int64_t* res, int64_t** slo
                     glwe_rsh1(n, cols, size, base2k, a);
                     for (size_t c = 0; c < cols; ++c) pzr_vec_znx_normalize_assign(n, base2k, tmp_b, cols, size, c);
                     memcpy(tmp, tmp_b, ct * sizeof(int64_t));                         /* tmp_b = phi(tmp_b) (glwe_automorphism_assign) */
-                    pzr_glwe_automorphism(t, rank, PZR_KS_AUTO, gals[i], tmp_b, size, base2k, tmp, size, base2k, keys[i], dnum, key_size, 1, base2k);
+                    pzr_glwe_automorphism(t, rank, PZR_KS_AUTO, gals[i], tmp_b, size, base2k, tmp, size, base2k, keys[i], dnum, key_size, 1, key_base2k);
                     for (size_t c = 0; c < cols; ++c) pzr_vec_znx_assign_op(1, n, a, cols, size, c, tmp_b, cols, size, c); /* a -= tmp_b */
                     for (size_t c = 0; c < cols; ++c) pzr_vec_znx_normalize_assign(n, base2k, a, cols, size, c);
                     glwe_rotate_to(n, cols, size, (int64_t)tt, tmp, a);              /* a = a * X^t */
@@ -2084,14 +2092,14 @@ void pzr_glwe_pack(const pzr_tables* t, size_t rank, int64_t* res, int64_t** slo
                 } else { /* :71-75 */
                     glwe_rsh1(n, cols, size, base2k, a);
                     memcpy(tmp, a, ct * sizeof(int64_t));
-                    pzr_glwe_automorphism(t, rank, PZR_KS_AUTO_ADD, gals[i], a, size, base2k, tmp, size, base2k, keys[i], dnum, key_size, 1, base2k);
+                    pzr_glwe_automorphism(t, rank, PZR_KS_AUTO_ADD, gals[i], a, size, base2k, tmp, size, base2k, keys[i], dnum, key_size, 1, key_base2k);
                 }
                 slots[j] = a; /* :168-169 */
             } else if (b) { /* :76-86 */
                 glwe_rotate_to(n, cols, size, (int64_t)tt, tmp_b, b);
                 glwe_rsh1(n, cols, size, base2k, tmp_b);
                 pzr_glwe_automorphism(t, rank, PZR_KS_AUTO_SUB_NEGATE, gals[i], b, size, base2k, tmp_b, size, base2k, keys[i], dnum, key_size, 1,
-                                      base2k);
+                                      key_base2k);
                 slots[j] = b; /* :170-171 */
             }
         }
@@ -2102,12 +2110,38 @@ void pzr_glwe_pack(const pzr_tables* t, size_t rank, int64_t* res, int64_t** slo
         free(tmp);
         return;
     }
-    memcpy(res, slots[0], ct * sizeof(int64_t));
     size_t skip = log_n - log_gap_out;
-    pzr_glwe_trace_assign(t, rank, res, size, base2k, log_n - skip, gals + skip, keys + skip, dnum, key_size, 1);
+    if (key_base2k == base2k) { /* glwe_copy both ways (trace_size == size) */
+        memcpy(res, slots[0], ct * sizeof(int64_t));
+        pzr_glwe_trace_assign(t, rank, res, size, base2k, log_n - skip, gals + skip, keys + skip, dnum, key_size, 1);
+    } else { /* glwe_normalize into the keys' base, trace there, glwe_normalize back */
+        int64_t* tr = (int64_t*)calloc(n * cols * trace_size, sizeof(int64_t));
+        for (size_t c = 0; c < cols; ++c) pzr_vec_znx_normalize(n, tr, cols, trace_size, key_base2k, 0, c, slots[0], cols, size, base2k, c);
+        pzr_glwe_trace_assign(t, rank, tr, trace_size, key_base2k, log_n - skip, gals + skip, keys + skip, dnum, key_size, 1);
+        for (size_t c = 0; c < cols; ++c) pzr_vec_znx_normalize(n, res, cols, size, base2k, 0, c, tr, cols, trace_size, key_base2k, c);
+        free(tr);
+    }
     free(tmp_b);
     free(tmp);
 }
+
+/* glwe_trace_assign with res in another base than the keys (glwe_trace.rs:153-163; test_suite/trace.rs:36-39 runs result base2k, keys
+ * base2k - 1): res re-expressed in the keys' base on conv_size = ceil(res.max_k / key_base2k) limbs, traced there, normalized back */
+void pzr_glwe_trace_assign_bases(const pzr_tables* t, size_t rank, int64_t* res, size_t res_size, size_t res_base2k, size_t conv_size,
+                                 size_t key_base2k, size_t nsteps, const int64_t* gals, const double* const* key_pmats,
+                                 size_t dnum, size_t key_size, size_t dsize) {
+    if (res_base2k == key_base2k) {
+        pzr_glwe_trace_assign(t, rank, res, res_size, res_base2k, nsteps, gals, key_pmats, dnum, key_size, dsize);
+        return;
+    }
+    size_t n = t->m << 1, cols = rank + 1;
+    int64_t* conv = (int64_t*)calloc(n * cols * conv_size, sizeof(int64_t));
+    for (size_t c = 0; c < cols; ++c) pzr_vec_znx_normalize(n, conv, cols, conv_size, key_base2k, 0, c, res, cols, res_size, res_base2k, c);
+    pzr_glwe_trace_assign(t, rank, conv, conv_size, key_base2k, nsteps, gals, key_pmats, dnum, key_size, dsize);
+    for (size_t c = 0; c < cols; ++c) pzr_vec_znx_normalize(n, res, cols, res_size, res_base2k, 0, c, conv, cols, conv_size, key_base2k, c);
+    free(conv);
+}
+
 
 /* poulpy-bin-fhe/src/circuit_bootstrapping/circuit.rs:219-370 with to_exponent = true and post_process :373-421, one base2k,
  * res_size <= glwe_size (so that every intermediate has the GLWE's size).  The lookup table, gap (:333) and log_gap_in (:342)

@@ -217,6 +217,15 @@ void pzr_circuit_bootstrap_to_constant(const pzr_tables* t, size_t rank, size_t 
 void pzr_glwe_pack(const pzr_tables* t, size_t rank, int64_t* res, int64_t** slots, size_t size, size_t base2k, size_t log_gap_out,
                    const int64_t* gals, const double* const* keys, size_t dnum, size_t key_size);
 
+/* glwe_pack with the automorphism keys in their own base (test_suite/glwe_packing.rs:40-42); trace_size = limbs of the closing trace's
+ * temporary, ceil(max(a.k, res.k) / key_base2k) (glwe_trace.rs:107-112) */
+void pzr_glwe_pack_bases(const pzr_tables* t, size_t rank, int64_t* res, int64_t** slots, size_t size, size_t base2k, size_t key_base2k,
+                         size_t trace_size, size_t log_gap_out, const int64_t* gals, const double* const* keys, size_t dnum, size_t key_size);
+/* glwe_trace_assign with res in another base than the keys (glwe_trace.rs:153-163); conv_size = ceil(res.max_k / key_base2k) */
+void pzr_glwe_trace_assign_bases(const pzr_tables* t, size_t rank, int64_t* res, size_t res_size, size_t res_base2k, size_t conv_size,
+                                 size_t key_base2k, size_t nsteps, const int64_t* gals, const double* const* key_pmats,
+                                 size_t dnum, size_t key_size, size_t dsize);
+
 /* circuit.rs:219-370 with to_exponent = true (+ post_process :373-421), one base2k, res_size <= glwe_size */
 void pzr_circuit_bootstrap_to_exponent(const pzr_tables* t, size_t rank, size_t base2k,
                                        size_t n_lwe, size_t block_size, const int64_t* lwe_2n, const int64_t* lut, size_t lut_size,

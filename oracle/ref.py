@@ -355,6 +355,29 @@ class RefModule:
         self.lib.pzr_glwe_pack(self.t, c_size_t(rank), _p(res.data), slots, *_sz(res.size, base2k, log_gap_out), g, ptrs,
                                *_sz(pmats[0].rows, pmats[0].size))
 
+    def glwe_pack_bases(self, res, base2k, key_base2k, trace_size, cts: dict, log_gap_out, gals, pmats):
+        """glwe_packing.rs:122-176 with the automorphism keys in their own base; trace_size: limbs of the closing trace's temporary."""
+        rank = res.cols - 1
+        n = self._n
+        slots = (c_void_p * n)()
+        for j, ct in cts.items():
+            assert ct.cols == res.cols and ct.size == res.size
+            slots[j] = ct.data.ctypes.data
+        ns = len(gals)
+        g = (c_int64 * ns)(*[int(x) for x in gals])
+        ptrs = (c_void_p * ns)(*[pm.data.ctypes.data for pm in pmats])
+        self.lib.pzr_glwe_pack_bases(self.t, c_size_t(rank), _p(res.data), slots, *_sz(res.size, base2k, key_base2k, trace_size, log_gap_out),
+                                     g, ptrs, *_sz(pmats[0].rows, pmats[0].size))
+
+    def glwe_trace_assign_bases(self, res, res_base2k, conv_size, key_base2k, gals, pmats, dsize=1):
+        """glwe_trace.rs:129-176 with res in another base than the keys (:153-163)."""
+        rank = res.cols - 1
+        ns = len(gals)
+        g = (c_int64 * ns)(*[int(x) for x in gals])
+        ptrs = (c_void_p * ns)(*[pm.data.ctypes.data for pm in pmats])
+        self.lib.pzr_glwe_trace_assign_bases(self.t, c_size_t(rank), _p(res.data), *_sz(res.size, res_base2k, conv_size, key_base2k),
+                                             c_size_t(ns), g, ptrs, *_sz(pmats[0].rows, pmats[0].size, dsize))
+
     def circuit_bootstrap_to_exponent(self, ggsw, base2k, lwe_2n, lut, brk, brk_dnum, brk_size, glwe_size, block_size, x_pow_a, gals,
                                       atk, tsk, gap, log_gap_in, log_gap_out, log_domain):
         """circuit.rs:219-421 (to_exponent = true, one base2k); gals / atk: all log_n trace steps."""

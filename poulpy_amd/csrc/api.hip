@@ -1075,14 +1075,34 @@ int pz_ggsw_from_gglwe_batched(pz_module* M, int64_t* ggsw, const int64_t* a, si
     return ggsw_expand_row(M, ggsw, dnum, tsk_pmat, p, count);  // (the module lock is not recursive)
 }
 
-// glwe_trace_assign (poulpy-core/src/glwe_trace.rs:129-176) on `batch` ciphertexts, equal base2k for res and keys:
+// glwe_trace_assign (poulpy-core/src/glwe_trace.rs:129-176) on `batch` ciphertexts:
 //   for every step s:  res = rsh(res, 1 bit) on every column (operations/glwe.rs:1096-1112);  res = glwe_automorphism_add_assign(res, key_s)
+// res in another base than the keys (:153-163; test_suite/trace.rs:36-39): (a_size, a_base2k = key_base2k) describe res re-expressed in
+// the keys' base (a_size = ceil(res.max_k / key_base2k)); normalize into a temporary of that layout, trace there, normalize back.
 int glwe_trace(pz_module* M, int64_t* res, size_t nsteps, const int64_t* gals, const double* const* key_pmats,
                       const pz_glwe_op_params* p, size_t batch) {
     PZ_REQUIRE(p != nullptr && (nsteps == 0 || (gals != nullptr && key_pmats != nullptr)), "glwe_trace: null argument");
-    PZ_REQUIRE(p->a_size == p->res_size && p->a_base2k == p->res_base2k && p->res_base2k == p->key_base2k && p->rank_out == p->rank,
-               "glwe_trace: res and keys must share base2k, and a/res one layout (the other cases re-normalize around this call)");
+    PZ_REQUIRE(p->rank_out == p->rank, "glwe_trace: rank_out != rank");
     PZ_REQUIRE(is_device_ptr(res), "batched entry points take device pointers");
+    if (p->res_base2k != p->key_base2k) {
+        PZ_REQUIRE(p->a_base2k == p->key_base2k && p->a_size >= 1 && p->res_size >= 1,
+                   "glwe_trace: with res in another base than the keys, (a_size, a_base2k) is its layout in the keys' base");
+        if (batch == 0) return PZ_OK;
+        const long long n = (long long)M->n;
+        const int cols = (int)p->rank + 1, B = (int)batch;
+        const long long ct_c = n * cols * (long long)p->a_size, ct_r = n * cols * (long long)p->res_size;
+        PZ_TRY(ws2_reserve(M, (size_t)B * ct_c * 8));
+        int64_t* conv = (int64_t*)M->ws2;
+        DV cv{conv, ct_c, cols, (int)p->a_size}, rv{res, ct_r, cols, (int)p->res_size};
+        for (int c = 0; c < cols; ++c) PZ_TRY(dev_normalize(M, B, cv, (int)p->key_base2k, 0, c, rv, (int)p->res_base2k, c));
+        pz_glwe_op_params q = *p;
+        q.res_size = p->a_size; q.res_base2k = p->key_base2k;
+        PZ_TRY(glwe_trace(M, conv, nsteps, gals, key_pmats, &q, batch));
+        for (int c = 0; c < cols; ++c) PZ_TRY(dev_normalize(M, B, rv, (int)p->res_base2k, 0, c, cv, (int)p->key_base2k, c));
+        return PZ_OK;
+    }
+    PZ_REQUIRE(p->a_size == p->res_size && p->a_base2k == p->res_base2k,
+               "glwe_trace: a and res describe the same ciphertexts when res is in the keys' base");
     if (batch == 0) return PZ_OK;
     const long long n = (long long)M->n;
     const int cols = (int)p->rank + 1;

@@ -286,7 +286,7 @@ int pz_blind_rotation_execute_batched(pz_module* M, int64_t* res, const int64_t*
 // ------------------------------------------------------------------------------
 static int glwe_pack(pz_module* M, int64_t* res, size_t nslots, const uint64_t* indices, int64_t* const* cts, size_t log_gap_out,
                      const int64_t* gals, const double* const* key_pmats, const pz_glwe_op_params* p, void* tmp, size_t tmp_bytes,
-                     size_t batch);
+                     size_t batch, size_t trace_size);
 struct CbtRepack { size_t log_gap_in, log_gap_out, log_domain; };  // exponent mode with log_gap_in != log_gap_out (post_process)
 static inline size_t cbt_atk_size(const pz_circuit_bootstrapping_params* p) { return (size_t)(p->atk_glwe_size ? p->atk_glwe_size : p->br.res_size); }
 static inline size_t cbt_tmp_size(const pz_circuit_bootstrapping_params* p) {
@@ -387,7 +387,7 @@ static int circuit_bootstrapping(pz_module* M, int64_t* ggsw, const int64_t* lwe
         }
         int64_t* packed = (int64_t*)(base + steps * rows_ct);
         void* pack_tmp = (void*)(base + (steps + 1) * rows_ct);
-        PZ_TRY(glwe_pack(M, packed, steps, idx.data(), cts.data(), rp->log_gap_out, gals, atk_pmats, &tp, pack_tmp, 3 * rows_ct, (size_t)B * rows));
+        PZ_TRY(glwe_pack(M, packed, steps, idx.data(), cts.data(), rp->log_gap_out, gals, atk_pmats, &tp, pack_tmp, 3 * rows_ct, (size_t)B * rows, 0));
         row_src = packed;
     }
     if (k_res == k_atk) {
@@ -454,18 +454,27 @@ size_t pz_glwe_pack_tmp_bytes(const pz_module* M, const pz_glwe_op_params* p, si
     if (!M || !p) return 0;
     return 3 * align256(batch * (size_t)M->n * (p->rank + 1) * p->res_size * 8);
 }
+size_t pz_glwe_pack_bases_tmp_bytes(const pz_module* M, const pz_glwe_op_params* p, size_t trace_size, size_t batch) {
+    if (!M || !p) return 0;
+    return pz_glwe_pack_tmp_bytes(M, p, batch) + align256(batch * (size_t)M->n * (p->rank + 1) * trace_size * 8);
+}
+// trace_size = 0: ciphertexts, keys and result share one base2k.  Otherwise the keys have their own (test_suite/glwe_packing.rs:40-42):
+// pack_internal's arithmetic stays in the ciphertexts' base, the automorphisms convert, and the closing glwe_trace (glwe_trace.rs:91-127)
+// runs on a temporary of trace_size limbs in the keys' base (behind the three ciphertext arrays of tmp).
 static int glwe_pack(pz_module* M, int64_t* res, size_t nslots, const uint64_t* indices, int64_t* const* cts, size_t log_gap_out,
                      const int64_t* gals, const double* const* key_pmats, const pz_glwe_op_params* p, void* tmp, size_t tmp_bytes,
-                     size_t batch) {
+                     size_t batch, size_t trace_size) {
     PZ_REQUIRE(p != nullptr && indices != nullptr && cts != nullptr && gals != nullptr && key_pmats != nullptr, "glwe_pack: null argument");
-    PZ_REQUIRE(p->a_size == p->res_size && p->a_base2k == p->res_base2k && p->res_base2k == p->key_base2k && p->rank_out == p->rank &&
-                   p->dsize == 1,
-               "glwe_pack: ciphertexts, keys and result share base2k and size (the other cases re-normalize around this call)");
+    PZ_REQUIRE(p->a_size == p->res_size && p->a_base2k == p->res_base2k && p->rank_out == p->rank && p->dsize == 1,
+               "glwe_pack: ciphertexts and result share base2k and size");
+    PZ_REQUIRE(p->res_base2k == p->key_base2k || trace_size >= 1,
+               "glwe_pack: keys in another base than the ciphertexts need pz_glwe_pack_bases_batched (trace_size)");
+    if (p->res_base2k == p->key_base2k) trace_size = 0;
     size_t log_n = 0;
     while (((size_t)1 << log_n) < (size_t)M->n) ++log_n;
     PZ_REQUIRE(log_gap_out <= log_n && nslots >= 1, "glwe_pack: bad shape");
     PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(tmp), "batched entry points take device pointers");
-    PZ_REQUIRE(tmp_bytes >= pz_glwe_pack_tmp_bytes(M, p, batch), "glwe_pack: tmp is smaller than pz_glwe_pack_tmp_bytes");
+    PZ_REQUIRE(tmp_bytes >= pz_glwe_pack_bases_tmp_bytes(M, p, trace_size, batch), "glwe_pack: tmp is smaller than pz_glwe_pack[_bases]_tmp_bytes");
     if (batch == 0) return PZ_OK;
     const long long n = (long long)M->n;
     const int cols = (int)p->rank + 1, size = (int)p->res_size, k = (int)p->res_base2k, B = (int)batch;
@@ -535,15 +544,34 @@ static int glwe_pack(pz_module* M, int64_t* res, size_t nslots, const uint64_t* 
         }
     }
     PZ_REQUIRE(slots[0] != nullptr, "glwe_pack: no ciphertext ends at index 0");   // :175 a.get(&0).unwrap()
-    PZ_TRY(launch_ew(M, EW_COPY, res, ct, n, slots[0], ct, n, nullptr, 0, 0, cols * size, B));
     const size_t skip = log_n - log_gap_out;
-    return glwe_trace(M, res, log_n - skip, gals + skip, key_pmats + skip, p, batch);
+    if (trace_size == 0) {   // glwe_copy both ways
+        PZ_TRY(launch_ew(M, EW_COPY, res, ct, n, slots[0], ct, n, nullptr, 0, 0, cols * size, B));
+        return glwe_trace(M, res, log_n - skip, gals + skip, key_pmats + skip, p, batch);
+    }
+    const int kk = (int)p->key_base2k, tsz = (int)trace_size;
+    const long long ct_t = n * cols * tsz;
+    int64_t* tr = (int64_t*)((char*)tmp + 3 * ctb);
+    DV tv{tr, ct_t, cols, tsz}, sv{slots[0], ct, cols, size}, rv{res, ct, cols, size};
+    for (int c = 0; c < cols; ++c) PZ_TRY(dev_normalize(M, B, tv, kk, 0, c, sv, k, c));
+    pz_glwe_op_params q = *p;
+    q.a_size = q.res_size = (uint64_t)tsz; q.a_base2k = q.res_base2k = p->key_base2k;
+    PZ_TRY(glwe_trace(M, tr, log_n - skip, gals + skip, key_pmats + skip, &q, batch));
+    for (int c = 0; c < cols; ++c) PZ_TRY(dev_normalize(M, B, rv, k, 0, c, tv, kk, c));
+    return PZ_OK;
 }
 int pz_glwe_pack_batched(pz_module* M, int64_t* res, size_t nslots, const uint64_t* indices, int64_t* const* cts, size_t log_gap_out,
                          const int64_t* gals, const double* const* key_pmats, const pz_glwe_op_params* p, void* tmp, size_t tmp_bytes,
                          size_t batch) {
     PZ_ENTER(M);
-    return glwe_pack(M, res, nslots, indices, cts, log_gap_out, gals, key_pmats, p, tmp, tmp_bytes, batch);
+    return glwe_pack(M, res, nslots, indices, cts, log_gap_out, gals, key_pmats, p, tmp, tmp_bytes, batch, 0);
+}
+int pz_glwe_pack_bases_batched(pz_module* M, int64_t* res, size_t nslots, const uint64_t* indices, int64_t* const* cts, size_t log_gap_out,
+                               const int64_t* gals, const double* const* key_pmats, const pz_glwe_op_params* p, size_t trace_size, void* tmp,
+                               size_t tmp_bytes, size_t batch) {
+    PZ_ENTER(M);
+    PZ_REQUIRE(trace_size >= 1, "glwe_pack: trace_size = 0");
+    return glwe_pack(M, res, nslots, indices, cts, log_gap_out, gals, key_pmats, p, tmp, tmp_bytes, batch, trace_size);
 }
 
 }  // extern "C"

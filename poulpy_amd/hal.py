@@ -78,7 +78,7 @@ def load_library(path: str | None = None) -> C.CDLL:
                  "pz_vmp_apply_dft_tmp_bytes", "pz_vmp_apply_dft_to_dft_tmp_bytes", "pz_vec_znx_big_normalize_tmp_bytes",
                  "pz_glwe_op_workspace_bytes", "pz_vec_znx_automorphism_assign_tmp_bytes",
                  "pz_vec_znx_big_automorphism_assign_tmp_bytes", "pz_blind_rotation_workspace_bytes", "pz_vec_znx_rsh_tmp_bytes", "pz_vec_znx_rotate_assign_tmp_bytes",
-                 "pz_circuit_bootstrapping_tmp_bytes", "pz_vec_znx_normalize_tmp_bytes", "pz_vec_znx_lsh_tmp_bytes", "pz_glwe_pack_tmp_bytes",
+                 "pz_circuit_bootstrapping_tmp_bytes", "pz_vec_znx_normalize_tmp_bytes", "pz_vec_znx_lsh_tmp_bytes", "pz_glwe_pack_tmp_bytes", "pz_glwe_pack_bases_tmp_bytes",
                  "pz_circuit_bootstrapping_to_exponent_tmp_bytes", "pz_blind_rotation_extended_tmp_bytes",
                  "pz_cnv_prepare_left_tmp_bytes", "pz_cnv_prepare_right_tmp_bytes", "pz_cnv_prepare_self_tmp_bytes", "pz_cnv_apply_dft_tmp_bytes",
                  "pz_cnv_pairwise_apply_dft_tmp_bytes", "pz_cnv_by_const_apply_tmp_bytes", "pz_glwe_tensor_apply_workspace_bytes",
@@ -487,6 +487,21 @@ class Module:
         kp = (c_void_p * ng)(*[p.value if isinstance(p, c_void_p) else int(p) for p in key_ptrs])
         self._ck(self.lib.pz_glwe_pack_batched(self.handle, res, c_size_t(ns), idx, cp, c_size_t(log_gap_out), g, kp, C.byref(params), tmp,
                                                c_size_t(tmp_bytes), c_size_t(batch)))
+
+    def glwe_pack_bases_tmp_bytes(self, params: GlweOpParams, trace_size: int, batch: int) -> int:
+        return self.lib.pz_glwe_pack_bases_tmp_bytes(self.handle, C.byref(params), c_size_t(trace_size), c_size_t(batch))
+
+    def glwe_pack_bases_batched(self, res: c_void_p, indices, ct_ptrs, log_gap_out: int, gals, key_ptrs, params: GlweOpParams,
+                                trace_size: int, tmp: c_void_p, tmp_bytes: int, batch: int):
+        """glwe_pack with the automorphism keys in their own base (poulpy-core test_suite/glwe_packing.rs:40-42)."""
+        ns = len(indices)
+        idx = (c_uint64 * ns)(*[int(i) for i in indices])
+        cp = (c_void_p * ns)(*[p.value if isinstance(p, c_void_p) else int(p) for p in ct_ptrs])
+        ng = len(gals)
+        g = (c_int64 * ng)(*[int(x) for x in gals])
+        kp = (c_void_p * ng)(*[p.value if isinstance(p, c_void_p) else int(p) for p in key_ptrs])
+        self._ck(self.lib.pz_glwe_pack_bases_batched(self.handle, res, c_size_t(ns), idx, cp, c_size_t(log_gap_out), g, kp, C.byref(params),
+                                                     c_size_t(trace_size), tmp, c_size_t(tmp_bytes), c_size_t(batch)))
 
     def set_graphs(self, enable: bool):
         """HIP-graph replay of the launch-bound composite calls (blind rotation, trace, circuit bootstrapping); on by default."""

@@ -1223,6 +1223,102 @@ def test_glwe_trace_batched(mods, fuse):
         assert np.array_equal(got, want), (n, rank, size)
 
 
+@pytest.mark.parametrize("n,rank,res_k,key_k,kbits,batch,nsteps", [
+    (256, 1, 14, 13, 4 * 14 + 1, 3, 8),     # poulpy-core test_suite/trace.rs:36-39: result base2k, keys base2k - 1, k = 4 base2k + 1, full trace
+    (256, 2, 12, 15, 40, 2, 5),             # keys in the larger base, partial trace
+    (4096, 1, 13, 12, 4 * 13 + 1, 5, 3),    # fused automorphism pipeline under the conversions
+])
+def test_glwe_trace_batched_result_in_another_base_than_the_keys(mods, n, rank, res_k, key_k, kbits, batch, nsteps):
+    """glwe_trace_assign with res.base2k != key.base2k (glwe_trace.rs:153-163): normalize into the keys' base, trace, normalize back."""
+    from poulpy_amd.hal import GlweOpParams
+    ref, hip = mods(n)
+    rng = seeded(n + rank + res_k)
+    cols = rank + 1
+    res_size, conv_size = -(-kbits // res_k), -(-kbits // key_k)
+    key_size = -(-(kbits + key_k) // key_k)
+    dnum = conv_size
+    log_n = n.bit_length() - 1
+    gals = ([-1] + [pow(5, 1 << i, 2 * n) for i in range(log_n - 1)])[log_n - nsteps:]
+    prs, d_keys = [], []
+    for _ in gals:
+        mat = MatZnx(n, dnum, rank, cols, key_size).fill_uniform(key_k, rng)
+        pr, ph = ref.vmp_pmat_alloc(dnum, rank, cols, key_size), hip.vmp_pmat_alloc(dnum, rank, cols, key_size)
+        ref.vmp_prepare(pr, mat)
+        hip.vmp_prepare(ph, mat)
+        prs.append(pr)
+        d_keys.append(hip.device_alloc(ph.data.nbytes).upload(ph.data))
+    cts = np.empty((batch, res_size, cols, n), dtype=np.int64)
+    want = np.empty_like(cts)
+    for b in range(batch):
+        ct = VecZnx(n, cols, res_size).fill_uniform(res_k, rng)
+        cts[b] = ct.data
+        ref.glwe_trace_assign_bases(ct, res_k, conv_size, key_k, gals, prs)
+        want[b] = ct.data
+    d_res = hip.device_alloc(cts.nbytes).upload(cts)
+    p = GlweOpParams(rank=rank, dnum=dnum, dsize=1, key_size=key_size, key_base2k=key_k, a_size=conv_size, a_base2k=key_k, res_size=res_size,
+                     res_base2k=res_k, rank_out=rank)
+    for _ in range(3):    # second and third call: captured / replayed as a HIP graph, same contents restored each time
+        d_res.upload(cts)
+        hip.glwe_trace_batched(d_res.ptr, gals, [d.ptr for d in d_keys], p, batch)
+        hip.sync()
+        got = d_res.download(np.int64, want.size).reshape(want.shape)
+        assert np.array_equal(got, want)
+    for d in d_keys + [d_res]:
+        d.free()
+
+
+@pytest.mark.parametrize("n,rank,size,ct_k,key_k,log_gap_out,indices,batch", [
+    (64, 3, 3, 12, 13, 0, [0, 5, 17, 32, 33, 63], 2),      # poulpy-core test_suite/glwe_packing.rs:40-45: ciphertexts base2k - 1, keys base2k, rank 3
+    (256, 1, 3, 15, 11, 3, [0, 8, 16, 128, 136], 3),      # keys in the smaller base
+    (4096, 1, 3, 12, 13, 9, [0, 512, 1024, 2048, 3584], 2),
+])
+def test_glwe_pack_batched_keys_in_another_base(mods, n, rank, size, ct_k, key_k, log_gap_out, indices, batch):
+    """glwe_pack with ciphertexts / result and automorphism keys in different bases: pack_internal's arithmetic in the ciphertexts' base,
+    converting automorphisms, closing trace on a temporary in the keys' base."""
+    from poulpy_amd.hal import GlweOpParams
+    ref, hip = mods(n)
+    rng = seeded(7100 + n + rank + log_gap_out)
+    cols = rank + 1
+    log_n = n.bit_length() - 1
+    kbits = size * ct_k - 3
+    trace_size = -(-kbits // key_k)
+    key_size = -(-(kbits + key_k) // key_k)
+    dnum = trace_size
+    gals = [-1] + [pow(5, 1 << i, 2 * n) for i in range(log_n - 1)]
+    keys_r, keys_d = [], []
+    for _ in gals:
+        mat = MatZnx(n, dnum, rank, cols, key_size).fill_uniform(key_k, rng)
+        pr, ph = ref.vmp_pmat_alloc(dnum, rank, cols, key_size), hip.vmp_pmat_alloc(dnum, rank, cols, key_size)
+        ref.vmp_prepare(pr, mat)
+        hip.vmp_prepare(ph, mat)
+        hip.sync()
+        keys_r.append(pr)
+        keys_d.append(hip.device_alloc(ph.data.nbytes).upload(ph.data))
+    data = {j: rng.integers(-(1 << (ct_k - 1)), 1 << (ct_k - 1), (batch, size, cols, n), dtype=np.int64) for j in indices}
+    want = np.empty((batch, size, cols, n), dtype=np.int64)
+    for b in range(batch):
+        cts = {j: VecZnx(n, cols, size, data[j][b].copy()) for j in indices}
+        res = VecZnx(n, cols, size)
+        ref.glwe_pack_bases(res, ct_k, key_k, trace_size, cts, log_gap_out, gals, keys_r)
+        want[b] = res.data
+    d_cts = [hip.device_alloc(data[j].nbytes).upload(data[j]) for j in indices]
+    d_res = hip.device_alloc(want.nbytes)
+    p = GlweOpParams(rank=rank, dnum=dnum, dsize=1, key_size=key_size, key_base2k=key_k, a_size=size, a_base2k=ct_k, res_size=size,
+                     res_base2k=ct_k, rank_out=rank)
+    nbytes = hip.glwe_pack_bases_tmp_bytes(p, trace_size, batch)
+    d_tmp = hip.device_alloc(nbytes)
+    from poulpy_amd.hal import PoulpyHipError
+    with pytest.raises(PoulpyHipError):     # the one-base entry point refuses keys in another base
+        hip.glwe_pack_batched(d_res.ptr, indices, [d.ptr for d in d_cts], log_gap_out, gals, [k.ptr for k in keys_d], p, d_tmp.ptr, nbytes, batch)
+    hip.glwe_pack_bases_batched(d_res.ptr, indices, [d.ptr for d in d_cts], log_gap_out, gals, [k.ptr for k in keys_d], p, trace_size,
+                                d_tmp.ptr, nbytes, batch)
+    hip.sync()
+    got = d_res.download(np.int64, want.size).reshape(want.shape)
+    for buf in keys_d + d_cts + [d_res, d_tmp]:
+        buf.free()
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("n", [32, 1024, 65536])
 def test_vec_znx_rotate(mods, n):
     """hal_impl.rs:225-232: res = X^k * a for any k (negative, > 2n), ragged sizes, the assign form, other columns untouched."""

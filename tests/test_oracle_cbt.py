@@ -131,3 +131,70 @@ def test_cbt_bases_rows_carry_the_same_torus_values_in_any_result_base():
     for i in range(res_dnum):
         for c in range(rank + 1):
             assert exact.torus_equal(rows[15][i, :, c, :], 15, rows[10][i, :, c, :], 10, 0, 2)
+
+
+@pytest.mark.parametrize("res_k,key_k,kbits,rank", [(14, 13, 57, 1), (12, 15, 40, 2)])
+def test_trace_assign_bases_is_normalize_trace_normalize(res_k, key_k, kbits, rank):
+    """pzr_glwe_trace_assign_bases == glwe_trace.rs:153-163 written out on the pinned normalize (P3) and the equal-base trace"""
+    n = 64
+    ref = RefModule(n)
+    rng = seeded(res_k * 100 + key_k)
+    cols = rank + 1
+    res_size, conv_size, key_size = cdiv(kbits, res_k), cdiv(kbits, key_k), cdiv(kbits + key_k, key_k)
+    log_n = n.bit_length() - 1
+    gals = [-1] + [pow(5, 1 << i, 2 * n) for i in range(log_n - 1)]
+    keys = []
+    for _ in gals:
+        mat = MatZnx(n, conv_size, rank, cols, key_size).fill_uniform(key_k, rng)
+        pr = ref.vmp_pmat_alloc(conv_size, rank, cols, key_size)
+        ref.vmp_prepare(pr, mat)
+        keys.append(pr)
+    ct = VecZnx(n, cols, res_size).fill_uniform(res_k, rng)
+    got = ct.copy()
+    ref.glwe_trace_assign_bases(got, res_k, conv_size, key_k, gals, keys)
+    conv = VecZnx(n, cols, conv_size)
+    for c in range(cols):
+        ref.vec_znx_normalize(conv, key_k, 0, c, ct, res_k, c)
+    ref.glwe_trace_assign(conv, key_k, gals, keys)
+    want = VecZnx(n, cols, res_size)
+    for c in range(cols):
+        ref.vec_znx_normalize(want, res_k, 0, c, conv, key_k, c)
+    assert np.array_equal(got.data, want.data)
+
+
+def test_pack_bases_with_equal_bases_is_pack_and_a_lone_ciphertext_is_its_trace():
+    """pzr_glwe_pack_bases at equal bases is pzr_glwe_pack (P11); with one ciphertext at index 0 and log_gap_out = log_n nothing is packed
+    and the closing glwe_trace (skip = 0) is everything: normalize into the keys' base, full trace, normalize back (glwe_trace.rs:107-126)"""
+    n, rank, size, k = 64, 1, 3, 13
+    ref = RefModule(n)
+    rng = seeded(42)
+    cols = rank + 1
+    log_n = n.bit_length() - 1
+    gals = [-1] + [pow(5, 1 << i, 2 * n) for i in range(log_n - 1)]
+    keys = []
+    for _ in gals:
+        mat = MatZnx(n, size, rank, cols, size + 1).fill_uniform(k, rng)
+        pr = ref.vmp_pmat_alloc(size, rank, cols, size + 1)
+        ref.vmp_prepare(pr, mat)
+        keys.append(pr)
+    data = {j: VecZnx(n, cols, size).fill_uniform(k, rng) for j in (0, 5, 17, 32)}
+    r1, r2 = VecZnx(n, cols, size), VecZnx(n, cols, size)
+    ref.glwe_pack(r1, k, {j: v.copy() for j, v in data.items()}, 0, gals, keys)
+    ref.glwe_pack_bases(r2, k, k, size, {j: v.copy() for j, v in data.items()}, 0, gals, keys)
+    assert np.array_equal(r1.data, r2.data)
+    lone = data[0]
+    r3 = VecZnx(n, cols, size)
+    conv, back = VecZnx(n, cols, 4), VecZnx(n, cols, size)
+    keys11 = []
+    for _ in gals:
+        mat = MatZnx(n, 4, rank, cols, 5).fill_uniform(11, rng)
+        pr = ref.vmp_pmat_alloc(4, rank, cols, 5)
+        ref.vmp_prepare(pr, mat)
+        keys11.append(pr)
+    ref.glwe_pack_bases(r3, k, 11, 4, {0: lone.copy()}, log_n, gals, keys11)
+    for c in range(cols):
+        ref.vec_znx_normalize(conv, 11, 0, c, lone, k, c)
+    ref.glwe_trace_assign(conv, 11, gals, keys11)
+    for c in range(cols):
+        ref.vec_znx_normalize(back, k, 0, c, conv, 11, c)
+    assert np.array_equal(r3.data, back.data)
