@@ -615,11 +615,12 @@ def test_ggsw_from_gglwe_batched(mods, n, rank, cols_in):
 # ------------------------------------------------------------------------------------------
 # SURVEY.md 8f rank 2 / BASELINE configs[3]: CGGI blind rotation on a batch of LWE ciphertexts
 # ------------------------------------------------------------------------------------------
-def _run_blind_rotation(hip, ref, n, rank, n_lwe, block_size, dnum, brk_size, res_size, base2k, batch, seed, fuse=(True, True)):
+def _run_blind_rotation(hip, ref, n, rank, n_lwe, block_size, dnum, brk_size, res_size, base2k, batch, seed, fuse=(True, True), lut_size=None):
     from poulpy_amd.hal import BlindRotationParams
     rng = seeded(seed)
     cols = rank + 1
-    lut = VecZnx(n, 1, res_size).fill_uniform(base2k, rng)
+    lut_size = res_size if lut_size is None else lut_size
+    lut = VecZnx(n, 1, lut_size).fill_uniform(base2k, rng)
     brk_r = np.empty((n_lwe, n * dnum * cols * cols * brk_size), dtype=np.float64)
     brk_h = np.empty_like(brk_r)
     for i in range(n_lwe):
@@ -644,7 +645,7 @@ def _run_blind_rotation(hip, ref, n, rank, n_lwe, block_size, dnum, brk_size, re
     d_res = hip.device_alloc(want.nbytes)
     hip.lib.pz_memset_d(hip.handle, d_res.ptr, 0x33, want.nbytes)
     p = BlindRotationParams(rank=rank, n_lwe=n_lwe, block_size=block_size, dnum=dnum, brk_size=brk_size, base2k=base2k,
-                            res_size=res_size, lut_size=res_size)
+                            res_size=res_size, lut_size=lut_size)
     hip.set_fusion(*fuse)
     hip.blind_rotation_execute_batched(d_res.ptr, d_lwe.ptr, d_lut.ptr, d_brk.ptr, p, batch)
     hip.sync()
@@ -678,6 +679,17 @@ def test_blind_rotation_shapes(mods):
         ref, hip = mods(n)
         got, want = _run_blind_rotation(hip, ref, n, rank, n_lwe, blk, dnum, bsz, rsz, k, batch=batch, seed=n + rank + blk)
         assert np.array_equal(got, want), (n, rank, n_lwe, blk, dnum, bsz, rsz, k, batch)
+
+
+@pytest.mark.parametrize("block_size", [1, 7])
+def test_reference_blind_rotation_test_shape(mods, block_size):
+    """the shape of poulpy-bin-fhe's own blind-rotation tests (blind_rotation/tests/fft64_ref.rs:24-35 `standard` / `block_binary`,
+    test_suite/generic_blind_rotation.rs:37-44): N = 512, n_lwe = 224, rank 1, base2k 19, key of 3 limbs x 2 rows, result 2 limbs, table
+    1 limb, block size 1 / 7 — all 224 coefficients, on random key material."""
+    n = 512
+    ref, hip = mods(n)
+    got, want = _run_blind_rotation(hip, ref, n, 1, 224, block_size, 2, 3, 2, 19, batch=3, seed=224 + block_size, lut_size=1)
+    assert np.array_equal(got, want)
 
 
 @pytest.mark.parametrize("n,block_size", [(1024, 7), (1024, 1), (2048, 4)])
@@ -1744,12 +1756,13 @@ def test_circuit_bootstrapping_one_base2k_per_object(mods, n, rank, bases, res_l
     (1024, 2, 2, 4, 2, 2, 3, 2, 5, True),
     (2048, 1, 2, 4, 2, 2, 2, 4, 2, True),      # result limbs beyond the key precision
     (256, 1, 4, 6, 3, 2, 2, 3, 3, False),
+    (512, 1, 2, 224, 7, 2, 3, 2, 2, True),     # blind_rotation/tests/fft64_ref.rs:36-40 `block_binary_extended` (base2k 19, all 224 coefficients)
 ])
 def test_blind_rotation_extended(mods, n, rank, ext, n_lwe, blk, dnum, bsz, rsz, batch, fuse):
     """execute_block_binary_extended (algorithm.rs:121-273, extension_factor > 1) vs the oracle's literal restatement; the LWE
     values include every special case of the reference (a = 0, a multiple of ext, ai_hi = 0 with ai_lo != 0, ai_hi + 1 = 2n)."""
     from poulpy_amd.hal import BlindRotationParams
-    k = 13
+    k = 19 if n_lwe == 224 else 13
     ref, hip = mods(n)
     rng = seeded(9900 + n + ext)
     cols = rank + 1
