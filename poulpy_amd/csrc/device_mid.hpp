@@ -290,7 +290,9 @@ k_mid128(MidArgs g) {
     constexpr int M2 = 128;
     constexpr int NT = CT * NP * 8;
     constexpr int NCG = NT / M2;       // thread groups in the product phase
-    constexpr int NC = NP == 32 ? 8 : 4;  // outputs per thread (NP = 32: two ciphertexts x 8 outputs, as in k_mid<2>)
+    // outputs per thread (NP = 32: two ciphertexts x 8 outputs, as in k_mid<2>).  8 for the 16-slot tile too (2 ciphertexts x 8 outputs per
+    // thread: half the operand reads from LDS, every key value fetched by two threads) was measured slower: 5.08 -> 5.39 ms
+    constexpr int NC = NP == 32 ? 8 : 4;
     constexpr int GC = NP / NC;        // column groups
     constexpr int GT = NCG / GC;       // ciphertext groups
     constexpr int CTt = CT / GT;       // ciphertexts per thread
@@ -488,7 +490,7 @@ k_mid128(MidArgs g) {
     }
             int it = 0;
             // (BR: deeper key prefetch — rings of three / four row slots — spills at the 256-VGPR cap and measured slower: 30.1 vs 26.8 ms)
-            if constexpr (NP == 32) {
+            if constexpr (NC == 8) {
                 // 8 key values per thread and row: the second register slot of the ping-pong is what pushes this shape over the 256-VGPR
                 // cap (132-164 bytes of scratch, 57.9 -> 50.3 ms per 10 launches at 16 limbs without it); one slot, the next row requested
                 // right after the current one has been consumed
