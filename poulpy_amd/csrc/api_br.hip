@@ -107,14 +107,19 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
                 cplx* S = (cplx*)M->ws;
                 cplx* A = (cplx*)((char*)M->ws + s_bytes);
                 PolyMap sm{npi / cols, cols, res_ct, (long long)cols * n, n, 0};
+                // the inverse kernel of a block also runs the forward transform of the new accumulator for the next block (POULPY_DBG_BR_SMALL=2:
+                // separate k_small_fwd launches), when its limbs are among the ones the inverse produces
+                const int fl = npi / cols;
+                const bool chain = br_small != 2 && fl <= bsz && fl <= rsz;
                 for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {
-                    PZ_TRY(launch_small_fwd(M, B * npi, (const long long*)res, sm, S, true));
+                    if (b0 == 0 || !chain) PZ_TRY(launch_small_fwd(M, B * npi, (const long long*)res, sm, S, true));
                     bool done = false;
                     PZ_TRY(br_block_step(M, (const double*)S, (long long)npi * n, (double*)A, (long long)ncols_key * n, brk, pmat_doubles, npi, ncols_key, B,
                                          b0, blk, lwe_2n, lwe_bs, &done));
                     if (!done) return fail(PZ_ERR_UNSUPPORTED, "blind_rotation: block step not launched");
+                    const bool more = b0 + 2 * blk <= n_lwe;
                     PZ_TRY(launch_small_inv(M, B, A, nullptr, ncols_key, 0, 0, cols, bsz, (long long*)res, res_ct, cols, rsz, (const long long*)res,
-                                            res_ct, cols, rsz, k, -1, true));
+                                            res_ct, cols, rsz, k, -1, true, (chain && more) ? S : nullptr, fl));
                 }
                 return PZ_OK;
             }

@@ -114,6 +114,9 @@ struct SmallInvArgs {
     const cplx* tw12t;
     const cplx* wL2;
     const cplx* tw1inv;          // [16] untwist with 1/m folded in
+    cplx* S_out;                 // FWD: spectra of the first fwd_limbs limbs of the NEW res column, standard order, [b][limb * cols_out + col]
+    const cplx* tw1;             // FWD: twist of the forward column pass
+    int fwd_limbs;               // FWD: <= min(KS, res_size)
     int dbg;                     // timing ablation (POULPY_DBG_SMALL_SKIP; results invalid): 1 no key loads, 2 no S loads, 4 no stores, 8 no LDS phases
 };
 
@@ -125,8 +128,10 @@ struct SmallInvArgs {
 // the next item's product in registers, role B: this item's transforms in the tile, hand-over between barriers) — at the 128-VGPR cap of a
 // 1024-thread workgroup role A's 64 accumulator registers leave no room for prefetch slots (spills, 0.93 ms at 4 limbs; 0.25 vs 0.17 ms
 // at 3).  KS = key limbs (g.ksz).  NOPROD: the spectra of the (ciphertext, column) are given, in the standard device order [q1 + M1 q2]:
-// S[b][l * cols_out + col] (npi = ksz * cols_out), no key (the blind rotation's block step produced them).
-template <int M1, int KS, bool NOPROD = false>
+// S[b][l * cols_out + col] (npi = ksz * cols_out), no key (the blind rotation's block step produced them).  FWD (blind rotation: the
+// result is the accumulator the next block transforms): the digits go back into the tile as doubles and the forward transform of
+// k_small_fwd runs on them before the workgroup ends - the next block's k_small_fwd launch and its read of the accumulator are saved.
+template <int M1, int KS, bool NOPROD = false, bool FWD = false>
 __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
     constexpr int NT = 64 * M1;          // 2 product positions per thread (m = 128 M1 points)
     constexpr int M2 = kSmallM2, RS = kSmallRS, L = KS;
@@ -312,7 +317,54 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
                 const long long x1 = (long long)(y2 & mask) - (long long)half;
                 cy = (long long)((unsigned long long)cr + (unsigned long long)((long long)y2 >> k));
                 if (writes && (!(g.dbg & 4) || x1 == 0x7fffffffffffLL)) st_stream(res_col + (long long)j * res_ls + JG * e * M2, x1);
+                if constexpr (FWD) {   // this thread's own slot (read above): component ch of z[limb j][j1][j2]
+                    if (j < g.fwd_limbs) reinterpret_cast<double*>(lds)[2 * ((j * M1 + JG * e + jq) * RS + cj2) + ch] = (double)x1;
+                }
             }
+        }
+    }
+    if constexpr (FWD) {
+        __syncthreads();
+        // ---------------- forward column pass (k_small_fwd), NT / 128 limbs at a time: thread = (limb, column j2) ----------------
+        for (int cl0 = 0; cl0 < g.fwd_limbs; cl0 += NT / 128) {
+            const int cl = cl0 + (tid >> 7), cj = tid & 127;
+            if (cl < g.fwd_limbs) {
+                cplx v[M1];
+#pragma unroll
+                for (int j1 = 0; j1 < M1; ++j1) v[j1] = cmul(lds[(cl * M1 + j1) * RS + cj], g.tw1[j1]);
+                Bfly<M1, false>::run(v);
+#pragma unroll
+                for (int q1 = 0; q1 < M1; ++q1) lds[(cl * M1 + q1) * RS + cj] = cmul(v[q1], g.tw12t[q1 * M2 + cj]);
+            }
+        }
+        __syncthreads();
+        // ---------------- forward row pass (k_small_fwd / k_mid128), 8 lanes per row; standard spectrum order out ----------------
+        const int rp = tid / (8 * M1), rrow = (tid % (8 * M1)) >> 3, ro = tid & 7;
+        if (rp < g.fwd_limbs) {
+            cplx* rowbuf = lds + (rp * M1 + rrow) * RS;
+            cplx x[16];
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) x[n1] = rowbuf[ro + 8 * n1];
+            row_sync();
+            Bfly<16, false>::run(x);
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) {
+                cplx v = x[k1];
+                if (k1 > 0) v = cmul(v, wl[ro * k1]);
+                rowbuf[k1 * 9 + ro] = v;
+            }
+            row_sync();
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int oo = 0; oo < 8; ++oo) x[8 * h + oo] = rowbuf[(ro + 8 * h) * 9 + oo];
+            Bfly<8, false>::run(x);
+            Bfly<8, false>::run(x + 8);
+            cplx* dst = g.S_out + ((long long)b * g.fwd_limbs * g.cols_out + (long long)rp * g.cols_out + col) * m + rrow + M1 * ro;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) dst[(8 * h + 16 * k2) * M1] = x[8 * h + k2];
         }
     }
 }

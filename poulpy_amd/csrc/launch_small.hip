@@ -84,7 +84,7 @@ int launch_small_fwd(pz_module* M, int npolys, const long long* src, PolyMap sma
 
 int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int npi, int nrows, int ncols, int cols_out, int ksz,
                      long long* res, long long res_bs, int res_cols, int res_size, const long long* small, long long small_bs,
-                     int small_cols, int small_size, int base2k, int body_col, bool noprod) {
+                     int small_cols, int small_size, int base2k, int body_col, bool noprod, cplx* fwd_S, int fwd_limbs) {
     if (batch <= 0) return PZ_OK;
     PZ_TRY(ensure_small_tables(M));
     SmallInvArgs g;
@@ -94,25 +94,30 @@ int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int
     g.tw12t = M->s_tw12t; g.wL2 = M->s_wL2; g.tw1inv = M->s_tw1inv;
     static const int skip = getenv("POULPY_DBG_SMALL_SKIP") ? atoi(getenv("POULPY_DBG_SMALL_SKIP")) : 0;
     g.dbg = skip;
+    g.S_out = fwd_S; g.tw1 = M->s_tw1; g.fwd_limbs = fwd_S ? fwd_limbs : 0;
+    if (fwd_S && !(noprod && fwd_limbs >= 1 && fwd_limbs <= ksz && fwd_limbs <= res_size && fwd_limbs <= 8))
+        return fail(PZ_ERR_INVALID, "small-ring pipeline: forward transform of %d limbs behind the inverse of %d", fwd_limbs, ksz);
     const int m1 = small_m1(M);
     const size_t lds = ((size_t)ksz * m1 * kSmallRS + kSmallM2) * sizeof(cplx);
     // workgroup id -> (xcd = id & 7, slot = id >> 3): ciphertext (slot / cols_out) * 8 + xcd, column slot % cols_out
     const int grid = ((batch + 7) / 8) * 8 * cols_out;
     KTimer kt(M, PZ_K_FUSED_TAIL);
+#define XL(K_)                                                                                                \
+    {                                                                                                         \
+        PZ_TRY(set_lds((K_), lds));                                                                           \
+        hipLaunchKernelGGL((K_), dim3(grid), dim3(64 * m1), lds, M->stream, g);                               \
+    }
 #define X(M1_, KS_)                                                                                           \
     if (m1 == M1_ && ksz == KS_) {                                                                            \
-        if (noprod) {                                                                                         \
-            PZ_TRY(set_lds((k_small_inv<M1_, KS_, true>), lds));                                              \
-            hipLaunchKernelGGL((k_small_inv<M1_, KS_, true>), dim3(grid), dim3(64 * M1_), lds, M->stream, g); \
-        } else {                                                                                              \
-            PZ_TRY(set_lds((k_small_inv<M1_, KS_>), lds));                                                    \
-            hipLaunchKernelGGL((k_small_inv<M1_, KS_>), dim3(grid), dim3(64 * M1_), lds, M->stream, g);       \
-        }                                                                                                     \
+        if (noprod && g.fwd_limbs) XL((k_small_inv<M1_, KS_, true, true>))                                    \
+        else if (noprod) XL((k_small_inv<M1_, KS_, true>))                                                    \
+        else XL((k_small_inv<M1_, KS_>))                                                                      \
         PZ_HIP(hipGetLastError());                                                                            \
         return PZ_OK;                                                                                         \
     }
     X(4, 1) X(4, 2) X(4, 3) X(4, 4) X(8, 1) X(8, 2) X(8, 3) X(8, 4) X(16, 1) X(16, 2) X(16, 3) X(16, 4)
 #undef X
+#undef XL
     return fail(PZ_ERR_UNSUPPORTED, "small-ring pipeline: m1 = %d, %d key limbs", m1, ksz);
 }
 
