@@ -761,12 +761,13 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
             PolyMap sm{a_size, s.cols_in, av.bs, (long long)av.cols * n, n, n * a_col0};
             // N = 4096, plain external product / key switch with <= 4 key limbs: two kernels, the spectra cross HBM once (device_small.hpp)
             static const int small_env = getenv("POULPY_DBG_SMALL") ? atoi(getenv("POULPY_DBG_SMALL")) : 1;
-            if (small_env && M->small_path && !au && !tensor && !digits && !cross_out && !M->probe && M->dbg_stages == 7 &&
+            static const int small_au4 = getenv("POULPY_DBG_SMALL_AUTO") ? atoi(getenv("POULPY_DBG_SMALL_AUTO")) : 1;
+            if (small_env && M->small_path && (!au || (small_au4 && ks && !lay)) && !tensor && !digits && !cross_out && !M->probe && M->dbg_stages == 7 &&
                 small_supported(M, npi, ksz)) {
                 PZ_TRY(launch_small_fwd(M, nb * npi, (const long long*)av.p, sm, T));
                 PZ_TRY(launch_small_inv(M, nb, T, Pp, npi, nrows, ncols, s.cols_out, ksz, (long long*)(res + (long long)b0 * res_bs), res_bs,
                                         s.cols_out, (int)p->res_size, ks ? (const long long*)av.p : nullptr, av.bs, s.cols_a, a_size,
-                                        (int)p->res_base2k, body_col));
+                                        (int)p->res_base2k, body_col, false, nullptr, 0, au != nullptr, au_p, au ? au->mode : 0));
                 continue;
             }
             if (M->dbg_stages & 1) PZ_TRY(launch_fwd_pass1(M, nb * npi, (const long long*)av.p, sm, T, true));
@@ -842,8 +843,10 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
     // limbs; anything else stays on the five-kernel path below ----
     {
         static const int small_env = getenv("POULPY_DBG_SMALL") ? atoi(getenv("POULPY_DBG_SMALL")) : 1;
-        if (small_env && M->small_path && M->fuse_mid && M->fuse_tail && M->n < 4096 && !au && !tensor && !digits && !cross_out && !s.convert &&
-            !M->probe && M->dbg_stages == 7 && small_supported(M, npi, ksz)) {
+        // (the automorphism family too: phi is an index / sign map inside the inverse kernel's carry-chain stage)
+        static const int small_au = getenv("POULPY_DBG_SMALL_AUTO") ? atoi(getenv("POULPY_DBG_SMALL_AUTO")) : 1;
+        if (small_env && M->small_path && M->fuse_mid && M->fuse_tail && M->n < 4096 && (!au || (small_au && ks && !lay)) && !tensor && !digits &&
+            !cross_out && !s.convert && !M->probe && M->dbg_stages == 7 && small_supported(M, npi, ksz)) {
             const size_t n8 = (size_t)M->n * 8;
             const size_t key_bytes = align256((size_t)nrows * ncols * n8), s_bytes = align256(chunk * npi * (size_t)M->m * sizeof(cplx));
             PZ_TRY(ws_reserve(M, key_bytes + s_bytes));
@@ -857,7 +860,7 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
                 PZ_TRY(launch_small_fwd(M, nb * npi, (const long long*)a_b, sm, S));
                 PZ_TRY(launch_small_inv(M, nb, S, Pp, npi, nrows, ncols, s.cols_out, ksz, (long long*)(res + (long long)b0 * res_bs), res_bs,
                                         s.cols_out, (int)p->res_size, ks ? (const long long*)a_b : nullptr, a_bs, s.cols_a, (int)p->a_size,
-                                        (int)p->res_base2k, body_col));
+                                        (int)p->res_base2k, body_col, false, nullptr, 0, au != nullptr, au_p, au ? au->mode : 0));
             }
             return PZ_OK;
         }

@@ -114,6 +114,9 @@ struct SmallInvArgs {
     const cplx* tw12t;
     const cplx* wL2;
     const cplx* tw1inv;          // [16] untwist with 1/m folded in
+    unsigned au_p;               // AU: Galois element mod 2n (coefficient i goes to i * au_p mod 2n, negated beyond n)
+    int au_mode;                 // AU: 0 phi(normalize(big)), 1 normalize(phi(big) + a), 2 normalize(phi(big) - a), 3 normalize(a - phi(big));
+                                 //     a = column `col` of `small` (the key-switch input itself), big includes the body (body_col)
     cplx* S_out;                 // FWD: spectra of the first fwd_limbs limbs of the NEW res column, standard order, [b][limb * cols_out + col]
     const cplx* tw1;             // FWD: twist of the forward column pass
     int fwd_limbs;               // FWD: <= min(KS, res_size)
@@ -131,7 +134,11 @@ struct SmallInvArgs {
 // S[b][l * cols_out + col] (npi = ksz * cols_out), no key (the blind rotation's block step produced them).  FWD (blind rotation: the
 // result is the accumulator the next block transforms): the digits go back into the tile as doubles and the forward transform of
 // k_small_fwd runs on them before the workgroup ends - the next block's k_small_fwd launch and its read of the accumulator are saved.
-template <int M1, int KS, bool NOPROD = false, bool FWD = false>
+// AU (glwe_automorphism family, automorphism/glwe_ct.rs:51-275): the thread that owns coefficient i of the big value negates it where
+// phi = X -> X^p wraps, adds / subtracts the operand at the OUTPUT position i p mod n, runs the carry chain and stores the digits
+// there (8-byte scatters inside one polynomial: the lines fill up in L2).  In place (res == a): the body values (input positions) are
+// read by every thread before any thread stores.
+template <int M1, int KS, bool NOPROD = false, bool FWD = false, bool AU = false>
 __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
     constexpr int NT = 64 * M1;          // 2 product positions per thread (m = 128 M1 points)
     constexpr int M2 = kSmallM2, RS = kSmallRS, L = KS;
@@ -290,10 +297,35 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
             ? g.small + (long long)b * g.small_bs + (g.body_col < 0 ? (long long)col * n : 0) + (ch ? m : 0) + cj2 + (long long)jq * M2
             : nullptr;
     const long long small_ls = (long long)g.small_cols * n;
+    // AU: output position and sign of this thread's four coefficients; the operand a[col] at those positions; the body read up front
+    long long opos[4];
+    bool oneg[4];
+    long long bodyv[AU ? KS : 1][4];
+    const long long* au_col = nullptr;
+    if constexpr (AU) {
+        const unsigned n2m = 2u * (unsigned)n - 1u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned i = (unsigned)((ch ? m : 0) + (long long)(JG * e + jq) * M2 + cj2);
+            const unsigned jj = (i * g.au_p) & n2m;
+            oneg[e] = jj >= (unsigned)n;
+            opos[e] = (long long)(jj & ((unsigned)n - 1u));
+        }
+        res_col = g.res + (long long)b * g.res_bs + (long long)col * n;
+        if (g.au_mode != 0 && g.small) au_col = g.small + (long long)b * g.small_bs + (long long)col * n;
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bodyv[j][e] = (small_col && j < g.small_size) ? small_col[(long long)j * small_ls + JG * e * M2] : 0;
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { opos[e] = JG * e * M2; oneg[e] = false; }
+    }
     // limbs of res beyond the precision of the big value are zero (normalize.rs:118-120)
     for (int j = L; j < g.res_size; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) res_col[(long long)j * res_ls + JG * e * M2] = 0;
+        for (int e = 0; e < 4; ++e) res_col[(long long)j * res_ls + opos[e]] = 0;
     const unsigned long long half = 1ull << (k - 1), mask = (1ull << k) - 1;
     const long long* xin = reinterpret_cast<const long long*>(lds) + ch;
 #pragma unroll
@@ -305,7 +337,15 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             long long x = xin[2 * ((j * M1 + JG * e + jq) * RS + cj2)];
-            if (add_small) x = (long long)((unsigned long long)x + (unsigned long long)sm_limb[JG * e * M2]);
+            if constexpr (AU) {
+                unsigned long long ux = (unsigned long long)x + (unsigned long long)bodyv[j][e];
+                if (g.au_mode != 0) {   // phi on the big value, then +- a over the common limbs (limbs beyond a: + 0, - 0, 0 - big)
+                    if (oneg[e]) ux = 0ull - ux;
+                    const unsigned long long aj = (au_col && j < g.small_size) ? (unsigned long long)au_col[(long long)j * small_ls + opos[e]] : 0ull;
+                    ux = g.au_mode == 1 ? ux + aj : (g.au_mode == 2 ? ux - aj : aj - ux);
+                }
+                x = (long long)ux;
+            } else if (add_small) x = (long long)((unsigned long long)x + (unsigned long long)sm_limb[JG * e * M2]);
             long long& cy = carry[e];
             const unsigned long long y = (unsigned long long)x + half;
             const long long d = (long long)(y & mask) - (long long)half;
@@ -316,7 +356,12 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
                 const unsigned long long y2 = (unsigned long long)d + (unsigned long long)cy + half;
                 const long long x1 = (long long)(y2 & mask) - (long long)half;
                 cy = (long long)((unsigned long long)cr + (unsigned long long)((long long)y2 >> k));
-                if (writes && (!(g.dbg & 4) || x1 == 0x7fffffffffffLL)) st_stream(res_col + (long long)j * res_ls + JG * e * M2, x1);
+                if (writes && (!(g.dbg & 4) || x1 == 0x7fffffffffffLL)) {
+                    // AU mode 0: phi acts on the normalized digits (glwe_ct.rs:69-71)
+                    const long long xs = (AU && g.au_mode == 0 && oneg[e]) ? (long long)(0ull - (unsigned long long)x1) : x1;
+                    if constexpr (AU) res_col[(long long)j * res_ls + opos[e]] = xs;   // scattered 8-byte stores: cacheable, so that the lines fill up in L2
+                    else st_stream(res_col + (long long)j * res_ls + opos[e], xs);
+                }
                 if constexpr (FWD) {   // this thread's own slot (read above): component ch of z[limb j][j1][j2]
                     if (j < g.fwd_limbs) reinterpret_cast<double*>(lds)[2 * ((j * M1 + JG * e + jq) * RS + cj2) + ch] = (double)x1;
                 }

@@ -84,7 +84,8 @@ int launch_small_fwd(pz_module* M, int npolys, const long long* src, PolyMap sma
 
 int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int npi, int nrows, int ncols, int cols_out, int ksz,
                      long long* res, long long res_bs, int res_cols, int res_size, const long long* small, long long small_bs,
-                     int small_cols, int small_size, int base2k, int body_col, bool noprod, cplx* fwd_S, int fwd_limbs) {
+                     int small_cols, int small_size, int base2k, int body_col, bool noprod, cplx* fwd_S, int fwd_limbs,
+                     bool au, unsigned au_p, int au_mode) {
     if (batch <= 0) return PZ_OK;
     PZ_TRY(ensure_small_tables(M));
     SmallInvArgs g;
@@ -95,6 +96,9 @@ int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int
     static const int skip = getenv("POULPY_DBG_SMALL_SKIP") ? atoi(getenv("POULPY_DBG_SMALL_SKIP")) : 0;
     g.dbg = skip;
     g.S_out = fwd_S; g.tw1 = M->s_tw1; g.fwd_limbs = fwd_S ? fwd_limbs : 0;
+    g.au_p = au_p; g.au_mode = au_mode;
+    if (au && (noprod || fwd_S || small == nullptr || small_cols != cols_out))
+        return fail(PZ_ERR_INVALID, "small-ring pipeline: the automorphism variant needs the key-switch operand");
     if (fwd_S && !(noprod && fwd_limbs >= 1 && fwd_limbs <= ksz && fwd_limbs <= res_size && fwd_limbs <= 8))
         return fail(PZ_ERR_INVALID, "small-ring pipeline: forward transform of %d limbs behind the inverse of %d", fwd_limbs, ksz);
     const int m1 = small_m1(M);
@@ -111,6 +115,7 @@ int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int
     if (m1 == M1_ && ksz == KS_) {                                                                            \
         if (noprod && g.fwd_limbs) XL((k_small_inv<M1_, KS_, true, true>))                                    \
         else if (noprod) XL((k_small_inv<M1_, KS_, true>))                                                    \
+        else if (au) XL((k_small_inv<M1_, KS_, false, false, true>))                                          \
         else XL((k_small_inv<M1_, KS_>))                                                                      \
         PZ_HIP(hipGetLastError());                                                                            \
         return PZ_OK;                                                                                         \

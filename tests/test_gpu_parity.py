@@ -720,6 +720,32 @@ def test_blind_rotation_block_step_on_the_glwe_pipeline(mods, n, rank, n_lwe, bl
     assert np.array_equal(got2, want)
 
 
+@pytest.mark.parametrize("in_place", [False, True], ids=["out-of-place", "in-place"])
+@pytest.mark.parametrize("mode", ["automorphism", "add", "sub", "sub_negate"])
+@pytest.mark.parametrize("n", [1024, 2048, 4096])
+def test_small_ring_automorphism_family(mods, n, mode, in_place):
+    """N = 1024 / 2048 / 4096: the glwe_automorphism family on the two-kernel pipeline (phi as an index / sign map in k_small_inv's carry-chain
+    stage: on the normalized digits for the plain form, on the big value before +- a for the others) against the oracle and the
+    five-kernel path bit for bit; Galois elements -1, 5, 5^(2^k) (the trace's), 3; ragged limb counts; in place (res == a)."""
+    k = 14
+    ref, hip = mods(n)
+    cases = [(1, -1, 4, 4, 4, 4, 9), (1, 5, 3, 4, 3, 3, 5), (2, pow(5, 16, 2 * n), 3, 3, 3, 3, 4), (1, 3, 4, 3, 4, 4, 3), (1, 2 * n - 5, 2, 4, 2, 3, 2)]
+    for (rank, gal, a_size, key_size, dnum, res_size, batch) in cases:
+        if in_place and a_size != res_size:
+            continue
+        hip.set_small_path(True)
+        got, want = _run_glwe_op(hip, ref, True, n, rank, rank, a_size, k, key_size, k, dnum, 1, res_size, k, batch, seed=300 + rank + a_size + batch,
+                                 auto=(gal, mode), in_place=in_place)
+        assert np.array_equal(got, want), (rank, gal, a_size, key_size, res_size)
+        hip.set_small_path(False)
+        try:
+            got2, _ = _run_glwe_op(hip, ref, True, n, rank, rank, a_size, k, key_size, k, dnum, 1, res_size, k, batch,
+                                   seed=300 + rank + a_size + batch, auto=(gal, mode), in_place=in_place)
+        finally:
+            hip.set_small_path(True)
+        assert np.array_equal(got2, want)
+
+
 @pytest.mark.parametrize("n,rank,n_lwe,blk,dnum,bsz,rsz,k,batch", [
     (2048, 1, 15, 7, 3, 3, 3, 13, 9),      # the gate-bootstrap key layout at N = 2048: two blocks + a trailing partial block, ragged batch
     (2048, 1, 8, 4, 2, 2, 3, 14, 3),       # result limbs beyond the key precision (zeroed)

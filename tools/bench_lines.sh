@@ -19,6 +19,10 @@ $B --base2k 14 >> $OUT 2>/dev/null
 $B --n 4096 --limbs 4 --base2k 17 >> $OUT 2>/dev/null
 $B --n 4096 --limbs 3 --base2k 18 --steps 100 >> $OUT 2>/dev/null   # poulpy-bench's default core shape (params.rs:113-121: n 2^12, base2k 18, k 54)
 $B --n 4096 --limbs 3 --base2k 18 --op keyswitch --steps 100 >> $OUT 2>/dev/null
+$B --n 4096 --limbs 3 --base2k 18 --op automorphism --steps 100 >> $OUT 2>/dev/null   # glwe_automorphism family on the two-kernel pipeline
+$B --n 4096 --limbs 3 --base2k 18 --op automorphism_add --steps 100 >> $OUT 2>/dev/null
+$B --n 2048 --limbs 4 --base2k 17 --op automorphism_add --steps 100 >> $OUT 2>/dev/null
+$B --n 1024 --limbs 4 --base2k 17 --op automorphism_add --steps 100 >> $OUT 2>/dev/null
 $B --n 131072 --batch 512 --steps 10 >> $OUT 2>/dev/null
 $B --n 2048 --limbs 4 --base2k 17 --steps 100 >> $OUT 2>/dev/null
 $B --n 1024 --limbs 4 --base2k 17 --steps 100 >> $OUT 2>/dev/null
