@@ -591,12 +591,27 @@ static FusedWs fused_ws(const pz_module* M, const pz_glwe_op_params* p, const Op
 // keyswitch: 0 external product, 1 key switch, 2 automorphism family, 3 tensor relinearization.  The figure is what the call reserves
 // in the module's grow-only workspace (+ the 12.5 % growth slack of its first allocation); a key that is neither pinned nor mirrored
 // costs its row-sliced copy, which is included.
+// N = 1024 / 2048: the two-kernel pipeline of device_small.hpp (plain products, key switches and the automorphism family; dsize 1, one
+// base2k, <= 4 key limbs); `packed` = no OpLayout (the automorphism family needs it)
+static bool small_ring_applies(const pz_module* M, const pz_glwe_op_params* p, const OpShape& s, bool ks, bool tensor, bool au, bool packed) {
+    static const int small_env = getenv("POULPY_DBG_SMALL") ? atoi(getenv("POULPY_DBG_SMALL")) : 1;
+    static const int small_au = getenv("POULPY_DBG_SMALL_AUTO") ? atoi(getenv("POULPY_DBG_SMALL_AUTO")) : 1;
+    return small_env && M->small_path && M->fuse_mid && M->fuse_tail && M->n < 4096 && (!au || (small_au && ks && packed)) && !tensor &&
+           p->dsize == 1 && p->res_base2k == p->key_base2k && !s.convert && !M->probe && M->dbg_stages == 7 &&
+           small_supported(M, s.cols_in * s.a_size_eff, (int)p->key_size);
+}
+
 size_t pz_glwe_op_workspace_bytes(const pz_module* M, const pz_glwe_op_params* p, size_t batch, int keyswitch) {
     if (!M || !p || p->key_size == 0 || p->a_size == 0) return 0;
     const bool tensor = keyswitch == 3, ks = keyswitch != 0, au = keyswitch == 2;
     const OpShape s = op_shape(p, ks, tensor);
     const size_t chunk = pick_chunk(M, p, s, batch);
-    const size_t bytes = fused_applies(M, p, s, ks, tensor, au) ? fused_ws(M, p, s, chunk, au).total : op_ws(M, p, s, chunk, ks, au).total;
+    size_t bytes;
+    if (fused_applies(M, p, s, ks, tensor, au)) bytes = fused_ws(M, p, s, chunk, au).total;
+    else if (small_ring_applies(M, p, s, ks, tensor, au, true))   // the key re-sliced + the spectra of one wave
+        bytes = align256((size_t)p->dnum * s.cols_in * s.cols_out * p->key_size * (size_t)M->n * 8) +
+                align256(chunk * (size_t)(s.cols_in * s.a_size_eff) * (size_t)M->m * sizeof(cplx));
+    else bytes = op_ws(M, p, s, chunk, ks, au).total;
     return bytes + (bytes >> 3);
 }
 
@@ -842,11 +857,8 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
     // pipeline of device_small.hpp with its own m = M1 x 128 tables.  Plain external product / key switch, dsize 1, one base2k, <= 4 key
     // limbs; anything else stays on the five-kernel path below ----
     {
-        static const int small_env = getenv("POULPY_DBG_SMALL") ? atoi(getenv("POULPY_DBG_SMALL")) : 1;
         // (the automorphism family too: phi is an index / sign map inside the inverse kernel's carry-chain stage)
-        static const int small_au = getenv("POULPY_DBG_SMALL_AUTO") ? atoi(getenv("POULPY_DBG_SMALL_AUTO")) : 1;
-        if (small_env && M->small_path && M->fuse_mid && M->fuse_tail && M->n < 4096 && (!au || (small_au && ks && !lay)) && !tensor && !digits &&
-            !cross_out && !s.convert && !M->probe && M->dbg_stages == 7 && small_supported(M, npi, ksz)) {
+        if (small_ring_applies(M, p, s, ks, tensor, au != nullptr, lay == nullptr)) {
             const size_t n8 = (size_t)M->n * 8;
             const size_t key_bytes = align256((size_t)nrows * ncols * n8), s_bytes = align256(chunk * npi * (size_t)M->m * sizeof(cplx));
             PZ_TRY(ws_reserve(M, key_bytes + s_bytes));
