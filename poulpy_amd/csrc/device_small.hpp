@@ -130,7 +130,10 @@ struct SmallInvArgs {
 // ciphertexts against 0.35 ms for the whole three-kernel pipeline).  Also tried: a persistent workgroup in two roles of 512 threads (role A:
 // the next item's product in registers, role B: this item's transforms in the tile, hand-over between barriers) — at the 128-VGPR cap of a
 // 1024-thread workgroup role A's 64 accumulator registers leave no room for prefetch slots (spills, 0.93 ms at 4 limbs; 0.25 vs 0.17 ms
-// at 3).  KS = key limbs (g.ksz).  NOPROD: the spectra of the (ciphertext, column) are given, in the standard device order [q1 + M1 q2]:
+// at 3).  And (end of round 2): a persistent 512-thread workgroup (four product positions per thread, 256 registers) with the next item's
+// product spread in eight row steps between the stages of the current item's transform - bit-exact, slower: 2.17 vs 3.05 M/s at 4 limbs,
+// 3.8 vs 4.07 at 3, key switch 3.5 vs 5.2 (the transform stages are latency-bound and take about twice as long with 8 waves instead of
+// 16, which costs more than the hidden loads; 116 - 276 bytes of scratch at 3 - 4 limbs).  KS = key limbs (g.ksz).  NOPROD: the spectra of the (ciphertext, column) are given, in the standard device order [q1 + M1 q2]:
 // S[b][l * cols_out + col] (npi = ksz * cols_out), no key (the blind rotation's block step produced them).  FWD (blind rotation: the
 // result is the accumulator the next block transforms): the digits go back into the tile as doubles and the forward transform of
 // k_small_fwd runs on them before the workgroup ends - the next block's k_small_fwd launch and its read of the accumulator are saved.
@@ -413,5 +416,6 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
         }
     }
 }
+
 
 }  // namespace pz
