@@ -754,6 +754,7 @@ def test_small_ring_automorphism_family(mods, n, mode, in_place):
     (1024, 2, 4, 2, 4, 3, 4, 12, 2),       # 12 inputs
     (2048, 2, 4, 2, 2, 2, 2, 15, 4),       # rank 2 at N = 2048
     (2048, 3, 6, 3, 2, 1, 2, 16, 3),       # rank 3, one key limb
+    (2048, 1, 6, 3, 3, 2, 3, 13, 4),       # more accumulator limbs transformed than the key has: the inverse kernel cannot chain the next forward
     (4096, 1, 6, 3, 3, 2, 2, 14, 4),       # N = 4096 with dnum > res_size: neither pipeline form applies (composed path, per-op kernels)
 ])
 def test_blind_rotation_small_ring_transforms(mods, n, rank, n_lwe, blk, dnum, bsz, rsz, k, batch):
