@@ -596,9 +596,9 @@ static FusedWs fused_ws(const pz_module* M, const pz_glwe_op_params* p, const Op
 static bool small_ring_applies(const pz_module* M, const pz_glwe_op_params* p, const OpShape& s, bool ks, bool tensor, bool au, bool packed) {
     static const int small_env = getenv("POULPY_DBG_SMALL") ? atoi(getenv("POULPY_DBG_SMALL")) : 1;
     static const int small_au = getenv("POULPY_DBG_SMALL_AUTO") ? atoi(getenv("POULPY_DBG_SMALL_AUTO")) : 1;
-    return small_env && M->small_path && M->fuse_mid && M->fuse_tail && M->n < 4096 && (!au || (small_au && ks && packed)) && !tensor &&
-           p->dsize == 1 && p->res_base2k == p->key_base2k && !s.convert && !M->probe && M->dbg_stages == 7 &&
-           small_supported(M, s.cols_in * s.a_size_eff, (int)p->key_size);
+    const bool cross_out = p->res_base2k != p->key_base2k;   // (with an automorphism: phi and the cross-base pass do not commute)
+    return small_env && M->small_path && M->fuse_mid && M->fuse_tail && M->n < 4096 && (!au || (small_au && ks && packed && !cross_out)) &&
+           !tensor && p->dsize == 1 && !M->probe && M->dbg_stages == 7 && small_supported(M, s.cols_in * s.a_size_eff, (int)p->key_size);
 }
 
 size_t pz_glwe_op_workspace_bytes(const pz_module* M, const pz_glwe_op_params* p, size_t batch, int keyswitch) {
@@ -610,7 +610,9 @@ size_t pz_glwe_op_workspace_bytes(const pz_module* M, const pz_glwe_op_params* p
     if (fused_applies(M, p, s, ks, tensor, au)) bytes = fused_ws(M, p, s, chunk, au).total;
     else if (small_ring_applies(M, p, s, ks, tensor, au, true))   // the key re-sliced + the spectra of one wave
         bytes = align256((size_t)p->dnum * s.cols_in * s.cols_out * p->key_size * (size_t)M->n * 8) +
-                align256(chunk * (size_t)(s.cols_in * s.a_size_eff) * (size_t)M->m * sizeof(cplx));
+                align256(chunk * (size_t)(s.cols_in * s.a_size_eff) * (size_t)M->m * sizeof(cplx)) +
+                (s.convert ? align256(chunk * (size_t)M->n * 8 * s.cols_a * s.a_size_eff) : 0) +
+                (p->res_base2k != p->key_base2k ? align256(chunk * (size_t)M->n * 8 * s.cols_out * p->key_size) : 0);
     else bytes = op_ws(M, p, s, chunk, ks, au).total;
     return bytes + (bytes >> 3);
 }
@@ -859,20 +861,41 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
     {
         // (the automorphism family too: phi is an index / sign map inside the inverse kernel's carry-chain stage)
         if (small_ring_applies(M, p, s, ks, tensor, au != nullptr, lay == nullptr)) {
+            // mixed bases as in the fused pipeline: `a` re-expressed in the key's base first (external_product/glwe.rs:124-132); a result in
+            // another base = balanced key-base digits from the inverse kernel (all key limbs), then one cross-base pass (same two exact
+            // steps as the three-kernel tail)
             const size_t n8 = (size_t)M->n * 8;
             const size_t key_bytes = align256((size_t)nrows * ncols * n8), s_bytes = align256(chunk * npi * (size_t)M->m * sizeof(cplx));
-            PZ_TRY(ws_reserve(M, key_bytes + s_bytes));
+            const size_t conv_bytes = s.convert ? align256(chunk * n8 * s.cols_a * s.a_size_eff) : 0;
+            const size_t tmp_bytes = cross_out ? align256(chunk * n8 * s.cols_out * ksz) : 0;
+            PZ_TRY(ws_reserve(M, key_bytes + s_bytes + conv_bytes + tmp_bytes));
             cplx* Pp = (cplx*)M->ws;
             cplx* S = (cplx*)((char*)M->ws + key_bytes);
+            int64_t* a_conv = (int64_t*)((char*)M->ws + key_bytes + s_bytes);
+            int64_t* key_digits = (int64_t*)((char*)M->ws + key_bytes + s_bytes + conv_bytes);
             PZ_TRY(launch_small_permute(M, pmat, Pp, nrows * ncols));
             for (size_t b0 = 0; b0 < batch; b0 += chunk) {
                 const int nb = (int)std::min(chunk, batch - b0);
-                const int64_t* a_b = a + (long long)b0 * a_bs;
-                PolyMap sm{(int)p->a_size, s.cols_in, a_bs, (long long)s.cols_a * n, n, n * s.a_col0};
-                PZ_TRY(launch_small_fwd(M, nb * npi, (const long long*)a_b, sm, S));
-                PZ_TRY(launch_small_inv(M, nb, S, Pp, npi, nrows, ncols, s.cols_out, ksz, (long long*)(res + (long long)b0 * res_bs), res_bs,
-                                        s.cols_out, (int)p->res_size, ks ? (const long long*)a_b : nullptr, a_bs, s.cols_a, (int)p->a_size,
-                                        (int)p->res_base2k, body_col, false, nullptr, 0, au != nullptr, au_p, au ? au->mode : 0));
+                DV av{(void*)(a + (long long)b0 * a_bs), a_bs, s.cols_a, (int)p->a_size};
+                if (s.convert) {
+                    DV cv{a_conv, n * s.cols_a * s.a_size_eff, s.cols_a, s.a_size_eff};
+                    for (int c = 0; c < s.cols_a; ++c) PZ_TRY(dev_normalize(M, nb, cv, (int)p->key_base2k, 0, c, av, (int)p->a_base2k, c));
+                    av = cv;
+                }
+                PolyMap sm{av.size, s.cols_in, av.bs, (long long)av.cols * n, n, n * s.a_col0};
+                PZ_TRY(launch_small_fwd(M, nb * npi, (const long long*)av.p, sm, S));
+                int64_t* res_b = res + (long long)b0 * res_bs;
+                if (cross_out) {
+                    const long long tmp_ct = n * s.cols_out * (long long)ksz;
+                    PZ_TRY(launch_small_inv(M, nb, S, Pp, npi, nrows, ncols, s.cols_out, ksz, (long long*)key_digits, tmp_ct, s.cols_out, ksz,
+                                            ks ? (const long long*)av.p : nullptr, av.bs, s.cols_a, av.size, (int)p->key_base2k, body_col));
+                    DV tv{key_digits, tmp_ct, s.cols_out, ksz}, rv{res_b, res_bs, s.cols_out, (int)p->res_size};
+                    for (int c = 0; c < s.cols_out; ++c) PZ_TRY(dev_normalize(M, nb, rv, (int)p->res_base2k, 0, c, tv, (int)p->key_base2k, c));
+                    continue;
+                }
+                PZ_TRY(launch_small_inv(M, nb, S, Pp, npi, nrows, ncols, s.cols_out, ksz, (long long*)res_b, res_bs, s.cols_out, (int)p->res_size,
+                                        ks ? (const long long*)av.p : nullptr, av.bs, s.cols_a, av.size, (int)p->res_base2k, body_col, false, nullptr,
+                                        0, au != nullptr, au_p, au ? au->mode : 0));
             }
             return PZ_OK;
         }

@@ -720,6 +720,31 @@ def test_blind_rotation_block_step_on_the_glwe_pipeline(mods, n, rank, n_lwe, bl
     assert np.array_equal(got2, want)
 
 
+@pytest.mark.parametrize("a_b,k_b,r_b", [(16, 13, 15), (13, 13, 15), (15, 13, 13), (12, 17, 12)],
+                         ids=["in-key-out all differ", "result in another base", "input in another base", "key in the larger base"])
+@pytest.mark.parametrize("n", [1024, 2048])
+def test_small_ring_mixed_bases(mods, n, a_b, k_b, r_b):
+    """N = 1024 / 2048 with the base2k triples poulpy-core's tests use (input, key, result all different: test_suite/external_product/
+    glwe_ct.rs:33-36, keyswitch/glwe_ct.rs:33-36, automorphism/glwe_ct.rs:35-38): the input is re-expressed in the key's base in front of
+    the two-kernel pipeline, a result in another base goes through balanced key-base digits and one cross-base pass; against the oracle
+    and the five-kernel path bit for bit.  The automorphism family rides along when only the input differs."""
+    ref, hip = mods(n)
+    cases = [(False, 1, 1, 4, 4, 3, 4, 7, None), (True, 1, 1, 3, 4, 3, 3, 9, None), (True, 2, 1, 3, 3, 3, 4, 4, None), (False, 2, 2, 2, 3, 2, 2, 3, None)]
+    if k_b == r_b:
+        cases += [(True, 1, 1, 3, 4, 3, 3, 5, (5, "add")), (True, 1, 1, 4, 3, 3, 4, 3, (-1, "automorphism")), (True, 2, 2, 3, 3, 3, 3, 2, (3, "sub_negate"))]
+    for (ks, rank, rank_out, a_size, key_size, dnum, res_size, batch, auto) in cases:
+        args = (ks, n, rank, rank_out, a_size, a_b, key_size, k_b, dnum, 1, res_size, r_b, batch)
+        hip.set_small_path(True)
+        got, want = _run_glwe_op(hip, ref, *args, seed=500 + rank + a_size + batch, auto=auto)
+        assert np.array_equal(got, want), (ks, rank, rank_out, a_size, key_size, res_size, auto)
+        hip.set_small_path(False)
+        try:
+            got2, _ = _run_glwe_op(hip, ref, *args, seed=500 + rank + a_size + batch, auto=auto)
+        finally:
+            hip.set_small_path(True)
+        assert np.array_equal(got2, want)
+
+
 @pytest.mark.parametrize("in_place", [False, True], ids=["out-of-place", "in-place"])
 @pytest.mark.parametrize("mode", ["automorphism", "add", "sub", "sub_negate"])
 @pytest.mark.parametrize("n", [1024, 2048, 4096])
