@@ -633,7 +633,9 @@ size_t pz_glwe_op_workspace_bytes(const pz_module* M, const pz_glwe_op_params* p
 //  the 4.7 TB/s the back-to-back sequence averages — and the three-deep chunk pipeline adds its fill / drain per call.)
 
 int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double* pmat, const pz_glwe_op_params* p, size_t batch,
-                   const AutoSpec* au, const OpLayout* lay, bool tensor) {
+                   const AutoSpec* au, const OpLayout* lay, bool tensor, bool* post_rsh) {
+    const bool want_rsh = post_rsh && *post_rsh;
+    if (post_rsh) *post_rsh = false;
     PZ_REQUIRE(p != nullptr, "null params");
     PZ_REQUIRE(p->dsize >= 1 && p->dnum >= 1 && p->key_size >= 1 && p->a_size >= 1 && p->res_size >= 1, "glwe op: empty shape");
     PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(a) && is_device_ptr(pmat), "batched entry points take device pointers");
@@ -815,10 +817,12 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
                 // operand of the body column, one stream: phi(body) + a0 (add) or -phi(body) + a0 (sub forms: the tail negates every operand)
                 PZ_TRY(launch_automorphism(M, nb * bl, (const long long*)av.p, bsm, (long long*)res_tmp, bdm, au_g, au->mode == 1 ? 1 : 3,
                                            (const long long*)av.p, bsm));
+                const bool rsh = want_rsh && tail_rsh_supported(M) && !cross_out && p->res_base2k <= 29;   // (32-bit shift steps: device_fft.hpp)
                 PZ_TRY(launch_inv_tail(M, nb, T2, ksz, s.cols_out, (long long*)res_b, res_bs, s.cols_out, (int)p->res_size,
                                        (const long long*)av.p, av.bs, s.cols_a, a_size, (int)p->res_base2k, true, true,
                                        au->mode == 3 ? 2u * (unsigned)n : 0u, au->mode == 3, 0u, false, body_col, (const long long*)res_tmp,
-                                       (long long)bl * n, n, au->mode != 1));
+                                       (long long)bl * n, n, au->mode != 1, rsh));
+                if (rsh) *post_rsh = true;
                 continue;
             }
             const long long* small = ks ? (const long long*)av.p : nullptr;
@@ -1145,11 +1149,17 @@ int glwe_trace(pz_module* M, int64_t* res, size_t nsteps, const int64_t* gals, c
     const long long n = (long long)M->n;
     const int cols = (int)p->rank + 1;
     const long long ct = n * cols * (long long)p->res_size;
+    // the one-bit shift in front of step s + 1 rides on the tail of step s where that path has the shifted-store variant
+    // (POULPY_DBG_TRACE_RSH=0: always the separate pass)
+    static const int fuse_rsh = getenv("POULPY_DBG_TRACE_RSH") ? atoi(getenv("POULPY_DBG_TRACE_RSH")) : 1;
+    bool shifted = false;
     for (size_t s = 0; s < nsteps; ++s) {
         PZ_REQUIRE((gals[s] & 1) != 0, "glwe_trace: Galois elements must be odd");
-        PZ_TRY(launch_rsh(M, (int)batch, (long long*)res, ct, cols, (int)p->res_size, 0, cols, (int)p->res_base2k, 1));
+        if (!shifted) PZ_TRY(launch_rsh(M, (int)batch, (long long*)res, ct, cols, (int)p->res_size, 0, cols, (int)p->res_base2k, 1));
         AutoSpec au{(long long)gals[s], 1};
-        PZ_TRY(glwe_op(M, true, res, res, key_pmats[s], p, batch, &au));
+        bool rsh = fuse_rsh && s + 1 < nsteps;
+        PZ_TRY(glwe_op(M, true, res, res, key_pmats[s], p, batch, &au, nullptr, false, &rsh));
+        shifted = rsh;
     }
     return PZ_OK;
 }

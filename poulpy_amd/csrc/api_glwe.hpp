@@ -98,7 +98,9 @@ extern "C" {
 // the batched GLWE product on device-resident data: external product (ks = false), key switch, automorphism family (au), strided
 // ciphertexts with the body landing in another column (lay), tensor relinearization
 int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double* pmat, const pz_glwe_op_params* p, size_t batch,
-            const AutoSpec* au = nullptr, const OpLayout* lay = nullptr, bool tensor = false);
+            const AutoSpec* au = nullptr, const OpLayout* lay = nullptr, bool tensor = false, bool* post_rsh = nullptr);
+// post_rsh (glwe_trace): in: the caller would like the result shifted right by one bit (vec_znx_rsh_assign on every column) as it is
+// stored; out: whether the path taken did that (spectral automorphism forms on the 256 x 128 plan) - otherwise the caller shifts itself
 // glwe_trace_assign on a batch (poulpy-core glwe_trace.rs:129-176): one prepared key per step
 int glwe_trace(pz_module* M, int64_t* res, size_t nsteps, const int64_t* gals, const double* const* key_pmats, const pz_glwe_op_params* p,
                size_t batch);

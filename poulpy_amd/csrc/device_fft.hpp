@@ -467,9 +467,19 @@ struct TailShape {
     static constexpr int NB = (SPLIT ? 2 : 1) * R2 * CB;        // B' threads
     static constexpr int NT = NB + R1 * CB;                     // + A' threads
 };
-template <int R1, int R2, int CB, bool PROBE, bool ROWMAJOR = false, bool SMALL = false>
+// RSH (with SMALL): the digits leave the carry chain through vec_znx_rsh_assign by ONE bit (reference/vec_znx/shift.rs:186-243, the
+// steps of znx/normalization.rs with lsh = base2k - 1) before they are stored - glwe_trace shifts its ciphertext between two
+// automorphisms (glwe_trace.rs:164-166), and that walk runs in the same direction as the chain: the last limb of res only leaves a
+// carry, the digit of every other limb j gives limb j + 1 of the shifted value, limb 0 is the digit of the last carry.  One read and
+// one write of the ciphertext less per trace step.
+// (32-bit: the digits that enter are balanced base2k-bit values, so every intermediate of the reference's i64 steps stays below
+//  2^(base2k + 1) - the launcher requires base2k <= 29)
+__device__ __forceinline__ int sx_digit(int k, int x) { return (int)((unsigned)x << (32 - k)) >> (32 - k); }
+__device__ __forceinline__ int sx_carry(int k, int x, int d) { return (x - d) >> k; }
+template <int R1, int R2, int CB, bool PROBE, bool ROWMAJOR = false, bool SMALL = false, bool RSH = false>
 __global__ void __launch_bounds__(((R1 == 16 ? 2 : 1) * R2 + R1) * CB, ((((R1 == 16 ? 2 : 1) * R2 + R1) * CB >= 512) ? 1 : (SMALL ? 2 : 3)))
 k_inv_tail(TailArgs g) {
+    static_assert(!RSH || SMALL, "the shifted store rides on the integer carry chain");
     constexpr bool SPLIT = TailShape<R1, R2, CB>::SPLIT;
     constexpr int RE = TailShape<R1, R2, CB>::RE;
     constexpr int NB = TailShape<R1, R2, CB>::NB;
@@ -561,8 +571,12 @@ k_inv_tail(TailArgs g) {
     const long long* small_col =
         (g.small && (col == g.body_col || g.small_all)) ? g.small + (long long)b * g.small_bs + (g.small_all ? (long long)col * n : 0) : nullptr;
     const long long small_ls = (long long)g.small_cols * n;
-    // limbs of res beyond the precision of the big value are zero (normalize.rs:118-120)
-    for (int j = L; j < g.res_size; ++j)
+    // limbs of res beyond the precision of the big value are zero (normalize.rs:118-120); RSH: limb L receives the bit shifted out of
+    // limb L - 1
+    int cy2[RSH ? 2 * RE : 1];
+#pragma unroll
+    for (int u = 0; u < (RSH ? 2 * RE : 1); ++u) cy2[u] = 0;
+    for (int j = L + (RSH ? 1 : 0); j < g.res_size; ++j)
 #pragma unroll
         for (int e = 0; e < RE; ++e) {
             const int n1 = PZ_TAIL_N1(e);
@@ -674,7 +688,23 @@ k_inv_tail(TailArgs g) {
                 const unsigned long long y2 = (unsigned long long)d + (unsigned long long)cy + half;         \
                 const long long x1 = (long long)(y2 & mask) - (long long)half;                               \
                 cy = (long long)((unsigned long long)cr + (unsigned long long)((long long)y2 >> k));         \
-                if (writes) { if (ROWMAJOR) st_stream(res_col + (long long)j * res_ls + idx, x1); else res_col[(long long)j * res_ls + idx] = x1; } \
+                if (RSH) {                                                                                   \
+                    if (writes) {                                                                            \
+                        int& c2 = cy2[RSH ? 2 * n1 + h : 0];                                                 \
+                        const int xd = (int)x1;                                                              \
+                        const int d1 = -(xd & 1);                                                            \
+                        const int cr1 = (xd - d1) >> 1;                                                      \
+                        if (j == g.res_size - 1) {                                                           \
+                            c2 = cr1;                                                                        \
+                        } else {                                                                             \
+                            const int dpc = d1 * (1 << (k - 1)) + c2;                                        \
+                            const int nv = sx_digit(k, dpc);                                                 \
+                            c2 = cr1 + sx_carry(k, dpc, nv);                                                 \
+                            st_stream(res_col + (long long)(j + 1) * res_ls + idx, (long long)nv);           \
+                        }                                                                                    \
+                        if (j == 0) st_stream(res_col + idx, (long long)sx_digit(k, c2));                    \
+                    }                                                                                        \
+                } else if (writes) { if (ROWMAJOR) st_stream(res_col + (long long)j * res_ls + idx, x1); else res_col[(long long)j * res_ls + idx] = x1; } \
             }                                                                                                \
         }                                                                                                    \
     }

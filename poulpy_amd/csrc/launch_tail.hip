@@ -12,12 +12,14 @@ namespace pz {
 
 // the two roles of k_inv_tail must be whole waves
 bool tail_supported(const pz_module* M) { return (M->plan.f1b * M->plan.cb) % 64 == 0; }
+// the variant whose digits leave through a one-bit vec_znx_rsh (glwe_trace): instantiated for the 256 x 128 plan of N = 2^16 only
+bool tail_rsh_supported(const pz_module* M) { return M->plan.f1a == 16 && M->plan.f1b == 16 && M->plan.cb == 16 && !M->probe; }
 
 static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
                                 int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
                                 int base2k, bool rowmajor, bool small_all, unsigned auto_mul, bool auto_neg, int col_base, int col_count,
                                 unsigned gather_mul = 0, bool gather_neg = false, int body_col = 0, const long long* body_src = nullptr,
-                                long long body_bs = 0, long long body_ls = 0, bool small_neg = false) {
+                                long long body_bs = 0, long long body_ls = 0, bool small_neg = false, bool post_rsh = false) {
     const FftPlan& pl = M->plan;
     int blocks = batch * col_count * (pl.m2 / pl.cb);
     if (blocks == 0) return PZ_OK;
@@ -42,6 +44,14 @@ static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlim
         blocks = ((nbc + 7) / 8) * 8 * ncb;
     }
     const bool has_small = small != nullptr;
+    if (post_rsh) {
+        if (!(tail_rsh_supported(M) && rowmajor && has_small)) return fail(PZ_ERR_UNSUPPORTED, "fused tail: no shifted-store variant for this plan");
+        const size_t lds = ((size_t)2 * (16 + 1) * 16 * 16 + 2 * 16 * 16) * sizeof(cplx);
+        PZ_TRY(set_lds((k_inv_tail<16, 16, 16, false, true, true, true>), lds));
+        hipLaunchKernelGGL((k_inv_tail<16, 16, 16, false, true, true, true>), dim3(blocks), dim3(TailShape<16, 16, 16>::NT), lds, M->stream, g);
+        PZ_HIP(hipGetLastError());
+        return PZ_OK;
+    }
 // one instantiation per (probe, row-major, body add) combination actually requested
 #define PZ_TAIL_ONE(A, B, C, P_, R_, S_)                                                                        \
     if (M->probe == P_ && rowmajor == R_ && has_small == S_) {                                                  \
@@ -70,7 +80,8 @@ int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncol
                     int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
                     int base2k, bool rowmajor, bool small_all, unsigned auto_mul, bool auto_neg,
                     unsigned gather_mul, bool gather_neg, int body_col, const long long* body_src,
-                    long long body_bs, long long body_ls, bool small_neg) {
+                    long long body_bs, long long body_ls, bool small_neg, bool post_rsh) {
+    if (post_rsh && !(small != nullptr && small_all)) return fail(PZ_ERR_UNSUPPORTED, "fused tail: shifted store needs an operand per column");
     if (small != nullptr && !small_all && ncols > 1) {
         PZ_TRY(launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, small, small_bs, small_cols, small_size,
                                     base2k, rowmajor, false, auto_mul, auto_neg, body_col, 1, 0, false, body_col));
@@ -82,7 +93,7 @@ int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncol
     }
     return launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, small, small_bs, small_cols, small_size, base2k,
                                 rowmajor, small_all, auto_mul, auto_neg, 0, ncols, gather_mul, gather_neg, body_col, body_src, body_bs, body_ls,
-                                small_neg);
+                                small_neg, post_rsh);
 }
 
 

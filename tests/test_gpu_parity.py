@@ -1287,6 +1287,44 @@ def test_glwe_trace_batched(mods, fuse):
         assert np.array_equal(got, want), (n, rank, size)
 
 
+@pytest.mark.parametrize("size,key_size,res_gals", [(8, 8, [-1, 5, 25, 625]), (3, 4, [5, 25]), (4, 3, [5, 25, 625])])
+def test_glwe_trace_n65536_shifted_stores(mods, size, key_size, res_gals):
+    """glwe_trace at N = 2^16 (256 x 128 plan): the one-bit vec_znx_rsh in front of a step rides on the previous step's tail where that
+    step runs the spectral automorphism form (Galois element = 1 mod 4) - k_inv_tail<.., RSH>; against the oracle's literal sequence
+    (rsh, glwe_automorphism_add_assign per step).  -1 first (the full trace's order): that step's tail has no shifted variant; key limbs
+    above / below the ciphertext's (zero-extended limb, carry-only first step)."""
+    from poulpy_amd.hal import GlweOpParams
+    n, rank, dnum, k, batch = 65536, 1, 2, 12, 2
+    ref, hip = mods(n)
+    rng = seeded(65536 + size)
+    cols = rank + 1
+    prs, d_keys = [], []
+    for _ in res_gals:
+        mat = MatZnx(n, dnum, rank, cols, key_size).fill_uniform(k, rng)
+        pr, ph = ref.vmp_pmat_alloc(dnum, rank, cols, key_size), hip.vmp_pmat_alloc(dnum, rank, cols, key_size)
+        ref.vmp_prepare(pr, mat)
+        hip.vmp_prepare(ph, mat)
+        prs.append(pr)
+        d_keys.append(hip.device_alloc(ph.data.nbytes).upload(ph.data))
+    gals = [g % (2 * n) if g > 0 else g for g in res_gals]
+    cts = np.empty((batch, size, cols, n), dtype=np.int64)
+    want = np.empty_like(cts)
+    for b in range(batch):
+        ct = VecZnx(n, cols, size).fill_uniform(k, rng)
+        cts[b] = ct.data
+        ref.glwe_trace_assign(ct, k, gals, prs)
+        want[b] = ct.data
+    d_res = hip.device_alloc(cts.nbytes).upload(cts)
+    p = GlweOpParams(rank=rank, dnum=dnum, dsize=1, key_size=key_size, key_base2k=k, a_size=size, a_base2k=k, res_size=size, res_base2k=k,
+                     rank_out=rank)
+    hip.glwe_trace_batched(d_res.ptr, gals, [d.ptr for d in d_keys], p, batch)
+    hip.sync()
+    got = d_res.download(np.int64, want.size).reshape(want.shape)
+    for d in d_keys + [d_res]:
+        d.free()
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("n,rank,res_k,key_k,kbits,batch,nsteps", [
     (256, 1, 14, 13, 4 * 14 + 1, 3, 8),     # poulpy-core test_suite/trace.rs:36-39: result base2k, keys base2k - 1, k = 4 base2k + 1, full trace
     (256, 2, 12, 15, 40, 2, 5),             # keys in the larger base, partial trace
