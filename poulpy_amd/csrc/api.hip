@@ -783,10 +783,12 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
             static const int small_au4 = getenv("POULPY_DBG_SMALL_AUTO") ? atoi(getenv("POULPY_DBG_SMALL_AUTO")) : 1;
             if (small_env && M->small_path && (!au || (small_au4 && ks && !lay)) && !tensor && !digits && !cross_out && !M->probe && M->dbg_stages == 7 &&
                 small_supported(M, npi, ksz)) {
+                const bool rsh4 = want_rsh && au && au->mode != 0 && p->res_base2k <= 29;
                 PZ_TRY(launch_small_fwd(M, nb * npi, (const long long*)av.p, sm, T));
                 PZ_TRY(launch_small_inv(M, nb, T, Pp, npi, nrows, ncols, s.cols_out, ksz, (long long*)(res + (long long)b0 * res_bs), res_bs,
                                         s.cols_out, (int)p->res_size, ks ? (const long long*)av.p : nullptr, av.bs, s.cols_a, a_size,
-                                        (int)p->res_base2k, body_col, false, nullptr, 0, au != nullptr, au_p, au ? au->mode : 0));
+                                        (int)p->res_base2k, body_col, false, nullptr, 0, au != nullptr, au_p, au ? au->mode : 0, rsh4));
+                if (rsh4) *post_rsh = true;
                 continue;
             }
             if (M->dbg_stages & 1) PZ_TRY(launch_fwd_pass1(M, nb * npi, (const long long*)av.p, sm, T, true));
@@ -878,6 +880,7 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
             int64_t* a_conv = (int64_t*)((char*)M->ws + key_bytes + s_bytes);
             int64_t* key_digits = (int64_t*)((char*)M->ws + key_bytes + s_bytes + conv_bytes);
             PZ_TRY(launch_small_permute(M, pmat, Pp, nrows * ncols));
+            const bool small_rsh = want_rsh && au && au->mode != 0 && !cross_out && p->res_base2k <= 29;
             for (size_t b0 = 0; b0 < batch; b0 += chunk) {
                 const int nb = (int)std::min(chunk, batch - b0);
                 DV av{(void*)(a + (long long)b0 * a_bs), a_bs, s.cols_a, (int)p->a_size};
@@ -899,8 +902,9 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
                 }
                 PZ_TRY(launch_small_inv(M, nb, S, Pp, npi, nrows, ncols, s.cols_out, ksz, (long long*)res_b, res_bs, s.cols_out, (int)p->res_size,
                                         ks ? (const long long*)av.p : nullptr, av.bs, s.cols_a, av.size, (int)p->res_base2k, body_col, false, nullptr,
-                                        0, au != nullptr, au_p, au ? au->mode : 0));
+                                        0, au != nullptr, au_p, au ? au->mode : 0, small_rsh));
             }
+            if (small_rsh) *post_rsh = true;
             return PZ_OK;
         }
     }

@@ -114,6 +114,7 @@ struct SmallInvArgs {
     const cplx* tw12t;
     const cplx* wL2;
     const cplx* tw1inv;          // [16] untwist with 1/m folded in
+    int post_rsh;                // AU: the digits leave through vec_znx_rsh_assign by one bit (k_inv_tail<.., RSH>, device_fft.hpp); base2k <= 29
     unsigned au_p;               // AU: Galois element mod 2n (coefficient i goes to i * au_p mod 2n, negated beyond n)
     int au_mode;                 // AU: 0 phi(normalize(big)), 1 normalize(phi(big) + a), 2 normalize(phi(big) - a), 3 normalize(a - phi(big));
                                  //     a = column `col` of `small` (the key-switch input itself), big includes the body (body_col)
@@ -325,8 +326,11 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { opos[e] = JG * e * M2; oneg[e] = false; }
     }
-    // limbs of res beyond the precision of the big value are zero (normalize.rs:118-120)
-    for (int j = L; j < g.res_size; ++j)
+    // limbs of res beyond the precision of the big value are zero (normalize.rs:118-120); shifted stores: limb L receives the bit shifted
+    // out of limb L - 1
+    const bool rsh = AU && g.post_rsh;
+    int cy2[4] = {0, 0, 0, 0};
+    for (int j = L + (rsh ? 1 : 0); j < g.res_size; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) res_col[(long long)j * res_ls + opos[e]] = 0;
     const unsigned long long half = 1ull << (k - 1), mask = (1ull << k) - 1;
@@ -362,8 +366,22 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
                 if (writes && (!(g.dbg & 4) || x1 == 0x7fffffffffffLL)) {
                     // AU mode 0: phi acts on the normalized digits (glwe_ct.rs:69-71)
                     const long long xs = (AU && g.au_mode == 0 && oneg[e]) ? (long long)(0ull - (unsigned long long)x1) : x1;
-                    if constexpr (AU) res_col[(long long)j * res_ls + opos[e]] = xs;   // scattered 8-byte stores: cacheable, so that the lines fill up in L2
-                    else st_stream(res_col + (long long)j * res_ls + opos[e], xs);
+                    if constexpr (AU) {   // scattered 8-byte stores: cacheable, so that the lines fill up in L2
+                        if (rsh) {
+                            const int xd = (int)xs, d1 = -(xd & 1), cr1 = (xd - d1) >> 1;
+                            if (j == g.res_size - 1) {
+                                cy2[e] = cr1;
+                            } else {
+                                const int dpc = d1 * (1 << (k - 1)) + cy2[e];
+                                const int nv = sx_digit(k, dpc);
+                                cy2[e] = cr1 + sx_carry(k, dpc, nv);
+                                res_col[(long long)(j + 1) * res_ls + opos[e]] = (long long)nv;
+                            }
+                            if (j == 0) res_col[opos[e]] = (long long)sx_digit(k, cy2[e]);
+                        } else {
+                            res_col[(long long)j * res_ls + opos[e]] = xs;
+                        }
+                    } else st_stream(res_col + (long long)j * res_ls + opos[e], xs);
                 }
                 if constexpr (FWD) {   // this thread's own slot (read above): component ch of z[limb j][j1][j2]
                     if (j < g.fwd_limbs) reinterpret_cast<double*>(lds)[2 * ((j * M1 + JG * e + jq) * RS + cj2) + ch] = (double)x1;

@@ -85,7 +85,7 @@ int launch_small_fwd(pz_module* M, int npolys, const long long* src, PolyMap sma
 int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int npi, int nrows, int ncols, int cols_out, int ksz,
                      long long* res, long long res_bs, int res_cols, int res_size, const long long* small, long long small_bs,
                      int small_cols, int small_size, int base2k, int body_col, bool noprod, cplx* fwd_S, int fwd_limbs,
-                     bool au, unsigned au_p, int au_mode) {
+                     bool au, unsigned au_p, int au_mode, bool post_rsh) {
     if (batch <= 0) return PZ_OK;
     PZ_TRY(ensure_small_tables(M));
     SmallInvArgs g;
@@ -96,7 +96,8 @@ int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int
     static const int skip = getenv("POULPY_DBG_SMALL_SKIP") ? atoi(getenv("POULPY_DBG_SMALL_SKIP")) : 0;
     g.dbg = skip;
     g.S_out = fwd_S; g.tw1 = M->s_tw1; g.fwd_limbs = fwd_S ? fwd_limbs : 0;
-    g.au_p = au_p; g.au_mode = au_mode;
+    g.au_p = au_p; g.au_mode = au_mode; g.post_rsh = (post_rsh && au) ? 1 : 0;
+    if (post_rsh && !(au && au_mode != 0 && base2k <= 29)) return fail(PZ_ERR_INVALID, "small-ring pipeline: shifted stores need an automorphism form with an operand, base2k <= 29");
     if (au && (noprod || fwd_S || small == nullptr || small_cols != cols_out))
         return fail(PZ_ERR_INVALID, "small-ring pipeline: the automorphism variant needs the key-switch operand");
     if (fwd_S && !(noprod && fwd_limbs >= 1 && fwd_limbs <= ksz && fwd_limbs <= res_size && fwd_limbs <= 8))
