@@ -9,6 +9,9 @@
 // one XCD).  Same tables, same stage formulas as k_fwd_pass1 / k_mid128 / k_inv_tail, regrouped; dsize = 1, one base2k, <= 4 key limbs.
 //   S  : S[poly][q1][q2]     (the tile layout of the middle kernel after its forward row pass)
 //   Pp : P'[q1][r][c][q2]    (the row-sliced key of the three-kernel pipeline)
+// Variants of k_small_inv (template flags): NOPROD - the spectra are given (blind rotation: the block step produced them), FWD - the
+// forward transform of the new digits follows in the same workgroup (the next block's input), AU - the glwe_automorphism family
+// (phi as an index / sign map in the carry-chain stage; optionally the trace's one-bit shift on the way out).
 #pragma once
 #include "device_fft.hpp"
 
