@@ -799,7 +799,9 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
             // +-(phi(body) +- a0) prepared by one k_automorphism pass over that column into the (cache-resident) workspace -- and
             // writes the final result: no permutation pass over the result, no gathers in the tail, in-place forms safe.
             static const int au_spec = getenv("POULPY_DBG_AUTO_SPECTRAL") ? atoi(getenv("POULPY_DBG_AUTO_SPECTRAL")) : 1;
-            const bool spec = au_spec && au_big && (au_p & 3u) == 1u && M->plan.m2 == 128 && M->dbg_stages == 7;
+            // (mode 0, phi(normalize(big)), rides on the same form: the tail undoes phi's signs in front of the carry chain and puts them
+            //  back on the digits; POULPY_DBG_AUTO_SPECTRAL=2 keeps the key switch + signed permutation pass for it)
+            const bool spec = au_spec && au && (au_big || au_spec == 1) && (au_p & 3u) == 1u && M->plan.m2 == 128 && M->dbg_stages == 7;
             unsigned perm_mul = 0, perm_add = 0;
             if (spec) {
                 const unsigned mm = (unsigned)M->m;
@@ -816,6 +818,13 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
                 // (the tail reads operand limbs j < min(key_size, a_size) only: the pre-pass covers exactly those)
                 const int bl = std::min(a_size, ksz);
                 PolyMap bsm{bl, 1, av.bs, (long long)av.cols * n, 0, 0}, bdm{bl, 1, (long long)bl * n, n, 0, 0};
+                if (!au_big) {   // plain form: the body column's operand is phi(body); no other operand
+                    PZ_TRY(launch_automorphism(M, nb * bl, (const long long*)av.p, bsm, (long long*)res_tmp, bdm, au_g, 1));
+                    PZ_TRY(launch_inv_tail(M, nb, T2, ksz, s.cols_out, (long long*)res_b, res_bs, s.cols_out, (int)p->res_size,
+                                           (const long long*)av.p, av.bs, s.cols_a, a_size, (int)p->res_base2k, true, true, au_g, false, 0u, false,
+                                           body_col, (const long long*)res_tmp, (long long)bl * n, n, false, false, true, true));
+                    continue;
+                }
                 // operand of the body column, one stream: phi(body) + a0 (add) or -phi(body) + a0 (sub forms: the tail negates every operand)
                 PZ_TRY(launch_automorphism(M, nb * bl, (const long long*)av.p, bsm, (long long*)res_tmp, bdm, au_g, au->mode == 1 ? 1 : 3,
                                            (const long long*)av.p, bsm));

@@ -449,6 +449,10 @@ struct TailArgs {
     int pre_body, small_neg;
     const long long* body_src;
     long long body_bs, body_ls;
+    // plain glwe_automorphism in the spectral form (res = phi(normalize(big)), glwe_ct.rs:65-71): the inverse transform is phi(big) with
+    // phi's signs; auto_mul undoes them in front of the carry chain (so that it runs on the values the reference normalizes), post_neg
+    // puts them back on the digits; body_only: only the body column has an operand (phi(body), from the workspace)
+    int post_neg, body_only;
 };
 
 // Workgroup = (R2 + R1)*CB threads in two wave-uniform roles (R2*CB must be a multiple of 64):
@@ -601,7 +605,8 @@ k_inv_tail(TailArgs g) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const long long ih = idx + (h ? m : 0);
-                    unsigned long long v = bsrc ? (unsigned long long)bsrc[ih] : (unsigned long long)small_col[(long long)j * small_ls + ih];
+                    unsigned long long v = bsrc ? (unsigned long long)bsrc[ih]
+                                                : (g.body_only ? 0ull : (unsigned long long)small_col[(long long)j * small_ls + ih]);
                     if (g.small_neg) v = 0ull - v;
                     sm[2 * e + h] = (long long)v;
                 }
@@ -674,8 +679,9 @@ k_inv_tail(TailArgs g) {
             if (PROBE) worst = fmax(worst, fabs(val - r));                                                   \
             long long x = CONVERT(r);                                                                        \
             if (SMALL && add_small) x = (long long)((unsigned long long)x + (unsigned long long)sm[SMALL ? 2 * n1 + h : 0]); \
+            bool ng_ = false;                                                                                \
             if (SMALL && g.auto_mul) {                                                                       \
-                const bool ng_ = (((unsigned)idx * g.auto_mul) & (unsigned)(2 * n - 1)) >= (unsigned)n;      \
+                ng_ = (((unsigned)idx * g.auto_mul) & (unsigned)(2 * n - 1)) >= (unsigned)n;                 \
                 if (ng_ != (g.auto_neg != 0)) x = (long long)(0ull - (unsigned long long)x);                 \
             }                                                                                                \
             long long& cy = carry[2 * n1 + h];                                                               \
@@ -686,8 +692,9 @@ k_inv_tail(TailArgs g) {
                 cy = cr;                                                                                     \
             } else {                                                                                         \
                 const unsigned long long y2 = (unsigned long long)d + (unsigned long long)cy + half;         \
-                const long long x1 = (long long)(y2 & mask) - (long long)half;                               \
+                long long x1 = (long long)(y2 & mask) - (long long)half;                                     \
                 cy = (long long)((unsigned long long)cr + (unsigned long long)((long long)y2 >> k));         \
+                if (SMALL && g.post_neg && ng_) x1 = (long long)(0ull - (unsigned long long)x1);             \
                 if (RSH) {                                                                                   \
                     if (writes) {                                                                            \
                         int& c2 = cy2[RSH ? 2 * n1 + h : 0];                                                 \

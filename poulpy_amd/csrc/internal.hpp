@@ -53,7 +53,8 @@ int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncol
                     int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
                     int base2k, bool rowmajor = false, bool small_all = false, unsigned auto_mul = 0, bool auto_neg = false,
                     unsigned gather_mul = 0, bool gather_neg = false, int body_col = 0, const long long* body_src = nullptr,
-                    long long body_bs = 0, long long body_ls = 0, bool small_neg = false, bool post_rsh = false);
+                    long long body_bs = 0, long long body_ls = 0, bool small_neg = false, bool post_rsh = false, bool post_neg = false,
+                    bool body_only = false);
 bool tail_rsh_supported(const pz_module* M);
 
 // ---- launch_mid.hip -----------------------------------------------------------------------------------------------

@@ -19,7 +19,8 @@ static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlim
                                 int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
                                 int base2k, bool rowmajor, bool small_all, unsigned auto_mul, bool auto_neg, int col_base, int col_count,
                                 unsigned gather_mul = 0, bool gather_neg = false, int body_col = 0, const long long* body_src = nullptr,
-                                long long body_bs = 0, long long body_ls = 0, bool small_neg = false, bool post_rsh = false) {
+                                long long body_bs = 0, long long body_ls = 0, bool small_neg = false, bool post_rsh = false, bool post_neg = false,
+                                bool body_only = false) {
     const FftPlan& pl = M->plan;
     int blocks = batch * col_count * (pl.m2 / pl.cb);
     if (blocks == 0) return PZ_OK;
@@ -33,6 +34,7 @@ static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlim
     g.col_base = col_base; g.col_count = col_count; g.body_col = body_col;
     g.gather_mul = gather_mul; g.gather_neg = gather_neg ? 1 : 0;
     g.pre_body = body_src != nullptr ? 1 : 0; g.small_neg = small_neg ? 1 : 0; g.body_src = body_src; g.body_bs = body_bs; g.body_ls = body_ls;
+    g.post_neg = post_neg ? 1 : 0; g.body_only = body_only ? 1 : 0;
     // XCD-aware block order (all column blocks of one (ciphertext, column) on one XCD, back to back): the gathers of the automorphism
     // forms need it for L2 locality, and the row-major pipeline streams faster with it (see k_fwd_pass1); the grid is padded to whole
     // groups of 8 (ciphertext, column) pairs
@@ -80,7 +82,7 @@ int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncol
                     int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
                     int base2k, bool rowmajor, bool small_all, unsigned auto_mul, bool auto_neg,
                     unsigned gather_mul, bool gather_neg, int body_col, const long long* body_src,
-                    long long body_bs, long long body_ls, bool small_neg, bool post_rsh) {
+                    long long body_bs, long long body_ls, bool small_neg, bool post_rsh, bool post_neg, bool body_only) {
     if (post_rsh && !(small != nullptr && small_all)) return fail(PZ_ERR_UNSUPPORTED, "fused tail: shifted store needs an operand per column");
     if (small != nullptr && !small_all && ncols > 1) {
         PZ_TRY(launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, small, small_bs, small_cols, small_size,
@@ -93,7 +95,7 @@ int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncol
     }
     return launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, small, small_bs, small_cols, small_size, base2k,
                                 rowmajor, small_all, auto_mul, auto_neg, 0, ncols, gather_mul, gather_neg, body_col, body_src, body_bs, body_ls,
-                                small_neg, post_rsh);
+                                small_neg, post_rsh, post_neg, body_only);
 }
 
 

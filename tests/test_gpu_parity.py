@@ -499,6 +499,25 @@ def test_config5_shape_automorphism_n65536(mods, mode):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("in_place", [False, True], ids=["out-of-place", "in-place"])
+@pytest.mark.parametrize("n", [8192, 65536])
+def test_plain_automorphism_spectral_form(mods, n, in_place):
+    """glwe_automorphism (res = phi(normalize(big)), glwe_ct.rs:51-72) for Galois elements = 1 mod 4 on the 128-point-row plans: the
+    permutation is folded into the middle kernel's spectrum position; the tail undoes phi's signs in front of the carry chain and puts
+    them back on the digits, so no permutation pass runs over the result.  5, 5^k, 2N - 3 (= 1 mod 4), ragged limbs, rank 2; 3 and -1
+    (= 3 mod 4) keep the key switch + signed permutation pass."""
+    ref, hip = mods(n)
+    k = 12
+    cases = [(1, 5, 4, 4, 4, 4, 3), (1, pow(5, 9, 2 * n), 3, 4, 3, 3, 2), (2, 2 * n - 3, 3, 3, 3, 3, 2), (1, 3, 4, 4, 4, 4, 2), (1, -1, 4, 3, 3, 4, 2),
+             (1, 5, 4, 3, 3, 4, 2)]
+    for (rank, gal, a_size, key_size, dnum, res_size, batch) in cases:
+        if in_place and a_size != res_size:
+            continue
+        got, want = _run_glwe_op(hip, ref, True, n, rank, rank, a_size, k, key_size, k, dnum, 1, res_size, k, batch, seed=700 + rank + a_size + batch,
+                                 auto=(gal, "automorphism"), in_place=in_place)
+        assert np.array_equal(got, want), (rank, gal, a_size, key_size, res_size)
+
+
 def test_ggsw_external_product(mods):
     """external_product/ggsw.rs:54-58: a loop of GLWE external products over the (row, column) entries of a GGSW."""
     from poulpy_amd.hal import GlweOpParams
