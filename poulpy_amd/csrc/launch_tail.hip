@@ -12,8 +12,16 @@ namespace pz {
 
 // the two roles of k_inv_tail must be whole waves
 bool tail_supported(const pz_module* M) { return (M->plan.f1b * M->plan.cb) % 64 == 0; }
-// the variant whose digits leave through a one-bit vec_znx_rsh (glwe_trace): instantiated for the 256 x 128 plan of N = 2^16 only
-bool tail_rsh_supported(const pz_module* M) { return M->plan.f1a == 16 && M->plan.f1b == 16 && M->plan.cb == 16 && !M->probe; }
+// the variant whose digits leave through a one-bit vec_znx_rsh (glwe_trace): instantiated for the
+// 128-point-row plans (N = 2^13 .. 2^16)
+#define PZ_RSH_CASES(X) X(4, 8, 16) X(8, 8, 16) X(8, 16, 16) X(16, 16, 16)
+bool tail_rsh_supported(const pz_module* M) {
+    if (M->probe) return false;
+#define X(A, B, C) if (M->plan.f1a == A && M->plan.f1b == B && M->plan.cb == C) return true;
+    PZ_RSH_CASES(X)
+#undef X
+    return false;
+}
 
 static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
                                 int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
@@ -48,11 +56,17 @@ static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlim
     const bool has_small = small != nullptr;
     if (post_rsh) {
         if (!(tail_rsh_supported(M) && rowmajor && has_small)) return fail(PZ_ERR_UNSUPPORTED, "fused tail: no shifted-store variant for this plan");
-        const size_t lds = ((size_t)2 * (16 + 1) * 16 * 16 + 2 * 16 * 16) * sizeof(cplx);
-        PZ_TRY(set_lds((k_inv_tail<16, 16, 16, false, true, true, true>), lds));
-        hipLaunchKernelGGL((k_inv_tail<16, 16, 16, false, true, true, true>), dim3(blocks), dim3(TailShape<16, 16, 16>::NT), lds, M->stream, g);
-        PZ_HIP(hipGetLastError());
-        return PZ_OK;
+#define X(A, B, C)                                                                                              \
+    if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
+        const size_t lds = ((size_t)2 * (A + 1) * C * B + 2 * A * B) * sizeof(cplx);                            \
+        PZ_TRY(set_lds((k_inv_tail<A, B, C, false, true, true, true>), lds));                                   \
+        hipLaunchKernelGGL((k_inv_tail<A, B, C, false, true, true, true>), dim3(blocks), dim3(TailShape<A, B, C>::NT), lds, M->stream, g); \
+        PZ_HIP(hipGetLastError());                                                                              \
+        return PZ_OK;                                                                                           \
+    }
+        PZ_RSH_CASES(X)
+#undef X
+        return fail(PZ_ERR_UNSUPPORTED, "fused tail: no shifted-store variant for this plan");
     }
 // one instantiation per (probe, row-major, body add) combination actually requested
 #define PZ_TAIL_ONE(A, B, C, P_, R_, S_)                                                                        \

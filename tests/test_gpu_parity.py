@@ -1307,7 +1307,7 @@ def test_glwe_trace_batched(mods, fuse):
 
 
 @pytest.mark.parametrize("size,key_size,res_gals", [(8, 8, [-1, 5, 25, 625]), (3, 4, [5, 25]), (4, 3, [5, 25, 625])])
-@pytest.mark.parametrize("n", [1024, 2048, 4096, 65536])
+@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192, 16384, 32768, 65536])
 def test_glwe_trace_shifted_stores(mods, n, size, key_size, res_gals):
     """glwe_trace where the one-bit vec_znx_rsh in front of a step rides on the previous step's last kernel: N = 2^16 (256 x 128 plan) on
     the tail of the spectral automorphism form (Galois element = 1 mod 4; k_inv_tail<.., RSH>), N <= 4096 on k_small_inv<.., AU>; against
@@ -1315,7 +1315,7 @@ def test_glwe_trace_shifted_stores(mods, n, size, key_size, res_gals):
     below the ciphertext's (zero-extended limb, carry-only first step)."""
     from poulpy_amd.hal import GlweOpParams
     rank, dnum, k, batch = 1, 2, 12, 2
-    if key_size > 4 and n < 65536:
+    if key_size > 4 and n <= 4096:
         key_size, size = 4, 4     # the small-ring pipeline takes up to four key limbs
     ref, hip = mods(n)
     rng = seeded(n + size)
