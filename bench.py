@@ -305,6 +305,29 @@ def main():
 
     # timed output of the LAST step -> parity sample against the CPU oracle (taken before the instrumented pass re-runs the op)
     parity = parity_sample(args, mod, a, res, mat_host, lo, nct, ks, auto_mode, trace or expand, cols, cols_in, relin, DSIZE) if args.parity_samples else None
+    if trace and args.parity_samples and mat_host is not None:   # (the rank that holds the key material on the host)
+        # the timed traces run in place on their own output; the check is one more (untimed) call from the original input - same
+        # pointers, batch and keys, so the same launches (and graph) - on two ciphertexts: log2(N) key switches each on the CPU
+        import numpy as np
+        from oracle.ref import RefModule
+        from poulpy_amd.layouts import MatZnx, VecZnx
+        res.copy_(a)
+        torch.cuda.synchronize()
+        step()
+        mod.sync()
+        ref = RefModule(N)
+        mh = mat_host
+        pm = ref.vmp_pmat_alloc(DNUM, cols_in, cols, SIZE)
+        ref.vmp_prepare(pm, MatZnx(N, DNUM, cols_in, cols, SIZE, np.ascontiguousarray(mh)))
+        bad = []
+        picks = sorted({0, nct - 1})
+        for i in picks:
+            ct = VecZnx(N, cols, SIZE, a[i].cpu().numpy().copy())
+            ref.glwe_trace_assign(ct, BASE2K, trace_gals, [pm] * len(trace_gals))
+            if not np.array_equal(res[i].cpu().numpy(), ct.data):
+                bad.append(int(lo + i))
+        parity = {"n": len(picks), "ok": not bad, "indices": [int(lo + i) for i in picks], "mismatched": bad,
+                  "against": "oracle/fft64_ref.c, bit-exact i64 limbs; one extra untimed call from the original input (the timed calls run in place)"}
 
     # roofline leg: the same steps again with one HIP-event pair per launch on the module stream
     stats = {}
