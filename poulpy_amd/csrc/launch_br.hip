@@ -122,6 +122,8 @@ int br_block_step(pz_module* M, const double* acc_dft, long long a_bs, double* a
                 const int ngroups = (nc + cgs - 1) / cgs;
                 // keys staged in LDS once per 4 waves x 2 ciphertexts (k_br_block_lds): POULPY_DBG_BR_LDS = 0 never, 1 only for
                 // more than 8 inputs, 2 always
+                // (four ciphertexts per wave for <= 6 inputs - every staged key value serving 16 ciphertexts instead of 8, at 256 registers -
+                //  measured slower at N = 2048: 11.06 vs 9.68 ms per 82 block steps)
                 static const int br_lds = getenv("POULPY_DBG_BR_LDS") ? atoi(getenv("POULPY_DBG_BR_LDS")) : 2;
                 const bool use_lds = M->m % 64 == 0 && (br_lds >= 2 || (br_lds == 1 && row_max > 8));
                 bool launched = false;
