@@ -23,6 +23,8 @@ $B --n 4096 --limbs 3 --base2k 18 --op automorphism --steps 100 >> $OUT 2>/dev/n
 $B --n 4096 --limbs 3 --base2k 18 --op automorphism_add --steps 100 >> $OUT 2>/dev/null
 $B --n 2048 --limbs 4 --base2k 17 --op automorphism_add --steps 100 >> $OUT 2>/dev/null
 $B --n 1024 --limbs 4 --base2k 17 --op automorphism_add --steps 100 >> $OUT 2>/dev/null
+$B --n 4096 --limbs 4 --base2k 17 --op trace --steps 20 >> $OUT 2>/dev/null            # 12 / 10 steps of shift + automorphism_add_assign
+$B --n 1024 --limbs 4 --base2k 17 --op trace --steps 20 >> $OUT 2>/dev/null
 $B --n 131072 --batch 512 --steps 10 >> $OUT 2>/dev/null
 $B --n 2048 --limbs 4 --base2k 17 --steps 100 >> $OUT 2>/dev/null
 $B --n 1024 --limbs 4 --base2k 17 --steps 100 >> $OUT 2>/dev/null
