@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
         if (CT == 2 && R0 == 8) asm volatile("" : "+v"(tidv));
         const bool from_lut = ACC32 && blk0 == 0;  // the accumulator is still X^b * LUT in global memory
         // ---- pack + twist: X[ct][r][j] = (acc[r][j] + i acc[r][j+m]) * exp(2 pi i j / 4m),  r = limb*cols + col (:319-320)
-        if (!(g.dbg_skip & 8))
+        if (!(PZ_DBG(g.dbg_skip) & 8))
         for (int pr = tidv >> lm; pr < CT * row_max; pr += NT >> lm) {  // (ciphertext, row) pairs; j = tid mod m is fixed
             const int j = tidv & (m - 1), ct = (CT == 2 && pr >= row_max) ? 1 : 0, r = pr - ct * row_max;
             const acc_t* a = acc + ((long long)ct * ct_polys + r) * n;
@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
         __syncthreads();
         // forward DFT of the CT*row_max input polynomials (they sit at poly index ct*P + r: run the passes over whole
         // ciphertext slots when row_max == P, otherwise per ciphertext)
-        if (!(g.dbg_skip & 1))
+        if (!(PZ_DBG(g.dbg_skip) & 1))
         for (int ct = 0; ct < (row_max == P ? 1 : CT); ++ct) {
             cplx* buf = X + ct * P * mp;
             const int np = row_max == P ? CT * P : row_max;
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
             br_pass<8, false, JM8, NT>(buf, np, mp, m, lm, R0 * 8, W, tidv);
         }
         // ---- product, in place: X[ct][c][q] = sum_i (DFT(X^a_i)[q] - 1) * sum_r X[ct][r][q] * BRK_i[r][c][q]   (:321-337)
-        if (!(g.dbg_skip & 2)) {
+        if (!(PZ_DBG(g.dbg_skip) & 2)) {
             cplx out[PJ][CT][CG];
 #pragma unroll
             for (int pj = 0; pj < PJ; ++pj) {
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
             __syncthreads();
         }
         // inverse DFT of the CT*ncols output polynomials
-        if (!(g.dbg_skip & 1))
+        if (!(PZ_DBG(g.dbg_skip) & 1))
         for (int ct = 0; ct < (ncols == P ? 1 : CT); ++ct) {
             cplx* buf = X + ct * P * mp;
             const int np = ncols == P ? CT * P : ncols;
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
         }
         // ---- untwist, round(x/m), + acc, carry chain from the last limb to limb 0 (:342-346); thread = (ct, column, j < m):
         //      coefficients j and j+m.  Same digit/carry arithmetic as the fused tail (device_fft.hpp, PZ_TAIL_COEFFS).
-        if (!(g.dbg_skip & 4))
+        if (!(PZ_DBG(g.dbg_skip) & 4))
         for (int pc = tidv >> lm; pc < CT * cols; pc += NT >> lm) {  // (ciphertext, column) pairs; j = tid mod m is fixed
             const int j = tidv & (m - 1), ct = (CT == 2 && pc >= cols) ? 1 : 0, col = pc - ct * cols;
             const cplx tw = tw_j;

@@ -248,7 +248,7 @@ __device__ __forceinline__ void brl_fetch(cplx (&nxt)[PER], const BrBlockArgs& g
         const int e = min(u * 4 + w, CG * MAXR - 1);
         const int j = e / MAXR, r = e % MAXR;
         const int c = min(cg * CG + j, g.ncols - 1);
-        nxt[u] = (g.dbg & 1) ? make_double2(1.0, (double)e) : (K + (long long)(min(r, g.row_max - 1) * g.ncols + c) * g.m)[q];
+        nxt[u] = (PZ_DBG(g.dbg) & 1) ? make_double2(1.0, (double)e) : (K + (long long)(min(r, g.row_max - 1) * g.ncols + c) * g.m)[q];
     }
 }
 template <int PER, int NE>
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(256) k_br_block_lds(BrBlockArgs g) {
         const int b = min(b0 + t, g.batch - 1);
 #pragma unroll
         for (int r = 0; r < MAXR; ++r)
-            a[t][r] = (r < g.row_max && !(g.dbg & 4)) ? g.acc_dft[(long long)b * g.a_bs + (long long)r * g.m + q] : make_double2(0.0, (double)b);
+            a[t][r] = (r < g.row_max && !(PZ_DBG(g.dbg) & 4)) ? g.acc_dft[(long long)b * g.a_bs + (long long)r * g.m + q] : make_double2(0.0, (double)b);
     }
     cplx out[CT][CG];
 #pragma unroll
@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(256) k_br_block_lds(BrBlockArgs g) {
             for (int j = 0; j < CG; ++j) sacc[t][j] = make_double2(0.0, 0.0);
 #pragma unroll
         for (int r = 0; r < MAXR; ++r) {
-            if (r < g.row_max && !(g.dbg & 2)) {
+            if (r < g.row_max && !(PZ_DBG(g.dbg) & 2)) {
 #pragma unroll
                 for (int j = 0; j < CG; ++j) {
                     const cplx kv = ks[buf][j * MAXR + r][lane];
@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(256) k_br_block_lds(BrBlockArgs g) {
                 }
             }
         }
-        if (!(g.dbg & 8)) brl_stage<PER, NE>(nxt, ks[buf ^ 1], w, lane);
+        if (!(PZ_DBG(g.dbg) & 8)) brl_stage<PER, NE>(nxt, ks[buf ^ 1], w, lane);
         __syncthreads();
         is = is_n;
         cgs = cg_n;

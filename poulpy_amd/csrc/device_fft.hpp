@@ -36,6 +36,14 @@ __device__ __forceinline__ cplx cmulc(cplx a, cplx b) {
 template <bool CONJ>
 __device__ __forceinline__ cplx cmul_t(cplx a, cplx b) { return CONJ ? cmulc(a, b) : cmul(a, b); }
 
+// Timing-ablation knobs (POULPY_DBG_MID_SKIP, POULPY_DBG_SMALL_SKIP, POULPY_DBG_BR_SKIP, POULPY_DBG_BRL) are compiled in only with
+// -DPZ_ABLATE=1 (POULPY_BUILD_DEFS=-DPZ_ABLATE=1 POULPY_BUILD_TAG=ablate): a run-time test around a global load inside a software-pipelined
+// loop makes the compiler's s_waitcnt insertion assume the worst case at every join (round 3: the product loop of k_mid128 waited with
+// vmcnt(0) for the key row it had just requested instead of vmcnt(4) for the one requested a row earlier).
+#ifndef PZ_ABLATE
+#define PZ_ABLATE 0
+#endif
+#define PZ_DBG(x) (PZ_ABLATE ? (x) : 0)
 // Streaming hints for data that is touched once per kernel (the i64 limbs, T', T2'): non-temporal loads / stores.  Measured on
 // MI355X (profiles/r02_hbm_copy_tuned.txt): a 16 B-per-lane copy runs at 6.25 TB/s plain and 6.5-6.6 TB/s with both hints.
 // PZ_STREAM_HINTS: bit 0 loads, bit 1 stores (build-time, for A/B runs; default both).
@@ -58,6 +66,13 @@ __device__ __forceinline__ void st_stream(cplx* p, cplx v) {
 __device__ __forceinline__ void st_stream(long long* p, long long v) {
     if ((PZ_STREAM_HINTS & 2) && PZ_STREAM_I64_NT) __builtin_nontemporal_store(v, p);
     else *p = v;
+}
+
+// A copy of v the optimizer cannot see through: everything derived from it is computed where it is used instead of being hoisted out
+// of the enclosing loop and kept live across it.
+__device__ __forceinline__ int pz_opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
 }
 
 // LDS traffic between the 16 lanes that own one row needs no workgroup barrier: the lanes are in one wave,

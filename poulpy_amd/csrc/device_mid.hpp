@@ -22,7 +22,13 @@ namespace pz {
 #ifndef PZ_MID_RS
 #define PZ_MID_RS 144
 #endif
-constexpr int kMidRS = PZ_MID_RS;   // row stride of the k_mid128 tile (see there; build-time for A/B runs)
+constexpr int kMidRS = PZ_MID_RS;
+#ifndef PZ_MID_STAMP
+#define PZ_MID_STAMP 0   // diagnostic build: per-phase s_memtime totals of k_mid128, printed by a few waves (tools/dbg/mid_stamps.sh)
+#endif
+#ifndef PZ_MID_RING
+#define PZ_MID_RING 4    // key-row slots of k_mid128's plain product (2: the ping-pong pair of rounds 1-2; build-time for A/B runs)
+#endif   // row stride of the k_mid128 tile (see there; build-time for A/B runs)
 
 struct MidArgs {
     const cplx* T;
@@ -284,9 +290,11 @@ k_mid(MidArgs g) {
 // NP = polynomial slots per ciphertext: 16; 8 for shapes with <= 8 polynomials in and out such as rank 1 with 4 limbs (twice the
 // ciphertexts per tile and per key fetch); 32 for rank 2-3 or 16 limbs (two ciphertexts per tile).  The 4 thread groups of the product phase split into GC column groups x GT
 // ciphertext groups so that a thread always owns 16 accumulators (4 ciphertexts x 4 outputs, or 2 x 8).
-template <int CT, int NP = 16, bool PERM = false, bool DS = false, bool BR = false>
+template <int CT, int NP = 16, bool PERM = false, bool DS = false, bool BR = false, bool SKIPW = false, int KR = 2>
 __global__ void __launch_bounds__(CT * NP * 8)
 k_mid128(MidArgs g) {
+    static_assert(KR == 2 || (KR == 4 && NP <= 16 && !BR && !DS), "key ring of four: plain product with 4 outputs per thread");
+    static_assert(!SKIPW || (NP > 8 && !BR && !DS), "wave skipping: 16- and 32-slot tiles of the plain product only");
     constexpr int M2 = 128;
     constexpr int NT = CT * NP * 8;
     constexpr int NCG = NT / M2;       // thread groups in the product phase
@@ -303,12 +311,20 @@ k_mid128(MidArgs g) {
     // passes are not on the critical path.  144 it stays (16 KiB of LDS less).
     constexpr int RS = kMidRS;
     extern __shared__ cplx lds[];      // CT*16 rows x RS | wL2[128] | tw12t row [128]
-    const int tid = threadIdx.x;
+    const int tid0 = threadIdx.x;
     const long long m = (long long)g.m1 * M2;
-    const int row = tid >> 3, o = tid & 7;
-    const int ctl = row / NP, rr = row % NP;
-    cplx* rowbuf = lds + row * RS;
     cplx* wl = lds + CT * NP * RS;
+    // Lane coordinates are re-derived from an OPAQUE copy of the thread index at the top of every phase (round 3).  Derived once, the
+    // compiler hoists every address that depends on them out of the tile loop - ~60 loop-invariant registers (LDS offsets of the
+    // exchange passes, twiddle addresses, row pointers) that sit beside the 64 accumulators and the 64 prefetched T' values and
+    // spill; recomputing them costs a few integer instructions per phase.
+#define PZ_MID_LANE                                                                               \
+    const int tid = pz_opaque(tid0);                                                              \
+    const int row = tid >> 3, o = tid & 7;                                                        \
+    const int ctl = row / NP, rr = row % NP;                                                      \
+    cplx* const rowbuf = lds + row * RS;                                                          \
+    const int vq2 = tid & (M2 - 1), vcg = (tid / M2) % GC, vtg = (tid / M2) / GC;                 \
+    (void)ctl; (void)rr; (void)rowbuf; (void)vq2; (void)vcg; (void)vtg; (void)o;
     cplx* twrow = wl + M2;
     unsigned* abuf = reinterpret_cast<unsigned*>(twrow + M2);   // BR: a_i mod 2n of the tile's ciphertexts, [ct][16]
 
@@ -319,7 +335,7 @@ k_mid128(MidArgs g) {
     const int rows_x = xcd_map ? g.m1 / 8 : g.m1;
     const int ntiles = rows_x * g.n_ct;
     if (w >= ntiles) return;
-    if (tid < M2) wl[tid] = g.wL2[tid];
+    if (tid0 < M2) wl[tid0] = g.wL2[tid0];
     __syncthreads();
     if (g.stagger > 0) {
         const int k = (blockIdx.x / 256) % g.stagger_mod;
@@ -329,30 +345,35 @@ k_mid128(MidArgs g) {
     cplx x[16];
     auto tile_q1 = [&](int L) { const int k = L / g.n_ct; return xcd_map ? k * 8 + xcd : k; };
     auto out_q1 = [&](int q1_) { return PERM ? (int)((g.perm_mul * (unsigned)q1_ + g.perm_add) & (unsigned)(g.m1 - 1)) : q1_; };
-    auto src_ptr = [&](int L) {
+    auto src_ptr = [&](int L, int ctl, int rr, int o) {
         const int Lc = min(L, ntiles - 1);
         const int b_ = min((Lc % g.n_ct) * CT + ctl, g.batch - 1);
         const int r_ = min(rr, g.npi - 1);
         return g.T + ((long long)b_ * g.npi + r_) * m + (long long)tile_q1(Lc) * M2 + o;
     };
-    auto in_active = [&](int L) { return L < ntiles && (L % g.n_ct) * CT + ctl < g.batch && rr < g.npi; };
+    auto in_active = [&](int L, int ctl, int rr) { return L < ntiles && (L % g.n_ct) * CT + ctl < g.batch && rr < g.npi; };
     // A wave owns 8 consecutive polynomial slots of one ciphertext.  Waves whose slots all lie beyond the input (resp. output)
     // polynomials skip the forward (resp. inverse) row pass, its loads and its stores altogether — e.g. the upper half of every
     // ciphertext's 16 slots in a key switch (8 polynomials in): the product never reads those rows.  (Wave-uniform branches.)
     // (only where a ciphertext has more than 8 slots, and not in the BR / DS variants, whose register allocation the extra branches push
     //  over the 256-VGPR cap)
-    constexpr bool SKIPW = NP > 8 && !BR && !DS;
-    const bool wave_in = !SKIPW || (rr & ~7) < g.npi, wave_out = !SKIPW || (rr & ~7) < g.npo;
+    // SKIPW is a template parameter (round 3): the branches around the tile's loads and stores make the compiler's s_waitcnt insertion
+    // assume the worst case at every join — in the 16-polynomial external product, which never skips a wave, the forward pass's
+    // prefetched T' loads were waited for with vmcnt(1) at the top of the inverse pass instead of after it.  launch_mid picks the
+    // variant with the branches only for shapes that have idle waves (npi or npo <= NP - 8).
+    const int rr0 = (tid0 >> 3) % NP;
+    const bool wave_in = !SKIPW || (rr0 & ~7) < g.npi, wave_out = !SKIPW || (rr0 & ~7) < g.npo;
 
     // forward row DFT: x[n1] = row[o + 8*n1] -> radix 16 over n1 (k1) -> x W128^(o*k1) -> z[k1][o];
     // then this lane takes k1 = o and o+8: radix 8 over o -> S[row][q2 = k1 + 16*k2]
-#define PZ_MID_FWD(ACTIVE)                                                                        \
+#define PZ_MID_FWD(LT)                                                                            \
     {                                                                                             \
       if (wave_in) {                                                                              \
-        if (!(ACTIVE)) {                                                                          \
+        PZ_MID_LANE                                                                               \
+        if (!in_active((LT), ctl, rr)) {                                                                        \
             _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1) x[n1] = make_double2(0.0, 0.0);     \
         }                                                                                         \
-        if (!(g.dbg & 16)) Bfly<16, false>::run(x);                                               \
+        if (!(PZ_DBG(g.dbg) & 16)) Bfly<16, false>::run(x);                                               \
         _Pragma("unroll") for (int k1 = 0; k1 < 16; ++k1) {                                       \
             cplx v = x[k1];                                                                       \
             if (k1 > 0) v = cmul(v, wl[o * k1]);                                                  \
@@ -362,7 +383,7 @@ k_mid128(MidArgs g) {
         _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                           \
             _Pragma("unroll") for (int oo = 0; oo < 8; ++oo) x[8 * h + oo] = rowbuf[(o + 8 * h) * 9 + oo]; \
         }                                                                                         \
-        if (!(g.dbg & 16)) { Bfly<8, false>::run(x); Bfly<8, false>::run(x + 8); }                \
+        if (!(PZ_DBG(g.dbg) & 16)) { Bfly<8, false>::run(x); Bfly<8, false>::run(x + 8); }                \
         row_sync();                                                                               \
         _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                           \
             _Pragma("unroll") for (int k2 = 0; k2 < 8; ++k2) rowbuf[o + 8 * h + 16 * k2] = x[8 * h + k2]; \
@@ -372,22 +393,36 @@ k_mid128(MidArgs g) {
     }
 
     cplx twn = make_double2(0.0, 0.0);
-    {
-        const cplx* src = src_ptr(w);
-        if (wave_in) {
-#pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) x[n1] = (g.dbg & 4) ? make_double2(1.0, (double)n1) : ld_stream(src + 8 * n1);
-        }
-        twn = g.tw12t[(long long)out_q1(tile_q1(w)) * M2 + (tid & (M2 - 1))];
+    // the T' rows and the inter-pass twiddle of tile LT start travelling (always 16 + 1 loads)
+#define PZ_MID_XLOAD(LT)                                                                               \
+    {                                                                                                  \
+        PZ_MID_LANE                                                                                    \
+        const cplx* src_ = src_ptr((LT), ctl, rr, o);                                                  \
+        if (wave_in) {                                                                                 \
+            _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1)                                          \
+                x[n1] = (PZ_DBG(g.dbg) & 4) ? make_double2(1.0, (double)n1) : ld_stream(src_ + 8 * n1); \
+        }                                                                                              \
+        twn = g.tw12t[(long long)out_q1(tile_q1(min((LT), ntiles - 1))) * M2 + (tid & (M2 - 1))];      \
     }
-    if (tid < M2) twrow[tid] = twn;
-    const int vq2 = tid & (M2 - 1), vcg = (tid / M2) % GC, vtg = (tid / M2) / GC;
+    PZ_MID_XLOAD(w)
+    if (tid0 < M2) twrow[tid0] = twn;
+#if PZ_MID_STAMP
+    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_t0 = st_t;
+    int st_tiles = 0;
+#define PZ_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; }
+#else
+#define PZ_STAMP(i)
+#endif
     const int nrow = DS ? g.ds_n : g.row_max;          // product terms per output (BR: br_blk * br_rm, in order)
+    if constexpr (!BR) __builtin_assume(nrow >= 1);                       // (launch_mid checks it) no path around the product loop: see SKIPW
     const int rot = (!BR && nrow > 0) ? (w % nrow) : 0;
     const unsigned w2n_mask = 4u * (unsigned)(g.m1 * M2) - 1u;   // 2n - 1
     // BR: the tile's exponents to LDS (read by the product phase after the forward pass's barrier)
 #define PZ_MID_ABUF(LT)                                                                              \
     if constexpr (BR) {                                                                                \
+        const int tid = tid0;                                                                          \
         if (tid < CT * 16) {                                                                           \
             const int ct_ = tid >> 4, i_ = tid & 15;                                                   \
             const int Lc_ = min((LT), ntiles - 1);                                                     \
@@ -398,22 +433,30 @@ k_mid128(MidArgs g) {
             abuf[tid] = a_;                                                                            \
         }                                                                                              \
     }
-    cplx pn[NC];
+    cplx pn[NC], pb[NC], k2[KR == 4 ? NC : 1], k3[KR == 4 ? NC : 1];   // key-row slots (KR = 2: pn / pb in ping-pong)
+    (void)k2; (void)k3;
 #define PZ_MID_P0(LT)                                                                                  \
     {                                                                                                  \
+        PZ_MID_LANE                                                                                    \
         const long long base_ = (long long)tile_q1(min((LT), ntiles - 1)) * g.nrows * g.ncols;         \
-        if (!(g.dbg & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j) {                           \
+        if (!(PZ_DBG(g.dbg) & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j) {                           \
             const int c_ = DS ? min(vcg * NC + j, max((int)g.ds_cb[rot], 1) - 1) + (int)g.ds_coff[rot] : min(vcg * NC + j, g.ncomp - 1); \
-            pn[j] = g.P[(base_ + (long long)(DS ? (int)g.ds_row[rot] : rot) * g.ncols + c_) * M2 + vq2]; } } \
+            pn[j] = g.P[(base_ + (long long)(DS ? (int)g.ds_row[rot] : rot) * g.ncols + c_) * M2 + vq2];         \
+            if constexpr (KR == 4) {   /* rows 1 and 2 of the ring (nrow >= 4) */                             \
+                const int r1_ = rot + 1 - ((rot + 1 >= nrow) ? nrow : 0), r2_ = rot + 2 - ((rot + 2 >= nrow) ? nrow : 0); \
+                pb[j] = g.P[(base_ + (long long)r1_ * g.ncols + c_) * M2 + vq2];                               \
+                k2[j] = g.P[(base_ + (long long)r2_ * g.ncols + c_) * M2 + vq2];                               \
+            } } }                                                                                              \
     }
     PZ_MID_P0(w)
     PZ_MID_ABUF(w)
-    PZ_MID_FWD(in_active(w))
+    PZ_MID_FWD(w)
+    PZ_STAMP(7)
 
     for (int L = w; L < ntiles; L += W) {
         const int q1 = tile_q1(L);
-        const int b = (L % g.n_ct) * CT + ctl;
         {
+            PZ_MID_LANE
             const int q2 = vq2, cg = vcg;
             // BR: monomial factors of the current (f) and the next (fn, raw table values) block coefficient for this thread's ciphertexts
             const unsigned tq = 4u * ((unsigned)q1 + ((unsigned)q2 << g.log_m1)) + 1u;
@@ -442,7 +485,6 @@ k_mid128(MidArgs g) {
                 pp[j] = g.P + ((long long)q1 * g.nrows * g.ncols + c) * M2 + q2;
             }
             const long long prow = (long long)g.ncols * M2;
-            cplx pb[NC];  // ping-pong with pn, as in k_mid
 #define PZ_LOADROW(DST, IT)                                                                     \
     {                                                                                           \
         int r_ = (IT) + rot;                                                                    \
@@ -451,12 +493,13 @@ k_mid128(MidArgs g) {
         if (DS) {                                                                               \
             const int cb_ = max((int)g.ds_cb[r_], 1) - 1, co_ = (int)g.ds_coff[r_];             \
             const long long ro_ = (long long)g.ds_row[r_] * prow;                               \
-            if (!(g.dbg & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j)                  \
+            if (!(PZ_DBG(g.dbg) & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j)                  \
                 DST[j] = pp[j][ro_ + (long long)(min(cg * NC + j, cb_) + co_) * M2]; }          \
         } else {                                                                                \
             const long long off_ = (long long)r_ * prow;                                        \
-            if (!(g.dbg & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = pp[j][off_]; }  \
+            if (!(PZ_DBG(g.dbg) & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = pp[j][off_]; }  \
         }                                                                                       \
+        if constexpr (BR) __builtin_amdgcn_sched_barrier(0);                                    \
     }
 #define PZ_USEROW(SRC, IT)                                                                      \
     {                                                                                           \
@@ -469,7 +512,7 @@ k_mid128(MidArgs g) {
             r_ = (int)g.ds_in[r_];                                                              \
         }                                                                                       \
         if constexpr (BR) r_ = br_slot;                                                         \
-        if (!(g.dbg & 1)) _Pragma("unroll") for (int i = 0; i < CTt; ++i) {                      \
+        if (!(PZ_DBG(g.dbg) & 1)) _Pragma("unroll") for (int i = 0; i < CTt; ++i) {                      \
             cplx av = lds[((vtg * CTt + i) * NP + r_) * RS + q2];                               \
             if constexpr (BR) av = cmul(av, f[i]);                                              \
             _Pragma("unroll") for (int j = 0; j < NC; ++j) {                                    \
@@ -486,31 +529,90 @@ k_mid128(MidArgs g) {
                 _Pragma("unroll") for (int i = 0; i < CTt; ++i) f[i] = make_double2(fn[i].x - 1.0, fn[i].y); \
                 PZ_MID_LOADF(fn, br_i + 1)                                                      \
             }                                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                  \
         }                                                                                       \
     }
             int it = 0;
             // (BR: deeper key prefetch — rings of three / four row slots — spills at the 256-VGPR cap and measured slower: 30.1 vs 26.8 ms)
-            if constexpr (NC == 8) {
+            if constexpr (KR == 4) {
+                // Round 3, plain product of the 16- and 8-slot tiles, nrow a multiple of 4 (launch_mid): a ring of FOUR key-row slots —
+                // a row is requested three rows before its use (P0 requested rows 0..2 in front of the forward pass) — and the tile's
+                // operands are read from LDS one row ahead into a second register set, so that neither an L2 nor an LDS latency sits in
+                // front of a row's 64 FMAs.  Measured with s_memtime stamps before this (profiles/r03_mid_stamps_before.txt): the product
+                // phase took 13.4 k cycles per tile for 8.2 k cycles of FMA issue per SIMD — the wave that loses the issue arbitration
+                // ran the last third of its rows alone on its SIMD, stalling on every ds_read / key row.  No row past the end is requested.
+                cplx avA[CTt], avB[CTt];
+#define PZ_AVLOAD(DST, IT)                                                                      \
+    {                                                                                           \
+        int r_ = (IT) + rot;                                                                    \
+        r_ -= (r_ >= nrow) ? nrow : 0;                                                          \
+        r_ -= (r_ >= nrow) ? nrow : 0;                                                          \
+        _Pragma("unroll") for (int i = 0; i < CTt; ++i) DST[i] = lds[((vtg * CTt + i) * NP + r_) * RS + q2]; \
+        __builtin_amdgcn_sched_barrier(0);   /* the machine scheduler otherwise sinks these reads down to their first use */ \
+    }
+#define PZ_FMAROW(AV, SRC)                                                                      \
+    {                                                                                           \
+        if (!(PZ_DBG(g.dbg) & 1)) _Pragma("unroll") for (int i = 0; i < CTt; ++i) {             \
+            _Pragma("unroll") for (int j = 0; j < NC; ++j) {                                    \
+                acc[i][j].x = __builtin_fma(AV[i].x, SRC[j].x, acc[i][j].x);                    \
+                acc[i][j].x = __builtin_fma(-AV[i].y, SRC[j].y, acc[i][j].x);                   \
+                acc[i][j].y = __builtin_fma(AV[i].x, SRC[j].y, acc[i][j].y);                    \
+                acc[i][j].y = __builtin_fma(AV[i].y, SRC[j].x, acc[i][j].y);                    \
+            }                                                                                   \
+        }                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    }
+                PZ_AVLOAD(avA, 0)
+                for (; it + 4 < nrow; it += 4) {
+                    PZ_LOADROW(k3, it + 3) PZ_AVLOAD(avB, it + 1) PZ_FMAROW(avA, pn)
+                    PZ_LOADROW(pn, it + 4) PZ_AVLOAD(avA, it + 2) PZ_FMAROW(avB, pb)
+                    PZ_LOADROW(pb, it + 5) PZ_AVLOAD(avB, it + 3) PZ_FMAROW(avA, k2)
+                    PZ_LOADROW(k2, it + 6) PZ_AVLOAD(avA, it + 4) PZ_FMAROW(avB, k3)
+                }
+                PZ_LOADROW(k3, it + 3) PZ_AVLOAD(avB, it + 1) PZ_FMAROW(avA, pn)
+                PZ_AVLOAD(avA, it + 2) PZ_FMAROW(avB, pb)
+                PZ_AVLOAD(avB, it + 3) PZ_FMAROW(avA, k2)
+                PZ_FMAROW(avB, k3)
+#undef PZ_AVLOAD
+#undef PZ_FMAROW
+            } else if constexpr (NC == 8) {
                 // 8 key values per thread and row: the second register slot of the ping-pong is what pushes this shape over the 256-VGPR
                 // cap (132-164 bytes of scratch, 57.9 -> 50.3 ms per 10 launches at 16 limbs without it); one slot, the next row requested
                 // right after the current one has been consumed
-                for (; it < nrow; ++it) {
+                for (; it + 1 < nrow; ++it) {
                     PZ_USEROW(pn, it)
                     PZ_LOADROW(pn, it + 1)
                 }
-            } else {
-            for (; it + 1 < nrow; it += 2) {
-                PZ_LOADROW(pb, it + 1)
                 PZ_USEROW(pn, it)
-                PZ_LOADROW(pn, it + 2)
-                PZ_USEROW(pb, it + 1)
-            }
-            if (it < nrow) PZ_USEROW(pn, it)
+            } else {
+                // two slots in ping-pong; no row is requested past the end
+                for (; it + 3 < nrow; it += 2) {
+                    PZ_LOADROW(pb, it + 1)
+                    PZ_USEROW(pn, it)
+                    PZ_LOADROW(pn, it + 2)
+                    PZ_USEROW(pb, it + 1)
+                }
+                const int left = nrow - it;   // 1..3 rows
+                if (left == 3) {
+                    PZ_LOADROW(pb, it + 1)
+                    PZ_USEROW(pn, it)
+                    PZ_LOADROW(pn, it + 2)
+                    PZ_USEROW(pb, it + 1)
+                    PZ_USEROW(pn, it + 2)
+                } else if (left == 2) {
+                    PZ_LOADROW(pb, it + 1)
+                    PZ_USEROW(pn, it)
+                    PZ_USEROW(pb, it + 1)
+                } else {
+                    PZ_USEROW(pn, it)
+                }
             }
 #undef PZ_LOADROW
 #undef PZ_USEROW
 #undef PZ_MID_LOADF
+            PZ_STAMP(0)
             lds_barrier();
+            PZ_STAMP(1)
 #pragma unroll
             for (int i = 0; i < CTt; ++i)
 #pragma unroll
@@ -520,24 +622,21 @@ k_mid128(MidArgs g) {
                     lds[((vtg * CTt + i) * NP + c) * RS + q2o] = (c < g.ncomp) ? acc[i][j] : make_double2(0.0, 0.0);
                 }
             lds_barrier();
+            PZ_STAMP(2)
         }
-        {
-            const cplx* src = src_ptr(L + W);
-            if (wave_in) {
-#pragma unroll
-                for (int n1 = 0; n1 < 16; ++n1) x[n1] = (g.dbg & 4) ? make_double2(1.0, (double)n1) : ld_stream(src + 8 * n1);
-            }
-            twn = g.tw12t[(long long)out_q1(tile_q1(min(L + W, ntiles - 1))) * M2 + (tid & (M2 - 1))];
-        }
+        PZ_MID_XLOAD(L + W)
+        PZ_STAMP(8)
         // inverse row DFT: this lane owns k1 = o and o+8: radix 8 over k2 -> z[k1][oo] x conj W128^(oo*k1);
         // then lane o gathers z[k1][o] over k1: radix 16 -> row[o + 8*n1]
         if (wave_out) {
+            PZ_MID_LANE
+            const int b = (L % g.n_ct) * CT + ctl;
             cplx u[16];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) u[8 * h + k2] = rowbuf[o + 8 * h + 16 * k2];
-            if (!(g.dbg & 16)) { Bfly<8, true>::run(u); Bfly<8, true>::run(u + 8); }
+            if (!(PZ_DBG(g.dbg) & 16)) { Bfly<8, true>::run(u); Bfly<8, true>::run(u + 8); }
             row_sync();
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -551,25 +650,329 @@ k_mid128(MidArgs g) {
             row_sync();
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) u[k1] = rowbuf[k1 * 9 + o];
-            if (!(g.dbg & 16)) Bfly<16, true>::run(u);
+            if (!(PZ_DBG(g.dbg) & 16)) Bfly<16, true>::run(u);
             const bool active = b < g.batch && rr < g.npo;
             // rows without an output polynomial store to a scratch row of their OWN workgroup (one 2 KiB row per tile row): with a
             // shared scratch every workgroup of the chip wrote the same lines, which cost more than the real stores (measured on the
             // blind-rotation block step, 6 of 8 slots active: middle kernel 37.8 -> 28 ms per 82 blocks)
             cplx* dst = active ? g.T2 + ((long long)b * g.npo + rr) * m + (long long)out_q1(q1) * M2 + o
                                : g.dummy + ((long long)blockIdx.x * (NT / 8) + row) * M2 + o;
+#if PZ_MID_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            PZ_STAMP(9)
+#endif
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) if (!(g.dbg & 8) || u[n1].x == 1.2345e300) st_stream(dst + 8 * n1, cmulc(u[n1], twrow[o + 8 * n1]));
+            for (int n1 = 0; n1 < 16; ++n1) if (!(PZ_DBG(g.dbg) & 8) || u[n1].x == 1.2345e300) st_stream(dst + 8 * n1, cmulc(u[n1], twrow[o + 8 * n1]));
         }
+        PZ_STAMP(3)
         lds_barrier();
-        if (tid < M2) twrow[tid] = twn;
+        PZ_STAMP(4)
+        if (tid0 < M2) twrow[tid0] = twn;
         PZ_MID_P0(L + W)
         PZ_MID_ABUF(L + W)
-        PZ_MID_FWD(in_active(L + W))
+#if PZ_MID_STAMP
+        PZ_STAMP(5)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the prefetched T' rows (the 4 key loads of P0 are younger)
+        PZ_STAMP(6)
+        ++st_tiles;
+#endif
+        PZ_MID_FWD(L + W)
+        PZ_STAMP(7)
     }
+#if PZ_MID_STAMP
+    if ((tid0 & 63) == 0 && (blockIdx.x == 0 || blockIdx.x == 9 || blockIdx.x == 130 || blockIdx.x == 255))
+        printf("STAMP wg %d wave %d tiles %d total %llu | product %llu bar1 %llu accwr %llu xload %llu invc %llu stores %llu bar4 %llu p0 %llu xwait %llu fwd %llu\n",
+               (int)blockIdx.x, tid0 >> 6, st_tiles, (unsigned long long)(st_t - st_t0), st_acc[0], st_acc[1], st_acc[2], st_acc[8], st_acc[9], st_acc[3], st_acc[4],
+               st_acc[5], st_acc[6], st_acc[7]);
+#endif
+#undef PZ_STAMP
 #undef PZ_MID_FWD
 #undef PZ_MID_P0
 #undef PZ_MID_ABUF
+#undef PZ_MID_XLOAD
+#undef PZ_MID_LANE
+}
+
+// =================================================================================
+// k_mid128r (round 3): the plain product of k_mid128 (no digits, no blind-rotation factors, no idle waves, a multiple of 4 product
+// rows) with the tile's GLOBAL-MEMORY instructions spread through the LDS / VALU phases.  Why — s_memtime stamps of k_mid128
+// (profiles/r03_mid_stamps_*.txt, cycles per tile of 4 ciphertexts, 34.4 k in all): the product phase is bound by the key stream
+// through the CU's vector-memory path (512 KiB per tile at the ~50 B/clk an L2-served stream reaches: 10.7 k), and ISSUING the next
+// tile's 16 + 1 loads took a wave 1.9 - 4.7 k cycles, its 16 stores 1.3 - 1.7 k, the 12 key loads in front of the forward pass 1.1 - 2 k:
+// a vector-memory instruction blocks its wave until the path accepts it, all eight waves reach the same burst together, and
+// meanwhile LDS and VALU idle — as the memory path idles during the 15 k cycles of butterflies and LDS exchanges.  Here
+//   * the next tile's T' loads go out in four groups between the steps of the inverse row pass,
+//   * the tile's 16 stores are held back (64 registers) and go out in four groups between the steps of the NEXT forward row pass,
+//   * the first key rows of the next product are requested between the last steps of that forward pass, KR - 1 of them,
+//   * the inter-pass twiddle row is double-buffered, so no workgroup barrier separates the inverse pass from the forward pass
+//     (both only touch the wave's own rows) and the waves drift apart instead of meeting the same resource at the same time.
+// The arithmetic, its order and therefore every output bit are those of k_mid128.
+// =================================================================================
+template <int CT, int NP, bool PERM, int KR = 4>
+__global__ void __launch_bounds__(512)
+k_mid128r(MidArgs g) {
+    constexpr int M2 = 128, NT = 512, NC = 4;
+    constexpr int GC = NP / NC, GT = (NT / M2) / GC, CTt = CT / GT;
+    static_assert(CT * NP * 8 == NT && GC * GT == NT / M2 && CTt * GT == CT && KR >= 4 && KR <= 6, "k_mid128r tile shape");
+    constexpr int RS = kMidRS;
+    extern __shared__ cplx lds[];      // CT*NP rows x RS | wL2[128] | tw12t rows [2][128]
+    const int tid0 = threadIdx.x;
+    const long long m = (long long)g.m1 * M2;
+    cplx* wl = lds + CT * NP * RS;
+    cplx* twrow2 = wl + M2;
+#define PZ_MID_LANE                                                                               \
+    const int tid = pz_opaque(tid0);                                                              \
+    const int row = tid >> 3, o = tid & 7;                                                        \
+    const int ctl = row / NP, rr = row % NP;                                                      \
+    cplx* const rowbuf = lds + row * RS;                                                          \
+    const int vq2 = tid & (M2 - 1), vcg = (tid / M2) % GC, vtg = (tid / M2) / GC;                 \
+    (void)ctl; (void)rr; (void)rowbuf; (void)vq2; (void)vcg; (void)vtg; (void)o;
+
+    const bool xcd_map = (g.m1 & 7) == 0 && (gridDim.x & 7) == 0;
+    const int xcd = xcd_map ? (blockIdx.x & 7) : 0;
+    const int w = xcd_map ? (blockIdx.x >> 3) : blockIdx.x;
+    const int W = xcd_map ? (gridDim.x >> 3) : gridDim.x;
+    const int rows_x = xcd_map ? g.m1 / 8 : g.m1;
+    const int ntiles = rows_x * g.n_ct;
+    if (w >= ntiles) return;
+    if (tid0 < M2) wl[tid0] = g.wL2[tid0];
+    __syncthreads();
+
+    auto tile_q1 = [&](int L) { const int k = L / g.n_ct; return xcd_map ? k * 8 + xcd : k; };
+    auto out_q1 = [&](int q1_) { return PERM ? (int)((g.perm_mul * (unsigned)q1_ + g.perm_add) & (unsigned)(g.m1 - 1)) : q1_; };
+    auto src_ptr = [&](int L, int ctl, int rr, int o) {
+        const int Lc = min(L, ntiles - 1);
+        const int b_ = min((Lc % g.n_ct) * CT + ctl, g.batch - 1);
+        const int r_ = min(rr, g.npi - 1);
+        return g.T + ((long long)b_ * g.npi + r_) * m + (long long)tile_q1(Lc) * M2 + o;
+    };
+    auto in_active = [&](int L, int ctl, int rr) { return L < ntiles && (L % g.n_ct) * CT + ctl < g.batch && rr < g.npi; };
+    const int nrow = g.row_max;
+    __builtin_assume(nrow >= 4);
+    const int rot = w % nrow;
+
+    cplx x[16];     // the next tile's T' values (in flight during the inverse pass), then the forward pass's working set
+    cplx u[16];     // the inverse pass's working set, then the tile's results until the forward pass has stored them
+    cplx* dst = nullptr;
+    cplx twn = make_double2(0.0, 0.0);
+    cplx kr[KR][NC];   // key-row ring: row i of a tile lives in slot i % KR; slots 0 .. KR-2 are requested before the product starts
+
+    // ---- pieces ----
+#define PZ_XGROUP(SRC, G4)   /* four of the next tile's 16 T' loads */                                   \
+    { _Pragma("unroll") for (int n1 = 4 * (G4); n1 < 4 * (G4) + 4; ++n1) x[n1] = ld_stream((SRC) + 8 * n1); }
+#define PZ_SGROUP(G4)        /* four of the previous tile's 16 stores */                                \
+    { _Pragma("unroll") for (int n1 = 4 * (G4); n1 < 4 * (G4) + 4; ++n1) st_stream(dst + 8 * n1, u[n1]); }
+#define PZ_KGROUP(LT, SLOT)  /* key row SLOT (< KR - 1) of tile LT's product */                         \
+    {                                                                                                  \
+        const long long base_ = (long long)tile_q1(min((LT), ntiles - 1)) * g.nrows * g.ncols;         \
+        int r_ = rot + (SLOT);                                                                         \
+        r_ -= (r_ >= nrow) ? nrow : 0;                                                                 \
+        r_ -= (r_ >= nrow) ? nrow : 0;                                                                 \
+        _Pragma("unroll") for (int j = 0; j < NC; ++j)                                                 \
+            kr[SLOT][j] = g.P[(base_ + (long long)r_ * g.ncols + min(vcg * NC + j, g.ncomp - 1)) * M2 + vq2]; \
+    }
+    // forward row DFT of x (see k_mid128) with the held-back stores (STORES) and the next product's first key rows in its gaps
+#define PZ_MIDR_FWD(LT, STORES)                                                                   \
+    {                                                                                             \
+        PZ_MID_LANE                                                                               \
+        if (STORES) { PZ_SGROUP(0) __builtin_amdgcn_sched_barrier(0); }                           \
+        if (!in_active((LT), ctl, rr)) {                                                          \
+            _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1) x[n1] = make_double2(0.0, 0.0);     \
+        }                                                                                         \
+        Bfly<16, false>::run(x);                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if (STORES) {   /* the twiddle row of tile LT (its load is older than the x loads the butterfly just waited for) */ \
+            if (tid0 < M2) twrow2[(par ^ 1) * M2 + tid0] = twn;                                   \
+            PZ_SGROUP(1) __builtin_amdgcn_sched_barrier(0);                                       \
+        }                                                                                         \
+        /* twiddles W128^(o k1) in two batches of reads ahead of their multiplies: read one by one, each of the 15 sits behind its own  */ \
+        /* LDS latency (the compiler does not batch them by itself)                                                                   */ \
+        _Pragma("unroll") for (int hb = 0; hb < 2; ++hb) {                                        \
+            cplx tw_[8];                                                                          \
+            _Pragma("unroll") for (int k1 = 8 * hb; k1 < 8 * hb + 8; ++k1) tw_[k1 - 8 * hb] = wl[o * k1]; \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+            _Pragma("unroll") for (int k1 = 8 * hb; k1 < 8 * hb + 8; ++k1) {                      \
+                cplx v = x[k1];                                                                   \
+                if (k1 > 0) v = cmul(v, tw_[k1 - 8 * hb]);                                        \
+                rowbuf[k1 * 9 + o] = v;                                                           \
+            }                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+        }                                                                                         \
+        if (STORES) { PZ_SGROUP(2) __builtin_amdgcn_sched_barrier(0); }                           \
+        row_sync();                                                                               \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                           \
+            _Pragma("unroll") for (int oo = 0; oo < 8; ++oo) x[8 * h + oo] = rowbuf[(o + 8 * h) * 9 + oo]; \
+        }                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if (STORES) { PZ_SGROUP(3) __builtin_amdgcn_sched_barrier(0); }                           \
+        PZ_KGROUP(LT, 0)                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        Bfly<8, false>::run(x);                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        PZ_KGROUP(LT, 1)                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        Bfly<8, false>::run(x + 8);                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        PZ_KGROUP(LT, 2)                                                                          \
+        if constexpr (KR > 4) PZ_KGROUP(LT, 3)                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        row_sync();                                                                               \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                           \
+            _Pragma("unroll") for (int k2 = 0; k2 < 8; ++k2) rowbuf[o + 8 * h + 16 * k2] = x[8 * h + k2]; \
+        }                                                                                         \
+        if constexpr (KR > 5) PZ_KGROUP(LT, 4)                                                    \
+        lds_barrier();                                                                            \
+    }
+
+    // ---- prologue: first tile ----
+    {
+        PZ_MID_LANE
+        const cplx* src_ = src_ptr(w, ctl, rr, o);
+        PZ_XGROUP(src_, 0) PZ_XGROUP(src_, 1) PZ_XGROUP(src_, 2) PZ_XGROUP(src_, 3)
+        twn = g.tw12t[(long long)out_q1(tile_q1(w)) * M2 + (tid & (M2 - 1))];
+    }
+    if (tid0 < M2) twrow2[tid0] = twn;
+    int par = 0;
+    PZ_MIDR_FWD(w, 0)
+
+    for (int L = w; L < ntiles; L += W, par ^= 1) {
+        const int q1 = tile_q1(L);
+        // ---------------- product: res[b][c][q] = sum_r a[b][r][q] * P[r][c][q] ----------------
+        {
+            PZ_MID_LANE
+            const int q2 = vq2, cg = vcg;
+            cplx acc[CTt][NC];
+#pragma unroll
+            for (int i = 0; i < CTt; ++i)
+#pragma unroll
+                for (int j = 0; j < NC; ++j) acc[i][j] = make_double2(0.0, 0.0);
+            const cplx* pp[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) pp[j] = g.P + ((long long)q1 * g.nrows * g.ncols + min(cg * NC + j, g.ncomp - 1)) * M2 + q2;
+            const long long prow = (long long)g.ncols * M2;
+            cplx avA[CTt], avB[CTt];
+#define PZ_LOADROW(DST, IT)                                                                     \
+    {                                                                                           \
+        int r_ = (IT) + rot;                                                                    \
+        r_ -= (r_ >= nrow) ? nrow : 0;                                                          \
+        r_ -= (r_ >= nrow) ? nrow : 0;                                                          \
+        const long long off_ = (long long)r_ * prow;                                            \
+        _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = pp[j][off_];                    \
+    }
+#define PZ_AVLOAD(DST, IT)                                                                      \
+    {                                                                                           \
+        int r_ = (IT) + rot;                                                                    \
+        r_ -= (r_ >= nrow) ? nrow : 0;                                                          \
+        r_ -= (r_ >= nrow) ? nrow : 0;                                                          \
+        _Pragma("unroll") for (int i = 0; i < CTt; ++i) DST[i] = lds[((vtg * CTt + i) * NP + r_) * RS + q2]; \
+        __builtin_amdgcn_sched_barrier(0);   /* the machine scheduler otherwise sinks these reads down to their first use */ \
+    }
+#define PZ_FMAROW(AV, SRC)                                                                      \
+    {                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < CTt; ++i) {                                       \
+            _Pragma("unroll") for (int j = 0; j < NC; ++j) {                                    \
+                acc[i][j].x = __builtin_fma(AV[i].x, SRC[j].x, acc[i][j].x);                    \
+                acc[i][j].x = __builtin_fma(-AV[i].y, SRC[j].y, acc[i][j].x);                   \
+                acc[i][j].y = __builtin_fma(AV[i].x, SRC[j].y, acc[i][j].y);                    \
+                acc[i][j].y = __builtin_fma(AV[i].y, SRC[j].x, acc[i][j].y);                    \
+            }                                                                                   \
+        }                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    }
+            // row `it` is in slot it % KR; the loop is unrolled by KR so that the slots are compile-time registers.  Rows are requested
+            // KR - 1 ahead; none is requested past the end (the first KR - 1 rows of the next tile are requested by its forward pass).
+            PZ_AVLOAD(avA, 0)
+            int it = 0;
+            if constexpr (KR == 4) {
+                for (; it + 4 < nrow; it += 4) {
+                    PZ_LOADROW(kr[3], it + 3) PZ_AVLOAD(avB, it + 1) PZ_FMAROW(avA, kr[0])
+                    PZ_LOADROW(kr[0], it + 4) PZ_AVLOAD(avA, it + 2) PZ_FMAROW(avB, kr[1])
+                    PZ_LOADROW(kr[1], it + 5) PZ_AVLOAD(avB, it + 3) PZ_FMAROW(avA, kr[2])
+                    PZ_LOADROW(kr[2], it + 6) PZ_AVLOAD(avA, it + 4) PZ_FMAROW(avB, kr[3])
+                }
+                PZ_LOADROW(kr[3], it + 3) PZ_AVLOAD(avB, it + 1) PZ_FMAROW(avA, kr[0])
+                PZ_AVLOAD(avA, it + 2) PZ_FMAROW(avB, kr[1])
+                PZ_AVLOAD(avB, it + 3) PZ_FMAROW(avA, kr[2])
+                PZ_FMAROW(avB, kr[3])
+            } else {
+                // KR = 6 (nrow a multiple of 4, >= 8): generic rotation written out for 12 rows per trip is not worth it; rows in groups of
+                // two with explicit slot arithmetic over the first nrow - (KR - 1) rows, then the drain
+                static_assert(KR == 4, "only KR = 4 is written out");
+            }
+#undef PZ_LOADROW
+#undef PZ_AVLOAD
+#undef PZ_FMAROW
+            lds_barrier();  // every a value has been read: the tile can be overwritten with the products
+#pragma unroll
+            for (int i = 0; i < CTt; ++i)
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {
+                    const int c = cg * NC + j;
+                    const int q2o = PERM ? (int)((((g.perm_mul * (unsigned)q1 + g.perm_add) >> g.log_m1) + g.perm_mul * (unsigned)q2) & (unsigned)(M2 - 1)) : q2;
+                    lds[((vtg * CTt + i) * NP + c) * RS + q2o] = (c < g.ncomp) ? acc[i][j] : make_double2(0.0, 0.0);
+                }
+            lds_barrier();
+        }
+        // ---------------- inverse row DFT of the wave's own 8 rows; the next tile's loads go out in its gaps ----------------
+        {
+            PZ_MID_LANE
+            const int b = (L % g.n_ct) * CT + ctl;
+            const cplx* src_ = src_ptr(L + W, ctl, rr, o);
+            const cplx* twr = twrow2 + par * M2;
+            PZ_XGROUP(src_, 0)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) u[8 * h + k2] = rowbuf[o + 8 * h + 16 * k2];
+            __builtin_amdgcn_sched_barrier(0);
+            PZ_XGROUP(src_, 1)
+            __builtin_amdgcn_sched_barrier(0);
+            Bfly<8, true>::run(u);
+            __builtin_amdgcn_sched_barrier(0);
+            PZ_XGROUP(src_, 2)
+            __builtin_amdgcn_sched_barrier(0);
+            Bfly<8, true>::run(u + 8);
+            row_sync();
+            // conj W128^(oo k1): read in two batches ahead of their multiplies, for every lane (k1 = 0 reads W^0 = 1: the product is
+            // exact), so that no lane-dependent branch cuts the batch
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k1 = o + 8 * h;
+                cplx tw_[8];
+#pragma unroll
+                for (int oo = 1; oo < 8; ++oo) tw_[oo] = wl[oo * k1];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int oo = 0; oo < 8; ++oo) {
+                    cplx v = u[8 * h + oo];
+                    if (oo > 0) v = cmulc(v, tw_[oo]);
+                    rowbuf[k1 * 9 + oo] = v;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            PZ_XGROUP(src_, 3)
+            twn = g.tw12t[(long long)out_q1(tile_q1(min(L + W, ntiles - 1))) * M2 + (tid & (M2 - 1))];
+            __builtin_amdgcn_sched_barrier(0);
+            row_sync();
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) u[k1] = rowbuf[k1 * 9 + o];
+            Bfly<16, true>::run(u);
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) u[n1] = cmulc(u[n1], twr[o + 8 * n1]);
+            const bool active = b < g.batch && rr < g.npo;
+            dst = active ? g.T2 + ((long long)b * g.npo + rr) * m + (long long)out_q1(q1) * M2 + o
+                         : g.dummy + ((long long)blockIdx.x * (NT / 8) + row) * M2 + o;
+        }
+        // no workgroup barrier: the forward pass below only rewrites this wave's own rows, and it writes the OTHER twiddle row
+        PZ_MIDR_FWD(L + W, 1)
+    }
+#undef PZ_XGROUP
+#undef PZ_SGROUP
+#undef PZ_KGROUP
+#undef PZ_MIDR_FWD
+#undef PZ_MID_LANE
 }
 
 // (Round 2 experiment, removed: "k_midr<LPR = 4>" — the same kernel for rows of 64 points owned by 4 lanes (m = 512 x 64): a tile of four

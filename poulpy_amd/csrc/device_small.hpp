@@ -191,8 +191,8 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
         cplx aA, kA[KS], aB, kB[KS];
 #define PZ_SMALL_LOAD(A_, K_, R_, J_)                                                              \
     {                                                                                               \
-        if (!(g.dbg & 2)) A_ = Sb[(long long)(R_) * m + NT * (J_)];                                 \
-        if (!(g.dbg & 1)) { _Pragma("unroll") for (int l = 0; l < KS; ++l) K_[l] = kp[(long long)(R_) * prow + l * lstride + (J_) * qstride]; } \
+        if (!(PZ_DBG(g.dbg) & 2)) A_ = Sb[(long long)(R_) * m + NT * (J_)];                                 \
+        if (!(PZ_DBG(g.dbg) & 1)) { _Pragma("unroll") for (int l = 0; l < KS; ++l) K_[l] = kp[(long long)(R_) * prow + l * lstride + (J_) * qstride]; } \
     }
 #define PZ_SMALL_USE(A_, K_, J_)                                                                   \
     {                                                                                               \
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
             c_.y = __builtin_fma(A_.y, K_[l].x, c_.y);                                              \
         }                                                                                           \
     }
-        if (g.dbg & 3) {
+        if (PZ_DBG(g.dbg) & 3) {
             aA = aB = make_double2(1.0, 2.0);
 #pragma unroll
             for (int l = 0; l < KS; ++l) kA[l] = kB[l] = make_double2(0.5, 0.25);
@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
                 const unsigned long long y2 = (unsigned long long)d + (unsigned long long)cy + half;
                 const long long x1 = (long long)(y2 & mask) - (long long)half;
                 cy = (long long)((unsigned long long)cr + (unsigned long long)((long long)y2 >> k));
-                if (writes && (!(g.dbg & 4) || x1 == 0x7fffffffffffLL)) {
+                if (writes && (!(PZ_DBG(g.dbg) & 4) || x1 == 0x7fffffffffffLL)) {
                     // AU mode 0: phi acts on the normalized digits (glwe_ct.rs:69-71)
                     const long long xs = (AU && g.au_mode == 0 && oneg[e]) ? (long long)(0ull - (unsigned long long)x1) : x1;
                     if constexpr (AU) {   // scattered 8-byte stores: cacheable, so that the lines fill up in L2

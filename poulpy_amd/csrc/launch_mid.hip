@@ -61,6 +61,7 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
     g.T = T; g.T2 = T2; g.P = Pp; g.npi = npi; g.npo = npo; g.nrows = nrows; g.ncols = ncols;
     g.row_max = br ? nrows : std::min(nrows, npi);
     g.ncomp = std::min(npo, ncols);
+    if ((ds ? g.ds_n : g.row_max) < 1) return PZ_ERR_INVALID;   // k_mid128 assumes at least one product term
     g.batch = batch; g.m1 = M->plan.m1; g.n_ct = 0;
     g.wL2 = M->wL2; g.tw12t = M->tw12t; g.dummy = dummy;
     static const int groups = getenv("POULPY_DBG_MID_GROUPS") ? atoi(getenv("POULPY_DBG_MID_GROUPS")) : 1;
@@ -75,11 +76,34 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, M->device);
         if (M->cu_count > 0) ncu = (M->cu_count / 8) * 8 > 0 ? (M->cu_count / 8) * 8 : M->cu_count;
+        static const bool mid_r = !(getenv("POULPY_DBG_MID_R") && atoi(getenv("POULPY_DBG_MID_R")) == 0);   // 0: k_mid128 with the key ring instead of k_mid128r (A/B)
         KTimer kt(M, PZ_K_FUSED_MID);
+#define PZ_MID128_GO(CT_, NP_, PERM_, SKIPW_, KR_)                                                                         \
+    {                                                                                                                      \
+        PZ_TRY(set_lds((k_mid128<CT_, NP_, PERM_, false, false, ((SKIPW_) && (NP_ > 8)), ((NP_ <= 16) ? (KR_) : 2)>), lds));                    \
+        hipLaunchKernelGGL((k_mid128<CT_, NP_, PERM_, false, false, ((SKIPW_) && (NP_ > 8)), ((NP_ <= 16) ? (KR_) : 2)>), grid_, dim3(512), lds, M->stream, g); \
+    }
+#define PZ_MID128_GOR(CT_, NP_, PERM_)   /* k_mid128r: 16- and 8-slot tiles only */                                        \
+    {                                                                                                                      \
+        PZ_TRY(set_lds((k_mid128r<((NP_ <= 16) ? CT_ : 4), ((NP_ <= 16) ? NP_ : 16), PERM_>), lds));                         \
+        hipLaunchKernelGGL((k_mid128r<((NP_ <= 16) ? CT_ : 4), ((NP_ <= 16) ? NP_ : 16), PERM_>), grid_, dim3(512), lds, M->stream, g); \
+    }
+    /* plain product: the interleaved kernel where it applies (no idle waves, a multiple of 4 product rows), the ring of four key rows */ \
+    /* inside k_mid128 for shapes with idle waves, the ping-pong pair otherwise */
+#define PZ_MID128_PICK(CT_, NP_, perm_, skipw_, ring_)                                                                     \
+    if (ring_ && !(skipw_) && mid_r) {                                                                                     \
+        if (perm_) PZ_MID128_GOR(CT_, NP_, true) else PZ_MID128_GOR(CT_, NP_, false)                                       \
+    } else if (ring_) {                                                                                                    \
+        if (perm_) { if (skipw_) PZ_MID128_GO(CT_, NP_, true, true, 4) else PZ_MID128_GO(CT_, NP_, true, false, 4) }       \
+        else       { if (skipw_) PZ_MID128_GO(CT_, NP_, false, true, 4) else PZ_MID128_GO(CT_, NP_, false, false, 4) }     \
+    } else {                                                                                                               \
+        if (perm_) { if (skipw_) PZ_MID128_GO(CT_, NP_, true, true, 2) else PZ_MID128_GO(CT_, NP_, true, false, 2) }       \
+        else       { if (skipw_) PZ_MID128_GO(CT_, NP_, false, true, 2) else PZ_MID128_GO(CT_, NP_, false, false, 2) }     \
+    }
 #define PZ_MID128_LAUNCH(CT_, NP_)                                                                                         \
     {                                                                                                                      \
         g.n_ct = (batch + CT_ - 1) / CT_;                                                                                  \
-        const size_t lds = ((size_t)CT_ * NP_ * kMidRS + 256 + 32) * sizeof(cplx);                                         \
+        const size_t lds = ((size_t)CT_ * NP_ * kMidRS + 384 + 32) * sizeof(cplx);   /* tile | wL2 | two twiddle rows | exponents */                                         \
         const dim3 grid_(std::min({ncu, 256, g.m1 * g.n_ct}));   /* <= 256: one scratch tile per workgroup (kMidDummyBytes) */ \
         if (br) {                                                                                                          \
             PZ_TRY(set_lds((k_mid128<CT_, NP_, false, false, true>), lds));                                                \
@@ -87,12 +111,10 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
         } else if (ds) {                                                                                                          \
             PZ_TRY(set_lds((k_mid128<CT_, NP_, false, true>), lds));                                                       \
             hipLaunchKernelGGL((k_mid128<CT_, NP_, false, true>), grid_, dim3(512), lds, M->stream, g);                    \
-        } else if (perm) {                                                                                                 \
-            PZ_TRY(set_lds((k_mid128<CT_, NP_, true>), lds));                                                              \
-            hipLaunchKernelGGL((k_mid128<CT_, NP_, true>), grid_, dim3(512), lds, M->stream, g);                           \
         } else {                                                                                                           \
-            PZ_TRY(set_lds((k_mid128<CT_, NP_, false>), lds));                                                             \
-            hipLaunchKernelGGL((k_mid128<CT_, NP_, false>), grid_, dim3(512), lds, M->stream, g);                          \
+            const bool skipw_ = NP_ > 8 && (npi <= NP_ - 8 || npo <= NP_ - 8);   /* shapes with idle waves */              \
+            const bool ring_ = NP_ <= 16 && PZ_MID_RING == 4 && g.row_max >= 4 && (g.row_max & 3) == 0;                      \
+            PZ_MID128_PICK(CT_, NP_, perm, skipw_, ring_)                                                                  \
         }                                                                                                                  \
     }
         if (npi <= 8 && npo <= 8) {
@@ -105,6 +127,9 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
             PZ_MID128_LAUNCH(4, 16)
         }
 #undef PZ_MID128_LAUNCH
+#undef PZ_MID128_PICK
+#undef PZ_MID128_GO
+#undef PZ_MID128_GOR
         PZ_HIP(hipGetLastError());
         return PZ_OK;
     }
