@@ -26,6 +26,9 @@ constexpr int kMidRS = PZ_MID_RS;
 #ifndef PZ_MID_STAMP
 #define PZ_MID_STAMP 0   // diagnostic build: per-phase s_memtime totals of k_mid128, printed by a few waves (tools/dbg/mid_stamps.sh)
 #endif
+#ifndef PZ_MIDR_KR
+#define PZ_MIDR_KR 6     // key-row slots of k_mid128r (rows requested KR - 1 ahead; build-time for A/B runs)
+#endif
 #ifndef PZ_MID_RING
 #define PZ_MID_RING 4    // key-row slots of k_mid128's plain product (2: the ping-pong pair of rounds 1-2; build-time for A/B runs)
 #endif   // row stride of the k_mid128 tile (see there; build-time for A/B runs)
@@ -337,7 +340,7 @@ k_mid128(MidArgs g) {
     if (w >= ntiles) return;
     if (tid0 < M2) wl[tid0] = g.wL2[tid0];
     __syncthreads();
-    if (g.stagger > 0) {
+    if (g.stagger > 0 && g.stagger_mod > 0) {
         const int k = (blockIdx.x / 256) % g.stagger_mod;
         for (int i = 0; i < k * g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     }
@@ -709,12 +712,12 @@ k_mid128(MidArgs g) {
 //     (both only touch the wave's own rows) and the waves drift apart instead of meeting the same resource at the same time.
 // The arithmetic, its order and therefore every output bit are those of k_mid128.
 // =================================================================================
-template <int CT, int NP, bool PERM, int KR = 4>
+template <int CT, int NP, bool PERM, int NR, int KR = PZ_MIDR_KR>
 __global__ void __launch_bounds__(512)
 k_mid128r(MidArgs g) {
     constexpr int M2 = 128, NT = 512, NC = 4;
     constexpr int GC = NP / NC, GT = (NT / M2) / GC, CTt = CT / GT;
-    static_assert(CT * NP * 8 == NT && GC * GT == NT / M2 && CTt * GT == CT && KR >= 4 && KR <= 6, "k_mid128r tile shape");
+    static_assert(CT * NP * 8 == NT && GC * GT == NT / M2 && CTt * GT == CT && KR >= 3 && KR <= 7 && KR <= NR, "k_mid128r tile shape");
     constexpr int RS = kMidRS;
     extern __shared__ cplx lds[];      // CT*NP rows x RS | wL2[128] | tw12t rows [2][128]
     const int tid0 = threadIdx.x;
@@ -738,6 +741,13 @@ k_mid128r(MidArgs g) {
     if (w >= ntiles) return;
     if (tid0 < M2) wl[tid0] = g.wL2[tid0];
     __syncthreads();
+    // experiments (POULPY_DBG_MID_STAGGER = n, POULPY_DBG_MID_STAGGER_MOD = mode bits): n x 128 cycles of delay for the second-dispatched
+    // half of the waves at the top of every inverse pass (mode bit 2: for the first half instead); mode bit 0: static priority 1 for the
+    // second half, bit 1: for the first half
+    const bool young = tid0 >= 256;
+    if (g.stagger_mod & 1) { if (young) __builtin_amdgcn_s_setprio(1); }
+    if (g.stagger_mod & 2) { if (!young) __builtin_amdgcn_s_setprio(1); }
+    const int nsleep = ((g.stagger_mod & 4) ? !young : young) ? g.stagger : 0;
 
     auto tile_q1 = [&](int L) { const int k = L / g.n_ct; return xcd_map ? k * 8 + xcd : k; };
     auto out_q1 = [&](int q1_) { return PERM ? (int)((g.perm_mul * (unsigned)q1_ + g.perm_add) & (unsigned)(g.m1 - 1)) : q1_; };
@@ -748,8 +758,7 @@ k_mid128r(MidArgs g) {
         return g.T + ((long long)b_ * g.npi + r_) * m + (long long)tile_q1(Lc) * M2 + o;
     };
     auto in_active = [&](int L, int ctl, int rr) { return L < ntiles && (L % g.n_ct) * CT + ctl < g.batch && rr < g.npi; };
-    const int nrow = g.row_max;
-    __builtin_assume(nrow >= 4);
+    constexpr int nrow = NR;           // product rows (launch_mid: g.row_max == NR)
     const int rot = w % nrow;
 
     cplx x[16];     // the next tile's T' values (in flight during the inverse pass), then the forward pass's working set
@@ -777,15 +786,13 @@ k_mid128r(MidArgs g) {
     {                                                                                             \
         PZ_MID_LANE                                                                               \
         if (STORES) { PZ_SGROUP(0) __builtin_amdgcn_sched_barrier(0); }                           \
+        if (PZ_MID_STAMP && STORES) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); PZ_STAMP(4) } \
         if (!in_active((LT), ctl, rr)) {                                                          \
             _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1) x[n1] = make_double2(0.0, 0.0);     \
         }                                                                                         \
         Bfly<16, false>::run(x);                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        if (STORES) {   /* the twiddle row of tile LT (its load is older than the x loads the butterfly just waited for) */ \
-            if (tid0 < M2) twrow2[(par ^ 1) * M2 + tid0] = twn;                                   \
-            PZ_SGROUP(1) __builtin_amdgcn_sched_barrier(0);                                       \
-        }                                                                                         \
+        if (STORES) { PZ_SGROUP(1) __builtin_amdgcn_sched_barrier(0); }                           \
         /* twiddles W128^(o k1) in two batches of reads ahead of their multiplies: read one by one, each of the 15 sits behind its own  */ \
         /* LDS latency (the compiler does not batch them by itself)                                                                   */ \
         _Pragma("unroll") for (int hb = 0; hb < 2; ++hb) {                                        \
@@ -814,14 +821,17 @@ k_mid128r(MidArgs g) {
         __builtin_amdgcn_sched_barrier(0);                                                        \
         Bfly<8, false>::run(x + 8);                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        PZ_KGROUP(LT, 2)                                                                          \
-        if constexpr (KR > 4) PZ_KGROUP(LT, 3)                                                    \
+        if constexpr (KR > 3) PZ_KGROUP(LT, 2)                                                    \
+        if constexpr (KR > 5) PZ_KGROUP(LT, 4)                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         row_sync();                                                                               \
-        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                           \
-            _Pragma("unroll") for (int k2 = 0; k2 < 8; ++k2) rowbuf[o + 8 * h + 16 * k2] = x[8 * h + k2]; \
-        }                                                                                         \
-        if constexpr (KR > 5) PZ_KGROUP(LT, 4)                                                    \
+        _Pragma("unroll") for (int k2 = 0; k2 < 8; ++k2) rowbuf[o + 16 * k2] = x[k2];             \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if constexpr (KR > 4) PZ_KGROUP(LT, 3)                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        _Pragma("unroll") for (int k2 = 0; k2 < 8; ++k2) rowbuf[o + 8 + 16 * k2] = x[8 + k2];     \
+        if constexpr (KR > 6) PZ_KGROUP(LT, 5)                                                    \
+        if (PZ_MID_STAMP && STORES) { PZ_STAMP(5) }                                               \
         lds_barrier();                                                                            \
     }
 
@@ -834,7 +844,19 @@ k_mid128r(MidArgs g) {
     }
     if (tid0 < M2) twrow2[tid0] = twn;
     int par = 0;
+#if PZ_MID_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t = 0;
+    int st_tiles = 0;
+#define PZ_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; }
+#else
+#define PZ_STAMP(i)
+#endif
     PZ_MIDR_FWD(w, 0)
+#if PZ_MID_STAMP
+    st_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_t0 = st_t;
+#endif
 
     for (int L = w; L < ntiles; L += W, par ^= 1) {
         const int q1 = tile_q1(L);
@@ -851,7 +873,7 @@ k_mid128r(MidArgs g) {
 #pragma unroll
             for (int j = 0; j < NC; ++j) pp[j] = g.P + ((long long)q1 * g.nrows * g.ncols + min(cg * NC + j, g.ncomp - 1)) * M2 + q2;
             const long long prow = (long long)g.ncols * M2;
-            cplx avA[CTt], avB[CTt];
+            cplx av[2][CTt];
 #define PZ_LOADROW(DST, IT)                                                                     \
     {                                                                                           \
         int r_ = (IT) + rot;                                                                    \
@@ -880,30 +902,22 @@ k_mid128r(MidArgs g) {
         }                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                      \
     }
-            // row `it` is in slot it % KR; the loop is unrolled by KR so that the slots are compile-time registers.  Rows are requested
-            // KR - 1 ahead; none is requested past the end (the first KR - 1 rows of the next tile are requested by its forward pass).
-            PZ_AVLOAD(avA, 0)
-            int it = 0;
-            if constexpr (KR == 4) {
-                for (; it + 4 < nrow; it += 4) {
-                    PZ_LOADROW(kr[3], it + 3) PZ_AVLOAD(avB, it + 1) PZ_FMAROW(avA, kr[0])
-                    PZ_LOADROW(kr[0], it + 4) PZ_AVLOAD(avA, it + 2) PZ_FMAROW(avB, kr[1])
-                    PZ_LOADROW(kr[1], it + 5) PZ_AVLOAD(avB, it + 3) PZ_FMAROW(avA, kr[2])
-                    PZ_LOADROW(kr[2], it + 6) PZ_AVLOAD(avA, it + 4) PZ_FMAROW(avB, kr[3])
-                }
-                PZ_LOADROW(kr[3], it + 3) PZ_AVLOAD(avB, it + 1) PZ_FMAROW(avA, kr[0])
-                PZ_AVLOAD(avA, it + 2) PZ_FMAROW(avB, kr[1])
-                PZ_AVLOAD(avB, it + 3) PZ_FMAROW(avA, kr[2])
-                PZ_FMAROW(avB, kr[3])
-            } else {
-                // KR = 6 (nrow a multiple of 4, >= 8): generic rotation written out for 12 rows per trip is not worth it; rows in groups of
-                // two with explicit slot arithmetic over the first nrow - (KR - 1) rows, then the drain
-                static_assert(KR == 4, "only KR = 4 is written out");
+            // row `it` is in slot it % KR; the row loop is fully unrolled (NR is a template parameter) so that the slots are compile-time
+            // registers.  Rows are requested KR - 1 ahead; none is requested past the end (the first KR - 1 rows of the next tile are
+            // requested by its forward pass).
+            PZ_AVLOAD(av[0], 0)
+#pragma unroll
+            for (int it = 0; it < NR; ++it) {
+                if (it + KR - 1 < NR) PZ_LOADROW(kr[(it + KR - 1) % KR], it + KR - 1)
+                if (it + 1 < NR) PZ_AVLOAD(av[(it + 1) & 1], it + 1)
+                PZ_FMAROW(av[it & 1], kr[it % KR])
             }
 #undef PZ_LOADROW
 #undef PZ_AVLOAD
 #undef PZ_FMAROW
+            PZ_STAMP(0)
             lds_barrier();  // every a value has been read: the tile can be overwritten with the products
+            PZ_STAMP(1)
 #pragma unroll
             for (int i = 0; i < CTt; ++i)
 #pragma unroll
@@ -913,13 +927,16 @@ k_mid128r(MidArgs g) {
                     lds[((vtg * CTt + i) * NP + c) * RS + q2o] = (c < g.ncomp) ? acc[i][j] : make_double2(0.0, 0.0);
                 }
             lds_barrier();
+            PZ_STAMP(2)
         }
         // ---------------- inverse row DFT of the wave's own 8 rows; the next tile's loads go out in its gaps ----------------
+        for (int i = 0; i < nsleep; ++i) __builtin_amdgcn_s_sleep(2);
         {
             PZ_MID_LANE
             const int b = (L % g.n_ct) * CT + ctl;
             const cplx* src_ = src_ptr(L + W, ctl, rr, o);
             const cplx* twr = twrow2 + par * M2;
+            twn = g.tw12t[(long long)out_q1(tile_q1(min(L + W, ntiles - 1))) * M2 + (tid & (M2 - 1))];
             PZ_XGROUP(src_, 0)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -953,21 +970,45 @@ k_mid128r(MidArgs g) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             PZ_XGROUP(src_, 3)
-            twn = g.tw12t[(long long)out_q1(tile_q1(min(L + W, ntiles - 1))) * M2 + (tid & (M2 - 1))];
             __builtin_amdgcn_sched_barrier(0);
             row_sync();
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) u[k1] = rowbuf[k1 * 9 + o];
             Bfly<16, true>::run(u);
+            __builtin_amdgcn_sched_barrier(0);
+            // inter-pass twiddles in two batches of 8 reads (all 16 at once, beside u[] and the 64 registers of x[] in flight, spill)
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) u[n1] = cmulc(u[n1], twr[o + 8 * n1]);
+            for (int hb = 0; hb < 2; ++hb) {
+                cplx tw_[8];
+#pragma unroll
+                for (int n1 = 8 * hb; n1 < 8 * hb + 8; ++n1) tw_[n1 - 8 * hb] = twr[o + 8 * n1];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int n1 = 8 * hb; n1 < 8 * hb + 8; ++n1) u[n1] = cmulc(u[n1], tw_[n1 - 8 * hb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the next tile's twiddle row (requested FIRST among this pass's loads, so that waiting for it here leaves the 16 T' loads in
+            // flight) goes to the row the next inverse pass reads
+            if (tid0 < M2) twrow2[(par ^ 1) * M2 + tid0] = twn;
             const bool active = b < g.batch && rr < g.npo;
             dst = active ? g.T2 + ((long long)b * g.npo + rr) * m + (long long)out_q1(q1) * M2 + o
                          : g.dummy + ((long long)blockIdx.x * (NT / 8) + row) * M2 + o;
         }
+        PZ_STAMP(3)
         // no workgroup barrier: the forward pass below only rewrites this wave's own rows, and it writes the OTHER twiddle row
         PZ_MIDR_FWD(L + W, 1)
+        PZ_STAMP(6)
+#if PZ_MID_STAMP
+        ++st_tiles;
+#endif
     }
+#if PZ_MID_STAMP
+    if ((tid0 & 63) == 0 && (blockIdx.x == 0 || blockIdx.x == 9 || blockIdx.x == 130 || blockIdx.x == 255))
+        printf("STAMP wg %d wave %d tiles %d total %llu | product %llu bar1 %llu accwr %llu inv %llu xwait %llu fwd %llu bar6 %llu\n",
+               (int)blockIdx.x, tid0 >> 6, st_tiles, (unsigned long long)(st_t - st_t0), st_acc[0], st_acc[1], st_acc[2], st_acc[3], st_acc[4],
+               st_acc[5], st_acc[6]);
+#endif
+#undef PZ_STAMP
 #undef PZ_XGROUP
 #undef PZ_SGROUP
 #undef PZ_KGROUP

@@ -71,7 +71,7 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
     static const int stg = getenv("POULPY_DBG_MID_STAGGER") ? atoi(getenv("POULPY_DBG_MID_STAGGER")) : -1;
     static const int stm = getenv("POULPY_DBG_MID_STAGGER_MOD") ? atoi(getenv("POULPY_DBG_MID_STAGGER_MOD")) : 4;
     g.stagger = stg >= 0 ? stg : (M->plan.m2 == 128 ? 0 : 1);
-    g.stagger_mod = std::max(1, stm);
+    g.stagger_mod = M->plan.m2 == 128 ? (getenv("POULPY_DBG_MID_STAGGER_MOD") ? stm : 0) : std::max(1, stm);   // m2 = 128: mode bits of k_mid128r's experiments
     if (M->plan.m2 == 128) {
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, M->device);
@@ -83,15 +83,20 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
         PZ_TRY(set_lds((k_mid128<CT_, NP_, PERM_, false, false, ((SKIPW_) && (NP_ > 8)), ((NP_ <= 16) ? (KR_) : 2)>), lds));                    \
         hipLaunchKernelGGL((k_mid128<CT_, NP_, PERM_, false, false, ((SKIPW_) && (NP_ > 8)), ((NP_ <= 16) ? (KR_) : 2)>), grid_, dim3(512), lds, M->stream, g); \
     }
-#define PZ_MID128_GOR(CT_, NP_, PERM_)   /* k_mid128r: 16- and 8-slot tiles only */                                        \
+#define PZ_MID128_GOR(CT_, NP_, PERM_)   /* k_mid128r: 16- and 8-slot tiles only, 16 or 8 product rows */                  \
     {                                                                                                                      \
-        PZ_TRY(set_lds((k_mid128r<((NP_ <= 16) ? CT_ : 4), ((NP_ <= 16) ? NP_ : 16), PERM_>), lds));                         \
-        hipLaunchKernelGGL((k_mid128r<((NP_ <= 16) ? CT_ : 4), ((NP_ <= 16) ? NP_ : 16), PERM_>), grid_, dim3(512), lds, M->stream, g); \
+        if (g.row_max == 16) {                                                                                             \
+            PZ_TRY(set_lds((k_mid128r<((NP_ <= 16) ? CT_ : 4), ((NP_ <= 16) ? NP_ : 16), PERM_, 16>), lds));                 \
+            hipLaunchKernelGGL((k_mid128r<((NP_ <= 16) ? CT_ : 4), ((NP_ <= 16) ? NP_ : 16), PERM_, 16>), grid_, dim3(512), lds, M->stream, g); \
+        } else {                                                                                                           \
+            PZ_TRY(set_lds((k_mid128r<((NP_ <= 16) ? CT_ : 4), ((NP_ <= 16) ? NP_ : 16), PERM_, 8>), lds));                  \
+            hipLaunchKernelGGL((k_mid128r<((NP_ <= 16) ? CT_ : 4), ((NP_ <= 16) ? NP_ : 16), PERM_, 8>), grid_, dim3(512), lds, M->stream, g); \
+        }                                                                                                                  \
     }
     /* plain product: the interleaved kernel where it applies (no idle waves, a multiple of 4 product rows), the ring of four key rows */ \
     /* inside k_mid128 for shapes with idle waves, the ping-pong pair otherwise */
 #define PZ_MID128_PICK(CT_, NP_, perm_, skipw_, ring_)                                                                     \
-    if (ring_ && !(skipw_) && mid_r) {                                                                                     \
+    if (ring_ && !(skipw_) && mid_r && (g.row_max == 16 || g.row_max == 8)) {                                                                                    \
         if (perm_) PZ_MID128_GOR(CT_, NP_, true) else PZ_MID128_GOR(CT_, NP_, false)                                       \
     } else if (ring_) {                                                                                                    \
         if (perm_) { if (skipw_) PZ_MID128_GO(CT_, NP_, true, true, 4) else PZ_MID128_GO(CT_, NP_, true, false, 4) }       \

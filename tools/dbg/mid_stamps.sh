@@ -1,7 +1,9 @@
 #!/bin/bash
 # per-phase cycle totals of k_mid128 (diagnostic build -DPZ_MID_STAMP=1, see device_mid.hpp): tools/dbg/mid_stamps.sh <lib relative to poulpy_amd/> [bench args]
 export POULPY_HIP_LIB=$PWD/poulpy_amd/$1; shift
-python bench.py --steps 1 --warmup 0 --no-cpu-baseline --parity-samples 0 --timing-steps 1 "$@" 2>&1 | grep STAMP | tail -32 | python -c "
+python bench.py --steps 1 --warmup 0 --no-cpu-baseline --parity-samples 0 --timing-steps 1 "$@" > /tmp/mid_stamps.log 2>&1
+grep -o '"kernel_ms": {[^}]*}' /tmp/mid_stamps.log | tail -1
+grep STAMP /tmp/mid_stamps.log | tail -32 | python -c "
 import sys,re
 rows=[]
 for l in sys.stdin:
