@@ -25,7 +25,8 @@ struct BrFusedArgs {
     const cplx* w2n;       // exp(2 pi i t / 4m), t < 4m
     long long key_stride;  // points between consecutive keys
     int n_lwe, blk, cols, rsz, dnum, bsz, lut_size, base2k, m, batch;
-    int dbg_skip;          // timing diagnostic (wrong results): 1 no DFT passes, 2 no product, 4 no carry phase, 8 no pack
+    int dbg_skip;          // (run-time on purpose: with the tests compiled out — PZ_DBG, device_fft.hpp — this kernel's register allocation changes and the
+                           //  N = 1024 two-ciphertext variants spill: 112 000 -> 89 000 rotations/s, round 3)  timing diagnostic (wrong results): 1 no DFT passes, 2 no product, 4 no carry phase, 8 no pack
 };
 
 template <bool ACC32> struct AccT { typedef long long type; };
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
         if (CT == 2 && R0 == 8) asm volatile("" : "+v"(tidv));
         const bool from_lut = ACC32 && blk0 == 0;  // the accumulator is still X^b * LUT in global memory
         // ---- pack + twist: X[ct][r][j] = (acc[r][j] + i acc[r][j+m]) * exp(2 pi i j / 4m),  r = limb*cols + col (:319-320)
-        if (!(PZ_DBG(g.dbg_skip) & 8))
+        if (!(g.dbg_skip & 8))
         for (int pr = tidv >> lm; pr < CT * row_max; pr += NT >> lm) {  // (ciphertext, row) pairs; j = tid mod m is fixed
             const int j = tidv & (m - 1), ct = (CT == 2 && pr >= row_max) ? 1 : 0, r = pr - ct * row_max;
             const acc_t* a = acc + ((long long)ct * ct_polys + r) * n;
@@ -156,7 +157,7 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
         __syncthreads();
         // forward DFT of the CT*row_max input polynomials (they sit at poly index ct*P + r: run the passes over whole
         // ciphertext slots when row_max == P, otherwise per ciphertext)
-        if (!(PZ_DBG(g.dbg_skip) & 1))
+        if (!(g.dbg_skip & 1))
         for (int ct = 0; ct < (row_max == P ? 1 : CT); ++ct) {
             cplx* buf = X + ct * P * mp;
             const int np = row_max == P ? CT * P : row_max;
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
             br_pass<8, false, JM8, NT>(buf, np, mp, m, lm, R0 * 8, W, tidv);
         }
         // ---- product, in place: X[ct][c][q] = sum_i (DFT(X^a_i)[q] - 1) * sum_r X[ct][r][q] * BRK_i[r][c][q]   (:321-337)
-        if (!(PZ_DBG(g.dbg_skip) & 2)) {
+        if (!(g.dbg_skip & 2)) {
             cplx out[PJ][CT][CG];
 #pragma unroll
             for (int pj = 0; pj < PJ; ++pj) {
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
             __syncthreads();
         }
         // inverse DFT of the CT*ncols output polynomials
-        if (!(PZ_DBG(g.dbg_skip) & 1))
+        if (!(g.dbg_skip & 1))
         for (int ct = 0; ct < (ncols == P ? 1 : CT); ++ct) {
             cplx* buf = X + ct * P * mp;
             const int np = ncols == P ? CT * P : ncols;
@@ -267,7 +268,7 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
         }
         // ---- untwist, round(x/m), + acc, carry chain from the last limb to limb 0 (:342-346); thread = (ct, column, j < m):
         //      coefficients j and j+m.  Same digit/carry arithmetic as the fused tail (device_fft.hpp, PZ_TAIL_COEFFS).
-        if (!(PZ_DBG(g.dbg_skip) & 4))
+        if (!(g.dbg_skip & 4))
         for (int pc = tidv >> lm; pc < CT * cols; pc += NT >> lm) {  // (ciphertext, column) pairs; j = tid mod m is fixed
             const int j = tidv & (m - 1), ct = (CT == 2 && pc >= cols) ? 1 : 0, col = pc - ct * cols;
             const cplx tw = tw_j;

@@ -29,9 +29,7 @@ constexpr int kMidRS = PZ_MID_RS;
 #ifndef PZ_MIDR_KR
 #define PZ_MIDR_KR 6     // key-row slots of k_mid128r (rows requested KR - 1 ahead; build-time for A/B runs)
 #endif
-#ifndef PZ_MID_RING
-#define PZ_MID_RING 4    // key-row slots of k_mid128's plain product (2: the ping-pong pair of rounds 1-2; build-time for A/B runs)
-#endif   // row stride of the k_mid128 tile (see there; build-time for A/B runs)
+   // row stride of the k_mid128 tile (see there; build-time for A/B runs)
 
 struct MidArgs {
     const cplx* T;
@@ -293,10 +291,9 @@ k_mid(MidArgs g) {
 // NP = polynomial slots per ciphertext: 16; 8 for shapes with <= 8 polynomials in and out such as rank 1 with 4 limbs (twice the
 // ciphertexts per tile and per key fetch); 32 for rank 2-3 or 16 limbs (two ciphertexts per tile).  The 4 thread groups of the product phase split into GC column groups x GT
 // ciphertext groups so that a thread always owns 16 accumulators (4 ciphertexts x 4 outputs, or 2 x 8).
-template <int CT, int NP = 16, bool PERM = false, bool DS = false, bool BR = false, bool SKIPW = false, int KR = 2>
+template <int CT, int NP = 16, bool PERM = false, bool DS = false, bool BR = false, bool SKIPW = false>
 __global__ void __launch_bounds__(CT * NP * 8)
 k_mid128(MidArgs g) {
-    static_assert(KR == 2 || (KR == 4 && NP <= 16 && !BR && !DS), "key ring of four: plain product with 4 outputs per thread");
     static_assert(!SKIPW || (NP > 8 && !BR && !DS), "wave skipping: 16- and 32-slot tiles of the plain product only");
     constexpr int M2 = 128;
     constexpr int NT = CT * NP * 8;
@@ -315,6 +312,9 @@ k_mid128(MidArgs g) {
     constexpr int RS = kMidRS;
     extern __shared__ cplx lds[];      // CT*16 rows x RS | wL2[128] | tw12t row [128]
     const int tid0 = threadIdx.x;
+    // ablation mask: compile-time zero (PZ_DBG) except in the BR variant, whose register allocation is better WITH the run-time tests
+    // (without them: 36 bytes of scratch and N = 2^14 blind rotation 6 240 -> 5 715/s, round 3)
+    const int dbgv = BR ? g.dbg : PZ_DBG(g.dbg);
     const long long m = (long long)g.m1 * M2;
     cplx* wl = lds + CT * NP * RS;
     // Lane coordinates are re-derived from an OPAQUE copy of the thread index at the top of every phase (round 3).  Derived once, the
@@ -376,7 +376,7 @@ k_mid128(MidArgs g) {
         if (!in_active((LT), ctl, rr)) {                                                                        \
             _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1) x[n1] = make_double2(0.0, 0.0);     \
         }                                                                                         \
-        if (!(PZ_DBG(g.dbg) & 16)) Bfly<16, false>::run(x);                                               \
+        if (!(dbgv & 16)) Bfly<16, false>::run(x);                                               \
         _Pragma("unroll") for (int k1 = 0; k1 < 16; ++k1) {                                       \
             cplx v = x[k1];                                                                       \
             if (k1 > 0) v = cmul(v, wl[o * k1]);                                                  \
@@ -386,7 +386,7 @@ k_mid128(MidArgs g) {
         _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                           \
             _Pragma("unroll") for (int oo = 0; oo < 8; ++oo) x[8 * h + oo] = rowbuf[(o + 8 * h) * 9 + oo]; \
         }                                                                                         \
-        if (!(PZ_DBG(g.dbg) & 16)) { Bfly<8, false>::run(x); Bfly<8, false>::run(x + 8); }                \
+        if (!(dbgv & 16)) { Bfly<8, false>::run(x); Bfly<8, false>::run(x + 8); }                \
         row_sync();                                                                               \
         _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                           \
             _Pragma("unroll") for (int k2 = 0; k2 < 8; ++k2) rowbuf[o + 8 * h + 16 * k2] = x[8 * h + k2]; \
@@ -403,7 +403,7 @@ k_mid128(MidArgs g) {
         const cplx* src_ = src_ptr((LT), ctl, rr, o);                                                  \
         if (wave_in) {                                                                                 \
             _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1)                                          \
-                x[n1] = (PZ_DBG(g.dbg) & 4) ? make_double2(1.0, (double)n1) : ld_stream(src_ + 8 * n1); \
+                x[n1] = (dbgv & 4) ? make_double2(1.0, (double)n1) : ld_stream(src_ + 8 * n1); \
         }                                                                                              \
         twn = g.tw12t[(long long)out_q1(tile_q1(min((LT), ntiles - 1))) * M2 + (tid & (M2 - 1))];      \
     }
@@ -436,20 +436,14 @@ k_mid128(MidArgs g) {
             abuf[tid] = a_;                                                                            \
         }                                                                                              \
     }
-    cplx pn[NC], pb[NC], k2[KR == 4 ? NC : 1], k3[KR == 4 ? NC : 1];   // key-row slots (KR = 2: pn / pb in ping-pong)
-    (void)k2; (void)k3;
+    cplx pn[NC], pb[NC];   // key-row slots in ping-pong
 #define PZ_MID_P0(LT)                                                                                  \
     {                                                                                                  \
         PZ_MID_LANE                                                                                    \
         const long long base_ = (long long)tile_q1(min((LT), ntiles - 1)) * g.nrows * g.ncols;         \
-        if (!(PZ_DBG(g.dbg) & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j) {                           \
+        if (!(dbgv & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j) {                           \
             const int c_ = DS ? min(vcg * NC + j, max((int)g.ds_cb[rot], 1) - 1) + (int)g.ds_coff[rot] : min(vcg * NC + j, g.ncomp - 1); \
-            pn[j] = g.P[(base_ + (long long)(DS ? (int)g.ds_row[rot] : rot) * g.ncols + c_) * M2 + vq2];         \
-            if constexpr (KR == 4) {   /* rows 1 and 2 of the ring (nrow >= 4) */                             \
-                const int r1_ = rot + 1 - ((rot + 1 >= nrow) ? nrow : 0), r2_ = rot + 2 - ((rot + 2 >= nrow) ? nrow : 0); \
-                pb[j] = g.P[(base_ + (long long)r1_ * g.ncols + c_) * M2 + vq2];                               \
-                k2[j] = g.P[(base_ + (long long)r2_ * g.ncols + c_) * M2 + vq2];                               \
-            } } }                                                                                              \
+            pn[j] = g.P[(base_ + (long long)(DS ? (int)g.ds_row[rot] : rot) * g.ncols + c_) * M2 + vq2]; } } \
     }
     PZ_MID_P0(w)
     PZ_MID_ABUF(w)
@@ -496,11 +490,11 @@ k_mid128(MidArgs g) {
         if (DS) {                                                                               \
             const int cb_ = max((int)g.ds_cb[r_], 1) - 1, co_ = (int)g.ds_coff[r_];             \
             const long long ro_ = (long long)g.ds_row[r_] * prow;                               \
-            if (!(PZ_DBG(g.dbg) & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j)                  \
+            if (!(dbgv & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j)                  \
                 DST[j] = pp[j][ro_ + (long long)(min(cg * NC + j, cb_) + co_) * M2]; }          \
         } else {                                                                                \
             const long long off_ = (long long)r_ * prow;                                        \
-            if (!(PZ_DBG(g.dbg) & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = pp[j][off_]; }  \
+            if (!(dbgv & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = pp[j][off_]; }  \
         }                                                                                       \
         if constexpr (BR) __builtin_amdgcn_sched_barrier(0);                                    \
     }
@@ -515,7 +509,7 @@ k_mid128(MidArgs g) {
             r_ = (int)g.ds_in[r_];                                                              \
         }                                                                                       \
         if constexpr (BR) r_ = br_slot;                                                         \
-        if (!(PZ_DBG(g.dbg) & 1)) _Pragma("unroll") for (int i = 0; i < CTt; ++i) {                      \
+        if (!(dbgv & 1)) _Pragma("unroll") for (int i = 0; i < CTt; ++i) {                      \
             cplx av = lds[((vtg * CTt + i) * NP + r_) * RS + q2];                               \
             if constexpr (BR) av = cmul(av, f[i]);                                              \
             _Pragma("unroll") for (int j = 0; j < NC; ++j) {                                    \
@@ -537,48 +531,7 @@ k_mid128(MidArgs g) {
     }
             int it = 0;
             // (BR: deeper key prefetch — rings of three / four row slots — spills at the 256-VGPR cap and measured slower: 30.1 vs 26.8 ms)
-            if constexpr (KR == 4) {
-                // Round 3, plain product of the 16- and 8-slot tiles, nrow a multiple of 4 (launch_mid): a ring of FOUR key-row slots —
-                // a row is requested three rows before its use (P0 requested rows 0..2 in front of the forward pass) — and the tile's
-                // operands are read from LDS one row ahead into a second register set, so that neither an L2 nor an LDS latency sits in
-                // front of a row's 64 FMAs.  Measured with s_memtime stamps before this (profiles/r03_mid_stamps_before.txt): the product
-                // phase took 13.4 k cycles per tile for 8.2 k cycles of FMA issue per SIMD — the wave that loses the issue arbitration
-                // ran the last third of its rows alone on its SIMD, stalling on every ds_read / key row.  No row past the end is requested.
-                cplx avA[CTt], avB[CTt];
-#define PZ_AVLOAD(DST, IT)                                                                      \
-    {                                                                                           \
-        int r_ = (IT) + rot;                                                                    \
-        r_ -= (r_ >= nrow) ? nrow : 0;                                                          \
-        r_ -= (r_ >= nrow) ? nrow : 0;                                                          \
-        _Pragma("unroll") for (int i = 0; i < CTt; ++i) DST[i] = lds[((vtg * CTt + i) * NP + r_) * RS + q2]; \
-        __builtin_amdgcn_sched_barrier(0);   /* the machine scheduler otherwise sinks these reads down to their first use */ \
-    }
-#define PZ_FMAROW(AV, SRC)                                                                      \
-    {                                                                                           \
-        if (!(PZ_DBG(g.dbg) & 1)) _Pragma("unroll") for (int i = 0; i < CTt; ++i) {             \
-            _Pragma("unroll") for (int j = 0; j < NC; ++j) {                                    \
-                acc[i][j].x = __builtin_fma(AV[i].x, SRC[j].x, acc[i][j].x);                    \
-                acc[i][j].x = __builtin_fma(-AV[i].y, SRC[j].y, acc[i][j].x);                   \
-                acc[i][j].y = __builtin_fma(AV[i].x, SRC[j].y, acc[i][j].y);                    \
-                acc[i][j].y = __builtin_fma(AV[i].y, SRC[j].x, acc[i][j].y);                    \
-            }                                                                                   \
-        }                                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-    }
-                PZ_AVLOAD(avA, 0)
-                for (; it + 4 < nrow; it += 4) {
-                    PZ_LOADROW(k3, it + 3) PZ_AVLOAD(avB, it + 1) PZ_FMAROW(avA, pn)
-                    PZ_LOADROW(pn, it + 4) PZ_AVLOAD(avA, it + 2) PZ_FMAROW(avB, pb)
-                    PZ_LOADROW(pb, it + 5) PZ_AVLOAD(avB, it + 3) PZ_FMAROW(avA, k2)
-                    PZ_LOADROW(k2, it + 6) PZ_AVLOAD(avA, it + 4) PZ_FMAROW(avB, k3)
-                }
-                PZ_LOADROW(k3, it + 3) PZ_AVLOAD(avB, it + 1) PZ_FMAROW(avA, pn)
-                PZ_AVLOAD(avA, it + 2) PZ_FMAROW(avB, pb)
-                PZ_AVLOAD(avB, it + 3) PZ_FMAROW(avA, k2)
-                PZ_FMAROW(avB, k3)
-#undef PZ_AVLOAD
-#undef PZ_FMAROW
-            } else if constexpr (NC == 8) {
+            if constexpr (NC == 8) {
                 // 8 key values per thread and row: the second register slot of the ping-pong is what pushes this shape over the 256-VGPR
                 // cap (132-164 bytes of scratch, 57.9 -> 50.3 ms per 10 launches at 16 limbs without it); one slot, the next row requested
                 // right after the current one has been consumed
@@ -587,6 +540,16 @@ k_mid128(MidArgs g) {
                     PZ_LOADROW(pn, it + 1)
                 }
                 PZ_USEROW(pn, it)
+            } else if constexpr (BR) {
+                // two slots in ping-pong; the request past the end wraps to a valid row and is unused (with the peeled loop below this
+                // variant spills)
+                for (; it + 1 < nrow; it += 2) {
+                    PZ_LOADROW(pb, it + 1)
+                    PZ_USEROW(pn, it)
+                    PZ_LOADROW(pn, it + 2)
+                    PZ_USEROW(pb, it + 1)
+                }
+                if (it < nrow) PZ_USEROW(pn, it)
             } else {
                 // two slots in ping-pong; no row is requested past the end
                 for (; it + 3 < nrow; it += 2) {
@@ -639,7 +602,7 @@ k_mid128(MidArgs g) {
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) u[8 * h + k2] = rowbuf[o + 8 * h + 16 * k2];
-            if (!(PZ_DBG(g.dbg) & 16)) { Bfly<8, true>::run(u); Bfly<8, true>::run(u + 8); }
+            if (!(dbgv & 16)) { Bfly<8, true>::run(u); Bfly<8, true>::run(u + 8); }
             row_sync();
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -653,7 +616,7 @@ k_mid128(MidArgs g) {
             row_sync();
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) u[k1] = rowbuf[k1 * 9 + o];
-            if (!(PZ_DBG(g.dbg) & 16)) Bfly<16, true>::run(u);
+            if (!(dbgv & 16)) Bfly<16, true>::run(u);
             const bool active = b < g.batch && rr < g.npo;
             // rows without an output polynomial store to a scratch row of their OWN workgroup (one 2 KiB row per tile row): with a
             // shared scratch every workgroup of the chip wrote the same lines, which cost more than the real stores (measured on the
@@ -666,7 +629,7 @@ k_mid128(MidArgs g) {
             PZ_STAMP(9)
 #endif
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) if (!(PZ_DBG(g.dbg) & 8) || u[n1].x == 1.2345e300) st_stream(dst + 8 * n1, cmulc(u[n1], twrow[o + 8 * n1]));
+            for (int n1 = 0; n1 < 16; ++n1) if (!(dbgv & 8) || u[n1].x == 1.2345e300) st_stream(dst + 8 * n1, cmulc(u[n1], twrow[o + 8 * n1]));
         }
         PZ_STAMP(3)
         lds_barrier();
@@ -712,9 +675,13 @@ k_mid128(MidArgs g) {
 //     (both only touch the wave's own rows) and the waves drift apart instead of meeting the same resource at the same time.
 // The arithmetic, its order and therefore every output bit are those of k_mid128.
 // =================================================================================
-template <int CT, int NP, bool PERM, int NR, int KR = PZ_MIDR_KR>
-__global__ void __launch_bounds__(512)
-k_mid128r(MidArgs g) {
+// IN = false: the code of a wave whose 8 polynomial slots carry no input (HALFIN shapes, e.g. the 8 input polynomials of a key switch in
+// a 16-slot tile): no T' loads, no forward pass; it still takes part in the product, runs the inverse pass of its 8 output rows and
+// issues its share of the stores and key requests in the same order.  Both codes execute the same barriers.  They are two
+// instantiations of this function rather than branches inside one loop because a branch around the loads makes the compiler's
+// s_waitcnt insertion assume the worst case at every join (k_mid128, SKIPW).
+template <int CT, int NP, bool PERM, int NR, int KR, bool HALFIN, bool IN>
+__device__ __forceinline__ void mid128r_body(const MidArgs& g) {
     constexpr int M2 = 128, NT = 512, NC = 4;
     constexpr int GC = NP / NC, GT = (NT / M2) / GC, CTt = CT / GT;
     static_assert(CT * NP * 8 == NT && GC * GT == NT / M2 && CTt * GT == CT && KR >= 3 && KR <= 7 && KR <= NR, "k_mid128r tile shape");
@@ -741,6 +708,8 @@ k_mid128r(MidArgs g) {
     if (w >= ntiles) return;
     if (tid0 < M2) wl[tid0] = g.wL2[tid0];
     __syncthreads();
+    // the threads that move the inter-pass twiddle row (128 entries): waves 0 and 1, or waves 0 and 2 where wave 1 carries no input
+    const int tw_e = HALFIN ? ((tid0 >> 6) == 0 ? tid0 : ((tid0 >> 6) == 2 ? tid0 - 64 : -1)) : (tid0 < M2 ? tid0 : -1);
     // experiments (POULPY_DBG_MID_STAGGER = n, POULPY_DBG_MID_STAGGER_MOD = mode bits): n x 128 cycles of delay for the second-dispatched
     // half of the waves at the top of every inverse pass (mode bit 2: for the first half instead); mode bit 0: static priority 1 for the
     // second half, bit 1: for the first half
@@ -787,15 +756,17 @@ k_mid128r(MidArgs g) {
         PZ_MID_LANE                                                                               \
         if (STORES) { PZ_SGROUP(0) __builtin_amdgcn_sched_barrier(0); }                           \
         if (PZ_MID_STAMP && STORES) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); PZ_STAMP(4) } \
+        if constexpr (IN) {                                                                       \
         if (!in_active((LT), ctl, rr)) {                                                          \
             _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1) x[n1] = make_double2(0.0, 0.0);     \
         }                                                                                         \
         Bfly<16, false>::run(x);                                                                  \
+        }                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         if (STORES) { PZ_SGROUP(1) __builtin_amdgcn_sched_barrier(0); }                           \
         /* twiddles W128^(o k1) in two batches of reads ahead of their multiplies: read one by one, each of the 15 sits behind its own  */ \
         /* LDS latency (the compiler does not batch them by itself)                                                                   */ \
-        _Pragma("unroll") for (int hb = 0; hb < 2; ++hb) {                                        \
+        if constexpr (IN) _Pragma("unroll") for (int hb = 0; hb < 2; ++hb) {                      \
             cplx tw_[8];                                                                          \
             _Pragma("unroll") for (int k1 = 8 * hb; k1 < 8 * hb + 8; ++k1) tw_[k1 - 8 * hb] = wl[o * k1]; \
             __builtin_amdgcn_sched_barrier(0);                                                    \
@@ -807,42 +778,45 @@ k_mid128r(MidArgs g) {
             __builtin_amdgcn_sched_barrier(0);                                                    \
         }                                                                                         \
         if (STORES) { PZ_SGROUP(2) __builtin_amdgcn_sched_barrier(0); }                           \
+        if constexpr (IN) {                                                                       \
         row_sync();                                                                               \
         _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                           \
             _Pragma("unroll") for (int oo = 0; oo < 8; ++oo) x[8 * h + oo] = rowbuf[(o + 8 * h) * 9 + oo]; \
+        }                                                                                         \
         }                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         if (STORES) { PZ_SGROUP(3) __builtin_amdgcn_sched_barrier(0); }                           \
         PZ_KGROUP(LT, 0)                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        Bfly<8, false>::run(x);                                                                   \
+        if constexpr (IN) Bfly<8, false>::run(x);                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         PZ_KGROUP(LT, 1)                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        Bfly<8, false>::run(x + 8);                                                               \
+        if constexpr (IN) Bfly<8, false>::run(x + 8);                                             \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         if constexpr (KR > 3) PZ_KGROUP(LT, 2)                                                    \
         if constexpr (KR > 5) PZ_KGROUP(LT, 4)                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                        \
+        if constexpr (IN) {                                                                       \
         row_sync();                                                                               \
         _Pragma("unroll") for (int k2 = 0; k2 < 8; ++k2) rowbuf[o + 16 * k2] = x[k2];             \
+        }                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         if constexpr (KR > 4) PZ_KGROUP(LT, 3)                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        _Pragma("unroll") for (int k2 = 0; k2 < 8; ++k2) rowbuf[o + 8 + 16 * k2] = x[8 + k2];     \
+        if constexpr (IN) { _Pragma("unroll") for (int k2 = 0; k2 < 8; ++k2) rowbuf[o + 8 + 16 * k2] = x[8 + k2]; } \
         if constexpr (KR > 6) PZ_KGROUP(LT, 5)                                                    \
         if (PZ_MID_STAMP && STORES) { PZ_STAMP(5) }                                               \
         lds_barrier();                                                                            \
     }
 
     // ---- prologue: first tile ----
-    {
+    if constexpr (IN) {
         PZ_MID_LANE
         const cplx* src_ = src_ptr(w, ctl, rr, o);
         PZ_XGROUP(src_, 0) PZ_XGROUP(src_, 1) PZ_XGROUP(src_, 2) PZ_XGROUP(src_, 3)
-        twn = g.tw12t[(long long)out_q1(tile_q1(w)) * M2 + (tid & (M2 - 1))];
+        if (tw_e >= 0) twrow2[tw_e] = g.tw12t[(long long)out_q1(tile_q1(w)) * M2 + tw_e];
     }
-    if (tid0 < M2) twrow2[tid0] = twn;
     int par = 0;
 #if PZ_MID_STAMP
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -936,19 +910,19 @@ k_mid128r(MidArgs g) {
             const int b = (L % g.n_ct) * CT + ctl;
             const cplx* src_ = src_ptr(L + W, ctl, rr, o);
             const cplx* twr = twrow2 + par * M2;
-            twn = g.tw12t[(long long)out_q1(tile_q1(min(L + W, ntiles - 1))) * M2 + (tid & (M2 - 1))];
-            PZ_XGROUP(src_, 0)
+            if constexpr (IN) twn = g.tw12t[(long long)out_q1(tile_q1(min(L + W, ntiles - 1))) * M2 + max(tw_e, 0)];
+            if constexpr (IN) PZ_XGROUP(src_, 0)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) u[8 * h + k2] = rowbuf[o + 8 * h + 16 * k2];
             __builtin_amdgcn_sched_barrier(0);
-            PZ_XGROUP(src_, 1)
+            if constexpr (IN) PZ_XGROUP(src_, 1)
             __builtin_amdgcn_sched_barrier(0);
             Bfly<8, true>::run(u);
             __builtin_amdgcn_sched_barrier(0);
-            PZ_XGROUP(src_, 2)
+            if constexpr (IN) PZ_XGROUP(src_, 2)
             __builtin_amdgcn_sched_barrier(0);
             Bfly<8, true>::run(u + 8);
             row_sync();
@@ -969,7 +943,7 @@ k_mid128r(MidArgs g) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            PZ_XGROUP(src_, 3)
+            if constexpr (IN) PZ_XGROUP(src_, 3)
             __builtin_amdgcn_sched_barrier(0);
             row_sync();
 #pragma unroll
@@ -989,7 +963,7 @@ k_mid128r(MidArgs g) {
             }
             // the next tile's twiddle row (requested FIRST among this pass's loads, so that waiting for it here leaves the 16 T' loads in
             // flight) goes to the row the next inverse pass reads
-            if (tid0 < M2) twrow2[(par ^ 1) * M2 + tid0] = twn;
+            if constexpr (IN) { if (tw_e >= 0) twrow2[(par ^ 1) * M2 + tw_e] = twn; }
             const bool active = b < g.batch && rr < g.npo;
             dst = active ? g.T2 + ((long long)b * g.npo + rr) * m + (long long)out_q1(q1) * M2 + o
                          : g.dummy + ((long long)blockIdx.x * (NT / 8) + row) * M2 + o;
@@ -1014,6 +988,21 @@ k_mid128r(MidArgs g) {
 #undef PZ_KGROUP
 #undef PZ_MIDR_FWD
 #undef PZ_MID_LANE
+}
+
+// HALFIN: a 16-slot tile whose ciphertexts carry at most 8 input polynomials (key switch, automorphism, ggsw_expand_row): the waves of
+// the upper 8 slots run the IN = false code.
+template <int CT, int NP, bool PERM, int NR, bool HALFIN = false, int KR = PZ_MIDR_KR>
+__global__ void __launch_bounds__(512)
+k_mid128r(MidArgs g) {
+    static_assert(!HALFIN || NP == 16, "HALFIN: 16-slot tiles");
+    if constexpr (HALFIN) {
+        if (((threadIdx.x >> 3) % NP) >= 8) {   // wave-uniform: a wave owns 8 consecutive slots of one ciphertext
+            mid128r_body<CT, NP, PERM, NR, KR, true, false>(g);
+            return;
+        }
+    }
+    mid128r_body<CT, NP, PERM, NR, KR, HALFIN, true>(g);
 }
 
 // (Round 2 experiment, removed: "k_midr<LPR = 4>" — the same kernel for rows of 64 points owned by 4 lanes (m = 512 x 64): a tile of four

@@ -76,34 +76,32 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, M->device);
         if (M->cu_count > 0) ncu = (M->cu_count / 8) * 8 > 0 ? (M->cu_count / 8) * 8 : M->cu_count;
-        static const bool mid_r = !(getenv("POULPY_DBG_MID_R") && atoi(getenv("POULPY_DBG_MID_R")) == 0);   // 0: k_mid128 with the key ring instead of k_mid128r (A/B)
+        static const bool mid_r = !(getenv("POULPY_DBG_MID_R") && atoi(getenv("POULPY_DBG_MID_R")) == 0);   // 0: k_mid128 (the kernel of rounds 1-2) instead of k_mid128r (A/B)
         KTimer kt(M, PZ_K_FUSED_MID);
-#define PZ_MID128_GO(CT_, NP_, PERM_, SKIPW_, KR_)                                                                         \
+#define PZ_MID128_GO(CT_, NP_, PERM_, SKIPW_)                                                                              \
     {                                                                                                                      \
-        PZ_TRY(set_lds((k_mid128<CT_, NP_, PERM_, false, false, ((SKIPW_) && (NP_ > 8)), ((NP_ <= 16) ? (KR_) : 2)>), lds));                    \
-        hipLaunchKernelGGL((k_mid128<CT_, NP_, PERM_, false, false, ((SKIPW_) && (NP_ > 8)), ((NP_ <= 16) ? (KR_) : 2)>), grid_, dim3(512), lds, M->stream, g); \
+        PZ_TRY(set_lds((k_mid128<CT_, NP_, PERM_, false, false, ((SKIPW_) && (NP_ > 8))>), lds));                           \
+        hipLaunchKernelGGL((k_mid128<CT_, NP_, PERM_, false, false, ((SKIPW_) && (NP_ > 8))>), grid_, dim3(512), lds, M->stream, g); \
+    }
+#define PZ_MID128_GOR1(CT_, NP_, PERM_, NR_, HALF_)                                                                        \
+    {                                                                                                                      \
+        PZ_TRY(set_lds((k_mid128r<((NP_ <= 16) ? CT_ : 4), ((NP_ <= 16) ? NP_ : 16), PERM_, NR_, ((HALF_) && (NP_ == 16))>), lds)); \
+        hipLaunchKernelGGL((k_mid128r<((NP_ <= 16) ? CT_ : 4), ((NP_ <= 16) ? NP_ : 16), PERM_, NR_, ((HALF_) && (NP_ == 16))>), grid_, dim3(512), lds, M->stream, g); \
     }
 #define PZ_MID128_GOR(CT_, NP_, PERM_)   /* k_mid128r: 16- and 8-slot tiles only, 16 or 8 product rows */                  \
     {                                                                                                                      \
-        if (g.row_max == 16) {                                                                                             \
-            PZ_TRY(set_lds((k_mid128r<((NP_ <= 16) ? CT_ : 4), ((NP_ <= 16) ? NP_ : 16), PERM_, 16>), lds));                 \
-            hipLaunchKernelGGL((k_mid128r<((NP_ <= 16) ? CT_ : 4), ((NP_ <= 16) ? NP_ : 16), PERM_, 16>), grid_, dim3(512), lds, M->stream, g); \
-        } else {                                                                                                           \
-            PZ_TRY(set_lds((k_mid128r<((NP_ <= 16) ? CT_ : 4), ((NP_ <= 16) ? NP_ : 16), PERM_, 8>), lds));                  \
-            hipLaunchKernelGGL((k_mid128r<((NP_ <= 16) ? CT_ : 4), ((NP_ <= 16) ? NP_ : 16), PERM_, 8>), grid_, dim3(512), lds, M->stream, g); \
-        }                                                                                                                  \
+        if (g.row_max == 16) PZ_MID128_GOR1(CT_, NP_, PERM_, 16, false)                                                    \
+        else if (NP_ == 16 && npi <= 8) PZ_MID128_GOR1(CT_, NP_, PERM_, 8, true)                                           \
+        else PZ_MID128_GOR1(CT_, NP_, PERM_, 8, false)                                                                     \
     }
-    /* plain product: the interleaved kernel where it applies (no idle waves, a multiple of 4 product rows), the ring of four key rows */ \
-    /* inside k_mid128 for shapes with idle waves, the ping-pong pair otherwise */
+    /* plain product: the interleaved kernel k_mid128r where it applies — 8 or 16 product rows, no idle waves or exactly the upper half */ \
+    /* of a 16-slot tile without input (key switch) — k_mid128 otherwise                                                            */
 #define PZ_MID128_PICK(CT_, NP_, perm_, skipw_, ring_)                                                                     \
-    if (ring_ && !(skipw_) && mid_r && (g.row_max == 16 || g.row_max == 8)) {                                                                                    \
+    if (ring_ && (!(skipw_) || (NP_ == 16 && npi <= 8 && npo > 8))) {                                                      \
         if (perm_) PZ_MID128_GOR(CT_, NP_, true) else PZ_MID128_GOR(CT_, NP_, false)                                       \
-    } else if (ring_) {                                                                                                    \
-        if (perm_) { if (skipw_) PZ_MID128_GO(CT_, NP_, true, true, 4) else PZ_MID128_GO(CT_, NP_, true, false, 4) }       \
-        else       { if (skipw_) PZ_MID128_GO(CT_, NP_, false, true, 4) else PZ_MID128_GO(CT_, NP_, false, false, 4) }     \
     } else {                                                                                                               \
-        if (perm_) { if (skipw_) PZ_MID128_GO(CT_, NP_, true, true, 2) else PZ_MID128_GO(CT_, NP_, true, false, 2) }       \
-        else       { if (skipw_) PZ_MID128_GO(CT_, NP_, false, true, 2) else PZ_MID128_GO(CT_, NP_, false, false, 2) }     \
+        if (perm_) { if (skipw_) PZ_MID128_GO(CT_, NP_, true, true) else PZ_MID128_GO(CT_, NP_, true, false) }             \
+        else       { if (skipw_) PZ_MID128_GO(CT_, NP_, false, true) else PZ_MID128_GO(CT_, NP_, false, false) }           \
     }
 #define PZ_MID128_LAUNCH(CT_, NP_)                                                                                         \
     {                                                                                                                      \
@@ -118,7 +116,7 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
             hipLaunchKernelGGL((k_mid128<CT_, NP_, false, true>), grid_, dim3(512), lds, M->stream, g);                    \
         } else {                                                                                                           \
             const bool skipw_ = NP_ > 8 && (npi <= NP_ - 8 || npo <= NP_ - 8);   /* shapes with idle waves */              \
-            const bool ring_ = NP_ <= 16 && PZ_MID_RING == 4 && g.row_max >= 4 && (g.row_max & 3) == 0;                      \
+            const bool ring_ = NP_ <= 16 && mid_r && (g.row_max == 16 || g.row_max == 8);                      \
             PZ_MID128_PICK(CT_, NP_, perm, skipw_, ring_)                                                                  \
         }                                                                                                                  \
     }
@@ -135,6 +133,7 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
 #undef PZ_MID128_PICK
 #undef PZ_MID128_GO
 #undef PZ_MID128_GOR
+#undef PZ_MID128_GOR1
         PZ_HIP(hipGetLastError());
         return PZ_OK;
     }
