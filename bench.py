@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """bench.py — GLWE (x) GGSW external products / s at N=2^16, 8 limbs on N MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver
-launches this file under torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints ONE
-JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  Under torch.distributed.run (WORLD_SIZE set: one rank
+per GPU, RCCL) it runs as one rank and requires WORLD_SIZE == --gpus.  Started plainly with --gpus N > 1 it launches
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py ...` itself as a CHILD process — before torch is
+imported or the GPU is touched — and relays the child's output and exit code.  Rank 0 prints ONE JSON line; a line never
+reports a GPU count other than the one asked for.
 
 Workload ("metric" row of BASELINE.md §3): rank 1 (cols = 2), dsize 1, base2k 12, 8 limbs,
 GGSW = VmpPMat(rows 8, cols_in 2, cols_out 2, size 8) shared by the whole batch.  A step is
@@ -67,37 +69,103 @@ def pmc_traffic(kernel_class: str, batch: int):
         return None
 
 
-def cpu_baseline(sample_cts_per_thread: int = 4, max_threads: int | None = None) -> dict:
-    """Oracle (C restatement, built -O3 -march=native on this host) timed on the host cores over a
-    bounded sample of the same workload: independent ciphertexts, one thread each."""
+def physical_core_cpus() -> list:
+    """One logical CPU per physical core among the CPUs this process may run on (sysfs thread_siblings_list; all allowed CPUs if the
+    topology cannot be read)."""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    seen, by_pkg = set(), {}
+    for c in allowed:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+            pkg = open(f"/sys/devices/system/cpu/cpu{c}/topology/physical_package_id").read().strip()
+        except OSError:
+            return allowed
+        if sib not in seen:
+            seen.add(sib)
+            by_pkg.setdefault(pkg, []).append(c)
+    # interleave the sockets: the first T cores of the list are spread over all of them (T threads then use every memory controller)
+    picks, lists = [], [by_pkg[k] for k in sorted(by_pkg)]
+    for i in range(max((len(l) for l in lists), default=0)):
+        picks += [l[i] for l in lists if i < len(l)]
+    return picks or allowed
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_threads(threads: int, min_seconds: float = 3.0, reps: int = 3) -> dict:
+    """Oracle (C restatement, built -O3 -march=native on this host) timed on `threads` host threads, each pinned to its own
+    physical core (then to the sibling hyperthreads once the cores run out), over a bounded sample of the same workload:
+    independent ciphertexts, one thread each, every timed repetition >= `min_seconds` of wall time, median of `reps`."""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
     from oracle.ref import RefModule
     from poulpy_amd.layouts import MatZnx, VecZnx
 
-    threads = min(os.cpu_count() or 1, max_threads or 128)
+    cores = physical_core_cpus()
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else cores
+    order = cores + [c for c in allowed if c not in set(cores)]     # physical cores first, hyperthread siblings after
     ref = RefModule(N, fast=True)
     rng = np.random.default_rng(0x6657)
     cols = RANK_GLWE + 1
     mat = MatZnx(N, DNUM, cols, cols, SIZE).fill_uniform(BASE2K, rng)
     pm = ref.vmp_pmat_alloc(DNUM, cols, cols, SIZE)
     ref.vmp_prepare(pm, mat)
-    cts = [VecZnx(N, cols, SIZE).fill_uniform(BASE2K, rng) for _ in range(threads)]
-    outs = [VecZnx(N, cols, SIZE) for _ in range(threads)]
+    cts, outs = [None] * threads, [None] * threads
 
-    def work(i):
-        for _ in range(sample_cts_per_thread):
+    def work(arg):
+        i, k = arg
+        if hasattr(os, "sched_setaffinity"):
+            try:
+                os.sched_setaffinity(0, {order[i % len(order)]})    # pid 0 = the calling thread
+            except OSError:
+                pass
+        if cts[i] is None:   # first touch on the worker's own core: its ciphertexts live on its socket's memory
+            cts[i] = VecZnx(N, cols, SIZE).fill_uniform(BASE2K, np.random.default_rng(0x6657 + i))
+            outs[i] = VecZnx(N, cols, SIZE)
+        for _ in range(k):
             ref.glwe_external_product(outs[i], BASE2K, cts[i], BASE2K, pm, 1, BASE2K)
 
-    with ThreadPoolExecutor(threads) as ex:
-        list(ex.map(work, range(threads)))  # warm-up (page faults, tables)
-        t0 = time.perf_counter()
-        list(ex.map(work, range(threads)))
-        dt = time.perf_counter() - t0
-    units = threads * sample_cts_per_thread
-    return {"value": units / dt, "unit": "external-products/s", "cores": threads, "kind": "port",
-            "sample": f"{units} external products (N=2^16, 8 limbs, rank 1, dnum 8), {threads} threads x "
-                      f"{sample_cts_per_thread}, oracle/fft64_ref.c built -O3 -march=native, {dt:.2f} s wall"}
+    main_aff = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    try:
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(work, [(i, 1) for i in range(threads)]))    # warm-up (page faults, tables)
+            t0 = time.perf_counter()
+            list(ex.map(work, [(i, 1) for i in range(threads)]))    # calibration
+            per = max(time.perf_counter() - t0, 1e-3)
+            k = max(1, int(np.ceil(1.1 * min_seconds / per)))
+            times = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                list(ex.map(work, [(i, k) for i in range(threads)]))
+                times.append(time.perf_counter() - t0)
+    finally:
+        if main_aff is not None:
+            os.sched_setaffinity(0, main_aff)
+    dt = sorted(times)[len(times) // 2]
+    units = threads * k
+    return {"value": units / dt, "threads": threads, "products_per_rep": units, "seconds_per_rep": [round(t, 3) for t in times]}
+
+
+def cpu_baseline() -> dict:
+    """The CPU figure beside the GPU number: the better of 64 and 128 pinned threads (the port scales poorly past one socket's worth of
+    threads on the GPU box's host), both reported.  kind "port": the reference's own poulpy-cpu-avx cannot be built here (Rust)."""
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    runs = [cpu_baseline_threads(t) for t in (64, 128) if t <= ncpu] or [cpu_baseline_threads(ncpu)]
+    best = max(runs, key=lambda r: r["value"])
+    return {"value": best["value"], "unit": "external-products/s", "cores": best["threads"], "kind": "port",
+            "by_threads": {str(r["threads"]): round(r["value"], 1) for r in runs},
+            "cpu_model": cpu_model(), "physical_cores_available": len(physical_core_cpus()),
+            "sample": f"{best['products_per_rep']} external products per repetition (N=2^16, 8 limbs, rank 1, dnum 8), {best['threads']} threads pinned "
+                      f"one per physical core (sockets interleaved, per-thread buffers first touched on their core), median of {len(best['seconds_per_rep'])} repetitions of {best['seconds_per_rep']} s, "
+                      f"oracle/fft64_ref.c built -O3 -march=native"}
 
 
 def parity_sample(args, mod, a, res, mat_host, lo, nct, ks, auto_mode, unsupported, cols, cols_in, relin=False, dsize=1) -> dict:
@@ -141,9 +209,37 @@ def parity_sample(args, mod, a, res, mat_host, lo, nct, ks, auto_mode, unsupport
             "against": "oracle/fft64_ref.c (strict build, -ffp-contract=off), bit-exact i64 limbs"}
 
 
+def launcher_argv(gpus: int, argv: list, port: int) -> list:
+    """The command `bench.py --gpus N` (N > 1, no WORLD_SIZE) runs as a child: one rank per GPU on this node, rendezvous on
+    127.0.0.1 (the container hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(gpus: int, argv: list) -> int:
+    """Parent side of `--gpus N`: nothing here imports torch or initialises HIP (the child processes own the GPUs)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver: RCCL needs it
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = launcher_argv(gpus, argv, int(os.environ.get("POULPY_BENCH_PORT", "0")) or free_port())
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--bcast", choices=("auto", "cabi", "torch"), default=os.environ.get("POULPY_BENCH_BCAST", "auto"),
+                    help="how the prepared key reaches the other ranks: cabi = pz_bcast_key (RCCL inside the C ABI, what a Rust / C++ caller "
+                         "uses), torch = torch.distributed.broadcast; auto = cabi, falling back to torch if the C-ABI communicator fails")
     ap.add_argument("--steps", type=int, default=100, help="timed steps (default: ~1.1 s of GPU time at the metric shape)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="ciphertexts per GPU per step (16 GiB of GLWE in + out at the metric shape)")
@@ -178,10 +274,19 @@ def main():
     if DSIZE > 1:
         DNUM = max(1, SIZE // DSIZE)
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started plainly: become the launcher (a child process per GPU; never exec from here, never touch the GPU here)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for a different GPU count "
+                         f"(launch with --nproc-per-node {args.gpus}, or plainly and let --gpus start the ranks)")
+
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or os.environ.get("POULPY_BENCH_FORCE_DIST") == "1"   # (the knob runs the RCCL path with one rank)
@@ -224,13 +329,23 @@ def main():
                                        C.c_size_t(DNUM), C.c_size_t(cols_in), C.c_size_t(cols), C.c_size_t(SIZE)))
         mod.sync()
         del mat
+    bcast_used, rccl_ranks = None, 0
     if distributed:
-        # the only collective of the path.  POULPY_BENCH_BCAST=cabi: through the C ABI (pz_bcast_key, RCCL on the module stream:
-        # what a Rust / C++ caller uses) instead of torch.distributed
-        if os.environ.get("POULPY_BENCH_BCAST", "torch") == "cabi":
-            pdist.broadcast_key_cabi(mod, pmat, src=0)
-        else:
+        # the only collective of the path: through the C ABI (pz_bcast_key, RCCL on the module stream: what a Rust / C++ caller uses);
+        # --bcast torch (or a failure of the C-ABI communicator under --bcast auto, on every rank alike) uses torch.distributed
+        bcast_used = "torch"
+        if args.bcast in ("auto", "cabi"):
+            try:
+                pdist.broadcast_key_cabi(mod, pmat, src=0)
+                bcast_used = "cabi"
+                rccl_ranks = int(mod.lib.pz_comm_world_size(mod.handle))
+            except Exception as e:
+                if args.bcast == "cabi":
+                    raise
+                print(f"[bench rank {rank}] pz_bcast_key failed ({e}); falling back to torch.distributed.broadcast", file=sys.stderr, flush=True)
+        if bcast_used == "torch":
             pdist.broadcast_key(pmat, src=0)
+            rccl_ranks = dist.get_world_size()
 
     # this rank's shard of the (weak-scaled) batch: `batch` ciphertexts per GPU, seeds by global index
     lo, hi = pdist.shard_range(args.batch * world, world, rank)
@@ -329,6 +444,23 @@ def main():
         parity = {"n": len(picks), "ok": not bad, "indices": [int(lo + i) for i in picks], "mismatched": bad,
                   "against": "oracle/fft64_ref.c, bit-exact i64 limbs; one extra untimed call from the original input (the timed calls run in place)"}
 
+    # the library measures the placement of its second intermediate over the calls 1..8 of a call shape (include/poulpy_hip.h,
+    # pz_module_set_phase_tuning): say whether the timed loop ran with a settled placement, and time the same loop with the FIXED one
+    placement = None
+    if N >= 32768 and not (trace or expand):
+        tuned, measuring = mod.phase_tuning_state()
+        mod.set_phase_tuning(False)
+        k_un = max(1, min(args.steps, 20))
+        step(); mod.sync()
+        t1 = time.perf_counter()
+        for _ in range(k_un):
+            step()
+        mod.sync()
+        dt_un = time.perf_counter() - t1
+        mod.set_phase_tuning(True)
+        placement = {"phase_tuned": bool(tuned >= 1 and measuring == 0), "shapes_tuned": tuned, "shapes_measuring": measuring,
+                     "untuned_value_this_rank": nct * k_un / dt_un / (DNUM if expand else 1), "untuned_steps": k_un}
+
     # roofline leg: the same steps again with one HIP-event pair per launch on the module stream
     stats = {}
     timing = (not args.no_kernel_timing)
@@ -375,6 +507,7 @@ def main():
                 roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS,
                         "traffic": pmc_traffic(name, args.batch) if (args.op == "external_product" and DSIZE == 1) else None,
+                        "traffic_source": "committed rocprofv3 PMC passes of this kernel at this shape (profiles/r*_traffic.json), not a counter of this run",
                         "avg_launch_ms": ms / cnt, "launches": cnt, "units_per_launch": units_per_launch,
                         "algorithmic_bytes_per_unit": b_unit,
                         "pipeline_achieved": value * (DNUM if expand else 1) / world * b_unit / 1e9,
@@ -393,16 +526,17 @@ def main():
                                     f"glwe_{args.op} (Galois element 5) via GGLWE VmpPMat, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize={DSIZE}" if auto_mode else
                                     f"GLWE(rank 1) key-switch via GGLWE VmpPMat, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize={DSIZE}" if ks else
                                     f"GLWE(rank 1) x GGSW external product, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize={DSIZE}"),
-                       "batch_per_gpu": args.batch, "parallelism": f"batch-sharded x{world}, key broadcast (RCCL)",
+                       "batch_per_gpu": args.batch,
+                       "parallelism": (f"batch-sharded x{world}, key broadcast once over RCCL ({bcast_used})" if distributed else "single GPU (no collective)"),
+                       "rccl_ranks": rccl_ranks,
                        "output_digits_balanced": ok, "setup_calls": setup_calls},
             "roofline": roof,
+            "placement": placement,
             "parity_sample": parity,
         }
         if world == 1 and not args.no_cpu_baseline and not ks:
             try:
-                # the port scales poorly past one socket's worth of threads on this host; report the better of two thread counts
-                cands = [cpu_baseline(max_threads=t) for t in (64, 128) if t <= (os.cpu_count() or 1)] or [cpu_baseline()]
-                line["cpu_baseline"] = max(cands, key=lambda c: c["value"])
+                line["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "external-products/s", "cores": 0, "kind": "port",
                                         "sample": f"failed: {e}"}

@@ -645,6 +645,20 @@ const char* pz_kernel_class_name(int kclass);
 int pz_module_set_margin_probe(pz_module* m, int enable);
 int pz_module_get_margin(pz_module* m, double* max_frac);
 
+/* Placement of the fused pipeline's second intermediate relative to the result buffer (N >= 2^15): by default the library measures
+ * eight candidate phases over the calls 1..8 of a given call SHAPE (batch, chunk, polynomial counts, parameters; not the pointers) —
+ * one candidate per call, timed with its own event pair, never waited for — and uses the fastest afterwards.  Results never depend
+ * on it.  enable = 0 pins the fixed placement (768 KiB out of phase).  pz_module_phase_tuning_state reports how many call shapes
+ * have settled / are still measuring. */
+int pz_module_set_phase_tuning(pz_module* m, int enable);
+int pz_module_phase_tuning_state(pz_module* m, int* shapes_tuned, int* shapes_measuring);
+
+/* Debug: workspace guards.  With POULPY_DBG_CANARY=1 in the environment every segment the library carves out of its workspaces is
+ * followed by a 256-byte guard that is verified when the API call returns (the process aborts with a message on an overrun; HIP
+ * graphs are not used in this mode).  pz_debug_workspace_overrun carves two segments of `bytes` and writes `overrun` bytes past the
+ * end of the first one: the self-test of that mechanism (returns PZ_OK when the mode is off: nothing is checked then). */
+int pz_debug_workspace_overrun(pz_module* m, size_t bytes, size_t overrun);
+
 #ifdef __cplusplus
 }
 #endif

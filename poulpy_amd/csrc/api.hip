@@ -140,7 +140,7 @@ static std::vector<std::pair<void*, size_t>> g_host_allocs;   // pz_alloc_bytes 
 extern "C" {
 
 const char* pz_last_error(void) { return last_error_ref().c_str(); }
-uint32_t pz_abi_version(void) { return 2; }
+uint32_t pz_abi_version(void) { return 3; }   // 3: + pz_module_set_phase_tuning / _phase_tuning_state, pz_debug_workspace_overrun
 
 int pz_module_new_on_device(uint64_t n, int device, pz_module** out) {
     if (!out) return fail(PZ_ERR_INVALID, "null out");
@@ -249,7 +249,7 @@ void pz_module_free(pz_module* M) {
     if (M->comm) (void)pz_comm_destroy(M);
     for (auto& t : M->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
     for (auto e : M->event_pool) (void)hipEventDestroy(e);
-    for (auto& pt : M->phase_tune) { (void)hipEventDestroy(pt.e0); (void)hipEventDestroy(pt.e1); }
+    for (auto& pt : M->phase_tune) for (int i = 0; i < 8; ++i) { (void)hipEventDestroy(pt.e0[i]); (void)hipEventDestroy(pt.e1[i]); }
     for (auto& ge : M->graphs) {
         if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
         if (ge.graph) (void)hipGraphDestroy(ge.graph);
@@ -370,6 +370,33 @@ int pz_module_set_kernel_timing(pz_module* M, int enable) {
     M->timing = enable != 0;
     if (enable) for (int i = 0; i < PZ_KCLASS_COUNT; ++i) { M->cls_ms[i] = 0; M->cls_count[i] = 0; }
     return PZ_OK;
+}
+int pz_module_set_phase_tuning(pz_module* M, int enable) {
+    PZ_ENTER(M);
+    M->phase_tuning = enable != 0;
+    return PZ_OK;
+}
+int pz_module_phase_tuning_state(pz_module* M, int* shapes_tuned, int* shapes_measuring) {
+    PZ_ENTER(M);
+    int t = 0, u = 0;
+    for (auto& e : M->phase_tune) {
+        if (e.calls > 8 && e.pending == 0u && e.best >= 0) ++t; else ++u;
+    }
+    if (shapes_tuned) *shapes_tuned = t;
+    if (shapes_measuring) *shapes_measuring = u;
+    return PZ_OK;
+}
+int pz_debug_workspace_overrun(pz_module* M, size_t bytes, size_t overrun) {
+    PZ_ENTER(M);
+    const size_t seg = align256(bytes);
+    PZ_TRY(ws_reserve(M, 2 * seg));
+    char* base = (char*)M->ws;
+    char* s0; char* s1;
+    PZ_TRY(ws_take(M, base, seg, &s0));
+    PZ_TRY(ws_take(M, base, seg, &s1));
+    PZ_HIP(hipMemsetAsync(s0, 0x11, seg + overrun, M->stream));   // `overrun` bytes land behind the first segment
+    PZ_HIP(hipMemsetAsync(s1, 0x22, seg, M->stream));
+    return PZ_OK;   // the scope object of PZ_ENTER verifies the guards on the way out
 }
 int pz_module_get_kernel_stats(pz_module* M, int kclass, uint64_t* launches, double* total_ms) {
     PZ_ENTER(M);
@@ -697,9 +724,10 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
         const size_t key_bytes = fw.key, conv_bytes = fw.conv, t_bytes = fw.t, t2_bytes = fw.t2, rtmp_bytes = fw.rtmp, small2_bytes = fw.small2;
         PZ_TRY(ws_reserve(M, fw.total));
         char* base = (char*)M->ws;
-        cplx* Pp = (cplx*)base; base += key_bytes;
-        int64_t* a_conv = (int64_t*)base; base += conv_bytes;
-        cplx* T = (cplx*)base; base += t_bytes;
+        cplx* Pp; int64_t* a_conv; cplx* T;
+        PZ_TRY(ws_take(M, base, key_bytes, &Pp));
+        PZ_TRY(ws_take(M, base, conv_bytes, &a_conv));
+        PZ_TRY(ws_take(M, base, t_bytes, &T));
         // Placement of T2' relative to the result.  The tail of ciphertext b reads T2' + X and writes res + X and res + X + N*4 bytes
         // (the two coefficient halves), the same X for every workgroup; with both buffers on the same 1 MiB phase (large allocations
         // are 2 MiB aligned) the read and the two write streams of every workgroup meet on the same HBM channels: tail 3.55 ms per
@@ -718,54 +746,62 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
             if (hipStreamIsCapturing(M->stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusActive; }
             if (cs == hipStreamCaptureStatusNone) {
                 KeyHash kh;
-                kh.add((const void*)res); kh.add((const void*)a); kh.add(batch); kh.add(chunk); kh.add(npi); kh.add(npo); kh.add(*p); kh.add(ks);
-                kh.add(M->ws);
+                kh.add(batch); kh.add(chunk); kh.add(npi); kh.add(npo); kh.add(*p); kh.add(ks);
                 for (auto& e : M->phase_tune) if (e.key == kh.h) tune = &e;
                 if (!tune) {
                     if (M->phase_tune.size() >= 16) {
                         size_t lru = 0;
                         for (size_t i = 1; i < M->phase_tune.size(); ++i) if (M->phase_tune[i].stamp < M->phase_tune[lru].stamp) lru = i;
-                        (void)hipEventDestroy(M->phase_tune[lru].e0); (void)hipEventDestroy(M->phase_tune[lru].e1);
+                        for (int i = 0; i < 8; ++i) { (void)hipEventDestroy(M->phase_tune[lru].e0[i]); (void)hipEventDestroy(M->phase_tune[lru].e1[i]); }
                         M->phase_tune.erase(M->phase_tune.begin() + (long)lru);
                     }
-                    pz_module::PhaseTune e{kh.h, 0, 0, 1e30f, -1, nullptr, nullptr, 0};
-                    if (hipEventCreate(&e.e0) == hipSuccess && hipEventCreate(&e.e1) == hipSuccess) {
+                    pz_module::PhaseTune e{};
+                    e.key = kh.h; e.calls = 0; e.best = -1; e.best_ms = 1e30f; e.pending = 0u; e.stamp = 0;
+                    bool ok = true;
+                    for (int i = 0; i < 8 && ok; ++i) ok = hipEventCreate(&e.e0[i]) == hipSuccess && hipEventCreate(&e.e1[i]) == hipSuccess;
+                    if (ok) {
                         M->phase_tune.push_back(e);
                         tune = &M->phase_tune.back();
                     } else (void)hipGetLastError();
                 }
                 if (tune) {
+                    static_assert(kPhaseCount == 8, "one event pair per candidate");
                     tune->stamp = ++M->phase_clock;
-                    if (tune->pending >= 0) {   // the previous call's measurement
+                    // measurements that have completed since the last call (never waited for)
+                    for (int i = 0; i < kPhaseCount && tune->pending; ++i) {
+                        if (!(tune->pending & (1u << i))) continue;
+                        const hipError_t q = hipEventQuery(tune->e1[i]);
+                        if (q == hipErrorNotReady) { (void)hipGetLastError(); continue; }
                         float ms = 0.f;
-                        if (hipEventSynchronize(tune->e1) == hipSuccess && hipEventElapsedTime(&ms, tune->e0, tune->e1) == hipSuccess) {
-                            if (tune_env > 1) fprintf(stderr, "[phase tune] phase %#zx: %.3f ms\n", kPhase[tune->pending], ms);
-                            if (ms < tune->best_ms) { tune->best_ms = ms; tune->best = tune->pending; }
+                        if (q == hipSuccess && hipEventElapsedTime(&ms, tune->e0[i], tune->e1[i]) == hipSuccess) {
+                            if (tune_env > 1) fprintf(stderr, "[phase tune] phase %#zx: %.3f ms\n", kPhase[i], ms);
+                            if (ms < tune->best_ms) { tune->best_ms = ms; tune->best = i; }
                         } else (void)hipGetLastError();
-                        tune->pending = -1;
+                        tune->pending &= ~(1u << i);
                     }
                     // call 0 warms up (first touch of the workspace: not representative), calls 1 .. kPhaseCount try the candidates
                     // (under per-launch kernel timing nothing is measured: the instrumented pass uses what the plain calls found)
-                    if (M->timing) phase_idx = tune->calls > kPhaseCount ? tune->best : 0;
+                    if (M->timing) phase_idx = tune->best >= 0 ? tune->best : 0;
                     else if (tune->calls == 0) { phase_idx = 0; tune->calls = 1; }
                     else if (tune->calls <= kPhaseCount) { phase_idx = tune->calls - 1; tune_measure = true; }
-                    else phase_idx = tune->best;
+                    else phase_idx = tune->best >= 0 ? tune->best : 0;
                 }
             }
         }
         base += ((size_t)kPhase[phase_idx] - (size_t)(((uintptr_t)base - (uintptr_t)res) & 0x3FFFFF)) & 0x3FFFFF;
         base += align256(M->ws_shift);
-        cplx* T2 = (cplx*)base; base += t2_bytes;
-        int64_t* res_tmp = (int64_t*)base; base += rtmp_bytes;
-        int64_t* small2 = (int64_t*)base; base += small2_bytes;
-        cplx* mid_dummy = (cplx*)base;
+        cplx* T2; int64_t* res_tmp; int64_t* small2; cplx* mid_dummy;
+        PZ_TRY(ws_take(M, base, t2_bytes, &T2));
+        PZ_TRY(ws_take(M, base, rtmp_bytes, &res_tmp));
+        PZ_TRY(ws_take(M, base, small2_bytes, &small2));
+        PZ_TRY(ws_take(M, base, kMidDummyBytes, &mid_dummy));
         // the key arrives in the standard device layout; its row-sliced copy is rebuilt per call (2 x 128 MiB of
         // traffic at the metric shape, ~4 % of a 128-ciphertext call) so that no stale copy can ever be used
         bool pinned = false;
         for (auto& pk : M->pinned)
             if (pk.key == (const void*)pmat && pk.sliced && pk.bytes == (size_t)nrows * ncols * (size_t)M->n * 8) { Pp = pk.sliced; pinned = true; }
         if (!pinned && (M->dbg_stages & 2)) PZ_TRY(launch_permute_pmat(M, pmat, Pp, nrows * ncols));
-        if (tune_measure) PZ_HIP(hipEventRecord(tune->e0, M->stream));
+        if (tune_measure) PZ_HIP(hipEventRecord(tune->e0[phase_idx], M->stream));
         for (size_t b0 = 0; b0 < batch; b0 += chunk) {
             const int nb = (int)std::min(chunk, batch - b0);
             DV av{(void*)(a + (long long)b0 * a_bs), a_bs, s.cols_a, (int)p->a_size};
@@ -863,8 +899,8 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
             }
         }
         if (tune_measure) {
-            PZ_HIP(hipEventRecord(tune->e1, M->stream));
-            tune->pending = phase_idx;
+            PZ_HIP(hipEventRecord(tune->e1[phase_idx], M->stream));
+            tune->pending |= 1u << phase_idx;
             tune->calls++;
         }
         return PZ_OK;
@@ -884,10 +920,12 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
             const size_t conv_bytes = s.convert ? align256(chunk * n8 * s.cols_a * s.a_size_eff) : 0;
             const size_t tmp_bytes = cross_out ? align256(chunk * n8 * s.cols_out * ksz) : 0;
             PZ_TRY(ws_reserve(M, key_bytes + s_bytes + conv_bytes + tmp_bytes));
-            cplx* Pp = (cplx*)M->ws;
-            cplx* S = (cplx*)((char*)M->ws + key_bytes);
-            int64_t* a_conv = (int64_t*)((char*)M->ws + key_bytes + s_bytes);
-            int64_t* key_digits = (int64_t*)((char*)M->ws + key_bytes + s_bytes + conv_bytes);
+            char* sbase = (char*)M->ws;
+            cplx* Pp; cplx* S; int64_t* a_conv; int64_t* key_digits;
+            PZ_TRY(ws_take(M, sbase, key_bytes, &Pp));
+            PZ_TRY(ws_take(M, sbase, s_bytes, &S));
+            PZ_TRY(ws_take(M, sbase, conv_bytes, &a_conv));
+            PZ_TRY(ws_take(M, sbase, tmp_bytes, &key_digits));
             PZ_TRY(launch_small_permute(M, pmat, Pp, nrows * ncols));
             const bool small_rsh = want_rsh && au && au->mode != 0 && !cross_out && p->res_base2k <= 29;
             for (size_t b0 = 0; b0 < batch; b0 += chunk) {
@@ -921,12 +959,13 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
     const OpWs w = op_ws(M, p, s, chunk, ks, au != nullptr);
     PZ_TRY(ws_reserve(M, w.total));
     char* base = (char*)M->ws;
-    int64_t* a_conv = (int64_t*)base; base += w.a_conv;
-    double* a_dft = (double*)base; base += w.a_dft;
-    double* res_dft = (double*)base; base += w.res_dft;
-    double* tmp_dft = (double*)base; base += w.tmp_dft;
-    cplx* T = (cplx*)base; base += w.T;
-    int64_t* res_tmp = (int64_t*)base;
+    int64_t* a_conv; double* a_dft; double* res_dft; double* tmp_dft; cplx* T; int64_t* res_tmp;
+    PZ_TRY(ws_take(M, base, w.a_conv, &a_conv));
+    PZ_TRY(ws_take(M, base, w.a_dft, &a_dft));
+    PZ_TRY(ws_take(M, base, w.res_dft, &res_dft));
+    PZ_TRY(ws_take(M, base, w.tmp_dft, &tmp_dft));
+    PZ_TRY(ws_take(M, base, w.T, &T));
+    PZ_TRY(ws_take(M, base, w.res_tmp, &res_tmp));
 
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const int nb = (int)std::min(chunk, batch - b0);

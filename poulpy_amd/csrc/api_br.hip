@@ -77,10 +77,11 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
                 const size_t t_bytes = align256(batch * npi * (size_t)M->m * sizeof(cplx)), t2_bytes = align256(batch * npo * (size_t)M->m * sizeof(cplx));
                 PZ_TRY(ws_reserve(M, key_bytes + t_bytes + t2_bytes + kMidDummyBytes));
                 char* base = (char*)M->ws;
-                cplx* Pp = (cplx*)base; base += key_bytes;
-                cplx* T = (cplx*)base; base += t_bytes;
-                cplx* T2 = (cplx*)base; base += t2_bytes;
-                cplx* mid_dummy = (cplx*)base;
+                cplx* Pp; cplx* T; cplx* T2; cplx* mid_dummy;
+                PZ_TRY(ws_take(M, base, key_bytes, &Pp));
+                PZ_TRY(ws_take(M, base, t_bytes, &T));
+                PZ_TRY(ws_take(M, base, t2_bytes, &T2));
+                PZ_TRY(ws_take(M, base, kMidDummyBytes, &mid_dummy));
                 PolyMap sm{npi / cols, cols, res_ct, (long long)cols * n, n, 0};
                 for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {
                     PZ_TRY(launch_permute_pmat(M, brk + (size_t)b0 * pmat_doubles, Pp, blk * nrows_key * ncols_key));
@@ -104,8 +105,10 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
                 blk <= 64) {
                 const size_t s_bytes = align256(batch * npi * (size_t)M->m * sizeof(cplx)), a_bytes = align256(batch * ncols_key * (size_t)M->m * sizeof(cplx));
                 PZ_TRY(ws_reserve(M, s_bytes + a_bytes));
-                cplx* S = (cplx*)M->ws;
-                cplx* A = (cplx*)((char*)M->ws + s_bytes);
+                char* base = (char*)M->ws;
+                cplx* S; cplx* A;
+                PZ_TRY(ws_take(M, base, s_bytes, &S));
+                PZ_TRY(ws_take(M, base, a_bytes, &A));
                 PolyMap sm{npi / cols, cols, res_ct, (long long)cols * n, n, 0};
                 // the inverse kernel of a block also runs the forward transform of the new accumulator for the next block (POULPY_DBG_BR_SMALL=2:
                 // separate k_small_fwd launches), when its limbs are among the ones the inverse produces
@@ -129,10 +132,11 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
         const size_t t_bytes = align256(batch * tp * (size_t)M->m * sizeof(cplx));
         PZ_TRY(ws_reserve(M, acc_dft_bytes + 2 * vr_bytes + t_bytes));
         char* base = (char*)M->ws;
-        double* acc_dft = (double*)base; base += acc_dft_bytes;
-        double* vmp_res = (double*)base; base += vr_bytes;
-        double* acc_add = (double*)base; base += vr_bytes;
-        cplx* T = (cplx*)base;
+        double* acc_dft; double* vmp_res; double* acc_add; cplx* T;
+        PZ_TRY(ws_take(M, base, acc_dft_bytes, &acc_dft));
+        PZ_TRY(ws_take(M, base, vr_bytes, &vmp_res));
+        PZ_TRY(ws_take(M, base, vr_bytes, &acc_add));
+        PZ_TRY(ws_take(M, base, t_bytes, &T));
         DV ad{acc_dft, n * cols * dnum, cols, dnum}, vr{vmp_res, n * cols * bsz, cols, bsz}, aa{acc_add, n * cols * bsz, cols, bsz};
         const bool tail = M->fuse_tail && tail_supported(M);
         for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {  // chunks_exact: a trailing partial block is ignored, as in the reference

@@ -227,12 +227,14 @@ int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, c
     const size_t s_tmp = align256(chunk * t.tmp), s_dg = align256(chunk * t.diag), s_T = align256(chunk * t.T);
     PZ_TRY(ws_reserve(M, s_pa + s_pb + s_rd + s_tmp + s_dg + s_T));
     char* base = (char*)M->ws;
-    double* pa = (double*)base; base += s_pa;
-    double* pb = square ? pa : (double*)base; base += s_pb;     // convolution.rs:134-138: right = left for FFT64
-    double* rd = (double*)base; base += s_rd;
-    int64_t* tmp = (int64_t*)base; base += s_tmp;
-    int64_t* diag = (int64_t*)base; base += s_dg;
-    cplx* T = (cplx*)base;
+    double* pa; double* pb; double* rd; int64_t* tmp; int64_t* diag; cplx* T;
+    PZ_TRY(ws_take(M, base, s_pa, &pa));
+    PZ_TRY(ws_take(M, base, s_pb, &pb));
+    if (square) pb = pa;                                        // convolution.rs:134-138: right = left for FFT64
+    PZ_TRY(ws_take(M, base, s_rd, &rd));
+    PZ_TRY(ws_take(M, base, s_tmp, &tmp));
+    PZ_TRY(ws_take(M, base, s_dg, &diag));
+    PZ_TRY(ws_take(M, base, s_T, &T));
     const long long a_ct = n * t.cols * t.a_size, b_ct = n * t.cols * t.b_size, r_ct = n * t.tcols * t.res_size;
     const long long pa_bs = n * t.cols * t.a_size, pb_bs = n * t.cols * t.b_size, rd_bs = n * std::max(t.dft_size, 1), tmp_bs = n * t.res_size;
     const long long dg_bs = n * t.cols * t.res_size;

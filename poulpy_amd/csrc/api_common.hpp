@@ -114,10 +114,18 @@ static inline int finish_call(pz_module* M, bool any_host) {
     return PZ_OK;
 }
 
+// verifies the workspace guards of the call when it returns, by whatever path (POULPY_DBG_CANARY; no-op otherwise)
+struct CanaryScope {
+    pz_module* M;
+    const char* fn;
+    CanaryScope(pz_module* M_, const char* fn_) : M(M_), fn(fn_) { if (canary_mode()) M->guards.clear(); }
+    ~CanaryScope() { if (canary_mode()) canary_verify(M, fn); }
+};
 #define PZ_ENTER(M)                                              \
     if (!(M)) return fail(PZ_ERR_INVALID, "null module");        \
     std::lock_guard<std::mutex> lock_((M)->mu);                  \
     PZ_HIP(hipSetDevice((M)->device));                           \
+    CanaryScope canary_((M), __func__);                          \
     arena_reset(M);
 
 static inline size_t vbytes(const pz_module* M, size_t cols, size_t size) { return (size_t)M->n * cols * size * 8; }

@@ -491,8 +491,10 @@ int pz_vmp_apply_dft(pz_module* M, double* res, size_t res_cols, size_t res_size
     const size_t sz = std::min(a_size, rows);
     const size_t adft_bytes = vbytes(M, cols_in, sz);
     PZ_TRY(ws_reserve(M, adft_bytes + sz * a_cols * M->m * sizeof(cplx)));
-    double* adft = (double*)M->ws;
-    cplx* T = (cplx*)((char*)M->ws + adft_bytes);
+    char* wbase = (char*)M->ws;
+    double* adft; cplx* T;
+    PZ_TRY(ws_take(M, wbase, adft_bytes, &adft));
+    PZ_TRY(ws_take(M, wbase, sz * a_cols * M->m * sizeof(cplx), &T));
     PZ_HIP(hipMemsetAsync(adft, 0, adft_bytes, M->stream));
     DV dad{adft, 0, (int)cols_in, (int)sz}, da{sa.dev, 0, (int)a_cols, (int)a_size};
     PZ_TRY(dev_dft_apply(M, 1, 1, 0, dad, (int)(cols_in - a_cols), da, 0, (int)a_cols, nullptr, T));

@@ -168,8 +168,10 @@ int pz_lwe_keyswitch_batched(pz_module* M, int64_t* res, size_t res_n_lwe, const
     const size_t n = M->n;
     const size_t in_b = align256(batch * n * 2 * p->a_size * 8), out_b = align256(batch * n * 2 * p->res_size * 8);
     PZ_TRY(ws2_reserve(M, in_b + out_b));
-    long long* glwe_in = (long long*)M->ws2;
-    long long* glwe_out = (long long*)((char*)M->ws2 + in_b);
+    char* wbase = (char*)M->ws2;
+    long long* glwe_in; long long* glwe_out;
+    PZ_TRY(ws_take(M, wbase, in_b, &glwe_in));
+    PZ_TRY(ws_take(M, wbase, out_b, &glwe_out));
     PZ_TRY(launch_lwe_embed(M, glwe_in, (int)p->a_size, (const long long*)a, (int)a_n_lwe, (int)p->a_size, (int)p->a_size, batch));
     PZ_TRY(glwe_keyswitch_nolock(M, (int64_t*)glwe_out, (const int64_t*)glwe_in, ksk_pmat, p, batch));
     return launch_lwe_extract(M, (long long*)res, (int)res_n_lwe, (int)p->res_size, glwe_out, 2, (int)p->res_size, batch);
@@ -191,12 +193,14 @@ int pz_glwe_from_lwe_batched(pz_module* M, int64_t* res, const int64_t* lwe, siz
     PZ_REQUIRE(!same || lwe_size <= gsz, "glwe_from_lwe: %zu LWE limbs do not fit the %zu limbs of the embedded GLWE", lwe_size, gsz);
     const size_t g_b = align256(batch * n * 2 * gsz * 8), c_b = same ? 0 : align256(batch * n * 2 * lwe_size * 8);
     PZ_TRY(ws2_reserve(M, g_b + c_b));
-    long long* glwe = (long long*)M->ws2;
+    char* wbase = (char*)M->ws2;
+    long long* glwe; long long* conv;
+    PZ_TRY(ws_take(M, wbase, g_b, &glwe));
+    PZ_TRY(ws_take(M, wbase, c_b, &conv));
     if (same) {
         PZ_TRY(launch_lwe_embed(M, glwe, (int)gsz, (const long long*)lwe, (int)n_lwe, (int)lwe_size, (int)lwe_size, batch));
     } else {
         // :82-116: each column embedded in the LWE's base, then vec_znx_normalize into the key's base
-        long long* conv = (long long*)((char*)M->ws2 + g_b);
         PZ_TRY(launch_lwe_embed(M, conv, (int)lwe_size, (const long long*)lwe, (int)n_lwe, (int)lwe_size, (int)lwe_size, batch));
         DV dg{glwe, (long long)(n * 2 * gsz), 2, (int)gsz}, dc{conv, (long long)(n * 2 * lwe_size), 2, (int)lwe_size};
         for (int c = 0; c < 2; ++c) PZ_TRY(dev_normalize(M, (int)batch, dg, (int)p->key_base2k, 0, c, dc, (int)lwe_base2k, c));
@@ -218,14 +222,16 @@ int pz_lwe_from_glwe_batched(pz_module* M, int64_t* res, size_t res_n_lwe, const
     const size_t in_b = a_idx ? align256(batch * n * cols * p->a_size * 8) : 0, out_b = align256(batch * n * 2 * p->res_size * 8);
     PZ_TRY(ws2_reserve(M, in_b + out_b));
     const long long* src = (const long long*)a;
+    char* wbase = (char*)M->ws2;
+    long long* rot; long long* glwe1;
+    PZ_TRY(ws_take(M, wbase, in_b, &rot));
+    PZ_TRY(ws_take(M, wbase, out_b, &glwe1));
     if (a_idx) {
-        long long* rot = (long long*)M->ws2;
         const int npolys = (int)(batch * cols * p->a_size);
         PolyMap mp{1, 1, (long long)n, 0, 0, 0};
         PZ_TRY(launch_rotate(M, npolys, src, mp, rot, mp, 0, 1, nullptr, 0, 0, -(long long)a_idx));
         src = rot;
     }
-    long long* glwe1 = (long long*)((char*)M->ws2 + in_b);
     PZ_TRY(glwe_keyswitch_nolock(M, (int64_t*)glwe1, (const int64_t*)src, ksk_pmat, p, batch));
     return launch_lwe_extract(M, (long long*)res, (int)res_n_lwe, (int)p->res_size, glwe1, 2, (int)p->res_size, batch);
 }

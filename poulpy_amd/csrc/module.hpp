@@ -171,10 +171,18 @@ struct pz_module {
     unsigned long long graph_launches = 0;
     // Placement of T2' relative to the result buffer (api.hip, fused pipeline): after a warm-up call, kPhaseCount calls with a given argument
     // set each try one phase and time the middle kernel + tail with events; later calls use the best one.
-    struct PhaseTune { uint64_t key; int calls; int best; float best_ms; int pending; hipEvent_t e0, e1; uint64_t stamp; };
+    // (round 3: keyed on the SHAPE of the call only - the placement is relative to the result buffer, so a caller that rotates its
+    //  buffers keeps its tuning - and never waits: call 0 warms up, calls 1..8 each run one candidate between their own event pair,
+    //  later calls read whichever pairs have completed (hipEventQuery) and use the best measured so far)
+    struct PhaseTune { uint64_t key; int calls; int best; float best_ms; unsigned pending; hipEvent_t e0[8], e1[8]; uint64_t stamp; };
     std::vector<PhaseTune> phase_tune;
     uint64_t phase_clock = 0;
     bool phase_tuning = true;
+    // POULPY_DBG_CANARY=1 (debug; tests/conftest.py runs the GPU suite with it once): a 256-byte guard behind every segment carved out
+    // of the workspaces and behind the end of every reservation, armed on the module stream when it is carved and verified when the
+    // API call returns (canary_verify, from PZ_ENTER's scope object).  An overrun into the slack between segments stays bit-exact
+    // and therefore invisible to the parity tests (the spectral automorphism's body operand).
+    std::vector<void*> guards;
 };
 
 namespace pz {
@@ -203,27 +211,83 @@ struct KTimer {
     }
 };
 
-inline int ws_reserve(pz_module* M, size_t bytes) {
-    if (bytes <= M->ws_bytes) return PZ_OK;
-    PZ_HIP(hipStreamSynchronize(M->stream));
-    if (M->ws) PZ_HIP(hipFree(M->ws));
-    M->ws = nullptr;
-    M->ws_bytes = 0;
-    size_t want = bytes + (bytes >> 3);
-    PZ_HIP(hipMalloc(&M->ws, want));
-    M->ws_bytes = want;
+constexpr size_t kGuardBytes = 256;
+constexpr size_t kGuardSlack = 64 * kGuardBytes;   // room for the guards of a call's segments: part of every reservation
+constexpr unsigned char kGuardByte = 0xC5;
+inline bool canary_mode() {
+    static const bool on = getenv("POULPY_DBG_CANARY") && atoi(getenv("POULPY_DBG_CANARY")) != 0;
+    return on;
+}
+// arms a guard at p (canary mode only)
+inline int guard_arm(pz_module* M, void* p) {
+    if (!canary_mode()) return PZ_OK;
+    PZ_HIP(hipMemsetAsync(p, kGuardByte, kGuardBytes, M->stream));
+    M->guards.push_back(p);
     return PZ_OK;
+}
+// One segment of `bytes` at `base`; in canary mode a guard sits right behind it (and the next segment starts behind the guard).
+// Call sites reserve kGuardSlack on top of the sum of their segments (ws_reserve does it for them).
+template <typename T>
+inline int ws_take(pz_module* M, char*& base, size_t bytes, T** out) {
+    *out = reinterpret_cast<T*>(base);
+    base += bytes;
+    if (canary_mode() && bytes) {
+        PZ_TRY(guard_arm(M, base));
+        base += kGuardBytes;
+    }
+    return PZ_OK;
+}
+// verifies and clears the guards armed since the call started; aborts loudly on an overrun (debug mode only)
+inline void canary_verify(pz_module* M, const char* where, const void* lo = nullptr, const void* hi = nullptr) {
+    if (M->guards.empty()) return;
+    std::vector<void*> gs, keep;
+    for (void* g : M->guards) ((lo == nullptr || ((const char*)g >= (const char*)lo && (const char*)g < (const char*)hi)) ? gs : keep).push_back(g);
+    M->guards.swap(keep);
+    if (gs.empty()) return;
+    if (hipStreamSynchronize(M->stream) != hipSuccess) { (void)hipGetLastError(); return; }
+    unsigned char host[kGuardBytes];
+    for (void* g : gs) {
+        if (hipMemcpy(host, g, kGuardBytes, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); continue; }
+        for (size_t i = 0; i < kGuardBytes; ++i)
+            if (host[i] != kGuardByte) {
+                fprintf(stderr, "[poulpy_hip] WORKSPACE OVERRUN in %s: guard at %p (ws %p + %zu, ws2 %p) byte %zu = %#x\n", where, g, M->ws,
+                        (size_t)((char*)g - (char*)M->ws), M->ws2, i, (unsigned)host[i]);
+                fflush(stderr);
+                abort();
+            }
+    }
+}
+
+inline int ws_reserve(pz_module* M, size_t bytes) {
+    // a new carve: the guards of the previous one (a composite call carves the workspace several times, with different layouts) are
+    // verified now, before their bytes become someone else's segment
+    if (canary_mode() && M->ws) canary_verify(M, "a workspace segment carved earlier in this call", M->ws, (char*)M->ws + M->ws_bytes);
+    const size_t need = bytes + kGuardSlack;
+    if (need > M->ws_bytes) {
+        PZ_HIP(hipStreamSynchronize(M->stream));
+        if (M->ws) PZ_HIP(hipFree(M->ws));
+        M->ws = nullptr;
+        M->ws_bytes = 0;
+        size_t want = need + (need >> 3);
+        PZ_HIP(hipMalloc(&M->ws, want));
+        M->ws_bytes = want;
+    }
+    // the end of what this call asked for (+ the room of its inner guards): nothing may be written from here on
+    return guard_arm(M, (char*)M->ws + need - kGuardBytes);
 }
 
 inline int ws2_reserve(pz_module* M, size_t bytes) {
-    if (bytes <= M->ws2_bytes) return PZ_OK;
-    PZ_HIP(hipStreamSynchronize(M->stream));
-    if (M->ws2) PZ_HIP(hipFree(M->ws2));
-    M->ws2 = nullptr;
-    M->ws2_bytes = 0;
-    PZ_HIP(hipMalloc(&M->ws2, bytes));
-    M->ws2_bytes = bytes;
-    return PZ_OK;
+    if (canary_mode() && M->ws2) canary_verify(M, "a workspace segment (ws2) carved earlier in this call", M->ws2, (char*)M->ws2 + M->ws2_bytes);
+    const size_t need = bytes + kGuardSlack;
+    if (need > M->ws2_bytes) {
+        PZ_HIP(hipStreamSynchronize(M->stream));
+        if (M->ws2) PZ_HIP(hipFree(M->ws2));
+        M->ws2 = nullptr;
+        M->ws2_bytes = 0;
+        PZ_HIP(hipMalloc(&M->ws2, need));
+        M->ws2_bytes = need;
+    }
+    return guard_arm(M, (char*)M->ws2 + need - kGuardBytes);
 }
 
 inline void arena_reset(pz_module* M) {

@@ -52,6 +52,7 @@ class GlweTensorParams(C.Structure):
 
 
 _lib = None
+PZ_ABI_VERSION = 3   # pz_abi_version() of include/poulpy_hip.h this mirror was written against
 
 
 def load_library(path: str | None = None) -> C.CDLL:
@@ -67,6 +68,9 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib = C.CDLL(p)
     lib.pz_last_error.restype = C.c_char_p
     lib.pz_abi_version.restype = C.c_uint32
+    if lib.pz_abi_version() != PZ_ABI_VERSION:   # struct layouts and entry points of this mirror belong to ONE generation of the header
+        raise PoulpyHipError(f"{p} has ABI version {lib.pz_abi_version()}, poulpy_amd/hal.py mirrors version {PZ_ABI_VERSION} "
+                             "(a stale or variant build: rebuild with __graft_entry__.build())")
     lib.pz_module_n.restype = c_uint64
     lib.pz_alloc_bytes.restype = c_void_p
     lib.pz_alloc_bytes.argtypes = [c_size_t]
@@ -205,6 +209,16 @@ class Module:
 
     KERNEL_CLASSES = ("fwd_pass1", "fwd_pass2", "vmp", "inv_pass2", "inv_pass1", "normalize", "elementwise", "fused_mid",
                       "fused_tail")
+
+    def set_phase_tuning(self, enable: bool):
+        """Measured (default) or fixed placement of the fused pipeline's second intermediate (include/poulpy_hip.h)."""
+        self._ck(self.lib.pz_module_set_phase_tuning(self.handle, c_int(1 if enable else 0)))
+
+    def phase_tuning_state(self) -> tuple:
+        """(call shapes whose placement has settled, call shapes still measuring)."""
+        t, u = c_int(0), c_int(0)
+        self._ck(self.lib.pz_module_phase_tuning_state(self.handle, C.byref(t), C.byref(u)))
+        return int(t.value), int(u.value)
 
     def set_kernel_timing(self, enable: bool):
         self._ck(self.lib.pz_module_set_kernel_timing(self.handle, c_int(1 if enable else 0)))

@@ -32,41 +32,105 @@ pub use ffi::{pz_blind_rotation_params, pz_circuit_bootstrapping_params, pz_glwe
 #[derive(Debug, Clone, Copy)]
 pub struct FFT64Hip;
 
+/// ABI generation of include/poulpy_hip.h this crate was generated against (`pz_abi_version()`); checked when a handle is created:
+/// a stale or variant libpoulpy_hip.so would otherwise be handed structs of another layout.
+pub const PZ_ABI_VERSION: u32 = 3;
+
+/// The sibling modules (`pz_module_clone`: own stream, workspaces and lock; shared immutable tables) that threads other than the
+/// creating one run on.  A thread LEASES one on its first call and returns it when it exits (thread-local destructor), so the pool
+/// is bounded by the largest number of threads that were alive at the same time — poulpy-bin-fhe spawns scoped threads on every
+/// evaluation (bdd_arithmetic/eval.rs:210-221) and thread ids are never reused: a map keyed by thread id would grow, each sibling
+/// holding a stream and grow-only workspaces, until the device runs out of memory.
+struct SiblingPool {
+    free: std::sync::Mutex<Vec<usize>>, // siblings no live thread holds
+    all: std::sync::Mutex<Vec<usize>>,  // every sibling ever cloned: freed with the handle
+    closed: std::sync::atomic::AtomicBool,
+}
+
+/// One thread's hold on a sibling of one handle; dropped by the thread-local destructor when the thread exits.
+struct Lease {
+    pool: std::sync::Arc<SiblingPool>,
+    handle_id: u64,
+    module: usize,
+}
+impl Drop for Lease {
+    fn drop(&mut self) {
+        if !self.pool.closed.load(std::sync::atomic::Ordering::Acquire) {
+            self.pool.free.lock().unwrap().push(self.module);
+        }
+    }
+}
+thread_local! {
+    static LEASES: std::cell::RefCell<Vec<Lease>> = const { std::cell::RefCell::new(Vec::new()) };
+}
+static NEXT_HANDLE_ID: std::sync::atomic::AtomicU64 = std::sync::atomic::AtomicU64::new(1);
+
 /// `Backend::Handle`: owns the C module and the siblings other threads use.  Calls on one C module are serialized inside the library (one
 /// HIP stream per module); `&Module<FFT64Hip>` is `Sync` like the CPU backends (`unsafe impl Sync for Module`, poulpy-hal/src/layouts/
-/// module.rs:103-104) and threads other than the creating one run on their own sibling module (`pz_module_clone`).
+/// module.rs:103-104) and threads other than the creating one run on a sibling module leased from a bounded pool.
 pub struct FFT64HipHandle {
     pub(crate) raw: *mut ffi::pz_module,
-    /// the thread that created the module uses `raw`; every other thread gets a sibling on first use (freed with the handle)
+    /// the thread that created the module uses `raw`
     owner: std::thread::ThreadId,
-    siblings: std::sync::Mutex<std::collections::HashMap<std::thread::ThreadId, usize>>,
+    /// unique per handle (a freed handle's address may be reused: leases are matched on this, never on the pointer)
+    id: u64,
+    pool: std::sync::Arc<SiblingPool>,
 }
 unsafe impl Send for FFT64HipHandle {}
 unsafe impl Sync for FFT64HipHandle {}
 
 impl FFT64HipHandle {
     pub(crate) fn new(raw: *mut ffi::pz_module) -> Self {
-        Self { raw, owner: std::thread::current().id(), siblings: std::sync::Mutex::new(std::collections::HashMap::new()) }
+        let v = unsafe { ffi::pz_abi_version() };
+        assert_eq!(v, PZ_ABI_VERSION, "libpoulpy_hip.so has ABI version {v}, this crate was generated for {PZ_ABI_VERSION}");
+        Self {
+            raw,
+            owner: std::thread::current().id(),
+            id: NEXT_HANDLE_ID.fetch_add(1, std::sync::atomic::Ordering::Relaxed),
+            pool: std::sync::Arc::new(SiblingPool {
+                free: std::sync::Mutex::new(Vec::new()),
+                all: std::sync::Mutex::new(Vec::new()),
+                closed: std::sync::atomic::AtomicBool::new(false),
+            }),
+        }
     }
 
     /// The C module for the calling thread (see `hal_impl::raw`).
     pub(crate) fn for_this_thread(&self) -> *mut ffi::pz_module {
-        let me = std::thread::current().id();
-        if me == self.owner {
+        if std::thread::current().id() == self.owner {
             return self.raw;
         }
-        let mut map = self.siblings.lock().unwrap();
-        if let Some(p) = map.get(&me) {
-            return *p as *mut ffi::pz_module;
-        }
-        let mut sib: *mut ffi::pz_module = std::ptr::null_mut();
-        ffi::check(unsafe { ffi::pz_module_clone(self.raw, &mut sib) }, "pz_module_clone");
-        map.insert(me, sib as usize);
-        sib
+        LEASES.with(|cell| {
+            let mut leases = cell.borrow_mut();
+            // leases of handles that have been destroyed meanwhile are dropped here (their modules are gone with the handle)
+            leases.retain(|l| !l.pool.closed.load(std::sync::atomic::Ordering::Acquire));
+            if let Some(l) = leases.iter().find(|l| l.handle_id == self.id) {
+                return l.module as *mut ffi::pz_module;
+            }
+            let reused = self.pool.free.lock().unwrap().pop();
+            let module = match reused {
+                Some(m) => m,
+                None => {
+                    let mut sib: *mut ffi::pz_module = std::ptr::null_mut();
+                    ffi::check(unsafe { ffi::pz_module_clone(self.raw, &mut sib) }, "pz_module_clone");
+                    self.pool.all.lock().unwrap().push(sib as usize);
+                    sib as usize
+                }
+            };
+            leases.push(Lease { pool: self.pool.clone(), handle_id: self.id, module });
+            module as *mut ffi::pz_module
+        })
+    }
+
+    /// Number of sibling modules created so far (bounded by the peak number of concurrently live threads; for tests).
+    pub fn sibling_count(&self) -> usize {
+        self.pool.all.lock().unwrap().len()
     }
 
     fn free_all(&self) {
-        for (_, p) in self.siblings.lock().unwrap().drain() {
+        self.pool.closed.store(true, std::sync::atomic::Ordering::Release);
+        self.pool.free.lock().unwrap().clear();
+        for p in self.pool.all.lock().unwrap().drain(..) {
             unsafe { ffi::pz_module_free(p as *mut ffi::pz_module) }
         }
         unsafe { ffi::pz_module_free(self.raw) }

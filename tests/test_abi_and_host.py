@@ -38,7 +38,8 @@ def test_header_declares_hot_path_entry_points():
 def test_library_exports_every_declared_symbol(lib):
     missing = [s for s in _declared_symbols() if not hasattr(lib, s)]
     assert not missing, f"declared in include/poulpy_hip.h but not exported: {missing}"
-    assert lib.pz_abi_version() >= 1
+    from poulpy_amd.hal import PZ_ABI_VERSION
+    assert lib.pz_abi_version() == PZ_ABI_VERSION
 
 
 def test_byte_sizes_match_reference_formulas(lib):

@@ -4,6 +4,8 @@ Mirrors the reference's cross-backend HAL suite (poulpy-hal/src/test_suite/{vec_
 vec_znx_big}.rs): DFT-domain values are never compared; results are pushed through
 idft + normalize and the final i64 limbs must be IDENTICAL (bit-exact).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1581,7 +1583,8 @@ def test_composite_calls_replay_as_hip_graphs(mods):
             res = VecZnx(n, cols, rsz)
             ref.blind_rotation_execute(res, k, np.ascontiguousarray(lwe[b]), lut, brk_r, dnum, bsz, blk, xpa)
             assert np.array_equal(got[b], res.data), (it, b)
-    assert hip.graph_launches() - before >= 2, "the repeated call was never served by a graph"
+    if os.environ.get("POULPY_DBG_CANARY") != "1":   # (the workspace-guard mode runs every call plainly: a replay would not re-arm the guards)
+        assert hip.graph_launches() - before >= 2, "the repeated call was never served by a graph"
     # switched off: plain launches again, same results
     hip.set_graphs(False)
     mid = hip.graph_launches()

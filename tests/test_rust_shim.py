@@ -209,3 +209,72 @@ def test_lib_znx_and_tests_rs():
     for f in ("lib.rs", "znx.rs", "tests.rs"):
         c = strip_rust_comments(read(CRATE, "src", f))
         assert c.count("{") == c.count("}") and c.count("(") == c.count(")"), f
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 3 (VERDICT r02 item 6 / ADVICE r02): the DEFAULT feature set must compile against the untouched reference.
+
+
+def _strip_ks_fused_blocks(src):
+    """core_impl.rs without the bodies that exist only under `#[cfg(feature = "ks-fused")]` (brace-matched)."""
+    out, i = [], 0
+    tag = '#[cfg(feature = "ks-fused")]'
+    while True:
+        j = src.find(tag, i)
+        if j < 0:
+            out.append(src[i:])
+            return "".join(out)
+        out.append(src[i:j])
+        k = src.index("{", j)
+        depth, p = 0, k
+        while True:
+            if src[p] == "{":
+                depth += 1
+            elif src[p] == "}":
+                depth -= 1
+                if depth == 0:
+                    break
+            p += 1
+        i = p + 1
+
+
+def test_default_features_only_touch_public_items_of_the_reference():
+    cargo = read(CRATE, "Cargo.toml")
+    feats = cargo[cargo.index("[features]"):]
+    assert re.search(r'^default\s*=\s*\["core-fused"\]', feats, flags=re.M)
+    assert re.search(r'^ks-fused\s*=\s*\["core-fused"\]', feats, flags=re.M)
+    assert "ks-fused" not in re.search(r'^default\s*=.*$', feats, flags=re.M).group(0)
+    assert os.path.exists(os.path.join(ROOT, "rust", "patches", "gglwe_prepared_data.patch"))
+    core = strip_rust_comments(read(CRATE, "src", "core_impl.rs"))
+    default_src = _strip_ks_fused_blocks(core)
+    # a GGLWEPrepared's VmpPMat has no public accessor upstream (poulpy-core/src/layouts/prepared/gglwe.rs:20): the default build
+    # must not reach for it; the key of every forward that remains is a GGSWPrepared (`g`), whose `data()` is public
+    assert "k.data()" not in default_src
+    assert "k.data()" in core                                             # ... and the gated forwards are still there
+    assert default_src.count("g.data().as_ptr()") >= 6                    # glwe / gglwe / ggsw external product (+ _assign)
+    for name in ("glwe_keyswitch", "glwe_keyswitch_assign", "gglwe_keyswitch", "gglwe_keyswitch_assign", "glwe_automorphism",
+                 "glwe_automorphism_add_assign", "glwe_automorphism_sub_negate"):
+        assert f"::{name}_default(" in default_src, name                  # without the feature: the reference algorithm
+    if os.path.isdir(REF):
+        ggsw = read(REF, "poulpy-core", "src", "layouts", "prepared", "ggsw.rs")
+        gglwe = read(REF, "poulpy-core", "src", "layouts", "prepared", "gglwe.rs")
+        assert re.search(r"pub fn data\(&self\)", ggsw)
+        assert not re.search(r"pub fn data\(&self\)", gglwe) and "pub(crate) data" in gglwe   # the reason for the feature split
+        # every inherent method the default build calls on a prepared key / layout view is `pub` in the reference
+        for meth, files in (("data", ("layouts/prepared/ggsw.rs",)), ("at", ("layouts/gglwe.rs", "layouts/ggsw.rs")),
+                            ("at_mut", ("layouts/gglwe.rs", "layouts/ggsw.rs"))):
+            assert any(re.search(r"pub fn %s\b" % meth, read(REF, "poulpy-core", "src", f)) for f in files), meth
+
+
+def test_sibling_modules_are_leased_from_a_bounded_pool():
+    """no grow-only map keyed by ThreadId; a sibling goes back to the pool when its thread exits."""
+    lib = strip_rust_comments(read(CRATE, "src", "lib.rs"))
+    assert "HashMap<std::thread::ThreadId" not in lib and "HashMap<ThreadId" not in lib
+    assert "struct SiblingPool" in lib and "struct Lease" in lib and "impl Drop for Lease" in lib
+    assert "thread_local!" in lib
+    assert re.search(r"self\.pool\.free\.lock\(\)\.unwrap\(\)\.pop\(\)", lib)        # reuse before cloning
+    assert lib.count("ffi::pz_module_clone(") == 1
+    assert "pz_abi_version()" in lib and "PZ_ABI_VERSION" in lib                     # checked when a handle is made
+    from poulpy_amd.hal import PZ_ABI_VERSION
+    assert re.search(r"pub const PZ_ABI_VERSION: u32 = (\d+);", lib).group(1) == str(PZ_ABI_VERSION)
+    assert re.search(r"pz_abi_version\(void\) \{ return (\d+); \}", read(ROOT, "poulpy_amd", "csrc", "api.hip")).group(1) == str(PZ_ABI_VERSION)

@@ -431,9 +431,11 @@ def core_main(ref: str):
 //!     takes host containers (staged H2D / D2H) and keeps a device mirror of host-resident prepared keys (include/poulpy_hip.h).
 //!   * every other method of these three families: `Core*Defaults` (the reference algorithm on top of this backend's HalImpl);
 //!   * the remaining families: the reference's own `impl_core_*_default_methods!` macros, unchanged.
-//! NOTE: `GGLWEPrepared` has no public accessor for its `VmpPMat` (poulpy-core/src/layouts/prepared/gglwe.rs:20 is `pub(crate)`,
-//! unlike `GGSWPrepared::data()`, prepared/ggsw.rs:177); the key-switch forwards below need that one-line accessor upstream
-//! (INTEGRATION.md).
+//! Features: `core-fused` (default) compiles against the UNTOUCHED reference: it forwards the forms whose key is a `GGSWPrepared`
+//! (`GGSWPrepared::data()` is public, prepared/ggsw.rs:177) - glwe / gglwe / ggsw external products.  `GGLWEPrepared` has no public
+//! accessor for its `VmpPMat` (prepared/gglwe.rs:20 is `pub(crate)`), so the key-switch and automorphism forwards are compiled only
+//! under the non-default feature `ks-fused`, which needs rust/patches/gglwe_prepared_data.patch applied to poulpy-core; without it
+//! those methods run `Core*Defaults` (the reference algorithm over this backend's HalImpl).
 #![allow(clippy::too_many_arguments)]
 use poulpy_core::{
     ScratchTakeCore,
@@ -473,7 +475,16 @@ unsafe impl CoreImpl<FFT64Hip> for FFT64Hip {
             h = re.sub(r"\bBE\b", "Self", h)
             h = re.sub(r"#\[allow\([^\]]*\)\]\s*", "", h)
             out.append("    " + h.strip() + (" {" if "where" not in h else "\n    {"))
-            if name in CORE_FORWARD:
+            if name in CORE_FORWARD and "k.data()" in CORE_FORWARD[name]:
+                # the key of these forms is a GGLWEPrepared, whose VmpPMat has no public accessor upstream (prepared/gglwe.rs:20):
+                # forwarded only under the non-default feature `ks-fused` (rust/patches/gglwe_prepared_data.patch)
+                out.append('        #[cfg(feature = "ks-fused")]\n        {')
+                out.append(_indent(CORE_FORWARD[name]))
+                out.append('        }\n        #[cfg(not(feature = "ks-fused"))]\n        {')
+                out.append(f"            <Self as {tr}<Self>>::{name}_default({', '.join(args)})")
+                out.append("        }")
+                n_fwd += 1
+            elif name in CORE_FORWARD:
                 out.append(CORE_FORWARD[name])
                 n_fwd += 1
             else:
