@@ -512,6 +512,19 @@ def main():
                         "algorithmic_bytes_per_unit": b_unit,
                         "pipeline_achieved": value * (DNUM if expand else 1) / world * b_unit / 1e9,
                         "kernel_ms": {k: round(v[1], 3) for k, v in stats.items() if v[0]}}
+        # the whole call against the three ceilings that can bound it (tools/roofline_models.py), with the kernel instantiation that ran
+        ceilings = None
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import roofline_models as rm
+            notes = mod.dispatch_notes()
+            unit_model = rm.glwe_op(N, cols_in, cols, SIZE, SIZE, DNUM, args.batch, a_cols=a_cols, extra_in_polys=(SIZE if auto_mode == "add" else 0))
+            per_unit = (DNUM * RANK_GLWE if expand else (N.bit_length() - 1) if trace else 1)   # key switches inside one unit
+            model = {k: unit_model[k] * per_unit for k in ("hbm_bytes", "flops", "key_stream_bytes")}
+            ceilings = rm.roofline(value / world, model, rm.key_share(notes) if "k_mid" in notes else 1)
+            ceilings["dispatch"] = notes
+        except Exception as e:   # reporting only
+            ceilings = {"error": str(e)}
         line = {
             "metric": (f"GLWE tensor relinearizations/sec (N=2^{N.bit_length() - 1}, {SIZE} limbs)" if relin else
                        f"GGSW expand-rows/sec (N=2^{N.bit_length() - 1}, {SIZE} limbs, {DNUM} rows)" if expand else
@@ -531,6 +544,7 @@ def main():
                        "rccl_ranks": rccl_ranks,
                        "output_digits_balanced": ok, "setup_calls": setup_calls},
             "roofline": roof,
+            "ceilings": ceilings,
             "placement": placement,
             "parity_sample": parity,
         }

@@ -653,6 +653,10 @@ int pz_module_get_margin(pz_module* m, double* max_frac);
 int pz_module_set_phase_tuning(pz_module* m, int enable);
 int pz_module_phase_tuning_state(pz_module* m, int* shapes_tuned, int* shapes_measuring);
 
+/* Which kernel instantiations the hot dispatch sites (middle kernel, blind-rotation kernels) have chosen since the last reset, as one
+ * "; "-separated string: measurement tools print it next to their numbers. */
+int pz_module_dispatch_notes(pz_module* m, char* buf, size_t len, int reset);
+
 /* Debug: workspace guards.  With POULPY_DBG_CANARY=1 in the environment every segment the library carves out of its workspaces is
  * followed by a 256-byte guard that is verified when the API call returns (the process aborts with a message on an overrun; HIP
  * graphs are not used in this mode).  pz_debug_workspace_overrun carves two segments of `bytes` and writes `overrun` bytes past the

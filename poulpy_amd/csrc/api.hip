@@ -386,6 +386,16 @@ int pz_module_phase_tuning_state(pz_module* M, int* shapes_tuned, int* shapes_me
     if (shapes_measuring) *shapes_measuring = u;
     return PZ_OK;
 }
+int pz_module_dispatch_notes(pz_module* M, char* buf, size_t len, int reset) {
+    PZ_ENTER(M);
+    if (buf && len) {
+        std::string all;
+        for (auto& s : M->notes) { if (!all.empty()) all += "; "; all += s; }
+        snprintf(buf, len, "%s", all.c_str());
+    }
+    if (reset) M->notes.clear();
+    return PZ_OK;
+}
 int pz_debug_workspace_overrun(pz_module* M, size_t bytes, size_t overrun) {
     PZ_ENTER(M);
     const size_t seg = align256(bytes);

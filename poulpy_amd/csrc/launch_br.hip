@@ -62,6 +62,7 @@ int br_try_fused(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_
     if (!launched && std_variant && r0 == R0_ && pj == PJ_ && mr == MR_ && cgsz == CG_) {                                    \
         PZ_TRY(set_lds((k_br_fused<R0_, 1, NT, PJ_, MR_, CG_, false, true>), lds));                                           \
         hipLaunchKernelGGL((k_br_fused<R0_, 1, NT, PJ_, MR_, CG_, false, true>), dim3(B), dim3(NT), lds, M->stream, g);       \
+        dispatch_note(M, "k_br_fused<R0=%d,CT=1,NT=512,PJ=%d,MR=%d,CG=%d,A32=0,STD=1> lds=%zu", R0_, PJ_, MR_, CG_, lds);     \
         launched = true;                                                                                                     \
     }
 #define PZ_BR_STD_SHAPES(R0_)                                                                                                \
@@ -71,6 +72,7 @@ int br_try_fused(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_
     if (!launched && !std_variant && r0 == R0_ && ct == CT_ && pj == PJ_ && mr == MR_ && cgsz == CG_ && a32 == A32_) {       \
         PZ_TRY(set_lds(k_br_fused<R0_, CT_, NT, PJ_, MR_, CG_, A32_>, lds));                                                 \
         hipLaunchKernelGGL((k_br_fused<R0_, CT_, NT, PJ_, MR_, CG_, A32_>), dim3((B + CT_ - 1) / CT_), dim3(NT), lds, M->stream, g); \
+        dispatch_note(M, "k_br_fused<R0=%d,CT=%d,NT=512,PJ=%d,MR=%d,CG=%d,A32=%d> lds=%zu", R0_, CT_, PJ_, MR_, CG_, (int)(A32_), lds); \
         launched = true;                                                                                                     \
     }
 #define PZ_BR_SHAPES(R0_, CT_, A32_)                                                                                         \
@@ -137,6 +139,7 @@ int br_block_step(pz_module* M, const double* acc_dft, long long a_bs, double* a
 #define PZ_BRB(MR_, CG_)                                                                                           \
     if (!launched && mr == MR_ && cgs == CG_) {                                                                    \
         hipLaunchKernelGGL((k_br_block_lds<2, MR_, CG_>), dim3(total), dim3(256), 0, M->stream, g);                \
+        dispatch_note(M, "k_br_block_lds<2,MR=%d,CG=%d> (8 ciphertexts per staged key value)", MR_, CG_);          \
         launched = true;                                                                                           \
     }
                     PZ_BRB(12, 2) PZ_BRB(9, 3) PZ_BRB(6, 3) PZ_BRB(8, 3) PZ_BRB(4, 4) PZ_BRB(8, 4)
@@ -145,6 +148,7 @@ int br_block_step(pz_module* M, const double* acc_dft, long long a_bs, double* a
 #define PZ_BRB(MR_, CG_)                                                                                           \
     if (!launched && mr == MR_ && cgs == CG_) {                                                                    \
         hipLaunchKernelGGL((k_br_block<CT, MR_, CG_>), dim3(gx, gy, (unsigned)ngroups), dim3(256), 0, M->stream, g); \
+        dispatch_note(M, "k_br_block<2,MR=%d,CG=%d>", MR_, CG_);                                                    \
         launched = true;                                                                                           \
     }
                     PZ_BRB(12, 2) PZ_BRB(9, 3) PZ_BRB(6, 3) PZ_BRB(8, 3) PZ_BRB(4, 4) PZ_BRB(8, 4)

@@ -82,11 +82,13 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
     {                                                                                                                      \
         PZ_TRY(set_lds((k_mid128<CT_, NP_, PERM_, false, false, ((SKIPW_) && (NP_ > 8))>), lds));                           \
         hipLaunchKernelGGL((k_mid128<CT_, NP_, PERM_, false, false, ((SKIPW_) && (NP_ > 8))>), grid_, dim3(512), lds, M->stream, g); \
+        dispatch_note(M, "k_mid128<CT=%d,NP=%d,PERM=%d,DS=0,BR=0,SKIPW=%d>", CT_, NP_, (int)(PERM_), (int)((SKIPW_) && (NP_ > 8))); \
     }
 #define PZ_MID128_GOR1(CT_, NP_, PERM_, NR_, HALF_)                                                                        \
     {                                                                                                                      \
         PZ_TRY(set_lds((k_mid128r<((NP_ <= 16) ? CT_ : 4), ((NP_ <= 16) ? NP_ : 16), PERM_, NR_, ((HALF_) && (NP_ == 16))>), lds)); \
         hipLaunchKernelGGL((k_mid128r<((NP_ <= 16) ? CT_ : 4), ((NP_ <= 16) ? NP_ : 16), PERM_, NR_, ((HALF_) && (NP_ == 16))>), grid_, dim3(512), lds, M->stream, g); \
+        dispatch_note(M, "k_mid128r<CT=%d,NP=%d,PERM=%d,NR=%d,HALFIN=%d,KR=%d>", CT_, NP_, (int)(PERM_), NR_, (int)((HALF_) && (NP_ == 16)), PZ_MIDR_KR); \
     }
 #define PZ_MID128_GOR(CT_, NP_, PERM_)   /* k_mid128r: 16- and 8-slot tiles only, 16 or 8 product rows */                  \
     {                                                                                                                      \
@@ -111,9 +113,11 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
         if (br) {                                                                                                          \
             PZ_TRY(set_lds((k_mid128<CT_, NP_, false, false, true>), lds));                                                \
             hipLaunchKernelGGL((k_mid128<CT_, NP_, false, false, true>), grid_, dim3(512), lds, M->stream, g);             \
+            dispatch_note(M, "k_mid128<CT=%d,NP=%d,BR=1> (%d ciphertexts per key value)", CT_, NP_, CT_);                  \
         } else if (ds) {                                                                                                          \
             PZ_TRY(set_lds((k_mid128<CT_, NP_, false, true>), lds));                                                       \
             hipLaunchKernelGGL((k_mid128<CT_, NP_, false, true>), grid_, dim3(512), lds, M->stream, g);                    \
+            dispatch_note(M, "k_mid128<CT=%d,NP=%d,DS=1>", CT_, NP_);                                                      \
         } else {                                                                                                           \
             const bool skipw_ = NP_ > 8 && (npi <= NP_ - 8 || npo <= NP_ - 8);   /* shapes with idle waves */              \
             const bool ring_ = NP_ <= 16 && mid_r && (g.row_max == 16 || g.row_max == 8);                      \

@@ -183,6 +183,9 @@ struct pz_module {
     // API call returns (canary_verify, from PZ_ENTER's scope object).  An overrun into the slack between segments stays bit-exact
     // and therefore invisible to the parity tests (the spectral automorphism's body operand).
     std::vector<void*> guards;
+    // the distinct kernel instantiations the hot dispatch sites chose since the last pz_module_dispatch_notes(reset) (bench tools print
+    // them next to their numbers: "which variant ran" is part of a measurement)
+    std::vector<std::string> notes;
 };
 
 namespace pz {
@@ -210,6 +213,16 @@ struct KTimer {
         }
     }
 };
+
+inline void dispatch_note(pz_module* M, const char* fmt, ...) {
+    char buf[160];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    for (auto& s : M->notes) if (s == buf) return;
+    if (M->notes.size() < 32) M->notes.emplace_back(buf);
+}
 
 constexpr size_t kGuardBytes = 256;
 constexpr size_t kGuardSlack = 64 * kGuardBytes;   // room for the guards of a call's segments: part of every reservation

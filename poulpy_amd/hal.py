@@ -220,6 +220,12 @@ class Module:
         self._ck(self.lib.pz_module_phase_tuning_state(self.handle, C.byref(t), C.byref(u)))
         return int(t.value), int(u.value)
 
+    def dispatch_notes(self, reset: bool = False) -> str:
+        """Kernel instantiations chosen by the hot dispatch sites since the last reset (include/poulpy_hip.h)."""
+        buf = C.create_string_buffer(4096)
+        self._ck(self.lib.pz_module_dispatch_notes(self.handle, buf, c_size_t(4096), c_int(1 if reset else 0)))
+        return buf.value.decode()
+
     def set_kernel_timing(self, enable: bool):
         self._ck(self.lib.pz_module_set_kernel_timing(self.handle, c_int(1 if enable else 0)))
 

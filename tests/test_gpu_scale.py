@@ -131,6 +131,67 @@ def test_config4_blind_rotation_n16384(mods):
     assert np.array_equal(got, want)
 
 
+def _br_pool_parity(hip, ref, n, rank, n_lwe, block_size, dnum, brk_size, res_size, base2k, batch, pool, seed):
+    """Blind rotation at the launch geometry of tools/bench_blind_rotation.py: a pool of `pool` distinct LWE
+    ciphertexts (coprime with every tile size: 2, 4, 8 ciphertexts per workgroup) whose rotations the oracle computes, replicated on
+    the device to `batch` ciphertexts; EVERY output is compared with its pool entry's oracle result on the device.  Returns the number
+    of mismatching ciphertexts."""
+    import torch
+    from poulpy_amd.hal import BlindRotationParams
+    from poulpy_amd.layouts import MatZnx, VecZnx
+    rng = np.random.default_rng(seed)
+    cols = rank + 1
+    lut = VecZnx(n, 1, res_size).fill_uniform(base2k, rng)
+    brk_r = np.empty((n_lwe, n * dnum * cols * cols * brk_size), dtype=np.float64)
+    brk_h = np.empty_like(brk_r)
+    for i in range(n_lwe):
+        mat = MatZnx(n, dnum, cols, cols, brk_size).fill_uniform(base2k, rng)
+        pr, ph = ref.vmp_pmat_alloc(dnum, cols, cols, brk_size), hip.vmp_pmat_alloc(dnum, cols, cols, brk_size)
+        ref.vmp_prepare(pr, mat)
+        hip.vmp_prepare(ph, mat)
+        brk_r[i], brk_h[i] = pr.data.reshape(-1), ph.data.reshape(-1)
+    lwe_pool = rng.integers(-n, n, (pool, n_lwe + 1), dtype=np.int64)
+    lwe_pool[0, 1] = 0
+    xpa = ref.blind_rotation_x_pow_a()
+    want_pool = np.empty((pool, res_size, cols, n), dtype=np.int64)
+    for b in range(pool):
+        r = VecZnx(n, cols, res_size)
+        ref.blind_rotation_execute(r, base2k, np.ascontiguousarray(lwe_pool[b]), lut, brk_r, dnum, brk_size, block_size, xpa)
+        want_pool[b] = r.data
+    dev = torch.device("cuda", 0)
+    idx = torch.arange(batch, device=dev) % pool
+    d_lwe = torch.from_numpy(lwe_pool).to(dev)[idx].contiguous()
+    d_want = torch.from_numpy(want_pool).to(dev)
+    d_lut = torch.from_numpy(lut.data).to(dev)
+    d_brk = torch.from_numpy(brk_h).to(dev)
+    d_res = torch.full((batch, res_size, cols, n), 0x3333, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    p = BlindRotationParams(rank=rank, n_lwe=n_lwe, block_size=block_size, dnum=dnum, brk_size=brk_size, base2k=base2k,
+                            res_size=res_size, lut_size=res_size)
+    C = __import__("ctypes")
+    hip.blind_rotation_execute_batched(C.c_void_p(d_res.data_ptr()), C.c_void_p(d_lwe.data_ptr()), C.c_void_p(d_lut.data_ptr()),
+                                       C.c_void_p(d_brk.data_ptr()), p, batch)
+    hip.sync()
+    bad = (d_res != d_want[idx]).flatten(1).any(dim=1)
+    return int(bad.sum().item())
+
+
+@pytest.mark.parametrize("n,rank,note", [(1024, 1, "one-kernel path, two ciphertexts per workgroup"),
+                                         (1024, 2, "rank 2 (circuit-bootstrapping key): small-ring transforms + LDS-staged block step"),
+                                         (2048, 1, "small-ring transforms + LDS-staged block step"),
+                                         (16384, 1, "block step on the three-kernel pipeline (k_mid128 BR)")])
+def test_config4_blind_rotation_pool_parity_at_bench_batch(mods, n, rank, note):
+    """BASELINE configs[3] at the batch the blind-rotation bench runs (>= 1027 ciphertexts: ragged against every tile size), every
+    output checked.  Short LWE (two blocks + a dropped partial one) so that the oracle's pool stays in seconds; the launch geometry
+    over the batch - tiles, XCD slots, last partial tile - is the bench's."""
+    ref, hip = mods(n)
+    dnum, bsz, rsz = (3, 4, 4) if rank == 2 else (3, 3, 3)
+    batch = 1027 if n < 16384 else 259      # N = 2^14: 16 MiB of accumulators per ciphertext column set; 259 = 32 tiles of 8 + 3
+    bad = _br_pool_parity(hip, ref, n, rank, n_lwe=15, block_size=7, dnum=dnum, brk_size=bsz, res_size=rsz, base2k=13, batch=batch, pool=7,
+                          seed=4000 + n + rank)
+    assert bad == 0, (note, bad)
+
+
 # ------------------------------------------------------------------------------------------
 # conversion quirks (SURVEY.md a5): round half away, saturating `as i64`, NaN -> 0, and the >= 2^51 slow path of the tail
 # reference: poulpy-cpu-ref/src/reference/fft64/reim/conversion.rs:43-60

@@ -75,6 +75,7 @@ def main():
                             base2k=s["base2k"], res_size=s["res_size"], lut_size=s["res_size"])
     ptr = lambda t: C.c_void_p(t.data_ptr())
     torch.cuda.synchronize()
+    mod.dispatch_notes(reset=True)
     mod.blind_rotation_execute_batched(ptr(res), ptr(lwe), ptr(lut), ptr(brk), p, args.batch)   # warm-up
     mod.sync()
     t0 = time.perf_counter()
@@ -118,6 +119,13 @@ def main():
                     "steps": "lwe_mod_switch_2n + blind_rotation_execute + lwe_from_glwe (key switch + sample extract), all device-resident"}
     out = {"metric": "CGGI blind rotations/s", "shape": args.shape, **s, "batch": args.batch, "value": args.batch / dt,
            "ms_per_batch": dt * 1e3, "kernel_classes_launches_ms": kstats, "digits_balanced": bool((res.min() >= -half).item() and (res.max() < half).item())}
+    # which kernel instantiations ran, and the rotation priced against the three ceilings that can bound it (tools/roofline_models.py)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import roofline_models as rm
+    notes = mod.dispatch_notes()
+    model = rm.blind_rotation(n, s["n_lwe"], s["rank"], s["block_size"], s["dnum"], s["brk_size"], s["res_size"], args.batch)
+    out["dispatch"] = notes
+    out["roofline"] = rm.roofline(out["value"], model, rm.key_share(notes))
     if ks_stats:
         out["gate_bootstrap"] = ks_stats
     # CPU port beside it (single thread) on a few of the same ciphertexts, and parity on those

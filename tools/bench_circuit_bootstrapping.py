@@ -81,6 +81,7 @@ def main():
         mod.circuit_bootstrapping_execute_to_constant_batched(ptr(res), ptr(lwe), ptr(lut), ptr(brk), gals, [t.data_ptr() for t in atk_p],
                                                               [t.data_ptr() for t in tsk_p], p, ptr(tmp), nbytes, args.batch)
 
+    mod.dispatch_notes(reset=True)
     run()
     mod.sync()
     t0 = time.perf_counter()
@@ -98,6 +99,26 @@ def main():
            "ms_per_batch": dt * 1e3, "host_submit_ms_per_call": t_submit * 1e3, "graph_launches": mod.graph_launches(),
            "kernel_classes_launches_ms": kstats,
            "digits_balanced": bool((res.min() >= -half).item() and (res.max() <= half).item())}
+    # the composition priced against the three ceilings (tools/roofline_models.py): blind rotation + res_dnum traces of log2(N)
+    # automorphism key switches + res_dnum x rank key switches of ggsw_expand_row; the key stream of each part divided by the
+    # ciphertexts that share one fetch in the kernel that ran (dispatch notes)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import roofline_models as rm
+    notes = mod.dispatch_notes()
+    br_m = rm.blind_rotation(n, s["n_lwe"], rank, s["block_size"], s["brk_dnum"], s["glwe_size"], s["glwe_size"], args.batch)
+    logn = n.bit_length() - 1
+    tr_m = rm.glwe_op(n, rank, cols, s["glwe_size"], s["atk_size"], s["atk_dnum"], args.batch * s["res_dnum"], a_cols=cols, extra_in_polys=s["glwe_size"])
+    ex_m = rm.glwe_op(n, rank, cols, s["res_size"], s["tsk_size"], s["tsk_dnum"], args.batch * s["res_dnum"], a_cols=cols)
+    br_share = rm.key_share(";".join(x for x in notes.split(";") if "k_br" in x)) if "k_br" in notes else 1
+    ks_share = rm.key_share(";".join(x for x in notes.split(";") if "k_mid128" in x)) if "k_mid128" in notes else 1
+    n_tr, n_ex = s["res_dnum"] * logn, s["res_dnum"] * rank
+    model = {"hbm_bytes": br_m["hbm_bytes"] + n_tr * tr_m["hbm_bytes"] + n_ex * ex_m["hbm_bytes"],
+             "flops": br_m["flops"] + n_tr * tr_m["flops"] + n_ex * ex_m["flops"],
+             "key_stream_bytes": br_m["key_stream_bytes"] / br_share + (n_tr * tr_m["key_stream_bytes"] + n_ex * ex_m["key_stream_bytes"]) / ks_share}
+    out["dispatch"] = notes
+    out["roofline"] = rm.roofline(out["value"], model, 1)
+    out["roofline"]["l2_stream"]["ciphertexts_per_key_fetch"] = {"blind_rotation": br_share, "key_switches": ks_share}
+    out["roofline"]["parts"] = {"blind_rotation_flops": br_m["flops"], "trace_flops": n_tr * tr_m["flops"], "expand_row_flops": n_ex * ex_m["flops"]}
     if args.cpu_cts:
         from oracle.ref import RefModule
         from poulpy_amd.layouts import MatZnx, VecZnx
