@@ -12,6 +12,8 @@
 #include <vector>
 
 #include "api_common.hpp"
+#include <unordered_map>
+
 #include "api_glwe.hpp"
 
 using namespace pz;
@@ -35,6 +37,33 @@ static uint64_t host_fingerprint(const void* p, size_t bytes) {
     for (size_t i = 0; i < nw; i += stride) mix(w[i]);
     return h;
 }
+// Process-wide invalidation of host-resident prepared keys: a sibling module on another thread may mirror the same host
+// buffer, and the sampled fingerprint can miss an in-place change.  Writers (pz_vmp_prepare, pz_vmp_zero, pz_module_forget_host_key,
+// pz_free_bytes) publish the host range under one small lock; a mirror is valid only if no range published after its validation
+// overlaps it.  The ring keeps the last kInvalRing ranges; a mirror older than the ring's horizon is revalidated conservatively.
+static std::mutex g_inval_mu;
+struct HostInval { const char* lo; const char* hi; uint64_t epoch; };
+static constexpr size_t kInvalRing = 1024;
+static std::vector<HostInval> g_inval;       // ring, oldest overwritten
+static size_t g_inval_next = 0;
+static uint64_t g_inval_epoch = 0;           // epoch of the newest published range
+static uint64_t g_inval_horizon = 0;         // ranges with epoch <= horizon have left the ring
+void host_key_invalidate(const void* p, size_t bytes) {
+    if (!p || is_device_ptr(p)) return;
+    std::lock_guard<std::mutex> g(g_inval_mu);
+    HostInval e{(const char*)p, (const char*)p + std::max<size_t>(bytes, 1), ++g_inval_epoch};
+    if (g_inval.size() < kInvalRing) g_inval.push_back(e);
+    else { g_inval_horizon = g_inval[g_inval_next].epoch; g_inval[g_inval_next] = e; g_inval_next = (g_inval_next + 1) % kInvalRing; }
+}
+// (current epoch, whether [p, p + bytes) was published after `since`)
+static bool host_key_stale(const void* p, size_t bytes, uint64_t since, uint64_t* now) {
+    std::lock_guard<std::mutex> g(g_inval_mu);
+    *now = g_inval_epoch;
+    if (since < g_inval_horizon) return true;   // older than the ring remembers
+    const char* lo = (const char*)p; const char* hi = lo + bytes;
+    for (const auto& e : g_inval) if (e.epoch > since && e.lo < hi && lo < e.hi) return true;
+    return false;
+}
 static void drop_mirror_at(pz_module* M, size_t i) {
     auto& mr = M->mirrors[i];
     for (size_t k = 0; k < M->pinned.size(); ++k)
@@ -48,6 +77,7 @@ static void drop_mirror_at(pz_module* M, size_t i) {
     M->graph_epoch++;
 }
 int forget_host_key(pz_module* M, const void* host) {
+    host_key_invalidate(host, 1);   // every module's mirror of this buffer, not only the caller's
     for (size_t i = 0; i < M->mirrors.size(); ++i)
         if (M->mirrors[i].host == host) {
             PZ_HIP(hipStreamSynchronize(M->stream));
@@ -60,6 +90,14 @@ int forget_host_key(pz_module* M, const void* host) {
 // the row-sliced copy of the fused pipeline (as pz_module_pin_key would build it), valid for as long as the mirror is
 static int resolve_key(pz_module* M, const double* pmat, size_t bytes, const double** out) {
     if (is_device_ptr(pmat)) { *out = pmat; return PZ_OK; }
+    // mirrors whose host range was (re)prepared, zeroed, forgotten or freed since their validation - by any module - go first
+    for (size_t i = M->mirrors.size(); i-- > 0;) {
+        uint64_t now = 0;
+        if (host_key_stale(M->mirrors[i].host, M->mirrors[i].bytes, M->mirrors[i].epoch, &now)) {
+            PZ_HIP(hipStreamSynchronize(M->stream));
+            drop_mirror_at(M, i);
+        } else M->mirrors[i].epoch = now;
+    }
     const uint64_t fp = host_fingerprint(pmat, bytes);
     for (size_t i = 0; i < M->mirrors.size(); ++i) {
         auto& mr = M->mirrors[i];
@@ -69,6 +107,8 @@ static int resolve_key(pz_module* M, const double* pmat, size_t bytes, const dou
         drop_mirror_at(M, i);
         break;
     }
+    uint64_t epoch_now = 0;
+    (void)host_key_stale(pmat, bytes, ~0ull >> 1, &epoch_now);   // (only reads the current epoch)
     size_t total = bytes;
     for (auto& mr : M->mirrors) total += mr.bytes;
     while (!M->mirrors.empty() && (M->mirrors.size() >= 64 || total > ((size_t)48 << 30))) {   // LRU: at most 64 keys / 48 GiB mirrored
@@ -84,7 +124,7 @@ static int resolve_key(pz_module* M, const double* pmat, size_t bytes, const dou
         (void)hipFree(dev);
         return fail(PZ_ERR_HIP, "upload of a host-resident prepared key failed");
     }
-    M->mirrors.push_back({(const void*)pmat, bytes, dev, fp, ++M->mirror_clock});
+    M->mirrors.push_back({(const void*)pmat, bytes, dev, fp, ++M->mirror_clock, epoch_now});
     M->graph_epoch++;
     if ((M->plan.m2 == 256 || M->plan.m2 == 128) && (M->plan.m1 % 16) == 0) {
         const size_t npolys = bytes / ((size_t)M->n * 8);
@@ -96,6 +136,9 @@ static int resolve_key(pz_module* M, const double* pmat, size_t bytes, const dou
             (void)hipGetLastError();   // no room for the sliced copy: the pipeline rebuilds it per call
         }
     }
+    // the caller may change or free the host key as soon as this call returns (with device-resident ciphertexts nothing else waits):
+    // a fresh mirror's upload is complete before it does
+    PZ_HIP(hipStreamSynchronize(M->stream));
     *out = (const double*)dev;
     return PZ_OK;
 }
@@ -132,7 +175,7 @@ static int glwe_args_out(pz_module* M, GlweArgs& g) {
 // Rust shim's `PinnedBuf::drop`): a later allocation at the same address then never meets a stale mirror, fingerprint or not
 static std::mutex g_modules_mu;
 static std::vector<pz_module*> g_modules;
-static std::vector<std::pair<void*, size_t>> g_host_allocs;   // pz_alloc_bytes blocks (a prepared key may sit inside one)
+static std::unordered_map<void*, size_t> g_host_allocs;   // pz_alloc_bytes blocks (a prepared key may sit inside one)
 
 // ------------------------------------------------------------------------------
 // public: misc
@@ -442,33 +485,22 @@ void* pz_alloc_bytes(size_t len) {
     memset(p, 0, len);
     {
         std::lock_guard<std::mutex> g(g_modules_mu);
-        g_host_allocs.emplace_back(p, len);
+        g_host_allocs[p] = len;
     }
     return p;
 }
 void pz_free_bytes(void* p) {
     if (!p) return;
+    size_t len = 1;
     {
         std::lock_guard<std::mutex> g(g_modules_mu);
-        size_t len = 1;
-        for (size_t i = 0; i < g_host_allocs.size(); ++i)
-            if (g_host_allocs[i].first == p) {
-                len = g_host_allocs[i].second;
-                g_host_allocs[i] = g_host_allocs.back();
-                g_host_allocs.pop_back();
-                break;
-            }
-        for (pz_module* M : g_modules) {
-            std::lock_guard<std::mutex> lock_(M->mu);
-            for (size_t i = M->mirrors.size(); i-- > 0;) {
-                const char* h = (const char*)M->mirrors[i].host;
-                if (h < (const char*)p || h >= (const char*)p + len) continue;
-                (void)hipSetDevice(M->device);
-                (void)hipStreamSynchronize(M->stream);
-                drop_mirror_at(M, i);
-            }
-        }
+        auto it = g_host_allocs.find(p);
+        if (it != g_host_allocs.end()) { len = it->second; g_host_allocs.erase(it); }
     }
+    // a prepared key may sit inside the block: publish the range instead of locking every live module (a buffer drop on one thread
+    // used to wait for whatever GPU call was in flight on every other thread's sibling module); the mirrors are dropped by their
+    // owners at their next key lookup
+    host_key_invalidate(p, len);
     (void)hipHostFree(p);
 }
 int pz_device_alloc(pz_module* M, size_t len, void** out) {
@@ -847,18 +879,29 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
             static const int au_spec = getenv("POULPY_DBG_AUTO_SPECTRAL") ? atoi(getenv("POULPY_DBG_AUTO_SPECTRAL")) : 1;
             // (mode 0, phi(normalize(big)), rides on the same form: the tail undoes phi's signs in front of the carry chain and puts them
             //  back on the digits; POULPY_DBG_AUTO_SPECTRAL=2 keeps the key switch + signed permutation pass for it)
-            const bool spec = au_spec && au && (au_big || au_spec == 1) && (au_p & 3u) == 1u && M->plan.m2 == 128 && M->dbg_stages == 7;
+            // (round 3) p = 3 mod 4 too - X -> X^-1, the first step of every trace, among them: the spectrum of phi(a) is then the CONJUGATE of
+            // a permuted spectrum (MidArgs::perm_ysign); POULPY_DBG_AUTO_SPECTRAL=3 keeps those Galois elements on the older path
+            const bool spec = au_spec && au && (au_big || au_spec == 1 || au_spec == 3) && ((au_p & 3u) == 1u || au_spec != 3) && M->plan.m2 == 128 &&
+                              M->dbg_stages == 7;
             unsigned perm_mul = 0, perm_add = 0;
+            bool perm_conj = false;
             if (spec) {
                 const unsigned mm = (unsigned)M->m;
-                perm_mul = au_g & (mm - 1u);
-                const unsigned long long c0 = (unsigned long long)(((au_p - 1u) >> 2) & (mm - 1u));
-                perm_add = (unsigned)((mm - (unsigned)(((unsigned long long)perm_mul * c0) & (unsigned long long)(mm - 1u))) & (mm - 1u));
+                if ((au_p & 3u) == 1u) {
+                    perm_mul = au_g & (mm - 1u);
+                    const unsigned long long c0 = (unsigned long long)(((au_p - 1u) >> 2) & (mm - 1u));
+                    perm_add = (unsigned)((mm - (unsigned)(((unsigned long long)perm_mul * c0) & (unsigned long long)(mm - 1u))) & (mm - 1u));
+                } else {
+                    perm_conj = true;
+                    perm_mul = (mm - (au_g & (mm - 1u))) & (mm - 1u);                                   // (-p)^-1 mod m
+                    const unsigned long long c0 = (unsigned long long)((((unsigned long long)au_p + 1ull) >> 2) & (unsigned long long)(mm - 1u));
+                    perm_add = (unsigned)(((unsigned long long)perm_mul * c0) & (unsigned long long)(mm - 1u));   // (-p)^-1 (p + 1)/4
+                }
             }
             if (digits && dg.n == 0) {   // nothing reaches the product (e.g. dsize > a.size): the big value is the body alone
                 PZ_HIP(hipMemsetAsync(T2, 0, (size_t)nb * npo * M->m * sizeof(cplx), M->stream));
             } else if (M->dbg_stages & 2)
-                PZ_TRY(launch_mid(M, nb, T, T2, Pp, npi, npo, nrows, ncols, mid_dummy, perm_mul, perm_add, digits ? &dg : nullptr));
+                PZ_TRY(launch_mid(M, nb, T, T2, Pp, npi, npo, nrows, ncols, mid_dummy, perm_mul, perm_add, digits ? &dg : nullptr, nullptr, perm_conj));
             int64_t* res_b = res + (long long)b0 * res_bs;
             if (spec) {
                 // (the tail reads operand limbs j < min(key_size, a_size) only: the pre-pass covers exactly those)
@@ -1129,6 +1172,15 @@ int pz_module_forget_host_key(pz_module* M, const double* host_pmat) {
 size_t pz_module_host_key_mirrors(pz_module* M) {
     if (!M) return 0;
     std::lock_guard<std::mutex> lock_(M->mu);
+    // mirrors whose host range has been invalidated since (possibly by another module or by pz_free_bytes) are released now
+    (void)hipSetDevice(M->device);
+    for (size_t i = M->mirrors.size(); i-- > 0;) {
+        uint64_t now = 0;
+        if (host_key_stale(M->mirrors[i].host, M->mirrors[i].bytes, M->mirrors[i].epoch, &now)) {
+            (void)hipStreamSynchronize(M->stream);
+            drop_mirror_at(M, i);
+        } else M->mirrors[i].epoch = now;
+    }
     return M->mirrors.size();
 }
 // ggsw_external_product (external_product/ggsw.rs:54-58): every (row, column) entry of the GGSW `a` is a GLWE and the entries

@@ -92,6 +92,7 @@ struct OpLayout {
 
 // api.hip: drops the device mirror of a host-resident prepared key (a rewritten buffer's mirror would be stale)
 int forget_host_key(pz_module* M, const void* host);
+void host_key_invalidate(const void* p, size_t bytes);   // api.hip: process-wide (every module's mirrors of that host range)
 
 // Defined inside api.hip's extern "C" block (C linkage, internal use; the caller holds the module lock):
 extern "C" {

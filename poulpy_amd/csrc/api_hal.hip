@@ -410,6 +410,7 @@ size_t pz_vmp_apply_dft_tmp_bytes(const pz_module* M, size_t res_size, size_t a_
 int pz_vmp_prepare(pz_module* M, double* pmat, const int64_t* mat, size_t rows, size_t cols_in, size_t cols_out, size_t size) {
     PZ_ENTER(M);
     PZ_TRY(forget_host_key(M, (const void*)pmat));   // (a device mirror of this host buffer would be stale)
+    host_key_invalidate(pmat, rows * cols_in * cols_out * size * (size_t)M->n * 8);
     const size_t npolys = rows * cols_in * cols_out * size;
     Stage sp, sm;
     PZ_TRY(sm.in(mat, npolys * M->n * 8, true, false, M));
@@ -437,6 +438,7 @@ int pz_vmp_zero(pz_module* M, double* pmat, size_t rows, size_t cols_in, size_t 
     PZ_ENTER(M);
     PZ_TRY(forget_host_key(M, (const void*)pmat));
     const size_t bytes = rows * cols_in * cols_out * size * M->n * 8;
+    host_key_invalidate(pmat, bytes);
     if (is_device_ptr(pmat)) PZ_HIP(hipMemsetAsync(pmat, 0, bytes, M->stream));
     else memset(pmat, 0, bytes);
     return PZ_OK;

@@ -48,7 +48,12 @@ struct MidArgs {
     // k_mid128<.., PERM = true>: the product is written to spectrum position q_out = perm_mul * q_in + perm_add (mod m), so that
     // the inverse transform of the result is phi(big) for X -> X^p with p = 1 mod 4:  DFT(phi(a))[q] = DFT(a)[p q + (p-1)/4],
     // perm_mul = p^-1, perm_add = -p^-1 (p-1)/4.  Rows map to rows (q1_out depends on q1 only), q2 moves inside the row.
+    // Galois elements p = 3 mod 4 (round 3): the evaluation points of the folded transform are the 2N-th roots with exponent 1 mod 4, and
+    // p (4q + 1) = 3 mod 4 names the CONJUGATE point of -p (4q + 1) = 1 mod 4, so DFT(phi(a))[q] = conj(DFT(a)[-p q - (p + 1)/4]):
+    // the same affine row-to-row map with perm_mul = (-p)^-1, perm_add = (-p)^-1 (p + 1)/4, and the product is conjugated as it is
+    // written (perm_ysign = -1.0; +1.0 otherwise).  X -> X^-1, the first step of glwe_trace, is the pure conjugation (identity map).
     unsigned perm_mul, perm_add;
+    double perm_ysign;
     int log_m1;
     // k_mid128<.., DS = true> (dsize > 1, poulpy-core external_product/glwe.rs:235-267, keyswitching/glwe.rs:332-379): the limbs of `a`
     // are digits of dsize groups; input polynomial ds_in[t] (its slot in the tile) multiplies key row ds_row[t] shifted by ds_coff[t]
@@ -585,6 +590,7 @@ k_mid128(MidArgs g) {
                 for (int j = 0; j < NC; ++j) {
                     const int c = cg * NC + j;
                     const int q2o = PERM ? (int)((((g.perm_mul * (unsigned)q1 + g.perm_add) >> g.log_m1) + g.perm_mul * (unsigned)q2) & (unsigned)(M2 - 1)) : q2;
+                    if constexpr (PERM) acc[i][j].y *= g.perm_ysign;
                     lds[((vtg * CTt + i) * NP + c) * RS + q2o] = (c < g.ncomp) ? acc[i][j] : make_double2(0.0, 0.0);
                 }
             lds_barrier();
@@ -898,6 +904,7 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
                 for (int j = 0; j < NC; ++j) {
                     const int c = cg * NC + j;
                     const int q2o = PERM ? (int)((((g.perm_mul * (unsigned)q1 + g.perm_add) >> g.log_m1) + g.perm_mul * (unsigned)q2) & (unsigned)(M2 - 1)) : q2;
+                    if constexpr (PERM) acc[i][j].y *= g.perm_ysign;
                     lds[((vtg * CTt + i) * NP + c) * RS + q2o] = (c < g.ncomp) ? acc[i][j] : make_double2(0.0, 0.0);
                 }
             lds_barrier();

@@ -78,7 +78,7 @@ struct MidBr {
     int i0, blk;            // first coefficient of the block, block size (<= 16)
 };
 int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp, int npi, int npo, int nrows, int ncols, cplx* dummy,
-               unsigned perm_mul = 0, unsigned perm_add = 0, const MidDigits* dg = nullptr, const MidBr* br = nullptr);
+               unsigned perm_mul = 0, unsigned perm_add = 0, const MidDigits* dg = nullptr, const MidBr* br = nullptr, bool perm_conj = false);
 
 // ---- launch_small.hip ---------------------------------------------------------------------------------------------
 // two-kernel pipeline for N = 1024 / 2048 / 4096 (device_small.hpp): full forward transform -> S[poly][q1][q2]; product with the row-sliced key +

@@ -39,7 +39,7 @@ static int launch_mid_ct(pz_module* M, MidArgs g, int batch) {
 }
 // perm_mul != 0: spectrum permutation of X -> X^p folded into the middle kernel (m2 = 128 plans only; see MidArgs)
 int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp, int npi, int npo, int nrows, int ncols, cplx* dummy,
-               unsigned perm_mul, unsigned perm_add, const MidDigits* dg, const MidBr* br) {
+               unsigned perm_mul, unsigned perm_add, const MidDigits* dg, const MidBr* br, bool perm_conj) {
     MidArgs g;
     g.br_lwe = nullptr; g.br_lwe_bs = 0; g.br_i0 = 0; g.br_blk = 0; g.br_rm = 0; g.w2n = M->w2n;
     if (br) {
@@ -53,7 +53,7 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
         g.ds_n = dg->n;
         for (int t = 0; t < dg->n; ++t) { g.ds_in[t] = dg->in[t]; g.ds_row[t] = dg->row[t]; g.ds_coff[t] = dg->coff[t]; g.ds_cb[t] = dg->cb[t]; }
     }
-    g.perm_mul = perm_mul; g.perm_add = perm_add; g.log_m1 = 0;
+    g.perm_mul = perm_mul; g.perm_add = perm_add; g.perm_ysign = perm_conj ? -1.0 : 1.0; g.log_m1 = 0;
     static const int mid_skip = getenv("POULPY_DBG_MID_SKIP") ? atoi(getenv("POULPY_DBG_MID_SKIP")) : 0;
     g.dbg = mid_skip;
     while ((1 << g.log_m1) < M->plan.m1) ++g.log_m1;

@@ -147,7 +147,9 @@ struct pz_module {
     // device mirrors of HOST-resident prepared keys handed to the batched GLWE entry points (the Rust shim's prepared layouts
     // live in pinned host memory, poulpy-hal requires host-addressable buffers): uploaded on first use, re-validated on every
     // call by a sampled fingerprint of the host bytes, dropped by pz_vmp_prepare / pz_vmp_zero / pz_module_forget_host_key
-    struct KeyMirror { const void* host; size_t bytes; void* dev; uint64_t fp; uint64_t stamp; };
+    // (round 3: + the process-wide invalidation epoch it was validated at: pz_vmp_prepare / pz_vmp_zero / pz_module_forget_host_key /
+    //  pz_free_bytes on ANY module or thread publish the host range they touch, api.hip host_key_invalidate)
+    struct KeyMirror { const void* host; size_t bytes; void* dev; uint64_t fp; uint64_t stamp; uint64_t epoch; };
     std::vector<KeyMirror> mirrors;
     uint64_t mirror_clock = 0;
     // RCCL communicator for pz_bcast_key (api_dist.hip); owned by the module

@@ -1067,6 +1067,45 @@ def test_concurrent_callers_on_one_module(mods):
     assert all(results)
 
 
+def test_host_key_change_through_one_module_reaches_its_siblings(mods):
+    """a sibling module that mirrors a host-resident prepared key must notice when ANOTHER module re-prepares that buffer,
+    also when the change would slip through the sampled fingerprint: keys 1 and 2 differ in ONE coefficient of one matrix
+    polynomial, prepared into the same host buffer through module A; module B (a clone) computed with key 1 before and must
+    compute with key 2 after.  And freeing a pz_alloc_bytes block invalidates the mirrors of keys inside it without touching the modules."""
+    import ctypes as C
+    from poulpy_amd.hal import GlweOpParams, Module
+    n, cols, size, k = 4096, 2, 3, 14
+    ref, _ = mods(n)
+    A = Module(n)
+    B = A.clone()
+    rng = seeded(77)
+    mat1 = MatZnx(n, size, cols, cols, size).fill_uniform(k, rng)
+    mat2 = MatZnx(n, size, cols, cols, size, mat1.data.copy())
+    mat2.data.reshape(-1)[12345] ^= 1          # one coefficient, one bit
+    a = VecZnx(n, cols, size).fill_uniform(k, rng)
+    p = GlweOpParams(rank=1, dnum=size, dsize=1, key_size=size, key_base2k=k, a_size=size, a_base2k=k, res_size=size, res_base2k=k, rank_out=1)
+    hp = lambda arr: arr.ctypes.data_as(C.c_void_p)
+    wants = []
+    for mat in (mat1, mat2):
+        pr = ref.vmp_pmat_alloc(size, cols, cols, size)
+        ref.vmp_prepare(pr, mat)
+        w = VecZnx(n, cols, size)
+        ref.glwe_external_product(w, k, a, k, pr, 1, k)
+        wants.append(w.data.copy())
+    assert not np.array_equal(wants[0], wants[1])
+    ph = A.vmp_pmat_alloc(size, cols, cols, size)           # ONE host buffer for both keys
+    A.vmp_prepare(ph, mat1)
+    got = np.zeros_like(wants[0])
+    B.glwe_external_product_batched(hp(got), hp(a.data), hp(ph.data), p, 1)     # B mirrors key 1
+    assert np.array_equal(got, wants[0])
+    A.vmp_prepare(ph, mat2)                                                      # re-prepared through A, same address
+    got[...] = 0
+    B.glwe_external_product_batched(hp(got), hp(a.data), hp(ph.data), p, 1)
+    assert np.array_equal(got, wants[1]), "the sibling kept computing with the stale mirror"
+    B.close()
+    A.close()
+
+
 def test_sibling_modules_run_concurrently(mods):
     """pz_module_clone: every worker thread on its own sibling (shared device tables; own stream, workspaces, lock) — per-op host calls
     and fused GLWE calls on host containers from 6 threads at once, each result against the oracle; siblings outlive their parent."""
