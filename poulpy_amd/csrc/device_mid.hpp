@@ -590,7 +590,6 @@ k_mid128(MidArgs g) {
                 for (int j = 0; j < NC; ++j) {
                     const int c = cg * NC + j;
                     const int q2o = PERM ? (int)((((g.perm_mul * (unsigned)q1 + g.perm_add) >> g.log_m1) + g.perm_mul * (unsigned)q2) & (unsigned)(M2 - 1)) : q2;
-                    if constexpr (PERM) acc[i][j].y *= g.perm_ysign;
                     lds[((vtg * CTt + i) * NP + c) * RS + q2o] = (c < g.ncomp) ? acc[i][j] : make_double2(0.0, 0.0);
                 }
             lds_barrier();
@@ -608,6 +607,10 @@ k_mid128(MidArgs g) {
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) u[8 * h + k2] = rowbuf[o + 8 * h + 16 * k2];
+            if constexpr (PERM) {   // Galois elements 3 mod 4: the conjugate of the permuted product (MidArgs::perm_ysign; +1.0 otherwise)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) u[t].y *= g.perm_ysign;
+            }
             if (!(dbgv & 16)) { Bfly<8, true>::run(u); Bfly<8, true>::run(u + 8); }
             row_sync();
 #pragma unroll
@@ -688,7 +691,8 @@ k_mid128(MidArgs g) {
 // s_waitcnt insertion assume the worst case at every join (k_mid128, SKIPW).
 template <int CT, int NP, bool PERM, int NR, int KR, bool HALFIN, bool IN>
 __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
-    constexpr int M2 = 128, NT = 512, NC = 4;
+    constexpr int M2 = 128, NT = 512;
+    constexpr int NC = NP == 32 ? 8 : 4;   // outputs per thread (32-slot tile: two ciphertexts x 8 outputs, as in k_mid128)
     constexpr int GC = NP / NC, GT = (NT / M2) / GC, CTt = CT / GT;
     static_assert(CT * NP * 8 == NT && GC * GT == NT / M2 && CTt * GT == CT && KR >= 3 && KR <= 7 && KR <= NR, "k_mid128r tile shape");
     constexpr int RS = kMidRS;
@@ -715,7 +719,7 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
     if (tid0 < M2) wl[tid0] = g.wL2[tid0];
     __syncthreads();
     // the threads that move the inter-pass twiddle row (128 entries): waves 0 and 1, or waves 0 and 2 where wave 1 carries no input
-    const int tw_e = HALFIN ? ((tid0 >> 6) == 0 ? tid0 : ((tid0 >> 6) == 2 ? tid0 - 64 : -1)) : (tid0 < M2 ? tid0 : -1);
+    const int tw_e = (HALFIN && NP == 16) ? ((tid0 >> 6) == 0 ? tid0 : ((tid0 >> 6) == 2 ? tid0 - 64 : -1)) : (tid0 < M2 ? tid0 : -1);
     // experiments (POULPY_DBG_MID_STAGGER = n, POULPY_DBG_MID_STAGGER_MOD = mode bits): n x 128 cycles of delay for the second-dispatched
     // half of the waves at the top of every inverse pass (mode bit 2: for the first half instead); mode bit 0: static priority 1 for the
     // second half, bit 1: for the first half
@@ -904,7 +908,6 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
                 for (int j = 0; j < NC; ++j) {
                     const int c = cg * NC + j;
                     const int q2o = PERM ? (int)((((g.perm_mul * (unsigned)q1 + g.perm_add) >> g.log_m1) + g.perm_mul * (unsigned)q2) & (unsigned)(M2 - 1)) : q2;
-                    if constexpr (PERM) acc[i][j].y *= g.perm_ysign;
                     lds[((vtg * CTt + i) * NP + c) * RS + q2o] = (c < g.ncomp) ? acc[i][j] : make_double2(0.0, 0.0);
                 }
             lds_barrier();
@@ -924,6 +927,10 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) u[8 * h + k2] = rowbuf[o + 8 * h + 16 * k2];
+            if constexpr (PERM) {   // Galois elements 3 mod 4: the conjugate of the permuted product (MidArgs::perm_ysign; +1.0 otherwise)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) u[t].y *= g.perm_ysign;
+            }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (IN) PZ_XGROUP(src_, 1)
             __builtin_amdgcn_sched_barrier(0);
@@ -999,12 +1006,13 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
 
 // HALFIN: a 16-slot tile whose ciphertexts carry at most 8 input polynomials (key switch, automorphism, ggsw_expand_row): the waves of
 // the upper 8 slots run the IN = false code.
-template <int CT, int NP, bool PERM, int NR, bool HALFIN = false, int KR = PZ_MIDR_KR>
+// (32-slot tiles - 16 limbs, rank 2-3 - carry 8 key values per thread and row: a ring of 3 slots there)
+template <int CT, int NP, bool PERM, int NR, bool HALFIN = false, int KR = (NP == 32 ? 3 : PZ_MIDR_KR)>
 __global__ void __launch_bounds__(512)
 k_mid128r(MidArgs g) {
-    static_assert(!HALFIN || NP == 16, "HALFIN: 16-slot tiles");
+    static_assert(!HALFIN || NP >= 16, "HALFIN: 16- and 32-slot tiles");
     if constexpr (HALFIN) {
-        if (((threadIdx.x >> 3) % NP) >= 8) {   // wave-uniform: a wave owns 8 consecutive slots of one ciphertext
+        if (((threadIdx.x >> 3) % NP) >= NP / 2) {   // wave-uniform: a wave owns 8 consecutive slots of one ciphertext
             mid128r_body<CT, NP, PERM, NR, KR, true, false>(g);
             return;
         }

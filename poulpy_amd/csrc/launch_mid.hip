@@ -86,20 +86,22 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
     }
 #define PZ_MID128_GOR1(CT_, NP_, PERM_, NR_, HALF_)                                                                        \
     {                                                                                                                      \
-        PZ_TRY(set_lds((k_mid128r<((NP_ <= 16) ? CT_ : 4), ((NP_ <= 16) ? NP_ : 16), PERM_, NR_, ((HALF_) && (NP_ == 16))>), lds)); \
-        hipLaunchKernelGGL((k_mid128r<((NP_ <= 16) ? CT_ : 4), ((NP_ <= 16) ? NP_ : 16), PERM_, NR_, ((HALF_) && (NP_ == 16))>), grid_, dim3(512), lds, M->stream, g); \
-        dispatch_note(M, "k_mid128r<CT=%d,NP=%d,PERM=%d,NR=%d,HALFIN=%d,KR=%d>", CT_, NP_, (int)(PERM_), NR_, (int)((HALF_) && (NP_ == 16)), PZ_MIDR_KR); \
+        PZ_TRY(set_lds((k_mid128r<CT_, NP_, PERM_, NR_, ((HALF_) && (NP_ >= 16))>), lds));                                  \
+        hipLaunchKernelGGL((k_mid128r<CT_, NP_, PERM_, NR_, ((HALF_) && (NP_ >= 16))>), grid_, dim3(512), lds, M->stream, g); \
+        dispatch_note(M, "k_mid128r<CT=%d,NP=%d,PERM=%d,NR=%d,HALFIN=%d,KR=%d>", CT_, NP_, (int)(PERM_), NR_, (int)((HALF_) && (NP_ >= 16)), NP_ == 32 ? 3 : PZ_MIDR_KR); \
     }
-#define PZ_MID128_GOR(CT_, NP_, PERM_)   /* k_mid128r: 16- and 8-slot tiles only, 16 or 8 product rows */                  \
+    /* k_mid128r: product rows = NP (no idle waves) or NP / 2 with the upper half of the slots without input (key switch) */ \
+    /* or, 8-slot tile, 8 rows                                                                                             */
+#define PZ_MID128_GOR(CT_, NP_, PERM_)                                                                                     \
     {                                                                                                                      \
-        if (g.row_max == 16) PZ_MID128_GOR1(CT_, NP_, PERM_, 16, false)                                                    \
-        else if (NP_ == 16 && npi <= 8) PZ_MID128_GOR1(CT_, NP_, PERM_, 8, true)                                           \
-        else PZ_MID128_GOR1(CT_, NP_, PERM_, 8, false)                                                                     \
+        if (g.row_max == NP_) PZ_MID128_GOR1(CT_, NP_, PERM_, NP_, false)                                                  \
+        else if (NP_ >= 16 && npi <= NP_ / 2) PZ_MID128_GOR1(CT_, NP_, PERM_, ((NP_ >= 16) ? NP_ / 2 : NP_), true)          \
+        else PZ_MID128_GOR1(CT_, NP_, PERM_, ((NP_ >= 16) ? NP_ / 2 : NP_), false)                                         \
     }
     /* plain product: the interleaved kernel k_mid128r where it applies — 8 or 16 product rows, no idle waves or exactly the upper half */ \
     /* of a 16-slot tile without input (key switch) — k_mid128 otherwise                                                            */
 #define PZ_MID128_PICK(CT_, NP_, perm_, skipw_, ring_)                                                                     \
-    if (ring_ && (!(skipw_) || (NP_ == 16 && npi <= 8 && npo > 8))) {                                                      \
+    if (ring_ && (!(skipw_) || (NP_ >= 16 && npi <= NP_ / 2 && npo > NP_ / 2))) {                                                      \
         if (perm_) PZ_MID128_GOR(CT_, NP_, true) else PZ_MID128_GOR(CT_, NP_, false)                                       \
     } else {                                                                                                               \
         if (perm_) { if (skipw_) PZ_MID128_GO(CT_, NP_, true, true) else PZ_MID128_GO(CT_, NP_, true, false) }             \
@@ -120,7 +122,7 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
             dispatch_note(M, "k_mid128<CT=%d,NP=%d,DS=1>", CT_, NP_);                                                      \
         } else {                                                                                                           \
             const bool skipw_ = NP_ > 8 && (npi <= NP_ - 8 || npo <= NP_ - 8);   /* shapes with idle waves */              \
-            const bool ring_ = NP_ <= 16 && mid_r && (g.row_max == 16 || g.row_max == 8);                      \
+            const bool ring_ = mid_r && (g.row_max == NP_ || (NP_ >= 16 && g.row_max == NP_ / 2));   /* product rows k_mid128r is built for */                      \
             PZ_MID128_PICK(CT_, NP_, perm, skipw_, ring_)                                                                  \
         }                                                                                                                  \
     }
