@@ -42,8 +42,12 @@ static inline int dev_dft_apply(pz_module* M, int batch, int step, int offset, D
         PolyMap sm{nv, ncs, a.bs, (long long)step * a.cols * n, n, n * ((long long)offset * a.cols + a_col)};
         PolyMap dm{nv, ncs, res.bs, (long long)res.cols * n, n, n * res_col};
         const int npolys = batch * nv * ncs;
-        PZ_TRY(launch_fwd_pass1(M, npolys, (const long long*)a.p, sm, T));
-        PZ_TRY(launch_fwd_pass2(M, npolys, T, (double*)res.p, dm, mul));
+        if (small_transform_supported(M)) {   // N <= 4096: the whole transform in LDS, one kernel, the spectrum's only trip through HBM
+            PZ_TRY(launch_small_fwd(M, npolys, (const long long*)a.p, sm, (cplx*)res.p, true, &dm, mul));
+        } else {
+            PZ_TRY(launch_fwd_pass1(M, npolys, (const long long*)a.p, sm, T));
+            PZ_TRY(launch_fwd_pass2(M, npolys, T, (double*)res.p, dm, mul));
+        }
     }
     // limbs [nv, min_steps) are left untouched (vec_znx_dft.rs:191-194); the rest is zeroed
     for (int c = 0; c < ncs; ++c)
@@ -59,6 +63,7 @@ static inline int dev_idft(pz_module* M, int batch, DV res, int res_col, DV a, i
     PolyMap sm{nlimbs, ncs, a.bs, (long long)a.cols * n, n, n * a_col};
     PolyMap dm{nlimbs, ncs, res.bs, (long long)res.cols * n, n, n * res_col};
     const int npolys = batch * nlimbs * ncs;
+    if (small_transform_supported(M) && !M->probe) return launch_small_idft(M, npolys, (const double*)a.p, sm, (long long*)res.p, dm);
     PZ_TRY(launch_inv_pass2(M, npolys, (const double*)a.p, sm, T));
     PZ_TRY(launch_inv_pass1(M, npolys, T, (long long*)res.p, dm));
     return PZ_OK;

@@ -18,6 +18,7 @@
 namespace pz {
 
 constexpr int kSmallM2 = 128, kSmallRS = 16 * 9;   // row stride as in k_mid128 (z[k1][o] at k1*9 + o)
+constexpr int kSmallIdftRS = kSmallRS + 1;
 
 struct SmallFwdArgs {
     const long long* src;
@@ -29,6 +30,11 @@ struct SmallFwdArgs {
     const cplx* wL2;     // exp(2 pi i t / 128)
     int natural;         // 1: spectrum written in the standard device order [q1 + M1 q2] (pointwise consumers holding standard keys: the
                          // blind rotation's block step) instead of S[q1][q2]; the 8 M1 threads of a store still cover 8 M1 consecutive points
+    // per-op vec_znx_dft_apply / svp_apply_dft in ONE kernel (round 3; natural order only): polynomial p goes to S + map_off(dmap, p) / 2
+    // instead of S + p m, multiplied pointwise by mul (an SvpPPol, standard order) when given
+    int use_dmap;
+    PolyMap dmap;
+    const cplx* mul;
 };
 
 // 256 threads = 2 polynomials x 128 threads; LDS 2 x M1 rows x 144 points + wL2
@@ -83,8 +89,15 @@ __global__ void __launch_bounds__(256, 2) k_small_fwd(SmallFwdArgs g) {
         Bfly<8, false>::run(x);
         Bfly<8, false>::run(x + 8);
         if (active) {
-            cplx* dst = g.S + (long long)p * m + (g.natural ? row + M1 * o : row * M2 + o);
+            cplx* dst = g.S + (g.use_dmap ? map_off(g.dmap, p) / 2 : (long long)p * m) + (g.natural ? row + M1 * o : row * M2 + o);
             const int qs = g.natural ? M1 : 1;
+            if (g.mul) {   // (natural order) x ppol[q], q = row + M1 (o + 8h + 16 k2)
+                const cplx* mp = g.mul + row + M1 * o;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; ++k2) x[8 * h + k2] = cmul(x[8 * h + k2], mp[(8 * h + 16 * k2) * M1]);
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -104,6 +117,103 @@ __global__ void __launch_bounds__(256) k_small_permute(const cplx* __restrict__ 
     const long long t = idx / M2;
     const int p = (int)(t % npolys), q1 = (int)(t / npolys);
     Pp[idx] = P[(long long)p * (M1 * M2) + q1 + M1 * q2];
+}
+
+// Per-op vec_znx_idft_apply in one kernel for N = 1024 / 2048 / 4096 (round 3): spectrum in the standard device order -> inverse row pass
+// (k_mid128's) x conj tw12 -> inverse column pass, x tw1inv (1/m folded in), round half away, saturating i64 -> VecZnxBig.  The per-op
+// path otherwise runs k_inv_pass2 + k_inv_pass1 with the spectrum's worth of T between them in HBM (32 B per coefficient instead of 16).
+struct SmallIdftArgs {
+    const cplx* S;       // spectra, polynomial p at S + map_off(smap, p) / 2 (standard order [q1 + M1 q2])
+    PolyMap smap;
+    long long* res;      // i64 coefficients, polynomial p at res + map_off(dmap, p)
+    PolyMap dmap;
+    int npolys;
+    const cplx* tw12t;
+    const cplx* wL2;
+    const cplx* tw1inv;
+};
+// 256 threads = 2 polynomials x 128 threads; LDS 2 x M1 rows x 144 points + wL2
+template <int M1>
+__global__ void __launch_bounds__(256, 2) k_small_idft(SmallIdftArgs g) {
+    // row stride 145 points (= 4 dwords mod 64 banks): the transposing drop below writes M1 consecutive rows at one column from
+    // consecutive lanes - with the tile's usual 144 (= 0 mod 64) that is an M1-way bank conflict (N = 4096: 0.79 vs 0.46 ms per GiB)
+    constexpr int M2 = kSmallM2, RS = kSmallIdftRS;
+    constexpr long long m = (long long)M1 * kSmallM2;
+    extern __shared__ cplx lds[];
+    const int tid = threadIdx.x, pl = tid >> 7, t = tid & 127;
+    cplx* wl = lds + 2 * M1 * RS;
+    if (tid < M2) wl[tid] = g.wL2[tid];
+    const int p = blockIdx.x * 2 + pl;
+    const bool active = p < g.npolys;
+    const cplx* src = g.S + map_off(g.smap, active ? p : g.npolys - 1) / 2;
+    cplx* buf = lds + pl * M1 * RS;
+    // consecutive threads read consecutive points q = q1 + M1 q2 and drop them at (q1, q2) of the tile
+#pragma unroll
+    for (int i = 0; i < M1; ++i) {
+        const int q = t + 128 * i;
+        buf[(q % M1) * RS + q / M1] = src[q];
+    }
+    __syncthreads();
+    // inverse row pass: 8 lanes per row (8 M1 of the polynomial's 128 threads)
+    const int row = t >> 3, o = t & 7;
+    if (row < M1) {
+        cplx* rowbuf = buf + row * RS;
+        cplx u[16];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) u[8 * h + k2] = rowbuf[o + 8 * h + 16 * k2];
+        Bfly<8, true>::run(u);
+        Bfly<8, true>::run(u + 8);
+        row_sync();
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int oo = 0; oo < 8; ++oo) {
+                cplx v = u[8 * h + oo];
+                const int k1 = o + 8 * h;
+                if (oo > 0) v = cmulc(v, wl[oo * k1]);   // (k1 = 0 reads W^0 = 1: exact)
+                rowbuf[k1 * 9 + oo] = v;
+            }
+        row_sync();
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) u[k1] = rowbuf[k1 * 9 + o];
+        Bfly<16, true>::run(u);
+        row_sync();
+        const cplx* tw = g.tw12t + row * M2 + o;
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) rowbuf[o + 8 * n1] = cmulc(u[n1], tw[8 * n1]);
+    }
+    __syncthreads();
+    // inverse column pass: thread t owns column j2 = t
+    {
+        cplx v[M1];
+#pragma unroll
+        for (int q1 = 0; q1 < M1; ++q1) v[q1] = buf[q1 * RS + t];
+        Bfly<M1, true>::run(v);
+        double big = 0.0;   // a SUM, so that a NaN or an infinity selects the saturating conversion (k_small_inv)
+#pragma unroll
+        for (int j1 = 0; j1 < M1; ++j1) big += fabs(v[j1].x) + fabs(v[j1].y);
+        big *= 1.0 / (double)m;
+        if (active) {
+            long long* dst = g.res + map_off(g.dmap, p) + t;
+            if (big < 2251799813685247.0) {
+#pragma unroll
+                for (int j1 = 0; j1 < M1; ++j1) {
+                    const cplx val = cmul(v[j1], g.tw1inv[j1]);
+                    dst[j1 * M2] = fast_i64_from_integral(round_half_away(val.x));
+                    dst[m + j1 * M2] = fast_i64_from_integral(round_half_away(val.y));
+                }
+            } else {
+#pragma unroll
+                for (int j1 = 0; j1 < M1; ++j1) {
+                    const cplx val = cmul(v[j1], g.tw1inv[j1]);
+                    dst[j1 * M2] = sat_i64_from_integral(round_half_away(val.x));
+                    dst[m + j1 * M2] = sat_i64_from_integral(round_half_away(val.y));
+                }
+            }
+        }
+    }
 }
 
 struct SmallInvArgs {

@@ -86,7 +86,10 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
 bool small_supported(const pz_module* M, int npi, int key_limbs);
 // standard device VmpPMat -> P'[q1][p][q2] with m = M1 x 128 (ring degrees whose plan is not M1 x 128: no launch_permute_pmat there)
 int launch_small_permute(pz_module* M, const double* P, cplx* Pp, int npolys);
-int launch_small_fwd(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* S, bool natural_order = false);
+int launch_small_fwd(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* S, bool natural_order = false,
+                     const PolyMap* dmap = nullptr, const cplx* mul = nullptr);
+bool small_transform_supported(const pz_module* M);   // N = 1024 / 2048 / 4096: per-op transforms in one kernel (launch_small.hip)
+int launch_small_idft(pz_module* M, int npolys, const double* a, PolyMap smap, long long* res, PolyMap dmap);
 int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int npi, int nrows, int ncols, int cols_out, int ksz,
                      long long* res, long long res_bs, int res_cols, int res_size, const long long* small, long long small_bs,
                      int small_cols, int small_size, int base2k, int body_col, bool noprod = false, cplx* fwd_S = nullptr, int fwd_limbs = 0,

@@ -61,11 +61,41 @@ int launch_small_permute(pz_module* M, const double* P, cplx* Pp, int npolys) {
     return PZ_OK;
 }
 
-int launch_small_fwd(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* S, bool natural_order) {
+// N = 1024 / 2048 / 4096: the per-op transforms in one kernel each (whole polynomial in LDS)
+bool small_transform_supported(const pz_module* M) {
+    const int m1 = small_m1(M);
+    static const int on = getenv("POULPY_DBG_SMALL_FFT") ? atoi(getenv("POULPY_DBG_SMALL_FFT")) : 1;   // 0: two-pass per-op transforms (A/B)
+    return on && (M->m % kSmallM2) == 0 && (m1 == 4 || m1 == 8 || m1 == 16);
+}
+int launch_small_idft(pz_module* M, int npolys, const double* a, PolyMap smap, long long* res, PolyMap dmap) {
+    if (npolys <= 0) return PZ_OK;
+    PZ_TRY(ensure_small_tables(M));
+    SmallIdftArgs g;
+    g.S = (const cplx*)a; g.smap = smap; g.res = res; g.dmap = dmap; g.npolys = npolys;
+    g.tw12t = M->s_tw12t; g.wL2 = M->s_wL2; g.tw1inv = M->s_tw1inv;
+    const int m1 = small_m1(M);
+    const size_t lds = ((size_t)2 * m1 * kSmallIdftRS + kSmallM2) * sizeof(cplx);
+    KTimer kt(M, PZ_K_INV_PASS1);
+    const dim3 grid((unsigned)((npolys + 1) / 2));
+#define X(M1_)                                                                                      \
+    if (m1 == M1_) {                                                                                \
+        PZ_TRY(set_lds(k_small_idft<M1_>, lds));                                                    \
+        hipLaunchKernelGGL(k_small_idft<M1_>, grid, dim3(256), lds, M->stream, g);                  \
+        PZ_HIP(hipGetLastError());                                                                  \
+        return PZ_OK;                                                                               \
+    }
+    X(4) X(8) X(16)
+#undef X
+    return fail(PZ_ERR_UNSUPPORTED, "small-ring transform: unsupported ring degree");
+}
+int launch_small_fwd(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* S, bool natural_order, const PolyMap* dmap,
+                     const cplx* mul) {
     if (npolys <= 0) return PZ_OK;
     PZ_TRY(ensure_small_tables(M));
     SmallFwdArgs g;
     g.src = src; g.smap = smap; g.S = S; g.npolys = npolys; g.tw1 = M->s_tw1; g.tw12t = M->s_tw12t; g.wL2 = M->s_wL2; g.natural = natural_order ? 1 : 0;
+    g.use_dmap = dmap ? 1 : 0; g.dmap = dmap ? *dmap : smap; g.mul = mul;
+    if ((dmap || mul) && !natural_order) return fail(PZ_ERR_INVALID, "small-ring forward transform: a destination map / factor needs the standard order");
     const int m1 = small_m1(M);
     const size_t lds = ((size_t)2 * m1 * kSmallRS + kSmallM2) * sizeof(cplx);
     KTimer kt(M, PZ_K_FWD_PASS1);
