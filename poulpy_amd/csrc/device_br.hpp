@@ -194,7 +194,11 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
 #pragma unroll
                         for (int j = 0; j < CG; ++j) out[pj][ct][j] = make_double2(0.0, 0.0);
                     // (a second register set that prefetches coefficient i+1 during the arithmetic of i was tried: it spills
-                    // at 256 VGPRs and is 5-12 % slower)
+                    // at 256 VGPRs and is 5-12 % slower.  Round 3: the coefficient loop as one stream of (coefficient, column) steps with
+                    // a ring of CG key slots requested CG - 1 steps ahead and the monomial factors one coefficient ahead - the
+                    // scheme that pays in k_mid128r - was bit-exact and SLOWER here, 129 500 -> 122 800 rotations/s at N = 512 and
+                    // 109 900 -> 107 500 at N = 1024 (52-76 bytes of scratch; profiles/r03_ab_br_pipe.txt): the latency of the
+                    // coefficient's requests is already covered by the other waves)
                     for (int i = blk0; i < blk0 + g.blk; ++i) {
                         const cplx* K = g.brk + (long long)i * g.key_stride;
                         cplx kv[CG][MAXR];
