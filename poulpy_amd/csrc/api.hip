@@ -859,8 +859,12 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
             // N = 4096, plain external product / key switch with <= 4 key limbs: two kernels, the spectra cross HBM once (device_small.hpp)
             static const int small_env = getenv("POULPY_DBG_SMALL") ? atoi(getenv("POULPY_DBG_SMALL")) : 1;
             static const int small_au4 = getenv("POULPY_DBG_SMALL_AUTO") ? atoi(getenv("POULPY_DBG_SMALL_AUTO")) : 1;
+            // (round 3: the 8-slot tile of k_mid128r - 8 polynomials in, 8 out, 8 product rows: the external product with 4 limbs, BASELINE
+            //  configs[1] - now beats the two-kernel form, 3.25 vs 3.16 M/s, profiles/r03_ab_small_vs_pipeline.txt; POULPY_DBG_SMALL=2 forces
+            //  the two-kernel form there too)
+            const bool mid8 = !ks && !au && npi == 8 && npo == 8 && std::min(nrows, npi) == 8 && small_env != 2;
             if (small_env && M->small_path && (!au || (small_au4 && ks && !lay)) && !tensor && !digits && !cross_out && !M->probe && M->dbg_stages == 7 &&
-                small_supported(M, npi, ksz)) {
+                small_supported(M, npi, ksz) && !mid8) {
                 const bool rsh4 = want_rsh && au && au->mode != 0 && p->res_base2k <= 29;
                 PZ_TRY(launch_small_fwd(M, nb * npi, (const long long*)av.p, sm, T));
                 PZ_TRY(launch_small_inv(M, nb, T, Pp, npi, nrows, ncols, s.cols_out, ksz, (long long*)(res + (long long)b0 * res_bs), res_bs,
