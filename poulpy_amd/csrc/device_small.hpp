@@ -19,6 +19,9 @@ namespace pz {
 
 constexpr int kSmallM2 = 128, kSmallRS = 16 * 9;   // row stride as in k_mid128 (z[k1][o] at k1*9 + o)
 constexpr int kSmallIdftRS = kSmallRS + 1;
+#ifndef PZ_SMALL_STAMP
+#define PZ_SMALL_STAMP 0   // diagnostic build: per-phase s_memtime totals of k_small_inv, printed by three waves of three workgroups
+#endif
 
 struct SmallFwdArgs {
     const long long* src;
@@ -142,16 +145,23 @@ __global__ void __launch_bounds__(256, 2) k_small_idft(SmallIdftArgs g) {
     extern __shared__ cplx lds[];
     const int tid = threadIdx.x, pl = tid >> 7, t = tid & 127;
     cplx* wl = lds + 2 * M1 * RS;
+    cplx* tw1i = wl + M2;   // untwist factors as LDS broadcasts (k_small_inv)
     if (tid < M2) wl[tid] = g.wL2[tid];
+    else if (tid < M2 + M1) tw1i[tid - M2] = g.tw1inv[tid - M2];
     const int p = blockIdx.x * 2 + pl;
     const bool active = p < g.npolys;
     const cplx* src = g.S + map_off(g.smap, active ? p : g.npolys - 1) / 2;
     cplx* buf = lds + pl * M1 * RS;
-    // consecutive threads read consecutive points q = q1 + M1 q2 and drop them at (q1, q2) of the tile
+    // consecutive threads read consecutive points q = q1 + M1 q2 and drop them at (q1, q2) of the tile; all M1 loads first (left to
+    // itself the compiler waited for each one before its LDS store: 61 of the 63 loads of the N = 4096 kernel sat behind vmcnt(0))
+    {
+        cplx in[M1];
 #pragma unroll
-    for (int i = 0; i < M1; ++i) {
-        const int q = t + 128 * i;
-        buf[(q % M1) * RS + q / M1] = src[q];
+        for (int i = 0; i < M1; ++i) in[i] = src[t + 128 * i];
+        // q = t + 128 i: q % M1 = t % M1, q / M1 = t / M1 + (128 / M1) i
+        cplx* drop = buf + (t % M1) * RS + t / M1;
+#pragma unroll
+        for (int i = 0; i < M1; ++i) drop[(128 / M1) * i] = in[i];
     }
     __syncthreads();
     // inverse row pass: 8 lanes per row (8 M1 of the polynomial's 128 threads)
@@ -182,7 +192,15 @@ __global__ void __launch_bounds__(256, 2) k_small_idft(SmallIdftArgs g) {
         row_sync();
         const cplx* tw = g.tw12t + row * M2 + o;
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) rowbuf[o + 8 * n1] = cmulc(u[n1], tw[8 * n1]);
+        for (int h = 0; h < 2; ++h) {   // two batches of 8 loads (k_small_inv)
+            cplx t8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t8[i] = tw[8 * (8 * h + i)];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rowbuf[o + 8 * (8 * h + i)] = cmulc(u[8 * h + i], t8[i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     __syncthreads();
     // inverse column pass: thread t owns column j2 = t
@@ -200,14 +218,14 @@ __global__ void __launch_bounds__(256, 2) k_small_idft(SmallIdftArgs g) {
             if (big < 2251799813685247.0) {
 #pragma unroll
                 for (int j1 = 0; j1 < M1; ++j1) {
-                    const cplx val = cmul(v[j1], g.tw1inv[j1]);
+                    const cplx val = cmul(v[j1], tw1i[j1]);
                     dst[j1 * M2] = fast_i64_from_integral(round_half_away(val.x));
                     dst[m + j1 * M2] = fast_i64_from_integral(round_half_away(val.y));
                 }
             } else {
 #pragma unroll
                 for (int j1 = 0; j1 < M1; ++j1) {
-                    const cplx val = cmul(v[j1], g.tw1inv[j1]);
+                    const cplx val = cmul(v[j1], tw1i[j1]);
                     dst[j1 * M2] = sat_i64_from_integral(round_half_away(val.x));
                     dst[m + j1 * M2] = sat_i64_from_integral(round_half_away(val.y));
                 }
@@ -267,9 +285,19 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
     const int b = (slot / g.cols_out) * 8 + xcd, col = slot % g.cols_out;
     if (b >= g.batch) return;
     cplx* wl = lds + KS * M1 * RS;
+    cplx* tw1i = wl + M2;   // the untwist factors, read as LDS broadcasts by the column pass (as loads from g.tw1inv they were vector loads, one L2 latency each)
     if (tid < M2) wl[tid] = g.wL2[tid];
+    else if (tid < M2 + M1) tw1i[tid - M2] = g.tw1inv[tid - M2];
     const int k = g.base2k;
     const int row_max = min(g.nrows, g.npi);
+#if PZ_SMALL_STAMP
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_t0 = st_t;
+#define PZ_SSTAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; }
+#else
+#define PZ_SSTAMP(i)
+#endif
     // ---------------- product, one pass over S: acc[l][j] = sum_r S[r][pos_j] * P'[q1_j][r][l * cols_out + col][q2_j], pos_j = tid + NT j ----------------
     const int pq2 = tid & 127, pq1 = tid >> 7;   // q1 = pq1 + (M1 / 2) j
     cplx acc[KS][2];
@@ -319,24 +347,33 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
 #pragma unroll
             for (int l = 0; l < KS; ++l) kA[l] = kB[l] = make_double2(0.5, 0.25);
         }
+        // the sched_barriers keep the two slots in ping-pong: without them the machine scheduler gathers the ten loads of a row at the top of
+        // the iteration and the wave drains to vmcnt(0) once per row (round 3: seen in the ISA, product phase 29 k cycles per item at N = 4096)
         PZ_SMALL_LOAD(aA, kA, 0, 0)
         for (int r = 0; r < row_max; ++r) {
             const int rn = min(r + 1, row_max - 1);   // (the last prefetch is simply unused)
             PZ_SMALL_LOAD(aB, kB, r, 1)
+            __builtin_amdgcn_sched_barrier(0);
             PZ_SMALL_USE(aA, kA, 0)
+            __builtin_amdgcn_sched_barrier(0);
             PZ_SMALL_LOAD(aA, kA, rn, 0)
+            __builtin_amdgcn_sched_barrier(0);
             PZ_SMALL_USE(aB, kB, 1)
+            __builtin_amdgcn_sched_barrier(0);
         }
 #undef PZ_SMALL_LOAD
 #undef PZ_SMALL_USE
     }
+    PZ_SSTAMP(0)
     if constexpr (!NOPROD) {
 #pragma unroll
         for (int l = 0; l < KS; ++l)
 #pragma unroll
             for (int j = 0; j < 2; ++j) lds[(l * M1 + pq1 + (M1 / 2) * j) * RS + pq2] = acc[l][j];
     }
+    PZ_SSTAMP(1)
     __syncthreads();
+    PZ_SSTAMP(2)
     // ---------------- inverse row pass (k_mid128) of the KS polynomials, x conj tw12, back into the tile as T2[q1][j2] ----------------
     {
         const int rp = tid / (8 * M1), rrow = (tid % (8 * M1)) >> 3, ro = tid & 7;   // 8 M1 threads per polynomial
@@ -347,8 +384,14 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) u[8 * h + k2] = rowbuf[ro + 8 * h + 16 * k2];
+#if PZ_SMALL_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); PZ_SSTAMP(8)
+#endif
             Bfly<8, true>::run(u);
             Bfly<8, true>::run(u + 8);
+#if PZ_SMALL_STAMP
+            __builtin_amdgcn_sched_barrier(0); PZ_SSTAMP(9)
+#endif
             row_sync();
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -360,16 +403,36 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
                     rowbuf[k1 * 9 + oo] = v;
                 }
             row_sync();
+#if PZ_SMALL_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); PZ_SSTAMP(10)
+#endif
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) u[k1] = rowbuf[k1 * 9 + ro];
+#if PZ_SMALL_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); PZ_SSTAMP(11)
+#endif
             Bfly<16, true>::run(u);
+#if PZ_SMALL_STAMP
+            __builtin_amdgcn_sched_barrier(0); PZ_SSTAMP(12)
+#endif
             row_sync();
+            // the 16 inter-pass twiddles in two batches of 8 (left to itself the compiler loads them one by one behind vmcnt(0): 16 L2 latencies)
             const cplx* tw = g.tw12t + rrow * M2 + ro;
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) rowbuf[ro + 8 * n1] = cmulc(u[n1], tw[8 * n1]);
+            for (int h = 0; h < 2; ++h) {
+                cplx t8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t8[i] = tw[8 * (8 * h + i)];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) rowbuf[ro + 8 * (8 * h + i)] = cmulc(u[8 * h + i], t8[i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
+    PZ_SSTAMP(3)
     __syncthreads();
+    PZ_SSTAMP(6)
     // ---------------- inverse column pass + rounding, NT / 128 limbs at a time: thread = (limb, column j2); the 2 M1 integers go back
     // into the tile in place of the column's M1 complex values (same bytes) ----------------
 #pragma unroll
@@ -389,7 +452,7 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
             longlong2* out = reinterpret_cast<longlong2*>(lds);
 #define PZ_SMALL_ROUND(CONVERT)                                                                               \
     _Pragma("unroll") for (int j1 = 0; j1 < M1; ++j1) {                                                      \
-        const cplx val = cmul(v[j1], g.tw1inv[j1]);                                                          \
+        const cplx val = cmul(v[j1], tw1i[j1]);                                                              \
         out[(cl * M1 + j1) * RS + cj] = make_longlong2(CONVERT(round_half_away(val.x)), CONVERT(round_half_away(val.y))); \
     }
             if (big < 2251799813685247.0) {   // 2^51 - 1 (false for NaN too)
@@ -400,7 +463,9 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
 #undef PZ_SMALL_ROUND
         }
     }
+    PZ_SSTAMP(4)
     __syncthreads();
+    PZ_SSTAMP(7)
     // ---------------- (+ key-switch body), carry chain from the last limb up, stores: thread = (column j2, component, j1 parity), 8 coefficients ----------------
     constexpr int JG = M1 / 4;   // thread groups over j1 (NT / 256): this thread's outputs are j1 = JG e + jq, e < 4
     const int cj2 = tid & 127, ch = (tid >> 7) & 1, jq = tid >> 8;   // component 0: coefficients j < m, 1: j >= m
@@ -439,6 +504,27 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { opos[e] = JG * e * M2; oneg[e] = false; }
     }
+    // key-switch body / per-column operand of this thread's coefficients, all limbs in one batch (inside the carry loop each load sat behind
+    // its own vmcnt(0): 4 KS L2 latencies).  Limbs beyond the operand's size: the last one is read again and masked
+    long long smv[AU ? 1 : KS][4];
+    if constexpr (!AU) {
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) smv[j][e] = 0;
+        if (small_col && g.small_size > 0) {
+#pragma unroll
+            for (int j = 0; j < KS; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) smv[j][e] = small_col[(long long)min(j, g.small_size - 1) * small_ls + JG * e * M2];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < KS; ++j)
+                if (j >= g.small_size)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) smv[j][e] = 0;
+        }
+    }
     // limbs of res beyond the precision of the big value are zero (normalize.rs:118-120); shifted stores: limb L receives the bit shifted
     // out of limb L - 1
     const bool rsh = AU && g.post_rsh;
@@ -450,8 +536,6 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
     const long long* xin = reinterpret_cast<const long long*>(lds) + ch;
 #pragma unroll
     for (int j = L - 1; j >= 0; --j) {
-        const bool add_small = small_col && j < g.small_size;
-        const long long* sm_limb = add_small ? small_col + (long long)j * small_ls : nullptr;
         const bool writes = j < g.res_size;
         const bool first = j == L - 1;
 #pragma unroll
@@ -465,7 +549,7 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
                     ux = g.au_mode == 1 ? ux + aj : (g.au_mode == 2 ? ux - aj : aj - ux);
                 }
                 x = (long long)ux;
-            } else if (add_small) x = (long long)((unsigned long long)x + (unsigned long long)sm_limb[JG * e * M2]);
+            } else x = (long long)((unsigned long long)x + (unsigned long long)smv[j][e]);
             long long& cy = carry[e];
             const unsigned long long y = (unsigned long long)x + half;
             const long long d = (long long)(y & mask) - (long long)half;
@@ -502,6 +586,13 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
             }
         }
     }
+    PZ_SSTAMP(5)
+#if PZ_SMALL_STAMP
+    if ((tid & 63) == 0 && blockIdx.x == 257)
+        printf("SSTAMP wg %d wave %2d t0 %llu total %llu | product %llu accwr %llu bar1 %llu rowpass [rd %llu b8 %llu tw+wr %llu rd %llu b16 %llu tw+wr %llu] bar2 %llu colpass %llu bar3 %llu carry %llu\n", (int)blockIdx.x, tid >> 6,
+               (unsigned long long)(st_t0 & 0xffffffull), (unsigned long long)(st_t - st_t0), st_acc[0], st_acc[1], st_acc[2], st_acc[8], st_acc[9], st_acc[10], st_acc[11], st_acc[12], st_acc[3], st_acc[6], st_acc[4], st_acc[7], st_acc[5]);
+#endif
+#undef PZ_SSTAMP
     if constexpr (FWD) {
         __syncthreads();
         // ---------------- forward column pass (k_small_fwd), NT / 128 limbs at a time: thread = (limb, column j2) ----------------

@@ -74,7 +74,7 @@ int launch_small_idft(pz_module* M, int npolys, const double* a, PolyMap smap, l
     g.S = (const cplx*)a; g.smap = smap; g.res = res; g.dmap = dmap; g.npolys = npolys;
     g.tw12t = M->s_tw12t; g.wL2 = M->s_wL2; g.tw1inv = M->s_tw1inv;
     const int m1 = small_m1(M);
-    const size_t lds = ((size_t)2 * m1 * kSmallIdftRS + kSmallM2) * sizeof(cplx);
+    const size_t lds = ((size_t)2 * m1 * kSmallIdftRS + kSmallM2 + m1) * sizeof(cplx);
     KTimer kt(M, PZ_K_INV_PASS1);
     const dim3 grid((unsigned)((npolys + 1) / 2));
 #define X(M1_)                                                                                      \
@@ -133,7 +133,7 @@ int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int
     if (fwd_S && !(noprod && fwd_limbs >= 1 && fwd_limbs <= ksz && fwd_limbs <= res_size && fwd_limbs <= 8))
         return fail(PZ_ERR_INVALID, "small-ring pipeline: forward transform of %d limbs behind the inverse of %d", fwd_limbs, ksz);
     const int m1 = small_m1(M);
-    const size_t lds = ((size_t)ksz * m1 * kSmallRS + kSmallM2) * sizeof(cplx);
+    const size_t lds = ((size_t)ksz * m1 * kSmallRS + kSmallM2 + m1) * sizeof(cplx);   // tile + wL2 + tw1inv
     // workgroup id -> (xcd = id & 7, slot = id >> 3): ciphertext (slot / cols_out) * 8 + xcd, column slot % cols_out
     const int grid = ((batch + 7) / 8) * 8 * cols_out;
     KTimer kt(M, PZ_K_FUSED_TAIL);
