@@ -247,6 +247,7 @@ struct SmallInvArgs {
     const cplx* tw1inv;          // [16] untwist with 1/m folded in
     int post_rsh;                // AU: the digits leave through vec_znx_rsh_assign by one bit (k_inv_tail<.., RSH>, device_fft.hpp); base2k <= 29
     unsigned au_p;               // AU: Galois element mod 2n (coefficient i goes to i * au_p mod 2n, negated beyond n)
+    unsigned au_pinv;            // AU: its inverse mod 2n (set by launch_small_inv)
     int au_mode;                 // AU: 0 phi(normalize(big)), 1 normalize(phi(big) + a), 2 normalize(phi(big) - a), 3 normalize(a - phi(big));
                                  //     a = column `col` of `small` (the key-switch input itself), big includes the body (body_col)
     cplx* S_out;                 // FWD: spectra of the first fwd_limbs limbs of the NEW res column, standard order, [b][limb * cols_out + col]
@@ -269,10 +270,12 @@ struct SmallInvArgs {
 // S[b][l * cols_out + col] (npi = ksz * cols_out), no key (the blind rotation's block step produced them).  FWD (blind rotation: the
 // result is the accumulator the next block transforms): the digits go back into the tile as doubles and the forward transform of
 // k_small_fwd runs on them before the workgroup ends - the next block's k_small_fwd launch and its read of the accumulator are saved.
-// AU (glwe_automorphism family, automorphism/glwe_ct.rs:51-275): the thread that owns coefficient i of the big value negates it where
-// phi = X -> X^p wraps, adds / subtracts the operand at the OUTPUT position i p mod n, runs the carry chain and stores the digits
-// there (8-byte scatters inside one polynomial: the lines fill up in L2).  In place (res == a): the body values (input positions) are
-// read by every thread before any thread stores.
+// AU (glwe_automorphism family, automorphism/glwe_ct.rs:51-275): a thread owns OUTPUT positions, takes the big value's coefficient
+// i = position * p^-1 mod 2n from the tile (LDS gather), negates it where phi = X -> X^p wraps, adds / subtracts the operand at its
+// position, runs the carry chain and stores the digits - coalesced (rounds 1 - 2 owned the SOURCE coefficient and scattered 8-byte
+// stores; round 3: glwe_trace at N = 4096 +24 %).  The key-switch body is added at the source positions by the column pass (coalesced
+// loads).  In place (res == a): those loads happen before the barrier in front of the carry phase, i.e. before any thread stores; the
+// operand at a thread's own positions is loaded before its first store.
 template <int M1, int KS, bool NOPROD = false, bool FWD = false, bool AU = false>
 __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
     constexpr int NT = 64 * M1;          // 2 product positions per thread (m = 128 M1 points)
@@ -452,10 +455,25 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
             for (int j1 = 0; j1 < M1; ++j1) big += fabs(v[j1].x) + fabs(v[j1].y);
             big *= 1.0 / (double)m;
             longlong2* out = reinterpret_cast<longlong2*>(lds);
+            // AU: the key-switch body joins the big value here, at the SOURCE positions this thread holds (coalesced loads, four j1 at a time);
+            // the carry phase then owns output positions and has nothing left to gather from global memory.  In place: read before the barrier
+            const long long* bsrc = nullptr;
+            if constexpr (AU) {
+                if (g.small && (col == g.body_col || g.body_col < 0) && cl < g.small_size)
+                    bsrc = g.small + (long long)b * g.small_bs + (g.body_col < 0 ? (long long)col * n : 0) + (long long)cl * g.small_cols * n + cj;
+            }
 #define PZ_SMALL_ROUND(CONVERT)                                                                               \
-    _Pragma("unroll") for (int j1 = 0; j1 < M1; ++j1) {                                                      \
-        const cplx val = cmul(v[j1], tw1i[j1]);                                                              \
-        out[(cl * M1 + j1) * RS + cj] = make_longlong2(CONVERT(round_half_away(val.x)), CONVERT(round_half_away(val.y))); \
+    _Pragma("unroll") for (int jb = 0; jb < M1; jb += 4) {                                                   \
+        long long bx_[4] = {0, 0, 0, 0}, by_[4] = {0, 0, 0, 0};                                              \
+        if (AU && bsrc) {                                                                                    \
+            _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) { bx_[t_] = bsrc[(jb + t_) * M2]; by_[t_] = bsrc[m + (jb + t_) * M2]; } \
+        }                                                                                                    \
+        _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                                   \
+            const int j1 = jb + t_;                                                                          \
+            const cplx val = cmul(v[j1], tw1i[j1]);                                                          \
+            out[(cl * M1 + j1) * RS + cj] = make_longlong2((long long)((unsigned long long)CONVERT(round_half_away(val.x)) + (unsigned long long)bx_[t_]), \
+                                                           (long long)((unsigned long long)CONVERT(round_half_away(val.y)) + (unsigned long long)by_[t_])); \
+        }                                                                                                    \
     }
             if (big < 2251799813685247.0) {   // 2^51 - 1 (false for NaN too)
                 PZ_SMALL_ROUND(fast_i64_from_integral)
@@ -481,30 +499,45 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
             ? g.small + (long long)b * g.small_bs + (g.body_col < 0 ? (long long)col * n : 0) + (ch ? m : 0) + cj2 + (long long)jq * M2
             : nullptr;
     const long long small_ls = (long long)g.small_cols * n;
-    // AU: output position and sign of this thread's four coefficients; the operand a[col] at those positions; the body read up front
+    // AU: the thread owns four OUTPUT positions (consecutive lanes, consecutive positions: stores and operand loads coalesce) and fetches
+    // their source coefficients i = position * p^-1 mod 2n (negated where that product is >= n) from the tile - an LDS gather instead of
+    // the 8-byte global scatters of round 2 (the key-switch body, which sits at the SOURCE positions, joined the tile in the column pass)
     long long opos[4];
     bool oneg[4];
-    long long bodyv[AU ? KS : 1][4];
+    int lsrc[4];   // index of the source coefficient's limb-0 value in the tile (as long long)
+    long long auv[AU ? KS : 1][4];   // operand of this thread's positions, all limbs, loaded in one batch (in place: before this thread's stores)
     const long long* au_col = nullptr;
     if constexpr (AU) {
         const unsigned n2m = 2u * (unsigned)n - 1u;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const unsigned i = (unsigned)((ch ? m : 0) + (long long)(JG * e + jq) * M2 + cj2);
-            const unsigned jj = (i * g.au_p) & n2m;
-            oneg[e] = jj >= (unsigned)n;
-            opos[e] = (long long)(jj & ((unsigned)n - 1u));
+            const unsigned jo = (unsigned)((ch ? m : 0) + (long long)(JG * e + jq) * M2 + cj2);   // output position
+            const unsigned i0 = (jo * g.au_pinv) & n2m;
+            oneg[e] = i0 >= (unsigned)n;
+            const unsigned i = i0 & ((unsigned)n - 1u), ich = i >= (unsigned)m ? 1u : 0u, ii = i - ich * (unsigned)m;
+            opos[e] = (long long)jo;
+            lsrc[e] = 2 * (int)((ii >> 7) * RS + (ii & 127u)) + (int)ich;
         }
         res_col = g.res + (long long)b * g.res_bs + (long long)col * n;
         if (g.au_mode != 0 && g.small) au_col = g.small + (long long)b * g.small_bs + (long long)col * n;
 #pragma unroll
         for (int j = 0; j < KS; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bodyv[j][e] = (small_col && j < g.small_size) ? small_col[(long long)j * small_ls + JG * e * M2] : 0;
-        __syncthreads();
+            for (int e = 0; e < 4; ++e) auv[j][e] = 0;
+        if (au_col && g.small_size > 0) {
+#pragma unroll
+            for (int j = 0; j < KS; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) auv[j][e] = au_col[(long long)min(j, g.small_size - 1) * small_ls + opos[e]];
+        }
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+            if (j >= g.small_size)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) auv[j][e] = 0;
     } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { opos[e] = JG * e * M2; oneg[e] = false; }
+        for (int e = 0; e < 4; ++e) { opos[e] = JG * e * M2; oneg[e] = false; lsrc[e] = 2 * ((JG * e + jq) * RS + cj2) + ch; }
     }
     // key-switch body / per-column operand of this thread's coefficients, all limbs in one batch (inside the carry loop each load sat behind
     // its own vmcnt(0): 4 KS L2 latencies).  Limbs beyond the operand's size: the last one is read again and masked
@@ -535,19 +568,19 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) res_col[(long long)j * res_ls + opos[e]] = 0;
     const unsigned long long half = 1ull << (k - 1), mask = (1ull << k) - 1;
-    const long long* xin = reinterpret_cast<const long long*>(lds) + ch;
+    const long long* xin = reinterpret_cast<const long long*>(lds);
 #pragma unroll
     for (int j = L - 1; j >= 0; --j) {
         const bool writes = j < g.res_size;
         const bool first = j == L - 1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            long long x = xin[2 * ((j * M1 + JG * e + jq) * RS + cj2)];
+            long long x = xin[lsrc[e] + 2 * j * M1 * RS];
             if constexpr (AU) {
-                unsigned long long ux = (unsigned long long)x + (unsigned long long)bodyv[j][e];
+                unsigned long long ux = (unsigned long long)x;   // (the body was added at the source position, in the column pass)
                 if (g.au_mode != 0) {   // phi on the big value, then +- a over the common limbs (limbs beyond a: + 0, - 0, 0 - big)
                     if (oneg[e]) ux = 0ull - ux;
-                    const unsigned long long aj = (au_col && j < g.small_size) ? (unsigned long long)au_col[(long long)j * small_ls + opos[e]] : 0ull;
+                    const unsigned long long aj = (unsigned long long)auv[j][e];
                     ux = g.au_mode == 1 ? ux + aj : (g.au_mode == 2 ? ux - aj : aj - ux);
                 }
                 x = (long long)ux;
@@ -565,7 +598,7 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
                 if (writes && (!(PZ_DBG(g.dbg) & 4) || x1 == 0x7fffffffffffLL)) {
                     // AU mode 0: phi acts on the normalized digits (glwe_ct.rs:69-71)
                     const long long xs = (AU && g.au_mode == 0 && oneg[e]) ? (long long)(0ull - (unsigned long long)x1) : x1;
-                    if constexpr (AU) {   // scattered 8-byte stores: cacheable, so that the lines fill up in L2
+                    if constexpr (AU) {   // (plain stores: in place the operand's lines are re-read by the next trace step)
                         if (rsh) {
                             const int xd = (int)xs, d1 = -(xd & 1), cr1 = (xd - d1) >> 1;
                             if (j == g.res_size - 1) {

@@ -127,6 +127,11 @@ int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int
     g.dbg = skip;
     g.S_out = fwd_S; g.tw1 = M->s_tw1; g.fwd_limbs = fwd_S ? fwd_limbs : 0;
     g.au_p = au_p; g.au_mode = au_mode; g.post_rsh = (post_rsh && au) ? 1 : 0;
+    {   // p^-1 mod 2^32 by Newton steps (p odd), reduced mod 2n in the kernel
+        unsigned x = au_p | 1u;
+        for (int it = 0; it < 5; ++it) x *= 2u - (au_p | 1u) * x;
+        g.au_pinv = x;
+    }
     if (post_rsh && !(au && au_mode != 0 && base2k <= 29)) return fail(PZ_ERR_INVALID, "small-ring pipeline: shifted stores need an automorphism form with an operand, base2k <= 29");
     if (au && (noprod || fwd_S || small == nullptr || small_cols != cols_out))
         return fail(PZ_ERR_INVALID, "small-ring pipeline: the automorphism variant needs the key-switch operand");

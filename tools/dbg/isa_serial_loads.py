@@ -41,7 +41,7 @@ for line in open(path):
             flush(); name = None
 names = [r[0] for r in rows]
 try:
-    dem = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+    dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
 except Exception:
     dem = names
 for (n, loads, lone), d in zip(rows, dem):
