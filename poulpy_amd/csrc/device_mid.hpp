@@ -689,7 +689,7 @@ k_mid128(MidArgs g) {
 // issues its share of the stores and key requests in the same order.  Both codes execute the same barriers.  They are two
 // instantiations of this function rather than branches inside one loop because a branch around the loads makes the compiler's
 // s_waitcnt insertion assume the worst case at every join (k_mid128, SKIPW).
-template <int CT, int NP, bool PERM, int NR, int KR, bool HALFIN, bool IN>
+template <int CT, int NP, bool PERM, int NR, int KR, bool HALFIN, bool IN, bool DS = false>
 __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
     constexpr int M2 = 128, NT = 512;
     constexpr int NC = NP == 32 ? 8 : 4;   // outputs per thread (32-slot tile: two ciphertexts x 8 outputs, as in k_mid128)
@@ -737,8 +737,10 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
         return g.T + ((long long)b_ * g.npi + r_) * m + (long long)tile_q1(Lc) * M2 + o;
     };
     auto in_active = [&](int L, int ctl, int rr) { return L < ntiles && (L % g.n_ct) * CT + ctl < g.batch && rr < g.npi; };
-    constexpr int nrow = NR;           // product rows (launch_mid: g.row_max == NR)
-    const int rot = w % nrow;
+    constexpr int nrow = NR;           // product rows (launch_mid: g.row_max == NR; DS: product terms, g.ds_n == NR)
+    // (DS: no rotation of the term order between workgroups - with a run-time first term every lookup in the ds_* tables is a scalar
+    //  load of its own in front of the row it steers; in program order the compiler fetches the tables once)
+    const int rot = DS ? 0 : w % nrow;
 
     cplx x[16];     // the next tile's T' values (in flight during the inverse pass), then the forward pass's working set
     cplx u[16];     // the inverse pass's working set, then the tile's results until the forward pass has stored them
@@ -757,8 +759,11 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
         int r_ = rot + (SLOT);                                                                         \
         r_ -= (r_ >= nrow) ? nrow : 0;                                                                 \
         r_ -= (r_ >= nrow) ? nrow : 0;                                                                 \
-        _Pragma("unroll") for (int j = 0; j < NC; ++j)                                                 \
-            kr[SLOT][j] = g.P[(base_ + (long long)r_ * g.ncols + min(vcg * NC + j, g.ncomp - 1)) * M2 + vq2]; \
+        const int krow_ = DS ? (int)g.ds_row[r_] : r_;                                                 \
+        _Pragma("unroll") for (int j = 0; j < NC; ++j) {                                               \
+            const int c_ = DS ? min(vcg * NC + j, max((int)g.ds_cb[r_], 1) - 1) + (int)g.ds_coff[r_] : min(vcg * NC + j, g.ncomp - 1); \
+            kr[SLOT][j] = g.P[(base_ + (long long)krow_ * g.ncols + c_) * M2 + vq2];                   \
+        }                                                                                              \
     }
     // forward row DFT of x (see k_mid128) with the held-back stores (STORES) and the next product's first key rows in its gaps
 #define PZ_MIDR_FWD(LT, STORES)                                                                   \
@@ -855,7 +860,7 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
                 for (int j = 0; j < NC; ++j) acc[i][j] = make_double2(0.0, 0.0);
             const cplx* pp[NC];
 #pragma unroll
-            for (int j = 0; j < NC; ++j) pp[j] = g.P + ((long long)q1 * g.nrows * g.ncols + min(cg * NC + j, g.ncomp - 1)) * M2 + q2;
+            for (int j = 0; j < NC; ++j) pp[j] = g.P + ((long long)q1 * g.nrows * g.ncols + (DS ? 0 : min(cg * NC + j, g.ncomp - 1))) * M2 + q2;   // DS: the column is part of the per-term offset
             const long long prow = (long long)g.ncols * M2;
             cplx av[2][CTt];
 #define PZ_LOADROW(DST, IT)                                                                     \
@@ -863,19 +868,34 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
         int r_ = (IT) + rot;                                                                    \
         r_ -= (r_ >= nrow) ? nrow : 0;                                                          \
         r_ -= (r_ >= nrow) ? nrow : 0;                                                          \
-        const long long off_ = (long long)r_ * prow;                                            \
-        _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = pp[j][off_];                    \
+        if constexpr (DS) {                                                                     \
+            const int cb_ = max((int)g.ds_cb[r_], 1) - 1, co_ = (int)g.ds_coff[r_];             \
+            const long long ro_ = (long long)g.ds_row[r_] * prow;                               \
+            _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = pp[j][ro_ + (long long)(min(cg * NC + j, cb_) + co_) * M2]; \
+        } else {                                                                                \
+            const long long off_ = (long long)r_ * prow;                                        \
+            _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = pp[j][off_];                \
+        }                                                                                       \
     }
 #define PZ_AVLOAD(DST, IT)                                                                      \
     {                                                                                           \
         int r_ = (IT) + rot;                                                                    \
         r_ -= (r_ >= nrow) ? nrow : 0;                                                          \
         r_ -= (r_ >= nrow) ? nrow : 0;                                                          \
-        _Pragma("unroll") for (int i = 0; i < CTt; ++i) DST[i] = lds[((vtg * CTt + i) * NP + r_) * RS + q2]; \
+        const int slot_ = DS ? (int)g.ds_in[r_] : r_;   /* DS: term r_ multiplies input polynomial ds_in[r_] */ \
+        _Pragma("unroll") for (int i = 0; i < CTt; ++i) DST[i] = lds[((vtg * CTt + i) * NP + slot_) * RS + q2]; \
         __builtin_amdgcn_sched_barrier(0);   /* the machine scheduler otherwise sinks these reads down to their first use */ \
     }
-#define PZ_FMAROW(AV, SRC)                                                                      \
+#define PZ_FMAROW(AV, SRC, IT)                                                                  \
     {                                                                                           \
+        if constexpr (DS) {   /* the term only reaches the first ds_cb outputs */               \
+            int r_ = (IT) + rot;                                                                \
+            r_ -= (r_ >= nrow) ? nrow : 0;                                                      \
+            r_ -= (r_ >= nrow) ? nrow : 0;                                                      \
+            const int cbv_ = (int)g.ds_cb[r_];                                                  \
+            _Pragma("unroll") for (int j = 0; j < NC; ++j)                                      \
+                if (cg * NC + j >= cbv_) SRC[j] = make_double2(0.0, 0.0);                       \
+        }                                                                                       \
         _Pragma("unroll") for (int i = 0; i < CTt; ++i) {                                       \
             _Pragma("unroll") for (int j = 0; j < NC; ++j) {                                    \
                 acc[i][j].x = __builtin_fma(AV[i].x, SRC[j].x, acc[i][j].x);                    \
@@ -894,7 +914,7 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
             for (int it = 0; it < NR; ++it) {
                 if (it + KR - 1 < NR) PZ_LOADROW(kr[(it + KR - 1) % KR], it + KR - 1)
                 if (it + 1 < NR) PZ_AVLOAD(av[(it + 1) & 1], it + 1)
-                PZ_FMAROW(av[it & 1], kr[it % KR])
+                PZ_FMAROW(av[it & 1], kr[it % KR], it)
             }
 #undef PZ_LOADROW
 #undef PZ_AVLOAD
@@ -1007,17 +1027,20 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
 // HALFIN: a 16-slot tile whose ciphertexts carry at most 8 input polynomials (key switch, automorphism, ggsw_expand_row): the waves of
 // the upper 8 slots run the IN = false code.
 // (32-slot tiles - 16 limbs, rank 2-3 - carry 8 key values per thread and row: a ring of 3 slots there)
-template <int CT, int NP, bool PERM, int NR, bool HALFIN = false, int KR = (NP == 32 ? 3 : PZ_MIDR_KR)>
+// DS (round 3, late): the digit-group product of dsize > 1 (MidArgs::ds_*: NR product terms, each with its input slot, key row, column
+// offset and column bound) - the addressing of k_mid128<.., DS> on this kernel's schedule.
+template <int CT, int NP, bool PERM, int NR, bool HALFIN = false, int KR = (NP == 32 ? 3 : PZ_MIDR_KR), bool DS = false>
 __global__ void __launch_bounds__(512)
 k_mid128r(MidArgs g) {
     static_assert(!HALFIN || NP >= 16, "HALFIN: 16- and 32-slot tiles");
+    static_assert(!DS || !PERM, "digit groups: plain product only");
     if constexpr (HALFIN) {
         if (((threadIdx.x >> 3) % NP) >= NP / 2) {   // wave-uniform: a wave owns 8 consecutive slots of one ciphertext
-            mid128r_body<CT, NP, PERM, NR, KR, true, false>(g);
+            mid128r_body<CT, NP, PERM, NR, KR, true, false, DS>(g);
             return;
         }
     }
-    mid128r_body<CT, NP, PERM, NR, KR, HALFIN, true>(g);
+    mid128r_body<CT, NP, PERM, NR, KR, HALFIN, true, DS>(g);
 }
 
 // (Round 2 experiment, removed: "k_midr<LPR = 4>" — the same kernel for rows of 64 points owned by 4 lanes (m = 512 x 64): a tile of four

@@ -117,9 +117,26 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
             hipLaunchKernelGGL((k_mid128<CT_, NP_, false, false, true>), grid_, dim3(512), lds, M->stream, g);             \
             dispatch_note(M, "k_mid128<CT=%d,NP=%d,BR=1> (%d ciphertexts per key value)", CT_, NP_, CT_);                  \
         } else if (ds) {                                                                                                          \
-            PZ_TRY(set_lds((k_mid128<CT_, NP_, false, true>), lds));                                                       \
-            hipLaunchKernelGGL((k_mid128<CT_, NP_, false, true>), grid_, dim3(512), lds, M->stream, g);                    \
-            dispatch_note(M, "k_mid128<CT=%d,NP=%d,DS=1>", CT_, NP_);                                                      \
+            /* 16-slot tile with 16 terms on 16 inputs (external product) or 8 terms on <= 8 inputs (key switch): k_mid128r */     \
+            bool done_ = false;                                                                                            \
+            if constexpr (CT_ == 4 && NP_ == 16) {                                                                         \
+                if (mid_r && g.ds_n == 16 && npi == 16) {                                                                  \
+                    PZ_TRY(set_lds((k_mid128r<4, 16, false, 16, false, PZ_MIDR_KR, true>), lds));                          \
+                    hipLaunchKernelGGL((k_mid128r<4, 16, false, 16, false, PZ_MIDR_KR, true>), grid_, dim3(512), lds, M->stream, g); \
+                    dispatch_note(M, "k_mid128r<CT=4,NP=16,NR=16,HALFIN=0,KR=%d,DS=1>", PZ_MIDR_KR);                       \
+                    done_ = true;                                                                                          \
+                } else if (mid_r && g.ds_n == 8 && npi <= 8 && npo > 8) {                                                  \
+                    PZ_TRY(set_lds((k_mid128r<4, 16, false, 8, true, PZ_MIDR_KR, true>), lds));                            \
+                    hipLaunchKernelGGL((k_mid128r<4, 16, false, 8, true, PZ_MIDR_KR, true>), grid_, dim3(512), lds, M->stream, g); \
+                    dispatch_note(M, "k_mid128r<CT=4,NP=16,NR=8,HALFIN=1,KR=%d,DS=1>", PZ_MIDR_KR);                        \
+                    done_ = true;                                                                                          \
+                }                                                                                                          \
+            }                                                                                                              \
+            if (!done_) {                                                                                                  \
+                PZ_TRY(set_lds((k_mid128<CT_, NP_, false, true>), lds));                                                   \
+                hipLaunchKernelGGL((k_mid128<CT_, NP_, false, true>), grid_, dim3(512), lds, M->stream, g);                \
+                dispatch_note(M, "k_mid128<CT=%d,NP=%d,DS=1>", CT_, NP_);                                                  \
+            }                                                                                                              \
         } else {                                                                                                           \
             const bool skipw_ = NP_ > 8 && (npi <= NP_ - 8 || npo <= NP_ - 8);   /* shapes with idle waves */              \
             const bool ring_ = mid_r && (g.row_max == NP_ || (NP_ >= 16 && g.row_max == NP_ / 2));   /* product rows k_mid128r is built for */                      \
