@@ -55,6 +55,9 @@ extern "C" {
 
 typedef struct pz_module pz_module;
 
+/* the ABI revision this header describes (pz_abi_version() of a matching library returns it) */
+#define PZ_ABI_VERSION 3u
+
 typedef enum {
     PZ_OK = 0,
     PZ_ERR_INVALID = -1,     /* shape / argument violation (reference: assert!/debug_assert!) */
@@ -65,7 +68,8 @@ typedef enum {
 } pz_status;
 
 const char* pz_last_error(void);
-/* library/ABI version, bumped on any signature change */
+/* library/ABI version, bumped on any signature change.  PZ_ABI_VERSION is the version this header describes: clients compare it
+ * with pz_abi_version() of the library they loaded before the first call (poulpy_hip.hpp's Module, hal.py and the Rust handle do) */
 uint32_t pz_abi_version(void);
 
 /* ---- module (Backend + HalImpl::new) ------------------------------------ */

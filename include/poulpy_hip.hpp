@@ -37,8 +37,13 @@ struct VmpPMat { double* data; size_t n, rows, cols_in, cols_out, size; };
 
 class Module {  // Module<FFT64Hip>, poulpy-hal/src/layouts/module.rs:97-189
   public:
-    explicit Module(uint64_t n) { check(pz_module_new(n, &m_), "Module::new"); }
-    Module(uint64_t n, int device) { check(pz_module_new_on_device(n, device, &m_), "Module::new"); }
+    explicit Module(uint64_t n) { check_abi(); check(pz_module_new(n, &m_), "Module::new"); }
+    Module(uint64_t n, int device) { check_abi(); check(pz_module_new_on_device(n, device, &m_), "Module::new"); }
+    // a library built from another revision of poulpy_hip.h would read mismatched struct layouts: refuse it before the first call
+    static void check_abi() {
+        if (pz_abi_version() != PZ_ABI_VERSION)
+            throw Error(PZ_ERR_INVALID, "libpoulpy_hip ABI version " + std::to_string(pz_abi_version()) + ", header expects " + std::to_string(PZ_ABI_VERSION));
+    }
     ~Module() { pz_module_free(m_); }
     Module(const Module&) = delete;
     Module& operator=(const Module&) = delete;

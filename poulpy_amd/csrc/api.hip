@@ -183,7 +183,7 @@ static std::unordered_map<void*, size_t> g_host_allocs;   // pz_alloc_bytes bloc
 extern "C" {
 
 const char* pz_last_error(void) { return last_error_ref().c_str(); }
-uint32_t pz_abi_version(void) { return 3; }   // 3: + pz_module_set_phase_tuning / _phase_tuning_state, pz_debug_workspace_overrun
+uint32_t pz_abi_version(void) { return PZ_ABI_VERSION; }   // 3: + pz_module_set_phase_tuning / _phase_tuning_state, pz_debug_workspace_overrun
 
 int pz_module_new_on_device(uint64_t n, int device, pz_module** out) {
     if (!out) return fail(PZ_ERR_INVALID, "null out");

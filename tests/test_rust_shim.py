@@ -47,6 +47,7 @@ C2R = {"size_t": "usize", "int64_t": "i64", "uint64_t": "u64", "uint32_t": "u32"
 def header_functions():
     """{name: (ret, [normalised C parameter types])} — a small independent parser of the header."""
     text = re.sub(r"/\*.*?\*/", " ", read(ROOT, "include", "poulpy_hip.h"), flags=re.S)
+    text = re.sub(r"^\s*#[^\n]*", " ", text, flags=re.M)   # preprocessor lines (include guards, PZ_ABI_VERSION)
     text = re.sub(r"typedef\s+struct\s*\{.*?\}\s*\w+\s*;", " ", text, flags=re.S)
     text = re.sub(r"(typedef\s+)?enum\s*\{.*?\}\s*\w*\s*;", " ", text, flags=re.S)
     out = {}
@@ -277,4 +278,6 @@ def test_sibling_modules_are_leased_from_a_bounded_pool():
     assert "pz_abi_version()" in lib and "PZ_ABI_VERSION" in lib                     # checked when a handle is made
     from poulpy_amd.hal import PZ_ABI_VERSION
     assert re.search(r"pub const PZ_ABI_VERSION: u32 = (\d+);", lib).group(1) == str(PZ_ABI_VERSION)
-    assert re.search(r"pz_abi_version\(void\) \{ return (\d+); \}", read(ROOT, "poulpy_amd", "csrc", "api.hip")).group(1) == str(PZ_ABI_VERSION)
+    assert re.search(r"#define PZ_ABI_VERSION (\d+)u", read(ROOT, "include", "poulpy_hip.h")).group(1) == str(PZ_ABI_VERSION)   # what the library returns
+    assert "return PZ_ABI_VERSION;" in read(ROOT, "poulpy_amd", "csrc", "api.hip")
+    assert "pz_abi_version() != PZ_ABI_VERSION" in read(ROOT, "include", "poulpy_hip.hpp")                      # the C++ mirror refuses another revision
