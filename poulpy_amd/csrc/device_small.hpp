@@ -438,6 +438,30 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
     PZ_SSTAMP(3)
     __syncthreads();
     PZ_SSTAMP(6)
+    // coordinates of the carry phase (thread = (column j2, component, j1 group), 4 coefficients per limb) and the key-switch body / per-column
+    // operand of those coefficients, all limbs, requested HERE, between the row and the column pass (in front of the row pass the 8 KS registers spill / cost the N = 2048 kernel its second workgroup per CU): in the blind rotation's tail this is the previous accumulator, fresh from HBM -
+    // requested at the top of the carry phase it cost that phase 4 - 8 k cycles of plain waiting (round 3 stamps)
+    constexpr int JG = M1 / 4;   // thread groups over j1 (NT / 256): this thread's outputs are j1 = JG e + jq, e < 4
+    const int cj2 = tid & 127, ch = (tid >> 7) & 1, jq = tid >> 8;   // component 0: coefficients j < m, 1: j >= m
+    const long long* small_col =
+        (g.small && (col == g.body_col || g.body_col < 0))   // body_col < 0: every column gets its own column of `small`
+            ? g.small + (long long)b * g.small_bs + (g.body_col < 0 ? (long long)col * n : 0) + (ch ? m : 0) + cj2 + (long long)jq * M2
+            : nullptr;
+    const long long small_ls = (long long)g.small_cols * n;
+    long long smv[AU ? 1 : KS][4];
+    if constexpr (!AU) {
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) smv[j][e] = 0;
+        if (small_col && g.small_size > 0) {
+#pragma unroll
+            for (int j = 0; j < KS; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) smv[j][e] = small_col[(long long)min(j, g.small_size - 1) * small_ls + JG * e * M2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // ---------------- inverse column pass + rounding, NT / 128 limbs at a time: thread = (limb, column j2); the 2 M1 integers go back
     // into the tile in place of the column's M1 complex values (same bytes) ----------------
 #pragma unroll
@@ -487,18 +511,11 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
     __syncthreads();
     PZ_SSTAMP(7)
     // ---------------- (+ key-switch body), carry chain from the last limb up, stores: thread = (column j2, component, j1 parity), 8 coefficients ----------------
-    constexpr int JG = M1 / 4;   // thread groups over j1 (NT / 256): this thread's outputs are j1 = JG e + jq, e < 4
-    const int cj2 = tid & 127, ch = (tid >> 7) & 1, jq = tid >> 8;   // component 0: coefficients j < m, 1: j >= m
     long long carry[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) carry[u] = 0;
     long long* res_col = g.res + (long long)b * g.res_bs + (long long)col * n + (ch ? m : 0) + cj2 + (long long)jq * M2;
     const long long res_ls = (long long)g.res_cols * n;
-    const long long* small_col =
-        (g.small && (col == g.body_col || g.body_col < 0))   // body_col < 0: every column gets its own column of `small`
-            ? g.small + (long long)b * g.small_bs + (g.body_col < 0 ? (long long)col * n : 0) + (ch ? m : 0) + cj2 + (long long)jq * M2
-            : nullptr;
-    const long long small_ls = (long long)g.small_cols * n;
     // AU: the thread owns four OUTPUT positions (consecutive lanes, consecutive positions: stores and operand loads coalesce) and fetches
     // their source coefficients i = position * p^-1 mod 2n (negated where that product is >= n) from the tile - an LDS gather instead of
     // the 8-byte global scatters of round 2 (the key-switch body, which sits at the SOURCE positions, joined the tile in the column pass)
@@ -539,29 +556,19 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { opos[e] = JG * e * M2; oneg[e] = false; lsrc[e] = 2 * ((JG * e + jq) * RS + cj2) + ch; }
     }
-    // key-switch body / per-column operand of this thread's coefficients, all limbs in one batch (inside the carry loop each load sat behind
-    // its own vmcnt(0): 4 KS L2 latencies).  Limbs beyond the operand's size: the last one is read again and masked
-    long long smv[AU ? 1 : KS][4];
+    // (the operand's loads were issued in front of the row pass) limbs beyond its size: the last one was read again, masked here
     if constexpr (!AU) {
 #pragma unroll
         for (int j = 0; j < KS; ++j)
+            if (!(small_col && j < g.small_size))
 #pragma unroll
-            for (int e = 0; e < 4; ++e) smv[j][e] = 0;
-        if (small_col && g.small_size > 0) {
-#pragma unroll
-            for (int j = 0; j < KS; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) smv[j][e] = small_col[(long long)min(j, g.small_size - 1) * small_ls + JG * e * M2];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < KS; ++j)
-                if (j >= g.small_size)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) smv[j][e] = 0;
-        }
+                for (int e = 0; e < 4; ++e) smv[j][e] = 0;
     }
     // limbs of res beyond the precision of the big value are zero (normalize.rs:118-120); shifted stores: limb L receives the bit shifted
     // out of limb L - 1
+#if PZ_SMALL_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); PZ_SSTAMP(13)   // operand / body loads have arrived
+#endif
     const bool rsh = AU && g.post_rsh;
     int cy2[4] = {0, 0, 0, 0};
     for (int j = L + (rsh ? 1 : 0); j < g.res_size; ++j)
@@ -623,9 +630,12 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
     }
     PZ_SSTAMP(5)
 #if PZ_SMALL_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PZ_SSTAMP(14)   // stores acknowledged
+#endif
+#if PZ_SMALL_STAMP
     if ((tid & 63) == 0 && blockIdx.x == 257)
-        printf("SSTAMP wg %d wave %2d t0 %llu total %llu | product %llu accwr %llu bar1 %llu rowpass [rd %llu b8 %llu tw+wr %llu rd %llu b16 %llu tw+wr %llu] bar2 %llu colpass %llu bar3 %llu carry %llu\n", (int)blockIdx.x, tid >> 6,
-               (unsigned long long)(st_t0 & 0xffffffull), (unsigned long long)(st_t - st_t0), st_acc[0], st_acc[1], st_acc[2], st_acc[8], st_acc[9], st_acc[10], st_acc[11], st_acc[12], st_acc[3], st_acc[6], st_acc[4], st_acc[7], st_acc[5]);
+        printf("SSTAMP wg %d wave %2d t0 %llu total %llu | product %llu accwr %llu bar1 %llu rowpass [rd %llu b8 %llu tw+wr %llu rd %llu b16 %llu tw+wr %llu] bar2 %llu colpass %llu bar3 %llu carry [opnd %llu chain %llu storeack %llu]\n", (int)blockIdx.x, tid >> 6,
+               (unsigned long long)(st_t0 & 0xffffffull), (unsigned long long)(st_t - st_t0), st_acc[0], st_acc[1], st_acc[2], st_acc[8], st_acc[9], st_acc[10], st_acc[11], st_acc[12], st_acc[3], st_acc[6], st_acc[4], st_acc[7], st_acc[13], st_acc[5], st_acc[14]);
 #endif
 #undef PZ_SSTAMP
     if constexpr (FWD) {

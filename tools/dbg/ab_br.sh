@@ -1,0 +1,13 @@
+#!/bin/bash
+# A/B library builds on the blind-rotation / circuit-bootstrapping tools: tools/dbg/ab_br.sh lib1.so lib2.so ...  (paths relative to poulpy_amd/)
+for lib in "$@"; do
+  export POULPY_HIP_LIB=$PWD/poulpy_amd/$lib
+  for sh in n2048 cbt; do
+    python tools/bench_blind_rotation.py --shape $sh --batch 1024 --cpu-cts 0 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('%-34s %-6s %8.0f /s  %s' % (sys.argv[1], sys.argv[2], d['value'], d['kernel_classes_launches_ms']))" $lib $sh
+  done
+  python tools/bench_circuit_bootstrapping.py --batch 512 --cpu-cts 0 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('%-34s %-6s %8.0f /s  %s' % (sys.argv[1], 'cbt512', d['value'], d.get('kernel_classes_launches_ms')))" $lib
+done
