@@ -362,3 +362,25 @@ def test_fused_pipeline_digits_and_cross_base_output(mods, n):
         got, want = _run_relinearize(hip, ref, n, rank, a_size, a_b, key_size, k_b, dnum, dsize, res_size, r_b, batch=3 if big else 7,
                                      seed=n + rank + dsize)
         assert np.array_equal(got, want), (n, "relinearize", rank, a_size, a_b, key_size, k_b, dnum, dsize, res_size, r_b)
+
+
+@pytest.mark.parametrize("n", [8192, 65536])
+def test_digit_groups_on_the_interleaved_middle_kernel(mods, n):
+    """dsize 2 at the bench's shapes (8 limbs, dnum 4: 16 product terms on 16 input polynomials for the external product, 8 terms on 8 for the
+    key switch) runs k_mid128r<.., DS> since round 3 (the digit-group addressing on the interleaved schedule, terms in program order);
+    smaller digit shapes stay on k_mid128<.., DS>.  Bit-exact against the oracle with a partial last tile (5 = 4 + 1 ciphertexts) and more
+    than two tiles per workgroup row (9); the kernel that ran is read back from the library."""
+    from tests.test_gpu_parity import _run_glwe_op
+    ref, hip = mods(n)
+    for ks, want_note in ((False, "k_mid128r<CT=4,NP=16,NR=16,HALFIN=0"), (True, "k_mid128r<CT=4,NP=16,NR=8,HALFIN=1")):
+        for batch in ((5,) if n == 65536 else (5, 9)):
+            hip.dispatch_notes(reset=True)
+            got, want = _run_glwe_op(hip, ref, ks, n, 1, 1, 8, 12, 8, 12, 4, 2, 8, 12, batch=batch, seed=n + batch + int(ks), fuse=(True, True))
+            assert np.array_equal(got, want), (n, ks, batch)
+            notes = hip.dispatch_notes()
+            assert want_note in notes and "DS=1" in notes, notes
+    # a digit shape outside the ring kernel's two forms (10 input polynomials): the older kernel, same answer
+    hip.dispatch_notes(reset=True)
+    got, want = _run_glwe_op(hip, ref, False, n, 1, 1, 5, 12, 6, 12, 3, 2, 4, 12, batch=5, seed=n + 1, fuse=(True, True))
+    assert np.array_equal(got, want)
+    assert "k_mid128<CT=4,NP=16,DS=1>" in hip.dispatch_notes()
