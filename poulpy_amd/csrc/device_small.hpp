@@ -266,7 +266,11 @@ struct SmallInvArgs {
 // at 3).  And (end of round 2): a persistent 512-thread workgroup (four product positions per thread, 256 registers) with the next item's
 // product spread in eight row steps between the stages of the current item's transform - bit-exact, slower: 2.17 vs 3.05 M/s at 4 limbs,
 // 3.8 vs 4.07 at 3, key switch 3.5 vs 5.2 (the transform stages are latency-bound and take about twice as long with 8 waves instead of
-// 16, which costs more than the hidden loads; 116 - 276 bytes of scratch at 3 - 4 limbs).  KS = key limbs (g.ksz).  NOPROD: the spectra of the (ciphertext, column) are given, in the standard device order [q1 + M1 q2]:
+// 16, which costs more than the hidden loads; 116 - 276 bytes of scratch at 3 - 4 limbs).  And (round 3): the same kernel as TWO 512-thread
+// workgroups per CU, each with two limbs in the tile at a time (75 KiB), four product positions per thread, the limb groups through the tile from the
+// last limb up with the carries and the waiting accumulators in registers - bit-exact, two workgroups resident, and 20 - 40 % slower (3 limbs 1.55 ->
+// 1.88 ms per 10 launches, key switch 1.25 -> 1.64, 4 limbs 2.31 -> 3.27; profiles/r03_small_inv_stamps.txt): 8 waves keep half as many key / spectrum
+// requests in flight per workgroup at the 128-register cap, and each transform stage runs on 4 waves.  KS = key limbs (g.ksz).  NOPROD: the spectra of the (ciphertext, column) are given, in the standard device order [q1 + M1 q2]:
 // S[b][l * cols_out + col] (npi = ksz * cols_out), no key (the blind rotation's block step produced them).  FWD (blind rotation: the
 // result is the accumulator the next block transforms): the digits go back into the tile as doubles and the forward transform of
 // k_small_fwd runs on them before the workgroup ends - the next block's k_small_fwd launch and its read of the accumulator are saved.
