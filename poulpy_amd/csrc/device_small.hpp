@@ -356,6 +356,7 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
         }
         // (measured and dropped, round 3: warming L2 with the ciphertext's spectra by one dword load per 128-byte line at the top of the
         // kernel - 7 - 10 % slower at every ring degree, profiles/r03_small_inv_stamps.txt)
+        // (static priority for the second-dispatched half of the waves, which finishes this phase late - 28 k vs 17 k cycles: no gain, round 3)
         // the sched_barriers keep the two slots in ping-pong: without them the machine scheduler gathers the ten loads of a row at the top of
         // the iteration and the wave drains to vmcnt(0) once per row (round 3: seen in the ISA, product phase 29 k cycles per item at N = 4096)
         PZ_SMALL_LOAD(aA, kA, 0, 0)
