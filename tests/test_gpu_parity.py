@@ -1622,7 +1622,8 @@ def test_composite_calls_replay_as_hip_graphs(mods):
             res = VecZnx(n, cols, rsz)
             ref.blind_rotation_execute(res, k, np.ascontiguousarray(lwe[b]), lut, brk_r, dnum, bsz, blk, xpa)
             assert np.array_equal(got[b], res.data), (it, b)
-    if os.environ.get("POULPY_DBG_CANARY") != "1":   # (the workspace-guard mode runs every call plainly: a replay would not re-arm the guards)
+    # (the workspace-guard mode runs every call plainly: a replay would not re-arm the guards; POULPY_DBG_GRAPHS=0 is the A/B knob for plain launches)
+    if os.environ.get("POULPY_DBG_CANARY") != "1" and os.environ.get("POULPY_DBG_GRAPHS") != "0":
         assert hip.graph_launches() - before >= 2, "the repeated call was never served by a graph"
     # switched off: plain launches again, same results
     hip.set_graphs(False)

@@ -11,6 +11,8 @@ PyTorch is plumbing only here (large device buffers, gather / compare on the dev
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -378,7 +380,8 @@ def test_digit_groups_on_the_interleaved_middle_kernel(mods, n):
             got, want = _run_glwe_op(hip, ref, ks, n, 1, 1, 8, 12, 8, 12, 4, 2, 8, 12, batch=batch, seed=n + batch + int(ks), fuse=(True, True))
             assert np.array_equal(got, want), (n, ks, batch)
             notes = hip.dispatch_notes()
-            assert want_note in notes and "DS=1" in notes, notes
+            if os.environ.get("POULPY_DBG_MID_R") != "0":   # (the A/B knob that keeps every plain product on k_mid128)
+                assert want_note in notes and "DS=1" in notes, notes
     # a digit shape outside the ring kernel's two forms (10 input polynomials): the older kernel, same answer
     hip.dispatch_notes(reset=True)
     got, want = _run_glwe_op(hip, ref, False, n, 1, 1, 5, 12, 6, 12, 3, 2, 4, 12, batch=5, seed=n + 1, fuse=(True, True))
