@@ -23,6 +23,9 @@ namespace pz {
 #define PZ_MID_RS 144
 #endif
 constexpr int kMidRS = PZ_MID_RS;
+#ifndef PZ_MID_BR_AVPF
+#define PZ_MID_BR_AVPF 1   // blind-rotation block step on k_mid128: operands of the next row read from LDS one row ahead (0: read at their use)
+#endif
 #ifndef PZ_MID_STAMP
 #define PZ_MID_STAMP 0   // diagnostic build: per-phase s_memtime totals of k_mid128, printed by a few waves (tools/dbg/mid_stamps.sh)
 #endif
@@ -296,7 +299,7 @@ k_mid(MidArgs g) {
 // NP = polynomial slots per ciphertext: 16; 8 for shapes with <= 8 polynomials in and out such as rank 1 with 4 limbs (twice the
 // ciphertexts per tile and per key fetch); 32 for rank 2-3 or 16 limbs (two ciphertexts per tile).  The 4 thread groups of the product phase split into GC column groups x GT
 // ciphertext groups so that a thread always owns 16 accumulators (4 ciphertexts x 4 outputs, or 2 x 8).
-template <int CT, int NP = 16, bool PERM = false, bool DS = false, bool BR = false, bool SKIPW = false>
+template <int CT, int NP = 16, bool PERM = false, bool DS = false, bool BR = false, bool SKIPW = false, int BRNEST = 0>
 __global__ void __launch_bounds__(CT * NP * 8)
 k_mid128(MidArgs g) {
     static_assert(!SKIPW || (NP > 8 && !BR && !DS), "wave skipping: 16- and 32-slot tiles of the plain product only");
@@ -319,7 +322,7 @@ k_mid128(MidArgs g) {
     const int tid0 = threadIdx.x;
     // ablation mask: compile-time zero (PZ_DBG) except in the BR variant, whose register allocation is better WITH the run-time tests
     // (without them: 36 bytes of scratch and N = 2^14 blind rotation 6 240 -> 5 715/s, round 3)
-    const int dbgv = BR ? g.dbg : PZ_DBG(g.dbg);
+    const int dbgv = (BR && BRNEST == 0) ? g.dbg : PZ_DBG(g.dbg);
     const long long m = (long long)g.m1 * M2;
     cplx* wl = lds + CT * NP * RS;
     // Lane coordinates are re-derived from an OPAQUE copy of the thread index at the top of every phase (round 3).  Derived once, the
@@ -462,7 +465,7 @@ k_mid128(MidArgs g) {
             const int q2 = vq2, cg = vcg;
             // BR: monomial factors of the current (f) and the next (fn, raw table values) block coefficient for this thread's ciphertexts
             const unsigned tq = 4u * ((unsigned)q1 + ((unsigned)q2 << g.log_m1)) + 1u;
-            cplx f[BR ? CTt : 1], fn[BR ? CTt : 1];
+            cplx f[BR ? CTt : 1], fn[BR ? CTt : 1], fl[BR ? CTt : 1];   // fl: the factor after next, in flight (see PZ_BR_USE)
             int br_slot = 0, br_i = 0;
 #define PZ_MID_LOADF(DST, II)                                                                   \
     {                                                                                           \
@@ -472,6 +475,7 @@ k_mid128(MidArgs g) {
             if constexpr (BR) {
                 PZ_MID_LOADF(f, 0)
                 PZ_MID_LOADF(fn, 1)
+                if constexpr (BRNEST != 0) PZ_MID_LOADF(fl, 2)
 #pragma unroll
                 for (int i = 0; i < CTt; ++i) f[i].x -= 1.0;
             }
@@ -546,6 +550,81 @@ k_mid128(MidArgs g) {
                 }
                 PZ_USEROW(pn, it)
             } else if constexpr (BR) {
+                // (round 3, late) the stamps show this phase at 62 k of the tile's 86 k cycles at N = 2^14: 56 rows of 84 floating-point
+                // instructions each.  What did NOT help on the flat row loop: a ring of four key-row slots (27.8 -> 28.0 ms per 82 blocks),
+                // the operands read from LDS one row ahead (27.6).  What the ISA showed: 115 VALU + 50 SALU instructions and six branches
+                // per row (run-time ablation tests, the row-index wrap with a 64-bit multiply, the factor rotation as a branch whose
+                // register homes made the allocator wait for the fresh factor load at once).  BRNEST (an even number of rows per
+                // coefficient): coefficient loop around a branch-free row-pair loop, running key offsets, factors rotated in
+                // straight-line code and requested two coefficients ahead, compile-time ablation mask: 87 VALU + 9 SALU per row, no
+                // branch - 28.35 -> 25.25 ms (N = 2^14: 5 530 -> 5 930 rotations/s, N = 4096: 25 300 -> 27 300).  Four key slots on top: +1 %, not kept.
+#if PZ_MID_BR_AVPF
+                cplx avA[CTt], avB[CTt];
+#define PZ_BR_AV(DST, SLOT_)                                                                     \
+    {                                                                                            \
+        const int s_ = (SLOT_);                                                                  \
+        _Pragma("unroll") for (int i = 0; i < CTt; ++i) DST[i] = lds[((vtg * CTt + i) * NP + s_) * RS + q2]; \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    }
+#define PZ_BR_FMA(SRC, AV)                                                                       \
+    {                                                                                            \
+        if (!(dbgv & 1)) _Pragma("unroll") for (int i = 0; i < CTt; ++i) {                       \
+            const cplx av = cmul(AV[i], f[i]);                                                   \
+            _Pragma("unroll") for (int j = 0; j < NC; ++j) {                                     \
+                acc[i][j].x = __builtin_fma(av.x, SRC[j].x, acc[i][j].x);                        \
+                acc[i][j].x = __builtin_fma(-av.y, SRC[j].y, acc[i][j].x);                       \
+                acc[i][j].y = __builtin_fma(av.x, SRC[j].y, acc[i][j].y);                        \
+                acc[i][j].y = __builtin_fma(av.y, SRC[j].x, acc[i][j].y);                        \
+            }                                                                                    \
+        }                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    }
+                if constexpr (BRNEST != 0) {   // launch_mid: g.br_rm even
+                    // coefficient by coefficient (an even number of rows each, so that the two key slots keep their parity): the factors
+                    // rotate in straight-line code at the top of a coefficient - current <- next (requested two coefficients ago) <- the one in
+                    // flight, which is requested here.  As a branch inside the flat row loop (below, odd row counts) the rotation made the
+                    // register allocator copy the in-flight factor behind vmcnt(0) on EVERY row (round 3 ISA).
+                    PZ_BR_AV(avA, 0)
+                    long long ko = 0;   // offset of key row `it`
+#define PZ_BR_KROW(DST, OFF_)                                                                    \
+    {                                                                                            \
+        const long long o_ = (OFF_);                                                             \
+        if (!(dbgv & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = pp[j][o_]; }  \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    }
+                    for (int ci = 0; ci < g.br_blk; ++ci) {
+                        if (ci > 0) {
+#pragma unroll
+                            for (int i = 0; i < CTt; ++i) { f[i] = fn[i]; f[i].x -= 1.0; fn[i] = fl[i]; }
+                            PZ_MID_LOADF(fl, ci + 2)
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        for (int sl = 0; sl < g.br_rm; sl += 2, it += 2, ko += 2 * prow) {
+                            // key rows at running offsets (rows come in order here: no wrap arithmetic, no 64-bit multiply per row); the
+                            // request past the last row re-reads it and is unused
+                            PZ_BR_KROW(pb, ko + prow)
+                            PZ_BR_AV(avB, sl + 1)
+                            PZ_BR_FMA(pn, avA)
+                            PZ_BR_KROW(pn, (it + 2 < nrow) ? ko + 2 * prow : ko + prow)
+                            PZ_BR_AV(avA, (sl + 2 == g.br_rm) ? 0 : sl + 2)
+                            PZ_BR_FMA(pb, avB)
+                        }
+                    }
+                } else {
+                    // an odd number of rows per coefficient: the flat row loop of rounds 1 - 3 (two slots in ping-pong; the request past the
+                    // end wraps to a valid row and is unused)
+                    for (; it + 1 < nrow; it += 2) {
+                        PZ_LOADROW(pb, it + 1)
+                        PZ_USEROW(pn, it)
+                        PZ_LOADROW(pn, it + 2)
+                        PZ_USEROW(pb, it + 1)
+                    }
+                    if (it < nrow) PZ_USEROW(pn, it)
+                }
+#undef PZ_BR_FMA
+#undef PZ_BR_AV
+#undef PZ_BR_KROW
+#else
                 // two slots in ping-pong; the request past the end wraps to a valid row and is unused (with the peeled loop below this
                 // variant spills)
                 for (; it + 1 < nrow; it += 2) {
@@ -555,6 +634,7 @@ k_mid128(MidArgs g) {
                     PZ_USEROW(pb, it + 1)
                 }
                 if (it < nrow) PZ_USEROW(pn, it)
+#endif
             } else {
                 // two slots in ping-pong; no row is requested past the end
                 for (; it + 3 < nrow; it += 2) {

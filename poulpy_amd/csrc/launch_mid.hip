@@ -112,7 +112,11 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
         g.n_ct = (batch + CT_ - 1) / CT_;                                                                                  \
         const size_t lds = ((size_t)CT_ * NP_ * kMidRS + 384 + 32) * sizeof(cplx);   /* tile | wL2 | two twiddle rows | exponents */                                         \
         const dim3 grid_(std::min({ncu, 256, g.m1 * g.n_ct}));   /* <= 256: one scratch tile per workgroup (kMidDummyBytes) */ \
-        if (br) {                                                                                                          \
+        if (br && NP_ < 32 && (g.br_rm & 1) == 0) {   /* an even number of key rows per coefficient: the nested form of the product loop */ \
+            PZ_TRY(set_lds((k_mid128<CT_, NP_, false, false, true, false, (NP_ < 32 ? 2 : 0)>), lds));                     \
+            hipLaunchKernelGGL((k_mid128<CT_, NP_, false, false, true, false, (NP_ < 32 ? 2 : 0)>), grid_, dim3(512), lds, M->stream, g); \
+            dispatch_note(M, "k_mid128<CT=%d,NP=%d,BR=1,BRNEST=2> (%d ciphertexts per key value)", CT_, NP_, CT_);         \
+        } else if (br) {                                                                                                   \
             PZ_TRY(set_lds((k_mid128<CT_, NP_, false, false, true>), lds));                                                \
             hipLaunchKernelGGL((k_mid128<CT_, NP_, false, false, true>), grid_, dim3(512), lds, M->stream, g);             \
             dispatch_note(M, "k_mid128<CT=%d,NP=%d,BR=1> (%d ciphertexts per key value)", CT_, NP_, CT_);                  \
