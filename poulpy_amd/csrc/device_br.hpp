@@ -215,31 +215,34 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
                             const unsigned ai = (unsigned)((unsigned long long)g.lwe[(long long)b * (g.n_lwe + 1) + 1 + i] & (unsigned long long)mask2);
                             xm[ct] = g.w2n[(ai * (4u * (unsigned)q + 1u)) & mask2];
                         }
-#pragma unroll
-                        for (int j = 0; j < CG; ++j) {
-#pragma unroll
-                            for (int ct = 0; ct < CT; ++ct) {
-                                cplx s = make_double2(0.0, 0.0);
-#pragma unroll
-                                for (int r = 0; r < MAXR; ++r) {
-                                    if (r < row_max) {
-                                        const cplx av = PZ_BR_A(ct, r);
-                                        s.x = __builtin_fma(av.x, kv[j][r].x, s.x);
-                                        s.x = __builtin_fma(-av.y, kv[j][r].y, s.x);
-                                        s.y = __builtin_fma(av.x, kv[j][r].y, s.y);
-                                        s.y = __builtin_fma(av.y, kv[j][r].x, s.y);
-                                    }
-                                }
-                                if (STD) {
-                                    out[pj][ct][j].x += s.x;
-                                    out[pj][ct][j].y += s.y;
-                                } else {
-                                    const cplx xv = cmul(xm[ct], s);
-                                    out[pj][ct][j].x = (out[pj][ct][j].x + xv.x) - s.x;
-                                    out[pj][ct][j].y = (out[pj][ct][j].y + xv.y) - s.y;
-                                }
-                            }
-                        }
+                        // GUARD_: row_max < MAXR (the template's row count is the next of 4 / 6 / 8).  With row_max == MAXR - the usual shapes -
+                        // the per-row test is dropped: as a run-time test inside the unrolled row loop it costs a branch per (column, ciphertext,
+                        // row), 64 branches and 167 scalar instructions per coefficient beside 188 floating-point ones (round 3 ISA)
+#define PZ_BR_FMAS(GUARD_)                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < CG; ++j) {                                                             \
+        _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) {                                                      \
+            cplx s = make_double2(0.0, 0.0);                                                                     \
+            _Pragma("unroll") for (int r = 0; r < MAXR; ++r) {                                                   \
+                if (!(GUARD_) || r < row_max) {                                                                  \
+                    const cplx av = PZ_BR_A(ct, r);                                                              \
+                    s.x = __builtin_fma(av.x, kv[j][r].x, s.x);                                                  \
+                    s.x = __builtin_fma(-av.y, kv[j][r].y, s.x);                                                 \
+                    s.y = __builtin_fma(av.x, kv[j][r].y, s.y);                                                  \
+                    s.y = __builtin_fma(av.y, kv[j][r].x, s.y);                                                  \
+                }                                                                                                \
+            }                                                                                                    \
+            if (STD) {                                                                                           \
+                out[pj][ct][j].x += s.x;                                                                         \
+                out[pj][ct][j].y += s.y;                                                                         \
+            } else {                                                                                             \
+                const cplx xv = cmul(xm[ct], s);                                                                 \
+                out[pj][ct][j].x = (out[pj][ct][j].x + xv.x) - s.x;                                              \
+                out[pj][ct][j].y = (out[pj][ct][j].y + xv.y) - s.y;                                              \
+            }                                                                                                    \
+        }                                                                                                        \
+    }
+                        if (row_max == MAXR) { PZ_BR_FMAS(false) } else { PZ_BR_FMAS(true) }
+#undef PZ_BR_FMAS
                     }
                 }
             }

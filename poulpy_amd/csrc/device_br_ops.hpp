@@ -331,23 +331,25 @@ __global__ void __launch_bounds__(256) k_br_block_lds(BrBlockArgs g) {
         for (int t = 0; t < CT; ++t)
 #pragma unroll
             for (int j = 0; j < CG; ++j) sacc[t][j] = make_double2(0.0, 0.0);
-#pragma unroll
-        for (int r = 0; r < MAXR; ++r) {
-            if (r < g.row_max && !(PZ_DBG(g.dbg) & 2)) {
-#pragma unroll
-                for (int j = 0; j < CG; ++j) {
-                    const cplx kv = ks[buf][j * MAXR + r][lane];
-#pragma unroll
-                    for (int t = 0; t < CT; ++t) {
-                        cplx& sv = sacc[t][j];
-                        sv.x = __builtin_fma(a[t][r].x, kv.x, sv.x);
-                        sv.x = __builtin_fma(-a[t][r].y, kv.y, sv.x);
-                        sv.y = __builtin_fma(a[t][r].x, kv.y, sv.y);
-                        sv.y = __builtin_fma(a[t][r].y, kv.x, sv.y);
-                    }
-                }
-            }
-        }
+        // (rows beyond row_max carry a = 0 and a clamped key value: with row_max == MAXR - the usual shapes - the per-row test, a branch per
+        //  row inside the unrolled loop, is dropped; round 3, as in k_br_fused)
+#define PZ_BRL_FMAS(GUARD_)                                                                       \
+    _Pragma("unroll") for (int r = 0; r < MAXR; ++r) {                                           \
+        if ((!(GUARD_) || r < g.row_max) && !(PZ_DBG(g.dbg) & 2)) {                              \
+            _Pragma("unroll") for (int j = 0; j < CG; ++j) {                                     \
+                const cplx kv = ks[buf][j * MAXR + r][lane];                                     \
+                _Pragma("unroll") for (int t = 0; t < CT; ++t) {                                 \
+                    cplx& sv = sacc[t][j];                                                       \
+                    sv.x = __builtin_fma(a[t][r].x, kv.x, sv.x);                                 \
+                    sv.x = __builtin_fma(-a[t][r].y, kv.y, sv.x);                                \
+                    sv.y = __builtin_fma(a[t][r].x, kv.y, sv.y);                                 \
+                    sv.y = __builtin_fma(a[t][r].y, kv.x, sv.y);                                 \
+                }                                                                                \
+            }                                                                                    \
+        }                                                                                        \
+    }
+        if (g.row_max == MAXR) { PZ_BRL_FMAS(false) } else { PZ_BRL_FMAS(true) }
+#undef PZ_BRL_FMAS
 #pragma unroll
         for (int j = 0; j < CG; ++j)
 #pragma unroll
