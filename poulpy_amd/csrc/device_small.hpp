@@ -581,10 +581,14 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
         for (int e = 0; e < 4; ++e) res_col[(long long)j * res_ls + opos[e]] = 0;
     const unsigned long long half = 1ull << (k - 1), mask = (1ull << k) - 1;
     const long long* xin = reinterpret_cast<const long long*>(lds);
+    // One limb at a time: the chain steps of the thread's four coefficients in straight-line code, then the stores / the FWD tile writes
+    // behind ONE uniform test each.  (Rounds 1 - 3 tested "carry only" - a last limb that is not stored - and `writes` per coefficient:
+    // a branch per (limb, coefficient) in the unrolled chain; the carry-only case needs no test at all, the chain starts from carry 0, for
+    // which the two-step form gives the same carry.)
 #pragma unroll
     for (int j = L - 1; j >= 0; --j) {
         const bool writes = j < g.res_size;
-        const bool first = j == L - 1;
+        long long x1v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             long long x = xin[lsrc[e] + 2 * j * M1 * RS];
@@ -601,13 +605,15 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
             const unsigned long long y = (unsigned long long)x + half;
             const long long d = (long long)(y & mask) - (long long)half;
             const long long cr = (long long)y >> k;
-            if (first && !writes) {
-                cy = cr;
-            } else {
-                const unsigned long long y2 = (unsigned long long)d + (unsigned long long)cy + half;
-                const long long x1 = (long long)(y2 & mask) - (long long)half;
-                cy = (long long)((unsigned long long)cr + (unsigned long long)((long long)y2 >> k));
-                if (writes && (!(PZ_DBG(g.dbg) & 4) || x1 == 0x7fffffffffffLL)) {
+            const unsigned long long y2 = (unsigned long long)d + (unsigned long long)cy + half;
+            x1v[e] = (long long)(y2 & mask) - (long long)half;
+            cy = (long long)((unsigned long long)cr + (unsigned long long)((long long)y2 >> k));
+        }
+        if (writes) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const long long x1 = x1v[e];
+                if (!(PZ_DBG(g.dbg) & 4) || x1 == 0x7fffffffffffLL) {
                     // AU mode 0: phi acts on the normalized digits (glwe_ct.rs:69-71)
                     const long long xs = (AU && g.au_mode == 0 && oneg[e]) ? (long long)(0ull - (unsigned long long)x1) : x1;
                     if constexpr (AU) {   // (plain stores: in place the operand's lines are re-read by the next trace step)
@@ -627,9 +633,12 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
                         }
                     } else st_stream(res_col + (long long)j * res_ls + opos[e], xs);
                 }
-                if constexpr (FWD) {   // this thread's own slot (read above): component ch of z[limb j][j1][j2]
-                    if (j < g.fwd_limbs) reinterpret_cast<double*>(lds)[2 * ((j * M1 + JG * e + jq) * RS + cj2) + ch] = (double)x1;
-                }
+            }
+        }
+        if constexpr (FWD) {   // this thread's own slots (read above): component ch of z[limb j][j1][j2]
+            if (j < g.fwd_limbs) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) reinterpret_cast<double*>(lds)[2 * ((j * M1 + JG * e + jq) * RS + cj2) + ch] = (double)x1v[e];
             }
         }
     }
