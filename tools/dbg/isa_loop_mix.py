@@ -38,7 +38,7 @@ for si, (st, nm) in enumerate(zip(starts, names)):
         br = sum(1 for x in seg if "s_cbranch" in x or "s_branch" in x)
         vm = sum(1 for x in seg if re.match(r"\s*(global|buffer|flat)_(load|store)", x))
         ds = sum(1 for x in seg if re.match(r"\s*ds_", x))
-        if fp < 32 or len(seg) > 2500: continue
+        if fp < 32 or len(seg) > 6000: continue
         flag = br >= 6 or salu > 0.35 * fp or (valu - fp) > 0.5 * fp
         if flag or show_all:
             print(f"{d[:58]:58s} {m.group(1):10s} fp {fp:4d} valu-other {valu - fp:4d} salu {salu:4d} branches {br:3d} mem {vm:3d} lds {ds:3d}{'   <--' if flag else ''}")
