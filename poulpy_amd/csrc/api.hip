@@ -88,6 +88,16 @@ int forget_host_key(pz_module* M, const void* host) {
 }
 // device pointer of a prepared key: itself when it is one, else its (validated, possibly refreshed) mirror; the mirror also gets
 // the row-sliced copy of the fused pipeline (as pz_module_pin_key would build it), valid for as long as the mirror is
+// the backend-private copy of a prepared key that the batched GLWE calls read: row-sliced for the fused pipeline (m = m1 x 128 / 256
+// plans), or P'[q1][poly][q2] for the small-ring pipeline at N = 1024 / 2048 (device_small.hpp) - those rings permuted their key on
+// every call until round 3 (5 - 9 % of a 1024-ciphertext call)
+static bool key_copy_applies(const pz_module* M) {
+    return ((M->plan.m2 == 256 || M->plan.m2 == 128) && (M->plan.m1 % 16) == 0) || small_transform_supported(M);
+}
+static int build_key_copy(pz_module* M, const double* dev, cplx* sliced, size_t npolys) {
+    if ((M->plan.m2 == 256 || M->plan.m2 == 128) && (M->plan.m1 % 16) == 0) return launch_permute_pmat(M, dev, sliced, (int)npolys);
+    return launch_small_permute(M, dev, sliced, (int)npolys);
+}
 static int resolve_key(pz_module* M, const double* pmat, size_t bytes, const double** out) {
     if (is_device_ptr(pmat)) { *out = pmat; return PZ_OK; }
     // mirrors whose host range was (re)prepared, zeroed, forgotten or freed since their validation - by any module - go first
@@ -126,11 +136,11 @@ static int resolve_key(pz_module* M, const double* pmat, size_t bytes, const dou
     }
     M->mirrors.push_back({(const void*)pmat, bytes, dev, fp, ++M->mirror_clock, epoch_now});
     M->graph_epoch++;
-    if ((M->plan.m2 == 256 || M->plan.m2 == 128) && (M->plan.m1 % 16) == 0) {
+    if (key_copy_applies(M)) {
         const size_t npolys = bytes / ((size_t)M->n * 8);
         cplx* sliced = nullptr;
         if (hipMalloc(&sliced, bytes) == hipSuccess) {
-            if (launch_permute_pmat(M, (const double*)dev, sliced, (int)npolys) == PZ_OK) M->pinned.push_back({(const void*)dev, sliced, bytes});
+            if (build_key_copy(M, (const double*)dev, sliced, npolys) == PZ_OK) M->pinned.push_back({(const void*)dev, sliced, bytes});
             else (void)hipFree(sliced);
         } else {
             (void)hipGetLastError();   // no room for the sliced copy: the pipeline rebuilds it per call
@@ -347,7 +357,7 @@ int pz_module_pin_key(pz_module* M, const double* pmat, size_t rows, size_t cols
     PZ_REQUIRE(is_device_ptr(pmat), "pz_module_pin_key takes a device pointer");
     PZ_REQUIRE(rows >= 1 && cols_in >= 1 && cols_out >= 1 && size >= 1, "pz_module_pin_key: empty shape");
     for (auto& k : M->pinned) PZ_REQUIRE(k.key != (const void*)pmat, "pz_module_pin_key: key already pinned");
-    if (!(M->plan.m2 == 256 || M->plan.m2 == 128) || (M->plan.m1 % 16) != 0) {  // no fused pipeline at this N: nothing to cache,
+    if (!key_copy_applies(M)) {                                                  // no fused / small-ring pipeline at this N: nothing to cache,
         M->pinned.push_back({(const void*)pmat, nullptr, 0});                      // but the pin is remembered so that unpin succeeds
         return PZ_OK;
     }
@@ -355,7 +365,7 @@ int pz_module_pin_key(pz_module* M, const double* pmat, size_t rows, size_t cols
     const size_t bytes = npolys * (size_t)M->n * 8;
     cplx* sliced = nullptr;
     PZ_HIP(hipMalloc(&sliced, bytes));
-    const int st = launch_permute_pmat(M, pmat, sliced, (int)npolys);
+    const int st = build_key_copy(M, pmat, sliced, npolys);
     if (st != PZ_OK) { (void)hipFree(sliced); return st; }
     M->pinned.push_back({(const void*)pmat, sliced, bytes});
     return PZ_OK;
@@ -983,7 +993,12 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
             PZ_TRY(ws_take(M, sbase, s_bytes, &S));
             PZ_TRY(ws_take(M, sbase, conv_bytes, &a_conv));
             PZ_TRY(ws_take(M, sbase, tmp_bytes, &key_digits));
-            PZ_TRY(launch_small_permute(M, pmat, Pp, nrows * ncols));
+            {   // a pinned (or mirrored) key brings its permuted copy along
+                bool pinned = false;
+                for (auto& pk : M->pinned)
+                    if (pk.key == (const void*)pmat && pk.sliced && pk.bytes == (size_t)nrows * ncols * n8) { Pp = pk.sliced; pinned = true; }
+                if (!pinned) PZ_TRY(launch_small_permute(M, pmat, Pp, nrows * ncols));
+            }
             const bool small_rsh = want_rsh && au && au->mode != 0 && !cross_out && p->res_base2k <= 29;
             for (size_t b0 = 0; b0 < batch; b0 += chunk) {
                 const int nb = (int)std::min(chunk, batch - b0);

@@ -368,6 +368,26 @@ def test_pinned_key_n65536(mods):
     buf.free()
 
 
+@pytest.mark.parametrize("n", [1024, 2048])
+def test_pinned_key_on_the_small_ring_pipeline(mods, n):
+    """N = 1024 / 2048: a pinned key carries its P'[q1][poly][q2] copy (round 3: these rings permuted the key on every batched call);
+    same bits as unpinned for the external product, the key switch and an automorphism form, and the permutation kernel no longer
+    runs inside the call."""
+    ref, hip = mods(n)
+    for (ks, auto) in ((False, None), (True, None), (True, (5, "add"))):
+        want_u, ref_u = _run_glwe_op(hip, ref, ks, n, 1, 1, 4, 14, 4, 14, 4, 1, 4, 14, batch=9, seed=n + int(ks), auto=auto)
+        assert np.array_equal(want_u, ref_u)
+        hip.set_kernel_timing(True)
+        try:
+            got, want = _run_glwe_op(hip, ref, ks, n, 1, 1, 4, 14, 4, 14, 4, 1, 4, 14, batch=9, seed=n + int(ks), auto=auto, pin=True)
+            stats = hip.kernel_stats()
+        finally:
+            hip.set_kernel_timing(False)
+        assert np.array_equal(got, want) and np.array_equal(got, want_u), (n, ks, auto)
+        # one k_small_permute launch: pz_module_pin_key's own - none inside the one (key switch, automorphism) or two (external product) calls
+        assert stats.get("elementwise", (0, 0.0))[0] == 1, stats
+
+
 def test_small_shapes_on_the_fused_pipeline(mods):
     """<= 8 polynomials in and out select the 8-slot tile of the middle kernel (8 ciphertexts per tile): 4 limbs at N = 2^16 and
     2^13, external product and key switch, batches that leave the last tile partly empty."""
