@@ -50,6 +50,51 @@ __global__ void __launch_bounds__(256) k_cnv_apply(CnvArgs g) {
     *out = acc;
 }
 
+// k_cnv_apply_lds (round 3): the same sums with the a_size + b_size operand limbs of 128 frequency points staged once in LDS (pairwise
+// sums a[i] + a[j], b[i] + b[j] formed while staging) and all min_size output limbs computed from there - every operand value is read from
+// global memory once per term instead of once per output limb it reaches (k_cnv_apply: two L2-served loads per multiply-add, 8 KiB per
+// point and term at 16 x 16 limbs: 3.1 ms per term and 256 ciphertext pairs at N = 2^16).  grid = (m / 128, batch), 256 threads: thread
+// = (point, output-limb parity).  Same order of the FMAs per output as k_cnv_apply (same bits).  Needs m % 128 == 0, a_size + b_size <= 64.
+__global__ void __launch_bounds__(256) k_cnv_apply_lds(CnvArgs g) {
+    extern __shared__ cplx lds[];   // [a_size + b_size][128]
+    const int tid = threadIdx.x, pt = tid & 127, par = tid >> 7;
+    const int q0 = blockIdx.x * 128, bt = blockIdx.y;
+    const cplx* a0 = g.a + (long long)bt * g.a_bs + (long long)g.a_i * g.a_size * g.m + q0;
+    const cplx* b0 = g.b + (long long)bt * g.b_bs + (long long)g.b_i * g.b_size * g.m + q0;
+    const cplx* a1 = g.a_j >= 0 ? g.a + (long long)bt * g.a_bs + (long long)g.a_j * g.a_size * g.m + q0 : nullptr;
+    const cplx* b1 = g.b_j >= 0 ? g.b + (long long)bt * g.b_bs + (long long)g.b_j * g.b_size * g.m + q0 : nullptr;
+    cplx* la = lds;
+    cplx* lb = lds + g.a_size * 128;
+    for (int l = par; l < g.a_size; l += 2) {
+        cplx v = a0[(long long)l * g.m + pt];
+        if (a1) v = cadd(v, a1[(long long)l * g.m + pt]);
+        la[l * 128 + pt] = v;
+    }
+    for (int l = par; l < g.b_size; l += 2) {
+        cplx v = b0[(long long)l * g.m + pt];
+        if (b1) v = cadd(v, b1[(long long)l * g.m + pt]);
+        lb[l * 128 + pt] = v;
+    }
+    __syncthreads();
+    for (int kk = par; kk < g.min_size; kk += 2) {
+        const int k = kk + g.offset;
+        cplx acc = make_double2(0.0, 0.0);
+        if (k < g.a_size + g.b_size) {
+            const int j_min = k >= g.a_size - 1 ? k - (g.a_size - 1) : 0;
+            const int j_max = min(k + 1, g.b_size);
+            for (int j = j_min; j < j_max; ++j) {
+                const cplx av = la[(k - j) * 128 + pt], bv = lb[j * 128 + pt];
+                acc.x = __builtin_fma(av.x, bv.x, acc.x);
+                acc.x = __builtin_fma(-av.y, bv.y, acc.x);
+                acc.y = __builtin_fma(av.x, bv.y, acc.y);
+                acc.y = __builtin_fma(av.y, bv.x, acc.y);
+            }
+        }
+        cplx* out = reinterpret_cast<cplx*>(g.res) + (long long)bt * g.res_bs + (long long)g.m * ((long long)kk * g.res_cols + g.res_col) + q0 + pt;
+        *out = acc;
+    }
+}
+
 // convolution.rs:147-203 + :395-421: res limb kk = sum_j a[kk + offset - j] * b[j], wrapping i64, coefficient-wise
 struct CnvConstArgs {
     long long* res;

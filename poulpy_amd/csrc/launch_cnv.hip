@@ -19,6 +19,22 @@ int launch_cnv_apply(pz_module* M, int batch, double* res, long long res_bs, int
     g.a_size = a_size; g.a_i = a_i; g.a_j = a_j; g.b_size = b_size; g.b_i = b_i; g.b_j = b_j;
     g.m = (int)M->m; g.batch = batch;
     KTimer kt(M, PZ_K_VMP);
+    // operands staged in LDS, all output limbs per workgroup (POULPY_DBG_CNV_LDS=0: one thread per (point, output limb), operands from L2)
+    static const bool cnv_lds = !(getenv("POULPY_DBG_CNV_LDS") && atoi(getenv("POULPY_DBG_CNV_LDS")) == 0);
+    if (cnv_lds && (M->m % 128) == 0 && a_size + b_size <= 64 && a != (const double*)res && b != (const double*)res) {
+        const size_t lds = (size_t)(a_size + b_size) * 128 * sizeof(cplx);
+        PZ_TRY(set_lds(k_cnv_apply_lds, lds));
+        for (int b0 = 0; b0 < batch; b0 += 65535) {   // gridDim.y limit
+            CnvArgs gb = g;
+            gb.res = res + (long long)b0 * res_bs;
+            gb.a = g.a + (long long)b0 * g.a_bs;
+            gb.b = g.b + (long long)b0 * g.b_bs;
+            const int nb = std::min(65535, batch - b0);
+            hipLaunchKernelGGL(k_cnv_apply_lds, dim3((unsigned)(M->m / 128), (unsigned)nb), dim3(256), lds, M->stream, gb);
+        }
+        PZ_HIP(hipGetLastError());
+        return PZ_OK;
+    }
     for (int b0 = 0; b0 < batch; b0 += 65535) {   // gridDim.z limit
         CnvArgs gb = g;
         gb.res = res + (long long)b0 * res_bs;

@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Secondary measurement: GLWE tensorings / s (glwe_tensor_apply, poulpy-core/src/operations/glwe.rs:700-807 - the convolution half of a
+CKKS multiplication; the relinearization half is `bench.py --op relinearize`) on one MI355X, at the shape of BASELINE configs[4]:
+N = 2^16, rank 1, 16 limbs, base2k 12 (so that FFT64 represents it).  Device-resident pairs of ciphertexts in, 3-column GLWETensors out;
+a few outputs are compared bit for bit with the oracle's composition (cnv_prepare_left / right, cnv_apply_dft, cnv_pairwise_apply_dft,
+idft, normalize).
+
+    python tools/bench_tensor.py [--batch 256] [--limbs 16] [--n 65536] [--steps 10] [--mode apply|square]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=65536)
+    ap.add_argument("--limbs", type=int, default=16)
+    ap.add_argument("--base2k", type=int, default=12)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", choices=("apply", "square"), default="apply")
+    ap.add_argument("--parity-samples", type=int, default=2)
+    args = ap.parse_args()
+    import ctypes as C
+    import torch
+    from poulpy_amd.hal import GlweTensorParams, Module
+    from poulpy_amd.layouts import VecZnx
+    n, size, k, rank = args.n, args.limbs, args.base2k, 1
+    cols, tcols = rank + 1, (rank + 1) * (rank + 2) // 2
+    dev = torch.device("cuda", 0)
+    mod = Module(n, device=0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x7e50)
+    half = 1 << (k - 1)
+    a = torch.randint(-half, half, (args.batch, size, cols, n), dtype=torch.int64, device=dev, generator=g)
+    b = a if args.mode == "square" else torch.randint(-half, half, (args.batch, size, cols, n), dtype=torch.int64, device=dev, generator=g)
+    res = torch.zeros((args.batch, size, tcols, n), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    cnv_offset = size * k - 20     # the offset of the 16-limb parity test (tests/test_gpu_cnv.py)
+    p = GlweTensorParams(rank=rank, a_size=size, b_size=size, ab_base2k=k, a_effective_k=size * k, b_effective_k=size * k, res_size=size,
+                         res_base2k=k, cnv_offset=cnv_offset)
+
+    def run():
+        mod.glwe_tensor_apply_batched(C.c_void_p(res.data_ptr()), C.c_void_p(a.data_ptr()), None if args.mode == "square" else C.c_void_p(b.data_ptr()),
+                                      p, args.mode, args.batch)
+
+    for _ in range(args.warmup):
+        run()
+    mod.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    mod.sync()
+    dt = (time.perf_counter() - t0) / args.steps
+    mod.set_kernel_timing(True)
+    run()
+    mod.sync()
+    stats = {kname: [c, round(ms, 3)] for kname, (c, ms) in mod.kernel_stats().items() if c}
+    mod.set_kernel_timing(False)
+    # parity of a few outputs against the oracle
+    ok = None
+    if args.parity_samples:
+        from oracle.ref import RefModule
+        ref = RefModule(n)   # strict build (-ffp-contract=off): the bits the parity tests pin
+        ok = True
+        got = res.cpu().numpy()
+        for t in sorted(set(np.linspace(0, args.batch - 1, args.parity_samples).astype(int).tolist())):
+            av = VecZnx(n, cols, size, a[t].cpu().numpy().copy())
+            bv = av if args.mode == "square" else VecZnx(n, cols, size, b[t].cpu().numpy().copy())
+            r = VecZnx(n, tcols, size, np.zeros((size, tcols, n), dtype=np.int64))
+            if args.mode == "square":
+                ref.glwe_tensor_square_apply(cnv_offset, r, k, av, size * k, k)
+            else:
+                ref.glwe_tensor_apply(cnv_offset, r, k, av, size * k, bv, size * k, k, add_assign=False)
+            ok = ok and bool(np.array_equal(got[t], r.data))
+    # algorithmic bytes per tensoring: both operands read, the tensor written; flops: forward transforms of both operands, the limb
+    # convolution of cols*(cols+1)/2 column pairs (Karatsuba for the cross column: cnv_pairwise), inverse transforms of the tensor
+    m = n // 2
+    nb = (2 * cols * size + tcols * size) * n * 8 if args.mode == "apply" else (cols * size + tcols * size) * n * 8
+    nprod = tcols * size * (size + 1) // 2      # complex pointwise products (upper bound: every limb pair that reaches a result limb)
+    fft = 5.0 * m * np.log2(m)
+    flops = ((2 if args.mode == "apply" else 1) * cols * size + tcols * size) * fft + nprod * m * 8.0
+    rate = args.batch / dt
+    print(json.dumps({
+        "metric": "GLWE tensorings/s (glwe_tensor_%s)" % ("apply" if args.mode == "apply" else "square_apply"),
+        "value": rate, "unit": "tensorings/s", "ms_per_step": dt * 1e3, "batch": args.batch, "parity_ok": ok,
+        "config": {"workload": f"glwe_tensor_{args.mode} (rank 1: 2-column GLWE x GLWE -> 3-column GLWETensor), N={n}, {size} limbs, base2k={k}, cnv_offset={cnv_offset}",
+                   "batch_per_gpu": args.batch},
+        "kernel_classes_launches_ms": stats,
+        "roofline": {"bound": "hbm", "achieved": rate * nb / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": rate * nb / 1e9 / 8000.0,
+                     "algorithmic_bytes_per_unit": nb, "fp64_tflops": rate * flops / 1e12, "fp64_frac": rate * flops / 1e12 / 68.0},
+        "dtype": "f64", "data": "synthetic"}))
+
+
+if __name__ == "__main__":
+    main()
