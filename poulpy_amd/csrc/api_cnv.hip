@@ -248,7 +248,7 @@ int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, c
         PZ_TRY(dev_cnv_prepare(M, nb, pa, pa_bs, t.cols, t.a_size, ab, a_ct, t.cols, t.a_size, a_mask, T));
         if (!square) PZ_TRY(dev_cnv_prepare(M, nb, pb, pb_bs, t.cols, t.b_size, b + (long long)b0 * b_ct, b_ct, t.cols, t.b_size, b_mask, T));
         // one product term (i, j): convolution -> inverse transform in place -> normalize(res_base2k, cnv_offset_lo) into `dst` column dcol
-        auto term = [&](int i, int j, int64_t* dst, long long dst_bs, int dst_cols, int dcol) -> int {
+        auto term = [&](int i, int j, int64_t* dst, long long dst_bs, int dst_cols, int dcol, const NzCombine* cb = nullptr) -> int {
             const int bound = t.a_size + t.b_size - 1;
             const int min_size = std::min(t.dft_size, bound), off = std::min(t.hi, bound);
             PZ_TRY(launch_cnv_apply(M, nb, rd, rd_bs, 1, 0, min_size, off, pa, pa_bs, t.a_size, i, i == j ? -1 : j, pb, pb_bs, t.b_size, i,
@@ -258,7 +258,7 @@ int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, c
             DV dv{rd, rd_bs, 1, t.dft_size};
             PZ_TRY(dev_idft(M, nb, dv, 0, dv, 0, 1, t.dft_size, T));
             DV out{dst, dst_bs, dst_cols, t.res_size};
-            return dev_normalize(M, nb, out, (int)p->res_base2k, t.lo, dcol, dv, (int)p->ab_base2k, 0);
+            return dev_normalize(M, nb, out, (int)p->res_base2k, t.lo, dcol, dv, (int)p->ab_base2k, 0, cb);
         };
         auto col_ptr = [&](int col) { return rb + (long long)col * n; };
         auto ew_res = [&](int op, int col, const int64_t* x, long long x_bs, long long x_ls, const int64_t* y, long long y_bs, long long y_ls) {
@@ -278,6 +278,30 @@ int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, c
                     PZ_TRY(ew_res(EW_SUB_I64, col_i + j, col_ptr(col_i + j), r_ct, rls, diag + (long long)j * n, dg_bs, (long long)t.cols * n));
                 }
             }
+            continue;
+        }
+        // One base2k, rank <= 2 (round 3): the digits of a term go straight from the normalize kernel into every tensor column that takes
+        // them - the diagonal term into its own column (= / +=) and, negated, into the cross columns (= - / -=), the pairwise term into
+        // its cross column (+=) - instead of a temporary and five element-wise passes over the tensor (POULPY_DBG_TENSOR_COMBINE=0).
+        static const bool combine_env = !(getenv("POULPY_DBG_TENSOR_COMBINE") && atoi(getenv("POULPY_DBG_TENSOR_COMBINE")) == 0);
+        if (combine_env && p->res_base2k == p->ab_base2k && t.cols <= 3) {
+            auto cidx = [&](int i, int j) { const int lo_ = std::min(i, j), hi_ = std::max(i, j); return lo_ * t.cols - (lo_ * (lo_ + 1) / 2) + hi_; };
+            for (int i = 0; i < t.cols; ++i) {
+                NzCombine cb{add ? 3 : 1, {0, 0}, {0, 0}};
+                int u = 0;
+                for (int j = 0; j < t.cols; ++j) {
+                    if (j == i) continue;
+                    cb.col2[u] = cidx(i, j);
+                    cb.mode2[u] = (j < i || add) ? 4 : 2;   // the cross column was started by the smaller index (= -v), every later term subtracts
+                    ++u;
+                }
+                PZ_TRY(term(i, i, rb, r_ct, t.tcols, cidx(i, i), &cb));
+            }
+            for (int i = 0; i < t.cols; ++i)
+                for (int j = i + 1; j < t.cols; ++j) {
+                    NzCombine cb{3, {0, 0}, {0, 0}};
+                    PZ_TRY(term(i, j, rb, r_ct, t.tcols, cidx(i, j), &cb));
+                }
             continue;
         }
         for (int i = 0; i < t.cols; ++i) {   // :762-783 / :870-890

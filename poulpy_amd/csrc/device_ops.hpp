@@ -380,9 +380,22 @@ struct NzArgs {
     int res_base2k, a_base2k;
     // same-base plan (normalize.rs:83-101)
     int lsh, res_end, res_start, a_end, a_start;
+    // k_normalize_inter<COMBINE>: how the digits reach `res` (mode) and up to two further columns of the same container that take them too
+    // (GLWE tensoring: the diagonal terms are stored in their own column and subtracted from the cross columns, operations/glwe.rs:762-805
+    // - five element-wise passes over the tensor in round 2).  Modes: 1 = v, 2 = -v, 3 += v, 4 -= v (wrapping i64, as the reference's
+    // vec_znx_{copy,negate,add_assign,sub_assign} on the normalized digits); 0: no such destination.
+    int mode;
+    int col2[2], mode2[2];
 };
 
+__device__ __forceinline__ void nz_put(long long* p, int mode, long long v) {
+    if (mode == 1) *p = v;
+    else if (mode == 2) *p = (long long)(0ull - (unsigned long long)v);
+    else if (mode == 3) *p = (long long)((unsigned long long)*p + (unsigned long long)v);
+    else if (mode == 4) *p = (long long)((unsigned long long)*p - (unsigned long long)v);
+}
 // normalize.rs:50-144 (vec_znx_normalize_inter_base2k)
+template <bool COMBINE = false>
 __global__ void __launch_bounds__(256) k_normalize_inter(NzArgs g) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)g.batch * g.n) return;
@@ -390,6 +403,18 @@ __global__ void __launch_bounds__(256) k_normalize_inter(NzArgs g) {
     const long long b = t / g.n;
     const long long* a = g.a + b * g.a_bs + (long long)g.a_col * g.n + i;
     long long* r = g.res + b * g.res_bs + (long long)g.res_col * g.n + i;
+    long long* r2a = COMBINE && g.mode2[0] ? g.res + b * g.res_bs + (long long)g.col2[0] * g.n + i : nullptr;
+    long long* r2b = COMBINE && g.mode2[1] ? g.res + b * g.res_bs + (long long)g.col2[1] * g.n + i : nullptr;
+#define PZ_NZ_STORE(J_, V_)                                                                        \
+    {                                                                                              \
+        const long long off_ = (long long)(J_) * rls;                                              \
+        const long long v_ = (V_);                                                                 \
+        if constexpr (COMBINE) {                                                                   \
+            nz_put(r + off_, g.mode, v_);                                                          \
+            if (r2a) nz_put(r2a + off_, g.mode2[0], v_);                                           \
+            if (r2b) nz_put(r2b + off_, g.mode2[1], v_);                                           \
+        } else r[off_] = v_;                                                                       \
+    }
     const long long als = (long long)g.a_cols * g.n;
     const long long rls = (long long)g.res_cols * g.n;
     const int k = g.res_base2k;
@@ -409,7 +434,7 @@ __global__ void __launch_bounds__(256) k_normalize_inter(NzArgs g) {
             c = wadd(cr, nz_carry(k, dpc, nz_digit(k, dpc)));
         }
     }
-    for (int j = g.res_start; j < g.res_size; ++j) r[(long long)j * rls] = 0;
+    for (int j = g.res_start; j < g.res_size; ++j) PZ_NZ_STORE(j, 0)
     const int mid = g.a_start > g.a_end ? g.a_start - g.a_end : 0;
     for (int j = 0; j < mid; ++j) {  // znx_normalize_middle_step<true>, normalization.rs:179-221
         const long long x = a[(long long)(g.a_start - j - 1) * als];
@@ -417,16 +442,17 @@ __global__ void __launch_bounds__(256) k_normalize_inter(NzArgs g) {
         const long long cr = nz_carry(kk, x, d);
         const long long dpc = wadd(wshl(d, lsh), c);
         const long long x1 = nz_digit(k, dpc);
-        r[(long long)(g.res_start - j - 1) * rls] = x1;
+        PZ_NZ_STORE(g.res_start - j - 1, x1)
         c = wadd(cr, nz_carry(k, dpc, x1));
     }
     for (int j = 0; j < g.res_end; ++j) {
         // limb zeroed, then middle_step_assign / final_step_assign on a zero limb:
         // digit(kk, 0) = 0 -> dpc = c  (normalization.rs:132-157, 254-272)
         const long long x1 = nz_digit(k, c);
-        r[(long long)(g.res_end - j - 1) * rls] = x1;
+        PZ_NZ_STORE(g.res_end - j - 1, x1)
         if (j != g.res_end - 1) c = nz_carry(k, c, x1);
     }
+#undef PZ_NZ_STORE
 }
 
 // normalize.rs:147-401 (vec_znx_normalize_cross_base2k).  The control flow depends

@@ -107,7 +107,11 @@ int launch_rsh(pz_module* M, int batch, long long* data, long long bs, int cols,
 // vmp_apply_dft_to_dft  [vmp.rs:144-264, zero-tail semantics for limb_offset > 0]
 int dev_vmp(pz_module* M, int batch, DV res, DV a, const double* pmat, int rows, int cols_in, int cols_out, int size, int limb_offset);
 // vec_znx_(big_)normalize on one column  [normalize.rs:18-401]
-int dev_normalize(pz_module* M, int batch, DV res, int res_base2k, long long res_offset, int res_col, DV a, int a_base2k, int a_col);
+// cb (same base2k only): how the digits reach res_col (mode) and up to two more columns of `res` that take them too - 1 = v, 2 = -v,
+// 3 += v, 4 -= v (wrapping), 0 none; nullptr: plain stores
+struct NzCombine { int mode; int col2[2]; int mode2[2]; };
+int dev_normalize(pz_module* M, int batch, DV res, int res_base2k, long long res_offset, int res_col, DV a, int a_base2k, int a_col,
+                  const NzCombine* cb = nullptr);
 
 // ---- launch_br.hip ------------------------------------------------------------------------------------------------
 // whole rotation in one kernel (device_br.hpp) when the shape fits: *launched says whether it did

@@ -107,8 +107,11 @@ int dev_vmp(pz_module* M, int batch, DV res, DV a, const double* pmat, int rows,
 
 // vec_znx_(big_)normalize on one column  [normalize.rs:18-401]
 int dev_normalize(pz_module* M, int batch, DV res, int res_base2k, long long res_offset, int res_col, DV a, int a_base2k,
-                         int a_col) {
+                         int a_col, const NzCombine* cb) {
+    if (cb && res_base2k != a_base2k) return fail(PZ_ERR_INVALID, "normalize with combined stores: one base2k only");
     NzArgs g;
+    g.mode = cb ? cb->mode : 1;
+    for (int u = 0; u < 2; ++u) { g.col2[u] = cb ? cb->col2[u] : 0; g.mode2[u] = cb ? cb->mode2[u] : 0; }
     g.res = (long long*)res.p; g.a = (const long long*)a.p;
     g.res_bs = res.bs; g.a_bs = a.bs;
     g.n = (int)M->n; g.batch = batch;
@@ -130,7 +133,8 @@ int dev_normalize(pz_module* M, int batch, DV res, int res_base2k, long long res
         g.res_start = (int)cl((long long)a.size - lo, 0, res.size);
         g.a_end = (int)cl(lo, 0, a.size);
         g.a_start = (int)cl((long long)res.size + lo, 0, a.size);
-        hipLaunchKernelGGL(k_normalize_inter, dim3(blocks), dim3(256), 0, M->stream, g);
+        if (cb) hipLaunchKernelGGL(k_normalize_inter<true>, dim3(blocks), dim3(256), 0, M->stream, g);
+        else hipLaunchKernelGGL(k_normalize_inter<false>, dim3(blocks), dim3(256), 0, M->stream, g);
     } else {
         hipLaunchKernelGGL(k_normalize_cross, dim3(blocks), dim3(256), 0, M->stream, g, res_offset);
     }
