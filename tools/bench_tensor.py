@@ -28,11 +28,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--mode", choices=("apply", "square"), default="apply")
     ap.add_argument("--parity-samples", type=int, default=2)
+    ap.add_argument("--relin", action="store_true", help="follow every tensoring with glwe_tensor_relinearize (tensor key 1 -> 1, dnum = limbs): "
+                    "the whole GLWE multiplication of a CKKS multiply (operations/glwe.rs:541-607 after :700-807)")
     args = ap.parse_args()
     import ctypes as C
     import torch
-    from poulpy_amd.hal import GlweTensorParams, Module
-    from poulpy_amd.layouts import VecZnx
+    from poulpy_amd.hal import GlweOpParams, GlweTensorParams, Module
+    from poulpy_amd.layouts import MatZnx, VecZnx
     n, size, k, rank = args.n, args.limbs, args.base2k, 1
     cols, tcols = rank + 1, (rank + 1) * (rank + 2) // 2
     dev = torch.device("cuda", 0)
@@ -48,9 +50,26 @@ def main():
     p = GlweTensorParams(rank=rank, a_size=size, b_size=size, ab_base2k=k, a_effective_k=size * k, b_effective_k=size * k, res_size=size,
                          res_base2k=k, cnv_offset=cnv_offset)
 
+    # --relin: a tensor key (GGLWE rank*(rank+1)/2 -> rank: rows = dnum, cols_in = 1, cols_out = 2), synthetic digits, prepared on the device
+    out = pmat = mat = rp = None
+    if args.relin:
+        dnum = size
+        mat = torch.randint(-half, half, (n * dnum * 1 * cols * size,), dtype=torch.int64, device=dev, generator=g)
+        pmat = torch.empty(mat.numel(), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        mod._ck(mod.lib.pz_vmp_prepare(mod.handle, C.c_void_p(pmat.data_ptr()), C.c_void_p(mat.data_ptr()), C.c_size_t(dnum), C.c_size_t(1),
+                                       C.c_size_t(cols), C.c_size_t(size)))
+        mod.sync()
+        mod.pin_key(C.c_void_p(pmat.data_ptr()), dnum, 1, cols, size)
+        out = torch.zeros((args.batch, size, cols, n), dtype=torch.int64, device=dev)
+        rp = GlweOpParams(rank=rank, dnum=dnum, dsize=1, key_size=size, key_base2k=k, a_size=size, a_base2k=k, res_size=size, res_base2k=k, rank_out=rank)
+        torch.cuda.synchronize()
+
     def run():
         mod.glwe_tensor_apply_batched(C.c_void_p(res.data_ptr()), C.c_void_p(a.data_ptr()), None if args.mode == "square" else C.c_void_p(b.data_ptr()),
                                       p, args.mode, args.batch)
+        if args.relin:
+            mod.glwe_tensor_relinearize_batched(C.c_void_p(out.data_ptr()), C.c_void_p(res.data_ptr()), C.c_void_p(pmat.data_ptr()), rp, args.batch)
 
     for _ in range(args.warmup):
         run()
@@ -81,6 +100,13 @@ def main():
             else:
                 ref.glwe_tensor_apply(cnv_offset, r, k, av, size * k, bv, size * k, k, add_assign=False)
             ok = ok and bool(np.array_equal(got[t], r.data))
+            if args.relin:
+                if t == 0:
+                    pm = ref.vmp_pmat_alloc(size, 1, cols, size)
+                    ref.vmp_prepare(pm, MatZnx(n, size, 1, cols, size, np.ascontiguousarray(mat.cpu().numpy())))
+                want = VecZnx(n, cols, size)
+                ref.glwe_tensor_relinearize(want, k, r, k, pm, 1, k)
+                ok = ok and bool(np.array_equal(out[t].cpu().numpy(), want.data))
     # algorithmic bytes per tensoring: both operands read, the tensor written; flops: forward transforms of both operands, the limb
     # convolution of cols*(cols+1)/2 column pairs (Karatsuba for the cross column: cnv_pairwise), inverse transforms of the tensor
     m = n // 2
@@ -89,10 +115,13 @@ def main():
     fft = 5.0 * m * np.log2(m)
     flops = ((2 if args.mode == "apply" else 1) * cols * size + tcols * size) * fft + nprod * m * 8.0
     rate = args.batch / dt
+    if args.relin:   # + read of the tensor, write of the GLWE, the key once per call; key switch of one column with `size` rows
+        nb += (tcols * size + cols * size) * n * 8 + size * cols * size * n * 8 // args.batch
+        flops += (size + cols * size) * fft + m * size * (cols * size) * 8.0
     print(json.dumps({
-        "metric": "GLWE tensorings/s (glwe_tensor_%s)" % ("apply" if args.mode == "apply" else "square_apply"),
-        "value": rate, "unit": "tensorings/s", "ms_per_step": dt * 1e3, "batch": args.batch, "parity_ok": ok,
-        "config": {"workload": f"glwe_tensor_{args.mode} (rank 1: 2-column GLWE x GLWE -> 3-column GLWETensor), N={n}, {size} limbs, base2k={k}, cnv_offset={cnv_offset}",
+        "metric": ("GLWE multiplications/s (glwe_tensor_%s + glwe_tensor_relinearize)" if args.relin else "GLWE tensorings/s (glwe_tensor_%s)") % ("apply" if args.mode == "apply" else "square_apply"),
+        "value": rate, "unit": "multiplications/s" if args.relin else "tensorings/s", "ms_per_step": dt * 1e3, "batch": args.batch, "parity_ok": ok,
+        "config": {"workload": f"glwe_tensor_{args.mode}" + (" + glwe_tensor_relinearize (tensor key 1 -> 1, dnum = limbs)" if args.relin else "") + f" (rank 1: 2-column GLWE x GLWE -> 3-column GLWETensor), N={n}, {size} limbs, base2k={k}, cnv_offset={cnv_offset}",
                    "batch_per_gpu": args.batch},
         "kernel_classes_launches_ms": stats,
         "roofline": {"bound": "hbm", "achieved": rate * nb / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": rate * nb / 1e9 / 8000.0,
