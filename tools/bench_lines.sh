@@ -43,3 +43,13 @@ for l in open("gpurun_out/bench_lines.jsonl"):
     print(f'{d["value"]:12.0f} {d["unit"]:24s} {d["ms_per_step"]:8.3f} ms/step  parity={d.get("parity_sample", {}).get("ok")}  {d["config"]["workload"][:110]}  batch={d["config"]["batch_per_gpu"]}  {r.get("kernel_ms")}')
 PY
 python tools/bench_host_path.py 2>/dev/null; python tools/bench_host_path.py --pinned 2>/dev/null
+# GLWE tensoring / multiplication at the configs[4] shape (tools/bench_tensor.py): profiles/rNN_tensor_lines.jsonl
+T=gpurun_out/tensor_lines.jsonl; : > $T
+python tools/bench_tensor.py 2>/dev/null | tail -1 >> $T
+python tools/bench_tensor.py --mode square 2>/dev/null | tail -1 >> $T
+python tools/bench_tensor.py --limbs 8 --batch 512 2>/dev/null | tail -1 >> $T
+python tools/bench_tensor.py --relin 2>/dev/null | tail -1 >> $T
+python -c "
+import json
+for l in open('gpurun_out/tensor_lines.jsonl'):
+    d = json.loads(l); print('%12.0f %-22s parity=%s %s batch=%d %s' % (d['value'], d['unit'], d['parity_ok'], d['config']['workload'][:100], d['batch'], d['kernel_classes_launches_ms']))"
