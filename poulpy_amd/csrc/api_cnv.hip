@@ -264,6 +264,29 @@ int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, c
         auto ew_res = [&](int op, int col, const int64_t* x, long long x_bs, long long x_ls, const int64_t* y, long long y_bs, long long y_ls) {
             return launch_ew(M, op, col_ptr(col), r_ct, rls, x, x_bs, x_ls, y, y_bs, y_ls, t.res_size, nb);
         };
+        static const bool combine_sq = !(getenv("POULPY_DBG_TENSOR_COMBINE") && atoi(getenv("POULPY_DBG_TENSOR_COMBINE")) == 0);
+        if (square && combine_sq && p->res_base2k == p->ab_base2k && t.cols <= 3) {
+            // (round 3) the same sums with the combination in the normalize kernel's stores: the pairwise terms first (=), then every diagonal
+            // term into its own column (=) and out of the cross columns it belongs to (-=); wrapping i64, any order gives the same digits
+            auto cidx = [&](int i, int j) { const int lo_ = std::min(i, j), hi_ = std::max(i, j); return lo_ * t.cols - (lo_ * (lo_ + 1) / 2) + hi_; };
+            for (int i = 0; i < t.cols; ++i)
+                for (int j = i + 1; j < t.cols; ++j) {
+                    NzCombine cb{1, {0, 0}, {0, 0}};
+                    PZ_TRY(term(i, j, rb, r_ct, t.tcols, cidx(i, j), &cb));
+                }
+            for (int i = 0; i < t.cols; ++i) {
+                NzCombine cb{1, {0, 0}, {0, 0}};
+                int u = 0;
+                for (int j = 0; j < t.cols; ++j) {
+                    if (j == i) continue;
+                    cb.col2[u] = cidx(i, j);
+                    cb.mode2[u] = 4;
+                    ++u;
+                }
+                PZ_TRY(term(i, i, rb, r_ct, t.tcols, cidx(i, i), &cb));
+            }
+            continue;
+        }
         if (square) {   // :651-697
             for (int i = 0; i < t.cols; ++i) {
                 const int col_i = i * t.cols - (i * (i + 1) / 2);
