@@ -245,12 +245,47 @@ int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, c
         const int nb = (int)std::min(chunk, batch - b0);
         const int64_t* ab = a + (long long)b0 * a_ct;
         int64_t* rb = res + (long long)b0 * r_ct;
-        PZ_TRY(dev_cnv_prepare(M, nb, pa, pa_bs, t.cols, t.a_size, ab, a_ct, t.cols, t.a_size, a_mask, T));
-        if (!square) PZ_TRY(dev_cnv_prepare(M, nb, pb, pb_bs, t.cols, t.b_size, b + (long long)b0 * b_ct, b_ct, t.cols, t.b_size, b_mask, T));
+        // Fused row pass (round 3, m = m1 x 128 plans, one base2k, rank <= 2): pass 1 of the operand limbs in the pipeline's row-major layout,
+        // then per term ONE kernel for forward row transform + limb convolution + inverse row transform (k_mid_cnv), the inverse column
+        // pass alone (k_inv_tail, raw), and the normalize kernel with the combination in its stores - instead of forward pass 2 of both
+        // operands, k_cnv_apply, inverse pass 2 and inverse pass 1 (POULPY_DBG_TENSOR_FUSED=0).
+        static const bool fused_env = !(getenv("POULPY_DBG_TENSOR_FUSED") && atoi(getenv("POULPY_DBG_TENSOR_FUSED")) == 0);
+        static const bool combine_ok_env = !(getenv("POULPY_DBG_TENSOR_COMBINE") && atoi(getenv("POULPY_DBG_TENSOR_COMBINE")) == 0);
+        const int bound_f = t.a_size + t.b_size - 1;
+        const bool fused = fused_env && combine_ok_env && p->res_base2k == p->ab_base2k && t.cols <= 3 && t.dft_size >= 1 && !M->probe &&
+                           mid_cnv_supported(M, t.a_size, t.b_size, std::min(t.dft_size, bound_f));
+        const size_t mpts = (size_t)M->m;
+        cplx *ta_main = nullptr, *ta_last = nullptr, *tb_main = nullptr, *tb_last = nullptr;
+        if (fused) {
+            auto prep_T = [&](const int64_t* src, long long ct, int size, long long mask, cplx* region, cplx** mainp, cplx** lastp) -> int {
+                *mainp = region;
+                *lastp = region + (size_t)nb * (size - 1) * t.cols * mpts;
+                if (size > 1) {
+                    PolyMap sm{size - 1, t.cols, ct, (long long)t.cols * n, n, 0};
+                    PZ_TRY(launch_fwd_pass1(M, nb * (size - 1) * t.cols, (const long long*)src, sm, *mainp, true));
+                }
+                PolyMap sl{1, t.cols, ct, 0, n, (long long)(size - 1) * t.cols * n};
+                return launch_fwd_pass1(M, nb * t.cols, (const long long*)src, sl, *lastp, true, mask);
+            };
+            PZ_TRY(prep_T(ab, a_ct, t.a_size, a_mask, (cplx*)pa, &ta_main, &ta_last));
+            if (square) { tb_main = ta_main; tb_last = ta_last; }
+            else PZ_TRY(prep_T(b + (long long)b0 * b_ct, b_ct, t.b_size, b_mask, (cplx*)pb, &tb_main, &tb_last));
+        } else {
+            PZ_TRY(dev_cnv_prepare(M, nb, pa, pa_bs, t.cols, t.a_size, ab, a_ct, t.cols, t.a_size, a_mask, T));
+            if (!square) PZ_TRY(dev_cnv_prepare(M, nb, pb, pb_bs, t.cols, t.b_size, b + (long long)b0 * b_ct, b_ct, t.cols, t.b_size, b_mask, T));
+        }
         // one product term (i, j): convolution -> inverse transform in place -> normalize(res_base2k, cnv_offset_lo) into `dst` column dcol
         auto term = [&](int i, int j, int64_t* dst, long long dst_bs, int dst_cols, int dcol, const NzCombine* cb = nullptr) -> int {
             const int bound = t.a_size + t.b_size - 1;
             const int min_size = std::min(t.dft_size, bound), off = std::min(t.hi, bound);
+            if (fused) {
+                PZ_TRY(launch_mid_cnv(M, nb, ta_main, ta_last, tb_main, tb_last, T, t.cols, t.a_size, t.b_size, i, i == j ? -1 : j, i, i == j ? -1 : j,
+                                      min_size, off));
+                PZ_TRY(launch_inv_tail_raw(M, nb, T, min_size, (long long*)rd, rd_bs, t.dft_size));
+                DV dvf{rd, rd_bs, 1, t.dft_size};
+                DV outf{dst, dst_bs, dst_cols, t.res_size};
+                return dev_normalize(M, nb, outf, (int)p->res_base2k, t.lo, dcol, dvf, (int)p->ab_base2k, 0, cb);
+            }
             PZ_TRY(launch_cnv_apply(M, nb, rd, rd_bs, 1, 0, min_size, off, pa, pa_bs, t.a_size, i, i == j ? -1 : j, pb, pb_bs, t.b_size, i,
                                     i == j ? -1 : j));
             if (t.dft_size > min_size)

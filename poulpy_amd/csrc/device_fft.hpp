@@ -468,6 +468,8 @@ struct TailArgs {
     // phi's signs; auto_mul undoes them in front of the carry chain (so that it runs on the values the reference normalizes), post_neg
     // puts them back on the digits; body_only: only the body column has an operand (phi(body), from the workspace)
     int post_neg, body_only;
+    // raw: store the rounded coefficients themselves (a VecZnxBig), no carry chain (launch_inv_tail_raw)
+    int raw;
 };
 
 // Workgroup = (R2 + R1)*CB threads in two wave-uniform roles (R2*CB must be a multiple of 64):
@@ -699,6 +701,10 @@ k_inv_tail(TailArgs g) {
                 ng_ = (((unsigned)idx * g.auto_mul) & (unsigned)(2 * n - 1)) >= (unsigned)n;                 \
                 if (ng_ != (g.auto_neg != 0)) x = (long long)(0ull - (unsigned long long)x);                 \
             }                                                                                                \
+            if (g.raw) {                                                                                     \
+                if (writes) { if (ROWMAJOR) st_stream(res_col + (long long)j * res_ls + idx, x); else res_col[(long long)j * res_ls + idx] = x; } \
+                continue;                                                                                    \
+            }                                                                                                \
             long long& cy = carry[2 * n1 + h];                                                               \
             const unsigned long long y = (unsigned long long)x + half;                                       \
             const long long d = (long long)(y & mask) - (long long)half;                                     \
@@ -730,7 +736,7 @@ k_inv_tail(TailArgs g) {
             }                                                                                                \
         }                                                                                                    \
     }
-        if (FCARRY && !icarry && big < 2251799813685247.0) {
+        if (FCARRY && !icarry && !g.raw && big < 2251799813685247.0) {
 #pragma unroll
             for (int n1 = 0; n1 < RE; ++n1) {
                 const int j1 = b_ov + R2 * PZ_TAIL_N1(n1);
@@ -750,7 +756,7 @@ k_inv_tail(TailArgs g) {
                 }
             }
         } else {
-            if (FCARRY && !icarry) {   // leave the f64 chain: the carries become integers, for good
+            if (FCARRY && !icarry && !g.raw) {   // leave the f64 chain: the carries become integers, for good
                 icarry = true;
 #pragma unroll
                 for (int u = 0; u < 2 * RE; ++u) carry[u] = fast_i64_from_integral(__longlong_as_double(carry[u]));

@@ -56,6 +56,10 @@ int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncol
                     long long body_bs = 0, long long body_ls = 0, bool small_neg = false, bool post_rsh = false, bool post_neg = false,
                     bool body_only = false);
 bool tail_rsh_supported(const pz_module* M);
+bool mid_cnv_supported(const pz_module* M, int a_size, int b_size, int min_size);
+int launch_mid_cnv(pz_module* M, int batch, const cplx* a_main, const cplx* a_last, const cplx* b_main, const cplx* b_last, cplx* T2, int cols,
+                   int a_size, int b_size, int a_i, int a_j, int b_i, int b_j, int min_size, int offset);
+int launch_inv_tail_raw(pz_module* M, int batch, const cplx* T, int nlimbs, long long* res, long long res_bs, int res_size);
 
 // ---- launch_mid.hip -----------------------------------------------------------------------------------------------
 // scratch rows behind T2: one 64-row x 128-point tile per persistent workgroup of k_mid128 (<= 256 of them: 32 MiB), which also covers

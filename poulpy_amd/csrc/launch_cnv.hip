@@ -47,6 +47,27 @@ int launch_cnv_apply(pz_module* M, int batch, double* res, long long res_bs, int
     return PZ_OK;
 }
 
+// one term of a tensoring on the row-major pipeline layout (device_cnv.hpp, k_mid_cnv); a/b: T' of the operand limbs (see MidCnvArgs)
+bool mid_cnv_supported(const pz_module* M, int a_size, int b_size, int min_size) {
+    return M->plan.m2 == 128 && (M->plan.m1 % 16) == 0 && tail_supported(M) && a_size >= 1 && b_size >= 1 && min_size >= 1 && min_size <= 32 &&
+           ((size_t)std::max(a_size + b_size, min_size) * kMidCnvRS + 256) * sizeof(cplx) <= (size_t)160 * 1024;
+}
+int launch_mid_cnv(pz_module* M, int batch, const cplx* a_main, const cplx* a_last, const cplx* b_main, const cplx* b_last, cplx* T2, int cols,
+                   int a_size, int b_size, int a_i, int a_j, int b_i, int b_j, int min_size, int offset) {
+    if (batch <= 0 || min_size <= 0) return PZ_OK;
+    MidCnvArgs g;
+    g.a_main = a_main; g.a_last = a_last; g.b_main = b_main; g.b_last = b_last; g.T2 = T2; g.cols = cols;
+    g.a_size = a_size; g.b_size = b_size; g.a_i = a_i; g.a_j = a_j; g.b_i = b_i; g.b_j = b_j; g.min_size = min_size; g.offset = offset;
+    g.m1 = M->plan.m1; g.batch = batch; g.wL2 = M->wL2; g.tw12t = M->tw12t;
+    const size_t lds = ((size_t)std::max(a_size + b_size, min_size) * kMidCnvRS + 256) * sizeof(cplx);
+    PZ_TRY(set_lds(k_mid_cnv, lds));
+    KTimer kt(M, PZ_K_FUSED_MID);
+    hipLaunchKernelGGL(k_mid_cnv, dim3((unsigned)((long long)batch * g.m1)), dim3(256), lds, M->stream, g);
+    dispatch_note(M, "k_mid_cnv (a %d + b %d limbs -> %d, lds=%zu)", a_size, b_size, min_size, lds);
+    PZ_HIP(hipGetLastError());
+    return PZ_OK;
+}
+
 int launch_cnv_by_const(pz_module* M, long long* res, int res_cols, int res_col, int min_size, int offset, const long long* a, int a_cols,
                         int a_size, int a_col, const long long* bconst, int b_size) {
     if (min_size <= 0) return PZ_OK;

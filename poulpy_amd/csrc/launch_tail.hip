@@ -28,7 +28,7 @@ static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlim
                                 int base2k, bool rowmajor, bool small_all, unsigned auto_mul, bool auto_neg, int col_base, int col_count,
                                 unsigned gather_mul = 0, bool gather_neg = false, int body_col = 0, const long long* body_src = nullptr,
                                 long long body_bs = 0, long long body_ls = 0, bool small_neg = false, bool post_rsh = false, bool post_neg = false,
-                                bool body_only = false) {
+                                bool body_only = false, bool raw = false) {
     const FftPlan& pl = M->plan;
     int blocks = batch * col_count * (pl.m2 / pl.cb);
     if (blocks == 0) return PZ_OK;
@@ -42,7 +42,7 @@ static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlim
     g.col_base = col_base; g.col_count = col_count; g.body_col = body_col;
     g.gather_mul = gather_mul; g.gather_neg = gather_neg ? 1 : 0;
     g.pre_body = body_src != nullptr ? 1 : 0; g.small_neg = small_neg ? 1 : 0; g.body_src = body_src; g.body_bs = body_bs; g.body_ls = body_ls;
-    g.post_neg = post_neg ? 1 : 0; g.body_only = body_only ? 1 : 0;
+    g.post_neg = post_neg ? 1 : 0; g.body_only = body_only ? 1 : 0; g.raw = raw ? 1 : 0;
     // XCD-aware block order (all column blocks of one (ciphertext, column) on one XCD, back to back): the gathers of the automorphism
     // forms need it for L2 locality, and the row-major pipeline streams faster with it (see k_fwd_pass1); the grid is padded to whole
     // groups of 8 (ciphertext, column) pairs
@@ -110,6 +110,13 @@ int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncol
     return launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, small, small_bs, small_cols, small_size, base2k,
                                 rowmajor, small_all, auto_mul, auto_neg, 0, ncols, gather_mul, gather_neg, body_col, body_src, body_bs, body_ls,
                                 small_neg, post_rsh, post_neg, body_only);
+}
+
+// the inverse column pass alone on the row-major T2': rounded i64 values (VecZnxBig), no carry chain (GLWE tensoring: its normalization
+// carries a bit offset and a column combination the tail does not know, api_cnv.hip)
+int launch_inv_tail_raw(pz_module* M, int batch, const cplx* T, int nlimbs, long long* res, long long res_bs, int res_size) {
+    return launch_inv_tail_cols(M, batch, T, nlimbs, 1, res, res_bs, 1, res_size, nullptr, 0, 1, 0, 12, true, false, 0, false, 0, 1, 0, false, 0,
+                                nullptr, 0, 0, false, false, false, false, true);
 }
 
 

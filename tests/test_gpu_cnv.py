@@ -5,6 +5,8 @@ Mirrors poulpy-hal/src/test_suite/convolution.rs (test_convolution, test_convolu
 a_size = b_size = 15, every cnv_offset, every column pair) — DFT-domain values are never compared, results go through
 idft + normalize — and poulpy-core's tensoring callers (operations/glwe.rs:541-913).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -171,6 +173,29 @@ def test_glwe_tensor_apply_batched(mods, rank, mode):
         got, want = _run_tensor(hip, ref, n, rank, a_size, b_size, res_size, ab, rb, off, mode, batch=5, seed=rank * 100 + off, chunk=2,
                                 a_bits_off=abo)
         assert np.array_equal(got, want), (rank, mode, a_size, b_size, res_size, ab, rb, off)
+
+
+@pytest.mark.parametrize("mode", ["apply", "add_assign", "square"])
+@pytest.mark.parametrize("rank", [1, 2])
+def test_glwe_tensor_apply_fused_row_pass(mods, rank, mode):
+    """N = 8192 (m = 32 x 128: the row-major pipeline layout): one base2k and rank <= 2 run the tensoring as pass 1 + k_mid_cnv (forward
+    row transform + limb convolution + inverse row transform in one kernel) + raw inverse column pass + normalize with the Karatsuba
+    combination in its stores (round 3).  Ragged limb counts, offsets below / at / above base2k, a masked bottom limb, chunks, a result
+    with more limbs than the product reaches; a two-base shape on the same ring takes the per-op composition.  Bit-exact vs the oracle."""
+    n = 8192
+    ref, hip = mods(n)
+    for (a_size, b_size, res_size, ab, rb, off, abo) in ((4, 3, 5, 12, 12, 5, 3), (3, 3, 4, 14, 14, 14, 0), (4, 4, 6, 12, 12, 30, 7),
+                                                         (2, 5, 3, 13, 13, 20, 0), (1, 1, 2, 12, 12, 0, 0), (5, 2, 9, 12, 12, 13, 0)):
+        hip.dispatch_notes(reset=True)
+        got, want = _run_tensor(hip, ref, n, rank, a_size, b_size, res_size, ab, rb, off, mode, batch=3, seed=rank * 1000 + off + a_size, chunk=2,
+                                a_bits_off=abo)
+        assert np.array_equal(got, want), (rank, mode, a_size, b_size, res_size, ab, rb, off)
+        if os.environ.get("POULPY_DBG_TENSOR_FUSED") != "0" and os.environ.get("POULPY_DBG_TENSOR_COMBINE") != "0":
+            assert "k_mid_cnv" in hip.dispatch_notes(), (rank, mode, a_size, b_size, res_size, off)
+    hip.dispatch_notes(reset=True)
+    got, want = _run_tensor(hip, ref, n, rank, 4, 4, 6, 12, 15, 30, mode, batch=3, seed=77 + rank, chunk=2, a_bits_off=7)   # two bases
+    assert np.array_equal(got, want)
+    assert "k_mid_cnv" not in hip.dispatch_notes()
 
 
 def test_glwe_tensor_apply_n65536_16_limbs(mods):
