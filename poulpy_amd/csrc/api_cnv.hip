@@ -281,6 +281,12 @@ int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, c
             if (fused) {
                 PZ_TRY(launch_mid_cnv(M, nb, ta_main, ta_last, tb_main, tb_last, T, t.cols, t.a_size, t.b_size, i, i == j ? -1 : j, i, i == j ? -1 : j,
                                       min_size, off));
+                // the inverse column pass normalizes on its way out (bit offset, combination and all: TailArgs::nz); POULPY_DBG_TENSOR_NZTAIL=0:
+                // raw inverse column pass into a VecZnxBig, then the normalize kernel
+                static const bool nztail = !(getenv("POULPY_DBG_TENSOR_NZTAIL") && atoi(getenv("POULPY_DBG_TENSOR_NZTAIL")) == 0);
+                if (nztail)
+                    return launch_inv_tail_nz(M, nb, T, min_size, (long long*)dst, dst_bs, dst_cols, t.res_size, dcol, (int)p->res_base2k, t.lo,
+                                              t.dft_size, cb);
                 PZ_TRY(launch_inv_tail_raw(M, nb, T, min_size, (long long*)rd, rd_bs, t.dft_size));
                 DV dvf{rd, rd_bs, 1, t.dft_size};
                 DV outf{dst, dst_bs, dst_cols, t.res_size};

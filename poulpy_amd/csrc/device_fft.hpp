@@ -470,7 +470,21 @@ struct TailArgs {
     int post_neg, body_only;
     // raw: store the rounded coefficients themselves (a VecZnxBig), no carry chain (launch_inv_tail_raw)
     int raw;
+    // nz (GLWE tensoring, round 3): the values leave through the SAME-BASE steps of vec_znx_normalize with a bit offset (normalize.rs:50-144 as
+    // k_normalize_inter walks them: carry-only steps for limbs >= nz_a_start, digit steps down to nz_a_end, then nz_res_end steps on the
+    // carry alone) into column nz_col of `res` (mode nz_mode) and up to two further columns (NzCombine's modes: 1 = v, 2 = -v, 3 += v,
+    // 4 -= v); res limbs >= nz_zero_from are zero.  The limb count of the transformed value may be smaller than the normalizer's a.size:
+    // the missing top-index limbs are zeros and come first in the chain, where they change nothing.
+    int nz, nz_lsh, nz_res_end, nz_res_start, nz_a_end, nz_a_start, nz_zero_from, nz_col, nz_mode, nz_col2[2], nz_mode2[2];
 };
+__device__ __forceinline__ long long tz_digit(int k, long long x) { return (long long)((unsigned long long)x << (64 - k)) >> (64 - k); }
+__device__ __forceinline__ long long tz_carry(int k, long long x, long long d) { return (long long)((unsigned long long)x - (unsigned long long)d) >> k; }
+__device__ __forceinline__ void tz_put(long long* p, int mode, long long v) {
+    if (mode == 1) *p = v;
+    else if (mode == 2) *p = (long long)(0ull - (unsigned long long)v);
+    else if (mode == 3) *p = (long long)((unsigned long long)*p + (unsigned long long)v);
+    else if (mode == 4) *p = (long long)((unsigned long long)*p - (unsigned long long)v);
+}
 
 // Workgroup = (R2 + R1)*CB threads in two wave-uniform roles (R2*CB must be a multiple of 64):
 //   B' waves (tid <  R2*CB): second butterfly stage of limb j, rounding, carry chain, stores;
@@ -587,8 +601,18 @@ k_inv_tail(TailArgs g) {
     constexpr bool FCARRY = !SMALL;
     bool icarry = !FCARRY || k > 31;
     const double halfd = (double)(1ull << (k - 1)), twok = 2.0 * halfd, invk = 1.0 / twok;
-    long long* res_col = g.res + (long long)b * g.res_bs + (long long)col * n;
+    long long* res_col = g.res + (long long)b * g.res_bs + (long long)(g.nz ? g.nz_col : col) * n;
     const long long res_ls = (long long)g.res_cols * n;
+    long long* nz_r2a = (g.nz && g.nz_mode2[0]) ? g.res + (long long)b * g.res_bs + (long long)g.nz_col2[0] * n : nullptr;
+    long long* nz_r2b = (g.nz && g.nz_mode2[1]) ? g.res + (long long)b * g.res_bs + (long long)g.nz_col2[1] * n : nullptr;
+#define PZ_TAIL_NZ_STORE(R_, IDX_, V_)                                                             \
+    {                                                                                              \
+        const long long off_ = (long long)(R_) * res_ls + (IDX_);                                  \
+        const long long v_ = (V_);                                                                 \
+        tz_put(res_col + off_, g.nz_mode, v_);                                                     \
+        if (nz_r2a) tz_put(nz_r2a + off_, g.nz_mode2[0], v_);                                      \
+        if (nz_r2b) tz_put(nz_r2b + off_, g.nz_mode2[1], v_);                                      \
+    }
     const long long* small_col =
         (g.small && (col == g.body_col || g.small_all)) ? g.small + (long long)b * g.small_bs + (g.small_all ? (long long)col * n : 0) : nullptr;
     const long long small_ls = (long long)g.small_cols * n;
@@ -597,13 +621,18 @@ k_inv_tail(TailArgs g) {
     int cy2[RSH ? 2 * RE : 1];
 #pragma unroll
     for (int u = 0; u < (RSH ? 2 * RE : 1); ++u) cy2[u] = 0;
-    for (int j = L + (RSH ? 1 : 0); j < g.res_size; ++j)
+    for (int j = g.nz ? g.nz_zero_from : L + (RSH ? 1 : 0); j < g.res_size; ++j)
 #pragma unroll
         for (int e = 0; e < RE; ++e) {
             const int n1 = PZ_TAIL_N1(e);
             const long long idx = (long long)(b_o + R2 * n1) * g.m2 + c0 + b_c;
-            res_col[(long long)j * res_ls + idx] = 0;
-            res_col[(long long)j * res_ls + idx + m] = 0;
+            if (g.nz) {
+                PZ_TAIL_NZ_STORE(j, idx, 0)
+                PZ_TAIL_NZ_STORE(j, idx + m, 0)
+            } else {
+                res_col[(long long)j * res_ls + idx] = 0;
+                res_col[(long long)j * res_ls + idx + m] = 0;
+            }
         }
     __syncthreads();  // matches the prologue iteration of role A'
     for (int j = L - 1; j >= 0; --j) {
@@ -705,6 +734,19 @@ k_inv_tail(TailArgs g) {
                 if (writes) { if (ROWMAJOR) st_stream(res_col + (long long)j * res_ls + idx, x); else res_col[(long long)j * res_ls + idx] = x; } \
                 continue;                                                                                    \
             }                                                                                                \
+            if (g.nz) {   /* k_normalize_inter's steps on limb j (carry starts at 0: its first-step special case is the general step) */ \
+                if (j >= g.nz_a_end) {                                                                       \
+                    long long& c_ = carry[2 * n1 + h];                                                       \
+                    const int kk_ = g.nz_lsh == 0 ? k : k - g.nz_lsh;                                        \
+                    const long long d_ = tz_digit(kk_, x);                                                   \
+                    const long long cr_ = tz_carry(kk_, x, d_);                                              \
+                    const long long dpc_ = (long long)(((unsigned long long)d_ << g.nz_lsh) + (unsigned long long)c_); \
+                    const long long x1_ = tz_digit(k, dpc_);                                                 \
+                    if (j < g.nz_a_start) PZ_TAIL_NZ_STORE(j - g.nz_a_start + g.nz_res_start, idx, x1_)      \
+                    c_ = (long long)((unsigned long long)cr_ + (unsigned long long)tz_carry(k, dpc_, x1_));  \
+                }                                                                                            \
+                continue;                                                                                    \
+            }                                                                                                \
             long long& cy = carry[2 * n1 + h];                                                               \
             const unsigned long long y = (unsigned long long)x + half;                                       \
             const long long d = (long long)(y & mask) - (long long)half;                                     \
@@ -736,7 +778,7 @@ k_inv_tail(TailArgs g) {
             }                                                                                                \
         }                                                                                                    \
     }
-        if (FCARRY && !icarry && !g.raw && big < 2251799813685247.0) {
+        if (FCARRY && !icarry && !g.raw && !g.nz && big < 2251799813685247.0) {
 #pragma unroll
             for (int n1 = 0; n1 < RE; ++n1) {
                 const int j1 = b_ov + R2 * PZ_TAIL_N1(n1);
@@ -756,7 +798,7 @@ k_inv_tail(TailArgs g) {
                 }
             }
         } else {
-            if (FCARRY && !icarry && !g.raw) {   // leave the f64 chain: the carries become integers, for good
+            if (FCARRY && !icarry && !g.raw && !g.nz) {   // leave the f64 chain: the carries become integers, for good
                 icarry = true;
 #pragma unroll
                 for (int u = 0; u < 2 * RE; ++u) carry[u] = fast_i64_from_integral(__longlong_as_double(carry[u]));
@@ -771,6 +813,23 @@ k_inv_tail(TailArgs g) {
         if (PROBE) atomicMax(g.margin, (unsigned long long)__double_as_longlong(worst));
         __syncthreads();
     }
+    if (g.nz) {   // the top res limbs are digits of the carry alone (middle_step_assign / final_step_assign on zero limbs, normalization.rs:132-157, 254-272)
+#pragma unroll
+        for (int n1 = 0; n1 < RE; ++n1) {
+            const int j1 = b_o + R2 * PZ_TAIL_N1(n1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const long long idx = (long long)j1 * g.m2 + c0 + b_c + (h ? m : 0);
+                long long c_ = carry[2 * n1 + h];
+                for (int jj = 0; jj < g.nz_res_end; ++jj) {
+                    const long long x1_ = tz_digit(k, c_);
+                    PZ_TAIL_NZ_STORE(g.nz_res_end - jj - 1, idx, x1_)
+                    if (jj != g.nz_res_end - 1) c_ = tz_carry(k, c_, x1_);
+                }
+            }
+        }
+    }
+#undef PZ_TAIL_NZ_STORE
 }
 
 #undef PZ_TAIL_N1

@@ -23,12 +23,13 @@ bool tail_rsh_supported(const pz_module* M) {
     return false;
 }
 
+struct TailNz { int lsh, res_end, res_start, a_end, a_start, zero_from, col, mode, col2[2], mode2[2]; };
 static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
                                 int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
                                 int base2k, bool rowmajor, bool small_all, unsigned auto_mul, bool auto_neg, int col_base, int col_count,
                                 unsigned gather_mul = 0, bool gather_neg = false, int body_col = 0, const long long* body_src = nullptr,
                                 long long body_bs = 0, long long body_ls = 0, bool small_neg = false, bool post_rsh = false, bool post_neg = false,
-                                bool body_only = false, bool raw = false) {
+                                bool body_only = false, bool raw = false, const TailNz* nz = nullptr) {
     const FftPlan& pl = M->plan;
     int blocks = batch * col_count * (pl.m2 / pl.cb);
     if (blocks == 0) return PZ_OK;
@@ -43,6 +44,10 @@ static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlim
     g.gather_mul = gather_mul; g.gather_neg = gather_neg ? 1 : 0;
     g.pre_body = body_src != nullptr ? 1 : 0; g.small_neg = small_neg ? 1 : 0; g.body_src = body_src; g.body_bs = body_bs; g.body_ls = body_ls;
     g.post_neg = post_neg ? 1 : 0; g.body_only = body_only ? 1 : 0; g.raw = raw ? 1 : 0;
+    g.nz = nz ? 1 : 0;
+    g.nz_lsh = nz ? nz->lsh : 0; g.nz_res_end = nz ? nz->res_end : 0; g.nz_res_start = nz ? nz->res_start : 0; g.nz_a_end = nz ? nz->a_end : 0;
+    g.nz_a_start = nz ? nz->a_start : 0; g.nz_zero_from = nz ? nz->zero_from : 0; g.nz_col = nz ? nz->col : 0; g.nz_mode = nz ? nz->mode : 0;
+    for (int u = 0; u < 2; ++u) { g.nz_col2[u] = nz ? nz->col2[u] : 0; g.nz_mode2[u] = nz ? nz->mode2[u] : 0; }
     // XCD-aware block order (all column blocks of one (ciphertext, column) on one XCD, back to back): the gathers of the automorphism
     // forms need it for L2 locality, and the row-major pipeline streams faster with it (see k_fwd_pass1); the grid is padded to whole
     // groups of 8 (ciphertext, column) pairs
@@ -110,6 +115,29 @@ int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncol
     return launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, small, small_bs, small_cols, small_size, base2k,
                                 rowmajor, small_all, auto_mul, auto_neg, 0, ncols, gather_mul, gather_neg, body_col, body_src, body_bs, body_ls,
                                 small_neg, post_rsh, post_neg, body_only);
+}
+
+// the inverse column pass on the row-major T2' with vec_znx_normalize's same-base steps (bit offset res_offset, a.size = a_size limbs of which
+// the first nlimbs are transformed and the rest are zero) and NzCombine's stores into `res` (GLWE tensoring: raw inverse pass + normalize
+// kernel in one; TailArgs::nz)
+int launch_inv_tail_nz(pz_module* M, int batch, const cplx* T, int nlimbs, long long* res, long long res_bs, int res_cols, int res_size, int res_col,
+                       int base2k, long long res_offset, int a_size, const NzCombine* cb) {
+    const long long k = base2k;
+    long long lsh = res_offset % k, lo = res_offset / k;
+    if (res_offset < 0 && lsh != 0) { lsh = (lsh + k) % k; lo -= 1; }
+    auto cl = [](long long v, long long lo_, long long hi_) { return v < lo_ ? lo_ : (v > hi_ ? hi_ : v); };
+    TailNz nz;
+    nz.lsh = (int)lsh;
+    nz.res_end = (int)cl(-lo, 0, res_size);
+    nz.res_start = (int)cl((long long)a_size - lo, 0, res_size);
+    nz.a_end = (int)cl(lo, 0, a_size);
+    nz.a_start = (int)cl((long long)res_size + lo, 0, a_size);
+    nz.zero_from = nz.res_start - std::max(0, nz.a_start - std::max(nlimbs, nz.a_end));
+    nz.col = res_col;
+    nz.mode = cb ? cb->mode : 1;
+    for (int u = 0; u < 2; ++u) { nz.col2[u] = cb ? cb->col2[u] : 0; nz.mode2[u] = cb ? cb->mode2[u] : 0; }
+    return launch_inv_tail_cols(M, batch, T, nlimbs, 1, res, res_bs, res_cols, res_size, nullptr, 0, 1, 0, base2k, true, false, 0, false, 0, 1, 0, false, 0,
+                                nullptr, 0, 0, false, false, false, false, false, &nz);
 }
 
 // the inverse column pass alone on the row-major T2': rounded i64 values (VecZnxBig), no carry chain (GLWE tensoring: its normalization
