@@ -511,10 +511,13 @@ struct TailShape {
 //  2^(base2k + 1) - the launcher requires base2k <= 29)
 __device__ __forceinline__ int sx_digit(int k, int x) { return (int)((unsigned)x << (32 - k)) >> (32 - k); }
 __device__ __forceinline__ int sx_carry(int k, int x, int d) { return (x - d) >> k; }
-template <int R1, int R2, int CB, bool PROBE, bool ROWMAJOR = false, bool SMALL = false, bool RSH = false>
+// NZ: the tensoring forms (TailArgs::raw / ::nz) are compiled in - a separate instantiation, so that the product tails keep their registers
+// (with the two run-time modes in the common kernel the N = 2^16 tail spilled 84 bytes)
+template <int R1, int R2, int CB, bool PROBE, bool ROWMAJOR = false, bool SMALL = false, bool RSH = false, bool NZ = false>
 __global__ void __launch_bounds__(((R1 == 16 ? 2 : 1) * R2 + R1) * CB, ((((R1 == 16 ? 2 : 1) * R2 + R1) * CB >= 512) ? 1 : (SMALL ? 2 : 3)))
 k_inv_tail(TailArgs g) {
     static_assert(!RSH || SMALL, "the shifted store rides on the integer carry chain");
+    static_assert(!NZ || (ROWMAJOR && !SMALL && !RSH && !PROBE), "tensoring forms: row-major pipeline layout, no operand");
     constexpr bool SPLIT = TailShape<R1, R2, CB>::SPLIT;
     constexpr int RE = TailShape<R1, R2, CB>::RE;
     constexpr int NB = TailShape<R1, R2, CB>::NB;
@@ -601,10 +604,10 @@ k_inv_tail(TailArgs g) {
     constexpr bool FCARRY = !SMALL;
     bool icarry = !FCARRY || k > 31;
     const double halfd = (double)(1ull << (k - 1)), twok = 2.0 * halfd, invk = 1.0 / twok;
-    long long* res_col = g.res + (long long)b * g.res_bs + (long long)(g.nz ? g.nz_col : col) * n;
+    long long* res_col = g.res + (long long)b * g.res_bs + (long long)((NZ && g.nz) ? g.nz_col : col) * n;
     const long long res_ls = (long long)g.res_cols * n;
-    long long* nz_r2a = (g.nz && g.nz_mode2[0]) ? g.res + (long long)b * g.res_bs + (long long)g.nz_col2[0] * n : nullptr;
-    long long* nz_r2b = (g.nz && g.nz_mode2[1]) ? g.res + (long long)b * g.res_bs + (long long)g.nz_col2[1] * n : nullptr;
+    long long* nz_r2a = (NZ && g.nz && g.nz_mode2[0]) ? g.res + (long long)b * g.res_bs + (long long)g.nz_col2[0] * n : nullptr;
+    long long* nz_r2b = (NZ && g.nz && g.nz_mode2[1]) ? g.res + (long long)b * g.res_bs + (long long)g.nz_col2[1] * n : nullptr;
 #define PZ_TAIL_NZ_STORE(R_, IDX_, V_)                                                             \
     {                                                                                              \
         const long long off_ = (long long)(R_) * res_ls + (IDX_);                                  \
@@ -621,12 +624,12 @@ k_inv_tail(TailArgs g) {
     int cy2[RSH ? 2 * RE : 1];
 #pragma unroll
     for (int u = 0; u < (RSH ? 2 * RE : 1); ++u) cy2[u] = 0;
-    for (int j = g.nz ? g.nz_zero_from : L + (RSH ? 1 : 0); j < g.res_size; ++j)
+    for (int j = (NZ && g.nz) ? g.nz_zero_from : L + (RSH ? 1 : 0); j < g.res_size; ++j)
 #pragma unroll
         for (int e = 0; e < RE; ++e) {
             const int n1 = PZ_TAIL_N1(e);
             const long long idx = (long long)(b_o + R2 * n1) * g.m2 + c0 + b_c;
-            if (g.nz) {
+            if (NZ && g.nz) {
                 PZ_TAIL_NZ_STORE(j, idx, 0)
                 PZ_TAIL_NZ_STORE(j, idx + m, 0)
             } else {
@@ -730,11 +733,11 @@ k_inv_tail(TailArgs g) {
                 ng_ = (((unsigned)idx * g.auto_mul) & (unsigned)(2 * n - 1)) >= (unsigned)n;                 \
                 if (ng_ != (g.auto_neg != 0)) x = (long long)(0ull - (unsigned long long)x);                 \
             }                                                                                                \
-            if (g.raw) {                                                                                     \
+            if (NZ && g.raw) {                                                                               \
                 if (writes) { if (ROWMAJOR) st_stream(res_col + (long long)j * res_ls + idx, x); else res_col[(long long)j * res_ls + idx] = x; } \
                 continue;                                                                                    \
             }                                                                                                \
-            if (g.nz) {   /* k_normalize_inter's steps on limb j (carry starts at 0: its first-step special case is the general step) */ \
+            if (NZ && g.nz) {   /* k_normalize_inter's steps on limb j (carry starts at 0: its first-step special case is the general step) */ \
                 if (j >= g.nz_a_end) {                                                                       \
                     long long& c_ = carry[2 * n1 + h];                                                       \
                     const int kk_ = g.nz_lsh == 0 ? k : k - g.nz_lsh;                                        \
@@ -778,7 +781,7 @@ k_inv_tail(TailArgs g) {
             }                                                                                                \
         }                                                                                                    \
     }
-        if (FCARRY && !icarry && !g.raw && !g.nz && big < 2251799813685247.0) {
+        if (FCARRY && !icarry && !(NZ && (g.raw || g.nz)) && big < 2251799813685247.0) {
 #pragma unroll
             for (int n1 = 0; n1 < RE; ++n1) {
                 const int j1 = b_ov + R2 * PZ_TAIL_N1(n1);
@@ -798,7 +801,7 @@ k_inv_tail(TailArgs g) {
                 }
             }
         } else {
-            if (FCARRY && !icarry && !g.raw && !g.nz) {   // leave the f64 chain: the carries become integers, for good
+            if (FCARRY && !icarry && !(NZ && (g.raw || g.nz))) {   // leave the f64 chain: the carries become integers, for good
                 icarry = true;
 #pragma unroll
                 for (int u = 0; u < 2 * RE; ++u) carry[u] = fast_i64_from_integral(__longlong_as_double(carry[u]));
@@ -813,7 +816,7 @@ k_inv_tail(TailArgs g) {
         if (PROBE) atomicMax(g.margin, (unsigned long long)__double_as_longlong(worst));
         __syncthreads();
     }
-    if (g.nz) {   // the top res limbs are digits of the carry alone (middle_step_assign / final_step_assign on zero limbs, normalization.rs:132-157, 254-272)
+    if (NZ && g.nz) {   // the top res limbs are digits of the carry alone (middle_step_assign / final_step_assign on zero limbs, normalization.rs:132-157, 254-272)
 #pragma unroll
         for (int n1 = 0; n1 < RE; ++n1) {
             const int j1 = b_o + R2 * PZ_TAIL_N1(n1);

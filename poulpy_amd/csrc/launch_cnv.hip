@@ -49,7 +49,8 @@ int launch_cnv_apply(pz_module* M, int batch, double* res, long long res_bs, int
 
 // one term of a tensoring on the row-major pipeline layout (device_cnv.hpp, k_mid_cnv); a/b: T' of the operand limbs (see MidCnvArgs)
 bool mid_cnv_supported(const pz_module* M, int a_size, int b_size, int min_size) {
-    return M->plan.m2 == 128 && (M->plan.m1 % 16) == 0 && tail_supported(M) && a_size >= 1 && b_size >= 1 && min_size >= 1 && min_size <= 32 &&
+    return M->plan.m2 == 128 && (M->plan.m1 % 16) == 0 && tail_supported(M) && tail_rsh_supported(M) &&   // (the tensoring tail exists for the plans of the shifted-store tail)
+           a_size >= 1 && b_size >= 1 && min_size >= 1 && min_size <= 32 &&
            ((size_t)std::max(a_size + b_size, min_size) * kMidCnvRS + 256) * sizeof(cplx) <= (size_t)160 * 1024;
 }
 int launch_mid_cnv(pz_module* M, int batch, const cplx* a_main, const cplx* a_last, const cplx* b_main, const cplx* b_last, cplx* T2, int cols,

@@ -73,6 +73,20 @@ static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlim
 #undef X
         return fail(PZ_ERR_UNSUPPORTED, "fused tail: no shifted-store variant for this plan");
     }
+    if (raw || nz) {   // the tensoring forms: their own instantiation of the row-major, operand-free tail
+        if (!(rowmajor && !has_small && !M->probe)) return fail(PZ_ERR_UNSUPPORTED, "fused tail: the tensoring forms need the row-major layout");
+#define X(A, B, C)                                                                                              \
+    if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
+        const size_t lds = ((size_t)2 * (A + 1) * C * B + 2 * A * B) * sizeof(cplx);                            \
+        PZ_TRY(set_lds((k_inv_tail<A, B, C, false, true, false, false, true>), lds));                           \
+        hipLaunchKernelGGL((k_inv_tail<A, B, C, false, true, false, false, true>), dim3(blocks), dim3(TailShape<A, B, C>::NT), lds, M->stream, g); \
+        PZ_HIP(hipGetLastError());                                                                              \
+        return PZ_OK;                                                                                           \
+    }
+        PZ_RSH_CASES(X)
+#undef X
+        return fail(PZ_ERR_UNSUPPORTED, "fused tail: no tensoring variant for this plan");
+    }
 // one instantiation per (probe, row-major, body add) combination actually requested
 #define PZ_TAIL_ONE(A, B, C, P_, R_, S_)                                                                        \
     if (M->probe == P_ && rowmajor == R_ && has_small == S_) {                                                  \
