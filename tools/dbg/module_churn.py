@@ -7,7 +7,7 @@ from poulpy_amd.hal import Module
 from poulpy_amd.layouts import VecZnx
 free0 = torch.cuda.mem_get_info()[0]
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
-    n = [256, 4096, 65536][it % 3]
+    n = [256, 2048, 4096, 65536][it % 4]
     m = Module(n)
     a = VecZnx(n, 2, 3).fill_uniform(12, np.random.default_rng(it))
     d = m.vec_znx_dft_alloc(2, 3)
