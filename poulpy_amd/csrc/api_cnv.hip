@@ -307,25 +307,18 @@ int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, c
         };
         static const bool combine_sq = !(getenv("POULPY_DBG_TENSOR_COMBINE") && atoi(getenv("POULPY_DBG_TENSOR_COMBINE")) == 0);
         if (square && combine_sq && p->res_base2k == p->ab_base2k && t.cols <= 3) {
-            // (round 3) the same sums with the combination in the normalize kernel's stores: the pairwise terms first (=), then every diagonal
-            // term into its own column (=) and out of the cross columns it belongs to (-=); wrapping i64, any order gives the same digits
+            // (round 3) the same sums with the combination in the normalize kernel's stores: the diagonal terms stored, each pairwise term
+            // then reads its two diagonal columns and stores pair - d_i - d_j (wrapping i64: the same digits as the reference's order)
             auto cidx = [&](int i, int j) { const int lo_ = std::min(i, j), hi_ = std::max(i, j); return lo_ * t.cols - (lo_ * (lo_ + 1) / 2) + hi_; };
-            for (int i = 0; i < t.cols; ++i)
-                for (int j = i + 1; j < t.cols; ++j) {
-                    NzCombine cb{1, {0, 0}, {0, 0}};
-                    PZ_TRY(term(i, j, rb, r_ct, t.tcols, cidx(i, j), &cb));
-                }
             for (int i = 0; i < t.cols; ++i) {
                 NzCombine cb{1, {0, 0}, {0, 0}};
-                int u = 0;
-                for (int j = 0; j < t.cols; ++j) {
-                    if (j == i) continue;
-                    cb.col2[u] = cidx(i, j);
-                    cb.mode2[u] = 4;
-                    ++u;
-                }
                 PZ_TRY(term(i, i, rb, r_ct, t.tcols, cidx(i, i), &cb));
             }
+            for (int i = 0; i < t.cols; ++i)
+                for (int j = i + 1; j < t.cols; ++j) {
+                    NzCombine cb{1, {cidx(i, i), cidx(j, j)}, {5, 5}};
+                    PZ_TRY(term(i, j, rb, r_ct, t.tcols, cidx(i, j), &cb));
+                }
             continue;
         }
         if (square) {   // :651-697
@@ -350,13 +343,27 @@ int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, c
         static const bool combine_env = !(getenv("POULPY_DBG_TENSOR_COMBINE") && atoi(getenv("POULPY_DBG_TENSOR_COMBINE")) == 0);
         if (combine_env && p->res_base2k == p->ab_base2k && t.cols <= 3) {
             auto cidx = [&](int i, int j) { const int lo_ = std::min(i, j), hi_ = std::max(i, j); return lo_ * t.cols - (lo_ * (lo_ + 1) / 2) + hi_; };
+            if (!add) {
+                // plain apply: the diagonal terms are stored, each pairwise term then reads the two diagonal columns it belongs to and stores
+                // pair - d_i - d_j (mode 5): one write per column, no read-modify-write of the cross columns
+                for (int i = 0; i < t.cols; ++i) {
+                    NzCombine cb{1, {0, 0}, {0, 0}};
+                    PZ_TRY(term(i, i, rb, r_ct, t.tcols, cidx(i, i), &cb));
+                }
+                for (int i = 0; i < t.cols; ++i)
+                    for (int j = i + 1; j < t.cols; ++j) {
+                        NzCombine cb{1, {cidx(i, i), cidx(j, j)}, {5, 5}};
+                        PZ_TRY(term(i, j, rb, r_ct, t.tcols, cidx(i, j), &cb));
+                    }
+                continue;
+            }
             for (int i = 0; i < t.cols; ++i) {
-                NzCombine cb{add ? 3 : 1, {0, 0}, {0, 0}};
+                NzCombine cb{3, {0, 0}, {0, 0}};
                 int u = 0;
                 for (int j = 0; j < t.cols; ++j) {
                     if (j == i) continue;
                     cb.col2[u] = cidx(i, j);
-                    cb.mode2[u] = (j < i || add) ? 4 : 2;   // the cross column was started by the smaller index (= -v), every later term subtracts
+                    cb.mode2[u] = 4;   // add_assign: the diagonal term goes into its column (+=) and out of the cross columns (-=)
                     ++u;
                 }
                 PZ_TRY(term(i, i, rb, r_ct, t.tcols, cidx(i, i), &cb));

@@ -473,7 +473,7 @@ struct TailArgs {
     // nz (GLWE tensoring, round 3): the values leave through the SAME-BASE steps of vec_znx_normalize with a bit offset (normalize.rs:50-144 as
     // k_normalize_inter walks them: carry-only steps for limbs >= nz_a_start, digit steps down to nz_a_end, then nz_res_end steps on the
     // carry alone) into column nz_col of `res` (mode nz_mode) and up to two further columns (NzCombine's modes: 1 = v, 2 = -v, 3 += v,
-    // 4 -= v); res limbs >= nz_zero_from are zero.  The limb count of the transformed value may be smaller than the normalizer's a.size:
+    // 4 -= v; 5 on BOTH further columns: their digits are read and subtracted from the value before it reaches nz_col); res limbs >= nz_zero_from are zero.  The limb count of the transformed value may be smaller than the normalizer's a.size:
     // the missing top-index limbs are zeros and come first in the chain, where they change nothing.
     int nz, nz_lsh, nz_res_end, nz_res_start, nz_a_end, nz_a_start, nz_zero_from, nz_col, nz_mode, nz_col2[2], nz_mode2[2];
 };
@@ -611,10 +611,16 @@ k_inv_tail(TailArgs g) {
 #define PZ_TAIL_NZ_STORE(R_, IDX_, V_)                                                             \
     {                                                                                              \
         const long long off_ = (long long)(R_) * res_ls + (IDX_);                                  \
-        const long long v_ = (V_);                                                                 \
-        tz_put(res_col + off_, g.nz_mode, v_);                                                     \
-        if (nz_r2a) tz_put(nz_r2a + off_, g.nz_mode2[0], v_);                                      \
-        if (nz_r2b) tz_put(nz_r2b + off_, g.nz_mode2[1], v_);                                      \
+        long long v_ = (V_);                                                                       \
+        if (g.nz_mode2[0] == 5) {   /* mode 5: a column whose digits are SUBTRACTED from the value on its way to the main column */ \
+            v_ = (long long)((unsigned long long)v_ - (unsigned long long)nz_r2a[off_]);           \
+            if (nz_r2b) v_ = (long long)((unsigned long long)v_ - (unsigned long long)nz_r2b[off_]); \
+            tz_put(res_col + off_, g.nz_mode, v_);                                                 \
+        } else {                                                                                   \
+            tz_put(res_col + off_, g.nz_mode, v_);                                                 \
+            if (nz_r2a) tz_put(nz_r2a + off_, g.nz_mode2[0], v_);                                  \
+            if (nz_r2b) tz_put(nz_r2b + off_, g.nz_mode2[1], v_);                                  \
+        }                                                                                          \
     }
     const long long* small_col =
         (g.small && (col == g.body_col || g.small_all)) ? g.small + (long long)b * g.small_bs + (g.small_all ? (long long)col * n : 0) : nullptr;

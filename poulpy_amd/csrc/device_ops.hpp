@@ -382,7 +382,7 @@ struct NzArgs {
     int lsh, res_end, res_start, a_end, a_start;
     // k_normalize_inter<COMBINE>: how the digits reach `res` (mode) and up to two further columns of the same container that take them too
     // (GLWE tensoring: the diagonal terms are stored in their own column and subtracted from the cross columns, operations/glwe.rs:762-805
-    // - five element-wise passes over the tensor in round 2).  Modes: 1 = v, 2 = -v, 3 += v, 4 -= v (wrapping i64, as the reference's
+    // - five element-wise passes over the tensor in round 2).  Modes: 1 = v, 2 = -v, 3 += v, 4 -= v, 5 (both further columns) = read-only: their digits are subtracted from v first (wrapping i64, as the reference's
     // vec_znx_{copy,negate,add_assign,sub_assign} on the normalized digits); 0: no such destination.
     int mode;
     int col2[2], mode2[2];
@@ -410,9 +410,15 @@ __global__ void __launch_bounds__(256) k_normalize_inter(NzArgs g) {
         const long long off_ = (long long)(J_) * rls;                                              \
         const long long v_ = (V_);                                                                 \
         if constexpr (COMBINE) {                                                                   \
-            nz_put(r + off_, g.mode, v_);                                                          \
-            if (r2a) nz_put(r2a + off_, g.mode2[0], v_);                                           \
-            if (r2b) nz_put(r2b + off_, g.mode2[1], v_);                                           \
+            if (g.mode2[0] == 5) {   /* the further columns' digits are subtracted on the way to the main column */ \
+                long long w_ = (long long)((unsigned long long)v_ - (unsigned long long)r2a[off_]); \
+                if (r2b) w_ = (long long)((unsigned long long)w_ - (unsigned long long)r2b[off_]);  \
+                nz_put(r + off_, g.mode, w_);                                                      \
+            } else {                                                                               \
+                nz_put(r + off_, g.mode, v_);                                                      \
+                if (r2a) nz_put(r2a + off_, g.mode2[0], v_);                                       \
+                if (r2b) nz_put(r2b + off_, g.mode2[1], v_);                                       \
+            }                                                                                      \
         } else r[off_] = v_;                                                                       \
     }
     const long long als = (long long)g.a_cols * g.n;
