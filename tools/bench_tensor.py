@@ -124,6 +124,7 @@ def main():
         "config": {"workload": f"glwe_tensor_{args.mode}" + (" + glwe_tensor_relinearize (tensor key 1 -> 1, dnum = limbs)" if args.relin else "") + f" (rank 1: 2-column GLWE x GLWE -> 3-column GLWETensor), N={n}, {size} limbs, base2k={k}, cnv_offset={cnv_offset}",
                    "batch_per_gpu": args.batch},
         "kernel_classes_launches_ms": stats,
+        "knobs": {k_: v_ for k_, v_ in os.environ.items() if k_.startswith("POULPY_DBG_")},
         "roofline": {"bound": "hbm", "achieved": rate * nb / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": rate * nb / 1e9 / 8000.0,
                      "algorithmic_bytes_per_unit": nb, "fp64_tflops": rate * flops / 1e12, "fp64_frac": rate * flops / 1e12 / 68.0},
         "dtype": "f64", "data": "synthetic"}))
