@@ -61,8 +61,8 @@ int launch_mid_cnv(pz_module* M, int batch, const cplx* a_main, const cplx* a_la
     g.a_size = a_size; g.b_size = b_size; g.a_i = a_i; g.a_j = a_j; g.b_i = b_i; g.b_j = b_j; g.min_size = min_size; g.offset = offset;
     g.m1 = M->plan.m1; g.batch = batch; g.wL2 = M->wL2; g.tw12t = M->tw12t;
     const size_t lds = ((size_t)std::max(a_size + b_size, min_size) * kMidCnvRS + 256) * sizeof(cplx);
-    PZ_TRY(set_lds(k_mid_cnv, lds));
     KTimer kt(M, PZ_K_FUSED_MID);
+    PZ_TRY(set_lds(k_mid_cnv, lds));
     hipLaunchKernelGGL(k_mid_cnv, dim3((unsigned)((long long)batch * g.m1)), dim3(256), lds, M->stream, g);
     dispatch_note(M, "k_mid_cnv (a %d + b %d limbs -> %d, lds=%zu)", a_size, b_size, min_size, lds);
     PZ_HIP(hipGetLastError());
