@@ -241,7 +241,10 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
             }                                                                                                    \
         }                                                                                                        \
     }
-                        if (row_max == MAXR) { PZ_BR_FMAS(false) } else { PZ_BR_FMAS(true) }
+                        // (both forms only where the tile re-reads its operands from LDS - two ciphertexts, more than 4 rows: there the test-free form
+                        //  is worth +15 %; in the register-resident variants the second copy of the block spilled 164 bytes for no gain)
+                        if constexpr (ALDS) { if (row_max == MAXR) { PZ_BR_FMAS(false) } else { PZ_BR_FMAS(true) } }
+                        else { PZ_BR_FMAS(true) }
 #undef PZ_BR_FMAS
                     }
                 }
