@@ -922,6 +922,48 @@ def test_seeded_shape_sweep(mods):
                                                dnum=dnum, a_b=a_b, key_b=key_b, res_b=res_b, batch=batch, kind=kind, chunk=chunk, fuse=fuse)
 
 
+def test_seeded_shape_sweep_wide_limbs(mods):
+    """The same sweep with 9 - 16 limbs on at least one of input / key / output, N <= 2^14 (the sweep above caps limbs at
+    8): 17 - 32 polynomials per ciphertext run the 32-slot tile of the middle kernel (k_mid128 / k_mid128r<2,32,..>, one register slot or a
+    ring of three for the key rows), more than 32 (rank 2 with > 10 limbs) the five-kernel path; N < 2^12 the small-ring and per-op paths."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("POULPY_SWEEP_SEED", "20260404")))
+    for case in range(int(os.environ.get("POULPY_SWEEP_CASES", "24"))):
+        n = int(2 ** rng.integers(9, 15))
+        rank = int(rng.integers(1, 3))
+        sizes = [int(x) for x in rng.integers(1, 17, 3)]
+        sizes[int(rng.integers(0, 3))] = int(rng.integers(9, 17))     # at least one container beyond 8 limbs
+        a_size, key_size, res_size = sizes
+        dsize = int(rng.integers(1, 3))
+        dnum = int(rng.integers(1, max(2, (a_size + dsize - 1) // dsize + 1)))
+        same = bool(rng.integers(0, 3))
+        key_b = int(rng.integers(10, 14))
+        a_b, res_b = (key_b, key_b) if same else (int(rng.integers(9, 16)), int(rng.integers(9, 16)))
+        batch = int(rng.integers(1, 10)) if n >= 8192 else int(rng.integers(1, 24))
+        kind = int(rng.integers(0, 4))
+        chunk = int(rng.integers(0, batch + 1)) if rng.integers(0, 2) else 0
+        fuse = (True, True) if rng.integers(0, 4) else (False, False)
+        ref, hip = mods(n)
+        seed = 7500 + case
+        desc = dict(case=case, n=n, rank=rank, a_size=a_size, key_size=key_size, res_size=res_size, dsize=dsize, dnum=dnum, a_b=a_b, key_b=key_b,
+                    res_b=res_b, batch=batch, kind=kind, chunk=chunk, fuse=fuse)
+        if os.environ.get("POULPY_SWEEP_VERBOSE"):
+            print(desc, flush=True)
+        if kind == 0:
+            got, want = _run_glwe_op(hip, ref, False, n, rank, rank, a_size, a_b, key_size, key_b, dnum, dsize, res_size, res_b, batch, seed,
+                                     chunk=chunk, fuse=fuse, pin=bool(rng.integers(0, 2)))
+        elif kind == 1:
+            rank_out = int(rng.integers(1, 3))
+            got, want = _run_glwe_op(hip, ref, True, n, rank, rank_out, a_size, a_b, key_size, key_b, dnum, dsize, res_size, res_b, batch, seed,
+                                     chunk=chunk, fuse=fuse)
+        else:
+            mode = ["automorphism", "add", "sub", "sub_negate"][int(rng.integers(0, 4))]
+            gal = int(rng.choice([-5, 5, 25, 2 * n - 1, 3]))
+            got, want = _run_glwe_op(hip, ref, True, n, rank, rank, a_size, a_b, key_size, key_b, dnum, dsize, res_size, res_b, batch, seed,
+                                     chunk=chunk, fuse=fuse, auto=(gal, mode))
+        assert np.array_equal(got, want), desc
+
+
 def test_seeded_blind_rotation_sweep(mods):
     """25 random blind-rotation shapes (fixed seed): N 2^8..2^11, rank 1-3, block size 1-5, 1-3 limbs for key / accumulator / LUT,
     dnum 1-3, ragged batches: the one-kernel path where it applies (N <= 1024 and the shape fits LDS), the composed path elsewhere."""

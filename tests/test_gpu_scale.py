@@ -119,6 +119,189 @@ def test_config5_shape_keyswitch_16_limbs_at_batch_256(mods):
     assert _pool_parity(hip, ref, True, n, 1, 16, 12, 16, batch=259, pool=7, seed=259, pin=True) == 0
 
 
+def _auto_pool_parity(hip, ref, n, rank, size, base2k, dnum, gal, mode, batch, pool, seed, pin=True, in_place=False, in_chunks=32):
+    """the glwe_automorphism family (key switch + X -> X^gal, poulpy-core automorphism/glwe_ct.rs:51-275) on `batch` device-resident
+    ciphertexts drawn from a pool of `pool` distinct ones; every output compared with its pool entry's oracle result on the device.
+    Returns the number of mismatching ciphertexts."""
+    import torch
+    from poulpy_amd.hal import GlweOpParams
+    rng = seeded(seed)
+    cols = rank + 1
+    mat = MatZnx(n, dnum, rank, cols, size).fill_uniform(base2k, rng)
+    pr, ph = ref.vmp_pmat_alloc(dnum, rank, cols, size), hip.vmp_pmat_alloc(dnum, rank, cols, size)
+    ref.vmp_prepare(pr, mat)
+    hip.vmp_prepare(ph, mat)
+    a_pool = np.empty((pool, size, cols, n), dtype=np.int64)
+    want_pool = np.empty((pool, size, cols, n), dtype=np.int64)
+    for i in range(pool):
+        a = VecZnx(n, cols, size).fill_uniform(base2k, rng)
+        a_pool[i] = a.data
+        r = VecZnx(n, cols, size)
+        ref.glwe_automorphism(r, base2k, a, base2k, pr, 1, base2k, gal, mode)
+        want_pool[i] = r.data
+    dev = torch.device("cuda", 0)
+    d_pool = torch.from_numpy(a_pool).to(dev)
+    d_want = torch.from_numpy(want_pool).to(dev)
+    idx = torch.arange(batch, device=dev) % pool
+    a_all = d_pool[idx].contiguous()
+    res = a_all if in_place else torch.full((batch, size, cols, n), 0x5A5A5A5A, dtype=torch.int64, device=dev)
+    key = torch.from_numpy(ph.data).to(dev)
+    torch.cuda.synchronize()
+    p = GlweOpParams(rank=rank, dnum=dnum, dsize=1, key_size=size, key_base2k=base2k, a_size=size, a_base2k=base2k,
+                     res_size=size, res_base2k=base2k, rank_out=rank)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    if pin:
+        hip.pin_key(ptr(key), dnum, rank, cols, size)
+    try:
+        hip.glwe_automorphism_batched(ptr(res), ptr(a_all), ptr(key), p, gal, mode, batch)
+        hip.sync()
+    finally:
+        if pin:
+            hip.unpin_key(ptr(key))
+    bad = 0
+    for b0 in range(0, batch, in_chunks):
+        b1 = min(batch, b0 + in_chunks)
+        eq = (res[b0:b1] == d_want[idx[b0:b1]]).reshape(b1 - b0, -1).all(dim=1)
+        bad += int((~eq).sum().item())
+    del a_all, res, d_pool, d_want, key
+    torch.cuda.empty_cache()
+    return bad
+
+
+@pytest.mark.parametrize("gal,mode", [(5, "automorphism"), (-1, "automorphism"), (5, "add"), (-1, "add")])
+def test_config5_rotate_16_limbs_pool_parity_at_bench_batch(mods, gal, mode):
+    """BASELINE configs[4], rotate half (CKKS rotate = glwe_automorphism, poulpy-ckks leveled/default/rotate.rs:47-50) at its own limb
+    count: N = 2^16, 16 limbs, rank 1, 259 ciphertexts per call, pinned key - the 32-slot tile k_mid128r<2,32,PERM=1,..> with the
+    permuted spectrum position and the permuting / sign-restoring tail (only 8 limbs were covered).  Galois
+    elements 5 (= 1 mod 4) and -1 (= 3 mod 4: conjugated spectrum); the plain form and `_add` (the trace's step), every output checked."""
+    n = 65536
+    ref, hip = mods(n)
+    assert _auto_pool_parity(hip, ref, n, 1, 16, 12, 16, gal, mode, batch=259, pool=5, seed=5000 + gal + len(mode)) == 0
+
+
+def test_config5_rotate_16_limbs_in_place(mods):
+    """glwe_automorphism_assign / _add_assign (res == a, glwe_ct.rs:74-94, :142-183) at the same geometry."""
+    n = 65536
+    ref, hip = mods(n)
+    assert _auto_pool_parity(hip, ref, n, 1, 16, 12, 16, 5, "add", batch=131, pool=5, seed=5131, in_place=True) == 0
+
+
+def _tensor_pool_parity(hip, ref, n, rank, size, base2k, cnv_offset, mode, batch, pool, seed, in_chunks=16):
+    """glwe_tensor_apply / _add_assign / _square (poulpy-core operations/glwe.rs:609-913) on `batch` pairs drawn from a pool; every
+    tensor compared with its pool entry's oracle result on the device.  Returns the number of mismatching tensors."""
+    import torch
+    from poulpy_amd.hal import GlweTensorParams
+    rng = seeded(seed)
+    cols = rank + 1
+    tcols = cols * (cols + 1) // 2
+    square = mode == "square"
+    k = base2k * size
+    a_pool = np.empty((pool, size, cols, n), dtype=np.int64)
+    b_pool = np.empty((pool, size, cols, n), dtype=np.int64)
+    prev_pool = rng.integers(-(1 << (base2k - 1)), 1 << (base2k - 1), (pool, size, tcols, n), dtype=np.int64)
+    want_pool = np.empty_like(prev_pool)
+    for i in range(pool):
+        a = VecZnx(n, cols, size).fill_uniform(base2k, rng)
+        b = a if square else VecZnx(n, cols, size).fill_uniform(base2k, rng)
+        a_pool[i], b_pool[i] = a.data, b.data
+        r = VecZnx(n, tcols, size, prev_pool[i].copy())
+        if square:
+            ref.glwe_tensor_square_apply(cnv_offset, r, base2k, a, k, base2k)
+        else:
+            ref.glwe_tensor_apply(cnv_offset, r, base2k, a, k, b, k, base2k, add_assign=(mode == "add_assign"))
+        want_pool[i] = r.data
+    dev = torch.device("cuda", 0)
+    idx = torch.arange(batch, device=dev) % pool
+    d_a = torch.from_numpy(a_pool).to(dev)[idx].contiguous()
+    d_b = None if square else torch.from_numpy(b_pool).to(dev)[idx].contiguous()
+    d_r = torch.from_numpy(prev_pool).to(dev)[idx].contiguous()
+    d_want = torch.from_numpy(want_pool).to(dev)
+    torch.cuda.synchronize()
+    p = GlweTensorParams(rank=rank, a_size=size, b_size=size, ab_base2k=base2k, a_effective_k=k, b_effective_k=k, res_size=size,
+                         res_base2k=base2k, cnv_offset=cnv_offset)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    hip.dispatch_notes(reset=True)
+    hip.glwe_tensor_apply_batched(ptr(d_r), ptr(d_a), None if square else ptr(d_b), p, mode, batch)
+    hip.sync()
+    notes = hip.dispatch_notes()
+    bad = 0
+    for b0 in range(0, batch, in_chunks):
+        b1 = min(batch, b0 + in_chunks)
+        eq = (d_r[b0:b1] == d_want[idx[b0:b1]]).reshape(b1 - b0, -1).all(dim=1)
+        bad += int((~eq).sum().item())
+    del d_a, d_b, d_r, d_want
+    torch.cuda.empty_cache()
+    return bad, notes
+
+
+@pytest.mark.parametrize("mode", ["apply", "add_assign", "square"])
+def test_config5_tensoring_16_limbs_pool_parity_at_bench_batch(mods, mode):
+    """BASELINE configs[4], multiply half at the bench geometry of tools/bench_tensor.py: N = 2^16, 16 limbs, rank 1, 259 pairs per call -
+    every k_mid_cnv tile of both workgroups per CU over many tiles per workgroup, every NzCombine mode of the normalizing inverse column
+    pass (plain / negated / read-modify-write stores, mode 5 for apply and square) - every tensor checked (batch 2-3
+    only)."""
+    n = 65536
+    ref, hip = mods(n)
+    bad, notes = _tensor_pool_parity(hip, ref, n, 1, 16, 12, 16 * 12 - 20, mode, batch=259, pool=3, seed=6000 + len(mode))
+    assert bad == 0, (mode, bad)
+    if os.environ.get("POULPY_DBG_TENSOR_FUSED") != "0" and os.environ.get("POULPY_DBG_TENSOR_COMBINE") != "0":
+        assert "k_mid_cnv" in notes, notes
+
+
+def test_config5_tensoring_rank2_pool_parity(mods):
+    """rank 2 (6 tensor columns, 3 pairwise terms) on the fused tensoring at a batch with many tiles per workgroup: N = 2^13, 8 limbs, 515
+    pairs."""
+    n = 8192
+    ref, hip = mods(n)
+    for mode in ("apply", "add_assign", "square"):
+        bad, notes = _tensor_pool_parity(hip, ref, n, 2, 8, 12, 8 * 12 - 9, mode, batch=515, pool=3, seed=6100 + len(mode))
+        assert bad == 0, (mode, bad)
+
+
+def test_config5_relinearize_16_limbs_pool_parity_at_bench_batch(mods):
+    """BASELINE configs[4]: tensor + relinearization at the bench geometry - the GLWETensors the tensoring produced at 16 limbs
+    (3 columns) through the tensor key (1 -> 1, dnum 16, 16 limbs), 259 per call, pinned key: k_mid128r<2,32,..> with one input column and the
+    tail that adds an operand to every column (`small_all`).  Every output checked."""
+    import torch
+    from poulpy_amd.hal import GlweOpParams
+    n, rank, size, base2k, dnum, batch, pool = 65536, 1, 16, 12, 16, 259, 5
+    ref, hip = mods(n)
+    rng = seeded(6200)
+    cols, pairs = rank + 1, rank * (rank + 1) // 2
+    mat = MatZnx(n, dnum, pairs, cols, size).fill_uniform(base2k, rng)
+    pr, ph = ref.vmp_pmat_alloc(dnum, pairs, cols, size), hip.vmp_pmat_alloc(dnum, pairs, cols, size)
+    ref.vmp_prepare(pr, mat)
+    hip.vmp_prepare(ph, mat)
+    a_pool = np.empty((pool, size, cols + pairs, n), dtype=np.int64)
+    want_pool = np.empty((pool, size, cols, n), dtype=np.int64)
+    for i in range(pool):
+        a = VecZnx(n, cols + pairs, size).fill_uniform(base2k, rng)
+        a_pool[i] = a.data
+        r = VecZnx(n, cols, size)
+        ref.glwe_tensor_relinearize(r, base2k, a, base2k, pr, 1, base2k)
+        want_pool[i] = r.data
+    dev = torch.device("cuda", 0)
+    idx = torch.arange(batch, device=dev) % pool
+    d_a = torch.from_numpy(a_pool).to(dev)[idx].contiguous()
+    d_want = torch.from_numpy(want_pool).to(dev)
+    d_r = torch.full((batch, size, cols, n), 0x5A5A5A5A, dtype=torch.int64, device=dev)
+    key = torch.from_numpy(ph.data).to(dev)
+    torch.cuda.synchronize()
+    p = GlweOpParams(rank=rank, dnum=dnum, dsize=1, key_size=size, key_base2k=base2k, a_size=size, a_base2k=base2k,
+                     res_size=size, res_base2k=base2k, rank_out=rank)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    hip.pin_key(ptr(key), dnum, pairs, cols, size)
+    try:
+        hip.glwe_tensor_relinearize_batched(ptr(d_r), ptr(d_a), ptr(key), p, batch)
+        hip.sync()
+    finally:
+        hip.unpin_key(ptr(key))
+    bad = int((d_r != d_want[idx]).flatten(1).any(dim=1).sum().item())
+    del d_a, d_r, d_want, key
+    torch.cuda.empty_cache()
+    assert bad == 0
+
+
 def test_config4_blind_rotation_n16384(mods):
     """BASELINE configs[3], N = 2^14 leg: CGGI block-binary blind rotation at N = 16384 (accumulators do not fit LDS: the composed
     path with the LDS-staged block step) on a short LWE so that the CPU oracle finishes in about a minute; batch 9 (ragged
