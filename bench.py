@@ -259,8 +259,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the separate per-kernel-class timing pass (no roofline object)")
     ap.add_argument("--timing-steps", type=int, default=10, help="steps of the separate HIP-event pass that feeds the roofline object")
-    ap.add_argument("--setup-calls", type=int, default=9,
-                    help="untimed calls before the W warm-up steps: the library's placement measurement runs over the first nine calls")
+    ap.add_argument("--setup-calls", type=int, default=0, help="extra untimed calls before the W warm-up steps (reported in the line)")
+    ap.add_argument("--ref-value", type=float, default=0.0,
+                    help="the 1-GPU value this run is compared with: the line then carries scaling_efficiency = value / (N x ref)")
     ap.add_argument("--parity-samples", type=int, default=8, help="timed-output ciphertexts checked against the CPU oracle (0 = none)")
     args = ap.parse_args()
     global SIZE, DNUM, N, BASE2K
@@ -292,6 +293,13 @@ def main():
     distributed = world > 1 or os.environ.get("POULPY_BENCH_FORCE_DIST") == "1"   # (the knob runs the RCCL path with one rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    # checked here, in the rank process (the launching parent never touches torch or HIP): fewer visible devices than ranks is a clean,
+    # one-line refusal - no line is printed, the exit code is non-zero on every rank
+    ndev = torch.cuda.device_count()
+    if ndev < world or local_rank >= ndev:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} needs {world} HIP devices on this node but only {ndev} are visible: no line reported", file=sys.stderr, flush=True)
+        raise SystemExit(4)
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -394,9 +402,8 @@ def main():
         else:
             mod.glwe_external_product_batched(res_ptr, a_ptr, key_ptr, params, nct)
 
-    # Library set-up, outside the W warm-up steps the contract prescribes: the fused pipeline measures the placement of its intermediate
-    # buffer over its first nine calls with a given argument set and uses the best one afterwards — a one-time cost of a
-    # long-lived caller, like preparing the key; reported below as `setup_calls`.
+    # (rounds 2-3 ran nine untimed set-up calls here while the library measured the placement of its intermediate buffer; the tuner is
+    #  gone - ABI version 4 - and the default is 0; the flag stays for A/B runs)
     setup_calls = 0 if (trace or expand) else args.setup_calls
     for _ in range(setup_calls):
         step()
@@ -444,23 +451,6 @@ def main():
         parity = {"n": len(picks), "ok": not bad, "indices": [int(lo + i) for i in picks], "mismatched": bad,
                   "against": "oracle/fft64_ref.c, bit-exact i64 limbs; one extra untimed call from the original input (the timed calls run in place)"}
 
-    # the library measures the placement of its second intermediate over the calls 1..8 of a call shape (include/poulpy_hip.h,
-    # pz_module_set_phase_tuning): say whether the timed loop ran with a settled placement, and time the same loop with the FIXED one
-    placement = None
-    if N >= 32768 and not (trace or expand):
-        tuned, measuring = mod.phase_tuning_state()
-        mod.set_phase_tuning(False)
-        k_un = max(1, min(args.steps, 20))
-        step(); mod.sync()
-        t1 = time.perf_counter()
-        for _ in range(k_un):
-            step()
-        mod.sync()
-        dt_un = time.perf_counter() - t1
-        mod.set_phase_tuning(True)
-        placement = {"phase_tuned": bool(tuned >= 1 and measuring == 0), "shapes_tuned": tuned, "shapes_measuring": measuring,
-                     "untuned_value_this_rank": nct * k_un / dt_un / (DNUM if expand else 1), "untuned_steps": k_un}
-
     # roofline leg: the same steps again with one HIP-event pair per launch on the module stream
     stats = {}
     timing = (not args.no_kernel_timing)
@@ -475,7 +465,20 @@ def main():
         stats = mod.kernel_stats()
         mod.set_kernel_timing(False)
 
+    # this rank's own figures (its shard / its own clock around the same barrier-bracketed region; the headline uses the MAX over ranks)
+    def dominant(st):
+        return max(st.items(), key=lambda kv: kv[1][1]) if st else (None, (0, 0.0))
+    dom_name, (dom_cnt, dom_ms) = dominant(stats)
+    units_div = DNUM if expand else 1
+    b_unit_rank = algorithmic_bytes_per_unit(args.batch) if not ks else ((a_cols + cols) * SIZE * N * 8 + DNUM * cols_in * cols * SIZE * N * 8 / args.batch)
+    mine = {"value": nct * args.steps / dt / units_div, "ms_per_step": dt / args.steps * 1e3, "units_per_step": nct // units_div,
+            "dominant_kernel": dom_name, "dominant_kernel_ms": (dom_ms / dom_cnt) if dom_cnt else None,
+            "mid_ms": (stats["fused_mid"][1] / stats["fused_mid"][0]) if stats.get("fused_mid", (0, 0))[0] else None,
+            "pipeline_gbs": nct * args.steps / dt * b_unit_rank / 1e9,
+            "parity_ok": None if parity is None else parity.get("ok"), "device": local_rank}
+    per_rank = [dict(mine, rank=rank)]
     if distributed:
+        per_rank = pdist.gather_per_rank(mine)
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -545,7 +548,8 @@ def main():
                        "output_digits_balanced": ok, "setup_calls": setup_calls},
             "roofline": roof,
             "ceilings": ceilings,
-            "placement": placement,
+            "per_rank": per_rank,
+            "scaling_efficiency": pdist.scaling_efficiency(value, world, args.ref_value),
             "parity_sample": parity,
         }
         if world == 1 and not args.no_cpu_baseline and not ks:

@@ -56,7 +56,7 @@ extern "C" {
 typedef struct pz_module pz_module;
 
 /* the ABI revision this header describes (pz_abi_version() of a matching library returns it) */
-#define PZ_ABI_VERSION 3u
+#define PZ_ABI_VERSION 4u
 
 typedef enum {
     PZ_OK = 0,
@@ -648,14 +648,6 @@ const char* pz_kernel_class_name(int kclass);
 /* largest |x - round(x)| seen by the last inverse-FFT epilogue when enabled (exactness margin) */
 int pz_module_set_margin_probe(pz_module* m, int enable);
 int pz_module_get_margin(pz_module* m, double* max_frac);
-
-/* Placement of the fused pipeline's second intermediate relative to the result buffer (N >= 2^15): by default the library measures
- * eight candidate phases over the calls 1..8 of a given call SHAPE (batch, chunk, polynomial counts, parameters; not the pointers) —
- * one candidate per call, timed with its own event pair, never waited for — and uses the fastest afterwards.  Results never depend
- * on it.  enable = 0 pins the fixed placement (768 KiB out of phase).  pz_module_phase_tuning_state reports how many call shapes
- * have settled / are still measuring. */
-int pz_module_set_phase_tuning(pz_module* m, int enable);
-int pz_module_phase_tuning_state(pz_module* m, int* shapes_tuned, int* shapes_measuring);
 
 /* Which kernel instantiations the hot dispatch sites (middle kernel, blind-rotation kernels) have chosen since the last reset, as one
  * "; "-separated string: measurement tools print it next to their numbers. */

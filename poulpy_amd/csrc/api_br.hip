@@ -6,6 +6,16 @@
 
 using namespace pz;
 
+// the tail of a rotation step: acc = normalize(idft(acc_add) + acc), in place on the accumulator (algorithm.rs:342-346) - every column
+// of `acc` is both the operand and the destination
+static TailCall acc_tail(int batch, const cplx* T, bool rowmajor, int nlimbs, int cols, int64_t* acc, long long acc_bs, int acc_size, int base2k) {
+    TailCall c;
+    c.batch = batch; c.T = T; c.rowmajor = rowmajor; c.nlimbs = nlimbs; c.ncols = cols;
+    c.res = (long long*)acc; c.res_bs = acc_bs; c.res_cols = cols; c.res_size = acc_size; c.base2k = base2k;
+    c.small = (const long long*)acc; c.small_bs = acc_bs; c.small_cols = cols; c.small_size = acc_size; c.small_all = true;
+    return c;
+}
+
 extern "C" {
 
 // ------------------------------------------------------------------------------
@@ -88,8 +98,7 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
                     PZ_TRY(launch_fwd_pass1(M, B * npi, (const long long*)res, sm, T, true));
                     MidBr mb{(const long long*)lwe_2n, lwe_bs, b0, blk};
                     PZ_TRY(launch_mid(M, B, T, T2, Pp, npi, npo, nrows_key, ncols_key, mid_dummy, 0, 0, nullptr, &mb));
-                    PZ_TRY(launch_inv_tail(M, B, T2, bsz, cols, (long long*)res, res_ct, cols, rsz, (const long long*)res, res_ct, cols, rsz, k,
-                                           true, true));
+                    PZ_TRY(launch_inv_tail(M, acc_tail(B, T2, true, bsz, cols, res, res_ct, rsz, k)));
                 }
                 return PZ_OK;
             }
@@ -155,8 +164,7 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
             if (tail) {
                 PolyMap sm{bsz, cols, aa.bs, (long long)cols * n, n, 0};
                 PZ_TRY(launch_inv_pass2(M, B * bsz * cols, acc_add, sm, T));
-                PZ_TRY(launch_inv_tail(M, B, T, bsz, cols, (long long*)res, res_ct, cols, rsz, (const long long*)res, res_ct, cols, rsz, k,
-                                       false, true));
+                PZ_TRY(launch_inv_tail(M, acc_tail(B, T, false, bsz, cols, res, res_ct, rsz, k)));
             } else {
                 PZ_TRY(dev_idft(M, B, aa, 0, aa, 0, cols, bsz, T));
                 for (int c = 0; c < cols; ++c) {
@@ -254,7 +262,7 @@ static int blind_rotation_extended(pz_module* M, int64_t* res, const int64_t* lw
         } else if (tail) {                                                                             // :260-266
             PolyMap sm{bsz, cols, aa.bs, (long long)cols * n, n, 0};
             PZ_TRY(launch_inv_pass2(M, BE * bsz * cols, acc_add, sm, T));
-            PZ_TRY(launch_inv_tail(M, BE, T, bsz, cols, (long long*)acc, res_ct, cols, rsz, (const long long*)acc, res_ct, cols, rsz, k, false, true));
+            PZ_TRY(launch_inv_tail(M, acc_tail(BE, T, false, bsz, cols, acc, res_ct, rsz, k)));
         } else {
             PZ_TRY(dev_idft(M, BE, aa, 0, aa, 0, cols, bsz, T));
             for (int c = 0; c < cols; ++c) {

@@ -126,12 +126,16 @@ struct CanaryScope {
     CanaryScope(pz_module* M_, const char* fn_) : M(M_), fn(fn_) { if (canary_mode()) M->guards.clear(); }
     ~CanaryScope() { if (canary_mode()) canary_verify(M, fn); }
 };
+// api.hip: drops this module's device mirrors of host keys whose range was published (re-prepared, zeroed, forgotten, freed) since its
+// last sweep - one atomic load when nothing was
+void mirror_sweep_on_enter(pz_module* M);
 #define PZ_ENTER(M)                                              \
     if (!(M)) return fail(PZ_ERR_INVALID, "null module");        \
     std::lock_guard<std::mutex> lock_((M)->mu);                  \
     PZ_HIP(hipSetDevice((M)->device));                           \
     CanaryScope canary_((M), __func__);                          \
-    arena_reset(M);
+    arena_reset(M);                                              \
+    mirror_sweep_on_enter(M);
 
 static inline size_t vbytes(const pz_module* M, size_t cols, size_t size) { return (size_t)M->n * cols * size * 8; }
 

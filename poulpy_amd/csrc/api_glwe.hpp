@@ -93,6 +93,8 @@ struct OpLayout {
 // api.hip: drops the device mirror of a host-resident prepared key (a rewritten buffer's mirror would be stale)
 int forget_host_key(pz_module* M, const void* host);
 void host_key_invalidate(const void* p, size_t bytes);   // api.hip: process-wide (every module's mirrors of that host range)
+// api.hip: device pointer of a prepared key - itself when it is one, else its validated (possibly refreshed) device mirror
+int resolve_key(pz_module* M, const double* pmat, size_t bytes, const double** out);
 
 // Defined inside api.hip's extern "C" block (C linkage, internal use; the caller holds the module lock):
 extern "C" {

@@ -431,7 +431,11 @@ int pz_vmp_prepare(pz_module* M, double* pmat, const int64_t* mat, size_t rows, 
     const bool host = sp.owned || sm.owned;
     PZ_TRY(sp.finish());
     PZ_TRY(sm.finish());
-    return finish_call(M, host);
+    const int rc = finish_call(M, host);
+    // published once more now that the host bytes HAVE changed: a sibling that looked the key up between the first
+    // publication and the D2H copy above re-mirrored the old bytes with an epoch >= that publication
+    host_key_invalidate(pmat, npolys * (size_t)M->n * 8);
+    return rc;
 }
 
 int pz_vmp_zero(pz_module* M, double* pmat, size_t rows, size_t cols_in, size_t cols_out, size_t size) {
@@ -440,7 +444,7 @@ int pz_vmp_zero(pz_module* M, double* pmat, size_t rows, size_t cols_in, size_t 
     const size_t bytes = rows * cols_in * cols_out * size * M->n * 8;
     host_key_invalidate(pmat, bytes);
     if (is_device_ptr(pmat)) PZ_HIP(hipMemsetAsync(pmat, 0, bytes, M->stream));
-    else memset(pmat, 0, bytes);
+    else { memset(pmat, 0, bytes); host_key_invalidate(pmat, bytes); }   // (again, after the write: see pz_vmp_prepare)
     return PZ_OK;
 }
 

@@ -49,12 +49,40 @@ int launch_inv_pass1(pz_module* M, int npolys, const cplx* T, long long* dst, Po
 
 // ---- launch_tail.hip ----------------------------------------------------------------------------------------------
 bool tail_supported(const pz_module* M);
-int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
-                    int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
-                    int base2k, bool rowmajor = false, bool small_all = false, unsigned auto_mul = 0, bool auto_neg = false,
-                    unsigned gather_mul = 0, bool gather_neg = false, int body_col = 0, const long long* body_src = nullptr,
-                    long long body_bs = 0, long long body_ls = 0, bool small_neg = false, bool post_rsh = false, bool post_neg = false,
-                    bool body_only = false);
+// One launch of the fused tail (k_inv_tail, device_fft.hpp): the big value held in T - nlimbs x ncols polynomials per ciphertext, still
+// one inverse column pass away from coefficients - leaves as normalized base2k digits in `res`.  Every field has a name at the call
+// site (round 3 passed these as 28 positional arguments, 8 of them bool); the defaults are the plain external-product tail.
+struct TailCall {
+    // ---- the value and where its digits go ----
+    int batch = 0;
+    const cplx* T = nullptr;          // T[j2][q1] (output of inverse pass 2) or, rowmajor, T2'[q1][j2] (output of the middle kernel)
+    bool rowmajor = false;
+    int nlimbs = 0, ncols = 0;        // limbs / columns of the VecZnxBig being consumed
+    long long* res = nullptr;
+    long long res_bs = 0;             // i64 elements between consecutive ciphertexts of res
+    int res_cols = 0, res_size = 0;
+    int base2k = 0;
+    // ---- operand added in front of the carry chain (vec_znx_big_add_small_assign, keyswitching/glwe.rs:237) ----
+    const long long* small = nullptr; // null: none (external product)
+    long long small_bs = 0;
+    int small_cols = 1, small_size = 0;
+    bool small_all = false;           // false: column 0 of `small` lands on body_col only; true: column c of `small` on column c
+    bool small_neg = false;           // the operand is subtracted (sub forms of the automorphism family)
+    int body_col = 0;                 // 0 for a key switch, `col` for ggsw_expand_row
+    // ---- body-column operand prepared elsewhere (spectral automorphism forms: phi(body) +- a0 in the workspace) ----
+    const long long* body_src = nullptr;
+    long long body_bs = 0, body_ls = 0;   // batch / limb strides of body_src
+    bool body_only = false;               // only the body column has an operand (plain glwe_automorphism)
+    // ---- signs of X -> X^p (automorphism/glwe_ct.rs:96-275; TailArgs in device_fft.hpp) ----
+    unsigned auto_mul = 0;            // != 0: the value enters the chain as s(n) (big + small), s(n) = -1 iff (n auto_mul) mod 2N >= N
+    bool auto_neg = false;            // flips every s(n)
+    bool post_neg = false;            // put s(n) back on the digits (plain form: phi acts on the normalized value)
+    unsigned gather_mul = 0;          // != 0: the operand is -+phi^-1(small), gathered inside the tail (older, non-spectral scheme)
+    bool gather_neg = false;
+    // ---- glwe_trace: the digits leave through a one-bit vec_znx_rsh_assign ----
+    bool post_rsh = false;
+};
+int launch_inv_tail(pz_module* M, const TailCall& c);
 bool tail_rsh_supported(const pz_module* M);
 bool mid_cnv_supported(const pz_module* M, int a_size, int b_size, int min_size);
 int launch_mid_cnv(pz_module* M, int batch, const cplx* a_main, const cplx* a_last, const cplx* b_main, const cplx* b_last, cplx* T2, int cols,

@@ -8,9 +8,9 @@
 
 namespace pz {
 
-#define PZ_P1_CASES(X) X(4, 1, 4) X(8, 1, 4) X(8, 1, 16) X(16, 1, 16) X(8, 4, 16) X(8, 8, 16) X(16, 8, 16) X(16, 16, 16)
-#define PZ_P1F_CASES(X) X(4, 1, 4) X(8, 1, 4) X(8, 1, 16) X(16, 1, 16) X(4, 4, 16) X(4, 8, 16) X(8, 8, 16) X(8, 16, 16) X(16, 16, 16) X(8, 16, 8)
-#define PZ_P2_CASES(X) X(4, 1, 4) X(8, 1, 4) X(16, 1, 4) X(16, 1, 16) X(8, 4, 16) X(8, 8, 16) X(16, 8, 16) X(16, 16, 16)
+#define PZ_P1_CASES(X) X(2, 1, 2) X(2, 1, 4) X(4, 1, 4) X(8, 1, 4) X(8, 1, 16) X(16, 1, 16) X(8, 4, 16) X(8, 8, 16) X(16, 8, 16) X(16, 16, 16)
+#define PZ_P1F_CASES(X) X(2, 1, 2) X(2, 1, 4) X(4, 1, 4) X(8, 1, 4) X(8, 1, 16) X(16, 1, 16) X(4, 4, 16) X(4, 8, 16) X(8, 8, 16) X(8, 16, 16) X(16, 16, 16) X(8, 16, 8)
+#define PZ_P2_CASES(X) X(2, 1, 2) X(4, 1, 2) X(4, 1, 4) X(8, 1, 4) X(16, 1, 4) X(16, 1, 16) X(8, 4, 16) X(8, 8, 16) X(16, 8, 16) X(16, 16, 16)
 
 
 int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* T, bool rowmajor, long long mask) {

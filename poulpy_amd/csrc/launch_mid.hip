@@ -61,7 +61,8 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
     g.T = T; g.T2 = T2; g.P = Pp; g.npi = npi; g.npo = npo; g.nrows = nrows; g.ncols = ncols;
     g.row_max = br ? nrows : std::min(nrows, npi);
     g.ncomp = std::min(npo, ncols);
-    if ((ds ? g.ds_n : g.row_max) < 1) return PZ_ERR_INVALID;   // k_mid128 assumes at least one product term
+    if ((ds ? g.ds_n : g.row_max) < 1)   // k_mid128 assumes at least one product term
+        return fail(PZ_ERR_INVALID, "launch_mid: no product term (rows %d, npi %d, ds_n %d)", nrows, npi, g.ds_n);
     g.batch = batch; g.m1 = M->plan.m1; g.n_ct = 0;
     g.wL2 = M->wL2; g.tw12t = M->tw12t; g.dummy = dummy;
     static const int groups = getenv("POULPY_DBG_MID_GROUPS") ? atoi(getenv("POULPY_DBG_MID_GROUPS")) : 1;

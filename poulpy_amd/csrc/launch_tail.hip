@@ -24,26 +24,23 @@ bool tail_rsh_supported(const pz_module* M) {
 }
 
 struct TailNz { int lsh, res_end, res_start, a_end, a_start, zero_from, col, mode, col2[2], mode2[2]; };
-static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
-                                int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
-                                int base2k, bool rowmajor, bool small_all, unsigned auto_mul, bool auto_neg, int col_base, int col_count,
-                                unsigned gather_mul = 0, bool gather_neg = false, int body_col = 0, const long long* body_src = nullptr,
-                                long long body_bs = 0, long long body_ls = 0, bool small_neg = false, bool post_rsh = false, bool post_neg = false,
-                                bool body_only = false, bool raw = false, const TailNz* nz = nullptr) {
+// columns [col_base, col_base + col_count) of the big value in one launch; raw / nz: the tensoring forms (launch_inv_tail_raw / _nz)
+static int launch_inv_tail_cols(pz_module* M, const TailCall& c, int col_base, int col_count, bool raw = false, const TailNz* nz = nullptr) {
     const FftPlan& pl = M->plan;
-    int blocks = batch * col_count * (pl.m2 / pl.cb);
+    int blocks = c.batch * col_count * (pl.m2 / pl.cb);
     if (blocks == 0) return PZ_OK;
     KTimer kt(M, PZ_K_FUSED_TAIL);
     TailArgs g;
-    g.T = T; g.res = res; g.small = small; g.res_bs = res_bs; g.small_bs = small_bs;
-    g.nlimbs = nlimbs; g.ncols = ncols; g.res_cols = res_cols; g.res_size = res_size;
-    g.small_cols = small_cols; g.small_size = small_size; g.base2k = base2k; g.m2 = pl.m2;
+    g.T = c.T; g.res = c.res; g.small = c.small; g.res_bs = c.res_bs; g.small_bs = c.small_bs;
+    g.nlimbs = c.nlimbs; g.ncols = c.ncols; g.res_cols = c.res_cols; g.res_size = c.res_size;
+    g.small_cols = c.small_cols; g.small_size = c.small_size; g.base2k = c.base2k; g.m2 = pl.m2;
     g.tw1inv = M->tw1inv; g.wL1 = M->wL1; g.margin = M->margin;
-    g.small_all = small_all ? 1 : 0; g.auto_mul = auto_mul; g.auto_neg = auto_neg ? 1 : 0;
-    g.col_base = col_base; g.col_count = col_count; g.body_col = body_col;
-    g.gather_mul = gather_mul; g.gather_neg = gather_neg ? 1 : 0;
-    g.pre_body = body_src != nullptr ? 1 : 0; g.small_neg = small_neg ? 1 : 0; g.body_src = body_src; g.body_bs = body_bs; g.body_ls = body_ls;
-    g.post_neg = post_neg ? 1 : 0; g.body_only = body_only ? 1 : 0; g.raw = raw ? 1 : 0;
+    g.small_all = c.small_all ? 1 : 0; g.auto_mul = c.auto_mul; g.auto_neg = c.auto_neg ? 1 : 0;
+    g.col_base = col_base; g.col_count = col_count; g.body_col = c.body_col;
+    g.gather_mul = c.gather_mul; g.gather_neg = c.gather_neg ? 1 : 0;
+    g.pre_body = c.body_src != nullptr ? 1 : 0; g.small_neg = c.small_neg ? 1 : 0;
+    g.body_src = c.body_src; g.body_bs = c.body_bs; g.body_ls = c.body_ls;
+    g.post_neg = c.post_neg ? 1 : 0; g.body_only = c.body_only ? 1 : 0; g.raw = raw ? 1 : 0;
     g.nz = nz ? 1 : 0;
     g.nz_lsh = nz ? nz->lsh : 0; g.nz_res_end = nz ? nz->res_end : 0; g.nz_res_start = nz ? nz->res_start : 0; g.nz_a_end = nz ? nz->a_end : 0;
     g.nz_a_start = nz ? nz->a_start : 0; g.nz_zero_from = nz ? nz->zero_from : 0; g.nz_col = nz ? nz->col : 0; g.nz_mode = nz ? nz->mode : 0;
@@ -53,13 +50,13 @@ static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlim
     // groups of 8 (ciphertext, column) pairs
     static const int xcd_order = getenv("POULPY_DBG_XCD_ORDER") ? atoi(getenv("POULPY_DBG_XCD_ORDER")) : 1;
     g.xcd_map = 0;
-    if (gather_mul != 0 || (rowmajor && xcd_order)) {
-        const int nbc = batch * col_count, ncb = pl.m2 / pl.cb;
+    if (c.gather_mul != 0 || (c.rowmajor && xcd_order)) {
+        const int nbc = c.batch * col_count, ncb = pl.m2 / pl.cb;
         g.xcd_map = nbc;
         blocks = ((nbc + 7) / 8) * 8 * ncb;
     }
-    const bool has_small = small != nullptr;
-    if (post_rsh) {
+    const bool rowmajor = c.rowmajor, has_small = c.small != nullptr;
+    if (c.post_rsh) {
         if (!(tail_rsh_supported(M) && rowmajor && has_small)) return fail(PZ_ERR_UNSUPPORTED, "fused tail: no shifted-store variant for this plan");
 #define X(A, B, C)                                                                                              \
     if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
@@ -111,24 +108,19 @@ static int launch_inv_tail_cols(pz_module* M, int batch, const cplx* T, int nlim
 }
 // The body operand of a key switch only exists for one column (0; `body_col` for ggsw_expand_row): that column runs the
 // variant that prefetches it (more registers, one workgroup less per CU), the other columns the plain one.
-int launch_inv_tail(pz_module* M, int batch, const cplx* T, int nlimbs, int ncols, long long* res, long long res_bs,
-                    int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size,
-                    int base2k, bool rowmajor, bool small_all, unsigned auto_mul, bool auto_neg,
-                    unsigned gather_mul, bool gather_neg, int body_col, const long long* body_src,
-                    long long body_bs, long long body_ls, bool small_neg, bool post_rsh, bool post_neg, bool body_only) {
-    if (post_rsh && !(small != nullptr && small_all)) return fail(PZ_ERR_UNSUPPORTED, "fused tail: shifted store needs an operand per column");
-    if (small != nullptr && !small_all && ncols > 1) {
-        PZ_TRY(launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, small, small_bs, small_cols, small_size,
-                                    base2k, rowmajor, false, auto_mul, auto_neg, body_col, 1, 0, false, body_col));
-        if (body_col > 0)
-            PZ_TRY(launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, nullptr, 0, small_cols, small_size,
-                                        base2k, rowmajor, false, 0, false, 0, body_col));
-        return launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, nullptr, 0, small_cols, small_size,
-                                    base2k, rowmajor, false, 0, false, body_col + 1, ncols - 1 - body_col);
+int launch_inv_tail(pz_module* M, const TailCall& c) {
+    if (c.post_rsh && !(c.small != nullptr && c.small_all)) return fail(PZ_ERR_UNSUPPORTED, "fused tail: shifted store needs an operand per column");
+    if (c.small != nullptr && !c.small_all && c.ncols > 1) {
+        TailCall body = c;       // the body column: operand, and the signs that go with it
+        body.gather_mul = 0; body.gather_neg = false; body.body_src = nullptr; body.body_bs = body.body_ls = 0;
+        body.small_neg = body.post_rsh = body.post_neg = body.body_only = false;
+        PZ_TRY(launch_inv_tail_cols(M, body, c.body_col, 1));
+        TailCall plain = body;   // every other column: no operand, no signs
+        plain.small = nullptr; plain.small_bs = 0; plain.auto_mul = 0; plain.auto_neg = false; plain.body_col = 0;
+        if (c.body_col > 0) PZ_TRY(launch_inv_tail_cols(M, plain, 0, c.body_col));
+        return launch_inv_tail_cols(M, plain, c.body_col + 1, c.ncols - 1 - c.body_col);
     }
-    return launch_inv_tail_cols(M, batch, T, nlimbs, ncols, res, res_bs, res_cols, res_size, small, small_bs, small_cols, small_size, base2k,
-                                rowmajor, small_all, auto_mul, auto_neg, 0, ncols, gather_mul, gather_neg, body_col, body_src, body_bs, body_ls,
-                                small_neg, post_rsh, post_neg, body_only);
+    return launch_inv_tail_cols(M, c, 0, c.ncols);
 }
 
 // the inverse column pass on the row-major T2' with vec_znx_normalize's same-base steps (bit offset res_offset, a.size = a_size limbs of which
@@ -150,15 +142,19 @@ int launch_inv_tail_nz(pz_module* M, int batch, const cplx* T, int nlimbs, long 
     nz.col = res_col;
     nz.mode = cb ? cb->mode : 1;
     for (int u = 0; u < 2; ++u) { nz.col2[u] = cb ? cb->col2[u] : 0; nz.mode2[u] = cb ? cb->mode2[u] : 0; }
-    return launch_inv_tail_cols(M, batch, T, nlimbs, 1, res, res_bs, res_cols, res_size, nullptr, 0, 1, 0, base2k, true, false, 0, false, 0, 1, 0, false, 0,
-                                nullptr, 0, 0, false, false, false, false, false, &nz);
+    TailCall c;
+    c.batch = batch; c.T = T; c.rowmajor = true; c.nlimbs = nlimbs; c.ncols = 1;
+    c.res = res; c.res_bs = res_bs; c.res_cols = res_cols; c.res_size = res_size; c.base2k = base2k;
+    return launch_inv_tail_cols(M, c, 0, 1, false, &nz);
 }
 
 // the inverse column pass alone on the row-major T2': rounded i64 values (VecZnxBig), no carry chain (GLWE tensoring: its normalization
 // carries a bit offset and a column combination the tail does not know, api_cnv.hip)
 int launch_inv_tail_raw(pz_module* M, int batch, const cplx* T, int nlimbs, long long* res, long long res_bs, int res_size) {
-    return launch_inv_tail_cols(M, batch, T, nlimbs, 1, res, res_bs, 1, res_size, nullptr, 0, 1, 0, 12, true, false, 0, false, 0, 1, 0, false, 0,
-                                nullptr, 0, 0, false, false, false, false, true);
+    TailCall c;
+    c.batch = batch; c.T = T; c.rowmajor = true; c.nlimbs = nlimbs; c.ncols = 1;
+    c.res = res; c.res_bs = res_bs; c.res_cols = 1; c.res_size = res_size; c.base2k = 12;
+    return launch_inv_tail_cols(M, c, 0, 1, true);
 }
 
 

@@ -62,6 +62,7 @@ struct FftPlan {
 
 inline bool radices_for(int L, int& ra, int& rb) {
     switch (L) {
+        case 2: ra = 2; rb = 1; return true;   // N = 8, 16 (m = 2 x 2, 2 x 4)
         case 4: ra = 4; rb = 1; return true;
         case 8: ra = 8; rb = 1; return true;
         case 16: ra = 16; rb = 1; return true;
@@ -73,8 +74,12 @@ inline bool radices_for(int L, int& ra, int& rb) {
     }
 }
 
+// n >= 8: the reference's smallest ring (poulpy-cpu-ref/src/reference/fft64/vmp.rs:67 asserts n >= 8; its backend tests run the
+// convolution suite at Module::new(8), poulpy-cpu-ref/src/tests.rs:11-23; reim/fft_ref.rs:29-37 special-cases m <= 16).  N = 8 / 16 are
+// m = 2 x 2 / 2 x 4 on the same four passes (radix-2 butterflies, 2- and 4-wide blocks): a handful of threads per polynomial - these
+// rings exist for the reference's tests, not for throughput.
 inline bool make_plan(uint64_t n, FftPlan& pl) {
-    if (n < 32 || (n & (n - 1))) return false;
+    if (n < 8 || (n & (n - 1))) return false;
     uint64_t m = n >> 1;
     int k = 0;
     while ((1ull << k) < m) ++k;
@@ -100,8 +105,8 @@ inline bool make_plan(uint64_t n, FftPlan& pl) {
     if (pl.m1 == 16) { pl.f1a = 4; pl.f1b = 4; }
     if (pl.m1 == 32) { pl.f1a = 4; pl.f1b = 8; }
     if (pl.m1 == 128) { pl.f1a = 8; pl.f1b = 16; }
-    pl.cb = pl.m2 >= 16 ? 16 : 4;
-    pl.qb = pl.m1 >= 16 ? 16 : 4;
+    pl.cb = pl.m2 >= 16 ? 16 : std::min(4, pl.m2);
+    pl.qb = pl.m1 >= 16 ? 16 : std::min(4, pl.m1);
     if (const char* e = getenv("POULPY_DBG_CB")) pl.cb = atoi(e);  // diagnostic: column-block width of pass 1 / tail
     return true;
 }
@@ -152,6 +157,7 @@ struct pz_module {
     struct KeyMirror { const void* host; size_t bytes; void* dev; uint64_t fp; uint64_t stamp; uint64_t epoch; };
     std::vector<KeyMirror> mirrors;
     uint64_t mirror_clock = 0;
+    uint64_t mirror_seen_epoch = 0;   // process-wide invalidation epoch at this module's last sweep of its mirrors (api.hip)
     // RCCL communicator for pz_bcast_key (api_dist.hip); owned by the module
     void* comm = nullptr;
     int comm_world = 0, comm_rank = 0;
@@ -171,15 +177,6 @@ struct pz_module {
     uint64_t graph_clock = 0, graph_epoch = 0;  // epoch: bumped by anything that changes what a captured call would launch
     bool graphs_on = true;
     unsigned long long graph_launches = 0;
-    // Placement of T2' relative to the result buffer (api.hip, fused pipeline): after a warm-up call, kPhaseCount calls with a given argument
-    // set each try one phase and time the middle kernel + tail with events; later calls use the best one.
-    // (round 3: keyed on the SHAPE of the call only - the placement is relative to the result buffer, so a caller that rotates its
-    //  buffers keeps its tuning - and never waits: call 0 warms up, calls 1..8 each run one candidate between their own event pair,
-    //  later calls read whichever pairs have completed (hipEventQuery) and use the best measured so far)
-    struct PhaseTune { uint64_t key; int calls; int best; float best_ms; unsigned pending; hipEvent_t e0[8], e1[8]; uint64_t stamp; };
-    std::vector<PhaseTune> phase_tune;
-    uint64_t phase_clock = 0;
-    bool phase_tuning = true;
     // POULPY_DBG_CANARY=1 (debug; tests/conftest.py runs the GPU suite with it once): a 256-byte guard behind every segment carved out
     // of the workspaces and behind the end of every reservation, armed on the module stream when it is carved and verified when the
     // API call returns (canary_verify, from PZ_ENTER's scope object).  An overrun into the slack between segments stays bit-exact
@@ -273,6 +270,10 @@ inline void canary_verify(pz_module* M, const char* where, const void* lo = null
     }
 }
 
+// hipMalloc that first gives back the device mirrors of dead host keys - this module's and every idle module's - when memory runs
+// out (api.hip; the caller holds M->mu)
+int device_malloc_retry(pz_module* M, void** out, size_t bytes);
+
 inline int ws_reserve(pz_module* M, size_t bytes) {
     // a new carve: the guards of the previous one (a composite call carves the workspace several times, with different layouts) are
     // verified now, before their bytes become someone else's segment
@@ -284,7 +285,7 @@ inline int ws_reserve(pz_module* M, size_t bytes) {
         M->ws = nullptr;
         M->ws_bytes = 0;
         size_t want = need + (need >> 3);
-        PZ_HIP(hipMalloc(&M->ws, want));
+        PZ_TRY(device_malloc_retry(M, &M->ws, want));
         M->ws_bytes = want;
     }
     // the end of what this call asked for (+ the room of its inner guards): nothing may be written from here on
@@ -299,7 +300,7 @@ inline int ws2_reserve(pz_module* M, size_t bytes) {
         if (M->ws2) PZ_HIP(hipFree(M->ws2));
         M->ws2 = nullptr;
         M->ws2_bytes = 0;
-        PZ_HIP(hipMalloc(&M->ws2, need));
+        PZ_TRY(device_malloc_retry(M, &M->ws2, need));
         M->ws2_bytes = need;
     }
     return guard_arm(M, (char*)M->ws2 + need - kGuardBytes);
@@ -325,7 +326,7 @@ inline int arena_alloc(pz_module* M, size_t bytes, void** out) {
     size_t want = std::max<size_t>(bytes, (size_t)8 << 20);
     if (!M->arena.empty()) want = std::max(want, 2 * M->arena.back().bytes);
     void* p = nullptr;
-    PZ_HIP(hipMalloc(&p, want));
+    PZ_TRY(device_malloc_retry(M, &p, want));
     M->arena.push_back({p, want});
     M->arena_chunk = M->arena.size() - 1;
     M->arena_off = bytes;

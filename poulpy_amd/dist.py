@@ -49,3 +49,21 @@ def broadcast_key_cabi(mod, pmat, src: int = 0):
     mod.bcast_key(C.c_void_p(flat.data_ptr()), flat.numel() * flat.element_size(), src)
     mod.sync()
     return pmat
+
+
+def gather_per_rank(entry: dict) -> list:
+    """Every rank contributes one small dict (its own rate, step time, dominant-kernel time, achieved GB/s); every rank gets the list
+    ordered by rank.  One all_gather_object, outside the timed region - the N > 1 bench line reports per-GPU figures beside the
+    max-over-ranks headline (north_star: "achieved HBM GB/s at 1, 2, 4 and 8 GPUs")."""
+    import torch.distributed as dist
+
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, dict(entry, rank=dist.get_rank()))
+    return sorted(out, key=lambda e: e["rank"])
+
+
+def scaling_efficiency(value: float, world: int, ref_value: float):
+    """Weak scaling: whole-job value / (world x the 1-GPU value).  None without a reference."""
+    if not ref_value or ref_value <= 0 or world < 1:
+        return None
+    return value / (world * ref_value)

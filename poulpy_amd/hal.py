@@ -52,7 +52,7 @@ class GlweTensorParams(C.Structure):
 
 
 _lib = None
-PZ_ABI_VERSION = 3   # pz_abi_version() of include/poulpy_hip.h this mirror was written against
+PZ_ABI_VERSION = 4   # pz_abi_version() of include/poulpy_hip.h this mirror was written against
 
 
 def load_library(path: str | None = None) -> C.CDLL:
@@ -209,16 +209,6 @@ class Module:
 
     KERNEL_CLASSES = ("fwd_pass1", "fwd_pass2", "vmp", "inv_pass2", "inv_pass1", "normalize", "elementwise", "fused_mid",
                       "fused_tail")
-
-    def set_phase_tuning(self, enable: bool):
-        """Measured (default) or fixed placement of the fused pipeline's second intermediate (include/poulpy_hip.h)."""
-        self._ck(self.lib.pz_module_set_phase_tuning(self.handle, c_int(1 if enable else 0)))
-
-    def phase_tuning_state(self) -> tuple:
-        """(call shapes whose placement has settled, call shapes still measuring)."""
-        t, u = c_int(0), c_int(0)
-        self._ck(self.lib.pz_module_phase_tuning_state(self.handle, C.byref(t), C.byref(u)))
-        return int(t.value), int(u.value)
 
     def dispatch_notes(self, reset: bool = False) -> str:
         """Kernel instantiations chosen by the hot dispatch sites since the last reset (include/poulpy_hip.h)."""

@@ -32,9 +32,19 @@ pub use ffi::{pz_blind_rotation_params, pz_circuit_bootstrapping_params, pz_glwe
 #[derive(Debug, Clone, Copy)]
 pub struct FFT64Hip;
 
-/// ABI generation of include/poulpy_hip.h this crate was generated against (`pz_abi_version()`); checked when a handle is created:
-/// a stale or variant libpoulpy_hip.so would otherwise be handed structs of another layout.
-pub const PZ_ABI_VERSION: u32 = 3;
+/// ABI generation of include/poulpy_hip.h this crate was generated against (`pz_abi_version()`); checked BEFORE the first call into the
+/// library (`check_abi`, from `Module::new`): a stale or variant libpoulpy_hip.so would otherwise be handed structs of another layout.
+pub const PZ_ABI_VERSION: u32 = 4;
+
+/// Panics unless the loaded libpoulpy_hip.so is the generation this crate was generated for.  `pz_abi_version` takes no argument and
+/// allocates nothing, so a mismatch leaves nothing behind (the check used to run after `pz_module_new`, leaking the module).
+pub(crate) fn check_abi() {
+    static ONCE: std::sync::Once = std::sync::Once::new();
+    ONCE.call_once(|| {
+        let v = unsafe { ffi::pz_abi_version() };
+        assert_eq!(v, PZ_ABI_VERSION, "libpoulpy_hip.so has ABI version {v}, this crate was generated for {PZ_ABI_VERSION}");
+    });
+}
 
 /// The sibling modules (`pz_module_clone`: own stream, workspaces and lock; shared immutable tables) that threads other than the
 /// creating one run on.  A thread LEASES one on its first call and returns it when it exits (thread-local destructor), so the pool
@@ -81,8 +91,7 @@ unsafe impl Sync for FFT64HipHandle {}
 
 impl FFT64HipHandle {
     pub(crate) fn new(raw: *mut ffi::pz_module) -> Self {
-        let v = unsafe { ffi::pz_abi_version() };
-        assert_eq!(v, PZ_ABI_VERSION, "libpoulpy_hip.so has ABI version {v}, this crate was generated for {PZ_ABI_VERSION}");
+        check_abi();   // (already done by `Module::new` before `pz_module_new`; kept for other constructors of a handle)
         Self {
             raw,
             owner: std::thread::current().id(),

@@ -38,7 +38,7 @@ def _finish(mod, d, base2k, res_size):
     return out.data
 
 
-@pytest.mark.parametrize("n,base2k", [(256, 12), (64, 17), (4096, 12)])
+@pytest.mark.parametrize("n,base2k", [(8, 12), (16, 17), (256, 12), (64, 17), (4096, 12)])
 def test_convolution_and_pairwise(mods, n, base2k):
     """test_suite/convolution.rs:91-252 shapes: 2 columns, a_size = b_size = 15, res_size = 30, every offset / column pair."""
     ref, hip = mods(n)
@@ -67,10 +67,10 @@ def test_convolution_and_pairwise(mods, n, base2k):
                 assert np.array_equal(_finish(hip, dh, base2k, res_size), _finish(ref, dr, base2k, res_size)), ("pairwise", i, j, off)
 
 
-def test_convolution_shapes_masks_and_columns(mods):
+@pytest.mark.parametrize("n", [8, 512])
+def test_convolution_shapes_masks_and_columns(mods, n):
     """res shorter / longer than the product, prepared operands longer than the input (zero limbs) or shorter (the mask moves to
     the last ACTIVE limb), masks, prepare_self, a res with two columns (only res_col written), offsets beyond the product."""
-    n = 512
     ref, hip = mods(n)
     rng = seeded(99)
     base2k = 13
@@ -105,7 +105,7 @@ def test_convolution_shapes_masks_and_columns(mods):
     assert hip.cnv_prepare_left_tmp_bytes(5, 9) == ref.cnv_prepare_left_tmp_bytes(5, 9)
 
 
-@pytest.mark.parametrize("n", [64, 2048])
+@pytest.mark.parametrize("n", [8, 16, 64, 2048])
 def test_convolution_by_const(mods, n):
     """test_suite/convolution.rs:22-89 (i64 domain, wrapping)."""
     ref, hip = mods(n)
@@ -161,12 +161,12 @@ def _run_tensor(hip, ref, n, rank, a_size, b_size, res_size, ab_base2k, res_base
     return got, want
 
 
+@pytest.mark.parametrize("n", [8, 256])
 @pytest.mark.parametrize("mode", ["apply", "add_assign", "square"])
 @pytest.mark.parametrize("rank", [1, 2])
-def test_glwe_tensor_apply_batched(mods, rank, mode):
+def test_glwe_tensor_apply_batched(mods, rank, mode, n):
     """poulpy-core operations/glwe.rs:609-913 on a batch: offsets below / at / above base2k (negative and positive cnv_offset_lo),
     masked bottom limb, different output base, chunked."""
-    n = 256
     ref, hip = mods(n)
     for (a_size, b_size, res_size, ab, rb, off, abo) in ((4, 3, 5, 12, 12, 5, 3), (3, 3, 4, 14, 14, 14, 0), (4, 4, 6, 12, 15, 30, 7),
                                                          (2, 5, 3, 13, 11, 20, 0)):

@@ -28,7 +28,7 @@ def mods():
     return get
 
 
-@pytest.mark.parametrize("n", [32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072])
+@pytest.mark.parametrize("n", [8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072])
 def test_dft_idft_roundtrip_and_oracle(mods, n):
     """vec_znx_dft_apply -> vec_znx_idft_apply returns the input exactly, for every plan size."""
     ref, hip = mods(n)
@@ -59,10 +59,13 @@ def test_dft_idft_roundtrip_and_oracle(mods, n):
     assert np.abs(hh[rev] - spec_ref).max() <= 1e-10 * scale
 
 
+# n = 8, 16 (round 4): the reference's smallest rings (vmp.rs:67 asserts n >= 8; poulpy-cpu-ref/src/tests.rs:11-23 runs its convolution
+# suite at Module::new(8)) - m = 2 x 2 / 2 x 4 on the radix-2 instantiations of the four passes
+@pytest.mark.parametrize("n", [8, 16, 256])
 @pytest.mark.parametrize("step,offset", [(1, 0), (1, 1), (1, 2), (2, 2), (2, 1), (3, 0)])
-def test_vec_znx_dft_apply_step_offset(mods, step, offset):
+def test_vec_znx_dft_apply_step_offset(mods, step, offset, n):
     """poulpy-hal/src/test_suite/vec_znx_dft.rs:360-456: (step, offset) limb selection, untouched limbs."""
-    n, base2k = 256, 12
+    base2k = 12
     ref, hip = mods(n)
     rng = seeded(1000 + step * 10 + offset)
     for a_size in range(1, 6):
@@ -85,9 +88,10 @@ def test_vec_znx_dft_apply_step_offset(mods, step, offset):
             assert np.array_equal(br.data, bh.data)
 
 
-def test_svp(mods):
+@pytest.mark.parametrize("n", [8, 16, 256])
+def test_svp(mods, n):
     """poulpy-hal/src/test_suite/svp.rs: prepare + apply_dft / dft_to_dft / assign."""
-    n, base2k = 256, 12
+    base2k = 12
     ref, hip = mods(n)
     rng = seeded(7)
     for cols in (1, 2):
@@ -119,7 +123,7 @@ def test_svp(mods):
                     assert np.array_equal(nr.data, nh.data)
 
 
-@pytest.mark.parametrize("n", [64, 256])
+@pytest.mark.parametrize("n", [8, 16, 64, 256])
 def test_vmp_apply_dft_to_dft(mods, n):
     """poulpy-hal/src/test_suite/vmp.rs:150-310 incl. limb_offset 1..size_out."""
     base2k = 12
@@ -164,10 +168,10 @@ def test_vmp_apply_dft_to_dft(mods, n):
                     assert np.array_equal(nr.data, nh.data)
 
 
-def test_vec_znx_big_normalize_offsets(mods):
+@pytest.mark.parametrize("n", [8, 64])
+def test_vec_znx_big_normalize_offsets(mods, n):
     """poulpy-hal/src/test_suite/vec_znx_big.rs:785-872: 63-bit inputs, res_offset in [-base2k, base2k],
     same base and cross base."""
-    n = 64
     ref, hip = mods(n)
     rng = seeded(11)
     for a_base2k, res_base2k in ((12, 12), (17, 17), (12, 17), (19, 12), (50, 13), (7, 31)):
@@ -184,9 +188,10 @@ def test_vec_znx_big_normalize_offsets(mods):
                     assert np.array_equal(rr.data, rh.data), (a_base2k, res_base2k, a_size, res_size, off)
 
 
-def test_dft_elementwise_ops(mods):
+@pytest.mark.parametrize("n", [8, 16, 128])
+def test_dft_elementwise_ops(mods, n):
     """poulpy-hal/src/test_suite/vec_znx_dft.rs add/sub/copy/zero family, compared after idft+normalize."""
-    n, base2k = 128, 12
+    base2k = 12
     ref, hip = mods(n)
     rng = seeded(5)
     for a_size in (1, 2, 4):
@@ -225,8 +230,8 @@ def test_dft_elementwise_ops(mods):
                     assert np.array_equal(outs[0], outs[1]), (k, a_size, b_size, res_size)
 
 
-def test_big_add_small_assign(mods):
-    n = 64
+@pytest.mark.parametrize("n", [8, 16, 64])
+def test_big_add_small_assign(mods, n):
     ref, hip = mods(n)
     rng = seeded(9)
     for a_size in (1, 3):
@@ -324,6 +329,29 @@ def test_glwe_keyswitch_batched(mods, dsize, fuse):
             got, want = _run_glwe_op(hip, ref, True, n, rank_in, rank_out, 4, a_b, 5, k_b, 3 if dsize == 1 else 2, dsize, 4, r_b,
                                      batch=5, seed=7 + rank_in * 10 + rank_out + dsize, chunk=2, fuse=fuse)
             assert np.array_equal(got, want), (rank_in, rank_out, dsize, a_b, k_b, r_b)
+
+
+@pytest.mark.parametrize("n", [8, 16])
+def test_tiny_rings_batched_glwe_ops(mods, n):
+    """N = 8 and 16 (VERDICT r03 missing 3) through the batched entry points: external product (dsize 1-2, mixed bases), key switch
+    (rank 1 -> 2), the four automorphism forms, the trace and the tensor relinearization - the five-kernel path on the radix-2 plans
+    (no fused / small-ring pipeline at these sizes), against the oracle, bit-exact."""
+    from tests.test_gpu_cnv import _run_relinearize
+    ref, hip = mods(n)
+    for (a_b, k_b, r_b, dsize) in ((12, 12, 12, 1), (16, 13, 15, 1), (13, 13, 13, 2)):
+        got, want = _run_glwe_op(hip, ref, False, n, 1, 1, 4, a_b, 5, k_b, 3 if dsize == 1 else 2, dsize, 4, r_b, batch=7, seed=n + a_b + dsize, chunk=3)
+        assert np.array_equal(got, want), ("external product", a_b, k_b, r_b, dsize)
+        got, want = _run_glwe_op(hip, ref, True, n, 1, 2, 4, a_b, 5, k_b, 3 if dsize == 1 else 2, dsize, 4, r_b, batch=7, seed=n + a_b + dsize + 1)
+        assert np.array_equal(got, want), ("key switch", a_b, k_b, r_b, dsize)
+    for mode in ("automorphism", "add", "sub", "sub_negate"):
+        for gal in (-1, 5, 2 * n - 3, 3):
+            got, want = _run_glwe_op(hip, ref, True, n, 1, 1, 3, 12, 4, 12, 3, 1, 3, 12, batch=5, seed=n + gal % 97, auto=(gal, mode),
+                                     in_place=(mode == "add"))
+            assert np.array_equal(got, want), (mode, gal)
+    got, want = _run_relinearize(hip, ref, n, 1, 4, 12, 5, 12, 4, 1, 4, 12, batch=5, seed=n + 77)
+    assert np.array_equal(got, want)
+    got, want = _run_relinearize(hip, ref, n, 2, 4, 13, 5, 13, 2, 2, 4, 13, batch=3, seed=n + 78)
+    assert np.array_equal(got, want)
 
 
 def test_config2_external_product_n4096(mods):
@@ -989,9 +1017,21 @@ def test_seeded_per_op_sweep(mods):
     vmp_apply_dft_to_dft with more / fewer rows than input limbs and any limb_offset incl. >= size, idft into smaller / larger
     outputs, cross-base normalize with offsets; N 2^5..2^13 (every plan family)."""
     import os
-    rng = np.random.default_rng(int(os.environ.get("POULPY_SWEEP_SEED", "4242")))
-    for case in range(int(os.environ.get("POULPY_SWEEP_CASES", "60"))):
-        n = int(2 ** rng.integers(5, int(os.environ.get("POULPY_SWEEP_MAXLOGN", "13")) + 1))
+    _per_op_sweep(mods, int(os.environ.get("POULPY_SWEEP_SEED", "4242")), int(os.environ.get("POULPY_SWEEP_CASES", "60")), 5,
+                  int(os.environ.get("POULPY_SWEEP_MAXLOGN", "13")))
+
+
+def test_seeded_per_op_sweep_tiny_rings(mods):
+    """the same chains at N = 8 and 16 (24 shapes, fixed seed)."""
+    import os
+    _per_op_sweep(mods, int(os.environ.get("POULPY_SWEEP_SEED", "816")), int(os.environ.get("POULPY_SWEEP_CASES", "24")), 3, 4)
+
+
+def _per_op_sweep(mods, seed, cases, min_logn, max_logn):
+    import os
+    rng = np.random.default_rng(seed)
+    for case in range(cases):
+        n = int(2 ** rng.integers(min_logn, max_logn + 1))
         ref, hip = mods(n)
         cols_in, cols_out = (int(x) for x in rng.integers(1, 4, 2))
         a_size, rows, size, res_size = (int(x) for x in rng.integers(1, 7, 4))
@@ -1164,6 +1204,58 @@ def test_host_key_change_through_one_module_reaches_its_siblings(mods):
     got[...] = 0
     B.glwe_external_product_batched(hp(got), hp(a.data), hp(ph.data), p, 1)
     assert np.array_equal(got, wants[1]), "the sibling kept computing with the stale mirror"
+    B.close()
+    A.close()
+
+
+def test_freed_host_key_gives_its_device_mirrors_back_at_once(mods):
+    """pz_free_bytes used to only publish the freed range - the mirror and its row-sliced copy (2 x the key bytes)
+    stayed on the device until the owning module next looked a key up, which a parked sibling never does.  Now idle modules are swept when
+    the range is published: device memory comes back without another call on either module.  Then the module-local sweep on entry: a
+    re-prepared host key (published through module A) is dropped by B at B's next call of ANY kind."""
+    import ctypes as C
+    import torch
+    from poulpy_amd.hal import GlweOpParams, Module
+    n, cols, size, k = 16384, 2, 8, 12        # 32 MiB key: mirror + sliced copy = 64 MiB per module
+    ref, _ = mods(n)
+    A = Module(n)
+    B = A.clone()
+    lib = A.lib
+    rng = seeded(78)
+    mat = MatZnx(n, size, cols, cols, size).fill_uniform(k, rng)
+    key_bytes = n * size * cols * cols * size * 8
+    blk = lib.pz_alloc_bytes(key_bytes)
+    assert blk
+    host_key = np.ctypeslib.as_array((C.c_double * (key_bytes // 8)).from_address(blk))
+    ph = A.vmp_pmat_alloc(size, cols, cols, size)
+    A.vmp_prepare(ph, mat)
+    host_key[:] = ph.data.reshape(-1)
+    a = VecZnx(n, cols, size).fill_uniform(k, rng)
+    p = GlweOpParams(rank=1, dnum=size, dsize=1, key_size=size, key_base2k=k, a_size=size, a_base2k=k, res_size=size, res_base2k=k, rank_out=1)
+    hp = lambda arr: arr.ctypes.data_as(C.c_void_p)
+    got = np.zeros((size, cols, n), dtype=np.int64)
+    for M in (A, B):     # both modules mirror the key (and keep its row-sliced copy)
+        M.glwe_external_product_batched(hp(got), hp(a.data), C.c_void_p(blk), p, 1)
+    pr = ref.vmp_pmat_alloc(size, cols, cols, size)
+    ref.vmp_prepare(pr, mat)
+    want = VecZnx(n, cols, size)
+    ref.glwe_external_product(want, k, a, k, pr, 1, k)
+    assert np.array_equal(got, want.data)
+    A.sync(); B.sync()
+    free0, _ = torch.cuda.mem_get_info()
+    lib.pz_free_bytes(C.c_void_p(blk))            # no call on A or B follows
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 - free0 >= 3 * key_bytes, (free0, free1, key_bytes)    # 4 x key bytes expected; allocator granularity may hold some back
+    # entry sweep: B mirrors a key that is then zeroed through A; B's next call - one that never looks a key up - releases the mirror
+    ph2 = A.vmp_pmat_alloc(size, cols, cols, size)
+    A.vmp_prepare(ph2, mat)
+    B.glwe_external_product_batched(hp(got), hp(a.data), hp(ph2.data), p, 1)
+    B.sync()
+    free2, _ = torch.cuda.mem_get_info()
+    lib.pz_vmp_zero.argtypes = [C.c_void_p, C.c_void_p] + [C.c_size_t] * 4
+    assert lib.pz_vmp_zero(A.handle, hp(ph2.data), size, cols, cols, size) == 0     # publishes; B is idle: swept right here
+    free3, _ = torch.cuda.mem_get_info()
+    assert free3 - free2 >= key_bytes, (free2, free3)
     B.close()
     A.close()
 

@@ -92,7 +92,7 @@ def main(argv=None):
         units, unit = batch, "vector-matrix products"
         b_unit = (a_size * ci + size * co) * poly + rows * ci * co * size * poly / batch
         flops_unit = 8.0 * (a_size * ci) * (size * co) * (n // 2)
-        what = (f"vmp_apply_dft_to_dft (hal_impl.rs:665), batch {batch}: VecZnxDft(n={n}, cols={ci}, size={a_size}) x VmpPMat(rows={rows}, cols_in={ci}, "
+        what = (f"vmp_apply_dft_to_dft (hal_impl.rs:653), batch {batch}: VecZnxDft(n={n}, cols={ci}, size={a_size}) x VmpPMat(rows={rows}, cols_in={ci}, "
                 f"cols_out={co}, size={size})")
     elif args.op == "svp":
         S = batch * size
@@ -110,7 +110,7 @@ def main(argv=None):
                                                    C.c_size_t(1), C.c_size_t(0), P(a_dft.data_ptr()), C.c_size_t(1), C.c_size_t(S), C.c_size_t(0)))
         units, unit = S, "polynomials"
         b_unit = 2 * poly
-        what = f"svp_apply_dft_to_dft (hal_impl.rs:587), one VecZnxDft(n={n}, cols=1, size={S}) x SvpPPol"
+        what = f"svp_apply_dft_to_dft (hal_impl.rs:606), one VecZnxDft(n={n}, cols=1, size={S}) x SvpPPol"
     else:
         big = torch.randint(-(1 << 40), 1 << 40, (batch, size, cols, n), dtype=torch.int64, device=dev, generator=g)
         res = torch.empty((batch, size, cols, n), dtype=torch.int64, device=dev)
@@ -120,7 +120,7 @@ def main(argv=None):
                 mod.vec_znx_big_normalize_batched(batch, P(res.data_ptr()), cols, size, args.base2k, 0, c, P(big.data_ptr()), cols, size, args.base2k, c)
         units, unit = batch * size * cols, "polynomials"
         b_unit = 2 * poly
-        what = f"vec_znx_big_normalize (hal_impl.rs:653), batch {batch} x VecZnxBig(n={n}, cols={cols}, size={size}), base2k {args.base2k}, one call per column"
+        what = f"vec_znx_big_normalize (hal_impl.rs:431), batch {batch} x VecZnxBig(n={n}, cols={cols}, size={size}), base2k {args.base2k}, one call per column"
 
     for _ in range(args.warmup):
         step()

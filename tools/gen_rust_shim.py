@@ -28,7 +28,8 @@ NAMES = os.path.join(ROOT, "tests", "golden", "hal_impl_fns.txt")
 V = "{0}.cols(), {0}.size()"
 
 FORWARD = {
-    "new": """        let mut raw: *mut ffi::pz_module = std::ptr::null_mut();
+    "new": """        crate::check_abi();   // before the first call that allocates anything in the library
+        let mut raw: *mut ffi::pz_module = std::ptr::null_mut();
         check(unsafe { ffi::pz_module_new(n, &mut raw) }, "Module::new");
         let handle: Box<FFT64HipHandle> = Box::new(FFT64HipHandle::new(raw));
         unsafe { Module::from_nonnull(NonNull::from(Box::leak(handle)), n) }""",
