@@ -431,9 +431,6 @@ k_inv_pass1(const cplx* __restrict__ T, long long* __restrict__ dst, PolyMap dma
 //   small  : optional VecZnx added to column 0 before normalizing (key-switch body, glwe.rs:237)
 // grid.x = batch*col_count*(m2/CB)
 // =================================================================================
-#ifndef PZ_TW_TAIL_REGS
-#define PZ_TW_TAIL_REGS 0   // 1: k_inv_tail<ROWMAJOR> can apply the inverse inter-pass twiddle itself (PZ_TW_IN_TAIL builds)
-#endif
 struct TailArgs {
     const cplx* T;
     long long* res;
@@ -479,9 +476,6 @@ struct TailArgs {
     // 4 -= v; 5 on BOTH further columns: their digits are read and subtracted from the value before it reaches nz_col); res limbs >= nz_zero_from are zero.  The limb count of the transformed value may be smaller than the normalizer's a.size:
     // the missing top-index limbs are zeros and come first in the chain, where they change nothing.
     int nz, nz_lsh, nz_res_end, nz_res_start, nz_a_end, nz_a_start, nz_zero_from, nz_col, nz_mode, nz_col2[2], nz_mode2[2];
-    // (PZ_TW_IN_TAIL experiment) != null: T2' arrives WITHOUT the inverse inter-pass twiddle; every value is multiplied by conj(tw12t[q1][j2])
-    // as it is loaded (the table entry depends on the position only: read once per workgroup, reused for every limb)
-    const cplx* tw12t;
 };
 __device__ __forceinline__ long long tz_digit(int k, long long x) { return (long long)((unsigned long long)x << (64 - k)) >> (64 - k); }
 __device__ __forceinline__ long long tz_carry(int k, long long x, long long d) { return (long long)((unsigned long long)x - (unsigned long long)d) >> k; }
@@ -572,29 +566,10 @@ k_inv_tail(TailArgs g) {
 #pragma unroll
             for (int k2 = 0; k2 < R2; ++k2) u[k2] = ROWMAJOR ? ld_stream(Tb + (long long)(L - 1) * limb_stride + k2s * k2) : Tb[(long long)(L - 1) * limb_stride + k2s * k2];
         }
-        // (PZ_TW_IN_TAIL) the twiddles are fetched for every limb from the L2-resident table (same position for every limb): held in 64
-        // registers across the butterfly they spill at the 168-register cap of this workgroup (188 bytes of scratch)
-        const bool twt = ROWMAJOR && PZ_TW_TAIL_REGS && g.tw12t != nullptr;
-
         // iteration t produces limb L-1-t into buffer (L-1-t)&1; t = 0 is the prologue
         for (int t = 0; t <= L; ++t) {
             const int j = L - 1 - t;  // limb produced in this iteration (none when j < 0)
             if (j >= 0) {
-                // requested here, not with the values (64 more registers across the barrier: 296 bytes of scratch), and in two halves
-                // (all 16 beside u[]: still 48 bytes)
-                if (twt) {
-                    const cplx* twp = g.tw12t + ((long long)pz_opaque(k1) * g.m2 + c0 + c);   // (opaque: 16 hoisted addresses would live across the limb loop)
-#pragma unroll
-                    for (int hb = 0; hb < 2; ++hb) {
-                        cplx tw_[R2 / 2 > 0 ? R2 / 2 : 1];
-#pragma unroll
-                        for (int k2 = 0; k2 < R2 / 2; ++k2) tw_[k2] = twp[(long long)R1 * g.m2 * (k2 + hb * (R2 / 2))];
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int k2 = 0; k2 < R2 / 2; ++k2) u[k2 + hb * (R2 / 2)] = cmulc(u[k2 + hb * (R2 / 2)], tw_[k2]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
                 Bfly<R2, true>::run(u);
                 cplx* buf = xch + (j & 1) * XCH;
 #pragma unroll

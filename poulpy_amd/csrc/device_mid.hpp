@@ -29,9 +29,6 @@ constexpr int kMidRS = PZ_MID_RS;
 #ifndef PZ_MID_STAMP
 #define PZ_MID_STAMP 0   // diagnostic build: per-phase s_memtime totals of k_mid128, printed by a few waves (tools/dbg/mid_stamps.sh)
 #endif
-#ifndef PZ_TW_IN_TAIL
-#define PZ_TW_IN_TAIL 0  // 1: k_mid128r leaves the inverse inter-pass twiddle (x conj tw12) to the tail (launch_mid records it in the module; A/B)
-#endif
 #ifndef PZ_MIDR_KR
 #define PZ_MIDR_KR 6     // key-row slots of k_mid128r (rows requested KR - 1 ahead; build-time for A/B runs)
 #endif
@@ -913,7 +910,7 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
         PZ_MID_LANE
         const cplx* src_ = src_ptr(w, ctl, rr, o);
         PZ_XGROUP(src_, 0) PZ_XGROUP(src_, 1) PZ_XGROUP(src_, 2) PZ_XGROUP(src_, 3)
-        if (!PZ_TW_IN_TAIL) { if (tw_e >= 0) twrow2[tw_e] = g.tw12t[(long long)out_q1(tile_q1(w)) * M2 + tw_e]; }
+        if (tw_e >= 0) twrow2[tw_e] = g.tw12t[(long long)out_q1(tile_q1(w)) * M2 + tw_e];
     }
     int par = 0;
 #if PZ_MID_STAMP
@@ -1023,7 +1020,7 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
             const int b = (L % g.n_ct) * CT + ctl;
             const cplx* src_ = src_ptr(L + W, ctl, rr, o);
             const cplx* twr = twrow2 + par * M2;
-            if constexpr (IN && !PZ_TW_IN_TAIL) twn = g.tw12t[(long long)out_q1(tile_q1(min(L + W, ntiles - 1))) * M2 + max(tw_e, 0)];
+            if constexpr (IN) twn = g.tw12t[(long long)out_q1(tile_q1(min(L + W, ntiles - 1))) * M2 + max(tw_e, 0)];
             if constexpr (IN) PZ_XGROUP(src_, 0)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1068,7 +1065,6 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
             Bfly<16, true>::run(u);
             __builtin_amdgcn_sched_barrier(0);
             // inter-pass twiddles in two batches of 8 reads (all 16 at once, beside u[] and the 64 registers of x[] in flight, spill)
-            if constexpr (!PZ_TW_IN_TAIL)
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
                 cplx tw_[8];
@@ -1081,7 +1077,7 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
             }
             // the next tile's twiddle row (requested FIRST among this pass's loads, so that waiting for it here leaves the 16 T' loads in
             // flight) goes to the row the next inverse pass reads
-            if constexpr (IN && !PZ_TW_IN_TAIL) { if (tw_e >= 0) twrow2[(par ^ 1) * M2 + tw_e] = twn; }
+            if constexpr (IN) { if (tw_e >= 0) twrow2[(par ^ 1) * M2 + tw_e] = twn; }
             const bool active = b < g.batch && rr < g.npo;
             dst = active ? g.T2 + ((long long)b * g.npo + rr) * m + (long long)out_q1(q1) * M2 + o
                          : g.dummy + ((long long)blockIdx.x * (NT / 8) + row) * M2 + o;
@@ -1107,6 +1103,10 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
 #undef PZ_MIDR_FWD
 #undef PZ_MID_LANE
 }
+
+// (Round 4 experiment, removed - git history has it: the inverse inter-pass twiddle (x conj tw12) left to k_inv_tail.  Bit-exact; this kernel
+//  did not move (4.50 -> 4.53 ms per 1024 although it dropped from 256 to 219 VGPRs, 16 LDS reads and 64 flops per thread-tile: its inverse
+//  row pass is not what bounds the tile) and the tail paid 0.19 ms for the extra L2 stream: profiles/r04_ab_twtail.txt.)
 
 // HALFIN: a 16-slot tile whose ciphertexts carry at most 8 input polynomials (key switch, automorphism, ggsw_expand_row): the waves of
 // the upper 8 slots run the IN = false code.

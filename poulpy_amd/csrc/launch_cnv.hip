@@ -56,7 +56,6 @@ bool mid_cnv_supported(const pz_module* M, int a_size, int b_size, int min_size)
 int launch_mid_cnv(pz_module* M, int batch, const cplx* a_main, const cplx* a_last, const cplx* b_main, const cplx* b_last, cplx* T2, int cols,
                    int a_size, int b_size, int a_i, int a_j, int b_i, int b_j, int min_size, int offset) {
     if (batch <= 0 || min_size <= 0) return PZ_OK;
-    M->t2_untwiddled = false;   // k_mid_cnv applies the inverse inter-pass twiddle itself
     MidCnvArgs g;
     g.a_main = a_main; g.a_last = a_last; g.b_main = b_main; g.b_last = b_last; g.T2 = T2; g.cols = cols;
     g.a_size = a_size; g.b_size = b_size; g.a_i = a_i; g.a_j = a_j; g.b_i = b_i; g.b_j = b_j; g.min_size = min_size; g.offset = offset;

@@ -40,7 +40,6 @@ static int launch_mid_ct(pz_module* M, MidArgs g, int batch) {
 // perm_mul != 0: spectrum permutation of X -> X^p folded into the middle kernel (m2 = 128 plans only; see MidArgs)
 int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp, int npi, int npo, int nrows, int ncols, cplx* dummy,
                unsigned perm_mul, unsigned perm_add, const MidDigits* dg, const MidBr* br, bool perm_conj) {
-    M->t2_untwiddled = false;
     MidArgs g;
     g.br_lwe = nullptr; g.br_lwe_bs = 0; g.br_i0 = 0; g.br_blk = 0; g.br_rm = 0; g.w2n = M->w2n;
     if (br) {
@@ -90,7 +89,6 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
     {                                                                                                                      \
         PZ_TRY(set_lds((k_mid128r<CT_, NP_, PERM_, NR_, ((HALF_) && (NP_ >= 16))>), lds));                                  \
         hipLaunchKernelGGL((k_mid128r<CT_, NP_, PERM_, NR_, ((HALF_) && (NP_ >= 16))>), grid_, dim3(512), lds, M->stream, g); \
-        M->t2_untwiddled = PZ_TW_IN_TAIL != 0;                                                                             \
         dispatch_note(M, "k_mid128r<CT=%d,NP=%d,PERM=%d,NR=%d,HALFIN=%d,KR=%d>", CT_, NP_, (int)(PERM_), NR_, (int)((HALF_) && (NP_ >= 16)), NP_ == 32 ? 3 : PZ_MIDR_KR); \
     }
     /* k_mid128r: product rows = NP (no idle waves) or NP / 2 with the upper half of the slots without input (key switch) */ \
@@ -130,13 +128,11 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
                 if (mid_r && g.ds_n == 16 && npi == 16) {                                                                  \
                     PZ_TRY(set_lds((k_mid128r<4, 16, false, 16, false, PZ_MIDR_KR, true>), lds));                          \
                     hipLaunchKernelGGL((k_mid128r<4, 16, false, 16, false, PZ_MIDR_KR, true>), grid_, dim3(512), lds, M->stream, g); \
-                    M->t2_untwiddled = PZ_TW_IN_TAIL != 0;                                                                 \
                     dispatch_note(M, "k_mid128r<CT=4,NP=16,NR=16,HALFIN=0,KR=%d,DS=1>", PZ_MIDR_KR);                       \
                     done_ = true;                                                                                          \
                 } else if (mid_r && g.ds_n == 8 && npi <= 8 && npo > 8) {                                                  \
                     PZ_TRY(set_lds((k_mid128r<4, 16, false, 8, true, PZ_MIDR_KR, true>), lds));                            \
                     hipLaunchKernelGGL((k_mid128r<4, 16, false, 8, true, PZ_MIDR_KR, true>), grid_, dim3(512), lds, M->stream, g); \
-                    M->t2_untwiddled = PZ_TW_IN_TAIL != 0;                                                                 \
                     dispatch_note(M, "k_mid128r<CT=4,NP=16,NR=8,HALFIN=1,KR=%d,DS=1>", PZ_MIDR_KR);                        \
                     done_ = true;                                                                                          \
                 }                                                                                                          \

@@ -41,7 +41,6 @@ static int launch_inv_tail_cols(pz_module* M, const TailCall& c, int col_base, i
     g.pre_body = c.body_src != nullptr ? 1 : 0; g.small_neg = c.small_neg ? 1 : 0;
     g.body_src = c.body_src; g.body_bs = c.body_bs; g.body_ls = c.body_ls;
     g.post_neg = c.post_neg ? 1 : 0; g.body_only = c.body_only ? 1 : 0; g.raw = raw ? 1 : 0;
-    g.tw12t = (c.rowmajor && M->t2_untwiddled) ? M->tw12t : nullptr;
     g.nz = nz ? 1 : 0;
     g.nz_lsh = nz ? nz->lsh : 0; g.nz_res_end = nz ? nz->res_end : 0; g.nz_res_start = nz ? nz->res_start : 0; g.nz_a_end = nz ? nz->a_end : 0;
     g.nz_a_start = nz ? nz->a_start : 0; g.nz_zero_from = nz ? nz->zero_from : 0; g.nz_col = nz ? nz->col : 0; g.nz_mode = nz ? nz->mode : 0;

@@ -161,7 +161,6 @@ struct pz_module {
     // RCCL communicator for pz_bcast_key (api_dist.hip); owned by the module
     void* comm = nullptr;
     int comm_world = 0, comm_rank = 0;
-    bool t2_untwiddled = false;              // the last middle kernel left the inverse inter-pass twiddle to the tail (PZ_TW_IN_TAIL experiment)
     bool fuse_tail = true, fuse_mid = true;  // kernel-fusion knobs of the batched GLWE ops (tests run both settings)
     bool small_path = true;                  // N = 4096: the two-kernel pipeline of device_small.hpp where it applies
     // per-kernel-class HIP-event timing (bench.py's roofline leg); off by default

@@ -8,6 +8,9 @@
 //!   * `hal_impl.rs`: `unsafe impl HalImpl<FFT64Hip>` — all 105 required methods: DFT-domain families forward to the C ABI;
 //!   * `core_impl.rs` (feature `core-fused`, default): `unsafe impl CoreImpl<FFT64Hip>` with the GLWE-level key switch / external
 //!     product / automorphism family on the fused three-kernel device pipeline;
+//!   * `batched.rs` (same feature): `HipBatched`, an ADDITIVE extension trait on `Module<FFT64Hip>` over device buffers - every
+//!     `pz_*_batched` entry point of the C ABI without `unsafe` in the caller (external products, key switches, the automorphism family,
+//!     trace, tensoring + relinearization, blind rotation, circuit bootstrapping, the LWE glue, the per-op batched HAL);
 //!   * `tests.rs`: the reference's own `cross_backend_test_suite!` against `FFT64Ref`, as poulpy-cpu-avx/src/fft64/tests.rs.
 //!
 //! Bytes of `VecZnxDft` / `SvpPPol` / `VmpPMat` / `CnvPVec*` are backend-private ("device order": natural-frequency, interleaved
@@ -18,6 +21,13 @@ mod znx;
 
 #[cfg(feature = "core-fused")]
 mod core_impl;
+
+/// The additive batched, device-resident API (`HipBatched` on `Module<FFT64Hip>`): the route to this backend's throughput and to the
+/// batched blind rotation / circuit bootstrapping, which poulpy-bin-fhe's blanket impls do not let a backend override (batched.rs).
+#[cfg(feature = "core-fused")]
+pub mod batched;
+#[cfg(feature = "core-fused")]
+pub use batched::{AutomorphismMode, DeviceBuf, DeviceVecZnx, DeviceVecZnxDft, DeviceVmpPMat, HipBatched, HipBatchedCore, TensorMode};
 
 #[cfg(test)]
 mod tests;

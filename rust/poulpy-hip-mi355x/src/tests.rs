@@ -60,6 +60,27 @@ backend_test_suite! {
     }
 }
 
+/// the reference's own instantiation: `Module::new(8)`, base2k 17 (poulpy-cpu-ref/src/tests.rs:11-27) - the smallest ring the FFT64
+/// family supports (vmp.rs:67 asserts n >= 8); since round 4 the device library has plans for N = 8 and 16
+#[test]
+fn test_convolution_by_const_fft64_hip() {
+    let module: Module<FFT64Hip> = Module::<FFT64Hip>::new(8);
+    test_convolution_by_const(&module, 17);
+}
+
+#[test]
+fn test_convolution_fft64_hip() {
+    let module: Module<FFT64Hip> = Module::<FFT64Hip>::new(8);
+    test_convolution(&module, 17);
+}
+
+#[test]
+fn test_convolution_pairwise_fft64_hip() {
+    let module: Module<FFT64Hip> = Module::<FFT64Hip>::new(8);
+    test_convolution_pairwise(&module, 17);
+}
+
+/// ... and at the HAL suite's ring (N = 256, base2k 12)
 #[test]
 fn convolution_against_the_naive_bivariate_product() {
     let module = Module::<FFT64Hip>::new(1 << 8);
@@ -68,10 +89,10 @@ fn convolution_against_the_naive_bivariate_product() {
     test_convolution_pairwise(&module, 12);
 }
 
-/// every FFT plan family of the device library (N = 32 .. 65536) creates and destroys cleanly
+/// every FFT plan family of the device library (N = 8 .. 65536) creates and destroys cleanly
 #[test]
 fn module_new_every_ring_degree() {
-    for log_n in 5..=16 {
+    for log_n in 3..=16 {
         let module = Module::<FFT64Hip>::new(1u64 << log_n);
         assert_eq!(module.n(), 1usize << log_n);
     }
