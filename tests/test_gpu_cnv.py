@@ -38,7 +38,7 @@ def _finish(mod, d, base2k, res_size):
     return out.data
 
 
-@pytest.mark.parametrize("n,base2k", [(8, 12), (16, 17), (256, 12), (64, 17), (4096, 12)])
+@pytest.mark.parametrize("n,base2k", [(8, 17), (8, 12), (16, 17), (256, 12), (64, 17), (4096, 12)])   # (8, 17): poulpy-cpu-ref/src/tests.rs:11-27
 def test_convolution_and_pairwise(mods, n, base2k):
     """test_suite/convolution.rs:91-252 shapes: 2 columns, a_size = b_size = 15, res_size = 30, every offset / column pair."""
     ref, hip = mods(n)
