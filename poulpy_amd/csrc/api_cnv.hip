@@ -196,13 +196,14 @@ static int tensor_plan(const pz_module* M, const pz_glwe_tensor_params* p, int m
     t.res_dft = n8 * std::max(t.dft_size, 1);
     t.tmp = n8 * t.res_size;
     t.diag = mode == PZ_TENSOR_SQUARE ? n8 * t.cols * t.res_size : 0;
-    t.T = (size_t)M->m * sizeof(cplx) * std::max({t.cols * t.a_size, t.cols * t.b_size, t.dft_size, 1});
+    // (k_mid_cnv3 leaves the three result sets of a rank-1 tensoring side by side: 3 x min(dft_size, a_size + b_size - 1) polynomials)
+    t.T = (size_t)M->m * sizeof(cplx) * std::max({t.cols * t.a_size, t.cols * t.b_size, t.dft_size, 1, t.cols == 2 ? 3 * std::min(t.dft_size, t.a_size + t.b_size - 1) : 0});
     t.per_ct = t.prep_a + t.prep_b + t.res_dft + t.tmp + t.diag + t.T;
     return PZ_OK;
 }
 static size_t tensor_chunk(const pz_module* M, const TensorPlan& t, size_t batch) {
     if (M->chunk) return std::min(M->chunk, batch);
-    size_t c = ((size_t)16 << 30) / std::max<size_t>(t.per_ct, 1);
+    size_t c = ((size_t)24 << 30) / std::max<size_t>(t.per_ct, 1);   // as the GLWE pipeline: ~24 GiB of the 288 (at 16 GiB the bench's 256 pairs of 16 limbs split 222 + 34)
     return std::min(std::max<size_t>(c, 1), batch);
 }
 size_t pz_glwe_tensor_apply_workspace_bytes(const pz_module* M, const pz_glwe_tensor_params* p, int mode, size_t batch) {
@@ -274,20 +275,27 @@ int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, c
             PZ_TRY(dev_cnv_prepare(M, nb, pa, pa_bs, t.cols, t.a_size, ab, a_ct, t.cols, t.a_size, a_mask, T));
             if (!square) PZ_TRY(dev_cnv_prepare(M, nb, pb, pb_bs, t.cols, t.b_size, b + (long long)b0 * b_ct, b_ct, t.cols, t.b_size, b_mask, T));
         }
+        // rank 1, 16 / 8 limbs (round 4): the three terms in ONE launch - operand rows loaded and forward-transformed once, the limb
+        // convolution with one operand vector in registers (k_mid_cnv3; POULPY_DBG_TENSOR_ALLTERMS=0: k_mid_cnv per term)
+        const int bound_all = t.a_size + t.b_size - 1, ms_all = std::min(t.dft_size, bound_all), off_all = std::min(t.hi, bound_all);
+        const bool all3 = fused && mid_cnv3_supported(M, t.cols, t.a_size, t.b_size, ms_all);
+        if (all3) PZ_TRY(launch_mid_cnv3(M, nb, ta_main, ta_last, tb_main, tb_last, T, t.a_size, ms_all, off_all));
         // one product term (i, j): convolution -> inverse transform in place -> normalize(res_base2k, cnv_offset_lo) into `dst` column dcol
         auto term = [&](int i, int j, int64_t* dst, long long dst_bs, int dst_cols, int dcol, const NzCombine* cb = nullptr) -> int {
             const int bound = t.a_size + t.b_size - 1;
             const int min_size = std::min(t.dft_size, bound), off = std::min(t.hi, bound);
             if (fused) {
-                PZ_TRY(launch_mid_cnv(M, nb, ta_main, ta_last, tb_main, tb_last, T, t.cols, t.a_size, t.b_size, i, i == j ? -1 : j, i, i == j ? -1 : j,
-                                      min_size, off));
+                const cplx* Tt = T;
+                if (all3) Tt = T + (size_t)(i == j ? i : 2) * nb * min_size * mpts;
+                else PZ_TRY(launch_mid_cnv(M, nb, ta_main, ta_last, tb_main, tb_last, T, t.cols, t.a_size, t.b_size, i, i == j ? -1 : j, i, i == j ? -1 : j,
+                                           min_size, off));
                 // the inverse column pass normalizes on its way out (bit offset, combination and all: TailArgs::nz); POULPY_DBG_TENSOR_NZTAIL=0:
                 // raw inverse column pass into a VecZnxBig, then the normalize kernel
                 static const bool nztail = !(getenv("POULPY_DBG_TENSOR_NZTAIL") && atoi(getenv("POULPY_DBG_TENSOR_NZTAIL")) == 0);
                 if (nztail)
-                    return launch_inv_tail_nz(M, nb, T, min_size, (long long*)dst, dst_bs, dst_cols, t.res_size, dcol, (int)p->res_base2k, t.lo,
+                    return launch_inv_tail_nz(M, nb, Tt, min_size, (long long*)dst, dst_bs, dst_cols, t.res_size, dcol, (int)p->res_base2k, t.lo,
                                               t.dft_size, cb);
-                PZ_TRY(launch_inv_tail_raw(M, nb, T, min_size, (long long*)rd, rd_bs, t.dft_size));
+                PZ_TRY(launch_inv_tail_raw(M, nb, Tt, min_size, (long long*)rd, rd_bs, t.dft_size));
                 DV dvf{rd, rd_bs, 1, t.dft_size};
                 DV outf{dst, dst_bs, dst_cols, t.res_size};
                 return dev_normalize(M, nb, outf, (int)p->res_base2k, t.lo, dcol, dvf, (int)p->ab_base2k, 0, cb);

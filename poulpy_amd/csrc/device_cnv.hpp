@@ -238,6 +238,232 @@ __global__ void __launch_bounds__(256) k_mid_cnv(MidCnvArgs g) {
     }
 }
 
+// k_mid_cnv3 (round 4): ALL THREE terms of a rank-1 tensoring per tile - (0,0) = a0 b0, (1,1) = a1 b1 and the pairwise (0,1) = (a0 + a1)(b0 + b1)
+// (operations/glwe.rs:609-913: the Karatsuba form the reference evaluates; each term is inverse-transformed and normalized on its own, so
+// three result sets leave the kernel).  Why: profiles/r03_roofline.md had the tensoring at 0.12 of HBM; per term k_mid_cnv re-loaded and
+// re-transformed the operand rows (128 row loads / 96 forward row DFTs per tile-triple where 64 / 64 suffice) and its convolution read two
+// operand values from LDS per multiply-add (206 GB of LDS reads per 256 pairs: ~3 ms at the LDS rate - the phase was LDS-bound).  Here:
+//   * tile = one frequency row q1 of one pair, 2 AS + 2 BS operand rows (a0, a1, b0, b1) loaded and forward-transformed ONCE (512 threads =
+//     64 rows x 8 lanes, one sweep, as k_mid128);
+//   * the limb convolution keeps one operand vector in REGISTERS: thread = (point, group); groups 0 / 1 = the diagonal terms (A vector of AS
+//     values in registers, B streamed, all AS + BS - 1 product limbs accumulated in registers, statically unrolled), groups 2 / 3 = the even /
+//     odd product limbs of the pairwise term (the sums a0 + a1, b0 + b1 formed from LDS on the way).  2 LDS reads per AS multiply-adds instead
+//     of 2 per 1.  The window [offset, offset + min_size) of product limbs is selected when the accumulators are written back (static register
+//     index, dynamic LDS row), limbs beyond the product are zero rows;
+//   * waves 0-1 / 2-3 / 4-5 / 6-7 = groups 0 / 1 / 2 / 3: every SIMD carries one diagonal wave and one half-pairwise wave (balanced);
+//   * inverse row DFT of the 3 x min_size result rows x conj tw12 -> T2'[term][pair][limb].
+// AS, BS compile-time (the register arrays must not be indexed dynamically): instantiated for the 16- and 8-limb shapes; other shapes keep
+// k_mid_cnv per term.
+struct MidCnv3Args {
+    const cplx *a_main, *a_last, *b_main, *b_last;   // as MidCnvArgs (cols = 2)
+    cplx* T2;                                         // [term < 3][pair][kk < min_size][m]
+    int min_size, offset, m1, batch;
+    const cplx* wL2;
+    const cplx* tw12t;
+};
+template <int AS, int BS>
+__global__ void __launch_bounds__(512) k_mid_cnv3(MidCnv3Args g) {
+    constexpr int M2 = 128, RS = kMidCnvRS, NR = 2 * AS + 2 * BS, NK = AS + BS - 1;
+    static_assert(NR <= 64, "k_mid_cnv3: at most 64 operand rows");
+    extern __shared__ cplx lds[];   // 64 rows x RS | wL2[128] | tw12t rows [2][128]
+    const int tid = threadIdx.x;
+    const long long m = (long long)g.m1 * M2;
+    cplx* wl = lds + 64 * RS;
+    cplx* twrow2 = wl + M2;
+    // PERSISTENT (one workgroup per CU: the tile fills LDS): tile L = (pair bt, frequency row q1), walked with stride gridDim.x; the next
+    // tile's operand rows are requested before the inverse row pass of the current one and travel under it (the first version, one tile per
+    // workgroup, left the CU idle while its only workgroup waited for its loads: 3.3 TB/s, profiles/r04_tensor_*).
+    const long long ntiles = (long long)g.batch * g.m1;
+    // Lane coordinates are re-derived from an OPAQUE copy of the thread index in every phase (as in k_mid128r): derived once, everything that
+    // depends on them - row pointers, LDS offsets of the exchange passes, the output address - is hoisted out of the tile loop and sits beside the
+    // 188 registers of the convolution (300 bytes of scratch).
+    // the operand row a thread's 8-lane group loads and transforms: (operand, column, limb) - the same for every tile
+    auto row_src = [&](long long L, int row, int o) {
+        const bool isb = row >= 2 * AS;
+        const int rr_ = isb ? row - 2 * AS : row, size_ = isb ? BS : AS;
+        const int col_ = rr_ / size_, limb_ = rr_ % size_;
+        const long long Lc = L < ntiles ? L : ntiles - 1;
+        const int q1 = (int)(Lc % g.m1);
+        const long long bt = Lc / g.m1;
+        return (limb_ < size_ - 1 ? (isb ? g.b_main : g.a_main) + ((bt * (size_ - 1) + limb_) * 2 + col_) * m
+                                  : (isb ? g.b_last : g.a_last) + (bt * 2 + col_) * m) + (long long)q1 * M2 + o;
+    };
+    cplx x[16];
+    long long L = blockIdx.x;
+    if (L >= ntiles) return;
+    {
+        const int row = tid >> 3, o = tid & 7;
+        if (row < NR) {
+            const cplx* src = row_src(L, row, o);
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) x[n1] = ld_stream(src + 8 * n1);
+        }
+    }
+    if (tid < M2) { wl[tid] = g.wL2[tid]; twrow2[tid] = g.tw12t[(long long)(L % g.m1) * M2 + tid]; }
+    __syncthreads();
+    int par = 0;
+    for (; L < ntiles; L += gridDim.x, par ^= 1) {
+        const int q1 = (int)(L % g.m1);
+        const long long bt = L / g.m1;
+        // ---- forward row DFT of the operand rows (see k_mid128) ----
+        const int tf = pz_opaque(tid);
+        if (NR == 64 || (tf >> 3) < NR) {
+            const int row = tf >> 3, o = tf & 7;
+            cplx* rowbuf = lds + row * RS;
+            Bfly<16, false>::run(x);
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) {
+                cplx v = x[k1];
+                if (k1 > 0) v = cmul(v, wl[o * k1]);
+                rowbuf[k1 * 9 + o] = v;
+            }
+            row_sync();
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int oo = 0; oo < 8; ++oo) x[8 * h + oo] = rowbuf[(o + 8 * h) * 9 + oo];
+            Bfly<8, false>::run(x);
+            Bfly<8, false>::run(x + 8);
+            row_sync();
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) rowbuf[o + 8 * h + 16 * k2] = x[8 * h + k2];
+        }
+        __syncthreads();
+        // ---- limb convolution, one operand vector in registers ----
+        {
+            const int tc = pz_opaque(tid);
+            const int pt = tc & 127, grp = tc >> 7;   // wave-uniform group
+            const cplx* A0 = lds + pt;
+            const cplx* A1 = A0 + AS * RS;
+            const cplx* B0 = A0 + 2 * AS * RS;
+            const cplx* B1 = B0 + BS * RS;
+            const int term = grp < 2 ? grp : 2;
+            cplx* out = lds + (term * g.min_size) * RS + pt;   // result rows [term][kk]: written only after every operand value has been read
+            constexpr int NKH = (NK + 1) / 2;
+            const int hp = grp - 2;    // groups 2 / 3: this thread's product limbs are k = 2 u + hp
+            cplx av[AS], acc[NK];      // (groups 2 / 3 use acc[0 .. NKH))
+#pragma unroll
+            for (int k = 0; k < NK; ++k) acc[k] = make_double2(0.0, 0.0);
+            if (grp < 2) {
+                const cplx* A = grp == 0 ? A0 : A1;
+                const cplx* B = grp == 0 ? B0 : B1;
+#pragma unroll
+                for (int i = 0; i < AS; ++i) av[i] = A[i * RS];
+#pragma unroll
+                for (int j = 0; j < BS; ++j) {
+                    const cplx bv = B[j * RS];
+#pragma unroll
+                    for (int i = 0; i < AS; ++i) {
+                        acc[i + j].x = __builtin_fma(av[i].x, bv.x, acc[i + j].x);
+                        acc[i + j].x = __builtin_fma(-av[i].y, bv.y, acc[i + j].x);
+                        acc[i + j].y = __builtin_fma(av[i].x, bv.y, acc[i + j].y);
+                        acc[i + j].y = __builtin_fma(av[i].y, bv.x, acc[i + j].y);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < AS; ++i) av[i] = cadd(A0[i * RS], A1[i * RS]);
+                if (hp == 0) {
+#pragma unroll
+                    for (int j = 0; j < BS; ++j) {
+                        const cplx bv = cadd(B0[j * RS], B1[j * RS]);
+#pragma unroll
+                        for (int i = (j & 1); i < AS; i += 2) {   // i + j even
+                            cplx& c = acc[(i + j) >> 1];
+                            c.x = __builtin_fma(av[i].x, bv.x, c.x);
+                            c.x = __builtin_fma(-av[i].y, bv.y, c.x);
+                            c.y = __builtin_fma(av[i].x, bv.y, c.y);
+                            c.y = __builtin_fma(av[i].y, bv.x, c.y);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < BS; ++j) {
+                        const cplx bv = cadd(B0[j * RS], B1[j * RS]);
+#pragma unroll
+                        for (int i = 1 - (j & 1); i < AS; i += 2) {   // i + j odd
+                            cplx& c = acc[(i + j) >> 1];
+                            c.x = __builtin_fma(av[i].x, bv.x, c.x);
+                            c.x = __builtin_fma(-av[i].y, bv.y, c.x);
+                            c.y = __builtin_fma(av[i].x, bv.y, c.y);
+                            c.y = __builtin_fma(av[i].y, bv.x, c.y);
+                        }
+                    }
+                }
+            }
+            __syncthreads();   // every operand value has been read: the result rows take the place of the first operand rows
+            if (grp < 2) {
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const int kk = k - g.offset;
+                    if (kk >= 0 && kk < g.min_size) out[kk * RS] = acc[k];
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NKH; ++u) {
+                    const int k = 2 * u + hp, kk = k - g.offset;
+                    if (k < NK && kk >= 0 && kk < g.min_size) out[kk * RS] = acc[u];
+                }
+            }
+            // product limbs beyond a_size + b_size - 2 are zero (reim4/arithmetic_ref.rs:235-247); groups 0, 1, 2 fill them for their term
+            if (grp < 3)
+                for (int kk = max(NK - g.offset, 0); kk < g.min_size; ++kk) out[kk * RS] = make_double2(0.0, 0.0);
+        }
+        __syncthreads();
+        // ---- the next tile's operand rows and twiddle row start travelling; inverse row DFT of the 3 x min_size result rows x conj tw12 -> T2' ----
+        cplx twn = make_double2(0.0, 0.0);
+        __builtin_amdgcn_sched_barrier(0);   // (the loads below must not be hoisted above the convolution: 64 more live registers there spill 300 bytes)
+        const int ti = pz_opaque(tid);
+        const int row = ti >> 3, o = ti & 7;
+        {
+            const long long Ln = L + gridDim.x;
+            if (tid < M2) twn = g.tw12t[(long long)((Ln < ntiles ? Ln : ntiles - 1) % g.m1) * M2 + tid];
+            if (NR == 64 || row < NR) {   // (512 threads = 64 rows: with 64 operand rows every thread loads - no path on which x would have to survive the convolution)
+                const cplx* src = row_src(Ln, row, o);
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) x[n1] = ld_stream(src + 8 * n1);
+            } else {
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) x[n1] = make_double2(0.0, 0.0);
+            }
+        }
+        if (row < 3 * g.min_size) {
+            const int term = row / g.min_size, kk = row % g.min_size;
+            const cplx* twrow = twrow2 + par * M2;
+            cplx* rowbuf = lds + row * RS;
+            cplx u[16];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) u[8 * h + k2] = rowbuf[o + 8 * h + 16 * k2];
+            Bfly<8, true>::run(u);
+            Bfly<8, true>::run(u + 8);
+            row_sync();
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int oo = 0; oo < 8; ++oo) {
+                    cplx v = u[8 * h + oo];
+                    const int k1 = o + 8 * h;
+                    if (k1 > 0 && oo > 0) v = cmulc(v, wl[oo * k1]);
+                    rowbuf[k1 * 9 + oo] = v;
+                }
+            row_sync();
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) u[k1] = rowbuf[k1 * 9 + o];
+            Bfly<16, true>::run(u);
+            cplx* dst = g.T2 + (((long long)term * g.batch + bt) * g.min_size + kk) * m + (long long)q1 * M2 + o;
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) st_stream(dst + 8 * n1, cmulc(u[n1], twrow[o + 8 * n1]));
+        }
+        if (tid < M2) twrow2[(par ^ 1) * M2 + tid] = twn;   // the other twiddle row: nobody reads it before the barrier below
+        lds_barrier();   // the result rows have been consumed: the forward pass of the next tile may overwrite the tile (LDS ordering only -
+                         // the stores above drain under the next tile)
+    }
+}
+
 // convolution.rs:147-203 + :395-421: res limb kk = sum_j a[kk + offset - j] * b[j], wrapping i64, coefficient-wise
 struct CnvConstArgs {
     long long* res;

@@ -479,9 +479,11 @@ struct TailArgs {
 };
 __device__ __forceinline__ long long tz_digit(int k, long long x) { return (long long)((unsigned long long)x << (64 - k)) >> (64 - k); }
 __device__ __forceinline__ long long tz_carry(int k, long long x, long long d) { return (long long)((unsigned long long)x - (unsigned long long)d) >> k; }
+// (modes 1 / 2 are written once and read by a LATER launch at the earliest: streaming stores, as the product tails - with plain stores the
+//  PMC write traffic of the tensoring tail was 1.45 x its bytes, profiles/r04_tensor_traffic.json)
 __device__ __forceinline__ void tz_put(long long* p, int mode, long long v) {
-    if (mode == 1) *p = v;
-    else if (mode == 2) *p = (long long)(0ull - (unsigned long long)v);
+    if (mode == 1) st_stream(p, v);
+    else if (mode == 2) st_stream(p, (long long)(0ull - (unsigned long long)v));
     else if (mode == 3) *p = (long long)((unsigned long long)*p + (unsigned long long)v);
     else if (mode == 4) *p = (long long)((unsigned long long)*p - (unsigned long long)v);
 }
@@ -648,8 +650,28 @@ k_inv_tail(TailArgs g) {
         // (SMALL: the per-output address arithmetic is loop-invariant and would be hoisted out of the limb loop into ~32
         //  live registers; an opaque copy of the lane coordinates per limb makes the compiler recompute it instead)
         int b_ov = b_o, b_cv = b_c;
-        if (SMALL) asm volatile("" : "+v"(b_ov), "+v"(b_cv));
+        if (SMALL || NZ) asm volatile("" : "+v"(b_ov), "+v"(b_cv));
         const cplx* buf = xch + (j & 1) * XCH;
+        // NZ, mode 5 (the pairwise term of a tensoring reads the two diagonal columns' digits at its own store position and subtracts them):
+        // requested HERE, at the top of the limb, so that their latency hides behind the butterfly - read at the store they were 32 dependent
+        // HBM loads per thread and limb, and the pairwise launch ran at 2.8 TB/s against 4.6 for the diagonal ones (profiles/r04_tensor_*).
+        // Low dwords only: the values are balanced base2k-bit digits (k <= 31 here; wider digits keep the loads at the store).
+        int d5a[NZ ? 2 * RE : 1], d5b[NZ ? 2 * RE : 1];
+        bool d5 = false;
+        if (NZ && g.nz && g.nz_mode2[0] == 5 && k <= 31 && j >= g.nz_a_end && j < g.nz_a_start) {
+            d5 = true;
+            const long long r5 = (long long)(j - g.nz_a_start + g.nz_res_start) * res_ls;
+#pragma unroll
+            for (int e = 0; e < RE; ++e) {
+                const long long idx = (long long)(b_ov + R2 * PZ_TAIL_N1(e)) * g.m2 + c0 + b_cv;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const long long off5 = r5 + idx + (h ? m : 0);
+                    d5a[NZ ? 2 * e + h : 0] = reinterpret_cast<const int*>(nz_r2a + off5)[0];
+                    d5b[NZ ? 2 * e + h : 0] = nz_r2b ? reinterpret_cast<const int*>(nz_r2b + off5)[0] : 0;
+                }
+            }
+        }
         // key-switch body limb: requested first so that its latency hides behind the butterfly
         long long sm[SMALL ? 2 * RE : 1];
         if (SMALL && small_col && j < g.small_size && g.pre_body) {
@@ -751,7 +773,11 @@ k_inv_tail(TailArgs g) {
                     const long long cr_ = tz_carry(kk_, x, d_);                                              \
                     const long long dpc_ = (long long)(((unsigned long long)d_ << g.nz_lsh) + (unsigned long long)c_); \
                     const long long x1_ = tz_digit(k, dpc_);                                                 \
-                    if (j < g.nz_a_start) PZ_TAIL_NZ_STORE(j - g.nz_a_start + g.nz_res_start, idx, x1_)      \
+                    if (j < g.nz_a_start) {                                                                  \
+                        if (d5) tz_put(res_col + (long long)(j - g.nz_a_start + g.nz_res_start) * res_ls + idx, g.nz_mode,  \
+                                       (long long)((unsigned long long)x1_ - (unsigned long long)((long long)d5a[NZ ? 2 * n1 + h : 0] + (long long)d5b[NZ ? 2 * n1 + h : 0]))); \
+                        else PZ_TAIL_NZ_STORE(j - g.nz_a_start + g.nz_res_start, idx, x1_)                    \
+                    }                                                                                        \
                     c_ = (long long)((unsigned long long)cr_ + (unsigned long long)tz_carry(k, dpc_, x1_));  \
                 }                                                                                            \
                 continue;                                                                                    \
@@ -787,7 +813,37 @@ k_inv_tail(TailArgs g) {
             }                                                                                                \
         }                                                                                                    \
     }
-        if (FCARRY && !icarry && !(NZ && (g.raw || g.nz)) && big < 2251799813685247.0) {
+        if (NZ && g.nz && !icarry && big < 2251799813685247.0) {
+            // (round 4) the same-base steps of vec_znx_normalize with a bit offset in f64, as the plain carry chain above: every value an exact
+            // integer below 2^51, digits of at most 31 bits.  Per coefficient (normalize.rs:50-144, znx/normalization.rs:107-221 with lsh):
+            //   d = digit_{k-lsh}(x), cr = carry_{k-lsh}(x);  dpc = d 2^lsh + c;  x1 = digit_k(dpc);  c <- cr + carry_k(dpc)
+            // with digit_w(y) = y - floor((y + 2^(w-1)) 2^-w) 2^w - the value of the reference's shift pairs - about 12 f64 operations where the
+            // integer form spends ~45 (64-bit shifts on a 32-bit ALU); the tensoring tails ran at 4.4 TB/s against 5.5 for the product tails.
+            if (j >= g.nz_a_end) {
+                const int kk_ = k - g.nz_lsh;
+                const double halfkk = (double)(1ull << (kk_ - 1)), twokk = 2.0 * halfkk, invkk = 1.0 / twokk, lshmul = (double)(1ull << g.nz_lsh);
+#pragma unroll
+                for (int n1 = 0; n1 < RE; ++n1) {
+                    const int j1 = b_ov + R2 * PZ_TAIL_N1(n1);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const long long idx = (long long)j1 * g.m2 + c0 + b_cv + (h ? m : 0);
+                        const double r = round_half_away(h ? v[n1].y : v[n1].x);
+                        const double q = floor((r + halfkk) * invkk);
+                        const double dd = __builtin_fma(-q, twokk, r);
+                        const double dpc = __builtin_fma(dd, lshmul, __longlong_as_double(carry[2 * n1 + h]));
+                        const double q2 = floor((dpc + halfd) * invk);
+                        carry[2 * n1 + h] = __double_as_longlong(q + q2);
+                        if (j < g.nz_a_start) {
+                            const long long x1_ = (long long)(int)__builtin_fma(-q2, twok, dpc);
+                            if (d5) tz_put(res_col + (long long)(j - g.nz_a_start + g.nz_res_start) * res_ls + idx, g.nz_mode,
+                                           (long long)((unsigned long long)x1_ - (unsigned long long)((long long)d5a[NZ ? 2 * n1 + h : 0] + (long long)d5b[NZ ? 2 * n1 + h : 0])));
+                            else PZ_TAIL_NZ_STORE(j - g.nz_a_start + g.nz_res_start, idx, x1_)
+                        }
+                    }
+                }
+            }
+        } else if (FCARRY && !icarry && !(NZ && (g.raw || g.nz)) && big < 2251799813685247.0) {
 #pragma unroll
             for (int n1 = 0; n1 < RE; ++n1) {
                 const int j1 = b_ov + R2 * PZ_TAIL_N1(n1);
@@ -807,7 +863,7 @@ k_inv_tail(TailArgs g) {
                 }
             }
         } else {
-            if (FCARRY && !icarry && !(NZ && (g.raw || g.nz))) {   // leave the f64 chain: the carries become integers, for good
+            if (FCARRY && !icarry && !(NZ && g.raw)) {   // leave the f64 chain: the carries become integers, for good
                 icarry = true;
 #pragma unroll
                 for (int u = 0; u < 2 * RE; ++u) carry[u] = fast_i64_from_integral(__longlong_as_double(carry[u]));
@@ -829,7 +885,7 @@ k_inv_tail(TailArgs g) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const long long idx = (long long)j1 * g.m2 + c0 + b_c + (h ? m : 0);
-                long long c_ = carry[2 * n1 + h];
+                long long c_ = icarry ? carry[2 * n1 + h] : fast_i64_from_integral(__longlong_as_double(carry[2 * n1 + h]));
                 for (int jj = 0; jj < g.nz_res_end; ++jj) {
                     const long long x1_ = tz_digit(k, c_);
                     PZ_TAIL_NZ_STORE(g.nz_res_end - jj - 1, idx, x1_)

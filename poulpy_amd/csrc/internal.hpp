@@ -87,6 +87,10 @@ bool tail_rsh_supported(const pz_module* M);
 bool mid_cnv_supported(const pz_module* M, int a_size, int b_size, int min_size);
 int launch_mid_cnv(pz_module* M, int batch, const cplx* a_main, const cplx* a_last, const cplx* b_main, const cplx* b_last, cplx* T2, int cols,
                    int a_size, int b_size, int a_i, int a_j, int b_i, int b_j, int min_size, int offset);
+// k_mid_cnv3: the three terms of a rank-1 tensoring in one launch; T2 = [term][pair][limb < min_size][m] (launch_cnv.hip)
+bool mid_cnv3_supported(const pz_module* M, int cols, int a_size, int b_size, int min_size);
+int launch_mid_cnv3(pz_module* M, int batch, const cplx* a_main, const cplx* a_last, const cplx* b_main, const cplx* b_last, cplx* T2, int a_size,
+                    int min_size, int offset);
 struct NzCombine;
 int launch_inv_tail_nz(pz_module* M, int batch, const cplx* T, int nlimbs, long long* res, long long res_bs, int res_cols, int res_size, int res_col,
                        int base2k, long long res_offset, int a_size, const NzCombine* cb);

@@ -69,6 +69,36 @@ int launch_mid_cnv(pz_module* M, int batch, const cplx* a_main, const cplx* a_la
     return PZ_OK;
 }
 
+// all three terms of a rank-1 tensoring in one launch (device_cnv.hpp, k_mid_cnv3): T2 = [term][pair][limb < min_size][m]
+bool mid_cnv3_supported(const pz_module* M, int cols, int a_size, int b_size, int min_size) {
+    static const bool on = !(getenv("POULPY_DBG_TENSOR_ALLTERMS") && atoi(getenv("POULPY_DBG_TENSOR_ALLTERMS")) == 0);
+    return on && cols == 2 && mid_cnv_supported(M, a_size, b_size, min_size) && a_size == b_size && (a_size == 16 || a_size == 8) && min_size <= 21 &&
+           3 * min_size <= 64;
+}
+int launch_mid_cnv3(pz_module* M, int batch, const cplx* a_main, const cplx* a_last, const cplx* b_main, const cplx* b_last, cplx* T2, int a_size,
+                    int min_size, int offset) {
+    if (batch <= 0 || min_size <= 0) return PZ_OK;
+    MidCnv3Args g;
+    g.a_main = a_main; g.a_last = a_last; g.b_main = b_main; g.b_last = b_last; g.T2 = T2;
+    g.min_size = min_size; g.offset = offset; g.m1 = M->plan.m1; g.batch = batch; g.wL2 = M->wL2; g.tw12t = M->tw12t;
+    const size_t lds = ((size_t)64 * kMidCnvRS + 384) * sizeof(cplx);   // tile | wL2 | two twiddle rows
+    KTimer kt(M, PZ_K_FUSED_MID);
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, M->device);
+    if (M->cu_count > 0) ncu = M->cu_count;
+    const dim3 grid((unsigned)std::min<long long>((long long)batch * g.m1, ncu));   // persistent: one workgroup per CU
+    if (a_size == 16) {
+        PZ_TRY(set_lds((k_mid_cnv3<16, 16>), lds));
+        hipLaunchKernelGGL((k_mid_cnv3<16, 16>), grid, dim3(512), lds, M->stream, g);
+    } else {
+        PZ_TRY(set_lds((k_mid_cnv3<8, 8>), lds));
+        hipLaunchKernelGGL((k_mid_cnv3<8, 8>), grid, dim3(512), lds, M->stream, g);
+    }
+    dispatch_note(M, "k_mid_cnv3<%d,%d> (3 terms, %d limbs each)", a_size, a_size, min_size);
+    PZ_HIP(hipGetLastError());
+    return PZ_OK;
+}
+
 int launch_cnv_by_const(pz_module* M, long long* res, int res_cols, int res_col, int min_size, int offset, const long long* a, int a_cols,
                         int a_size, int a_col, const long long* bconst, int b_size) {
     if (min_size <= 0) return PZ_OK;

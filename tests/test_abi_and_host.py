@@ -58,7 +58,8 @@ def test_module_new_rejects_bad_n_before_touching_the_device(lib):
     h = C.c_void_p()
     assert lib.pz_module_new(C.c_uint64(12345), C.byref(h)) == -1  # PZ_ERR_INVALID: not a power of two
     assert b"power of two" in lib.pz_last_error()
-    assert lib.pz_module_new(C.c_uint64(16), C.byref(h)) == -2     # PZ_ERR_UNSUPPORTED: n < 32
+    assert lib.pz_module_new(C.c_uint64(4), C.byref(h)) == -2      # PZ_ERR_UNSUPPORTED: n < 8 (vmp.rs:67 asserts n >= 8)
+    assert lib.pz_module_new(C.c_uint64(1 << 18), C.byref(h)) == -2  # beyond the largest plan
 
 
 def test_no_cpu_fallback_without_a_device():

@@ -186,7 +186,7 @@ def test_config5_rotate_16_limbs_in_place(mods):
     assert _auto_pool_parity(hip, ref, n, 1, 16, 12, 16, 5, "add", batch=131, pool=5, seed=5131, in_place=True) == 0
 
 
-def _tensor_pool_parity(hip, ref, n, rank, size, base2k, cnv_offset, mode, batch, pool, seed, in_chunks=16):
+def _tensor_pool_parity(hip, ref, n, rank, size, base2k, cnv_offset, mode, batch, pool, seed, in_chunks=16, res_size=None):
     """glwe_tensor_apply / _add_assign / _square (poulpy-core operations/glwe.rs:609-913) on `batch` pairs drawn from a pool; every
     tensor compared with its pool entry's oracle result on the device.  Returns the number of mismatching tensors."""
     import torch
@@ -196,15 +196,16 @@ def _tensor_pool_parity(hip, ref, n, rank, size, base2k, cnv_offset, mode, batch
     tcols = cols * (cols + 1) // 2
     square = mode == "square"
     k = base2k * size
+    res_size = res_size or size
     a_pool = np.empty((pool, size, cols, n), dtype=np.int64)
     b_pool = np.empty((pool, size, cols, n), dtype=np.int64)
-    prev_pool = rng.integers(-(1 << (base2k - 1)), 1 << (base2k - 1), (pool, size, tcols, n), dtype=np.int64)
+    prev_pool = rng.integers(-(1 << (base2k - 1)), 1 << (base2k - 1), (pool, res_size, tcols, n), dtype=np.int64)
     want_pool = np.empty_like(prev_pool)
     for i in range(pool):
         a = VecZnx(n, cols, size).fill_uniform(base2k, rng)
         b = a if square else VecZnx(n, cols, size).fill_uniform(base2k, rng)
         a_pool[i], b_pool[i] = a.data, b.data
-        r = VecZnx(n, tcols, size, prev_pool[i].copy())
+        r = VecZnx(n, tcols, res_size, prev_pool[i].copy())
         if square:
             ref.glwe_tensor_square_apply(cnv_offset, r, base2k, a, k, base2k)
         else:
@@ -217,7 +218,7 @@ def _tensor_pool_parity(hip, ref, n, rank, size, base2k, cnv_offset, mode, batch
     d_r = torch.from_numpy(prev_pool).to(dev)[idx].contiguous()
     d_want = torch.from_numpy(want_pool).to(dev)
     torch.cuda.synchronize()
-    p = GlweTensorParams(rank=rank, a_size=size, b_size=size, ab_base2k=base2k, a_effective_k=k, b_effective_k=k, res_size=size,
+    p = GlweTensorParams(rank=rank, a_size=size, b_size=size, ab_base2k=base2k, a_effective_k=k, b_effective_k=k, res_size=res_size,
                          res_base2k=base2k, cnv_offset=cnv_offset)
     ptr = lambda t: C.c_void_p(t.data_ptr())
     hip.dispatch_notes(reset=True)
@@ -246,6 +247,23 @@ def test_config5_tensoring_16_limbs_pool_parity_at_bench_batch(mods, mode):
     assert bad == 0, (mode, bad)
     if os.environ.get("POULPY_DBG_TENSOR_FUSED") != "0" and os.environ.get("POULPY_DBG_TENSOR_COMBINE") != "0":
         assert "k_mid_cnv" in notes, notes
+        if os.environ.get("POULPY_DBG_TENSOR_ALLTERMS") != "0":
+            assert "k_mid_cnv3<16,16>" in notes, notes
+
+
+@pytest.mark.parametrize("mode", ["apply", "add_assign", "square"])
+def test_tensoring_all_terms_kernel_shapes(mods, mode):
+    """k_mid_cnv3 (round 4: the three terms of a rank-1 tensoring in one launch, one operand vector in registers) on its 8-limb instantiation
+    and on the windows it selects at write-back: offsets below base2k (negative bit offset, window at limb 0), around the middle, near the top
+    of the product (zero rows beyond a_size + b_size - 2), results shorter and longer than the operands; batch 67 at N = 2^13 (many tiles per
+    CU).  The per-term kernel (POULPY_DBG_TENSOR_ALLTERMS=0) must give the same digits - both against the oracle."""
+    n = 8192
+    ref, hip = mods(n)
+    for (size, res_size, off) in ((8, 8, 8 * 12 - 9), (8, 5, 40), (8, 12, 7), (8, 16, 3 * 12), (8, 8, 15 * 12 + 5), (8, 3, 14 * 12)):
+        bad, notes = _tensor_pool_parity(hip, ref, n, 1, size, 12, off, mode, batch=67, pool=3, seed=6300 + off + res_size, res_size=res_size)
+        assert bad == 0, (mode, size, res_size, off, bad)
+        if os.environ.get("POULPY_DBG_TENSOR_FUSED") != "0" and os.environ.get("POULPY_DBG_TENSOR_COMBINE") != "0" and os.environ.get("POULPY_DBG_TENSOR_ALLTERMS") != "0":
+            assert "k_mid_cnv3<8,8>" in notes, (notes, size, res_size, off)
 
 
 def test_config5_tensoring_rank2_pool_parity(mods):

@@ -109,15 +109,11 @@ def main():
                 ok = ok and bool(np.array_equal(out[t].cpu().numpy(), want.data))
     # algorithmic bytes per tensoring: both operands read, the tensor written; flops: forward transforms of both operands, the limb
     # convolution of cols*(cols+1)/2 column pairs (Karatsuba for the cross column: cnv_pairwise), inverse transforms of the tensor
-    m = n // 2
-    nb = (2 * cols * size + tcols * size) * n * 8 if args.mode == "apply" else (cols * size + tcols * size) * n * 8
-    nprod = tcols * size * (size + 1) // 2      # complex pointwise products (upper bound: every limb pair that reaches a result limb)
-    fft = 5.0 * m * np.log2(m)
-    flops = ((2 if args.mode == "apply" else 1) * cols * size + tcols * size) * fft + nprod * m * 8.0
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import roofline_models as rm
+    model = rm.tensoring(n, rank, size, args.mode, args.relin, args.batch)   # the byte / flop model lives beside the other benched operations'
+    nb, flops = model["hbm_bytes"], model["flops"]
     rate = args.batch / dt
-    if args.relin:   # + read of the tensor, write of the GLWE, the key once per call; key switch of one column with `size` rows
-        nb += (tcols * size + cols * size) * n * 8 + size * cols * size * n * 8 // args.batch
-        flops += (size + cols * size) * fft + m * size * (cols * size) * 8.0
     print(json.dumps({
         "metric": ("GLWE multiplications/s (glwe_tensor_%s + glwe_tensor_relinearize)" if args.relin else "GLWE tensorings/s (glwe_tensor_%s)") % ("apply" if args.mode == "apply" else "square_apply"),
         "value": rate, "unit": "multiplications/s" if args.relin else "tensorings/s", "ms_per_step": dt * 1e3, "batch": args.batch, "parity_ok": ok,

@@ -39,6 +39,26 @@ def blind_rotation(n, n_lwe, rank, block_size, dnum, brk_size, res_size, batch):
     return {"hbm_bytes": hbm, "flops": flops, "key_stream_bytes": key_bytes, "npi": npi, "npo": npo, "blocks": nb}
 
 
+def tensoring(n, rank, size, mode="apply", relin=False, batch=1):
+    """GLWE tensoring (poulpy-core operations/glwe.rs:609-913; the convolution half of a CKKS multiplication) per pair, optionally followed
+    by glwe_tensor_relinearize (:541-607).  Algorithmic bytes: both operands read (one for `square`), the (rank+1)(rank+2)/2 tensor columns
+    written; flops: forward transforms of the operand limbs, the limb convolution of every column pair (Karatsuba cross terms: one product
+    per pair, reim4/arithmetic_ref.rs:235-247 upper bound: every limb pair that reaches a result limb), inverse transforms of the tensor."""
+    m, cols = n // 2, rank + 1
+    tcols = cols * (cols + 1) // 2
+    ops = 1 if mode == "square" else 2
+    hbm = (ops * cols * size + tcols * size) * n * 8
+    nprod = tcols * size * (size + 1) // 2
+    flops = (ops * cols * size + tcols * size) * fft_flops(m) + nprod * m * 8.0
+    key = 0
+    if relin:   # + read of the tensor, write of the GLWE, the key once per call: key switch of rank (rank+1)/2 columns with `size` rows
+        pairs = rank * (rank + 1) // 2
+        key = size * pairs * cols * size * n * 8
+        hbm += (tcols * size + cols * size) * n * 8 + key / batch
+        flops += (pairs * size + cols * size) * fft_flops(m) + m * (pairs * size) * (cols * size) * 8.0
+    return {"hbm_bytes": hbm, "flops": flops, "key_stream_bytes": key}
+
+
 def key_share(notes: str) -> int:
     """ciphertexts that share one fetch of a key value, from the library's dispatch notes"""
     best = 1
