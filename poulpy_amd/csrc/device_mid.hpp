@@ -299,7 +299,10 @@ k_mid(MidArgs g) {
 // NP = polynomial slots per ciphertext: 16; 8 for shapes with <= 8 polynomials in and out such as rank 1 with 4 limbs (twice the
 // ciphertexts per tile and per key fetch); 32 for rank 2-3 or 16 limbs (two ciphertexts per tile).  The 4 thread groups of the product phase split into GC column groups x GT
 // ciphertext groups so that a thread always owns 16 accumulators (4 ciphertexts x 4 outputs, or 2 x 8).
-template <int CT, int NP = 16, bool PERM = false, bool DS = false, bool BR = false, bool SKIPW = false, int BRNEST = 0>
+// NCO (round 4): outputs per thread when the tile's 8 slots carry SIX output polynomials (blind rotation at rank 1 with 3 key limbs): 3, so that
+// the two column groups cover exactly the 6 columns - with the default 4 a quarter of the product's multiply-adds and key loads went to two
+// columns that do not exist (clamped loads, results discarded): product phase 48 k of the tile's 70 k cycles at N = 2^14 (r04_br_probe.txt).
+template <int CT, int NP = 16, bool PERM = false, bool DS = false, bool BR = false, bool SKIPW = false, int BRNEST = 0, int NCO = 0>
 __global__ void __launch_bounds__(CT * NP * 8)
 k_mid128(MidArgs g) {
     static_assert(!SKIPW || (NP > 8 && !BR && !DS), "wave skipping: 16- and 32-slot tiles of the plain product only");
@@ -308,8 +311,8 @@ k_mid128(MidArgs g) {
     constexpr int NCG = NT / M2;       // thread groups in the product phase
     // outputs per thread (NP = 32: two ciphertexts x 8 outputs, as in k_mid<2>).  8 for the 16-slot tile too (2 ciphertexts x 8 outputs per
     // thread: half the operand reads from LDS, every key value fetched by two threads) was measured slower: 5.08 -> 5.39 ms
-    constexpr int NC = NP == 32 ? 8 : 4;
-    constexpr int GC = NP / NC;        // column groups
+    constexpr int NC = NCO ? NCO : (NP == 32 ? 8 : 4);
+    constexpr int GC = NCO == 3 ? 2 : NP / NC;   // column groups (NCO = 3: 2 x 3 columns of an 8-slot tile)
     constexpr int GT = NCG / GC;       // ciphertext groups
     constexpr int CTt = CT / GT;       // ciphertexts per thread
     static_assert(GC * GT == NCG && CTt * GT == CT && NT == 512, "k_mid128 tile shape");

@@ -78,6 +78,7 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, M->device);
         if (M->cu_count > 0) ncu = (M->cu_count / 8) * 8 > 0 ? (M->cu_count / 8) * 8 : M->cu_count;
         static const bool mid_r = !(getenv("POULPY_DBG_MID_R") && atoi(getenv("POULPY_DBG_MID_R")) == 0);   // 0: k_mid128 (the kernel of rounds 1-2) instead of k_mid128r (A/B)
+        static const bool br_nc3 = !(getenv("POULPY_DBG_BR_NC3") && atoi(getenv("POULPY_DBG_BR_NC3")) == 0);   // 0: 4 outputs per thread also for 6-column block steps (A/B)
         KTimer kt(M, PZ_K_FUSED_MID);
 #define PZ_MID128_GO(CT_, NP_, PERM_, SKIPW_)                                                                              \
     {                                                                                                                      \
@@ -113,7 +114,11 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
         g.n_ct = (batch + CT_ - 1) / CT_;                                                                                  \
         const size_t lds = ((size_t)CT_ * NP_ * kMidRS + 384 + 32) * sizeof(cplx);   /* tile | wL2 | two twiddle rows | exponents */                                         \
         const dim3 grid_(std::min({ncu, 256, g.m1 * g.n_ct}));   /* <= 256: one scratch tile per workgroup (kMidDummyBytes) */ \
-        if (br && NP_ < 32 && (g.br_rm & 1) == 0) {   /* an even number of key rows per coefficient: the nested form of the product loop */ \
+        if (br && NP_ == 8 && (g.br_rm & 1) == 0 && g.ncomp == 6 && npi <= 6 && br_nc3) {   /* six output columns in an 8-slot tile: 2 x 3 per thread */ \
+            PZ_TRY(set_lds((k_mid128<CT_, NP_, false, false, true, false, (NP_ == 8 ? 2 : 0), (NP_ == 8 ? 3 : 0)>), lds));  \
+            hipLaunchKernelGGL((k_mid128<CT_, NP_, false, false, true, false, (NP_ == 8 ? 2 : 0), (NP_ == 8 ? 3 : 0)>), grid_, dim3(512), lds, M->stream, g); \
+            dispatch_note(M, "k_mid128<CT=%d,NP=%d,BR=1,BRNEST=2,NCO=3> (%d ciphertexts per key value)", CT_, NP_, CT_);   \
+        } else if (br && NP_ < 32 && (g.br_rm & 1) == 0) {   /* an even number of key rows per coefficient: the nested form of the product loop */ \
             PZ_TRY(set_lds((k_mid128<CT_, NP_, false, false, true, false, (NP_ < 32 ? 2 : 0)>), lds));                     \
             hipLaunchKernelGGL((k_mid128<CT_, NP_, false, false, true, false, (NP_ < 32 ? 2 : 0)>), grid_, dim3(512), lds, M->stream, g); \
             dispatch_note(M, "k_mid128<CT=%d,NP=%d,BR=1,BRNEST=2> (%d ciphertexts per key value)", CT_, NP_, CT_);         \
