@@ -28,8 +28,10 @@ for kind in ("pmc_fetch", "pmc_write"):
     for f in files:
         os.remove(f)
 PY
-# steady-state averages: bench.py times the LAST `--steps` steps (2 launches each); the --stats average above also contains the set-up,
-# parity and warm-up launches (cold clocks: the maximum of the column).  Per pz kernel: average over its last 40 dispatches.
+# steady-state averages.  With these ARGS (no parity sample, no per-kernel timing pass, no set-up calls: the placement tuner and its extra
+# bench leg are gone since round 4) every pipeline kernel is dispatched warmup + steps = 2 + 20 times and the LAST 20 are exactly bench.py's
+# timed region (round 3's "last 40" window mixed 19 timed launches with 21 of the placement leg).  The --stats average above also
+# contains the warm-up launches (cold clocks: the maximum of the column).
 python3 - <<'PY'
 import csv, glob, collections, os
 files = sorted(glob.glob("trace/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
@@ -38,12 +40,12 @@ if files:
     for r in csv.DictReader(open(files[-1])):
         rows[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     with open("trace_steady.txt", "w") as o:
-        o.write("# kernel, dispatches, avg ms over all, avg ms over the last 40 (= bench.py's timed region at --steps 20)\n")
+        o.write("# kernel, dispatches, avg ms over all, avg ms over the last 20 (= bench.py's timed region at --steps 20: warm-up 2 + timed 20, nothing behind it)\n")
         for k, v in sorted(rows.items(), key=lambda kv: -sum(d for _, d in kv[1])):
             if "pz::" not in k: continue
             v.sort()
             d = [x[1] for x in v]
-            last = d[-40:]
+            last = d[-20:]
             o.write("%s\t%d\t%.4f\t%.4f\n" % (k[:70], len(d), sum(d) / len(d) / 1e6, sum(last) / len(last) / 1e6))
     print(open("trace_steady.txt").read())
 PY
