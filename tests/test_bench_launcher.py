@@ -69,3 +69,15 @@ def test_single_rank_rccl_path_through_the_c_abi():
     assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1
     assert "cabi" in line["config"]["parallelism"]
     assert line["parity_sample"]["ok"] is True
+
+
+@pytest.mark.gpu
+def test_fewer_devices_than_ranks_is_a_one_line_refusal():
+    """A rank that finds fewer HIP devices than WORLD_SIZE exits 4 with one line on rank 0 and no JSON:
+    run here as rank 0 of a pretended 64-rank job, more than any node has."""
+    env = dict(os.environ, WORLD_SIZE="64", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29534")
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "64", "--steps", "1"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert out.returncode == 4, (out.returncode, out.stderr[-500:])
+    mine = [l for l in out.stderr.splitlines() if l.startswith("bench.py:")]
+    assert len(mine) == 1 and "needs 64 HIP devices" in mine[0] and "no line reported" in mine[0]
+    assert not any(l.startswith("{") for l in out.stdout.splitlines())

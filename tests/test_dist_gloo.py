@@ -47,11 +47,15 @@ def _worker(rank, world, port, total, outq):
         out[idx] = res.data.copy()
     gathered = [None] * world
     dist.all_gather_object(gathered, out)
+    # the per-rank block of the N > 1 bench line: one small dict from every rank, ordered by rank on every rank
+    per_rank = pdist.gather_per_rank({"value": 100.0 + rank, "ms_per_step": 10.0 - rank, "device": f"gpu{rank}", "parity_ok": True})
+    assert [e["rank"] for e in per_rank] == list(range(world))
+    assert [e["value"] for e in per_rank] == [100.0 + r for r in range(world)]
     if rank == 0:
         merged = {}
         for g in gathered:
             merged.update(g)
-        outq.put(merged)
+        outq.put((merged, per_rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -66,10 +70,16 @@ def test_two_rank_sharded_external_products_match_single_process():
     procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
     for p in procs:
         p.start()
-    merged = q.get(timeout=120)
+    merged, per_rank = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    import json
+    from poulpy_amd import dist as pdist
+    assert json.loads(json.dumps(per_rank)) == per_rank and len(per_rank) == world      # goes into the JSON line as is
+    assert set(per_rank[1]) == {"value", "ms_per_step", "device", "parity_ok", "rank"}
+    assert pdist.scaling_efficiency(190.0, 2, 100.0) == pytest.approx(0.95)
+    assert pdist.scaling_efficiency(190.0, 2, None) is None and pdist.scaling_efficiency(190.0, 2, 0.0) is None
     n, base2k, cols, size = 64, 12, 2, 3
     ref = RefModule(n)
     mat = MatZnx(n, size, cols, cols, size).fill_uniform(base2k, np.random.default_rng(1))
