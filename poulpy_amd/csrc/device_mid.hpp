@@ -29,6 +29,9 @@ constexpr int kMidRS = PZ_MID_RS;
 #ifndef PZ_MID_STAMP
 #define PZ_MID_STAMP 0   // diagnostic build: per-phase s_memtime totals of k_mid128, printed by a few waves (tools/dbg/mid_stamps.sh)
 #endif
+#ifndef PZ_MIDR_HALFKEY
+#define PZ_MIDR_HALFKEY 0   // timing ablation (results invalid): every second key row of k_mid128r's product is never requested - what the product phase
+#endif                      // would cost with eight ciphertexts per key fetch, before any of that scheme's own costs
 #ifndef PZ_MIDR_KR
 #define PZ_MIDR_KR 6     // key-row slots of k_mid128r (rows requested KR - 1 ahead; build-time for A/B runs)
 #endif
@@ -830,6 +833,12 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
     cplx* dst = nullptr;
     cplx twn = make_double2(0.0, 0.0);
     cplx kr[KR][NC];   // key-row ring: row i of a tile lives in slot i % KR; slots 0 .. KR-2 are requested before the product starts
+#if PZ_MIDR_HALFKEY
+#pragma unroll
+    for (int i = 0; i < KR; ++i)
+#pragma unroll
+        for (int j = 0; j < NC; ++j) kr[i][j] = make_double2(1.0, 0.0);
+#endif
 
     // ---- pieces ----
 #define PZ_XGROUP(SRC, G4)   /* four of the next tile's 16 T' loads */                                   \
@@ -837,7 +846,7 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
 #define PZ_SGROUP(G4)        /* four of the previous tile's 16 stores */                                \
     { _Pragma("unroll") for (int n1 = 4 * (G4); n1 < 4 * (G4) + 4; ++n1) st_stream(dst + 8 * n1, u[n1]); }
 #define PZ_KGROUP(LT, SLOT)  /* key row SLOT (< KR - 1) of tile LT's product */                         \
-    {                                                                                                  \
+    if (!(PZ_MIDR_HALFKEY && ((SLOT) & 1))) {                                                          \
         const long long base_ = (long long)tile_q1(min((LT), ntiles - 1)) * g.nrows * g.ncols;         \
         int r_ = rot + (SLOT);                                                                         \
         r_ -= (r_ >= nrow) ? nrow : 0;                                                                 \
@@ -947,7 +956,7 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
             const long long prow = (long long)g.ncols * M2;
             cplx av[2][CTt];
 #define PZ_LOADROW(DST, IT)                                                                     \
-    {                                                                                           \
+    if (!(PZ_MIDR_HALFKEY && ((IT) & 1))) {                                                     \
         int r_ = (IT) + rot;                                                                    \
         r_ -= (r_ >= nrow) ? nrow : 0;                                                          \
         r_ -= (r_ >= nrow) ? nrow : 0;                                                          \
