@@ -9,6 +9,6 @@ for lib in "$@"; do
     python bench.py $ARGS 2>/dev/null | tail -1 | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())
-print('%-36s %9.0f /s  parity=%s  %s' % ('$lib', d['value'], d.get('parity_sample',{}).get('ok'), {k: round(v,3) for k,v in d['roofline'].get('kernel_ms',{}).items()}))"
+print('%-36s %9.0f /s  parity=%s  %s' % ('$lib', d['value'], (d.get('parity_sample') or {}).get('ok'), {k: round(v,3) for k,v in d['roofline'].get('kernel_ms',{}).items()}))"
   done
 done
