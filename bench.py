@@ -198,7 +198,7 @@ def parity_sample(args, mod, a, res, mat_host, lo, nct, ks, auto_mode, unsupport
         if relin:
             ref.glwe_tensor_relinearize(want, BASE2K, ai, BASE2K, pm, dsize, BASE2K)
         elif auto_mode:
-            ref.glwe_automorphism(want, BASE2K, ai, BASE2K, pm, dsize, BASE2K, 5, auto_mode)
+            ref.glwe_automorphism(want, BASE2K, ai, BASE2K, pm, dsize, BASE2K, args.galois, auto_mode)
         elif ks:
             ref.glwe_keyswitch(want, BASE2K, ai, BASE2K, pm, dsize, BASE2K)
         else:
@@ -254,6 +254,7 @@ def main():
     ap.add_argument("--base2k", type=int, default=0)
     ap.add_argument("--limbs", type=int, default=0, help="override the number of limbs (and dnum); 16 = CKKS shape of BASELINE configs[4]; "
                                                          "0 = the metric configuration (8)")
+    ap.add_argument("--galois", type=int, default=5, help="Galois element of --op automorphism / automorphism_add (odd; negative = mod 2N)")
     ap.add_argument("--dsize", type=int, default=1, help="digit size of the key (dnum = limbs / dsize rows); > 1 runs the digit-selected middle kernel")
     ap.add_argument("--no-pin-key", action="store_true", help="rebuild the key's row-sliced copy on every call (pz_module_pin_key not used)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -396,7 +397,7 @@ def main():
         elif relin:
             mod.glwe_tensor_relinearize_batched(res_ptr, a_ptr, key_ptr, params, nct)
         elif auto_mode:
-            mod.glwe_automorphism_batched(res_ptr, a_ptr, key_ptr, params, 5, auto_mode, nct)
+            mod.glwe_automorphism_batched(res_ptr, a_ptr, key_ptr, params, args.galois, auto_mode, nct)
         elif ks:
             mod.glwe_keyswitch_batched(res_ptr, a_ptr, key_ptr, params, nct)
         else:
@@ -539,7 +540,7 @@ def main():
             "config": {"workload": (f"glwe_tensor_relinearize (rank 1: 3-column GLWETensor, tensor key 1 -> 1 via GGLWE VmpPMat), N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize={DSIZE}" if relin else
                                     f"ggsw_expand_row on batch/{DNUM} GGSWs of {DNUM} rows (rank {RANK_GLWE}: one key switch per row, body on column 1), N={N}, {SIZE} limbs, base2k={BASE2K}, key dnum={DNUM}" if expand else
                                     f"glwe_trace (log2 N steps of rsh + glwe_automorphism_add_assign, one key per step), N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}" if trace else
-                                    f"glwe_{args.op} (Galois element 5) via GGLWE VmpPMat, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize={DSIZE}" if auto_mode else
+                                    f"glwe_{args.op} (Galois element {args.galois}) via GGLWE VmpPMat, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize={DSIZE}" if auto_mode else
                                     f"GLWE(rank 1) key-switch via GGLWE VmpPMat, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize={DSIZE}" if ks else
                                     f"GLWE(rank 1) x GGSW external product, N={N}, {SIZE} limbs, base2k={BASE2K}, dnum={DNUM}, dsize={DSIZE}"),
                        "batch_per_gpu": args.batch,

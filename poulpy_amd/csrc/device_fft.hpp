@@ -675,7 +675,12 @@ k_inv_tail(TailArgs g) {
         // key-switch body limb: requested first so that its latency hides behind the butterfly
         long long sm[SMALL ? 2 * RE : 1];
         if (SMALL && small_col && j < g.small_size && g.pre_body) {
-            const long long* bsrc = col == g.body_col ? g.body_src + (long long)b * g.body_bs + (long long)j * g.body_ls : nullptr;
+            // body column: phi(body) (+ a0) either prepared by k_automorphism in the workspace (body_src) or, gather_mul != 0, gathered here
+            // from the body itself (column 0 of `small`) - the pre-pass and its round trip through HBM are gone, the 8-byte gathers are
+            // served by the XCD's L2 (all column blocks of one ciphertext column run on one XCD)
+            const bool isbody = col == g.body_col;
+            const long long* bsrc = (isbody && !g.gather_mul) ? g.body_src + (long long)b * g.body_bs + (long long)j * g.body_ls : nullptr;
+            const long long* gsrc = (isbody && g.gather_mul) ? g.small + (long long)b * g.small_bs + (long long)j * small_ls : nullptr;
 #pragma unroll
             for (int e = 0; e < RE; ++e) {
                 const long long idx = (long long)(b_ov + R2 * PZ_TAIL_N1(e)) * g.m2 + c0 + b_cv;
@@ -684,6 +689,11 @@ k_inv_tail(TailArgs g) {
                     const long long ih = idx + (h ? m : 0);
                     unsigned long long v = bsrc ? (unsigned long long)bsrc[ih]
                                                 : (g.body_only ? 0ull : (unsigned long long)small_col[(long long)j * small_ls + ih]);
+                    if (gsrc) {
+                        const unsigned i0 = ((unsigned)ih * g.gather_mul) & (unsigned)(2 * n - 1);
+                        const unsigned long long w = (unsigned long long)gsrc[(long long)(i0 & (unsigned)(n - 1))];
+                        v += ((i0 >= (unsigned)n) != (g.gather_neg != 0)) ? 0ull - w : w;
+                    }
                     if (g.small_neg) v = 0ull - v;
                     sm[2 * e + h] = (long long)v;
                 }

@@ -73,6 +73,8 @@ struct TailCall {
     const long long* body_src = nullptr;
     long long body_bs = 0, body_ls = 0;   // batch / limb strides of body_src
     bool body_only = false;               // only the body column has an operand (plain glwe_automorphism)
+    bool body_gather = false;             // instead of body_src: the tail gathers +-phi(body) from column 0 of `small` itself (gather_mul,
+                                          // gather_neg) - no pre-pass
     // ---- signs of X -> X^p (automorphism/glwe_ct.rs:96-275; TailArgs in device_fft.hpp) ----
     unsigned auto_mul = 0;            // != 0: the value enters the chain as s(n) (big + small), s(n) = -1 iff (n auto_mul) mod 2N >= N
     bool auto_neg = false;            // flips every s(n)

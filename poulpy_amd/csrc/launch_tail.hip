@@ -38,7 +38,7 @@ static int launch_inv_tail_cols(pz_module* M, const TailCall& c, int col_base, i
     g.small_all = c.small_all ? 1 : 0; g.auto_mul = c.auto_mul; g.auto_neg = c.auto_neg ? 1 : 0;
     g.col_base = col_base; g.col_count = col_count; g.body_col = c.body_col;
     g.gather_mul = c.gather_mul; g.gather_neg = c.gather_neg ? 1 : 0;
-    g.pre_body = c.body_src != nullptr ? 1 : 0; g.small_neg = c.small_neg ? 1 : 0;
+    g.pre_body = (c.body_src != nullptr || c.body_gather) ? 1 : 0; g.small_neg = c.small_neg ? 1 : 0;
     g.body_src = c.body_src; g.body_bs = c.body_bs; g.body_ls = c.body_ls;
     g.post_neg = c.post_neg ? 1 : 0; g.body_only = c.body_only ? 1 : 0; g.raw = raw ? 1 : 0;
     g.nz = nz ? 1 : 0;
