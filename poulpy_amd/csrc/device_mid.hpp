@@ -32,6 +32,9 @@ constexpr int kMidRS = PZ_MID_RS;
 #ifndef PZ_MIDR_HALFKEY
 #define PZ_MIDR_HALFKEY 0   // timing ablation (results invalid): every second key row of k_mid128r's product is never requested - what the product phase
 #endif                      // would cost with eight ciphertexts per key fetch, before any of that scheme's own costs
+#ifndef PZ_MIDR_ILV
+#define PZ_MIDR_ILV 1       // k_mid128r: inverse row pass of tile t and forward row pass of tile t + 1 interleaved (0: one after the other, rounds 3 - 4a)
+#endif
 #ifndef PZ_MIDR_KR
 #define PZ_MIDR_KR 6     // key-row slots of k_mid128r (rows requested KR - 1 ahead; build-time for A/B runs)
 #endif
@@ -671,13 +674,14 @@ k_mid128(MidArgs g) {
             lds_barrier();
             PZ_STAMP(1)
 #pragma unroll
-            for (int i = 0; i < CTt; ++i)
+            for (int i = 0; i < CTt; ++i) {
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
                     const int c = cg * NC + j;
                     const int q2o = PERM ? (int)((((g.perm_mul * (unsigned)q1 + g.perm_add) >> g.log_m1) + g.perm_mul * (unsigned)q2) & (unsigned)(M2 - 1)) : q2;
                     lds[((vtg * CTt + i) * NP + c) * RS + q2o] = (c < g.ncomp) ? acc[i][j] : make_double2(0.0, 0.0);
                 }
+            }
             lds_barrier();
             PZ_STAMP(2)
         }
@@ -1015,16 +1019,158 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
             lds_barrier();  // every a value has been read: the tile can be overwritten with the products
             PZ_STAMP(1)
 #pragma unroll
-            for (int i = 0; i < CTt; ++i)
+            for (int i = 0; i < CTt; ++i) {
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
                     const int c = cg * NC + j;
                     const int q2o = PERM ? (int)((((g.perm_mul * (unsigned)q1 + g.perm_add) >> g.log_m1) + g.perm_mul * (unsigned)q2) & (unsigned)(M2 - 1)) : q2;
                     lds[((vtg * CTt + i) * NP + c) * RS + q2o] = (c < g.ncomp) ? acc[i][j] : make_double2(0.0, 0.0);
                 }
+            }
             lds_barrier();
             PZ_STAMP(2)
         }
+#if PZ_MIDR_ILV
+        // ---------------- inverse row DFT of this tile and forward row DFT of the next one, INTERLEAVED (round 4) ----------------
+        // The two transforms work on different registers (u / x) and share only the wave's own rows of the tile, which the inverse pass
+        // is done with once it has read its second exchange back.  From there on every LDS batch of the forward pass is followed by a
+        // piece of the inverse pass's remaining arithmetic (last butterfly, inter-pass twiddles) instead of a wait: within the row passes
+        // VALU, LDS and the memory path used to take turns (their busy times ADD UP to the passes' 16 k cycles per tile).
+        // Same arithmetic in the same order per value: bit-identical.  Middle kernel 4.52 -> 4.38 ms per 1024 (profiles/r04_ab_midr_interleave.txt).
+        // Measured and dropped on the way (same file): the next tile's T' loads issued earlier - behind the last key rows of the product, or
+        // between the accumulator stores of the write-back - so that the forward pass's first butterfly could also fill the inverse pass's
+        // FIRST exchange wait: both lose the gain again (4.50 - 4.52 ms; the loads then compete with the key stream / delay the write-back).
+        for (int i = 0; i < nsleep; ++i) __builtin_amdgcn_s_sleep(2);
+        {
+            PZ_MID_LANE
+            const int b = (L % g.n_ct) * CT + ctl;
+            const cplx* src_ = src_ptr(L + W, ctl, rr, o);
+            const cplx* twr = twrow2 + par * M2;
+            if constexpr (IN) twn = g.tw12t[(long long)out_q1(tile_q1(min(L + W, ntiles - 1))) * M2 + max(tw_e, 0)];
+            if constexpr (IN) { PZ_XGROUP(src_, 0) PZ_XGROUP(src_, 1) }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) u[8 * h + k2] = rowbuf[o + 8 * h + 16 * k2];
+            if constexpr (PERM) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) u[t].y *= g.perm_ysign;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (IN) PZ_XGROUP(src_, 2)
+            __builtin_amdgcn_sched_barrier(0);
+            Bfly<8, true>::run(u);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (IN) PZ_XGROUP(src_, 3)
+            __builtin_amdgcn_sched_barrier(0);
+            Bfly<8, true>::run(u + 8);
+            row_sync();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k1 = o + 8 * h;
+                cplx tw_[8];
+#pragma unroll
+                for (int oo = 1; oo < 8; ++oo) tw_[oo] = wl[oo * k1];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int oo = 0; oo < 8; ++oo) {
+                    cplx v = u[8 * h + oo];
+                    if (oo > 0) v = cmulc(v, tw_[oo]);
+                    rowbuf[k1 * 9 + oo] = v;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            row_sync();
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) u[k1] = rowbuf[k1 * 9 + o];
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- the wave's rows are free from here: the forward pass of the next tile starts while u is still being finished ----
+            if constexpr (IN) {
+                if (!in_active(L + W, ctl, rr)) {
+#pragma unroll
+                    for (int n1 = 0; n1 < 16; ++n1) x[n1] = make_double2(0.0, 0.0);
+                }
+                Bfly<16, false>::run(x);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    cplx tw_[8];
+#pragma unroll
+                    for (int k1 = 8 * hb; k1 < 8 * hb + 8; ++k1) tw_[k1 - 8 * hb] = wl[o * k1];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k1 = 8 * hb; k1 < 8 * hb + 8; ++k1) {
+                        cplx v = x[k1];
+                        if (k1 > 0) v = cmul(v, tw_[k1 - 8 * hb]);
+                        rowbuf[k1 * 9 + o] = v;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // (forward exchange writes in flight) last butterfly of the inverse pass
+            Bfly<16, true>::run(u);
+            __builtin_amdgcn_sched_barrier(0);
+            cplx twa[8];
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) twa[n1] = twr[o + 8 * n1];
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (IN) {
+                row_sync();
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int oo = 0; oo < 8; ++oo) x[8 * h + oo] = rowbuf[(o + 8 * h) * 9 + oo];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // (forward exchange reads in flight) inter-pass twiddles of the inverse pass, first half; the second half's roots behind them
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) u[n1] = cmulc(u[n1], twa[n1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) twa[n1] = twr[o + 8 * (n1 + 8)];
+            __builtin_amdgcn_sched_barrier(0);
+            const bool active = b < g.batch && rr < g.npo;
+            dst = active ? g.T2 + ((long long)b * g.npo + rr) * m + (long long)out_q1(q1) * M2 + o
+                         : g.dummy + ((long long)blockIdx.x * (NT / 8) + row) * M2 + o;
+            PZ_SGROUP(0)
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (IN) Bfly<8, false>::run(x);
+            __builtin_amdgcn_sched_barrier(0);
+            PZ_SGROUP(1)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) u[n1 + 8] = cmulc(u[n1 + 8], twa[n1]);
+            if constexpr (IN) { if (tw_e >= 0) twrow2[(par ^ 1) * M2 + tw_e] = twn; }
+            __builtin_amdgcn_sched_barrier(0);
+            PZ_KGROUP(L + W, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (IN) Bfly<8, false>::run(x + 8);
+            __builtin_amdgcn_sched_barrier(0);
+            PZ_SGROUP(2)
+            PZ_KGROUP(L + W, 1)
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (IN) {
+                row_sync();
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) rowbuf[o + 16 * k2] = x[k2];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            PZ_SGROUP(3)
+            if constexpr (KR > 3) PZ_KGROUP(L + W, 2)
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (IN) {
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) rowbuf[o + 8 + 16 * k2] = x[8 + k2];
+            }
+            if constexpr (KR > 4) PZ_KGROUP(L + W, 3)
+            if constexpr (KR > 5) PZ_KGROUP(L + W, 4)
+            if constexpr (KR > 6) PZ_KGROUP(L + W, 5)
+            PZ_STAMP(3)
+            lds_barrier();
+        }
+#else
         // ---------------- inverse row DFT of the wave's own 8 rows; the next tile's loads go out in its gaps ----------------
         for (int i = 0; i < nsleep; ++i) __builtin_amdgcn_s_sleep(2);
         {
@@ -1097,6 +1243,7 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
         PZ_STAMP(3)
         // no workgroup barrier: the forward pass below only rewrites this wave's own rows, and it writes the OTHER twiddle row
         PZ_MIDR_FWD(L + W, 1)
+#endif
         PZ_STAMP(6)
 #if PZ_MID_STAMP
         ++st_tiles;
