@@ -32,6 +32,9 @@ constexpr int kMidRS = PZ_MID_RS;
 #ifndef PZ_MIDR_HALFKEY
 #define PZ_MIDR_HALFKEY 0   // timing ablation (results invalid): every second key row of k_mid128r's product is never requested - what the product phase
 #endif                      // would cost with eight ciphertexts per key fetch, before any of that scheme's own costs
+#ifndef PZ_MIDR_SADDR
+#define PZ_MIDR_SADDR 1     // k_mid128r product: uniform key-row base + 32-bit lane offsets, lane base + scalar row offset in LDS (0: 64-bit lane pointers, A/B)
+#endif
 #ifndef PZ_MIDR_ILV
 #define PZ_MIDR_ILV 1       // k_mid128r: inverse row pass of tile t and forward row pass of tile t + 1 interleaved (0: one after the other, rounds 3 - 4a)
 #endif
@@ -856,9 +859,15 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
         r_ -= (r_ >= nrow) ? nrow : 0;                                                                 \
         r_ -= (r_ >= nrow) ? nrow : 0;                                                                 \
         const int krow_ = DS ? (int)g.ds_row[r_] : r_;                                                 \
-        _Pragma("unroll") for (int j = 0; j < NC; ++j) {                                               \
-            const int c_ = DS ? min(vcg * NC + j, max((int)g.ds_cb[r_], 1) - 1) + (int)g.ds_coff[r_] : min(vcg * NC + j, g.ncomp - 1); \
-            kr[SLOT][j] = g.P[(base_ + (long long)krow_ * g.ncols + c_) * M2 + vq2];                   \
+        if constexpr (DS || !PZ_MIDR_SADDR) {                                                          \
+            _Pragma("unroll") for (int j = 0; j < NC; ++j) {                                           \
+                const int c_ = DS ? min(vcg * NC + j, max((int)g.ds_cb[r_], 1) - 1) + (int)g.ds_coff[r_] : min(vcg * NC + j, g.ncomp - 1); \
+                kr[SLOT][j] = g.P[(base_ + (long long)krow_ * g.ncols + c_) * M2 + vq2];               \
+            }                                                                                          \
+        } else {   /* uniform row base + one 32-bit lane offset per column: no 64-bit vector address arithmetic (see the product loop) */ \
+            const char* rp_ = (const char*)(g.P + (base_ + (long long)krow_ * g.ncols) * M2);          \
+            _Pragma("unroll") for (int j = 0; j < NC; ++j)                                             \
+                kr[SLOT][j] = *(const cplx*)(rp_ + (unsigned)(min(vcg * NC + j, g.ncomp - 1) * M2 + vq2) * 16u); \
         }                                                                                              \
     }
     // forward row DFT of x (see k_mid128) with the held-back stores (STORES) and the next product's first key rows in its gaps
@@ -958,6 +967,15 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
 #pragma unroll
             for (int j = 0; j < NC; ++j) pp[j] = g.P + ((long long)q1 * g.nrows * g.ncols + (DS ? 0 : min(cg * NC + j, g.ncomp - 1))) * M2 + q2;   // DS: the column is part of the per-term offset
             const long long prow = (long long)g.ncols * M2;
+            // plain product (round 4): the key row's address is a UNIFORM base (scalar registers, moved from row to row by scalar adds) plus
+            // one 32-bit lane offset per column, and the operand's LDS address a lane base plus a scalar row offset.  With a 64-bit lane
+            // pointer per column every load cost a 64-bit vector add, and the operand index a 64-bit multiply-add (quarter rate): 9 address
+            // instructions per row beside its 64 FMAs, on the unit that paces this phase.
+            const char* const kbase = (const char*)(g.P + (long long)q1 * g.nrows * g.ncols * M2);
+            unsigned koff[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) koff[j] = (unsigned)(min(cg * NC + j, g.ncomp - 1) * M2 + q2) * 16u;
+            const cplx* const avp = lds + vtg * CTt * NP * RS + q2;
             cplx av[2][CTt];
 #define PZ_LOADROW(DST, IT)                                                                     \
     if (!(PZ_MIDR_HALFKEY && ((IT) & 1))) {                                                     \
@@ -968,9 +986,12 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
             const int cb_ = max((int)g.ds_cb[r_], 1) - 1, co_ = (int)g.ds_coff[r_];             \
             const long long ro_ = (long long)g.ds_row[r_] * prow;                               \
             _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = pp[j][ro_ + (long long)(min(cg * NC + j, cb_) + co_) * M2]; \
-        } else {                                                                                \
+        } else if constexpr (!PZ_MIDR_SADDR) {                                                  \
             const long long off_ = (long long)r_ * prow;                                        \
             _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = pp[j][off_];                \
+        } else {                                                                                \
+            const char* rp_ = kbase + (long long)r_ * prow * 16;                                \
+            _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = *(const cplx*)(rp_ + koff[j]); \
         }                                                                                       \
     }
 #define PZ_AVLOAD(DST, IT)                                                                      \
@@ -979,7 +1000,12 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
         r_ -= (r_ >= nrow) ? nrow : 0;                                                          \
         r_ -= (r_ >= nrow) ? nrow : 0;                                                          \
         const int slot_ = DS ? (int)g.ds_in[r_] : r_;   /* DS: term r_ multiplies input polynomial ds_in[r_] */ \
-        _Pragma("unroll") for (int i = 0; i < CTt; ++i) DST[i] = lds[((vtg * CTt + i) * NP + slot_) * RS + q2]; \
+        if constexpr (!PZ_MIDR_SADDR) {                                                         \
+            _Pragma("unroll") for (int i = 0; i < CTt; ++i) DST[i] = lds[((vtg * CTt + i) * NP + slot_) * RS + q2]; \
+        } else {                                                                                \
+            const cplx* ar_ = avp + slot_ * RS;                                                 \
+            _Pragma("unroll") for (int i = 0; i < CTt; ++i) DST[i] = ar_[i * NP * RS];          \
+        }                                                                                       \
         __builtin_amdgcn_sched_barrier(0);   /* the machine scheduler otherwise sinks these reads down to their first use */ \
     }
 #define PZ_FMAROW(AV, SRC, IT)                                                                  \
