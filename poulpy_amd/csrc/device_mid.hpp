@@ -572,10 +572,17 @@ k_mid128(MidArgs g) {
                 // branch - 28.35 -> 25.25 ms (N = 2^14: 5 530 -> 5 930 rotations/s, N = 4096: 25 300 -> 27 300).  Four key slots on top: +1 %, not kept.
 #if PZ_MID_BR_AVPF
                 cplx avA[CTt], avB[CTt];
+            // (round 4, as in k_mid128r's product: lane base + scalar row offset for the operands, uniform key-row base + 32-bit lane offsets
+            //  for the key - no 64-bit vector address arithmetic beside the row's 64 floating-point instructions)
+            const cplx* const avp = lds + vtg * CTt * NP * RS + q2;
+            const char* const kbase = (const char*)(g.P + (long long)q1 * g.nrows * g.ncols * M2);
+            unsigned koff[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) koff[j] = (unsigned)((DS ? 0 : min(cg * NC + j, g.ncomp - 1)) * M2 + q2) * 16u;
 #define PZ_BR_AV(DST, SLOT_)                                                                     \
     {                                                                                            \
-        const int s_ = (SLOT_);                                                                  \
-        _Pragma("unroll") for (int i = 0; i < CTt; ++i) DST[i] = lds[((vtg * CTt + i) * NP + s_) * RS + q2]; \
+        const cplx* ar_ = avp + (SLOT_) * RS;                                                    \
+        _Pragma("unroll") for (int i = 0; i < CTt; ++i) DST[i] = ar_[i * NP * RS];               \
         __builtin_amdgcn_sched_barrier(0);                                                       \
     }
 #define PZ_BR_FMA(SRC, AV)                                                                       \
@@ -600,8 +607,8 @@ k_mid128(MidArgs g) {
                     long long ko = 0;   // offset of key row `it`
 #define PZ_BR_KROW(DST, OFF_)                                                                    \
     {                                                                                            \
-        const long long o_ = (OFF_);                                                             \
-        if (!(dbgv & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = pp[j][o_]; }  \
+        const char* rp_ = kbase + (OFF_) * 16;                                                   \
+        if (!(dbgv & 2)) { _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = *(const cplx*)(rp_ + koff[j]); }  \
         __builtin_amdgcn_sched_barrier(0);                                                       \
     }
                     for (int ci = 0; ci < g.br_blk; ++ci) {
