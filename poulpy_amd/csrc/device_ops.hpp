@@ -307,6 +307,44 @@ __global__ void __launch_bounds__(256) k_automorphism(AutoArgs g) {
     *reinterpret_cast<ulonglong2*>(dst + j) = make_ulonglong2(out[0], out[1]);
 }
 
+// The same map for Galois elements without locality (round 4).  k_automorphism lets consecutive lanes own consecutive OUTPUT coefficients and
+// gather their sources g apart: for g = 5^k, the steps of glwe_trace, ... every 8-byte load touches a line of its own and the 128 bytes that
+// come back from L2 per element (16 x the useful bytes) pace the kernel - 3.0 ms per 1024 ciphertexts x 8 limbs against 1.8 for g = 5.  Here
+// a thread owns a CHUNK of 4 consecutive outputs at j0 = g^-1 * 4e mod 2N (a multiple of 4), whose sources are 4e + x g (x = 0..3): for each x
+// the lanes of a wave read every fourth coefficient of one contiguous run (4 x amplification instead of 16), and the outputs (and the `add`
+// operand) move as whole 32-byte sectors.  Chunk e and chunk e + N/4 are the two halves of the index range mod 2N: e runs over [0, N/4)
+// and a wrapped base (j0 >= N) is the same position with every sign flipped.
+__global__ void __launch_bounds__(256) k_automorphism_chunk(AutoArgs g, unsigned hinv) {
+    const int bpp = g.n / 1024;   // blocks per polynomial (launcher: n >= 1024)
+    const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+    const int poly = (r / bpp) * 8 + xcd, blk = r % bpp;
+    if (poly >= g.npolys) return;
+    const long long* src = g.src + map_off(g.sm, poly);
+    long long* dst = g.dst + map_off(g.dm, poly);
+    const bool has_add = g.add != nullptr && (!(g.flags & 4) || (poly % g.am.ni) == 0);
+    const long long* add = has_add ? g.add + map_off(g.am, poly) : nullptr;
+    const unsigned mask2 = 2u * (unsigned)g.n - 1u, nn = (unsigned)g.n;
+    const unsigned e4 = 4u * (unsigned)(blk * 256 + threadIdx.x);
+    const unsigned j0v = (hinv * e4) & mask2;
+    const unsigned j0 = j0v & (nn - 1u);
+    const unsigned i0 = e4 + (j0v >= nn ? nn : 0u);
+    unsigned long long out[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const unsigned i = (i0 + (unsigned)x * g.mul) & mask2;
+        unsigned long long v = (unsigned long long)src[i & (nn - 1u)];
+        bool neg = (g.flags & 1) && i >= nn;
+        if (g.flags & 2) neg = !neg;
+        out[x] = neg ? 0ull - v : v;
+    }
+    if (has_add) {
+        const ulonglong2 w0 = *reinterpret_cast<const ulonglong2*>(add + j0), w1 = *reinterpret_cast<const ulonglong2*>(add + j0 + 2);
+        out[0] += w0.x; out[1] += w0.y; out[2] += w1.x; out[3] += w1.y;
+    }
+    *reinterpret_cast<ulonglong2*>(dst + j0) = make_ulonglong2(out[0], out[1]);
+    *reinterpret_cast<ulonglong2*>(dst + j0 + 2) = make_ulonglong2(out[2], out[3]);
+}
+
 // =================================================================================
 // vec_znx_rotate family with a per-ciphertext exponent (reference/znx/rotate.rs:3-27: res = X^k * src), gather form:
 //   res[j] = +-src[(j - k) mod 2n]   (negated when that index is >= n).

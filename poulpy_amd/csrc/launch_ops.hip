@@ -36,9 +36,25 @@ int launch_automorphism(pz_module* M, int npolys, const long long* src, PolyMap 
     AutoArgs g;
     g.src = src; g.dst = dst; g.add = add; g.sm = sm; g.dm = dm; g.am = am;
     g.npolys = npolys; g.n = (int)M->n; g.mul = mul; g.flags = flags;
+    KTimer kt(M, PZ_K_ELEMENTWISE);
+    // Galois elements whose gather has no locality (neither g nor -g small): chunks of 4 outputs per thread, sources read in runs
+    // (k_automorphism_chunk; POULPY_DBG_AUTO_CHUNK=0: always the plain gather, =2: always the chunked form)
+    static const int chunk_knob = getenv("POULPY_DBG_AUTO_CHUNK") ? atoi(getenv("POULPY_DBG_AUTO_CHUNK")) : 1;
+    const unsigned two_n = 2u * (unsigned)M->n, gm = mul & (two_n - 1u);
+    unsigned hinv = gm;   // g^-1 mod 2N by Newton's iteration (g odd): x <- x (2 - g x), 3 -> 6 -> 12 -> 24 -> 48 correct bits
+    for (int it = 0; it < 5; ++it) hinv *= 2u - gm * hinv;
+    hinv &= two_n - 1u;
+    // (the plain gather has locality when the multiplier OR its inverse is small in absolute value: sources g apart share lines, or
+    //  outputs g^-1 apart do and the workgroup's 512 outputs cover the 16 of a line: measured equal or better up to 25, profiles/r04_ab_auto_chunk.txt)
+    const unsigned dist = std::min(std::min(gm, two_n - gm), std::min(hinv, two_n - hinv));
+    if (M->n >= 1024 && (chunk_knob == 2 || (chunk_knob == 1 && dist > 32))) {
+        const int bpp = (int)(M->n / 1024);
+        hipLaunchKernelGGL(k_automorphism_chunk, dim3(((npolys + 7) / 8) * 8 * bpp), dim3(256), 0, M->stream, g, hinv);
+        PZ_HIP(hipGetLastError());
+        return PZ_OK;
+    }
     const int bpp = M->n >= 512 ? (int)(M->n / 512) : 1;
     const int blocks = ((npolys + 7) / 8) * 8 * bpp;
-    KTimer kt(M, PZ_K_ELEMENTWISE);
     hipLaunchKernelGGL(k_automorphism, dim3(blocks), dim3(256), 0, M->stream, g);
     PZ_HIP(hipGetLastError());
     return PZ_OK;
