@@ -515,7 +515,9 @@ __device__ __forceinline__ int sx_digit(int k, int x) { return (int)((unsigned)x
 __device__ __forceinline__ int sx_carry(int k, int x, int d) { return (x - d) >> k; }
 // NZ: the tensoring forms (TailArgs::raw / ::nz) are compiled in - a separate instantiation, so that the product tails keep their registers
 // (with the two run-time modes in the common kernel the N = 2^16 tail spilled 84 bytes)
-template <int R1, int R2, int CB, bool PROBE, bool ROWMAJOR = false, bool SMALL = false, bool RSH = false, bool NZ = false>
+// (NZ = 2: with the prefetch of the diagonal digits for NzCombine mode 5 - the pairwise launch; NZ = 1, the diagonal launches, is spared its
+//  32 registers: 88 bytes of scratch otherwise)
+template <int R1, int R2, int CB, bool PROBE, bool ROWMAJOR = false, bool SMALL = false, bool RSH = false, int NZ = 0>
 __global__ void __launch_bounds__(((R1 == 16 ? 2 : 1) * R2 + R1) * CB, ((((R1 == 16 ? 2 : 1) * R2 + R1) * CB >= 512) ? 1 : (SMALL ? 2 : 3)))
 k_inv_tail(TailArgs g) {
     static_assert(!RSH || SMALL, "the shifted store rides on the integer carry chain");
@@ -656,9 +658,9 @@ k_inv_tail(TailArgs g) {
         // requested HERE, at the top of the limb, so that their latency hides behind the butterfly - read at the store they were 32 dependent
         // HBM loads per thread and limb, and the pairwise launch ran at 2.8 TB/s against 4.6 for the diagonal ones (profiles/r04_tensor_*).
         // Low dwords only: the values are balanced base2k-bit digits (k <= 31 here; wider digits keep the loads at the store).
-        int d5a[NZ ? 2 * RE : 1], d5b[NZ ? 2 * RE : 1];
+        int d5a[NZ == 2 ? 2 * RE : 1], d5b[NZ == 2 ? 2 * RE : 1];
         bool d5 = false;
-        if (NZ && g.nz && g.nz_mode2[0] == 5 && k <= 31 && j >= g.nz_a_end && j < g.nz_a_start) {
+        if (NZ == 2 && g.nz && g.nz_mode2[0] == 5 && k <= 31 && j >= g.nz_a_end && j < g.nz_a_start) {
             d5 = true;
             const long long r5 = (long long)(j - g.nz_a_start + g.nz_res_start) * res_ls;
 #pragma unroll
@@ -667,8 +669,8 @@ k_inv_tail(TailArgs g) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const long long off5 = r5 + idx + (h ? m : 0);
-                    d5a[NZ ? 2 * e + h : 0] = reinterpret_cast<const int*>(nz_r2a + off5)[0];
-                    d5b[NZ ? 2 * e + h : 0] = nz_r2b ? reinterpret_cast<const int*>(nz_r2b + off5)[0] : 0;
+                    d5a[NZ == 2 ? 2 * e + h : 0] = reinterpret_cast<const int*>(nz_r2a + off5)[0];
+                    d5b[NZ == 2 ? 2 * e + h : 0] = nz_r2b ? reinterpret_cast<const int*>(nz_r2b + off5)[0] : 0;
                 }
             }
         }
@@ -785,7 +787,7 @@ k_inv_tail(TailArgs g) {
                     const long long x1_ = tz_digit(k, dpc_);                                                 \
                     if (j < g.nz_a_start) {                                                                  \
                         if (d5) tz_put(res_col + (long long)(j - g.nz_a_start + g.nz_res_start) * res_ls + idx, g.nz_mode,  \
-                                       (long long)((unsigned long long)x1_ - (unsigned long long)((long long)d5a[NZ ? 2 * n1 + h : 0] + (long long)d5b[NZ ? 2 * n1 + h : 0]))); \
+                                       (long long)((unsigned long long)x1_ - (unsigned long long)((long long)d5a[NZ == 2 ? 2 * n1 + h : 0] + (long long)d5b[NZ == 2 ? 2 * n1 + h : 0]))); \
                         else PZ_TAIL_NZ_STORE(j - g.nz_a_start + g.nz_res_start, idx, x1_)                    \
                     }                                                                                        \
                     c_ = (long long)((unsigned long long)cr_ + (unsigned long long)tz_carry(k, dpc_, x1_));  \
