@@ -825,10 +825,42 @@ k_inv_tail(TailArgs g) {
             }                                                                                                \
         }                                                                                                    \
     }
-        // (Round 4 experiment, removed - git history has it: the nz steps in f64 - d = digit_{k-lsh}(x), dpc = d 2^lsh + c, x1 = digit_k(dpc) with
-        //  digit_w(y) = y - floor((y + 2^(w-1)) 2^-w) 2^w: 12 f64 operations instead of ~45 integer ones, bit-exact - with the integer steps kept as
-        //  the fallback for values beyond 2^51.  Two carry-chain bodies in one kernel at the 168-register cap: 88 -> 140 bytes of scratch and the
-        //  three tensoring tails went from 4.4 to 5.0 ms per 256 pairs.  The instruction count was never the limit here; the registers are.)
+        // NZ = 1 (the diagonal launches of a tensoring): the same-base steps of vec_znx_normalize with a bit offset in f64, as the plain carry
+        // chain below - every value an exact integer below 2^51, digits of at most 31 bits.  Per coefficient (normalize.rs:50-144,
+        // znx/normalization.rs:107-221 with lsh):  d = digit_{k-lsh}(x), cr = carry_{k-lsh}(x);  dpc = d 2^lsh + c;  x1 = digit_k(dpc);
+        // c <- cr + carry_k(dpc), with digit_w(y) = y - floor((y + 2^(w-1)) 2^-w) 2^w - the value of the reference's shift pairs - about 12 f64
+        // operations where the integer form spends ~45 (64-bit shifts at quarter rate).  Built earlier in round 4 inside the one NZ
+        // instantiation, where it spilled (88 -> 140 B of scratch, tails 4.4 -> 5.0 ms); the instantiation without the mode-5 prefetch has the
+        // registers for it.  The integer steps stay as the fallback for values beyond 2^51 (the carries are converted once, for good).
+        // (Measured and dropped: the per-coefficient tests of the store forms - raw / carry-only / plain / minus the diagonal digits / the
+        //  NzCombine modes: ~10 scalar branches in front of every store, 4 000 in the instantiation - hoisted into one choice per limb with
+        //  straight-line bodies.  The compiler then keeps every chain of a thread in flight: 290 - 550 B of scratch whatever the
+        //  sched_barriers; the branches are what bounds its live ranges here.)
+        const bool nzf = NZ == 1 && g.nz != 0;
+        if (nzf && !icarry && big < 2251799813685247.0) {
+            if (j >= g.nz_a_end) {
+                const int kk_ = k - g.nz_lsh;
+                const double halfkk = (double)(1ull << (kk_ - 1)), twokk = 2.0 * halfkk, invkk = 1.0 / twokk, lshmul = (double)(1ull << g.nz_lsh);
+#pragma unroll
+                for (int n1 = 0; n1 < RE; ++n1) {
+                    const int j1 = b_ov + R2 * PZ_TAIL_N1(n1);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const long long idx = (long long)j1 * g.m2 + c0 + b_cv + (h ? m : 0);
+                        const double r = round_half_away(h ? v[n1].y : v[n1].x);
+                        const double q = floor((r + halfkk) * invkk);
+                        const double dd = __builtin_fma(-q, twokk, r);
+                        const double dpc = __builtin_fma(dd, lshmul, __longlong_as_double(carry[2 * n1 + h]));
+                        const double q2 = floor((dpc + halfd) * invk);
+                        carry[2 * n1 + h] = __double_as_longlong(q + q2);
+                        if (j < g.nz_a_start) {
+                            const long long x1_ = (long long)(int)__builtin_fma(-q2, twok, dpc);
+                            PZ_TAIL_NZ_STORE(j - g.nz_a_start + g.nz_res_start, idx, x1_)
+                        }
+                    }
+                }
+            }
+        } else
         if (FCARRY && !icarry && !(NZ && (g.raw || g.nz)) && big < 2251799813685247.0) {
 #pragma unroll
             for (int n1 = 0; n1 < RE; ++n1) {
@@ -849,7 +881,7 @@ k_inv_tail(TailArgs g) {
                 }
             }
         } else {
-            if (FCARRY && !icarry && !(NZ && (g.raw || g.nz))) {   // leave the f64 chain: the carries become integers, for good
+            if (FCARRY && !icarry && !(NZ && (g.raw || (g.nz && !nzf)))) {   // leave the f64 chain: the carries become integers, for good
                 icarry = true;
 #pragma unroll
                 for (int u = 0; u < 2 * RE; ++u) carry[u] = fast_i64_from_integral(__longlong_as_double(carry[u]));
@@ -871,7 +903,7 @@ k_inv_tail(TailArgs g) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const long long idx = (long long)j1 * g.m2 + c0 + b_c + (h ? m : 0);
-                long long c_ = carry[2 * n1 + h];
+                long long c_ = (NZ == 1 && !icarry) ? fast_i64_from_integral(__longlong_as_double(carry[2 * n1 + h])) : carry[2 * n1 + h];
                 for (int jj = 0; jj < g.nz_res_end; ++jj) {
                     const long long x1_ = tz_digit(k, c_);
                     PZ_TAIL_NZ_STORE(g.nz_res_end - jj - 1, idx, x1_)
