@@ -515,8 +515,9 @@ __device__ __forceinline__ int sx_digit(int k, int x) { return (int)((unsigned)x
 __device__ __forceinline__ int sx_carry(int k, int x, int d) { return (x - d) >> k; }
 // NZ: the tensoring forms (TailArgs::raw / ::nz) are compiled in - a separate instantiation, so that the product tails keep their registers
 // (with the two run-time modes in the common kernel the N = 2^16 tail spilled 84 bytes)
-// (NZ = 2: with the prefetch of the diagonal digits for NzCombine mode 5 - the pairwise launch; NZ = 1, the diagonal launches, is spared its
-//  32 registers: 88 bytes of scratch otherwise)
+// (NZ = 2: every NzCombine mode, with the prefetch of the diagonal digits for mode 5 - the pairwise launch; NZ = 1: digits stored as they are
+//  (mode 1, no second column: the diagonal launches of apply / square) - spared the prefetch's 32 registers (88 bytes of scratch otherwise)
+//  and the tests in front of every store)
 template <int R1, int R2, int CB, bool PROBE, bool ROWMAJOR = false, bool SMALL = false, bool RSH = false, int NZ = 0>
 __global__ void __launch_bounds__(((R1 == 16 ? 2 : 1) * R2 + R1) * CB, ((((R1 == 16 ? 2 : 1) * R2 + R1) * CB >= 512) ? 1 : (SMALL ? 2 : 3)))
 k_inv_tail(TailArgs g) {
@@ -616,7 +617,9 @@ k_inv_tail(TailArgs g) {
     {                                                                                              \
         const long long off_ = (long long)(R_) * res_ls + (IDX_);                                  \
         long long v_ = (V_);                                                                       \
-        if (g.nz_mode2[0] == 5) {   /* mode 5: a column whose digits are SUBTRACTED from the value on its way to the main column */ \
+        if (NZ == 1) {   /* the launcher sends only plain stores here (mode 1, no second column): no test in front of the store */ \
+            st_stream(res_col + off_, v_);                                                         \
+        } else if (g.nz_mode2[0] == 5) {   /* mode 5: a column whose digits are SUBTRACTED from the value on its way to the main column */ \
             v_ = (long long)((unsigned long long)v_ - (unsigned long long)nz_r2a[off_]);           \
             if (nz_r2b) v_ = (long long)((unsigned long long)v_ - (unsigned long long)nz_r2b[off_]); \
             tz_put(res_col + off_, g.nz_mode, v_);                                                 \

@@ -75,7 +75,7 @@ static int launch_inv_tail_cols(pz_module* M, const TailCall& c, int col_base, i
 #define X(A, B, C)                                                                                              \
     if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
         const size_t lds = ((size_t)2 * (A + 1) * C * B + 2 * A * B) * sizeof(cplx);                            \
-        if (nz && nz->mode2[0] == 5 && c.base2k <= 31) {   /* pairwise term: with the prefetch of the diagonal digits */ \
+        if (raw || !(nz->mode == 1 && nz->mode2[0] == 0 && nz->mode2[1] == 0)) {   /* raw values, or any NzCombine mode (pairwise term: with the prefetch of the diagonal digits) */ \
             PZ_TRY(set_lds((k_inv_tail<A, B, C, false, true, false, false, 2>), lds));                          \
             hipLaunchKernelGGL((k_inv_tail<A, B, C, false, true, false, false, 2>), dim3(blocks), dim3(TailShape<A, B, C>::NT), lds, M->stream, g); \
         } else {                                                                                                \
