@@ -757,6 +757,13 @@ k_inv_tail(TailArgs g) {
             v[e] = cmul(v[e], twi[b_ov + R2 * PZ_TAIL_N1(e)]);
             big = fmax(big, fmax(fabs(v[e].x), fabs(v[e].y)));
         }
+        if (NZ == 2 && d5) {   // the two diagonal digits are only ever used as their sum: one register per coefficient from here on (the
+                               // pairwise instantiation's 88 B of scratch were 2.7 GB of extra HBM writes per launch, profiles/r04_tensor_traffic.json)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < (NZ == 2 ? 2 * RE : 1); ++t) d5a[t] += d5b[t];
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const unsigned long long half = 1ull << (k - 1), mask = (1ull << k) - 1;
         // One pass per coefficient: round, convert, (+ body), carry step, store.  digit(x) = ((x + 2^(k-1)) mod 2^k) -
         // 2^(k-1), carry(x) = (x + 2^(k-1)) >> k: the values of the reference's shift pairs
@@ -790,7 +797,7 @@ k_inv_tail(TailArgs g) {
                     const long long x1_ = tz_digit(k, dpc_);                                                 \
                     if (j < g.nz_a_start) {                                                                  \
                         if (d5) tz_put(res_col + (long long)(j - g.nz_a_start + g.nz_res_start) * res_ls + idx, g.nz_mode,  \
-                                       (long long)((unsigned long long)x1_ - (unsigned long long)((long long)d5a[NZ == 2 ? 2 * n1 + h : 0] + (long long)d5b[NZ == 2 ? 2 * n1 + h : 0]))); \
+                                       (long long)((unsigned long long)x1_ - (unsigned long long)(long long)d5a[NZ == 2 ? 2 * n1 + h : 0])); \
                         else PZ_TAIL_NZ_STORE(j - g.nz_a_start + g.nz_res_start, idx, x1_)                    \
                     }                                                                                        \
                     c_ = (long long)((unsigned long long)cr_ + (unsigned long long)tz_carry(k, dpc_, x1_));  \
