@@ -518,11 +518,14 @@ __device__ __forceinline__ int sx_carry(int k, int x, int d) { return (x - d) >>
 // (NZ = 2: every NzCombine mode, with the prefetch of the diagonal digits for mode 5 - the pairwise launch; NZ = 1: digits stored as they are
 //  (mode 1, no second column: the diagonal launches of apply / square) - spared the prefetch's 32 registers (88 bytes of scratch otherwise)
 //  and the tests in front of every store)
-template <int R1, int R2, int CB, bool PROBE, bool ROWMAJOR = false, bool SMALL = false, bool RSH = false, int NZ = 0>
+// SGN (round 4): the signs of X -> X^p (TailArgs::auto_mul / auto_neg / post_neg) without an operand - the columns of a plain spectral
+// glwe_automorphism that carry no body: they ride on the f64 chain like a product's columns instead of the operand variant's integer chain
+template <int R1, int R2, int CB, bool PROBE, bool ROWMAJOR = false, bool SMALL = false, bool RSH = false, int NZ = 0, bool SGN = false>
 __global__ void __launch_bounds__(((R1 == 16 ? 2 : 1) * R2 + R1) * CB, ((((R1 == 16 ? 2 : 1) * R2 + R1) * CB >= 512) ? 1 : (SMALL ? 2 : 3)))
 k_inv_tail(TailArgs g) {
     static_assert(!RSH || SMALL, "the shifted store rides on the integer carry chain");
     static_assert(!NZ || (ROWMAJOR && !SMALL && !RSH && !PROBE), "tensoring forms: row-major pipeline layout, no operand");
+    static_assert(!SGN || (ROWMAJOR && !SMALL && !RSH && !PROBE && !NZ), "sign-only form: row-major pipeline layout, no operand");
     constexpr bool SPLIT = TailShape<R1, R2, CB>::SPLIT;
     constexpr int RE = TailShape<R1, R2, CB>::RE;
     constexpr int NB = TailShape<R1, R2, CB>::NB;
@@ -655,7 +658,7 @@ k_inv_tail(TailArgs g) {
         // (SMALL: the per-output address arithmetic is loop-invariant and would be hoisted out of the limb loop into ~32
         //  live registers; an opaque copy of the lane coordinates per limb makes the compiler recompute it instead)
         int b_ov = b_o, b_cv = b_c;
-        if (SMALL || NZ) asm volatile("" : "+v"(b_ov), "+v"(b_cv));
+        if (SMALL || NZ || SGN) asm volatile("" : "+v"(b_ov), "+v"(b_cv));
         const cplx* buf = xch + (j & 1) * XCH;
         // NZ, mode 5 (the pairwise term of a tensoring reads the two diagonal columns' digits at its own store position and subtracts them):
         // requested HERE, at the top of the limb, so that their latency hides behind the butterfly - read at the store they were 32 dependent
@@ -779,7 +782,7 @@ k_inv_tail(TailArgs g) {
             long long x = CONVERT(r);                                                                        \
             if (SMALL && add_small) x = (long long)((unsigned long long)x + (unsigned long long)sm[SMALL ? 2 * n1 + h : 0]); \
             bool ng_ = false;                                                                                \
-            if (SMALL && g.auto_mul) {                                                                       \
+            if ((SMALL || SGN) && g.auto_mul) {                                                              \
                 ng_ = (((unsigned)idx * g.auto_mul) & (unsigned)(2 * n - 1)) >= (unsigned)n;                 \
                 if (ng_ != (g.auto_neg != 0)) x = (long long)(0ull - (unsigned long long)x);                 \
             }                                                                                                \
@@ -814,7 +817,7 @@ k_inv_tail(TailArgs g) {
                 const unsigned long long y2 = (unsigned long long)d + (unsigned long long)cy + half;         \
                 long long x1 = (long long)(y2 & mask) - (long long)half;                                     \
                 cy = (long long)((unsigned long long)cr + (unsigned long long)((long long)y2 >> k));         \
-                if (SMALL && g.post_neg && ng_) x1 = (long long)(0ull - (unsigned long long)x1);             \
+                if ((SMALL || SGN) && g.post_neg && ng_) x1 = (long long)(0ull - (unsigned long long)x1);    \
                 if (RSH) {                                                                                   \
                     if (writes) {                                                                            \
                         int& c2 = cy2[RSH ? 2 * n1 + h : 0];                                                 \
@@ -879,13 +882,19 @@ k_inv_tail(TailArgs g) {
                 for (int h = 0; h < 2; ++h) {
                     const long long idx = (long long)j1 * g.m2 + c0 + b_cv + (h ? m : 0);
                     const double val = h ? v[n1].y : v[n1].x;
-                    const double r = round_half_away(val);
+                    double r = round_half_away(val);
                     if (PROBE) worst = fmax(worst, fabs(val - r));
+                    bool ng_ = false;
+                    if (SGN) {   // s(n) in front of the chain, and back on the digit (the integer path's steps, on the f64 chain)
+                        ng_ = (((unsigned)idx * g.auto_mul) & (unsigned)(2 * n - 1)) >= (unsigned)n;
+                        if (ng_ != (g.auto_neg != 0)) r = -r;
+                    }
                     const double vv = r + __longlong_as_double(carry[2 * n1 + h]);
                     const double q = floor((vv + halfd) * invk);
                     carry[2 * n1 + h] = __double_as_longlong(q);
                     if (writes) {
-                        const long long x1 = (long long)(int)__builtin_fma(-q, twok, vv);
+                        long long x1 = (long long)(int)__builtin_fma(-q, twok, vv);
+                        if (SGN && g.post_neg && ng_) x1 = -x1;
                         if (ROWMAJOR) st_stream(res_col + (long long)j * res_ls + idx, x1); else res_col[(long long)j * res_ls + idx] = x1;
                     }
                 }

@@ -70,6 +70,19 @@ static int launch_inv_tail_cols(pz_module* M, const TailCall& c, int col_base, i
 #undef X
         return fail(PZ_ERR_UNSUPPORTED, "fused tail: no shifted-store variant for this plan");
     }
+    if (!has_small && c.auto_mul != 0) {   // signs without an operand (launch_inv_tail: the body-less columns of a plain spectral automorphism)
+        if (!(rowmajor && !M->probe && !raw && !nz && tail_rsh_supported(M))) return fail(PZ_ERR_UNSUPPORTED, "fused tail: no sign-only variant for this plan");
+#define X(A, B, C)                                                                                              \
+    if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
+        const size_t lds = ((size_t)2 * (A + 1) * C * B + 2 * A * B) * sizeof(cplx);                            \
+        PZ_TRY(set_lds((k_inv_tail<A, B, C, false, true, false, false, 0, true>), lds));                        \
+        hipLaunchKernelGGL((k_inv_tail<A, B, C, false, true, false, false, 0, true>), dim3(blocks), dim3(TailShape<A, B, C>::NT), lds, M->stream, g); \
+        PZ_HIP(hipGetLastError());                                                                              \
+        return PZ_OK;                                                                                           \
+    }
+        PZ_RSH_CASES(X)
+#undef X
+    }
     if (raw || nz) {   // the tensoring forms: their own instantiation of the row-major, operand-free tail
         if (!(rowmajor && !has_small && !M->probe)) return fail(PZ_ERR_UNSUPPORTED, "fused tail: the tensoring forms need the row-major layout");
 #define X(A, B, C)                                                                                              \
@@ -124,6 +137,18 @@ int launch_inv_tail(pz_module* M, const TailCall& c) {
         plain.small = nullptr; plain.small_bs = 0; plain.auto_mul = 0; plain.auto_neg = false; plain.body_col = 0;
         if (c.body_col > 0) PZ_TRY(launch_inv_tail_cols(M, plain, 0, c.body_col));
         return launch_inv_tail_cols(M, plain, c.body_col + 1, c.ncols - 1 - c.body_col);
+    }
+    // plain spectral glwe_automorphism (only the body column has an operand): that column on the operand variant, the others on the
+    // sign-only variant of the f64 chain (POULPY_DBG_AUTO_SGN=0: every column on the operand variant, as in round 3)
+    static const int sgn_knob = getenv("POULPY_DBG_AUTO_SGN") ? atoi(getenv("POULPY_DBG_AUTO_SGN")) : 1;
+    if (sgn_knob && c.small != nullptr && c.small_all && c.body_only && c.auto_mul != 0 && c.ncols > 1 && !c.post_rsh && c.rowmajor &&
+        !M->probe && tail_rsh_supported(M)) {
+        PZ_TRY(launch_inv_tail_cols(M, c, c.body_col, 1));
+        TailCall rest = c;
+        rest.small = nullptr; rest.small_bs = 0; rest.small_all = false; rest.small_size = 0;
+        rest.body_src = nullptr; rest.body_bs = rest.body_ls = 0; rest.body_only = false; rest.body_gather = false; rest.gather_mul = 0;
+        if (c.body_col > 0) PZ_TRY(launch_inv_tail_cols(M, rest, 0, c.body_col));
+        return launch_inv_tail_cols(M, rest, c.body_col + 1, c.ncols - 1 - c.body_col);
     }
     return launch_inv_tail_cols(M, c, 0, c.ncols);
 }
