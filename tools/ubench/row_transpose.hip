@@ -26,6 +26,20 @@ __device__ __forceinline__ void transpose_lds(cplx (&x)[16], cplx* rowbuf, int o
     row_sync();
 }
 
+// the same exchange with the real and imaginary parts in two planes: 8-byte LDS accesses, contiguous over the 8 lanes of a row
+__device__ __forceinline__ void transpose_lds_planar(cplx (&x)[16], double* re, double* im, int o) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int oo = 0; oo < 8; ++oo) { re[(8 * h + oo) * 9 + o] = x[8 * h + oo].x; im[(8 * h + oo) * 9 + o] = x[8 * h + oo].y; }
+    row_sync();
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int oo = 0; oo < 8; ++oo) { x[8 * h + oo].x = re[(8 * h + o) * 9 + oo]; x[8 * h + oo].y = im[(8 * h + o) * 9 + oo]; }
+    row_sync();
+}
+
 template <int CTRL, int BANK>
 __device__ __forceinline__ int dpp(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xf, BANK, false); }
 
@@ -74,7 +88,7 @@ __device__ __forceinline__ void transpose_dpp(cplx (&x)[16], int o) {
         }
 }
 
-template <int MODE>   // 0: LDS, 1: DPP, 2: neither (loop overhead)
+template <int MODE>   // 0: LDS, 1: DPP, 2: neither (loop overhead), 3: LDS, planar (two 8-byte accesses per value)
 __global__ void __launch_bounds__(512) k_transpose(cplx* out, int iters) {
     extern __shared__ cplx lds[];
     const int tid = threadIdx.x, row = tid >> 3, o = tid & 7;
@@ -85,6 +99,7 @@ __global__ void __launch_bounds__(512) k_transpose(cplx* out, int iters) {
     for (int it = 0; it < iters; ++it) {
         if (MODE == 0) transpose_lds(x, rowbuf, o);
         if (MODE == 1) transpose_dpp(x, o);
+        if (MODE == 3) transpose_lds_planar(x, (double*)rowbuf, (double*)rowbuf + 144, o);
 #pragma unroll
         for (int i = 0; i < 16; ++i) { x[i].x += 1.0; asm volatile("" : "+v"(x[i].y)); }
     }
@@ -94,7 +109,7 @@ __global__ void __launch_bounds__(512) k_transpose(cplx* out, int iters) {
 
 int main() {
     const int grid = 256, iters = 2000;
-    cplx* out[3];
+    cplx* out[4];
     for (auto& p : out) hipMalloc(&p, (size_t)grid * 512 * 16 * sizeof(cplx));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const size_t lds = 64 * 144 * sizeof(cplx);
@@ -102,13 +117,15 @@ int main() {
     (void)hipFuncSetAttribute((const void*)k_transpose<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)k_transpose<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)k_transpose<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    float ms[3];
-    for (int mode = 0; mode < 3; ++mode) {
+    (void)hipFuncSetAttribute((const void*)k_transpose<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    float ms[4];
+    for (int mode = 0; mode < 4; ++mode) {
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0);
             if (mode == 0) k_transpose<0><<<grid, 512, lds>>>(out[0], iters);
             if (mode == 1) k_transpose<1><<<grid, 512, lds>>>(out[1], iters);
             if (mode == 2) k_transpose<2><<<grid, 512, lds>>>(out[2], iters);
+            if (mode == 3) k_transpose<3><<<grid, 512, lds>>>(out[3], iters);
             hipEventRecord(e1); hipEventSynchronize(e1);
             hipEventElapsedTime(&ms[mode], e0, e1);
         }
@@ -128,6 +145,13 @@ int main() {
         printf("%-28s %8.3f ms for %d transposes of a 64-row tile per CU  -> %7.0f cycles per transpose (2 waves per SIMD in lockstep)\n",
                mode == 0 ? "LDS (stride 9, b128)" : mode == 1 ? "DPP (xor 1, 2, 4 stages)" : "neither (loop + increments)", ms[mode], iters,
                ms[mode] * clk / iters);
+    k_transpose<3><<<grid, 512, lds>>>(out[3], 1);
+    hipDeviceSynchronize();
+    hipMemcpy(b.data(), out[3], b.size() * sizeof(cplx), hipMemcpyDeviceToHost);
+    bad = 0;
+    for (size_t i = 0; i < a.size(); ++i) bad += (a[i].x != b[i].x || a[i].y != b[i].y);
+    printf("planar LDS transpose == LDS transpose: %s (%zu differ); %8.3f ms -> %7.0f cycles per transpose, net %.0f\n", bad ? "NO" : "yes", bad, ms[3],
+           ms[3] * clk / iters, (ms[3] - ms[2]) * clk / iters);
     printf("net: LDS %.0f cycles, DPP %.0f cycles per transpose; k_mid128r does 4 such transposes per tile of ~29 700 cycles\n",
            (ms[0] - ms[2]) * clk / iters, (ms[1] - ms[2]) * clk / iters);
     return 0;
