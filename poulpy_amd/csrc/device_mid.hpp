@@ -791,10 +791,10 @@ k_mid128(MidArgs g) {
 // s_waitcnt insertion assume the worst case at every join (k_mid128, SKIPW).
 template <int CT, int NP, bool PERM, int NR, int KR, bool HALFIN, bool IN, bool DS = false>
 __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
-    constexpr int M2 = 128, NT = 512;
-    constexpr int NC = NP == 32 ? 8 : 4;   // outputs per thread (32-slot tile: two ciphertexts x 8 outputs, as in k_mid128)
+    constexpr int M2 = 128, NT = CT * NP * 8;   // 512 threads (64 rows), or 256 (32 rows: two workgroups per CU, round-4 experiment)
+    constexpr int NC = (NP * M2 / NT) > 4 ? (NP * M2 / NT) : 4;   // outputs per thread (32-slot tile: two ciphertexts x 8 outputs, as in k_mid128)
     constexpr int GC = NP / NC, GT = (NT / M2) / GC, CTt = CT / GT;
-    static_assert(CT * NP * 8 == NT && GC * GT == NT / M2 && CTt * GT == CT && KR >= 3 && KR <= 7 && KR <= NR, "k_mid128r tile shape");
+    static_assert((NT == 512 || NT == 256) && GC * GT == NT / M2 && CTt * GT == CT && KR >= 3 && KR <= 7 && KR <= NR, "k_mid128r tile shape");
     constexpr int RS = kMidRS;
     extern __shared__ cplx lds[];      // CT*NP rows x RS | wL2[128] | tw12t rows [2][128]
     const int tid0 = threadIdx.x;
@@ -1313,8 +1313,8 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
 // (32-slot tiles - 16 limbs, rank 2-3 - carry 8 key values per thread and row: a ring of 3 slots there)
 // DS (round 3, late): the digit-group product of dsize > 1 (MidArgs::ds_*: NR product terms, each with its input slot, key row, column
 // offset and column bound) - the addressing of k_mid128<.., DS> on this kernel's schedule.
-template <int CT, int NP, bool PERM, int NR, bool HALFIN = false, int KR = (NP == 32 ? 3 : PZ_MIDR_KR), bool DS = false>
-__global__ void __launch_bounds__(512)
+template <int CT, int NP, bool PERM, int NR, bool HALFIN = false, int KR = ((NP == 32 || CT * NP * 8 == 256) ? 3 : PZ_MIDR_KR), bool DS = false>
+__global__ void __launch_bounds__(CT * NP * 8)
 k_mid128r(MidArgs g) {
     static_assert(!HALFIN || NP >= 16, "HALFIN: 16- and 32-slot tiles");
     static_assert(!DS || !PERM, "digit groups: plain product only");

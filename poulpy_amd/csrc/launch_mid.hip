@@ -109,6 +109,19 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
         if (perm_) { if (skipw_) PZ_MID128_GO(CT_, NP_, true, true) else PZ_MID128_GO(CT_, NP_, true, false) }             \
         else       { if (skipw_) PZ_MID128_GO(CT_, NP_, false, true) else PZ_MID128_GO(CT_, NP_, false, false) }           \
     }
+        // experiment (POULPY_DBG_MID_CT2=1): the plain 16 x 16 product on 256-thread workgroups - two ciphertexts per tile, two workgroups per
+        // CU that are not coupled by barriers (k_mid128r<2,16>; twice the key fetches per ciphertext)
+        static const bool mid_ct2 = getenv("POULPY_DBG_MID_CT2") && atoi(getenv("POULPY_DBG_MID_CT2")) == 1;
+        if (mid_ct2 && mid_r && !br && !ds && !perm && npi == 16 && npo == 16 && g.row_max == 16 && g.ncomp == 16) {
+            g.n_ct = (batch + 1) / 2;
+            const size_t lds = ((size_t)2 * 16 * kMidRS + 384 + 32) * sizeof(cplx);
+            const dim3 grid_(std::min({2 * ncu, 512, g.m1 * g.n_ct}));
+            PZ_TRY(set_lds((k_mid128r<2, 16, false, 16, false>), lds));
+            hipLaunchKernelGGL((k_mid128r<2, 16, false, 16, false>), grid_, dim3(256), lds, M->stream, g);
+            dispatch_note(M, "k_mid128r<CT=2,NP=16,NR=16,KR=3> (256 threads, two workgroups per CU)");
+            PZ_HIP(hipGetLastError());
+            return PZ_OK;
+        }
 #define PZ_MID128_LAUNCH(CT_, NP_)                                                                                         \
     {                                                                                                                      \
         g.n_ct = (batch + CT_ - 1) / CT_;                                                                                  \
