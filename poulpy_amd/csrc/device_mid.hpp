@@ -866,11 +866,16 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
         r_ -= (r_ >= nrow) ? nrow : 0;                                                                 \
         r_ -= (r_ >= nrow) ? nrow : 0;                                                                 \
         const int krow_ = DS ? (int)g.ds_row[r_] : r_;                                                 \
-        if constexpr (DS || !PZ_MIDR_SADDR) {                                                          \
+        if constexpr (!PZ_MIDR_SADDR) {                                                                \
             _Pragma("unroll") for (int j = 0; j < NC; ++j) {                                           \
                 const int c_ = DS ? min(vcg * NC + j, max((int)g.ds_cb[r_], 1) - 1) + (int)g.ds_coff[r_] : min(vcg * NC + j, g.ncomp - 1); \
                 kr[SLOT][j] = g.P[(base_ + (long long)krow_ * g.ncols + c_) * M2 + vq2];               \
             }                                                                                          \
+        } else if constexpr (DS) {                                                                     \
+            const int cb_ = max((int)g.ds_cb[r_], 1) - 1;                                              \
+            const char* rp_ = (const char*)(g.P + (base_ + (long long)krow_ * g.ncols + (int)g.ds_coff[r_]) * M2); \
+            _Pragma("unroll") for (int j = 0; j < NC; ++j)                                             \
+                kr[SLOT][j] = *(const cplx*)(rp_ + (unsigned)(min(vcg * NC + j, cb_) * M2 + vq2) * 16u); \
         } else {   /* uniform row base + one 32-bit lane offset per column: no 64-bit vector address arithmetic (see the product loop) */ \
             const char* rp_ = (const char*)(g.P + (base_ + (long long)krow_ * g.ncols) * M2);          \
             _Pragma("unroll") for (int j = 0; j < NC; ++j)                                             \
@@ -989,10 +994,15 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
         int r_ = (IT) + rot;                                                                    \
         r_ -= (r_ >= nrow) ? nrow : 0;                                                          \
         r_ -= (r_ >= nrow) ? nrow : 0;                                                          \
-        if constexpr (DS) {                                                                     \
+        if constexpr (DS && !PZ_MIDR_SADDR) {                                                   \
             const int cb_ = max((int)g.ds_cb[r_], 1) - 1, co_ = (int)g.ds_coff[r_];             \
             const long long ro_ = (long long)g.ds_row[r_] * prow;                               \
             _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = pp[j][ro_ + (long long)(min(cg * NC + j, cb_) + co_) * M2]; \
+        } else if constexpr (DS) {   /* uniform base of the term's key row and column window, lane offset of the (clamped) column */ \
+            const int cb_ = max((int)g.ds_cb[r_], 1) - 1;                                       \
+            const char* rp_ = kbase + ((long long)g.ds_row[r_] * prow + (long long)g.ds_coff[r_] * M2) * 16; \
+            _Pragma("unroll") for (int j = 0; j < NC; ++j)                                      \
+                DST[j] = *(const cplx*)(rp_ + (unsigned)(min(cg * NC + j, cb_) * M2 + q2) * 16u); \
         } else if constexpr (!PZ_MIDR_SADDR) {                                                  \
             const long long off_ = (long long)r_ * prow;                                        \
             _Pragma("unroll") for (int j = 0; j < NC; ++j) DST[j] = pp[j][off_];                \
