@@ -364,7 +364,7 @@ static int wave_spectral_tail(const GlweCall& c, const FusedBufs& f, size_t b0, 
     // (never in place: other workgroups would gather from a body that this launch is already overwriting)
     const int64_t* a_end = c.a + (long long)c.batch * c.a_bs;
     const int64_t* r_end = c.res + (long long)c.batch * c.res_bs;
-    const bool fold = fold_knob != 0 && (c.res >= a_end || c.a >= r_end);
+    const bool fold = fold_knob != 0 && (c.res >= a_end || c.a >= r_end) && !c.want_rsh;   // (not for glwe_trace: the shifted-store variant has no gathered form)
     if (fold) { t.body_gather = true; t.gather_mul = c.au_g; }
     else { t.body_src = (const long long*)f.res_tmp; t.body_bs = (long long)bl * n; t.body_ls = n; }
     if (!c.au_big) {
@@ -375,10 +375,16 @@ static int wave_spectral_tail(const GlweCall& c, const FusedBufs& f, size_t b0, 
         return launch_inv_tail(M, t);
     }
     // operand of the body column, one stream: phi(body) + a0 (add) or -phi(body) + a0 (sub forms: the tail negates every operand)
-    if (fold) t.gather_neg = c.au->mode != 1;
-    else PZ_TRY(launch_automorphism(M, nb * bl, (const long long*)av.p, bsm, (long long*)f.res_tmp, bdm, c.au_g, c.au->mode == 1 ? 1 : 3,
-                                    (const long long*)av.p, bsm));
+    // POULPY_DBG_AUTO_BODYADD=1: the pre-pass only permutes (+-phi(body)) and the tail adds a0 from the ciphertext itself (a second operand
+    // stream on the body column) instead of a pre-pass with an add operand; not with the shifted stores of glwe_trace (registers)
+    static const int bodyadd_knob = getenv("POULPY_DBG_AUTO_BODYADD") ? atoi(getenv("POULPY_DBG_AUTO_BODYADD")) : 0;
     const bool rsh = c.want_rsh && tail_rsh_supported(M) && !c.cross_out && c.p->res_base2k <= 29;   // (32-bit shift steps: device_fft.hpp)
+    if (fold) t.gather_neg = c.au->mode != 1;
+    else if (bodyadd_knob && !rsh) {
+        PZ_TRY(launch_automorphism(M, nb * bl, (const long long*)av.p, bsm, (long long*)f.res_tmp, bdm, c.au_g, c.au->mode == 1 ? 1 : 3));
+        t.body_add = true;
+    } else PZ_TRY(launch_automorphism(M, nb * bl, (const long long*)av.p, bsm, (long long*)f.res_tmp, bdm, c.au_g, c.au->mode == 1 ? 1 : 3,
+                                      (const long long*)av.p, bsm));
     if (c.au->mode == 3) { t.auto_mul = 2u * (unsigned)n; t.auto_neg = true; }   // a - phi(big): every sign flipped
     t.small_neg = c.au->mode != 1;
     t.post_rsh = rsh;

@@ -462,6 +462,7 @@ struct TailArgs {
     // transform is phi(big)); the operand is one stream per column at the natural index: small[col][n], or on the body column
     // body_src[n] (phi(body) +- a0, prepared by k_automorphism in the workspace); small_neg negates it (sub forms)
     int pre_body, small_neg;
+    int body_add;   // body column: the operand is body_src[n] + small[body column][n] (the pre-pass then only permutes, no second operand)
     const long long* body_src;
     long long body_bs, body_ls;
     // plain glwe_automorphism in the spectral form (res = phi(normalize(big)), glwe_ct.rs:65-71): the inverse transform is phi(big) with
@@ -686,26 +687,38 @@ k_inv_tail(TailArgs g) {
             // body column: phi(body) (+ a0) either prepared by k_automorphism in the workspace (body_src) or, gather_mul != 0, gathered here
             // from the body itself (column 0 of `small`) - the pre-pass and its round trip through HBM are gone, the 8-byte gathers are
             // served by the XCD's L2 (all column blocks of one ciphertext column run on one XCD)
+            // (one straight-line loop per form, chosen here: with the form tested per element - a branch around the second load - the compiler
+            //  waits for every load on the spot, 32 exposed latencies per limb: that, not the gathers, is what the first builds of the
+            //  gathered and of the two-stream form measured, 8.3 - 8.8 ms against 5.05)
             const bool isbody = col == g.body_col;
             const long long* bsrc = (isbody && !g.gather_mul) ? g.body_src + (long long)b * g.body_bs + (long long)j * g.body_ls : nullptr;
             const long long* gsrc = (isbody && g.gather_mul) ? g.small + (long long)b * g.small_bs + (long long)j * small_ls : nullptr;
-#pragma unroll
-            for (int e = 0; e < RE; ++e) {
-                const long long idx = (long long)(b_ov + R2 * PZ_TAIL_N1(e)) * g.m2 + c0 + b_cv;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const long long ih = idx + (h ? m : 0);
-                    unsigned long long v = bsrc ? (unsigned long long)bsrc[ih]
-                                                : (g.body_only ? 0ull : (unsigned long long)small_col[(long long)j * small_ls + ih]);
-                    if (gsrc) {
-                        const unsigned i0 = ((unsigned)ih * g.gather_mul) & (unsigned)(2 * n - 1);
-                        const unsigned long long w = (unsigned long long)gsrc[(long long)(i0 & (unsigned)(n - 1))];
-                        v += ((i0 >= (unsigned)n) != (g.gather_neg != 0)) ? 0ull - w : w;
-                    }
-                    if (g.small_neg) v = 0ull - v;
-                    sm[2 * e + h] = (long long)v;
-                }
-            }
+            const long long* scol = small_col + (long long)j * small_ls;
+#define PZ_TAIL_OPERAND(EXPR_)                                                                      \
+    _Pragma("unroll") for (int e = 0; e < RE; ++e) {                                                \
+        const long long idx = (long long)(b_ov + R2 * PZ_TAIL_N1(e)) * g.m2 + c0 + b_cv;             \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                             \
+            const long long ih = idx + (h ? m : 0);                                                 \
+            unsigned long long v = (EXPR_);                                                         \
+            if (g.small_neg) v = 0ull - v;                                                          \
+            sm[2 * e + h] = (long long)v;                                                           \
+        }                                                                                           \
+    }
+#define PZ_TAIL_GATHERED(IH_) ([&]() -> unsigned long long {                                        \
+        const unsigned i0 = ((unsigned)(IH_) * g.gather_mul) & (unsigned)(2 * n - 1);               \
+        const unsigned long long w = (unsigned long long)gsrc[(long long)(i0 & (unsigned)(n - 1))]; \
+        return ((i0 >= (unsigned)n) != (g.gather_neg != 0)) ? 0ull - w : w; }())
+            if constexpr (RSH) {   // (the shifted-store variant sits at the register cap: one loop, the source picked by a select - round 3's form)
+                PZ_TAIL_OPERAND(bsrc ? (unsigned long long)bsrc[ih] : (g.body_only ? 0ull : (unsigned long long)scol[ih]))
+            } else
+            if (!RSH && bsrc && g.body_add) PZ_TAIL_OPERAND((unsigned long long)bsrc[ih] + (unsigned long long)scol[ih])   /* (not in the shifted-store variant: no registers left there) */
+            else if (bsrc) PZ_TAIL_OPERAND((unsigned long long)bsrc[ih])
+            else if (!RSH && gsrc && g.body_only) PZ_TAIL_OPERAND(PZ_TAIL_GATHERED(ih))   /* (the host never asks the shifted-store variant for the gathered or two-stream forms) */
+            else if (!RSH && gsrc) PZ_TAIL_OPERAND((unsigned long long)scol[ih] + PZ_TAIL_GATHERED(ih))
+            else if (g.body_only) PZ_TAIL_OPERAND(0ull)
+            else PZ_TAIL_OPERAND((unsigned long long)scol[ih])
+#undef PZ_TAIL_GATHERED
+#undef PZ_TAIL_OPERAND
         } else if (SMALL && small_col && j < g.small_size && g.gather_mul) {
             const long long* body = col == g.body_col ? g.small + (long long)b * g.small_bs + (long long)j * small_ls : nullptr;
 #pragma unroll

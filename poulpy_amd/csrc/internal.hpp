@@ -73,6 +73,7 @@ struct TailCall {
     const long long* body_src = nullptr;
     long long body_bs = 0, body_ls = 0;   // batch / limb strides of body_src
     bool body_only = false;               // only the body column has an operand (plain glwe_automorphism)
+    bool body_add = false;                // body column: body_src[n] + small[body column][n] (spectral add / sub forms: the pre-pass only permutes)
     bool body_gather = false;             // instead of body_src: the tail gathers +-phi(body) from column 0 of `small` itself (gather_mul,
                                           // gather_neg) - no pre-pass
     // ---- signs of X -> X^p (automorphism/glwe_ct.rs:96-275; TailArgs in device_fft.hpp) ----

@@ -40,7 +40,7 @@ static int launch_inv_tail_cols(pz_module* M, const TailCall& c, int col_base, i
     g.gather_mul = c.gather_mul; g.gather_neg = c.gather_neg ? 1 : 0;
     g.pre_body = (c.body_src != nullptr || c.body_gather) ? 1 : 0; g.small_neg = c.small_neg ? 1 : 0;
     g.body_src = c.body_src; g.body_bs = c.body_bs; g.body_ls = c.body_ls;
-    g.post_neg = c.post_neg ? 1 : 0; g.body_only = c.body_only ? 1 : 0; g.raw = raw ? 1 : 0;
+    g.body_add = c.body_add ? 1 : 0; g.post_neg = c.post_neg ? 1 : 0; g.body_only = c.body_only ? 1 : 0; g.raw = raw ? 1 : 0;
     g.nz = nz ? 1 : 0;
     g.nz_lsh = nz ? nz->lsh : 0; g.nz_res_end = nz ? nz->res_end : 0; g.nz_res_start = nz ? nz->res_start : 0; g.nz_a_end = nz ? nz->a_end : 0;
     g.nz_a_start = nz ? nz->a_start : 0; g.nz_zero_from = nz ? nz->zero_from : 0; g.nz_col = nz ? nz->col : 0; g.nz_mode = nz ? nz->mode : 0;
@@ -131,7 +131,7 @@ int launch_inv_tail(pz_module* M, const TailCall& c) {
     if (c.small != nullptr && !c.small_all && c.ncols > 1) {
         TailCall body = c;       // the body column: operand, and the signs that go with it
         body.gather_mul = 0; body.gather_neg = false; body.body_src = nullptr; body.body_bs = body.body_ls = 0;
-        body.small_neg = body.post_rsh = body.post_neg = body.body_only = false;
+        body.small_neg = body.post_rsh = body.post_neg = body.body_only = body.body_add = false;
         PZ_TRY(launch_inv_tail_cols(M, body, c.body_col, 1));
         TailCall plain = body;   // every other column: no operand, no signs
         plain.small = nullptr; plain.small_bs = 0; plain.auto_mul = 0; plain.auto_neg = false; plain.body_col = 0;
@@ -146,7 +146,7 @@ int launch_inv_tail(pz_module* M, const TailCall& c) {
         PZ_TRY(launch_inv_tail_cols(M, c, c.body_col, 1));
         TailCall rest = c;
         rest.small = nullptr; rest.small_bs = 0; rest.small_all = false; rest.small_size = 0;
-        rest.body_src = nullptr; rest.body_bs = rest.body_ls = 0; rest.body_only = false; rest.body_gather = false; rest.gather_mul = 0;
+        rest.body_src = nullptr; rest.body_bs = rest.body_ls = 0; rest.body_only = false; rest.body_add = false; rest.body_gather = false; rest.gather_mul = 0;
         if (c.body_col > 0) PZ_TRY(launch_inv_tail_cols(M, rest, 0, c.body_col));
         return launch_inv_tail_cols(M, rest, c.body_col + 1, c.ncols - 1 - c.body_col);
     }
