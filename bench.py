@@ -297,9 +297,10 @@ def main():
     # checked here, in the rank process (the launching parent never touches torch or HIP): fewer visible devices than ranks is a clean,
     # one-line refusal - no line is printed, the exit code is non-zero on every rank
     ndev = torch.cuda.device_count()
-    if ndev < world or local_rank >= ndev:
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))   # ranks on THIS node (torchrun sets it; a multi-node world is larger)
+    if ndev < local_world or local_rank >= ndev:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} needs {world} HIP devices on this node but only {ndev} are visible: no line reported", file=sys.stderr, flush=True)
+            print(f"bench.py: --gpus {args.gpus} needs {local_world} HIP devices on this node but only {ndev} are visible: no line reported", file=sys.stderr, flush=True)
         raise SystemExit(4)
     torch.cuda.set_device(local_rank)
     if distributed:
@@ -341,20 +342,11 @@ def main():
     bcast_used, rccl_ranks = None, 0
     if distributed:
         # the only collective of the path: through the C ABI (pz_bcast_key, RCCL on the module stream: what a Rust / C++ caller uses);
-        # --bcast torch (or a failure of the C-ABI communicator under --bcast auto, on every rank alike) uses torch.distributed
-        bcast_used = "torch"
-        if args.bcast in ("auto", "cabi"):
-            try:
-                pdist.broadcast_key_cabi(mod, pmat, src=0)
-                bcast_used = "cabi"
-                rccl_ranks = int(mod.lib.pz_comm_world_size(mod.handle))
-            except Exception as e:
-                if args.bcast == "cabi":
-                    raise
-                print(f"[bench rank {rank}] pz_bcast_key failed ({e}); falling back to torch.distributed.broadcast", file=sys.stderr, flush=True)
-        if bcast_used == "torch":
-            pdist.broadcast_key(pmat, src=0)
-            rccl_ranks = dist.get_world_size()
+        # --bcast torch (or a C-ABI communicator that is not available on EVERY rank under --bcast auto) uses torch.distributed
+        # the route is agreed on by all ranks before anyone enters a collective (pdist.broadcast_key_agreed): no rank falls back alone
+        bcast_used = pdist.broadcast_key_agreed(mod, pmat, src=0, route=args.bcast,
+                                                log=lambda m: print(f"[bench] {m}", file=sys.stderr, flush=True))
+        rccl_ranks = int(mod.lib.pz_comm_world_size(mod.handle)) if bcast_used == "cabi" else dist.get_world_size()
 
     # this rank's shard of the (weak-scaled) batch: `batch` ciphertexts per GPU, seeds by global index
     lo, hi = pdist.shard_range(args.batch * world, world, rank)

@@ -46,6 +46,7 @@ static uint64_t host_fingerprint(const void* p, size_t bytes) {
 // Rust shim's `PinnedBuf::drop`): a later allocation at the same address then never meets a stale mirror, fingerprint or not
 static std::mutex g_modules_mu;
 static std::vector<pz_module*> g_modules;
+static std::mutex g_host_allocs_mu;   // its own lock: pz_alloc_bytes / pz_free_bytes never wait behind a mirror sweep's device syncs
 static std::unordered_map<void*, size_t> g_host_allocs;   // pz_alloc_bytes blocks (a prepared key may sit inside one)
 static std::mutex g_inval_mu;
 struct HostInval { const char* lo; const char* hi; uint64_t epoch; };
@@ -119,6 +120,7 @@ size_t sweep_idle_modules(pz_module* self) {
     for (pz_module* O : g_modules) {
         if (O == self || !O->mu.try_lock()) continue;
         if (!O->mirrors.empty()) {
+            if (dev0 < 0) { O->mu.unlock(); continue; }   // cannot restore the caller's device afterwards: leave the sibling alone
             (void)hipSetDevice(O->device);
             dropped += sweep_own_mirrors(O);
         }
@@ -510,7 +512,7 @@ void* pz_alloc_bytes(size_t len) {
     }
     memset(p, 0, len);
     {
-        std::lock_guard<std::mutex> g(g_modules_mu);
+        std::lock_guard<std::mutex> g(g_host_allocs_mu);
         g_host_allocs[p] = len;
     }
     return p;
@@ -519,7 +521,7 @@ void pz_free_bytes(void* p) {
     if (!p) return;
     size_t len = 1;
     {
-        std::lock_guard<std::mutex> g(g_modules_mu);
+        std::lock_guard<std::mutex> g(g_host_allocs_mu);
         auto it = g_host_allocs.find(p);
         if (it != g_host_allocs.end()) { len = it->second; g_host_allocs.erase(it); }
     }

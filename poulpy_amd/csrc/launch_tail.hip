@@ -82,9 +82,13 @@ static int launch_inv_tail_cols(pz_module* M, const TailCall& c, int col_base, i
     }
         PZ_RSH_CASES(X)
 #undef X
+        return fail(PZ_ERR_UNSUPPORTED, "fused tail: no sign-only variant for this plan");
     }
     if (raw || nz) {   // the tensoring forms: their own instantiation of the row-major, operand-free tail
         if (!(rowmajor && !has_small && !M->probe)) return fail(PZ_ERR_UNSUPPORTED, "fused tail: the tensoring forms need the row-major layout");
+        // contract of the NZ = 1 instantiation (device_fft.hpp): plain normalized store (mode 1, no second result), shift below one limb;
+        // NzCombine mode 5 reads diagonal columns that a mode-1 launch of the same call wrote before it
+        if (nz && !(nz->lsh >= 0 && nz->lsh < c.base2k)) return fail(PZ_ERR_INVALID, "fused tail: normalizing store needs 0 <= lsh < base2k");
 #define X(A, B, C)                                                                                              \
     if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
         const size_t lds = ((size_t)2 * (A + 1) * C * B + 2 * A * B) * sizeof(cplx);                            \

@@ -51,6 +51,66 @@ def broadcast_key_cabi(mod, pmat, src: int = 0):
     return pmat
 
 
+def all_agree(ok: bool) -> bool:
+    """True iff `ok` on EVERY rank: one all_reduce(MIN) of a flag on the default process group (device tensor under nccl / RCCL, host
+    tensor under gloo).  The step that keeps ranks from taking different routes into a collective."""
+    import torch
+    import torch.distributed as dist
+
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.item()))
+
+
+def broadcast_key_agreed(mod, pmat, src: int = 0, route: str = "auto", log=None) -> str:
+    """Broadcast the prepared key by ONE route on every rank and return its name ("cabi" | "torch").
+
+    route "cabi": the C-ABI communicator or an exception on every rank; "torch": torch.distributed only; "auto": the C ABI when EVERY rank
+    can use it, torch.distributed on every rank otherwise.  No rank falls back alone: each local step that may fail (loading RCCL / drawing
+    an id, ncclCommInitRank) is followed by `all_agree`, so a rank whose librccl is missing cannot leave the others inside ncclBroadcast."""
+    import torch.distributed as dist
+
+    if route not in ("auto", "cabi", "torch"):
+        raise ValueError(f"unknown broadcast route {route!r}")
+    if route == "torch":
+        broadcast_key(pmat, src=src)
+        return "torch"
+    world, rank = dist.get_world_size(), dist.get_rank()
+    err = None
+    have_comm = mod.lib.pz_comm_world_size(mod.handle) != 0
+    # step 1 (local): RCCL loads here and an id can be drawn (every rank probes; only src's id is used)
+    my_id = None
+    if not have_comm:
+        try:
+            my_id = mod.comm_unique_id()
+        except Exception as e:   # noqa: BLE001 - any failure means "not by this route"
+            err = e
+    ok = all_agree(err is None)
+    # step 2 (collective, entered by all ranks or by none): the communicator
+    if ok and not all_agree(have_comm):
+        if have_comm:   # a communicator on some ranks only: start over on all of them
+            mod.comm_destroy()
+        obj = [my_id if rank == src else None]
+        dist.broadcast_object_list(obj, src=src)
+        try:
+            mod.comm_init_rank(world, rank, obj[0])
+        except Exception as e:   # noqa: BLE001
+            err = e
+        ok = all_agree(err is None)
+        if not ok and err is None:
+            mod.comm_destroy()
+    if not ok:
+        if route == "cabi":
+            raise RuntimeError(f"rank {rank}: the C-ABI communicator is not available on every rank" + (f" (here: {err})" if err else ""))
+        if log and err is not None:
+            log(f"rank {rank}: pz_comm_* failed ({err}); every rank uses torch.distributed.broadcast")
+        broadcast_key(pmat, src=src)
+        return "torch"
+    broadcast_key_cabi(mod, pmat, src=src)
+    return "cabi"
+
+
 def gather_per_rank(entry: dict) -> list:
     """Every rank contributes one small dict (its own rate, step time, dominant-kernel time, achieved GB/s); every rank gets the list
     ordered by rank.  One all_gather_object, outside the timed region - the N > 1 bench line reports per-GPU figures beside the

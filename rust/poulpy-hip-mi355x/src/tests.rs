@@ -97,3 +97,26 @@ fn module_new_every_ring_degree() {
         assert_eq!(module.n(), 1usize << log_n);
     }
 }
+
+/// The per-op batched wrappers stride by the module's ring degree: a container of another degree (an LWE batch has n = n_lwe + 1) must be
+/// refused in safe code, before the C ABI sees it (batched.rs `owns`).
+#[test]
+#[should_panic(expected = "vec_znx_copy_batched: layouts")]
+fn batched_per_op_wrappers_refuse_lwe_containers() {
+    use crate::batched::HipBatched;
+    let module = Module::<FFT64Hip>::new(1 << 10);
+    let a = module.lwe_batch_alloc(4, 636, 2, 17);
+    let mut res = module.lwe_batch_alloc(4, 636, 2, 17);
+    module.vec_znx_copy_batched(&mut res, 0, &a, 0);
+}
+
+/// ... and a container that belongs to a module of another ring degree
+#[test]
+#[should_panic(expected = "vec_znx_add_assign_batched: layouts")]
+fn batched_per_op_wrappers_refuse_containers_of_another_ring() {
+    use crate::batched::HipBatched;
+    let (small, large) = (Module::<FFT64Hip>::new(1 << 8), Module::<FFT64Hip>::new(1 << 10));
+    let a = small.vec_znx_batch_alloc(2, 1, 2, 17);
+    let mut res = large.vec_znx_batch_alloc(2, 1, 2, 17);
+    large.vec_znx_add_assign_batched(&mut res, 0, &a, 0);
+}

@@ -91,3 +91,103 @@ def test_two_rank_sharded_external_products_match_single_process():
         res = VecZnx(n, cols, size)
         ref.glwe_external_product(res, base2k, a, base2k, pm, 1, base2k)
         assert np.array_equal(res.data, merged[idx])
+
+
+class _FakeLib:
+    def __init__(self, owner):
+        self.owner = owner
+
+    def pz_comm_world_size(self, handle):
+        return self.owner.world if self.owner.comm else 0
+
+
+class _FakeModule:
+    """Stands in for hal.Module's communicator surface (comm_unique_id / comm_init_rank / comm_destroy / bcast_key): the agreement step
+    is host logic, the RCCL calls behind it need GPUs."""
+
+    def __init__(self, fail_id=False, fail_init=False):
+        self.fail_id, self.fail_init = fail_id, fail_init
+        self.comm, self.world, self.handle = False, 0, None
+        self.lib = _FakeLib(self)
+        self.calls = []
+
+    def comm_unique_id(self):
+        self.calls.append("id")
+        if self.fail_id:
+            raise RuntimeError("RCCL not found (dlopen librccl.so.1)")
+        return b"\x01" * 128
+
+    def comm_init_rank(self, world, rank, uid):
+        self.calls.append("init")
+        assert uid == b"\x01" * 128
+        if self.fail_init:
+            raise RuntimeError("ncclCommInitRank failed")
+        self.comm, self.world = True, world
+
+    def comm_destroy(self):
+        self.calls.append("destroy")
+        self.comm = False
+
+    def bcast_key(self, ptr, nbytes, root):
+        self.calls.append("bcast")   # the payload travels by torch in this stand-in (below)
+
+    def sync(self):
+        pass
+
+
+def _agree_worker(rank, world, port, outq):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from poulpy_amd import dist as pdist
+    results = {}
+    assert pdist.all_agree(True) is True
+    assert pdist.all_agree(rank != 1) is False
+    # (a) every rank can use the C ABI -> "cabi" everywhere
+    m = _FakeModule()
+    key = torch.full((1000,), float(rank == 0))
+    results["ok"] = (pdist.broadcast_key_agreed(m, key, src=0, route="auto"), list(m.calls))
+    # (b) rank 1 cannot load RCCL -> every rank takes torch, nobody initialises a communicator, the key still arrives
+    m = _FakeModule(fail_id=(rank == 1))
+    key = torch.full((1000,), 7.0 if rank == 0 else 0.0)
+    route = pdist.broadcast_key_agreed(m, key, src=0, route="auto")
+    results["no_rccl_on_1"] = (route, list(m.calls), float(key.sum()))
+    # (c) ncclCommInitRank fails on rank 1 only -> rank 0 destroys its communicator, both take torch
+    m = _FakeModule(fail_init=(rank == 1))
+    key = torch.full((10,), 3.0 if rank == 0 else 0.0)
+    route = pdist.broadcast_key_agreed(m, key, src=0, route="auto")
+    results["init_fails_on_1"] = (route, list(m.calls), float(key.sum()), m.comm)
+    # (d) --bcast cabi: an error on EVERY rank, not a hang
+    m = _FakeModule(fail_id=(rank == 1))
+    try:
+        pdist.broadcast_key_agreed(m, torch.zeros(4), src=0, route="cabi")
+        results["cabi_strict"] = "no error"
+    except RuntimeError as e:
+        results["cabi_strict"] = "raised" + (" here" if "here:" in str(e) else "")
+    outq.put((rank, results))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_route_is_agreed_before_any_collective():
+    """bench.py --bcast auto: a rank whose C-ABI communicator fails must not fall back alone while the others sit
+    in ncclBroadcast; the route is settled by all_reduce(MIN) after each step that may fail locally."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert got[r]["ok"] == ("cabi", ["id", "init", "bcast"])
+        route, calls, total = got[r]["no_rccl_on_1"]
+        assert route == "torch" and "init" not in calls and "bcast" not in calls and total == 7000.0
+        route, calls, total, comm = got[r]["init_fails_on_1"]
+        assert route == "torch" and "bcast" not in calls and total == 30.0 and comm is False
+    assert got[0]["init_fails_on_1"][1] == ["id", "init", "destroy"]
+    assert got[0]["cabi_strict"] == "raised" and got[1]["cabi_strict"] == "raised here"

@@ -397,3 +397,26 @@ def test_batched_api_only_uses_public_items_of_the_reference():
     assert re.search(r"impl<D: DataRef, BRT: BlindRotationAlgo> WriterTo for BlindRotationKey<D, BRT>", read(REF, "poulpy-bin-fhe/src/blind_rotation/layouts/key.rs"))
     assert "pub(crate) data: Vec<VecZnx<Vec<u8>>>" in read(REF, "poulpy-bin-fhe/src/blind_rotation/lut.rs")
     assert "pub(crate) data" in read(REF, "poulpy-core/src/layouts/prepared/gglwe.rs")
+
+
+def test_batched_per_op_wrappers_check_the_ring_degree_against_the_module():
+    """the C ABI's per-op `pz_vec_znx_*_batched` entry points stride by the MODULE's n; a safe wrapper that only
+    compared the containers with each other let an LWE batch (n = n_lwe + 1) or a container of another module through.  Every wrapper
+    that passes a DeviceVecZnx to such an entry point asserts `owns(self, ..)` for each container; `owns` pins n, byte length and device."""
+    code = strip_rust_comments(read(CRATE, "src", "batched.rs"))
+    m = re.search(r"fn owns\(module: &Module<FFT64Hip>, v: &DeviceVecZnx\) -> bool \{(.*?)\n\}", code, re.S)
+    assert m, "owns() helper missing"
+    body = m.group(1)
+    assert "v.n == module.n()" in body and "v.buf.len()" in body and "pz_module_device" in body
+    per_op = ["add_into", "sub", "add_assign", "sub_assign", "sub_negate_assign", "negate", "copy", "zero", "rotate", "lsh", "rsh", "normalize", "big_normalize"]
+    for name in per_op:
+        fm = re.search(r"\n    fn vec_znx_%s_batched\(&self([^\n;]*)\) \{(.*?)\n    \}" % name, code, re.S)
+        assert fm, name
+        sig, fbody = fm.group(1), fm.group(2)
+        containers = re.findall(r"(\w+): &(?:mut )?DeviceVecZnx", sig)
+        assert containers, name
+        for c in containers:
+            assert f"owns(self, {c})" in fbody, (name, c)
+        assert fbody.index("assert!") < fbody.index("ffi::pz_vec_znx_"), name
+    tests_rs = strip_rust_comments(read(CRATE, "src", "tests.rs"))
+    assert tests_rs.count("#[should_panic") >= 2 and "lwe_batch_alloc(4, 636" in tests_rs and "vec_znx_copy_batched(&mut res, 0, &a, 0)" in tests_rs
