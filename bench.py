@@ -258,6 +258,7 @@ def main():
     ap.add_argument("--dsize", type=int, default=1, help="digit size of the key (dnum = limbs / dsize rows); > 1 runs the digit-selected middle kernel")
     ap.add_argument("--no-pin-key", action="store_true", help="rebuild the key's row-sliced copy on every call (pz_module_pin_key not used)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-margin", action="store_true", help="skip the extra untimed step that measures the rounding margin")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the separate per-kernel-class timing pass (no roofline object)")
     ap.add_argument("--timing-steps", type=int, default=10, help="steps of the separate HIP-event pass that feeds the roofline object")
     ap.add_argument("--setup-calls", type=int, default=0, help="extra untimed calls before the W warm-up steps (reported in the line)")
@@ -458,6 +459,15 @@ def main():
         stats = mod.kernel_stats()
         mod.set_kernel_timing(False)
 
+    # rounding margin of this configuration (one more untimed step with the probing instantiations of the rounding kernels): how far the
+    # f64 transforms stay from a wrong i64 limb on THESE inputs - 0.5 would be one (backend_safety_contract.md:25-27)
+    margin = None
+    if not args.no_margin:
+        if trace:
+            res.copy_(a)
+            torch.cuda.synchronize()
+        margin = mod.rounding_margin_of(step)
+
     # this rank's own figures (its shard / its own clock around the same barrier-bracketed region; the headline uses the MAX over ranks)
     def dominant(st):
         return max(st.items(), key=lambda kv: kv[1][1]) if st else (None, (0, 0.0))
@@ -544,6 +554,7 @@ def main():
             "per_rank": per_rank,
             "scaling_efficiency": pdist.scaling_efficiency(value, world, args.ref_value),
             "parity_sample": parity,
+            "rounding_margin": margin,
         }
         if world == 1 and not args.no_cpu_baseline and not ks:
             try:

@@ -253,7 +253,7 @@ int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, c
         static const bool fused_env = !(getenv("POULPY_DBG_TENSOR_FUSED") && atoi(getenv("POULPY_DBG_TENSOR_FUSED")) == 0);
         static const bool combine_ok_env = !(getenv("POULPY_DBG_TENSOR_COMBINE") && atoi(getenv("POULPY_DBG_TENSOR_COMBINE")) == 0);
         const int bound_f = t.a_size + t.b_size - 1;
-        const bool fused = fused_env && combine_ok_env && p->res_base2k == p->ab_base2k && t.cols <= 3 && t.dft_size >= 1 && !M->probe &&
+        const bool fused = fused_env && combine_ok_env && p->res_base2k == p->ab_base2k && t.cols <= 3 && t.dft_size >= 1 &&
                            mid_cnv_supported(M, t.a_size, t.b_size, std::min(t.dft_size, bound_f));
         const size_t mpts = (size_t)M->m;
         cplx *ta_main = nullptr, *ta_last = nullptr, *tb_main = nullptr, *tb_last = nullptr;

@@ -63,7 +63,7 @@ static inline int dev_idft(pz_module* M, int batch, DV res, int res_col, DV a, i
     PolyMap sm{nlimbs, ncs, a.bs, (long long)a.cols * n, n, n * a_col};
     PolyMap dm{nlimbs, ncs, res.bs, (long long)res.cols * n, n, n * res_col};
     const int npolys = batch * nlimbs * ncs;
-    if (small_transform_supported(M) && !M->probe) return launch_small_idft(M, npolys, (const double*)a.p, sm, (long long*)res.p, dm);
+    if (small_transform_supported(M)) return launch_small_idft(M, npolys, (const double*)a.p, sm, (long long*)res.p, dm);
     PZ_TRY(launch_inv_pass2(M, npolys, (const double*)a.p, sm, T));
     PZ_TRY(launch_inv_pass1(M, npolys, T, (long long*)res.p, dm));
     return PZ_OK;

@@ -151,7 +151,7 @@ static bool small_ring_applies(const pz_module* M, const pz_glwe_op_params* p, c
     static const int small_au = getenv("POULPY_DBG_SMALL_AUTO") ? atoi(getenv("POULPY_DBG_SMALL_AUTO")) : 1;
     const bool cross_out = p->res_base2k != p->key_base2k;   // (with an automorphism: phi and the cross-base pass do not commute)
     return small_env && M->small_path && M->fuse_mid && M->fuse_tail && M->n < 4096 && (!au || (small_au && ks && packed && !cross_out)) &&
-           !tensor && p->dsize == 1 && !M->probe && M->dbg_stages == 7 && small_supported(M, s.cols_in * s.a_size_eff, (int)p->key_size);
+           !tensor && p->dsize == 1 && M->dbg_stages == 7 && small_supported(M, s.cols_in * s.a_size_eff, (int)p->key_size);
 }
 struct SmallWs {
     size_t key, spectra, conv, digits, total;
@@ -308,7 +308,7 @@ static bool n4096_two_kernel(const GlweCall& c) {
     static const int small_au4 = getenv("POULPY_DBG_SMALL_AUTO") ? atoi(getenv("POULPY_DBG_SMALL_AUTO")) : 1;
     const pz_module* M = c.M;
     const bool mid8 = !c.ks && !c.au && c.npi == 8 && c.npo == 8 && std::min(c.nrows, c.npi) == 8 && small_env != 2;
-    return small_env && M->small_path && (!c.au || (small_au4 && c.ks && !c.lay)) && !c.tensor && !c.digits && !c.cross_out && !M->probe &&
+    return small_env && M->small_path && (!c.au || (small_au4 && c.ks && !c.lay)) && !c.tensor && !c.digits && !c.cross_out &&
            M->dbg_stages == 7 && small_supported(M, c.npi, c.ksz) && !mid8;
 }
 static int wave_n4096_two_kernel(const GlweCall& c, const FusedBufs& f, size_t b0, int nb, const DV& av, const PolyMap& sm) {

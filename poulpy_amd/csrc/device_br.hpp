@@ -25,6 +25,7 @@ struct BrFusedArgs {
     const cplx* w2n;       // exp(2 pi i t / 4m), t < 4m
     long long key_stride;  // points between consecutive keys
     int n_lwe, blk, cols, rsz, dnum, bsz, lut_size, base2k, m, batch;
+    unsigned long long* margin;   // rounding-margin probe (margin_note, device_fft.hpp); null = off
     int dbg_skip;          // (run-time on purpose: with the tests compiled out — PZ_DBG, device_fft.hpp — this kernel's register allocation changes and the
                            //  N = 1024 two-ciphertext variants spill: 112 000 -> 89 000 rotations/s, round 3)  timing diagnostic (wrong results): 1 no DFT passes, 2 no product, 4 no carry phase, 8 no pack
 };
@@ -292,6 +293,7 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
                 for (int h = 0; h < 2; ++h) {
                     const double val = (h ? v.y : v.x) * inv_m;
                     const double rv = round_half_away(val);
+                    if (g.margin) margin_note(g.margin, fabs(val - rv));
                     // 3-instruction conversion when exact (|x| < 2^51), the saturating one otherwise (Rust `as i64`)
                     long long x = fabs(rv) < 2251799813685247.0 ? fast_i64_from_integral(rv) : sat_i64_from_integral(rv);
                     if (writes && !STD) {

@@ -178,6 +178,15 @@ __device__ __forceinline__ long long sat_i64_from_integral(double r) {
     return v;
 }
 __device__ __forceinline__ long long round_to_i64(double x) { return sat_i64_from_integral(round_half_away(x)); }
+// Rounding-margin probe (pz_module_set_margin_probe / pz_module_get_margin): the largest |x - round(x)| over every value an inverse
+// transform rounds, on the kernels the product path dispatches (a run-time, wave-uniform `margin != nullptr`; no instantiation of its own
+// and nothing live in registers when it is off: the distance is taken from the values still in registers, in a block of its own in front of
+// the rounding loop).  Bits of a non-negative double order like the double; the plain read keeps all but the first few lanes off the atomic.
+__device__ __forceinline__ double margin_dist(double x) { return fabs(x - round_half_away(x)); }
+__device__ __forceinline__ void margin_note(unsigned long long* margin, double worst) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(worst);   // NaN / inf inputs read as a huge margin, on purpose
+    if (bits > __atomic_load_n(margin, __ATOMIC_RELAXED)) atomicMax(margin, bits);
+}
 // exact for |r| < 2^51, r integral: the integer sits in the mantissa of r + 1.5*2^52
 __device__ __forceinline__ long long fast_i64_from_integral(double r) {
     const double magic = 6755399441055744.0;  // 1.5 * 2^52
@@ -362,9 +371,9 @@ k_inv_pass2(const double* __restrict__ src, PolyMap smap, cplx* __restrict__ T, 
 // =================================================================================
 // inverse pass 1: T[j2][q1] -> i64 coefficients, round(x/m) half-away, saturating
 // (tw1inv[j1] = conj(psi1^j1)/m carries the exact power-of-two scale).
-// PROBE: record max |x - round(x)| (exactness margin) through atomicMax on bits.
+// margin != nullptr: record max |x - round(x)| (exactness margin), margin_note above.
 // =================================================================================
-template <int R1, int R2, int CB, bool PROBE>
+template <int R1, int R2, int CB>
 __global__ void __launch_bounds__((R1 > R2 ? R1 : R2) * CB)
 k_inv_pass1(const cplx* __restrict__ T, long long* __restrict__ dst, PolyMap dmap, int m2,
             const cplx* __restrict__ tw1inv, const cplx* __restrict__ wL1, unsigned long long* __restrict__ margin) {
@@ -398,20 +407,21 @@ k_inv_pass1(const cplx* __restrict__ T, long long* __restrict__ dst, PolyMap dma
 #pragma unroll
         for (int k1 = 0; k1 < R1; ++k1) v[k1] = lds[(o * CB + c) * (R1 + 1) + k1];
         Bfly<R1, true>::run(v);
-        double worst = 0.0;
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) v[n1] = cmul(v[n1], tw1inv[o + R2 * n1]);
+        if (margin) {
+            double worst = 0.0;
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) worst = fmax(worst, fmax(margin_dist(v[n1].x), margin_dist(v[n1].y)));
+            margin_note(margin, worst);
+        }
 #pragma unroll
         for (int n1 = 0; n1 < R1; ++n1) {
             const int j1 = o + R2 * n1;
-            const cplx w = cmul(v[n1], tw1inv[j1]);
             const long long idx = (long long)j1 * m2 + c0 + c;
-            out[idx] = round_to_i64(w.x);
-            out[idx + m] = round_to_i64(w.y);
-            if (PROBE) {
-                worst = fmax(worst, fabs(w.x - round(w.x)));
-                worst = fmax(worst, fabs(w.y - round(w.y)));
-            }
+            out[idx] = round_to_i64(v[n1].x);
+            out[idx + m] = round_to_i64(v[n1].y);
         }
-        if (PROBE) atomicMax(margin, (unsigned long long)__double_as_longlong(worst));
     }
 }
 
@@ -521,12 +531,12 @@ __device__ __forceinline__ int sx_carry(int k, int x, int d) { return (x - d) >>
 //  and the tests in front of every store)
 // SGN (round 4): the signs of X -> X^p (TailArgs::auto_mul / auto_neg / post_neg) without an operand - the columns of a plain spectral
 // glwe_automorphism that carry no body: they ride on the f64 chain like a product's columns instead of the operand variant's integer chain
-template <int R1, int R2, int CB, bool PROBE, bool ROWMAJOR = false, bool SMALL = false, bool RSH = false, int NZ = 0, bool SGN = false>
+template <int R1, int R2, int CB, bool ROWMAJOR = false, bool SMALL = false, bool RSH = false, int NZ = 0, bool SGN = false, bool PROBE = false>
 __global__ void __launch_bounds__(((R1 == 16 ? 2 : 1) * R2 + R1) * CB, ((((R1 == 16 ? 2 : 1) * R2 + R1) * CB >= 512) ? 1 : (SMALL ? 2 : 3)))
 k_inv_tail(TailArgs g) {
     static_assert(!RSH || SMALL, "the shifted store rides on the integer carry chain");
-    static_assert(!NZ || (ROWMAJOR && !SMALL && !RSH && !PROBE), "tensoring forms: row-major pipeline layout, no operand");
-    static_assert(!SGN || (ROWMAJOR && !SMALL && !RSH && !PROBE && !NZ), "sign-only form: row-major pipeline layout, no operand");
+    static_assert(!NZ || (ROWMAJOR && !SMALL && !RSH), "tensoring forms: row-major pipeline layout, no operand");
+    static_assert(!SGN || (ROWMAJOR && !SMALL && !RSH && !NZ), "sign-only form: row-major pipeline layout, no operand");
     constexpr bool SPLIT = TailShape<R1, R2, CB>::SPLIT;
     constexpr int RE = TailShape<R1, R2, CB>::RE;
     constexpr int NB = TailShape<R1, R2, CB>::NB;
@@ -765,13 +775,20 @@ k_inv_tail(TailArgs g) {
         const bool writes = j < g.res_size;
         const bool first = j == L - 1;
         const bool add_small = small_col && j < g.small_size;
-        double worst = 0.0;
         // scale/untwist in place and bound the magnitudes: below 2^51 the 3-instruction conversion is exact
         double big = 0.0;
 #pragma unroll
         for (int e = 0; e < RE; ++e) {
             v[e] = cmul(v[e], twi[b_ov + R2 * PZ_TAIL_N1(e)]);
             big = fmax(big, fmax(fabs(v[e].x), fabs(v[e].y)));
+        }
+        if (PROBE) {   // rounding-margin probe (margin_note): every value this limb rounds, in every form of the tail.  Compile-time here (its own
+                       // instantiation of each form): a run-time test in front of the carry loop cost the operand forms 10 - 45 registers (200 B of
+                       // scratch at N = 2^16), the block boundary keeps the operand prefetch from being scheduled across it
+            double worst = 0.0;
+#pragma unroll
+            for (int e = 0; e < RE; ++e) worst = fmax(worst, fmax(margin_dist(v[e].x), margin_dist(v[e].y)));
+            margin_note(g.margin, worst);
         }
         if (NZ == 2 && d5) {   // the two diagonal digits are only ever used as their sum: one register per coefficient from here on (the
                                // pairwise instantiation's 88 B of scratch were 2.7 GB of extra HBM writes per launch, profiles/r04_tensor_traffic.json)
@@ -791,7 +808,6 @@ k_inv_tail(TailArgs g) {
             const long long idx = (long long)j1 * g.m2 + c0 + b_cv + (h ? m : 0);                             \
             const double val = h ? v[n1].y : v[n1].x;                                                        \
             const double r = round_half_away(val);                                                           \
-            if (PROBE) worst = fmax(worst, fabs(val - r));                                                   \
             long long x = CONVERT(r);                                                                        \
             if (SMALL && add_small) x = (long long)((unsigned long long)x + (unsigned long long)sm[SMALL ? 2 * n1 + h : 0]); \
             bool ng_ = false;                                                                                \
@@ -896,7 +912,6 @@ k_inv_tail(TailArgs g) {
                     const long long idx = (long long)j1 * g.m2 + c0 + b_cv + (h ? m : 0);
                     const double val = h ? v[n1].y : v[n1].x;
                     double r = round_half_away(val);
-                    if (PROBE) worst = fmax(worst, fabs(val - r));
                     bool ng_ = false;
                     if (SGN) {   // s(n) in front of the chain, and back on the digit (the integer path's steps, on the f64 chain)
                         ng_ = (((unsigned)idx * g.auto_mul) & (unsigned)(2 * n - 1)) >= (unsigned)n;
@@ -925,7 +940,6 @@ k_inv_tail(TailArgs g) {
             }
         }
 #undef PZ_TAIL_COEFFS
-        if (PROBE) atomicMax(g.margin, (unsigned long long)__double_as_longlong(worst));
         __syncthreads();
     }
     if (NZ && g.nz) {   // the top res limbs are digits of the carry alone (middle_step_assign / final_step_assign on zero limbs, normalization.rs:132-157, 254-272)

@@ -134,6 +134,7 @@ struct SmallIdftArgs {
     const cplx* tw12t;
     const cplx* wL2;
     const cplx* tw1inv;
+    unsigned long long* margin;   // rounding-margin probe (margin_note, device_fft.hpp); null = off
 };
 // 256 threads = 2 polynomials x 128 threads; LDS 2 x M1 rows x 144 points + wL2
 template <int M1>
@@ -213,6 +214,15 @@ __global__ void __launch_bounds__(256, 2) k_small_idft(SmallIdftArgs g) {
 #pragma unroll
         for (int j1 = 0; j1 < M1; ++j1) big += fabs(v[j1].x) + fabs(v[j1].y);
         big *= 1.0 / (double)m;
+        if (g.margin && active) {
+            double worst = 0.0;
+#pragma unroll
+            for (int j1 = 0; j1 < M1; ++j1) {
+                const cplx val = cmul(v[j1], tw1i[j1]);
+                worst = fmax(worst, fmax(margin_dist(val.x), margin_dist(val.y)));
+            }
+            margin_note(g.margin, worst);
+        }
         if (active) {
             long long* dst = g.res + map_off(g.dmap, p) + t;
             if (big < 2251799813685247.0) {
@@ -254,6 +264,7 @@ struct SmallInvArgs {
     const cplx* tw1;             // FWD: twist of the forward column pass
     int fwd_limbs;               // FWD: <= min(KS, res_size)
     int dbg;                     // timing ablation (POULPY_DBG_SMALL_SKIP; results invalid): 1 no key loads, 2 no S loads, 4 no stores, 8 no LDS phases
+    unsigned long long* margin;  // rounding-margin probe (margin_note, device_fft.hpp); null = off
 };
 
 // 64 M1 threads (1024 at N = 4096: 16 waves, the product phase is latency-bound with fewer); LDS holds the KS output polynomials of one
@@ -490,6 +501,15 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
             if constexpr (AU) {
                 if (g.small && (col == g.body_col || g.body_col < 0) && cl < g.small_size)
                     bsrc = g.small + (long long)b * g.small_bs + (g.body_col < 0 ? (long long)col * n : 0) + (long long)cl * g.small_cols * n + cj;
+            }
+            if (g.margin) {   // rounding-margin probe: the values PZ_SMALL_ROUND rounds
+                double worst = 0.0;
+#pragma unroll
+                for (int j1 = 0; j1 < M1; ++j1) {
+                    const cplx val = cmul(v[j1], tw1i[j1]);
+                    worst = fmax(worst, fmax(margin_dist(val.x), margin_dist(val.y)));
+                }
+                margin_note(g.margin, worst);
             }
 #define PZ_SMALL_ROUND(CONVERT)                                                                               \
     _Pragma("unroll") for (int jb = 0; jb < M1; jb += 4) {                                                   \

@@ -55,7 +55,7 @@ int br_try_fused(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_
                 g.n_lwe = n_lwe; g.blk = blk; g.cols = cols; g.rsz = rsz; g.dnum = dnum; g.bsz = bsz; g.lut_size = (int)p->lut_size;
                 g.base2k = k; g.m = m; g.batch = B;
                 static const int br_skip = getenv("POULPY_DBG_BR_SKIP") ? atoi(getenv("POULPY_DBG_BR_SKIP")) : 0;
-                g.dbg_skip = br_skip;
+                g.dbg_skip = br_skip; g.margin = M->probe ? M->margin : nullptr;
                 KTimer kt(M, PZ_K_FUSED_MID);
                 bool launched = false;
 #define PZ_BR_STD(R0_, PJ_, MR_, CG_)                                                                                        \

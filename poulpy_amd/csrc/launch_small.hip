@@ -72,7 +72,7 @@ int launch_small_idft(pz_module* M, int npolys, const double* a, PolyMap smap, l
     PZ_TRY(ensure_small_tables(M));
     SmallIdftArgs g;
     g.S = (const cplx*)a; g.smap = smap; g.res = res; g.dmap = dmap; g.npolys = npolys;
-    g.tw12t = M->s_tw12t; g.wL2 = M->s_wL2; g.tw1inv = M->s_tw1inv;
+    g.tw12t = M->s_tw12t; g.wL2 = M->s_wL2; g.tw1inv = M->s_tw1inv; g.margin = M->probe ? M->margin : nullptr;
     const int m1 = small_m1(M);
     const size_t lds = ((size_t)2 * m1 * kSmallIdftRS + kSmallM2 + m1) * sizeof(cplx);
     KTimer kt(M, PZ_K_INV_PASS1);
@@ -124,7 +124,7 @@ int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int
     g.res_cols = res_cols; g.res_size = res_size; g.small_cols = small_cols; g.small_size = small_size; g.base2k = base2k; g.body_col = body_col;
     g.tw12t = M->s_tw12t; g.wL2 = M->s_wL2; g.tw1inv = M->s_tw1inv;
     static const int skip = getenv("POULPY_DBG_SMALL_SKIP") ? atoi(getenv("POULPY_DBG_SMALL_SKIP")) : 0;
-    g.dbg = skip;
+    g.dbg = skip; g.margin = M->probe ? M->margin : nullptr;
     g.S_out = fwd_S; g.tw1 = M->s_tw1; g.fwd_limbs = fwd_S ? fwd_limbs : 0;
     g.au_p = au_p; g.au_mode = au_mode; g.post_rsh = (post_rsh && au) ? 1 : 0;
     {   // p^-1 mod 2^32 by Newton steps (p odd), reduced mod 2n in the kernel

@@ -5,18 +5,13 @@
 #include <vector>
 
 #include "internal.hpp"
+#include "tail_forms.hpp"
 
 namespace pz {
 
-#define PZ_P1F_CASES(X) X(4, 1, 4) X(8, 1, 4) X(8, 1, 16) X(16, 1, 16) X(4, 4, 16) X(4, 8, 16) X(8, 8, 16) X(8, 16, 16) X(16, 16, 16) X(8, 16, 8)
-
 // the two roles of k_inv_tail must be whole waves
 bool tail_supported(const pz_module* M) { return (M->plan.f1b * M->plan.cb) % 64 == 0; }
-// the variant whose digits leave through a one-bit vec_znx_rsh (glwe_trace): instantiated for the
-// 128-point-row plans (N = 2^13 .. 2^16)
-#define PZ_RSH_CASES(X) X(4, 8, 16) X(8, 8, 16) X(8, 16, 16) X(16, 16, 16)
 bool tail_rsh_supported(const pz_module* M) {
-    if (M->probe) return false;
 #define X(A, B, C) if (M->plan.f1a == A && M->plan.f1b == B && M->plan.cb == C) return true;
     PZ_RSH_CASES(X)
 #undef X
@@ -25,16 +20,12 @@ bool tail_rsh_supported(const pz_module* M) {
 
 struct TailNz { int lsh, res_end, res_start, a_end, a_start, zero_from, col, mode, col2[2], mode2[2]; };
 // columns [col_base, col_base + col_count) of the big value in one launch; raw / nz: the tensoring forms (launch_inv_tail_raw / _nz)
-static int launch_inv_tail_cols(pz_module* M, const TailCall& c, int col_base, int col_count, bool raw = false, const TailNz* nz = nullptr) {
-    const FftPlan& pl = M->plan;
-    int blocks = c.batch * col_count * (pl.m2 / pl.cb);
-    if (blocks == 0) return PZ_OK;
-    KTimer kt(M, PZ_K_FUSED_TAIL);
+static TailArgs tail_args(const pz_module* M, const TailCall& c, int col_base, int col_count, bool raw, const TailNz* nz) {
     TailArgs g;
     g.T = c.T; g.res = c.res; g.small = c.small; g.res_bs = c.res_bs; g.small_bs = c.small_bs;
     g.nlimbs = c.nlimbs; g.ncols = c.ncols; g.res_cols = c.res_cols; g.res_size = c.res_size;
-    g.small_cols = c.small_cols; g.small_size = c.small_size; g.base2k = c.base2k; g.m2 = pl.m2;
-    g.tw1inv = M->tw1inv; g.wL1 = M->wL1; g.margin = M->margin;
+    g.small_cols = c.small_cols; g.small_size = c.small_size; g.base2k = c.base2k; g.m2 = M->plan.m2;
+    g.tw1inv = M->tw1inv; g.wL1 = M->wL1; g.margin = M->probe ? M->margin : nullptr;
     g.small_all = c.small_all ? 1 : 0; g.auto_mul = c.auto_mul; g.auto_neg = c.auto_neg ? 1 : 0;
     g.col_base = col_base; g.col_count = col_count; g.body_col = c.body_col;
     g.gather_mul = c.gather_mul; g.gather_neg = c.gather_neg ? 1 : 0;
@@ -45,88 +36,44 @@ static int launch_inv_tail_cols(pz_module* M, const TailCall& c, int col_base, i
     g.nz_lsh = nz ? nz->lsh : 0; g.nz_res_end = nz ? nz->res_end : 0; g.nz_res_start = nz ? nz->res_start : 0; g.nz_a_end = nz ? nz->a_end : 0;
     g.nz_a_start = nz ? nz->a_start : 0; g.nz_zero_from = nz ? nz->zero_from : 0; g.nz_col = nz ? nz->col : 0; g.nz_mode = nz ? nz->mode : 0;
     for (int u = 0; u < 2; ++u) { g.nz_col2[u] = nz ? nz->col2[u] : 0; g.nz_mode2[u] = nz ? nz->mode2[u] : 0; }
+    g.xcd_map = 0;
+    return g;
+}
+static int launch_inv_tail_cols(pz_module* M, const TailCall& c, int col_base, int col_count, bool raw = false, const TailNz* nz = nullptr) {
+    const FftPlan& pl = M->plan;
+    int blocks = c.batch * col_count * (pl.m2 / pl.cb);
+    if (blocks == 0) return PZ_OK;
+    KTimer kt(M, PZ_K_FUSED_TAIL);
+    TailArgs g = tail_args(M, c, col_base, col_count, raw, nz);
     // XCD-aware block order (all column blocks of one (ciphertext, column) on one XCD, back to back): the gathers of the automorphism
     // forms need it for L2 locality, and the row-major pipeline streams faster with it (see k_fwd_pass1); the grid is padded to whole
     // groups of 8 (ciphertext, column) pairs
-    static const int xcd_order = getenv("POULPY_DBG_XCD_ORDER") ? atoi(getenv("POULPY_DBG_XCD_ORDER")) : 1;
-    g.xcd_map = 0;
-    if (c.gather_mul != 0 || (c.rowmajor && xcd_order)) {
+    if (c.gather_mul != 0 || c.rowmajor) {
         const int nbc = c.batch * col_count, ncb = pl.m2 / pl.cb;
         g.xcd_map = nbc;
         blocks = ((nbc + 7) / 8) * 8 * ncb;
     }
-    const bool rowmajor = c.rowmajor, has_small = c.small != nullptr;
+    // which form of the kernel: shifted store | sign-only | tensoring (pairwise / diagonal) | plain (with or without the body operand)
+    const bool has_small = c.small != nullptr;
+    TailForm f;
+    f.rowmajor = c.rowmajor; f.has_small = has_small;
     if (c.post_rsh) {
-        if (!(tail_rsh_supported(M) && rowmajor && has_small)) return fail(PZ_ERR_UNSUPPORTED, "fused tail: no shifted-store variant for this plan");
-#define X(A, B, C)                                                                                              \
-    if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
-        const size_t lds = ((size_t)2 * (A + 1) * C * B + 2 * A * B) * sizeof(cplx);                            \
-        PZ_TRY(set_lds((k_inv_tail<A, B, C, false, true, true, true>), lds));                                   \
-        hipLaunchKernelGGL((k_inv_tail<A, B, C, false, true, true, true>), dim3(blocks), dim3(TailShape<A, B, C>::NT), lds, M->stream, g); \
-        PZ_HIP(hipGetLastError());                                                                              \
-        return PZ_OK;                                                                                           \
-    }
-        PZ_RSH_CASES(X)
-#undef X
-        return fail(PZ_ERR_UNSUPPORTED, "fused tail: no shifted-store variant for this plan");
-    }
-    if (!has_small && c.auto_mul != 0) {   // signs without an operand (launch_inv_tail: the body-less columns of a plain spectral automorphism)
-        if (!(rowmajor && !M->probe && !raw && !nz && tail_rsh_supported(M))) return fail(PZ_ERR_UNSUPPORTED, "fused tail: no sign-only variant for this plan");
-#define X(A, B, C)                                                                                              \
-    if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
-        const size_t lds = ((size_t)2 * (A + 1) * C * B + 2 * A * B) * sizeof(cplx);                            \
-        PZ_TRY(set_lds((k_inv_tail<A, B, C, false, true, false, false, 0, true>), lds));                        \
-        hipLaunchKernelGGL((k_inv_tail<A, B, C, false, true, false, false, 0, true>), dim3(blocks), dim3(TailShape<A, B, C>::NT), lds, M->stream, g); \
-        PZ_HIP(hipGetLastError());                                                                              \
-        return PZ_OK;                                                                                           \
-    }
-        PZ_RSH_CASES(X)
-#undef X
-        return fail(PZ_ERR_UNSUPPORTED, "fused tail: no sign-only variant for this plan");
-    }
-    if (raw || nz) {   // the tensoring forms: their own instantiation of the row-major, operand-free tail
-        if (!(rowmajor && !has_small && !M->probe)) return fail(PZ_ERR_UNSUPPORTED, "fused tail: the tensoring forms need the row-major layout");
+        if (!(tail_rsh_supported(M) && c.rowmajor && has_small)) return fail(PZ_ERR_UNSUPPORTED, "fused tail: no shifted-store variant for this plan");
+        f.kind = TailForm::RSH;
+    } else if (!has_small && c.auto_mul != 0) {   // signs without an operand (launch_inv_tail: the body-less columns of a plain spectral automorphism)
+        if (!(c.rowmajor && !raw && !nz && tail_rsh_supported(M))) return fail(PZ_ERR_UNSUPPORTED, "fused tail: no sign-only variant for this plan");
+        f.kind = TailForm::SGN;
+    } else if (raw || nz) {   // the tensoring forms: their own instantiation of the row-major, operand-free tail
+        if (!(c.rowmajor && !has_small && tail_rsh_supported(M))) return fail(PZ_ERR_UNSUPPORTED, "fused tail: the tensoring forms need the row-major layout of a 128-point-row plan");
         // contract of the NZ = 1 instantiation (device_fft.hpp): plain normalized store (mode 1, no second result), shift below one limb;
         // NzCombine mode 5 reads diagonal columns that a mode-1 launch of the same call wrote before it
         if (nz && !(nz->lsh >= 0 && nz->lsh < c.base2k)) return fail(PZ_ERR_INVALID, "fused tail: normalizing store needs 0 <= lsh < base2k");
-#define X(A, B, C)                                                                                              \
-    if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
-        const size_t lds = ((size_t)2 * (A + 1) * C * B + 2 * A * B) * sizeof(cplx);                            \
-        if (raw || !(nz->mode == 1 && nz->mode2[0] == 0 && nz->mode2[1] == 0)) {   /* raw values, or any NzCombine mode (pairwise term: with the prefetch of the diagonal digits) */ \
-            PZ_TRY(set_lds((k_inv_tail<A, B, C, false, true, false, false, 2>), lds));                          \
-            hipLaunchKernelGGL((k_inv_tail<A, B, C, false, true, false, false, 2>), dim3(blocks), dim3(TailShape<A, B, C>::NT), lds, M->stream, g); \
-        } else {                                                                                                \
-            PZ_TRY(set_lds((k_inv_tail<A, B, C, false, true, false, false, 1>), lds));                          \
-            hipLaunchKernelGGL((k_inv_tail<A, B, C, false, true, false, false, 1>), dim3(blocks), dim3(TailShape<A, B, C>::NT), lds, M->stream, g); \
-        }                                                                                                       \
-        PZ_HIP(hipGetLastError());                                                                              \
-        return PZ_OK;                                                                                           \
+        // raw values, or any NzCombine mode (pairwise term: with the prefetch of the diagonal digits): NZ2; the diagonal launches: NZ1
+        f.kind = (raw || !(nz->mode == 1 && nz->mode2[0] == 0 && nz->mode2[1] == 0)) ? TailForm::NZ2 : TailForm::NZ1;
     }
-        PZ_RSH_CASES(X)
-#undef X
-        return fail(PZ_ERR_UNSUPPORTED, "fused tail: no tensoring variant for this plan");
-    }
-// one instantiation per (probe, row-major, body add) combination actually requested
-#define PZ_TAIL_ONE(A, B, C, P_, R_, S_)                                                                        \
-    if (M->probe == P_ && rowmajor == R_ && has_small == S_) {                                                  \
-        PZ_TRY(set_lds(k_inv_tail<A, B, C, P_, R_, S_>, lds));                                                  \
-        hipLaunchKernelGGL((k_inv_tail<A, B, C, P_, R_, S_>), dim3(blocks), dim3(TailShape<A, B, C>::NT), lds, M->stream, g); \
-    }
-#define PZ_TAIL_LAUNCH(A, B, C)                                                                                 \
-    PZ_TAIL_ONE(A, B, C, false, false, false) PZ_TAIL_ONE(A, B, C, false, false, true)                          \
-    PZ_TAIL_ONE(A, B, C, false, true, false) PZ_TAIL_ONE(A, B, C, false, true, true)                            \
-    PZ_TAIL_ONE(A, B, C, true, false, false) PZ_TAIL_ONE(A, B, C, true, false, true)                            \
-    PZ_TAIL_ONE(A, B, C, true, true, false) PZ_TAIL_ONE(A, B, C, true, true, true)
-#define X(A, B, C)                                                                                              \
-    if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
-        const size_t lds = ((size_t)2 * (A + 1) * C * B + 2 * A * B) * sizeof(cplx);                  \
-        PZ_TAIL_LAUNCH(A, B, C)                                                                                 \
-        PZ_HIP(hipGetLastError());                                                                              \
-        return PZ_OK;                                                                                           \
-    }
-    PZ_P1F_CASES(X)
-#undef X
-    return fail(PZ_ERR_UNSUPPORTED, "no fused tail kernel for m1=%d", pl.m1);
+    // the rounding-margin instantiation of the same form when the module's probe is on (pz_module_set_margin_probe): the same source with the
+    // probe block compiled in, so that the margin is measured on the form the product path dispatches (launch_tail_probe.hip)
+    return M->probe ? tail_launch_form_probe(M, g, blocks, f) : tail_launch_form<false>(M, g, blocks, f);
 }
 // The body operand of a key switch only exists for one column (0; `body_col` for ggsw_expand_row): that column runs the
 // variant that prefetches it (more registers, one workgroup less per CU), the other columns the plain one.
@@ -146,7 +93,7 @@ int launch_inv_tail(pz_module* M, const TailCall& c) {
     // sign-only variant of the f64 chain (POULPY_DBG_AUTO_SGN=0: every column on the operand variant, as in round 3)
     static const int sgn_knob = getenv("POULPY_DBG_AUTO_SGN") ? atoi(getenv("POULPY_DBG_AUTO_SGN")) : 1;
     if (sgn_knob && c.small != nullptr && c.small_all && c.body_only && c.auto_mul != 0 && c.ncols > 1 && !c.post_rsh && c.rowmajor &&
-        !M->probe && tail_rsh_supported(M)) {
+        tail_rsh_supported(M)) {
         PZ_TRY(launch_inv_tail_cols(M, c, c.body_col, 1));
         TailCall rest = c;
         rest.small = nullptr; rest.small_bs = 0; rest.small_all = false; rest.small_size = 0;

@@ -207,6 +207,18 @@ class Module:
         self._ck(self.lib.pz_module_get_margin(self.handle, C.byref(out)))
         return out.value
 
+    def rounding_margin_of(self, run) -> float:
+        """max |x - round(x)| over every value the inverse transforms of `run()` round (0.5 = a wrong limb): one more execution of `run`
+        with the probing instantiations of the rounding kernels in the same dispatch (pz_module_set_margin_probe)."""
+        self.sync()
+        self.set_margin_probe(True)
+        try:
+            run()
+            self.sync()
+            return self.get_margin()
+        finally:
+            self.set_margin_probe(False)
+
     KERNEL_CLASSES = ("fwd_pass1", "fwd_pass2", "vmp", "inv_pass2", "inv_pass1", "normalize", "elementwise", "fused_mid",
                       "fused_tail")
 

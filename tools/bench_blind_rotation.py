@@ -88,6 +88,7 @@ def main():
     mod.sync()
     kstats = {k: (v[0], round(v[1], 3)) for k, v in mod.kernel_stats().items() if v[0]}
     mod.set_kernel_timing(False)
+    margin = mod.rounding_margin_of(lambda: mod.blind_rotation_execute_batched(ptr(res), ptr(lwe), ptr(lut), ptr(brk), p, args.batch))
     ks_stats = None
     if args.with_keyswitch and s["rank"] == 1:
         # key-switching key: GGLWE rows = dnum, cols_in = 1, cols_out = 2, same size / base2k as the accumulator
@@ -118,7 +119,7 @@ def main():
         ks_stats = {"gate_bootstraps_per_s": args.batch / dtb, "ms_per_batch": dtb * 1e3,
                     "steps": "lwe_mod_switch_2n + blind_rotation_execute + lwe_from_glwe (key switch + sample extract), all device-resident"}
     out = {"metric": "CGGI blind rotations/s", "shape": args.shape, **s, "batch": args.batch, "value": args.batch / dt,
-           "ms_per_batch": dt * 1e3, "kernel_classes_launches_ms": kstats, "digits_balanced": bool((res.min() >= -half).item() and (res.max() < half).item())}
+           "ms_per_batch": dt * 1e3, "rounding_margin": margin, "kernel_classes_launches_ms": kstats, "digits_balanced": bool((res.min() >= -half).item() and (res.max() < half).item())}
     # which kernel instantiations ran, and the rotation priced against the three ceilings that can bound it (tools/roofline_models.py)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import roofline_models as rm

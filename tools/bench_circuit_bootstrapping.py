@@ -95,8 +95,9 @@ def main():
     mod.sync()
     kstats = {k: (v[0], round(v[1], 3)) for k, v in mod.kernel_stats().items() if v[0]}
     mod.set_kernel_timing(False)
+    margin = mod.rounding_margin_of(run)   # blind rotation, the traces' key switches and the row expansion: the worst of all their roundings
     out = {"metric": "circuit bootstrappings/s (LWE -> GGSW, constant mode)", **s, "batch": args.batch, "value": args.batch / dt,
-           "ms_per_batch": dt * 1e3, "host_submit_ms_per_call": t_submit * 1e3, "graph_launches": mod.graph_launches(),
+           "ms_per_batch": dt * 1e3, "rounding_margin": margin, "host_submit_ms_per_call": t_submit * 1e3, "graph_launches": mod.graph_launches(),
            "kernel_classes_launches_ms": kstats,
            "digits_balanced": bool((res.min() >= -half).item() and (res.max() <= half).item())}
     # the composition priced against the three ceilings (tools/roofline_models.py): blind rotation + res_dnum traces of log2(N)

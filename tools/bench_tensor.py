@@ -84,6 +84,7 @@ def main():
     mod.sync()
     stats = {kname: [c, round(ms, 3)] for kname, (c, ms) in mod.kernel_stats().items() if c}
     mod.set_kernel_timing(False)
+    margin = mod.rounding_margin_of(run)
     # parity of a few outputs against the oracle
     ok = None
     if args.parity_samples:
@@ -116,7 +117,7 @@ def main():
     rate = args.batch / dt
     print(json.dumps({
         "metric": ("GLWE multiplications/s (glwe_tensor_%s + glwe_tensor_relinearize)" if args.relin else "GLWE tensorings/s (glwe_tensor_%s)") % ("apply" if args.mode == "apply" else "square_apply"),
-        "value": rate, "unit": "multiplications/s" if args.relin else "tensorings/s", "ms_per_step": dt * 1e3, "batch": args.batch, "parity_ok": ok,
+        "value": rate, "unit": "multiplications/s" if args.relin else "tensorings/s", "ms_per_step": dt * 1e3, "batch": args.batch, "parity_ok": ok, "rounding_margin": margin,
         "config": {"workload": f"glwe_tensor_{args.mode}" + (" + glwe_tensor_relinearize (tensor key 1 -> 1, dnum = limbs)" if args.relin else "") + f" (rank 1: 2-column GLWE x GLWE -> 3-column GLWETensor), N={n}, {size} limbs, base2k={k}, cnv_offset={cnv_offset}",
                    "batch_per_gpu": args.batch},
         "kernel_classes_launches_ms": stats,
