@@ -83,12 +83,15 @@ def _pool_parity(hip, ref, ks, n, rank, size, base2k, dnum, batch, pool, seed, c
         bad = count_bad()
         # the same call with the rounding margin measured on the kernels it dispatches: thin margins are reported before they become wrong limbs
         res.fill_(0x5A5A5A5A)
+        torch.cuda.synchronize()   # torch's stream and the module's stream are not ordered
         margin = probed_margin(hip, run)
-        bad += count_bad()
+        bad_probe = count_bad()
     finally:
         if pin:
             hip.unpin_key(ptr(key))
         hip.set_chunk(0)
+    assert bad_probe == 0 or bad != 0, f"the probing instantiations changed {bad_probe} results (the product kernels were right)"
+    bad += bad_probe
     assert margin < MARGIN_MAX, f"rounding margin too thin: max |x - round(x)| = {margin} (N = {n}, base2k {base2k}, {size} limbs)"
     del a_all, res, d_pool, d_want, key
     torch.cuda.empty_cache()
@@ -177,11 +180,14 @@ def _auto_pool_parity(hip, ref, n, rank, size, base2k, dnum, gal, mode, batch, p
         a_all.copy_(d_pool[idx])
         if not in_place:
             res.fill_(0x5A5A5A5A)
+        torch.cuda.synchronize()   # torch's stream and the module's stream are not ordered
         margin = probed_margin(hip, run)
-        bad += count_bad()
+        bad_probe = count_bad()
     finally:
         if pin:
             hip.unpin_key(ptr(key))
+    assert bad_probe == 0 or bad != 0, f"the probing instantiations changed {bad_probe} results (the product kernels were right)"
+    bad += bad_probe
     assert margin < MARGIN_MAX, f"rounding margin too thin: max |x - round(x)| = {margin} (N = {n}, base2k {base2k}, {size} limbs, automorphism {mode})"
     del a_all, res, d_pool, d_want, key
     torch.cuda.empty_cache()
@@ -257,8 +263,11 @@ def _tensor_pool_parity(hip, ref, n, rank, size, base2k, cnv_offset, mode, batch
     bad = count_bad()
     # once more with the rounding margin measured on the tensoring tails (the previous content of res again: add_assign accumulates)
     d_r.copy_(d_prev[idx])
+    torch.cuda.synchronize()   # torch's stream and the module's stream are not ordered
     margin = probed_margin(hip, run)
-    bad += count_bad()
+    bad_probe = count_bad()
+    assert bad_probe == 0 or bad != 0, f"the probing instantiations changed {bad_probe} results (the product kernels were right)"
+    bad += bad_probe
     assert margin < MARGIN_MAX, f"rounding margin too thin: max |x - round(x)| = {margin} (N = {n}, base2k {base2k}, {size} limbs, tensor {mode})"
     del d_a, d_b, d_r, d_want, d_prev
     torch.cuda.empty_cache()
@@ -409,8 +418,11 @@ def _br_pool_parity(hip, ref, n, rank, n_lwe, block_size, dnum, brk_size, res_si
     bad = int((d_res != d_want[idx]).flatten(1).any(dim=1).sum().item())
     # once more with the rounding margin measured on the rotation's own kernels (one-kernel carry phase / small-ring tail / pipeline tail)
     d_res.fill_(0x3333)
+    torch.cuda.synchronize()   # torch's stream and the module's stream are not ordered
     margin = probed_margin(hip, run)
-    bad += int((d_res != d_want[idx]).flatten(1).any(dim=1).sum().item())
+    bad_probe = int((d_res != d_want[idx]).flatten(1).any(dim=1).sum().item())
+    assert bad_probe == 0 or bad != 0, f"the probing instantiations changed {bad_probe} results (the product kernels were right)"
+    bad += bad_probe
     assert margin < MARGIN_MAX, f"rounding margin too thin: max |x - round(x)| = {margin} (blind rotation, N = {n}, base2k {base2k})"
     return bad
 
