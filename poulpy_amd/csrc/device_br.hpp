@@ -89,7 +89,7 @@ __device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int mp, int m
 // STD = execute_standard (algorithm.rs:370-440, block size 1): per LWE coefficient  tmp = external_product(acc, BRK_i)  (product
 // without the monomial factor, rounding, carry chain WITHOUT adding acc),  acc += (X^a_i - 1) * tmp  on the i64 limbs (a gather in
 // LDS), and one in-place normalization of acc at the very end; needs a second accumulator-sized LDS array for tmp.
-template <int R0, int CT, int NT, int PJ, int MAXR, int CG, bool ACC32, bool STD = false>
+template <int R0, int CT, int NT, int PJ, int MAXR, int CG, bool ACC32, bool STD = false, bool PROBE = false>
 __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
     static_assert(!(STD && ACC32), "the standard variant keeps un-normalized sums: 64-bit accumulators");
     typedef typename AccT<ACC32>::type acc_t;
@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
                 for (int h = 0; h < 2; ++h) {
                     const double val = (h ? v.y : v.x) * inv_m;
                     const double rv = round_half_away(val);
-                    if (g.margin) margin_note(g.margin, fabs(val - rv));
+                    if (PROBE) margin_note(g.margin, fabs(val - rv));   // rounding-margin instantiation (br_forms.hpp)
                     // 3-instruction conversion when exact (|x| < 2^51), the saturating one otherwise (Rust `as i64`)
                     long long x = fabs(rv) < 2251799813685247.0 ? fast_i64_from_integral(rv) : sat_i64_from_integral(rv);
                     if (writes && !STD) {

@@ -23,6 +23,9 @@ constexpr int kSmallIdftRS = kSmallRS + 1;
 #define PZ_SMALL_STAMP 0   // diagnostic build: per-phase s_memtime totals of k_small_inv, printed by three waves of three workgroups
 #endif
 
+#ifndef PZ_SMALL_PROBE
+#define PZ_SMALL_PROBE 1   // (A/B: -DPZ_SMALL_PROBE=0 compiles the run-time rounding-margin probe out of the small-ring kernels)
+#endif
 struct SmallFwdArgs {
     const long long* src;
     PolyMap smap;
@@ -214,7 +217,7 @@ __global__ void __launch_bounds__(256, 2) k_small_idft(SmallIdftArgs g) {
 #pragma unroll
         for (int j1 = 0; j1 < M1; ++j1) big += fabs(v[j1].x) + fabs(v[j1].y);
         big *= 1.0 / (double)m;
-        if (g.margin && active) {
+        if (PZ_SMALL_PROBE && g.margin && active) {
             double worst = 0.0;
 #pragma unroll
             for (int j1 = 0; j1 < M1; ++j1) {
@@ -502,7 +505,7 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
                 if (g.small && (col == g.body_col || g.body_col < 0) && cl < g.small_size)
                     bsrc = g.small + (long long)b * g.small_bs + (g.body_col < 0 ? (long long)col * n : 0) + (long long)cl * g.small_cols * n + cj;
             }
-            if (g.margin) {   // rounding-margin probe: the values PZ_SMALL_ROUND rounds
+            if (PZ_SMALL_PROBE && g.margin) {   // rounding-margin probe: the values PZ_SMALL_ROUND rounds
                 double worst = 0.0;
 #pragma unroll
                 for (int j1 = 0; j1 < M1; ++j1) {

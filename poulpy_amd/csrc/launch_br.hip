@@ -8,92 +8,28 @@
 #include "internal.hpp"
 #include "device_br.hpp"
 #include "device_br_ops.hpp"
+#include "br_forms.hpp"
 
 namespace pz {
 
 int br_try_fused(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
                  const pz_blind_rotation_params* p, size_t batch, bool* launched_out) {
     *launched_out = false;
-    const long long n = (long long)M->n;
-    const int cols = (int)p->rank + 1, dnum = (int)p->dnum, bsz = (int)p->brk_size, rsz = (int)p->res_size;
-    const int B = (int)batch, n_lwe = (int)p->n_lwe, blk = (int)p->block_size, k = (int)p->base2k;
-    const size_t pmat_doubles = (size_t)n * dnum * cols * cols * bsz;
-    {
-        // whole rotation in one kernel, accumulators resident in LDS (device_br.hpp), when the shape fits
-        // (std_variant: execute_standard, one ciphertext per workgroup and a second accumulator-sized array)
-        const bool std_variant = blk == 1;
-        {
-            const int in_limbs = std::min(dnum, rsz), row_max = cols * in_limbs, ncols = cols * bsz, P = std::max(row_max, ncols);
-            const int m = (int)M->m, mp = m + (m >> 4);
-            constexpr int NT = 512;
-            const int r0 = m == 128 ? 2 : (m == 256 ? 4 : 8);
-            auto lds_for = [&](int ct, bool a32) {
-                return ((size_t)m + (size_t)ct * P * mp) * sizeof(cplx) + (size_t)ct * rsz * cols * (size_t)n * (a32 ? 4 : 8) * (std_variant ? 2 : 1);
-            };
-            auto fits = [&](int ct, bool a32) {
-                return lds_for(ct, a32) <= 160 * 1024 && ct * P * (m / 8) <= ((ct == 2 && r0 == 8) ? 2 : 1) * NT && ct * P * (m / r0) <= 2 * NT &&
-                       (!a32 || k <= 31);
-            };
-            static const int force_ct = getenv("POULPY_DBG_BR_CT") ? atoi(getenv("POULPY_DBG_BR_CT")) : 0;
-            const int cgsz = (ncols % 3 == 0 && ncols % 4 != 0) ? 3 : 4;  // 6 output polynomials: two groups of 3, no idle slot
-            const int pj = m * ((ncols + cgsz - 1) / cgsz) <= NT ? 1 : 2;
-            static const int br_one = getenv("POULPY_DBG_BR_ONE") ? atoi(getenv("POULPY_DBG_BR_ONE")) : 1;  // 0: composed path everywhere
-            if (br_one && M->fuse_mid && (m == 128 || m == 256 || m == 512) && NT % m == 0 && row_max <= 8 && ncols <= 8 &&
-                m * ((ncols + cgsz - 1) / cgsz) <= 2 * NT && fits(1, false)) {
-                // two ciphertexts per workgroup share every key value; with 64-bit accumulators when that fits in LDS, else
-                // with 32-bit digit accumulators (m = 128 is only built with one ciphertext per workgroup)
-                int ct = 1;
-                bool a32 = false;
-                if (force_ct != 1 && B >= 2 && m != 128 && !std_variant) {
-                    if (fits(2, false)) ct = 2;
-                    else if (fits(2, true)) { ct = 2; a32 = true; }
-                }
-                const size_t lds = lds_for(ct, a32);
-                BrFusedArgs g;
-                g.res = (long long*)res; g.lut = (const long long*)lut; g.lwe = (const long long*)lwe_2n; g.brk = (const cplx*)brk;
-                g.w2n = M->w2n; g.key_stride = (long long)(pmat_doubles / 2);
-                g.n_lwe = n_lwe; g.blk = blk; g.cols = cols; g.rsz = rsz; g.dnum = dnum; g.bsz = bsz; g.lut_size = (int)p->lut_size;
-                g.base2k = k; g.m = m; g.batch = B;
-                static const int br_skip = getenv("POULPY_DBG_BR_SKIP") ? atoi(getenv("POULPY_DBG_BR_SKIP")) : 0;
-                g.dbg_skip = br_skip; g.margin = M->probe ? M->margin : nullptr;
-                KTimer kt(M, PZ_K_FUSED_MID);
-                bool launched = false;
-#define PZ_BR_STD(R0_, PJ_, MR_, CG_)                                                                                        \
-    if (!launched && std_variant && r0 == R0_ && pj == PJ_ && mr == MR_ && cgsz == CG_) {                                    \
-        PZ_TRY(set_lds((k_br_fused<R0_, 1, NT, PJ_, MR_, CG_, false, true>), lds));                                           \
-        hipLaunchKernelGGL((k_br_fused<R0_, 1, NT, PJ_, MR_, CG_, false, true>), dim3(B), dim3(NT), lds, M->stream, g);       \
-        dispatch_note(M, "k_br_fused<R0=%d,CT=1,NT=512,PJ=%d,MR=%d,CG=%d,A32=0,STD=1> lds=%zu", R0_, PJ_, MR_, CG_, lds);     \
-        launched = true;                                                                                                     \
-    }
-#define PZ_BR_STD_SHAPES(R0_)                                                                                                \
-    PZ_BR_STD(R0_, 1, 4, 4) PZ_BR_STD(R0_, 2, 4, 4) PZ_BR_STD(R0_, 1, 6, 3) PZ_BR_STD(R0_, 2, 6, 3)                          \
-    PZ_BR_STD(R0_, 1, 8, 4) PZ_BR_STD(R0_, 2, 8, 4) PZ_BR_STD(R0_, 1, 8, 3) PZ_BR_STD(R0_, 2, 8, 3)
-#define PZ_BR_ONE(R0_, CT_, PJ_, MR_, CG_, A32_)                                                                             \
-    if (!launched && !std_variant && r0 == R0_ && ct == CT_ && pj == PJ_ && mr == MR_ && cgsz == CG_ && a32 == A32_) {       \
-        PZ_TRY(set_lds(k_br_fused<R0_, CT_, NT, PJ_, MR_, CG_, A32_>, lds));                                                 \
-        hipLaunchKernelGGL((k_br_fused<R0_, CT_, NT, PJ_, MR_, CG_, A32_>), dim3((B + CT_ - 1) / CT_), dim3(NT), lds, M->stream, g); \
-        dispatch_note(M, "k_br_fused<R0=%d,CT=%d,NT=512,PJ=%d,MR=%d,CG=%d,A32=%d> lds=%zu", R0_, CT_, PJ_, MR_, CG_, (int)(A32_), lds); \
-        launched = true;                                                                                                     \
-    }
-#define PZ_BR_SHAPES(R0_, CT_, A32_)                                                                                         \
-    PZ_BR_ONE(R0_, CT_, 1, 4, 4, A32_) PZ_BR_ONE(R0_, CT_, 2, 4, 4, A32_) PZ_BR_ONE(R0_, CT_, 1, 6, 3, A32_) PZ_BR_ONE(R0_, CT_, 2, 6, 3, A32_) \
-    PZ_BR_ONE(R0_, CT_, 1, 8, 4, A32_) PZ_BR_ONE(R0_, CT_, 2, 8, 4, A32_) PZ_BR_ONE(R0_, CT_, 1, 8, 3, A32_) PZ_BR_ONE(R0_, CT_, 2, 8, 3, A32_)
-                const int mr = row_max <= 4 && cgsz == 4 ? 4 : (row_max <= 6 && cgsz == 3 ? 6 : 8);
-                PZ_BR_STD_SHAPES(2) PZ_BR_STD_SHAPES(4) PZ_BR_STD_SHAPES(8)
-                PZ_BR_SHAPES(2, 1, false)
-                PZ_BR_SHAPES(4, 1, false) PZ_BR_SHAPES(4, 2, false) PZ_BR_SHAPES(4, 2, true)
-                PZ_BR_SHAPES(8, 1, false) PZ_BR_SHAPES(8, 2, false) PZ_BR_SHAPES(8, 2, true)
-#undef PZ_BR_SHAPES
-#undef PZ_BR_ONE
-#undef PZ_BR_STD_SHAPES
-#undef PZ_BR_STD
-                if (!launched) return fail(PZ_ERR_UNSUPPORTED, "blind_rotation: no one-kernel variant for this shape");
-                PZ_HIP(hipGetLastError());
-                *launched_out = true;
-                return PZ_OK;
-            }
-        }
-    }
+    // whole rotation in one kernel, accumulators resident in LDS (device_br.hpp), when the shape fits and has an instantiation
+    // (br_forms.hpp); everything else runs the composed path
+    BrFusedPlan pl;
+    if (!br_fused_plan(M, p, batch, &pl)) return PZ_OK;
+    BrFusedArgs g;
+    g.res = (long long*)res; g.lut = (const long long*)lut; g.lwe = (const long long*)lwe_2n; g.brk = (const cplx*)brk;
+    g.w2n = M->w2n; g.key_stride = (long long)(pl.pmat_doubles / 2);
+    g.n_lwe = (int)p->n_lwe; g.blk = (int)p->block_size; g.cols = (int)p->rank + 1; g.rsz = (int)p->res_size; g.dnum = (int)p->dnum;
+    g.bsz = (int)p->brk_size; g.lut_size = (int)p->lut_size; g.base2k = (int)p->base2k; g.m = (int)M->m; g.batch = (int)batch;
+    g.dbg_skip = 0; g.margin = M->probe ? M->margin : nullptr;
+    KTimer kt(M, PZ_K_FUSED_MID);
+    // the rounding-margin instantiation of the same form while the module's probe is on (launch_br_probe.hip)
+    PZ_TRY(M->probe ? br_fused_launch_probe(M, g, pl) : br_fused_launch<false>(M, g, pl));
+    PZ_HIP(hipGetLastError());
+    *launched_out = true;
     return PZ_OK;
 }
 

@@ -221,6 +221,13 @@ inline void dispatch_note(pz_module* M, const char* fmt, ...) {
     va_end(ap);
     for (auto& s : M->notes) if (s == buf) return;
     if (M->notes.size() < 32) M->notes.emplace_back(buf);
+#ifdef PZ_EXPERIMENT
+    // experiment builds (-DPZ_EXPERIMENT): every new note of a module also goes to the file POULPY_DBG_DISPATCH_LOG names - the census of
+    // instantiations a test / bench run dispatches (what tools/dbg/dispatch_census.sh collects before instantiations are pruned)
+    if (const char* path = getenv("POULPY_DBG_DISPATCH_LOG")) {
+        if (FILE* f = fopen(path, "a")) { fprintf(f, "%s\n", buf); fclose(f); }
+    }
+#endif
 }
 
 constexpr size_t kGuardBytes = 256;
