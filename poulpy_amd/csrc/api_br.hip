@@ -29,7 +29,8 @@ size_t pz_blind_rotation_workspace_bytes(const pz_module* M, const pz_blind_rota
     const size_t T = align256(batch * tp * (size_t)M->m * sizeof(cplx));
     if (p->block_size > 1) {
         // the composed path, or (plans with 128-point rows) the row-sliced keys of one block + T' + T2' of the three-kernel block step
-        const size_t composed = align256(batch * n8 * cols * p->dnum) + 2 * align256(batch * n8 * cols * p->brk_size) + T;
+        const size_t composed = align256(batch * n8 * cols * p->dnum) + 2 * align256(batch * n8 * cols * p->brk_size) + T +
+                                align256(batch * (size_t)M->n * cols * p->res_size * sizeof(int));   // (+ the 32-bit digits of the accumulator between blocks)
         const size_t mid = align256((size_t)p->block_size * p->dnum * cols * cols * p->brk_size * n8) +
                            align256(batch * n8 * cols * std::min((size_t)p->dnum, (size_t)p->res_size)) + align256(batch * n8 * cols * p->brk_size) +
                            kMidDummyBytes;
@@ -113,11 +114,17 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
             if (br_small && M->small_path && M->fuse_mid && M->fuse_tail && small_supported(M, npi, bsz) && npi == nrows_key && npi <= 12 &&
                 blk <= 64) {
                 const size_t s_bytes = align256(batch * npi * (size_t)M->m * sizeof(cplx)), a_bytes = align256(batch * ncols_key * (size_t)M->m * sizeof(cplx));
-                PZ_TRY(ws_reserve(M, s_bytes + a_bytes));
+                // between two blocks the accumulator holds normalized digits: kept as 32-bit values in the workspace (base2k <= 31), read and
+                // written by the inverse kernel at half the bytes; the caller's `res` receives the i64 limbs from the last block
+                const int nblocks = n_lwe / blk;
+                const bool acc32 = k <= 31 && nblocks >= 2;
+                const size_t d_bytes = acc32 ? align256((size_t)B * res_ct * sizeof(int)) : 0;
+                PZ_TRY(ws_reserve(M, s_bytes + a_bytes + d_bytes));
                 char* base = (char*)M->ws;
-                cplx* S; cplx* A;
+                cplx* S; cplx* A; int* D = nullptr;
                 PZ_TRY(ws_take(M, base, s_bytes, &S));
                 PZ_TRY(ws_take(M, base, a_bytes, &A));
+                if (acc32) PZ_TRY(ws_take(M, base, d_bytes, &D));
                 PolyMap sm{npi / cols, cols, res_ct, (long long)cols * n, n, 0};
                 // the inverse kernel of a block also runs the forward transform of the new accumulator for the next block (POULPY_DBG_BR_SMALL=2:
                 // separate k_small_fwd launches), when its limbs are among the ones the inverse produces
@@ -130,8 +137,13 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
                                          b0, blk, lwe_2n, lwe_bs, &done));
                     if (!done) return fail(PZ_ERR_UNSUPPORTED, "blind_rotation: block step not launched");
                     const bool more = b0 + 2 * blk <= n_lwe;
-                    PZ_TRY(launch_small_inv(M, B, A, nullptr, ncols_key, 0, 0, cols, bsz, (long long*)res, res_ct, cols, rsz, (const long long*)res,
-                                            res_ct, cols, rsz, k, -1, true, (chain && more) ? S : nullptr, fl));
+                    // operand: `res` in the first block, the 32-bit digits afterwards; destination: the 32-bit digits while blocks follow
+                    // (the separate forward launch of the unchained form reads `res`: i64 throughout there)
+                    const bool use32 = acc32 && chain;
+                    const bool in32 = use32 && b0 > 0, out32 = use32 && more;
+                    PZ_TRY(launch_small_inv(M, B, A, nullptr, ncols_key, 0, 0, cols, bsz, out32 ? (long long*)D : (long long*)res, res_ct, cols, rsz,
+                                            in32 ? (const long long*)D : (const long long*)res, res_ct, cols, rsz, k, -1, true,
+                                            (chain && more) ? S : nullptr, fl, false, 0, 0, false, (in32 ? 1 : 0) | (out32 ? 2 : 0)));
                 }
                 return PZ_OK;
             }

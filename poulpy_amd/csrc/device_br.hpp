@@ -215,6 +215,7 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
                             const int b = min(b0 + ct, g.batch - 1);
                             const unsigned ai = (unsigned)((unsigned long long)g.lwe[(long long)b * (g.n_lwe + 1) + 1 + i] & (unsigned long long)mask2);
                             xm[ct] = g.w2n[(ai * (4u * (unsigned)q + 1u)) & mask2];
+                            if (!STD) xm[ct].x -= 1.0;   // d = DFT(X^a_i)[q] - 1: the factor enters as four FMAs (round 5)
                         }
                         // GUARD_: row_max < MAXR (the template's row count is the next of 4 / 6 / 8).  With row_max == MAXR - the usual shapes -
                         // the per-row test is dropped: as a run-time test inside the unrolled row loop it costs a branch per (column, ciphertext,
@@ -236,9 +237,10 @@ __global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
                 out[pj][ct][j].x += s.x;                                                                         \
                 out[pj][ct][j].y += s.y;                                                                         \
             } else {                                                                                             \
-                const cplx xv = cmul(xm[ct], s);                                                                 \
-                out[pj][ct][j].x = (out[pj][ct][j].x + xv.x) - s.x;                                              \
-                out[pj][ct][j].y = (out[pj][ct][j].y + xv.y) - s.y;                                              \
+                out[pj][ct][j].x = __builtin_fma(xm[ct].x, s.x, out[pj][ct][j].x);                               \
+                out[pj][ct][j].x = __builtin_fma(-xm[ct].y, s.y, out[pj][ct][j].x);                              \
+                out[pj][ct][j].y = __builtin_fma(xm[ct].x, s.y, out[pj][ct][j].y);                               \
+                out[pj][ct][j].y = __builtin_fma(xm[ct].y, s.x, out[pj][ct][j].y);                               \
             }                                                                                                    \
         }                                                                                                        \
     }

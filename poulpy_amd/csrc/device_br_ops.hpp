@@ -195,6 +195,7 @@ __global__ void __launch_bounds__(256) k_br_block(BrBlockArgs g) {
 #pragma unroll
             for (int t = 0; t < CT; ++t) {
                 xm[t] = xn[t];
+                xm[t].x -= 1.0;   // d = DFT(X^a)[q] - 1
                 xn[t] = g.w2n[((unsigned)__builtin_amdgcn_readlane((int)aiv[t], nx) * qf) & mask];
             }
         }
@@ -212,9 +213,12 @@ __global__ void __launch_bounds__(256) k_br_block(BrBlockArgs g) {
                         s.y = __builtin_fma(a[t][r].y, kv[j][r].x, s.y);
                     }
                 }
-                const cplx xv = cmul(xm[t], s);
-                out[t][j].x = (out[t][j].x + xv.x) - s.x;
-                out[t][j].y = (out[t][j].y + xv.y) - s.y;
+                // (DFT(X^a) - 1) s as four FMAs on the difference d = DFT(X^a) - 1 (round 5) instead of x s, + out, - s: eight operations
+                // per (ciphertext, column, coefficient) beside the 4 * rows FMAs of the product
+                out[t][j].x = __builtin_fma(xm[t].x, s.x, out[t][j].x);
+                out[t][j].x = __builtin_fma(-xm[t].y, s.y, out[t][j].x);
+                out[t][j].y = __builtin_fma(xm[t].x, s.y, out[t][j].y);
+                out[t][j].y = __builtin_fma(xm[t].y, s.x, out[t][j].y);
             }
         }
     }
@@ -259,11 +263,22 @@ __device__ __forceinline__ void brl_stage(const cplx (&nxt)[PER], cplx (*ks)[64]
         if (e < NE) ks[e][lane] = nxt[u];
     }
 }
+#ifndef PZ_BRL_STAMP
+#define PZ_BRL_STAMP 0   // diagnostic build: per-phase s_memtime totals of k_br_block_lds, printed by a few waves (tools/dbg/brl_stamps.sh)
+#endif
 template <int CT, int MAXR, int CG>
-__global__ void __launch_bounds__(256) k_br_block_lds(BrBlockArgs g) {
+__global__ void __launch_bounds__(256, (MAXR == 6 ? 3 : 2)) k_br_block_lds(BrBlockArgs g) {   // 6 rows x 3 columns: three workgroups per CU (168 registers)
     constexpr int NW = 4, NE = CG * MAXR, PER = (NE + NW - 1) / NW;
     __shared__ cplx ks[2][NE][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#if PZ_BRL_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_t0 = st_t;
+#define PZ_BSTAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; }
+#else
+#define PZ_BSTAMP(i)
+#endif
     int tile, cg0;
     if (g.allcg) {
         tile = blockIdx.x;
@@ -311,6 +326,10 @@ __global__ void __launch_bounds__(256) k_br_block_lds(BrBlockArgs g) {
     }
     brl_stage<PER, NE>(nxt, ks[0], w, lane);
     __syncthreads();
+#if PZ_BRL_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the accumulator tile has arrived: the prologue's share of the wave's life)
+#endif
+    PZ_BSTAMP(0)
     // stages = (column group, coefficient) pairs in order; the loads of stage s+1 are in flight while stage s is multiplied
     const int nst = (g.allcg ? g.gz : 1) * g.blk;
     int is = 0, cgs = cg0;
@@ -324,6 +343,7 @@ __global__ void __launch_bounds__(256) k_br_block_lds(BrBlockArgs g) {
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
             xm[t] = xn[t];
+            xm[t].x -= 1.0;   // d = DFT(X^a)[q] - 1 (k_br_block)
             xn[t] = g.w2n[((unsigned)__builtin_amdgcn_readlane((int)aiv[t], is_n) * qf) & mask];
         }
         cplx sacc[CT][CG];
@@ -348,16 +368,20 @@ __global__ void __launch_bounds__(256) k_br_block_lds(BrBlockArgs g) {
             }                                                                                    \
         }                                                                                        \
     }
+        PZ_BSTAMP(1)   // fetch issue + monomial gather issue
         if (g.row_max == MAXR) { PZ_BRL_FMAS(false) } else { PZ_BRL_FMAS(true) }
 #undef PZ_BRL_FMAS
+        PZ_BSTAMP(2)   // LDS reads + FMA chains
 #pragma unroll
         for (int j = 0; j < CG; ++j)
 #pragma unroll
             for (int t = 0; t < CT; ++t) {
-                const cplx xv = cmul(xm[t], sacc[t][j]);
-                out[t][j].x = (out[t][j].x + xv.x) - sacc[t][j].x;
-                out[t][j].y = (out[t][j].y + xv.y) - sacc[t][j].y;
+                out[t][j].x = __builtin_fma(xm[t].x, sacc[t][j].x, out[t][j].x);
+                out[t][j].x = __builtin_fma(-xm[t].y, sacc[t][j].y, out[t][j].x);
+                out[t][j].y = __builtin_fma(xm[t].x, sacc[t][j].y, out[t][j].y);
+                out[t][j].y = __builtin_fma(xm[t].y, sacc[t][j].x, out[t][j].y);
             }
+        PZ_BSTAMP(3)   // monomial factor (waits for its gather)
         if (is == g.blk - 1) {  // last coefficient of this column group: store and restart the accumulators
 #pragma unroll
             for (int t = 0; t < CT; ++t) {
@@ -370,11 +394,22 @@ __global__ void __launch_bounds__(256) k_br_block_lds(BrBlockArgs g) {
                 }
             }
         }
+        PZ_BSTAMP(4)   // result stores (issue)
         if (!(PZ_DBG(g.dbg) & 8)) brl_stage<PER, NE>(nxt, ks[buf ^ 1], w, lane);
+        PZ_BSTAMP(5)   // wait for the next stage's key values + LDS writes
         __syncthreads();
+        PZ_BSTAMP(6)   // barrier
         is = is_n;
         cgs = cg_n;
     }
+#if PZ_BRL_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PZ_BSTAMP(7)       // stores acknowledged
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1) && g.i0 == g.blk)
+        printf("BSTAMP wg %d wave %d total %llu | prologue %llu | per stage (%d stages): issue %llu fma %llu monomial %llu stores %llu keywait+stage %llu barrier %llu | storeack %llu\n",
+               (int)blockIdx.x, w, st_t - st_t0, st_acc[0], nst, st_acc[1] / nst, st_acc[2] / nst, st_acc[3] / nst, st_acc[4] / nst, st_acc[5] / nst, st_acc[6] / nst, st_acc[7]);
+#endif
+#undef PZ_BSTAMP
 }
 
 

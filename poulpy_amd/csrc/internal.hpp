@@ -135,7 +135,7 @@ int launch_small_idft(pz_module* M, int npolys, const double* a, PolyMap smap, l
 int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int npi, int nrows, int ncols, int cols_out, int ksz,
                      long long* res, long long res_bs, int res_cols, int res_size, const long long* small, long long small_bs,
                      int small_cols, int small_size, int base2k, int body_col, bool noprod = false, cplx* fwd_S = nullptr, int fwd_limbs = 0,
-                     bool au = false, unsigned au_p = 0, int au_mode = 0, bool post_rsh = false);
+                     bool au = false, unsigned au_p = 0, int au_mode = 0, bool post_rsh = false, int acc32 = 0);
 
 // ---- launch_ops.hip -----------------------------------------------------------------------------------------------
 int launch_ew(pz_module* M, int op, void* res, long long res_bs, long long res_ls, const void* a, long long a_bs,

@@ -115,7 +115,7 @@ int launch_small_fwd(pz_module* M, int npolys, const long long* src, PolyMap sma
 int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int npi, int nrows, int ncols, int cols_out, int ksz,
                      long long* res, long long res_bs, int res_cols, int res_size, const long long* small, long long small_bs,
                      int small_cols, int small_size, int base2k, int body_col, bool noprod, cplx* fwd_S, int fwd_limbs,
-                     bool au, unsigned au_p, int au_mode, bool post_rsh) {
+                     bool au, unsigned au_p, int au_mode, bool post_rsh, int acc32) {
     if (batch <= 0) return PZ_OK;
     PZ_TRY(ensure_small_tables(M));
     SmallInvArgs g;
@@ -125,6 +125,8 @@ int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int
     g.tw12t = M->s_tw12t; g.wL2 = M->s_wL2; g.tw1inv = M->s_tw1inv;
     static const int skip = getenv("POULPY_DBG_SMALL_SKIP") ? atoi(getenv("POULPY_DBG_SMALL_SKIP")) : 0;
     g.dbg = skip; g.margin = M->probe ? M->margin : nullptr;
+    if (acc32 && !(noprod && base2k <= 31)) return fail(PZ_ERR_INVALID, "small-ring pipeline: 32-bit accumulator digits need the product-free form and base2k <= 31");
+    g.acc32 = acc32;
     g.S_out = fwd_S; g.tw1 = M->s_tw1; g.fwd_limbs = fwd_S ? fwd_limbs : 0;
     g.au_p = au_p; g.au_mode = au_mode; g.post_rsh = (post_rsh && au) ? 1 : 0;
     {   // p^-1 mod 2^32 by Newton steps (p odd), reduced mod 2n in the kernel
