@@ -266,6 +266,13 @@ __device__ __forceinline__ void brl_stage(const cplx (&nxt)[PER], cplx (*ks)[64]
 #ifndef PZ_BRL_STAMP
 #define PZ_BRL_STAMP 0   // diagnostic build: per-phase s_memtime totals of k_br_block_lds, printed by a few waves (tools/dbg/brl_stamps.sh)
 #endif
+// (Round 5, measured and dropped, both on the evidence of the stamps' 0.5 - 2.3 k cycles per stage in front of the LDS writes
+//  (profiles/r05_brl_stamps.txt): (1) the stage's key values L2 -> LDS by global_load_lds instead of through registers + ds_write - 20 - 28
+//  registers fewer, no ds_write, and 5 - 8 % SLOWER, 8.10 -> 8.50 ms per 82 block steps at N = 2048, 5.38 -> 5.81 for the rank-2 shape: an
+//  LDS-DMA piece costs the issuing wave far more than a global_load + ds_write pair here (profiles/r05_ab_brl_dma.txt); (2) the key values
+//  requested TWO stages ahead, two register sets in ping-pong with the stage loop unrolled by two: 5.38 -> 5.48 ms for the rank-2 shape (no
+//  spill at 240 registers), 8.07 -> 8.47 for the 6-row shape (at two workgroups per CU instead of three) - profiles/r05_ab_brl_pf2.txt.
+//  The wait the stamps show in that phase is not the requests' latency.)
 template <int CT, int MAXR, int CG>
 __global__ void __launch_bounds__(256, (MAXR == 6 ? 3 : 2)) k_br_block_lds(BrBlockArgs g) {   // 6 rows x 3 columns: three workgroups per CU (168 registers)
     constexpr int NW = 4, NE = CG * MAXR, PER = (NE + NW - 1) / NW;
