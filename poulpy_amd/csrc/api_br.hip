@@ -33,7 +33,7 @@ size_t pz_blind_rotation_workspace_bytes(const pz_module* M, const pz_blind_rota
                                 align256(batch * (size_t)M->n * cols * p->res_size * sizeof(int));   // (+ the 32-bit digits of the accumulator between blocks)
         const size_t mid = align256((size_t)p->block_size * p->dnum * cols * cols * p->brk_size * n8) +
                            align256(batch * n8 * cols * std::min((size_t)p->dnum, (size_t)p->res_size)) + align256(batch * n8 * cols * p->brk_size) +
-                           kMidDummyBytes;
+                           kMidDummyBytes + align256(batch * (size_t)M->n * cols * p->res_size * sizeof(int));
         return std::max(composed, mid);
     }
     pz_glwe_op_params ep;
@@ -86,20 +86,31 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
                 npi == nrows_key && blk <= 16) {
                 const size_t key_bytes = align256((size_t)blk * nrows_key * ncols_key * n8);
                 const size_t t_bytes = align256(batch * npi * (size_t)M->m * sizeof(cplx)), t2_bytes = align256(batch * npo * (size_t)M->m * sizeof(cplx));
-                PZ_TRY(ws_reserve(M, key_bytes + t_bytes + t2_bytes + kMidDummyBytes));
+                // between two blocks the accumulator holds normalized digits: 32-bit values in the workspace (base2k <= 31) - pass 1 and the tail
+                // move them at half the bytes; the caller's `res` is the operand of the first block and the destination of the last
+                const int nblocks = n_lwe / blk;
+                const bool acc32 = k <= 31 && nblocks >= 2 && tail_acc32_supported(M);
+                const size_t d_bytes = acc32 ? align256((size_t)B * res_ct * sizeof(int)) : 0;
+                PZ_TRY(ws_reserve(M, key_bytes + t_bytes + t2_bytes + kMidDummyBytes + d_bytes));
                 char* base = (char*)M->ws;
-                cplx* Pp; cplx* T; cplx* T2; cplx* mid_dummy;
+                cplx* Pp; cplx* T; cplx* T2; cplx* mid_dummy; int* D = nullptr;
                 PZ_TRY(ws_take(M, base, key_bytes, &Pp));
                 PZ_TRY(ws_take(M, base, t_bytes, &T));
                 PZ_TRY(ws_take(M, base, t2_bytes, &T2));
                 PZ_TRY(ws_take(M, base, kMidDummyBytes, &mid_dummy));
+                if (acc32) PZ_TRY(ws_take(M, base, d_bytes, &D));
                 PolyMap sm{npi / cols, cols, res_ct, (long long)cols * n, n, 0};
                 for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {
+                    const bool in32 = acc32 && b0 > 0, out32 = acc32 && b0 + 2 * blk <= n_lwe;
                     PZ_TRY(launch_permute_pmat(M, brk + (size_t)b0 * pmat_doubles, Pp, blk * nrows_key * ncols_key));
-                    PZ_TRY(launch_fwd_pass1(M, B * npi, (const long long*)res, sm, T, true));
+                    PZ_TRY(launch_fwd_pass1(M, B * npi, in32 ? (const long long*)D : (const long long*)res, sm, T, true, -1, in32));
                     MidBr mb{(const long long*)lwe_2n, lwe_bs, b0, blk};
                     PZ_TRY(launch_mid(M, B, T, T2, Pp, npi, npo, nrows_key, ncols_key, mid_dummy, 0, 0, nullptr, &mb));
-                    PZ_TRY(launch_inv_tail(M, acc_tail(B, T2, true, bsz, cols, res, res_ct, rsz, k)));
+                    TailCall tc = acc_tail(B, T2, true, bsz, cols, res, res_ct, rsz, k);
+                    if (in32) tc.small = (const long long*)D;
+                    if (out32) tc.res = (long long*)D;
+                    tc.acc32 = (in32 ? 1 : 0) | (out32 ? 2 : 0);
+                    PZ_TRY(launch_inv_tail(M, tc));
                 }
                 return PZ_OK;
             }

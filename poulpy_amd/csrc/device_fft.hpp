@@ -199,7 +199,8 @@ __device__ __forceinline__ long long fast_i64_from_integral(double r) {
 // =================================================================================
 // ROWMAJOR = true writes T'[q1][j2] (rows of m2 contiguous points, what the fused middle kernel
 // consumes; tw12 must then be the [q1][j2] copy of the table) instead of the transposed T[j2][q1].
-template <int R1, int R2, int CB, bool ROWMAJOR = false>
+// SRC32: the coefficients are 32-bit digits at the same element offsets (the blind rotation's accumulator between two blocks, api_br.hip)
+template <int R1, int R2, int CB, bool ROWMAJOR = false, bool SRC32 = false>
 __global__ void __launch_bounds__((R1 > R2 ? R1 : R2) * CB)
 k_fwd_pass1(const long long* __restrict__ src, PolyMap smap, cplx* __restrict__ T, int m2,
             const cplx* __restrict__ tw1, const cplx* __restrict__ wL1, const cplx* __restrict__ tw12, long long mask, int npolys_xcd) {
@@ -235,8 +236,14 @@ k_fwd_pass1(const long long* __restrict__ src, PolyMap smap, cplx* __restrict__ 
 #pragma unroll
         for (int n1 = 0; n1 < R1; ++n1) {
             const long long idx = (long long)(o + R2 * n1) * m2 + c0 + c;
-            raw_re[n1] = (ROWMAJOR ? ld_stream(a + idx) : a[idx]) & mask;   // mask = -1 except for cnv_prepare's last active limb (reim/conversion.rs:31-40)
-            raw_im[n1] = (ROWMAJOR ? ld_stream(a + idx + m) : a[idx + m]) & mask;
+            if constexpr (SRC32) {
+                const int* a32 = reinterpret_cast<const int*>(src) + map_off(smap, p);
+                raw_re[n1] = (long long)a32[idx];
+                raw_im[n1] = (long long)a32[idx + m];
+            } else {
+                raw_re[n1] = (ROWMAJOR ? ld_stream(a + idx) : a[idx]) & mask;   // mask = -1 except for cnv_prepare's last active limb (reim/conversion.rs:31-40)
+                raw_im[n1] = (ROWMAJOR ? ld_stream(a + idx + m) : a[idx + m]) & mask;
+            }
         }
     }
     for (int t = tid; t < M1; t += NT) {
@@ -453,6 +460,7 @@ struct TailArgs {
     const cplx* tw1inv;
     const cplx* wL1;
     unsigned long long* margin;
+    int acc32;   // k_inv_tail<.., ACC32>: bit 0 `small` holds 32-bit digits, bit 1 `res` takes 32-bit digits (same element strides)
     // automorphism family (poulpy-core automorphism/glwe_ct.rs:96-275): the value that enters the carry chain is
     // s(n) * (big[n] + small[n]) with s(n) = -1 iff (n * auto_mul) mod 2N >= N (auto_neg flips every sign);
     // small_all: `small` has an operand for every column, not only the body column
@@ -531,10 +539,13 @@ __device__ __forceinline__ int sx_carry(int k, int x, int d) { return (x - d) >>
 //  and the tests in front of every store)
 // SGN (round 4): the signs of X -> X^p (TailArgs::auto_mul / auto_neg / post_neg) without an operand - the columns of a plain spectral
 // glwe_automorphism that carry no body: they ride on the f64 chain like a product's columns instead of the operand variant's integer chain
-template <int R1, int R2, int CB, bool ROWMAJOR = false, bool SMALL = false, bool RSH = false, int NZ = 0, bool SGN = false, bool PROBE = false>
+// ACC32 (round 5; with SMALL, every column its own operand): the blind rotation's accumulator between two blocks of the pipeline path - operand and /
+// or result as 32-bit digits (TailArgs::acc32), half the bytes of the two streams this kernel moves beside T2'
+template <int R1, int R2, int CB, bool ROWMAJOR = false, bool SMALL = false, bool RSH = false, int NZ = 0, bool SGN = false, bool PROBE = false, bool ACC32 = false>
 __global__ void __launch_bounds__(((R1 == 16 ? 2 : 1) * R2 + R1) * CB, ((((R1 == 16 ? 2 : 1) * R2 + R1) * CB >= 512) ? 1 : (SMALL ? 2 : 3)))
 k_inv_tail(TailArgs g) {
     static_assert(!RSH || SMALL, "the shifted store rides on the integer carry chain");
+    static_assert(!ACC32 || (ROWMAJOR && SMALL && !RSH && !NZ && !SGN), "32-bit accumulator digits: the plain operand form of the row-major pipeline");
     static_assert(!NZ || (ROWMAJOR && !SMALL && !RSH), "tensoring forms: row-major pipeline layout, no operand");
     static_assert(!SGN || (ROWMAJOR && !SMALL && !RSH && !NZ), "sign-only form: row-major pipeline layout, no operand");
     constexpr bool SPLIT = TailShape<R1, R2, CB>::SPLIT;
@@ -659,6 +670,10 @@ k_inv_tail(TailArgs g) {
             if (NZ && g.nz) {
                 PZ_TAIL_NZ_STORE(j, idx, 0)
                 PZ_TAIL_NZ_STORE(j, idx + m, 0)
+            } else if (ACC32 && (g.acc32 & 2)) {
+                int* r32 = reinterpret_cast<int*>(g.res) + (res_col - g.res);
+                r32[(long long)j * res_ls + idx] = 0;
+                r32[(long long)j * res_ls + idx + m] = 0;
             } else {
                 res_col[(long long)j * res_ls + idx] = 0;
                 res_col[(long long)j * res_ls + idx + m] = 0;
@@ -743,6 +758,14 @@ k_inv_tail(TailArgs g) {
                     if (body) v += (unsigned long long)body[ih];
                     sm[2 * e + h] = (long long)v;
                 }
+            }
+        } else if (ACC32 && (g.acc32 & 1) && small_col && j < g.small_size) {
+            const int* s32 = reinterpret_cast<const int*>(g.small) + (small_col - g.small) + (long long)j * small_ls;
+#pragma unroll
+            for (int e = 0; e < RE; ++e) {
+                const long long idx = (long long)(b_ov + R2 * PZ_TAIL_N1(e)) * g.m2 + c0 + b_cv;
+                sm[SMALL ? 2 * e : 0] = (long long)s32[idx];
+                sm[SMALL ? 2 * e + 1 : 0] = (long long)s32[idx + m];
             }
         } else if (SMALL && small_col && j < g.small_size) {
 #pragma unroll
@@ -863,7 +886,11 @@ k_inv_tail(TailArgs g) {
                         }                                                                                    \
                         if (j == 0) st_stream(res_col + idx, (long long)sx_digit(k, c2));                    \
                     }                                                                                        \
-                } else if (writes) { if (ROWMAJOR) st_stream(res_col + (long long)j * res_ls + idx, x1); else res_col[(long long)j * res_ls + idx] = x1; } \
+                } else if (writes) {                                                                         \
+                    if (ACC32 && (g.acc32 & 2)) (reinterpret_cast<int*>(g.res) + (res_col - g.res))[(long long)j * res_ls + idx] = (int)x1; \
+                    else if (ROWMAJOR) st_stream(res_col + (long long)j * res_ls + idx, x1);                 \
+                    else res_col[(long long)j * res_ls + idx] = x1;                                          \
+                }                                                                                            \
             }                                                                                                \
         }                                                                                                    \
     }

@@ -19,6 +19,11 @@ namespace pz {
 
 constexpr int kSmallM2 = 128, kSmallRS = 16 * 9;   // row stride as in k_mid128 (z[k1][o] at k1*9 + o)
 constexpr int kSmallIdftRS = kSmallRS + 1;
+// k_small_inv<.., NOPROD> (blind rotation's tail): the spectra arrive in the standard order and consecutive lanes drop them at M1 consecutive ROWS
+// of the tile - with a row stride of 144 points (= 0 mod 64 banks) an M1-way bank conflict on every write (round 5 counters: 4.6 conflict cycles per
+// LDS instruction, profiles/r05_br_pmc/n2048_pmc.txt).  Row stride = 144 + d with (row * d + column) mod 16 distinct over the 16 lanes of a
+// 128-bit access: d = 4 (M1 = 4: 4 rows x 4 columns), 2 (8 rows x 2 columns), 1 (16 rows).  The in-row layout (k1 * 9 + o) is untouched.
+constexpr int small_inv_rs(int m1, bool noprod) { return noprod ? kSmallRS + (m1 == 16 ? 1 : (m1 == 8 ? 2 : 4)) : kSmallRS; }
 #ifndef PZ_SMALL_STAMP
 #define PZ_SMALL_STAMP 0   // diagnostic build: per-phase s_memtime totals of k_small_inv, printed by three waves of three workgroups
 #endif
@@ -300,7 +305,7 @@ struct SmallInvArgs {
 template <int M1, int KS, bool NOPROD = false, bool FWD = false, bool AU = false>
 __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
     constexpr int NT = 64 * M1;          // 2 product positions per thread (m = 128 M1 points)
-    constexpr int M2 = kSmallM2, RS = kSmallRS, L = KS;
+    constexpr int M2 = kSmallM2, RS = small_inv_rs(M1, NOPROD), L = KS;
     constexpr long long m = (long long)M1 * kSmallM2, n = 2 * m;
     extern __shared__ cplx lds[];
     const int tid = threadIdx.x;

@@ -42,7 +42,8 @@ inline void* poly_ptr(const pz_module* M, const DV& v, int col, int limb) {
 }
 
 // ---- launch_fft.hip -----------------------------------------------------------------------------------------------
-int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* T, bool rowmajor = false, long long mask = -1);
+int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* T, bool rowmajor = false, long long mask = -1,
+                     bool src32 = false);   // src32 (row-major, 128-point-row plans): `src` holds 32-bit digits at the same element offsets
 int launch_fwd_pass2(pz_module* M, int npolys, const cplx* T, double* dst, PolyMap dmap, const cplx* mul);
 int launch_inv_pass2(pz_module* M, int npolys, const double* src, PolyMap smap, cplx* T);
 int launch_inv_pass1(pz_module* M, int npolys, const cplx* T, long long* dst, PolyMap dmap);
@@ -82,11 +83,14 @@ struct TailCall {
     bool post_neg = false;            // put s(n) back on the digits (plain form: phi acts on the normalized value)
     unsigned gather_mul = 0;          // != 0: the operand is -+phi^-1(small), gathered inside the tail (older, non-spectral scheme)
     bool gather_neg = false;
+    // ---- blind rotation's accumulator between two blocks: 32-bit digits (bit 0: `small`, bit 1: `res`; same element strides) ----
+    int acc32 = 0;
     // ---- glwe_trace: the digits leave through a one-bit vec_znx_rsh_assign ----
     bool post_rsh = false;
 };
 int launch_inv_tail(pz_module* M, const TailCall& c);
 bool tail_rsh_supported(const pz_module* M);
+bool tail_acc32_supported(const pz_module* M);   // 32-bit accumulator digits (TailCall::acc32; launch_fwd_pass1's src32 covers the same plans)
 bool mid_cnv_supported(const pz_module* M, int a_size, int b_size, int min_size);
 int launch_mid_cnv(pz_module* M, int batch, const cplx* a_main, const cplx* a_last, const cplx* b_main, const cplx* b_last, cplx* T2, int cols,
                    int a_size, int b_size, int a_i, int a_j, int b_i, int b_j, int min_size, int offset);

@@ -9,6 +9,9 @@
 #include "device_br.hpp"
 #include "device_br_ops.hpp"
 #include "br_forms.hpp"
+#ifndef PZ_BRL_94
+#define PZ_BRL_94 1   // rank 2 (9 rows, 12 columns): three column groups of 4 instead of four of 3 - 21 stages instead of 28, 5.36 -> 5.22 ms per 82 block steps (profiles/r05_ab_brl94.txt)
+#endif
 
 namespace pz {
 
@@ -54,7 +57,7 @@ int br_block_step(pz_module* M, const double* acc_dft, long long a_bs, double* a
                 // circuit-bootstrapping shape) has 9 or 12 inputs, so fewer columns per workgroup there
                 int mr, cgs;
                 if (row_max > 9 || (row_max > 8 && nc % 3 != 0)) { mr = 12; cgs = 2; }
-                else if (row_max > 8) { mr = 9; cgs = 3; }
+                else if (row_max > 8) { mr = 9; cgs = (nc % 4 == 0 && PZ_BRL_94) ? 4 : 3; }
                 else if (nc % 3 == 0 && nc % 4 != 0) { mr = row_max <= 6 ? 6 : 8; cgs = 3; }   // 3, 6 columns: groups of 3
                 else { mr = row_max <= 4 ? 4 : 8; cgs = 4; }
                 const int ngroups = (nc + cgs - 1) / cgs;
@@ -78,7 +81,7 @@ int br_block_step(pz_module* M, const double* acc_dft, long long a_bs, double* a
         dispatch_note(M, "k_br_block_lds<2,MR=%d,CG=%d> (8 ciphertexts per staged key value)", MR_, CG_);          \
         launched = true;                                                                                           \
     }
-                    PZ_BRB(12, 2) PZ_BRB(9, 3) PZ_BRB(6, 3) PZ_BRB(8, 3) PZ_BRB(4, 4) PZ_BRB(8, 4)
+                    PZ_BRB(12, 2) PZ_BRB(9, 3) PZ_BRB(9, 4) PZ_BRB(6, 3) PZ_BRB(8, 3) PZ_BRB(4, 4) PZ_BRB(8, 4)
 #undef PZ_BRB
                 } else {
 #define PZ_BRB(MR_, CG_)                                                                                           \

@@ -13,7 +13,7 @@ namespace pz {
 #define PZ_P2_CASES(X) X(2, 1, 2) X(4, 1, 2) X(4, 1, 4) X(8, 1, 4) X(16, 1, 4) X(16, 1, 16) X(8, 4, 16) X(8, 8, 16) X(16, 8, 16) X(16, 16, 16)
 
 
-int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* T, bool rowmajor, long long mask) {
+int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* T, bool rowmajor, long long mask, bool src32) {
     const FftPlan& pl = M->plan;
     if (npolys == 0) return PZ_OK;
     KTimer kt(M, PZ_K_FWD_PASS1);
@@ -27,6 +27,21 @@ int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap sma
     static const int xcd_order = getenv("POULPY_DBG_XCD_ORDER") ? atoi(getenv("POULPY_DBG_XCD_ORDER")) : 1;
     const int npx = (rowmajor && xcd_order) ? npolys : 0;
     const int blocks_rm = npx ? ((npolys + 7) / 8) * 8 * ncb : blocks;
+    if (src32) {   // 32-bit source digits: the row-major form of the 128-point-row plans (the blind rotation's pipeline path)
+        if (!(rowmajor && mask == -1)) return fail(PZ_ERR_INVALID, "forward pass 1: 32-bit source digits need the row-major form");
+#define X(A, B, C)                                                                                              \
+    if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
+        const size_t lds = ((size_t)(A + 1) * C * B + 2 * A * B) * sizeof(cplx);                                \
+        PZ_TRY(set_lds((k_fwd_pass1<A, B, C, true, true>), lds));                                               \
+        hipLaunchKernelGGL((k_fwd_pass1<A, B, C, true, true>), dim3(blocks_rm), dim3((A > B ? A : B) * C), lds, M->stream, src, smap, \
+                           T, pl.m2, M->tw1, M->wL1, M->tw12t, mask, npx);                                      \
+        PZ_HIP(hipGetLastError());                                                                              \
+        return PZ_OK;                                                                                           \
+    }
+        X(4, 4, 16) X(4, 8, 16) X(8, 8, 16) X(8, 16, 16) X(16, 16, 16)
+#undef X
+        return fail(PZ_ERR_UNSUPPORTED, "forward pass 1: no 32-bit-source form for this plan");
+    }
 #define X(A, B, C)                                                                                              \
     if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
         const size_t lds = ((size_t)(A + 1) * C * B + 2 * A * B) * sizeof(cplx);                                              \

@@ -140,7 +140,7 @@ int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int
     if (fwd_S && !(noprod && fwd_limbs >= 1 && fwd_limbs <= ksz && fwd_limbs <= res_size && fwd_limbs <= 8))
         return fail(PZ_ERR_INVALID, "small-ring pipeline: forward transform of %d limbs behind the inverse of %d", fwd_limbs, ksz);
     const int m1 = small_m1(M);
-    const size_t lds = ((size_t)ksz * m1 * kSmallRS + kSmallM2 + m1) * sizeof(cplx);   // tile + wL2 + tw1inv
+    const size_t lds = ((size_t)ksz * m1 * small_inv_rs(m1, noprod) + kSmallM2 + m1) * sizeof(cplx);   // tile + wL2 + tw1inv
     // workgroup id -> (xcd = id & 7, slot = id >> 3): ciphertext (slot / cols_out) * 8 + xcd, column slot % cols_out
     const int grid = ((batch + 7) / 8) * 8 * cols_out;
     KTimer kt(M, PZ_K_FUSED_TAIL);

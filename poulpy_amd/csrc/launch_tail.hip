@@ -11,6 +11,12 @@ namespace pz {
 
 // the two roles of k_inv_tail must be whole waves
 bool tail_supported(const pz_module* M) { return (M->plan.f1b * M->plan.cb) % 64 == 0; }
+bool tail_acc32_supported(const pz_module* M) {
+#define X(A, B, C) if (M->plan.f1a == A && M->plan.f1b == B && M->plan.cb == C) return true;
+    PZ_ACC32_CASES(X)
+#undef X
+    return false;
+}
 bool tail_rsh_supported(const pz_module* M) {
 #define X(A, B, C) if (M->plan.f1a == A && M->plan.f1b == B && M->plan.cb == C) return true;
     PZ_RSH_CASES(X)
@@ -36,6 +42,7 @@ static TailArgs tail_args(const pz_module* M, const TailCall& c, int col_base, i
     g.nz_lsh = nz ? nz->lsh : 0; g.nz_res_end = nz ? nz->res_end : 0; g.nz_res_start = nz ? nz->res_start : 0; g.nz_a_end = nz ? nz->a_end : 0;
     g.nz_a_start = nz ? nz->a_start : 0; g.nz_zero_from = nz ? nz->zero_from : 0; g.nz_col = nz ? nz->col : 0; g.nz_mode = nz ? nz->mode : 0;
     for (int u = 0; u < 2; ++u) { g.nz_col2[u] = nz ? nz->col2[u] : 0; g.nz_mode2[u] = nz ? nz->mode2[u] : 0; }
+    g.acc32 = c.acc32;
     g.xcd_map = 0;
     return g;
 }
@@ -57,7 +64,12 @@ static int launch_inv_tail_cols(pz_module* M, const TailCall& c, int col_base, i
     const bool has_small = c.small != nullptr;
     TailForm f;
     f.rowmajor = c.rowmajor; f.has_small = has_small;
-    if (c.post_rsh) {
+    if (c.acc32) {   // 32-bit accumulator digits: the plain every-column-operand form, nothing else
+        if (!(tail_acc32_supported(M) && c.rowmajor && has_small && c.small_all && !c.post_rsh && !raw && !nz && c.auto_mul == 0 && c.gather_mul == 0 &&
+              c.body_src == nullptr && !c.body_gather && c.base2k <= 31))
+            return fail(PZ_ERR_UNSUPPORTED, "fused tail: no 32-bit-accumulator variant for this call");
+        f.kind = TailForm::ACC32;
+    } else if (c.post_rsh) {
         if (!(tail_rsh_supported(M) && c.rowmajor && has_small)) return fail(PZ_ERR_UNSUPPORTED, "fused tail: no shifted-store variant for this plan");
         f.kind = TailForm::RSH;
     } else if (!has_small && c.auto_mul != 0) {   // signs without an operand (launch_inv_tail: the body-less columns of a plain spectral automorphism)

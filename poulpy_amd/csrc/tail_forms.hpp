@@ -10,22 +10,31 @@ namespace pz {
 // the forms beyond the plain one - digits leaving through a one-bit vec_znx_rsh (glwe_trace), the sign-only tail of a spectral automorphism,
 // the tensoring tails - are instantiated for the 128-point-row plans (N = 2^13 .. 2^16)
 #define PZ_RSH_CASES(X) X(4, 8, 16) X(8, 8, 16) X(8, 16, 16) X(16, 16, 16)
+// the 32-bit-accumulator form (blind rotation on the pipeline): every 128-point-row plan it runs on, N = 2^12 .. 2^16
+#define PZ_ACC32_CASES(X) X(4, 4, 16) PZ_RSH_CASES(X)
 
 struct TailForm {
-    enum Kind { PLAIN, RSH, SGN, NZ1, NZ2 } kind = PLAIN;
+    enum Kind { PLAIN, RSH, SGN, NZ1, NZ2, ACC32 } kind = PLAIN;   // ACC32: 32-bit accumulator digits (blind rotation's pipeline path)
     bool rowmajor = false, has_small = false;   // PLAIN: one instantiation per (row-major, body add) combination
 };
 
 template <bool PROBE>
 static int tail_launch_form(pz_module* M, const TailArgs& g, int blocks, const TailForm& f) {
     const FftPlan& pl = M->plan;
-#define PZ_TAIL_GO(A, B, C, R_, S_, RSH_, NZ_, SGN_)                                                            \
+#define PZ_TAIL_GO(A, B, C, R_, S_, RSH_, NZ_, SGN_) PZ_TAIL_GO2(A, B, C, R_, S_, RSH_, NZ_, SGN_, false)
+#define PZ_TAIL_GO2(A, B, C, R_, S_, RSH_, NZ_, SGN_, A32_)                                                     \
     {                                                                                                           \
         const size_t lds = ((size_t)2 * (A + 1) * C * B + 2 * A * B) * sizeof(cplx);                            \
-        PZ_TRY(set_lds((k_inv_tail<A, B, C, R_, S_, RSH_, NZ_, SGN_, PROBE>), lds));                            \
-        hipLaunchKernelGGL((k_inv_tail<A, B, C, R_, S_, RSH_, NZ_, SGN_, PROBE>), dim3(blocks), dim3(TailShape<A, B, C>::NT), lds, M->stream, g); \
+        PZ_TRY(set_lds((k_inv_tail<A, B, C, R_, S_, RSH_, NZ_, SGN_, PROBE, A32_>), lds));                      \
+        hipLaunchKernelGGL((k_inv_tail<A, B, C, R_, S_, RSH_, NZ_, SGN_, PROBE, A32_>), dim3(blocks), dim3(TailShape<A, B, C>::NT), lds, M->stream, g); \
         PZ_HIP(hipGetLastError());                                                                              \
         return PZ_OK;                                                                                           \
+    }
+    if (f.kind == TailForm::ACC32) {
+#define X(A, B, C) if (pl.f1a == A && pl.f1b == B && pl.cb == C) PZ_TAIL_GO2(A, B, C, true, true, false, 0, false, true)
+        PZ_ACC32_CASES(X)
+#undef X
+        return fail(PZ_ERR_UNSUPPORTED, "fused tail: the 32-bit-accumulator form is not instantiated for this plan");
     }
     if (f.kind != TailForm::PLAIN) {
 #define X(A, B, C)                                                                                              \
@@ -49,6 +58,7 @@ static int tail_launch_form(pz_module* M, const TailArgs& g, int blocks, const T
     PZ_P1F_CASES(X)
 #undef X
 #undef PZ_TAIL_GO
+#undef PZ_TAIL_GO2
     return fail(PZ_ERR_UNSUPPORTED, "no fused tail kernel for m1=%d", pl.m1);
 }
 // launch_tail_probe.hip
