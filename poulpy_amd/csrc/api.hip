@@ -340,6 +340,9 @@ void pz_module_free(pz_module* M) {
         if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
         if (ge.graph) (void)hipGraphDestroy(ge.graph);
     }
+    if (M->stream2) { (void)hipStreamSynchronize(M->stream2); (void)hipStreamDestroy(M->stream2); }
+    if (M->ev_fork) (void)hipEventDestroy(M->ev_fork);
+    if (M->ev_join) (void)hipEventDestroy(M->ev_join);
     if (M->stream) (void)hipStreamDestroy(M->stream);
     delete M;
 }

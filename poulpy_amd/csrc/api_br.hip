@@ -100,6 +100,8 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
                 PZ_TRY(ws_take(M, base, kMidDummyBytes, &mid_dummy));
                 if (acc32) PZ_TRY(ws_take(M, base, d_bytes, &D));
                 PolyMap sm{npi / cols, cols, res_ct, (long long)cols * n, n, 0};
+                // (round 5, measured and dropped: the two-stream split of the small-ring path below applied here - the persistent middle kernel holds every
+                //  CU's LDS, so the other half's pass 1 / tail cannot run beside it: N = 4096 -3.6 %, N = 2^14 +-0; profiles/r05_ab_br_two_streams_pipe.txt)
                 for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {
                     const bool in32 = acc32 && b0 > 0, out32 = acc32 && b0 + 2 * blk <= n_lwe;
                     PZ_TRY(launch_permute_pmat(M, brk + (size_t)b0 * pmat_doubles, Pp, blk * nrows_key * ncols_key));
@@ -141,22 +143,38 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
                 // separate k_small_fwd launches), when its limbs are among the ones the inverse produces
                 const int fl = npi / cols;
                 const bool chain = br_small != 2 && fl <= bsz && fl <= rsz;
+                // Two halves of the batch on two streams (round 5): the block step is bound by FP64 issue, the inverse / forward kernel around it by
+                // HBM and LDS latency - issued back to back on one stream each leaves the other's unit idle; as two independent chains the step of one
+                // half overlaps with the transforms of the other (split at a tile boundary of the block step: 8 ciphertexts)
+                // (measured, profiles/r05_ab_br_two_streams*.txt: N = 2048 at 1024 / 512 / 256 per call +5.5 % / +10 % / -16 %; rank 2 at N = 1024:
+                //  1024 per call +1 %, 512 -4 % - a half must still fill the chip: >= 2^19 coefficients per column)
+                const int hA = ((long long)(B / 2) * n >= (1ll << 19) && !M->timing) ? ((B / 2 + 7) / 8) * 8 : B;
+                SideStream ss(M);
+                if (hA < B) PZ_TRY(ss.fork());
                 for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {
-                    if (b0 == 0 || !chain) PZ_TRY(launch_small_fwd(M, B * npi, (const long long*)res, sm, S, true));
-                    bool done = false;
-                    PZ_TRY(br_block_step(M, (const double*)S, (long long)npi * n, (double*)A, (long long)ncols_key * n, brk, pmat_doubles, npi, ncols_key, B,
-                                         b0, blk, lwe_2n, lwe_bs, &done));
-                    if (!done) return fail(PZ_ERR_UNSUPPORTED, "blind_rotation: block step not launched");
                     const bool more = b0 + 2 * blk <= n_lwe;
                     // operand: `res` in the first block, the 32-bit digits afterwards; destination: the 32-bit digits while blocks follow
                     // (the separate forward launch of the unchained form reads `res`: i64 throughout there)
                     const bool use32 = acc32 && chain;
                     const bool in32 = use32 && b0 > 0, out32 = use32 && more;
-                    PZ_TRY(launch_small_inv(M, B, A, nullptr, ncols_key, 0, 0, cols, bsz, out32 ? (long long*)D : (long long*)res, res_ct, cols, rsz,
-                                            in32 ? (const long long*)D : (const long long*)res, res_ct, cols, rsz, k, -1, true,
-                                            (chain && more) ? S : nullptr, fl, false, 0, 0, false, (in32 ? 1 : 0) | (out32 ? 2 : 0)));
+                    for (int half = 0; half < (hA < B ? 2 : 1); ++half) {
+                        const int c0 = half ? hA : 0, nb = half ? B - hA : hA;
+                        ss.on(half == 1);
+                        int64_t* res_h = res + (long long)c0 * res_ct;
+                        int* D_h = D ? D + (long long)c0 * res_ct : nullptr;
+                        cplx* S_h = S + (size_t)c0 * npi * M->m;
+                        cplx* A_h = A + (size_t)c0 * ncols_key * M->m;
+                        if (b0 == 0 || !chain) PZ_TRY(launch_small_fwd(M, nb * npi, (const long long*)res_h, sm, S_h, true));
+                        bool done = false;
+                        PZ_TRY(br_block_step(M, (const double*)S_h, (long long)npi * n, (double*)A_h, (long long)ncols_key * n, brk, pmat_doubles, npi, ncols_key,
+                                             nb, b0, blk, lwe_2n + (long long)c0 * lwe_bs, lwe_bs, &done));
+                        if (!done) return fail(PZ_ERR_UNSUPPORTED, "blind_rotation: block step not launched");
+                        PZ_TRY(launch_small_inv(M, nb, A_h, nullptr, ncols_key, 0, 0, cols, bsz, out32 ? (long long*)D_h : (long long*)res_h, res_ct, cols, rsz,
+                                                in32 ? (const long long*)D_h : (const long long*)res_h, res_ct, cols, rsz, k, -1, true,
+                                                (chain && more) ? S_h : nullptr, fl, false, 0, 0, false, (in32 ? 1 : 0) | (out32 ? 2 : 0)));
+                    }
                 }
-                return PZ_OK;
+                return ss.join();
             }
         }
         const size_t acc_dft_bytes = align256(batch * n8 * cols * dnum), vr_bytes = align256(batch * n8 * cols * bsz);

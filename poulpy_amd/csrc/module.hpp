@@ -118,6 +118,9 @@ struct pz_module {
     int device = 0;
     pz::FftPlan plan{};
     hipStream_t stream = nullptr;
+    // side stream of two-stream sections (SideStream below): a second chain of launches that runs beside the module stream and joins it again
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int cu_count = 0;   // CUs the module stream may use (0 = all; diagnostic POULPY_DBG_CU_MASK): grid of the persistent kernels
     // device tables (cplx): tw1[m1], tw1inv[m1], wL1[m1], wL2[m2], tw12[m] ([j2][q1])
     pz::cplx *tw1 = nullptr, *tw1inv = nullptr, *wL1 = nullptr, *wL2 = nullptr, *tw12 = nullptr;
@@ -229,6 +232,38 @@ inline void dispatch_note(pz_module* M, const char* fmt, ...) {
     }
 #endif
 }
+
+// Two-stream section of one API call: independent halves of a batch whose kernels are bound by different units (a compute-bound product beside a
+// memory-bound transform) run on the module stream and on a side stream and overlap on the device.  fork(): the side stream waits for everything
+// issued so far; on(side): the launchers' M->stream; the destructor (or join()) makes the module stream wait for the side stream and restores
+// M->stream.  Legal under stream capture (fork / join by events: the graph gets two parallel branches).
+struct SideStream {
+    pz_module* M;
+    hipStream_t main;
+    bool forked = false;
+    explicit SideStream(pz_module* M_) : M(M_), main(M_->stream) {}
+    int fork() {
+        if (!M->stream2) {
+            if (hipStreamCreateWithFlags(&M->stream2, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); M->stream2 = nullptr; return PZ_ERR_HIP; }
+            if (hipEventCreateWithFlags(&M->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&M->ev_join, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                return PZ_ERR_HIP;
+            }
+        }
+        if (hipEventRecord(M->ev_fork, main) != hipSuccess || hipStreamWaitEvent(M->stream2, M->ev_fork, 0) != hipSuccess) { (void)hipGetLastError(); return PZ_ERR_HIP; }
+        forked = true;
+        return PZ_OK;
+    }
+    void on(bool side) { M->stream = (side && forked) ? M->stream2 : main; }
+    int join() {
+        M->stream = main;
+        if (!forked) return PZ_OK;
+        forked = false;
+        if (hipEventRecord(M->ev_join, M->stream2) != hipSuccess || hipStreamWaitEvent(main, M->ev_join, 0) != hipSuccess) { (void)hipGetLastError(); return PZ_ERR_HIP; }
+        return PZ_OK;
+    }
+    ~SideStream() { (void)join(); }
+};
 
 constexpr size_t kGuardBytes = 256;
 constexpr size_t kGuardSlack = 64 * kGuardBytes;   // room for the guards of a call's segments: part of every reservation

@@ -24,7 +24,7 @@ SHAPE = dict(n=1024, n_lwe=574, rank=2, block_size=7, base2k=13, brk_dnum=3, glw
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=1024, help="LWEs per call (BASELINE configs[3]: 8192 over 8 GPUs = 1024 per GPU; 512 was the default of rounds 2 - 4)")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--n-lwe", type=int, default=0)
     ap.add_argument("--rank", type=int, default=0)
