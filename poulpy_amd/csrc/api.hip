@@ -341,6 +341,7 @@ void pz_module_free(pz_module* M) {
         if (ge.graph) (void)hipGraphDestroy(ge.graph);
     }
     if (M->stream2) { (void)hipStreamSynchronize(M->stream2); (void)hipStreamDestroy(M->stream2); }
+    if (M->stream_out) { (void)hipStreamSynchronize(M->stream_out); (void)hipStreamDestroy(M->stream_out); }
     if (M->ev_fork) (void)hipEventDestroy(M->ev_fork);
     if (M->ev_join) (void)hipEventDestroy(M->ev_join);
     if (M->stream) (void)hipStreamDestroy(M->stream);

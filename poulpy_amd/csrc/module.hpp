@@ -121,6 +121,7 @@ struct pz_module {
     // side stream of two-stream sections (SideStream below): a second chain of launches that runs beside the module stream and joins it again
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream_out = nullptr;   // device -> host copies of the duplex host path (api_glwe.hip: glwe_entry_duplex); stream2 carries its host -> device copies
     int cu_count = 0;   // CUs the module stream may use (0 = all; diagnostic POULPY_DBG_CU_MASK): grid of the persistent kernels
     // device tables (cplx): tw1[m1], tw1inv[m1], wL1[m1], wL2[m2], tw12[m] ([j2][q1])
     pz::cplx *tw1 = nullptr, *tw1inv = nullptr, *wL1 = nullptr, *wL2 = nullptr, *tw12 = nullptr;

@@ -2364,3 +2364,65 @@ def test_glwe_ops_on_host_containers(mods, n):
         assert lib.pz_module_host_key_mirrors(hip.handle) == before
         for buf in (d_a, d_r):
             buf.free()
+
+
+@pytest.mark.parametrize("n,size", [(4096, 3), (65536, 8)])
+def test_glwe_ops_on_pinned_host_containers_duplex(mods, n, size):
+    """The duplex host path (round 5): pinned host ciphertexts (pz_alloc_bytes: what the Rust shim's buffers are), several
+    per call - the call runs as waves on three streams (upload | kernels | download).  Ragged batch (11 ciphertexts: waves of 2, the last of 1),
+    out of place and in place (`*_assign`), a host-resident key; every ciphertext against the oracle, and the bytes beyond the batch untouched.
+    Contract: logically synchronous (poulpy-hal/docs/backend_safety_contract.md:3-19) - the results are in host memory when the call returns."""
+    import ctypes as C
+    from poulpy_amd.hal import GlweOpParams
+    ref, hip = mods(n)
+    rng = seeded(n + 811)
+    rank, base2k, dnum, batch = 1, 12, size, 11
+    cols = rank + 1
+
+    def pinned(shape, dtype):
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = hip.lib.pz_alloc_bytes(C.c_size_t(nbytes))
+        assert ptr
+        return np.frombuffer((C.c_char * nbytes).from_address(ptr), dtype=dtype).reshape(shape), ptr
+    hp = lambda arr: arr.ctypes.data_as(C.c_void_p)
+    p = GlweOpParams(rank=rank, dnum=dnum, dsize=1, key_size=size, key_base2k=base2k, a_size=size, a_base2k=base2k, res_size=size,
+                     res_base2k=base2k, rank_out=rank)
+    held = []
+    try:
+        for ks in (False, True):
+            cols_in = rank if ks else cols
+            mat = MatZnx(n, dnum, cols_in, cols, size).fill_uniform(base2k, rng)
+            pr, ph = ref.vmp_pmat_alloc(dnum, cols_in, cols, size), hip.vmp_pmat_alloc(dnum, cols_in, cols, size)
+            ref.vmp_prepare(pr, mat)
+            hip.vmp_prepare(ph, mat)
+            key_host, kp = pinned(ph.data.shape, np.float64)
+            held.append(kp)
+            key_host[...] = ph.data
+            a_host, ap = pinned((batch + 1, size, cols, n), np.int64)      # one guard ciphertext behind the batch
+            r_host, rp = pinned((batch + 1, size, cols, n), np.int64)
+            held += [ap, rp]
+            want = np.empty((batch, size, cols, n), dtype=np.int64)
+            for t in range(batch):
+                a = VecZnx(n, cols, size).fill_uniform(base2k, rng)
+                a_host[t] = a.data
+                r = VecZnx(n, cols, size)
+                (ref.glwe_keyswitch if ks else ref.glwe_external_product)(r, base2k, a, base2k, pr, 1, base2k)
+                want[t] = r.data
+            a_host[batch] = 0x1111
+            r_host[...] = 0x5A5A
+            call = hip.glwe_keyswitch_batched if ks else hip.glwe_external_product_batched
+            call(hp(r_host), hp(a_host), hp(key_host), p, batch)           # no sync call: the results must be there already
+            assert np.array_equal(r_host[:batch], want), "duplex host path, out of place"
+            assert (r_host[batch] == 0x5A5A).all() and (a_host[batch] == 0x1111).all()
+            # same call again (graphs / key mirror re-used), then in place
+            r_host[...] = 0
+            call(hp(r_host), hp(a_host), hp(key_host), p, batch)
+            assert np.array_equal(r_host[:batch], want)
+            call(hp(a_host), hp(a_host), hp(key_host), p, batch)
+            assert np.array_equal(a_host[:batch], want), "duplex host path, in place"
+            assert (a_host[batch] == 0x1111).all()
+            hip.forget_host_key(hp(key_host)) if hasattr(hip, "forget_host_key") else None
+    finally:
+        hip.sync()
+        for ptr in held:
+            hip.lib.pz_free_bytes(C.c_void_p(ptr))

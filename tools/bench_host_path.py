@@ -26,7 +26,7 @@ def pinned(mod, shape, dtype):
 
 
 def main():
-    n, cols, size, dnum, k, reps = 65536, 2, 8, 8, 12, 10
+    n, cols, size, dnum, k, reps = 65536, 2, 8, 8, 12, 20
     use_pinned = "--pinned" in sys.argv
     mod = Module(n)
     rng = np.random.default_rng(1)
@@ -80,6 +80,8 @@ def main():
         ab[...] = a.data
         mod.glwe_external_product_batched(hp(rb), hp(ab), hp(key_host), p, batch)      # uploads the key mirror
         assert np.array_equal(rb[0], res.data)
+        for _ in range(10):                                                              # steady state (the first calls of a fresh process also pay the
+            mod.glwe_external_product_batched(hp(rb), hp(ab), hp(key_host), p, batch)    # driver's first mapping of the pinned pages: 3.9k vs 4.9k/s)
         t0 = time.perf_counter()
         for _ in range(reps):
             mod.glwe_external_product_batched(hp(rb), hp(ab), hp(key_host), p, batch)
