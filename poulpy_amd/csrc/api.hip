@@ -244,6 +244,7 @@ int pz_module_new_on_device(uint64_t n, int device, pz_module** out) {
     M->n = n; M->m = n >> 1; M->device = device; M->plan = pl;
     int r = PZ_OK;
     do {
+#ifdef PZ_EXPERIMENT
         if (const char* cm = getenv("POULPY_DBG_CU_MASK")) {
             // diagnostic: restrict the module stream to N CUs ("N" or "N,mode": mode 0 = the first N mask bits, 1 = spread evenly)
             int ncus = atoi(cm), mode = 0;
@@ -257,6 +258,7 @@ int pz_module_new_on_device(uint64_t n, int device, pz_module** out) {
             if (hipExtStreamCreateWithCUMask(&M->stream, 8, mask) != hipSuccess) { r = fail(PZ_ERR_HIP, "masked stream create failed"); break; }
             M->cu_count = on;
         } else
+#endif
         if (hipStreamCreateWithFlags(&M->stream, hipStreamNonBlocking) != hipSuccess) { r = fail(PZ_ERR_HIP, "stream create failed"); break; }
         if ((r = build_tables(M)) != PZ_OK) break;
         if (hipMalloc(&M->margin, 8) != hipSuccess) { r = fail(PZ_ERR_HIP, "margin alloc failed"); break; }

@@ -81,7 +81,7 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
         // (inverse column pass + accumulator + carry chain): the spectra never reach HBM and one launch covers the whole block
         {
             const int npi = cols * std::min(dnum, rsz), npo = cols * bsz, nrows_key = dnum * cols, ncols_key = cols * bsz;
-            static const int br_mid = getenv("POULPY_DBG_BR_MID") ? atoi(getenv("POULPY_DBG_BR_MID")) : 1;
+            static const int br_mid = exp_knob("POULPY_DBG_BR_MID", 1);
             if (br_mid && M->fuse_mid && M->fuse_tail && tail_supported(M) && M->plan.m2 == 128 && mid_supported(M, npi, npo) &&
                 npi == nrows_key && blk <= 16) {
                 const size_t key_bytes = align256((size_t)blk * nrows_key * ncols_key * n8);
@@ -123,7 +123,7 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
         // whole inverse transform + accumulator + carry chain per (ciphertext, column) - instead of pass 1 / pass 2 and pass 2 / tail
         {
             const int npi = cols * std::min(dnum, rsz), nrows_key = dnum * cols, ncols_key = cols * bsz;
-            static const int br_small = getenv("POULPY_DBG_BR_SMALL") ? atoi(getenv("POULPY_DBG_BR_SMALL")) : 1;
+            static const int br_small = exp_knob("POULPY_DBG_BR_SMALL", 1);
             if (br_small && M->small_path && M->fuse_mid && M->fuse_tail && small_supported(M, npi, bsz) && npi == nrows_key && npi <= 12 &&
                 blk <= 64) {
                 const size_t s_bytes = align256(batch * npi * (size_t)M->m * sizeof(cplx)), a_bytes = align256(batch * ncols_key * (size_t)M->m * sizeof(cplx));
@@ -283,7 +283,7 @@ static int blind_rotation_extended(pz_module* M, int64_t* res, const int64_t* lw
     DV ad{acc_dft, n * cols * dnum, cols, dnum}, vr{vmp_res, n * cols * bsz, cols, bsz}, aa{acc_add, n * cols * bsz, cols, bsz};
     const bool tail = M->fuse_tail && tail_supported(M);
     // N = 1024 / 2048 / 4096: the transforms of the small-ring pipeline around the per-coefficient steps, as in blind_rotation()
-    static const int br_small = getenv("POULPY_DBG_BR_SMALL") ? atoi(getenv("POULPY_DBG_BR_SMALL")) : 1;
+    static const int br_small = exp_knob("POULPY_DBG_BR_SMALL", 1);
     const int npi = cols * std::min(dnum, rsz);
     const bool small_tf = br_small && M->small_path && M->fuse_mid && M->fuse_tail && small_supported(M, npi, bsz) && npi == dnum * cols;
     for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {

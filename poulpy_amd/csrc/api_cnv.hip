@@ -250,8 +250,8 @@ int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, c
         // then per term ONE kernel for forward row transform + limb convolution + inverse row transform (k_mid_cnv), the inverse column
         // pass alone (k_inv_tail, raw), and the normalize kernel with the combination in its stores - instead of forward pass 2 of both
         // operands, k_cnv_apply, inverse pass 2 and inverse pass 1 (POULPY_DBG_TENSOR_FUSED=0).
-        static const bool fused_env = !(getenv("POULPY_DBG_TENSOR_FUSED") && atoi(getenv("POULPY_DBG_TENSOR_FUSED")) == 0);
-        static const bool combine_ok_env = !(getenv("POULPY_DBG_TENSOR_COMBINE") && atoi(getenv("POULPY_DBG_TENSOR_COMBINE")) == 0);
+        static const bool fused_env = (rt_knob("POULPY_DBG_TENSOR_FUSED", 1) != 0);
+        static const bool combine_ok_env = (rt_knob("POULPY_DBG_TENSOR_COMBINE", 1) != 0);
         const int bound_f = t.a_size + t.b_size - 1;
         const bool fused = fused_env && combine_ok_env && p->res_base2k == p->ab_base2k && t.cols <= 3 && t.dft_size >= 1 &&
                            mid_cnv_supported(M, t.a_size, t.b_size, std::min(t.dft_size, bound_f));
@@ -291,7 +291,7 @@ int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, c
                                            min_size, off));
                 // the inverse column pass normalizes on its way out (bit offset, combination and all: TailArgs::nz); POULPY_DBG_TENSOR_NZTAIL=0:
                 // raw inverse column pass into a VecZnxBig, then the normalize kernel
-                static const bool nztail = !(getenv("POULPY_DBG_TENSOR_NZTAIL") && atoi(getenv("POULPY_DBG_TENSOR_NZTAIL")) == 0);
+                static const bool nztail = (exp_knob("POULPY_DBG_TENSOR_NZTAIL", 1) != 0);
                 if (nztail)
                     return launch_inv_tail_nz(M, nb, Tt, min_size, (long long*)dst, dst_bs, dst_cols, t.res_size, dcol, (int)p->res_base2k, t.lo,
                                               t.dft_size, cb);
@@ -313,7 +313,7 @@ int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, c
         auto ew_res = [&](int op, int col, const int64_t* x, long long x_bs, long long x_ls, const int64_t* y, long long y_bs, long long y_ls) {
             return launch_ew(M, op, col_ptr(col), r_ct, rls, x, x_bs, x_ls, y, y_bs, y_ls, t.res_size, nb);
         };
-        static const bool combine_sq = !(getenv("POULPY_DBG_TENSOR_COMBINE") && atoi(getenv("POULPY_DBG_TENSOR_COMBINE")) == 0);
+        static const bool combine_sq = (rt_knob("POULPY_DBG_TENSOR_COMBINE", 1) != 0);
         if (square && combine_sq && p->res_base2k == p->ab_base2k && t.cols <= 3) {
             // (round 3) the same sums with the combination in the normalize kernel's stores: the diagonal terms stored, each pairwise term
             // then reads its two diagonal columns and stores pair - d_i - d_j (wrapping i64: the same digits as the reference's order)
@@ -348,7 +348,7 @@ int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, c
         // One base2k, rank <= 2 (round 3): the digits of a term go straight from the normalize kernel into every tensor column that takes
         // them - the diagonal term into its own column (= / +=) and, negated, into the cross columns (= - / -=), the pairwise term into
         // its cross column (+=) - instead of a temporary and five element-wise passes over the tensor (POULPY_DBG_TENSOR_COMBINE=0).
-        static const bool combine_env = !(getenv("POULPY_DBG_TENSOR_COMBINE") && atoi(getenv("POULPY_DBG_TENSOR_COMBINE")) == 0);
+        static const bool combine_env = (rt_knob("POULPY_DBG_TENSOR_COMBINE", 1) != 0);
         if (combine_env && p->res_base2k == p->ab_base2k && t.cols <= 3) {
             auto cidx = [&](int i, int j) { const int lo_ = std::min(i, j), hi_ = std::max(i, j); return lo_ * t.cols - (lo_ * (lo_ + 1) / 2) + hi_; };
             if (!add) {

@@ -147,8 +147,8 @@ static FusedWs fused_ws(const pz_module* M, const pz_glwe_op_params* p, const Op
 // N = 1024 / 2048: the two-kernel pipeline of device_small.hpp (plain products, key switches and the automorphism family; dsize 1, one
 // base2k, <= 4 key limbs); `packed` = no OpLayout (the automorphism family needs it)
 static bool small_ring_applies(const pz_module* M, const pz_glwe_op_params* p, const OpShape& s, bool ks, bool tensor, bool au, bool packed) {
-    static const int small_env = getenv("POULPY_DBG_SMALL") ? atoi(getenv("POULPY_DBG_SMALL")) : 1;
-    static const int small_au = getenv("POULPY_DBG_SMALL_AUTO") ? atoi(getenv("POULPY_DBG_SMALL_AUTO")) : 1;
+    static const int small_env = exp_knob("POULPY_DBG_SMALL", 1);
+    static const int small_au = exp_knob("POULPY_DBG_SMALL_AUTO", 1);
     const bool cross_out = p->res_base2k != p->key_base2k;   // (with an automorphism: phi and the cross-base pass do not commute)
     return small_env && M->small_path && M->fuse_mid && M->fuse_tail && M->n < 4096 && (!au || (small_au && ks && packed && !cross_out)) &&
            !tensor && p->dsize == 1 && M->dbg_stages == 7 && small_supported(M, s.cols_in * s.a_size_eff, (int)p->key_size);
@@ -304,8 +304,8 @@ static int fused_carve(const GlweCall& c, FusedBufs* f) {
 // limbs, BASELINE configs[1] - beats the two-kernel form, 3.25 vs 3.16 M/s, profiles/r03_ab_small_vs_pipeline.txt; POULPY_DBG_SMALL=2
 // forces the two-kernel form there too)
 static bool n4096_two_kernel(const GlweCall& c) {
-    static const int small_env = getenv("POULPY_DBG_SMALL") ? atoi(getenv("POULPY_DBG_SMALL")) : 1;
-    static const int small_au4 = getenv("POULPY_DBG_SMALL_AUTO") ? atoi(getenv("POULPY_DBG_SMALL_AUTO")) : 1;
+    static const int small_env = exp_knob("POULPY_DBG_SMALL", 1);
+    static const int small_au4 = exp_knob("POULPY_DBG_SMALL_AUTO", 1);
     const pz_module* M = c.M;
     const bool mid8 = !c.ks && !c.au && c.npi == 8 && c.npo == 8 && std::min(c.nrows, c.npi) == 8 && small_env != 2;
     return small_env && M->small_path && (!c.au || (small_au4 && c.ks && !c.lay)) && !c.tensor && !c.digits && !c.cross_out &&
@@ -328,7 +328,7 @@ static int wave_n4096_two_kernel(const GlweCall& c, const FusedBufs& f, size_t b
 // POULPY_DBG_AUTO_SPECTRAL: 0 never; 2 not for the plain form (mode 0: key switch + signed permutation pass instead); 3 only p = 1 mod 4.
 struct SpectralPerm { bool on = false; unsigned mul = 0, add = 0; bool conj = false; };
 static SpectralPerm spectral_perm(const GlweCall& c) {
-    static const int au_spec = getenv("POULPY_DBG_AUTO_SPECTRAL") ? atoi(getenv("POULPY_DBG_AUTO_SPECTRAL")) : 1;
+    static const int au_spec = exp_knob("POULPY_DBG_AUTO_SPECTRAL", 1);
     SpectralPerm sp;
     sp.on = au_spec && c.au && (c.au_big || au_spec == 1 || au_spec == 3) && ((c.au_p & 3u) == 1u || au_spec != 3) && c.M->plan.m2 == 128 &&
             c.M->dbg_stages == 7;
@@ -360,7 +360,7 @@ static int wave_spectral_tail(const GlweCall& c, const FusedBufs& f, size_t b0, 
     // item 3) - bit-exact and one kernel and 8.6 GB of traffic less per 1024 ciphertexts, but the tail goes from 5.05 to 8.3 - 8.8 ms
     // (the pre-pass costs 1.8 - 3.0): 16 dependent 8-byte gathers per thread and limb in front of the carry chain, for every Galois
     // element tried, conjugation included (profiles/r04_ab_auto_fold.txt).  A copy-rate pre-pass is the cheaper form.
-    static const int fold_knob = getenv("POULPY_DBG_AUTO_FOLD") ? atoi(getenv("POULPY_DBG_AUTO_FOLD")) : 0;
+    static const int fold_knob = exp_knob("POULPY_DBG_AUTO_FOLD", 0);
     // (never in place: other workgroups would gather from a body that this launch is already overwriting)
     const int64_t* a_end = c.a + (long long)c.batch * c.a_bs;
     const int64_t* r_end = c.res + (long long)c.batch * c.res_bs;
@@ -377,7 +377,7 @@ static int wave_spectral_tail(const GlweCall& c, const FusedBufs& f, size_t b0, 
     // operand of the body column, one stream: phi(body) + a0 (add) or -phi(body) + a0 (sub forms: the tail negates every operand)
     // POULPY_DBG_AUTO_BODYADD=1: the pre-pass only permutes (+-phi(body)) and the tail adds a0 from the ciphertext itself (a second operand
     // stream on the body column) instead of a pre-pass with an add operand; not with the shifted stores of glwe_trace (registers)
-    static const int bodyadd_knob = getenv("POULPY_DBG_AUTO_BODYADD") ? atoi(getenv("POULPY_DBG_AUTO_BODYADD")) : 0;
+    static const int bodyadd_knob = exp_knob("POULPY_DBG_AUTO_BODYADD", 0);
     const bool rsh = c.want_rsh && tail_rsh_supported(M) && !c.cross_out && c.p->res_base2k <= 29;   // (32-bit shift steps: device_fft.hpp)
     if (fold) t.gather_neg = c.au->mode != 1;
     else if (bodyadd_knob && !rsh) {
@@ -884,7 +884,7 @@ int glwe_trace(pz_module* M, int64_t* res, size_t nsteps, const int64_t* gals, c
     const long long ct = n * cols * (long long)p->res_size;
     // the one-bit shift in front of step s + 1 rides on the tail of step s where that path has the shifted-store variant
     // (POULPY_DBG_TRACE_RSH=0: always the separate pass)
-    static const int fuse_rsh = getenv("POULPY_DBG_TRACE_RSH") ? atoi(getenv("POULPY_DBG_TRACE_RSH")) : 1;
+    static const int fuse_rsh = exp_knob("POULPY_DBG_TRACE_RSH", 1);
     bool shifted = false;
     for (size_t s = 0; s < nsteps; ++s) {
         PZ_REQUIRE((gals[s] & 1) != 0, "glwe_trace: Galois elements must be odd");

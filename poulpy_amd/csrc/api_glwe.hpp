@@ -30,7 +30,7 @@ static void graph_drop(pz_module::GraphEntry& e) {
 }
 template <typename F>
 static int with_graph(pz_module* M, uint64_t key, F&& body) {
-    static const int env_on = getenv("POULPY_DBG_GRAPHS") ? atoi(getenv("POULPY_DBG_GRAPHS")) : 1;
+    static const int env_on = rt_knob("POULPY_DBG_GRAPHS", 1);
     if (!env_on || !M->graphs_on || M->timing || canary_mode()) return body();   // (a replayed graph would not re-arm the workspace guards)
     pz_module::GraphEntry* e = nullptr;
     for (auto& ge : M->graphs) if (ge.key == key) e = &ge;

@@ -47,7 +47,7 @@ int br_block_step(pz_module* M, const double* acc_dft, long long a_bs, double* a
                 g.brk = (const cplx*)brk; g.key_stride = (long long)(pmat_doubles / 2);
                 g.row_max = row_max; g.ncols = ncols; g.m = (int)M->m; g.batch = B; g.i0 = i0; g.blk = blk;
                 g.lwe = (const long long*)lwe_2n; g.lwe_bs = lwe_bs; g.w2n = M->w2n;
-                static const int brl_dbg = getenv("POULPY_DBG_BRL") ? atoi(getenv("POULPY_DBG_BRL")) : 0;
+                static const int brl_dbg = exp_knob("POULPY_DBG_BRL", 0);
                 g.dbg = brl_dbg; g.gx = g.gy = g.gz = 1; g.xcd = 0; g.allcg = 0;
                 constexpr int CT = 2;
                 KTimer kt(M, PZ_K_VMP);
@@ -65,14 +65,14 @@ int br_block_step(pz_module* M, const double* acc_dft, long long a_bs, double* a
                 // more than 8 inputs, 2 always
                 // (four ciphertexts per wave for <= 6 inputs - every staged key value serving 16 ciphertexts instead of 8, at 256 registers -
                 //  measured slower at N = 2048: 11.06 vs 9.68 ms per 82 block steps)
-                static const int br_lds = getenv("POULPY_DBG_BR_LDS") ? atoi(getenv("POULPY_DBG_BR_LDS")) : 2;
+                static const int br_lds = exp_knob("POULPY_DBG_BR_LDS", 2);
                 const bool use_lds = M->m % 64 == 0 && (br_lds >= 2 || (br_lds == 1 && row_max > 8));
                 bool launched = false;
                 if (use_lds) {
                     g.gx = (B + 7) / 8; g.gy = (int)(M->m / 64); g.gz = ngroups;
-                    static const int br_xcd = getenv("POULPY_DBG_BR_XCD") ? atoi(getenv("POULPY_DBG_BR_XCD")) : 1;
+                    static const int br_xcd = exp_knob("POULPY_DBG_BR_XCD", 1);
                     g.xcd = (br_xcd && (g.gx * g.gy) % 8 == 0) ? 1 : 0;
-                    static const int br_allcg = getenv("POULPY_DBG_BR_ALLCG") ? atoi(getenv("POULPY_DBG_BR_ALLCG")) : 1;
+                    static const int br_allcg = exp_knob("POULPY_DBG_BR_ALLCG", 1);
                     g.allcg = br_allcg ? 1 : 0;
                     const unsigned total = (unsigned)(g.gx * g.gy * (g.allcg ? 1 : g.gz));
 #define PZ_BRB(MR_, CG_)                                                                                           \

@@ -20,7 +20,7 @@ int launch_cnv_apply(pz_module* M, int batch, double* res, long long res_bs, int
     g.m = (int)M->m; g.batch = batch;
     KTimer kt(M, PZ_K_VMP);
     // operands staged in LDS, all output limbs per workgroup (POULPY_DBG_CNV_LDS=0: one thread per (point, output limb), operands from L2)
-    static const bool cnv_lds = !(getenv("POULPY_DBG_CNV_LDS") && atoi(getenv("POULPY_DBG_CNV_LDS")) == 0);
+    static const bool cnv_lds = (exp_knob("POULPY_DBG_CNV_LDS", 1) != 0);
     if (cnv_lds && (M->m % 128) == 0 && a_size + b_size <= 64 && a != (const double*)res && b != (const double*)res) {
         const size_t lds = (size_t)(a_size + b_size) * 128 * sizeof(cplx);
         PZ_TRY(set_lds(k_cnv_apply_lds, lds));
@@ -71,7 +71,7 @@ int launch_mid_cnv(pz_module* M, int batch, const cplx* a_main, const cplx* a_la
 
 // all three terms of a rank-1 tensoring in one launch (device_cnv.hpp, k_mid_cnv3): T2 = [term][pair][limb < min_size][m]
 bool mid_cnv3_supported(const pz_module* M, int cols, int a_size, int b_size, int min_size) {
-    static const bool on = !(getenv("POULPY_DBG_TENSOR_ALLTERMS") && atoi(getenv("POULPY_DBG_TENSOR_ALLTERMS")) == 0);
+    static const bool on = (rt_knob("POULPY_DBG_TENSOR_ALLTERMS", 1) != 0);
     return on && cols == 2 && mid_cnv_supported(M, a_size, b_size, min_size) && a_size == b_size && (a_size == 16 || a_size == 8) && min_size <= 21 &&
            3 * min_size <= 64;
 }

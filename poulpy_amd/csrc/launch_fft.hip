@@ -24,7 +24,7 @@ int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap sma
     const int ncb = pl.m2 / pl.cb;
     const int blocks = npolys * ncb;
     // row-major (pipeline) launches use the XCD-aware block order of k_fwd_pass1: grid padded to whole groups of 8 polynomials
-    static const int xcd_order = getenv("POULPY_DBG_XCD_ORDER") ? atoi(getenv("POULPY_DBG_XCD_ORDER")) : 1;
+    static const int xcd_order = exp_knob("POULPY_DBG_XCD_ORDER", 1);
     const int npx = (rowmajor && xcd_order) ? npolys : 0;
     const int blocks_rm = npx ? ((npolys + 7) / 8) * 8 * ncb : blocks;
     if (src32) {   // 32-bit source digits: the row-major form of the 128-point-row plans (the blind rotation's pipeline path)

@@ -54,7 +54,7 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
         for (int t = 0; t < dg->n; ++t) { g.ds_in[t] = dg->in[t]; g.ds_row[t] = dg->row[t]; g.ds_coff[t] = dg->coff[t]; g.ds_cb[t] = dg->cb[t]; }
     }
     g.perm_mul = perm_mul; g.perm_add = perm_add; g.perm_ysign = perm_conj ? -1.0 : 1.0; g.log_m1 = 0;
-    static const int mid_skip = getenv("POULPY_DBG_MID_SKIP") ? atoi(getenv("POULPY_DBG_MID_SKIP")) : 0;
+    static const int mid_skip = exp_knob("POULPY_DBG_MID_SKIP", 0);
     g.dbg = mid_skip;
     while ((1 << g.log_m1) < M->plan.m1) ++g.log_m1;
     const bool perm = perm_mul != 0;
@@ -65,20 +65,20 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
         return fail(PZ_ERR_INVALID, "launch_mid: no product term (rows %d, npi %d, ds_n %d)", nrows, npi, g.ds_n);
     g.batch = batch; g.m1 = M->plan.m1; g.n_ct = 0;
     g.wL2 = M->wL2; g.tw12t = M->tw12t; g.dummy = dummy;
-    static const int groups = getenv("POULPY_DBG_MID_GROUPS") ? atoi(getenv("POULPY_DBG_MID_GROUPS")) : 1;
+    static const int groups = exp_knob("POULPY_DBG_MID_GROUPS", 1);
     g.groups = groups;
     // phase stagger: workgroup w starts (w mod 4) x ~3.4 us late so that the HBM-heavy row passes of some CUs overlap
     // the L2-heavy product phases of others (measured: middle kernel -3 %); off for the m2 = 128 form, where it did not pay
-    static const int stg = getenv("POULPY_DBG_MID_STAGGER") ? atoi(getenv("POULPY_DBG_MID_STAGGER")) : -1;
-    static const int stm = getenv("POULPY_DBG_MID_STAGGER_MOD") ? atoi(getenv("POULPY_DBG_MID_STAGGER_MOD")) : 4;
+    static const int stg = exp_knob("POULPY_DBG_MID_STAGGER", -1);
+    static const int stm = exp_knob("POULPY_DBG_MID_STAGGER_MOD", 4);
     g.stagger = stg >= 0 ? stg : (M->plan.m2 == 128 ? 0 : 1);
-    g.stagger_mod = M->plan.m2 == 128 ? (getenv("POULPY_DBG_MID_STAGGER_MOD") ? stm : 0) : std::max(1, stm);   // m2 = 128: mode bits of k_mid128r's experiments
+    g.stagger_mod = M->plan.m2 == 128 ? (exp_knob("POULPY_DBG_MID_STAGGER_MOD", -1) >= 0 ? stm : 0) : std::max(1, stm);   // m2 = 128: mode bits of k_mid128r's experiments
     if (M->plan.m2 == 128) {
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, M->device);
         if (M->cu_count > 0) ncu = (M->cu_count / 8) * 8 > 0 ? (M->cu_count / 8) * 8 : M->cu_count;
-        static const bool mid_r = !(getenv("POULPY_DBG_MID_R") && atoi(getenv("POULPY_DBG_MID_R")) == 0);   // 0: k_mid128 (the kernel of rounds 1-2) instead of k_mid128r (A/B)
-        static const bool br_nc3 = !(getenv("POULPY_DBG_BR_NC3") && atoi(getenv("POULPY_DBG_BR_NC3")) == 0);   // 0: 4 outputs per thread also for 6-column block steps (A/B)
+        static const bool mid_r = (rt_knob("POULPY_DBG_MID_R", 1) != 0);   // 0: k_mid128 (the kernel of rounds 1-2) instead of k_mid128r (A/B)
+        static const bool br_nc3 = (exp_knob("POULPY_DBG_BR_NC3", 1) != 0);   // 0: 4 outputs per thread also for 6-column block steps (A/B)
         KTimer kt(M, PZ_K_FUSED_MID);
 #define PZ_MID128_GO(CT_, NP_, PERM_, SKIPW_)                                                                              \
     {                                                                                                                      \
@@ -109,9 +109,10 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
         if (perm_) { if (skipw_) PZ_MID128_GO(CT_, NP_, true, true) else PZ_MID128_GO(CT_, NP_, true, false) }             \
         else       { if (skipw_) PZ_MID128_GO(CT_, NP_, false, true) else PZ_MID128_GO(CT_, NP_, false, false) }           \
     }
+#ifdef PZ_EXPERIMENT
         // experiment (POULPY_DBG_MID_CT2=1): the plain 16 x 16 product on 256-thread workgroups - two ciphertexts per tile, two workgroups per
         // CU that are not coupled by barriers (k_mid128r<2,16>; twice the key fetches per ciphertext)
-        static const bool mid_ct2 = getenv("POULPY_DBG_MID_CT2") && atoi(getenv("POULPY_DBG_MID_CT2")) == 1;
+        static const bool mid_ct2 = (exp_knob("POULPY_DBG_MID_CT2", 0) == 1);
         if (mid_ct2 && mid_r && !br && !ds && !perm && npi == 16 && npo == 16 && g.row_max == 16 && g.ncomp == 16) {
             g.n_ct = (batch + 1) / 2;
             const size_t lds = ((size_t)2 * 16 * kMidRS + 384 + 32) * sizeof(cplx);
@@ -122,6 +123,7 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
             PZ_HIP(hipGetLastError());
             return PZ_OK;
         }
+#endif
 #define PZ_MID128_LAUNCH(CT_, NP_)                                                                                         \
     {                                                                                                                      \
         g.n_ct = (batch + CT_ - 1) / CT_;                                                                                  \
@@ -183,7 +185,7 @@ int launch_mid(pz_module* M, int batch, const cplx* T, cplx* T2, const cplx* Pp,
         PZ_HIP(hipGetLastError());
         return PZ_OK;
     }
-    static const int ct = getenv("POULPY_DBG_MID_CT") ? atoi(getenv("POULPY_DBG_MID_CT")) : 2;  // diagnostic knob
+    static const int ct = exp_knob("POULPY_DBG_MID_CT", 2);  // diagnostic knob
     if (ct == 1) return launch_mid_ct<1>(M, g, batch);
     return launch_mid_ct<2>(M, g, batch);
 }

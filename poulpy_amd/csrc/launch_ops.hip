@@ -39,7 +39,7 @@ int launch_automorphism(pz_module* M, int npolys, const long long* src, PolyMap 
     KTimer kt(M, PZ_K_ELEMENTWISE);
     // Galois elements whose gather has no locality (neither g nor -g small): chunks of 4 outputs per thread, sources read in runs
     // (k_automorphism_chunk; POULPY_DBG_AUTO_CHUNK=0: always the plain gather, =2: always the chunked form)
-    static const int chunk_knob = getenv("POULPY_DBG_AUTO_CHUNK") ? atoi(getenv("POULPY_DBG_AUTO_CHUNK")) : 1;
+    static const int chunk_knob = exp_knob("POULPY_DBG_AUTO_CHUNK", 1);
     const unsigned two_n = 2u * (unsigned)M->n, gm = mul & (two_n - 1u);
     unsigned hinv = gm;   // g^-1 mod 2N by Newton's iteration (g odd): x <- x (2 - g x), 3 -> 6 -> 12 -> 24 -> 48 correct bits
     for (int it = 0; it < 5; ++it) hinv *= 2u - gm * hinv;

@@ -64,7 +64,7 @@ int launch_small_permute(pz_module* M, const double* P, cplx* Pp, int npolys) {
 // N = 1024 / 2048 / 4096: the per-op transforms in one kernel each (whole polynomial in LDS)
 bool small_transform_supported(const pz_module* M) {
     const int m1 = small_m1(M);
-    static const int on = getenv("POULPY_DBG_SMALL_FFT") ? atoi(getenv("POULPY_DBG_SMALL_FFT")) : 1;   // 0: two-pass per-op transforms (A/B)
+    static const int on = exp_knob("POULPY_DBG_SMALL_FFT", 1);   // 0: two-pass per-op transforms (A/B)
     return on && (M->m % kSmallM2) == 0 && (m1 == 4 || m1 == 8 || m1 == 16);
 }
 int launch_small_idft(pz_module* M, int npolys, const double* a, PolyMap smap, long long* res, PolyMap dmap) {
@@ -123,7 +123,7 @@ int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int
     g.batch = batch; g.npi = npi; g.nrows = nrows; g.ncols = ncols; g.cols_out = cols_out; g.ksz = ksz;
     g.res_cols = res_cols; g.res_size = res_size; g.small_cols = small_cols; g.small_size = small_size; g.base2k = base2k; g.body_col = body_col;
     g.tw12t = M->s_tw12t; g.wL2 = M->s_wL2; g.tw1inv = M->s_tw1inv;
-    static const int skip = getenv("POULPY_DBG_SMALL_SKIP") ? atoi(getenv("POULPY_DBG_SMALL_SKIP")) : 0;
+    static const int skip = exp_knob("POULPY_DBG_SMALL_SKIP", 0);
     g.dbg = skip; g.margin = M->probe ? M->margin : nullptr;
     if (acc32 && !(noprod && base2k <= 31)) return fail(PZ_ERR_INVALID, "small-ring pipeline: 32-bit accumulator digits need the product-free form and base2k <= 31");
     g.acc32 = acc32;

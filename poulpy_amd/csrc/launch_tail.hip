@@ -103,7 +103,7 @@ int launch_inv_tail(pz_module* M, const TailCall& c) {
     }
     // plain spectral glwe_automorphism (only the body column has an operand): that column on the operand variant, the others on the
     // sign-only variant of the f64 chain (POULPY_DBG_AUTO_SGN=0: every column on the operand variant, as in round 3)
-    static const int sgn_knob = getenv("POULPY_DBG_AUTO_SGN") ? atoi(getenv("POULPY_DBG_AUTO_SGN")) : 1;
+    static const int sgn_knob = exp_knob("POULPY_DBG_AUTO_SGN", 1);
     if (sgn_knob && c.small != nullptr && c.small_all && c.body_only && c.auto_mul != 0 && c.ncols > 1 && !c.post_rsh && c.rowmajor &&
         tail_rsh_supported(M)) {
         PZ_TRY(launch_inv_tail_cols(M, c, c.body_col, 1));

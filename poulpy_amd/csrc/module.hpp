@@ -21,6 +21,23 @@
 
 namespace pz {
 
+// Run-time switches.  rt_knob: the few a product build reads - alternative paths kept for cross-checks, each exercised by a -m gpu test
+// (POULPY_DBG_CANARY, _GRAPHS, _SPLIT, _MID_R, _TENSOR_FUSED, _TENSOR_COMBINE, _TENSOR_ALLTERMS).  exp_knob: the switches of
+// measured experiments (A/B records under profiles/): the default, as a constant, unless the library is built with -DPZ_EXPERIMENT
+// (POULPY_BUILD_DEFS=-DPZ_EXPERIMENT POULPY_BUILD_TAG=exp ..., like -DPZ_ABLATE for the result-invalidating timing ablations).
+inline int rt_knob(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+inline int exp_knob(const char* name, int dflt) {
+#ifdef PZ_EXPERIMENT
+    return rt_knob(name, dflt);
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+
 inline std::string& last_error_ref() {
     thread_local std::string e;
     return e;
@@ -107,7 +124,9 @@ inline bool make_plan(uint64_t n, FftPlan& pl) {
     if (pl.m1 == 128) { pl.f1a = 8; pl.f1b = 16; }
     pl.cb = pl.m2 >= 16 ? 16 : std::min(4, pl.m2);
     pl.qb = pl.m1 >= 16 ? 16 : std::min(4, pl.m1);
-    if (const char* e = getenv("POULPY_DBG_CB")) pl.cb = atoi(e);  // diagnostic: column-block width of pass 1 / tail
+#ifdef PZ_EXPERIMENT
+    if (const char* e = getenv("POULPY_DBG_CB")) pl.cb = atoi(e);  // experiment builds: column-block width of pass 1 / tail
+#endif
     return true;
 }
 
@@ -270,7 +289,7 @@ constexpr size_t kGuardBytes = 256;
 constexpr size_t kGuardSlack = 64 * kGuardBytes;   // room for the guards of a call's segments: part of every reservation
 constexpr unsigned char kGuardByte = 0xC5;
 inline bool canary_mode() {
-    static const bool on = getenv("POULPY_DBG_CANARY") && atoi(getenv("POULPY_DBG_CANARY")) != 0;
+    static const bool on = (rt_knob("POULPY_DBG_CANARY", 0) != 0);
     return on;
 }
 // arms a guard at p (canary mode only)
