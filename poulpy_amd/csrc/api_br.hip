@@ -42,184 +42,194 @@ size_t pz_blind_rotation_workspace_bytes(const pz_module* M, const pz_blind_rota
     return align256(batch * n8 * cols * p->res_size) + pz_glwe_op_workspace_bytes(M, &ep, batch, 0);
 }
 
-static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
-                          const pz_blind_rotation_params* p, size_t batch) {
-    PZ_REQUIRE(p != nullptr, "null params");
-    PZ_REQUIRE(p->n_lwe >= 1 && p->block_size >= 1 && p->dnum >= 1 && p->brk_size >= 1 && p->res_size >= 1 && p->lut_size >= 1,
-               "blind_rotation: empty shape");
-    PZ_REQUIRE(p->base2k >= 1 && p->base2k <= 63, "blind_rotation: base2k out of range");
-    PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(lwe_2n) && is_device_ptr(lut) && is_device_ptr(brk),
-               "batched entry points take device pointers");
-    if (batch == 0) return PZ_OK;
-    const long long n = (long long)M->n;
-    const int cols = (int)p->rank + 1, dnum = (int)p->dnum, bsz = (int)p->brk_size, rsz = (int)p->res_size;
-    const int B = (int)batch, n_lwe = (int)p->n_lwe, blk = (int)p->block_size, k = (int)p->base2k;
-    const long long lwe_bs = (long long)n_lwe + 1;
-    const size_t pmat_doubles = (size_t)n * dnum * cols * cols * bsz;
-    const long long res_ct = n * cols * rsz;
-    DV rv{res, res_ct, cols, rsz};
+// One rotation call: the shape, read once; the paths below take it by reference
+struct BrCall {
+    pz_module* M;
+    int64_t* res;
+    const int64_t* lwe_2n;
+    const int64_t* lut;
+    const double* brk;
+    const pz_blind_rotation_params* p;
+    size_t batch;
+    long long n, lwe_bs, res_ct;
+    int cols, dnum, bsz, rsz, B, n_lwe, blk, k;
+    size_t pmat_doubles, n8;
+};
+#define PZ_BR_UNPACK(c)                                                                                                                  \
+    pz_module* const M = (c).M; int64_t* const res = (c).res; const int64_t* const lwe_2n = (c).lwe_2n; const double* const brk = (c).brk;   \
+    const pz_blind_rotation_params* const p = (c).p; const size_t batch = (c).batch; const long long n = (c).n, lwe_bs = (c).lwe_bs, res_ct = (c).res_ct; \
+    const int cols = (c).cols, dnum = (c).dnum, bsz = (c).bsz, rsz = (c).rsz, B = (c).B, n_lwe = (c).n_lwe, blk = (c).blk, k = (c).k;      \
+    const size_t pmat_doubles = (c).pmat_doubles, n8 = (c).n8;                                                                              \
+    (void)p; (void)batch; (void)n; (void)lwe_bs; (void)res_ct; (void)cols; (void)dnum; (void)bsz; (void)rsz; (void)B; (void)n_lwe; (void)blk; (void)k; \
+    (void)pmat_doubles; (void)n8; (void)res; (void)lwe_2n; (void)brk; (void)M;
 
-    // acc = X^b * LUT in column 0, zero elsewhere (:298-301 / :413-416)
+// acc = X^b * LUT in column 0, zero elsewhere (:298-301 / :413-416)
+static int br_init_accumulator(const BrCall& c) {
+    PZ_BR_UNPACK(c)
     PZ_HIP(hipMemsetAsync(res, 0, (size_t)B * res_ct * 8, M->stream));
-    {
-        const int nl = std::min(rsz, (int)p->lut_size);
-        PolyMap sm{nl, 1, 0, n, 0, 0};                     // the LUT is shared: batch stride 0, VecZnx(1, lut_size)
-        PolyMap dm{nl, 1, res_ct, (long long)cols * n, 0, 0};
-        PZ_TRY(launch_rotate(M, B * nl, (const long long*)lut, sm, (long long*)res, dm, 0, nl, (const long long*)lwe_2n, lwe_bs, 0, 0));
-    }
+    const int nl = std::min(rsz, (int)p->lut_size);
+    PolyMap sm{nl, 1, 0, n, 0, 0};                     // the LUT is shared: batch stride 0, VecZnx(1, lut_size)
+    PolyMap dm{nl, 1, res_ct, (long long)cols * n, 0, 0};
+    return launch_rotate(M, B * nl, (const long long*)c.lut, sm, (long long*)res, dm, 0, nl, (const long long*)lwe_2n, lwe_bs, 0, 0);
+}
 
-    PZ_TRY(ensure_w2n(M));
-    {
-        bool launched = false;
-        PZ_TRY(br_try_fused(M, res, lwe_2n, lut, brk, p, batch, &launched));
-        if (launched) return PZ_OK;
-    }
-    if (blk > 1) {
-        const size_t n8 = (size_t)M->n * 8;
-        // plans with 128-point rows (N >= 4096): the block step on the three-kernel pipeline of the GLWE products — pass 1 of the
-        // accumulator limbs | k_mid128<.., BR> (row DFT, the block's blk products weighted by DFT(X^a_i - 1), inverse row DFT) | tail
-        // (inverse column pass + accumulator + carry chain): the spectra never reach HBM and one launch covers the whole block
-        {
-            const int npi = cols * std::min(dnum, rsz), npo = cols * bsz, nrows_key = dnum * cols, ncols_key = cols * bsz;
-            static const int br_mid = exp_knob("POULPY_DBG_BR_MID", 1);
-            if (br_mid && M->fuse_mid && M->fuse_tail && tail_supported(M) && M->plan.m2 == 128 && mid_supported(M, npi, npo) &&
-                npi == nrows_key && blk <= 16) {
-                const size_t key_bytes = align256((size_t)blk * nrows_key * ncols_key * n8);
-                const size_t t_bytes = align256(batch * npi * (size_t)M->m * sizeof(cplx)), t2_bytes = align256(batch * npo * (size_t)M->m * sizeof(cplx));
-                // between two blocks the accumulator holds normalized digits: 32-bit values in the workspace (base2k <= 31) - pass 1 and the tail
-                // move them at half the bytes; the caller's `res` is the operand of the first block and the destination of the last
-                const int nblocks = n_lwe / blk;
-                const bool acc32 = k <= 31 && nblocks >= 2 && tail_acc32_supported(M);
-                const size_t d_bytes = acc32 ? align256((size_t)B * res_ct * sizeof(int)) : 0;
-                PZ_TRY(ws_reserve(M, key_bytes + t_bytes + t2_bytes + kMidDummyBytes + d_bytes));
-                char* base = (char*)M->ws;
-                cplx* Pp; cplx* T; cplx* T2; cplx* mid_dummy; int* D = nullptr;
-                PZ_TRY(ws_take(M, base, key_bytes, &Pp));
-                PZ_TRY(ws_take(M, base, t_bytes, &T));
-                PZ_TRY(ws_take(M, base, t2_bytes, &T2));
-                PZ_TRY(ws_take(M, base, kMidDummyBytes, &mid_dummy));
-                if (acc32) PZ_TRY(ws_take(M, base, d_bytes, &D));
-                PolyMap sm{npi / cols, cols, res_ct, (long long)cols * n, n, 0};
-                // (round 5, measured and dropped: the two-stream split of the small-ring path below applied here - the persistent middle kernel holds every
-                //  CU's LDS, so the other half's pass 1 / tail cannot run beside it: N = 4096 -3.6 %, N = 2^14 +-0; profiles/r05_ab_br_two_streams_pipe.txt)
-                for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {
-                    const bool in32 = acc32 && b0 > 0, out32 = acc32 && b0 + 2 * blk <= n_lwe;
-                    PZ_TRY(launch_permute_pmat(M, brk + (size_t)b0 * pmat_doubles, Pp, blk * nrows_key * ncols_key));
-                    PZ_TRY(launch_fwd_pass1(M, B * npi, in32 ? (const long long*)D : (const long long*)res, sm, T, true, -1, in32));
-                    MidBr mb{(const long long*)lwe_2n, lwe_bs, b0, blk};
-                    PZ_TRY(launch_mid(M, B, T, T2, Pp, npi, npo, nrows_key, ncols_key, mid_dummy, 0, 0, nullptr, &mb));
-                    TailCall tc = acc_tail(B, T2, true, bsz, cols, res, res_ct, rsz, k);
-                    if (in32) tc.small = (const long long*)D;
-                    if (out32) tc.res = (long long*)D;
-                    tc.acc32 = (in32 ? 1 : 0) | (out32 ? 2 : 0);
-                    PZ_TRY(launch_inv_tail(M, tc));
-                }
-                return PZ_OK;
-            }
-        }
-        // N = 1024 / 2048 (4096 with POULPY_DBG_BR_MID=0) off the one-kernel path (accumulators beyond LDS: N = 2048, rank 2 at N = 1024):
-        // the transforms around the block step are the two kernels of the small-ring pipeline (device_small.hpp) - the whole forward
-        // transform of the accumulator limbs in LDS, written in the standard spectrum order | the block step on the standard keys |
-        // whole inverse transform + accumulator + carry chain per (ciphertext, column) - instead of pass 1 / pass 2 and pass 2 / tail
-        {
-            const int npi = cols * std::min(dnum, rsz), nrows_key = dnum * cols, ncols_key = cols * bsz;
-            static const int br_small = exp_knob("POULPY_DBG_BR_SMALL", 1);
-            if (br_small && M->small_path && M->fuse_mid && M->fuse_tail && small_supported(M, npi, bsz) && npi == nrows_key && npi <= 12 &&
-                blk <= 64) {
-                const size_t s_bytes = align256(batch * npi * (size_t)M->m * sizeof(cplx)), a_bytes = align256(batch * ncols_key * (size_t)M->m * sizeof(cplx));
-                // between two blocks the accumulator holds normalized digits: kept as 32-bit values in the workspace (base2k <= 31), read and
-                // written by the inverse kernel at half the bytes; the caller's `res` receives the i64 limbs from the last block
-                const int nblocks = n_lwe / blk;
-                const bool acc32 = k <= 31 && nblocks >= 2;
-                const size_t d_bytes = acc32 ? align256((size_t)B * res_ct * sizeof(int)) : 0;
-                PZ_TRY(ws_reserve(M, s_bytes + a_bytes + d_bytes));
-                char* base = (char*)M->ws;
-                cplx* S; cplx* A; int* D = nullptr;
-                PZ_TRY(ws_take(M, base, s_bytes, &S));
-                PZ_TRY(ws_take(M, base, a_bytes, &A));
-                if (acc32) PZ_TRY(ws_take(M, base, d_bytes, &D));
-                PolyMap sm{npi / cols, cols, res_ct, (long long)cols * n, n, 0};
-                // the inverse kernel of a block also runs the forward transform of the new accumulator for the next block (POULPY_DBG_BR_SMALL=2:
-                // separate k_small_fwd launches), when its limbs are among the ones the inverse produces
-                const int fl = npi / cols;
-                const bool chain = br_small != 2 && fl <= bsz && fl <= rsz;
-                // Two halves of the batch on two streams (round 5): the block step is bound by FP64 issue, the inverse / forward kernel around it by
-                // HBM and LDS latency - issued back to back on one stream each leaves the other's unit idle; as two independent chains the step of one
-                // half overlaps with the transforms of the other (split at a tile boundary of the block step: 8 ciphertexts)
-                // (measured, profiles/r05_ab_br_two_streams*.txt: N = 2048 at 1024 / 512 / 256 per call +5.5 % / +10 % / -16 %; rank 2 at N = 1024:
-                //  1024 per call +1 %, 512 -4 % - a half must still fill the chip: >= 2^19 coefficients per column)
-                const int hA = ((long long)(B / 2) * n >= (1ll << 19) && !M->timing) ? ((B / 2 + 7) / 8) * 8 : B;
-                SideStream ss(M);
-                if (hA < B) PZ_TRY(ss.fork());
-                for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {
-                    const bool more = b0 + 2 * blk <= n_lwe;
-                    // operand: `res` in the first block, the 32-bit digits afterwards; destination: the 32-bit digits while blocks follow
-                    // (the separate forward launch of the unchained form reads `res`: i64 throughout there)
-                    const bool use32 = acc32 && chain;
-                    const bool in32 = use32 && b0 > 0, out32 = use32 && more;
-                    for (int half = 0; half < (hA < B ? 2 : 1); ++half) {
-                        const int c0 = half ? hA : 0, nb = half ? B - hA : hA;
-                        ss.on(half == 1);
-                        int64_t* res_h = res + (long long)c0 * res_ct;
-                        int* D_h = D ? D + (long long)c0 * res_ct : nullptr;
-                        cplx* S_h = S + (size_t)c0 * npi * M->m;
-                        cplx* A_h = A + (size_t)c0 * ncols_key * M->m;
-                        if (b0 == 0 || !chain) PZ_TRY(launch_small_fwd(M, nb * npi, (const long long*)res_h, sm, S_h, true));
-                        bool done = false;
-                        PZ_TRY(br_block_step(M, (const double*)S_h, (long long)npi * n, (double*)A_h, (long long)ncols_key * n, brk, pmat_doubles, npi, ncols_key,
-                                             nb, b0, blk, lwe_2n + (long long)c0 * lwe_bs, lwe_bs, &done));
-                        if (!done) return fail(PZ_ERR_UNSUPPORTED, "blind_rotation: block step not launched");
-                        PZ_TRY(launch_small_inv(M, nb, A_h, nullptr, ncols_key, 0, 0, cols, bsz, out32 ? (long long*)D_h : (long long*)res_h, res_ct, cols, rsz,
-                                                in32 ? (const long long*)D_h : (const long long*)res_h, res_ct, cols, rsz, k, -1, true,
-                                                (chain && more) ? S_h : nullptr, fl, false, 0, 0, false, (in32 ? 1 : 0) | (out32 ? 2 : 0)));
-                    }
-                }
-                return ss.join();
-            }
-        }
-        const size_t acc_dft_bytes = align256(batch * n8 * cols * dnum), vr_bytes = align256(batch * n8 * cols * bsz);
-        const size_t tp = (size_t)cols * std::max({dnum, bsz, rsz});
-        const size_t t_bytes = align256(batch * tp * (size_t)M->m * sizeof(cplx));
-        PZ_TRY(ws_reserve(M, acc_dft_bytes + 2 * vr_bytes + t_bytes));
-        char* base = (char*)M->ws;
-        double* acc_dft; double* vmp_res; double* acc_add; cplx* T;
-        PZ_TRY(ws_take(M, base, acc_dft_bytes, &acc_dft));
-        PZ_TRY(ws_take(M, base, vr_bytes, &vmp_res));
-        PZ_TRY(ws_take(M, base, vr_bytes, &acc_add));
-        PZ_TRY(ws_take(M, base, t_bytes, &T));
-        DV ad{acc_dft, n * cols * dnum, cols, dnum}, vr{vmp_res, n * cols * bsz, cols, bsz}, aa{acc_add, n * cols * bsz, cols, bsz};
-        const bool tail = M->fuse_tail && tail_supported(M);
-        for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {  // chunks_exact: a trailing partial block is ignored, as in the reference
-            PZ_TRY(dev_dft_apply(M, B, 1, 0, ad, 0, rv, 0, cols, nullptr, T));                      // :319-321
-            const int row_max = std::min(dnum * cols, cols * std::min(dnum, rsz));
-            bool block_done = false;
-            if (M->fuse_mid) PZ_TRY(br_block_step(M, acc_dft, ad.bs, acc_add, aa.bs, brk, pmat_doubles, row_max, cols * bsz, B, b0, blk, lwe_2n, lwe_bs, &block_done));
-            if (!block_done) {
-            PZ_HIP(hipMemsetAsync(acc_add, 0, (size_t)B * aa.bs * 8, M->stream));                     // :321
-            for (int i = b0; i < b0 + blk; ++i) {                                                       // :324-337
-                PZ_TRY(dev_vmp(M, B, vr, ad, brk + (size_t)i * pmat_doubles, dnum, cols, cols, bsz, 0));
-                PZ_TRY(launch_xai_acc(M, acc_add, aa.bs, vmp_res, vr.bs, cols * bsz, B, lwe_2n, lwe_bs, i));
-            }
-            }
-            // acc = normalize(idft(acc_add) + acc)  (:342-346)
-            if (tail) {
-                PolyMap sm{bsz, cols, aa.bs, (long long)cols * n, n, 0};
-                PZ_TRY(launch_inv_pass2(M, B * bsz * cols, acc_add, sm, T));
-                PZ_TRY(launch_inv_tail(M, acc_tail(B, T, false, bsz, cols, res, res_ct, rsz, k)));
-            } else {
-                PZ_TRY(dev_idft(M, B, aa, 0, aa, 0, cols, bsz, T));
-                for (int c = 0; c < cols; ++c) {
-                    PZ_TRY(launch_ew(M, EW_ADD_I64, (int64_t*)acc_add + (long long)c * n, aa.bs, (long long)cols * n,
-                                     (int64_t*)acc_add + (long long)c * n, aa.bs, (long long)cols * n, res + (long long)c * n, res_ct,
-                                     (long long)cols * n, std::min(bsz, rsz), B));
-                    PZ_TRY(dev_normalize(M, B, rv, k, 0, c, aa, k, c));
-                }
-            }
-        }
+// plans with 128-point rows (N >= 4096): the block step on the three-kernel pipeline of the GLWE products - pass 1 of the accumulator limbs |
+// k_mid128<.., BR> (row DFT, the block's blk products weighted by DFT(X^a_i - 1), inverse row DFT) | tail (inverse column pass + accumulator +
+// carry chain): the spectra never reach HBM and one launch covers the whole block.  *taken = false: the shape is not covered
+static int br_pipeline_path(const BrCall& c, bool* taken) {
+    PZ_BR_UNPACK(c)
+    *taken = false;
+    const int npi = cols * std::min(dnum, rsz), npo = cols * bsz, nrows_key = dnum * cols, ncols_key = cols * bsz;
+    static const int br_mid = exp_knob("POULPY_DBG_BR_MID", 1);
+    if (!(br_mid && M->fuse_mid && M->fuse_tail && tail_supported(M) && M->plan.m2 == 128 && mid_supported(M, npi, npo) && npi == nrows_key && blk <= 16))
         return PZ_OK;
+    *taken = true;
+    const size_t key_bytes = align256((size_t)blk * nrows_key * ncols_key * n8);
+    const size_t t_bytes = align256(batch * npi * (size_t)M->m * sizeof(cplx)), t2_bytes = align256(batch * npo * (size_t)M->m * sizeof(cplx));
+    // between two blocks the accumulator holds normalized digits: 32-bit values in the workspace (base2k <= 31) - pass 1 and the tail
+    // move them at half the bytes; the caller's `res` is the operand of the first block and the destination of the last
+    const int nblocks = n_lwe / blk;
+    const bool acc32 = k <= 31 && nblocks >= 2 && tail_acc32_supported(M);
+    const size_t d_bytes = acc32 ? align256((size_t)B * res_ct * sizeof(int)) : 0;
+    PZ_TRY(ws_reserve(M, key_bytes + t_bytes + t2_bytes + kMidDummyBytes + d_bytes));
+    char* base = (char*)M->ws;
+    cplx* Pp; cplx* T; cplx* T2; cplx* mid_dummy; int* D = nullptr;
+    PZ_TRY(ws_take(M, base, key_bytes, &Pp));
+    PZ_TRY(ws_take(M, base, t_bytes, &T));
+    PZ_TRY(ws_take(M, base, t2_bytes, &T2));
+    PZ_TRY(ws_take(M, base, kMidDummyBytes, &mid_dummy));
+    if (acc32) PZ_TRY(ws_take(M, base, d_bytes, &D));
+    PolyMap sm{npi / cols, cols, res_ct, (long long)cols * n, n, 0};
+    // (round 5, measured and dropped: the two-stream split of the small-ring path below applied here - the persistent middle kernel holds every
+    //  CU's LDS, so the other half's pass 1 / tail cannot run beside it: N = 4096 -3.6 %, N = 2^14 +-0; profiles/r05_ab_br_two_streams_pipe.txt)
+    for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {
+        const bool in32 = acc32 && b0 > 0, out32 = acc32 && b0 + 2 * blk <= n_lwe;
+        PZ_TRY(launch_permute_pmat(M, brk + (size_t)b0 * pmat_doubles, Pp, blk * nrows_key * ncols_key));
+        PZ_TRY(launch_fwd_pass1(M, B * npi, in32 ? (const long long*)D : (const long long*)res, sm, T, true, -1, in32));
+        MidBr mb{(const long long*)lwe_2n, lwe_bs, b0, blk};
+        PZ_TRY(launch_mid(M, B, T, T2, Pp, npi, npo, nrows_key, ncols_key, mid_dummy, 0, 0, nullptr, &mb));
+        TailCall tc = acc_tail(B, T2, true, bsz, cols, res, res_ct, rsz, k);
+        if (in32) tc.small = (const long long*)D;
+        if (out32) tc.res = (long long*)D;
+        tc.acc32 = (in32 ? 1 : 0) | (out32 ? 2 : 0);
+        PZ_TRY(launch_inv_tail(M, tc));
     }
+    return PZ_OK;
+}
 
-    // standard: acc += (X^a_i - 1) * (acc (x) BRK_i) per coefficient, one normalization at the end (:423-437)
+// N = 1024 / 2048 off the one-kernel path (accumulators beyond LDS: N = 2048, rank 2 at N = 1024): the transforms around the block step are the
+// two kernels of the small-ring pipeline (device_small.hpp) - the whole forward transform of the accumulator limbs in LDS, written in the
+// standard spectrum order | the block step on the standard keys | whole inverse transform + accumulator + carry chain per (ciphertext, column) -
+// instead of pass 1 / pass 2 and pass 2 / tail.  *taken = false: the shape is not covered
+static int br_small_ring_path(const BrCall& c, bool* taken) {
+    PZ_BR_UNPACK(c)
+    *taken = false;
+    const int npi = cols * std::min(dnum, rsz), nrows_key = dnum * cols, ncols_key = cols * bsz;
+    static const int br_small = exp_knob("POULPY_DBG_BR_SMALL", 1);
+    if (!(br_small && M->small_path && M->fuse_mid && M->fuse_tail && small_supported(M, npi, bsz) && npi == nrows_key && npi <= 12 && blk <= 64))
+        return PZ_OK;
+    *taken = true;
+    const size_t s_bytes = align256(batch * npi * (size_t)M->m * sizeof(cplx)), a_bytes = align256(batch * ncols_key * (size_t)M->m * sizeof(cplx));
+    // between two blocks the accumulator holds normalized digits: kept as 32-bit values in the workspace (base2k <= 31), read and
+    // written by the inverse kernel at half the bytes; the caller's `res` receives the i64 limbs from the last block
+    const int nblocks = n_lwe / blk;
+    const bool acc32 = k <= 31 && nblocks >= 2;
+    const size_t d_bytes = acc32 ? align256((size_t)B * res_ct * sizeof(int)) : 0;
+    PZ_TRY(ws_reserve(M, s_bytes + a_bytes + d_bytes));
+    char* base = (char*)M->ws;
+    cplx* S; cplx* A; int* D = nullptr;
+    PZ_TRY(ws_take(M, base, s_bytes, &S));
+    PZ_TRY(ws_take(M, base, a_bytes, &A));
+    if (acc32) PZ_TRY(ws_take(M, base, d_bytes, &D));
+    PolyMap sm{npi / cols, cols, res_ct, (long long)cols * n, n, 0};
+    // the inverse kernel of a block also runs the forward transform of the new accumulator for the next block (POULPY_DBG_BR_SMALL=2:
+    // separate k_small_fwd launches), when its limbs are among the ones the inverse produces
+    const int fl = npi / cols;
+    const bool chain = br_small != 2 && fl <= bsz && fl <= rsz;
+    // Two halves of the batch on two streams (round 5): the block step is bound by FP64 issue, the inverse / forward kernel around it by
+    // HBM and LDS latency - issued back to back on one stream each leaves the other's unit idle; as two independent chains the step of one
+    // half overlaps with the transforms of the other (split at a tile boundary of the block step: 8 ciphertexts)
+    // (measured, profiles/r05_ab_br_two_streams*.txt: N = 2048 at 1024 / 512 / 256 per call +5.5 % / +10 % / -16 %; rank 2 at N = 1024:
+    //  1024 per call +1 %, 512 -4 % - a half must still fill the chip: >= 2^19 coefficients per column)
+    const int hA = ((long long)(B / 2) * n >= (1ll << 19) && !M->timing) ? ((B / 2 + 7) / 8) * 8 : B;
+    SideStream ss(M);
+    if (hA < B) PZ_TRY(ss.fork());
+    for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {
+        const bool more = b0 + 2 * blk <= n_lwe;
+        // operand: `res` in the first block, the 32-bit digits afterwards; destination: the 32-bit digits while blocks follow
+        // (the separate forward launch of the unchained form reads `res`: i64 throughout there)
+        const bool use32 = acc32 && chain;
+        const bool in32 = use32 && b0 > 0, out32 = use32 && more;
+        for (int half = 0; half < (hA < B ? 2 : 1); ++half) {
+            const int c0 = half ? hA : 0, nb = half ? B - hA : hA;
+            ss.on(half == 1);
+            int64_t* res_h = res + (long long)c0 * res_ct;
+            int* D_h = D ? D + (long long)c0 * res_ct : nullptr;
+            cplx* S_h = S + (size_t)c0 * npi * M->m;
+            cplx* A_h = A + (size_t)c0 * ncols_key * M->m;
+            if (b0 == 0 || !chain) PZ_TRY(launch_small_fwd(M, nb * npi, (const long long*)res_h, sm, S_h, true));
+            bool done = false;
+            PZ_TRY(br_block_step(M, (const double*)S_h, (long long)npi * n, (double*)A_h, (long long)ncols_key * n, brk, pmat_doubles, npi, ncols_key,
+                                 nb, b0, blk, lwe_2n + (long long)c0 * lwe_bs, lwe_bs, &done));
+            if (!done) return fail(PZ_ERR_UNSUPPORTED, "blind_rotation: block step not launched");
+            PZ_TRY(launch_small_inv(M, nb, A_h, nullptr, ncols_key, 0, 0, cols, bsz, out32 ? (long long*)D_h : (long long*)res_h, res_ct, cols, rsz,
+                                    in32 ? (const long long*)D_h : (const long long*)res_h, res_ct, cols, rsz, k, -1, true,
+                                    (chain && more) ? S_h : nullptr, fl, false, 0, 0, false, (in32 ? 1 : 0) | (out32 ? 2 : 0)));
+        }
+    }
+    return ss.join();
+}
+
+// every other block-binary shape: per-op transforms around the fused block step (or, without it, the reference's own op sequence)
+static int br_composed_path(const BrCall& c) {
+    PZ_BR_UNPACK(c)
+    DV rv{res, res_ct, cols, rsz};
+    const size_t acc_dft_bytes = align256(batch * n8 * cols * dnum), vr_bytes = align256(batch * n8 * cols * bsz);
+    const size_t tp = (size_t)cols * std::max({dnum, bsz, rsz});
+    const size_t t_bytes = align256(batch * tp * (size_t)M->m * sizeof(cplx));
+    PZ_TRY(ws_reserve(M, acc_dft_bytes + 2 * vr_bytes + t_bytes));
+    char* base = (char*)M->ws;
+    double* acc_dft; double* vmp_res; double* acc_add; cplx* T;
+    PZ_TRY(ws_take(M, base, acc_dft_bytes, &acc_dft));
+    PZ_TRY(ws_take(M, base, vr_bytes, &vmp_res));
+    PZ_TRY(ws_take(M, base, vr_bytes, &acc_add));
+    PZ_TRY(ws_take(M, base, t_bytes, &T));
+    DV ad{acc_dft, n * cols * dnum, cols, dnum}, vr{vmp_res, n * cols * bsz, cols, bsz}, aa{acc_add, n * cols * bsz, cols, bsz};
+    const bool tail = M->fuse_tail && tail_supported(M);
+    for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {  // chunks_exact: a trailing partial block is ignored, as in the reference
+        PZ_TRY(dev_dft_apply(M, B, 1, 0, ad, 0, rv, 0, cols, nullptr, T));                      // :319-321
+        const int row_max = std::min(dnum * cols, cols * std::min(dnum, rsz));
+        bool block_done = false;
+        if (M->fuse_mid) PZ_TRY(br_block_step(M, acc_dft, ad.bs, acc_add, aa.bs, brk, pmat_doubles, row_max, cols * bsz, B, b0, blk, lwe_2n, lwe_bs, &block_done));
+        if (!block_done) {
+        PZ_HIP(hipMemsetAsync(acc_add, 0, (size_t)B * aa.bs * 8, M->stream));                     // :321
+        for (int i = b0; i < b0 + blk; ++i) {                                                       // :324-337
+            PZ_TRY(dev_vmp(M, B, vr, ad, brk + (size_t)i * pmat_doubles, dnum, cols, cols, bsz, 0));
+            PZ_TRY(launch_xai_acc(M, acc_add, aa.bs, vmp_res, vr.bs, cols * bsz, B, lwe_2n, lwe_bs, i));
+        }
+        }
+        // acc = normalize(idft(acc_add) + acc)  (:342-346)
+        if (tail) {
+            PolyMap sm{bsz, cols, aa.bs, (long long)cols * n, n, 0};
+            PZ_TRY(launch_inv_pass2(M, B * bsz * cols, acc_add, sm, T));
+            PZ_TRY(launch_inv_tail(M, acc_tail(B, T, false, bsz, cols, res, res_ct, rsz, k)));
+        } else {
+            PZ_TRY(dev_idft(M, B, aa, 0, aa, 0, cols, bsz, T));
+            for (int c = 0; c < cols; ++c) {
+                PZ_TRY(launch_ew(M, EW_ADD_I64, (int64_t*)acc_add + (long long)c * n, aa.bs, (long long)cols * n,
+                                 (int64_t*)acc_add + (long long)c * n, aa.bs, (long long)cols * n, res + (long long)c * n, res_ct,
+                                 (long long)cols * n, std::min(bsz, rsz), B));
+                PZ_TRY(dev_normalize(M, B, rv, k, 0, c, aa, k, c));
+            }
+        }
+    }
+    return PZ_OK;
+}
+
+// execute_standard (block size 1): acc += (X^a_i - 1) * (acc (x) BRK_i) per coefficient, one normalization at the end (:423-437)
+static int br_standard_path(const BrCall& c) {
+    PZ_BR_UNPACK(c)
+    DV rv{res, res_ct, cols, rsz};
     pz_glwe_op_params ep;
     ep.rank = p->rank; ep.dnum = p->dnum; ep.dsize = 1; ep.key_size = p->brk_size; ep.key_base2k = p->base2k;
     ep.a_size = p->res_size; ep.a_base2k = p->base2k; ep.res_size = p->res_size; ep.res_base2k = p->base2k; ep.rank_out = p->rank;
@@ -237,6 +247,36 @@ static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, con
     DV tv{acc_tmp, res_ct, cols, rsz};
     for (int c = 0; c < cols; ++c) PZ_TRY(dev_normalize(M, B, rv, k, 0, c, tv, k, c));
     return PZ_OK;
+}
+
+static int blind_rotation(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_t* lut, const double* brk,
+                          const pz_blind_rotation_params* p, size_t batch) {
+    PZ_REQUIRE(p != nullptr, "null params");
+    PZ_REQUIRE(p->n_lwe >= 1 && p->block_size >= 1 && p->dnum >= 1 && p->brk_size >= 1 && p->res_size >= 1 && p->lut_size >= 1,
+               "blind_rotation: empty shape");
+    PZ_REQUIRE(p->base2k >= 1 && p->base2k <= 63, "blind_rotation: base2k out of range");
+    PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(lwe_2n) && is_device_ptr(lut) && is_device_ptr(brk),
+               "batched entry points take device pointers");
+    if (batch == 0) return PZ_OK;
+    BrCall c;
+    c.M = M; c.res = res; c.lwe_2n = lwe_2n; c.lut = lut; c.brk = brk; c.p = p; c.batch = batch;
+    c.n = (long long)M->n; c.cols = (int)p->rank + 1; c.dnum = (int)p->dnum; c.bsz = (int)p->brk_size; c.rsz = (int)p->res_size;
+    c.B = (int)batch; c.n_lwe = (int)p->n_lwe; c.blk = (int)p->block_size; c.k = (int)p->base2k;
+    c.lwe_bs = (long long)c.n_lwe + 1;
+    c.pmat_doubles = (size_t)c.n * c.dnum * c.cols * c.cols * c.bsz;
+    c.res_ct = c.n * c.cols * c.rsz;
+    c.n8 = (size_t)M->n * 8;
+    PZ_TRY(br_init_accumulator(c));
+    PZ_TRY(ensure_w2n(M));
+    bool taken = false;
+    PZ_TRY(br_try_fused(M, res, lwe_2n, lut, brk, p, batch, &taken));   // the whole rotation in one kernel (device_br.hpp, br_forms.hpp)
+    if (taken) return PZ_OK;
+    if (c.blk == 1) return br_standard_path(c);
+    PZ_TRY(br_pipeline_path(c, &taken));
+    if (taken) return PZ_OK;
+    PZ_TRY(br_small_ring_path(c, &taken));
+    if (taken) return PZ_OK;
+    return br_composed_path(c);
 }
 
 // execute_block_binary_extended (algorithm.rs:121-273; extension_factor > 1, block_size > 1): the ext accumulators of a
@@ -368,6 +408,39 @@ size_t pz_circuit_bootstrapping_to_exponent_tmp_bytes(const pz_module* M, const 
     // acc | rotated rows | 2^log_domain shifted copies | packed result | glwe_pack scratch (3 ciphertext arrays)
     return pz_circuit_bootstrapping_tmp_bytes(M, p, batch) + (((size_t)1 << log_domain) + 1 + 3) * rows_ct;
 }
+// circuit bootstrapping, exponent mode - post_process (circuit.rs:373-421) with log_gap_in != log_gap_out: partial trace of the `count` rows in
+// `tr`, 2^log_domain shifted copies, glwe_pack.  *row_src = the packed rows (behind `tr` in the caller's scratch)
+static int cbt_repack_rows(pz_module* M, int64_t* tr, const int64_t** row_src, size_t nsteps, const int64_t* gals, const double* const* atk_pmats,
+                           const pz_glwe_op_params* tp, const CbtRepack* rp, int count, int tsz, int gsz, int cols) {
+    const long long n = (long long)M->n, ct_t = n * cols * tsz;
+    size_t log_n = 0;
+    while (((size_t)1 << log_n) < (size_t)M->n) ++log_n;
+    PZ_REQUIRE(nsteps == log_n, "circuit_bootstrapping (exponent mode): gals / atk_pmats must cover all log2(n) trace steps");
+    PZ_REQUIRE(tsz == gsz, "circuit_bootstrapping (exponent mode): the GGSW must not be more precise than the GLWE of the rotation");
+    PZ_REQUIRE(rp->log_gap_in >= 1 && rp->log_gap_in <= log_n && rp->log_gap_out <= log_n && rp->log_domain <= 20 &&
+                   (((size_t)1 << rp->log_domain) - 1) << rp->log_gap_out < (size_t)M->n,
+               "circuit_bootstrapping (exponent mode): gaps / domain out of range");
+    const size_t skip = log_n - rp->log_gap_in + 1;
+    PZ_TRY(glwe_trace(M, tr, log_n - skip, gals + skip, atk_pmats + skip, tp, (size_t)count));
+    const size_t steps = (size_t)1 << rp->log_domain;
+    const size_t rows_ct = align256((size_t)count * ct_t * 8);
+    char* base = (char*)tr + rows_ct;
+    std::vector<int64_t*> cts(steps);
+    std::vector<uint64_t> idx(steps);
+    const PolyMap pm{tsz, cols, ct_t, (long long)cols * n, n, 0};
+    for (size_t sidx = 0; sidx < steps; ++sidx) {
+        cts[sidx] = (int64_t*)(base + sidx * rows_ct);
+        idx[sidx] = (uint64_t)(sidx << rp->log_gap_out);
+        PZ_TRY(launch_rotate(M, count * tsz * cols, (const long long*)tr, pm, (long long*)cts[sidx], pm, 0, tsz * cols, nullptr, 0, 0,
+                             -(long long)(sidx << rp->log_gap_in)));
+    }
+    int64_t* packed = (int64_t*)(base + steps * rows_ct);
+    void* pack_tmp = (void*)(base + (steps + 1) * rows_ct);
+    PZ_TRY(glwe_pack(M, packed, steps, idx.data(), cts.data(), rp->log_gap_out, gals, atk_pmats, tp, pack_tmp, 3 * rows_ct, (size_t)count, 0));
+    *row_src = packed;
+    return PZ_OK;
+}
+
 static int circuit_bootstrapping(pz_module* M, int64_t* ggsw, const int64_t* lwe_2n, const int64_t* lut, const double* brk, size_t nsteps,
                                  const int64_t* gals, const double* const* atk_pmats, const double* const* tsk_pmats,
                                  const pz_circuit_bootstrapping_params* p, void* tmp, size_t tmp_bytes, size_t batch,
@@ -421,32 +494,7 @@ static int circuit_bootstrapping(pz_module* M, int64_t* ggsw, const int64_t* lwe
     if (!rp) {
         PZ_TRY(glwe_trace(M, tr, nsteps, gals, atk_pmats, &tp, (size_t)B * rows));
     } else {
-        // post_process (circuit.rs:373-421) with log_gap_in != log_gap_out: partial trace, 2^log_domain shifted copies, glwe_pack
-        size_t log_n = 0;
-        while (((size_t)1 << log_n) < (size_t)M->n) ++log_n;
-        PZ_REQUIRE(nsteps == log_n, "circuit_bootstrapping (exponent mode): gals / atk_pmats must cover all log2(n) trace steps");
-        PZ_REQUIRE(tsz == gsz, "circuit_bootstrapping (exponent mode): the GGSW must not be more precise than the GLWE of the rotation");
-        PZ_REQUIRE(rp->log_gap_in >= 1 && rp->log_gap_in <= log_n && rp->log_gap_out <= log_n && rp->log_domain <= 20 &&
-                       (((size_t)1 << rp->log_domain) - 1) << rp->log_gap_out < (size_t)M->n,
-                   "circuit_bootstrapping (exponent mode): gaps / domain out of range");
-        const size_t skip = log_n - rp->log_gap_in + 1;
-        PZ_TRY(glwe_trace(M, tr, log_n - skip, gals + skip, atk_pmats + skip, &tp, (size_t)B * rows));
-        const size_t steps = (size_t)1 << rp->log_domain;
-        const size_t rows_ct = align256((size_t)B * rows * ct_t * 8);
-        char* base = (char*)tr + rows_ct;
-        std::vector<int64_t*> cts(steps);
-        std::vector<uint64_t> idx(steps);
-        const PolyMap pm{tsz, cols, ct_t, (long long)cols * n, n, 0};
-        for (size_t sidx = 0; sidx < steps; ++sidx) {
-            cts[sidx] = (int64_t*)(base + sidx * rows_ct);
-            idx[sidx] = (uint64_t)(sidx << rp->log_gap_out);
-            PZ_TRY(launch_rotate(M, B * rows * tsz * cols, (const long long*)tr, pm, (long long*)cts[sidx], pm, 0, tsz * cols, nullptr, 0, 0,
-                                 -(long long)(sidx << rp->log_gap_in)));
-        }
-        int64_t* packed = (int64_t*)(base + steps * rows_ct);
-        void* pack_tmp = (void*)(base + (steps + 1) * rows_ct);
-        PZ_TRY(glwe_pack(M, packed, steps, idx.data(), cts.data(), rp->log_gap_out, gals, atk_pmats, &tp, pack_tmp, 3 * rows_ct, (size_t)B * rows, 0));
-        row_src = packed;
+        PZ_TRY(cbt_repack_rows(M, tr, &row_src, nsteps, gals, atk_pmats, &tp, rp, B * rows, tsz, gsz, cols));
     }
     if (k_res == k_atk) {
         // glwe_copy(res.at(i, 0), tmp) (glwe_trace.rs:121-123): the first res_size limbs, into the strided (row, 0) entries
@@ -519,6 +567,63 @@ size_t pz_glwe_pack_bases_tmp_bytes(const pz_module* M, const pz_glwe_op_params*
 // trace_size = 0: ciphertexts, keys and result share one base2k.  Otherwise the keys have their own (test_suite/glwe_packing.rs:40-42):
 // pack_internal's arithmetic stays in the ciphertexts' base, the automorphisms convert, and the closing glwe_trace (glwe_trace.rs:91-127)
 // runs on a temporary of trace_size limbs in the keys' base (behind the three ciphertext arrays of tmp).
+// The limb-wise steps of glwe_pack on `B` ciphertexts at a time (poulpy-core glwe_packing.rs:41-86), and one merge of two slots
+struct PackStep {
+    pz_module* M;
+    const pz_glwe_op_params* p;
+    size_t batch;
+    long long n, ct;
+    int cols, size, k, B;
+    int64_t *tmp_b, *t1, *t2;
+    PolyMap pm() const { return PolyMap{size, cols, ct, (long long)cols * n, n, 0}; }
+    int rotate_to(long long kk, int64_t* dst, const int64_t* src) {
+        return launch_rotate(M, B * size * cols, (const long long*)src, pm(), (long long*)dst, pm(), 0, size * cols, nullptr, 0, 0, kk);
+    }
+    int rotate_assign(long long kk, int64_t* x) {
+        PZ_TRY(rotate_to(kk, t1, x));
+        return launch_ew(M, EW_COPY, x, ct, n, t1, ct, n, nullptr, 0, 0, cols * size, B);
+    }
+    int ew3(int op, int64_t* r, const int64_t* x, const int64_t* y) {   // limb-wise over whole ciphertexts (equal sizes)
+        return launch_ew(M, op, r, ct, n, x, ct, n, y, ct, n, cols * size, B);
+    }
+    int rsh1(int64_t* x) { return launch_rsh(M, B, (long long*)x, ct, cols, size, 0, cols, k, 1); }
+    int normalize_assign(int64_t* x) {
+        PZ_TRY(launch_ew(M, EW_COPY, t2, ct, n, x, ct, n, nullptr, 0, 0, cols * size, B));
+        DV xv{x, ct, cols, size}, tv{t2, ct, cols, size};
+        for (int c = 0; c < cols; ++c) PZ_TRY(dev_normalize(M, B, xv, k, 0, c, tv, k, c));
+        return PZ_OK;
+    }
+    // slots j (a) and j + tt (b) of one level -> *out (null when both are empty)
+    int merge(int64_t* a, int64_t* b, size_t tt, int64_t gal, const double* key, int64_t** out) {
+        *out = nullptr;
+        if (a && b) {                                                       // :41-70
+            PZ_TRY(rotate_assign(-(long long)tt, a));
+            PZ_TRY(ew3(EW_SUB_I64, tmp_b, a, b));
+            PZ_TRY(rsh1(tmp_b));
+            PZ_TRY(ew3(EW_ADD_I64, a, a, b));
+            PZ_TRY(rsh1(a));
+            PZ_TRY(normalize_assign(tmp_b));
+            AutoSpec au{(long long)gal, 0};
+            PZ_TRY(glwe_op(M, true, tmp_b, tmp_b, key, p, batch, &au));
+            PZ_TRY(ew3(EW_SUB_I64, a, a, tmp_b));
+            PZ_TRY(normalize_assign(a));
+            PZ_TRY(rotate_assign((long long)tt, a));
+            *out = a;
+        } else if (a) {                                                     // :71-75
+            PZ_TRY(rsh1(a));
+            AutoSpec au{(long long)gal, 1};
+            PZ_TRY(glwe_op(M, true, a, a, key, p, batch, &au));
+            *out = a;
+        } else if (b) {                                                     // :76-86
+            PZ_TRY(rotate_to((long long)tt, tmp_b, b));
+            PZ_TRY(rsh1(tmp_b));
+            AutoSpec au{(long long)gal, 3};
+            PZ_TRY(glwe_op(M, true, b, tmp_b, key, p, batch, &au));
+            *out = b;
+        }
+        return PZ_OK;
+    }
+};
 static int glwe_pack(pz_module* M, int64_t* res, size_t nslots, const uint64_t* indices, int64_t* const* cts, size_t log_gap_out,
                      const int64_t* gals, const double* const* key_pmats, const pz_glwe_op_params* p, void* tmp, size_t tmp_bytes,
                      size_t batch, size_t trace_size) {
@@ -534,71 +639,30 @@ static int glwe_pack(pz_module* M, int64_t* res, size_t nslots, const uint64_t* 
     PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(tmp), "batched entry points take device pointers");
     PZ_REQUIRE(tmp_bytes >= pz_glwe_pack_bases_tmp_bytes(M, p, trace_size, batch), "glwe_pack: tmp is smaller than pz_glwe_pack[_bases]_tmp_bytes");
     if (batch == 0) return PZ_OK;
-    const long long n = (long long)M->n;
-    const int cols = (int)p->rank + 1, size = (int)p->res_size, k = (int)p->res_base2k, B = (int)batch;
-    const long long ct = n * cols * size;
+    PackStep st;
+    st.M = M; st.p = p; st.batch = batch; st.n = (long long)M->n;
+    st.cols = (int)p->rank + 1; st.size = (int)p->res_size; st.k = (int)p->res_base2k; st.B = (int)batch;
+    st.ct = st.n * st.cols * st.size;
+    const long long n = st.n, ct = st.ct;
+    const int cols = st.cols, size = st.size, k = st.k, B = st.B;
     const size_t ctb = align256((size_t)B * ct * 8);
-    int64_t* tmp_b = (int64_t*)tmp;
-    int64_t* t1 = (int64_t*)((char*)tmp + ctb);
-    int64_t* t2 = (int64_t*)((char*)tmp + 2 * ctb);
+    st.tmp_b = (int64_t*)tmp;
+    st.t1 = (int64_t*)((char*)tmp + ctb);
+    st.t2 = (int64_t*)((char*)tmp + 2 * ctb);
     std::vector<int64_t*> slots((size_t)M->n, nullptr);
-    for (size_t s = 0; s < nslots; ++s) {
-        PZ_REQUIRE(indices[s] < (uint64_t)M->n, "glwe_pack: index out of range");   // glwe_packing.rs:138
-        PZ_REQUIRE(cts[s] != nullptr && is_device_ptr(cts[s]) && slots[indices[s]] == nullptr, "glwe_pack: bad or duplicate entry");
-        slots[indices[s]] = cts[s];
+    for (size_t s_ = 0; s_ < nslots; ++s_) {
+        PZ_REQUIRE(indices[s_] < (uint64_t)M->n, "glwe_pack: index out of range");   // glwe_packing.rs:138
+        PZ_REQUIRE(cts[s_] != nullptr && is_device_ptr(cts[s_]) && slots[indices[s_]] == nullptr, "glwe_pack: bad or duplicate entry");
+        slots[indices[s_]] = cts[s_];
     }
-    const PolyMap pm{size, cols, ct, (long long)cols * n, n, 0};
-    const int npolys = B * size * cols;
-    auto rotate_to = [&](long long kk, int64_t* dst, const int64_t* src) {
-        return launch_rotate(M, npolys, (const long long*)src, pm, (long long*)dst, pm, 0, size * cols, nullptr, 0, 0, kk);
-    };
-    auto rotate_assign = [&](long long kk, int64_t* x) {
-        PZ_TRY(rotate_to(kk, t1, x));
-        return launch_ew(M, EW_COPY, x, ct, n, t1, ct, n, nullptr, 0, 0, cols * size, B);
-    };
-    auto ew3 = [&](int op, int64_t* r, const int64_t* x, const int64_t* y) {   // limb-wise over whole ciphertexts (equal sizes)
-        return launch_ew(M, op, r, ct, n, x, ct, n, y, ct, n, cols * size, B);
-    };
-    auto rsh1 = [&](int64_t* x) { return launch_rsh(M, B, (long long*)x, ct, cols, size, 0, cols, k, 1); };
-    auto normalize_assign = [&](int64_t* x) {
-        PZ_TRY(launch_ew(M, EW_COPY, t2, ct, n, x, ct, n, nullptr, 0, 0, cols * size, B));
-        DV xv{x, ct, cols, size}, tv{t2, ct, cols, size};
-        for (int c = 0; c < cols; ++c) PZ_TRY(dev_normalize(M, B, xv, k, 0, c, tv, k, c));
-        return (int)PZ_OK;
-    };
     for (size_t i = 0; i + log_gap_out < log_n; ++i) {
         const size_t tt = (size_t)1 << (log_n - 1 - i);
         PZ_REQUIRE((gals[i] & 1) != 0 && key_pmats[i] != nullptr, "glwe_pack: bad automorphism key");
         for (size_t j = 0; j < tt; ++j) {
             int64_t* a = slots[j];
             int64_t* b = slots[j + tt];
-            slots[j] = nullptr;
             slots[j + tt] = nullptr;
-            if (a && b) {                                                       // :41-70
-                PZ_TRY(rotate_assign(-(long long)tt, a));
-                PZ_TRY(ew3(EW_SUB_I64, tmp_b, a, b));
-                PZ_TRY(rsh1(tmp_b));
-                PZ_TRY(ew3(EW_ADD_I64, a, a, b));
-                PZ_TRY(rsh1(a));
-                PZ_TRY(normalize_assign(tmp_b));
-                AutoSpec au{(long long)gals[i], 0};
-                PZ_TRY(glwe_op(M, true, tmp_b, tmp_b, key_pmats[i], p, batch, &au));
-                PZ_TRY(ew3(EW_SUB_I64, a, a, tmp_b));
-                PZ_TRY(normalize_assign(a));
-                PZ_TRY(rotate_assign((long long)tt, a));
-                slots[j] = a;
-            } else if (a) {                                                     // :71-75
-                PZ_TRY(rsh1(a));
-                AutoSpec au{(long long)gals[i], 1};
-                PZ_TRY(glwe_op(M, true, a, a, key_pmats[i], p, batch, &au));
-                slots[j] = a;
-            } else if (b) {                                                     // :76-86
-                PZ_TRY(rotate_to((long long)tt, tmp_b, b));
-                PZ_TRY(rsh1(tmp_b));
-                AutoSpec au{(long long)gals[i], 3};
-                PZ_TRY(glwe_op(M, true, b, tmp_b, key_pmats[i], p, batch, &au));
-                slots[j] = b;
-            }
+            PZ_TRY(st.merge(a, b, tt, gals[i], key_pmats[i], &slots[j]));
         }
     }
     PZ_REQUIRE(slots[0] != nullptr, "glwe_pack: no ciphertext ends at index 0");   // :175 a.get(&0).unwrap()

@@ -212,112 +212,114 @@ size_t pz_glwe_tensor_apply_workspace_bytes(const pz_module* M, const pz_glwe_te
     return tensor_chunk(M, t, batch) * (t.per_ct + 6 * 256);
 }
 
-int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, const int64_t* b, const pz_glwe_tensor_params* p, int mode,
-                                 size_t batch) {
-    PZ_ENTER(M);
+// One wave of a GLWE tensoring (glwe_tensor_apply / _add_assign / _square, poulpy-core operations/glwe.rs:609-913): `nb` pairs whose operands have
+// been prepared, the product terms (i, j) one at a time into the tensor columns.  State shared by the steps below; the entry point owns the loop
+// over waves.
+struct TensorWave {
+    pz_module* M;
+    const pz_glwe_tensor_params* p;
     TensorPlan t;
-    PZ_TRY(tensor_plan(M, p, mode, t));
-    const bool square = mode == PZ_TENSOR_SQUARE, add = mode == PZ_TENSOR_APPLY_ADD_ASSIGN;
-    if (square) b = a;
-    PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(a) && is_device_ptr(b), "batched entry points take device pointers");
-    PZ_REQUIRE((const void*)res != (const void*)a && (const void*)res != (const void*)b, "glwe_tensor_apply: res must not alias an operand");
-    if (batch == 0) return PZ_OK;
-    const long long n = (long long)M->n;
-    const size_t chunk = tensor_chunk(M, t, batch);
-    const size_t s_pa = align256(chunk * t.prep_a), s_pb = square ? 0 : align256(chunk * t.prep_b), s_rd = align256(chunk * t.res_dft);
-    const size_t s_tmp = align256(chunk * t.tmp), s_dg = align256(chunk * t.diag), s_T = align256(chunk * t.T);
-    PZ_TRY(ws_reserve(M, s_pa + s_pb + s_rd + s_tmp + s_dg + s_T));
-    char* base = (char*)M->ws;
-    double* pa; double* pb; double* rd; int64_t* tmp; int64_t* diag; cplx* T;
-    PZ_TRY(ws_take(M, base, s_pa, &pa));
-    PZ_TRY(ws_take(M, base, s_pb, &pb));
-    if (square) pb = pa;                                        // convolution.rs:134-138: right = left for FFT64
-    PZ_TRY(ws_take(M, base, s_rd, &rd));
-    PZ_TRY(ws_take(M, base, s_tmp, &tmp));
-    PZ_TRY(ws_take(M, base, s_dg, &diag));
-    PZ_TRY(ws_take(M, base, s_T, &T));
-    const long long a_ct = n * t.cols * t.a_size, b_ct = n * t.cols * t.b_size, r_ct = n * t.tcols * t.res_size;
-    const long long pa_bs = n * t.cols * t.a_size, pb_bs = n * t.cols * t.b_size, rd_bs = n * std::max(t.dft_size, 1), tmp_bs = n * t.res_size;
-    const long long dg_bs = n * t.cols * t.res_size;
-    const long long a_mask = msb_mask_bottom_limb(p->ab_base2k, p->a_effective_k);
-    const long long b_mask = square ? a_mask : msb_mask_bottom_limb(p->ab_base2k, p->b_effective_k);
-    const long long rls = (long long)t.tcols * n;   // limb stride of the tensor
-    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
-        const int nb = (int)std::min(chunk, batch - b0);
-        const int64_t* ab = a + (long long)b0 * a_ct;
-        int64_t* rb = res + (long long)b0 * r_ct;
-        // Fused row pass (round 3, m = m1 x 128 plans, one base2k, rank <= 2): pass 1 of the operand limbs in the pipeline's row-major layout,
-        // then per term ONE kernel for forward row transform + limb convolution + inverse row transform (k_mid_cnv), the inverse column
-        // pass alone (k_inv_tail, raw), and the normalize kernel with the combination in its stores - instead of forward pass 2 of both
-        // operands, k_cnv_apply, inverse pass 2 and inverse pass 1 (POULPY_DBG_TENSOR_FUSED=0).
+    bool square, add;
+    long long n;
+    // workspace of a wave
+    double *pa = nullptr, *pb = nullptr, *rd = nullptr;
+    int64_t *tmp = nullptr, *diag = nullptr;
+    cplx* T = nullptr;
+    long long r_ct = 0, pa_bs = 0, pb_bs = 0, rd_bs = 0, tmp_bs = 0, dg_bs = 0, rls = 0, a_mask = 0, b_mask = 0;
+    // the wave
+    int nb = 0;
+    int64_t* rb = nullptr;
+    bool fused = false, all3 = false;
+    cplx *ta_main = nullptr, *ta_last = nullptr, *tb_main = nullptr, *tb_last = nullptr;
+
+    int take_workspace(size_t chunk) {
+        const size_t s_pa = align256(chunk * t.prep_a), s_pb = square ? 0 : align256(chunk * t.prep_b), s_rd = align256(chunk * t.res_dft);
+        const size_t s_tmp = align256(chunk * t.tmp), s_dg = align256(chunk * t.diag), s_T = align256(chunk * t.T);
+        PZ_TRY(ws_reserve(M, s_pa + s_pb + s_rd + s_tmp + s_dg + s_T));
+        char* base = (char*)M->ws;
+        PZ_TRY(ws_take(M, base, s_pa, &pa));
+        PZ_TRY(ws_take(M, base, s_pb, &pb));
+        if (square) pb = pa;                                        // convolution.rs:134-138: right = left for FFT64
+        PZ_TRY(ws_take(M, base, s_rd, &rd));
+        PZ_TRY(ws_take(M, base, s_tmp, &tmp));
+        PZ_TRY(ws_take(M, base, s_dg, &diag));
+        PZ_TRY(ws_take(M, base, s_T, &T));
+        r_ct = n * t.tcols * t.res_size;
+        pa_bs = n * t.cols * t.a_size; pb_bs = n * t.cols * t.b_size; rd_bs = n * std::max(t.dft_size, 1); tmp_bs = n * t.res_size;
+        dg_bs = n * t.cols * t.res_size;
+        a_mask = msb_mask_bottom_limb(p->ab_base2k, p->a_effective_k);
+        b_mask = square ? a_mask : msb_mask_bottom_limb(p->ab_base2k, p->b_effective_k);
+        rls = (long long)t.tcols * n;   // limb stride of the tensor
+        return PZ_OK;
+    }
+    // pass 1 of one operand's limbs in the pipeline's row-major layout: all limbs but the last, then the last one under its mask
+    int prep_T(const int64_t* src, long long ct, int size, long long mask, cplx* region, cplx** mainp, cplx** lastp) {
+        *mainp = region;
+        *lastp = region + (size_t)nb * (size - 1) * t.cols * (size_t)M->m;
+        if (size > 1) {
+            PolyMap sm{size - 1, t.cols, ct, (long long)t.cols * n, n, 0};
+            PZ_TRY(launch_fwd_pass1(M, nb * (size - 1) * t.cols, (const long long*)src, sm, *mainp, true));
+        }
+        PolyMap sl{1, t.cols, ct, 0, n, (long long)(size - 1) * t.cols * n};
+        return launch_fwd_pass1(M, nb * t.cols, (const long long*)src, sl, *lastp, true, mask);
+    }
+    // Operands of the wave.  Fused row pass (round 3, m = m1 x 128 plans, one base2k, rank <= 2): pass 1 of the operand limbs, then per term ONE
+    // kernel for forward row transform + limb convolution + inverse row transform (k_mid_cnv), the inverse column pass with the normalization
+    // and the combination in its stores - instead of forward pass 2 of both operands, k_cnv_apply, inverse pass 2 and inverse pass 1
+    // (POULPY_DBG_TENSOR_FUSED=0).  Rank 1, 16 / 8 limbs (round 4): the three terms in ONE launch - operand rows loaded and forward-transformed
+    // once, the limb convolution with one operand vector in registers (k_mid_cnv3; POULPY_DBG_TENSOR_ALLTERMS=0: k_mid_cnv per term)
+    int prepare(const int64_t* ab, const int64_t* bb) {
+        const long long a_ct = n * t.cols * t.a_size, b_ct = n * t.cols * t.b_size;
         static const bool fused_env = (rt_knob("POULPY_DBG_TENSOR_FUSED", 1) != 0);
         static const bool combine_ok_env = (rt_knob("POULPY_DBG_TENSOR_COMBINE", 1) != 0);
-        const int bound_f = t.a_size + t.b_size - 1;
-        const bool fused = fused_env && combine_ok_env && p->res_base2k == p->ab_base2k && t.cols <= 3 && t.dft_size >= 1 &&
-                           mid_cnv_supported(M, t.a_size, t.b_size, std::min(t.dft_size, bound_f));
-        const size_t mpts = (size_t)M->m;
-        cplx *ta_main = nullptr, *ta_last = nullptr, *tb_main = nullptr, *tb_last = nullptr;
+        const int bound = t.a_size + t.b_size - 1;
+        fused = fused_env && combine_ok_env && p->res_base2k == p->ab_base2k && t.cols <= 3 && t.dft_size >= 1 &&
+                mid_cnv_supported(M, t.a_size, t.b_size, std::min(t.dft_size, bound));
         if (fused) {
-            auto prep_T = [&](const int64_t* src, long long ct, int size, long long mask, cplx* region, cplx** mainp, cplx** lastp) -> int {
-                *mainp = region;
-                *lastp = region + (size_t)nb * (size - 1) * t.cols * mpts;
-                if (size > 1) {
-                    PolyMap sm{size - 1, t.cols, ct, (long long)t.cols * n, n, 0};
-                    PZ_TRY(launch_fwd_pass1(M, nb * (size - 1) * t.cols, (const long long*)src, sm, *mainp, true));
-                }
-                PolyMap sl{1, t.cols, ct, 0, n, (long long)(size - 1) * t.cols * n};
-                return launch_fwd_pass1(M, nb * t.cols, (const long long*)src, sl, *lastp, true, mask);
-            };
             PZ_TRY(prep_T(ab, a_ct, t.a_size, a_mask, (cplx*)pa, &ta_main, &ta_last));
             if (square) { tb_main = ta_main; tb_last = ta_last; }
-            else PZ_TRY(prep_T(b + (long long)b0 * b_ct, b_ct, t.b_size, b_mask, (cplx*)pb, &tb_main, &tb_last));
+            else PZ_TRY(prep_T(bb, b_ct, t.b_size, b_mask, (cplx*)pb, &tb_main, &tb_last));
         } else {
             PZ_TRY(dev_cnv_prepare(M, nb, pa, pa_bs, t.cols, t.a_size, ab, a_ct, t.cols, t.a_size, a_mask, T));
-            if (!square) PZ_TRY(dev_cnv_prepare(M, nb, pb, pb_bs, t.cols, t.b_size, b + (long long)b0 * b_ct, b_ct, t.cols, t.b_size, b_mask, T));
+            if (!square) PZ_TRY(dev_cnv_prepare(M, nb, pb, pb_bs, t.cols, t.b_size, bb, b_ct, t.cols, t.b_size, b_mask, T));
         }
-        // rank 1, 16 / 8 limbs (round 4): the three terms in ONE launch - operand rows loaded and forward-transformed once, the limb
-        // convolution with one operand vector in registers (k_mid_cnv3; POULPY_DBG_TENSOR_ALLTERMS=0: k_mid_cnv per term)
-        const int bound_all = t.a_size + t.b_size - 1, ms_all = std::min(t.dft_size, bound_all), off_all = std::min(t.hi, bound_all);
-        const bool all3 = fused && mid_cnv3_supported(M, t.cols, t.a_size, t.b_size, ms_all);
+        const int ms_all = std::min(t.dft_size, bound), off_all = std::min(t.hi, bound);
+        all3 = fused && mid_cnv3_supported(M, t.cols, t.a_size, t.b_size, ms_all);
         if (all3) PZ_TRY(launch_mid_cnv3(M, nb, ta_main, ta_last, tb_main, tb_last, T, t.a_size, ms_all, off_all));
-        // one product term (i, j): convolution -> inverse transform in place -> normalize(res_base2k, cnv_offset_lo) into `dst` column dcol
-        auto term = [&](int i, int j, int64_t* dst, long long dst_bs, int dst_cols, int dcol, const NzCombine* cb = nullptr) -> int {
-            const int bound = t.a_size + t.b_size - 1;
-            const int min_size = std::min(t.dft_size, bound), off = std::min(t.hi, bound);
-            if (fused) {
-                const cplx* Tt = T;
-                if (all3) Tt = T + (size_t)(i == j ? i : 2) * nb * min_size * mpts;
-                else PZ_TRY(launch_mid_cnv(M, nb, ta_main, ta_last, tb_main, tb_last, T, t.cols, t.a_size, t.b_size, i, i == j ? -1 : j, i, i == j ? -1 : j,
-                                           min_size, off));
-                // the inverse column pass normalizes on its way out (bit offset, combination and all: TailArgs::nz); POULPY_DBG_TENSOR_NZTAIL=0:
-                // raw inverse column pass into a VecZnxBig, then the normalize kernel
-                static const bool nztail = (exp_knob("POULPY_DBG_TENSOR_NZTAIL", 1) != 0);
-                if (nztail)
-                    return launch_inv_tail_nz(M, nb, Tt, min_size, (long long*)dst, dst_bs, dst_cols, t.res_size, dcol, (int)p->res_base2k, t.lo,
-                                              t.dft_size, cb);
-                PZ_TRY(launch_inv_tail_raw(M, nb, Tt, min_size, (long long*)rd, rd_bs, t.dft_size));
-                DV dvf{rd, rd_bs, 1, t.dft_size};
-                DV outf{dst, dst_bs, dst_cols, t.res_size};
-                return dev_normalize(M, nb, outf, (int)p->res_base2k, t.lo, dcol, dvf, (int)p->ab_base2k, 0, cb);
-            }
-            PZ_TRY(launch_cnv_apply(M, nb, rd, rd_bs, 1, 0, min_size, off, pa, pa_bs, t.a_size, i, i == j ? -1 : j, pb, pb_bs, t.b_size, i,
-                                    i == j ? -1 : j));
-            if (t.dft_size > min_size)
-                PZ_TRY(launch_ew(M, EW_ZERO, rd + (long long)min_size * n, rd_bs, n, nullptr, 0, 0, nullptr, 0, 0, t.dft_size - min_size, nb));
-            DV dv{rd, rd_bs, 1, t.dft_size};
-            PZ_TRY(dev_idft(M, nb, dv, 0, dv, 0, 1, t.dft_size, T));
-            DV out{dst, dst_bs, dst_cols, t.res_size};
-            return dev_normalize(M, nb, out, (int)p->res_base2k, t.lo, dcol, dv, (int)p->ab_base2k, 0, cb);
-        };
-        auto col_ptr = [&](int col) { return rb + (long long)col * n; };
-        auto ew_res = [&](int op, int col, const int64_t* x, long long x_bs, long long x_ls, const int64_t* y, long long y_bs, long long y_ls) {
-            return launch_ew(M, op, col_ptr(col), r_ct, rls, x, x_bs, x_ls, y, y_bs, y_ls, t.res_size, nb);
-        };
-        static const bool combine_sq = (rt_knob("POULPY_DBG_TENSOR_COMBINE", 1) != 0);
-        if (square && combine_sq && p->res_base2k == p->ab_base2k && t.cols <= 3) {
-            // (round 3) the same sums with the combination in the normalize kernel's stores: the diagonal terms stored, each pairwise term
-            // then reads its two diagonal columns and stores pair - d_i - d_j (wrapping i64: the same digits as the reference's order)
-            auto cidx = [&](int i, int j) { const int lo_ = std::min(i, j), hi_ = std::max(i, j); return lo_ * t.cols - (lo_ * (lo_ + 1) / 2) + hi_; };
+        return PZ_OK;
+    }
+    // one product term (i, j): convolution -> inverse transform in place -> normalize(res_base2k, cnv_offset_lo) into `dst` column dcol
+    int term(int i, int j, int64_t* dst, long long dst_bs, int dst_cols, int dcol, const NzCombine* cb = nullptr) {
+        const int bound = t.a_size + t.b_size - 1;
+        const int min_size = std::min(t.dft_size, bound), off = std::min(t.hi, bound);
+        if (fused) {
+            const cplx* Tt = T;
+            if (all3) Tt = T + (size_t)(i == j ? i : 2) * nb * min_size * (size_t)M->m;
+            else PZ_TRY(launch_mid_cnv(M, nb, ta_main, ta_last, tb_main, tb_last, T, t.cols, t.a_size, t.b_size, i, i == j ? -1 : j, i, i == j ? -1 : j,
+                                       min_size, off));
+            // the inverse column pass normalizes on its way out (bit offset, combination and all: TailArgs::nz)
+            return launch_inv_tail_nz(M, nb, Tt, min_size, (long long*)dst, dst_bs, dst_cols, t.res_size, dcol, (int)p->res_base2k, t.lo, t.dft_size, cb);
+        }
+        PZ_TRY(launch_cnv_apply(M, nb, rd, rd_bs, 1, 0, min_size, off, pa, pa_bs, t.a_size, i, i == j ? -1 : j, pb, pb_bs, t.b_size, i, i == j ? -1 : j));
+        if (t.dft_size > min_size)
+            PZ_TRY(launch_ew(M, EW_ZERO, rd + (long long)min_size * n, rd_bs, n, nullptr, 0, 0, nullptr, 0, 0, t.dft_size - min_size, nb));
+        DV dv{rd, rd_bs, 1, t.dft_size};
+        PZ_TRY(dev_idft(M, nb, dv, 0, dv, 0, 1, t.dft_size, T));
+        DV out{dst, dst_bs, dst_cols, t.res_size};
+        return dev_normalize(M, nb, out, (int)p->res_base2k, t.lo, dcol, dv, (int)p->ab_base2k, 0, cb);
+    }
+    int64_t* col_ptr(int col) const { return rb + (long long)col * n; }
+    int ew_res(int op, int col, const int64_t* x, long long x_bs, long long x_ls, const int64_t* y, long long y_bs, long long y_ls) {
+        return launch_ew(M, op, col_ptr(col), r_ct, rls, x, x_bs, x_ls, y, y_bs, y_ls, t.res_size, nb);
+    }
+    int cidx(int i, int j) const { const int lo_ = std::min(i, j), hi_ = std::max(i, j); return lo_ * t.cols - (lo_ * (lo_ + 1) / 2) + hi_; }
+
+    // One base2k, rank <= 2 (round 3): the digits of a term go straight from the normalizing store into every tensor column that takes them.
+    // apply / square: the diagonal terms are stored, each pairwise term then reads the two diagonal columns it belongs to and stores
+    // pair - d_i - d_j (mode 5: one write per column, no read-modify-write; wrapping i64: the same digits as the reference's order).
+    // add_assign: the diagonal term goes into its column (+=) and out of the cross columns (-=), the pairwise term into its cross column (+=)
+    int combine_in_stores() {
+        if (!add) {
             for (int i = 0; i < t.cols; ++i) {
                 NzCombine cb{1, {0, 0}, {0, 0}};
                 PZ_TRY(term(i, i, rb, r_ct, t.tcols, cidx(i, i), &cb));
@@ -327,86 +329,88 @@ int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, c
                     NzCombine cb{1, {cidx(i, i), cidx(j, j)}, {5, 5}};
                     PZ_TRY(term(i, j, rb, r_ct, t.tcols, cidx(i, j), &cb));
                 }
-            continue;
+            return PZ_OK;
         }
-        if (square) {   // :651-697
-            for (int i = 0; i < t.cols; ++i) {
-                const int col_i = i * t.cols - (i * (i + 1) / 2);
-                PZ_TRY(term(i, i, diag, dg_bs, t.cols, i));
-                PZ_TRY(ew_res(EW_COPY, col_i + i, diag + (long long)i * n, dg_bs, (long long)t.cols * n, nullptr, 0, 0));
-            }
-            for (int i = 0; i < t.cols; ++i) {
-                const int col_i = i * t.cols - (i * (i + 1) / 2);
-                for (int j = i + 1; j < t.cols; ++j) {
-                    PZ_TRY(term(i, j, rb, r_ct, t.tcols, col_i + j));
-                    PZ_TRY(ew_res(EW_SUB_I64, col_i + j, col_ptr(col_i + j), r_ct, rls, diag + (long long)i * n, dg_bs, (long long)t.cols * n));
-                    PZ_TRY(ew_res(EW_SUB_I64, col_i + j, col_ptr(col_i + j), r_ct, rls, diag + (long long)j * n, dg_bs, (long long)t.cols * n));
-                }
-            }
-            continue;
-        }
-        // One base2k, rank <= 2 (round 3): the digits of a term go straight from the normalize kernel into every tensor column that takes
-        // them - the diagonal term into its own column (= / +=) and, negated, into the cross columns (= - / -=), the pairwise term into
-        // its cross column (+=) - instead of a temporary and five element-wise passes over the tensor (POULPY_DBG_TENSOR_COMBINE=0).
-        static const bool combine_env = (rt_knob("POULPY_DBG_TENSOR_COMBINE", 1) != 0);
-        if (combine_env && p->res_base2k == p->ab_base2k && t.cols <= 3) {
-            auto cidx = [&](int i, int j) { const int lo_ = std::min(i, j), hi_ = std::max(i, j); return lo_ * t.cols - (lo_ * (lo_ + 1) / 2) + hi_; };
-            if (!add) {
-                // plain apply: the diagonal terms are stored, each pairwise term then reads the two diagonal columns it belongs to and stores
-                // pair - d_i - d_j (mode 5): one write per column, no read-modify-write of the cross columns
-                for (int i = 0; i < t.cols; ++i) {
-                    NzCombine cb{1, {0, 0}, {0, 0}};
-                    PZ_TRY(term(i, i, rb, r_ct, t.tcols, cidx(i, i), &cb));
-                }
-                for (int i = 0; i < t.cols; ++i)
-                    for (int j = i + 1; j < t.cols; ++j) {
-                        NzCombine cb{1, {cidx(i, i), cidx(j, j)}, {5, 5}};
-                        PZ_TRY(term(i, j, rb, r_ct, t.tcols, cidx(i, j), &cb));
-                    }
-                continue;
-            }
-            for (int i = 0; i < t.cols; ++i) {
-                NzCombine cb{3, {0, 0}, {0, 0}};
-                int u = 0;
-                for (int j = 0; j < t.cols; ++j) {
-                    if (j == i) continue;
-                    cb.col2[u] = cidx(i, j);
-                    cb.mode2[u] = 4;   // add_assign: the diagonal term goes into its column (+=) and out of the cross columns (-=)
-                    ++u;
-                }
-                PZ_TRY(term(i, i, rb, r_ct, t.tcols, cidx(i, i), &cb));
-            }
-            for (int i = 0; i < t.cols; ++i)
-                for (int j = i + 1; j < t.cols; ++j) {
-                    NzCombine cb{3, {0, 0}, {0, 0}};
-                    PZ_TRY(term(i, j, rb, r_ct, t.tcols, cidx(i, j), &cb));
-                }
-            continue;
-        }
-        for (int i = 0; i < t.cols; ++i) {   // :762-783 / :870-890
-            const int col_i = i * t.cols - (i * (i + 1) / 2);
-            PZ_TRY(term(i, i, tmp, tmp_bs, 1, 0));
-            if (add) PZ_TRY(ew_res(EW_ADD_I64, col_i + i, col_ptr(col_i + i), r_ct, rls, tmp, tmp_bs, n));
-            else PZ_TRY(ew_res(EW_COPY, col_i + i, tmp, tmp_bs, n, nullptr, 0, 0));
+        for (int i = 0; i < t.cols; ++i) {
+            NzCombine cb{3, {0, 0}, {0, 0}};
+            int u = 0;
             for (int j = 0; j < t.cols; ++j) {
                 if (j == i) continue;
-                if (j < i) {
-                    const int col_j = j * t.cols - (j * (j + 1) / 2);
-                    PZ_TRY(ew_res(EW_SUB_I64, col_j + i, col_ptr(col_j + i), r_ct, rls, tmp, tmp_bs, n));
-                } else if (add) {
-                    PZ_TRY(ew_res(EW_SUB_I64, col_i + j, col_ptr(col_i + j), r_ct, rls, tmp, tmp_bs, n));
-                } else {
-                    PZ_TRY(ew_res(EW_NEG_I64, col_i + j, tmp, tmp_bs, n, nullptr, 0, 0));
-                }
+                cb.col2[u] = cidx(i, j);
+                cb.mode2[u] = 4;
+                ++u;
+            }
+            PZ_TRY(term(i, i, rb, r_ct, t.tcols, cidx(i, i), &cb));
+        }
+        for (int i = 0; i < t.cols; ++i)
+            for (int j = i + 1; j < t.cols; ++j) {
+                NzCombine cb{3, {0, 0}, {0, 0}};
+                PZ_TRY(term(i, j, rb, r_ct, t.tcols, cidx(i, j), &cb));
+            }
+        return PZ_OK;
+    }
+    // glwe_tensor_square_apply in the reference's order (:651-697): diagonal terms kept aside, each pairwise term minus its two diagonals
+    int square_reference_order() {
+        for (int i = 0; i < t.cols; ++i) {
+            PZ_TRY(term(i, i, diag, dg_bs, t.cols, i));
+            PZ_TRY(ew_res(EW_COPY, cidx(i, i), diag + (long long)i * n, dg_bs, (long long)t.cols * n, nullptr, 0, 0));
+        }
+        for (int i = 0; i < t.cols; ++i)
+            for (int j = i + 1; j < t.cols; ++j) {
+                const int c = cidx(i, j);
+                PZ_TRY(term(i, j, rb, r_ct, t.tcols, c));
+                PZ_TRY(ew_res(EW_SUB_I64, c, col_ptr(c), r_ct, rls, diag + (long long)i * n, dg_bs, (long long)t.cols * n));
+                PZ_TRY(ew_res(EW_SUB_I64, c, col_ptr(c), r_ct, rls, diag + (long long)j * n, dg_bs, (long long)t.cols * n));
+            }
+        return PZ_OK;
+    }
+    // glwe_tensor_apply / _add_assign in the reference's order (:762-805 / :870-890): a temporary per term, element-wise passes over the tensor
+    int apply_reference_order() {
+        for (int i = 0; i < t.cols; ++i) {
+            PZ_TRY(term(i, i, tmp, tmp_bs, 1, 0));
+            if (add) PZ_TRY(ew_res(EW_ADD_I64, cidx(i, i), col_ptr(cidx(i, i)), r_ct, rls, tmp, tmp_bs, n));
+            else PZ_TRY(ew_res(EW_COPY, cidx(i, i), tmp, tmp_bs, n, nullptr, 0, 0));
+            for (int j = 0; j < t.cols; ++j) {
+                if (j == i) continue;
+                const int c = cidx(i, j);
+                if (j < i || add) PZ_TRY(ew_res(EW_SUB_I64, c, col_ptr(c), r_ct, rls, tmp, tmp_bs, n));
+                else PZ_TRY(ew_res(EW_NEG_I64, c, tmp, tmp_bs, n, nullptr, 0, 0));
             }
         }
-        for (int i = 0; i < t.cols; ++i) {   // :785-805
-            const int col_i = i * t.cols - (i * (i + 1) / 2);
+        for (int i = 0; i < t.cols; ++i)
             for (int j = i + 1; j < t.cols; ++j) {
                 PZ_TRY(term(i, j, tmp, tmp_bs, 1, 0));
-                PZ_TRY(ew_res(EW_ADD_I64, col_i + j, col_ptr(col_i + j), r_ct, rls, tmp, tmp_bs, n));
+                PZ_TRY(ew_res(EW_ADD_I64, cidx(i, j), col_ptr(cidx(i, j)), r_ct, rls, tmp, tmp_bs, n));
             }
-        }
+        return PZ_OK;
+    }
+};
+
+int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, const int64_t* b, const pz_glwe_tensor_params* p, int mode,
+                                 size_t batch) {
+    PZ_ENTER(M);
+    TensorPlan t;
+    PZ_TRY(tensor_plan(M, p, mode, t));
+    const bool square = mode == PZ_TENSOR_SQUARE;
+    if (square) b = a;
+    PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(a) && is_device_ptr(b), "batched entry points take device pointers");
+    PZ_REQUIRE((const void*)res != (const void*)a && (const void*)res != (const void*)b, "glwe_tensor_apply: res must not alias an operand");
+    if (batch == 0) return PZ_OK;
+    TensorWave w;
+    w.M = M; w.p = p; w.t = t; w.square = square; w.add = mode == PZ_TENSOR_APPLY_ADD_ASSIGN; w.n = (long long)M->n;
+    const size_t chunk = tensor_chunk(M, t, batch);
+    PZ_TRY(w.take_workspace(chunk));
+    const long long a_ct = w.n * t.cols * t.a_size, b_ct = w.n * t.cols * t.b_size;
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        w.nb = (int)std::min(chunk, batch - b0);
+        w.rb = res + (long long)b0 * w.r_ct;
+        PZ_TRY(w.prepare(a + (long long)b0 * a_ct, b + (long long)b0 * b_ct));
+        // where the digits of a term can go straight from the normalizing store into every tensor column that takes them (one base2k,
+        // rank <= 2; POULPY_DBG_TENSOR_COMBINE=0: the reference's own order of element-wise passes)
+        static const bool combine_env = (rt_knob("POULPY_DBG_TENSOR_COMBINE", 1) != 0);
+        if (combine_env && p->res_base2k == p->ab_base2k && t.cols <= 3) PZ_TRY(w.combine_in_stores());
+        else if (square) PZ_TRY(w.square_reference_order());
+        else PZ_TRY(w.apply_reference_order());
     }
     return PZ_OK;
 }
