@@ -145,7 +145,7 @@ static int br_small_ring_path(const BrCall& c, bool* taken) {
     // the inverse kernel of a block also runs the forward transform of the new accumulator for the next block (POULPY_DBG_BR_SMALL=2:
     // separate k_small_fwd launches), when its limbs are among the ones the inverse produces
     const int fl = npi / cols;
-    const bool chain = br_small != 2 && fl <= bsz && fl <= rsz;
+    const bool chain = br_small != 2 && fl <= bsz && fl <= rsz && M->n < 4096;   // (N = 4096 - block sizes the pipeline path declines - has no chained form)
     // Two halves of the batch on two streams (round 5): the block step is bound by FP64 issue, the inverse / forward kernel around it by
     // HBM and LDS latency - issued back to back on one stream each leaves the other's unit idle; as two independent chains the step of one
     // half overlaps with the transforms of the other (split at a tile boundary of the block step: 8 ciphertexts)

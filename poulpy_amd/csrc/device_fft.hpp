@@ -378,9 +378,10 @@ k_inv_pass2(const double* __restrict__ src, PolyMap smap, cplx* __restrict__ T, 
 // =================================================================================
 // inverse pass 1: T[j2][q1] -> i64 coefficients, round(x/m) half-away, saturating
 // (tw1inv[j1] = conj(psi1^j1)/m carries the exact power-of-two scale).
-// margin != nullptr: record max |x - round(x)| (exactness margin), margin_note above.
+// PROBE: record max |x - round(x)| (exactness margin, margin_note above) - compile-time: as a run-time test in front of the store loop it cost
+// this kernel 3.12 -> 4.57 ms per 16 Ki polynomials at N = 2^16 (round 5, profiles/r05_bench_lines_hal.txt vs r04).
 // =================================================================================
-template <int R1, int R2, int CB>
+template <int R1, int R2, int CB, bool PROBE>
 __global__ void __launch_bounds__((R1 > R2 ? R1 : R2) * CB)
 k_inv_pass1(const cplx* __restrict__ T, long long* __restrict__ dst, PolyMap dmap, int m2,
             const cplx* __restrict__ tw1inv, const cplx* __restrict__ wL1, unsigned long long* __restrict__ margin) {
@@ -414,21 +415,19 @@ k_inv_pass1(const cplx* __restrict__ T, long long* __restrict__ dst, PolyMap dma
 #pragma unroll
         for (int k1 = 0; k1 < R1; ++k1) v[k1] = lds[(o * CB + c) * (R1 + 1) + k1];
         Bfly<R1, true>::run(v);
-#pragma unroll
-        for (int n1 = 0; n1 < R1; ++n1) v[n1] = cmul(v[n1], tw1inv[o + R2 * n1]);
-        if (margin) {
-            double worst = 0.0;
-#pragma unroll
-            for (int n1 = 0; n1 < R1; ++n1) worst = fmax(worst, fmax(margin_dist(v[n1].x), margin_dist(v[n1].y)));
-            margin_note(margin, worst);
-        }
+        double worst = 0.0;
 #pragma unroll
         for (int n1 = 0; n1 < R1; ++n1) {
             const int j1 = o + R2 * n1;
+            const cplx w = cmul(v[n1], tw1inv[j1]);
             const long long idx = (long long)j1 * m2 + c0 + c;
-            out[idx] = round_to_i64(v[n1].x);
-            out[idx + m] = round_to_i64(v[n1].y);
+            out[idx] = round_to_i64(w.x);
+            out[idx + m] = round_to_i64(w.y);
+            if (PROBE) {
+                worst = fmax(worst, fmax(margin_dist(w.x), margin_dist(w.y)));
+            }
         }
+        if (PROBE) margin_note(margin, worst);
     }
 }
 

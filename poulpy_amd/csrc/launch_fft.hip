@@ -108,9 +108,15 @@ int launch_inv_pass1(pz_module* M, int npolys, const cplx* T, long long* dst, Po
 #define X(A, B, C)                                                                                              \
     if (pl.r1a == A && pl.r1b == B && pl.cb == C) {                                                             \
         const size_t lds = (size_t)(A + 1) * C * B * sizeof(cplx);                                              \
-        PZ_TRY(set_lds(k_inv_pass1<A, B, C>, lds));                                                             \
-        hipLaunchKernelGGL((k_inv_pass1<A, B, C>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, T,  \
-                           dst, dmap, pl.m2, M->tw1inv, M->wL1, M->probe ? M->margin : nullptr);                \
+        if (M->probe) {                                                                                         \
+            PZ_TRY(set_lds(k_inv_pass1<A, B, C, true>, lds));                                                   \
+            hipLaunchKernelGGL((k_inv_pass1<A, B, C, true>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, T, \
+                               dst, dmap, pl.m2, M->tw1inv, M->wL1, M->margin);                                 \
+        } else {                                                                                                \
+            PZ_TRY(set_lds(k_inv_pass1<A, B, C, false>, lds));                                                  \
+            hipLaunchKernelGGL((k_inv_pass1<A, B, C, false>), dim3(blocks), dim3((A > B ? A : B) * C), lds, M->stream, T, \
+                               dst, dmap, pl.m2, M->tw1inv, M->wL1, M->margin);                                 \
+        }                                                                                                       \
         PZ_HIP(hipGetLastError());                                                                              \
         return PZ_OK;                                                                                           \
     }

@@ -149,9 +149,15 @@ int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int
         PZ_TRY(set_lds((K_), lds));                                                                           \
         hipLaunchKernelGGL((K_), dim3(grid), dim3(64 * m1), lds, M->stream, g);                               \
     }
+    // (the product-free form with the chained forward transform - the blind rotation's tail - exists for N <= 2048: at N = 4096 the rotation runs
+    //  on the three-kernel pipeline, and these four instantiations carried 28 B of scratch each)
+    if (noprod && g.fwd_limbs && m1 == 16) return fail(PZ_ERR_UNSUPPORTED, "small-ring pipeline: no chained forward transform at N = 4096");
+#define XFWD_4(KS_) XL((k_small_inv<4, KS_, true, true>))
+#define XFWD_8(KS_) XL((k_small_inv<8, KS_, true, true>))
+#define XFWD_16(KS_) {}
 #define X(M1_, KS_)                                                                                           \
     if (m1 == M1_ && ksz == KS_) {                                                                            \
-        if (noprod && g.fwd_limbs) XL((k_small_inv<M1_, KS_, true, true>))                                    \
+        if (noprod && g.fwd_limbs) XFWD_##M1_(KS_)                                                            \
         else if (noprod) XL((k_small_inv<M1_, KS_, true>))                                                    \
         else if (au) XL((k_small_inv<M1_, KS_, false, false, true>))                                          \
         else XL((k_small_inv<M1_, KS_>))                                                                      \
@@ -160,6 +166,9 @@ int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int
     }
     X(4, 1) X(4, 2) X(4, 3) X(4, 4) X(8, 1) X(8, 2) X(8, 3) X(8, 4) X(16, 1) X(16, 2) X(16, 3) X(16, 4)
 #undef X
+#undef XFWD_4
+#undef XFWD_8
+#undef XFWD_16
 #undef XL
     return fail(PZ_ERR_UNSUPPORTED, "small-ring pipeline: m1 = %d, %d key limbs", m1, ksz);
 }
