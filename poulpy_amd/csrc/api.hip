@@ -227,7 +227,7 @@ int resolve_key(pz_module* M, const double* pmat, size_t bytes, const double** o
 extern "C" {
 
 const char* pz_last_error(void) { return last_error_ref().c_str(); }
-uint32_t pz_abi_version(void) { return PZ_ABI_VERSION; }   // 4: - pz_module_set_phase_tuning / _phase_tuning_state (the placement tuner measured nothing)
+uint32_t pz_abi_version(void) { return PZ_ABI_VERSION; }   // 4: - pz_module_set_phase_tuning / _phase_tuning_state (the placement tuner measured nothing, NOTEBOOK.md 13)
 
 int pz_module_new_on_device(uint64_t n, int device, pz_module** out) {
     if (!out) return fail(PZ_ERR_INVALID, "null out");

@@ -31,12 +31,12 @@ constexpr int kMidRS = PZ_MID_RS;
 #endif
 #ifndef PZ_MIDR_HALFKEY
 #define PZ_MIDR_HALFKEY 0   // timing ablation (results invalid): every second key row of k_mid128r's product is never requested - what the product phase
-#endif                      // would cost with eight ciphertexts per key fetch, before any of that scheme's own costs
+#endif                      // would cost with eight ciphertexts per key fetch, before any of that scheme's own costs (NOTEBOOK.md 13.2)
 #ifndef PZ_MIDR_SADDR
 #define PZ_MIDR_SADDR 1     // k_mid128r product: uniform key-row base + 32-bit lane offsets, lane base + scalar row offset in LDS (0: 64-bit lane pointers, A/B)
 #endif
 #ifndef PZ_MIDR_ILV
-#define PZ_MIDR_ILV 1       // k_mid128r: inverse row pass of tile t and forward row pass of tile t + 1 interleaved (0: one after the other, rounds 3 - 4a)
+#define PZ_MIDR_ILV 1       // k_mid128r: inverse row pass of tile t and forward row pass of tile t + 1 interleaved (0: one after the other, rounds 3 - 4a; NOTEBOOK.md 13.2)
 #endif
 #ifndef PZ_MIDR_KR
 #define PZ_MIDR_KR 6     // key-row slots of k_mid128r (rows requested KR - 1 ahead; build-time for A/B runs)
@@ -303,7 +303,7 @@ k_mid(MidArgs g) {
 // Measured (round 1): middle kernel 16-19 % faster than the m2 = 256 form (the key slice is streamed from L2 half as
 // often); default at N = 2^16 since the radix 16 x 16 tail of the m1 = 256 column passes no longer spills
 // (device_fft.hpp, SPLIT).  POULPY_DBG_SPLIT=t selects the 128 x 256 split (k_mid<2>) instead.  (Two ciphertexts per tile
-// with two workgroups per CU was no faster: DESIGN.md.)
+// with two workgroups per CU was no faster: NOTEBOOK.md 4.)
 // =================================================================================
 // NP = polynomial slots per ciphertext: 16; 8 for shapes with <= 8 polynomials in and out such as rank 1 with 4 limbs (twice the
 // ciphertexts per tile and per key fetch); 32 for rank 2-3 or 16 limbs (two ciphertexts per tile).  The 4 thread groups of the product phase split into GC column groups x GT

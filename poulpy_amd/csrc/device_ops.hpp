@@ -11,7 +11,7 @@ namespace pz {
 //   (reference/fft64/vmp.rs:186-264 computes the same sums 4 points at a time)
 // a, res: VecZnxDft in device order, polynomial r at r*m cplx.
 // P     : device VmpPMat = the rows*cols_in x size*cols_out matrix of spectra,
-//         entry (r, c) at (r*ncols + c)*m cplx  (see DESIGN.md "VmpPMat layout").
+//         entry (r, c) at (r*ncols + c)*m cplx  (DESIGN.md 3).
 // One lane per frequency point; each lane keeps a CT x CC block of accumulators
 // (CT ciphertexts x CC output polynomials) so that every P and a value fetched is
 // used CT resp. CC times.  Waves of a workgroup take different column tiles of the
