@@ -2426,3 +2426,21 @@ def test_glwe_ops_on_pinned_host_containers_duplex(mods, n, size):
         hip.sync()
         for ptr in held:
             hip.lib.pz_free_bytes(C.c_void_p(ptr))
+
+
+@pytest.mark.parametrize("n,rank,blk,dnum,bsz,rsz,k", [
+    (2048, 1, 3, 2, 3, 2, 15),     # small-ring path (chained forward transform, 32-bit digits between blocks)
+    (1024, 2, 3, 2, 3, 3, 14),     # rank 2 at N = 1024: small-ring path with the 9 / 6-row block step
+    (4096, 1, 3, 2, 3, 2, 15),     # pipeline path, plan 16 x 128
+    (8192, 1, 2, 3, 3, 3, 13),     # pipeline path, plan 32 x 128
+])
+@pytest.mark.parametrize("nblocks,extra", [(1, 0), (2, 0), (3, 1), (4, 2)])
+def test_blind_rotation_block_counts_and_accumulator_forms(mods, n, rank, blk, dnum, bsz, rsz, k, nblocks, extra):
+    """Round 5: between two blocks the accumulator lives as 32-bit digits in the workspace - the caller's `res` is the operand of the FIRST block and
+    the destination of the LAST.  One block (no 32-bit form at all), two (first -> last), three and four (middle blocks read and write the digits), with a
+    dropped partial block behind them (chunks_exact, algorithm.rs:303); ragged batch.  Every limb against the oracle."""
+    from tests.test_gpu_parity import _run_blind_rotation
+    ref, hip = mods(n)
+    n_lwe = nblocks * blk + extra
+    got, want = _run_blind_rotation(hip, ref, n, rank, n_lwe, blk, dnum, bsz, rsz, k, batch=5, seed=n + 31 * nblocks + rank)
+    assert np.array_equal(got, want)
