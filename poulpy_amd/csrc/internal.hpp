@@ -101,7 +101,6 @@ int launch_mid_cnv3(pz_module* M, int batch, const cplx* a_main, const cplx* a_l
 struct NzCombine;
 int launch_inv_tail_nz(pz_module* M, int batch, const cplx* T, int nlimbs, long long* res, long long res_bs, int res_cols, int res_size, int res_col,
                        int base2k, long long res_offset, int a_size, const NzCombine* cb);
-int launch_inv_tail_raw(pz_module* M, int batch, const cplx* T, int nlimbs, long long* res, long long res_bs, int res_size);
 
 // ---- launch_mid.hip -----------------------------------------------------------------------------------------------
 // scratch rows behind T2: one 64-row x 128-point tile per persistent workgroup of k_mid128 (<= 256 of them: 32 MiB), which also covers

@@ -141,14 +141,6 @@ int launch_inv_tail_nz(pz_module* M, int batch, const cplx* T, int nlimbs, long 
     return launch_inv_tail_cols(M, c, 0, 1, false, &nz);
 }
 
-// the inverse column pass alone on the row-major T2': rounded i64 values (VecZnxBig), no carry chain (GLWE tensoring: its normalization
-// carries a bit offset and a column combination the tail does not know, api_cnv.hip)
-int launch_inv_tail_raw(pz_module* M, int batch, const cplx* T, int nlimbs, long long* res, long long res_bs, int res_size) {
-    TailCall c;
-    c.batch = batch; c.T = T; c.rowmajor = true; c.nlimbs = nlimbs; c.ncols = 1;
-    c.res = res; c.res_bs = res_bs; c.res_cols = 1; c.res_size = res_size; c.base2k = 12;
-    return launch_inv_tail_cols(M, c, 0, 1, true);
-}
 
 
 }  // namespace pz
