@@ -23,6 +23,9 @@ namespace pz {
 #define PZ_MID_RS 144
 #endif
 constexpr int kMidRS = PZ_MID_RS;
+#ifndef PZ_MID_BR_POST
+#define PZ_MID_BR_POST 1   // blind-rotation block step on k_mid128 (nested form): monomial factor on the coefficient's sum (0: on every input value, rounds 3 - 4)
+#endif
 #ifndef PZ_MID_BR_AVPF
 #define PZ_MID_BR_AVPF 1   // blind-rotation block step on k_mid128: operands of the next row read from LDS one row ahead (0: read at their use)
 #endif
@@ -585,15 +588,20 @@ k_mid128(MidArgs g) {
         _Pragma("unroll") for (int i = 0; i < CTt; ++i) DST[i] = ar_[i * NP * RS];               \
         __builtin_amdgcn_sched_barrier(0);                                                       \
     }
+            // PZ_MID_BR_POST (round 5, nested form): the monomial factor d = DFT(X^a) - 1 multiplies the coefficient's SUM over its key rows (NC
+            // complex FMAs per ciphertext and coefficient) instead of every input value in front of its row's FMAs (br_rm complex products)
+            constexpr bool POSTF = PZ_MID_BR_POST && BRNEST != 0 && NCO == 3;   // (the 4-column forms spill with the extra sums: 96 - 100 B)
+            cplx sacc[POSTF ? CTt : 1][POSTF ? NC : 1];
 #define PZ_BR_FMA(SRC, AV)                                                                       \
     {                                                                                            \
         if (!(dbgv & 1)) _Pragma("unroll") for (int i = 0; i < CTt; ++i) {                       \
-            const cplx av = cmul(AV[i], f[i]);                                                   \
+            const cplx av = POSTF ? AV[i] : cmul(AV[i], f[i]);                                   \
             _Pragma("unroll") for (int j = 0; j < NC; ++j) {                                     \
-                acc[i][j].x = __builtin_fma(av.x, SRC[j].x, acc[i][j].x);                        \
-                acc[i][j].x = __builtin_fma(-av.y, SRC[j].y, acc[i][j].x);                       \
-                acc[i][j].y = __builtin_fma(av.x, SRC[j].y, acc[i][j].y);                        \
-                acc[i][j].y = __builtin_fma(av.y, SRC[j].x, acc[i][j].y);                        \
+                cplx& d_ = POSTF ? sacc[POSTF ? i : 0][POSTF ? j : 0] : acc[i][j];               \
+                d_.x = __builtin_fma(av.x, SRC[j].x, d_.x);                                      \
+                d_.x = __builtin_fma(-av.y, SRC[j].y, d_.x);                                     \
+                d_.y = __builtin_fma(av.x, SRC[j].y, d_.y);                                      \
+                d_.y = __builtin_fma(av.y, SRC[j].x, d_.y);                                      \
             }                                                                                    \
         }                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                       \
@@ -613,10 +621,28 @@ k_mid128(MidArgs g) {
     }
                     for (int ci = 0; ci < g.br_blk; ++ci) {
                         if (ci > 0) {
+                            if constexpr (POSTF) {   // the finished coefficient's sum enters the accumulators with its factor
+#pragma unroll
+                                for (int i = 0; i < CTt; ++i)
+#pragma unroll
+                                    for (int j = 0; j < NC; ++j) {
+                                        const cplx sv = sacc[POSTF ? i : 0][POSTF ? j : 0];
+                                        acc[i][j].x = __builtin_fma(f[i].x, sv.x, acc[i][j].x);
+                                        acc[i][j].x = __builtin_fma(-f[i].y, sv.y, acc[i][j].x);
+                                        acc[i][j].y = __builtin_fma(f[i].x, sv.y, acc[i][j].y);
+                                        acc[i][j].y = __builtin_fma(f[i].y, sv.x, acc[i][j].y);
+                                    }
+                            }
 #pragma unroll
                             for (int i = 0; i < CTt; ++i) { f[i] = fn[i]; f[i].x -= 1.0; fn[i] = fl[i]; }
                             PZ_MID_LOADF(fl, ci + 2)
                             __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if constexpr (POSTF) {
+#pragma unroll
+                            for (int i = 0; i < CTt; ++i)
+#pragma unroll
+                                for (int j = 0; j < NC; ++j) sacc[POSTF ? i : 0][POSTF ? j : 0] = make_double2(0.0, 0.0);
                         }
                         for (int sl = 0; sl < g.br_rm; sl += 2, it += 2, ko += 2 * prow) {
                             // key rows at running offsets (rows come in order here: no wrap arithmetic, no 64-bit multiply per row); the
@@ -628,6 +654,18 @@ k_mid128(MidArgs g) {
                             PZ_BR_AV(avA, (sl + 2 == g.br_rm) ? 0 : sl + 2)
                             PZ_BR_FMA(pb, avB)
                         }
+                    }
+                    if constexpr (POSTF) {   // the last coefficient's sum
+#pragma unroll
+                        for (int i = 0; i < CTt; ++i)
+#pragma unroll
+                            for (int j = 0; j < NC; ++j) {
+                                const cplx sv = sacc[POSTF ? i : 0][POSTF ? j : 0];
+                                acc[i][j].x = __builtin_fma(f[i].x, sv.x, acc[i][j].x);
+                                acc[i][j].x = __builtin_fma(-f[i].y, sv.y, acc[i][j].x);
+                                acc[i][j].y = __builtin_fma(f[i].x, sv.y, acc[i][j].y);
+                                acc[i][j].y = __builtin_fma(f[i].y, sv.x, acc[i][j].y);
+                            }
                     }
                 } else {
                     // an odd number of rows per coefficient: the flat row loop of rounds 1 - 3 (two slots in ping-pong; the request past the
