@@ -37,7 +37,8 @@
  *    independent objects laid out back to back (object b at ptr + b*object_len).
  *    Exception: the four GLWE-level calls pz_glwe_external_product_batched, pz_glwe_keyswitch_batched,
  *    pz_glwe_automorphism_batched and pz_glwe_tensor_relinearize_batched also accept HOST containers for res / a (staged, the
- *    call is then logically synchronous) and a HOST-resident prepared key: poulpy-hal's buffers are host-addressable by contract
+ *    call is then logically synchronous; when both are PINNED and batch >= 2 the first three run upload, kernels and download
+ *    of successive slices on three streams at once) and a HOST-resident prepared key: poulpy-hal's buffers are host-addressable by contract
  *    (Backend::OwnedBuf: DataMut), so this is what the Rust shim's CoreImpl overrides pass.  A host key is mirrored on the
  *    device on first use and re-used afterwards; the mirror is validated on every call by a sampled fingerprint of the host
  *    bytes and dropped by pz_vmp_prepare / pz_vmp_zero on that buffer and by pz_free_bytes of its block.  A caller that modifies a prepared matrix in place by
@@ -645,7 +646,10 @@ int pz_module_set_kernel_timing(pz_module* m, int enable); /* enabling resets th
 int pz_module_get_kernel_stats(pz_module* m, int kclass, uint64_t* launches, double* total_ms);
 const char* pz_kernel_class_name(int kclass);
 
-/* largest |x - round(x)| seen by the last inverse-FFT epilogue when enabled (exactness margin) */
+/* Rounding-margin probe.  While enabled, EVERY kernel that rounds an inverse-FFT value to an integer (the fused tail in all its
+ * forms, the per-op inverse pass, the small-ring inverse, the one-kernel blind rotation) records the largest |x - round(x)| it
+ * saw; pz_module_get_margin returns that maximum since the probe was last enabled.  0.5 is the point where a rounding flips,
+ * the tests assert < 0.05 on every path.  The probed instantiations are separate (slower) kernels: measure with the probe off. */
 int pz_module_set_margin_probe(pz_module* m, int enable);
 int pz_module_get_margin(pz_module* m, double* max_frac);
 
