@@ -16,7 +16,7 @@
 namespace pz {
 
 struct BrFusedPlan {
-    int r0 = 0, ct = 1, pj = 1, mr = 4, cg = 4;
+    int r0 = 0, ct = 1, pj = 1, mr = 4, cg = 4, nt = 512;
     bool a32 = false, std_variant = false;
     size_t lds = 0, pmat_doubles = 0;
 };
@@ -29,6 +29,8 @@ constexpr int kBrNT = 512;
     X(8, 1, 1, 4, 4, false) X(8, 1, 1, 6, 3, false) X(8, 1, 2, 4, 4, false) X(8, 1, 2, 6, 3, false)                          \
     X(8, 2, 1, 4, 4, false) X(8, 2, 1, 6, 3, false) X(8, 2, 2, 4, 4, false) X(8, 2, 2, 6, 3, false)                          \
     X(8, 2, 1, 4, 4, true) X(8, 2, 1, 6, 3, true) X(8, 2, 2, 4, 4, true) X(8, 2, 2, 6, 3, true)
+// (R0, PJ, MR, CG) of the 256-thread forms: one ciphertext per workgroup, two workgroups per CU whose barriers do not line up
+#define PZ_BR_HALF_FORMS(X) X(4, 2, 4, 4) X(4, 2, 6, 3)
 #define PZ_BR_STD_FORMS(X)                                                                                                   \
     X(2, 1, 4, 4) X(2, 1, 6, 3) X(4, 1, 4, 4) X(4, 1, 6, 3) X(8, 1, 4, 4) X(8, 1, 6, 3) X(8, 2, 4, 4) X(8, 2, 6, 3)
 
@@ -36,6 +38,12 @@ inline bool br_form_exists(const BrFusedPlan& pl) {
     if (pl.std_variant) {
 #define X(R0_, PJ_, MR_, CG_) if (pl.r0 == R0_ && pl.ct == 1 && pl.pj == PJ_ && pl.mr == MR_ && pl.cg == CG_ && !pl.a32) return true;
         PZ_BR_STD_FORMS(X)
+#undef X
+        return false;
+    }
+    if (pl.nt == 256) {
+#define X(R0_, PJ_, MR_, CG_) if (pl.r0 == R0_ && pl.ct == 1 && pl.pj == PJ_ && pl.mr == MR_ && pl.cg == CG_ && !pl.a32) return true;
+        PZ_BR_HALF_FORMS(X)
 #undef X
         return false;
     }
@@ -71,7 +79,16 @@ inline bool br_fused_plan(const pz_module* M, const pz_blind_rotation_params* p,
         return false;
     // two ciphertexts per workgroup share every key value; with 64-bit accumulators when that fits in LDS, else with 32-bit digit
     // accumulators (m = 128 is only built with one ciphertext per workgroup)
-    if (B >= 2 && m != 128 && !pl.std_variant) {
+    // Ciphertexts per workgroup against the batch (profiles/r05_ab_br_form.txt, N = 512 / 1024): a workgroup with two ciphertexts shares every key
+    // value but takes 1.3 - 1.6 x as long as one with one, so a batch that gives every ciphertext its own CU runs one per workgroup (batch 64 -
+    // 256: 2.4 instead of 4.0 ms); above that two.  POULPY_DBG_BR_FORM (experiment builds): 1 one ciphertext per workgroup, 2 two, 3 the
+    // 256-thread form below.
+    static const int form = exp_knob("POULPY_DBG_BR_FORM", 0);
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, M->device);
+    if (M->cu_count > 0) ncu = M->cu_count;
+    const bool two = form == 2 || (form == 0 && B > ncu);
+    if (B >= 2 && m != 128 && !pl.std_variant && two) {
         if (fits(2, false)) pl.ct = 2;
         else if (fits(2, true)) { pl.ct = 2; pl.a32 = true; }
     }
@@ -83,6 +100,16 @@ inline bool br_fused_plan(const pz_module* M, const pz_blind_rotation_params* p,
         one.ct = 1; one.a32 = false; one.lds = lds_for(1, false);
         if (pl.ct == 2 && br_form_exists(one)) pl = one;
         else return false;
+    }
+    // m = 256, more than two ciphertexts per CU: one ciphertext per 256-thread workgroup, two workgroups per CU.  The same rate as the
+    // two-ciphertext workgroup when the batch is a multiple of 2 x CUs (129 700 vs 129 600 rotations/s at 1024: neither the barriers shared
+    // by eight waves nor the shared key values are what bounds this kernel), but workgroups of half the size fill a ragged last wave
+    // (768: 6.87 instead of 7.94 ms; 2048: + 2.8 %).
+    if ((form == 3 || (form == 0 && B > 2 * ncu)) && m == 256 && !pl.std_variant) {
+        BrFusedPlan h = pl;
+        h.nt = 256; h.ct = 1; h.a32 = false; h.lds = lds_for(1, false);
+        h.pj = (m * ((ncols + pl.cg - 1) / pl.cg) + 255) / 256;
+        if (P * (m / 8) <= 256 && P * (m / pl.r0) <= 2 * 256 && 2 * h.lds <= 160 * 1024 && br_form_exists(h)) pl = h;
     }
     *out = pl;
     return true;
@@ -103,6 +130,18 @@ static int br_fused_launch(pz_module* M, const BrFusedArgs& g, const BrFusedPlan
         PZ_BR_STD_FORMS(X)
 #undef X
         return fail(PZ_ERR_UNSUPPORTED, "blind_rotation: no one-kernel standard form for this plan");
+    }
+    if (pl.nt == 256) {
+#define X(R0_, PJ_, MR_, CG_)                                                                                                \
+    if (pl.r0 == R0_ && pl.pj == PJ_ && pl.mr == MR_ && pl.cg == CG_) {                                                      \
+        PZ_TRY(set_lds((k_br_fused<R0_, 1, 256, PJ_, MR_, CG_, false, false, PROBE>), pl.lds));                              \
+        hipLaunchKernelGGL((k_br_fused<R0_, 1, 256, PJ_, MR_, CG_, false, false, PROBE>), dim3(B), dim3(256), pl.lds, M->stream, g); \
+        dispatch_note(M, "k_br_fused<R0=%d,CT=1,NT=256,PJ=%d,MR=%d,CG=%d,A32=0> lds=%zu", R0_, PJ_, MR_, CG_, pl.lds);       \
+        return PZ_OK;                                                                                                        \
+    }
+        PZ_BR_HALF_FORMS(X)
+#undef X
+        return fail(PZ_ERR_UNSUPPORTED, "blind_rotation: no 256-thread one-kernel form for this plan");
     }
 #define X(R0_, CT_, PJ_, MR_, CG_, A32_)                                                                                     \
     if (pl.r0 == R0_ && pl.ct == CT_ && pl.pj == PJ_ && pl.mr == MR_ && pl.cg == CG_ && pl.a32 == A32_) {                   \

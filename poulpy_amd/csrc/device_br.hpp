@@ -90,7 +90,7 @@ __device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int mp, int m
 // without the monomial factor, rounding, carry chain WITHOUT adding acc),  acc += (X^a_i - 1) * tmp  on the i64 limbs (a gather in
 // LDS), and one in-place normalization of acc at the very end; needs a second accumulator-sized LDS array for tmp.
 template <int R0, int CT, int NT, int PJ, int MAXR, int CG, bool ACC32, bool STD = false, bool PROBE = false>
-__global__ void __launch_bounds__(NT) k_br_fused(BrFusedArgs g) {
+__global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
     static_assert(!(STD && ACC32), "the standard variant keeps un-normalized sums: 64-bit accumulators");
     typedef typename AccT<ACC32>::type acc_t;
     // radix-8 butterflies a thread may own per pass (CT*P*m/8 <= JM8*NT, host-checked): two only for m = 512 with CT = 2

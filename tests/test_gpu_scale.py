@@ -443,6 +443,31 @@ def test_config4_blind_rotation_pool_parity_at_bench_batch(mods, n, rank, note):
     assert bad == 0, (note, bad)
 
 
+@pytest.mark.parametrize("n,rank,blk,dnum,bsz,rsz,k,note", [
+    (512, 3, 3, 1, 2, 1, 18, "the reference bench's shape: 4 rows, 8 output polynomials"),
+    (512, 1, 3, 3, 3, 3, 13, "6 rows, 6 output polynomials in two groups of 3"),
+    (1024, 1, 7, 3, 3, 3, 13, "N = 1024: 32-bit accumulators when two ciphertexts share a workgroup"),
+    (1024, 1, 2, 2, 2, 2, 17, "N = 1024, 4 rows, 4 output polynomials: 64-bit accumulators for two ciphertexts"),
+    (256, 1, 3, 2, 3, 2, 15, "N = 256: always one ciphertext per workgroup"),
+])
+def test_one_kernel_rotation_forms_by_batch(mods, n, rank, blk, dnum, bsz, rsz, k, note):
+    """Round 5: the one-kernel rotation picks its form from the batch (br_forms.hpp) - one ciphertext per 512-thread workgroup while every
+    ciphertext can have a CU of its own, two above that, and at N = 512 one per 256-thread workgroup above two per CU.  Each regime at a
+    ragged batch, every output against the oracle's pool, the dispatched form read back from the module."""
+    import torch
+    ref, hip = mods(n)
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    regimes = [(ncu // 3 + 2, "CT=1,NT=512"), (ncu + 45, "CT=1,NT=512" if n == 256 else "CT=2,NT=512"),
+               (2 * ncu + 91, "CT=1,NT=256" if n == 512 else ("CT=1,NT=512" if n == 256 else "CT=2,NT=512"))]
+    for batch, form in regimes:
+        hip.dispatch_notes(reset=True)
+        bad = _br_pool_parity(hip, ref, n, rank, n_lwe=2 * blk + 1, block_size=blk, dnum=dnum, brk_size=bsz, res_size=rsz, base2k=k, batch=batch,
+                              pool=7, seed=5200 + n + rank + batch)
+        notes = hip.dispatch_notes()
+        assert bad == 0, (note, batch, bad)
+        assert "k_br_fused" in notes and form in notes, (note, batch, form, notes)
+
+
 # ------------------------------------------------------------------------------------------
 # conversion quirks (SURVEY.md a5): round half away, saturating `as i64`, NaN -> 0, and the >= 2^51 slow path of the tail
 # reference: poulpy-cpu-ref/src/reference/fft64/reim/conversion.rs:43-60
