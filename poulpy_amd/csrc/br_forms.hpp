@@ -30,7 +30,7 @@ constexpr int kBrNT = 512;
     X(8, 2, 1, 4, 4, false) X(8, 2, 1, 6, 3, false) X(8, 2, 2, 4, 4, false) X(8, 2, 2, 6, 3, false)                          \
     X(8, 2, 1, 4, 4, true) X(8, 2, 1, 6, 3, true) X(8, 2, 2, 4, 4, true) X(8, 2, 2, 6, 3, true)
 // (R0, PJ, MR, CG) of the 256-thread forms: one ciphertext per workgroup, two workgroups per CU whose barriers do not line up
-#define PZ_BR_HALF_FORMS(X) X(4, 2, 4, 4) X(4, 2, 6, 3)
+#define PZ_BR_HALF_FORMS(X) X(4, 2, 4, 4, false) X(4, 2, 6, 3, false)
 #define PZ_BR_STD_FORMS(X)                                                                                                   \
     X(2, 1, 4, 4) X(2, 1, 6, 3) X(4, 1, 4, 4) X(4, 1, 6, 3) X(8, 1, 4, 4) X(8, 1, 6, 3) X(8, 2, 4, 4) X(8, 2, 6, 3)
 
@@ -42,7 +42,7 @@ inline bool br_form_exists(const BrFusedPlan& pl) {
         return false;
     }
     if (pl.nt == 256) {
-#define X(R0_, PJ_, MR_, CG_) if (pl.r0 == R0_ && pl.ct == 1 && pl.pj == PJ_ && pl.mr == MR_ && pl.cg == CG_ && !pl.a32) return true;
+#define X(R0_, PJ_, MR_, CG_, A32_) if (pl.r0 == R0_ && pl.ct == 1 && pl.pj == PJ_ && pl.mr == MR_ && pl.cg == CG_ && pl.a32 == A32_) return true;
         PZ_BR_HALF_FORMS(X)
 #undef X
         return false;
@@ -101,11 +101,13 @@ inline bool br_fused_plan(const pz_module* M, const pz_blind_rotation_params* p,
         if (pl.ct == 2 && br_form_exists(one)) pl = one;
         else return false;
     }
-    // m = 256, more than two ciphertexts per CU: one ciphertext per 256-thread workgroup, two workgroups per CU.  The same rate as the
-    // two-ciphertext workgroup when the batch is a multiple of 2 x CUs (129 700 vs 129 600 rotations/s at 1024: neither the barriers shared
-    // by eight waves nor the shared key values are what bounds this kernel), but workgroups of half the size fill a ragged last wave
-    // (768: 6.87 instead of 7.94 ms; 2048: + 2.8 %).
-    if ((form == 3 || (form == 0 && B > 2 * ncu)) && m == 256 && !pl.std_variant) {
+    // m = 256, a batch whose last wave of two-ciphertext workgroups would be at most half full (B mod 2 CUs in 1 .. CUs): one ciphertext per
+    // 256-thread workgroup, two workgroups per CU, fills it (768: 6.87 instead of 7.94 ms).  At a multiple of 2 x CUs this form ran at the SAME
+    // rate as the two-ciphertext workgroup before the latter's per-ciphertext passes were merged (129 700 vs 129 600 rotations/s at 1024: neither
+    // the barriers shared by eight waves nor the shared key values are what bounds this kernel); a third workgroup per CU (32-bit accumulators,
+    // 168 registers with 150 - 250 B of scratch) gave + 2 % at multiples of 3 x CUs and lost elsewhere: not built.
+    const int ragged = B % (2 * ncu);
+    if ((form == 3 || (form == 0 && B > 2 * ncu && ragged >= 1 && ragged <= ncu)) && m == 256 && !pl.std_variant) {
         BrFusedPlan h = pl;
         h.nt = 256; h.ct = 1; h.a32 = false; h.lds = lds_for(1, false);
         h.pj = (m * ((ncols + pl.cg - 1) / pl.cg) + 255) / 256;
@@ -132,11 +134,11 @@ static int br_fused_launch(pz_module* M, const BrFusedArgs& g, const BrFusedPlan
         return fail(PZ_ERR_UNSUPPORTED, "blind_rotation: no one-kernel standard form for this plan");
     }
     if (pl.nt == 256) {
-#define X(R0_, PJ_, MR_, CG_)                                                                                                \
-    if (pl.r0 == R0_ && pl.pj == PJ_ && pl.mr == MR_ && pl.cg == CG_) {                                                      \
-        PZ_TRY(set_lds((k_br_fused<R0_, 1, 256, PJ_, MR_, CG_, false, false, PROBE>), pl.lds));                              \
-        hipLaunchKernelGGL((k_br_fused<R0_, 1, 256, PJ_, MR_, CG_, false, false, PROBE>), dim3(B), dim3(256), pl.lds, M->stream, g); \
-        dispatch_note(M, "k_br_fused<R0=%d,CT=1,NT=256,PJ=%d,MR=%d,CG=%d,A32=0> lds=%zu", R0_, PJ_, MR_, CG_, pl.lds);       \
+#define X(R0_, PJ_, MR_, CG_, A32_)                                                                                          \
+    if (pl.r0 == R0_ && pl.pj == PJ_ && pl.mr == MR_ && pl.cg == CG_ && pl.a32 == A32_) {                                    \
+        PZ_TRY(set_lds((k_br_fused<R0_, 1, 256, PJ_, MR_, CG_, A32_, false, PROBE>), pl.lds));                               \
+        hipLaunchKernelGGL((k_br_fused<R0_, 1, 256, PJ_, MR_, CG_, A32_, false, PROBE>), dim3(B), dim3(256), pl.lds, M->stream, g); \
+        dispatch_note(M, "k_br_fused<R0=%d,CT=1,NT=256,PJ=%d,MR=%d,CG=%d,A32=%d> lds=%zu", R0_, PJ_, MR_, CG_, (int)(A32_), pl.lds); \
         return PZ_OK;                                                                                                        \
     }
         PZ_BR_HALF_FORMS(X)

@@ -42,8 +42,11 @@ __device__ __forceinline__ int br_pad(int i) { return i + (i >> 4); }
 template <int R> struct Log2 { static constexpr int v = 1 + Log2<R / 2>::v; };
 template <> struct Log2<1> { static constexpr int v = 0; };
 
+// Polynomials of the pass: njobs_poly of them, np1 per ciphertext, ciphertext slots P polynomials apart (np1 < P: the transform runs over fewer
+// polynomials than a slot holds - both ciphertexts of a workgroup still share ONE pass and its two barriers; until round 5 they ran one after the
+// other with a quarter of the threads busy at the reference's shape: 4 input rows in slots of 8).
 template <int R, bool INV, int JMAX, int NT>
-__device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int mp, int m, int lm, int p, const cplx* W, int tid) {
+__device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int np1, int P, int mp, int m, int lm, int p, const cplx* W, int tid) {
     // m, p and R are powers of two: positions come from shifts and masks (lm = log2 m), never from integer division
     const int lt = lm - Log2<R>::v;
     const int t = 1 << lt;
@@ -56,7 +59,7 @@ __device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int mp, int m
         if (job < njobs) {
             const int poly = job >> lt, i = job & (t - 1);
             const int k = i & (p - 1);
-            const cplx* src = buf + poly * mp;
+            const cplx* src = buf + (poly < np1 ? poly : poly - np1 + P) * mp;
 #pragma unroll
             for (int r = 0; r < R; ++r) u[jj][r] = src[br_pad(i + r * t)];
             if (p > 1) {
@@ -73,7 +76,7 @@ __device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int mp, int m
         if (job < njobs) {
             const int poly = job >> lt, i = job & (t - 1);
             const int k = i & (p - 1);
-            cplx* dst = buf + poly * mp;
+            cplx* dst = buf + (poly < np1 ? poly : poly - np1 + P) * mp;
             const int j = (i - k) * R + k;
 #pragma unroll
             for (int s = 0; s < R; ++s) dst[br_pad(j + s * p)] = u[jj][s];
@@ -156,21 +159,22 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
             X[(ct * P + r) * mp + br_pad(j)] = cmul(z, tw_j);
         }
         __syncthreads();
-        // forward DFT of the CT*row_max input polynomials (they sit at poly index ct*P + r: run the passes over whole
-        // ciphertext slots when row_max == P, otherwise per ciphertext)
+        // forward DFT of the CT*row_max input polynomials (they sit at poly index ct*P + r)
         if (!(g.dbg_skip & 1))
-        for (int ct = 0; ct < (row_max == P ? 1 : CT); ++ct) {
-            cplx* buf = X + ct * P * mp;
-            const int np = row_max == P ? CT * P : row_max;
-            br_pass<R0, false, 2, NT>(buf, np, mp, m, lm, 1, W, tidv);
-            br_pass<8, false, JM8, NT>(buf, np, mp, m, lm, R0, W, tidv);
-            br_pass<8, false, JM8, NT>(buf, np, mp, m, lm, R0 * 8, W, tidv);
+        {
+            br_pass<R0, false, 2, NT>(X, CT * row_max, row_max, P, mp, m, lm, 1, W, tidv);
+            br_pass<8, false, JM8, NT>(X, CT * row_max, row_max, P, mp, m, lm, R0, W, tidv);
+            br_pass<8, false, JM8, NT>(X, CT * row_max, row_max, P, mp, m, lm, R0 * 8, W, tidv);
         }
         // ---- product, in place: X[ct][c][q] = sum_i (DFT(X^a_i)[q] - 1) * sum_r X[ct][r][q] * BRK_i[r][c][q]   (:321-337)
         if (!(g.dbg_skip & 2)) {
             cplx out[PJ][CT][CG];
+            // EARLY (two jobs per thread, rows <= CG): the second job's column group starts at output polynomial CG >= row_max, which no thread
+            // reads as an input - it runs first and stores at once, so only one job's sums are live across the barrier
+            constexpr bool EARLY = PJ == 2 && MAXR <= CG;
 #pragma unroll
-            for (int pj = 0; pj < PJ; ++pj) {
+            for (int pjr = 0; pjr < PJ; ++pjr) {
+                const int pj = EARLY ? PJ - 1 - pjr : pjr;
                 const int job = tidv + pj * NT;
                 if (job < njobs_prod) {
                     // m is a multiple of 64, so a wave has one column group: keep it (and every key row pointer) in SGPRs,
@@ -250,12 +254,21 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
                         else { PZ_BR_FMAS(true) }
 #undef PZ_BR_FMAS
                     }
+                    if (EARLY && pj == 1) {
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                            for (int j = 0; j < CG; ++j) {
+                                const int c = cg * CG + j;
+                                if (c < ncols) X[(ct * P + c) * mp + br_pad(q)] = out[pj][ct][j];
+                            }
+                    }
                 }
             }
 #undef PZ_BR_A
             __syncthreads();  // every input point has been read: the outputs may overwrite them
 #pragma unroll
-            for (int pj = 0; pj < PJ; ++pj) {
+            for (int pj = 0; pj < (EARLY ? 1 : PJ); ++pj) {
                 const int job = tidv + pj * NT;
                 if (job < njobs_prod) {
                     const int q = job & (m - 1), cg = job >> lm;
@@ -272,12 +285,10 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
         }
         // inverse DFT of the CT*ncols output polynomials
         if (!(g.dbg_skip & 1))
-        for (int ct = 0; ct < (ncols == P ? 1 : CT); ++ct) {
-            cplx* buf = X + ct * P * mp;
-            const int np = ncols == P ? CT * P : ncols;
-            br_pass<R0, true, 2, NT>(buf, np, mp, m, lm, 1, W, tidv);
-            br_pass<8, true, JM8, NT>(buf, np, mp, m, lm, R0, W, tidv);
-            br_pass<8, true, JM8, NT>(buf, np, mp, m, lm, R0 * 8, W, tidv);
+        {
+            br_pass<R0, true, 2, NT>(X, CT * ncols, ncols, P, mp, m, lm, 1, W, tidv);
+            br_pass<8, true, JM8, NT>(X, CT * ncols, ncols, P, mp, m, lm, R0, W, tidv);
+            br_pass<8, true, JM8, NT>(X, CT * ncols, ncols, P, mp, m, lm, R0 * 8, W, tidv);
         }
         // ---- untwist, round(x/m), + acc, carry chain from the last limb to limb 0 (:342-346); thread = (ct, column, j < m):
         //      coefficients j and j+m.  Same digit/carry arithmetic as the fused tail (device_fft.hpp, PZ_TAIL_COEFFS).
@@ -285,6 +296,9 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
         for (int pc = tidv >> lm; pc < CT * cols; pc += NT >> lm) {  // (ciphertext, column) pairs; j = tid mod m is fixed
             const int j = tidv & (m - 1), ct = (CT == 2 && pc >= cols) ? 1 : 0, col = pc - ct * cols;
             const cplx tw = tw_j;
+            // (Round 5: the chain in f64 as in the fused tail - v = r + acc + carry, q = floor((v + 2^(k-1)) 2^-k), digit = v - q 2^k, 13 instructions
+            //  where this integer form spends about 30 - was bit-exact and SLOWER: 137 600 -> 128 600 rotations/s at N = 512, no change at N = 1024.
+            //  Its floor and the conversions are quarter-rate FP64 instructions; the 32-bit integer ones here are full rate.)
             long long cy[2] = {0, 0};
             for (int limb = g.bsz - 1; limb >= 0; --limb) {
                 const cplx v = cmulc(X[(ct * P + limb * cols + col) * mp + br_pad(j)], tw);

@@ -27,7 +27,7 @@ int br_try_fused(pz_module* M, int64_t* res, const int64_t* lwe_2n, const int64_
     g.w2n = M->w2n; g.key_stride = (long long)(pl.pmat_doubles / 2);
     g.n_lwe = (int)p->n_lwe; g.blk = (int)p->block_size; g.cols = (int)p->rank + 1; g.rsz = (int)p->res_size; g.dnum = (int)p->dnum;
     g.bsz = (int)p->brk_size; g.lut_size = (int)p->lut_size; g.base2k = (int)p->base2k; g.m = (int)M->m; g.batch = (int)batch;
-    g.dbg_skip = 0; g.margin = M->probe ? M->margin : nullptr;
+    g.dbg_skip = exp_knob("POULPY_DBG_BR_SKIP", 0); g.margin = M->probe ? M->margin : nullptr;
     KTimer kt(M, PZ_K_FUSED_MID);
     // the rounding-margin instantiation of the same form while the module's probe is on (launch_br_probe.hip)
     PZ_TRY(M->probe ? br_fused_launch_probe(M, g, pl) : br_fused_launch<false>(M, g, pl));
