@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
                         // (both forms only where the tile re-reads its operands from LDS - two ciphertexts, more than 4 rows: there the test-free form
                         //  is worth +15 %; in the register-resident variants the second copy of the block spilled 164 bytes for no gain)
                         if constexpr (ALDS) { if (row_max == MAXR) { PZ_BR_FMAS(false) } else { PZ_BR_FMAS(true) } }
-                        else { PZ_BR_FMAS(true) }
+                        else { PZ_BR_FMAS(false) }   // rows beyond row_max hold zeros (a) and a clamped key row: their FMAs add exact zeros
 #undef PZ_BR_FMAS
                     }
                     if (EARLY && pj == 1) {
