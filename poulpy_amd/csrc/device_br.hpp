@@ -13,6 +13,7 @@
 // work IN PLACE on the one buffer: all threads first read their inputs into registers, a barrier, then they write.
 // Sizes: m = N/2 in {128, 256, 512}; rows of the product <= 8, output polynomials <= 8; LDS <= 160 KiB.
 #pragma once
+#include <type_traits>
 #include "device_fft.hpp"
 
 namespace pz {
@@ -292,49 +293,77 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
         }
         // ---- untwist, round(x/m), + acc, carry chain from the last limb to limb 0 (:342-346); thread = (ct, column, j < m):
         //      coefficients j and j+m.  Same digit/carry arithmetic as the fused tail (device_fft.hpp, PZ_TAIL_COEFFS).
-        if (!(g.dbg_skip & 4))
-        for (int pc = tidv >> lm; pc < CT * cols; pc += NT >> lm) {  // (ciphertext, column) pairs; j = tid mod m is fixed
-            const int j = tidv & (m - 1), ct = (CT == 2 && pc >= cols) ? 1 : 0, col = pc - ct * cols;
+        // The (ciphertext, column) pairs of a thread run their chains side by side, CU at a time (4 when the thread has more than two pairs): a chain
+        // is ~30 dependent integer operations per limb and coefficient, and the two coefficients of one pair alone leave the SIMD waiting on its
+        // own results (N = 512: 147 900 -> 151 500 rotations/s with two, 153 400 with four; four where a thread has only two pairs: - 11 %).
+        auto carry_phase = [&](auto cu_tag) {
+        constexpr int CU = decltype(cu_tag)::value;
+        for (int pc0 = tidv >> lm; pc0 < CT * cols; pc0 += CU * (NT >> lm)) {  // (ciphertext, column) pairs; j = tid mod m is fixed
+            const int j = tidv & (m - 1);
             const cplx tw = tw_j;
+            int ctv[CU], colv[CU];
+            bool on[CU];
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                const int pc = pc0 + u * (NT >> lm);
+                on[u] = pc < CT * cols;
+                const int pcc = on[u] ? pc : pc0;
+                ctv[u] = (CT == 2 && pcc >= cols) ? 1 : 0;
+                colv[u] = pcc - ctv[u] * cols;
+            }
             // (Round 5: the chain in f64 as in the fused tail - v = r + acc + carry, q = floor((v + 2^(k-1)) 2^-k), digit = v - q 2^k, 13 instructions
             //  where this integer form spends about 30 - was bit-exact and SLOWER: 137 600 -> 128 600 rotations/s at N = 512, no change at N = 1024.
             //  Its floor and the conversions are quarter-rate FP64 instructions; the 32-bit integer ones here are full rate.)
-            long long cy[2] = {0, 0};
+            long long cy[CU][2];
+#pragma unroll
+            for (int u = 0; u < CU; ++u) cy[u][0] = cy[u][1] = 0;
             for (int limb = g.bsz - 1; limb >= 0; --limb) {
-                const cplx v = cmulc(X[(ct * P + limb * cols + col) * mp + br_pad(j)], tw);
                 const bool writes = limb < g.rsz;
                 const bool first = limb == g.bsz - 1;
-                acc_t* a = (STD ? tmpd : acc) + ((long long)ct * ct_polys + (long long)limb * cols + col) * n;
+                cplx v[CU];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const double val = (h ? v.y : v.x) * inv_m;
-                    const double rv = round_half_away(val);
-                    if (PROBE) margin_note(g.margin, fabs(val - rv));   // rounding-margin instantiation (br_forms.hpp)
-                    // 3-instruction conversion when exact (|x| < 2^51), the saturating one otherwise (Rust `as i64`)
-                    long long x = fabs(rv) < 2251799813685247.0 ? fast_i64_from_integral(rv) : sat_i64_from_integral(rv);
-                    if (writes && !STD) {
-                        const long long prev = from_lut ? lut_rot(ct, limb, col, j + h * m) : (long long)a[j + h * m];
-                        x = (long long)((unsigned long long)x + (unsigned long long)prev);
-                    }
-                    const unsigned long long y = (unsigned long long)x + half;
-                    const long long d = (long long)(y & dmask) - (long long)half;
-                    const long long cr = (long long)y >> k;
-                    if (first && !writes) {
-                        cy[h] = cr;
-                    } else {
-                        const unsigned long long y2 = (unsigned long long)d + (unsigned long long)cy[h] + half;
-                        const long long x1 = (long long)(y2 & dmask) - (long long)half;
-                        cy[h] = (long long)((unsigned long long)cr + (unsigned long long)((long long)y2 >> k));
-                        if (writes) a[j + h * m] = (acc_t)x1;
+                for (int u = 0; u < CU; ++u) v[u] = cmulc(X[(ctv[u] * P + limb * cols + colv[u]) * mp + br_pad(j)], tw);
+#pragma unroll
+                for (int u = 0; u < CU; ++u) {
+                    const int ct = ctv[u], col = colv[u];
+                    acc_t* a = (STD ? tmpd : acc) + ((long long)ct * ct_polys + (long long)limb * cols + col) * n;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const double val = (h ? v[u].y : v[u].x) * inv_m;
+                        const double rv = round_half_away(val);
+                        if (PROBE) margin_note(g.margin, fabs(val - rv));   // rounding-margin instantiation (br_forms.hpp)
+                        // 3-instruction conversion when exact (|x| < 2^51), the saturating one otherwise (Rust `as i64`)
+                        long long x = fabs(rv) < 2251799813685247.0 ? fast_i64_from_integral(rv) : sat_i64_from_integral(rv);
+                        if (writes && !STD) {
+                            const long long prev = from_lut ? lut_rot(ct, limb, col, j + h * m) : (long long)a[j + h * m];
+                            x = (long long)((unsigned long long)x + (unsigned long long)prev);
+                        }
+                        const unsigned long long y = (unsigned long long)x + half;
+                        const long long d = (long long)(y & dmask) - (long long)half;
+                        const long long cr = (long long)y >> k;
+                        if (first && !writes) {
+                            cy[u][h] = cr;
+                        } else {
+                            const unsigned long long y2 = (unsigned long long)d + (unsigned long long)cy[u][h] + half;
+                            const long long x1 = (long long)(y2 & dmask) - (long long)half;
+                            cy[u][h] = (long long)((unsigned long long)cr + (unsigned long long)((long long)y2 >> k));
+                            if (writes && on[u]) a[j + h * m] = (acc_t)x1;
+                        }
                     }
                 }
             }
             // limbs of acc beyond the precision of the big value are zero (normalize.rs:118-120)
-            for (int limb = g.bsz; limb < g.rsz; ++limb) {
-                acc_t* a = (STD ? tmpd : acc) + ((long long)ct * ct_polys + (long long)limb * cols + col) * n;
-                a[j] = 0;
-                a[j + m] = 0;
-            }
+#pragma unroll
+            for (int u = 0; u < CU; ++u)
+                for (int limb = g.bsz; limb < g.rsz; ++limb) {
+                    acc_t* a = (STD ? tmpd : acc) + ((long long)ctv[u] * ct_polys + (long long)limb * cols + colv[u]) * n;
+                    if (on[u]) { a[j] = 0; a[j + m] = 0; }
+                }
+        }
+        };
+        if (!(g.dbg_skip & 4)) {
+            if (CT * cols > 2 * (NT >> lm)) carry_phase(std::integral_constant<int, 4>());
+            else carry_phase(std::integral_constant<int, 2>());
         }
         __syncthreads();
         if (STD) {
