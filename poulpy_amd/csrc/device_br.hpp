@@ -46,7 +46,15 @@ template <> struct Log2<1> { static constexpr int v = 0; };
 // Polynomials of the pass: njobs_poly of them, np1 per ciphertext, ciphertext slots P polynomials apart (np1 < P: the transform runs over fewer
 // polynomials than a slot holds - both ciphertexts of a workgroup still share ONE pass and its two barriers; until round 5 they ran one after the
 // other with a quarter of the threads busy at the reference's shape: 4 input rows in slots of 8).
-template <int R, bool INV, int JMAX, int NT>
+// WOWN (m >= 256): a wave owns the same polynomials in all three passes of a transform - 64 radix-8 jobs are two polynomials at m = 256, one at
+// m = 512, and the first pass (64 jobs per polynomial for R0 = 4 and 8 alike) takes its jobs in that order too (PAIR: polynomials 2w, 2w + 1) -
+// so inside a transform nothing crosses waves: the LDS serves one wave's reads and writes in issue order, and the passes need no workgroup
+// barrier, only the compiler kept from moving LDS accesses across the pass boundary.  The caller puts one barrier behind the last pass.
+__device__ __forceinline__ void br_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+template <int R, bool INV, int JMAX, int NT, bool WOWN = false, bool PAIR = false>
 __device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int np1, int P, int mp, int m, int lm, int p, const cplx* W, int tid) {
     // m, p and R are powers of two: positions come from shifts and masks (lm = log2 m), never from integer division
     const int lt = lm - Log2<R>::v;
@@ -56,7 +64,7 @@ __device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int np1, int 
     cplx u[JMAX][R];
 #pragma unroll
     for (int jj = 0; jj < JMAX; ++jj) {
-        const int job = tid + jj * NT;
+        const int job = PAIR ? (((tid >> 6) * 2 + jj) << 6) + (tid & 63) : tid + jj * NT;
         if (job < njobs) {
             const int poly = job >> lt, i = job & (t - 1);
             const int k = i & (p - 1);
@@ -70,10 +78,10 @@ __device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int np1, int 
             Bfly<R, INV>::run(u[jj]);
         }
     }
-    __syncthreads();
+    if (WOWN) br_wave_sync(); else __syncthreads();
 #pragma unroll
     for (int jj = 0; jj < JMAX; ++jj) {
-        const int job = tid + jj * NT;
+        const int job = PAIR ? (((tid >> 6) * 2 + jj) << 6) + (tid & 63) : tid + jj * NT;
         if (job < njobs) {
             const int poly = job >> lt, i = job & (t - 1);
             const int k = i & (p - 1);
@@ -83,7 +91,7 @@ __device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int np1, int 
             for (int s = 0; s < R; ++s) dst[br_pad(j + s * p)] = u[jj][s];
         }
     }
-    __syncthreads();
+    if (WOWN) br_wave_sync(); else __syncthreads();
 }
 
 // CT ciphertexts per workgroup, NT threads, output polynomials in groups of CG, PJ product jobs per thread
@@ -99,6 +107,7 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
     typedef typename AccT<ACC32>::type acc_t;
     // radix-8 butterflies a thread may own per pass (CT*P*m/8 <= JM8*NT, host-checked): two only for m = 512 with CT = 2
     constexpr int JM8 = (CT == 2 && R0 == 8) ? 2 : 1;
+    constexpr bool WOWN = R0 != 2;   // br_pass: waves own their polynomials through a transform (m = 128: four polynomials per radix-8 wave, two per first-pass wave)
     extern __shared__ cplx lds_br[];
     const int tid = threadIdx.x;
     const int m = g.m, n = 2 * m, cols = g.cols;
@@ -163,9 +172,10 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
         // forward DFT of the CT*row_max input polynomials (they sit at poly index ct*P + r)
         if (!(g.dbg_skip & 1))
         {
-            br_pass<R0, false, 2, NT>(X, CT * row_max, row_max, P, mp, m, lm, 1, W, tidv);
-            br_pass<8, false, JM8, NT>(X, CT * row_max, row_max, P, mp, m, lm, R0, W, tidv);
-            br_pass<8, false, JM8, NT>(X, CT * row_max, row_max, P, mp, m, lm, R0 * 8, W, tidv);
+            br_pass<R0, false, 2, NT, WOWN, WOWN && R0 == 4>(X, CT * row_max, row_max, P, mp, m, lm, 1, W, tidv);
+            br_pass<8, false, JM8, NT, WOWN>(X, CT * row_max, row_max, P, mp, m, lm, R0, W, tidv);
+            br_pass<8, false, JM8, NT, WOWN>(X, CT * row_max, row_max, P, mp, m, lm, R0 * 8, W, tidv);
+            if (WOWN) __syncthreads();
         }
         // ---- product, in place: X[ct][c][q] = sum_i (DFT(X^a_i)[q] - 1) * sum_r X[ct][r][q] * BRK_i[r][c][q]   (:321-337)
         if (!(g.dbg_skip & 2)) {
@@ -287,9 +297,10 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
         // inverse DFT of the CT*ncols output polynomials
         if (!(g.dbg_skip & 1))
         {
-            br_pass<R0, true, 2, NT>(X, CT * ncols, ncols, P, mp, m, lm, 1, W, tidv);
-            br_pass<8, true, JM8, NT>(X, CT * ncols, ncols, P, mp, m, lm, R0, W, tidv);
-            br_pass<8, true, JM8, NT>(X, CT * ncols, ncols, P, mp, m, lm, R0 * 8, W, tidv);
+            br_pass<R0, true, 2, NT, WOWN, WOWN && R0 == 4>(X, CT * ncols, ncols, P, mp, m, lm, 1, W, tidv);
+            br_pass<8, true, JM8, NT, WOWN>(X, CT * ncols, ncols, P, mp, m, lm, R0, W, tidv);
+            br_pass<8, true, JM8, NT, WOWN>(X, CT * ncols, ncols, P, mp, m, lm, R0 * 8, W, tidv);
+            if (WOWN) __syncthreads();
         }
         // ---- untwist, round(x/m), + acc, carry chain from the last limb to limb 0 (:342-346); thread = (ct, column, j < m):
         //      coefficients j and j+m.  Same digit/carry arithmetic as the fused tail (device_fft.hpp, PZ_TAIL_COEFFS).
