@@ -74,7 +74,7 @@ inline bool br_fused_plan(const pz_module* M, const pz_blind_rotation_params* p,
     };
     pl.cg = (ncols % 3 == 0 && ncols % 4 != 0) ? 3 : 4;  // 6 output polynomials: two groups of 3, no idle slot
     pl.pj = m * ((ncols + pl.cg - 1) / pl.cg) <= NT ? 1 : 2;
-    if (!(M->fuse_mid && (m == 128 || m == 256 || m == 512) && NT % m == 0 && row_max <= 8 && ncols <= 8 &&
+    if (!(M->fuse_mid && (m == 128 || m == 256 || m == 512) && NT % m == 0 && row_max <= 8 && ncols <= 8 && blk <= 64 &&   // (blk: one lane per rotation amount)
           m * ((ncols + pl.cg - 1) / pl.cg) <= 2 * NT && fits(1, false)))
         return false;
     // two ciphertexts per workgroup share every key value; with 64-bit accumulators when that fits in LDS, else with 32-bit digit

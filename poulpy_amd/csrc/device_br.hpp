@@ -151,6 +151,32 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
     const int ncg = (ncols + CG - 1) / CG;    // output polynomials are handled CG at a time
     const int njobs_prod = m * ncg;           // product jobs (q, column group); a job covers the CT ciphertexts
 
+    // Monomial factors.  DFT(X^a_i)[q] needs a_i (one word of the LWE sample) and then an entry of the root table at a_i (4q + 1): two dependent
+    // requests, which until round 5 were made per coefficient inside the product loop - two memory latencies in front of every coefficient's last
+    // FMAs.  Now: lane l of a wave holds a_(blk0 + l) of the block (blk <= 64, host-checked), requested one block ahead; the factor of coefficient
+    // i + 1 is requested while coefficient i is multiplied, that of a block's first coefficient at the end of the previous block's product phase.
+    const int lane = tid & 63;
+    const unsigned qf = 4u * (unsigned)(tid & (m - 1)) + 1u;   // (NT is a multiple of m: a thread's product jobs share q)
+    auto load_amounts = [&](unsigned (&dst)[CT], int first) {
+        const int i = min(first + min(lane, g.blk - 1), g.n_lwe - 1);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int b = min(b0 + ct, g.batch - 1);
+            dst[ct] = (unsigned)((unsigned long long)g.lwe[(long long)b * (g.n_lwe + 1) + 1 + i] & (unsigned long long)mask2);
+        }
+    };
+    auto load_factors = [&](cplx (&dst)[CT], const unsigned (&amounts)[CT], int l) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) dst[ct] = g.w2n[((unsigned)__builtin_amdgcn_readlane((int)amounts[ct], l) * qf) & mask2];
+    };
+    unsigned aiv[CT], aivn[CT];
+    cplx xmn[CT];   // factors of the coming block's first coefficient
+    load_amounts(aiv, 0);
+    if (!STD) load_factors(xmn, aiv, 0);
+    // (Measured and dropped: the key values of a block's first coefficient requested at the end of the previous block's product phase, so that they
+    //  arrive during the transforms and the carry chains - 64 registers live across every phase, affordable only with the thread-index arithmetic
+    //  recomputed per phase: N = 512 154 600 -> 148 800 - 153 600 rotations/s.)
+
     for (int blk0 = 0; blk0 + g.blk <= g.n_lwe; blk0 += g.blk) {
         // Everything the phases derive from the thread index (butterfly positions, LDS offsets, key offsets) is loop-invariant;
         // hoisted out of this loop it would stay live across all phases and spill.  An opaque copy of the index per
@@ -179,6 +205,7 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
         }
         // ---- product, in place: X[ct][c][q] = sum_i (DFT(X^a_i)[q] - 1) * sum_r X[ct][r][q] * BRK_i[r][c][q]   (:321-337)
         if (!(g.dbg_skip & 2)) {
+            load_amounts(aivn, blk0 + g.blk);   // the next block's rotation amounts
             cplx out[PJ][CT][CG];
             // EARLY (two jobs per thread, rows <= CG): the second job's column group starts at output polynomial CG >= row_max, which no thread
             // reads as an input - it runs first and stores at once, so only one job's sums are live across the barrier
@@ -215,6 +242,9 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
                     // scheme that pays in k_mid128r - was bit-exact and SLOWER here, 129 500 -> 122 800 rotations/s at N = 512 and
                     // 109 900 -> 107 500 at N = 1024 (52-76 bytes of scratch; profiles/r03_ab_br_pipe.txt): the latency of the
                     // coefficient's requests is already covered by the other waves)
+                    cplx xn[CT];
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) xn[ct] = xmn[ct];
                     for (int i = blk0; i < blk0 + g.blk; ++i) {
                         const cplx* K = g.brk + (long long)i * g.key_stride;
                         cplx kv[CG][MAXR];
@@ -222,16 +252,20 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
                         for (int j = 0; j < CG; ++j) {
                             const int c = min(cg * CG + j, ncols - 1);
 #pragma unroll
-                            for (int r = 0; r < MAXR; ++r) kv[j][r] = (K + (long long)(min(r, row_max - 1) * ncols + c) * m)[q];
+                            for (int r = 0; r < MAXR; ++r)
+                                kv[j][r] = (PZ_DBG(g.dbg_skip) & 16) ? make_double2(1.0, (double)(q + r)) : (K + (long long)(min(r, row_max - 1) * ncols + c) * m)[q];
                         }
                         cplx xm[CT];
+                        if (!STD) {
 #pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) {
-                            const int b = min(b0 + ct, g.batch - 1);
-                            const unsigned ai = (unsigned)((unsigned long long)g.lwe[(long long)b * (g.n_lwe + 1) + 1 + i] & (unsigned long long)mask2);
-                            xm[ct] = g.w2n[(ai * (4u * (unsigned)q + 1u)) & mask2];
-                            if (!STD) xm[ct].x -= 1.0;   // d = DFT(X^a_i)[q] - 1: the factor enters as four FMAs (round 5)
+                            for (int ct = 0; ct < CT; ++ct) {
+                                xm[ct] = xn[ct];
+                                xm[ct].x -= 1.0;   // d = DFT(X^a_i)[q] - 1: the factor enters as four FMAs (round 5)
+                            }
+                            load_factors(xn, aiv, min(i + 1 - blk0, g.blk - 1));   // the next coefficient's (the last request of a block is unused)
                         }
+                        // (Round 5, measured and dropped: the sums of 2 columns x 2 ciphertexts side by side - 8 FMA chains interleaved instead of the 2 the
+                        //  compiler leaves from this order: no gain on any form, - 1 % at N = 1024; the other wave of the SIMD already fills the gaps.)
                         // GUARD_: row_max < MAXR (the template's row count is the next of 4 / 6 / 8).  With row_max == MAXR - the usual shapes -
                         // the per-row test is dropped: as a run-time test inside the unrolled row loop it costs a branch per (column, ciphertext,
                         // row), 64 branches and 167 scalar instructions per coefficient beside 188 floating-point ones (round 3 ISA)
@@ -277,6 +311,9 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
                 }
             }
 #undef PZ_BR_A
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) aiv[ct] = aivn[ct];
+            if (!STD) load_factors(xmn, aiv, 0);
             __syncthreads();  // every input point has been read: the outputs may overwrite them
 #pragma unroll
             for (int pj = 0; pj < (EARLY ? 1 : PJ); ++pj) {
