@@ -27,8 +27,8 @@ constexpr int kBrNT = 512;
     X(2, 1, 1, 4, 4, false) X(2, 1, 1, 6, 3, false)                                                                          \
     X(4, 1, 1, 4, 4, false) X(4, 1, 1, 6, 3, false) X(4, 2, 1, 4, 4, false) X(4, 2, 1, 6, 3, false) X(4, 2, 1, 4, 4, true) X(4, 2, 1, 6, 3, true) \
     X(8, 1, 1, 4, 4, false) X(8, 1, 1, 6, 3, false) X(8, 1, 2, 4, 4, false) X(8, 1, 2, 6, 3, false)                          \
-    X(8, 2, 1, 4, 4, false) X(8, 2, 1, 6, 3, false) X(8, 2, 2, 4, 4, false) X(8, 2, 2, 6, 3, false)                          \
-    X(8, 2, 1, 4, 4, true) X(8, 2, 1, 6, 3, true) X(8, 2, 2, 4, 4, true) X(8, 2, 2, 6, 3, true)
+    X(8, 2, 1, 4, 4, false) X(8, 2, 1, 6, 3, false) X(8, 2, 2, 6, 3, false)                                                  \
+    X(8, 2, 1, 4, 4, true) X(8, 2, 1, 6, 3, true) X(8, 2, 2, 6, 3, true)   /* (8, 2, 2, 4, 4, *): 16 work polynomials of 512 points never fit */
 // (R0, PJ, MR, CG) of the 256-thread forms: one ciphertext per workgroup, two workgroups per CU whose barriers do not line up
 #define PZ_BR_HALF_FORMS(X) X(4, 2, 4, 4, false) X(4, 2, 6, 3, false)
 #define PZ_BR_STD_FORMS(X)                                                                                                   \

@@ -468,6 +468,30 @@ def test_one_kernel_rotation_forms_by_batch(mods, n, rank, blk, dnum, bsz, rsz, 
         assert "k_br_fused" in notes and form in notes, (note, batch, form, notes)
 
 
+@pytest.mark.parametrize("n,rank,blk,dnum,bsz,rsz,k,form", [
+    (512, 3, 3, 1, 2, 3, 18, "R0=4,CT=2,NT=512,PJ=1,MR=4,CG=4,A32=1"),     # 12 accumulator polynomials per ciphertext: 32-bit digits in LDS
+    (512, 1, 3, 3, 3, 7, 13, "R0=4,CT=2,NT=512,PJ=1,MR=6,CG=3,A32=1"),     # 6 rows, 7 result limbs
+    (1024, 1, 2, 3, 3, 1, 13, "R0=8,CT=2,NT=512,PJ=2,MR=6,CG=3,A32=0"),    # one result limb: 64-bit accumulators fit beside 12 work polynomials
+    (1024, 1, 2, 2, 2, 4, 14, "R0=8,CT=2,NT=512,PJ=1,MR=4,CG=4,A32=1"),    # 4 result limbs
+    (1024, 2, 2, 2, 1, 1, 14, "R0=8,CT=2,NT=512,PJ=1,MR=6,CG=3,A32=0"),    # rank 2 with a one-limb key: 3 output polynomials, one column group
+    (1024, 2, 2, 1, 1, 4, 14, "R0=8,CT=2,NT=512,PJ=1,MR=6,CG=3,A32=1"),
+])
+def test_one_kernel_rotation_two_ciphertext_forms(mods, n, rank, blk, dnum, bsz, rsz, k, form):
+    """The two-ciphertext forms of the one-kernel rotation that only shapes with many accumulator limbs (32-bit digits in LDS) or a single one reach -
+    since round 5 a batch above one ciphertext per CU is what selects them, so the small-batch shape tests no longer do.  Ragged batch, every output
+    against the oracle's pool; the same shape at a small batch runs the one-ciphertext form."""
+    import torch
+    ref, hip = mods(n)
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    for batch, want in ((ncu + 45, form), (7, form.replace("CT=2", "CT=1").replace("A32=1", "A32=0"))):
+        hip.dispatch_notes(reset=True)
+        bad = _br_pool_parity(hip, ref, n, rank, n_lwe=2 * blk + 1, block_size=blk, dnum=dnum, brk_size=bsz, res_size=rsz, base2k=k, batch=batch,
+                              pool=5, seed=5300 + n + rank + rsz + batch)
+        notes = hip.dispatch_notes()
+        assert bad == 0, (form, batch, bad)
+        assert want in notes, (batch, want, notes)
+
+
 # ------------------------------------------------------------------------------------------
 # conversion quirks (SURVEY.md a5): round half away, saturating `as i64`, NaN -> 0, and the >= 2^51 slow path of the tail
 # reference: poulpy-cpu-ref/src/reference/fft64/reim/conversion.rs:43-60
