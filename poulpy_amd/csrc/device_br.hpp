@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
     // Monomial factors.  DFT(X^a_i)[q] needs a_i (one word of the LWE sample) and then an entry of the root table at a_i (4q + 1): two dependent
     // requests, which until round 5 were made per coefficient inside the product loop - two memory latencies in front of every coefficient's last
     // FMAs.  Now: lane l of a wave holds a_(blk0 + l) of the block (blk <= 64, host-checked), requested one block ahead; the factor of coefficient
-    // i + 1 is requested while coefficient i is multiplied, that of a block's first coefficient at the end of the previous block's product phase.
+    // i + 1 is requested while coefficient i is multiplied (a block's first one together with its key values: it is used behind their FMAs).
     const int lane = tid & 63;
     const unsigned qf = 4u * (unsigned)(tid & (m - 1)) + 1u;   // (NT is a multiple of m: a thread's product jobs share q)
     auto load_amounts = [&](unsigned (&dst)[CT], int first) {
@@ -176,10 +176,16 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) dst[ct] = g.w2n[((unsigned)__builtin_amdgcn_readlane((int)amounts[ct], l) * qf) & mask2];
     };
+    // XPRE (m = 512): the factors of a block's first coefficient are requested at the end of the previous block's product phase (N = 1024: + 2.4 %; at
+    // m = 256 their eight registers, live across every phase, cost more than the request in flight with the first key values: - 2.5 %)
+    constexpr bool XPRE = R0 == 8;
     unsigned aiv[CT], aivn[CT];
-    cplx xmn[CT];   // factors of the coming block's first coefficient
+    cplx xmn[XPRE ? CT : 1];
     load_amounts(aiv, 0);
-    if (!STD) load_factors(xmn, aiv, 0);
+    if (XPRE && !STD) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) xmn[XPRE ? ct : 0] = g.w2n[((unsigned)__builtin_amdgcn_readlane((int)aiv[ct], 0) * qf) & mask2];
+    }
     // (Measured and dropped: the key values of a block's first coefficient requested at the end of the previous block's product phase, so that they
     //  arrive during the transforms and the carry chains - 64 registers live across every phase, affordable only with the thread-index arithmetic
     //  recomputed per phase: N = 512 154 600 -> 148 800 - 153 600 rotations/s.)
@@ -254,8 +260,14 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
                     // 109 900 -> 107 500 at N = 1024 (52-76 bytes of scratch; profiles/r03_ab_br_pipe.txt): the latency of the
                     // coefficient's requests is already covered by the other waves)
                     cplx xn[CT];
+                    if (!STD) {
+                        if constexpr (XPRE) {
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) xn[ct] = xmn[ct];
+                            for (int ct = 0; ct < CT; ++ct) xn[ct] = xmn[XPRE ? ct : 0];
+                        } else {
+                            load_factors(xn, aiv, 0);   // (in flight with the first coefficient's key values; used behind its FMAs)
+                        }
+                    }
                     for (int i = blk0; i < blk0 + g.blk; ++i) {
                         const cplx* K = g.brk + (long long)i * g.key_stride;
                         cplx kv[CG][MAXR];
@@ -306,7 +318,40 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
     }
                         // (both forms only where the tile re-reads its operands from LDS - two ciphertexts, more than 4 rows: there the test-free form
                         //  is worth +15 %; in the register-resident variants the second copy of the block spilled 164 bytes for no gain)
-                        if constexpr (ALDS) { if (row_max == MAXR) { PZ_BR_FMAS(false) } else { PZ_BR_FMAS(true) } }
+                        // ALDS, every row in use (the usual shapes): the operands of row r + 1 are read from LDS in front of row r's FMAs.  Written as in
+                        // PZ_BR_FMAS the compiler put each read directly in front of its four FMAs behind lgkmcnt(0) - 30 of a coefficient's 36 LDS reads
+                        // fully exposed (round 5 ISA).  Same chains, same order inside each chain.
+#define PZ_BR_FMAS_LDS                                                                                            \
+    {                                                                                                            \
+        cplx cur[CT], nxt[CT];                                                                                   \
+        _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) cur[ct] = PZ_BR_A(ct, 0);                              \
+        _Pragma("unroll") for (int j = 0; j < CG; ++j) {                                                         \
+            cplx s[CT];                                                                                          \
+            _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) s[ct] = make_double2(0.0, 0.0);                    \
+            _Pragma("unroll") for (int r = 0; r < MAXR; ++r) {                                                   \
+                if (!(j == CG - 1 && r == MAXR - 1)) {                                                           \
+                    _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) nxt[ct] = PZ_BR_A(ct, (r + 1) % MAXR);     \
+                }                                                                                                \
+                _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) {                                              \
+                    s[ct].x = __builtin_fma(cur[ct].x, kv[j][r].x, s[ct].x);                                     \
+                    s[ct].x = __builtin_fma(-cur[ct].y, kv[j][r].y, s[ct].x);                                    \
+                    s[ct].y = __builtin_fma(cur[ct].x, kv[j][r].y, s[ct].y);                                     \
+                    s[ct].y = __builtin_fma(cur[ct].y, kv[j][r].x, s[ct].y);                                     \
+                }                                                                                                \
+                _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) cur[ct] = nxt[ct];                             \
+            }                                                                                                    \
+            _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) {                                                  \
+                out[pj][ct][j].x = __builtin_fma(xm[ct].x, s[ct].x, out[pj][ct][j].x);                           \
+                out[pj][ct][j].x = __builtin_fma(-xm[ct].y, s[ct].y, out[pj][ct][j].x);                          \
+                out[pj][ct][j].y = __builtin_fma(xm[ct].x, s[ct].y, out[pj][ct][j].y);                           \
+                out[pj][ct][j].y = __builtin_fma(xm[ct].y, s[ct].x, out[pj][ct][j].y);                           \
+            }                                                                                                    \
+        }                                                                                                        \
+    }
+                        // (m = 256: the compiler keeps the re-read operands of the pipelined form in registers and spills 100 - 170 B)
+                        if constexpr (ALDS && R0 == 8) { if (row_max == MAXR) { PZ_BR_FMAS_LDS } else { PZ_BR_FMAS(true) } }
+                        else if constexpr (ALDS) { if (row_max == MAXR) { PZ_BR_FMAS(false) } else { PZ_BR_FMAS(true) } }
+#undef PZ_BR_FMAS_LDS
                         else { PZ_BR_FMAS(false) }   // rows beyond row_max hold zeros (a) and a clamped key row: their FMAs add exact zeros
 #undef PZ_BR_FMAS
                     }
@@ -324,7 +369,10 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
 #undef PZ_BR_A
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) aiv[ct] = aivn[ct];
-            if (!STD) load_factors(xmn, aiv, 0);
+            if (XPRE && !STD) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) xmn[XPRE ? ct : 0] = g.w2n[((unsigned)__builtin_amdgcn_readlane((int)aiv[ct], 0) * qf) & mask2];
+            }
             __syncthreads();  // every input point has been read: the outputs may overwrite them
 #pragma unroll
             for (int pj = 0; pj < (EARLY ? 1 : PJ); ++pj) {
