@@ -78,8 +78,12 @@ __device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int np1, int 
 #pragma unroll
             for (int r = 0; r < R; ++r) u[jj][r] = src[br_pad(i + r * t)];
             if (p > 1) {
+                // (all R - 1 twiddle reads in front of the products: written read-and-multiply per r, each read sat behind lgkmcnt(0) - round 5 ISA)
+                cplx twd[R];
 #pragma unroll
-                for (int r = 1; r < R; ++r) u[jj][r] = cmul_t<INV>(u[jj][r], W[(r * k) * wstep]);
+                for (int r = 1; r < R; ++r) twd[r] = W[(r * k) * wstep];
+#pragma unroll
+                for (int r = 1; r < R; ++r) u[jj][r] = cmul_t<INV>(u[jj][r], twd[r]);
             }
             Bfly<R, INV>::run(u[jj]);
         }
@@ -376,7 +380,11 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
             __syncthreads();  // every input point has been read: the outputs may overwrite them
 #pragma unroll
             for (int pj = 0; pj < (EARLY ? 1 : PJ); ++pj) {
-                const int job = tidv + pj * NT;
+                // (an opaque copy of the index: the store offsets below, hoisted out of the block loop, were what the register-bound forms spilled -
+                //  reloaded here one by one, each behind vmcnt(0); round 5 ISA)
+                int tst = tidv;
+                if (!(CT == 2 && R0 == 8)) asm volatile("" : "+v"(tst));   // (there tidv is opaque already)
+                const int job = tst + pj * NT;
                 if (job < njobs_prod) {
                     const int q = job & (m - 1), cg = job >> lm;
 #pragma unroll
