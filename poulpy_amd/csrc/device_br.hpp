@@ -436,38 +436,90 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
             long long cy[CU][2];
 #pragma unroll
             for (int u = 0; u < CU; ++u) cy[u][0] = cy[u][1] = 0;
+            // Per limb, in stages over all 2 CU coefficients of the thread: the LDS reads (values, accumulator digits) together, the conversions
+            // behind ONE test (every value below 2^51: the three-instruction form), the chain steps as straight-line code behind the limb's uniform
+            // tests.  (Until round 5 each coefficient walked through its own tests: ~10 scalar / exec branches per coefficient, every LDS read
+            // directly in front of its use behind lgkmcnt(0).)
             for (int limb = g.bsz - 1; limb >= 0; --limb) {
                 const bool writes = limb < g.rsz;
                 const bool first = limb == g.bsz - 1;
                 cplx v[CU];
 #pragma unroll
-                for (int u = 0; u < CU; ++u) v[u] = cmulc(X[(ctv[u] * P + limb * cols + colv[u]) * mp + br_pad(j)], tw);
+                for (int u = 0; u < CU; ++u) v[u] = X[(ctv[u] * P + limb * cols + colv[u]) * mp + br_pad(j)];
+                acc_t* ap[CU];
+#pragma unroll
+                for (int u = 0; u < CU; ++u) ap[u] = (STD ? tmpd : acc) + ((long long)ctv[u] * ct_polys + (long long)limb * cols + colv[u]) * n + j;
+                long long prev[CU][2];
+                if (writes && !STD) {
+                    if (from_lut) {
+#pragma unroll
+                        for (int u = 0; u < CU; ++u)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) prev[u][h] = lut_rot(ctv[u], limb, colv[u], j + h * m);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < CU; ++u)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) prev[u][h] = (long long)ap[u][h * m];
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < CU; ++u) prev[u][0] = prev[u][1] = 0;
+                }
+                double rv[CU][2];
+                double big = 0.0;
 #pragma unroll
                 for (int u = 0; u < CU; ++u) {
-                    const int ct = ctv[u], col = colv[u];
-                    acc_t* a = (STD ? tmpd : acc) + ((long long)ct * ct_polys + (long long)limb * cols + col) * n;
+                    const cplx w = cmulc(v[u], tw);
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const double val = (h ? v[u].y : v[u].x) * inv_m;
-                        const double rv = round_half_away(val);
-                        if (PROBE) margin_note(g.margin, fabs(val - rv));   // rounding-margin instantiation (br_forms.hpp)
-                        // 3-instruction conversion when exact (|x| < 2^51), the saturating one otherwise (Rust `as i64`)
-                        long long x = fabs(rv) < 2251799813685247.0 ? fast_i64_from_integral(rv) : sat_i64_from_integral(rv);
-                        if (writes && !STD) {
-                            const long long prev = from_lut ? lut_rot(ct, limb, col, j + h * m) : (long long)a[j + h * m];
-                            x = (long long)((unsigned long long)x + (unsigned long long)prev);
+                        const double val = (h ? w.y : w.x) * inv_m;
+                        rv[u][h] = round_half_away(val);
+                        if (PROBE) margin_note(g.margin, fabs(val - rv[u][h]));   // rounding-margin instantiation (br_forms.hpp)
+                        big = fmax(big, fabs(rv[u][h]));   // (fmax drops a NaN: the test below sends it to the saturating form, which maps it to 0)
+                        if (rv[u][h] != rv[u][h]) big = 1.0e300;
+                    }
+                }
+                long long x[CU][2];
+                // 3-instruction conversion when exact (|x| < 2^51), the saturating one otherwise (Rust `as i64`)
+                if (big < 2251799813685247.0) {
+#pragma unroll
+                    for (int u = 0; u < CU; ++u)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) x[u][h] = fast_i64_from_integral(rv[u][h]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < CU; ++u)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            x[u][h] = fabs(rv[u][h]) < 2251799813685247.0 ? fast_i64_from_integral(rv[u][h]) : sat_i64_from_integral(rv[u][h]);
+                }
+                long long dg[CU][2], cr[CU][2];
+#pragma unroll
+                for (int u = 0; u < CU; ++u)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const unsigned long long y = (unsigned long long)x[u][h] + (unsigned long long)prev[u][h] + half;
+                        dg[u][h] = (long long)(y & dmask) - (long long)half;
+                        cr[u][h] = (long long)y >> k;
+                    }
+                if (first && !writes) {
+#pragma unroll
+                    for (int u = 0; u < CU; ++u) { cy[u][0] = cr[u][0]; cy[u][1] = cr[u][1]; }
+                } else {
+                    long long x1[CU][2];
+#pragma unroll
+                    for (int u = 0; u < CU; ++u)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const unsigned long long y2 = (unsigned long long)dg[u][h] + (unsigned long long)cy[u][h] + half;
+                            x1[u][h] = (long long)(y2 & dmask) - (long long)half;
+                            cy[u][h] = (long long)((unsigned long long)cr[u][h] + (unsigned long long)((long long)y2 >> k));
                         }
-                        const unsigned long long y = (unsigned long long)x + half;
-                        const long long d = (long long)(y & dmask) - (long long)half;
-                        const long long cr = (long long)y >> k;
-                        if (first && !writes) {
-                            cy[u][h] = cr;
-                        } else {
-                            const unsigned long long y2 = (unsigned long long)d + (unsigned long long)cy[u][h] + half;
-                            const long long x1 = (long long)(y2 & dmask) - (long long)half;
-                            cy[u][h] = (long long)((unsigned long long)cr + (unsigned long long)((long long)y2 >> k));
-                            if (writes && on[u]) a[j + h * m] = (acc_t)x1;
-                        }
+                    if (writes) {
+#pragma unroll
+                        for (int u = 0; u < CU; ++u)
+                            if (on[u]) { ap[u][0] = (acc_t)x1[u][0]; ap[u][m] = (acc_t)x1[u][1]; }
                     }
                 }
             }
