@@ -16,11 +16,8 @@
 #include <type_traits>
 #include "device_fft.hpp"
 
-// PZ_BR_R16 = 1: m = 256 as two radix-16 passes (a wave owns four polynomials) instead of 4 x 8 x 8.  A third fewer LDS stores, 40 % fewer LDS reads,
-// half as many busy waves: 154 100 -> 155 000 rotations/s at 1024 per call, 107 100 -> 103 600 at 256 (round 5); off.
-#ifndef PZ_BR_R16
-#define PZ_BR_R16 0
-#endif
+// (Round 5, measured and removed: m = 256 as two radix-16 passes, a wave owning four polynomials - a third fewer LDS stores, 40 % fewer LDS reads, half as many
+//  busy waves: 154 100 -> 155 000 rotations/s at 1024 per call, 107 100 -> 103 600 at 256.)
 
 namespace pz {
 
@@ -45,6 +42,8 @@ __device__ __forceinline__ int br_pad(int i) { return i + (i >> 4); }
 
 // Stockham autosort pass, in place (natural order in and out): sub-transforms of length p are done, this pass makes p*R.
 //   u[r] = buf[i + r*m/R] * w^(+-k r), w = exp(2 pi i/(pR)), k = i mod p;  DFT_R;  buf[(i-k)*R + k + s*p] = u[s]
+// The factors w^(k r) of a pass come from its own table T[(r - 1) p + k] (round 5): the lanes of a read differ in k only, so it touches consecutive
+// 16-byte entries.  From one table exp(2 pi i t / m) indexed r k m/(pR) the reads of even r were 2- and 4-way bank conflicts (a third of the LDS's busy time).
 // A thread owns up to JMAX butterflies (job = tid + jj*NT) and keeps them in registers across the barrier.
 template <int R> struct Log2 { static constexpr int v = 1 + Log2<R / 2>::v; };
 template <> struct Log2<1> { static constexpr int v = 0; };
@@ -61,11 +60,10 @@ __device__ __forceinline__ void br_wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 template <int R, bool INV, int JMAX, int NT, bool WOWN = false, bool PAIR = false>
-__device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int np1, int P, int mp, int m, int lm, int p, const cplx* W, int tid) {
+__device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int np1, int P, int mp, int m, int lm, int p, const cplx* T, int tid) {
     // m, p and R are powers of two: positions come from shifts and masks (lm = log2 m), never from integer division
     const int lt = lm - Log2<R>::v;
     const int t = 1 << lt;
-    const int wstep = (m >> Log2<R>::v) / p;
     const int njobs = njobs_poly << lt;
     cplx u[JMAX][R];
 #pragma unroll
@@ -81,7 +79,7 @@ __device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int np1, int 
                 // (all R - 1 twiddle reads in front of the products: written read-and-multiply per r, each read sat behind lgkmcnt(0) - round 5 ISA)
                 cplx twd[R];
 #pragma unroll
-                for (int r = 1; r < R; ++r) twd[r] = W[(r * k) * wstep];
+                for (int r = 1; r < R; ++r) twd[r] = T[(r - 1) * p + k];   // w^(r k), w = exp(2 pi i / (p R)): the pass's own table, k contiguous
 #pragma unroll
                 for (int r = 1; r < R; ++r) u[jj][r] = cmul_t<INV>(u[jj][r], twd[r]);
             }
@@ -106,7 +104,7 @@ __device__ __forceinline__ void br_pass(cplx* buf, int njobs_poly, int np1, int 
 
 // CT ciphertexts per workgroup, NT threads, output polynomials in groups of CG, PJ product jobs per thread
 // (m * ceil(ncols/CG) <= PJ*NT), row_max <= MAXR.
-// LDS: W[m] | X[CT][P][mp] (cplx) | acc[CT][rsz][cols][n].  ACC32 stores the accumulators as 32-bit digits (base2k <= 31):
+// LDS: T2, T3 (m entries) | X[CT][P][mp] (cplx) | acc[CT][rsz][cols][n].  ACC32 stores the accumulators as 32-bit digits (base2k <= 31):
 // after the first block they are normalized digits; the first block reads X^b * LUT (any i64) straight from global memory.
 // STD = execute_standard (algorithm.rs:370-440, block size 1): per LWE coefficient  tmp = external_product(acc, BRK_i)  (product
 // without the monomial factor, rounding, carry chain WITHOUT adding acc),  acc += (X^a_i - 1) * tmp  on the i64 limbs (a gather in
@@ -117,7 +115,6 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
     typedef typename AccT<ACC32>::type acc_t;
     // radix-8 butterflies a thread may own per pass (CT*P*m/8 <= JM8*NT, host-checked): two only for m = 512 with CT = 2
     constexpr int JM8 = (CT == 2 && R0 == 8) ? 2 : 1;
-    constexpr bool R16 = PZ_BR_R16 && R0 == 4;   // m = 256 as two radix-16 passes instead of 4 x 8 x 8
     constexpr bool WOWN = R0 != 2;   // br_pass: waves own their polynomials through a transform (m = 128: four polynomials per radix-8 wave, two per first-pass wave)
     extern __shared__ cplx lds_br[];
     const int tid = threadIdx.x;
@@ -128,14 +125,21 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
     const int row_max = cols * in_limbs, ncols = cols * g.bsz;
     const int P = max(row_max, ncols);
     const int ct_polys = g.rsz * cols;        // accumulator polynomials per ciphertext
-    cplx* W = lds_br;                         // exp(2 pi i t / m)
-    cplx* X = W + m;
+    cplx* T2 = lds_br;                        // twiddle tables of the second and third pass (m entries reserved, 63 R0 used)
+    cplx* T3 = T2 + 7 * R0;
+    cplx* X = T2 + m;
     acc_t* acc = reinterpret_cast<acc_t*>(X + CT * P * mp);
     acc_t* tmpd = acc + (STD ? CT * g.rsz * cols * n : 0);  // STD: digits of the current external product
     const int b0 = blockIdx.x * CT;
     const unsigned mask2 = 2u * (unsigned)n - 1u;
 
-    for (int t = tid; t < m; t += NT) W[t] = g.w2n[4 * t];
+    // T2[(r - 1) R0 + k] = exp(2 pi i r k / (8 R0)), k < R0;  T3[(r - 1) 8 R0 + k] = exp(2 pi i r k / m), k < 8 R0  (7 R0 + 56 R0 <= m entries)
+    for (int e = tid; e < 63 * R0; e += NT) {
+        const bool second = e >= 7 * R0;
+        const int ee = second ? e - 7 * R0 : e, pp = second ? 8 * R0 : R0;
+        const int r = ee / pp + 1, kk = ee % pp;
+        T2[e] = g.w2n[4 * (r * kk * (second ? 1 : 8))];   // w2n[4 t] = exp(2 pi i t / m); m = 64 R0
+    }
     // NT is a multiple of m (host-checked): a thread's pack / carry jobs all have j = tid mod m, so its twist factor
     // exp(2 pi i j / 4m) is fetched once
     const cplx tw_j = g.w2n[tid % m];
@@ -214,14 +218,10 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
         __syncthreads();
         // forward DFT of the CT*row_max input polynomials (they sit at poly index ct*P + r)
         if (!(g.dbg_skip & 1))
-        if constexpr (R16) {   // m = 256 = 16 x 16: two passes, a wave owns four polynomials
-            br_pass<16, false, 1, NT, true>(X, CT * row_max, row_max, P, mp, m, lm, 1, W, tidv);
-            br_pass<16, false, 1, NT, true>(X, CT * row_max, row_max, P, mp, m, lm, 16, W, tidv);
-            __syncthreads();
-        } else {
-            br_pass<R0, false, 2, NT, WOWN, WOWN && R0 == 4>(X, CT * row_max, row_max, P, mp, m, lm, 1, W, tidv);
-            br_pass<8, false, JM8, NT, WOWN>(X, CT * row_max, row_max, P, mp, m, lm, R0, W, tidv);
-            br_pass<8, false, JM8, NT, WOWN>(X, CT * row_max, row_max, P, mp, m, lm, R0 * 8, W, tidv);
+        {
+            br_pass<R0, false, 2, NT, WOWN, WOWN && R0 == 4>(X, CT * row_max, row_max, P, mp, m, lm, 1, T2, tidv);
+            br_pass<8, false, JM8, NT, WOWN>(X, CT * row_max, row_max, P, mp, m, lm, R0, T2, tidv);
+            br_pass<8, false, JM8, NT, WOWN>(X, CT * row_max, row_max, P, mp, m, lm, R0 * 8, T3, tidv);
             if (WOWN) __syncthreads();
         }
         // ---- product, in place: X[ct][c][q] = sum_i (DFT(X^a_i)[q] - 1) * sum_r X[ct][r][q] * BRK_i[r][c][q]   (:321-337)
@@ -400,14 +400,10 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
         }
         // inverse DFT of the CT*ncols output polynomials
         if (!(g.dbg_skip & 1))
-        if constexpr (R16) {
-            br_pass<16, true, 1, NT, true>(X, CT * ncols, ncols, P, mp, m, lm, 1, W, tidv);
-            br_pass<16, true, 1, NT, true>(X, CT * ncols, ncols, P, mp, m, lm, 16, W, tidv);
-            __syncthreads();
-        } else {
-            br_pass<R0, true, 2, NT, WOWN, WOWN && R0 == 4>(X, CT * ncols, ncols, P, mp, m, lm, 1, W, tidv);
-            br_pass<8, true, JM8, NT, WOWN>(X, CT * ncols, ncols, P, mp, m, lm, R0, W, tidv);
-            br_pass<8, true, JM8, NT, WOWN>(X, CT * ncols, ncols, P, mp, m, lm, R0 * 8, W, tidv);
+        {
+            br_pass<R0, true, 2, NT, WOWN, WOWN && R0 == 4>(X, CT * ncols, ncols, P, mp, m, lm, 1, T2, tidv);
+            br_pass<8, true, JM8, NT, WOWN>(X, CT * ncols, ncols, P, mp, m, lm, R0, T2, tidv);
+            br_pass<8, true, JM8, NT, WOWN>(X, CT * ncols, ncols, P, mp, m, lm, R0 * 8, T3, tidv);
             if (WOWN) __syncthreads();
         }
         // ---- untwist, round(x/m), + acc, carry chain from the last limb to limb 0 (:342-346); thread = (ct, column, j < m):
