@@ -37,7 +37,11 @@ struct BrFusedArgs {
 template <bool ACC32> struct AccT { typedef long long type; };
 template <> struct AccT<true> { typedef int type; };
 
-// one extra point per 16: radix passes read with stride m/R and write with stride p, both powers of two
+// one extra point per 16: radix passes read with stride m/R and write with stride p, both powers of two.
+// (Round 5, measured and dropped: position i ^ ((i >> 3) & 7) without padding - by the bank model of tools/dbg/lds_bank_model.py every access of every pass
+//  then takes the conflict-free number of LDS cycles, where this layout reads at 2 x and writes the first two passes at 2 x, and a polynomial takes m entries
+//  instead of 17 m / 16.  Same rate (N = 512: 170 000 - 171 200 vs 171 200 - 173 000 rotations/s, N = 1024: 146 700 - 148 300 vs 145 800 - 147 600), but the XORed
+//  offsets no longer fold into base + constant: 20 forms spill 12 - 148 B.  What did cost time were the twiddle reads, now from per-pass tables.)
 __device__ __forceinline__ int br_pad(int i) { return i + (i >> 4); }
 
 // Stockham autosort pass, in place (natural order in and out): sub-transforms of length p are done, this pass makes p*R.
