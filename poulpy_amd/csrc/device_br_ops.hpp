@@ -375,9 +375,29 @@ __global__ void __launch_bounds__(256, (MAXR == 6 ? 3 : 2)) k_br_block_lds(BrBlo
             }                                                                                    \
         }                                                                                        \
     }
+        // every row in use (the usual shapes): the staged key value of step (r, j) + 1 is read from LDS in front of step (r, j)'s FMAs - written as
+        // above the compiler put most reads directly in front of their eight FMAs behind lgkmcnt(0) (round 5 ISA).  Same chains, same order.
+#define PZ_BRL_FMAS_PIPE                                                                          \
+    if (!(PZ_DBG(g.dbg) & 2)) {                                                                  \
+        cplx kcur = ks[buf][0][lane], knxt;                                                      \
+        _Pragma("unroll") for (int r = 0; r < MAXR; ++r) {                                       \
+            _Pragma("unroll") for (int j = 0; j < CG; ++j) {                                     \
+                if (!(r == MAXR - 1 && j == CG - 1)) knxt = ks[buf][(j + 1 < CG ? (j + 1) * MAXR + r : r + 1)][lane]; \
+                _Pragma("unroll") for (int t = 0; t < CT; ++t) {                                 \
+                    cplx& sv = sacc[t][j];                                                       \
+                    sv.x = __builtin_fma(a[t][r].x, kcur.x, sv.x);                               \
+                    sv.x = __builtin_fma(-a[t][r].y, kcur.y, sv.x);                              \
+                    sv.y = __builtin_fma(a[t][r].x, kcur.y, sv.y);                               \
+                    sv.y = __builtin_fma(a[t][r].y, kcur.x, sv.y);                               \
+                }                                                                                \
+                kcur = knxt;                                                                     \
+            }                                                                                    \
+        }                                                                                        \
+    }
         PZ_BSTAMP(1)   // fetch issue + monomial gather issue
-        if (g.row_max == MAXR) { PZ_BRL_FMAS(false) } else { PZ_BRL_FMAS(true) }
+        if (g.row_max == MAXR) { PZ_BRL_FMAS_PIPE } else { PZ_BRL_FMAS(true) }
 #undef PZ_BRL_FMAS
+#undef PZ_BRL_FMAS_PIPE
         PZ_BSTAMP(2)   // LDS reads + FMA chains
 #pragma unroll
         for (int j = 0; j < CG; ++j)
