@@ -492,6 +492,35 @@ def test_one_kernel_rotation_two_ciphertext_forms(mods, n, rank, blk, dnum, bsz,
         assert want in notes, (batch, want, notes)
 
 
+def test_seeded_one_kernel_rotation_sweep_above_one_per_cu(mods):
+    """16 random blind-rotation shapes (fixed seed; POULPY_SWEEP_SEED / POULPY_SWEEP_CASES for others) at N = 256 / 512 / 1024 and a ragged batch above
+    one ciphertext per CU - where the one-kernel rotation puts two ciphertexts into a workgroup (or, at N = 512, uses the 256-thread form): the
+    small-batch sweep of test_gpu_parity.py only reaches the one-ciphertext forms since round 5.  Every output against the oracle's pool; shapes
+    the one-kernel path does not take run the composed path and are checked all the same."""
+    import torch
+    rng = np.random.default_rng(int(os.environ.get("POULPY_SWEEP_SEED", "5151")))
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    fused = 0
+    for case in range(int(os.environ.get("POULPY_SWEEP_CASES", "16"))):
+        n = int(2 ** rng.integers(8, 11))
+        rank = int(rng.integers(1, 4))
+        blk = int(rng.integers(1, 6))
+        n_lwe = int(rng.integers(1, 3)) * blk + int(rng.integers(0, blk))
+        dnum, bsz, rsz = (int(x) for x in rng.integers(1, 4, 3))
+        k = int(rng.integers(10, 16))
+        batch = ncu + int(rng.integers(1, 2 * ncu))
+        ref, hip = mods(n)
+        hip.dispatch_notes(reset=True)
+        desc = dict(case=case, n=n, rank=rank, blk=blk, n_lwe=n_lwe, dnum=dnum, bsz=bsz, rsz=rsz, k=k, batch=batch)
+        if os.environ.get("POULPY_SWEEP_VERBOSE"):
+            print(desc, flush=True)
+        bad = _br_pool_parity(hip, ref, n, rank, n_lwe=n_lwe, block_size=blk, dnum=dnum, brk_size=bsz, res_size=rsz, base2k=k, batch=batch, pool=5,
+                              seed=5400 + case)
+        assert bad == 0, (desc, bad, hip.dispatch_notes())
+        fused += "k_br_fused" in hip.dispatch_notes()
+    assert fused >= 4, f"only {fused} of the sweep's shapes ran the one-kernel path"
+
+
 # ------------------------------------------------------------------------------------------
 # conversion quirks (SURVEY.md a5): round half away, saturating `as i64`, NaN -> 0, and the >= 2^51 slow path of the tail
 # reference: poulpy-cpu-ref/src/reference/fft64/reim/conversion.rs:43-60
