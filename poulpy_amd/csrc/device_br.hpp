@@ -295,6 +295,8 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
                             }
                             load_factors(xn, aiv, min(i + 1 - blk0, g.blk - 1));   // the next coefficient's (the last request of a block is unused)
                         }
+                        // (Round 5, not measured: the key values in two halves of two columns, each half requested for the next coefficient right behind its
+                        //  FMAs - the same 64 registers on paper, 212 B of scratch in the reference shape's form, 60 B with one ciphertext: as in round 3.)
                         // (Round 5, measured and dropped: the sums of 2 columns x 2 ciphertexts side by side - 8 FMA chains interleaved instead of the 2 the
                         //  compiler leaves from this order: no gain on any form, - 1 % at N = 1024; the other wave of the SIMD already fills the gaps.)
                         // GUARD_: row_max < MAXR (the template's row count is the next of 4 / 6 / 8).  With row_max == MAXR - the usual shapes -
