@@ -521,6 +521,21 @@ def test_seeded_one_kernel_rotation_sweep_above_one_per_cu(mods):
     assert fused >= 4, f"only {fused} of the sweep's shapes ran the one-kernel path"
 
 
+def test_blind_rotation_block_larger_than_a_wave(mods):
+    """Block sizes above 64: the one-kernel rotation keeps a block's rotation amounts one per lane (round 5) and leaves such shapes to the composed path;
+    70 coefficients in one block and 2 x 65 + a dropped partial block, small and above-one-per-CU batches."""
+    import torch
+    n = 256
+    ref, hip = mods(n)
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    for blk, n_lwe, batch in ((70, 70, 5), (65, 133, ncu + 9)):
+        hip.dispatch_notes(reset=True)
+        bad = _br_pool_parity(hip, ref, n, 1, n_lwe=n_lwe, block_size=blk, dnum=2, brk_size=2, res_size=2, base2k=14, batch=batch, pool=3,
+                              seed=5500 + blk)
+        assert bad == 0, (blk, n_lwe, batch, bad)
+        assert "k_br_fused" not in hip.dispatch_notes(), hip.dispatch_notes()
+
+
 # ------------------------------------------------------------------------------------------
 # conversion quirks (SURVEY.md a5): round half away, saturating `as i64`, NaN -> 0, and the >= 2^51 slow path of the tail
 # reference: poulpy-cpu-ref/src/reference/fft64/reim/conversion.rs:43-60
