@@ -49,6 +49,15 @@ __device__ __forceinline__ int br_pad(int i) { return i + (i >> 4); }
 // The factors w^(k r) of a pass come from its own table T[(r - 1) p + k] (round 5): the lanes of a read differ in k only, so it touches consecutive
 // 16-byte entries.  From one table exp(2 pi i t / m) indexed r k m/(pR) the reads of even r were 2- and 4-way bank conflicts (a third of the LDS's busy time).
 // A thread owns up to JMAX butterflies (job = tid + jj*NT) and keeps them in registers across the barrier.
+// 16-byte key value by buffer load: resource in SGPRs, scalar byte offset, 32-bit lane offset
+typedef int br_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ cplx br_key_load(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    const br_v4i v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+    cplx d;
+    __builtin_memcpy(&d, &v, 16);
+    return d;
+}
+
 template <int R> struct Log2 { static constexpr int v = 1 + Log2<R / 2>::v; };
 template <> struct Log2<1> { static constexpr int v = 0; };
 
@@ -278,13 +287,17 @@ __global__ void __launch_bounds__(NT, 2) k_br_fused(BrFusedArgs g) {
                     }
                     for (int i = blk0; i < blk0 + g.blk; ++i) {
                         const cplx* K = g.brk + (long long)i * g.key_stride;
+                        const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, -1, 0x00027000);   // raw buffer, no bounds
                         cplx kv[CG][MAXR];
 #pragma unroll
                         for (int j = 0; j < CG; ++j) {
                             const int c = min(cg * CG + j, ncols - 1);
 #pragma unroll
                             for (int r = 0; r < MAXR; ++r)
-                                kv[j][r] = (PZ_DBG(g.dbg_skip) & 16) ? make_double2(1.0, (double)(q + r)) : (K + (long long)(min(r, row_max - 1) * ncols + c) * m)[q];
+                                // (buffer load: the coefficient's key as the resource, the row's byte offset in an SGPR, ONE 32-bit lane offset shared by all
+                                //  CG x MAXR loads - as global loads each had its own 64-bit vector add in front; round 5 ISA)
+                                kv[j][r] = (PZ_DBG(g.dbg_skip) & 16) ? make_double2(1.0, (double)(q + r))
+                                         : br_key_load(krs, (unsigned)q * 16u, (unsigned)((min(r, row_max - 1) * ncols + c) * m) * 16u);
                         }
                         cplx xm[CT];
                         if (!STD) {
