@@ -69,6 +69,68 @@ def pmc_traffic(kernel_class: str, batch: int):
         return None
 
 
+SMI_SAMPLER = r"""
+import json, subprocess, sys, time
+out = sys.argv[1]
+dev = 'card' + sys.argv[2]
+with open(out, 'a') as f:
+    while True:
+        t = time.time()
+        try:
+            d = json.loads(subprocess.run(['rocm-smi', '--showclocks', '--showpower', '--showuse', '--json'], capture_output=True, text=True, timeout=5).stdout)
+            c = d.get(dev) or next(iter(d.values()))
+            rec = {'t': t}
+            for k, v in c.items():
+                kl = k.lower()
+                if 'sclk clock speed' in kl:
+                    rec['sclk_mhz'] = float(''.join(ch for ch in v if ch.isdigit() or ch == '.'))
+                elif 'power (w)' in kl and 'max' not in kl:
+                    rec['power_w'] = float(v)
+                elif 'gpu use' in kl:
+                    rec['busy_pct'] = float(v)
+            f.write(json.dumps(rec) + '\n'); f.flush()
+        except Exception:
+            pass
+        time.sleep(0.25)
+"""
+
+
+def start_smi_sampler(device: int):
+    """A helper PROCESS that samples rocm-smi (clock, socket power, busy %) four times a second into a temporary file; started before this
+    process touches torch or HIP (the sampler never does either).  Returns (process, path) or (None, None) when rocm-smi is not there."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocm-smi") is None:
+        return None, None
+    fd, path = tempfile.mkstemp(prefix="poulpy_smi_", suffix=".jsonl")
+    os.close(fd)
+    try:
+        proc = subprocess.Popen([sys.executable, "-c", SMI_SAMPLER, path, str(device)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except OSError:
+        return None, None
+    return proc, path
+
+
+def smi_window(path, t0: float, t1: float) -> dict:
+    """Median clock / power / busy % of the samples taken inside [t0, t1] (wall clock)."""
+    vals = {"sclk_mhz": [], "power_w": [], "busy_pct": []}
+    try:
+        for line in open(path):
+            try:
+                r = json.loads(line)
+            except ValueError:
+                continue
+            if t0 <= r.get("t", 0.0) <= t1:
+                for k in vals:
+                    if k in r:
+                        vals[k].append(r[k])
+    except OSError:
+        return {}
+    med = lambda v: sorted(v)[len(v) // 2] if v else None
+    return {"sclk_mhz": med(vals["sclk_mhz"]), "power_w": med(vals["power_w"]), "busy_pct": med(vals["busy_pct"]), "samples": len(vals["sclk_mhz"])}
+
+
 def physical_core_cpus() -> list:
     """One logical CPU per physical core among the CPUs this process may run on (sysfs thread_siblings_list; all allowed CPUs if the
     topology cannot be read)."""
@@ -209,29 +271,20 @@ def parity_sample(args, mod, a, res, mat_host, lo, nct, ks, auto_mode, unsupport
             "against": "oracle/fft64_ref.c (strict build, -ffp-contract=off), bit-exact i64 limbs"}
 
 
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import multirank   # noqa: E402  (torch-free at module level: the launcher, the refusals, the per-rank block - shared with tools/bench_*.py)
+
+
 def launcher_argv(gpus: int, argv: list, port: int) -> list:
-    """The command `bench.py --gpus N` (N > 1, no WORLD_SIZE) runs as a child: one rank per GPU on this node, rendezvous on
-    127.0.0.1 (the container hostname may not resolve)."""
-    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
-            "--master-port", str(port), os.path.abspath(__file__), *argv]
+    """The command `bench.py --gpus N` (N > 1, no WORLD_SIZE) runs as a child (tools/multirank.py)."""
+    return multirank.launcher_argv(__file__, gpus, argv, port)
 
 
-def free_port() -> int:
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        return sk.getsockname()[1]
+free_port = multirank.free_port
 
 
 def self_launch(gpus: int, argv: list) -> int:
-    """Parent side of `--gpus N`: nothing here imports torch or initialises HIP (the child processes own the GPUs)."""
-    import subprocess
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver: RCCL needs it
-    env.setdefault("MASTER_ADDR", "127.0.0.1")
-    cmd = launcher_argv(gpus, argv, int(os.environ.get("POULPY_BENCH_PORT", "0")) or free_port())
-    proc = subprocess.run(cmd, env=env)
-    return proc.returncode
+    return multirank.self_launch(__file__, gpus, argv)
 
 
 def main():
@@ -264,6 +317,9 @@ def main():
     ap.add_argument("--setup-calls", type=int, default=0, help="extra untimed calls before the W warm-up steps (reported in the line)")
     ap.add_argument("--ref-value", type=float, default=0.0,
                     help="the 1-GPU value this run is compared with: the line then carries scaling_efficiency = value / (N x ref)")
+    ap.add_argument("--sustained-seconds", type=float, default=5.0,
+                    help="after the timed K steps and the parity sample: loop the same step for at least this many seconds of wall time (no events) and "
+                         "report the rate beside the headline (`sustained`; the reference's harness measures for 5 s, poulpy-bench/src/lib.rs:41-45); 0 = skip")
     ap.add_argument("--parity-samples", type=int, default=8, help="timed-output ciphertexts checked against the CPU oracle (0 = none)")
     args = ap.parse_args()
     global SIZE, DNUM, N, BASE2K
@@ -277,36 +333,14 @@ def main():
     if DSIZE > 1:
         DNUM = max(1, SIZE // DSIZE)
 
-    if args.gpus < 1:
-        raise SystemExit("--gpus must be >= 1")
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        # started plainly: become the launcher (a child process per GPU; never exec from here, never touch the GPU here)
-        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for a different GPU count "
-                         f"(launch with --nproc-per-node {args.gpus}, or plainly and let --gpus start the ranks)")
+    # started plainly with --gpus N > 1: become the launcher and exit with the child's code; under torch.distributed.run: refuse a WORLD_SIZE
+    # other than --gpus (tools/multirank.py - before torch is imported or the GPU is touched)
+    R = multirank.enter(__file__, args.gpus, sys.argv[1:])
+    world, rank, local_rank, distributed = R.world, R.rank, R.local_rank, R.distributed
+    # clock / power / busy samples for the sustained leg: a helper process, started before this one imports torch or touches the GPU
+    smi_proc, smi_path = start_smi_sampler(local_rank) if (rank == 0 and args.sustained_seconds > 0) else (None, None)
 
-    import torch
-    import torch.distributed as dist
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1 or os.environ.get("POULPY_BENCH_FORCE_DIST") == "1"   # (the knob runs the RCCL path with one rank)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
-    # checked here, in the rank process (the launching parent never touches torch or HIP): fewer visible devices than ranks is a clean,
-    # one-line refusal - no line is printed, the exit code is non-zero on every rank
-    ndev = torch.cuda.device_count()
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))   # ranks on THIS node (torchrun sets it; a multi-node world is larger)
-    if ndev < local_world or local_rank >= ndev:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} needs {local_world} HIP devices on this node but only {ndev} are visible: no line reported", file=sys.stderr, flush=True)
-        raise SystemExit(4)
-    torch.cuda.set_device(local_rank)
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch, dist = R.init()   # device checks (exit 4: fewer HIP devices than local ranks), set_device, process group "nccl" = RCCL
 
     from poulpy_amd.hal import GlweOpParams, Module
     from poulpy_amd import dist as pdist
@@ -445,6 +479,52 @@ def main():
         parity = {"n": len(picks), "ok": not bad, "indices": [int(lo + i) for i in picks], "mismatched": bad,
                   "against": "oracle/fft64_ref.c, bit-exact i64 limbs; one extra untimed call from the original input (the timed calls run in place)"}
 
+    # sustained leg (always on): the same step() looped for >= --sustained-seconds of wall time, no events; the headline stays the K-step figure
+    sustained = None
+    if args.sustained_seconds > 0:
+        if trace:
+            res.copy_(a)
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        w0 = time.time()
+        s0 = time.perf_counter()
+        n_sus, burst = 0, max(1, min(args.steps, 50))
+        while True:
+            for _ in range(burst):
+                step()
+            mod.sync()
+            n_sus += burst
+            # every rank runs the same number of bursts: rank 0's clock decides, the others follow its verdict
+            go = time.perf_counter() - s0 < args.sustained_seconds
+            if distributed:
+                flag = torch.tensor([1 if go else 0], dtype=torch.int64, device=dev)
+                dist.broadcast(flag, src=0)
+                go = bool(flag.item())
+            if not go:
+                break
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        s_dt = time.perf_counter() - s0
+        w1 = time.time()
+        if distributed:
+            t = torch.tensor([s_dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            s_dt = float(t.item())
+        sustained = {"value": args.batch * world * n_sus / s_dt / (DNUM if expand else 1), "seconds": round(s_dt, 3), "steps": n_sus,
+                     "sclk_mhz": None, "power_w": None}
+        if smi_path:
+            time.sleep(0.3)
+            sustained.update(smi_window(smi_path, w0 + 0.5, w1))
+    if smi_proc is not None:
+        smi_proc.kill()
+        smi_proc.wait()
+        try:
+            os.unlink(smi_path)
+        except OSError:
+            pass
+
     # roofline leg: the same steps again with one HIP-event pair per launch on the module stream
     stats = {}
     timing = (not args.no_kernel_timing)
@@ -478,7 +558,7 @@ def main():
             "dominant_kernel": dom_name, "dominant_kernel_ms": (dom_ms / dom_cnt) if dom_cnt else None,
             "mid_ms": (stats["fused_mid"][1] / stats["fused_mid"][0]) if stats.get("fused_mid", (0, 0))[0] else None,
             "pipeline_gbs": nct * args.steps / dt * b_unit_rank / 1e9,
-            "parity_ok": None if parity is None else parity.get("ok"), "device": local_rank}
+            "parity_ok": None if parity is None else parity.get("ok"), "device": local_rank, "rounding_margin": margin}
     per_rank = [dict(mine, rank=rank)]
     if distributed:
         per_rank = pdist.gather_per_rank(mine)
@@ -554,14 +634,22 @@ def main():
             "per_rank": per_rank,
             "scaling_efficiency": pdist.scaling_efficiency(value, world, args.ref_value),
             "parity_sample": parity,
-            "rounding_margin": margin,
+            "rounding_margin": max([e["rounding_margin"] for e in per_rank if e.get("rounding_margin") is not None], default=margin),   # worst shard
+            "sustained": sustained,
         }
         if world == 1 and not args.no_cpu_baseline and not ks:
-            try:
-                line["cpu_baseline"] = cpu_baseline()
-            except Exception as e:  # the baseline is reported, never required for the GPU number
+            err = None
+            for attempt in range(2):   # a host hiccup (a busy core, an allocation failure) gets one more try before the line reports "failed"
+                try:
+                    line["cpu_baseline"] = cpu_baseline()
+                    err = None
+                    break
+                except Exception as e:  # the baseline is reported, never required for the GPU number
+                    err = e
+                    time.sleep(1.0)
+            if err is not None:
                 line["cpu_baseline"] = {"value": None, "unit": "external-products/s", "cores": 0, "kind": "port",
-                                        "sample": f"failed: {e}"}
+                                        "sample": f"failed twice: {err}"}
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()

@@ -612,6 +612,7 @@ int pz_vec_znx_rsh_batched(pz_module* m, size_t batch, size_t base2k, size_t k, 
  * over xGMI, on the module stream.  RCCL is loaded on first use.  Bootstrap like NCCL: rank 0 obtains an id, every rank
  * receives it out of band (MPI, a file, torch.distributed ...) and calls pz_comm_init_rank. */
 size_t pz_comm_unique_id_bytes(void);                 /* 128 */
+int pz_comm_available(void);                          /* PZ_OK when RCCL can be loaded in this process (dlopen + symbols); no id drawn, no socket opened */
 int pz_comm_unique_id(void* out_id);                  /* ncclGetUniqueId */
 int pz_comm_init_rank(pz_module* m, int world_size, int rank, const void* unique_id);
 int pz_comm_destroy(pz_module* m);

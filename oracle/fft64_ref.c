@@ -626,15 +626,32 @@ static inline int64_t f64_to_i64_sat(double x) {
     return (int64_t)x;
 }
 
+/* Rounding-margin probe of the ORACLE (round 6; not in the reference): max |x - round(x)| over every value the two conversions below
+ * round while the probe is on - how far cpu-ref's own f64 transforms stay from a wrong limb on the inputs of a test
+ * (poulpy-hal/docs/backend_safety_contract.md:25-27 asks for a documented tolerance; tools/margin.py, tests/test_gpu_structured.py).
+ * A plain global: single-threaded diagnostic use only; off by default (the timed cpu_baseline leg never turns it on). */
+static int pzr_margin_on = 0;
+static double pzr_margin_max = 0.0;
+void pzr_margin_probe_set(int on) { pzr_margin_on = on; pzr_margin_max = 0.0; }
+double pzr_margin_probe_get(void) { return pzr_margin_max; }
+static inline void pzr_margin_note(double x) {
+    if (x == x && fabs(x) < 4503599627370496.0) {   /* |x| < 2^52: the value has a fractional part at all */
+        double d = fabs(x - round(x));
+        if (d > pzr_margin_max) pzr_margin_max = d;
+    }
+}
+
 /* conversion.rs:43-52 ; f64::round = half away from zero = C round() */
 void pzr_reim_to_znx_i64(int64_t* res, double divisor, const double* a, size_t len) {
     double inv_div = 1. / divisor;
+    if (pzr_margin_on) for (size_t i = 0; i < len; ++i) pzr_margin_note(a[i] * inv_div);
     for (size_t i = 0; i < len; ++i) res[i] = f64_to_i64_sat(round(a[i] * inv_div));
 }
 
 /* conversion.rs:55-60 */
 void pzr_reim_to_znx_i64_assign(double* res, double divisor, size_t len) {
     double inv_div = 1. / divisor;
+    if (pzr_margin_on) for (size_t i = 0; i < len; ++i) pzr_margin_note(res[i] * inv_div);
     for (size_t i = 0; i < len; ++i) {
         int64_t v = f64_to_i64_sat(round(res[i] * inv_div));
         memcpy(&res[i], &v, sizeof(v));

@@ -47,6 +47,9 @@ void pzr_ifft(const pzr_tables* t, double* data);
 
 /* reim/conversion.rs:19-60 */
 void pzr_reim_from_znx_i64(double* res, const int64_t* a, size_t len);
+/* rounding-margin probe of the oracle itself (not in the reference; diagnostic, single-threaded) */
+void pzr_margin_probe_set(int on);
+double pzr_margin_probe_get(void);
 void pzr_reim_to_znx_i64(int64_t* res, double divisor, const double* a, size_t len);
 void pzr_reim_to_znx_i64_assign(double* res, double divisor, size_t len);
 

@@ -42,6 +42,7 @@ def load(fast: bool = False) -> C.CDLL:
                  "pzr_cnv_pairwise_apply_dft_tmp_bytes", "pzr_cnv_by_const_apply_tmp_bytes"):
         getattr(lib, name).restype = c_size_t
     lib.pzr_msb_mask_bottom_limb.restype = c_int64
+    lib.pzr_margin_probe_get.restype = c_double
     return lib
 
 
@@ -65,6 +66,16 @@ class RefModule:
 
     def n(self):
         return self._n
+
+    def rounding_margin_of(self, run) -> float:
+        """max |x - round(x)| over every value the oracle rounds (reim_to_znx_i64[_assign]) while `run()` executes: the oracle's own
+        distance from a wrong limb on these inputs (pzr_margin_probe_*: diagnostic, single-threaded; 0.5 = a wrong limb)."""
+        self.lib.pzr_margin_probe_set(1)
+        try:
+            run()
+            return float(self.lib.pzr_margin_probe_get())
+        finally:
+            self.lib.pzr_margin_probe_set(0)
 
     def __del__(self):
         try:

@@ -172,7 +172,7 @@ static inline size_t tensor_dft_size(size_t full, size_t res_size, size_t res_ba
 struct TensorPlan {
     int cols, tcols, a_size, b_size, res_size, dft_size, hi;
     long long lo;
-    size_t prep_a, prep_b, res_dft, tmp, diag, T, per_ct;
+    size_t prep_a, prep_b, res_dft, tmp, diag, T, d16, per_ct;
 };
 static int tensor_plan(const pz_module* M, const pz_glwe_tensor_params* p, int mode, TensorPlan& t) {
     PZ_REQUIRE(p != nullptr, "null params");
@@ -198,7 +198,9 @@ static int tensor_plan(const pz_module* M, const pz_glwe_tensor_params* p, int m
     t.diag = mode == PZ_TENSOR_SQUARE ? n8 * t.cols * t.res_size : 0;
     // (k_mid_cnv3 leaves the three result sets of a rank-1 tensoring side by side: 3 x min(dft_size, a_size + b_size - 1) polynomials)
     t.T = (size_t)M->m * sizeof(cplx) * std::max({t.cols * t.a_size, t.cols * t.b_size, t.dft_size, 1, t.cols == 2 ? 3 * std::min(t.dft_size, t.a_size + t.b_size - 1) : 0});
-    t.per_ct = t.prep_a + t.prep_b + t.res_dft + t.tmp + t.diag + t.T;
+    // 16-bit side copies of the diagonal terms' digits for the pairwise tails (apply / square with base2k <= 16; TailD16)
+    t.d16 = (mode != PZ_TENSOR_APPLY_ADD_ASSIGN && p->res_base2k <= 16 && p->res_base2k == p->ab_base2k) ? (size_t)M->n * 2 * t.cols * t.res_size : 0;
+    t.per_ct = t.prep_a + t.prep_b + t.res_dft + t.tmp + t.diag + t.T + t.d16;
     return PZ_OK;
 }
 static size_t tensor_chunk(const pz_module* M, const TensorPlan& t, size_t batch) {
@@ -224,6 +226,7 @@ struct TensorWave {
     // workspace of a wave
     double *pa = nullptr, *pb = nullptr, *rd = nullptr;
     int64_t *tmp = nullptr, *diag = nullptr;
+    short* d16 = nullptr;   // [diagonal term i][pair][res limb][n] (TensorPlan::d16)
     cplx* T = nullptr;
     long long r_ct = 0, pa_bs = 0, pb_bs = 0, rd_bs = 0, tmp_bs = 0, dg_bs = 0, rls = 0, a_mask = 0, b_mask = 0;
     // the wave
@@ -234,8 +237,8 @@ struct TensorWave {
 
     int take_workspace(size_t chunk) {
         const size_t s_pa = align256(chunk * t.prep_a), s_pb = square ? 0 : align256(chunk * t.prep_b), s_rd = align256(chunk * t.res_dft);
-        const size_t s_tmp = align256(chunk * t.tmp), s_dg = align256(chunk * t.diag), s_T = align256(chunk * t.T);
-        PZ_TRY(ws_reserve(M, s_pa + s_pb + s_rd + s_tmp + s_dg + s_T));
+        const size_t s_tmp = align256(chunk * t.tmp), s_dg = align256(chunk * t.diag), s_T = align256(chunk * t.T), s_d16 = align256(chunk * t.d16);
+        PZ_TRY(ws_reserve(M, s_pa + s_pb + s_rd + s_tmp + s_dg + s_T + s_d16));
         char* base = (char*)M->ws;
         PZ_TRY(ws_take(M, base, s_pa, &pa));
         PZ_TRY(ws_take(M, base, s_pb, &pb));
@@ -244,6 +247,8 @@ struct TensorWave {
         PZ_TRY(ws_take(M, base, s_tmp, &tmp));
         PZ_TRY(ws_take(M, base, s_dg, &diag));
         PZ_TRY(ws_take(M, base, s_T, &T));
+        PZ_TRY(ws_take(M, base, s_d16, &d16));
+        if (!s_d16) d16 = nullptr;
         r_ct = n * t.tcols * t.res_size;
         pa_bs = n * t.cols * t.a_size; pb_bs = n * t.cols * t.b_size; rd_bs = n * std::max(t.dft_size, 1); tmp_bs = n * t.res_size;
         dg_bs = n * t.cols * t.res_size;
@@ -289,7 +294,7 @@ struct TensorWave {
         return PZ_OK;
     }
     // one product term (i, j): convolution -> inverse transform in place -> normalize(res_base2k, cnv_offset_lo) into `dst` column dcol
-    int term(int i, int j, int64_t* dst, long long dst_bs, int dst_cols, int dcol, const NzCombine* cb = nullptr) {
+    int term(int i, int j, int64_t* dst, long long dst_bs, int dst_cols, int dcol, const NzCombine* cb = nullptr, const TailD16* d16s = nullptr) {
         const int bound = t.a_size + t.b_size - 1;
         const int min_size = std::min(t.dft_size, bound), off = std::min(t.hi, bound);
         if (fused) {
@@ -298,7 +303,7 @@ struct TensorWave {
             else PZ_TRY(launch_mid_cnv(M, nb, ta_main, ta_last, tb_main, tb_last, T, t.cols, t.a_size, t.b_size, i, i == j ? -1 : j, i, i == j ? -1 : j,
                                        min_size, off));
             // the inverse column pass normalizes on its way out (bit offset, combination and all: TailArgs::nz)
-            return launch_inv_tail_nz(M, nb, Tt, min_size, (long long*)dst, dst_bs, dst_cols, t.res_size, dcol, (int)p->res_base2k, t.lo, t.dft_size, cb);
+            return launch_inv_tail_nz(M, nb, Tt, min_size, (long long*)dst, dst_bs, dst_cols, t.res_size, dcol, (int)p->res_base2k, t.lo, t.dft_size, cb, d16s);
         }
         PZ_TRY(launch_cnv_apply(M, nb, rd, rd_bs, 1, 0, min_size, off, pa, pa_bs, t.a_size, i, i == j ? -1 : j, pb, pb_bs, t.b_size, i, i == j ? -1 : j));
         if (t.dft_size > min_size)
@@ -320,14 +325,23 @@ struct TensorWave {
     // add_assign: the diagonal term goes into its column (+=) and out of the cross columns (-=), the pairwise term into its cross column (+=)
     int combine_in_stores() {
         if (!add) {
+            // the diagonal launches leave 16-bit copies of their digits beside the tensor columns (base2k <= 16, fused tails): the pairwise
+            // launches read those - 2 B per coefficient and diagonal column instead of the 8 B a line of the i64 column costs
+            static const bool d16_on = (exp_knob("POULPY_DBG_TENSOR_D16", 1) != 0);
+            const bool use16 = d16_on && d16 != nullptr && fused;
+            const long long d16_ts = (long long)nb * t.res_size * n;   // one diagonal term's copies
             for (int i = 0; i < t.cols; ++i) {
                 NzCombine cb{1, {0, 0}, {0, 0}};
-                PZ_TRY(term(i, i, rb, r_ct, t.tcols, cidx(i, i), &cb));
+                TailD16 dw;
+                dw.w = use16 ? d16 + i * d16_ts : nullptr;
+                PZ_TRY(term(i, i, rb, r_ct, t.tcols, cidx(i, i), &cb, use16 ? &dw : nullptr));
             }
             for (int i = 0; i < t.cols; ++i)
                 for (int j = i + 1; j < t.cols; ++j) {
                     NzCombine cb{1, {cidx(i, i), cidx(j, j)}, {5, 5}};
-                    PZ_TRY(term(i, j, rb, r_ct, t.tcols, cidx(i, j), &cb));
+                    TailD16 dr;
+                    dr.ra = use16 ? d16 + i * d16_ts : nullptr; dr.rb = use16 ? d16 + j * d16_ts : nullptr;
+                    PZ_TRY(term(i, j, rb, r_ct, t.tcols, cidx(i, j), &cb, use16 ? &dr : nullptr));
                 }
             return PZ_OK;
         }

@@ -53,6 +53,9 @@ extern "C" {
 
 size_t pz_comm_unique_id_bytes(void) { return sizeof(rccl_unique_id); }
 
+// the cheap probe of the non-root ranks (poulpy_amd/dist.py::broadcast_key_agreed): ncclGetUniqueId opens a bootstrap listener per call
+int pz_comm_available(void) { return rccl_load(); }
+
 int pz_comm_unique_id(void* out_id) {
     if (!out_id) return fail(PZ_ERR_INVALID, "null id");
     PZ_TRY(rccl_load());

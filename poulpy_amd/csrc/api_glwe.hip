@@ -767,14 +767,20 @@ static int glwe_entry(pz_module* M, bool ks, bool tensor, int64_t* res, const in
     PZ_REQUIRE(p->dsize >= 1 && p->dnum >= 1 && p->key_size >= 1 && p->a_size >= 1 && p->res_size >= 1, "glwe op: empty shape");
     const OpShape s = op_shape(p, ks || tensor, tensor);
     const size_t n8 = (size_t)M->n * 8;
-    if (batch >= 2 && res != nullptr && a != nullptr && pmat != nullptr && !M->timing && !canary_mode() && is_pinned_host(a) && is_pinned_host(res)) {
+    // in place (*_assign forms): one layout for a and res - checked HERE, in front of both host paths (the duplex path below does not go through
+    // glwe_args_in: with res == a and a larger res every wave's kernels would write past the a-sized arena block).  Host ranges that overlap
+    // without being equal take the serial path: there the whole input is on the device before the first result travels back
+    const size_t res_ct_bytes = n8 * s.cols_out * p->res_size, a_ct_bytes = n8 * s.cols_a * p->a_size;
+    if (res != nullptr && (const void*)res == (const void*)a) PZ_REQUIRE(res_ct_bytes == a_ct_bytes, "in-place call with different layouts for a and res");
+    const bool partial_overlap = res != nullptr && a != nullptr && (const void*)res != (const void*)a &&
+                                 (const char*)res < (const char*)a + batch * a_ct_bytes && (const char*)a < (const char*)res + batch * res_ct_bytes;
+    if (batch >= 2 && res != nullptr && a != nullptr && pmat != nullptr && !partial_overlap && !M->timing && !canary_mode() && is_pinned_host(a) && is_pinned_host(res)) {
         const double* key = nullptr;
         PZ_TRY(resolve_key(M, pmat, n8 * p->dnum * s.cols_in * s.cols_out * p->key_size, &key));
-        return glwe_entry_duplex(M, ks, tensor, res, a, key, p, batch, au, n8 * s.cols_out * p->res_size, n8 * s.cols_a * p->a_size);
+        return glwe_entry_duplex(M, ks, tensor, res, a, key, p, batch, au, res_ct_bytes, a_ct_bytes);
     }
     GlweArgs g;
-    PZ_TRY(glwe_args_in(M, g, res, a, pmat, batch * n8 * s.cols_out * p->res_size, batch * n8 * s.cols_a * p->a_size,
-                        n8 * p->dnum * s.cols_in * s.cols_out * p->key_size));
+    PZ_TRY(glwe_args_in(M, g, res, a, pmat, batch * res_ct_bytes, batch * a_ct_bytes, n8 * p->dnum * s.cols_in * s.cols_out * p->key_size));
     PZ_TRY(glwe_op(M, ks, g.res, g.a, g.key, p, batch, au, nullptr, tensor));
     return glwe_args_out(M, g);
 }

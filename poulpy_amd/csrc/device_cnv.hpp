@@ -261,17 +261,49 @@ struct MidCnv3Args {
     const cplx* wL2;
     const cplx* tw12t;
 };
-template <int AS, int BS>
+#ifndef PZ_CNV_STAMP
+#define PZ_CNV_STAMP 0   // diagnostic build: per-phase s_memtime totals of k_mid_cnv3, printed by a few waves (tools/dbg/cnv_stamps.sh)
+#endif
+#ifndef PZ_CNV_EARLY
+#define PZ_CNV_EARLY 1   // static-window forms: the next tile's operand loads travel under the convolution (0: under the inverse row pass, as the WLO = 0 forms)
+#endif
+#ifndef PZ_CNV_SPREAD
+#define PZ_CNV_SPREAD 1  // the next tile's operand loads go out in four groups between the steps of the inverse row pass (0: all 16 in front of it, rounds 4 - 5)
+#endif
+// acc += x * y (four FMAs; the order of the reference's reim4 kernels is not needed: only the rounded integers are compared)
+#define PZ_CMAC(ACC_, X_, Y_)                                    \
+    {                                                            \
+        (ACC_).x = __builtin_fma((X_).x, (Y_).x, (ACC_).x);      \
+        (ACC_).x = __builtin_fma(-(X_).y, (Y_).y, (ACC_).x);     \
+        (ACC_).y = __builtin_fma((X_).x, (Y_).y, (ACC_).y);      \
+        (ACC_).y = __builtin_fma((X_).y, (Y_).x, (ACC_).y);      \
+    }
+// Round 6 (stamps: profiles/r06_cnv_stamps.txt - per tile of 30 k cycles the limb convolution takes 8 k, VALU-bound: 6.1 k cycles of FMA issue per
+// SIMD; issuing the next tile's 16 loads 2.6 - 5 k):
+//   * WLO (compile time): only the product limbs k in [offset, offset + min_size) leave the kernel (convolution.rs:235-247: res limb kk = product
+//     limb kk + offset), yet every one of the AS x BS multiply-adds ran - at the configs[4] shape (offset 13, 17 limbs kept of 31) 36 % of them fed
+//     accumulators that were dropped at write-back.  The multiply-adds with i + j < WLO are not compiled in (and their accumulators do not
+//     exist); the launcher picks the largest instantiated WLO <= offset (0 or AS - 4).  Tested per block of 4 at run time against the offset the
+//     same skip measured SLOWER than none (conv 5.2 -> 8.0 k cycles: a branch per block keeps the operand reads from travelling ahead);
+//   * SQ (glwe_tensor_square_apply, b = a): 2 AS operand rows instead of 4 AS (half the row loads and forward row transforms), and the three
+//     products are squares - sum_{i + j = k} a_i a_j = 2 sum_{i < j} a_i a_j + [k even] a_{k/2}^2: 136 multiply-adds per diagonal term
+//     instead of 256, no operand streamed from LDS at all (both factors live in the thread's registers): 3.55 -> 2.55 ms per 256 squares;
+//   * the next tile's operand loads in four groups between the steps of the inverse row pass (as k_mid128r), LDS-only barriers.
+template <int AS, int BS, bool SQ = false, int WLO = 0>
 __global__ void __launch_bounds__(512) k_mid_cnv3(MidCnv3Args g) {
-    constexpr int M2 = 128, RS = kMidCnvRS, NR = 2 * AS + 2 * BS, NK = AS + BS - 1;
+    static_assert(!SQ || AS == BS, "square form: one operand");
+    static_assert(BS == 16 || BS == 8, "k_mid_cnv3: the early operand loads are written for 16 / 8 limbs");
+    constexpr int M2 = 128, RS = kMidCnvRS, NR = SQ ? 2 * AS : 2 * AS + 2 * BS, NK = AS + BS - 1;
     static_assert(NR <= 64, "k_mid_cnv3: at most 64 operand rows");
+    static_assert(WLO >= 0 && WLO < NK, "k_mid_cnv3: the static window starts inside the product");
+    constexpr bool EARLY = PZ_CNV_EARLY && WLO > 0 && !SQ;   // (square form: measured slower with the early loads, 2.62 vs 2.48 ms per 256 - half the rows load at all)
     extern __shared__ cplx lds[];   // 64 rows x RS | wL2[128] | tw12t rows [2][128]
     const int tid = threadIdx.x;
     const long long m = (long long)g.m1 * M2;
     cplx* wl = lds + 64 * RS;
     cplx* twrow2 = wl + M2;
     // PERSISTENT (one workgroup per CU: the tile fills LDS): tile L = (pair bt, frequency row q1), walked with stride gridDim.x; the next
-    // tile's operand rows are requested before the inverse row pass of the current one and travel under it (the first version, one tile per
+    // tile's operand rows are requested during the inverse row pass of the current one and travel under it (the first version, one tile per
     // workgroup, left the CU idle while its only workgroup waited for its loads: 3.3 TB/s, profiles/r04_tensor_*).
     const long long ntiles = (long long)g.batch * g.m1;
     // Lane coordinates are re-derived from an OPAQUE copy of the thread index in every phase (as in k_mid128r): derived once, everything that
@@ -279,7 +311,7 @@ __global__ void __launch_bounds__(512) k_mid_cnv3(MidCnv3Args g) {
     // 188 registers of the convolution (300 bytes of scratch).
     // the operand row a thread's 8-lane group loads and transforms: (operand, column, limb) - the same for every tile
     auto row_src = [&](long long L, int row, int o) {
-        const bool isb = row >= 2 * AS;
+        const bool isb = !SQ && row >= 2 * AS;
         const int rr_ = isb ? row - 2 * AS : row, size_ = isb ? BS : AS;
         const int col_ = rr_ / size_, limb_ = rr_ % size_;
         const long long Lc = L < ntiles ? L : ntiles - 1;
@@ -301,6 +333,15 @@ __global__ void __launch_bounds__(512) k_mid_cnv3(MidCnv3Args g) {
     }
     if (tid < M2) { wl[tid] = g.wL2[tid]; twrow2[tid] = g.tw12t[(long long)(L % g.m1) * M2 + tid]; }
     __syncthreads();
+#if PZ_CNV_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_t0 = st_t;
+    int st_tiles = 0;
+#define PZ_CSTAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; }
+#else
+#define PZ_CSTAMP(i)
+#endif
     int par = 0;
     for (; L < ntiles; L += gridDim.x, par ^= 1) {
         const int q1 = (int)(L % g.m1);
@@ -310,6 +351,10 @@ __global__ void __launch_bounds__(512) k_mid_cnv3(MidCnv3Args g) {
         if (NR == 64 || (tf >> 3) < NR) {
             const int row = tf >> 3, o = tf & 7;
             cplx* rowbuf = lds + row * RS;
+#if PZ_CNV_STAMP
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PZ_CSTAMP(0)   // wait for the operand rows
+#endif
             Bfly<16, false>::run(x);
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) {
@@ -330,73 +375,126 @@ __global__ void __launch_bounds__(512) k_mid_cnv3(MidCnv3Args g) {
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) rowbuf[o + 8 * h + 16 * k2] = x[8 * h + k2];
         }
-        __syncthreads();
+        PZ_CSTAMP(1)   // forward row transforms
+        lds_barrier();   // (LDS ordering only: the previous tile's stores keep draining)
+        PZ_CSTAMP(2)   // barrier
         // ---- limb convolution, one operand vector in registers ----
         {
             const int tc = pz_opaque(tid);
-            const int pt = tc & 127, grp = tc >> 7;   // wave-uniform group
+            const int pt = tc & 127, grp = __builtin_amdgcn_readfirstlane(tc >> 7);   // wave-uniform group, in a scalar register: the branches on it below are
+                                                                                         // scalar branches (as a vector value both sides of every `if` were emitted under exec masks, and the
+                                                                                         // second side waited for the first side's loads into the same registers)
             const cplx* A0 = lds + pt;
             const cplx* A1 = A0 + AS * RS;
-            const cplx* B0 = A0 + 2 * AS * RS;
+            const cplx* B0 = A0 + 2 * AS * RS;        // (!SQ)
             const cplx* B1 = B0 + BS * RS;
             const int term = grp < 2 ? grp : 2;
             cplx* out = lds + (term * g.min_size) * RS + pt;   // result rows [term][kk]: written only after every operand value has been read
             constexpr int NKH = (NK + 1) / 2;
             const int hp = grp - 2;    // groups 2 / 3: this thread's product limbs are k = 2 u + hp
-            cplx av[AS], acc[NK];      // (groups 2 / 3 use acc[0 .. NKH))
+            cplx av[AS], acc[NK];      // (groups 2 / 3 use acc[0 .. NKH); product limbs below WLO are never touched: no registers)
 #pragma unroll
             for (int k = 0; k < NK; ++k) acc[k] = make_double2(0.0, 0.0);
-            if (grp < 2) {
+            // EARLY (the forms with a static window: 163 registers instead of 210): the next tile's 16 operand loads go out one (two at 8 limbs)
+            // per step of the j loop below - the convolution is VALU-bound and leaves the vector-memory path idle, while issued in front of the
+            // inverse pass they cost a wave 2.6 - 5 k cycles (profiles/r06_cnv_stamps.txt)
+            const bool xl_on = NR == 64 || (tc >> 3) < NR;
+            const cplx* const xsrc = row_src(L + gridDim.x, xl_on ? (tc >> 3) : 0, tc & 7);
+#define PZ_XL(J_)                                                                                              \
+    if constexpr (EARLY) {                                                                                     \
+        x[(J_) * (16 / BS)] = xl_on ? ld_stream(xsrc + 8 * ((J_) * (16 / BS))) : make_double2(0.0, 0.0);      \
+        if constexpr (BS == 8) x[(J_) * 2 + 1] = xl_on ? ld_stream(xsrc + 8 * ((J_) * 2 + 1)) : make_double2(0.0, 0.0); \
+    }
+            if constexpr (SQ) {
+                if (grp < 2) {
+                    const cplx* A = grp == 0 ? A0 : A1;
+#pragma unroll
+                    for (int i = 0; i < AS; ++i) av[i] = A[i * RS];
+                    PZ_XL(0)
+#pragma unroll
+                    for (int j = 1; j < AS; ++j) {
+                        PZ_XL(j)
+#pragma unroll
+                        for (int i = 0; i < j; ++i)
+                            if (i + j >= WLO) PZ_CMAC(acc[i + j], av[i], av[j])     // pairs i < j, doubled below
+                    }
+#pragma unroll
+                    for (int k = WLO; k < NK; ++k) {
+                        acc[k].x += acc[k].x; acc[k].y += acc[k].y;
+                        if ((k & 1) == 0) PZ_CMAC(acc[k], av[k >> 1], av[k >> 1])
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < AS; ++i) av[i] = cadd(A0[i * RS], A1[i * RS]);
+                    // hp (wave-uniform) selects the parity of i + j: two straight-line bodies
+#define PZ_SQ_HALF(HP_)                                                                                       \
+    {                                                                                                         \
+        PZ_XL(0)                                                                                              \
+        _Pragma("unroll") for (int j = 1; j < AS; ++j) {                                                      \
+            PZ_XL(j)                                                                                          \
+            _Pragma("unroll") for (int i = ((j & 1) ^ (HP_)); i < j; i += 2)                                  \
+                if (i + j >= WLO) PZ_CMAC(acc[(i + j) >> 1], av[i], av[j])                                    \
+        }                                                                                                     \
+        _Pragma("unroll") for (int u = 0; u < NKH; ++u) {                                                     \
+            if (2 * u + (HP_) >= WLO) {                                                                       \
+                acc[u].x += acc[u].x; acc[u].y += acc[u].y;                                                   \
+                if ((HP_) == 0 && u < AS) PZ_CMAC(acc[u], av[u], av[u])                                       \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+                    if (hp == 0) PZ_SQ_HALF(0) else PZ_SQ_HALF(1)
+#undef PZ_SQ_HALF
+                }
+            } else if (grp < 2) {
                 const cplx* A = grp == 0 ? A0 : A1;
                 const cplx* B = grp == 0 ? B0 : B1;
 #pragma unroll
                 for (int i = 0; i < AS; ++i) av[i] = A[i * RS];
+                // the operand of row j + 1 is read while row j's multiply-adds issue (read at the top of its own row, every row waited a full LDS
+                // latency: `ds_read; s_waitcnt lgkmcnt(0)` sixteen times per thread in the ISA)
+                constexpr int J0 = WLO > AS - 1 ? WLO - (AS - 1) : 0;   // first row that reaches the window
+                cplx bn = B[J0 * RS];
 #pragma unroll
                 for (int j = 0; j < BS; ++j) {
-                    const cplx bv = B[j * RS];
+                    PZ_XL(j)
+                    if (j >= J0) {
+                        const cplx bv = bn;
+                        if (j + 1 < BS) bn = B[(j + 1) * RS];
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < AS; ++i) {
-                        acc[i + j].x = __builtin_fma(av[i].x, bv.x, acc[i + j].x);
-                        acc[i + j].x = __builtin_fma(-av[i].y, bv.y, acc[i + j].x);
-                        acc[i + j].y = __builtin_fma(av[i].x, bv.y, acc[i + j].y);
-                        acc[i + j].y = __builtin_fma(av[i].y, bv.x, acc[i + j].y);
+                        for (int i = 0; i < AS; ++i)
+                            if (i + j >= WLO) PZ_CMAC(acc[i + j], av[i], bv)
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < AS; ++i) av[i] = cadd(A0[i * RS], A1[i * RS]);
-                if (hp == 0) {
-#pragma unroll
-                    for (int j = 0; j < BS; ++j) {
-                        const cplx bv = cadd(B0[j * RS], B1[j * RS]);
-#pragma unroll
-                        for (int i = (j & 1); i < AS; i += 2) {   // i + j even
-                            cplx& c = acc[(i + j) >> 1];
-                            c.x = __builtin_fma(av[i].x, bv.x, c.x);
-                            c.x = __builtin_fma(-av[i].y, bv.y, c.x);
-                            c.y = __builtin_fma(av[i].x, bv.y, c.y);
-                            c.y = __builtin_fma(av[i].y, bv.x, c.y);
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < BS; ++j) {
-                        const cplx bv = cadd(B0[j * RS], B1[j * RS]);
-#pragma unroll
-                        for (int i = 1 - (j & 1); i < AS; i += 2) {   // i + j odd
-                            cplx& c = acc[(i + j) >> 1];
-                            c.x = __builtin_fma(av[i].x, bv.x, c.x);
-                            c.x = __builtin_fma(-av[i].y, bv.y, c.x);
-                            c.y = __builtin_fma(av[i].x, bv.y, c.y);
-                            c.y = __builtin_fma(av[i].y, bv.x, c.y);
-                        }
-                    }
-                }
+#define PZ_PW_HALF(HP_)                                                                                       \
+    {                                                                                                         \
+        constexpr int J0 = WLO > AS - 1 ? WLO - (AS - 1) : 0;                                                 \
+        cplx b0n = B0[J0 * RS], b1n = B1[J0 * RS];   /* row j + 1 is read while row j's multiply-adds issue */ \
+        _Pragma("unroll") for (int j = 0; j < BS; ++j) {                                                      \
+            PZ_XL(j)                                                                                          \
+            if (j >= J0) {                                                                                    \
+                const cplx bv = cadd(b0n, b1n);                                                               \
+                if (j + 1 < BS) { b0n = B0[(j + 1) * RS]; b1n = B1[(j + 1) * RS]; }                           \
+                __builtin_amdgcn_sched_barrier(0);                                                            \
+                _Pragma("unroll") for (int i = ((j & 1) ^ (HP_)); i < AS; i += 2)   /* i + j of parity HP_ */  \
+                    if (i + j >= WLO) PZ_CMAC(acc[(i + j) >> 1], av[i], bv)                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                            \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+                if (hp == 0) PZ_PW_HALF(0) else PZ_PW_HALF(1)
+#undef PZ_PW_HALF
             }
-            __syncthreads();   // every operand value has been read: the result rows take the place of the first operand rows
+#undef PZ_XL
+            PZ_CSTAMP(3)   // limb convolution
+            lds_barrier();   // every operand value has been read: the result rows take the place of the first operand rows
             if (grp < 2) {
 #pragma unroll
-                for (int k = 0; k < NK; ++k) {
+                for (int k = WLO; k < NK; ++k) {
                     const int kk = k - g.offset;
                     if (kk >= 0 && kk < g.min_size) out[kk * RS] = acc[k];
                 }
@@ -404,32 +502,37 @@ __global__ void __launch_bounds__(512) k_mid_cnv3(MidCnv3Args g) {
 #pragma unroll
                 for (int u = 0; u < NKH; ++u) {
                     const int k = 2 * u + hp, kk = k - g.offset;
-                    if (k < NK && kk >= 0 && kk < g.min_size) out[kk * RS] = acc[u];
+                    if (k >= WLO && k < NK && kk >= 0 && kk < g.min_size) out[kk * RS] = acc[u];
                 }
             }
             // product limbs beyond a_size + b_size - 2 are zero (reim4/arithmetic_ref.rs:235-247); groups 0, 1, 2 fill them for their term
             if (grp < 3)
                 for (int kk = max(NK - g.offset, 0); kk < g.min_size; ++kk) out[kk * RS] = make_double2(0.0, 0.0);
         }
-        __syncthreads();
-        // ---- the next tile's operand rows and twiddle row start travelling; inverse row DFT of the 3 x min_size result rows x conj tw12 -> T2' ----
+        lds_barrier();
+        PZ_CSTAMP(4)   // barrier + write-back + barrier
+        // ---- inverse row DFT of the 3 x min_size result rows x conj tw12 -> T2'; the next tile's operand rows and twiddle row start travelling
+        //      in its gaps (four groups of four loads: a vector-memory instruction blocks its wave until the path accepts it) ----
         cplx twn = make_double2(0.0, 0.0);
         __builtin_amdgcn_sched_barrier(0);   // (the loads below must not be hoisted above the convolution: 64 more live registers there spill 300 bytes)
         const int ti = pz_opaque(tid);
         const int row = ti >> 3, o = ti & 7;
-        {
-            const long long Ln = L + gridDim.x;
-            if (tid < M2) twn = g.tw12t[(long long)((Ln < ntiles ? Ln : ntiles - 1) % g.m1) * M2 + tid];
-            if (NR == 64 || row < NR) {   // (512 threads = 64 rows: with 64 operand rows every thread loads - no path on which x would have to survive the convolution)
-                const cplx* src = row_src(Ln, row, o);
-#pragma unroll
-                for (int n1 = 0; n1 < 16; ++n1) x[n1] = ld_stream(src + 8 * n1);
-            } else {
-#pragma unroll
-                for (int n1 = 0; n1 < 16; ++n1) x[n1] = make_double2(0.0, 0.0);
-            }
-        }
-        if (row < 3 * g.min_size) {
+        const long long Ln = L + gridDim.x;
+        const cplx* nsrc = row_src(Ln, (NR == 64 || row < NR) ? row : 0, o);
+#define PZ_XGROUP(G4)                                                                                          \
+    {                                                                                                          \
+        if (NR == 64 || row < NR) {                                                                            \
+            _Pragma("unroll") for (int n1 = 4 * (G4); n1 < 4 * (G4) + 4; ++n1) x[n1] = ld_stream(nsrc + 8 * n1); \
+        } else {                                                                                               \
+            _Pragma("unroll") for (int n1 = 4 * (G4); n1 < 4 * (G4) + 4; ++n1) x[n1] = make_double2(0.0, 0.0); \
+        }                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }
+        if (tid < M2) twn = g.tw12t[(long long)((Ln < ntiles ? Ln : ntiles - 1) % g.m1) * M2 + tid];
+        if (!EARLY) PZ_XGROUP(0)
+        if (!EARLY && !PZ_CNV_SPREAD) { PZ_XGROUP(1) PZ_XGROUP(2) PZ_XGROUP(3) }
+        PZ_CSTAMP(5)   // issue of the next tile's first loads
+        if (row < 3 * g.min_size) {   // (one block: with the four steps as four conditionals the working set is live across their joins - 256 registers + 64 B)
             const int term = row / g.min_size, kk = row % g.min_size;
             const cplx* twrow = twrow2 + par * M2;
             cplx* rowbuf = lds + row * RS;
@@ -439,6 +542,8 @@ __global__ void __launch_bounds__(512) k_mid_cnv3(MidCnv3Args g) {
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) u[8 * h + k2] = rowbuf[o + 8 * h + 16 * k2];
             Bfly<8, true>::run(u);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!EARLY && PZ_CNV_SPREAD) PZ_XGROUP(1)
             Bfly<8, true>::run(u + 8);
             row_sync();
 #pragma unroll
@@ -450,19 +555,39 @@ __global__ void __launch_bounds__(512) k_mid_cnv3(MidCnv3Args g) {
                     if (k1 > 0 && oo > 0) v = cmulc(v, wl[oo * k1]);
                     rowbuf[k1 * 9 + oo] = v;
                 }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!EARLY && PZ_CNV_SPREAD) PZ_XGROUP(2)
             row_sync();
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) u[k1] = rowbuf[k1 * 9 + o];
             Bfly<16, true>::run(u);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!EARLY && PZ_CNV_SPREAD) PZ_XGROUP(3)
             cplx* dst = g.T2 + (((long long)term * g.batch + bt) * g.min_size + kk) * m + (long long)q1 * M2 + o;
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) st_stream(dst + 8 * n1, cmulc(u[n1], twrow[o + 8 * n1]));
+        } else if (!EARLY && PZ_CNV_SPREAD) {
+            PZ_XGROUP(1) PZ_XGROUP(2) PZ_XGROUP(3)
         }
+#undef PZ_XGROUP
         if (tid < M2) twrow2[(par ^ 1) * M2 + tid] = twn;   // the other twiddle row: nobody reads it before the barrier below
+        PZ_CSTAMP(6)   // inverse row transforms + stores (issue)
         lds_barrier();   // the result rows have been consumed: the forward pass of the next tile may overwrite the tile (LDS ordering only -
                          // the stores above drain under the next tile)
+        PZ_CSTAMP(7)   // barrier
+#if PZ_CNV_STAMP
+        ++st_tiles;
+#endif
     }
+#if PZ_CNV_STAMP
+    if ((tid & 63) == 0 && (blockIdx.x == 0 || blockIdx.x == 9 || blockIdx.x == 130 || blockIdx.x == 255))
+        printf("CSTAMP wg %d wave %d tiles %d total %llu | xwait %llu fwd %llu bar1 %llu conv %llu wb %llu issue %llu inv %llu bar2 %llu\n",
+               (int)blockIdx.x, tid >> 6, st_tiles, (unsigned long long)(st_t - st_t0), st_acc[0], st_acc[1], st_acc[2], st_acc[3], st_acc[4],
+               st_acc[5], st_acc[6], st_acc[7]);
+#endif
+#undef PZ_CSTAMP
 }
+#undef PZ_CMAC
 
 // convolution.rs:147-203 + :395-421: res limb kk = sum_j a[kk + offset - j] * b[j], wrapping i64, coefficient-wise
 struct CnvConstArgs {

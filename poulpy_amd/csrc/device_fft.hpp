@@ -51,6 +51,7 @@ __device__ __forceinline__ cplx cmul_t(cplx a, cplx b) { return CONJ ? cmulc(a, 
 #define PZ_STREAM_HINTS 3
 #endif
 typedef double pz_dbl2 __attribute__((ext_vector_type(2)));
+typedef short pz_short2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ cplx ld_stream(const cplx* p) {
     if (PZ_STREAM_HINTS & 1) { const pz_dbl2 v = __builtin_nontemporal_load(reinterpret_cast<const pz_dbl2*>(p)); return make_double2(v.x, v.y); }
     return *p;
@@ -494,6 +495,13 @@ struct TailArgs {
     // 4 -= v; 5 on BOTH further columns: their digits are read and subtracted from the value before it reaches nz_col); res limbs >= nz_zero_from are zero.  The limb count of the transformed value may be smaller than the normalizer's a.size:
     // the missing top-index limbs are zeros and come first in the chain, where they change nothing.
     int nz, nz_lsh, nz_res_end, nz_res_start, nz_a_end, nz_a_start, nz_zero_from, nz_col, nz_mode, nz_col2[2], nz_mode2[2];
+    // 16-bit side copies of the diagonal terms' digits (round 6, TailD16 in internal.hpp; base2k <= 16): [pair][res limb][n] int16, a limb in the
+    // tail's tile order - workgroup block (c0 / CB), then (half h, row j1), then the CB columns: element idx = h m + j1 m2 + c0 + c sits at
+    // (c0 / CB) 2 M1 CB + (idx >> log2 m2) CB + c, so that a wave's store / load of one (h, n1) is one 128-byte run.
+    // d16w: the NZ = 1 launch mirrors every digit it stores; d16a / d16b: the NZ = 2 launch's mode-5 prefetch reads them instead of the low
+    // dwords of the two i64 columns
+    short* d16w;
+    const short *d16a, *d16b;
 };
 __device__ __forceinline__ long long tz_digit(int k, long long x) { return (long long)((unsigned long long)x << (64 - k)) >> (64 - k); }
 __device__ __forceinline__ long long tz_carry(int k, long long x, long long d) { return (long long)((unsigned long long)x - (unsigned long long)d) >> k; }
@@ -540,10 +548,15 @@ __device__ __forceinline__ int sx_carry(int k, int x, int d) { return (x - d) >>
 // glwe_automorphism that carry no body: they ride on the f64 chain like a product's columns instead of the operand variant's integer chain
 // ACC32 (round 5; with SMALL, every column its own operand): the blind rotation's accumulator between two blocks of the pipeline path - operand and /
 // or result as 32-bit digits (TailArgs::acc32), half the bytes of the two streams this kernel moves beside T2'
-template <int R1, int R2, int CB, bool ROWMAJOR = false, bool SMALL = false, bool RSH = false, int NZ = 0, bool SGN = false, bool PROBE = false, bool ACC32 = false>
+template <int R1, int R2, int CB, bool ROWMAJOR = false, bool SMALL = false, bool RSH = false, int NZF = 0, bool SGN = false, bool PROBE = false, bool ACC32 = false>
 __global__ void __launch_bounds__(((R1 == 16 ? 2 : 1) * R2 + R1) * CB, ((((R1 == 16 ? 2 : 1) * R2 + R1) * CB >= 512) ? 1 : (SMALL ? 2 : 3)))
 k_inv_tail(TailArgs g) {
     static_assert(!RSH || SMALL, "the shifted store rides on the integer carry chain");
+    // NZF: 0 none | 1 diagonal tensoring tail | 2 pairwise / raw | 3 = 1 + 16-bit side copy of every digit (TailArgs::d16w) | 4 = 2 with the mode-5
+    // prefetch reading 16-bit side copies (TailArgs::d16a / d16b) instead of the i64 columns' low dwords.  Forms of their own: with both prefetch
+    // paths in one instantiation the pairwise tail went from 12 to 28 B of scratch at its 168-register cap
+    constexpr int NZ = NZF == 3 ? 1 : (NZF == 4 ? 2 : NZF);
+    constexpr bool D16W = NZF == 3, D16R = NZF == 4;
     static_assert(!ACC32 || (ROWMAJOR && SMALL && !RSH && !NZ && !SGN), "32-bit accumulator digits: the plain operand form of the row-major pipeline");
     static_assert(!NZ || (ROWMAJOR && !SMALL && !RSH), "tensoring forms: row-major pipeline layout, no operand");
     static_assert(!SGN || (ROWMAJOR && !SMALL && !RSH && !NZ), "sign-only form: row-major pipeline layout, no operand");
@@ -637,12 +650,17 @@ k_inv_tail(TailArgs g) {
     const long long res_ls = (long long)g.res_cols * n;
     long long* nz_r2a = (NZ && g.nz && g.nz_mode2[0]) ? g.res + (long long)b * g.res_bs + (long long)g.nz_col2[0] * n : nullptr;
     long long* nz_r2b = (NZ && g.nz && g.nz_mode2[1]) ? g.res + (long long)b * g.res_bs + (long long)g.nz_col2[1] * n : nullptr;
+    // 16-bit side copies (TailArgs::d16*): this workgroup's tile of limb r starts at (b res_size + r) n + (c0 / CB) 2 M1 CB
+    const int d16_sh = 31 - __builtin_clz((unsigned)g.m2);
+    const long long d16_base = (long long)b * g.res_size * n + (long long)(c0 / CB) * (2 * M1 * CB);
+#define PZ_TAIL_D16_IDX(R_, IDX_) (d16_base + (long long)(R_) * n + (long long)((((IDX_) >> d16_sh) * CB) + ((IDX_) & (CB - 1))))
 #define PZ_TAIL_NZ_STORE(R_, IDX_, V_)                                                             \
     {                                                                                              \
         const long long off_ = (long long)(R_) * res_ls + (IDX_);                                  \
         long long v_ = (V_);                                                                       \
         if (NZ == 1) {   /* the launcher sends only plain stores here (mode 1, no second column): no test in front of the store */ \
             st_stream(res_col + off_, v_);                                                         \
+            if (D16W) g.d16w[PZ_TAIL_D16_IDX(R_, IDX_)] = (short)v_;                               \
         } else if (g.nz_mode2[0] == 5) {   /* mode 5: a column whose digits are SUBTRACTED from the value on its way to the main column */ \
             v_ = (long long)((unsigned long long)v_ - (unsigned long long)nz_r2a[off_]);           \
             if (nz_r2b) v_ = (long long)((unsigned long long)v_ - (unsigned long long)nz_r2b[off_]); \
@@ -689,9 +707,28 @@ k_inv_tail(TailArgs g) {
         // requested HERE, at the top of the limb, so that their latency hides behind the butterfly - read at the store they were 32 dependent
         // HBM loads per thread and limb, and the pairwise launch ran at 2.8 TB/s against 4.6 for the diagonal ones (profiles/r04_tensor_*).
         // Low dwords only: the values are balanced base2k-bit digits (k <= 31 here; wider digits keep the loads at the store).
-        int d5a[NZ == 2 ? 2 * RE : 1], d5b[NZ == 2 ? 2 * RE : 1];
+        int d5a[NZ == 2 ? 2 * RE : 1], d5b[(NZ == 2 && !D16R) ? 2 * RE : 1];
+        pz_short2 d5p[D16R ? 2 * RE : 1];
         bool d5 = false;
-        if (NZ == 2 && g.nz && g.nz_mode2[0] == 5 && k <= 31 && j >= g.nz_a_end && j < g.nz_a_start) {
+        if (D16R && g.nz && g.nz_mode2[0] == 5 && j >= g.nz_a_end && j < g.nz_a_start) {
+            // the diagonal launches left 16-bit copies of their digits (TailArgs::d16*, base2k <= 16): 2 B per coefficient and column, in this
+            // workgroup's own tile order (one base per thread, constant offsets), instead of the 8 B a line of the i64 column costs
+            d5 = true;
+            const long long rb_ = d16_base + (long long)(j - g.nz_a_start + g.nz_res_start) * n + (b_ov * CB + b_cv) + (SPLIT ? hs * R2 * CB : 0);
+            const short* pa_ = g.d16a + rb_;
+            const short* pb_ = g.d16b ? g.d16b + rb_ : pa_;   // (one diagonal column only: read twice, halved below - never dispatched today)
+#pragma unroll
+            for (int e = 0; e < RE; ++e)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int o_ = h * M1 * CB + (SPLIT ? 2 : 1) * R2 * CB * e;
+                    pz_short2 v_;   // the two digits of a coefficient share one register (d16 loads into the low / high half)
+                    v_.x = pa_[o_];
+                    v_.y = pb_[o_];
+                    d5p[D16R ? 2 * e + h : 0] = v_;
+                }
+        } else
+        if (NZ == 2 && !D16R && g.nz && g.nz_mode2[0] == 5 && k <= 31 && j >= g.nz_a_end && j < g.nz_a_start) {
             d5 = true;
             const long long r5 = (long long)(j - g.nz_a_start + g.nz_res_start) * res_ls;
 #pragma unroll
@@ -816,7 +853,10 @@ k_inv_tail(TailArgs g) {
                                // pairwise instantiation's 88 B of scratch were 2.7 GB of extra HBM writes per launch, profiles/r04_tensor_traffic.json)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < (NZ == 2 ? 2 * RE : 1); ++t) d5a[t] += d5b[t];
+            for (int t = 0; t < (NZ == 2 ? 2 * RE : 1); ++t) {
+                if constexpr (D16R) d5a[t] = (int)d5p[D16R ? t : 0].x + (g.d16b ? (int)d5p[D16R ? t : 0].y : 0);
+                else d5a[t] += d5b[(NZ == 2 && !D16R) ? t : 0];
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         const unsigned long long half = 1ull << (k - 1), mask = (1ull << k) - 1;
@@ -985,6 +1025,7 @@ k_inv_tail(TailArgs g) {
         }
     }
 #undef PZ_TAIL_NZ_STORE
+#undef PZ_TAIL_D16_IDX
 }
 
 #undef PZ_TAIL_N1

@@ -99,8 +99,12 @@ bool mid_cnv3_supported(const pz_module* M, int cols, int a_size, int b_size, in
 int launch_mid_cnv3(pz_module* M, int batch, const cplx* a_main, const cplx* a_last, const cplx* b_main, const cplx* b_last, cplx* T2, int a_size,
                     int min_size, int offset);
 struct NzCombine;
+// 16-bit side copies of the diagonal terms' digits (round 6; base2k <= 16): [pair][res limb][n] int16 in the tail's own tile order.  A diagonal
+// launch (NZ1) mirrors every digit it stores into `w`; the pairwise launch (mode 5) reads `ra` / `rb` instead of the low dwords of the two
+// i64 tensor columns (8 B fetched per coefficient and column for a 12-bit digit: 4.3 of the pairwise launch's 8.8 GB, profiles/r04_tensor_traffic.json)
+struct TailD16 { short* w = nullptr; const short* ra = nullptr; const short* rb = nullptr; };
 int launch_inv_tail_nz(pz_module* M, int batch, const cplx* T, int nlimbs, long long* res, long long res_bs, int res_cols, int res_size, int res_col,
-                       int base2k, long long res_offset, int a_size, const NzCombine* cb);
+                       int base2k, long long res_offset, int a_size, const NzCombine* cb, const TailD16* d16 = nullptr);
 
 // ---- launch_mid.hip -----------------------------------------------------------------------------------------------
 // scratch rows behind T2: one 64-row x 128-point tile per persistent workgroup of k_mid128 (<= 256 of them: 32 MiB), which also covers

@@ -87,14 +87,23 @@ int launch_mid_cnv3(pz_module* M, int batch, const cplx* a_main, const cplx* a_l
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, M->device);
     if (M->cu_count > 0) ncu = M->cu_count;
     const dim3 grid((unsigned)std::min<long long>((long long)batch * g.m1, ncu));   // persistent: one workgroup per CU
-    if (a_size == 16) {
-        PZ_TRY(set_lds((k_mid_cnv3<16, 16>), lds));
-        hipLaunchKernelGGL((k_mid_cnv3<16, 16>), grid, dim3(512), lds, M->stream, g);
-    } else {
-        PZ_TRY(set_lds((k_mid_cnv3<8, 8>), lds));
-        hipLaunchKernelGGL((k_mid_cnv3<8, 8>), grid, dim3(512), lds, M->stream, g);
+    // b = a (glwe_tensor_square_apply): the square form - half the operand rows, symmetric limb products
+    const bool sq = a_main == b_main && a_last == b_last;
+    // the static window: multiply-adds with i + j < WLO are not compiled in; WLO = a_size - 4 when the offset allows it (CKKS keeps the top limbs
+    // of the product: offset ~ a_size), else 0
+    const int wlo = offset >= a_size - 4 ? a_size - 4 : 0;
+#define PZ_CNV3_LAUNCH(K_) { PZ_TRY(set_lds((K_), lds)); hipLaunchKernelGGL((K_), grid, dim3(512), lds, M->stream, g); }
+#define PZ_CNV3_FORMS(AS_)                                                                                                  \
+    {                                                                                                                       \
+        if (sq && wlo) PZ_CNV3_LAUNCH((k_mid_cnv3<AS_, AS_, true, AS_ - 4>))                                                \
+        else if (sq) PZ_CNV3_LAUNCH((k_mid_cnv3<AS_, AS_, true, 0>))                                                        \
+        else if (wlo) PZ_CNV3_LAUNCH((k_mid_cnv3<AS_, AS_, false, AS_ - 4>))                                                \
+        else PZ_CNV3_LAUNCH((k_mid_cnv3<AS_, AS_, false, 0>))                                                               \
     }
-    dispatch_note(M, "k_mid_cnv3<%d,%d> (3 terms, %d limbs each)", a_size, a_size, min_size);
+    if (a_size == 16) PZ_CNV3_FORMS(16) else PZ_CNV3_FORMS(8)
+#undef PZ_CNV3_FORMS
+#undef PZ_CNV3_LAUNCH
+    dispatch_note(M, "k_mid_cnv3<%d,%d> SQ=%d WLO=%d (3 terms, %d limbs each, product limbs [%d, %d))", a_size, a_size, (int)sq, wlo, min_size, offset, offset + min_size);
     PZ_HIP(hipGetLastError());
     return PZ_OK;
 }

@@ -24,7 +24,7 @@ bool tail_rsh_supported(const pz_module* M) {
     return false;
 }
 
-struct TailNz { int lsh, res_end, res_start, a_end, a_start, zero_from, col, mode, col2[2], mode2[2]; };
+struct TailNz { int lsh, res_end, res_start, a_end, a_start, zero_from, col, mode, col2[2], mode2[2]; TailD16 d16; };
 // columns [col_base, col_base + col_count) of the big value in one launch; raw / nz: the tensoring forms (launch_inv_tail_raw / _nz)
 static TailArgs tail_args(const pz_module* M, const TailCall& c, int col_base, int col_count, bool raw, const TailNz* nz) {
     TailArgs g;
@@ -44,6 +44,7 @@ static TailArgs tail_args(const pz_module* M, const TailCall& c, int col_base, i
     for (int u = 0; u < 2; ++u) { g.nz_col2[u] = nz ? nz->col2[u] : 0; g.nz_mode2[u] = nz ? nz->mode2[u] : 0; }
     g.acc32 = c.acc32;
     g.xcd_map = 0;
+    g.d16w = nz ? nz->d16.w : nullptr; g.d16a = nz ? nz->d16.ra : nullptr; g.d16b = nz ? nz->d16.rb : nullptr;
     return g;
 }
 static int launch_inv_tail_cols(pz_module* M, const TailCall& c, int col_base, int col_count, bool raw = false, const TailNz* nz = nullptr) {
@@ -82,6 +83,12 @@ static int launch_inv_tail_cols(pz_module* M, const TailCall& c, int col_base, i
         if (nz && !(nz->lsh >= 0 && nz->lsh < c.base2k)) return fail(PZ_ERR_INVALID, "fused tail: normalizing store needs 0 <= lsh < base2k");
         // raw values, or any NzCombine mode (pairwise term: with the prefetch of the diagonal digits): NZ2; the diagonal launches: NZ1
         f.kind = (raw || !(nz->mode == 1 && nz->mode2[0] == 0 && nz->mode2[1] == 0)) ? TailForm::NZ2 : TailForm::NZ1;
+        // 16-bit side copies (TailD16): the diagonal launch that writes them, the pairwise launch (mode 5) that reads them
+        if (nz && f.kind == TailForm::NZ1 && nz->d16.w) f.kind = TailForm::NZ1W;
+        if (nz && f.kind == TailForm::NZ2 && nz->d16.ra) {
+            if (!(nz->mode2[0] == 5)) return fail(PZ_ERR_INVALID, "fused tail: 16-bit side copies are read by the mode-5 pairwise launch only");
+            f.kind = TailForm::NZ2R;
+        }
     }
     // the rounding-margin instantiation of the same form when the module's probe is on (pz_module_set_margin_probe): the same source with the
     // probe block compiled in, so that the margin is measured on the form the product path dispatches (launch_tail_probe.hip)
@@ -120,7 +127,7 @@ int launch_inv_tail(pz_module* M, const TailCall& c) {
 // the first nlimbs are transformed and the rest are zero) and NzCombine's stores into `res` (GLWE tensoring: raw inverse pass + normalize
 // kernel in one; TailArgs::nz)
 int launch_inv_tail_nz(pz_module* M, int batch, const cplx* T, int nlimbs, long long* res, long long res_bs, int res_cols, int res_size, int res_col,
-                       int base2k, long long res_offset, int a_size, const NzCombine* cb) {
+                       int base2k, long long res_offset, int a_size, const NzCombine* cb, const TailD16* d16) {
     const long long k = base2k;
     long long lsh = res_offset % k, lo = res_offset / k;
     if (res_offset < 0 && lsh != 0) { lsh = (lsh + k) % k; lo -= 1; }
@@ -135,6 +142,10 @@ int launch_inv_tail_nz(pz_module* M, int batch, const cplx* T, int nlimbs, long 
     nz.col = res_col;
     nz.mode = cb ? cb->mode : 1;
     for (int u = 0; u < 2; ++u) { nz.col2[u] = cb ? cb->col2[u] : 0; nz.mode2[u] = cb ? cb->mode2[u] : 0; }
+    if (d16) {
+        PZ_REQUIRE(base2k <= 16, "fused tail: 16-bit side copies of the digits need base2k <= 16");
+        nz.d16 = *d16;
+    }
     TailCall c;
     c.batch = batch; c.T = T; c.rowmajor = true; c.nlimbs = nlimbs; c.ncols = 1;
     c.res = res; c.res_bs = res_bs; c.res_cols = res_cols; c.res_size = res_size; c.base2k = base2k;

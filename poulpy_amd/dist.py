@@ -16,11 +16,15 @@ def shard_range(total: int, world: int, rank: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def broadcast_key(pmat, src: int = 0, bucket_bytes: int = 64 << 20):
+def broadcast_key(pmat, src: int = 0, bucket_bytes: int = 0):
     """Broadcast a prepared key (a flat torch tensor, device or host) from `src` to all ranks
-    in buckets of `bucket_bytes` (xGMI links are point-to-point: a few large transfers, not many
-    small ones)."""
+    in buckets of `bucket_bytes` (default 64 MiB; POULPY_BCAST_BUCKET_BYTES overrides it - the CPU tests use small buckets; xGMI links are
+    point-to-point: a few large transfers, not many small ones)."""
+    import os
+
     import torch.distributed as dist
+
+    bucket_bytes = bucket_bytes or int(os.environ.get("POULPY_BCAST_BUCKET_BYTES", str(64 << 20)))
 
     flat = pmat.view(-1)
     per = max(1, bucket_bytes // flat.element_size())
@@ -79,11 +83,15 @@ def broadcast_key_agreed(mod, pmat, src: int = 0, route: str = "auto", log=None)
     world, rank = dist.get_world_size(), dist.get_rank()
     err = None
     have_comm = mod.lib.pz_comm_world_size(mod.handle) != 0
-    # step 1 (local): RCCL loads here and an id can be drawn (every rank probes; only src's id is used)
+    # step 1 (local): RCCL loads here; only src draws an id (ncclGetUniqueId opens a bootstrap listener: the other ranks probe with
+    # pz_comm_available, which loads the library and nothing else)
     my_id = None
     if not have_comm:
         try:
-            my_id = mod.comm_unique_id()
+            if rank == src:
+                my_id = mod.comm_unique_id()
+            else:
+                mod.comm_available()
         except Exception as e:   # noqa: BLE001 - any failure means "not by this route"
             err = e
     ok = all_agree(err is None)
@@ -91,15 +99,22 @@ def broadcast_key_agreed(mod, pmat, src: int = 0, route: str = "auto", log=None)
     if ok and not all_agree(have_comm):
         if have_comm:   # a communicator on some ranks only: start over on all of them
             mod.comm_destroy()
-        obj = [my_id if rank == src else None]
-        dist.broadcast_object_list(obj, src=src)
-        try:
-            mod.comm_init_rank(world, rank, obj[0])
-        except Exception as e:   # noqa: BLE001
-            err = e
-        ok = all_agree(err is None)
-        if not ok and err is None:
-            mod.comm_destroy()
+        if rank == src and my_id is None:   # src had a communicator (so it drew no id in step 1) and another rank did not
+            try:
+                my_id = mod.comm_unique_id()
+            except Exception as e:   # noqa: BLE001
+                err = e
+        ok = all_agree(err is None)   # nobody enters ncclCommInitRank with an id that was never drawn
+        if ok:
+            obj = [my_id if rank == src else None]
+            dist.broadcast_object_list(obj, src=src)
+            try:
+                mod.comm_init_rank(world, rank, obj[0])
+            except Exception as e:   # noqa: BLE001
+                err = e
+            ok = all_agree(err is None)
+            if not ok and err is None:
+                mod.comm_destroy()
     if not ok:
         if route == "cabi":
             raise RuntimeError(f"rank {rank}: the C-ABI communicator is not available on every rank" + (f" (here: {err})" if err else ""))

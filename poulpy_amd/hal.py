@@ -681,6 +681,10 @@ class Module:
         self._ck(self.lib.pz_lwe_from_glwe_batched(self.handle, res, c_size_t(res_n_lwe), a, c_size_t(a_idx), ksk_pmat, C.byref(params), c_size_t(batch)))
 
     # -- multi-GPU: RCCL broadcast of prepared keys on the module stream ---------------------
+    def comm_available(self):
+        """Raises unless RCCL can be loaded in this process (pz_comm_available: dlopen + symbols; draws no id, opens no socket)."""
+        self._ck(self.lib.pz_comm_available())
+
     def comm_unique_id(self) -> bytes:
         """ncclGetUniqueId (call on ONE rank, ship the bytes to the others out of band)."""
         n = self.lib.pz_comm_unique_id_bytes()

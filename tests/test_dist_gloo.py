@@ -111,6 +111,11 @@ class _FakeModule:
         self.lib = _FakeLib(self)
         self.calls = []
 
+    def comm_available(self):
+        self.calls.append("probe")
+        if self.fail_id:
+            raise RuntimeError("RCCL not found (dlopen librccl.so.1)")
+
     def comm_unique_id(self):
         self.calls.append("id")
         if self.fail_id:
@@ -164,6 +169,13 @@ def _agree_worker(rank, world, port, outq):
         results["cabi_strict"] = "no error"
     except RuntimeError as e:
         results["cabi_strict"] = "raised" + (" here" if "here:" in str(e) else "")
+    # (e) ADVICE r05: src already has a communicator, rank 1 has none -> src destroys its own, draws a FRESH id, both initialise, route "cabi"
+    m = _FakeModule()
+    if rank == 0:
+        m.comm, m.world = True, world
+    key = torch.full((10,), 5.0 if rank == 0 else 0.0)
+    route = pdist.broadcast_key_agreed(m, key, src=0, route="cabi")
+    results["src_has_comm"] = (route, list(m.calls), m.comm)
     outq.put((rank, results))
     dist.barrier()
     dist.destroy_process_group()
@@ -184,10 +196,12 @@ def test_broadcast_route_is_agreed_before_any_collective():
         p.join(timeout=60)
         assert p.exitcode == 0
     for r in range(world):
-        assert got[r]["ok"] == ("cabi", ["id", "init", "bcast"])
+        assert got[r]["ok"] == ("cabi", ["id" if r == 0 else "probe", "init", "bcast"])   # only src draws an id (ncclGetUniqueId opens a listener)
         route, calls, total = got[r]["no_rccl_on_1"]
         assert route == "torch" and "init" not in calls and "bcast" not in calls and total == 7000.0
         route, calls, total, comm = got[r]["init_fails_on_1"]
         assert route == "torch" and "bcast" not in calls and total == 30.0 and comm is False
     assert got[0]["init_fails_on_1"][1] == ["id", "init", "destroy"]
+    assert got[0]["src_has_comm"] == ("cabi", ["destroy", "id", "init", "bcast"], True)
+    assert got[1]["src_has_comm"] == ("cabi", ["probe", "init", "bcast"], True)
     assert got[0]["cabi_strict"] == "raised" and got[1]["cabi_strict"] == "raised here"

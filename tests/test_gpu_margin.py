@@ -1,8 +1,9 @@
 """The rounding margin as a first-class output, for every kernel family that rounds ("fp tolerance must be documented",
 poulpy-hal/docs/backend_safety_contract.md:25-27; SURVEY.md 7 "exactness margin").
 
-pz_module_set_margin_probe switches each rounding kernel of a call to its probing form IN THE SAME DISPATCH (k_inv_tail<.., PROBE> for
-every form of the fused tail; a run-time test in k_small_inv, k_small_idft, k_br_fused and k_inv_pass1): the results must stay bit-identical
+pz_module_set_margin_probe switches each rounding kernel of a call to its probing form IN THE SAME DISPATCH (compile-time PROBE
+instantiations in their own translation units for every form of the fused tail, k_br_fused and k_inv_pass1 - launch_tail_probe.hip,
+launch_br_probe.hip; a run-time wave-uniform test in k_small_inv and k_small_idft): the results must stay bit-identical
 to the oracle's, and the margin max |x - round(x)| must be (a) non-zero - the probe really ran on this path, (b) far from 0.5 at the
 reference's parameters, (c) growing with base2k the way the error model says (about x4 per bit)."""
 import numpy as np

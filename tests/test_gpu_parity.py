@@ -2428,6 +2428,62 @@ def test_glwe_ops_on_pinned_host_containers_duplex(mods, n, size):
             hip.lib.pz_free_bytes(C.c_void_p(ptr))
 
 
+def test_pinned_host_in_place_mismatch_and_partial_overlap(mods):
+    """the duplex host path runs in front of glwe_args_in and used to skip its in-place check - res == a with a larger res
+    layout let every wave write past the a-sized arena block.  Now: PZ_ERR_INVALID before anything is launched (as on the serial path), and host
+    ranges that overlap without being equal take the serial path (whole input on the device before the first result travels back): correct
+    results for the non-overlapped... whole batch."""
+    import ctypes as C
+    from poulpy_amd.hal import GlweOpParams, PoulpyHipError
+    n, size, rank, base2k, batch = 4096, 3, 1, 12, 6
+    ref, hip = mods(n)
+    rng = seeded(9157)
+    cols = rank + 1
+
+    def pinned(shape, dtype):
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = hip.lib.pz_alloc_bytes(C.c_size_t(nbytes))
+        assert ptr
+        return np.frombuffer((C.c_char * nbytes).from_address(ptr), dtype=dtype).reshape(shape), ptr
+    hp = lambda arr: arr.ctypes.data_as(C.c_void_p)
+    held = []
+    try:
+        mat = MatZnx(n, size, cols, cols, size).fill_uniform(base2k, rng)
+        pr, ph = ref.vmp_pmat_alloc(size, cols, cols, size), hip.vmp_pmat_alloc(size, cols, cols, size)
+        ref.vmp_prepare(pr, mat)
+        hip.vmp_prepare(ph, mat)
+        key_host, kp = pinned(ph.data.shape, np.float64)
+        held.append(kp)
+        key_host[...] = ph.data
+        # (1) in place with res_size > a_size: refused, nothing written
+        big, bp = pinned((batch, size + 1, cols, n), np.int64)
+        held.append(bp)
+        big[...] = 0x3C3C
+        p_bad = GlweOpParams(rank=rank, dnum=size, dsize=1, key_size=size, key_base2k=base2k, a_size=size, a_base2k=base2k, res_size=size + 1,
+                             res_base2k=base2k, rank_out=rank)
+        with pytest.raises(PoulpyHipError, match="in-place"):
+            hip.glwe_external_product_batched(hp(big), hp(big), hp(key_host), p_bad, batch)
+        assert (big == 0x3C3C).all()
+        # (2) res overlaps a, shifted by one ciphertext: the serial path, every result against the oracle
+        p = GlweOpParams(rank=rank, dnum=size, dsize=1, key_size=size, key_base2k=base2k, a_size=size, a_base2k=base2k, res_size=size,
+                         res_base2k=base2k, rank_out=rank)
+        buf, pp = pinned((batch + 1, size, cols, n), np.int64)
+        held.append(pp)
+        want = np.empty((batch, size, cols, n), dtype=np.int64)
+        for t in range(batch):
+            a = VecZnx(n, cols, size).fill_uniform(base2k, rng)
+            buf[t + 1] = a.data
+            r = VecZnx(n, cols, size)
+            ref.glwe_external_product(r, base2k, a, base2k, pr, 1, base2k)
+            want[t] = r.data
+        hip.glwe_external_product_batched(hp(buf[0:]), hp(buf[1:]), hp(key_host), p, batch)   # res = a - one ciphertext
+        assert np.array_equal(buf[:batch], want), "partially overlapping pinned host ranges"
+    finally:
+        hip.sync()
+        for ptr in held:
+            hip.lib.pz_free_bytes(C.c_void_p(ptr))
+
+
 @pytest.mark.parametrize("n,rank,blk,dnum,bsz,rsz,k", [
     (2048, 1, 3, 2, 3, 2, 15),     # small-ring path (chained forward transform, 32-bit digits between blocks)
     (1024, 2, 3, 2, 3, 3, 14),     # rank 2 at N = 1024: small-ring path with the 9 / 6-row block step

@@ -6,7 +6,11 @@ base2k 18, dnum 1, key size 2, res size 1); `cbt` = the blind-rotation layout of
 (circuit_bootstrapping.rs:48-55: n_glwe 1024, n_lwe 574, base2k 13, dnum 3, rank 1), block size 7.
 Synthetic key material (uniform digits); the oracle is timed single-threaded on a few ciphertexts beside it.
 
-    python tools/bench_blind_rotation.py [--shape ref|cbt] [--batch 1024] [--reps 3]
+    python tools/bench_blind_rotation.py [--shape ref|cbt] [--batch 1024] [--reps 3] [--gpus N]
+
+--gpus N (round 6; BASELINE configs[3]: "batch = 8192 sharded over 8 MI355X" = 1024 per GPU): one rank per GPU (tools/multirank.py), `--batch`
+LWE ciphertexts per GPU (weak scaling), the blind-rotation key - n_lwe prepared GGSWs - and the key-switching key prepared on rank 0 and
+broadcast once (poulpy_amd.dist.broadcast_key_agreed: pz_bcast_key = RCCL inside the C ABI, or torch.distributed); no other collective.
 """
 import argparse
 import ctypes as C
@@ -42,8 +46,12 @@ def main():
     ap.add_argument("--with-keyswitch", action="store_true",
                     help="also time blind rotation + GLWE key switch of the result (the two heavy steps of a gate bootstrap, "
                          "BASELINE configs[3]); rank-1 shapes only")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import multirank
+    multirank.add_arguments(ap)
     args = ap.parse_args()
-    import torch
+    R = multirank.enter(__file__, args.gpus, sys.argv[1:])   # --gpus N > 1 started plainly: launches the ranks and exits with their code
+    torch, dist = R.init()
     from poulpy_amd.hal import BlindRotationParams, GlweOpParams, Module
     s = dict(SHAPES[args.shape])
     if args.block_size:
@@ -53,22 +61,26 @@ def main():
     if args.n_lwe:
         s["n_lwe"] = args.n_lwe
     n, cols = s["n"], s["rank"] + 1
-    dev = torch.device("cuda", 0)
-    mod = Module(n, device=0)
+    dev = R.dev
+    mod = Module(n, device=R.local_rank)
     half = 1 << (s["base2k"] - 1)
     g = torch.Generator(device=dev)
     g.manual_seed(7)
     pm_elems = n * s["dnum"] * cols * cols * s["brk_size"]
     brk = torch.empty((s["n_lwe"], pm_elems), dtype=torch.float64, device=dev)
-    mat = torch.randint(-half, half, (pm_elems,), dtype=torch.int64, device=dev, generator=g)
-    for i in range(s["n_lwe"]):   # same synthetic GGSW for every coefficient would let caches lie: permute it per key
+    mat = torch.randint(-half, half, (pm_elems,), dtype=torch.int64, device=dev, generator=g)   # (same seed on every rank: the lookup table and the key digits of the CPU check)
+    for i in range(s["n_lwe"] if R.rank == 0 else 0):   # rank 0 prepares the key; same synthetic GGSW for every coefficient would let caches lie: permute it per key
         mi = torch.roll(mat, i * 977)
         torch.cuda.synchronize()   # torch's stream and the module's stream are not ordered: the roll must have finished
         mod._ck(mod.lib.pz_vmp_prepare(mod.handle, C.c_void_p(brk[i].data_ptr()), C.c_void_p(mi.data_ptr()), C.c_size_t(s["dnum"]),
                                        C.c_size_t(cols), C.c_size_t(cols), C.c_size_t(s["brk_size"])))
         mod.sync()   # device-pointer calls are stream-ordered on the module's stream: `mi` must outlive the kernels that read it
     mod.sync()
+    # the only collective: the whole blind-rotation key (n_lwe prepared GGSWs, several 64 MiB buckets) from rank 0 to every rank
+    route = R.broadcast_keys(mod, [brk], args.bcast, log=lambda m: print(f"[bench_blind_rotation] {m}", file=sys.stderr, flush=True))
     lut = torch.randint(-half, half, (s["res_size"], 1, n), dtype=torch.int64, device=dev, generator=g)
+    lo, hi = R.shard(args.batch * R.world)   # this rank's block of the global batch (weak scaling: args.batch per GPU)
+    g.manual_seed(0xB007 + lo)               # the LWE ciphertexts of a rank are drawn from its first global index
     lwe = torch.randint(-n, n, (args.batch, s["n_lwe"] + 1), dtype=torch.int64, device=dev, generator=g)
     res = torch.empty((args.batch, s["res_size"], cols, n), dtype=torch.int64, device=dev)
     p = BlindRotationParams(rank=s["rank"], n_lwe=s["n_lwe"], block_size=s["block_size"], dnum=s["dnum"], brk_size=s["brk_size"],
@@ -78,11 +90,14 @@ def main():
     mod.dispatch_notes(reset=True)
     mod.blind_rotation_execute_batched(ptr(res), ptr(lwe), ptr(lut), ptr(brk), p, args.batch)   # warm-up
     mod.sync()
+    R.sync_all()
     t0 = time.perf_counter()
     for _ in range(args.reps):
         mod.blind_rotation_execute_batched(ptr(res), ptr(lwe), ptr(lut), ptr(brk), p, args.batch)
     mod.sync()
-    dt = (time.perf_counter() - t0) / args.reps
+    R.sync_all()
+    dt_mine = (time.perf_counter() - t0) / args.reps
+    dt = R.max_seconds(dt_mine)   # the slowest rank's clock around the same barrier-bracketed region
     mod.set_kernel_timing(True)   # one more pass with per-class HIP-event timing (adds event overhead: not the timed run)
     mod.blind_rotation_execute_batched(ptr(res), ptr(lwe), ptr(lut), ptr(brk), p, args.batch)
     mod.sync()
@@ -93,10 +108,16 @@ def main():
     if args.with_keyswitch and s["rank"] == 1:
         # key-switching key: GGLWE rows = dnum, cols_in = 1, cols_out = 2, same size / base2k as the accumulator
         ksz = s["res_size"]
+        g.manual_seed(0x4B53)   # the key digits: the same on every rank (rank 0 prepares and broadcasts, every rank's CPU check re-prepares them)
         kmat = torch.randint(-half, half, (n * ksz * 1 * cols * ksz,), dtype=torch.int64, device=dev, generator=g)
+        g.manual_seed(0xB107 + lo)
         kpm = torch.empty(kmat.numel(), dtype=torch.float64, device=dev)
-        mod._ck(mod.lib.pz_vmp_prepare(mod.handle, C.c_void_p(kpm.data_ptr()), C.c_void_p(kmat.data_ptr()), C.c_size_t(ksz), C.c_size_t(1),
-                                       C.c_size_t(cols), C.c_size_t(ksz)))
+        torch.cuda.synchronize()
+        if R.rank == 0:
+            mod._ck(mod.lib.pz_vmp_prepare(mod.handle, C.c_void_p(kpm.data_ptr()), C.c_void_p(kmat.data_ptr()), C.c_size_t(ksz), C.c_size_t(1),
+                                           C.c_size_t(cols), C.c_size_t(ksz)))
+            mod.sync()
+        R.broadcast_keys(mod, [kpm], route or args.bcast)
         kp = GlweOpParams(rank=1, dnum=ksz, dsize=1, key_size=ksz, key_base2k=s["base2k"], a_size=ksz, a_base2k=s["base2k"],
                           res_size=ksz, res_base2k=s["base2k"], rank_out=1)
         # the whole gate bootstrap on the device (BASELINE configs[3]): 2-limb LWE -> mod_switch_2n -> blind rotation ->
@@ -111,14 +132,16 @@ def main():
             mod.lwe_from_glwe_batched(ptr(lwe_out), s["n_lwe"], ptr(res), 0, ptr(kpm), kp, args.batch)
         bootstrap()
         mod.sync()
+        R.sync_all()
         t0 = time.perf_counter()
         for _ in range(args.reps):
             bootstrap()
         mod.sync()
-        dtb = (time.perf_counter() - t0) / args.reps
-        ks_stats = {"gate_bootstraps_per_s": args.batch / dtb, "ms_per_batch": dtb * 1e3,
+        R.sync_all()
+        dtb = R.max_seconds((time.perf_counter() - t0) / args.reps)
+        ks_stats = {"gate_bootstraps_per_s": args.batch * R.world / dtb, "ms_per_batch": dtb * 1e3,
                     "steps": "lwe_mod_switch_2n + blind_rotation_execute + lwe_from_glwe (key switch + sample extract), all device-resident"}
-    out = {"metric": "CGGI blind rotations/s", "shape": args.shape, **s, "batch": args.batch, "value": args.batch / dt,
+    out = {"metric": "CGGI blind rotations/s", "shape": args.shape, **s, "batch": args.batch, "value": args.batch * R.world / dt, "unit": "rotations/s",
            "ms_per_batch": dt * 1e3, "rounding_margin": margin, "kernel_classes_launches_ms": kstats, "digits_balanced": bool((res.min() >= -half).item() and (res.max() < half).item())}
     # which kernel instantiations ran, and the rotation priced against the three ceilings that can bound it (tools/roofline_models.py)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -126,7 +149,7 @@ def main():
     notes = mod.dispatch_notes()
     model = rm.blind_rotation(n, s["n_lwe"], s["rank"], s["block_size"], s["dnum"], s["brk_size"], s["res_size"], args.batch)
     out["dispatch"] = notes
-    out["roofline"] = rm.roofline(out["value"], model, rm.key_share(notes))
+    out["roofline"] = rm.roofline(out["value"] / R.world, model, rm.key_share(notes))   # per GPU
     if ks_stats:
         out["gate_bootstrap"] = ks_stats
     # CPU port beside it (single thread) on a few of the same ciphertexts, and parity on those
@@ -170,7 +193,21 @@ def main():
                 acc = VecZnx(n, cols, s["res_size"], np.ascontiguousarray(got[b]))
                 ok2 = ok2 and bool(np.array_equal(ref.lwe_from_glwe(s["n_lwe"], ksz, s["base2k"], acc, s["base2k"], 0, kpr, 1, s["base2k"]), lout[b]))
             out["gate_bootstrap"]["parity_on_cpu_sample"] = ok2
-    print(json.dumps(out))
+    # every rank checked its own sample; the line reports the AND, the per-rank block and the job-level fields (tools/multirank.py)
+    mine = {"value": args.batch / dt_mine, "ms_per_batch": dt_mine * 1e3, "global_first_index": lo, "parity_ok": out.get("parity_on_cpu_sample"),
+            "rounding_margin": margin, "device": R.local_rank}
+    per_rank = R.gather(mine)
+    all_ok = R.all_true(out.get("parity_on_cpu_sample"))
+    if R.distributed:
+        out["parity_on_cpu_sample"] = all_ok if args.cpu_cts else None
+        out["rounding_margin"] = max(e["rounding_margin"] for e in per_rank)
+    out.update(R.line_fields(out["value"], args.ref_value, route, mod))
+    out["per_rank"] = per_rank
+    if R.rank == 0:
+        print(json.dumps(out), flush=True)
+    R.finish()
+    if all_ok is False:
+        raise SystemExit(3)   # a fast wrong answer is not a result
 
 
 if __name__ == "__main__":

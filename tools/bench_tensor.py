@@ -5,7 +5,10 @@ N = 2^16, rank 1, 16 limbs, base2k 12 (so that FFT64 represents it).  Device-res
 a few outputs are compared bit for bit with the oracle's composition (cnv_prepare_left / right, cnv_apply_dft, cnv_pairwise_apply_dft,
 idft, normalize).
 
-    python tools/bench_tensor.py [--batch 256] [--limbs 16] [--n 65536] [--steps 10] [--mode apply|square]
+    python tools/bench_tensor.py [--batch 256] [--limbs 16] [--n 65536] [--steps 10] [--mode apply|square] [--relin] [--gpus N]
+
+--gpus N (round 6; BASELINE configs[4]: "batch = 2048 sharded over 8 MI355X" = 256 per GPU): one rank per GPU (tools/multirank.py), `--batch`
+pairs per GPU (weak scaling); with --relin the tensor key is prepared on rank 0 and broadcast once (broadcast_key_agreed); no other collective.
 """
 import argparse
 import json
@@ -30,17 +33,22 @@ def main():
     ap.add_argument("--parity-samples", type=int, default=2)
     ap.add_argument("--relin", action="store_true", help="follow every tensoring with glwe_tensor_relinearize (tensor key 1 -> 1, dnum = limbs): "
                     "the whole GLWE multiplication of a CKKS multiply (operations/glwe.rs:541-607 after :700-807)")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import multirank
+    multirank.add_arguments(ap)
     args = ap.parse_args()
+    R = multirank.enter(__file__, args.gpus, sys.argv[1:])   # --gpus N > 1 started plainly: launches the ranks and exits with their code
     import ctypes as C
-    import torch
+    torch, dist = R.init()
     from poulpy_amd.hal import GlweOpParams, GlweTensorParams, Module
     from poulpy_amd.layouts import MatZnx, VecZnx
     n, size, k, rank = args.n, args.limbs, args.base2k, 1
     cols, tcols = rank + 1, (rank + 1) * (rank + 2) // 2
-    dev = torch.device("cuda", 0)
-    mod = Module(n, device=0)
+    dev = R.dev
+    mod = Module(n, device=R.local_rank)
     g = torch.Generator(device=dev)
-    g.manual_seed(0x7e50)
+    lo, hi = R.shard(args.batch * R.world)   # this rank's block of the global batch (weak scaling: args.batch pairs per GPU)
+    g.manual_seed(0x7e50 + lo)               # a rank's operands are drawn from its first global index (rank 0 of any world: the round-5 inputs)
     half = 1 << (k - 1)
     a = torch.randint(-half, half, (args.batch, size, cols, n), dtype=torch.int64, device=dev, generator=g)
     b = a if args.mode == "square" else torch.randint(-half, half, (args.batch, size, cols, n), dtype=torch.int64, device=dev, generator=g)
@@ -51,15 +59,19 @@ def main():
                          res_base2k=k, cnv_offset=cnv_offset)
 
     # --relin: a tensor key (GGLWE rank*(rank+1)/2 -> rank: rows = dnum, cols_in = 1, cols_out = 2), synthetic digits, prepared on the device
-    out = pmat = mat = rp = None
+    out = pmat = mat = rp = route = None
     if args.relin:
         dnum = size
-        mat = torch.randint(-half, half, (n * dnum * 1 * cols * size,), dtype=torch.int64, device=dev, generator=g)
+        gk = torch.Generator(device=dev)
+        gk.manual_seed(0x7e51)   # the key digits: the same on every rank (rank 0 prepares and broadcasts; every rank's CPU check re-prepares them)
+        mat = torch.randint(-half, half, (n * dnum * 1 * cols * size,), dtype=torch.int64, device=dev, generator=gk)
         pmat = torch.empty(mat.numel(), dtype=torch.float64, device=dev)
         torch.cuda.synchronize()
-        mod._ck(mod.lib.pz_vmp_prepare(mod.handle, C.c_void_p(pmat.data_ptr()), C.c_void_p(mat.data_ptr()), C.c_size_t(dnum), C.c_size_t(1),
-                                       C.c_size_t(cols), C.c_size_t(size)))
-        mod.sync()
+        if R.rank == 0:
+            mod._ck(mod.lib.pz_vmp_prepare(mod.handle, C.c_void_p(pmat.data_ptr()), C.c_void_p(mat.data_ptr()), C.c_size_t(dnum), C.c_size_t(1),
+                                           C.c_size_t(cols), C.c_size_t(size)))
+            mod.sync()
+        route = R.broadcast_keys(mod, [pmat], args.bcast, log=lambda m: print(f"[bench_tensor] {m}", file=sys.stderr, flush=True))   # the only collective
         mod.pin_key(C.c_void_p(pmat.data_ptr()), dnum, 1, cols, size)
         out = torch.zeros((args.batch, size, cols, n), dtype=torch.int64, device=dev)
         rp = GlweOpParams(rank=rank, dnum=dnum, dsize=1, key_size=size, key_base2k=k, a_size=size, a_base2k=k, res_size=size, res_base2k=k, rank_out=rank)
@@ -74,11 +86,14 @@ def main():
     for _ in range(args.warmup):
         run()
     mod.sync()
+    R.sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
     mod.sync()
-    dt = (time.perf_counter() - t0) / args.steps
+    R.sync_all()
+    dt_mine = (time.perf_counter() - t0) / args.steps
+    dt = R.max_seconds(dt_mine)   # the slowest rank's clock around the same barrier-bracketed region
     mod.set_kernel_timing(True)
     run()
     mod.sync()
@@ -114,17 +129,27 @@ def main():
     import roofline_models as rm
     model = rm.tensoring(n, rank, size, args.mode, args.relin, args.batch)   # the byte / flop model lives beside the other benched operations'
     nb, flops = model["hbm_bytes"], model["flops"]
-    rate = args.batch / dt
-    print(json.dumps({
+    rate = args.batch * R.world / dt
+    per_rank = R.gather({"value": args.batch / dt_mine, "ms_per_step": dt_mine * 1e3, "global_first_index": lo, "parity_ok": ok, "rounding_margin": margin,
+                         "device": R.local_rank})
+    all_ok = R.all_true(ok)
+    if R.distributed:
+        ok = all_ok if args.parity_samples else None
+        margin = max(e["rounding_margin"] for e in per_rank)
+    if R.rank == 0:
+        print(json.dumps({**R.line_fields(rate, args.ref_value, route, mod), "per_rank": per_rank,
         "metric": ("GLWE multiplications/s (glwe_tensor_%s + glwe_tensor_relinearize)" if args.relin else "GLWE tensorings/s (glwe_tensor_%s)") % ("apply" if args.mode == "apply" else "square_apply"),
         "value": rate, "unit": "multiplications/s" if args.relin else "tensorings/s", "ms_per_step": dt * 1e3, "batch": args.batch, "parity_ok": ok, "rounding_margin": margin,
         "config": {"workload": f"glwe_tensor_{args.mode}" + (" + glwe_tensor_relinearize (tensor key 1 -> 1, dnum = limbs)" if args.relin else "") + f" (rank 1: 2-column GLWE x GLWE -> 3-column GLWETensor), N={n}, {size} limbs, base2k={k}, cnv_offset={cnv_offset}",
                    "batch_per_gpu": args.batch},
         "kernel_classes_launches_ms": stats,
         "knobs": {k_: v_ for k_, v_ in os.environ.items() if k_.startswith("POULPY_DBG_")},
-        "roofline": {"bound": "hbm", "achieved": rate * nb / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": rate * nb / 1e9 / 8000.0,
-                     "algorithmic_bytes_per_unit": nb, "fp64_tflops": rate * flops / 1e12, "fp64_frac": rate * flops / 1e12 / 68.0},
-        "dtype": "f64", "data": "synthetic"}))
+        "roofline": {"bound": "hbm", "achieved": rate / R.world * nb / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": rate / R.world * nb / 1e9 / 8000.0,   # per GPU
+                     "algorithmic_bytes_per_unit": nb, "fp64_tflops": rate / R.world * flops / 1e12, "fp64_frac": rate / R.world * flops / 1e12 / 68.0},
+        "dtype": "f64", "data": "synthetic"}), flush=True)
+    R.finish()
+    if all_ok is False:
+        raise SystemExit(3)   # a fast wrong answer is not a result
 
 
 if __name__ == "__main__":

@@ -10,8 +10,8 @@ def rows(lines):
         if not ln:
             continue
         d = json.loads(ln)
-        if d.get("skipped"):
-            out.append((d["n_gpus"], None))
+        if d.get("skipped") or d.get("failed"):
+            out.append((d["n_gpus"], None if d.get("skipped") else {"failed": d.get("rc")}))
             continue
         n = d["n_gpus"]
         per = d.get("per_rank") or []
@@ -34,6 +34,9 @@ def fmt(table):
     for n, r in table:
         if r is None:
             lines.append(f"| {n} | skipped (not that many devices on this node) | | | | | | |")
+            continue
+        if "failed" in r:
+            lines.append(f"| {n} | FAILED rc={r['failed']} (see gpurun_out/scale_n{n}.err) | | | | | | |")
             continue
         g = "-" if r["gbps_min"] is None else f"{r['gbps_min']:.0f} - {r['gbps_max']:.0f}"
         e = "-" if r["eff"] is None else f"{r['eff']:.3f}"
