@@ -63,7 +63,17 @@ def pmc_traffic(kernel_class: str, batch: int):
             return None
         data = doc["kernels"]
         prefix = KERNEL_OF_CLASS.get(kernel_class, "?")
-        best = max((v["hbm_bytes_per_dispatch_corrected"] for k, v in data.items() if k.startswith(prefix)), default=None)
+        # the counters belong to the kernel they were taken on: quoted only while the kernel in the library that runs NOW carries the same code-object
+        # signature (registers / scratch / LDS / workgroup size, tools/kres_so.py) - a profile of another build is not this run's traffic
+        sigs = doc.get("kernel_signatures") or {}
+        if not sigs or "error" in sigs:
+            return None
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from traffic_json import kernel_signatures
+        names = [k for k in data if k.startswith(prefix)]
+        now = kernel_signatures(names, os.environ.get("POULPY_HIP_LIB") or None)
+        names = [k for k in names if k in sigs and now.get(k) == sigs[k]]
+        best = max((data[k]["hbm_bytes_per_dispatch_corrected"] for k in names), default=None)
         return best
     except Exception:
         return None
@@ -593,7 +603,7 @@ def main():
                 roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS,
                         "traffic": pmc_traffic(name, args.batch) if (args.op == "external_product" and DSIZE == 1) else None,
-                        "traffic_source": "committed rocprofv3 PMC passes of this kernel at this shape (profiles/r*_traffic.json), not a counter of this run",
+                        "traffic_source": "committed rocprofv3 PMC passes of this kernel at this shape (profiles/r*_traffic.json; quoted only while the kernel's code-object signature is the profiled one), not a counter of this run",
                         "avg_launch_ms": ms / cnt, "launches": cnt, "units_per_launch": units_per_launch,
                         "algorithmic_bytes_per_unit": b_unit,
                         "pipeline_achieved": value * (DNUM if expand else 1) / world * b_unit / 1e9,

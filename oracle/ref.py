@@ -27,8 +27,13 @@ def build(fast: bool = False) -> str:
 
 def load(fast: bool = False) -> C.CDLL:
     path = SO_FAST if fast else SO
-    if not os.path.exists(path):
+    # always through make: a prebuilt library that is older than fft64_ref.c (it travels with the snapshot to the GPU box) is rebuilt, a fresh
+    # one costs a no-op; without a compiler the existing file is used as it is
+    try:
         build(fast)
+    except (subprocess.CalledProcessError, OSError):
+        if not os.path.exists(path):
+            raise
     lib = C.CDLL(path)
     lib.pzr_tables_new.restype = c_void_p
     lib.pzr_tables_new.argtypes = [c_uint64]

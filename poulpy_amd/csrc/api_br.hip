@@ -66,7 +66,7 @@ struct BrCall {
 // acc = X^b * LUT in column 0, zero elsewhere (:298-301 / :413-416)
 static int br_init_accumulator(const BrCall& c) {
     PZ_BR_UNPACK(c)
-    PZ_HIP(hipMemsetAsync(res, 0, (size_t)B * res_ct * 8, M->stream));
+    PZ_TRY(launch_zero_bytes(M, res, (size_t)B * res_ct * 8));
     const int nl = std::min(rsz, (int)p->lut_size);
     PolyMap sm{nl, 1, 0, n, 0, 0};                     // the LUT is shared: batch stride 0, VecZnx(1, lut_size)
     PolyMap dm{nl, 1, res_ct, (long long)cols * n, 0, 0};
@@ -202,7 +202,7 @@ static int br_composed_path(const BrCall& c) {
         bool block_done = false;
         if (M->fuse_mid) PZ_TRY(br_block_step(M, acc_dft, ad.bs, acc_add, aa.bs, brk, pmat_doubles, row_max, cols * bsz, B, b0, blk, lwe_2n, lwe_bs, &block_done));
         if (!block_done) {
-        PZ_HIP(hipMemsetAsync(acc_add, 0, (size_t)B * aa.bs * 8, M->stream));                     // :321
+        PZ_TRY(launch_zero_bytes(M, acc_add, (size_t)B * aa.bs * 8));                     // :321
         for (int i = b0; i < b0 + blk; ++i) {                                                       // :324-337
             PZ_TRY(dev_vmp(M, B, vr, ad, brk + (size_t)i * pmat_doubles, dnum, cols, cols, bsz, 0));
             PZ_TRY(launch_xai_acc(M, acc_add, aa.bs, vmp_res, vr.bs, cols * bsz, B, lwe_2n, lwe_bs, i));
@@ -243,7 +243,7 @@ static int br_standard_path(const BrCall& c) {
                              lwe_bs, 1 + i, 0));
     }
     // vec_znx_normalize_assign (normalize.rs:403-425) == out-of-place same-base normalize of a copy
-    PZ_HIP(hipMemcpyAsync(acc_tmp, res, (size_t)B * res_ct * 8, hipMemcpyDeviceToDevice, M->stream));
+    PZ_TRY(launch_ew(M, EW_COPY, acc_tmp, res_ct, n, res, res_ct, n, nullptr, 0, 0, cols * rsz, B));   // (a kernel node, not a memcpy node: see launch_zero_bytes)
     DV tv{acc_tmp, res_ct, cols, rsz};
     for (int c = 0; c < cols; ++c) PZ_TRY(dev_normalize(M, B, rv, k, 0, c, tv, k, c));
     return PZ_OK;
@@ -316,7 +316,7 @@ static int blind_rotation_extended(pz_module* M, int64_t* res, const int64_t* lw
     double* acc_add = (double*)base; base += align256((size_t)BE * n8 * cols * bsz);
     cplx* T = (cplx*)base;
     // :159-161 zero, :180-190 rotated table
-    PZ_HIP(hipMemsetAsync(acc, 0, (size_t)BE * res_ct * 8, M->stream));
+    PZ_TRY(launch_zero_bytes(M, acc, (size_t)BE * res_ct * 8));
     PZ_REQUIRE(BE <= 65535, "blind_rotation: batch * extension_factor exceeds 65535 (split the batch)");
     PZ_TRY(launch_br_ext_init(M, acc, lut, lwe_2n, lwe_bs, log_ext, cols, rsz, (int)p->lut_size, B));
     DV rv{acc, res_ct, cols, rsz};
@@ -332,7 +332,7 @@ static int blind_rotation_extended(pz_module* M, int64_t* res, const int64_t* lw
             PZ_TRY(launch_small_fwd(M, BE * npi, (const long long*)acc, sm, (cplx*)acc_dft, true));
         } else
         PZ_TRY(dev_dft_apply(M, BE, 1, 0, ad, 0, rv, 0, cols, nullptr, T));                           // :195-200
-        PZ_HIP(hipMemsetAsync(acc_add, 0, (size_t)BE * aa.bs * 8, M->stream));
+        PZ_TRY(launch_zero_bytes(M, acc_add, (size_t)BE * aa.bs * 8));
         for (int i = b0; i < b0 + blk; ++i) {
             PZ_TRY(dev_vmp(M, BE, vr, ad, brk + (size_t)i * pmat_doubles, dnum, cols, cols, bsz, 0));   // :209-211
             PZ_TRY(launch_xai_ext(M, acc_add, vmp_res, cols * bsz, log_ext, B, lwe_2n, lwe_bs, i));
@@ -480,7 +480,7 @@ static int circuit_bootstrapping(pz_module* M, int64_t* ggsw, const int64_t* lwe
         DV dv{acc, ct_g, cols, gsz}, sv{acc_brk, ct_b, cols, bsz_g};
         for (int c = 0; c < cols; ++c) PZ_TRY(dev_normalize(M, B, dv, k_atk, 0, c, sv, k_brk, c));
     }
-    if (tsz > gsz) PZ_HIP(hipMemsetAsync(tr, 0, (size_t)B * rows * ct_t * 8, M->stream));  // glwe_copy zero-extends (glwe_trace.rs:114)
+    if (tsz > gsz) PZ_TRY(launch_zero_bytes(M, tr, (size_t)B * rows * ct_t * 8));  // glwe_copy zero-extends (glwe_trace.rs:114)
     for (int i = 0; i < rows; ++i) {
         PolyMap sm{gsz, cols, ct_g, (long long)cols * n, n, 0};
         PolyMap dm{gsz, cols, (long long)rows * ct_t, (long long)cols * n, n, (long long)i * ct_t};

@@ -443,7 +443,7 @@ static int glwe_fused(const GlweCall& c) {
         if (two_kernel) { PZ_TRY(wave_n4096_two_kernel(c, f, b0, nb, av, sm)); continue; }
         if (M->dbg_stages & 1) PZ_TRY(launch_fwd_pass1(M, nb * c.npi, (const long long*)av.p, sm, f.T, true));
         if (c.digits && dg.n == 0) {   // nothing reaches the product (e.g. dsize > a.size): the big value is the body alone
-            PZ_HIP(hipMemsetAsync(f.T2, 0, (size_t)nb * c.npo * M->m * sizeof(cplx), M->stream));
+            PZ_TRY(launch_zero_bytes(M, f.T2, (size_t)nb * c.npo * M->m * sizeof(cplx)));
         } else if (M->dbg_stages & 2) {
             PZ_TRY(launch_mid(M, nb, f.T, f.T2, f.Pp, c.npi, c.npo, c.nrows, c.ncols, f.mid_dummy, sp.mul, sp.add, c.digits ? &dg : nullptr, nullptr,
                               sp.conj));
@@ -479,8 +479,14 @@ static int glwe_small_ring(const GlweCall& c) {
         DV av;
         PZ_TRY(wave_input(c, b0, nb, a_conv, &av));
         PolyMap sm{av.size, c.s.cols_in, av.bs, (long long)av.cols * c.n, c.n, c.n * c.s.a_col0};
-        PZ_TRY(launch_small_fwd(M, nb * c.npi, (const long long*)av.p, sm, S));
         const long long* body = c.ks ? (const long long*)av.p : nullptr;
+        // plain product / key switch of a rank-1 ciphertext: one kernel, the spectra never leave the CU (round 6, device_small_one.hpp)
+        if (!c.au && !c.cross_out && small_one_supported(M, c.npi, c.nrows, c.ncols, c.s.cols_out, c.ksz)) {
+            PZ_TRY(launch_small_one(M, nb, (const long long*)av.p, sm, Pp, c.npi, c.nrows, c.ncols, c.ksz, (long long*)c.res_at(b0), c.res_bs, c.s.cols_out,
+                                    (int)c.p->res_size, body, av.bs, c.s.cols_a, av.size, (int)c.p->res_base2k, c.body_col));
+            continue;
+        }
+        PZ_TRY(launch_small_fwd(M, nb * c.npi, (const long long*)av.p, sm, S));
         if (c.cross_out) {
             const long long tmp_ct = c.n * c.s.cols_out * (long long)c.ksz;
             PZ_TRY(launch_small_inv(M, nb, S, Pp, c.npi, c.nrows, c.ncols, c.s.cols_out, c.ksz, (long long*)key_digits, tmp_ct, c.s.cols_out, c.ksz,
@@ -517,7 +523,7 @@ static int wave_unfused_product(const GlweCall& c, const UnfusedBufs& u, int nb,
     }
     // external_product/glwe.rs:235-267 ; keyswitching/glwe.rs:332-379
     // res_dft starts zeroed (glwe.rs:122): limbs skipped by the first iterations are only ever added to
-    PZ_HIP(hipMemsetAsync(u.res_dft, 0, (size_t)nb * rd.bs * 8, M->stream));
+    PZ_TRY(launch_zero_bytes(M, u.res_dft, (size_t)nb * rd.bs * 8));
     DV td{u.tmp_dft, n * c.s.cols_out * c.ksz, c.s.cols_out, c.ksz};
     for (int di = 0; di < c.dsize; ++di) {
         int a_sz = (a_size + di) / c.dsize;

@@ -827,8 +827,15 @@ k_mid128(MidArgs g) {
 // issues its share of the stores and key requests in the same order.  Both codes execute the same barriers.  They are two
 // instantiations of this function rather than branches inside one loop because a branch around the loads makes the compiler's
 // s_waitcnt insertion assume the worst case at every join (k_mid128, SKIPW).
-template <int CT, int NP, bool PERM, int NR, int KR, bool HALFIN, bool IN, bool DS = false>
+// C2 (round 6, the 16-limb key switch family: 16 polynomials in, 32 = 16 limbs x 2 columns out): the tile of the 32-slot form holds 2 ciphertexts, so
+// every key value a thread loads serves 2 ciphertexts and the product phase is paced by the L2 -> CU key stream (1 MiB per tile at ~50 B/clk:
+// 21 k of the tile's 36 k cycles, profiles/r05_roofline.md "l2_stream").  Here the tile is 4 ciphertexts x 16 slots and the two output COLUMNS are
+// two consecutive virtual tiles V = 2 k + col of the same inputs: slot j of pass `col` is key column / output polynomial 2 j + col.  Each key
+// value serves 4 ciphertexts (half the key stream per ciphertext); the price is a second load (L2: the rows were read a tile ago) and forward
+// row transform of the 16 input rows.
+template <int CT, int NP, bool PERM, int NR, int KR, bool HALFIN, bool IN, bool DS = false, bool C2 = false>
 __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
+    static_assert(!C2 || (!DS && !HALFIN && NP == 16), "two-column passes: the plain 16-slot tile");
     constexpr int M2 = 128, NT = CT * NP * 8;   // 512 threads (64 rows), or 256 (32 rows: two workgroups per CU, round-4 experiment)
     constexpr int NC = (NP * M2 / NT) > 4 ? (NP * M2 / NT) : 4;   // outputs per thread (32-slot tile: two ciphertexts x 8 outputs, as in k_mid128)
     constexpr int GC = NP / NC, GT = (NT / M2) / GC, CTt = CT / GT;
@@ -866,6 +873,12 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
     if (g.stagger_mod & 2) { if (!young) __builtin_amdgcn_s_setprio(1); }
     const int nsleep = ((g.stagger_mod & 4) ? !young : young) ? g.stagger : 0;
 
+    // virtual tiles: V = L without C2 (stride W); with C2 V = 2 k + col for L = w + k W
+    auto vL = [&](int V) { return C2 ? w + (V >> 1) * W : V; };
+    auto vcol = [&](int V) { return C2 ? (V & 1) : 0; };
+    auto vnext = [&](int V) { return C2 ? V + 1 : V + W; };
+    const int V0 = C2 ? 0 : w;
+    auto kcol = [&](int slot, int col) { return C2 ? 2 * slot + col : min(slot, g.ncomp - 1); };   // key column / output polynomial of a tile slot
     auto tile_q1 = [&](int L) { const int k = L / g.n_ct; return xcd_map ? k * 8 + xcd : k; };
     auto out_q1 = [&](int q1_) { return PERM ? (int)((g.perm_mul * (unsigned)q1_ + g.perm_add) & (unsigned)(g.m1 - 1)) : q1_; };
     auto src_ptr = [&](int L, int ctl, int rr, int o) {
@@ -899,14 +912,15 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
     { _Pragma("unroll") for (int n1 = 4 * (G4); n1 < 4 * (G4) + 4; ++n1) st_stream(dst + 8 * n1, u[n1]); }
 #define PZ_KGROUP(LT, SLOT)  /* key row SLOT (< KR - 1) of tile LT's product */                         \
     if (!(PZ_MIDR_HALFKEY && ((SLOT) & 1))) {                                                          \
-        const long long base_ = (long long)tile_q1(min((LT), ntiles - 1)) * g.nrows * g.ncols;         \
+        const long long base_ = (long long)tile_q1(min(vL(LT), ntiles - 1)) * g.nrows * g.ncols;     \
+        const int kc_ = vcol(LT); (void)kc_;                                                           \
         int r_ = rot + (SLOT);                                                                         \
         r_ -= (r_ >= nrow) ? nrow : 0;                                                                 \
         r_ -= (r_ >= nrow) ? nrow : 0;                                                                 \
         const int krow_ = DS ? (int)g.ds_row[r_] : r_;                                                 \
         if constexpr (!PZ_MIDR_SADDR) {                                                                \
             _Pragma("unroll") for (int j = 0; j < NC; ++j) {                                           \
-                const int c_ = DS ? min(vcg * NC + j, max((int)g.ds_cb[r_], 1) - 1) + (int)g.ds_coff[r_] : min(vcg * NC + j, g.ncomp - 1); \
+                const int c_ = DS ? min(vcg * NC + j, max((int)g.ds_cb[r_], 1) - 1) + (int)g.ds_coff[r_] : kcol(vcg * NC + j, kc_); \
                 kr[SLOT][j] = g.P[(base_ + (long long)krow_ * g.ncols + c_) * M2 + vq2];               \
             }                                                                                          \
         } else if constexpr (DS) {                                                                     \
@@ -917,7 +931,7 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
         } else {   /* uniform row base + one 32-bit lane offset per column: no 64-bit vector address arithmetic (see the product loop) */ \
             const char* rp_ = (const char*)(g.P + (base_ + (long long)krow_ * g.ncols) * M2);          \
             _Pragma("unroll") for (int j = 0; j < NC; ++j)                                             \
-                kr[SLOT][j] = *(const cplx*)(rp_ + (unsigned)(min(vcg * NC + j, g.ncomp - 1) * M2 + vq2) * 16u); \
+                kr[SLOT][j] = *(const cplx*)(rp_ + (unsigned)(kcol(vcg * NC + j, kc_) * M2 + vq2) * 16u); \
         }                                                                                              \
     }
     // forward row DFT of x (see k_mid128) with the held-back stores (STORES) and the next product's first key rows in its gaps
@@ -927,7 +941,7 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
         if (STORES) { PZ_SGROUP(0) __builtin_amdgcn_sched_barrier(0); }                           \
         if (PZ_MID_STAMP && STORES) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); PZ_STAMP(4) } \
         if constexpr (IN) {                                                                       \
-        if (!in_active((LT), ctl, rr)) {                                                          \
+        if (!in_active(vL(LT), ctl, rr)) {                                                        \
             _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1) x[n1] = make_double2(0.0, 0.0);     \
         }                                                                                         \
         Bfly<16, false>::run(x);                                                                  \
@@ -983,9 +997,9 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
     // ---- prologue: first tile ----
     if constexpr (IN) {
         PZ_MID_LANE
-        const cplx* src_ = src_ptr(w, ctl, rr, o);
+        const cplx* src_ = src_ptr(vL(V0), ctl, rr, o);
         PZ_XGROUP(src_, 0) PZ_XGROUP(src_, 1) PZ_XGROUP(src_, 2) PZ_XGROUP(src_, 3)
-        if (tw_e >= 0) twrow2[tw_e] = g.tw12t[(long long)out_q1(tile_q1(w)) * M2 + tw_e];
+        if (tw_e >= 0) twrow2[tw_e] = g.tw12t[(long long)out_q1(tile_q1(vL(V0))) * M2 + tw_e];
     }
     int par = 0;
 #if PZ_MID_STAMP
@@ -996,13 +1010,15 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
 #else
 #define PZ_STAMP(i)
 #endif
-    PZ_MIDR_FWD(w, 0)
+    PZ_MIDR_FWD(V0, 0)
 #if PZ_MID_STAMP
     st_t = __builtin_amdgcn_s_memtime();
     const unsigned long long st_t0 = st_t;
 #endif
 
-    for (int L = w; L < ntiles; L += W, par ^= 1) {
+    for (int V = V0; vL(V) < ntiles; V = vnext(V), par ^= 1) {
+        const int L = vL(V), Vn = vnext(V), Ln = vL(Vn), col = vcol(V);
+        (void)col; (void)Ln;
         const int q1 = tile_q1(L);
         // ---------------- product: res[b][c][q] = sum_r a[b][r][q] * P[r][c][q] ----------------
         {
@@ -1015,7 +1031,7 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
                 for (int j = 0; j < NC; ++j) acc[i][j] = make_double2(0.0, 0.0);
             const cplx* pp[NC];
 #pragma unroll
-            for (int j = 0; j < NC; ++j) pp[j] = g.P + ((long long)q1 * g.nrows * g.ncols + (DS ? 0 : min(cg * NC + j, g.ncomp - 1))) * M2 + q2;   // DS: the column is part of the per-term offset
+            for (int j = 0; j < NC; ++j) pp[j] = g.P + ((long long)q1 * g.nrows * g.ncols + (DS ? 0 : kcol(cg * NC + j, col))) * M2 + q2;   // DS: the column is part of the per-term offset
             const long long prow = (long long)g.ncols * M2;
             // plain product (round 4): the key row's address is a UNIFORM base (scalar registers, moved from row to row by scalar adds) plus
             // one 32-bit lane offset per column, and the operand's LDS address a lane base plus a scalar row offset.  With a 64-bit lane
@@ -1024,7 +1040,7 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
             const char* const kbase = (const char*)(g.P + (long long)q1 * g.nrows * g.ncols * M2);
             unsigned koff[NC];
 #pragma unroll
-            for (int j = 0; j < NC; ++j) koff[j] = (unsigned)(min(cg * NC + j, g.ncomp - 1) * M2 + q2) * 16u;
+            for (int j = 0; j < NC; ++j) koff[j] = (unsigned)(kcol(cg * NC + j, col) * M2 + q2) * 16u;
             const cplx* const avp = lds + vtg * CTt * NP * RS + q2;
             cplx av[2][CTt];
 #define PZ_LOADROW(DST, IT)                                                                     \
@@ -1104,7 +1120,7 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
                 // (a 64-bit multiply-add and four selects per value otherwise: 96 instructions for these 16 stores)
                 const int q2o = PERM ? (int)((((g.perm_mul * (unsigned)q1 + g.perm_add) >> g.log_m1) + g.perm_mul * (unsigned)q2) & (unsigned)(M2 - 1)) : q2;
                 cplx* const wb = lds + (vtg * CTt * NP + cg * NC) * RS + q2o;
-                if (g.ncomp >= NP) {
+                if (C2 || g.ncomp >= NP) {
 #pragma unroll
                     for (int i = 0; i < CTt; ++i)
 #pragma unroll
@@ -1133,9 +1149,9 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
         {
             PZ_MID_LANE
             const int b = (L % g.n_ct) * CT + ctl;
-            const cplx* src_ = src_ptr(L + W, ctl, rr, o);
+            const cplx* src_ = src_ptr(Ln, ctl, rr, o);
             const cplx* twr = twrow2 + par * M2;
-            if constexpr (IN) twn = g.tw12t[(long long)out_q1(tile_q1(min(L + W, ntiles - 1))) * M2 + max(tw_e, 0)];
+            if constexpr (IN) twn = g.tw12t[(long long)out_q1(tile_q1(min(Ln, ntiles - 1))) * M2 + max(tw_e, 0)];
             if constexpr (IN) { PZ_XGROUP(src_, 0) PZ_XGROUP(src_, 1) }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1176,7 +1192,7 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
             __builtin_amdgcn_sched_barrier(0);
             // ---- the wave's rows are free from here: the forward pass of the next tile starts while u is still being finished ----
             if constexpr (IN) {
-                if (!in_active(L + W, ctl, rr)) {
+                if (!in_active(Ln, ctl, rr)) {
 #pragma unroll
                     for (int n1 = 0; n1 < 16; ++n1) x[n1] = make_double2(0.0, 0.0);
                 }
@@ -1220,8 +1236,8 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
 #pragma unroll
             for (int n1 = 0; n1 < 8; ++n1) twa[n1] = twr[o + 8 * (n1 + 8)];
             __builtin_amdgcn_sched_barrier(0);
-            const bool active = b < g.batch && rr < g.npo;
-            dst = active ? g.T2 + ((long long)b * g.npo + rr) * m + (long long)out_q1(q1) * M2 + o
+            const bool active = b < g.batch && rr < (C2 ? NP : g.npo);
+            dst = active ? g.T2 + ((long long)b * g.npo + (C2 ? 2 * rr + col : rr)) * m + (long long)out_q1(q1) * M2 + o
                          : g.dummy + ((long long)blockIdx.x * (NT / 8) + row) * M2 + o;
             PZ_SGROUP(0)
             __builtin_amdgcn_sched_barrier(0);
@@ -1233,12 +1249,12 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
             for (int n1 = 0; n1 < 8; ++n1) u[n1 + 8] = cmulc(u[n1 + 8], twa[n1]);
             if constexpr (IN) { if (tw_e >= 0) twrow2[(par ^ 1) * M2 + tw_e] = twn; }
             __builtin_amdgcn_sched_barrier(0);
-            PZ_KGROUP(L + W, 0)
+            PZ_KGROUP(Vn, 0)
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (IN) Bfly<8, false>::run(x + 8);
             __builtin_amdgcn_sched_barrier(0);
             PZ_SGROUP(2)
-            PZ_KGROUP(L + W, 1)
+            PZ_KGROUP(Vn, 1)
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (IN) {
                 row_sync();
@@ -1247,15 +1263,15 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
             }
             __builtin_amdgcn_sched_barrier(0);
             PZ_SGROUP(3)
-            if constexpr (KR > 3) PZ_KGROUP(L + W, 2)
+            if constexpr (KR > 3) PZ_KGROUP(Vn, 2)
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (IN) {
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) rowbuf[o + 8 + 16 * k2] = x[8 + k2];
             }
-            if constexpr (KR > 4) PZ_KGROUP(L + W, 3)
-            if constexpr (KR > 5) PZ_KGROUP(L + W, 4)
-            if constexpr (KR > 6) PZ_KGROUP(L + W, 5)
+            if constexpr (KR > 4) PZ_KGROUP(Vn, 3)
+            if constexpr (KR > 5) PZ_KGROUP(Vn, 4)
+            if constexpr (KR > 6) PZ_KGROUP(Vn, 5)
             PZ_STAMP(3)
             lds_barrier();
         }
@@ -1265,9 +1281,9 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
         {
             PZ_MID_LANE
             const int b = (L % g.n_ct) * CT + ctl;
-            const cplx* src_ = src_ptr(L + W, ctl, rr, o);
+            const cplx* src_ = src_ptr(Ln, ctl, rr, o);
             const cplx* twr = twrow2 + par * M2;
-            if constexpr (IN) twn = g.tw12t[(long long)out_q1(tile_q1(min(L + W, ntiles - 1))) * M2 + max(tw_e, 0)];
+            if constexpr (IN) twn = g.tw12t[(long long)out_q1(tile_q1(min(Ln, ntiles - 1))) * M2 + max(tw_e, 0)];
             if constexpr (IN) PZ_XGROUP(src_, 0)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1325,13 +1341,13 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
             // the next tile's twiddle row (requested FIRST among this pass's loads, so that waiting for it here leaves the 16 T' loads in
             // flight) goes to the row the next inverse pass reads
             if constexpr (IN) { if (tw_e >= 0) twrow2[(par ^ 1) * M2 + tw_e] = twn; }
-            const bool active = b < g.batch && rr < g.npo;
-            dst = active ? g.T2 + ((long long)b * g.npo + rr) * m + (long long)out_q1(q1) * M2 + o
+            const bool active = b < g.batch && rr < (C2 ? NP : g.npo);
+            dst = active ? g.T2 + ((long long)b * g.npo + (C2 ? 2 * rr + col : rr)) * m + (long long)out_q1(q1) * M2 + o
                          : g.dummy + ((long long)blockIdx.x * (NT / 8) + row) * M2 + o;
         }
         PZ_STAMP(3)
         // no workgroup barrier: the forward pass below only rewrites this wave's own rows, and it writes the OTHER twiddle row
-        PZ_MIDR_FWD(L + W, 1)
+        PZ_MIDR_FWD(Vn, 1)
 #endif
         PZ_STAMP(6)
 #if PZ_MID_STAMP
@@ -1361,18 +1377,18 @@ __device__ __forceinline__ void mid128r_body(const MidArgs& g) {
 // (32-slot tiles - 16 limbs, rank 2-3 - carry 8 key values per thread and row: a ring of 3 slots there)
 // DS (round 3, late): the digit-group product of dsize > 1 (MidArgs::ds_*: NR product terms, each with its input slot, key row, column
 // offset and column bound) - the addressing of k_mid128<.., DS> on this kernel's schedule.
-template <int CT, int NP, bool PERM, int NR, bool HALFIN = false, int KR = ((NP == 32 || CT * NP * 8 == 256) ? 3 : PZ_MIDR_KR), bool DS = false>
+template <int CT, int NP, bool PERM, int NR, bool HALFIN = false, int KR = ((NP == 32 || CT * NP * 8 == 256) ? 3 : PZ_MIDR_KR), bool DS = false, bool C2 = false>
 __global__ void __launch_bounds__(CT * NP * 8)
 k_mid128r(MidArgs g) {
     static_assert(!HALFIN || NP >= 16, "HALFIN: 16- and 32-slot tiles");
     static_assert(!DS || !PERM, "digit groups: plain product only");
     if constexpr (HALFIN) {
         if (((threadIdx.x >> 3) % NP) >= NP / 2) {   // wave-uniform: a wave owns 8 consecutive slots of one ciphertext
-            mid128r_body<CT, NP, PERM, NR, KR, true, false, DS>(g);
+            mid128r_body<CT, NP, PERM, NR, KR, true, false, DS, C2>(g);
             return;
         }
     }
-    mid128r_body<CT, NP, PERM, NR, KR, HALFIN, true, DS>(g);
+    mid128r_body<CT, NP, PERM, NR, KR, HALFIN, true, DS, C2>(g);
 }
 
 // (Round 2 experiment, removed: "k_midr<LPR = 4>" — the same kernel for rows of 64 points owned by 4 lanes (m = 512 x 64): a tile of four

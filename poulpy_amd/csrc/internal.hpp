@@ -143,10 +143,18 @@ int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int
                      long long* res, long long res_bs, int res_cols, int res_size, const long long* small, long long small_bs,
                      int small_cols, int small_size, int base2k, int body_col, bool noprod = false, cplx* fwd_S = nullptr, int fwd_limbs = 0,
                      bool au = false, unsigned au_p = 0, int au_mode = 0, bool post_rsh = false, int acc32 = 0);
+// ONE kernel per call for N = 1024 / 2048 (device_small_one.hpp): forward transforms, product, inverse transforms and carry chains of a ciphertext in
+// one workgroup; rank 1 (2 output columns), <= 8 input polynomials, <= 4 key limbs, key columns = ksz * 2
+bool small_one_supported(const pz_module* M, int npi, int nrows, int ncols, int cols_out, int ksz);
+int launch_small_one(pz_module* M, int batch, const long long* src, PolyMap smap, const cplx* Pp, int npi, int nrows, int ncols, int ksz, long long* res,
+                     long long res_bs, int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size, int base2k,
+                     int body_col);
 
 // ---- launch_ops.hip -----------------------------------------------------------------------------------------------
 int launch_ew(pz_module* M, int op, void* res, long long res_bs, long long res_ls, const void* a, long long a_bs,
               long long a_ls, const void* b, long long b_bs, long long b_ls, int nlimbs, int batch);
+// zero-fill as a kernel node (not hipMemsetAsync: see launch_ops.hip) - for everything that can run under graph capture
+int launch_zero_bytes(pz_module* M, void* ptr, size_t bytes);
 // dst = +-src(X^p-gather with multiplier mul) [+ add]; see k_automorphism
 int launch_automorphism(pz_module* M, int npolys, const long long* src, PolyMap sm, long long* dst, PolyMap dm, unsigned mul,
                         int flags, const long long* add = nullptr, PolyMap am = PolyMap{1, 1, 0, 0, 0, 0});

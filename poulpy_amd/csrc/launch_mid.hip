@@ -135,6 +135,25 @@ if (ring_ && (!(skipw_) || (NP_ >= 16 && npi <= NP_ / 2 && npo > NP_ / 2))) {   
         PZ_MID128_PICK(CT_, NP_, perm, skipw_, ring_)                                                                  \
     }                                                                                                                  \
 }
+    // 16 polynomials in, 32 = 16 limbs x 2 columns out, 16 key rows of 32 columns (rank-1 key switch / automorphism / relinearization at 16 limbs:
+    // BASELINE configs[4]): 4 ciphertexts per tile and the two output columns as two passes over the same inputs - every key value serves 4
+    // ciphertexts instead of the 32-slot tile's 2 (k_mid128r<.., C2>; POULPY_DBG_MID_C2=0 in an experiment build: the 32-slot tile)
+    static const bool c2_on = (exp_knob("POULPY_DBG_MID_C2", 1) != 0);
+    if (c2_on && mid_r && !br && !ds && npi == 16 && npo == 32 && g.row_max == 16 && g.ncols == 32 && g.ncomp == 32) {
+        g.n_ct = (batch + 3) / 4;
+        const size_t lds = ((size_t)4 * 16 * kMidRS + 384 + 32) * sizeof(cplx);
+        const dim3 grid_(std::min({ncu, 256, g.m1 * g.n_ct}));
+        if (perm) {
+            PZ_TRY(set_lds((k_mid128r<4, 16, true, 16, false, PZ_MIDR_KR, false, true>), lds));
+            hipLaunchKernelGGL((k_mid128r<4, 16, true, 16, false, PZ_MIDR_KR, false, true>), grid_, dim3(512), lds, M->stream, g);
+        } else {
+            PZ_TRY(set_lds((k_mid128r<4, 16, false, 16, false, PZ_MIDR_KR, false, true>), lds));
+            hipLaunchKernelGGL((k_mid128r<4, 16, false, 16, false, PZ_MIDR_KR, false, true>), grid_, dim3(512), lds, M->stream, g);
+        }
+        dispatch_note(M, "k_mid128r<CT=4,NP=16,PERM=%d,NR=16,HALFIN=0,KR=%d,C2=1> (two output-column passes per tile of 4 ciphertexts)", (int)perm, PZ_MIDR_KR);
+        PZ_HIP(hipGetLastError());
+        return PZ_OK;
+    }
     if (npi <= 8 && npo <= 8) {
         // <= 8 polynomials in and out (e.g. rank 1 with 4 limbs, BASELINE configs[1]): 8 ciphertexts x 8 slots per tile
         PZ_MID128_LAUNCH(8, 8)

@@ -73,6 +73,27 @@ int launch_rotate(pz_module* M, int npolys, const long long* src, PolyMap sm, lo
     PZ_HIP(hipGetLastError());
     return PZ_OK;
 }
+// Zero-fill as a KERNEL (round 6).  hipMemsetAsync inside a captured call becomes a memset node of the HIP graph; replayed under the HIP runtime that
+// PyTorch ships (7.0) such a graph gave non-deterministic results at launch-bound sizes - the blind rotation at N = 2^14 with 2 ciphertexts per call,
+// found by tests/test_gpu_structured.py: round-5 library alike, plain launches and the system runtime unaffected (tools/dbg/br_graph_repro.py).
+// The composite calls that can run under capture zero through this kernel instead: the graph then holds kernel nodes only.
+__global__ void __launch_bounds__(256) k_zero_words(unsigned long long* p, size_t nwords) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256) p[i] = 0ull;
+}
+int launch_zero_bytes(pz_module* M, void* ptr, size_t bytes) {
+    if (bytes == 0) return PZ_OK;
+    if (((uintptr_t)ptr & 7) != 0 || (bytes & 7) != 0) {   // (never the case for the polynomial buffers; kept correct for any caller)
+        PZ_HIP(hipMemsetAsync(ptr, 0, bytes, M->stream));
+        return PZ_OK;
+    }
+    const size_t nwords = bytes / 8;
+    const unsigned grid = (unsigned)std::min<size_t>((nwords + 255) / 256, 4096);
+    KTimer kt(M, PZ_K_ELEMENTWISE);
+    hipLaunchKernelGGL(k_zero_words, dim3(grid), dim3(256), 0, M->stream, (unsigned long long*)ptr, nwords);
+    PZ_HIP(hipGetLastError());
+    return PZ_OK;
+}
+
 int launch_rsh(pz_module* M, int batch, long long* data, long long bs, int cols, int size, int col0, int ncols, int base2k, int k) {
     if (batch <= 0 || ncols <= 0 || size <= 0) return PZ_OK;
     RshArgs g;

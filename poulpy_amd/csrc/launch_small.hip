@@ -6,6 +6,7 @@
 
 #include "internal.hpp"
 #include "device_small.hpp"
+#include "device_small_one.hpp"
 
 namespace pz {
 
@@ -171,6 +172,41 @@ int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int
 #undef XFWD_16
 #undef XL
     return fail(PZ_ERR_UNSUPPORTED, "small-ring pipeline: m1 = %d, %d key limbs", m1, ksz);
+}
+
+// N = 1024 / 2048, plain product / key switch of a rank-1 ciphertext: ONE kernel per call (device_small_one.hpp)
+bool small_one_supported(const pz_module* M, int npi, int nrows, int ncols, int cols_out, int ksz) {
+    static const bool on = (exp_knob("POULPY_DBG_SMALL_ONE", 1) != 0);
+    const int m1 = small_m1(M);
+    // measured (profiles/r06_ab_small_one.txt, 1024 per call): N = 1024 + 7 ... + 20 % on every shape; N = 2048 + 4 % for the external product (8 input
+    // polynomials), - 4 % for the key switch (4 inputs: the two-kernel pipeline has two workgroups per CU there, this kernel one) - which stays on two kernels
+    return on && (M->m % kSmallM2) == 0 && (m1 == 4 || (m1 == 8 && npi > 4)) && cols_out == 2 && ksz >= 1 && ksz <= 4 && ncols == ksz * cols_out && npi >= 1 &&
+           npi <= 8 && nrows >= 1;
+}
+int launch_small_one(pz_module* M, int batch, const long long* src, PolyMap smap, const cplx* Pp, int npi, int nrows, int ncols, int ksz, long long* res,
+                     long long res_bs, int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size, int base2k,
+                     int body_col) {
+    if (batch <= 0) return PZ_OK;
+    PZ_TRY(ensure_small_tables(M));
+    SmallOneArgs g;
+    g.src = src; g.smap = smap; g.Pp = Pp; g.res = res; g.small = small; g.res_bs = res_bs; g.small_bs = small_bs;
+    g.batch = batch; g.npi = npi; g.nrows = nrows; g.ncols = ncols; g.ksz = ksz;
+    g.res_cols = res_cols; g.res_size = res_size; g.small_cols = small_cols; g.small_size = small_size; g.base2k = base2k; g.body_col = body_col;
+    g.tw1 = M->s_tw1; g.tw12t = M->s_tw12t; g.wL2 = M->s_wL2; g.tw1inv = M->s_tw1inv; g.margin = M->probe ? M->margin : nullptr;
+    const int m1 = small_m1(M);
+    const size_t lds = ((size_t)8 * m1 * kSmallRS + kSmallM2 + m1) * sizeof(cplx);   // tile of 8 polynomials + wL2 + tw1inv
+    KTimer kt(M, PZ_K_FUSED_TAIL);
+#define X(M1_, KS_)                                                                                           \
+    if (m1 == M1_ && ksz == KS_) {                                                                            \
+        PZ_TRY(set_lds((k_small_one<M1_, KS_>), lds));                                                        \
+        hipLaunchKernelGGL((k_small_one<M1_, KS_>), dim3(batch), dim3(512), lds, M->stream, g);               \
+        dispatch_note(M, "k_small_one<M1=%d,KS=%d> (one kernel per ciphertext, %d input polynomials)", M1_, KS_, npi); \
+        PZ_HIP(hipGetLastError());                                                                            \
+        return PZ_OK;                                                                                         \
+    }
+    X(4, 1) X(4, 2) X(4, 3) X(4, 4) X(8, 1) X(8, 2) X(8, 3) X(8, 4)
+#undef X
+    return fail(PZ_ERR_UNSUPPORTED, "one-kernel product: m1 = %d, %d key limbs", m1, ksz);
 }
 
 }  // namespace pz

@@ -15,9 +15,10 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 SCRATCH_ALLOWED = {
     "k_br_fused<4, 2, 512, 1, 6, 3, *>": (32, "one-kernel rotation, N = 512 rank 3 with two ciphertexts per workgroup, at the 256-register cap: 3 - 6 "
                                                "registers spilled since the key values arrive through buffer loads (round 5, 79aa705); stored once per block"),
-    "k_mid128r<4, 16, false, 16, false, 6, true>": (24, "digit-selected (dsize > 1) middle kernel: 5 registers of the per-term tables, stored once in "
+    "k_mid128r<4, 16, false, 16, false, 6, true, false>": (24, "digit-selected (dsize > 1) middle kernel: 5 registers of the per-term tables, stored once in "
                                                          "the prologue and re-read once per tile (NOTEBOOK 12.7)"),
     "k_mid128<4, 16, *, false, false, true, 0, 0>": (104, "digit-selected k_mid128: only reached with POULPY_DBG_MID_R=0 (the cross-check path of k_mid128r<..,DS>)"),
+    "k_small_one<4, 3>": (16, "one-kernel product at N = 1024 with 3 key limbs at the 128-register cap of its two workgroups per CU: 3 registers"),
     "k_inv_tail<8, 8, 16, true, false, false, 2, *>": (12, "pairwise tensoring tail (mode-5 prefetch of the diagonal digits) at the 168-register cap of its 3 waves per SIMD"),
     "k_inv_tail<16, 16, 16, true, false, false, 2, *>": (16, "pairwise tensoring tail at N = 2^16: as above, 2 registers"),
     "k_inv_tail<16, 16, 16, true, false, false, 4, *>": (16, "pairwise tensoring tail reading the 16-bit side copies (round 6): 1 - 2 registers at the same cap"),
@@ -61,7 +62,7 @@ def test_allow_list_has_no_dead_entries(table):
 
 def test_headline_kernels_are_spill_free(table):
     by = {r["name"]: r for r in table}
-    for name in ("k_mid128r<4, 16, false, 16, false, 6, false>", "k_fwd_pass1<16, 16, 16, true, false>",
+    for name in ("k_mid128r<4, 16, false, 16, false, 6, false, false>", "k_mid128r<4, 16, false, 16, false, 6, false, true>", "k_fwd_pass1<16, 16, 16, true, false>",
                  "k_inv_tail<16, 16, 16, true, false, false, 0, false, false, false>", "k_mid_cnv3<16, 16, false, 12>", "k_mid_cnv3<16, 16, true, 12>", "k_mid_cnv3<16, 16, false, 0>", "k_mid_cnv3<16, 16, true, 0>",
                  "k_inv_tail<16, 16, 16, true, false, false, 3, false, false, false>"):
         assert name in by, "kernel not found in the library: %s" % name
