@@ -90,13 +90,20 @@ def main():
     mod.dispatch_notes(reset=True)
     mod.blind_rotation_execute_batched(ptr(res), ptr(lwe), ptr(lut), ptr(brk), p, args.batch)   # warm-up
     mod.sync()
+    # at least ~0.3 s of timed work (a 7 ms call timed over 3 repetitions ran on clocks still ramping: the gate-bootstrap line, timed later in the same
+    # process, came out FASTER than the rotation inside it)
+    t0 = time.perf_counter()
+    mod.blind_rotation_execute_batched(ptr(res), ptr(lwe), ptr(lut), ptr(brk), p, args.batch)
+    mod.sync()
+    one = max(time.perf_counter() - t0, 1e-4)
+    reps = max(args.reps, min(100, int(0.3 / one) + 1))
     R.sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.reps):
+    for _ in range(reps):
         mod.blind_rotation_execute_batched(ptr(res), ptr(lwe), ptr(lut), ptr(brk), p, args.batch)
     mod.sync()
     R.sync_all()
-    dt_mine = (time.perf_counter() - t0) / args.reps
+    dt_mine = (time.perf_counter() - t0) / reps
     dt = R.max_seconds(dt_mine)   # the slowest rank's clock around the same barrier-bracketed region
     mod.set_kernel_timing(True)   # one more pass with per-class HIP-event timing (adds event overhead: not the timed run)
     mod.blind_rotation_execute_batched(ptr(res), ptr(lwe), ptr(lut), ptr(brk), p, args.batch)
@@ -134,15 +141,15 @@ def main():
         mod.sync()
         R.sync_all()
         t0 = time.perf_counter()
-        for _ in range(args.reps):
+        for _ in range(reps):
             bootstrap()
         mod.sync()
         R.sync_all()
-        dtb = R.max_seconds((time.perf_counter() - t0) / args.reps)
+        dtb = R.max_seconds((time.perf_counter() - t0) / reps)
         ks_stats = {"gate_bootstraps_per_s": args.batch * R.world / dtb, "ms_per_batch": dtb * 1e3,
                     "steps": "lwe_mod_switch_2n + blind_rotation_execute + lwe_from_glwe (key switch + sample extract), all device-resident"}
     out = {"metric": "CGGI blind rotations/s", "shape": args.shape, **s, "batch": args.batch, "value": args.batch * R.world / dt, "unit": "rotations/s",
-           "ms_per_batch": dt * 1e3, "rounding_margin": margin, "kernel_classes_launches_ms": kstats, "digits_balanced": bool((res.min() >= -half).item() and (res.max() < half).item())}
+           "ms_per_batch": dt * 1e3, "timed_calls": reps, "rounding_margin": margin, "kernel_classes_launches_ms": kstats, "digits_balanced": bool((res.min() >= -half).item() and (res.max() < half).item())}
     # which kernel instantiations ran, and the rotation priced against the three ceilings that can bound it (tools/roofline_models.py)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import roofline_models as rm

@@ -1,7 +1,7 @@
 #!/bin/bash
 # secondary bench.py lines at HEAD (run on the GPU box through gpurun): one JSON line each into gpurun_out/bench_lines.jsonl
 OUT=gpurun_out/bench_lines.jsonl; : > $OUT
-B="python bench.py --no-cpu-baseline --parity-samples 4 --steps 30"
+B="python bench.py --no-cpu-baseline --parity-samples 4 --steps 30 --sustained-seconds 0"   # (the sustained leg belongs to the default run: profiles/rNN_bench_default.json)
 $B >> $OUT 2>/dev/null
 $B --op keyswitch >> $OUT 2>/dev/null
 $B --op keyswitch --batch 4096 --steps 10 >> $OUT 2>/dev/null
@@ -28,6 +28,8 @@ $B --n 1024 --limbs 4 --base2k 17 --op trace --steps 20 >> $OUT 2>/dev/null
 $B --n 131072 --batch 512 --steps 10 >> $OUT 2>/dev/null
 $B --n 2048 --limbs 4 --base2k 17 --steps 100 >> $OUT 2>/dev/null
 $B --n 1024 --limbs 4 --base2k 17 --steps 100 >> $OUT 2>/dev/null
+$B --n 2048 --limbs 4 --base2k 17 --op keyswitch --steps 100 >> $OUT 2>/dev/null   # (N = 2048 key switch: the two-kernel pipeline; the external products above: k_small_one)
+$B --n 1024 --limbs 4 --base2k 17 --op keyswitch --steps 100 >> $OUT 2>/dev/null
 $B --n 8192 >> $OUT 2>/dev/null
 $B --n 16384 >> $OUT 2>/dev/null
 $B --n 32768 >> $OUT 2>/dev/null
@@ -45,10 +47,10 @@ PY
 python tools/bench_host_path.py 2>/dev/null; python tools/bench_host_path.py --pinned 2>/dev/null
 # GLWE tensoring / multiplication at the configs[4] shape (tools/bench_tensor.py): profiles/rNN_tensor_lines.jsonl
 T=gpurun_out/tensor_lines.jsonl; : > $T
-python tools/bench_tensor.py 2>/dev/null | tail -1 >> $T
-python tools/bench_tensor.py --mode square 2>/dev/null | tail -1 >> $T
-python tools/bench_tensor.py --limbs 8 --batch 512 2>/dev/null | tail -1 >> $T
-python tools/bench_tensor.py --relin 2>/dev/null | tail -1 >> $T
+python tools/bench_tensor.py 2>/dev/null | grep "^{" | tail -1 >> $T
+python tools/bench_tensor.py --mode square 2>/dev/null | grep "^{" | tail -1 >> $T
+python tools/bench_tensor.py --limbs 8 --batch 512 2>/dev/null | grep "^{" | tail -1 >> $T
+python tools/bench_tensor.py --relin 2>/dev/null | grep "^{" | tail -1 >> $T
 python -c "
 import json
 for l in open('gpurun_out/tensor_lines.jsonl'):

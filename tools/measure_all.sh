@@ -9,4 +9,5 @@ bash tools/prof.sh > $O/r${R}_prof.log 2>&1
 cp $O/prof/trace_steady.txt $O/r${R}_kernel_steady.txt 2>/dev/null
 find $O/prof/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/r${R}_kernel_stats.csv
 cp $O/prof/pmc_fetch_summary.txt $O/r${R}_pmc_fetch_summary.txt; cp $O/prof/pmc_write_summary.txt $O/r${R}_pmc_write_summary.txt
+python tools/traffic_json.py $O/r${R}_pmc_fetch_summary.txt $O/r${R}_pmc_write_summary.txt $O/r${R}_traffic.json 1024 > $O/r${R}_traffic.txt 2>&1   # (with the kernels' code-object signatures)
 ls -la $O | grep r${R}_ | head -30
