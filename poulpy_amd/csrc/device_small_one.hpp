@@ -19,7 +19,7 @@
 //   A  forward column pass   thread = (polynomial, column j2): i64 -> f64, twist, radix-M1 butterfly, x tw12 -> tile[p][q1][j2]     (k_small_fwd)
 //   B  forward row pass      8 lanes per row, spectrum S[p][q1][q2] in place                                                       (k_mid128)
 //   C  product               thread = M1 / 4 frequency points; sum_r S[r] x P'[q1][r][c][q2] for all 2 KS output polynomials in registers
-//   per output column:  D inverse row pass, E inverse column pass + rounding, F carry chain from the last limb up + stores          (k_small_inv)
+//   both output columns: D inverse row pass, E inverse column pass + rounding, F carry chain from the last limb up + stores         (k_small_inv)
 // Same tables, same stage formulas as the two-kernel pipeline; the results are the same i64 limbs (tests/test_gpu_parity.py, pool tests).
 #pragma once
 #include "device_small.hpp"
@@ -45,6 +45,9 @@ struct SmallOneArgs {
 // (Measured and dropped, round 6: input groups of 4 polynomials through a 32-row tile at N = 2048 - 73.7 KiB, two workgroups per CU, the product's sums
 //  waiting in registers between the groups: at the 128-register cap of 16 waves per CU the kernel spills 76 - 640 B per lane, and the group loop alone
 //  costs the N = 1024 forms 12 - 112 B.  One group, the whole ciphertext in the tile.)
+// (Also measured and dropped: the i64 loads of both column-pass sweeps requested before the first butterfly, and the key values of the product's first row
+//  requested in front of the forward row pass - N = 1024: 16.55 -> 16.5 M external products/s, key switch 20.7 -> 19.9 M/s, 2 limbs 30.9 -> 29.5 M/s; N = 2048
+//  7.9 -> 7.8 M/s: with two workgroups per CU the other workgroup already fills those waits, and the extra live registers cost; profiles/r06_ab_small_one.txt)
 template <int M1, int KS>
 __global__ void __launch_bounds__(512, (M1 == 4 ? 4 : 2)) k_small_one(SmallOneArgs g) {   // (waves per SIMD: two workgroups per CU at N = 1024, one at 2048)
     constexpr int NT = 512, M2 = kSmallM2, RS = kSmallRS, CO = 2, NPO = CO * KS, PP = M1 / 4;
@@ -157,122 +160,128 @@ __global__ void __launch_bounds__(512, (M1 == 4 ? 4 : 2)) k_small_one(SmallOneAr
 #undef PZ_ONE_LOAD
 #undef PZ_ONE_USE
     }
-    // ---------------- per output column: D inverse row pass, E inverse column pass + rounding, F carry chain + stores (k_small_inv) ----------------
-    constexpr int JG = M1 / 4;   // thread groups over j1: the chain thread's outputs are j1 = JG e + jq, e < 4
-    const int cj2 = tid & 127, ch = (tid >> 7) & 1, jq = tid >> 8;   // chain threads: tid < 64 M1 (component 0: coefficients j < m, 1: j >= m)
-    const bool chain_thread = tid < 64 * M1;
+    // ---------------- BOTH output columns through the tile at once (2 KS polynomials x M1 rows <= the tile's 8 M1): D inverse row pass, E inverse column pass +
+    // rounding, F carry chain + stores (k_small_inv's stages).  (First version: one column at a time - eight barriers and a quarter to a half of the threads
+    // busy in D and F; this form: four barriers.)  Tile slot of output polynomial (limb l, column col) = col * KS + l ----------------
+    constexpr int JG = M1 / 4;         // thread groups over j1: a chain thread's outputs are j1 = JG e + jq, e < 4
+    constexpr int CT_N = 64 * M1;      // chain threads per column
+    constexpr int CPR = NT / CT_N;     // columns per chain round: 2 at N = 1024, 1 at N = 2048
     const unsigned long long half = 1ull << (k - 1), mask = (1ull << k) - 1;
+    __syncthreads();   // every spectrum value has been read
 #pragma unroll
-    for (int col = 0; col < CO; ++col) {
-        __syncthreads();   // every spectrum value (col 0) / every integer of the previous column (col 1) has been read
+    for (int c = 0; c < NPO; ++c)
 #pragma unroll
-        for (int l = 0; l < KS; ++l)
+        for (int j = 0; j < PP; ++j) lds[(((c % CO) * KS + c / CO) * M1 + pq1 + 4 * j) * RS + pq2] = acc[c][j];
+    __syncthreads();
+    // ---- D: inverse row pass of the 2 KS polynomials, x conj tw12, back into the tile as T2[q1][j2]
+    {
+        const int rp = tid / (8 * M1), rrow = (tid % (8 * M1)) >> 3, ro = tid & 7;   // 8 M1 threads per polynomial: 16 / 8 polynomials per sweep
+        if (rp < NPO) {
+            cplx* rowbuf = lds + (rp * M1 + rrow) * RS;
+            cplx u[16];
 #pragma unroll
-            for (int j = 0; j < PP; ++j) lds[(l * M1 + pq1 + 4 * j) * RS + pq2] = acc[l * CO + col][j];
-        __syncthreads();
-        // ---- D: inverse row pass of the KS polynomials, x conj tw12, back into the tile as T2[q1][j2]
-        {
-            const int rp = tid / (8 * M1), rrow = (tid % (8 * M1)) >> 3, ro = tid & 7;   // 8 M1 threads per polynomial
-            if (rp < KS) {
-                cplx* rowbuf = lds + (rp * M1 + rrow) * RS;
-                cplx u[16];
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int k2 = 0; k2 < 8; ++k2) u[8 * h + k2] = rowbuf[ro + 8 * h + 16 * k2];
+            Bfly<8, true>::run(u);
+            Bfly<8, true>::run(u + 8);
+            row_sync();
 #pragma unroll
-                    for (int k2 = 0; k2 < 8; ++k2) u[8 * h + k2] = rowbuf[ro + 8 * h + 16 * k2];
-                Bfly<8, true>::run(u);
-                Bfly<8, true>::run(u + 8);
-                row_sync();
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int oo = 0; oo < 8; ++oo) {
+                    cplx v = u[8 * h + oo];
+                    const int k1 = ro + 8 * h;
+                    if (k1 > 0 && oo > 0) v = cmulc(v, wl[oo * k1]);
+                    rowbuf[k1 * 9 + oo] = v;
+                }
+            row_sync();
 #pragma unroll
-                    for (int oo = 0; oo < 8; ++oo) {
-                        cplx v = u[8 * h + oo];
-                        const int k1 = ro + 8 * h;
-                        if (k1 > 0 && oo > 0) v = cmulc(v, wl[oo * k1]);
-                        rowbuf[k1 * 9 + oo] = v;
-                    }
-                row_sync();
+            for (int k1 = 0; k1 < 16; ++k1) u[k1] = rowbuf[k1 * 9 + ro];
+            Bfly<16, true>::run(u);
+            row_sync();
+            const cplx* tw = g.tw12t + rrow * M2 + ro;
 #pragma unroll
-                for (int k1 = 0; k1 < 16; ++k1) u[k1] = rowbuf[k1 * 9 + ro];
-                Bfly<16, true>::run(u);
-                row_sync();
-                const cplx* tw = g.tw12t + rrow * M2 + ro;
+            for (int h = 0; h < 2; ++h) {   // the 16 inter-pass twiddles in two batches of 8 (k_small_inv)
+                cplx t8[8];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {   // the 16 inter-pass twiddles in two batches of 8 (k_small_inv)
-                    cplx t8[8];
+                for (int i = 0; i < 8; ++i) t8[i] = tw[8 * (8 * h + i)];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) t8[i] = tw[8 * (8 * h + i)];
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < 8; ++i) rowbuf[ro + 8 * (8 * h + i)] = cmulc(u[8 * h + i], t8[i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- E: inverse column pass + rounding: thread = (polynomial slot, column j2), 4 slots per sweep; the 2 M1 integers take the place of the column's M1 complex values
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) rowbuf[ro + 8 * (8 * h + i)] = cmulc(u[8 * h + i], t8[i]);
-                    __builtin_amdgcn_sched_barrier(0);
+    for (int cl0 = 0; cl0 < NPO; cl0 += NT / 128) {
+        const int cl = cl0 + (tid >> 7), cj = tid & 127;
+        if (cl < NPO) {
+            cplx v[M1];
+#pragma unroll
+            for (int q1 = 0; q1 < M1; ++q1) v[q1] = lds[(cl * M1 + q1) * RS + cj];
+            Bfly<M1, true>::run(v);
+            double big = 0.0;   // a SUM: a NaN or an infinity anywhere selects the saturating conversion (k_small_inv)
+#pragma unroll
+            for (int j1 = 0; j1 < M1; ++j1) big += fabs(v[j1].x) + fabs(v[j1].y);
+            big *= 1.0 / (double)m;
+            longlong2* out = reinterpret_cast<longlong2*>(lds);
+            if (PZ_SMALL_PROBE && g.margin) {   // rounding-margin probe: the values rounded below
+                double worst = 0.0;
+#pragma unroll
+                for (int j1 = 0; j1 < M1; ++j1) {
+                    const cplx val = cmul(v[j1], tw1i[j1]);
+                    worst = fmax(worst, fmax(margin_dist(val.x), margin_dist(val.y)));
+                }
+                margin_note(g.margin, worst);
+            }
+            if (big < 2251799813685247.0) {   // 2^51 - 1 (false for NaN too)
+#pragma unroll
+                for (int j1 = 0; j1 < M1; ++j1) {
+                    const cplx val = cmul(v[j1], tw1i[j1]);
+                    out[(cl * M1 + j1) * RS + cj] = make_longlong2(fast_i64_from_integral(round_half_away(val.x)), fast_i64_from_integral(round_half_away(val.y)));
+                }
+            } else {
+#pragma unroll
+                for (int j1 = 0; j1 < M1; ++j1) {
+                    const cplx val = cmul(v[j1], tw1i[j1]);
+                    out[(cl * M1 + j1) * RS + cj] = make_longlong2(sat_i64_from_integral(round_half_away(val.x)), sat_i64_from_integral(round_half_away(val.y)));
                 }
             }
         }
-        __syncthreads();
-        // the key-switch body of the chain thread's coefficients, all limbs, requested between the row and the column pass (k_small_inv)
-        const long long* small_col =
-            (chain_thread && g.small && (col == g.body_col || g.body_col < 0))
-                ? g.small + (long long)b * g.small_bs + (g.body_col < 0 ? (long long)col * n : 0) + (ch ? m : 0) + cj2 + (long long)jq * M2
-                : nullptr;
-        const long long small_ls = (long long)g.small_cols * n;
-        long long smv[KS][4];
+    }
+    __syncthreads();
+    // ---- F: (+ key-switch body), carry chain from the last limb up, stores: thread = (column of the ciphertext, column j2, component, j1 group), 4 coefficients
+    // per limb; no barrier between the rounds (the chains only read the tile)
+    {
+        const int tl = tid % CT_N;
+        const int cj2 = tl & 127, ch = (tl >> 7) & 1, jq = tl >> 8;   // component 0: coefficients j < m, 1: j >= m
+        const long long* xin = reinterpret_cast<const long long*>(lds);
 #pragma unroll
-        for (int j = 0; j < KS; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) smv[j][e] = 0;
-        if (small_col && g.small_size > 0) {
+        for (int c0 = 0; c0 < CO; c0 += CPR) {
+            const int col = c0 + tid / CT_N;
+            const long long* small_col =
+                (g.small && (col == g.body_col || g.body_col < 0))
+                    ? g.small + (long long)b * g.small_bs + (g.body_col < 0 ? (long long)col * n : 0) + (ch ? m : 0) + cj2 + (long long)jq * M2
+                    : nullptr;
+            const long long small_ls = (long long)g.small_cols * n;
+            long long smv[KS][4];
 #pragma unroll
             for (int j = 0; j < KS; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) smv[j][e] = small_col[(long long)min(j, g.small_size - 1) * small_ls + JG * e * M2];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- E: inverse column pass + rounding: thread = (limb, column j2); the 2 M1 integers take the place of the column's M1 complex values
-        {
-            const int cl = tid >> 7, cj = tid & 127;
-            if (cl < KS) {
-                cplx v[M1];
+                for (int e = 0; e < 4; ++e) smv[j][e] = 0;
+            if (small_col && g.small_size > 0) {   // the body operand of this thread's coefficients, all limbs, in one batch
 #pragma unroll
-                for (int q1 = 0; q1 < M1; ++q1) v[q1] = lds[(cl * M1 + q1) * RS + cj];
-                Bfly<M1, true>::run(v);
-                double big = 0.0;   // a SUM: a NaN or an infinity anywhere selects the saturating conversion (k_small_inv)
+                for (int j = 0; j < KS; ++j)
 #pragma unroll
-                for (int j1 = 0; j1 < M1; ++j1) big += fabs(v[j1].x) + fabs(v[j1].y);
-                big *= 1.0 / (double)m;
-                longlong2* out = reinterpret_cast<longlong2*>(lds);
-                if (PZ_SMALL_PROBE && g.margin) {   // rounding-margin probe: the values rounded below
-                    double worst = 0.0;
-#pragma unroll
-                    for (int j1 = 0; j1 < M1; ++j1) {
-                        const cplx val = cmul(v[j1], tw1i[j1]);
-                        worst = fmax(worst, fmax(margin_dist(val.x), margin_dist(val.y)));
-                    }
-                    margin_note(g.margin, worst);
-                }
-                if (big < 2251799813685247.0) {   // 2^51 - 1 (false for NaN too)
-#pragma unroll
-                    for (int j1 = 0; j1 < M1; ++j1) {
-                        const cplx val = cmul(v[j1], tw1i[j1]);
-                        out[(cl * M1 + j1) * RS + cj] = make_longlong2(fast_i64_from_integral(round_half_away(val.x)), fast_i64_from_integral(round_half_away(val.y)));
-                    }
-                } else {
-#pragma unroll
-                    for (int j1 = 0; j1 < M1; ++j1) {
-                        const cplx val = cmul(v[j1], tw1i[j1]);
-                        out[(cl * M1 + j1) * RS + cj] = make_longlong2(sat_i64_from_integral(round_half_away(val.x)), sat_i64_from_integral(round_half_away(val.y)));
-                    }
-                }
+                    for (int e = 0; e < 4; ++e) smv[j][e] = small_col[(long long)min(j, g.small_size - 1) * small_ls + JG * e * M2];
             }
-        }
-        __syncthreads();
-        // ---- F: (+ key-switch body), carry chain from the last limb up, stores: thread = (column j2, component, j1 group), 4 coefficients per limb
-        if (chain_thread) {
+            __builtin_amdgcn_sched_barrier(0);
             long long carry[4] = {0, 0, 0, 0};
             long long* res_col = g.res + (long long)b * g.res_bs + (long long)col * n + (ch ? m : 0) + cj2 + (long long)jq * M2;
             const long long res_ls = (long long)g.res_cols * n;
-            const long long* xin = reinterpret_cast<const long long*>(lds);
             // limbs of res beyond the precision of the big value are zero (normalize.rs:118-120)
             for (int j = KS; j < g.res_size; ++j)
 #pragma unroll
@@ -283,7 +292,7 @@ __global__ void __launch_bounds__(512, (M1 == 4 ? 4 : 2)) k_small_one(SmallOneAr
                 long long x1v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    long long x = xin[2 * ((j * M1 + JG * e + jq) * RS + cj2) + ch];
+                    long long x = xin[2 * (((col * KS + j) * M1 + JG * e + jq) * RS + cj2) + ch];
                     if (has_body) x = (long long)((unsigned long long)x + (unsigned long long)smv[j][e]);
                     long long& cy = carry[e];
                     const unsigned long long y = (unsigned long long)x + half;

@@ -124,6 +124,27 @@ def test_config2_external_product_at_batch_1024(mods):
     assert _pool_parity(hip, ref, False, n, 1, 4, 17, 4, batch=1027, pool=41, seed=1027, pin=True) == 0
 
 
+@pytest.mark.parametrize("n,size,base2k,ks,one_kernel", [
+    (1024, 4, 17, False, True),    # external product, N = 1024: two workgroups per CU, both output columns through the tile at once
+    (1024, 4, 17, True, True),     # key switch, N = 1024: 4 input polynomials, body operand on column 0
+    (1024, 2, 20, False, True),    # 2 limbs
+    (2048, 4, 17, False, True),    # external product, N = 2048: one workgroup per CU, the chain in two rounds
+    (2048, 3, 18, False, True),    # 3 limbs (KS = 3)
+    (2048, 4, 17, True, False),    # key switch at N = 2048 stays on the two-kernel pipeline (measured - 4 % on one kernel)
+])
+def test_one_kernel_product_pool_parity_at_bench_batch(mods, n, size, base2k, ks, one_kernel):
+    """Round 6, k_small_one (device_small_one.hpp): forward transforms, product, inverse transforms and carry chains of a ciphertext in ONE workgroup at N = 1024 /
+    2048 - 1027 ciphertexts per call (ragged against nothing: one workgroup per ciphertext, the last CU round is partial), pinned and unpinned key, every
+    output against its pool entry, the margin probe re-run on the same dispatch; the dispatch note names the form."""
+    ref, hip = mods(n)
+    for pin in (False, True):
+        hip.dispatch_notes(reset=True)
+        assert _pool_parity(hip, ref, ks, n, 1, size, base2k, size, batch=1027, pool=23, seed=7000 + n + size + int(ks), pin=pin) == 0
+        notes = hip.dispatch_notes()
+        if os.environ.get("POULPY_DBG_SMALL_ONE", "1") != "0":
+            assert ("k_small_one<M1=%d,KS=%d>" % (n // 256, size) in notes) == one_kernel, notes
+
+
 def test_config5_shape_keyswitch_16_limbs_at_batch_256(mods):
     """BASELINE configs[4] shape (N = 2^16, 16 limbs: 32 output polynomials, k_mid128<2,32>) at 259 ciphertexts per call."""
     n = 65536

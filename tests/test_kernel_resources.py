@@ -18,7 +18,6 @@ SCRATCH_ALLOWED = {
     "k_mid128r<4, 16, false, 16, false, 6, true, false>": (24, "digit-selected (dsize > 1) middle kernel: 5 registers of the per-term tables, stored once in "
                                                          "the prologue and re-read once per tile (NOTEBOOK 12.7)"),
     "k_mid128<4, 16, *, false, false, true, 0, 0>": (104, "digit-selected k_mid128: only reached with POULPY_DBG_MID_R=0 (the cross-check path of k_mid128r<..,DS>)"),
-    "k_small_one<4, 3>": (16, "one-kernel product at N = 1024 with 3 key limbs at the 128-register cap of its two workgroups per CU: 3 registers"),
     "k_inv_tail<8, 8, 16, true, false, false, 2, *>": (12, "pairwise tensoring tail (mode-5 prefetch of the diagonal digits) at the 168-register cap of its 3 waves per SIMD"),
     "k_inv_tail<16, 16, 16, true, false, false, 2, *>": (16, "pairwise tensoring tail at N = 2^16: as above, 2 registers"),
     "k_inv_tail<16, 16, 16, true, false, false, 4, *>": (16, "pairwise tensoring tail reading the 16-bit side copies (round 6): 1 - 2 registers at the same cap"),
