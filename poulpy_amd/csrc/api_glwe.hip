@@ -481,7 +481,7 @@ static int glwe_small_ring(const GlweCall& c) {
         PolyMap sm{av.size, c.s.cols_in, av.bs, (long long)av.cols * c.n, c.n, c.n * c.s.a_col0};
         const long long* body = c.ks ? (const long long*)av.p : nullptr;
         // plain product / key switch of a rank-1 ciphertext: one kernel, the spectra never leave the CU (round 6, device_small_one.hpp)
-        if (!c.au && !c.cross_out && small_one_supported(M, c.npi, c.nrows, c.ncols, c.s.cols_out, c.ksz)) {
+        if (!c.au && !c.cross_out && small_one_supported(M, c.npi, c.nrows, c.ncols, c.s.cols_out, c.ksz, nb)) {
             PZ_TRY(launch_small_one(M, nb, (const long long*)av.p, sm, Pp, c.npi, c.nrows, c.ncols, c.ksz, (long long*)c.res_at(b0), c.res_bs, c.s.cols_out,
                                     (int)c.p->res_size, body, av.bs, c.s.cols_a, av.size, (int)c.p->res_base2k, c.body_col));
             continue;

@@ -264,6 +264,9 @@ struct MidCnv3Args {
 #ifndef PZ_CNV_STAMP
 #define PZ_CNV_STAMP 0   // diagnostic build: per-phase s_memtime totals of k_mid_cnv3, printed by a few waves (tools/dbg/cnv_stamps.sh)
 #endif
+#ifndef PZ_CNV_PRIO
+#define PZ_CNV_PRIO 0    // A/B: static wave priority (1 - 3) for the half-pairwise waves during the convolution
+#endif
 #ifndef PZ_CNV_EARLY
 #define PZ_CNV_EARLY 1   // static-window forms: the next tile's operand loads travel under the convolution (0: under the inverse row pass, as the WLO = 0 forms)
 #endif
@@ -392,6 +395,11 @@ __global__ void __launch_bounds__(512) k_mid_cnv3(MidCnv3Args g) {
             cplx* out = lds + (term * g.min_size) * RS + pt;   // result rows [term][kk]: written only after every operand value has been read
             constexpr int NKH = (NK + 1) / 2;
             const int hp = grp - 2;    // groups 2 / 3: this thread's product limbs are k = 2 u + hp
+#if PZ_CNV_PRIO
+            // the half-pairwise wave of a SIMD has half the multiply-adds of the diagonal wave beside it but starts later (32 + 32 operand reads and their sums) and,
+            // dispatched second, loses the arbitration: with static priority it finishes first and the diagonal wave fills its gaps
+            if (grp >= 2) __builtin_amdgcn_s_setprio(PZ_CNV_PRIO);
+#endif
             cplx av[AS], acc[NK];      // (groups 2 / 3 use acc[0 .. NKH); product limbs below WLO are never touched: no registers)
 #pragma unroll
             for (int k = 0; k < NK; ++k) acc[k] = make_double2(0.0, 0.0);
@@ -490,6 +498,9 @@ __global__ void __launch_bounds__(512) k_mid_cnv3(MidCnv3Args g) {
 #undef PZ_PW_HALF
             }
 #undef PZ_XL
+#if PZ_CNV_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             PZ_CSTAMP(3)   // limb convolution
             lds_barrier();   // every operand value has been read: the result rows take the place of the first operand rows
             if (grp < 2) {

@@ -145,7 +145,7 @@ int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int
                      bool au = false, unsigned au_p = 0, int au_mode = 0, bool post_rsh = false, int acc32 = 0);
 // ONE kernel per call for N = 1024 / 2048 (device_small_one.hpp): forward transforms, product, inverse transforms and carry chains of a ciphertext in
 // one workgroup; rank 1 (2 output columns), <= 8 input polynomials, <= 4 key limbs, key columns = ksz * 2
-bool small_one_supported(const pz_module* M, int npi, int nrows, int ncols, int cols_out, int ksz);
+bool small_one_supported(const pz_module* M, int npi, int nrows, int ncols, int cols_out, int ksz, int batch);
 int launch_small_one(pz_module* M, int batch, const long long* src, PolyMap smap, const cplx* Pp, int npi, int nrows, int ncols, int ksz, long long* res,
                      long long res_bs, int res_cols, int res_size, const long long* small, long long small_bs, int small_cols, int small_size, int base2k,
                      int body_col);

@@ -175,12 +175,16 @@ int launch_small_inv(pz_module* M, int batch, const cplx* S, const cplx* Pp, int
 }
 
 // N = 1024 / 2048, plain product / key switch of a rank-1 ciphertext: ONE kernel per call (device_small_one.hpp)
-bool small_one_supported(const pz_module* M, int npi, int nrows, int ncols, int cols_out, int ksz) {
+bool small_one_supported(const pz_module* M, int npi, int nrows, int ncols, int cols_out, int ksz, int batch) {
     static const bool on = (exp_knob("POULPY_DBG_SMALL_ONE", 1) != 0);
     const int m1 = small_m1(M);
     // measured (profiles/r06_ab_small_one.txt, 1024 per call): N = 1024 + 7 ... + 20 % on every shape; N = 2048 + 4 % for the external product (8 input
-    // polynomials), - 4 % for the key switch (4 inputs: the two-kernel pipeline has two workgroups per CU there, this kernel one) - which stays on two kernels
-    return on && (M->m % kSmallM2) == 0 && (m1 == 4 || (m1 == 8 && npi > 4)) && cols_out == 2 && ksz >= 1 && ksz <= 4 && ncols == ksz * cols_out && npi >= 1 &&
+    // polynomials), - 5 ... 8 % for the key switch (4 inputs: the two-kernel pipeline has two workgroups per CU there, this kernel one) - which stays on two kernels
+    // below ~3000 ciphertexts per call (at 4096 the one-kernel form is + 7 %: the two-kernel path's spectra no longer sit in the Infinity Cache)
+#ifndef PZ_SMALL_ONE_ALL
+#define PZ_SMALL_ONE_ALL 0   // A/B builds: 1 = also the N = 2048 shapes with <= 4 input polynomials
+#endif
+    return on && (M->m % kSmallM2) == 0 && (m1 == 4 || (m1 == 8 && (npi > 4 || batch >= 3072 || PZ_SMALL_ONE_ALL))) && cols_out == 2 && ksz >= 1 && ksz <= 4 && ncols == ksz * cols_out && npi >= 1 &&
            npi <= 8 && nrows >= 1;
 }
 int launch_small_one(pz_module* M, int batch, const long long* src, PolyMap smap, const cplx* Pp, int npi, int nrows, int ncols, int ksz, long long* res,

@@ -81,3 +81,26 @@ def test_fewer_devices_than_ranks_is_a_one_line_refusal():
     mine = [l for l in out.stderr.splitlines() if l.startswith("bench.py:")]
     assert len(mine) == 1 and "needs 64 HIP devices" in mine[0] and "no line reported" in mine[0]
     assert not any(l.startswith("{") for l in out.stdout.splitlines())
+
+
+def test_roofline_traffic_is_keyed_on_the_kernel_signature(tmp_path, monkeypatch):
+    """bench.py quotes the committed PMC traffic only while the kernel in the library that runs NOW carries the code-object signature the
+    profile was taken on (tools/traffic_json.py::kernel_signatures); a profile of another build yields traffic = null instead of a stale number."""
+    import glob as _glob
+    import shutil
+    b = _load_bench()
+    if not os.path.exists(os.path.join(ROOT, "poulpy_amd", "libpoulpy_hip.so")) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("needs the built library and llvm-readelf")
+    files = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    doc = json.load(open(files[-1]))
+    assert doc.get("kernel_signatures") and "error" not in doc["kernel_signatures"], "the newest profiles/r*_traffic.json must carry kernel signatures"
+    live = b.pmc_traffic("fused_mid", int(doc["batch_per_launch"]))
+    assert live is not None and 1.6e10 < live < 1.9e10, live          # ~17.3 GB per 1024 products: one HBM round trip of the middle kernel
+    # the same profile with another build's signature: not this run's traffic
+    stale = dict(doc, kernel_signatures={k: "1/2/3/4/5" for k in doc["kernel_signatures"]})
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "r99_traffic.json").write_text(json.dumps(stale))
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    shutil.copytree(os.path.join(ROOT, "tools"), str(tmp_path / "tools"))
+    assert b.pmc_traffic("fused_mid", int(doc["batch_per_launch"])) is None
