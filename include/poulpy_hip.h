@@ -420,6 +420,14 @@ int pz_glwe_tensor_apply_batched(pz_module* m, int64_t* res, const int64_t* a, c
  * (rank+1, p->res_size).  Runs on the fused three-kernel pipeline for dsize = 1 and equal base2k (the configs[4] case). */
 int pz_glwe_tensor_relinearize_batched(pz_module* m, int64_t* res, const int64_t* a, const double* tsk_pmat, const pz_glwe_op_params* p,
                                        size_t batch);
+/* glwe_tensor_apply (mode PZ_TENSOR_APPLY) or glwe_tensor_square_apply (PZ_TENSOR_SQUARE, b ignored) followed by glwe_tensor_relinearize
+ * with the GLWETensor in scratch - poulpy-ckks's ciphertext multiplication / square (poulpy-ckks/src/leveled/default/mul.rs:49-85,
+ * :131-170: `tmp` taken from the scratch space, filled by the tensoring, consumed by the relinearization).  tp describes the tensoring
+ * (tp->res_size / res_base2k: the tensor), rp the relinearization (rp->a_size = tp->res_size, rp->a_base2k = tp->res_base2k).  Same
+ * digits as the two calls above on an i64 tensor; where every digit of the tensor fits 16 bits (one base2k <= 14 throughout, pipeline
+ * plans) the tensor only exists as 16-bit copies in the workspace: 2 B per coefficient written and read instead of 8.  Device pointers. */
+int pz_glwe_tensor_mul_relinearize_batched(pz_module* m, int64_t* res, const int64_t* a, const int64_t* b, const double* tsk_pmat,
+                                           const pz_glwe_tensor_params* tp, const pz_glwe_op_params* rp, int mode, size_t batch);
 
 /* BlindRotationExecute<CGGI>::blind_rotation_execute (poulpy-bin-fhe/src/blind_rotation/algorithms/cggi/algorithm.rs:76-118)
  * on `batch` LWE ciphertexts that share the lookup table and the prepared blind-rotation key:

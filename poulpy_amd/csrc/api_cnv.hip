@@ -2,6 +2,7 @@
 // poulpy-cpu-ref/src/reference/fft64/convolution.rs) and of GLWE tensoring on device-resident batches
 // (poulpy-core/src/operations/glwe.rs:609-913), SURVEY.md §8f rank 4 / BASELINE configs[4].
 #include "api_common.hpp"
+#include "api_glwe.hpp"
 
 // CnvPVecL / CnvPVecR bytes in this backend: polynomial (col, limb) = its spectrum in device order at (col*size + limb)*n doubles.
 static inline size_t cnv_bytes(const pz_module* M, size_t cols, size_t size) { return (size_t)M->n * cols * size * 8; }
@@ -227,6 +228,10 @@ struct TensorWave {
     double *pa = nullptr, *pb = nullptr, *rd = nullptr;
     int64_t *tmp = nullptr, *diag = nullptr;
     short* d16 = nullptr;   // [diagonal term i][pair][res limb][n] (TensorPlan::d16)
+    // the fused multiply + relinearize (pz_glwe_tensor_mul_relinearize_batched): the GLWETensor leaves ONLY as 16-bit digits,
+    // t16[tensor column][pair][res limb][n] in the tail's tile order; `rb` is not written
+    short* t16 = nullptr;
+    long long t16_cs = 0;   // int16 elements between tensor columns
     cplx* T = nullptr;
     long long r_ct = 0, pa_bs = 0, pb_bs = 0, rd_bs = 0, tmp_bs = 0, dg_bs = 0, rls = 0, a_mask = 0, b_mask = 0;
     // the wave
@@ -324,6 +329,23 @@ struct TensorWave {
     // pair - d_i - d_j (mode 5: one write per column, no read-modify-write; wrapping i64: the same digits as the reference's order).
     // add_assign: the diagonal term goes into its column (+=) and out of the cross columns (-=), the pairwise term into its cross column (+=)
     int combine_in_stores() {
+        if (!add && t16) {
+            const long long ts = t16_cs;   // one tensor column
+            for (int i = 0; i < t.cols; ++i) {
+                NzCombine cb{1, {0, 0}, {0, 0}};
+                TailD16 dw;
+                dw.w = t16 + cidx(i, i) * ts; dw.only = true;
+                PZ_TRY(term(i, i, rb, r_ct, t.tcols, cidx(i, i), &cb, &dw));
+            }
+            for (int i = 0; i < t.cols; ++i)
+                for (int j = i + 1; j < t.cols; ++j) {
+                    NzCombine cb{1, {cidx(i, i), cidx(j, j)}, {5, 5}};
+                    TailD16 dr;
+                    dr.ra = t16 + cidx(i, i) * ts; dr.rb = t16 + cidx(j, j) * ts; dr.w = t16 + cidx(i, j) * ts; dr.only = true;
+                    PZ_TRY(term(i, j, rb, r_ct, t.tcols, cidx(i, j), &cb, &dr));
+                }
+            return PZ_OK;
+        }
         if (!add) {
             // the diagonal launches leave 16-bit copies of their digits beside the tensor columns (base2k <= 16, fused tails): the pairwise
             // launches read those - 2 B per coefficient and diagonal column instead of the 8 B a line of the i64 column costs
@@ -400,9 +422,13 @@ struct TensorWave {
     }
 };
 
+static int tensor_apply_nolock(pz_module* M, int64_t* res, const int64_t* a, const int64_t* b, const pz_glwe_tensor_params* p, int mode, size_t batch);
 int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, const int64_t* b, const pz_glwe_tensor_params* p, int mode,
                                  size_t batch) {
     PZ_ENTER(M);
+    return tensor_apply_nolock(M, res, a, b, p, mode, batch);
+}
+static int tensor_apply_nolock(pz_module* M, int64_t* res, const int64_t* a, const int64_t* b, const pz_glwe_tensor_params* p, int mode, size_t batch) {
     TensorPlan t;
     PZ_TRY(tensor_plan(M, p, mode, t));
     const bool square = mode == PZ_TENSOR_SQUARE;
@@ -425,6 +451,59 @@ int pz_glwe_tensor_apply_batched(pz_module* M, int64_t* res, const int64_t* a, c
         if (combine_env && p->res_base2k == p->ab_base2k && t.cols <= 3) PZ_TRY(w.combine_in_stores());
         else if (square) PZ_TRY(w.square_reference_order());
         else PZ_TRY(w.apply_reference_order());
+    }
+    return PZ_OK;
+}
+
+// glwe_tensor_apply (or _square_apply) followed by glwe_tensor_relinearize with the GLWETensor in scratch - poulpy-ckks's multiplication
+// (poulpy-ckks/src/leveled/default/mul.rs:49-85 ckks_mul_into_default, :131-170 the square: `tmp` is taken from the scratch space, filled by
+// glwe_tensor_apply and consumed by glwe_tensor_relinearize; operations/glwe.rs:609-913 and :541-607).  The tensor never reaches the caller, so
+// where its digits fit 16 bits (one base2k <= 14 throughout, pipeline plans) it only ever exists as int16 copies in the tails' own tile
+// order: the tensoring tails write 2 B per coefficient instead of 8, the relinearization's forward pass and tail read 2 B instead of 8
+// (9.6 GB less HBM traffic per 256 multiplications at N = 2^16, 16 limbs).  Everywhere else: the i64 tensor in the workspace, the two calls as they are.
+int pz_glwe_tensor_mul_relinearize_batched(pz_module* M, int64_t* res, const int64_t* a, const int64_t* b, const double* tsk_pmat,
+                                           const pz_glwe_tensor_params* tp, const pz_glwe_op_params* rp, int mode, size_t batch) {
+    PZ_ENTER(M);
+    PZ_REQUIRE(mode == PZ_TENSOR_APPLY || mode == PZ_TENSOR_SQUARE, "glwe_tensor_mul_relinearize: mode is apply or square");
+    TensorPlan t;
+    PZ_TRY(tensor_plan(M, tp, mode, t));
+    PZ_REQUIRE(rp != nullptr, "null params");
+    PZ_REQUIRE(rp->rank == tp->rank && rp->rank_out == rp->rank, "glwe_tensor_mul_relinearize: the tensor key maps rank (rank + 1) / 2 -> rank");
+    PZ_REQUIRE(rp->a_size == tp->res_size && rp->a_base2k == tp->res_base2k, "glwe_tensor_mul_relinearize: (a_size, a_base2k) of the relinearization describe the tensor");
+    const bool square = mode == PZ_TENSOR_SQUARE;
+    if (square) b = a;
+    PZ_REQUIRE(is_device_ptr(res) && is_device_ptr(a) && is_device_ptr(b) && is_device_ptr(tsk_pmat), "batched entry points take device pointers");
+    if (batch == 0) return PZ_OK;
+    TensorWave w;
+    w.M = M; w.p = tp; w.t = t; w.square = square; w.add = false; w.n = (long long)M->n;
+    static const bool t16_env = (exp_knob("POULPY_DBG_MUL_T16", 1) != 0);
+    static const bool combine_env = (rt_knob("POULPY_DBG_TENSOR_COMBINE", 1) != 0), fused_env = (rt_knob("POULPY_DBG_TENSOR_FUSED", 1) != 0);
+    const bool compact = t16_env && combine_env && fused_env && tp->res_base2k <= 14 && tp->res_base2k == tp->ab_base2k && t.cols <= 3 && t.dft_size >= 1 &&
+                         mid_cnv_supported(M, t.a_size, t.b_size, std::min(t.dft_size, t.a_size + t.b_size - 1)) && glwe_relin_t16_supported(M, rp);
+    const size_t chunk = std::min(tensor_chunk(M, t, batch), glwe_relin_chunk(M, rp, batch));
+    const long long a_ct = w.n * t.cols * t.a_size, b_ct = w.n * t.cols * t.b_size, res_ct = w.n * t.cols * (long long)rp->res_size;
+    const long long tensor_ct = w.n * t.tcols * t.res_size;
+    // the tensor of a wave: ws2 (the two halves of the call carve the main workspace one after the other).  16-bit form: the columns of a wave
+    // sit a fraction of the 4 MiB channel interleave out of phase - the pairwise tail reads two columns and writes the third at the same offset,
+    // the relinearization's tail reads one beside its spectrum and result streams (as T2' against the result, kT2Phase in api_glwe.hip)
+    static const long long t16_phase = (long long)exp_knob("POULPY_DBG_T16_PHASE_KIB", 768) * 1024 / 2;
+    const long long t16_cs = (long long)chunk * t.res_size * w.n + t16_phase;
+    PZ_TRY(ws2_reserve(M, compact ? (size_t)t16_cs * t.tcols * 2 : chunk * (size_t)tensor_ct * 8));
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const size_t nb = std::min(chunk, batch - b0);
+        int64_t* r0 = res + (long long)b0 * res_ct;
+        if (!compact) {
+            // (not through the public entry points: the module lock is held)
+            PZ_TRY(tensor_apply_nolock(M, (int64_t*)M->ws2, a + (long long)b0 * a_ct, b + (long long)b0 * b_ct, tp, mode, nb));
+            PZ_TRY(glwe_op(M, true, r0, (const int64_t*)M->ws2, tsk_pmat, rp, nb, nullptr, nullptr, true));
+            continue;
+        }
+        PZ_TRY(w.take_workspace(nb));
+        w.nb = (int)nb; w.rb = nullptr; w.t16 = (short*)M->ws2; w.t16_cs = t16_cs;
+        PZ_TRY(w.prepare(a + (long long)b0 * a_ct, b + (long long)b0 * b_ct));
+        PZ_REQUIRE(w.fused, "glwe_tensor_mul_relinearize: the fused tensoring path was expected here");
+        PZ_TRY(w.combine_in_stores());
+        PZ_TRY(glwe_relin_t16(M, r0, (const short*)M->ws2, t16_cs, tsk_pmat, rp, nb));
     }
     return PZ_OK;
 }

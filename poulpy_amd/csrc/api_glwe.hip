@@ -188,6 +188,10 @@ struct GlweCall {
     bool digits, cross_out;
     bool want_rsh;         // glwe_trace asked for the one-bit shift on the way out
     bool* post_rsh;        // ... and is told here whether it happened
+    // relinearization of a GLWETensor that exists only as 16-bit digits in the fused tail's tile order (glwe_relin_t16 below):
+    // a16[column][ciphertext of this call][limb][n], a16_cs int16 elements between columns; `a` is not read
+    const short* a16 = nullptr;
+    long long a16_cs = 0;
     int cols_in() const { return s.cols_in; }
     int64_t* res_at(size_t b0) const { return res + (long long)b0 * res_bs; }
 };
@@ -415,6 +419,7 @@ static int wave_plain_tail(const GlweCall& c, const FusedBufs& f, size_t b0, int
         TailCall t = wave_tail(c, nb, f.T2, b0);
         if (c.au) { t.res = (long long*)f.res_tmp; t.res_bs = c.res_ct; }
         if (c.ks) tail_operand(t, av, c.au_big || c.tensor);
+        if (c.a16) { t.acc32 = 4; t.small16 = c.a16 + (long long)b0 * av.size * c.n; t.small16_cs = c.a16_cs; t.small_bs = 0; }
         if (c.au_big) { t.auto_mul = c.au_p; t.gather_mul = c.au_p; t.gather_neg = c.au->mode != 1; }
         t.auto_neg = c.au && c.au->mode == 3;
         PZ_TRY(launch_inv_tail(M, t));
@@ -441,6 +446,10 @@ static int glwe_fused(const GlweCall& c) {
         PZ_TRY(wave_input(c, b0, nb, f.a_conv, &av));
         PolyMap sm{av.size, c.s.cols_in, av.bs, (long long)av.cols * c.n, c.n, c.n * c.s.a_col0};
         if (two_kernel) { PZ_TRY(wave_n4096_two_kernel(c, f, b0, nb, av, sm)); continue; }
+        if (c.a16) {
+            PolyMap s16{av.size, c.s.cols_in, (long long)av.size * c.n, c.n, c.a16_cs, c.a16_cs * c.s.a_col0};
+            PZ_TRY(launch_fwd_pass1_t16(M, nb * c.npi, c.a16 + (long long)b0 * av.size * c.n, s16, f.T));
+        } else
         if (M->dbg_stages & 1) PZ_TRY(launch_fwd_pass1(M, nb * c.npi, (const long long*)av.p, sm, f.T, true));
         if (c.digits && dg.n == 0) {   // nothing reaches the product (e.g. dsize > a.size): the big value is the body alone
             PZ_TRY(launch_zero_bytes(M, f.T2, (size_t)nb * c.npo * M->m * sizeof(cplx)));
@@ -699,6 +708,23 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
     if (fused_applies(M, p, c.s, c.tensor, au != nullptr)) return glwe_fused(c);
     if (small_ring_applies(M, p, c.s, c.ks, c.tensor, au != nullptr, lay == nullptr)) return glwe_small_ring(c);
     return glwe_unfused(c);
+}
+
+// glwe_tensor_relinearize on a GLWETensor kept as 16-bit digits (the fused multiply + relinearize, api_cnv.hip): forward pass 1 reads the pair
+// columns, the tail adds the first rank + 1 columns - both from a16 (GlweCall::a16)
+bool glwe_relin_t16_supported(const pz_module* M, const pz_glwe_op_params* p) {
+    if (!p || p->dsize != 1 || p->a_base2k != p->key_base2k || p->res_base2k != p->key_base2k || p->rank_out != p->rank || p->rank < 1) return false;
+    const OpShape s = op_shape(p, true, true);
+    return fused_applies(M, p, s, true, false) && tail_d16_only_supported(M) && M->dbg_stages == 7;
+}
+size_t glwe_relin_chunk(const pz_module* M, const pz_glwe_op_params* p, size_t batch) { return pick_chunk(M, p, op_shape(p, true, true), std::max<size_t>(batch, 1)); }
+int glwe_relin_t16(pz_module* M, int64_t* res, const short* a16, long long a16_cs, const double* pmat, const pz_glwe_op_params* p, size_t batch) {
+    GlweCall c;
+    PZ_TRY(glwe_call_init(c, M, true, res, reinterpret_cast<const int64_t*>(a16), pmat, p, batch, nullptr, nullptr, true, nullptr));
+    PZ_REQUIRE(glwe_relin_t16_supported(M, p) && !n4096_two_kernel(c), "glwe_relin_t16: the pipeline path only");
+    if (batch == 0) return PZ_OK;
+    c.a16 = a16; c.a16_cs = a16_cs;
+    return glwe_fused(c);
 }
 
 // The four GLWE-level entry points accept device pointers (batched, device-resident: the measured path) or HOST containers

@@ -107,6 +107,10 @@ int glwe_op(pz_module* M, bool ks, int64_t* res, const int64_t* a, const double*
 // glwe_trace_assign on a batch (poulpy-core glwe_trace.rs:129-176): one prepared key per step
 int glwe_trace(pz_module* M, int64_t* res, size_t nsteps, const int64_t* gals, const double* const* key_pmats, const pz_glwe_op_params* p,
                size_t batch);
+// tensor relinearization of GLWETensors held as 16-bit digits in the fused tail's tile order (api_cnv.hip's fused multiply + relinearize)
+bool glwe_relin_t16_supported(const pz_module* M, const pz_glwe_op_params* p);
+size_t glwe_relin_chunk(const pz_module* M, const pz_glwe_op_params* p, size_t batch);
+int glwe_relin_t16(pz_module* M, int64_t* res, const short* a16, long long a16_cs, const double* pmat, const pz_glwe_op_params* p, size_t batch);
 // ggsw_expand_row on `count` GGSWs (conversion/gglwe_to_ggsw.rs:116-268)
 int ggsw_expand_row(pz_module* M, int64_t* ggsw, size_t dnum, const double* const* tsk_pmat, const pz_glwe_op_params* p, size_t count);
 }

@@ -63,6 +63,12 @@ __device__ __forceinline__ void st_stream(cplx* p, cplx v) {
 }
 #ifndef PZ_STREAM_I64_NT
 #define PZ_STREAM_I64_NT 1   // the tail's digit stores (A/B knob)
+#ifndef PZ_TAIL_D16_ADDR
+#define PZ_TAIL_D16_ADDR 1   // 16-bit digit stores: 1 one base per thread + constant offsets, 0 the element from the coefficient's row / column (A/B knob)
+#endif
+#ifndef PZ_TAIL_D16R_F64
+#define PZ_TAIL_D16R_F64 0   // the pairwise tensoring tails that read 16-bit side copies: f64 normalization steps (0: the integer steps, A/B knob)
+#endif
 #endif
 __device__ __forceinline__ void st_stream(long long* p, long long v) {
     if ((PZ_STREAM_HINTS & 2) && PZ_STREAM_I64_NT) __builtin_nontemporal_store(v, p);
@@ -201,10 +207,13 @@ __device__ __forceinline__ long long fast_i64_from_integral(double r) {
 // ROWMAJOR = true writes T'[q1][j2] (rows of m2 contiguous points, what the fused middle kernel
 // consumes; tw12 must then be the [q1][j2] copy of the table) instead of the transposed T[j2][q1].
 // SRC32: the coefficients are 32-bit digits at the same element offsets (the blind rotation's accumulator between two blocks, api_br.hip)
-template <int R1, int R2, int CB, bool ROWMAJOR = false, bool SRC32 = false>
-__global__ void __launch_bounds__((R1 > R2 ? R1 : R2) * CB)
-k_fwd_pass1(const long long* __restrict__ src, PolyMap smap, cplx* __restrict__ T, int m2,
-            const cplx* __restrict__ tw1, const cplx* __restrict__ wL1, const cplx* __restrict__ tw12, long long mask, int npolys_xcd) {
+// SRC = 0 i64 coefficients | 1 = SRC32 | 2: 16-bit digits in the fused tail's tile order (TailArgs::d16*: smap addresses a limb of n int16, the
+// workgroup's tile [half h][row j1][CB columns] starts at (c0 / CB) 2 M1 CB) - the fused multiply + relinearize reads the pair column of a
+// GLWETensor that only ever existed as those copies (api_cnv.hip)
+template <int R1, int R2, int CB, bool ROWMAJOR, int SRC>
+__device__ __forceinline__ void fwd_pass1_body(const long long* __restrict__ src, PolyMap smap, cplx* __restrict__ T, int m2,
+                                               const cplx* __restrict__ tw1, const cplx* __restrict__ wL1, const cplx* __restrict__ tw12, long long mask, int npolys_xcd) {
+    constexpr bool SRC32 = SRC == 1;
     constexpr int M1 = R1 * R2;
     constexpr int NT = (R1 > R2 ? R1 : R2) * CB;
     extern __shared__ cplx lds[];  // (R1+1)*CB*R2 exchange | tw1[M1] | wL1[M1]
@@ -237,7 +246,11 @@ k_fwd_pass1(const long long* __restrict__ src, PolyMap smap, cplx* __restrict__ 
 #pragma unroll
         for (int n1 = 0; n1 < R1; ++n1) {
             const long long idx = (long long)(o + R2 * n1) * m2 + c0 + c;
-            if constexpr (SRC32) {
+            if constexpr (SRC == 2) {
+                const short* a16 = reinterpret_cast<const short*>(src) + map_off(smap, p) + (long long)(c0 / CB) * (2 * M1 * CB) + (o + R2 * n1) * CB + c;
+                raw_re[n1] = (long long)a16[0];
+                raw_im[n1] = (long long)a16[M1 * CB];
+            } else if constexpr (SRC32) {
                 const int* a32 = reinterpret_cast<const int*>(src) + map_off(smap, p);
                 raw_re[n1] = (long long)a32[idx];
                 raw_im[n1] = (long long)a32[idx + m];
@@ -280,6 +293,18 @@ k_fwd_pass1(const long long* __restrict__ src, PolyMap smap, cplx* __restrict__ 
             else Tp[tix] = cmul(u[k2], tw12[tix]);
         }
     }
+}
+template <int R1, int R2, int CB, bool ROWMAJOR = false, bool SRC32 = false>
+__global__ void __launch_bounds__((R1 > R2 ? R1 : R2) * CB)
+k_fwd_pass1(const long long* __restrict__ src, PolyMap smap, cplx* __restrict__ T, int m2,
+            const cplx* __restrict__ tw1, const cplx* __restrict__ wL1, const cplx* __restrict__ tw12, long long mask, int npolys_xcd) {
+    fwd_pass1_body<R1, R2, CB, ROWMAJOR, SRC32 ? 1 : 0>(src, smap, T, m2, tw1, wL1, tw12, mask, npolys_xcd);
+}
+template <int R1, int R2, int CB>
+__global__ void __launch_bounds__((R1 > R2 ? R1 : R2) * CB)
+k_fwd_pass1_t16(const long long* __restrict__ src, PolyMap smap, cplx* __restrict__ T, int m2,
+                const cplx* __restrict__ tw1, const cplx* __restrict__ wL1, const cplx* __restrict__ tw12, int npolys_xcd) {
+    fwd_pass1_body<R1, R2, CB, true, 2>(src, smap, T, m2, tw1, wL1, tw12, -1ll, npolys_xcd);
 }
 
 // =================================================================================
@@ -460,7 +485,8 @@ struct TailArgs {
     const cplx* tw1inv;
     const cplx* wL1;
     unsigned long long* margin;
-    int acc32;   // k_inv_tail<.., ACC32>: bit 0 `small` holds 32-bit digits, bit 1 `res` takes 32-bit digits (same element strides)
+    int acc32;   // k_inv_tail<.., ACC32>: bit 0 `small` holds 32-bit digits, bit 1 `res` takes 32-bit digits (same element strides); bit 2: the operand is
+                 // d16a[column][ciphertext][limb][n] int16 in the tile order below (body_bs = elements between columns): a GLWETensor kept as 16-bit digits
     // automorphism family (poulpy-core automorphism/glwe_ct.rs:96-275): the value that enters the carry chain is
     // s(n) * (big[n] + small[n]) with s(n) = -1 iff (n * auto_mul) mod 2N >= N (auto_neg flips every sign);
     // small_all: `small` has an operand for every column, not only the body column
@@ -555,8 +581,10 @@ k_inv_tail(TailArgs g) {
     // NZF: 0 none | 1 diagonal tensoring tail | 2 pairwise / raw | 3 = 1 + 16-bit side copy of every digit (TailArgs::d16w) | 4 = 2 with the mode-5
     // prefetch reading 16-bit side copies (TailArgs::d16a / d16b) instead of the i64 columns' low dwords.  Forms of their own: with both prefetch
     // paths in one instantiation the pairwise tail went from 12 to 28 B of scratch at its 168-register cap
-    constexpr int NZ = NZF == 3 ? 1 : (NZF == 4 ? 2 : NZF);
-    constexpr bool D16W = NZF == 3, D16R = NZF == 4;
+    // 5 / 6 = 3 / 4 whose digits leave ONLY as 16-bit copies (the fused multiply + relinearize never materializes the i64 GLWETensor; 6 writes the
+    // pairwise column's values pair - d_i - d_j, which fit 16 bits while base2k <= 14)
+    constexpr int NZ = (NZF == 3 || NZF == 5) ? 1 : ((NZF == 4 || NZF == 6) ? 2 : NZF);
+    constexpr bool D16W = NZF == 3 || NZF >= 5, D16R = NZF == 4 || NZF == 6, D16ONLY = NZF >= 5;
     static_assert(!ACC32 || (ROWMAJOR && SMALL && !RSH && !NZ && !SGN), "32-bit accumulator digits: the plain operand form of the row-major pipeline");
     static_assert(!NZ || (ROWMAJOR && !SMALL && !RSH), "tensoring forms: row-major pipeline layout, no operand");
     static_assert(!SGN || (ROWMAJOR && !SMALL && !RSH && !NZ), "sign-only form: row-major pipeline layout, no operand");
@@ -651,16 +679,25 @@ k_inv_tail(TailArgs g) {
     long long* nz_r2a = (NZ && g.nz && g.nz_mode2[0]) ? g.res + (long long)b * g.res_bs + (long long)g.nz_col2[0] * n : nullptr;
     long long* nz_r2b = (NZ && g.nz && g.nz_mode2[1]) ? g.res + (long long)b * g.res_bs + (long long)g.nz_col2[1] * n : nullptr;
     // 16-bit side copies (TailArgs::d16*): this workgroup's tile of limb r starts at (b res_size + r) n + (c0 / CB) 2 M1 CB
-    const int d16_sh = 31 - __builtin_clz((unsigned)g.m2);
     const long long d16_base = (long long)b * g.res_size * n + (long long)(c0 / CB) * (2 * M1 * CB);
-#define PZ_TAIL_D16_IDX(R_, IDX_) (d16_base + (long long)(R_) * n + (long long)((((IDX_) >> d16_sh) * CB) + ((IDX_) & (CB - 1))))
-#define PZ_TAIL_NZ_STORE(R_, IDX_, V_)                                                             \
+    // (the thread's E-th value, half H, of limb R: one base per thread and constant offsets - the tile order is this kernel's own)
+#if PZ_TAIL_D16_ADDR
+    const long long d16_t = d16_base + (b_o * CB + b_c) + (SPLIT ? hs * R2 * CB : 0);
+#define PZ_TAIL_D16_AT(R_, E_, H_, IDX_) (d16_t + (long long)(R_) * n + ((H_) * M1 * CB + (SPLIT ? 2 : 1) * R2 * CB * (E_)))
+#else   // the same element from the coefficient index (recomputed at every store: nothing of it stays live across the limb)
+    const int d16_sh = 31 - __builtin_clz((unsigned)g.m2);
+#define PZ_TAIL_D16_AT(R_, E_, H_, IDX_) (d16_base + (long long)(R_) * n + (long long)((((IDX_) >> d16_sh) * CB) + ((IDX_) & (CB - 1))))
+#endif
+#define PZ_TAIL_NZ_STORE(R_, IDX_, V_, E_, H_)                                                     \
     {                                                                                              \
         const long long off_ = (long long)(R_) * res_ls + (IDX_);                                  \
         long long v_ = (V_);                                                                       \
         if (NZ == 1) {   /* the launcher sends only plain stores here (mode 1, no second column): no test in front of the store */ \
-            st_stream(res_col + off_, v_);                                                         \
-            if (D16W) g.d16w[PZ_TAIL_D16_IDX(R_, IDX_)] = (short)v_;                               \
+            if (!D16ONLY) st_stream(res_col + off_, v_);                                           \
+            if (D16W) g.d16w[PZ_TAIL_D16_AT(R_, E_, H_, IDX_)] = (short)v_;                              \
+        } else if (D16ONLY) {   /* (the zero limbs and the carry-only top limbs of the pairwise column; its digit limbs leave through the d5 store) */ \
+            const long long at_ = PZ_TAIL_D16_AT(R_, E_, H_, IDX_);                                      \
+            g.d16w[at_] = (short)((int)v_ - (int)g.d16a[at_] - (g.d16b ? (int)g.d16b[at_] : 0));   \
         } else if (g.nz_mode2[0] == 5) {   /* mode 5: a column whose digits are SUBTRACTED from the value on its way to the main column */ \
             v_ = (long long)((unsigned long long)v_ - (unsigned long long)nz_r2a[off_]);           \
             if (nz_r2b) v_ = (long long)((unsigned long long)v_ - (unsigned long long)nz_r2b[off_]); \
@@ -685,8 +722,8 @@ k_inv_tail(TailArgs g) {
             const int n1 = PZ_TAIL_N1(e);
             const long long idx = (long long)(b_o + R2 * n1) * g.m2 + c0 + b_c;
             if (NZ && g.nz) {
-                PZ_TAIL_NZ_STORE(j, idx, 0)
-                PZ_TAIL_NZ_STORE(j, idx + m, 0)
+                PZ_TAIL_NZ_STORE(j, idx, 0, e, 0)
+                PZ_TAIL_NZ_STORE(j, idx + m, 0, e, 1)
             } else if (ACC32 && (g.acc32 & 2)) {
                 int* r32 = reinterpret_cast<int*>(g.res) + (res_col - g.res);
                 r32[(long long)j * res_ls + idx] = 0;
@@ -795,6 +832,17 @@ k_inv_tail(TailArgs g) {
                     sm[2 * e + h] = (long long)v;
                 }
             }
+        } else if (ACC32 && (g.acc32 & 4) && small_col && j < g.small_size) {
+            // the operand is a GLWETensor column that exists only as 16-bit digits in this kernel's own tile order (fused multiply + relinearize,
+            // api_cnv.hip): d16a[column][ciphertext][limb][n], body_bs = int16 elements between columns
+            const short* s16 = g.d16a + (long long)col * g.body_bs + ((long long)b * g.small_size + j) * n + (long long)(c0 / CB) * (2 * M1 * CB) +
+                               (b_ov * CB + b_cv) + (SPLIT ? hs * R2 * CB : 0);
+#pragma unroll
+            for (int e = 0; e < RE; ++e) {
+                const int o_ = (SPLIT ? 2 : 1) * R2 * CB * e;
+                sm[SMALL ? 2 * e : 0] = (long long)s16[o_];
+                sm[SMALL ? 2 * e + 1 : 0] = (long long)s16[M1 * CB + o_];
+            }
         } else if (ACC32 && (g.acc32 & 1) && small_col && j < g.small_size) {
             const int* s32 = reinterpret_cast<const int*>(g.small) + (small_col - g.small) + (long long)j * small_ls;
 #pragma unroll
@@ -890,9 +938,10 @@ k_inv_tail(TailArgs g) {
                     const long long dpc_ = (long long)(((unsigned long long)d_ << g.nz_lsh) + (unsigned long long)c_); \
                     const long long x1_ = tz_digit(k, dpc_);                                                 \
                     if (j < g.nz_a_start) {                                                                  \
-                        if (d5) tz_put(res_col + (long long)(j - g.nz_a_start + g.nz_res_start) * res_ls + idx, g.nz_mode,  \
+                        if (d5 && D16ONLY) g.d16w[PZ_TAIL_D16_AT(j - g.nz_a_start + g.nz_res_start, n1, h, idx)] = (short)((int)x1_ - d5a[NZ == 2 ? 2 * n1 + h : 0]); \
+                        else if (d5) tz_put(res_col + (long long)(j - g.nz_a_start + g.nz_res_start) * res_ls + idx, g.nz_mode,  \
                                        (long long)((unsigned long long)x1_ - (unsigned long long)(long long)d5a[NZ == 2 ? 2 * n1 + h : 0])); \
-                        else PZ_TAIL_NZ_STORE(j - g.nz_a_start + g.nz_res_start, idx, x1_)                    \
+                        else if constexpr (!D16R) PZ_TAIL_NZ_STORE(j - g.nz_a_start + g.nz_res_start, idx, x1_, n1, h)   /* (D16R: every digit limb has its prefetch) */ \
                     }                                                                                        \
                     c_ = (long long)((unsigned long long)cr_ + (unsigned long long)tz_carry(k, dpc_, x1_));  \
                 }                                                                                            \
@@ -944,7 +993,9 @@ k_inv_tail(TailArgs g) {
         //  NzCombine modes: ~10 scalar branches in front of every store, 4 000 in the instantiation - hoisted into one choice per limb with
         //  straight-line bodies.  The compiler then keeps every chain of a thread in flight: 290 - 550 B of scratch whatever the
         //  sched_barriers; the branches are what bounds its live ranges here.)
-        const bool nzf = NZ == 1 && g.nz != 0;
+        // (round 6: the pairwise forms that read the 16-bit side copies ride on the same f64 steps - the digit minus the two diagonal digits leaves
+        //  through the store; on the integer steps the N = 2^16 pairwise launch ran at 2.2 TB/s of its own bytes once it wrote 16-bit digits only)
+        const bool nzf = (NZ == 1 || (D16R && PZ_TAIL_D16R_F64)) && g.nz != 0;
         if (nzf && !icarry && big < 2251799813685247.0) {
             if (j >= g.nz_a_end) {
                 const int kk_ = k - g.nz_lsh;
@@ -963,7 +1014,12 @@ k_inv_tail(TailArgs g) {
                         carry[2 * n1 + h] = __double_as_longlong(q + q2);
                         if (j < g.nz_a_start) {
                             const long long x1_ = (long long)(int)__builtin_fma(-q2, twok, dpc);
-                            PZ_TAIL_NZ_STORE(j - g.nz_a_start + g.nz_res_start, idx, x1_)
+                            if constexpr (D16R) {
+                                const int xv_ = (int)x1_ - (d5 ? d5a[NZ == 2 ? 2 * n1 + h : 0] : 0);
+                                if (D16ONLY) g.d16w[PZ_TAIL_D16_AT(j - g.nz_a_start + g.nz_res_start, n1, h, idx)] = (short)xv_;
+                                else tz_put(res_col + (long long)(j - g.nz_a_start + g.nz_res_start) * res_ls + idx, g.nz_mode, (long long)xv_);
+                            } else
+                            PZ_TAIL_NZ_STORE(j - g.nz_a_start + g.nz_res_start, idx, x1_, n1, h)
                         }
                     }
                 }
@@ -1015,17 +1071,17 @@ k_inv_tail(TailArgs g) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const long long idx = (long long)j1 * g.m2 + c0 + b_c + (h ? m : 0);
-                long long c_ = (NZ == 1 && !icarry) ? fast_i64_from_integral(__longlong_as_double(carry[2 * n1 + h])) : carry[2 * n1 + h];
+                long long c_ = ((NZ == 1 || (D16R && PZ_TAIL_D16R_F64)) && !icarry) ? fast_i64_from_integral(__longlong_as_double(carry[2 * n1 + h])) : carry[2 * n1 + h];
                 for (int jj = 0; jj < g.nz_res_end; ++jj) {
                     const long long x1_ = tz_digit(k, c_);
-                    PZ_TAIL_NZ_STORE(g.nz_res_end - jj - 1, idx, x1_)
+                    PZ_TAIL_NZ_STORE(g.nz_res_end - jj - 1, idx, x1_, n1, h)
                     if (jj != g.nz_res_end - 1) c_ = tz_carry(k, c_, x1_);
                 }
             }
         }
     }
 #undef PZ_TAIL_NZ_STORE
-#undef PZ_TAIL_D16_IDX
+#undef PZ_TAIL_D16_AT
 }
 
 #undef PZ_TAIL_N1

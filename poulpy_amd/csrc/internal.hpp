@@ -43,7 +43,10 @@ inline void* poly_ptr(const pz_module* M, const DV& v, int col, int limb) {
 
 // ---- launch_fft.hip -----------------------------------------------------------------------------------------------
 int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* T, bool rowmajor = false, long long mask = -1,
-                     bool src32 = false);   // src32 (row-major, 128-point-row plans): `src` holds 32-bit digits at the same element offsets
+                     bool src32 = false);
+// the row-major form on 16-bit digits in the fused tail's tile order (TailD16; smap addresses limbs of n int16)
+int launch_fwd_pass1_t16(pz_module* M, int npolys, const short* src, PolyMap smap, cplx* T);
+bool tail_d16_only_supported(const pz_module* M);   // the tensoring tails that leave 16-bit digits only + the operand form that reads them   // src32 (row-major, 128-point-row plans): `src` holds 32-bit digits at the same element offsets
 int launch_fwd_pass2(pz_module* M, int npolys, const cplx* T, double* dst, PolyMap dmap, const cplx* mul);
 int launch_inv_pass2(pz_module* M, int npolys, const double* src, PolyMap smap, cplx* T);
 int launch_inv_pass1(pz_module* M, int npolys, const cplx* T, long long* dst, PolyMap dmap);
@@ -85,6 +88,10 @@ struct TailCall {
     bool gather_neg = false;
     // ---- blind rotation's accumulator between two blocks: 32-bit digits (bit 0: `small`, bit 1: `res`; same element strides) ----
     int acc32 = 0;
+    // bit 2 (with small_all): the operand is a GLWETensor held as 16-bit digits in the tail's tile order, small16[column][ciphertext][limb][n],
+    // small16_cs int16 elements between columns (`small` only has to be non-null then)
+    const short* small16 = nullptr;
+    long long small16_cs = 0;
     // ---- glwe_trace: the digits leave through a one-bit vec_znx_rsh_assign ----
     bool post_rsh = false;
 };
@@ -102,7 +109,9 @@ struct NzCombine;
 // 16-bit side copies of the diagonal terms' digits (round 6; base2k <= 16): [pair][res limb][n] int16 in the tail's own tile order.  A diagonal
 // launch (NZ1) mirrors every digit it stores into `w`; the pairwise launch (mode 5) reads `ra` / `rb` instead of the low dwords of the two
 // i64 tensor columns (8 B fetched per coefficient and column for a 12-bit digit: 4.3 of the pairwise launch's 8.8 GB, profiles/r04_tensor_traffic.json)
-struct TailD16 { short* w = nullptr; const short* ra = nullptr; const short* rb = nullptr; };
+// only: the digits leave ONLY as those copies, the i64 column is not written (the fused multiply + relinearize, api_cnv.hip: the pairwise launch
+// then writes its own values pair - d_i - d_j into `w` too, base2k <= 14)
+struct TailD16 { short* w = nullptr; const short* ra = nullptr; const short* rb = nullptr; bool only = false; };
 int launch_inv_tail_nz(pz_module* M, int batch, const cplx* T, int nlimbs, long long* res, long long res_bs, int res_cols, int res_size, int res_col,
                        int base2k, long long res_offset, int a_size, const NzCombine* cb, const TailD16* d16 = nullptr);
 

@@ -17,6 +17,7 @@ bool tail_acc32_supported(const pz_module* M) {
 #undef X
     return false;
 }
+bool tail_d16_only_supported(const pz_module* M) { return tail_rsh_supported(M) && tail_acc32_supported(M); }
 bool tail_rsh_supported(const pz_module* M) {
 #define X(A, B, C) if (M->plan.f1a == A && M->plan.f1b == B && M->plan.cb == C) return true;
     PZ_RSH_CASES(X)
@@ -45,6 +46,7 @@ static TailArgs tail_args(const pz_module* M, const TailCall& c, int col_base, i
     g.acc32 = c.acc32;
     g.xcd_map = 0;
     g.d16w = nz ? nz->d16.w : nullptr; g.d16a = nz ? nz->d16.ra : nullptr; g.d16b = nz ? nz->d16.rb : nullptr;
+    if (c.acc32 & 4) { g.d16a = c.small16; g.body_bs = c.small16_cs; }
     return g;
 }
 static int launch_inv_tail_cols(pz_module* M, const TailCall& c, int col_base, int col_count, bool raw = false, const TailNz* nz = nullptr) {
@@ -67,7 +69,7 @@ static int launch_inv_tail_cols(pz_module* M, const TailCall& c, int col_base, i
     f.rowmajor = c.rowmajor; f.has_small = has_small;
     if (c.acc32) {   // 32-bit accumulator digits: the plain every-column-operand form, nothing else
         if (!(tail_acc32_supported(M) && c.rowmajor && has_small && c.small_all && !c.post_rsh && !raw && !nz && c.auto_mul == 0 && c.gather_mul == 0 &&
-              c.body_src == nullptr && !c.body_gather && c.base2k <= 31))
+              c.body_src == nullptr && !c.body_gather && c.base2k <= 31 && (!(c.acc32 & 4) || (c.acc32 == 4 && c.small16 != nullptr))))
             return fail(PZ_ERR_UNSUPPORTED, "fused tail: no 32-bit-accumulator variant for this call");
         f.kind = TailForm::ACC32;
     } else if (c.post_rsh) {
@@ -88,6 +90,11 @@ static int launch_inv_tail_cols(pz_module* M, const TailCall& c, int col_base, i
         if (nz && f.kind == TailForm::NZ2 && nz->d16.ra) {
             if (!(nz->mode2[0] == 5)) return fail(PZ_ERR_INVALID, "fused tail: 16-bit side copies are read by the mode-5 pairwise launch only");
             f.kind = TailForm::NZ2R;
+        }
+        if (nz && nz->d16.only) {   // the digits leave only as 16-bit copies
+            if (f.kind == TailForm::NZ1W) f.kind = TailForm::NZ1O;
+            else if (f.kind == TailForm::NZ2R && nz->d16.w) f.kind = TailForm::NZ2O;
+            else return fail(PZ_ERR_INVALID, "fused tail: 16-bit-only digits need the side-copy forms (a diagonal launch that writes them, a pairwise launch that reads and writes them)");
         }
     }
     // the rounding-margin instantiation of the same form when the module's probe is on (pz_module_set_margin_probe): the same source with the
@@ -144,6 +151,7 @@ int launch_inv_tail_nz(pz_module* M, int batch, const cplx* T, int nlimbs, long 
     for (int u = 0; u < 2; ++u) { nz.col2[u] = cb ? cb->col2[u] : 0; nz.mode2[u] = cb ? cb->mode2[u] : 0; }
     if (d16) {
         PZ_REQUIRE(base2k <= 16, "fused tail: 16-bit side copies of the digits need base2k <= 16");
+        PZ_REQUIRE(!d16->only || base2k <= 14, "fused tail: a pairwise column kept as 16-bit values needs base2k <= 14");
         nz.d16 = *d16;
     }
     TailCall c;

@@ -14,7 +14,7 @@ namespace pz {
 #define PZ_ACC32_CASES(X) X(4, 4, 16) PZ_RSH_CASES(X)
 
 struct TailForm {
-    enum Kind { PLAIN, RSH, SGN, NZ1, NZ2, ACC32, NZ1W, NZ2R } kind = PLAIN;   // NZ1W / NZ2R: the tensoring tails with 16-bit side copies (write / read)   // ACC32: 32-bit accumulator digits (blind rotation's pipeline path)
+    enum Kind { PLAIN, RSH, SGN, NZ1, NZ2, ACC32, NZ1W, NZ2R, NZ1O, NZ2O } kind = PLAIN;   // NZ1W / NZ2R: the tensoring tails with 16-bit side copies (write / read); NZ1O / NZ2O: 16-bit digits ONLY   // ACC32: 32-bit accumulator digits (blind rotation's pipeline path)
     bool rowmajor = false, has_small = false;   // PLAIN: one instantiation per (row-major, body add) combination
 };
 
@@ -45,6 +45,8 @@ static int tail_launch_form(pz_module* M, const TailArgs& g, int blocks, const T
         if (f.kind == TailForm::NZ1) PZ_TAIL_GO(A, B, C, true, false, false, 1, false)                          \
         if (f.kind == TailForm::NZ1W) PZ_TAIL_GO(A, B, C, true, false, false, 3, false)                         \
         if (f.kind == TailForm::NZ2R) PZ_TAIL_GO(A, B, C, true, false, false, 4, false)                         \
+        if (f.kind == TailForm::NZ1O) PZ_TAIL_GO(A, B, C, true, false, false, 5, false)                         \
+        if (f.kind == TailForm::NZ2O) PZ_TAIL_GO(A, B, C, true, false, false, 6, false)                         \
     }
         PZ_RSH_CASES(X)
 #undef X

@@ -655,6 +655,14 @@ class Module:
         """poulpy-core operations/glwe.rs:541-607 on device-resident GLWETensors sharing one prepared tensor key."""
         self._ck(self.lib.pz_glwe_tensor_relinearize_batched(self.handle, res, a, tsk_pmat, C.byref(params), c_size_t(batch)))
 
+    def glwe_tensor_mul_relinearize_batched(self, res: c_void_p, a: c_void_p, b, tsk_pmat: c_void_p, tparams: GlweTensorParams, rparams: GlweOpParams,
+                                            mode, batch: int):
+        """glwe_tensor_apply / _square_apply + glwe_tensor_relinearize with the tensor in scratch (poulpy-ckks leveled/default/mul.rs:49-85, :131-170);
+        mode: "apply" | "square"."""
+        mode = self.TENSOR_MODES[mode] if isinstance(mode, str) else int(mode)
+        self._ck(self.lib.pz_glwe_tensor_mul_relinearize_batched(self.handle, res, a, b if b is not None else a, tsk_pmat, C.byref(tparams),
+                                                                 C.byref(rparams), c_int(mode), c_size_t(batch)))
+
     # -- LWE glue of the gate bootstrap (device-resident batches; an LWE = VecZnx(n_lwe + 1, 1, size)) -------------
     def lwe_mod_switch_2n_batched(self, res: c_void_p, lwe: c_void_p, n_lwe: int, lwe_size: int, base2k: int, n2: int, negate: bool, batch: int):
         """poulpy-bin-fhe blind_rotation/algorithms/mod.rs:136-176."""

@@ -270,6 +270,90 @@ def test_config5_relinearize_n65536_16_limbs(mods):
         assert np.array_equal(got, want), pin
 
 
+def _run_mul_relinearize(hip, ref, n, rank, a_size, b_size, t_size, base2k, cnv_offset, key_size, key_base2k, dnum, dsize, res_size, res_base2k, mode, batch,
+                         seed, chunk=0, a_bits_off=0, pin=False):
+    """glwe_tensor_apply / _square_apply into a scratch tensor (t_size limbs, base2k) + glwe_tensor_relinearize: poulpy-ckks's
+    ckks_mul_into_default / square (leveled/default/mul.rs:49-85, :131-170), oracle = the two reference operations one after the other."""
+    from poulpy_amd.hal import GlweOpParams, GlweTensorParams
+    rng = seeded(seed)
+    cols, pairs = rank + 1, rank * (rank + 1) // 2
+    tcols = cols + pairs
+    square = mode == "square"
+    a_k = base2k * a_size - a_bits_off
+    b_k = a_k if square else base2k * b_size
+    mat = MatZnx(n, dnum, pairs, cols, key_size).fill_uniform(key_base2k, rng)
+    pr, ph = ref.vmp_pmat_alloc(dnum, pairs, cols, key_size), hip.vmp_pmat_alloc(dnum, pairs, cols, key_size)
+    ref.vmp_prepare(pr, mat)
+    hip.vmp_prepare(ph, mat)
+    a_all = np.empty((batch, a_size, cols, n), dtype=np.int64)
+    b_all = np.empty((batch, (a_size if square else b_size), cols, n), dtype=np.int64)
+    want = np.empty((batch, res_size, cols, n), dtype=np.int64)
+    for t in range(batch):
+        a = VecZnx(n, cols, a_size).fill_uniform(base2k, rng)
+        b = a if square else VecZnx(n, cols, b_size).fill_uniform(base2k, rng)
+        a_all[t], b_all[t] = a.data, b.data
+        tmp = VecZnx(n, tcols, t_size)
+        if square:
+            ref.glwe_tensor_square_apply(cnv_offset, tmp, base2k, a, a_k, base2k)
+        else:
+            ref.glwe_tensor_apply(cnv_offset, tmp, base2k, a, a_k, b, b_k, base2k)
+        r = VecZnx(n, cols, res_size)
+        ref.glwe_tensor_relinearize(r, res_base2k, tmp, base2k, pr, dsize, key_base2k)
+        want[t] = r.data
+    d_a = hip.device_alloc(a_all.nbytes).upload(a_all)
+    d_b = hip.device_alloc(b_all.nbytes).upload(b_all)
+    d_k = hip.device_alloc(ph.data.nbytes).upload(ph.data)
+    d_r = hip.device_alloc(want.nbytes)
+    hip.lib.pz_memset_d(hip.handle, d_r.ptr, 0x5A, want.nbytes)
+    tp = GlweTensorParams(rank=rank, a_size=a_size, b_size=b_size, ab_base2k=base2k, a_effective_k=a_k, b_effective_k=b_k, res_size=t_size,
+                          res_base2k=base2k, cnv_offset=cnv_offset)
+    rp = GlweOpParams(rank=rank, dnum=dnum, dsize=dsize, key_size=key_size, key_base2k=key_base2k, a_size=t_size, a_base2k=base2k,
+                      res_size=res_size, res_base2k=res_base2k, rank_out=rank)
+    hip.set_chunk(chunk)
+    if pin:
+        hip.pin_key(d_k.ptr, dnum, pairs, cols, key_size)
+    hip.glwe_tensor_mul_relinearize_batched(d_r.ptr, d_a.ptr, None if square else d_b.ptr, d_k.ptr, tp, rp, mode, batch)
+    hip.sync()
+    if pin:
+        hip.unpin_key(d_k.ptr)
+    hip.set_chunk(0)
+    got = d_r.download(np.int64, want.size).reshape(want.shape)
+    for buf in (d_a, d_b, d_k, d_r):
+        buf.free()
+    return got, want
+
+
+@pytest.mark.parametrize("mode", ["apply", "square"])
+@pytest.mark.parametrize("rank", [1, 2])
+def test_glwe_tensor_mul_relinearize_batched(mods, rank, mode):
+    """pz_glwe_tensor_mul_relinearize_batched == glwe_tensor_apply / _square_apply then glwe_tensor_relinearize of the oracle, bit for bit.
+    N = 8192 (pipeline plan): one base2k <= 14 keeps the tensor as 16-bit digits in the workspace (tensoring tails NZF 5 / 6, forward pass 1 on
+    the tile-order copies, the relinearization's tail adding them: k_fwd_pass1_t16 in the dispatch notes' place is checked through the result
+    alone) - ragged limb counts, offsets below / at / above base2k, a masked bottom limb, chunks, base2k 14 (the widest the pairwise column's
+    pair - d_i - d_j fits); base2k 15, a key in another base, dsize 2 and the small rings take the i64 tensor in the workspace."""
+    for n in (8192, 256):
+        ref, hip = mods(n)
+        for (a_size, b_size, t_size, k, off, key_size, key_k, dnum, dsize, res_size, res_k, abo) in (
+                (4, 3, 5, 12, 5, 5, 12, 5, 1, 4, 12, 3), (3, 3, 4, 14, 14, 4, 14, 4, 1, 4, 14, 0), (4, 4, 6, 12, 30, 6, 12, 6, 1, 5, 12, 7),
+                (2, 5, 3, 13, 20, 4, 13, 3, 1, 3, 13, 0), (3, 3, 4, 15, 14, 4, 15, 4, 1, 4, 15, 0), (4, 4, 4, 12, 16, 5, 13, 5, 1, 4, 12, 0),
+                (4, 4, 4, 13, 16, 5, 13, 2, 2, 4, 13, 0)):
+            if n == 256 and a_size == 2:
+                continue
+            got, want = _run_mul_relinearize(hip, ref, n, rank, a_size, b_size, t_size, k, off, key_size, key_k, dnum, dsize, res_size, res_k, mode,
+                                             batch=5, seed=n + 31 * rank + off + k, chunk=2, a_bits_off=abo)
+            assert np.array_equal(got, want), (n, rank, mode, a_size, b_size, t_size, k, off, key_size, key_k, dnum, dsize, res_size, res_k)
+
+
+def test_config5_mul_relinearize_n65536_16_limbs(mods):
+    """BASELINE configs[4] as ONE call: N = 2^16, 16 limbs, rank 1, base2k 12 - tensoring + relinearization with the tensor as 16-bit digits;
+    apply and square, pinned and unpinned tensor key."""
+    n = 65536
+    ref, hip = mods(n)
+    for mode, pin in (("apply", False), ("square", True)):
+        got, want = _run_mul_relinearize(hip, ref, n, 1, 16, 16, 16, 12, 16 * 12 - 20, 16, 12, 16, 1, 16, 12, mode, batch=3, seed=6 + pin, pin=pin)
+        assert np.array_equal(got, want), (mode, pin)
+
+
 # ------------------------------------------------------------------------------------------
 # batched i64 VecZnx family (pz_vec_znx_*_batched): one launch for `batch` device-resident containers
 # ------------------------------------------------------------------------------------------

@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--parity-samples", type=int, default=2)
     ap.add_argument("--relin", action="store_true", help="follow every tensoring with glwe_tensor_relinearize (tensor key 1 -> 1, dnum = limbs): "
                     "the whole GLWE multiplication of a CKKS multiply (operations/glwe.rs:541-607 after :700-807)")
+    ap.add_argument("--one-call", action="store_true", help="with --relin: tensoring + relinearization as ONE call with the tensor in scratch "
+                    "(pz_glwe_tensor_mul_relinearize_batched: poulpy-ckks's ckks_mul_into_default, leveled/default/mul.rs:49-85) instead of the two calls")
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import multirank
     multirank.add_arguments(ap)
@@ -77,7 +79,14 @@ def main():
         rp = GlweOpParams(rank=rank, dnum=dnum, dsize=1, key_size=size, key_base2k=k, a_size=size, a_base2k=k, res_size=size, res_base2k=k, rank_out=rank)
         torch.cuda.synchronize()
 
+    if args.one_call and not args.relin:
+        raise SystemExit("--one-call goes with --relin")
+
     def run():
+        if args.one_call:
+            mod.glwe_tensor_mul_relinearize_batched(C.c_void_p(out.data_ptr()), C.c_void_p(a.data_ptr()), None if args.mode == "square" else C.c_void_p(b.data_ptr()),
+                                                    C.c_void_p(pmat.data_ptr()), p, rp, args.mode, args.batch)
+            return
         mod.glwe_tensor_apply_batched(C.c_void_p(res.data_ptr()), C.c_void_p(a.data_ptr()), None if args.mode == "square" else C.c_void_p(b.data_ptr()),
                                       p, args.mode, args.batch)
         if args.relin:
@@ -115,7 +124,8 @@ def main():
                 ref.glwe_tensor_square_apply(cnv_offset, r, k, av, size * k, k)
             else:
                 ref.glwe_tensor_apply(cnv_offset, r, k, av, size * k, bv, size * k, k, add_assign=False)
-            ok = ok and bool(np.array_equal(got[t], r.data))
+            if not args.one_call:   # (one call: the tensor never leaves the workspace)
+                ok = ok and bool(np.array_equal(got[t], r.data))
             if args.relin:
                 if t == 0:
                     pm = ref.vmp_pmat_alloc(size, 1, cols, size)
@@ -127,7 +137,7 @@ def main():
     # convolution of cols*(cols+1)/2 column pairs (Karatsuba for the cross column: cnv_pairwise), inverse transforms of the tensor
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import roofline_models as rm
-    model = rm.tensoring(n, rank, size, args.mode, args.relin, args.batch)   # the byte / flop model lives beside the other benched operations'
+    model = rm.tensoring(n, rank, size, args.mode, args.relin, args.batch, one_call=args.one_call)   # the byte / flop model lives beside the other benched operations'
     nb, flops = model["hbm_bytes"], model["flops"]
     rate = args.batch * R.world / dt
     per_rank = R.gather({"value": args.batch / dt_mine, "ms_per_step": dt_mine * 1e3, "global_first_index": lo, "parity_ok": ok, "rounding_margin": margin,
@@ -140,7 +150,7 @@ def main():
         print(json.dumps({**R.line_fields(rate, args.ref_value, route, mod), "per_rank": per_rank,
         "metric": ("GLWE multiplications/s (glwe_tensor_%s + glwe_tensor_relinearize)" if args.relin else "GLWE tensorings/s (glwe_tensor_%s)") % ("apply" if args.mode == "apply" else "square_apply"),
         "value": rate, "unit": "multiplications/s" if args.relin else "tensorings/s", "ms_per_step": dt * 1e3, "batch": args.batch, "parity_ok": ok, "rounding_margin": margin,
-        "config": {"workload": f"glwe_tensor_{args.mode}" + (" + glwe_tensor_relinearize (tensor key 1 -> 1, dnum = limbs)" if args.relin else "") + f" (rank 1: 2-column GLWE x GLWE -> 3-column GLWETensor), N={n}, {size} limbs, base2k={k}, cnv_offset={cnv_offset}",
+        "config": {"workload": f"glwe_tensor_{args.mode}" + (" + glwe_tensor_relinearize (tensor key 1 -> 1, dnum = limbs)" if args.relin else "") + (", ONE call, tensor in scratch" if args.one_call else "") + f" (rank 1: 2-column GLWE x GLWE -> 3-column GLWETensor), N={n}, {size} limbs, base2k={k}, cnv_offset={cnv_offset}",
                    "batch_per_gpu": args.batch},
         "kernel_classes_launches_ms": stats,
         "knobs": {k_: v_ for k_, v_ in os.environ.items() if k_.startswith("POULPY_DBG_")},

@@ -39,7 +39,7 @@ def blind_rotation(n, n_lwe, rank, block_size, dnum, brk_size, res_size, batch):
     return {"hbm_bytes": hbm, "flops": flops, "key_stream_bytes": key_bytes, "npi": npi, "npo": npo, "blocks": nb}
 
 
-def tensoring(n, rank, size, mode="apply", relin=False, batch=1):
+def tensoring(n, rank, size, mode="apply", relin=False, batch=1, one_call=False):
     """GLWE tensoring (poulpy-core operations/glwe.rs:609-913; the convolution half of a CKKS multiplication) per pair, optionally followed
     by glwe_tensor_relinearize (:541-607).  Algorithmic bytes: both operands read (one for `square`), the (rank+1)(rank+2)/2 tensor columns
     written; flops: forward transforms of the operand limbs, the limb convolution of every column pair (Karatsuba cross terms: one product
@@ -55,6 +55,8 @@ def tensoring(n, rank, size, mode="apply", relin=False, batch=1):
         pairs = rank * (rank + 1) // 2
         key = size * pairs * cols * size * n * 8
         hbm += (tcols * size + cols * size) * n * 8 + key / batch
+        if one_call:   # the tensor is scratch (ckks_mul_into_default): algorithmically neither written nor read - operands in, GLWE out, the key
+            hbm = (ops * cols * size + cols * size) * n * 8 + key / batch
         flops += (pairs * size + cols * size) * fft_flops(m) + m * (pairs * size) * (cols * size) * 8.0
     return {"hbm_bytes": hbm, "flops": flops, "key_stream_bytes": key}
 
