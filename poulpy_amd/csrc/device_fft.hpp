@@ -66,6 +66,9 @@ __device__ __forceinline__ void st_stream(cplx* p, cplx v) {
 #ifndef PZ_TAIL_D16_ADDR
 #define PZ_TAIL_D16_ADDR 1   // 16-bit digit stores: 1 one base per thread + constant offsets, 0 the element from the coefficient's row / column (A/B knob)
 #endif
+#ifndef PZ_TAIL_NZD
+#define PZ_TAIL_NZD 1   // side-copy tensoring tails: "normalizing, not raw" known at compile time (0: tested at run time as in the other forms, A/B knob)
+#endif
 #ifndef PZ_TAIL_D16R_F64
 #define PZ_TAIL_D16R_F64 0   // the pairwise tensoring tails that read 16-bit side copies: f64 normalization steps (0: the integer steps, A/B knob)
 #endif
@@ -585,6 +588,11 @@ k_inv_tail(TailArgs g) {
     // pairwise column's values pair - d_i - d_j, which fit 16 bits while base2k <= 14)
     constexpr int NZ = (NZF == 3 || NZF == 5) ? 1 : ((NZF == 4 || NZF == 6) ? 2 : NZF);
     constexpr bool D16W = NZF == 3 || NZF >= 5, D16R = NZF == 4 || NZF == 6, D16ONLY = NZF >= 5;
+    // the side-copy forms are only ever launched as normalizing tails (launch_tail.hip: TailArgs::nz set, never raw): what the run-time tests below
+    // would keep compiled in beside them - the plain chain, the raw store - costs registers and issue slots in the limb loop
+    constexpr bool NZD = PZ_TAIL_NZD && (D16W || D16R);
+#define PZ_TAIL_IS_NZ (NZ && (NZD || g.nz))
+#define PZ_TAIL_IS_RAW (NZ && !NZD && g.raw)
     static_assert(!ACC32 || (ROWMAJOR && SMALL && !RSH && !NZ && !SGN), "32-bit accumulator digits: the plain operand form of the row-major pipeline");
     static_assert(!NZ || (ROWMAJOR && !SMALL && !RSH), "tensoring forms: row-major pipeline layout, no operand");
     static_assert(!SGN || (ROWMAJOR && !SMALL && !RSH && !NZ), "sign-only form: row-major pipeline layout, no operand");
@@ -674,7 +682,7 @@ k_inv_tail(TailArgs g) {
     constexpr bool FCARRY = !SMALL;
     bool icarry = !FCARRY || k > 31;
     const double halfd = (double)(1ull << (k - 1)), twok = 2.0 * halfd, invk = 1.0 / twok;
-    long long* res_col = g.res + (long long)b * g.res_bs + (long long)((NZ && g.nz) ? g.nz_col : col) * n;
+    long long* res_col = g.res + (long long)b * g.res_bs + (long long)(PZ_TAIL_IS_NZ ? g.nz_col : col) * n;
     const long long res_ls = (long long)g.res_cols * n;
     long long* nz_r2a = (NZ && g.nz && g.nz_mode2[0]) ? g.res + (long long)b * g.res_bs + (long long)g.nz_col2[0] * n : nullptr;
     long long* nz_r2b = (NZ && g.nz && g.nz_mode2[1]) ? g.res + (long long)b * g.res_bs + (long long)g.nz_col2[1] * n : nullptr;
@@ -716,12 +724,12 @@ k_inv_tail(TailArgs g) {
     int cy2[RSH ? 2 * RE : 1];
 #pragma unroll
     for (int u = 0; u < (RSH ? 2 * RE : 1); ++u) cy2[u] = 0;
-    for (int j = (NZ && g.nz) ? g.nz_zero_from : L + (RSH ? 1 : 0); j < g.res_size; ++j)
+    for (int j = PZ_TAIL_IS_NZ ? g.nz_zero_from : L + (RSH ? 1 : 0); j < g.res_size; ++j)
 #pragma unroll
         for (int e = 0; e < RE; ++e) {
             const int n1 = PZ_TAIL_N1(e);
             const long long idx = (long long)(b_o + R2 * n1) * g.m2 + c0 + b_c;
-            if (NZ && g.nz) {
+            if (PZ_TAIL_IS_NZ) {
                 PZ_TAIL_NZ_STORE(j, idx, 0, e, 0)
                 PZ_TAIL_NZ_STORE(j, idx + m, 0, e, 1)
             } else if (ACC32 && (g.acc32 & 2)) {
@@ -747,7 +755,7 @@ k_inv_tail(TailArgs g) {
         int d5a[NZ == 2 ? 2 * RE : 1], d5b[(NZ == 2 && !D16R) ? 2 * RE : 1];
         pz_short2 d5p[D16R ? 2 * RE : 1];
         bool d5 = false;
-        if (D16R && g.nz && g.nz_mode2[0] == 5 && j >= g.nz_a_end && j < g.nz_a_start) {
+        if (D16R && (NZD || (g.nz && g.nz_mode2[0] == 5)) && j >= g.nz_a_end && j < g.nz_a_start) {
             // the diagonal launches left 16-bit copies of their digits (TailArgs::d16*, base2k <= 16): 2 B per coefficient and column, in this
             // workgroup's own tile order (one base per thread, constant offsets), instead of the 8 B a line of the i64 column costs
             d5 = true;
@@ -925,11 +933,11 @@ k_inv_tail(TailArgs g) {
                 ng_ = (((unsigned)idx * g.auto_mul) & (unsigned)(2 * n - 1)) >= (unsigned)n;                 \
                 if (ng_ != (g.auto_neg != 0)) x = (long long)(0ull - (unsigned long long)x);                 \
             }                                                                                                \
-            if (NZ && g.raw) {                                                                               \
+            if (PZ_TAIL_IS_RAW) {                                                                            \
                 if (writes) { if (ROWMAJOR) st_stream(res_col + (long long)j * res_ls + idx, x); else res_col[(long long)j * res_ls + idx] = x; } \
                 continue;                                                                                    \
             }                                                                                                \
-            if (NZ && g.nz) {   /* k_normalize_inter's steps on limb j (carry starts at 0: its first-step special case is the general step) */ \
+            if (PZ_TAIL_IS_NZ) {   /* k_normalize_inter's steps on limb j (carry starts at 0: its first-step special case is the general step) */ \
                 if (j >= g.nz_a_end) {                                                                       \
                     long long& c_ = carry[2 * n1 + h];                                                       \
                     const int kk_ = g.nz_lsh == 0 ? k : k - g.nz_lsh;                                        \
@@ -995,7 +1003,7 @@ k_inv_tail(TailArgs g) {
         //  sched_barriers; the branches are what bounds its live ranges here.)
         // (round 6: the pairwise forms that read the 16-bit side copies ride on the same f64 steps - the digit minus the two diagonal digits leaves
         //  through the store; on the integer steps the N = 2^16 pairwise launch ran at 2.2 TB/s of its own bytes once it wrote 16-bit digits only)
-        const bool nzf = (NZ == 1 || (D16R && PZ_TAIL_D16R_F64)) && g.nz != 0;
+        const bool nzf = (NZ == 1 || (D16R && PZ_TAIL_D16R_F64)) && (NZD || g.nz != 0);
         if (nzf && !icarry && big < 2251799813685247.0) {
             if (j >= g.nz_a_end) {
                 const int kk_ = k - g.nz_lsh;
@@ -1025,7 +1033,7 @@ k_inv_tail(TailArgs g) {
                 }
             }
         } else
-        if (FCARRY && !icarry && !(NZ && (g.raw || g.nz)) && big < 2251799813685247.0) {
+        if (FCARRY && !icarry && !(PZ_TAIL_IS_RAW || PZ_TAIL_IS_NZ) && big < 2251799813685247.0) {
 #pragma unroll
             for (int n1 = 0; n1 < RE; ++n1) {
                 const int j1 = b_ov + R2 * PZ_TAIL_N1(n1);
@@ -1050,7 +1058,7 @@ k_inv_tail(TailArgs g) {
                 }
             }
         } else {
-            if (FCARRY && !icarry && !(NZ && (g.raw || (g.nz && !nzf)))) {   // leave the f64 chain: the carries become integers, for good
+            if (FCARRY && !icarry && !(PZ_TAIL_IS_RAW || (PZ_TAIL_IS_NZ && !nzf))) {   // leave the f64 chain: the carries become integers, for good
                 icarry = true;
 #pragma unroll
                 for (int u = 0; u < 2 * RE; ++u) carry[u] = fast_i64_from_integral(__longlong_as_double(carry[u]));
@@ -1064,7 +1072,7 @@ k_inv_tail(TailArgs g) {
 #undef PZ_TAIL_COEFFS
         __syncthreads();
     }
-    if (NZ && g.nz) {   // the top res limbs are digits of the carry alone (middle_step_assign / final_step_assign on zero limbs, normalization.rs:132-157, 254-272)
+    if (PZ_TAIL_IS_NZ) {   // the top res limbs are digits of the carry alone (middle_step_assign / final_step_assign on zero limbs, normalization.rs:132-157, 254-272)
 #pragma unroll
         for (int n1 = 0; n1 < RE; ++n1) {
             const int j1 = b_o + R2 * PZ_TAIL_N1(n1);
@@ -1082,6 +1090,8 @@ k_inv_tail(TailArgs g) {
     }
 #undef PZ_TAIL_NZ_STORE
 #undef PZ_TAIL_D16_AT
+#undef PZ_TAIL_IS_NZ
+#undef PZ_TAIL_IS_RAW
 }
 
 #undef PZ_TAIL_N1

@@ -20,11 +20,6 @@ SCRATCH_ALLOWED = {
     "k_mid128<4, 16, *, false, false, true, 0, 0>": (104, "digit-selected k_mid128: only reached with POULPY_DBG_MID_R=0 (the cross-check path of k_mid128r<..,DS>)"),
     "k_inv_tail<8, 8, 16, true, false, false, 2, *>": (12, "pairwise tensoring tail (mode-5 prefetch of the diagonal digits) at the 168-register cap of its 3 waves per SIMD"),
     "k_inv_tail<16, 16, 16, true, false, false, 2, *>": (16, "pairwise tensoring tail at N = 2^16: as above, 2 registers"),
-    "k_inv_tail<16, 16, 16, true, false, false, 4, *>": (16, "pairwise tensoring tail reading the 16-bit side copies (round 6): 1 - 2 registers at the same cap"),
-    "k_inv_tail<8, 8, 16, true, false, false, 3, *>": (24, "diagonal tensoring tail writing the 16-bit side copies at N = 2^14 (3 workgroups per CU: 168-register cap)"),
-    "k_inv_tail<8, 8, 16, true, false, false, 4, *>": (40, "pairwise tail reading them at N = 2^14 (same cap; not a BASELINE shape)"),
-    "k_inv_tail<8, 8, 16, true, false, false, 6, *>": (24, "pairwise tail of the fused multiply + relinearize (16-bit digits only) at N = 2^14: same cap, 3 registers; "
-                                                           "scratch-free on the N = 2^15 / 2^16 plans"),
 }
 
 
