@@ -261,8 +261,8 @@ int pz_module_new_on_device(uint64_t n, int device, pz_module** out) {
 #endif
         if (hipStreamCreateWithFlags(&M->stream, hipStreamNonBlocking) != hipSuccess) { r = fail(PZ_ERR_HIP, "stream create failed"); break; }
         if ((r = build_tables(M)) != PZ_OK) break;
-        if (hipMalloc(&M->margin, 8) != hipSuccess) { r = fail(PZ_ERR_HIP, "margin alloc failed"); break; }
-        if (hipMemset(M->margin, 0, 8) != hipSuccess) { r = fail(PZ_ERR_HIP, "margin memset failed"); break; }
+        if (hipMalloc(&M->margin, 16) != hipSuccess) { r = fail(PZ_ERR_HIP, "margin alloc failed"); break; }
+        if (hipMemset(M->margin, 0, 16) != hipSuccess) { r = fail(PZ_ERR_HIP, "margin memset failed"); break; }
     } while (0);
     if (r != PZ_OK) { pz_module_free(M); return r; }
     M->tables_ref = new std::atomic<int>(1);
@@ -294,8 +294,8 @@ int pz_module_clone(pz_module* P, pz_module** out) {
     int r = PZ_OK;
     do {
         if (hipStreamCreateWithFlags(&M->stream, hipStreamNonBlocking) != hipSuccess) { r = fail(PZ_ERR_HIP, "stream create failed"); break; }
-        if (hipMalloc(&M->margin, 8) != hipSuccess) { r = fail(PZ_ERR_HIP, "margin alloc failed"); break; }
-        if (hipMemset(M->margin, 0, 8) != hipSuccess) { r = fail(PZ_ERR_HIP, "margin memset failed"); break; }
+        if (hipMalloc(&M->margin, 16) != hipSuccess) { r = fail(PZ_ERR_HIP, "margin alloc failed"); break; }
+        if (hipMemset(M->margin, 0, 16) != hipSuccess) { r = fail(PZ_ERR_HIP, "margin memset failed"); break; }
     } while (0);
     if (r != PZ_OK) { M->tables_ref->fetch_sub(1); M->tables_ref = nullptr; M->tw1 = M->tw1inv = M->wL1 = M->wL2 = M->tw12 = M->tw12t = M->w2n = nullptr; }
     if (r != PZ_OK) { pz_module* dead = M; M = nullptr; pz_module_free(dead); return r; }

@@ -369,12 +369,28 @@ static int wave_spectral_tail(const GlweCall& c, const FusedBufs& f, size_t b0, 
     const int64_t* a_end = c.a + (long long)c.batch * c.a_bs;
     const int64_t* r_end = c.res + (long long)c.batch * c.res_bs;
     const bool fold = fold_knob != 0 && (c.res >= a_end || c.a >= r_end) && !c.want_rsh;   // (not for glwe_trace: the shifted-store variant has no gathered form)
+    // Round 6, plain form: the pre-pass leaves phi(body) as 16-bit values in the tail's own tile order (2 B written and 2 B read per coefficient
+    // instead of 8) where the digits are expected to fit - a key base of at most 16 bits - and the body column then rides on the f64 chain of the
+    // sign-only tail with that operand (k_inv_tail<.., NZF = 7, SGN>) instead of the operand variant's integer chain.  A value that does not fit
+    // (un-normalized input) raises a device flag: the 16-bit form returns at once and the gathering operand variant (the fold form), launched
+    // beside it, does the column - the same bits, slower.  Out of place and without the shifted store, as fold.
+    static const int b16_knob = exp_knob("POULPY_DBG_AUTO_BODY16", 1);
+    // (not under the rounding-margin probe: its instantiation of the tail keeps the i64 operand - the values that are rounded are the same)
+    const bool body16 = b16_knob != 0 && !fold && !M->probe && !c.au_big && (c.res >= a_end || c.a >= r_end) && !c.want_rsh && n >= 1024 &&
+                        (int)c.p->key_base2k <= 16 && (int)c.p->res_base2k <= 31 && tail_rsh_supported(M);
+    short* b16 = body16 ? (short*)f.res_tmp : nullptr;
+    if (body16) {
+        PZ_TRY(launch_zero_bytes(M, M->margin + 1, 8));   // the flag word (module.hpp: wide16)
+        t.body_gather = true; t.gather_mul = c.au_g;
+        t.body16 = b16; t.body16_limbs = bl; t.body16_wide = M->wide16();
+    } else
     if (fold) { t.body_gather = true; t.gather_mul = c.au_g; }
     else { t.body_src = (const long long*)f.res_tmp; t.body_bs = (long long)bl * n; t.body_ls = n; }
     if (!c.au_big) {
         // plain form, res = phi(normalize(big)) (glwe_ct.rs:65-71): the inverse transform is phi(big) with phi's signs; the tail undoes
         // them in front of the carry chain (auto_mul) and puts them back on the digits (post_neg); only the body column has an operand
-        if (!fold) PZ_TRY(launch_automorphism(M, nb * bl, (const long long*)av.p, bsm, (long long*)f.res_tmp, bdm, c.au_g, 1));
+        if (body16) PZ_TRY(launch_automorphism(M, nb * bl, (const long long*)av.p, bsm, nullptr, bdm, c.au_g, 1, nullptr, PolyMap{1, 1, 0, 0, 0, 0}, b16));
+        else if (!fold) PZ_TRY(launch_automorphism(M, nb * bl, (const long long*)av.p, bsm, (long long*)f.res_tmp, bdm, c.au_g, 1));
         t.auto_mul = c.au_g; t.post_neg = true; t.body_only = true;
         return launch_inv_tail(M, t);
     }

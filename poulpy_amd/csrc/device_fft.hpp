@@ -63,6 +63,7 @@ __device__ __forceinline__ void st_stream(cplx* p, cplx v) {
 }
 #ifndef PZ_STREAM_I64_NT
 #define PZ_STREAM_I64_NT 1   // the tail's digit stores (A/B knob)
+#endif
 #ifndef PZ_TAIL_D16_ADDR
 #define PZ_TAIL_D16_ADDR 1   // 16-bit digit stores: 1 one base per thread + constant offsets, 0 the element from the coefficient's row / column (A/B knob)
 #endif
@@ -71,7 +72,6 @@ __device__ __forceinline__ void st_stream(cplx* p, cplx v) {
 #endif
 #ifndef PZ_TAIL_D16R_F64
 #define PZ_TAIL_D16R_F64 0   // the pairwise tensoring tails that read 16-bit side copies: f64 normalization steps (0: the integer steps, A/B knob)
-#endif
 #endif
 __device__ __forceinline__ void st_stream(long long* p, long long v) {
     if ((PZ_STREAM_HINTS & 2) && PZ_STREAM_I64_NT) __builtin_nontemporal_store(v, p);
@@ -531,6 +531,10 @@ struct TailArgs {
     // dwords of the two i64 columns
     short* d16w;
     const short *d16a, *d16b;
+    // pre_body with a gathered body (gather_mul != 0) and body16_wide != null: the body-column operand +-phi(body) (+ a0) was left by the pre-pass as
+    // 16-bit values in the tile order, d16a[ciphertext][limb][n] with body_bs int16 elements per ciphertext; read from there unless *body16_wide
+    // (a value did not fit 16 bits: the gathers below then produce the same operand from the body itself)
+    const unsigned* body16_wide;
 };
 __device__ __forceinline__ long long tz_digit(int k, long long x) { return (long long)((unsigned long long)x << (64 - k)) >> (64 - k); }
 __device__ __forceinline__ long long tz_carry(int k, long long x, long long d) { return (long long)((unsigned long long)x - (unsigned long long)d) >> k; }
@@ -586,7 +590,12 @@ k_inv_tail(TailArgs g) {
     // paths in one instantiation the pairwise tail went from 12 to 28 B of scratch at its 168-register cap
     // 5 / 6 = 3 / 4 whose digits leave ONLY as 16-bit copies (the fused multiply + relinearize never materializes the i64 GLWETensor; 6 writes the
     // pairwise column's values pair - d_i - d_j, which fit 16 bits while base2k <= 14)
-    constexpr int NZ = (NZF == 3 || NZF == 5) ? 1 : ((NZF == 4 || NZF == 6) ? 2 : NZF);
+    // 7 (with SGN): not a tensoring form - the sign-only tail with a 16-BIT OPERAND in front of the chain (OP16: the body column of a plain spectral
+    // automorphism whose pre-pass left phi(body) as 16-bit values in the tile order, TailArgs::body16_wide); rides on the f64 chain like the operand-free
+    // columns - the operand variant's integer chain ran that column at 1.3 x the time of a product column
+    constexpr bool OP16 = NZF == 7;
+    constexpr int NZ = OP16 ? 0 : ((NZF == 3 || NZF == 5) ? 1 : ((NZF == 4 || NZF == 6) ? 2 : NZF));
+    static_assert(!OP16 || SGN, "the 16-bit operand rides on the sign-only form");
     constexpr bool D16W = NZF == 3 || NZF >= 5, D16R = NZF == 4 || NZF == 6, D16ONLY = NZF >= 5;
     // the side-copy forms are only ever launched as normalizing tails (launch_tail.hip: TailArgs::nz set, never raw): what the run-time tests below
     // would keep compiled in beside them - the plain chain, the raw store - costs registers and issue slots in the limb loop
@@ -613,6 +622,10 @@ k_inv_tail(TailArgs g) {
         twi[t] = g.tw1inv[t];
     }
     __syncthreads();
+    // the two launches that share the body column of a plain spectral automorphism: the 16-bit-operand form does the work unless the pre-pass found a
+    // value that did not fit (flag up), the gathering operand form only then (launch_inv_tail)
+    if (OP16 && __builtin_amdgcn_readfirstlane((int)*g.body16_wide) != 0) return;
+    if (SMALL && g.body16_wide && __builtin_amdgcn_readfirstlane((int)*g.body16_wide) == 0) return;
     const int ncb = g.m2 / CB;
     int bid = blockIdx.x;
     if (g.xcd_map) {  // gridDim.x = ceil(nbc / 8) * 8 * ncb, nbc = (ciphertext, column) pairs of this launch = g.xcd_map
@@ -787,6 +800,24 @@ k_inv_tail(TailArgs g) {
                 }
             }
         }
+        // OP16: this limb of the 16-bit operand (tile order: one base, constant offsets), requested first like the body limb below
+        pz_short2 op16[OP16 ? RE : 1];   // (.x: the coefficient below m, .y: the one above - two 16-bit loads into one register)
+        if constexpr (OP16) {
+            if (j < g.small_size) {
+                const short* s16 = g.d16a + (long long)b * g.body_bs + (long long)j * n + (long long)(c0 / CB) * (2 * M1 * CB) + (b_ov * CB + b_cv) +
+                                   (SPLIT ? hs * R2 * CB : 0);
+#pragma unroll
+                for (int e = 0; e < RE; ++e) {
+                    pz_short2 v_;
+                    v_.x = s16[(SPLIT ? 2 : 1) * R2 * CB * e];
+                    v_.y = s16[M1 * CB + (SPLIT ? 2 : 1) * R2 * CB * e];
+                    op16[OP16 ? e : 0] = v_;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < RE; ++t) { op16[OP16 ? t : 0].x = 0; op16[OP16 ? t : 0].y = 0; }
+            }
+        }
         // key-switch body limb: requested first so that its latency hides behind the butterfly
         long long sm[SMALL ? 2 * RE : 1];
         if (SMALL && small_col && j < g.small_size && g.pre_body) {
@@ -817,6 +848,7 @@ k_inv_tail(TailArgs g) {
             if constexpr (RSH) {   // (the shifted-store variant sits at the register cap: one loop, the source picked by a select - round 3's form)
                 PZ_TAIL_OPERAND(bsrc ? (unsigned long long)bsrc[ih] : (g.body_only ? 0ull : (unsigned long long)scol[ih]))
             } else
+
             if (!RSH && bsrc && g.body_add) PZ_TAIL_OPERAND((unsigned long long)bsrc[ih] + (unsigned long long)scol[ih])   /* (not in the shifted-store variant: no registers left there) */
             else if (bsrc) PZ_TAIL_OPERAND((unsigned long long)bsrc[ih])
             else if (!RSH && gsrc && g.body_only) PZ_TAIL_OPERAND(PZ_TAIL_GATHERED(ih))   /* (the host never asks the shifted-store variant for the gathered or two-stream forms) */
@@ -928,6 +960,7 @@ k_inv_tail(TailArgs g) {
             const double r = round_half_away(val);                                                           \
             long long x = CONVERT(r);                                                                        \
             if (SMALL && add_small) x = (long long)((unsigned long long)x + (unsigned long long)sm[SMALL ? 2 * n1 + h : 0]); \
+            if (OP16) x = (long long)((unsigned long long)x + (unsigned long long)(long long)(h ? op16[OP16 ? n1 : 0].y : op16[OP16 ? n1 : 0].x));   \
             bool ng_ = false;                                                                                \
             if ((SMALL || SGN) && g.auto_mul) {                                                              \
                 ng_ = (((unsigned)idx * g.auto_mul) & (unsigned)(2 * n - 1)) >= (unsigned)n;                 \
@@ -1042,6 +1075,7 @@ k_inv_tail(TailArgs g) {
                     const long long idx = (long long)j1 * g.m2 + c0 + b_cv + (h ? m : 0);
                     const double val = h ? v[n1].y : v[n1].x;
                     double r = round_half_away(val);
+                    if (OP16) r += (double)(int)(h ? op16[OP16 ? n1 : 0].y : op16[OP16 ? n1 : 0].x);   // (an exact integer below 2^51 + 2^15)
                     bool ng_ = false;
                     if (SGN) {   // s(n) in front of the chain, and back on the digit (the integer path's steps, on the f64 chain)
                         ng_ = (((unsigned)idx * g.auto_mul) & (unsigned)(2 * n - 1)) >= (unsigned)n;

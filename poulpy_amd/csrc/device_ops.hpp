@@ -276,7 +276,20 @@ struct AutoArgs {
     int npolys, n;
     unsigned mul;          // gather multiplier g (odd, < 2n)
     int flags;
+    // flags & 8: the output leaves as 16-bit values in the fused tail's tile order (k_inv_tail, TailArgs::d16*) at dst16 + map_off(dm) - the body
+    // operand of the spectral automorphism forms at 2 B per coefficient.  A value beyond 16 bits sets *wide: the tail then gathers the body
+    // itself (the older "fold" form) instead of reading the copies - un-normalized inputs stay correct, only slower.
+    short* dst16;
+    unsigned* wide;
+    int t16_m1, t16_cb, t16_m2sh;   // tile: m1 rows, cb columns per block, log2 m2
 };
+// tile-order position of coefficient j (TailArgs::d16*): j = h m + j1 m2 + cc  ->  (cc / cb) 2 m1 cb + (h m1 + j1) cb + cc % cb
+__device__ __forceinline__ long long auto_t16_pos(const AutoArgs& g, unsigned j) {
+    const unsigned row = j >> g.t16_m2sh;                       // h m1 + j1
+    const unsigned cc = j & ((1u << g.t16_m2sh) - 1u);
+    return (long long)(cc / (unsigned)g.t16_cb) * (2 * g.t16_m1 * g.t16_cb) + (long long)row * g.t16_cb + (cc % (unsigned)g.t16_cb);
+}
+__device__ __forceinline__ bool auto_wide(unsigned long long v) { return (v + 32768ull) >= 65536ull; }
 
 __global__ void __launch_bounds__(256) k_automorphism(AutoArgs g) {
     const int bpp = g.n >= 512 ? g.n / 512 : 1;  // blocks per polynomial, 2 coefficients per thread
@@ -303,6 +316,13 @@ __global__ void __launch_bounds__(256) k_automorphism(AutoArgs g) {
         const ulonglong2 w = *reinterpret_cast<const ulonglong2*>(add + j);
         out[0] += w.x;
         out[1] += w.y;
+    }
+    if (g.flags & 8) {   // (j even: both values in one row, one column block)
+        short2 s2;
+        s2.x = (short)out[0]; s2.y = (short)out[1];
+        *reinterpret_cast<short2*>(g.dst16 + map_off(g.dm, poly) + auto_t16_pos(g, (unsigned)j)) = s2;
+        if (auto_wide(out[0]) || auto_wide(out[1])) atomicOr(g.wide, 1u);
+        return;
     }
     *reinterpret_cast<ulonglong2*>(dst + j) = make_ulonglong2(out[0], out[1]);
 }
@@ -341,8 +361,65 @@ __global__ void __launch_bounds__(256) k_automorphism_chunk(AutoArgs g, unsigned
         const ulonglong2 w0 = *reinterpret_cast<const ulonglong2*>(add + j0), w1 = *reinterpret_cast<const ulonglong2*>(add + j0 + 2);
         out[0] += w0.x; out[1] += w0.y; out[2] += w1.x; out[3] += w1.y;
     }
+    if (g.flags & 8) {   // (j0 a multiple of 4: the four values share a row and a column block)
+        short4 s4;
+        s4.x = (short)out[0]; s4.y = (short)out[1]; s4.z = (short)out[2]; s4.w = (short)out[3];
+        *reinterpret_cast<short4*>(g.dst16 + map_off(g.dm, poly) + auto_t16_pos(g, j0)) = s4;
+        if (auto_wide(out[0]) || auto_wide(out[1]) || auto_wide(out[2]) || auto_wide(out[3])) atomicOr(g.wide, 1u);
+        return;
+    }
     *reinterpret_cast<ulonglong2*>(dst + j0) = make_ulonglong2(out[0], out[1]);
     *reinterpret_cast<ulonglong2*>(dst + j0 + 2) = make_ulonglong2(out[2], out[3]);
+}
+
+// The 16-bit tile-order output through LDS (round 6): a polynomial of 16-bit values is n x 2 B = 128 KiB at N = 2^16 - it fits the CU.  One workgroup per
+// polynomial: the source is read ONCE in whole lines (the gathers above fetch every line 4 - 5 x from L2: 1.76 ms per 512 x 16 limbs against the
+// 0.8 its bytes take), narrowed to int16 into LDS, and the outputs are produced in the tile order itself - 4 consecutive values per thread, whole
+// 512-byte runs per wave - by reading LDS at the Galois-permuted index.  Any Galois element alike.  A value outside +-32767 raises *wide
+// (-32768 included: its negation does not fit).  flags as k_automorphism (1 sign, 2 negate all); no `add` operand.
+__global__ void __launch_bounds__(1024) k_automorphism_t16(AutoArgs g) {
+    extern __shared__ short a16[];   // the source polynomial, natural order
+    const int poly = blockIdx.x;
+    const long long* src = g.src + map_off(g.sm, poly);
+    const int tid = threadIdx.x;
+    bool wide = false;
+    for (int i = tid * 2; i < g.n; i += 2048 * 4) {   // 4 x 16 B in flight per thread
+        typedef unsigned long long pz_u64x2 __attribute__((ext_vector_type(2)));
+        pz_u64x2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * 2048 < g.n) v[u] = __builtin_nontemporal_load(reinterpret_cast<const pz_u64x2*>(src + i + u * 2048));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * 2048 < g.n) {
+                wide = wide || (v[u].x + 32767ull) >= 65535ull || (v[u].y + 32767ull) >= 65535ull;
+                short2 s2;
+                s2.x = (short)v[u].x; s2.y = (short)v[u].y;
+                *reinterpret_cast<short2*>(a16 + i + u * 2048) = s2;
+            }
+    }
+    if (wide) atomicOr(g.wide, 1u);
+    __syncthreads();
+    short* dst = g.dst16 + map_off(g.dm, poly);
+    const unsigned mask2 = 2u * (unsigned)g.n - 1u, nn = (unsigned)g.n;
+    const unsigned m2 = 1u << g.t16_m2sh, tile = 2u * (unsigned)g.t16_m1 * (unsigned)g.t16_cb;
+    for (unsigned t = (unsigned)tid * 4u; t < nn; t += 4096u) {
+        // tile-order position t -> coefficient j: block t / tile, row (t % tile) / cb = h m1 + j1, column block * cb + (t % cb)
+        const unsigned blk = t / tile, rem = t % tile;
+        const unsigned j = (rem / (unsigned)g.t16_cb) * m2 + blk * (unsigned)g.t16_cb + (rem % (unsigned)g.t16_cb);
+        short o[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const unsigned i0 = ((j + (unsigned)x) * g.mul) & mask2;
+            const int v = (int)a16[i0 & (nn - 1u)];
+            bool neg = (g.flags & 1) && i0 >= nn;
+            if (g.flags & 2) neg = !neg;
+            o[x] = (short)(neg ? -v : v);
+        }
+        short4 s4;
+        s4.x = o[0]; s4.y = o[1]; s4.z = o[2]; s4.w = o[3];
+        *reinterpret_cast<short4*>(dst + t) = s4;
+    }
 }
 
 // =================================================================================

@@ -80,6 +80,11 @@ struct TailCall {
     bool body_add = false;                // body column: body_src[n] + small[body column][n] (spectral add / sub forms: the pre-pass only permutes)
     bool body_gather = false;             // instead of body_src: the tail gathers +-phi(body) from column 0 of `small` itself (gather_mul,
                                           // gather_neg) - no pre-pass
+    // with body_gather: the pre-pass left the body-column operand as 16-bit values in the tail's tile order, body16[ciphertext][limb][n] with
+    // body16_limbs limbs per ciphertext, and raised *body16_wide if a value did not fit - the tail reads the copies, or gathers when the flag is up
+    const short* body16 = nullptr;
+    int body16_limbs = 0;
+    const unsigned* body16_wide = nullptr;
     // ---- signs of X -> X^p (automorphism/glwe_ct.rs:96-275; TailArgs in device_fft.hpp) ----
     unsigned auto_mul = 0;            // != 0: the value enters the chain as s(n) (big + small), s(n) = -1 iff (n auto_mul) mod 2N >= N
     bool auto_neg = false;            // flips every s(n)
@@ -166,7 +171,7 @@ int launch_ew(pz_module* M, int op, void* res, long long res_bs, long long res_l
 int launch_zero_bytes(pz_module* M, void* ptr, size_t bytes);
 // dst = +-src(X^p-gather with multiplier mul) [+ add]; see k_automorphism
 int launch_automorphism(pz_module* M, int npolys, const long long* src, PolyMap sm, long long* dst, PolyMap dm, unsigned mul,
-                        int flags, const long long* add = nullptr, PolyMap am = PolyMap{1, 1, 0, 0, 0, 0});
+                        int flags, const long long* add = nullptr, PolyMap am = PolyMap{1, 1, 0, 0, 0, 0}, short* dst16 = nullptr);
 int launch_rotate(pz_module* M, int npolys, const long long* src, PolyMap sm, long long* dst, PolyMap dm, int mode,
                   int polys_per_batch, const long long* shift, long long shift_bs, long long shift_idx, long long shift_const);
 int launch_rsh(pz_module* M, int batch, long long* data, long long bs, int cols, int size, int col0, int ncols, int base2k, int k);

@@ -31,11 +31,29 @@ int launch_ew(pz_module* M, int op, void* res, long long res_bs, long long res_l
 
 // dst = +-src(X^p-gather with multiplier mul) [+ add]; see k_automorphism
 int launch_automorphism(pz_module* M, int npolys, const long long* src, PolyMap sm, long long* dst, PolyMap dm, unsigned mul,
-                               int flags, const long long* add, PolyMap am) {
+                               int flags, const long long* add, PolyMap am, short* dst16) {
     if (npolys <= 0) return PZ_OK;
     AutoArgs g;
     g.src = src; g.dst = dst; g.add = add; g.sm = sm; g.dm = dm; g.am = am;
-    g.npolys = npolys; g.n = (int)M->n; g.mul = mul; g.flags = flags;
+    g.npolys = npolys; g.n = (int)M->n; g.mul = mul; g.flags = flags & 7;
+    g.dst16 = dst16; g.wide = M->wide16();
+    g.t16_m1 = M->plan.f1a * M->plan.f1b; g.t16_cb = M->plan.cb; g.t16_m2sh = 0;
+    while ((1 << g.t16_m2sh) < M->plan.m2) ++g.t16_m2sh;
+    if (dst16) {   // 16-bit tile-order output (the spectral automorphism forms' body operand; dm addresses limbs of n int16)
+        if (M->n < 1024 || (M->plan.m2 % M->plan.cb) != 0 || M->plan.cb % 4 != 0) return fail(PZ_ERR_UNSUPPORTED, "automorphism pre-pass: no 16-bit tile-order output on this plan");
+        g.flags |= 8;
+        // through LDS (one workgroup per polynomial, every source line read once) where the polynomial fits it as int16 and no second operand is added;
+        // POULPY_DBG_AUTO_T16_LDS=0: the gather kernels with a 16-bit store
+        static const int lds_knob = exp_knob("POULPY_DBG_AUTO_T16_LDS", 1);
+        if (lds_knob && add == nullptr && M->n <= 65536 && M->n >= 4096) {
+            KTimer kt(M, PZ_K_ELEMENTWISE);
+            const size_t lds = (size_t)M->n * sizeof(short);
+            PZ_TRY(set_lds(k_automorphism_t16, lds));
+            hipLaunchKernelGGL(k_automorphism_t16, dim3(npolys), dim3(1024), lds, M->stream, g);
+            PZ_HIP(hipGetLastError());
+            return PZ_OK;
+        }
+    }
     KTimer kt(M, PZ_K_ELEMENTWISE);
     // Galois elements whose gather has no locality (neither g nor -g small): chunks of 4 outputs per thread, sources read in runs
     // (k_automorphism_chunk; POULPY_DBG_AUTO_CHUNK=0: always the plain gather, =2: always the chunked form)

@@ -47,6 +47,8 @@ static TailArgs tail_args(const pz_module* M, const TailCall& c, int col_base, i
     g.xcd_map = 0;
     g.d16w = nz ? nz->d16.w : nullptr; g.d16a = nz ? nz->d16.ra : nullptr; g.d16b = nz ? nz->d16.rb : nullptr;
     if (c.acc32 & 4) { g.d16a = c.small16; g.body_bs = c.small16_cs; }
+    g.body16_wide = nullptr;
+    if (c.body16) { g.d16a = c.body16; g.body_bs = (long long)c.body16_limbs * (long long)M->n; g.body16_wide = c.body16_wide; }
     return g;
 }
 static int launch_inv_tail_cols(pz_module* M, const TailCall& c, int col_base, int col_count, bool raw = false, const TailNz* nz = nullptr) {
@@ -77,7 +79,8 @@ static int launch_inv_tail_cols(pz_module* M, const TailCall& c, int col_base, i
         f.kind = TailForm::RSH;
     } else if (!has_small && c.auto_mul != 0) {   // signs without an operand (launch_inv_tail: the body-less columns of a plain spectral automorphism)
         if (!(c.rowmajor && !raw && !nz && tail_rsh_supported(M))) return fail(PZ_ERR_UNSUPPORTED, "fused tail: no sign-only variant for this plan");
-        f.kind = TailForm::SGN;
+        f.kind = c.body16 ? TailForm::SGN16 : TailForm::SGN;   // (+ the 16-bit operand of the body column, launch_inv_tail)
+        if (c.body16) { g.small_size = c.small_size; if (c.base2k > 31) return fail(PZ_ERR_UNSUPPORTED, "fused tail: the 16-bit-operand form needs digits of at most 31 bits"); }
     } else if (raw || nz) {   // the tensoring forms: their own instantiation of the row-major, operand-free tail
         if (!(c.rowmajor && !has_small && tail_rsh_supported(M))) return fail(PZ_ERR_UNSUPPORTED, "fused tail: the tensoring forms need the row-major layout of a 128-point-row plan");
         // contract of the NZ = 1 instantiation (device_fft.hpp): plain normalized store (mode 1, no second result), shift below one limb;
@@ -120,10 +123,14 @@ int launch_inv_tail(pz_module* M, const TailCall& c) {
     static const int sgn_knob = exp_knob("POULPY_DBG_AUTO_SGN", 1);
     if (sgn_knob && c.small != nullptr && c.small_all && c.body_only && c.auto_mul != 0 && c.ncols > 1 && !c.post_rsh && c.rowmajor &&
         tail_rsh_supported(M)) {
+        // (body16: the body column twice - the gathering operand variant returns at once unless the pre-pass raised the flag, the 16-bit-operand form
+        //  of the sign-only tail returns at once if it did; exactly one of them writes the column)
         PZ_TRY(launch_inv_tail_cols(M, c, c.body_col, 1));
         TailCall rest = c;
-        rest.small = nullptr; rest.small_bs = 0; rest.small_all = false; rest.small_size = 0;
+        rest.small = nullptr; rest.small_bs = 0; rest.small_all = false;
         rest.body_src = nullptr; rest.body_bs = rest.body_ls = 0; rest.body_only = false; rest.body_add = false; rest.body_gather = false; rest.gather_mul = 0;
+        if (c.body16) PZ_TRY(launch_inv_tail_cols(M, rest, c.body_col, 1));   // (small_size: the operand's limbs)
+        rest.small_size = 0; rest.body16 = nullptr; rest.body16_wide = nullptr; rest.body16_limbs = 0;
         if (c.body_col > 0) PZ_TRY(launch_inv_tail_cols(M, rest, 0, c.body_col));
         return launch_inv_tail_cols(M, rest, c.body_col + 1, c.ncols - 1 - c.body_col);
     }

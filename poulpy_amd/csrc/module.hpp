@@ -164,7 +164,9 @@ struct pz_module {
     struct PendingOut { void* host; const void* dev; size_t bytes; };
     std::vector<PendingOut> pending_out;
     std::mutex mu;
-    unsigned long long* margin = nullptr;  // device word, bits of max |x-round(x)|
+    unsigned long long* margin = nullptr;  // device word, bits of max |x-round(x)|; the word behind it: the "wide digits" flag of the 16-bit body
+                                           // pre-pass of the spectral automorphism forms (wide16 below)
+    unsigned* wide16() const { return reinterpret_cast<unsigned*>(margin + 1); }
     bool probe = false;
     size_t chunk = 0;
     size_t ws_shift = 0;   // diagnostic: extra bytes of padding in front of T2' in the fused workspace (placement experiments)

@@ -248,8 +248,9 @@ def test_big_add_small_assign(mods, n):
 # batched, device-resident GLWE operations (CoreImpl-level boundary)
 # ------------------------------------------------------------------------------------------
 def _run_glwe_op(hip, ref, ks, n, rank, rank_out, a_size, a_base2k, key_size, key_base2k, dnum, dsize, res_size, res_base2k, batch,
-                 seed, chunk=0, fuse=(True, True), auto=None, in_place=False, pin=False):
-    """auto = (galois element, mode) runs the glwe_automorphism family on top of the key switch."""
+                 seed, chunk=0, fuse=(True, True), auto=None, in_place=False, pin=False, wide_in=None):
+    """auto = (galois element, mode) runs the glwe_automorphism family on top of the key switch.  wide_in = (ciphertext, bits): that ciphertext's
+    digits are drawn from +-2^(bits-1) instead of the balanced a_base2k range (an un-normalized input)."""
     from poulpy_amd.hal import GlweOpParams
     rng = seeded(seed)
     cols_a = rank + 1
@@ -263,6 +264,8 @@ def _run_glwe_op(hip, ref, ks, n, rank, rank_out, a_size, a_base2k, key_size, ke
     want = np.empty((batch, res_size, cols_out, n), dtype=np.int64)
     for b in range(batch):
         a = VecZnx(n, cols_a, a_size).fill_uniform(a_base2k, rng)
+        if wide_in is not None and b == wide_in[0]:
+            a.data[...] = rng.integers(-(1 << (wide_in[1] - 1)), 1 << (wide_in[1] - 1), a.data.shape, dtype=np.int64)
         a_all[b] = a.data
         res = VecZnx(n, cols_out, res_size)
         if auto is not None:
@@ -2242,6 +2245,22 @@ def test_glwe_automorphism_spectral_path(mods, n, rank, p, mode, in_place):
                              in_place=in_place)
     assert np.array_equal(got, want)
 
+
+
+@pytest.mark.parametrize("mode", ["automorphism", "add", "sub", "sub_negate"])
+@pytest.mark.parametrize("n,p", [(8192, 5), (65536, 5 ** 9), (8192, 3)])
+def test_glwe_automorphism_body_as_16_bit_copies_and_wide_inputs(mods, n, p, mode):
+    """Round 6: on the spectral forms the pre-pass leaves the body-column operand (+-phi(body) [+ a0]) as 16-bit values in the tail's tile order
+    (k_automorphism / _chunk with flags & 8, TailArgs::body16_wide); a value beyond 16 bits - an un-normalized input - raises the device flag and
+    the tail gathers the operand itself.  Both branches against the oracle: normalized digits at base2k 12 and 15 / 16 (the widest the copies
+    take), one ciphertext of the batch with 20-bit digits (flag up for that wave: chunk = 2 keeps the other waves on the copies), and a
+    Galois element = 3 mod 4 (p = 3: the conjugating spectral form for add / sub; the plain form keeps its permutation pass there)."""
+    ref, hip = mods(n)
+    limbs = 3 if n < 65536 else 4
+    for (k, wide) in ((12, None), (15, None), (16 if mode == "automorphism" else 15, None), (12, (1, 20)), (12, (2, 17))):
+        got, want = _run_glwe_op(hip, ref, True, n, 1, 1, limbs, k, limbs, k, limbs, 1, limbs, k, batch=4, seed=8100 + k + (wide[1] if wide else 0),
+                                 auto=(p % (2 * n), mode), chunk=2, wide_in=wide)
+        assert np.array_equal(got, want), (n, p, mode, k, wide)
 
 
 @pytest.mark.parametrize("n,a_size,key_size,res_size,batch,chunk", [(4096, 8, 2, 1, 16, 0), (65536, 8, 2, 1, 5, 4), (8192, 6, 3, 1, 9, 0)])
