@@ -13,6 +13,7 @@ $B --op relinearize >> $OUT 2>/dev/null
 $B --op relinearize --limbs 16 --batch 512 --steps 20 >> $OUT 2>/dev/null
 $B --op keyswitch --limbs 16 --batch 512 --steps 20 >> $OUT 2>/dev/null
 $B --op automorphism --limbs 16 --batch 512 --steps 20 >> $OUT 2>/dev/null
+$B --op automorphism --limbs 16 --batch 512 --steps 20 --galois 1979 >> $OUT 2>/dev/null   # a Galois element without locality
 $B --dsize 2 >> $OUT 2>/dev/null
 $B --op keyswitch --dsize 2 >> $OUT 2>/dev/null
 $B --base2k 14 >> $OUT 2>/dev/null
@@ -51,6 +52,9 @@ python tools/bench_tensor.py 2>/dev/null | grep "^{" | tail -1 >> $T
 python tools/bench_tensor.py --mode square 2>/dev/null | grep "^{" | tail -1 >> $T
 python tools/bench_tensor.py --limbs 8 --batch 512 2>/dev/null | grep "^{" | tail -1 >> $T
 python tools/bench_tensor.py --relin 2>/dev/null | grep "^{" | tail -1 >> $T
+python tools/bench_tensor.py --relin --one-call 2>/dev/null | grep "^{" | tail -1 >> $T                  # the multiplication as ONE call, tensor in scratch (poulpy-ckks ckks_mul_into_default)
+python tools/bench_tensor.py --relin --one-call --mode square 2>/dev/null | grep "^{" | tail -1 >> $T
+python tools/bench_tensor.py --relin --one-call --limbs 8 --batch 512 2>/dev/null | grep "^{" | tail -1 >> $T
 python -c "
 import json
 for l in open('gpurun_out/tensor_lines.jsonl'):

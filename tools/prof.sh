@@ -5,8 +5,8 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 20 --warmup 2 --no-cpu-baseline --no-kernel-timing --parity-samples 0"
-ARGS_PMC="--steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --parity-samples 0"
+ARGS="--steps 20 --warmup 2 --no-cpu-baseline --no-kernel-timing --parity-samples 0 --sustained-seconds 0"
+ARGS_PMC="--steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --parity-samples 0 --sustained-seconds 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py $ARGS_PMC > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py $ARGS_PMC > $OUT/pmc_write.log 2>&1
