@@ -376,8 +376,10 @@ static int wave_spectral_tail(const GlweCall& c, const FusedBufs& f, size_t b0, 
     // beside it, does the column - the same bits, slower.  Out of place and without the shifted store, as fold.
     static const int b16_knob = exp_knob("POULPY_DBG_AUTO_BODY16", 1);
     // (not under the rounding-margin probe: its instantiation of the tail keeps the i64 operand - the values that are rounded are the same)
-    const bool body16 = b16_knob != 0 && !fold && !M->probe && !c.au_big && (c.res >= a_end || c.a >= r_end) && !c.want_rsh && n >= 1024 &&
-                        (int)c.p->key_base2k <= 16 && (int)c.p->res_base2k <= 31 && tail_rsh_supported(M);
+    // (add / sub forms: the operand phi(body) +- a0 is a sum of two digits - a key base of at most 15 bits; the other columns keep their 8-byte operand)
+    const bool body16 = b16_knob != 0 && !fold && !M->probe && (c.res >= a_end || c.a >= r_end) && !c.want_rsh && n >= 4096 && n <= 65536 &&
+                        (int)c.p->key_base2k <= (c.au_big ? 15 : 16) && (int)c.p->res_base2k <= 31 && tail_rsh_supported(M) &&
+                        !(c.au_big && exp_knob("POULPY_DBG_AUTO_BODYADD", 0));
     short* b16 = body16 ? (short*)f.res_tmp : nullptr;
     if (body16) {
         PZ_TRY(launch_zero_bytes(M, M->margin + 1, 8));   // the flag word (module.hpp: wide16)
@@ -399,6 +401,12 @@ static int wave_spectral_tail(const GlweCall& c, const FusedBufs& f, size_t b0, 
     // stream on the body column) instead of a pre-pass with an add operand; not with the shifted stores of glwe_trace (registers)
     static const int bodyadd_knob = exp_knob("POULPY_DBG_AUTO_BODYADD", 0);
     const bool rsh = c.want_rsh && tail_rsh_supported(M) && !c.cross_out && c.p->res_base2k <= 29;   // (32-bit shift steps: device_fft.hpp)
+    if (body16) {
+        // the pre-pass writes the operand the chain adds: phi(body) + a0 (add), phi(body) - a0 (sub forms; the i64 scheme stores -phi(body) + a0 and
+        // lets the tail negate it); what the gathers produce when the flag is up is the fold form's operand, negated by the tail as there
+        t.gather_neg = c.au->mode != 1;
+        PZ_TRY(launch_automorphism(M, nb * bl, (const long long*)av.p, bsm, nullptr, bdm, c.au_g, c.au->mode == 1 ? 1 : (1 | 16), (const long long*)av.p, bsm, b16));
+    } else
     if (fold) t.gather_neg = c.au->mode != 1;
     else if (bodyadd_knob && !rsh) {
         PZ_TRY(launch_automorphism(M, nb * bl, (const long long*)av.p, bsm, (long long*)f.res_tmp, bdm, c.au_g, c.au->mode == 1 ? 1 : 3));

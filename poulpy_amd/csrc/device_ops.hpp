@@ -376,7 +376,8 @@ __global__ void __launch_bounds__(256) k_automorphism_chunk(AutoArgs g, unsigned
 // polynomial: the source is read ONCE in whole lines (the gathers above fetch every line 4 - 5 x from L2: 1.76 ms per 512 x 16 limbs against the
 // 0.8 its bytes take), narrowed to int16 into LDS, and the outputs are produced in the tile order itself - 4 consecutive values per thread, whole
 // 512-byte runs per wave - by reading LDS at the Galois-permuted index.  Any Galois element alike.  A value outside +-32767 raises *wide
-// (-32768 included: its negation does not fit).  flags as k_automorphism (1 sign, 2 negate all); no `add` operand.
+// (-32768 included: its negation does not fit).  flags as k_automorphism (1 sign, 2 negate all); `add` (natural order, i64) is added to - flags & 16:
+// subtracted from - the permuted value, and a sum beyond 16 bits raises *wide too (the add / sub forms' body operand phi(body) +- a0).
 __global__ void __launch_bounds__(1024) k_automorphism_t16(AutoArgs g) {
     extern __shared__ short a16[];   // the source polynomial, natural order
     const int poly = blockIdx.x;
@@ -401,6 +402,8 @@ __global__ void __launch_bounds__(1024) k_automorphism_t16(AutoArgs g) {
     if (wide) atomicOr(g.wide, 1u);
     __syncthreads();
     short* dst = g.dst16 + map_off(g.dm, poly);
+    const long long* add = g.add ? g.add + map_off(g.am, poly) : nullptr;
+    bool wide2 = false;
     const unsigned mask2 = 2u * (unsigned)g.n - 1u, nn = (unsigned)g.n;
     const unsigned m2 = 1u << g.t16_m2sh, tile = 2u * (unsigned)g.t16_m1 * (unsigned)g.t16_cb;
     for (unsigned t = (unsigned)tid * 4u; t < nn; t += 4096u) {
@@ -408,18 +411,26 @@ __global__ void __launch_bounds__(1024) k_automorphism_t16(AutoArgs g) {
         const unsigned blk = t / tile, rem = t % tile;
         const unsigned j = (rem / (unsigned)g.t16_cb) * m2 + blk * (unsigned)g.t16_cb + (rem % (unsigned)g.t16_cb);
         short o[4];
+        long long w[4] = {0, 0, 0, 0};
+        if (add) {   // (j a multiple of 4: 32 contiguous bytes)
+            const longlong2 w0 = *reinterpret_cast<const longlong2*>(add + j), w1 = *reinterpret_cast<const longlong2*>(add + j + 2);
+            w[0] = w0.x; w[1] = w0.y; w[2] = w1.x; w[3] = w1.y;
+        }
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
             const unsigned i0 = ((j + (unsigned)x) * g.mul) & mask2;
             const int v = (int)a16[i0 & (nn - 1u)];
             bool neg = (g.flags & 1) && i0 >= nn;
             if (g.flags & 2) neg = !neg;
-            o[x] = (short)(neg ? -v : v);
+            const unsigned long long s = (unsigned long long)(long long)(neg ? -v : v) + ((g.flags & 16) ? 0ull - (unsigned long long)w[x] : (unsigned long long)w[x]);
+            wide2 = wide2 || (s + 32767ull) >= 65535ull;
+            o[x] = (short)s;
         }
         short4 s4;
         s4.x = o[0]; s4.y = o[1]; s4.z = o[2]; s4.w = o[3];
         *reinterpret_cast<short4*>(dst + t) = s4;
     }
+    if (wide2) atomicOr(g.wide, 1u);
 }
 
 // =================================================================================

@@ -36,6 +36,7 @@ int launch_automorphism(pz_module* M, int npolys, const long long* src, PolyMap 
     AutoArgs g;
     g.src = src; g.dst = dst; g.add = add; g.sm = sm; g.dm = dm; g.am = am;
     g.npolys = npolys; g.n = (int)M->n; g.mul = mul; g.flags = flags & 7;
+    if (dst16 && (flags & 16)) g.flags |= 16;   // (16-bit output only: `add` is subtracted)
     g.dst16 = dst16; g.wide = M->wide16();
     g.t16_m1 = M->plan.f1a * M->plan.f1b; g.t16_cb = M->plan.cb; g.t16_m2sh = 0;
     while ((1 << g.t16_m2sh) < M->plan.m2) ++g.t16_m2sh;
@@ -45,7 +46,7 @@ int launch_automorphism(pz_module* M, int npolys, const long long* src, PolyMap 
         // through LDS (one workgroup per polynomial, every source line read once) where the polynomial fits it as int16 and no second operand is added;
         // POULPY_DBG_AUTO_T16_LDS=0: the gather kernels with a 16-bit store
         static const int lds_knob = exp_knob("POULPY_DBG_AUTO_T16_LDS", 1);
-        if (lds_knob && add == nullptr && M->n <= 65536 && M->n >= 4096) {
+        if (lds_knob && M->n <= 65536 && M->n >= 4096) {
             KTimer kt(M, PZ_K_ELEMENTWISE);
             const size_t lds = (size_t)M->n * sizeof(short);
             PZ_TRY(set_lds(k_automorphism_t16, lds));
@@ -53,6 +54,7 @@ int launch_automorphism(pz_module* M, int npolys, const long long* src, PolyMap 
             PZ_HIP(hipGetLastError());
             return PZ_OK;
         }
+        if (g.flags & 16) return fail(PZ_ERR_UNSUPPORTED, "automorphism pre-pass: the subtracting 16-bit form exists through LDS only");
     }
     KTimer kt(M, PZ_K_ELEMENTWISE);
     // Galois elements whose gather has no locality (neither g nor -g small): chunks of 4 outputs per thread, sources read in runs

@@ -77,7 +77,7 @@ static int launch_inv_tail_cols(pz_module* M, const TailCall& c, int col_base, i
     } else if (c.post_rsh) {
         if (!(tail_rsh_supported(M) && c.rowmajor && has_small)) return fail(PZ_ERR_UNSUPPORTED, "fused tail: no shifted-store variant for this plan");
         f.kind = TailForm::RSH;
-    } else if (!has_small && c.auto_mul != 0) {   // signs without an operand (launch_inv_tail: the body-less columns of a plain spectral automorphism)
+    } else if (!has_small && (c.auto_mul != 0 || c.body16)) {   // signs without an operand (launch_inv_tail: the body-less columns of a plain spectral automorphism)
         if (!(c.rowmajor && !raw && !nz && tail_rsh_supported(M))) return fail(PZ_ERR_UNSUPPORTED, "fused tail: no sign-only variant for this plan");
         f.kind = c.body16 ? TailForm::SGN16 : TailForm::SGN;   // (+ the 16-bit operand of the body column, launch_inv_tail)
         if (c.body16) { g.small_size = c.small_size; if (c.base2k > 31) return fail(PZ_ERR_UNSUPPORTED, "fused tail: the 16-bit-operand form needs digits of at most 31 bits"); }
@@ -133,6 +133,21 @@ int launch_inv_tail(pz_module* M, const TailCall& c) {
         rest.small_size = 0; rest.body16 = nullptr; rest.body16_wide = nullptr; rest.body16_limbs = 0;
         if (c.body_col > 0) PZ_TRY(launch_inv_tail_cols(M, rest, 0, c.body_col));
         return launch_inv_tail_cols(M, rest, c.body_col + 1, c.ncols - 1 - c.body_col);
+    }
+    // add / sub forms of the spectral automorphism with the body-column operand phi(body) +- a0 as 16-bit copies (TailCall::body16): that column as
+    // above - the 16-bit-operand form on the f64 chain, the gathering operand variant beside it for the flag-up case - every other column on the
+    // operand variant with its own +-a[col]
+    if (c.body16 && c.small != nullptr && c.small_all && !c.body_only && !c.post_rsh && c.rowmajor && tail_rsh_supported(M)) {
+        PZ_TRY(launch_inv_tail_cols(M, c, c.body_col, 1));   // (returns at once unless the pre-pass raised the flag)
+        TailCall b16 = c;
+        b16.small = nullptr; b16.small_bs = 0; b16.small_all = false; b16.small_neg = false;   // (the sign of the operand is the pre-pass's)
+        b16.body_src = nullptr; b16.body_bs = b16.body_ls = 0; b16.body_add = false; b16.body_gather = false; b16.gather_mul = 0; b16.gather_neg = false;
+        PZ_TRY(launch_inv_tail_cols(M, b16, c.body_col, 1));
+        TailCall rest = c;
+        rest.body16 = nullptr; rest.body16_wide = nullptr; rest.body16_limbs = 0;
+        if (c.body_col > 0) PZ_TRY(launch_inv_tail_cols(M, rest, 0, c.body_col));
+        if (c.ncols - 1 - c.body_col > 0) PZ_TRY(launch_inv_tail_cols(M, rest, c.body_col + 1, c.ncols - 1 - c.body_col));
+        return PZ_OK;
     }
     return launch_inv_tail_cols(M, c, 0, c.ncols);
 }
