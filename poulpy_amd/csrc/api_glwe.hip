@@ -372,27 +372,29 @@ static int wave_spectral_tail(const GlweCall& c, const FusedBufs& f, size_t b0, 
     // Round 6, plain form: the pre-pass leaves phi(body) as 16-bit values in the tail's own tile order (2 B written and 2 B read per coefficient
     // instead of 8) where the digits are expected to fit - a key base of at most 16 bits - and the body column then rides on the f64 chain of the
     // sign-only tail with that operand (k_inv_tail<.., NZF = 7, SGN>) instead of the operand variant's integer chain.  A value that does not fit
-    // (un-normalized input) raises a device flag: the 16-bit form returns at once and the gathering operand variant (the fold form), launched
-    // beside it, does the column - the same bits, slower.  Out of place and without the shifted store, as fold.
+    // (un-normalized input) raises a device flag, and the wave then runs exactly the i64 scheme: a second, CONDITIONAL pre-pass writes the i64 operand
+    // over the copies (its blocks return at once while the flag is down), the 16-bit form of the tail returns at once and the operand variant, launched
+    // beside it and returning at once while the flag is down, does the column.  In-place calls included (both pre-passes read the input before any
+    // tail writes); not with the shifted store of glwe_trace.
     static const int b16_knob = exp_knob("POULPY_DBG_AUTO_BODY16", 1);
     // (not under the rounding-margin probe: its instantiation of the tail keeps the i64 operand - the values that are rounded are the same)
     // (add / sub forms: the operand phi(body) +- a0 is a sum of two digits - a key base of at most 15 bits; the other columns keep their 8-byte operand)
-    const bool body16 = b16_knob != 0 && !fold && !M->probe && (c.res >= a_end || c.a >= r_end) && !c.want_rsh && n >= 4096 && n <= 65536 &&
+    const bool body16 = b16_knob != 0 && !fold && !M->probe && !c.want_rsh && n >= 4096 && n <= 65536 &&
                         (int)c.p->key_base2k <= (c.au_big ? 15 : 16) && (int)c.p->res_base2k <= 31 && tail_rsh_supported(M) &&
                         !(c.au_big && exp_knob("POULPY_DBG_AUTO_BODYADD", 0));
     short* b16 = body16 ? (short*)f.res_tmp : nullptr;
     if (body16) {
         PZ_TRY(launch_zero_bytes(M, M->margin + 1, 8));   // the flag word (module.hpp: wide16)
-        t.body_gather = true; t.gather_mul = c.au_g;
         t.body16 = b16; t.body16_limbs = bl; t.body16_wide = M->wide16();
-    } else
+    }
     if (fold) { t.body_gather = true; t.gather_mul = c.au_g; }
     else { t.body_src = (const long long*)f.res_tmp; t.body_bs = (long long)bl * n; t.body_ls = n; }
+    const int cond = body16 ? 32 : 0;   // (launch_automorphism: the i64 pre-pass only if the flag is up)
     if (!c.au_big) {
         // plain form, res = phi(normalize(big)) (glwe_ct.rs:65-71): the inverse transform is phi(big) with phi's signs; the tail undoes
         // them in front of the carry chain (auto_mul) and puts them back on the digits (post_neg); only the body column has an operand
         if (body16) PZ_TRY(launch_automorphism(M, nb * bl, (const long long*)av.p, bsm, nullptr, bdm, c.au_g, 1, nullptr, PolyMap{1, 1, 0, 0, 0, 0}, b16));
-        else if (!fold) PZ_TRY(launch_automorphism(M, nb * bl, (const long long*)av.p, bsm, (long long*)f.res_tmp, bdm, c.au_g, 1));
+        if (!fold) PZ_TRY(launch_automorphism(M, nb * bl, (const long long*)av.p, bsm, (long long*)f.res_tmp, bdm, c.au_g, 1 | cond));
         t.auto_mul = c.au_g; t.post_neg = true; t.body_only = true;
         return launch_inv_tail(M, t);
     }
@@ -401,17 +403,14 @@ static int wave_spectral_tail(const GlweCall& c, const FusedBufs& f, size_t b0, 
     // stream on the body column) instead of a pre-pass with an add operand; not with the shifted stores of glwe_trace (registers)
     static const int bodyadd_knob = exp_knob("POULPY_DBG_AUTO_BODYADD", 0);
     const bool rsh = c.want_rsh && tail_rsh_supported(M) && !c.cross_out && c.p->res_base2k <= 29;   // (32-bit shift steps: device_fft.hpp)
-    if (body16) {
-        // the pre-pass writes the operand the chain adds: phi(body) + a0 (add), phi(body) - a0 (sub forms; the i64 scheme stores -phi(body) + a0 and
-        // lets the tail negate it); what the gathers produce when the flag is up is the fold form's operand, negated by the tail as there
-        t.gather_neg = c.au->mode != 1;
-        PZ_TRY(launch_automorphism(M, nb * bl, (const long long*)av.p, bsm, nullptr, bdm, c.au_g, c.au->mode == 1 ? 1 : (1 | 16), (const long long*)av.p, bsm, b16));
-    } else
+    // (16-bit scheme: the pre-pass writes the operand the chain adds - phi(body) + a0 (add), phi(body) - a0 (sub forms; the i64 scheme stores
+    //  -phi(body) + a0 and lets the tail negate it))
+    if (body16) PZ_TRY(launch_automorphism(M, nb * bl, (const long long*)av.p, bsm, nullptr, bdm, c.au_g, c.au->mode == 1 ? 1 : (1 | 16), (const long long*)av.p, bsm, b16));
     if (fold) t.gather_neg = c.au->mode != 1;
     else if (bodyadd_knob && !rsh) {
         PZ_TRY(launch_automorphism(M, nb * bl, (const long long*)av.p, bsm, (long long*)f.res_tmp, bdm, c.au_g, c.au->mode == 1 ? 1 : 3));
         t.body_add = true;
-    } else PZ_TRY(launch_automorphism(M, nb * bl, (const long long*)av.p, bsm, (long long*)f.res_tmp, bdm, c.au_g, c.au->mode == 1 ? 1 : 3,
+    } else PZ_TRY(launch_automorphism(M, nb * bl, (const long long*)av.p, bsm, (long long*)f.res_tmp, bdm, c.au_g, (c.au->mode == 1 ? 1 : 3) | cond,
                                       (const long long*)av.p, bsm));
     if (c.au->mode == 3) { t.auto_mul = 2u * (unsigned)n; t.auto_neg = true; }   // a - phi(big): every sign flipped
     t.small_neg = c.au->mode != 1;

@@ -282,6 +282,9 @@ struct AutoArgs {
     short* dst16;
     unsigned* wide;
     int t16_m1, t16_cb, t16_m2sh;   // tile: m1 rows, cb columns per block, log2 m2
+    // cond_total != 0: the launch only works if *wide is up (the i64 fallback of the 16-bit body pre-pass: values that did not fit) - a small grid
+    // whose blocks return at once otherwise, and walk the cond_total block positions of the plain launch if it is
+    int cond_total;
 };
 // tile-order position of coefficient j (TailArgs::d16*): j = h m + j1 m2 + cc  ->  (cc / cb) 2 m1 cb + (h m1 + j1) cb + cc % cb
 __device__ __forceinline__ long long auto_t16_pos(const AutoArgs& g, unsigned j) {
@@ -291,9 +294,9 @@ __device__ __forceinline__ long long auto_t16_pos(const AutoArgs& g, unsigned j)
 }
 __device__ __forceinline__ bool auto_wide(unsigned long long v) { return (v + 32768ull) >= 65536ull; }
 
-__global__ void __launch_bounds__(256) k_automorphism(AutoArgs g) {
+__device__ __forceinline__ void automorphism_block(const AutoArgs& g, int bid) {
     const int bpp = g.n >= 512 ? g.n / 512 : 1;  // blocks per polynomial, 2 coefficients per thread
-    const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+    const int xcd = bid & 7, r = bid >> 3;
     const int poly = (r / bpp) * 8 + xcd, blk = r % bpp;
     if (poly >= g.npolys) return;
     const long long* src = g.src + map_off(g.sm, poly);
@@ -327,6 +330,13 @@ __global__ void __launch_bounds__(256) k_automorphism(AutoArgs g) {
     *reinterpret_cast<ulonglong2*>(dst + j) = make_ulonglong2(out[0], out[1]);
 }
 
+__global__ void __launch_bounds__(256) k_automorphism(AutoArgs g) { automorphism_block(g, blockIdx.x); }
+// (the conditional form, AutoArgs::cond_total - a kernel of its own: the walk over block positions would cost the plain launch registers)
+__global__ void __launch_bounds__(256) k_automorphism_cond(AutoArgs g) {
+    if (__builtin_amdgcn_readfirstlane((int)*g.wide) == 0) return;
+    for (int vb = blockIdx.x; vb < g.cond_total; vb += gridDim.x) automorphism_block(g, vb);
+}
+
 // The same map for Galois elements without locality (round 4).  k_automorphism lets consecutive lanes own consecutive OUTPUT coefficients and
 // gather their sources g apart: for g = 5^k, the steps of glwe_trace, ... every 8-byte load touches a line of its own and the 128 bytes that
 // come back from L2 per element (16 x the useful bytes) pace the kernel - 3.0 ms per 1024 ciphertexts x 8 limbs against 1.8 for g = 5.  Here
@@ -334,9 +344,9 @@ __global__ void __launch_bounds__(256) k_automorphism(AutoArgs g) {
 // the lanes of a wave read every fourth coefficient of one contiguous run (4 x amplification instead of 16), and the outputs (and the `add`
 // operand) move as whole 32-byte sectors.  Chunk e and chunk e + N/4 are the two halves of the index range mod 2N: e runs over [0, N/4)
 // and a wrapped base (j0 >= N) is the same position with every sign flipped.
-__global__ void __launch_bounds__(256) k_automorphism_chunk(AutoArgs g, unsigned hinv) {
+__device__ __forceinline__ void automorphism_chunk_block(const AutoArgs& g, unsigned hinv, int bid) {
     const int bpp = g.n / 1024;   // blocks per polynomial (launcher: n >= 1024)
-    const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+    const int xcd = bid & 7, r = bid >> 3;
     const int poly = (r / bpp) * 8 + xcd, blk = r % bpp;
     if (poly >= g.npolys) return;
     const long long* src = g.src + map_off(g.sm, poly);
@@ -370,6 +380,12 @@ __global__ void __launch_bounds__(256) k_automorphism_chunk(AutoArgs g, unsigned
     }
     *reinterpret_cast<ulonglong2*>(dst + j0) = make_ulonglong2(out[0], out[1]);
     *reinterpret_cast<ulonglong2*>(dst + j0 + 2) = make_ulonglong2(out[2], out[3]);
+}
+
+__global__ void __launch_bounds__(256) k_automorphism_chunk(AutoArgs g, unsigned hinv) { automorphism_chunk_block(g, hinv, blockIdx.x); }
+__global__ void __launch_bounds__(256) k_automorphism_chunk_cond(AutoArgs g, unsigned hinv) {
+    if (__builtin_amdgcn_readfirstlane((int)*g.wide) == 0) return;
+    for (int vb = blockIdx.x; vb < g.cond_total; vb += gridDim.x) automorphism_chunk_block(g, hinv, vb);
 }
 
 // The 16-bit tile-order output through LDS (round 6): a polynomial of 16-bit values is n x 2 B = 128 KiB at N = 2^16 - it fits the CU.  One workgroup per

@@ -38,6 +38,8 @@ int launch_automorphism(pz_module* M, int npolys, const long long* src, PolyMap 
     g.npolys = npolys; g.n = (int)M->n; g.mul = mul; g.flags = flags & 7;
     if (dst16 && (flags & 16)) g.flags |= 16;   // (16-bit output only: `add` is subtracted)
     g.dst16 = dst16; g.wide = M->wide16();
+    g.cond_total = 0;
+    const bool cond = (flags & 32) != 0;   // the i64 fallback of the 16-bit body pre-pass: only if the flag is up (k_automorphism: cond_total)
     g.t16_m1 = M->plan.f1a * M->plan.f1b; g.t16_cb = M->plan.cb; g.t16_m2sh = 0;
     while ((1 << g.t16_m2sh) < M->plan.m2) ++g.t16_m2sh;
     if (dst16) {   // 16-bit tile-order output (the spectral automorphism forms' body operand; dm addresses limbs of n int16)
@@ -69,13 +71,20 @@ int launch_automorphism(pz_module* M, int npolys, const long long* src, PolyMap 
     const unsigned dist = std::min(std::min(gm, two_n - gm), std::min(hinv, two_n - hinv));
     if (M->n >= 1024 && (chunk_knob == 2 || (chunk_knob == 1 && dist > 32))) {
         const int bpp = (int)(M->n / 1024);
-        hipLaunchKernelGGL(k_automorphism_chunk, dim3(((npolys + 7) / 8) * 8 * bpp), dim3(256), 0, M->stream, g, hinv);
+        const int blocks = ((npolys + 7) / 8) * 8 * bpp;
+        if (cond) {
+            g.cond_total = blocks;
+            hipLaunchKernelGGL(k_automorphism_chunk_cond, dim3(std::min(blocks, 4096)), dim3(256), 0, M->stream, g, hinv);
+        } else hipLaunchKernelGGL(k_automorphism_chunk, dim3(blocks), dim3(256), 0, M->stream, g, hinv);
         PZ_HIP(hipGetLastError());
         return PZ_OK;
     }
     const int bpp = M->n >= 512 ? (int)(M->n / 512) : 1;
     const int blocks = ((npolys + 7) / 8) * 8 * bpp;
-    hipLaunchKernelGGL(k_automorphism, dim3(blocks), dim3(256), 0, M->stream, g);
+    if (cond) {
+        g.cond_total = blocks;
+        hipLaunchKernelGGL(k_automorphism_cond, dim3(std::min(blocks, 4096)), dim3(256), 0, M->stream, g);
+    } else hipLaunchKernelGGL(k_automorphism, dim3(blocks), dim3(256), 0, M->stream, g);
     PZ_HIP(hipGetLastError());
     return PZ_OK;
 }

@@ -2252,15 +2252,16 @@ def test_glwe_automorphism_spectral_path(mods, n, rank, p, mode, in_place):
 def test_glwe_automorphism_body_as_16_bit_copies_and_wide_inputs(mods, n, p, mode):
     """Round 6: on the spectral forms the pre-pass leaves the body-column operand (+-phi(body) [+ a0]) as 16-bit values in the tail's tile order
     (k_automorphism / _chunk with flags & 8, TailArgs::body16_wide); a value beyond 16 bits - an un-normalized input - raises the device flag and
-    the tail gathers the operand itself.  Both branches against the oracle: normalized digits at base2k 12 and 15 / 16 (the widest the copies
+    the wave runs the i64 scheme (a conditional second pre-pass + the operand variant of the tail).  Both branches against the oracle, out of place and in place: normalized digits at base2k 12 and 15 / 16 (the widest the copies
     take), one ciphertext of the batch with 20-bit digits (flag up for that wave: chunk = 2 keeps the other waves on the copies), and a
     Galois element = 3 mod 4 (p = 3: the conjugating spectral form for add / sub; the plain form keeps its permutation pass there)."""
     ref, hip = mods(n)
     limbs = 3 if n < 65536 else 4
-    for (k, wide) in ((12, None), (15, None), (16 if mode == "automorphism" else 15, None), (12, (1, 20)), (12, (2, 17))):
-        got, want = _run_glwe_op(hip, ref, True, n, 1, 1, limbs, k, limbs, k, limbs, 1, limbs, k, batch=4, seed=8100 + k + (wide[1] if wide else 0),
-                                 auto=(p % (2 * n), mode), chunk=2, wide_in=wide)
-        assert np.array_equal(got, want), (n, p, mode, k, wide)
+    for in_place in (False, True):
+        for (k, wide) in ((12, None), (15, None), (16 if mode == "automorphism" else 15, None), (12, (1, 20)), (12, (2, 17))):
+            got, want = _run_glwe_op(hip, ref, True, n, 1, 1, limbs, k, limbs, k, limbs, 1, limbs, k, batch=4, seed=8100 + k + (wide[1] if wide else 0),
+                                     auto=(p % (2 * n), mode), chunk=2, wide_in=wide, in_place=in_place)
+            assert np.array_equal(got, want), (n, p, mode, k, wide, in_place)
 
 
 @pytest.mark.parametrize("n,a_size,key_size,res_size,batch,chunk", [(4096, 8, 2, 1, 16, 0), (65536, 8, 2, 1, 5, 4), (8192, 6, 3, 1, 9, 0)])
