@@ -426,6 +426,8 @@ def main():
         nst = N.bit_length() - 1
         trace_gals = [-1] + [pow(5, 1 << i, 2 * N) for i in range(nst - 1)]
         trace_keys = [pmat] + [pmat.clone() for _ in range(nst - 1)]          # one (synthetic) prepared key per step
+        torch.cuda.synchronize()   # the clones are torch's copies on torch's stream; pin_key reads them on the module's stream (round 6: without this
+                                   # the pinned copies of keys of >= 11 limbs were built from clones still in flight - wrong traces, margin 0.5)
         if not args.no_pin_key:
             for t in trace_keys[1:]:
                 mod.pin_key(C.c_void_p(t.data_ptr()), DNUM, cols_in, cols, SIZE)

@@ -375,12 +375,14 @@ static int wave_spectral_tail(const GlweCall& c, const FusedBufs& f, size_t b0, 
     // (un-normalized input) raises a device flag, and the wave then runs exactly the i64 scheme: a second, CONDITIONAL pre-pass writes the i64 operand
     // over the copies (its blocks return at once while the flag is down), the 16-bit form of the tail returns at once and the operand variant, launched
     // beside it and returning at once while the flag is down, does the column.  In-place calls included (both pre-passes read the input before any
-    // tail writes); not with the shifted store of glwe_trace.
+    // tail writes); with the shifted store of glwe_trace too (k_inv_tail<..,RSH,7,SGN>: the one-bit shift behind the f64 chain).
     static const int b16_knob = exp_knob("POULPY_DBG_AUTO_BODY16", 1);
     // (not under the rounding-margin probe: its instantiation of the tail keeps the i64 operand - the values that are rounded are the same)
     // (add / sub forms: the operand phi(body) +- a0 is a sum of two digits - a key base of at most 15 bits; the other columns keep their 8-byte operand)
-    const bool body16 = b16_knob != 0 && !fold && !M->probe && !c.want_rsh && n >= 4096 && n <= 65536 &&
-                        (int)c.p->key_base2k <= (c.au_big ? 15 : 16) && (int)c.p->res_base2k <= 31 && tail_rsh_supported(M) &&
+    // (glwe_trace's steps, want_rsh: their input is the previous step's - or the initial shift's - normalized output, so with a base of at most 14 bits
+    //  the operand always fits and the flag-up launches of the shifted-store forms stay what they are there: never taken)
+    const bool body16 = b16_knob != 0 && !fold && !M->probe && (!c.want_rsh || (c.au_big && (int)c.p->key_base2k <= 14 && (int)c.p->res_base2k <= 29)) &&
+                        n >= 4096 && n <= 65536 && (int)c.p->key_base2k <= (c.au_big ? 15 : 16) && (int)c.p->res_base2k <= 31 && tail_rsh_supported(M) &&
                         !(c.au_big && exp_knob("POULPY_DBG_AUTO_BODYADD", 0));
     short* b16 = body16 ? (short*)f.res_tmp : nullptr;
     if (body16) {

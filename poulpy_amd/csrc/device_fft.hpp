@@ -584,7 +584,7 @@ __device__ __forceinline__ int sx_carry(int k, int x, int d) { return (x - d) >>
 template <int R1, int R2, int CB, bool ROWMAJOR = false, bool SMALL = false, bool RSH = false, int NZF = 0, bool SGN = false, bool PROBE = false, bool ACC32 = false>
 __global__ void __launch_bounds__(((R1 == 16 ? 2 : 1) * R2 + R1) * CB, ((((R1 == 16 ? 2 : 1) * R2 + R1) * CB >= 512) ? 1 : (SMALL ? 2 : 3)))
 k_inv_tail(TailArgs g) {
-    static_assert(!RSH || SMALL, "the shifted store rides on the integer carry chain");
+    static_assert(!RSH || SMALL || NZF == 7, "the shifted store rides on the operand forms (the integer chain, or the 16-bit operand on the f64 chain)");
     // NZF: 0 none | 1 diagonal tensoring tail | 2 pairwise / raw | 3 = 1 + 16-bit side copy of every digit (TailArgs::d16w) | 4 = 2 with the mode-5
     // prefetch reading 16-bit side copies (TailArgs::d16a / d16b) instead of the i64 columns' low dwords.  Forms of their own: with both prefetch
     // paths in one instantiation the pairwise tail went from 12 to 28 B of scratch at its 168-register cap
@@ -604,7 +604,7 @@ k_inv_tail(TailArgs g) {
 #define PZ_TAIL_IS_RAW (NZ && !NZD && g.raw)
     static_assert(!ACC32 || (ROWMAJOR && SMALL && !RSH && !NZ && !SGN), "32-bit accumulator digits: the plain operand form of the row-major pipeline");
     static_assert(!NZ || (ROWMAJOR && !SMALL && !RSH), "tensoring forms: row-major pipeline layout, no operand");
-    static_assert(!SGN || (ROWMAJOR && !SMALL && !RSH && !NZ), "sign-only form: row-major pipeline layout, no operand");
+    static_assert(!SGN || (ROWMAJOR && !SMALL && (!RSH || NZF == 7) && !NZ), "sign-only form: row-major pipeline layout, no operand");
     constexpr bool SPLIT = TailShape<R1, R2, CB>::SPLIT;
     constexpr int RE = TailShape<R1, R2, CB>::RE;
     constexpr int NB = TailShape<R1, R2, CB>::NB;
@@ -951,6 +951,23 @@ k_inv_tail(TailArgs g) {
         // One pass per coefficient: round, convert, (+ body), carry step, store.  digit(x) = ((x + 2^(k-1)) mod 2^k) -
         // 2^(k-1), carry(x) = (x + 2^(k-1)) >> k: the values of the reference's shift pairs
         // (reference/znx/normalization.rs:4-11,24-41,107-129,179-221) with fewer 64-bit operations.
+        // (RSH) the digit leaves through vec_znx_rsh_assign by one bit: limb j's digit gives limb j + 1 of the shifted value
+#define PZ_TAIL_RSH_STORE(X1_)                                                                               \
+    {                                                                                                        \
+        int& c2 = cy2[RSH ? 2 * n1 + h : 0];                                                                 \
+        const int xd = (int)(X1_);                                                                           \
+        const int d1 = -(xd & 1);                                                                            \
+        const int cr1 = (xd - d1) >> 1;                                                                      \
+        if (j == g.res_size - 1) {                                                                           \
+            c2 = cr1;                                                                                        \
+        } else {                                                                                             \
+            const int dpc = d1 * (1 << (k - 1)) + c2;                                                        \
+            const int nv = sx_digit(k, dpc);                                                                 \
+            c2 = cr1 + sx_carry(k, dpc, nv);                                                                 \
+            st_stream(res_col + (long long)(j + 1) * res_ls + idx, (long long)nv);                           \
+        }                                                                                                    \
+        if (j == 0) st_stream(res_col + idx, (long long)sx_digit(k, c2));                                    \
+    }
 #define PZ_TAIL_COEFFS(CONVERT)                                                                               \
     _Pragma("unroll") for (int n1 = 0; n1 < RE; ++n1) {                                                      \
         const int j1 = b_ov + R2 * PZ_TAIL_N1(n1);                                                            \
@@ -1000,21 +1017,7 @@ k_inv_tail(TailArgs g) {
                 cy = (long long)((unsigned long long)cr + (unsigned long long)((long long)y2 >> k));         \
                 if ((SMALL || SGN) && g.post_neg && ng_) x1 = (long long)(0ull - (unsigned long long)x1);    \
                 if (RSH) {                                                                                   \
-                    if (writes) {                                                                            \
-                        int& c2 = cy2[RSH ? 2 * n1 + h : 0];                                                 \
-                        const int xd = (int)x1;                                                              \
-                        const int d1 = -(xd & 1);                                                            \
-                        const int cr1 = (xd - d1) >> 1;                                                      \
-                        if (j == g.res_size - 1) {                                                           \
-                            c2 = cr1;                                                                        \
-                        } else {                                                                             \
-                            const int dpc = d1 * (1 << (k - 1)) + c2;                                        \
-                            const int nv = sx_digit(k, dpc);                                                 \
-                            c2 = cr1 + sx_carry(k, dpc, nv);                                                 \
-                            st_stream(res_col + (long long)(j + 1) * res_ls + idx, (long long)nv);           \
-                        }                                                                                    \
-                        if (j == 0) st_stream(res_col + idx, (long long)sx_digit(k, c2));                    \
-                    }                                                                                        \
+                    if (writes) PZ_TAIL_RSH_STORE(x1)                                                        \
                 } else if (writes) {                                                                         \
                     if (ACC32 && (g.acc32 & 2)) (reinterpret_cast<int*>(g.res) + (res_col - g.res))[(long long)j * res_ls + idx] = (int)x1; \
                     else if (ROWMAJOR) st_stream(res_col + (long long)j * res_ls + idx, x1);                 \
@@ -1087,6 +1090,8 @@ k_inv_tail(TailArgs g) {
                     if (writes) {
                         long long x1 = (long long)(int)__builtin_fma(-q, twok, vv);
                         if (SGN && g.post_neg && ng_) x1 = -x1;
+                        if constexpr (RSH) PZ_TAIL_RSH_STORE(x1)
+                        else
                         if (ROWMAJOR) st_stream(res_col + (long long)j * res_ls + idx, x1); else res_col[(long long)j * res_ls + idx] = x1;
                     }
                 }
@@ -1104,6 +1109,7 @@ k_inv_tail(TailArgs g) {
             }
         }
 #undef PZ_TAIL_COEFFS
+#undef PZ_TAIL_RSH_STORE
         __syncthreads();
     }
     if (PZ_TAIL_IS_NZ) {   // the top res limbs are digits of the carry alone (middle_step_assign / final_step_assign on zero limbs, normalization.rs:132-157, 254-272)

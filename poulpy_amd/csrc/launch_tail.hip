@@ -74,6 +74,10 @@ static int launch_inv_tail_cols(pz_module* M, const TailCall& c, int col_base, i
               c.body_src == nullptr && !c.body_gather && c.base2k <= 31 && (!(c.acc32 & 4) || (c.acc32 == 4 && c.small16 != nullptr))))
             return fail(PZ_ERR_UNSUPPORTED, "fused tail: no 32-bit-accumulator variant for this call");
         f.kind = TailForm::ACC32;
+    } else if (c.post_rsh && c.body16 && !has_small) {   // the 16-bit-operand form with the shifted store (glwe_trace's body column)
+        if (!(tail_rsh_supported(M) && c.rowmajor && !raw && !nz && c.base2k <= 29)) return fail(PZ_ERR_UNSUPPORTED, "fused tail: no shifted-store 16-bit-operand variant for this call");
+        f.kind = TailForm::SGN16R;
+        g.small_size = c.small_size;
     } else if (c.post_rsh) {
         if (!(tail_rsh_supported(M) && c.rowmajor && has_small)) return fail(PZ_ERR_UNSUPPORTED, "fused tail: no shifted-store variant for this plan");
         f.kind = TailForm::RSH;
@@ -137,7 +141,7 @@ int launch_inv_tail(pz_module* M, const TailCall& c) {
     // add / sub forms of the spectral automorphism with the body-column operand phi(body) +- a0 as 16-bit copies (TailCall::body16): that column as
     // above - the 16-bit-operand form on the f64 chain, the gathering operand variant beside it for the flag-up case - every other column on the
     // operand variant with its own +-a[col]
-    if (c.body16 && c.small != nullptr && c.small_all && !c.body_only && !c.post_rsh && c.rowmajor && tail_rsh_supported(M)) {
+    if (c.body16 && c.small != nullptr && c.small_all && !c.body_only && c.rowmajor && tail_rsh_supported(M)) {
         PZ_TRY(launch_inv_tail_cols(M, c, c.body_col, 1));   // (returns at once unless the pre-pass raised the flag)
         TailCall b16 = c;
         b16.small = nullptr; b16.small_bs = 0; b16.small_all = false; b16.small_neg = false;   // (the sign of the operand is the pre-pass's)

@@ -14,7 +14,7 @@ namespace pz {
 #define PZ_ACC32_CASES(X) X(4, 4, 16) PZ_RSH_CASES(X)
 
 struct TailForm {
-    enum Kind { PLAIN, RSH, SGN, NZ1, NZ2, ACC32, NZ1W, NZ2R, NZ1O, NZ2O, SGN16 } kind = PLAIN;   // SGN16: the sign-only form with a 16-bit operand   // NZ1W / NZ2R: the tensoring tails with 16-bit side copies (write / read); NZ1O / NZ2O: 16-bit digits ONLY   // ACC32: 32-bit accumulator digits (blind rotation's pipeline path)
+    enum Kind { PLAIN, RSH, SGN, NZ1, NZ2, ACC32, NZ1W, NZ2R, NZ1O, NZ2O, SGN16, SGN16R } kind = PLAIN;   // SGN16: the sign-only form with a 16-bit operand; SGN16R: + the shifted store   // NZ1W / NZ2R: the tensoring tails with 16-bit side copies (write / read); NZ1O / NZ2O: 16-bit digits ONLY   // ACC32: 32-bit accumulator digits (blind rotation's pipeline path)
     bool rowmajor = false, has_small = false;   // PLAIN: one instantiation per (row-major, body add) combination
 };
 
@@ -42,6 +42,7 @@ static int tail_launch_form(pz_module* M, const TailArgs& g, int blocks, const T
         if (f.kind == TailForm::RSH) PZ_TAIL_GO(A, B, C, true, true, true, 0, false)                            \
         if (f.kind == TailForm::SGN) PZ_TAIL_GO(A, B, C, true, false, false, 0, true)                           \
         if (f.kind == TailForm::SGN16) PZ_TAIL_GO(A, B, C, true, false, false, 7, true)                         \
+        if (f.kind == TailForm::SGN16R) PZ_TAIL_GO(A, B, C, true, false, true, 7, true)                         \
         if (f.kind == TailForm::NZ2) PZ_TAIL_GO(A, B, C, true, false, false, 2, false)                          \
         if (f.kind == TailForm::NZ1) PZ_TAIL_GO(A, B, C, true, false, false, 1, false)                          \
         if (f.kind == TailForm::NZ1W) PZ_TAIL_GO(A, B, C, true, false, false, 3, false)                         \

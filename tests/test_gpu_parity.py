@@ -1515,9 +1515,22 @@ def test_glwe_trace_shifted_stores(mods, n, size, key_size, res_gals):
     """glwe_trace where the one-bit vec_znx_rsh in front of a step rides on the previous step's last kernel: N = 2^16 (256 x 128 plan) on
     the tail of the spectral automorphism form (Galois element = 1 mod 4; k_inv_tail<.., RSH>), N <= 4096 on k_small_inv<.., AU>; against
     the oracle's literal sequence (rsh, glwe_automorphism_add_assign per step).  -1 first (the full trace's order); key limbs above /
-    below the ciphertext's (zero-extended limb, carry-only first step)."""
+    below the ciphertext's (zero-extended limb, carry-only first step).  Round 6: on the pipeline plans the body column of every step takes
+    the 16-bit operand with the shifted store behind the f64 chain (k_inv_tail<.., RSH, 7, SGN>; base2k <= 14)."""
+    _trace_shifted_stores(mods, n, size, key_size, res_gals, 12)
+
+
+@pytest.mark.parametrize("k", [14, 15])
+def test_glwe_trace_shifted_stores_wider_bases(mods, k):
+    """base2k 14: the widest base at which the trace's steps take the 16-bit body operand (phi(body) + a0 of two normalized digits always fits);
+    base2k 15: the i64 pre-pass and the operand variant with the shifted store, as before."""
+    _trace_shifted_stores(mods, 8192, 3, 4, [-1, 5, 25, 625], k)
+    _trace_shifted_stores(mods, 16384, 4, 3, [5, 25], k)
+
+
+def _trace_shifted_stores(mods, n, size, key_size, res_gals, k):
     from poulpy_amd.hal import GlweOpParams
-    rank, dnum, k, batch = 1, 2, 12, 2
+    rank, dnum, batch = 1, 2, 2
     if key_size > 4 and n <= 4096:
         key_size, size = 4, 4     # the small-ring pipeline takes up to four key limbs
     ref, hip = mods(n)
