@@ -90,6 +90,10 @@ static int br_pipeline_path(const BrCall& c, bool* taken) {
     // move them at half the bytes; the caller's `res` is the operand of the first block and the destination of the last
     const int nblocks = n_lwe / blk;
     const bool acc32 = k <= 31 && nblocks >= 2 && tail_acc32_supported(M);
+    // round 6: 16-bit values in the tails' own tile order where the digits fit them (base2k <= 15): a quarter of the i64 bytes, whole 128-byte runs for
+    // pass 1 (k_fwd_pass1_t16) and the tail (TailCall::acc32 bits 3 / 4); POULPY_DBG_BR_ACC16=0: the 32-bit form
+    static const int acc16_knob = exp_knob("POULPY_DBG_BR_ACC16", 1);
+    const bool acc16 = acc32 && acc16_knob && k <= 15;
     const size_t d_bytes = acc32 ? align256((size_t)B * res_ct * sizeof(int)) : 0;
     PZ_TRY(ws_reserve(M, key_bytes + t_bytes + t2_bytes + kMidDummyBytes + d_bytes));
     char* base = (char*)M->ws;
@@ -105,13 +109,14 @@ static int br_pipeline_path(const BrCall& c, bool* taken) {
     for (int b0 = 0; b0 + blk <= n_lwe; b0 += blk) {
         const bool in32 = acc32 && b0 > 0, out32 = acc32 && b0 + 2 * blk <= n_lwe;
         PZ_TRY(launch_permute_pmat(M, brk + (size_t)b0 * pmat_doubles, Pp, blk * nrows_key * ncols_key));
-        PZ_TRY(launch_fwd_pass1(M, B * npi, in32 ? (const long long*)D : (const long long*)res, sm, T, true, -1, in32));
+        if (in32 && acc16) PZ_TRY(launch_fwd_pass1_t16(M, B * npi, (const short*)D, sm, T));
+        else PZ_TRY(launch_fwd_pass1(M, B * npi, in32 ? (const long long*)D : (const long long*)res, sm, T, true, -1, in32));
         MidBr mb{(const long long*)lwe_2n, lwe_bs, b0, blk};
         PZ_TRY(launch_mid(M, B, T, T2, Pp, npi, npo, nrows_key, ncols_key, mid_dummy, 0, 0, nullptr, &mb));
         TailCall tc = acc_tail(B, T2, true, bsz, cols, res, res_ct, rsz, k);
         if (in32) tc.small = (const long long*)D;
         if (out32) tc.res = (long long*)D;
-        tc.acc32 = (in32 ? 1 : 0) | (out32 ? 2 : 0);
+        tc.acc32 = acc16 ? ((in32 ? 8 : 0) | (out32 ? 16 : 0)) : ((in32 ? 1 : 0) | (out32 ? 2 : 0));
         PZ_TRY(launch_inv_tail(M, tc));
     }
     return PZ_OK;

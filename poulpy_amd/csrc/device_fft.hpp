@@ -488,7 +488,8 @@ struct TailArgs {
     const cplx* tw1inv;
     const cplx* wL1;
     unsigned long long* margin;
-    int acc32;   // k_inv_tail<.., ACC32>: bit 0 `small` holds 32-bit digits, bit 1 `res` takes 32-bit digits (same element strides); bit 2: the operand is
+    int acc32;   // k_inv_tail<.., ACC32>: bit 0 `small` holds 32-bit digits, bit 1 `res` takes 32-bit digits (same element strides); bits 3 / 4: `small` holds /
+                 // `res` takes 16-bit digits in the tile order below, every polynomial at its i64 element offset (the blind rotation's accumulator); bit 2: the operand is
                  // d16a[column][ciphertext][limb][n] int16 in the tile order below (body_bs = elements between columns): a GLWETensor kept as 16-bit digits
     // automorphism family (poulpy-core automorphism/glwe_ct.rs:96-275): the value that enters the carry chain is
     // s(n) * (big[n] + small[n]) with s(n) = -1 iff (n * auto_mul) mod 2N >= N (auto_neg flips every sign);
@@ -745,6 +746,11 @@ k_inv_tail(TailArgs g) {
             if (PZ_TAIL_IS_NZ) {
                 PZ_TAIL_NZ_STORE(j, idx, 0, e, 0)
                 PZ_TAIL_NZ_STORE(j, idx + m, 0, e, 1)
+            } else if (ACC32 && (g.acc32 & 16)) {   // (16-bit tile-order result, same element offsets: see the store below)
+                short* r16 = reinterpret_cast<short*>(g.res) + (res_col - g.res) + (long long)j * res_ls + (long long)(c0 / CB) * (2 * M1 * CB) +
+                             (b_o * CB + b_c) + (SPLIT ? hs * R2 * CB : 0) + (SPLIT ? 2 : 1) * R2 * CB * e;
+                r16[0] = 0;
+                r16[M1 * CB] = 0;
             } else if (ACC32 && (g.acc32 & 2)) {
                 int* r32 = reinterpret_cast<int*>(g.res) + (res_col - g.res);
                 r32[(long long)j * res_ls + idx] = 0;
@@ -876,6 +882,17 @@ k_inv_tail(TailArgs g) {
             // the operand is a GLWETensor column that exists only as 16-bit digits in this kernel's own tile order (fused multiply + relinearize,
             // api_cnv.hip): d16a[column][ciphertext][limb][n], body_bs = int16 elements between columns
             const short* s16 = g.d16a + (long long)col * g.body_bs + ((long long)b * g.small_size + j) * n + (long long)(c0 / CB) * (2 * M1 * CB) +
+                               (b_ov * CB + b_cv) + (SPLIT ? hs * R2 * CB : 0);
+#pragma unroll
+            for (int e = 0; e < RE; ++e) {
+                const int o_ = (SPLIT ? 2 : 1) * R2 * CB * e;
+                sm[SMALL ? 2 * e : 0] = (long long)s16[o_];
+                sm[SMALL ? 2 * e + 1 : 0] = (long long)s16[M1 * CB + o_];
+            }
+        } else if (ACC32 && (g.acc32 & 8) && small_col && j < g.small_size) {
+            // the operand as 16-bit digits in the tile order at the SAME element offsets as the i64 container (the blind rotation's accumulator
+            // between two blocks, base2k <= 15: api_br.hip)
+            const short* s16 = reinterpret_cast<const short*>(g.small) + (small_col - g.small) + (long long)j * small_ls + (long long)(c0 / CB) * (2 * M1 * CB) +
                                (b_ov * CB + b_cv) + (SPLIT ? hs * R2 * CB : 0);
 #pragma unroll
             for (int e = 0; e < RE; ++e) {
@@ -1019,7 +1036,8 @@ k_inv_tail(TailArgs g) {
                 if (RSH) {                                                                                   \
                     if (writes) PZ_TAIL_RSH_STORE(x1)                                                        \
                 } else if (writes) {                                                                         \
-                    if (ACC32 && (g.acc32 & 2)) (reinterpret_cast<int*>(g.res) + (res_col - g.res))[(long long)j * res_ls + idx] = (int)x1; \
+                    if (ACC32 && (g.acc32 & 16)) (reinterpret_cast<short*>(g.res) + (res_col - g.res))[(long long)j * res_ls + (long long)(c0 / CB) * (2 * M1 * CB) + (b_ov * CB + b_cv) + (SPLIT ? hs * R2 * CB : 0) + (h * M1 * CB + (SPLIT ? 2 : 1) * R2 * CB * n1)] = (short)x1; \
+                    else if (ACC32 && (g.acc32 & 2)) (reinterpret_cast<int*>(g.res) + (res_col - g.res))[(long long)j * res_ls + idx] = (int)x1; \
                     else if (ROWMAJOR) st_stream(res_col + (long long)j * res_ls + idx, x1);                 \
                     else res_col[(long long)j * res_ls + idx] = x1;                                          \
                 }                                                                                            \

@@ -77,7 +77,7 @@ int launch_fwd_pass1_t16(pz_module* M, int npolys, const short* src, PolyMap sma
         PZ_HIP(hipGetLastError());                                                                              \
         return PZ_OK;                                                                                           \
     }
-    X(4, 8, 16) X(8, 8, 16) X(8, 16, 16) X(16, 16, 16)
+    X(4, 4, 16) X(4, 8, 16) X(8, 8, 16) X(8, 16, 16) X(16, 16, 16)
 #undef X
     return fail(PZ_ERR_UNSUPPORTED, "forward pass 1: no 16-bit-source form for this plan");
 }
