@@ -532,9 +532,9 @@ struct TailArgs {
     // dwords of the two i64 columns
     short* d16w;
     const short *d16a, *d16b;
-    // pre_body with a gathered body (gather_mul != 0) and body16_wide != null: the body-column operand +-phi(body) (+ a0) was left by the pre-pass as
-    // 16-bit values in the tile order, d16a[ciphertext][limb][n] with body_bs int16 elements per ciphertext; read from there unless *body16_wide
-    // (a value did not fit 16 bits: the gathers below then produce the same operand from the body itself)
+    // body16_wide != null: the body-column operand (+-phi(body), + - a0 in the add / sub forms) was left by the automorphism pre-pass as 16-bit values in the
+    // tile order, d16a[ciphertext][limb][n] with body_bs int16 elements per ciphertext, and *body16_wide says whether a value did not fit.  The 16-bit-operand
+    // form (NZF = 7) reads the copies and returns at once if the flag is up; an operand form (SMALL) launched with this pointer returns at once if it is down
     const unsigned* body16_wide;
 };
 __device__ __forceinline__ long long tz_digit(int k, long long x) { return (long long)((unsigned long long)x << (64 - k)) >> (64 - k); }

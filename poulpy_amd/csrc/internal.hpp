@@ -80,8 +80,9 @@ struct TailCall {
     bool body_add = false;                // body column: body_src[n] + small[body column][n] (spectral add / sub forms: the pre-pass only permutes)
     bool body_gather = false;             // instead of body_src: the tail gathers +-phi(body) from column 0 of `small` itself (gather_mul,
                                           // gather_neg) - no pre-pass
-    // with body_gather: the pre-pass left the body-column operand as 16-bit values in the tail's tile order, body16[ciphertext][limb][n] with
-    // body16_limbs limbs per ciphertext, and raised *body16_wide if a value did not fit - the tail reads the copies, or gathers when the flag is up
+    // the pre-pass left the body-column operand as 16-bit values in the tail's tile order, body16[ciphertext][limb][n] with body16_limbs limbs per
+    // ciphertext, and raised *body16_wide if a value did not fit; launch_inv_tail then runs that column twice - the 16-bit-operand form (returns at
+    // once if the flag is up) and the operand variant on body_src, which a conditional second pre-pass filled (returns at once if the flag is down)
     const short* body16 = nullptr;
     int body16_limbs = 0;
     const unsigned* body16_wide = nullptr;

@@ -127,7 +127,7 @@ int launch_inv_tail(pz_module* M, const TailCall& c) {
     static const int sgn_knob = exp_knob("POULPY_DBG_AUTO_SGN", 1);
     if (sgn_knob && c.small != nullptr && c.small_all && c.body_only && c.auto_mul != 0 && c.ncols > 1 && !c.post_rsh && c.rowmajor &&
         tail_rsh_supported(M)) {
-        // (body16: the body column twice - the gathering operand variant returns at once unless the pre-pass raised the flag, the 16-bit-operand form
+        // (body16: the body column twice - the operand variant returns at once unless the pre-pass raised the flag, the 16-bit-operand form
         //  of the sign-only tail returns at once if it did; exactly one of them writes the column)
         PZ_TRY(launch_inv_tail_cols(M, c, c.body_col, 1));
         TailCall rest = c;
