@@ -23,6 +23,9 @@
 // Same tables, same stage formulas as the two-kernel pipeline; the results are the same i64 limbs (tests/test_gpu_parity.py, pool tests).
 #pragma once
 #include "device_small.hpp"
+#ifndef PZ_SMALL_ONE_STAMP
+#define PZ_SMALL_ONE_STAMP 0
+#endif
 
 namespace pz {
 
@@ -62,6 +65,14 @@ __global__ void __launch_bounds__(512, (M1 == 4 ? 4 : 2)) k_small_one(SmallOneAr
     else if (tid < M2 + M1) tw1i[tid - M2] = g.tw1inv[tid - M2];
     const int k = g.base2k;
     const int row_max = min(g.nrows, g.npi);
+#if PZ_SMALL_ONE_STAMP   // diagnostic build: per-phase s_memtime totals of one workgroup (tools/dbg/small_one_stamps.sh; NOTEBOOK.md 15.9)
+    unsigned long long so_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long so_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long so_t0 = so_t;
+#define PZ_OSTAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); so_acc[i] += t_ - so_t; so_t = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define PZ_OSTAMP(i)
+#endif
     // ---------------- A: forward column pass (k_small_fwd): 4 polynomials per sweep ----------------
     {
         const int t = tid & 127;
@@ -81,7 +92,9 @@ __global__ void __launch_bounds__(512, (M1 == 4 ? 4 : 2)) k_small_one(SmallOneAr
             for (int q1 = 0; q1 < M1; ++q1) lds[(p * M1 + q1) * RS + t] = cmul(v[q1], g.tw12t[q1 * M2 + t]);
         }
     }
+    PZ_OSTAMP(0)
     __syncthreads();
+    PZ_OSTAMP(1)
     // ---------------- B: forward row pass, 8 lanes per row; the spectrum stays in the tile as S[p][q1][q2] ----------------
     {
         const int row = tid >> 3, o = tid & 7;
@@ -112,7 +125,9 @@ __global__ void __launch_bounds__(512, (M1 == 4 ? 4 : 2)) k_small_one(SmallOneAr
                 for (int k2 = 0; k2 < 8; ++k2) rowbuf[o + 8 * h + 16 * k2] = x[8 * h + k2];
         }
     }
+    PZ_OSTAMP(2)
     __syncthreads();
+    PZ_OSTAMP(3)
     // ---------------- C: product, all NPO output polynomials of the ciphertext in registers: acc[c][j] = sum_r S[r][pos_j] * P'[q1_j][r][c][q2] ----------------
     const int pq2 = tid & 127, pq1 = tid >> 7;   // q1_j = pq1 + 4 j
     cplx acc[NPO][PP];
@@ -167,12 +182,14 @@ __global__ void __launch_bounds__(512, (M1 == 4 ? 4 : 2)) k_small_one(SmallOneAr
     constexpr int CT_N = 64 * M1;      // chain threads per column
     constexpr int CPR = NT / CT_N;     // columns per chain round: 2 at N = 1024, 1 at N = 2048
     const unsigned long long half = 1ull << (k - 1), mask = (1ull << k) - 1;
+    PZ_OSTAMP(4)
     __syncthreads();   // every spectrum value has been read
 #pragma unroll
     for (int c = 0; c < NPO; ++c)
 #pragma unroll
         for (int j = 0; j < PP; ++j) lds[(((c % CO) * KS + c / CO) * M1 + pq1 + 4 * j) * RS + pq2] = acc[c][j];
     __syncthreads();
+    PZ_OSTAMP(5)
     // ---- D: inverse row pass of the 2 KS polynomials, x conj tw12, back into the tile as T2[q1][j2]
     {
         const int rp = tid / (8 * M1), rrow = (tid % (8 * M1)) >> 3, ro = tid & 7;   // 8 M1 threads per polynomial: 16 / 8 polynomials per sweep
@@ -213,7 +230,9 @@ __global__ void __launch_bounds__(512, (M1 == 4 ? 4 : 2)) k_small_one(SmallOneAr
             }
         }
     }
+    PZ_OSTAMP(6)
     __syncthreads();
+    PZ_OSTAMP(7)
     // ---- E: inverse column pass + rounding: thread = (polynomial slot, column j2), 4 slots per sweep; the 2 M1 integers take the place of the column's M1 complex values
 #pragma unroll
     for (int cl0 = 0; cl0 < NPO; cl0 += NT / 128) {
@@ -252,7 +271,9 @@ __global__ void __launch_bounds__(512, (M1 == 4 ? 4 : 2)) k_small_one(SmallOneAr
             }
         }
     }
+    PZ_OSTAMP(8)
     __syncthreads();
+    PZ_OSTAMP(9)
     // ---- F: (+ key-switch body), carry chain from the last limb up, stores: thread = (column of the ciphertext, column j2, component, j1 group), 4 coefficients
     // per limb; no barrier between the rounds (the chains only read the tile)
     {
@@ -309,6 +330,14 @@ __global__ void __launch_bounds__(512, (M1 == 4 ? 4 : 2)) k_small_one(SmallOneAr
             }
         }
     }
+#if PZ_SMALL_ONE_STAMP
+    PZ_OSTAMP(10)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PZ_OSTAMP(11)
+    if ((tid & 63) == 0 && (blockIdx.x == 300 || blockIdx.x == 3000))
+        printf("OSTAMP wg %d wave %d total %llu | A colpass(loads+bfly) %llu bar %llu | B rowpass %llu bar %llu | C product(key from L2) %llu | bar+acc->tile %llu | D inv rowpass %llu bar %llu | E inv colpass %llu bar %llu | F chains+stores %llu storeack %llu\n",
+               (int)blockIdx.x, tid >> 6, (unsigned long long)(so_t - so_t0), so_acc[0], so_acc[1], so_acc[2], so_acc[3], so_acc[4], so_acc[5], so_acc[6], so_acc[7], so_acc[8], so_acc[9], so_acc[10], so_acc[11]);
+#endif
+#undef PZ_OSTAMP
 }
 
 }  // namespace pz
