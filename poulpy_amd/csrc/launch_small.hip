@@ -180,11 +180,13 @@ bool small_one_supported(const pz_module* M, int npi, int nrows, int ncols, int 
     const int m1 = small_m1(M);
     // measured (profiles/r06_ab_small_one.txt, 1024 per call): N = 1024 + 7 ... + 20 % on every shape; N = 2048 + 4 % for the external product (8 input
     // polynomials), - 5 ... 8 % for the key switch (4 inputs: the two-kernel pipeline has two workgroups per CU there, this kernel one) - which stays on two kernels
-    // below ~3000 ciphertexts per call (at 4096 the one-kernel form is + 7 %: the two-kernel path's spectra no longer sit in the Infinity Cache)
+    // below ~3000 ciphertexts per call (at 4096 the one-kernel form is + 7 %: the two-kernel path's spectra no longer sit in the Infinity Cache).  After the
+    // both-columns form (tools/dbg/r6_run35.sh): the key switch still - 3 ... 4 % at 4 / 3 limbs, but the 2-limb external product (4 inputs, 2 key limbs) + 15 %:
+    // shapes with at most two key limbs take the one-kernel form too
 #ifndef PZ_SMALL_ONE_ALL
 #define PZ_SMALL_ONE_ALL 0   // A/B builds: 1 = also the N = 2048 shapes with <= 4 input polynomials
 #endif
-    return on && (M->m % kSmallM2) == 0 && (m1 == 4 || (m1 == 8 && (npi > 4 || batch >= 3072 || PZ_SMALL_ONE_ALL))) && cols_out == 2 && ksz >= 1 && ksz <= 4 && ncols == ksz * cols_out && npi >= 1 &&
+    return on && (M->m % kSmallM2) == 0 && (m1 == 4 || (m1 == 8 && (npi > 4 || batch >= 3072 || (npi == 4 && ksz <= 2) || PZ_SMALL_ONE_ALL))) && cols_out == 2 && ksz >= 1 && ksz <= 4 && ncols == ksz * cols_out && npi >= 1 &&
            npi <= 8 && nrows >= 1;
 }
 int launch_small_one(pz_module* M, int batch, const long long* src, PolyMap smap, const cplx* Pp, int npi, int nrows, int ncols, int ksz, long long* res,
