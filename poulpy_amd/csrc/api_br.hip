@@ -165,6 +165,9 @@ static int br_small_ring_path(const BrCall& c, bool* taken) {
         // (the separate forward launch of the unchained form reads `res`: i64 throughout there)
         const bool use32 = acc32 && chain;
         const bool in32 = use32 && b0 > 0, out32 = use32 && more;
+        // (round 6: 16-bit digits - natural order here, the small-ring kernels read whole rows - where base2k <= 15; POULPY_DBG_BR_ACC16=0: 32-bit)
+        static const int acc16_knob_s = exp_knob("POULPY_DBG_BR_ACC16", 1);
+        const bool use16 = use32 && acc16_knob_s && k <= 15;
         for (int half = 0; half < (hA < B ? 2 : 1); ++half) {
             const int c0 = half ? hA : 0, nb = half ? B - hA : hA;
             ss.on(half == 1);
@@ -179,7 +182,8 @@ static int br_small_ring_path(const BrCall& c, bool* taken) {
             if (!done) return fail(PZ_ERR_UNSUPPORTED, "blind_rotation: block step not launched");
             PZ_TRY(launch_small_inv(M, nb, A_h, nullptr, ncols_key, 0, 0, cols, bsz, out32 ? (long long*)D_h : (long long*)res_h, res_ct, cols, rsz,
                                     in32 ? (const long long*)D_h : (const long long*)res_h, res_ct, cols, rsz, k, -1, true,
-                                    (chain && more) ? S_h : nullptr, fl, false, 0, 0, false, (in32 ? 1 : 0) | (out32 ? 2 : 0)));
+                                    (chain && more) ? S_h : nullptr, fl, false, 0, 0, false,
+                                    use16 ? ((in32 ? 4 : 0) | (out32 ? 8 : 0)) : ((in32 ? 1 : 0) | (out32 ? 2 : 0))));
         }
     }
     return ss.join();

@@ -273,7 +273,7 @@ struct SmallInvArgs {
     int fwd_limbs;               // FWD: <= min(KS, res_size)
     int dbg;                     // timing ablation (POULPY_DBG_SMALL_SKIP; results invalid): 1 no key loads, 2 no S loads, 4 no stores, 8 no LDS phases
     unsigned long long* margin;  // rounding-margin probe (margin_note, device_fft.hpp); null = off
-    int acc32;                   // NOPROD (blind rotation's tail): bit 0 `small` holds 32-bit digits, bit 1 `res` takes 32-bit digits - same
+    int acc32;                   // NOPROD (blind rotation's tail): bit 0 `small` holds 32-bit digits, bit 1 `res` takes 32-bit digits (bits 2 / 3: 16-bit digits) - same
                                  // element strides, half the bytes: between the blocks of a rotation the accumulator only ever holds normalized
                                  // digits (base2k <= 31), and this kernel moves them at HBM rate (api_br.hip)
 };
@@ -481,6 +481,13 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
         for (int j = 0; j < KS; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) smv[j][e] = 0;
+        if (NOPROD && (g.acc32 & 4) && small_col && g.small_size > 0) {   // 16-bit digits at the same element offsets (base2k <= 15, round 6)
+            const short* sc16 = reinterpret_cast<const short*>(g.small) + (small_col - g.small);
+#pragma unroll
+            for (int j = 0; j < KS; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) smv[j][e] = (long long)sc16[(long long)min(j, g.small_size - 1) * small_ls + JG * e * M2];
+        } else
         if (NOPROD && (g.acc32 & 1) && small_col && g.small_size > 0) {   // 32-bit digits at the same element offsets
             const int* sc32 = reinterpret_cast<const int*>(g.small) + (small_col - g.small);
 #pragma unroll
@@ -613,12 +620,14 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
 #endif
     const bool rsh = AU && g.post_rsh;
     int cy2[4] = {0, 0, 0, 0};
-    const bool res32 = NOPROD && (g.acc32 & 2);
+    const bool res32 = NOPROD && (g.acc32 & 2), res16 = NOPROD && (g.acc32 & 8);
     int* res_col32 = reinterpret_cast<int*>(g.res) + (res_col - g.res);
+    short* res_col16 = reinterpret_cast<short*>(g.res) + (res_col - g.res);
     for (int j = L + (rsh ? 1 : 0); j < g.res_size; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if (res32) res_col32[(long long)j * res_ls + opos[e]] = 0;
+            if (res16) res_col16[(long long)j * res_ls + opos[e]] = 0;
+            else if (res32) res_col32[(long long)j * res_ls + opos[e]] = 0;
             else res_col[(long long)j * res_ls + opos[e]] = 0;
         }
     const unsigned long long half = 1ull << (k - 1), mask = (1ull << k) - 1;
@@ -673,7 +682,8 @@ __global__ void __launch_bounds__(64 * M1) k_small_inv(SmallInvArgs g) {
                         } else {
                             res_col[(long long)j * res_ls + opos[e]] = xs;
                         }
-                    } else if (res32) res_col32[(long long)j * res_ls + opos[e]] = (int)xs;
+                    } else if (res16) res_col16[(long long)j * res_ls + opos[e]] = (short)xs;
+                    else if (res32) res_col32[(long long)j * res_ls + opos[e]] = (int)xs;
                     else st_stream(res_col + (long long)j * res_ls + opos[e], xs);
                 }
             }
