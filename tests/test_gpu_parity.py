@@ -2275,6 +2275,11 @@ def test_glwe_automorphism_body_as_16_bit_copies_and_wide_inputs(mods, n, p, mod
             got, want = _run_glwe_op(hip, ref, True, n, 1, 1, limbs, k, limbs, k, limbs, 1, limbs, k, batch=4, seed=8100 + k + (wide[1] if wide else 0),
                                      auto=(p % (2 * n), mode), chunk=2, wide_in=wide, in_place=in_place)
             assert np.array_equal(got, want), (n, p, mode, k, wide, in_place)
+    if n == 8192:   # rank 2: two body-less columns beside the body column
+        for wide in (None, (0, 18)):
+            got, want = _run_glwe_op(hip, ref, True, n, 2, 2, 3, 13, 3, 13, 3, 1, 3, 13, batch=3, seed=8300 + (wide[1] if wide else 0),
+                                     auto=(p % (2 * n), mode), wide_in=wide)
+            assert np.array_equal(got, want), (n, p, mode, "rank 2", wide)
 
 
 @pytest.mark.parametrize("n,a_size,key_size,res_size,batch,chunk", [(4096, 8, 2, 1, 16, 0), (65536, 8, 2, 1, 5, 4), (8192, 6, 3, 1, 9, 0)])
