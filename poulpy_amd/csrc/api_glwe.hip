@@ -285,6 +285,7 @@ static MidDigits digit_terms(const GlweCall& c) {
 struct FusedBufs {
     cplx* key_scratch; int64_t* a_conv; cplx* T; cplx* T2; int64_t* res_tmp; int64_t* key_digits; cplx* mid_dummy;
     const cplx* Pp;
+    short* side16 = nullptr;   // this wave's 16-bit side copy of pass 1's input (add / sub automorphism forms at rank 1: wave_spectral_tail), or null
 };
 static int fused_carve(const GlweCall& c, FusedBufs* f) {
     pz_module* M = c.M;
@@ -353,6 +354,19 @@ static SpectralPerm spectral_perm(const GlweCall& c) {
 // The tail of the spectral form adds ONE operand stream per column at the natural index: +-a[col] and, on the body column, the stream
 // prepared here by one k_automorphism pass over that column into the (cache-resident) workspace - phi(body) for the plain form,
 // +-phi(body) + a0 for add / sub / sub_negate.  No permutation pass over the result, no gathers in the tail, in-place forms safe.
+// whether the spectral tail takes its body-column operand as 16-bit copies (see wave_spectral_tail)
+static bool spectral_body16(const GlweCall& c) {
+    pz_module* M = c.M;
+    const long long n = c.n;
+    static const int fold_knob = exp_knob("POULPY_DBG_AUTO_FOLD", 0);
+    static const int b16_knob = exp_knob("POULPY_DBG_AUTO_BODY16", 1);
+    const int64_t* a_end = c.a + (long long)c.batch * c.a_bs;
+    const int64_t* r_end = c.res + (long long)c.batch * c.res_bs;
+    const bool fold = fold_knob != 0 && (c.res >= a_end || c.a >= r_end) && !c.want_rsh;
+    return b16_knob != 0 && !fold && !M->probe && (!c.want_rsh || (c.au_big && (int)c.p->key_base2k <= 14 && (int)c.p->res_base2k <= 29)) &&
+           n >= 4096 && n <= 65536 && (int)c.p->key_base2k <= (c.au_big ? 15 : 16) && (int)c.p->res_base2k <= 31 && tail_rsh_supported(M) &&
+           !(c.au_big && exp_knob("POULPY_DBG_AUTO_BODYADD", 0));
+}
 static int wave_spectral_tail(const GlweCall& c, const FusedBufs& f, size_t b0, int nb, const DV& av) {
     pz_module* M = c.M;
     const long long n = c.n;
@@ -381,13 +395,12 @@ static int wave_spectral_tail(const GlweCall& c, const FusedBufs& f, size_t b0, 
     // (add / sub forms: the operand phi(body) +- a0 is a sum of two digits - a key base of at most 15 bits; the other columns keep their 8-byte operand)
     // (glwe_trace's steps, want_rsh: their input is the previous step's - or the initial shift's - normalized output, so with a base of at most 14 bits
     //  the operand always fits and the flag-up launches of the shifted-store forms stay what they are there: never taken)
-    const bool body16 = b16_knob != 0 && !fold && !M->probe && (!c.want_rsh || (c.au_big && (int)c.p->key_base2k <= 14 && (int)c.p->res_base2k <= 29)) &&
-                        n >= 4096 && n <= 65536 && (int)c.p->key_base2k <= (c.au_big ? 15 : 16) && (int)c.p->res_base2k <= 31 && tail_rsh_supported(M) &&
-                        !(c.au_big && exp_knob("POULPY_DBG_AUTO_BODYADD", 0));
+    const bool body16 = spectral_body16(c);   // (glwe_fused zeroed the flag word in front of pass 1: that kernel may raise it too, f.side16)
+    (void)b16_knob;
     short* b16 = body16 ? (short*)f.res_tmp : nullptr;
     if (body16) {
-        PZ_TRY(launch_zero_bytes(M, M->margin + 1, 8));   // the flag word (module.hpp: wide16)
         t.body16 = b16; t.body16_limbs = bl; t.body16_wide = M->wide16();
+        if (f.side16 && c.au_big) t.other16 = f.side16;
     }
     if (fold) { t.body_gather = true; t.gather_mul = c.au_g; }
     else { t.body_src = (const long long*)f.res_tmp; t.body_bs = (long long)bl * n; t.body_ls = n; }
@@ -471,11 +484,25 @@ static int glwe_fused(const GlweCall& c) {
         PZ_TRY(wave_input(c, b0, nb, f.a_conv, &av));
         PolyMap sm{av.size, c.s.cols_in, av.bs, (long long)av.cols * c.n, c.n, c.n * c.s.a_col0};
         if (two_kernel) { PZ_TRY(wave_n4096_two_kernel(c, f, b0, nb, av, sm)); continue; }
+        f.side16 = nullptr;
+        if (sp.on && spectral_body16(c)) {
+            PZ_TRY(launch_zero_bytes(M, M->margin + 1, 8));   // the wide flag (module.hpp: wide16), in front of everything that may raise it
+            // add / sub forms at rank 1 (one mask column = the key switch's input): pass 1 also leaves its input as 16-bit values for the tail's other
+            // column, behind the body operand's segment of res_tmp when there is room (16 res_size - 8 bl >= 2 a_size limbs' worth per ciphertext)
+            static const int side_knob = exp_knob("POULPY_DBG_AUTO_SIDE16", 1);
+            const int bl_ = std::min(av.size, c.ksz);
+            if (side_knob && c.au_big && c.s.cols_in == 1 && c.s.cols_out == 2 && !c.digits && !c.a16 && (M->dbg_stages & 1) &&
+                16 * (long long)c.p->res_size - 8 * (long long)bl_ >= 2 * (long long)av.size)
+                f.side16 = (short*)((char*)f.res_tmp + (size_t)nb * bl_ * c.n * 8);
+        }
         if (c.a16) {
             PolyMap s16{av.size, c.s.cols_in, (long long)av.size * c.n, c.n, c.a16_cs, c.a16_cs * c.s.a_col0};
             PZ_TRY(launch_fwd_pass1_t16(M, nb * c.npi, c.a16 + (long long)b0 * av.size * c.n, s16, f.T));
-        } else
-        if (M->dbg_stages & 1) PZ_TRY(launch_fwd_pass1(M, nb * c.npi, (const long long*)av.p, sm, f.T, true));
+        } else if (f.side16) {
+            PZ_TRY(launch_fwd_pass1_w16(M, nb * c.npi, (const long long*)av.p, sm, f.T, f.side16));
+        } else if (M->dbg_stages & 1) {
+            PZ_TRY(launch_fwd_pass1(M, nb * c.npi, (const long long*)av.p, sm, f.T, true));
+        }
         if (c.digits && dg.n == 0) {   // nothing reaches the product (e.g. dsize > a.size): the big value is the body alone
             PZ_TRY(launch_zero_bytes(M, f.T2, (size_t)nb * c.npo * M->m * sizeof(cplx)));
         } else if (M->dbg_stages & 2) {

@@ -213,9 +213,12 @@ __device__ __forceinline__ long long fast_i64_from_integral(double r) {
 // SRC = 0 i64 coefficients | 1 = SRC32 | 2: 16-bit digits in the fused tail's tile order (TailArgs::d16*: smap addresses a limb of n int16, the
 // workgroup's tile [half h][row j1][CB columns] starts at (c0 / CB) 2 M1 CB) - the fused multiply + relinearize reads the pair column of a
 // GLWETensor that only ever existed as those copies (api_cnv.hip)
-template <int R1, int R2, int CB, bool ROWMAJOR, int SRC>
+// W16 (with SRC = 0): the coefficients just read also leave as 16-bit values in the fused tail's tile order, polynomial p at w16 + p n (the mask column of
+// the add / sub automorphism forms, whose tail then takes it as a 16-bit operand); a value beyond 16 bits raises *wide (launch_fwd_pass1_w16)
+template <int R1, int R2, int CB, bool ROWMAJOR, int SRC, bool W16 = false>
 __device__ __forceinline__ void fwd_pass1_body(const long long* __restrict__ src, PolyMap smap, cplx* __restrict__ T, int m2,
-                                               const cplx* __restrict__ tw1, const cplx* __restrict__ wL1, const cplx* __restrict__ tw12, long long mask, int npolys_xcd) {
+                                               const cplx* __restrict__ tw1, const cplx* __restrict__ wL1, const cplx* __restrict__ tw12, long long mask, int npolys_xcd,
+                                               short* __restrict__ w16 = nullptr, unsigned* __restrict__ wide = nullptr) {
     constexpr bool SRC32 = SRC == 1;
     constexpr int M1 = R1 * R2;
     constexpr int NT = (R1 > R2 ? R1 : R2) * CB;
@@ -268,6 +271,19 @@ __device__ __forceinline__ void fwd_pass1_body(const long long* __restrict__ src
         wls[t] = wL1[t];
     }
     __syncthreads();
+    if constexpr (W16) {
+        if (is_a) {
+            short* d = w16 + (long long)p * (2 * m) + (long long)(c0 / CB) * (2 * M1 * CB) + o * CB + c;
+            bool wd = false;
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) {
+                wd = wd || ((unsigned long long)raw_re[n1] + 32767ull) >= 65535ull || ((unsigned long long)raw_im[n1] + 32767ull) >= 65535ull;
+                d[(R2 * n1) * CB] = (short)raw_re[n1];
+                d[(M1 + R2 * n1) * CB] = (short)raw_im[n1];
+            }
+            if (wd) atomicOr(wide, 1u);
+        }
+    }
     if (is_a) {
         cplx v[R1];
 #pragma unroll
@@ -302,6 +318,12 @@ __global__ void __launch_bounds__((R1 > R2 ? R1 : R2) * CB)
 k_fwd_pass1(const long long* __restrict__ src, PolyMap smap, cplx* __restrict__ T, int m2,
             const cplx* __restrict__ tw1, const cplx* __restrict__ wL1, const cplx* __restrict__ tw12, long long mask, int npolys_xcd) {
     fwd_pass1_body<R1, R2, CB, ROWMAJOR, SRC32 ? 1 : 0>(src, smap, T, m2, tw1, wL1, tw12, mask, npolys_xcd);
+}
+template <int R1, int R2, int CB>
+__global__ void __launch_bounds__((R1 > R2 ? R1 : R2) * CB)
+k_fwd_pass1_w16(const long long* __restrict__ src, PolyMap smap, cplx* __restrict__ T, int m2,
+                const cplx* __restrict__ tw1, const cplx* __restrict__ wL1, const cplx* __restrict__ tw12, int npolys_xcd, short* __restrict__ w16, unsigned* __restrict__ wide) {
+    fwd_pass1_body<R1, R2, CB, true, 0, true>(src, smap, T, m2, tw1, wL1, tw12, -1ll, npolys_xcd, w16, wide);
 }
 template <int R1, int R2, int CB>
 __global__ void __launch_bounds__((R1 > R2 ? R1 : R2) * CB)
@@ -994,7 +1016,7 @@ k_inv_tail(TailArgs g) {
             const double r = round_half_away(val);                                                           \
             long long x = CONVERT(r);                                                                        \
             if (SMALL && add_small) x = (long long)((unsigned long long)x + (unsigned long long)sm[SMALL ? 2 * n1 + h : 0]); \
-            if (OP16) x = (long long)((unsigned long long)x + (unsigned long long)(long long)(h ? op16[OP16 ? n1 : 0].y : op16[OP16 ? n1 : 0].x));   \
+            if (OP16) { const long long op_ = (long long)(h ? op16[OP16 ? n1 : 0].y : op16[OP16 ? n1 : 0].x); x = (long long)((unsigned long long)x + (unsigned long long)(g.small_neg ? -op_ : op_)); }   \
             bool ng_ = false;                                                                                \
             if ((SMALL || SGN) && g.auto_mul) {                                                              \
                 ng_ = (((unsigned)idx * g.auto_mul) & (unsigned)(2 * n - 1)) >= (unsigned)n;                 \
@@ -1096,7 +1118,7 @@ k_inv_tail(TailArgs g) {
                     const long long idx = (long long)j1 * g.m2 + c0 + b_cv + (h ? m : 0);
                     const double val = h ? v[n1].y : v[n1].x;
                     double r = round_half_away(val);
-                    if (OP16) r += (double)(int)(h ? op16[OP16 ? n1 : 0].y : op16[OP16 ? n1 : 0].x);   // (an exact integer below 2^51 + 2^15)
+                    if (OP16) { const double op_ = (double)(int)(h ? op16[OP16 ? n1 : 0].y : op16[OP16 ? n1 : 0].x); r += g.small_neg ? -op_ : op_; }   // (an exact integer below 2^51 + 2^15)
                     bool ng_ = false;
                     if (SGN) {   // s(n) in front of the chain, and back on the digit (the integer path's steps, on the f64 chain)
                         ng_ = (((unsigned)idx * g.auto_mul) & (unsigned)(2 * n - 1)) >= (unsigned)n;

@@ -46,6 +46,9 @@ int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap sma
                      bool src32 = false);
 // the row-major form on 16-bit digits in the fused tail's tile order (TailD16; smap addresses limbs of n int16)
 int launch_fwd_pass1_t16(pz_module* M, int npolys, const short* src, PolyMap smap, cplx* T);
+// the row-major form on i64 coefficients that also leaves them as 16-bit values in the tile order, polynomial p at w16 + p n, and raises the module's
+// wide flag (module.hpp: wide16) for a value beyond 16 bits
+int launch_fwd_pass1_w16(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* T, short* w16);
 bool tail_d16_only_supported(const pz_module* M);   // the tensoring tails that leave 16-bit digits only + the operand form that reads them   // src32 (row-major, 128-point-row plans): `src` holds 32-bit digits at the same element offsets
 int launch_fwd_pass2(pz_module* M, int npolys, const cplx* T, double* dst, PolyMap dmap, const cplx* mul);
 int launch_inv_pass2(pz_module* M, int npolys, const double* src, PolyMap smap, cplx* T);
@@ -86,6 +89,9 @@ struct TailCall {
     const short* body16 = nullptr;
     int body16_limbs = 0;
     const unsigned* body16_wide = nullptr;
+    // add / sub forms at rank 1: the other column's operand +-a[1] as 16-bit values too (pass 1 of the key switch left them: launch_fwd_pass1_w16),
+    // other16[ciphertext][limb][n] with small_size limbs per ciphertext; same flag, same pair of launches on that column
+    const short* other16 = nullptr;
     // ---- signs of X -> X^p (automorphism/glwe_ct.rs:96-275; TailArgs in device_fft.hpp) ----
     unsigned auto_mul = 0;            // != 0: the value enters the chain as s(n) (big + small), s(n) = -1 iff (n auto_mul) mod 2N >= N
     bool auto_neg = false;            // flips every s(n)

@@ -62,6 +62,26 @@ int launch_fwd_pass1(pz_module* M, int npolys, const long long* src, PolyMap sma
     return fail(PZ_ERR_UNSUPPORTED, "no forward pass-1 kernel for m1=%d", pl.m1);
 }
 
+int launch_fwd_pass1_w16(pz_module* M, int npolys, const long long* src, PolyMap smap, cplx* T, short* w16) {
+    const FftPlan& pl = M->plan;
+    if (npolys == 0) return PZ_OK;
+    KTimer kt(M, PZ_K_FWD_PASS1);
+    const int ncb = pl.m2 / pl.cb;
+    const int blocks_rm = ((npolys + 7) / 8) * 8 * ncb;
+#define X(A, B, C)                                                                                              \
+    if (pl.f1a == A && pl.f1b == B && pl.cb == C) {                                                             \
+        const size_t lds = ((size_t)(A + 1) * C * B + 2 * A * B) * sizeof(cplx);                                \
+        PZ_TRY(set_lds((k_fwd_pass1_w16<A, B, C>), lds));                                                       \
+        hipLaunchKernelGGL((k_fwd_pass1_w16<A, B, C>), dim3(blocks_rm), dim3((A > B ? A : B) * C), lds, M->stream, src, smap, T, pl.m2, M->tw1, M->wL1, \
+                           M->tw12t, npolys, w16, M->wide16());                                                 \
+        PZ_HIP(hipGetLastError());                                                                              \
+        return PZ_OK;                                                                                           \
+    }
+    X(4, 8, 16) X(8, 8, 16) X(8, 16, 16) X(16, 16, 16)
+#undef X
+    return fail(PZ_ERR_UNSUPPORTED, "forward pass 1: no side-copy form for this plan");
+}
+
 int launch_fwd_pass1_t16(pz_module* M, int npolys, const short* src, PolyMap smap, cplx* T) {
     const FftPlan& pl = M->plan;
     if (npolys == 0) return PZ_OK;

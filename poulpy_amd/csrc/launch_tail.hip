@@ -148,6 +148,14 @@ int launch_inv_tail(pz_module* M, const TailCall& c) {
         b16.body_src = nullptr; b16.body_bs = b16.body_ls = 0; b16.body_add = false; b16.body_gather = false; b16.gather_mul = 0; b16.gather_neg = false;
         PZ_TRY(launch_inv_tail_cols(M, b16, c.body_col, 1));
         TailCall rest = c;
+        if (c.other16 && c.ncols == 2 && c.body_col == 0) {
+            // the other column the same way: its +-a[1] was left as 16-bit values by pass 1 - the operand variant only if the flag is up (rest keeps
+            // body16_wide), the 16-bit-operand form with the operand's sign (small_neg) otherwise
+            PZ_TRY(launch_inv_tail_cols(M, rest, 1, 1));
+            TailCall o16 = b16;
+            o16.body16 = c.other16; o16.body16_limbs = c.small_size; o16.small_neg = c.small_neg;
+            return launch_inv_tail_cols(M, o16, 1, 1);
+        }
         rest.body16 = nullptr; rest.body16_wide = nullptr; rest.body16_limbs = 0;
         if (c.body_col > 0) PZ_TRY(launch_inv_tail_cols(M, rest, 0, c.body_col));
         if (c.ncols - 1 - c.body_col > 0) PZ_TRY(launch_inv_tail_cols(M, rest, c.body_col + 1, c.ncols - 1 - c.body_col));
